@@ -1,0 +1,224 @@
+"""Synthetic inputs for the PloidyFrost hot path.
+
+Nothing here is product code: it only manufactures inputs -- polyploid
+haplotypes, the KMC count database that ``kmc -k25 -ci1 -cs10000`` would
+produce for them (KMC1 on-disk layout, the one parsed by
+KMC/kmc_api/kmc_file.cpp:246-299 of the reference), and, through
+``ploidyfrost_amd.cdbg_build``, a compacted de Bruijn graph in Bifrost's
+GFA dialect -- for tests, fixtures and bench.py.
+
+All generators are seeded and deterministic.
+"""
+from __future__ import annotations
+
+import os
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+BASES = np.frombuffer(b"ACGT", dtype=np.uint8)
+_M64 = (1 << 64) - 1
+
+
+# --------------------------------------------------------------------------
+# haplotypes
+# --------------------------------------------------------------------------
+@dataclass
+class HapSpec:
+    genome_len: int
+    ploidy: int = 2
+    seed: int = 1
+    gap_lo: int = 15
+    gap_hi: int = 900
+    p_snp: float = 0.75
+    p_del: float = 0.13          # 1-bp deletion
+    max_ins: int = 6             # 1..max_ins bp insertion for the remainder
+    p_multi: float = 0.03        # SNP sites carrying two different ALT bases (ploidy >= 3)
+
+
+def make_haplotypes(spec: HapSpec) -> list[np.ndarray]:
+    """Base genome + ``ploidy`` haplotypes as uint8 arrays of 2-bit codes (A0 C1 G2 T3)."""
+    rng = np.random.default_rng(spec.seed)
+    L = spec.genome_len
+    base = rng.integers(0, 4, size=L, dtype=np.uint8)
+    # variant positions
+    n_max = L // spec.gap_lo + 2
+    gaps = rng.integers(spec.gap_lo, spec.gap_hi + 1, size=n_max)
+    pos = np.cumsum(gaps)
+    pos = pos[pos < L - 64]
+    pos = pos[pos > 64]
+    nv = len(pos)
+    kind_r = rng.random(nv)
+    kind = np.where(kind_r < spec.p_snp, 0, np.where(kind_r < spec.p_snp + spec.p_del, 1, 2)).astype(np.int8)
+    ins_len = rng.integers(1, spec.max_ins + 1, size=nv)
+    ins_seq = rng.integers(0, 4, size=(nv, spec.max_ins), dtype=np.uint8)
+    alt_shift = rng.integers(1, 4, size=nv, dtype=np.uint8)
+    alt_shift2 = rng.integers(1, 4, size=nv, dtype=np.uint8)
+    multi = (rng.random(nv) < spec.p_multi) & (spec.ploidy >= 3)
+    # carrier mask: non-empty proper subset of haplotypes
+    full = (1 << spec.ploidy) - 1
+    carriers = rng.integers(1, full, size=nv) if full > 1 else np.ones(nv, dtype=np.int64)
+    second = rng.integers(0, spec.ploidy, size=nv)
+
+    haps = []
+    for h in range(spec.ploidy):
+        seq = base.copy()
+        has = ((carriers >> h) & 1).astype(bool)
+        # SNPs
+        m = has & (kind == 0)
+        seq[pos[m]] = (base[pos[m]] + alt_shift[m]) & 3
+        # a second ALT allele on one more haplotype at multi-allelic sites
+        m2 = multi & (kind == 0) & (second == h) & ~has
+        if m2.any():
+            a2 = (base[pos[m2]] + alt_shift2[m2]) & 3
+            seq[pos[m2]] = a2
+        keep = np.ones(L, dtype=bool)
+        md = has & (kind == 1)
+        keep[pos[md]] = False
+        mi = np.nonzero(has & (kind == 2))[0]
+        if len(mi):
+            ins_at = np.repeat(pos[mi], ins_len[mi])
+            ins_vals = np.concatenate([ins_seq[i, : ins_len[i]] for i in mi])
+        else:
+            ins_at = np.zeros(0, dtype=np.int64)
+            ins_vals = np.zeros(0, dtype=np.uint8)
+        # apply deletions then insertions (positions refer to the base genome)
+        # map base coordinates -> coordinates after deletions
+        newidx = np.cumsum(keep) - keep  # index of each kept base in the deleted sequence
+        seq_d = seq[keep]
+        if len(ins_at):
+            seq_d = np.insert(seq_d, newidx[ins_at], ins_vals)
+        haps.append(seq_d.astype(np.uint8))
+    return haps
+
+
+def write_fasta(path: str, haps: list[np.ndarray], width: int = 0) -> None:
+    with open(path, "wb") as f:
+        for i, h in enumerate(haps):
+            f.write(b">hap%d\n" % i)
+            f.write(BASES[h].tobytes())
+            f.write(b"\n")
+
+
+# --------------------------------------------------------------------------
+# k-mers
+# --------------------------------------------------------------------------
+def kmers_u64(seq: np.ndarray, k: int) -> tuple[np.ndarray, np.ndarray]:
+    """Forward and reverse-complement k-mers (2 bits/base, first base most significant)."""
+    n = len(seq) - k + 1
+    if n <= 0:
+        z = np.zeros(0, dtype=np.uint64)
+        return z, z
+    s = seq.astype(np.uint64)
+    fw = np.zeros(n, dtype=np.uint64)
+    rc = np.zeros(n, dtype=np.uint64)
+    for j in range(k):
+        fw |= s[j : j + n] << np.uint64(2 * (k - 1 - j))
+        rc |= (np.uint64(3) - s[j : j + n]) << np.uint64(2 * j)
+    return fw, rc
+
+
+def canonical_counts(haps: list[np.ndarray], k: int) -> tuple[np.ndarray, np.ndarray]:
+    """Sorted distinct canonical k-mers and their multiplicity over all haplotypes."""
+    parts = []
+    for h in haps:
+        fw, rc = kmers_u64(h, k)
+        parts.append(np.minimum(fw, rc))
+    allk = np.concatenate(parts)
+    return np.unique(allk, return_counts=True)
+
+
+def mix64(x: np.ndarray) -> np.ndarray:
+    """splitmix64 finaliser -- the deterministic 'hash of the k-mer' used for count jitter."""
+    x = x.astype(np.uint64).copy()
+    with np.errstate(over="ignore"):
+        x ^= x >> np.uint64(30)
+        x *= np.uint64(0xBF58476D1CE4E5B9)
+        x ^= x >> np.uint64(27)
+        x *= np.uint64(0x94D049BB133111EB)
+        x ^= x >> np.uint64(31)
+    return x
+
+
+def synth_counts(kmers: np.ndarray, mult: np.ndarray, depth: int = 20, jitter: int = 3) -> np.ndarray:
+    """count = multiplicity*depth + jitter in [-jitter, +jitter] (hash of the k-mer), clamped to >= 1."""
+    j = (mix64(kmers) % np.uint64(2 * jitter + 1)).astype(np.int64) - jitter
+    c = mult.astype(np.int64) * depth + j
+    return np.maximum(c, 1).astype(np.uint32)
+
+
+# --------------------------------------------------------------------------
+# KMC1 database writer
+# --------------------------------------------------------------------------
+def lut_prefix_len(k: int) -> int:
+    """A prefix length p with (k-p) % 4 == 0 (kmc_file.cpp:283 sufix_size = (k-p)/4)."""
+    for p in (5, 6, 7, 4, 3, 2, 1, 8):
+        if p < k and (k - p) % 4 == 0:
+            return p
+    raise ValueError(k)
+
+
+def write_kmc1(prefix: str, kmers: np.ndarray, counts: np.ndarray, k: int, *, counter_size: int = 2,
+               min_count: int = 1, max_count: int = 65535, both_strands: bool = True,
+               p: int | None = None) -> None:
+    """Write ``prefix.kmc_pre`` / ``prefix.kmc_suf`` in the KMC1 layout.
+
+    ``kmers`` must be sorted ascending (2-bit, first base most significant) and distinct.
+    Layout as parsed by the reference reader (KMC/kmc_api/kmc_file.cpp:140-179, 246-299):
+      .kmc_pre = 'KMCP' | u64 LUT[4^p] | u64 sentinel(=total) | header(7 x u64) | u32 header_offset | 'KMCP'
+      .kmc_suf = 'KMCS' | total x { (k-p)/4 suffix bytes MSB-first | counter_size bytes LE } | 'KMCS'
+    The u64 after the LUT is the word the reader indexes as LUT[4^p]; emitting it keeps
+    the last prefix range inside the suffix array.
+    """
+    if p is None:
+        p = lut_prefix_len(k)
+    assert (k - p) % 4 == 0
+    total = len(kmers)
+    kmers = kmers.astype(np.uint64)
+    suf_bytes = (k - p) // 4
+    pre = (kmers >> np.uint64(2 * (k - p))).astype(np.int64)
+    lut = np.searchsorted(pre, np.arange(4 ** p, dtype=np.int64), side="left").astype(np.uint64)
+    header = np.zeros(7, dtype=np.uint64)
+    header[0] = k | (0 << 32)                       # kmer_length | mode<<32
+    header[1] = counter_size | (p << 32)            # counter_size | lut_prefix_length<<32
+    header[2] = min_count | ((max_count & 0xFFFFFFFF) << 32)
+    header[3] = total
+    header[4] = 0 if both_strands else 1            # low nibble 1 => "not both strands"
+    header[5] = 0
+    header[6] = 0                                    # trailing u32 = version 0 (KMC1)
+    header_offset = 7 * 8
+    with open(prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        f.write(struct.pack("<Q", total))
+        # the header must sit at (size - header_offset)/8 where size excludes markers and the offset word
+        hb = header.tobytes()
+        # version word = the u32 at EOF-12, i.e. the last 4 bytes of the header block
+        f.write(hb)
+        f.write(struct.pack("<I", header_offset))
+        f.write(b"KMCP")
+    rec = np.zeros((total, suf_bytes + counter_size), dtype=np.uint8)
+    suf = kmers & np.uint64((1 << (2 * (k - p))) - 1)
+    for b in range(suf_bytes):
+        rec[:, b] = ((suf >> np.uint64(8 * (suf_bytes - 1 - b))) & np.uint64(0xFF)).astype(np.uint8)
+    c = counts.astype(np.uint64)
+    for b in range(counter_size):
+        rec[:, suf_bytes + b] = ((c >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8)
+    with open(prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        f.write(rec.tobytes())
+        f.write(b"KMCS")
+
+
+def make_dataset(outdir: str, name: str, spec: HapSpec, k: int = 25, depth: int = 20):
+    """haplotype FASTA + KMC1 database for ``spec``; returns (fasta_path, kmc_prefix, haps)."""
+    os.makedirs(outdir, exist_ok=True)
+    haps = make_haplotypes(spec)
+    fa = os.path.join(outdir, name + ".fa")
+    write_fasta(fa, haps)
+    km, mult = canonical_counts(haps, k)
+    cnt = synth_counts(km, mult, depth=depth)
+    db = os.path.join(outdir, name + "_kmc")
+    write_kmc1(db, km, cnt, k)
+    return fa, db, haps
