@@ -1,0 +1,171 @@
+/*
+ * ploidyfrost_hip.h -- C ABI of the MI355X (gfx950) device layer for PloidyFrost's
+ * superbubble + variant-calling hot path.
+ *
+ * PloidyFrost has no plugin/FFI mechanism: its hot path sits behind the C++ classes CDBG
+ * (reference src/CDBG.hpp:20-41) and CCDBG, called only from main() (src/Main.cpp:829-849).
+ * This header is the boundary a maintainer would bind instead: every entry point names the
+ * reference function(s) whose compute it replaces.  Plain C types only; every buffer is
+ * caller-allocated; every call returns an int status (PF_OK = 0) instead of exit();
+ * one context per host thread / per GPU.
+ *
+ * Pointers marked [host|dev] may be host or device addresses (copied with
+ * hipMemcpyDefault), which lets a PyTorch caller hand in tensor storage directly.
+ *
+ * Conventions
+ *   unitig index u : 0-based, in the reference's iteration order (id = u + 1,
+ *                    src/CDBG.cpp:131-136: long unitigs in S-line order, then short ones)
+ *   oriented vertex: ov = 2*u + (strand ? 0 : 1); ov ^ 1 is the reverse complement
+ *   k-mer          : uint64, 2 bits/base (A0 C1 G2 T3), first base most significant,
+ *                    right aligned; 3 <= k <= 31
+ *   PF_NONE        : empty adjacency slot / no vertex
+ */
+#ifndef PLOIDYFROST_HIP_H_
+#define PLOIDYFROST_HIP_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PF_NONE 0xFFFFFFFFu
+
+enum pf_status {
+    PF_OK = 0,
+    PF_ERR_ARG = 1,         /* bad argument / call order */
+    PF_ERR_HIP = 2,         /* HIP runtime error, see pf_last_error() */
+    PF_ERR_NO_DEVICE = 3,   /* no gfx950 device visible: there is no CPU fallback */
+    PF_ERR_OVERFLOW = 4,    /* a caller-provided output buffer is too small */
+    PF_ERR_MISSING_KMER = 5 /* a graph k-mer is absent from the count table
+                               (the reference exit()s: src/CDBG.cpp:52-56, 92-96) */
+};
+
+typedef struct pf_ctx pf_ctx;
+
+/* ---- context ------------------------------------------------------------------------- */
+int pf_create(int device, pf_ctx **out);
+void pf_destroy(pf_ctx *);
+const char *pf_last_error(const pf_ctx *); /* ctx may be NULL: last creation error */
+/* Launch on this hipStream_t (e.g. torch's current stream) instead of the context's own. */
+int pf_set_stream(pf_ctx *, void *hip_stream);
+int pf_synchronize(pf_ctx *);
+/* Per-kernel HIP-event timing: when enabled every launch is bracketed by events on the
+ * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
+enum pf_kernel {
+    PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_COUNT_
+};
+int pf_enable_timing(pf_ctx *, int on);
+int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
+int pf_reset_timing(pf_ctx *);
+const char *pf_kernel_name(int kernel);
+
+/* ---- graph (replaces Bifrost's CompactedDBG storage for this path) --------------------- */
+/* Packed unitigs: unitig u occupies words [seq_off[u], seq_off[u] + ceil(len_bp[u]/32)) of
+ * seq_words; base j sits in word j/32 at bits [62 - 2*(j%32), 63 - 2*(j%32)] (first base
+ * most significant), padding bits zero.  seq_off has n_unitigs + 1 entries. [host|dev] */
+int pf_upload_graph(pf_ctx *, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp,
+                    uint32_t n_unitigs, int k);
+/* G2: neighbour discovery (bifrost/src/NeighborIterator.tcc:25-47 via
+ * CompactedDBG::find(km, extremities_only=true), CompactedDBG.tcc:1403-1523): joins the
+ * end k-mers of all unitigs on the device and fills the CSR kept in the context.
+ * succ/pred (2*n_unitigs*4 entries, A,C,G,T slot order) may be NULL. [host|dev] */
+int pf_build_adjacency(pf_ctx *, uint32_t *succ, uint32_t *pred);
+
+/* ---- k-mer count table (replaces CKMCFile, KMC/kmc_api/kmc_file.cpp) ------------------- */
+/* K1/K2: builds the device hash table from the database records (exact k-mers as stored, any
+ * order).  Records with count outside [min_count, max_count] are not retrievable, as in
+ * CKMCFile::BinarySearch (kmc_file.cpp:1459).  both_strands mirrors GetBothStrands();
+ * only both_strands = 1 databases are supported.  [host|dev] */
+int pf_upload_counts(pf_ctx *, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t min_count,
+                     uint64_t max_count, int both_strands);
+/* K2+K3 composite of src/CDBG.cpp:38-56 for a batch of k-mers:
+ * "if (!IsKmer(fwd)) reverse(); CheckKmer()".  found[i] = 0 when absent. [host|dev] */
+int pf_lookup_kmers(pf_ctx *, const uint64_t *kmers, uint64_t n, uint32_t *counts, uint8_t *found);
+
+/* ---- C1: CDBG::readCov(const UnitigMap&) (src/CDBG.cpp:66-120) for unitigs [u0, u1) ------ */
+/* sum = sum of canonical counts over the unitig's k-mers, min = min(10000, counts),
+ * miss = 1 if some k-mer is absent.  Arrays are indexed from u0.  The host does the one
+ * division (mean = sum / len). Returns PF_ERR_MISSING_KMER after filling the arrays if
+ * any miss flag is set. [host|dev] */
+int pf_unitig_cov(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *min, uint8_t *miss);
+
+/* ---- S2: CDBG::extractSuperBubble_ptr (src/CDBG.cpp:253-415), pure part ------------------ */
+typedef struct pf_bfs_record {
+    uint32_t entrance;  /* oriented vertex s */
+    uint32_t exit;      /* oriented vertex t, PF_NONE when outcome == PF_BFS_NONE */
+    uint32_t n_seen;    /* |vec_km_seen| (full length, even when list not stored) */
+    uint32_t n_list;    /* entries stored at list_off: seen[] for outcomes 1..3, the
+                           cycle set for outcome 0 with flag_cycle */
+    uint64_t list_off;  /* offset into the vertex pool */
+    uint8_t outcome;    /* enum pf_bfs_outcome */
+    uint8_t flag_cycle;
+    uint8_t flag_tip;
+    uint8_t strict;     /* accept only: the structural test of src/CDBG.cpp:765-782 passed */
+    uint32_t pad_;
+} pf_bfs_record;
+
+enum pf_bfs_outcome {
+    PF_BFS_NONE = 0,       /* stack ran empty: no exit (src/CDBG.cpp:373-414 applies) */
+    PF_BFS_CYCLE_EXIT = 1, /* exit found, s is a successor of t  -> setNoBubble_ptr_cycle */
+    PF_BFS_REJECT = 2,     /* exit found, cycle or tip inside     -> setNoBubble_ptr(seen, p) */
+    PF_BFS_ACCEPT = 3      /* exit found, clean                   -> setNoBubble_ptr(p, seen) */
+};
+
+/* Candidates: every oriented vertex with out-degree > 1 (the order-dependent
+ * `partner == NULL` gate of src/CDBG.cpp:206,211 is applied by the host during replay).
+ * pf_count_candidates returns how many lie in unitigs [u0, u1); pf_bfs_candidates traverses
+ * them, one wavefront each, and writes one record per candidate in ascending entrance
+ * order plus the variable-length vertex lists into pool (pool_cap entries).
+ * PF_ERR_OVERFLOW: *pool_used tells the size needed. [host|dev] */
+int pf_count_candidates(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *n_candidates);
+int pf_bfs_candidates(pf_ctx *, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap,
+                      uint32_t *pool, uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used);
+
+/* ---- A1: SeqAlign::needlemanWunch + traceback (src/SeqAlign.cpp:480-549, 306-478) ------- */
+/* One job = one pairwise alignment A x B.  Sequences are ASCII over {A,C,G,T,-}
+ * ('-' only in A, when A is a row of an earlier alignment).  For every job the device
+ * performs the full-matrix fill (scores in `int = long + double` arithmetic, +1 same-direction
+ * bonus, look-ahead rule, all tying directions flagged) and the all-co-optimal traceback with
+ * the shrinking 5-gap-open budgets, and returns the kept alignments in traceback order. */
+typedef struct pf_align_job {
+    uint64_t a_off, b_off; /* offsets into the text buffer */
+    uint32_t a_len, b_len;
+} pf_align_job;
+
+typedef struct pf_align_hit {
+    uint64_t text_off;   /* aligned rows: a at text_off, b at text_off + len (out_text) */
+    uint64_t gap_off;    /* gap_pos entries at gap_off (out_gaps), traceback order */
+    uint32_t len;        /* aligned length */
+    uint32_t n_gaps;
+    int64_t score;       /* variantAnalyze score (src/SeqAlign.cpp:255) */
+    uint32_t n_pos;      /* variant positions */
+    uint32_t n_indel;
+} pf_align_hit;
+
+/* hits of job j are hit_first[j] .. hit_first[j+1]-1 (hit_first has n_jobs+1 entries).
+ * PF_ERR_OVERFLOW when a capacity is too small: needed sizes are returned in used[3] =
+ * {hits, text bytes, gap entries}. [host|dev for text/jobs; outputs host|dev] */
+int pf_align_batch(pf_ctx *, const char *text, uint64_t text_len, const pf_align_job *jobs, uint32_t n_jobs,
+                   double match, double mismatch, double gap, uint64_t *hit_first, pf_align_hit *hits,
+                   uint64_t hit_cap, char *out_text, uint64_t text_cap, uint32_t *out_gaps, uint64_t gap_cap,
+                   uint64_t used[3]);
+
+/* ---- C2: CDBG::readCov(const string&, low, up) (src/CDBG.cpp:29-60) ---------------------- */
+/* strings are ASCII ACGT, string i = text[str_off[i] .. str_off[i+1]).  sum[i] = sum of
+ * canonical counts, ok[i] = 0 if any count is outside (low, up) (sum forced to 0), miss[i] = 1 if
+ * a k-mer is absent. [host|dev] */
+int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t n_str, uint32_t low, uint32_t up,
+                  uint64_t *sum, uint8_t *ok, uint8_t *miss);
+
+/* ---- introspection ---------------------------------------------------------------------- */
+int pf_device_name(pf_ctx *, char *buf, size_t cap);
+uint64_t pf_table_capacity(const pf_ctx *);
+uint64_t pf_num_kmers(const pf_ctx *);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PLOIDYFROST_HIP_H_ */

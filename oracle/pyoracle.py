@@ -1,0 +1,198 @@
+"""ctypes binding of the CPU ORACLE (oracle/pf_oracle.h) -- TEST INFRASTRUCTURE ONLY.
+
+May be imported by tests/, by __graft_entry__.smoke() and by the cpu_baseline leg of
+bench.py; never by anything under ploidyfrost_amd/.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(HERE, "_build", "libpf_oracle.so")
+CLI = os.path.join(HERE, "_build", "pf_oracle_cli")
+REF_BIN = os.path.join(HERE, "_ref", "PloidyFrost")
+REF_BIFROST = os.path.join(HERE, "_ref", "Bifrost")
+
+NONE = 0xFFFFFFFF
+OUTCOMES = {0: "none", 1: "cycle_exit", 2: "reject", 3: "accept"}
+
+
+def build() -> str:
+    """g++ the restatement into oracle/_build (no-op when up to date / no compiler)."""
+    if shutil.which("make") and shutil.which("g++"):
+        r = subprocess.run(["make", "-C", HERE], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("oracle build failed:\n" + r.stdout)
+    if not os.path.exists(LIB):
+        raise RuntimeError("oracle library missing and cannot be built")
+    return LIB
+
+
+def build_reference() -> str | None:
+    """oracle/_ref from /root/reference -- only where that tree exists (the build container)."""
+    ref = os.environ.get("PF_REFERENCE", "/root/reference")
+    if not os.path.isdir(os.path.join(ref, "src")):
+        return REF_BIN if os.path.exists(REF_BIN) else None
+    r = subprocess.run(["make", "-f", os.path.join("oracle", "Makefile.ref"), "-j8", "REF=" + ref], cwd=ROOT,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("reference build failed:\n" + r.stdout[-4000:])
+    return REF_BIN
+
+
+_lib = None
+
+
+def lib() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    build()
+    L = C.CDLL(LIB)
+    vp, u32, u64 = C.c_void_p, C.c_uint32, C.c_uint64
+    L.pfo_open.restype = vp
+    L.pfo_open.argtypes = [C.c_char_p, C.c_char_p]
+    L.pfo_close.argtypes = [vp]
+    L.pfo_last_error.restype = C.c_char_p
+    L.pfo_k.argtypes = [vp]
+    L.pfo_num_unitigs.restype = u32
+    L.pfo_num_unitigs.argtypes = [vp]
+    L.pfo_num_kmers.restype = u64
+    L.pfo_num_kmers.argtypes = [vp]
+    L.pfo_unitig_seq.restype = u32
+    L.pfo_unitig_seq.argtypes = [vp, u32, C.c_char_p, u32]
+    L.pfo_adjacency.argtypes = [vp, vp, vp]
+    L.pfo_unitig_cov.argtypes = [vp, u32, C.POINTER(u64), C.POINTER(u32)]
+    L.pfo_string_cov.argtypes = [vp, C.c_char_p, u32, u32, u32, C.POINTER(u64), C.POINTER(C.c_int)]
+    L.pfo_kmer_count.argtypes = [vp, C.c_char_p, C.POINTER(u32)]
+    L.pfo_extract.argtypes = [vp, u32, C.POINTER(u32), C.POINTER(u32), vp, C.POINTER(u32), vp, u32,
+                              C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pfo_seq_align.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, u32,
+                                C.POINTER(u32), vp, C.POINTER(u32), vp, C.POINTER(u32), vp, C.POINTER(u32), vp, u32, u32]
+    L.pfo_set_unitig_id.argtypes = [vp, C.c_char_p, C.c_char_p]
+    L.pfo_find_superbubbles.argtypes = [vp, C.c_char_p, C.c_char_p, u32, C.POINTER(u64)]
+    L.pfo_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
+                                        C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
+    L.pfo_state.argtypes = [vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+class Oracle:
+    """One loaded graph + k-mer database."""
+
+    def __init__(self, gfa: str, kmc_prefix: str | None):
+        self.L = lib()
+        self.h = self.L.pfo_open(gfa.encode(), (kmc_prefix or "").encode())
+        if not self.h:
+            raise RuntimeError("oracle: " + self.L.pfo_last_error().decode())
+        self.k = self.L.pfo_k(self.h)
+        self.n = self.L.pfo_num_unitigs(self.h)
+        self.n_kmers = self.L.pfo_num_kmers(self.h)
+
+    def close(self):
+        if self.h:
+            self.L.pfo_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sequences(self) -> list[bytes]:
+        out = []
+        buf = C.create_string_buffer(1 << 16)
+        for u in range(self.n):
+            n = self.L.pfo_unitig_seq(self.h, u, buf, len(buf))
+            if n > len(buf):
+                buf = C.create_string_buffer(n + 16)
+                self.L.pfo_unitig_seq(self.h, u, buf, len(buf))
+            out.append(buf.raw[:n])
+        return out
+
+    def adjacency(self):
+        succ = np.empty(self.n * 8, dtype=np.uint32)
+        pred = np.empty(self.n * 8, dtype=np.uint32)
+        self.L.pfo_adjacency(self.h, succ.ctypes.data, pred.ctypes.data)
+        return succ.reshape(-1, 4), pred.reshape(-1, 4)
+
+    def unitig_cov(self):
+        s = np.zeros(self.n, dtype=np.uint64)
+        m = np.zeros(self.n, dtype=np.uint32)
+        miss = np.zeros(self.n, dtype=np.uint8)
+        a, b = C.c_uint64(), C.c_uint32()
+        for u in range(self.n):
+            miss[u] = self.L.pfo_unitig_cov(self.h, u, C.byref(a), C.byref(b))
+            s[u], m[u] = a.value, b.value
+        return s, m, miss
+
+    def string_cov(self, text: bytes, low: int, up: int):
+        a, ok = C.c_uint64(), C.c_int()
+        miss = self.L.pfo_string_cov(self.h, text, len(text), low, up, C.byref(a), C.byref(ok))
+        return a.value, ok.value, miss
+
+    def extract(self, s_ov: int, cap: int = 1 << 16):
+        ex, ns, nc = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        fc, ft = C.c_int(), C.c_int()
+        seen = np.empty(cap, dtype=np.uint32)
+        cyc = np.empty(cap, dtype=np.uint32)
+        oc = self.L.pfo_extract(self.h, s_ov, C.byref(ex), C.byref(ns), seen.ctypes.data, C.byref(nc), cyc.ctypes.data,
+                                cap, C.byref(fc), C.byref(ft))
+        return dict(outcome=oc, exit=ex.value, seen=seen[: ns.value].copy(), cyc=cyc[: nc.value].copy(),
+                    flag_cycle=fc.value, flag_tip=ft.value)
+
+    def run(self, outdir: str, prefix: str, z=8, lower=10, upper=1000, M=2.0, D=-1.0, G=-3.0):
+        L = self.L
+        if L.pfo_set_unitig_id(self.h, outdir.encode(), prefix.encode()):
+            raise RuntimeError(L.pfo_last_error().decode())
+        nb = C.c_uint64()
+        if L.pfo_find_superbubbles(self.h, outdir.encode(), prefix.encode(), z, C.byref(nb)):
+            raise RuntimeError(L.pfo_last_error().decode())
+        allele = (C.c_uint64 * 4)()
+        cc, cn = C.c_uint64(), C.c_uint64()
+        rc = L.pfo_ploidy_estimation(self.h, outdir.encode(), prefix.encode(), lower, upper, M, D, G, allele, C.byref(cc),
+                                     C.byref(cn))
+        if rc:
+            raise RuntimeError(L.pfo_last_error().decode())
+        return dict(bubbles=nb.value, allele=list(allele), core_cov=cc.value, core_num=cn.value)
+
+    def find_superbubbles(self, z=8):
+        nb = C.c_uint64()
+        if self.L.pfo_find_superbubbles(self.h, None, None, z, C.byref(nb)):
+            raise RuntimeError(self.L.pfo_last_error().decode())
+        return nb.value
+
+    def state(self):
+        f = np.empty(self.n, dtype=np.uint8)
+        p = np.empty(self.n, dtype=np.uint32)
+        m = np.empty(self.n, dtype=np.uint32)
+        self.L.pfo_state(self.h, f.ctypes.data, p.ctypes.data, m.ctypes.data)
+        return f, p, m
+
+
+def seq_align(strs: list[bytes], M=2.0, D=-1.0, G=-3.0):
+    L = lib()
+    arr = (C.c_char_p * len(strs))(*strs)
+    cap = 1 << 20
+    out = C.create_string_buffer(cap)
+    pos_cap, part_cap = 1 << 14, 1 << 18
+    n_snp, n_indel, n_len, n_cols = C.c_uint32(), C.c_uint32(), C.c_uint32(), C.c_uint32()
+    snp = np.zeros(pos_cap, dtype=np.uint32)
+    indel = np.zeros(pos_cap, dtype=np.uint32)
+    ilen = np.zeros(pos_cap, dtype=np.uint32)
+    part = np.zeros(part_cap, dtype=np.uint16)
+    rows = L.pfo_seq_align(M, D, G, arr, len(strs), out, cap, C.byref(n_snp), snp.ctypes.data, C.byref(n_indel),
+                           indel.ctypes.data, C.byref(n_len), ilen.ctypes.data, C.byref(n_cols), part.ctypes.data,
+                           pos_cap, part_cap)
+    text = out.value.split(b"\n")[:rows]
+    return dict(rows=text, snp_pos=snp[: n_snp.value].copy(), indel_pos=indel[: n_indel.value].copy(),
+                indel_len=ilen[: n_len.value].copy(),
+                partition=part[: n_cols.value * max(rows, 1)].reshape(n_cols.value, max(rows, 1)).copy() if rows else None)

@@ -1,0 +1,786 @@
+// gfx950 device layer behind include/ploidyfrost_hip.h: context, tables, and the kernels
+//   K-TABLE  count-table build           (CKMCFile::OpenForRA data -> device hash table)
+//   K-ADJ    end-k-mer join -> CSR       (Bifrost neighbour discovery, NeighborIterator.tcc:25-47)
+//   K-COV    per-unitig coverage         (CDBG::readCov(UnitigMap), src/CDBG.cpp:66-120)
+//   K-BFS    superbubble traversal       (CDBG::extractSuperBubble_ptr, src/CDBG.cpp:253-372)
+//   K-STRCOV site-string coverage        (CDBG::readCov(string), src/CDBG.cpp:29-60)
+// K-ALN lives in pf_align.hip.  Integer / index-bound work: no MFMA anywhere.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pf_bfs.hpp"
+#include "pf_ctx.hpp"
+#include "pf_device_common.hpp"
+#include "ploidyfrost_hip.h"
+
+using namespace pf;
+
+static std::string g_create_err;
+
+#define PF_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return PF_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+// ------------------------------------------------------------------------------------------
+// kernels
+// ------------------------------------------------------------------------------------------
+
+__global__ void k_fill_slots(Slot *t, uint64_t n) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint4 v;
+        v.x = 0xFFFFFFFFu; v.y = 0xFFFFFFFFu; v.z = 0xFFFFFFFFu; v.w = 0;
+        *reinterpret_cast<uint4 *>(t + i) = v;
+    }
+}
+
+// K-TABLE: one thread per database record.
+__global__ void k_table_build(Slot *t, uint64_t mask, const uint64_t *__restrict__ kmers,
+                              const uint32_t *__restrict__ counts, uint64_t n, uint64_t min_count, uint64_t max_count) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t c = counts[i];
+        if (c < min_count || c > max_count) continue;  // not retrievable (kmc_file.cpp:1459)
+        const uint64_t key = kmers[i];
+        uint64_t s = mix64(key) & mask;
+        for (;;) {
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&t[s].key), EMPTY_KEY, key);
+            if (old == EMPTY_KEY || old == key) { t[s].val = c; break; }
+            s = (s + 1) & mask;
+        }
+    }
+}
+
+__global__ void k_lookup(const Slot *__restrict__ t, uint64_t mask, int k, const uint64_t *__restrict__ kmers, uint64_t n,
+                         uint32_t *__restrict__ counts, uint8_t *__restrict__ found) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        uint32_t c = 0;
+        bool ok = canonical_count(t, mask, kmers[i], k, c);
+        counts[i] = ok ? c : 0;
+        found[i] = ok;
+    }
+}
+
+// K-ADJ insert: the canonical k-mer at each extremity of each unitig.
+// value = (u << 2) | (is_tail << 1) | stored_is_canonical; the minimum wins, i.e. the lowest
+// unitig and its head first -- the order a sequential insert-if-absent would produce.
+__global__ void k_adj_insert(Slot *t, uint64_t mask, const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                             const uint32_t *__restrict__ len, uint32_t N, int k) {
+    uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (; u < N; u += stride) {
+        const uint64_t *w = seq + off[u];
+        const uint32_t L = len[u];
+        const int ends = L > (uint32_t)k ? 2 : 1;
+        for (int e = 0; e < ends; ++e) {
+            const uint64_t x = kmer_at(w, e ? L - k : 0, k);
+            const uint64_t r = rc_kmer(x, k);
+            const uint64_t c = x < r ? x : r;
+            const uint32_t v = (u << 2) | ((uint32_t)e << 1) | (x == c ? 1u : 0u);
+            uint64_t s = mix64(c) & mask;
+            for (;;) {
+                unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&t[s].key), EMPTY_KEY, c);
+                if (old == EMPTY_KEY || old == c) { atomicMin(&t[s].val, v); break; }
+                s = (s + 1) & mask;
+            }
+        }
+    }
+}
+
+__device__ inline uint32_t adj_find(const Slot *__restrict__ t, uint64_t mask, uint64_t q, int k) {
+    const uint64_t r = rc_kmer(q, k);
+    const uint64_t c = q < r ? q : r;
+    uint32_t v;
+    if (!table_find(t, mask, c, v)) return NONE;
+    // strand = (the query itself, not its twin, is what is stored): CompactedDBG.tcc:1476-1499
+    const bool strand = ((q == c) == ((v & 1u) != 0));
+    return ((v >> 2) << 1) | (strand ? 0u : 1u);
+}
+
+// K-ADJ probe: one thread per oriented vertex, 4 successor + 4 predecessor probes, two 16-B rows out.
+__global__ void k_adj_probe(const Slot *__restrict__ t, uint64_t mask, const uint64_t *__restrict__ seq,
+                            const uint64_t *__restrict__ off, const uint32_t *__restrict__ len, uint32_t N, int k,
+                            uint32_t *__restrict__ succ, uint32_t *__restrict__ pred) {
+    uint32_t ov = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    for (; ov < 2 * N; ov += stride) {
+        const uint32_t u = ov >> 1;
+        const uint64_t *w = seq + off[u];
+        const uint32_t L = len[u];
+        const uint64_t head = kmer_at(w, 0, k);
+        const uint64_t tail = L > (uint32_t)k ? kmer_at(w, L - k, k) : head;
+        // NeighborIterator.tcc:16-17
+        const uint64_t km_head = (ov & 1) ? rc_kmer(tail, k) : head;
+        const uint64_t km_tail = (ov & 1) ? rc_kmer(head, k) : tail;
+        uint4 so, po;
+        so.x = adj_find(t, mask, ((km_tail << 2) | 0) & kmask, k);
+        so.y = adj_find(t, mask, ((km_tail << 2) | 1) & kmask, k);
+        so.z = adj_find(t, mask, ((km_tail << 2) | 2) & kmask, k);
+        so.w = adj_find(t, mask, ((km_tail << 2) | 3) & kmask, k);
+        po.x = adj_find(t, mask, (km_head >> 2) | (0ull << (2 * (k - 1))), k);
+        po.y = adj_find(t, mask, (km_head >> 2) | (1ull << (2 * (k - 1))), k);
+        po.z = adj_find(t, mask, (km_head >> 2) | (2ull << (2 * (k - 1))), k);
+        po.w = adj_find(t, mask, (km_head >> 2) | (3ull << (2 * (k - 1))), k);
+        *reinterpret_cast<uint4 *>(succ + (size_t)ov * 4) = so;
+        *reinterpret_cast<uint4 *>(pred + (size_t)ov * 4) = po;
+    }
+}
+
+__global__ void k_mark_candidates(const uint32_t *__restrict__ succ, uint32_t n_ov, uint8_t *__restrict__ flag) {
+    uint32_t ov = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (; ov < n_ov; ov += stride) {
+        const uint4 s = *reinterpret_cast<const uint4 *>(succ + (size_t)ov * 4);
+        const int d = (s.x != NONE) + (s.y != NONE) + (s.z != NONE) + (s.w != NONE);
+        flag[ov] = d > 1;
+    }
+}
+
+// K-COV: one wavefront per unitig, lanes over its k-mers (64 per pass).
+// Launch: 256 threads = 4 waves per block, grid-stride over [u0, u1).
+__global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_t mask, const uint64_t *__restrict__ seq,
+                                             const uint64_t *__restrict__ off, const uint32_t *__restrict__ len, int k,
+                                             uint32_t u0, uint32_t u1, uint64_t *__restrict__ out_sum,
+                                             uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
+    const int lane = lane_id();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    for (uint32_t u = u0 + wave; u < u1; u += n_waves) {
+        const uint64_t *w = seq + off[u];
+        const uint32_t nk = len[u] - k + 1;
+        uint64_t sum = 0;
+        uint32_t mn = 10000;  // src/CDBG.cpp:71
+        bool miss = false;
+        for (uint32_t p = lane; p < nk; p += WAVE) {
+            uint32_t c;
+            if (canonical_count(t, mask, kmer_at(w, p, k), k, c)) {
+                sum += c;
+                mn = c < mn ? c : mn;
+            } else {
+                miss = true;
+            }
+        }
+        sum = wave_sum_u64(sum);
+        mn = wave_min_u32(mn);
+        const bool any_miss = __ballot(miss) != 0;
+        if (lane == 0) {
+            out_sum[u - u0] = sum;
+            out_min[u - u0] = mn;
+            out_miss[u - u0] = any_miss;
+        }
+    }
+}
+
+// K-STRCOV: one thread per string (strings are k .. k+few bases long).
+__global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, const char *__restrict__ text,
+                         const uint64_t *__restrict__ str_off, uint32_t n_str, uint32_t low, uint32_t up,
+                         uint64_t *__restrict__ out_sum, uint8_t *__restrict__ out_ok, uint8_t *__restrict__ out_miss) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    for (; i < n_str; i += stride) {
+        const char *s = text + str_off[i];
+        const uint32_t L = (uint32_t)(str_off[i + 1] - str_off[i]);
+        uint64_t sum = 0, x = 0;
+        uint8_t ok = 1, miss = 0;
+        for (uint32_t j = 0; j < L; ++j) {
+            const char ch = s[j];
+            const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+            x = ((x << 2) | b) & kmask;
+            if (j + 1 >= (uint32_t)k) {
+                uint32_t c;
+                if (!canonical_count(t, mask, x, k, c)) { miss = 1; break; }
+                if (c > low && c < up) sum += c;
+                else { sum = 0; ok = 0; break; }  // src/CDBG.cpp:45-50
+            }
+        }
+        out_sum[i] = sum;
+        out_ok[i] = ok;
+        out_miss[i] = miss;
+    }
+}
+
+// K-BFS, LDS tier: 4 waves per block, each with its own LDS slice of CAP entries.
+constexpr uint32_t BFS_LDS_CAP = 128;
+constexpr uint32_t BFS_BIG_CAP = 1u << 16;
+
+struct BfsOut {
+    pf_bfs_record *rec;
+    uint32_t *pool;
+    uint64_t pool_cap;
+    unsigned long long *pool_head;  // running total (may exceed pool_cap: tells the size needed)
+    uint32_t *deferred;             // candidate indices for the big tier
+    unsigned int *n_deferred;
+};
+
+__device__ inline void bfs_emit(const BfsOut &o, uint64_t ci, uint32_t s, const BfsResult &r, const BfsStore &st) {
+    const int lane = lane_id();
+    // what the host replay needs: seen[] when an exit was found, the cycle set otherwise
+    const bool want_seen = r.outcome != PF_BFS_NONE;
+    const uint32_t n_list = want_seen ? r.n_seen : (r.flag_cycle ? r.n_cyc : 0);
+    const uint32_t *src = want_seen ? st.ent : st.cyc;
+    unsigned long long off = 0;
+    if (lane == 0 && n_list) off = atomicAdd(o.pool_head, (unsigned long long)n_list);
+    off = ((unsigned long long)__shfl((uint32_t)(off >> 32), 0, WAVE) << 32) | __shfl((uint32_t)off, 0, WAVE);
+    if (off + n_list <= o.pool_cap)
+        for (uint32_t i = lane; i < n_list; i += WAVE) o.pool[off + i] = src[i];
+    if (lane == 0) {
+        pf_bfs_record rec;
+        rec.entrance = s;
+        rec.exit = r.exit_ov;
+        rec.n_seen = r.n_seen;
+        rec.n_list = n_list;
+        rec.list_off = off;
+        rec.outcome = r.outcome;
+        rec.flag_cycle = r.flag_cycle;
+        rec.flag_tip = r.flag_tip;
+        rec.strict = r.strict;
+        rec.pad_ = 0;
+        o.rec[ci] = rec;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
+                                             const uint32_t *__restrict__ cand, uint64_t c0, uint64_t c1, BfsOut o) {
+    __shared__ uint32_t s_ent[4][BFS_LDS_CAP];
+    __shared__ uint32_t s_todo[4][BFS_LDS_CAP];
+    __shared__ uint32_t s_cyc[4][BFS_LDS_CAP];
+    __shared__ uint8_t s_meta[4][BFS_LDS_CAP];
+    const int wv = threadIdx.x >> 6;
+    BfsStore st{s_ent[wv], s_meta[wv], s_todo[wv], s_cyc[wv], BFS_LDS_CAP};
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t c = c0 + wave; c < c1; c += n_waves) {
+        const uint32_t s = cand[c];
+        BfsResult r = bfs_traverse(succ, pred, st, s);
+        if (r.overflow) {
+            if (lane_id() == 0) {
+                pf_bfs_record rec;
+                memset(&rec, 0, sizeof(rec));
+                rec.entrance = s;
+                rec.exit = NONE;
+                rec.outcome = BFS_DEFERRED;
+                o.rec[c - c0] = rec;
+                const unsigned int d = atomicAdd(o.n_deferred, 1u);
+                o.deferred[d] = (uint32_t)(c - c0);
+            }
+        } else {
+            bfs_emit(o, c - c0, s, r, st);
+        }
+        wave_sync();
+    }
+}
+
+// K-BFS, big tier: same traversal over per-wave global scratch (BFS_BIG_CAP entries per table).
+__global__ __launch_bounds__(64) void k_bfs_big(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
+                                                const uint32_t *__restrict__ cand, uint64_t c0, unsigned int n_deferred,
+                                                uint32_t *scratch32, uint8_t *scratch8, BfsOut o) {
+    const uint32_t wave = blockIdx.x;
+    uint32_t *base = scratch32 + (size_t)wave * 3 * BFS_BIG_CAP;
+    BfsStore st{base, scratch8 + (size_t)wave * BFS_BIG_CAP, base + BFS_BIG_CAP, base + 2 * BFS_BIG_CAP, BFS_BIG_CAP};
+    for (unsigned int d = wave; d < n_deferred; d += gridDim.x) {
+        const uint32_t ci = o.deferred[d];
+        const uint32_t s = cand[c0 + ci];
+        BfsResult r = bfs_traverse(succ, pred, st, s);
+        if (r.overflow) {
+            if (lane_id() == 0) o.rec[ci].outcome = BFS_TOO_LARGE;
+        } else {
+            bfs_emit(o, ci, s, r, st);
+        }
+        wave_sync();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side of the C ABI
+// ------------------------------------------------------------------------------------------
+namespace pf {
+
+static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
+                                                "k_bfs_big",     "k_align",      "k_align_big", "k_strcov"};
+
+int ctx_begin(pf_ctx *ctx, int kernel) {
+    if (!ctx->timing) return 0;
+    TimedLaunch tl;
+    tl.kernel = kernel;
+    if (hipEventCreate(&tl.a) != hipSuccess || hipEventCreate(&tl.b) != hipSuccess) return 1;
+    hipEventRecord(tl.a, ctx->stream);
+    ctx->launches.push_back(tl);
+    return 0;
+}
+void ctx_end(pf_ctx *ctx) {
+    if (!ctx->timing || ctx->launches.empty()) return;
+    hipEventRecord(ctx->launches.back().b, ctx->stream);
+}
+
+int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu) {
+    uint64_t want = (work_items + block - 1) / block;
+    uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
+    if (want < 1) want = 1;
+    return (int)std::min<uint64_t>(want, cap);
+}
+
+}  // namespace pf
+
+// helper: device staging of an input that may live on the host
+template <typename T>
+static int stage_in(pf_ctx *ctx, const T *src, size_t n, T **dev, bool *owned) {
+    hipPointerAttribute_t at;
+    *owned = false;
+    if (n == 0) { *dev = nullptr; return PF_OK; }
+    if (hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeDevice) {
+        *dev = const_cast<T *>(src);
+        return PF_OK;
+    }
+    (void)hipGetLastError();
+    PF_HIP(hipMalloc(dev, n * sizeof(T)));
+    *owned = true;
+    PF_HIP(hipMemcpyAsync(*dev, src, n * sizeof(T), hipMemcpyDefault, ctx->stream));
+    return PF_OK;
+}
+
+extern "C" {
+
+const char *pf_kernel_name(int kernel) { return (kernel >= 0 && kernel < PF_K_COUNT_) ? kKernelNames[kernel] : "?"; }
+
+const char *pf_last_error(const pf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int pf_create(int device, pf_ctx **out) {
+    if (!out) return PF_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) {
+        g_create_err = "no HIP device visible: the PloidyFrost device layer has no CPU fallback";
+        return PF_ERR_NO_DEVICE;
+    }
+    if (device < 0 || device >= n) { g_create_err = "device index out of range"; return PF_ERR_ARG; }
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
+        g_create_err = "hipSetDevice / hipGetDeviceProperties failed";
+        return PF_ERR_HIP;
+    }
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0) {
+        g_create_err = std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only";
+        return PF_ERR_NO_DEVICE;
+    }
+    pf_ctx *ctx = new pf_ctx();
+    ctx->device = device;
+    ctx->n_cu = prop.multiProcessorCount;
+    ctx->name = prop.name;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        g_create_err = "hipStreamCreate failed";
+        delete ctx;
+        return PF_ERR_HIP;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return PF_OK;
+}
+
+static void free_graph(pf_ctx *ctx) {
+    hipFree(ctx->d_seq); hipFree(ctx->d_off); hipFree(ctx->d_len); hipFree(ctx->d_succ); hipFree(ctx->d_pred);
+    hipFree(ctx->d_cand);
+    ctx->d_seq = ctx->d_off = nullptr;
+    ctx->d_len = ctx->d_succ = ctx->d_pred = ctx->d_cand = nullptr;
+    ctx->h_cand.clear();
+    ctx->has_adj = false;
+}
+
+void pf_destroy(pf_ctx *ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
+    free_graph(ctx);
+    hipFree(ctx->d_tab);
+    hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+int pf_set_stream(pf_ctx *ctx, void *s) {
+    if (!ctx) return PF_ERR_ARG;
+    ctx->stream = s ? (hipStream_t)s : ctx->own_stream;
+    return PF_OK;
+}
+
+int pf_synchronize(pf_ctx *ctx) {
+    if (!ctx) return PF_ERR_ARG;
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    return PF_OK;
+}
+
+int pf_enable_timing(pf_ctx *ctx, int on) {
+    if (!ctx) return PF_ERR_ARG;
+    ctx->timing = on != 0;
+    return PF_OK;
+}
+
+int pf_reset_timing(pf_ctx *ctx) {
+    if (!ctx) return PF_ERR_ARG;
+    hipStreamSynchronize(ctx->stream);
+    for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
+    ctx->launches.clear();
+    return PF_OK;
+}
+
+int pf_kernel_time(pf_ctx *ctx, int kernel, double *total_ms, uint64_t *launches) {
+    if (!ctx || kernel < 0 || kernel >= PF_K_COUNT_) return PF_ERR_ARG;
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    double tot = 0;
+    uint64_t n = 0;
+    for (auto &tl : ctx->launches) {
+        if (tl.kernel != kernel) continue;
+        float ms = 0;
+        PF_HIP(hipEventElapsedTime(&ms, tl.a, tl.b));
+        tot += ms;
+        n++;
+    }
+    if (total_ms) *total_ms = tot;
+    if (launches) *launches = n;
+    return PF_OK;
+}
+
+int pf_device_name(pf_ctx *ctx, char *buf, size_t cap) {
+    if (!ctx || !buf || !cap) return PF_ERR_ARG;
+    snprintf(buf, cap, "%s", ctx->name.c_str());
+    return PF_OK;
+}
+
+uint64_t pf_table_capacity(const pf_ctx *ctx) { return ctx ? ctx->tab_cap : 0; }
+uint64_t pf_num_kmers(const pf_ctx *ctx) { return ctx ? ctx->n_kmers : 0; }
+
+int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp,
+                    uint32_t N, int k) {
+    if (!ctx || !seq_words || !seq_off || !len_bp || N == 0 || k < 3 || k > 31) return PF_ERR_ARG;
+    if (N >= (1u << 30)) { ctx->err = "more than 2^30 unitigs"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    free_graph(ctx);
+    // seq_off[N] = total words; fetch it (host or device pointer)
+    uint64_t total_words = 0;
+    PF_HIP(hipMemcpy(&total_words, seq_off + N, 8, hipMemcpyDefault));
+    ctx->N = N;
+    ctx->k = k;
+    ctx->n_words = total_words;
+    PF_HIP(hipMalloc(&ctx->d_seq, (total_words + 2) * 8));
+    PF_HIP(hipMemsetAsync(ctx->d_seq, 0, (total_words + 2) * 8, ctx->stream));
+    PF_HIP(hipMalloc(&ctx->d_off, ((size_t)N + 1) * 8));
+    PF_HIP(hipMalloc(&ctx->d_len, (size_t)N * 4));
+    PF_HIP(hipMemcpyAsync(ctx->d_seq, seq_words, total_words * 8, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(ctx->d_off, seq_off, ((size_t)N + 1) * 8, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(ctx->d_len, len_bp, (size_t)N * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    // host-side validation of what the kernels assume (lengths >= k, offsets cover lengths)
+    std::vector<uint32_t> hl(N);
+    std::vector<uint64_t> ho((size_t)N + 1);
+    PF_HIP(hipMemcpy(hl.data(), ctx->d_len, (size_t)N * 4, hipMemcpyDeviceToHost));
+    PF_HIP(hipMemcpy(ho.data(), ctx->d_off, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost));
+    uint64_t nk = 0;
+    for (uint32_t u = 0; u < N; ++u) {
+        if (hl[u] < (uint32_t)k) { ctx->err = "unitig shorter than k"; free_graph(ctx); return PF_ERR_ARG; }
+        if (ho[u + 1] < ho[u] || (ho[u + 1] - ho[u]) * 32 < hl[u] || ho[u + 1] > total_words) {
+            ctx->err = "seq_off does not cover len_bp";
+            free_graph(ctx);
+            return PF_ERR_ARG;
+        }
+        nk += hl[u] - k + 1;
+    }
+    ctx->n_kmers = nk;
+    return PF_OK;
+}
+
+int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
+    if (!ctx || !ctx->d_seq) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    const uint32_t N = ctx->N;
+    uint64_t cap = 1;
+    while (cap < (uint64_t)N * 4) cap <<= 1;
+    Slot *ends = nullptr;
+    PF_HIP(hipMalloc(&ends, cap * sizeof(Slot)));
+    if (!ctx->d_succ) PF_HIP(hipMalloc(&ctx->d_succ, (size_t)N * 8 * 4));
+    if (!ctx->d_pred) PF_HIP(hipMalloc(&ctx->d_pred, (size_t)N * 8 * 4));
+    k_fill_slots<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ends, cap);
+    ctx_begin(ctx, PF_K_ADJ_INSERT);
+    k_adj_insert<<<ctx_grid(ctx, N, 256, 8), 256, 0, ctx->stream>>>(ends, cap - 1, ctx->d_seq, ctx->d_off, ctx->d_len, N, ctx->k);
+    ctx_end(ctx);
+    ctx_begin(ctx, PF_K_ADJ_PROBE);
+    k_adj_probe<<<ctx_grid(ctx, (uint64_t)N * 2, 256, 8), 256, 0, ctx->stream>>>(ends, cap - 1, ctx->d_seq, ctx->d_off,
+                                                                               ctx->d_len, N, ctx->k, ctx->d_succ, ctx->d_pred);
+    ctx_end(ctx);
+    // candidate list: oriented vertices with out-degree > 1, ascending
+    uint8_t *flag = nullptr;
+    uint32_t *d_num = nullptr;
+    PF_HIP(hipMalloc(&flag, (size_t)N * 2));
+    PF_HIP(hipMalloc(&d_num, 4));
+    hipFree(ctx->d_cand);
+    ctx->d_cand = nullptr;
+    PF_HIP(hipMalloc(&ctx->d_cand, (size_t)N * 2 * 4));
+    k_mark_candidates<<<ctx_grid(ctx, (uint64_t)N * 2, 256, 8), 256, 0, ctx->stream>>>(ctx->d_succ, N * 2, flag);
+    {
+        hipcub::CountingInputIterator<uint32_t> ids(0);
+        size_t tmp_bytes = 0;
+        void *tmp = nullptr;
+        PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, ids, flag, ctx->d_cand, d_num, (int)(N * 2), ctx->stream));
+        PF_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+        PF_HIP(hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, ids, flag, ctx->d_cand, d_num, (int)(N * 2), ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+        hipFree(tmp);
+    }
+    uint32_t n_cand = 0;
+    PF_HIP(hipMemcpy(&n_cand, d_num, 4, hipMemcpyDeviceToHost));
+    ctx->h_cand.resize(n_cand);
+    if (n_cand) PF_HIP(hipMemcpy(ctx->h_cand.data(), ctx->d_cand, (size_t)n_cand * 4, hipMemcpyDeviceToHost));
+    hipFree(flag);
+    hipFree(d_num);
+    hipFree(ends);
+    ctx->has_adj = true;
+    if (succ) PF_HIP(hipMemcpyAsync(succ, ctx->d_succ, (size_t)N * 8 * 4, hipMemcpyDefault, ctx->stream));
+    if (pred) PF_HIP(hipMemcpyAsync(pred, ctx->d_pred, (size_t)N * 8 * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    return PF_OK;
+}
+
+int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t min_count,
+                     uint64_t max_count, int both_strands) {
+    if (!ctx || (n && (!kmers || !counts))) return PF_ERR_ARG;
+    if (!both_strands) {
+        ctx->err = "databases built without canonical counting (GetBothStrands() == false) are not supported";
+        return PF_ERR_ARG;
+    }
+    PF_HIP(hipSetDevice(ctx->device));
+    hipFree(ctx->d_tab);
+    ctx->d_tab = nullptr;
+    uint64_t cap = 1024;
+    while (cap < n * 2) cap <<= 1;
+    PF_HIP(hipMalloc(&ctx->d_tab, cap * sizeof(Slot)));
+    ctx->tab_cap = cap;
+    ctx->tab_n = n;
+    k_fill_slots<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap);
+    // stage the records on the device if the caller passed host memory
+    hipPointerAttribute_t at;
+    const bool on_dev = n && hipPointerGetAttributes(&at, kmers) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    uint64_t *dk = nullptr;
+    uint32_t *dc = nullptr;
+    const uint64_t *pk = kmers;
+    const uint32_t *pc = counts;
+    if (!on_dev && n) {
+        PF_HIP(hipMalloc(&dk, n * 8));
+        PF_HIP(hipMalloc(&dc, n * 4));
+        PF_HIP(hipMemcpyAsync(dk, kmers, n * 8, hipMemcpyDefault, ctx->stream));
+        PF_HIP(hipMemcpyAsync(dc, counts, n * 4, hipMemcpyDefault, ctx->stream));
+        pk = dk;
+        pc = dc;
+    }
+    if (n) {
+        ctx_begin(ctx, PF_K_TABLE_BUILD);
+        k_table_build<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap - 1, pk, pc, n, min_count, max_count);
+        ctx_end(ctx);
+    }
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    hipFree(dk);
+    hipFree(dc);
+    return PF_OK;
+}
+
+int pf_lookup_kmers(pf_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *counts, uint8_t *found) {
+    if (!ctx || !ctx->d_tab || !kmers || !counts || !found) return PF_ERR_ARG;
+    if (n == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    uint64_t *dk;
+    bool own;
+    int rc = stage_in(ctx, kmers, n, &dk, &own);
+    if (rc) return rc;
+    uint32_t *dc;
+    uint8_t *df;
+    PF_HIP(hipMalloc(&dc, n * 4));
+    PF_HIP(hipMalloc(&df, n));
+    k_lookup<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, dk, n, dc, df);
+    PF_HIP(hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(found, df, n, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    if (own) hipFree(dk);
+    hipFree(dc);
+    hipFree(df);
+    return PF_OK;
+}
+
+int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
+    if (!ctx || !ctx->d_seq || !ctx->d_tab || u0 > u1 || u1 > ctx->N || !sum || !mn || !miss) return PF_ERR_ARG;
+    if (u0 == u1) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    const uint32_t n = u1 - u0;
+    // outputs: write straight into device memory when the caller gave device pointers
+    hipPointerAttribute_t at;
+    const bool dev_out = hipPointerGetAttributes(&at, sum) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    uint64_t *ds = sum;
+    uint32_t *dm = mn;
+    uint8_t *dx = miss;
+    if (!dev_out) {
+        if (ctx->cov_cap < n) {
+            hipFree(ctx->d_cov_sum); hipFree(ctx->d_cov_min); hipFree(ctx->d_cov_miss);
+            ctx->d_cov_sum = nullptr; ctx->d_cov_min = nullptr; ctx->d_cov_miss = nullptr;
+            PF_HIP(hipMalloc(&ctx->d_cov_sum, (size_t)n * 8));
+            PF_HIP(hipMalloc(&ctx->d_cov_min, (size_t)n * 4));
+            PF_HIP(hipMalloc(&ctx->d_cov_miss, (size_t)n));
+            ctx->cov_cap = n;
+        }
+        ds = ctx->d_cov_sum; dm = ctx->d_cov_min; dx = ctx->d_cov_miss;
+    }
+    // one wave per unitig, 4 waves per block; enough blocks to keep every CU at 8 waves/SIMD
+    const int grid = ctx_grid(ctx, (uint64_t)n * 64, 256, 16);
+    ctx_begin(ctx, PF_K_COV);
+    k_cov<<<grid, 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, u0, u1, ds, dm, dx);
+    ctx_end(ctx);
+    if (!dev_out) {
+        PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipMemcpyAsync(mn, dm, (size_t)n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipMemcpyAsync(miss, dx, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+        for (uint32_t i = 0; i < n; ++i)
+            if (miss[i]) { ctx->err = "a k-mer of the graph is missing from the count table"; return PF_ERR_MISSING_KMER; }
+    }
+    return PF_OK;
+}
+
+int pf_string_cov(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32_t n_str, uint32_t low, uint32_t up,
+                  uint64_t *sum, uint8_t *ok, uint8_t *miss) {
+    if (!ctx || !ctx->d_tab || (n_str && (!text || !str_off || !sum || !ok || !miss))) return PF_ERR_ARG;
+    if (n_str == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    uint64_t total = 0;
+    PF_HIP(hipMemcpy(&total, str_off + n_str, 8, hipMemcpyDefault));
+    char *dt;
+    uint64_t *doff;
+    bool own_t, own_o;
+    int rc = stage_in(ctx, text, (size_t)total, &dt, &own_t);
+    if (rc) return rc;
+    rc = stage_in(ctx, str_off, (size_t)n_str + 1, &doff, &own_o);
+    if (rc) return rc;
+    uint64_t *ds;
+    uint8_t *dk, *dm;
+    PF_HIP(hipMalloc(&ds, (size_t)n_str * 8));
+    PF_HIP(hipMalloc(&dk, n_str));
+    PF_HIP(hipMalloc(&dm, n_str));
+    ctx_begin(ctx, PF_K_STRCOV);
+    k_strcov<<<ctx_grid(ctx, n_str, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, dt, doff, n_str, low, up, ds, dk, dm);
+    ctx_end(ctx);
+    PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n_str * 8, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(ok, dk, n_str, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(miss, dm, n_str, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    if (own_t) hipFree(dt);
+    if (own_o) hipFree(doff);
+    hipFree(ds); hipFree(dk); hipFree(dm);
+    return PF_OK;
+}
+
+static void cand_range(const pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *c0, uint64_t *c1) {
+    const auto &v = ctx->h_cand;
+    *c0 = std::lower_bound(v.begin(), v.end(), u0 * 2) - v.begin();
+    *c1 = std::lower_bound(v.begin(), v.end(), u1 * 2) - v.begin();
+}
+
+int pf_count_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *n) {
+    if (!ctx || !ctx->has_adj || u0 > u1 || u1 > ctx->N || !n) return PF_ERR_ARG;
+    uint64_t c0, c1;
+    cand_range(ctx, u0, u1, &c0, &c1);
+    *n = c1 - c0;
+    return PF_OK;
+}
+
+int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
+                      uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used) {
+    if (!ctx || !ctx->has_adj || u0 > u1 || u1 > ctx->N || !records || !pool || !n_records || !pool_used) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    uint64_t c0, c1;
+    cand_range(ctx, u0, u1, &c0, &c1);
+    const uint64_t n = c1 - c0;
+    *n_records = n;
+    *pool_used = 0;
+    if (n > rec_cap) { ctx->err = "record buffer too small"; return PF_ERR_OVERFLOW; }
+    if (n == 0) return PF_OK;
+    hipPointerAttribute_t at;
+    const bool dev_out = hipPointerGetAttributes(&at, records) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    pf_bfs_record *d_rec = records;
+    uint32_t *d_pool = pool;
+    if (!dev_out) {
+        PF_HIP(hipMalloc(&d_rec, n * sizeof(pf_bfs_record)));
+        PF_HIP(hipMalloc(&d_pool, (pool_cap ? pool_cap : 1) * 4));
+    }
+    unsigned long long *d_head;
+    unsigned int *d_ndef;
+    uint32_t *d_def;
+    PF_HIP(hipMalloc(&d_head, 8));
+    PF_HIP(hipMalloc(&d_ndef, 4));
+    PF_HIP(hipMalloc(&d_def, n * 4));
+    PF_HIP(hipMemsetAsync(d_head, 0, 8, ctx->stream));
+    PF_HIP(hipMemsetAsync(d_ndef, 0, 4, ctx->stream));
+    BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef};
+    const int grid = ctx_grid(ctx, n * 64, 256, 8);
+    ctx_begin(ctx, PF_K_BFS);
+    k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o);
+    ctx_end(ctx);
+    unsigned int n_def = 0;
+    PF_HIP(hipMemcpyAsync(&n_def, d_ndef, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    int status = PF_OK;
+    if (n_def) {
+        const unsigned int waves = std::min<unsigned int>(n_def, 256);
+        uint32_t *sc32;
+        uint8_t *sc8;
+        PF_HIP(hipMalloc(&sc32, (size_t)waves * 3 * BFS_BIG_CAP * 4));
+        PF_HIP(hipMalloc(&sc8, (size_t)waves * BFS_BIG_CAP));
+        ctx_begin(ctx, PF_K_BFS_BIG);
+        k_bfs_big<<<waves, 64, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, n_def, sc32, sc8, o);
+        ctx_end(ctx);
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+        hipFree(sc32);
+        hipFree(sc8);
+    }
+    ctx->bfs_deferred = n_def;
+    unsigned long long head = 0;
+    PF_HIP(hipMemcpy(&head, d_head, 8, hipMemcpyDeviceToHost));
+    *pool_used = head;
+    if (head > pool_cap) {
+        ctx->err = "vertex pool too small";
+        status = PF_ERR_OVERFLOW;
+    }
+    if (!dev_out) {
+        if (status == PF_OK) {
+            PF_HIP(hipMemcpy(records, d_rec, n * sizeof(pf_bfs_record), hipMemcpyDeviceToHost));
+            PF_HIP(hipMemcpy(pool, d_pool, (size_t)head * 4, hipMemcpyDeviceToHost));
+            for (uint64_t i = 0; i < n; ++i)
+                if (records[i].outcome == BFS_TOO_LARGE) {
+                    ctx->err = "a traversal visited more than 65536 unitigs";
+                    status = PF_ERR_OVERFLOW;
+                    break;
+                }
+        }
+        hipFree(d_rec);
+        hipFree(d_pool);
+    }
+    hipFree(d_head);
+    hipFree(d_ndef);
+    hipFree(d_def);
+    return status;
+}
+
+}  // extern "C"

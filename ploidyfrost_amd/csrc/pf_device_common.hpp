@@ -1,0 +1,97 @@
+// Device-side helpers shared by the gfx950 kernels: 2-bit k-mer arithmetic, the open-addressing
+// tables, wave64 reductions.  gfx950 only: wavefront = 64 lanes, no dual paths.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace pf {
+
+constexpr int WAVE = 64;
+constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+// 16-byte slot: one probe = one 16-B load inside one 64-B sector.
+struct __attribute__((aligned(16))) Slot {
+    uint64_t key;
+    uint32_t val;
+    uint32_t pad;
+};
+
+__host__ __device__ inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 30;
+    x *= 0xBF58476D1CE4E5B9ull;
+    x ^= x >> 27;
+    x *= 0x94D049BB133111EBull;
+    x ^= x >> 31;
+    return x;
+}
+
+// k-mer starting at base p of a unitig whose packed words start at `w`
+// (first base most significant inside each word).
+__device__ inline uint64_t kmer_at(const uint64_t *__restrict__ w, uint32_t p, int k) {
+    const uint32_t wi = p >> 5;
+    const int s = (int)(p & 31) * 2;
+    uint64_t hi = w[wi];
+    uint64_t x = hi << s;
+    if (s + 2 * k > 64) x |= w[wi + 1] >> (64 - s);  // s > 0 here because 2k <= 62
+    return x >> (64 - 2 * k);
+}
+
+// reverse complement of a right-aligned 2-bit k-mer
+__device__ inline uint64_t rc_kmer(uint64_t x, int k) {
+    x = ~x;
+    x = __brevll(x);
+    x = ((x & 0x5555555555555555ull) << 1) | ((x >> 1) & 0x5555555555555555ull);
+    return x >> (64 - 2 * k);
+}
+
+__device__ inline Slot load_slot(const Slot *t, uint64_t i) {
+    // one 16-B vector load
+    const uint4 v = *reinterpret_cast<const uint4 *>(t + i);
+    Slot s;
+    s.key = ((uint64_t)v.y << 32) | v.x;
+    s.val = v.z;
+    s.pad = v.w;
+    return s;
+}
+
+// exact-key probe; returns true and the value when present
+__device__ inline bool table_find(const Slot *__restrict__ t, uint64_t mask, uint64_t key, uint32_t &val) {
+    uint64_t i = mix64(key) & mask;
+    for (;;) {
+        Slot s = load_slot(t, i);
+        if (s.key == key) { val = s.val; return true; }
+        if (s.key == EMPTY_KEY) return false;
+        i = (i + 1) & mask;
+    }
+}
+
+// The hot path's composite lookup (reference src/CDBG.cpp:38-56):
+// "if (!IsKmer(fwd)) reverse(); CheckKmer(...)".
+__device__ inline bool canonical_count(const Slot *__restrict__ t, uint64_t mask, uint64_t fwd, int k, uint32_t &cnt) {
+    if (table_find(t, mask, fwd, cnt)) return true;
+    return table_find(t, mask, rc_kmer(fwd, k), cnt);
+}
+
+__device__ inline uint64_t wave_sum_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t lo = __shfl_down((uint32_t)v, o, WAVE);
+        uint32_t hi = __shfl_down((uint32_t)(v >> 32), o, WAVE);
+        v += ((uint64_t)hi << 32) | lo;
+    }
+    return v;
+}
+
+__device__ inline uint32_t wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t x = __shfl_down(v, o, WAVE);
+        v = x < v ? x : v;
+    }
+    return v;
+}
+
+__device__ inline int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
+
+}  // namespace pf

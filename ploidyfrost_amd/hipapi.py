@@ -1,0 +1,287 @@
+"""ctypes binding of the gfx950 device layer (include/ploidyfrost_hip.h).
+
+The library is the product; this module is plumbing so that Python callers (bench.py, the
+tests, torch.distributed launchers) can drive it.  torch is imported first on purpose: PyTorch
+ships its own libamdhip64.so.7, and loading it first makes this library bind to the same HIP
+runtime, so torch tensors and torch streams can be handed straight to the C ABI.
+
+There is no CPU fallback: a missing library or a missing GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_hip.so")
+
+NONE = 0xFFFFFFFF
+PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
+KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
+           "k_strcov"]
+
+BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
+                       ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
+ALIGN_JOB = np.dtype([("a_off", "<u8"), ("b_off", "<u8"), ("a_len", "<u4"), ("b_len", "<u4")])
+ALIGN_HIT = np.dtype([("text_off", "<u8"), ("gap_off", "<u8"), ("len", "<u4"), ("n_gaps", "<u4"), ("score", "<i8"),
+                      ("n_pos", "<u4"), ("n_indel", "<u4")])
+assert BFS_RECORD.itemsize == 32 and ALIGN_JOB.itemsize == 24 and ALIGN_HIT.itemsize == 40
+
+_lib = None
+
+
+class DeviceError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__("ploidyfrost_hip status %d: %s" % (status, msg))
+        self.status = status
+
+
+def load_library() -> C.CDLL:
+    """Load libploidyfrost_hip.so (fails loudly when it has not been built)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(there is no CPU fallback for the device layer)" % LIB_PATH)
+    try:
+        import torch  # noqa: F401  (binds libamdhip64.so.7 first, see module docstring)
+    except Exception:  # pragma: no cover - torch is optional for pure ctypes use
+        pass
+    L = C.CDLL(LIB_PATH)
+    vp, u32, u64, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
+    sig = {
+        "pf_create": (i, [i, C.POINTER(vp)]),
+        "pf_destroy": (None, [vp]),
+        "pf_last_error": (C.c_char_p, [vp]),
+        "pf_set_stream": (i, [vp, vp]),
+        "pf_synchronize": (i, [vp]),
+        "pf_enable_timing": (i, [vp, i]),
+        "pf_kernel_time": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(u64)]),
+        "pf_reset_timing": (i, [vp]),
+        "pf_kernel_name": (C.c_char_p, [i]),
+        "pf_upload_graph": (i, [vp, vp, vp, vp, u32, i]),
+        "pf_build_adjacency": (i, [vp, vp, vp]),
+        "pf_upload_counts": (i, [vp, vp, vp, u64, u64, u64, i]),
+        "pf_lookup_kmers": (i, [vp, vp, u64, vp, vp]),
+        "pf_unitig_cov": (i, [vp, u32, u32, vp, vp, vp]),
+        "pf_count_candidates": (i, [vp, u32, u32, C.POINTER(u64)]),
+        "pf_bfs_candidates": (i, [vp, u32, u32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
+        "pf_align_batch": (i, [vp, vp, u64, vp, u32, C.c_double, C.c_double, C.c_double, vp, vp, u64, vp, u64, vp, u64,
+                               C.POINTER(u64)]),
+        "pf_string_cov": (i, [vp, vp, vp, u32, u32, u32, vp, vp, vp]),
+        "pf_device_name": (i, [vp, C.c_char_p, C.c_size_t]),
+        "pf_table_capacity": (u64, [vp]),
+        "pf_num_kmers": (u64, [vp]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)  # AttributeError = header / library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
+                    "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
+                    "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
+                    "pf_align_batch", "pf_string_cov", "pf_device_name", "pf_table_capacity", "pf_num_kmers"]
+
+
+def pack_unitigs(seqs: list[bytes]):
+    """2-bit pack (layout of pf_upload_graph): returns (words u64, off u64[N+1], len u32[N])."""
+    n = len(seqs)
+    lens = np.fromiter((len(s) for s in seqs), dtype=np.uint32, count=n)
+    nwords = (lens.astype(np.uint64) + 31) // 32
+    off = np.zeros(n + 1, dtype=np.uint64)
+    np.cumsum(nwords, out=off[1:])
+    total = int(off[-1])
+    codes = np.zeros(total * 32, dtype=np.uint8)
+    lut = np.zeros(256, dtype=np.uint8)
+    for ch, v in zip(b"ACGTacgt", [0, 1, 2, 3, 0, 1, 2, 3]):
+        lut[ch] = v
+    for u, s in enumerate(seqs):
+        b = int(off[u]) * 32
+        codes[b : b + len(s)] = lut[np.frombuffer(s, dtype=np.uint8)]
+    c = codes.reshape(total, 32).astype(np.uint64)
+    shifts = (np.uint64(62) - np.arange(32, dtype=np.uint64) * np.uint64(2))
+    words = (c << shifts).sum(axis=1, dtype=np.uint64) if total else np.zeros(0, dtype=np.uint64)
+    return np.ascontiguousarray(words), off, lens
+
+
+def _ptr(a):
+    """Address of a numpy array or a torch tensor (host or device)."""
+    if a is None:
+        return None
+    if isinstance(a, np.ndarray):
+        assert a.flags["C_CONTIGUOUS"]
+        return a.ctypes.data
+    return a.data_ptr()  # torch.Tensor
+
+
+class Device:
+    """One pf_ctx: graph + count table resident in the HBM of one MI355X."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        h = C.c_void_p()
+        st = self.L.pf_create(device, C.byref(h))
+        if st != PF_OK:
+            raise DeviceError(st, self.L.pf_last_error(None).decode())
+        self.h = h
+        self.n = 0
+        self.k = 0
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pf_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st: int, allow=()):
+        if st != PF_OK and st not in allow:
+            raise DeviceError(st, self.L.pf_last_error(self.h).decode())
+        return st
+
+    @property
+    def name(self) -> str:
+        buf = C.create_string_buffer(256)
+        self._check(self.L.pf_device_name(self.h, buf, 256))
+        return buf.value.decode()
+
+    def set_stream(self, stream_ptr: int | None):
+        self._check(self.L.pf_set_stream(self.h, stream_ptr))
+
+    def synchronize(self):
+        self._check(self.L.pf_synchronize(self.h))
+
+    def enable_timing(self, on=True):
+        self._check(self.L.pf_enable_timing(self.h, int(on)))
+
+    def reset_timing(self):
+        self._check(self.L.pf_reset_timing(self.h))
+
+    def kernel_times(self) -> dict:
+        out = {}
+        for i, name in enumerate(KERNELS):
+            ms, n = C.c_double(), C.c_uint64()
+            self._check(self.L.pf_kernel_time(self.h, i, C.byref(ms), C.byref(n)))
+            if n.value:
+                out[name] = (ms.value, n.value)
+        return out
+
+    # ---- uploads
+    def upload_graph(self, words, off, lens, k: int):
+        self.n = int(len(lens))
+        self.k = k
+        self._keep = (words, off, lens)
+        self._check(self.L.pf_upload_graph(self.h, _ptr(words), _ptr(off), _ptr(lens), self.n, k))
+
+    def build_adjacency(self, want_host=True):
+        if want_host:
+            succ = np.empty((self.n * 2, 4), dtype=np.uint32)
+            pred = np.empty((self.n * 2, 4), dtype=np.uint32)
+            self._check(self.L.pf_build_adjacency(self.h, succ.ctypes.data, pred.ctypes.data))
+            return succ, pred
+        self._check(self.L.pf_build_adjacency(self.h, None, None))
+        return None
+
+    def upload_counts(self, kmers, counts, min_count=1, max_count=0xFFFFFFFF, both_strands=True):
+        n = int(kmers.shape[0])
+        self._check(self.L.pf_upload_counts(self.h, _ptr(kmers), _ptr(counts), n, min_count, max_count, int(both_strands)))
+
+    def lookup(self, kmers: np.ndarray):
+        n = len(kmers)
+        c = np.zeros(n, dtype=np.uint32)
+        f = np.zeros(n, dtype=np.uint8)
+        self._check(self.L.pf_lookup_kmers(self.h, _ptr(np.ascontiguousarray(kmers, dtype=np.uint64)), n, _ptr(c), _ptr(f)))
+        return c, f
+
+    # ---- kernels
+    def unitig_cov(self, u0=0, u1=None, out=None):
+        u1 = self.n if u1 is None else u1
+        if out is None:
+            s = np.zeros(u1 - u0, dtype=np.uint64)
+            m = np.zeros(u1 - u0, dtype=np.uint32)
+            x = np.zeros(u1 - u0, dtype=np.uint8)
+        else:
+            s, m, x = out
+        st = self._check(self.L.pf_unitig_cov(self.h, u0, u1, _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
+        return s, m, x, st
+
+    def count_candidates(self, u0=0, u1=None) -> int:
+        u1 = self.n if u1 is None else u1
+        n = C.c_uint64()
+        self._check(self.L.pf_count_candidates(self.h, u0, u1, C.byref(n)))
+        return n.value
+
+    def bfs(self, u0=0, u1=None, pool_cap=None):
+        u1 = self.n if u1 is None else u1
+        n = self.count_candidates(u0, u1)
+        rec = np.zeros(max(n, 1), dtype=BFS_RECORD)
+        pool_cap = pool_cap or max(1024, n * 8)
+        while True:
+            pool = np.zeros(pool_cap, dtype=np.uint32)
+            nr, used = C.c_uint64(), C.c_uint64()
+            st = self.L.pf_bfs_candidates(self.h, u0, u1, rec.ctypes.data, len(rec), pool.ctypes.data, pool_cap, C.byref(nr),
+                                          C.byref(used))
+            if st == PF_ERR_OVERFLOW and used.value > pool_cap:
+                pool_cap = int(used.value)
+                continue
+            self._check(st)
+            return rec[: nr.value], pool[: used.value]
+
+    def string_cov(self, strings: list[bytes], low: int, up: int):
+        n = len(strings)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in strings], out=off[1:])
+        text = np.frombuffer(b"".join(strings) + b"\0", dtype=np.uint8).copy()
+        s = np.zeros(n, dtype=np.uint64)
+        ok = np.zeros(n, dtype=np.uint8)
+        miss = np.zeros(n, dtype=np.uint8)
+        self._check(self.L.pf_string_cov(self.h, text.ctypes.data, off.ctypes.data, n, low, up, s.ctypes.data, ok.ctypes.data,
+                                         miss.ctypes.data))
+        return s, ok, miss
+
+    def align_batch(self, pairs: list[tuple[bytes, bytes]], M=2.0, D=-1.0, G=-3.0):
+        """Returns, per job, the list of (a_row, b_row, gap_pos, score, n_pos, n_indel)."""
+        n = len(pairs)
+        jobs = np.zeros(n, dtype=ALIGN_JOB)
+        chunks = []
+        pos = 0
+        for j, (a, b) in enumerate(pairs):
+            jobs[j] = (pos, pos + len(a), len(a), len(b))
+            chunks += [a, b]
+            pos += len(a) + len(b)
+        text = np.frombuffer(b"".join(chunks) + b"\0", dtype=np.uint8).copy()
+        hit_cap, text_cap, gap_cap = max(64, 4 * n), max(4096, 8 * pos), max(1024, 4 * n * 8)
+        while True:
+            first = np.zeros(n + 1, dtype=np.uint64)
+            hits = np.zeros(hit_cap, dtype=ALIGN_HIT)
+            otext = np.zeros(text_cap, dtype=np.uint8)
+            ogap = np.zeros(gap_cap, dtype=np.uint32)
+            used = (C.c_uint64 * 3)()
+            st = self.L.pf_align_batch(self.h, text.ctypes.data, pos, jobs.ctypes.data, n, M, D, G, first.ctypes.data,
+                                       hits.ctypes.data, hit_cap, otext.ctypes.data, text_cap, ogap.ctypes.data, gap_cap, used)
+            if st == PF_ERR_OVERFLOW and (used[0] > hit_cap or used[1] > text_cap or used[2] > gap_cap):
+                hit_cap, text_cap, gap_cap = max(hit_cap, used[0]), max(text_cap, used[1]), max(gap_cap, used[2])
+                continue
+            self._check(st)
+            break
+        out = []
+        tb = otext.tobytes()
+        for j in range(n):
+            lst = []
+            for h in hits[int(first[j]) : int(first[j + 1])]:
+                o, ln = int(h["text_off"]), int(h["len"])
+                gp = ogap[int(h["gap_off"]) : int(h["gap_off"]) + int(h["n_gaps"])].copy()
+                lst.append((tb[o : o + ln], tb[o + ln : o + 2 * ln], gp, int(h["score"]), int(h["n_pos"]), int(h["n_indel"])))
+            out.append(lst)
+        return out

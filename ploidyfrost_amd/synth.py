@@ -54,25 +54,23 @@ def make_haplotypes(spec: HapSpec) -> list[np.ndarray]:
     ins_len = rng.integers(1, spec.max_ins + 1, size=nv)
     ins_seq = rng.integers(0, 4, size=(nv, spec.max_ins), dtype=np.uint8)
     alt_shift = rng.integers(1, 4, size=nv, dtype=np.uint8)
-    alt_shift2 = rng.integers(1, 4, size=nv, dtype=np.uint8)
     multi = (rng.random(nv) < spec.p_multi) & (spec.ploidy >= 3)
     # carrier mask: non-empty proper subset of haplotypes
     full = (1 << spec.ploidy) - 1
     carriers = rng.integers(1, full, size=nv) if full > 1 else np.ones(nv, dtype=np.int64)
-    second = rng.integers(0, spec.ploidy, size=nv)
+    # multi-allelic SNP sites: every haplotype draws its own allele (up to 4 alleles)
+    multi_shift = rng.integers(0, 4, size=(spec.ploidy, nv), dtype=np.uint8)
 
     haps = []
     for h in range(spec.ploidy):
         seq = base.copy()
         has = ((carriers >> h) & 1).astype(bool)
         # SNPs
-        m = has & (kind == 0)
+        m = has & (kind == 0) & ~multi
         seq[pos[m]] = (base[pos[m]] + alt_shift[m]) & 3
-        # a second ALT allele on one more haplotype at multi-allelic sites
-        m2 = multi & (kind == 0) & (second == h) & ~has
+        m2 = multi & (kind == 0)
         if m2.any():
-            a2 = (base[pos[m2]] + alt_shift2[m2]) & 3
-            seq[pos[m2]] = a2
+            seq[pos[m2]] = (base[pos[m2]] + multi_shift[h][m2]) & 3
         keep = np.ones(L, dtype=bool)
         md = has & (kind == 1)
         keep[pos[md]] = False
@@ -222,3 +220,36 @@ def make_dataset(outdir: str, name: str, spec: HapSpec, k: int = 25, depth: int 
     db = os.path.join(outdir, name + "_kmc")
     write_kmc1(db, km, cnt, k)
     return fa, db, haps
+
+
+def read_kmc1(prefix: str):
+    """Inverse of write_kmc1 (KMC1 layout only): returns (kmers u64 sorted, counts u32, meta dict)."""
+    pre = np.fromfile(prefix + ".kmc_pre", dtype=np.uint8)
+    suf = np.fromfile(prefix + ".kmc_suf", dtype=np.uint8)
+    assert pre[:4].tobytes() == b"KMCP" and pre[-4:].tobytes() == b"KMCP" and suf[:4].tobytes() == b"KMCS"
+    assert int(pre[-12:-8].view("<u4")[0]) == 0, "KMC1 layout expected"
+    header_offset = int(pre[-8])
+    body = pre[4:-8]
+    words = body[: (len(body) // 8) * 8].view("<u8")
+    hi = (len(body) - header_offset) // 8
+    k = int(words[hi] & 0xFFFFFFFF)
+    counter_size = int(words[hi + 1] & 0xFFFFFFFF)
+    p = int(words[hi + 1] >> np.uint64(32))
+    min_count = int(words[hi + 2] & 0xFFFFFFFF)
+    max_count = int(words[hi + 2] >> np.uint64(32))
+    total = int(words[hi + 3])
+    both = (int(words[hi + 4]) & 0xF) != 1
+    lut = words[: 4 ** p + 1].astype(np.int64).copy()
+    lut[4 ** p] = total
+    sb = (k - p) // 4
+    rec = suf[4 : 4 + total * (sb + counter_size)].reshape(total, sb + counter_size)
+    sfx = np.zeros(total, dtype=np.uint64)
+    for b in range(sb):
+        sfx = (sfx << np.uint64(8)) | rec[:, b].astype(np.uint64)
+    cnt = np.zeros(total, dtype=np.uint64)
+    for b in range(counter_size):
+        cnt |= rec[:, sb + b].astype(np.uint64) << np.uint64(8 * b)
+    prefix_of = np.repeat(np.arange(4 ** p, dtype=np.uint64), np.diff(lut))
+    kmers = (prefix_of << np.uint64(2 * (k - p))) | sfx
+    return kmers, cnt.astype(np.uint32), dict(k=k, p=p, min_count=min_count, max_count=max_count, both_strands=both,
+                                              total=total)

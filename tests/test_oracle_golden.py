@@ -1,0 +1,34 @@
+"""The oracle (oracle/pf_oracle*.cpp) against the committed outputs of the real reference
+binary (tests/golden/<case>/expected, produced by tests/golden/make_golden.py with -t 1).
+This is the pin that lets the oracle stand in for the reference on the GPU box."""
+import os
+import sys
+
+import pytest
+
+from conftest import ROOT, compare_outputs, golden_cases, load_case
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle  # noqa: E402
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_oracle_matches_reference_outputs(case, tmp_path):
+    meta = load_case(case)
+    o = pyoracle.Oracle(meta["gfa"], meta["db"])
+    assert o.k == meta["k"] and o.n == meta["unitigs"]
+    op = meta["opts"]
+    o.run(str(tmp_path), "g", z=int(op["-z"]), lower=int(op["-l"]), upper=int(op["-u"]), M=float(op["-M"]),
+          D=float(op["-D"]), G=float(op["-G"]))
+    bad = compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+    assert not bad, "files differ from the reference: %s" % bad
+
+
+@pytest.mark.skipif(not os.path.exists(pyoracle.REF_BIN), reason="reference binary (oracle/_ref) not built here")
+def test_reference_binary_reproduces_golden(tmp_path):
+    """The committed expectations really are what the reference emits (guards against stale fixtures)."""
+    import subprocess
+    meta = load_case("dip20k")
+    subprocess.run([pyoracle.REF_BIN, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "1"] + meta["args"],
+                   cwd=tmp_path, check=True, stdout=subprocess.DEVNULL)
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(tmp_path, "PloidyFrost_output"))
