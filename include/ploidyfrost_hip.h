@@ -145,13 +145,14 @@ typedef struct pf_align_hit {
     uint32_t n_indel;
 } pf_align_hit;
 
-/* hits of job j are hit_first[j] .. hit_first[j+1]-1 (hit_first has n_jobs+1 entries).
- * PF_ERR_OVERFLOW when a capacity is too small: needed sizes are returned in used[3] =
- * {hits, text bytes, gap entries}. [host|dev for text/jobs; outputs host|dev] */
+/* hits of job j are hits[hit_first[j] .. hit_first[j] + hit_count[j]) (both arrays have n_jobs
+ * entries; jobs are published in completion order, so the ranges are not sorted by j).
+ * PF_ERR_OVERFLOW when a capacity is too small: the sizes needed are returned in used[3] =
+ * {hits, text bytes, gap entries}. [text, jobs and all outputs: host|dev] */
 int pf_align_batch(pf_ctx *, const char *text, uint64_t text_len, const pf_align_job *jobs, uint32_t n_jobs,
-                   double match, double mismatch, double gap, uint64_t *hit_first, pf_align_hit *hits,
-                   uint64_t hit_cap, char *out_text, uint64_t text_cap, uint32_t *out_gaps, uint64_t gap_cap,
-                   uint64_t used[3]);
+                   double match, double mismatch, double gap, uint64_t *hit_first, uint32_t *hit_count,
+                   pf_align_hit *hits, uint64_t hit_cap, char *out_text, uint64_t text_cap, uint32_t *out_gaps,
+                   uint64_t gap_cap, uint64_t used[3]);
 
 /* ---- C2: CDBG::readCov(const string&, low, up) (src/CDBG.cpp:29-60) ---------------------- */
 /* strings are ASCII ACGT, string i = text[str_off[i] .. str_off[i+1]).  sum[i] = sum of

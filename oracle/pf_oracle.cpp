@@ -454,6 +454,26 @@ int pfo_seq_align(double M, double D, double G, const char *const *strs, int n, 
     return (int)r.rows.size();
 }
 
+// needlemanWunch + traceback for one pair, serialised one alignment per line:
+//   a_row \t b_row \t score \t n_pos \t indel \t gap_pos,gap_pos,...
+int pfo_pairwise(double M, double D, double G, const char *a, const char *b, char *out, uint32_t cap) {
+    Scoring sc{M, D, G};
+    std::vector<Aln> v = pairwise_all_optimal(sc, a, b);
+    std::string joined;
+    for (auto &al : v) {
+        joined += al.a + "\t" + al.b + "\t" + std::to_string(al.score) + "\t" + std::to_string(al.n_pos) + "\t" +
+                  std::to_string(al.indel) + "\t";
+        for (size_t i = 0; i < al.gap_pos.size(); ++i) joined += (i ? "," : "") + std::to_string(al.gap_pos[i]);
+        joined += "\n";
+    }
+    if (out && cap) {
+        uint32_t m = std::min<uint32_t>(cap - 1, (uint32_t)joined.size());
+        memcpy(out, joined.data(), m);
+        out[m] = 0;
+    }
+    return joined.size() + 1 > cap ? -(int)v.size() : (int)v.size();
+}
+
 // setUnitigId, CDBG.cpp:121-143
 int pfo_set_unitig_id(pfo_ctx *c, const char *outdir, const char *prefix) {
     if (!ensure_dir(outdir)) { g_err = "cannot create output directory"; return 1; }

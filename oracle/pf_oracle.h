@@ -68,6 +68,11 @@ int pfo_seq_align(double M, double D, double G, const char *const *strs, int n, 
                   uint32_t *n_indel_len, uint32_t *indel_len, uint32_t *n_cols, uint16_t *partition,
                   uint32_t pos_cap, uint32_t part_cap);
 
+/* needlemanWunch + traceback for one pair (SeqAlign.cpp:480-549, 306-478): the kept alignments,
+ * one per line "a_row\tb_row\tscore\tn_pos\tindel\tgap,gap,..."; returns their number (negative
+ * when out was too small). */
+int pfo_pairwise(double M, double D, double G, const char *a, const char *b, char *out, uint32_t cap);
+
 /* S1 + P1..P3 + O1: the whole path; writes the twelve <outdir>/<prefix>_*.txt files.
  * Per-unitig state after findSuperBubble is kept in the context.  0 = ok. */
 int pfo_set_unitig_id(pfo_ctx *, const char *outdir, const char *prefix);

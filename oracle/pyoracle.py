@@ -75,6 +75,7 @@ def lib() -> C.CDLL:
                               C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pfo_seq_align.argtypes = [C.c_double, C.c_double, C.c_double, C.POINTER(C.c_char_p), C.c_int, C.c_char_p, u32,
                                 C.POINTER(u32), vp, C.POINTER(u32), vp, C.POINTER(u32), vp, C.POINTER(u32), vp, u32, u32]
+    L.pfo_pairwise.argtypes = [C.c_double, C.c_double, C.c_double, C.c_char_p, C.c_char_p, C.c_char_p, u32]
     L.pfo_set_unitig_id.argtypes = [vp, C.c_char_p, C.c_char_p]
     L.pfo_find_superbubbles.argtypes = [vp, C.c_char_p, C.c_char_p, u32, C.POINTER(u64)]
     L.pfo_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
@@ -196,3 +197,21 @@ def seq_align(strs: list[bytes], M=2.0, D=-1.0, G=-3.0):
     return dict(rows=text, snp_pos=snp[: n_snp.value].copy(), indel_pos=indel[: n_indel.value].copy(),
                 indel_len=ilen[: n_len.value].copy(),
                 partition=part[: n_cols.value * max(rows, 1)].reshape(n_cols.value, max(rows, 1)).copy() if rows else None)
+
+
+def pairwise(a: bytes, b: bytes, M=2.0, D=-1.0, G=-3.0):
+    """[(a_row, b_row, gap_pos list, score, n_pos, indel)] in traceback order."""
+    L = lib()
+    cap = 1 << 16
+    while True:
+        out = C.create_string_buffer(cap)
+        n = L.pfo_pairwise(M, D, G, a, b, out, cap)
+        if n >= 0:
+            break
+        cap *= 8
+    res = []
+    for line in out.value.split(b"\n")[:n]:
+        f = line.split(b"\t")
+        gp = [int(x) for x in f[5].split(b",")] if f[5] else []
+        res.append((f[0], f[1], gp, int(f[2]), int(f[3]), int(f[4])))
+    return res

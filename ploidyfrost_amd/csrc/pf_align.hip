@@ -1,8 +1,562 @@
-// K-ALN placeholder (replaced by the real kernel).
+// K-ALN: SeqAlign::needlemanWunch + SeqAlign::traceback (reference src/SeqAlign.cpp:480-549,
+// 306-478) on gfx950 -- one wavefront per pairwise job.
+//
+//   fill      anti-diagonal sweep, lanes over the cells of a diagonal.  Only the 3 direction
+//             flags per cell are kept (1 byte: low nibble = the by-value `matrix`, high nibble =
+//             `matrix_temp`); scores live in three rolling diagonals.  Everything sits in LDS
+//             (dynamic LDS sized per size class); jobs too large for LDS run the same code over
+//             per-wave global scratch.  Score arithmetic is the reference's `int = long + double`
+//             (truncation), +1 when the move continues the predecessor's own direction, with the
+//             `A[i] == '-'` look-ahead rule; every direction that ties the maximum is flagged.
+//   traceback data-dependent DFS over all co-optimal paths (Left, then Up, then LeftUp) on lane 0,
+//             with the gap-open budgets that start at 5 and shrink to the best alignment found,
+//             permanent flag clearing on refused moves, and the reference's asymmetric gap-open
+//             bookkeeping for row B.  Each completed path is scored as variantAnalyze does
+//             (src/SeqAlign.cpp:237-305) and kept / replaces / is dropped per AlignUnit::operator-
+//             (src/SeqAlign.hpp:43-67).
+// No MFMA: integer compare/select on byte flags.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstring>
+#include <string>
+#include <vector>
+
 #include "pf_ctx.hpp"
+#include "pf_device_common.hpp"
 #include "ploidyfrost_hip.h"
-extern "C" int pf_align_batch(pf_ctx *ctx, const char *, uint64_t, const pf_align_job *, uint32_t, double, double, double,
-                              uint64_t *, pf_align_hit *, uint64_t, char *, uint64_t, uint32_t *, uint64_t, uint64_t[3]) {
-    if (ctx) ctx->err = "pf_align_batch: not built yet";
-    return PF_ERR_ARG;
+
+using namespace pf;
+
+#define PF_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return PF_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+enum : uint8_t { UP = 1, DIAG = 2, LEFT = 4 };
+
+__host__ __device__ inline uint32_t al4(uint32_t x) { return (x + 3u) & ~3u; }
+
+// bytes of working storage one job needs (must match the carve-up in align_job)
+__host__ __device__ inline uint64_t job_bytes(uint32_t m, uint32_t n) {
+    const uint64_t cells = (uint64_t)(m + 1) * (n + 1);
+    return ((cells + 3) & ~3ull) + 12ull * (m + 1) + al4(m) + al4(n) + 3ull * al4(m + n) + al4(2 * (m + n)) + 16;
+}
+
+struct AlnScratch {  // per-wave staging of the kept alignments (global memory)
+    char *text;
+    uint32_t *gaps;
+    pf_align_hit *hits;
+    uint32_t text_cap, gap_cap, hit_cap;
+};
+
+struct AlnOut {
+    uint64_t *hit_first;
+    uint32_t *hit_count;
+    pf_align_hit *hits;
+    uint64_t hit_cap;
+    char *text;
+    uint64_t text_cap;
+    uint32_t *gaps;
+    uint64_t gap_cap;
+    unsigned long long *heads;  // [0] hits, [1] text bytes, [2] gap entries (running totals)
+    uint32_t *retry;            // jobs whose staging overflowed
+    unsigned int *n_retry;
+};
+
+__device__ inline void aln_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+}
+
+// One job on one wavefront.  `base` = working storage (LDS or global), job_bytes(m, n) bytes.
+// Returns false when the staging area overflowed.
+__device__ bool align_job(uint8_t *base, const char *__restrict__ ga, const char *__restrict__ gb, uint32_t m, uint32_t n,
+                          double M, double D, double G, const AlnScratch &sc, uint32_t &n_hits_out, uint32_t &text_out,
+                          uint32_t &gaps_out) {
+    const int lane = lane_id();
+    const uint32_t W = n + 1;
+    const uint32_t cells = (m + 1) * W;
+    uint8_t *dir = base;
+    int *s0 = reinterpret_cast<int *>(base + ((cells + 3) & ~3u));
+    int *s1 = s0 + (m + 1);
+    int *s2 = s1 + (m + 1);
+    char *A = reinterpret_cast<char *>(s2 + (m + 1));
+    char *B = A + al4(m);
+    char *ra = B + al4(n);
+    char *rb = ra + al4(m + n);
+    uint8_t *mv = reinterpret_cast<uint8_t *>(rb + al4(m + n));
+    uint16_t *gp = reinterpret_cast<uint16_t *>(mv + al4(m + n));
+
+    for (uint32_t i = lane; i < m; i += WAVE) A[i] = ga[i];
+    for (uint32_t j = lane; j < n; j += WAVE) B[j] = gb[j];
+    // borders (src/SeqAlign.cpp:486-496)
+    for (uint32_t i = lane; i <= m; i += WAVE) dir[i * W] = i ? (uint8_t)(UP | (UP << 4)) : 0;
+    for (uint32_t j = 1 + lane; j <= n; j += WAVE) dir[j] = (uint8_t)(LEFT | (LEFT << 4));
+    // rolling diagonals, indexed by row: p2 = diagonal d-2, p1 = d-1, cur = d
+    int *p2 = s0, *p1 = s1, *cur = s2;
+    if (lane == 0) {
+        p2[0] = 0;                                  // (0,0)
+        p1[0] = n >= 1 ? (int)(long)(G * 1) : 0;    // (0,1)
+        if (m >= 1) p1[1] = (int)(long)(G * 1);     // (1,0)
+    }
+    aln_sync();
+    for (uint32_t d = 2; d <= m + n; ++d) {
+        const uint32_t lo = d > n ? d - n : 1;
+        const uint32_t hi = d - 1 < m ? d - 1 : m;
+        for (uint32_t i = lo + lane; i <= hi; i += WAVE) {
+            const uint32_t j = d - i;
+            const uint8_t f_up = dir[(i - 1) * W + j], f_dg = dir[(i - 1) * W + j - 1], f_lf = dir[i * W + j - 1];
+            int up = (int)((double)(long)p1[i - 1] + G);
+            if (f_up & UP) up += 1;
+            const char a = A[i - 1], b = B[j - 1];
+            const double sub = a == b ? M : ((a == '-' || b == '-') ? G : D);
+            int dg = (int)((double)(long)p2[i - 1] + sub);
+            if (f_dg & DIAG) dg += 1;
+            int lf = (int)((double)(long)p1[i] + G);
+            if (f_lf & LEFT) lf += 1;
+            int best = up > dg ? up : dg;
+            best = best > lf ? best : lf;
+            if (best == lf && i != m && A[i] == '-') {  // :528-532
+                lf = INT_MIN;
+                best = up > dg ? up : dg;
+            }
+            uint8_t f = 0;
+            if (up == best) f |= UP;
+            if (dg == best) f |= DIAG;
+            if (lf == best) f |= LEFT;
+            cur[i] = best;
+            dir[i * W + j] = (uint8_t)(f | (f << 4));
+        }
+        if (lane == 0) {
+            if (d <= n) cur[0] = (int)(long)(G * (double)d);  // (0,d)
+            if (d <= m) cur[d] = (int)(long)(G * (double)d);  // (d,0)
+        }
+        aln_sync();
+        int *t = p2;
+        p2 = p1;
+        p1 = cur;
+        cur = t;
+    }
+
+    // ---- traceback (lane 0) --------------------------------------------------------------
+    uint32_t n_hits = 0, text_used = 0, gaps_used = 0;
+    bool overflow = false;
+    if (lane == 0) {
+        uint64_t open_a = 0, open_b = 0, lim_a = 5, lim_b = 5;  // size_t in the reference
+        uint32_t len = 0, ng = 0;
+        uint32_t i = m, j = n;
+        bool have = false;
+        long long last_score = 0;
+        uint32_t last_npos = 0, last_indel = 0;
+        for (;;) {
+            const uint32_t c = i * W + j;
+            if (i == 0 && j == 0 && open_a <= lim_a && open_b <= lim_b) {
+                // variantAnalyze over the forward strings (stored back to front)
+                long long score = 0;
+                uint32_t npos = 0, indel = 0;
+                uint8_t run = 0;
+                for (uint32_t t = len; t-- > 0;) {
+                    const char a = ra[t] == '+' ? '-' : ra[t];
+                    const char b = rb[t];
+                    const double s = (a == '-' || b == '-') ? G : (a == b ? M : D);
+                    score = (long long)((double)score + s);
+                    if (a != b) {
+                        if (a == '-') { if (run != 1) { run = 1; indel++; npos++; } }
+                        else if (b == '-') { if (run != 2) { run = 2; indel++; npos++; } }
+                        else { run = 0; npos++; }
+                    } else {
+                        run = 0;
+                    }
+                }
+                bool take = true;
+                if (have) {
+                    long long diff;  // last - this (src/SeqAlign.hpp:43-67)
+                    if (last_score == score) {
+                        if (last_npos == npos) diff = last_indel == indel ? 0 : (long long)indel - (long long)last_indel;
+                        else diff = (long long)npos - (long long)last_npos;
+                    } else {
+                        diff = last_score > score ? 1 : -1;
+                    }
+                    const int d32 = (int)diff;
+                    if (d32 < 0) { n_hits = 0; text_used = 0; gaps_used = 0; }
+                    else if (d32 > 0) take = false;
+                }
+                if (take) {
+                    if (n_hits >= sc.hit_cap || text_used + 2 * len > sc.text_cap || gaps_used + ng > sc.gap_cap) {
+                        overflow = true;
+                        break;
+                    }
+                    pf_align_hit h;
+                    h.text_off = text_used;
+                    h.gap_off = gaps_used;
+                    h.len = len;
+                    h.n_gaps = ng;
+                    h.score = score;
+                    h.n_pos = npos;
+                    h.n_indel = indel;
+                    sc.hits[n_hits++] = h;
+                    char *ta = sc.text + text_used, *tb = ta + len;
+                    for (uint32_t t = 0; t < len; ++t) {
+                        const char a = ra[len - 1 - t];
+                        ta[t] = a == '+' ? '-' : a;
+                        tb[t] = rb[len - 1 - t];
+                    }
+                    for (uint32_t t = 0; t < ng; ++t) sc.gaps[gaps_used + t] = gp[t];
+                    text_used += 2 * len;
+                    gaps_used += ng;
+                    lim_a = open_a;
+                    lim_b = open_b;
+                    have = true;
+                    last_score = score;
+                    last_npos = npos;
+                    last_indel = indel;
+                }
+            }
+            const uint8_t dc = dir[c];
+            const uint8_t work = dc >> 4;
+            const char fa = len ? ra[len - 1] : '\0';
+            const char fb = len ? rb[len - 1] : '\0';
+            if (work & LEFT) {
+                bool go;
+                if (open_a < lim_a) {
+                    if (len == 0 || fa != '+') ++open_a;
+                    go = true;
+                } else if (open_a == lim_a) {
+                    go = fa == '+';
+                } else {
+                    go = false;
+                }
+                if (!go) {
+                    dir[c] = dc & (uint8_t) ~(LEFT | (LEFT << 4));
+                    continue;
+                }
+                dir[c] = dc & (uint8_t) ~(LEFT << 4);
+                ra[len] = '+';
+                rb[len] = B[j - 1];
+                mv[len] = LEFT;
+                gp[ng++] = (uint16_t)i;
+                len++;
+                j -= 1;
+            } else if (work & UP) {
+                bool go;
+                if (open_b < lim_b) {
+                    if (len == 0 || fb == '-') ++open_b;
+                    go = true;
+                } else if (open_b == lim_b) {
+                    go = fb == '-';
+                } else {
+                    go = false;
+                }
+                if (!go) {
+                    dir[c] = dc & (uint8_t) ~(UP | (UP << 4));
+                    continue;
+                }
+                dir[c] = dc & (uint8_t) ~(UP << 4);
+                ra[len] = A[i - 1];
+                rb[len] = '-';
+                mv[len] = UP;
+                len++;
+                i -= 1;
+            } else if (work & DIAG) {
+                dir[c] = dc & (uint8_t) ~(DIAG << 4);
+                ra[len] = A[i - 1];
+                rb[len] = B[j - 1];
+                mv[len] = DIAG;
+                len++;
+                i -= 1;
+                j -= 1;
+            } else {
+                if (len == 0) break;
+                dir[c] = (uint8_t)((dc & 0x0F) | ((dc & 0x0F) << 4));  // matrix_temp[p] = matrix[p]
+                if (fa == '+') {
+                    if (len >= 2) { if (ra[len - 2] != '+') --open_a; }
+                    else --open_a;
+                }
+                if (fb == '-') {
+                    if (len >= 2) { if (rb[len - 2] != '-') --open_b; }
+                    else --open_b;
+                }
+                if (fa == '+') ng--;
+                const uint8_t mvv = mv[len - 1];
+                if (mvv == LEFT) j += 1;
+                else if (mvv == UP) i += 1;
+                else { i += 1; j += 1; }
+                len--;
+            }
+        }
+    }
+    aln_sync();
+    n_hits_out = __shfl(n_hits, 0, WAVE);
+    text_out = __shfl(text_used, 0, WAVE);
+    gaps_out = __shfl(gaps_used, 0, WAVE);
+    return __shfl((int)overflow, 0, WAVE) == 0;
+}
+
+// publish the staged alignments of one job into the caller's pools (whole wave)
+__device__ void publish(const AlnOut &o, uint32_t job, const AlnScratch &sc, uint32_t n_hits, uint32_t text_used,
+                        uint32_t gaps_used) {
+    const int lane = lane_id();
+    unsigned long long h0 = 0, t0 = 0, g0 = 0;
+    if (lane == 0) {
+        h0 = atomicAdd(&o.heads[0], (unsigned long long)n_hits);
+        t0 = atomicAdd(&o.heads[1], (unsigned long long)text_used);
+        g0 = atomicAdd(&o.heads[2], (unsigned long long)gaps_used);
+        o.hit_first[job] = h0;
+        o.hit_count[job] = n_hits;
+    }
+    h0 = ((unsigned long long)__shfl((uint32_t)(h0 >> 32), 0, WAVE) << 32) | __shfl((uint32_t)h0, 0, WAVE);
+    t0 = ((unsigned long long)__shfl((uint32_t)(t0 >> 32), 0, WAVE) << 32) | __shfl((uint32_t)t0, 0, WAVE);
+    g0 = ((unsigned long long)__shfl((uint32_t)(g0 >> 32), 0, WAVE) << 32) | __shfl((uint32_t)g0, 0, WAVE);
+    if (h0 + n_hits > o.hit_cap || t0 + text_used > o.text_cap || g0 + gaps_used > o.gap_cap) return;  // host sees heads
+    for (uint32_t i = lane; i < n_hits; i += WAVE) {
+        pf_align_hit h = sc.hits[i];
+        h.text_off += t0;
+        h.gap_off += g0;
+        o.hits[h0 + i] = h;
+    }
+    for (uint32_t i = lane; i < text_used; i += WAVE) o.text[t0 + i] = sc.text[i];
+    for (uint32_t i = lane; i < gaps_used; i += WAVE) o.gaps[g0 + i] = sc.gaps[i];
+}
+
+struct AlnParams {
+    const char *text;
+    const pf_align_job *jobs;
+    const uint32_t *idx;  // job indices of this launch
+    uint32_t n;
+    double M, D, G;
+    // per-wave staging
+    char *st_text;
+    uint32_t *st_gaps;
+    pf_align_hit *st_hits;
+    uint32_t st_text_cap, st_gap_cap, st_hit_cap;
+    // global working storage (global tier only)
+    uint8_t *work;
+    uint64_t work_per_wave;
+    int final_tier;  // overflow here is an error, not a retry
+};
+
+template <bool LDS>
+__global__ __launch_bounds__(64) void k_align(AlnParams p, AlnOut o) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *base;
+    if constexpr (LDS) base = smem;
+    else base = p.work + (uint64_t)blockIdx.x * p.work_per_wave;
+    AlnScratch sc;
+    sc.text = p.st_text + (uint64_t)blockIdx.x * p.st_text_cap;
+    sc.gaps = p.st_gaps + (uint64_t)blockIdx.x * p.st_gap_cap;
+    sc.hits = p.st_hits + (uint64_t)blockIdx.x * p.st_hit_cap;
+    sc.text_cap = p.st_text_cap;
+    sc.gap_cap = p.st_gap_cap;
+    sc.hit_cap = p.st_hit_cap;
+    for (uint32_t q = blockIdx.x; q < p.n; q += gridDim.x) {
+        const uint32_t job = p.idx[q];
+        const pf_align_job jb = p.jobs[job];
+        uint32_t nh, tu, gu;
+        const bool ok = align_job(base, p.text + jb.a_off, p.text + jb.b_off, jb.a_len, jb.b_len, p.M, p.D, p.G, sc, nh, tu, gu);
+        if (ok) {
+            publish(o, job, sc, nh, tu, gu);
+        } else if (lane_id() == 0) {
+            if (p.final_tier) {
+                o.hit_first[job] = 0;
+                o.hit_count[job] = 0xFFFFFFFFu;  // error marker
+            } else {
+                const unsigned int r = atomicAdd(o.n_retry, 1u);
+                o.retry[r] = job;
+            }
+        }
+        aln_sync();
+    }
+}
+
+}  // namespace
+
+extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, const pf_align_job *jobs, uint32_t n_jobs,
+                              double match, double mismatch, double gap, uint64_t *hit_first, uint32_t *hit_count,
+                              pf_align_hit *hits, uint64_t hit_cap, char *out_text, uint64_t text_cap, uint32_t *out_gaps,
+                              uint64_t gap_cap, uint64_t used[3]) {
+    if (!ctx || !used || (n_jobs && (!text || !jobs || !hit_first || !hit_count || !hits || !out_text || !out_gaps)))
+        return PF_ERR_ARG;
+    used[0] = used[1] = used[2] = 0;
+    if (n_jobs == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    // host copy of the job table (size classes, argument validation)
+    std::vector<pf_align_job> hj(n_jobs);
+    PF_HIP(hipMemcpy(hj.data(), jobs, (size_t)n_jobs * sizeof(pf_align_job), hipMemcpyDefault));
+    constexpr uint32_t LIM = 60000;
+    const uint64_t cls_bytes[3] = {5 * 1024, 20 * 1024, 64 * 1024};
+    std::vector<uint32_t> cls[4];
+    uint64_t max_need = 0;
+    for (uint32_t j = 0; j < n_jobs; ++j) {
+        const pf_align_job &jb = hj[j];
+        if (jb.a_len == 0 || jb.b_len == 0 || jb.a_len > LIM || jb.b_len > LIM || jb.a_off + jb.a_len > text_len ||
+            jb.b_off + jb.b_len > text_len || (uint64_t)(jb.a_len + 1) * (jb.b_len + 1) > (1ull << 31)) {
+            ctx->err = "pf_align_batch: job outside the text buffer or longer than 60000 bases";
+            return PF_ERR_ARG;
+        }
+        const uint64_t need = job_bytes(jb.a_len, jb.b_len);
+        int c = 3;
+        for (int t = 0; t < 3; ++t)
+            if (need <= cls_bytes[t]) { c = t; break; }
+        cls[c].push_back(j);
+        if (c == 3) max_need = std::max(max_need, need);
+    }
+    // device copies of inputs
+    auto is_dev = [](const void *p) {
+        hipPointerAttribute_t at;
+        bool d = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        return d;
+    };
+    char *d_text = const_cast<char *>(text);
+    pf_align_job *d_jobs = const_cast<pf_align_job *>(jobs);
+    const bool own_text = !is_dev(text), own_jobs = !is_dev(jobs);
+    if (own_text) {
+        PF_HIP(hipMalloc(&d_text, text_len + 1));
+        PF_HIP(hipMemcpyAsync(d_text, text, text_len, hipMemcpyHostToDevice, st));
+    }
+    if (own_jobs) {
+        PF_HIP(hipMalloc(&d_jobs, (size_t)n_jobs * sizeof(pf_align_job)));
+        PF_HIP(hipMemcpyAsync(d_jobs, hj.data(), (size_t)n_jobs * sizeof(pf_align_job), hipMemcpyHostToDevice, st));
+    }
+    const bool dev_out = is_dev(hits);
+    AlnOut o;
+    unsigned long long *d_heads;
+    unsigned int *d_nretry;
+    uint32_t *d_retry, *d_idx;
+    PF_HIP(hipMalloc(&d_heads, 24));
+    PF_HIP(hipMalloc(&d_nretry, 4));
+    PF_HIP(hipMalloc(&d_retry, (size_t)n_jobs * 4));
+    PF_HIP(hipMalloc(&d_idx, (size_t)n_jobs * 4));
+    PF_HIP(hipMemsetAsync(d_heads, 0, 24, st));
+    PF_HIP(hipMemsetAsync(d_nretry, 0, 4, st));
+    if (dev_out) {
+        o.hit_first = hit_first; o.hit_count = hit_count; o.hits = hits; o.text = out_text; o.gaps = out_gaps;
+    } else {
+        PF_HIP(hipMalloc(&o.hit_first, (size_t)n_jobs * 8));
+        PF_HIP(hipMalloc(&o.hit_count, (size_t)n_jobs * 4));
+        PF_HIP(hipMalloc(&o.hits, std::max<uint64_t>(hit_cap, 1) * sizeof(pf_align_hit)));
+        PF_HIP(hipMalloc(&o.text, std::max<uint64_t>(text_cap, 1)));
+        PF_HIP(hipMalloc(&o.gaps, std::max<uint64_t>(gap_cap, 1) * 4));
+    }
+    o.hit_cap = hit_cap; o.text_cap = text_cap; o.gap_cap = gap_cap;
+    o.heads = d_heads; o.retry = d_retry; o.n_retry = d_nretry;
+
+    // per-wave staging for the LDS tiers
+    const uint32_t ST_TEXT = 64 * 1024, ST_GAPS = 8 * 1024, ST_HITS = 512;
+    const int max_waves = ctx->n_cu * 8;
+    char *st_text;
+    uint32_t *st_gaps;
+    pf_align_hit *st_hits;
+    PF_HIP(hipMalloc(&st_text, (size_t)max_waves * ST_TEXT));
+    PF_HIP(hipMalloc(&st_gaps, (size_t)max_waves * ST_GAPS * 4));
+    PF_HIP(hipMalloc(&st_hits, (size_t)max_waves * ST_HITS * sizeof(pf_align_hit)));
+
+    AlnParams p;
+    p.text = d_text; p.jobs = d_jobs; p.idx = d_idx; p.M = match; p.D = mismatch; p.G = gap;
+    p.st_text = st_text; p.st_gaps = st_gaps; p.st_hits = st_hits;
+    p.st_text_cap = ST_TEXT; p.st_gap_cap = ST_GAPS; p.st_hit_cap = ST_HITS;
+    p.work = nullptr; p.work_per_wave = 0; p.final_tier = 0;
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_align<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+    }
+    uint32_t idx_off = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (cls[c].empty()) continue;
+        const uint32_t nc = (uint32_t)cls[c].size();
+        PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[c].data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
+        p.idx = d_idx + idx_off;
+        p.n = nc;
+        const int grid = (int)std::min<uint32_t>(nc, (uint32_t)max_waves);
+        ctx_begin(ctx, PF_K_ALIGN);
+        k_align<true><<<grid, 64, cls_bytes[c], st>>>(p, o);
+        ctx_end(ctx);
+        idx_off += nc;
+    }
+    // global tier: jobs too large for LDS
+    uint8_t *work = nullptr;
+    if (!cls[3].empty()) {
+        const uint32_t nc = (uint32_t)cls[3].size();
+        const int grid = (int)std::min<uint32_t>(nc, 256);
+        const uint64_t per = (max_need + 255) & ~255ull;
+        PF_HIP(hipMalloc(&work, per * grid));
+        PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[3].data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
+        p.idx = d_idx + idx_off;
+        p.n = nc;
+        p.work = work;
+        p.work_per_wave = per;
+        ctx_begin(ctx, PF_K_ALIGN_BIG);
+        k_align<false><<<grid, 64, 0, st>>>(p, o);
+        ctx_end(ctx);
+    }
+    unsigned int n_retry = 0;
+    PF_HIP(hipMemcpyAsync(&n_retry, d_nretry, 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    int status = PF_OK;
+    uint8_t *work2 = nullptr;
+    char *bt = nullptr;
+    uint32_t *bg = nullptr;
+    pf_align_hit *bh = nullptr;
+    if (n_retry) {
+        // staging overflow: rerun those jobs in the global tier with 256x the staging
+        std::vector<uint32_t> rj(n_retry);
+        PF_HIP(hipMemcpy(rj.data(), d_retry, (size_t)n_retry * 4, hipMemcpyDeviceToHost));
+        uint64_t need = 0;
+        for (uint32_t j : rj) need = std::max(need, job_bytes(hj[j].a_len, hj[j].b_len));
+        const int grid = (int)std::min<uint32_t>(n_retry, 16);
+        const uint64_t per = (need + 255) & ~255ull;
+        const uint32_t BT = 16u << 20, BG = 2u << 20, BH = 128u << 10;
+        PF_HIP(hipMalloc(&work2, per * grid));
+        PF_HIP(hipMalloc(&bt, (size_t)grid * BT));
+        PF_HIP(hipMalloc(&bg, (size_t)grid * BG * 4));
+        PF_HIP(hipMalloc(&bh, (size_t)grid * BH * sizeof(pf_align_hit)));
+        PF_HIP(hipMemcpyAsync(d_idx, rj.data(), (size_t)n_retry * 4, hipMemcpyHostToDevice, st));
+        p.idx = d_idx; p.n = n_retry; p.work = work2; p.work_per_wave = per; p.final_tier = 1;
+        p.st_text = bt; p.st_gaps = bg; p.st_hits = bh;
+        p.st_text_cap = BT; p.st_gap_cap = BG; p.st_hit_cap = BH;
+        ctx_begin(ctx, PF_K_ALIGN_BIG);
+        k_align<false><<<grid, 64, 0, st>>>(p, o);
+        ctx_end(ctx);
+        PF_HIP(hipStreamSynchronize(st));
+    }
+    unsigned long long heads[3];
+    PF_HIP(hipMemcpy(heads, d_heads, 24, hipMemcpyDeviceToHost));
+    used[0] = heads[0]; used[1] = heads[1]; used[2] = heads[2];
+    if (heads[0] > hit_cap || heads[1] > text_cap || heads[2] > gap_cap) {
+        ctx->err = "pf_align_batch: output buffers too small";
+        status = PF_ERR_OVERFLOW;
+    }
+    if (!dev_out) {
+        if (status == PF_OK) {
+            PF_HIP(hipMemcpy(hit_first, o.hit_first, (size_t)n_jobs * 8, hipMemcpyDeviceToHost));
+            PF_HIP(hipMemcpy(hit_count, o.hit_count, (size_t)n_jobs * 4, hipMemcpyDeviceToHost));
+            PF_HIP(hipMemcpy(hits, o.hits, (size_t)heads[0] * sizeof(pf_align_hit), hipMemcpyDeviceToHost));
+            PF_HIP(hipMemcpy(out_text, o.text, (size_t)heads[1], hipMemcpyDeviceToHost));
+            PF_HIP(hipMemcpy(out_gaps, o.gaps, (size_t)heads[2] * 4, hipMemcpyDeviceToHost));
+            if (n_retry)
+                for (uint32_t j = 0; j < n_jobs; ++j)
+                    if (hit_count[j] == 0xFFFFFFFFu) {
+                        ctx->err = "pf_align_batch: a job has more co-optimal alignments than the staging area holds";
+                        status = PF_ERR_OVERFLOW;
+                        break;
+                    }
+        }
+        hipFree(o.hit_first); hipFree(o.hit_count); hipFree(o.hits); hipFree(o.text); hipFree(o.gaps);
+    }
+    if (own_text) hipFree(d_text);
+    if (own_jobs) hipFree(d_jobs);
+    hipFree(d_heads); hipFree(d_nretry); hipFree(d_retry); hipFree(d_idx);
+    hipFree(st_text); hipFree(st_gaps); hipFree(st_hits);
+    hipFree(work); hipFree(work2); hipFree(bt); hipFree(bg); hipFree(bh);
+    return status;
 }

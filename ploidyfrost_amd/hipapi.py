@@ -69,7 +69,7 @@ def load_library() -> C.CDLL:
         "pf_unitig_cov": (i, [vp, u32, u32, vp, vp, vp]),
         "pf_count_candidates": (i, [vp, u32, u32, C.POINTER(u64)]),
         "pf_bfs_candidates": (i, [vp, u32, u32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
-        "pf_align_batch": (i, [vp, vp, u64, vp, u32, C.c_double, C.c_double, C.c_double, vp, vp, u64, vp, u64, vp, u64,
+        "pf_align_batch": (i, [vp, vp, u64, vp, u32, C.c_double, C.c_double, C.c_double, vp, vp, vp, u64, vp, u64, vp, u64,
                                C.POINTER(u64)]),
         "pf_string_cov": (i, [vp, vp, vp, u32, u32, u32, vp, vp, vp]),
         "pf_device_name": (i, [vp, C.c_char_p, C.c_size_t]),
@@ -263,13 +263,14 @@ class Device:
         text = np.frombuffer(b"".join(chunks) + b"\0", dtype=np.uint8).copy()
         hit_cap, text_cap, gap_cap = max(64, 4 * n), max(4096, 8 * pos), max(1024, 4 * n * 8)
         while True:
-            first = np.zeros(n + 1, dtype=np.uint64)
+            first = np.zeros(n, dtype=np.uint64)
+            count = np.zeros(n, dtype=np.uint32)
             hits = np.zeros(hit_cap, dtype=ALIGN_HIT)
             otext = np.zeros(text_cap, dtype=np.uint8)
             ogap = np.zeros(gap_cap, dtype=np.uint32)
             used = (C.c_uint64 * 3)()
             st = self.L.pf_align_batch(self.h, text.ctypes.data, pos, jobs.ctypes.data, n, M, D, G, first.ctypes.data,
-                                       hits.ctypes.data, hit_cap, otext.ctypes.data, text_cap, ogap.ctypes.data, gap_cap, used)
+                                       count.ctypes.data, hits.ctypes.data, hit_cap, otext.ctypes.data, text_cap, ogap.ctypes.data, gap_cap, used)
             if st == PF_ERR_OVERFLOW and (used[0] > hit_cap or used[1] > text_cap or used[2] > gap_cap):
                 hit_cap, text_cap, gap_cap = max(hit_cap, used[0]), max(text_cap, used[1]), max(gap_cap, used[2])
                 continue
@@ -279,7 +280,7 @@ class Device:
         tb = otext.tobytes()
         for j in range(n):
             lst = []
-            for h in hits[int(first[j]) : int(first[j + 1])]:
+            for h in hits[int(first[j]) : int(first[j]) + int(count[j])]:
                 o, ln = int(h["text_off"]), int(h["len"])
                 gp = ogap[int(h["gap_off"]) : int(h["gap_off"]) + int(h["n_gaps"])].copy()
                 lst.append((tb[o : o + ln], tb[o + ln : o + 2 * ln], gp, int(h["score"]), int(h["n_pos"]), int(h["n_indel"])))
