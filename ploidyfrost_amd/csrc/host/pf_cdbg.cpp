@@ -1,0 +1,729 @@
+#include "pf_cdbg.hpp"
+
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <set>
+
+namespace pfh {
+
+namespace {
+using clk = std::chrono::steady_clock;
+inline double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+// MyUnitig::b bit layout (reference src/MyUnitig.hpp:37-46, 52-85, 97-130)
+constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_NON_SUPER = 0x04, B_STRICT_M = 0x08, B_STRICT_P = 0x10,
+                  B_COMPLEX_M = 0x20, B_COMPLEX_P = 0x40;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+inline bool plus_of(uint32_t ov) { return (ov & 1) == 0; }
+
+// `ostream << double` with default flags == printf("%g") (precision 6)
+inline void put_double(std::string &s, double x) {
+    char buf[40];
+    int n = snprintf(buf, sizeof buf, "%g", x);
+    s.append(buf, (size_t)n);
+}
+inline void put_uint(std::string &s, uint64_t x) {
+    char buf[24];
+    int n = snprintf(buf, sizeof buf, "%llu", (unsigned long long)x);
+    s.append(buf, (size_t)n);
+}
+}  // namespace
+
+// one bubble to call, in output order
+struct CDBG::Task {
+    uint32_t u = 0;        // owner endpoint (unitig index)
+    uint32_t exit_ov = 0;
+    bool strict = false;
+    double core_mean = 0;
+    // strict: inner unitigs sorted by (mean coverage desc, reference string desc) and their means
+    std::vector<double> cov;
+    double cov_sum = 0;
+};
+
+CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db, int device)
+    : g_(graph), complex_size_(complexsize) {
+    sc_.match = m;
+    sc_.mismatch = d;
+    sc_.gap = g;
+    int st = pf_create(device, &ctx_);
+    if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: ") + pf_last_error(nullptr)); return; }
+    st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
+    if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: graph upload: ") + pf_last_error(ctx_)); return; }
+    const uint32_t N = g_.n();
+    succ_.resize((size_t)N * 8);
+    pred_.resize((size_t)N * 8);
+    st = pf_build_adjacency(ctx_, succ_.data(), pred_.data());
+    if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: adjacency: ") + pf_last_error(ctx_)); return; }
+    if (!kmc_db.empty()) {
+        KmcRecords db;
+        std::string e;
+        if (!db.load(kmc_db, e)) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: Open kmc database error . (" + e + ")"); return; }
+        if ((int)db.k != g_.k) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: k of the kmc database differs from the graph's"); return; }
+        both_strands_ = db.both_strands;
+        st = pf_upload_counts(ctx_, db.kmers.data(), db.counts.data(), db.total, db.min_count, db.max_count, db.both_strands);
+        if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: ") + pf_last_error(ctx_)); return; }
+    }
+    flags_.assign(N, 0);
+    plus_.assign(N, 0);
+    minus_.assign(N, 0);
+    if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");
+}
+
+CDBG::~CDBG() { pf_destroy(ctx_); }
+
+int CDBG::fail(int st, const std::string &msg) {
+    status_ = st ? st : PF_ERR_ARG;
+    err_ = msg;
+    return status_;
+}
+
+int CDBG::ensure_dir() {
+    struct stat sb;
+    if (stat(outdir_.c_str(), &sb) == 0) return 0;
+    if (mkdir(outdir_.c_str(), 0777) != 0 && access(outdir_.c_str(), 0)) return fail(PF_ERR_ARG, "cannot create " + outdir_);
+    return 0;
+}
+
+int CDBG::write_file(const std::string &name, const std::string &data) {
+    out_bytes_ += data.size();
+    if (!write_files_) return 0;
+    FILE *f = fopen((outdir_ + "/" + name).c_str(), "wb");
+    if (!f) return fail(PF_ERR_ARG, "CDBG:: Open " + name + " file error");
+    if (!data.empty() && fwrite(data.data(), 1, data.size(), f) != data.size()) {
+        fclose(f);
+        return fail(PF_ERR_ARG, "CDBG:: write error on " + name);
+    }
+    fclose(f);
+    return 0;
+}
+
+// ---- setUnitigId (reference src/CDBG.cpp:121-143) -----------------------------------------
+int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size_t &) {
+    if (status_) return status_;
+    if (write_files_ && ensure_dir()) return status_;
+    if (!quiet_) printf("CDBG::setUnitigId(): Setting Unitig Id\n");
+    clock_t c0 = clock();
+    time_t w0 = time(nullptr);
+    std::string out;
+    out.reserve(g_.text.size() + (size_t)g_.n() * 10);
+    for (uint32_t u = 0; u < g_.n(); ++u) {
+        put_uint(out, u + 1);
+        out.push_back('\t');
+        std::string_view s = g_.seq(u);
+        out.append(s.data(), s.size());
+        out.push_back('\n');
+    }
+    if (write_file(outpre + "_Unitig_Id.txt", out)) return status_;
+    if (!quiet_) {
+        printf("CDBG::setUnitigId(): Cpu time : %gs\n", (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("CDBG::setUnitigId(): Real time : %gs\n", difftime(time(nullptr), w0));
+    }
+    return 0;
+}
+
+// ---- printInfo (reference src/CDBG.cpp:144-162): <outpre>_graph_info.txt in the CWD --------
+int CDBG::printInfo(const bool &verbose, const std::string &outpre) {
+    if (status_) return status_;
+    uint64_t length = 0;
+    for (uint32_t u = 0; u < g_.n(); ++u) length += g_.size_bp(u);
+    char line[256];
+    snprintf(line, sizeof line, "k:%d\tg:%d\tnbKmer:%llu\tnbUnitig:%u\tlength:%llu\t", g_.k, g_.g,
+             (unsigned long long)g_.n_kmers, g_.n(), (unsigned long long)length);
+    if (verbose) printf(">>>>>>>>>Bifrost Graph Information>>>>>>>>>\n%s\n", line);
+    FILE *f = fopen((outpre + "_graph_info.txt").c_str(), "w");
+    if (f) { fputs(line, f); fclose(f); }
+    return 0;
+}
+
+// ---- MyUnitig state -------------------------------------------------------------------------
+void CDBG::side_self(uint32_t u, bool plus_side) {
+    if (plus_side) { plus_[u] = u + 1; flags_[u] &= (uint8_t)~B_PLUS; }
+    else { minus_[u] = u + 1; flags_[u] &= (uint8_t)~B_MINUS; }
+}
+// "if (ex->get_plus() == me) ex->set_plus_self(); else ex->set_minus_self();"
+void CDBG::release(uint32_t ex, uint32_t me) { side_self(ex, plus_[ex] == me + 1); }
+// interior vertex of any committed traversal (e.g. src/CDBG.cpp:800-826)
+void CDBG::poison(uint32_t u) {
+    uint32_t p = plus_[u];
+    if (p != 0 && p != u + 1) release(p - 1, u);
+    side_self(u, true);
+    p = minus_[u];
+    if (p != 0 && p != u + 1) release(p - 1, u);
+    side_self(u, false);
+    flags_[u] |= B_NON_SUPER;
+}
+
+// Order-dependent part of extractSuperBubble_ptr: the three setNoBubble commits
+// (src/CDBG.cpp:552-846) and the no-exit tail (:373-413), applied to one device record.
+void CDBG::replay(const pf_bfs_record &r, const uint32_t *list) {
+    const uint32_t s = r.entrance, su = s >> 1;
+    if (r.outcome == PF_BFS_NONE) {
+        if (!r.flag_cycle) return;
+        for (uint32_t i = 0; i < r.n_list; ++i) poison(list[i] >> 1);
+        side_self(su, plus_of(s));
+        return;
+    }
+    const uint32_t t = r.exit, tu = t >> 1;
+    if (r.outcome == PF_BFS_CYCLE_EXIT) {  // setNoBubble_ptr_cycle
+        for (uint32_t i = 0; i < r.n_list; ++i) poison(list[i] >> 1);
+        side_self(su, plus_of(s));
+        side_self(tu, !plus_of(t));
+        return;
+    }
+    if (r.outcome == PF_BFS_REJECT) {  // setNoBubble_ptr(seen, p)
+        uint32_t p = plus_of(s) ? plus_[su] : minus_[su];
+        if (p != 0) release(p - 1, su);
+        side_self(su, plus_of(s));
+        p = !plus_of(t) ? plus_[tu] : minus_[tu];
+        if (p != 0) release(p - 1, tu);
+        side_self(tu, !plus_of(t));
+        for (uint32_t i = 0; i < r.n_list; ++i)
+            if (list[i] != s && list[i] != t) poison(list[i] >> 1);
+        return;
+    }
+    // PF_BFS_ACCEPT: setNoBubble_ptr(p, seen)
+    if (r.n_seen < 4) return;
+    if ((flags_[tu] & B_NON_SUPER) || (flags_[su] & B_NON_SUPER)) {
+        for (uint32_t i = 0; i < r.n_list; ++i) {
+            const uint32_t w = list[i];
+            if (w == s) side_self(su, plus_of(s));
+            else if (w == t) side_self(tu, !plus_of(t));
+            else poison(w >> 1);
+        }
+        return;
+    }
+    if (r.strict) {  // n_seen <= 6 and the structural test, evaluated on the device
+        flags_[su] |= plus_of(s) ? B_STRICT_P : B_STRICT_M;
+        flags_[tu] |= !plus_of(t) ? B_STRICT_P : B_STRICT_M;
+    }
+    if (r.n_seen > complex_size_) {
+        flags_[su] |= plus_of(s) ? B_COMPLEX_P : B_COMPLEX_M;
+        flags_[tu] |= !plus_of(t) ? B_COMPLEX_P : B_COMPLEX_M;
+    }
+    for (uint32_t i = 0; i < r.n_list; ++i)
+        if (list[i] != s && list[i] != t) poison(list[i] >> 1);
+    if (plus_of(s)) { plus_[su] = tu + 1; flags_[su] |= B_PLUS; }
+    else { minus_[su] = tu + 1; flags_[su] |= B_MINUS; }
+    if (plus_of(t)) { minus_[tu] = su + 1; flags_[tu] |= B_MINUS; }
+    else { plus_[tu] = su + 1; flags_[tu] |= B_PLUS; }
+}
+
+// ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
+int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &) {
+    if (status_) return status_;
+    if (!quiet_) printf("CDBG::findSuperBubble(): Finding superbubbles\n");
+    if (write_files_ && ensure_dir()) return status_;
+    const auto t_all = clk::now();
+    clock_t c0 = clock();
+    const uint32_t N = g_.n();
+    if (!quiet_) printf("CDBG::findSuperBubble(): There are %u unitigs \n", N);
+    std::fill(flags_.begin(), flags_.end(), 0);
+    std::fill(plus_.begin(), plus_.end(), 0);
+    std::fill(minus_.begin(), minus_.end(), 0);
+
+    // every candidate entrance is traversed on the device, one wavefront each
+    auto t0 = clk::now();
+    uint64_t n_cand = 0;
+    int st = pf_count_candidates(ctx_, 0, N, &n_cand);
+    if (st != PF_OK) return fail(st, pf_last_error(ctx_));
+    std::vector<pf_bfs_record> rec(std::max<uint64_t>(n_cand, 1));
+    std::vector<uint32_t> pool(std::max<uint64_t>(n_cand * 6, 1024));
+    uint64_t n_rec = 0, used = 0;
+    for (;;) {
+        st = pf_bfs_candidates(ctx_, 0, N, rec.data(), rec.size(), pool.data(), pool.size(), &n_rec, &used);
+        if (st == PF_ERR_OVERFLOW && used > pool.size()) { pool.resize(used + used / 8); continue; }
+        break;
+    }
+    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    times_.bfs_device_s = since(t0);
+    times_.candidates = n_rec;
+
+    // sequential replay in the reference's visiting order, with its `partner == NULL` gate
+    // (src/CDBG.cpp:206, 211): records are in ascending oriented-vertex order = unitig order,
+    // '+' before '-'.
+    t0 = clk::now();
+    for (uint64_t i = 0; i < n_rec; ++i) {
+        const pf_bfs_record &r = rec[i];
+        const uint32_t u = r.entrance >> 1;
+        if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
+        replay(r, pool.data() + r.list_off);
+    }
+    times_.replay_s = since(t0);
+    if (!quiet_) {
+        printf("CDBG::findSuperBubble():  Cpu time : %gs\n", (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("CDBG::findSuperBubble():  Real time : %gs\n", since(t_all));
+    }
+    t0 = clk::now();
+    std::string out = "BubbleId\tEntrance\tStrand\tExit\tisSimple\tisComplex\n";
+    uint64_t nb = 0;
+    for (uint32_t u = 0; u < N; ++u) {
+        const uint8_t f = flags_[u];
+        if ((f & 3) == 0) continue;
+        for (int side = 0; side < 2; ++side) {
+            const bool ps = side == 0;
+            if (!(f & (ps ? B_PLUS : B_MINUS))) continue;
+            put_uint(out, ++nb);
+            out.push_back('\t');
+            put_uint(out, u + 1);
+            out += ps ? "\t+\t" : "\t-\t";
+            put_uint(out, ps ? plus_[u] : minus_[u]);
+            out += (f & (ps ? B_STRICT_P : B_STRICT_M)) ? "\t1" : "\t0";
+            out += (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? "\t1\n" : "\t0\n";
+        }
+    }
+    n_super_bubble_ = nb;
+    times_.bubbles_out = nb;
+    if (write_file(outpre + "_super_bubble.txt", out)) return status_;
+    times_.bubble_write_s = since(t0);
+    times_.find_total_s = since(t_all);
+    if (!quiet_) printf("CDBG::findSuperBubble(): %llu  SuperBubbles Found\n", (unsigned long long)nb);
+    return 0;
+}
+
+// ---- sorting of the paths -----------------------------------------------------------------
+namespace {
+// sortSeq_simple (reference src/CDBG.cpp:482-551): the reference's own non-stable quicksort --
+// descending mean coverage, ties by descending reference string.  The exact swap sequence
+// matters for ties, so it is the same partition scheme.
+void sort_inner(const UnitigSet &g, std::vector<double> &cov, std::vector<uint32_t> &ov, int low, int high) {
+    if (high <= low) return;
+    auto gt = [&](int a, int b) {  // strcmp(ref(a), ref(b)) > 0
+        return g.seq(ov[a] >> 1).compare(g.seq(ov[b] >> 1)) > 0;
+    };
+    auto lt = [&](int a, int b) { return g.seq(ov[a] >> 1).compare(g.seq(ov[b] >> 1)) < 0; };
+    int i = low, j = high;
+    for (;;) {
+        while (cov[i] >= cov[low]) {
+            if (cov[i] > cov[low] || gt(i, low)) i++;
+            else break;
+            if (i == high) break;
+        }
+        while (cov[j] <= cov[low]) {
+            if (cov[j] < cov[low] || lt(j, low)) j--;
+            else break;
+            if (j == low) break;
+        }
+        if (i >= j) break;
+        std::swap(cov[i], cov[j]);
+        std::swap(ov[i], ov[j]);
+    }
+    std::swap(cov[low], cov[j]);
+    std::swap(ov[low], ov[j]);
+    sort_inner(g, cov, ov, low, j - 1);
+    sort_inner(g, cov, ov, j + 1, high);
+}
+
+// sortSeq_branching (reference src/CDBG.cpp:417-480): descending length, ties by descending strcmp
+void sort_paths(std::vector<std::string> &v, int low, int high) {
+    if (high <= low) return;
+    auto before = [&](int a, int b) {  // a sorts strictly before b
+        return v[a].size() > v[b].size() || (v[a].size() == v[b].size() && v[a].compare(v[b]) > 0);
+    };
+    int i = low, j = high;
+    for (;;) {
+        while (v[i].size() >= v[low].size()) {
+            if (before(i, low)) i++;
+            else break;
+            if (i == high) break;
+        }
+        while (v[j].size() <= v[low].size()) {
+            if (before(low, j)) j--;
+            else break;
+            if (j == low) break;
+        }
+        if (i >= j) break;
+        std::swap(v[i], v[j]);
+    }
+    std::swap(v[low], v[j]);
+    sort_paths(v, low, j - 1);
+    sort_paths(v, j + 1, high);
+}
+
+std::string without_gaps(const std::string &s, size_t n) {
+    std::string r;
+    for (size_t i = 0; i < n && i < s.size(); ++i)
+        if (s[i] != '-') r.push_back(s[i]);
+    return r;
+}
+}  // namespace
+
+// ---- ploidyEstimation (reference src/CDBG.cpp:1101-1705) -----------------------------------
+int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int &lower, const int &upper, const size_t &) {
+    if (status_) return status_;
+    const auto t_all = clk::now();
+    clock_t c0 = clock();
+    if (!quiet_) printf("CDBG::PloidyEstimation():  Analyzing superbubbles to generate sites' information\n");
+    if (write_files_ && ensure_dir()) return status_;
+    const uint32_t N = g_.n();
+    const int k = g_.k;
+    const uint32_t low = (uint32_t)lower, up = (uint32_t)upper;
+
+    // C1 for every unitig in one launch (the reference calls readCov per use)
+    auto t0 = clk::now();
+    std::vector<uint64_t> cov_sum(N);
+    std::vector<uint32_t> cov_min(N);
+    std::vector<uint8_t> cov_miss(N);
+    int st = pf_unitig_cov(ctx_, 0, N, cov_sum.data(), cov_min.data(), cov_miss.data());
+    if (st != PF_OK && st != PF_ERR_MISSING_KMER) return fail(st, std::string("CDBG::PloidyEstimation(): ") + pf_last_error(ctx_));
+    times_.cov_device_s = since(t0);
+    auto mean_of = [&](uint32_t u) { return (double)cov_sum[u] / (double)g_.len_km(u); };
+    auto missing = [&](uint32_t u) -> int {
+        if (!cov_miss[u]) return 0;
+        return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of unitig " + std::to_string(u + 1) + " can not found .");
+    };
+    auto succ_row = [&](uint32_t ov) { return &succ_[(size_t)ov * 4]; };
+    auto first_succ = [&](uint32_t ov) -> uint32_t {
+        const uint32_t *r = succ_row(ov);
+        for (int b = 0; b < 4; ++b)
+            if (r[b] != NONE) return r[b];
+        return NONE;
+    };
+
+    // the ten per-site streams + alignseq
+    std::string allfre, s_var, fre[4], cov[4];
+    uint64_t var_count = 0;
+    allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
+    core_cov_ = core_num_ = 0;
+
+    // Tasks are discovered by replaying the reference's driver loop (it only depends on the
+    // state bits, the CSR and the reference strings), then processed in chunks: path strings
+    // -> GPU alignment rounds -> site strings -> GPU coverage -> text.
+    const size_t CHUNK = 1u << 17;
+    std::vector<Task> tasks;
+    std::vector<std::vector<std::string>> paths;
+    std::vector<Msa> msa;
+    uint32_t scan_u = 0;
+    while (scan_u < N || !tasks.empty()) {
+        t0 = clk::now();
+        tasks.clear();
+        paths.clear();
+        for (; scan_u < N && tasks.size() < CHUNK; ++scan_u) {
+            const uint32_t u = scan_u;
+            uint8_t &f = flags_[u];
+            while ((f & 3) != 0) {
+                bool ps;
+                if (f & B_PLUS) {
+                    ps = true;
+                    if (f & B_COMPLEX_P) { f &= (uint8_t)~B_PLUS; continue; }
+                } else {
+                    ps = false;
+                    if (f & B_COMPLEX_M) { f &= (uint8_t)~B_MINUS; break; }
+                }
+                const uint32_t uo = 2 * u + (ps ? 0 : 1);
+                const bool strict = (f & (ps ? B_STRICT_P : B_STRICT_M)) != 0;
+                if (missing(u)) return status_;  // core = readCov(u)
+                uint32_t exit_ov;
+                if (strict) {
+                    exit_ov = first_succ(first_succ(uo));
+                } else {
+                    const uint32_t want = ps ? plus_[u] : minus_[u];
+                    exit_ov = first_succ(uo);
+                    while (exit_ov != NONE && (exit_ov >> 1) + 1 != want) exit_ov = first_succ(exit_ov);
+                    if (exit_ov == NONE) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): exit of a bubble is not reachable");
+                }
+                const uint32_t eu = exit_ov >> 1;
+                if (g_.seq(u).compare(g_.seq(eu)) < 0) {  // the other endpoint owns this bubble
+                    f &= (uint8_t) ~(ps ? B_PLUS : B_MINUS);
+                    continue;
+                }
+                Task t;
+                t.u = u;
+                t.exit_ov = exit_ov;
+                t.strict = strict;
+                t.core_mean = mean_of(u);
+                std::vector<std::string> strs;
+                bool aligned = true;
+                if (strict) {
+                    std::vector<uint32_t> inner;
+                    for (int b = 0; b < 4 && aligned; ++b) {
+                        const uint32_t w = succ_row(uo)[b];
+                        if (w == NONE) continue;
+                        inner.push_back(w);
+                        if (missing(w >> 1)) return status_;
+                        if (cov_min[w >> 1] > low && cov_min[w >> 1] < up) {
+                            const double mcov = mean_of(w >> 1);
+                            t.cov.push_back(mcov);
+                            t.cov_sum += mcov;
+                        } else {
+                            aligned = false;
+                        }
+                    }
+                    if (aligned) {
+                        // the reference also reads the predecessors' coverage and drops it (:1224-1239)
+                        for (int b = 0; b < 4; ++b) {
+                            const uint32_t w = pred_[(size_t)uo * 4 + b];
+                            if (w != NONE && missing(w >> 1)) return status_;
+                        }
+                        sort_inner(g_, t.cov, inner, 0, (int)t.cov.size() - 1);
+                        for (uint32_t w : inner) strs.push_back(g_.mapped(w));
+                    }
+                } else {
+                    // every s->t path, from the start of s's last k-mer through t's first k-mer
+                    // (two-stack DFS of src/CDBG.cpp:1364-1412)
+                    std::vector<uint32_t> major, minor;
+                    std::string walk;
+                    const uint32_t ulen = g_.len_km(u);
+                    minor.push_back(uo);
+                    while (!minor.empty()) {
+                        const uint32_t w = minor.back();
+                        minor.pop_back();
+                        major.push_back(w);
+                        const uint32_t wlen = g_.len_km(w >> 1);
+                        const size_t before = walk.size();
+                        g_.append_mapped(w, walk);
+                        if ((w >> 1) == eu) {
+                            const size_t total = walk.size();
+                            strs.push_back(walk.substr(ulen - 1, total - ulen + 1 - wlen + 1));
+                            walk.resize(before);
+                            major.pop_back();
+                            while (!major.empty() && !minor.empty()) {
+                                const uint32_t *r = succ_row(major.back());
+                                if (r[0] == minor.back() || r[1] == minor.back() || r[2] == minor.back() || r[3] == minor.back()) break;
+                                walk.resize(walk.size() - g_.len_km(major.back() >> 1));
+                                major.pop_back();
+                            }
+                        } else {
+                            walk.resize(before + wlen);  // keep only the first len characters
+                            const uint32_t *r = succ_row(w);
+                            for (int b = 0; b < 4; ++b)
+                                if (r[b] != NONE) minor.push_back(r[b]);
+                        }
+                    }
+                    sort_paths(strs, 0, (int)strs.size() - 1);
+                }
+                if (aligned) {
+                    tasks.push_back(std::move(t));
+                    paths.push_back(std::move(strs));
+                }
+                // src/CDBG.cpp:1656-1679: both endpoint sides are done
+                f &= (uint8_t) ~(ps ? B_PLUS : B_MINUS);
+                flags_[eu] &= (uint8_t) ~(plus_of(exit_ov) ? B_MINUS : B_PLUS);
+            }
+        }
+        times_.tasks_s += since(t0);
+        if (tasks.empty()) break;
+        times_.tasks += tasks.size();
+
+        // A1 on the device
+        t0 = clk::now();
+        AlignStats as;
+        std::string e;
+        st = align_bubbles(ctx_, sc_, paths, msa, &as, e);
+        if (st != PF_OK) return fail(st, "CDBG::PloidyEstimation(): alignment: " + e);
+        times_.align_jobs += as.jobs;
+        times_.align_s += since(t0);
+
+        // site strings of the branching bubbles (src/CDBG.cpp:1448-1600) -> one C2 batch
+        t0 = clk::now();
+        struct SiteStr { uint32_t first, count; };  // index range into `strings` per (task, site, group)
+        std::vector<std::string> strings;
+        std::vector<std::vector<std::vector<SiteStr>>> site_groups(tasks.size());  // [task][site][group]
+        std::vector<std::vector<uint32_t>> var_sites(tasks.size());
+        for (size_t ti = 0; ti < tasks.size(); ++ti) {
+            const Msa &m = msa[ti];
+            if (m.rows.empty()) continue;
+            const size_t R = m.rows.size();
+            std::vector<uint32_t> &vs = var_sites[ti];
+            for (uint32_t c = 0; c < m.n_cols; ++c)
+                if (m.group_at(c, (uint32_t)R - 1) > 0) vs.push_back(c);
+            if (tasks[ti].strict) continue;
+            site_groups[ti].resize(vs.size());
+            uint32_t indel = 0;
+            for (size_t si = 0; si < vs.size(); ++si) {
+                const uint32_t site = vs[si];
+                uint16_t maxnum = 0;
+                for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
+                std::vector<std::string> kstr(R);
+                const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
+                if (is_indel) {
+                    std::vector<int> at(R, (int)site);
+                    for (;;) {
+                        char first = 0;
+                        bool differ = false;
+                        for (size_t p = 0; p < R; ++p) {
+                            while (m.rows[p].at((size_t)at[p]) == '-') at[p]++;
+                            const char ch = m.rows[p].at((size_t)at[p]);
+                            at[p]++;
+                            kstr[p].push_back(ch);
+                            if (p == 0) first = ch;
+                            else if (ch != first) differ = true;
+                        }
+                        if (differ) break;
+                    }
+                    for (size_t p = 0; p < R; ++p) {
+                        const int n = (int)kstr[p].size();
+                        if (indel == 0) {
+                            kstr[p] = m.rows[p].substr((size_t)(site - k + n), (size_t)(k - n)) + kstr[p];
+                        } else {
+                            std::string tmp = without_gaps(m.rows[p], site);
+                            if (tmp.size() < (size_t)(k - n)) {
+                                kstr[p] = tmp + kstr[p];
+                                for (int x = at[p]; kstr[p].size() < (size_t)k; ++x) {
+                                    const char ch = m.rows[p].at((size_t)x);
+                                    if (ch != '-') kstr[p].push_back(ch);
+                                }
+                            } else {
+                                kstr[p] = tmp.substr(tmp.size() - (size_t)k + n, (size_t)(k - n)) + kstr[p];
+                            }
+                        }
+                    }
+                    ++indel;
+                } else if (indel > 0) {
+                    for (size_t p = 0; p < R; ++p) {
+                        std::string tmp = without_gaps(m.rows[p], site + 1);
+                        if (tmp.size() < (size_t)k) {
+                            kstr[p] = tmp;
+                            for (int x = (int)site + 1; kstr[p].size() < (size_t)k; ++x) {
+                                const char ch = m.rows[p].at((size_t)x);
+                                if (ch != '-') kstr[p].push_back(ch);
+                            }
+                        } else {
+                            kstr[p] = tmp.substr(tmp.size() - (size_t)k, (size_t)k);
+                        }
+                    }
+                } else {
+                    for (size_t p = 0; p < R; ++p) kstr[p] = m.rows[p].substr((size_t)(site - k + 1), (size_t)k);
+                }
+                // distinct strings per allele group, in std::set order
+                std::vector<std::set<std::string>> groups(maxnum);
+                for (size_t p = 0; p < R; ++p) groups[m.group_at(site, (uint32_t)p) - 1].insert(std::move(kstr[p]));
+                auto &sg = site_groups[ti][si];
+                for (auto &gs : groups) {
+                    sg.push_back({(uint32_t)strings.size(), (uint32_t)gs.size()});
+                    for (auto &s : gs) strings.push_back(s);
+                }
+            }
+        }
+        std::vector<uint64_t> str_sum(strings.size());
+        std::vector<uint8_t> str_ok(strings.size()), str_miss(strings.size());
+        if (!strings.empty()) {
+            std::string text;
+            std::vector<uint64_t> soff(strings.size() + 1, 0);
+            for (size_t i = 0; i < strings.size(); ++i) { soff[i] = text.size(); text += strings[i]; }
+            soff[strings.size()] = text.size();
+            st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)strings.size(), low, up, str_sum.data(), str_ok.data(),
+                               str_miss.data());
+            if (st != PF_OK) return fail(st, std::string("CDBG::PloidyEstimation(): ") + pf_last_error(ctx_));
+            times_.site_strings += strings.size();
+        }
+        times_.sites_s += since(t0);
+
+        // text
+        t0 = clk::now();
+        for (size_t ti = 0; ti < tasks.size(); ++ti) {
+            const Task &t = tasks[ti];
+            const Msa &m = msa[ti];
+            if (m.rows.empty()) continue;
+            const size_t R = m.rows.size();
+            ++var_count;
+            for (const std::string &row : m.rows) {
+                put_uint(s_var, var_count);
+                s_var += t.strict ? "\t1\t" : "\t0\t";
+                put_uint(s_var, t.u + 1);
+                s_var.push_back('\t');
+                put_uint(s_var, (t.exit_ov >> 1) + 1);
+                s_var.push_back('\t');
+                s_var += row;
+                s_var.push_back('\n');
+            }
+            core_cov_ += (uint64_t)t.core_mean;
+            core_num_++;
+            const std::vector<uint32_t> &vs = var_sites[ti];
+            const size_t usize = g_.size_bp(t.u), esize = g_.size_bp(t.exit_ov >> 1);
+            uint32_t indel = 0;
+            for (size_t i = 0; i < vs.size(); ++i) {
+                const uint32_t site = vs[i];
+                // distance to the neighbouring sites / unitig ends (src/CDBG.cpp:1279-1298)
+                uint32_t vd;
+                if (i == 0) {
+                    if (vs.size() != 1) vd = (uint32_t)std::min((size_t)(uint32_t)(vs[1] - vs[0] - 1), usize);
+                    else vd = (uint32_t)std::min(usize, esize);
+                } else if (i == vs.size() - 1) {
+                    vd = (uint32_t)std::min((size_t)(uint32_t)(vs[i] - vs[i - 1] - 1), esize);
+                } else {
+                    vd = std::min((uint32_t)(vs[i] - vs[i - 1] - 1), (uint32_t)(vs[i + 1] - vs[i] - 1));
+                }
+                uint16_t maxnum = 0;
+                for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
+                const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
+                std::vector<double> tc(maxnum, 0.0);
+                double denom;
+                if (t.strict) {
+                    for (size_t p = 0; p < R; ++p) tc[m.group_at(site, (uint32_t)p) - 1] += t.cov[p];
+                    denom = t.cov_sum;
+                    if (is_indel) ++indel;
+                } else {
+                    if (is_indel) ++indel;  // counted even when the site is dropped below
+                    const auto &sg = site_groups[ti][i];
+                    bool ok = true;
+                    double sum = 0;
+                    for (size_t gi = 0; gi < sg.size() && ok; ++gi) {
+                        for (uint32_t q = sg[gi].first; q < sg[gi].first + sg[gi].count; ++q) {
+                            if (str_miss[q]) return fail(PF_ERR_MISSING_KMER, "CDBG::readCov():" + strings[q] + " kmer can not found .");
+                            if (!str_ok[q]) { ok = false; break; }
+                            tc[gi] += (double)str_sum[q] / (double)(strings[q].size() - (size_t)k + 1);
+                        }
+                        sum += tc[gi];
+                    }
+                    if (!ok) continue;
+                    denom = sum;
+                }
+                std::string cov_info, fre_info;
+                for (double x : tc) {
+                    put_double(cov_info, x);
+                    cov_info.push_back('\t');
+                    put_double(fre_info, x / denom);
+                    fre_info.push_back('\n');
+                }
+                cov_info += t.strict ? "1\t" : "0\t";
+                if (is_indel) put_uint(cov_info, m.indel_len[indel - 1]);
+                else cov_info.push_back('0');
+                cov_info.push_back('\t');
+                put_uint(cov_info, var_count);
+                cov_info.push_back('\t');
+                put_uint(cov_info, vs.size());
+                cov_info.push_back('\t');
+                put_uint(cov_info, vd);
+                cov_info += "\t\n";
+                allfre += fre_info;
+                if (maxnum >= 2 && maxnum <= 5) {
+                    ++allele_[maxnum - 2];
+                    fre[maxnum - 2] += fre_info;
+                    cov[maxnum - 2] += cov_info;
+                }
+            }
+        }
+        times_.format_s += since(t0);
+        tasks.clear();
+    }
+
+    t0 = clk::now();
+    static const char *kArity[4] = {"bi", "tri", "tetra", "penta"};
+    if (write_file(outpre + "_allele_frequency.txt", allfre)) return status_;
+    if (write_file(outpre + "_alignseq.txt", s_var)) return status_;
+    for (int a = 0; a < 4; ++a) {
+        if (write_file(outpre + "_" + kArity[a] + "fre.txt", fre[a])) return status_;
+        if (write_file(outpre + "_" + kArity[a] + "cov.txt", cov[a])) return status_;
+    }
+    times_.write_s = since(t0);
+    times_.ploidy_total_s = since(t_all);
+    if (!quiet_) {
+        printf("CDBG::PloidyEstimation():  Cpu time : %gs\n", (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("CDBG::PloidyEstimation():  Real time : %gs\n", times_.ploidy_total_s);
+        printf("CDBG::PloidyEstimation(): Alleles in SuperBubbles  :\t2 :%llu\t3 :%llu\t4 :%llu\t5 :%llu\n",
+               (unsigned long long)allele_[0], (unsigned long long)allele_[1], (unsigned long long)allele_[2],
+               (unsigned long long)allele_[3]);
+        // the reference divides unguarded (src/CDBG.cpp:1703) and dies with SIGFPE when no site exists
+        if (core_num_) printf("CDBG::PloidyEstimation(): Sites' Average Coverage:%d\n", (int)(core_cov_ / core_num_));
+    }
+    return 0;
+}
+
+}  // namespace pfh

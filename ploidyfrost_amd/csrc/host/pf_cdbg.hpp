@@ -1,0 +1,99 @@
+// pfh::CDBG -- the product's host-side mirror of the reference class CDBG
+// (reference src/CDBG.hpp:20-41, driven from src/Main.cpp:829-849):
+//
+//     CDBG g(graph, z, M, D, G, kmc_prefix);
+//     g.setUnitigId(outpre, graphfile, threads);
+//     g.printInfo(verbose, outpre);                              // only with -i
+//     g.findSuperBubble_multithread_ptr(outpre, threads);
+//     g.ploidyEstimation_multithread_ptr(outpre, lower, upper, threads);
+//
+// Same method names, argument meaning, output files (./PloidyFrost_output/<outpre>_*.txt) and
+// stdout lines.  Differences, all deliberate:
+//   * every compute-heavy step runs on the MI355X through include/ploidyfrost_hip.h
+//     (adjacency join, superbubble traversals, per-unitig and per-string k-mer coverage,
+//     Needleman-Wunsch fill + traceback); the host keeps only the order-dependent state
+//     replay, the progressive-alignment bookkeeping and the text formatting;
+//   * methods return an int status instead of calling exit(); main() turns a failure into the
+//     reference's "message + exit(EXIT_FAILURE)";
+//   * output is always the deterministic `-t 1` ordering, whatever `threads` says.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "pf_host_align.hpp"
+#include "pf_host_graph.hpp"
+#include "ploidyfrost_hip.h"
+
+namespace pfh {
+
+struct PhaseTimes {
+    double bfs_device_s = 0, replay_s = 0, bubble_write_s = 0;
+    double cov_device_s = 0, tasks_s = 0, align_s = 0, sites_s = 0, format_s = 0, write_s = 0;
+    double find_total_s = 0, ploidy_total_s = 0;
+    uint64_t candidates = 0, bfs_deferred = 0, bubbles_out = 0, tasks = 0, align_jobs = 0, site_strings = 0;
+};
+
+class CDBG {
+public:
+    CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db = "",
+         int device = 0);
+    ~CDBG();
+    CDBG(const CDBG &) = delete;
+    CDBG &operator=(const CDBG &) = delete;
+
+    bool good() const { return status_ == 0; }
+    int status() const { return status_; }
+    const std::string &error() const { return err_; }
+
+    int setUnitigId(const std::string &outpre, const std::string &graphfile, const size_t &thr);
+    int printInfo(const bool &verbose, const std::string &outpre);
+    int findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thread);
+    int ploidyEstimation_multithread_ptr(const std::string &outpre, const int &lower, const int &upper, const size_t &thr);
+
+    // extras (not in the reference interface)
+    void set_output_dir(const std::string &dir) { outdir_ = dir; }  // default "PloidyFrost_output"
+    void set_quiet(bool q) { quiet_ = q; }
+    void set_write_files(bool w) { write_files_ = w; }              // bench: format but do not touch the disk
+    pf_ctx *device() { return ctx_; }
+    const PhaseTimes &times() const { return times_; }
+    uint64_t allele_sites(int arity) const { return allele_[arity - 2]; }
+    uint64_t core_cov() const { return core_cov_; }
+    uint64_t core_num() const { return core_num_; }
+    uint64_t n_superbubbles() const { return n_super_bubble_; }
+    const std::vector<uint8_t> &state_flags() const { return flags_; }
+    const std::vector<uint32_t> &state_plus() const { return plus_; }
+    const std::vector<uint32_t> &state_minus() const { return minus_; }
+    uint64_t output_bytes() const { return out_bytes_; }
+
+private:
+    struct Task;
+    int fail(int st, const std::string &msg);
+    int ensure_dir();
+    int write_file(const std::string &name, const std::string &data);
+    // MyUnitig state (reference src/MyUnitig.hpp), array-indexed
+    void side_self(uint32_t u, bool plus_side);
+    void release(uint32_t ex, uint32_t me);
+    void poison(uint32_t u);
+    void replay(const pf_bfs_record &r, const uint32_t *list);
+
+    UnitigSet &g_;
+    size_t complex_size_;
+    Scoring sc_;
+    std::string outdir_ = "PloidyFrost_output";
+    pf_ctx *ctx_ = nullptr;
+    int status_ = 0;
+    std::string err_;
+    bool quiet_ = false, write_files_ = true;
+    bool both_strands_ = true;
+
+    std::vector<uint32_t> succ_, pred_;  // host copy of the CSR, [2N][4]
+    std::vector<uint8_t> flags_;
+    std::vector<uint32_t> plus_, minus_;  // 0 = NULL, id = u + 1
+
+    PhaseTimes times_;
+    uint64_t allele_[4] = {0, 0, 0, 0};
+    uint64_t core_cov_ = 0, core_num_ = 0, n_super_bubble_ = 0, out_bytes_ = 0;
+};
+
+}  // namespace pfh

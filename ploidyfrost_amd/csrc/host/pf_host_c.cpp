@@ -1,0 +1,70 @@
+#include <chrono>
+#include <cstring>
+#include <memory>
+#include <string>
+
+#include "pf_cdbg.hpp"
+#include "ploidyfrost_host.h"
+
+struct pfh_run {
+    pfh::UnitigSet graph;
+    std::unique_ptr<pfh::CDBG> cdbg;
+    double z_M = 2, z_D = -1, z_G = -3;
+    size_t z = 8;
+    double load_s = 0, upload_s = 0;
+    std::string err;
+};
+
+static std::string g_open_err;
+
+extern "C" {
+
+pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex_size, double match, double mismatch,
+                  double gap, int device) {
+    using clk = std::chrono::steady_clock;
+    auto r = std::make_unique<pfh_run>();
+    auto t0 = clk::now();
+    if (!r->graph.load_gfa(gfa_path, g_open_err)) return nullptr;
+    r->load_s = std::chrono::duration<double>(clk::now() - t0).count();
+    r->z = complex_size;
+    r->z_M = match; r->z_D = mismatch; r->z_G = gap;
+    t0 = clk::now();
+    r->cdbg = std::make_unique<pfh::CDBG>(r->graph, r->z, r->z_M, r->z_D, r->z_G, kmc_prefix ? kmc_prefix : "", device);
+    r->cdbg->set_quiet(true);
+    r->upload_s = std::chrono::duration<double>(clk::now() - t0).count();
+    if (!r->cdbg->good()) { g_open_err = r->cdbg->error(); return nullptr; }
+    return r.release();
+}
+
+void pfh_close(pfh_run *r) { delete r; }
+const char *pfh_last_error(const pfh_run *r) { return r ? r->cdbg->error().c_str() : g_open_err.c_str(); }
+void pfh_set_output_dir(pfh_run *r, const char *dir) { r->cdbg->set_output_dir(dir); }
+void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0); }
+int pfh_set_unitig_id(pfh_run *r, const char *outpre) { return r->cdbg->setUnitigId(outpre, "", 1); }
+int pfh_find_superbubbles(pfh_run *r, const char *outpre) { return r->cdbg->findSuperBubble_multithread_ptr(outpre, 1); }
+int pfh_ploidy_estimation(pfh_run *r, const char *outpre, int lower, int upper) {
+    return r->cdbg->ploidyEstimation_multithread_ptr(outpre, lower, upper, 1);
+}
+void *pfh_device_ctx(pfh_run *r) { return r->cdbg->device(); }
+
+void pfh_get_times(const pfh_run *r, pfh_times *o) {
+    memset(o, 0, sizeof(*o));
+    const pfh::PhaseTimes &t = r->cdbg->times();
+    o->load_s = r->load_s; o->upload_s = r->upload_s;
+    o->bfs_device_s = t.bfs_device_s; o->replay_s = t.replay_s; o->bubble_write_s = t.bubble_write_s; o->find_total_s = t.find_total_s;
+    o->cov_device_s = t.cov_device_s; o->tasks_s = t.tasks_s; o->align_s = t.align_s; o->sites_s = t.sites_s;
+    o->format_s = t.format_s; o->write_s = t.write_s; o->ploidy_total_s = t.ploidy_total_s;
+    o->unitigs = r->graph.n(); o->kmers = r->graph.n_kmers; o->candidates = t.candidates; o->superbubbles = r->cdbg->n_superbubbles();
+    o->tasks = t.tasks; o->align_jobs = t.align_jobs; o->site_strings = t.site_strings; o->output_bytes = r->cdbg->output_bytes();
+    for (int a = 0; a < 4; ++a) o->allele[a] = r->cdbg->allele_sites(a + 2);
+    o->core_cov = r->cdbg->core_cov(); o->core_num = r->cdbg->core_num();
+}
+
+void pfh_state(const pfh_run *r, uint8_t *flags, uint32_t *plus, uint32_t *minus) {
+    const size_t N = r->graph.n();
+    if (flags) memcpy(flags, r->cdbg->state_flags().data(), N);
+    if (plus) memcpy(plus, r->cdbg->state_plus().data(), N * 4);
+    if (minus) memcpy(minus, r->cdbg->state_minus().data(), N * 4);
+}
+
+}  // extern "C"

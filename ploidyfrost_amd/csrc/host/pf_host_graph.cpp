@@ -1,0 +1,256 @@
+#include "pf_host_graph.hpp"
+
+#include <fcntl.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace pfh {
+
+namespace {
+inline int code_of(char c) {
+    switch (c) {
+        case 'A': case 'a': return 0;
+        case 'C': case 'c': return 1;
+        case 'G': case 'g': return 2;
+        case 'T': case 't': return 3;
+        default: return -1;
+    }
+}
+const char kBase[4] = {'A', 'C', 'G', 'T'};
+
+struct Mapped {
+    const char *p = nullptr;
+    size_t n = 0;
+    int fd = -1;
+    bool open(const std::string &path) {
+        fd = ::open(path.c_str(), O_RDONLY);
+        if (fd < 0) return false;
+        struct stat st;
+        if (fstat(fd, &st) != 0) return false;
+        n = (size_t)st.st_size;
+        if (n == 0) { p = ""; return true; }
+        void *m = mmap(nullptr, n, PROT_READ, MAP_PRIVATE, fd, 0);
+        if (m == MAP_FAILED) return false;
+        p = (const char *)m;
+        return true;
+    }
+    ~Mapped() {
+        if (p && n) munmap((void *)p, n);
+        if (fd >= 0) close(fd);
+    }
+};
+}  // namespace
+
+void UnitigSet::append_mapped(uint32_t ov, std::string &dst) const {
+    std::string_view s = seq(ov >> 1);
+    if ((ov & 1) == 0) {
+        dst.append(s.data(), s.size());
+    } else {
+        size_t at = dst.size();
+        dst.resize(at + s.size());
+        for (size_t i = 0; i < s.size(); ++i) {
+            char c = s[s.size() - 1 - i];
+            dst[at + i] = c == 'A' ? 'T' : c == 'C' ? 'G' : c == 'G' ? 'C' : 'A';
+        }
+    }
+}
+
+bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
+    Mapped f;
+    if (!f.open(path)) { err = "cannot open " + path; return false; }
+    const char *p = f.p, *end = f.p + f.n;
+    auto line_end = [&](const char *q) -> const char * { return (const char *)memchr(q, '\n', (size_t)(end - q)); };
+    const char *le = line_end(p);
+    if (!le || p == le || *p != 'H') { err = "GFA header line missing"; return false; }
+    int version = 1;
+    if (le - p >= 10 && memcmp(p, "H\tVN:Z:2.0", 10) == 0) version = 2;
+    {
+        // tags of the header line (CompactedDBG.tcc:868-884)
+        const char *q = p + 2;
+        while (q < le) {
+            const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
+            if (!t) t = le;
+            if (t - q > 5 && memcmp(q, "KL:Z:", 5) == 0) k = atoi(std::string(q + 5, t).c_str());
+            else if (t - q > 5 && memcmp(q, "ML:Z:", 5) == 0) g = atoi(std::string(q + 5, t).c_str());
+            q = t + 1;
+        }
+    }
+    if (k < 3 || k > 31) { err = "k outside 3..31"; return false; }
+    // pass 1: locate the sequence field of every complete S-line
+    struct Seg { const char *s; uint32_t len; };
+    std::vector<Seg> longs, shorts;
+    uint64_t long_bp = 0;
+    const char *q = le + 1;
+    while (q < end) {
+        const char *e = line_end(q);
+        if (!e) break;  // unterminated last line is dropped
+        if (e - q >= 2 && q[0] == 'S' && q[1] == '\t') {
+            const char *fld = q + 2;
+            for (int skip = (version == 1 ? 1 : 2); skip > 0 && fld; --skip) {
+                const char *t = (const char *)memchr(fld, '\t', (size_t)(e - fld));
+                fld = t ? t + 1 : nullptr;
+            }
+            if (!fld) { err = "missing fields in a segment line"; return false; }
+            const char *t = (const char *)memchr(fld, '\t', (size_t)(e - fld));
+            if (!t) t = e;
+            uint32_t len = (uint32_t)(t - fld);
+            if (len && fld[len - 1] == '\r') len--;
+            if ((int)len < k) { err = "segment shorter than k"; return false; }
+            if ((int)len == k) shorts.push_back({fld, len});
+            else { longs.push_back({fld, len}); long_bp += len; }
+        }
+        q = e + 1;
+    }
+    const size_t N = longs.size() + shorts.size();
+    if (N == 0) { err = "no segments in the GFA file"; return false; }
+    if (N >= (1u << 30)) { err = "more than 2^30 unitigs"; return false; }
+    n_short = shorts.size();
+    text.resize(long_bp + (uint64_t)shorts.size() * k);
+    off.resize(N + 1);
+    len_bp.resize(N);
+    uint64_t at = 0;
+    size_t u = 0;
+    for (const Seg &s : longs) {
+        off[u] = at;
+        len_bp[u] = s.len;
+        for (uint32_t i = 0; i < s.len; ++i) {
+            int c = code_of(s.s[i]);
+            if (c < 0) { err = "non-ACGT base in a segment"; return false; }
+            text[at + i] = kBase[c];
+        }
+        at += s.len;
+        ++u;
+    }
+    std::string fw((size_t)k, 'A'), rc((size_t)k, 'A');
+    for (const Seg &s : shorts) {
+        off[u] = at;
+        len_bp[u] = (uint32_t)k;
+        for (int i = 0; i < k; ++i) {
+            int c = code_of(s.s[i]);
+            if (c < 0) { err = "non-ACGT base in a segment"; return false; }
+            fw[i] = kBase[c];
+            rc[k - 1 - i] = kBase[3 - c];
+        }
+        const std::string &keep = rc < fw ? rc : fw;  // km_rep (CompactedDBG.tcc:3945-3954)
+        memcpy(text.data() + at, keep.data(), (size_t)k);
+        at += k;
+        ++u;
+    }
+    off[N] = at;
+    pack();
+    return true;
+}
+
+void UnitigSet::from_sequences(const std::vector<std::string> &seqs, int k_) {
+    k = k_;
+    const size_t N = seqs.size();
+    off.assign(N + 1, 0);
+    len_bp.resize(N);
+    uint64_t tot = 0;
+    for (size_t u = 0; u < N; ++u) { off[u] = tot; len_bp[u] = (uint32_t)seqs[u].size(); tot += seqs[u].size(); }
+    off[N] = tot;
+    text.resize(tot);
+    for (size_t u = 0; u < N; ++u) memcpy(text.data() + off[u], seqs[u].data(), seqs[u].size());
+    pack();
+}
+
+void UnitigSet::pack() {
+    const size_t N = len_bp.size();
+    word_off.assign(N + 1, 0);
+    n_kmers = 0;
+    for (size_t u = 0; u < N; ++u) {
+        word_off[u + 1] = word_off[u] + (len_bp[u] + 31) / 32;
+        n_kmers += len_bp[u] - (uint32_t)k + 1;
+    }
+    words.assign(word_off[N] + 1, 0);
+    for (size_t u = 0; u < N; ++u) {
+        const char *s = text.data() + off[u];
+        uint64_t *w = words.data() + word_off[u];
+        const uint32_t L = len_bp[u];
+        for (uint32_t i = 0; i < L; ++i) w[i >> 5] |= (uint64_t)code_of(s[i]) << (62 - 2 * (i & 31));
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+static bool read_all(const std::string &path, std::vector<uint8_t> &buf) {
+    FILE *f = fopen(path.c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    long sz = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    buf.resize((size_t)sz);
+    size_t got = sz ? fread(buf.data(), 1, (size_t)sz, f) : 0;
+    fclose(f);
+    return got == (size_t)sz;
+}
+
+bool KmcRecords::load(const std::string &prefix, std::string &err) {
+    std::vector<uint8_t> pre, suf;
+    if (!read_all(prefix + ".kmc_pre", pre) || !read_all(prefix + ".kmc_suf", suf)) {
+        err = "cannot read " + prefix + ".kmc_pre / .kmc_suf";
+        return false;
+    }
+    auto marker = [](const std::vector<uint8_t> &b, const char *m) {
+        return b.size() >= 8 && memcmp(b.data(), m, 4) == 0 && memcmp(b.data() + b.size() - 4, m, 4) == 0;
+    };
+    if (!marker(pre, "KMCP") || !marker(suf, "KMCS") || pre.size() < 24) { err = "not a KMC database (markers)"; return false; }
+    uint32_t version;
+    memcpy(&version, pre.data() + pre.size() - 12, 4);
+    if (version == 0x200) {
+        err = "KMC2-layout databases are not supported yet (convert with `kmc_tools transform ... kmc1` or use a KMC1 writer)";
+        return false;
+    }
+    if (version != 0) { err = "unknown KMC database version"; return false; }
+    // KMC1: 'KMCP' | u64 LUT[...] | header | u32 header_offset | 'KMCP'
+    const uint8_t *body = pre.data() + 4;
+    const uint64_t body_sz = pre.size() - 8 - 4;  // without markers and the header_offset word
+    const uint64_t header_offset = pre[pre.size() - 8];
+    if (header_offset > body_sz || header_offset < 40) { err = "bad KMC header offset"; return false; }
+    const uint64_t hi = (body_sz - header_offset) / 8;
+    auto word = [&](uint64_t i) { uint64_t v; memcpy(&v, body + 8 * i, 8); return v; };
+    k = (uint32_t)word(hi);
+    mode = (uint32_t)(word(hi) >> 32);
+    counter_size = (uint32_t)word(hi + 1);
+    lut_prefix_len = (uint32_t)(word(hi + 1) >> 32);
+    min_count = (uint32_t)word(hi + 2);
+    max_count = word(hi + 2) >> 32;
+    total = word(hi + 3);
+    both_strands = (word(hi + 4) & 0xF) != 1;
+    max_count += word(hi + 4) & 0xFFFFFFFF00000000ull;
+    if (mode != 0) { err = "KMC databases with float counters (mode 1) are not supported"; return false; }
+    const uint32_t p = lut_prefix_len;
+    if (k < 3 || k > 31 || p == 0 || p >= k || (k - p) % 4 || counter_size == 0 || counter_size > 8) {
+        err = "unsupported k / lut_prefix_length / counter_size in the KMC header";
+        return false;
+    }
+    const uint64_t n_pref = 1ull << (2 * p);
+    if (hi < n_pref) { err = "KMC prefix table shorter than 4^p"; return false; }
+    const uint32_t sb = (k - p) / 4, rec = sb + counter_size;
+    if (suf.size() - 8 < total * rec) { err = "kmc_suf holds fewer records than total_kmers"; return false; }
+    kmers.resize(total);
+    counts.resize(total);
+    const uint8_t *r = suf.data() + 4;
+    for (uint64_t x = 0; x < n_pref; ++x) {
+        uint64_t lo = word(x);
+        uint64_t hi_rec = (x + 1 < hi) ? word(x + 1) : total;  // the reader patches LUT[end] = total + 1 (:292)
+        if (x + 1 == n_pref && (x + 1 >= hi || hi_rec > total)) hi_rec = total;
+        if (hi_rec > total) hi_rec = total;
+        for (uint64_t i = lo; i < hi_rec; ++i) {
+            const uint8_t *q = r + i * rec;
+            uint64_t s = 0;
+            for (uint32_t b = 0; b < sb; ++b) s = (s << 8) | q[b];
+            uint64_t c = 0;
+            for (uint32_t b = 0; b < counter_size; ++b) c |= (uint64_t)q[sb + b] << (8 * b);
+            kmers[i] = (x << (2 * (k - p))) | s;
+            counts[i] = (uint32_t)c;
+        }
+    }
+    return true;
+}
+
+}  // namespace pfh

@@ -1,0 +1,142 @@
+// `ploidyfrost` -- command line of the MI355X build, same option surface as the reference's
+// single-sample run (reference src/Main.cpp:124-198 getopt string and cases, :278-541 checks,
+// :812-849 dispatch):
+//     ploidyfrost -g <BifrostGraph.gfa> -d <KMCDatabase> -o <prefix> [-t T -l L -u U -z Z -M m -D d -G g -v -i]
+// Output: ./PloidyFrost_output/<prefix>_*.txt, byte-identical to the reference run with -t 1.
+// The colored path (-f/-C), the `model` and `cutoffL/cutoffU` sub-commands are outside this
+// build's scope and say so.
+#include <getopt.h>
+#include <sys/stat.h>
+
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <iostream>
+#include <string>
+#include <thread>
+
+#include "pf_cdbg.hpp"
+
+using namespace std;
+
+namespace {
+void PrintUsage() {
+    cout << "Usage: PloidyFrost -g <BifrostGraph> -d <KMCDatabase> -o <outfile_prefix> ..." << endl << endl;
+    cout << "parameters with required argument:" << endl << endl
+         << "  -g,             Input Bifrost Graph file (GFA format)" << endl
+         << "  -o,             Prefix for Output files (default : 'output')" << endl
+         << "  -t,             Number of Threads (default is 1; output always follows the -t 1 order)" << endl
+         << "  -d,             Load KMC Database" << endl
+         << "  -l,             Lower coverage threshold (default : 10 )" << endl
+         << "  -u,             Upper coverage threshold (default : 1000 )" << endl
+         << "  -z,             Maximum number of unitigs in superbubble (default : 8 )" << endl
+         << "  -M,             Match score (default : 2 )" << endl
+         << "  -D,             Mismatch penalty (default : -1 )" << endl
+         << "  -G,             Gap penalty (default : -3 )" << endl << endl
+         << "parameters with no argument:" << endl << endl
+         << "  -v,             Print information messages during construction" << endl
+         << "  -i,             Output Information about Bifrost graph" << endl << endl
+         << "Not part of this build: colored graphs (-f, -C), `model`, `cutoffL`, `cutoffU`." << endl;
+}
+
+struct Options {
+    string graphfile, colorfile, outprefix = "output", db, coveragefile, hist;
+    size_t nb_threads = 1, complex_size = 8;
+    bool verbose = false, info = false;
+    int coverage_lower = 10, coverage_upper = 1000, k = 25;
+    double match = 2, mismatch = -1, gap = -3;
+};
+
+bool file_exists(const string &p) {
+    struct stat sb;
+    return stat(p.c_str(), &sb) == 0;
+}
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 2) { PrintUsage(); return 0; }
+    if (!strcmp(argv[1], "model") || !strcmp(argv[1], "cutoffL") || !strcmp(argv[1], "cutoffU")) {
+        cerr << "Error: the `" << argv[1] << "` sub-command is not part of the MI355X build (hot path only)." << endl;
+        return EXIT_FAILURE;
+    }
+    Options opt;
+    int oc;
+    while ((oc = getopt(argc, argv, "M:D:G:z:a:l:q:u:e:C:R:o:t:g:f:k:d:m:n:h:ibvpNSc")) != -1) {
+        switch (oc) {
+            case 'z': opt.complex_size = (size_t)atoi(optarg); break;
+            case 'M': opt.match = atof(optarg); break;
+            case 'D': opt.mismatch = atof(optarg); break;
+            case 'G': opt.gap = atof(optarg); break;
+            case 'u': opt.coverage_upper = atoi(optarg);  // falls through, as in the reference (:149-153)
+            case 'C': opt.coveragefile = optarg; break;
+            case 'h': opt.hist = optarg; break;
+            case 'g': opt.graphfile = optarg; break;
+            case 'f': opt.colorfile = optarg; break;
+            case 'o': opt.outprefix = optarg; break;
+            case 'l': opt.coverage_lower = atoi(optarg); break;
+            case 't': opt.nb_threads = (size_t)atoi(optarg); break;
+            case 'k': opt.k = atoi(optarg); break;
+            case 'v': opt.verbose = true; break;
+            case 'd': opt.db = optarg; break;
+            case 'i': opt.info = true; break;
+            case 'q': case 'm': case 'n': case 'a': case 'b': case 'p': break;  // accepted, no effect on this path
+            default:
+                cout << "Invalid option" << endl;
+                PrintUsage();
+                exit(EXIT_FAILURE);
+        }
+    }
+    // check_ProgramOptions (:278-541), single-sample subset
+    bool ok = true;
+    const size_t max_threads = std::thread::hardware_concurrency();
+    if ((long)opt.nb_threads <= 0) { cerr << "Error: Number of threads cannot be less than or equal to 0." << endl; ok = false; }
+    if (opt.nb_threads > max_threads) { cerr << "Error: Number of threads cannot be greater than or equal to " << max_threads << "." << endl; ok = false; }
+    if (!opt.colorfile.empty()) { cerr << "Error: colored graphs (-f) are not part of this build." << endl; ok = false; }
+    if (opt.db.empty()) { cerr << "Error: Need input a kmc database prefix!\n"; ok = false; }
+    else if (!file_exists(opt.db + ".kmc_pre") || !file_exists(opt.db + ".kmc_suf")) {
+        cerr << "Error: Could not read the input kmc database " << opt.db << "." << endl;
+        ok = false;
+    }
+    if (opt.complex_size < 4) { cerr << "Error: Maximum number of unitigs in superbubble is at least 4 !" << endl; ok = false; }
+    if (opt.mismatch > opt.match) { cerr << "Error: Mismatch penalty should be smaller than match score !" << endl; ok = false; }
+    if (opt.gap > opt.match) { cerr << "Error: Gap penalty should be smaller than match score !" << endl; ok = false; }
+    if (opt.outprefix.empty()) { cerr << "Error: No output filename prefix given." << endl; ok = false; }
+    if (opt.coverage_lower < 0 || opt.coverage_upper < 0) { cerr << "Error: Filter coverage need a positive number." << endl; ok = false; }
+    if (opt.coverage_lower > opt.coverage_upper) { cerr << "Error: lower cutoff need be smaller than upper cutoff " << endl; ok = false; }
+    if (opt.graphfile.empty()) { cerr << "Error: No graph file was provided in input." << endl; ok = false; }
+    else if (!file_exists(opt.graphfile)) { cerr << "Error: The graph file does not exist." << endl; ok = false; }
+    if (!ok) { PrintUsage(); return 0; }
+
+    pfh::UnitigSet graph;
+    std::string err;
+    auto t0 = std::chrono::steady_clock::now();
+    if (!graph.load_gfa(opt.graphfile, err)) {
+        cout << "CompactedDBG::read(): Graph could not be loaded! Exit. (" << err << ")" << endl;
+        exit(EXIT_FAILURE);
+    }
+    cout << "CompactedDBG::read(): Graph loading successful" << endl;
+    cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
+
+    pfh::CDBG g(graph, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db);
+    auto die = [&]() {
+        cerr << g.error() << endl;
+        exit(EXIT_FAILURE);
+    };
+    if (!g.good()) die();
+    if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
+    if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
+    if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) die();
+    cout << "CDBG:: Minimum Coverage:" << opt.coverage_lower << endl;
+    cout << "CDBG:: Maximum Coverage:" << opt.coverage_upper << endl;
+    if (g.ploidyEstimation_multithread_ptr(opt.outprefix, opt.coverage_lower, opt.coverage_upper, opt.nb_threads)) die();
+    if (opt.verbose) {
+        const pfh::PhaseTimes &t = g.times();
+        printf("[device] candidates %llu (big tier %llu)  bfs %.3fs replay %.3fs | cov %.3fs tasks %.3fs (%llu) align %.3fs (%llu jobs) "
+               "sites %.3fs (%llu strings) format %.3fs write %.3fs\n",
+               (unsigned long long)t.candidates, (unsigned long long)t.bfs_deferred, t.bfs_device_s, t.replay_s, t.cov_device_s,
+               t.tasks_s, (unsigned long long)t.tasks, t.align_s, (unsigned long long)t.align_jobs, t.sites_s,
+               (unsigned long long)t.site_strings, t.format_s, t.write_s);
+    }
+    return 0;
+}

@@ -1,0 +1,112 @@
+"""ctypes binding of the C facade over the C++ host layer (include/ploidyfrost_host.h)."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import hipapi
+
+PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_host.so")
+
+
+class Times(C.Structure):
+    _fields_ = [(n, C.c_double) for n in ("load_s", "upload_s", "bfs_device_s", "replay_s", "bubble_write_s", "find_total_s",
+                                          "cov_device_s", "tasks_s", "align_s", "sites_s", "format_s", "write_s",
+                                          "ploidy_total_s")] + \
+               [(n, C.c_uint64) for n in ("unitigs", "kmers", "candidates", "superbubbles", "tasks", "align_jobs", "site_strings",
+                                          "output_bytes")] + [("allele", C.c_uint64 * 4), ("core_cov", C.c_uint64),
+                                                              ("core_num", C.c_uint64)]
+
+
+_lib = None
+DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_unitig_id",
+                    "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state"]
+
+
+def load_library() -> C.CDLL:
+    global _lib
+    if _lib is not None:
+        return _lib
+    hipapi.load_library()  # device layer first (and torch's HIP runtime before it)
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("%s is missing: build with `make -C ploidyfrost_amd/csrc`" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.pfh_open.restype = vp
+    L.pfh_open.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_int]
+    L.pfh_close.argtypes = [vp]
+    L.pfh_last_error.restype = C.c_char_p
+    L.pfh_last_error.argtypes = [vp]
+    L.pfh_set_output_dir.argtypes = [vp, C.c_char_p]
+    L.pfh_set_write_files.argtypes = [vp, C.c_int]
+    L.pfh_set_unitig_id.argtypes = [vp, C.c_char_p]
+    L.pfh_find_superbubbles.argtypes = [vp, C.c_char_p]
+    L.pfh_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
+    L.pfh_get_times.argtypes = [vp, C.POINTER(Times)]
+    L.pfh_device_ctx.restype = vp
+    L.pfh_device_ctx.argtypes = [vp]
+    L.pfh_state.argtypes = [vp, vp, vp, vp]
+    _lib = L
+    return L
+
+
+class Run:
+    """CompactedDBG::read + CDBG::CDBG of the reference's main(): graph and count table in HBM."""
+
+    def __init__(self, gfa: str, kmc_prefix: str, z: int = 8, M: float = 2.0, D: float = -1.0, G: float = -3.0,
+                 device: int = 0):
+        self.L = load_library()
+        self.h = self.L.pfh_open(gfa.encode(), kmc_prefix.encode(), z, M, D, G, device)
+        if not self.h:
+            raise RuntimeError("ploidyfrost host layer: " + self.L.pfh_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pfh_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, st):
+        if st != 0:
+            raise hipapi.DeviceError(st, self.L.pfh_last_error(self.h).decode())
+
+    def set_output_dir(self, d: str):
+        self.L.pfh_set_output_dir(self.h, d.encode())
+
+    def set_write_files(self, on: bool):
+        self.L.pfh_set_write_files(self.h, int(on))
+
+    def set_unitig_id(self, outpre: str):
+        self._check(self.L.pfh_set_unitig_id(self.h, outpre.encode()))
+
+    def find_superbubbles(self, outpre: str):
+        self._check(self.L.pfh_find_superbubbles(self.h, outpre.encode()))
+
+    def ploidy_estimation(self, outpre: str, lower: int = 10, upper: int = 1000):
+        self._check(self.L.pfh_ploidy_estimation(self.h, outpre.encode(), lower, upper))
+
+    def times(self) -> dict:
+        t = Times()
+        self.L.pfh_get_times(self.h, C.byref(t))
+        d = {n: getattr(t, n) for n, _ in Times._fields_ if n != "allele"}
+        d["allele"] = list(t.allele)
+        return d
+
+    def device_ctx(self) -> int:
+        return self.L.pfh_device_ctx(self.h)
+
+    def state(self):
+        n = self.times()["unitigs"]
+        f = np.empty(n, dtype=np.uint8)
+        p = np.empty(n, dtype=np.uint32)
+        m = np.empty(n, dtype=np.uint32)
+        self.L.pfh_state(self.h, f.ctypes.data, p.ctypes.data, m.ctypes.data)
+        return f, p, m

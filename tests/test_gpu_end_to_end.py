@@ -1,0 +1,82 @@
+"""The whole path through the product (C++ host layer + HIP kernels) against the committed
+outputs of the real reference binary: all twelve files byte-identical, for every fixture."""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, compare_outputs, golden_cases, load_case
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle  # noqa: E402
+
+from ploidyfrost_amd import hostapi  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+CLI = os.path.join(ROOT, "ploidyfrost_amd", "csrc", "ploidyfrost")
+
+
+@pytest.mark.parametrize("case", golden_cases())
+def test_cli_outputs_match_reference(case, tmp_path):
+    meta = load_case(case)
+    r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "1"] + meta["args"], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout
+    bad = compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(tmp_path, "PloidyFrost_output"))
+    assert not bad, "files differ from the reference: %s\n%s" % (bad, r.stdout)
+    # the summary lines the reference prints
+    for line in meta["reference_log"]:
+        assert line.strip() in r.stdout.replace("\r", ""), line
+
+
+@pytest.mark.parametrize("case", ["tet60k", "weird12k", "hex30k"])
+def test_state_after_find_superbubbles_matches_oracle(case, tmp_path):
+    meta = load_case(case)
+    op = meta["opts"]
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]))
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    run.find_superbubbles("g")
+    f, p, m = run.state()
+    o = pyoracle.Oracle(meta["gfa"], meta["db"])
+    nb = o.find_superbubbles(z=int(op["-z"]))
+    ef, ep, em = o.state()
+    assert np.array_equal(f, ef) and np.array_equal(p, ep) and np.array_equal(m, em)
+    assert run.times()["superbubbles"] == nb
+
+
+def test_facade_full_run_and_no_disk_mode(tmp_path):
+    meta = load_case("tet60k")
+    run = hostapi.Run(meta["gfa"], meta["db"])
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    run.find_superbubbles("g")
+    run.ploidy_estimation("g", 5, 1000)
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+    t = run.times()
+    assert t["tasks"] > 0 and t["align_jobs"] >= t["tasks"] and t["output_bytes"] > 0
+    # format-only mode (bench): same bytes produced, nothing written
+    run2 = hostapi.Run(meta["gfa"], meta["db"])
+    d2 = tmp_path / "none"
+    run2.set_output_dir(str(d2))
+    run2.set_write_files(False)
+    run2.set_unitig_id("g")
+    run2.find_superbubbles("g")
+    run2.ploidy_estimation("g", 5, 1000)
+    assert run2.times()["output_bytes"] == t["output_bytes"] and not d2.exists()
+
+
+def test_missing_database_kmer_fails_like_the_reference(tmp_path):
+    """reference: "kmer can not found" + exit(EXIT_FAILURE) (src/CDBG.cpp:52-56, 92-96)"""
+    from ploidyfrost_amd import synth
+    meta = load_case("dip20k")
+    kmers, counts, km = synth.read_kmc1(meta["db"])
+    keep = np.ones(len(kmers), dtype=bool)
+    keep[::3] = False
+    synth.write_kmc1(str(tmp_path / "holes"), kmers[keep], counts[keep], km["k"])
+    r = subprocess.run([CLI, "-g", meta["gfa"], "-d", str(tmp_path / "holes"), "-o", "g", "-l", "5"], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode != 0 and "can not found" in r.stdout
