@@ -1,0 +1,266 @@
+#!/usr/bin/env python3
+"""bench.py -- unitigs/s through superbubble detection + variant calling (k=25, z=8) on MI355X.
+
+One "step" = one full pass of the hot path (CDBG::findSuperBubble + CDBG::ploidyEstimation of the
+reference, src/Main.cpp:838-848) over a synthetic compacted de Bruijn graph whose packed unitigs,
+CSR adjacency and k-mer count table are already resident in HBM; graph generation, GFA/KMC
+parsing, upload and Unitig_Id writing are outside the timed region.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W] [--unitigs U]
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU; every rank owns an independent partition of the unitig set (its own
+chromosome-sized connected components: no edge crosses ranks, so the path needs no data-path
+collective); the per-rank site counters and output sizes are all-gathered over RCCL at the end,
+as the reference-order concatenation needs them.  value = unitigs of all ranks / max-over-ranks time.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+K = 25
+Z = 8
+LOWER, UPPER = 5, 1000
+# ~26 unitigs per kb of genome at ploidy 4 with these gaps (SURVEY.md 8d ratios)
+GAP_LO, GAP_HI = 15, 215
+UNITIGS_PER_BP = 0.0262
+
+
+def log(*a):
+    print("[bench]", *a, file=sys.stderr, flush=True)
+
+
+def make_inputs(workdir: str, name: str, genome_len: int, seed: int, device):
+    """haplotypes -> compacted dBG (GFA) + KMC1 count database; returns (gfa, db_prefix, n_unitigs, n_kmers)."""
+    from ploidyfrost_amd import cdbg_build, synth
+    t0 = time.time()
+    spec = synth.HapSpec(genome_len=genome_len, ploidy=4, seed=seed, gap_lo=GAP_LO, gap_hi=GAP_HI, p_multi=0.03)
+    haps = synth.make_haplotypes(spec)
+    g = cdbg_build.build_cdbg(haps, K, device)
+    gfa = os.path.join(workdir, name + ".gfa")
+    n_unitigs = cdbg_build.write_gfa(gfa, g)
+    counts = synth.synth_counts(g["kmers"], g["mult"])
+    db = os.path.join(workdir, name + "_kmc")
+    synth.write_kmc1(db, g["kmers"], counts, K)
+    log("inputs %s: genome %d bp x4 -> %d unitigs, %d k-mers (%.1fs)" % (name, genome_len, n_unitigs, len(g["kmers"]),
+                                                                        time.time() - t0))
+    return gfa, db, n_unitigs, len(g["kmers"])
+
+
+def cpu_baseline(workdir: str, target_unitigs: int, device):
+    """The reference (oracle/_ref/PloidyFrost -t 1) -- or, where that binary is absent, the oracle
+    restatement -- on a bounded sample of the same workload, timed on this host's CPU."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    genome = int(target_unitigs / UNITIGS_PER_BP)
+    gfa, db, n_unitigs, _ = make_inputs(workdir, "cpu_sample", genome, 4242, device)
+    cwd = os.path.join(workdir, "cpu_run")
+    os.makedirs(cwd, exist_ok=True)
+    if os.path.exists(pyoracle.REF_BIN):
+        kind = "reference"
+        cmd = [pyoracle.REF_BIN, "-g", gfa, "-d", db, "-o", "b", "-t", "1", "-l", str(LOWER), "-u", str(UPPER), "-z", str(Z)]
+        pat = r"(?:findSuperBubble\(\):|PloidyEstimation\(\):)\s+Cpu time : ([0-9.e+-]+)s"
+    else:
+        kind = "port"
+        pyoracle.build()
+        cmd = [pyoracle.CLI, "-g", gfa, "-d", db, "-o", "b", "-l", str(LOWER), "-u", str(UPPER), "-z", str(Z)]
+        pat = r"(?:findSuperBubble\(\):|PloidyEstimation\(\):)\s+Real time : ([0-9.e+-]+)s"
+    r = subprocess.run(cmd, cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        log("cpu baseline failed:", r.stdout[-2000:])
+        return None
+    secs = [float(x) for x in re.findall(pat, r.stdout)]
+    if len(secs) != 2:
+        return None
+    t = sum(secs)
+    log("cpu baseline (%s): %d unitigs in %.2fs (find %.2fs + ploidy %.2fs)" % (kind, n_unitigs, t, secs[0], secs[1]))
+    return {"value": n_unitigs / t, "unit": "unitigs/s", "cores": 1, "kind": kind,
+            "sample": "same generator (tetraploid, k=25, z=8, -l %d -u %d), %d-unitig graph, findSuperBubble+PloidyEstimation "
+                      "time of one -t 1 run on %s" % (LOWER, UPPER, n_unitigs, cpu_model()), "seconds": t}
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return "%s (%d logical CPUs)" % (line.split(":", 1)[1].strip(), os.cpu_count())
+    except OSError:
+        pass
+    return "unknown CPU"
+
+
+# algorithmic HBM bytes per launch (restated in DESIGN.md)
+def algorithmic_bytes(kernel: str, t: dict) -> float | None:
+    if kernel == "k_cov":
+        return 12.25 * t["kmers"] + 16.0 * t["unitigs"]
+    if kernel == "k_bfs":
+        return 600.0 * t["candidates"]
+    if kernel == "k_align":
+        return 300.0 * t["align_jobs"]
+    if kernel == "k_strcov":
+        return 12.0 * 2.0 * t["site_strings"]
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--unitigs", type=int, default=1_000_000, help="target unitigs per GPU (config[1] = 1 M)")
+    ap.add_argument("--cpu-sample-unitigs", type=int, default=150_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--keep", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    from ploidyfrost_amd import dist as pfdist
+    from ploidyfrost_amd import hipapi, hostapi
+    pfdist.init("nccl", dev)
+    workdir = tempfile.mkdtemp(prefix="pf_bench_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    try:
+        genome = int(args.unitigs / UNITIGS_PER_BP)
+        gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, 1000 + rank, dev)
+        torch.cuda.empty_cache()
+        t0 = time.time()
+        run = hostapi.Run(gfa, db, z=Z, device=local_rank)
+        run.set_output_dir(os.path.join(workdir, "PloidyFrost_output"))
+        run.set_unitig_id("b")
+        log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, time.time() - t0, torch.cuda.get_device_name(local_rank)))
+        L = hipapi.load_library()
+        import ctypes as C
+        ctx = C.c_void_p(run.device_ctx())
+
+        gathered_bytes = [0]
+
+        def step():
+            run.find_superbubbles("b")
+            run.ploidy_estimation("b", LOWER, UPPER)
+            if world > 1:
+                # end-of-pass exchange over RCCL: counters + the ordered allele-frequency record slab
+                tt_ = run.times()
+                pfdist.all_gather_counters(tt_["allele"] + [tt_["tasks"]], dev)
+                slabs = pfdist.all_gather_slabs(run.last_allele_frequency(), dev)
+                gathered_bytes[0] = sum(int(x.size) for x in slabs)
+
+        for _ in range(args.warmup):
+            step()
+        L.pf_enable_timing(ctx, 1)
+        L.pf_reset_timing(ctx)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        phase = {}
+        for _ in range(args.steps):
+            step()
+            tt = run.times()
+            for key in ("bfs_device_s", "replay_s", "bubble_write_s", "cov_device_s", "tasks_s", "align_s", "sites_s", "format_s",
+                        "write_s", "find_total_s", "ploidy_total_s"):
+                phase[key] = phase.get(key, 0.0) + tt[key]
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        elapsed = time.perf_counter() - t0
+        tt = run.times()
+
+        # kernel times from HIP events recorded by the library on its launch stream
+        ktimes = {}
+        for i, name in enumerate(hipapi.KERNELS):
+            ms, n = C.c_double(), C.c_uint64()
+            L.pf_kernel_time(ctx, i, C.byref(ms), C.byref(n))
+            if n.value:
+                ktimes[name] = (ms.value, n.value)
+
+        allstats = pfdist.all_gather_counters([n_unitigs, tt["superbubbles"], tt["tasks"], tt["output_bytes"]] + tt["allele"] +
+                                              [int(elapsed * 1e6)], dev)
+        max_elapsed = allstats[:, -1].max() / 1e6
+        total_unitigs = int(allstats[:, 0].sum())
+
+        if rank == 0:
+            value = total_unitigs * args.steps / max_elapsed
+            kernels = {}
+            dom, dom_ms = None, -1.0
+            for name, (ms, n) in ktimes.items():
+                ab = algorithmic_bytes(name, tt)
+                avg_ms = ms / n
+                launches_per_step = n / args.steps
+                entry = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
+                         "ms_per_step": round(ms / args.steps, 3)}
+                if ab is not None:
+                    per_launch = ab / launches_per_step
+                    entry["algorithmic_bytes_per_launch"] = per_launch
+                    entry["achieved_GBps"] = round(per_launch / (avg_ms * 1e-3) / 1e9, 2)
+                kernels[name] = entry
+                if ms > dom_ms and ab is not None:
+                    dom, dom_ms = name, ms
+            roof = None
+            if dom:
+                e = kernels[dom]
+                roof = {"kernel": dom, "bound": "hbm", "achieved": e["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                        "frac": round(e["achieved_GBps"] / 8000.0, 5), "traffic": load_traffic(dom)}
+            cpu = None
+            if not args.no_cpu_baseline:
+                cpu = cpu_baseline(workdir, args.cpu_sample_unitigs, dev)
+            out = {
+                "metric": "unitigs/s through superbubble+SeqAlign (k=25, z=8)",
+                "value": round(value, 1), "unit": "unitigs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(max_elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+                "config": {"workload": "single-sample synthetic tetraploid graph, %d unitigs/GPU (config[1] = 1 M), k=25 z=8, "
+                                       "-l %d -u %d, M=2 D=-1 G=-3" % (n_unitigs, LOWER, UPPER),
+                           "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers,
+                           "partitioning": "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
+                                           "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0]},
+                "roofline": roof, "cpu_baseline": cpu,
+                "kernels": kernels,
+                "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},
+                "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"], "bubbles_called": tt["tasks"],
+                           "align_jobs": tt["align_jobs"], "site_strings": tt["site_strings"], "sites": tt["allele"],
+                           "output_bytes": tt["output_bytes"]},
+            }
+            if cpu:
+                out["speedup_vs_cpu_1core"] = round(value / world / cpu["value"], 2)
+            print(json.dumps(out), flush=True)
+        run.close()
+    finally:
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        if not args.keep:
+            shutil.rmtree(workdir, ignore_errors=True)
+
+
+def load_traffic(kernel: str):
+    """HBM bytes per launch of the dominant kernel from the committed PMC profile, if any."""
+    p = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(p) as f:
+            return json.load(f).get(kernel)
+    except (OSError, ValueError):
+        return None
+
+
+if __name__ == "__main__":
+    main()

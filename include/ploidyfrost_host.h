@@ -40,6 +40,9 @@ int pfh_ploidy_estimation(pfh_run *, const char *outpre, int lower, int upper);
 void pfh_get_times(const pfh_run *, pfh_times *out);
 /* the pf_ctx of include/ploidyfrost_hip.h that this run drives (timing, stream control) */
 void *pfh_device_ctx(pfh_run *);
+/* <outpre>_allele_frequency.txt of the last pfh_ploidy_estimation, in memory (valid until the next
+ * run): the per-rank record slab that a multi-GPU job all-gathers. */
+const char *pfh_last_allele_frequency(const pfh_run *, uint64_t *len);
 /* per-unitig state after pfh_find_superbubbles (MyUnitig flag byte, partner ids; 0 = NULL) */
 void pfh_state(const pfh_run *, uint8_t *flags, uint32_t *plus, uint32_t *minus);
 

@@ -1,6 +1,6 @@
 """Build helper: compile the gfx950 device library + C++ host layer in-tree.
-hipcc cross-compiles without a GPU.  (The CPU oracle is test infrastructure and is built by
-oracle/pyoracle.py, never from inside this package.)"""
+hipcc cross-compiles without a GPU.  (The CPU checker is test infrastructure; it has its own
+build script outside this package and is never built or loaded from here.)"""
 from __future__ import annotations
 
 import os

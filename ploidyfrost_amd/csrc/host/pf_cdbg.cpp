@@ -47,8 +47,9 @@ struct CDBG::Task {
     double cov_sum = 0;
 };
 
-CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db, int device)
-    : g_(graph), complex_size_(complexsize) {
+CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db, int device,
+           bool quiet)
+    : g_(graph), complex_size_(complexsize), quiet_(quiet) {
     sc_.match = m;
     sc_.mismatch = d;
     sc_.gap = g;
@@ -224,6 +225,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     clock_t c0 = clock();
     const uint32_t N = g_.n();
     if (!quiet_) printf("CDBG::findSuperBubble(): There are %u unitigs \n", N);
+    out_bytes_ = 0;
     std::fill(flags_.begin(), flags_.end(), 0);
     std::fill(plus_.begin(), plus_.end(), 0);
     std::fill(minus_.begin(), minus_.end(), 0);
@@ -364,6 +366,8 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     const uint32_t N = g_.n();
     const int k = g_.k;
     const uint32_t low = (uint32_t)lower, up = (uint32_t)upper;
+    times_.cov_device_s = times_.tasks_s = times_.align_s = times_.sites_s = times_.format_s = times_.write_s = 0;
+    times_.tasks = times_.align_jobs = times_.site_strings = 0;
 
     // C1 for every unitig in one launch (the reference calls readCov per use)
     auto t0 = clk::now();
@@ -707,6 +711,7 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     t0 = clk::now();
     static const char *kArity[4] = {"bi", "tri", "tetra", "penta"};
     if (write_file(outpre + "_allele_frequency.txt", allfre)) return status_;
+    last_allfre_.swap(allfre);
     if (write_file(outpre + "_alignseq.txt", s_var)) return status_;
     for (int a = 0; a < 4; ++a) {
         if (write_file(outpre + "_" + kArity[a] + "fre.txt", fre[a])) return status_;

@@ -37,7 +37,7 @@ struct PhaseTimes {
 class CDBG {
 public:
     CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db = "",
-         int device = 0);
+         int device = 0, bool quiet = false);
     ~CDBG();
     CDBG(const CDBG &) = delete;
     CDBG &operator=(const CDBG &) = delete;
@@ -65,6 +65,8 @@ public:
     const std::vector<uint32_t> &state_plus() const { return plus_; }
     const std::vector<uint32_t> &state_minus() const { return minus_; }
     uint64_t output_bytes() const { return out_bytes_; }
+    // text of <outpre>_allele_frequency.txt of the last run (the record slab a multi-GPU job gathers)
+    const std::string &last_allele_frequency() const { return last_allfre_; }
 
 private:
     struct Task;
@@ -92,6 +94,7 @@ private:
     std::vector<uint32_t> plus_, minus_;  // 0 = NULL, id = u + 1
 
     PhaseTimes times_;
+    std::string last_allfre_;
     uint64_t allele_[4] = {0, 0, 0, 0};
     uint64_t core_cov_ = 0, core_num_ = 0, n_super_bubble_ = 0, out_bytes_ = 0;
 };

@@ -29,8 +29,7 @@ pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex
     r->z = complex_size;
     r->z_M = match; r->z_D = mismatch; r->z_G = gap;
     t0 = clk::now();
-    r->cdbg = std::make_unique<pfh::CDBG>(r->graph, r->z, r->z_M, r->z_D, r->z_G, kmc_prefix ? kmc_prefix : "", device);
-    r->cdbg->set_quiet(true);
+    r->cdbg = std::make_unique<pfh::CDBG>(r->graph, r->z, r->z_M, r->z_D, r->z_G, kmc_prefix ? kmc_prefix : "", device, true);
     r->upload_s = std::chrono::duration<double>(clk::now() - t0).count();
     if (!r->cdbg->good()) { g_open_err = r->cdbg->error(); return nullptr; }
     return r.release();
@@ -58,6 +57,12 @@ void pfh_get_times(const pfh_run *r, pfh_times *o) {
     o->tasks = t.tasks; o->align_jobs = t.align_jobs; o->site_strings = t.site_strings; o->output_bytes = r->cdbg->output_bytes();
     for (int a = 0; a < 4; ++a) o->allele[a] = r->cdbg->allele_sites(a + 2);
     o->core_cov = r->cdbg->core_cov(); o->core_num = r->cdbg->core_num();
+}
+
+const char *pfh_last_allele_frequency(const pfh_run *r, uint64_t *len) {
+    const std::string &s = r->cdbg->last_allele_frequency();
+    if (len) *len = s.size();
+    return s.data();
 }
 
 void pfh_state(const pfh_run *r, uint8_t *flags, uint32_t *plus, uint32_t *minus) {

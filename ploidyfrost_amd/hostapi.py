@@ -23,7 +23,7 @@ class Times(C.Structure):
 
 _lib = None
 DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_unitig_id",
-                    "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state"]
+                    "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency"]
 
 
 def load_library() -> C.CDLL:
@@ -49,6 +49,8 @@ def load_library() -> C.CDLL:
     L.pfh_device_ctx.restype = vp
     L.pfh_device_ctx.argtypes = [vp]
     L.pfh_state.argtypes = [vp, vp, vp, vp]
+    L.pfh_last_allele_frequency.restype = C.c_void_p
+    L.pfh_last_allele_frequency.argtypes = [vp, C.POINTER(C.c_uint64)]
     _lib = L
     return L
 
@@ -99,6 +101,14 @@ class Run:
         d = {n: getattr(t, n) for n, _ in Times._fields_ if n != "allele"}
         d["allele"] = list(t.allele)
         return d
+
+    def last_allele_frequency(self) -> np.ndarray:
+        """bytes of <outpre>_allele_frequency.txt of the last run (copy)"""
+        n = C.c_uint64()
+        p = self.L.pfh_last_allele_frequency(self.h, C.byref(n))
+        if not n.value:
+            return np.zeros(0, dtype=np.uint8)
+        return np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).copy()
 
     def device_ctx(self) -> int:
         return self.L.pfh_device_ctx(self.h)

@@ -1,0 +1,102 @@
+"""Host-side logic that needs no GPU: input generators, the packed layout handed to
+pf_upload_graph, the KMC1 writer/reader pair, and the graph builder used by bench.py (checked
+against the Bifrost-built fixture graphs)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, golden_cases, load_case
+
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import pyoracle  # noqa: E402
+
+from ploidyfrost_amd import cdbg_build, hipapi, synth  # noqa: E402
+
+
+def rc(s: bytes) -> bytes:
+    return s.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1]
+
+
+def test_pack_unitigs_layout():
+    seqs = [b"ACGT" * 10 + b"A", b"T" * 33, b"G" * 25]
+    words, off, lens = hipapi.pack_unitigs(seqs)
+    assert list(lens) == [41, 33, 25] and list(off) == [0, 2, 4, 5]
+    for u, s in enumerate(seqs):
+        for j, ch in enumerate(s):
+            w = int(words[int(off[u]) + j // 32])
+            assert (w >> (62 - 2 * (j % 32))) & 3 == b"ACGT".index(ch)
+    # padding bits are zero
+    assert int(words[1]) & ((1 << (64 - 2 * 9)) - 1) == 0
+
+
+def test_kmc1_roundtrip_and_oracle_reader(tmp_path):
+    rng = np.random.default_rng(3)
+    k = 25
+    kmers = np.unique(rng.integers(0, 1 << 50, size=5000, dtype=np.uint64))
+    counts = rng.integers(1, 60000, size=len(kmers)).astype(np.uint32)
+    synth.write_kmc1(str(tmp_path / "db"), kmers, counts, k)
+    k2, c2, meta = synth.read_kmc1(str(tmp_path / "db"))
+    assert np.array_equal(kmers, k2) and np.array_equal(counts, c2) and meta["k"] == k and meta["both_strands"]
+    # the oracle's reader (a restatement of the reference's CheckKmer) finds every record
+    seq = "ACGT" * 10
+    (tmp_path / "g.gfa").write_text("H\tVN:Z:1.0\tKL:Z:25\tML:Z:17\nS\t1\t%s\n" % seq)
+    o = pyoracle.Oracle(str(tmp_path / "g.gfa"), str(tmp_path / "db"))
+    import ctypes as C
+    for x, c in list(zip(kmers.tolist(), counts.tolist()))[:300]:
+        s = bytes(b"ACGT"[(x >> (2 * (k - 1 - j))) & 3] for j in range(k))
+        got = C.c_uint32()
+        assert o.L.pfo_kmer_count(o.h, s, C.byref(got)) == 1 and got.value == c
+        assert o.L.pfo_kmer_count(o.h, rc(s), C.byref(got)) == 1 and got.value == c
+
+
+@pytest.mark.parametrize("case", ["dip20k", "tet60k", "k31_z16"])
+def test_count_database_covers_every_graph_kmer(case):
+    meta = load_case(case)
+    o = pyoracle.Oracle(meta["gfa"], meta["db"])
+    s, m, miss = o.unitig_cov()
+    assert not miss.any() and (m >= 1).all() and o.n_kmers == len(synth.read_kmc1(meta["db"])[0])
+
+
+@pytest.mark.parametrize("spec,k", [(synth.HapSpec(60000, 4, seed=5, gap_lo=15, gap_hi=215), 25),
+                                    (synth.HapSpec(30000, 6, seed=8, gap_lo=5, gap_hi=60), 25),
+                                    (synth.HapSpec(30000, 3, seed=9, gap_lo=10, gap_hi=200, max_ins=40), 31)])
+def test_graph_builder_is_a_valid_compacted_dbg(spec, k, tmp_path):
+    haps = synth.make_haplotypes(spec)
+    g = cdbg_build.build_cdbg(haps, k, "cpu")
+    units = cdbg_build.unitig_strings(g)
+    km, mult = synth.canonical_counts(haps, k)
+    assert np.array_equal(g["kmers"], km) and np.array_equal(g["mult"], mult)
+    # every canonical k-mer exactly once over all unitigs
+    seen = []
+    for s in units:
+        codes = np.frombuffer(s.translate(bytes.maketrans(b"ACGT", bytes([0, 1, 2, 3]))), dtype=np.uint8)
+        fw, rcv = synth.kmers_u64(codes, k)
+        seen.append(np.minimum(fw, rcv))
+    seen = np.sort(np.concatenate(seen))
+    assert np.array_equal(seen, km)
+    # maximal: through the oracle's adjacency no unitig end can be glued to a unique neighbour
+    gfa = str(tmp_path / "g.gfa")
+    cdbg_build.write_gfa(gfa, g)
+    o = pyoracle.Oracle(gfa, None)
+    succ, pred = o.adjacency()
+    NONE = 0xFFFFFFFF
+    outdeg = (succ != NONE).sum(axis=1)
+    indeg = (pred != NONE).sum(axis=1)
+    for ov in np.nonzero(outdeg == 1)[0]:
+        w = int(succ[ov][succ[ov] != NONE][0])
+        assert indeg[w] != 1 or (w >> 1) == (ov >> 1), "unitigs %d and %d should have been merged" % (ov >> 1, w >> 1)
+
+
+def test_shard_ranges_partition_in_order():
+    from ploidyfrost_amd import dist as pfdist
+    w = np.random.default_rng(1).integers(1, 100, size=1000)
+    for world in (1, 2, 3, 8):
+        for weights in (None, w):
+            cuts = [pfdist.shard_range(1000, r, world, weights) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == 1000
+            assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:]))
+        if world > 1:
+            loads = [w[a:b].sum() for a, b in [pfdist.shard_range(1000, r, world, w) for r in range(world)]]
+            assert max(loads) < 1.3 * w.sum() / world
