@@ -122,6 +122,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--unitigs", type=int, default=1_000_000, help="target unitigs per GPU (config[1] = 1 M)")
     ap.add_argument("--cpu-sample-unitigs", type=int, default=150_000)
+    ap.add_argument("--host-threads", type=int, default=0, help="host threads per rank (0 = min(32, cpus/ranks))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep", action="store_true")
     args = ap.parse_args()
@@ -145,6 +146,8 @@ def main():
         torch.cuda.empty_cache()
         t0 = time.time()
         run = hostapi.Run(gfa, db, z=Z, device=local_rank)
+        host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+        run.set_threads(host_threads)
         run.set_output_dir(os.path.join(workdir, "PloidyFrost_output"))
         run.set_unitig_id("b")
         log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, time.time() - t0, torch.cuda.get_device_name(local_rank)))
@@ -230,7 +233,7 @@ def main():
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": "single-sample synthetic tetraploid graph, %d unitigs/GPU (config[1] = 1 M), k=25 z=8, "
                                        "-l %d -u %d, M=2 D=-1 G=-3" % (n_unitigs, LOWER, UPPER),
-                           "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers,
+                           "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
                            "partitioning": "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
                                            "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0]},
                 "roofline": roof, "cpu_baseline": cpu,

@@ -161,6 +161,10 @@ int pf_align_batch(pf_ctx *, const char *text, uint64_t text_len, const pf_align
 int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t n_str, uint32_t low, uint32_t up,
                   uint64_t *sum, uint8_t *ok, uint8_t *miss);
 
+/* ---- pinned host memory for the exchange buffers (optional: pageable memory works, slower) ---- */
+int pf_host_alloc(pf_ctx *, size_t bytes, void **out);
+void pf_host_free(pf_ctx *, void *p);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 int pf_device_name(pf_ctx *, char *buf, size_t cap);
 uint64_t pf_table_capacity(const pf_ctx *);

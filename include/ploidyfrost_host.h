@@ -34,6 +34,8 @@ void pfh_close(pfh_run *);
 const char *pfh_last_error(const pfh_run *);
 void pfh_set_output_dir(pfh_run *, const char *dir); /* default ./PloidyFrost_output */
 void pfh_set_write_files(pfh_run *, int on);         /* 0: format everything, write nothing */
+void pfh_set_threads(pfh_run *, uint32_t threads);   /* host threads for the per-bubble phases (the reference's -t);
+                                                         output order is always the -t 1 one */
 int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);
 int pfh_ploidy_estimation(pfh_run *, const char *outpre, int lower, int upper);

@@ -4,11 +4,15 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <charconv>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <ctime>
 #include <set>
+#include <stdexcept>
+
+#include "pf_parallel.hpp"
 
 namespace pfh {
 
@@ -24,26 +28,29 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 inline bool plus_of(uint32_t ov) { return (ov & 1) == 0; }
 
 // `ostream << double` with default flags == printf("%g") (precision 6)
+// (std::to_chars with chars_format::general and a precision is specified as that printf conversion)
 inline void put_double(std::string &s, double x) {
-    char buf[40];
-    int n = snprintf(buf, sizeof buf, "%g", x);
-    s.append(buf, (size_t)n);
+    char buf[48];
+    auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::general, 6);
+    s.append(buf, (size_t)(r.ptr - buf));
 }
 inline void put_uint(std::string &s, uint64_t x) {
     char buf[24];
-    int n = snprintf(buf, sizeof buf, "%llu", (unsigned long long)x);
-    s.append(buf, (size_t)n);
+    auto r = std::to_chars(buf, buf + sizeof buf, x);
+    s.append(buf, (size_t)(r.ptr - buf));
 }
 }  // namespace
 
 // one bubble to call, in output order
 struct CDBG::Task {
     uint32_t u = 0;        // owner endpoint (unitig index)
-    uint32_t exit_ov = 0;
+    uint32_t entrance_ov = 0, exit_ov = 0;
     bool strict = false;
     double core_mean = 0;
     // strict: inner unitigs sorted by (mean coverage desc, reference string desc) and their means
-    std::vector<double> cov;
+    uint32_t inner[4] = {0, 0, 0, 0};
+    double cov[4] = {0, 0, 0, 0};
+    uint8_t n_inner = 0, n_cov = 0;
     double cov_sum = 0;
 };
 
@@ -77,7 +84,10 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");
 }
 
-CDBG::~CDBG() { pf_destroy(ctx_); }
+CDBG::~CDBG() {
+    aligner_.reset();  // releases pinned buffers before the context goes
+    pf_destroy(ctx_);
+}
 
 int CDBG::fail(int st, const std::string &msg) {
     status_ = st ? st : PF_ERR_ARG;
@@ -294,7 +304,7 @@ namespace {
 // sortSeq_simple (reference src/CDBG.cpp:482-551): the reference's own non-stable quicksort --
 // descending mean coverage, ties by descending reference string.  The exact swap sequence
 // matters for ties, so it is the same partition scheme.
-void sort_inner(const UnitigSet &g, std::vector<double> &cov, std::vector<uint32_t> &ov, int low, int high) {
+void sort_inner(const UnitigSet &g, double *cov, uint32_t *ov, int low, int high) {
     if (high <= low) return;
     auto gt = [&](int a, int b) {  // strcmp(ref(a), ref(b)) > 0
         return g.seq(ov[a] >> 1).compare(g.seq(ov[b] >> 1)) > 0;
@@ -357,7 +367,15 @@ std::string without_gaps(const std::string &s, size_t n) {
 }  // namespace
 
 // ---- ploidyEstimation (reference src/CDBG.cpp:1101-1705) -----------------------------------
-int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int &lower, const int &upper, const size_t &) {
+// The reference handles one bubble at a time; here the same work is laid out in phases so that
+// each phase is either one batched device call or an embarrassingly parallel loop over bubbles:
+//   scan     (sequential, light)  replay of the driver loop: which endpoint owns which bubble,
+//                                 in which order -- depends only on state bits, CSR, reference strings
+//   paths    (parallel)           path strings: oriented inner unitigs / two-stack DFS + quicksorts
+//   align    (GPU rounds)         SeqAlign::SequenceAlignment for all bubbles at once
+//   sites    (parallel + GPU)     per-site k-length strings -> one K-STRCOV launch
+//   format   (parallel)           text of the eleven files, concatenated in bubble order
+int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int &lower, const int &upper, const size_t &thr) {
     if (status_) return status_;
     const auto t_all = clk::now();
     clock_t c0 = clock();
@@ -366,8 +384,10 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     const uint32_t N = g_.n();
     const int k = g_.k;
     const uint32_t low = (uint32_t)lower, up = (uint32_t)upper;
+    const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
     times_.cov_device_s = times_.tasks_s = times_.align_s = times_.sites_s = times_.format_s = times_.write_s = 0;
     times_.tasks = times_.align_jobs = times_.site_strings = 0;
+    times_.align_build_s = times_.align_device_s = times_.align_post_s = times_.align_choose_s = times_.scan_s = 0;
 
     // C1 for every unitig in one launch (the reference calls readCov per use)
     auto t0 = clk::now();
@@ -396,18 +416,16 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
     core_cov_ = core_num_ = 0;
 
-    // Tasks are discovered by replaying the reference's driver loop (it only depends on the
-    // state bits, the CSR and the reference strings), then processed in chunks: path strings
-    // -> GPU alignment rounds -> site strings -> GPU coverage -> text.
-    const size_t CHUNK = 1u << 17;
+    const size_t CHUNK = 1u << 18;  // bubbles per batch
+    constexpr size_t PCH = 256;     // bubbles per parallel work item
     std::vector<Task> tasks;
     std::vector<std::vector<std::string>> paths;
     std::vector<Msa> msa;
     uint32_t scan_u = 0;
-    while (scan_u < N || !tasks.empty()) {
+    while (scan_u < N) {
+        // ---- scan ------------------------------------------------------------------------------
         t0 = clk::now();
         tasks.clear();
-        paths.clear();
         for (; scan_u < N && tasks.size() < CHUNK; ++scan_u) {
             const uint32_t u = scan_u;
             uint8_t &f = flags_[u];
@@ -439,21 +457,20 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                 }
                 Task t;
                 t.u = u;
+                t.entrance_ov = uo;
                 t.exit_ov = exit_ov;
                 t.strict = strict;
                 t.core_mean = mean_of(u);
-                std::vector<std::string> strs;
                 bool aligned = true;
                 if (strict) {
-                    std::vector<uint32_t> inner;
                     for (int b = 0; b < 4 && aligned; ++b) {
                         const uint32_t w = succ_row(uo)[b];
                         if (w == NONE) continue;
-                        inner.push_back(w);
+                        t.inner[t.n_inner++] = w;
                         if (missing(w >> 1)) return status_;
                         if (cov_min[w >> 1] > low && cov_min[w >> 1] < up) {
                             const double mcov = mean_of(w >> 1);
-                            t.cov.push_back(mcov);
+                            t.cov[t.n_cov++] = mcov;
                             t.cov_sum += mcov;
                         } else {
                             aligned = false;
@@ -465,247 +482,325 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                             const uint32_t w = pred_[(size_t)uo * 4 + b];
                             if (w != NONE && missing(w >> 1)) return status_;
                         }
-                        sort_inner(g_, t.cov, inner, 0, (int)t.cov.size() - 1);
-                        for (uint32_t w : inner) strs.push_back(g_.mapped(w));
+                        sort_inner(g_, t.cov, t.inner, 0, (int)t.n_cov - 1);
                     }
-                } else {
-                    // every s->t path, from the start of s's last k-mer through t's first k-mer
-                    // (two-stack DFS of src/CDBG.cpp:1364-1412)
-                    std::vector<uint32_t> major, minor;
-                    std::string walk;
-                    const uint32_t ulen = g_.len_km(u);
-                    minor.push_back(uo);
-                    while (!minor.empty()) {
-                        const uint32_t w = minor.back();
-                        minor.pop_back();
-                        major.push_back(w);
-                        const uint32_t wlen = g_.len_km(w >> 1);
-                        const size_t before = walk.size();
-                        g_.append_mapped(w, walk);
-                        if ((w >> 1) == eu) {
-                            const size_t total = walk.size();
-                            strs.push_back(walk.substr(ulen - 1, total - ulen + 1 - wlen + 1));
-                            walk.resize(before);
-                            major.pop_back();
-                            while (!major.empty() && !minor.empty()) {
-                                const uint32_t *r = succ_row(major.back());
-                                if (r[0] == minor.back() || r[1] == minor.back() || r[2] == minor.back() || r[3] == minor.back()) break;
-                                walk.resize(walk.size() - g_.len_km(major.back() >> 1));
-                                major.pop_back();
-                            }
-                        } else {
-                            walk.resize(before + wlen);  // keep only the first len characters
-                            const uint32_t *r = succ_row(w);
-                            for (int b = 0; b < 4; ++b)
-                                if (r[b] != NONE) minor.push_back(r[b]);
-                        }
-                    }
-                    sort_paths(strs, 0, (int)strs.size() - 1);
                 }
-                if (aligned) {
-                    tasks.push_back(std::move(t));
-                    paths.push_back(std::move(strs));
-                }
+                if (aligned) tasks.push_back(t);
                 // src/CDBG.cpp:1656-1679: both endpoint sides are done
                 f &= (uint8_t) ~(ps ? B_PLUS : B_MINUS);
                 flags_[eu] &= (uint8_t) ~(plus_of(exit_ov) ? B_MINUS : B_PLUS);
             }
         }
-        times_.tasks_s += since(t0);
-        if (tasks.empty()) break;
-        times_.tasks += tasks.size();
+        times_.scan_s += since(t0);
+        if (tasks.empty()) continue;
+        const size_t NT = tasks.size();
+        times_.tasks += NT;
 
-        // A1 on the device
+        // ---- paths -----------------------------------------------------------------------------
+        paths.assign(NT, {});
+        parallel_chunks(NT, PCH, T, [&](size_t, size_t tb, size_t te) {
+            std::vector<uint32_t> major, minor;
+            std::string walk;
+            for (size_t ti = tb; ti < te; ++ti) {
+                const Task &t = tasks[ti];
+                std::vector<std::string> &strs = paths[ti];
+                if (t.strict) {
+                    for (int q = 0; q < t.n_inner; ++q) strs.push_back(g_.mapped(t.inner[q]));
+                    continue;
+                }
+                // every s->t path, from the start of s's last k-mer through t's first k-mer
+                // (two-stack DFS of src/CDBG.cpp:1364-1412)
+                const uint32_t eu = t.exit_ov >> 1;
+                const uint32_t ulen = g_.len_km(t.u);
+                major.clear();
+                minor.clear();
+                walk.clear();
+                minor.push_back(t.entrance_ov);
+                while (!minor.empty()) {
+                    const uint32_t w = minor.back();
+                    minor.pop_back();
+                    major.push_back(w);
+                    const uint32_t wlen = g_.len_km(w >> 1);
+                    const size_t before = walk.size();
+                    g_.append_mapped(w, walk);
+                    if ((w >> 1) == eu) {
+                        const size_t total = walk.size();
+                        strs.push_back(walk.substr(ulen - 1, total - ulen + 1 - wlen + 1));
+                        walk.resize(before);
+                        major.pop_back();
+                        while (!major.empty() && !minor.empty()) {
+                            const uint32_t *r = succ_row(major.back());
+                            if (r[0] == minor.back() || r[1] == minor.back() || r[2] == minor.back() || r[3] == minor.back()) break;
+                            walk.resize(walk.size() - g_.len_km(major.back() >> 1));
+                            major.pop_back();
+                        }
+                    } else {
+                        walk.resize(before + wlen);  // keep only the first len characters
+                        const uint32_t *r = succ_row(w);
+                        for (int b = 0; b < 4; ++b)
+                            if (r[b] != NONE) minor.push_back(r[b]);
+                    }
+                }
+                sort_paths(strs, 0, (int)strs.size() - 1);
+            }
+        });
+        times_.tasks_s += since(t0);
+
+        // ---- align (A1 on the device) ----------------------------------------------------------
         t0 = clk::now();
         AlignStats as;
         std::string e;
-        st = align_bubbles(ctx_, sc_, paths, msa, &as, e);
+        if (!aligner_) aligner_.reset(new Aligner(ctx_));
+        st = aligner_->align(sc_, paths, msa, &as, e, T);
         if (st != PF_OK) return fail(st, "CDBG::PloidyEstimation(): alignment: " + e);
         times_.align_jobs += as.jobs;
         times_.align_s += since(t0);
+        times_.align_build_s += as.build_s;
+        times_.align_device_s += as.device_s;
+        times_.align_post_s += as.post_s;
+        times_.align_choose_s += as.choose_s;
 
-        // site strings of the branching bubbles (src/CDBG.cpp:1448-1600) -> one C2 batch
+        // ---- sites: strings of the branching bubbles (src/CDBG.cpp:1448-1600) -> one C2 batch ----
         t0 = clk::now();
-        struct SiteStr { uint32_t first, count; };  // index range into `strings` per (task, site, group)
-        std::vector<std::string> strings;
-        std::vector<std::vector<std::vector<SiteStr>>> site_groups(tasks.size());  // [task][site][group]
-        std::vector<std::vector<uint32_t>> var_sites(tasks.size());
-        for (size_t ti = 0; ti < tasks.size(); ++ti) {
-            const Msa &m = msa[ti];
-            if (m.rows.empty()) continue;
-            const size_t R = m.rows.size();
-            std::vector<uint32_t> &vs = var_sites[ti];
-            for (uint32_t c = 0; c < m.n_cols; ++c)
-                if (m.group_at(c, (uint32_t)R - 1) > 0) vs.push_back(c);
-            if (tasks[ti].strict) continue;
-            site_groups[ti].resize(vs.size());
-            uint32_t indel = 0;
-            for (size_t si = 0; si < vs.size(); ++si) {
-                const uint32_t site = vs[si];
-                uint16_t maxnum = 0;
-                for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
+        struct GroupRef { uint32_t first, count; };          // range of chunk-local string indices
+        struct TaskSites {
+            std::vector<uint32_t> cols;                       // var_site
+            std::vector<uint32_t> group_first;                // per site: index into `groups`
+            std::vector<GroupRef> groups;
+        };
+        std::vector<TaskSites> tsites(NT);
+        const size_t n_pch = n_chunks_of(NT, PCH);
+        std::vector<std::vector<std::string>> chunk_strings(n_pch);
+        std::vector<int> chunk_err(n_pch, 0);
+        parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
+            std::vector<std::string> &strings = chunk_strings[ci];
+            try {
+            for (size_t ti = tb; ti < te; ++ti) {
+                const Msa &m = msa[ti];
+                if (m.rows.empty()) continue;
+                const size_t R = m.rows.size();
+                TaskSites &ts = tsites[ti];
+                for (uint32_t c = 0; c < m.n_cols; ++c)
+                    if (m.group_at(c, (uint32_t)R - 1) > 0) ts.cols.push_back(c);
+                if (tasks[ti].strict) continue;
+                uint32_t indel = 0;
                 std::vector<std::string> kstr(R);
-                const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
-                if (is_indel) {
-                    std::vector<int> at(R, (int)site);
-                    for (;;) {
-                        char first = 0;
-                        bool differ = false;
-                        for (size_t p = 0; p < R; ++p) {
-                            while (m.rows[p].at((size_t)at[p]) == '-') at[p]++;
-                            const char ch = m.rows[p].at((size_t)at[p]);
-                            at[p]++;
-                            kstr[p].push_back(ch);
-                            if (p == 0) first = ch;
-                            else if (ch != first) differ = true;
+                std::vector<int> at(R);
+                for (size_t si = 0; si < ts.cols.size(); ++si) {
+                    const uint32_t site = ts.cols[si];
+                    uint16_t maxnum = 0;
+                    for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
+                    for (auto &x : kstr) x.clear();
+                    const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
+                    if (is_indel) {
+                        std::fill(at.begin(), at.end(), (int)site);
+                        for (;;) {
+                            char first = 0;
+                            bool differ = false;
+                            for (size_t p = 0; p < R; ++p) {
+                                while (m.rows[p].at((size_t)at[p]) == '-') at[p]++;
+                                const char ch = m.rows[p].at((size_t)at[p]);
+                                at[p]++;
+                                kstr[p].push_back(ch);
+                                if (p == 0) first = ch;
+                                else if (ch != first) differ = true;
+                            }
+                            if (differ) break;
                         }
-                        if (differ) break;
-                    }
-                    for (size_t p = 0; p < R; ++p) {
-                        const int n = (int)kstr[p].size();
-                        if (indel == 0) {
-                            kstr[p] = m.rows[p].substr((size_t)(site - k + n), (size_t)(k - n)) + kstr[p];
-                        } else {
-                            std::string tmp = without_gaps(m.rows[p], site);
-                            if (tmp.size() < (size_t)(k - n)) {
-                                kstr[p] = tmp + kstr[p];
-                                for (int x = at[p]; kstr[p].size() < (size_t)k; ++x) {
+                        for (size_t p = 0; p < R; ++p) {
+                            const int n = (int)kstr[p].size();
+                            if (indel == 0) {
+                                kstr[p] = m.rows[p].substr((size_t)(site - k + n), (size_t)(k - n)) + kstr[p];
+                            } else {
+                                std::string tmp = without_gaps(m.rows[p], site);
+                                if (tmp.size() < (size_t)(k - n)) {
+                                    kstr[p] = tmp + kstr[p];
+                                    for (int x = at[p]; kstr[p].size() < (size_t)k; ++x) {
+                                        const char ch = m.rows[p].at((size_t)x);
+                                        if (ch != '-') kstr[p].push_back(ch);
+                                    }
+                                } else {
+                                    kstr[p] = tmp.substr(tmp.size() - (size_t)k + n, (size_t)(k - n)) + kstr[p];
+                                }
+                            }
+                        }
+                        ++indel;
+                    } else if (indel > 0) {
+                        for (size_t p = 0; p < R; ++p) {
+                            std::string tmp = without_gaps(m.rows[p], site + 1);
+                            if (tmp.size() < (size_t)k) {
+                                kstr[p] = tmp;
+                                for (int x = (int)site + 1; kstr[p].size() < (size_t)k; ++x) {
                                     const char ch = m.rows[p].at((size_t)x);
                                     if (ch != '-') kstr[p].push_back(ch);
                                 }
                             } else {
-                                kstr[p] = tmp.substr(tmp.size() - (size_t)k + n, (size_t)(k - n)) + kstr[p];
+                                kstr[p] = tmp.substr(tmp.size() - (size_t)k, (size_t)k);
                             }
                         }
+                    } else {
+                        for (size_t p = 0; p < R; ++p) kstr[p] = m.rows[p].substr((size_t)(site - k + 1), (size_t)k);
                     }
-                    ++indel;
-                } else if (indel > 0) {
-                    for (size_t p = 0; p < R; ++p) {
-                        std::string tmp = without_gaps(m.rows[p], site + 1);
-                        if (tmp.size() < (size_t)k) {
-                            kstr[p] = tmp;
-                            for (int x = (int)site + 1; kstr[p].size() < (size_t)k; ++x) {
-                                const char ch = m.rows[p].at((size_t)x);
-                                if (ch != '-') kstr[p].push_back(ch);
-                            }
-                        } else {
-                            kstr[p] = tmp.substr(tmp.size() - (size_t)k, (size_t)k);
-                        }
+                    // distinct strings per allele group, in std::set order
+                    std::vector<std::set<std::string>> groups(maxnum);
+                    for (size_t p = 0; p < R; ++p) groups[m.group_at(site, (uint32_t)p) - 1].insert(kstr[p]);
+                    ts.group_first.push_back((uint32_t)ts.groups.size());
+                    for (auto &gs : groups) {
+                        ts.groups.push_back({(uint32_t)strings.size(), (uint32_t)gs.size()});
+                        for (auto &s : gs) strings.push_back(s);
                     }
-                } else {
-                    for (size_t p = 0; p < R; ++p) kstr[p] = m.rows[p].substr((size_t)(site - k + 1), (size_t)k);
                 }
-                // distinct strings per allele group, in std::set order
-                std::vector<std::set<std::string>> groups(maxnum);
-                for (size_t p = 0; p < R; ++p) groups[m.group_at(site, (uint32_t)p) - 1].insert(std::move(kstr[p]));
-                auto &sg = site_groups[ti][si];
-                for (auto &gs : groups) {
-                    sg.push_back({(uint32_t)strings.size(), (uint32_t)gs.size()});
-                    for (auto &s : gs) strings.push_back(s);
-                }
+                ts.group_first.push_back((uint32_t)ts.groups.size());
             }
-        }
-        std::vector<uint64_t> str_sum(strings.size());
-        std::vector<uint8_t> str_ok(strings.size()), str_miss(strings.size());
-        if (!strings.empty()) {
+            } catch (const std::out_of_range &) {
+                chunk_err[ci] = 1;  // the reference dies in std::string::substr here (malformed bubble)
+            }
+        });
+        for (int ce : chunk_err)
+            if (ce) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): site string outside an aligned row");
+        std::vector<uint64_t> chunk_base(n_pch + 1, 0);
+        for (size_t c = 0; c < n_pch; ++c) chunk_base[c + 1] = chunk_base[c] + chunk_strings[c].size();
+        const size_t n_strings = chunk_base[n_pch];
+        std::vector<uint64_t> str_sum(n_strings), str_len(n_strings);
+        std::vector<uint8_t> str_ok(n_strings), str_miss(n_strings);
+        if (n_strings) {
             std::string text;
-            std::vector<uint64_t> soff(strings.size() + 1, 0);
-            for (size_t i = 0; i < strings.size(); ++i) { soff[i] = text.size(); text += strings[i]; }
-            soff[strings.size()] = text.size();
-            st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)strings.size(), low, up, str_sum.data(), str_ok.data(),
+            std::vector<uint64_t> soff(n_strings + 1, 0);
+            size_t q = 0;
+            for (auto &cs : chunk_strings)
+                for (auto &sx : cs) { soff[q] = text.size(); str_len[q] = sx.size(); text += sx; ++q; }
+            soff[n_strings] = text.size();
+            st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)n_strings, low, up, str_sum.data(), str_ok.data(),
                                str_miss.data());
             if (st != PF_OK) return fail(st, std::string("CDBG::PloidyEstimation(): ") + pf_last_error(ctx_));
-            times_.site_strings += strings.size();
+            for (size_t i = 0; i < n_strings; ++i)
+                if (str_miss[i]) return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of a site string can not found .");
+            times_.site_strings += n_strings;
         }
         times_.sites_s += since(t0);
 
-        // text
+        // ---- format ------------------------------------------------------------------------------
         t0 = clk::now();
-        for (size_t ti = 0; ti < tasks.size(); ++ti) {
-            const Task &t = tasks[ti];
-            const Msa &m = msa[ti];
-            if (m.rows.empty()) continue;
-            const size_t R = m.rows.size();
-            ++var_count;
-            for (const std::string &row : m.rows) {
-                put_uint(s_var, var_count);
-                s_var += t.strict ? "\t1\t" : "\t0\t";
-                put_uint(s_var, t.u + 1);
-                s_var.push_back('\t');
-                put_uint(s_var, (t.exit_ov >> 1) + 1);
-                s_var.push_back('\t');
-                s_var += row;
-                s_var.push_back('\n');
-            }
-            core_cov_ += (uint64_t)t.core_mean;
-            core_num_++;
-            const std::vector<uint32_t> &vs = var_sites[ti];
-            const size_t usize = g_.size_bp(t.u), esize = g_.size_bp(t.exit_ov >> 1);
-            uint32_t indel = 0;
-            for (size_t i = 0; i < vs.size(); ++i) {
-                const uint32_t site = vs[i];
-                // distance to the neighbouring sites / unitig ends (src/CDBG.cpp:1279-1298)
-                uint32_t vd;
-                if (i == 0) {
-                    if (vs.size() != 1) vd = (uint32_t)std::min((size_t)(uint32_t)(vs[1] - vs[0] - 1), usize);
-                    else vd = (uint32_t)std::min(usize, esize);
-                } else if (i == vs.size() - 1) {
-                    vd = (uint32_t)std::min((size_t)(uint32_t)(vs[i] - vs[i - 1] - 1), esize);
-                } else {
-                    vd = std::min((uint32_t)(vs[i] - vs[i - 1] - 1), (uint32_t)(vs[i + 1] - vs[i] - 1));
-                }
-                uint16_t maxnum = 0;
-                for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
-                const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
-                std::vector<double> tc(maxnum, 0.0);
-                double denom;
-                if (t.strict) {
-                    for (size_t p = 0; p < R; ++p) tc[m.group_at(site, (uint32_t)p) - 1] += t.cov[p];
-                    denom = t.cov_sum;
-                    if (is_indel) ++indel;
-                } else {
-                    if (is_indel) ++indel;  // counted even when the site is dropped below
-                    const auto &sg = site_groups[ti][i];
-                    bool ok = true;
-                    double sum = 0;
-                    for (size_t gi = 0; gi < sg.size() && ok; ++gi) {
-                        for (uint32_t q = sg[gi].first; q < sg[gi].first + sg[gi].count; ++q) {
-                            if (str_miss[q]) return fail(PF_ERR_MISSING_KMER, "CDBG::readCov():" + strings[q] + " kmer can not found .");
-                            if (!str_ok[q]) { ok = false; break; }
-                            tc[gi] += (double)str_sum[q] / (double)(strings[q].size() - (size_t)k + 1);
-                        }
-                        sum += tc[gi];
-                    }
-                    if (!ok) continue;
-                    denom = sum;
-                }
-                std::string cov_info, fre_info;
-                for (double x : tc) {
-                    put_double(cov_info, x);
-                    cov_info.push_back('\t');
-                    put_double(fre_info, x / denom);
-                    fre_info.push_back('\n');
-                }
-                cov_info += t.strict ? "1\t" : "0\t";
-                if (is_indel) put_uint(cov_info, m.indel_len[indel - 1]);
-                else cov_info.push_back('0');
-                cov_info.push_back('\t');
-                put_uint(cov_info, var_count);
-                cov_info.push_back('\t');
-                put_uint(cov_info, vs.size());
-                cov_info.push_back('\t');
-                put_uint(cov_info, vd);
-                cov_info += "\t\n";
-                allfre += fre_info;
-                if (maxnum >= 2 && maxnum <= 5) {
-                    ++allele_[maxnum - 2];
-                    fre[maxnum - 2] += fre_info;
-                    cov[maxnum - 2] += cov_info;
-                }
-            }
+        std::vector<uint64_t> vc(NT);  // var_count of each bubble (1-based over non-empty alignments)
+        for (size_t ti = 0; ti < NT; ++ti) {
+            if (!msa[ti].rows.empty()) ++var_count;
+            vc[ti] = var_count;
         }
+        struct ChunkOut {
+            std::string s_var, allfre, fre[4], cov[4];
+            uint64_t allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
+        };
+        std::vector<ChunkOut> outs(n_pch);
+        parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
+            ChunkOut &o = outs[ci];
+            std::string cov_info, fre_info;
+            std::vector<double> tc;
+            for (size_t ti = tb; ti < te; ++ti) {
+                const Task &t = tasks[ti];
+                const Msa &m = msa[ti];
+                if (m.rows.empty()) continue;
+                const size_t R = m.rows.size();
+                const uint64_t my_vc = vc[ti];
+                for (const std::string &row : m.rows) {
+                    put_uint(o.s_var, my_vc);
+                    o.s_var += t.strict ? "\t1\t" : "\t0\t";
+                    put_uint(o.s_var, t.u + 1);
+                    o.s_var.push_back('\t');
+                    put_uint(o.s_var, (t.exit_ov >> 1) + 1);
+                    o.s_var.push_back('\t');
+                    o.s_var += row;
+                    o.s_var.push_back('\n');
+                }
+                o.core_cov += (uint64_t)t.core_mean;
+                o.core_num++;
+                const TaskSites &ts = tsites[ti];
+                const std::vector<uint32_t> &vs = ts.cols;
+                const size_t usize = g_.size_bp(t.u), esize = g_.size_bp(t.exit_ov >> 1);
+                uint32_t indel = 0;
+                for (size_t i = 0; i < vs.size(); ++i) {
+                    const uint32_t site = vs[i];
+                    // distance to the neighbouring sites / unitig ends (src/CDBG.cpp:1279-1298)
+                    uint32_t vd;
+                    if (i == 0) {
+                        if (vs.size() != 1) vd = (uint32_t)std::min((size_t)(uint32_t)(vs[1] - vs[0] - 1), usize);
+                        else vd = (uint32_t)std::min(usize, esize);
+                    } else if (i == vs.size() - 1) {
+                        vd = (uint32_t)std::min((size_t)(uint32_t)(vs[i] - vs[i - 1] - 1), esize);
+                    } else {
+                        vd = std::min((uint32_t)(vs[i] - vs[i - 1] - 1), (uint32_t)(vs[i + 1] - vs[i] - 1));
+                    }
+                    uint16_t maxnum = 0;
+                    for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
+                    const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
+                    tc.assign(maxnum, 0.0);
+                    double denom;
+                    if (is_indel) ++indel;  // counted even when the site is dropped below (src/CDBG.cpp:1526)
+                    if (t.strict) {
+                        for (size_t p = 0; p < R; ++p) tc[m.group_at(site, (uint32_t)p) - 1] += t.cov[p];
+                        denom = t.cov_sum;
+                    } else {
+                        const uint64_t base = chunk_base[ci];
+                        bool ok = true;
+                        double sum = 0;
+                        for (uint32_t gi = ts.group_first[i]; gi < ts.group_first[i + 1] && ok; ++gi) {
+                            const GroupRef &gr = ts.groups[gi];
+                            double &acc = tc[gi - ts.group_first[i]];
+                            for (uint64_t q = base + gr.first; q < base + gr.first + gr.count; ++q) {
+                                if (!str_ok[q]) { ok = false; break; }
+                                acc += (double)str_sum[q] / (double)(str_len[q] - (size_t)k + 1);
+                            }
+                            sum += acc;
+                        }
+                        if (!ok) continue;
+                        denom = sum;
+                    }
+                    cov_info.clear();
+                    fre_info.clear();
+                    for (double x : tc) {
+                        put_double(cov_info, x);
+                        cov_info.push_back('\t');
+                        put_double(fre_info, x / denom);
+                        fre_info.push_back('\n');
+                    }
+                    cov_info += t.strict ? "1\t" : "0\t";
+                    if (is_indel) put_uint(cov_info, m.indel_len[indel - 1]);
+                    else cov_info.push_back('0');
+                    cov_info.push_back('\t');
+                    put_uint(cov_info, my_vc);
+                    cov_info.push_back('\t');
+                    put_uint(cov_info, vs.size());
+                    cov_info.push_back('\t');
+                    put_uint(cov_info, vd);
+                    cov_info += "\t\n";
+                    o.allfre += fre_info;
+                    if (maxnum >= 2 && maxnum <= 5) {
+                        ++o.allele[maxnum - 2];
+                        o.fre[maxnum - 2] += fre_info;
+                        o.cov[maxnum - 2] += cov_info;
+                    }
+                }
+            }
+        });
+        for (ChunkOut &o : outs) {
+            s_var += o.s_var;
+            allfre += o.allfre;
+            for (int a = 0; a < 4; ++a) {
+                fre[a] += o.fre[a];
+                cov[a] += o.cov[a];
+                allele_[a] += o.allele[a];
+            }
+            core_cov_ += o.core_cov;
+            core_num_ += o.core_num;
+        }
+        // release the per-bubble strings in parallel (millions of small allocations)
+        parallel_chunks(NT, PCH, T, [&](size_t, size_t tb, size_t te) {
+            for (size_t ti = tb; ti < te; ++ti) {
+                std::vector<std::string>().swap(paths[ti]);
+                msa[ti] = Msa();
+                tsites[ti] = TaskSites();
+            }
+        });
         times_.format_s += since(t0);
-        tasks.clear();
     }
 
     t0 = clk::now();

@@ -18,6 +18,7 @@
 //   * output is always the deterministic `-t 1` ordering, whatever `threads` says.
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <vector>
 
@@ -31,6 +32,7 @@ struct PhaseTimes {
     double bfs_device_s = 0, replay_s = 0, bubble_write_s = 0;
     double cov_device_s = 0, tasks_s = 0, align_s = 0, sites_s = 0, format_s = 0, write_s = 0;
     double find_total_s = 0, ploidy_total_s = 0;
+    double scan_s = 0, align_build_s = 0, align_device_s = 0, align_post_s = 0, align_choose_s = 0;
     uint64_t candidates = 0, bfs_deferred = 0, bubbles_out = 0, tasks = 0, align_jobs = 0, site_strings = 0;
 };
 
@@ -54,6 +56,7 @@ public:
     // extras (not in the reference interface)
     void set_output_dir(const std::string &dir) { outdir_ = dir; }  // default "PloidyFrost_output"
     void set_quiet(bool q) { quiet_ = q; }
+    void set_threads(unsigned t) { threads_ = t; }                  // host threads; 0 = use the `thr` argument
     void set_write_files(bool w) { write_files_ = w; }              // bench: format but do not touch the disk
     pf_ctx *device() { return ctx_; }
     const PhaseTimes &times() const { return times_; }
@@ -88,11 +91,13 @@ private:
     std::string err_;
     bool quiet_ = false, write_files_ = true;
     bool both_strands_ = true;
+    unsigned threads_ = 0;
 
     std::vector<uint32_t> succ_, pred_;  // host copy of the CSR, [2N][4]
     std::vector<uint8_t> flags_;
     std::vector<uint32_t> plus_, minus_;  // 0 = NULL, id = u + 1
 
+    std::unique_ptr<Aligner> aligner_;
     PhaseTimes times_;
     std::string last_allfre_;
     uint64_t allele_[4] = {0, 0, 0, 0};

@@ -1,82 +1,125 @@
 #include "pf_host_align.hpp"
 
+#include "pf_parallel.hpp"
+
 #include <algorithm>
+#include <chrono>
 #include <climits>
+#include <cstdlib>
 #include <cstring>
 
 namespace pfh {
 
 namespace {
 
-struct Hit {
-    std::string a, b;
-    std::vector<uint32_t> gaps;  // rows of A where gaps were opened, traceback order
-    long score;
-    uint32_t n_pos, n_indel;
+// grow-only pinned host buffer (falls back to pageable memory if pinning fails)
+template <typename T>
+struct PinnedBuf {
+    pf_ctx *ctx = nullptr;
+    T *p = nullptr;
+    size_t cap = 0;
+    bool pinned = false;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf &) = delete;
+    PinnedBuf &operator=(const PinnedBuf &) = delete;
+    ~PinnedBuf() { release(); }
+    void release() {
+        if (!p) return;
+        if (pinned) pf_host_free(ctx, p); else free(p);
+        p = nullptr;
+        cap = 0;
+    }
+    void ensure(pf_ctx *c, size_t n) {  // contents are NOT preserved
+        if (n <= cap) return;
+        release();
+        ctx = c;
+        const size_t want = n + n / 4 + 64;
+        void *q = nullptr;
+        if (pf_host_alloc(c, want * sizeof(T), &q) == PF_OK) { p = (T *)q; pinned = true; }
+        else { p = (T *)malloc(want * sizeof(T)); pinned = false; }
+        cap = want;
+    }
+    T *data() { return p; }
+    const T *data() const { return p; }
+    size_t size() const { return cap; }
 };
 
-// ---- one device call --------------------------------------------------------------------
+// Raw output of pf_align_batch: kept alignments per job, read in place (no per-hit copies).
+struct RawHits {
+    PinnedBuf<uint64_t> first;
+    PinnedBuf<uint32_t> count;
+    PinnedBuf<pf_align_hit> hits;
+    PinnedBuf<char> text;
+    PinnedBuf<uint32_t> gaps;
+    uint32_t n(uint32_t job) const { return count.p[job]; }
+    const pf_align_hit &hit(uint32_t job, uint32_t h) const { return hits.p[first.p[job] + h]; }
+    std::string a(const pf_align_hit &x) const { return std::string(text.p + x.text_off, x.len); }
+    std::string b(const pf_align_hit &x) const { return std::string(text.p + x.text_off + x.len, x.len); }
+    const uint32_t *gap_ptr(const pf_align_hit &x) const { return gaps.p + x.gap_off; }
+};
+
 class JobBatch {
 public:
-    uint32_t add(const std::string &a, const std::string &b) {
+    void clear() { used_ = 0; jobs_.clear(); }
+    void reserve(pf_ctx *ctx, size_t jobs, size_t bytes) {
+        jobs_.reserve(jobs);
+        grow(ctx, bytes);
+    }
+    uint32_t add(pf_ctx *ctx, const std::string &a, const std::string &b) {
+        if (used_ + a.size() + b.size() > text_.cap) grow(ctx, (used_ + a.size() + b.size()) * 2);
         pf_align_job j;
-        j.a_off = text_.size();
+        j.a_off = used_;
         j.a_len = (uint32_t)a.size();
-        text_ += a;
-        j.b_off = text_.size();
+        memcpy(text_.p + used_, a.data(), a.size());
+        used_ += a.size();
+        j.b_off = used_;
         j.b_len = (uint32_t)b.size();
-        text_ += b;
+        memcpy(text_.p + used_, b.data(), b.size());
+        used_ += b.size();
         jobs_.push_back(j);
         return (uint32_t)jobs_.size() - 1;
     }
     size_t size() const { return jobs_.size(); }
 
-    int run(pf_ctx *ctx, const Scoring &sc, std::vector<std::vector<Hit>> &per_job, std::string &err) {
+    int run(pf_ctx *ctx, const Scoring &sc, RawHits &out, std::string &err) {
         const uint32_t n = (uint32_t)jobs_.size();
-        per_job.assign(n, {});
         if (n == 0) return PF_OK;
-        uint64_t hit_cap = (uint64_t)n * 2 + 64, text_cap = text_.size() * 3 + 4096, gap_cap = (uint64_t)n * 8 + 1024;
-        std::vector<uint64_t> first(n);
-        std::vector<uint32_t> count(n);
+        out.first.ensure(ctx, n);
+        out.count.ensure(ctx, n);
+        uint64_t hit_cap = (uint64_t)n * 2 + 64, text_cap = used_ * 3 + 4096, gap_cap = (uint64_t)n * 8 + 1024;
         for (;;) {
-            hits_.resize(hit_cap);
-            otext_.resize(text_cap);
-            ogaps_.resize(gap_cap);
+            out.hits.ensure(ctx, hit_cap);
+            out.text.ensure(ctx, text_cap);
+            out.gaps.ensure(ctx, gap_cap);
             uint64_t used[3] = {0, 0, 0};
-            int st = pf_align_batch(ctx, text_.data(), text_.size(), jobs_.data(), n, sc.match, sc.mismatch, sc.gap, first.data(),
-                                    count.data(), hits_.data(), hit_cap, otext_.data(), text_cap, ogaps_.data(), gap_cap, used);
-            if (st == PF_ERR_OVERFLOW && (used[0] > hit_cap || used[1] > text_cap || used[2] > gap_cap)) {
-                hit_cap = std::max(hit_cap, used[0] + used[0] / 8);
-                text_cap = std::max(text_cap, used[1] + used[1] / 8);
-                gap_cap = std::max(gap_cap, used[2] + used[2] / 8);
+            int st = pf_align_batch(ctx, text_.p, used_, jobs_.data(), n, sc.match, sc.mismatch, sc.gap, out.first.p, out.count.p,
+                                    out.hits.p, out.hits.cap, out.text.p, out.text.cap, out.gaps.p, out.gaps.cap, used);
+            if (st == PF_ERR_OVERFLOW && (used[0] > out.hits.cap || used[1] > out.text.cap || used[2] > out.gaps.cap)) {
+                hit_cap = std::max<uint64_t>(out.hits.cap, used[0] + used[0] / 8);
+                text_cap = std::max<uint64_t>(out.text.cap, used[1] + used[1] / 8);
+                gap_cap = std::max<uint64_t>(out.gaps.cap, used[2] + used[2] / 8);
                 continue;
             }
             if (st != PF_OK) { err = pf_last_error(ctx); return st; }
             break;
         }
-        for (uint32_t j = 0; j < n; ++j) {
-            auto &dst = per_job[j];
-            dst.resize(count[j]);
-            for (uint32_t h = 0; h < count[j]; ++h) {
-                const pf_align_hit &src = hits_[first[j] + h];
-                Hit &d = dst[h];
-                d.a.assign(otext_.data() + src.text_off, src.len);
-                d.b.assign(otext_.data() + src.text_off + src.len, src.len);
-                d.gaps.assign(ogaps_.begin() + src.gap_off, ogaps_.begin() + src.gap_off + src.n_gaps);
-                d.score = (long)src.score;
-                d.n_pos = src.n_pos;
-                d.n_indel = src.n_indel;
-            }
-        }
         return PF_OK;
     }
 
 private:
-    std::string text_;
+    void grow(pf_ctx *ctx, size_t bytes) {
+        if (bytes <= text_.cap) return;
+        PinnedBuf<char> bigger;
+        bigger.ensure(ctx, bytes);
+        if (used_) memcpy(bigger.p, text_.p, used_);
+        std::swap(text_.p, bigger.p);
+        std::swap(text_.cap, bigger.cap);
+        std::swap(text_.pinned, bigger.pinned);
+        std::swap(text_.ctx, bigger.ctx);
+    }
+    PinnedBuf<char> text_;
+    size_t used_ = 0;
     std::vector<pf_align_job> jobs_;
-    std::vector<pf_align_hit> hits_;
-    std::vector<char> otext_;
-    std::vector<uint32_t> ogaps_;
 };
 
 // ---- row scoring: SeqAlign::variantAnalyze (src/SeqAlign.cpp:237-305) --------------------
@@ -111,12 +154,12 @@ int rank_diff(const RowScore &l, const RowScore &r) {
 }
 
 // an older row with the gaps of a new pairwise alignment re-opened (src/SeqAlign.cpp:583-597)
-std::string reopen_gaps(const std::string &row, const std::vector<uint32_t> &gaps) {
-    if (gaps.empty()) return row;
+std::string reopen_gaps(const std::string &row, const uint32_t *gaps, uint32_t n_gaps) {
+    if (n_gaps == 0) return row;
     std::string out;
-    out.reserve(row.size() + gaps.size());
+    out.reserve(row.size() + n_gaps);
     uint32_t from = 0;
-    for (size_t s = gaps.size(); s-- > 0;) {
+    for (size_t s = n_gaps; s-- > 0;) {
         out.append(row, from, gaps[s] - from);
         out.push_back('-');
         from = gaps[s];
@@ -265,86 +308,139 @@ void choose_alignment(const std::vector<std::vector<std::string>> &cands, Msa &o
 
 }  // namespace
 
-int align_bubbles(pf_ctx *ctx, const Scoring &sc, const std::vector<std::vector<std::string>> &paths, std::vector<Msa> &out,
-                  AlignStats *stats, std::string &err) {
+struct Aligner::Impl {
+    RawHits raw;
+    JobBatch jb;
+};
+
+Aligner::Aligner(pf_ctx *ctx) : impl_(new Impl()), ctx_(ctx) {}
+Aligner::~Aligner() { delete impl_; }
+
+int Aligner::align(const Scoring &sc, const std::vector<std::vector<std::string>> &paths, std::vector<Msa> &out,
+                   AlignStats *stats, std::string &err, unsigned threads) {
+    pf_ctx *ctx = ctx_;
     const size_t T = paths.size();
-    out.assign(T, Msa());
+    constexpr size_t CH = 512;
+    if (out.size() != T) {
+        parallel_chunks(out.size(), CH, threads, [&](size_t, size_t b, size_t e) {
+            for (size_t t = b; t < e; ++t) out[t] = Msa();
+        });
+        out.resize(T);
+    }
     // kept[t] = the alignments (lists of rows) still in play for bubble t
     std::vector<std::vector<std::vector<std::string>>> kept(T);
+    std::vector<uint32_t> first_job(T, 0);
     size_t max_rows = 0;
-    std::vector<std::vector<Hit>> hits;
+    RawHits &raw = impl_->raw;
+    using clk = std::chrono::steady_clock;
+    auto lap = [](clk::time_point &t) { auto n = clk::now(); double d = std::chrono::duration<double>(n - t).count(); t = n; return d; };
+    AlignStats dummy;
+    AlignStats &S = stats ? *stats : dummy;
+    clk::time_point tp = clk::now();
     {
-        JobBatch jb;
+        JobBatch &jb = impl_->jb;
+        jb.clear();
+        size_t bytes = 0;
+        for (size_t t = 0; t < T; ++t)
+            if (paths[t].size() >= 2) bytes += paths[t][0].size() + paths[t][1].size();
+        jb.reserve(ctx, T, bytes);
         for (size_t t = 0; t < T; ++t) {
             max_rows = std::max(max_rows, paths[t].size());
-            if (paths[t].size() >= 2) jb.add(paths[t][0], paths[t][1]);
+            if (paths[t].size() >= 2) first_job[t] = jb.add(ctx, paths[t][0], paths[t][1]);
         }
-        if (stats) { stats->jobs += jb.size(); stats->rounds++; }
-        int st = jb.run(ctx, sc, hits, err);
+        S.jobs += jb.size();
+        S.rounds++;
+        S.build_s += lap(tp);
+        int st = jb.run(ctx, sc, raw, err);
         if (st != PF_OK) return st;
-        size_t j = 0;
-        for (size_t t = 0; t < T; ++t) {
-            if (paths[t].size() < 2) continue;
-            for (Hit &h : hits[j]) kept[t].push_back({std::move(h.a), std::move(h.b)});
-            if (stats) stats->hits += hits[j].size();
-            ++j;
-        }
+        S.device_s += lap(tp);
+        parallel_chunks(T, CH, threads, [&](size_t, size_t b, size_t e) {
+            for (size_t t = b; t < e; ++t) {
+                if (paths[t].size() < 2) continue;
+                const uint32_t j = first_job[t];
+                kept[t].reserve(raw.n(j));
+                for (uint32_t h = 0; h < raw.n(j); ++h) {
+                    const pf_align_hit &x = raw.hit(j, h);
+                    kept[t].push_back({raw.a(x), raw.b(x)});
+                }
+            }
+        });
+        S.post_s += lap(tp);
     }
     // progressive rounds: row i against row 0 of every kept alignment (src/SeqAlign.cpp:559-638)
-    std::vector<uint32_t> first_job(T);
     for (size_t i = 2; i < max_rows; ++i) {
-        JobBatch jb;
+        JobBatch &jb = impl_->jb;
+        jb.clear();
         for (size_t t = 0; t < T; ++t) {
             if (paths[t].size() <= i || kept[t].empty()) continue;
             first_job[t] = (uint32_t)jb.size();
-            for (const auto &rows : kept[t]) jb.add(rows[0], paths[t][i]);
+            for (const auto &rows : kept[t]) jb.add(ctx, rows[0], paths[t][i]);
         }
         if (jb.size() == 0) continue;
-        if (stats) { stats->jobs += jb.size(); stats->rounds++; }
-        int st = jb.run(ctx, sc, hits, err);
+        S.jobs += jb.size();
+        S.rounds++;
+        S.build_s += lap(tp);
+        int st = jb.run(ctx, sc, raw, err);
         if (st != PF_OK) return st;
-        for (size_t t = 0; t < T; ++t) {
-            if (paths[t].size() <= i || kept[t].empty()) continue;
-            std::vector<std::vector<std::string>> prev;
-            prev.swap(kept[t]);
-            int best_total = INT_MIN;
-            for (size_t kk = 0; kk < prev.size(); ++kk) {
-                std::vector<Hit> &cand = hits[first_job[t] + kk];
-                if (stats) stats->hits += cand.size();
-                std::vector<std::vector<std::string>> built(cand.size());
-                std::vector<int> alive(cand.size());
-                for (size_t c = 0; c < cand.size(); ++c) { alive[c] = (int)c; built[c].push_back(cand[c].a); }
-                uint32_t total = 0;  // int in the reference; sums of INT_MIN wrap
-                for (size_t j = 1; j < i; ++j) {
-                    RowScore top;
-                    top.score = INT_MIN;
-                    int best_j = INT_MIN;
-                    std::vector<int> next;
-                    for (int c : alive) {
-                        std::string re = reopen_gaps(prev[kk][j], cand[c].gaps);
-                        RowScore rs = score_pair(sc, re, cand[c].b);
-                        const int diff = rank_diff(rs, top);
-                        if (diff > 0) { top = rs; next.clear(); }
-                        if (diff >= 0) {
-                            best_j = (int)top.score;
-                            next.push_back(c);
-                            built[c].push_back(std::move(re));
+        S.device_s += lap(tp);
+        parallel_chunks(T, CH, threads, [&](size_t, size_t tb, size_t te) {
+            for (size_t t = tb; t < te; ++t) {
+                if (paths[t].size() <= i || kept[t].empty()) continue;
+                std::vector<std::vector<std::string>> prev;
+                prev.swap(kept[t]);
+                int best_total = INT_MIN;
+                for (size_t kk = 0; kk < prev.size(); ++kk) {
+                    const uint32_t job = first_job[t] + (uint32_t)kk;
+                    const uint32_t nc = raw.n(job);
+                    std::vector<std::vector<std::string>> built(nc);
+                    std::vector<std::string> cand_b(nc);
+                    std::vector<int> alive(nc);
+                    for (uint32_t c = 0; c < nc; ++c) {
+                        const pf_align_hit &x = raw.hit(job, c);
+                        alive[c] = (int)c;
+                        built[c].push_back(raw.a(x));
+                        cand_b[c] = raw.b(x);
+                    }
+                    uint32_t total = 0;  // int in the reference; sums of INT_MIN wrap
+                    for (size_t j = 1; j < i; ++j) {
+                        RowScore top;
+                        top.score = INT_MIN;
+                        int best_j = INT_MIN;
+                        std::vector<int> next;
+                        for (int c : alive) {
+                            const pf_align_hit &x = raw.hit(job, (uint32_t)c);
+                            std::string re = reopen_gaps(prev[kk][j], raw.gap_ptr(x), x.n_gaps);
+                            RowScore rs = score_pair(sc, re, cand_b[c]);
+                            const int diff = rank_diff(rs, top);
+                            if (diff > 0) { top = rs; next.clear(); }
+                            if (diff >= 0) {
+                                best_j = (int)top.score;
+                                next.push_back(c);
+                                built[c].push_back(std::move(re));
+                            }
                         }
+                        alive.swap(next);
+                        total += (uint32_t)best_j;
                     }
-                    alive.swap(next);
-                    total += (uint32_t)best_j;
+                    const int tk = (int)total;
+                    if (tk > best_total) { best_total = tk; kept[t].clear(); }
+                    if (tk >= best_total)
+                        for (int c : alive) {
+                            built[c].push_back(std::move(cand_b[c]));
+                            kept[t].push_back(std::move(built[c]));
+                        }
                 }
-                const int tk = (int)total;
-                if (tk > best_total) { best_total = tk; kept[t].clear(); }
-                if (tk >= best_total)
-                    for (int c : alive) {
-                        built[c].push_back(cand[c].b);
-                        kept[t].push_back(std::move(built[c]));
-                    }
             }
-        }
+        });
     }
-    for (size_t t = 0; t < T; ++t) choose_alignment(kept[t], out[t]);
+    S.post_s += lap(tp);
+    parallel_chunks(T, CH, threads, [&](size_t, size_t b, size_t e) {
+        for (size_t t = b; t < e; ++t) {
+            choose_alignment(kept[t], out[t]);
+            std::vector<std::vector<std::string>>().swap(kept[t]);  // free here, in parallel
+        }
+    });
+    S.choose_s += lap(tp);
     return PF_OK;
 }
 

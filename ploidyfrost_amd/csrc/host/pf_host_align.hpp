@@ -26,11 +26,25 @@ struct Msa {
 
 struct AlignStats {
     uint64_t jobs = 0, rounds = 0, hits = 0;
+    double build_s = 0, device_s = 0, post_s = 0, choose_s = 0;
 };
 
-// paths[t] = the (already sorted) path strings of bubble t, at least two each.
-// Returns PF_OK or the device status (message in err).
-int align_bubbles(pf_ctx *ctx, const Scoring &sc, const std::vector<std::vector<std::string>> &paths,
-                  std::vector<Msa> &out, AlignStats *stats, std::string &err);
+// Owns the pinned exchange buffers that are reused from call to call.
+class Aligner {
+public:
+    explicit Aligner(pf_ctx *ctx);
+    ~Aligner();
+    Aligner(const Aligner &) = delete;
+    Aligner &operator=(const Aligner &) = delete;
+    // paths[t] = the (already sorted) path strings of bubble t, at least two each.
+    // Returns PF_OK or the device status (message in err).
+    int align(const Scoring &sc, const std::vector<std::vector<std::string>> &paths, std::vector<Msa> &out, AlignStats *stats,
+              std::string &err, unsigned threads = 1);
+
+private:
+    struct Impl;
+    Impl *impl_;
+    pf_ctx *ctx_;
+};
 
 }  // namespace pfh

@@ -39,6 +39,7 @@ void pfh_close(pfh_run *r) { delete r; }
 const char *pfh_last_error(const pfh_run *r) { return r ? r->cdbg->error().c_str() : g_open_err.c_str(); }
 void pfh_set_output_dir(pfh_run *r, const char *dir) { r->cdbg->set_output_dir(dir); }
 void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0); }
+void pfh_set_threads(pfh_run *r, uint32_t threads) { r->cdbg->set_threads(threads); }
 int pfh_set_unitig_id(pfh_run *r, const char *outpre) { return r->cdbg->setUnitigId(outpre, "", 1); }
 int pfh_find_superbubbles(pfh_run *r, const char *outpre) { return r->cdbg->findSuperBubble_multithread_ptr(outpre, 1); }
 int pfh_ploidy_estimation(pfh_run *r, const char *outpre, int lower, int upper) {

@@ -124,6 +124,7 @@ int main(int argc, char **argv) {
         exit(EXIT_FAILURE);
     };
     if (!g.good()) die();
+    g.set_threads((unsigned)opt.nb_threads);
     if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
     if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
     if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) die();
@@ -137,6 +138,8 @@ int main(int argc, char **argv) {
                (unsigned long long)t.candidates, (unsigned long long)t.bfs_deferred, t.bfs_device_s, t.replay_s, t.cov_device_s,
                t.tasks_s, (unsigned long long)t.tasks, t.align_s, (unsigned long long)t.align_jobs, t.sites_s,
                (unsigned long long)t.site_strings, t.format_s, t.write_s);
+        printf("[host]   scan %.3fs | align: build %.3fs device-call %.3fs post %.3fs choose %.3fs\n", t.scan_s, t.align_build_s,
+               t.align_device_s, t.align_post_s, t.align_choose_s);
     }
     return 0;
 }

@@ -419,32 +419,33 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
     pf_align_job *d_jobs = const_cast<pf_align_job *>(jobs);
     const bool own_text = !is_dev(text), own_jobs = !is_dev(jobs);
     if (own_text) {
-        PF_HIP(hipMalloc(&d_text, text_len + 1));
+        d_text = (char *)ctx_ws(ctx, WS_ALN_TEXT, text_len + 1);
+        if (!d_text) return PF_ERR_HIP;
         PF_HIP(hipMemcpyAsync(d_text, text, text_len, hipMemcpyHostToDevice, st));
     }
     if (own_jobs) {
-        PF_HIP(hipMalloc(&d_jobs, (size_t)n_jobs * sizeof(pf_align_job)));
+        d_jobs = (pf_align_job *)ctx_ws(ctx, WS_ALN_JOBS, (size_t)n_jobs * sizeof(pf_align_job));
+        if (!d_jobs) return PF_ERR_HIP;
         PF_HIP(hipMemcpyAsync(d_jobs, hj.data(), (size_t)n_jobs * sizeof(pf_align_job), hipMemcpyHostToDevice, st));
     }
     const bool dev_out = is_dev(hits);
     AlnOut o;
-    unsigned long long *d_heads;
-    unsigned int *d_nretry;
-    uint32_t *d_retry, *d_idx;
-    PF_HIP(hipMalloc(&d_heads, 24));
-    PF_HIP(hipMalloc(&d_nretry, 4));
-    PF_HIP(hipMalloc(&d_retry, (size_t)n_jobs * 4));
-    PF_HIP(hipMalloc(&d_idx, (size_t)n_jobs * 4));
-    PF_HIP(hipMemsetAsync(d_heads, 0, 24, st));
-    PF_HIP(hipMemsetAsync(d_nretry, 0, 4, st));
+    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_ALN_SMALL, 64);
+    uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_ALN_RETRY, (size_t)n_jobs * 4);
+    uint32_t *d_idx = (uint32_t *)ctx_ws(ctx, WS_ALN_IDX, (size_t)n_jobs * 4);
+    if (!small || !d_retry || !d_idx) return PF_ERR_HIP;
+    unsigned long long *d_heads = reinterpret_cast<unsigned long long *>(small);
+    unsigned int *d_nretry = reinterpret_cast<unsigned int *>(small + 32);
+    PF_HIP(hipMemsetAsync(small, 0, 64, st));
     if (dev_out) {
         o.hit_first = hit_first; o.hit_count = hit_count; o.hits = hits; o.text = out_text; o.gaps = out_gaps;
     } else {
-        PF_HIP(hipMalloc(&o.hit_first, (size_t)n_jobs * 8));
-        PF_HIP(hipMalloc(&o.hit_count, (size_t)n_jobs * 4));
-        PF_HIP(hipMalloc(&o.hits, std::max<uint64_t>(hit_cap, 1) * sizeof(pf_align_hit)));
-        PF_HIP(hipMalloc(&o.text, std::max<uint64_t>(text_cap, 1)));
-        PF_HIP(hipMalloc(&o.gaps, std::max<uint64_t>(gap_cap, 1) * 4));
+        o.hit_first = (uint64_t *)ctx_ws(ctx, WS_ALN_OFIRST, (size_t)n_jobs * 8);
+        o.hit_count = (uint32_t *)ctx_ws(ctx, WS_ALN_OCOUNT, (size_t)n_jobs * 4);
+        o.hits = (pf_align_hit *)ctx_ws(ctx, WS_ALN_OHITS, std::max<uint64_t>(hit_cap, 1) * sizeof(pf_align_hit));
+        o.text = (char *)ctx_ws(ctx, WS_ALN_OTEXT, std::max<uint64_t>(text_cap, 1));
+        o.gaps = (uint32_t *)ctx_ws(ctx, WS_ALN_OGAPS, std::max<uint64_t>(gap_cap, 1) * 4);
+        if (!o.hit_first || !o.hit_count || !o.hits || !o.text || !o.gaps) return PF_ERR_HIP;
     }
     o.hit_cap = hit_cap; o.text_cap = text_cap; o.gap_cap = gap_cap;
     o.heads = d_heads; o.retry = d_retry; o.n_retry = d_nretry;
@@ -452,12 +453,10 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
     // per-wave staging for the LDS tiers
     const uint32_t ST_TEXT = 64 * 1024, ST_GAPS = 8 * 1024, ST_HITS = 512;
     const int max_waves = ctx->n_cu * 8;
-    char *st_text;
-    uint32_t *st_gaps;
-    pf_align_hit *st_hits;
-    PF_HIP(hipMalloc(&st_text, (size_t)max_waves * ST_TEXT));
-    PF_HIP(hipMalloc(&st_gaps, (size_t)max_waves * ST_GAPS * 4));
-    PF_HIP(hipMalloc(&st_hits, (size_t)max_waves * ST_HITS * sizeof(pf_align_hit)));
+    char *st_text = (char *)ctx_ws(ctx, WS_ALN_STTEXT, (size_t)max_waves * ST_TEXT);
+    uint32_t *st_gaps = (uint32_t *)ctx_ws(ctx, WS_ALN_STGAPS, (size_t)max_waves * ST_GAPS * 4);
+    pf_align_hit *st_hits = (pf_align_hit *)ctx_ws(ctx, WS_ALN_STHITS, (size_t)max_waves * ST_HITS * sizeof(pf_align_hit));
+    if (!st_text || !st_gaps || !st_hits) return PF_ERR_HIP;
 
     AlnParams p;
     p.text = d_text; p.jobs = d_jobs; p.idx = d_idx; p.M = match; p.D = mismatch; p.G = gap;
@@ -489,7 +488,8 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
         const uint32_t nc = (uint32_t)cls[3].size();
         const int grid = (int)std::min<uint32_t>(nc, 256);
         const uint64_t per = (max_need + 255) & ~255ull;
-        PF_HIP(hipMalloc(&work, per * grid));
+        work = (uint8_t *)ctx_ws(ctx, WS_ALN_WORK, per * grid);
+        if (!work) return PF_ERR_HIP;
         PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[3].data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
         p.idx = d_idx + idx_off;
         p.n = nc;
@@ -551,12 +551,7 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
                         break;
                     }
         }
-        hipFree(o.hit_first); hipFree(o.hit_count); hipFree(o.hits); hipFree(o.text); hipFree(o.gaps);
     }
-    if (own_text) hipFree(d_text);
-    if (own_jobs) hipFree(d_jobs);
-    hipFree(d_heads); hipFree(d_nretry); hipFree(d_retry); hipFree(d_idx);
-    hipFree(st_text); hipFree(st_gaps); hipFree(st_hits);
-    hipFree(work); hipFree(work2); hipFree(bt); hipFree(bg); hipFree(bh);
+    hipFree(work2); hipFree(bt); hipFree(bg); hipFree(bh);
     return status;
 }

@@ -46,6 +46,9 @@ struct pf_ctx {
 
     unsigned int bfs_deferred = 0;  // candidates of the last pf_bfs_candidates that needed the big tier
 
+    // grow-only device workspaces reused across calls (slot ids: enum pf::WsSlot)
+    std::vector<std::pair<void *, size_t>> ws;
+
     bool timing = false;
     std::vector<pf::TimedLaunch> launches;
 };
@@ -54,4 +57,11 @@ namespace pf {
 int ctx_begin(pf_ctx *ctx, int kernel);
 void ctx_end(pf_ctx *ctx);
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
+// device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
+void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
+enum WsSlot {
+    WS_ALN_TEXT = 0, WS_ALN_JOBS, WS_ALN_SMALL, WS_ALN_RETRY, WS_ALN_IDX, WS_ALN_OFIRST, WS_ALN_OCOUNT, WS_ALN_OHITS, WS_ALN_OTEXT,
+    WS_ALN_OGAPS, WS_ALN_STTEXT, WS_ALN_STGAPS, WS_ALN_STHITS, WS_ALN_WORK, WS_BFS_REC, WS_BFS_POOL, WS_BFS_SMALL, WS_BFS_DEF,
+    WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS, WS_COUNT_
+};
 }  // namespace pf

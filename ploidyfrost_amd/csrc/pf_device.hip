@@ -329,6 +329,19 @@ void ctx_end(pf_ctx *ctx) {
     hipEventRecord(ctx->launches.back().b, ctx->stream);
 }
 
+void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes) {
+    if (ctx->ws.size() < (size_t)WS_COUNT_) ctx->ws.resize(WS_COUNT_, {nullptr, 0});
+    auto &w = ctx->ws[slot];
+    if (w.second >= bytes && w.first) return w.first;
+    if (w.first) { hipFree(w.first); w.first = nullptr; w.second = 0; }
+    const size_t want = bytes + bytes / 4 + 256;
+    void *p = nullptr;
+    if (hipMalloc(&p, want) != hipSuccess) { ctx->err = "hipMalloc of a workspace failed"; return nullptr; }
+    w.first = p;
+    w.second = want;
+    return p;
+}
+
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu) {
     uint64_t want = (work_items + block - 1) / block;
     uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
@@ -409,6 +422,8 @@ void pf_destroy(pf_ctx *ctx) {
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
     free_graph(ctx);
     hipFree(ctx->d_tab);
+    hipFree(ctx->d_cov_sum); hipFree(ctx->d_cov_min); hipFree(ctx->d_cov_miss);
+    for (auto &w : ctx->ws) hipFree(w.first);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -454,6 +469,18 @@ int pf_kernel_time(pf_ctx *ctx, int kernel, double *total_ms, uint64_t *launches
     if (total_ms) *total_ms = tot;
     if (launches) *launches = n;
     return PF_OK;
+}
+
+int pf_host_alloc(pf_ctx *ctx, size_t bytes, void **out) {
+    if (!ctx || !out) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    return PF_OK;
+}
+
+void pf_host_free(pf_ctx *ctx, void *p) {
+    (void)ctx;
+    if (p) hipHostFree(p);
 }
 
 int pf_device_name(pf_ctx *ctx, char *buf, size_t cap) {
@@ -666,18 +693,14 @@ int pf_string_cov(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32
     PF_HIP(hipSetDevice(ctx->device));
     uint64_t total = 0;
     PF_HIP(hipMemcpy(&total, str_off + n_str, 8, hipMemcpyDefault));
-    char *dt;
-    uint64_t *doff;
-    bool own_t, own_o;
-    int rc = stage_in(ctx, text, (size_t)total, &dt, &own_t);
-    if (rc) return rc;
-    rc = stage_in(ctx, str_off, (size_t)n_str + 1, &doff, &own_o);
-    if (rc) return rc;
-    uint64_t *ds;
-    uint8_t *dk, *dm;
-    PF_HIP(hipMalloc(&ds, (size_t)n_str * 8));
-    PF_HIP(hipMalloc(&dk, n_str));
-    PF_HIP(hipMalloc(&dm, n_str));
+    char *dt = (char *)ctx_ws(ctx, WS_STR_TEXT, (size_t)total + 1);
+    uint64_t *doff = (uint64_t *)ctx_ws(ctx, WS_STR_OFF, ((size_t)n_str + 1) * 8);
+    uint64_t *ds = (uint64_t *)ctx_ws(ctx, WS_STR_SUM, (size_t)n_str * 8);
+    uint8_t *dk = (uint8_t *)ctx_ws(ctx, WS_STR_OK, n_str);
+    uint8_t *dm = (uint8_t *)ctx_ws(ctx, WS_STR_MISS, n_str);
+    if (!dt || !doff || !ds || !dk || !dm) return PF_ERR_HIP;
+    PF_HIP(hipMemcpyAsync(dt, text, (size_t)total, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(doff, str_off, ((size_t)n_str + 1) * 8, hipMemcpyDefault, ctx->stream));
     ctx_begin(ctx, PF_K_STRCOV);
     k_strcov<<<ctx_grid(ctx, n_str, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, dt, doff, n_str, low, up, ds, dk, dm);
     ctx_end(ctx);
@@ -685,9 +708,6 @@ int pf_string_cov(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32
     PF_HIP(hipMemcpyAsync(ok, dk, n_str, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(miss, dm, n_str, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
-    if (own_t) hipFree(dt);
-    if (own_o) hipFree(doff);
-    hipFree(ds); hipFree(dk); hipFree(dm);
     return PF_OK;
 }
 
@@ -722,17 +742,16 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
     pf_bfs_record *d_rec = records;
     uint32_t *d_pool = pool;
     if (!dev_out) {
-        PF_HIP(hipMalloc(&d_rec, n * sizeof(pf_bfs_record)));
-        PF_HIP(hipMalloc(&d_pool, (pool_cap ? pool_cap : 1) * 4));
+        d_rec = (pf_bfs_record *)ctx_ws(ctx, WS_BFS_REC, n * sizeof(pf_bfs_record));
+        d_pool = (uint32_t *)ctx_ws(ctx, WS_BFS_POOL, (pool_cap ? pool_cap : 1) * 4);
+        if (!d_rec || !d_pool) return PF_ERR_HIP;
     }
-    unsigned long long *d_head;
-    unsigned int *d_ndef;
-    uint32_t *d_def;
-    PF_HIP(hipMalloc(&d_head, 8));
-    PF_HIP(hipMalloc(&d_ndef, 4));
-    PF_HIP(hipMalloc(&d_def, n * 4));
-    PF_HIP(hipMemsetAsync(d_head, 0, 8, ctx->stream));
-    PF_HIP(hipMemsetAsync(d_ndef, 0, 4, ctx->stream));
+    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BFS_SMALL, 64);
+    uint32_t *d_def = (uint32_t *)ctx_ws(ctx, WS_BFS_DEF, n * 4);
+    if (!small || !d_def) return PF_ERR_HIP;
+    unsigned long long *d_head = reinterpret_cast<unsigned long long *>(small);
+    unsigned int *d_ndef = reinterpret_cast<unsigned int *>(small + 16);
+    PF_HIP(hipMemsetAsync(small, 0, 64, ctx->stream));
     BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef};
     const int grid = ctx_grid(ctx, n * 64, 256, 8);
     ctx_begin(ctx, PF_K_BFS);
@@ -774,12 +793,7 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
                     break;
                 }
         }
-        hipFree(d_rec);
-        hipFree(d_pool);
     }
-    hipFree(d_head);
-    hipFree(d_ndef);
-    hipFree(d_def);
     return status;
 }
 

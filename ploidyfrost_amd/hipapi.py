@@ -72,6 +72,8 @@ def load_library() -> C.CDLL:
         "pf_align_batch": (i, [vp, vp, u64, vp, u32, C.c_double, C.c_double, C.c_double, vp, vp, vp, u64, vp, u64, vp, u64,
                                C.POINTER(u64)]),
         "pf_string_cov": (i, [vp, vp, vp, u32, u32, u32, vp, vp, vp]),
+        "pf_host_alloc": (i, [vp, C.c_size_t, C.POINTER(vp)]),
+        "pf_host_free": (None, [vp, vp]),
         "pf_device_name": (i, [vp, C.c_char_p, C.c_size_t]),
         "pf_table_capacity": (u64, [vp]),
         "pf_num_kmers": (u64, [vp]),
@@ -87,7 +89,7 @@ def load_library() -> C.CDLL:
 DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
                     "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
-                    "pf_align_batch", "pf_string_cov", "pf_device_name", "pf_table_capacity", "pf_num_kmers"]
+                    "pf_align_batch", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers"]
 
 
 def pack_unitigs(seqs: list[bytes]):

@@ -69,6 +69,20 @@ def test_facade_full_run_and_no_disk_mode(tmp_path):
     assert run2.times()["output_bytes"] == t["output_bytes"] and not d2.exists()
 
 
+@pytest.mark.parametrize("case", ["hex30k", "k31_z16", "tet_frac"])
+def test_host_threads_do_not_change_a_byte(case, tmp_path):
+    """-t in the reference reorders rows; here threads only speed up the per-bubble phases"""
+    meta = load_case(case)
+    op = meta["opts"]
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    run.set_threads(7)
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    run.find_superbubbles("g")
+    run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+
+
 def test_missing_database_kmer_fails_like_the_reference(tmp_path):
     """reference: "kmer can not found" + exit(EXIT_FAILURE) (src/CDBG.cpp:52-56, 92-96)"""
     from ploidyfrost_amd import synth
