@@ -55,7 +55,7 @@ int pf_synchronize(pf_ctx *);
  * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
-    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_COUNT_
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -153,6 +153,52 @@ int pf_align_batch(pf_ctx *, const char *text, uint64_t text_len, const pf_align
                    double match, double mismatch, double gap, uint64_t *hit_first, uint32_t *hit_count,
                    pf_align_hit *hits, uint64_t hit_cap, char *out_text, uint64_t text_cap, uint32_t *out_gaps,
                    uint64_t gap_cap, uint64_t used[3]);
+
+/* ---- A1 complete: SeqAlign::SequenceAlignment (src/SeqAlign.cpp:550-640) -------------------- */
+/* One task = one bubble: its N >= 2 path strings in the order the host sorted them.  The device
+ * runs the whole multiple alignment for it on one wavefront: needlemanWunch + traceback of rows 0
+ * and 1, then rows 2..N-1 progressively against row 0 of every kept alignment (re-opening the new
+ * gaps in the older rows, re-scoring them as variantAnalyze does, keeping the best-ranked
+ * candidates), and finally the selection ladder of compareStrPair (src/SeqAlign.cpp:8-236).
+ * A path is either a slice of `text` (ASCII ACGT) or, with ov != PF_NONE, the whole oriented
+ * unitig ov decoded from the packed graph (mappedSequenceToString). */
+typedef struct pf_bubble_path {
+    uint64_t text_off;
+    uint32_t len;
+    uint32_t ov;
+} pf_bubble_path;
+
+typedef struct pf_bubble_task {
+    uint64_t path_first; /* index into paths */
+    uint32_t n_paths;
+    uint32_t pad_;
+} pf_bubble_task;
+
+typedef struct pf_bubble_site { /* one column with partition[col].back() > 0 */
+    uint32_t col;
+    uint8_t is_indel; /* col is in indel_pos (opens an indel) */
+    uint8_t maxnum;   /* number of allele groups */
+    uint16_t pad_;
+} pf_bubble_site;
+
+typedef struct pf_bubble_result {
+    uint64_t rows_off;  /* n_rows * n_cols chars, row-major, in out_text */
+    uint64_t site_off;  /* n_sites records in out_sites */
+    uint64_t group_off; /* n_sites * n_rows bytes in out_groups: 1-based allele group of every row */
+    uint64_t ilen_off;  /* n_indel_len u32 in out_ilen (indel_len_vec) */
+    uint32_t n_rows;    /* 0: no alignment survived (the reference skips the bubble, src/CDBG.cpp:1254) */
+    uint32_t n_cols;
+    uint32_t n_sites;
+    uint32_t n_indel_len;
+} pf_bubble_result;
+
+/* PF_ERR_OVERFLOW when a pool is too small: used[4] = {text bytes, sites, group bytes, ilen entries}
+ * tells the sizes needed.  [all pointers host|dev] */
+int pf_align_bubbles(pf_ctx *, const char *text, uint64_t text_len, const pf_bubble_path *paths, uint64_t n_paths,
+                     const pf_bubble_task *tasks, uint32_t n_tasks, double match, double mismatch, double gap,
+                     pf_bubble_result *results, char *out_text, uint64_t text_cap, pf_bubble_site *out_sites,
+                     uint64_t site_cap, uint8_t *out_groups, uint64_t group_cap, uint32_t *out_ilen, uint64_t ilen_cap,
+                     uint64_t used[4]);
 
 /* ---- C2: CDBG::readCov(const string&, low, up) (src/CDBG.cpp:29-60) ---------------------- */
 /* strings are ASCII ACGT, string i = text[str_off[i] .. str_off[i+1]).  sum[i] = sum of

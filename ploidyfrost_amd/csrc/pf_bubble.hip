@@ -1,0 +1,809 @@
+// K-BUBBLE: the whole of SeqAlign::SequenceAlignment (reference src/SeqAlign.cpp:550-640) for one
+// bubble on one wavefront.
+//
+//   round 0     needlemanWunch + traceback of paths 0 and 1 (pf_align_dev.hpp) -> kept alignments
+//   round i>=2  for every kept alignment: NW + traceback of its row 0 against path i; for every
+//               older row j the new gaps are re-opened (src/SeqAlign.cpp:583-597), the row is
+//               re-scored against the new row as variantAnalyze does (:237-305) and only the
+//               best-ranked candidates (AlignUnit::operator-, SeqAlign.hpp:43-67) stay alive; the
+//               per-alignment totals decide which groups of candidates survive (:619-636)
+//   choose      compareStrPair (:8-236): column classification of every surviving alignment and
+//               the seven-step selection ladder; the winner's rows, variant columns, allele groups
+//               and indel lengths are published
+//
+// Work split inside the wave: the sequential decisions (candidate lists, ladder) are executed
+// redundantly by all 64 lanes on wave-uniform values; everything that touches characters is
+// lane-parallel over columns -- path decoding from the 2-bit graph, gap re-opening (each lane finds
+// its column's source by counting gaps), row scoring (per-column score / new-indel flags, wave
+// reductions; a lane-0 chain only for non-integral scores, where the reference's `long += double`
+// truncates at every column), column classification, row copies.  Alignments live in two per-wave
+// arenas in global memory (ping-pong between rounds); the NW matrices are in LDS as in K-ALN.
+// No MFMA: byte compares and integer reductions.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pf_align_dev.hpp"
+#include "pf_ctx.hpp"
+#include "pf_device_common.hpp"
+#include "ploidyfrost_hip.h"
+
+using namespace pf;
+
+#define PF_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return PF_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+struct MsaRef {
+    uint32_t off;   // rows * len chars, row-major, in the arena
+    uint32_t len;
+    uint32_t rows;
+};
+
+struct BubCaps {  // per-wave scratch capacities (all multiples of 8)
+    uint32_t st_text, st_gaps, st_hits;  // traceback staging
+    uint32_t pbuf;                       // decoded path strings
+    uint32_t arena;                      // each of the two alignment arenas
+    uint32_t list;                       // alignments per list
+    uint32_t row;                        // longest aligned row
+};
+
+__host__ __device__ inline uint64_t bub_scratch_bytes(const BubCaps &c) {
+    return (uint64_t)c.st_text + 4ull * c.st_gaps + sizeof(pf_align_hit) * (uint64_t)c.st_hits + c.pbuf + 2ull * c.arena +
+           2ull * sizeof(MsaRef) * c.list + 2ull * 2 * c.st_hits + 2ull * c.row + 3ull * 4 * c.row + 64;
+}
+
+struct BubParams {
+    const char *text;
+    const pf_bubble_path *paths;
+    const pf_bubble_task *tasks;
+    const uint32_t *idx;
+    uint32_t n;
+    double M, D, G;
+    int integral;
+    const uint64_t *seq;
+    const uint64_t *off;
+    const uint32_t *len;
+    uint32_t n_unitigs;
+    uint8_t *scratch;
+    uint64_t scratch_per_wave;
+    BubCaps caps;
+    uint8_t *work;          // NW working storage when not in LDS
+    uint64_t work_per_wave;
+    uint32_t work_bytes;    // bytes available per wave for one NW job (LDS or global)
+    int final_tier;
+};
+
+struct BubOut {
+    pf_bubble_result *res;
+    char *text;
+    uint64_t text_cap;
+    pf_bubble_site *sites;
+    uint64_t site_cap;
+    uint8_t *groups;
+    uint64_t group_cap;
+    uint32_t *ilen;
+    uint64_t ilen_cap;
+    unsigned long long *heads;  // [0] text, [1] sites, [2] groups, [3] ilen
+    uint32_t *retry;
+    unsigned int *n_retry;
+};
+
+struct RowScore {
+    long long score;
+    uint32_t n_pos, indel;
+};
+
+__device__ inline long long bcast_i64(long long v) {
+    const uint32_t lo = __shfl((uint32_t)v, 0, WAVE), hi = __shfl((uint32_t)((unsigned long long)v >> 32), 0, WAVE);
+    return (long long)(((unsigned long long)hi << 32) | lo);
+}
+
+// AlignUnit::operator- truncated to int (src/SeqAlign.hpp:43-67)
+__device__ inline int rank_diff(const RowScore &l, const RowScore &r) {
+    long long d;
+    if (l.score != r.score) d = l.score > r.score ? 1 : -1;
+    else if (l.n_pos != r.n_pos) d = (long long)r.n_pos - (long long)l.n_pos;
+    else d = (long long)r.indel - (long long)l.indel;
+    return (int)d;
+}
+
+// column p of `row` after re-opening gaps (gaps in traceback order = descending; src/SeqAlign.cpp:583-597)
+__device__ inline char regap_char(const char *row, const uint32_t *gaps, uint32_t ng, uint32_t p) {
+    uint32_t c = 0;
+    while (c < ng && gaps[ng - 1 - c] + c < p) ++c;
+    if (c < ng && gaps[ng - 1 - c] + c == p) return '-';
+    return row[p - c];
+}
+
+// variantAnalyze (src/SeqAlign.cpp:237-305) of two equal-length rows; wave-uniform result
+__device__ inline RowScore score_rows(const char *x, const char *y, uint32_t L, double M, double D, double G, int integral) {
+    const int lane = lane_id();
+    long long isum = 0;
+    uint32_t npos = 0, nind = 0;
+    for (uint32_t base = 0; base < L; base += WAVE) {
+        const uint32_t p = base + lane;
+        if (p < L) {
+            const char a = x[p], b = y[p];
+            if (integral) isum += (long long)((a == '-' || b == '-') ? G : (a == b ? M : D));
+            if (a != b) {
+                const int side = a == '-' ? 1 : (b == '-' ? 2 : 3);
+                if (side == 3) {
+                    npos++;
+                } else {
+                    int prev_run = 0;  // gap side of the previous column, 0 if it was equal or a snp
+                    if (p > 0) {
+                        const char pa = x[p - 1], pb = y[p - 1];
+                        if (pa != pb) prev_run = pa == '-' ? 1 : (pb == '-' ? 2 : 0);
+                    }
+                    if (prev_run != side) { npos++; nind++; }
+                }
+            }
+        }
+    }
+    RowScore r;
+    r.n_pos = (uint32_t)wave_sum_u64(npos);
+    r.indel = (uint32_t)wave_sum_u64(nind);
+    r.n_pos = __shfl(r.n_pos, 0, WAVE);
+    r.indel = __shfl(r.indel, 0, WAVE);
+    if (integral) {
+        r.score = bcast_i64((long long)wave_sum_u64((uint64_t)isum));
+    } else {
+        long long sc = 0;
+        if (lane == 0)
+            for (uint32_t p = 0; p < L; ++p) {
+                const char a = x[p], b = y[p];
+                const double s = (a == '-' || b == '-') ? G : (a == b ? M : D);
+                sc = (long long)((double)sc + s);
+            }
+        r.score = bcast_i64(sc);
+    }
+    return r;
+}
+
+// strcmp(a, b) > 0 for strings of length la / lb without NULs; wave-uniform
+__device__ inline bool str_greater(const char *a, uint32_t la, const char *b, uint32_t lb) {
+    const int lane = lane_id();
+    const uint32_t L = la < lb ? la : lb;
+    for (uint32_t base = 0; base < L; base += WAVE) {
+        const uint32_t p = base + lane;
+        const bool diff = p < L && a[p] != b[p];
+        const unsigned long long m = __ballot(diff);
+        if (m) {
+            const uint32_t q = base + (uint32_t)__ffsll((long long)m) - 1;
+            return (unsigned char)a[q] > (unsigned char)b[q];
+        }
+    }
+    return la > lb;
+}
+
+// compute_dis (src/SeqAlign.cpp:10-38) over the merge of two ascending lists (either may be empty)
+__device__ inline uint64_t spread_merged(const uint32_t *a, uint32_t na, const uint32_t *b, uint32_t nb, uint64_t L) {
+    const uint32_t n = na + nb;
+    if (n == 0) return 0;
+    uint32_t ia = 0, ib = 0;
+    auto next = [&]() -> uint32_t {
+        // std::merge takes from the second range only when it is strictly smaller
+        if (ib < nb && (ia >= na || b[ib] < a[ia])) return b[ib++];
+        return a[ia++];
+    };
+    const uint32_t v0 = next();
+    if (n == 1) {
+        const int left = (int)v0, right = (int)(L - v0) - 1;
+        return left > right ? (uint64_t)(left + 1) : (uint64_t)right;
+    }
+    uint64_t d = v0;
+    uint32_t prev = v0;
+    for (uint32_t i = 1; i < n; ++i) {
+        const uint32_t v = next();
+        const int gap = (int)(v - prev - 1);
+        d = (uint64_t)(gap < (int)d ? gap : (int)d);
+        prev = v;
+    }
+    const uint64_t tail = L - prev - 1;
+    return d < tail ? d : tail;
+}
+
+struct Metrics {
+    int snp, indel;  // the reference's 8-bit counters, widened after wrap
+    uint32_t n_snp_pos, n_indel_pos, n_indel_len;
+    int first_site, last_site;  // of the merged list (0 when empty, as the reference's UB reads do here)
+    bool any_site;
+};
+
+// Column classification of one alignment (src/SeqAlign.cpp:56-157): per-column pass lane-parallel,
+// list building sequential over one flag byte per column.  Fills snp_pos / indel_pos / indel_len.
+__device__ inline Metrics classify(const char *rows, uint32_t R, uint32_t L, uint8_t *colinfo, uint32_t *snp_pos,
+                                   uint32_t *indel_pos, uint32_t *indel_len) {
+    const int lane = lane_id();
+    for (uint32_t base = 0; base < L; base += WAVE) {
+        const uint32_t j = base + lane;
+        if (j < L) {
+            char seen[5];
+            int n_seen = 0;
+            bool has_gap = false, same_status = j > 0;
+            for (uint32_t r = 0; r < R; ++r) {
+                const char c = rows[(size_t)r * L + j];
+                int q = 0;
+                while (q < n_seen && seen[q] != c) ++q;
+                if (q == n_seen && n_seen < 5) seen[n_seen++] = c;
+                has_gap |= c == '-';
+                if (j > 0 && ((c == '-') != (rows[(size_t)r * L + j - 1] == '-'))) same_status = false;
+            }
+            uint8_t t = 0;
+            if (n_seen > 1) t = has_gap ? 2 : 1;
+            colinfo[j] = (uint8_t)(t | (same_status ? 4 : 0) | (n_seen > 2 ? 8 : 0));
+        }
+    }
+    aln_sync();
+    Metrics m;
+    uint8_t snp = 0, indel = 0;
+    uint32_t ns = 0, ni = 0, nl = 0;
+    bool open = false;
+    for (uint32_t j = 0; j < L; ++j) {
+        const uint8_t ci = colinfo[j];
+        const uint8_t t = ci & 3;
+        uint8_t lab = 0;  // bit 4: labelled column, bit 5: opens an indel
+        if (t != 2) {
+            if (open) { if (lane == 0) indel_len[nl] = j - indel_pos[(uint8_t)(indel - 1)]; nl++; open = false; }
+            if (t == 1) { if (lane == 0) snp_pos[ns] = j; ns++; snp++; lab = 16; }
+        } else {
+            const bool same_run = open && (ci & 4);
+            if (open && !same_run) { if (lane == 0) indel_len[nl] = j - indel_pos[(uint8_t)(indel - 1)]; nl++; }
+            if (!same_run) {
+                ++indel;
+                if (lane == 0) indel_pos[ni] = j;
+                ni++;
+                open = true;
+                lab = 16 | 32;  // (indel_pos is written and read back by lane 0 only)
+            } else if (ci & 8) {
+                lab = 16;
+            }
+        }
+        if (lane == 0 && lab) colinfo[j] = (uint8_t)(ci | lab);
+    }
+    aln_sync();
+    m.snp = snp;
+    m.indel = indel;
+    m.n_snp_pos = ns;
+    m.n_indel_pos = ni;
+    m.n_indel_len = nl;
+    m.any_site = ns + ni > 0;
+    int f = 0, l = 0;
+    if (ns + ni) {
+        const uint32_t s0 = ns ? snp_pos[0] : 0xFFFFFFFFu, i0 = ni ? indel_pos[0] : 0xFFFFFFFFu;
+        f = (int)(s0 < i0 ? s0 : i0);
+        const uint32_t s1 = ns ? snp_pos[ns - 1] : 0, i1 = ni ? indel_pos[ni - 1] : 0;
+        l = (int)(s1 > i1 ? s1 : i1);
+    }
+    m.first_site = f;
+    m.last_site = l;
+    return m;
+}
+
+// returns 0 ok, 1 = a capacity of this tier was exceeded (rerun in the next tier)
+template <bool LDS>
+__device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, uint8_t *nw_base, uint8_t *scr) {
+    const int lane = lane_id();
+    const BubCaps &C = p.caps;
+    // carve the per-wave scratch
+    AlnScratch st;
+    st.text = reinterpret_cast<char *>(scr);
+    st.gaps = reinterpret_cast<uint32_t *>(scr + C.st_text);
+    st.hits = reinterpret_cast<pf_align_hit *>(scr + C.st_text + 4ull * C.st_gaps);
+    st.text_cap = C.st_text;
+    st.gap_cap = C.st_gaps;
+    st.hit_cap = C.st_hits;
+    uint8_t *q = scr + C.st_text + 4ull * C.st_gaps + sizeof(pf_align_hit) * (uint64_t)C.st_hits;
+    char *pbuf = reinterpret_cast<char *>(q);
+    q += C.pbuf;
+    char *arena[2] = {reinterpret_cast<char *>(q), reinterpret_cast<char *>(q + C.arena)};
+    q += 2ull * C.arena;
+    MsaRef *list[2] = {reinterpret_cast<MsaRef *>(q), reinterpret_cast<MsaRef *>(q + sizeof(MsaRef) * C.list)};
+    q += 2ull * sizeof(MsaRef) * C.list;
+    uint16_t *alive[2] = {reinterpret_cast<uint16_t *>(q), reinterpret_cast<uint16_t *>(q + 2ull * C.st_hits)};
+    q += 2ull * 2 * C.st_hits;
+    char *tmp_row = reinterpret_cast<char *>(q);
+    q += C.row;
+    uint8_t *colinfo = q;
+    q += C.row;
+    uint32_t *snp_pos = reinterpret_cast<uint32_t *>(q);
+    uint32_t *indel_pos = snp_pos + C.row;
+    uint32_t *indel_len = indel_pos + C.row;
+
+    const pf_bubble_task tk = p.tasks[job];
+    const uint32_t N = tk.n_paths;
+    const pf_bubble_path *paths = p.paths + tk.path_first;
+
+    // ---- path strings into pbuf (decode oriented unitigs from the 2-bit graph) ------------------
+    uint32_t poff_total = 0;
+    for (uint32_t i = 0; i < N; ++i) poff_total += paths[i].len;
+    if (poff_total > C.pbuf) return 1;
+    {
+        uint32_t at = 0;
+        for (uint32_t i = 0; i < N; ++i) {
+            const pf_bubble_path pp = paths[i];
+            if (pp.ov == PF_NONE) {
+                const char *src = p.text + pp.text_off;
+                for (uint32_t t = lane; t < pp.len; t += WAVE) pbuf[at + t] = src[t];
+            } else {
+                const uint32_t u = pp.ov >> 1;
+                const uint64_t *w = p.seq + p.off[u];
+                const bool rev = (pp.ov & 1) != 0;
+                for (uint32_t t = lane; t < pp.len; t += WAVE) {
+                    const uint32_t j = rev ? pp.len - 1 - t : t;
+                    const uint32_t b = (uint32_t)(w[j >> 5] >> (62 - 2 * (j & 31))) & 3u;
+                    pbuf[at + t] = "ACGT"[rev ? 3 - b : b];
+                }
+            }
+            at += pp.len;
+        }
+    }
+    aln_sync();
+    auto path_ptr = [&](uint32_t i) -> const char * {
+        uint32_t at = 0;
+        for (uint32_t x = 0; x < i; ++x) at += paths[x].len;
+        return pbuf + at;
+    };
+
+    // ---- round 0 ---------------------------------------------------------------------------------
+    int cur = 0;
+    uint32_t n_kept = 0, used[2] = {0, 0};
+    {
+        const uint32_t m = paths[0].len, n = paths[1].len;
+        if (job_bytes(m, n) > p.work_bytes) return 1;
+        uint32_t nh, tu, gu;
+        if (!align_job(nw_base, path_ptr(0), path_ptr(1), m, n, p.M, p.D, p.G, st, nh, tu, gu)) return 1;
+        if (nh > C.list) return 1;
+        for (uint32_t h = 0; h < nh; ++h) {
+            const pf_align_hit hh = st.hits[h];
+            if (hh.len > C.row || used[cur] + 2ull * hh.len > C.arena) return 1;
+            const char *src = st.text + hh.text_off;
+            char *dst = arena[cur] + used[cur];
+            for (uint32_t t = lane; t < 2 * hh.len; t += WAVE) dst[t] = src[t];
+            if (lane == 0) list[cur][h] = MsaRef{used[cur], hh.len, 2};
+            used[cur] += 2 * hh.len;
+        }
+        n_kept = nh;
+        aln_sync();
+    }
+
+    // ---- progressive rounds (src/SeqAlign.cpp:559-638) ------------------------------------------
+    for (uint32_t i = 2; i < N; ++i) {
+        const int nxt = cur ^ 1;
+        uint32_t n_new = 0;
+        used[nxt] = 0;
+        int best_total = INT_MIN;
+        const char *pi = path_ptr(i);
+        const uint32_t li = paths[i].len;
+        for (uint32_t kk = 0; kk < n_kept; ++kk) {
+            const MsaRef M = list[cur][kk];
+            const char *mrows = arena[cur] + M.off;
+            if (job_bytes(M.len, li) > p.work_bytes) return 1;
+            uint32_t nh, tu, gu;
+            if (!align_job(nw_base, mrows, pi, M.len, li, p.M, p.D, p.G, st, nh, tu, gu)) return 1;
+            // candidates alive, in traceback order
+            uint32_t n_alive = nh;
+            int ab = 0;
+            for (uint32_t c = lane; c < nh; c += WAVE) alive[ab][c] = (uint16_t)c;
+            aln_sync();
+            uint32_t total = 0;  // `int` in the reference; sums of INT_MIN wrap
+            for (uint32_t j = 1; j < i; ++j) {
+                RowScore top;
+                top.score = INT_MIN;
+                top.n_pos = 0;
+                top.indel = 0;
+                int best_j = INT_MIN;
+                uint32_t n_next = 0;
+                for (uint32_t a = 0; a < n_alive; ++a) {
+                    const uint32_t c = alive[ab][a];
+                    const pf_align_hit hh = st.hits[c];
+                    if (hh.len > C.row) return 1;
+                    const char *old = mrows + (size_t)j * M.len;
+                    const uint32_t *gp = st.gaps + hh.gap_off;
+                    for (uint32_t t = lane; t < hh.len; t += WAVE) tmp_row[t] = regap_char(old, gp, hh.n_gaps, t);
+                    aln_sync();
+                    const RowScore rs = score_rows(tmp_row, st.text + hh.text_off + hh.len, hh.len, p.M, p.D, p.G, p.integral);
+                    const int diff = rank_diff(rs, top);
+                    if (diff > 0) { top = rs; n_next = 0; }
+                    if (diff >= 0) {
+                        best_j = (int)top.score;
+                        if (lane == 0) alive[ab ^ 1][n_next] = (uint16_t)c;
+                        n_next++;
+                    }
+                    aln_sync();
+                }
+                ab ^= 1;
+                n_alive = n_next;
+                total += (uint32_t)best_j;
+            }
+            const int tkk = (int)total;
+            if (tkk > best_total) { best_total = tkk; n_new = 0; used[nxt] = 0; }
+            if (tkk >= best_total) {
+                for (uint32_t a = 0; a < n_alive; ++a) {
+                    const uint32_t c = alive[ab][a];
+                    const pf_align_hit hh = st.hits[c];
+                    const uint32_t rows = i + 1;
+                    if (n_new >= C.list || hh.len > C.row || used[nxt] + (uint64_t)rows * hh.len > C.arena) return 1;
+                    char *dst = arena[nxt] + used[nxt];
+                    const char *ha = st.text + hh.text_off;
+                    const uint32_t *gp = st.gaps + hh.gap_off;
+                    for (uint32_t t = lane; t < hh.len; t += WAVE) {
+                        dst[t] = ha[t];                                      // new row 0
+                        dst[(size_t)i * hh.len + t] = ha[hh.len + t];         // the new row
+                        for (uint32_t j = 1; j < i; ++j)
+                            dst[(size_t)j * hh.len + t] = regap_char(mrows + (size_t)j * M.len, gp, hh.n_gaps, t);
+                    }
+                    if (lane == 0) list[nxt][n_new] = MsaRef{used[nxt], hh.len, rows};
+                    n_new++;
+                    used[nxt] += rows * hh.len;
+                }
+            }
+            aln_sync();
+        }
+        cur = nxt;
+        n_kept = n_new;
+    }
+
+    // ---- compareStrPair (src/SeqAlign.cpp:8-236) ---------------------------------------------------
+    int best = -1;
+    {
+        const uint64_t Lref = n_kept ? list[cur][n_kept - 1].len : 0;
+        int best_snp = INT_MAX / 2, best_indel = INT_MAX / 2;
+        int d_snp = INT_MAX, d_indel = INT_MAX, d_all = INT_MAX, left = -1, right = -1;
+        for (uint32_t c = 0; c < n_kept; ++c) {
+            const MsaRef M = list[cur][c];
+            const char *rows = arena[cur] + M.off;
+            // the NW working storage is idle now: keep the per-column flags there (LDS in the LDS tiers)
+            uint8_t *ci = M.len <= p.work_bytes ? nw_base : colinfo;
+            const Metrics m = classify(rows, M.rows, M.len, ci, snp_pos, indel_pos, indel_len);
+            int verdict = 0;  // 1 take, 2 take on the strcmp tie-break
+            uint64_t c_indel = 0, c_snp = 0, c_all = 0;
+            const int total = m.snp + m.indel, btotal = best_snp + best_indel;
+            if (total < btotal) verdict = 1;
+            else if (total == btotal) {
+                if (m.indel < best_indel) verdict = 1;
+                else if (m.indel == best_indel) {
+                    c_indel = spread_merged(indel_pos, m.n_indel_pos, nullptr, 0, Lref);
+                    if (c_indel > (uint64_t)d_indel) verdict = 1;
+                    else if (c_indel == (uint64_t)d_indel) {
+                        c_snp = spread_merged(snp_pos, m.n_snp_pos, nullptr, 0, Lref);
+                        if (c_snp > (uint64_t)d_snp) verdict = 1;
+                        else if (c_snp == (uint64_t)d_snp) {
+                            c_all = spread_merged(snp_pos, m.n_snp_pos, indel_pos, m.n_indel_pos, Lref);
+                            if (c_all > (uint64_t)d_all) verdict = 1;
+                            else if (c_all == (uint64_t)d_all) {
+                                if (m.first_site > left || m.last_site > right) verdict = 1;
+                                else if (m.first_site == left && m.last_site == right && best >= 0) {
+                                    const MsaRef B = list[cur][best];
+                                    const char *brows = arena[cur] + B.off;
+                                    for (uint32_t r = 0; r < M.rows; ++r)
+                                        if (str_greater(rows + (size_t)r * M.len, M.len, brows + (size_t)r * B.len, B.len)) {
+                                            verdict = 2;
+                                            break;
+                                        }
+                                    if (verdict == 2) { left = m.first_site; right = m.last_site; }
+                                }
+                            }
+                        }
+                    }
+                }
+            }
+            if (verdict == 0) continue;
+            if (verdict == 1) {
+                const int f = m.any_site ? m.first_site : -1, l = m.any_site ? m.last_site : -1;
+                left = left > f ? left : f;
+                right = right > l ? right : l;
+                c_all = spread_merged(snp_pos, m.n_snp_pos, indel_pos, m.n_indel_pos, Lref);
+                c_snp = spread_merged(snp_pos, m.n_snp_pos, nullptr, 0, Lref);
+                c_indel = spread_merged(indel_pos, m.n_indel_pos, nullptr, 0, Lref);
+            }
+            d_all = (int)c_all;
+            d_snp = (int)c_snp;
+            d_indel = (int)c_indel;
+            best_snp = m.snp;
+            best_indel = m.indel;
+            best = (int)c;
+        }
+    }
+
+    // ---- publish ---------------------------------------------------------------------------------
+    pf_bubble_result res;
+    memset(&res, 0, sizeof(res));
+    if (best < 0) {
+        if (lane == 0) o.res[job] = res;
+        return 0;
+    }
+    const MsaRef B = list[cur][best];
+    const char *rows = arena[cur] + B.off;
+    if (B.len <= p.work_bytes) colinfo = nw_base;
+    const Metrics m = classify(rows, B.rows, B.len, colinfo, snp_pos, indel_pos, indel_len);
+    // variant columns = labelled columns (every row gets a group >= 1 there)
+    uint32_t n_sites = 0;
+    for (uint32_t base = 0; base < B.len; base += WAVE) {
+        const uint32_t j = base + lane;
+        n_sites += (uint32_t)__popcll(__ballot(j < B.len && (colinfo[j] & 16)));
+    }
+    unsigned long long t0 = 0, s0 = 0, g0 = 0, l0 = 0;
+    if (lane == 0) {
+        t0 = atomicAdd(&o.heads[0], (unsigned long long)B.rows * B.len);
+        s0 = atomicAdd(&o.heads[1], (unsigned long long)n_sites);
+        g0 = atomicAdd(&o.heads[2], (unsigned long long)n_sites * B.rows);
+        l0 = atomicAdd(&o.heads[3], (unsigned long long)m.n_indel_len);
+    }
+    t0 = (unsigned long long)bcast_i64((long long)t0);
+    s0 = (unsigned long long)bcast_i64((long long)s0);
+    g0 = (unsigned long long)bcast_i64((long long)g0);
+    l0 = (unsigned long long)bcast_i64((long long)l0);
+    res.rows_off = t0;
+    res.site_off = s0;
+    res.group_off = g0;
+    res.ilen_off = l0;
+    res.n_rows = B.rows;
+    res.n_cols = B.len;
+    res.n_sites = n_sites;
+    res.n_indel_len = m.n_indel_len;
+    if (lane == 0) o.res[job] = res;
+    if (t0 + (uint64_t)B.rows * B.len > o.text_cap || s0 + n_sites > o.site_cap || g0 + (uint64_t)n_sites * B.rows > o.group_cap ||
+        l0 + m.n_indel_len > o.ilen_cap)
+        return 0;  // the host sees the heads and asks again with larger pools
+    for (uint32_t t = lane; t < B.rows * B.len; t += WAVE) o.text[t0 + t] = rows[t];
+    for (uint32_t t = lane; t < m.n_indel_len; t += WAVE) o.ilen[l0 + t] = indel_len[t];
+    uint32_t rank_base = 0;
+    for (uint32_t base = 0; base < B.len; base += WAVE) {
+        const uint32_t j = base + lane;
+        const bool is_site = j < B.len && (colinfo[j] & 16);
+        const unsigned long long mask = __ballot(is_site);
+        if (is_site) {
+            const uint32_t rk = rank_base + (uint32_t)__popcll(mask & ((1ull << lane) - 1));
+            uint8_t *grp = o.groups + g0 + (uint64_t)rk * B.rows;
+            uint8_t next = 0;
+            for (uint32_t r = 0; r < B.rows; ++r) {
+                const char c = rows[(size_t)r * B.len + j];
+                uint32_t e = 0;
+                while (e < r && rows[(size_t)e * B.len + j] != c) ++e;
+                grp[r] = e < r ? grp[e] : ++next;
+            }
+            pf_bubble_site sr;
+            sr.col = j;
+            sr.is_indel = (colinfo[j] & 32) ? 1 : 0;
+            sr.maxnum = next;
+            sr.pad_ = 0;
+            o.sites[s0 + rk] = sr;
+        }
+        rank_base += (uint32_t)__popcll(mask);
+    }
+    return 0;
+}
+
+template <bool LDS>
+__global__ __launch_bounds__(64) void k_bubble(BubParams p, BubOut o) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t *nw_base;
+    if constexpr (LDS) nw_base = smem;
+    else nw_base = p.work + (uint64_t)blockIdx.x * p.work_per_wave;
+    uint8_t *scr = p.scratch + (uint64_t)blockIdx.x * p.scratch_per_wave;
+    for (uint32_t q = blockIdx.x; q < p.n; q += gridDim.x) {
+        const uint32_t job = p.idx[q];
+        const int rc = bubble_task<LDS>(p, o, job, nw_base, scr);
+        if (rc != 0 && lane_id() == 0) {
+            if (p.final_tier) {
+                pf_bubble_result r;
+                memset(&r, 0, sizeof(r));
+                r.n_rows = 0xFFFFFFFFu;  // error marker
+                o.res[job] = r;
+            } else {
+                const unsigned int x = atomicAdd(o.n_retry, 1u);
+                o.retry[x] = job;
+            }
+        }
+        aln_sync();
+    }
+}
+
+}  // namespace
+
+extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len, const pf_bubble_path *paths, uint64_t n_paths,
+                                const pf_bubble_task *tasks, uint32_t n_tasks, double match, double mismatch, double gap,
+                                pf_bubble_result *results, char *out_text, uint64_t text_cap, pf_bubble_site *out_sites,
+                                uint64_t site_cap, uint8_t *out_groups, uint64_t group_cap, uint32_t *out_ilen,
+                                uint64_t ilen_cap, uint64_t used[4]) {
+    if (!ctx || !used || (n_tasks && (!paths || !tasks || !results || !out_text || !out_sites || !out_groups || !out_ilen)))
+        return PF_ERR_ARG;
+    used[0] = used[1] = used[2] = used[3] = 0;
+    if (n_tasks == 0) return PF_OK;
+    if (!ctx->d_seq) { ctx->err = "pf_align_bubbles: no graph uploaded"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    auto is_dev = [](const void *p) {
+        hipPointerAttribute_t at;
+        bool d = p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        return d;
+    };
+    // host copies for validation and size classes
+    std::vector<pf_bubble_task> ht(n_tasks);
+    std::vector<pf_bubble_path> hp(n_paths);
+    PF_HIP(hipMemcpy(ht.data(), tasks, (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyDefault));
+    if (n_paths) PF_HIP(hipMemcpy(hp.data(), paths, (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyDefault));
+    std::vector<uint32_t> hlen;  // unitig lengths, fetched lazily for ov paths
+    const uint64_t cls_bytes[3] = {5 * 1024, 20 * 1024, 64 * 1024};
+    std::vector<uint32_t> cls[4];
+    uint64_t max_need = 0;
+    for (uint32_t t = 0; t < n_tasks; ++t) {
+        const pf_bubble_task &tk = ht[t];
+        if (tk.n_paths < 2 || tk.path_first + tk.n_paths > n_paths) { ctx->err = "pf_align_bubbles: bad task"; return PF_ERR_ARG; }
+        uint32_t l0 = 0, lmax = 0;
+        for (uint32_t i = 0; i < tk.n_paths; ++i) {
+            pf_bubble_path &pp = hp[tk.path_first + i];
+            if (pp.ov != PF_NONE) {
+                if ((pp.ov >> 1) >= ctx->N) { ctx->err = "pf_align_bubbles: path unitig out of range"; return PF_ERR_ARG; }
+                if (hlen.empty()) {
+                    hlen.resize(ctx->N);
+                    PF_HIP(hipMemcpy(hlen.data(), ctx->d_len, (size_t)ctx->N * 4, hipMemcpyDeviceToHost));
+                }
+                if (pp.len != hlen[pp.ov >> 1]) { ctx->err = "pf_align_bubbles: path length differs from the unitig's"; return PF_ERR_ARG; }
+            } else if (pp.text_off + pp.len > text_len) {
+                ctx->err = "pf_align_bubbles: path outside the text buffer";
+                return PF_ERR_ARG;
+            }
+            if (pp.len == 0 || pp.len > 60000) { ctx->err = "pf_align_bubbles: empty path or longer than 60000"; return PF_ERR_ARG; }
+            if (i == 0) l0 = pp.len;
+            lmax = std::max(lmax, pp.len);
+        }
+        // row 0 can grow by the gaps opened in later rounds: leave headroom, the device re-checks every job
+        const uint64_t need = job_bytes(std::max(l0, lmax) + 32, lmax);
+        int c = 3;
+        for (int x = 0; x < 3; ++x)
+            if (need <= cls_bytes[x]) { c = x; break; }
+        cls[c].push_back(t);
+        if (c == 3) max_need = std::max(max_need, need);
+    }
+    // device inputs
+    const char *d_text = text;
+    if (text_len && !is_dev(text)) {
+        char *b = (char *)ctx_ws(ctx, WS_BUB_TEXT, text_len + 1);
+        if (!b) return PF_ERR_HIP;
+        PF_HIP(hipMemcpyAsync(b, text, text_len, hipMemcpyHostToDevice, st));
+        d_text = b;
+    }
+    pf_bubble_path *d_paths = (pf_bubble_path *)ctx_ws(ctx, WS_BUB_PATHS, std::max<uint64_t>(n_paths, 1) * sizeof(pf_bubble_path));
+    pf_bubble_task *d_tasks = (pf_bubble_task *)ctx_ws(ctx, WS_BUB_TASKS, (size_t)n_tasks * sizeof(pf_bubble_task));
+    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 64);
+    uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_BUB_RETRY, (size_t)n_tasks * 4);
+    uint32_t *d_idx = (uint32_t *)ctx_ws(ctx, WS_BUB_IDX, (size_t)n_tasks * 4);
+    if (!d_paths || !d_tasks || !small || !d_retry || !d_idx) return PF_ERR_HIP;
+    PF_HIP(hipMemcpyAsync(d_paths, hp.data(), (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyHostToDevice, st));
+    PF_HIP(hipMemcpyAsync(d_tasks, ht.data(), (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyHostToDevice, st));
+    PF_HIP(hipMemsetAsync(small, 0, 64, st));
+    const bool dev_out = is_dev(results);
+    BubOut o;
+    if (dev_out) {
+        o.res = results; o.text = out_text; o.sites = out_sites; o.groups = out_groups; o.ilen = out_ilen;
+    } else {
+        o.res = (pf_bubble_result *)ctx_ws(ctx, WS_BUB_RES, (size_t)n_tasks * sizeof(pf_bubble_result));
+        o.text = (char *)ctx_ws(ctx, WS_BUB_OTEXT, std::max<uint64_t>(text_cap, 1));
+        o.sites = (pf_bubble_site *)ctx_ws(ctx, WS_BUB_OSITES, std::max<uint64_t>(site_cap, 1) * sizeof(pf_bubble_site));
+        o.groups = (uint8_t *)ctx_ws(ctx, WS_BUB_OGROUPS, std::max<uint64_t>(group_cap, 1));
+        o.ilen = (uint32_t *)ctx_ws(ctx, WS_BUB_OILEN, std::max<uint64_t>(ilen_cap, 1) * 4);
+        if (!o.res || !o.text || !o.sites || !o.groups || !o.ilen) return PF_ERR_HIP;
+    }
+    o.text_cap = text_cap; o.site_cap = site_cap; o.group_cap = group_cap; o.ilen_cap = ilen_cap;
+    o.heads = reinterpret_cast<unsigned long long *>(small);
+    o.n_retry = reinterpret_cast<unsigned int *>(small + 40);
+    o.retry = d_retry;
+
+    BubParams p;
+    memset(&p, 0, sizeof(p));
+    p.text = d_text; p.paths = d_paths; p.tasks = d_tasks; p.M = match; p.D = mismatch; p.G = gap;
+    p.integral = (match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap) &&
+                  std::fabs(match) < 1e6 && std::fabs(mismatch) < 1e6 && std::fabs(gap) < 1e6) ? 1 : 0;
+    p.seq = ctx->d_seq; p.off = ctx->d_off; p.len = ctx->d_len; p.n_unitigs = ctx->N;
+    const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
+    const int max_waves = ctx->n_cu * 8;
+    p.caps = std_caps;
+    p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
+    p.scratch = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
+    if (!p.scratch) return PF_ERR_HIP;
+
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bubble<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+    }
+    uint32_t idx_off = 0;
+    for (int c = 0; c < 3; ++c) {
+        if (cls[c].empty()) continue;
+        const uint32_t nc = (uint32_t)cls[c].size();
+        PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[c].data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
+        p.idx = d_idx + idx_off;
+        p.n = nc;
+        p.work_bytes = (uint32_t)cls_bytes[c];
+        const int grid = (int)std::min<uint32_t>(nc, (uint32_t)max_waves);
+        ctx_begin(ctx, PF_K_BUBBLE);
+        k_bubble<true><<<grid, 64, cls_bytes[c], st>>>(p, o);
+        ctx_end(ctx);
+        idx_off += nc;
+    }
+    if (!cls[3].empty()) {
+        const uint32_t nc = (uint32_t)cls[3].size();
+        const int grid = (int)std::min<uint32_t>(nc, 256);
+        const uint64_t per = (std::min<uint64_t>(max_need * 2, 1ull << 31) + 255) & ~255ull;
+        uint8_t *work = (uint8_t *)ctx_ws(ctx, WS_BUB_WORK, per * grid);
+        if (!work) return PF_ERR_HIP;
+        PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[3].data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
+        p.idx = d_idx + idx_off;
+        p.n = nc;
+        p.work = work;
+        p.work_per_wave = per;
+        p.work_bytes = (uint32_t)std::min<uint64_t>(per, 0xFFFFFFFFu);
+        ctx_begin(ctx, PF_K_BUBBLE_BIG);
+        k_bubble<false><<<grid, 64, 0, st>>>(p, o);
+        ctx_end(ctx);
+    }
+    unsigned int n_retry = 0;
+    PF_HIP(hipMemcpyAsync(&n_retry, o.n_retry, 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    int status = PF_OK;
+    uint8_t *big_scratch = nullptr, *big_work = nullptr;
+    if (n_retry) {
+        // some capacity of the standard tier was exceeded: rerun with 32x the scratch on a few waves
+        std::vector<uint32_t> rj(n_retry);
+        PF_HIP(hipMemcpy(rj.data(), d_retry, (size_t)n_retry * 4, hipMemcpyDeviceToHost));
+        uint64_t need = 1 << 20;
+        for (uint32_t t : rj) {
+            uint64_t sum = 0, lmax = 0;
+            for (uint32_t i = 0; i < ht[t].n_paths; ++i) { sum += hp[ht[t].path_first + i].len; lmax = std::max<uint64_t>(lmax, hp[ht[t].path_first + i].len); }
+            need = std::max(need, job_bytes((uint32_t)std::min<uint64_t>(sum, 60000), (uint32_t)lmax));
+        }
+        const BubCaps big{2u << 20, 256 * 1024, 16 * 1024, 512 * 1024, 4u << 20, 8192, 256 * 1024};
+        const int grid = (int)std::min<uint32_t>(n_retry, 8);
+        const uint64_t per_s = (bub_scratch_bytes(big) + 255) & ~255ull;
+        const uint64_t per_w = (std::min<uint64_t>(need, 0xFFFFFF00u) + 255) & ~255ull;
+        PF_HIP(hipMalloc(&big_scratch, per_s * grid));
+        PF_HIP(hipMalloc(&big_work, per_w * grid));
+        PF_HIP(hipMemcpyAsync(d_idx, rj.data(), (size_t)n_retry * 4, hipMemcpyHostToDevice, st));
+        p.idx = d_idx; p.n = n_retry; p.caps = big; p.scratch = big_scratch; p.scratch_per_wave = per_s;
+        p.work = big_work; p.work_per_wave = per_w; p.work_bytes = (uint32_t)per_w; p.final_tier = 1;
+        ctx_begin(ctx, PF_K_BUBBLE_BIG);
+        k_bubble<false><<<grid, 64, 0, st>>>(p, o);
+        ctx_end(ctx);
+        PF_HIP(hipStreamSynchronize(st));
+    }
+    unsigned long long heads[4];
+    PF_HIP(hipMemcpy(heads, o.heads, 32, hipMemcpyDeviceToHost));
+    for (int x = 0; x < 4; ++x) used[x] = heads[x];
+    if (heads[0] > text_cap || heads[1] > site_cap || heads[2] > group_cap || heads[3] > ilen_cap) {
+        ctx->err = "pf_align_bubbles: output pools too small";
+        status = PF_ERR_OVERFLOW;
+    }
+    if (!dev_out && status == PF_OK) {
+        PF_HIP(hipMemcpyAsync(results, o.res, (size_t)n_tasks * sizeof(pf_bubble_result), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_text, o.text, (size_t)heads[0], hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_sites, o.sites, (size_t)heads[1] * sizeof(pf_bubble_site), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_groups, o.groups, (size_t)heads[2], hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_ilen, o.ilen, (size_t)heads[3] * 4, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        if (n_retry)
+            for (uint32_t t = 0; t < n_tasks; ++t)
+                if (results[t].n_rows == 0xFFFFFFFFu) {
+                    ctx->err = "pf_align_bubbles: a bubble exceeds the largest scratch tier";
+                    status = PF_ERR_OVERFLOW;
+                    break;
+                }
+    }
+    hipFree(big_scratch);
+    hipFree(big_work);
+    return status;
+}

@@ -313,7 +313,8 @@ __global__ __launch_bounds__(64) void k_bfs_big(const uint32_t *__restrict__ suc
 namespace pf {
 
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
-                                                "k_bfs_big",     "k_align",      "k_align_big", "k_strcov"};
+                                                "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
+                                                "k_bubble_big"};
 
 int ctx_begin(pf_ctx *ctx, int kernel) {
     if (!ctx->timing) return 0;

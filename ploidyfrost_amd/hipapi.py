@@ -20,14 +20,20 @@ LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_hip.so")
 NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
-           "k_strcov"]
+           "k_strcov", "k_bubble", "k_bubble_big"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
 ALIGN_JOB = np.dtype([("a_off", "<u8"), ("b_off", "<u8"), ("a_len", "<u4"), ("b_len", "<u4")])
 ALIGN_HIT = np.dtype([("text_off", "<u8"), ("gap_off", "<u8"), ("len", "<u4"), ("n_gaps", "<u4"), ("score", "<i8"),
                       ("n_pos", "<u4"), ("n_indel", "<u4")])
+BUBBLE_PATH = np.dtype([("text_off", "<u8"), ("len", "<u4"), ("ov", "<u4")])
+BUBBLE_TASK = np.dtype([("path_first", "<u8"), ("n_paths", "<u4"), ("pad", "<u4")])
+BUBBLE_SITE = np.dtype([("col", "<u4"), ("is_indel", "u1"), ("maxnum", "u1"), ("pad", "<u2")])
+BUBBLE_RESULT = np.dtype([("rows_off", "<u8"), ("site_off", "<u8"), ("group_off", "<u8"), ("ilen_off", "<u8"), ("n_rows", "<u4"),
+                          ("n_cols", "<u4"), ("n_sites", "<u4"), ("n_indel_len", "<u4")])
 assert BFS_RECORD.itemsize == 32 and ALIGN_JOB.itemsize == 24 and ALIGN_HIT.itemsize == 40
+assert BUBBLE_PATH.itemsize == 16 and BUBBLE_TASK.itemsize == 16 and BUBBLE_SITE.itemsize == 8 and BUBBLE_RESULT.itemsize == 48
 
 _lib = None
 
@@ -71,6 +77,8 @@ def load_library() -> C.CDLL:
         "pf_bfs_candidates": (i, [vp, u32, u32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
         "pf_align_batch": (i, [vp, vp, u64, vp, u32, C.c_double, C.c_double, C.c_double, vp, vp, vp, u64, vp, u64, vp, u64,
                                C.POINTER(u64)]),
+        "pf_align_bubbles": (i, [vp, vp, u64, vp, u64, vp, u32, C.c_double, C.c_double, C.c_double, vp, vp, u64, vp, u64, vp, u64,
+                                 vp, u64, C.POINTER(u64)]),
         "pf_string_cov": (i, [vp, vp, vp, u32, u32, u32, vp, vp, vp]),
         "pf_host_alloc": (i, [vp, C.c_size_t, C.POINTER(vp)]),
         "pf_host_free": (None, [vp, vp]),
@@ -89,7 +97,7 @@ def load_library() -> C.CDLL:
 DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
                     "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
-                    "pf_align_batch", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers"]
+                    "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers"]
 
 
 def pack_unitigs(seqs: list[bytes]):
@@ -287,4 +295,58 @@ class Device:
                 gp = ogap[int(h["gap_off"]) : int(h["gap_off"]) + int(h["n_gaps"])].copy()
                 lst.append((tb[o : o + ln], tb[o + ln : o + 2 * ln], gp, int(h["score"]), int(h["n_pos"]), int(h["n_indel"])))
             out.append(lst)
+        return out
+
+    def align_bubbles(self, bubbles: list[list], M=2.0, D=-1.0, G=-3.0):
+        """bubbles[t] = list of paths, each either bytes (ASCII) or an int oriented-unitig id.
+        Returns per bubble None (no alignment) or dict(rows, sites=[(col, is_indel, groups)], indel_len)."""
+        nt = len(bubbles)
+        tasks = np.zeros(nt, dtype=BUBBLE_TASK)
+        paths = []
+        chunks = []
+        pos = 0
+        lens = self._keep[2]
+        for t, b in enumerate(bubbles):
+            tasks[t] = (len(paths), len(b), 0)
+            for x in b:
+                if isinstance(x, (bytes, bytearray)):
+                    paths.append((pos, len(x), NONE))
+                    chunks.append(bytes(x))
+                    pos += len(x)
+                else:
+                    paths.append((0, int(lens[int(x) >> 1]), int(x)))
+        parr = np.array(paths, dtype=BUBBLE_PATH)
+        text = np.frombuffer(b"".join(chunks) + b"\0", dtype=np.uint8).copy()
+        caps = [max(4096, 4 * int(parr["len"].sum())), max(256, 8 * nt), max(1024, 32 * nt), max(256, 4 * nt)]
+        while True:
+            res = np.zeros(nt, dtype=BUBBLE_RESULT)
+            otext = np.zeros(caps[0], dtype=np.uint8)
+            osites = np.zeros(caps[1], dtype=BUBBLE_SITE)
+            ogroups = np.zeros(caps[2], dtype=np.uint8)
+            oilen = np.zeros(caps[3], dtype=np.uint32)
+            used = (C.c_uint64 * 4)()
+            st = self.L.pf_align_bubbles(self.h, text.ctypes.data, pos, parr.ctypes.data, len(parr), tasks.ctypes.data, nt, M, D, G,
+                                         res.ctypes.data, otext.ctypes.data, caps[0], osites.ctypes.data, caps[1],
+                                         ogroups.ctypes.data, caps[2], oilen.ctypes.data, caps[3], used)
+            if st == PF_ERR_OVERFLOW and any(used[i] > caps[i] for i in range(4)):
+                caps = [max(caps[i], int(used[i])) for i in range(4)]
+                continue
+            self._check(st)
+            break
+        out = []
+        tb = otext.tobytes()
+        for r in res:
+            R, L = int(r["n_rows"]), int(r["n_cols"])
+            if R == 0:
+                out.append(None)
+                continue
+            o = int(r["rows_off"])
+            rows = [tb[o + i * L : o + (i + 1) * L] for i in range(R)]
+            sites = []
+            for i in range(int(r["n_sites"])):
+                srec = osites[int(r["site_off"]) + i]
+                g0 = int(r["group_off"]) + i * R
+                sites.append((int(srec["col"]), int(srec["is_indel"]), int(srec["maxnum"]), ogroups[g0 : g0 + R].tolist()))
+            il = oilen[int(r["ilen_off"]) : int(r["ilen_off"]) + int(r["n_indel_len"])].tolist()
+            out.append(dict(rows=rows, sites=sites, indel_len=il))
         return out
