@@ -108,7 +108,7 @@ def algorithmic_bytes(kernel: str, t: dict) -> float | None:
         return 12.25 * t["kmers"] + 16.0 * t["unitigs"]
     if kernel == "k_bfs":
         return 600.0 * t["candidates"]
-    if kernel == "k_align":
+    if kernel in ("k_align", "k_bubble"):
         return 300.0 * t["align_jobs"]
     if kernel == "k_strcov":
         return 12.0 * 2.0 * t["site_strings"]

@@ -85,7 +85,7 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
 }
 
 CDBG::~CDBG() {
-    aligner_.reset();  // releases pinned buffers before the context goes
+    bx_.release_all();  // pinned buffers go before the context
     pf_destroy(ctx_);
 }
 
@@ -358,12 +358,6 @@ void sort_paths(std::vector<std::string> &v, int low, int high) {
     sort_paths(v, j + 1, high);
 }
 
-std::string without_gaps(const std::string &s, size_t n) {
-    std::string r;
-    for (size_t i = 0; i < n && i < s.size(); ++i)
-        if (s[i] != '-') r.push_back(s[i]);
-    return r;
-}
 }  // namespace
 
 // ---- ploidyEstimation (reference src/CDBG.cpp:1101-1705) -----------------------------------
@@ -416,11 +410,9 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
     core_cov_ = core_num_ = 0;
 
-    const size_t CHUNK = 1u << 18;  // bubbles per batch
+    const size_t CHUNK = 1u << 19;  // bubbles per batch
     constexpr size_t PCH = 256;     // bubbles per parallel work item
     std::vector<Task> tasks;
-    std::vector<std::vector<std::string>> paths;
-    std::vector<Msa> msa;
     uint32_t scan_u = 0;
     while (scan_u < N) {
         // ---- scan ------------------------------------------------------------------------------
@@ -494,27 +486,35 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
         times_.scan_s += since(t0);
         if (tasks.empty()) continue;
         const size_t NT = tasks.size();
+        const size_t n_pch = n_chunks_of(NT, PCH);
         times_.tasks += NT;
 
-        // ---- paths -----------------------------------------------------------------------------
-        paths.assign(NT, {});
-        parallel_chunks(NT, PCH, T, [&](size_t, size_t tb, size_t te) {
+        // ---- paths: oriented inner unitigs are decoded on the device; the s->t walks of the branching
+        //      bubbles are enumerated here (two-stack DFS of src/CDBG.cpp:1364-1412) ---------------
+        struct PathChunk {
+            std::vector<pf_bubble_path> paths;  // text_off relative to this chunk's text
+            std::vector<uint32_t> count;        // paths per bubble
+            std::string text;
+        };
+        std::vector<PathChunk> pchunks(n_pch);
+        parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
+            PathChunk &pc = pchunks[ci];
             std::vector<uint32_t> major, minor;
             std::string walk;
+            std::vector<std::string> strs;
             for (size_t ti = tb; ti < te; ++ti) {
                 const Task &t = tasks[ti];
-                std::vector<std::string> &strs = paths[ti];
                 if (t.strict) {
-                    for (int q = 0; q < t.n_inner; ++q) strs.push_back(g_.mapped(t.inner[q]));
+                    for (int q = 0; q < t.n_inner; ++q) pc.paths.push_back({0, g_.size_bp(t.inner[q] >> 1), t.inner[q]});
+                    pc.count.push_back(t.n_inner);
                     continue;
                 }
-                // every s->t path, from the start of s's last k-mer through t's first k-mer
-                // (two-stack DFS of src/CDBG.cpp:1364-1412)
                 const uint32_t eu = t.exit_ov >> 1;
                 const uint32_t ulen = g_.len_km(t.u);
                 major.clear();
                 minor.clear();
                 walk.clear();
+                strs.clear();
                 minor.push_back(t.entrance_ov);
                 while (!minor.empty()) {
                     const uint32_t w = minor.back();
@@ -542,81 +542,157 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                     }
                 }
                 sort_paths(strs, 0, (int)strs.size() - 1);
+                for (const std::string &sx : strs) {
+                    pc.paths.push_back({(uint64_t)pc.text.size(), (uint32_t)sx.size(), NONE});
+                    pc.text += sx;
+                }
+                pc.count.push_back((uint32_t)strs.size());
             }
+        });
+        // one flat batch: bubbles with fewer than two paths (the reference indexes str[1] blindly) are skipped
+        std::vector<uint64_t> text_base(n_pch + 1, 0), path_base(n_pch + 1, 0);
+        for (size_t c = 0; c < n_pch; ++c) {
+            text_base[c + 1] = text_base[c] + pchunks[c].text.size();
+            path_base[c + 1] = path_base[c] + pchunks[c].paths.size();
+        }
+        bx_.text.ensure(ctx_, text_base[n_pch] + 1);
+        bx_.paths.ensure(ctx_, path_base[n_pch] + 1);
+        bx_.tasks.ensure(ctx_, NT);
+        std::vector<uint32_t> dev_index(NT, NONE);  // bubble -> index in the device batch
+        uint32_t n_dev = 0;
+        {
+            size_t ti = 0;
+            for (size_t c = 0; c < n_pch; ++c) {
+                uint64_t pf = path_base[c];
+                for (uint32_t cnt : pchunks[c].count) {
+                    if (cnt >= 2) {
+                        bx_.tasks.p[n_dev] = pf_bubble_task{pf, cnt, 0};
+                        dev_index[ti] = n_dev++;
+                    }
+                    pf += cnt;
+                    ++ti;
+                }
+            }
+        }
+        parallel_chunks(n_pch, 1, T, [&](size_t c, size_t, size_t) {
+            PathChunk &pc = pchunks[c];
+            if (!pc.text.empty()) memcpy(bx_.text.p + text_base[c], pc.text.data(), pc.text.size());
+            pf_bubble_path *dst = bx_.paths.p + path_base[c];
+            for (size_t i = 0; i < pc.paths.size(); ++i) {
+                dst[i] = pc.paths[i];
+                if (dst[i].ov == NONE) dst[i].text_off += text_base[c];
+            }
+            PathChunk().text.swap(pc.text);
+            std::vector<pf_bubble_path>().swap(pc.paths);
         });
         times_.tasks_s += since(t0);
 
-        // ---- align (A1 on the device) ----------------------------------------------------------
+        // ---- align: SeqAlign::SequenceAlignment of every bubble, one wavefront each ------------------
         t0 = clk::now();
-        AlignStats as;
-        std::string e;
-        if (!aligner_) aligner_.reset(new Aligner(ctx_));
-        st = aligner_->align(sc_, paths, msa, &as, e, T);
-        if (st != PF_OK) return fail(st, "CDBG::PloidyEstimation(): alignment: " + e);
-        times_.align_jobs += as.jobs;
+        bx_.res.ensure(ctx_, std::max<uint32_t>(n_dev, 1));
+        uint64_t cap_text = std::max<uint64_t>(bx_.otext.cap, (text_base[n_pch] + 128ull * n_dev) * 2 + 4096);
+        uint64_t cap_sites = std::max<uint64_t>(bx_.osites.cap, 4ull * n_dev + 64);
+        uint64_t cap_groups = std::max<uint64_t>(bx_.ogroups.cap, 16ull * n_dev + 64);
+        uint64_t cap_ilen = std::max<uint64_t>(bx_.oilen.cap, 2ull * n_dev + 64);
+        for (;;) {
+            bx_.otext.ensure(ctx_, cap_text);
+            bx_.osites.ensure(ctx_, cap_sites);
+            bx_.ogroups.ensure(ctx_, cap_groups);
+            bx_.oilen.ensure(ctx_, cap_ilen);
+            uint64_t used[4];
+            st = pf_align_bubbles(ctx_, bx_.text.p, text_base[n_pch], bx_.paths.p, path_base[n_pch], bx_.tasks.p, n_dev, sc_.match,
+                                  sc_.mismatch, sc_.gap, bx_.res.p, bx_.otext.p, bx_.otext.cap, bx_.osites.p, bx_.osites.cap,
+                                  bx_.ogroups.p, bx_.ogroups.cap, bx_.oilen.p, bx_.oilen.cap, used);
+            if (st == PF_ERR_OVERFLOW && (used[0] > bx_.otext.cap || used[1] > bx_.osites.cap || used[2] > bx_.ogroups.cap ||
+                                          used[3] > bx_.oilen.cap)) {
+                cap_text = std::max<uint64_t>(bx_.otext.cap, used[0] + used[0] / 8);
+                cap_sites = std::max<uint64_t>(bx_.osites.cap, used[1] + used[1] / 8);
+                cap_groups = std::max<uint64_t>(bx_.ogroups.cap, used[2] + used[2] / 8);
+                cap_ilen = std::max<uint64_t>(bx_.oilen.cap, used[3] + used[3] / 8);
+                continue;
+            }
+            break;
+        }
+        if (st != PF_OK) return fail(st, std::string("CDBG::PloidyEstimation(): alignment: ") + pf_last_error(ctx_));
+        times_.align_jobs += n_dev;
         times_.align_s += since(t0);
-        times_.align_build_s += as.build_s;
-        times_.align_device_s += as.device_s;
-        times_.align_post_s += as.post_s;
-        times_.align_choose_s += as.choose_s;
+        static const pf_bubble_result kNoResult = {0, 0, 0, 0, 0, 0, 0, 0};
+        auto result_of = [&](size_t ti) -> const pf_bubble_result & {
+            return dev_index[ti] == NONE ? kNoResult : bx_.res.p[dev_index[ti]];
+        };
 
         // ---- sites: strings of the branching bubbles (src/CDBG.cpp:1448-1600) -> one C2 batch ----
         t0 = clk::now();
-        struct GroupRef { uint32_t first, count; };          // range of chunk-local string indices
+        struct GroupRef { uint32_t first, count; };           // range of chunk-local string indices
         struct TaskSites {
-            std::vector<uint32_t> cols;                       // var_site
-            std::vector<uint32_t> group_first;                // per site: index into `groups`
-            std::vector<GroupRef> groups;
+            uint32_t group_first = 0;                          // index into the chunk's `groups`
         };
-        std::vector<TaskSites> tsites(NT);
-        const size_t n_pch = n_chunks_of(NT, PCH);
-        std::vector<std::vector<std::string>> chunk_strings(n_pch);
-        std::vector<int> chunk_err(n_pch, 0);
+        struct SiteChunk {
+            std::vector<std::string> strings;
+            std::vector<GroupRef> groups;      // per (branching bubble, site, allele group), in order
+            std::vector<uint32_t> first_group;  // per bubble of the chunk: index of its first GroupRef
+            int err = 0;
+        };
+        std::vector<SiteChunk> schunks(n_pch);
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
-            std::vector<std::string> &strings = chunk_strings[ci];
-            try {
+            SiteChunk &sc = schunks[ci];
+            sc.first_group.reserve(te - tb);
+            std::vector<std::string> kstr;
+            std::vector<int> at;
+            std::vector<std::set<std::string>> groups;
             for (size_t ti = tb; ti < te; ++ti) {
-                const Msa &m = msa[ti];
-                if (m.rows.empty()) continue;
-                const size_t R = m.rows.size();
-                TaskSites &ts = tsites[ti];
-                for (uint32_t c = 0; c < m.n_cols; ++c)
-                    if (m.group_at(c, (uint32_t)R - 1) > 0) ts.cols.push_back(c);
-                if (tasks[ti].strict) continue;
+                sc.first_group.push_back((uint32_t)sc.groups.size());
+                const pf_bubble_result &r = result_of(ti);
+                if (r.n_rows == 0 || tasks[ti].strict) continue;
+                const size_t R = r.n_rows, L = r.n_cols;
+                const char *rows = bx_.otext.p + r.rows_off;
+                auto row_at = [&](size_t p, size_t x) -> char {  // std::string::at of the reference: out of range is fatal
+                    if (x >= L) { sc.err = 1; return 'A'; }
+                    return rows[p * L + x];
+                };
+                auto sub = [&](size_t p, long from, long n) -> std::string {  // substr(from, n)
+                    if (from < 0 || (size_t)from > L || n < 0) { sc.err = 1; return std::string(); }
+                    return std::string(rows + p * L + from, std::min<size_t>((size_t)n, L - (size_t)from));
+                };
+                auto ungapped_prefix = [&](size_t p, size_t n) {
+                    std::string o;
+                    for (size_t x = 0; x < n && x < L; ++x)
+                        if (rows[p * L + x] != '-') o.push_back(rows[p * L + x]);
+                    return o;
+                };
+                kstr.assign(R, std::string());
+                at.assign(R, 0);
                 uint32_t indel = 0;
-                std::vector<std::string> kstr(R);
-                std::vector<int> at(R);
-                for (size_t si = 0; si < ts.cols.size(); ++si) {
-                    const uint32_t site = ts.cols[si];
-                    uint16_t maxnum = 0;
-                    for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
+                for (uint32_t si = 0; si < r.n_sites && !sc.err; ++si) {
+                    const pf_bubble_site &sr = bx_.osites.p[r.site_off + si];
+                    const uint8_t *grp = bx_.ogroups.p + r.group_off + (uint64_t)si * R;
+                    const uint32_t site = sr.col;
                     for (auto &x : kstr) x.clear();
-                    const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
-                    if (is_indel) {
+                    if (sr.is_indel) {
                         std::fill(at.begin(), at.end(), (int)site);
                         for (;;) {
                             char first = 0;
                             bool differ = false;
                             for (size_t p = 0; p < R; ++p) {
-                                while (m.rows[p].at((size_t)at[p]) == '-') at[p]++;
-                                const char ch = m.rows[p].at((size_t)at[p]);
+                                while (row_at(p, (size_t)at[p]) == '-') at[p]++;
+                                const char ch = row_at(p, (size_t)at[p]);
                                 at[p]++;
                                 kstr[p].push_back(ch);
                                 if (p == 0) first = ch;
                                 else if (ch != first) differ = true;
                             }
-                            if (differ) break;
+                            if (differ || sc.err) break;
                         }
                         for (size_t p = 0; p < R; ++p) {
                             const int n = (int)kstr[p].size();
                             if (indel == 0) {
-                                kstr[p] = m.rows[p].substr((size_t)(site - k + n), (size_t)(k - n)) + kstr[p];
+                                kstr[p] = sub(p, (long)site - k + n, k - n) + kstr[p];
                             } else {
-                                std::string tmp = without_gaps(m.rows[p], site);
+                                std::string tmp = ungapped_prefix(p, site);
                                 if (tmp.size() < (size_t)(k - n)) {
                                     kstr[p] = tmp + kstr[p];
-                                    for (int x = at[p]; kstr[p].size() < (size_t)k; ++x) {
-                                        const char ch = m.rows[p].at((size_t)x);
+                                    for (int x = at[p]; kstr[p].size() < (size_t)k && !sc.err; ++x) {
+                                        const char ch = row_at(p, (size_t)x);
                                         if (ch != '-') kstr[p].push_back(ch);
                                     }
                                 } else {
@@ -627,11 +703,11 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                         ++indel;
                     } else if (indel > 0) {
                         for (size_t p = 0; p < R; ++p) {
-                            std::string tmp = without_gaps(m.rows[p], site + 1);
+                            std::string tmp = ungapped_prefix(p, site + 1);
                             if (tmp.size() < (size_t)k) {
                                 kstr[p] = tmp;
-                                for (int x = (int)site + 1; kstr[p].size() < (size_t)k; ++x) {
-                                    const char ch = m.rows[p].at((size_t)x);
+                                for (int x = (int)site + 1; kstr[p].size() < (size_t)k && !sc.err; ++x) {
+                                    const char ch = row_at(p, (size_t)x);
                                     if (ch != '-') kstr[p].push_back(ch);
                                 }
                             } else {
@@ -639,27 +715,22 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                             }
                         }
                     } else {
-                        for (size_t p = 0; p < R; ++p) kstr[p] = m.rows[p].substr((size_t)(site - k + 1), (size_t)k);
+                        for (size_t p = 0; p < R; ++p) kstr[p] = sub(p, (long)site - k + 1, k);
                     }
                     // distinct strings per allele group, in std::set order
-                    std::vector<std::set<std::string>> groups(maxnum);
-                    for (size_t p = 0; p < R; ++p) groups[m.group_at(site, (uint32_t)p) - 1].insert(kstr[p]);
-                    ts.group_first.push_back((uint32_t)ts.groups.size());
+                    groups.assign(sr.maxnum, std::set<std::string>());
+                    for (size_t p = 0; p < R; ++p) groups[grp[p] - 1].insert(kstr[p]);
                     for (auto &gs : groups) {
-                        ts.groups.push_back({(uint32_t)strings.size(), (uint32_t)gs.size()});
-                        for (auto &s : gs) strings.push_back(s);
+                        sc.groups.push_back({(uint32_t)sc.strings.size(), (uint32_t)gs.size()});
+                        for (auto &sx : gs) sc.strings.push_back(sx);
                     }
                 }
-                ts.group_first.push_back((uint32_t)ts.groups.size());
-            }
-            } catch (const std::out_of_range &) {
-                chunk_err[ci] = 1;  // the reference dies in std::string::substr here (malformed bubble)
             }
         });
-        for (int ce : chunk_err)
-            if (ce) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): site string outside an aligned row");
+        for (auto &scx : schunks)
+            if (scx.err) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): site string outside an aligned row");
         std::vector<uint64_t> chunk_base(n_pch + 1, 0);
-        for (size_t c = 0; c < n_pch; ++c) chunk_base[c + 1] = chunk_base[c] + chunk_strings[c].size();
+        for (size_t c = 0; c < n_pch; ++c) chunk_base[c + 1] = chunk_base[c] + schunks[c].strings.size();
         const size_t n_strings = chunk_base[n_pch];
         std::vector<uint64_t> str_sum(n_strings), str_len(n_strings);
         std::vector<uint8_t> str_ok(n_strings), str_miss(n_strings);
@@ -667,8 +738,8 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             std::string text;
             std::vector<uint64_t> soff(n_strings + 1, 0);
             size_t q = 0;
-            for (auto &cs : chunk_strings)
-                for (auto &sx : cs) { soff[q] = text.size(); str_len[q] = sx.size(); text += sx; ++q; }
+            for (auto &scx : schunks)
+                for (auto &sx : scx.strings) { soff[q] = text.size(); str_len[q] = sx.size(); text += sx; ++q; }
             soff[n_strings] = text.size();
             st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)n_strings, low, up, str_sum.data(), str_ok.data(),
                                str_miss.data());
@@ -683,7 +754,7 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
         t0 = clk::now();
         std::vector<uint64_t> vc(NT);  // var_count of each bubble (1-based over non-empty alignments)
         for (size_t ti = 0; ti < NT; ++ti) {
-            if (!msa[ti].rows.empty()) ++var_count;
+            if (result_of(ti).n_rows) ++var_count;
             vc[ti] = var_count;
         }
         struct ChunkOut {
@@ -693,82 +764,87 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
         std::vector<ChunkOut> outs(n_pch);
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
             ChunkOut &o = outs[ci];
+            const SiteChunk &sc = schunks[ci];
             std::string cov_info, fre_info;
-            std::vector<double> tc;
+            double tc[256];
             for (size_t ti = tb; ti < te; ++ti) {
                 const Task &t = tasks[ti];
-                const Msa &m = msa[ti];
-                if (m.rows.empty()) continue;
-                const size_t R = m.rows.size();
+                const pf_bubble_result &r = result_of(ti);
+                if (r.n_rows == 0) continue;
+                const size_t R = r.n_rows, L = r.n_cols;
+                const char *rows = bx_.otext.p + r.rows_off;
                 const uint64_t my_vc = vc[ti];
-                for (const std::string &row : m.rows) {
+                for (size_t p = 0; p < R; ++p) {
                     put_uint(o.s_var, my_vc);
                     o.s_var += t.strict ? "\t1\t" : "\t0\t";
                     put_uint(o.s_var, t.u + 1);
                     o.s_var.push_back('\t');
                     put_uint(o.s_var, (t.exit_ov >> 1) + 1);
                     o.s_var.push_back('\t');
-                    o.s_var += row;
+                    o.s_var.append(rows + p * L, L);
                     o.s_var.push_back('\n');
                 }
                 o.core_cov += (uint64_t)t.core_mean;
                 o.core_num++;
-                const TaskSites &ts = tsites[ti];
-                const std::vector<uint32_t> &vs = ts.cols;
+                const pf_bubble_site *sites = bx_.osites.p + r.site_off;
+                const uint32_t *ilen = bx_.oilen.p + r.ilen_off;
                 const size_t usize = g_.size_bp(t.u), esize = g_.size_bp(t.exit_ov >> 1);
+                const uint32_t ns = r.n_sites;
                 uint32_t indel = 0;
-                for (size_t i = 0; i < vs.size(); ++i) {
-                    const uint32_t site = vs[i];
+                uint32_t gcur = sc.first_group[ti - tb];  // walks this bubble's GroupRefs (branching only)
+                for (uint32_t i = 0; i < ns; ++i) {
+                    const pf_bubble_site &sr = sites[i];
+                    const uint8_t *grp = bx_.ogroups.p + r.group_off + (uint64_t)i * R;
                     // distance to the neighbouring sites / unitig ends (src/CDBG.cpp:1279-1298)
                     uint32_t vd;
                     if (i == 0) {
-                        if (vs.size() != 1) vd = (uint32_t)std::min((size_t)(uint32_t)(vs[1] - vs[0] - 1), usize);
+                        if (ns != 1) vd = (uint32_t)std::min((size_t)(uint32_t)(sites[1].col - sites[0].col - 1), usize);
                         else vd = (uint32_t)std::min(usize, esize);
-                    } else if (i == vs.size() - 1) {
-                        vd = (uint32_t)std::min((size_t)(uint32_t)(vs[i] - vs[i - 1] - 1), esize);
+                    } else if (i == ns - 1) {
+                        vd = (uint32_t)std::min((size_t)(uint32_t)(sites[i].col - sites[i - 1].col - 1), esize);
                     } else {
-                        vd = std::min((uint32_t)(vs[i] - vs[i - 1] - 1), (uint32_t)(vs[i + 1] - vs[i] - 1));
+                        vd = std::min((uint32_t)(sites[i].col - sites[i - 1].col - 1), (uint32_t)(sites[i + 1].col - sites[i].col - 1));
                     }
-                    uint16_t maxnum = 0;
-                    for (size_t p = 0; p < R; ++p) maxnum = std::max(maxnum, m.group_at(site, (uint32_t)p));
-                    const bool is_indel = std::find(m.indel_pos.begin(), m.indel_pos.end(), site) != m.indel_pos.end();
-                    tc.assign(maxnum, 0.0);
+                    const uint32_t maxnum = sr.maxnum;
+                    for (uint32_t x = 0; x < maxnum; ++x) tc[x] = 0.0;
                     double denom;
-                    if (is_indel) ++indel;  // counted even when the site is dropped below (src/CDBG.cpp:1526)
+                    if (sr.is_indel) ++indel;  // counted even when the site is dropped below (src/CDBG.cpp:1526)
                     if (t.strict) {
-                        for (size_t p = 0; p < R; ++p) tc[m.group_at(site, (uint32_t)p) - 1] += t.cov[p];
+                        for (size_t p = 0; p < R; ++p) tc[grp[p] - 1] += t.cov[p];
                         denom = t.cov_sum;
                     } else {
                         const uint64_t base = chunk_base[ci];
                         bool ok = true;
                         double sum = 0;
-                        for (uint32_t gi = ts.group_first[i]; gi < ts.group_first[i + 1] && ok; ++gi) {
-                            const GroupRef &gr = ts.groups[gi];
-                            double &acc = tc[gi - ts.group_first[i]];
-                            for (uint64_t q = base + gr.first; q < base + gr.first + gr.count; ++q) {
-                                if (!str_ok[q]) { ok = false; break; }
-                                acc += (double)str_sum[q] / (double)(str_len[q] - (size_t)k + 1);
+                        for (uint32_t gi = 0; gi < maxnum; ++gi) {
+                            const GroupRef &gr = sc.groups[gcur + gi];
+                            if (ok) {
+                                for (uint64_t q = base + gr.first; q < base + gr.first + gr.count; ++q) {
+                                    if (!str_ok[q]) { ok = false; break; }
+                                    tc[gi] += (double)str_sum[q] / (double)(str_len[q] - (size_t)k + 1);
+                                }
+                                if (ok) sum += tc[gi];
                             }
-                            sum += acc;
                         }
+                        gcur += maxnum;
                         if (!ok) continue;
                         denom = sum;
                     }
                     cov_info.clear();
                     fre_info.clear();
-                    for (double x : tc) {
-                        put_double(cov_info, x);
+                    for (uint32_t x = 0; x < maxnum; ++x) {
+                        put_double(cov_info, tc[x]);
                         cov_info.push_back('\t');
-                        put_double(fre_info, x / denom);
+                        put_double(fre_info, tc[x] / denom);
                         fre_info.push_back('\n');
                     }
                     cov_info += t.strict ? "1\t" : "0\t";
-                    if (is_indel) put_uint(cov_info, m.indel_len[indel - 1]);
+                    if (sr.is_indel) put_uint(cov_info, ilen[indel - 1]);
                     else cov_info.push_back('0');
                     cov_info.push_back('\t');
                     put_uint(cov_info, my_vc);
                     cov_info.push_back('\t');
-                    put_uint(cov_info, vs.size());
+                    put_uint(cov_info, ns);
                     cov_info.push_back('\t');
                     put_uint(cov_info, vd);
                     cov_info += "\t\n";
@@ -792,14 +868,6 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             core_cov_ += o.core_cov;
             core_num_ += o.core_num;
         }
-        // release the per-bubble strings in parallel (millions of small allocations)
-        parallel_chunks(NT, PCH, T, [&](size_t, size_t tb, size_t te) {
-            for (size_t ti = tb; ti < te; ++ti) {
-                std::vector<std::string>().swap(paths[ti]);
-                msa[ti] = Msa();
-                tsites[ti] = TaskSites();
-            }
-        });
         times_.format_s += since(t0);
     }
 

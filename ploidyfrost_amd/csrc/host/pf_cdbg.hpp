@@ -22,11 +22,15 @@
 #include <string>
 #include <vector>
 
-#include "pf_host_align.hpp"
 #include "pf_host_graph.hpp"
+#include "pf_pinned.hpp"
 #include "ploidyfrost_hip.h"
 
 namespace pfh {
+
+struct Scoring {
+    double match = 2, mismatch = -1, gap = -3;
+};
 
 struct PhaseTimes {
     double bfs_device_s = 0, replay_s = 0, bubble_write_s = 0;
@@ -97,7 +101,20 @@ private:
     std::vector<uint8_t> flags_;
     std::vector<uint32_t> plus_, minus_;  // 0 = NULL, id = u + 1
 
-    std::unique_ptr<Aligner> aligner_;
+    // pinned exchange buffers of pf_align_bubbles, reused from pass to pass
+    struct BubbleExchange {
+        PinnedBuf<char> text, otext;
+        PinnedBuf<pf_bubble_path> paths;
+        PinnedBuf<pf_bubble_task> tasks;
+        PinnedBuf<pf_bubble_result> res;
+        PinnedBuf<pf_bubble_site> osites;
+        PinnedBuf<uint8_t> ogroups;
+        PinnedBuf<uint32_t> oilen;
+        void release_all() {
+            text.release(); otext.release(); paths.release(); tasks.release(); res.release(); osites.release();
+            ogroups.release(); oilen.release();
+        }
+    } bx_;
     PhaseTimes times_;
     std::string last_allfre_;
     uint64_t allele_[4] = {0, 0, 0, 0};
