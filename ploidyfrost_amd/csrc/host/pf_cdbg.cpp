@@ -115,6 +115,20 @@ int CDBG::write_file(const std::string &name, const std::string &data) {
     return 0;
 }
 
+// thread-safe: touches no member state (the caller accounts the bytes)
+int CDBG::write_pieces(const std::string &name, const std::vector<const std::string *> &pieces, uint64_t &bytes) const {
+    bytes = 0;
+    for (const std::string *p : pieces) bytes += p->size();
+    if (!write_files_) return 0;
+    FILE *f = fopen((outdir_ + "/" + name).c_str(), "wb");
+    if (!f) return 1;
+    int rc = 0;
+    for (const std::string *p : pieces)
+        if (!p->empty() && fwrite(p->data(), 1, p->size(), f) != p->size()) { rc = 1; break; }
+    fclose(f);
+    return rc;
+}
+
 // ---- setUnitigId (reference src/CDBG.cpp:121-143) -----------------------------------------
 int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size_t &) {
     if (status_) return status_;
@@ -227,7 +241,7 @@ void CDBG::replay(const pf_bfs_record &r, const uint32_t *list) {
 }
 
 // ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
-int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &) {
+int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thr) {
     if (status_) return status_;
     if (!quiet_) printf("CDBG::findSuperBubble(): Finding superbubbles\n");
     if (write_files_ && ensure_dir()) return status_;
@@ -273,26 +287,49 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         printf("CDBG::findSuperBubble():  Real time : %gs\n", since(t_all));
     }
     t0 = clk::now();
-    std::string out = "BubbleId\tEntrance\tStrand\tExit\tisSimple\tisComplex\n";
-    uint64_t nb = 0;
-    for (uint32_t u = 0; u < N; ++u) {
-        const uint8_t f = flags_[u];
-        if ((f & 3) == 0) continue;
-        for (int side = 0; side < 2; ++side) {
-            const bool ps = side == 0;
-            if (!(f & (ps ? B_PLUS : B_MINUS))) continue;
-            put_uint(out, ++nb);
-            out.push_back('\t');
-            put_uint(out, u + 1);
-            out += ps ? "\t+\t" : "\t-\t";
-            put_uint(out, ps ? plus_[u] : minus_[u]);
-            out += (f & (ps ? B_STRICT_P : B_STRICT_M)) ? "\t1" : "\t0";
-            out += (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? "\t1\n" : "\t0\n";
+    // super_bubble.txt: one row per open endpoint side in unitig order; rows are numbered with a prefix
+    // count so that unitig ranges can be formatted in parallel
+    const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
+    constexpr size_t UCH = 16384;
+    const size_t n_uch = n_chunks_of(N, UCH);
+    std::vector<uint64_t> row_base(n_uch + 1, 0);
+    parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
+        uint64_t c = 0;
+        for (size_t u = ub; u < ue; ++u) c += (flags_[u] & B_PLUS ? 1 : 0) + (flags_[u] & B_MINUS ? 1 : 0);
+        row_base[ci + 1] = c;
+    });
+    for (size_t c = 0; c < n_uch; ++c) row_base[c + 1] += row_base[c];
+    std::vector<std::string> pieces(n_uch + 1);
+    pieces[0] = "BubbleId\tEntrance\tStrand\tExit\tisSimple\tisComplex\n";
+    parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
+        std::string &out = pieces[ci + 1];
+        uint64_t nb = row_base[ci];
+        for (uint32_t u = (uint32_t)ub; u < (uint32_t)ue; ++u) {
+            const uint8_t f = flags_[u];
+            if ((f & 3) == 0) continue;
+            for (int side = 0; side < 2; ++side) {
+                const bool ps = side == 0;
+                if (!(f & (ps ? B_PLUS : B_MINUS))) continue;
+                put_uint(out, ++nb);
+                out.push_back('\t');
+                put_uint(out, u + 1);
+                out += ps ? "\t+\t" : "\t-\t";
+                put_uint(out, ps ? plus_[u] : minus_[u]);
+                out += (f & (ps ? B_STRICT_P : B_STRICT_M)) ? "\t1" : "\t0";
+                out += (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? "\t1\n" : "\t0\n";
+            }
         }
-    }
+    });
+    const uint64_t nb = row_base[n_uch];
     n_super_bubble_ = nb;
     times_.bubbles_out = nb;
-    if (write_file(outpre + "_super_bubble.txt", out)) return status_;
+    {
+        std::vector<const std::string *> ptrs;
+        for (auto &pc : pieces) ptrs.push_back(&pc);
+        uint64_t bytes = 0;
+        if (write_pieces(outpre + "_super_bubble.txt", ptrs, bytes)) return fail(PF_ERR_ARG, "CDBG:: Open super_bubble file error");
+        out_bytes_ += bytes;
+    }
     times_.bubble_write_s = since(t0);
     times_.find_total_s = since(t_all);
     if (!quiet_) printf("CDBG::findSuperBubble(): %llu  SuperBubbles Found\n", (unsigned long long)nb);
@@ -405,61 +442,80 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     };
 
     // the ten per-site streams + alignseq
-    std::string allfre, s_var, fre[4], cov[4];
     uint64_t var_count = 0;
     allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
     core_cov_ = core_num_ = 0;
 
-    const size_t CHUNK = 1u << 19;  // bubbles per batch
-    constexpr size_t PCH = 256;     // bubbles per parallel work item
-    std::vector<Task> tasks;
-    uint32_t scan_u = 0;
-    while (scan_u < N) {
-        // ---- scan ------------------------------------------------------------------------------
-        t0 = clk::now();
-        tasks.clear();
-        for (; scan_u < N && tasks.size() < CHUNK; ++scan_u) {
-            const uint32_t u = scan_u;
-            uint8_t &f = flags_[u];
-            while ((f & 3) != 0) {
-                bool ps;
-                if (f & B_PLUS) {
-                    ps = true;
-                    if (f & B_COMPLEX_P) { f &= (uint8_t)~B_PLUS; continue; }
-                } else {
-                    ps = false;
-                    if (f & B_COMPLEX_M) { f &= (uint8_t)~B_MINUS; break; }
+    // ---- scan, part A (parallel): what each open endpoint side would do if it is still open when the
+    //      driver loop of src/CDBG.cpp:1146-1186 reaches it -- exit, ownership, coverage gate, sorted
+    //      inner unitigs.  Depends only on static state (partners, strict/complex bits, CSR, strings).
+    t0 = clk::now();
+    struct SideRec {
+        Task t;
+        uint8_t plus_side;
+        uint8_t kind;  // 1 complex, 2 the other endpoint owns the bubble, 3 processed here
+        uint8_t aligned;
+        uint8_t err;   // 1 missing k-mer, 2 exit unreachable (raised only if the side is still open)
+        uint32_t err_unitig;
+    };
+    constexpr size_t UCH = 4096;
+    const size_t n_uch = n_chunks_of(N, UCH);
+    std::vector<std::vector<SideRec>> side_chunks(n_uch);
+    parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
+        std::vector<SideRec> &out = side_chunks[ci];
+        for (uint32_t u = (uint32_t)ub; u < (uint32_t)ue; ++u) {
+            const uint8_t f = flags_[u];
+            if ((f & 3) == 0) continue;
+            for (int side = 0; side < 2; ++side) {
+                const bool ps = side == 0;
+                if (!(f & (ps ? B_PLUS : B_MINUS))) continue;
+                SideRec r;
+                r.plus_side = ps;
+                r.kind = 0;
+                r.aligned = 0;
+                r.err = 0;
+                r.err_unitig = 0;
+                r.t.u = u;
+                if (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) {
+                    r.kind = 1;
+                    out.push_back(r);
+                    continue;
                 }
                 const uint32_t uo = 2 * u + (ps ? 0 : 1);
                 const bool strict = (f & (ps ? B_STRICT_P : B_STRICT_M)) != 0;
-                if (missing(u)) return status_;  // core = readCov(u)
+                if (cov_miss[u]) { r.err = 1; r.err_unitig = u; out.push_back(r); continue; }  // core = readCov(u)
                 uint32_t exit_ov;
                 if (strict) {
                     exit_ov = first_succ(first_succ(uo));
                 } else {
                     const uint32_t want = ps ? plus_[u] : minus_[u];
                     exit_ov = first_succ(uo);
-                    while (exit_ov != NONE && (exit_ov >> 1) + 1 != want) exit_ov = first_succ(exit_ov);
-                    if (exit_ov == NONE) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): exit of a bubble is not reachable");
+                    // (bounded: a walk longer than the graph means the partner is not on the first-successor chain)
+                    for (uint32_t steps = 0; exit_ov != NONE && (exit_ov >> 1) + 1 != want; ++steps) {
+                        if (steps > N) { exit_ov = NONE; break; }
+                        exit_ov = first_succ(exit_ov);
+                    }
                 }
+                if (exit_ov == NONE) { r.err = 2; out.push_back(r); continue; }
                 const uint32_t eu = exit_ov >> 1;
+                r.t.entrance_ov = uo;
+                r.t.exit_ov = exit_ov;
+                r.t.strict = strict;
                 if (g_.seq(u).compare(g_.seq(eu)) < 0) {  // the other endpoint owns this bubble
-                    f &= (uint8_t) ~(ps ? B_PLUS : B_MINUS);
+                    r.kind = 2;
+                    out.push_back(r);
                     continue;
                 }
-                Task t;
-                t.u = u;
-                t.entrance_ov = uo;
-                t.exit_ov = exit_ov;
-                t.strict = strict;
-                t.core_mean = mean_of(u);
+                r.kind = 3;
+                r.t.core_mean = mean_of(u);
                 bool aligned = true;
                 if (strict) {
-                    for (int b = 0; b < 4 && aligned; ++b) {
+                    Task &t = r.t;
+                    for (int b = 0; b < 4 && aligned && !r.err; ++b) {
                         const uint32_t w = succ_row(uo)[b];
                         if (w == NONE) continue;
                         t.inner[t.n_inner++] = w;
-                        if (missing(w >> 1)) return status_;
+                        if (cov_miss[w >> 1]) { r.err = 1; r.err_unitig = w >> 1; break; }
                         if (cov_min[w >> 1] > low && cov_min[w >> 1] < up) {
                             const double mcov = mean_of(w >> 1);
                             t.cov[t.n_cov++] = mcov;
@@ -468,24 +524,52 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                             aligned = false;
                         }
                     }
-                    if (aligned) {
+                    if (aligned && !r.err) {
                         // the reference also reads the predecessors' coverage and drops it (:1224-1239)
                         for (int b = 0; b < 4; ++b) {
                             const uint32_t w = pred_[(size_t)uo * 4 + b];
-                            if (w != NONE && missing(w >> 1)) return status_;
+                            if (w != NONE && cov_miss[w >> 1]) { r.err = 1; r.err_unitig = w >> 1; break; }
                         }
-                        sort_inner(g_, t.cov, t.inner, 0, (int)t.n_cov - 1);
+                        if (!r.err) sort_inner(g_, t.cov, t.inner, 0, (int)t.n_cov - 1);
                     }
                 }
-                if (aligned) tasks.push_back(t);
-                // src/CDBG.cpp:1656-1679: both endpoint sides are done
-                f &= (uint8_t) ~(ps ? B_PLUS : B_MINUS);
-                flags_[eu] &= (uint8_t) ~(plus_of(exit_ov) ? B_MINUS : B_PLUS);
+                r.aligned = aligned;
+                out.push_back(r);
             }
         }
-        times_.scan_s += since(t0);
-        if (tasks.empty()) continue;
-        const size_t NT = tasks.size();
+    });
+    // ---- scan, part B (sequential, light): the driver loop itself -- a side is handled only if its bit
+    //      is still set when its unitig comes up; handling a bubble closes both endpoint sides (:1656-1679)
+    std::vector<Task> all_tasks;
+    for (auto &chunk : side_chunks) {
+        for (const SideRec &r : chunk) {
+            const uint32_t u = r.t.u;
+            const uint8_t own = r.plus_side ? B_PLUS : B_MINUS;
+            if (!(flags_[u] & own)) continue;
+            if (r.kind == 1) { flags_[u] &= (uint8_t)~own; continue; }
+            if (r.err == 1) { missing(r.err_unitig); return status_; }
+            if (r.err == 2) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): exit of a bubble is not reachable");
+            flags_[u] &= (uint8_t)~own;
+            if (r.kind == 2) continue;
+            if (r.aligned) all_tasks.push_back(r.t);
+            flags_[r.t.exit_ov >> 1] &= (uint8_t) ~(plus_of(r.t.exit_ov) ? B_MINUS : B_PLUS);
+        }
+        std::vector<SideRec>().swap(chunk);
+    }
+    times_.scan_s += since(t0);
+
+    const size_t CHUNK = 1u << 19;  // bubbles per batch
+    constexpr size_t PCH = 256;     // bubbles per parallel work item
+    struct ChunkOut {
+        std::string s_var, allfre, fre[4], cov[4];
+        uint64_t allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
+    };
+    std::vector<std::vector<ChunkOut>> all_outs;  // per batch, per work item: concatenated at the end
+    for (size_t batch0 = 0; batch0 < all_tasks.size(); batch0 += CHUNK) {
+        t0 = clk::now();
+        const Task *tasks = all_tasks.data() + batch0;
+        const size_t NT_ = std::min(CHUNK, all_tasks.size() - batch0);
+        const size_t NT = NT_;
         const size_t n_pch = n_chunks_of(NT, PCH);
         times_.tasks += NT;
 
@@ -757,11 +841,8 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             if (result_of(ti).n_rows) ++var_count;
             vc[ti] = var_count;
         }
-        struct ChunkOut {
-            std::string s_var, allfre, fre[4], cov[4];
-            uint64_t allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
-        };
-        std::vector<ChunkOut> outs(n_pch);
+        all_outs.emplace_back(n_pch);
+        std::vector<ChunkOut> &outs = all_outs.back();
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
             ChunkOut &o = outs[ci];
             const SiteChunk &sc = schunks[ci];
@@ -858,13 +939,7 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             }
         });
         for (ChunkOut &o : outs) {
-            s_var += o.s_var;
-            allfre += o.allfre;
-            for (int a = 0; a < 4; ++a) {
-                fre[a] += o.fre[a];
-                cov[a] += o.cov[a];
-                allele_[a] += o.allele[a];
-            }
+            for (int a = 0; a < 4; ++a) allele_[a] += o.allele[a];
             core_cov_ += o.core_cov;
             core_num_ += o.core_num;
         }
@@ -873,12 +948,33 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
 
     t0 = clk::now();
     static const char *kArity[4] = {"bi", "tri", "tetra", "penta"};
-    if (write_file(outpre + "_allele_frequency.txt", allfre)) return status_;
-    last_allfre_.swap(allfre);
-    if (write_file(outpre + "_alignseq.txt", s_var)) return status_;
-    for (int a = 0; a < 4; ++a) {
-        if (write_file(outpre + "_" + kArity[a] + "fre.txt", fre[a])) return status_;
-        if (write_file(outpre + "_" + kArity[a] + "cov.txt", cov[a])) return status_;
+    {
+        // ten files, each the in-order concatenation of the per-work-item pieces; written concurrently
+        std::vector<std::pair<std::string, std::vector<const std::string *>>> files(10);
+        files[0].first = outpre + "_allele_frequency.txt";
+        files[1].first = outpre + "_alignseq.txt";
+        for (int a = 0; a < 4; ++a) {
+            files[2 + a].first = outpre + "_" + kArity[a] + "fre.txt";
+            files[6 + a].first = outpre + "_" + kArity[a] + "cov.txt";
+        }
+        for (auto &batch : all_outs)
+            for (ChunkOut &o : batch) {
+                files[0].second.push_back(&o.allfre);
+                files[1].second.push_back(&o.s_var);
+                for (int a = 0; a < 4; ++a) {
+                    files[2 + a].second.push_back(&o.fre[a]);
+                    files[6 + a].second.push_back(&o.cov[a]);
+                }
+            }
+        std::vector<int> rc(10, 0);
+        std::vector<uint64_t> bytes(10, 0);
+        parallel_chunks(10, 1, T, [&](size_t i, size_t, size_t) { rc[i] = write_pieces(files[i].first, files[i].second, bytes[i]); });
+        for (int i = 0; i < 10; ++i) {
+            out_bytes_ += bytes[i];
+            if (rc[i]) return fail(PF_ERR_ARG, "CDBG:: PloidyEstimation():Open file error");
+        }
+        last_allfre_.clear();
+        for (const std::string *piece : files[0].second) last_allfre_ += *piece;
     }
     times_.write_s = since(t0);
     times_.ploidy_total_s = since(t_all);

@@ -80,6 +80,7 @@ private:
     int fail(int st, const std::string &msg);
     int ensure_dir();
     int write_file(const std::string &name, const std::string &data);
+    int write_pieces(const std::string &name, const std::vector<const std::string *> &pieces, uint64_t &bytes) const;
     // MyUnitig state (reference src/MyUnitig.hpp), array-indexed
     void side_self(uint32_t u, bool plus_side);
     void release(uint32_t ex, uint32_t me);

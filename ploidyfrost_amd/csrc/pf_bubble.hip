@@ -23,6 +23,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -83,6 +85,7 @@ struct BubParams {
     uint64_t work_per_wave;
     uint32_t work_bytes;    // bytes available per wave for one NW job (LDS or global)
     int final_tier;
+    unsigned long long *task_clk;  // diagnostic: per-task wall clock ticks (100 MHz), or nullptr
 };
 
 struct BubOut {
@@ -596,7 +599,9 @@ __global__ __launch_bounds__(64) void k_bubble(BubParams p, BubOut o) {
     uint8_t *scr = p.scratch + (uint64_t)blockIdx.x * p.scratch_per_wave;
     for (uint32_t q = blockIdx.x; q < p.n; q += gridDim.x) {
         const uint32_t job = p.idx[q];
+        const unsigned long long c0 = p.task_clk ? wall_clock64() : 0;
         const int rc = bubble_task<LDS>(p, o, job, nw_base, scr);
+        if (p.task_clk && lane_id() == 0) p.task_clk[job] = wall_clock64() - c0;
         if (rc != 0 && lane_id() == 0) {
             if (p.final_tier) {
                 pf_bubble_result r;
@@ -714,12 +719,21 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
                   std::fabs(match) < 1e6 && std::fabs(mismatch) < 1e6 && std::fabs(gap) < 1e6) ? 1 : 0;
     p.seq = ctx->d_seq; p.off = ctx->d_off; p.len = ctx->d_len; p.n_unitigs = ctx->N;
     const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
-    const int max_waves = ctx->n_cu * 8;
+    // waves in flight: the kernel is a chain of dependent LDS / global accesses per bubble, so it wants
+    // every wave slot the LDS budget allows (5 KiB class: 32 per CU by LDS, capped at 24)
+    const int max_waves = ctx->n_cu * 24;
     p.caps = std_caps;
     p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
     p.scratch = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
     if (!p.scratch) return PF_ERR_HIP;
 
+    unsigned long long *d_clk = nullptr;
+    const bool want_clk = getenv("PF_BUBBLE_STATS") != nullptr;
+    if (want_clk) {
+        PF_HIP(hipMalloc(&d_clk, (size_t)n_tasks * 8));
+        PF_HIP(hipMemsetAsync(d_clk, 0, (size_t)n_tasks * 8, st));
+        p.task_clk = d_clk;
+    }
     static bool attr_set = false;
     if (!attr_set) {
         PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bubble<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
@@ -733,7 +747,8 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         p.idx = d_idx + idx_off;
         p.n = nc;
         p.work_bytes = (uint32_t)cls_bytes[c];
-        const int grid = (int)std::min<uint32_t>(nc, (uint32_t)max_waves);
+        const int per_cu = c == 0 ? 24 : (c == 1 ? 7 : 2);
+        const int grid = (int)std::min<uint32_t>(nc, (uint32_t)(ctx->n_cu * per_cu));
         ctx_begin(ctx, PF_K_BUBBLE);
         k_bubble<true><<<grid, 64, cls_bytes[c], st>>>(p, o);
         ctx_end(ctx);
@@ -783,6 +798,24 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         k_bubble<false><<<grid, 64, 0, st>>>(p, o);
         ctx_end(ctx);
         PF_HIP(hipStreamSynchronize(st));
+    }
+    if (want_clk) {
+        std::vector<unsigned long long> clk(n_tasks);
+        PF_HIP(hipMemcpy(clk.data(), d_clk, (size_t)n_tasks * 8, hipMemcpyDeviceToHost));
+        hipFree(d_clk);
+        std::vector<unsigned long long> srt(clk);
+        std::sort(srt.begin(), srt.end());
+        unsigned long long tot = 0;
+        for (auto c : srt) tot += c;
+        fprintf(stderr, "[pf_align_bubbles] %u tasks: ticks(10ns) sum %llu  median %llu  p90 %llu  p99 %llu  p99.9 %llu  max %llu\n", n_tasks, tot,
+                srt[n_tasks / 2], srt[(size_t)(n_tasks * 0.9)], srt[(size_t)(n_tasks * 0.99)], srt[(size_t)(n_tasks * 0.999)], srt[n_tasks - 1]);
+        for (int top = 0; top < 5 && top < (int)n_tasks; ++top) {
+            const uint32_t t = (uint32_t)(std::max_element(clk.begin(), clk.end()) - clk.begin());
+            fprintf(stderr, "   slowest: task %u ticks %llu paths %u lens", t, clk[t], ht[t].n_paths);
+            for (uint32_t i = 0; i < ht[t].n_paths && i < 8; ++i) fprintf(stderr, " %u", hp[ht[t].path_first + i].len);
+            fprintf(stderr, "\n");
+            clk[t] = 0;
+        }
     }
     unsigned long long heads[4];
     PF_HIP(hipMemcpy(heads, o.heads, 32, hipMemcpyDeviceToHost));
