@@ -1,5 +1,6 @@
 #include "pf_cdbg.hpp"
 
+#include <fcntl.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -127,6 +128,19 @@ int CDBG::write_pieces(const std::string &name, const std::vector<const std::str
         if (!p->empty() && fwrite(p->data(), 1, p->size(), f) != p->size()) { rc = 1; break; }
     fclose(f);
     return rc;
+}
+
+// Several files, each the concatenation of its pieces; one writer thread per file (concurrent
+// writers into one tmpfs/ext4 inode only contend on its lock).
+int CDBG::write_many(const std::vector<std::pair<std::string, std::vector<const std::string *>>> &files, unsigned threads) {
+    std::vector<int> rc(files.size(), 0);
+    std::vector<uint64_t> bytes(files.size(), 0);
+    parallel_chunks(files.size(), 1, threads, [&](size_t i, size_t, size_t) { rc[i] = write_pieces(files[i].first, files[i].second, bytes[i]); });
+    for (size_t i = 0; i < files.size(); ++i) {
+        out_bytes_ += bytes[i];
+        if (rc[i]) return fail(PF_ERR_ARG, "CDBG:: Open " + files[i].first + " file error");
+    }
+    return 0;
 }
 
 // ---- setUnitigId (reference src/CDBG.cpp:121-143) -----------------------------------------
@@ -259,12 +273,14 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     uint64_t n_cand = 0;
     int st = pf_count_candidates(ctx_, 0, N, &n_cand);
     if (st != PF_OK) return fail(st, pf_last_error(ctx_));
-    std::vector<pf_bfs_record> rec(std::max<uint64_t>(n_cand, 1));
-    std::vector<uint32_t> pool(std::max<uint64_t>(n_cand * 6, 1024));
+    // pinned, reused from pass to pass; the pool guess leaves room for the per-wave chunk slack
+    bx_.bfs_rec.ensure(ctx_, std::max<uint64_t>(n_cand, 1));
+    bx_.bfs_pool.ensure(ctx_, std::max<uint64_t>(n_cand * 6 + (4u << 20), 1024));
+    pf_bfs_record *rec = bx_.bfs_rec.p;
     uint64_t n_rec = 0, used = 0;
     for (;;) {
-        st = pf_bfs_candidates(ctx_, 0, N, rec.data(), rec.size(), pool.data(), pool.size(), &n_rec, &used);
-        if (st == PF_ERR_OVERFLOW && used > pool.size()) { pool.resize(used + used / 8); continue; }
+        st = pf_bfs_candidates(ctx_, 0, N, rec, bx_.bfs_rec.cap, bx_.bfs_pool.p, bx_.bfs_pool.cap, &n_rec, &used);
+        if (st == PF_ERR_OVERFLOW && used > bx_.bfs_pool.cap) { bx_.bfs_pool.ensure(ctx_, used + used / 8); continue; }
         break;
     }
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
@@ -279,7 +295,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         const pf_bfs_record &r = rec[i];
         const uint32_t u = r.entrance >> 1;
         if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
-        replay(r, pool.data() + r.list_off);
+        replay(r, bx_.bfs_pool.p + r.list_off);
     }
     times_.replay_s = since(t0);
     if (!quiet_) {
@@ -324,11 +340,10 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     n_super_bubble_ = nb;
     times_.bubbles_out = nb;
     {
-        std::vector<const std::string *> ptrs;
-        for (auto &pc : pieces) ptrs.push_back(&pc);
-        uint64_t bytes = 0;
-        if (write_pieces(outpre + "_super_bubble.txt", ptrs, bytes)) return fail(PF_ERR_ARG, "CDBG:: Open super_bubble file error");
-        out_bytes_ += bytes;
+        std::vector<std::pair<std::string, std::vector<const std::string *>>> files(1);
+        files[0].first = outpre + "_super_bubble.txt";
+        for (auto &pc : pieces) files[0].second.push_back(&pc);
+        if (write_many(files, T)) return status_;
     }
     times_.bubble_write_s = since(t0);
     times_.find_total_s = since(t_all);
@@ -422,10 +437,13 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
 
     // C1 for every unitig in one launch (the reference calls readCov per use)
     auto t0 = clk::now();
-    std::vector<uint64_t> cov_sum(N);
-    std::vector<uint32_t> cov_min(N);
-    std::vector<uint8_t> cov_miss(N);
-    int st = pf_unitig_cov(ctx_, 0, N, cov_sum.data(), cov_min.data(), cov_miss.data());
+    bx_.cov_sum.ensure(ctx_, N);
+    bx_.cov_min.ensure(ctx_, N);
+    bx_.cov_miss.ensure(ctx_, N);
+    const uint64_t *cov_sum = bx_.cov_sum.p;
+    const uint32_t *cov_min = bx_.cov_min.p;
+    const uint8_t *cov_miss = bx_.cov_miss.p;
+    int st = pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
     if (st != PF_OK && st != PF_ERR_MISSING_KMER) return fail(st, std::string("CDBG::PloidyEstimation(): ") + pf_last_error(ctx_));
     times_.cov_device_s = since(t0);
     auto mean_of = [&](uint32_t u) { return (double)cov_sum[u] / (double)g_.len_km(u); };
@@ -966,13 +984,7 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                     files[6 + a].second.push_back(&o.cov[a]);
                 }
             }
-        std::vector<int> rc(10, 0);
-        std::vector<uint64_t> bytes(10, 0);
-        parallel_chunks(10, 1, T, [&](size_t i, size_t, size_t) { rc[i] = write_pieces(files[i].first, files[i].second, bytes[i]); });
-        for (int i = 0; i < 10; ++i) {
-            out_bytes_ += bytes[i];
-            if (rc[i]) return fail(PF_ERR_ARG, "CDBG:: PloidyEstimation():Open file error");
-        }
+        if (write_many(files, T)) return status_;
         last_allfre_.clear();
         for (const std::string *piece : files[0].second) last_allfre_ += *piece;
     }

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "pf_host_graph.hpp"
@@ -81,6 +82,7 @@ private:
     int ensure_dir();
     int write_file(const std::string &name, const std::string &data);
     int write_pieces(const std::string &name, const std::vector<const std::string *> &pieces, uint64_t &bytes) const;
+    int write_many(const std::vector<std::pair<std::string, std::vector<const std::string *>>> &files, unsigned threads);
     // MyUnitig state (reference src/MyUnitig.hpp), array-indexed
     void side_self(uint32_t u, bool plus_side);
     void release(uint32_t ex, uint32_t me);
@@ -111,9 +113,15 @@ private:
         PinnedBuf<pf_bubble_site> osites;
         PinnedBuf<uint8_t> ogroups;
         PinnedBuf<uint32_t> oilen;
+        PinnedBuf<pf_bfs_record> bfs_rec;
+        PinnedBuf<uint32_t> bfs_pool;
+        PinnedBuf<uint64_t> cov_sum;
+        PinnedBuf<uint32_t> cov_min;
+        PinnedBuf<uint8_t> cov_miss;
         void release_all() {
             text.release(); otext.release(); paths.release(); tasks.release(); res.release(); osites.release();
-            ogroups.release(); oilen.release();
+            ogroups.release(); oilen.release(); bfs_rec.release(); bfs_pool.release(); cov_sum.release(); cov_min.release();
+            cov_miss.release();
         }
     } bx_;
     PhaseTimes times_;

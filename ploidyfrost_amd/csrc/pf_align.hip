@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -72,6 +73,7 @@ struct AlnParams {
     const uint32_t *idx;  // job indices of this launch
     uint32_t n;
     double M, D, G;
+    int integral;
     // per-wave staging
     char *st_text;
     uint32_t *st_gaps;
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64) void k_align(AlnParams p, AlnOut o) {
         const uint32_t job = p.idx[q];
         const pf_align_job jb = p.jobs[job];
         uint32_t nh, tu, gu;
-        const bool ok = align_job(base, p.text + jb.a_off, p.text + jb.b_off, jb.a_len, jb.b_len, p.M, p.D, p.G, sc, nh, tu, gu);
+        const bool ok = align_job(base, p.text + jb.a_off, p.text + jb.b_off, jb.a_len, jb.b_len, p.M, p.D, p.G, p.integral, sc, nh, tu, gu);
         if (ok) {
             publish(o, job, sc, nh, tu, gu);
         } else if (lane_id() == 0) {
@@ -201,6 +203,8 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
 
     AlnParams p;
     p.text = d_text; p.jobs = d_jobs; p.idx = d_idx; p.M = match; p.D = mismatch; p.G = gap;
+    p.integral = (match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap) &&
+                  std::fabs(match) < 1e6 && std::fabs(mismatch) < 1e6 && std::fabs(gap) < 1e6) ? 1 : 0;
     p.st_text = st_text; p.st_gaps = st_gaps; p.st_hits = st_hits;
     p.st_text_cap = ST_TEXT; p.st_gap_cap = ST_GAPS; p.st_hit_cap = ST_HITS;
     p.work = nullptr; p.work_per_wave = 0; p.final_tier = 0;

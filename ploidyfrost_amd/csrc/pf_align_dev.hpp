@@ -18,7 +18,8 @@ __host__ __device__ inline uint32_t al4(uint32_t x) { return (x + 3u) & ~3u; }
 // bytes of working storage one job needs (must match the carve-up in align_job)
 __host__ __device__ inline uint64_t job_bytes(uint32_t m, uint32_t n) {
     const uint64_t cells = (uint64_t)(m + 1) * (n + 1);
-    return ((cells + 3) & ~3ull) + 12ull * (m + 1) + al4(m) + al4(n) + 3ull * al4(m + n) + al4(2 * (m + n)) + 16;
+    const uint64_t mx = m > n ? m : n;
+    return ((cells + 3) & ~3ull) + 12ull * (mx + 1) + al4(m) + al4(n) + 3ull * al4(m + n) + al4(2 * (m + n)) + 16;
 }
 
 struct AlnScratch {  // per-wave staging of the kept alignments (global memory)
@@ -50,77 +51,219 @@ __device__ inline void aln_sync() {
 // One job on one wavefront.  `base` = working storage (LDS or global), job_bytes(m, n) bytes.
 // Returns false when the staging area overflowed.
 __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, const char *__restrict__ gb, uint32_t m, uint32_t n,
-                          double M, double D, double G, const AlnScratch &sc, uint32_t &n_hits_out, uint32_t &text_out,
-                          uint32_t &gaps_out) {
+                          double M, double D, double G, int integral, const AlnScratch &sc, uint32_t &n_hits_out,
+                          uint32_t &text_out, uint32_t &gaps_out, unsigned long long *prof = nullptr) {
     const int lane = lane_id();
     const uint32_t W = n + 1;
     const uint32_t cells = (m + 1) * W;
     uint8_t *dir = base;
     int *s0 = reinterpret_cast<int *>(base + ((cells + 3) & ~3u));
-    int *s1 = s0 + (m + 1);
-    int *s2 = s1 + (m + 1);
-    char *A = reinterpret_cast<char *>(s2 + (m + 1));
+    const uint32_t mx = m > n ? m : n;
+    char *A = reinterpret_cast<char *>(s0 + 3 * (mx + 1));
     char *B = A + al4(m);
     char *ra = B + al4(n);
     char *rb = ra + al4(m + n);
     uint8_t *mv = reinterpret_cast<uint8_t *>(rb + al4(m + n));
     uint16_t *gp = reinterpret_cast<uint16_t *>(mv + al4(m + n));
 
+    const unsigned long long pc0 = prof ? wall_clock64() : 0;
     for (uint32_t i = lane; i < m; i += WAVE) A[i] = ga[i];
     for (uint32_t j = lane; j < n; j += WAVE) B[j] = gb[j];
     // borders (src/SeqAlign.cpp:486-496)
     for (uint32_t i = lane; i <= m; i += WAVE) dir[i * W] = i ? (uint8_t)(UP | (UP << 4)) : 0;
     for (uint32_t j = 1 + lane; j <= n; j += WAVE) dir[j] = (uint8_t)(LEFT | (LEFT << 4));
-    // rolling diagonals, indexed by row: p2 = diagonal d-2, p1 = d-1, cur = d
-    int *p2 = s0, *p1 = s1, *cur = s2;
-    if (lane == 0) {
-        p2[0] = 0;                                  // (0,0)
-        p1[0] = n >= 1 ? (int)(long)(G * 1) : 0;    // (0,1)
-        if (m >= 1) p1[1] = (int)(long)(G * 1);     // (1,0)
-    }
     aln_sync();
-    for (uint32_t d = 2; d <= m + n; ++d) {
-        const uint32_t lo = d > n ? d - n : 1;
-        const uint32_t hi = d - 1 < m ? d - 1 : m;
-        for (uint32_t i = lo + lane; i <= hi; i += WAVE) {
-            const uint32_t j = d - i;
-            const uint8_t f_up = dir[(i - 1) * W + j], f_dg = dir[(i - 1) * W + j - 1], f_lf = dir[i * W + j - 1];
-            int up = (int)((double)(long)p1[i - 1] + G);
-            if (f_up & UP) up += 1;
-            const char a = A[i - 1], b = B[j - 1];
-            const double sub = a == b ? M : ((a == '-' || b == '-') ? G : D);
-            int dg = (int)((double)(long)p2[i - 1] + sub);
-            if (f_dg & DIAG) dg += 1;
-            int lf = (int)((double)(long)p1[i] + G);
-            if (f_lf & LEFT) lf += 1;
-            int best = up > dg ? up : dg;
-            best = best > lf ? best : lf;
-            if (best == lf && i != m && A[i] == '-') {  // :528-532
-                lf = INT_MIN;
-                best = up > dg ? up : dg;
+    // ---- fill ---------------------------------------------------------------------------------
+    // Rows are processed in blocks of 64, one row per lane; inside a block the anti-diagonal
+    // wavefront lives in registers: at step t lane l owns cell (row, t - l + 1), its left neighbour is
+    // its own previous cell, the cells above / above-left are what lane l-1 produced one / two steps
+    // earlier (one DPP wave shift each).  LDS sees only the flag byte of each finished cell and, for
+    // m > 64, the last row of a block (read back by lane 0 of the next block).
+    int *brow_s = s0;
+    uint8_t *brow_f = reinterpret_cast<uint8_t *>(s0 + (n + 1));
+    const uint32_t n_blocks = (m + 63) / 64;
+    for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+        const uint32_t row0 = blk * 64;  // the row above this block
+        const uint32_t r = row0 + lane + 1;
+        const bool row_ok = r <= m;
+        const char a = row_ok ? A[r - 1] : '\0';
+        const bool next_is_gap = row_ok && r != m && A[r] == '-';  // the look-ahead of :528-532
+        const uint32_t rows_here = m - row0 < 64 ? m - row0 : 64;
+        const bool feeds_next = blk + 1 < n_blocks && lane == 63;
+        // integral scores (the default 2 / -1 / -3): the reference's `int = long + double` is plain
+        // integer arithmetic; otherwise the fp64 form with its truncation is kept
+        const int Mi = (int)M, Di = (int)D, Gi = (int)G;
+        int last_s = integral ? Gi * (int)r : (int)(long)(G * (double)r), last2_s = 0;  // (r, 0): border, flag Up
+        int last_f = UP, last2_f = 0;
+        int carry_s = blk == 0 ? 0 : (integral ? Gi * (int)row0 : (int)(long)(G * (double)row0));  // (row0, 0)
+        int carry_f = blk == 0 ? 0 : UP;
+        int b_reg = 0;
+        const uint32_t steps = n + rows_here - 1;
+        for (uint32_t t = 0; t < steps; ++t) {
+            const int b_in = t < n ? (int)B[t] : 0;
+            b_reg = __builtin_amdgcn_update_dpp(0, b_reg, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            int up_s = __builtin_amdgcn_update_dpp(0, last_s, 0x138, 0xf, 0xf, false);
+            int up_f = __builtin_amdgcn_update_dpp(0, last_f, 0x138, 0xf, 0xf, false);
+            int dg_s = __builtin_amdgcn_update_dpp(0, last2_s, 0x138, 0xf, 0xf, false);
+            int dg_f = __builtin_amdgcn_update_dpp(0, last2_f, 0x138, 0xf, 0xf, false);
+            const int j = (int)t - lane + 1;
+            if (lane == 0) {
+                b_reg = b_in;
+                dg_s = carry_s;
+                dg_f = carry_f;
+                if (t < n) {
+                    if (blk == 0) { up_s = integral ? Gi * j : (int)(long)(G * (double)j); up_f = LEFT; }
+                    else { up_s = brow_s[j]; up_f = brow_f[j]; }
+                }
+                carry_s = up_s;
+                carry_f = up_f;
             }
-            uint8_t f = 0;
-            if (up == best) f |= UP;
-            if (dg == best) f |= DIAG;
-            if (lf == best) f |= LEFT;
-            cur[i] = best;
-            dir[i * W + j] = (uint8_t)(f | (f << 4));
-        }
-        if (lane == 0) {
-            if (d <= n) cur[0] = (int)(long)(G * (double)d);  // (0,d)
-            if (d <= m) cur[d] = (int)(long)(G * (double)d);  // (d,0)
+            if (row_ok && j >= 1 && j <= (int)n) {
+                const char b = (char)b_reg;
+                int up, dg, lf;
+                if (integral) {
+                    up = up_s + Gi;
+                    dg = dg_s + (a == b ? Mi : ((a == '-' || b == '-') ? Gi : Di));
+                    lf = last_s + Gi;
+                } else {
+                    const double sub = a == b ? M : ((a == '-' || b == '-') ? G : D);
+                    up = (int)((double)up_s + G);
+                    dg = (int)((double)dg_s + sub);
+                    lf = (int)((double)last_s + G);
+                }
+                if (up_f & UP) up += 1;
+                if (dg_f & DIAG) dg += 1;
+                if (last_f & LEFT) lf += 1;
+                int best = up > dg ? up : dg;
+                best = best > lf ? best : lf;
+                if (best == lf && next_is_gap) {
+                    lf = INT_MIN;
+                    best = up > dg ? up : dg;
+                }
+                int f = 0;
+                if (up == best) f |= UP;
+                if (dg == best) f |= DIAG;
+                if (lf == best) f |= LEFT;
+                last2_s = last_s;
+                last2_f = last_f;
+                last_s = best;
+                last_f = f;
+                dir[r * W + j] = (uint8_t)(f | (f << 4));
+                if (feeds_next) { brow_s[j] = best; brow_f[j] = (uint8_t)f; }
+            }
         }
         aln_sync();
-        int *t = p2;
-        p2 = p1;
-        p1 = cur;
-        cur = t;
     }
 
-    // ---- traceback (lane 0) --------------------------------------------------------------
+    const unsigned long long pc1 = prof ? wall_clock64() : 0;
+    // ---- traceback ------------------------------------------------------------------------------
     uint32_t n_hits = 0, text_used = 0, gaps_used = 0;
     bool overflow = false;
-    if (lane == 0) {
+    // Fast path (all lanes, wave-uniform): most matrices have exactly one optimal path -- every cell on
+    // it carries a single direction flag.  Then the reference's DFS descends it once, emits that one
+    // alignment and unwinds without finding an alternative, so walking the path is the whole
+    // traceback.  Any cell with two flags, or a gap move at an exhausted budget, falls back to the full
+    // DFS below on the untouched matrix.
+    bool unique = true;
+    uint32_t f_len = 0, f_ng = 0;
+    {
+        uint32_t i = m, j = n, oa = 0, ob = 0;
+        char fa = '\0', fb = '\0';
+        while (i > 0 || j > 0) {
+            const uint8_t f = dir[i * W + j] & 7;
+            char ca, cb;
+            if (f == DIAG) {
+                ca = A[i - 1];
+                cb = B[j - 1];
+                i--;
+                j--;
+            } else if (f == LEFT) {
+                if (oa >= 5) { unique = false; break; }
+                if (f_len == 0 || fa != '+') ++oa;
+                ca = '+';
+                cb = B[j - 1];
+                if (lane == 0) gp[f_ng] = (uint16_t)i;
+                f_ng++;
+                j--;
+            } else if (f == UP) {
+                if (ob >= 5) { unique = false; break; }
+                if (f_len == 0 || fb == '-') ++ob;
+                ca = A[i - 1];
+                cb = '-';
+                i--;
+            } else {
+                unique = false;
+                break;
+            }
+            if (lane == 0) { ra[f_len] = ca; rb[f_len] = cb; }
+            fa = ca;
+            fb = cb;
+            f_len++;
+        }
+    }
+    if (unique) {
+        aln_sync();
+        // variantAnalyze (src/SeqAlign.cpp:237-305), lane-parallel over the columns
+        long long isum = 0, score = 0;
+        uint32_t npos = 0, nind = 0;
+        const int Mi = (int)M, Di = (int)D, Gi = (int)G;
+        for (uint32_t base0 = 0; base0 < f_len; base0 += WAVE) {
+            const uint32_t t = base0 + lane;
+            if (t < f_len) {
+                const char ax = ra[f_len - 1 - t], a = ax == '+' ? '-' : ax, b = rb[f_len - 1 - t];
+                if (integral) isum += (a == '-' || b == '-') ? Gi : (a == b ? Mi : Di);
+                if (a != b) {
+                    const int side = a == '-' ? 1 : (b == '-' ? 2 : 3);
+                    if (side == 3) {
+                        npos++;
+                    } else {
+                        int prev_run = 0;
+                        if (t > 0) {
+                            const char px = ra[f_len - t], pa = px == '+' ? '-' : px, pb = rb[f_len - t];
+                            if (pa != pb) prev_run = pa == '-' ? 1 : (pb == '-' ? 2 : 0);
+                        }
+                        if (prev_run != side) { npos++; nind++; }
+                    }
+                }
+            }
+        }
+        npos = __shfl((uint32_t)wave_sum_u64(npos), 0, WAVE);
+        nind = __shfl((uint32_t)wave_sum_u64(nind), 0, WAVE);
+        if (integral) {
+            score = (long long)wave_sum_u64((uint64_t)isum);
+        } else if (lane == 0) {
+            for (uint32_t t = f_len; t-- > 0;) {
+                const char a = ra[t] == '+' ? '-' : ra[t], b = rb[t];
+                const double sx = (a == '-' || b == '-') ? G : (a == b ? M : D);
+                score = (long long)((double)score + sx);
+            }
+        }
+        if (2 * f_len > sc.text_cap || f_ng > sc.gap_cap || sc.hit_cap < 1) {
+            overflow = true;
+        } else {
+            char *ta = sc.text, *tb = ta + f_len;
+            for (uint32_t t = lane; t < f_len; t += WAVE) {
+                const char ax = ra[f_len - 1 - t];
+                ta[t] = ax == '+' ? '-' : ax;
+                tb[t] = rb[f_len - 1 - t];
+            }
+            for (uint32_t t = lane; t < f_ng; t += WAVE) sc.gaps[t] = gp[t];
+            if (lane == 0) {
+                pf_align_hit h;
+                h.text_off = 0;
+                h.gap_off = 0;
+                h.len = f_len;
+                h.n_gaps = f_ng;
+                h.score = score;
+                h.n_pos = npos;
+                h.n_indel = nind;
+                sc.hits[0] = h;
+            }
+            n_hits = 1;
+            text_used = 2 * f_len;
+            gaps_used = f_ng;
+        }
+    } else if (lane == 0) {
         uint64_t open_a = 0, open_b = 0, lim_a = 5, lim_b = 5;  // size_t in the reference
         uint32_t len = 0, ng = 0;
         uint32_t i = m, j = n;
@@ -265,6 +408,10 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         }
     }
     aln_sync();
+    if (prof && lane == 0) {
+        atomicAdd(&prof[0], pc1 - pc0);
+        atomicAdd(&prof[1], wall_clock64() - pc1);
+    }
     n_hits_out = __shfl(n_hits, 0, WAVE);
     text_out = __shfl(text_used, 0, WAVE);
     gaps_out = __shfl(gaps_used, 0, WAVE);

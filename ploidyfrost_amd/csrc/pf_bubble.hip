@@ -86,6 +86,7 @@ struct BubParams {
     uint32_t work_bytes;    // bytes available per wave for one NW job (LDS or global)
     int final_tier;
     unsigned long long *task_clk;  // diagnostic: per-task wall clock ticks (100 MHz), or nullptr
+    unsigned long long *prof;      // diagnostic: [0] fill [1] traceback [2] decode [3] round0 copy [4] rounds [5] choose [6] publish
 };
 
 struct BubOut {
@@ -102,6 +103,25 @@ struct BubOut {
     uint32_t *retry;
     unsigned int *n_retry;
 };
+
+// Per-wave bump allocation in the four output pools (one atomic per chunk instead of four per bubble).
+struct BubAlloc {
+    unsigned long long cur[4] = {0, 0, 0, 0}, end[4] = {0, 0, 0, 0};
+};
+__device__ inline unsigned long long bub_take(const BubOut &o, BubAlloc &al, int pool, unsigned long long n, unsigned long long chunk) {
+    if (n == 0) return al.cur[pool];
+    if (n > al.end[pool] - al.cur[pool]) {
+        const unsigned long long want = n > chunk ? n : chunk;
+        unsigned long long got = 0;
+        if (lane_id() == 0) got = atomicAdd(&o.heads[pool], want);
+        got = ((unsigned long long)__shfl((uint32_t)(got >> 32), 0, WAVE) << 32) | __shfl((uint32_t)got, 0, WAVE);
+        al.cur[pool] = got;
+        al.end[pool] = got + want;
+    }
+    const unsigned long long off = al.cur[pool];
+    al.cur[pool] += n;
+    return off;
+}
 
 struct RowScore {
     long long score;
@@ -297,7 +317,7 @@ __device__ inline Metrics classify(const char *rows, uint32_t R, uint32_t L, uin
 
 // returns 0 ok, 1 = a capacity of this tier was exceeded (rerun in the next tier)
 template <bool LDS>
-__device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, uint8_t *nw_base, uint8_t *scr) {
+__device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, uint32_t job, uint8_t *nw_base, uint8_t *scr) {
     const int lane = lane_id();
     const BubCaps &C = p.caps;
     // carve the per-wave scratch
@@ -329,6 +349,13 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
     const uint32_t N = tk.n_paths;
     const pf_bubble_path *paths = p.paths + tk.path_first;
 
+    unsigned long long tq = p.prof ? wall_clock64() : 0;
+    auto mark = [&](int slot) {
+        if (!p.prof) return;
+        const unsigned long long now = wall_clock64();
+        if (lane == 0) atomicAdd(&p.prof[slot], now - tq);
+        tq = now;
+    };
     // ---- path strings into pbuf (decode oriented unitigs from the 2-bit graph) ------------------
     uint32_t poff_total = 0;
     for (uint32_t i = 0; i < N; ++i) poff_total += paths[i].len;
@@ -360,6 +387,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
         return pbuf + at;
     };
 
+    mark(2);
     // ---- round 0 ---------------------------------------------------------------------------------
     int cur = 0;
     uint32_t n_kept = 0, used[2] = {0, 0};
@@ -367,7 +395,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
         const uint32_t m = paths[0].len, n = paths[1].len;
         if (job_bytes(m, n) > p.work_bytes) return 1;
         uint32_t nh, tu, gu;
-        if (!align_job(nw_base, path_ptr(0), path_ptr(1), m, n, p.M, p.D, p.G, st, nh, tu, gu)) return 1;
+        if (!align_job(nw_base, path_ptr(0), path_ptr(1), m, n, p.M, p.D, p.G, p.integral, st, nh, tu, gu, p.prof)) return 1;
         if (nh > C.list) return 1;
         for (uint32_t h = 0; h < nh; ++h) {
             const pf_align_hit hh = st.hits[h];
@@ -382,6 +410,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
         aln_sync();
     }
 
+    mark(3);
     // ---- progressive rounds (src/SeqAlign.cpp:559-638) ------------------------------------------
     for (uint32_t i = 2; i < N; ++i) {
         const int nxt = cur ^ 1;
@@ -395,7 +424,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
             const char *mrows = arena[cur] + M.off;
             if (job_bytes(M.len, li) > p.work_bytes) return 1;
             uint32_t nh, tu, gu;
-            if (!align_job(nw_base, mrows, pi, M.len, li, p.M, p.D, p.G, st, nh, tu, gu)) return 1;
+            if (!align_job(nw_base, mrows, pi, M.len, li, p.M, p.D, p.G, p.integral, st, nh, tu, gu, p.prof)) return 1;
             // candidates alive, in traceback order
             uint32_t n_alive = nh;
             int ab = 0;
@@ -459,13 +488,17 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
         n_kept = n_new;
     }
 
+    mark(4);
     // ---- compareStrPair (src/SeqAlign.cpp:8-236) ---------------------------------------------------
     int best = -1;
     {
         const uint64_t Lref = n_kept ? list[cur][n_kept - 1].len : 0;
         int best_snp = INT_MAX / 2, best_indel = INT_MAX / 2;
         int d_snp = INT_MAX, d_indel = INT_MAX, d_all = INT_MAX, left = -1, right = -1;
-        for (uint32_t c = 0; c < n_kept; ++c) {
+        // a single surviving alignment wins whatever its metrics (the first candidate always beats the
+        // initial INT_MAX/2 counts), so the ladder is only run when there is a choice
+        if (n_kept == 1) best = 0;
+        for (uint32_t c = 0; n_kept > 1 && c < n_kept; ++c) {
             const MsaRef M = list[cur][c];
             const char *rows = arena[cur] + M.off;
             // the NW working storage is idle now: keep the per-column flags there (LDS in the LDS tiers)
@@ -521,6 +554,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
         }
     }
 
+    mark(5);
     // ---- publish ---------------------------------------------------------------------------------
     pf_bubble_result res;
     memset(&res, 0, sizeof(res));
@@ -538,17 +572,10 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
         const uint32_t j = base + lane;
         n_sites += (uint32_t)__popcll(__ballot(j < B.len && (colinfo[j] & 16)));
     }
-    unsigned long long t0 = 0, s0 = 0, g0 = 0, l0 = 0;
-    if (lane == 0) {
-        t0 = atomicAdd(&o.heads[0], (unsigned long long)B.rows * B.len);
-        s0 = atomicAdd(&o.heads[1], (unsigned long long)n_sites);
-        g0 = atomicAdd(&o.heads[2], (unsigned long long)n_sites * B.rows);
-        l0 = atomicAdd(&o.heads[3], (unsigned long long)m.n_indel_len);
-    }
-    t0 = (unsigned long long)bcast_i64((long long)t0);
-    s0 = (unsigned long long)bcast_i64((long long)s0);
-    g0 = (unsigned long long)bcast_i64((long long)g0);
-    l0 = (unsigned long long)bcast_i64((long long)l0);
+    const unsigned long long t0 = bub_take(o, al, 0, (unsigned long long)B.rows * B.len, 4096);
+    const unsigned long long s0 = bub_take(o, al, 1, n_sites, 64);
+    const unsigned long long g0 = bub_take(o, al, 2, (unsigned long long)n_sites * B.rows, 256);
+    const unsigned long long l0 = bub_take(o, al, 3, m.n_indel_len, 32);
     res.rows_off = t0;
     res.site_off = s0;
     res.group_off = g0;
@@ -587,6 +614,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, uint32_t job, ui
         }
         rank_base += (uint32_t)__popcll(mask);
     }
+    mark(6);
     return 0;
 }
 
@@ -597,10 +625,11 @@ __global__ __launch_bounds__(64) void k_bubble(BubParams p, BubOut o) {
     if constexpr (LDS) nw_base = smem;
     else nw_base = p.work + (uint64_t)blockIdx.x * p.work_per_wave;
     uint8_t *scr = p.scratch + (uint64_t)blockIdx.x * p.scratch_per_wave;
+    BubAlloc al;
     for (uint32_t q = blockIdx.x; q < p.n; q += gridDim.x) {
         const uint32_t job = p.idx[q];
         const unsigned long long c0 = p.task_clk ? wall_clock64() : 0;
-        const int rc = bubble_task<LDS>(p, o, job, nw_base, scr);
+        const int rc = bubble_task<LDS>(p, o, al, job, nw_base, scr);
         if (p.task_clk && lane_id() == 0) p.task_clk[job] = wall_clock64() - c0;
         if (rc != 0 && lane_id() == 0) {
             if (p.final_tier) {
@@ -730,9 +759,10 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     unsigned long long *d_clk = nullptr;
     const bool want_clk = getenv("PF_BUBBLE_STATS") != nullptr;
     if (want_clk) {
-        PF_HIP(hipMalloc(&d_clk, (size_t)n_tasks * 8));
-        PF_HIP(hipMemsetAsync(d_clk, 0, (size_t)n_tasks * 8, st));
+        PF_HIP(hipMalloc(&d_clk, ((size_t)n_tasks + 8) * 8));
+        PF_HIP(hipMemsetAsync(d_clk, 0, ((size_t)n_tasks + 8) * 8, st));
         p.task_clk = d_clk;
+        p.prof = d_clk + n_tasks;
     }
     static bool attr_set = false;
     if (!attr_set) {
@@ -800,8 +830,11 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         PF_HIP(hipStreamSynchronize(st));
     }
     if (want_clk) {
-        std::vector<unsigned long long> clk(n_tasks);
-        PF_HIP(hipMemcpy(clk.data(), d_clk, (size_t)n_tasks * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> clk(n_tasks + 8);
+        PF_HIP(hipMemcpy(clk.data(), d_clk, ((size_t)n_tasks + 8) * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pf_align_bubbles] ticks by phase: fill %llu traceback %llu | decode %llu round0(incl. NW) %llu rounds %llu choose %llu publish %llu\n",
+                clk[n_tasks], clk[n_tasks + 1], clk[n_tasks + 2], clk[n_tasks + 3], clk[n_tasks + 4], clk[n_tasks + 5], clk[n_tasks + 6]);
+        clk.resize(n_tasks);
         hipFree(d_clk);
         std::vector<unsigned long long> srt(clk);
         std::sort(srt.begin(), srt.end());

@@ -229,15 +229,33 @@ struct BfsOut {
     unsigned int *n_deferred;
 };
 
-__device__ inline void bfs_emit(const BfsOut &o, uint64_t ci, uint32_t s, const BfsResult &r, const BfsStore &st) {
+// Per-wave bump allocation in the vertex pool: a wave reserves BFS_POOL_CHUNK entries with one
+// atomic and hands them out locally, so the single pool head is touched once per ~50 candidates instead
+// of once per candidate (one hot word saturates at ~90 atomics/us chip-wide).
+constexpr uint32_t BFS_POOL_CHUNK = 256;
+struct BfsAlloc {
+    unsigned long long cur = 0, end = 0;
+};
+
+__device__ inline void bfs_emit(const BfsOut &o, BfsAlloc &al, uint64_t ci, uint32_t s, const BfsResult &r, const BfsStore &st) {
     const int lane = lane_id();
     // what the host replay needs: seen[] when an exit was found, the cycle set otherwise
     const bool want_seen = r.outcome != PF_BFS_NONE;
     const uint32_t n_list = want_seen ? r.n_seen : (r.flag_cycle ? r.n_cyc : 0);
     const uint32_t *src = want_seen ? st.ent : st.cyc;
     unsigned long long off = 0;
-    if (lane == 0 && n_list) off = atomicAdd(o.pool_head, (unsigned long long)n_list);
-    off = ((unsigned long long)__shfl((uint32_t)(off >> 32), 0, WAVE) << 32) | __shfl((uint32_t)off, 0, WAVE);
+    if (n_list) {
+        if (n_list > al.end - al.cur) {
+            const uint32_t want = n_list > BFS_POOL_CHUNK ? n_list : BFS_POOL_CHUNK;
+            unsigned long long got = 0;
+            if (lane == 0) got = atomicAdd(o.pool_head, (unsigned long long)want);
+            got = ((unsigned long long)__shfl((uint32_t)(got >> 32), 0, WAVE) << 32) | __shfl((uint32_t)got, 0, WAVE);
+            al.cur = got;
+            al.end = got + want;
+        }
+        off = al.cur;
+        al.cur += n_list;
+    }
     if (off + n_list <= o.pool_cap)
         for (uint32_t i = lane; i < n_list; i += WAVE) o.pool[off + i] = src[i];
     if (lane == 0) {
@@ -266,6 +284,7 @@ __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, 
     BfsStore st{s_ent[wv], s_meta[wv], s_todo[wv], s_cyc[wv], BFS_LDS_CAP};
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    BfsAlloc al;
     for (uint64_t c = c0 + wave; c < c1; c += n_waves) {
         const uint32_t s = cand[c];
         BfsResult r = bfs_traverse(succ, pred, st, s);
@@ -281,7 +300,7 @@ __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, 
                 o.deferred[d] = (uint32_t)(c - c0);
             }
         } else {
-            bfs_emit(o, c - c0, s, r, st);
+            bfs_emit(o, al, c - c0, s, r, st);
         }
         wave_sync();
     }
@@ -294,6 +313,7 @@ __global__ __launch_bounds__(64) void k_bfs_big(const uint32_t *__restrict__ suc
     const uint32_t wave = blockIdx.x;
     uint32_t *base = scratch32 + (size_t)wave * 3 * BFS_BIG_CAP;
     BfsStore st{base, scratch8 + (size_t)wave * BFS_BIG_CAP, base + BFS_BIG_CAP, base + 2 * BFS_BIG_CAP, BFS_BIG_CAP};
+    BfsAlloc al;
     for (unsigned int d = wave; d < n_deferred; d += gridDim.x) {
         const uint32_t ci = o.deferred[d];
         const uint32_t s = cand[c0 + ci];
@@ -301,7 +321,7 @@ __global__ __launch_bounds__(64) void k_bfs_big(const uint32_t *__restrict__ suc
         if (r.overflow) {
             if (lane_id() == 0) o.rec[ci].outcome = BFS_TOO_LARGE;
         } else {
-            bfs_emit(o, ci, s, r, st);
+            bfs_emit(o, al, ci, s, r, st);
         }
         wave_sync();
     }
@@ -475,7 +495,8 @@ int pf_kernel_time(pf_ctx *ctx, int kernel, double *total_ms, uint64_t *launches
 int pf_host_alloc(pf_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return PF_ERR_ARG;
     PF_HIP(hipSetDevice(ctx->device));
-    PF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocDefault));
+    // cached on the CPU side (the host layer reads these buffers element by element after each copy)
+    PF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocNonCoherent));
     return PF_OK;
 }
 
