@@ -37,6 +37,7 @@ struct pf_ctx {
     // k-mer count table (HBM): open addressing, 16-B slots, capacity = power of two >= 2n
     pf::Slot *d_tab = nullptr;
     uint64_t tab_cap = 0, tab_n = 0;
+    bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked at upload)
 
     // reusable result staging for host-pointer callers
     uint64_t *d_cov_sum = nullptr;

@@ -15,6 +15,7 @@
 #include <vector>
 
 #include "pf_bfs.hpp"
+#include "pf_bfs_huge.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
 #include "ploidyfrost_hip.h"
@@ -64,13 +65,26 @@ __global__ void k_table_build(Slot *t, uint64_t mask, const uint64_t *__restrict
     }
 }
 
-__global__ void k_lookup(const Slot *__restrict__ t, uint64_t mask, int k, const uint64_t *__restrict__ kmers, uint64_t n,
-                         uint32_t *__restrict__ counts, uint8_t *__restrict__ found) {
+// Does the table hold both orientations of some k-mer?  One thread per slot.
+__global__ void k_table_two_strands(const Slot *__restrict__ t, uint64_t cap, int k, unsigned int *flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < cap; i += stride) {
+        const Slot s = load_slot(t, i);
+        if (s.key == EMPTY_KEY) continue;
+        const uint64_t r = rc_kmer(s.key, k);
+        uint32_t c;
+        if (r != s.key && table_find(t, cap - 1, r, c)) atomicOr(flag, 1u);
+    }
+}
+
+__global__ void k_lookup(const Slot *__restrict__ t, uint64_t mask, int k, bool one_strand, const uint64_t *__restrict__ kmers,
+                         uint64_t n, uint32_t *__restrict__ counts, uint8_t *__restrict__ found) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
     for (; i < n; i += stride) {
         uint32_t c = 0;
-        bool ok = canonical_count(t, mask, kmers[i], k, c);
+        bool ok = canonical_count(t, mask, kmers[i], k, c, one_strand);
         counts[i] = ok ? c : 0;
         found[i] = ok;
     }
@@ -156,7 +170,7 @@ __global__ void k_mark_candidates(const uint32_t *__restrict__ succ, uint32_t n_
 // Launch: 256 threads = 4 waves per block, grid-stride over [u0, u1).
 __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_t mask, const uint64_t *__restrict__ seq,
                                              const uint64_t *__restrict__ off, const uint32_t *__restrict__ len, int k,
-                                             uint32_t u0, uint32_t u1, uint64_t *__restrict__ out_sum,
+                                             bool one_strand, uint32_t u0, uint32_t u1, uint64_t *__restrict__ out_sum,
                                              uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
     const int lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -169,7 +183,7 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
         bool miss = false;
         for (uint32_t p = lane; p < nk; p += WAVE) {
             uint32_t c;
-            if (canonical_count(t, mask, kmer_at(w, p, k), k, c)) {
+            if (canonical_count(t, mask, kmer_at(w, p, k), k, c, one_strand)) {
                 sum += c;
                 mn = c < mn ? c : mn;
             } else {
@@ -188,7 +202,7 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
 }
 
 // K-STRCOV: one thread per string (strings are k .. k+few bases long).
-__global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, const char *__restrict__ text,
+__global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, bool one_strand, const char *__restrict__ text,
                          const uint64_t *__restrict__ str_off, uint32_t n_str, uint32_t low, uint32_t up,
                          uint64_t *__restrict__ out_sum, uint8_t *__restrict__ out_ok, uint8_t *__restrict__ out_miss) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -205,7 +219,7 @@ __global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, const
             x = ((x << 2) | b) & kmask;
             if (j + 1 >= (uint32_t)k) {
                 uint32_t c;
-                if (!canonical_count(t, mask, x, k, c)) { miss = 1; break; }
+                if (!canonical_count(t, mask, x, k, c, one_strand)) { miss = 1; break; }
                 if (c > low && c < up) sum += c;
                 else { sum = 0; ok = 0; break; }  // src/CDBG.cpp:45-50
             }
@@ -218,7 +232,7 @@ __global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, const
 
 // K-BFS, LDS tier: 4 waves per block, each with its own LDS slice of CAP entries.
 constexpr uint32_t BFS_LDS_CAP = 128;
-constexpr uint32_t BFS_BIG_CAP = 1u << 16;
+constexpr uint32_t BFS_BIG_CAP = 1u << 12;  // linear-scan tables: beyond this the direct-indexed tier takes over
 
 struct BfsOut {
     pf_bfs_record *rec;
@@ -227,6 +241,8 @@ struct BfsOut {
     unsigned long long *pool_head;  // running total (may exceed pool_cap: tells the size needed)
     uint32_t *deferred;             // candidate indices for the big tier
     unsigned int *n_deferred;
+    uint32_t *deferred2;            // ... and for the direct-indexed tier
+    unsigned int *n_deferred2;
 };
 
 // Per-wave bump allocation in the vertex pool: a wave reserves BFS_POOL_CHUNK entries with one
@@ -319,9 +335,37 @@ __global__ __launch_bounds__(64) void k_bfs_big(const uint32_t *__restrict__ suc
         const uint32_t s = cand[c0 + ci];
         BfsResult r = bfs_traverse(succ, pred, st, s);
         if (r.overflow) {
-            if (lane_id() == 0) o.rec[ci].outcome = BFS_TOO_LARGE;
+            if (lane_id() == 0) {
+                const unsigned int d2 = atomicAdd(o.n_deferred2, 1u);
+                o.deferred2[d2] = ci;
+            }
         } else {
             bfs_emit(o, al, ci, s, r, st);
+        }
+        wave_sync();
+    }
+}
+
+// K-BFS, last tier: direct-indexed state (pf_bfs_huge.hpp), one candidate per wave.
+__global__ __launch_bounds__(64) void k_bfs_huge(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
+                                                 const uint32_t *__restrict__ cand, uint64_t c0, unsigned int n_deferred2,
+                                                 uint32_t *scratch, uint32_t n_unitigs, BfsOut o) {
+    const uint32_t wave = blockIdx.x;
+    const size_t N = n_unitigs;
+    uint32_t *b = scratch + (size_t)wave * (9 * N + 16);
+    HugeStore st{b, b + N, b + 2 * N, b + 4 * N, b + 5 * N + 4, b + 7 * N + 12, n_unitigs};
+    BfsStore view{st.seen, nullptr, st.todo, st.cyc, n_unitigs};
+    BfsAlloc al;
+    uint32_t epoch = 0;
+    for (unsigned int d = wave; d < n_deferred2; d += gridDim.x) {
+        const uint32_t ci = o.deferred2[d];
+        const uint32_t s = cand[c0 + ci];
+        ++epoch;
+        BfsResult r = bfs_traverse_huge(succ, pred, st, epoch, s);
+        if (r.overflow) {
+            if (lane_id() == 0) o.rec[ci].outcome = BFS_TOO_LARGE;
+        } else {
+            bfs_emit(o, al, ci, s, r, view);
         }
         wave_sync();
     }
@@ -641,7 +685,18 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
         k_table_build<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap - 1, pk, pc, n, min_count, max_count);
         ctx_end(ctx);
     }
-    PF_HIP(hipStreamSynchronize(ctx->stream));
+    // one orientation per k-mer?  (decides the probe order of the composite lookup, never its result)
+    {
+        unsigned int *d_flag = nullptr, h_flag = 0;
+        PF_HIP(hipMalloc(&d_flag, 4));
+        PF_HIP(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
+        if (n && ctx->k)
+            k_table_two_strands<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap, ctx->k, d_flag);
+        PF_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+        hipFree(d_flag);
+        ctx->tab_one_strand = (n && ctx->k) ? h_flag == 0 : false;
+    }
     hipFree(dk);
     hipFree(dc);
     return PF_OK;
@@ -659,7 +714,7 @@ int pf_lookup_kmers(pf_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *co
     uint8_t *df;
     PF_HIP(hipMalloc(&dc, n * 4));
     PF_HIP(hipMalloc(&df, n));
-    k_lookup<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, dk, n, dc, df);
+    k_lookup<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->tab_one_strand, dk, n, dc, df);
     PF_HIP(hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(found, df, n, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
@@ -695,7 +750,8 @@ int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t
     // one wave per unitig, 4 waves per block; enough blocks to keep every CU at 8 waves/SIMD
     const int grid = ctx_grid(ctx, (uint64_t)n * 64, 256, 16);
     ctx_begin(ctx, PF_K_COV);
-    k_cov<<<grid, 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, u0, u1, ds, dm, dx);
+    k_cov<<<grid, 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k,
+                                         ctx->tab_one_strand, u0, u1, ds, dm, dx);
     ctx_end(ctx);
     if (!dev_out) {
         PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -724,7 +780,7 @@ int pf_string_cov(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32
     PF_HIP(hipMemcpyAsync(dt, text, (size_t)total, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(doff, str_off, ((size_t)n_str + 1) * 8, hipMemcpyDefault, ctx->stream));
     ctx_begin(ctx, PF_K_STRCOV);
-    k_strcov<<<ctx_grid(ctx, n_str, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, dt, doff, n_str, low, up, ds, dk, dm);
+    k_strcov<<<ctx_grid(ctx, n_str, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->tab_one_strand, dt, doff, n_str, low, up, ds, dk, dm);
     ctx_end(ctx);
     PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n_str * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ok, dk, n_str, hipMemcpyDefault, ctx->stream));
@@ -769,12 +825,13 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
         if (!d_rec || !d_pool) return PF_ERR_HIP;
     }
     uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BFS_SMALL, 64);
-    uint32_t *d_def = (uint32_t *)ctx_ws(ctx, WS_BFS_DEF, n * 4);
+    uint32_t *d_def = (uint32_t *)ctx_ws(ctx, WS_BFS_DEF, (n * 2 + 8) * 4);
     if (!small || !d_def) return PF_ERR_HIP;
     unsigned long long *d_head = reinterpret_cast<unsigned long long *>(small);
     unsigned int *d_ndef = reinterpret_cast<unsigned int *>(small + 16);
+    unsigned int *d_ndef2 = reinterpret_cast<unsigned int *>(small + 32);
     PF_HIP(hipMemsetAsync(small, 0, 64, ctx->stream));
-    BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef};
+    BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef, d_def + n + 4, d_ndef2};
     const int grid = ctx_grid(ctx, n * 64, 256, 8);
     ctx_begin(ctx, PF_K_BFS);
     k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o);
@@ -792,9 +849,24 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
         ctx_begin(ctx, PF_K_BFS_BIG);
         k_bfs_big<<<waves, 64, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, n_def, sc32, sc8, o);
         ctx_end(ctx);
+        unsigned int n_def2 = 0;
+        PF_HIP(hipMemcpyAsync(&n_def2, d_ndef2, 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
         hipFree(sc32);
         hipFree(sc8);
+        if (n_def2) {
+            // traversals beyond the linear tables: direct-indexed state sized by the graph, a few waves
+            const unsigned int hw = std::min<unsigned int>(n_def2, 8);
+            const size_t per = 9 * (size_t)ctx->N + 16;
+            uint32_t *hs = nullptr;
+            PF_HIP(hipMalloc(&hs, per * hw * 4));
+            PF_HIP(hipMemsetAsync(hs, 0, per * hw * 4, ctx->stream));
+            ctx_begin(ctx, PF_K_BFS_BIG);
+            k_bfs_huge<<<hw, 64, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, n_def2, hs, ctx->N, o);
+            ctx_end(ctx);
+            PF_HIP(hipStreamSynchronize(ctx->stream));
+            hipFree(hs);
+        }
     }
     ctx->bfs_deferred = n_def;
     unsigned long long head = 0;
@@ -810,7 +882,7 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
             PF_HIP(hipMemcpy(pool, d_pool, (size_t)head * 4, hipMemcpyDeviceToHost));
             for (uint64_t i = 0; i < n; ++i)
                 if (records[i].outcome == BFS_TOO_LARGE) {
-                    ctx->err = "a traversal visited more than 65536 unitigs";
+                    ctx->err = "a traversal exceeded the direct-indexed tier (internal limit)";
                     status = PF_ERR_OVERFLOW;
                     break;
                 }

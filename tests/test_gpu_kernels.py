@@ -169,3 +169,91 @@ def test_string_cov_matches_oracle(case):
     bogus = b"A" * (k + 2)
     s, ok, miss = dev.string_cov([bogus], 5, 1000)
     assert int(miss[0]) == o.string_cov(bogus, 5, 1000)[2] == 1
+
+
+def test_two_strand_database_keeps_forward_first_order():
+    """A database holding BOTH orientations of a k-mer (not what canonical counting produces) must
+    still answer as the reference does: the forward form wins (src/CDBG.cpp:38-56).  The upload-time
+    check then disables the canonical-first probe order."""
+    meta, o, dev, seqs = setup_case("dip20k")
+    kmers, counts, km = synth.read_kmc1(meta["db"])
+    k = o.k
+
+    def rc(x):
+        r = 0
+        for j in range(k):
+            r |= (3 - ((x >> (2 * j)) & 3)) << (2 * (k - 1 - j))
+        return r
+
+    extra = np.array([rc(int(x)) for x in kmers[:500]], dtype=np.uint64)
+    both_k = np.concatenate([kmers, extra])
+    both_c = np.concatenate([counts, counts[:500] + 1000]).astype(np.uint32)
+    d2 = hipapi.Device(0)
+    d2.upload_graph(*hipapi.pack_unitigs(seqs), k)
+    d2.upload_counts(both_k, both_c, 1, 65535, True)
+    c, f = d2.lookup(kmers[:500])
+    assert f.all() and np.array_equal(c, counts[:500])            # forward form present -> its own count
+    c, f = d2.lookup(extra)
+    assert f.all() and np.array_equal(c, counts[:500] + 1000)     # the reverse form queried forward -> its own count
+    c, f = d2.lookup(kmers[500:1000])
+    assert f.all() and np.array_equal(c, counts[500:1000])
+
+
+def lattice_gfa(path, k=25, depth=7, seed=3):
+    """A superbubble wider than the LDS tables of K-BFS: a binary tree of `depth` levels fanning out
+    from one entrance and its mirror image collapsing into one exit (2^depth unitigs in the middle)."""
+    rng = np.random.default_rng(seed)
+
+    def rnd(n):
+        return bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+
+    segs = [rnd(60)]
+    level = [0]  # indices into segs
+    # expanding half: node -> two children that start with the node's last k-1 bases + a distinct base
+    for _ in range(depth):
+        nxt = []
+        for i in level:
+            for b in (b"A", b"C"):
+                segs.append(segs[i][-(k - 1):] + b + rnd(30))
+                nxt.append(len(segs) - 1)
+        level = nxt
+    # collapsing half: two parents are extended so that both end with the same k-1 bases after distinct bases
+    while len(level) > 1:
+        nxt = []
+        for i in range(0, len(level), 2):
+            join = rnd(k - 1)
+            segs[level[i]] += b"G" + join
+            segs[level[i + 1]] += b"T" + join
+            segs.append(join + rnd(30))
+            nxt.append(len(segs) - 1)
+        level = nxt
+    with open(path, "wb") as f:
+        f.write(b"H\tVN:Z:1.0\tKL:Z:%d\tML:Z:17\n" % k)
+        for i, s in enumerate(segs):
+            f.write(b"S\t%d\t%s\n" % (i + 1, s))
+    return len(segs)
+
+
+@pytest.mark.parametrize("depth,limit", [(7, 128), (12, 4096)])
+def test_bfs_big_tier_matches_oracle(tmp_path, depth, limit):
+    """traversals that outgrow the 128-entry LDS tables rerun over global scratch (k_bfs_big, linear
+    tables up to 4096 entries), and beyond that over direct-indexed state (k_bfs_huge)"""
+    gfa = str(tmp_path / "lattice.gfa")
+    n = lattice_gfa(gfa, depth=depth)
+    o = pyoracle.Oracle(gfa, None)
+    assert o.n == n
+    dev = hipapi.Device(0)
+    dev.upload_graph(*hipapi.pack_unitigs(o.sequences()), o.k)
+    succ, pred = dev.build_adjacency()
+    es, ep = o.adjacency()
+    assert np.array_equal(succ, es) and np.array_equal(pred, ep)
+    rec, pool = dev.bfs()
+    big = 0
+    for r in rec:
+        e = o.extract(int(r["entrance"]))
+        assert (int(r["outcome"]), int(r["exit"]), int(r["n_seen"])) == (e["outcome"], e["exit"], len(e["seen"]))
+        lst = pool[int(r["list_off"]) : int(r["list_off"]) + int(r["n_list"])]
+        if e["outcome"] != 0:
+            assert np.array_equal(lst, e["seen"])
+        big += len(e["seen"]) > limit
+    assert big >= 2  # the whole lattice from either end

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Full-scale parity check on a GPU box: a bench-style synthetic graph of <unitigs> unitigs (default
+# 1 M, BASELINE.json configs[1]) is run through the real reference binary (oracle/_ref/PloidyFrost
+# -t 1, single CPU core) and through this repository's CLI; all twelve output files must be
+# byte-identical.  Prints both timings.   usage: tools/fullscale_parity.sh [unitigs] [seed]
+set -e
+ROOT=$(cd "$(dirname "$0")/.." && pwd)
+N=${1:-1000000}; SEED=${2:-77}
+W=$(mktemp -d /tmp/pf_parity.XXXXXX)
+python "$ROOT/tools/make_graph.py" "$W/in" "$N" "$SEED" | tail -1
+mkdir -p "$W/ref" "$W/gpu"
+( cd "$W/ref" && /usr/bin/time -f "reference wall %es" "$ROOT/oracle/_ref/PloidyFrost" -g "$W/in/g.gfa" -d "$W/in/g_kmc" -o x -l 5 -u 1000 -t 1 > ref.log ) 2>&1 | tail -1
+grep -E "findSuperBubble\(\):  Cpu time|PloidyEstimation\(\):  Cpu time|Alleles" "$W/ref/ref.log"
+( cd "$W/gpu" && /usr/bin/time -f "ploidyfrost (MI355X) wall %es" "$ROOT/ploidyfrost_amd/csrc/ploidyfrost" -g "$W/in/g.gfa" -d "$W/in/g_kmc" -o x -l 5 -u 1000 -t 32 > gpu.log ) 2>&1 | tail -1
+grep -E "findSuperBubble\(\):  Real time|PloidyEstimation\(\):  Real time|Alleles" "$W/gpu/gpu.log"
+bad=0
+for f in "$W"/ref/PloidyFrost_output/*; do
+  if cmp -s "$f" "$W/gpu/PloidyFrost_output/$(basename "$f")"; then echo "IDENTICAL $(basename "$f") $(stat -c %s "$f") bytes"; else echo "DIFFERENT $(basename "$f")"; bad=1; fi
+done
+rm -rf "$W"
+exit $bad

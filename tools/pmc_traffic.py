@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Turn two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as the TCC slot
+budget requires) into profiles/pmc_traffic.json: HBM bytes per launch for each of this repository's
+kernels, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): counters are in KiB;
+FETCH_SIZE under-reports coalesced reads by 2x and is doubled; WRITE_SIZE is taken as is.
+
+usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+"""
+import csv
+import glob
+import json
+import os
+import sys
+from collections import defaultdict
+
+
+def per_kernel(d, counter):
+    files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+    acc = defaultdict(lambda: [0.0, 0])
+    for f in files:
+        with open(f) as fh:
+            for row in csv.DictReader(fh):
+                if row.get("Counter_Name") != counter:
+                    continue
+                name = row["Kernel_Name"]
+                acc[name][0] += float(row["Counter_Value"])
+                acc[name][1] += 1
+    return acc
+
+
+def short(name):
+    for k in ("k_cov", "k_bfs_big", "k_bfs", "k_bubble", "k_align", "k_strcov", "k_table_build", "k_adj_insert", "k_adj_probe"):
+        if k + "(" in name or k + "<" in name:
+            if k == "k_bubble" and "Lb0" in name:
+                return "k_bubble_big"
+            return k
+    return None
+
+
+def main(fetch_dir, write_dir, out):
+    res = {}
+    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
+    write = per_kernel(write_dir, "WRITE_SIZE")
+    names = set(filter(None, (short(n) for n in list(fetch) + list(write))))
+    for k in sorted(names):
+        fs = [(v[0], v[1]) for n, v in fetch.items() if short(n) == k]
+        ws = [(v[0], v[1]) for n, v in write.items() if short(n) == k]
+        fk = sum(x[0] for x in fs) / max(1, sum(x[1] for x in fs))
+        wk = sum(x[0] for x in ws) / max(1, sum(x[1] for x in ws))
+        res[k] = {"fetch_bytes_per_launch": fk * 1024 * 2, "write_bytes_per_launch": wk * 1024,
+                  "hbm_bytes_per_launch": fk * 1024 * 2 + wk * 1024, "launches_sampled": sum(x[1] for x in fs),
+                  "raw_FETCH_SIZE_KiB": fk, "raw_WRITE_SIZE_KiB": wk}
+    flat = {k: v["hbm_bytes_per_launch"] for k, v in res.items()}
+    with open(out, "w") as f:
+        json.dump({"_detail": res, **flat}, f, indent=1)
+    for k, v in res.items():
+        print("%-14s fetch %.1f MB (x2 corrected)  write %.1f MB per launch" % (k, v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
+
+
+if __name__ == "__main__":
+    main(*sys.argv[1:4])
