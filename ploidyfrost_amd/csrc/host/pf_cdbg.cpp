@@ -291,8 +291,11 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // (src/CDBG.cpp:206, 211): records are in ascending oriented-vertex order = unitig order,
     // '+' before '-'.
     t0 = clk::now();
+    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;
     for (uint64_t i = 0; i < n_rec; ++i) {
         const pf_bfs_record &r = rec[i];
+        if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
+        if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
         const uint32_t u = r.entrance >> 1;
         if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
         replay(r, bx_.bfs_pool.p + r.list_off);

@@ -34,10 +34,15 @@ __device__ inline bool huge_cyc_add(const HugeStore &st, uint32_t epoch, uint32_
         st.cyc[n_cyc] = ov;
     }
     n_cyc++;
-    wave_sync();
+    __builtin_amdgcn_wave_barrier();
     return true;
 }
 
+// Per popped vertex the memory round trips are: the vertex itself (skipped when it was pushed in the
+// previous step), {its state word, its successor row}, {the four predecessor rows, the successors'
+// state words}, {the predecessors' state words} -- each group one wave-wide load.  State words
+// changed while the successors are resolved in order are patched in the lanes that prefetched them,
+// so no load is repeated and a single fence per step orders the stores.
 __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
                                               const HugeStore &st, uint32_t epoch, uint32_t s) {
     const int lane = lane_id();
@@ -49,10 +54,7 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
     r.flag_cycle = r.flag_tip = r.strict = 0;
     r.overflow = false;
     const uint32_t tag = epoch << 4;
-    auto state_of = [&](uint32_t u) -> uint32_t {  // 0 = not in state_map
-        const uint32_t x = st.info[u];
-        return (x >> 4) == epoch ? (x & 15) : 0;
-    };
+    auto decode = [&](uint32_t x) -> uint32_t { return (x >> 4) == epoch ? (x & 15) : 0; };  // 0 = not in state_map
     uint32_t n = 1, top = 1, n_cyc = 0, n_pending = 0;  // n_pending = entries in state `seen` (2)
     bool cyc_flag = false, tip_flag = false;
     if (lane == 0) {
@@ -60,19 +62,30 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
         st.first[s >> 1] = s;
         st.todo[0] = s;
     }
+    uint32_t cached_top = s;  // value of todo[top-1] when known without a load
+    bool have_top = true;
     wave_sync();
     while (top > 0) {
-        const uint32_t v = st.todo[top - 1];
+        const uint32_t v = have_top ? cached_top : st.todo[top - 1];
+        have_top = false;
         top--;
-        {   // state_map[id(v)] = visited; strand_map[id(v)] = v.strand
-            const uint32_t old = state_of(v >> 1);
-            if ((old & 3) == 2) n_pending--;
-            if (lane == 0) st.info[v >> 1] = tag | 1u | (((v & 1) == 0) ? 4u : 0u);
-        }
-        wave_sync();
-        const uint32_t my_succ = lane < 4 ? succ[(size_t)v * 4 + lane] : NONE;
+        // {state word of v, successor row of v}
+        const uint32_t ld1 = lane < 4 ? succ[(size_t)v * 4 + lane] : (lane == 4 ? st.info[v >> 1] : 0u);
+        const uint32_t my_succ = lane < 4 ? ld1 : NONE;
+        const uint32_t v_old = decode(__shfl(ld1, 4, WAVE));
+        if ((v_old & 3) == 2) n_pending--;
+        const uint32_t v_info = tag | 1u | (((v & 1) == 0) ? 4u : 0u);  // visited; strand_map[id(v)] = v.strand
+        if (lane == 0) st.info[v >> 1] = v_info;
+        // {predecessor rows of the successors, state words of the successors}
         const uint32_t sb = __shfl(my_succ, lane >> 2, WAVE);
         const uint32_t my_pred = (lane < 16 && sb != NONE) ? pred[(size_t)sb * 4 + (lane & 3)] : NONE;
+        uint32_t my_sinfo = (lane < 4 && my_succ != NONE) ? ((my_succ >> 1) == (v >> 1) ? v_info : st.info[my_succ >> 1]) : 0u;
+        // {state words of the predecessors}
+        uint32_t my_pinfo = (lane < 16 && my_pred != NONE) ? ((my_pred >> 1) == (v >> 1) ? v_info : st.info[my_pred >> 1]) : 0u;
+        auto patch = [&](uint32_t unitig, uint32_t word) {
+            if (lane < 4 && my_succ != NONE && (my_succ >> 1) == unitig) my_sinfo = word;
+            if (lane < 16 && my_pred != NONE && (my_pred >> 1) == unitig) my_pinfo = word;
+        };
         if (__ballot(my_succ != NONE) == 0) {
             tip_flag = true;
         } else {
@@ -84,7 +97,7 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
                     if (!huge_cyc_add(st, epoch, n_cyc, s) || !huge_cyc_add(st, epoch, n_cyc, v)) { r.overflow = true; return r; }
                     continue;
                 }
-                const uint32_t um = state_of(u >> 1);
+                const uint32_t um = decode(__shfl(my_sinfo, b, WAVE));
                 // the entrance sits in `seen` before it has a state; it is popped first, so afterwards
                 // "in state_map" and "in seen" coincide
                 if (um == 0 || (um & 3) != 1) {
@@ -103,12 +116,12 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
                         new_info = tag | 2u | (um & 4);  // state was already `seen`
                     }
                     if (lane == 0) st.info[u >> 1] = new_info;
-                    wave_sync();
+                    patch(u >> 1, new_info);
                     bool all_pred = true;
                     for (int j = 0; j < 4; ++j) {
                         const uint32_t p = __shfl(my_pred, b * 4 + j, WAVE);
+                        const uint32_t pm = decode(__shfl(my_pinfo, b * 4 + j, WAVE));
                         if (p == NONE) continue;
-                        const uint32_t pm = state_of(p >> 1);
                         if (pm != 0) {
                             if ((pm & 3) != 1) all_pred = false;
                             if (((pm >> 2) & 1) != ((p & 1) == 0 ? 1u : 0u)) {
@@ -123,17 +136,22 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
                         if (top >= 2 * st.n_unitigs + 8) { r.overflow = true; return r; }
                         if (lane == 0) st.todo[top] = u;
                         top++;
+                        cached_top = u;
+                        have_top = true;
                     }
                 } else {
                     cyc_flag = true;
                     if (!huge_cyc_add(st, epoch, n_cyc, v) || !huge_cyc_add(st, epoch, n_cyc, u)) { r.overflow = true; return r; }
                 }
-                wave_sync();
             }
         }
+        // No fence between steps: a wave's vector-memory instructions execute in program order and the L1
+        // is write-through, so the next step's loads observe this step's stores (same-wave RAW); the
+        // barrier only pins the compiler's ordering.
+        __builtin_amdgcn_wave_barrier();
         if (top == 1) {
-            const uint32_t t0 = st.todo[0];
-            const uint32_t tm = state_of(t0 >> 1);
+            const uint32_t t0 = have_top ? cached_top : st.todo[0];
+            const uint32_t tm = decode(st.info[t0 >> 1]);
             const uint32_t mine = ((tm & 3) == 2 && st.first[t0 >> 1] == t0) ? 1u : 0u;
             if (n_pending == mine) {
                 r.exit_ov = t0;

@@ -856,7 +856,8 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
         hipFree(sc8);
         if (n_def2) {
             // traversals beyond the linear tables: direct-indexed state sized by the graph, a few waves
-            const unsigned int hw = std::min<unsigned int>(n_def2, 8);
+            // one wave per traversal, as many side by side as ~16 GiB of state allow
+            const unsigned int hw = (unsigned int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_def2, 64), (16ull << 30) / (36 * (size_t)ctx->N + 64)));
             const size_t per = 9 * (size_t)ctx->N + 16;
             uint32_t *hs = nullptr;
             PF_HIP(hipMalloc(&hs, per * hw * 4));

@@ -9,9 +9,13 @@ N=${1:-1000000}; SEED=${2:-77}
 W=$(mktemp -d /tmp/pf_parity.XXXXXX)
 python "$ROOT/tools/make_graph.py" "$W/in" "$N" "$SEED" | tail -1
 mkdir -p "$W/ref" "$W/gpu"
-( cd "$W/ref" && /usr/bin/time -f "reference wall %es" "$ROOT/oracle/_ref/PloidyFrost" -g "$W/in/g.gfa" -d "$W/in/g_kmc" -o x -l 5 -u 1000 -t 1 > ref.log ) 2>&1 | tail -1
+t0=$(date +%s%N)
+( cd "$W/ref" && "$ROOT/oracle/_ref/PloidyFrost" -g "$W/in/g.gfa" -d "$W/in/g_kmc" -o x -l 5 -u 1000 -t 1 > ref.log )
+echo "reference wall $(( ($(date +%s%N) - t0) / 1000000 )) ms"
 grep -E "findSuperBubble\(\):  Cpu time|PloidyEstimation\(\):  Cpu time|Alleles" "$W/ref/ref.log"
-( cd "$W/gpu" && /usr/bin/time -f "ploidyfrost (MI355X) wall %es" "$ROOT/ploidyfrost_amd/csrc/ploidyfrost" -g "$W/in/g.gfa" -d "$W/in/g_kmc" -o x -l 5 -u 1000 -t 32 > gpu.log ) 2>&1 | tail -1
+t0=$(date +%s%N)
+( cd "$W/gpu" && "$ROOT/ploidyfrost_amd/csrc/ploidyfrost" -g "$W/in/g.gfa" -d "$W/in/g_kmc" -o x -l 5 -u 1000 -t 32 > gpu.log )
+echo "ploidyfrost (MI355X) wall $(( ($(date +%s%N) - t0) / 1000000 )) ms"
 grep -E "findSuperBubble\(\):  Real time|PloidyEstimation\(\):  Real time|Alleles" "$W/gpu/gpu.log"
 bad=0
 for f in "$W"/ref/PloidyFrost_output/*; do
