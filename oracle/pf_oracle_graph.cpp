@@ -59,7 +59,7 @@ bool KmcDb::load(const std::string &prefix) {
         err = "bad KMC markers";
         return false;
     }
-    uint32_t version = rd32(pre.data() + pre.size() - 12);  // kmc_file.cpp:188-192
+    version = rd32(pre.data() + pre.size() - 12);  // kmc_file.cpp:188-192
     uint64_t size = pre.size() - 8;                          // without both markers
     const uint8_t *body = pre.data() + 4;
     if (version == 0) {
@@ -83,8 +83,49 @@ bool KmcDb::load(const std::string &prefix) {
         max_count += lut[hi + 4] & 0xFFFFFFFF00000000ull;
         lut[hi] = total + 1;  // :292
     } else if (version == 0x200) {
-        err = "KMC2-layout databases (signature-binned LUT) are not supported by the oracle yet";
-        return false;
+        // KMC2 (kmc_file.cpp:196-245): LUT[n_bins*4^p + 1] | signature_map[4^sig_len + 1] | header | offset
+        const uint64_t header_offset = pre[pre.size() - 8];
+        size -= 4;
+        if (header_offset + 8 > pre.size() || header_offset < 37) { err = "bad KMC2 header offset"; return false; }
+        const uint8_t *h = pre.data() + pre.size() - (header_offset + 8);
+        k = rd32(h);
+        mode = rd32(h + 4);
+        counter_size = rd32(h + 8);
+        p = rd32(h + 12);
+        sig_len = rd32(h + 16);
+        min_count = rd32(h + 20);
+        max_count = rd32(h + 24);
+        total = rd64(h + 28);
+        both_strands = !h[36];
+        if (sig_len < 5 || sig_len > 11) { err = "unsupported KMC2 signature length"; return false; }
+        const uint64_t sig_entries = (1ull << (2 * sig_len)) + 1;
+        if (size < sig_entries * 4 + header_offset + 8) { err = "kmc_pre too short for the KMC2 layout"; return false; }
+        const uint64_t lut_area = size - (sig_entries * 4 + header_offset + 8);
+        single_lut = 1ull << (2 * p);
+        lut_words = (lut_area + 8) / 8;
+        lut.resize(lut_words);
+        for (uint64_t i = 0; i < lut_words; ++i) lut[i] = rd64(body + 8 * i);
+        lut[lut_area / 8] = total + 1;
+        sig_map.resize(sig_entries);
+        for (uint64_t i = 0; i < sig_entries; ++i) sig_map[i] = rd32(body + lut_area + 8 + 4 * i);
+        // norm table of CMmer (mmer.h:34-87)
+        const uint32_t n = 1u << (2 * sig_len);
+        auto allowed = [&](uint32_t m) {
+            if ((m & 0x3f) == 0x3f || (m & 0x3f) == 0x3b || (m & 0x3c) == 0x3c) return false;
+            for (uint32_t j = 0; j + 3 < sig_len; ++j) {
+                if ((m & 0xf) == 0) return false;
+                m >>= 2;
+            }
+            if (m == 0 || m == 0x04 || (m & 0xf) == 0) return false;
+            return true;
+        };
+        norm.resize(n);
+        for (uint32_t i = 0; i < n; ++i) {
+            uint32_t rev = 0, t = i;
+            for (uint32_t j = 0; j < sig_len; ++j) { rev |= (3 - (t & 3)) << (2 * (sig_len - 1 - j)); t >>= 2; }
+            const uint32_t a = allowed(i) ? i : n, b = allowed(rev) ? rev : n;
+            norm[i] = a < b ? a : b;
+        }
     } else {
         err = "unsupported KMC version";
         return false;
@@ -110,9 +151,21 @@ bool KmcDb::load(const std::string &prefix) {
     return true;
 }
 
+uint32_t KmcDb::signature(uint64_t kmer) const {
+    const uint64_t mask = (1ull << (2 * sig_len)) - 1;
+    uint32_t best = 0xFFFFFFFFu;
+    for (uint32_t i = 0; i + sig_len <= k; ++i) {
+        const uint32_t v = norm[(kmer >> (2 * (k - sig_len - i))) & mask];
+        if (v < best) best = v;
+    }
+    return best;
+}
+
 bool KmcDb::check(uint64_t kmer, uint32_t &cnt) const {
     uint64_t prefix = kmer >> (2 * (k - p));
-    if (prefix + 1 >= lut_words) return false;  // :345-346 (and keeps lut[prefix+1] in range)
+    if (prefix >= lut_words) return false;  // :345-346
+    if (version == 0x200) prefix += (uint64_t)sig_map[signature(kmer)] * single_lut;  // :348-356
+    if (prefix + 1 >= lut_words) return false;  // (keeps lut[prefix+1] in range)
     int64_t lo = (int64_t)lut[prefix], hi = (int64_t)lut[prefix + 1] - 1;
     if (lo >= (int64_t)total) return false;  // :1385
     // The reference would read one record past the buffer when lut[prefix+1]-1 == total

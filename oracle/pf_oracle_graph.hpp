@@ -43,6 +43,11 @@ struct KmcDb {
     uint32_t k = 0, mode = 0, counter_size = 0, p = 0;
     uint64_t min_count = 0, max_count = 0, total = 0;
     bool both_strands = true;
+    uint32_t version = 0;          // 0 = KMC1 layout, 0x200 = KMC2 layout
+    uint32_t sig_len = 0;
+    uint64_t single_lut = 0;       // 4^p
+    std::vector<uint32_t> sig_map; // KMC2: signature -> bin
+    std::vector<uint32_t> norm;    // KMC2: m-mer normalisation table (mmer.h)
     std::vector<uint64_t> lut;     // as the reader indexes it: lut[x], lut[x+1]
     uint64_t lut_words = 0;        // prefix_file_buf_size analogue
     std::vector<uint64_t> suffix;  // total records, (k-p) symbols each, numeric
@@ -55,6 +60,7 @@ struct KmcDb {
     bool check(uint64_t kmer, uint32_t &cnt) const;
     // the hot path's composite (CDBG.cpp:38-56): if (!IsKmer(fwd)) reverse(); CheckKmer()
     bool canonical_count(uint64_t fwd, uint32_t &cnt) const;
+    uint32_t signature(uint64_t kmer) const;  // CKmerAPI::get_signature (kmer_api.h:653-673)
 };
 
 // ---- graph (G1, G2) -------------------------------------------------------------------

@@ -202,8 +202,57 @@ bool KmcRecords::load(const std::string &prefix, std::string &err) {
     uint32_t version;
     memcpy(&version, pre.data() + pre.size() - 12, 4);
     if (version == 0x200) {
-        err = "KMC2-layout databases are not supported yet (convert with `kmc_tools transform ... kmc1` or use a KMC1 writer)";
-        return false;
+        // KMC2 (kmc_file.cpp:196-245): 'KMCP' | u64 LUT[n_bins*4^p + 1] | u32 signature_map[4^sig + 1] | header | u32 off | 'KMCP'.
+        // The lookup of the reference goes signature -> bin -> LUT row -> binary search; to enumerate the
+        // records only the LUT is needed: entry b*4^p + x covers the records of bin b whose prefix is x.
+        const uint64_t header_offset = pre[pre.size() - 8];
+        if (header_offset + 8 > pre.size() || header_offset < 37) { err = "bad KMC2 header offset"; return false; }
+        const uint8_t *h = pre.data() + pre.size() - (header_offset + 8);
+        auto u32at = [&](size_t o) { uint32_t v; memcpy(&v, h + o, 4); return v; };
+        k = u32at(0);
+        mode = u32at(4);
+        counter_size = u32at(8);
+        lut_prefix_len = u32at(12);
+        const uint32_t sig_len = u32at(16);
+        min_count = u32at(20);
+        max_count = u32at(24);
+        memcpy(&total, h + 28, 8);
+        both_strands = !h[36];
+        if (mode != 0) { err = "KMC databases with float counters (mode 1) are not supported"; return false; }
+        const uint32_t p = lut_prefix_len;
+        if (k < 3 || k > 31 || p == 0 || p >= k || (k - p) % 4 || counter_size == 0 || counter_size > 8 || sig_len < 5 || sig_len > 11) {
+            err = "unsupported k / lut_prefix_length / counter_size / signature length in the KMC2 header";
+            return false;
+        }
+        const uint64_t size = pre.size() - 12;  // without markers and the header_offset word
+        const uint64_t sig_bytes = ((1ull << (2 * sig_len)) + 1) * 4;
+        if (size < sig_bytes + header_offset + 8) { err = "kmc_pre too short for the KMC2 layout"; return false; }
+        const uint64_t n_lut = (size - sig_bytes - header_offset) / 8;  // n_bins * 4^p + 1
+        const uint64_t n_pref = 1ull << (2 * p);
+        if (n_lut < n_pref + 1 || (n_lut - 1) % n_pref) { err = "KMC2 prefix table is not a whole number of bins"; return false; }
+        const uint8_t *body = pre.data() + 4;
+        auto word = [&](uint64_t i) { uint64_t v; memcpy(&v, body + 8 * i, 8); return v; };
+        const uint32_t sb = (k - p) / 4, rec = sb + counter_size;
+        if (suf.size() - 8 < total * rec) { err = "kmc_suf holds fewer records than total_kmers"; return false; }
+        kmers.assign(total, 0);
+        counts.assign(total, 0);
+        const uint8_t *r = suf.data() + 4;
+        for (uint64_t e = 0; e + 1 < n_lut; ++e) {
+            const uint64_t x = e % n_pref;
+            const uint64_t lo = word(e);
+            uint64_t hi_rec = e + 2 < n_lut ? word(e + 1) : total;  // the reader patches the last word to total + 1
+            if (hi_rec > total) hi_rec = total;
+            for (uint64_t i = lo; i < hi_rec; ++i) {
+                const uint8_t *q = r + i * rec;
+                uint64_t s = 0;
+                for (uint32_t b2 = 0; b2 < sb; ++b2) s = (s << 8) | q[b2];
+                uint64_t c = 0;
+                for (uint32_t b2 = 0; b2 < counter_size; ++b2) c |= (uint64_t)q[sb + b2] << (8 * b2);
+                kmers[i] = (x << (2 * (k - p))) | s;
+                counts[i] = (uint32_t)c;
+            }
+        }
+        return true;
     }
     if (version != 0) { err = "unknown KMC database version"; return false; }
     // KMC1: 'KMCP' | u64 LUT[...] | header | u32 header_offset | 'KMCP'

@@ -253,3 +253,125 @@ def read_kmc1(prefix: str):
     kmers = (prefix_of << np.uint64(2 * (k - p))) | sfx
     return kmers, cnt.astype(np.uint32), dict(k=k, p=p, min_count=min_count, max_count=max_count, both_strands=both,
                                               total=total)
+
+
+# --------------------------------------------------------------------------
+# KMC2 ("0x200") layout: signature-binned prefix table, what `kmc` >= 2 really writes
+# --------------------------------------------------------------------------
+def kmc_norm_table(sig_len: int) -> np.ndarray:
+    """norm[m] = min(allowed(m), allowed(revcomp(m))), disallowed -> 4^len  (KMC/kmc_api/mmer.h:34-87)."""
+    n = 1 << (2 * sig_len)
+    m = np.arange(n, dtype=np.uint32)
+
+    def allowed(x):
+        ok = np.ones(n, dtype=bool)
+        ok &= (x & 0x3F) != 0x3F          # TTT suffix
+        ok &= (x & 0x3F) != 0x3B          # TGT suffix
+        ok &= (x & 0x3C) != 0x3C          # TG* suffix
+        y = x.copy()
+        for _ in range(sig_len - 3):
+            ok &= (y & 0xF) != 0          # AA inside
+            y = y >> 2
+        ok &= y != 0                      # AAA prefix
+        ok &= y != 0x04                   # ACA prefix
+        ok &= (y & 0xF) != 0              # *AA prefix
+        return ok
+
+    rev = np.zeros(n, dtype=np.uint32)
+    t = m.copy()
+    for i in range(sig_len):
+        rev |= (np.uint32(3) - (t & np.uint32(3))) << np.uint32(2 * (sig_len - 1 - i))
+        t = t >> np.uint32(2)
+    special = np.uint32(n)
+    a = np.where(allowed(m), m, special)
+    b = np.where(allowed(rev), rev, special)
+    return np.minimum(a, b).astype(np.uint32)
+
+
+def kmc_signatures(kmers: np.ndarray, k: int, sig_len: int) -> np.ndarray:
+    """CKmerAPI::get_signature (kmer_api.h:653-673): min over the k-sig_len+1 windows of norm[window]."""
+    norm = kmc_norm_table(sig_len)
+    mask = np.uint64((1 << (2 * sig_len)) - 1)
+    best = np.full(len(kmers), 1 << (2 * sig_len), dtype=np.uint32)
+    for i in range(k - sig_len + 1):
+        w = ((kmers >> np.uint64(2 * (k - sig_len - i))) & mask).astype(np.int64)
+        best = np.minimum(best, norm[w])
+    return best
+
+
+def write_kmc2(prefix: str, kmers: np.ndarray, counts: np.ndarray, k: int, *, counter_size: int = 2, sig_len: int = 9,
+               n_bins: int = 37, min_count: int = 1, max_count: int = 65535, both_strands: bool = True,
+               p: int | None = None) -> None:
+    """Write the KMC2 layout parsed by kmc_file.cpp:196-245:
+      .kmc_pre = 'KMCP' | u64 LUT[n_bins*4^p + 1] | u32 signature_map[4^sig_len + 1] | header(64 B) | u32 64 | 'KMCP'
+      .kmc_suf = 'KMCS' | records grouped by bin, sorted inside each bin | 'KMCS'
+    header = u32 x7 {k, mode, counter_size, p, sig_len, min_count, max_count}, u64 total, u8 !both_strands, padding,
+    u32 version 0x200 as its last word."""
+    if p is None:
+        p = lut_prefix_len(k)
+    total = len(kmers)
+    kmers = kmers.astype(np.uint64)
+    sig = kmc_signatures(kmers, k, sig_len)
+    n_sig = (1 << (2 * sig_len)) + 1
+    sig_map = (mix64(np.arange(n_sig, dtype=np.uint64)) % np.uint64(n_bins)).astype(np.uint32)
+    bins = sig_map[sig]
+    order = np.lexsort((kmers, bins))
+    kb, cb, bb = kmers[order], counts[order], bins[order]
+    pre = (kb >> np.uint64(2 * (k - p))).astype(np.int64)
+    key = bb.astype(np.int64) * (4 ** p) + pre
+    lut = np.searchsorted(key, np.arange(n_bins * 4 ** p + 1, dtype=np.int64), side="left").astype(np.uint64)
+    header = struct.pack("<7I", k, 0, counter_size, p, sig_len, min_count, max_count & 0xFFFFFFFF) + struct.pack("<Q", total) + \
+        struct.pack("<B", 0 if both_strands else 1)
+    header += b"\0" * (60 - len(header)) + struct.pack("<I", 0x200)
+    with open(prefix + ".kmc_pre", "wb") as f:
+        f.write(b"KMCP")
+        f.write(lut.tobytes())
+        f.write(sig_map.tobytes())
+        f.write(header)
+        f.write(struct.pack("<I", 64))
+        f.write(b"KMCP")
+    suf_bytes = (k - p) // 4
+    rec = np.zeros((total, suf_bytes + counter_size), dtype=np.uint8)
+    suf = kb & np.uint64((1 << (2 * (k - p))) - 1)
+    for b in range(suf_bytes):
+        rec[:, b] = ((suf >> np.uint64(8 * (suf_bytes - 1 - b))) & np.uint64(0xFF)).astype(np.uint8)
+    c = cb.astype(np.uint64)
+    for b in range(counter_size):
+        rec[:, suf_bytes + b] = ((c >> np.uint64(8 * b)) & np.uint64(0xFF)).astype(np.uint8)
+    with open(prefix + ".kmc_suf", "wb") as f:
+        f.write(b"KMCS")
+        f.write(rec.tobytes())
+        f.write(b"KMCS")
+
+
+def read_kmc(prefix: str):
+    """(kmers u64 in file order, counts u32, meta) for a KMC1- or KMC2-layout database."""
+    pre = np.fromfile(prefix + ".kmc_pre", dtype=np.uint8)
+    version = int(pre[-12:-8].view("<u4")[0])
+    if version == 0:
+        return read_kmc1(prefix)
+    assert version == 0x200, "unknown KMC version"
+    suf = np.fromfile(prefix + ".kmc_suf", dtype=np.uint8)
+    header_offset = int(pre[-8])
+    h = pre[len(pre) - header_offset - 8 :]
+    k, mode, counter_size, p, sig_len, min_count, max_count = (int(x) for x in h[:28].view("<u4"))
+    total = int(h[28:36].view("<u8")[0])
+    both = not bool(h[36])
+    size = len(pre) - 12
+    sig_bytes = (4 ** sig_len + 1) * 4
+    n_lut = (size - sig_bytes - header_offset) // 8
+    lut = pre[4 : 4 + 8 * n_lut].view("<u8").astype(np.int64).copy()
+    lut[-1] = total
+    n_pref = 4 ** p
+    sb = (k - p) // 4
+    rec = suf[4 : 4 + total * (sb + counter_size)].reshape(total, sb + counter_size)
+    sfx = np.zeros(total, dtype=np.uint64)
+    for b in range(sb):
+        sfx = (sfx << np.uint64(8)) | rec[:, b].astype(np.uint64)
+    cnt = np.zeros(total, dtype=np.uint64)
+    for b in range(counter_size):
+        cnt |= rec[:, sb + b].astype(np.uint64) << np.uint64(8 * b)
+    prefix_of = np.repeat((np.arange(n_lut - 1, dtype=np.uint64) % np.uint64(n_pref)), np.diff(lut))
+    kmers = (prefix_of << np.uint64(2 * (k - p))) | sfx
+    return kmers, cnt.astype(np.uint32), dict(k=k, p=p, min_count=min_count, max_count=max_count, both_strands=both,
+                                              total=total, layout="kmc2", sig_len=sig_len)

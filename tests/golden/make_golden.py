@@ -86,6 +86,8 @@ CASES = {
     "weird12k": (lambda: weird_haplotypes(23), 25, ["-l", "5", "-u", "1000"]),
     "cutoff": (lambda: synth.make_haplotypes(synth.HapSpec(30000, 4, seed=29, gap_lo=10, gap_hi=200)), 25,
                ["-l", "25", "-u", "70"]),
+    # the same kind of data with the count database in the KMC2 layout (signature-binned prefix table)
+    "dip_kmc2": (lambda: synth.make_haplotypes(synth.HapSpec(16000, 2, seed=31)), 25, ["-l", "5", "-u", "1000"], "kmc2"),
 }
 
 
@@ -97,7 +99,8 @@ def run(cmd, **kw):
 
 
 def make_case(name: str) -> None:
-    factory, k, args = CASES[name]
+    factory, k, args = CASES[name][:3]
+    layout = CASES[name][3] if len(CASES[name]) > 3 else "kmc1"
     out = os.path.join(HERE, name)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(os.path.join(out, "expected"))
@@ -109,7 +112,10 @@ def make_case(name: str) -> None:
         shutil.copy(os.path.join(tmp, "graph.gfa"), os.path.join(out, "graph.gfa"))
         km, mult = synth.canonical_counts(haps, k)
         cnt = synth.synth_counts(km, mult)
-        synth.write_kmc1(os.path.join(out, "db"), km, cnt, k)
+        if layout == "kmc2":
+            synth.write_kmc2(os.path.join(out, "db"), km, cnt, k, sig_len=7, n_bins=11)
+        else:
+            synth.write_kmc1(os.path.join(out, "db"), km, cnt, k)
         log = run([os.path.join(REF, "PloidyFrost"), "-g", os.path.join(out, "graph.gfa"), "-d", os.path.join(out, "db"),
                    "-o", "g", "-t", "1"] + args, cwd=tmp)
         for f in sorted(os.listdir(os.path.join(tmp, "PloidyFrost_output"))):
@@ -117,7 +123,7 @@ def make_case(name: str) -> None:
     n_unitigs = sum(1 for line in open(os.path.join(out, "graph.gfa")) if line.startswith("S\t"))
     summary = [l for l in log.splitlines() if "SuperBubbles Found" in l or "Alleles in" in l]
     with open(os.path.join(out, "args.json"), "w") as f:
-        json.dump({"k": k, "args": args, "prefix": "g", "unitigs": n_unitigs, "reference_log": summary}, f, indent=1)
+        json.dump({"k": k, "args": args, "prefix": "g", "unitigs": n_unitigs, "kmc_layout": layout, "reference_log": summary}, f, indent=1)
     print(name, n_unitigs, "unitigs;", " | ".join(s.strip() for s in summary))
 
 

@@ -87,7 +87,7 @@ def test_missing_database_kmer_fails_like_the_reference(tmp_path):
     """reference: "kmer can not found" + exit(EXIT_FAILURE) (src/CDBG.cpp:52-56, 92-96)"""
     from ploidyfrost_amd import synth
     meta = load_case("dip20k")
-    kmers, counts, km = synth.read_kmc1(meta["db"])
+    kmers, counts, km = synth.read_kmc(meta["db"])
     keep = np.ones(len(kmers), dtype=bool)
     keep[::3] = False
     synth.write_kmc1(str(tmp_path / "holes"), kmers[keep], counts[keep], km["k"])

@@ -28,7 +28,7 @@ def setup_case(case):
     dev = hipapi.Device(0)
     words, off, lens = hipapi.pack_unitigs(seqs)
     dev.upload_graph(words, off, lens, o.k)
-    kmers, counts, km = synth.read_kmc1(meta["db"])
+    kmers, counts, km = synth.read_kmc(meta["db"])
     dev.upload_counts(kmers, counts, km["min_count"], km["max_count"], km["both_strands"])
     _cache[case] = (meta, o, dev, seqs)
     return _cache[case]
@@ -59,7 +59,7 @@ def test_unitig_cov_matches_oracle(case):
 
 def test_missing_kmer_is_reported():
     meta, o, dev, _ = setup_case("dip20k")
-    kmers, counts, km = synth.read_kmc1(meta["db"])
+    kmers, counts, km = synth.read_kmc(meta["db"])
     dev2 = hipapi.Device(0)
     dev2.upload_graph(*hipapi.pack_unitigs(o.sequences()), o.k)
     dev2.upload_counts(kmers[::2].copy(), counts[::2].copy(), 1, 65535, True)
@@ -70,7 +70,7 @@ def test_missing_kmer_is_reported():
 def test_count_range_filter():
     """records outside [min_count, max_count] are not retrievable (kmc_file.cpp:1459)"""
     meta, o, dev, _ = setup_case("dip20k")
-    kmers, counts, km = synth.read_kmc1(meta["db"])
+    kmers, counts, km = synth.read_kmc(meta["db"])
     dev2 = hipapi.Device(0)
     dev2.upload_graph(*hipapi.pack_unitigs(o.sequences()), o.k)
     dev2.upload_counts(kmers, counts, 30, 45, True)
@@ -83,7 +83,7 @@ def test_count_range_filter():
 @pytest.mark.parametrize("case", golden_cases())
 def test_lookup_both_orientations(case):
     meta, o, dev, _ = setup_case(case)
-    kmers, counts, km = synth.read_kmc1(meta["db"])
+    kmers, counts, km = synth.read_kmc(meta["db"])
     k = o.k
     # reverse complements must find the same counts; random k-mers must miss
     x = kmers.copy()
@@ -176,7 +176,7 @@ def test_two_strand_database_keeps_forward_first_order():
     still answer as the reference does: the forward form wins (src/CDBG.cpp:38-56).  The upload-time
     check then disables the canonical-first probe order."""
     meta, o, dev, seqs = setup_case("dip20k")
-    kmers, counts, km = synth.read_kmc1(meta["db"])
+    kmers, counts, km = synth.read_kmc(meta["db"])
     k = o.k
 
     def rc(x):

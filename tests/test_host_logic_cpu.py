@@ -56,7 +56,7 @@ def test_count_database_covers_every_graph_kmer(case):
     meta = load_case(case)
     o = pyoracle.Oracle(meta["gfa"], meta["db"])
     s, m, miss = o.unitig_cov()
-    assert not miss.any() and (m >= 1).all() and o.n_kmers == len(synth.read_kmc1(meta["db"])[0])
+    assert not miss.any() and (m >= 1).all() and o.n_kmers == len(synth.read_kmc(meta["db"])[0])
 
 
 @pytest.mark.parametrize("spec,k", [(synth.HapSpec(60000, 4, seed=5, gap_lo=15, gap_hi=215), 25),
@@ -100,3 +100,27 @@ def test_shard_ranges_partition_in_order():
         if world > 1:
             loads = [w[a:b].sum() for a, b in [pfdist.shard_range(1000, r, world, w) for r in range(world)]]
             assert max(loads) < 1.3 * w.sum() / world
+
+
+def test_kmc2_layout_roundtrip_and_signature_lookup(tmp_path):
+    """KMC2 layout (what kmc >= 2 writes): the writer's signature binning, the enumerating reader,
+    and the oracle's signature -> bin -> LUT -> binary-search lookup (kmc_file.cpp:330-366) agree."""
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    k = 25
+    kmers = np.unique(rng.integers(0, 1 << 50, size=4000, dtype=np.uint64))
+    counts = rng.integers(1, 60000, size=len(kmers)).astype(np.uint32)
+    for sig_len, n_bins in ((7, 11), (9, 37)):
+        pre = str(tmp_path / ("db%d" % sig_len))
+        synth.write_kmc2(pre, kmers, counts, k, sig_len=sig_len, n_bins=n_bins)
+        k2, c2, meta = synth.read_kmc(pre)
+        order = np.argsort(k2)
+        assert meta["layout"] == "kmc2" and np.array_equal(k2[order], kmers) and np.array_equal(c2[order], counts)
+        (tmp_path / "g.gfa").write_text("H\tVN:Z:1.0\tKL:Z:25\tML:Z:17\nS\t1\t%s\n" % ("ACGT" * 10))
+        o = pyoracle.Oracle(str(tmp_path / "g.gfa"), pre)
+        for x, c in list(zip(kmers.tolist(), counts.tolist()))[:400]:
+            s = bytes(b"ACGT"[(x >> (2 * (k - 1 - j))) & 3] for j in range(k))
+            got = C.c_uint32()
+            assert o.L.pfo_kmer_count(o.h, s, C.byref(got)) == 1 and got.value == c
+            assert o.L.pfo_kmer_count(o.h, rc(s), C.byref(got)) == 1 and got.value == c
+        assert o.L.pfo_kmer_count(o.h, b"A" * k, C.byref(got)) == 0
