@@ -43,19 +43,21 @@ def log(*a):
     print("[bench]", *a, file=sys.stderr, flush=True)
 
 
-def make_inputs(workdir: str, name: str, genome_len: int, seed: int, device):
+def make_inputs(workdir: str, name: str, genome_len: int, seed: int, device, k: int = K, max_ins: int = 6, ploidy: int = 4,
+                p_snp: float = 0.75, p_del: float = 0.13):
     """haplotypes -> compacted dBG (GFA) + KMC1 count database; returns (gfa, db_prefix, n_unitigs, n_kmers)."""
     from ploidyfrost_amd import cdbg_build, synth
     t0 = time.time()
-    spec = synth.HapSpec(genome_len=genome_len, ploidy=4, seed=seed, gap_lo=GAP_LO, gap_hi=GAP_HI, p_multi=0.03)
+    spec = synth.HapSpec(genome_len=genome_len, ploidy=ploidy, seed=seed, gap_lo=GAP_LO, gap_hi=GAP_HI, p_multi=0.03,
+                         max_ins=max_ins, p_snp=p_snp, p_del=p_del)
     haps = synth.make_haplotypes(spec)
-    g = cdbg_build.build_cdbg(haps, K, device)
+    g = cdbg_build.build_cdbg(haps, k, device)
     gfa = os.path.join(workdir, name + ".gfa")
     n_unitigs = cdbg_build.write_gfa(gfa, g)
     counts = synth.synth_counts(g["kmers"], g["mult"])
     db = os.path.join(workdir, name + "_kmc")
-    synth.write_kmc1(db, g["kmers"], counts, K)
-    log("inputs %s: genome %d bp x4 -> %d unitigs, %d k-mers (%.1fs)" % (name, genome_len, n_unitigs, len(g["kmers"]),
+    synth.write_kmc1(db, g["kmers"], counts, k)
+    log("inputs %s: genome %d bp x%d -> %d unitigs, %d k-mers (%.1fs)" % (name, genome_len, ploidy, n_unitigs, len(g["kmers"]),
                                                                         time.time() - t0))
     return gfa, db, n_unitigs, len(g["kmers"])
 
@@ -118,8 +120,8 @@ def algorithmic_bytes(kernel: str, t: dict) -> float | None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--unitigs", type=int, default=1_000_000, help="target unitigs per GPU (config[1] = 1 M)")
     ap.add_argument("--cpu-sample-unitigs", type=int, default=150_000)
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per rank (0 = min(32, cpus/ranks))")
@@ -134,23 +136,28 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # PF_BENCH_SHARE_GPU=1 (debugging on a one-GPU box only): every rank uses GPU 0 and the end-of-pass
+    # exchange runs over gloo on CPU tensors, because RCCL refuses two ranks on one device.
+    share = os.environ.get("PF_BENCH_SHARE_GPU") == "1"
+    gpu_index = 0 if share else local_rank
+    torch.cuda.set_device(gpu_index)
+    dev = torch.device("cuda", gpu_index)
     from ploidyfrost_amd import dist as pfdist
     from ploidyfrost_amd import hipapi, hostapi
-    pfdist.init("nccl", dev)
+    pfdist.init("gloo" if share else "nccl", None if share else dev)
+    xdev = torch.device("cpu") if share else dev  # where the collectives' tensors live
     workdir = tempfile.mkdtemp(prefix="pf_bench_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         genome = int(args.unitigs / UNITIGS_PER_BP)
         gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, 1000 + rank, dev)
         torch.cuda.empty_cache()
         t0 = time.time()
-        run = hostapi.Run(gfa, db, z=Z, device=local_rank)
+        run = hostapi.Run(gfa, db, z=Z, device=gpu_index)
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
         run.set_threads(host_threads)
         run.set_output_dir(os.path.join(workdir, "PloidyFrost_output"))
         run.set_unitig_id("b")
-        log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, time.time() - t0, torch.cuda.get_device_name(local_rank)))
+        log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, time.time() - t0, torch.cuda.get_device_name(gpu_index)))
         L = hipapi.load_library()
         import ctypes as C
         ctx = C.c_void_p(run.device_ctx())
@@ -163,8 +170,8 @@ def main():
             if world > 1:
                 # end-of-pass exchange over RCCL: counters + the ordered allele-frequency record slab
                 tt_ = run.times()
-                pfdist.all_gather_counters(tt_["allele"] + [tt_["tasks"]], dev)
-                slabs = pfdist.all_gather_slabs(run.last_allele_frequency(), dev)
+                pfdist.all_gather_counters(tt_["allele"] + [tt_["tasks"]], xdev)
+                slabs = pfdist.all_gather_slabs(run.last_allele_frequency(), xdev)
                 gathered_bytes[0] = sum(int(x.size) for x in slabs)
 
         for _ in range(args.warmup):
@@ -197,7 +204,7 @@ def main():
                 ktimes[name] = (ms.value, n.value)
 
         allstats = pfdist.all_gather_counters([n_unitigs, tt["superbubbles"], tt["tasks"], tt["output_bytes"]] + tt["allele"] +
-                                              [int(elapsed * 1e6)], dev)
+                                              [int(elapsed * 1e6)], xdev)
         max_elapsed = allstats[:, -1].max() / 1e6
         total_unitigs = int(allstats[:, 0].sum())
 

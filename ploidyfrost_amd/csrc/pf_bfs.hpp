@@ -107,7 +107,7 @@ __device__ inline BfsResult bfs_traverse(const uint32_t *__restrict__ succ, cons
             tip_flag = true;  // :273-276
         } else {
             for (int b = 0; b < 4; ++b) {
-                const uint32_t u = __shfl(my_succ, b, WAVE);
+                const uint32_t u = read_lane(my_succ, b);
                 if (u == NONE) continue;
                 if (u == s) {  // :281-287
                     cyc_flag = true;
@@ -137,7 +137,7 @@ __device__ inline BfsResult bfs_traverse(const uint32_t *__restrict__ succ, cons
                     wave_sync();
                     bool all_pred = true;  // :305-325
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t p = __shfl(my_pred, b * 4 + j, WAVE);
+                        const uint32_t p = read_lane(my_pred, b * 4 + j);
                         if (p == NONE) continue;
                         const int pe = bfs_find(st, n, p);
                         const uint8_t pm = pe >= 0 ? st.meta[pe] : 0;

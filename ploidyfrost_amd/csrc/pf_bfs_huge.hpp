@@ -38,12 +38,16 @@ __device__ inline bool huge_cyc_add(const HugeStore &st, uint32_t epoch, uint32_
     return true;
 }
 
-// Per popped vertex the memory round trips are: the vertex itself (skipped when it was pushed in the
-// previous step), {its state word, its successor row}, {the four predecessor rows, the successors'
-// state words}, {the predecessors' state words} -- each group one wave-wide load.  State words
-// changed while the successors are resolved in order are patched in the lanes that prefetched them,
-// so no load is repeated and a single fence per step orders the stores.
-__device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
+// Memory round trips decide the speed of a chromosome-long traversal, so each step needs only one in
+// the common case:
+//   * `pred16[ov]` holds, for each of the four successor slots of ov, the predecessor row of that
+//     successor (a two-hop row built once per graph), so the neighbourhood of v is two loads off v;
+//   * the next vertex popped is almost always the successor pushed last, so while the state words of
+//     v's successors and predecessors are in flight the rows (succ + pred16) of all four successors
+//     are fetched speculatively; the chosen one is then already in registers;
+//   * state words changed while the successors are resolved in order are patched in the lanes that
+//     prefetched them; no load is repeated and no fence is needed inside a step.
+__device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred16,
                                               const HugeStore &st, uint32_t epoch, uint32_t s) {
     const int lane = lane_id();
     BfsResult r;
@@ -62,26 +66,50 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
         st.first[s >> 1] = s;
         st.todo[0] = s;
     }
-    uint32_t cached_top = s;  // value of todo[top-1] when known without a load
+    // speculative rows of the previous step's successors: spec_S lanes 4c..4c+3 = succ row of
+    // candidate c, spec_P lanes 16c..16c+15 = its pred16 row; spec_v[c] = the candidate itself
+    uint32_t spec_S = NONE, spec_P = NONE, spec_cand = NONE;  // spec_cand: lanes 0..3 hold the candidates
+    uint32_t cached_top = s, cached_word = 0, cached_first = s;
     bool have_top = true;
-    wave_sync();
+    __builtin_amdgcn_wave_barrier();
     while (top > 0) {
         const uint32_t v = have_top ? cached_top : st.todo[top - 1];
         have_top = false;
         top--;
-        // {state word of v, successor row of v}
-        const uint32_t ld1 = lane < 4 ? succ[(size_t)v * 4 + lane] : (lane == 4 ? st.info[v >> 1] : 0u);
-        const uint32_t my_succ = lane < 4 ? ld1 : NONE;
-        const uint32_t v_old = decode(__shfl(ld1, 4, WAVE));
+        // rows of v: from the speculation of the previous step when v was one of its successors
+        uint32_t my_succ, my_pred;
+        {
+            const unsigned long long hit = __ballot(lane < 4 && spec_cand == v);
+            if (hit) {
+                const int c = __ffsll((long long)hit) - 1;
+                my_succ = __shfl(spec_S, 4 * c + (lane & 3), WAVE);
+                my_pred = __shfl(spec_P, 16 * c + (lane & 15), WAVE);
+                if (lane >= 4) my_succ = NONE;
+                if (lane >= 16) my_pred = NONE;
+            } else {
+                my_succ = lane < 4 ? succ[(size_t)v * 4 + lane] : NONE;
+                my_pred = lane < 16 ? pred16[(size_t)v * 16 + lane] : NONE;
+            }
+        }
+        // one round trip: state words of v, of its successors and of their predecessors, plus the
+        // rows of the four successors for the next step
+        const uint32_t v_word = st.info[v >> 1];
+        uint32_t my_sinfo = (lane < 4 && my_succ != NONE) ? st.info[my_succ >> 1] : 0u;
+        uint32_t my_pinfo = (lane < 16 && my_pred != NONE) ? st.info[my_pred >> 1] : 0u;
+        {
+            const uint32_t cs = __shfl(my_succ, lane >> 2, WAVE);   // candidate of my 4-lane group (lanes 0..15)
+            const uint32_t cp = __shfl(my_succ, lane >> 4, WAVE);   // candidate of my 16-lane group
+            spec_S = (lane < 16 && cs != NONE) ? succ[(size_t)cs * 4 + (lane & 3)] : NONE;
+            spec_P = cp != NONE ? pred16[(size_t)cp * 16 + (lane & 15)] : NONE;
+            spec_cand = my_succ;
+        }
+        const uint32_t v_old = decode(v_word);
         if ((v_old & 3) == 2) n_pending--;
         const uint32_t v_info = tag | 1u | (((v & 1) == 0) ? 4u : 0u);  // visited; strand_map[id(v)] = v.strand
         if (lane == 0) st.info[v >> 1] = v_info;
-        // {predecessor rows of the successors, state words of the successors}
-        const uint32_t sb = __shfl(my_succ, lane >> 2, WAVE);
-        const uint32_t my_pred = (lane < 16 && sb != NONE) ? pred[(size_t)sb * 4 + (lane & 3)] : NONE;
-        uint32_t my_sinfo = (lane < 4 && my_succ != NONE) ? ((my_succ >> 1) == (v >> 1) ? v_info : st.info[my_succ >> 1]) : 0u;
-        // {state words of the predecessors}
-        uint32_t my_pinfo = (lane < 16 && my_pred != NONE) ? ((my_pred >> 1) == (v >> 1) ? v_info : st.info[my_pred >> 1]) : 0u;
+        // v's own word may be among the prefetched ones (self loops, hairpins)
+        if (lane < 4 && my_succ != NONE && (my_succ >> 1) == (v >> 1)) my_sinfo = v_info;
+        if (lane < 16 && my_pred != NONE && (my_pred >> 1) == (v >> 1)) my_pinfo = v_info;
         auto patch = [&](uint32_t unitig, uint32_t word) {
             if (lane < 4 && my_succ != NONE && (my_succ >> 1) == unitig) my_sinfo = word;
             if (lane < 16 && my_pred != NONE && (my_pred >> 1) == unitig) my_pinfo = word;
@@ -90,14 +118,14 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
             tip_flag = true;
         } else {
             for (int b = 0; b < 4; ++b) {
-                const uint32_t u = __shfl(my_succ, b, WAVE);
+                const uint32_t u = read_lane(my_succ, b);
                 if (u == NONE) continue;
                 if (u == s) {
                     cyc_flag = true;
                     if (!huge_cyc_add(st, epoch, n_cyc, s) || !huge_cyc_add(st, epoch, n_cyc, v)) { r.overflow = true; return r; }
                     continue;
                 }
-                const uint32_t um = decode(__shfl(my_sinfo, b, WAVE));
+                const uint32_t um = decode(read_lane(my_sinfo, b));
                 // the entrance sits in `seen` before it has a state; it is popped first, so afterwards
                 // "in state_map" and "in seen" coincide
                 if (um == 0 || (um & 3) != 1) {
@@ -119,8 +147,8 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
                     patch(u >> 1, new_info);
                     bool all_pred = true;
                     for (int j = 0; j < 4; ++j) {
-                        const uint32_t p = __shfl(my_pred, b * 4 + j, WAVE);
-                        const uint32_t pm = decode(__shfl(my_pinfo, b * 4 + j, WAVE));
+                        const uint32_t p = read_lane(my_pred, b * 4 + j);
+                        const uint32_t pm = decode(read_lane(my_pinfo, b * 4 + j));
                         if (p == NONE) continue;
                         if (pm != 0) {
                             if ((pm & 3) != 1) all_pred = false;
@@ -137,6 +165,8 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
                         if (lane == 0) st.todo[top] = u;
                         top++;
                         cached_top = u;
+                        cached_word = new_info;
+                        cached_first = um == 0 ? u : NONE;  // first[] of a vertex seen earlier has to be loaded
                         have_top = true;
                     }
                 } else {
@@ -151,8 +181,9 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
         __builtin_amdgcn_wave_barrier();
         if (top == 1) {
             const uint32_t t0 = have_top ? cached_top : st.todo[0];
-            const uint32_t tm = decode(st.info[t0 >> 1]);
-            const uint32_t mine = ((tm & 3) == 2 && st.first[t0 >> 1] == t0) ? 1u : 0u;
+            const uint32_t tm = decode(have_top ? cached_word : st.info[t0 >> 1]);
+            uint32_t mine = 0;
+            if ((tm & 3) == 2) mine = ((have_top && cached_first != NONE) ? cached_first : st.first[t0 >> 1]) == t0 ? 1u : 0u;
             if (n_pending == mine) {
                 r.exit_ov = t0;
                 const uint32_t ts = lane < 4 ? succ[(size_t)t0 * 4 + lane] : NONE;

@@ -30,6 +30,7 @@ struct pf_ctx {
     int k = 0;
     uint64_t n_words = 0, n_kmers = 0;
     uint32_t *d_succ = nullptr, *d_pred = nullptr;  // [2N][4]
+    uint32_t *d_pred16 = nullptr;                   // [2N][4][4] two-hop rows, built on first use by the huge BFS tier
     bool has_adj = false;
     uint32_t *d_cand = nullptr;    // oriented vertices with out-degree > 1, ascending
     std::vector<uint32_t> h_cand;  // host copy (shard range queries)

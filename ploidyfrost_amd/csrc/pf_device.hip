@@ -347,6 +347,20 @@ __global__ __launch_bounds__(64) void k_bfs_big(const uint32_t *__restrict__ suc
 }
 
 // K-BFS, last tier: direct-indexed state (pf_bfs_huge.hpp), one candidate per wave.
+// two-hop rows for the huge tier: the predecessor rows of the four successors of every oriented vertex
+__global__ void k_pred16(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred, uint32_t n_ov,
+                         uint32_t *__restrict__ pred16) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < (uint64_t)n_ov * 4; i += stride) {
+        const uint32_t sv = succ[i];
+        uint4 row;
+        row.x = row.y = row.z = row.w = NONE;
+        if (sv != NONE) row = *reinterpret_cast<const uint4 *>(pred + (size_t)sv * 4);
+        *reinterpret_cast<uint4 *>(pred16 + i * 4) = row;
+    }
+}
+
 __global__ __launch_bounds__(64) void k_bfs_huge(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
                                                  const uint32_t *__restrict__ cand, uint64_t c0, unsigned int n_deferred2,
                                                  uint32_t *scratch, uint32_t n_unitigs, BfsOut o) {
@@ -474,6 +488,8 @@ int pf_create(int device, pf_ctx **out) {
 static void free_graph(pf_ctx *ctx) {
     hipFree(ctx->d_seq); hipFree(ctx->d_off); hipFree(ctx->d_len); hipFree(ctx->d_succ); hipFree(ctx->d_pred);
     hipFree(ctx->d_cand);
+    hipFree(ctx->d_pred16);
+    ctx->d_pred16 = nullptr;
     ctx->d_seq = ctx->d_off = nullptr;
     ctx->d_len = ctx->d_succ = ctx->d_pred = ctx->d_cand = nullptr;
     ctx->h_cand.clear();
@@ -622,6 +638,8 @@ int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
     PF_HIP(hipMalloc(&d_num, 4));
     hipFree(ctx->d_cand);
     ctx->d_cand = nullptr;
+    hipFree(ctx->d_pred16);  // stale two-hop rows of a previous adjacency
+    ctx->d_pred16 = nullptr;
     PF_HIP(hipMalloc(&ctx->d_cand, (size_t)N * 2 * 4));
     k_mark_candidates<<<ctx_grid(ctx, (uint64_t)N * 2, 256, 8), 256, 0, ctx->stream>>>(ctx->d_succ, N * 2, flag);
     {
@@ -863,7 +881,11 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
             PF_HIP(hipMalloc(&hs, per * hw * 4));
             PF_HIP(hipMemsetAsync(hs, 0, per * hw * 4, ctx->stream));
             ctx_begin(ctx, PF_K_BFS_BIG);
-            k_bfs_huge<<<hw, 64, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, n_def2, hs, ctx->N, o);
+            if (!ctx->d_pred16) {
+                PF_HIP(hipMalloc(&ctx->d_pred16, (size_t)ctx->N * 2 * 16 * 4));
+                k_pred16<<<ctx_grid(ctx, (uint64_t)ctx->N * 8, 256, 8), 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->N * 2, ctx->d_pred16);
+            }
+            k_bfs_huge<<<hw, 64, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred16, ctx->d_cand, c0, n_def2, hs, ctx->N, o);
             ctx_end(ctx);
             PF_HIP(hipStreamSynchronize(ctx->stream));
             hipFree(hs);

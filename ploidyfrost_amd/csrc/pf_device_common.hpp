@@ -102,4 +102,8 @@ __device__ inline uint32_t wave_min_u32(uint32_t v) {
 
 __device__ inline int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 
+// value of `x` in lane `i` (wave-uniform i): v_readlane_b32 into an SGPR, a few cycles, where a
+// general __shfl is an LDS-crossbar ds_bpermute with LDS latency
+__device__ inline uint32_t read_lane(uint32_t x, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)x, i); }
+
 }  // namespace pf
