@@ -248,10 +248,10 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
     PF_HIP(hipMemcpyAsync(&n_retry, d_nretry, 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     int status = PF_OK;
-    uint8_t *work2 = nullptr;
-    char *bt = nullptr;
-    uint32_t *bg = nullptr;
-    pf_align_hit *bh = nullptr;
+    DevTmp<uint8_t> work2_;
+    DevTmp<char> bt_;
+    DevTmp<uint32_t> bg_;
+    DevTmp<pf_align_hit> bh_;
     if (n_retry) {
         // staging overflow: rerun those jobs in the global tier with 256x the staging
         std::vector<uint32_t> rj(n_retry);
@@ -261,10 +261,14 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
         const int grid = (int)std::min<uint32_t>(n_retry, 16);
         const uint64_t per = (need + 255) & ~255ull;
         const uint32_t BT = 16u << 20, BG = 2u << 20, BH = 128u << 10;
-        PF_HIP(hipMalloc(&work2, per * grid));
-        PF_HIP(hipMalloc(&bt, (size_t)grid * BT));
-        PF_HIP(hipMalloc(&bg, (size_t)grid * BG * 4));
-        PF_HIP(hipMalloc(&bh, (size_t)grid * BH * sizeof(pf_align_hit)));
+        PF_HIP(work2_.alloc(per * grid));
+        PF_HIP(bt_.alloc((size_t)grid * BT));
+        PF_HIP(bg_.alloc((size_t)grid * BG * 4));
+        PF_HIP(bh_.alloc((size_t)grid * BH * sizeof(pf_align_hit)));
+        uint8_t *work2 = work2_.p;
+        char *bt = bt_.p;
+        uint32_t *bg = bg_.p;
+        pf_align_hit *bh = bh_.p;
         PF_HIP(hipMemcpyAsync(d_idx, rj.data(), (size_t)n_retry * 4, hipMemcpyHostToDevice, st));
         p.idx = d_idx; p.n = n_retry; p.work = work2; p.work_per_wave = per; p.final_tier = 1;
         p.st_text = bt; p.st_gaps = bg; p.st_hits = bh;
@@ -297,6 +301,5 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
                     }
         }
     }
-    hipFree(work2); hipFree(bt); hipFree(bg); hipFree(bh);
     return status;
 }

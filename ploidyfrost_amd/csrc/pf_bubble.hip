@@ -756,10 +756,12 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     p.scratch = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
     if (!p.scratch) return PF_ERR_HIP;
 
+    DevTmp<unsigned long long> clk_;
     unsigned long long *d_clk = nullptr;
     const bool want_clk = getenv("PF_BUBBLE_STATS") != nullptr;
     if (want_clk) {
-        PF_HIP(hipMalloc(&d_clk, ((size_t)n_tasks + 8) * 8));
+        PF_HIP(clk_.alloc(((size_t)n_tasks + 8) * 8));
+        d_clk = clk_.p;
         PF_HIP(hipMemsetAsync(d_clk, 0, ((size_t)n_tasks + 8) * 8, st));
         p.task_clk = d_clk;
         p.prof = d_clk + n_tasks;
@@ -804,7 +806,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     PF_HIP(hipMemcpyAsync(&n_retry, o.n_retry, 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     int status = PF_OK;
-    uint8_t *big_scratch = nullptr, *big_work = nullptr;
+    DevTmp<uint8_t> big_scratch_, big_work_;
     if (n_retry) {
         // some capacity of the standard tier was exceeded: rerun with 32x the scratch on a few waves
         std::vector<uint32_t> rj(n_retry);
@@ -819,8 +821,9 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         const int grid = (int)std::min<uint32_t>(n_retry, 8);
         const uint64_t per_s = (bub_scratch_bytes(big) + 255) & ~255ull;
         const uint64_t per_w = (std::min<uint64_t>(need, 0xFFFFFF00u) + 255) & ~255ull;
-        PF_HIP(hipMalloc(&big_scratch, per_s * grid));
-        PF_HIP(hipMalloc(&big_work, per_w * grid));
+        PF_HIP(big_scratch_.alloc(per_s * grid));
+        PF_HIP(big_work_.alloc(per_w * grid));
+        uint8_t *big_scratch = big_scratch_.p, *big_work = big_work_.p;
         PF_HIP(hipMemcpyAsync(d_idx, rj.data(), (size_t)n_retry * 4, hipMemcpyHostToDevice, st));
         p.idx = d_idx; p.n = n_retry; p.caps = big; p.scratch = big_scratch; p.scratch_per_wave = per_s;
         p.work = big_work; p.work_per_wave = per_w; p.work_bytes = (uint32_t)per_w; p.final_tier = 1;
@@ -835,7 +838,6 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         fprintf(stderr, "[pf_align_bubbles] ticks by phase: fill %llu traceback %llu | decode %llu round0(incl. NW) %llu rounds %llu choose %llu publish %llu\n",
                 clk[n_tasks], clk[n_tasks + 1], clk[n_tasks + 2], clk[n_tasks + 3], clk[n_tasks + 4], clk[n_tasks + 5], clk[n_tasks + 6]);
         clk.resize(n_tasks);
-        hipFree(d_clk);
         std::vector<unsigned long long> srt(clk);
         std::sort(srt.begin(), srt.end());
         unsigned long long tot = 0;
@@ -872,7 +874,5 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
                     break;
                 }
     }
-    hipFree(big_scratch);
-    hipFree(big_work);
     return status;
 }

@@ -9,6 +9,17 @@
 #include "pf_device_common.hpp"
 
 namespace pf {
+// device allocation that lives until the end of the enclosing call, freed on every return path
+template <typename T>
+struct DevTmp {
+    T *p = nullptr;
+    DevTmp() = default;
+    DevTmp(const DevTmp &) = delete;
+    DevTmp &operator=(const DevTmp &) = delete;
+    ~DevTmp() { if (p) (void)hipFree(p); }
+    hipError_t alloc(size_t bytes) { return hipMalloc(reinterpret_cast<void **>(&p), bytes ? bytes : 1); }
+};
+
 struct TimedLaunch {
     int kernel;
     hipEvent_t a, b;

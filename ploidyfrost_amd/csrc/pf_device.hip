@@ -619,8 +619,9 @@ int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
     const uint32_t N = ctx->N;
     uint64_t cap = 1;
     while (cap < (uint64_t)N * 4) cap <<= 1;
-    Slot *ends = nullptr;
-    PF_HIP(hipMalloc(&ends, cap * sizeof(Slot)));
+    DevTmp<Slot> ends_;
+    PF_HIP(ends_.alloc(cap * sizeof(Slot)));
+    Slot *ends = ends_.p;
     if (!ctx->d_succ) PF_HIP(hipMalloc(&ctx->d_succ, (size_t)N * 8 * 4));
     if (!ctx->d_pred) PF_HIP(hipMalloc(&ctx->d_pred, (size_t)N * 8 * 4));
     k_fill_slots<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ends, cap);
@@ -632,10 +633,12 @@ int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
                                                                                ctx->d_len, N, ctx->k, ctx->d_succ, ctx->d_pred);
     ctx_end(ctx);
     // candidate list: oriented vertices with out-degree > 1, ascending
-    uint8_t *flag = nullptr;
-    uint32_t *d_num = nullptr;
-    PF_HIP(hipMalloc(&flag, (size_t)N * 2));
-    PF_HIP(hipMalloc(&d_num, 4));
+    DevTmp<uint8_t> flag_;
+    DevTmp<uint32_t> num_;
+    PF_HIP(flag_.alloc((size_t)N * 2));
+    PF_HIP(num_.alloc(4));
+    uint8_t *flag = flag_.p;
+    uint32_t *d_num = num_.p;
     hipFree(ctx->d_cand);
     ctx->d_cand = nullptr;
     hipFree(ctx->d_pred16);  // stale two-hop rows of a previous adjacency
@@ -645,20 +648,16 @@ int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
     {
         hipcub::CountingInputIterator<uint32_t> ids(0);
         size_t tmp_bytes = 0;
-        void *tmp = nullptr;
+        DevTmp<uint8_t> tmp_;
         PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, ids, flag, ctx->d_cand, d_num, (int)(N * 2), ctx->stream));
-        PF_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
-        PF_HIP(hipcub::DeviceSelect::Flagged(tmp, tmp_bytes, ids, flag, ctx->d_cand, d_num, (int)(N * 2), ctx->stream));
+        PF_HIP(tmp_.alloc(tmp_bytes));
+        PF_HIP(hipcub::DeviceSelect::Flagged(tmp_.p, tmp_bytes, ids, flag, ctx->d_cand, d_num, (int)(N * 2), ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
-        hipFree(tmp);
     }
     uint32_t n_cand = 0;
     PF_HIP(hipMemcpy(&n_cand, d_num, 4, hipMemcpyDeviceToHost));
     ctx->h_cand.resize(n_cand);
     if (n_cand) PF_HIP(hipMemcpy(ctx->h_cand.data(), ctx->d_cand, (size_t)n_cand * 4, hipMemcpyDeviceToHost));
-    hipFree(flag);
-    hipFree(d_num);
-    hipFree(ends);
     ctx->has_adj = true;
     if (succ) PF_HIP(hipMemcpyAsync(succ, ctx->d_succ, (size_t)N * 8 * 4, hipMemcpyDefault, ctx->stream));
     if (pred) PF_HIP(hipMemcpyAsync(pred, ctx->d_pred, (size_t)N * 8 * 4, hipMemcpyDefault, ctx->stream));
@@ -686,17 +685,17 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
     hipPointerAttribute_t at;
     const bool on_dev = n && hipPointerGetAttributes(&at, kmers) == hipSuccess && at.type == hipMemoryTypeDevice;
     (void)hipGetLastError();
-    uint64_t *dk = nullptr;
-    uint32_t *dc = nullptr;
+    DevTmp<uint64_t> dk_;
+    DevTmp<uint32_t> dc_;
     const uint64_t *pk = kmers;
     const uint32_t *pc = counts;
     if (!on_dev && n) {
-        PF_HIP(hipMalloc(&dk, n * 8));
-        PF_HIP(hipMalloc(&dc, n * 4));
-        PF_HIP(hipMemcpyAsync(dk, kmers, n * 8, hipMemcpyDefault, ctx->stream));
-        PF_HIP(hipMemcpyAsync(dc, counts, n * 4, hipMemcpyDefault, ctx->stream));
-        pk = dk;
-        pc = dc;
+        PF_HIP(dk_.alloc(n * 8));
+        PF_HIP(dc_.alloc(n * 4));
+        PF_HIP(hipMemcpyAsync(dk_.p, kmers, n * 8, hipMemcpyDefault, ctx->stream));
+        PF_HIP(hipMemcpyAsync(dc_.p, counts, n * 4, hipMemcpyDefault, ctx->stream));
+        pk = dk_.p;
+        pc = dc_.p;
     }
     if (n) {
         ctx_begin(ctx, PF_K_TABLE_BUILD);
@@ -705,18 +704,17 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
     }
     // one orientation per k-mer?  (decides the probe order of the composite lookup, never its result)
     {
-        unsigned int *d_flag = nullptr, h_flag = 0;
-        PF_HIP(hipMalloc(&d_flag, 4));
+        DevTmp<unsigned int> flag_;
+        unsigned int h_flag = 0;
+        PF_HIP(flag_.alloc(4));
+        unsigned int *d_flag = flag_.p;
         PF_HIP(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
         if (n && ctx->k)
             k_table_two_strands<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap, ctx->k, d_flag);
         PF_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
-        hipFree(d_flag);
         ctx->tab_one_strand = (n && ctx->k) ? h_flag == 0 : false;
     }
-    hipFree(dk);
-    hipFree(dc);
     return PF_OK;
 }
 
@@ -728,17 +726,18 @@ int pf_lookup_kmers(pf_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *co
     bool own;
     int rc = stage_in(ctx, kmers, n, &dk, &own);
     if (rc) return rc;
-    uint32_t *dc;
-    uint8_t *df;
-    PF_HIP(hipMalloc(&dc, n * 4));
-    PF_HIP(hipMalloc(&df, n));
+    DevTmp<uint64_t> own_;
+    if (own) own_.p = dk;  // freed on every return path
+    DevTmp<uint32_t> dc_;
+    DevTmp<uint8_t> df_;
+    PF_HIP(dc_.alloc(n * 4));
+    PF_HIP(df_.alloc(n));
+    uint32_t *dc = dc_.p;
+    uint8_t *df = df_.p;
     k_lookup<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->tab_one_strand, dk, n, dc, df);
     PF_HIP(hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(found, df, n, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
-    if (own) hipFree(dk);
-    hipFree(dc);
-    hipFree(df);
     return PF_OK;
 }
 
@@ -860,25 +859,26 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
     int status = PF_OK;
     if (n_def) {
         const unsigned int waves = std::min<unsigned int>(n_def, 256);
-        uint32_t *sc32;
-        uint8_t *sc8;
-        PF_HIP(hipMalloc(&sc32, (size_t)waves * 3 * BFS_BIG_CAP * 4));
-        PF_HIP(hipMalloc(&sc8, (size_t)waves * BFS_BIG_CAP));
+        DevTmp<uint32_t> sc32_;
+        DevTmp<uint8_t> sc8_;
+        PF_HIP(sc32_.alloc((size_t)waves * 3 * BFS_BIG_CAP * 4));
+        PF_HIP(sc8_.alloc((size_t)waves * BFS_BIG_CAP));
+        uint32_t *sc32 = sc32_.p;
+        uint8_t *sc8 = sc8_.p;
         ctx_begin(ctx, PF_K_BFS_BIG);
         k_bfs_big<<<waves, 64, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, n_def, sc32, sc8, o);
         ctx_end(ctx);
         unsigned int n_def2 = 0;
         PF_HIP(hipMemcpyAsync(&n_def2, d_ndef2, 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
-        hipFree(sc32);
-        hipFree(sc8);
         if (n_def2) {
             // traversals beyond the linear tables: direct-indexed state sized by the graph, a few waves
             // one wave per traversal, as many side by side as ~16 GiB of state allow
             const unsigned int hw = (unsigned int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_def2, 64), (16ull << 30) / (36 * (size_t)ctx->N + 64)));
             const size_t per = 9 * (size_t)ctx->N + 16;
-            uint32_t *hs = nullptr;
-            PF_HIP(hipMalloc(&hs, per * hw * 4));
+            DevTmp<uint32_t> hs_;
+            PF_HIP(hs_.alloc(per * hw * 4));
+            uint32_t *hs = hs_.p;
             PF_HIP(hipMemsetAsync(hs, 0, per * hw * 4, ctx->stream));
             ctx_begin(ctx, PF_K_BFS_BIG);
             if (!ctx->d_pred16) {
@@ -888,7 +888,6 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
             k_bfs_huge<<<hw, 64, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred16, ctx->d_cand, c0, n_def2, hs, ctx->N, o);
             ctx_end(ctx);
             PF_HIP(hipStreamSynchronize(ctx->stream));
-            hipFree(hs);
         }
     }
     ctx->bfs_deferred = n_def;
