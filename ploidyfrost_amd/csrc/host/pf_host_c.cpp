@@ -1,5 +1,6 @@
 #include <chrono>
 #include <cstring>
+#include <exception>
 #include <memory>
 #include <string>
 
@@ -22,6 +23,7 @@ extern "C" {
 pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex_size, double match, double mismatch,
                   double gap, int device) {
     using clk = std::chrono::steady_clock;
+    try {
     auto r = std::make_unique<pfh_run>();
     auto t0 = clk::now();
     if (!r->graph.load_gfa(gfa_path, g_open_err)) return nullptr;
@@ -33,17 +35,42 @@ pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex
     r->upload_s = std::chrono::duration<double>(clk::now() - t0).count();
     if (!r->cdbg->good()) { g_open_err = r->cdbg->error(); return nullptr; }
     return r.release();
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return nullptr;
+    }
 }
 
 void pfh_close(pfh_run *r) { delete r; }
-const char *pfh_last_error(const pfh_run *r) { return r ? r->cdbg->error().c_str() : g_open_err.c_str(); }
+const char *pfh_last_error(const pfh_run *r) {
+    if (!r) return g_open_err.c_str();
+    return !r->err.empty() ? r->err.c_str() : r->cdbg->error().c_str();
+}
 void pfh_set_output_dir(pfh_run *r, const char *dir) { r->cdbg->set_output_dir(dir); }
 void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0); }
 void pfh_set_threads(pfh_run *r, uint32_t threads) { r->cdbg->set_threads(threads); }
-int pfh_set_unitig_id(pfh_run *r, const char *outpre) { return r->cdbg->setUnitigId(outpre, "", 1); }
-int pfh_find_superbubbles(pfh_run *r, const char *outpre) { return r->cdbg->findSuperBubble_multithread_ptr(outpre, 1); }
+// no C++ exception may cross the C boundary
+template <class F>
+static int guarded(pfh_run *r, F &&f) {
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        r->err = std::string("ploidyfrost host layer: ") + e.what();
+        return PF_ERR_ARG;
+    } catch (...) {
+        r->err = "ploidyfrost host layer: unknown exception";
+        return PF_ERR_ARG;
+    }
+}
+
+int pfh_set_unitig_id(pfh_run *r, const char *outpre) {
+    return guarded(r, [&] { return r->cdbg->setUnitigId(outpre, "", 1); });
+}
+int pfh_find_superbubbles(pfh_run *r, const char *outpre) {
+    return guarded(r, [&] { return r->cdbg->findSuperBubble_multithread_ptr(outpre, 1); });
+}
 int pfh_ploidy_estimation(pfh_run *r, const char *outpre, int lower, int upper) {
-    return r->cdbg->ploidyEstimation_multithread_ptr(outpre, lower, upper, 1);
+    return guarded(r, [&] { return r->cdbg->ploidyEstimation_multithread_ptr(outpre, lower, upper, 1); });
 }
 void *pfh_device_ctx(pfh_run *r) { return r->cdbg->device(); }
 
