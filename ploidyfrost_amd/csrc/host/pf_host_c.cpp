@@ -18,6 +18,21 @@ struct pfh_run {
 
 static std::string g_open_err;
 
+// no C++ exception may cross the C boundary
+template <class F>
+static int guarded(pfh_run *r, F &&f) {
+    try {
+        return f();
+    } catch (const std::exception &e) {
+        r->err = std::string("ploidyfrost host layer: ") + e.what();
+        return PF_ERR_ARG;
+    } catch (...) {
+        r->err = "ploidyfrost host layer: unknown exception";
+        return PF_ERR_ARG;
+    }
+}
+
+
 extern "C" {
 
 pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex_size, double match, double mismatch,
@@ -49,20 +64,6 @@ const char *pfh_last_error(const pfh_run *r) {
 void pfh_set_output_dir(pfh_run *r, const char *dir) { r->cdbg->set_output_dir(dir); }
 void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0); }
 void pfh_set_threads(pfh_run *r, uint32_t threads) { r->cdbg->set_threads(threads); }
-// no C++ exception may cross the C boundary
-template <class F>
-static int guarded(pfh_run *r, F &&f) {
-    try {
-        return f();
-    } catch (const std::exception &e) {
-        r->err = std::string("ploidyfrost host layer: ") + e.what();
-        return PF_ERR_ARG;
-    } catch (...) {
-        r->err = "ploidyfrost host layer: unknown exception";
-        return PF_ERR_ARG;
-    }
-}
-
 int pfh_set_unitig_id(pfh_run *r, const char *outpre) {
     return guarded(r, [&] { return r->cdbg->setUnitigId(outpre, "", 1); });
 }
