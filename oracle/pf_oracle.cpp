@@ -18,62 +18,12 @@
 
 using namespace pfo;
 
-namespace {
+#include "pf_oracle_ctx.hpp"
+
+using namespace pfo_int;
+
+namespace pfo_int {
 std::string g_err;
-
-// MyUnitig flag bits (src/MyUnitig.hpp:37-46, 52-85, 97-130)
-enum : uint8_t {
-    F_PLUS_OPEN = 0x01,
-    F_MINUS_OPEN = 0x02,
-    F_NON_SUPER = 0x04,
-    F_STRICT_MINUS = 0x08,
-    F_STRICT_PLUS = 0x10,
-    F_COMPLEX_MINUS = 0x20,
-    F_COMPLEX_PLUS = 0x40,
-};
-}  // namespace
-
-struct pfo_ctx {
-    Graph g;
-    KmcDb db;
-    // MyUnitig state: partner ids are 1-based, 0 = NULL
-    std::vector<uint8_t> flags;
-    std::vector<uint32_t> plus, minus;
-    uint32_t complex_size = 8;
-
-    uint32_t id(uint32_t ov) const { return (ov >> 1) + 1; }
-    bool strand(uint32_t ov) const { return (ov & 1) == 0; }
-
-    // --- MyUnitig mutators on unitig index d
-    void set_plus_self(uint32_t d) { plus[d] = d + 1; flags[d] &= 0xFE; }
-    void set_minus_self(uint32_t d) { minus[d] = d + 1; flags[d] &= 0xFD; }
-    void set_side_self(uint32_t d, bool plus_side) { plus_side ? set_plus_self(d) : set_minus_self(d); }
-    uint32_t &side(uint32_t d, bool plus_side) { return plus_side ? plus[d] : minus[d]; }
-    // "if (ex->get_plus() == me) ex->set_plus_self(); else ex->set_minus_self();"
-    void release_partner(uint32_t ex, uint32_t me) {
-        if (plus[ex] == me + 1) set_plus_self(ex); else set_minus_self(ex);
-    }
-    // interior treatment shared by all three commits (e.g. CDBG.cpp:800-826)
-    void poison(uint32_t d) {
-        for (int s = 0; s < 2; ++s) {
-            bool ps = (s == 0);
-            uint32_t p = side(d, ps);
-            if (p != 0 && p != d + 1) release_partner(p - 1, d);
-            set_side_self(d, ps);
-        }
-        flags[d] |= F_NON_SUPER;
-    }
-};
-
-namespace {
-
-struct Traversal {
-    int outcome = PFO_BFS_NONE;
-    uint32_t exit_ov = NONE;
-    std::vector<uint32_t> seen;  // vec_km_seen
-    std::vector<uint32_t> cyc;   // cycle_unitig_set, insertion order, deduplicated
-    bool flag_cycle = false, flag_tip = false;
-};
 
 // extractSuperBubble_ptr, CDBG.cpp:253-372 (pure part: topology + ids only)
 Traversal traverse(const pfo_ctx &c, uint32_t s) {
@@ -232,9 +182,9 @@ void commit_no_exit(pfo_ctx &c, const Traversal &t, uint32_t s) {
 void run_candidate(pfo_ctx &c, uint32_t s) {
     Traversal t = traverse(c, s);
     switch (t.outcome) {
-        case PFO_BFS_CYCLE_EXIT: commit_cycle_exit(c, t, s); break;
-        case PFO_BFS_REJECT: commit_reject(c, t, s); break;
-        case PFO_BFS_ACCEPT: commit_accept(c, t, s); break;
+        case PFO_BFS_CYCLE_EXIT: c.colored ? commit_cycle_exit_colored(c, t, s) : commit_cycle_exit(c, t, s); break;
+        case PFO_BFS_REJECT: commit_reject(c, t, s); break;  // CCDBG.cpp:2662-2758 is CDBG.cpp:603-699 verbatim
+        case PFO_BFS_ACCEPT: c.colored ? commit_accept_colored(c, t, s) : commit_accept(c, t, s); break;
         default: commit_no_exit(c, t, s); break;
     }
 }
@@ -340,7 +290,7 @@ bool ensure_dir(const std::string &d) {
     return mkdir(d.c_str(), 0777) == 0;
 }
 
-}  // namespace
+}  // namespace pfo_int
 
 // ------------------------------------------------------------------------------------------
 // C interface
@@ -504,6 +454,16 @@ int pfo_find_superbubbles(pfo_ctx *c, const char *outdir, const char *prefix, ui
         for (uint32_t u = 0; u < N; ++u) {
             uint8_t f = c->flags[u];
             if ((f & 3) == 0) continue;
+            if (c->colored) {
+                // CCDBG.cpp:2106-2132 prints a side whenever its partner pointer is non-NULL -- self included
+                if (c->plus[u] != 0)
+                    o << ++nb << "\t" << (u + 1) << "\t+\t" << c->plus[u] << "\t" << ((f & F_STRICT_PLUS) ? "1" : "0")
+                      << "\t" << ((f & F_COMPLEX_PLUS) ? "1" : "0") << "\n";
+                if (c->minus[u] != 0)
+                    o << ++nb << "\t" << (u + 1) << "\t-\t" << c->minus[u] << "\t" << ((f & F_STRICT_MINUS) ? "1" : "0")
+                      << "\t" << ((f & F_COMPLEX_MINUS) ? "1" : "0") << "\n";
+                continue;
+            }
             if (f & F_PLUS_OPEN) {
                 o << ++nb << "\t" << (u + 1) << "\t+\t" << c->plus[u] << "\t" << ((f & F_STRICT_PLUS) ? "1" : "0")
                   << "\t" << ((f & F_COMPLEX_PLUS) ? "1" : "0") << "\n";
@@ -514,7 +474,10 @@ int pfo_find_superbubbles(pfo_ctx *c, const char *outdir, const char *prefix, ui
             }
         }
     } else {
-        for (uint32_t u = 0; u < N; ++u) nb += ((c->flags[u] & 1) != 0) + ((c->flags[u] & 2) != 0);
+        for (uint32_t u = 0; u < N; ++u) {
+            if (c->colored) { if (c->flags[u] & 3) nb += (c->plus[u] != 0) + (c->minus[u] != 0); }
+            else nb += ((c->flags[u] & 1) != 0) + ((c->flags[u] & 2) != 0);
+        }
     }
     if (n_bubbles) *n_bubbles = nb;
     return 0;

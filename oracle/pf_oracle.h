@@ -85,6 +85,26 @@ int pfo_ploidy_estimation(pfo_ctx *, const char *outdir, const char *prefix, int
  * plus / minus partner ids (0 = NULL, own id = self) */
 void pfo_state(const pfo_ctx *, uint8_t *flags, uint32_t *plus, uint32_t *minus);
 
+/* ---- colored (multi-sample) twin, reference src/CCDBG.cpp ------------------------------------
+ * colors_dump: the text oracle/_ref/colors_dump (oracle/ref_colors_dump.cpp) wrote for the graph, i.e.
+ * the real Bifrost's reading of its .bfg_colors; db_list_file: one KMC prefix per line, one per colour
+ * (CCDBG.cpp:13-43).  pfo_set_unitig_id / pfo_find_superbubbles / pfo_state work on such a context
+ * with the colored commits (CCDBG.cpp:2349-2661) and the colored super_bubble listing (:2105-2132). */
+pfo_ctx *pfo_open_colored(const char *gfa_path, const char *colors_dump, const char *db_list_file);
+uint32_t pfo_num_colors(const pfo_ctx *);
+/* out[colour * n_kmers + i] = 1 when k-mer i of unitig u carries the colour; returns UnitigColors::size(um) */
+uint64_t pfo_unitig_colors(const pfo_ctx *, uint32_t u, uint8_t *out, uint32_t *n_full_enc);
+/* readCovUni / readCov(string) for one colour (CCDBG.cpp:123-156, 89-122): *ok = 0 when a k-mer is
+ * missing or a count lies outside (low, up) */
+void pfo_unitig_cov_color(const pfo_ctx *, uint32_t colour, uint32_t u, uint32_t low, uint32_t up, double *mean, int *ok);
+void pfo_string_cov_color(const pfo_ctx *, uint32_t colour, const char *s, uint32_t len, uint32_t low, uint32_t up,
+                          double *mean, int *ok);
+/* CompactedDBG::findUnitig(s, 0, len): 1 = found; unitig index, forward dist, matched k-mers */
+int pfo_find_unitig(const pfo_ctx *, const char *s, uint32_t len, uint32_t *u, uint32_t *dist, uint32_t *n);
+/* lower/upper: one cutoff pair per colour (Main.cpp:398-455) */
+int pfo_ploidy_estimation_colored(pfo_ctx *, const char *outdir, const char *prefix, const int *lower, const int *upper,
+                                  double M, double D, double G, uint64_t allele[4], uint64_t *core_cov, uint64_t *core_num);
+
 #ifdef __cplusplus
 }
 #endif

@@ -18,6 +18,7 @@ LIB = os.path.join(HERE, "_build", "libpf_oracle.so")
 CLI = os.path.join(HERE, "_build", "pf_oracle_cli")
 REF_BIN = os.path.join(HERE, "_ref", "PloidyFrost")
 REF_BIFROST = os.path.join(HERE, "_ref", "Bifrost")
+REF_COLORS_DUMP = os.path.join(HERE, "_ref", "colors_dump")
 
 NONE = 0xFFFFFFFF
 OUTCOMES = {0: "none", 1: "cycle_exit", 2: "reject", 3: "accept"}
@@ -81,6 +82,17 @@ def lib() -> C.CDLL:
     L.pfo_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_double, C.c_double, C.c_double,
                                         C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     L.pfo_state.argtypes = [vp, vp, vp, vp]
+    L.pfo_open_colored.restype = vp
+    L.pfo_open_colored.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p]
+    L.pfo_num_colors.restype = u32
+    L.pfo_num_colors.argtypes = [vp]
+    L.pfo_unitig_colors.restype = u64
+    L.pfo_unitig_colors.argtypes = [vp, u32, vp, C.POINTER(u32)]
+    L.pfo_unitig_cov_color.argtypes = [vp, u32, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.pfo_string_cov_color.argtypes = [vp, u32, C.c_char_p, u32, u32, u32, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    L.pfo_find_unitig.argtypes = [vp, C.c_char_p, u32, C.POINTER(u32), C.POINTER(u32), C.POINTER(u32)]
+    L.pfo_ploidy_estimation_colored.argtypes = [vp, C.c_char_p, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_double,
+                                                C.c_double, C.c_double, C.POINTER(u64), C.POINTER(u64), C.POINTER(u64)]
     _lib = L
     return L
 
@@ -177,6 +189,63 @@ class Oracle:
         m = np.empty(self.n, dtype=np.uint32)
         self.L.pfo_state(self.h, f.ctypes.data, p.ctypes.data, m.ctypes.data)
         return f, p, m
+
+
+class ColoredOracle(Oracle):
+    """Colored twin (reference src/CCDBG.cpp): graph + the real Bifrost's colour dump + one database per colour."""
+
+    def __init__(self, gfa: str, colors_dump: str, db_prefixes: list[str], workdir: str):
+        self.L = lib()
+        lst = os.path.join(workdir, "oracle_dbs.txt")
+        with open(lst, "w") as f:
+            f.write("".join(p + "\n" for p in db_prefixes))
+        self.h = self.L.pfo_open_colored(gfa.encode(), colors_dump.encode(), lst.encode() if db_prefixes else b"")
+        if not self.h:
+            raise RuntimeError("oracle: " + self.L.pfo_last_error().decode())
+        self.k = self.L.pfo_k(self.h)
+        self.n = self.L.pfo_num_unitigs(self.h)
+        self.n_kmers = self.L.pfo_num_kmers(self.h)
+        self.n_colors = self.L.pfo_num_colors(self.h)
+
+    def unitig_colors(self, u: int, n_kmers: int):
+        """(presence[colour, kmer] uint8, UnitigColors::size, n_full_enc)"""
+        out = np.zeros((self.n_colors, n_kmers), dtype=np.uint8)
+        nf = C.c_uint32()
+        sz = self.L.pfo_unitig_colors(self.h, u, out.ctypes.data, C.byref(nf))
+        return out, sz, nf.value
+
+    def unitig_cov_color(self, colour: int, u: int, low: int, up: int):
+        m, ok = C.c_double(), C.c_int()
+        self.L.pfo_unitig_cov_color(self.h, colour, u, low, up, C.byref(m), C.byref(ok))
+        return m.value, ok.value
+
+    def string_cov_color(self, colour: int, text: bytes, low: int, up: int):
+        m, ok = C.c_double(), C.c_int()
+        self.L.pfo_string_cov_color(self.h, colour, text, len(text), low, up, C.byref(m), C.byref(ok))
+        return m.value, ok.value
+
+    def find_unitig(self, text: bytes):
+        u, d, n = C.c_uint32(), C.c_uint32(), C.c_uint32()
+        if not self.L.pfo_find_unitig(self.h, text, len(text), C.byref(u), C.byref(d), C.byref(n)):
+            return None
+        return u.value, d.value, n.value
+
+    def run(self, outdir: str, prefix: str, cutoffs, z=8, M=2.0, D=-1.0, G=-3.0):
+        L = self.L
+        if L.pfo_set_unitig_id(self.h, outdir.encode(), prefix.encode()):
+            raise RuntimeError(L.pfo_last_error().decode())
+        nb = C.c_uint64()
+        if L.pfo_find_superbubbles(self.h, outdir.encode(), prefix.encode(), z, C.byref(nb)):
+            raise RuntimeError(L.pfo_last_error().decode())
+        lo = (C.c_int * self.n_colors)(*[c[0] for c in cutoffs])
+        up = (C.c_int * self.n_colors)(*[c[1] for c in cutoffs])
+        allele = (C.c_uint64 * 4)()
+        cc, cn = C.c_uint64(), C.c_uint64()
+        rc = L.pfo_ploidy_estimation_colored(self.h, outdir.encode(), prefix.encode(), lo, up, M, D, G, allele, C.byref(cc),
+                                             C.byref(cn))
+        if rc:
+            raise RuntimeError(L.pfo_last_error().decode())
+        return dict(bubbles=nb.value, allele=list(allele), core_cov=cc.value, core_num=cn.value)
 
 
 def seq_align(strs: list[bytes], M=2.0, D=-1.0, G=-3.0):

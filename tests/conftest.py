@@ -16,8 +16,25 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
+def _cases(colored):
+    out = []
+    for d in sorted(os.listdir(GOLDEN)):
+        a = os.path.join(GOLDEN, d, "args.json")
+        if os.path.isfile(a):
+            with open(a) as f:
+                if bool(json.load(f).get("colored")) == colored:
+                    out.append(d)
+    return out
+
+
 def golden_cases():
-    return sorted(d for d in os.listdir(GOLDEN) if os.path.isfile(os.path.join(GOLDEN, d, "args.json")))
+    """single-sample cases (reference src/CDBG.cpp)"""
+    return _cases(False)
+
+
+def colored_cases():
+    """multi-sample cases (reference src/CCDBG.cpp)"""
+    return _cases(True)
 
 
 def load_case(name):
@@ -27,6 +44,10 @@ def load_case(name):
     meta["dir"] = d
     meta["gfa"] = os.path.join(d, "graph.gfa")
     meta["db"] = os.path.join(d, "db")
+    if meta.get("colored"):
+        meta["colors"] = os.path.join(d, "graph.bfg_colors")
+        meta["colors_dump"] = os.path.join(d, "colors.txt")
+        meta["dbs"] = [os.path.join(d, "db%d" % i) for i in range(meta["n_colors"])]
     opts = {"-l": "10", "-u": "1000", "-z": "8", "-M": "2", "-D": "-1", "-G": "-3"}
     a = meta["args"]
     for i in range(0, len(a), 2):

@@ -10,6 +10,13 @@ case it writes
     expected/<prefix>_*  the twelve files the reference wrote with ``-t 1``
 The fixtures are data (inputs + expected outputs); no reference source is stored.
 
+Colored (multi-sample, reference src/CCDBG.cpp) cases additionally hold
+    graph.bfg_colors     written by the reference's ``Bifrost build -c`` (one colour per sample FASTA)
+    colors.txt           oracle/_ref/colors_dump: how the real Bifrost reads that file (k-mer x colour presence,
+                         UnitigColors::size) -- data that pins the oracle's and the product's colour semantics
+    db<i>.kmc_pre/.suf   one count database per colour
+and args.json carries the per-colour cutoffs (the -C file) instead of -l/-u.
+
 usage: python tests/golden/make_golden.py [case ...]
 """
 from __future__ import annotations
@@ -91,6 +98,54 @@ CASES = {
 }
 
 
+def trimmed(haps, cuts):
+    """Drop cuts[i] = (head, tail) bases from haplotype i: sequence ends inside shared unitigs -> partial colours."""
+    return [h[a: len(h) - b] for h, (a, b) in zip(haps, cuts)]
+
+
+def col3_dip():
+    haps = synth.make_haplotypes(synth.HapSpec(30000, 6, seed=41, gap_lo=15, gap_hi=300, p_multi=0.05))
+    rng = np.random.default_rng(41007)
+    samples = []
+    for s in range(3):
+        hs = haps[2 * s: 2 * s + 2]
+        if s > 0:   # sample-private sequence: unitigs that do not carry every colour
+            hs = [np.concatenate([h, rng.integers(0, 4, size=400, dtype=np.uint8)]) for h in hs]
+        samples.append(hs)
+    return samples
+
+
+def col4_mix():
+    """Four samples of ploidy 4,2,2,4 on one base genome, longer insertions (branching bubbles), multi-allelic
+    sites, and haplotypes that start/stop at different places (k-mer ranges of unitigs without a colour)."""
+    haps = synth.make_haplotypes(synth.HapSpec(36000, 12, seed=53, gap_lo=10, gap_hi=150, p_multi=0.1, max_ins=12, p_snp=0.6,
+                                               p_del=0.15))
+    groups = [haps[0:4], haps[4:6], haps[6:8], haps[8:12]]
+    groups[1] = trimmed(groups[1], [(1234, 0), (1234, 977)])
+    groups[2] = trimmed(groups[2], [(0, 2100), (311, 2100)])
+    groups[3] = trimmed(groups[3], [(0, 0), (40, 0), (0, 55), (5000, 7000)])
+    return groups
+
+
+def col2_weird():
+    """Two samples over the repeat-rich genome (cycles, hairpins, tips) of weird_haplotypes."""
+    h0, h1 = weird_haplotypes(23)
+    rng = np.random.default_rng(77)
+    g0 = h0.copy()
+    sites = np.cumsum(rng.integers(20, 260, size=len(g0) // 20))
+    sites = sites[(sites > 40) & (sites < len(g0) - 40)]
+    g0[sites] = (g0[sites] + rng.integers(1, 4, size=len(sites)).astype(np.uint8)) & 3
+    return [[h0, h1], [g0, h1[200:-150]]]
+
+
+# name: (sample factory -> list of per-sample haplotype lists, k, PloidyFrost args, per-colour cutoffs)
+COLORED_CASES = {
+    "col3_dip": (col3_dip, 25, [], [(5, 1000)] * 3),
+    "col4_mix": (col4_mix, 25, ["-z", "10"], [(5, 1000), (5, 1000), (25, 70), (5, 1000)]),
+    "col2_weird": (col2_weird, 31, ["-M", "1.5", "-D", "-0.5", "-G", "-2.25"], [(5, 1000), (10, 400)]),
+}
+
+
 def run(cmd, **kw):
     r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, **kw)
     if r.returncode != 0:
@@ -127,6 +182,47 @@ def make_case(name: str) -> None:
     print(name, n_unitigs, "unitigs;", " | ".join(s.strip() for s in summary))
 
 
+def make_colored_case(name: str) -> None:
+    factory, k, args, cutoffs = COLORED_CASES[name]
+    out = os.path.join(HERE, name)
+    shutil.rmtree(out, ignore_errors=True)
+    os.makedirs(os.path.join(out, "expected"))
+    samples = factory()
+    with tempfile.TemporaryDirectory() as tmp:
+        fas = []
+        for i, hs in enumerate(samples):
+            fa = os.path.join(tmp, "sample%d.fa" % i)
+            synth.write_fasta(fa, hs)
+            fas.append(fa)
+            km, mult = synth.canonical_counts(hs, k)
+            synth.write_kmc1(os.path.join(out, "db%d" % i), km, synth.synth_counts(km, mult), k)
+        with open(os.path.join(tmp, "refs.txt"), "w") as f:
+            f.write("".join(p + "\n" for p in fas))
+        run([os.path.join(REF, "Bifrost"), "build", "-c", "-r", os.path.join(tmp, "refs.txt"), "-k", str(k), "-o",
+             os.path.join(tmp, "graph"), "-t", "1"])
+        for ext in ("gfa", "bfg_colors"):
+            shutil.copy(os.path.join(tmp, "graph." + ext), os.path.join(out, "graph." + ext))
+        dump = run([os.path.join(REF, "colors_dump"), os.path.join(out, "graph.gfa"), os.path.join(out, "graph.bfg_colors")])
+        # colour names are the temporary FASTA paths: keep the basename only
+        dump = "".join(("#name\t" + os.path.basename(l.split("\t")[1]) if l.startswith("#name") else l) + "\n" for l in dump.splitlines())
+        with open(os.path.join(out, "colors.txt"), "w") as f:
+            f.write(dump)
+        with open(os.path.join(tmp, "dbs.txt"), "w") as f:
+            f.write("".join(os.path.join(out, "db%d" % i) + "\n" for i in range(len(samples))))
+        with open(os.path.join(tmp, "cutoffs.txt"), "w") as f:
+            f.write("".join("%d\t%d\n" % c for c in cutoffs))
+        log = run([os.path.join(REF, "PloidyFrost"), "-g", os.path.join(out, "graph.gfa"), "-f", os.path.join(out, "graph.bfg_colors"),
+                   "-d", os.path.join(tmp, "dbs.txt"), "-C", os.path.join(tmp, "cutoffs.txt"), "-o", "g", "-t", "1"] + args, cwd=tmp)
+        for f in sorted(os.listdir(os.path.join(tmp, "PloidyFrost_output"))):
+            shutil.copy(os.path.join(tmp, "PloidyFrost_output", f), os.path.join(out, "expected", f))
+    n_unitigs = sum(1 for line in open(os.path.join(out, "graph.gfa")) if line.startswith("S\t"))
+    summary = [l for l in log.splitlines() if "SuperBubbles Found" in l or "Alleles in" in l]
+    with open(os.path.join(out, "args.json"), "w") as f:
+        json.dump({"k": k, "args": args, "prefix": "g", "unitigs": n_unitigs, "colored": True, "n_colors": len(samples),
+                   "cutoffs": [list(c) for c in cutoffs], "kmc_layout": "kmc1", "reference_log": summary}, f, indent=1)
+    print(name, n_unitigs, "unitigs;", " | ".join(s.strip() for s in summary))
+
+
 if __name__ == "__main__":
-    for c in (sys.argv[1:] or list(CASES)):
-        make_case(c)
+    for c in (sys.argv[1:] or list(CASES) + list(COLORED_CASES)):
+        make_colored_case(c) if c in COLORED_CASES else make_case(c)

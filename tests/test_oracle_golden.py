@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT, compare_outputs, golden_cases, load_case
+from conftest import ROOT, colored_cases, compare_outputs, golden_cases, load_case
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle  # noqa: E402
@@ -21,6 +21,19 @@ def test_oracle_matches_reference_outputs(case, tmp_path):
     o.run(str(tmp_path), "g", z=int(op["-z"]), lower=int(op["-l"]), upper=int(op["-u"]), M=float(op["-M"]),
           D=float(op["-D"]), G=float(op["-G"]))
     bad = compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+    assert not bad, "files differ from the reference: %s" % bad
+
+
+@pytest.mark.parametrize("case", colored_cases())
+def test_colored_oracle_matches_reference_outputs(case, tmp_path):
+    """CCDBG twin: oracle fed with the real Bifrost's colour dump against the reference's twelve files."""
+    meta = load_case(case)
+    o = pyoracle.ColoredOracle(meta["gfa"], meta["colors_dump"], meta["dbs"], str(tmp_path))
+    assert o.k == meta["k"] and o.n == meta["unitigs"] and o.n_colors == meta["n_colors"]
+    op = meta["opts"]
+    out = tmp_path / "out"
+    o.run(str(out), "g", meta["cutoffs"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    bad = compare_outputs(os.path.join(meta["dir"], "expected"), str(out))
     assert not bad, "files differ from the reference: %s" % bad
 
 
