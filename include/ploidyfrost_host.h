@@ -48,6 +48,24 @@ const char *pfh_last_allele_frequency(const pfh_run *, uint64_t *len);
 /* per-unitig state after pfh_find_superbubbles (MyUnitig flag byte, partner ids; 0 = NULL) */
 void pfh_state(const pfh_run *, uint8_t *flags, uint32_t *plus, uint32_t *minus);
 
+/* ---- colour sets of a colored graph (no GPU involved) -----------------------------------------
+ * The product's own reader of Bifrost's .bfg_colors (ploidyfrost_amd/csrc/host/pf_host_colors.hpp), which
+ * replaces ColoredCDBG::read -> DataStorage::read -> UnitigColors::read (bifrost/src/ColoredCDBG.tcc:428,
+ * DataStorage.tcc:790, ColorSet.cpp:1228) on the CCDBG path.  Exposed so that tests can hold it against
+ * the real Bifrost's reading of the same file. */
+typedef struct pfh_colors pfh_colors;
+pfh_colors *pfh_colors_open(const char *gfa_path, const char *colors_path, uint32_t threads); /* NULL: pfh_last_error(NULL) */
+void pfh_colors_close(pfh_colors *);
+uint32_t pfh_colors_count(const pfh_colors *);                 /* ColoredCDBG::getNbColors */
+uint32_t pfh_colors_unitigs(const pfh_colors *);
+const char *pfh_colors_name(const pfh_colors *, uint32_t colour);
+/* presence[colour * n_kmers + i] = 1 when k-mer i (reference orientation) of unitig u carries the colour
+ * (UnitigColors::contains, ColorSet.cpp:776); returns UnitigColors::size(um) (ColorSet.cpp:898);
+ * *n_full_enc = colours the file stores in the {full colours, rest} pair form, 0 otherwise */
+uint64_t pfh_colors_unitig(const pfh_colors *, uint32_t u, uint8_t *presence, uint32_t *n_kmers, uint32_t *n_full_enc);
+/* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
+uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);
+
 #ifdef __cplusplus
 }
 #endif

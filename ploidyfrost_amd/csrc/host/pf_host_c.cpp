@@ -5,6 +5,7 @@
 #include <string>
 
 #include "pf_cdbg.hpp"
+#include "pf_host_colors.hpp"
 #include "ploidyfrost_host.h"
 
 struct pfh_run {
@@ -100,5 +101,43 @@ void pfh_state(const pfh_run *r, uint8_t *flags, uint32_t *plus, uint32_t *minus
     if (plus) memcpy(plus, r->cdbg->state_plus().data(), N * 4);
     if (minus) memcpy(minus, r->cdbg->state_minus().data(), N * 4);
 }
+
+// ---- colour sets (host only) ---------------------------------------------------------------------
+}  // extern "C"
+
+struct pfh_colors {
+    pfh::UnitigSet graph;
+    pfh::ColorSets sets;
+};
+
+extern "C" {
+
+pfh_colors *pfh_colors_open(const char *gfa_path, const char *colors_path, uint32_t threads) {
+    try {
+        auto c = std::make_unique<pfh_colors>();
+        if (!c->graph.load_gfa(gfa_path, g_open_err)) return nullptr;
+        if (!c->sets.load(colors_path, c->graph, threads ? threads : 1, g_open_err)) return nullptr;
+        return c.release();
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return nullptr;
+    }
+}
+void pfh_colors_close(pfh_colors *c) { delete c; }
+uint32_t pfh_colors_count(const pfh_colors *c) { return c->sets.n_colors; }
+uint32_t pfh_colors_unitigs(const pfh_colors *c) { return c->graph.n(); }
+const char *pfh_colors_name(const pfh_colors *c, uint32_t colour) {
+    return colour < c->sets.names.size() ? c->sets.names[colour].c_str() : "";
+}
+uint64_t pfh_colors_unitig(const pfh_colors *c, uint32_t u, uint8_t *presence, uint32_t *n_kmers, uint32_t *n_full_enc) {
+    const uint32_t km = c->graph.len_km(u);
+    if (n_kmers) *n_kmers = km;
+    if (n_full_enc) *n_full_enc = c->sets.n_full_enc[u];
+    if (presence)
+        for (uint32_t ci = 0; ci < c->sets.n_colors; ++ci)
+            for (uint32_t i = 0; i < km; ++i) presence[(size_t)ci * km + i] = c->sets.contains(u, ci, i, 1);
+    return c->sets.size_total[u];
+}
+uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed) { return pfh::bifrost_kmer_hash(left_aligned_kmer, seed); }
 
 }  // extern "C"

@@ -82,9 +82,10 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
     }
     if (k < 3 || k > 31) { err = "k outside 3..31"; return false; }
     // pass 1: locate the sequence field of every complete S-line
-    struct Seg { const char *s; uint32_t len; };
+    struct Seg { const char *s; uint32_t len; int16_t da; };
     std::vector<Seg> longs, shorts;
     uint64_t long_bp = 0;
+    bool any_da = false;
     const char *q = le + 1;
     while (q < end) {
         const char *e = line_end(q);
@@ -101,8 +102,15 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
             uint32_t len = (uint32_t)(t - fld);
             if (len && fld[len - 1] == '\r') len--;
             if ((int)len < k) { err = "segment shorter than k"; return false; }
-            if ((int)len == k) shorts.push_back({fld, len});
-            else { longs.push_back({fld, len}); long_bp += len; }
+            int16_t da = -1;
+            for (const char *tag = t; tag < e;) {  // optional tags after the sequence
+                const char *nt = (const char *)memchr(tag + 1, '\t', (size_t)(e - tag - 1));
+                if (!nt) nt = e;
+                if (nt - tag > 6 && memcmp(tag + 1, "DA:Z:", 5) == 0) { da = (int16_t)atoi(std::string(tag + 6, nt).c_str()); any_da = true; }
+                tag = nt;
+            }
+            if ((int)len == k) shorts.push_back({fld, len, da});
+            else { longs.push_back({fld, len, da}); long_bp += len; }
         }
         q = e + 1;
     }
@@ -142,6 +150,12 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
         ++u;
     }
     off[N] = at;
+    da_tag.clear();
+    if (any_da) {
+        da_tag.reserve(N);
+        for (const Seg &s : longs) da_tag.push_back(s.da);
+        for (const Seg &s : shorts) da_tag.push_back(s.da);
+    }
     pack();
     return true;
 }

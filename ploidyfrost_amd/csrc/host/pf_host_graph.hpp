@@ -24,6 +24,9 @@ struct UnitigSet {
     std::vector<uint32_t> len_bp;
     uint64_t n_kmers = 0;
     uint64_t n_short = 0;
+    // Bifrost's per-segment "DA:Z:<n>" tag (which hash seed places the unitig's colour set,
+    // bifrost/src/ColoredCDBG.tcc:496-533); -1 where a segment has none.  Empty when no segment has one.
+    std::vector<int16_t> da_tag;
 
     uint32_t n() const { return (uint32_t)len_bp.size(); }
     std::string_view seq(uint32_t u) const { return std::string_view(text.data() + off[u], len_bp[u]); }

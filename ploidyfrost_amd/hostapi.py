@@ -23,7 +23,9 @@ class Times(C.Structure):
 
 _lib = None
 DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_unitig_id",
-                    "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency"]
+                    "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
+                    "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash"]
 
 
 def load_library() -> C.CDLL:
@@ -52,8 +54,53 @@ def load_library() -> C.CDLL:
     L.pfh_state.argtypes = [vp, vp, vp, vp]
     L.pfh_last_allele_frequency.restype = C.c_void_p
     L.pfh_last_allele_frequency.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.pfh_colors_open.restype = vp
+    L.pfh_colors_open.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
+    L.pfh_colors_close.argtypes = [vp]
+    L.pfh_colors_count.restype = C.c_uint32
+    L.pfh_colors_count.argtypes = [vp]
+    L.pfh_colors_unitigs.restype = C.c_uint32
+    L.pfh_colors_unitigs.argtypes = [vp]
+    L.pfh_colors_name.restype = C.c_char_p
+    L.pfh_colors_name.argtypes = [vp, C.c_uint32]
+    L.pfh_colors_unitig.restype = C.c_uint64
+    L.pfh_colors_unitig.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.pfh_bifrost_kmer_hash.restype = C.c_uint64
+    L.pfh_bifrost_kmer_hash.argtypes = [C.c_uint64, C.c_uint64]
     _lib = L
     return L
+
+
+class Colors:
+    """The product's reading of a colored graph's .bfg_colors (host only, no GPU)."""
+
+    def __init__(self, gfa: str, colors: str, threads: int = 1):
+        self.L = load_library()
+        self.h = self.L.pfh_colors_open(gfa.encode(), colors.encode(), threads)
+        if not self.h:
+            raise RuntimeError("ploidyfrost host layer: " + self.L.pfh_last_error(None).decode())
+        self.n_colors = self.L.pfh_colors_count(self.h)
+        self.n = self.L.pfh_colors_unitigs(self.h)
+        self.names = [self.L.pfh_colors_name(self.h, c).decode() for c in range(self.n_colors)]
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pfh_colors_close(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def unitig(self, u: int):
+        """(presence[colour, kmer] uint8, UnitigColors::size(um), n_full_enc)"""
+        km, nf = C.c_uint32(), C.c_uint32()
+        self.L.pfh_colors_unitig(self.h, u, None, C.byref(km), C.byref(nf))
+        out = np.zeros((self.n_colors, km.value), dtype=np.uint8)
+        sz = self.L.pfh_colors_unitig(self.h, u, out.ctypes.data, C.byref(km), C.byref(nf))
+        return out, sz, nf.value
 
 
 class Run:
