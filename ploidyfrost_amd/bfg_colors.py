@@ -7,7 +7,7 @@ reference's reader (``ColoredCDBG::read``) and the product's own reader
 and it can emit *every* colour-set encoding ``UnitigColors::write`` has (bifrost/src/ColorSet.cpp:1174-1226)
 -- including the ones a small ``Bifrost build`` never produces (Roaring bitmaps, the {full colours, rest}
 pair that ``optimizeFullColors`` creates on > 1 GiB colourings).  ``tests/test_colors_cpu.py`` checks, where the
-real Bifrost is available (oracle/_ref/colors_dump), that the real library reads these files as intended.
+real Bifrost has been built, that the real library reads these files as intended.
 """
 from __future__ import annotations
 
