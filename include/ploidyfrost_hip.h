@@ -55,7 +55,7 @@ int pf_synchronize(pf_ctx *);
  * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
-    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COUNT_
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -206,6 +206,28 @@ int pf_align_bubbles(pf_ctx *, const char *text, uint64_t text_len, const pf_bub
  * a k-mer is absent. [host|dev] */
 int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t n_str, uint32_t low, uint32_t up,
                   uint64_t *sum, uint8_t *ok, uint8_t *miss);
+
+/* ---- colored (multi-sample) coverage: reference src/CCDBG.cpp ------------------------------------- */
+/* CCDBG::CCDBG (src/CCDBG.cpp:13-43) opens one KMC database per colour.  Here the records of all colours
+ * are joined into one HBM table keyed by the stored k-mer with one count per colour, so a k-mer costs one
+ * random access whatever the number of colours.  kmers[c] / counts[c]: n[c] records of colour c (exact
+ * k-mers as stored, any order); min_count / max_count / both_strands per colour as in pf_upload_counts.
+ * Requires pf_upload_graph first (k).  [host|dev per array] */
+#define PF_MAX_COLORS 62
+int pf_upload_counts_colored(pf_ctx *, uint32_t n_colors, const uint64_t *const *kmers, const uint32_t *const *counts,
+                             const uint64_t *n, const uint64_t *min_count, const uint64_t *max_count, const int *both_strands);
+uint32_t pf_num_colors(const pf_ctx *);
+/* CCDBG::readCovUni (src/CCDBG.cpp:123-156) for unitigs [u0, u1) and every colour at once; arrays are
+ * colour-major: x[c * (u1 - u0) + (u - u0)].  sum / min / max over the k-mers colour c's database holds,
+ * miss = 1 when it lacks one.  readCovUni(u, low, up, c) == (sum / len, true) iff !miss && min > low &&
+ * max < up, else (0, false) -- the caller applies its cutoffs.  [host|dev] */
+int pf_unitig_cov_colored(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *min_count, uint32_t *max_count,
+                          uint8_t *miss);
+/* CCDBG::readCov(string, low, up, colour) (src/CCDBG.cpp:89-122) for every (string, colour): low / up hold one
+ * cutoff per colour; arrays are string-major: x[i * n_colors + c].  ok = 0 (and sum = 0) when a k-mer is
+ * missing from colour c's database or a count lies outside (low[c], up[c]).  [host|dev] */
+int pf_string_cov_colored(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t n_str, const uint32_t *low,
+                          const uint32_t *up, uint64_t *sum, uint8_t *ok);
 
 /* ---- pinned host memory for the exchange buffers (optional: pageable memory works, slower) ---- */
 int pf_host_alloc(pf_ctx *, size_t bytes, void **out);

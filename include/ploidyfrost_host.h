@@ -48,6 +48,17 @@ const char *pfh_last_allele_frequency(const pfh_run *, uint64_t *len);
 /* per-unitig state after pfh_find_superbubbles (MyUnitig flag byte, partner ids; 0 = NULL) */
 void pfh_state(const pfh_run *, uint8_t *flags, uint32_t *plus, uint32_t *minus);
 
+/* ---- colored (multi-sample) runs: the call sequence of src/Main.cpp:775-810 --------------------------
+ *   pfh_open_colored(gfa, bfg_colors, kmc_list, ...)          ColoredCDBG::read + CCDBG::CCDBG
+ *   pfh_set_unitig_id / pfh_find_superbubbles                 CCDBG::setUnitigId / findSuperBubble_multithread_ptr
+ *   pfh_ploidy_estimation_colored(h, outpre, lower, upper, n) CCDBG::ploidyEstimation_multithread_ptr, one
+ *                                                             (lower, upper) cutoff per colour (the -C file)
+ * kmc_list_file: one KMC database prefix per line, one line per colour (src/CCDBG.cpp:13-43). */
+pfh_run *pfh_open_colored(const char *gfa_path, const char *colors_path, const char *kmc_list_file, uint32_t complex_size,
+                          double match, double mismatch, double gap, uint32_t threads, int device);
+uint32_t pfh_num_colors(const pfh_run *);
+int pfh_ploidy_estimation_colored(pfh_run *, const char *outpre, const int *lower, const int *upper, uint32_t n_colors);
+
 /* ---- colour sets of a colored graph (no GPU involved) -----------------------------------------
  * The product's own reader of Bifrost's .bfg_colors (ploidyfrost_amd/csrc/host/pf_host_colors.hpp), which
  * replaces ColoredCDBG::read -> DataStorage::read -> UnitigColors::read (bifrost/src/ColoredCDBG.tcc:428,

@@ -6,6 +6,7 @@
 
 #include <algorithm>
 #include <charconv>
+#include <cmath>
 #include <chrono>
 #include <cstdio>
 #include <cstring>
@@ -53,7 +54,25 @@ struct CDBG::Task {
     double cov[4] = {0, 0, 0, 0};
     uint8_t n_inner = 0, n_cov = 0;
     double cov_sum = 0;
+    // colored strict bubble: where its [colour][inner] coverage matrix sits (chunk << 32 | offset into the chunk's pool)
+    uint64_t cov_ref = 0;
 };
+
+int CDBG::init_device(int device) {
+    int st = pf_create(device, &ctx_);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: " + pf_last_error(nullptr));
+    st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));
+    const uint32_t N = g_.n();
+    succ_.resize((size_t)N * 8);
+    pred_.resize((size_t)N * 8);
+    st = pf_build_adjacency(ctx_, succ_.data(), pred_.data());
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: adjacency: " + pf_last_error(ctx_));
+    flags_.assign(N, 0);
+    plus_.assign(N, 0);
+    minus_.assign(N, 0);
+    return 0;
+}
 
 CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db, int device,
            bool quiet)
@@ -61,28 +80,26 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     sc_.match = m;
     sc_.mismatch = d;
     sc_.gap = g;
-    int st = pf_create(device, &ctx_);
-    if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: ") + pf_last_error(nullptr)); return; }
-    st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
-    if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: graph upload: ") + pf_last_error(ctx_)); return; }
-    const uint32_t N = g_.n();
-    succ_.resize((size_t)N * 8);
-    pred_.resize((size_t)N * 8);
-    st = pf_build_adjacency(ctx_, succ_.data(), pred_.data());
-    if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: adjacency: ") + pf_last_error(ctx_)); return; }
+    if (init_device(device)) return;
     if (!kmc_db.empty()) {
         KmcRecords db;
         std::string e;
         if (!db.load(kmc_db, e)) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: Open kmc database error . (" + e + ")"); return; }
         if ((int)db.k != g_.k) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: k of the kmc database differs from the graph's"); return; }
         both_strands_ = db.both_strands;
-        st = pf_upload_counts(ctx_, db.kmers.data(), db.counts.data(), db.total, db.min_count, db.max_count, db.both_strands);
+        int st = pf_upload_counts(ctx_, db.kmers.data(), db.counts.data(), db.total, db.min_count, db.max_count, db.both_strands);
         if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: ") + pf_last_error(ctx_)); return; }
     }
-    flags_.assign(N, 0);
-    plus_.assign(N, 0);
-    minus_.assign(N, 0);
     if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");
+}
+
+CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, int device, bool quiet, NoCounts)
+    : g_(graph), complex_size_(complexsize), quiet_(quiet) {
+    sc_.match = m;
+    sc_.mismatch = d;
+    sc_.gap = g;
+    tag_ = "CCDBG";
+    init_device(device);
 }
 
 CDBG::~CDBG() {
@@ -147,7 +164,7 @@ int CDBG::write_many(const std::vector<std::pair<std::string, std::vector<const 
 int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size_t &) {
     if (status_) return status_;
     if (write_files_ && ensure_dir()) return status_;
-    if (!quiet_) printf("CDBG::setUnitigId(): Setting Unitig Id\n");
+    if (!quiet_) printf("%s::setUnitigId(): Setting Unitig Id\n", tag_);
     clock_t c0 = clock();
     time_t w0 = time(nullptr);
     std::string out;
@@ -161,8 +178,8 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
     }
     if (write_file(outpre + "_Unitig_Id.txt", out)) return status_;
     if (!quiet_) {
-        printf("CDBG::setUnitigId(): Cpu time : %gs\n", (double)(clock() - c0) / CLOCKS_PER_SEC);
-        printf("CDBG::setUnitigId(): Real time : %gs\n", difftime(time(nullptr), w0));
+        printf("%s::setUnitigId(): Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("%s::setUnitigId(): Real time : %gs\n", tag_, difftime(time(nullptr), w0));
     }
     return 0;
 }
@@ -211,6 +228,17 @@ void CDBG::replay(const pf_bfs_record &r, const uint32_t *list) {
     }
     const uint32_t t = r.exit, tu = t >> 1;
     if (r.outcome == PF_BFS_CYCLE_EXIT) {  // setNoBubble_ptr_cycle
+        if (col_) {
+            // src/CCDBG.cpp:2351-2384: a side is self-marked only if it held a real partner
+            for (uint32_t i = 0; i < r.n_list; ++i) {
+                const uint32_t w = list[i] >> 1;
+                uint32_t p = plus_[w];
+                if (p != 0 && p != w + 1) { release(p - 1, w); side_self(w, true); }
+                p = minus_[w];
+                if (p != 0 && p != w + 1) { release(p - 1, w); side_self(w, false); }
+                flags_[w] |= B_NON_SUPER;
+            }
+        } else
         for (uint32_t i = 0; i < r.n_list; ++i) poison(list[i] >> 1);
         side_self(su, plus_of(s));
         side_self(tu, !plus_of(t));
@@ -248,21 +276,53 @@ void CDBG::replay(const pf_bfs_record &r, const uint32_t *list) {
     }
     for (uint32_t i = 0; i < r.n_list; ++i)
         if (list[i] != s && list[i] != t) poison(list[i] >> 1);
+    if (col_ && !colours_allow(r, list)) {
+        side_self(su, plus_of(s));
+        side_self(tu, !plus_of(t));
+        return;
+    }
     if (plus_of(s)) { plus_[su] = tu + 1; flags_[su] |= B_PLUS; }
     else { minus_[su] = tu + 1; flags_[su] |= B_MINUS; }
     if (plus_of(t)) { minus_[tu] = su + 1; flags_[tu] |= B_MINUS; }
     else { plus_[tu] = su + 1; flags_[tu] |= B_PLUS; }
 }
 
+// The colored accept commit's extra gates (src/CCDBG.cpp:2530-2621): both endpoints carry every colour on every
+// k-mer, and every colour a vertex of the bubble carries in full continues, in full, on one of its successors.
+bool CDBG::colours_allow(const pf_bfs_record &r, const uint32_t *list) {
+    const ColorSets &col = *col_;
+    const uint32_t C = col.n_colors;
+    const uint32_t s = r.entrance, su = s >> 1, t = r.exit, tu = t >> 1;
+    const uint64_t km_s = g_.len_km(su), km_t = g_.len_km(tu);
+    bool f = true;
+    if (col.size_with(su, km_s, km_s) != km_s * C) { f = false; flags_[su] |= B_NON_SUPER; }
+    // the exit's set is sized with the entrance's mapping (:2552): only the pair encoding notices
+    if (col.size_with(tu, km_t, km_s) != km_t * C) { f = false; flags_[tu] |= B_NON_SUPER; }
+    if (!f) return false;
+    const uint64_t all = C == 64 ? ~0ull : ((1ull << C) - 1);
+    for (uint32_t i = 0; i < r.n_list; ++i) {
+        const uint32_t w = list[i];
+        if (w == t) continue;
+        // the reference keys its colour lists by unitig id and pre-loads both endpoints with every colour
+        const uint64_t mine = ((w >> 1) == su || (w >> 1) == tu) ? all : col.full_mask[w >> 1];
+        uint64_t cont = 0;
+        const uint32_t *row = &succ_[(size_t)w * 4];
+        for (int b = 0; b < 4; ++b)
+            if (row[b] != NONE) cont |= col.full_mask[row[b] >> 1];
+        if ((cont & mine) != mine) return false;
+    }
+    return true;
+}
+
 // ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
 int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thr) {
     if (status_) return status_;
-    if (!quiet_) printf("CDBG::findSuperBubble(): Finding superbubbles\n");
+    if (!quiet_) printf("%s::findSuperBubble(): Finding superbubbles\n", tag_);
     if (write_files_ && ensure_dir()) return status_;
     const auto t_all = clk::now();
     clock_t c0 = clock();
     const uint32_t N = g_.n();
-    if (!quiet_) printf("CDBG::findSuperBubble(): There are %u unitigs \n", N);
+    if (!quiet_) printf("%s::findSuperBubble(): There are %u unitigs \n", tag_, N);
     out_bytes_ = 0;
     std::fill(flags_.begin(), flags_.end(), 0);
     std::fill(plus_.begin(), plus_.end(), 0);
@@ -302,8 +362,8 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     }
     times_.replay_s = since(t0);
     if (!quiet_) {
-        printf("CDBG::findSuperBubble():  Cpu time : %gs\n", (double)(clock() - c0) / CLOCKS_PER_SEC);
-        printf("CDBG::findSuperBubble():  Real time : %gs\n", since(t_all));
+        printf("%s::findSuperBubble():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("%s::findSuperBubble():  Real time : %gs\n", tag_, since(t_all));
     }
     t0 = clk::now();
     // super_bubble.txt: one row per open endpoint side in unitig order; rows are numbered with a prefix
@@ -314,7 +374,12 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     std::vector<uint64_t> row_base(n_uch + 1, 0);
     parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
         uint64_t c = 0;
-        for (size_t u = ub; u < ue; ++u) c += (flags_[u] & B_PLUS ? 1 : 0) + (flags_[u] & B_MINUS ? 1 : 0);
+        if (col_) {  // src/CCDBG.cpp:2106-2132: an open unitig lists every side whose partner pointer is set, self included
+            for (size_t u = ub; u < ue; ++u)
+                if (flags_[u] & 3) c += (plus_[u] != 0) + (minus_[u] != 0);
+        } else {
+            for (size_t u = ub; u < ue; ++u) c += (flags_[u] & B_PLUS ? 1 : 0) + (flags_[u] & B_MINUS ? 1 : 0);
+        }
         row_base[ci + 1] = c;
     });
     for (size_t c = 0; c < n_uch; ++c) row_base[c + 1] += row_base[c];
@@ -328,7 +393,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             if ((f & 3) == 0) continue;
             for (int side = 0; side < 2; ++side) {
                 const bool ps = side == 0;
-                if (!(f & (ps ? B_PLUS : B_MINUS))) continue;
+                if (col_ ? (ps ? plus_[u] : minus_[u]) == 0 : !(f & (ps ? B_PLUS : B_MINUS))) continue;
                 put_uint(out, ++nb);
                 out.push_back('\t');
                 put_uint(out, u + 1);
@@ -350,7 +415,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     }
     times_.bubble_write_s = since(t0);
     times_.find_total_s = since(t_all);
-    if (!quiet_) printf("CDBG::findSuperBubble(): %llu  SuperBubbles Found\n", (unsigned long long)nb);
+    if (!quiet_) printf("%s::findSuperBubble(): %llu  SuperBubbles Found\n", tag_, (unsigned long long)nb);
     return 0;
 }
 
@@ -425,31 +490,115 @@ void sort_paths(std::vector<std::string> &v, int low, int high) {
 //   sites    (parallel + GPU)     per-site k-length strings -> one K-STRCOV launch
 //   format   (parallel)           text of the eleven files, concatenated in bubble order
 int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int &lower, const int &upper, const size_t &thr) {
+    return ploidy_estimation(outpre, {{lower, upper}}, thr);
+}
+
+namespace {
+// computeCramerVCoefficient (reference src/CCDBG.cpp:330-366) on two rows of a [colour][allele] coverage matrix
+double cramer_v(const double *A, const double *B, size_t n_alleles) {
+    double n = 0, nA = 0, nB = 0, chi = 0;
+    uint8_t count = 0;
+    double p[256];
+    for (size_t i = 0; i < n_alleles; ++i) {
+        nA += A[i];
+        nB += B[i];
+        p[i] = A[i] + B[i];
+        n = n + p[i];
+        if (p[i] != 0) ++count;
+    }
+    if (count < 2) return 0;
+    for (size_t i = 0; i < n_alleles; ++i) {
+        if (p[i] == 0) continue;
+        const double exA = nA * p[i] / n, exB = nB * p[i] / n;
+        chi += std::pow(A[i] - exA, 2) / exA;
+        chi += std::pow(B[i] - exB, 2) / exB;
+    }
+    return std::sqrt(chi / n);
+}
+// the maximum over all colour pairs (src/CCDBG.cpp:2964-2970, 3285-3291); m is [n_colors][stride]
+double max_cramer_v(const double *m, size_t n_colors, size_t stride, size_t n_alleles) {
+    double c = 0;
+    for (size_t ci = 0; ci + 1 < n_colors; ++ci)
+        for (size_t cj = ci + 1; cj < n_colors; ++cj) c = std::max(c, cramer_v(m + ci * stride, m + cj * stride, n_alleles));
+    return c;
+}
+
+// colored sortSeq_simple (reference src/CCDBG.cpp:368-480): descending number of colours, then descending length,
+// then descending reference string; cov is [n_colors][stride], permuted along with the unitigs
+void sort_inner_colored(const UnitigSet &g, size_t *pc, uint32_t *ov, double *cov, size_t n_colors, size_t stride, int low, int high) {
+    if (high <= low) return;
+    auto ref = [&](int x) { return g.seq(ov[x] >> 1); };
+    auto swap_at = [&](int a, int b) {
+        std::swap(pc[a], pc[b]);
+        std::swap(ov[a], ov[b]);
+        for (size_t c = 0; c < n_colors; ++c) std::swap(cov[c * stride + a], cov[c * stride + b]);
+    };
+    int i = low, j = high;
+    for (;;) {
+        while (pc[i] >= pc[low]) {
+            if (pc[i] > pc[low]) i++;
+            else if (ref(i).size() > ref(low).size()) i++;
+            else if (ref(i).size() == ref(low).size() && ref(i).compare(ref(low)) > 0) i++;
+            else break;
+            if (i == high) break;
+        }
+        while (pc[j] <= pc[low]) {
+            if (pc[j] < pc[low]) j--;
+            else if (ref(j).size() < ref(low).size()) j--;
+            else if (ref(j).size() == ref(low).size() && ref(j).compare(ref(low)) < 0) j--;
+            else break;
+            if (j == low) break;
+        }
+        if (i >= j) break;
+        swap_at(i, j);
+    }
+    swap_at(low, j);
+    sort_inner_colored(g, pc, ov, cov, n_colors, stride, low, j - 1);
+    sort_inner_colored(g, pc, ov, cov, n_colors, stride, j + 1, high);
+}
+}  // namespace
+
+int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr) {
     if (status_) return status_;
     const auto t_all = clk::now();
     clock_t c0 = clock();
-    if (!quiet_) printf("CDBG::PloidyEstimation():  Analyzing superbubbles to generate sites' information\n");
+    if (!quiet_) printf("%s::PloidyEstimation():  Analyzing superbubbles to generate sites' information\n", tag_);
     if (write_files_ && ensure_dir()) return status_;
     const uint32_t N = g_.n();
     const int k = g_.k;
-    const uint32_t low = (uint32_t)lower, up = (uint32_t)upper;
+    const bool colored = col_ != nullptr;
+    const uint32_t C = colored ? col_->n_colors : 1;
+    if (cutoff.size() != C) return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): one (lower, upper) cutoff per colour is required");
+    const uint32_t low = (uint32_t)cutoff[0].first, up = (uint32_t)cutoff[0].second;
+    std::vector<uint32_t> lows(C), ups(C);
+    for (uint32_t c = 0; c < C; ++c) { lows[c] = (uint32_t)cutoff[c].first; ups[c] = (uint32_t)cutoff[c].second; }
     const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
     times_.cov_device_s = times_.tasks_s = times_.align_s = times_.sites_s = times_.format_s = times_.write_s = 0;
     times_.tasks = times_.align_jobs = times_.site_strings = 0;
     times_.align_build_s = times_.align_device_s = times_.align_post_s = times_.align_choose_s = times_.scan_s = 0;
 
-    // C1 for every unitig in one launch (the reference calls readCov per use)
+    // C1 for every unitig (and, colored, every colour) in one launch (the reference calls readCov per use)
     auto t0 = clk::now();
-    bx_.cov_sum.ensure(ctx_, N);
-    bx_.cov_min.ensure(ctx_, N);
-    bx_.cov_miss.ensure(ctx_, N);
+    bx_.cov_sum.ensure(ctx_, (size_t)N * C);
+    bx_.cov_min.ensure(ctx_, (size_t)N * C);
+    bx_.cov_miss.ensure(ctx_, (size_t)N * C);
+    if (colored) bx_.cov_max.ensure(ctx_, (size_t)N * C);
     const uint64_t *cov_sum = bx_.cov_sum.p;
     const uint32_t *cov_min = bx_.cov_min.p;
+    const uint32_t *cov_max = bx_.cov_max.p;
     const uint8_t *cov_miss = bx_.cov_miss.p;
-    int st = pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
-    if (st != PF_OK && st != PF_ERR_MISSING_KMER) return fail(st, std::string("CDBG::PloidyEstimation(): ") + pf_last_error(ctx_));
+    int st = colored ? pf_unitig_cov_colored(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_max.p, bx_.cov_miss.p)
+                     : pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
+    if (st != PF_OK && st != PF_ERR_MISSING_KMER) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
     times_.cov_device_s = since(t0);
     auto mean_of = [&](uint32_t u) { return (double)cov_sum[u] / (double)g_.len_km(u); };
+    // readCovUni(u, low, up, c) of src/CCDBG.cpp:123-156: (sum / len, true) iff every k-mer is in colour c's database
+    // with low < count < up, else (0, false)
+    auto cov_ok_c = [&](uint32_t c, uint32_t u) {
+        const size_t o = (size_t)c * N + u;
+        return !cov_miss[o] && cov_min[o] > lows[c] && cov_max[o] < ups[c];
+    };
+    auto mean_of_c = [&](uint32_t c, uint32_t u) { return (double)cov_sum[(size_t)c * N + u] / (double)g_.len_km(u); };
     auto missing = [&](uint32_t u) -> int {
         if (!cov_miss[u]) return 0;
         return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of unitig " + std::to_string(u + 1) + " can not found .");
@@ -482,6 +631,8 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     constexpr size_t UCH = 4096;
     const size_t n_uch = n_chunks_of(N, UCH);
     std::vector<std::vector<SideRec>> side_chunks(n_uch);
+    // colored strict bubbles: [colour][4] mean-coverage matrices, one pool per chunk (Task::cov_ref points into them)
+    std::vector<std::vector<double>> cov_pools(colored ? n_uch : 0);
     parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
         std::vector<SideRec> &out = side_chunks[ci];
         for (uint32_t u = (uint32_t)ub; u < (uint32_t)ue; ++u) {
@@ -504,7 +655,7 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                 }
                 const uint32_t uo = 2 * u + (ps ? 0 : 1);
                 const bool strict = (f & (ps ? B_STRICT_P : B_STRICT_M)) != 0;
-                if (cov_miss[u]) { r.err = 1; r.err_unitig = u; out.push_back(r); continue; }  // core = readCov(u)
+                if (!colored && cov_miss[u]) { r.err = 1; r.err_unitig = u; out.push_back(r); continue; }  // core = readCov(u)
                 uint32_t exit_ov;
                 if (strict) {
                     exit_ov = first_succ(first_succ(uo));
@@ -528,6 +679,60 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                     continue;
                 }
                 r.kind = 3;
+                if (colored) {
+                    // src/CCDBG.cpp:2838-2853: the per-colour means are summed until a colour fails its range test
+                    // (the `flag == false;` there is a no-op, so the bubble is processed regardless)
+                    double core = 0;
+                    for (uint32_t c = 0; c < C; ++c) {
+                        if (!cov_ok_c(c, u)) break;
+                        core += mean_of_c(c, u);
+                    }
+                    r.t.core_mean = core;
+                    bool flag = true;
+                    if (strict) {  // :2867-2931
+                        Task &t = r.t;
+                        std::vector<double> &pool = cov_pools[ci];
+                        const size_t base = pool.size();
+                        pool.resize(base + (size_t)C * 4, 0.0);
+                        double *m = pool.data() + base;
+                        size_t pc[4] = {0, 0, 0, 0};
+                        uint32_t path = 0;
+                        for (int b = 0; b < 4 && flag; ++b) {
+                            const uint32_t w = succ_row(uo)[b];
+                            if (w == NONE) continue;
+                            const uint32_t wu = w >> 1;
+                            t.inner[t.n_inner++] = w;
+                            size_t j = 0;
+                            for (uint32_t c = 0; c < C; ++c) {
+                                if (!col_->full(wu, c)) continue;
+                                j++;
+                                if (cov_ok_c(c, wu)) m[(size_t)c * 4 + path] = mean_of_c(c, wu);
+                                else { flag = false; break; }
+                            }
+                            if (!flag) break;
+                            if (col_->size_total[wu] != j * (uint64_t)g_.len_km(wu)) { flag = false; break; }  // a colour on part of it
+                            pc[path++] = j;
+                        }
+                        if (flag) {  // some colour must see more than one of the paths
+                            flag = false;
+                            for (uint32_t c = 0; c < C && !flag; ++c) {
+                                int nz = 0;
+                                for (uint32_t q = 0; q < path; ++q) nz += m[(size_t)c * 4 + q] != 0.0;
+                                flag = nz > 1;
+                            }
+                        }
+                        if (flag) {
+                            sort_inner_colored(g_, pc, t.inner, m, C, 4, 0, (int)path - 1);
+                            t.n_cov = (uint8_t)path;
+                            t.cov_ref = ((uint64_t)ci << 32) | base;
+                        } else {
+                            pool.resize(base);
+                        }
+                    }
+                    r.aligned = flag;
+                    out.push_back(r);
+                    continue;
+                }
                 r.t.core_mean = mean_of(u);
                 bool aligned = true;
                 if (strict) {
@@ -600,6 +805,8 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             std::vector<pf_bubble_path> paths;  // text_off relative to this chunk's text
             std::vector<uint32_t> count;        // paths per bubble
             std::string text;
+            // colored: the oriented unitigs the walks of each branching bubble visit (findUnitig of the site strings)
+            std::vector<uint32_t> walk_ovs, walk_first;
         };
         std::vector<PathChunk> pchunks(n_pch);
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
@@ -609,6 +816,7 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             std::vector<std::string> strs;
             for (size_t ti = tb; ti < te; ++ti) {
                 const Task &t = tasks[ti];
+                if (colored) pc.walk_first.push_back((uint32_t)pc.walk_ovs.size());
                 if (t.strict) {
                     for (int q = 0; q < t.n_inner; ++q) pc.paths.push_back({0, g_.size_bp(t.inner[q] >> 1), t.inner[q]});
                     pc.count.push_back(t.n_inner);
@@ -625,6 +833,8 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                     const uint32_t w = minor.back();
                     minor.pop_back();
                     major.push_back(w);
+                    if (colored && std::find(pc.walk_ovs.begin() + pc.walk_first.back(), pc.walk_ovs.end(), w) == pc.walk_ovs.end())
+                        pc.walk_ovs.push_back(w);
                     const uint32_t wlen = g_.len_km(w >> 1);
                     const size_t before = walk.size();
                     g_.append_mapped(w, walk);
@@ -653,6 +863,7 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                 }
                 pc.count.push_back((uint32_t)strs.size());
             }
+            if (colored) pc.walk_first.push_back((uint32_t)pc.walk_ovs.size());
         });
         // one flat batch: bubbles with fewer than two paths (the reference indexes str[1] blindly) are skipped
         std::vector<uint64_t> text_base(n_pch + 1, 0), path_base(n_pch + 1, 0);
@@ -736,9 +947,49 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             std::vector<std::string> strings;
             std::vector<GroupRef> groups;      // per (branching bubble, site, allele group), in order
             std::vector<uint32_t> first_group;  // per bubble of the chunk: index of its first GroupRef
+            std::vector<uint64_t> mask;         // colored, per string: colours its findUnitig() mapping carries in full
             int err = 0;
         };
         std::vector<SiteChunk> schunks(n_pch);
+        // cdbg.findUnitig(s, 0, len) of src/CCDBG.cpp:3251, 3390 followed by UnitigColors::contains on that mapping: the
+        // first k-mer of a site string lies on one of the bubble's unitigs (each k-mer occurs once in the graph); the
+        // mapping is extended along that unitig while the characters agree (CompactedDBG.tcc:3815-3837,
+        // CompressedSequence.cpp:497-520).  Returns the mask of colours present on every k-mer of the mapping.
+        auto colours_of_string = [&](const std::string &sx, const uint32_t *ovs, size_t n_ovs, int &err) -> uint64_t {
+            std::string rc((size_t)k, 'A');
+            for (int i = 0; i < k; ++i) {
+                const char ch = sx[(size_t)k - 1 - i];
+                rc[i] = ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : 'A';
+            }
+            const std::string_view head(sx.data(), (size_t)k), rhead(rc);
+            for (size_t q = 0; q < n_ovs; ++q) {
+                const uint32_t u = ovs[q] >> 1;
+                const std::string_view seq = g_.seq(u);
+                uint32_t dist, len;
+                size_t p = seq.find(head);
+                if (p != std::string_view::npos) {
+                    size_t j = 0;
+                    while (j < sx.size() && p + j < seq.size() && sx[j] == seq[p + j]) ++j;
+                    len = (uint32_t)(j - (size_t)k + 1);
+                    dist = (uint32_t)p;
+                } else if ((p = seq.find(rhead)) != std::string_view::npos) {
+                    long pos = (long)p + k - 1;
+                    size_t j = 0;
+                    auto comp = [](char ch) { return ch == 'A' ? 'T' : ch == 'C' ? 'G' : ch == 'G' ? 'C' : 'A'; };
+                    while (j < sx.size() && pos >= 0 && sx[j] == comp(seq[(size_t)pos])) { ++j; --pos; }
+                    len = (uint32_t)(j - (size_t)k + 1);
+                    dist = (uint32_t)p - (len - 1);
+                } else {
+                    continue;
+                }
+                uint64_t m = 0;
+                for (uint32_t c = 0; c < C; ++c)
+                    if (col_->contains(u, c, dist, len)) m |= 1ull << c;
+                return m;
+            }
+            err = 2;
+            return 0;
+        };
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
             SiteChunk &sc = schunks[ci];
             sc.first_group.reserve(te - tb);
@@ -827,18 +1078,27 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                     for (size_t p = 0; p < R; ++p) groups[grp[p] - 1].insert(kstr[p]);
                     for (auto &gs : groups) {
                         sc.groups.push_back({(uint32_t)sc.strings.size(), (uint32_t)gs.size()});
-                        for (auto &sx : gs) sc.strings.push_back(sx);
+                        for (auto &sx : gs) {
+                            sc.strings.push_back(sx);
+                            if (colored) {
+                                const PathChunk &pc = pchunks[ci];
+                                const uint32_t w0 = pc.walk_first[ti - tb], w1 = pc.walk_first[ti - tb + 1];
+                                sc.mask.push_back(colours_of_string(sx, pc.walk_ovs.data() + w0, w1 - w0, sc.err));
+                            }
+                        }
                     }
                 }
             }
         });
-        for (auto &scx : schunks)
+        for (auto &scx : schunks) {
+            if (scx.err == 2) return fail(PF_ERR_ARG, "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble");
             if (scx.err) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): site string outside an aligned row");
+        }
         std::vector<uint64_t> chunk_base(n_pch + 1, 0);
         for (size_t c = 0; c < n_pch; ++c) chunk_base[c + 1] = chunk_base[c] + schunks[c].strings.size();
         const size_t n_strings = chunk_base[n_pch];
-        std::vector<uint64_t> str_sum(n_strings), str_len(n_strings);
-        std::vector<uint8_t> str_ok(n_strings), str_miss(n_strings);
+        std::vector<uint64_t> str_sum(n_strings * C), str_len(n_strings);  // colored: [string][colour]
+        std::vector<uint8_t> str_ok(n_strings * C), str_miss(colored ? 0 : n_strings);
         if (n_strings) {
             std::string text;
             std::vector<uint64_t> soff(n_strings + 1, 0);
@@ -846,10 +1106,14 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
             for (auto &scx : schunks)
                 for (auto &sx : scx.strings) { soff[q] = text.size(); str_len[q] = sx.size(); text += sx; ++q; }
             soff[n_strings] = text.size();
-            st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)n_strings, low, up, str_sum.data(), str_ok.data(),
-                               str_miss.data());
-            if (st != PF_OK) return fail(st, std::string("CDBG::PloidyEstimation(): ") + pf_last_error(ctx_));
-            for (size_t i = 0; i < n_strings; ++i)
+            if (colored)  // a missing k-mer is (0, false) on this path, not an exit (src/CCDBG.cpp:113-117)
+                st = pf_string_cov_colored(ctx_, text.data(), soff.data(), (uint32_t)n_strings, lows.data(), ups.data(), str_sum.data(),
+                                           str_ok.data());
+            else
+                st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)n_strings, low, up, str_sum.data(), str_ok.data(),
+                                   str_miss.data());
+            if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+            for (size_t i = 0; i < str_miss.size(); ++i)
                 if (str_miss[i]) return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of a site string can not found .");
             times_.site_strings += n_strings;
         }
@@ -867,8 +1131,10 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
             ChunkOut &o = outs[ci];
             const SiteChunk &sc = schunks[ci];
-            std::string cov_info, fre_info;
+            std::string cov_info, fre_info, tail;
             double tc[256];
+            std::vector<double> gc;  // colored: [colour][allele group] coverage of the site
+            const uint64_t all_colours = C == 64 ? ~0ull : ((1ull << C) - 1);
             for (size_t ti = tb; ti < te; ++ti) {
                 const Task &t = tasks[ti];
                 const pf_bubble_result &r = result_of(ti);
@@ -911,6 +1177,77 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
                     for (uint32_t x = 0; x < maxnum; ++x) tc[x] = 0.0;
                     double denom;
                     if (sr.is_indel) ++indel;  // counted even when the site is dropped below (src/CDBG.cpp:1526)
+                    if (colored) {
+                        // src/CCDBG.cpp:2971-3059 (strict), :3236-3339 and :3374-3475 (branching): one row per colour that
+                        // sees at least two allele groups, each with the colour id and the largest Cramer's V over colour pairs
+                        gc.assign((size_t)C * maxnum, 0.0);
+                        double coefficient;
+                        if (t.strict) {
+                            const double *m = cov_pools[t.cov_ref >> 32].data() + (uint32_t)t.cov_ref;  // [colour][4], sorted paths
+                            for (uint32_t c = 0; c < C; ++c)
+                                for (size_t p = 0; p < R; ++p) gc[(size_t)c * maxnum + grp[p] - 1] += m[(size_t)c * 4 + p];
+                            coefficient = max_cramer_v(m, C, 4, R);
+                        } else {
+                            const uint64_t base = chunk_base[ci];
+                            uint64_t seen_colours = 0;
+                            bool ok = true;
+                            for (uint32_t gi = 0; gi < maxnum && ok; ++gi) {
+                                const GroupRef &gr = sc.groups[gcur + gi];
+                                for (uint32_t qi = gr.first; qi < gr.first + gr.count && ok; ++qi) {
+                                    const uint64_t q = base + qi, mask = sc.mask[qi];
+                                    for (uint32_t c = 0; c < C; ++c) {
+                                        if (!((mask >> c) & 1)) continue;
+                                        seen_colours |= 1ull << c;
+                                        if (!str_ok[q * C + c]) { ok = false; break; }
+                                        gc[(size_t)c * maxnum + gi] += (double)str_sum[q * C + c] / (double)(str_len[q] - (size_t)k + 1);
+                                    }
+                                }
+                            }
+                            gcur += maxnum;
+                            if (seen_colours != all_colours || !ok) continue;
+                            coefficient = max_cramer_v(gc.data(), C, maxnum, maxnum);
+                        }
+                        tail.clear();
+                        tail += t.strict ? "1\t" : "0\t";
+                        if (sr.is_indel) put_uint(tail, ilen[indel - 1]);
+                        else tail.push_back('0');
+                        tail.push_back('\t');
+                        put_uint(tail, my_vc);
+                        tail.push_back('\t');
+                        put_uint(tail, ns);
+                        tail.push_back('\t');
+                        put_double(tail, coefficient);
+                        tail.push_back('\t');
+                        put_uint(tail, vd);
+                        tail += "\t\n";
+                        for (uint32_t c = 0; c < C; ++c) {
+                            const double *row = gc.data() + (size_t)c * maxnum;
+                            uint32_t n_res = 0;
+                            double sum = 0;
+                            for (uint32_t x = 0; x < maxnum; ++x)
+                                if (row[x] > 0.0) { ++n_res; sum += row[x]; }
+                            if (n_res < 2) continue;
+                            cov_info.clear();
+                            fre_info.clear();
+                            for (uint32_t x = 0; x < maxnum; ++x) {
+                                if (!(row[x] > 0.0)) continue;
+                                put_double(cov_info, row[x]);
+                                cov_info.push_back('\t');
+                                put_double(fre_info, row[x] / sum);
+                                fre_info.push_back('\n');
+                            }
+                            put_uint(cov_info, c);
+                            cov_info.push_back('\t');
+                            cov_info += tail;
+                            o.allfre += fre_info;
+                            if (n_res >= 2 && n_res <= 5) {
+                                ++o.allele[n_res - 2];
+                                o.fre[n_res - 2] += fre_info;
+                                o.cov[n_res - 2] += cov_info;
+                            }
+                        }
+                        continue;
+                    }
                     if (t.strict) {
                         for (size_t p = 0; p < R; ++p) tc[grp[p] - 1] += t.cov[p];
                         denom = t.cov_sum;
@@ -994,15 +1331,77 @@ int CDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const int 
     times_.write_s = since(t0);
     times_.ploidy_total_s = since(t_all);
     if (!quiet_) {
-        printf("CDBG::PloidyEstimation():  Cpu time : %gs\n", (double)(clock() - c0) / CLOCKS_PER_SEC);
-        printf("CDBG::PloidyEstimation():  Real time : %gs\n", times_.ploidy_total_s);
-        printf("CDBG::PloidyEstimation(): Alleles in SuperBubbles  :\t2 :%llu\t3 :%llu\t4 :%llu\t5 :%llu\n",
+        printf("%s::PloidyEstimation():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("%s::PloidyEstimation():  Real time : %gs\n", tag_, times_.ploidy_total_s);
+        printf("%s::PloidyEstimation(): Alleles in SuperBubbles  :\t2 :%llu\t3 :%llu\t4 :%llu\t5 :%llu\n", tag_,
                (unsigned long long)allele_[0], (unsigned long long)allele_[1], (unsigned long long)allele_[2],
                (unsigned long long)allele_[3]);
         // the reference divides unguarded (src/CDBG.cpp:1703) and dies with SIGFPE when no site exists
-        if (core_num_) printf("CDBG::PloidyEstimation(): Sites' Average Coverage:%d\n", (int)(core_cov_ / core_num_));
+        if (core_num_) printf("%s::PloidyEstimation(): Sites' Average Coverage:%d\n", tag_, (int)(core_cov_ / core_num_));
     }
     return 0;
+}
+
+// ---- colored graph + CCDBG (reference src/CCDBG.cpp) -------------------------------------------------
+bool ColoredUnitigSet::read(const std::string &graphfile, const std::string &colorfile, size_t nb_threads, bool verbose) {
+    if (verbose) printf("ColoredCDBG::read(): Reading graph.\n");
+    if (!graph.load_gfa(graphfile, err)) return false;
+    if (verbose) printf("ColoredCDBG::read(): Reading colors.\n");
+    return colors.load(colorfile, graph, (unsigned)std::max<size_t>(nb_threads, 1), err);
+}
+
+CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db_list,
+             const size_t &thread, int device, bool quiet)
+    : CDBG(graph.graph, complexsize, m, d, g, device, quiet, NoCounts{}), cg_(graph) {
+    if (status_) return;
+    col_ = &cg_.colors;
+    const uint32_t C = cg_.colors.n_colors;
+    if (C > PF_MAX_COLORS) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: more colours than the device table holds"); return; }
+    if (!kmc_db_list.empty()) {
+        // src/CCDBG.cpp:13-43: one database name per line, one line per colour
+        FILE *f = fopen(kmc_db_list.c_str(), "r");
+        if (!f) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: Open kmc database name file error"); return; }
+        std::vector<std::string> names;
+        {
+            std::string cur;
+            int ch;
+            while ((ch = fgetc(f)) != EOF) {
+                if (ch == '\n') { names.push_back(cur); cur.clear(); }
+                else cur.push_back((char)ch);
+            }
+            if (!cur.empty()) names.push_back(cur);
+            fclose(f);
+        }
+        names.resize(C);  // missing lines read as empty names, which fail to open below as in the reference
+        std::vector<KmcRecords> dbs(C);
+        std::vector<std::string> errs(C);
+        std::vector<int> bad(C, 0);
+        parallel_chunks(C, 1, (unsigned)std::max<size_t>(thread, 1), [&](size_t c, size_t, size_t) { bad[c] = !dbs[c].load(names[c], errs[c]); });
+        for (uint32_t c = 0; c < C; ++c) {
+            if (bad[c]) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: Open kmc database " + names[c] + " error (" + errs[c] + ")"); return; }
+            if ((int)dbs[c].k != g_.k) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: k of kmc database " + names[c] + " differs from the graph's"); return; }
+            if (!quiet_) printf("CCDBG::CCDBG(): kmc database %s initialized\n", names[c].c_str());
+        }
+        std::vector<const uint64_t *> pk(C);
+        std::vector<const uint32_t *> pc(C);
+        std::vector<uint64_t> n(C), mn(C), mx(C);
+        std::vector<int> both(C);
+        for (uint32_t c = 0; c < C; ++c) {
+            pk[c] = dbs[c].kmers.data();
+            pc[c] = dbs[c].counts.data();
+            n[c] = dbs[c].total;
+            mn[c] = dbs[c].min_count;
+            mx[c] = dbs[c].max_count;
+            both[c] = dbs[c].both_strands;
+        }
+        int st = pf_upload_counts_colored(ctx_, C, pk.data(), pc.data(), n.data(), mn.data(), mx.data(), both.data());
+        if (st != PF_OK) { fail(st, std::string("CCDBG::CCDBG():Error: ") + pf_last_error(ctx_)); return; }
+    }
+    if (!quiet_) printf("CCDBG::CCDBG():CCDBG initialized!\n");
+}
+
+int CCDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr) {
+    return ploidy_estimation(outpre, cutoff, thr);
 }
 
 }  // namespace pfh

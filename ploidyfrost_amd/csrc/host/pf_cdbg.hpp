@@ -23,6 +23,7 @@
 #include <utility>
 #include <vector>
 
+#include "pf_host_colors.hpp"
 #include "pf_host_graph.hpp"
 #include "pf_pinned.hpp"
 #include "ploidyfrost_hip.h"
@@ -46,7 +47,7 @@ class CDBG {
 public:
     CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db = "",
          int device = 0, bool quiet = false);
-    ~CDBG();
+    virtual ~CDBG();
     CDBG(const CDBG &) = delete;
     CDBG &operator=(const CDBG &) = delete;
 
@@ -77,7 +78,17 @@ public:
     // text of <outpre>_allele_frequency.txt of the last run (the record slab a multi-GPU job gathers)
     const std::string &last_allele_frequency() const { return last_allfre_; }
 
-private:
+protected:
+    // graph + adjacency on the device, no count database yet (the colored subclass brings its own)
+    struct NoCounts {};
+    CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, int device, bool quiet, NoCounts);
+    int init_device(int device);
+    // the path proper; cutoff holds one (lower, upper) pair (single sample) or one per colour
+    int ploidy_estimation(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
+    // set by CCDBG: the colour sets of the graph's unitigs (reference src/CCDBG.cpp path) and the stdout tag
+    const ColorSets *col_ = nullptr;
+    const char *tag_ = "CDBG";
+
     struct Task;
     int fail(int st, const std::string &msg);
     int ensure_dir();
@@ -89,6 +100,7 @@ private:
     void release(uint32_t ex, uint32_t me);
     void poison(uint32_t u);
     void replay(const pf_bfs_record &r, const uint32_t *list);
+    bool colours_allow(const pf_bfs_record &r, const uint32_t *list);
 
     UnitigSet &g_;
     size_t complex_size_;
@@ -119,7 +131,9 @@ private:
         PinnedBuf<uint64_t> cov_sum;
         PinnedBuf<uint32_t> cov_min;
         PinnedBuf<uint8_t> cov_miss;
+        PinnedBuf<uint32_t> cov_max;  // colored path: per (colour, unitig) arrays, colour-major
         void release_all() {
+            cov_max.release();
             text.release(); otext.release(); paths.release(); tasks.release(); res.release(); osites.release();
             ogroups.release(); oilen.release(); bfs_rec.release(); bfs_pool.release(); cov_sum.release(); cov_min.release();
             cov_miss.release();
@@ -129,6 +143,38 @@ private:
     std::string last_allfre_;
     uint64_t allele_[4] = {0, 0, 0, 0};
     uint64_t core_cov_ = 0, core_num_ = 0, n_super_bubble_ = 0, out_bytes_ = 0;
+};
+
+// pfh::ColoredUnitigSet -- what the colored path needs of the reference's ColoredCDBG<MyUnitig>
+// (bifrost/src/ColoredCDBG.hpp): the unitigs of the GFA file and their colour sets from the .bfg_colors file.
+struct ColoredUnitigSet {
+    UnitigSet graph;
+    ColorSets colors;
+    std::string err;
+    // ColoredCDBG::read(graphfile, colorfile, nb_threads, verbose) (bifrost/src/ColoredCDBG.tcc:428-600)
+    bool read(const std::string &graphfile, const std::string &colorfile, size_t nb_threads = 1, bool verbose = false);
+    size_t getNbColors() const { return colors.n_colors; }
+    int getK() const { return graph.k; }
+    size_t size() const { return graph.n(); }
+};
+
+// pfh::CCDBG -- mirror of the reference class CCDBG (src/CCDBG.hpp:18-40, driven from src/Main.cpp:775-810):
+//
+//     CCDBG g(cdbg, z, M, D, G, kmc_list_file, threads);
+//     g.setUnitigId(outpre, graphfile, threads);
+//     g.findSuperBubble_multithread_ptr(outpre, threads);
+//     g.ploidyEstimation_multithread_ptr(outpre, cutoffs, threads);      // one (lower, upper) per colour
+//
+// Output files are byte-identical to the reference's `-t 1` run.  All colours' count databases live in one
+// HBM table (include/ploidyfrost_hip.h, pf_upload_counts_colored).
+class CCDBG : public CDBG {
+public:
+    CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db_list = "",
+          const size_t &thread = 1, int device = 0, bool quiet = false);
+    int ploidyEstimation_multithread_ptr(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
+
+private:
+    ColoredUnitigSet &cg_;
 };
 
 }  // namespace pfh

@@ -3,6 +3,7 @@
 #include <exception>
 #include <memory>
 #include <string>
+#include <vector>
 
 #include "pf_cdbg.hpp"
 #include "pf_host_colors.hpp"
@@ -10,7 +11,10 @@
 
 struct pfh_run {
     pfh::UnitigSet graph;
+    std::unique_ptr<pfh::ColoredUnitigSet> cgraph;  // colored runs: graph + colour sets (then `graph` stays empty)
     std::unique_ptr<pfh::CDBG> cdbg;
+    pfh::CCDBG *ccdbg = nullptr;                     // == cdbg.get() for colored runs
+    const pfh::UnitigSet &g() const { return cgraph ? cgraph->graph : graph; }
     double z_M = 2, z_D = -1, z_G = -3;
     size_t z = 8;
     double load_s = 0, upload_s = 0;
@@ -57,6 +61,42 @@ pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex
     }
 }
 
+pfh_run *pfh_open_colored(const char *gfa_path, const char *colors_path, const char *kmc_list_file, uint32_t complex_size,
+                          double match, double mismatch, double gap, uint32_t threads, int device) {
+    using clk = std::chrono::steady_clock;
+    try {
+        auto r = std::make_unique<pfh_run>();
+        auto t0 = clk::now();
+        r->cgraph = std::make_unique<pfh::ColoredUnitigSet>();
+        if (!r->cgraph->read(gfa_path, colors_path, threads ? threads : 1, false)) { g_open_err = r->cgraph->err; return nullptr; }
+        r->load_s = std::chrono::duration<double>(clk::now() - t0).count();
+        r->z = complex_size;
+        r->z_M = match; r->z_D = mismatch; r->z_G = gap;
+        t0 = clk::now();
+        auto cc = std::make_unique<pfh::CCDBG>(*r->cgraph, r->z, r->z_M, r->z_D, r->z_G, kmc_list_file ? kmc_list_file : "",
+                                               (size_t)(threads ? threads : 1), device, true);
+        r->upload_s = std::chrono::duration<double>(clk::now() - t0).count();
+        if (!cc->good()) { g_open_err = cc->error(); return nullptr; }
+        r->ccdbg = cc.get();
+        r->cdbg = std::move(cc);
+        return r.release();
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return nullptr;
+    }
+}
+
+uint32_t pfh_num_colors(const pfh_run *r) { return r->cgraph ? (uint32_t)r->cgraph->getNbColors() : 0; }
+
+int pfh_ploidy_estimation_colored(pfh_run *r, const char *outpre, const int *lower, const int *upper, uint32_t n_colors) {
+    if (!r->ccdbg) { r->err = "pfh_ploidy_estimation_colored: the run was not opened with pfh_open_colored"; return PF_ERR_ARG; }
+    return guarded(r, [&] {
+        std::vector<std::pair<int, int>> cut(n_colors);
+        for (uint32_t c = 0; c < n_colors; ++c) cut[c] = {lower[c], upper[c]};
+        return r->ccdbg->ploidyEstimation_multithread_ptr(outpre, cut, 1);
+    });
+}
+
 void pfh_close(pfh_run *r) { delete r; }
 const char *pfh_last_error(const pfh_run *r) {
     if (!r) return g_open_err.c_str();
@@ -83,7 +123,7 @@ void pfh_get_times(const pfh_run *r, pfh_times *o) {
     o->bfs_device_s = t.bfs_device_s; o->replay_s = t.replay_s; o->bubble_write_s = t.bubble_write_s; o->find_total_s = t.find_total_s;
     o->cov_device_s = t.cov_device_s; o->tasks_s = t.tasks_s; o->align_s = t.align_s; o->sites_s = t.sites_s;
     o->format_s = t.format_s; o->write_s = t.write_s; o->ploidy_total_s = t.ploidy_total_s;
-    o->unitigs = r->graph.n(); o->kmers = r->graph.n_kmers; o->candidates = t.candidates; o->superbubbles = r->cdbg->n_superbubbles();
+    o->unitigs = r->g().n(); o->kmers = r->g().n_kmers; o->candidates = t.candidates; o->superbubbles = r->cdbg->n_superbubbles();
     o->tasks = t.tasks; o->align_jobs = t.align_jobs; o->site_strings = t.site_strings; o->output_bytes = r->cdbg->output_bytes();
     for (int a = 0; a < 4; ++a) o->allele[a] = r->cdbg->allele_sites(a + 2);
     o->core_cov = r->cdbg->core_cov(); o->core_num = r->cdbg->core_num();
@@ -96,7 +136,7 @@ const char *pfh_last_allele_frequency(const pfh_run *r, uint64_t *len) {
 }
 
 void pfh_state(const pfh_run *r, uint8_t *flags, uint32_t *plus, uint32_t *minus) {
-    const size_t N = r->graph.n();
+    const size_t N = r->g().n();
     if (flags) memcpy(flags, r->cdbg->state_flags().data(), N);
     if (plus) memcpy(plus, r->cdbg->state_plus().data(), N * 4);
     if (minus) memcpy(minus, r->cdbg->state_minus().data(), N * 4);

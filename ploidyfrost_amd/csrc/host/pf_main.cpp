@@ -1,10 +1,10 @@
 // `ploidyfrost` -- command line of the MI355X build, same option surface as the reference's
-// single-sample run (reference src/Main.cpp:124-198 getopt string and cases, :278-541 checks,
-// :812-849 dispatch):
+// hot path (reference src/Main.cpp:124-198 getopt string and cases, :278-541 checks, :770-849 dispatch):
 //     ploidyfrost -g <BifrostGraph.gfa> -d <KMCDatabase> -o <prefix> [-t T -l L -u U -z Z -M m -D d -G g -v -i]
+//     ploidyfrost -g <BifrostGraph.gfa> -f <BifrostGraph.bfg_colors> -d <KMCDatabaseList> [-C <cutoffs>] -o <prefix> ...
 // Output: ./PloidyFrost_output/<prefix>_*.txt, byte-identical to the reference run with -t 1.
-// The colored path (-f/-C), the `model` and `cutoffL/cutoffU` sub-commands are outside this
-// build's scope and say so.
+// The `model` and `cutoffL/cutoffU` sub-commands (and the -h histogram cutoffs) are outside this build's
+// scope and say so.
 #include <getopt.h>
 #include <sys/stat.h>
 
@@ -14,7 +14,9 @@
 #include <cstring>
 #include <iostream>
 #include <string>
+#include <fstream>
 #include <thread>
+#include <vector>
 
 #include "pf_cdbg.hpp"
 
@@ -27,7 +29,9 @@ void PrintUsage() {
          << "  -g,             Input Bifrost Graph file (GFA format)" << endl
          << "  -o,             Prefix for Output files (default : 'output')" << endl
          << "  -t,             Number of Threads (default is 1; output always follows the -t 1 order)" << endl
-         << "  -d,             Load KMC Database" << endl
+         << "  -d,             Load KMC Database (with -f: a file listing one database per colour)" << endl
+         << "  -f,             Input Bifrost color file (BFG_COLORS format): colored, multi-sample analysis" << endl
+         << "  -C,             Coverage thresholds file, one \"lower<TAB>upper\" line per colour (default : 10 1000)" << endl
          << "  -l,             Lower coverage threshold (default : 10 )" << endl
          << "  -u,             Upper coverage threshold (default : 1000 )" << endl
          << "  -z,             Maximum number of unitigs in superbubble (default : 8 )" << endl
@@ -37,7 +41,7 @@ void PrintUsage() {
          << "parameters with no argument:" << endl << endl
          << "  -v,             Print information messages during construction" << endl
          << "  -i,             Output Information about Bifrost graph" << endl << endl
-         << "Not part of this build: colored graphs (-f, -C), `model`, `cutoffL`, `cutoffU`." << endl;
+         << "Not part of this build: `model`, `cutoffL`, `cutoffU`, -h." << endl;
 }
 
 struct Options {
@@ -45,6 +49,7 @@ struct Options {
     size_t nb_threads = 1, complex_size = 8;
     bool verbose = false, info = false;
     int coverage_lower = 10, coverage_upper = 1000, k = 25;
+    vector<pair<int, int>> coverage_vec;
     double match = 2, mismatch = -1, gap = -3;
 };
 
@@ -92,11 +97,50 @@ int main(int argc, char **argv) {
     const size_t max_threads = std::thread::hardware_concurrency();
     if ((long)opt.nb_threads <= 0) { cerr << "Error: Number of threads cannot be less than or equal to 0." << endl; ok = false; }
     if (opt.nb_threads > max_threads) { cerr << "Error: Number of threads cannot be greater than or equal to " << max_threads << "." << endl; ok = false; }
-    if (!opt.colorfile.empty()) { cerr << "Error: colored graphs (-f) are not part of this build." << endl; ok = false; }
+    if (!opt.hist.empty()) { cerr << "Error: histogram-derived cutoffs (-h) are not part of this build; pass -l/-u or -C." << endl; ok = false; }
+    size_t kmc_db_num = 0;
     if (opt.db.empty()) { cerr << "Error: Need input a kmc database prefix!\n"; ok = false; }
-    else if (!file_exists(opt.db + ".kmc_pre") || !file_exists(opt.db + ".kmc_suf")) {
-        cerr << "Error: Could not read the input kmc database " << opt.db << "." << endl;
-        ok = false;
+    else if (opt.colorfile.empty()) {
+        if (!file_exists(opt.db + ".kmc_pre") || !file_exists(opt.db + ".kmc_suf")) {
+            cerr << "Error: Could not read the input kmc database " << opt.db << "." << endl;
+            ok = false;
+        }
+    } else {
+        // :326-353: the -d file lists one database per line
+        ifstream in(opt.db);
+        if (!file_exists(opt.db) || in.fail()) { ok = false; }
+        else {
+            string name;
+            while (getline(in, name, '\n')) {
+                ++kmc_db_num;
+                if (!file_exists(name + ".kmc_pre") || !file_exists(name + ".kmc_suf")) {
+                    cerr << "Error: Could not read the input kmc database " << name << "." << endl;
+                    ok = false;
+                    break;
+                }
+            }
+        }
+        // :398-455: -C "lower\tupper" per database, default (10, 1000)
+        if (!opt.coveragefile.empty()) {
+            ifstream cin_(opt.coveragefile);
+            if (!file_exists(opt.coveragefile) || cin_.fail()) { ok = false; }
+            else {
+                string line;
+                size_t i = 0;
+                while (getline(cin_, line, '\n')) {
+                    const size_t pos1 = line.find("\t");
+                    if (pos1 == string::npos) { cerr << "Error: Coverage File is badly Formatted." << endl; exit(EXIT_FAILURE); }
+                    opt.coverage_vec.push_back({(int)atoll(line.substr(0, pos1).c_str()), (int)atoll(line.substr(pos1 + 1).c_str())});
+                    if (opt.coverage_vec[i].first < 0 || opt.coverage_vec[i].second < 0) { cerr << "Error: Filter coverage need a positive number." << endl; ok = false; }
+                    if (opt.coverage_vec[i].first > opt.coverage_vec[i].second) { cerr << "Error: lower cutoff need be smaller than upper cutoff " << endl; ok = false; }
+                    i++;
+                }
+                if (i != kmc_db_num) { cerr << "ERROR: the numbers of kmc databases and coverages are not equal! " << endl; exit(EXIT_FAILURE); }
+            }
+        } else {
+            opt.coverage_vec.insert(opt.coverage_vec.end(), kmc_db_num, pair<int, int>(10, 1000));
+        }
+        if (!file_exists(opt.colorfile)) { cerr << "Error: The input color file does not exist." << endl; ok = false; }
     }
     if (opt.complex_size < 4) { cerr << "Error: Maximum number of unitigs in superbubble is at least 4 !" << endl; ok = false; }
     if (opt.mismatch > opt.match) { cerr << "Error: Mismatch penalty should be smaller than match score !" << endl; ok = false; }
@@ -107,6 +151,44 @@ int main(int argc, char **argv) {
     if (opt.graphfile.empty()) { cerr << "Error: No graph file was provided in input." << endl; ok = false; }
     else if (!file_exists(opt.graphfile)) { cerr << "Error: The graph file does not exist." << endl; ok = false; }
     if (!ok) { PrintUsage(); return 0; }
+
+    if (!opt.colorfile.empty()) {  // src/Main.cpp:775-810
+        pfh::ColoredUnitigSet cdbg;
+        auto t0 = std::chrono::steady_clock::now();
+        if (!cdbg.read(opt.graphfile, opt.colorfile, opt.nb_threads, opt.verbose)) {
+            cout << "ColoredCDBG::read(): Graph could not be loaded! Exit. (" << cdbg.err << ")" << endl;
+            exit(EXIT_FAILURE);
+        }
+        cout << "ColoredCDBG::read(): Graph loading successful" << endl;
+        cout << "CCDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
+        if (cdbg.getNbColors() != kmc_db_num) {
+            cerr << "CCDBG::CCDBG():Error: " << kmc_db_num << " kmc databases listed for " << cdbg.getNbColors() << " colors" << endl;
+            exit(EXIT_FAILURE);
+        }
+        pfh::CCDBG g(cdbg, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db, opt.nb_threads);
+        auto die = [&]() {
+            cerr << g.error() << endl;
+            exit(EXIT_FAILURE);
+        };
+        if (!g.good()) die();
+        g.set_threads((unsigned)opt.nb_threads);
+        if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
+        if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
+        if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) die();
+        for (size_t i = 0; i < opt.coverage_vec.size(); i++) {
+            cout << "CCDBG:: Database " << i << " Minimum Coverage:" << opt.coverage_vec[i].first << endl;
+            cout << "CCDBG:: Maximum Coverage:" << opt.coverage_vec[i].second << endl;
+        }
+        if (g.ploidyEstimation_multithread_ptr(opt.outprefix, opt.coverage_vec, opt.nb_threads)) die();
+        if (opt.verbose) {
+            const pfh::PhaseTimes &t = g.times();
+            printf("[device] candidates %llu  bfs %.3fs replay %.3fs | cov %.3fs tasks %.3fs (%llu) align %.3fs (%llu jobs) "
+                   "sites %.3fs (%llu strings) format %.3fs write %.3fs\n",
+                   (unsigned long long)t.candidates, t.bfs_device_s, t.replay_s, t.cov_device_s, t.tasks_s, (unsigned long long)t.tasks,
+                   t.align_s, (unsigned long long)t.align_jobs, t.sites_s, (unsigned long long)t.site_strings, t.format_s, t.write_s);
+        }
+        return 0;
+    }
 
     pfh::UnitigSet graph;
     std::string err;

@@ -1,0 +1,336 @@
+// Colored (multi-sample) coverage on gfx950: the device side of reference src/CCDBG.cpp's
+// readCovUni (:123-156) and readCov(string, low, up, colour) (:89-122) over *one* count database per colour
+// (CCDBG::CCDBG, :13-43).
+//
+// MI355X layout: the C databases are joined into ONE open-addressing table keyed by the stored k-mer,
+// each slot = { u64 key, u32 count[C] } padded to a power-of-two stride (16 B for C <= 2, 32 B for C <= 6,
+// 64 B for C <= 14, ...), so that a k-mer costs one random HBM access for all colours instead of C.  An absent
+// (k-mer, colour) pair is the all-ones count.  K-COV-C walks the unitigs exactly like K-COV (one wavefront per
+// unitig, lanes over its k-mers) and reduces sum / min / max / missing per colour, four colours per pass
+// in registers; the range test of readCovUni ("low < count < up" for every k-mer) is min > low && max < up on
+// the host, which keeps the cutoffs out of the resident result.  Integer / index work: no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include "pf_ctx.hpp"
+#include "pf_device_common.hpp"
+#include "ploidyfrost_hip.h"
+
+using namespace pf;
+
+#define PF_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return PF_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+constexpr uint32_t MISSING = 0xFFFFFFFFu;
+constexpr int CPP = 4;  // colours per pass of K-COV-C
+
+struct CTab {
+    const uint8_t *base;
+    uint64_t mask;
+    uint32_t shift;  // log2(stride bytes)
+};
+
+__device__ inline const uint8_t *ctab_slot(const CTab &t, uint64_t i) { return t.base + (i << t.shift); }
+
+// slot of an exact key, or nullptr
+__device__ inline const uint8_t *ctab_find(const CTab &t, uint64_t key) {
+    uint64_t i = mix64(key) & t.mask;
+    for (;;) {
+        const uint8_t *s = ctab_slot(t, i);
+        const uint64_t kx = *reinterpret_cast<const uint64_t *>(s);
+        if (kx == key) return s;
+        if (kx == EMPTY_KEY) return nullptr;
+        i = (i + 1) & t.mask;
+    }
+}
+
+// The composite lookup of CCDBG.cpp:98-103 per colour -- "if (!IsKmer(fwd)) reverse(); CheckKmer()" -- for CPP
+// colours starting at c0: the count the colour's database holds for the forward k-mer, else for its reverse
+// complement, else MISSING.  When no k-mer is a key of the table in both orientations (`one_strand`) the canonical
+// form is probed first and the second probe only happens for k-mers absent from the table.
+__device__ inline void colored_counts(const CTab &t, uint64_t fwd, int k, bool one_strand, uint32_t c0, uint32_t n_here,
+                                      uint32_t out[CPP]) {
+    const uint64_t rc = rc_kmer(fwd, k);
+    const uint64_t first = (one_strand && rc < fwd) ? rc : fwd;
+    const uint8_t *a = ctab_find(t, first);
+    const uint8_t *b = (a && one_strand) ? nullptr : ctab_find(t, first == fwd ? rc : fwd);
+#pragma unroll
+    for (int j = 0; j < CPP; ++j) {
+        uint32_t v = MISSING;
+        if ((uint32_t)j < n_here) {
+            if (a) v = *reinterpret_cast<const uint32_t *>(a + 8 + 4 * (c0 + j));
+            if (v == MISSING && b) v = *reinterpret_cast<const uint32_t *>(b + 8 + 4 * (c0 + j));
+        }
+        out[j] = v;
+    }
+}
+
+// K-TABLE-C: one thread per record of colour `colour`
+__global__ void k_ctab_build(uint8_t *base, uint64_t mask, uint32_t shift, const uint64_t *__restrict__ kmers,
+                             const uint32_t *__restrict__ counts, uint64_t n, uint64_t min_count, uint64_t max_count, uint32_t colour) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        const uint32_t c = counts[i];
+        if (c < min_count || c > max_count) continue;  // not retrievable (kmc_file.cpp:1459)
+        const uint64_t key = kmers[i];
+        uint64_t s = mix64(key) & mask;
+        for (;;) {
+            uint8_t *slot = base + (s << shift);
+            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), EMPTY_KEY, key);
+            if (old == EMPTY_KEY || old == key) {
+                *reinterpret_cast<uint32_t *>(slot + 8 + 4 * colour) = c;
+                break;
+            }
+            s = (s + 1) & mask;
+        }
+    }
+}
+
+// is some k-mer a key in both orientations (whatever the colours)?  one thread per slot
+__global__ void k_ctab_two_strands(const uint8_t *base, uint64_t cap, uint32_t shift, int k, unsigned int *flag) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    CTab t{base, cap - 1, shift};
+    for (; i < cap; i += stride) {
+        const uint8_t *s = ctab_slot(t, i);
+        const uint64_t key = *reinterpret_cast<const uint64_t *>(s);
+        if (key == EMPTY_KEY) continue;
+        const uint64_t r = rc_kmer(key, k);
+        if (r == key) continue;
+        if (ctab_find(t, r)) atomicOr(flag, 1u);
+    }
+}
+
+// K-COV-C: one wavefront per unitig, lanes over its k-mers, CPP colours per pass.
+// out_*[c * n + (u - u0)], n = u1 - u0.
+__global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                     const uint32_t *__restrict__ len, int k, bool one_strand, uint32_t n_colors,
+                                                     uint32_t u0, uint32_t u1, uint64_t *__restrict__ out_sum,
+                                                     uint32_t *__restrict__ out_min, uint32_t *__restrict__ out_max,
+                                                     uint8_t *__restrict__ out_miss) {
+    const int lane = lane_id();
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
+    const uint32_t n = u1 - u0;
+    for (uint32_t u = u0 + wave; u < u1; u += n_waves) {
+        const uint64_t *w = seq + off[u];
+        const uint32_t nk = len[u] - k + 1;
+        for (uint32_t c0 = 0; c0 < n_colors; c0 += CPP) {
+            const uint32_t n_here = min((uint32_t)CPP, n_colors - c0);
+            uint64_t sum[CPP];
+            uint32_t mn[CPP], mx[CPP];
+            bool miss[CPP];
+#pragma unroll
+            for (int j = 0; j < CPP; ++j) { sum[j] = 0; mn[j] = MISSING; mx[j] = 0; miss[j] = false; }
+            for (uint32_t p = lane; p < nk; p += WAVE) {
+                uint32_t cnt[CPP];
+                colored_counts(t, kmer_at(w, p, k), k, one_strand, c0, n_here, cnt);
+#pragma unroll
+                for (int j = 0; j < CPP; ++j) {
+                    if (cnt[j] == MISSING) { miss[j] = true; continue; }
+                    sum[j] += cnt[j];
+                    mn[j] = cnt[j] < mn[j] ? cnt[j] : mn[j];
+                    mx[j] = cnt[j] > mx[j] ? cnt[j] : mx[j];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < CPP; ++j) {
+                if ((uint32_t)j >= n_here) break;
+                const uint64_t s = wave_sum_u64(sum[j]);
+                const uint32_t lo = wave_min_u32(mn[j]);
+                const uint32_t hi = ~wave_min_u32(~mx[j]);
+                const bool any_miss = __ballot(miss[j]) != 0;
+                if (lane == 0) {
+                    const size_t o = (size_t)(c0 + j) * n + (u - u0);
+                    out_sum[o] = s;
+                    out_min[o] = lo;
+                    out_max[o] = hi;
+                    out_miss[o] = any_miss;
+                }
+            }
+        }
+    }
+}
+
+// K-STRCOV-C: one thread per (string, colour); out_*[i * n_colors + c]
+__global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colors, const char *__restrict__ text,
+                                 const uint64_t *__restrict__ str_off, uint32_t n_str, const uint32_t *__restrict__ low,
+                                 const uint32_t *__restrict__ up, uint64_t *__restrict__ out_sum, uint8_t *__restrict__ out_ok) {
+    uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint64_t total = (uint64_t)n_str * n_colors;
+    for (; id < total; id += stride) {
+        const uint32_t i = (uint32_t)(id / n_colors), c = (uint32_t)(id % n_colors);
+        const char *s = text + str_off[i];
+        const uint32_t L = (uint32_t)(str_off[i + 1] - str_off[i]);
+        const uint32_t lo = low[c], hi = up[c];
+        uint64_t sum = 0, x = 0;
+        uint8_t ok = 1;
+        for (uint32_t j = 0; j < L; ++j) {
+            const char ch = s[j];
+            const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+            x = ((x << 2) | b) & kmask;
+            if (j + 1 >= (uint32_t)k) {
+                uint32_t cnt[CPP];
+                colored_counts(t, x, k, one_strand, c, 1, cnt);
+                // a missing k-mer and a count outside (low, up) both give (0, false): CCDBG.cpp:105-117
+                if (cnt[0] != MISSING && cnt[0] > lo && cnt[0] < hi) sum += cnt[0];
+                else { sum = 0; ok = 0; break; }
+            }
+        }
+        out_sum[id] = sum;
+        out_ok[id] = ok;
+    }
+}
+
+template <typename T>
+bool on_device(const T *p) {
+    hipPointerAttribute_t at;
+    const bool dev = p && hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice;
+    (void)hipGetLastError();
+    return dev;
+}
+
+}  // namespace
+
+extern "C" {
+
+uint32_t pf_num_colors(const pf_ctx *ctx) { return ctx ? ctx->n_colors : 0; }
+
+int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *const *kmers, const uint32_t *const *counts,
+                             const uint64_t *n, const uint64_t *min_count, const uint64_t *max_count, const int *both_strands) {
+    if (!ctx || n_colors == 0 || !kmers || !counts || !n || !min_count || !max_count || !both_strands) return PF_ERR_ARG;
+    if (n_colors > PF_MAX_COLORS) { ctx->err = "more colours than the device table holds (PF_MAX_COLORS)"; return PF_ERR_ARG; }
+    uint64_t total = 0, biggest = 0;
+    for (uint32_t c = 0; c < n_colors; ++c) {
+        if (!both_strands[c]) {
+            ctx->err = "databases built without canonical counting (GetBothStrands() == false) are not supported";
+            return PF_ERR_ARG;
+        }
+        if (n[c] && (!kmers[c] || !counts[c])) return PF_ERR_ARG;
+        total += n[c];
+        biggest = std::max(biggest, n[c]);
+    }
+    PF_HIP(hipSetDevice(ctx->device));
+    if (ctx->d_ctab) { (void)hipFree(ctx->d_ctab); ctx->d_ctab = nullptr; }
+    ctx->n_colors = 0;
+    // distinct keys <= total: a capacity above 1.25 * total always leaves empty slots; colours that share most
+    // k-mers (samples of one species) end at a load factor near max(n) / cap <= 0.5
+    uint64_t cap = 1024;
+    while (cap < 2 * biggest || cap < total + total / 4 + 1) cap <<= 1;
+    uint32_t shift = 4;
+    while ((1u << shift) < 8 + 4 * n_colors) ++shift;
+    PF_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_ctab), cap << shift));
+    PF_HIP(hipMemsetAsync(ctx->d_ctab, 0xFF, cap << shift, ctx->stream));  // EMPTY_KEY keys, MISSING counts
+    ctx->ctab_cap = cap;
+    ctx->ctab_shift = shift;
+    for (uint32_t c = 0; c < n_colors; ++c) {
+        if (!n[c]) continue;
+        DevTmp<uint64_t> dk_;
+        DevTmp<uint32_t> dc_;
+        const uint64_t *pk = kmers[c];
+        const uint32_t *pc = counts[c];
+        if (!on_device(kmers[c])) {
+            PF_HIP(dk_.alloc(n[c] * 8));
+            PF_HIP(dc_.alloc(n[c] * 4));
+            PF_HIP(hipMemcpyAsync(dk_.p, kmers[c], n[c] * 8, hipMemcpyDefault, ctx->stream));
+            PF_HIP(hipMemcpyAsync(dc_.p, counts[c], n[c] * 4, hipMemcpyDefault, ctx->stream));
+            pk = dk_.p;
+            pc = dc_.p;
+        }
+        ctx_begin(ctx, PF_K_TABLE_BUILD);
+        k_ctab_build<<<ctx_grid(ctx, n[c], 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap - 1, shift, pk, pc, n[c], min_count[c],
+                                                                           max_count[c], c);
+        ctx_end(ctx);
+        PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffers die at the end of this iteration
+    }
+    {
+        DevTmp<unsigned int> flag_;
+        unsigned int h_flag = 0;
+        PF_HIP(flag_.alloc(4));
+        PF_HIP(hipMemsetAsync(flag_.p, 0, 4, ctx->stream));
+        if (total && ctx->k)
+            k_ctab_two_strands<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap, shift, ctx->k, flag_.p);
+        PF_HIP(hipMemcpyAsync(&h_flag, flag_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+        ctx->ctab_one_strand = (total && ctx->k) ? h_flag == 0 : false;
+    }
+    ctx->n_colors = n_colors;
+    return PF_OK;
+}
+
+int pf_unitig_cov_colored(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint32_t *mx, uint8_t *miss) {
+    if (!ctx || !ctx->d_seq || !ctx->d_ctab || !ctx->n_colors || u0 > u1 || u1 > ctx->N || !sum || !mn || !mx || !miss) return PF_ERR_ARG;
+    if (u0 == u1) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    const size_t n = (size_t)(u1 - u0) * ctx->n_colors;
+    const bool dev_out = on_device(sum);
+    uint64_t *ds = sum;
+    uint32_t *dlo = mn, *dhi = mx;
+    uint8_t *dx = miss;
+    if (!dev_out) {
+        ds = (uint64_t *)ctx_ws(ctx, WS_CCOV_SUM, n * 8);
+        dlo = (uint32_t *)ctx_ws(ctx, WS_CCOV_MIN, n * 4);
+        dhi = (uint32_t *)ctx_ws(ctx, WS_CCOV_MAX, n * 4);
+        dx = (uint8_t *)ctx_ws(ctx, WS_CCOV_MISS, n);
+        if (!ds || !dlo || !dhi || !dx) return PF_ERR_HIP;
+    }
+    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
+    const int grid = ctx_grid(ctx, (uint64_t)(u1 - u0) * 64, 256, 16);
+    ctx_begin(ctx, PF_K_COV_COLORED);
+    k_cov_colored<<<grid, 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand, ctx->n_colors, u0, u1,
+                                                 ds, dlo, dhi, dx);
+    ctx_end(ctx);
+    if (!dev_out) {
+        PF_HIP(hipMemcpyAsync(sum, ds, n * 8, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipMemcpyAsync(mn, dlo, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipMemcpyAsync(mx, dhi, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipMemcpyAsync(miss, dx, n, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return PF_OK;
+}
+
+int pf_string_cov_colored(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32_t n_str, const uint32_t *low,
+                          const uint32_t *up, uint64_t *sum, uint8_t *ok) {
+    if (!ctx || !ctx->d_ctab || !ctx->n_colors || !low || !up || (n_str && (!text || !str_off || !sum || !ok))) return PF_ERR_ARG;
+    if (n_str == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    const uint32_t C = ctx->n_colors;
+    uint64_t total = 0;
+    PF_HIP(hipMemcpy(&total, str_off + n_str, 8, hipMemcpyDefault));
+    char *dt = (char *)ctx_ws(ctx, WS_STR_TEXT, (size_t)total + 1);
+    uint64_t *doff = (uint64_t *)ctx_ws(ctx, WS_STR_OFF, ((size_t)n_str + 1) * 8);
+    uint64_t *ds = (uint64_t *)ctx_ws(ctx, WS_STR_SUM, (size_t)n_str * C * 8);
+    uint8_t *dk = (uint8_t *)ctx_ws(ctx, WS_STR_OK, (size_t)n_str * C);
+    uint32_t *dcut = (uint32_t *)ctx_ws(ctx, WS_STR_MISS, (size_t)C * 8);
+    if (!dt || !doff || !ds || !dk || !dcut) return PF_ERR_HIP;
+    PF_HIP(hipMemcpyAsync(dt, text, (size_t)total, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(doff, str_off, ((size_t)n_str + 1) * 8, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(dcut, low, (size_t)C * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(dcut + C, up, (size_t)C * 4, hipMemcpyDefault, ctx->stream));
+    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
+    ctx_begin(ctx, PF_K_STRCOV_COLORED);
+    k_strcov_colored<<<ctx_grid(ctx, (uint64_t)n_str * C, 256, 8), 256, 0, ctx->stream>>>(t, ctx->k, ctx->ctab_one_strand, C, dt, doff, n_str,
+                                                                                          dcut, dcut + C, ds, dk);
+    ctx_end(ctx);
+    PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n_str * C * 8, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(ok, dk, (size_t)n_str * C, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    return PF_OK;
+}
+
+}  // extern "C"

@@ -51,6 +51,13 @@ struct pf_ctx {
     uint64_t tab_cap = 0, tab_n = 0;
     bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked at upload)
 
+    // colored path: the count databases of all colours in one table, slot = { u64 key, u32 count[n_colors] }
+    // padded to 1 << ctab_shift bytes (pf_colored.hip)
+    uint8_t *d_ctab = nullptr;
+    uint64_t ctab_cap = 0;
+    uint32_t ctab_shift = 4, n_colors = 0;
+    bool ctab_one_strand = false;
+
     // reusable result staging for host-pointer callers
     uint64_t *d_cov_sum = nullptr;
     uint32_t *d_cov_min = nullptr;
@@ -77,6 +84,6 @@ enum WsSlot {
     WS_ALN_OGAPS, WS_ALN_STTEXT, WS_ALN_STGAPS, WS_ALN_STHITS, WS_ALN_WORK, WS_BFS_REC, WS_BFS_POOL, WS_BFS_SMALL, WS_BFS_DEF,
     WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS,
     WS_BUB_TEXT, WS_BUB_PATHS, WS_BUB_TASKS, WS_BUB_SMALL, WS_BUB_RETRY, WS_BUB_IDX, WS_BUB_RES, WS_BUB_OTEXT, WS_BUB_OSITES,
-    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_COUNT_
+    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_COUNT_
 };
 }  // namespace pf

@@ -392,7 +392,7 @@ namespace pf {
 
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
-                                                "k_bubble_big"};
+                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored"};
 
 int ctx_begin(pf_ctx *ctx, int kernel) {
     if (!ctx->timing) return 0;
@@ -503,6 +503,7 @@ void pf_destroy(pf_ctx *ctx) {
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
     free_graph(ctx);
     hipFree(ctx->d_tab);
+    hipFree(ctx->d_ctab);
     hipFree(ctx->d_cov_sum); hipFree(ctx->d_cov_min); hipFree(ctx->d_cov_miss);
     for (auto &w : ctx->ws) hipFree(w.first);
     hipStreamDestroy(ctx->own_stream);

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_hip.so")
 NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
-           "k_strcov", "k_bubble", "k_bubble_big"]
+           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
@@ -85,6 +85,10 @@ def load_library() -> C.CDLL:
         "pf_device_name": (i, [vp, C.c_char_p, C.c_size_t]),
         "pf_table_capacity": (u64, [vp]),
         "pf_num_kmers": (u64, [vp]),
+        "pf_upload_counts_colored": (i, [vp, u32, vp, vp, vp, vp, vp, vp]),
+        "pf_num_colors": (u32, [vp]),
+        "pf_unitig_cov_colored": (i, [vp, u32, u32, vp, vp, vp, vp]),
+        "pf_string_cov_colored": (i, [vp, vp, vp, u32, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = header / library mismatch
@@ -97,7 +101,8 @@ def load_library() -> C.CDLL:
 DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
                     "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
-                    "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers"]
+                    "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
+                    "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored"]
 
 
 def pack_unitigs(seqs: list[bytes]):
@@ -213,6 +218,45 @@ class Device:
         f = np.zeros(n, dtype=np.uint8)
         self._check(self.L.pf_lookup_kmers(self.h, _ptr(np.ascontiguousarray(kmers, dtype=np.uint64)), n, _ptr(c), _ptr(f)))
         return c, f
+
+    def upload_counts_colored(self, dbs, min_count=1, max_count=0xFFFFFFFF):
+        """dbs: list of (kmers u64, counts u32) per colour -> one joined table (pf_upload_counts_colored)."""
+        nc = len(dbs)
+        self.n_colors = nc
+        km = [np.ascontiguousarray(k, dtype=np.uint64) for k, _ in dbs]
+        ct = [np.ascontiguousarray(c, dtype=np.uint32) for _, c in dbs]
+        pk = (C.c_void_p * nc)(*[a.ctypes.data for a in km])
+        pc = (C.c_void_p * nc)(*[a.ctypes.data for a in ct])
+        n = np.array([len(a) for a in km], dtype=np.uint64)
+        mn = np.full(nc, min_count, dtype=np.uint64)
+        mx = np.full(nc, max_count, dtype=np.uint64)
+        both = np.ones(nc, dtype=np.int32)
+        self._check(self.L.pf_upload_counts_colored(self.h, nc, pk, pc, n.ctypes.data, mn.ctypes.data, mx.ctypes.data, both.ctypes.data))
+
+    def unitig_cov_colored(self, u0=0, u1=None):
+        """(sum, min, max, miss), each [n_colors, u1 - u0]"""
+        u1 = self.n if u1 is None else u1
+        shape = (self.n_colors, u1 - u0)
+        s = np.zeros(shape, dtype=np.uint64)
+        lo = np.zeros(shape, dtype=np.uint32)
+        hi = np.zeros(shape, dtype=np.uint32)
+        x = np.zeros(shape, dtype=np.uint8)
+        self._check(self.L.pf_unitig_cov_colored(self.h, u0, u1, _ptr(s), _ptr(lo), _ptr(hi), _ptr(x)))
+        return s, lo, hi, x
+
+    def string_cov_colored(self, strings: list[bytes], low, up):
+        """(sum, ok), each [n_strings, n_colors]; low / up: one cutoff per colour"""
+        n = len(strings)
+        off = np.zeros(n + 1, dtype=np.uint64)
+        np.cumsum([len(s) for s in strings], out=off[1:])
+        text = np.frombuffer(b"".join(strings) + b"\0", dtype=np.uint8).copy()
+        lo = np.ascontiguousarray(low, dtype=np.uint32)
+        hi = np.ascontiguousarray(up, dtype=np.uint32)
+        s = np.zeros((n, self.n_colors), dtype=np.uint64)
+        ok = np.zeros((n, self.n_colors), dtype=np.uint8)
+        self._check(self.L.pf_string_cov_colored(self.h, text.ctypes.data, off.ctypes.data, n, lo.ctypes.data, hi.ctypes.data,
+                                                 s.ctypes.data, ok.ctypes.data))
+        return s, ok
 
     # ---- kernels
     def unitig_cov(self, u0=0, u1=None, out=None):

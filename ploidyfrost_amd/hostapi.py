@@ -24,6 +24,7 @@ class Times(C.Structure):
 _lib = None
 DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_unitig_id",
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
+                    "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
                     "pfh_colors_unitig", "pfh_bifrost_kmer_hash"]
 
@@ -54,6 +55,11 @@ def load_library() -> C.CDLL:
     L.pfh_state.argtypes = [vp, vp, vp, vp]
     L.pfh_last_allele_frequency.restype = C.c_void_p
     L.pfh_last_allele_frequency.argtypes = [vp, C.POINTER(C.c_uint64)]
+    L.pfh_open_colored.restype = vp
+    L.pfh_open_colored.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_uint32, C.c_double, C.c_double, C.c_double, C.c_uint32, C.c_int]
+    L.pfh_num_colors.restype = C.c_uint32
+    L.pfh_num_colors.argtypes = [vp]
+    L.pfh_ploidy_estimation_colored.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.c_uint32]
     L.pfh_colors_open.restype = vp
     L.pfh_colors_open.argtypes = [C.c_char_p, C.c_char_p, C.c_uint32]
     L.pfh_colors_close.argtypes = [vp]
@@ -171,3 +177,25 @@ class Run:
         m = np.empty(n, dtype=np.uint32)
         self.L.pfh_state(self.h, f.ctypes.data, p.ctypes.data, m.ctypes.data)
         return f, p, m
+
+
+class ColoredRun(Run):
+    """ColoredCDBG::read + CCDBG::CCDBG (reference src/Main.cpp:775-795): graph, colour sets, and the count
+    databases of all colours joined in one HBM table."""
+
+    def __init__(self, gfa: str, colors: str, db_prefixes: list[str], workdir: str, z: int = 8, M: float = 2.0, D: float = -1.0,
+                 G: float = -3.0, threads: int = 1, device: int = 0):
+        self.L = load_library()
+        lst = os.path.join(workdir, "kmc_databases.txt")
+        with open(lst, "w") as f:
+            f.write("".join(p + "\n" for p in db_prefixes))
+        self.h = self.L.pfh_open_colored(gfa.encode(), colors.encode(), lst.encode(), z, M, D, G, threads, device)
+        if not self.h:
+            raise RuntimeError("ploidyfrost host layer: " + self.L.pfh_last_error(None).decode())
+        self.n_colors = self.L.pfh_num_colors(self.h)
+
+    def ploidy_estimation(self, outpre: str, cutoffs):
+        """cutoffs: one (lower, upper) per colour, the reference's -C file"""
+        lo = (C.c_int * self.n_colors)(*[int(c[0]) for c in cutoffs])
+        up = (C.c_int * self.n_colors)(*[int(c[1]) for c in cutoffs])
+        self._check(self.L.pfh_ploidy_estimation_colored(self.h, outpre.encode(), lo, up, len(cutoffs)))
