@@ -62,6 +62,74 @@ def make_inputs(workdir: str, name: str, genome_len: int, seed: int, device, k: 
     return gfa, db, n_unitigs, len(g["kmers"])
 
 
+def make_colored_inputs(workdir: str, name: str, genome_len: int, seed: int, device, k: int = K, samples: int = 3, ploidy: int = 2,
+                        max_ins: int = 6):
+    """BASELINE.json configs[3]: `samples` samples of `ploidy` haplotypes each on one base genome -> colored compacted dBG
+    (GFA with DA tags + .bfg_colors written by ploidyfrost_amd.bfg_colors) + one KMC1 database per sample.  Samples
+    after the first lose a few bases at both ends (inside the variant-free flanks, so the graph is unchanged) and the
+    first and last unitig carry those colours on part of their k-mers only.
+    Returns (gfa, colors, [db prefixes], n_unitigs, n_kmers)."""
+    from ploidyfrost_amd import bfg_colors, cdbg_build, synth
+    t0 = time.time()
+    spec = synth.HapSpec(genome_len=genome_len, ploidy=samples * ploidy, seed=seed, gap_lo=GAP_LO, gap_hi=GAP_HI, p_multi=0.03,
+                         max_ins=max_ins)
+    haps = synth.make_haplotypes(spec)
+    groups = []
+    for s_ in range(samples):
+        hs = haps[s_ * ploidy: (s_ + 1) * ploidy]
+        if s_:
+            hs = [h[9 * s_ + 3 * i: len(h) - 7 * s_ - 2 * i] for i, h in enumerate(hs)]
+        groups.append(hs)
+    g = cdbg_build.build_cdbg(haps, k, device)
+    off = np.asarray(g["off"], dtype=np.int64)
+    codes = np.asarray(g["codes"], dtype=np.uint8)
+    n_unitigs = len(off) - 1
+    sizes = np.diff(off)
+    km_per = sizes - k + 1
+    # canonical k-mer of every (unitig, position): all windows of the concatenated text minus those spanning a boundary
+    fw, rc = synth.kmers_u64(codes, k)
+    start = np.repeat(off[:-1], km_per) + (np.arange(int(km_per.sum())) - np.repeat(np.cumsum(km_per) - km_per, km_per))
+    # the colour set of a unitig is placed by the hash of its head k-mer as the graph stores it: k-length unitigs are
+    # kept canonical (bifrost/src/CompactedDBG.tcc:3945-3954)
+    head_fw, head_rc = fw[off[:-1]], rc[off[:-1]]
+    heads = bfg_colors.left_align(np.where(sizes == k, np.minimum(head_fw, head_rc), head_fw), k)
+    can = np.minimum(fw[start], rc[start])
+    del fw, rc, start
+    first = np.cumsum(km_per) - km_per
+    full_mask = np.zeros(n_unitigs, dtype=np.uint64)
+    present = []
+    dbs = []
+    for s_, hs in enumerate(groups):
+        km_s, mult_s = synth.canonical_counts(hs, k)
+        db = os.path.join(workdir, "%s_kmc%d" % (name, s_))
+        synth.write_kmc1(db, km_s, synth.synth_counts(km_s, mult_s), k)
+        dbs.append(db)
+        idx = np.searchsorted(km_s, can)
+        idx[idx >= len(km_s)] = len(km_s) - 1
+        has = km_s[idx] == can
+        cnt = np.add.reduceat(has.astype(np.int64), first)
+        full_mask |= (cnt == km_per).astype(np.uint64) << np.uint64(s_)
+        present.append((has, cnt))
+    partial_ids = {}
+    part = np.zeros(n_unitigs, dtype=bool)
+    for has, cnt in present:
+        part |= (cnt > 0) & (cnt < km_per)
+    for u in np.nonzero(part)[0]:
+        ids = []
+        for s_, (has, cnt) in enumerate(present):
+            row = has[first[u]: first[u] + km_per[u]]
+            ids.extend(int(s_ * km_per[u] + p) for p in np.nonzero(row)[0])
+        partial_ids[int(u)] = ids
+    colors = os.path.join(workdir, name + ".bfg_colors")
+    da = bfg_colors.write_bfg_colors(colors, heads, sizes, k, ["sample%d" % s_ for s_ in range(samples)], full_mask=full_mask,
+                                     partial_ids=partial_ids)
+    gfa = os.path.join(workdir, name + ".gfa")
+    cdbg_build.write_gfa(gfa, g, da_tags=da)
+    log("colored inputs %s: genome %d bp, %d samples x%d -> %d unitigs, %d k-mers, %d unitigs with a partial colour (%.1fs)" %
+        (name, genome_len, samples, ploidy, n_unitigs, len(g["kmers"]), len(partial_ids), time.time() - t0))
+    return gfa, colors, dbs, n_unitigs, len(g["kmers"])
+
+
 def cpu_baseline(workdir: str, target_unitigs: int, device):
     """The reference (oracle/_ref/PloidyFrost -t 1) -- or, where that binary is absent, the oracle
     restatement -- on a bounded sample of the same workload, timed on this host's CPU."""

@@ -206,11 +206,12 @@ def pair_ids(n_kmers: int, full_colors, partial: dict | None = None) -> list[int
 
 
 def write_bfg_colors(path: str, heads: np.ndarray, sizes_bp: np.ndarray, k: int, names: list[str], sets: list[bytes] | None = None, *,
-                     full_mask: np.ndarray | None = None, nb_seeds: int = 31, seed: int = 12345, overflow_every: int = 0,
+                     full_mask: np.ndarray | None = None, partial_ids: dict | None = None, nb_seeds: int = 31, seed: int = 12345, overflow_every: int = 0,
                      slack: float = 1.0) -> np.ndarray:
     """Write the colour file of a graph whose unitig u has head k-mer ``heads[u]`` (Bifrost layout, see
     ``left_align``) and ``sizes_bp[u]`` bases.  Colour sets come either encoded (``sets[u]`` from ``encode_set``) or, for
-    large graphs, as ``full_mask[u]`` (bit c = colour c on every k-mer; encoded with the natural encoding).
+    large graphs, as ``full_mask[u]`` (bit c = colour c on every k-mer; encoded with the natural encoding) plus
+    ``partial_ids[u]`` = the complete sorted id list of the few unitigs that carry a colour on part of their k-mers.
     Returns the ``DA:Z:`` tag of every unitig (0 = overflow table) for the GFA segment lines."""
     n = len(heads)
     heads = heads.astype(np.uint64)
@@ -251,7 +252,11 @@ def write_bfg_colors(path: str, heads: np.ndarray, sizes_bp: np.ndarray, k: int,
         km = (sizes_bp - np.uint64(k) + np.uint64(1)).astype(np.int64)
         cache = {}
 
+        partial_ids = partial_ids or {}
+
         def natural(u):
+            if u in partial_ids:
+                return encode_set(partial_ids[u], "auto")
             key = (int(km[u]), int(full_mask[u]))
             b = cache.get(key)
             if b is None:

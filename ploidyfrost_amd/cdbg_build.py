@@ -120,8 +120,9 @@ def build_cdbg(haps: list[np.ndarray], k: int, device=None) -> dict:
                 mult=mult.cpu().numpy(), k=k)
 
 
-def write_gfa(path: str, g: dict, min_len_tag: int = 17) -> int:
-    """Bifrost-style GFA 1.0: header with KL/ML tags, one S line per unitig."""
+def write_gfa(path: str, g: dict, min_len_tag: int = 17, da_tags=None) -> int:
+    """Bifrost-style GFA 1.0: header with KL/ML tags, one S line per unitig (with its ``DA:Z:`` colour-set tag when
+    ``da_tags`` is given, as ``Bifrost build -c`` writes them)."""
     lut = np.frombuffer(b"ACGT", dtype=np.uint8)
     text = lut[g["codes"]].tobytes()
     off = g["off"]
@@ -130,7 +131,10 @@ def write_gfa(path: str, g: dict, min_len_tag: int = 17) -> int:
         f.write(b"H\tVN:Z:1.0\tBV:Z:1.0.6\tKL:Z:%d\tML:Z:%d\n" % (g["k"], min_len_tag))
         chunk = []
         for u in range(n):
-            chunk.append(b"S\t%d\t%s\n" % (u + 1, text[off[u] : off[u + 1]]))
+            if da_tags is None:
+                chunk.append(b"S\t%d\t%s\n" % (u + 1, text[off[u] : off[u + 1]]))
+            else:
+                chunk.append(b"S\t%d\t%s\tDA:Z:%d\n" % (u + 1, text[off[u] : off[u + 1]], da_tags[u]))
             if len(chunk) >= 65536:
                 f.write(b"".join(chunk))
                 chunk = []
