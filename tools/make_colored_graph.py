@@ -17,8 +17,7 @@ ploidy = int(sys.argv[6]) if len(sys.argv) > 6 else 2
 os.makedirs(out, exist_ok=True)
 import torch
 dev = "cuda" if torch.cuda.is_available() else "cpu"
-# unitigs per bp grows with the number of haplotypes: calibrated on the tetraploid bench graph
-genome = int(target / bench.UNITIGS_PER_BP * 4 / (samples * ploidy))
+genome = int(target / bench.UNITIGS_PER_BP)  # measured: 3 x 2 haplotypes give the tetraploid bench graph's density
 gfa, colors, dbs, n, nk = bench.make_colored_inputs(out, "g", genome, seed, dev, k=k, samples=samples, ploidy=ploidy)
 with open(os.path.join(out, "dbs.txt"), "w") as f:
     f.write("".join(d + "\n" for d in dbs))
