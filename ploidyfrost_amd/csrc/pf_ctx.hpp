@@ -40,6 +40,11 @@ struct pf_ctx {
     uint32_t N = 0;
     int k = 0;
     uint64_t n_words = 0, n_kmers = 0;
+    // k-mer numbering for the k-mer-parallel coverage kernels: d_kpre[u] = k-mers of unitigs < u (N + 1 entries),
+    // d_kwin[w] = the unitig holding global k-mer 256 * w
+    uint64_t *d_kpre = nullptr;
+    uint32_t *d_kwin = nullptr;
+    uint64_t n_kwin = 0;
     uint32_t *d_succ = nullptr, *d_pred = nullptr;  // [2N][4]
     uint32_t *d_pred16 = nullptr;                   // [2N][4][4] two-hop rows, built on first use by the huge BFS tier
     bool has_adj = false;

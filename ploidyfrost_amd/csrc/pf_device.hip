@@ -166,38 +166,94 @@ __global__ void k_mark_candidates(const uint32_t *__restrict__ succ, uint32_t n_
     }
 }
 
-// K-COV: one wavefront per unitig, lanes over its k-mers (64 per pass).
-// Launch: 256 threads = 4 waves per block, grid-stride over [u0, u1).
-__global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_t mask, const uint64_t *__restrict__ seq,
-                                             const uint64_t *__restrict__ off, const uint32_t *__restrict__ len, int k,
-                                             bool one_strand, uint32_t u0, uint32_t u1, uint64_t *__restrict__ out_sum,
-                                             uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
+// K-COV: k-mer-parallel.  Global k-mer g (unitigs laid end to end) belongs to unitig u with kpre[u] <= g < kpre[u+1].
+// A wavefront takes a window of 256 consecutive k-mers, four per lane (lane, lane + 64, ...), so that every lane
+// keeps four table probes in flight -- the kernel is bound by the latency of dependent random accesses, not by
+// bytes -- and the work per wave does not depend on unitig lengths.  The window's slice of the prefix array sits in
+// LDS; each lane finds its unitig by binary search there.  Per-unitig sum / min / missing are combined with a
+// segmented wave scan (lanes of one unitig are contiguous) and one atomic per (window row, unitig) into outputs
+// initialised by k_cov_init (sum 0, min 10000 as src/CDBG.cpp:71, missing 0).
+constexpr int KCOV_PER_LANE = 4;
+constexpr int KCOV_WIN = WAVE * KCOV_PER_LANE;  // 256, also the granularity of pf_ctx::d_kwin
+
+__global__ void k_cov_init(uint32_t n, uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t stride = gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { out_sum[i] = 0; out_min[i] = 10000; out_miss[i] = 0; }
+}
+
+__global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_t mask, int k, const uint64_t *__restrict__ seq,
+                                             const uint64_t *__restrict__ off, const uint64_t *__restrict__ kpre, const uint32_t *__restrict__ kwin, uint32_t N,
+                                             bool one_strand, uint32_t u0, uint64_t g_begin, uint64_t g_end, uint64_t w_begin,
+                                             uint64_t n_win, uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min,
+                                             uint8_t *__restrict__ out_miss) {
+    __shared__ uint64_t s_pre[4][KCOV_WIN + 2];
     const int lane = lane_id();
-    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
-    const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
-    for (uint32_t u = u0 + wave; u < u1; u += n_waves) {
-        const uint64_t *w = seq + off[u];
-        const uint32_t nk = len[u] - k + 1;
-        uint64_t sum = 0;
-        uint32_t mn = 10000;  // src/CDBG.cpp:71
-        bool miss = false;
-        for (uint32_t p = lane; p < nk; p += WAVE) {
-            uint32_t c;
-            if (canonical_count(t, mask, kmer_at(w, p, k), k, c, one_strand)) {
-                sum += c;
-                mn = c < mn ? c : mn;
-            } else {
-                miss = true;
+    const int wi = threadIdx.x >> 6;
+    uint64_t *P = s_pre[wi];
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
+        const uint64_t w = w_begin + wx;
+        const uint64_t g0 = w * KCOV_WIN;
+        const uint32_t ub = kwin[w];
+        // P[x] = kpre[ub + x], x = 0..256: the window cannot reach beyond unitig ub + 256
+        for (int x = lane; x <= KCOV_WIN; x += WAVE) {
+            const uint64_t ux = (uint64_t)ub + x;
+            P[x] = kpre[ux < N ? ux : N];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");  // lanes read what other lanes of the wave wrote
+        __builtin_amdgcn_wave_barrier();
+        CountProbe pr[KCOV_PER_LANE];
+        uint32_t uu[KCOV_PER_LANE];
+        bool act[KCOV_PER_LANE];
+#pragma unroll
+        for (int j = 0; j < KCOV_PER_LANE; ++j) {
+            const uint64_t g = g0 + (uint64_t)j * WAVE + lane;
+            act[j] = g >= g_begin && g < g_end;
+            uu[j] = NONE;
+            if (act[j]) {
+                int lo = 0, hi = KCOV_WIN;  // largest x with P[x] <= g (P[0] <= g0 by construction)
+                while (lo < hi) {
+                    const int mid = (lo + hi + 1) >> 1;
+                    if (P[mid] <= g) lo = mid; else hi = mid - 1;
+                }
+                uu[j] = ub + (uint32_t)lo;
+                count_probe(t, mask, kmer_at(seq + off[uu[j]], (uint32_t)(g - P[lo]), k), k, one_strand, pr[j]);
             }
         }
-        sum = wave_sum_u64(sum);
-        mn = wave_min_u32(mn);
-        const bool any_miss = __ballot(miss) != 0;
-        if (lane == 0) {
-            out_sum[u - u0] = sum;
-            out_min[u - u0] = mn;
-            out_miss[u - u0] = any_miss;
+#pragma unroll
+        for (int j = 0; j < KCOV_PER_LANE; ++j) {
+            uint64_t sum = 0;
+            uint32_t mn = 0xFFFFFFFFu;
+            uint32_t miss = 0;
+            if (act[j]) {
+                uint32_t c;
+                if (count_finish(t, mask, pr[j], c)) { sum = c; mn = c; }
+                else miss = 1;
+            }
+            // segmented inclusive scan over lanes of the same unitig (contiguous runs, inactive lanes carry NONE)
+            const uint32_t u = uu[j];
+#pragma unroll
+            for (int o = 1; o < WAVE; o <<= 1) {
+                const uint32_t uo = __shfl_up(u, o, WAVE);
+                const uint32_t slo = __shfl_up((uint32_t)sum, o, WAVE), shi = __shfl_up((uint32_t)(sum >> 32), o, WAVE);
+                const uint32_t mo = __shfl_up(mn, o, WAVE), xo = __shfl_up(miss, o, WAVE);
+                if (lane >= o && uo == u) {
+                    sum += ((uint64_t)shi << 32) | slo;
+                    mn = mo < mn ? mo : mn;
+                    miss |= xo;
+                }
+            }
+            const uint32_t un = __shfl_down(u, 1, WAVE);
+            if (u != NONE && (lane == WAVE - 1 || un != u)) {  // last lane of its unitig in this row
+                const uint32_t o = u - u0;
+                atomicAdd(reinterpret_cast<unsigned long long *>(out_sum + o), (unsigned long long)sum);
+                if (mn != 0xFFFFFFFFu) atomicMin(out_min + o, mn);
+                if (miss) out_miss[o] = 1;
+            }
         }
+        __builtin_amdgcn_wave_barrier();  // P is rewritten by the next window
     }
 }
 
@@ -489,6 +545,10 @@ static void free_graph(pf_ctx *ctx) {
     hipFree(ctx->d_seq); hipFree(ctx->d_off); hipFree(ctx->d_len); hipFree(ctx->d_succ); hipFree(ctx->d_pred);
     hipFree(ctx->d_cand);
     hipFree(ctx->d_pred16);
+    hipFree(ctx->d_kpre);
+    hipFree(ctx->d_kwin);
+    ctx->d_kpre = nullptr;
+    ctx->d_kwin = nullptr;
     ctx->d_pred16 = nullptr;
     ctx->d_seq = ctx->d_off = nullptr;
     ctx->d_len = ctx->d_succ = ctx->d_pred = ctx->d_cand = nullptr;
@@ -611,6 +671,25 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         nk += hl[u] - k + 1;
     }
     ctx->n_kmers = nk;
+    // k-mer numbering for the k-mer-parallel kernels
+    {
+        std::vector<uint64_t> kpre((size_t)N + 1);
+        const uint64_t n_win = nk / 256 + 1;
+        std::vector<uint32_t> kwin(n_win);
+        uint64_t g = 0, w = 0;
+        for (uint32_t u = 0; u < N; ++u) {
+            kpre[u] = g;
+            g += hl[u] - k + 1;
+            for (; w < n_win && w * 256 < g; ++w) kwin[w] = u;
+        }
+        kpre[N] = g;
+        for (; w < n_win; ++w) kwin[w] = N - 1;
+        PF_HIP(hipMalloc(&ctx->d_kpre, ((size_t)N + 1) * 8));
+        PF_HIP(hipMalloc(&ctx->d_kwin, n_win * 4));
+        PF_HIP(hipMemcpy(ctx->d_kpre, kpre.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
+        PF_HIP(hipMemcpy(ctx->d_kwin, kwin.data(), n_win * 4, hipMemcpyHostToDevice));
+        ctx->n_kwin = n_win;
+    }
     return PF_OK;
 }
 
@@ -765,11 +844,17 @@ int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t
         }
         ds = ctx->d_cov_sum; dm = ctx->d_cov_min; dx = ctx->d_cov_miss;
     }
-    // one wave per unitig, 4 waves per block; enough blocks to keep every CU at 8 waves/SIMD
-    const int grid = ctx_grid(ctx, (uint64_t)n * 64, 256, 16);
+    // 256 k-mers per wavefront, 4 wavefronts per block
+    uint64_t g_range[2];
+    PF_HIP(hipMemcpyAsync(&g_range[0], ctx->d_kpre + u0, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipMemcpyAsync(&g_range[1], ctx->d_kpre + u1, 8, hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    const uint64_t w_begin = g_range[0] / KCOV_WIN, w_end = (g_range[1] + KCOV_WIN - 1) / KCOV_WIN;
     ctx_begin(ctx, PF_K_COV);
-    k_cov<<<grid, 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k,
-                                         ctx->tab_one_strand, u0, u1, ds, dm, dx);
+    k_cov_init<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(n, ds, dm, dx);
+    k_cov<<<ctx_grid(ctx, (w_end - w_begin) * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
+                                                                                 ctx->d_kwin, ctx->N, ctx->tab_one_strand, u0, g_range[0],
+                                                                                 g_range[1], w_begin, w_end - w_begin, ds, dm, dx);
     ctx_end(ctx);
     if (!dev_out) {
         PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));

@@ -81,6 +81,32 @@ __device__ inline bool canonical_count(const Slot *__restrict__ t, uint64_t mask
     return table_find(t, mask, first == fwd ? rc : fwd, cnt);
 }
 
+// The same lookup split in two so that a lane can keep several k-mers in flight: count_probe() issues the first
+// 16-B probe of the form that is tried first, count_finish() consumes it and walks on only if it has to.
+struct CountProbe {
+    uint64_t first, second;
+    Slot s;
+};
+__device__ inline void count_probe(const Slot *__restrict__ t, uint64_t mask, uint64_t fwd, int k, bool one_strand, CountProbe &p) {
+    const uint64_t rc = rc_kmer(fwd, k);
+    p.first = (one_strand && rc < fwd) ? rc : fwd;
+    p.second = p.first == fwd ? rc : fwd;
+    p.s = load_slot(t, mix64(p.first) & mask);
+}
+__device__ inline bool count_finish(const Slot *__restrict__ t, uint64_t mask, const CountProbe &p, uint32_t &cnt) {
+    if (p.s.key == p.first) { cnt = p.s.val; return true; }
+    if (p.s.key != EMPTY_KEY) {  // occupied by another key: continue the linear probe behind it
+        uint64_t i = (mix64(p.first) + 1) & mask;
+        for (;;) {
+            const Slot s = load_slot(t, i);
+            if (s.key == p.first) { cnt = s.val; return true; }
+            if (s.key == EMPTY_KEY) break;
+            i = (i + 1) & mask;
+        }
+    }
+    return table_find(t, mask, p.second, cnt);
+}
+
 __device__ inline uint64_t wave_sum_u64(uint64_t v) {
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {

@@ -257,3 +257,39 @@ def test_bfs_big_tier_matches_oracle(tmp_path, depth, limit):
             assert np.array_equal(lst, e["seen"])
         big += len(e["seen"]) > limit
     assert big >= 2  # the whole lattice from either end
+
+
+@pytest.mark.parametrize("k", [5, 9, 25, 31])
+def test_count_table_low_complexity_and_both_orientations(k):
+    """The count table is laid out by strand-symmetric minimizers and the minimizer's position in the key: k-mers
+    in which the minimizer m-mer repeats (homopolymers, tandem repeats, palindromic halves) must be found from
+    either orientation, and every k-mer of a heavy minimizer (thousands of k-mers sharing one bucket) too."""
+    rng = np.random.default_rng(k)
+    base = rng.integers(0, 4, size=3000, dtype=np.uint8)
+    parts = [base]
+    for unit in ([0], [0, 1], [0, 1, 2], [3, 0], [0, 0, 3, 3], [1, 2]):
+        parts.append(np.array((unit * 64)[:64], dtype=np.uint8))
+        parts.append(rng.integers(0, 4, size=40, dtype=np.uint8))
+    half = rng.integers(0, 4, size=20, dtype=np.uint8)
+    parts.append(np.concatenate([half, (3 - half)[::-1]]))            # reverse-complement palindrome
+    # one m-mer followed by many different continuations: a crowded bucket that spills into its neighbours
+    core = rng.integers(0, 4, size=13, dtype=np.uint8)
+    for _ in range(300):
+        parts.append(np.concatenate([rng.integers(0, 4, size=20, dtype=np.uint8), core, rng.integers(0, 4, size=20, dtype=np.uint8)]))
+    seq = np.concatenate(parts)
+    fw, rc = synth.kmers_u64(seq, k)
+    can, idx = np.unique(np.minimum(fw, rc), return_index=True)
+    counts = (np.arange(len(can), dtype=np.uint32) % 60000) + 1
+    dev = hipapi.Device(0)
+    dev.upload_graph(*hipapi.pack_unitigs([synth.BASES[seq].tobytes()]), k)
+    dev.upload_counts(can, counts, 1, 65535, True)
+    want = counts[np.searchsorted(can, np.minimum(fw, rc))]
+    for q in (fw, rc):
+        c, f = dev.lookup(q)
+        assert f.all() and np.array_equal(c, want)
+    absent = np.setdiff1d(rng.integers(0, 1 << (2 * k), size=2000, dtype=np.uint64), np.concatenate([fw, rc]))
+    c, f = dev.lookup(absent)
+    assert not f.any()
+    s, m, miss, st = dev.unitig_cov()
+    assert st == 0 and int(s[0]) == int(want.astype(np.uint64).sum()) and int(m[0]) == int(want.min())
+    dev.close()
