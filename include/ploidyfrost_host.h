@@ -74,6 +74,10 @@ const char *pfh_colors_name(const pfh_colors *, uint32_t colour);
  * (UnitigColors::contains, ColorSet.cpp:776); returns UnitigColors::size(um) (ColorSet.cpp:898);
  * *n_full_enc = colours the file stores in the {full colours, rest} pair form, 0 otherwise */
 uint64_t pfh_colors_unitig(const pfh_colors *, uint32_t u, uint8_t *presence, uint32_t *n_kmers, uint32_t *n_full_enc);
+/* Known limit of the reproduced unitig numbering: the number of k-length unitigs of the GFA
+ * file that Bifrost certainly files as "abundant" k-mers (hash-ordered, numbered last; CompactedDBG.tcc:4013-4021)
+ * because more than 15 of them share a minimizer.  0 = ids are the reference's.  UINT64_MAX = unreadable file. */
+uint64_t pfh_gfa_abundant_suspects(const char *gfa_path);
 /* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);
 

@@ -178,6 +178,16 @@ uint64_t pfh_colors_unitig(const pfh_colors *c, uint32_t u, uint8_t *presence, u
             for (uint32_t i = 0; i < km; ++i) presence[(size_t)ci * km + i] = c->sets.contains(u, ci, i, 1);
     return c->sets.size_total[u];
 }
+uint64_t pfh_gfa_abundant_suspects(const char *gfa_path) {
+    try {
+        pfh::UnitigSet g;
+        if (!g.load_gfa(gfa_path, g_open_err)) return ~0ull;
+        return g.abundant_suspects;
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return ~0ull;
+    }
+}
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed) { return pfh::bifrost_kmer_hash(left_aligned_kmer, seed); }
 
 }  // extern "C"

@@ -60,6 +60,8 @@ void UnitigSet::append_mapped(uint32_t ov, std::string &dst) const {
     }
 }
 
+static uint64_t count_abundant_suspects(const UnitigSet &g);
+
 bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
     Mapped f;
     if (!f.open(path)) { err = "cannot open " + path; return false; }
@@ -157,7 +159,68 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
         for (const Seg &s : shorts) da_tag.push_back(s.da);
     }
     pack();
+    abundant_suspects = count_abundant_suspects(*this);
     return true;
+}
+
+namespace {
+// Bifrost's minimizer hash of a g-mer (bifrost/src/RepHash.hpp:28-95): two rolling words, one per strand, combined
+// strand-symmetrically through wyhash (final version 3, 16-byte key)
+const uint64_t kHvals[4] = {2053695854357871005ULL, 5073395517033431291ULL, 10060236952204337488ULL, 7783083932390163561ULL};
+inline uint64_t rotl1(uint64_t x) { return (x << 1) | (x >> 63); }
+inline uint64_t wymix64(uint64_t a, uint64_t b) {
+    __uint128_t r = (__uint128_t)a * b;
+    return (uint64_t)r ^ (uint64_t)(r >> 64);
+}
+uint64_t rephash(const char *s, int g) {
+    uint64_t h = 0, ht = 0;
+    for (int i = 0; i < g; ++i) {
+        h = rotl1(h) ^ kHvals[((unsigned char)s[i] & 6) >> 1];
+        ht = rotl1(ht) ^ kHvals[(((unsigned char)s[g - 1 - i] ^ 4) & 6) >> 1];
+    }
+    const uint64_t lo = h < ht ? h : ht, hi = h < ht ? ht : h;
+    // wyhash of the 16 bytes {lo, hi}, seed 0
+    const uint64_t wyp0 = 0xa0761d6478bd642full, wyp1 = 0xe7037ed1a0b428dbull;
+    const uint64_t a = ((lo & 0xFFFFFFFFull) << 32) | (hi & 0xFFFFFFFFull);
+    const uint64_t b = ((hi >> 32) << 32) | (lo >> 32);
+    return wymix64(wyp1 ^ 16, wymix64(a ^ wyp1, b ^ wyp0));
+}
+}  // namespace
+
+// k-length unitigs that Bifrost certainly files as abundant k-mers: more than 15 of them share a minimizer
+// (the bucket of a minimizer gains one entry per k-length unitig, bifrost/src/CompactedDBG.tcc:4011-4031; entries
+// of longer unitigs only add to it, so this is a lower bound)
+static uint64_t count_abundant_suspects(const UnitigSet &g) {
+    const int k = g.k, gl = g.g;
+    if (gl < 1 || gl > k - 2 || gl > 31 || g.n_short < 16) return 0;
+    std::vector<uint64_t> mins;
+    mins.reserve(g.n_short);
+    for (uint32_t u = g.n() - (uint32_t)g.n_short; u < g.n(); ++u) {
+        const char *s = g.text.data() + g.off[u];
+        // minHashIterator with nh = true: the minimizer may not start at offset 0 or k-g (minHashIterator.hpp:232-262)
+        uint64_t best = ~0ull;
+        int at = 1;
+        for (int j = 1; j + gl <= k - 1; ++j) {
+            const uint64_t h = rephash(s + j, gl);
+            if (h < best) { best = h; at = j; }
+        }
+        uint64_t fw = 0, rc = 0;
+        for (int i = 0; i < gl; ++i) {
+            const uint64_t c = (uint64_t)code_of(s[at + i]);
+            fw = (fw << 2) | c;
+            rc |= (3 - c) << (2 * i);
+        }
+        mins.push_back(fw < rc ? fw : rc);
+    }
+    std::sort(mins.begin(), mins.end());
+    uint64_t suspects = 0;
+    for (size_t i = 0; i < mins.size();) {
+        size_t j = i;
+        while (j < mins.size() && mins[j] == mins[i]) ++j;
+        if (j - i > 15) suspects += (j - i) - 15;
+        i = j;
+    }
+    return suspects;
 }
 
 void UnitigSet::from_sequences(const std::vector<std::string> &seqs, int k_) {

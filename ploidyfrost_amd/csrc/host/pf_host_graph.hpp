@@ -27,6 +27,11 @@ struct UnitigSet {
     // Bifrost's per-segment "DA:Z:<n>" tag (which hash seed places the unitig's colour set,
     // bifrost/src/ColoredCDBG.tcc:496-533); -1 where a segment has none.  Empty when no segment has one.
     std::vector<int16_t> da_tag;
+    // Known limit of the id order reproduced here: Bifrost moves a k-length unitig into a hash table
+    // of "abundant" k-mers, iterated last and in hash order, when its minimizer's bucket already holds >= 15 entries
+    // (bifrost/src/CompactedDBG.tcc:4013-4021).  load_gfa counts the k-length unitigs for which that certainly
+    // happens (more than 15 of them share a minimizer); 0 on every graph whose ids are guaranteed to match.
+    uint64_t abundant_suspects = 0;
 
     uint32_t n() const { return (uint32_t)len_bp.size(); }
     std::string_view seq(uint32_t u) const { return std::string_view(text.data() + off[u], len_bp[u]); }

@@ -160,6 +160,11 @@ int main(int argc, char **argv) {
             exit(EXIT_FAILURE);
         }
         cout << "ColoredCDBG::read(): Graph loading successful" << endl;
+        if (cdbg.graph.abundant_suspects)
+            cerr << "Warning: " << cdbg.graph.abundant_suspects << " k-length unitigs share a minimizer with more than 15 others: Bifrost keeps such "
+                 << "k-mers in a hash table and numbers them last, in hash order; unitig ids (and the row order of the outputs) may differ "
+                 << "from the reference's for this graph." << endl;
+
         cout << "CCDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
         if (cdbg.getNbColors() != kmc_db_num) {
             cerr << "CCDBG::CCDBG():Error: " << kmc_db_num << " kmc databases listed for " << cdbg.getNbColors() << " colors" << endl;
@@ -198,6 +203,11 @@ int main(int argc, char **argv) {
         exit(EXIT_FAILURE);
     }
     cout << "CompactedDBG::read(): Graph loading successful" << endl;
+    if (graph.abundant_suspects)
+        cerr << "Warning: " << graph.abundant_suspects << " k-length unitigs share a minimizer with more than 15 others: Bifrost keeps such "
+             << "k-mers in a hash table and numbers them last, in hash order; unitig ids (and the row order of the outputs) may differ "
+             << "from the reference's for this graph." << endl;
+
     cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
 
     pfh::CDBG g(graph, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db);

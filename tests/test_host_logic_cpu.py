@@ -124,3 +124,77 @@ def test_kmc2_layout_roundtrip_and_signature_lookup(tmp_path):
             assert o.L.pfo_kmer_count(o.h, s, C.byref(got)) == 1 and got.value == c
             assert o.L.pfo_kmer_count(o.h, rc(s), C.byref(got)) == 1 and got.value == c
         assert o.L.pfo_kmer_count(o.h, b"A" * k, C.byref(got)) == 0
+
+
+# ---- the one known limit of the reproduced unitig numbering: Bifrost's "abundant" k-mers ----------------------
+def _rephash(s: bytes) -> int:
+    """Bifrost's minimizer hash (bifrost/src/RepHash.hpp) restated for building the test graph."""
+    M = (1 << 64) - 1
+    hv = [2053695854357871005, 5073395517033431291, 10060236952204337488, 7783083932390163561]
+    g, h, ht = len(s), 0, 0
+    for i in range(g):
+        h = (((h << 1) | (h >> 63)) & M) ^ hv[(s[i] & 6) >> 1]
+        ht = (((ht << 1) | (ht >> 63)) & M) ^ hv[((s[g - 1 - i] ^ 4) & 6) >> 1]
+    lo, hi = min(h, ht), max(h, ht)
+    a = ((lo & 0xFFFFFFFF) << 32) | (hi & 0xFFFFFFFF)
+    b = ((hi >> 32) << 32) | (lo >> 32)
+
+    def mix(x, y):
+        r = (x & M) * (y & M)
+        return (r & M) ^ (r >> 64)
+    return mix(0xE7037ED1A0B428DB ^ 16, mix(a ^ 0xE7037ED1A0B428DB, b ^ 0xA0761D6478BD642F))
+
+
+def _graph_with_a_crowded_minimizer(tmp_path, n_sharing):
+    k, g = 25, 17
+    rng = np.random.default_rng(2)
+    rnd = lambda n: synth.BASES[rng.integers(0, 4, size=n, dtype=np.uint8)].tobytes()  # noqa: E731
+    core = min((rnd(g) for _ in range(4000)), key=_rephash)      # a g-mer that wins the minimizer race in its k-mers
+    seqs = [rnd(60) for _ in range(5)]
+    for i in range(n_sharing):
+        off = 1 + i % 7                                          # minimizers may not start at offset 0 or k-g
+        seqs.append(rnd(off) + core + rnd(k - g - off))
+    seqs += [rnd(25) for _ in range(10)]
+    gfa = str(tmp_path / "g.gfa")
+    with open(gfa, "wb") as f:
+        f.write(b"H\tVN:Z:1.0\tBV:Z:1.0.6\tKL:Z:%d\tML:Z:%d\n" % (k, g))
+        for i, s in enumerate(seqs):
+            f.write(b"S\t%d\t%s\n" % (i + 1, s))
+    return gfa, seqs, k
+
+
+def test_abundant_kmer_suspects_are_counted(tmp_path):
+    from ploidyfrost_amd import hostapi
+    L = hostapi.load_library()
+    gfa, _, _ = _graph_with_a_crowded_minimizer(tmp_path, 60)
+    assert L.pfh_gfa_abundant_suspects(gfa.encode()) == 60 - 15
+    (tmp_path / "few").mkdir()
+    gfa2, _, _ = _graph_with_a_crowded_minimizer(tmp_path / "few", 15)
+    assert L.pfh_gfa_abundant_suspects(gfa2.encode()) == 0
+    for case in ("dip20k", "weird12k", "col4_mix"):
+        assert L.pfh_gfa_abundant_suspects(load_case(case)["gfa"].encode()) == 0
+
+
+def test_abundant_kmer_count_agrees_with_the_reference(tmp_path):
+    """Where the reference binary exists: it numbers exactly the first 15 sharers in file order and moves the others
+    to the end -- the count reported by the product is the number of displaced unitigs."""
+    import subprocess
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    if not os.path.exists(pyoracle.REF_BIN):
+        pytest.skip("reference binary (oracle/_ref) not built here")
+    from ploidyfrost_amd import hostapi
+    gfa, seqs, k = _graph_with_a_crowded_minimizer(tmp_path, 40)
+    inv = {65: 0, 67: 1, 71: 2, 84: 3}
+    km, mult = synth.canonical_counts([np.array([inv[c] for c in s], dtype=np.uint8) for s in seqs], k)
+    synth.write_kmc1(str(tmp_path / "db"), km, synth.synth_counts(km, mult), k)
+    # (the reference may die after setUnitigId on this bubble-free graph -- it divides by the number of sites, 0 here)
+    subprocess.run([pyoracle.REF_BIN, "-g", gfa, "-d", str(tmp_path / "db"), "-o", "x", "-t", "1"], cwd=tmp_path,
+                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    ref = [line.split("\t")[1].strip() for line in open(tmp_path / "PloidyFrost_output" / "x_Unitig_Id.txt")]
+    mine = [s.decode() for s in pyoracle.Oracle(gfa, str(tmp_path / "db")).sequences()]
+    assert sorted(ref) == sorted(mine)
+    moved = hostapi.load_library().pfh_gfa_abundant_suspects(gfa.encode())
+    assert moved == 25
+    assert ref[: 5 + 15] == mine[: 5 + 15]                       # long unitigs and the first 15 sharers keep their rank
+    assert set(ref[-moved:]) == set(mine[5 + 15: 5 + 40])       # the others are numbered last (in hash order)
