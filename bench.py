@@ -223,6 +223,9 @@ def main():
         run = hostapi.Run(gfa, db, z=Z, device=gpu_index)
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
         run.set_threads(host_threads)
+        run.set_overlap_output(True)  # super_bubble.txt is written while PloidyEstimation runs; complete when it returns
+        if os.environ.get("PF_BATCH_BUBBLES"):  # experiments: bubbles per batch of the align/format pipeline
+            run.set_batch_bubbles(int(os.environ["PF_BATCH_BUBBLES"]))
         run.set_output_dir(os.path.join(workdir, "PloidyFrost_output"))
         run.set_unitig_id("b")
         log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, time.time() - t0, torch.cuda.get_device_name(gpu_index)))

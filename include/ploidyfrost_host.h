@@ -36,6 +36,9 @@ void pfh_set_output_dir(pfh_run *, const char *dir); /* default ./PloidyFrost_ou
 void pfh_set_write_files(pfh_run *, int on);         /* 0: format everything, write nothing */
 void pfh_set_threads(pfh_run *, uint32_t threads);   /* host threads for the per-bubble phases (the reference's -t);
                                                          output order is always the -t 1 one */
+void pfh_set_overlap_output(pfh_run *, int on);      /* 1: <outpre>_super_bubble.txt is written in the background and is complete
+                                                         when pfh_ploidy_estimation (or pfh_close) returns; default 0 */
+void pfh_set_batch_bubbles(pfh_run *, uint64_t n);   /* bubbles per batch of the align/format pipeline (default 65536) */
 int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);
 int pfh_ploidy_estimation(pfh_run *, const char *outpre, int lower, int upper);

@@ -11,7 +11,10 @@
 #include <cstdio>
 #include <cstring>
 #include <ctime>
+#include <condition_variable>
+#include <mutex>
 #include <set>
+#include <thread>
 #include <stdexcept>
 
 #include "pf_parallel.hpp"
@@ -102,8 +105,20 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     init_device(device);
 }
 
+int CDBG::join_pending_write() {
+    if (pending_write_.joinable()) {
+        pending_write_.join();
+        std::vector<std::string>().swap(pending_pieces_);
+        if (pending_rc_) { pending_rc_ = 0; return fail(PF_ERR_ARG, "CDBG:: Open super_bubble file error"); }
+    }
+    return 0;
+}
+
 CDBG::~CDBG() {
+    join_pending_write();
     bx_.release_all();  // pinned buffers go before the context
+    ax_[0].release_all();
+    ax_[1].release_all();
     pf_destroy(ctx_);
 }
 
@@ -317,6 +332,7 @@ bool CDBG::colours_allow(const pf_bfs_record &r, const uint32_t *list) {
 // ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
 int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thr) {
     if (status_) return status_;
+    if (join_pending_write()) return status_;
     if (!quiet_) printf("%s::findSuperBubble(): Finding superbubbles\n", tag_);
     if (write_files_ && ensure_dir()) return status_;
     const auto t_all = clk::now();
@@ -407,7 +423,20 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     const uint64_t nb = row_base[n_uch];
     n_super_bubble_ = nb;
     times_.bubbles_out = nb;
-    {
+    if (overlap_output_ && write_files_) {
+        // written behind the caller's back while PloidyEstimation starts; joined there (or by the next use of the file)
+        join_pending_write();
+        pending_pieces_ = std::move(pieces);
+        uint64_t bytes = 0;
+        for (const std::string &pc : pending_pieces_) bytes += pc.size();
+        out_bytes_ += bytes;
+        pending_write_ = std::thread([this, name = outpre + "_super_bubble.txt"] {
+            std::vector<const std::string *> ptrs;
+            for (const std::string &pc : pending_pieces_) ptrs.push_back(&pc);
+            uint64_t b = 0;
+            pending_rc_ = write_pieces(name, ptrs, b);
+        });
+    } else {
         std::vector<std::pair<std::string, std::vector<const std::string *>>> files(1);
         files[0].first = outpre + "_super_bubble.txt";
         for (auto &pc : pieces) files[0].second.push_back(&pc);
@@ -784,31 +813,67 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     }
     times_.scan_s += since(t0);
 
-    const size_t CHUNK = 1u << 19;  // bubbles per batch
+    const size_t CHUNK = std::max<size_t>(batch_bubbles_, 1);  // bubbles per batch
     constexpr size_t PCH = 256;     // bubbles per parallel work item
     struct ChunkOut {
         std::string s_var, allfre, fre[4], cov[4];
         uint64_t allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
     };
     std::vector<std::vector<ChunkOut>> all_outs;  // per batch, per work item: concatenated at the end
-    for (size_t batch0 = 0; batch0 < all_tasks.size(); batch0 += CHUNK) {
-        t0 = clk::now();
-        const Task *tasks = all_tasks.data() + batch0;
-        const size_t NT_ = std::min(CHUNK, all_tasks.size() - batch0);
-        const size_t NT = NT_;
+    struct PathChunk {
+        std::vector<pf_bubble_path> paths;  // text_off relative to this chunk's text
+        std::vector<uint32_t> count;        // paths per bubble
+        std::string text;
+        // colored: the oriented unitigs the walks of each branching bubble visit (findUnitig of the site strings)
+        std::vector<uint32_t> walk_ovs, walk_first;
+    };
+    // The bubbles are processed in batches through a two-stage software pipeline: while stage 1 (its own host thread:
+    // path strings, K-BUBBLE, site strings, K-STRCOV -- every device call of this phase, a pf_ctx is not re-entrant)
+    // works on batch b+1, the calling thread turns batch b into text (stage 2: formatting).  Two sets of pinned
+    // exchange buffers go round.  Batches are consumed in order, so var_count and the output order are those of one
+    // sequential pass.
+    struct GroupRef { uint32_t first, count; };           // range of chunk-local string indices
+    struct TaskSites {
+        uint32_t group_first = 0;                          // index into the chunk's `groups`
+    };
+    struct SiteChunk {
+        std::vector<std::string> strings;
+        std::vector<GroupRef> groups;      // per (branching bubble, site, allele group), in order
+        std::vector<uint32_t> first_group;  // per bubble of the chunk: index of its first GroupRef
+        std::vector<uint64_t> mask;         // colored, per string: colours its findUnitig() mapping carries in full
+        int err = 0;
+    };
+    struct Batch {
+        size_t batch0 = 0, NT = 0;
+        std::vector<SiteChunk> schunks;
+        std::vector<uint64_t> chunk_base, str_sum, str_len;
+        std::vector<uint8_t> str_ok;
+        uint64_t site_strings = 0;
+        double sites_s = 0;
+        AlignExchange *ax = nullptr;
+        std::vector<PathChunk> pchunks;
+        std::vector<uint32_t> dev_index;
+        uint32_t n_dev = 0;
+        double tasks_s = 0, align_s = 0;
+        int st = PF_OK;
+        std::string err;
+    };
+    static const pf_bubble_result kNoResult = {0, 0, 0, 0, 0, 0, 0, 0};
+    // stage 1 of a batch (its own thread): path strings, SeqAlign on the device, site strings and their coverage
+    auto produce = [&](Batch &B) -> int {
+        auto t0 = clk::now();
+        AlignExchange &X = *B.ax;
+        const Task *tasks = all_tasks.data() + B.batch0;
+        const size_t NT = B.NT;
         const size_t n_pch = n_chunks_of(NT, PCH);
-        times_.tasks += NT;
+        std::vector<PathChunk> &pchunks = B.pchunks;
+        std::vector<uint32_t> &dev_index = B.dev_index;
+        uint32_t &n_dev = B.n_dev;
+        int st = PF_OK;
 
         // ---- paths: oriented inner unitigs are decoded on the device; the s->t walks of the branching
         //      bubbles are enumerated here (two-stack DFS of src/CDBG.cpp:1364-1412) ---------------
-        struct PathChunk {
-            std::vector<pf_bubble_path> paths;  // text_off relative to this chunk's text
-            std::vector<uint32_t> count;        // paths per bubble
-            std::string text;
-            // colored: the oriented unitigs the walks of each branching bubble visit (findUnitig of the site strings)
-            std::vector<uint32_t> walk_ovs, walk_first;
-        };
-        std::vector<PathChunk> pchunks(n_pch);
+        pchunks.assign(n_pch, PathChunk());
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
             PathChunk &pc = pchunks[ci];
             std::vector<uint32_t> major, minor;
@@ -871,18 +936,18 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             text_base[c + 1] = text_base[c] + pchunks[c].text.size();
             path_base[c + 1] = path_base[c] + pchunks[c].paths.size();
         }
-        bx_.text.ensure(ctx_, text_base[n_pch] + 1);
-        bx_.paths.ensure(ctx_, path_base[n_pch] + 1);
-        bx_.tasks.ensure(ctx_, NT);
-        std::vector<uint32_t> dev_index(NT, NONE);  // bubble -> index in the device batch
-        uint32_t n_dev = 0;
+        X.text.ensure(ctx_, text_base[n_pch] + 1);
+        X.paths.ensure(ctx_, path_base[n_pch] + 1);
+        X.tasks.ensure(ctx_, NT);
+        dev_index.assign(NT, NONE);  // bubble -> index in the device batch
+        n_dev = 0;
         {
             size_t ti = 0;
             for (size_t c = 0; c < n_pch; ++c) {
                 uint64_t pf = path_base[c];
                 for (uint32_t cnt : pchunks[c].count) {
                     if (cnt >= 2) {
-                        bx_.tasks.p[n_dev] = pf_bubble_task{pf, cnt, 0};
+                        X.tasks.p[n_dev] = pf_bubble_task{pf, cnt, 0};
                         dev_index[ti] = n_dev++;
                     }
                     pf += cnt;
@@ -892,8 +957,8 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         }
         parallel_chunks(n_pch, 1, T, [&](size_t c, size_t, size_t) {
             PathChunk &pc = pchunks[c];
-            if (!pc.text.empty()) memcpy(bx_.text.p + text_base[c], pc.text.data(), pc.text.size());
-            pf_bubble_path *dst = bx_.paths.p + path_base[c];
+            if (!pc.text.empty()) memcpy(X.text.p + text_base[c], pc.text.data(), pc.text.size());
+            pf_bubble_path *dst = X.paths.p + path_base[c];
             for (size_t i = 0; i < pc.paths.size(); ++i) {
                 dst[i] = pc.paths[i];
                 if (dst[i].ov == NONE) dst[i].text_off += text_base[c];
@@ -901,56 +966,44 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             PathChunk().text.swap(pc.text);
             std::vector<pf_bubble_path>().swap(pc.paths);
         });
-        times_.tasks_s += since(t0);
+        B.tasks_s = since(t0);
 
         // ---- align: SeqAlign::SequenceAlignment of every bubble, one wavefront each ------------------
         t0 = clk::now();
-        bx_.res.ensure(ctx_, std::max<uint32_t>(n_dev, 1));
-        uint64_t cap_text = std::max<uint64_t>(bx_.otext.cap, (text_base[n_pch] + 128ull * n_dev) * 2 + 4096);
-        uint64_t cap_sites = std::max<uint64_t>(bx_.osites.cap, 4ull * n_dev + 64);
-        uint64_t cap_groups = std::max<uint64_t>(bx_.ogroups.cap, 16ull * n_dev + 64);
-        uint64_t cap_ilen = std::max<uint64_t>(bx_.oilen.cap, 2ull * n_dev + 64);
+        X.res.ensure(ctx_, std::max<uint32_t>(n_dev, 1));
+        uint64_t cap_text = std::max<uint64_t>(X.otext.cap, (text_base[n_pch] + 128ull * n_dev) * 2 + 4096);
+        uint64_t cap_sites = std::max<uint64_t>(X.osites.cap, 4ull * n_dev + 64);
+        uint64_t cap_groups = std::max<uint64_t>(X.ogroups.cap, 16ull * n_dev + 64);
+        uint64_t cap_ilen = std::max<uint64_t>(X.oilen.cap, 2ull * n_dev + 64);
         for (;;) {
-            bx_.otext.ensure(ctx_, cap_text);
-            bx_.osites.ensure(ctx_, cap_sites);
-            bx_.ogroups.ensure(ctx_, cap_groups);
-            bx_.oilen.ensure(ctx_, cap_ilen);
+            X.otext.ensure(ctx_, cap_text);
+            X.osites.ensure(ctx_, cap_sites);
+            X.ogroups.ensure(ctx_, cap_groups);
+            X.oilen.ensure(ctx_, cap_ilen);
             uint64_t used[4];
-            st = pf_align_bubbles(ctx_, bx_.text.p, text_base[n_pch], bx_.paths.p, path_base[n_pch], bx_.tasks.p, n_dev, sc_.match,
-                                  sc_.mismatch, sc_.gap, bx_.res.p, bx_.otext.p, bx_.otext.cap, bx_.osites.p, bx_.osites.cap,
-                                  bx_.ogroups.p, bx_.ogroups.cap, bx_.oilen.p, bx_.oilen.cap, used);
-            if (st == PF_ERR_OVERFLOW && (used[0] > bx_.otext.cap || used[1] > bx_.osites.cap || used[2] > bx_.ogroups.cap ||
-                                          used[3] > bx_.oilen.cap)) {
-                cap_text = std::max<uint64_t>(bx_.otext.cap, used[0] + used[0] / 8);
-                cap_sites = std::max<uint64_t>(bx_.osites.cap, used[1] + used[1] / 8);
-                cap_groups = std::max<uint64_t>(bx_.ogroups.cap, used[2] + used[2] / 8);
-                cap_ilen = std::max<uint64_t>(bx_.oilen.cap, used[3] + used[3] / 8);
+            st = pf_align_bubbles(ctx_, X.text.p, text_base[n_pch], X.paths.p, path_base[n_pch], X.tasks.p, n_dev, sc_.match,
+                                  sc_.mismatch, sc_.gap, X.res.p, X.otext.p, X.otext.cap, X.osites.p, X.osites.cap,
+                                  X.ogroups.p, X.ogroups.cap, X.oilen.p, X.oilen.cap, used);
+            if (st == PF_ERR_OVERFLOW && (used[0] > X.otext.cap || used[1] > X.osites.cap || used[2] > X.ogroups.cap ||
+                                          used[3] > X.oilen.cap)) {
+                cap_text = std::max<uint64_t>(X.otext.cap, used[0] + used[0] / 8);
+                cap_sites = std::max<uint64_t>(X.osites.cap, used[1] + used[1] / 8);
+                cap_groups = std::max<uint64_t>(X.ogroups.cap, used[2] + used[2] / 8);
+                cap_ilen = std::max<uint64_t>(X.oilen.cap, used[3] + used[3] / 8);
                 continue;
             }
             break;
         }
-        if (st != PF_OK) return fail(st, std::string("CDBG::PloidyEstimation(): alignment: ") + pf_last_error(ctx_));
-        times_.align_jobs += n_dev;
-        times_.align_s += since(t0);
-        static const pf_bubble_result kNoResult = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (st != PF_OK) { B.err = std::string(tag_) + "::PloidyEstimation(): alignment: " + pf_last_error(ctx_); return st; }
+        B.align_s = since(t0);
         auto result_of = [&](size_t ti) -> const pf_bubble_result & {
-            return dev_index[ti] == NONE ? kNoResult : bx_.res.p[dev_index[ti]];
+            return dev_index[ti] == NONE ? kNoResult : X.res.p[dev_index[ti]];
         };
 
         // ---- sites: strings of the branching bubbles (src/CDBG.cpp:1448-1600) -> one C2 batch ----
         t0 = clk::now();
-        struct GroupRef { uint32_t first, count; };           // range of chunk-local string indices
-        struct TaskSites {
-            uint32_t group_first = 0;                          // index into the chunk's `groups`
-        };
-        struct SiteChunk {
-            std::vector<std::string> strings;
-            std::vector<GroupRef> groups;      // per (branching bubble, site, allele group), in order
-            std::vector<uint32_t> first_group;  // per bubble of the chunk: index of its first GroupRef
-            std::vector<uint64_t> mask;         // colored, per string: colours its findUnitig() mapping carries in full
-            int err = 0;
-        };
-        std::vector<SiteChunk> schunks(n_pch);
+        std::vector<SiteChunk> &schunks = B.schunks;
+        schunks.assign(n_pch, SiteChunk());
         // cdbg.findUnitig(s, 0, len) of src/CCDBG.cpp:3251, 3390 followed by UnitigColors::contains on that mapping: the
         // first k-mer of a site string lies on one of the bubble's unitigs (each k-mer occurs once in the graph); the
         // mapping is extended along that unitig while the characters agree (CompactedDBG.tcc:3815-3837,
@@ -1001,7 +1054,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 const pf_bubble_result &r = result_of(ti);
                 if (r.n_rows == 0 || tasks[ti].strict) continue;
                 const size_t R = r.n_rows, L = r.n_cols;
-                const char *rows = bx_.otext.p + r.rows_off;
+                const char *rows = X.otext.p + r.rows_off;
                 auto row_at = [&](size_t p, size_t x) -> char {  // std::string::at of the reference: out of range is fatal
                     if (x >= L) { sc.err = 1; return 'A'; }
                     return rows[p * L + x];
@@ -1020,8 +1073,8 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 at.assign(R, 0);
                 uint32_t indel = 0;
                 for (uint32_t si = 0; si < r.n_sites && !sc.err; ++si) {
-                    const pf_bubble_site &sr = bx_.osites.p[r.site_off + si];
-                    const uint8_t *grp = bx_.ogroups.p + r.group_off + (uint64_t)si * R;
+                    const pf_bubble_site &sr = X.osites.p[r.site_off + si];
+                    const uint8_t *grp = X.ogroups.p + r.group_off + (uint64_t)si * R;
                     const uint32_t site = sr.col;
                     for (auto &x : kstr) x.clear();
                     if (sr.is_indel) {
@@ -1091,14 +1144,19 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             }
         });
         for (auto &scx : schunks) {
-            if (scx.err == 2) return fail(PF_ERR_ARG, "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble");
-            if (scx.err) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): site string outside an aligned row");
+            if (scx.err == 2) { B.err = "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble"; return PF_ERR_ARG; }
+            if (scx.err) { B.err = "CDBG::PloidyEstimation(): site string outside an aligned row"; return PF_ERR_ARG; }
         }
-        std::vector<uint64_t> chunk_base(n_pch + 1, 0);
+        std::vector<uint64_t> &chunk_base = B.chunk_base;
+        chunk_base.assign(n_pch + 1, 0);
         for (size_t c = 0; c < n_pch; ++c) chunk_base[c + 1] = chunk_base[c] + schunks[c].strings.size();
         const size_t n_strings = chunk_base[n_pch];
-        std::vector<uint64_t> str_sum(n_strings * C), str_len(n_strings);  // colored: [string][colour]
-        std::vector<uint8_t> str_ok(n_strings * C), str_miss(colored ? 0 : n_strings);
+        std::vector<uint64_t> &str_sum = B.str_sum, &str_len = B.str_len;  // colored: [string][colour]
+        std::vector<uint8_t> &str_ok = B.str_ok;
+        str_sum.assign(n_strings * C, 0);
+        str_len.assign(n_strings, 0);
+        str_ok.assign(n_strings * C, 0);
+        std::vector<uint8_t> str_miss(colored ? 0 : n_strings);
         if (n_strings) {
             std::string text;
             std::vector<uint64_t> soff(n_strings + 1, 0);
@@ -1112,15 +1170,31 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             else
                 st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)n_strings, low, up, str_sum.data(), str_ok.data(),
                                    str_miss.data());
-            if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+            if (st != PF_OK) { B.err = std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_); return st; }
             for (size_t i = 0; i < str_miss.size(); ++i)
-                if (str_miss[i]) return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of a site string can not found .");
-            times_.site_strings += n_strings;
+                if (str_miss[i]) { B.err = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
+            B.site_strings = n_strings;
         }
-        times_.sites_s += since(t0);
+        B.sites_s = since(t0);
 
+        return PF_OK;
+    };
+
+    // stage 2 of a batch (the calling thread): formatting
+    auto consume = [&](Batch &B) -> int {
+        AlignExchange &X = *B.ax;
+        const Task *tasks = all_tasks.data() + B.batch0;
+        const size_t NT = B.NT;
+        const size_t n_pch = n_chunks_of(NT, PCH);
+        const std::vector<uint32_t> &dev_index = B.dev_index;
+        const std::vector<SiteChunk> &schunks = B.schunks;
+        const std::vector<uint64_t> &chunk_base = B.chunk_base, &str_sum = B.str_sum, &str_len = B.str_len;
+        const std::vector<uint8_t> &str_ok = B.str_ok;
+        auto result_of = [&](size_t ti) -> const pf_bubble_result & {
+            return dev_index[ti] == NONE ? kNoResult : X.res.p[dev_index[ti]];
+        };
         // ---- format ------------------------------------------------------------------------------
-        t0 = clk::now();
+        auto t0 = clk::now();
         std::vector<uint64_t> vc(NT);  // var_count of each bubble (1-based over non-empty alignments)
         for (size_t ti = 0; ti < NT; ++ti) {
             if (result_of(ti).n_rows) ++var_count;
@@ -1140,7 +1214,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 const pf_bubble_result &r = result_of(ti);
                 if (r.n_rows == 0) continue;
                 const size_t R = r.n_rows, L = r.n_cols;
-                const char *rows = bx_.otext.p + r.rows_off;
+                const char *rows = X.otext.p + r.rows_off;
                 const uint64_t my_vc = vc[ti];
                 for (size_t p = 0; p < R; ++p) {
                     put_uint(o.s_var, my_vc);
@@ -1154,15 +1228,15 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 }
                 o.core_cov += (uint64_t)t.core_mean;
                 o.core_num++;
-                const pf_bubble_site *sites = bx_.osites.p + r.site_off;
-                const uint32_t *ilen = bx_.oilen.p + r.ilen_off;
+                const pf_bubble_site *sites = X.osites.p + r.site_off;
+                const uint32_t *ilen = X.oilen.p + r.ilen_off;
                 const size_t usize = g_.size_bp(t.u), esize = g_.size_bp(t.exit_ov >> 1);
                 const uint32_t ns = r.n_sites;
                 uint32_t indel = 0;
                 uint32_t gcur = sc.first_group[ti - tb];  // walks this bubble's GroupRefs (branching only)
                 for (uint32_t i = 0; i < ns; ++i) {
                     const pf_bubble_site &sr = sites[i];
-                    const uint8_t *grp = bx_.ogroups.p + r.group_off + (uint64_t)i * R;
+                    const uint8_t *grp = X.ogroups.p + r.group_off + (uint64_t)i * R;
                     // distance to the neighbouring sites / unitig ends (src/CDBG.cpp:1279-1298)
                     uint32_t vd;
                     if (i == 0) {
@@ -1302,33 +1376,129 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             core_num_ += o.core_num;
         }
         times_.format_s += since(t0);
+        return PF_OK;
+    };
+
+    // the ten result files are appended to batch by batch (stage 2), one writer per file
+    static const char *kArity[4] = {"bi", "tri", "tetra", "penta"};
+    struct OutFile {
+        std::string name;
+        FILE *f = nullptr;
+        uint64_t bytes = 0;
+        int rc = 0;
+    };
+    std::vector<OutFile> files(10);
+    files[0].name = outpre + "_allele_frequency.txt";
+    files[1].name = outpre + "_alignseq.txt";
+    for (int a = 0; a < 4; ++a) {
+        files[2 + a].name = outpre + "_" + kArity[a] + "fre.txt";
+        files[6 + a].name = outpre + "_" + kArity[a] + "cov.txt";
+    }
+    auto close_files = [&] {
+        for (OutFile &of : files)
+            if (of.f) { fclose(of.f); of.f = nullptr; }
+    };
+    if (write_files_)
+        for (OutFile &of : files) {
+            of.f = fopen((outdir_ + "/" + of.name).c_str(), "wb");
+            if (!of.f) { close_files(); return fail(PF_ERR_ARG, "CDBG:: Open " + of.name + " file error"); }
+        }
+    last_allfre_.clear();
+    double write_s = 0;
+    auto write_batch = [&](std::vector<ChunkOut> &outs) {
+        const auto tw = clk::now();
+        parallel_chunks(files.size(), 1, T, [&](size_t fi, size_t, size_t) {
+            OutFile &of = files[fi];
+            for (ChunkOut &o : outs) {
+                const std::string &piece = fi == 0 ? o.allfre : fi == 1 ? o.s_var : fi < 6 ? o.fre[fi - 2] : o.cov[fi - 6];
+                of.bytes += piece.size();
+                if (of.f && !piece.empty() && fwrite(piece.data(), 1, piece.size(), of.f) != piece.size()) of.rc = 1;
+                if (fi == 0) last_allfre_ += piece;
+            }
+        });
+        std::vector<ChunkOut>().swap(outs);
+        write_s += since(tw);
+    };
+
+    {
+        const size_t n_batches = (all_tasks.size() + CHUNK - 1) / CHUNK;
+        std::vector<Batch> batches(n_batches);
+        for (size_t b = 0; b < n_batches; ++b) {
+            batches[b].batch0 = b * CHUNK;
+            batches[b].NT = std::min(CHUNK, all_tasks.size() - b * CHUNK);
+            batches[b].ax = &ax_[b & 1];
+        }
+        std::mutex mu;
+        std::condition_variable cv;
+        size_t produced = 0, consumed = 0;  // batches finished by stage 1 / stage 2
+        bool stop = false;
+        std::thread stage1;
+        if (n_batches > 1)
+            stage1 = std::thread([&] {
+                for (size_t b = 0; b < n_batches; ++b) {
+                    {  // the exchange buffers of batch b are those of batch b - 2
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || b < consumed + 2; });
+                        if (stop) return;
+                    }
+                    batches[b].st = produce(batches[b]);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        produced = b + 1;
+                        if (batches[b].st != PF_OK) stop = true;
+                    }
+                    cv.notify_all();
+                    if (batches[b].st != PF_OK) return;
+                }
+            });
+        int rc = PF_OK;
+        std::string rc_err;
+        for (size_t b = 0; b < n_batches && rc == PF_OK; ++b) {
+            if (n_batches > 1) {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return produced > b; });
+            } else {
+                batches[b].st = produce(batches[b]);
+            }
+            Batch &B = batches[b];
+            times_.tasks += B.NT;
+            times_.tasks_s += B.tasks_s;
+            times_.align_s += B.align_s;
+            times_.align_jobs += B.n_dev;
+            times_.sites_s += B.sites_s;
+            times_.site_strings += B.site_strings;
+            if (B.st != PF_OK) { rc = B.st; rc_err = B.err; break; }
+            rc = consume(B);
+            if (rc == PF_OK) write_batch(all_outs.back());
+            std::vector<PathChunk>().swap(B.pchunks);
+            std::vector<uint32_t>().swap(B.dev_index);
+            std::vector<SiteChunk>().swap(B.schunks);
+            std::vector<uint64_t>().swap(B.str_sum);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                consumed = b + 1;
+                if (rc != PF_OK) stop = true;
+            }
+            cv.notify_all();
+        }
+        if (stage1.joinable()) {
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            stage1.join();
+        }
+        if (rc != PF_OK) { close_files(); return rc_err.empty() ? status_ : fail(rc, rc_err); }
     }
 
+
     t0 = clk::now();
-    static const char *kArity[4] = {"bi", "tri", "tetra", "penta"};
-    {
-        // ten files, each the in-order concatenation of the per-work-item pieces; written concurrently
-        std::vector<std::pair<std::string, std::vector<const std::string *>>> files(10);
-        files[0].first = outpre + "_allele_frequency.txt";
-        files[1].first = outpre + "_alignseq.txt";
-        for (int a = 0; a < 4; ++a) {
-            files[2 + a].first = outpre + "_" + kArity[a] + "fre.txt";
-            files[6 + a].first = outpre + "_" + kArity[a] + "cov.txt";
-        }
-        for (auto &batch : all_outs)
-            for (ChunkOut &o : batch) {
-                files[0].second.push_back(&o.allfre);
-                files[1].second.push_back(&o.s_var);
-                for (int a = 0; a < 4; ++a) {
-                    files[2 + a].second.push_back(&o.fre[a]);
-                    files[6 + a].second.push_back(&o.cov[a]);
-                }
-            }
-        if (write_many(files, T)) return status_;
-        last_allfre_.clear();
-        for (const std::string *piece : files[0].second) last_allfre_ += *piece;
+    if (join_pending_write()) { close_files(); return status_; }
+    close_files();
+    for (OutFile &of : files) {
+        out_bytes_ += of.bytes;
+        if (of.rc) return fail(PF_ERR_ARG, "CDBG:: write error on " + of.name);
     }
-    times_.write_s = since(t0);
+    write_s += since(t0);
+    times_.write_s = write_s;
     times_.ploidy_total_s = since(t_all);
     if (!quiet_) {
         printf("%s::PloidyEstimation():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);

@@ -20,6 +20,7 @@
 #include <cstdint>
 #include <memory>
 #include <string>
+#include <thread>
 #include <utility>
 #include <vector>
 
@@ -65,6 +66,10 @@ public:
     void set_quiet(bool q) { quiet_ = q; }
     void set_threads(unsigned t) { threads_ = t; }                  // host threads; 0 = use the `thr` argument
     void set_write_files(bool w) { write_files_ = w; }              // bench: format but do not touch the disk
+    void set_batch_bubbles(size_t n) { batch_bubbles_ = n; }
+    // write <outpre>_super_bubble.txt in the background while PloidyEstimation runs (complete when that call, the next
+    // findSuperBubble or the destructor returns); off by default: the file is complete when findSuperBubble returns
+    void set_overlap_output(bool on) { overlap_output_ = on; }        // bubbles per pipeline batch (tests force small ones)
     pf_ctx *device() { return ctx_; }
     const PhaseTimes &times() const { return times_; }
     uint64_t allele_sites(int arity) const { return allele_[arity - 2]; }
@@ -91,6 +96,11 @@ protected:
 
     struct Task;
     int fail(int st, const std::string &msg);
+    int join_pending_write();
+    bool overlap_output_ = false;
+    std::thread pending_write_;
+    std::vector<std::string> pending_pieces_;
+    int pending_rc_ = 0;
     int ensure_dir();
     int write_file(const std::string &name, const std::string &data);
     int write_pieces(const std::string &name, const std::vector<const std::string *> &pieces, uint64_t &bytes) const;
@@ -117,8 +127,8 @@ protected:
     std::vector<uint8_t> flags_;
     std::vector<uint32_t> plus_, minus_;  // 0 = NULL, id = u + 1
 
-    // pinned exchange buffers of pf_align_bubbles, reused from pass to pass
-    struct BubbleExchange {
+    // pinned exchange buffers of pf_align_bubbles, two sets: one per batch in flight (reused from pass to pass)
+    struct AlignExchange {
         PinnedBuf<char> text, otext;
         PinnedBuf<pf_bubble_path> paths;
         PinnedBuf<pf_bubble_task> tasks;
@@ -126,6 +136,14 @@ protected:
         PinnedBuf<pf_bubble_site> osites;
         PinnedBuf<uint8_t> ogroups;
         PinnedBuf<uint32_t> oilen;
+        void release_all() {
+            text.release(); otext.release(); paths.release(); tasks.release(); res.release(); osites.release();
+            ogroups.release(); oilen.release();
+        }
+    } ax_[2];
+    size_t batch_bubbles_ = 1u << 16;
+    // pinned buffers of the whole-graph device calls
+    struct BubbleExchange {
         PinnedBuf<pf_bfs_record> bfs_rec;
         PinnedBuf<uint32_t> bfs_pool;
         PinnedBuf<uint64_t> cov_sum;
@@ -134,8 +152,7 @@ protected:
         PinnedBuf<uint32_t> cov_max;  // colored path: per (colour, unitig) arrays, colour-major
         void release_all() {
             cov_max.release();
-            text.release(); otext.release(); paths.release(); tasks.release(); res.release(); osites.release();
-            ogroups.release(); oilen.release(); bfs_rec.release(); bfs_pool.release(); cov_sum.release(); cov_min.release();
+            bfs_rec.release(); bfs_pool.release(); cov_sum.release(); cov_min.release();
             cov_miss.release();
         }
     } bx_;

@@ -105,6 +105,8 @@ const char *pfh_last_error(const pfh_run *r) {
 void pfh_set_output_dir(pfh_run *r, const char *dir) { r->cdbg->set_output_dir(dir); }
 void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0); }
 void pfh_set_threads(pfh_run *r, uint32_t threads) { r->cdbg->set_threads(threads); }
+void pfh_set_overlap_output(pfh_run *r, int on) { r->cdbg->set_overlap_output(on != 0); }
+void pfh_set_batch_bubbles(pfh_run *r, uint64_t n) { r->cdbg->set_batch_bubbles((size_t)n); }
 int pfh_set_unitig_id(pfh_run *r, const char *outpre) {
     return guarded(r, [&] { return r->cdbg->setUnitigId(outpre, "", 1); });
 }

@@ -177,6 +177,7 @@ int main(int argc, char **argv) {
         };
         if (!g.good()) die();
         g.set_threads((unsigned)opt.nb_threads);
+        g.set_overlap_output(true);
         if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
         if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
         if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) die();
@@ -217,6 +218,7 @@ int main(int argc, char **argv) {
     };
     if (!g.good()) die();
     g.set_threads((unsigned)opt.nb_threads);
+    g.set_overlap_output(true);
     if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
     if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
     if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) die();

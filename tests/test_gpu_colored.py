@@ -163,3 +163,17 @@ def test_wrong_number_of_cutoffs_is_an_error(tmp_path):
     run.find_superbubbles("g")
     with pytest.raises(hipapi.DeviceError, match="cutoff"):
         run.ploidy_estimation("g", meta["cutoffs"][:-1])
+
+
+def test_pipeline_batches_colored(tmp_path):
+    meta = load_case("col2_weird")
+    op = meta["opts"]
+    run = hostapi.ColoredRun(meta["gfa"], meta["colors"], meta["dbs"], str(tmp_path), z=int(op["-z"]), M=float(op["-M"]),
+                             D=float(op["-D"]), G=float(op["-G"]))
+    run.set_batch_bubbles(16)
+    run.set_threads(4)
+    run.set_output_dir(str(tmp_path / "out"))
+    run.set_unitig_id("g")
+    run.find_superbubbles("g")
+    run.ploidy_estimation("g", meta["cutoffs"])
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path / "out"))

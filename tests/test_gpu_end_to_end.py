@@ -94,3 +94,35 @@ def test_missing_database_kmer_fails_like_the_reference(tmp_path):
     r = subprocess.run([CLI, "-g", meta["gfa"], "-d", str(tmp_path / "holes"), "-o", "g", "-l", "5"], cwd=tmp_path,
                        stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
     assert r.returncode != 0 and "can not found" in r.stdout
+
+
+@pytest.mark.parametrize("case,batch", [("tet60k", 64), ("hex30k", 1), ("k31_z16", 500), ("weird12k", 37)])
+def test_pipeline_batches_do_not_change_a_byte(case, batch, tmp_path):
+    """PloidyEstimation runs its bubbles through a two-stage pipeline in batches; tiny batches force many hand-overs."""
+    meta = load_case(case)
+    op = meta["opts"]
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    run.set_threads(5)
+    run.set_batch_bubbles(batch)
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    for _ in range(2):  # the second pass reuses the exchange buffers
+        run.find_superbubbles("g")
+        run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+        assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+
+
+def test_overlapped_output_is_complete_when_ploidy_returns(tmp_path):
+    meta = load_case("tet60k")
+    run = hostapi.Run(meta["gfa"], meta["db"])
+    run.set_overlap_output(True)
+    run.set_batch_bubbles(200)
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    for _ in range(3):
+        run.find_superbubbles("g")
+        run.ploidy_estimation("g", 5, 1000)
+        assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+    run.find_superbubbles("g")   # pending write joined by close()
+    run.close()
+    assert open(os.path.join(meta["dir"], "expected", "g_super_bubble.txt"), "rb").read() == open(tmp_path / "g_super_bubble.txt", "rb").read()
