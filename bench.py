@@ -258,7 +258,7 @@ def main():
             step()
             tt = run.times()
             for key in ("bfs_device_s", "replay_s", "bubble_write_s", "cov_device_s", "tasks_s", "align_s", "sites_s", "format_s",
-                        "write_s", "find_total_s", "ploidy_total_s"):
+                        "write_s", "scan_s", "scan_serial_s", "find_total_s", "ploidy_total_s"):
                 phase[key] = phase.get(key, 0.0) + tt[key]
         torch.cuda.synchronize()
         if world > 1:

@@ -25,6 +25,7 @@ typedef struct pfh_times {
     double cov_device_s, tasks_s, align_s, sites_s, format_s, write_s, ploidy_total_s;
     uint64_t unitigs, kmers, candidates, superbubbles, tasks, align_jobs, site_strings, output_bytes;
     uint64_t allele[4], core_cov, core_num;
+    double scan_s, scan_serial_s; /* owner/order scan of PloidyEstimation: whole, and its sequential part */
 } pfh_times;
 
 /* NULL on failure: message via pfh_last_error(NULL) */

@@ -796,8 +796,14 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     // ---- scan, part B (sequential, light): the driver loop itself -- a side is handled only if its bit
     //      is still set when its unitig comes up; handling a bubble closes both endpoint sides (:1656-1679)
     std::vector<Task> all_tasks;
-    for (auto &chunk : side_chunks) {
-        for (const SideRec &r : chunk) {
+    const auto t_serial = clk::now();
+    // the sequential pass only decides; the kept tasks are gathered afterwards, chunks in parallel
+    std::vector<std::vector<uint32_t>> kept(n_uch);
+    for (size_t ci = 0; ci < n_uch; ++ci) {
+        const std::vector<SideRec> &chunk = side_chunks[ci];
+        std::vector<uint32_t> &keep = kept[ci];
+        for (uint32_t ri = 0; ri < chunk.size(); ++ri) {
+            const SideRec &r = chunk[ri];
             const uint32_t u = r.t.u;
             const uint8_t own = r.plus_side ? B_PLUS : B_MINUS;
             if (!(flags_[u] & own)) continue;
@@ -806,10 +812,20 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             if (r.err == 2) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): exit of a bubble is not reachable");
             flags_[u] &= (uint8_t)~own;
             if (r.kind == 2) continue;
-            if (r.aligned) all_tasks.push_back(r.t);
+            if (r.aligned) keep.push_back(ri);
             flags_[r.t.exit_ov >> 1] &= (uint8_t) ~(plus_of(r.t.exit_ov) ? B_MINUS : B_PLUS);
         }
-        std::vector<SideRec>().swap(chunk);
+    }
+    times_.scan_serial_s = since(t_serial);
+    {
+        std::vector<size_t> base(n_uch + 1, 0);
+        for (size_t ci = 0; ci < n_uch; ++ci) base[ci + 1] = base[ci] + kept[ci].size();
+        all_tasks.resize(base[n_uch]);
+        parallel_chunks(n_uch, 1, T, [&](size_t ci, size_t, size_t) {
+            Task *dst = all_tasks.data() + base[ci];
+            for (uint32_t ri : kept[ci]) *dst++ = side_chunks[ci][ri].t;
+            std::vector<SideRec>().swap(side_chunks[ci]);
+        });
     }
     times_.scan_s += since(t0);
 

@@ -39,7 +39,7 @@ struct PhaseTimes {
     double bfs_device_s = 0, replay_s = 0, bubble_write_s = 0;
     double cov_device_s = 0, tasks_s = 0, align_s = 0, sites_s = 0, format_s = 0, write_s = 0;
     double find_total_s = 0, ploidy_total_s = 0;
-    double scan_s = 0, align_build_s = 0, align_device_s = 0, align_post_s = 0, align_choose_s = 0;
+    double scan_s = 0, scan_serial_s = 0, align_build_s = 0, align_device_s = 0, align_post_s = 0, align_choose_s = 0;
     uint64_t bfs_large = 0, bfs_large_seen = 0, bfs_max_seen = 0;  // traversals beyond 4096 unitigs
     uint64_t candidates = 0, bfs_deferred = 0, bubbles_out = 0, tasks = 0, align_jobs = 0, site_strings = 0;
 };

@@ -129,6 +129,7 @@ void pfh_get_times(const pfh_run *r, pfh_times *o) {
     o->tasks = t.tasks; o->align_jobs = t.align_jobs; o->site_strings = t.site_strings; o->output_bytes = r->cdbg->output_bytes();
     for (int a = 0; a < 4; ++a) o->allele[a] = r->cdbg->allele_sites(a + 2);
     o->core_cov = r->cdbg->core_cov(); o->core_num = r->cdbg->core_num();
+    o->scan_s = t.scan_s; o->scan_serial_s = t.scan_serial_s;
 }
 
 const char *pfh_last_allele_frequency(const pfh_run *r, uint64_t *len) {

@@ -666,12 +666,22 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         (void)hipGetLastError();
         return d;
     };
-    // host copies for validation and size classes
-    std::vector<pf_bubble_task> ht(n_tasks);
-    std::vector<pf_bubble_path> hp(n_paths);
-    PF_HIP(hipMemcpy(ht.data(), tasks, (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyDefault));
-    if (n_paths) PF_HIP(hipMemcpy(hp.data(), paths, (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyDefault));
-    std::vector<uint32_t> hlen;  // unitig lengths, fetched lazily for ov paths
+    // host view of the arguments for validation and size classes (copied only when they live on the device)
+    std::vector<pf_bubble_task> ht_own;
+    std::vector<pf_bubble_path> hp_own;
+    const pf_bubble_task *ht = tasks;
+    const pf_bubble_path *hp = paths;
+    if (is_dev(tasks)) {
+        ht_own.resize(n_tasks);
+        PF_HIP(hipMemcpy(ht_own.data(), tasks, (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyDeviceToHost));
+        ht = ht_own.data();
+    }
+    if (n_paths && is_dev(paths)) {
+        hp_own.resize(n_paths);
+        PF_HIP(hipMemcpy(hp_own.data(), paths, (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyDeviceToHost));
+        hp = hp_own.data();
+    }
+    const std::vector<uint32_t> &hlen = ctx->h_len;  // unitig lengths for ov paths
     const uint64_t cls_bytes[3] = {5 * 1024, 20 * 1024, 64 * 1024};
     std::vector<uint32_t> cls[4];
     uint64_t max_need = 0;
@@ -683,13 +693,9 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         }
         uint32_t l0 = 0, lmax = 0;
         for (uint32_t i = 0; i < tk.n_paths; ++i) {
-            pf_bubble_path &pp = hp[tk.path_first + i];
+            const pf_bubble_path &pp = hp[tk.path_first + i];
             if (pp.ov != PF_NONE) {
                 if ((pp.ov >> 1) >= ctx->N) { ctx->err = "pf_align_bubbles: path unitig out of range"; return PF_ERR_ARG; }
-                if (hlen.empty()) {
-                    hlen.resize(ctx->N);
-                    PF_HIP(hipMemcpy(hlen.data(), ctx->d_len, (size_t)ctx->N * 4, hipMemcpyDeviceToHost));
-                }
                 if (pp.len != hlen[pp.ov >> 1]) { ctx->err = "pf_align_bubbles: path length differs from the unitig's"; return PF_ERR_ARG; }
             } else if (pp.text_off + pp.len > text_len) {
                 ctx->err = "pf_align_bubbles: path outside the text buffer";
@@ -721,8 +727,8 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_BUB_RETRY, (size_t)n_tasks * 4);
     uint32_t *d_idx = (uint32_t *)ctx_ws(ctx, WS_BUB_IDX, (size_t)n_tasks * 4);
     if (!d_paths || !d_tasks || !small || !d_retry || !d_idx) return PF_ERR_HIP;
-    PF_HIP(hipMemcpyAsync(d_paths, hp.data(), (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyHostToDevice, st));
-    PF_HIP(hipMemcpyAsync(d_tasks, ht.data(), (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyHostToDevice, st));
+    PF_HIP(hipMemcpyAsync(d_paths, hp, (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyHostToDevice, st));
+    PF_HIP(hipMemcpyAsync(d_tasks, ht, (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyHostToDevice, st));
     PF_HIP(hipMemsetAsync(small, 0, 64, st));
     const bool dev_out = is_dev(results);
     BubOut o;

@@ -50,6 +50,7 @@ struct pf_ctx {
     bool has_adj = false;
     uint32_t *d_cand = nullptr;    // oriented vertices with out-degree > 1, ascending
     std::vector<uint32_t> h_cand;  // host copy (shard range queries)
+    std::vector<uint32_t> h_len;   // host copy of the unitig lengths (argument validation)
 
     // k-mer count table (HBM): open addressing, 16-B slots, capacity = power of two >= 2n
     pf::Slot *d_tab = nullptr;

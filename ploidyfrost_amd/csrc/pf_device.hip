@@ -671,6 +671,7 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         nk += hl[u] - k + 1;
     }
     ctx->n_kmers = nk;
+    ctx->h_len = hl;
     // k-mer numbering for the k-mer-parallel kernels
     {
         std::vector<uint64_t> kpre((size_t)N + 1);
