@@ -368,7 +368,26 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // '+' before '-'.
     t0 = clk::now();
     times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;
+    const uint32_t *pool = bx_.bfs_pool.p;
     for (uint64_t i = 0; i < n_rec; ++i) {
+        // the commits chase per-unitig state at random: pull the state of a record a few iterations ahead into cache
+        if (i + 12 < n_rec) {
+            const pf_bfs_record &nx = rec[i + 12];
+            __builtin_prefetch(pool + nx.list_off);
+            __builtin_prefetch(&plus_[nx.entrance >> 1]);
+            __builtin_prefetch(&minus_[nx.entrance >> 1]);
+        }
+        if (i + 6 < n_rec) {
+            const pf_bfs_record &nx = rec[i + 6];
+            const uint32_t *l = pool + nx.list_off;
+            const uint32_t nl = nx.n_list < 6 ? nx.n_list : 6;
+            for (uint32_t q = 0; q < nl; ++q) {
+                const uint32_t w = l[q] >> 1;
+                __builtin_prefetch(&flags_[w]);
+                __builtin_prefetch(&plus_[w]);
+                __builtin_prefetch(&minus_[w]);
+            }
+        }
         const pf_bfs_record &r = rec[i];
         if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
         if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
