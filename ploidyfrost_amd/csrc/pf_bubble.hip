@@ -394,7 +394,34 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
     {
         const uint32_t m = paths[0].len, n = paths[1].len;
         if (job_bytes(m, n) > p.work_bytes) return 1;
+        // Two equally long paths that differ in exactly one base -- the bi-allelic SNP bubble, most of all bubbles --
+        // need no dynamic programming when the scores make the diagonal the strict optimum of every diagonal cell.
+        // With b = 1 the bonus for continuing a direction (src/SeqAlign.cpp:512-526) and h <= 1 mismatches so far:
+        //   S(i,i) = sum of substitution scores + (i-1) b, reached by the diagonal move alone, as long as it beats
+        //   the moves out of the neighbours (i-1,i) and (i,i-1);
+        //   any cell obeys S(i,j) <= min(i,j) (M+b) + |i-j| (G+b) when M >= D and M + b >= 2 (G + b);
+        //   so diag - up >= M - h (M-D) - 2G - 2b >= D - 2G - 2b.
+        // If D - 2G - 2b > 0 every diagonal cell carries the single flag DIAG, the traceback finds exactly one
+        // alignment -- the two strings unchanged -- and all the tie-breaking machinery has nothing to decide.
+        bool snp_only = false;
+        if (p.integral && m == n && p.M >= p.D && p.M + 1 >= 2 * (p.G + 1) && p.D - 2 * p.G - 2 > 0) {
+            const char *x = path_ptr(0), *y = path_ptr(1);
+            uint32_t diff = 0;
+            for (uint32_t t = lane; t < m; t += WAVE) diff += x[t] != y[t];
+            snp_only = read_lane((uint32_t)wave_sum_u64(diff), 0) == 1;
+        }
         uint32_t nh, tu, gu;
+        if (snp_only) {
+            if (m > C.row || 2ull * m > C.arena || C.list < 1) return 1;
+            const char *src = path_ptr(0);  // paths 0 and 1 are adjacent in pbuf: the two rows, as traceback would emit them
+            char *dst = arena[cur];
+            for (uint32_t t = lane; t < 2 * m; t += WAVE) dst[t] = src[t];
+            if (lane == 0) list[cur][0] = MsaRef{0, m, 2};
+            used[cur] = 2 * m;
+            nh = 0;
+            n_kept = 1;
+            aln_sync();
+        } else {
         if (!align_job(nw_base, path_ptr(0), path_ptr(1), m, n, p.M, p.D, p.G, p.integral, st, nh, tu, gu, p.prof)) return 1;
         if (nh > C.list) return 1;
         for (uint32_t h = 0; h < nh; ++h) {
@@ -408,6 +435,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
         }
         n_kept = nh;
         aln_sync();
+        }
     }
 
     mark(3);

@@ -133,3 +133,37 @@ def test_no_alignment_survives(dev):
     exp = [expected(b, 2.0, -1.0, -3.0) for b in bubbles]
     assert [g is None for g in got] == [e is None for e in exp] and any(e is None for e in exp)
     check(dev, bubbles)
+
+
+@pytest.mark.parametrize("scores", [(2, -1, -3), (1, -1, -1), (3, -2, -4), (5, 4, -1), (1, -3, -2), (2, 0, -2), (2, -1, -1), (4, -1, -2),
+                                    (2, 2, -3), (7, -5, -9)])
+def test_single_snp_pairs_under_many_scorings(dev, scores):
+    """Equal-length paths differing in one base skip the dynamic programming when the scores make the diagonal the
+    strict optimum (the shortcut in round 0 of K-BUBBLE); with other scores they take the full path.  Both must give
+    the oracle's answer -- including SNPs at the very first and last base, in homopolymers and in tandem repeats."""
+    M, D, G = (float(x) for x in scores)
+    rng = np.random.default_rng(abs(hash(scores)) % (1 << 31))
+    bubbles = []
+    for i in range(120):
+        L = int(rng.integers(3, 90))
+        kind = i % 4
+        if kind == 0:
+            base = bytes(rng.choice(list(b"ACGT"), size=L).tolist())
+        elif kind == 1:
+            base = bytes(rng.choice(list(b"AC"), size=L, p=[0.85, 0.15]).tolist())
+        elif kind == 2:
+            unit = bytes(rng.choice(list(b"ACGT"), size=int(rng.integers(1, 4))).tolist())
+            base = (unit * L)[:L]
+        else:
+            base = bytes([b"ACGT"[int(rng.integers(0, 4))]]) * L
+        pos = 0 if i % 7 == 0 else (L - 1 if i % 7 == 1 else int(rng.integers(0, L)))
+        alt = bytes([rng.choice([c for c in b"ACGT" if c != base[pos]])])
+        other = base[:pos] + alt + base[pos + 1:]
+        pair = sorted([base, other], reverse=True)
+        bubbles.append(pair)
+        if i % 5 == 0:  # a third path makes the progressive rounds start from the shortcut's rows
+            third = mutate(rng, base, 1, 1, 3)
+            if third not in pair:
+                trio = sorted(pair + [third], key=lambda s: (len(s), s), reverse=True)
+                bubbles.append(trio)
+    check(dev, bubbles, M, D, G)
