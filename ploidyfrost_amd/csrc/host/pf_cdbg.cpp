@@ -625,6 +625,48 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     times_.tasks = times_.align_jobs = times_.site_strings = 0;
     times_.align_build_s = times_.align_device_s = times_.align_post_s = times_.align_choose_s = times_.scan_s = 0;
 
+    // the ten result files are appended to batch by batch (stage 2 of the pipeline below), one writer per file; they are
+    // opened -- truncating what an earlier pass left there costs milliseconds -- by a helper thread while coverage and
+    // the scan run
+    static const char *kArity[4] = {"bi", "tri", "tetra", "penta"};
+    struct OutFile {
+        std::string name;
+        FILE *f = nullptr;
+        uint64_t bytes = 0;
+        int rc = 0;
+    };
+    std::vector<OutFile> files(10);
+    files[0].name = outpre + "_allele_frequency.txt";
+    files[1].name = outpre + "_alignseq.txt";
+    for (int a = 0; a < 4; ++a) {
+        files[2 + a].name = outpre + "_" + kArity[a] + "fre.txt";
+        files[6 + a].name = outpre + "_" + kArity[a] + "cov.txt";
+    }
+    auto close_files = [&] {
+        for (OutFile &of : files)
+            if (of.f) { fclose(of.f); of.f = nullptr; }
+    };
+    int open_failed = -1;
+    std::thread opener;
+    if (write_files_)
+        opener = std::thread([&] {
+            for (size_t i = 0; i < files.size(); ++i) {
+                files[i].f = fopen((outdir_ + "/" + files[i].name).c_str(), "wb");
+                if (!files[i].f) { open_failed = (int)i; return; }
+            }
+        });
+    struct OpenerGuard {  // every early return below must not leave the helper running or files open
+        std::thread &t;
+        std::vector<OutFile> &f;
+        ~OpenerGuard() {
+            if (t.joinable()) t.join();
+            for (OutFile &of : f)
+                if (of.f) { fclose(of.f); of.f = nullptr; }
+        }
+    } opener_guard{opener, files};
+
+    const bool trace = getenv("PF_TRACE_PLOIDY") != nullptr;
+    auto tp = [&](const char *what) { if (trace) fprintf(stderr, "[ploidy] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
     // C1 for every unitig (and, colored, every colour) in one launch (the reference calls readCov per use)
     auto t0 = clk::now();
     bx_.cov_sum.ensure(ctx_, (size_t)N * C);
@@ -639,6 +681,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                      : pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
     if (st != PF_OK && st != PF_ERR_MISSING_KMER) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
     times_.cov_device_s = since(t0);
+    tp("coverage done");
     auto mean_of = [&](uint32_t u) { return (double)cov_sum[u] / (double)g_.len_km(u); };
     // readCovUni(u, low, up, c) of src/CCDBG.cpp:123-156: (sum / len, true) iff every k-mer is in colour c's database
     // with low < count < up, else (0, false)
@@ -847,6 +890,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         });
     }
     times_.scan_s += since(t0);
+    tp("scan done");
 
     const size_t CHUNK = std::max<size_t>(batch_bubbles_, 1);  // bubbles per batch
     constexpr size_t PCH = 256;     // bubbles per parallel work item
@@ -1414,31 +1458,10 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         return PF_OK;
     };
 
-    // the ten result files are appended to batch by batch (stage 2), one writer per file
-    static const char *kArity[4] = {"bi", "tri", "tetra", "penta"};
-    struct OutFile {
-        std::string name;
-        FILE *f = nullptr;
-        uint64_t bytes = 0;
-        int rc = 0;
-    };
-    std::vector<OutFile> files(10);
-    files[0].name = outpre + "_allele_frequency.txt";
-    files[1].name = outpre + "_alignseq.txt";
-    for (int a = 0; a < 4; ++a) {
-        files[2 + a].name = outpre + "_" + kArity[a] + "fre.txt";
-        files[6 + a].name = outpre + "_" + kArity[a] + "cov.txt";
-    }
-    auto close_files = [&] {
-        for (OutFile &of : files)
-            if (of.f) { fclose(of.f); of.f = nullptr; }
-    };
-    if (write_files_)
-        for (OutFile &of : files) {
-            of.f = fopen((outdir_ + "/" + of.name).c_str(), "wb");
-            if (!of.f) { close_files(); return fail(PF_ERR_ARG, "CDBG:: Open " + of.name + " file error"); }
-        }
+    if (opener.joinable()) opener.join();
+    if (open_failed >= 0) { close_files(); return fail(PF_ERR_ARG, "CDBG:: Open " + files[(size_t)open_failed].name + " file error"); }
     last_allfre_.clear();
+    tp("files open");
     double write_s = 0;
     auto write_batch = [&](std::vector<ChunkOut> &outs) {
         const auto tw = clk::now();
@@ -1525,6 +1548,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     }
 
 
+    tp("pipeline done");
     t0 = clk::now();
     if (join_pending_write()) { close_files(); return status_; }
     close_files();
@@ -1534,6 +1558,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     }
     write_s += since(t0);
     times_.write_s = write_s;
+    tp("files closed");
     times_.ploidy_total_s = since(t_all);
     if (!quiet_) {
         printf("%s::PloidyEstimation():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
