@@ -29,7 +29,7 @@ def per_kernel(d, counter):
 
 
 def short(name):
-    for k in ("k_cov", "k_bfs_big", "k_bfs", "k_bubble", "k_align", "k_strcov", "k_table_build", "k_adj_insert", "k_adj_probe"):
+    for k in ("k_cov_init", "k_cov_colored", "k_cov", "k_bfs_huge", "k_bfs_big", "k_bfs", "k_bubble", "k_strcov_colored", "k_align", "k_strcov", "k_table_build", "k_adj_insert", "k_adj_probe"):
         if k + "(" in name or k + "<" in name:
             if k == "k_bubble" and "Lb0" in name:
                 return "k_bubble_big"
