@@ -3,14 +3,17 @@
 //     ploidyfrost -g <BifrostGraph.gfa> -d <KMCDatabase> -o <prefix> [-t T -l L -u U -z Z -M m -D d -G g -v -i]
 //     ploidyfrost -g <BifrostGraph.gfa> -f <BifrostGraph.bfg_colors> -d <KMCDatabaseList> [-C <cutoffs>] -o <prefix> ...
 // Output: ./PloidyFrost_output/<prefix>_*.txt, byte-identical to the reference run with -t 1.
-// The `model` and `cutoffL/cutoffU` sub-commands (and the -h histogram cutoffs) are outside this build's
-// scope and say so.
+// The coverage thresholds of the path can be derived from k-mer histograms exactly as in the reference: the
+// `cutoffL` / `cutoffU` sub-commands and `-h <histogram>` (with -f: a list of histograms) with `-q <quantile>`
+// (src/Main.cpp:200-277, 354-396, 721-762).  The `model` sub-command (GMM ploidy inference, downstream of the
+// path) is outside this build's scope and says so.
 #include <getopt.h>
 #include <sys/stat.h>
 
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <cmath>
 #include <cstring>
 #include <iostream>
 #include <string>
@@ -41,7 +44,48 @@ void PrintUsage() {
          << "parameters with no argument:" << endl << endl
          << "  -v,             Print information messages during construction" << endl
          << "  -i,             Output Information about Bifrost graph" << endl << endl
-         << "Not part of this build: `model`, `cutoffL`, `cutoffU`, -h." << endl;
+         << "  -h,             k-mer histogram file (with -f: a list of them): thresholds = cutoffL / cutoffU of it" << endl
+         << "  -q,             quantile for the upper threshold derived from -h (default : 0.998 )" << endl << endl
+         << "Usage: PloidyFrost cutoffL kmer_histogram_file" << endl
+         << "Usage: PloidyFrost cutoffU kmer_histogram_file (quantile[<1 ,default:0.998])" << endl << endl
+         << "Not part of this build: `model`." << endl;
+}
+
+// lower threshold: 1.25 x the position of the first local minimum of the histogram (src/Main.cpp:200-235)
+int cutoffL(const string &file) {
+    ifstream f(file);
+    if (!f.is_open()) { cout << "ERROR:Open Histogram File " << file << " error!" << endl; exit(EXIT_FAILURE); }
+    vector<size_t> v;
+    string s;
+    while (getline(f, s, '\n')) {
+        const size_t pos1 = s.find("\t");
+        if (pos1 == string::npos) { cerr << "Error: Histogram File is badly Formatted." << endl; exit(EXIT_FAILURE); }
+        v.emplace_back((size_t)atoll(s.substr(pos1 + 1).c_str()));
+    }
+    size_t peak;
+    for (peak = 1; peak < v.size(); peak++)
+        if (v[peak - 1] < v[peak]) break;
+    return int(round(1.25 * ((double)peak - 1)));
+}
+
+// upper threshold: the multiplicity below which `frequency` of the k-mers beyond the first bin lie (src/Main.cpp:236-277)
+int cutoffH(const string &file, double frequency = 0.998) {
+    ifstream f(file);
+    if (!f.is_open()) { cout << "ERROR:Open Histogram File " << file << " error!" << endl; exit(EXIT_FAILURE); }
+    vector<size_t> v;
+    v.emplace_back(0);
+    string s;
+    while (getline(f, s, '\n')) {
+        const size_t pos1 = s.find("\t");
+        if (pos1 == string::npos) { cerr << "Error: Histogram File is badly Formatted." << endl; exit(EXIT_FAILURE); }
+        v.emplace_back((size_t)atoll(s.substr(pos1 + 1).c_str()) + v.back());
+    }
+    if (v.size() <= 2) { cerr << "Error: Histogram File is badly Formatted." << endl; exit(EXIT_FAILURE); }
+    const size_t cf = (size_t)(frequency * (double)(v.back() - v[1]) + (double)v[1]);
+    size_t peak;
+    for (peak = 2; peak < v.size(); peak++)
+        if (v[peak] > cf) break;
+    return (int)peak;
 }
 
 struct Options {
@@ -50,7 +94,7 @@ struct Options {
     bool verbose = false, info = false;
     int coverage_lower = 10, coverage_upper = 1000, k = 25;
     vector<pair<int, int>> coverage_vec;
-    double match = 2, mismatch = -1, gap = -3;
+    double match = 2, mismatch = -1, gap = -3, frequency = 0.998;
 };
 
 bool file_exists(const string &p) {
@@ -61,9 +105,29 @@ bool file_exists(const string &p) {
 
 int main(int argc, char **argv) {
     if (argc < 2) { PrintUsage(); return 0; }
-    if (!strcmp(argv[1], "model") || !strcmp(argv[1], "cutoffL") || !strcmp(argv[1], "cutoffU")) {
-        cerr << "Error: the `" << argv[1] << "` sub-command is not part of the MI355X build (hot path only)." << endl;
+    if (!strcmp(argv[1], "model")) {
+        cerr << "Error: the `model` sub-command is not part of the MI355X build (hot path only)." << endl;
         return EXIT_FAILURE;
+    }
+    if (!strcmp(argv[1], "cutoffL")) {  // src/Main.cpp:721-730
+        if (argc != 3) { cout << "Usage:PloidyFrost cutoffL kmer_histogram_file" << endl; exit(EXIT_FAILURE); }
+        cout << max(10, cutoffL(argv[2])) << endl;
+        return 0;
+    }
+    if (!strcmp(argv[1], "cutoffU")) {  // src/Main.cpp:731-762 (no newline after the value when a quantile is given)
+        const char *usage = "Usage:PloidyFrost cutoffU kmer_histogram_file (quantile[<1 ,default:0.998]) ";
+        if (argc == 3) {
+            cout << cutoffH(argv[2]) << endl;
+        } else if (argc == 4) {
+            double y;
+            try { y = stod(argv[3]); } catch (const exception &) { cout << usage << endl; exit(EXIT_FAILURE); }
+            if (y >= 1) { cout << usage << endl; exit(EXIT_FAILURE); }
+            cout << cutoffH(argv[2], y);
+        } else {
+            cout << usage << endl;
+            exit(EXIT_FAILURE);
+        }
+        return 0;
     }
     Options opt;
     int oc;
@@ -85,7 +149,8 @@ int main(int argc, char **argv) {
             case 'v': opt.verbose = true; break;
             case 'd': opt.db = optarg; break;
             case 'i': opt.info = true; break;
-            case 'q': case 'm': case 'n': case 'a': case 'b': case 'p': break;  // accepted, no effect on this path
+            case 'q': opt.frequency = atof(optarg); break;
+            case 'm': case 'n': case 'a': case 'b': case 'p': break;  // accepted, no effect on this path
             default:
                 cout << "Invalid option" << endl;
                 PrintUsage();
@@ -97,13 +162,17 @@ int main(int argc, char **argv) {
     const size_t max_threads = std::thread::hardware_concurrency();
     if ((long)opt.nb_threads <= 0) { cerr << "Error: Number of threads cannot be less than or equal to 0." << endl; ok = false; }
     if (opt.nb_threads > max_threads) { cerr << "Error: Number of threads cannot be greater than or equal to " << max_threads << "." << endl; ok = false; }
-    if (!opt.hist.empty()) { cerr << "Error: histogram-derived cutoffs (-h) are not part of this build; pass -l/-u or -C." << endl; ok = false; }
+    if (opt.frequency < 0 || opt.frequency > 1) { cerr << "Error: frequency cutoff value should be between 0 and 1 " << endl; ok = false; }
     size_t kmc_db_num = 0;
     if (opt.db.empty()) { cerr << "Error: Need input a kmc database prefix!\n"; ok = false; }
     else if (opt.colorfile.empty()) {
         if (!file_exists(opt.db + ".kmc_pre") || !file_exists(opt.db + ".kmc_suf")) {
             cerr << "Error: Could not read the input kmc database " << opt.db << "." << endl;
             ok = false;
+        }
+        if (!opt.hist.empty()) {  // :354-358
+            opt.coverage_lower = max(10, cutoffL(opt.hist));
+            opt.coverage_upper = cutoffH(opt.hist, opt.frequency);
         }
     } else {
         // :326-353: the -d file lists one database per line
@@ -120,6 +189,20 @@ int main(int argc, char **argv) {
                 }
             }
         }
+        if (!opt.hist.empty()) {  // :359-396: one histogram file per line, one per database
+            ifstream hin(opt.hist);
+            if (!file_exists(opt.hist) || hin.fail()) { ok = false; }
+            else {
+                string name;
+                size_t i = 0;
+                while (getline(hin, name, '\n')) {
+                    opt.coverage_vec.push_back({max(10, cutoffL(name)), cutoffH(name, opt.frequency)});
+                    if (opt.coverage_vec[i].first > opt.coverage_vec[i].second) { cerr << "Error: lower cutoff need be smaller than upper cutoff " << endl; ok = false; }
+                    i++;
+                }
+                if (i != kmc_db_num) { cerr << "ERROR: the numbers of kmc databases and hist files are not equal! " << endl; exit(EXIT_FAILURE); }
+            }
+        } else
         // :398-455: -C "lower\tupper" per database, default (10, 1000)
         if (!opt.coveragefile.empty()) {
             ifstream cin_(opt.coveragefile);

@@ -95,3 +95,24 @@ def test_cli_option_errors_mirror_the_reference():
     for msg in ("Could not read the input kmc database", "Maximum number of unitigs in superbubble is at least 4",
                 "Mismatch penalty should be smaller than match score", "The graph file does not exist", "Usage: PloidyFrost"):
         assert msg in r.stdout, msg
+
+
+def test_cli_cutoff_subcommands(tmp_path):
+    """cutoffL / cutoffU (reference src/Main.cpp:200-277, 721-762): thresholds from a k-mer histogram.  Expected values
+    are worked out by hand from the definitions; where the reference binary exists it must print the same bytes."""
+    cli = os.path.join(ROOT, "ploidyfrost_amd", "csrc", "ploidyfrost")
+    hist = tmp_path / "hist.txt"
+    counts = [900, 500, 200, 80, 60, 90, 150, 300, 420, 380, 260, 140, 70, 30, 12, 5, 2, 1]
+    hist.write_text("".join("%d\t%d\n" % (i + 1, c) for i, c in enumerate(counts)))
+    out = lambda *a: subprocess.run([cli] + list(a), stdout=subprocess.PIPE, text=True).stdout  # noqa: E731
+    # first rise is at index 5 (60 -> 90): round(1.25 * 4) = 5 -> max(10, 5)
+    assert out("cutoffL", str(hist)) == "10\n"
+    # k-mers beyond the first bin: 2700; 0.998 of them + 900 = 3594 -> the first prefix sum above it is that of bin 16 (3597)
+    assert out("cutoffU", str(hist)) == "16\n"
+    assert out("cutoffU", str(hist), "0.5") == "8"      # 900 + 1350 = 2250 < prefix(8) = 2280; no newline, as the reference
+    assert "Usage:PloidyFrost cutoffU" in out("cutoffU", str(hist), "1.5")
+    assert "Usage:PloidyFrost cutoffL" in out("cutoffL")
+    ref = os.path.join(ROOT, "oracle", "_ref", "PloidyFrost")
+    if os.path.exists(ref):
+        for args in (["cutoffL", str(hist)], ["cutoffU", str(hist)], ["cutoffU", str(hist), "0.5"], ["cutoffU", str(hist), "0.9"]):
+            assert subprocess.run([ref] + args, stdout=subprocess.PIPE, text=True).stdout == out(*args)
