@@ -117,8 +117,7 @@ int CDBG::join_pending_write() {
 CDBG::~CDBG() {
     join_pending_write();
     bx_.release_all();  // pinned buffers go before the context
-    ax_[0].release_all();
-    ax_[1].release_all();
+    for (auto &a : ax_) a.release_all();
     pf_destroy(ctx_);
 }
 
@@ -906,11 +905,11 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         // colored: the oriented unitigs the walks of each branching bubble visit (findUnitig of the site strings)
         std::vector<uint32_t> walk_ovs, walk_first;
     };
-    // The bubbles are processed in batches through a two-stage software pipeline: while stage 1 (its own host thread:
-    // path strings, K-BUBBLE, site strings, K-STRCOV -- every device call of this phase, a pf_ctx is not re-entrant)
-    // works on batch b+1, the calling thread turns batch b into text (stage 2: formatting).  Two sets of pinned
-    // exchange buffers go round.  Batches are consumed in order, so var_count and the output order are those of one
-    // sequential pass.
+    // The bubbles are processed in batches through a three-stage software pipeline: stage 1 (a host thread) builds the
+    // path strings of batch b+2, stage 2 (another thread, the only one issuing device calls in this phase -- a pf_ctx is
+    // not re-entrant) runs K-BUBBLE, the site strings and K-STRCOV of batch b+1, and the calling thread turns batch b
+    // into text and appends it to the result files (stage 3).  Three sets of pinned exchange buffers go round.  Batches
+    // are consumed in order, so var_count and the output order are those of one sequential pass.
     struct GroupRef { uint32_t first, count; };           // range of chunk-local string indices
     struct TaskSites {
         uint32_t group_first = 0;                          // index into the chunk's `groups`
@@ -934,12 +933,13 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         std::vector<uint32_t> dev_index;
         uint32_t n_dev = 0;
         double tasks_s = 0, align_s = 0;
+        uint64_t text_len = 0, n_paths = 0;
         int st = PF_OK;
         std::string err;
     };
     static const pf_bubble_result kNoResult = {0, 0, 0, 0, 0, 0, 0, 0};
-    // stage 1 of a batch (its own thread): path strings, SeqAlign on the device, site strings and their coverage
-    auto produce = [&](Batch &B) -> int {
+    // stage 1 of a batch (its own thread): path strings into the exchange buffers
+    auto prepare = [&](Batch &B) -> int {
         auto t0 = clk::now();
         AlignExchange &X = *B.ax;
         const Task *tasks = all_tasks.data() + B.batch0;
@@ -948,7 +948,6 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         std::vector<PathChunk> &pchunks = B.pchunks;
         std::vector<uint32_t> &dev_index = B.dev_index;
         uint32_t &n_dev = B.n_dev;
-        int st = PF_OK;
 
         // ---- paths: oriented inner unitigs are decoded on the device; the s->t walks of the branching
         //      bubbles are enumerated here (two-stack DFS of src/CDBG.cpp:1364-1412) ---------------
@@ -1046,11 +1045,25 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             std::vector<pf_bubble_path>().swap(pc.paths);
         });
         B.tasks_s = since(t0);
-
+        B.text_len = text_base[n_pch];
+        B.n_paths = path_base[n_pch];
+        return PF_OK;
+    };
+    // stage 2 of a batch (its own thread, the only one that talks to the device in this phase): SeqAlign on the
+    // device, site strings and their coverage
+    auto produce = [&](Batch &B) -> int {
+        AlignExchange &X = *B.ax;
+        const Task *tasks = all_tasks.data() + B.batch0;
+        const size_t NT = B.NT;
+        const size_t n_pch = n_chunks_of(NT, PCH);
+        std::vector<PathChunk> &pchunks = B.pchunks;
+        std::vector<uint32_t> &dev_index = B.dev_index;
+        const uint32_t n_dev = B.n_dev;
+        int st = PF_OK;
         // ---- align: SeqAlign::SequenceAlignment of every bubble, one wavefront each ------------------
-        t0 = clk::now();
+        auto t0 = clk::now();
         X.res.ensure(ctx_, std::max<uint32_t>(n_dev, 1));
-        uint64_t cap_text = std::max<uint64_t>(X.otext.cap, (text_base[n_pch] + 128ull * n_dev) * 2 + 4096);
+        uint64_t cap_text = std::max<uint64_t>(X.otext.cap, (B.text_len + 128ull * n_dev) * 2 + 4096);
         uint64_t cap_sites = std::max<uint64_t>(X.osites.cap, 4ull * n_dev + 64);
         uint64_t cap_groups = std::max<uint64_t>(X.ogroups.cap, 16ull * n_dev + 64);
         uint64_t cap_ilen = std::max<uint64_t>(X.oilen.cap, 2ull * n_dev + 64);
@@ -1060,7 +1073,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             X.ogroups.ensure(ctx_, cap_groups);
             X.oilen.ensure(ctx_, cap_ilen);
             uint64_t used[4];
-            st = pf_align_bubbles(ctx_, X.text.p, text_base[n_pch], X.paths.p, path_base[n_pch], X.tasks.p, n_dev, sc_.match,
+            st = pf_align_bubbles(ctx_, X.text.p, B.text_len, X.paths.p, B.n_paths, X.tasks.p, n_dev, sc_.match,
                                   sc_.mismatch, sc_.gap, X.res.p, X.otext.p, X.otext.cap, X.osites.p, X.osites.cap,
                                   X.ogroups.p, X.ogroups.cap, X.oilen.p, X.oilen.cap, used);
             if (st == PF_ERR_OVERFLOW && (used[0] > X.otext.cap || used[1] > X.osites.cap || used[2] > X.ogroups.cap ||
@@ -1259,7 +1272,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         return PF_OK;
     };
 
-    // stage 2 of a batch (the calling thread): formatting
+    // stage 3 of a batch (the calling thread): formatting and appending to the result files
     auto consume = [&](Batch &B) -> int {
         AlignExchange &X = *B.ax;
         const Task *tasks = all_tasks.data() + B.batch0;
@@ -1479,36 +1492,57 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     };
 
     {
+        constexpr size_t kRing = 3;  // sets of exchange buffers = batches in flight
         const size_t n_batches = (all_tasks.size() + CHUNK - 1) / CHUNK;
         std::vector<Batch> batches(n_batches);
         for (size_t b = 0; b < n_batches; ++b) {
             batches[b].batch0 = b * CHUNK;
             batches[b].NT = std::min(CHUNK, all_tasks.size() - b * CHUNK);
-            batches[b].ax = &ax_[b & 1];
+            batches[b].ax = &ax_[b % kRing];
         }
         std::mutex mu;
         std::condition_variable cv;
-        size_t produced = 0, consumed = 0;  // batches finished by stage 1 / stage 2
+        size_t prepared = 0, produced = 0, consumed = 0;  // batches finished by stage 1 / 2 / 3
         bool stop = false;
-        std::thread stage1;
-        if (n_batches > 1)
+        std::thread stage1, stage2;
+        if (n_batches > 1) {
             stage1 = std::thread([&] {
                 for (size_t b = 0; b < n_batches; ++b) {
-                    {  // the exchange buffers of batch b are those of batch b - 2
+                    {  // the exchange buffers of batch b are those of batch b - 3
                         std::unique_lock<std::mutex> lk(mu);
-                        cv.wait(lk, [&] { return stop || b < consumed + 2; });
+                        cv.wait(lk, [&] { return stop || b < consumed + kRing; });
                         if (stop) return;
                     }
-                    batches[b].st = produce(batches[b]);
+                    batches[b].st = prepare(batches[b]);
                     {
                         std::lock_guard<std::mutex> lk(mu);
-                        produced = b + 1;
+                        prepared = b + 1;
                         if (batches[b].st != PF_OK) stop = true;
                     }
                     cv.notify_all();
                     if (batches[b].st != PF_OK) return;
                 }
             });
+            stage2 = std::thread([&] {
+                for (size_t b = 0; b < n_batches; ++b) {
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        cv.wait(lk, [&] { return stop || prepared > b; });
+                        if (prepared <= b) return;  // stopped before this batch was prepared
+                        if (batches[b].st != PF_OK) { produced = b + 1; cv.notify_all(); return; }
+                    }
+                    const int st2 = produce(batches[b]);
+                    {
+                        std::lock_guard<std::mutex> lk(mu);
+                        batches[b].st = st2;
+                        produced = b + 1;
+                        if (st2 != PF_OK) stop = true;
+                    }
+                    cv.notify_all();
+                    if (st2 != PF_OK) return;
+                }
+            });
+        }
         int rc = PF_OK;
         std::string rc_err;
         for (size_t b = 0; b < n_batches && rc == PF_OK; ++b) {
@@ -1516,7 +1550,8 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return produced > b; });
             } else {
-                batches[b].st = produce(batches[b]);
+                batches[b].st = prepare(batches[b]);
+                if (batches[b].st == PF_OK) batches[b].st = produce(batches[b]);
             }
             Batch &B = batches[b];
             times_.tasks += B.NT;
@@ -1543,6 +1578,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             { std::lock_guard<std::mutex> lk(mu); stop = true; }
             cv.notify_all();
             stage1.join();
+            stage2.join();
         }
         if (rc != PF_OK) { close_files(); return rc_err.empty() ? status_ : fail(rc, rc_err); }
     }

@@ -127,7 +127,7 @@ protected:
     std::vector<uint8_t> flags_;
     std::vector<uint32_t> plus_, minus_;  // 0 = NULL, id = u + 1
 
-    // pinned exchange buffers of pf_align_bubbles, two sets: one per batch in flight (reused from pass to pass)
+    // pinned exchange buffers of pf_align_bubbles, three sets: one per batch in flight (reused from pass to pass)
     struct AlignExchange {
         PinnedBuf<char> text, otext;
         PinnedBuf<pf_bubble_path> paths;
@@ -140,7 +140,7 @@ protected:
             text.release(); otext.release(); paths.release(); tasks.release(); res.release(); osites.release();
             ogroups.release(); oilen.release();
         }
-    } ax_[2];
+    } ax_[3];
     size_t batch_bubbles_ = 1u << 16;
     // pinned buffers of the whole-graph device calls
     struct BubbleExchange {

@@ -198,3 +198,16 @@ def test_abundant_kmer_count_agrees_with_the_reference(tmp_path):
     assert moved == 25
     assert ref[: 5 + 15] == mine[: 5 + 15]                       # long unitigs and the first 15 sharers keep their rank
     assert set(ref[-moved:]) == set(mine[5 + 15: 5 + 40])       # the others are numbered last (in hash order)
+
+
+def test_work_pool(tmp_path):
+    """The host layer's persistent fork-join pool, on its own (no GPU, no library): tests/cpp/test_workpool.cpp."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "test_workpool")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(ROOT, "ploidyfrost_amd", "csrc", "host"),
+                    os.path.join(ROOT, "tests", "cpp", "test_workpool.cpp"), "-o", exe], check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
