@@ -145,20 +145,20 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
                     }
                     if (lane == 0) st.info[u >> 1] = new_info;
                     patch(u >> 1, new_info);
-                    bool all_pred = true;
-                    for (int j = 0; j < 4; ++j) {
-                        const uint32_t p = read_lane(my_pred, b * 4 + j);
-                        const uint32_t pm = decode(read_lane(my_pinfo, b * 4 + j));
-                        if (p == NONE) continue;
-                        if (pm != 0) {
-                            if ((pm & 3) != 1) all_pred = false;
-                            if (((pm >> 2) & 1) != ((p & 1) == 0 ? 1u : 0u)) {
-                                cyc_flag = true;
-                                if (!huge_cyc_add(st, epoch, n_cyc, u) || !huge_cyc_add(st, epoch, n_cyc, p)) { r.overflow = true; return r; }
-                            }
-                        } else {
-                            all_pred = false;
-                        }
+                    // the four predecessors of u sit in lanes 4b..4b+3 (with their state words, patched above):
+                    // judged by those lanes at once, two ballots instead of a scalar walk over them
+                    const uint32_t pm_l = decode(my_pinfo);
+                    const bool p_valid = lane < 16 && my_pred != NONE;
+                    const bool p_blocks = p_valid && (pm_l == 0 || (pm_l & 3) != 1);
+                    const bool p_strand = p_valid && pm_l != 0 && (((pm_l >> 2) & 1) != ((my_pred & 1) == 0 ? 1u : 0u));
+                    const unsigned long long group = 0xFull << (4 * b);
+                    const bool all_pred = (__ballot(p_blocks) & group) == 0;
+                    unsigned long long bad = __ballot(p_strand) & group;
+                    while (bad) {  // ascending j, as the reference's loop over the predecessors
+                        const int l = __ffsll((long long)bad) - 1;
+                        bad &= bad - 1;
+                        cyc_flag = true;
+                        if (!huge_cyc_add(st, epoch, n_cyc, u) || !huge_cyc_add(st, epoch, n_cyc, read_lane(my_pred, l))) { r.overflow = true; return r; }
                     }
                     if (all_pred) {
                         if (top >= 2 * st.n_unitigs + 8) { r.overflow = true; return r; }
