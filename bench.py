@@ -301,6 +301,15 @@ def main():
                 e = kernels[dom]
                 roof = {"kernel": dom, "bound": "hbm", "achieved": e["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
                         "frac": round(e["achieved_GBps"] / 8000.0, 5), "traffic": load_traffic(dom)}
+            # the streaming kernel of the path, next to the dominant one: K-COV is the kernel SURVEY.md 8(d) names as able to
+            # approach the HBM roof; `traffic_frac` = PMC-measured HBM bytes per launch / its duration / peak
+            roof_cov = None
+            if "k_cov" in kernels:
+                e = kernels["k_cov"]
+                tr = load_traffic("k_cov")
+                roof_cov = {"kernel": "k_cov", "bound": "hbm", "achieved": e["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+                            "frac": round(e["achieved_GBps"] / 8000.0, 5), "traffic": tr,
+                            "traffic_frac": round(tr / (e["avg_ms"] * 1e-3) / 8e12, 4) if tr else None}
             cpu = None
             if not args.no_cpu_baseline:
                 cpu = cpu_baseline(workdir, args.cpu_sample_unitigs, dev)
@@ -314,7 +323,7 @@ def main():
                            "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
                            "partitioning": "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
                                            "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0]},
-                "roofline": roof, "cpu_baseline": cpu,
+                "roofline": roof, "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "kernels": kernels,
                 "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},
                 "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"], "bubbles_called": tt["tasks"],
