@@ -411,6 +411,45 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
             snp_only = read_lane((uint32_t)wave_sum_u64(diff), 0) == 1;
         }
         uint32_t nh, tu, gu;
+        if (snp_only && N == 2) {
+            // ... and with only these two paths there is nothing left to choose or classify: the answer is the two rows,
+            // one SNP column, groups {1, 2} (what classify + publish below produce for such rows)
+            const char *x = path_ptr(0), *y = path_ptr(1);
+            uint32_t my_pos = 0;
+            bool mine = false;
+            for (uint32_t t = lane; t < m; t += WAVE)
+                if (x[t] != y[t]) { my_pos = t; mine = true; }
+            const uint32_t col = read_lane(my_pos, __ffsll((long long)__ballot(mine)) - 1);
+            const unsigned long long t0 = bub_take(o, al, 0, 2ull * m, 4096);
+            const unsigned long long s0 = bub_take(o, al, 1, 1, 64);
+            const unsigned long long g0 = bub_take(o, al, 2, 2, 256);
+            const unsigned long long l0 = bub_take(o, al, 3, 0, 32);
+            pf_bubble_result res;
+            memset(&res, 0, sizeof(res));
+            res.rows_off = t0;
+            res.site_off = s0;
+            res.group_off = g0;
+            res.ilen_off = l0;
+            res.n_rows = 2;
+            res.n_cols = m;
+            res.n_sites = 1;
+            res.n_indel_len = 0;
+            if (lane == 0) o.res[job] = res;
+            if (t0 + 2ull * m > o.text_cap || s0 + 1 > o.site_cap || g0 + 2 > o.group_cap || l0 > o.ilen_cap) return 0;
+            for (uint32_t t = lane; t < 2 * m; t += WAVE) o.text[t0 + t] = x[t];  // paths 0 and 1 are adjacent in pbuf
+            if (lane == 0) {
+                o.groups[g0] = 1;
+                o.groups[g0 + 1] = 2;
+                pf_bubble_site sr;
+                sr.col = col;
+                sr.is_indel = 0;
+                sr.maxnum = 2;
+                sr.pad_ = 0;
+                o.sites[s0] = sr;
+            }
+            mark(6);
+            return 0;
+        }
         if (snp_only) {
             if (m > C.row || 2ull * m > C.arena || C.list < 1) return 1;
             const char *src = path_ptr(0);  // paths 0 and 1 are adjacent in pbuf: the two rows, as traceback would emit them
