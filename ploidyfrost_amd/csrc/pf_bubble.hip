@@ -86,6 +86,7 @@ struct BubParams {
     uint32_t work_bytes;    // bytes available per wave for one NW job (LDS or global)
     int final_tier;
     unsigned long long *task_clk;  // diagnostic: per-task wall clock ticks (100 MHz), or nullptr
+    unsigned int *next;            // work queue head of this launch
     unsigned long long *prof;      // diagnostic: [0] fill [1] traceback [2] decode [3] round0 copy [4] rounds [5] choose [6] publish
 };
 
@@ -693,7 +694,13 @@ __global__ __launch_bounds__(64) void k_bubble(BubParams p, BubOut o) {
     else nw_base = p.work + (uint64_t)blockIdx.x * p.work_per_wave;
     uint8_t *scr = p.scratch + (uint64_t)blockIdx.x * p.scratch_per_wave;
     BubAlloc al;
-    for (uint32_t q = blockIdx.x; q < p.n; q += gridDim.x) {
+    // Tasks are handed out through one counter per launch (the host lists the multi-path ones first): a bubble
+    // costs anything between 10 us and 2 ms, so a static split leaves most waves idle behind the unlucky ones.
+    for (;;) {
+        uint32_t q = 0;
+        if (lane_id() == 0) q = atomicAdd(p.next, 1u);
+        q = read_lane(q, 0);
+        if (q >= p.n) break;
         const uint32_t job = p.idx[q];
         const unsigned long long c0 = p.task_clk ? wall_clock64() : 0;
         const int rc = bubble_task<LDS>(p, o, al, job, nw_base, scr);
@@ -751,6 +758,8 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     const std::vector<uint32_t> &hlen = ctx->h_len;  // unitig lengths for ov paths
     const uint64_t cls_bytes[3] = {5 * 1024, 20 * 1024, 64 * 1024};
     std::vector<uint32_t> cls[4];
+    std::vector<char> heavy;
+    heavy.reserve(n_tasks);
     uint64_t max_need = 0;
     for (uint32_t t = 0; t < n_tasks; ++t) {
         const pf_bubble_task &tk = ht[t];
@@ -778,8 +787,11 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         for (int x = 0; x < 3; ++x)
             if (need <= cls_bytes[x]) { c = x; break; }
         cls[c].push_back(t);
+        heavy.push_back(tk.n_paths > 2 || lmax > 64);
         if (c == 3) max_need = std::max(max_need, need);
     }
+    for (auto &v : cls)  // multi-path / long bubbles first (stable: the order inside each half is kept)
+        std::stable_partition(v.begin(), v.end(), [&](uint32_t t) { return heavy[t]; });
     // device inputs
     const char *d_text = text;
     if (text_len && !is_dev(text)) {
@@ -790,13 +802,13 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     }
     pf_bubble_path *d_paths = (pf_bubble_path *)ctx_ws(ctx, WS_BUB_PATHS, std::max<uint64_t>(n_paths, 1) * sizeof(pf_bubble_path));
     pf_bubble_task *d_tasks = (pf_bubble_task *)ctx_ws(ctx, WS_BUB_TASKS, (size_t)n_tasks * sizeof(pf_bubble_task));
-    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 64);
+    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 128);  // pool heads, retry count, one queue head per launch
     uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_BUB_RETRY, (size_t)n_tasks * 4);
     uint32_t *d_idx = (uint32_t *)ctx_ws(ctx, WS_BUB_IDX, (size_t)n_tasks * 4);
     if (!d_paths || !d_tasks || !small || !d_retry || !d_idx) return PF_ERR_HIP;
     PF_HIP(hipMemcpyAsync(d_paths, hp, (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyHostToDevice, st));
     PF_HIP(hipMemcpyAsync(d_tasks, ht, (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyHostToDevice, st));
-    PF_HIP(hipMemsetAsync(small, 0, 64, st));
+    PF_HIP(hipMemsetAsync(small, 0, 128, st));
     const bool dev_out = is_dev(results);
     BubOut o;
     if (dev_out) {
@@ -812,6 +824,8 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     o.text_cap = text_cap; o.site_cap = site_cap; o.group_cap = group_cap; o.ilen_cap = ilen_cap;
     o.heads = reinterpret_cast<unsigned long long *>(small);
     o.n_retry = reinterpret_cast<unsigned int *>(small + 40);
+    unsigned int *queue_heads = reinterpret_cast<unsigned int *>(small + 64);
+    int n_launch = 0;
     o.retry = d_retry;
 
     BubParams p;
@@ -854,6 +868,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         p.work_bytes = (uint32_t)cls_bytes[c];
         const int per_cu = c == 0 ? 24 : (c == 1 ? 7 : 2);
         const int grid = (int)std::min<uint32_t>(nc, (uint32_t)(ctx->n_cu * per_cu));
+        p.next = queue_heads + n_launch++;
         ctx_begin(ctx, PF_K_BUBBLE);
         k_bubble<true><<<grid, 64, cls_bytes[c], st>>>(p, o);
         ctx_end(ctx);
@@ -871,6 +886,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         p.work = work;
         p.work_per_wave = per;
         p.work_bytes = (uint32_t)std::min<uint64_t>(per, 0xFFFFFFFFu);
+        p.next = queue_heads + n_launch++;
         ctx_begin(ctx, PF_K_BUBBLE_BIG);
         k_bubble<false><<<grid, 64, 0, st>>>(p, o);
         ctx_end(ctx);
@@ -900,6 +916,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         PF_HIP(hipMemcpyAsync(d_idx, rj.data(), (size_t)n_retry * 4, hipMemcpyHostToDevice, st));
         p.idx = d_idx; p.n = n_retry; p.caps = big; p.scratch = big_scratch; p.scratch_per_wave = per_s;
         p.work = big_work; p.work_per_wave = per_w; p.work_bytes = (uint32_t)per_w; p.final_tier = 1;
+        p.next = queue_heads + n_launch++;
         ctx_begin(ctx, PF_K_BUBBLE_BIG);
         k_bubble<false><<<grid, 64, 0, st>>>(p, o);
         ctx_end(ctx);
