@@ -12,6 +12,7 @@
 #include <cstring>
 #include <ctime>
 #include <condition_variable>
+#include <deque>
 #include <mutex>
 #include <set>
 #include <thread>
@@ -1490,10 +1491,41 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         std::vector<ChunkOut>().swap(outs);
         write_s += since(tw);
     };
+    // stage 4: a writer thread appends the finished batches, in order, while the next ones are formatted
+    std::mutex wmu;
+    std::condition_variable wcv;
+    std::deque<std::vector<ChunkOut> *> wqueue;
+    bool wdone = false;
+    std::thread writer([&] {
+        for (;;) {
+            std::vector<ChunkOut> *outs = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(wmu);
+                wcv.wait(lk, [&] { return wdone || !wqueue.empty(); });
+                if (wqueue.empty()) return;
+                outs = wqueue.front();
+                wqueue.pop_front();
+            }
+            write_batch(*outs);
+        }
+    });
+    struct WriterGuard {  // joined on every way out
+        std::thread &t;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &done;
+        ~WriterGuard() {
+            if (!t.joinable()) return;
+            { std::lock_guard<std::mutex> lk(mu); done = true; }
+            cv.notify_all();
+            t.join();
+        }
+    } writer_guard{writer, wmu, wcv, wdone};
 
     {
         constexpr size_t kRing = 3;  // sets of exchange buffers = batches in flight
         const size_t n_batches = (all_tasks.size() + CHUNK - 1) / CHUNK;
+        all_outs.reserve(n_batches);  // the writer holds pointers to its elements
         std::vector<Batch> batches(n_batches);
         for (size_t b = 0; b < n_batches; ++b) {
             batches[b].batch0 = b * CHUNK;
@@ -1562,7 +1594,10 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             times_.site_strings += B.site_strings;
             if (B.st != PF_OK) { rc = B.st; rc_err = B.err; break; }
             rc = consume(B);
-            if (rc == PF_OK) write_batch(all_outs.back());
+            if (rc == PF_OK) {
+                { std::lock_guard<std::mutex> lk(wmu); wqueue.push_back(&all_outs.back()); }
+                wcv.notify_all();
+            }
             std::vector<PathChunk>().swap(B.pchunks);
             std::vector<uint32_t>().swap(B.dev_index);
             std::vector<SiteChunk>().swap(B.schunks);
@@ -1580,10 +1615,21 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             stage1.join();
             stage2.join();
         }
-        if (rc != PF_OK) { close_files(); return rc_err.empty() ? status_ : fail(rc, rc_err); }
+        if (rc != PF_OK) {
+            { std::lock_guard<std::mutex> lk(wmu); wdone = true; }
+            wcv.notify_all();
+            writer.join();
+            close_files();
+            return rc_err.empty() ? status_ : fail(rc, rc_err);
+        }
     }
 
 
+    {
+        { std::lock_guard<std::mutex> lk(wmu); wdone = true; }
+        wcv.notify_all();
+        writer.join();
+    }
     tp("pipeline done");
     t0 = clk::now();
     if (join_pending_write()) { close_files(); return status_; }
