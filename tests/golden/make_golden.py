@@ -77,6 +77,25 @@ def weird_haplotypes(seed: int, n: int = 12000) -> list[np.ndarray]:
     return [h0, h1]
 
 
+def reads_case(seed=61, genome_len=20000, n_reads=10000, read_len=100, err=0.0006):
+    """BASELINE.json configs[0]: a diploid genome sampled by 10 k error-bearing reads -- the graph Bifrost builds from
+    *reads* with every k-mer kept (`build -r`) has the tips, error bubbles inside real bubbles and count-1 k-mers that
+    haplotype-built graphs lack.  Returns the reads; counts come from the reads themselves."""
+    haps = synth.make_haplotypes(synth.HapSpec(genome_len, 2, seed=seed, gap_lo=40, gap_hi=400))
+    rng = np.random.default_rng(seed + 1)
+    reads = []
+    for _ in range(n_reads):
+        h = haps[int(rng.integers(0, 2))]
+        a = int(rng.integers(0, len(h) - read_len + 1))
+        r = h[a: a + read_len].copy()
+        hit = rng.random(read_len) < err
+        r[hit] = (r[hit] + rng.integers(1, 4, size=int(hit.sum())).astype(np.uint8)) & 3
+        if rng.random() < 0.5:
+            r = (3 - r)[::-1]
+        reads.append(r)
+    return reads
+
+
 CASES = {
     # name: (haplotype factory, k, PloidyFrost args)
     "dip20k": (lambda: synth.make_haplotypes(synth.HapSpec(20000, 2, seed=7)), 25, ["-l", "5", "-u", "1000"]),
@@ -94,6 +113,8 @@ CASES = {
     "cutoff": (lambda: synth.make_haplotypes(synth.HapSpec(30000, 4, seed=29, gap_lo=10, gap_hi=200)), 25,
                ["-l", "25", "-u", "70"]),
     # the same kind of data with the count database in the KMC2 layout (signature-binned prefix table)
+    # graph built from reads, counts = k-mer multiplicities in the reads
+    "reads10k": (reads_case, 25, ["-l", "3", "-u", "1000"], "kmc1", "reads"),
     "dip_kmc2": (lambda: synth.make_haplotypes(synth.HapSpec(16000, 2, seed=31)), 25, ["-l", "5", "-u", "1000"], "kmc2"),
 }
 
@@ -156,6 +177,7 @@ def run(cmd, **kw):
 def make_case(name: str) -> None:
     factory, k, args = CASES[name][:3]
     layout = CASES[name][3] if len(CASES[name]) > 3 else "kmc1"
+    from_reads = len(CASES[name]) > 4 and CASES[name][4] == "reads"
     out = os.path.join(HERE, name)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(os.path.join(out, "expected"))
@@ -163,10 +185,11 @@ def make_case(name: str) -> None:
     with tempfile.TemporaryDirectory() as tmp:
         fa = os.path.join(tmp, "haps.fa")
         synth.write_fasta(fa, haps)
-        run([os.path.join(REF, "Bifrost"), "build", "-r", fa, "-k", str(k), "-o", os.path.join(tmp, "graph"), "-t", "1"])
+        run([os.path.join(REF, "Bifrost"), "build", "-r", fa, "-k", str(k), "-o", os.path.join(tmp, "graph"),
+             "-t", "1"])
         shutil.copy(os.path.join(tmp, "graph.gfa"), os.path.join(out, "graph.gfa"))
         km, mult = synth.canonical_counts(haps, k)
-        cnt = synth.synth_counts(km, mult)
+        cnt = mult.astype(np.uint32) if from_reads else synth.synth_counts(km, mult)
         if layout == "kmc2":
             synth.write_kmc2(os.path.join(out, "db"), km, cnt, k, sig_len=7, n_bins=11)
         else:
