@@ -344,58 +344,116 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     std::fill(plus_.begin(), plus_.end(), 0);
     std::fill(minus_.begin(), minus_.end(), 0);
 
-    // every candidate entrance is traversed on the device, one wavefront each
+    // Every candidate entrance is traversed on the device, one wavefront each.  The unitig range is cut into slices:
+    // a helper thread (the only one issuing device calls here) runs K-BFS slice by slice and, after the last one, the
+    // coverage kernel PloidyEstimation starts with -- while this thread replays the records of the finished slices in
+    // the reference's visiting order, with its `partner == NULL` gate (src/CDBG.cpp:206, 211): records come in
+    // ascending oriented-vertex order = unitig order, '+' before '-'.
     auto t0 = clk::now();
-    uint64_t n_cand = 0;
-    int st = pf_count_candidates(ctx_, 0, N, &n_cand);
-    if (st != PF_OK) return fail(st, pf_last_error(ctx_));
-    // pinned, reused from pass to pass; the pool guess leaves room for the per-wave chunk slack
-    bx_.bfs_rec.ensure(ctx_, std::max<uint64_t>(n_cand, 1));
-    bx_.bfs_pool.ensure(ctx_, std::max<uint64_t>(n_cand * 6 + (4u << 20), 1024));
+    constexpr int kSlices = 4;
+    uint32_t s_u0[kSlices + 1];
+    uint64_t s_cand[kSlices], s_rec0[kSlices + 1], s_pool0[kSlices + 1], s_nrec[kSlices], s_used[kSlices];
+    s_rec0[0] = s_pool0[0] = 0;
+    for (int i = 0; i <= kSlices; ++i) s_u0[i] = (uint32_t)((uint64_t)N * i / kSlices);
+    for (int i = 0; i < kSlices; ++i) {
+        int st0 = pf_count_candidates(ctx_, s_u0[i], s_u0[i + 1], &s_cand[i]);
+        if (st0 != PF_OK) return fail(st0, pf_last_error(ctx_));
+        s_rec0[i + 1] = s_rec0[i] + std::max<uint64_t>(s_cand[i], 1);
+        // the pool guess leaves room for the per-wave chunk slack
+        s_pool0[i + 1] = s_pool0[i] + s_cand[i] * 6 + (1u << 20);
+        s_nrec[i] = s_used[i] = 0;
+    }
+    // pinned, reused from pass to pass
+    bx_.bfs_rec.ensure(ctx_, s_rec0[kSlices]);
+    bx_.bfs_pool.ensure(ctx_, s_pool0[kSlices]);
     pf_bfs_record *rec = bx_.bfs_rec.p;
-    uint64_t n_rec = 0, used = 0;
-    for (;;) {
-        st = pf_bfs_candidates(ctx_, 0, N, rec, bx_.bfs_rec.cap, bx_.bfs_pool.p, bx_.bfs_pool.cap, &n_rec, &used);
-        if (st == PF_ERR_OVERFLOW && used > bx_.bfs_pool.cap) { bx_.bfs_pool.ensure(ctx_, used + used / 8); continue; }
-        break;
-    }
-    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
-    times_.bfs_device_s = since(t0);
-    times_.candidates = n_rec;
-
-    // sequential replay in the reference's visiting order, with its `partner == NULL` gate
-    // (src/CDBG.cpp:206, 211): records are in ascending oriented-vertex order = unitig order,
-    // '+' before '-'.
-    t0 = clk::now();
-    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;
-    const uint32_t *pool = bx_.bfs_pool.p;
-    for (uint64_t i = 0; i < n_rec; ++i) {
-        // the commits chase per-unitig state at random: pull the state of a record a few iterations ahead into cache
-        if (i + 12 < n_rec) {
-            const pf_bfs_record &nx = rec[i + 12];
-            __builtin_prefetch(pool + nx.list_off);
-            __builtin_prefetch(&plus_[nx.entrance >> 1]);
-            __builtin_prefetch(&minus_[nx.entrance >> 1]);
-        }
-        if (i + 6 < n_rec) {
-            const pf_bfs_record &nx = rec[i + 6];
-            const uint32_t *l = pool + nx.list_off;
-            const uint32_t nl = nx.n_list < 6 ? nx.n_list : 6;
-            for (uint32_t q = 0; q < nl; ++q) {
-                const uint32_t w = l[q] >> 1;
-                __builtin_prefetch(&flags_[w]);
-                __builtin_prefetch(&plus_[w]);
-                __builtin_prefetch(&minus_[w]);
+    // a slice whose pool guess was too small gets a buffer of its own
+    std::vector<std::unique_ptr<PinnedBuf<uint32_t>>> own_pool(kSlices);
+    const uint32_t *slice_pool[kSlices];
+    std::mutex mu;
+    std::condition_variable cv;
+    int done = 0, dev_st = PF_OK;
+    std::string dev_err;
+    double bfs_s = 0;
+    const bool prefetch_cov = overlap_output_;  // the same switch: work of the next call started behind the caller's back
+    cov_ready_ = false;
+    std::thread device([&] {
+        for (int i = 0; i < kSlices; ++i) {
+            const auto tb = clk::now();
+            uint32_t *pl = bx_.bfs_pool.p + s_pool0[i];
+            uint64_t cap = s_pool0[i + 1] - s_pool0[i];
+            int st1;
+            for (;;) {
+                st1 = pf_bfs_candidates(ctx_, s_u0[i], s_u0[i + 1], rec + s_rec0[i], s_rec0[i + 1] - s_rec0[i], pl, cap, &s_nrec[i], &s_used[i]);
+                if (st1 == PF_ERR_OVERFLOW && s_used[i] > cap) {
+                    own_pool[i] = std::make_unique<PinnedBuf<uint32_t>>();
+                    own_pool[i]->ensure(ctx_, s_used[i] + s_used[i] / 8);
+                    pl = own_pool[i]->p;
+                    cap = own_pool[i]->cap;
+                    continue;
+                }
+                break;
             }
+            bfs_s += since(tb);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                slice_pool[i] = pl;
+                if (st1 != PF_OK) { dev_st = st1; dev_err = pf_last_error(ctx_); }
+                done = i + 1;
+            }
+            cv.notify_all();
+            if (st1 != PF_OK) return;
         }
-        const pf_bfs_record &r = rec[i];
-        if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
-        if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
-        const uint32_t u = r.entrance >> 1;
-        if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
-        replay(r, bx_.bfs_pool.p + r.list_off);
+        if (prefetch_cov) cov_ready_ = launch_coverage() == PF_OK;
+    });
+    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;
+    uint64_t n_rec_total = 0;
+    double replay_s = 0;
+    int st = PF_OK;
+    for (int sl = 0; sl < kSlices; ++sl) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done > sl || dev_st != PF_OK; });
+            if (done <= sl || (dev_st != PF_OK && done == sl + 1)) { st = dev_st; break; }
+        }
+        const auto tr = clk::now();
+        const pf_bfs_record *srec = rec + s_rec0[sl];
+        const uint64_t n_rec = s_nrec[sl];
+        const uint32_t *pool = slice_pool[sl];
+        n_rec_total += n_rec;
+        for (uint64_t i = 0; i < n_rec; ++i) {
+            // the commits chase per-unitig state at random: pull the state of a record a few iterations ahead into cache
+            if (i + 12 < n_rec) {
+                const pf_bfs_record &nx = srec[i + 12];
+                __builtin_prefetch(pool + nx.list_off);
+                __builtin_prefetch(&plus_[nx.entrance >> 1]);
+                __builtin_prefetch(&minus_[nx.entrance >> 1]);
+            }
+            if (i + 6 < n_rec) {
+                const pf_bfs_record &nx = srec[i + 6];
+                const uint32_t *l = pool + nx.list_off;
+                const uint32_t nl = nx.n_list < 6 ? nx.n_list : 6;
+                for (uint32_t q = 0; q < nl; ++q) {
+                    const uint32_t w = l[q] >> 1;
+                    __builtin_prefetch(&flags_[w]);
+                    __builtin_prefetch(&plus_[w]);
+                    __builtin_prefetch(&minus_[w]);
+                }
+            }
+            const pf_bfs_record &r = srec[i];
+            if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
+            if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
+            const uint32_t u = r.entrance >> 1;
+            if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
+            replay(r, pool + r.list_off);
+        }
+        replay_s += since(tr);
     }
-    times_.replay_s = since(t0);
+    device.join();
+    if (st != PF_OK || dev_st != PF_OK) return fail(dev_st != PF_OK ? dev_st : st, std::string("CDBG::findSuperBubble(): ") + dev_err);
+    times_.bfs_device_s = bfs_s;
+    times_.candidates = n_rec_total;
+    times_.replay_s = replay_s;
     if (!quiet_) {
         printf("%s::findSuperBubble():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
         printf("%s::findSuperBubble():  Real time : %gs\n", tag_, since(t_all));
@@ -465,6 +523,21 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     times_.find_total_s = since(t_all);
     if (!quiet_) printf("%s::findSuperBubble(): %llu  SuperBubbles Found\n", tag_, (unsigned long long)nb);
     return 0;
+}
+
+// K-COV (colored: K-COV-C) for all unitigs into the pinned result buffers.  A missing k-mer is not an error here: the
+// single-sample path raises it only for the unitigs it really uses, the colored path never (src/CCDBG.cpp:113-117).
+int CDBG::launch_coverage() {
+    const uint32_t N = g_.n();
+    const uint32_t C = col_ ? col_->n_colors : 1;
+    bx_.cov_sum.ensure(ctx_, (size_t)N * C);
+    bx_.cov_min.ensure(ctx_, (size_t)N * C);
+    bx_.cov_miss.ensure(ctx_, (size_t)N * C);
+    if (col_) bx_.cov_max.ensure(ctx_, (size_t)N * C);
+    const int st = col_ ? pf_unitig_cov_colored(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_max.p, bx_.cov_miss.p)
+                        : pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
+    if (st != PF_OK && st != PF_ERR_MISSING_KMER) { cov_err_ = pf_last_error(ctx_); return st; }
+    return PF_OK;
 }
 
 // ---- sorting of the paths -----------------------------------------------------------------
@@ -667,19 +740,17 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
 
     const bool trace = getenv("PF_TRACE_PLOIDY") != nullptr;
     auto tp = [&](const char *what) { if (trace) fprintf(stderr, "[ploidy] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
-    // C1 for every unitig (and, colored, every colour) in one launch (the reference calls readCov per use)
+    // C1 for every unitig (and, colored, every colour) in one launch (the reference calls readCov per use); already
+    // there when findSuperBubble started it behind its replay
     auto t0 = clk::now();
-    bx_.cov_sum.ensure(ctx_, (size_t)N * C);
-    bx_.cov_min.ensure(ctx_, (size_t)N * C);
-    bx_.cov_miss.ensure(ctx_, (size_t)N * C);
-    if (colored) bx_.cov_max.ensure(ctx_, (size_t)N * C);
+    int st = PF_OK;
+    if (!cov_ready_) st = launch_coverage();
+    cov_ready_ = false;
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + cov_err_);
     const uint64_t *cov_sum = bx_.cov_sum.p;
     const uint32_t *cov_min = bx_.cov_min.p;
     const uint32_t *cov_max = bx_.cov_max.p;
     const uint8_t *cov_miss = bx_.cov_miss.p;
-    int st = colored ? pf_unitig_cov_colored(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_max.p, bx_.cov_miss.p)
-                     : pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
-    if (st != PF_OK && st != PF_ERR_MISSING_KMER) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
     times_.cov_device_s = since(t0);
     tp("coverage done");
     auto mean_of = [&](uint32_t u) { return (double)cov_sum[u] / (double)g_.len_km(u); };

@@ -97,6 +97,9 @@ protected:
     struct Task;
     int fail(int st, const std::string &msg);
     int join_pending_write();
+    int launch_coverage();
+    bool cov_ready_ = false;  // the coverage arrays in bx_ are those of the current graph and count table
+    std::string cov_err_;
     bool overlap_output_ = false;
     std::thread pending_write_;
     std::vector<std::string> pending_pieces_;
