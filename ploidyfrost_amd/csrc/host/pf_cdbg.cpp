@@ -350,9 +350,13 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // the reference's visiting order, with its `partner == NULL` gate (src/CDBG.cpp:206, 211): records come in
     // ascending oriented-vertex order = unitig order, '+' before '-'.
     auto t0 = clk::now();
-    constexpr int kSlices = 4;
-    uint32_t s_u0[kSlices + 1];
-    uint64_t s_cand[kSlices], s_rec0[kSlices + 1], s_pool0[kSlices + 1], s_nrec[kSlices], s_used[kSlices];
+    // Slicing costs when a graph has chromosome-long traversals: each slice would run its own serially instead of all of
+    // them side by side.  So the first pass over a graph is one slice, and later passes are sliced only if none was seen.
+    constexpr int kMaxSlices = 4;
+    const int kSlices = (find_passes_ > 0 && times_.bfs_large == 0) ? kMaxSlices : 1;
+    ++find_passes_;
+    uint32_t s_u0[kMaxSlices + 1];
+    uint64_t s_cand[kMaxSlices], s_rec0[kMaxSlices + 1], s_pool0[kMaxSlices + 1], s_nrec[kMaxSlices], s_used[kMaxSlices];
     s_rec0[0] = s_pool0[0] = 0;
     for (int i = 0; i <= kSlices; ++i) s_u0[i] = (uint32_t)((uint64_t)N * i / kSlices);
     for (int i = 0; i < kSlices; ++i) {
@@ -369,7 +373,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     pf_bfs_record *rec = bx_.bfs_rec.p;
     // a slice whose pool guess was too small gets a buffer of its own
     std::vector<std::unique_ptr<PinnedBuf<uint32_t>>> own_pool(kSlices);
-    const uint32_t *slice_pool[kSlices];
+    const uint32_t *slice_pool[kMaxSlices];
     std::mutex mu;
     std::condition_variable cv;
     int done = 0, dev_st = PF_OK;
@@ -406,7 +410,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         }
         if (prefetch_cov) cov_ready_ = launch_coverage() == PF_OK;
     });
-    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;
+    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;  // (kSlices above looked at the previous pass)
     uint64_t n_rec_total = 0;
     double replay_s = 0;
     int st = PF_OK;

@@ -98,6 +98,7 @@ protected:
     int fail(int st, const std::string &msg);
     int join_pending_write();
     int launch_coverage();
+    uint64_t find_passes_ = 0;
     bool cov_ready_ = false;  // the coverage arrays in bx_ are those of the current graph and count table
     std::string cov_err_;
     bool overlap_output_ = false;
