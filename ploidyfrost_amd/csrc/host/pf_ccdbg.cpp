@@ -1,0 +1,85 @@
+// pfh::ColoredUnitigSet and pfh::CCDBG: the colored (multi-sample) front end, reference src/CCDBG.cpp.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <mutex>
+#include <set>
+#include <stdexcept>
+#include <thread>
+
+#include "pf_cdbg_impl.hpp"
+#include "pf_parallel.hpp"
+
+namespace pfh {
+
+// ---- colored graph + CCDBG (reference src/CCDBG.cpp) -------------------------------------------------
+bool ColoredUnitigSet::read(const std::string &graphfile, const std::string &colorfile, size_t nb_threads, bool verbose) {
+    if (verbose) printf("ColoredCDBG::read(): Reading graph.\n");
+    if (!graph.load_gfa(graphfile, err)) return false;
+    if (verbose) printf("ColoredCDBG::read(): Reading colors.\n");
+    return colors.load(colorfile, graph, (unsigned)std::max<size_t>(nb_threads, 1), err);
+}
+
+CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db_list,
+             const size_t &thread, int device, bool quiet)
+    : CDBG(graph.graph, complexsize, m, d, g, device, quiet, NoCounts{}), cg_(graph) {
+    if (status_) return;
+    col_ = &cg_.colors;
+    const uint32_t C = cg_.colors.n_colors;
+    if (C > PF_MAX_COLORS) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: more colours than the device table holds"); return; }
+    if (!kmc_db_list.empty()) {
+        // src/CCDBG.cpp:13-43: one database name per line, one line per colour
+        FILE *f = fopen(kmc_db_list.c_str(), "r");
+        if (!f) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: Open kmc database name file error"); return; }
+        std::vector<std::string> names;
+        {
+            std::string cur;
+            int ch;
+            while ((ch = fgetc(f)) != EOF) {
+                if (ch == '\n') { names.push_back(cur); cur.clear(); }
+                else cur.push_back((char)ch);
+            }
+            if (!cur.empty()) names.push_back(cur);
+            fclose(f);
+        }
+        names.resize(C);  // missing lines read as empty names, which fail to open below as in the reference
+        std::vector<KmcRecords> dbs(C);
+        std::vector<std::string> errs(C);
+        std::vector<int> bad(C, 0);
+        parallel_chunks(C, 1, (unsigned)std::max<size_t>(thread, 1), [&](size_t c, size_t, size_t) { bad[c] = !dbs[c].load(names[c], errs[c]); });
+        for (uint32_t c = 0; c < C; ++c) {
+            if (bad[c]) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: Open kmc database " + names[c] + " error (" + errs[c] + ")"); return; }
+            if ((int)dbs[c].k != g_.k) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: k of kmc database " + names[c] + " differs from the graph's"); return; }
+            if (!quiet_) printf("CCDBG::CCDBG(): kmc database %s initialized\n", names[c].c_str());
+        }
+        std::vector<const uint64_t *> pk(C);
+        std::vector<const uint32_t *> pc(C);
+        std::vector<uint64_t> n(C), mn(C), mx(C);
+        std::vector<int> both(C);
+        for (uint32_t c = 0; c < C; ++c) {
+            pk[c] = dbs[c].kmers.data();
+            pc[c] = dbs[c].counts.data();
+            n[c] = dbs[c].total;
+            mn[c] = dbs[c].min_count;
+            mx[c] = dbs[c].max_count;
+            both[c] = dbs[c].both_strands;
+        }
+        int st = pf_upload_counts_colored(ctx_, C, pk.data(), pc.data(), n.data(), mn.data(), mx.data(), both.data());
+        if (st != PF_OK) { fail(st, std::string("CCDBG::CCDBG():Error: ") + pf_last_error(ctx_)); return; }
+    }
+    if (!quiet_) printf("CCDBG::CCDBG():CCDBG initialized!\n");
+}
+
+int CCDBG::ploidyEstimation_multithread_ptr(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr) {
+    return ploidy_estimation(outpre, cutoff, thr);
+}
+
+}  // namespace pfh

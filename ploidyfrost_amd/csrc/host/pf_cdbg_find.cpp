@@ -1,0 +1,238 @@
+// pfh::CDBG::findSuperBubble_multithread_ptr and the coverage launch it may start for the next phase.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cmath>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <mutex>
+#include <set>
+#include <stdexcept>
+#include <thread>
+
+#include "pf_cdbg_impl.hpp"
+#include "pf_parallel.hpp"
+
+namespace pfh {
+
+// ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
+int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thr) {
+    if (status_) return status_;
+    if (join_pending_write()) return status_;
+    if (!quiet_) printf("%s::findSuperBubble(): Finding superbubbles\n", tag_);
+    if (write_files_ && ensure_dir()) return status_;
+    const auto t_all = clk::now();
+    clock_t c0 = clock();
+    const uint32_t N = g_.n();
+    if (!quiet_) printf("%s::findSuperBubble(): There are %u unitigs \n", tag_, N);
+    out_bytes_ = 0;
+    std::fill(flags_.begin(), flags_.end(), 0);
+    std::fill(plus_.begin(), plus_.end(), 0);
+    std::fill(minus_.begin(), minus_.end(), 0);
+
+    // Every candidate entrance is traversed on the device, one wavefront each.  The unitig range is cut into slices:
+    // a helper thread (the only one issuing device calls here) runs K-BFS slice by slice and, after the last one, the
+    // coverage kernel PloidyEstimation starts with -- while this thread replays the records of the finished slices in
+    // the reference's visiting order, with its `partner == NULL` gate (src/CDBG.cpp:206, 211): records come in
+    // ascending oriented-vertex order = unitig order, '+' before '-'.
+    auto t0 = clk::now();
+    // Slicing costs when a graph has chromosome-long traversals: each slice would run its own serially instead of all of
+    // them side by side.  So the first pass over a graph is one slice, and later passes are sliced only if none was seen.
+    constexpr int kMaxSlices = 4;
+    const int kSlices = (find_passes_ > 0 && times_.bfs_large == 0) ? kMaxSlices : 1;
+    ++find_passes_;
+    uint32_t s_u0[kMaxSlices + 1];
+    uint64_t s_cand[kMaxSlices], s_rec0[kMaxSlices + 1], s_pool0[kMaxSlices + 1], s_nrec[kMaxSlices], s_used[kMaxSlices];
+    s_rec0[0] = s_pool0[0] = 0;
+    for (int i = 0; i <= kSlices; ++i) s_u0[i] = (uint32_t)((uint64_t)N * i / kSlices);
+    for (int i = 0; i < kSlices; ++i) {
+        int st0 = pf_count_candidates(ctx_, s_u0[i], s_u0[i + 1], &s_cand[i]);
+        if (st0 != PF_OK) return fail(st0, pf_last_error(ctx_));
+        s_rec0[i + 1] = s_rec0[i] + std::max<uint64_t>(s_cand[i], 1);
+        // the pool guess leaves room for the per-wave chunk slack
+        s_pool0[i + 1] = s_pool0[i] + s_cand[i] * 6 + (1u << 20);
+        s_nrec[i] = s_used[i] = 0;
+    }
+    // pinned, reused from pass to pass
+    bx_.bfs_rec.ensure(ctx_, s_rec0[kSlices]);
+    bx_.bfs_pool.ensure(ctx_, s_pool0[kSlices]);
+    pf_bfs_record *rec = bx_.bfs_rec.p;
+    // a slice whose pool guess was too small gets a buffer of its own
+    std::vector<std::unique_ptr<PinnedBuf<uint32_t>>> own_pool(kSlices);
+    const uint32_t *slice_pool[kMaxSlices];
+    std::mutex mu;
+    std::condition_variable cv;
+    int done = 0, dev_st = PF_OK;
+    std::string dev_err;
+    double bfs_s = 0;
+    const bool prefetch_cov = overlap_output_;  // the same switch: work of the next call started behind the caller's back
+    cov_ready_ = false;
+    std::thread device([&] {
+        for (int i = 0; i < kSlices; ++i) {
+            const auto tb = clk::now();
+            uint32_t *pl = bx_.bfs_pool.p + s_pool0[i];
+            uint64_t cap = s_pool0[i + 1] - s_pool0[i];
+            int st1;
+            for (;;) {
+                st1 = pf_bfs_candidates(ctx_, s_u0[i], s_u0[i + 1], rec + s_rec0[i], s_rec0[i + 1] - s_rec0[i], pl, cap, &s_nrec[i], &s_used[i]);
+                if (st1 == PF_ERR_OVERFLOW && s_used[i] > cap) {
+                    own_pool[i] = std::make_unique<PinnedBuf<uint32_t>>();
+                    own_pool[i]->ensure(ctx_, s_used[i] + s_used[i] / 8);
+                    pl = own_pool[i]->p;
+                    cap = own_pool[i]->cap;
+                    continue;
+                }
+                break;
+            }
+            bfs_s += since(tb);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                slice_pool[i] = pl;
+                if (st1 != PF_OK) { dev_st = st1; dev_err = pf_last_error(ctx_); }
+                done = i + 1;
+            }
+            cv.notify_all();
+            if (st1 != PF_OK) return;
+        }
+        if (prefetch_cov) cov_ready_ = launch_coverage() == PF_OK;
+    });
+    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;  // (kSlices above looked at the previous pass)
+    uint64_t n_rec_total = 0;
+    double replay_s = 0;
+    int st = PF_OK;
+    for (int sl = 0; sl < kSlices; ++sl) {
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return done > sl || dev_st != PF_OK; });
+            if (done <= sl || (dev_st != PF_OK && done == sl + 1)) { st = dev_st; break; }
+        }
+        const auto tr = clk::now();
+        const pf_bfs_record *srec = rec + s_rec0[sl];
+        const uint64_t n_rec = s_nrec[sl];
+        const uint32_t *pool = slice_pool[sl];
+        n_rec_total += n_rec;
+        for (uint64_t i = 0; i < n_rec; ++i) {
+            // the commits chase per-unitig state at random: pull the state of a record a few iterations ahead into cache
+            if (i + 12 < n_rec) {
+                const pf_bfs_record &nx = srec[i + 12];
+                __builtin_prefetch(pool + nx.list_off);
+                __builtin_prefetch(&plus_[nx.entrance >> 1]);
+                __builtin_prefetch(&minus_[nx.entrance >> 1]);
+            }
+            if (i + 6 < n_rec) {
+                const pf_bfs_record &nx = srec[i + 6];
+                const uint32_t *l = pool + nx.list_off;
+                const uint32_t nl = nx.n_list < 6 ? nx.n_list : 6;
+                for (uint32_t q = 0; q < nl; ++q) {
+                    const uint32_t w = l[q] >> 1;
+                    __builtin_prefetch(&flags_[w]);
+                    __builtin_prefetch(&plus_[w]);
+                    __builtin_prefetch(&minus_[w]);
+                }
+            }
+            const pf_bfs_record &r = srec[i];
+            if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
+            if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
+            const uint32_t u = r.entrance >> 1;
+            if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
+            replay(r, pool + r.list_off);
+        }
+        replay_s += since(tr);
+    }
+    device.join();
+    if (st != PF_OK || dev_st != PF_OK) return fail(dev_st != PF_OK ? dev_st : st, std::string("CDBG::findSuperBubble(): ") + dev_err);
+    times_.bfs_device_s = bfs_s;
+    times_.candidates = n_rec_total;
+    times_.replay_s = replay_s;
+    if (!quiet_) {
+        printf("%s::findSuperBubble():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("%s::findSuperBubble():  Real time : %gs\n", tag_, since(t_all));
+    }
+    t0 = clk::now();
+    // super_bubble.txt: one row per open endpoint side in unitig order; rows are numbered with a prefix
+    // count so that unitig ranges can be formatted in parallel
+    const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
+    constexpr size_t UCH = 16384;
+    const size_t n_uch = n_chunks_of(N, UCH);
+    std::vector<uint64_t> row_base(n_uch + 1, 0);
+    parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
+        uint64_t c = 0;
+        if (col_) {  // src/CCDBG.cpp:2106-2132: an open unitig lists every side whose partner pointer is set, self included
+            for (size_t u = ub; u < ue; ++u)
+                if (flags_[u] & 3) c += (plus_[u] != 0) + (minus_[u] != 0);
+        } else {
+            for (size_t u = ub; u < ue; ++u) c += (flags_[u] & B_PLUS ? 1 : 0) + (flags_[u] & B_MINUS ? 1 : 0);
+        }
+        row_base[ci + 1] = c;
+    });
+    for (size_t c = 0; c < n_uch; ++c) row_base[c + 1] += row_base[c];
+    std::vector<std::string> pieces(n_uch + 1);
+    pieces[0] = "BubbleId\tEntrance\tStrand\tExit\tisSimple\tisComplex\n";
+    parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
+        std::string &out = pieces[ci + 1];
+        uint64_t nb = row_base[ci];
+        for (uint32_t u = (uint32_t)ub; u < (uint32_t)ue; ++u) {
+            const uint8_t f = flags_[u];
+            if ((f & 3) == 0) continue;
+            for (int side = 0; side < 2; ++side) {
+                const bool ps = side == 0;
+                if (col_ ? (ps ? plus_[u] : minus_[u]) == 0 : !(f & (ps ? B_PLUS : B_MINUS))) continue;
+                put_uint(out, ++nb);
+                out.push_back('\t');
+                put_uint(out, u + 1);
+                out += ps ? "\t+\t" : "\t-\t";
+                put_uint(out, ps ? plus_[u] : minus_[u]);
+                out += (f & (ps ? B_STRICT_P : B_STRICT_M)) ? "\t1" : "\t0";
+                out += (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? "\t1\n" : "\t0\n";
+            }
+        }
+    });
+    const uint64_t nb = row_base[n_uch];
+    n_super_bubble_ = nb;
+    times_.bubbles_out = nb;
+    if (overlap_output_ && write_files_) {
+        // written behind the caller's back while PloidyEstimation starts; joined there (or by the next use of the file)
+        join_pending_write();
+        pending_pieces_ = std::move(pieces);
+        uint64_t bytes = 0;
+        for (const std::string &pc : pending_pieces_) bytes += pc.size();
+        out_bytes_ += bytes;
+        pending_write_ = std::thread([this, name = outpre + "_super_bubble.txt"] {
+            std::vector<const std::string *> ptrs;
+            for (const std::string &pc : pending_pieces_) ptrs.push_back(&pc);
+            uint64_t b = 0;
+            pending_rc_ = write_pieces(name, ptrs, b);
+        });
+    } else {
+        std::vector<std::pair<std::string, std::vector<const std::string *>>> files(1);
+        files[0].first = outpre + "_super_bubble.txt";
+        for (auto &pc : pieces) files[0].second.push_back(&pc);
+        if (write_many(files, T)) return status_;
+    }
+    times_.bubble_write_s = since(t0);
+    times_.find_total_s = since(t_all);
+    if (!quiet_) printf("%s::findSuperBubble(): %llu  SuperBubbles Found\n", tag_, (unsigned long long)nb);
+    return 0;
+}
+
+// K-COV (colored: K-COV-C) for all unitigs into the pinned result buffers.  A missing k-mer is not an error here: the
+// single-sample path raises it only for the unitigs it really uses, the colored path never (src/CCDBG.cpp:113-117).
+int CDBG::launch_coverage() {
+    const uint32_t N = g_.n();
+    const uint32_t C = col_ ? col_->n_colors : 1;
+    bx_.cov_sum.ensure(ctx_, (size_t)N * C);
+    bx_.cov_min.ensure(ctx_, (size_t)N * C);
+    bx_.cov_miss.ensure(ctx_, (size_t)N * C);
+    if (col_) bx_.cov_max.ensure(ctx_, (size_t)N * C);
+    const int st = col_ ? pf_unitig_cov_colored(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_max.p, bx_.cov_miss.p)
+                        : pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
+    if (st != PF_OK && st != PF_ERR_MISSING_KMER) { cov_err_ = pf_last_error(ctx_); return st; }
+    return PF_OK;
+}
+
+}  // namespace pfh

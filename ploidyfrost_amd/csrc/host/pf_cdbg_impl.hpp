@@ -1,0 +1,55 @@
+// Private to the host layer: what the translation units of pfh::CDBG / pfh::CCDBG share (pf_cdbg.cpp: construction,
+// output plumbing, MyUnitig state and the commit replay; pf_cdbg_find.cpp: findSuperBubble; pf_cdbg_ploidy.cpp:
+// PloidyEstimation; pf_ccdbg.cpp: the colored front end).
+#pragma once
+#include <charconv>
+#include <chrono>
+#include <cstdint>
+#include <string>
+
+#include "pf_cdbg.hpp"
+
+namespace pfh {
+
+namespace {
+using clk = std::chrono::steady_clock;
+inline double since(clk::time_point t0) { return std::chrono::duration<double>(clk::now() - t0).count(); }
+
+// MyUnitig::b bit layout (reference src/MyUnitig.hpp:37-46, 52-85, 97-130)
+constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_NON_SUPER = 0x04, B_STRICT_M = 0x08, B_STRICT_P = 0x10,
+                  B_COMPLEX_M = 0x20, B_COMPLEX_P = 0x40;
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+
+inline bool plus_of(uint32_t ov) { return (ov & 1) == 0; }
+
+// `ostream << double` with default flags == printf("%g") (precision 6)
+// (std::to_chars with chars_format::general and a precision is specified as that printf conversion)
+inline void put_double(std::string &s, double x) {
+    char buf[48];
+    auto r = std::to_chars(buf, buf + sizeof buf, x, std::chars_format::general, 6);
+    s.append(buf, (size_t)(r.ptr - buf));
+}
+inline void put_uint(std::string &s, uint64_t x) {
+    char buf[24];
+    auto r = std::to_chars(buf, buf + sizeof buf, x);
+    s.append(buf, (size_t)(r.ptr - buf));
+}
+}  // namespace
+
+// one bubble to call, in output order
+struct CDBG::Task {
+    uint32_t u = 0;        // owner endpoint (unitig index)
+    uint32_t entrance_ov = 0, exit_ov = 0;
+    bool strict = false;
+    double core_mean = 0;
+    // strict: inner unitigs sorted by (mean coverage desc, reference string desc) and their means
+    uint32_t inner[4] = {0, 0, 0, 0};
+    double cov[4] = {0, 0, 0, 0};
+    uint8_t n_inner = 0, n_cov = 0;
+    double cov_sum = 0;
+    // colored strict bubble: where its [colour][inner] coverage matrix sits (chunk << 32 | offset into the chunk's pool)
+    uint64_t cov_ref = 0;
+};
+
+
+}  // namespace pfh
