@@ -188,7 +188,7 @@ def algorithmic_bytes(kernel: str, t: dict) -> float | None:
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--unitigs", type=int, default=1_000_000, help="target unitigs per GPU (config[1] = 1 M)")
     ap.add_argument("--cpu-sample-unitigs", type=int, default=150_000)
