@@ -182,6 +182,11 @@ def algorithmic_bytes(kernel: str, t: dict) -> float | None:
         return 300.0 * t["align_jobs"]
     if kernel == "k_strcov":
         return 12.0 * 2.0 * t["site_strings"]
+    if kernel == "k_cov_colored":  # one slot of 8 + 4 C bytes per k-mer, 17 B of results per (colour, unitig)
+        c = t.get("n_colors", 3)
+        return (0.25 + 8.0 + 4.0 * c) * t["kmers"] + 17.0 * c * t["unitigs"]
+    if kernel == "k_strcov_colored":
+        return 12.0 * 2.0 * t["site_strings"] * t.get("n_colors", 3)
     return None
 
 
@@ -195,6 +200,9 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per rank (0 = min(32, cpus/ranks))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--workload", choices=["single", "colored"], default="single",
+                    help="single = the headline metric (BASELINE.json configs[1]); colored = the CCDBG path on 3 diploid "
+                         "samples (configs[3]), same JSON line with config.workload saying so")
     args = ap.parse_args()
 
     import torch
@@ -217,11 +225,20 @@ def main():
     workdir = tempfile.mkdtemp(prefix="pf_bench_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     try:
         genome = int(args.unitigs / UNITIGS_PER_BP)
-        gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, 1000 + rank, dev)
+        colored = args.workload == "colored"
+        host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+        if colored:
+            n_samples = 3
+            gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(workdir, "graph", genome, 1000 + rank, dev, samples=n_samples)
+            cutoffs = [(LOWER, UPPER)] * n_samples
+        else:
+            gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, 1000 + rank, dev)
         torch.cuda.empty_cache()
         t0 = time.time()
-        run = hostapi.Run(gfa, db, z=Z, device=gpu_index)
-        host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+        if colored:
+            run = hostapi.ColoredRun(gfa, colors, dbs, workdir, z=Z, threads=host_threads, device=gpu_index)
+        else:
+            run = hostapi.Run(gfa, db, z=Z, device=gpu_index)
         run.set_threads(host_threads)
         run.set_overlap_output(True)  # super_bubble.txt is written while PloidyEstimation runs; complete when it returns
         if os.environ.get("PF_BATCH_BUBBLES"):  # experiments: bubbles per batch of the align/format pipeline
@@ -237,7 +254,10 @@ def main():
 
         def step():
             run.find_superbubbles("b")
-            run.ploidy_estimation("b", LOWER, UPPER)
+            if colored:
+                run.ploidy_estimation("b", cutoffs)
+            else:
+                run.ploidy_estimation("b", LOWER, UPPER)
             if world > 1:
                 # end-of-pass exchange over RCCL: counters + the ordered allele-frequency record slab
                 tt_ = run.times()
@@ -311,15 +331,17 @@ def main():
                             "frac": round(e["achieved_GBps"] / 8000.0, 5), "traffic": tr,
                             "traffic_frac": round(tr / (e["avg_ms"] * 1e-3) / 8e12, 4) if tr else None}
             cpu = None
-            if not args.no_cpu_baseline:
+            if not args.no_cpu_baseline and not colored:
                 cpu = cpu_baseline(workdir, args.cpu_sample_unitigs, dev)
             out = {
                 "metric": "unitigs/s through superbubble+SeqAlign (k=25, z=8)",
                 "value": round(value, 1), "unit": "unitigs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                 "ms_per_step": round(max_elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-                "config": {"workload": "single-sample synthetic tetraploid graph, %d unitigs/GPU (config[1] = 1 M), k=25 z=8, "
-                                       "-l %d -u %d, M=2 D=-1 G=-3" % (n_unitigs, LOWER, UPPER),
+                "config": {"workload": ("colored graph of 3 synthetic diploid samples (CCDBG path, configs[3]), %d unitigs/GPU, k=25 z=8, "
+                                        "cutoffs %d/%d per sample, M=2 D=-1 G=-3" if colored else
+                                        "single-sample synthetic tetraploid graph, %d unitigs/GPU (config[1] = 1 M), k=25 z=8, "
+                                        "-l %d -u %d, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER),
                            "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
                            "partitioning": "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
                                            "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0]},
