@@ -41,6 +41,7 @@ struct PhaseTimes {
     double find_total_s = 0, ploidy_total_s = 0;
     double scan_s = 0, scan_serial_s = 0, align_build_s = 0, align_device_s = 0, align_post_s = 0, align_choose_s = 0;
     uint64_t bfs_large = 0, bfs_large_seen = 0, bfs_max_seen = 0;  // traversals beyond 4096 unitigs
+    uint64_t bfs_large_used = 0, bfs_large_used_max = 0;            // ... that the replay's gate let through, and the longest of those
     uint64_t candidates = 0, bfs_deferred = 0, bubbles_out = 0, tasks = 0, align_jobs = 0, site_strings = 0;
 };
 

@@ -102,6 +102,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         if (prefetch_cov) cov_ready_ = launch_coverage() == PF_OK;
     });
     times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;  // (kSlices above looked at the previous pass)
+    times_.bfs_large_used = times_.bfs_large_used_max = 0;
     uint64_t n_rec_total = 0;
     double replay_s = 0;
     int st = PF_OK;
@@ -140,6 +141,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
             const uint32_t u = r.entrance >> 1;
             if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
+            if (r.n_seen > 4096) { times_.bfs_large_used++; if (r.n_seen > times_.bfs_large_used_max) times_.bfs_large_used_max = r.n_seen; }
             replay(r, pool + r.list_off);
         }
         replay_s += since(tr);

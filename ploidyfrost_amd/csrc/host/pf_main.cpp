@@ -315,8 +315,9 @@ int main(int argc, char **argv) {
                (unsigned long long)t.candidates, (unsigned long long)t.bfs_deferred, t.bfs_device_s, t.replay_s, t.cov_device_s,
                t.tasks_s, (unsigned long long)t.tasks, t.align_s, (unsigned long long)t.align_jobs, t.sites_s,
                (unsigned long long)t.site_strings, t.format_s, t.write_s);
-        printf("[bfs]    traversals > 4096 unitigs: %llu (sum of seen %llu, largest %llu)\n", (unsigned long long)t.bfs_large,
-               (unsigned long long)t.bfs_large_seen, (unsigned long long)t.bfs_max_seen);
+        printf("[bfs]    traversals > 4096 unitigs: %llu (sum of seen %llu, largest %llu); committed by the replay: %llu (largest %llu)\n",
+               (unsigned long long)t.bfs_large, (unsigned long long)t.bfs_large_seen, (unsigned long long)t.bfs_max_seen,
+               (unsigned long long)t.bfs_large_used, (unsigned long long)t.bfs_large_used_max);
         printf("[host]   scan %.3fs | align: build %.3fs device-call %.3fs post %.3fs choose %.3fs\n", t.scan_s, t.align_build_s,
                t.align_device_s, t.align_post_s, t.align_choose_s);
     }
