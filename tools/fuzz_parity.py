@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Differential fuzzing on a GPU box: random small inputs (ploidy, k, -z, variant density, insertion lengths, repeat-rich
+genomes, integral and fractional scores, tight and loose cutoffs; single-sample and colored) through this repository's CLI
+and through the CPU oracle (oracle/_build/pf_oracle_cli, itself pinned to the reference on the golden fixtures); all twelve
+output files must be byte-identical.   usage: tools/fuzz_parity.py [n_cases] [first_seed]
+Graphs come from ploidyfrost_amd.cdbg_build (seeds whose repeat structure it cannot compact are skipped); colour sets are
+written by ploidyfrost_amd.bfg_colors and read back for the oracle by oracle/_ref/colors_dump (the real Bifrost)."""
+import os
+import subprocess
+import sys
+import tempfile
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+import bench  # noqa: E402
+import pyoracle  # noqa: E402
+from ploidyfrost_amd import cdbg_build, synth  # noqa: E402
+
+CLI = os.path.join(ROOT, "ploidyfrost_amd", "csrc", "ploidyfrost")
+FILES = ["Unitig_Id", "super_bubble", "alignseq", "allele_frequency", "bicov", "bifre", "tricov", "trifre", "tetracov", "tetrafre",
+         "pentacov", "pentafre"]
+
+
+def repeat_rich(rng, n):
+    base = rng.integers(0, 4, size=n, dtype=np.uint8)
+    parts, pos = [], 0
+    while pos < n:
+        step = int(rng.integers(150, 500))
+        seg = base[pos: pos + step]
+        parts.append(seg)
+        if len(seg) > 120 and rng.random() < 0.6:
+            a = int(rng.integers(0, len(seg) - 100))
+            ln = int(rng.integers(30, 100))
+            piece = seg[a: a + ln]
+            kind = int(rng.integers(0, 3))
+            parts += [piece, piece] if kind == 0 else [(3 - piece)[::-1]] if kind == 1 else [base[a: a + ln]]
+        pos += step
+    return np.concatenate(parts)
+
+
+def one_case(seed, tmp, dev):
+    rng = np.random.default_rng(seed)
+    k = int(rng.choice([21, 25, 25, 31]))
+    ploidy = int(rng.integers(2, 7))
+    z = int(rng.integers(4, 13))
+    L = int(rng.integers(8000, 40000))
+    spec = synth.HapSpec(L, ploidy, seed=seed, gap_lo=int(rng.integers(5, 30)), gap_hi=int(rng.integers(40, 500)),
+                         p_multi=float(rng.choice([0.0, 0.05, 0.15])), max_ins=int(rng.choice([3, 6, 12, 30])),
+                         p_snp=float(rng.choice([0.5, 0.75, 0.9])), p_del=0.1)
+    haps = synth.make_haplotypes(spec)
+    if rng.random() < 0.3:  # splice the variants onto a repeat-rich genome: cycles, hairpins, tips
+        rep = repeat_rich(rng, L)
+        haps = [np.concatenate([rep[: len(rep) // 2], h[200:-200], rep[len(rep) // 2:]]) for h in haps]
+    scores = [(2, -1, -3), (2, -1, -3), (1, -1, -1), (3, -2, -4), (1.5, -0.5, -2.25), (2, -1, -2)][int(rng.integers(0, 6))]
+    lower, upper = [(5, 1000), (5, 1000), (15, 70), (1, 100000)][int(rng.integers(0, 4))]
+    colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4
+    try:
+        if colored:
+            # make_colored_inputs draws its own haplotypes: samples x 2 on one genome
+            gfa, colors, dbs, n_unitigs, _ = bench.make_colored_inputs(tmp, "g", L, seed, dev, k=k, samples=ploidy // 2, ploidy=2,
+                                                                      max_ins=spec.max_ins)
+        else:
+            g = cdbg_build.build_cdbg(haps, k, dev)
+            gfa = os.path.join(tmp, "g.gfa")
+            n_unitigs = cdbg_build.write_gfa(gfa, g)
+            db = os.path.join(tmp, "g_kmc")
+            synth.write_kmc1(db, g["kmers"], synth.synth_counts(g["kmers"], g["mult"]), k)
+    except RuntimeError as e:
+        return "skipped (%s)" % str(e)[:60]
+    common = ["-o", "x", "-z", str(z), "-M", str(scores[0]), "-D", str(scores[1]), "-G", str(scores[2])]
+    og, gg = os.path.join(tmp, "oracle"), os.path.join(tmp, "gpu")
+    os.makedirs(og), os.makedirs(gg)
+    if colored:
+        dump = os.path.join(tmp, "colors.txt")
+        with open(dump, "w") as f:
+            subprocess.run([pyoracle.REF_COLORS_DUMP, gfa, colors], check=True, stdout=f)
+        lst, cut = os.path.join(tmp, "dbs.txt"), os.path.join(tmp, "cut.txt")
+        open(lst, "w").write("".join(d + "\n" for d in dbs))
+        open(cut, "w").write(("%d\t%d\n" % (lower, upper)) * len(dbs))
+        ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-f", dump, "-d", lst, "-C", cut, "-O", os.path.join(og, "PloidyFrost_output")] + common,
+                            cwd=og, capture_output=True, text=True)
+        rg = subprocess.run([CLI, "-g", gfa, "-f", colors, "-d", lst, "-C", cut, "-t", "8"] + common, cwd=gg, capture_output=True, text=True)
+    else:
+        ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-O", os.path.join(og, "PloidyFrost_output")]
+                            + common, cwd=og, capture_output=True, text=True)
+        rg = subprocess.run([CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-t", "8"] + common, cwd=gg, capture_output=True,
+                            text=True)
+    desc = "k=%d ploidy=%d z=%d L=%d scores=%s cut=%d/%d %s unitigs=%d" % (k, ploidy, z, L, scores, lower, upper,
+                                                                          "colored" if colored else "single", n_unitigs)
+    if ro.returncode != 0 or rg.returncode != 0:
+        # both must fail alike (e.g. a k-mer missing from the database)
+        return "%s: oracle rc %d, product rc %d%s" % (desc, ro.returncode, rg.returncode, "" if (ro.returncode != 0) == (rg.returncode != 0)
+                                                      else "  MISMATCH\n" + ro.stderr[-300:] + rg.stderr[-300:] + rg.stdout[-300:])
+    bad = []
+    for suf in FILES:
+        a = open(os.path.join(og, "PloidyFrost_output", "x_%s.txt" % suf), "rb").read()
+        b = open(os.path.join(gg, "PloidyFrost_output", "x_%s.txt" % suf), "rb").read()
+        if a != b:
+            bad.append(suf)
+    return "%s: %s" % (desc, "identical" if not bad else "DIFFERENT " + ",".join(bad))
+
+
+def main():
+    n = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+    first = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    import torch
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    pyoracle.build()
+    failures = 0
+    for seed in range(first, first + n):
+        with tempfile.TemporaryDirectory() as tmp:
+            msg = one_case(seed, tmp, dev)
+        print("seed %d: %s" % (seed, msg), flush=True)
+        failures += "DIFFERENT" in msg or "MISMATCH" in msg
+    print("%d cases, %d failures" % (n, failures))
+    return 1 if failures else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
