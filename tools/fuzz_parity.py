@@ -4,7 +4,9 @@ genomes, integral and fractional scores, tight and loose cutoffs; single-sample 
 and through the CPU oracle (oracle/_build/pf_oracle_cli, itself pinned to the reference on the golden fixtures); all twelve
 output files must be byte-identical.   usage: tools/fuzz_parity.py [n_cases] [first_seed]
 Graphs come from ploidyfrost_amd.cdbg_build (seeds whose repeat structure it cannot compact are skipped); colour sets are
-written by ploidyfrost_amd.bfg_colors and read back for the oracle by oracle/_ref/colors_dump (the real Bifrost)."""
+written by ploidyfrost_amd.bfg_colors and read back for the oracle by oracle/_ref/colors_dump (the real Bifrost).
+With PF_FUZZ_BIFROST=1 the graphs (and colour files) are built by the reference's own `Bifrost build` (oracle/_ref/Bifrost)
+instead: any repeat structure, samples that start and stop at different places (colours on part of a unitig)."""
 import os
 import subprocess
 import sys
@@ -57,8 +59,37 @@ def one_case(seed, tmp, dev):
     scores = [(2, -1, -3), (2, -1, -3), (1, -1, -1), (3, -2, -4), (1.5, -0.5, -2.25), (2, -1, -2)][int(rng.integers(0, 6))]
     lower, upper = [(5, 1000), (5, 1000), (15, 70), (1, 100000)][int(rng.integers(0, 4))]
     colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4
+    use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1"
     try:
-        if colored:
+        if use_bifrost:
+            groups = [haps[2 * i: 2 * i + 2] for i in range(ploidy // 2)] if colored else [haps]
+            if colored:  # samples that do not span the whole genome
+                groups = [[h[int(rng.integers(0, 1500)): len(h) - int(rng.integers(0, 1500))] for h in hs] if i else hs for i, hs in enumerate(groups)]
+            fas = []
+            for i, hs in enumerate(groups):
+                fa = os.path.join(tmp, "s%d.fa" % i)
+                synth.write_fasta(fa, hs)
+                fas.append(fa)
+            refs = os.path.join(tmp, "refs.txt")
+            open(refs, "w").write("".join(f + "\n" for f in fas))
+            r = subprocess.run([pyoracle.REF_BIFROST, "build", "-r", refs, "-k", str(k), "-o", os.path.join(tmp, "g"), "-t", "1"] + (["-c"] if colored else []),
+                               capture_output=True, text=True)
+            if r.returncode != 0:
+                return "skipped (Bifrost build failed)"
+            gfa = os.path.join(tmp, "g.gfa")
+            n_unitigs = sum(1 for line in open(gfa) if line.startswith("S\t"))
+            if colored:
+                colors = os.path.join(tmp, "g.bfg_colors")
+                dbs = []
+                for i, hs in enumerate(groups):
+                    km, mult = synth.canonical_counts(hs, k)
+                    dbs.append(os.path.join(tmp, "db%d" % i))
+                    synth.write_kmc1(dbs[-1], km, synth.synth_counts(km, mult), k)
+            else:
+                km, mult = synth.canonical_counts(haps, k)
+                db = os.path.join(tmp, "g_kmc")
+                synth.write_kmc1(db, km, synth.synth_counts(km, mult), k)
+        elif colored:
             # make_colored_inputs draws its own haplotypes: samples x 2 on one genome
             gfa, colors, dbs, n_unitigs, _ = bench.make_colored_inputs(tmp, "g", L, seed, dev, k=k, samples=ploidy // 2, ploidy=2,
                                                                       max_ins=spec.max_ins)
