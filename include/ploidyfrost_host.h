@@ -78,10 +78,18 @@ const char *pfh_colors_name(const pfh_colors *, uint32_t colour);
  * (UnitigColors::contains, ColorSet.cpp:776); returns UnitigColors::size(um) (ColorSet.cpp:898);
  * *n_full_enc = colours the file stores in the {full colours, rest} pair form, 0 otherwise */
 uint64_t pfh_colors_unitig(const pfh_colors *, uint32_t u, uint8_t *presence, uint32_t *n_kmers, uint32_t *n_full_enc);
-/* Known limit of the reproduced unitig numbering: the number of k-length unitigs of the GFA
- * file that Bifrost certainly files as "abundant" k-mers (hash-ordered, numbered last; CompactedDBG.tcc:4013-4021)
- * because more than 15 of them share a minimizer.  0 = ids are the reference's.  UINT64_MAX = unreadable file. */
-uint64_t pfh_gfa_abundant_suspects(const char *gfa_path);
+/* The unitig numbering is the reference's `-t 1` one: long unitigs in S-line order, then k-length unitigs in S-line
+ * order, then the k-length unitigs Bifrost files as "abundant" k-mers (their minimizer's bucket already held 15 entries
+ * when they were read, CompactedDBG.tcc:4013-4021, 4031-4068) in the slot order of its k-mer hash table
+ * (KmerHashTable.hpp:326-354; UnitigIterator.tcc:32-58).
+ * pfh_gfa_abundant_kmers: how many unitigs of the file end up in that last group (UINT64_MAX = unreadable file).
+ * pfh_gfa_write_unitig_ids: writes `id<TAB>sequence` per unitig, the content of <prefix>_Unitig_Id.txt (src/CDBG.cpp:121-143),
+ * from the GFA file alone (no device involved); 0 = ok.
+ * pfh_gfa_numbering_replays: 0 when no minimizer bucket can reach 15 entries (nothing to decide), else how many times the
+ * loader replayed Bifrost's bucket bookkeeping (> 1: long unitigs were redirected into buckets it had not followed). */
+uint64_t pfh_gfa_abundant_kmers(const char *gfa_path);
+uint32_t pfh_gfa_numbering_replays(const char *gfa_path);
+int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path);
 /* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);
 

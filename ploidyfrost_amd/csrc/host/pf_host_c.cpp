@@ -181,14 +181,41 @@ uint64_t pfh_colors_unitig(const pfh_colors *c, uint32_t u, uint8_t *presence, u
             for (uint32_t i = 0; i < km; ++i) presence[(size_t)ci * km + i] = c->sets.contains(u, ci, i, 1);
     return c->sets.size_total[u];
 }
-uint64_t pfh_gfa_abundant_suspects(const char *gfa_path) {
+uint64_t pfh_gfa_abundant_kmers(const char *gfa_path) {
     try {
         pfh::UnitigSet g;
         if (!g.load_gfa(gfa_path, g_open_err)) return ~0ull;
-        return g.abundant_suspects;
+        return g.n_abundant;
     } catch (const std::exception &e) {
         g_open_err = std::string("ploidyfrost host layer: ") + e.what();
         return ~0ull;
+    }
+}
+uint32_t pfh_gfa_numbering_replays(const char *gfa_path) {
+    try {
+        pfh::UnitigSet g;
+        if (!g.load_gfa(gfa_path, g_open_err)) return ~0u;
+        return g.numbering_replays;
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return ~0u;
+    }
+}
+int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path) {
+    try {
+        pfh::UnitigSet g;
+        if (!g.load_gfa(gfa_path, g_open_err)) return 1;
+        FILE *f = fopen(out_path, "w");
+        if (!f) { g_open_err = std::string("cannot write ") + out_path; return 1; }
+        for (uint32_t u = 0; u < g.n(); ++u) {
+            const std::string_view s = g.seq(u);
+            fprintf(f, "%u\t%.*s\n", u + 1, (int)s.size(), s.data());
+        }
+        fclose(f);
+        return 0;
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return 1;
     }
 }
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed) { return pfh::bifrost_kmer_hash(left_aligned_kmer, seed); }

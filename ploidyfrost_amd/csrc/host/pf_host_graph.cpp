@@ -1,4 +1,5 @@
 #include "pf_host_graph.hpp"
+#include "pf_host_minz.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -8,6 +9,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <thread>
 
 namespace pfh {
 
@@ -60,8 +62,6 @@ void UnitigSet::append_mapped(uint32_t ov, std::string &dst) const {
     }
 }
 
-static uint64_t count_abundant_suspects(const UnitigSet &g);
-
 bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
     Mapped f;
     if (!f.open(path)) { err = "cannot open " + path; return false; }
@@ -84,7 +84,7 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
     }
     if (k < 3 || k > 31) { err = "k outside 3..31"; return false; }
     // pass 1: locate the sequence field of every complete S-line
-    struct Seg { const char *s; uint32_t len; int16_t da; };
+    struct Seg { const char *s; uint32_t len; int16_t da; uint32_t rank; };
     std::vector<Seg> longs, shorts;
     uint64_t long_bp = 0;
     bool any_da = false;
@@ -111,8 +111,9 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
                 if (nt - tag > 6 && memcmp(tag + 1, "DA:Z:", 5) == 0) { da = (int16_t)atoi(std::string(tag + 6, nt).c_str()); any_da = true; }
                 tag = nt;
             }
-            if ((int)len == k) shorts.push_back({fld, len, da});
-            else { longs.push_back({fld, len, da}); long_bp += len; }
+            const uint32_t rank = (uint32_t)(longs.size() + shorts.size());
+            if ((int)len == k) shorts.push_back({fld, len, da, rank});
+            else { longs.push_back({fld, len, da, rank}); long_bp += len; }
         }
         q = e + 1;
     }
@@ -152,6 +153,34 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
         ++u;
     }
     off[N] = at;
+    // k-length unitigs Bifrost keeps in its table of abundant k-mers are iterated last, in that table's slot order
+    n_abundant = 0;
+    if (!shorts.empty() && g >= 1 && g <= k - 2) {
+        std::vector<SegRef> refs(N);
+        std::vector<uint32_t> short_of_rank(N, UINT32_MAX);
+        for (size_t i = 0; i < longs.size(); ++i) refs[longs[i].rank] = SegRef{text.data() + off[i], longs[i].len};
+        for (size_t i = 0; i < shorts.size(); ++i) {
+            refs[shorts[i].rank] = SegRef{text.data() + off[longs.size() + i], (uint32_t)k};
+            short_of_rank[shorts[i].rank] = (uint32_t)i;
+        }
+        UnitigNumbering num;
+        bifrost_numbering(k, g, refs, std::min(16u, std::max(1u, std::thread::hardware_concurrency())), num);
+        numbering_replays = num.replays;
+        if (!num.abundant.empty()) {
+            n_abundant = num.abundant.size();
+            std::vector<uint8_t> moved(shorts.size(), 0);
+            std::vector<Seg> order;
+            order.reserve(shorts.size());
+            for (uint32_t r : num.abundant) moved[short_of_rank[r]] = 1;
+            for (size_t i = 0; i < shorts.size(); ++i)
+                if (!moved[i]) order.push_back(shorts[i]);
+            for (uint32_t r : num.abundant) order.push_back(shorts[short_of_rank[r]]);
+            std::vector<char> old(text.begin() + (ptrdiff_t)long_bp, text.end());
+            for (size_t i = 0; i < order.size(); ++i)
+                memcpy(text.data() + long_bp + i * (size_t)k, old.data() + (size_t)short_of_rank[order[i].rank] * (size_t)k, (size_t)k);
+            shorts.swap(order);
+        }
+    }
     da_tag.clear();
     if (any_da) {
         da_tag.reserve(N);
@@ -159,68 +188,7 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
         for (const Seg &s : shorts) da_tag.push_back(s.da);
     }
     pack();
-    abundant_suspects = count_abundant_suspects(*this);
     return true;
-}
-
-namespace {
-// Bifrost's minimizer hash of a g-mer (bifrost/src/RepHash.hpp:28-95): two rolling words, one per strand, combined
-// strand-symmetrically through wyhash (final version 3, 16-byte key)
-const uint64_t kHvals[4] = {2053695854357871005ULL, 5073395517033431291ULL, 10060236952204337488ULL, 7783083932390163561ULL};
-inline uint64_t rotl1(uint64_t x) { return (x << 1) | (x >> 63); }
-inline uint64_t wymix64(uint64_t a, uint64_t b) {
-    __uint128_t r = (__uint128_t)a * b;
-    return (uint64_t)r ^ (uint64_t)(r >> 64);
-}
-uint64_t rephash(const char *s, int g) {
-    uint64_t h = 0, ht = 0;
-    for (int i = 0; i < g; ++i) {
-        h = rotl1(h) ^ kHvals[((unsigned char)s[i] & 6) >> 1];
-        ht = rotl1(ht) ^ kHvals[(((unsigned char)s[g - 1 - i] ^ 4) & 6) >> 1];
-    }
-    const uint64_t lo = h < ht ? h : ht, hi = h < ht ? ht : h;
-    // wyhash of the 16 bytes {lo, hi}, seed 0
-    const uint64_t wyp0 = 0xa0761d6478bd642full, wyp1 = 0xe7037ed1a0b428dbull;
-    const uint64_t a = ((lo & 0xFFFFFFFFull) << 32) | (hi & 0xFFFFFFFFull);
-    const uint64_t b = ((hi >> 32) << 32) | (lo >> 32);
-    return wymix64(wyp1 ^ 16, wymix64(a ^ wyp1, b ^ wyp0));
-}
-}  // namespace
-
-// k-length unitigs that Bifrost certainly files as abundant k-mers: more than 15 of them share a minimizer
-// (the bucket of a minimizer gains one entry per k-length unitig, bifrost/src/CompactedDBG.tcc:4011-4031; entries
-// of longer unitigs only add to it, so this is a lower bound)
-static uint64_t count_abundant_suspects(const UnitigSet &g) {
-    const int k = g.k, gl = g.g;
-    if (gl < 1 || gl > k - 2 || gl > 31 || g.n_short < 16) return 0;
-    std::vector<uint64_t> mins;
-    mins.reserve(g.n_short);
-    for (uint32_t u = g.n() - (uint32_t)g.n_short; u < g.n(); ++u) {
-        const char *s = g.text.data() + g.off[u];
-        // minHashIterator with nh = true: the minimizer may not start at offset 0 or k-g (minHashIterator.hpp:232-262)
-        uint64_t best = ~0ull;
-        int at = 1;
-        for (int j = 1; j + gl <= k - 1; ++j) {
-            const uint64_t h = rephash(s + j, gl);
-            if (h < best) { best = h; at = j; }
-        }
-        uint64_t fw = 0, rc = 0;
-        for (int i = 0; i < gl; ++i) {
-            const uint64_t c = (uint64_t)code_of(s[at + i]);
-            fw = (fw << 2) | c;
-            rc |= (3 - c) << (2 * i);
-        }
-        mins.push_back(fw < rc ? fw : rc);
-    }
-    std::sort(mins.begin(), mins.end());
-    uint64_t suspects = 0;
-    for (size_t i = 0; i < mins.size();) {
-        size_t j = i;
-        while (j < mins.size() && mins[j] == mins[i]) ++j;
-        if (j - i > 15) suspects += (j - i) - 15;
-        i = j;
-    }
-    return suspects;
 }
 
 void UnitigSet::from_sequences(const std::vector<std::string> &seqs, int k_) {

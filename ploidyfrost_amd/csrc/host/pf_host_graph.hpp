@@ -27,11 +27,9 @@ struct UnitigSet {
     // Bifrost's per-segment "DA:Z:<n>" tag (which hash seed places the unitig's colour set,
     // bifrost/src/ColoredCDBG.tcc:496-533); -1 where a segment has none.  Empty when no segment has one.
     std::vector<int16_t> da_tag;
-    // Known limit of the id order reproduced here: Bifrost moves a k-length unitig into a hash table
-    // of "abundant" k-mers, iterated last and in hash order, when its minimizer's bucket already holds >= 15 entries
-    // (bifrost/src/CompactedDBG.tcc:4013-4021).  load_gfa counts the k-length unitigs for which that certainly
-    // happens (more than 15 of them share a minimizer); 0 on every graph whose ids are guaranteed to match.
-    uint64_t abundant_suspects = 0;
+    // k-length unitigs Bifrost files as "abundant" k-mers (pf_host_minz.hpp): they are the last n_abundant unitigs
+    uint64_t n_abundant = 0;
+    uint32_t numbering_replays = 0;
 
     uint32_t n() const { return (uint32_t)len_bp.size(); }
     std::string_view seq(uint32_t u) const { return std::string_view(text.data() + off[u], len_bp[u]); }
@@ -43,7 +41,7 @@ struct UnitigSet {
 
     // Loads the S-lines of a GFA 1/2 file in the reference's unitig order: long unitigs
     // (length > k) in file order, then k-length ones, each stored as min(seq, revcomp)
-    // (SURVEY.md 3.1).  A last line without '\n' is ignored, as in bifrost/src/GFA_Parser.cpp:486.
+    // (SURVEY.md 3.1), the abundant ones last (pf_host_minz.hpp).  A last line without '\n' is ignored, as in bifrost/src/GFA_Parser.cpp:486.
     bool load_gfa(const std::string &path, std::string &err);
     // builds from already ordered sequences (tests, generators)
     void from_sequences(const std::vector<std::string> &seqs, int k_);

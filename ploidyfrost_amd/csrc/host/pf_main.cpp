@@ -243,10 +243,8 @@ int main(int argc, char **argv) {
             exit(EXIT_FAILURE);
         }
         cout << "ColoredCDBG::read(): Graph loading successful" << endl;
-        if (cdbg.graph.abundant_suspects)
-            cerr << "Warning: " << cdbg.graph.abundant_suspects << " k-length unitigs share a minimizer with more than 15 others: Bifrost keeps such "
-                 << "k-mers in a hash table and numbers them last, in hash order; unitig ids (and the row order of the outputs) may differ "
-                 << "from the reference's for this graph." << endl;
+        if (opt.verbose && cdbg.graph.n_abundant)
+            cout << "ColoredCDBG::read(): " << cdbg.graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
 
         cout << "CCDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
         if (cdbg.getNbColors() != kmc_db_num) {
@@ -287,10 +285,8 @@ int main(int argc, char **argv) {
         exit(EXIT_FAILURE);
     }
     cout << "CompactedDBG::read(): Graph loading successful" << endl;
-    if (graph.abundant_suspects)
-        cerr << "Warning: " << graph.abundant_suspects << " k-length unitigs share a minimizer with more than 15 others: Bifrost keeps such "
-             << "k-mers in a hash table and numbers them last, in hash order; unitig ids (and the row order of the outputs) may differ "
-             << "from the reference's for this graph." << endl;
+    if (opt.verbose && graph.n_abundant)
+        cout << "CompactedDBG::read(): " << graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
 
     cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
 

@@ -26,7 +26,7 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
-                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_suspects"]
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays"]
 
 
 def load_library() -> C.CDLL:
@@ -73,8 +73,12 @@ def load_library() -> C.CDLL:
     L.pfh_colors_name.argtypes = [vp, C.c_uint32]
     L.pfh_colors_unitig.restype = C.c_uint64
     L.pfh_colors_unitig.argtypes = [vp, C.c_uint32, vp, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
-    L.pfh_gfa_abundant_suspects.restype = C.c_uint64
-    L.pfh_gfa_abundant_suspects.argtypes = [C.c_char_p]
+    L.pfh_gfa_abundant_kmers.restype = C.c_uint64
+    L.pfh_gfa_abundant_kmers.argtypes = [C.c_char_p]
+    L.pfh_gfa_numbering_replays.restype = C.c_uint32
+    L.pfh_gfa_numbering_replays.argtypes = [C.c_char_p]
+    L.pfh_gfa_write_unitig_ids.restype = C.c_int
+    L.pfh_gfa_write_unitig_ids.argtypes = [C.c_char_p, C.c_char_p]
     L.pfh_bifrost_kmer_hash.restype = C.c_uint64
     L.pfh_bifrost_kmer_hash.argtypes = [C.c_uint64, C.c_uint64]
     _lib = L

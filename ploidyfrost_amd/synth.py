@@ -37,11 +37,14 @@ class HapSpec:
     p_multi: float = 0.03        # SNP sites carrying two different ALT bases (ploidy >= 3)
 
 
-def make_haplotypes(spec: HapSpec) -> list[np.ndarray]:
-    """Base genome + ``ploidy`` haplotypes as uint8 arrays of 2-bit codes (A0 C1 G2 T3)."""
+def make_haplotypes(spec: HapSpec, base_edit=None) -> list[np.ndarray]:
+    """Base genome + ``ploidy`` haplotypes as uint8 arrays of 2-bit codes (A0 C1 G2 T3).  ``base_edit(base) -> base``
+    may rewrite the base genome (same length) before the variants are laid on it."""
     rng = np.random.default_rng(spec.seed)
     L = spec.genome_len
     base = rng.integers(0, 4, size=L, dtype=np.uint8)
+    if base_edit is not None:
+        base = base_edit(base)
     # variant positions
     n_max = L // spec.gap_lo + 2
     gaps = rng.integers(spec.gap_lo, spec.gap_hi + 1, size=n_max)
@@ -375,3 +378,35 @@ def read_kmc(prefix: str):
     kmers = (prefix_of << np.uint64(2 * (k - p))) | sfx
     return kmers, cnt.astype(np.uint32), dict(k=k, p=p, min_count=min_count, max_count=max_count, both_strands=both,
                                               total=total, layout="kmc2", sig_len=sig_len)
+
+
+def bifrost_minimizer_hash(s: bytes) -> int:
+    """Bifrost's minimizer hash of a g-mer (bifrost/src/RepHash.hpp:24-103: two rolling words, one per strand, through
+    wyhash) -- generators use it to plant a g-mer that wins the minimizer race in the k-mers around it."""
+    M = (1 << 64) - 1
+    hv = [2053695854357871005, 5073395517033431291, 10060236952204337488, 7783083932390163561]
+    g, h, ht = len(s), 0, 0
+    for i in range(g):
+        h = (((h << 1) | (h >> 63)) & M) ^ hv[(s[i] & 6) >> 1]
+        ht = (((ht << 1) | (ht >> 63)) & M) ^ hv[((s[g - 1 - i] ^ 4) & 6) >> 1]
+    lo, hi = min(h, ht), max(h, ht)
+    a = ((lo & 0xFFFFFFFF) << 32) | (hi & 0xFFFFFFFF)
+    b = ((hi >> 32) << 32) | (lo >> 32)
+
+    def mix(x, y):
+        r = (x & M) * (y & M)
+        return (r & M) ^ (r >> 64)
+    return mix(0xE7037ED1A0B428DB ^ 16, mix(a ^ 0xE7037ED1A0B428DB, b ^ 0xA0761D6478BD642F))
+
+
+def plant_crowded_minimizer(rng, base, g, copies, tries=3000):
+    """Overwrites `copies` places of the genome `base` (uint8 codes) with one g-mer whose minimizer hash is the lowest of
+    `tries` random ones: the k-mers around every copy share that minimizer, which crowds its bucket in Bifrost's index."""
+    cands = [rng.integers(0, 4, size=g, dtype=np.uint8) for _ in range(tries)]
+    core = min(cands, key=lambda c: bifrost_minimizer_hash(BASES[c].tobytes()))
+    out = base.copy()
+    step = len(out) // (copies + 1)
+    for i in range(copies):
+        at = (i + 1) * step + int(rng.integers(-step // 4, step // 4))
+        out[at: at + g] = core
+    return out

@@ -16,20 +16,27 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
 
-def _cases(colored):
+def _cases(colored, abundant=False):
     out = []
     for d in sorted(os.listdir(GOLDEN)):
         a = os.path.join(GOLDEN, d, "args.json")
         if os.path.isfile(a):
             with open(a) as f:
-                if bool(json.load(f).get("colored")) == colored:
-                    out.append(d)
+                meta = json.load(f)
+            if bool(meta.get("colored")) == colored and bool(meta.get("abundant")) == abundant:
+                out.append(d)
     return out
 
 
 def golden_cases():
     """single-sample cases (reference src/CDBG.cpp)"""
     return _cases(False)
+
+
+def abundant_cases():
+    """single-sample cases in which Bifrost numbers some k-length unitigs last ("abundant" k-mers); the expected files
+    come from the reference, the oracle does not restate that part of the numbering"""
+    return _cases(False, True)
 
 
 def colored_cases():

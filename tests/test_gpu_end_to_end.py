@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, compare_outputs, golden_cases, load_case
+from conftest import ROOT, abundant_cases, compare_outputs, golden_cases, load_case
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle  # noqa: E402
@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 CLI = os.path.join(ROOT, "ploidyfrost_amd", "csrc", "ploidyfrost")
 
 
-@pytest.mark.parametrize("case", golden_cases())
+@pytest.mark.parametrize("case", golden_cases() + abundant_cases())
 def test_cli_outputs_match_reference(case, tmp_path):
     meta = load_case(case)
     r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "1"] + meta["args"], cwd=tmp_path,

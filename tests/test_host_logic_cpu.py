@@ -126,78 +126,135 @@ def test_kmc2_layout_roundtrip_and_signature_lookup(tmp_path):
         assert o.L.pfo_kmer_count(o.h, b"A" * k, C.byref(got)) == 0
 
 
-# ---- the one known limit of the reproduced unitig numbering: Bifrost's "abundant" k-mers ----------------------
-def _rephash(s: bytes) -> int:
-    """Bifrost's minimizer hash (bifrost/src/RepHash.hpp) restated for building the test graph."""
-    M = (1 << 64) - 1
-    hv = [2053695854357871005, 5073395517033431291, 10060236952204337488, 7783083932390163561]
-    g, h, ht = len(s), 0, 0
-    for i in range(g):
-        h = (((h << 1) | (h >> 63)) & M) ^ hv[(s[i] & 6) >> 1]
-        ht = (((ht << 1) | (ht >> 63)) & M) ^ hv[((s[g - 1 - i] ^ 4) & 6) >> 1]
-    lo, hi = min(h, ht), max(h, ht)
-    a = ((lo & 0xFFFFFFFF) << 32) | (hi & 0xFFFFFFFF)
-    b = ((hi >> 32) << 32) | (lo >> 32)
-
-    def mix(x, y):
-        r = (x & M) * (y & M)
-        return (r & M) ^ (r >> 64)
-    return mix(0xE7037ED1A0B428DB ^ 16, mix(a ^ 0xE7037ED1A0B428DB, b ^ 0xA0761D6478BD642F))
+# ---- unitig numbering: Bifrost's "abundant" k-mers are numbered last, in its hash table's slot order ---------------
+_rephash = synth.bifrost_minimizer_hash
+_B = b"ACGT"
 
 
-def _graph_with_a_crowded_minimizer(tmp_path, n_sharing):
-    k, g = 25, 17
-    rng = np.random.default_rng(2)
-    rnd = lambda n: synth.BASES[rng.integers(0, 4, size=n, dtype=np.uint8)].tobytes()  # noqa: E731
-    core = min((rnd(g) for _ in range(4000)), key=_rephash)      # a g-mer that wins the minimizer race in its k-mers
-    seqs = [rnd(60) for _ in range(5)]
-    for i in range(n_sharing):
-        off = 1 + i % 7                                          # minimizers may not start at offset 0 or k-g
-        seqs.append(rnd(off) + core + rnd(k - g - off))
-    seqs += [rnd(25) for _ in range(10)]
-    gfa = str(tmp_path / "g.gfa")
-    with open(gfa, "wb") as f:
+def _write_gfa(path, seqs, k, g):
+    with open(path, "wb") as f:
         f.write(b"H\tVN:Z:1.0\tBV:Z:1.0.6\tKL:Z:%d\tML:Z:%d\n" % (k, g))
         for i, s in enumerate(seqs):
             f.write(b"S\t%d\t%s\n" % (i + 1, s))
-    return gfa, seqs, k
 
 
-def test_abundant_kmer_suspects_are_counted(tmp_path):
+def _crowded_graphs(seed, k, g):
+    """S-line sets that crowd minimizer buckets in different ways (not valid de Bruijn graphs -- numbering only)."""
+    rng = np.random.default_rng(seed)
+    rnd = lambda n: bytes(_B[i] for i in rng.integers(0, 4, size=n))  # noqa: E731
+    cores = sorted((rnd(g) for _ in range(3000)), key=_rephash)[:6]   # g-mers that win the minimizer race in their k-mers
+    core = cores[0]
+    out = {}
+    # k-length unitigs only: the first 15 sharers keep their rank, the others move to the end
+    out["shorts"] = [rnd(60) for _ in range(5)] + [rnd(1 + i % (k - g - 1)) + core + rnd(k - g - 1 - i % (k - g - 1)) for i in range(50)] \
+        + [rnd(k) for _ in range(10)]
+    # long unitigs through the same minimizer, interleaved: they are redirected to their next-best minimizer
+    seqs = []
+    for i in range(80):
+        if i % 3 == 0:
+            seqs.append(rnd(int(rng.integers(5, 40))) + core + rnd(int(rng.integers(5, 40))))
+        else:
+            o = 1 + int(rng.integers(0, k - g - 1))
+            seqs.append(rnd(o) + core + rnd(k - g - o))
+        if i % 7 == 0:
+            seqs.append(rnd(int(rng.integers(k, 90))))
+    out["mixed"] = seqs
+    # several crowded minimizers per unitig: redirect chains
+    seqs = []
+    for i in range(300):
+        parts = [rnd(int(rng.integers(1, 8)))]
+        for _ in range(int(rng.integers(1, 5))):
+            parts += [cores[int(rng.integers(0, len(cores)))], rnd(int(rng.integers(0, 9)))]
+        s = b"".join(parts)
+        seqs.append(s + rnd(max(0, k - len(s))))
+    out["chains"] = list(dict.fromkeys(seqs))
+    # more abundant k-mers than the hash table's first 1024 slots take: it is rebuilt twice
+    seqs = []
+    for i in range(2600):
+        c = cores[int(rng.integers(0, len(cores)))]
+        o = 1 + int(rng.integers(0, k - g - 1))
+        seqs.append(rnd(o) + c + rnd(k - g - o))
+    out["many"] = list(dict.fromkeys(seqs))
+    # low complexity: the same g-mer several times inside one k-mer (tied minimizer positions)
+    seqs = []
+    for i in range(150):
+        unit = rnd(int(rng.integers(1, 4)))
+        s = bytearray((unit * 40)[: int(rng.integers(k, k + 30))])
+        for _ in range(int(rng.integers(0, 3))):
+            s[int(rng.integers(0, len(s)))] = _B[int(rng.integers(0, 4))]
+        seqs.append(bytes(s))
+    out["lowcomplexity"] = list(dict.fromkeys(seqs))
+    return out
+
+
+def _ids_written_by_the_loader(L, gfa, tmp_path):
+    out = str(tmp_path / "ids.txt")
+    assert L.pfh_gfa_write_unitig_ids(gfa.encode(), out.encode()) == 0
+    with open(out, "rb") as f:
+        return f.read()
+
+
+def test_unitig_numbering_of_every_fixture(tmp_path):
+    """Unitig_Id.txt of the reference, from the GFA file alone; the crowded fixture has abundant k-mers, the others none."""
+    from conftest import abundant_cases, colored_cases
     from ploidyfrost_amd import hostapi
     L = hostapi.load_library()
-    gfa, _, _ = _graph_with_a_crowded_minimizer(tmp_path, 60)
-    assert L.pfh_gfa_abundant_suspects(gfa.encode()) == 60 - 15
-    (tmp_path / "few").mkdir()
-    gfa2, _, _ = _graph_with_a_crowded_minimizer(tmp_path / "few", 15)
-    assert L.pfh_gfa_abundant_suspects(gfa2.encode()) == 0
-    for case in ("dip20k", "weird12k", "col4_mix"):
-        assert L.pfh_gfa_abundant_suspects(load_case(case)["gfa"].encode()) == 0
+    for case in golden_cases() + colored_cases() + abundant_cases():
+        meta = load_case(case)
+        with open(os.path.join(meta["dir"], "expected", "g_Unitig_Id.txt"), "rb") as f:
+            assert _ids_written_by_the_loader(L, meta["gfa"], tmp_path) == f.read(), case
+        n = L.pfh_gfa_abundant_kmers(meta["gfa"].encode())
+        if meta.get("abundant"):
+            assert n > 0 and L.pfh_gfa_numbering_replays(meta["gfa"].encode()) >= 1
+        else:
+            assert n == 0
+    assert abundant_cases()
 
 
-def test_abundant_kmer_count_agrees_with_the_reference(tmp_path):
-    """Where the reference binary exists: it numbers exactly the first 15 sharers in file order and moves the others
-    to the end -- the count reported by the product is the number of displaced unitigs."""
+def test_abundant_kmers_move_to_the_end(tmp_path):
+    from ploidyfrost_amd import hostapi
+    L = hostapi.load_library()
+    k, g = 25, 17
+    seqs = _crowded_graphs(2, k, g)["shorts"]
+    gfa = str(tmp_path / "g.gfa")
+    _write_gfa(gfa, seqs, k, g)
+    assert L.pfh_gfa_abundant_kmers(gfa.encode()) == 50 - 15
+    ids = [line.split(b"\t")[1] for line in _ids_written_by_the_loader(L, gfa, tmp_path).splitlines()]
+    canon = lambda s: min(s, s.translate(bytes.maketrans(b"ACGT", b"TGCA"))[::-1])  # noqa: E731
+    assert ids[:5] == seqs[:5]
+    kept = [canon(s) for s in seqs[5: 5 + 15] + seqs[55:]]        # the first 15 sharers and the unrelated k-mers keep file order
+    assert ids[5: 5 + 25] == kept
+    assert sorted(ids[30:]) == sorted(canon(s) for s in seqs[20:55])
+    _write_gfa(gfa, seqs[:5 + 15] + seqs[55:], k, g)               # 15 sharers only: nothing is crowded yet
+    assert L.pfh_gfa_abundant_kmers(gfa.encode()) == 0
+
+
+@pytest.mark.parametrize("k,g", [(25, 17), (31, 23), (21, 13), (15, 8)])
+def test_abundant_numbering_agrees_with_the_reference(tmp_path, k, g):
+    """Where the reference binary exists (this container): its Unitig_Id.txt on graphs built to crowd minimizer buckets."""
     import subprocess
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
     if not os.path.exists(pyoracle.REF_BIN):
         pytest.skip("reference binary (oracle/_ref) not built here")
     from ploidyfrost_amd import hostapi
-    gfa, seqs, k = _graph_with_a_crowded_minimizer(tmp_path, 40)
+    L = hostapi.load_library()
     inv = {65: 0, 67: 1, 71: 2, 84: 3}
-    km, mult = synth.canonical_counts([np.array([inv[c] for c in s], dtype=np.uint8) for s in seqs], k)
-    synth.write_kmc1(str(tmp_path / "db"), km, synth.synth_counts(km, mult), k)
-    # (the reference may die after setUnitigId on this bubble-free graph -- it divides by the number of sites, 0 here)
-    subprocess.run([pyoracle.REF_BIN, "-g", gfa, "-d", str(tmp_path / "db"), "-o", "x", "-t", "1"], cwd=tmp_path,
-                   stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-    ref = [line.split("\t")[1].strip() for line in open(tmp_path / "PloidyFrost_output" / "x_Unitig_Id.txt")]
-    mine = [s.decode() for s in pyoracle.Oracle(gfa, str(tmp_path / "db")).sequences()]
-    assert sorted(ref) == sorted(mine)
-    moved = hostapi.load_library().pfh_gfa_abundant_suspects(gfa.encode())
-    assert moved == 25
-    assert ref[: 5 + 15] == mine[: 5 + 15]                       # long unitigs and the first 15 sharers keep their rank
-    assert set(ref[-moved:]) == set(mine[5 + 15: 5 + 40])       # the others are numbered last (in hash order)
+    replays = 0
+    for name, seqs in _crowded_graphs(k, k, g).items():
+        d = tmp_path / name
+        d.mkdir()
+        gfa = str(d / "g.gfa")
+        _write_gfa(gfa, seqs, k, g)
+        km, mult = synth.canonical_counts([np.array([inv[c] for c in s], dtype=np.uint8) for s in seqs], k)
+        synth.write_kmc1(str(d / "db"), km, synth.synth_counts(km, mult), k)
+        # (the reference may die after setUnitigId on these bubble-free graphs -- it divides by the number of sites, 0 here)
+        subprocess.run([pyoracle.REF_BIN, "-g", gfa, "-d", str(d / "db"), "-o", "x", "-t", "1"], cwd=d,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        with open(d / "PloidyFrost_output" / "x_Unitig_Id.txt", "rb") as f:
+            assert _ids_written_by_the_loader(L, gfa, d) == f.read(), name
+        replays = max(replays, L.pfh_gfa_numbering_replays(gfa.encode()))
+    assert replays >= 2   # redirects into buckets the first replay had not followed
 
 
 def test_work_pool(tmp_path):

@@ -6,7 +6,11 @@ output files must be byte-identical.   usage: tools/fuzz_parity.py [n_cases] [fi
 Graphs come from ploidyfrost_amd.cdbg_build (seeds whose repeat structure it cannot compact are skipped); colour sets are
 written by ploidyfrost_amd.bfg_colors and read back for the oracle by oracle/_ref/colors_dump (the real Bifrost).
 With PF_FUZZ_BIFROST=1 the graphs (and colour files) are built by the reference's own `Bifrost build` (oracle/_ref/Bifrost)
-instead: any repeat structure, samples that start and stop at different places (colours on part of a unitig)."""
+instead: any repeat structure, samples that start and stop at different places (colours on part of a unitig).
+With PF_FUZZ_REFERENCE=1 the comparator is the reference binary itself (oracle/_ref/PloidyFrost -t 1) instead of the oracle.
+With PF_FUZZ_CROWD=1 (implies both of the above) a g-mer with a very low minimizer hash is planted at 20-120 places of the
+genome, so that Bifrost files some k-length unitigs as "abundant" k-mers and numbers them last, in hash-table order -- the
+part of the unitig numbering the oracle's loader does not restate (pf_host_minz.hpp)."""
 import os
 import subprocess
 import sys
@@ -52,14 +56,21 @@ def one_case(seed, tmp, dev):
     spec = synth.HapSpec(L, ploidy, seed=seed, gap_lo=int(rng.integers(5, 30)), gap_hi=int(rng.integers(40, 500)),
                          p_multi=float(rng.choice([0.0, 0.05, 0.15])), max_ins=int(rng.choice([3, 6, 12, 30])),
                          p_snp=float(rng.choice([0.5, 0.75, 0.9])), p_del=0.1)
-    haps = synth.make_haplotypes(spec)
+    crowd = os.environ.get("PF_FUZZ_CROWD") == "1"
+    edit = None
+    if crowd:
+        g_len = k - 8 if k >= 15 else k - 4   # Bifrost's default minimizer length (CompactedDBG.hpp DEFAULT_G_DEC1/2)
+        copies = int(rng.integers(20, 120))
+        edit = lambda base: synth.plant_crowded_minimizer(np.random.default_rng(seed + 7), base, g_len, copies, tries=1500)  # noqa: E731
+    haps = synth.make_haplotypes(spec, edit)
     if rng.random() < 0.3:  # splice the variants onto a repeat-rich genome: cycles, hairpins, tips
         rep = repeat_rich(rng, L)
         haps = [np.concatenate([rep[: len(rep) // 2], h[200:-200], rep[len(rep) // 2:]]) for h in haps]
     scores = [(2, -1, -3), (2, -1, -3), (1, -1, -1), (3, -2, -4), (1.5, -0.5, -2.25), (2, -1, -2)][int(rng.integers(0, 6))]
     lower, upper = [(5, 1000), (5, 1000), (15, 70), (1, 100000)][int(rng.integers(0, 4))]
     colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4
-    use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1"
+    use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1" or crowd
+    use_reference = os.environ.get("PF_FUZZ_REFERENCE") == "1" or crowd
     try:
         if use_bifrost:
             groups = [haps[2 * i: 2 * i + 2] for i in range(ploidy // 2)] if colored else [haps]
@@ -111,16 +122,26 @@ def one_case(seed, tmp, dev):
         lst, cut = os.path.join(tmp, "dbs.txt"), os.path.join(tmp, "cut.txt")
         open(lst, "w").write("".join(d + "\n" for d in dbs))
         open(cut, "w").write(("%d\t%d\n" % (lower, upper)) * len(dbs))
-        ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-f", dump, "-d", lst, "-C", cut, "-O", os.path.join(og, "PloidyFrost_output")] + common,
-                            cwd=og, capture_output=True, text=True)
+        if use_reference:
+            ro = subprocess.run([pyoracle.REF_BIN, "-g", gfa, "-f", colors, "-d", lst, "-C", cut, "-t", "1"] + common, cwd=og, capture_output=True, text=True)
+        else:
+            ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-f", dump, "-d", lst, "-C", cut, "-O", os.path.join(og, "PloidyFrost_output")] + common,
+                                cwd=og, capture_output=True, text=True)
         rg = subprocess.run([CLI, "-g", gfa, "-f", colors, "-d", lst, "-C", cut, "-t", "8"] + common, cwd=gg, capture_output=True, text=True)
     else:
-        ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-O", os.path.join(og, "PloidyFrost_output")]
-                            + common, cwd=og, capture_output=True, text=True)
+        if use_reference:
+            ro = subprocess.run([pyoracle.REF_BIN, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-t", "1"] + common, cwd=og,
+                                capture_output=True, text=True)
+        else:
+            ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-O", os.path.join(og, "PloidyFrost_output")]
+                                + common, cwd=og, capture_output=True, text=True)
         rg = subprocess.run([CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-t", "8"] + common, cwd=gg, capture_output=True,
                             text=True)
     desc = "k=%d ploidy=%d z=%d L=%d scores=%s cut=%d/%d %s unitigs=%d" % (k, ploidy, z, L, scores, lower, upper,
                                                                           "colored" if colored else "single", n_unitigs)
+    if crowd:
+        from ploidyfrost_amd import hostapi
+        desc += " abundant=%d" % hostapi.load_library().pfh_gfa_abundant_kmers(gfa.encode())
     if ro.returncode != 0 or rg.returncode != 0:
         # both must fail alike (e.g. a k-mer missing from the database)
         return "%s: oracle rc %d, product rc %d%s" % (desc, ro.returncode, rg.returncode, "" if (ro.returncode != 0) == (rg.returncode != 0)
