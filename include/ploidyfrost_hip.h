@@ -55,7 +55,7 @@ int pf_synchronize(pf_ctx *);
  * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
-    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_COUNT_
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -228,6 +228,18 @@ int pf_unitig_cov_colored(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uin
  * missing from colour c's database or a count lies outside (low[c], up[c]).  [host|dev] */
 int pf_string_cov_colored(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t n_str, const uint32_t *low,
                           const uint32_t *up, uint64_t *sum, uint8_t *ok);
+
+/* ---- `PloidyFrost model`: the Gaussian-mixture fit of the allele frequencies (src/GmmModel.cpp, src/Main.cpp:636-692) ----
+ * pf_gmm_upload keeps the values (GmmModel::allele_fre, after the reader's frequency filter) in HBM; pf_gmm_fit is
+ * GmmModel::resize(gauss) + emIterate() (src/GmmModel.cpp:8-20, 371-385) on them: means fixed at i/(gauss+1), weights and
+ * variances re-estimated until the log-likelihood gains at most max_delta or max_iter iterations ran, with emStep's weight
+ * thresholds m_thre / n_thre (:318-330).  Outputs: gauss weights / means / variances, the log-likelihood (the sum, not the
+ * average) and the number of iterations.  fp64; sums are tree-shaped (the reference's are sequential), same order every run. */
+#define PF_GMM_MAX_GAUSS 16
+int pf_gmm_upload(pf_ctx *, const double *values, uint64_t n);
+uint64_t pf_gmm_count(const pf_ctx *);
+int pf_gmm_fit(pf_ctx *, uint32_t gauss, double m_thre, double n_thre, int32_t max_iter, double max_delta, double *weights,
+               double *means, double *vars, double *loglik, uint32_t *iterations);
 
 /* ---- pinned host memory for the exchange buffers (optional: pageable memory works, slower) ---- */
 int pf_host_alloc(pf_ctx *, size_t bytes, void **out);

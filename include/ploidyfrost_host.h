@@ -90,6 +90,27 @@ uint64_t pfh_colors_unitig(const pfh_colors *, uint32_t u, uint8_t *presence, ui
 uint64_t pfh_gfa_abundant_kmers(const char *gfa_path);
 uint32_t pfh_gfa_numbering_replays(const char *gfa_path);
 int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path);
+/* ---- `PloidyFrost model`: class GmmModel (src/GmmModel.hpp:5-49) and the driver of src/Main.cpp:636-692 ------------------
+ * pfh_gmm_open needs no device; the readers are the reference's text parsers (readFreFile src/GmmModel.cpp:240-257,
+ * readCovFile :21-239); pfh_gmm_fit = setMThreshold/setNThreshold/setMaxIterNum/setMaxDeltaNum + resize(gauss) +
+ * emIterate() on the GPU (fails without one); pfh_gmm_run fits gauss = min..max and writes <outprefix>_model_result.txt
+ * (Main.cpp:659-690).  Every call: 0 = ok, else pfh_gmm_last_error(). */
+typedef struct pfh_gmm pfh_gmm;
+pfh_gmm *pfh_gmm_open(int device);
+void pfh_gmm_close(pfh_gmm *);
+const char *pfh_gmm_last_error(const pfh_gmm *);
+int pfh_gmm_read_fre(pfh_gmm *, const char *allele_frequency_file, double min_frequency);
+int pfh_gmm_read_cov(pfh_gmm *, const char *coverage_file_prefix, double min_frequency);
+int pfh_gmm_set_values(pfh_gmm *, const double *values, uint64_t n);   /* GmmModel::readData */
+uint64_t pfh_gmm_size(const pfh_gmm *);
+int pfh_gmm_values(const pfh_gmm *, double *out);
+int pfh_gmm_fit(pfh_gmm *, uint32_t gauss, double m_thre, double n_thre, int32_t max_iter, double max_delta, double *weights,
+                double *means, double *vars, double *loglik, double *aic, uint32_t *iterations);
+int pfh_gmm_run(pfh_gmm *, int min_gauss, int max_gauss, double m_thre, double n_thre, int32_t max_iter, double max_delta,
+                const char *outprefix);
+/* enable = 1 / 0 switches the HIP-event timing of the K-GMM launches on / off; enable < 0 reads the totals */
+int pfh_gmm_kernel_time(pfh_gmm *, int enable, double *total_ms, uint64_t *launches);
+
 /* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);
 

@@ -105,6 +105,21 @@ int pfo_find_unitig(const pfo_ctx *, const char *s, uint32_t len, uint32_t *u, u
 int pfo_ploidy_estimation_colored(pfo_ctx *, const char *outdir, const char *prefix, const int *lower, const int *upper,
                                   double M, double D, double G, uint64_t allele[4], uint64_t *core_cov, uint64_t *core_num);
 
+/* ---- `PloidyFrost model` (src/GmmModel.cpp, src/Main.cpp:636-692), pf_oracle_gmm.cpp ---------------------------------- */
+typedef struct pfo_gmm pfo_gmm;
+pfo_gmm *pfo_gmm_open(void);
+void pfo_gmm_close(pfo_gmm *);
+const char *pfo_gmm_error(const pfo_gmm *);
+int pfo_gmm_read_fre(pfo_gmm *, const char *file, double min_frequency);      /* GmmModel::readFreFile */
+int pfo_gmm_read_cov(pfo_gmm *, const char *prefix, double min_frequency);    /* GmmModel::readCovFile */
+void pfo_gmm_set_values(pfo_gmm *, const double *values, uint64_t n);
+uint64_t pfo_gmm_size(const pfo_gmm *);
+void pfo_gmm_values(const pfo_gmm *, double *out);
+void pfo_gmm_fit(pfo_gmm *, uint32_t gauss, double m_thre, double n_thre, int max_iter, double max_delta, double *weights,
+                 double *means, double *vars, double *loglik, double *aic, uint32_t *iterations);
+int pfo_gmm_run(pfo_gmm *, int min_gauss, int max_gauss, double m_thre, double n_thre, int max_iter, double max_delta,
+                const char *outprefix);
+
 #ifdef __cplusplus
 }
 #endif

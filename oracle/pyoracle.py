@@ -284,3 +284,58 @@ def pairwise(a: bytes, b: bytes, M=2.0, D=-1.0, G=-3.0):
         gp = [int(x) for x in f[5].split(b",")] if f[5] else []
         res.append((f[0], f[1], gp, int(f[2]), int(f[3]), int(f[4])))
     return res
+
+
+class GmmOracle:
+    """`PloidyFrost model` restated on the CPU (oracle/pf_oracle_gmm.cpp; reference src/GmmModel.cpp)."""
+
+    def __init__(self):
+        self.L = lib()
+        L, vp, d = self.L, C.c_void_p, C.c_double
+        L.pfo_gmm_open.restype = vp
+        L.pfo_gmm_close.argtypes = [vp]
+        L.pfo_gmm_error.restype = C.c_char_p
+        L.pfo_gmm_error.argtypes = [vp]
+        L.pfo_gmm_read_fre.argtypes = [vp, C.c_char_p, d]
+        L.pfo_gmm_read_cov.argtypes = [vp, C.c_char_p, d]
+        L.pfo_gmm_set_values.argtypes = [vp, vp, C.c_uint64]
+        L.pfo_gmm_size.restype = C.c_uint64
+        L.pfo_gmm_size.argtypes = [vp]
+        L.pfo_gmm_values.argtypes = [vp, vp]
+        L.pfo_gmm_fit.argtypes = [vp, C.c_uint32, d, d, C.c_int, d, vp, vp, vp, C.POINTER(d), C.POINTER(d), C.POINTER(C.c_uint32)]
+        L.pfo_gmm_run.argtypes = [vp, C.c_int, C.c_int, d, d, C.c_int, d, C.c_char_p]
+        self.h = L.pfo_gmm_open()
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            self.L.pfo_gmm_close(self.h)
+            self.h = None
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.pfo_gmm_error(self.h).decode())
+
+    def read_fre(self, path, min_frequency=0.0):
+        self._check(self.L.pfo_gmm_read_fre(self.h, path.encode(), min_frequency))
+
+    def read_cov(self, prefix, min_frequency=0.0):
+        self._check(self.L.pfo_gmm_read_cov(self.h, prefix.encode(), min_frequency))
+
+    def set_values(self, v):
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        self.L.pfo_gmm_set_values(self.h, v.ctypes.data, len(v))
+
+    def values(self):
+        out = np.zeros(self.L.pfo_gmm_size(self.h), dtype=np.float64)
+        self.L.pfo_gmm_values(self.h, out.ctypes.data)
+        return out
+
+    def fit(self, gauss, m_thre=5.0, n_thre=2.0, max_iter=1000, max_delta=0.01):
+        w, mean, var = (np.zeros(gauss) for _ in range(3))
+        ll, aic, it = C.c_double(), C.c_double(), C.c_uint32()
+        self.L.pfo_gmm_fit(self.h, gauss, m_thre, n_thre, max_iter, max_delta, w.ctypes.data, mean.ctypes.data, var.ctypes.data,
+                           C.byref(ll), C.byref(aic), C.byref(it))
+        return {"weights": w, "means": mean, "vars": var, "loglik": ll.value, "aic": aic.value, "iterations": it.value}
+
+    def run(self, outprefix, lo=1, hi=9, m_thre=5.0, n_thre=2.0, max_iter=1000, max_delta=0.01):
+        self._check(self.L.pfo_gmm_run(self.h, lo, hi, m_thre, n_thre, max_iter, max_delta, outprefix.encode()))

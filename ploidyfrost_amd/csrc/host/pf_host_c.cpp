@@ -6,6 +6,7 @@
 #include <vector>
 
 #include "pf_cdbg.hpp"
+#include "pf_gmm_model.hpp"
 #include "pf_host_colors.hpp"
 #include "ploidyfrost_host.h"
 
@@ -37,6 +38,23 @@ static int guarded(pfh_run *r, F &&f) {
     }
 }
 
+
+struct pfh_gmm {
+    pfh::GmmModel model;
+    std::string err;
+    explicit pfh_gmm(int device) : model(device) {}
+};
+template <class F>
+static int gmm_guard(pfh_gmm *m, F &&fn) {
+    if (!m) return 1;
+    m->err.clear();
+    try {
+        return fn();
+    } catch (const std::exception &e) {
+        m->err = std::string("ploidyfrost host layer: ") + e.what();
+        return 1;
+    }
+}
 
 extern "C" {
 
@@ -218,6 +236,70 @@ int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path) {
         return 1;
     }
 }
+// ---- `PloidyFrost model` ---------------------------------------------------------------------------------------------
+pfh_gmm *pfh_gmm_open(int device) {
+    try {
+        return new pfh_gmm(device);
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return nullptr;
+    }
+}
+void pfh_gmm_close(pfh_gmm *m) { delete m; }
+const char *pfh_gmm_last_error(const pfh_gmm *m) { return m ? (m->err.empty() ? m->model.error().c_str() : m->err.c_str()) : g_open_err.c_str(); }
+int pfh_gmm_read_fre(pfh_gmm *m, const char *file, double min_frequency) {
+    return gmm_guard(m, [&] { return m->model.readFreFile(file, min_frequency); });
+}
+int pfh_gmm_read_cov(pfh_gmm *m, const char *prefix, double min_frequency) {
+    return gmm_guard(m, [&] { return m->model.readCovFile(prefix, min_frequency); });
+}
+int pfh_gmm_set_values(pfh_gmm *m, const double *values, uint64_t n) {
+    return gmm_guard(m, [&] { m->model.readData(std::vector<double>(values, values + n)); return 0; });
+}
+uint64_t pfh_gmm_size(const pfh_gmm *m) { return m ? m->model.values().size() : 0; }
+int pfh_gmm_values(const pfh_gmm *m, double *out) {
+    if (!m || !out) return 1;
+    std::copy(m->model.values().begin(), m->model.values().end(), out);
+    return 0;
+}
+int pfh_gmm_fit(pfh_gmm *m, uint32_t gauss, double m_thre, double n_thre, int32_t max_iter, double max_delta, double *weights,
+                double *means, double *vars, double *loglik, double *aic, uint32_t *iterations) {
+    return gmm_guard(m, [&] {
+        m->model.setMThreshold(m_thre);
+        m->model.setNThreshold(n_thre);
+        m->model.setMaxIterNum(max_iter);
+        m->model.setMaxDeltaNum(max_delta);
+        m->model.resize(gauss);
+        if (m->model.emIterate()) return 1;
+        for (uint32_t i = 0; i < gauss; ++i) {
+            if (weights) weights[i] = m->model.getWeights()[i];
+            if (means) means[i] = m->model.getMeans()[i];
+            if (vars) vars[i] = m->model.getVars()[i];
+        }
+        if (loglik) *loglik = m->model.getLogLikelihood();
+        if (aic) *aic = m->model.getAIC();
+        if (iterations) *iterations = m->model.iterations();
+        return 0;
+    });
+}
+int pfh_gmm_run(pfh_gmm *m, int min_gauss, int max_gauss, double m_thre, double n_thre, int32_t max_iter, double max_delta,
+                const char *outprefix) {
+    return gmm_guard(m, [&] {
+        m->model.setMThreshold(m_thre);
+        m->model.setNThreshold(n_thre);
+        m->model.setMaxIterNum(max_iter);
+        m->model.setMaxDeltaNum(max_delta);
+        return pfh::run_model(m->model, min_gauss, max_gauss, outprefix, m->err);
+    });
+}
+int pfh_gmm_kernel_time(pfh_gmm *m, int enable, double *total_ms, uint64_t *launches) {
+    if (!m) return 1;
+    pf_ctx *ctx = m->model.device_context();
+    if (!ctx) return 1;
+    if (enable >= 0) return pf_enable_timing(ctx, enable);
+    return pf_kernel_time(ctx, PF_K_GMM, total_ms, launches);
+}
+
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed) { return pfh::bifrost_kmer_hash(left_aligned_kmer, seed); }
 
 }  // extern "C"

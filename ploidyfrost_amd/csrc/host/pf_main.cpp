@@ -22,6 +22,8 @@
 #include <vector>
 
 #include "pf_cdbg.hpp"
+#include "pf_gmm_model.hpp"
+#include "ploidyfrost_hip.h"
 
 using namespace std;
 
@@ -101,14 +103,80 @@ bool file_exists(const string &p) {
     struct stat sb;
     return stat(p.c_str(), &sb) == 0;
 }
+
+void PrintModelUsage() {  // src/Main.cpp:694-718
+    cout << "Usage: PloidyFrost model" << endl
+         << "GMM model" << endl
+         << "  -f,             Prefix of coverage files" << endl
+         << "  -g,             Allele frequency file" << endl
+         << "  -l,             Minimum ploidy level" << endl
+         << "  -u,             Maximum ploidy level" << endl
+         << "  -q,             Minimum allele frequency" << endl
+         << "  -m,             Weigth minimum threshold ( each_weight > 1/(p-1)/m , default value of m is 5)" << endl
+         << "  -n,             Weigth minimum threshold ( first_weight > maximum_weight/(p-1)/n , default value of n is 2)" << endl
+         << "  -k,             Maximum iterations" << endl
+         << "  -a,             Maximum delta" << endl
+         << "  -o,             Output prefix" << endl
+         << endl;
+}
+
+// `PloidyFrost model` (src/Main.cpp:636-719): option defaults, check_Model_ProgramOptions (:542-617), the fits on the device
+int model_main(int argc, char **argv) {
+    string graphfile, colorfile, outprefix = "output";
+    int lower = 1, upper = 9, iters = 1000;
+    double frequency = 0, delta = 0.01, mthreshold = 5.0, nthreshold = 2.0;
+    int oc;
+    while ((oc = getopt(argc, argv, "M:D:G:z:a:l:q:u:e:C:R:o:t:g:f:k:d:m:n:h:ibvpNSc")) != -1) {
+        switch (oc) {
+            case 'q': frequency = atof(optarg); break;
+            case 'm': mthreshold = atof(optarg); break;
+            case 'n': nthreshold = atof(optarg); break;
+            case 'l': lower = atoi(optarg); break;
+            case 'u': upper = atoi(optarg); break;
+            case 'a': delta = atof(optarg); break;
+            case 'o': outprefix = optarg; break;
+            case 'g': graphfile = optarg; break;
+            case 'f': colorfile = optarg; break;
+            case 'k': iters = atoi(optarg); break;
+            default: break;
+        }
+    }
+    bool ok = true;
+    if (lower > upper) { cerr << "Error:  min gauss <= max gauss  " << endl; ok = false; }
+    if (lower < 1 || upper < 1) { cerr << "Error: gauss > 0  " << endl; ok = false; }
+    if (frequency >= 0.5) { cerr << "Error: frequency cutoff value should < 0.5  " << endl; ok = false; }
+    if (iters < 0) { cerr << "Error: iterate count should > 0 " << endl; ok = false; }
+    if (delta < 0) { cerr << "Error: iterate delta should > 0 " << endl; ok = false; }
+    if (mthreshold < 0) { cerr << "Error: minimum threshold should > 0 " << endl; ok = false; }
+    if (nthreshold < 0) { cerr << "Error: minimum threshold should > 0 " << endl; ok = false; }
+    if (colorfile.empty() && graphfile.empty()) { cout << "ERROR: input a frequency or coverage file " << endl; ok = false; }
+    if (!graphfile.empty() && !file_exists(graphfile)) { cout << "ERROR: open frequency file " << graphfile << " error!" << endl; ok = false; }
+    if (!colorfile.empty())
+        for (const char *suf : {"_bicov.txt", "_tricov.txt", "_tetracov.txt"})
+            if (!file_exists(colorfile + suf)) { cout << "ERROR: open coverage file " << colorfile + suf << " error!" << endl; ok = false; }
+    if (ok && upper > PF_GMM_MAX_GAUSS) { cerr << "Error: this build fits at most " << PF_GMM_MAX_GAUSS << " Gaussians (-u)" << endl; ok = false; }
+    if (!ok) { PrintModelUsage(); return 0; }
+    pfh::GmmModel model;
+    model.setMThreshold(mthreshold);
+    model.setNThreshold(nthreshold);
+    model.setMaxIterNum(iters);
+    model.setMaxDeltaNum(delta);
+    if (!colorfile.empty() ? model.readCovFile(colorfile, frequency) : model.readFreFile(graphfile, frequency)) {
+        cout << model.error() << endl;
+        exit(EXIT_FAILURE);
+    }
+    string err;
+    if (pfh::run_model(model, lower, upper, outprefix, err)) {
+        cout << err << endl;
+        exit(EXIT_FAILURE);
+    }
+    return 0;
+}
 }  // namespace
 
 int main(int argc, char **argv) {
     if (argc < 2) { PrintUsage(); return 0; }
-    if (!strcmp(argv[1], "model")) {
-        cerr << "Error: the `model` sub-command is not part of the MI355X build (hot path only)." << endl;
-        return EXIT_FAILURE;
-    }
+    if (!strcmp(argv[1], "model")) return model_main(argc, argv);
     if (!strcmp(argv[1], "cutoffL")) {  // src/Main.cpp:721-730
         if (argc != 3) { cout << "Usage:PloidyFrost cutoffL kmer_histogram_file" << endl; exit(EXIT_FAILURE); }
         cout << max(10, cutoffL(argv[2])) << endl;

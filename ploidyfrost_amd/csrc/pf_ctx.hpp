@@ -70,6 +70,10 @@ struct pf_ctx {
     uint8_t *d_cov_miss = nullptr;
     uint32_t cov_cap = 0;
 
+    // `model` sub-command (pf_gmm.hip): allele frequencies resident in workspace WS_GMM_X
+    uint64_t gmm_n = 0;
+    bool gmm_loaded = false;
+
     unsigned int bfs_deferred = 0;  // candidates of the last pf_bfs_candidates that needed the big tier
 
     // grow-only device workspaces reused across calls (slot ids: enum pf::WsSlot)
@@ -90,6 +94,6 @@ enum WsSlot {
     WS_ALN_OGAPS, WS_ALN_STTEXT, WS_ALN_STGAPS, WS_ALN_STHITS, WS_ALN_WORK, WS_BFS_REC, WS_BFS_POOL, WS_BFS_SMALL, WS_BFS_DEF,
     WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS,
     WS_BUB_TEXT, WS_BUB_PATHS, WS_BUB_TASKS, WS_BUB_SMALL, WS_BUB_RETRY, WS_BUB_IDX, WS_BUB_RES, WS_BUB_OTEXT, WS_BUB_OSITES,
-    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_COUNT_
+    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART, WS_COUNT_
 };
 }  // namespace pf

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_hip.so")
 NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
-           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored"]
+           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
@@ -89,6 +89,9 @@ def load_library() -> C.CDLL:
         "pf_num_colors": (u32, [vp]),
         "pf_unitig_cov_colored": (i, [vp, u32, u32, vp, vp, vp, vp]),
         "pf_string_cov_colored": (i, [vp, vp, vp, u32, vp, vp, vp, vp]),
+        "pf_gmm_upload": (i, [vp, vp, u64]),
+        "pf_gmm_count": (u64, [vp]),
+        "pf_gmm_fit": (i, [vp, u32, C.c_double, C.c_double, C.c_int32, C.c_double, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = header / library mismatch
@@ -102,7 +105,8 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
-                    "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored"]
+                    "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
+                    "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit"]
 
 
 def pack_unitigs(seqs: list[bytes]):

@@ -26,7 +26,9 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
-                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays"]
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays",
+                    "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
+                    "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
 
 
 def load_library() -> C.CDLL:
@@ -213,3 +215,75 @@ class ColoredRun(Run):
         lo = (C.c_int * self.n_colors)(*[int(c[0]) for c in cutoffs])
         up = (C.c_int * self.n_colors)(*[int(c[1]) for c in cutoffs])
         self._check(self.L.pfh_ploidy_estimation_colored(self.h, outpre.encode(), lo, up, len(cutoffs)))
+
+
+class Gmm:
+    """`PloidyFrost model` (reference class GmmModel, src/GmmModel.hpp): readers on the host, the EM fit on the GPU."""
+
+    def __init__(self, device: int = 0):
+        self.L = load_library()
+        L, vp, d = self.L, C.c_void_p, C.c_double
+        L.pfh_gmm_open.restype = vp
+        L.pfh_gmm_open.argtypes = [C.c_int]
+        L.pfh_gmm_close.argtypes = [vp]
+        L.pfh_gmm_last_error.restype = C.c_char_p
+        L.pfh_gmm_last_error.argtypes = [vp]
+        L.pfh_gmm_read_fre.argtypes = [vp, C.c_char_p, d]
+        L.pfh_gmm_read_cov.argtypes = [vp, C.c_char_p, d]
+        L.pfh_gmm_set_values.argtypes = [vp, vp, C.c_uint64]
+        L.pfh_gmm_size.restype = C.c_uint64
+        L.pfh_gmm_size.argtypes = [vp]
+        L.pfh_gmm_values.argtypes = [vp, vp]
+        L.pfh_gmm_fit.argtypes = [vp, C.c_uint32, d, d, C.c_int32, d, vp, vp, vp, C.POINTER(d), C.POINTER(d), C.POINTER(C.c_uint32)]
+        L.pfh_gmm_run.argtypes = [vp, C.c_int, C.c_int, d, d, C.c_int32, d, C.c_char_p]
+        L.pfh_gmm_kernel_time.argtypes = [vp, C.c_int, C.POINTER(d), C.POINTER(C.c_uint64)]
+        self.h = L.pfh_gmm_open(device)
+        if not self.h:
+            raise RuntimeError(L.pfh_gmm_last_error(None).decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pfh_gmm_close(self.h)
+            self.h = None
+
+    __del__ = close
+
+    def _check(self, rc):
+        if rc != 0:
+            raise RuntimeError(self.L.pfh_gmm_last_error(self.h).decode())
+
+    def read_fre(self, path, min_frequency=0.0):
+        self._check(self.L.pfh_gmm_read_fre(self.h, path.encode(), min_frequency))
+
+    def read_cov(self, prefix, min_frequency=0.0):
+        self._check(self.L.pfh_gmm_read_cov(self.h, prefix.encode(), min_frequency))
+
+    def set_values(self, v):
+        import numpy as np
+        v = np.ascontiguousarray(v, dtype=np.float64)
+        self._check(self.L.pfh_gmm_set_values(self.h, v.ctypes.data, len(v)))
+
+    def values(self):
+        import numpy as np
+        out = np.zeros(self.L.pfh_gmm_size(self.h), dtype=np.float64)
+        self._check(self.L.pfh_gmm_values(self.h, out.ctypes.data if len(out) else None) if len(out) else 0)
+        return out
+
+    def fit(self, gauss, m_thre=5.0, n_thre=2.0, max_iter=1000, max_delta=0.01):
+        import numpy as np
+        w, mean, var = (np.zeros(gauss) for _ in range(3))
+        ll, aic, it = C.c_double(), C.c_double(), C.c_uint32()
+        self._check(self.L.pfh_gmm_fit(self.h, gauss, m_thre, n_thre, max_iter, max_delta, w.ctypes.data, mean.ctypes.data,
+                                       var.ctypes.data, C.byref(ll), C.byref(aic), C.byref(it)))
+        return {"weights": w, "means": mean, "vars": var, "loglik": ll.value, "aic": aic.value, "iterations": it.value}
+
+    def run(self, outprefix, lo=1, hi=9, m_thre=5.0, n_thre=2.0, max_iter=1000, max_delta=0.01):
+        self._check(self.L.pfh_gmm_run(self.h, lo, hi, m_thre, n_thre, max_iter, max_delta, outprefix.encode()))
+
+    def enable_timing(self, on=True):
+        self._check(self.L.pfh_gmm_kernel_time(self.h, 1 if on else 0, None, None))
+
+    def kernel_time(self):
+        ms, n = C.c_double(), C.c_uint64()
+        self._check(self.L.pfh_gmm_kernel_time(self.h, -1, C.byref(ms), C.byref(n)))
+        return ms.value, n.value
