@@ -55,7 +55,7 @@ int pf_synchronize(pf_ctx *);
  * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
-    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_COUNT_
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -75,6 +75,17 @@ int pf_upload_graph(pf_ctx *, const uint64_t *seq_words, const uint64_t *seq_off
 int pf_build_adjacency(pf_ctx *, uint32_t *succ, uint32_t *pred);
 
 /* ---- k-mer count table (replaces CKMCFile, KMC/kmc_api/kmc_file.cpp) ------------------- */
+/* K-KMC: KMC database ingest on the device.  `records` = the record area of <db>.kmc_suf (after its 4-byte marker): n_records
+ * records of suffix_bytes = (k - lut_prefix_len) / 4 suffix bytes (most significant first) + counter_bytes counter bytes (least
+ * significant first), ordered as the prefix table says (KMC/kmc_api/kmc_file.cpp:185-302, 775-782): lut[e] = index of the first
+ * record of table entry e, e = prefix for the KMC1 layout and bin * 4^p + prefix for the KMC2 (signature-binned) layout, with
+ * n_lut entries plus lut[n_lut] = n_records.  Output: two device arrays (exact k-mers as stored, counts truncated to 32 bits)
+ * to hand to pf_upload_counts / pf_upload_counts_colored, released with pf_device_free.  records: [host|dev]; lut: host */
+int pf_kmc_decode(pf_ctx *, const uint8_t *records, uint64_t n_records, uint32_t suffix_bytes, uint32_t counter_bytes,
+                  const uint64_t *lut, uint64_t n_lut, uint32_t lut_prefix_len, uint32_t k, uint64_t **kmers_dev, uint32_t **counts_dev);
+void pf_device_free(pf_ctx *, void *device_pointer);
+int pf_copy_to_host(pf_ctx *, void *dst, const void *src_dev, size_t bytes);
+
 /* K1/K2: builds the device hash table from the database records (exact k-mers as stored, any
  * order).  Records with count outside [min_count, max_count] are not retrievable, as in
  * CKMCFile::BinarySearch (kmc_file.cpp:1459).  both_strands mirrors GetBothStrands();

@@ -60,19 +60,22 @@ CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, doub
             if ((int)dbs[c].k != g_.k) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: k of kmc database " + names[c] + " differs from the graph's"); return; }
             if (!quiet_) printf("CCDBG::CCDBG(): kmc database %s initialized\n", names[c].c_str());
         }
-        std::vector<const uint64_t *> pk(C);
-        std::vector<const uint32_t *> pc(C);
+        // every database is decoded on the device (K-KMC) from its mapped record file; the joint table is built from those arrays
+        std::vector<uint64_t *> pk(C, nullptr);
+        std::vector<uint32_t *> pc(C, nullptr);
         std::vector<uint64_t> n(C), mn(C), mx(C);
         std::vector<int> both(C);
-        for (uint32_t c = 0; c < C; ++c) {
-            pk[c] = dbs[c].kmers.data();
-            pc[c] = dbs[c].counts.data();
+        int st = PF_OK;
+        for (uint32_t c = 0; c < C && st == PF_OK; ++c) {
+            st = pf_kmc_decode(ctx_, dbs[c].records, dbs[c].total, dbs[c].suffix_bytes, dbs[c].counter_size, dbs[c].lut.data(), dbs[c].n_lut(),
+                               dbs[c].lut_prefix_len, dbs[c].k, &pk[c], &pc[c]);
             n[c] = dbs[c].total;
             mn[c] = dbs[c].min_count;
             mx[c] = dbs[c].max_count;
             both[c] = dbs[c].both_strands;
         }
-        int st = pf_upload_counts_colored(ctx_, C, pk.data(), pc.data(), n.data(), mn.data(), mx.data(), both.data());
+        if (st == PF_OK) st = pf_upload_counts_colored(ctx_, C, pk.data(), pc.data(), n.data(), mn.data(), mx.data(), both.data());
+        for (uint32_t c = 0; c < C; ++c) { pf_device_free(ctx_, pk[c]); pf_device_free(ctx_, pc[c]); }
         if (st != PF_OK) { fail(st, std::string("CCDBG::CCDBG():Error: ") + pf_last_error(ctx_)); return; }
     }
     if (!quiet_) printf("CCDBG::CCDBG():CCDBG initialized!\n");

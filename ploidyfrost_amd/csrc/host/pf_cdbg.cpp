@@ -49,7 +49,13 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
         if (!db.load(kmc_db, e)) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: Open kmc database error . (" + e + ")"); return; }
         if ((int)db.k != g_.k) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: k of the kmc database differs from the graph's"); return; }
         both_strands_ = db.both_strands;
-        int st = pf_upload_counts(ctx_, db.kmers.data(), db.counts.data(), db.total, db.min_count, db.max_count, db.both_strands);
+        // the records are decoded on the device (K-KMC) straight from the mapped file, then hashed into the count table
+        uint64_t *dk = nullptr;
+        uint32_t *dc = nullptr;
+        int st = pf_kmc_decode(ctx_, db.records, db.total, db.suffix_bytes, db.counter_size, db.lut.data(), db.n_lut(), db.lut_prefix_len, db.k, &dk, &dc);
+        if (st == PF_OK) st = pf_upload_counts(ctx_, dk, dc, db.total, db.min_count, db.max_count, db.both_strands);
+        pf_device_free(ctx_, dk);
+        pf_device_free(ctx_, dc);
         if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: ") + pf_last_error(ctx_)); return; }
     }
     if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");

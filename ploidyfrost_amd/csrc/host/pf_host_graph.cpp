@@ -234,18 +234,41 @@ static bool read_all(const std::string &path, std::vector<uint8_t> &buf) {
     return got == (size_t)sz;
 }
 
+KmcRecords::~KmcRecords() {
+    if (map_ && map_n_) munmap(map_, map_n_);
+}
+
 bool KmcRecords::load(const std::string &prefix, std::string &err) {
-    std::vector<uint8_t> pre, suf;
-    if (!read_all(prefix + ".kmc_pre", pre) || !read_all(prefix + ".kmc_suf", suf)) {
-        err = "cannot read " + prefix + ".kmc_pre / .kmc_suf";
+    std::vector<uint8_t> pre;
+    if (!read_all(prefix + ".kmc_pre", pre)) { err = "cannot read " + prefix + ".kmc_pre / .kmc_suf"; return false; }
+    {
+        const std::string path = prefix + ".kmc_suf";
+        const int fd = ::open(path.c_str(), O_RDONLY);
+        struct stat st;
+        if (fd < 0 || fstat(fd, &st) != 0) {
+            if (fd >= 0) close(fd);
+            err = "cannot read " + prefix + ".kmc_pre / .kmc_suf";
+            return false;
+        }
+        map_n_ = (size_t)st.st_size;
+        if (map_n_) {
+            map_ = mmap(nullptr, map_n_, PROT_READ, MAP_PRIVATE | MAP_POPULATE, fd, 0);
+            if (map_ == MAP_FAILED) { map_ = nullptr; map_n_ = 0; close(fd); err = "cannot map " + path; return false; }
+        }
+        close(fd);
+    }
+    const uint8_t *suf = (const uint8_t *)map_;
+    const size_t suf_n = map_n_;
+    if (pre.size() < 24 || memcmp(pre.data(), "KMCP", 4) != 0 || memcmp(pre.data() + pre.size() - 4, "KMCP", 4) != 0 || suf_n < 8 ||
+        memcmp(suf, "KMCS", 4) != 0 || memcmp(suf + suf_n - 4, "KMCS", 4) != 0) {
+        err = "not a KMC database (markers)";
         return false;
     }
-    auto marker = [](const std::vector<uint8_t> &b, const char *m) {
-        return b.size() >= 8 && memcmp(b.data(), m, 4) == 0 && memcmp(b.data() + b.size() - 4, m, 4) == 0;
-    };
-    if (!marker(pre, "KMCP") || !marker(suf, "KMCS") || pre.size() < 24) { err = "not a KMC database (markers)"; return false; }
     uint32_t version;
     memcpy(&version, pre.data() + pre.size() - 12, 4);
+    const uint8_t *body = pre.data() + 4;
+    auto word = [&](uint64_t i) { uint64_t v; memcpy(&v, body + 8 * i, 8); return v; };
+    uint64_t n_entries = 0;
     if (version == 0x200) {
         // KMC2 (kmc_file.cpp:196-245): 'KMCP' | u64 LUT[n_bins*4^p + 1] | u32 signature_map[4^sig + 1] | header | u32 off | 'KMCP'.
         // The lookup of the reference goes signature -> bin -> LUT row -> binary search; to enumerate the
@@ -272,78 +295,49 @@ bool KmcRecords::load(const std::string &prefix, std::string &err) {
         const uint64_t size = pre.size() - 12;  // without markers and the header_offset word
         const uint64_t sig_bytes = ((1ull << (2 * sig_len)) + 1) * 4;
         if (size < sig_bytes + header_offset + 8) { err = "kmc_pre too short for the KMC2 layout"; return false; }
-        const uint64_t n_lut = (size - sig_bytes - header_offset) / 8;  // n_bins * 4^p + 1
+        const uint64_t n_words = (size - sig_bytes - header_offset) / 8;  // n_bins * 4^p + 1
         const uint64_t n_pref = 1ull << (2 * p);
-        if (n_lut < n_pref + 1 || (n_lut - 1) % n_pref) { err = "KMC2 prefix table is not a whole number of bins"; return false; }
-        const uint8_t *body = pre.data() + 4;
-        auto word = [&](uint64_t i) { uint64_t v; memcpy(&v, body + 8 * i, 8); return v; };
-        const uint32_t sb = (k - p) / 4, rec = sb + counter_size;
-        if (suf.size() - 8 < total * rec) { err = "kmc_suf holds fewer records than total_kmers"; return false; }
-        kmers.assign(total, 0);
-        counts.assign(total, 0);
-        const uint8_t *r = suf.data() + 4;
-        for (uint64_t e = 0; e + 1 < n_lut; ++e) {
-            const uint64_t x = e % n_pref;
-            const uint64_t lo = word(e);
-            uint64_t hi_rec = e + 2 < n_lut ? word(e + 1) : total;  // the reader patches the last word to total + 1
-            if (hi_rec > total) hi_rec = total;
-            for (uint64_t i = lo; i < hi_rec; ++i) {
-                const uint8_t *q = r + i * rec;
-                uint64_t s = 0;
-                for (uint32_t b2 = 0; b2 < sb; ++b2) s = (s << 8) | q[b2];
-                uint64_t c = 0;
-                for (uint32_t b2 = 0; b2 < counter_size; ++b2) c |= (uint64_t)q[sb + b2] << (8 * b2);
-                kmers[i] = (x << (2 * (k - p))) | s;
-                counts[i] = (uint32_t)c;
-            }
+        if (n_words < n_pref + 1 || (n_words - 1) % n_pref) { err = "KMC2 prefix table is not a whole number of bins"; return false; }
+        n_entries = n_words - 1;  // the reader patches the last word to total + 1
+    } else if (version == 0) {
+        // KMC1: 'KMCP' | u64 LUT[...] | header | u32 header_offset | 'KMCP'
+        const uint64_t body_sz = pre.size() - 8 - 4;  // without markers and the header_offset word
+        const uint64_t header_offset = pre[pre.size() - 8];
+        if (header_offset > body_sz || header_offset < 40) { err = "bad KMC header offset"; return false; }
+        const uint64_t hi = (body_sz - header_offset) / 8;
+        k = (uint32_t)word(hi);
+        mode = (uint32_t)(word(hi) >> 32);
+        counter_size = (uint32_t)word(hi + 1);
+        lut_prefix_len = (uint32_t)(word(hi + 1) >> 32);
+        min_count = (uint32_t)word(hi + 2);
+        max_count = word(hi + 2) >> 32;
+        total = word(hi + 3);
+        both_strands = (word(hi + 4) & 0xF) != 1;
+        max_count += word(hi + 4) & 0xFFFFFFFF00000000ull;
+        if (mode != 0) { err = "KMC databases with float counters (mode 1) are not supported"; return false; }
+        const uint32_t p = lut_prefix_len;
+        if (k < 3 || k > 31 || p == 0 || p >= k || (k - p) % 4 || counter_size == 0 || counter_size > 8) {
+            err = "unsupported k / lut_prefix_length / counter_size in the KMC header";
+            return false;
         }
-        return true;
-    }
-    if (version != 0) { err = "unknown KMC database version"; return false; }
-    // KMC1: 'KMCP' | u64 LUT[...] | header | u32 header_offset | 'KMCP'
-    const uint8_t *body = pre.data() + 4;
-    const uint64_t body_sz = pre.size() - 8 - 4;  // without markers and the header_offset word
-    const uint64_t header_offset = pre[pre.size() - 8];
-    if (header_offset > body_sz || header_offset < 40) { err = "bad KMC header offset"; return false; }
-    const uint64_t hi = (body_sz - header_offset) / 8;
-    auto word = [&](uint64_t i) { uint64_t v; memcpy(&v, body + 8 * i, 8); return v; };
-    k = (uint32_t)word(hi);
-    mode = (uint32_t)(word(hi) >> 32);
-    counter_size = (uint32_t)word(hi + 1);
-    lut_prefix_len = (uint32_t)(word(hi + 1) >> 32);
-    min_count = (uint32_t)word(hi + 2);
-    max_count = word(hi + 2) >> 32;
-    total = word(hi + 3);
-    both_strands = (word(hi + 4) & 0xF) != 1;
-    max_count += word(hi + 4) & 0xFFFFFFFF00000000ull;
-    if (mode != 0) { err = "KMC databases with float counters (mode 1) are not supported"; return false; }
-    const uint32_t p = lut_prefix_len;
-    if (k < 3 || k > 31 || p == 0 || p >= k || (k - p) % 4 || counter_size == 0 || counter_size > 8) {
-        err = "unsupported k / lut_prefix_length / counter_size in the KMC header";
+        n_entries = 1ull << (2 * p);
+        if (hi < n_entries) { err = "KMC prefix table shorter than 4^p"; return false; }
+    } else {
+        err = "unknown KMC database version";
         return false;
     }
-    const uint64_t n_pref = 1ull << (2 * p);
-    if (hi < n_pref) { err = "KMC prefix table shorter than 4^p"; return false; }
-    const uint32_t sb = (k - p) / 4, rec = sb + counter_size;
-    if (suf.size() - 8 < total * rec) { err = "kmc_suf holds fewer records than total_kmers"; return false; }
-    kmers.resize(total);
-    counts.resize(total);
-    const uint8_t *r = suf.data() + 4;
-    for (uint64_t x = 0; x < n_pref; ++x) {
-        uint64_t lo = word(x);
-        uint64_t hi_rec = (x + 1 < hi) ? word(x + 1) : total;  // the reader patches LUT[end] = total + 1 (:292)
-        if (x + 1 == n_pref && (x + 1 >= hi || hi_rec > total)) hi_rec = total;
-        if (hi_rec > total) hi_rec = total;
-        for (uint64_t i = lo; i < hi_rec; ++i) {
-            const uint8_t *q = r + i * rec;
-            uint64_t s = 0;
-            for (uint32_t b = 0; b < sb; ++b) s = (s << 8) | q[b];
-            uint64_t c = 0;
-            for (uint32_t b = 0; b < counter_size; ++b) c |= (uint64_t)q[sb + b] << (8 * b);
-            kmers[i] = (x << (2 * (k - p))) | s;
-            counts[i] = (uint32_t)c;
-        }
+    suffix_bytes = (k - lut_prefix_len) / 4;
+    if (suf_n - 8 < total * (uint64_t)(suffix_bytes + counter_size)) { err = "kmc_suf holds fewer records than total_kmers"; return false; }
+    lut.resize(n_entries + 1);
+    uint64_t prev = 0;
+    for (uint64_t e = 0; e < n_entries; ++e) {
+        uint64_t v = word(e);
+        if (v > total) v = total;
+        if (v < prev || (e == 0 && v != 0)) { err = "KMC prefix table is not ascending from 0"; return false; }
+        lut[e] = prev = v;
     }
+    lut[n_entries] = total;
+    records = suf + 4;
     return true;
 }
 

@@ -48,14 +48,25 @@ struct UnitigSet {
     void pack();
 };
 
+// A KMC database opened for the device: header and prefix table parsed on the host (a few KB .. MB), the record area of
+// <db>.kmc_suf mapped and handed to pf_kmc_decode as it lies on disk (KMC1 layout kmc_file.cpp:246-299, KMC2 :196-245).
 struct KmcRecords {
-    uint32_t k = 0, counter_size = 0, lut_prefix_len = 0, mode = 0;
+    uint32_t k = 0, counter_size = 0, lut_prefix_len = 0, mode = 0, suffix_bytes = 0;
     uint64_t min_count = 0, max_count = 0, total = 0;
     bool both_strands = true;
-    std::vector<uint64_t> kmers;   // exact k-mers as stored, ascending inside each prefix
-    std::vector<uint32_t> counts;
-    // Parses prefix.kmc_pre / prefix.kmc_suf (KMC1 layout, kmc_file.cpp:246-299).
+    std::vector<uint64_t> lut;          // first record of every prefix-table entry, plus lut[n_lut()] = total
+    const uint8_t *records = nullptr;   // total * (suffix_bytes + counter_size) bytes inside the mapped file
+    uint64_t n_lut() const { return lut.empty() ? 0 : lut.size() - 1; }
+
+    KmcRecords() = default;
+    KmcRecords(const KmcRecords &) = delete;
+    KmcRecords &operator=(const KmcRecords &) = delete;
+    ~KmcRecords();
     bool load(const std::string &prefix, std::string &err);
+
+private:
+    void *map_ = nullptr;
+    size_t map_n_ = 0;
 };
 
 }  // namespace pfh

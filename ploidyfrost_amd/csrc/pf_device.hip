@@ -65,6 +65,37 @@ __global__ void k_table_build(Slot *t, uint64_t mask, const uint64_t *__restrict
     }
 }
 
+// K-KMC: the records of a KMC database as they lie in <db>.kmc_suf -- (k-p)/4 suffix bytes, most significant first, then the
+// counter, least significant byte first (KMC/kmc_api/kmc_file.cpp:775-782, 1383-1462) -- decoded into (k-mer, count) pairs.
+// lut[e] = first record of prefix-table entry e (KMC1: e = prefix; KMC2: e = bin * 4^p + prefix), lut[n_lut] = n.  One thread
+// decodes KMC_PER_THREAD consecutive records: one binary search, then a forward walk over the entries.
+constexpr int KMC_PER_THREAD = 4;
+__global__ void k_kmc_decode(const uint8_t *__restrict__ rec, uint64_t n, uint32_t sb, uint32_t cb, const uint64_t *__restrict__ lut,
+                             uint64_t n_lut, uint32_t pref_mask, uint32_t suffix_bits, uint64_t *__restrict__ kmers,
+                             uint32_t *__restrict__ counts) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    const uint32_t rb = sb + cb;
+    for (uint64_t i0 = t * KMC_PER_THREAD; i0 < n; i0 += stride * KMC_PER_THREAD) {
+        uint64_t lo = 0, hi = n_lut;  // the last entry e with lut[e] <= i0
+        while (hi - lo > 1) {
+            const uint64_t mid = (lo + hi) >> 1;
+            if (lut[mid] <= i0) lo = mid; else hi = mid;
+        }
+        uint64_t e = lo;
+        const uint64_t i1 = i0 + KMC_PER_THREAD < n ? i0 + KMC_PER_THREAD : n;
+        for (uint64_t i = i0; i < i1; ++i) {
+            while (e + 1 < n_lut && lut[e + 1] <= i) ++e;
+            const uint8_t *q = rec + i * rb;
+            uint64_t s = 0, c = 0;
+            for (uint32_t b = 0; b < sb; ++b) s = (s << 8) | q[b];
+            for (uint32_t b = 0; b < cb; ++b) c |= (uint64_t)q[sb + b] << (8 * b);
+            kmers[i] = ((uint64_t)(e & pref_mask) << suffix_bits) | s;
+            counts[i] = (uint32_t)c;
+        }
+    }
+}
+
 // Does the table hold both orientations of some k-mer?  One thread per slot.
 __global__ void k_table_two_strands(const Slot *__restrict__ t, uint64_t cap, int k, unsigned int *flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -448,7 +479,7 @@ namespace pf {
 
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
-                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm"};
+                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode"};
 
 int ctx_begin(pf_ctx *ctx, int kernel) {
     if (!ctx->timing) return 0;
@@ -742,6 +773,64 @@ int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
     ctx->has_adj = true;
     if (succ) PF_HIP(hipMemcpyAsync(succ, ctx->d_succ, (size_t)N * 8 * 4, hipMemcpyDefault, ctx->stream));
     if (pred) PF_HIP(hipMemcpyAsync(pred, ctx->d_pred, (size_t)N * 8 * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    return PF_OK;
+}
+
+int pf_kmc_decode(pf_ctx *ctx, const uint8_t *records, uint64_t n_records, uint32_t suffix_bytes, uint32_t counter_bytes,
+                  const uint64_t *lut, uint64_t n_lut, uint32_t lut_prefix_len, uint32_t k, uint64_t **kmers_dev, uint32_t **counts_dev) {
+    if (!ctx || !kmers_dev || !counts_dev || (n_records && (!records || !lut)) || n_lut == 0 || lut_prefix_len == 0 || lut_prefix_len > 15 ||
+        k > 31 || lut_prefix_len >= k || (k - lut_prefix_len) != suffix_bytes * 4 || counter_bytes == 0 || counter_bytes > 8) {
+        if (ctx) ctx->err = "pf_kmc_decode: inconsistent k / lut_prefix_len / suffix_bytes / counter_bytes";
+        return PF_ERR_ARG;
+    }
+    *kmers_dev = nullptr;
+    *counts_dev = nullptr;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (lut[0] != 0 || lut[n_lut] != n_records) { ctx->err = "pf_kmc_decode: lut must start at 0 and end (entry n_lut) at n_records"; return PF_ERR_ARG; }
+    for (uint64_t e = 0; e < n_lut; ++e)
+        if (lut[e] > lut[e + 1]) { ctx->err = "pf_kmc_decode: lut is not non-decreasing"; return PF_ERR_ARG; }
+    DevTmp<uint8_t> drec;
+    DevTmp<uint64_t> dlut;
+    uint64_t *dk = nullptr;
+    uint32_t *dc = nullptr;
+    const size_t rec_bytes = (size_t)n_records * (suffix_bytes + counter_bytes);
+    PF_HIP(drec.alloc(rec_bytes));
+    PF_HIP(dlut.alloc((n_lut + 1) * 8));
+    PF_HIP(hipMalloc(&dk, n_records ? n_records * 8 : 8));
+    if (hipMalloc(&dc, n_records ? n_records * 4 : 4) != hipSuccess) { hipFree(dk); ctx->err = "hipMalloc of the decoded counts failed"; return PF_ERR_HIP; }
+    hipError_t e1 = hipMemcpyAsync(drec.p, records, rec_bytes, hipMemcpyDefault, ctx->stream);
+    hipError_t e2 = hipMemcpyAsync(dlut.p, lut, (n_lut + 1) * 8, hipMemcpyDefault, ctx->stream);
+    if (e1 == hipSuccess && e2 == hipSuccess && n_records) {
+        ctx_begin(ctx, PF_K_KMC_DECODE);
+        k_kmc_decode<<<ctx_grid(ctx, (n_records + KMC_PER_THREAD - 1) / KMC_PER_THREAD, 256, 8), 256, 0, ctx->stream>>>(
+            drec.p, n_records, suffix_bytes, counter_bytes, dlut.p, n_lut, (1u << (2 * lut_prefix_len)) - 1, 8 * suffix_bytes, dk, dc);
+        ctx_end(ctx);
+        e1 = hipGetLastError();
+    }
+    if (e1 == hipSuccess) e1 = e2;
+    if (e1 == hipSuccess) e1 = hipStreamSynchronize(ctx->stream);
+    if (e1 != hipSuccess) {
+        hipFree(dk);
+        hipFree(dc);
+        ctx->err = std::string("pf_kmc_decode: ") + hipGetErrorString(e1);
+        return PF_ERR_HIP;
+    }
+    *kmers_dev = dk;
+    *counts_dev = dc;
+    return PF_OK;
+}
+
+void pf_device_free(pf_ctx *ctx, void *p) {
+    if (!p) return;
+    if (ctx) (void)hipSetDevice(ctx->device);
+    (void)hipFree(p);
+}
+
+int pf_copy_to_host(pf_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
+    if (!ctx || (bytes && (!dst || !src_dev))) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipMemcpyAsync(dst, src_dev, bytes, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
     return PF_OK;
 }

@@ -293,3 +293,30 @@ def test_count_table_low_complexity_and_both_orientations(k):
     s, m, miss, st = dev.unitig_cov()
     assert st == 0 and int(s[0]) == int(want.astype(np.uint64).sum()) and int(m[0]) == int(want.min())
     dev.close()
+
+
+@pytest.mark.parametrize("k,p,cs", [(25, 5, 2), (31, 7, 4), (21, 1, 1), (9, 1, 3)])
+def test_kmc_records_are_decoded_on_the_device(k, p, cs, tmp_path):
+    """K-KMC against the writer's own arrays: records of a KMC1-layout file, bin-wise tables (KMC2 style), empty entries."""
+    rng = np.random.default_rng(k)
+    n = 50_000 if k > 9 else 3000
+    km = np.unique(rng.integers(0, 1 << (2 * k), size=n, dtype=np.uint64))
+    ct = rng.integers(1, min(1 << (8 * cs), 1 << 32), size=len(km), dtype=np.uint64).astype(np.uint32)
+    synth.write_kmc1(str(tmp_path / "db"), km, ct, k, counter_size=cs, max_count=(1 << (8 * cs)) - 1, p=p)
+    raw = np.fromfile(str(tmp_path / "db.kmc_suf"), dtype=np.uint8)[4:-4]
+    sb = (k - p) // 4
+    pre = (km >> np.uint64(2 * (k - p))).astype(np.int64)
+    lut = np.append(np.searchsorted(pre, np.arange(4 ** p, dtype=np.int64), side="left"), len(km)).astype(np.uint64)
+    dev = hipapi.Device()
+    got_k, got_c = dev.kmc_decode(raw, len(km), sb, cs, lut, p, k)
+    assert np.array_equal(got_k, km) and np.array_equal(got_c, ct)
+    # two "bins": the same records split in the middle, each half with its own prefix table (the KMC2 arrangement)
+    h = len(km) // 2
+    lut2 = np.concatenate([np.minimum(lut[:-1], h), np.maximum(lut[:-1], h), [len(km)]]).astype(np.uint64)
+    got_k, got_c = dev.kmc_decode(raw, len(km), sb, cs, lut2, p, k)
+    assert np.array_equal(got_k, km) and np.array_equal(got_c, ct)
+    # nothing to decode / a table that does not cover the records
+    e_k, e_c = dev.kmc_decode(raw[:0], 0, sb, cs, np.zeros(4 ** p + 1, dtype=np.uint64), p, k)
+    assert len(e_k) == 0 and len(e_c) == 0
+    with pytest.raises(RuntimeError):
+        dev.kmc_decode(raw, len(km), sb, cs, lut[:-1], p, k)
