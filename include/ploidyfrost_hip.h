@@ -55,7 +55,7 @@ int pf_synchronize(pf_ctx *);
  * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
-    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_COUNT_
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -75,6 +75,16 @@ int pf_upload_graph(pf_ctx *, const uint64_t *seq_words, const uint64_t *seq_off
 int pf_build_adjacency(pf_ctx *, uint32_t *succ, uint32_t *pred);
 
 /* ---- k-mer count table (replaces CKMCFile, KMC/kmc_api/kmc_file.cpp) ------------------- */
+/* K-MINZ (GFA ingest, unitig numbering): how often does the most frequent minimizer occur in the uploaded graph?  Bifrost numbers
+ * a k-length unitig last when the bucket of its minimizer already holds 15 entries (CompactedDBG.tcc:3928-4080); the loader has to
+ * replay that bookkeeping on the host only when some bucket can get that full.  Counts every g-mer position that is the minimum
+ * (bifrost/src/RepHash.hpp hash; not at either end of the k-mer, minHashIterator.hpp:63-119) of the window of some k-mer containing it,
+ * in a table of pf_minimizer_table_slots(n_kmers) slots indexed by a mix of the canonical minimizer -- per slot an upper bound of
+ * the entries Bifrost can file there.  *max_occurrences < 15  =>  no abundant k-mer: ids are long unitigs, then k-length ones, in
+ * file order.  crowded_slots (optional): slots that reached `limit`; table_out (optional, host or device): the u32 counters. */
+uint64_t pf_minimizer_table_slots(uint64_t n_kmers);
+int pf_minimizer_crowding(pf_ctx *, int g, uint32_t limit, uint32_t *max_occurrences, uint64_t *crowded_slots, uint32_t *table_out);
+
 /* K-KMC: KMC database ingest on the device.  `records` = the record area of <db>.kmc_suf (after its 4-byte marker): n_records
  * records of suffix_bytes = (k - lut_prefix_len) / 4 suffix bytes (most significant first) + counter_bytes counter bytes (least
  * significant first), ordered as the prefix table says (KMC/kmc_api/kmc_file.cpp:185-302, 775-782): lut[e] = index of the first

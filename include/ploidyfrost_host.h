@@ -89,6 +89,9 @@ uint64_t pfh_colors_unitig(const pfh_colors *, uint32_t u, uint8_t *presence, ui
  * loader replayed Bifrost's bucket bookkeeping (> 1: long unitigs were redirected into buckets it had not followed). */
 uint64_t pfh_gfa_abundant_kmers(const char *gfa_path);
 uint32_t pfh_gfa_numbering_replays(const char *gfa_path);
+/* the host pass's saturating minimizer-occurrence counters (what K-MINZ, pf_minimizer_crowding, bounds from above): returns
+ * the number of slots (0 when the graph has no k-length unitig to decide about) and fills counters when slots suffices */
+uint64_t pfh_gfa_minimizer_counts(const char *gfa_path, uint8_t *counters, uint64_t slots);
 int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path);
 /* ---- `PloidyFrost model`: class GmmModel (src/GmmModel.hpp:5-49) and the driver of src/Main.cpp:636-692 ------------------
  * pfh_gmm_open needs no device; the readers are the reference's text parsers (readFreFile src/GmmModel.cpp:240-257,

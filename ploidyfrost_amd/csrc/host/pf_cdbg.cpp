@@ -4,6 +4,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -20,16 +21,52 @@
 
 namespace pfh {
 
+namespace {
+struct LoadTrace {  // PF_TRACE_LOAD=1: where construction spends its time, on stderr
+    bool on = getenv("PF_TRACE_LOAD") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[load] %-28s %.3fs\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
 int CDBG::init_device(int device) {
+    LoadTrace trace;
     int st = pf_create(device, &ctx_);
+    trace.mark("device: context");
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: " + pf_last_error(nullptr));
     st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));
+    trace.mark("device: graph upload");
+    if (g_.numbering_deferred) {
+        // unitig numbering, last part: K-MINZ bounds the fill of every minimizer bucket; only a graph that can crowd one
+        // (15 entries, bifrost/src/CompactedDBG.tcc:4013) needs the host replay of Bifrost's bookkeeping and a second upload
+        uint32_t most = 0;
+        if (g_.n_short && g_.g >= 1 && g_.g <= g_.k - 2 && g_.g <= 31) {
+            st = pf_minimizer_crowding(ctx_, g_.g, 15, &most, nullptr, nullptr);
+            if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: minimizer census: " + pf_last_error(ctx_));
+        }
+        if (most >= 15) {
+            g_.finish_numbering();
+            if (g_.n_abundant) {
+                st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
+                if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));
+            }
+        } else {
+            g_.numbering_settled();
+        }
+        trace.mark(most >= 15 ? "device: numbering (replayed)" : "device: numbering (K-MINZ)");
+    }
     const uint32_t N = g_.n();
     succ_.resize((size_t)N * 8);
     pred_.resize((size_t)N * 8);
     st = pf_build_adjacency(ctx_, succ_.data(), pred_.data());
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: adjacency: " + pf_last_error(ctx_));
+    trace.mark("device: adjacency");
     flags_.assign(N, 0);
     plus_.assign(N, 0);
     minus_.assign(N, 0);
@@ -44,10 +81,12 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     sc_.gap = g;
     if (init_device(device)) return;
     if (!kmc_db.empty()) {
+        LoadTrace trace;
         KmcRecords db;
         std::string e;
         if (!db.load(kmc_db, e)) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: Open kmc database error . (" + e + ")"); return; }
         if ((int)db.k != g_.k) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: k of the kmc database differs from the graph's"); return; }
+        trace.mark("kmc: map + prefix table");
         both_strands_ = db.both_strands;
         // the records are decoded on the device (K-KMC) straight from the mapped file, then hashed into the count table
         uint64_t *dk = nullptr;
@@ -56,6 +95,7 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
         if (st == PF_OK) st = pf_upload_counts(ctx_, dk, dc, db.total, db.min_count, db.max_count, db.both_strands);
         pf_device_free(ctx_, dk);
         pf_device_free(ctx_, dc);
+        trace.mark("kmc: device decode + table");
         if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: ") + pf_last_error(ctx_)); return; }
     }
     if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");
@@ -146,16 +186,28 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
     if (!quiet_) printf("%s::setUnitigId(): Setting Unitig Id\n", tag_);
     clock_t c0 = clock();
     time_t w0 = time(nullptr);
-    std::string out;
-    out.reserve(g_.text.size() + (size_t)g_.n() * 10);
-    for (uint32_t u = 0; u < g_.n(); ++u) {
-        put_uint(out, u + 1);
-        out.push_back('\t');
-        std::string_view s = g_.seq(u);
-        out.append(s.data(), s.size());
-        out.push_back('\n');
+    // `id<TAB>sequence` rows, formatted in unitig ranges side by side and written in order
+    const unsigned T = threads_ ? threads_ : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+    constexpr size_t UCH = 65536;
+    std::vector<std::string> parts(n_chunks_of(g_.n(), UCH));
+    parallel_chunks(g_.n(), UCH, T, [&](size_t ci, size_t u0, size_t u1) {
+        std::string &out = parts[ci];
+        out.reserve((size_t)(g_.off[u1] - g_.off[u0]) + (u1 - u0) * 10);
+        for (size_t u = u0; u < u1; ++u) {
+            put_uint(out, u + 1);
+            out.push_back('\t');
+            std::string_view s = g_.seq((uint32_t)u);
+            out.append(s.data(), s.size());
+            out.push_back('\n');
+        }
+    });
+    {
+        std::vector<const std::string *> pieces;
+        for (const std::string &p : parts) pieces.push_back(&p);
+        uint64_t bytes = 0;
+        if (write_pieces(outpre + "_Unitig_Id.txt", pieces, bytes)) return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + "_Unitig_Id.txt file error");
+        out_bytes_ += bytes;
     }
-    if (write_file(outpre + "_Unitig_Id.txt", out)) return status_;
     if (!quiet_) {
         printf("%s::setUnitigId(): Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
         printf("%s::setUnitigId(): Real time : %gs\n", tag_, difftime(time(nullptr), w0));

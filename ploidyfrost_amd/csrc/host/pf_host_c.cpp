@@ -64,7 +64,7 @@ pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex
     try {
     auto r = std::make_unique<pfh_run>();
     auto t0 = clk::now();
-    if (!r->graph.load_gfa(gfa_path, g_open_err)) return nullptr;
+    if (!r->graph.load_gfa(gfa_path, g_open_err, true)) return nullptr;  // numbering finished by the CDBG constructor (K-MINZ)
     r->load_s = std::chrono::duration<double>(clk::now() - t0).count();
     r->z = complex_size;
     r->z_M = match; r->z_D = mismatch; r->z_G = gap;
@@ -217,6 +217,19 @@ uint32_t pfh_gfa_numbering_replays(const char *gfa_path) {
     } catch (const std::exception &e) {
         g_open_err = std::string("ploidyfrost host layer: ") + e.what();
         return ~0u;
+    }
+}
+uint64_t pfh_gfa_minimizer_counts(const char *gfa_path, uint8_t *counters, uint64_t slots) {
+    try {
+        pfh::UnitigSet g;
+        if (!g.load_gfa(gfa_path, g_open_err, true)) return ~0ull;
+        std::vector<uint8_t> c;
+        g.finish_numbering(&c);
+        if (counters && slots >= c.size()) std::copy(c.begin(), c.end(), counters);
+        return c.size();
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return ~0ull;
     }
 }
 int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path) {

@@ -1,5 +1,6 @@
 #include "pf_host_graph.hpp"
 #include "pf_host_minz.hpp"
+#include "pf_parallel.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -8,6 +9,9 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <atomic>
+#include <chrono>
+#include <cstdlib>
 #include <cstring>
 #include <thread>
 
@@ -62,7 +66,21 @@ void UnitigSet::append_mapped(uint32_t ov, std::string &dst) const {
     }
 }
 
-bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
+namespace {
+struct LoadTrace {  // PF_TRACE_LOAD=1: where the loader spends its time, on stderr
+    bool on = getenv("PF_TRACE_LOAD") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[load] %-28s %.3fs\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+}  // namespace
+
+bool UnitigSet::load_gfa(const std::string &path, std::string &err, bool defer_numbering) {
+    LoadTrace trace;
     Mapped f;
     if (!f.open(path)) { err = "cannot open " + path; return false; }
     const char *p = f.p, *end = f.p + f.n;
@@ -83,40 +101,76 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
         }
     }
     if (k < 3 || k > 31) { err = "k outside 3..31"; return false; }
-    // pass 1: locate the sequence field of every complete S-line
+    // pass 1: locate the sequence field of every complete S-line -- the file is cut into pieces at line starts, the pieces
+    // are scanned side by side and their segment lists joined in file order
     struct Seg { const char *s; uint32_t len; int16_t da; uint32_t rank; };
+    const unsigned T = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    const char *body = le + 1;
+    const size_t body_n = (size_t)(end - body);
+    const size_t n_pieces = std::max<size_t>(1, std::min<size_t>((size_t)T * 4, body_n / (1u << 20)));
+    std::vector<const char *> cut(n_pieces + 1, end);
+    cut[0] = body;
+    for (size_t i = 1; i < n_pieces; ++i) {
+        const char *c = body + body_n / n_pieces * i;
+        const char *nl = (const char *)memchr(c, '\n', (size_t)(end - c));
+        cut[i] = nl ? nl + 1 : end;
+    }
+    struct Piece { std::vector<Seg> segs; std::string err; bool any_da = false; };
+    std::vector<Piece> pieces(n_pieces);
+    parallel_chunks(n_pieces, 1, T, [&](size_t pi, size_t, size_t) {
+        Piece &pc = pieces[pi];
+        const char *q = cut[pi];
+        const char *stop = cut[pi + 1];
+        while (q < stop) {
+            const char *e = line_end(q);
+            if (!e) break;  // unterminated last line is dropped
+            if (e - q >= 2 && q[0] == 'S' && q[1] == '\t') {
+                const char *fld = q + 2;
+                for (int skip = (version == 1 ? 1 : 2); skip > 0 && fld; --skip) {
+                    const char *t = (const char *)memchr(fld, '\t', (size_t)(e - fld));
+                    fld = t ? t + 1 : nullptr;
+                }
+                if (!fld) { pc.err = "missing fields in a segment line"; return; }
+                const char *t = (const char *)memchr(fld, '\t', (size_t)(e - fld));
+                if (!t) t = e;
+                uint32_t len = (uint32_t)(t - fld);
+                if (len && fld[len - 1] == '\r') len--;
+                if ((int)len < k) { pc.err = "segment shorter than k"; return; }
+                int16_t da = -1;
+                for (const char *tag = t; tag < e;) {  // optional tags after the sequence
+                    const char *nt = (const char *)memchr(tag + 1, '\t', (size_t)(e - tag - 1));
+                    if (!nt) nt = e;
+                    if (nt - tag > 6 && memcmp(tag + 1, "DA:Z:", 5) == 0) { da = (int16_t)atoi(std::string(tag + 6, nt).c_str()); pc.any_da = true; }
+                    tag = nt;
+                }
+                pc.segs.push_back({fld, len, da, 0});
+            }
+            q = e + 1;
+        }
+    });
     std::vector<Seg> longs, shorts;
     uint64_t long_bp = 0;
     bool any_da = false;
-    const char *q = le + 1;
-    while (q < end) {
-        const char *e = line_end(q);
-        if (!e) break;  // unterminated last line is dropped
-        if (e - q >= 2 && q[0] == 'S' && q[1] == '\t') {
-            const char *fld = q + 2;
-            for (int skip = (version == 1 ? 1 : 2); skip > 0 && fld; --skip) {
-                const char *t = (const char *)memchr(fld, '\t', (size_t)(e - fld));
-                fld = t ? t + 1 : nullptr;
-            }
-            if (!fld) { err = "missing fields in a segment line"; return false; }
-            const char *t = (const char *)memchr(fld, '\t', (size_t)(e - fld));
-            if (!t) t = e;
-            uint32_t len = (uint32_t)(t - fld);
-            if (len && fld[len - 1] == '\r') len--;
-            if ((int)len < k) { err = "segment shorter than k"; return false; }
-            int16_t da = -1;
-            for (const char *tag = t; tag < e;) {  // optional tags after the sequence
-                const char *nt = (const char *)memchr(tag + 1, '\t', (size_t)(e - tag - 1));
-                if (!nt) nt = e;
-                if (nt - tag > 6 && memcmp(tag + 1, "DA:Z:", 5) == 0) { da = (int16_t)atoi(std::string(tag + 6, nt).c_str()); any_da = true; }
-                tag = nt;
-            }
-            const uint32_t rank = (uint32_t)(longs.size() + shorts.size());
-            if ((int)len == k) shorts.push_back({fld, len, da, rank});
-            else { longs.push_back({fld, len, da, rank}); long_bp += len; }
+    {
+        size_t nl = 0, ns = 0;
+        for (const Piece &pc : pieces) {
+            if (!pc.err.empty()) { err = pc.err; return false; }
+            any_da |= pc.any_da;
+            for (const Seg &sg : pc.segs) ((int)sg.len == k ? ns : nl)++;
         }
-        q = e + 1;
+        longs.reserve(nl);
+        shorts.reserve(ns);
+        uint32_t rank = 0;
+        for (Piece &pc : pieces) {
+            for (Seg sg : pc.segs) {
+                sg.rank = rank++;
+                if ((int)sg.len == k) shorts.push_back(sg);
+                else { longs.push_back(sg); long_bp += sg.len; }
+            }
+            std::vector<Seg>().swap(pc.segs);
+        }
     }
+    trace.mark("gfa: locate segments");
     const size_t N = longs.size() + shorts.size();
     if (N == 0) { err = "no segments in the GFA file"; return false; }
     if (N >= (1u << 30)) { err = "more than 2^30 unitigs"; return false; }
@@ -124,71 +178,93 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err) {
     text.resize(long_bp + (uint64_t)shorts.size() * k);
     off.resize(N + 1);
     len_bp.resize(N);
-    uint64_t at = 0;
-    size_t u = 0;
-    for (const Seg &s : longs) {
-        off[u] = at;
-        len_bp[u] = s.len;
-        for (uint32_t i = 0; i < s.len; ++i) {
-            int c = code_of(s.s[i]);
-            if (c < 0) { err = "non-ACGT base in a segment"; return false; }
-            text[at + i] = kBase[c];
-        }
-        at += s.len;
-        ++u;
+    {
+        uint64_t at = 0;
+        for (size_t i = 0; i < longs.size(); ++i) { off[i] = at; len_bp[i] = longs[i].len; at += longs[i].len; }
+        for (size_t i = 0; i < shorts.size(); ++i) { off[longs.size() + i] = at; len_bp[longs.size() + i] = (uint32_t)k; at += (uint64_t)k; }
+        off[N] = at;
     }
-    std::string fw((size_t)k, 'A'), rc((size_t)k, 'A');
-    for (const Seg &s : shorts) {
-        off[u] = at;
-        len_bp[u] = (uint32_t)k;
-        for (int i = 0; i < k; ++i) {
-            int c = code_of(s.s[i]);
-            if (c < 0) { err = "non-ACGT base in a segment"; return false; }
-            fw[i] = kBase[c];
-            rc[k - 1 - i] = kBase[3 - c];
+    std::atomic<bool> bad_base{false};
+    parallel_chunks(longs.size(), 4096, T, [&](size_t, size_t b0, size_t b1) {
+        for (size_t i = b0; i < b1; ++i) {
+            const Seg &sg = longs[i];
+            char *dst = text.data() + off[i];
+            for (uint32_t j = 0; j < sg.len; ++j) {
+                const int c = code_of(sg.s[j]);
+                if (c < 0) { bad_base.store(true, std::memory_order_relaxed); return; }
+                dst[j] = kBase[c];
+            }
         }
-        const std::string &keep = rc < fw ? rc : fw;  // km_rep (CompactedDBG.tcc:3945-3954)
-        memcpy(text.data() + at, keep.data(), (size_t)k);
-        at += k;
-        ++u;
-    }
-    off[N] = at;
-    // k-length unitigs Bifrost keeps in its table of abundant k-mers are iterated last, in that table's slot order
-    n_abundant = 0;
-    if (!shorts.empty() && g >= 1 && g <= k - 2) {
-        std::vector<SegRef> refs(N);
-        std::vector<uint32_t> short_of_rank(N, UINT32_MAX);
-        for (size_t i = 0; i < longs.size(); ++i) refs[longs[i].rank] = SegRef{text.data() + off[i], longs[i].len};
-        for (size_t i = 0; i < shorts.size(); ++i) {
-            refs[shorts[i].rank] = SegRef{text.data() + off[longs.size() + i], (uint32_t)k};
-            short_of_rank[shorts[i].rank] = (uint32_t)i;
+    });
+    parallel_chunks(shorts.size(), 16384, T, [&](size_t, size_t b0, size_t b1) {
+        char fw[32], rc[32];
+        for (size_t i = b0; i < b1; ++i) {
+            const Seg &sg = shorts[i];
+            for (int j = 0; j < k; ++j) {
+                const int c = code_of(sg.s[j]);
+                if (c < 0) { bad_base.store(true, std::memory_order_relaxed); return; }
+                fw[j] = kBase[c];
+                rc[k - 1 - j] = kBase[3 - c];
+            }
+            memcpy(text.data() + off[longs.size() + i], memcmp(rc, fw, (size_t)k) < 0 ? rc : fw, (size_t)k);  // km_rep (CompactedDBG.tcc:3945-3954)
         }
-        UnitigNumbering num;
-        bifrost_numbering(k, g, refs, std::min(16u, std::max(1u, std::thread::hardware_concurrency())), num);
-        numbering_replays = num.replays;
-        if (!num.abundant.empty()) {
-            n_abundant = num.abundant.size();
-            std::vector<uint8_t> moved(shorts.size(), 0);
-            std::vector<Seg> order;
-            order.reserve(shorts.size());
-            for (uint32_t r : num.abundant) moved[short_of_rank[r]] = 1;
-            for (size_t i = 0; i < shorts.size(); ++i)
-                if (!moved[i]) order.push_back(shorts[i]);
-            for (uint32_t r : num.abundant) order.push_back(shorts[short_of_rank[r]]);
-            std::vector<char> old(text.begin() + (ptrdiff_t)long_bp, text.end());
-            for (size_t i = 0; i < order.size(); ++i)
-                memcpy(text.data() + long_bp + i * (size_t)k, old.data() + (size_t)short_of_rank[order[i].rank] * (size_t)k, (size_t)k);
-            shorts.swap(order);
-        }
-    }
+    });
+    if (bad_base.load()) { err = "non-ACGT base in a segment"; return false; }
+    trace.mark("gfa: copy sequences");
     da_tag.clear();
     if (any_da) {
         da_tag.reserve(N);
         for (const Seg &s : longs) da_tag.push_back(s.da);
         for (const Seg &s : shorts) da_tag.push_back(s.da);
     }
+    // k-length unitigs Bifrost keeps in its table of abundant k-mers are iterated last, in that table's slot order
+    n_abundant = 0;
+    numbering_replays = 0;
+    file_rank.resize(N);
+    for (size_t i = 0; i < longs.size(); ++i) file_rank[i] = longs[i].rank;
+    for (size_t i = 0; i < shorts.size(); ++i) file_rank[longs.size() + i] = shorts[i].rank;
+    numbering_deferred = true;
+    if (!defer_numbering) finish_numbering();
+    trace.mark(defer_numbering ? "gfa: numbering deferred" : "gfa: unitig numbering");
+    if (numbering_deferred || n_abundant == 0)
     pack();
+    trace.mark("gfa: 2-bit pack");
     return true;
+}
+
+void UnitigSet::finish_numbering(std::vector<uint8_t> *counters) {
+    const size_t N = len_bp.size(), n_long = N - (size_t)n_short;
+    if (numbering_deferred && n_short && g >= 1 && g <= k - 2 && g <= 31 && file_rank.size() == N) {
+        const unsigned T = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+        std::vector<SegRef> refs(N);
+        std::vector<uint32_t> short_of_rank(N, UINT32_MAX);
+        for (size_t u = 0; u < N; ++u) {
+            refs[file_rank[u]] = SegRef{text.data() + off[u], len_bp[u]};
+            if (u >= n_long) short_of_rank[file_rank[u]] = (uint32_t)(u - n_long);
+        }
+        UnitigNumbering num;
+        bifrost_numbering(k, g, refs, T, num, counters);
+        numbering_replays = num.replays;
+        if (!num.abundant.empty()) {
+            n_abundant = num.abundant.size();
+            std::vector<uint8_t> moved((size_t)n_short, 0);
+            std::vector<uint32_t> order;   // old index (among the k-length unitigs) of the unitig that takes each place
+            order.reserve((size_t)n_short);
+            for (uint32_t r : num.abundant) moved[short_of_rank[r]] = 1;
+            for (uint32_t i = 0; i < (uint32_t)n_short; ++i)
+                if (!moved[i]) order.push_back(i);
+            for (uint32_t r : num.abundant) order.push_back(short_of_rank[r]);
+            const uint64_t base = off[n_long];
+            std::vector<char> old(text.begin() + (ptrdiff_t)base, text.end());
+            for (size_t i = 0; i < order.size(); ++i) memcpy(text.data() + base + i * (size_t)k, old.data() + (size_t)order[i] * (size_t)k, (size_t)k);
+            if (!da_tag.empty()) {
+                std::vector<int16_t> od(da_tag.begin() + (ptrdiff_t)n_long, da_tag.end());
+                for (size_t i = 0; i < order.size(); ++i) da_tag[n_long + i] = od[order[i]];
+            }
+            pack();
+        }
+    }
+    numbering_settled();
 }
 
 void UnitigSet::from_sequences(const std::vector<std::string> &seqs, int k_) {
@@ -212,13 +288,22 @@ void UnitigSet::pack() {
         word_off[u + 1] = word_off[u] + (len_bp[u] + 31) / 32;
         n_kmers += len_bp[u] - (uint32_t)k + 1;
     }
-    words.assign(word_off[N] + 1, 0);
-    for (size_t u = 0; u < N; ++u) {
-        const char *s = text.data() + off[u];
-        uint64_t *w = words.data() + word_off[u];
-        const uint32_t L = len_bp[u];
-        for (uint32_t i = 0; i < L; ++i) w[i >> 5] |= (uint64_t)code_of(s[i]) << (62 - 2 * (i & 31));
-    }
+    words.resize(word_off[N] + 1);
+    words[word_off[N]] = 0;
+    const unsigned T = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    parallel_chunks(N, 8192, T, [&](size_t, size_t u0, size_t u1) {
+        for (size_t u = u0; u < u1; ++u) {
+            const char *s = text.data() + off[u];
+            uint64_t *w = words.data() + word_off[u];
+            const uint32_t L = len_bp[u];
+            for (uint32_t i = 0; i < L; i += 32) {
+                uint64_t x = 0;
+                const uint32_t m = std::min<uint32_t>(32, L - i);
+                for (uint32_t j = 0; j < m; ++j) x |= (uint64_t)code_of(s[i + j]) << (62 - 2 * j);
+                w[i >> 5] = x;
+            }
+        }
+    });
 }
 
 // ------------------------------------------------------------------------------------------

@@ -30,6 +30,13 @@ struct UnitigSet {
     // k-length unitigs Bifrost files as "abundant" k-mers (pf_host_minz.hpp): they are the last n_abundant unitigs
     uint64_t n_abundant = 0;
     uint32_t numbering_replays = 0;
+    // load_gfa(..., defer_numbering = true) leaves the abundant k-mers undecided: the unitigs stand in provisional order
+    // (long, then k-length, in file order -- final unless a minimizer bucket can get crowded) and file_rank[u] is the S-line
+    // rank of unitig u.  The owner of the device decides with K-MINZ and calls finish_numbering() only if it has to.
+    bool numbering_deferred = false;
+    std::vector<uint32_t> file_rank;
+    void finish_numbering(std::vector<uint8_t> *counters = nullptr);   // host replay (pf_host_minz.hpp); repacks when the order changed
+    void numbering_settled() { numbering_deferred = false; std::vector<uint32_t>().swap(file_rank); }
 
     uint32_t n() const { return (uint32_t)len_bp.size(); }
     std::string_view seq(uint32_t u) const { return std::string_view(text.data() + off[u], len_bp[u]); }
@@ -42,7 +49,7 @@ struct UnitigSet {
     // Loads the S-lines of a GFA 1/2 file in the reference's unitig order: long unitigs
     // (length > k) in file order, then k-length ones, each stored as min(seq, revcomp)
     // (SURVEY.md 3.1), the abundant ones last (pf_host_minz.hpp).  A last line without '\n' is ignored, as in bifrost/src/GFA_Parser.cpp:486.
-    bool load_gfa(const std::string &path, std::string &err);
+    bool load_gfa(const std::string &path, std::string &err, bool defer_numbering = false);
     // builds from already ordered sequences (tests, generators)
     void from_sequences(const std::vector<std::string> &seqs, int k_);
     void pack();

@@ -1,6 +1,9 @@
 #include "pf_host_minz.hpp"
 
 #include <atomic>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <unordered_map>
@@ -280,7 +283,15 @@ struct Replay {
 
 }  // namespace
 
-void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned threads, UnitigNumbering &out) {
+void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned threads, UnitigNumbering &out, std::vector<uint8_t> *counters) {
+    const bool trace = getenv("PF_TRACE_LOAD") != nullptr;
+    auto t_last = std::chrono::steady_clock::now();
+    auto mark = [&](const char *what) {
+        if (!trace) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[load]   numbering: %-18s %.3fs\n", what, std::chrono::duration<double>(now - t_last).count());
+        t_last = now;
+    };
     out = UnitigNumbering();
     const size_t S = segs.size();
     if (S == 0 || g < 1 || g > k - 2 || g > 31) return;
@@ -293,6 +304,7 @@ void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned t
     parallel_chunks((size_t)cap, (size_t)1 << 20, threads, [&](size_t, size_t b0, size_t b1) {
         for (size_t i = b0; i < b1; ++i) cnt[i].store(0, std::memory_order_relaxed);
     });
+    mark("counter table");
     std::atomic<bool> any_crowded{false};
     parallel_chunks(S, kChunk, threads, [&](size_t, size_t s0, size_t s1) {
         std::vector<MinRes> scratch;
@@ -306,6 +318,11 @@ void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned t
         }
         if (crowded) any_crowded.store(true, std::memory_order_relaxed);
     });
+    mark("count occurrences");
+    if (counters) {
+        counters->resize(cap);
+        for (uint64_t i = 0; i < cap; ++i) (*counters)[i] = cnt[i].load(std::memory_order_relaxed);
+    }
     if (!any_crowded.load()) return;
 
     std::unordered_set<uint64_t> extra;
@@ -328,6 +345,7 @@ void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned t
                 touches[i] = hit;
             }
         });
+        mark("flag unitigs");
         out.replays++;
         out.replayed_unitigs = 0;
         KmerTable table;
@@ -347,6 +365,7 @@ void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned t
             } else if (is_short) ++n_short;
             else ++n_long;
         }
+        mark("replay");
         if (!rp.newly.empty()) {
             extra.insert(rp.newly.begin(), rp.newly.end());
             continue;

@@ -30,7 +30,9 @@ struct UnitigNumbering {
     uint64_t replayed_unitigs = 0;
 };
 
-// segs in file order; g <= k - 2 (bifrost/src/CompactedDBG.tcc:8383)
-void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned threads, UnitigNumbering &out);
+// segs in file order; g <= k - 2 (bifrost/src/CompactedDBG.tcc:8383).  counters (optional): the saturating occurrence
+// counters of step 1, slot = mix(canonical minimizer) & (size - 1) -- the table the device pass (K-MINZ) bounds from above.
+void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned threads, UnitigNumbering &out,
+                       std::vector<uint8_t> *counters = nullptr);
 
 }  // namespace pfh

@@ -348,13 +348,11 @@ int main(int argc, char **argv) {
     pfh::UnitigSet graph;
     std::string err;
     auto t0 = std::chrono::steady_clock::now();
-    if (!graph.load_gfa(opt.graphfile, err)) {
+    if (!graph.load_gfa(opt.graphfile, err, true)) {  // abundant k-mers are decided with the device (K-MINZ) in the CDBG constructor
         cout << "CompactedDBG::read(): Graph could not be loaded! Exit. (" << err << ")" << endl;
         exit(EXIT_FAILURE);
     }
     cout << "CompactedDBG::read(): Graph loading successful" << endl;
-    if (opt.verbose && graph.n_abundant)
-        cout << "CompactedDBG::read(): " << graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
 
     cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
 
@@ -364,6 +362,8 @@ int main(int argc, char **argv) {
         exit(EXIT_FAILURE);
     };
     if (!g.good()) die();
+    if (opt.verbose && graph.n_abundant)
+        cout << "CompactedDBG::read(): " << graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
     g.set_threads((unsigned)opt.nb_threads);
     g.set_overlap_output(true);
     if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();

@@ -479,7 +479,7 @@ namespace pf {
 
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
-                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode"};
+                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count"};
 
 int ctx_begin(pf_ctx *ctx, int kernel) {
     if (!ctx->timing) return 0;

@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_hip.so")
 NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
-           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode"]
+           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
@@ -89,6 +89,8 @@ def load_library() -> C.CDLL:
         "pf_num_colors": (u32, [vp]),
         "pf_unitig_cov_colored": (i, [vp, u32, u32, vp, vp, vp, vp]),
         "pf_string_cov_colored": (i, [vp, vp, vp, u32, vp, vp, vp, vp]),
+        "pf_minimizer_table_slots": (u64, [u64]),
+        "pf_minimizer_crowding": (i, [vp, i, u32, vp, vp, vp]),
         "pf_kmc_decode": (i, [vp, vp, u64, u32, u32, vp, u64, u32, u32, vp, vp]),
         "pf_device_free": (None, [vp, vp]),
         "pf_copy_to_host": (i, [vp, vp, vp, C.c_size_t]),
@@ -109,7 +111,8 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
-                    "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host"]
+                    "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
+                    "pf_minimizer_table_slots", "pf_minimizer_crowding"]
 
 
 def pack_unitigs(seqs: list[bytes]):
@@ -218,6 +221,13 @@ class Device:
     def upload_counts(self, kmers, counts, min_count=1, max_count=0xFFFFFFFF, both_strands=True):
         n = int(kmers.shape[0])
         self._check(self.L.pf_upload_counts(self.h, _ptr(kmers), _ptr(counts), n, min_count, max_count, int(both_strands)))
+
+    def minimizer_crowding(self, g: int, limit: int = 15, want_table: bool = False):
+        """K-MINZ: (max occurrences of a minimizer slot, slots that reached `limit`[, the u32 counter table])."""
+        mx, crowded = C.c_uint32(), C.c_uint64()
+        table = np.zeros(self.L.pf_minimizer_table_slots(self.L.pf_num_kmers(self.h)), dtype=np.uint32) if want_table else None
+        self._check(self.L.pf_minimizer_crowding(self.h, g, limit, C.byref(mx), C.byref(crowded), _ptr(table) if want_table else None))
+        return (mx.value, crowded.value, table) if want_table else (mx.value, crowded.value)
 
     def kmc_decode(self, records: np.ndarray, n: int, suffix_bytes: int, counter_bytes: int, lut: np.ndarray, p: int, k: int):
         """K-KMC on raw .kmc_suf records (pf_kmc_decode): returns (kmers u64, counts u32) copied back to the host."""

@@ -26,7 +26,7 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
-                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays",
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts",
                     "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
                     "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
 
@@ -79,6 +79,8 @@ def load_library() -> C.CDLL:
     L.pfh_gfa_abundant_kmers.argtypes = [C.c_char_p]
     L.pfh_gfa_numbering_replays.restype = C.c_uint32
     L.pfh_gfa_numbering_replays.argtypes = [C.c_char_p]
+    L.pfh_gfa_minimizer_counts.restype = C.c_uint64
+    L.pfh_gfa_minimizer_counts.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
     L.pfh_gfa_write_unitig_ids.restype = C.c_int
     L.pfh_gfa_write_unitig_ids.argtypes = [C.c_char_p, C.c_char_p]
     L.pfh_bifrost_kmer_hash.restype = C.c_uint64

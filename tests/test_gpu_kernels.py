@@ -320,3 +320,46 @@ def test_kmc_records_are_decoded_on_the_device(k, p, cs, tmp_path):
     assert len(e_k) == 0 and len(e_c) == 0
     with pytest.raises(RuntimeError):
         dev.kmc_decode(raw, len(km), sb, cs, lut[:-1], p, k)
+
+
+def _minz_tables(gfa):
+    """(device K-MINZ counters, host counters of pf_host_minz.cpp) of one GFA file"""
+    from ploidyfrost_amd import hostapi
+    L = hostapi.load_library()
+    slots = L.pfh_gfa_minimizer_counts(gfa.encode(), None, 0)
+    host = np.zeros(slots, dtype=np.uint8)
+    assert L.pfh_gfa_minimizer_counts(gfa.encode(), host.ctypes.data, slots) == slots
+    import ctypes as C
+    out = os.path.join(os.path.dirname(gfa), "ids_for_minz.txt")
+    assert L.pfh_gfa_write_unitig_ids(gfa.encode(), out.encode()) == 0
+    seqs = [line.split(b"\t")[1].strip() for line in open(out, "rb")]
+    k = int([f for f in open(gfa, "rb").readline().split(b"\t") if f.startswith(b"KL:Z:")][0][5:])
+    g = int([f for f in open(gfa, "rb").readline().split(b"\t") if f.startswith(b"ML:Z:")][0][5:])
+    dev = hipapi.Device()
+    dev.upload_graph(*hipapi.pack_unitigs(seqs), k)
+    mx, crowded, table = dev.minimizer_crowding(g, 15, want_table=True)
+    assert len(table) == slots
+    return mx, crowded, table, host, C
+
+
+@pytest.mark.parametrize("case", ["dip20k", "weird12k", "reads10k", "k31_z16", "crowd25"])
+def test_minimizer_census_bounds_the_host_counters(case):
+    """K-MINZ counts every position the reference's minimizer iterator reports (and, with tied hashes, possibly more): slot by
+    slot >= the host pass, equal where no window has tied minima; a crowded graph is seen as crowded."""
+    meta = load_case(case)
+    mx, crowded, table, host, _ = _minz_tables(meta["gfa"])
+    assert np.all(table >= host)
+    assert int(table.sum()) - int(host.sum()) <= max(4, int(host.sum()) // 1000), (int(table.sum()), int(host.sum()))
+    assert mx == table.max() and crowded == int((table >= 15).sum())
+    assert (mx >= 15) == bool(meta.get("abundant"))
+
+
+def test_minimizer_census_on_graphs_built_to_crowd_buckets(tmp_path):
+    from test_host_logic_cpu import _crowded_graphs, _write_gfa
+    for k, g in ((25, 17), (31, 23), (15, 8)):
+        for name, seqs in _crowded_graphs(k, k, g).items():
+            gfa = str(tmp_path / ("%s_%d.gfa" % (name, k)))
+            _write_gfa(gfa, seqs, k, g)
+            mx, crowded, table, host, _ = _minz_tables(gfa)
+            assert np.all(table >= host), name
+            assert mx >= 15 or host.max() < 15, name
