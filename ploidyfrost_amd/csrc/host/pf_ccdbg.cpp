@@ -23,15 +23,22 @@ namespace pfh {
 // ---- colored graph + CCDBG (reference src/CCDBG.cpp) -------------------------------------------------
 bool ColoredUnitigSet::read(const std::string &graphfile, const std::string &colorfile, size_t nb_threads, bool verbose) {
     if (verbose) printf("ColoredCDBG::read(): Reading graph.\n");
-    if (!graph.load_gfa(graphfile, err)) return false;
+    // abundant k-mers (unitig numbering) are decided by the CCDBG constructor with the device (K-MINZ); on the rare graph
+    // whose order changes there, the colour sets are read again for the final order
+    if (!graph.load_gfa(graphfile, err, true)) return false;
     if (verbose) printf("ColoredCDBG::read(): Reading colors.\n");
-    return colors.load(colorfile, graph, (unsigned)std::max<size_t>(nb_threads, 1), err);
+    colorfile_ = colorfile;
+    color_threads_ = (unsigned)std::max<size_t>(nb_threads, 1);
+    return colors.load(colorfile, graph, color_threads_, err);
 }
+
+bool ColoredUnitigSet::reload_colors() { return colors.load(colorfile_, graph, color_threads_, err); }
 
 CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db_list,
              const size_t &thread, int device, bool quiet)
     : CDBG(graph.graph, complexsize, m, d, g, device, quiet, NoCounts{}), cg_(graph) {
     if (status_) return;
+    if (cg_.graph.n_abundant && !cg_.reload_colors()) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: " + cg_.err); return; }
     col_ = &cg_.colors;
     const uint32_t C = cg_.colors.n_colors;
     if (C > PF_MAX_COLORS) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: more colours than the device table holds"); return; }

@@ -178,6 +178,11 @@ struct ColoredUnitigSet {
     size_t getNbColors() const { return colors.n_colors; }
     int getK() const { return graph.k; }
     size_t size() const { return graph.n(); }
+    bool reload_colors();   // after the unitig order changed (abundant k-mers found by the device census)
+
+private:
+    std::string colorfile_;
+    unsigned color_threads_ = 1;
 };
 
 // pfh::CCDBG -- mirror of the reference class CCDBG (src/CCDBG.hpp:18-40, driven from src/Main.cpp:775-810):

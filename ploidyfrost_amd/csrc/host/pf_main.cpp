@@ -311,8 +311,6 @@ int main(int argc, char **argv) {
             exit(EXIT_FAILURE);
         }
         cout << "ColoredCDBG::read(): Graph loading successful" << endl;
-        if (opt.verbose && cdbg.graph.n_abundant)
-            cout << "ColoredCDBG::read(): " << cdbg.graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
 
         cout << "CCDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
         if (cdbg.getNbColors() != kmc_db_num) {
@@ -320,6 +318,8 @@ int main(int argc, char **argv) {
             exit(EXIT_FAILURE);
         }
         pfh::CCDBG g(cdbg, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db, opt.nb_threads);
+        if (opt.verbose && cdbg.graph.n_abundant)
+            cout << "ColoredCDBG::read(): " << cdbg.graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
         auto die = [&]() {
             cerr << g.error() << endl;
             exit(EXIT_FAILURE);
