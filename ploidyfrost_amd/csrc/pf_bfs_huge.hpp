@@ -73,6 +73,7 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
     bool have_top = true;
     __builtin_amdgcn_wave_barrier();
     while (top > 0) {
+        const bool popped_cached = have_top;
         const uint32_t v = have_top ? cached_top : st.todo[top - 1];
         have_top = false;
         top--;
@@ -93,7 +94,8 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
         }
         // one round trip: state words of v, of its successors and of their predecessors, plus the
         // rows of the four successors for the next step
-        const uint32_t v_word = st.info[v >> 1];
+        // the word of a vertex pushed in the previous step is still in registers
+        const uint32_t v_word = popped_cached ? cached_word : st.info[v >> 1];
         uint32_t my_sinfo = (lane < 4 && my_succ != NONE) ? st.info[my_succ >> 1] : 0u;
         uint32_t my_pinfo = (lane < 16 && my_pred != NONE) ? st.info[my_pred >> 1] : 0u;
         {
@@ -113,6 +115,7 @@ __device__ inline BfsResult bfs_traverse_huge(const uint32_t *__restrict__ succ,
         auto patch = [&](uint32_t unitig, uint32_t word) {
             if (lane < 4 && my_succ != NONE && (my_succ >> 1) == unitig) my_sinfo = word;
             if (lane < 16 && my_pred != NONE && (my_pred >> 1) == unitig) my_pinfo = word;
+            if (have_top && (cached_top >> 1) == unitig) cached_word = word;
         };
         if (__ballot(my_succ != NONE) == 0) {
             tip_flag = true;
