@@ -1058,6 +1058,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 wqueue.pop_front();
             }
             write_batch(*outs);
+            tp("  batch written");
         }
     });
     struct WriterGuard {  // joined on every way out
@@ -1097,6 +1098,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                         if (stop) return;
                     }
                     batches[b].st = prepare(batches[b]);
+                    tp("  batch prepared (paths)");
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         prepared = b + 1;
@@ -1115,6 +1117,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                         if (batches[b].st != PF_OK) { produced = b + 1; cv.notify_all(); return; }
                     }
                     const int st2 = produce(batches[b]);
+                    tp("  batch produced (device)");
                     {
                         std::lock_guard<std::mutex> lk(mu);
                         batches[b].st = st2;
@@ -1145,6 +1148,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             times_.site_strings += B.site_strings;
             if (B.st != PF_OK) { rc = B.st; rc_err = B.err; break; }
             rc = consume(B);
+            tp("  batch consumed (format)");
             if (rc == PF_OK) {
                 { std::lock_guard<std::mutex> lk(wmu); wqueue.push_back(&all_outs.back()); }
                 wcv.notify_all();
