@@ -227,12 +227,13 @@ def main():
         genome = int(args.unitigs / UNITIGS_PER_BP)
         colored = args.workload == "colored"
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
+        seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + rank
         if colored:
             n_samples = 3
-            gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(workdir, "graph", genome, 1000 + rank, dev, samples=n_samples)
+            gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(workdir, "graph", genome, seed, dev, samples=n_samples)
             cutoffs = [(LOWER, UPPER)] * n_samples
         else:
-            gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, 1000 + rank, dev)
+            gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, seed, dev)
         torch.cuda.empty_cache()
         t0 = time.time()
         if colored:

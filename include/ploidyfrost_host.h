@@ -26,6 +26,7 @@ typedef struct pfh_times {
     uint64_t unitigs, kmers, candidates, superbubbles, tasks, align_jobs, site_strings, output_bytes;
     uint64_t allele[4], core_cov, core_num;
     double scan_s, scan_serial_s; /* owner/order scan of PloidyEstimation: whole, and its sequential part */
+    uint64_t bfs_large, bfs_max_seen; /* K-BFS traversals of more than 4096 vertices in the last findSuperBubble; the longest one */
 } pfh_times;
 
 /* NULL on failure: message via pfh_last_error(NULL) */
@@ -39,6 +40,9 @@ void pfh_set_threads(pfh_run *, uint32_t threads);   /* host threads for the per
                                                          output order is always the -t 1 one */
 void pfh_set_overlap_output(pfh_run *, int on);      /* 1: <outpre>_super_bubble.txt is written in the background and is complete
                                                          when pfh_ploidy_estimation (or pfh_close) returns; default 0 */
+/* K-BFS traversals beyond 4096 vertices: on host cores (default, pf_bfs_candidates_split + host/pf_bfs_host.cpp: one thread per
+ * traversal) or, with on = 0, on the device (k_bfs_huge: one wavefront per traversal).  Same records either way. */
+void pfh_set_third_tier_on_host(pfh_run *, int on);
 void pfh_set_batch_bubbles(pfh_run *, uint64_t n);   /* bubbles per batch of the align/format pipeline (default 65536) */
 int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);

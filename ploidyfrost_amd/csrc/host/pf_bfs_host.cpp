@@ -1,0 +1,122 @@
+#include "pf_bfs_host.hpp"
+
+#include <algorithm>
+#include <unordered_set>
+
+namespace pfh {
+
+namespace {
+constexpr uint32_t NONE = 0xFFFFFFFFu;
+}
+
+const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32_t *pred, uint32_t N, uint32_t s, pf_bfs_record &r) {
+    if (info.size() != N) { info.assign(N, 0); first.assign(N, 0); epoch = 0; }
+    if (++epoch >= (1u << 28)) { std::fill(info.begin(), info.end(), 0); epoch = 1; }
+    const uint32_t tag = epoch << 4;
+    auto state_of = [&](uint32_t unitig) -> uint32_t { const uint32_t x = info[unitig]; return (x >> 4) == epoch ? (x & 15) : 0; };  // 0 = not in state_map
+    auto strand_bit = [](uint32_t ov) -> uint32_t { return (ov & 1) == 0 ? 4u : 0u; };
+    seen.clear();
+    todo.clear();
+    cyc.clear();
+    bool flag_cycle = false, flag_tip = false;
+    std::unordered_set<uint32_t> in_cyc;
+    auto cyc_add = [&](uint32_t ov) {  // unordered_set<UnitigMap>: kept in insertion order, the commits do not depend on it
+        if (in_cyc.insert(ov).second) cyc.push_back(ov);
+    };
+    uint64_t n_pending = 0;  // unitigs in state `seen` (0x02)
+    seen.push_back(s);
+    first[s >> 1] = s;
+    todo.push_back(s);
+    r.entrance = s;
+    r.exit = NONE;
+    r.outcome = PF_BFS_NONE;
+    r.strict = 0;
+    r.pad_ = 0;
+    while (!todo.empty()) {
+        const uint32_t v = todo.back();
+        todo.pop_back();
+        if ((state_of(v >> 1) & 3) == 2) --n_pending;
+        info[v >> 1] = tag | 1u | strand_bit(v);  // state_map[id] = 0x01; strand_map[id] = v.strand
+        const uint32_t *row = succ + (size_t)v * 4;
+        // the rows the next steps will want
+        for (int b = 0; b < 4; ++b)
+            if (row[b] != NONE) {
+                __builtin_prefetch(succ + (size_t)row[b] * 4);
+                __builtin_prefetch(pred + (size_t)row[b] * 4);
+                __builtin_prefetch(&info[row[b] >> 1]);
+            }
+        bool any = false;
+        for (int b = 0; b < 4; ++b) {
+            const uint32_t u = row[b];
+            if (u == NONE) continue;
+            any = true;
+            if (u == s) {
+                flag_cycle = true;
+                cyc_add(s);
+                cyc_add(v);
+                continue;
+            }
+            const uint32_t um = state_of(u >> 1);
+            if (um == 0 || (um & 3) != 1) {
+                if (um == 0) {
+                    seen.push_back(u);
+                    first[u >> 1] = u;
+                    info[u >> 1] = tag | 2u | strand_bit(u);
+                    ++n_pending;
+                } else {
+                    if ((um & 4) != strand_bit(u)) {
+                        flag_cycle = true;
+                        cyc_add(u);
+                        cyc_add(v);
+                    }
+                    info[u >> 1] = tag | 2u | (um & 4);  // it was `seen` already
+                }
+                bool all_pred = true;
+                const uint32_t *prow = pred + (size_t)u * 4;
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t p = prow[j];
+                    if (p == NONE) continue;
+                    const uint32_t pm = state_of(p >> 1);
+                    if (pm != 0) {
+                        if ((pm & 3) != 1) all_pred = false;
+                        if ((pm & 4) != strand_bit(p)) {
+                            flag_cycle = true;
+                            cyc_add(u);
+                            cyc_add(p);
+                        }
+                    } else {
+                        all_pred = false;
+                    }
+                }
+                if (all_pred) todo.push_back(u);
+            } else {
+                flag_cycle = true;
+                cyc_add(v);
+                cyc_add(u);
+            }
+        }
+        if (!any) flag_tip = true;
+        if (todo.size() == 1) {
+            // "no other entry of vec_km_seen is in state 0x02" (src/CDBG.cpp:337-351) by counting
+            const uint32_t t0 = todo[0];
+            const uint32_t tm = state_of(t0 >> 1);
+            const uint64_t mine = ((tm & 3) == 2 && first[t0 >> 1] == t0) ? 1 : 0;
+            if (n_pending == mine) {
+                r.exit = t0;
+                bool back = false;
+                const uint32_t *trow = succ + (size_t)t0 * 4;
+                for (int b = 0; b < 4; ++b) back |= trow[b] == s;
+                r.outcome = back ? PF_BFS_CYCLE_EXIT : (flag_cycle || flag_tip) ? PF_BFS_REJECT : PF_BFS_ACCEPT;
+                break;
+            }
+        }
+    }
+    r.n_seen = (uint32_t)seen.size();
+    r.flag_cycle = flag_cycle;
+    r.flag_tip = flag_tip;
+    const std::vector<uint32_t> &list = r.outcome != PF_BFS_NONE ? seen : cyc;
+    r.n_list = r.outcome != PF_BFS_NONE ? (uint32_t)seen.size() : (flag_cycle ? (uint32_t)cyc.size() : 0);
+    return list;
+}
+
+}  // namespace pfh

@@ -17,6 +17,10 @@
 //     reference's "message + exit(EXIT_FAILURE)";
 //   * output is always the deterministic `-t 1` ordering, whatever `threads` says.
 #pragma once
+#include <memory>
+#include <mutex>
+
+#include "pf_bfs_host.hpp"
 #include <cstdint>
 #include <memory>
 #include <string>
@@ -65,7 +69,8 @@ public:
     // extras (not in the reference interface)
     void set_output_dir(const std::string &dir) { outdir_ = dir; }  // default "PloidyFrost_output"
     void set_quiet(bool q) { quiet_ = q; }
-    void set_threads(unsigned t) { threads_ = t; }                  // host threads; 0 = use the `thr` argument
+    void set_threads(unsigned t) { threads_ = t; }
+    void set_third_tier_on_host(bool on) { third_tier_on_host_ = on; }   // default on; off = one wavefront per giant traversal                  // host threads; 0 = use the `thr` argument
     void set_write_files(bool w) { write_files_ = w; }              // bench: format but do not touch the disk
     void set_batch_bubbles(size_t n) { batch_bubbles_ = n; }
     // write <outpre>_super_bubble.txt in the background while PloidyEstimation runs (complete when that call, the next
@@ -127,6 +132,13 @@ protected:
     bool quiet_ = false, write_files_ = true;
     bool both_strands_ = true;
     unsigned threads_ = 0;
+    // third K-BFS tier (traversals beyond 4096 vertices) on host cores, pf_bfs_host.hpp; false = the device's k_bfs_huge
+    bool third_tier_on_host_ = true;
+    std::vector<std::unique_ptr<HugeWalker>> walkers_;
+    std::mutex walkers_mu_;
+    // vertex lists of the records walked on the host (pf_bfs_record::pad_ == 1, list_off = index), per K-BFS slice: a slice's
+    // lists are complete before its records are handed to the replay
+    std::vector<std::vector<uint32_t>> huge_lists_[4];
 
     std::vector<uint32_t> succ_, pred_;  // host copy of the CSR, [2N][4]
     std::vector<uint8_t> flags_;

@@ -72,13 +72,24 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     double bfs_s = 0;
     const bool prefetch_cov = overlap_output_;  // the same switch: work of the next call started behind the caller's back
     cov_ready_ = false;
+    static_assert(kMaxSlices <= 4, "huge_lists_ holds four slices");
+    for (auto &hl : huge_lists_) hl.clear();
+    const unsigned walk_threads = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
     std::thread device([&] {
+        std::vector<uint32_t> deferred;
         for (int i = 0; i < kSlices; ++i) {
             const auto tb = clk::now();
             uint32_t *pl = bx_.bfs_pool.p + s_pool0[i];
             uint64_t cap = s_pool0[i + 1] - s_pool0[i];
+            uint64_t n_deferred = 0;
+            if (third_tier_on_host_ && deferred.size() < 4096) deferred.resize(4096);
             int st1;
             for (;;) {
+                if (third_tier_on_host_) {
+                    st1 = pf_bfs_candidates_split(ctx_, s_u0[i], s_u0[i + 1], rec + s_rec0[i], s_rec0[i + 1] - s_rec0[i], pl, cap, &s_nrec[i], &s_used[i],
+                                                  deferred.data(), deferred.size(), &n_deferred);
+                    if (st1 == PF_ERR_OVERFLOW && n_deferred > deferred.size()) { deferred.resize(n_deferred + n_deferred / 4); continue; }
+                } else
                 st1 = pf_bfs_candidates(ctx_, s_u0[i], s_u0[i + 1], rec + s_rec0[i], s_rec0[i + 1] - s_rec0[i], pl, cap, &s_nrec[i], &s_used[i]);
                 if (st1 == PF_ERR_OVERFLOW && s_used[i] > cap) {
                     own_pool[i] = std::make_unique<PinnedBuf<uint32_t>>();
@@ -88,6 +99,29 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                     continue;
                 }
                 break;
+            }
+            if (st1 == PF_OK && n_deferred) {
+                // third tier: one host thread per giant traversal, side by side; lists go to huge_pool_
+                pf_bfs_record *srec = rec + s_rec0[i];
+                huge_lists_[i].assign((size_t)n_deferred, std::vector<uint32_t>());
+                parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
+                    std::unique_ptr<HugeWalker> w;
+                    {
+                        std::lock_guard<std::mutex> lk(walkers_mu_);
+                        if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
+                    }
+                    if (!w) w = std::make_unique<HugeWalker>();
+                    pf_bfs_record &r = srec[deferred[d]];
+                    const uint32_t s = r.entrance;
+                    const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, s, r);
+                    huge_lists_[i][d].assign(list.begin(), list.begin() + r.n_list);
+                    r.list_off = d;
+                    r.pad_ = 1;
+                    {
+                        std::lock_guard<std::mutex> lk(walkers_mu_);
+                        walkers_.push_back(std::move(w));
+                    }
+                });
             }
             bfs_s += since(tb);
             {
@@ -121,13 +155,13 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             // the commits chase per-unitig state at random: pull the state of a record a few iterations ahead into cache
             if (i + 12 < n_rec) {
                 const pf_bfs_record &nx = srec[i + 12];
-                __builtin_prefetch(pool + nx.list_off);
+                if (!nx.pad_) __builtin_prefetch(pool + nx.list_off);
                 __builtin_prefetch(&plus_[nx.entrance >> 1]);
                 __builtin_prefetch(&minus_[nx.entrance >> 1]);
             }
             if (i + 6 < n_rec) {
                 const pf_bfs_record &nx = srec[i + 6];
-                const uint32_t *l = pool + nx.list_off;
+                const uint32_t *l = nx.pad_ ? huge_lists_[sl][nx.list_off].data() : pool + nx.list_off;
                 const uint32_t nl = nx.n_list < 6 ? nx.n_list : 6;
                 for (uint32_t q = 0; q < nl; ++q) {
                     const uint32_t w = l[q] >> 1;
@@ -142,7 +176,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             const uint32_t u = r.entrance >> 1;
             if ((plus_of(r.entrance) ? plus_[u] : minus_[u]) != 0) continue;
             if (r.n_seen > 4096) { times_.bfs_large_used++; if (r.n_seen > times_.bfs_large_used_max) times_.bfs_large_used_max = r.n_seen; }
-            replay(r, pool + r.list_off);
+            replay(r, r.pad_ ? huge_lists_[sl][r.list_off].data() : pool + r.list_off);
         }
         replay_s += since(tr);
     }

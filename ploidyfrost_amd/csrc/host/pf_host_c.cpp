@@ -124,6 +124,7 @@ void pfh_set_output_dir(pfh_run *r, const char *dir) { r->cdbg->set_output_dir(d
 void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0); }
 void pfh_set_threads(pfh_run *r, uint32_t threads) { r->cdbg->set_threads(threads); }
 void pfh_set_overlap_output(pfh_run *r, int on) { r->cdbg->set_overlap_output(on != 0); }
+void pfh_set_third_tier_on_host(pfh_run *r, int on) { r->cdbg->set_third_tier_on_host(on != 0); }
 void pfh_set_batch_bubbles(pfh_run *r, uint64_t n) { r->cdbg->set_batch_bubbles((size_t)n); }
 int pfh_set_unitig_id(pfh_run *r, const char *outpre) {
     return guarded(r, [&] { return r->cdbg->setUnitigId(outpre, "", 1); });
@@ -148,6 +149,7 @@ void pfh_get_times(const pfh_run *r, pfh_times *o) {
     for (int a = 0; a < 4; ++a) o->allele[a] = r->cdbg->allele_sites(a + 2);
     o->core_cov = r->cdbg->core_cov(); o->core_num = r->cdbg->core_num();
     o->scan_s = t.scan_s; o->scan_serial_s = t.scan_serial_s;
+    o->bfs_large = t.bfs_large; o->bfs_max_seen = t.bfs_max_seen;
 }
 
 const char *pfh_last_allele_frequency(const pfh_run *r, uint64_t *len) {

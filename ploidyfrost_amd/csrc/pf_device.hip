@@ -996,9 +996,12 @@ int pf_count_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *n) {
     return PF_OK;
 }
 
-int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
-                      uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used) {
+// deferred != nullptr: the third tier is left to the caller (pf_bfs_candidates_split)
+static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
+                               uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint64_t deferred_cap,
+                               uint64_t *n_deferred) {
     if (!ctx || !ctx->has_adj || u0 > u1 || u1 > ctx->N || !records || !pool || !n_records || !pool_used) return PF_ERR_ARG;
+    if (n_deferred) *n_deferred = 0;
     PF_HIP(hipSetDevice(ctx->device));
     uint64_t c0, c1;
     cand_range(ctx, u0, u1, &c0, &c1);
@@ -1047,7 +1050,12 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
         unsigned int n_def2 = 0;
         PF_HIP(hipMemcpyAsync(&n_def2, d_ndef2, 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
-        if (n_def2) {
+        if (n_def2 && deferred) {
+            // the caller walks these itself: hand over their record indices
+            if (n_deferred) *n_deferred = n_def2;
+            if (n_def2 > deferred_cap) { ctx->err = "deferred-candidate buffer too small"; status = PF_ERR_OVERFLOW; }
+            else PF_HIP(hipMemcpy(deferred, d_def + n + 4, (size_t)n_def2 * 4, hipMemcpyDeviceToHost));
+        } else if (n_def2) {
             // traversals beyond the linear tables: direct-indexed state sized by the graph, a few waves
             // one wave per traversal, as many side by side as ~16 GiB of state allow
             const unsigned int hw = (unsigned int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_def2, 64), (16ull << 30) / (36 * (size_t)ctx->N + 64)));
@@ -1078,6 +1086,13 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
         if (status == PF_OK) {
             PF_HIP(hipMemcpy(records, d_rec, n * sizeof(pf_bfs_record), hipMemcpyDeviceToHost));
             PF_HIP(hipMemcpy(pool, d_pool, (size_t)head * 4, hipMemcpyDeviceToHost));
+            if (deferred && n_deferred)
+                for (uint64_t d = 0; d < *n_deferred; ++d) {  // records the caller fills: entrance set, everything else empty
+                    pf_bfs_record &r = records[deferred[d]];
+                    memset(&r, 0, sizeof r);
+                    r.entrance = ctx->h_cand[c0 + deferred[d]];
+                    r.exit = NONE;
+                }
             for (uint64_t i = 0; i < n; ++i)
                 if (records[i].outcome == BFS_TOO_LARGE) {
                     ctx->err = "a traversal exceeded the direct-indexed tier (internal limit)";
@@ -1087,6 +1102,26 @@ int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *reco
         }
     }
     return status;
+}
+
+int pf_bfs_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
+                      uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used) {
+    return bfs_candidates_impl(ctx, u0, u1, records, rec_cap, pool, pool_cap, n_records, pool_used, nullptr, 0, nullptr);
+}
+
+int pf_bfs_candidates_split(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
+                            uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint64_t deferred_cap,
+                            uint64_t *n_deferred) {
+    if (!deferred || !n_deferred) return PF_ERR_ARG;
+    if (ctx) {
+        hipPointerAttribute_t at;
+        if (records && hipPointerGetAttributes(&at, records) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            ctx->err = "pf_bfs_candidates_split fills host records";
+            return PF_ERR_ARG;
+        }
+        (void)hipGetLastError();
+    }
+    return bfs_candidates_impl(ctx, u0, u1, records, rec_cap, pool, pool_cap, n_records, pool_used, deferred, deferred_cap, n_deferred);
 }
 
 }  // extern "C"

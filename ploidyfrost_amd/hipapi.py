@@ -112,7 +112,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
-                    "pf_minimizer_table_slots", "pf_minimizer_crowding"]
+                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split"]
 
 
 def pack_unitigs(seqs: list[bytes]):

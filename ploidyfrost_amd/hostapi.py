@@ -18,11 +18,12 @@ class Times(C.Structure):
                                           "ploidy_total_s")] + \
                [(n, C.c_uint64) for n in ("unitigs", "kmers", "candidates", "superbubbles", "tasks", "align_jobs", "site_strings",
                                           "output_bytes")] + [("allele", C.c_uint64 * 4), ("core_cov", C.c_uint64),
-                                                              ("core_num", C.c_uint64), ("scan_s", C.c_double), ("scan_serial_s", C.c_double)]
+                                                              ("core_num", C.c_uint64), ("scan_s", C.c_double), ("scan_serial_s", C.c_double),
+                                                              ("bfs_large", C.c_uint64), ("bfs_max_seen", C.c_uint64)]
 
 
 _lib = None
-DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_overlap_output", "pfh_set_unitig_id",
+DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_unitig_id",
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
@@ -50,6 +51,7 @@ def load_library() -> C.CDLL:
     L.pfh_set_threads.argtypes = [vp, C.c_uint32]
     L.pfh_set_batch_bubbles.argtypes = [vp, C.c_uint64]
     L.pfh_set_overlap_output.argtypes = [vp, C.c_int]
+    L.pfh_set_third_tier_on_host.argtypes = [vp, C.c_int]
     L.pfh_set_unitig_id.argtypes = [vp, C.c_char_p]
     L.pfh_find_superbubbles.argtypes = [vp, C.c_char_p]
     L.pfh_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
@@ -157,6 +159,9 @@ class Run:
 
     def set_overlap_output(self, on: bool):
         self.L.pfh_set_overlap_output(self.h, int(on))
+
+    def set_third_tier_on_host(self, on: bool):
+        self.L.pfh_set_third_tier_on_host(self.h, int(on))
 
     def set_batch_bubbles(self, n: int):
         self.L.pfh_set_batch_bubbles(self.h, n)

@@ -126,3 +126,27 @@ def test_overlapped_output_is_complete_when_ploidy_returns(tmp_path):
     run.find_superbubbles("g")   # pending write joined by close()
     run.close()
     assert open(os.path.join(meta["dir"], "expected", "g_super_bubble.txt"), "rb").read() == open(tmp_path / "g_super_bubble.txt", "rb").read()
+
+
+def test_third_tier_on_host_and_on_device_agree_with_the_oracle(tmp_path):
+    """giant7k: a repeat links two loci, the traversals entering it visit > 4096 vertices.  Those run on host cores by default
+    (pf_bfs_candidates_split + pf_bfs_host.cpp) or on the device (k_bfs_huge); state, counters and files must not differ."""
+    meta = load_case("giant7k")
+    op = meta["opts"]
+    o = pyoracle.Oracle(meta["gfa"], meta["db"])
+    nb = o.find_superbubbles(z=int(op["-z"]))
+    ef, ep, em = o.state()
+    for on_host in (True, False):
+        d = tmp_path / ("host" if on_host else "device")
+        run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]))
+        run.set_third_tier_on_host(on_host)
+        run.set_threads(4)
+        run.set_output_dir(str(d))
+        run.set_unitig_id("g")
+        run.find_superbubbles("g")
+        f, p, m = run.state()
+        assert np.array_equal(f, ef) and np.array_equal(p, ep) and np.array_equal(m, em), on_host
+        t = run.times()
+        assert t["superbubbles"] == nb and t["bfs_large"] >= 1, t
+        run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+        assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(d)), on_host
