@@ -118,11 +118,11 @@ CASES = {
     "dip_kmc2": (lambda: synth.make_haplotypes(synth.HapSpec(16000, 2, seed=31)), 25, ["-l", "5", "-u", "1000"], "kmc2"),
     # a 17-mer with a very low minimizer hash planted at 100 places: its bucket in Bifrost's minimizer index is crowded, the
     # k-length unitigs read after the 15th entry become "abundant" k-mers and are numbered last, in hash-table order
-    # a (k-1)-mer copied from 4 % to 30 % of the genome: no k-mer is shared, but the unitig ending in it at either locus gains
-    # the other locus's continuation as a second successor, whose own predecessor is never visited -- the traversal from that
-    # unitig cannot close and runs on to the end of the chromosome: more than 4096 vertices, the third K-BFS tier
+    # a 32-bp segment copied from 4 % to 8 % of the genome: the shared unitig has both loci's continuations as successors, each
+    # with no other predecessor, so the traversal entering there walks one locus to the end of the chromosome (a tip) before it
+    # can come back to the other -- more than 4096 vertices: the third K-BFS tier
     "giant7k": (lambda: synth.make_haplotypes(synth.HapSpec(270000, 4, seed=5, gap_lo=15, gap_hi=300),
-                                              lambda b: np.concatenate([b[:81000], b[10800:10824], b[81024:]])), 25,
+                                              lambda b: np.concatenate([b[:21600], b[10800:10832], b[21632:]])), 25,
                 ["-l", "5", "-u", "1000"]),
     "crowd25": (lambda: synth.make_haplotypes(synth.HapSpec(24000, 4, seed=4, gap_lo=8, gap_hi=150, p_multi=0.05),
                                               lambda b: synth.plant_crowded_minimizer(np.random.default_rng(41), b, 17, 100)), 25,
