@@ -366,6 +366,7 @@ int main(int argc, char **argv) {
         cout << "CompactedDBG::read(): " << graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
     g.set_threads((unsigned)opt.nb_threads);
     g.set_overlap_output(true);
+    if (getenv("PF_BFS_HUGE_ON_DEVICE")) g.set_third_tier_on_host(false);   // experiments: giant traversals on one wavefront each
     if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
     if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
     if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) die();

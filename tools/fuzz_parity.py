@@ -10,7 +10,10 @@ instead: any repeat structure, samples that start and stop at different places (
 With PF_FUZZ_REFERENCE=1 the comparator is the reference binary itself (oracle/_ref/PloidyFrost -t 1) instead of the oracle.
 With PF_FUZZ_CROWD=1 (implies both of the above) a g-mer with a very low minimizer hash is planted at 20-120 places of the
 genome, so that Bifrost files some k-length unitigs as "abundant" k-mers and numbers them last, in hash-table order -- the
-part of the unitig numbering the oracle's loader does not restate (pf_host_minz.hpp)."""
+part of the unitig numbering the oracle's loader does not restate (pf_host_minz.hpp).
+With PF_FUZZ_GIANT=1 the genomes are 250-400 kb long and carry one to three copied segments (k .. 2k bp) near their start: the
+shared unitig's traversal cannot close before it has walked a whole locus to the end of the chromosome -- traversals of more
+than 4096 vertices, the third K-BFS tier (host walkers by default; PF_FUZZ_GIANT=device switches every other case to k_bfs_huge)."""
 import os
 import subprocess
 import sys
@@ -57,19 +60,33 @@ def one_case(seed, tmp, dev):
                          p_multi=float(rng.choice([0.0, 0.05, 0.15])), max_ins=int(rng.choice([3, 6, 12, 30])),
                          p_snp=float(rng.choice([0.5, 0.75, 0.9])), p_del=0.1)
     crowd = os.environ.get("PF_FUZZ_CROWD") == "1"
+    giant = os.environ.get("PF_FUZZ_GIANT")
     edit = None
+    if giant:
+        L = int(rng.integers(250000, 400000))
+        spec.genome_len = L
+
+        def edit(base, rng2=np.random.default_rng(seed + 11), k=k):
+            out = base.copy()
+            for _ in range(int(rng2.integers(1, 4))):
+                ln = int(rng2.integers(k, 2 * k))
+                a = int(rng2.integers(2000, 12000))
+                b = int(rng2.integers(14000, 30000))
+                seg = out[a: a + ln] if rng2.random() < 0.8 else (3 - out[a: a + ln])[::-1]   # sometimes inverted
+                out[b: b + ln] = seg
+            return out
     if crowd:
         g_len = k - 8 if k >= 15 else k - 4   # Bifrost's default minimizer length (CompactedDBG.hpp DEFAULT_G_DEC1/2)
         copies = int(rng.integers(20, 120))
         edit = lambda base: synth.plant_crowded_minimizer(np.random.default_rng(seed + 7), base, g_len, copies, tries=1500)  # noqa: E731
     haps = synth.make_haplotypes(spec, edit)
-    if rng.random() < 0.3:  # splice the variants onto a repeat-rich genome: cycles, hairpins, tips
+    if rng.random() < 0.3 and not giant:  # splice the variants onto a repeat-rich genome: cycles, hairpins, tips
         rep = repeat_rich(rng, L)
         haps = [np.concatenate([rep[: len(rep) // 2], h[200:-200], rep[len(rep) // 2:]]) for h in haps]
     scores = [(2, -1, -3), (2, -1, -3), (1, -1, -1), (3, -2, -4), (1.5, -0.5, -2.25), (2, -1, -2)][int(rng.integers(0, 6))]
     lower, upper = [(5, 1000), (5, 1000), (15, 70), (1, 100000)][int(rng.integers(0, 4))]
-    colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4
-    use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1" or crowd
+    colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4 and not giant
+    use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1" or crowd or bool(giant)
     use_reference = os.environ.get("PF_FUZZ_REFERENCE") == "1" or crowd
     try:
         if use_bifrost:
@@ -135,10 +152,17 @@ def one_case(seed, tmp, dev):
         else:
             ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-O", os.path.join(og, "PloidyFrost_output")]
                                 + common, cwd=og, capture_output=True, text=True)
-        rg = subprocess.run([CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-t", "8"] + common, cwd=gg, capture_output=True,
-                            text=True)
+        env = dict(os.environ)
+        if giant == "device" and seed % 2:
+            env["PF_BFS_HUGE_ON_DEVICE"] = "1"
+        rg = subprocess.run([CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-t", "8", "-v"] + common, cwd=gg, capture_output=True,
+                            text=True, env=env)
     desc = "k=%d ploidy=%d z=%d L=%d scores=%s cut=%d/%d %s unitigs=%d" % (k, ploidy, z, L, scores, lower, upper,
                                                                           "colored" if colored else "single", n_unitigs)
+    if giant and not colored:
+        import re
+        mm = re.search(r"traversals > 4096 unitigs: (\d+) \(sum of seen \d+, largest (\d+)\)", rg.stdout)
+        desc += " giants=%s largest=%s" % (mm.group(1), mm.group(2)) if mm else " giants=?"
     if crowd:
         from ploidyfrost_amd import hostapi
         desc += " abundant=%d" % hostapi.load_library().pfh_gfa_abundant_kmers(gfa.encode())
