@@ -144,9 +144,9 @@ enum pf_bfs_outcome {
 int pf_count_candidates(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *n_candidates);
 int pf_bfs_candidates(pf_ctx *, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap,
                       uint32_t *pool, uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used);
-/* The same with the third tier left to the caller: a traversal that outgrows the device's 4096-entry tables is one long
- * dependent chain of memory accesses (LIFO order fixes its result), which a host core walks several times faster than a lone
- * wavefront.  records / pool must be host memory; deferred[0 .. *n_deferred) = indices (into records) of those candidates,
+/* The same with everything beyond the first (LDS, 128-entry) tier left to the caller: a long traversal is one chain of
+ * dependent memory accesses (LIFO order fixes its result), which a host core walks two orders of magnitude faster than a lone
+ * wavefront (~20 ns against ~2.4 us per vertex).  records / pool must be host memory; deferred[0 .. *n_deferred) = indices (into records) of those candidates,
  * whose records come back with only `entrance` set (exit = PF_NONE, outcome = PF_BFS_NONE, no list) for the caller to fill. */
 int pf_bfs_candidates_split(pf_ctx *, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
                             uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint64_t deferred_cap,

@@ -38,10 +38,8 @@ const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32
         if ((state_of(v >> 1) & 3) == 2) --n_pending;
         info[v >> 1] = tag | 1u | strand_bit(v);  // state_map[id] = 0x01; strand_map[id] = v.strand
         const uint32_t *row = succ + (size_t)v * 4;
-        // the rows the next steps will want
         for (int b = 0; b < 4; ++b)
             if (row[b] != NONE) {
-                __builtin_prefetch(succ + (size_t)row[b] * 4);
                 __builtin_prefetch(pred + (size_t)row[b] * 4);
                 __builtin_prefetch(&info[row[b] >> 1]);
             }
@@ -88,7 +86,10 @@ const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32
                         all_pred = false;
                     }
                 }
-                if (all_pred) todo.push_back(u);
+                if (all_pred) {
+                    todo.push_back(u);
+                    __builtin_prefetch(succ + (size_t)u * 4);   // u is popped soon (LIFO): its own row first
+                }
             } else {
                 flag_cycle = true;
                 cyc_add(v);

@@ -100,6 +100,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                 }
                 break;
             }
+            if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] device tiers of slice %d: %.2f ms, %llu candidates left for the third tier\n", i, since(tb) * 1e3, (unsigned long long)n_deferred);
             if (st1 == PF_OK && n_deferred) {
                 // third tier: one host thread per giant traversal, side by side; lists go to huge_pool_
                 pf_bfs_record *srec = rec + s_rec0[i];
@@ -113,7 +114,9 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                     if (!w) w = std::make_unique<HugeWalker>();
                     pf_bfs_record &r = srec[deferred[d]];
                     const uint32_t s = r.entrance;
+                    const auto tw = clk::now();
                     const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, s, r);
+                    if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] host walk from %u: %u vertices, outcome %d, %.2f ms\n", s, r.n_seen, (int)r.outcome, since(tw) * 1e3);
                     huge_lists_[i][d].assign(list.begin(), list.begin() + r.n_list);
                     r.list_off = d;
                     r.pad_ = 1;

@@ -1036,7 +1036,13 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     PF_HIP(hipMemcpyAsync(&n_def, d_ndef, 4, hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
     int status = PF_OK;
-    if (n_def) {
+    if (n_def && deferred) {
+        // the caller walks everything that outgrew the LDS tier itself (a host core needs ~20 ns per vertex; the 4096-entry
+        // tier below searches its tables linearly and is quadratic in the traversal's size)
+        if (n_deferred) *n_deferred = n_def;
+        if (n_def > deferred_cap) { ctx->err = "deferred-candidate buffer too small"; status = PF_ERR_OVERFLOW; }
+        else PF_HIP(hipMemcpy(deferred, d_def, (size_t)n_def * 4, hipMemcpyDeviceToHost));
+    } else if (n_def) {
         const unsigned int waves = std::min<unsigned int>(n_def, 256);
         DevTmp<uint32_t> sc32_;
         DevTmp<uint8_t> sc8_;
@@ -1050,12 +1056,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
         unsigned int n_def2 = 0;
         PF_HIP(hipMemcpyAsync(&n_def2, d_ndef2, 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
-        if (n_def2 && deferred) {
-            // the caller walks these itself: hand over their record indices
-            if (n_deferred) *n_deferred = n_def2;
-            if (n_def2 > deferred_cap) { ctx->err = "deferred-candidate buffer too small"; status = PF_ERR_OVERFLOW; }
-            else PF_HIP(hipMemcpy(deferred, d_def + n + 4, (size_t)n_def2 * 4, hipMemcpyDeviceToHost));
-        } else if (n_def2) {
+        if (n_def2) {
             // traversals beyond the linear tables: direct-indexed state sized by the graph, a few waves
             // one wave per traversal, as many side by side as ~16 GiB of state allow
             const unsigned int hw = (unsigned int)std::max<size_t>(1, std::min<size_t>(std::min<size_t>(n_def2, 64), (16ull << 30) / (36 * (size_t)ctx->N + 64)));
