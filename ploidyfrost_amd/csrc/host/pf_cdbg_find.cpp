@@ -44,7 +44,8 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // Slicing costs when a graph has chromosome-long traversals: each slice would run its own serially instead of all of
     // them side by side.  So the first pass over a graph is one slice, and later passes are sliced only if none was seen.
     constexpr int kMaxSlices = 4;
-    const int kSlices = (find_passes_ > 0 && times_.bfs_large == 0) ? kMaxSlices : 1;
+    // (with the long traversals on host cores a slice's own are walked in a few milliseconds: no reason to avoid slicing then)
+    const int kSlices = (find_passes_ > 0 && (times_.bfs_large == 0 || third_tier_on_host_)) ? kMaxSlices : 1;
     ++find_passes_;
     uint32_t s_u0[kMaxSlices + 1];
     uint64_t s_cand[kMaxSlices], s_rec0[kMaxSlices + 1], s_pool0[kMaxSlices + 1], s_nrec[kMaxSlices], s_used[kMaxSlices];
