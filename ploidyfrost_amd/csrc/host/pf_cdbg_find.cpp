@@ -75,7 +75,8 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     cov_ready_ = false;
     static_assert(kMaxSlices <= 4, "huge_lists_ holds four slices");
     for (auto &hl : huge_lists_) hl.clear();
-    const unsigned walk_threads = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
+    // host walkers of the long traversals: each keeps 8 bytes of state per unitig, at most ~4 GiB of it in total
+    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
     std::thread device([&] {
         std::vector<uint32_t> deferred;
         for (int i = 0; i < kSlices; ++i) {
