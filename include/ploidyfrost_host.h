@@ -13,6 +13,8 @@
 #ifndef PLOIDYFROST_HOST_H_
 #define PLOIDYFROST_HOST_H_
 #include <stdint.h>
+
+#include "ploidyfrost_hip.h" /* pf_bfs_record */
 #ifdef __cplusplus
 extern "C" {
 #endif
@@ -117,6 +119,13 @@ int pfh_gmm_run(pfh_gmm *, int min_gauss, int max_gauss, double m_thre, double n
                 const char *outprefix);
 /* enable = 1 / 0 switches the HIP-event timing of the K-GMM launches on / off; enable < 0 reads the totals */
 int pfh_gmm_kernel_time(pfh_gmm *, int enable, double *total_ms, uint64_t *launches);
+
+/* The host tier of K-BFS on its own (host/pf_bfs_host.hpp; no device involved): extractSuperBubble_ptr's traversal
+ * (src/CDBG.cpp:253-372) from one oriented vertex over CSR rows laid out as pf_build_adjacency returns them.  Fills *record
+ * (list_off = 0) and copies its list -- seen[] when an exit was found, the cycle set otherwise -- to `list`.
+ * 0 = ok, 2 = list_cap too small (record->n_list says how much is needed). */
+int pfh_host_walk(const uint32_t *succ, const uint32_t *pred, uint32_t n_unitigs, uint32_t entrance, pf_bfs_record *record, uint32_t *list,
+                  uint64_t list_cap);
 
 /* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);

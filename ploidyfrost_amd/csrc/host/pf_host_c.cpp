@@ -5,6 +5,7 @@
 #include <string>
 #include <vector>
 
+#include "pf_bfs_host.hpp"
 #include "pf_cdbg.hpp"
 #include "pf_gmm_model.hpp"
 #include "pf_host_colors.hpp"
@@ -219,6 +220,21 @@ uint32_t pfh_gfa_numbering_replays(const char *gfa_path) {
     } catch (const std::exception &e) {
         g_open_err = std::string("ploidyfrost host layer: ") + e.what();
         return ~0u;
+    }
+}
+int pfh_host_walk(const uint32_t *succ, const uint32_t *pred, uint32_t n_unitigs, uint32_t entrance, pf_bfs_record *record, uint32_t *list,
+                  uint64_t list_cap) {
+    if (!succ || !pred || !record || n_unitigs == 0 || (entrance >> 1) >= n_unitigs) return 1;
+    try {
+        static thread_local pfh::HugeWalker walker;
+        const std::vector<uint32_t> &l = walker.walk(succ, pred, n_unitigs, entrance, *record);
+        record->list_off = 0;
+        if (record->n_list > list_cap) return 2;
+        if (list) std::copy(l.begin(), l.begin() + record->n_list, list);
+        return 0;
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return 1;
     }
 }
 uint64_t pfh_gfa_minimizer_counts(const char *gfa_path, uint8_t *counters, uint64_t slots) {
