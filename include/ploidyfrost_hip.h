@@ -112,6 +112,11 @@ int pf_lookup_kmers(pf_ctx *, const uint64_t *kmers, uint64_t n, uint32_t *count
  * division (mean = sum / len). Returns PF_ERR_MISSING_KMER after filling the arrays if
  * any miss flag is set. [host|dev] */
 int pf_unitig_cov(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *min, uint8_t *miss);
+/* The branch for a database built without canonical counting (GetBothStrands() == false, src/CDBG.cpp:94-117): every k-mer of
+ * mappedSequenceToString() is looked up as it reads.  reverse = 0: the unitig as stored; 1: its reverse complement (the '-'
+ * orientation).  pf_unitig_cov refuses such a table; pf_string_cov returns sum 0 / ok 1 for it without looking anything up, as
+ * readCov(string) does (:34, :59). [host|dev] */
+int pf_unitig_cov_exact(pf_ctx *, uint32_t u0, uint32_t u1, int reverse, uint64_t *sum, uint32_t *min, uint8_t *miss);
 
 /* ---- S2: CDBG::extractSuperBubble_ptr (src/CDBG.cpp:253-415), pure part ------------------ */
 typedef struct pf_bfs_record {

@@ -347,6 +347,10 @@ int pfo_unitig_cov(const pfo_ctx *c, uint32_t u, uint64_t *sum, uint32_t *min_co
     return unitig_cov(*c, u * 2, *sum, *min_count);
 }
 
+int pfo_unitig_cov_oriented(const pfo_ctx *c, uint32_t ov, uint64_t *sum, uint32_t *min_count) {
+    return unitig_cov(*c, ov, *sum, *min_count);
+}
+
 int pfo_string_cov(const pfo_ctx *c, const char *s, uint32_t len, uint32_t low, uint32_t up, uint64_t *sum,
                    int *ok) {
     bool o;

@@ -48,6 +48,8 @@ void pfo_adjacency(const pfo_ctx *, uint32_t *succ, uint32_t *pred);
 
 /* C1: per-unitig coverage.  Returns 0 ok, 1 if some k-mer is missing (reference would exit). */
 int pfo_unitig_cov(const pfo_ctx *, uint32_t u, uint64_t *sum, uint32_t *min_count);
+/* the same for an oriented unitig ov = 2u + (strand ? 0 : 1): the orientation matters only for a database without canonical counting */
+int pfo_unitig_cov_oriented(const pfo_ctx *, uint32_t ov, uint64_t *sum, uint32_t *min_count);
 /* C2: coverage of a >=k-length string; *ok = 0 when a count is outside (low,up);
  * returns 1 if a k-mer is missing. */
 int pfo_string_cov(const pfo_ctx *, const char *s, uint32_t len, uint32_t low, uint32_t up,

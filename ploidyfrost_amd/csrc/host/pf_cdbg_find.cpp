@@ -265,13 +265,20 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
 // single-sample path raises it only for the unitigs it really uses, the colored path never (src/CCDBG.cpp:113-117).
 int CDBG::launch_coverage() {
     const uint32_t N = g_.n();
-    const uint32_t C = col_ ? col_->n_colors : 1;
+    // a database without canonical counting (single-sample only) is read per orientation: [0, N) the unitigs as stored,
+    // [N, 2N) their reverse complements (readCov(UnitigMap), src/CDBG.cpp:94-117)
+    const uint32_t C = col_ ? col_->n_colors : (both_strands_ ? 1 : 2);
     bx_.cov_sum.ensure(ctx_, (size_t)N * C);
     bx_.cov_min.ensure(ctx_, (size_t)N * C);
     bx_.cov_miss.ensure(ctx_, (size_t)N * C);
     if (col_) bx_.cov_max.ensure(ctx_, (size_t)N * C);
-    const int st = col_ ? pf_unitig_cov_colored(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_max.p, bx_.cov_miss.p)
-                        : pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
+    int st;
+    if (col_) st = pf_unitig_cov_colored(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_max.p, bx_.cov_miss.p);
+    else if (both_strands_) st = pf_unitig_cov(ctx_, 0, N, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
+    else {
+        st = pf_unitig_cov_exact(ctx_, 0, N, 0, bx_.cov_sum.p, bx_.cov_min.p, bx_.cov_miss.p);
+        if (st == PF_OK || st == PF_ERR_MISSING_KMER) st = pf_unitig_cov_exact(ctx_, 0, N, 1, bx_.cov_sum.p + N, bx_.cov_min.p + N, bx_.cov_miss.p + N);
+    }
     if (st != PF_OK && st != PF_ERR_MISSING_KMER) { cov_err_ = pf_last_error(ctx_); return st; }
     return PF_OK;
 }

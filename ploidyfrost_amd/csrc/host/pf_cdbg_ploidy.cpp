@@ -234,6 +234,10 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     times_.cov_device_s = since(t0);
     tp("coverage done");
     auto mean_of = [&](uint32_t u) { return (double)cov_sum[u] / (double)g_.len_km(u); };
+    // coverage slot of an oriented unitig: one per unitig, or (database without canonical counting) one per orientation
+    const bool per_strand = !colored && !both_strands_;
+    auto cslot = [&](uint32_t ov) -> size_t { return per_strand && (ov & 1) ? (size_t)N + (ov >> 1) : (size_t)(ov >> 1); };
+    auto mean_of_ov = [&](uint32_t ov) { return (double)cov_sum[cslot(ov)] / (double)g_.len_km(ov >> 1); };
     // readCovUni(u, low, up, c) of src/CCDBG.cpp:123-156: (sum / len, true) iff every k-mer is in colour c's database
     // with low < count < up, else (0, false)
     auto cov_ok_c = [&](uint32_t c, uint32_t u) {
@@ -297,7 +301,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 }
                 const uint32_t uo = 2 * u + (ps ? 0 : 1);
                 const bool strict = (f & (ps ? B_STRICT_P : B_STRICT_M)) != 0;
-                if (!colored && cov_miss[u]) { r.err = 1; r.err_unitig = u; out.push_back(r); continue; }  // core = readCov(u)
+                if (!colored && cov_miss[cslot(uo)]) { r.err = 1; r.err_unitig = u; out.push_back(r); continue; }  // core = readCov(u), u oriented
                 uint32_t exit_ov;
                 if (strict) {
                     exit_ov = first_succ(first_succ(uo));
@@ -375,7 +379,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                     out.push_back(r);
                     continue;
                 }
-                r.t.core_mean = mean_of(u);
+                r.t.core_mean = per_strand ? mean_of_ov(uo) : mean_of(u);
                 bool aligned = true;
                 if (strict) {
                     Task &t = r.t;
@@ -383,9 +387,9 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                         const uint32_t w = succ_row(uo)[b];
                         if (w == NONE) continue;
                         t.inner[t.n_inner++] = w;
-                        if (cov_miss[w >> 1]) { r.err = 1; r.err_unitig = w >> 1; break; }
-                        if (cov_min[w >> 1] > low && cov_min[w >> 1] < up) {
-                            const double mcov = mean_of(w >> 1);
+                        if (cov_miss[cslot(w)]) { r.err = 1; r.err_unitig = w >> 1; break; }
+                        if (cov_min[cslot(w)] > low && cov_min[cslot(w)] < up) {
+                            const double mcov = mean_of_ov(w);
                             t.cov[t.n_cov++] = mcov;
                             t.cov_sum += mcov;
                         } else {
@@ -396,7 +400,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                         // the reference also reads the predecessors' coverage and drops it (:1224-1239)
                         for (int b = 0; b < 4; ++b) {
                             const uint32_t w = pred_[(size_t)uo * 4 + b];
-                            if (w != NONE && cov_miss[w >> 1]) { r.err = 1; r.err_unitig = w >> 1; break; }
+                            if (w != NONE && cov_miss[cslot(w)]) { r.err = 1; r.err_unitig = w >> 1; break; }
                         }
                         if (!r.err) sort_inner(g_, t.cov, t.inner, 0, (int)t.n_cov - 1);
                     }

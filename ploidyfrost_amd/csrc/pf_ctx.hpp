@@ -56,6 +56,7 @@ struct pf_ctx {
     pf::Slot *d_tab = nullptr;
     uint64_t tab_cap = 0, tab_n = 0;
     bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked at upload)
+    bool tab_exact = false;       // database built without canonical counting: no composite lookups
 
     // colored path: the count databases of all colours in one table, slot = { u64 key, u32 count[n_colors] }
     // padded to 1 << ctab_shift bytes (pf_colored.hip)

@@ -215,7 +215,7 @@ __global__ void k_cov_init(uint32_t n, uint64_t *__restrict__ out_sum, uint32_t 
 
 __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_t mask, int k, const uint64_t *__restrict__ seq,
                                              const uint64_t *__restrict__ off, const uint64_t *__restrict__ kpre, const uint32_t *__restrict__ kwin, uint32_t N,
-                                             bool one_strand, uint32_t u0, uint64_t g_begin, uint64_t g_end, uint64_t w_begin,
+                                             bool one_strand, int exact, uint32_t u0, uint64_t g_begin, uint64_t g_end, uint64_t w_begin,
                                              uint64_t n_win, uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min,
                                              uint8_t *__restrict__ out_miss) {
     __shared__ uint64_t s_pre[4][KCOV_WIN + 2];
@@ -250,7 +250,14 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
                     if (P[mid] <= g) lo = mid; else hi = mid - 1;
                 }
                 uu[j] = ub + (uint32_t)lo;
-                count_probe(t, mask, kmer_at(seq + off[uu[j]], (uint32_t)(g - P[lo]), k), k, one_strand, pr[j]);
+                const uint64_t fwd = kmer_at(seq + off[uu[j]], (uint32_t)(g - P[lo]), k);
+                if (exact) {  // database without canonical counting: the k-mer as it reads in the wanted orientation, nothing else
+                    const uint64_t key = exact == 2 ? rc_kmer(fwd, k) : fwd;
+                    pr[j].first = pr[j].second = key;
+                    pr[j].s = load_slot(t, mix64(key) & mask);
+                } else {
+                    count_probe(t, mask, fwd, k, one_strand, pr[j]);
+                }
             }
         }
 #pragma unroll
@@ -838,10 +845,7 @@ int pf_copy_to_host(pf_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
 int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t min_count,
                      uint64_t max_count, int both_strands) {
     if (!ctx || (n && (!kmers || !counts))) return PF_ERR_ARG;
-    if (!both_strands) {
-        ctx->err = "databases built without canonical counting (GetBothStrands() == false) are not supported";
-        return PF_ERR_ARG;
-    }
+    ctx->tab_exact = !both_strands;   // GetBothStrands() == false: lookups take the k-mer as it reads (src/CDBG.cpp:94-117)
     PF_HIP(hipSetDevice(ctx->device));
     hipFree(ctx->d_tab);
     ctx->d_tab = nullptr;
@@ -911,7 +915,7 @@ int pf_lookup_kmers(pf_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *co
     return PF_OK;
 }
 
-int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
+static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
     if (!ctx || !ctx->d_seq || !ctx->d_tab || u0 > u1 || u1 > ctx->N || !sum || !mn || !miss) return PF_ERR_ARG;
     if (u0 == u1) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
@@ -943,7 +947,7 @@ int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t
     ctx_begin(ctx, PF_K_COV);
     k_cov_init<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(n, ds, dm, dx);
     k_cov<<<ctx_grid(ctx, (w_end - w_begin) * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
-                                                                                 ctx->d_kwin, ctx->N, ctx->tab_one_strand, u0, g_range[0],
+                                                                                 ctx->d_kwin, ctx->N, ctx->tab_one_strand, exact, u0, g_range[0],
                                                                                  g_range[1], w_begin, w_end - w_begin, ds, dm, dx);
     ctx_end(ctx);
     if (!dev_out) {
@@ -957,11 +961,40 @@ int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t
     return PF_OK;
 }
 
+int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
+    if (ctx && ctx->tab_exact) {
+        ctx->err = "the count database was built without canonical counting: pf_unitig_cov_exact gives its per-orientation coverage";
+        return PF_ERR_ARG;
+    }
+    return unitig_cov_impl(ctx, u0, u1, 0, sum, mn, miss);
+}
+
+int pf_unitig_cov_exact(pf_ctx *ctx, uint32_t u0, uint32_t u1, int reverse, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
+    return unitig_cov_impl(ctx, u0, u1, reverse ? 2 : 1, sum, mn, miss);
+}
+
 int pf_string_cov(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32_t n_str, uint32_t low, uint32_t up,
                   uint64_t *sum, uint8_t *ok, uint8_t *miss) {
     if (!ctx || !ctx->d_tab || (n_str && (!text || !str_off || !sum || !ok || !miss))) return PF_ERR_ARG;
     if (n_str == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
+    if (ctx->tab_exact) {
+        // readCov(string) looks nothing up in a database without canonical counting and returns (0, true) (src/CDBG.cpp:34, 59)
+        hipPointerAttribute_t at;
+        const bool dev_out = hipPointerGetAttributes(&at, sum) == hipSuccess && at.type == hipMemoryTypeDevice;
+        (void)hipGetLastError();
+        if (dev_out) {
+            PF_HIP(hipMemsetAsync(sum, 0, (size_t)n_str * 8, ctx->stream));
+            PF_HIP(hipMemsetAsync(ok, 1, n_str, ctx->stream));
+            PF_HIP(hipMemsetAsync(miss, 0, n_str, ctx->stream));
+            PF_HIP(hipStreamSynchronize(ctx->stream));
+        } else {
+            memset(sum, 0, (size_t)n_str * 8);
+            memset(ok, 1, n_str);
+            memset(miss, 0, n_str);
+        }
+        return PF_OK;
+    }
     uint64_t total = 0;
     PF_HIP(hipMemcpy(&total, str_off + n_str, 8, hipMemcpyDefault));
     char *dt = (char *)ctx_ws(ctx, WS_STR_TEXT, (size_t)total + 1);

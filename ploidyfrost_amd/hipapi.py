@@ -89,6 +89,7 @@ def load_library() -> C.CDLL:
         "pf_num_colors": (u32, [vp]),
         "pf_unitig_cov_colored": (i, [vp, u32, u32, vp, vp, vp, vp]),
         "pf_string_cov_colored": (i, [vp, vp, vp, u32, vp, vp, vp, vp]),
+        "pf_unitig_cov_exact": (i, [vp, u32, u32, i, vp, vp, vp]),
         "pf_minimizer_table_slots": (u64, [u64]),
         "pf_minimizer_crowding": (i, [vp, i, u32, vp, vp, vp]),
         "pf_kmc_decode": (i, [vp, vp, u64, u32, u32, vp, u64, u32, u32, vp, vp]),
@@ -112,7 +113,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
-                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split"]
+                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact"]
 
 
 def pack_unitigs(seqs: list[bytes]):
@@ -219,6 +220,7 @@ class Device:
         return None
 
     def upload_counts(self, kmers, counts, min_count=1, max_count=0xFFFFFFFF, both_strands=True):
+        self.both_strands = bool(both_strands)
         n = int(kmers.shape[0])
         self._check(self.L.pf_upload_counts(self.h, _ptr(kmers), _ptr(counts), n, min_count, max_count, int(both_strands)))
 
@@ -301,7 +303,19 @@ class Device:
             x = np.zeros(u1 - u0, dtype=np.uint8)
         else:
             s, m, x = out
-        st = self._check(self.L.pf_unitig_cov(self.h, u0, u1, _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
+        if getattr(self, "both_strands", True):
+            st = self._check(self.L.pf_unitig_cov(self.h, u0, u1, _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
+        else:  # database without canonical counting: the unitigs as stored
+            st = self._check(self.L.pf_unitig_cov_exact(self.h, u0, u1, 0, _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
+        return s, m, x, st
+
+    def unitig_cov_exact(self, reverse: bool, u0=0, u1=None):
+        """pf_unitig_cov_exact: every k-mer looked up as it reads in the given orientation"""
+        u1 = self.n if u1 is None else u1
+        s = np.zeros(u1 - u0, dtype=np.uint64)
+        m = np.zeros(u1 - u0, dtype=np.uint32)
+        x = np.zeros(u1 - u0, dtype=np.uint8)
+        st = self._check(self.L.pf_unitig_cov_exact(self.h, u0, u1, int(reverse), _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
         return s, m, x, st
 
     def count_candidates(self, u0=0, u1=None) -> int:

@@ -149,6 +149,25 @@ def synth_counts(kmers: np.ndarray, mult: np.ndarray, depth: int = 20, jitter: i
     return np.maximum(c, 1).astype(np.uint32)
 
 
+def revcomp_u64(kmers: np.ndarray, k: int) -> np.ndarray:
+    """reverse complement of 2-bit packed k-mers (first base most significant)"""
+    x = ~kmers.astype(np.uint64) & np.uint64((1 << (2 * k)) - 1)
+    out = np.zeros_like(x)
+    for _ in range(k):
+        out = (out << np.uint64(2)) | (x & np.uint64(3))
+        x = x >> np.uint64(2)
+    return out
+
+
+def stranded_counts(kmers: np.ndarray, mult: np.ndarray, k: int, depth: int = 20, jitter: int = 3):
+    """A database counted without canonical merging (kmc -b): every k-mer in both orientations, each with its own count
+    (multiplicity * depth/2 plus a jitter that depends on the oriented k-mer).  Returns (sorted distinct k-mers, counts)."""
+    both = np.concatenate([kmers, revcomp_u64(kmers, k)])
+    m = np.concatenate([mult, mult])
+    both, idx = np.unique(both, return_index=True)
+    return both, synth_counts(both, m[idx], depth=max(1, depth // 2), jitter=jitter)
+
+
 # --------------------------------------------------------------------------
 # KMC1 database writer
 # --------------------------------------------------------------------------

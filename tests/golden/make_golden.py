@@ -124,6 +124,9 @@ CASES = {
     "giant7k": (lambda: synth.make_haplotypes(synth.HapSpec(270000, 4, seed=5, gap_lo=15, gap_hi=300),
                                               lambda b: np.concatenate([b[:21600], b[10800:10832], b[21632:]])), 25,
                 ["-l", "5", "-u", "1000"]),
+    # the count database written without canonical counting (kmc -b): coverage per orientation, no site-string coverage
+    "stranded20k": (lambda: synth.make_haplotypes(synth.HapSpec(24000, 3, seed=43, gap_lo=10, gap_hi=200, p_multi=0.05)), 25,
+                    ["-l", "2", "-u", "1000"], "kmc1_stranded"),
     "crowd25": (lambda: synth.make_haplotypes(synth.HapSpec(24000, 4, seed=4, gap_lo=8, gap_hi=150, p_multi=0.05),
                                               lambda b: synth.plant_crowded_minimizer(np.random.default_rng(41), b, 17, 100)), 25,
                 ["-l", "5", "-u", "1000"], "kmc1", "haps", "abundant"),
@@ -201,7 +204,10 @@ def make_case(name: str) -> None:
         shutil.copy(os.path.join(tmp, "graph.gfa"), os.path.join(out, "graph.gfa"))
         km, mult = synth.canonical_counts(haps, k)
         cnt = mult.astype(np.uint32) if from_reads else synth.synth_counts(km, mult)
-        if layout == "kmc2":
+        if layout == "kmc1_stranded":
+            skm, scnt = synth.stranded_counts(km, mult, k)
+            synth.write_kmc1(os.path.join(out, "db"), skm, scnt, k, both_strands=False)
+        elif layout == "kmc2":
             synth.write_kmc2(os.path.join(out, "db"), km, cnt, k, sig_len=7, n_bins=11)
         else:
             synth.write_kmc1(os.path.join(out, "db"), km, cnt, k)

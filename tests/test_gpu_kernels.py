@@ -80,7 +80,7 @@ def test_count_range_filter():
     assert np.array_equal(c[inside], counts[inside])
 
 
-@pytest.mark.parametrize("case", golden_cases())
+@pytest.mark.parametrize("case", [c for c in golden_cases() if load_case(c).get("kmc_layout") != "kmc1_stranded"])
 def test_lookup_both_orientations(case):
     meta, o, dev, _ = setup_case(case)
     kmers, counts, km = synth.read_kmc(meta["db"])
@@ -368,3 +368,26 @@ def test_minimizer_census_on_graphs_built_to_crowd_buckets(tmp_path):
             mx, crowded, table, host, _ = _minz_tables(gfa)
             assert np.all(table >= host), name
             assert mx >= 15 or host.max() < 15, name
+
+
+def test_database_without_canonical_counting_is_read_per_orientation():
+    """stranded20k: every k-mer stored in both orientations with different counts (kmc -b).  readCov(UnitigMap) looks the
+    mapped sequence up as it reads (src/CDBG.cpp:94-117), readCov(string) returns (0, true) without a lookup (:34, :59)."""
+    import ctypes as C
+    meta, o, dev, seqs = setup_case("stranded20k")
+    assert dev.both_strands is False
+    o.L.pfo_unitig_cov_oriented.argtypes = [C.c_void_p, C.c_uint32, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    for rev in (False, True):
+        s, m, miss, st = dev.unitig_cov_exact(rev)
+        assert st == hipapi.PF_OK and not miss.any()
+        for u in range(dev.n):
+            es, em = C.c_uint64(), C.c_uint32()
+            assert o.L.pfo_unitig_cov_oriented(o.h, 2 * u + int(rev), C.byref(es), C.byref(em)) == 0
+            assert (int(s[u]), min(int(m[u]), 10000)) == (es.value, min(em.value, 10000)), (u, rev)
+    fwd, rev = dev.unitig_cov_exact(False)[0], dev.unitig_cov_exact(True)[0]
+    assert (fwd != rev).any()
+    with pytest.raises(hipapi.DeviceError):   # the composite lookup of canonical databases does not apply to this table
+        s0, m0, x0 = np.zeros(dev.n, dtype=np.uint64), np.zeros(dev.n, dtype=np.uint32), np.zeros(dev.n, dtype=np.uint8)
+        dev._check(dev.L.pf_unitig_cov(dev.h, 0, dev.n, s0.ctypes.data, m0.ctypes.data, x0.ctypes.data))
+    ssum, ok, smiss = dev.string_cov([seqs[0][:40], seqs[1][:30]], 5, 1000)
+    assert list(ssum) == [0, 0] and list(ok) == [1, 1] and not smiss.any()
