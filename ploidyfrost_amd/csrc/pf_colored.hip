@@ -117,7 +117,7 @@ __global__ void k_ctab_two_strands(const uint8_t *base, uint64_t cap, uint32_t s
 // out_*[c * n + (u - u0)], n = u1 - u0.
 __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                      const uint32_t *__restrict__ len, int k, bool one_strand, uint32_t n_colors,
-                                                     uint32_t u0, uint32_t u1, uint64_t *__restrict__ out_sum,
+                                                     uint32_t u0, uint32_t u1, uint64_t unread, uint64_t *__restrict__ out_sum,
                                                      uint32_t *__restrict__ out_min, uint32_t *__restrict__ out_max,
                                                      uint8_t *__restrict__ out_miss) {
     const int lane = lane_id();
@@ -154,10 +154,13 @@ __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__r
                 const bool any_miss = __ballot(miss[j]) != 0;
                 if (lane == 0) {
                     const size_t o = (size_t)(c0 + j) * n + (u - u0);
-                    out_sum[o] = s;
-                    out_min[o] = lo;
-                    out_max[o] = hi;
-                    out_miss[o] = any_miss;
+                    // a colour whose database was written without canonical counting is never looked up: readCovUni returns
+                    // (0, true) for it (src/CCDBG.cpp:128, 155) -- sum 0, nothing missing, every count "inside" any cutoffs
+                    const bool skip = (unread >> (c0 + j)) & 1;
+                    out_sum[o] = skip ? 0 : s;
+                    out_min[o] = skip ? MISSING : lo;
+                    out_max[o] = skip ? 0 : hi;
+                    out_miss[o] = skip ? 0 : any_miss;
                 }
             }
         }
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__r
 }
 
 // K-STRCOV-C: one thread per (string, colour); out_*[i * n_colors + c]
-__global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colors, const char *__restrict__ text,
+__global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colors, uint64_t unread, const char *__restrict__ text,
                                  const uint64_t *__restrict__ str_off, uint32_t n_str, const uint32_t *__restrict__ low,
                                  const uint32_t *__restrict__ up, uint64_t *__restrict__ out_sum, uint8_t *__restrict__ out_ok) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -179,6 +182,11 @@ __global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colo
         const uint32_t lo = low[c], hi = up[c];
         uint64_t sum = 0, x = 0;
         uint8_t ok = 1;
+        if ((unread >> c) & 1) {  // readCov(s, low, up, c) without canonical counting: (0, true), no lookup (src/CCDBG.cpp:94, 121)
+            out_sum[id] = 0;
+            out_ok[id] = 1;
+            continue;
+        }
         for (uint32_t j = 0; j < L; ++j) {
             const char ch = s[j];
             const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
@@ -216,14 +224,14 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
     if (n_colors > PF_MAX_COLORS) { ctx->err = "more colours than the device table holds (PF_MAX_COLORS)"; return PF_ERR_ARG; }
     uint64_t total = 0, biggest = 0;
     for (uint32_t c = 0; c < n_colors; ++c) {
-        if (!both_strands[c]) {
-            ctx->err = "databases built without canonical counting (GetBothStrands() == false) are not supported";
-            return PF_ERR_ARG;
-        }
         if (n[c] && (!kmers[c] || !counts[c])) return PF_ERR_ARG;
+        if (!both_strands[c]) continue;   // never looked up (src/CCDBG.cpp:94, 128): its records stay out of the table
         total += n[c];
         biggest = std::max(biggest, n[c]);
     }
+    ctx->ctab_unread = 0;
+    for (uint32_t c = 0; c < n_colors; ++c)
+        if (!both_strands[c]) ctx->ctab_unread |= 1ull << c;
     PF_HIP(hipSetDevice(ctx->device));
     if (ctx->d_ctab) { (void)hipFree(ctx->d_ctab); ctx->d_ctab = nullptr; }
     ctx->n_colors = 0;
@@ -238,7 +246,7 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
     ctx->ctab_cap = cap;
     ctx->ctab_shift = shift;
     for (uint32_t c = 0; c < n_colors; ++c) {
-        if (!n[c]) continue;
+        if (!n[c] || !both_strands[c]) continue;
         DevTmp<uint64_t> dk_;
         DevTmp<uint32_t> dc_;
         const uint64_t *pk = kmers[c];
@@ -292,7 +300,7 @@ int pf_unitig_cov_colored(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, 
     const int grid = ctx_grid(ctx, (uint64_t)(u1 - u0) * 64, 256, 16);
     ctx_begin(ctx, PF_K_COV_COLORED);
     k_cov_colored<<<grid, 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand, ctx->n_colors, u0, u1,
-                                                 ds, dlo, dhi, dx);
+                                                 ctx->ctab_unread, ds, dlo, dhi, dx);
     ctx_end(ctx);
     if (!dev_out) {
         PF_HIP(hipMemcpyAsync(sum, ds, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -324,7 +332,7 @@ int pf_string_cov_colored(pf_ctx *ctx, const char *text, const uint64_t *str_off
     PF_HIP(hipMemcpyAsync(dcut + C, up, (size_t)C * 4, hipMemcpyDefault, ctx->stream));
     const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
     ctx_begin(ctx, PF_K_STRCOV_COLORED);
-    k_strcov_colored<<<ctx_grid(ctx, (uint64_t)n_str * C, 256, 8), 256, 0, ctx->stream>>>(t, ctx->k, ctx->ctab_one_strand, C, dt, doff, n_str,
+    k_strcov_colored<<<ctx_grid(ctx, (uint64_t)n_str * C, 256, 8), 256, 0, ctx->stream>>>(t, ctx->k, ctx->ctab_one_strand, C, ctx->ctab_unread, dt, doff, n_str,
                                                                                           dcut, dcut + C, ds, dk);
     ctx_end(ctx);
     PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n_str * C * 8, hipMemcpyDefault, ctx->stream));

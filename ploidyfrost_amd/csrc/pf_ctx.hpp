@@ -64,6 +64,7 @@ struct pf_ctx {
     uint64_t ctab_cap = 0;
     uint32_t ctab_shift = 4, n_colors = 0;
     bool ctab_one_strand = false;
+    uint64_t ctab_unread = 0;   // colours whose database was written without canonical counting: never looked up
 
     // reusable result staging for host-pointer callers
     uint64_t *d_cov_sum = nullptr;

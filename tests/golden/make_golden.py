@@ -178,6 +178,8 @@ COLORED_CASES = {
     "col3_dip": (col3_dip, 25, [], [(5, 1000)] * 3),
     "col4_mix": (col4_mix, 25, ["-z", "10"], [(5, 1000), (5, 1000), (25, 70), (5, 1000)]),
     "col2_weird": (col2_weird, 31, ["-M", "1.5", "-D", "-0.5", "-G", "-2.25"], [(5, 1000), (10, 400)]),
+    # the second sample's database written without canonical counting: that colour is never looked up and counts as coverage 0
+    "col3_stranded": (col3_dip, 25, [], [(5, 1000)] * 3, {1}),
 }
 
 
@@ -227,7 +229,8 @@ def make_case(name: str) -> None:
 
 
 def make_colored_case(name: str) -> None:
-    factory, k, args, cutoffs = COLORED_CASES[name]
+    factory, k, args, cutoffs = COLORED_CASES[name][:4]
+    stranded = COLORED_CASES[name][4] if len(COLORED_CASES[name]) > 4 else set()
     out = os.path.join(HERE, name)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(os.path.join(out, "expected"))
@@ -239,7 +242,11 @@ def make_colored_case(name: str) -> None:
             synth.write_fasta(fa, hs)
             fas.append(fa)
             km, mult = synth.canonical_counts(hs, k)
-            synth.write_kmc1(os.path.join(out, "db%d" % i), km, synth.synth_counts(km, mult), k)
+            if i in stranded:
+                skm, scnt = synth.stranded_counts(km, mult, k)
+                synth.write_kmc1(os.path.join(out, "db%d" % i), skm, scnt, k, both_strands=False)
+            else:
+                synth.write_kmc1(os.path.join(out, "db%d" % i), km, synth.synth_counts(km, mult), k)
         with open(os.path.join(tmp, "refs.txt"), "w") as f:
             f.write("".join(p + "\n" for p in fas))
         run([os.path.join(REF, "Bifrost"), "build", "-c", "-r", os.path.join(tmp, "refs.txt"), "-k", str(k), "-o",
