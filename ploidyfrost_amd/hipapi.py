@@ -256,17 +256,17 @@ class Device:
         return c, f
 
     def upload_counts_colored(self, dbs, min_count=1, max_count=0xFFFFFFFF):
-        """dbs: list of (kmers u64, counts u32) per colour -> one joined table (pf_upload_counts_colored)."""
+        """dbs: list of (kmers u64, counts u32[, both_strands]) per colour -> one joined table (pf_upload_counts_colored)."""
         nc = len(dbs)
         self.n_colors = nc
-        km = [np.ascontiguousarray(k, dtype=np.uint64) for k, _ in dbs]
-        ct = [np.ascontiguousarray(c, dtype=np.uint32) for _, c in dbs]
+        km = [np.ascontiguousarray(d[0], dtype=np.uint64) for d in dbs]
+        ct = [np.ascontiguousarray(d[1], dtype=np.uint32) for d in dbs]
         pk = (C.c_void_p * nc)(*[a.ctypes.data for a in km])
         pc = (C.c_void_p * nc)(*[a.ctypes.data for a in ct])
         n = np.array([len(a) for a in km], dtype=np.uint64)
         mn = np.full(nc, min_count, dtype=np.uint64)
         mx = np.full(nc, max_count, dtype=np.uint64)
-        both = np.ones(nc, dtype=np.int32)
+        both = np.array([int(d[2]) if len(d) > 2 else 1 for d in dbs], dtype=np.int32)
         self._check(self.L.pf_upload_counts_colored(self.h, nc, pk, pc, n.ctypes.data, mn.ctypes.data, mx.ctypes.data, both.ctypes.data))
 
     def unitig_cov_colored(self, u0=0, u1=None):

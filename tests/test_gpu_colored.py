@@ -26,8 +26,8 @@ def _device_with_colours(meta):
     dev.upload_graph(words, off, lens, o.k)
     dbs = []
     for p in meta["dbs"]:
-        km, cnt, _ = synth.read_kmc(p)
-        dbs.append((km, cnt))
+        km, cnt, hdr = synth.read_kmc(p)
+        dbs.append((km, cnt, hdr["both_strands"]))
     dev.upload_counts_colored(dbs)
     return o, dev, seqs, dbs
 
