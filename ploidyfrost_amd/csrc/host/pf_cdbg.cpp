@@ -18,21 +18,9 @@
 
 #include "pf_cdbg_impl.hpp"
 #include "pf_parallel.hpp"
+#include "pf_trace.hpp"
 
 namespace pfh {
-
-namespace {
-struct LoadTrace {  // PF_TRACE_LOAD=1: where construction spends its time, on stderr
-    bool on = getenv("PF_TRACE_LOAD") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void mark(const char *what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[load] %-28s %.3fs\n", what, std::chrono::duration<double>(now - t).count());
-        t = now;
-    }
-};
-}  // namespace
 
 int CDBG::init_device(int device) {
     LoadTrace trace;

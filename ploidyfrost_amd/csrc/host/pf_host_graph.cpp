@@ -1,6 +1,7 @@
 #include "pf_host_graph.hpp"
 #include "pf_host_minz.hpp"
 #include "pf_parallel.hpp"
+#include "pf_trace.hpp"
 
 #include <fcntl.h>
 #include <sys/mman.h>
@@ -65,19 +66,6 @@ void UnitigSet::append_mapped(uint32_t ov, std::string &dst) const {
         }
     }
 }
-
-namespace {
-struct LoadTrace {  // PF_TRACE_LOAD=1: where the loader spends its time, on stderr
-    bool on = getenv("PF_TRACE_LOAD") != nullptr;
-    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
-    void mark(const char *what) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[load] %-28s %.3fs\n", what, std::chrono::duration<double>(now - t).count());
-        t = now;
-    }
-};
-}  // namespace
 
 bool UnitigSet::load_gfa(const std::string &path, std::string &err, bool defer_numbering) {
     LoadTrace trace;
