@@ -200,6 +200,10 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per rank (0 = min(32, cpus/ranks))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep", action="store_true")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="weak (default, the driver's contract): every rank its own graph of --unitigs unitigs; strong: ONE graph of "
+                         "--unitigs unitigs on all ranks, findSuperBubble on every rank, PloidyEstimation cut into slices of the bubble "
+                         "list (SURVEY.md 8e), rank 0 joins the ranks' files")
     ap.add_argument("--workload", choices=["single", "colored"], default="single",
                     help="single = the headline metric (BASELINE.json configs[1]); colored = the CCDBG path on 3 diploid "
                          "samples (configs[3]), same JSON line with config.workload saying so")
@@ -227,7 +231,8 @@ def main():
         genome = int(args.unitigs / UNITIGS_PER_BP)
         colored = args.workload == "colored"
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
-        seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + rank
+        strong = args.scaling == "strong" and world > 1
+        seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + (0 if strong else rank)
         if colored:
             n_samples = 3
             gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(workdir, "graph", genome, seed, dev, samples=n_samples)
@@ -245,6 +250,11 @@ def main():
         if os.environ.get("PF_BATCH_BUBBLES"):  # experiments: bubbles per batch of the align/format pipeline
             run.set_batch_bubbles(int(os.environ["PF_BATCH_BUBBLES"]))
         run.set_output_dir(os.path.join(workdir, "PloidyFrost_output"))
+        if strong:
+            run.set_partition(rank, world)
+            # the ranks' result directories, known to rank 0 (one node, one file system), which joins them after every pass
+            dirs = [None] * world
+            dist.all_gather_object(dirs, os.path.join(workdir, "PloidyFrost_output"))
         run.set_unitig_id("b")
         log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, time.time() - t0, torch.cuda.get_device_name(gpu_index)))
         L = hipapi.load_library()
@@ -265,6 +275,17 @@ def main():
                 pfdist.all_gather_counters(tt_["allele"] + [tt_["tasks"]], xdev)
                 slabs = pfdist.all_gather_slabs(run.last_allele_frequency(), xdev)
                 gathered_bytes[0] = sum(int(x.size) for x in slabs)
+                if strong and rank == 0:
+                    # rank-order concatenation of the slices = the reference's files (Unitig_Id / super_bubble: rank 0's own)
+                    final = os.path.join(workdir, "joined")
+                    os.makedirs(final, exist_ok=True)
+                    for suf in ("alignseq", "allele_frequency", "bicov", "bifre", "tricov", "trifre", "tetracov", "tetrafre", "pentacov", "pentafre"):
+                        with open(os.path.join(final, "b_%s.txt" % suf), "wb") as fo:
+                            for d in dirs:
+                                with open(os.path.join(d, "b_%s.txt" % suf), "rb") as fi:
+                                    n_left = os.fstat(fi.fileno()).st_size
+                                    while n_left > 0:
+                                        n_left -= os.sendfile(fo.fileno(), fi.fileno(), None, n_left)
 
         for _ in range(args.warmup):
             step()
@@ -298,7 +319,7 @@ def main():
         allstats = pfdist.all_gather_counters([n_unitigs, tt["superbubbles"], tt["tasks"], tt["output_bytes"]] + tt["allele"] +
                                               [int(elapsed * 1e6)], xdev)
         max_elapsed = allstats[:, -1].max() / 1e6
-        total_unitigs = int(allstats[:, 0].sum())
+        total_unitigs = int(allstats[0, 0]) if strong else int(allstats[:, 0].sum())
 
         if rank == 0:
             value = total_unitigs * args.steps / max_elapsed
@@ -337,15 +358,18 @@ def main():
             out = {
                 "metric": "unitigs/s through superbubble+SeqAlign (k=25, z=8)",
                 "value": round(value, 1), "unit": "unitigs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(max_elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak",
+                "ms_per_step": round(max_elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": ("colored graph of 3 synthetic diploid samples (CCDBG path, configs[3]), %d unitigs/GPU, k=25 z=8, "
                                         "cutoffs %d/%d per sample, M=2 D=-1 G=-3" if colored else
                                         "single-sample synthetic tetraploid graph, %d unitigs/GPU (config[1] = 1 M), k=25 z=8, "
                                         "-l %d -u %d, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER),
                            "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
-                           "partitioning": "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
-                                           "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0]},
+                           "partitioning": ("one graph on every rank, findSuperBubble replicated, PloidyEstimation in contiguous slices of the "
+                                            "bubble list, rank 0 joins the files; per-pass all-gather of counters and allele-frequency slabs "
+                                            "(%d bytes)" if strong else
+                                            "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
+                                            "and allele-frequency record slabs (%d bytes)") % gathered_bytes[0]},
                 "roofline": roof, "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "kernels": kernels,
                 "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},

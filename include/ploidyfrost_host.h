@@ -45,6 +45,10 @@ void pfh_set_overlap_output(pfh_run *, int on);      /* 1: <outpre>_super_bubble
 /* K-BFS traversals beyond 4096 vertices: on host cores (default, pf_bfs_candidates_split + host/pf_bfs_host.cpp: one thread per
  * traversal) or, with on = 0, on the device (k_bfs_huge: one wavefront per traversal).  Same records either way. */
 void pfh_set_third_tier_on_host(pfh_run *, int on);
+/* One graph on `world` GPUs (every rank opens the same graph and databases): pfh_find_superbubbles runs whole on every rank,
+ * pfh_ploidy_estimation calls, numbers and writes only slice `rank` of the bubble list.  The result files of the run are the
+ * ranks' files concatenated in rank order (Unitig_Id and super_bubble: any rank's); pfh_get_times counters add up over ranks. */
+void pfh_set_partition(pfh_run *, uint32_t rank, uint32_t world);
 void pfh_set_batch_bubbles(pfh_run *, uint64_t n);   /* bubbles per batch of the align/format pipeline (default 65536) */
 int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);

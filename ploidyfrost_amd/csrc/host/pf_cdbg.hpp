@@ -69,8 +69,13 @@ public:
     // extras (not in the reference interface)
     void set_output_dir(const std::string &dir) { outdir_ = dir; }  // default "PloidyFrost_output"
     void set_quiet(bool q) { quiet_ = q; }
-    void set_threads(unsigned t) { threads_ = t; }
-    void set_third_tier_on_host(bool on) { third_tier_on_host_ = on; }   // default on; off = one wavefront per giant traversal                  // host threads; 0 = use the `thr` argument
+    void set_threads(unsigned t) { threads_ = t; }                  // host threads; 0 = use the `thr` argument
+    void set_third_tier_on_host(bool on) { third_tier_on_host_ = on; }   // default on; off = one wavefront per giant traversal
+    // One graph on several GPUs: every rank holds the whole graph and runs findSuperBubble itself (the
+    // commit replay is sequential and cheap); PloidyEstimation is cut into `world` contiguous slices of the bubble list
+    // -- the reference's output order -- and rank r calls, numbers (var_count continues where slice r-1 ends) and writes
+    // slice r only.  The files of the whole run are the ranks' files concatenated in rank order; counters add up.
+    void set_partition(unsigned rank, unsigned world) { part_rank_ = world ? rank % world : 0; part_world_ = world ? world : 1; }
     void set_write_files(bool w) { write_files_ = w; }              // bench: format but do not touch the disk
     void set_batch_bubbles(size_t n) { batch_bubbles_ = n; }
     // write <outpre>_super_bubble.txt in the background while PloidyEstimation runs (complete when that call, the next
@@ -132,6 +137,7 @@ protected:
     bool quiet_ = false, write_files_ = true;
     bool both_strands_ = true;
     unsigned threads_ = 0;
+    unsigned part_rank_ = 0, part_world_ = 1;
     // third K-BFS tier (traversals beyond 4096 vertices) on host cores, pf_bfs_host.hpp; false = the device's k_bfs_huge
     bool third_tier_on_host_ = true;
     std::vector<std::unique_ptr<HugeWalker>> walkers_;

@@ -444,6 +444,49 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             std::vector<SideRec>().swap(side_chunks[ci]);
         });
     }
+    if (part_world_ > 1) {
+        // this rank's slice of the bubble list; var_count starts at the number of bubbles before it that get aligned
+        // at all: a strict bubble kept by the scan always is, a branching one when it has at least two s->t paths
+        const size_t total = all_tasks.size();
+        const size_t t_lo = total * part_rank_ / part_world_, t_hi = total * (part_rank_ + 1) / part_world_;
+        std::vector<uint64_t> part(n_chunks_of(t_lo, 4096), 0);
+        parallel_chunks(t_lo, 4096, T, [&](size_t ci, size_t tb, size_t te) {
+            std::vector<uint32_t> major, minor;
+            uint64_t n = 0;
+            for (size_t ti = tb; ti < te; ++ti) {
+                const Task &t = all_tasks[ti];
+                if (t.strict) { n += t.n_inner >= 2; continue; }
+                const uint32_t eu = t.exit_ov >> 1;   // the two-stack walk of src/CDBG.cpp:1364-1412, counting arrivals only
+                uint32_t paths = 0;
+                major.clear();
+                minor.clear();
+                minor.push_back(t.entrance_ov);
+                while (!minor.empty() && paths < 2) {
+                    const uint32_t w = minor.back();
+                    minor.pop_back();
+                    major.push_back(w);
+                    if ((w >> 1) == eu) {
+                        ++paths;
+                        major.pop_back();
+                        while (!major.empty() && !minor.empty()) {
+                            const uint32_t *r = succ_row(major.back());
+                            if (r[0] == minor.back() || r[1] == minor.back() || r[2] == minor.back() || r[3] == minor.back()) break;
+                            major.pop_back();
+                        }
+                    } else {
+                        const uint32_t *r = succ_row(w);
+                        for (int b = 0; b < 4; ++b)
+                            if (r[b] != NONE) minor.push_back(r[b]);
+                    }
+                }
+                n += paths >= 2;
+            }
+            part[ci] = n;
+        });
+        for (uint64_t n : part) var_count += n;
+        std::vector<Task> mine(all_tasks.begin() + (ptrdiff_t)t_lo, all_tasks.begin() + (ptrdiff_t)t_hi);
+        all_tasks.swap(mine);
+    }
     times_.scan_s += since(t0);
     tp("scan done");
 

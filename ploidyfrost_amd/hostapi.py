@@ -23,7 +23,7 @@ class Times(C.Structure):
 
 
 _lib = None
-DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_unitig_id",
+DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_partition", "pfh_set_unitig_id",
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
@@ -52,6 +52,7 @@ def load_library() -> C.CDLL:
     L.pfh_set_batch_bubbles.argtypes = [vp, C.c_uint64]
     L.pfh_set_overlap_output.argtypes = [vp, C.c_int]
     L.pfh_set_third_tier_on_host.argtypes = [vp, C.c_int]
+    L.pfh_set_partition.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.pfh_set_unitig_id.argtypes = [vp, C.c_char_p]
     L.pfh_find_superbubbles.argtypes = [vp, C.c_char_p]
     L.pfh_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
@@ -162,6 +163,10 @@ class Run:
 
     def set_third_tier_on_host(self, on: bool):
         self.L.pfh_set_third_tier_on_host(self.h, int(on))
+
+    def set_partition(self, rank: int, world: int):
+        """one graph on `world` GPUs: this run handles slice `rank` of the bubble list in ploidy_estimation"""
+        self.L.pfh_set_partition(self.h, rank, world)
 
     def set_batch_bubbles(self, n: int):
         self.L.pfh_set_batch_bubbles(self.h, n)

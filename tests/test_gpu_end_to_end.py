@@ -150,3 +150,45 @@ def test_third_tier_on_host_and_on_device_agree_with_the_oracle(tmp_path):
         assert t["superbubbles"] == nb and t["bfs_large"] >= 1, t
         run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
         assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(d)), on_host
+
+
+def _merge_parts(parts, merged):
+    """the files of a partitioned run: every rank's files concatenated in rank order (Unitig_Id, super_bubble: rank 0's)"""
+    os.makedirs(merged, exist_ok=True)
+    from conftest import OUTPUT_SUFFIXES
+    for suf in OUTPUT_SUFFIXES:
+        with open(os.path.join(merged, "g_%s.txt" % suf), "wb") as out:
+            for d in (parts[:1] if suf in ("Unitig_Id", "super_bubble") else parts):
+                with open(os.path.join(d, "g_%s.txt" % suf), "rb") as f:
+                    out.write(f.read())
+
+
+@pytest.mark.parametrize("case,world", [("tet60k", 2), ("hex30k", 3), ("weird12k", 5), ("k31_z16", 4), ("giant7k", 2), ("stranded20k", 3)])
+def test_one_graph_partitioned_over_ranks(case, world, tmp_path):
+    """the whole graph on every rank, PloidyEstimation cut into contiguous slices of the bubble list; rank-order
+    concatenation of the ranks' files is the reference's output, var_count included, and the counters add up."""
+    meta = load_case(case)
+    op = meta["opts"]
+    parts, allele, tasks = [], np.zeros(4, dtype=np.int64), 0
+    for rank in range(world):
+        d = str(tmp_path / ("rank%d" % rank))
+        run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+        run.set_partition(rank, world)
+        run.set_threads(3)
+        run.set_output_dir(d)
+        run.set_unitig_id("g")
+        run.find_superbubbles("g")
+        run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+        t = run.times()
+        allele += np.array(t["allele"], dtype=np.int64)
+        tasks += t["tasks"]
+        parts.append(d)
+    _merge_parts(parts, str(tmp_path / "merged"))
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path / "merged"))
+    whole = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    whole.set_output_dir(str(tmp_path / "whole"))
+    whole.set_unitig_id("g")
+    whole.find_superbubbles("g")
+    whole.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+    tw = whole.times()
+    assert list(allele) == tw["allele"] and tasks == tw["tasks"]
