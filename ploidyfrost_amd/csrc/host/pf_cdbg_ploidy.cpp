@@ -444,48 +444,15 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             std::vector<SideRec>().swap(side_chunks[ci]);
         });
     }
+    // One graph over several ranks: this rank formats and writes only its contiguous slice [skip_before, size) of the
+    // bubble list.  var_count continues where the previous slice ends, and whether a bubble counts is known only once it
+    // was aligned (SequenceAlignment may leave no rows, src/CDBG.cpp:1254, 1423), so the bubbles ahead of the slice go
+    // through the device stages as well -- in batches that are counted, not formatted.
+    size_t skip_before = 0;
     if (part_world_ > 1) {
-        // this rank's slice of the bubble list; var_count starts at the number of bubbles before it that get aligned
-        // at all: a strict bubble kept by the scan always is, a branching one when it has at least two s->t paths
         const size_t total = all_tasks.size();
-        const size_t t_lo = total * part_rank_ / part_world_, t_hi = total * (part_rank_ + 1) / part_world_;
-        std::vector<uint64_t> part(n_chunks_of(t_lo, 4096), 0);
-        parallel_chunks(t_lo, 4096, T, [&](size_t ci, size_t tb, size_t te) {
-            std::vector<uint32_t> major, minor;
-            uint64_t n = 0;
-            for (size_t ti = tb; ti < te; ++ti) {
-                const Task &t = all_tasks[ti];
-                if (t.strict) { n += t.n_inner >= 2; continue; }
-                const uint32_t eu = t.exit_ov >> 1;   // the two-stack walk of src/CDBG.cpp:1364-1412, counting arrivals only
-                uint32_t paths = 0;
-                major.clear();
-                minor.clear();
-                minor.push_back(t.entrance_ov);
-                while (!minor.empty() && paths < 2) {
-                    const uint32_t w = minor.back();
-                    minor.pop_back();
-                    major.push_back(w);
-                    if ((w >> 1) == eu) {
-                        ++paths;
-                        major.pop_back();
-                        while (!major.empty() && !minor.empty()) {
-                            const uint32_t *r = succ_row(major.back());
-                            if (r[0] == minor.back() || r[1] == minor.back() || r[2] == minor.back() || r[3] == minor.back()) break;
-                            major.pop_back();
-                        }
-                    } else {
-                        const uint32_t *r = succ_row(w);
-                        for (int b = 0; b < 4; ++b)
-                            if (r[b] != NONE) minor.push_back(r[b]);
-                    }
-                }
-                n += paths >= 2;
-            }
-            part[ci] = n;
-        });
-        for (uint64_t n : part) var_count += n;
-        std::vector<Task> mine(all_tasks.begin() + (ptrdiff_t)t_lo, all_tasks.begin() + (ptrdiff_t)t_hi);
-        all_tasks.swap(mine);
+        skip_before = total * part_rank_ / part_world_;
+        all_tasks.resize(total * (part_rank_ + 1) / part_world_);
     }
     times_.scan_s += since(t0);
     tp("scan done");
@@ -533,6 +500,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         uint32_t n_dev = 0;
         double tasks_s = 0, align_s = 0;
         uint64_t text_len = 0, n_paths = 0;
+        bool count_only = false;   // a batch ahead of this rank's slice: aligned for var_count only
         int st = PF_OK;
         std::string err;
     };
@@ -891,6 +859,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             if (result_of(ti).n_rows) ++var_count;
             vc[ti] = var_count;
         }
+        if (B.count_only) return PF_OK;
         all_outs.emplace_back(n_pch);
         std::vector<ChunkOut> &outs = all_outs.back();
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
@@ -1123,12 +1092,17 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
 
     {
         constexpr size_t kRing = 3;  // sets of exchange buffers = batches in flight
-        const size_t n_batches = (all_tasks.size() + CHUNK - 1) / CHUNK;
+        std::vector<std::pair<size_t, size_t>> cuts;  // (first bubble, bubbles); the slice boundary is a batch boundary
+        for (size_t at = 0; at < skip_before; at += CHUNK) cuts.emplace_back(at, std::min(CHUNK, skip_before - at));
+        const size_t n_counted = cuts.size();
+        for (size_t at = skip_before; at < all_tasks.size(); at += CHUNK) cuts.emplace_back(at, std::min(CHUNK, all_tasks.size() - at));
+        const size_t n_batches = cuts.size();
         all_outs.reserve(n_batches);  // the writer holds pointers to its elements
         std::vector<Batch> batches(n_batches);
         for (size_t b = 0; b < n_batches; ++b) {
-            batches[b].batch0 = b * CHUNK;
-            batches[b].NT = std::min(CHUNK, all_tasks.size() - b * CHUNK);
+            batches[b].batch0 = cuts[b].first;
+            batches[b].NT = cuts[b].second;
+            batches[b].count_only = b < n_counted;
             batches[b].ax = &ax_[b % kRing];
         }
         std::mutex mu;
@@ -1187,16 +1161,18 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 if (batches[b].st == PF_OK) batches[b].st = produce(batches[b]);
             }
             Batch &B = batches[b];
-            times_.tasks += B.NT;
+            if (!B.count_only) {  // counters are this rank's share: they add up over the ranks of a partitioned run
+                times_.tasks += B.NT;
+                times_.align_jobs += B.n_dev;
+                times_.site_strings += B.site_strings;
+            }
             times_.tasks_s += B.tasks_s;
             times_.align_s += B.align_s;
-            times_.align_jobs += B.n_dev;
             times_.sites_s += B.sites_s;
-            times_.site_strings += B.site_strings;
             if (B.st != PF_OK) { rc = B.st; rc_err = B.err; break; }
             rc = consume(B);
             tp("  batch consumed (format)");
-            if (rc == PF_OK) {
+            if (rc == PF_OK && !B.count_only) {
                 { std::lock_guard<std::mutex> lk(wmu); wqueue.push_back(&all_outs.back()); }
                 wcv.notify_all();
             }
