@@ -373,8 +373,11 @@ def main():
                 "roofline": roof, "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "kernels": kernels,
                 "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},
-                "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"], "bubbles_called": tt["tasks"],
-                           "align_jobs": tt["align_jobs"], "site_strings": tt["site_strings"], "sites": tt["allele"],
+                # rank 0's graph; for one graph over all ranks (strong) the per-slice counters are added up
+                "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"],
+                           "bubbles_called": int(allstats[:, 2].sum()) if strong else tt["tasks"],
+                           "align_jobs": tt["align_jobs"], "site_strings": tt["site_strings"],
+                           "sites": [int(x) for x in allstats[:, 4:8].sum(axis=0)] if strong else tt["allele"],
                            "output_bytes": tt["output_bytes"]},
             }
             if cpu:
