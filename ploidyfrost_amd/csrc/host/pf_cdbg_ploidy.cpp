@@ -655,6 +655,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         }
         if (st != PF_OK) { B.err = std::string(tag_) + "::PloidyEstimation(): alignment: " + pf_last_error(ctx_); return st; }
         B.align_s = since(t0);
+        if (B.count_only) return PF_OK;  // ahead of this rank's slice: only whether each alignment has rows matters
         auto result_of = [&](size_t ti) -> const pf_bubble_result & {
             return dev_index[ti] == NONE ? kNoResult : X.res.p[dev_index[ti]];
         };
