@@ -60,8 +60,12 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         s_nrec[i] = s_used[i] = 0;
     }
     // pinned, reused from pass to pass
+    const bool trace_find = getenv("PF_TRACE_FIND") != nullptr;
+    auto tf = [&](const char *what) { if (trace_find) fprintf(stderr, "[find] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
+    tf("candidates counted");
     bx_.bfs_rec.ensure(ctx_, s_rec0[kSlices]);
     bx_.bfs_pool.ensure(ctx_, s_pool0[kSlices]);
+    tf("pinned record buffers");
     pf_bfs_record *rec = bx_.bfs_rec.p;
     // a slice whose pool guess was too small gets a buffer of its own
     std::vector<std::unique_ptr<PinnedBuf<uint32_t>>> own_pool(kSlices);
@@ -185,7 +189,9 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         }
         replay_s += since(tr);
     }
+    tf("replay done");
     device.join();
+    tf("device thread joined");
     if (st != PF_OK || dev_st != PF_OK) return fail(dev_st != PF_OK ? dev_st : st, std::string("CDBG::findSuperBubble(): ") + dev_err);
     times_.bfs_device_s = bfs_s;
     times_.candidates = n_rec_total;
@@ -257,6 +263,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     }
     times_.bubble_write_s = since(t0);
     times_.find_total_s = since(t_all);
+    tf("super_bubble rows done");
     if (!quiet_) printf("%s::findSuperBubble(): %llu  SuperBubbles Found\n", tag_, (unsigned long long)nb);
     return 0;
 }
