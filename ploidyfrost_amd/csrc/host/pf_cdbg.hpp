@@ -142,6 +142,7 @@ protected:
     bool third_tier_on_host_ = true;
     std::vector<std::unique_ptr<HugeWalker>> walkers_;
     std::mutex walkers_mu_;
+    std::vector<uint32_t> deferred_;   // record indices pf_bfs_candidates_split leaves to the host walkers
     // vertex lists of the records walked on the host (pf_bfs_record::pad_ == 1, list_off = index), per K-BFS slice: a slice's
     // lists are complete before its records are handed to the replay
     std::vector<std::vector<uint32_t>> huge_lists_[4];

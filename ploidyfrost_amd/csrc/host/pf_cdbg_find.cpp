@@ -82,7 +82,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // host walkers of the long traversals: each keeps 8 bytes of state per unitig, at most ~4 GiB of it in total
     const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
     std::thread device([&] {
-        std::vector<uint32_t> deferred;
+        std::vector<uint32_t> &deferred = deferred_;   // keeps its size from pass to pass
         for (int i = 0; i < kSlices; ++i) {
             const auto tb = clk::now();
             uint32_t *pl = bx_.bfs_pool.p + s_pool0[i];
