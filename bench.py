@@ -174,7 +174,9 @@ def cpu_model() -> str:
 
 # algorithmic HBM bytes per launch (restated in DESIGN.md)
 def algorithmic_bytes(kernel: str, t: dict) -> float | None:
-    if kernel == "k_cov":
+    if kernel == "k_cov":  # streaming form: 4 B count + 1 head bit per k-mer, 4 B row id per 64 k-mers, 16 B of results per unitig
+        return (4.0 + 1.0 / 8 + 4.0 / 64) * t["kmers"] + 16.0 * t["unitigs"]
+    if kernel in ("k_cov_probe", "k_cov_join"):  # 0.25 B sequence + 12 B table slot per k-mer (+ 4 B joined count / 16 B result)
         return 12.25 * t["kmers"] + 16.0 * t["unitigs"]
     if kernel == "k_bfs":
         return 600.0 * t["candidates"]
@@ -316,6 +318,23 @@ def main():
             if n.value:
                 ktimes[name] = (ms.value, n.value)
 
+        # outside the timed region: C1 computed the other way (every k-mer probed in the hash table, what K-COV-JOIN does once
+        # at load) -- its duration, and that both routes agree on this graph
+        probe = None
+        if rank == 0 and not colored:
+            import numpy as np
+            res = [(np.zeros(n_unitigs, np.uint64), np.zeros(n_unitigs, np.uint32), np.zeros(n_unitigs, np.uint8)) for _ in range(2)]
+            L.pf_reset_timing(ctx)
+            for fn, (s_, m_, x_) in ((L.pf_unitig_cov, res[0]), (L.pf_unitig_cov_probe, res[1]), (L.pf_unitig_cov_probe, res[1])):
+                fn(ctx, 0, n_unitigs, s_.ctypes.data, m_.ctypes.data, x_.ctypes.data)
+                if fn is L.pf_unitig_cov:
+                    L.pf_reset_timing(ctx)
+            ms, n = C.c_double(), C.c_uint64()
+            L.pf_kernel_time(ctx, hipapi.KERNELS.index("k_cov"), C.byref(ms), C.byref(n))
+            if n.value:
+                probe = {"avg_ms": round(ms.value / n.value, 4),
+                         "equals_streamed": bool(all(np.array_equal(a, b) for a, b in zip(res[0], res[1])))}
+
         allstats = pfdist.all_gather_counters([n_unitigs, tt["superbubbles"], tt["tasks"], tt["output_bytes"]] + tt["allele"] +
                                               [int(elapsed * 1e6)], xdev)
         max_elapsed = allstats[:, -1].max() / 1e6
@@ -371,7 +390,7 @@ def main():
                                             "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
                                             "and allele-frequency record slabs (%d bytes)") % gathered_bytes[0]},
                 "roofline": roof, "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
-                "kernels": kernels,
+                "kernels": kernels, "k_cov_probe": probe,
                 "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},
                 # rank 0's graph; for one graph over all ranks (strong) the per-slice counters are added up
                 "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"],

@@ -55,7 +55,7 @@ int pf_synchronize(pf_ctx *);
  * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
-    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COUNT_
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -112,6 +112,15 @@ int pf_lookup_kmers(pf_ctx *, const uint64_t *kmers, uint64_t n, uint32_t *count
  * division (mean = sum / len). Returns PF_ERR_MISSING_KMER after filling the arrays if
  * any miss flag is set. [host|dev] */
 int pf_unitig_cov(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *min, uint8_t *miss);
+/* How pf_unitig_cov gets there: as soon as a graph and a canonical count table are both resident (whichever of
+ * pf_upload_graph / pf_upload_counts comes second) the device joins them once -- every graph k-mer's count is written
+ * to its position in graph order, a per-k-mer coverage SoA beside the sequence SoA (kernel PF_K_COV_JOIN; the
+ * load-time counterpart of pf_build_adjacency).  pf_unitig_cov then streams that array: a segmented sum / min over
+ * 4 contiguous bytes per k-mer instead of one random table access per k-mer.  pf_unitig_cov_probe is the same
+ * function computed the other way -- every k-mer looked up in the hash table at call time -- kept for databases the
+ * SoA cannot hold (max_count = 2^32 - 1) and as the independent check of the join (tests, measurements).
+ * Identical results by construction. [host|dev] */
+int pf_unitig_cov_probe(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *min, uint8_t *miss);
 /* The branch for a database built without canonical counting (GetBothStrands() == false, src/CDBG.cpp:94-117): every k-mer of
  * mappedSequenceToString() is looked up as it reads.  reverse = 0: the unitig as stored; 1: its reverse complement (the '-'
  * orientation).  pf_unitig_cov refuses such a table; pf_string_cov returns sum 0 / ok 1 for it without looking anything up, as

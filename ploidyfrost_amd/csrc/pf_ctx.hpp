@@ -57,6 +57,17 @@ struct pf_ctx {
     uint64_t tab_cap = 0, tab_n = 0;
     bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked at upload)
     bool tab_exact = false;       // database built without canonical counting: no composite lookups
+    uint64_t tab_max_count = 0;   // upper count filter of the last upload (decides the width of K-COV's row sums)
+
+    // per-k-mer coverage SoA in graph order (K-COV-JOIN at load, streamed by K-COV every pass):
+    // d_gcov[g] = count of graph k-mer g (unitigs laid end to end, numbering of d_kpre), PF_GCOV_MISSING = not in the table;
+    // bit g % 64 of d_khead[g / 64] = k-mer g is the first of its unitig (bit n_kmers is set as well);
+    // d_krow[r] = the unitig holding k-mer 64 * r
+    uint32_t *d_gcov = nullptr;
+    uint64_t *d_khead = nullptr;
+    uint32_t *d_krow = nullptr;
+    uint64_t n_krow = 0;
+    bool gcov_valid = false;
 
     // colored path: the count databases of all colours in one table, slot = { u64 key, u32 count[n_colors] }
     // padded to 1 << ctab_shift bytes (pf_colored.hip)
@@ -89,6 +100,7 @@ namespace pf {
 int ctx_begin(pf_ctx *ctx, int kernel);
 void ctx_end(pf_ctx *ctx);
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
+int join_graph_counts(pf_ctx *ctx);  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
 // device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
 enum WsSlot {

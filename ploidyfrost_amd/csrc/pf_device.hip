@@ -12,6 +12,7 @@
 #include <cstdio>
 #include <cstring>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "pf_bfs.hpp"
@@ -217,7 +218,7 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
                                              const uint64_t *__restrict__ off, const uint64_t *__restrict__ kpre, const uint32_t *__restrict__ kwin, uint32_t N,
                                              bool one_strand, int exact, uint32_t u0, uint64_t g_begin, uint64_t g_end, uint64_t w_begin,
                                              uint64_t n_win, uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min,
-                                             uint8_t *__restrict__ out_miss) {
+                                             uint8_t *__restrict__ out_miss, uint32_t *__restrict__ gcov) {
     __shared__ uint64_t s_pre[4][KCOV_WIN + 2];
     const int lane = lane_id();
     const int wi = threadIdx.x >> 6;
@@ -270,6 +271,10 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
                 if (count_finish(t, mask, pr[j], c)) { sum = c; mn = c; }
                 else miss = 1;
             }
+            if (gcov) {  // K-COV-JOIN: the count goes to the k-mer's place in graph order (coalesced), nothing is reduced
+                if (act[j]) gcov[g0 + (uint64_t)j * WAVE + lane] = miss ? GCOV_MISSING : (uint32_t)sum;
+                continue;
+            }
             // segmented inclusive scan over lanes of the same unitig (contiguous runs, inactive lanes carry NONE)
             const uint32_t u = uu[j];
 #pragma unroll
@@ -292,6 +297,127 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
             }
         }
         __builtin_amdgcn_wave_barrier();  // P is rewritten by the next window
+    }
+}
+
+// K-COV, streaming form (canonical databases): the counts of the graph's k-mers sit in graph order in gcov (written once per
+// graph + database by K-COV-JOIN), so C1 is a segmented reduction over a contiguous array: 4 B per k-mer, fully coalesced.
+// A wavefront takes windows of KCS_ROWS rows of 64 consecutive k-mers; all loads of a window are issued before the first is
+// used.  Segments (unitigs) are described by one bit per k-mer (khead, scalar load per row) and the unitig of the row's
+// first k-mer (krow): lane -> unitig is a popcount, "same unitig as lane - o" a mask test, no search.  Row partial sums are
+// 32-bit when 64 * max_count fits (WIDE = false).  Outputs as the probing form: initialised by k_cov_init, one atomic pair
+// per (row, unitig).
+constexpr int KCS_ROWS = 8;
+
+// one DPP move: lanes the control leaves without a source (or outside row_mask) keep `old`
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_u32(uint32_t old, uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline unsigned long long dpp_u64(unsigned long long old, unsigned long long v) {
+    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)old, (uint32_t)v), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(old >> 32), (uint32_t)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+template <int CTRL, int ROW_MASK>
+__device__ inline uint32_t dpp_any(uint32_t old, uint32_t v) { return dpp_u32<CTRL, ROW_MASK>(old, v); }
+template <int CTRL, int ROW_MASK>
+__device__ inline unsigned long long dpp_any(unsigned long long old, unsigned long long v) { return dpp_u64<CTRL, ROW_MASK>(old, v); }
+
+// DPP = true: the segmented scan runs on the VALU's data-parallel primitives (row_shr 1/2/4/8 inside rows of 16 lanes, then
+// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) instead of twelve ds_bpermute per row through the LDS crossbar.
+template <bool WIDE, bool DPP>
+__global__ __launch_bounds__(256) void k_cov_stream(const uint32_t *__restrict__ gcov, const uint64_t *__restrict__ khead,
+                                                    const uint32_t *__restrict__ krow, uint32_t u0, uint64_t g_begin, uint64_t g_end,
+                                                    uint64_t r_begin, uint64_t r_end, uint64_t *__restrict__ out_sum,
+                                                    uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
+    typedef typename std::conditional<WIDE, unsigned long long, uint32_t>::type sum_t;
+    const int lane = lane_id();
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row metadata comes through scalar loads
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t n_win = (r_end - r_begin + KCS_ROWS - 1) / KCS_ROWS;
+    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);  // bits 0..lane
+    for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
+        const uint64_t r0 = r_begin + wx * KCS_ROWS;
+        uint32_t c[KCS_ROWS];
+#pragma unroll
+        for (int j = 0; j < KCS_ROWS; ++j) {
+            const uint64_t g = (r0 + j) * 64 + lane;
+            c[j] = (g >= g_begin && g < g_end) ? gcov[g] : 0u;
+        }
+#pragma unroll
+        for (int j = 0; j < KCS_ROWS; ++j) {
+            const uint64_t r = r0 + j;
+            if (r >= r_end) break;
+            const uint64_t heads = khead[r];
+            const uint32_t ub = krow[r];
+            const uint64_t g = r * 64 + lane;
+            const bool act = g >= g_begin && g < g_end;  // the range begins and ends on unitig boundaries
+            const bool miss = act && c[j] == GCOV_MISSING;
+            sum_t sum = (act && !miss) ? c[j] : 0u;
+            uint32_t mn = (act && !miss) ? c[j] : 0xFFFFFFFFu;
+            if (DPP) {
+                const int li = lane & 15;
+#define PF_KCS_ROW_STEP(O)                                                                              \
+    {                                                                                                   \
+        const sum_t so = dpp_any<0x110 | (O), 0xF>((sum_t)0, sum);                                      \
+        const uint32_t mo = dpp_any<0x110 | (O), 0xF>(0xFFFFFFFFu, mn);                                 \
+        const int sh = li >= (O) ? lane - (O) + 1 : 0;                                                  \
+        if (li >= (O) && ((heads >> sh) & ((1ull << (O)) - 1)) == 0) {                                  \
+            sum += so;                                                                                  \
+            mn = mo < mn ? mo : mn;                                                                     \
+        }                                                                                               \
+    }
+                PF_KCS_ROW_STEP(1)
+                PF_KCS_ROW_STEP(2)
+                PF_KCS_ROW_STEP(4)
+                PF_KCS_ROW_STEP(8)
+#undef PF_KCS_ROW_STEP
+                // no unitig begins between the start of this lane's row of 16 and the lane: the carry of the row before applies
+                const bool open16 = ((heads >> (lane & ~15)) & ((2ull << li) - 1)) == 0;
+                {
+                    const sum_t so = dpp_any<0x142, 0xA>((sum_t)0, sum);          // row_bcast:15 -> rows 1, 3
+                    const uint32_t mo = dpp_any<0x142, 0xA>(0xFFFFFFFFu, mn);
+                    if ((lane & 16) && open16) {
+                        sum += so;
+                        mn = mo < mn ? mo : mn;
+                    }
+                }
+                {
+                    const sum_t so = dpp_any<0x143, 0xC>((sum_t)0, sum);          // row_bcast:31 -> rows 2, 3
+                    const uint32_t mo = dpp_any<0x143, 0xC>(0xFFFFFFFFu, mn);
+                    const bool open32 = lane >= 32 && ((heads >> 32) & ((2ull << (lane - 32 >= 0 ? lane - 32 : 0)) - 1)) == 0;
+                    if (open32) {
+                        sum += so;
+                        mn = mo < mn ? mo : mn;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const sum_t so = __shfl_up(sum, o, WAVE);
+                    const uint32_t mo = __shfl_up(mn, o, WAVE);
+                    // lane - o is in this lane's unitig iff no unitig begins at lanes lane - o + 1 .. lane
+                    const int sh = lane >= o ? lane - o + 1 : 0;
+                    const bool same = lane >= o && ((heads >> sh) & ((1ull << o) - 1)) == 0;
+                    if (same) {
+                        sum += so;
+                        mn = mo < mn ? mo : mn;
+                    }
+                }
+            }
+            if (act) {
+                const uint32_t u = ub + (uint32_t)__popcll(heads & le_mask & ~1ull);
+                const bool last = lane == 63 || ((heads >> (lane + 1)) & 1ull);
+                const uint32_t o = u - u0;
+                if (last) {
+                    atomicAdd(reinterpret_cast<unsigned long long *>(out_sum + o), (unsigned long long)sum);
+                    if (mn != 0xFFFFFFFFu) atomicMin(out_min + o, mn);
+                }
+                if (miss) out_miss[o] = 1;
+            }
+        }
     }
 }
 
@@ -486,7 +612,7 @@ namespace pf {
 
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
-                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count"};
+                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join"};
 
 int ctx_begin(pf_ctx *ctx, int kernel) {
     if (!ctx->timing) return 0;
@@ -522,6 +648,30 @@ int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu) {
     return (int)std::min<uint64_t>(want, cap);
 }
 
+}  // namespace pf
+
+// K-COV-JOIN: hash join of the graph's k-mers with the count table, once per (graph, database): every graph k-mer's canonical
+// count (K2 + K3 composite, filter [min_count, max_count] applied at table build) lands at its position in graph order.
+// This is the load-time counterpart of K-ADJ: what CDBG::readCov looks up k-mer by k-mer (src/CDBG.cpp:66-120) becomes a
+// per-k-mer coverage SoA next to the 2-bit sequence SoA.  A count equal to the marker value cannot be represented: such a
+// database (max_count = 2^32 - 1) keeps the probing K-COV.
+namespace pf {
+int join_graph_counts(pf_ctx *ctx) {
+    ctx->gcov_valid = false;
+    if (!ctx->d_seq || !ctx->d_tab || ctx->tab_exact || ctx->tab_max_count >= GCOV_MISSING || ctx->n_kmers == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (!ctx->d_gcov) PF_HIP(hipMalloc(&ctx->d_gcov, (ctx->n_krow * 64) * sizeof(uint32_t)));
+    const uint64_t n_win = (ctx->n_kmers + KCOV_WIN - 1) / KCOV_WIN;
+    ctx_begin(ctx, PF_K_COV_JOIN);
+    k_cov<<<ctx_grid(ctx, n_win * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
+                                                                        ctx->d_kwin, ctx->N, ctx->tab_one_strand, 0, 0, 0, ctx->n_kmers, 0, n_win,
+                                                                        nullptr, nullptr, nullptr, ctx->d_gcov);
+    ctx_end(ctx);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->gcov_valid = true;
+    return PF_OK;
+}
 }  // namespace pf
 
 // helper: device staging of an input that may live on the host
@@ -585,6 +735,11 @@ static void free_graph(pf_ctx *ctx) {
     hipFree(ctx->d_pred16);
     hipFree(ctx->d_kpre);
     hipFree(ctx->d_kwin);
+    hipFree(ctx->d_gcov); hipFree(ctx->d_khead); hipFree(ctx->d_krow);
+    ctx->d_gcov = nullptr;
+    ctx->d_khead = nullptr;
+    ctx->d_krow = nullptr;
+    ctx->gcov_valid = false;
     ctx->d_kpre = nullptr;
     ctx->d_kwin = nullptr;
     ctx->d_pred16 = nullptr;
@@ -728,7 +883,25 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         PF_HIP(hipMemcpy(ctx->d_kpre, kpre.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
         PF_HIP(hipMemcpy(ctx->d_kwin, kwin.data(), n_win * 4, hipMemcpyHostToDevice));
         ctx->n_kwin = n_win;
+        // segment description for the streaming K-COV: one bit per k-mer (unitig starts, plus the end of the last one)
+        // and the unitig of every 64th k-mer
+        const uint64_t n_row = nk / 64 + 1;
+        std::vector<uint64_t> khead(n_row, 0);
+        std::vector<uint32_t> krow(n_row);
+        uint64_t r = 0;
+        for (uint32_t u = 0; u < N; ++u) {
+            khead[kpre[u] >> 6] |= 1ull << (kpre[u] & 63);
+            for (; r < n_row && r * 64 < kpre[u + 1]; ++r) krow[r] = u;
+        }
+        khead[nk >> 6] |= 1ull << (nk & 63);
+        for (; r < n_row; ++r) krow[r] = N - 1;
+        PF_HIP(hipMalloc(&ctx->d_khead, n_row * 8));
+        PF_HIP(hipMalloc(&ctx->d_krow, n_row * 4));
+        PF_HIP(hipMemcpy(ctx->d_khead, khead.data(), n_row * 8, hipMemcpyHostToDevice));
+        PF_HIP(hipMemcpy(ctx->d_krow, krow.data(), n_row * 4, hipMemcpyHostToDevice));
+        ctx->n_krow = n_row;
     }
+    if (ctx->d_tab && !ctx->tab_exact) return pf::join_graph_counts(ctx);
     return PF_OK;
 }
 
@@ -846,9 +1019,13 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
                      uint64_t max_count, int both_strands) {
     if (!ctx || (n && (!kmers || !counts))) return PF_ERR_ARG;
     ctx->tab_exact = !both_strands;   // GetBothStrands() == false: lookups take the k-mer as it reads (src/CDBG.cpp:94-117)
+    ctx->tab_max_count = max_count;
     PF_HIP(hipSetDevice(ctx->device));
     hipFree(ctx->d_tab);
     ctx->d_tab = nullptr;
+    hipFree(ctx->d_gcov);
+    ctx->d_gcov = nullptr;
+    ctx->gcov_valid = false;
     uint64_t cap = 1024;
     while (cap < n * 2) cap <<= 1;
     PF_HIP(hipMalloc(&ctx->d_tab, cap * sizeof(Slot)));
@@ -889,6 +1066,7 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
         PF_HIP(hipStreamSynchronize(ctx->stream));
         ctx->tab_one_strand = (n && ctx->k) ? h_flag == 0 : false;
     }
+    if (ctx->d_seq && !ctx->tab_exact) return pf::join_graph_counts(ctx);
     return PF_OK;
 }
 
@@ -915,7 +1093,7 @@ int pf_lookup_kmers(pf_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *co
     return PF_OK;
 }
 
-static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
+static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uint64_t *sum, uint32_t *mn, uint8_t *miss, bool probe = false) {
     if (!ctx || !ctx->d_seq || !ctx->d_tab || u0 > u1 || u1 > ctx->N || !sum || !mn || !miss) return PF_ERR_ARG;
     if (u0 == u1) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
@@ -944,11 +1122,27 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
     PF_HIP(hipMemcpyAsync(&g_range[1], ctx->d_kpre + u1, 8, hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
     const uint64_t w_begin = g_range[0] / KCOV_WIN, w_end = (g_range[1] + KCOV_WIN - 1) / KCOV_WIN;
+    if (!exact && !probe && !ctx->gcov_valid) {  // graph and table were uploaded before the join existed for them
+        const int rc = join_graph_counts(ctx);
+        if (rc) return rc;
+    }
     ctx_begin(ctx, PF_K_COV);
     k_cov_init<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(n, ds, dm, dx);
-    k_cov<<<ctx_grid(ctx, (w_end - w_begin) * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
-                                                                                 ctx->d_kwin, ctx->N, ctx->tab_one_strand, exact, u0, g_range[0],
-                                                                                 g_range[1], w_begin, w_end - w_begin, ds, dm, dx);
+    if (!exact && !probe && ctx->gcov_valid) {
+        // streaming form: rows of 64 k-mers, KCS_ROWS rows per wavefront window
+        const uint64_t r_begin = g_range[0] / 64, r_end = (g_range[1] + 63) / 64;
+        const int grid = ctx_grid(ctx, (r_end - r_begin + KCS_ROWS - 1) / KCS_ROWS * 64, 256, 8);
+        static const bool dpp = [] { const char *e = getenv("PF_KCOV_SCAN"); return !(e && !strcmp(e, "bpermute")); }();
+        const bool wide = ctx->tab_max_count >= (1ull << 25);
+#define PF_KCS_LAUNCH(W, D) k_cov_stream<W, D><<<grid, 256, 0, ctx->stream>>>(ctx->d_gcov, ctx->d_khead, ctx->d_krow, u0, g_range[0], g_range[1], r_begin, r_end, ds, dm, dx)
+        if (wide) { if (dpp) PF_KCS_LAUNCH(true, true); else PF_KCS_LAUNCH(true, false); }
+        else { if (dpp) PF_KCS_LAUNCH(false, true); else PF_KCS_LAUNCH(false, false); }
+#undef PF_KCS_LAUNCH
+    } else {
+        k_cov<<<ctx_grid(ctx, (w_end - w_begin) * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
+                                                                                     ctx->d_kwin, ctx->N, ctx->tab_one_strand, exact, u0, g_range[0],
+                                                                                     g_range[1], w_begin, w_end - w_begin, ds, dm, dx, nullptr);
+    }
     ctx_end(ctx);
     if (!dev_out) {
         PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -967,6 +1161,14 @@ int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t
         return PF_ERR_ARG;
     }
     return unitig_cov_impl(ctx, u0, u1, 0, sum, mn, miss);
+}
+
+int pf_unitig_cov_probe(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
+    if (ctx && ctx->tab_exact) {
+        ctx->err = "the count database was built without canonical counting: pf_unitig_cov_exact gives its per-orientation coverage";
+        return PF_ERR_ARG;
+    }
+    return unitig_cov_impl(ctx, u0, u1, 0, sum, mn, miss, true);
 }
 
 int pf_unitig_cov_exact(pf_ctx *ctx, uint32_t u0, uint32_t u1, int reverse, uint64_t *sum, uint32_t *mn, uint8_t *miss) {

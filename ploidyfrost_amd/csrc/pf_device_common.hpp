@@ -9,6 +9,7 @@ namespace pf {
 constexpr int WAVE = 64;
 constexpr uint64_t EMPTY_KEY = 0xFFFFFFFFFFFFFFFFull;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
+constexpr uint32_t GCOV_MISSING = 0xFFFFFFFFu;  // pf_ctx::d_gcov: the k-mer is not in the count table
 
 // 16-byte slot: one probe = one 16-B load inside one 64-B sector.
 struct __attribute__((aligned(16))) Slot {

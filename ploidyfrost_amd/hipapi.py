@@ -20,7 +20,7 @@ LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_hip.so")
 NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
-           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count"]
+           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
@@ -73,6 +73,7 @@ def load_library() -> C.CDLL:
         "pf_upload_counts": (i, [vp, vp, vp, u64, u64, u64, i]),
         "pf_lookup_kmers": (i, [vp, vp, u64, vp, vp]),
         "pf_unitig_cov": (i, [vp, u32, u32, vp, vp, vp]),
+        "pf_unitig_cov_probe": (i, [vp, u32, u32, vp, vp, vp]),
         "pf_count_candidates": (i, [vp, u32, u32, C.POINTER(u64)]),
         "pf_bfs_candidates": (i, [vp, u32, u32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64)]),
         "pf_align_batch": (i, [vp, vp, u64, vp, u32, C.c_double, C.c_double, C.c_double, vp, vp, vp, u64, vp, u64, vp, u64,
@@ -113,7 +114,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
-                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact"]
+                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe"]
 
 
 def pack_unitigs(seqs: list[bytes]):
@@ -307,6 +308,15 @@ class Device:
             st = self._check(self.L.pf_unitig_cov(self.h, u0, u1, _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
         else:  # database without canonical counting: the unitigs as stored
             st = self._check(self.L.pf_unitig_cov_exact(self.h, u0, u1, 0, _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
+        return s, m, x, st
+
+    def unitig_cov_probe(self, u0=0, u1=None):
+        """pf_unitig_cov_probe: C1 with every k-mer looked up in the hash table at call time (never the joined SoA)"""
+        u1 = self.n if u1 is None else u1
+        s = np.zeros(u1 - u0, dtype=np.uint64)
+        m = np.zeros(u1 - u0, dtype=np.uint32)
+        x = np.zeros(u1 - u0, dtype=np.uint8)
+        st = self._check(self.L.pf_unitig_cov_probe(self.h, u0, u1, _ptr(s), _ptr(m), _ptr(x)), allow=(PF_ERR_MISSING_KMER,))
         return s, m, x, st
 
     def unitig_cov_exact(self, reverse: bool, u0=0, u1=None):

@@ -57,6 +57,75 @@ def test_unitig_cov_matches_oracle(case):
     assert np.array_equal(s2, es[h:]) and np.array_equal(m2, em[h:])
 
 
+@pytest.mark.parametrize("case", golden_cases())
+def test_unitig_cov_streamed_equals_probed(case):
+    """K-COV streams the per-k-mer coverage SoA joined at load (PF_K_COV_JOIN); pf_unitig_cov_probe looks every k-mer up
+    at call time.  Same function (src/CDBG.cpp:66-120), two independent routes: whole range and ragged sub-ranges."""
+    meta, o, dev, _ = setup_case(case)
+    if not getattr(dev, "both_strands", True):
+        pytest.skip("database without canonical counting: neither form applies (pf_unitig_cov_exact)")
+    s, m, x, st = dev.unitig_cov()
+    ps, pm, px, pst = dev.unitig_cov_probe()
+    assert st == pst == hipapi.PF_OK
+    assert np.array_equal(s, ps) and np.array_equal(m, pm) and np.array_equal(x, px)
+    rng = np.random.default_rng(7)
+    for _ in range(6):
+        u0 = int(rng.integers(0, dev.n))
+        u1 = int(rng.integers(u0 + 1, dev.n + 1))
+        a, b = dev.unitig_cov(u0, u1), dev.unitig_cov_probe(u0, u1)
+        assert np.array_equal(a[0], s[u0:u1]) and np.array_equal(a[1], m[u0:u1])
+        assert np.array_equal(b[0], s[u0:u1]) and np.array_equal(b[1], m[u0:u1])
+    for u in (0, dev.n - 1):  # a single unitig at either end of the array
+        a = dev.unitig_cov(u, u + 1)
+        assert a[0][0] == s[u] and a[1][0] == m[u]
+
+
+@pytest.mark.parametrize("max_count", [65535, (1 << 25) - 1, (1 << 25), (1 << 32) - 2, (1 << 32) - 1])
+def test_unitig_cov_wide_counts_and_reupload(max_count):
+    """Row sums are 32-bit only while 64 * max_count fits; a database whose max_count is the SoA's marker value keeps the
+    probing form; a second pf_upload_counts replaces the joined SoA.  Counts close to max_count exercise both sum widths."""
+    meta, o, dev, seqs = setup_case("dip20k")
+    kmers, counts, km = synth.read_kmc(meta["db"])
+    big = counts.astype(np.uint32).copy()
+    bump = min(1 << 31, max_count - 65536) if max_count > 65535 else 0   # every bumped count stays inside [1, max_count]
+    if bump:
+        big[::3] += np.uint32(bump)
+    d = hipapi.Device(0)
+    d.upload_graph(*hipapi.pack_unitigs(seqs), o.k)
+    d.upload_counts(kmers, counts, 1, 65535, True)      # first database: joined ...
+    first = d.unitig_cov()
+    d.upload_counts(kmers, big, 1, max_count, True)      # ... then replaced
+    s, m, x, st = d.unitig_cov()
+    ps, pm, px, pst = d.unitig_cov_probe()
+    assert st == pst == hipapi.PF_OK and not x.any()
+    assert np.array_equal(s, ps) and np.array_equal(m, pm)
+    es, em, _ = o.unitig_cov()
+    assert np.array_equal(first[0], es) and np.array_equal(first[1], em)
+    if bump:
+        assert int(s.sum()) > int(es.sum()) + bump and (s >= es).all()
+    else:
+        assert np.array_equal(s, es)
+    d.close()
+
+
+def test_cov_join_is_timed_as_its_own_kernel():
+    meta, o, dev, seqs = setup_case("dip20k")
+    kmers, counts, km = synth.read_kmc(meta["db"])
+    d = hipapi.Device(0)
+    d.enable_timing(True)
+    d.upload_graph(*hipapi.pack_unitigs(seqs), o.k)
+    d.upload_counts(kmers, counts, 1, 65535, True)
+    d.unitig_cov()
+    t = d.kernel_times()
+    assert t["k_cov_join"][1] == 1 and t["k_cov"][1] == 1
+    d.upload_graph(*hipapi.pack_unitigs(seqs), o.k)      # a new graph under the same table: joined again
+    s, m, x, st = d.unitig_cov()
+    es, em, _ = o.unitig_cov()
+    assert np.array_equal(s, es) and np.array_equal(m, em)
+    assert d.kernel_times()["k_cov_join"][1] == 2
+    d.close()
+
+
 def test_missing_kmer_is_reported():
     meta, o, dev, _ = setup_case("dip20k")
     kmers, counts, km = synth.read_kmc(meta["db"])

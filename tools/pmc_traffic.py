@@ -29,6 +29,10 @@ def per_kernel(d, counter):
 
 
 def short(name):
+    if "k_cov_stream<" in name:   # the per-pass K-COV (streams the joined per-k-mer coverage SoA)
+        return "k_cov"
+    if "k_cov(" in name:          # the probing form: K-COV-JOIN at load, pf_unitig_cov_probe
+        return "k_cov_probe"
     for k in ("k_cov_init", "k_cov_colored", "k_cov", "k_bfs_huge", "k_bfs_big", "k_bfs", "k_bubble", "k_strcov_colored", "k_align", "k_strcov", "k_table_build", "k_adj_insert", "k_adj_probe"):
         if k + "(" in name or k + "<" in name:
             if k == "k_bubble" and "Lb0" in name:
