@@ -421,6 +421,185 @@ __global__ __launch_bounds__(256) void k_cov_stream(const uint32_t *__restrict__
     }
 }
 
+// K-COV, streaming form with four k-mers per lane (the default): a lane takes 16 contiguous bytes of gcov (one dwordx4
+// load), reduces its four k-mers serially -- `pre` = the k-mers before the lane's first unitig start, `suf` = those from its
+// last unitig start on, both = all four when no unitig starts in the lane -- and the wavefront scans 64 lane aggregates
+// instead of 64 k-mers: a quarter of the scan work per k-mer, which is what bounded the one-k-mer-per-lane form (VALU issue,
+// not bytes).  A window is KC4_SR super-rows of 256 k-mers handled in order with a wave-uniform carry, so a unitig whose
+// first and last k-mer lie in one window (2048 k-mers) is reduced completely in registers and written with plain stores;
+// only what crosses a window border goes through atomics (about two per window instead of two per row and unitig).
+//   lane with a unitig start at its k-mer i0: closes the unitig running up to i0 - 1 (value = scan of the lane before, or
+//   the carry for lane 0, + pre), plain store if that unitig began inside the window, atomics otherwise;
+//   further starts inside the same lane delimit unitigs of <= 3 k-mers, stored directly;
+//   the open unitig at the end of the window is flushed with atomics.
+constexpr int KC4_SR = 8;
+
+template <typename S>
+__device__ inline void seg_scan_dpp(S &sum, uint32_t &mn, uint64_t heads, int lane) {
+    const int li = lane & 15;
+#define PF_SCAN_ROW_STEP(O)                                                                             \
+    {                                                                                                   \
+        const S so = dpp_any<0x110 | (O), 0xF>((S)0, sum);                                              \
+        const uint32_t mo = dpp_any<0x110 | (O), 0xF>(0xFFFFFFFFu, mn);                                 \
+        const int sh = li >= (O) ? lane - (O) + 1 : 0;                                                  \
+        if (li >= (O) && ((heads >> sh) & ((1ull << (O)) - 1)) == 0) {                                  \
+            sum += so;                                                                                  \
+            mn = mo < mn ? mo : mn;                                                                     \
+        }                                                                                               \
+    }
+    PF_SCAN_ROW_STEP(1)
+    PF_SCAN_ROW_STEP(2)
+    PF_SCAN_ROW_STEP(4)
+    PF_SCAN_ROW_STEP(8)
+#undef PF_SCAN_ROW_STEP
+    const bool open16 = ((heads >> (lane & ~15)) & ((2ull << li) - 1)) == 0;
+    {
+        const S so = dpp_any<0x142, 0xA>((S)0, sum);          // row_bcast:15 -> rows 1, 3
+        const uint32_t mo = dpp_any<0x142, 0xA>(0xFFFFFFFFu, mn);
+        if ((lane & 16) && open16) {
+            sum += so;
+            mn = mo < mn ? mo : mn;
+        }
+    }
+    {
+        const S so = dpp_any<0x143, 0xC>((S)0, sum);          // row_bcast:31 -> rows 2, 3
+        const uint32_t mo = dpp_any<0x143, 0xC>(0xFFFFFFFFu, mn);
+        const bool open32 = lane >= 32 && ((heads >> 32) & ((2ull << (lane >= 32 ? lane - 32 : 0)) - 1)) == 0;
+        if (open32) {
+            sum += so;
+            mn = mo < mn ? mo : mn;
+        }
+    }
+}
+
+template <typename S>
+__device__ inline void kc4_emit(uint32_t o, uint32_t n_out, S sum, uint32_t mn, bool complete, uint64_t *__restrict__ out_sum,
+                                uint32_t *__restrict__ out_min) {
+    if (o >= n_out) return;
+    if (complete) {
+        out_sum[o] = (uint64_t)sum;
+        out_min[o] = mn < 10000u ? mn : 10000u;  // min initialised 10000: src/CDBG.cpp:71
+    } else {
+        atomicAdd(reinterpret_cast<unsigned long long *>(out_sum + o), (unsigned long long)sum);
+        if (mn != 0xFFFFFFFFu) atomicMin(out_min + o, mn);
+    }
+}
+
+template <bool WIDE>
+__global__ __launch_bounds__(256) void k_cov_stream4(const uint32_t *__restrict__ gcov, const uint64_t *__restrict__ khead,
+                                                     const uint32_t *__restrict__ krow, uint32_t u0, uint32_t n_out, uint64_t g_begin,
+                                                     uint64_t g_end, uint64_t sr_begin, uint64_t sr_end, uint64_t *__restrict__ out_sum,
+                                                     uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
+    typedef typename std::conditional<WIDE, unsigned long long, uint32_t>::type sum_t;
+    const int lane = lane_id();
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t n_win = (sr_end - sr_begin + KC4_SR - 1) / KC4_SR;
+    const int w = lane >> 4, sh = (lane & 15) * 4;
+    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);  // lanes 0..lane
+    const uint64_t lt_mask = (1ull << lane) - 1;                         // lanes below
+    for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
+        const uint64_t sr0 = sr_begin + wx * KC4_SR;
+        uint4 c[KC4_SR];
+#pragma unroll
+        for (int j = 0; j < KC4_SR; ++j)
+            c[j] = sr0 + j < sr_end ? *reinterpret_cast<const uint4 *>(gcov + (sr0 + j) * 256 + 4 * lane) : make_uint4(0, 0, 0, 0);
+        sum_t csum = 0;           // carry: the unitig open at the end of the super-row before (wave-uniform)
+        uint32_t cmin = 0xFFFFFFFFu;
+        bool cstarted = false;    // ... began inside this window
+        uint32_t ulast = 0;
+#pragma unroll
+        for (int j = 0; j < KC4_SR; ++j) {
+            const uint64_t sr = sr0 + j;
+            if (sr >= sr_end) break;
+            const uint64_t H0 = khead[sr * 4], H1 = khead[sr * 4 + 1], H2 = khead[sr * 4 + 2], H3 = khead[sr * 4 + 3];
+            const uint32_t kb = krow[sr * 4];
+            const uint64_t g0 = sr * 256;
+            const bool edge = g0 < g_begin || g0 + 256 > g_end;
+            const uint64_t word = w == 0 ? H0 : w == 1 ? H1 : w == 2 ? H2 : H3;
+            const uint32_t h = (uint32_t)(word >> sh) & 0xFu;
+            const uint32_t below = (w > 0 ? __popcll(H0) : 0) + (w > 1 ? __popcll(H1) : 0) + (w > 2 ? __popcll(H2) : 0) +
+                                   __popcll(word & ((2ull << sh) - 1));
+            const uint32_t ub = kb + below - (uint32_t)(H0 & 1);  // unitig of the lane's first k-mer
+            uint32_t v[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
+            if (edge) {  // k-mers outside [g_begin, g_end) (other unitigs, or the padding past the last k-mer) count as absent
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint64_t g = g0 + 4 * lane + i;
+                    v[i] = (g >= g_begin && g < g_end) ? v[i] : GCOV_MISSING;
+                }
+            }
+            sum_t s[4];
+            bool anymiss = false;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool x = v[i] == GCOV_MISSING;
+                anymiss |= x;
+                s[i] = x ? 0u : v[i];
+            }
+            if (anymiss) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const uint32_t o = ub + __popc((h >> 1) & ((1u << i) - 1)) - u0;
+                    if (v[i] == GCOV_MISSING && o < n_out) out_miss[o] = 1;
+                }
+            }
+            // pre: k-mers with no unitig start at or before them; suf: k-mers with no unitig start after them
+            sum_t ps = 0, ss = 0;
+            uint32_t pm = 0xFFFFFFFFu, sm = 0xFFFFFFFFu;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                if ((h & ((2u << i) - 1)) == 0) { ps += s[i]; pm = v[i] < pm ? v[i] : pm; }
+                if ((h >> (i + 1)) == 0) { ss += s[i]; sm = v[i] < sm ? v[i] : sm; }
+            }
+            if (h & (h - 1)) {  // two or more starts in the lane: the unitigs between them are complete here
+#pragma unroll
+                for (int i = 0; i < 3; ++i) {
+                    if (((h >> i) & 1) && (h >> (i + 1))) {
+                        sum_t es = 0;
+                        uint32_t em = 0xFFFFFFFFu;
+                        bool in = true;
+#pragma unroll
+                        for (int q = i; q < 4; ++q) {
+                            if (q > i && ((h >> q) & 1)) in = false;
+                            if (in) { es += s[q]; em = v[q] < em ? v[q] : em; }
+                        }
+                        kc4_emit<sum_t>(ub + __popc((h >> 1) & ((1u << i) - 1)) - u0, n_out, es, em, true, out_sum, out_min);
+                    }
+                }
+            }
+            const uint64_t F = __ballot(h != 0);
+            sum_t vs = ss;
+            uint32_t vm = sm;
+            seg_scan_dpp<sum_t>(vs, vm, F, lane);
+            if ((F & le_mask) == 0) {  // still inside the unitig carried in
+                vs += csum;
+                vm = cmin < vm ? cmin : vm;
+            }
+            sum_t prev_s = __shfl_up(vs, 1, WAVE);
+            uint32_t prev_m = __shfl_up(vm, 1, WAVE);
+            if (lane == 0) { prev_s = csum; prev_m = cmin; }
+            if (h != 0 && !(j == 0 && lane == 0 && (h & 1))) {  // (a start on the window's first k-mer closes nothing of this window)
+                const sum_t es = prev_s + ps;
+                const uint32_t em = prev_m < pm ? prev_m : pm;
+                const bool started = (F & lt_mask) != 0 || cstarted;
+                kc4_emit<sum_t>(ub - (h & 1u) - u0, n_out, es, em, started, out_sum, out_min);
+            }
+            if (WIDE) {
+                csum = ((unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)vs >> 32), 63) << 32) |
+                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)vs, 63);
+            } else {
+                csum = (sum_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)vs, 63);
+            }
+            cmin = (uint32_t)__builtin_amdgcn_readlane((int)vm, 63);
+            cstarted = cstarted || F != 0;
+            ulast = (uint32_t)__builtin_amdgcn_readlane((int)(ub + __popc(h >> 1)), 63);
+        }
+        if (lane == 0) kc4_emit<sum_t>(ulast - u0, n_out, csum, cmin, false, out_sum, out_min);
+    }
+}
+
 // K-STRCOV: one thread per string (strings are k .. k+few bases long).
 __global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, bool one_strand, const char *__restrict__ text,
                          const uint64_t *__restrict__ str_off, uint32_t n_str, uint32_t low, uint32_t up,
@@ -660,7 +839,7 @@ int join_graph_counts(pf_ctx *ctx) {
     ctx->gcov_valid = false;
     if (!ctx->d_seq || !ctx->d_tab || ctx->tab_exact || ctx->tab_max_count >= GCOV_MISSING || ctx->n_kmers == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
-    if (!ctx->d_gcov) PF_HIP(hipMalloc(&ctx->d_gcov, (ctx->n_krow * 64) * sizeof(uint32_t)));
+    if (!ctx->d_gcov) PF_HIP(hipMalloc(&ctx->d_gcov, ((ctx->n_krow + 4) * 64) * sizeof(uint32_t)));  // whole super-rows of 256
     const uint64_t n_win = (ctx->n_kmers + KCOV_WIN - 1) / KCOV_WIN;
     ctx_begin(ctx, PF_K_COV_JOIN);
     k_cov<<<ctx_grid(ctx, n_win * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
@@ -885,9 +1064,9 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         ctx->n_kwin = n_win;
         // segment description for the streaming K-COV: one bit per k-mer (unitig starts, plus the end of the last one)
         // and the unitig of every 64th k-mer
-        const uint64_t n_row = nk / 64 + 1;
-        std::vector<uint64_t> khead(n_row, 0);
-        std::vector<uint32_t> krow(n_row);
+        const uint64_t n_row = nk / 64 + 1, n_row_pad = n_row + 8;  // padded: the four-per-lane kernel reads whole super-rows (4 words)
+        std::vector<uint64_t> khead(n_row_pad, 0);
+        std::vector<uint32_t> krow(n_row_pad, N - 1);
         uint64_t r = 0;
         for (uint32_t u = 0; u < N; ++u) {
             khead[kpre[u] >> 6] |= 1ull << (kpre[u] & 63);
@@ -895,10 +1074,10 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         }
         khead[nk >> 6] |= 1ull << (nk & 63);
         for (; r < n_row; ++r) krow[r] = N - 1;
-        PF_HIP(hipMalloc(&ctx->d_khead, n_row * 8));
-        PF_HIP(hipMalloc(&ctx->d_krow, n_row * 4));
-        PF_HIP(hipMemcpy(ctx->d_khead, khead.data(), n_row * 8, hipMemcpyHostToDevice));
-        PF_HIP(hipMemcpy(ctx->d_krow, krow.data(), n_row * 4, hipMemcpyHostToDevice));
+        PF_HIP(hipMalloc(&ctx->d_khead, n_row_pad * 8));
+        PF_HIP(hipMalloc(&ctx->d_krow, n_row_pad * 4));
+        PF_HIP(hipMemcpy(ctx->d_khead, khead.data(), n_row_pad * 8, hipMemcpyHostToDevice));
+        PF_HIP(hipMemcpy(ctx->d_krow, krow.data(), n_row_pad * 4, hipMemcpyHostToDevice));
         ctx->n_krow = n_row;
     }
     if (ctx->d_tab && !ctx->tab_exact) return pf::join_graph_counts(ctx);
@@ -1132,12 +1311,28 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
         // streaming form: rows of 64 k-mers, KCS_ROWS rows per wavefront window
         const uint64_t r_begin = g_range[0] / 64, r_end = (g_range[1] + 63) / 64;
         const int grid = ctx_grid(ctx, (r_end - r_begin + KCS_ROWS - 1) / KCS_ROWS * 64, 256, 8);
-        static const bool dpp = [] { const char *e = getenv("PF_KCOV_SCAN"); return !(e && !strcmp(e, "bpermute")); }();
+        static const int form = [] {  // PF_KCOV_SCAN: "dpp" / "bpermute" select the one-k-mer-per-lane form (measurements, tests)
+            const char *e = getenv("PF_KCOV_SCAN");
+            return !e ? 4 : !strcmp(e, "bpermute") ? 0 : !strcmp(e, "dpp") ? 1 : 4;
+        }();
+        if (form == 4) {
+            const uint64_t sr_begin = g_range[0] / 256, sr_end = (g_range[1] + 255) / 256;
+            // one wavefront per window, four per block: the hardware hands out blocks as wavefronts retire (a capped persistent
+            // grid leaves 3.7 windows per wavefront at 1 M unitigs: a quarter of the chip idle in the last round)
+            const int grid4 = (int)(((sr_end - sr_begin + KC4_SR - 1) / KC4_SR + 3) / 4);
+            // a window's carry sums up to KC4_SR * 256 counts in the narrow type
+            if (ctx->tab_max_count < (1ull << 20))
+                k_cov_stream4<false><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, dx);
+            else
+                k_cov_stream4<true><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, dx);
+        } else {
+        const bool dpp = form == 1;
         const bool wide = ctx->tab_max_count >= (1ull << 25);
 #define PF_KCS_LAUNCH(W, D) k_cov_stream<W, D><<<grid, 256, 0, ctx->stream>>>(ctx->d_gcov, ctx->d_khead, ctx->d_krow, u0, g_range[0], g_range[1], r_begin, r_end, ds, dm, dx)
         if (wide) { if (dpp) PF_KCS_LAUNCH(true, true); else PF_KCS_LAUNCH(true, false); }
         else { if (dpp) PF_KCS_LAUNCH(false, true); else PF_KCS_LAUNCH(false, false); }
 #undef PF_KCS_LAUNCH
+        }
     } else {
         k_cov<<<ctx_grid(ctx, (w_end - w_begin) * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
                                                                                      ctx->d_kwin, ctx->N, ctx->tab_one_strand, exact, u0, g_range[0],
