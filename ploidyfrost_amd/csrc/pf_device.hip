@@ -432,17 +432,24 @@ __global__ __launch_bounds__(256) void k_cov_stream(const uint32_t *__restrict__
 //   the carry for lane 0, + pre), plain store if that unitig began inside the window, atomics otherwise;
 //   further starts inside the same lane delimit unitigs of <= 3 k-mers, stored directly;
 //   the open unitig at the end of the window is flushed with atomics.
-constexpr int KC4_SR = 8;
+constexpr int KC4_SR = 8;   // measured at 1 M unitigs: 4 -> 0.093 ms, 8 -> 0.072 ms, 16 -> 0.081 ms (profiles/r01j_kcov_stream.txt)
+
+// Segmented inclusive scan (sum, min) over the 64 lanes; segments begin at the lanes set in `heads`.  `d` = distance from
+// the lane to the last segment start at or below it (>= 64: none) turns every "same segment?" test into a 32-bit compare.
+__device__ inline int seg_distance(uint64_t heads, int lane) {
+    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);
+    const uint64_t m = heads & le_mask;
+    return m ? lane - (63 - __clzll((long long)m)) : 127;
+}
 
 template <typename S>
-__device__ inline void seg_scan_dpp(S &sum, uint32_t &mn, uint64_t heads, int lane) {
+__device__ inline void seg_scan_dpp(S &sum, uint32_t &mn, int d, int lane) {
     const int li = lane & 15;
 #define PF_SCAN_ROW_STEP(O)                                                                             \
     {                                                                                                   \
         const S so = dpp_any<0x110 | (O), 0xF>((S)0, sum);                                              \
         const uint32_t mo = dpp_any<0x110 | (O), 0xF>(0xFFFFFFFFu, mn);                                 \
-        const int sh = li >= (O) ? lane - (O) + 1 : 0;                                                  \
-        if (li >= (O) && ((heads >> sh) & ((1ull << (O)) - 1)) == 0) {                                  \
+        if (li >= (O) && d >= (O)) {   /* no segment starts at lanes lane - O + 1 .. lane */            \
             sum += so;                                                                                  \
             mn = mo < mn ? mo : mn;                                                                     \
         }                                                                                               \
@@ -452,11 +459,10 @@ __device__ inline void seg_scan_dpp(S &sum, uint32_t &mn, uint64_t heads, int la
     PF_SCAN_ROW_STEP(4)
     PF_SCAN_ROW_STEP(8)
 #undef PF_SCAN_ROW_STEP
-    const bool open16 = ((heads >> (lane & ~15)) & ((2ull << li) - 1)) == 0;
     {
         const S so = dpp_any<0x142, 0xA>((S)0, sum);          // row_bcast:15 -> rows 1, 3
         const uint32_t mo = dpp_any<0x142, 0xA>(0xFFFFFFFFu, mn);
-        if ((lane & 16) && open16) {
+        if ((lane & 16) && d > li) {                          // nothing starts between the row's first lane and this one
             sum += so;
             mn = mo < mn ? mo : mn;
         }
@@ -464,8 +470,7 @@ __device__ inline void seg_scan_dpp(S &sum, uint32_t &mn, uint64_t heads, int la
     {
         const S so = dpp_any<0x143, 0xC>((S)0, sum);          // row_bcast:31 -> rows 2, 3
         const uint32_t mo = dpp_any<0x143, 0xC>(0xFFFFFFFFu, mn);
-        const bool open32 = lane >= 32 && ((heads >> 32) & ((2ull << (lane >= 32 ? lane - 32 : 0)) - 1)) == 0;
-        if (open32) {
+        if (lane >= 32 && d > lane - 32) {
             sum += so;
             mn = mo < mn ? mo : mn;
         }
@@ -497,7 +502,6 @@ __global__ __launch_bounds__(256) void k_cov_stream4(const uint32_t *__restrict_
     const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
     const uint64_t n_win = (sr_end - sr_begin + KC4_SR - 1) / KC4_SR;
     const int w = lane >> 4, sh = (lane & 15) * 4;
-    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);  // lanes 0..lane
     const uint64_t lt_mask = (1ull << lane) - 1;                         // lanes below
     for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
         const uint64_t sr0 = sr_begin + wx * KC4_SR;
@@ -572,8 +576,9 @@ __global__ __launch_bounds__(256) void k_cov_stream4(const uint32_t *__restrict_
             const uint64_t F = __ballot(h != 0);
             sum_t vs = ss;
             uint32_t vm = sm;
-            seg_scan_dpp<sum_t>(vs, vm, F, lane);
-            if ((F & le_mask) == 0) {  // still inside the unitig carried in
+            const int d = seg_distance(F, lane);
+            seg_scan_dpp<sum_t>(vs, vm, d, lane);
+            if (d > lane) {  // no start at or below this lane: still inside the unitig carried in
                 vs += csum;
                 vm = cmin < vm ? cmin : vm;
             }

@@ -29,7 +29,7 @@ def per_kernel(d, counter):
 
 
 def short(name):
-    if "k_cov_stream<" in name:   # the per-pass K-COV (streams the joined per-k-mer coverage SoA)
+    if "k_cov_stream" in name:    # the per-pass K-COV (k_cov_stream4 / k_cov_stream: streams the joined per-k-mer coverage SoA)
         return "k_cov"
     if "k_cov(" in name:          # the probing form: K-COV-JOIN at load, pf_unitig_cov_probe
         return "k_cov_probe"
