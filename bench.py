@@ -184,9 +184,9 @@ def algorithmic_bytes(kernel: str, t: dict) -> float | None:
         return 300.0 * t["align_jobs"]
     if kernel == "k_strcov":
         return 12.0 * 2.0 * t["site_strings"]
-    if kernel == "k_cov_colored":  # one slot of 8 + 4 C bytes per k-mer, 17 B of results per (colour, unitig)
+    if kernel == "k_cov_colored":  # streaming form: 4 B count per (k-mer, colour), head bit + row id per k-mer, 17 B of results per (colour, unitig)
         c = t.get("n_colors", 3)
-        return (0.25 + 8.0 + 4.0 * c) * t["kmers"] + 17.0 * c * t["unitigs"]
+        return (4.0 * c + 1.0 / 8 + 4.0 / 64) * t["kmers"] + 17.0 * c * t["unitigs"]
     if kernel == "k_strcov_colored":
         return 12.0 * 2.0 * t["site_strings"] * t.get("n_colors", 3)
     return None

@@ -265,6 +265,11 @@ uint32_t pf_num_colors(const pf_ctx *);
  * max < up, else (0, false) -- the caller applies its cutoffs.  [host|dev] */
 int pf_unitig_cov_colored(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *min_count, uint32_t *max_count,
                           uint8_t *miss);
+/* pf_unitig_cov_colored streams a colour-major per-k-mer coverage SoA that the device joins once when graph and databases are
+ * both resident (as pf_unitig_cov does, see there); this is the same function with every k-mer looked up at call time -- the
+ * independent check, and the route for a max_count of 2^32 - 1.  [host|dev] */
+int pf_unitig_cov_colored_probe(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *min_count, uint32_t *max_count,
+                          uint8_t *miss);
 /* CCDBG::readCov(string, low, up, colour) (src/CCDBG.cpp:89-122) for every (string, colour): low / up hold one
  * cutoff per colour; arrays are string-major: x[i * n_colors + c].  ok = 0 (and sum = 0) when a k-mer is
  * missing from colour c's database or a count lies outside (low[c], up[c]).  [host|dev] */

@@ -12,9 +12,12 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <cstdlib>
+#include <cstring>
 #include <string>
 #include <vector>
 
+#include "pf_cov_stream.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
 #include "ploidyfrost_hip.h"
@@ -119,7 +122,8 @@ __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__r
                                                      const uint32_t *__restrict__ len, int k, bool one_strand, uint32_t n_colors,
                                                      uint32_t u0, uint32_t u1, uint64_t unread, uint64_t *__restrict__ out_sum,
                                                      uint32_t *__restrict__ out_min, uint32_t *__restrict__ out_max,
-                                                     uint8_t *__restrict__ out_miss) {
+                                                     uint8_t *__restrict__ out_miss, const uint64_t *__restrict__ kpre,
+                                                     uint32_t *__restrict__ gcov, uint64_t g_stride) {
     const int lane = lane_id();
     const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint32_t n_waves = (gridDim.x * blockDim.x) >> 6;
@@ -137,6 +141,12 @@ __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__r
             for (uint32_t p = lane; p < nk; p += WAVE) {
                 uint32_t cnt[CPP];
                 colored_counts(t, kmer_at(w, p, k), k, one_strand, c0, n_here, cnt);
+                if (gcov) {  // K-COV-C-JOIN: every colour's count goes to the k-mer's place in graph order, nothing is reduced
+#pragma unroll
+                    for (int j = 0; j < CPP; ++j)
+                        if ((uint32_t)j < n_here) gcov[(uint64_t)(c0 + j) * g_stride + kpre[u] + p] = cnt[j];
+                    continue;
+                }
 #pragma unroll
                 for (int j = 0; j < CPP; ++j) {
                     if (cnt[j] == MISSING) { miss[j] = true; continue; }
@@ -145,6 +155,7 @@ __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__r
                     mx[j] = cnt[j] > mx[j] ? cnt[j] : mx[j];
                 }
             }
+            if (gcov) continue;
 #pragma unroll
             for (int j = 0; j < CPP; ++j) {
                 if ((uint32_t)j >= n_here) break;
@@ -165,6 +176,14 @@ __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__r
             }
         }
     }
+}
+
+// results of the streaming K-COV-C before the kernel: nothing seen (also the final answer for colours that are never looked up)
+__global__ void k_ccov_init(uint64_t n, uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min, uint32_t *__restrict__ out_max,
+                            uint8_t *__restrict__ out_miss) {
+    uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) { out_sum[i] = 0; out_min[i] = MISSING; out_max[i] = 0; out_miss[i] = 0; }
 }
 
 // K-STRCOV-C: one thread per (string, colour); out_*[i * n_colors + c]
@@ -214,6 +233,34 @@ bool on_device(const T *p) {
 
 }  // namespace
 
+// K-COV-C-JOIN: the colored counterpart of pf::join_graph_counts (pf_device.hip): one probe of the joined table per graph
+// k-mer leaves every colour's count (all ones = the colour's database lacks the k-mer) at the k-mer's position in graph
+// order, colour-major.  Once per (graph, set of databases); pf_unitig_cov_colored then streams it.  A count equal to the
+// marker cannot be represented: such a set of databases keeps the probing K-COV-C.
+namespace pf {
+int join_graph_counts_colored(pf_ctx *ctx) {
+    ctx->gcov_c_valid = false;
+    if (!ctx->d_seq || !ctx->d_ctab || !ctx->n_colors || !ctx->d_kpre || ctx->n_kmers == 0 || ctx->ctab_max_count >= MISSING) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    const uint64_t stride = (ctx->n_krow + 4) * 64;  // whole super-rows of 256 k-mers, 16-byte aligned slices
+    if (!ctx->d_gcov_c || ctx->gcov_c_stride != stride) {
+        if (ctx->d_gcov_c) { (void)hipFree(ctx->d_gcov_c); ctx->d_gcov_c = nullptr; }
+        PF_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_gcov_c), stride * ctx->n_colors * sizeof(uint32_t)));
+        ctx->gcov_c_stride = stride;
+    }
+    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
+    ctx_begin(ctx, PF_K_COV_JOIN);
+    k_cov_colored<<<ctx_grid(ctx, (uint64_t)ctx->N * 64, 256, 16), 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand,
+                                                                                        ctx->n_colors, 0, ctx->N, ctx->ctab_unread, nullptr, nullptr,
+                                                                                        nullptr, nullptr, ctx->d_kpre, ctx->d_gcov_c, stride);
+    ctx_end(ctx);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->gcov_c_valid = true;
+    return PF_OK;
+}
+}  // namespace pf
+
 extern "C" {
 
 uint32_t pf_num_colors(const pf_ctx *ctx) { return ctx ? ctx->n_colors : 0; }
@@ -230,8 +277,13 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
         biggest = std::max(biggest, n[c]);
     }
     ctx->ctab_unread = 0;
-    for (uint32_t c = 0; c < n_colors; ++c)
+    ctx->ctab_max_count = 0;
+    for (uint32_t c = 0; c < n_colors; ++c) {
         if (!both_strands[c]) ctx->ctab_unread |= 1ull << c;
+        else ctx->ctab_max_count = std::max<uint64_t>(ctx->ctab_max_count, max_count[c]);
+    }
+    if (ctx->d_gcov_c) { (void)hipFree(ctx->d_gcov_c); ctx->d_gcov_c = nullptr; }
+    ctx->gcov_c_valid = false;
     PF_HIP(hipSetDevice(ctx->device));
     if (ctx->d_ctab) { (void)hipFree(ctx->d_ctab); ctx->d_ctab = nullptr; }
     ctx->n_colors = 0;
@@ -277,10 +329,10 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
         ctx->ctab_one_strand = (total && ctx->k) ? h_flag == 0 : false;
     }
     ctx->n_colors = n_colors;
-    return PF_OK;
+    return join_graph_counts_colored(ctx);
 }
 
-int pf_unitig_cov_colored(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint32_t *mx, uint8_t *miss) {
+static int unitig_cov_colored_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint32_t *mx, uint8_t *miss, bool probe) {
     if (!ctx || !ctx->d_seq || !ctx->d_ctab || !ctx->n_colors || u0 > u1 || u1 > ctx->N || !sum || !mn || !mx || !miss) return PF_ERR_ARG;
     if (u0 == u1) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
@@ -296,11 +348,37 @@ int pf_unitig_cov_colored(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, 
         dx = (uint8_t *)ctx_ws(ctx, WS_CCOV_MISS, n);
         if (!ds || !dlo || !dhi || !dx) return PF_ERR_HIP;
     }
-    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
-    const int grid = ctx_grid(ctx, (uint64_t)(u1 - u0) * 64, 256, 16);
+    static const bool env_probe = [] { const char *e = getenv("PF_KCOV_COLORED"); return e && !strcmp(e, "probe"); }();  // measurements: A/B of the two forms
+    probe = probe || env_probe;
+    if (!probe && !ctx->gcov_c_valid) {  // the graph was replaced under the table
+        const int rc = join_graph_counts_colored(ctx);
+        if (rc) return rc;
+    }
+    const bool stream = !probe && ctx->gcov_c_valid;
+    uint64_t g_range[2] = {0, 0};
+    if (stream) {
+        PF_HIP(hipMemcpyAsync(&g_range[0], ctx->d_kpre + u0, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipMemcpyAsync(&g_range[1], ctx->d_kpre + u1, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+    }
     ctx_begin(ctx, PF_K_COV_COLORED);
-    k_cov_colored<<<grid, 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand, ctx->n_colors, u0, u1,
-                                                 ctx->ctab_unread, ds, dlo, dhi, dx);
+    if (stream) {
+        // streaming form (pf_cov_stream.hpp): one grid row per colour over that colour's slice of the coverage SoA
+        const uint64_t sr_begin = g_range[0] / 256, sr_end = (g_range[1] + 255) / 256;
+        const dim3 grid4((unsigned)(((sr_end - sr_begin + KC4_SR - 1) / KC4_SR + 3) / 4), ctx->n_colors);
+        k_ccov_init<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(n, ds, dlo, dhi, dx);
+        if (ctx->ctab_max_count < (1ull << 20))
+            k_cov_stream4<false, true><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov_c, ctx->gcov_c_stride, ctx->ctab_unread, ctx->d_khead, ctx->d_krow, u0,
+                                                                       u1 - u0, g_range[0], g_range[1], sr_begin, sr_end, ds, dlo, dhi, dx);
+        else
+            k_cov_stream4<true, true><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov_c, ctx->gcov_c_stride, ctx->ctab_unread, ctx->d_khead, ctx->d_krow, u0,
+                                                                      u1 - u0, g_range[0], g_range[1], sr_begin, sr_end, ds, dlo, dhi, dx);
+    } else {
+        const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
+        const int grid = ctx_grid(ctx, (uint64_t)(u1 - u0) * 64, 256, 16);
+        k_cov_colored<<<grid, 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand, ctx->n_colors, u0, u1,
+                                                     ctx->ctab_unread, ds, dlo, dhi, dx, nullptr, nullptr, 0);
+    }
     ctx_end(ctx);
     if (!dev_out) {
         PF_HIP(hipMemcpyAsync(sum, ds, n * 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -310,6 +388,14 @@ int pf_unitig_cov_colored(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, 
         PF_HIP(hipStreamSynchronize(ctx->stream));
     }
     return PF_OK;
+}
+
+int pf_unitig_cov_colored(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint32_t *mx, uint8_t *miss) {
+    return unitig_cov_colored_impl(ctx, u0, u1, sum, mn, mx, miss, false);
+}
+
+int pf_unitig_cov_colored_probe(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint32_t *mx, uint8_t *miss) {
+    return unitig_cov_colored_impl(ctx, u0, u1, sum, mn, mx, miss, true);
 }
 
 int pf_string_cov_colored(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32_t n_str, const uint32_t *low,

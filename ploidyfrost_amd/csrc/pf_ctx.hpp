@@ -76,6 +76,11 @@ struct pf_ctx {
     uint32_t ctab_shift = 4, n_colors = 0;
     bool ctab_one_strand = false;
     uint64_t ctab_unread = 0;   // colours whose database was written without canonical counting: never looked up
+    uint64_t ctab_max_count = 0;  // largest upper count filter among the colours that are looked up
+    // colored per-k-mer coverage SoA: colour c's count of graph k-mer g at d_gcov_c[c * gcov_c_stride + g] (K-COV-C-JOIN)
+    uint32_t *d_gcov_c = nullptr;
+    uint64_t gcov_c_stride = 0;
+    bool gcov_c_valid = false;
 
     // reusable result staging for host-pointer callers
     uint64_t *d_cov_sum = nullptr;
@@ -100,7 +105,8 @@ namespace pf {
 int ctx_begin(pf_ctx *ctx, int kernel);
 void ctx_end(pf_ctx *ctx);
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
-int join_graph_counts(pf_ctx *ctx);  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
+int join_graph_counts(pf_ctx *ctx);
+int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the joined table of all colours (pf_ctx::d_gcov_c)  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
 // device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
 enum WsSlot {

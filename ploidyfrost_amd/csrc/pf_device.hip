@@ -17,6 +17,7 @@
 
 #include "pf_bfs.hpp"
 #include "pf_bfs_huge.hpp"
+#include "pf_cov_stream.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
 #include "ploidyfrost_hip.h"
@@ -309,21 +310,6 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
 // per (row, unitig).
 constexpr int KCS_ROWS = 8;
 
-// one DPP move: lanes the control leaves without a source (or outside row_mask) keep `old`
-template <int CTRL, int ROW_MASK>
-__device__ inline uint32_t dpp_u32(uint32_t old, uint32_t v) {
-    return (uint32_t)__builtin_amdgcn_update_dpp((int)old, (int)v, CTRL, ROW_MASK, 0xF, false);
-}
-template <int CTRL, int ROW_MASK>
-__device__ inline unsigned long long dpp_u64(unsigned long long old, unsigned long long v) {
-    const uint32_t lo = dpp_u32<CTRL, ROW_MASK>((uint32_t)old, (uint32_t)v), hi = dpp_u32<CTRL, ROW_MASK>((uint32_t)(old >> 32), (uint32_t)(v >> 32));
-    return ((unsigned long long)hi << 32) | lo;
-}
-template <int CTRL, int ROW_MASK>
-__device__ inline uint32_t dpp_any(uint32_t old, uint32_t v) { return dpp_u32<CTRL, ROW_MASK>(old, v); }
-template <int CTRL, int ROW_MASK>
-__device__ inline unsigned long long dpp_any(unsigned long long old, unsigned long long v) { return dpp_u64<CTRL, ROW_MASK>(old, v); }
-
 // DPP = true: the segmented scan runs on the VALU's data-parallel primitives (row_shr 1/2/4/8 inside rows of 16 lanes, then
 // row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) instead of twelve ds_bpermute per row through the LDS crossbar.
 template <bool WIDE, bool DPP>
@@ -418,190 +404,6 @@ __global__ __launch_bounds__(256) void k_cov_stream(const uint32_t *__restrict__
                 if (miss) out_miss[o] = 1;
             }
         }
-    }
-}
-
-// K-COV, streaming form with four k-mers per lane (the default): a lane takes 16 contiguous bytes of gcov (one dwordx4
-// load), reduces its four k-mers serially -- `pre` = the k-mers before the lane's first unitig start, `suf` = those from its
-// last unitig start on, both = all four when no unitig starts in the lane -- and the wavefront scans 64 lane aggregates
-// instead of 64 k-mers: a quarter of the scan work per k-mer, which is what bounded the one-k-mer-per-lane form (VALU issue,
-// not bytes).  A window is KC4_SR super-rows of 256 k-mers handled in order with a wave-uniform carry, so a unitig whose
-// first and last k-mer lie in one window (2048 k-mers) is reduced completely in registers and written with plain stores;
-// only what crosses a window border goes through atomics (about two per window instead of two per row and unitig).
-//   lane with a unitig start at its k-mer i0: closes the unitig running up to i0 - 1 (value = scan of the lane before, or
-//   the carry for lane 0, + pre), plain store if that unitig began inside the window, atomics otherwise;
-//   further starts inside the same lane delimit unitigs of <= 3 k-mers, stored directly;
-//   the open unitig at the end of the window is flushed with atomics.
-constexpr int KC4_SR = 8;   // measured at 1 M unitigs: 4 -> 0.093 ms, 8 -> 0.072 ms, 16 -> 0.081 ms (profiles/r01j_kcov_stream.txt)
-
-// Segmented inclusive scan (sum, min) over the 64 lanes; segments begin at the lanes set in `heads`.  `d` = distance from
-// the lane to the last segment start at or below it (>= 64: none) turns every "same segment?" test into a 32-bit compare.
-__device__ inline int seg_distance(uint64_t heads, int lane) {
-    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);
-    const uint64_t m = heads & le_mask;
-    return m ? lane - (63 - __clzll((long long)m)) : 127;
-}
-
-template <typename S>
-__device__ inline void seg_scan_dpp(S &sum, uint32_t &mn, int d, int lane) {
-    const int li = lane & 15;
-#define PF_SCAN_ROW_STEP(O)                                                                             \
-    {                                                                                                   \
-        const S so = dpp_any<0x110 | (O), 0xF>((S)0, sum);                                              \
-        const uint32_t mo = dpp_any<0x110 | (O), 0xF>(0xFFFFFFFFu, mn);                                 \
-        if (li >= (O) && d >= (O)) {   /* no segment starts at lanes lane - O + 1 .. lane */            \
-            sum += so;                                                                                  \
-            mn = mo < mn ? mo : mn;                                                                     \
-        }                                                                                               \
-    }
-    PF_SCAN_ROW_STEP(1)
-    PF_SCAN_ROW_STEP(2)
-    PF_SCAN_ROW_STEP(4)
-    PF_SCAN_ROW_STEP(8)
-#undef PF_SCAN_ROW_STEP
-    {
-        const S so = dpp_any<0x142, 0xA>((S)0, sum);          // row_bcast:15 -> rows 1, 3
-        const uint32_t mo = dpp_any<0x142, 0xA>(0xFFFFFFFFu, mn);
-        if ((lane & 16) && d > li) {                          // nothing starts between the row's first lane and this one
-            sum += so;
-            mn = mo < mn ? mo : mn;
-        }
-    }
-    {
-        const S so = dpp_any<0x143, 0xC>((S)0, sum);          // row_bcast:31 -> rows 2, 3
-        const uint32_t mo = dpp_any<0x143, 0xC>(0xFFFFFFFFu, mn);
-        if (lane >= 32 && d > lane - 32) {
-            sum += so;
-            mn = mo < mn ? mo : mn;
-        }
-    }
-}
-
-template <typename S>
-__device__ inline void kc4_emit(uint32_t o, uint32_t n_out, S sum, uint32_t mn, bool complete, uint64_t *__restrict__ out_sum,
-                                uint32_t *__restrict__ out_min) {
-    if (o >= n_out) return;
-    if (complete) {
-        out_sum[o] = (uint64_t)sum;
-        out_min[o] = mn < 10000u ? mn : 10000u;  // min initialised 10000: src/CDBG.cpp:71
-    } else {
-        atomicAdd(reinterpret_cast<unsigned long long *>(out_sum + o), (unsigned long long)sum);
-        if (mn != 0xFFFFFFFFu) atomicMin(out_min + o, mn);
-    }
-}
-
-template <bool WIDE>
-__global__ __launch_bounds__(256) void k_cov_stream4(const uint32_t *__restrict__ gcov, const uint64_t *__restrict__ khead,
-                                                     const uint32_t *__restrict__ krow, uint32_t u0, uint32_t n_out, uint64_t g_begin,
-                                                     uint64_t g_end, uint64_t sr_begin, uint64_t sr_end, uint64_t *__restrict__ out_sum,
-                                                     uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
-    typedef typename std::conditional<WIDE, unsigned long long, uint32_t>::type sum_t;
-    const int lane = lane_id();
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t n_win = (sr_end - sr_begin + KC4_SR - 1) / KC4_SR;
-    const int w = lane >> 4, sh = (lane & 15) * 4;
-    const uint64_t lt_mask = (1ull << lane) - 1;                         // lanes below
-    for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
-        const uint64_t sr0 = sr_begin + wx * KC4_SR;
-        uint4 c[KC4_SR];
-#pragma unroll
-        for (int j = 0; j < KC4_SR; ++j)
-            c[j] = sr0 + j < sr_end ? *reinterpret_cast<const uint4 *>(gcov + (sr0 + j) * 256 + 4 * lane) : make_uint4(0, 0, 0, 0);
-        sum_t csum = 0;           // carry: the unitig open at the end of the super-row before (wave-uniform)
-        uint32_t cmin = 0xFFFFFFFFu;
-        bool cstarted = false;    // ... began inside this window
-        uint32_t ulast = 0;
-#pragma unroll
-        for (int j = 0; j < KC4_SR; ++j) {
-            const uint64_t sr = sr0 + j;
-            if (sr >= sr_end) break;
-            const uint64_t H0 = khead[sr * 4], H1 = khead[sr * 4 + 1], H2 = khead[sr * 4 + 2], H3 = khead[sr * 4 + 3];
-            const uint32_t kb = krow[sr * 4];
-            const uint64_t g0 = sr * 256;
-            const bool edge = g0 < g_begin || g0 + 256 > g_end;
-            const uint64_t word = w == 0 ? H0 : w == 1 ? H1 : w == 2 ? H2 : H3;
-            const uint32_t h = (uint32_t)(word >> sh) & 0xFu;
-            const uint32_t below = (w > 0 ? __popcll(H0) : 0) + (w > 1 ? __popcll(H1) : 0) + (w > 2 ? __popcll(H2) : 0) +
-                                   __popcll(word & ((2ull << sh) - 1));
-            const uint32_t ub = kb + below - (uint32_t)(H0 & 1);  // unitig of the lane's first k-mer
-            uint32_t v[4] = {c[j].x, c[j].y, c[j].z, c[j].w};
-            if (edge) {  // k-mers outside [g_begin, g_end) (other unitigs, or the padding past the last k-mer) count as absent
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint64_t g = g0 + 4 * lane + i;
-                    v[i] = (g >= g_begin && g < g_end) ? v[i] : GCOV_MISSING;
-                }
-            }
-            sum_t s[4];
-            bool anymiss = false;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const bool x = v[i] == GCOV_MISSING;
-                anymiss |= x;
-                s[i] = x ? 0u : v[i];
-            }
-            if (anymiss) {
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const uint32_t o = ub + __popc((h >> 1) & ((1u << i) - 1)) - u0;
-                    if (v[i] == GCOV_MISSING && o < n_out) out_miss[o] = 1;
-                }
-            }
-            // pre: k-mers with no unitig start at or before them; suf: k-mers with no unitig start after them
-            sum_t ps = 0, ss = 0;
-            uint32_t pm = 0xFFFFFFFFu, sm = 0xFFFFFFFFu;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                if ((h & ((2u << i) - 1)) == 0) { ps += s[i]; pm = v[i] < pm ? v[i] : pm; }
-                if ((h >> (i + 1)) == 0) { ss += s[i]; sm = v[i] < sm ? v[i] : sm; }
-            }
-            if (h & (h - 1)) {  // two or more starts in the lane: the unitigs between them are complete here
-#pragma unroll
-                for (int i = 0; i < 3; ++i) {
-                    if (((h >> i) & 1) && (h >> (i + 1))) {
-                        sum_t es = 0;
-                        uint32_t em = 0xFFFFFFFFu;
-                        bool in = true;
-#pragma unroll
-                        for (int q = i; q < 4; ++q) {
-                            if (q > i && ((h >> q) & 1)) in = false;
-                            if (in) { es += s[q]; em = v[q] < em ? v[q] : em; }
-                        }
-                        kc4_emit<sum_t>(ub + __popc((h >> 1) & ((1u << i) - 1)) - u0, n_out, es, em, true, out_sum, out_min);
-                    }
-                }
-            }
-            const uint64_t F = __ballot(h != 0);
-            sum_t vs = ss;
-            uint32_t vm = sm;
-            const int d = seg_distance(F, lane);
-            seg_scan_dpp<sum_t>(vs, vm, d, lane);
-            if (d > lane) {  // no start at or below this lane: still inside the unitig carried in
-                vs += csum;
-                vm = cmin < vm ? cmin : vm;
-            }
-            sum_t prev_s = __shfl_up(vs, 1, WAVE);
-            uint32_t prev_m = __shfl_up(vm, 1, WAVE);
-            if (lane == 0) { prev_s = csum; prev_m = cmin; }
-            if (h != 0 && !(j == 0 && lane == 0 && (h & 1))) {  // (a start on the window's first k-mer closes nothing of this window)
-                const sum_t es = prev_s + ps;
-                const uint32_t em = prev_m < pm ? prev_m : pm;
-                const bool started = (F & lt_mask) != 0 || cstarted;
-                kc4_emit<sum_t>(ub - (h & 1u) - u0, n_out, es, em, started, out_sum, out_min);
-            }
-            if (WIDE) {
-                csum = ((unsigned long long)__builtin_amdgcn_readlane((int)(uint32_t)((unsigned long long)vs >> 32), 63) << 32) |
-                       (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)vs, 63);
-            } else {
-                csum = (sum_t)(uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)vs, 63);
-            }
-            cmin = (uint32_t)__builtin_amdgcn_readlane((int)vm, 63);
-            cstarted = cstarted || F != 0;
-            ulast = (uint32_t)__builtin_amdgcn_readlane((int)(ub + __popc(h >> 1)), 63);
-        }
-        if (lane == 0) kc4_emit<sum_t>(ulast - u0, n_out, csum, cmin, false, out_sum, out_min);
     }
 }
 
@@ -919,8 +721,10 @@ static void free_graph(pf_ctx *ctx) {
     hipFree(ctx->d_pred16);
     hipFree(ctx->d_kpre);
     hipFree(ctx->d_kwin);
-    hipFree(ctx->d_gcov); hipFree(ctx->d_khead); hipFree(ctx->d_krow);
+    hipFree(ctx->d_gcov); hipFree(ctx->d_khead); hipFree(ctx->d_krow); hipFree(ctx->d_gcov_c);
     ctx->d_gcov = nullptr;
+    ctx->d_gcov_c = nullptr;
+    ctx->gcov_c_valid = false;
     ctx->d_khead = nullptr;
     ctx->d_krow = nullptr;
     ctx->gcov_valid = false;
@@ -1327,9 +1131,9 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
             const int grid4 = (int)(((sr_end - sr_begin + KC4_SR - 1) / KC4_SR + 3) / 4);
             // a window's carry sums up to KC4_SR * 256 counts in the narrow type
             if (ctx->tab_max_count < (1ull << 20))
-                k_cov_stream4<false><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, dx);
+                k_cov_stream4<false, false><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, nullptr, dx);
             else
-                k_cov_stream4<true><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, dx);
+                k_cov_stream4<true, false><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, nullptr, dx);
         } else {
         const bool dpp = form == 1;
         const bool wide = ctx->tab_max_count >= (1ull << 25);

@@ -89,6 +89,7 @@ def load_library() -> C.CDLL:
         "pf_upload_counts_colored": (i, [vp, u32, vp, vp, vp, vp, vp, vp]),
         "pf_num_colors": (u32, [vp]),
         "pf_unitig_cov_colored": (i, [vp, u32, u32, vp, vp, vp, vp]),
+        "pf_unitig_cov_colored_probe": (i, [vp, u32, u32, vp, vp, vp, vp]),
         "pf_string_cov_colored": (i, [vp, vp, vp, u32, vp, vp, vp, vp]),
         "pf_unitig_cov_exact": (i, [vp, u32, u32, i, vp, vp, vp]),
         "pf_minimizer_table_slots": (u64, [u64]),
@@ -114,7 +115,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
-                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe"]
+                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe"]
 
 
 def pack_unitigs(seqs: list[bytes]):
@@ -270,15 +271,16 @@ class Device:
         both = np.array([int(d[2]) if len(d) > 2 else 1 for d in dbs], dtype=np.int32)
         self._check(self.L.pf_upload_counts_colored(self.h, nc, pk, pc, n.ctypes.data, mn.ctypes.data, mx.ctypes.data, both.ctypes.data))
 
-    def unitig_cov_colored(self, u0=0, u1=None):
-        """(sum, min, max, miss), each [n_colors, u1 - u0]"""
+    def unitig_cov_colored(self, u0=0, u1=None, probe=False):
+        """(sum, min, max, miss), each [n_colors, u1 - u0]; probe: pf_unitig_cov_colored_probe (table look-ups at call time)"""
         u1 = self.n if u1 is None else u1
         shape = (self.n_colors, u1 - u0)
         s = np.zeros(shape, dtype=np.uint64)
         lo = np.zeros(shape, dtype=np.uint32)
         hi = np.zeros(shape, dtype=np.uint32)
         x = np.zeros(shape, dtype=np.uint8)
-        self._check(self.L.pf_unitig_cov_colored(self.h, u0, u1, _ptr(s), _ptr(lo), _ptr(hi), _ptr(x)))
+        fn = self.L.pf_unitig_cov_colored_probe if probe else self.L.pf_unitig_cov_colored
+        self._check(fn(self.h, u0, u1, _ptr(s), _ptr(lo), _ptr(hi), _ptr(x)))
         return s, lo, hi, x
 
     def string_cov_colored(self, strings: list[bytes], low, up):

@@ -51,6 +51,32 @@ def test_unitig_coverage_per_colour_matches_oracle(case):
 
 
 @pytest.mark.parametrize("case", colored_cases())
+def test_unitig_coverage_streamed_equals_probed(case):
+    """K-COV-C streams the colour-major coverage SoA joined at load; pf_unitig_cov_colored_probe looks every k-mer up at call
+    time.  Same function (src/CCDBG.cpp:123-156), two routes: whole range, ragged sub-ranges, single unitigs."""
+    meta = load_case(case)
+    o, dev, seqs, _ = _device_with_colours(meta)
+    full = dev.unitig_cov_colored()
+    probed = dev.unitig_cov_colored(probe=True)
+    for a, b in zip(full, probed):
+        assert np.array_equal(a, b)
+    rng = np.random.default_rng(3)
+    spans = [(int(a), int(b)) for a, b in ((rng.integers(0, dev.n), 0) for _ in range(5))]
+    spans = [(a, int(rng.integers(a + 1, dev.n + 1))) for a, _ in spans] + [(0, 1), (dev.n - 1, dev.n)]
+    for u0, u1 in spans:
+        part = dev.unitig_cov_colored(u0, u1)
+        for a, b in zip(part, full):
+            assert np.array_equal(a, b[:, u0:u1]), (case, u0, u1)
+    # a new graph under the same table is joined again on the next call
+    words, off, lens = hipapi.pack_unitigs(seqs)
+    dev.upload_graph(words, off, lens, o.k)
+    again = dev.unitig_cov_colored()
+    for a, b in zip(again, full):
+        assert np.array_equal(a, b)
+    dev.close()
+
+
+@pytest.mark.parametrize("case", colored_cases())
 def test_string_coverage_per_colour_matches_oracle(case):
     """K-STRCOV-C == readCov(string, low, up, colour) (src/CCDBG.cpp:89-122)."""
     meta = load_case(case)
