@@ -245,7 +245,11 @@ int join_graph_counts_colored(pf_ctx *ctx) {
     const uint64_t stride = (ctx->n_krow + 4) * 64;  // whole super-rows of 256 k-mers, 16-byte aligned slices
     if (!ctx->d_gcov_c || ctx->gcov_c_stride != stride) {
         if (ctx->d_gcov_c) { (void)hipFree(ctx->d_gcov_c); ctx->d_gcov_c = nullptr; }
-        PF_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_gcov_c), stride * ctx->n_colors * sizeof(uint32_t)));
+        if (hipMalloc(reinterpret_cast<void **>(&ctx->d_gcov_c), stride * ctx->n_colors * sizeof(uint32_t)) != hipSuccess) {
+            (void)hipGetLastError();  // no room for the SoA: pf_unitig_cov_colored keeps probing the table every pass (same results)
+            ctx->d_gcov_c = nullptr;
+            return PF_OK;
+        }
         ctx->gcov_c_stride = stride;
     }
     const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};

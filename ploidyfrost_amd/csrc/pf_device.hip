@@ -646,7 +646,11 @@ int join_graph_counts(pf_ctx *ctx) {
     ctx->gcov_valid = false;
     if (!ctx->d_seq || !ctx->d_tab || ctx->tab_exact || ctx->tab_max_count >= GCOV_MISSING || ctx->n_kmers == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
-    if (!ctx->d_gcov) PF_HIP(hipMalloc(&ctx->d_gcov, ((ctx->n_krow + 4) * 64) * sizeof(uint32_t)));  // whole super-rows of 256
+    if (!ctx->d_gcov && hipMalloc(&ctx->d_gcov, ((ctx->n_krow + 4) * 64) * sizeof(uint32_t)) != hipSuccess) {  // whole super-rows of 256
+        (void)hipGetLastError();  // no room for the SoA: pf_unitig_cov keeps probing the table every pass (same results)
+        ctx->d_gcov = nullptr;
+        return PF_OK;
+    }
     const uint64_t n_win = (ctx->n_kmers + KCOV_WIN - 1) / KCOV_WIN;
     ctx_begin(ctx, PF_K_COV_JOIN);
     k_cov<<<ctx_grid(ctx, n_win * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
