@@ -368,15 +368,11 @@ static int unitig_cov_colored_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64
     ctx_begin(ctx, PF_K_COV_COLORED);
     if (stream) {
         // streaming form (pf_cov_stream.hpp): one grid row per colour over that colour's slice of the coverage SoA
-        const uint64_t sr_begin = g_range[0] / 256, sr_end = (g_range[1] + 255) / 256;
-        const dim3 grid4((unsigned)(((sr_end - sr_begin + KC4_SR - 1) / KC4_SR + 3) / 4), ctx->n_colors);
         k_ccov_init<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(n, ds, dlo, dhi, dx);
-        if (ctx->ctab_max_count < (1ull << 20))
-            k_cov_stream4<false, true><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov_c, ctx->gcov_c_stride, ctx->ctab_unread, ctx->d_khead, ctx->d_krow, u0,
-                                                                       u1 - u0, g_range[0], g_range[1], sr_begin, sr_end, ds, dlo, dhi, dx);
-        else
-            k_cov_stream4<true, true><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov_c, ctx->gcov_c_stride, ctx->ctab_unread, ctx->d_khead, ctx->d_krow, u0,
-                                                                      u1 - u0, g_range[0], g_range[1], sr_begin, sr_end, ds, dlo, dhi, dx);
+        Kc4Args a{ctx->d_gcov_c, ctx->gcov_c_stride, ctx->ctab_unread, ctx->d_khead, ctx->d_krow, u0, u1 - u0, g_range[0], g_range[1],
+                  g_range[0] / 256, (g_range[1] + 255) / 256, ds, dlo, dhi, dx};
+        const int rc = launch_cov_stream(ctx, a, ctx->n_colors, ctx->ctab_max_count >= (1ull << 20), true);
+        if (rc) return rc;
     } else {
         const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
         const int grid = ctx_grid(ctx, (uint64_t)(u1 - u0) * 64, 256, 16);

@@ -71,6 +71,42 @@ __device__ inline void seg_scan_dpp(S &sum, uint32_t &mn, uint32_t &mx, int d, i
 #undef PF_SCAN_STEP
 }
 
+// The same scan for narrow counts (every value below 2^26, sums below 2^32) without a single per-step condition: the sum is
+// an ordinary inclusive prefix sum minus the prefix at the lane before the segment's first lane (one gather); min and max
+// are ordinary scans of keys that carry the segment's first lane S above the value -- (63 - S) << 26 | v for the min, so
+// that lanes of earlier segments can never win, S << 26 | v for the max.  6 fused DPP operations per quantity instead of
+// 6 x (two moves, a test, two selects, the operation).
+template <int OP>  // 0 add, 1 min, 2 max
+__device__ inline uint32_t scan_u32_dpp(uint32_t x) {
+    const uint32_t ident = OP == 1 ? 0xFFFFFFFFu : 0u;
+#define PF_USCAN_STEP(CTRL, MASK)                                            \
+    {                                                                        \
+        const uint32_t y = dpp_u32<CTRL, MASK>(ident, x);                    \
+        x = OP == 0 ? x + y : OP == 1 ? (y < x ? y : x) : (y > x ? y : x);   \
+    }
+    PF_USCAN_STEP(0x111, 0xF)
+    PF_USCAN_STEP(0x112, 0xF)
+    PF_USCAN_STEP(0x114, 0xF)
+    PF_USCAN_STEP(0x118, 0xF)
+    PF_USCAN_STEP(0x142, 0xA)
+    PF_USCAN_STEP(0x143, 0xC)
+#undef PF_USCAN_STEP
+    return x;
+}
+
+template <bool MAXV>
+__device__ inline void seg_scan_narrow(uint32_t &sum, uint32_t &mn, uint32_t &mx, int d, int lane) {
+    constexpr uint32_t K26 = (1u << 26) - 1;
+    const int S = d < 64 ? lane - d : 0;  // first lane of this lane's segment (0: the segment carried in)
+    const uint32_t P = scan_u32_dpp<0>(sum);
+    const uint32_t before = __shfl(P, S > 0 ? S - 1 : 0, WAVE);
+    sum = P - (S > 0 ? before : 0u);
+    uint32_t key = ((uint32_t)(63 - S) << 26) | (mn > K26 ? K26 : mn);
+    key = scan_u32_dpp<1>(key) & K26;
+    mn = key == K26 ? 0xFFFFFFFFu : key;
+    if (MAXV) mx = scan_u32_dpp<2>(((uint32_t)S << 26) | mx) & K26;
+}
+
 // one finished (complete) or partial piece of a unitig.  CAP10K: C1's "min initialised 10000" (src/CDBG.cpp:71); the colored
 // twin has no such cap and keeps a max (src/CCDBG.cpp:123-156)
 template <typename S, bool COLORED>
@@ -98,43 +134,35 @@ __device__ inline unsigned long long readlane63<unsigned long long>(unsigned lon
            (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)v, 63);
 }
 
-// COLORED: blockIdx.y = colour; its counts at gcov + colour * g_stride, its results at out_* + colour * n_out
-// (colour-major, the layout of pf_unitig_cov_colored); colours in `unread` are left as the init kernel wrote them.
-template <bool WIDE, bool COLORED>
-__global__ __launch_bounds__(256) void k_cov_stream4(const uint32_t *__restrict__ gcov, uint64_t g_stride, uint64_t unread,
-                                                     const uint64_t *__restrict__ khead, const uint32_t *__restrict__ krow, uint32_t u0,
-                                                     uint32_t n_out, uint64_t g_begin, uint64_t g_end, uint64_t sr_begin, uint64_t sr_end,
-                                                     uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min,
-                                                     uint32_t *__restrict__ out_max, uint8_t *__restrict__ out_miss) {
+// what a launch of the streaming kernels works on
+struct Kc4Args {
+    const uint32_t *gcov;
+    uint64_t g_stride, unread;      // colored: slice stride of gcov, colours never looked up
+    const uint64_t *khead;
+    const uint32_t *krow;
+    uint32_t u0, n_out;
+    uint64_t g_begin, g_end, sr_begin, sr_end;
+    uint64_t *out_sum;
+    uint32_t *out_min, *out_max;
+    uint8_t *out_miss;
+};
+
+// one window: NSR super-rows starting at sr0, their counts already requested into c
+template <bool WIDE, bool COLORED, int NSR>
+__device__ inline void kc4_window(const uint4 (&c)[NSR], uint64_t sr0, int lane, const uint64_t *__restrict__ khead,
+                                  const uint32_t *__restrict__ krow, uint32_t u0, uint32_t n_out, uint64_t g_begin, uint64_t g_end,
+                                  uint64_t sr_end, uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min,
+                                  uint32_t *__restrict__ out_max, uint8_t *__restrict__ out_miss) {
     typedef typename std::conditional<WIDE, unsigned long long, uint32_t>::type sum_t;
-    if (COLORED) {
-        const uint32_t colour = blockIdx.y;
-        if ((unread >> colour) & 1) return;
-        gcov += (uint64_t)colour * g_stride;
-        out_sum += (uint64_t)colour * n_out;
-        out_min += (uint64_t)colour * n_out;
-        out_max += (uint64_t)colour * n_out;
-        out_miss += (uint64_t)colour * n_out;
-    }
-    const int lane = lane_id();
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row metadata comes through scalar loads
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t n_win = (sr_end - sr_begin + KC4_SR - 1) / KC4_SR;
     const int w = lane >> 4, sh = (lane & 15) * 4;
     const uint64_t lt_mask = (1ull << lane) - 1;                         // lanes below
-    for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
-        const uint64_t sr0 = sr_begin + wx * KC4_SR;
-        uint4 c[KC4_SR];
-#pragma unroll
-        for (int j = 0; j < KC4_SR; ++j)
-            c[j] = sr0 + j < sr_end ? *reinterpret_cast<const uint4 *>(gcov + (sr0 + j) * 256 + 4 * lane) : make_uint4(0, 0, 0, 0);
+    {
         sum_t csum = 0;           // carry: the unitig open at the end of the super-row before (wave-uniform)
         uint32_t cmin = 0xFFFFFFFFu, cmax = 0;
         bool cstarted = false;    // ... began inside this window
         uint32_t ulast = 0;
 #pragma unroll
-        for (int j = 0; j < KC4_SR; ++j) {
+        for (int j = 0; j < NSR; ++j) {
             const uint64_t sr = sr0 + j;
             if (sr >= sr_end) break;
             const uint64_t H0 = khead[sr * 4], H1 = khead[sr * 4 + 1], H2 = khead[sr * 4 + 2], H3 = khead[sr * 4 + 3];
@@ -209,7 +237,8 @@ __global__ __launch_bounds__(256) void k_cov_stream4(const uint32_t *__restrict_
             sum_t vs = ss;
             uint32_t vm = sm, vx = sx;
             const int d = seg_distance(F, lane);
-            seg_scan_dpp<sum_t, COLORED>(vs, vm, vx, d, lane);
+            if constexpr (WIDE) seg_scan_dpp<sum_t, COLORED>(vs, vm, vx, d, lane);
+            else seg_scan_narrow<COLORED>(vs, vm, vx, d, lane);   // counts < 2^20 (the launch condition): keys and sums fit
             if (d > lane) {  // no start at or below this lane: still inside the unitig carried in
                 vs += csum;
                 vm = cmin < vm ? cmin : vm;
@@ -233,6 +262,44 @@ __global__ __launch_bounds__(256) void k_cov_stream4(const uint32_t *__restrict_
             ulast = readlane63<uint32_t>(ub + __popc(h >> 1));
         }
         if (lane == 0) kc4_emit<sum_t, COLORED>(ulast - u0, n_out, csum, cmin, cmax, false, out_sum, out_min, out_max);
+    }
+}
+
+template <int NSR>
+__device__ inline void kc4_load(uint4 (&c)[NSR], const uint32_t *__restrict__ gcov, uint64_t sr0, uint64_t sr_end, int lane) {
+#pragma unroll
+    for (int j = 0; j < NSR; ++j)
+        c[j] = sr0 + j < sr_end ? *reinterpret_cast<const uint4 *>(gcov + (sr0 + j) * 256 + 4 * lane) : make_uint4(0, 0, 0, 0);
+}
+
+// COLORED: blockIdx.y = colour; its counts at gcov + colour * g_stride, its results at out_* + colour * n_out
+// (colour-major, the layout of pf_unitig_cov_colored); colours in `unread` are left as the init kernel wrote them.
+// One wavefront per window of KC4_SR super-rows, uncapped grid.  Measured alternatives at 1 M unitigs (0.072 ms for this form,
+// profiles/r01o_kcov_forms.txt): a persistent grid of resident wavefronts with round-robin windows of 4 super-rows and the
+// next window's loads in flight during the reduction: 0.106-0.115 ms (4-7 blocks per CU); the same with windows handed out
+// through one atomic counter: 0.59 ms (45 000 returning atomics on one address).
+template <bool WIDE, bool COLORED>
+__global__ __launch_bounds__(256) void k_cov_stream4(Kc4Args a) {
+    if (COLORED) {
+        const uint32_t colour = blockIdx.y;
+        if ((a.unread >> colour) & 1) return;
+        a.gcov += (uint64_t)colour * a.g_stride;
+        a.out_sum += (uint64_t)colour * a.n_out;
+        a.out_min += (uint64_t)colour * a.n_out;
+        a.out_max += (uint64_t)colour * a.n_out;
+        a.out_miss += (uint64_t)colour * a.n_out;
+    }
+    const int lane = lane_id();
+    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row metadata comes through scalar loads
+    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
+    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
+    const uint64_t n_win = (a.sr_end - a.sr_begin + KC4_SR - 1) / KC4_SR;
+    for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
+        const uint64_t sr0 = a.sr_begin + wx * KC4_SR;
+        uint4 c[KC4_SR];
+        kc4_load<KC4_SR>(c, a.gcov, sr0, a.sr_end, lane);
+        kc4_window<WIDE, COLORED, KC4_SR>(c, sr0, lane, a.khead, a.krow, a.u0, a.n_out, a.g_begin, a.g_end, a.sr_end, a.out_sum, a.out_min,
+                                          a.out_max, a.out_miss);
     }
 }
 

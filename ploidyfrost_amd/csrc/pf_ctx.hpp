@@ -102,6 +102,8 @@ struct pf_ctx {
 };
 
 namespace pf {
+struct Kc4Args;
+int launch_cov_stream(pf_ctx *ctx, Kc4Args a, uint32_t n_colors, bool wide, bool colored);  // pf_device.hip
 int ctx_begin(pf_ctx *ctx, int kernel);
 void ctx_end(pf_ctx *ctx);
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);

@@ -636,6 +636,25 @@ int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu) {
 
 }  // namespace pf
 
+// Launch of the streaming coverage kernel (pf_cov_stream.hpp) for K-COV and K-COV-C: one wavefront per window.
+namespace pf {
+int launch_cov_stream(pf_ctx *ctx, Kc4Args a, uint32_t n_colors, bool wide, bool colored) {
+    const uint64_t n_sr = a.sr_end - a.sr_begin;
+    // four wavefronts per block: the hardware hands out blocks as wavefronts retire (a capped grid-stride launch leaves 3.7
+    // windows per wavefront at 1 M unitigs: a quarter of the chip idle in the last round)
+    const dim3 grid((unsigned)(((n_sr + KC4_SR - 1) / KC4_SR + 3) / 4), n_colors);
+    if (colored) {
+        if (wide) k_cov_stream4<true, true><<<grid, 256, 0, ctx->stream>>>(a);
+        else k_cov_stream4<false, true><<<grid, 256, 0, ctx->stream>>>(a);
+    } else {
+        if (wide) k_cov_stream4<true, false><<<grid, 256, 0, ctx->stream>>>(a);
+        else k_cov_stream4<false, false><<<grid, 256, 0, ctx->stream>>>(a);
+    }
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+}  // namespace pf
+
 // K-COV-JOIN: hash join of the graph's k-mers with the count table, once per (graph, database): every graph k-mer's canonical
 // count (K2 + K3 composite, filter [min_count, max_count] applied at table build) lands at its position in graph order.
 // This is the load-time counterpart of K-ADJ: what CDBG::readCov looks up k-mer by k-mer (src/CDBG.cpp:66-120) becomes a
@@ -1124,20 +1143,16 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
         // streaming form: rows of 64 k-mers, KCS_ROWS rows per wavefront window
         const uint64_t r_begin = g_range[0] / 64, r_end = (g_range[1] + 63) / 64;
         const int grid = ctx_grid(ctx, (r_end - r_begin + KCS_ROWS - 1) / KCS_ROWS * 64, 256, 8);
-        static const int form = [] {  // PF_KCOV_SCAN: "dpp" / "bpermute" select the one-k-mer-per-lane form (measurements, tests)
+        static const int form = [] {  // PF_KCOV_SCAN (measurements, tests): "dpp" / "bpermute" select the one-k-mer-per-lane form
             const char *e = getenv("PF_KCOV_SCAN");
             return !e ? 4 : !strcmp(e, "bpermute") ? 0 : !strcmp(e, "dpp") ? 1 : 4;
         }();
         if (form == 4) {
-            const uint64_t sr_begin = g_range[0] / 256, sr_end = (g_range[1] + 255) / 256;
-            // one wavefront per window, four per block: the hardware hands out blocks as wavefronts retire (a capped persistent
-            // grid leaves 3.7 windows per wavefront at 1 M unitigs: a quarter of the chip idle in the last round)
-            const int grid4 = (int)(((sr_end - sr_begin + KC4_SR - 1) / KC4_SR + 3) / 4);
-            // a window's carry sums up to KC4_SR * 256 counts in the narrow type
-            if (ctx->tab_max_count < (1ull << 20))
-                k_cov_stream4<false, false><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, nullptr, dx);
-            else
-                k_cov_stream4<true, false><<<grid4, 256, 0, ctx->stream>>>(ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], sr_begin, sr_end, ds, dm, nullptr, dx);
+            Kc4Args a{ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], g_range[0] / 256, (g_range[1] + 255) / 256,
+                      ds, dm, nullptr, dx};
+            const bool wide = ctx->tab_max_count >= (1ull << 20);  // a window's carry sums up to KC4_SR * 256 counts in the narrow type
+            const int rc = launch_cov_stream(ctx, a, 1, wide, false);
+            if (rc) return rc;
         } else {
         const bool dpp = form == 1;
         const bool wide = ctx->tab_max_count >= (1ull << 25);
