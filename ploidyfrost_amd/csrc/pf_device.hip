@@ -301,112 +301,6 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
     }
 }
 
-// K-COV, streaming form (canonical databases): the counts of the graph's k-mers sit in graph order in gcov (written once per
-// graph + database by K-COV-JOIN), so C1 is a segmented reduction over a contiguous array: 4 B per k-mer, fully coalesced.
-// A wavefront takes windows of KCS_ROWS rows of 64 consecutive k-mers; all loads of a window are issued before the first is
-// used.  Segments (unitigs) are described by one bit per k-mer (khead, scalar load per row) and the unitig of the row's
-// first k-mer (krow): lane -> unitig is a popcount, "same unitig as lane - o" a mask test, no search.  Row partial sums are
-// 32-bit when 64 * max_count fits (WIDE = false).  Outputs as the probing form: initialised by k_cov_init, one atomic pair
-// per (row, unitig).
-constexpr int KCS_ROWS = 8;
-
-// DPP = true: the segmented scan runs on the VALU's data-parallel primitives (row_shr 1/2/4/8 inside rows of 16 lanes, then
-// row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3) instead of twelve ds_bpermute per row through the LDS crossbar.
-template <bool WIDE, bool DPP>
-__global__ __launch_bounds__(256) void k_cov_stream(const uint32_t *__restrict__ gcov, const uint64_t *__restrict__ khead,
-                                                    const uint32_t *__restrict__ krow, uint32_t u0, uint64_t g_begin, uint64_t g_end,
-                                                    uint64_t r_begin, uint64_t r_end, uint64_t *__restrict__ out_sum,
-                                                    uint32_t *__restrict__ out_min, uint8_t *__restrict__ out_miss) {
-    typedef typename std::conditional<WIDE, unsigned long long, uint32_t>::type sum_t;
-    const int lane = lane_id();
-    const uint32_t wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);  // wave-uniform: row metadata comes through scalar loads
-    const uint64_t wave = (uint64_t)blockIdx.x * (blockDim.x >> 6) + wv;
-    const uint64_t n_waves = (uint64_t)gridDim.x * (blockDim.x >> 6);
-    const uint64_t n_win = (r_end - r_begin + KCS_ROWS - 1) / KCS_ROWS;
-    const uint64_t le_mask = lane == 63 ? ~0ull : ((2ull << lane) - 1);  // bits 0..lane
-    for (uint64_t wx = wave; wx < n_win; wx += n_waves) {
-        const uint64_t r0 = r_begin + wx * KCS_ROWS;
-        uint32_t c[KCS_ROWS];
-#pragma unroll
-        for (int j = 0; j < KCS_ROWS; ++j) {
-            const uint64_t g = (r0 + j) * 64 + lane;
-            c[j] = (g >= g_begin && g < g_end) ? gcov[g] : 0u;
-        }
-#pragma unroll
-        for (int j = 0; j < KCS_ROWS; ++j) {
-            const uint64_t r = r0 + j;
-            if (r >= r_end) break;
-            const uint64_t heads = khead[r];
-            const uint32_t ub = krow[r];
-            const uint64_t g = r * 64 + lane;
-            const bool act = g >= g_begin && g < g_end;  // the range begins and ends on unitig boundaries
-            const bool miss = act && c[j] == GCOV_MISSING;
-            sum_t sum = (act && !miss) ? c[j] : 0u;
-            uint32_t mn = (act && !miss) ? c[j] : 0xFFFFFFFFu;
-            if (DPP) {
-                const int li = lane & 15;
-#define PF_KCS_ROW_STEP(O)                                                                              \
-    {                                                                                                   \
-        const sum_t so = dpp_any<0x110 | (O), 0xF>((sum_t)0, sum);                                      \
-        const uint32_t mo = dpp_any<0x110 | (O), 0xF>(0xFFFFFFFFu, mn);                                 \
-        const int sh = li >= (O) ? lane - (O) + 1 : 0;                                                  \
-        if (li >= (O) && ((heads >> sh) & ((1ull << (O)) - 1)) == 0) {                                  \
-            sum += so;                                                                                  \
-            mn = mo < mn ? mo : mn;                                                                     \
-        }                                                                                               \
-    }
-                PF_KCS_ROW_STEP(1)
-                PF_KCS_ROW_STEP(2)
-                PF_KCS_ROW_STEP(4)
-                PF_KCS_ROW_STEP(8)
-#undef PF_KCS_ROW_STEP
-                // no unitig begins between the start of this lane's row of 16 and the lane: the carry of the row before applies
-                const bool open16 = ((heads >> (lane & ~15)) & ((2ull << li) - 1)) == 0;
-                {
-                    const sum_t so = dpp_any<0x142, 0xA>((sum_t)0, sum);          // row_bcast:15 -> rows 1, 3
-                    const uint32_t mo = dpp_any<0x142, 0xA>(0xFFFFFFFFu, mn);
-                    if ((lane & 16) && open16) {
-                        sum += so;
-                        mn = mo < mn ? mo : mn;
-                    }
-                }
-                {
-                    const sum_t so = dpp_any<0x143, 0xC>((sum_t)0, sum);          // row_bcast:31 -> rows 2, 3
-                    const uint32_t mo = dpp_any<0x143, 0xC>(0xFFFFFFFFu, mn);
-                    const bool open32 = lane >= 32 && ((heads >> 32) & ((2ull << (lane - 32 >= 0 ? lane - 32 : 0)) - 1)) == 0;
-                    if (open32) {
-                        sum += so;
-                        mn = mo < mn ? mo : mn;
-                    }
-                }
-            } else {
-#pragma unroll
-                for (int o = 1; o < WAVE; o <<= 1) {
-                    const sum_t so = __shfl_up(sum, o, WAVE);
-                    const uint32_t mo = __shfl_up(mn, o, WAVE);
-                    // lane - o is in this lane's unitig iff no unitig begins at lanes lane - o + 1 .. lane
-                    const int sh = lane >= o ? lane - o + 1 : 0;
-                    const bool same = lane >= o && ((heads >> sh) & ((1ull << o) - 1)) == 0;
-                    if (same) {
-                        sum += so;
-                        mn = mo < mn ? mo : mn;
-                    }
-                }
-            }
-            if (act) {
-                const uint32_t u = ub + (uint32_t)__popcll(heads & le_mask & ~1ull);
-                const bool last = lane == 63 || ((heads >> (lane + 1)) & 1ull);
-                const uint32_t o = u - u0;
-                if (last) {
-                    atomicAdd(reinterpret_cast<unsigned long long *>(out_sum + o), (unsigned long long)sum);
-                    if (mn != 0xFFFFFFFFu) atomicMin(out_min + o, mn);
-                }
-                if (miss) out_miss[o] = 1;
-            }
-        }
-    }
-}
-
 // K-STRCOV: one thread per string (strings are k .. k+few bases long).
 __global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, bool one_strand, const char *__restrict__ text,
                          const uint64_t *__restrict__ str_off, uint32_t n_str, uint32_t low, uint32_t up,
@@ -1142,27 +1036,13 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
     ctx_begin(ctx, PF_K_COV);
     k_cov_init<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(n, ds, dm, dx);
     if (!exact && !probe && ctx->gcov_valid) {
-        // streaming form: rows of 64 k-mers, KCS_ROWS rows per wavefront window
-        const uint64_t r_begin = g_range[0] / 64, r_end = (g_range[1] + 63) / 64;
-        const int grid = ctx_grid(ctx, (r_end - r_begin + KCS_ROWS - 1) / KCS_ROWS * 64, 256, 8);
-        static const int form = [] {  // PF_KCOV_SCAN (measurements, tests): "dpp" / "bpermute" select the one-k-mer-per-lane form
-            const char *e = getenv("PF_KCOV_SCAN");
-            return !e ? 4 : !strcmp(e, "bpermute") ? 0 : !strcmp(e, "dpp") ? 1 : 4;
-        }();
-        if (form == 4) {
-            Kc4Args a{ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], g_range[0] / 256, (g_range[1] + 255) / 256,
-                      ds, dm, nullptr, dx};
-            const bool wide = ctx->tab_max_count >= (1ull << 20);  // a window's carry sums up to KC4_SR * 256 counts in the narrow type
-            const int rc = launch_cov_stream(ctx, a, 1, wide, false);
-            if (rc) return rc;
-        } else {
-        const bool dpp = form == 1;
-        const bool wide = ctx->tab_max_count >= (1ull << 25);
-#define PF_KCS_LAUNCH(W, D) k_cov_stream<W, D><<<grid, 256, 0, ctx->stream>>>(ctx->d_gcov, ctx->d_khead, ctx->d_krow, u0, g_range[0], g_range[1], r_begin, r_end, ds, dm, dx)
-        if (wide) { if (dpp) PF_KCS_LAUNCH(true, true); else PF_KCS_LAUNCH(true, false); }
-        else { if (dpp) PF_KCS_LAUNCH(false, true); else PF_KCS_LAUNCH(false, false); }
-#undef PF_KCS_LAUNCH
-        }
+        // streaming form (pf_cov_stream.hpp): four k-mers per lane, windows of KC4_SR super-rows of 256 k-mers.  Earlier forms of
+        // this round -- one k-mer per lane with the scan on DPP (0.111 ms) or ds_bpermute (0.123 ms) -- are in profiles/r01j_kcov_stream.txt
+        Kc4Args a{ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], g_range[0] / 256, (g_range[1] + 255) / 256,
+                  ds, dm, nullptr, dx};
+        const bool wide = ctx->tab_max_count >= (1ull << 20);  // a window's carry sums up to KC4_SR * 256 counts in the narrow type
+        const int rc = launch_cov_stream(ctx, a, 1, wide, false);
+        if (rc) return rc;
     } else {
         k_cov<<<ctx_grid(ctx, (w_end - w_begin) * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
                                                                                      ctx->d_kwin, ctx->N, ctx->tab_one_strand, exact, u0, g_range[0],
