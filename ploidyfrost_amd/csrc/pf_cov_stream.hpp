@@ -1,6 +1,10 @@
 // Streaming per-unitig coverage reduction over the per-k-mer coverage SoA (K-COV, K-COV-C): shared by pf_device.hip and
 // pf_colored.hip.  Reference functions: CDBG::readCov(const UnitigMap&) (src/CDBG.cpp:66-120), CCDBG::readCovUni
 // (src/CCDBG.cpp:123-156).
+// Inputs (pf_ctx.hpp): gcov[g] = count of graph k-mer g in graph order (GCOV_MISSING = absent), written by the load-time join;
+// khead = one bit per k-mer, set where a unitig begins (and after the last k-mer); krow[r] = the unitig of k-mer 64 r.
+// The scans use DPP row shifts / broadcasts: they are called from wave-uniform control flow only (all 64 lanes active), the
+// per-lane conditions are applied to the moved values afterwards.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
