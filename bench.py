@@ -192,6 +192,20 @@ def algorithmic_bytes(kernel: str, t: dict) -> float | None:
     return None
 
 
+def cov_roofline(kernels: dict, colored: bool):
+    """`roofline_k_cov`: the streaming coverage kernel of the workload (K-COV, or K-COV-C for the colored one) -- the kernel
+    SURVEY.md 8(d) names as able to approach the HBM roof.  `traffic` = PMC-measured HBM bytes per launch from the committed
+    profile (single-sample kernel only), `traffic_frac` = traffic / duration / peak."""
+    name = "k_cov_colored" if colored else "k_cov"
+    e = kernels.get(name)
+    if not e or "achieved_GBps" not in e:
+        return None
+    tr = None if colored else load_traffic(name)
+    return {"kernel": name, "bound": "hbm", "achieved": e["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
+            "frac": round(e["achieved_GBps"] / 8000.0, 5), "traffic": tr,
+            "traffic_frac": round(tr / (e["avg_ms"] * 1e-3) / 8e12, 4) if tr else None}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -364,13 +378,7 @@ def main():
                         "frac": round(e["achieved_GBps"] / 8000.0, 5), "traffic": load_traffic(dom)}
             # the streaming kernel of the path, next to the dominant one: K-COV is the kernel SURVEY.md 8(d) names as able to
             # approach the HBM roof; `traffic_frac` = PMC-measured HBM bytes per launch / its duration / peak
-            roof_cov = None
-            if "k_cov" in kernels:
-                e = kernels["k_cov"]
-                tr = load_traffic("k_cov")
-                roof_cov = {"kernel": "k_cov", "bound": "hbm", "achieved": e["achieved_GBps"], "peak": 8000.0, "unit": "GB/s",
-                            "frac": round(e["achieved_GBps"] / 8000.0, 5), "traffic": tr,
-                            "traffic_frac": round(tr / (e["avg_ms"] * 1e-3) / 8e12, 4) if tr else None}
+            roof_cov = cov_roofline(kernels, colored)
             cpu = None
             if not args.no_cpu_baseline and not colored:
                 cpu = cpu_baseline(workdir, args.cpu_sample_unitigs, dev)

@@ -268,3 +268,14 @@ def test_work_pool(tmp_path):
                     os.path.join(ROOT, "tests", "cpp", "test_workpool.cpp"), "-o", exe], check=True)
     r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=120)
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
+
+
+def test_bench_cov_roofline_picks_the_streaming_kernel_of_the_workload():
+    """bench.py `roofline_k_cov`: K-COV for the single-sample workload (with the committed PMC traffic), K-COV-C for the colored."""
+    import bench
+    k = {"k_cov": {"avg_ms": 0.1, "achieved_GBps": 2000.0}, "k_cov_colored": {"avg_ms": 0.3, "achieved_GBps": 2400.0}, "k_bfs": {"avg_ms": 1.0}}
+    a, b = bench.cov_roofline(k, False), bench.cov_roofline(k, True)
+    assert a["kernel"] == "k_cov" and a["frac"] == 0.25 and a["bound"] == "hbm" and a["peak"] == 8000.0
+    assert b["kernel"] == "k_cov_colored" and b["frac"] == 0.3 and b["traffic"] is None
+    assert bench.cov_roofline({"k_bfs": {"avg_ms": 1.0}}, False) is None
+    assert bench.algorithmic_bytes("k_cov", {"kmers": 64, "unitigs": 2}) == 64 * (4 + 1 / 8 + 1 / 16) + 32
