@@ -4,6 +4,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <condition_variable>
 #include <cstdio>
@@ -81,6 +82,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     for (auto &hl : huge_lists_) hl.clear();
     // host walkers of the long traversals: each keeps 8 bytes of state per unitig, at most ~4 GiB of it in total
     const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
+    std::atomic<uint64_t> n_deferred_total{0};
     std::thread device([&] {
         std::vector<uint32_t> &deferred = deferred_;   // keeps its size from pass to pass
         for (int i = 0; i < kSlices; ++i) {
@@ -106,6 +108,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                 }
                 break;
             }
+            n_deferred_total += n_deferred;
             if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] device tiers of slice %d: %.2f ms, %llu candidates left for the third tier\n", i, since(tb) * 1e3, (unsigned long long)n_deferred);
             if (st1 == PF_OK && n_deferred) {
                 // third tier: one host thread per giant traversal, side by side; lists go to huge_pool_
@@ -145,6 +148,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         if (prefetch_cov) cov_ready_ = launch_coverage() == PF_OK;
     });
     times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;  // (kSlices above looked at the previous pass)
+    times_.bfs_deferred = 0;
     times_.bfs_large_used = times_.bfs_large_used_max = 0;
     uint64_t n_rec_total = 0;
     double replay_s = 0;
@@ -195,6 +199,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     if (st != PF_OK || dev_st != PF_OK) return fail(dev_st != PF_OK ? dev_st : st, std::string("CDBG::findSuperBubble(): ") + dev_err);
     times_.bfs_device_s = bfs_s;
     times_.candidates = n_rec_total;
+    times_.bfs_deferred = n_deferred_total.load();
     times_.replay_s = replay_s;
     if (!quiet_) {
         printf("%s::findSuperBubble():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);

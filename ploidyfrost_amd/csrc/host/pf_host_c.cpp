@@ -152,6 +152,7 @@ void pfh_get_times(const pfh_run *r, pfh_times *o) {
     o->core_cov = r->cdbg->core_cov(); o->core_num = r->cdbg->core_num();
     o->scan_s = t.scan_s; o->scan_serial_s = t.scan_serial_s;
     o->bfs_large = t.bfs_large; o->bfs_max_seen = t.bfs_max_seen;
+    o->bfs_deferred = t.bfs_deferred;
 }
 
 const char *pfh_last_allele_frequency(const pfh_run *r, uint64_t *len) {

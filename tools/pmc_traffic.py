@@ -2,9 +2,12 @@
 """Turn two rocprofv3 PMC passes (FETCH_SIZE and WRITE_SIZE, collected separately as the TCC slot
 budget requires) into profiles/pmc_traffic.json: HBM bytes per launch for each of this repository's
 kernels, with the gfx950 corrections of MI355X_MICROARCH.md (HBM section): counters are in KiB;
-FETCH_SIZE under-reports coalesced reads by 2x and is doubled; WRITE_SIZE is taken as is.
+FETCH_SIZE under-reports wide coalesced reads by 2x and is doubled FOR THE STREAMING KERNELS ONLY (STREAMING below: whole
+cache lines consumed by consecutive lanes); for kernels whose reads are random 16/32-byte probes or dependent pointer chases
+the raw value is kept (doubling would overstate them) and both figures are recorded.  WRITE_SIZE is taken as is.
 
-usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json>
+usage: tools/pmc_traffic.py <fetch_dir> <write_dir> <out.json> [<bench.json of the profiled command>]
+The optional bench line supplies `_meta` (unitigs, k-mers): bench.py emits a traffic figure only for that very workload.
 """
 import csv
 import glob
@@ -28,6 +31,10 @@ def per_kernel(d, counter):
     return acc
 
 
+# kernels that read wide coalesced streams: the x2 FETCH_SIZE correction applies to these and only these
+STREAMING = {"k_cov", "k_cov_init", "k_cov_colored", "k_call_gather", "k_call_format", "k_kmc_decode"}
+
+
 def short(name):
     if "k_cov_stream" in name:    # the per-pass K-COV (k_cov_stream4 / k_cov_stream: streams the joined per-k-mer coverage SoA)
         return "k_cov"
@@ -41,8 +48,16 @@ def short(name):
     return None
 
 
-def main(fetch_dir, write_dir, out):
+def main(fetch_dir, write_dir, out, bench_json=None):
     res = {}
+    meta = {}
+    if bench_json:
+        try:
+            with open(bench_json) as f:
+                b = json.loads(f.read().strip().splitlines()[-1])
+            meta = {"unitigs": b["config"]["unitigs_total"], "kmers": b["config"]["kmers_per_gpu"], "workload": b["config"]["workload"]}
+        except (OSError, ValueError, KeyError, IndexError) as e:
+            print("pmc_traffic: no _meta (%s)" % e, file=sys.stderr)
     fetch = per_kernel(fetch_dir, "FETCH_SIZE")
     write = per_kernel(write_dir, "WRITE_SIZE")
     names = set(filter(None, (short(n) for n in list(fetch) + list(write))))
@@ -51,15 +66,19 @@ def main(fetch_dir, write_dir, out):
         ws = [(v[0], v[1]) for n, v in write.items() if short(n) == k]
         fk = sum(x[0] for x in fs) / max(1, sum(x[1] for x in fs))
         wk = sum(x[0] for x in ws) / max(1, sum(x[1] for x in ws))
-        res[k] = {"fetch_bytes_per_launch": fk * 1024 * 2, "write_bytes_per_launch": wk * 1024,
-                  "hbm_bytes_per_launch": fk * 1024 * 2 + wk * 1024, "launches_sampled": sum(x[1] for x in fs),
-                  "raw_FETCH_SIZE_KiB": fk, "raw_WRITE_SIZE_KiB": wk}
+        corr = 2 if k in STREAMING else 1
+        res[k] = {"fetch_bytes_per_launch": fk * 1024 * corr, "write_bytes_per_launch": wk * 1024,
+                  "hbm_bytes_per_launch": fk * 1024 * corr + wk * 1024, "launches_sampled": sum(x[1] for x in fs),
+                  "fetch_correction": corr, "raw_FETCH_SIZE_KiB": fk, "raw_WRITE_SIZE_KiB": wk}
     flat = {k: v["hbm_bytes_per_launch"] for k, v in res.items()}
     with open(out, "w") as f:
-        json.dump({"_detail": res, **flat}, f, indent=1)
+        json.dump({"_meta": meta, "_detail": res, **flat}, f, indent=1)
+    if not res:
+        print("pmc_traffic: no counter rows found in %s / %s" % (fetch_dir, write_dir), file=sys.stderr)
+        sys.exit(1)
     for k, v in res.items():
-        print("%-14s fetch %.1f MB (x2 corrected)  write %.1f MB per launch" % (k, v["fetch_bytes_per_launch"] / 1e6, v["write_bytes_per_launch"] / 1e6))
+        print("%-14s fetch %.1f MB (x%d)  write %.1f MB per launch" % (k, v["fetch_bytes_per_launch"] / 1e6, v["fetch_correction"], v["write_bytes_per_launch"] / 1e6))
 
 
 if __name__ == "__main__":
-    main(*sys.argv[1:4])
+    main(*sys.argv[1:5])
