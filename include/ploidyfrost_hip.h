@@ -55,7 +55,8 @@ int pf_synchronize(pf_ctx *);
  * launch stream; pf_kernel_time() synchronises and returns the accumulated time / count. */
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
-    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN, PF_K_COUNT_
+    PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN,
+    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -248,6 +249,66 @@ int pf_align_bubbles(pf_ctx *, const char *text, uint64_t text_len, const pf_bub
  * a k-mer is absent. [host|dev] */
 int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t n_str, uint32_t low, uint32_t up,
                   uint64_t *sum, uint8_t *ok, uint8_t *miss);
+
+/* ---- P1-P4 + O1 resident: CDBG::ploidyEstimation_ptr (src/CDBG.cpp:1101-1705) between the commit replay and the files -------
+ * The caller keeps what is sequential by construction -- the commit replay of findSuperBubble and the light pass of the driver
+ * loop that decides which endpoint sides are still open when reached (:1146-1186, 1656-1679) -- and the file system.  Everything
+ * else runs on the device and comes back as text: owner / coverage-gate scan, path enumeration and sorting (strict: sortSeq_simple
+ * :482-551; branching: two-stack walk :1364-1412 + sortSeq_branching :417-480), SequenceAlignment, per-site strings and their
+ * readCov (:1448-1600, 29-60), and the rows of the ten result files with `ostream << double` formatting (:1259, 1303-1340,
+ * 1552-1652).  Call order: pf_call_set_state, pf_call_coverage, pf_call_scan, pf_call_sides, pf_call_select, then pf_call_run /
+ * pf_call_fetch per batch.  Single-sample path (CDBG); the colored twin keeps pf_align_bubbles + pf_string_cov_colored. */
+
+/* T1: the MyUnitig state after findSuperBubble (src/MyUnitig.hpp:37-130): b bits; plus / minus partners (0 = NULL, id = u + 1).
+ * n_unitigs entries each. [host|dev] */
+int pf_call_set_state(pf_ctx *, const uint8_t *flags, const uint32_t *plus, const uint32_t *minus);
+/* C1 for every unitig into device-resident arrays the scan reads (pf_unitig_cov / pf_unitig_cov_exact without the copy back; a
+ * missing k-mer is reported by the scan only where the driver loop reads that unitig's coverage). */
+int pf_call_coverage(pf_ctx *);
+
+typedef struct pf_call_side { /* one open endpoint side, in the driver loop's order: unitig ascending, '+' side first */
+    uint32_t u;          /* unitig index */
+    uint32_t exit_ov;    /* the bubble's other endpoint as an oriented vertex; PF_NONE: not found (err = 2) */
+    uint32_t err_unitig; /* err = 1: the unitig with a k-mer missing from the count table */
+    uint8_t plus_side;
+    uint8_t kind;        /* 1 complex (skipped, :1163), 2 the other endpoint owns the bubble (:1190, 1352), 3 owner: called here */
+    uint8_t aligned;     /* kind 3: passes the coverage gate of the strict branch (:1210-1220); branching bubbles always do */
+    uint8_t err;         /* 0, 1 missing k-mer, 2 exit unreachable -- raised by the caller only if the side is still open */
+} pf_call_side;
+/* part A of the driver loop for every open side, from static state only; *n_sides = number of records */
+int pf_call_scan(pf_ctx *, uint32_t lower, uint32_t upper, uint64_t *n_sides);
+int pf_call_sides(pf_ctx *, pf_call_side *out, uint64_t cap); /* [host|dev] */
+/* part B's verdict: the records (indices into the scan's output, ascending) whose bubble is called, in output order [host|dev] */
+int pf_call_select(pf_ctx *, const uint32_t *side_index, uint64_t n_bubbles);
+
+#define PF_CALL_STREAMS 10
+enum pf_call_stream { /* <outpre>_<name>.txt */
+    PF_OUT_ALLELE_FREQUENCY = 0, PF_OUT_ALIGNSEQ = 1, PF_OUT_BIFRE = 2, PF_OUT_TRIFRE = 3, PF_OUT_TETRAFRE = 4, PF_OUT_PENTAFRE = 5,
+    PF_OUT_BICOV = 6, PF_OUT_TRICOV = 7, PF_OUT_TETRACOV = 8, PF_OUT_PENTACOV = 9
+};
+typedef struct pf_call_result {
+    uint64_t text_len[PF_CALL_STREAMS]; /* bytes of each stream this batch produced */
+    uint64_t allele[4];                 /* sites with 2, 3, 4, 5 alleles */
+    uint64_t core_cov, core_num;        /* coreCov / coreNum (:1261-1262) */
+    uint64_t n_called;                  /* bubbles whose alignment left rows: var_count advances by this */
+    uint64_t align_jobs, site_strings, n_branching;
+} pf_call_result;
+/* Bubbles [t0, t1) of the selection (at most 2^24): everything up to the text of the ten streams, left in slab 0 or 1 of the
+ * context; var_count_base = bubbles called by earlier batches.  complex_size = -z (bounds the walk stacks). */
+int pf_call_run(pf_ctx *, int slab, uint64_t t0, uint64_t t1, uint64_t var_count_base, uint32_t complex_size, double match,
+                double mismatch, double gap, pf_call_result *out);
+/* The same in two steps, for a bubble list cut over several GPUs: a rank learns how many of its bubbles are
+ * called (pf_call_align: paths, alignment, site coverages; fills n_called, align_jobs, site_strings, n_branching), the ranks
+ * exchange those counts, and only then is the text written with the rank's var_count_base (pf_call_text: text_len, allele, core_*). */
+int pf_call_align(pf_ctx *, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
+                  pf_call_result *out);
+int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *out);
+/* Copies the first len bytes of one stream of a slab to dst (host memory, pinned for speed) on a stream of its own: may be
+ * called from another thread while pf_call_run fills the other slab. */
+int pf_call_fetch(pf_ctx *, int slab, int stream, char *dst, uint64_t len);
+/* O1's number formatting alone (test hook): text + 32 * i receives printf("%g", values[i]) without terminator, len[i] its length
+ * [host|dev] */
+int pf_format_doubles(pf_ctx *, const double *values, uint64_t n, char *text, uint8_t *len);
 
 /* ---- colored (multi-sample) coverage: reference src/CCDBG.cpp ------------------------------------- */
 /* CCDBG::CCDBG (src/CCDBG.cpp:13-43) opens one KMC database per colour.  Here the records of all colours

@@ -67,6 +67,7 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     sc_.match = m;
     sc_.mismatch = d;
     sc_.gap = g;
+    if (const char *e = getenv("PF_CALL")) resident_ = strcmp(e, "host") != 0;  // measurements: the host-threaded pipeline
     if (init_device(device)) return;
     if (!kmc_db.empty()) {
         LoadTrace trace;
@@ -111,6 +112,7 @@ CDBG::~CDBG() {
     join_pending_write();
     bx_.release_all();  // pinned buffers go before the context
     for (auto &a : ax_) a.release_all();
+    cx_.release_all();
     pf_destroy(ctx_);
 }
 

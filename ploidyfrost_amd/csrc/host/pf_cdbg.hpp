@@ -80,7 +80,10 @@ public:
     void set_batch_bubbles(size_t n) { batch_bubbles_ = n; }
     // write <outpre>_super_bubble.txt in the background while PloidyEstimation runs (complete when that call, the next
     // findSuperBubble or the destructor returns); off by default: the file is complete when findSuperBubble returns
-    void set_overlap_output(bool on) { overlap_output_ = on; }        // bubbles per pipeline batch (tests force small ones)
+    void set_overlap_output(bool on) { overlap_output_ = on; }
+    // PloidyEstimation through the device's resident calling pipeline (pf_call_*, the default for the single-sample path) or,
+    // off, through the host-threaded pipeline around pf_align_bubbles / pf_string_cov (what the colored path uses)
+    void set_resident_calling(bool on) { resident_ = on; }
     pf_ctx *device() { return ctx_; }
     const PhaseTimes &times() const { return times_; }
     uint64_t allele_sites(int arity) const { return allele_[arity - 2]; }
@@ -101,6 +104,10 @@ protected:
     int init_device(int device);
     // the path proper; cutoff holds one (lower, upper) pair (single sample) or one per colour
     int ploidy_estimation(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
+    // the same through pf_call_* (pf_cdbg_call.cpp); call_select = scan + the sequential pass of the driver loop
+    int ploidy_estimation_resident(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
+    int call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &n_tasks);
+    bool resident_path() const { return resident_ && col_ == nullptr && part_world_ == 1; }
     // set by CCDBG: the colour sets of the graph's unitigs (reference src/CCDBG.cpp path) and the stdout tag
     const ColorSets *col_ = nullptr;
     const char *tag_ = "CDBG";
@@ -180,6 +187,14 @@ protected:
             cov_miss.release();
         }
     } bx_;
+    // exchange buffers of the resident calling pipeline: side records down, selection up, text slabs down
+    struct CallExchange {
+        PinnedBuf<pf_call_side> sides;
+        PinnedBuf<uint32_t> kept;
+        PinnedBuf<char> slab[2];
+        void release_all() { sides.release(); kept.release(); slab[0].release(); slab[1].release(); }
+    } cx_;
+    bool resident_ = true;
     PhaseTimes times_;
     std::string last_allfre_;
     uint64_t allele_[4] = {0, 0, 0, 0};

@@ -1,0 +1,279 @@
+// pfh::CDBG::ploidy_estimation_resident: CDBG::ploidyEstimation_ptr (reference src/CDBG.cpp:1101-1705) with the device's
+// resident calling pipeline (include/ploidyfrost_hip.h, pf_call_*).  What stays on the host is what is sequential by
+// construction or belongs to the operating system:
+//   * the light pass of the driver loop (:1146-1186, 1656-1679) -- a side is handled only if its bit is still set when its
+//     unitig comes up, and handling a bubble closes both endpoint sides -- over 16-byte side records the device scanned;
+//   * appending the text slabs the device formatted to the ten result files.
+// Bubbles are processed in batches; while the device works on batch b the slabs of batch b-1 are copied back and written.
+#include <fcntl.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstdio>
+#include <cstring>
+#include <ctime>
+#include <deque>
+#include <mutex>
+#include <thread>
+
+#include "pf_cdbg_impl.hpp"
+#include "pf_parallel.hpp"
+
+namespace pfh {
+
+namespace {
+const char *kStreamSuffix[PF_CALL_STREAMS] = {"_allele_frequency.txt", "_alignseq.txt", "_bifre.txt",    "_trifre.txt",   "_tetrafre.txt",
+                                              "_pentafre.txt",         "_bicov.txt",    "_tricov.txt",   "_tetracov.txt", "_pentacov.txt"};
+}
+
+// ---- first half: everything up to the list of bubbles to call (device scan + the sequential pass) ----
+int CDBG::call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &n_tasks) {
+    const uint32_t low = (uint32_t)cutoff[0].first, up = (uint32_t)cutoff[0].second;
+    auto t0 = clk::now();
+    int st = PF_OK;
+    if (!cov_ready_) st = launch_coverage();
+    cov_ready_ = false;
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + cov_err_);
+    times_.cov_device_s = since(t0);
+    t0 = clk::now();
+    st = pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    uint64_t n_sides = 0;
+    if (st == PF_OK) st = pf_call_scan(ctx_, low, up, &n_sides);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): scan: " + pf_last_error(ctx_));
+    cx_.sides.ensure(ctx_, std::max<uint64_t>(n_sides, 1));
+    cx_.kept.ensure(ctx_, std::max<uint64_t>(n_sides, 1));
+    st = pf_call_sides(ctx_, cx_.sides.p, cx_.sides.cap);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): scan: " + pf_last_error(ctx_));
+    // the driver loop itself: sequential, a few nanoseconds per side
+    const auto t_serial = clk::now();
+    const pf_call_side *sides = cx_.sides.p;
+    uint32_t *kept = cx_.kept.p;
+    uint64_t nk = 0;
+    for (uint64_t ri = 0; ri < n_sides; ++ri) {
+        const pf_call_side &r = sides[ri];
+        const uint32_t u = r.u;
+        const uint8_t own = r.plus_side ? B_PLUS : B_MINUS;
+        if (!(flags_[u] & own)) continue;
+        if (r.kind == 1) { flags_[u] &= (uint8_t)~own; continue; }
+        if (r.err == 1)
+            return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of unitig " + std::to_string(r.err_unitig + 1) + " can not found .");
+        if (r.err == 2) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): exit of a bubble is not reachable");
+        flags_[u] &= (uint8_t)~own;
+        if (r.kind == 2) continue;
+        if (r.aligned) kept[nk++] = (uint32_t)ri;
+        flags_[r.exit_ov >> 1] &= (uint8_t) ~(plus_of(r.exit_ov) ? B_MINUS : B_PLUS);
+    }
+    times_.scan_serial_s = since(t_serial);
+    st = pf_call_select(ctx_, kept, nk);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+    times_.scan_s = since(t0);
+    n_tasks = nk;
+    return 0;
+}
+
+int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr) {
+    const auto t_all = clk::now();
+    clock_t c0 = clock();
+    if (!quiet_) printf("%s::PloidyEstimation():  Analyzing superbubbles to generate sites' information\n", tag_);
+    if (write_files_ && ensure_dir()) return status_;
+    const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
+    times_.cov_device_s = times_.tasks_s = times_.align_s = times_.sites_s = times_.format_s = times_.write_s = 0;
+    times_.tasks = times_.align_jobs = times_.site_strings = 0;
+    times_.align_build_s = times_.align_device_s = times_.align_post_s = times_.align_choose_s = times_.scan_s = 0;
+    allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
+    core_cov_ = core_num_ = 0;
+    const bool trace = getenv("PF_TRACE_PLOIDY") != nullptr;
+    auto tp = [&](const char *what) { if (trace) fprintf(stderr, "[ploidy] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
+
+    // The ten result files are opened without truncation (freeing the pages of an earlier run costs milliseconds) and cut to
+    // their final length at the end; a helper thread opens them while the scan runs.
+    struct OutFile {
+        std::string name;
+        int fd = -1;
+        uint64_t bytes = 0;
+        int rc = 0;
+    };
+    std::vector<OutFile> files(PF_CALL_STREAMS);
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].name = outpre + kStreamSuffix[s];
+    int open_failed = -1;
+    std::thread opener;
+    if (write_files_)
+        opener = std::thread([&] {
+            for (size_t i = 0; i < files.size(); ++i) {
+                files[i].fd = open((outdir_ + "/" + files[i].name).c_str(), O_WRONLY | O_CREAT, 0666);
+                if (files[i].fd < 0) { open_failed = (int)i; return; }
+            }
+        });
+    struct OpenerGuard {  // every early return below must not leave the helper running or files open
+        std::thread &t;
+        std::vector<OutFile> &f;
+        ~OpenerGuard() {
+            if (t.joinable()) t.join();
+            for (OutFile &of : f)
+                if (of.fd >= 0) { close(of.fd); of.fd = -1; }
+        }
+    } opener_guard{opener, files};
+
+    uint64_t n_tasks = 0;
+    if (call_select(cutoff, n_tasks)) return status_;
+    tp("scan + selection done");
+    if (opener.joinable()) opener.join();
+    if (open_failed >= 0) return fail(PF_ERR_ARG, "CDBG:: Open " + files[(size_t)open_failed].name + " file error");
+    last_allfre_.clear();
+
+    // ---- batches: device (this thread) | copy back + append (writer thread) ----
+    const size_t CHUNK = std::min<size_t>(std::max<size_t>(batch_bubbles_ ? batch_bubbles_ * 4 : 1, 1), (size_t)1 << 24);
+    const size_t n_batches = (n_tasks + CHUNK - 1) / CHUNK;
+    struct Done {
+        pf_call_result res;
+        int slab;
+    };
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<Done> ready;
+    size_t fetched = 0;  // batches whose slabs have been copied off the device
+    bool stop = false, producer_done = false;
+    int wst = PF_OK;
+    std::string werr;
+    double write_s = 0;
+    std::thread writer([&] {
+        size_t b = 0;
+        for (;;) {
+            Done d;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !ready.empty() || producer_done; });
+                if (stop || ready.empty()) return;
+                d = ready.front();
+                ready.pop_front();
+            }
+            const auto tw = clk::now();
+            uint64_t total = 0, off[PF_CALL_STREAMS + 1];
+            for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
+            off[PF_CALL_STREAMS] = total;
+            PinnedBuf<char> &hb = cx_.slab[d.slab];
+            hb.ensure(ctx_, std::max<uint64_t>(total, 1));
+            int st = PF_OK;
+            for (int s = 0; s < PF_CALL_STREAMS && st == PF_OK; ++s)
+                st = pf_call_fetch(ctx_, d.slab, s, hb.p + off[s], d.res.text_len[s]);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                fetched = b + 1;
+                if (st != PF_OK) { wst = st; werr = "copy of a text slab failed"; stop = true; }
+            }
+            cv.notify_all();
+            if (st != PF_OK) return;
+            if (trace) fprintf(stderr, "[ploidy]   batch %zu fetched (%.1f MB) %.2f ms\n", b, total / 1e6, since(t_all) * 1e3);
+            // append: every stream at its running offset, the large ones cut into pieces written side by side
+            constexpr uint64_t PIECE = 4u << 20;
+            struct Piece { int s; uint64_t at, len; };
+            std::vector<Piece> pieces;
+            for (int s = 0; s < PF_CALL_STREAMS; ++s)
+                for (uint64_t at = 0; at < d.res.text_len[s]; at += PIECE) pieces.push_back({s, at, std::min<uint64_t>(PIECE, d.res.text_len[s] - at)});
+            std::vector<int> prc(pieces.size(), 0);
+            if (write_files_)
+                parallel_chunks(pieces.size(), 1, T, [&](size_t i, size_t, size_t) {
+                    const Piece &pc = pieces[i];
+                    const char *src = hb.p + off[pc.s] + pc.at;
+                    uint64_t left = pc.len, fo = files[(size_t)pc.s].bytes + pc.at;
+                    while (left) {
+                        const ssize_t w = pwrite(files[(size_t)pc.s].fd, src, left, (off_t)fo);
+                        if (w <= 0) { prc[i] = 1; return; }
+                        left -= (uint64_t)w;
+                        src += w;
+                        fo += (uint64_t)w;
+                    }
+                });
+            last_allfre_.append(hb.p + off[0], d.res.text_len[0]);
+            for (size_t i = 0; i < pieces.size(); ++i)
+                if (prc[i]) files[(size_t)pieces[i].s].rc = 1;
+            for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].bytes += d.res.text_len[s];
+            write_s += since(tw);
+            if (trace) fprintf(stderr, "[ploidy]   batch %zu written %.2f ms\n", b, since(t_all) * 1e3);
+            ++b;
+        }
+    });
+    struct WriterGuard {  // joined on every way out
+        std::thread &t;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &stop;
+        ~WriterGuard() {
+            if (!t.joinable()) return;
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            t.join();
+        }
+    } writer_guard{writer, mu, cv, stop};
+
+    uint64_t var_count = 0;
+    int rc = PF_OK;
+    std::string rc_err;
+    const auto t_dev = clk::now();
+    for (size_t b = 0; b < n_batches; ++b) {
+        {   // slab b % 2 was last used by batch b - 2
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || b < fetched + 2; });
+            if (stop) break;
+        }
+        const uint64_t t0 = (uint64_t)b * CHUNK, t1 = std::min<uint64_t>(n_tasks, t0 + CHUNK);
+        Done d;
+        d.slab = (int)(b & 1);
+        const int st = pf_call_run(ctx_, d.slab, t0, t1, var_count, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch,
+                                   sc_.gap, &d.res);
+        if (st != PF_OK) { rc = st; rc_err = pf_last_error(ctx_); break; }
+        if (trace) fprintf(stderr, "[ploidy]   batch %zu on the device done %.2f ms\n", b, since(t_all) * 1e3);
+        var_count += d.res.n_called;
+        times_.tasks += t1 - t0;
+        times_.align_jobs += d.res.align_jobs;
+        times_.site_strings += d.res.site_strings;
+        for (int a = 0; a < 4; ++a) allele_[a] += d.res.allele[a];
+        core_cov_ += d.res.core_cov;
+        core_num_ += d.res.core_num;
+        { std::lock_guard<std::mutex> lk(mu); ready.push_back(d); }
+        cv.notify_all();
+    }
+    times_.align_s = since(t_dev);
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        producer_done = true;
+        if (rc != PF_OK) stop = true;
+    }
+    cv.notify_all();
+    writer.join();
+    tp("pipeline done");
+    if (rc != PF_OK) {
+        // the device layer words the reference's own messages (missing k-mer, site string outside its row)
+        return fail(rc, rc_err.rfind("CDBG::", 0) == 0 ? rc_err : std::string(tag_) + "::PloidyEstimation(): " + rc_err);
+    }
+    if (wst != PF_OK) return fail(wst, std::string(tag_) + "::PloidyEstimation(): " + werr);
+    auto t0 = clk::now();
+    if (join_pending_write()) return status_;
+    for (OutFile &of : files) {
+        out_bytes_ += of.bytes;
+        if (of.fd >= 0) {
+            if (ftruncate(of.fd, (off_t)of.bytes) != 0) of.rc = 1;
+            close(of.fd);
+            of.fd = -1;
+        }
+        if (of.rc) return fail(PF_ERR_ARG, "CDBG:: write error on " + of.name);
+    }
+    write_s += since(t0);
+    times_.write_s = write_s;
+    tp("files closed");
+    times_.ploidy_total_s = since(t_all);
+    if (!quiet_) {
+        printf("%s::PloidyEstimation():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf("%s::PloidyEstimation():  Real time : %gs\n", tag_, times_.ploidy_total_s);
+        printf("%s::PloidyEstimation(): Alleles in SuperBubbles  :\t2 :%llu\t3 :%llu\t4 :%llu\t5 :%llu\n", tag_,
+               (unsigned long long)allele_[0], (unsigned long long)allele_[1], (unsigned long long)allele_[2],
+               (unsigned long long)allele_[3]);
+        // the reference divides unguarded (src/CDBG.cpp:1703) and dies with SIGFPE when no site exists
+        if (core_num_) printf("%s::PloidyEstimation(): Sites' Average Coverage:%d\n", tag_, (int)(core_cov_ / core_num_));
+    }
+    return 0;
+}
+
+}  // namespace pfh

@@ -276,6 +276,11 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
 // K-COV (colored: K-COV-C) for all unitigs into the pinned result buffers.  A missing k-mer is not an error here: the
 // single-sample path raises it only for the unitigs it really uses, the colored path never (src/CCDBG.cpp:113-117).
 int CDBG::launch_coverage() {
+    if (resident_path()) {  // the results stay on the device, where the scan of the calling pipeline reads them
+        const int st = pf_call_coverage(ctx_);
+        if (st != PF_OK) cov_err_ = pf_last_error(ctx_);
+        return st;
+    }
     const uint32_t N = g_.n();
     // a database without canonical counting (single-sample only) is read per orientation: [0, N) the unitigs as stored,
     // [N, 2N) their reverse complements (readCov(UnitigMap), src/CDBG.cpp:94-117)

@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "pf_align_dev.hpp"
+#include "pf_bubble_launch.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
 #include "ploidyfrost_hip.h"
@@ -88,6 +89,7 @@ struct BubParams {
     unsigned long long *task_clk;  // diagnostic: per-task wall clock ticks (100 MHz), or nullptr
     unsigned int *next;            // work queue head of this launch
     unsigned long long *prof;      // diagnostic: [0] fill [1] traceback [2] decode [3] round0 copy [4] rounds [5] choose [6] publish
+    unsigned int *bad;             // final tier: bubbles that exceed even its capacities
 };
 
 struct BubOut {
@@ -711,6 +713,7 @@ __global__ __launch_bounds__(64) void k_bubble(BubParams p, BubOut o) {
                 memset(&r, 0, sizeof(r));
                 r.n_rows = 0xFFFFFFFFu;  // error marker
                 o.res[job] = r;
+                if (p.bad) atomicAdd(p.bad, 1u);
             } else {
                 const unsigned int x = atomicAdd(o.n_retry, 1u);
                 o.retry[x] = job;
@@ -721,6 +724,152 @@ __global__ __launch_bounds__(64) void k_bubble(BubParams p, BubOut o) {
 }
 
 }  // namespace
+
+namespace pf {
+
+// Launch part of K-BUBBLE shared by pf_align_bubbles (host-described batches) and the resident calling pipeline
+// (pf_call.hip: paths, tasks and the per-class work queues are produced on the device).  d_idx holds the four class
+// queues back to back (class c: n_cls[c] task indices, heavy ones first); results / pools are device memory.
+// Leaves the pool heads in heads[4]; returns PF_ERR_OVERFLOW when a bubble exceeds the largest scratch tier
+// (its result then carries n_rows = 0xFFFFFFFF).
+int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]) {
+    hipStream_t st = ctx->stream;
+    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 128);  // pool heads, retry count, one queue head per launch
+    uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_BUB_RETRY, (size_t)std::max<uint32_t>(L.n_tasks, 1) * 4);
+    if (!small || !d_retry) return PF_ERR_HIP;
+    PF_HIP(hipMemsetAsync(small, 0, 128, st));
+    BubOut o;
+    o.res = L.res; o.text = L.otext; o.sites = L.osites; o.groups = L.ogroups; o.ilen = L.oilen;
+    o.text_cap = L.text_cap; o.site_cap = L.site_cap; o.group_cap = L.group_cap; o.ilen_cap = L.ilen_cap;
+    o.heads = reinterpret_cast<unsigned long long *>(small);
+    o.n_retry = reinterpret_cast<unsigned int *>(small + 40);
+    unsigned int *queue_heads = reinterpret_cast<unsigned int *>(small + 64);
+    int n_launch = 0;
+    o.retry = d_retry;
+
+    BubParams p;
+    memset(&p, 0, sizeof(p));
+    p.text = L.text; p.paths = L.paths; p.tasks = L.tasks; p.M = L.match; p.D = L.mismatch; p.G = L.gap;
+    p.integral = (L.match == std::floor(L.match) && L.mismatch == std::floor(L.mismatch) && L.gap == std::floor(L.gap) &&
+                  std::fabs(L.match) < 1e6 && std::fabs(L.mismatch) < 1e6 && std::fabs(L.gap) < 1e6) ? 1 : 0;
+    p.seq = ctx->d_seq; p.off = ctx->d_off; p.len = ctx->d_len; p.n_unitigs = ctx->N;
+    const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
+    // waves in flight: the kernel is a chain of dependent LDS / global accesses per bubble, so it wants
+    // every wave slot the LDS budget allows (5 KiB class: 32 per CU by LDS, capped at 24)
+    const int max_waves = ctx->n_cu * 24;
+    p.caps = std_caps;
+    p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
+    p.scratch = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
+    if (!p.scratch) return PF_ERR_HIP;
+
+    DevTmp<unsigned long long> clk_;
+    unsigned long long *d_clk = nullptr;
+    const bool want_clk = getenv("PF_BUBBLE_STATS") != nullptr;
+    if (want_clk) {
+        PF_HIP(clk_.alloc(((size_t)L.n_tasks + 8) * 8));
+        d_clk = clk_.p;
+        PF_HIP(hipMemsetAsync(d_clk, 0, ((size_t)L.n_tasks + 8) * 8, st));
+        p.task_clk = d_clk;
+        p.prof = d_clk + L.n_tasks;
+    }
+    static bool attr_set = false;
+    if (!attr_set) {
+        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bubble<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
+        attr_set = true;
+    }
+    uint32_t idx_off = 0;
+    for (int c = 0; c < 3; ++c) {
+        const uint32_t nc = L.n_cls[c];
+        if (nc == 0) continue;
+        p.idx = L.idx + idx_off;
+        p.n = nc;
+        p.work_bytes = (uint32_t)kBubClassBytes[c];
+        const int per_cu = c == 0 ? 24 : (c == 1 ? 7 : 2);
+        const int grid = (int)std::min<uint32_t>(nc, (uint32_t)(ctx->n_cu * per_cu));
+        p.next = queue_heads + n_launch++;
+        ctx_begin(ctx, PF_K_BUBBLE);
+        k_bubble<true><<<grid, 64, kBubClassBytes[c], st>>>(p, o);
+        ctx_end(ctx);
+        idx_off += nc;
+    }
+    if (L.n_cls[3]) {
+        const uint32_t nc = L.n_cls[3];
+        const int grid = (int)std::min<uint32_t>(nc, 256);
+        const uint64_t per = (std::min<uint64_t>(L.max_need * 2, 1ull << 31) + 255) & ~255ull;
+        uint8_t *work = (uint8_t *)ctx_ws(ctx, WS_BUB_WORK, per * grid);
+        if (!work) return PF_ERR_HIP;
+        p.idx = L.idx + idx_off;
+        p.n = nc;
+        p.work = work;
+        p.work_per_wave = per;
+        p.work_bytes = (uint32_t)std::min<uint64_t>(per, 0xFFFFFFFFu);
+        p.next = queue_heads + n_launch++;
+        ctx_begin(ctx, PF_K_BUBBLE_BIG);
+        k_bubble<false><<<grid, 64, 0, st>>>(p, o);
+        ctx_end(ctx);
+    }
+    unsigned int n_retry = 0;
+    PF_HIP(hipMemcpyAsync(&n_retry, o.n_retry, 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    int status = PF_OK;
+    DevTmp<uint8_t> big_scratch_, big_work_;
+    DevTmp<unsigned int> bad_;
+    if (n_retry) {
+        // some capacity of the standard tier was exceeded: rerun with 32x the scratch on a few waves.  The working storage a
+        // retried bubble needs is bounded by the longest rows it can produce: the sum of its path lengths (the host knows the
+        // exact figure when it described the batch; the resident caller passes the bound of its batch).
+        const uint64_t need = std::max<uint64_t>(1 << 20, L.retry_need);
+        const BubCaps big{2u << 20, 256 * 1024, 16 * 1024, 512 * 1024, 4u << 20, 8192, 256 * 1024};
+        const int grid = (int)std::min<uint32_t>(n_retry, 8);
+        const uint64_t per_s = (bub_scratch_bytes(big) + 255) & ~255ull;
+        const uint64_t per_w = (std::min<uint64_t>(need, 0xFFFFFF00u) + 255) & ~255ull;
+        PF_HIP(big_scratch_.alloc(per_s * grid));
+        PF_HIP(big_work_.alloc(per_w * grid));
+        PF_HIP(bad_.alloc(4));
+        PF_HIP(hipMemsetAsync(bad_.p, 0, 4, st));
+        // the retry list becomes the queue of the last launch (copied: the kernel appends to o.retry again on failure paths only
+        // in non-final tiers)
+        uint32_t *d_q = (uint32_t *)ctx_ws(ctx, WS_BUB_IDX2, (size_t)n_retry * 4);
+        if (!d_q) return PF_ERR_HIP;
+        PF_HIP(hipMemcpyAsync(d_q, d_retry, (size_t)n_retry * 4, hipMemcpyDeviceToDevice, st));
+        p.idx = d_q; p.n = n_retry; p.caps = big; p.scratch = big_scratch_.p; p.scratch_per_wave = per_s;
+        p.work = big_work_.p; p.work_per_wave = per_w; p.work_bytes = (uint32_t)per_w; p.final_tier = 1;
+        p.bad = bad_.p;
+        p.next = queue_heads + n_launch++;
+        ctx_begin(ctx, PF_K_BUBBLE_BIG);
+        k_bubble<false><<<grid, 64, 0, st>>>(p, o);
+        ctx_end(ctx);
+        unsigned int bad = 0;
+        PF_HIP(hipMemcpyAsync(&bad, bad_.p, 4, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        if (bad) {
+            ctx->err = "pf_align_bubbles: a bubble exceeds the largest scratch tier";
+            status = PF_ERR_OVERFLOW;
+        }
+    }
+    if (want_clk) {
+        const uint32_t n_tasks = L.n_tasks;
+        std::vector<unsigned long long> clk(n_tasks + 8);
+        PF_HIP(hipMemcpy(clk.data(), d_clk, ((size_t)n_tasks + 8) * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pf_align_bubbles] ticks by phase: fill %llu traceback %llu | decode %llu round0(incl. NW) %llu rounds %llu choose %llu publish %llu\n",
+                clk[n_tasks], clk[n_tasks + 1], clk[n_tasks + 2], clk[n_tasks + 3], clk[n_tasks + 4], clk[n_tasks + 5], clk[n_tasks + 6]);
+        clk.resize(n_tasks);
+        std::vector<unsigned long long> srt(clk);
+        std::sort(srt.begin(), srt.end());
+        unsigned long long tot = 0;
+        for (auto c : srt) tot += c;
+        fprintf(stderr, "[pf_align_bubbles] %u tasks: ticks(10ns) sum %llu  median %llu  p90 %llu  p99 %llu  p99.9 %llu  max %llu\n", n_tasks, tot,
+                srt[n_tasks / 2], srt[(size_t)(n_tasks * 0.9)], srt[(size_t)(n_tasks * 0.99)], srt[(size_t)(n_tasks * 0.999)], srt[n_tasks - 1]);
+    }
+    PF_HIP(hipMemcpy(heads, o.heads, 32, hipMemcpyDeviceToHost));
+    if (status == PF_OK && (heads[0] > L.text_cap || heads[1] > L.site_cap || heads[2] > L.group_cap || heads[3] > L.ilen_cap)) {
+        ctx->err = "pf_align_bubbles: output pools too small";
+        status = PF_ERR_OVERFLOW;
+    }
+    return status;
+}
+
+}  // namespace pf
 
 extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len, const pf_bubble_path *paths, uint64_t n_paths,
                                 const pf_bubble_task *tasks, uint32_t n_tasks, double match, double mismatch, double gap,
@@ -756,11 +905,10 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         hp = hp_own.data();
     }
     const std::vector<uint32_t> &hlen = ctx->h_len;  // unitig lengths for ov paths
-    const uint64_t cls_bytes[3] = {5 * 1024, 20 * 1024, 64 * 1024};
     std::vector<uint32_t> cls[4];
     std::vector<char> heavy;
     heavy.reserve(n_tasks);
-    uint64_t max_need = 0;
+    uint64_t max_need = 0, retry_need = 0;
     for (uint32_t t = 0; t < n_tasks; ++t) {
         const pf_bubble_task &tk = ht[t];
         if (tk.n_paths < 2 || tk.n_paths > 255 || tk.path_first + tk.n_paths > n_paths) {
@@ -768,6 +916,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
             return PF_ERR_ARG;
         }
         uint32_t l0 = 0, lmax = 0;
+        uint64_t sum = 0;
         for (uint32_t i = 0; i < tk.n_paths; ++i) {
             const pf_bubble_path &pp = hp[tk.path_first + i];
             if (pp.ov != PF_NONE) {
@@ -780,15 +929,13 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
             if (pp.len == 0 || pp.len > 60000) { ctx->err = "pf_align_bubbles: empty path or longer than 60000"; return PF_ERR_ARG; }
             if (i == 0) l0 = pp.len;
             lmax = std::max(lmax, pp.len);
+            sum += pp.len;
         }
-        // row 0 can grow by the gaps opened in later rounds: leave headroom, the device re-checks every job
-        const uint64_t need = job_bytes(std::max(l0, lmax) + 32, lmax);
-        int c = 3;
-        for (int x = 0; x < 3; ++x)
-            if (need <= cls_bytes[x]) { c = x; break; }
+        const int c = bubble_class(l0, lmax);
         cls[c].push_back(t);
         heavy.push_back(tk.n_paths > 2 || lmax > 64);
-        if (c == 3) max_need = std::max(max_need, need);
+        if (c == 3) max_need = std::max(max_need, bubble_need(l0, lmax));
+        retry_need = std::max(retry_need, job_bytes((uint32_t)std::min<uint64_t>(sum, 60000), lmax));
     }
     for (auto &v : cls)  // multi-path / long bubbles first (stable: the order inside each half is kept)
         std::stable_partition(v.begin(), v.end(), [&](uint32_t t) { return heavy[t]; });
@@ -802,167 +949,45 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     }
     pf_bubble_path *d_paths = (pf_bubble_path *)ctx_ws(ctx, WS_BUB_PATHS, std::max<uint64_t>(n_paths, 1) * sizeof(pf_bubble_path));
     pf_bubble_task *d_tasks = (pf_bubble_task *)ctx_ws(ctx, WS_BUB_TASKS, (size_t)n_tasks * sizeof(pf_bubble_task));
-    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 128);  // pool heads, retry count, one queue head per launch
-    uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_BUB_RETRY, (size_t)n_tasks * 4);
     uint32_t *d_idx = (uint32_t *)ctx_ws(ctx, WS_BUB_IDX, (size_t)n_tasks * 4);
-    if (!d_paths || !d_tasks || !small || !d_retry || !d_idx) return PF_ERR_HIP;
+    if (!d_paths || !d_tasks || !d_idx) return PF_ERR_HIP;
     PF_HIP(hipMemcpyAsync(d_paths, hp, (size_t)n_paths * sizeof(pf_bubble_path), hipMemcpyHostToDevice, st));
     PF_HIP(hipMemcpyAsync(d_tasks, ht, (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyHostToDevice, st));
-    PF_HIP(hipMemsetAsync(small, 0, 128, st));
     const bool dev_out = is_dev(results);
-    BubOut o;
+    BubbleLaunch L;
     if (dev_out) {
-        o.res = results; o.text = out_text; o.sites = out_sites; o.groups = out_groups; o.ilen = out_ilen;
+        L.res = results; L.otext = out_text; L.osites = out_sites; L.ogroups = out_groups; L.oilen = out_ilen;
     } else {
-        o.res = (pf_bubble_result *)ctx_ws(ctx, WS_BUB_RES, (size_t)n_tasks * sizeof(pf_bubble_result));
-        o.text = (char *)ctx_ws(ctx, WS_BUB_OTEXT, std::max<uint64_t>(text_cap, 1));
-        o.sites = (pf_bubble_site *)ctx_ws(ctx, WS_BUB_OSITES, std::max<uint64_t>(site_cap, 1) * sizeof(pf_bubble_site));
-        o.groups = (uint8_t *)ctx_ws(ctx, WS_BUB_OGROUPS, std::max<uint64_t>(group_cap, 1));
-        o.ilen = (uint32_t *)ctx_ws(ctx, WS_BUB_OILEN, std::max<uint64_t>(ilen_cap, 1) * 4);
-        if (!o.res || !o.text || !o.sites || !o.groups || !o.ilen) return PF_ERR_HIP;
+        L.res = (pf_bubble_result *)ctx_ws(ctx, WS_BUB_RES, (size_t)n_tasks * sizeof(pf_bubble_result));
+        L.otext = (char *)ctx_ws(ctx, WS_BUB_OTEXT, std::max<uint64_t>(text_cap, 1));
+        L.osites = (pf_bubble_site *)ctx_ws(ctx, WS_BUB_OSITES, std::max<uint64_t>(site_cap, 1) * sizeof(pf_bubble_site));
+        L.ogroups = (uint8_t *)ctx_ws(ctx, WS_BUB_OGROUPS, std::max<uint64_t>(group_cap, 1));
+        L.oilen = (uint32_t *)ctx_ws(ctx, WS_BUB_OILEN, std::max<uint64_t>(ilen_cap, 1) * 4);
+        if (!L.res || !L.otext || !L.osites || !L.ogroups || !L.oilen) return PF_ERR_HIP;
     }
-    o.text_cap = text_cap; o.site_cap = site_cap; o.group_cap = group_cap; o.ilen_cap = ilen_cap;
-    o.heads = reinterpret_cast<unsigned long long *>(small);
-    o.n_retry = reinterpret_cast<unsigned int *>(small + 40);
-    unsigned int *queue_heads = reinterpret_cast<unsigned int *>(small + 64);
-    int n_launch = 0;
-    o.retry = d_retry;
-
-    BubParams p;
-    memset(&p, 0, sizeof(p));
-    p.text = d_text; p.paths = d_paths; p.tasks = d_tasks; p.M = match; p.D = mismatch; p.G = gap;
-    p.integral = (match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap) &&
-                  std::fabs(match) < 1e6 && std::fabs(mismatch) < 1e6 && std::fabs(gap) < 1e6) ? 1 : 0;
-    p.seq = ctx->d_seq; p.off = ctx->d_off; p.len = ctx->d_len; p.n_unitigs = ctx->N;
-    const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
-    // waves in flight: the kernel is a chain of dependent LDS / global accesses per bubble, so it wants
-    // every wave slot the LDS budget allows (5 KiB class: 32 per CU by LDS, capped at 24)
-    const int max_waves = ctx->n_cu * 24;
-    p.caps = std_caps;
-    p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
-    p.scratch = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
-    if (!p.scratch) return PF_ERR_HIP;
-
-    DevTmp<unsigned long long> clk_;
-    unsigned long long *d_clk = nullptr;
-    const bool want_clk = getenv("PF_BUBBLE_STATS") != nullptr;
-    if (want_clk) {
-        PF_HIP(clk_.alloc(((size_t)n_tasks + 8) * 8));
-        d_clk = clk_.p;
-        PF_HIP(hipMemsetAsync(d_clk, 0, ((size_t)n_tasks + 8) * 8, st));
-        p.task_clk = d_clk;
-        p.prof = d_clk + n_tasks;
-    }
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bubble<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set = true;
-    }
+    L.text_cap = text_cap; L.site_cap = site_cap; L.group_cap = group_cap; L.ilen_cap = ilen_cap;
+    L.text = d_text; L.paths = d_paths; L.tasks = d_tasks; L.n_tasks = n_tasks;
+    L.match = match; L.mismatch = mismatch; L.gap = gap;
     uint32_t idx_off = 0;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < 4; ++c) {
+        L.n_cls[c] = (uint32_t)cls[c].size();
         if (cls[c].empty()) continue;
-        const uint32_t nc = (uint32_t)cls[c].size();
-        PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[c].data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
-        p.idx = d_idx + idx_off;
-        p.n = nc;
-        p.work_bytes = (uint32_t)cls_bytes[c];
-        const int per_cu = c == 0 ? 24 : (c == 1 ? 7 : 2);
-        const int grid = (int)std::min<uint32_t>(nc, (uint32_t)(ctx->n_cu * per_cu));
-        p.next = queue_heads + n_launch++;
-        ctx_begin(ctx, PF_K_BUBBLE);
-        k_bubble<true><<<grid, 64, cls_bytes[c], st>>>(p, o);
-        ctx_end(ctx);
-        idx_off += nc;
+        PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[c].data(), cls[c].size() * 4, hipMemcpyHostToDevice, st));
+        idx_off += (uint32_t)cls[c].size();
     }
-    if (!cls[3].empty()) {
-        const uint32_t nc = (uint32_t)cls[3].size();
-        const int grid = (int)std::min<uint32_t>(nc, 256);
-        const uint64_t per = (std::min<uint64_t>(max_need * 2, 1ull << 31) + 255) & ~255ull;
-        uint8_t *work = (uint8_t *)ctx_ws(ctx, WS_BUB_WORK, per * grid);
-        if (!work) return PF_ERR_HIP;
-        PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[3].data(), (size_t)nc * 4, hipMemcpyHostToDevice, st));
-        p.idx = d_idx + idx_off;
-        p.n = nc;
-        p.work = work;
-        p.work_per_wave = per;
-        p.work_bytes = (uint32_t)std::min<uint64_t>(per, 0xFFFFFFFFu);
-        p.next = queue_heads + n_launch++;
-        ctx_begin(ctx, PF_K_BUBBLE_BIG);
-        k_bubble<false><<<grid, 64, 0, st>>>(p, o);
-        ctx_end(ctx);
-    }
-    unsigned int n_retry = 0;
-    PF_HIP(hipMemcpyAsync(&n_retry, o.n_retry, 4, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
-    int status = PF_OK;
-    DevTmp<uint8_t> big_scratch_, big_work_;
-    if (n_retry) {
-        // some capacity of the standard tier was exceeded: rerun with 32x the scratch on a few waves
-        std::vector<uint32_t> rj(n_retry);
-        PF_HIP(hipMemcpy(rj.data(), d_retry, (size_t)n_retry * 4, hipMemcpyDeviceToHost));
-        uint64_t need = 1 << 20;
-        for (uint32_t t : rj) {
-            uint64_t sum = 0, lmax = 0;
-            for (uint32_t i = 0; i < ht[t].n_paths; ++i) { sum += hp[ht[t].path_first + i].len; lmax = std::max<uint64_t>(lmax, hp[ht[t].path_first + i].len); }
-            need = std::max(need, job_bytes((uint32_t)std::min<uint64_t>(sum, 60000), (uint32_t)lmax));
-        }
-        const BubCaps big{2u << 20, 256 * 1024, 16 * 1024, 512 * 1024, 4u << 20, 8192, 256 * 1024};
-        const int grid = (int)std::min<uint32_t>(n_retry, 8);
-        const uint64_t per_s = (bub_scratch_bytes(big) + 255) & ~255ull;
-        const uint64_t per_w = (std::min<uint64_t>(need, 0xFFFFFF00u) + 255) & ~255ull;
-        PF_HIP(big_scratch_.alloc(per_s * grid));
-        PF_HIP(big_work_.alloc(per_w * grid));
-        uint8_t *big_scratch = big_scratch_.p, *big_work = big_work_.p;
-        PF_HIP(hipMemcpyAsync(d_idx, rj.data(), (size_t)n_retry * 4, hipMemcpyHostToDevice, st));
-        p.idx = d_idx; p.n = n_retry; p.caps = big; p.scratch = big_scratch; p.scratch_per_wave = per_s;
-        p.work = big_work; p.work_per_wave = per_w; p.work_bytes = (uint32_t)per_w; p.final_tier = 1;
-        p.next = queue_heads + n_launch++;
-        ctx_begin(ctx, PF_K_BUBBLE_BIG);
-        k_bubble<false><<<grid, 64, 0, st>>>(p, o);
-        ctx_end(ctx);
-        PF_HIP(hipStreamSynchronize(st));
-    }
-    if (want_clk) {
-        std::vector<unsigned long long> clk(n_tasks + 8);
-        PF_HIP(hipMemcpy(clk.data(), d_clk, ((size_t)n_tasks + 8) * 8, hipMemcpyDeviceToHost));
-        fprintf(stderr, "[pf_align_bubbles] ticks by phase: fill %llu traceback %llu | decode %llu round0(incl. NW) %llu rounds %llu choose %llu publish %llu\n",
-                clk[n_tasks], clk[n_tasks + 1], clk[n_tasks + 2], clk[n_tasks + 3], clk[n_tasks + 4], clk[n_tasks + 5], clk[n_tasks + 6]);
-        clk.resize(n_tasks);
-        std::vector<unsigned long long> srt(clk);
-        std::sort(srt.begin(), srt.end());
-        unsigned long long tot = 0;
-        for (auto c : srt) tot += c;
-        fprintf(stderr, "[pf_align_bubbles] %u tasks: ticks(10ns) sum %llu  median %llu  p90 %llu  p99 %llu  p99.9 %llu  max %llu\n", n_tasks, tot,
-                srt[n_tasks / 2], srt[(size_t)(n_tasks * 0.9)], srt[(size_t)(n_tasks * 0.99)], srt[(size_t)(n_tasks * 0.999)], srt[n_tasks - 1]);
-        for (int top = 0; top < 5 && top < (int)n_tasks; ++top) {
-            const uint32_t t = (uint32_t)(std::max_element(clk.begin(), clk.end()) - clk.begin());
-            fprintf(stderr, "   slowest: task %u ticks %llu paths %u lens", t, clk[t], ht[t].n_paths);
-            for (uint32_t i = 0; i < ht[t].n_paths && i < 8; ++i) fprintf(stderr, " %u", hp[ht[t].path_first + i].len);
-            fprintf(stderr, "\n");
-            clk[t] = 0;
-        }
-    }
-    unsigned long long heads[4];
-    PF_HIP(hipMemcpy(heads, o.heads, 32, hipMemcpyDeviceToHost));
+    L.idx = d_idx;
+    L.max_need = max_need;
+    L.retry_need = retry_need;
+    unsigned long long heads[4] = {0, 0, 0, 0};
+    int status = bubble_launch(ctx, L, heads);
     for (int x = 0; x < 4; ++x) used[x] = heads[x];
-    if (heads[0] > text_cap || heads[1] > site_cap || heads[2] > group_cap || heads[3] > ilen_cap) {
-        ctx->err = "pf_align_bubbles: output pools too small";
-        status = PF_ERR_OVERFLOW;
-    }
     if (!dev_out && status == PF_OK) {
-        PF_HIP(hipMemcpyAsync(results, o.res, (size_t)n_tasks * sizeof(pf_bubble_result), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipMemcpyAsync(out_text, o.text, (size_t)heads[0], hipMemcpyDeviceToHost, st));
-        PF_HIP(hipMemcpyAsync(out_sites, o.sites, (size_t)heads[1] * sizeof(pf_bubble_site), hipMemcpyDeviceToHost, st));
-        PF_HIP(hipMemcpyAsync(out_groups, o.groups, (size_t)heads[2], hipMemcpyDeviceToHost, st));
-        PF_HIP(hipMemcpyAsync(out_ilen, o.ilen, (size_t)heads[3] * 4, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(results, L.res, (size_t)n_tasks * sizeof(pf_bubble_result), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_text, L.otext, (size_t)heads[0], hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_sites, L.osites, (size_t)heads[1] * sizeof(pf_bubble_site), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_groups, L.ogroups, (size_t)heads[2], hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(out_ilen, L.oilen, (size_t)heads[3] * 4, hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
-        if (n_retry)
-            for (uint32_t t = 0; t < n_tasks; ++t)
-                if (results[t].n_rows == 0xFFFFFFFFu) {
-                    ctx->err = "pf_align_bubbles: a bubble exceeds the largest scratch tier";
-                    status = PF_ERR_OVERFLOW;
-                    break;
-                }
     }
     return status;
 }

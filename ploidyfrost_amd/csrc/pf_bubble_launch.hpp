@@ -1,0 +1,50 @@
+// K-BUBBLE launch interface shared by pf_bubble.hip (pf_align_bubbles: batches described by the host) and pf_call.hip (the
+// resident calling pipeline: paths, tasks and per-class work queues produced on the device).
+#pragma once
+#include <stdint.h>
+
+#include "pf_align_dev.hpp"
+#include "ploidyfrost_hip.h"
+
+struct pf_ctx;
+
+namespace pf {
+
+// LDS size classes of the Needleman-Wunsch working storage (bytes per wavefront); class 3 = global memory
+constexpr uint64_t kBubClassBytes[3] = {5 * 1024, 20 * 1024, 64 * 1024};
+
+// working storage a bubble whose first path has l0 characters and whose longest has lmax may need: row 0 can grow by the gaps
+// opened in later rounds, so there is headroom; the device re-checks every job against its tier
+__host__ __device__ inline uint64_t bubble_need(uint32_t l0, uint32_t lmax) {
+    return job_bytes((l0 > lmax ? l0 : lmax) + 32, lmax);
+}
+__host__ __device__ inline int bubble_class(uint32_t l0, uint32_t lmax) {
+    const uint64_t need = bubble_need(l0, lmax);
+    for (int x = 0; x < 3; ++x)
+        if (need <= kBubClassBytes[x]) return x;
+    return 3;
+}
+
+struct BubbleLaunch {
+    // inputs, device memory
+    const char *text = nullptr;
+    const pf_bubble_path *paths = nullptr;
+    const pf_bubble_task *tasks = nullptr;
+    uint32_t n_tasks = 0;             // size of tasks / res (queues may list fewer)
+    const uint32_t *idx = nullptr;    // class queues back to back
+    uint32_t n_cls[4] = {0, 0, 0, 0};
+    uint64_t max_need = 0;            // largest bubble_need among class 3
+    uint64_t retry_need = 0;          // working storage bound for the retry tier
+    double match = 2, mismatch = -1, gap = -3;
+    // outputs, device memory
+    pf_bubble_result *res = nullptr;
+    char *otext = nullptr;
+    pf_bubble_site *osites = nullptr;
+    uint8_t *ogroups = nullptr;
+    uint32_t *oilen = nullptr;
+    uint64_t text_cap = 0, site_cap = 0, group_cap = 0, ilen_cap = 0;
+};
+
+int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]);
+
+}  // namespace pf

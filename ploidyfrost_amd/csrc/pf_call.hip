@@ -1,0 +1,1389 @@
+// The resident calling pipeline: CDBG::ploidyEstimation_ptr (reference src/CDBG.cpp:1101-1705) with everything between
+// the commit replay and the file system on the MI355X.  The host uploads the MyUnitig state, runs the light sequential
+// part of the driver loop on compact side records, and appends the text slabs it gets back to the ten result files;
+// bubbles never exist on the host as objects.
+//
+//   K-SCAN    k_call_sides   one thread per unitig: for each open endpoint side what the driver loop (:1146-1222, 1347-1363)
+//                            would do there -- exit by first successors, ownership (reference-string compare on the
+//                            2-bit words), coverage gate, sortSeq_simple -- from static state only
+//   K-PREP    k_call_prep    one thread per selected bubble: strict bubbles become K-BUBBLE tasks whose paths are oriented
+//                            unitigs; branching ones are queued for K-PATHS; every task lands in the work queue of its
+//                            LDS size class
+//   K-PATHS   k_call_paths   one wavefront per branching bubble: the two-stack enumeration of all s->t walks (:1364-1412),
+//                            path strings decoded lane-parallel from the 2-bit graph, sortSeq_branching as a rank sort
+//   K-BUBBLE  (pf_bubble.hip) SeqAlign::SequenceAlignment for every task
+//   K-SITES   k_call_sites   one wavefront per branching bubble: per-site k-length strings (:1448-1600), de-duplicated per
+//                            allele group in std::set order, looked up in the count table (readCov(string), :29-60),
+//                            group coverages accumulated in the reference's order
+//   K-TEXT    k_call_format  one thread per bubble, twice: measure, (scan,) write -- the rows of alignseq.txt,
+//                            allele_frequency.txt and the eight {bi,tri,tetra,penta}{cov,fre}.txt files, numbers printed
+//                            as `ostream << double` does (pf_format_dev.hpp); bubble numbering (var_count) by a scan
+//
+// All integer / byte work with data-dependent control flow; HBM traffic is the text itself.  No MFMA.
+#include <hip/hip_runtime.h>
+
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "pf_bubble_launch.hpp"
+#include "pf_call_dev.hpp"
+#include "pf_ctx.hpp"
+#include "pf_device_common.hpp"
+#include "pf_format_dev.hpp"
+#include "ploidyfrost_hip.h"
+
+using namespace pf;
+
+#define PF_HIP(call)                                                                         \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            return PF_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+namespace {
+
+constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_STRICT_M = 0x08, B_STRICT_P = 0x10, B_COMPLEX_M = 0x20, B_COMPLEX_P = 0x40;
+constexpr int N_STREAMS = PF_CALL_STREAMS;
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    template <typename T>
+    T *as() const { return reinterpret_cast<T *>(p); }
+    // contents are not preserved
+    bool ensure(size_t bytes) {
+        if (bytes <= cap && p) return true;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t want = bytes + bytes / 4 + 256;
+        if (hipMalloc(&p, want) != hipSuccess) { (void)hipGetLastError(); p = nullptr; return false; }
+        cap = want;
+        return true;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// counters of one batch, device side (zeroed per batch)
+struct CallCounters {
+    unsigned int q_n[8];            // work queues: class c heavy = q_n[2c], light = q_n[2c + 1]
+    unsigned int n_branching;
+    unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
+    unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
+                                    // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
+    unsigned long long path_head, text_head, sv_head;
+    unsigned long long max_need, retry_need;
+    unsigned long long allele[4], core_cov, core_num, n_called, site_strings;
+};
+
+}  // namespace
+
+namespace pf {
+
+struct CallState {
+    // T1 state
+    DevBuf flags, plus, minus;
+    bool have_state = false;
+    // C1 results, one slot per unitig (two per unitig for a database without canonical counting)
+    DevBuf cov_sum, cov_min, cov_miss;
+    bool have_cov = false, per_strand = false;
+    // scan
+    DevBuf side_cnt, side_base, sides, ctask, scan_tmp;
+    uint64_t n_sides = 0;
+    uint32_t low = 0, up = 0;
+    // selection
+    DevBuf kept;
+    uint64_t n_tasks = 0;
+    // per batch
+    DevBuf counters, btask, bpath, ptext, queues, blist, res, otext, osites, ogroups, oilen, sv_off, sv, has, vc, sizes, offs, totals,
+        scan_tmp2, paths_scr, sites_scr;
+    uint64_t path_pool = 0, text_pool = 0, sv_pool = 0;   // capacities learnt from earlier batches
+    uint64_t otext_cap = 0, osites_cap = 0, ogroups_cap = 0, oilen_cap = 0;
+    // output slabs: two sets, so that one can be fetched while the next batch is formatted
+    DevBuf out[2][N_STREAMS];
+    uint64_t out_len[2][N_STREAMS] = {};
+    hipStream_t copy_stream = nullptr;
+    // the batch pf_call_align left resident for pf_call_text
+    uint64_t cur_t0 = 0;
+    uint32_t cur_nb = 0;
+    pf_call_result cur = {};
+    void release_all() {
+        DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &kept, &counters,
+                         &btask, &bpath, &ptext, &queues, &blist, &res, &otext, &osites, &ogroups, &oilen, &sv_off, &sv, &has, &vc, &sizes, &offs,
+                         &totals, &scan_tmp2, &paths_scr, &sites_scr};
+        for (DevBuf *b : all) b->release();
+        for (auto &s : out)
+            for (DevBuf &b : s) b.release();
+        if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+    }
+};
+
+void call_destroy(pf_ctx *ctx) {
+    if (!ctx->call) return;
+    ctx->call->release_all();
+    delete ctx->call;
+    ctx->call = nullptr;
+}
+void call_invalidate(pf_ctx *ctx) {  // a new graph or count table: resident scan results no longer apply
+    if (!ctx->call) return;
+    ctx->call->have_cov = false;
+    ctx->call->have_state = false;
+    ctx->call->n_sides = ctx->call->n_tasks = 0;
+}
+
+}  // namespace pf
+
+namespace {
+
+CallState *state_of(pf_ctx *ctx) {
+    if (!ctx->call) {
+        ctx->call = new CallState();
+        // copies of finished text slabs run beside the next batch's kernels
+        if (hipStreamCreateWithFlags(&ctx->call->copy_stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); ctx->call->copy_stream = nullptr; }
+    }
+    return ctx->call;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-SCAN
+struct ScanArgs {
+    const uint8_t *flags;
+    const uint32_t *plus, *minus, *succ, *pred;
+    const uint64_t *seq, *off;
+    const uint32_t *len;
+    uint32_t N;
+    int k;
+    const uint64_t *cov_sum;
+    const uint32_t *cov_min;
+    const uint8_t *cov_miss;
+    int per_strand;
+    uint32_t low, up;
+    const uint32_t *side_base;  // exclusive scan of the per-unitig side counts
+    pf_call_side *sides;
+    CallTask *tasks;
+};
+
+__global__ void k_call_count_sides(const uint8_t *__restrict__ flags, uint32_t N, uint32_t *__restrict__ cnt) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u <= N) cnt[u] = u < N ? (uint32_t)__popc(flags[u] & 3u) : 0u;
+}
+
+__device__ inline uint32_t first_succ(const uint32_t *__restrict__ succ, uint32_t ov) {
+    const uint4 r = *reinterpret_cast<const uint4 *>(succ + (size_t)ov * 4);
+    if (r.x != NONE) return r.x;
+    if (r.y != NONE) return r.y;
+    if (r.z != NONE) return r.z;
+    return r.w;
+}
+
+__global__ __launch_bounds__(256) void k_call_sides(ScanArgs a) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.N) return;
+    const uint8_t f = a.flags[u];
+    if ((f & 3) == 0) return;
+    uint32_t slot = a.side_base[u];
+    const uint32_t N = a.N;
+    auto cslot = [&](uint32_t ov) -> size_t { return (a.per_strand && (ov & 1)) ? (size_t)N + (ov >> 1) : (size_t)(ov >> 1); };
+    auto len_km = [&](uint32_t x) { return a.len[x] - (uint32_t)a.k + 1; };
+    auto mean_ov = [&](uint32_t ov) { return (double)a.cov_sum[cslot(ov)] / (double)len_km(ov >> 1); };
+    for (int side = 0; side < 2; ++side) {
+        const bool ps = side == 0;
+        if (!(f & (ps ? B_PLUS : B_MINUS))) continue;
+        pf_call_side r;
+        r.u = u;
+        r.exit_ov = NONE;
+        r.err_unitig = 0;
+        r.plus_side = ps;
+        r.kind = 0;
+        r.aligned = 0;
+        r.err = 0;
+        CallTask t;
+        t.u = u;
+        t.entrance_ov = t.exit_ov = 0;
+        t.strict = t.n_inner = t.n_cov = t.pad_ = 0;
+        for (int q = 0; q < 4; ++q) { t.inner[q] = 0; t.cov[q] = 0; }
+        t.core_mean = t.cov_sum = 0;
+        const uint32_t my = slot++;
+        do {
+            if (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) { r.kind = 1; break; }
+            const uint32_t uo = 2 * u + (ps ? 0 : 1);
+            const bool strict = (f & (ps ? B_STRICT_P : B_STRICT_M)) != 0;
+            if (a.cov_miss[cslot(uo)]) { r.err = 1; r.err_unitig = u; break; }  // core = readCov(u), u oriented
+            uint32_t exit_ov;
+            if (strict) {
+                exit_ov = first_succ(a.succ, uo);
+                if (exit_ov != NONE) exit_ov = first_succ(a.succ, exit_ov);
+            } else {
+                const uint32_t want = ps ? a.plus[u] : a.minus[u];
+                exit_ov = first_succ(a.succ, uo);
+                // (bounded: a walk longer than the graph means the partner is not on the first-successor chain)
+                for (uint32_t steps = 0; exit_ov != NONE && (exit_ov >> 1) + 1 != want; ++steps) {
+                    if (steps > N) { exit_ov = NONE; break; }
+                    exit_ov = first_succ(a.succ, exit_ov);
+                }
+            }
+            if (exit_ov == NONE) { r.err = 2; break; }
+            const uint32_t eu = exit_ov >> 1;
+            r.exit_ov = exit_ov;
+            t.entrance_ov = uo;
+            t.exit_ov = exit_ov;
+            t.strict = strict;
+            if (unitig_cmp(a.seq, a.off, a.len, u, eu) < 0) { r.kind = 2; break; }  // the other endpoint owns this bubble
+            r.kind = 3;
+            t.core_mean = mean_ov(uo);
+            bool aligned = true;
+            if (strict) {
+                const uint32_t *row = a.succ + (size_t)uo * 4;
+                for (int b = 0; b < 4 && aligned && !r.err; ++b) {
+                    const uint32_t w = row[b];
+                    if (w == NONE) continue;
+                    t.inner[t.n_inner++] = w;
+                    if (a.cov_miss[cslot(w)]) { r.err = 1; r.err_unitig = w >> 1; break; }
+                    const uint32_t mn = a.cov_min[cslot(w)];
+                    if (mn > a.low && mn < a.up) {
+                        const double mcov = mean_ov(w);
+                        t.cov[t.n_cov++] = mcov;
+                        t.cov_sum += mcov;
+                    } else {
+                        aligned = false;
+                    }
+                }
+                if (aligned && !r.err) {
+                    // the reference also reads the predecessors' coverage and drops it (src/CDBG.cpp:1224-1239)
+                    const uint32_t *prow = a.pred + (size_t)uo * 4;
+                    for (int b = 0; b < 4; ++b) {
+                        const uint32_t w = prow[b];
+                        if (w != NONE && a.cov_miss[cslot(w)]) { r.err = 1; r.err_unitig = w >> 1; break; }
+                    }
+                    if (!r.err) sort_inner_dev(a.seq, a.off, a.len, t.cov, t.inner, (int)t.n_cov);
+                }
+            }
+            r.aligned = aligned;
+        } while (false);
+        a.sides[my] = r;
+        a.tasks[my] = t;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-PREP
+struct PrepArgs {
+    const CallTask *ct;
+    const uint32_t *kept;
+    uint64_t t0;
+    uint32_t nb;
+    const uint32_t *len;
+    pf_bubble_task *btask;
+    pf_bubble_path *bpath;
+    pf_bubble_result *res;
+    uint32_t *queues;  // 8 lists of nb entries
+    uint32_t *blist;   // branching bubbles (batch-local indices)
+    CallCounters *cnt;
+};
+
+// appends `val` to one of 9 lists chosen by key (0..7 work queues, 8 branching list; 9 = none): one atomic per key and wave
+__device__ inline void wave_append(int key, uint32_t val, uint32_t *queues, uint32_t nb, uint32_t *blist, CallCounters *cnt) {
+    for (int x = 0; x < 9; ++x) {
+        const unsigned long long m = __ballot(key == x);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane_id() == leader) base = atomicAdd(x < 8 ? &cnt->q_n[x] : &cnt->n_branching, (unsigned int)__popcll(m));
+        base = __shfl(base, leader, WAVE);
+        if (key == x) {
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
+            if (x < 8) queues[(size_t)x * nb + at] = val;
+            else blist[at] = val;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    int key = 9;
+    unsigned long long need3 = 0, retry = 0;
+    if (j < a.nb) {
+        const CallTask &t = a.ct[a.kept[a.t0 + j]];
+        pf_bubble_result z;
+        z.rows_off = z.site_off = z.group_off = z.ilen_off = 0;
+        z.n_rows = z.n_cols = z.n_sites = z.n_indel_len = 0;
+        a.res[j] = z;
+        if (t.strict) {
+            uint32_t l0 = 0, lmax = 0, sum = 0;
+            for (int q = 0; q < t.n_inner; ++q) {
+                const uint32_t L = a.len[t.inner[q] >> 1];
+                a.bpath[(size_t)4 * j + q] = pf_bubble_path{0, L, t.inner[q]};
+                if (q == 0) l0 = L;
+                lmax = L > lmax ? L : lmax;
+                sum += L;
+            }
+            a.btask[j] = pf_bubble_task{(uint64_t)4 * j, t.n_inner, 0};
+            if (t.n_inner >= 2) {  // fewer than two paths: the reference indexes str[1] blindly; skipped
+                const int c = bubble_class(l0, lmax);
+                key = 2 * c + ((t.n_inner > 2 || lmax > 64) ? 0 : 1);
+                if (c == 3) need3 = bubble_need(l0, lmax);
+                retry = job_bytes(sum < 60000u ? sum : 60000u, lmax);
+            }
+        } else {
+            a.btask[j] = pf_bubble_task{0, 0, 0};
+            key = 8;
+        }
+    }
+    wave_append(key, j, a.queues, a.nb, a.blist, a.cnt);
+    // class 3 / retry sizing: rare, one atomic per wave that has any
+    unsigned long long m3 = need3, mr = retry;
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned long long x3 = ((unsigned long long)__shfl_down((uint32_t)(m3 >> 32), o, WAVE) << 32) | __shfl_down((uint32_t)m3, o, WAVE);
+        const unsigned long long xr = ((unsigned long long)__shfl_down((uint32_t)(mr >> 32), o, WAVE) << 32) | __shfl_down((uint32_t)mr, o, WAVE);
+        m3 = x3 > m3 ? x3 : m3;
+        mr = xr > mr ? xr : mr;
+    }
+    if (lane_id() == 0) {
+        if (m3) atomicMax(&a.cnt->max_need, m3);
+        if (mr) atomicMax(&a.cnt->retry_need, mr);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-PATHS
+struct PathArgs {
+    const CallTask *ct;
+    const uint32_t *kept;
+    uint64_t t0;
+    uint32_t nb;
+    const uint32_t *blist;
+    const uint32_t *succ;
+    const uint64_t *seq, *off;
+    const uint32_t *len;
+    int k;
+    uint32_t depth_cap;     // entries of the major stack (complex size + slack); minor holds 4x
+    uint8_t *scratch;       // per wave: major[depth_cap], minor[4 depth_cap], poff[256] (u64), plen[256]
+    uint64_t scratch_per_wave;
+    pf_bubble_task *btask;
+    pf_bubble_path *bpath;  // strict region [0, 4 nb), then the pool
+    uint64_t path_cap;      // entries available behind the strict region
+    char *text;
+    uint64_t text_cap;
+    uint32_t *queues;
+    CallCounters *cnt;
+};
+
+constexpr uint32_t MAX_PATHS = 255;
+
+__device__ inline char path_char(const PathArgs &a, const uint32_t *major, const uint32_t *seg_start, uint32_t n_seg, uint32_t pos,
+                                 uint32_t first_idx) {
+    // segment holding character `pos` of the path string: linear search, segments are few
+    uint32_t x = 0;
+    while (x + 1 < n_seg && seg_start[x + 1] <= pos) ++x;
+    const uint32_t idx = pos - seg_start[x] + (x == 0 ? first_idx : 0);
+    return "ACGT"[oriented_base(a.seq, a.off, a.len, major[x], idx)];
+}
+
+__global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
+    const int lane = lane_id();
+    uint8_t *scr = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
+    unsigned long long *poff = reinterpret_cast<unsigned long long *>(scr);   // 256 entries
+    uint32_t *plen = reinterpret_cast<uint32_t *>(poff + 256);                  // 256
+    uint32_t *major = plen + 256;                                               // depth_cap
+    uint32_t *minor = major + a.depth_cap;                                      // 4 depth_cap
+    uint32_t *seg_start = minor + 4 * a.depth_cap;                              // depth_cap + 1
+    const uint32_t n_branching = a.cnt->n_branching;
+    unsigned long long tx_cur = 0, tx_end = 0;  // this wave's chunk of the text pool (one atomic per ~40 paths)
+    for (;;) {
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(&a.cnt->paths_next, 1u);
+        q = read_lane(q, 0);
+        if (q >= n_branching) break;
+        const uint32_t j = a.blist[q];
+        const CallTask &t = a.ct[a.kept[a.t0 + j]];
+        const uint32_t eu = t.exit_ov >> 1;
+        const uint32_t ulen = a.len[t.u] - (uint32_t)a.k + 1;
+        // ---- two-stack enumeration of every s -> t walk (src/CDBG.cpp:1364-1412); wave-uniform ----
+        uint32_t n_major = 0, n_minor = 0, n_paths = 0;
+        bool too_many = false, too_deep = false;
+        if (lane == 0) minor[0] = t.entrance_ov;
+        n_minor = 1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        while (n_minor && !too_many && !too_deep) {
+            const uint32_t w = minor[n_minor - 1];
+            --n_minor;
+            if (n_major >= a.depth_cap) { too_deep = true; break; }
+            if (lane == 0) major[n_major] = w;
+            ++n_major;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            if ((w >> 1) == eu) {
+                // the string from the start of s's last k-mer through t's first k-mer: one character of s, the first len - k + 1
+                // characters of every inner unitig, the first k of t
+                if (n_paths >= MAX_PATHS) { too_many = true; break; }
+                uint32_t total = 0;
+                for (uint32_t x = 0; x < n_major; ++x) {
+                    if (lane == 0) seg_start[x] = total;
+                    const uint32_t wl = a.len[major[x] >> 1] - (uint32_t)a.k + 1;
+                    total += x == 0 ? 1u : (x + 1 == n_major ? (uint32_t)a.k : wl);
+                }
+                if (n_major == 1) total = 0;  // s == t cannot be a bubble; keep the arithmetic sane
+                if (total > tx_end - tx_cur) {
+                    const unsigned long long want = total > 4096u ? total : 4096u;
+                    unsigned long long got = 0;
+                    if (lane == 0) got = atomicAdd(&a.cnt->text_head, want);
+                    got = ((unsigned long long)read_lane((uint32_t)(got >> 32), 0) << 32) | read_lane((uint32_t)got, 0);
+                    tx_cur = got;
+                    tx_end = got + want;
+                }
+                const unsigned long long at = tx_cur;
+                tx_cur += total;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (at + total <= a.text_cap)
+                    for (uint32_t p = lane; p < total; p += WAVE) a.text[at + p] = path_char(a, major, seg_start, n_major, p, ulen - 1);
+                if (lane == 0) { poff[n_paths] = at; plen[n_paths] = total; }
+                ++n_paths;
+                --n_major;
+                while (n_major && n_minor) {
+                    const uint32_t *r = a.succ + (size_t)major[n_major - 1] * 4;
+                    const uint32_t nx = minor[n_minor - 1];
+                    if (r[0] == nx || r[1] == nx || r[2] == nx || r[3] == nx) break;
+                    --n_major;
+                }
+            } else {
+                const uint32_t *r = a.succ + (size_t)w * 4;
+                for (int b = 0; b < 4; ++b) {
+                    const uint32_t x = r[b];
+                    if (x == NONE) continue;
+                    if (n_minor >= 4 * a.depth_cap) { too_deep = true; break; }
+                    if (lane == 0) minor[n_minor] = x;
+                    ++n_minor;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        if (too_many || too_deep) {
+            if (lane == 0) { atomicOr(&a.cnt->err, too_many ? 1u : 32u); a.btask[j] = pf_bubble_task{0, 0, 0}; }
+            continue;
+        }
+        // ---- sortSeq_branching (src/CDBG.cpp:417-480): descending length, ties by descending strcmp.  Distinct walks spell
+        //      distinct strings, so the order is total and a rank sort gives what the reference's quicksort gives ----
+        unsigned long long first = 0;
+        if (lane == 0) first = atomicAdd(&a.cnt->path_head, (unsigned long long)n_paths);
+        first = ((unsigned long long)read_lane((uint32_t)(first >> 32), 0) << 32) | read_lane((uint32_t)first, 0);
+        const bool fits = first + n_paths <= a.path_cap;
+        bool text_ok = true;
+        uint32_t lmax = 0;
+        uint64_t sum = 0;
+        for (uint32_t i = 0; i < n_paths; ++i) {
+            const uint32_t L = plen[i];
+            lmax = L > lmax ? L : lmax;
+            sum += L;
+            if (poff[i] + L > a.text_cap) text_ok = false;
+        }
+        if (fits && text_ok) {
+            for (uint32_t i = lane; i < n_paths; i += WAVE) {
+                const char *si = a.text + poff[i];
+                const uint32_t li = plen[i];
+                uint32_t rank = 0;
+                for (uint32_t o = 0; o < n_paths; ++o) {
+                    if (o == i) continue;
+                    const uint32_t lo = plen[o];
+                    bool before;
+                    if (lo != li) before = lo > li;
+                    else {
+                        const char *so = a.text + poff[o];
+                        uint32_t p = 0;
+                        while (p < li && so[p] == si[p]) ++p;
+                        before = p < li ? (unsigned char)so[p] > (unsigned char)si[p] : o < i;
+                    }
+                    rank += before;
+                }
+                a.bpath[(size_t)4 * a.nb + first + rank] = pf_bubble_path{poff[i], li, PF_NONE};
+            }
+        } else if (lane == 0) {
+            atomicOr(&a.cnt->err, 8u);
+        }
+        if (lane == 0) {
+            a.btask[j] = pf_bubble_task{(uint64_t)4 * a.nb + first, n_paths, 0};
+            if (n_paths >= 2 && fits && text_ok) {
+                const int c = bubble_class(lmax, lmax);  // sorted by length: the first path is the longest
+                const int key = 2 * c + ((n_paths > 2 || lmax > 64) ? 0 : 1);
+                const uint32_t at = atomicAdd(&a.cnt->q_n[key], 1u);
+                a.queues[(size_t)key * a.nb + at] = j;
+                if (c == 3) atomicMax(&a.cnt->max_need, (unsigned long long)bubble_need(lmax, lmax));
+                atomicMax(&a.cnt->retry_need, (unsigned long long)job_bytes((uint32_t)(sum < 60000 ? sum : 60000), lmax));
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-SITES
+struct SiteArgs {
+    const CallTask *ct;
+    const uint32_t *kept;
+    uint64_t t0;
+    const uint32_t *blist;
+    const pf_bubble_result *res;
+    const char *otext;
+    pf_bubble_site *osites;     // pad_ receives the site's ok flag
+    const uint8_t *ogroups;
+    int k;
+    const Slot *tab;
+    uint64_t mask;
+    int one_strand, tab_exact;
+    uint32_t low, up;
+    uint32_t ks;                // capacity of one site string
+    uint8_t *scratch;
+    uint64_t scratch_per_wave;
+    uint64_t *sv_off;           // per bubble: first value in sv
+    double *sv;                 // per site: maxnum group coverages, then their sum
+    uint64_t sv_cap;
+    CallCounters *cnt;
+};
+
+__global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
+    const int lane = lane_id();
+    const uint32_t KS = a.ks;
+    const int k = a.k;
+    uint8_t *scr = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
+    // per row (256 rows): appended characters, final string, and the per-row scalars
+    char *app = reinterpret_cast<char *>(scr);
+    char *fin = app + (size_t)256 * KS;
+    uint32_t *flen = reinterpret_cast<uint32_t *>(fin + (size_t)256 * KS);
+    uint32_t *at = flen + 256;
+    uint32_t *rank = at + 256;
+    uint8_t *dup = reinterpret_cast<uint8_t *>(rank + 256);
+    uint8_t *sok = dup + 256;
+    double *mean = reinterpret_cast<double *>(sok + 256);
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    const uint32_t n_branching = a.cnt->n_branching;
+    auto sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+    };
+    for (;;) {
+        uint32_t q = 0;
+        if (lane == 0) q = atomicAdd(&a.cnt->sites_next, 1u);
+        q = read_lane(q, 0);
+        if (q >= n_branching) break;
+        const uint32_t j = a.blist[q];
+        const pf_bubble_result r = a.res[j];
+        if (r.n_rows == 0 || r.n_rows == 0xFFFFFFFFu) continue;
+        const uint32_t R = r.n_rows, L = r.n_cols;
+        const char *rows = a.otext + r.rows_off;
+        // values: one slot per allele group and site, plus the site's sum
+        uint32_t n_val = 0;
+        for (uint32_t si = 0; si < r.n_sites; ++si) n_val += (uint32_t)a.osites[r.site_off + si].maxnum + 1;
+        unsigned long long v0 = 0;
+        if (lane == 0) v0 = atomicAdd(&a.cnt->sv_head, (unsigned long long)n_val);
+        v0 = ((unsigned long long)read_lane((uint32_t)(v0 >> 32), 0) << 32) | read_lane((uint32_t)v0, 0);
+        if (lane == 0) a.sv_off[j] = v0;
+        const bool room = v0 + n_val <= a.sv_cap;
+        uint32_t err = 0, n_strings = 0;
+        uint32_t indel = 0;
+        unsigned long long vcur = v0;
+        for (uint32_t si = 0; si < r.n_sites && !err; ++si) {
+            const pf_bubble_site sr = a.osites[r.site_off + si];
+            const uint8_t *grp = a.ogroups + r.group_off + (uint64_t)si * R;
+            const uint32_t site = sr.col;
+            const uint32_t maxnum = sr.maxnum;
+            uint32_t napp = 0;
+            if (sr.is_indel) {
+                // every path: the next non-gap character at / after the site, again and again until the characters just appended
+                // are not all equal (src/CDBG.cpp:1474-1493)
+                for (uint32_t p = lane; p < R; p += WAVE) at[p] = site;
+                sync();
+                for (;;) {
+                    uint32_t bad = 0;
+                    for (uint32_t base = 0; base < R; base += WAVE) {
+                        const uint32_t p = base + lane;
+                        bool e = false;
+                        if (p < R) {
+                            uint32_t x = at[p];
+                            while (x < L && rows[(size_t)p * L + x] == '-') ++x;
+                            if (x >= L) e = true;
+                            else {
+                                if (napp < KS) app[(size_t)p * KS + napp] = rows[(size_t)p * L + x];
+                                at[p] = x + 1;
+                            }
+                        }
+                        if (__ballot(e)) bad = 1;
+                    }
+                    if (napp >= KS) bad = 16;
+                    sync();
+                    if (bad) { err = bad == 16 ? 16 : 4; break; }
+                    const char first = app[napp];
+                    bool differ = false;
+                    for (uint32_t base = 0; base < R; base += WAVE) {
+                        const uint32_t p = base + lane;
+                        if (__ballot(p < R && app[(size_t)p * KS + napp] != first)) differ = true;
+                    }
+                    ++napp;
+                    if (differ) break;
+                }
+                if (err) break;
+            }
+            // the k-length string of every path around the site (src/CDBG.cpp:1494-1525, 1559-1596)
+            uint32_t row_err = 0;
+            for (uint32_t base = 0; base < R; base += WAVE) {
+                const uint32_t p = base + lane;
+                uint32_t e = 0;
+                if (p < R) {
+                    const char *row = rows + (size_t)p * L;
+                    char *out = fin + (size_t)p * KS;
+                    uint32_t n = 0;
+                    auto push = [&](char c) { if (n < KS) out[n] = c; ++n; };
+                    if (sr.is_indel) {
+                        const long need = (long)k - (long)napp;
+                        if (indel == 0) {
+                            const long from = (long)site - k + (long)napp;
+                            if (from < 0 || (uint64_t)from > L || need < 0) e = 4;
+                            else {
+                                const uint32_t take = (uint32_t)std::min<uint64_t>((uint64_t)need, L - (uint64_t)from);
+                                for (uint32_t x = 0; x < take; ++x) push(row[from + x]);
+                                for (uint32_t x = 0; x < napp; ++x) push(app[(size_t)p * KS + x]);
+                            }
+                        } else {
+                            uint32_t c = 0;
+                            for (uint32_t x = 0; x < site && x < L; ++x) c += row[x] != '-';
+                            if (need < 0 || (long)c < need) {
+                                for (uint32_t x = 0; x < site && x < L; ++x)
+                                    if (row[x] != '-') push(row[x]);
+                                for (uint32_t x = 0; x < napp; ++x) push(app[(size_t)p * KS + x]);
+                                for (uint32_t x = at[p]; n < (uint32_t)k; ++x) {
+                                    if (x >= L) { e = 4; break; }
+                                    if (row[x] != '-') push(row[x]);
+                                }
+                            } else {
+                                // the last `need` non-gap characters before the site
+                                uint32_t skip = c - (uint32_t)need;
+                                for (uint32_t x = 0; x < site && x < L; ++x) {
+                                    if (row[x] == '-') continue;
+                                    if (skip) { --skip; continue; }
+                                    push(row[x]);
+                                }
+                                for (uint32_t x = 0; x < napp; ++x) push(app[(size_t)p * KS + x]);
+                            }
+                        }
+                    } else if (indel > 0) {
+                        uint32_t c = 0;
+                        for (uint32_t x = 0; x <= site && x < L; ++x) c += row[x] != '-';
+                        if (c < (uint32_t)k) {
+                            for (uint32_t x = 0; x <= site && x < L; ++x)
+                                if (row[x] != '-') push(row[x]);
+                            for (uint32_t x = site + 1; n < (uint32_t)k; ++x) {
+                                if (x >= L) { e = 4; break; }
+                                if (row[x] != '-') push(row[x]);
+                            }
+                        } else {
+                            uint32_t skip = c - (uint32_t)k;
+                            for (uint32_t x = 0; x <= site && x < L; ++x) {
+                                if (row[x] == '-') continue;
+                                if (skip) { --skip; continue; }
+                                push(row[x]);
+                            }
+                        }
+                    } else {
+                        const long from = (long)site - k + 1;
+                        if (from < 0 || (uint64_t)from > L) e = 4;
+                        else {
+                            const uint32_t take = (uint32_t)std::min<uint64_t>((uint64_t)k, L - (uint64_t)from);
+                            for (uint32_t x = 0; x < take; ++x) push(row[from + x]);
+                        }
+                    }
+                    if (n > KS) e = 16;
+                    flen[p] = n;
+                }
+                if (__ballot(e == 4)) row_err |= 4;
+                if (__ballot(e == 16)) row_err |= 16;
+            }
+            if (sr.is_indel) ++indel;
+            sync();
+            if (row_err) { err = (row_err & 4) ? 4 : 16; break; }
+            // distinct strings per allele group in std::set order, their coverage (readCov(string), src/CDBG.cpp:29-60)
+            uint32_t miss_any = 0;
+            for (uint32_t base = 0; base < R; base += WAVE) {
+                const uint32_t p = base + lane;
+                bool miss = false;
+                if (p < R) {
+                    const char *sp = fin + (size_t)p * KS;
+                    const uint32_t lp = flen[p];
+                    const uint8_t g = grp[p];
+                    bool d = false;
+                    uint32_t rk = 0;
+                    for (uint32_t o = 0; o < R; ++o) {
+                        if (o == p || grp[o] != g) continue;
+                        const char *so = fin + (size_t)o * KS;
+                        const uint32_t lo = flen[o], lm = lo < lp ? lo : lp;
+                        uint32_t x = 0;
+                        while (x < lm && so[x] == sp[x]) ++x;
+                        int cmp;  // so <=> sp
+                        if (x < lm) cmp = (unsigned char)so[x] < (unsigned char)sp[x] ? -1 : 1;
+                        else cmp = lo < lp ? -1 : (lo > lp ? 1 : 0);
+                        if (cmp == 0) { if (o < p) d = true; }
+                        else if (cmp < 0) ++rk;
+                    }
+                    dup[p] = d;
+                    rank[p] = rk;   // counts duplicates of smaller strings as well: only the order of the ranks matters
+                    uint8_t ok = 1;
+                    double mn = 0.0;
+                    if (!d) {
+                        uint64_t sum = 0, x = 0;
+                        if (!a.tab_exact) {
+                            for (uint32_t c = 0; c < lp; ++c) {
+                                const char ch = sp[c];
+                                const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                                x = ((x << 2) | b) & kmask;
+                                if (c + 1 >= (uint32_t)k) {
+                                    uint32_t cnt;
+                                    if (!canonical_count(a.tab, a.mask, x, k, cnt, a.one_strand != 0)) { miss = true; break; }
+                                    if (cnt > a.low && cnt < a.up) sum += cnt;
+                                    else { sum = 0; ok = 0; break; }  // src/CDBG.cpp:45-50
+                                }
+                            }
+                        }
+                        mn = (double)sum / (double)((uint64_t)lp - (uint64_t)k + 1);
+                    }
+                    sok[p] = ok;
+                    mean[p] = mn;
+                }
+                if (__ballot(miss)) miss_any = 1;
+                n_strings += (uint32_t)__popcll(__ballot(p < R && !dup[p]));
+            }
+            sync();
+            if (miss_any) { err = 2; break; }
+            // group coverages in set order; the first string out of range drops the site (src/CDBG.cpp:1527-1551)
+            bool ok = true;
+            double total = 0.0;
+            for (uint32_t gi = 0; gi < maxnum; ++gi) {
+                double tc = 0.0;
+                if (ok) {
+                    // rows of this group, ascending rank: wave-uniform selection of the next smallest rank
+                    uint32_t last = 0;
+                    bool have_last = false;
+                    for (;;) {
+                        uint32_t best = 0xFFFFFFFFu, bp = 0;
+                        for (uint32_t p = 0; p < R; ++p) {
+                            if (grp[p] != gi + 1 || dup[p]) continue;
+                            const uint32_t rk = rank[p];
+                            if (have_last && rk <= last) continue;
+                            if (rk < best) { best = rk; bp = p; }
+                        }
+                        if (best == 0xFFFFFFFFu) break;
+                        if (!sok[bp]) { ok = false; break; }
+                        tc += mean[bp];
+                        last = best;
+                        have_last = true;
+                    }
+                    if (ok) total += tc;
+                }
+                if (lane == 0 && room) a.sv[vcur + gi] = tc;
+            }
+            if (lane == 0 && room) a.sv[vcur + maxnum] = total;
+            if (lane == 0) a.osites[r.site_off + si].pad_ = ok ? 1 : 0;
+            vcur += maxnum + 1;
+            sync();
+        }
+        if (lane == 0) {
+            if (err) atomicOr(&a.cnt->err, err);
+            atomicAdd(&a.cnt->site_strings, (unsigned long long)n_strings);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-TEXT
+struct FmtArgs {
+    const CallTask *ct;
+    const uint32_t *kept;
+    uint64_t t0;
+    uint32_t nb;
+    const pf_bubble_result *res;
+    const char *otext;
+    const pf_bubble_site *osites;
+    const uint8_t *ogroups;
+    const uint32_t *oilen;
+    const uint64_t *sv_off;
+    const double *sv;
+    const uint32_t *vc;       // inclusive count of called bubbles inside the batch
+    uint64_t vc_base;
+    const uint32_t *len;
+    uint32_t *sizes;          // [N_STREAMS][nb + 1]
+    const uint64_t *offs;     // exclusive scan of sizes, one run over all streams
+    char *out[N_STREAMS];
+    CallCounters *cnt;
+};
+
+template <bool W>
+struct Row {  // one output stream position: a pointer when writing, a byte count when measuring
+    char *p;
+    uint32_t n;
+    __device__ inline void put(char c) { if (W) *p++ = c; else ++n; }
+};
+
+__global__ void k_call_has(const pf_bubble_result *__restrict__ res, uint32_t nb, uint32_t *__restrict__ has) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j < nb) has[j] = (res[j].n_rows != 0 && res[j].n_rows != 0xFFFFFFFFu) ? 1u : 0u;
+}
+
+template <bool W>
+__global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    unsigned long long allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
+    if (j < a.nb) {
+        const size_t stride = (size_t)a.nb + 1;
+        Row<W> s_all{nullptr, 0}, s_aln{nullptr, 0}, s_fre[4], s_cov[4];
+        for (int x = 0; x < 4; ++x) { s_fre[x] = Row<W>{nullptr, 0}; s_cov[x] = Row<W>{nullptr, 0}; }
+        if (W) {
+            s_all.p = a.out[0] + (a.offs[0 * stride + j] - a.offs[0 * stride]);
+            s_aln.p = a.out[1] + (a.offs[1 * stride + j] - a.offs[1 * stride]);
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                s_fre[x].p = a.out[2 + x] + (a.offs[(2 + x) * stride + j] - a.offs[(2 + x) * stride]);
+                s_cov[x].p = a.out[6 + x] + (a.offs[(6 + x) * stride + j] - a.offs[(6 + x) * stride]);
+            }
+        }
+        const pf_bubble_result r = a.res[j];
+        if (r.n_rows != 0 && r.n_rows != 0xFFFFFFFFu) {
+            const CallTask &t = a.ct[a.kept[a.t0 + j]];
+            const uint32_t R = r.n_rows, L = r.n_cols;
+            const char *rows = a.otext + r.rows_off;
+            const uint64_t my_vc = a.vc_base + a.vc[j];
+            // alignseq: var_count, strict flag, entrance id, exit id, aligned row (src/CDBG.cpp:1259, 1428)
+            for (uint32_t p = 0; p < R; ++p) {
+                put_uint(s_aln, my_vc);
+                s_aln.put('\t'); s_aln.put(t.strict ? '1' : '0'); s_aln.put('\t');
+                put_uint(s_aln, (uint64_t)t.u + 1);
+                s_aln.put('\t');
+                put_uint(s_aln, (uint64_t)(t.exit_ov >> 1) + 1);
+                s_aln.put('\t');
+                if (W) { for (uint32_t x = 0; x < L; ++x) s_aln.p[x] = rows[(size_t)p * L + x]; s_aln.p += L; }
+                else s_aln.n += L;
+                s_aln.put('\n');
+            }
+            core_cov = (unsigned long long)t.core_mean;
+            core_num = 1;
+            const pf_bubble_site *sites = a.osites + r.site_off;
+            const uint32_t *ilen = a.oilen + r.ilen_off;
+            const size_t usize = a.len[t.u], esize = a.len[t.exit_ov >> 1];
+            const uint32_t ns = r.n_sites;
+            uint32_t indel = 0;
+            uint64_t vcur = t.strict ? 0 : a.sv_off[j];
+            for (uint32_t i = 0; i < ns; ++i) {
+                const pf_bubble_site sr = sites[i];
+                const uint8_t *grp = a.ogroups + r.group_off + (uint64_t)i * R;
+                // distance to the neighbouring sites / unitig ends (src/CDBG.cpp:1279-1298)
+                uint32_t vd;
+                if (i == 0) {
+                    if (ns != 1) vd = (uint32_t)std::min((size_t)(uint32_t)(sites[1].col - sites[0].col - 1), usize);
+                    else vd = (uint32_t)std::min(usize, esize);
+                } else if (i == ns - 1) {
+                    vd = (uint32_t)std::min((size_t)(uint32_t)(sites[i].col - sites[i - 1].col - 1), esize);
+                } else {
+                    vd = std::min((uint32_t)(sites[i].col - sites[i - 1].col - 1), (uint32_t)(sites[i + 1].col - sites[i].col - 1));
+                }
+                const uint32_t maxnum = sr.maxnum;
+                if (sr.is_indel) ++indel;  // counted even when the site is dropped below (src/CDBG.cpp:1526)
+                double denom;
+                const double *vals = nullptr;
+                if (t.strict) {
+                    denom = t.cov_sum;
+                } else {
+                    vals = a.sv + vcur;
+                    vcur += maxnum + 1;
+                    if (!sr.pad_) continue;
+                    denom = vals[maxnum];
+                }
+                const int ar = (int)maxnum - 2;  // file of this arity, if 0..3
+                Row<W> cov = ar == 0 ? s_cov[0] : ar == 1 ? s_cov[1] : ar == 2 ? s_cov[2] : s_cov[3];
+                Row<W> fre = ar == 0 ? s_fre[0] : ar == 1 ? s_fre[1] : ar == 2 ? s_fre[2] : s_fre[3];
+                const bool filed = ar >= 0 && ar <= 3;
+                for (uint32_t x = 0; x < maxnum; ++x) {
+                    double tc;
+                    if (t.strict) {
+                        tc = 0.0;
+                        for (uint32_t p = 0; p < R; ++p)
+                            if ((uint32_t)grp[p] - 1 == x) tc += t.cov[p < 4 ? p : 3];
+                    } else {
+                        tc = vals[x];
+                    }
+                    if (filed) { put_double(cov, tc); cov.put('\t'); }
+                    // the frequency row goes to allele_frequency.txt and, for 2..5 alleles, to the arity's fre file
+                    if (W) {
+                        char *before = s_all.p;
+                        put_double(s_all, tc / denom);
+                        s_all.put('\n');
+                        if (filed) { for (char *c = before; c < s_all.p; ++c) *fre.p++ = *c; }
+                    } else {
+                        const uint32_t before = s_all.n;
+                        put_double(s_all, tc / denom);
+                        s_all.put('\n');
+                        if (filed) fre.n += s_all.n - before;
+                    }
+                }
+                if (filed) {
+                    cov.put(t.strict ? '1' : '0'); cov.put('\t');
+                    if (sr.is_indel) put_uint(cov, ilen[indel - 1]);
+                    else cov.put('0');
+                    cov.put('\t');
+                    put_uint(cov, my_vc);
+                    cov.put('\t');
+                    put_uint(cov, ns);
+                    cov.put('\t');
+                    put_uint(cov, vd);
+                    cov.put('\t'); cov.put('\n');
+                    ++allele[ar];
+                    if (ar == 0) { s_cov[0] = cov; s_fre[0] = fre; }
+                    else if (ar == 1) { s_cov[1] = cov; s_fre[1] = fre; }
+                    else if (ar == 2) { s_cov[2] = cov; s_fre[2] = fre; }
+                    else { s_cov[3] = cov; s_fre[3] = fre; }
+                }
+            }
+        }
+        if (!W) {
+            a.sizes[0 * stride + j] = s_all.n;
+            a.sizes[1 * stride + j] = s_aln.n;
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+                a.sizes[(2 + x) * stride + j] = s_fre[x].n;
+                a.sizes[(6 + x) * stride + j] = s_cov[x].n;
+            }
+        }
+    }
+    if (!W) {
+        // counters: one atomic per wave and counter
+        unsigned long long v[7] = {allele[0], allele[1], allele[2], allele[3], core_cov, core_num, 0};
+        for (int x = 0; x < 6; ++x) {
+            const unsigned long long s = wave_sum_u64(v[x]);
+            if (lane_id() == 0 && s) atomicAdd(x < 4 ? &a.cnt->allele[x] : (x == 4 ? &a.cnt->core_cov : &a.cnt->core_num), s);
+        }
+        if (j <= a.nb && j == a.nb) {
+            const size_t stride = (size_t)a.nb + 1;
+            for (int s = 0; s < N_STREAMS; ++s) a.sizes[s * stride + a.nb] = 0;
+        }
+    }
+}
+
+__global__ void k_call_totals(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ sizes, uint32_t nb, uint64_t *__restrict__ totals) {
+    const int s = threadIdx.x;
+    const size_t stride = (size_t)nb + 1;
+    if (s < N_STREAMS) totals[s] = offs[s * stride + nb] - offs[s * stride];
+    (void)sizes;
+}
+
+struct Widen {
+    __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; }
+};
+
+__global__ void k_format_doubles(const double *__restrict__ x, uint64_t n, char *__restrict__ out, uint8_t *__restrict__ len) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    BufSink s{out + i * 32};
+    put_double(s, x[i]);
+    len[i] = (uint8_t)(s.p - (out + i * 32));
+}
+
+}  // namespace
+
+// =====================================================================================================================
+extern "C" {
+
+int pf_format_doubles(pf_ctx *ctx, const double *values, uint64_t n, char *text, uint8_t *len) {
+    if (!ctx || (n && (!values || !text || !len))) return PF_ERR_ARG;
+    if (n == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    DevTmp<double> dx;
+    DevTmp<char> dt;
+    DevTmp<uint8_t> dl;
+    PF_HIP(dx.alloc(n * 8));
+    PF_HIP(dt.alloc(n * 32));
+    PF_HIP(dl.alloc(n));
+    PF_HIP(hipMemcpyAsync(dx.p, values, n * 8, hipMemcpyDefault, ctx->stream));
+    k_format_doubles<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(dx.p, n, dt.p, dl.p);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(text, dt.p, n * 32, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(len, dl.p, n, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    return PF_OK;
+}
+
+int pf_call_set_state(pf_ctx *ctx, const uint8_t *flags, const uint32_t *plus, const uint32_t *minus) {
+    if (!ctx || !flags || !plus || !minus) return PF_ERR_ARG;
+    if (!ctx->d_seq || !ctx->has_adj) { ctx->err = "pf_call_set_state: graph and adjacency first"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    CallState *S = state_of(ctx);
+    const size_t N = ctx->N;
+    if (!S->flags.ensure(N + 1) || !S->plus.ensure(N * 4) || !S->minus.ensure(N * 4)) { ctx->err = "pf_call_set_state: out of device memory"; return PF_ERR_HIP; }
+    PF_HIP(hipMemcpyAsync(S->flags.p, flags, N, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(S->plus.p, plus, N * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(S->minus.p, minus, N * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    S->have_state = true;
+    S->n_sides = S->n_tasks = 0;
+    return PF_OK;
+}
+
+int pf_call_coverage(pf_ctx *ctx) {
+    if (!ctx || !ctx->d_seq || !ctx->d_tab) { if (ctx) ctx->err = "pf_call_coverage: graph and count table first"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    CallState *S = state_of(ctx);
+    const size_t N = ctx->N;
+    const int slots = ctx->tab_exact ? 2 : 1;
+    if (!S->cov_sum.ensure(N * slots * 8) || !S->cov_min.ensure(N * slots * 4) || !S->cov_miss.ensure(N * slots)) {
+        ctx->err = "pf_call_coverage: out of device memory";
+        return PF_ERR_HIP;
+    }
+    int st;
+    if (!ctx->tab_exact) {
+        st = pf_unitig_cov(ctx, 0, (uint32_t)N, S->cov_sum.as<uint64_t>(), S->cov_min.as<uint32_t>(), S->cov_miss.as<uint8_t>());
+    } else {
+        st = pf_unitig_cov_exact(ctx, 0, (uint32_t)N, 0, S->cov_sum.as<uint64_t>(), S->cov_min.as<uint32_t>(), S->cov_miss.as<uint8_t>());
+        if (st == PF_OK || st == PF_ERR_MISSING_KMER)
+            st = pf_unitig_cov_exact(ctx, 0, (uint32_t)N, 1, S->cov_sum.as<uint64_t>() + N, S->cov_min.as<uint32_t>() + N, S->cov_miss.as<uint8_t>() + N);
+    }
+    if (st != PF_OK && st != PF_ERR_MISSING_KMER) return st;  // a missing k-mer matters only where the driver loop reads it
+    S->per_strand = ctx->tab_exact;
+    S->have_cov = true;
+    return PF_OK;
+}
+
+int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides) {
+    if (!ctx || !n_sides) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (!S || !S->have_state || !S->have_cov) { ctx->err = "pf_call_scan: pf_call_set_state and pf_call_coverage first"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t N = ctx->N;
+    if (!S->side_cnt.ensure(((size_t)N + 1) * 4) || !S->side_base.ensure(((size_t)N + 1) * 4)) { ctx->err = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
+    k_call_count_sides<<<(N + 1 + 255) / 256, 256, 0, st>>>(S->flags.as<uint8_t>(), N, S->side_cnt.as<uint32_t>());
+    size_t tmp = 0;
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, S->side_cnt.as<uint32_t>(), S->side_base.as<uint32_t>(), (int)(N + 1), st));
+    if (!S->scan_tmp.ensure(tmp)) { ctx->err = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, tmp, S->side_cnt.as<uint32_t>(), S->side_base.as<uint32_t>(), (int)(N + 1), st));
+    uint32_t total = 0;
+    PF_HIP(hipMemcpyAsync(&total, S->side_base.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    S->n_sides = total;
+    S->n_tasks = 0;
+    S->low = lower;
+    S->up = upper;
+    *n_sides = total;
+    if (total == 0) return PF_OK;
+    if (!S->sides.ensure((size_t)total * sizeof(pf_call_side)) || !S->ctask.ensure((size_t)total * sizeof(CallTask))) {
+        ctx->err = "pf_call_scan: out of device memory";
+        return PF_ERR_HIP;
+    }
+    ScanArgs a;
+    a.flags = S->flags.as<uint8_t>(); a.plus = S->plus.as<uint32_t>(); a.minus = S->minus.as<uint32_t>();
+    a.succ = ctx->d_succ; a.pred = ctx->d_pred; a.seq = ctx->d_seq; a.off = ctx->d_off; a.len = ctx->d_len; a.N = N; a.k = ctx->k;
+    a.cov_sum = S->cov_sum.as<uint64_t>(); a.cov_min = S->cov_min.as<uint32_t>(); a.cov_miss = S->cov_miss.as<uint8_t>();
+    a.per_strand = S->per_strand; a.low = lower; a.up = upper;
+    a.side_base = S->side_base.as<uint32_t>(); a.sides = S->sides.as<pf_call_side>(); a.tasks = S->ctask.as<CallTask>();
+    ctx_begin(ctx, PF_K_CALL_SCAN);
+    k_call_sides<<<(N + 255) / 256, 256, 0, st>>>(a);
+    ctx_end(ctx);
+    PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+int pf_call_sides(pf_ctx *ctx, pf_call_side *out, uint64_t cap) {
+    if (!ctx || !ctx->call) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (cap < S->n_sides || (S->n_sides && !out)) return PF_ERR_OVERFLOW;
+    if (S->n_sides == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipMemcpyAsync(out, S->sides.p, (size_t)S->n_sides * sizeof(pf_call_side), hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    return PF_OK;
+}
+
+int pf_call_select(pf_ctx *ctx, const uint32_t *side_index, uint64_t n_tasks) {
+    if (!ctx || !ctx->call || (n_tasks && !side_index)) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (n_tasks > S->n_sides) { ctx->err = "pf_call_select: more bubbles than open sides"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    if (!S->kept.ensure(std::max<size_t>(n_tasks, 1) * 4)) { ctx->err = "pf_call_select: out of device memory"; return PF_ERR_HIP; }
+    if (n_tasks) PF_HIP(hipMemcpyAsync(S->kept.p, side_index, (size_t)n_tasks * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    S->n_tasks = n_tasks;
+    return PF_OK;
+}
+
+// one batch, first half: bubbles [t0, t1) of the selection up to the site coverages; out->n_called tells how far var_count advances
+int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
+                  pf_call_result *out) {
+    if (!ctx || !out) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (!S || t0 > t1 || t1 > S->n_tasks) { ctx->err = "pf_call_align: range outside the selection"; return PF_ERR_ARG; }
+    memset(out, 0, sizeof(*out));
+    S->cur_nb = 0;
+    S->cur_t0 = t0;
+    if (t1 == t0) return PF_OK;
+    if (t1 - t0 > (1u << 24)) { ctx->err = "pf_call_align: at most 2^24 bubbles per batch"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t nb = (uint32_t)(t1 - t0);
+    const int k = ctx->k;
+    const char *oom = "pf_call_run: out of device memory";
+#define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = oom; return PF_ERR_HIP; } } while (0)
+    NEED(S->counters, sizeof(CallCounters));
+    NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
+    NEED(S->queues, (size_t)8 * nb * 4);
+    NEED(S->blist, (size_t)nb * 4);
+    NEED(S->res, (size_t)nb * sizeof(pf_bubble_result));
+    NEED(S->sv_off, (size_t)nb * 8);
+    NEED(S->has, (size_t)nb * 4);
+    NEED(S->vc, (size_t)nb * 4);
+    NEED(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
+    NEED(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
+    NEED(S->totals, 16 * 8);
+    CallCounters *d_cnt = S->counters.as<CallCounters>();
+    CallCounters hc;
+    // K-PATHS scratch: stacks sized by the complex size (a non-complex bubble has at most that many vertices)
+    const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
+    const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (6ull * depth_cap + 4) * 4) + 255) & ~255ull;
+    const int paths_grid = ctx->n_cu * 8;
+    NEED(S->paths_scr, paths_per_wave * paths_grid);
+
+    // ---- paths + queues; the pools grow until the batch fits ----
+    for (int attempt = 0;; ++attempt) {
+        const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 1024);
+        const uint64_t text_cap = std::max<uint64_t>(S->text_pool, (uint64_t)nb * 32 + (1u << 16));
+        NEED(S->bpath, ((size_t)4 * nb + path_cap) * sizeof(pf_bubble_path));
+        NEED(S->ptext, text_cap);
+        PF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(CallCounters), st));
+        PrepArgs pa;
+        pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
+        pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = S->res.as<pf_bubble_result>();
+        pa.queues = S->queues.as<uint32_t>(); pa.blist = S->blist.as<uint32_t>(); pa.cnt = d_cnt;
+        ctx_begin(ctx, PF_K_CALL_PREP);
+        k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
+        ctx_end(ctx);
+        PathArgs ph;
+        ph.ct = pa.ct; ph.kept = pa.kept; ph.t0 = t0; ph.nb = nb; ph.blist = pa.blist; ph.succ = ctx->d_succ; ph.seq = ctx->d_seq;
+        ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
+        ph.scratch_per_wave = paths_per_wave; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
+        ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.queues; ph.cnt = d_cnt;
+        ctx_begin(ctx, PF_K_CALL_PATHS);
+        k_call_paths<<<paths_grid, 64, 0, st>>>(ph);
+        ctx_end(ctx);
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        if (hc.err & 1u) { ctx->err = "pf_call_run: a bubble has more than 255 paths"; return PF_ERR_ARG; }
+        if (hc.err & 32u) { ctx->err = "pf_call_run: a bubble is deeper than the complex size allows"; return PF_ERR_ARG; }
+        if (hc.path_head > path_cap || hc.text_head > text_cap) {
+            if (attempt >= 3) { ctx->err = "pf_call_run: path pools do not converge"; return PF_ERR_OVERFLOW; }
+            S->path_pool = std::max<uint64_t>(S->path_pool, hc.path_head + hc.path_head / 8 + 1024);
+            S->text_pool = std::max<uint64_t>(S->text_pool, hc.text_head + hc.text_head / 8 + 4096);
+            continue;
+        }
+        S->path_pool = std::max(S->path_pool, path_cap);
+        S->text_pool = std::max(S->text_pool, text_cap);
+        break;
+    }
+    out->n_branching = hc.n_branching;
+    uint64_t n_jobs = 0;
+    for (int x = 0; x < 8; ++x) n_jobs += hc.q_n[x];
+    out->align_jobs = n_jobs;
+
+    // ---- K-BUBBLE: the queues are heavy-then-light per class; compact them into one index array ----
+    NEED(S->scan_tmp2, std::max<size_t>((size_t)n_jobs, 1) * 4);
+    {
+        uint32_t *d_idx = S->scan_tmp2.as<uint32_t>();
+        size_t at = 0;
+        for (int x = 0; x < 8; ++x) {
+            if (!hc.q_n[x]) continue;
+            PF_HIP(hipMemcpyAsync(d_idx + at, S->queues.as<uint32_t>() + (size_t)x * nb, (size_t)hc.q_n[x] * 4, hipMemcpyDeviceToDevice, st));
+            at += hc.q_n[x];
+        }
+    }
+    unsigned long long heads[4] = {0, 0, 0, 0};
+    if (n_jobs) {
+        for (int attempt = 0;; ++attempt) {
+            const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, (hc.text_head + 128ull * nb) * 2 + 4096);
+            const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, 4ull * nb + 64);
+            const uint64_t cap_groups = std::max<uint64_t>(S->ogroups_cap, 16ull * nb + 64);
+            const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, 2ull * nb + 64);
+            NEED(S->otext, cap_text);
+            NEED(S->osites, cap_sites * sizeof(pf_bubble_site));
+            NEED(S->ogroups, cap_groups);
+            NEED(S->oilen, cap_ilen * 4);
+            BubbleLaunch BL;
+            BL.text = S->ptext.as<char>(); BL.paths = S->bpath.as<pf_bubble_path>(); BL.tasks = S->btask.as<pf_bubble_task>();
+            BL.n_tasks = nb; BL.idx = S->scan_tmp2.as<uint32_t>();
+            for (int c = 0; c < 4; ++c) BL.n_cls[c] = hc.q_n[2 * c] + hc.q_n[2 * c + 1];
+            BL.max_need = hc.max_need; BL.retry_need = hc.retry_need;
+            BL.match = match; BL.mismatch = mismatch; BL.gap = gap;
+            BL.res = S->res.as<pf_bubble_result>(); BL.otext = S->otext.as<char>(); BL.osites = S->osites.as<pf_bubble_site>();
+            BL.ogroups = S->ogroups.as<uint8_t>(); BL.oilen = S->oilen.as<uint32_t>();
+            BL.text_cap = cap_text; BL.site_cap = cap_sites; BL.group_cap = cap_groups; BL.ilen_cap = cap_ilen;
+            const int bst = bubble_launch(ctx, BL, heads);
+            S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
+            S->ogroups_cap = std::max(S->ogroups_cap, cap_groups); S->oilen_cap = std::max(S->oilen_cap, cap_ilen);
+            if (bst == PF_ERR_OVERFLOW && (heads[0] > cap_text || heads[1] > cap_sites || heads[2] > cap_groups || heads[3] > cap_ilen)) {
+                if (attempt >= 3) return bst;
+                S->otext_cap = std::max<uint64_t>(S->otext_cap, heads[0] + heads[0] / 8);
+                S->osites_cap = std::max<uint64_t>(S->osites_cap, heads[1] + heads[1] / 8);
+                S->ogroups_cap = std::max<uint64_t>(S->ogroups_cap, heads[2] + heads[2] / 8);
+                S->oilen_cap = std::max<uint64_t>(S->oilen_cap, heads[3] + heads[3] / 8);
+                // the results of the failed attempt are void: clear them (skipped bubbles must read n_rows == 0)
+                PF_HIP(hipMemsetAsync(S->res.p, 0, (size_t)nb * sizeof(pf_bubble_result), st));
+                continue;
+            }
+            if (bst != PF_OK) return bst;
+            break;
+        }
+    } else {
+        NEED(S->otext, 16); NEED(S->osites, 16); NEED(S->ogroups, 16); NEED(S->oilen, 16);
+    }
+
+    // ---- K-SITES ----
+    const uint32_t KS = (uint32_t)(2 * k + 64);
+    if (hc.n_branching) {
+        const uint64_t sites_per_wave = (((uint64_t)512 * KS + 256ull * (4 + 4 + 4 + 1 + 1 + 8)) + 255) & ~255ull;
+        const int sites_grid = (int)std::min<uint32_t>(hc.n_branching, (uint32_t)ctx->n_cu * 4);
+        NEED(S->sites_scr, sites_per_wave * sites_grid);
+        for (int attempt = 0;; ++attempt) {
+            const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * hc.n_branching + 1024);
+            NEED(S->sv, sv_cap * 8);
+            SiteArgs sa;
+            sa.ct = S->ctask.as<CallTask>(); sa.kept = S->kept.as<uint32_t>(); sa.t0 = t0; sa.blist = S->blist.as<uint32_t>();
+            sa.res = S->res.as<pf_bubble_result>(); sa.otext = S->otext.as<char>(); sa.osites = S->osites.as<pf_bubble_site>();
+            sa.ogroups = S->ogroups.as<uint8_t>(); sa.k = k; sa.tab = ctx->d_tab; sa.mask = ctx->tab_cap - 1;
+            sa.one_strand = ctx->tab_one_strand; sa.tab_exact = ctx->tab_exact; sa.low = S->low; sa.up = S->up; sa.ks = KS;
+            sa.scratch = S->sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = S->sv_off.as<uint64_t>();
+            sa.sv = S->sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
+            PF_HIP(hipMemsetAsync(&d_cnt->sites_next, 0, 4, st));
+            PF_HIP(hipMemsetAsync(&d_cnt->sv_head, 0, 8, st));
+            PF_HIP(hipMemsetAsync(&d_cnt->site_strings, 0, 8, st));
+            ctx_begin(ctx, PF_K_CALL_SITES);
+            k_call_sites<<<sites_grid, 64, 0, st>>>(sa);
+            ctx_end(ctx);
+            PF_HIP(hipGetLastError());
+            PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+            PF_HIP(hipStreamSynchronize(st));
+            if (hc.err & 2u) { ctx->err = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
+            if (hc.err & 4u) { ctx->err = "CDBG::PloidyEstimation(): site string outside an aligned row"; return PF_ERR_ARG; }
+            if (hc.err & 16u) { ctx->err = "CDBG::PloidyEstimation(): site string longer than 2k + 64"; return PF_ERR_ARG; }
+            if (hc.sv_head > sv_cap) {
+                if (attempt >= 2) { ctx->err = "pf_call_run: site value pool does not converge"; return PF_ERR_OVERFLOW; }
+                S->sv_pool = hc.sv_head + hc.sv_head / 8 + 1024;
+                continue;
+            }
+            S->sv_pool = std::max(S->sv_pool, sv_cap);
+            break;
+        }
+    } else {
+        NEED(S->sv, 16);
+    }
+    out->site_strings = hc.site_strings;
+
+    // ---- bubble numbering inside the batch ----
+    k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(S->res.as<pf_bubble_result>(), nb, S->has.as<uint32_t>());
+    size_t tmp1 = 0;
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, S->has.as<uint32_t>(), S->vc.as<uint32_t>(), (int)nb, st));
+    NEED(S->scan_tmp, tmp1);
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(S->scan_tmp.p, tmp1, S->has.as<uint32_t>(), S->vc.as<uint32_t>(), (int)nb, st));
+    uint32_t n_called = 0;
+    PF_HIP(hipMemcpyAsync(&n_called, S->vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    out->n_called = n_called;
+    S->cur_nb = nb;
+    S->cur = *out;
+#undef NEED
+    return PF_OK;
+}
+
+// one batch, second half: K-TEXT of the bubbles pf_call_align left resident, into slab 0 or 1
+int pf_call_text(pf_ctx *ctx, int slab, uint64_t var_count_base, pf_call_result *out) {
+    if (!ctx || !out || slab < 0 || slab > 1) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (!S) return PF_ERR_ARG;
+    for (int s = 0; s < N_STREAMS; ++s) S->out_len[slab][s] = 0;
+    *out = S->cur;
+    if (S->cur_nb == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t nb = S->cur_nb;
+    const uint64_t t0 = S->cur_t0;
+    const char *oom = "pf_call_text: out of device memory";
+#define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = oom; return PF_ERR_HIP; } } while (0)
+    CallCounters *d_cnt = S->counters.as<CallCounters>();
+    CallCounters hc;
+    size_t tmp2 = 0;
+    const size_t n_sizes = (size_t)N_STREAMS * (nb + 1);
+    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
+    NEED(S->scan_tmp, tmp2);
+    PF_HIP(hipMemsetAsync(&d_cnt->allele[0], 0, 6 * 8, st));  // allele[4], core_cov, core_num
+    FmtArgs fa;
+    fa.ct = S->ctask.as<CallTask>(); fa.kept = S->kept.as<uint32_t>(); fa.t0 = t0; fa.nb = nb; fa.res = S->res.as<pf_bubble_result>();
+    fa.otext = S->otext.as<char>(); fa.osites = S->osites.as<pf_bubble_site>(); fa.ogroups = S->ogroups.as<uint8_t>();
+    fa.oilen = S->oilen.as<uint32_t>(); fa.sv_off = S->sv_off.as<uint64_t>(); fa.sv = S->sv.as<double>(); fa.vc = S->vc.as<uint32_t>();
+    fa.vc_base = var_count_base; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
+    for (int s = 0; s < N_STREAMS; ++s) fa.out[s] = nullptr;
+    ctx_begin(ctx, PF_K_CALL_FORMAT);
+    k_call_format<false><<<(nb + 1 + 255) / 256, 256, 0, st>>>(fa);
+    ctx_end(ctx);
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
+    k_call_totals<<<1, 64, 0, st>>>(S->offs.as<uint64_t>(), S->sizes.as<uint32_t>(), nb, S->totals.as<uint64_t>());
+    uint64_t totals[N_STREAMS + 1] = {};
+    PF_HIP(hipMemcpyAsync(totals, S->totals.p, N_STREAMS * 8, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    for (int s = 0; s < N_STREAMS; ++s) {
+        NEED(S->out[slab][s], std::max<uint64_t>(totals[s], 16));
+        fa.out[s] = S->out[slab][s].as<char>();
+        S->out_len[slab][s] = totals[s];
+        out->text_len[s] = totals[s];
+    }
+    ctx_begin(ctx, PF_K_CALL_FORMAT);
+    k_call_format<true><<<(nb + 255) / 256, 256, 0, st>>>(fa);
+    ctx_end(ctx);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(st));
+    for (int x = 0; x < 4; ++x) out->allele[x] = hc.allele[x];
+    out->core_cov = hc.core_cov;
+    out->core_num = hc.core_num;
+#undef NEED
+    return PF_OK;
+}
+
+int pf_call_run(pf_ctx *ctx, int slab, uint64_t t0, uint64_t t1, uint64_t var_count_base, uint32_t complex_size, double match,
+                double mismatch, double gap, pf_call_result *out) {
+    const int st = pf_call_align(ctx, t0, t1, complex_size, match, mismatch, gap, out);
+    if (st != PF_OK) return st;
+    return pf_call_text(ctx, slab, var_count_base, out);
+}
+
+int pf_call_fetch(pf_ctx *ctx, int slab, int stream, char *dst, uint64_t len) {
+    if (!ctx || !ctx->call || slab < 0 || slab > 1 || stream < 0 || stream >= N_STREAMS) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (len > S->out_len[slab][stream] || (len && !dst)) return PF_ERR_ARG;
+    if (len == 0) return PF_OK;
+    // its own stream, and no context state written: safe beside a pf_call_run on the other slab
+    if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
+    if (!S->copy_stream) return PF_ERR_HIP;
+    if (hipMemcpyAsync(dst, S->out[slab][stream].p, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    return PF_OK;
+}
+
+}  // extern "C"

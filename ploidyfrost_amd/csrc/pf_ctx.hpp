@@ -24,6 +24,7 @@ struct TimedLaunch {
     int kernel;
     hipEvent_t a, b;
 };
+struct CallState;  // pf_call.hip: buffers of the resident calling pipeline
 }  // namespace pf
 
 struct pf_ctx {
@@ -92,6 +93,8 @@ struct pf_ctx {
     uint64_t gmm_n = 0;
     bool gmm_loaded = false;
 
+    pf::CallState *call = nullptr;
+
     unsigned int bfs_deferred = 0;  // candidates of the last pf_bfs_candidates that needed the big tier
 
     // grow-only device workspaces reused across calls (slot ids: enum pf::WsSlot)
@@ -111,11 +114,13 @@ int join_graph_counts(pf_ctx *ctx);
 int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the joined table of all colours (pf_ctx::d_gcov_c)  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
 // device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
+void call_destroy(pf_ctx *ctx);     // pf_call.hip
+void call_invalidate(pf_ctx *ctx);  // graph or count table replaced
 enum WsSlot {
     WS_ALN_TEXT = 0, WS_ALN_JOBS, WS_ALN_SMALL, WS_ALN_RETRY, WS_ALN_IDX, WS_ALN_OFIRST, WS_ALN_OCOUNT, WS_ALN_OHITS, WS_ALN_OTEXT,
     WS_ALN_OGAPS, WS_ALN_STTEXT, WS_ALN_STGAPS, WS_ALN_STHITS, WS_ALN_WORK, WS_BFS_REC, WS_BFS_POOL, WS_BFS_SMALL, WS_BFS_DEF,
     WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS,
     WS_BUB_TEXT, WS_BUB_PATHS, WS_BUB_TASKS, WS_BUB_SMALL, WS_BUB_RETRY, WS_BUB_IDX, WS_BUB_RES, WS_BUB_OTEXT, WS_BUB_OSITES,
-    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART, WS_COUNT_
+    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_BUB_IDX2, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART, WS_COUNT_
 };
 }  // namespace pf

@@ -492,7 +492,8 @@ namespace pf {
 
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
-                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join"};
+                                                "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
+                                                "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format"};
 
 int ctx_begin(pf_ctx *ctx, int kernel) {
     if (!ctx->timing) return 0;
@@ -633,6 +634,7 @@ int pf_create(int device, pf_ctx **out) {
 }
 
 static void free_graph(pf_ctx *ctx) {
+    call_invalidate(ctx);
     hipFree(ctx->d_seq); hipFree(ctx->d_off); hipFree(ctx->d_len); hipFree(ctx->d_succ); hipFree(ctx->d_pred);
     hipFree(ctx->d_cand);
     hipFree(ctx->d_pred16);
@@ -659,6 +661,7 @@ void pf_destroy(pf_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
+    call_destroy(ctx);
     free_graph(ctx);
     hipFree(ctx->d_tab);
     hipFree(ctx->d_ctab);
@@ -925,6 +928,7 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
     if (!ctx || (n && (!kmers || !counts))) return PF_ERR_ARG;
     ctx->tab_exact = !both_strands;   // GetBothStrands() == false: lookups take the k-mer as it reads (src/CDBG.cpp:94-117)
     ctx->tab_max_count = max_count;
+    call_invalidate(ctx);
     PF_HIP(hipSetDevice(ctx->device));
     hipFree(ctx->d_tab);
     ctx->d_tab = nullptr;

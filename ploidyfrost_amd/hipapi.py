@@ -20,13 +20,19 @@ LIB_PATH = os.path.join(PKG, "csrc", "libploidyfrost_hip.so")
 NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
-           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join"]
+           "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
+           "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
 ALIGN_JOB = np.dtype([("a_off", "<u8"), ("b_off", "<u8"), ("a_len", "<u4"), ("b_len", "<u4")])
 ALIGN_HIT = np.dtype([("text_off", "<u8"), ("gap_off", "<u8"), ("len", "<u4"), ("n_gaps", "<u4"), ("score", "<i8"),
                       ("n_pos", "<u4"), ("n_indel", "<u4")])
+CALL_SIDE = np.dtype([("u", "<u4"), ("exit_ov", "<u4"), ("err_unitig", "<u4"), ("plus_side", "u1"), ("kind", "u1"), ("aligned", "u1"),
+                      ("err", "u1")])
+CALL_RESULT = np.dtype([("text_len", "<u8", (10,)), ("allele", "<u8", (4,)), ("core_cov", "<u8"), ("core_num", "<u8"), ("n_called", "<u8"),
+                        ("align_jobs", "<u8"), ("site_strings", "<u8"), ("n_branching", "<u8")])
+CALL_STREAMS = ["allele_frequency", "alignseq", "bifre", "trifre", "tetrafre", "pentafre", "bicov", "tricov", "tetracov", "pentacov"]
 BUBBLE_PATH = np.dtype([("text_off", "<u8"), ("len", "<u4"), ("ov", "<u4")])
 BUBBLE_TASK = np.dtype([("path_first", "<u8"), ("n_paths", "<u4"), ("pad", "<u4")])
 BUBBLE_SITE = np.dtype([("col", "<u4"), ("is_indel", "u1"), ("maxnum", "u1"), ("pad", "<u2")])
@@ -100,6 +106,16 @@ def load_library() -> C.CDLL:
         "pf_gmm_upload": (i, [vp, vp, u64]),
         "pf_gmm_count": (u64, [vp]),
         "pf_gmm_fit": (i, [vp, u32, C.c_double, C.c_double, C.c_int32, C.c_double, vp, vp, vp, vp, vp]),
+        "pf_call_set_state": (i, [vp, vp, vp, vp]),
+        "pf_call_coverage": (i, [vp]),
+        "pf_call_scan": (i, [vp, u32, u32, C.POINTER(u64)]),
+        "pf_call_sides": (i, [vp, vp, u64]),
+        "pf_call_select": (i, [vp, vp, u64]),
+        "pf_call_run": (i, [vp, i, u64, u64, u64, u32, C.c_double, C.c_double, C.c_double, vp]),
+        "pf_call_align": (i, [vp, u64, u64, u32, C.c_double, C.c_double, C.c_double, vp]),
+        "pf_call_text": (i, [vp, i, u64, vp]),
+        "pf_call_fetch": (i, [vp, i, i, vp, u64]),
+        "pf_format_doubles": (i, [vp, vp, u64, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)  # AttributeError = header / library mismatch
@@ -115,7 +131,9 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
-                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe"]
+                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
+                    "pf_call_set_state", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_select", "pf_call_run", "pf_call_align",
+                    "pf_call_text", "pf_call_fetch", "pf_format_doubles"]
 
 
 def pack_unitigs(seqs: list[bytes]):
@@ -204,6 +222,14 @@ class Device:
             if n.value:
                 out[name] = (ms.value, n.value)
         return out
+
+    def format_doubles(self, values: np.ndarray) -> list[bytes]:
+        """printf("%g") of every value, formatted on the device (the result rows' number formatting, pf_format_doubles)"""
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        text = np.zeros((len(v), 32), dtype=np.uint8)
+        ln = np.zeros(len(v), dtype=np.uint8)
+        self._check(self.L.pf_format_doubles(self.h, _ptr(v), len(v), _ptr(text), _ptr(ln)))
+        return [text[i, :ln[i]].tobytes() for i in range(len(v))]
 
     # ---- uploads
     def upload_graph(self, words, off, lens, k: int):
