@@ -9,10 +9,12 @@ parsing, upload and Unitig_Id writing are outside the timed region (BASELINE.md 
   python bench.py [--gpus N] [--steps K] [--warmup W] [--unitigs U]
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
-N > 1: one process per GPU; every rank owns an independent partition of the unitig set (its own
-chromosome-sized connected components: no edge crosses ranks, so the path needs no data-path
-collective); the per-rank site counters and output sizes are all-gathered over RCCL at the end,
-as the reference-order concatenation needs them.  value = unitigs of all ranks / max-over-ranks time.
+N > 1: one process per GPU, ONE graph (BASELINE.json configs[2]: "5 M-unitig ... 1->8 MI355X scaling"), replicated in every
+GPU's HBM and cut by entrance vertex (ploidyfrost_amd/dist.py): each rank traverses the candidate entrances of its unitig range,
+the traversal records are all-gathered over RCCL and replayed on every rank; each rank aligns, formats and writes its slice of the
+bubble list into the shared result files after two small all-gathers (bubbles called, slab sizes + allele histograms).
+"scaling": "strong"; value = unitigs of the graph * steps / max-over-ranks time.  --scaling weak keeps the other reading (every
+rank its own graph, no data-path collective).
 """
 from __future__ import annotations
 
@@ -233,10 +235,10 @@ def main():
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per rank (0 = min(32, cpus/ranks))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--keep", action="store_true")
-    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
-                    help="weak (default, the driver's contract): every rank its own graph of --unitigs unitigs; strong: ONE graph of "
-                         "--unitigs unitigs on all ranks, findSuperBubble on every rank, PloidyEstimation cut into slices of the bubble "
-                         "list (SURVEY.md 8e), rank 0 joins the ranks' files")
+    ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the comparison of the shared result files with a pass of rank 0 alone")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
+                    help="strong (default: the metric's config is one 5 M-unitig graph at 1..8 GPUs): ONE graph of --unitigs unitigs cut "
+                         "by entrance vertex over the ranks (SURVEY.md 8e); weak: every rank its own graph of --unitigs unitigs")
     ap.add_argument("--workload", choices=["single", "colored"], default="single",
                     help="single = the headline metric (BASELINE.json configs[1]); colored = the CCDBG path on 3 diploid "
                          "samples (configs[3]), same JSON line with config.workload saying so")
@@ -265,7 +267,7 @@ def main():
         genome = int(args.unitigs / UNITIGS_PER_BP)
         colored = args.workload == "colored"
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
-        strong = args.scaling == "strong" and world > 1
+        strong = args.scaling == "strong" and world > 1 and args.workload == "single"
         seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + (0 if strong else rank)
         if colored:
             n_samples = 3
@@ -285,11 +287,10 @@ def main():
             run.set_batch_bubbles(int(os.environ["PF_BATCH_BUBBLES"]))
         run.set_output_dir(os.path.join(workdir, "PloidyFrost_output"))
         if strong:
-            run.set_partition(rank, world)
-            # the ranks' result directories, known to rank 0 (one node, one file system), which joins them after every pass
-            dirs = [None] * world
-            dist.all_gather_object(dirs, os.path.join(workdir, "PloidyFrost_output"))
-        run.set_unitig_id("b")
+            # one node, one file system: every rank writes its slabs into rank 0's result files at its own offsets
+            run.set_output_dir(pfdist.broadcast_str(os.path.join(workdir, "PloidyFrost_output")))
+        if not strong or rank == 0:
+            run.set_unitig_id("b")
         load_s = time.time() - t0
         log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, load_s, torch.cuda.get_device_name(gpu_index)))
         L = hipapi.load_library()
@@ -298,7 +299,15 @@ def main():
 
         gathered_bytes = [0]
 
+        shard_stats = {}
+
         def step():
+            if strong:
+                pfdist.sharded_find(run, "b", xdev, shard_stats)
+                totals_, counters_ = pfdist.sharded_ploidy(run, "b", LOWER, UPPER, xdev, shard_stats)
+                shard_stats["counters"] = [int(x) for x in counters_]
+                shard_stats["output_bytes"] = int(totals_.sum())
+                return
             run.find_superbubbles("b")
             if colored:
                 run.ploidy_estimation("b", cutoffs)
@@ -310,17 +319,6 @@ def main():
                 pfdist.all_gather_counters(tt_["allele"] + [tt_["tasks"]], xdev)
                 slabs = pfdist.all_gather_slabs(run.last_allele_frequency(), xdev)
                 gathered_bytes[0] = sum(int(x.size) for x in slabs)
-                if strong and rank == 0:
-                    # rank-order concatenation of the slices = the reference's files (Unitig_Id / super_bubble: rank 0's own)
-                    final = os.path.join(workdir, "joined")
-                    os.makedirs(final, exist_ok=True)
-                    for suf in ("alignseq", "allele_frequency", "bicov", "bifre", "tricov", "trifre", "tetracov", "tetrafre", "pentacov", "pentafre"):
-                        with open(os.path.join(final, "b_%s.txt" % suf), "wb") as fo:
-                            for d in dirs:
-                                with open(os.path.join(d, "b_%s.txt" % suf), "rb") as fi:
-                                    n_left = os.fstat(fi.fileno()).st_size
-                                    while n_left > 0:
-                                        n_left -= os.sendfile(fo.fileno(), fi.fileno(), None, n_left)
 
         first_pass = None
         for w_ in range(args.warmup):
@@ -374,6 +372,34 @@ def main():
                 probe = {"avg_ms": round(ms.value / n.value, 4),
                          "equals_streamed": bool(all(np.array_equal(a, b) for a, b in zip(res[0], res[1])))}
 
+        # one graph over several ranks: hold the shared files against a pass of rank 0 alone, once, outside the timed region
+        sharded_identical = None
+        if strong and not args.no_verify:
+            if rank == 0:
+                import hashlib
+                shared = os.path.join(workdir, "PloidyFrost_output")
+                names = sorted(f for f in os.listdir(shared) if f.startswith("b_"))
+                def digest(d):
+                    out = {}
+                    for f in names:
+                        h = hashlib.md5()
+                        with open(os.path.join(d, f), "rb") as fh:
+                            for blk in iter(lambda: fh.read(1 << 24), b""):
+                                h.update(blk)
+                        out[f] = h.hexdigest()
+                    return out
+                got = digest(shared)
+                alone = os.path.join(workdir, "alone")
+                run.set_output_dir(alone)
+                run.set_unitig_id("b")
+                run.find_superbubbles("b")
+                run.ploidy_estimation("b", LOWER, UPPER)
+                want = digest(alone)
+                sharded_identical = {"files": len(names), "identical": got == want,
+                                     "differing": [f for f in names if got[f] != want.get(f)]}
+                log("sharded run vs rank 0 alone: %s" % sharded_identical)
+            dist.barrier()
+
         allstats = pfdist.all_gather_counters([n_unitigs, tt["superbubbles"], tt["tasks"], tt["output_bytes"]] + tt["allele"] +
                                               [int(elapsed * 1e6)], xdev)
         max_elapsed = allstats[:, -1].max() / 1e6
@@ -412,21 +438,22 @@ def main():
             out = {
                 "metric": "unitigs/s through superbubble+SeqAlign (k=25, z=8)",
                 "value": round(value, 1), "unit": "unitigs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(max_elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "strong" if strong else "weak",
+                "ms_per_step": round(max_elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak" if (world > 1 and not strong) else "strong",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
                 "config": {"workload": ("colored graph of 3 synthetic diploid samples (CCDBG path, configs[3]), %d unitigs/GPU, k=25 z=8, "
                                         "cutoffs %d/%d per sample, M=2 D=-1 G=-3" if colored else
                                         "single-sample synthetic tetraploid graph, %d unitigs (BASELINE.json configs[2] = 5 M; configs[1] = 1 M with --unitigs 1000000), k=25 z=8, "
                                         "-l %d -u %d, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER),
                            "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
-                           "partitioning": ("one graph on every rank, findSuperBubble replicated, PloidyEstimation in contiguous slices of the "
-                                            "bubble list, rank 0 joins the files; per-pass all-gather of counters and allele-frequency slabs "
-                                            "(%d bytes)" if strong else
+                           "partitioning": ("one graph replicated on every rank, cut by entrance vertex: K-BFS records all-gathered over RCCL "
+                                            "(%d bytes per pass) and replayed on every rank; bubble list in contiguous slices, two small "
+                                            "all-gathers (bubbles called; slab sizes + allele histograms), every rank writes its slabs into "
+                                            "the shared files" % shard_stats.get("find_gathered_bytes", 0) if strong else
                                             "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
-                                            "and allele-frequency record slabs (%d bytes)") % gathered_bytes[0]},
+                                            "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0])},
                 "roofline": roof, "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for e in kernels.values()), 3),
-                "first_pass": first_pass, "load_s": round(load_s, 3),
+                "first_pass": first_pass, "load_s": round(load_s, 3), "sharded_output_check": sharded_identical,
                 "kernels": kernels, "k_cov_probe": probe,
                 "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},
                 # rank 0's graph; for one graph over all ranks (strong) the per-slice counters are added up
@@ -435,10 +462,10 @@ def main():
                         "deferred_frac": round(tt["bfs_deferred"] / max(tt["candidates"], 1), 8),
                         "traversals_beyond_4096": tt["bfs_large"], "longest_traversal": tt["bfs_max_seen"]},
                 "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"],
-                           "bubbles_called": int(allstats[:, 2].sum()) if strong else tt["tasks"],
+                           "bubbles_called": shard_stats["counters"][7] if strong else tt["tasks"],
                            "align_jobs": tt["align_jobs"], "site_strings": tt["site_strings"],
-                           "sites": [int(x) for x in allstats[:, 4:8].sum(axis=0)] if strong else tt["allele"],
-                           "output_bytes": tt["output_bytes"]},
+                           "sites": shard_stats["counters"][:4] if strong else tt["allele"],
+                           "output_bytes": shard_stats["output_bytes"] if strong else tt["output_bytes"]},
             }
             if cpu:
                 out["speedup_vs_cpu_1core"] = round(value / cpu["value"], 2)

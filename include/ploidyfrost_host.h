@@ -46,10 +46,6 @@ void pfh_set_overlap_output(pfh_run *, int on);      /* 1: <outpre>_super_bubble
 /* K-BFS traversals beyond 4096 vertices: on host cores (default, pf_bfs_candidates_split + host/pf_bfs_host.cpp: one thread per
  * traversal) or, with on = 0, on the device (k_bfs_huge: one wavefront per traversal).  Same records either way. */
 void pfh_set_third_tier_on_host(pfh_run *, int on);
-/* One graph on `world` GPUs (every rank opens the same graph and databases): pfh_find_superbubbles runs whole on every rank,
- * pfh_ploidy_estimation calls, numbers and writes only slice `rank` of the bubble list.  The result files of the run are the
- * ranks' files concatenated in rank order (Unitig_Id and super_bubble: any rank's); pfh_get_times counters add up over ranks. */
-void pfh_set_partition(pfh_run *, uint32_t rank, uint32_t world);
 void pfh_set_batch_bubbles(pfh_run *, uint64_t n);   /* bubbles per batch of the align/format pipeline (default 65536) */
 int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);
@@ -131,6 +127,42 @@ int pfh_gmm_kernel_time(pfh_gmm *, int enable, double *total_ms, uint64_t *launc
  * 0 = ok, 2 = list_cap too small (record->n_list says how much is needed). */
 int pfh_host_walk(const uint32_t *succ, const uint32_t *pred, uint32_t n_unitigs, uint32_t entrance, pf_bfs_record *record, uint32_t *list,
                   uint64_t list_cap);
+
+/* ---- one graph over several GPUs: every rank opens the same graph and database -------------------------------
+ * findSuperBubble:   pfh_find_shard(u0, u1) traverses the candidate entrances on this rank's unitig range (K-BFS + host walkers);
+ *                    pfh_shard_records / pfh_shard_pool expose the records (pf_bfs_record, list_off relative to the pool) for the
+ *                    exchange (RCCL all-gather); pfh_find_replay applies the records of all shards in shard order -- the
+ *                    reference's visiting order with its `partner == NULL` gate (src/CDBG.cpp:206-214) -- so that every rank ends
+ *                    with the same MyUnitig state; write_file = 1 on the rank that writes <outpre>_super_bubble.txt.
+ * PloidyEstimation:  pfh_ploidy_select (scan + sequential pass, on every rank) -> n_bubbles, the run's bubble list in output
+ *                    order; the rank aligns its contiguous slice [t0, t1) (pfh_ploidy_align -> how many of them are called:
+ *                    var_count, src/CDBG.cpp:1254-1258); after exchanging those counts it formats with the number of bubbles
+ *                    called by the ranks before it (pfh_ploidy_text -> the byte sizes of its ten slabs and counters[8] =
+ *                    {2,3,4,5-allele sites, coreCov, coreNum, called, bubbles}); after exchanging the sizes it writes its slabs at
+ *                    its offsets of the shared result files (pfh_ploidy_write; truncate = 1 cuts them to `totals`: pass it on
+ *                    every rank, the length is the same).  Rank-order concatenation = the reference's `-t 1` files, because a
+ *                    bubble's position is fixed by its owner endpoint (:1190, 1352, 1656-1679). */
+int pfh_find_shard(pfh_run *, uint32_t u0, uint32_t u1);
+const pf_bfs_record *pfh_shard_records(const pfh_run *, uint64_t *n_records);
+const uint32_t *pfh_shard_pool(const pfh_run *, uint64_t *n_entries);
+int pfh_find_replay(pfh_run *, const char *outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
+                    const uint32_t *const *pools, int write_file);
+int pfh_ploidy_select(pfh_run *, int lower, int upper, uint64_t *n_bubbles);
+int pfh_ploidy_align(pfh_run *, uint64_t t0, uint64_t t1, uint64_t *n_called);
+int pfh_ploidy_text(pfh_run *, uint64_t var_count_base, uint64_t sizes[10], uint64_t counters[8]);
+int pfh_ploidy_write(pfh_run *, const char *outpre, const uint64_t offsets[10], const uint64_t totals[10], int truncate);
+
+/* The same exchange without a device (CPU tests of the N > 1 path): the records of a unitig range from the host walker alone
+ * (pfh_host_walk_range: every oriented vertex with out-degree > 1 on unitigs [u0, u1), ascending; returns the number of records,
+ * *pool_used the list entries; UINT64_MAX when a capacity is too small) and the commit replay on a bare state
+ * (pfh_replay_open: n_unitigs, -z; pfh_replay_apply: one shard's records, in shard order; pfh_replay_state as pfh_state). */
+uint64_t pfh_host_walk_range(const uint32_t *succ, const uint32_t *pred, uint32_t n_unitigs, uint32_t u0, uint32_t u1,
+                             pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool, uint64_t pool_cap, uint64_t *pool_used);
+typedef struct pfh_replay pfh_replay;
+pfh_replay *pfh_replay_open(uint32_t n_unitigs, uint32_t complex_size);
+void pfh_replay_close(pfh_replay *);
+int pfh_replay_apply(pfh_replay *, const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool);
+void pfh_replay_state(const pfh_replay *, uint8_t *flags, uint32_t *plus, uint32_t *minus);
 
 /* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);

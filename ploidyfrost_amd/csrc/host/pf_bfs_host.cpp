@@ -113,6 +113,23 @@ const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32
         }
     }
     r.n_seen = (uint32_t)seen.size();
+    // the structural "strict" test of the accept commit (src/CDBG.cpp:765-782): at most 6 vertices and every inner one has exactly
+    // one predecessor, on s's unitig, and one successor, on t's (what K-BFS evaluates for the traversals it keeps)
+    if (r.outcome == PF_BFS_ACCEPT && seen.size() >= 4 && seen.size() <= 6) {
+        bool ok = true;
+        for (uint32_t w : seen) {
+            if (w == s || w == r.exit) continue;
+            int din = 0, dout = 0;
+            uint32_t fp = NONE, fs = NONE;
+            for (int b = 0; b < 4; ++b) {
+                const uint32_t p = pred[(size_t)w * 4 + b], q = succ[(size_t)w * 4 + b];
+                if (p != NONE) { if (!din) fp = p; ++din; }
+                if (q != NONE) { if (!dout) fs = q; ++dout; }
+            }
+            if (!(din == 1 && dout == 1 && (fp >> 1) == (s >> 1) && (fs >> 1) == (r.exit >> 1))) { ok = false; break; }
+        }
+        r.strict = ok;
+    }
     r.flag_cycle = flag_cycle;
     r.flag_tip = flag_tip;
     const std::vector<uint32_t> &list = r.outcome != PF_BFS_NONE ? seen : cyc;

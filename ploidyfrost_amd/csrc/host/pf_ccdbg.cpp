@@ -40,6 +40,7 @@ CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, doub
     if (status_) return;
     if (cg_.graph.n_abundant && !cg_.reload_colors()) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: " + cg_.err); return; }
     col_ = &cg_.colors;
+    st_.col = col_;
     const uint32_t C = cg_.colors.n_colors;
     if (C > PF_MAX_COLORS) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: more colours than the device table holds"); return; }
     if (!kmc_db_list.empty()) {

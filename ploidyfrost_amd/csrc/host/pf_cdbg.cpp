@@ -55,9 +55,10 @@ int CDBG::init_device(int device) {
     st = pf_build_adjacency(ctx_, succ_.data(), pred_.data());
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: adjacency: " + pf_last_error(ctx_));
     trace.mark("device: adjacency");
-    flags_.assign(N, 0);
-    plus_.assign(N, 0);
-    minus_.assign(N, 0);
+    st_.reset(N);
+    st_.complex_size = complex_size_;
+    st_.g = &g_;
+    st_.succ = succ_.data();
     return 0;
 }
 
@@ -217,122 +218,6 @@ int CDBG::printInfo(const bool &verbose, const std::string &outpre) {
     FILE *f = fopen((outpre + "_graph_info.txt").c_str(), "w");
     if (f) { fputs(line, f); fclose(f); }
     return 0;
-}
-
-// ---- MyUnitig state -------------------------------------------------------------------------
-void CDBG::side_self(uint32_t u, bool plus_side) {
-    if (plus_side) { plus_[u] = u + 1; flags_[u] &= (uint8_t)~B_PLUS; }
-    else { minus_[u] = u + 1; flags_[u] &= (uint8_t)~B_MINUS; }
-}
-// "if (ex->get_plus() == me) ex->set_plus_self(); else ex->set_minus_self();"
-void CDBG::release(uint32_t ex, uint32_t me) { side_self(ex, plus_[ex] == me + 1); }
-// interior vertex of any committed traversal (e.g. src/CDBG.cpp:800-826)
-void CDBG::poison(uint32_t u) {
-    uint32_t p = plus_[u];
-    if (p != 0 && p != u + 1) release(p - 1, u);
-    side_self(u, true);
-    p = minus_[u];
-    if (p != 0 && p != u + 1) release(p - 1, u);
-    side_self(u, false);
-    flags_[u] |= B_NON_SUPER;
-}
-
-// Order-dependent part of extractSuperBubble_ptr: the three setNoBubble commits
-// (src/CDBG.cpp:552-846) and the no-exit tail (:373-413), applied to one device record.
-void CDBG::replay(const pf_bfs_record &r, const uint32_t *list) {
-    const uint32_t s = r.entrance, su = s >> 1;
-    if (r.outcome == PF_BFS_NONE) {
-        if (!r.flag_cycle) return;
-        for (uint32_t i = 0; i < r.n_list; ++i) poison(list[i] >> 1);
-        side_self(su, plus_of(s));
-        return;
-    }
-    const uint32_t t = r.exit, tu = t >> 1;
-    if (r.outcome == PF_BFS_CYCLE_EXIT) {  // setNoBubble_ptr_cycle
-        if (col_) {
-            // src/CCDBG.cpp:2351-2384: a side is self-marked only if it held a real partner
-            for (uint32_t i = 0; i < r.n_list; ++i) {
-                const uint32_t w = list[i] >> 1;
-                uint32_t p = plus_[w];
-                if (p != 0 && p != w + 1) { release(p - 1, w); side_self(w, true); }
-                p = minus_[w];
-                if (p != 0 && p != w + 1) { release(p - 1, w); side_self(w, false); }
-                flags_[w] |= B_NON_SUPER;
-            }
-        } else
-        for (uint32_t i = 0; i < r.n_list; ++i) poison(list[i] >> 1);
-        side_self(su, plus_of(s));
-        side_self(tu, !plus_of(t));
-        return;
-    }
-    if (r.outcome == PF_BFS_REJECT) {  // setNoBubble_ptr(seen, p)
-        uint32_t p = plus_of(s) ? plus_[su] : minus_[su];
-        if (p != 0) release(p - 1, su);
-        side_self(su, plus_of(s));
-        p = !plus_of(t) ? plus_[tu] : minus_[tu];
-        if (p != 0) release(p - 1, tu);
-        side_self(tu, !plus_of(t));
-        for (uint32_t i = 0; i < r.n_list; ++i)
-            if (list[i] != s && list[i] != t) poison(list[i] >> 1);
-        return;
-    }
-    // PF_BFS_ACCEPT: setNoBubble_ptr(p, seen)
-    if (r.n_seen < 4) return;
-    if ((flags_[tu] & B_NON_SUPER) || (flags_[su] & B_NON_SUPER)) {
-        for (uint32_t i = 0; i < r.n_list; ++i) {
-            const uint32_t w = list[i];
-            if (w == s) side_self(su, plus_of(s));
-            else if (w == t) side_self(tu, !plus_of(t));
-            else poison(w >> 1);
-        }
-        return;
-    }
-    if (r.strict) {  // n_seen <= 6 and the structural test, evaluated on the device
-        flags_[su] |= plus_of(s) ? B_STRICT_P : B_STRICT_M;
-        flags_[tu] |= !plus_of(t) ? B_STRICT_P : B_STRICT_M;
-    }
-    if (r.n_seen > complex_size_) {
-        flags_[su] |= plus_of(s) ? B_COMPLEX_P : B_COMPLEX_M;
-        flags_[tu] |= !plus_of(t) ? B_COMPLEX_P : B_COMPLEX_M;
-    }
-    for (uint32_t i = 0; i < r.n_list; ++i)
-        if (list[i] != s && list[i] != t) poison(list[i] >> 1);
-    if (col_ && !colours_allow(r, list)) {
-        side_self(su, plus_of(s));
-        side_self(tu, !plus_of(t));
-        return;
-    }
-    if (plus_of(s)) { plus_[su] = tu + 1; flags_[su] |= B_PLUS; }
-    else { minus_[su] = tu + 1; flags_[su] |= B_MINUS; }
-    if (plus_of(t)) { minus_[tu] = su + 1; flags_[tu] |= B_MINUS; }
-    else { plus_[tu] = su + 1; flags_[tu] |= B_PLUS; }
-}
-
-// The colored accept commit's extra gates (src/CCDBG.cpp:2530-2621): both endpoints carry every colour on every
-// k-mer, and every colour a vertex of the bubble carries in full continues, in full, on one of its successors.
-bool CDBG::colours_allow(const pf_bfs_record &r, const uint32_t *list) {
-    const ColorSets &col = *col_;
-    const uint32_t C = col.n_colors;
-    const uint32_t s = r.entrance, su = s >> 1, t = r.exit, tu = t >> 1;
-    const uint64_t km_s = g_.len_km(su), km_t = g_.len_km(tu);
-    bool f = true;
-    if (col.size_with(su, km_s, km_s) != km_s * C) { f = false; flags_[su] |= B_NON_SUPER; }
-    // the exit's set is sized with the entrance's mapping (:2552): only the pair encoding notices
-    if (col.size_with(tu, km_t, km_s) != km_t * C) { f = false; flags_[tu] |= B_NON_SUPER; }
-    if (!f) return false;
-    const uint64_t all = C == 64 ? ~0ull : ((1ull << C) - 1);
-    for (uint32_t i = 0; i < r.n_list; ++i) {
-        const uint32_t w = list[i];
-        if (w == t) continue;
-        // the reference keys its colour lists by unitig id and pre-loads both endpoints with every colour
-        const uint64_t mine = ((w >> 1) == su || (w >> 1) == tu) ? all : col.full_mask[w >> 1];
-        uint64_t cont = 0;
-        const uint32_t *row = &succ_[(size_t)w * 4];
-        for (int b = 0; b < 4; ++b)
-            if (row[b] != NONE) cont |= col.full_mask[row[b] >> 1];
-        if ((cont & mine) != mine) return false;
-    }
-    return true;
 }
 
 }  // namespace pfh

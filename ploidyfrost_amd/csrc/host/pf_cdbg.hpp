@@ -17,6 +17,7 @@
 //     reference's "message + exit(EXIT_FAILURE)";
 //   * output is always the deterministic `-t 1` ordering, whatever `threads` says.
 #pragma once
+#include <chrono>
 #include <memory>
 #include <mutex>
 
@@ -31,6 +32,7 @@
 #include "pf_host_colors.hpp"
 #include "pf_host_graph.hpp"
 #include "pf_pinned.hpp"
+#include "pf_state.hpp"
 #include "ploidyfrost_hip.h"
 
 namespace pfh {
@@ -71,11 +73,6 @@ public:
     void set_quiet(bool q) { quiet_ = q; }
     void set_threads(unsigned t) { threads_ = t; }                  // host threads; 0 = use the `thr` argument
     void set_third_tier_on_host(bool on) { third_tier_on_host_ = on; }   // default on; off = one wavefront per giant traversal
-    // One graph on several GPUs: every rank holds the whole graph and runs findSuperBubble itself (the
-    // commit replay is sequential and cheap); PloidyEstimation is cut into `world` contiguous slices of the bubble list
-    // -- the reference's output order -- and rank r calls, numbers (var_count continues where slice r-1 ends) and writes
-    // slice r only.  The files of the whole run are the ranks' files concatenated in rank order; counters add up.
-    void set_partition(unsigned rank, unsigned world) { part_rank_ = world ? rank % world : 0; part_world_ = world ? world : 1; }
     void set_write_files(bool w) { write_files_ = w; }              // bench: format but do not touch the disk
     void set_batch_bubbles(size_t n) { batch_bubbles_ = n; }
     // write <outpre>_super_bubble.txt in the background while PloidyEstimation runs (complete when that call, the next
@@ -84,6 +81,21 @@ public:
     // PloidyEstimation through the device's resident calling pipeline (pf_call_*, the default for the single-sample path) or,
     // off, through the host-threaded pipeline around pf_align_bubbles / pf_string_cov (what the colored path uses)
     void set_resident_calling(bool on) { resident_ = on; }
+    // ---- one graph over several GPUs (reference owner rule src/CDBG.cpp:1190, 1352, 1656-1679) -------------
+    // findSuperBubble: every rank traverses the entrances of its unitig range (find_shard), the ranks exchange the records,
+    // every rank replays all of them (find_replay; rank 0 writes the file).  PloidyEstimation: the scan and the sequential pass
+    // run on every rank (ploidy_select), each rank aligns its slice of the bubble list (ploidy_align), the ranks exchange how
+    // many of their bubbles were called, format with that base (ploidy_text) and, knowing every rank's slab sizes, write
+    // their slabs at their offsets of the shared result files (ploidy_write).
+    int find_shard(uint32_t u0, uint32_t u1);
+    const std::vector<pf_bfs_record> &shard_records() const { return shard_rec_; }
+    const std::vector<uint32_t> &shard_pool() const { return shard_pool_; }
+    int find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
+                    const uint32_t *const *pools, bool write_file);
+    int ploidy_select(int lower, int upper, uint64_t &n_bubbles);
+    int ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called);
+    int ploidy_text(uint64_t var_count_base, uint64_t sizes[PF_CALL_STREAMS], uint64_t counters[8]);
+    int ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL_STREAMS], const uint64_t totals[PF_CALL_STREAMS], bool truncate);
     pf_ctx *device() { return ctx_; }
     const PhaseTimes &times() const { return times_; }
     uint64_t allele_sites(int arity) const { return allele_[arity - 2]; }
@@ -107,12 +119,17 @@ protected:
     // the same through pf_call_* (pf_cdbg_call.cpp); call_select = scan + the sequential pass of the driver loop
     int ploidy_estimation_resident(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
     int call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &n_tasks);
-    bool resident_path() const { return resident_ && col_ == nullptr && part_world_ == 1; }
+    bool resident_path() const { return resident_ && col_ == nullptr; }
     // set by CCDBG: the colour sets of the graph's unitigs (reference src/CCDBG.cpp path) and the stdout tag
     const ColorSets *col_ = nullptr;
     const char *tag_ = "CDBG";
 
     struct Task;
+    using clk_time = std::chrono::steady_clock::time_point;
+    int finish_find(const std::string &outpre, const size_t &thr, clk_time t_all, bool write_file);
+    std::vector<pf_bfs_record> shard_rec_;
+    std::vector<uint32_t> shard_pool_;
+    pf_call_result slice_res_ = {};
     int fail(int st, const std::string &msg);
     int join_pending_write();
     int launch_coverage();
@@ -127,12 +144,7 @@ protected:
     int write_file(const std::string &name, const std::string &data);
     int write_pieces(const std::string &name, const std::vector<const std::string *> &pieces, uint64_t &bytes) const;
     int write_many(const std::vector<std::pair<std::string, std::vector<const std::string *>>> &files, unsigned threads);
-    // MyUnitig state (reference src/MyUnitig.hpp), array-indexed
-    void side_self(uint32_t u, bool plus_side);
-    void release(uint32_t ex, uint32_t me);
-    void poison(uint32_t u);
-    void replay(const pf_bfs_record &r, const uint32_t *list);
-    bool colours_allow(const pf_bfs_record &r, const uint32_t *list);
+    void replay(const pf_bfs_record &r, const uint32_t *list) { st_.replay(r, list); }
 
     UnitigSet &g_;
     size_t complex_size_;
@@ -144,7 +156,6 @@ protected:
     bool quiet_ = false, write_files_ = true;
     bool both_strands_ = true;
     unsigned threads_ = 0;
-    unsigned part_rank_ = 0, part_world_ = 1;
     // third K-BFS tier (traversals beyond 4096 vertices) on host cores, pf_bfs_host.hpp; false = the device's k_bfs_huge
     bool third_tier_on_host_ = true;
     std::vector<std::unique_ptr<HugeWalker>> walkers_;
@@ -155,8 +166,10 @@ protected:
     std::vector<std::vector<uint32_t>> huge_lists_[4];
 
     std::vector<uint32_t> succ_, pred_;  // host copy of the CSR, [2N][4]
-    std::vector<uint8_t> flags_;
-    std::vector<uint32_t> plus_, minus_;  // 0 = NULL, id = u + 1
+    // MyUnitig state (reference src/MyUnitig.hpp), array-indexed, with the commits that mutate it (pf_state.hpp)
+    UnitigState st_;
+    std::vector<uint8_t> &flags_ = st_.flags;
+    std::vector<uint32_t> &plus_ = st_.plus, &minus_ = st_.minus;  // 0 = NULL, id = u + 1
 
     // pinned exchange buffers of pf_align_bubbles, three sets: one per batch in flight (reused from pass to pass)
     struct AlignExchange {

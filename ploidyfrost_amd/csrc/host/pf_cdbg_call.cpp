@@ -73,6 +73,105 @@ int CDBG::call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &
     return 0;
 }
 
+// ---- the same in steps, for a bubble list cut over several ranks ----
+int CDBG::ploidy_select(int lower, int upper, uint64_t &n_bubbles) {
+    if (status_) return status_;
+    if (col_) return fail(PF_ERR_ARG, "CDBG::ploidy_select(): single-sample path only");
+    times_.tasks = times_.align_jobs = times_.site_strings = 0;
+    allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
+    core_cov_ = core_num_ = 0;
+    const bool keep = resident_;
+    resident_ = true;   // coverage must land in the device arrays the scan reads
+    const int rc = call_select({{lower, upper}}, n_bubbles);
+    resident_ = keep;
+    return rc;
+}
+
+int CDBG::ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called) {
+    if (status_) return status_;
+    const auto t = clk::now();
+    const int st = pf_call_align(ctx_, t0, t1, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch, sc_.gap, &slice_res_);
+    if (st != PF_OK) {
+        const std::string e = pf_last_error(ctx_);
+        return fail(st, e.rfind("CDBG::", 0) == 0 ? e : std::string(tag_) + "::PloidyEstimation(): " + e);
+    }
+    n_called = slice_res_.n_called;
+    times_.tasks = t1 - t0;
+    times_.align_jobs = slice_res_.align_jobs;
+    times_.site_strings = slice_res_.site_strings;
+    times_.align_s = since(t);
+    return 0;
+}
+
+int CDBG::ploidy_text(uint64_t var_count_base, uint64_t sizes[PF_CALL_STREAMS], uint64_t counters[8]) {
+    if (status_) return status_;
+    const auto t = clk::now();
+    const int st = pf_call_text(ctx_, 0, var_count_base, &slice_res_);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) sizes[s] = slice_res_.text_len[s];
+    for (int a = 0; a < 4; ++a) { counters[a] = slice_res_.allele[a]; allele_[a] = slice_res_.allele[a]; }
+    counters[4] = core_cov_ = slice_res_.core_cov;
+    counters[5] = core_num_ = slice_res_.core_num;
+    counters[6] = slice_res_.n_called;
+    counters[7] = times_.tasks;
+    times_.format_s = since(t);
+    return 0;
+}
+
+// this rank's slabs into the shared result files, each at the offset the ranks before it leave; the last writer of a run (or any
+// one rank, after a barrier) passes truncate = true to cut the files to their total length
+int CDBG::ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL_STREAMS], const uint64_t totals[PF_CALL_STREAMS], bool truncate) {
+    if (status_) return status_;
+    if (ensure_dir()) return status_;
+    const auto t = clk::now();
+    const unsigned T = threads_ ? threads_ : 1;
+    uint64_t total = 0, off[PF_CALL_STREAMS + 1];
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += slice_res_.text_len[s]; }
+    PinnedBuf<char> &hb = cx_.slab[0];
+    hb.ensure(ctx_, std::max<uint64_t>(total, 1));
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+        const int st = pf_call_fetch(ctx_, 0, s, hb.p + off[s], slice_res_.text_len[s]);
+        if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): copy of a text slab failed");
+    }
+    last_allfre_.assign(hb.p + off[0], slice_res_.text_len[0]);
+    int fds[PF_CALL_STREAMS];
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+        fds[s] = open((outdir_ + "/" + outpre + kStreamSuffix[s]).c_str(), O_WRONLY | O_CREAT, 0666);
+        if (fds[s] < 0) {
+            for (int x = 0; x < s; ++x) close(fds[x]);
+            return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + kStreamSuffix[s] + " file error");
+        }
+    }
+    constexpr uint64_t PIECE = 4u << 20;
+    struct Piece { int s; uint64_t at, len; };
+    std::vector<Piece> pieces;
+    for (int s = 0; s < PF_CALL_STREAMS; ++s)
+        for (uint64_t at = 0; at < slice_res_.text_len[s]; at += PIECE) pieces.push_back({s, at, std::min<uint64_t>(PIECE, slice_res_.text_len[s] - at)});
+    std::vector<int> prc(pieces.size(), 0);
+    parallel_chunks(pieces.size(), 1, T, [&](size_t i, size_t, size_t) {
+        const Piece &pc = pieces[i];
+        const char *src = hb.p + off[pc.s] + pc.at;
+        uint64_t left = pc.len, fo = offsets[pc.s] + pc.at;
+        while (left) {
+            const ssize_t w = pwrite(fds[pc.s], src, left, (off_t)fo);
+            if (w <= 0) { prc[i] = 1; return; }
+            left -= (uint64_t)w;
+            src += w;
+            fo += (uint64_t)w;
+        }
+    });
+    int rc = 0;
+    for (int x : prc) rc |= x;
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+        if (truncate && ftruncate(fds[s], (off_t)totals[s]) != 0) rc = 1;
+        close(fds[s]);
+        out_bytes_ += slice_res_.text_len[s];
+    }
+    times_.write_s = since(t);
+    if (rc) return fail(PF_ERR_ARG, "CDBG:: write error on the result files");
+    return 0;
+}
+
 int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr) {
     const auto t_all = clk::now();
     clock_t c0 = clock();

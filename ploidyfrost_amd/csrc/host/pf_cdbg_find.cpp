@@ -41,7 +41,6 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // coverage kernel PloidyEstimation starts with -- while this thread replays the records of the finished slices in
     // the reference's visiting order, with its `partner == NULL` gate (src/CDBG.cpp:206, 211): records come in
     // ascending oriented-vertex order = unitig order, '+' before '-'.
-    auto t0 = clk::now();
     // Slicing costs when a graph has chromosome-long traversals: each slice would run its own serially instead of all of
     // them side by side.  So the first pass over a graph is one slice, and later passes are sliced only if none was seen.
     constexpr int kMaxSlices = 4;
@@ -205,7 +204,15 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         printf("%s::findSuperBubble():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
         printf("%s::findSuperBubble():  Real time : %gs\n", tag_, since(t_all));
     }
-    t0 = clk::now();
+    return finish_find(outpre, thr, t_all, true);
+}
+
+// second half of findSuperBubble (reference src/CDBG.cpp:222-252): the rows of <outpre>_super_bubble.txt from the final state
+int CDBG::finish_find(const std::string &outpre, const size_t &thr, clk_time t_all, bool write_file) {
+    const uint32_t N = g_.n();
+    const bool trace_find = getenv("PF_TRACE_FIND") != nullptr;
+    auto tf = [&](const char *what) { if (trace_find) fprintf(stderr, "[find] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
+    auto t0 = clk::now();
     // super_bubble.txt: one row per open endpoint side in unitig order; rows are numbered with a prefix
     // count so that unitig ranges can be formatted in parallel
     const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
@@ -247,7 +254,9 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     const uint64_t nb = row_base[n_uch];
     n_super_bubble_ = nb;
     times_.bubbles_out = nb;
-    if (overlap_output_ && write_files_) {
+    if (!write_file) {
+        for (const std::string &pc : pieces) out_bytes_ += pc.size();
+    } else if (overlap_output_ && write_files_) {
         // written behind the caller's back while PloidyEstimation starts; joined there (or by the next use of the file)
         join_pending_write();
         pending_pieces_ = std::move(pieces);
@@ -271,6 +280,103 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     tf("super_bubble rows done");
     if (!quiet_) printf("%s::findSuperBubble(): %llu  SuperBubbles Found\n", tag_, (unsigned long long)nb);
     return 0;
+}
+
+// ---- one graph over several GPUs: a rank traverses the candidate entrances of its unitig range only ----
+// K-BFS (LDS tier on the device, the long traversals on host cores) for the entrances on unitigs [u0, u1); the records and their
+// vertex lists are left self-contained in shard_rec_ / shard_pool_ (list_off relative to shard_pool_) for the exchange.
+int CDBG::find_shard(uint32_t u0, uint32_t u1) {
+    if (status_) return status_;
+    const uint32_t N = g_.n();
+    if (u0 > u1 || u1 > N) return fail(PF_ERR_ARG, "CDBG::find_shard(): range outside the graph");
+    const auto tb = clk::now();
+    uint64_t n_cand = 0;
+    int st = pf_count_candidates(ctx_, u0, u1, &n_cand);
+    if (st != PF_OK) return fail(st, pf_last_error(ctx_));
+    bx_.bfs_rec.ensure(ctx_, std::max<uint64_t>(n_cand, 1));
+    bx_.bfs_pool.ensure(ctx_, n_cand * 6 + (1u << 20));
+    std::vector<uint32_t> &deferred = deferred_;
+    if (deferred.size() < 4096) deferred.resize(4096);
+    uint64_t n_rec = 0, used = 0, n_deferred = 0;
+    for (;;) {
+        st = pf_bfs_candidates_split(ctx_, u0, u1, bx_.bfs_rec.p, bx_.bfs_rec.cap, bx_.bfs_pool.p, bx_.bfs_pool.cap, &n_rec, &used, deferred.data(),
+                                     deferred.size(), &n_deferred);
+        if (st == PF_ERR_OVERFLOW && n_deferred > deferred.size()) { deferred.resize(n_deferred + n_deferred / 4); continue; }
+        if (st == PF_ERR_OVERFLOW && used > bx_.bfs_pool.cap) { bx_.bfs_pool.ensure(ctx_, used + used / 8); continue; }
+        break;
+    }
+    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    shard_rec_.assign(bx_.bfs_rec.p, bx_.bfs_rec.p + n_rec);
+    shard_pool_.assign(bx_.bfs_pool.p, bx_.bfs_pool.p + used);
+    if (n_deferred) {
+        const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : 1, (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
+        std::vector<std::vector<uint32_t>> lists((size_t)n_deferred);
+        parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
+            std::unique_ptr<HugeWalker> w;
+            {
+                std::lock_guard<std::mutex> lk(walkers_mu_);
+                if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
+            }
+            if (!w) w = std::make_unique<HugeWalker>();
+            pf_bfs_record &r = shard_rec_[deferred[d]];
+            const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, r.entrance, r);
+            lists[d].assign(list.begin(), list.begin() + r.n_list);
+            std::lock_guard<std::mutex> lk(walkers_mu_);
+            walkers_.push_back(std::move(w));
+        });
+        for (size_t d = 0; d < (size_t)n_deferred; ++d) {
+            pf_bfs_record &r = shard_rec_[deferred[d]];
+            r.list_off = shard_pool_.size();
+            r.pad_ = 0;
+            shard_pool_.insert(shard_pool_.end(), lists[d].begin(), lists[d].end());
+        }
+    }
+    times_.bfs_device_s = since(tb);
+    times_.bfs_deferred = n_deferred;
+    return 0;
+}
+
+// The commit replay over the records of all shards, in shard order = entrance order (reference visiting order, src/CDBG.cpp:
+// 206-214), then the rows of super_bubble.txt; every rank ends with the same state.
+int CDBG::find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
+                      const uint32_t *const *pools, bool write_file) {
+    if (status_) return status_;
+    if (join_pending_write()) return status_;
+    if (write_file && write_files_ && ensure_dir()) return status_;
+    const auto t_all = clk::now();
+    out_bytes_ = 0;
+    std::fill(flags_.begin(), flags_.end(), 0);
+    std::fill(plus_.begin(), plus_.end(), 0);
+    std::fill(minus_.begin(), minus_.end(), 0);
+    cov_ready_ = false;
+    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = times_.bfs_large_used = times_.bfs_large_used_max = 0;
+    const auto tr = clk::now();
+    uint64_t total = 0;
+    uint32_t last = 0;
+    for (uint32_t sh = 0; sh < n_shards; ++sh) {
+        const pf_bfs_record *rec = records[sh];
+        const uint32_t *pool = pools[sh];
+        const uint64_t n = n_records[sh];
+        total += n;
+        for (uint64_t i = 0; i < n; ++i) {
+            if (i + 8 < n) {
+                const pf_bfs_record &nx = rec[i + 8];
+                __builtin_prefetch(pool + nx.list_off);
+                __builtin_prefetch(&plus_[nx.entrance >> 1]);
+                __builtin_prefetch(&minus_[nx.entrance >> 1]);
+            }
+            const pf_bfs_record &r = rec[i];
+            if ((r.entrance >> 1) >= g_.n() || (total > 1 && r.entrance < last)) return fail(PF_ERR_ARG, "CDBG::find_replay(): records out of order");
+            last = r.entrance;
+            if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
+            if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
+            if (!st_.gate_open(r.entrance)) continue;
+            replay(r, pool + r.list_off);
+        }
+    }
+    times_.replay_s = since(tr);
+    times_.candidates = total;
+    return finish_find(outpre, 1, t_all, write_file);
 }
 
 // K-COV (colored: K-COV-C) for all unitigs into the pinned result buffers.  A missing k-mer is not an error here: the

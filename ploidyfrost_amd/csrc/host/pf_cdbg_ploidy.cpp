@@ -448,16 +448,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             std::vector<SideRec>().swap(side_chunks[ci]);
         });
     }
-    // One graph over several ranks: this rank formats and writes only its contiguous slice [skip_before, size) of the
-    // bubble list.  var_count continues where the previous slice ends, and whether a bubble counts is known only once it
-    // was aligned (SequenceAlignment may leave no rows, src/CDBG.cpp:1254, 1423), so the bubbles ahead of the slice go
-    // through the device stages as well -- in batches that are counted, not formatted.
-    size_t skip_before = 0;
-    if (part_world_ > 1) {
-        const size_t total = all_tasks.size();
-        skip_before = total * part_rank_ / part_world_;
-        all_tasks.resize(total * (part_rank_ + 1) / part_world_);
-    }
+    const size_t skip_before = 0;
     times_.scan_s += since(t0);
     tp("scan done");
 

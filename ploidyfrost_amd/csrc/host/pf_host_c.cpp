@@ -126,7 +126,6 @@ void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0)
 void pfh_set_threads(pfh_run *r, uint32_t threads) { r->cdbg->set_threads(threads); }
 void pfh_set_overlap_output(pfh_run *r, int on) { r->cdbg->set_overlap_output(on != 0); }
 void pfh_set_third_tier_on_host(pfh_run *r, int on) { r->cdbg->set_third_tier_on_host(on != 0); }
-void pfh_set_partition(pfh_run *r, uint32_t rank, uint32_t world) { r->cdbg->set_partition(rank, world); }
 void pfh_set_batch_bubbles(pfh_run *r, uint64_t n) { r->cdbg->set_batch_bubbles((size_t)n); }
 int pfh_set_unitig_id(pfh_run *r, const char *outpre) {
     return guarded(r, [&] { return r->cdbg->setUnitigId(outpre, "", 1); });
@@ -138,6 +137,35 @@ int pfh_ploidy_estimation(pfh_run *r, const char *outpre, int lower, int upper) 
     return guarded(r, [&] { return r->cdbg->ploidyEstimation_multithread_ptr(outpre, lower, upper, 1); });
 }
 void *pfh_device_ctx(pfh_run *r) { return r->cdbg->device(); }
+
+// ---- one graph over several GPUs -------------------------------------------------------------------
+int pfh_find_shard(pfh_run *r, uint32_t u0, uint32_t u1) {
+    return guarded(r, [&] { return r->cdbg->find_shard(u0, u1); });
+}
+const pf_bfs_record *pfh_shard_records(const pfh_run *r, uint64_t *n) {
+    if (n) *n = r->cdbg->shard_records().size();
+    return r->cdbg->shard_records().data();
+}
+const uint32_t *pfh_shard_pool(const pfh_run *r, uint64_t *n) {
+    if (n) *n = r->cdbg->shard_pool().size();
+    return r->cdbg->shard_pool().data();
+}
+int pfh_find_replay(pfh_run *r, const char *outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
+                    const uint32_t *const *pools, int write_file) {
+    return guarded(r, [&] { return r->cdbg->find_replay(outpre, n_shards, records, n_records, pools, write_file != 0); });
+}
+int pfh_ploidy_select(pfh_run *r, int lower, int upper, uint64_t *n_bubbles) {
+    return guarded(r, [&] { uint64_t n = 0; const int rc = r->cdbg->ploidy_select(lower, upper, n); if (n_bubbles) *n_bubbles = n; return rc; });
+}
+int pfh_ploidy_align(pfh_run *r, uint64_t t0, uint64_t t1, uint64_t *n_called) {
+    return guarded(r, [&] { uint64_t n = 0; const int rc = r->cdbg->ploidy_align(t0, t1, n); if (n_called) *n_called = n; return rc; });
+}
+int pfh_ploidy_text(pfh_run *r, uint64_t var_count_base, uint64_t sizes[10], uint64_t counters[8]) {
+    return guarded(r, [&] { return r->cdbg->ploidy_text(var_count_base, sizes, counters); });
+}
+int pfh_ploidy_write(pfh_run *r, const char *outpre, const uint64_t offsets[10], const uint64_t totals[10], int truncate) {
+    return guarded(r, [&] { return r->cdbg->ploidy_write(outpre, offsets, totals, truncate != 0); });
+}
 
 void pfh_get_times(const pfh_run *r, pfh_times *o) {
     memset(o, 0, sizeof(*o));
@@ -166,6 +194,45 @@ void pfh_state(const pfh_run *r, uint8_t *flags, uint32_t *plus, uint32_t *minus
     if (flags) memcpy(flags, r->cdbg->state_flags().data(), N);
     if (plus) memcpy(plus, r->cdbg->state_plus().data(), N * 4);
     if (minus) memcpy(minus, r->cdbg->state_minus().data(), N * 4);
+}
+
+// ---- the commit replay on a bare state (no device) ----
+}  // extern "C"
+struct pfh_replay {
+    pfh::UnitigState st;
+    uint32_t last = 0;
+    bool any = false;
+};
+extern "C" {
+pfh_replay *pfh_replay_open(uint32_t n_unitigs, uint32_t complex_size) {
+    try {
+        auto h = std::make_unique<pfh_replay>();
+        h->st.reset(n_unitigs);
+        h->st.complex_size = complex_size;
+        return h.release();
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return nullptr;
+    }
+}
+void pfh_replay_close(pfh_replay *h) { delete h; }
+int pfh_replay_apply(pfh_replay *h, const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool) {
+    if (!h || (n_records && (!records || !pool))) return 1;
+    for (uint64_t i = 0; i < n_records; ++i) {
+        const pf_bfs_record &r = records[i];
+        if ((r.entrance >> 1) >= h->st.flags.size() || (h->any && r.entrance < h->last)) return 2;  // shards must arrive in order
+        h->last = r.entrance;
+        h->any = true;
+        if (!h->st.gate_open(r.entrance)) continue;
+        h->st.replay(r, pool + r.list_off);
+    }
+    return 0;
+}
+void pfh_replay_state(const pfh_replay *h, uint8_t *flags, uint32_t *plus, uint32_t *minus) {
+    const size_t N = h->st.flags.size();
+    if (flags) memcpy(flags, h->st.flags.data(), N);
+    if (plus) memcpy(plus, h->st.plus.data(), N * 4);
+    if (minus) memcpy(minus, h->st.minus.data(), N * 4);
 }
 
 // ---- colour sets (host only) ---------------------------------------------------------------------
@@ -237,6 +304,37 @@ int pfh_host_walk(const uint32_t *succ, const uint32_t *pred, uint32_t n_unitigs
     } catch (const std::exception &e) {
         g_open_err = std::string("ploidyfrost host layer: ") + e.what();
         return 1;
+    }
+}
+uint64_t pfh_host_walk_range(const uint32_t *succ, const uint32_t *pred, uint32_t n_unitigs, uint32_t u0, uint32_t u1,
+                             pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool, uint64_t pool_cap, uint64_t *pool_used) {
+    if (!succ || !pred || u0 > u1 || u1 > n_unitigs) return ~0ull;
+    try {
+        pfh::HugeWalker walker;
+        uint64_t n = 0, used = 0;
+        bool fits = true;
+        for (uint32_t ov = 2 * u0; ov < 2 * u1; ++ov) {
+            int deg = 0;
+            for (int b = 0; b < 4; ++b) deg += succ[(size_t)ov * 4 + b] != 0xFFFFFFFFu;
+            if (deg < 2) continue;
+            pf_bfs_record r;
+            memset(&r, 0, sizeof(r));
+            const std::vector<uint32_t> &l = walker.walk(succ, pred, n_unitigs, ov, r);
+            r.list_off = used;
+            if (n < rec_cap && used + r.n_list <= pool_cap && records && pool) {
+                records[n] = r;
+                std::copy(l.begin(), l.begin() + r.n_list, pool + used);
+            } else {
+                fits = false;
+            }
+            ++n;
+            used += r.n_list;
+        }
+        if (pool_used) *pool_used = used;
+        return fits ? n : ~0ull;
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return ~0ull;
     }
 }
 uint64_t pfh_gfa_minimizer_counts(const char *gfa_path, uint8_t *counters, uint64_t slots) {

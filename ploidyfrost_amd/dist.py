@@ -1,8 +1,17 @@
-"""Multi-GPU plumbing: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on ROCm;
-"gloo" in the CPU tests).  The hot path itself needs no data-path collective -- ranks own disjoint
-unitig partitions -- so the only exchange is at the end of a pass: every rank contributes its site
-counters and its ordered record slab (the text of <prefix>_allele_frequency.txt), and the
-reference-order result is their rank-order concatenation.
+"""Multi-GPU plumbing: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI on ROCm; "gloo" in the CPU tests).
+
+One graph, replicated in every GPU's HBM, is cut over the ranks by entrance vertex:
+
+  findSuperBubble    rank r traverses the candidate entrances on its contiguous unitig range (K-BFS); the traversal records and
+                     their vertex lists are all-gathered (sizes, then max-padded payloads); every rank replays all records in
+                     entrance order -- the commit replay is sequential by construction and cheap -- so all ranks hold the
+                     same MyUnitig state.  Rank 0 writes super_bubble.txt.
+  PloidyEstimation   the owner scan and the sequential pass run on every rank and give the same bubble list in output order;
+                     rank r aligns its contiguous slice.  Two small all-gathers follow: how many bubbles each rank called
+                     (var_count numbers bubbles across the whole run, src/CDBG.cpp:1254-1258), then the byte sizes of each
+                     rank's ten text slabs together with its allele histograms and coverage counters.  With the sizes every
+                     rank knows its offsets and writes its slabs straight into the shared result files: rank-order concatenation
+                     is the reference's `-t 1` output, and no payload crosses ranks.
 """
 from __future__ import annotations
 
@@ -73,3 +82,47 @@ def all_gather_slabs(slab: np.ndarray, device: torch.device) -> list[np.ndarray]
     out = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
     return [o[: int(n)].cpu().numpy() for o, n in zip(out, sizes)]
+
+
+def broadcast_str(text: str | None, src: int = 0) -> str:
+    """A path (e.g. rank 0's output directory) to every rank."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return text
+    box = [text]
+    dist.broadcast_object_list(box, src=src)
+    return box[0]
+
+
+def sharded_find(run, outpre: str, device: torch.device, stats: dict | None = None) -> None:
+    """findSuperBubble of one graph over all ranks (see module docstring); `run` = hostapi.Run of the same graph on every rank."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    n = run.times()["unitigs"]
+    u0, u1 = shard_range(n, rank, world)
+    rec, pool = run.find_shard(u0, u1)
+    recs = all_gather_slabs(rec.view(np.uint8).reshape(-1), device)
+    pools = all_gather_slabs(pool.view(np.uint8).reshape(-1), device)
+    if stats is not None:
+        stats["find_gathered_bytes"] = int(sum(x.size for x in recs) + sum(x.size for x in pools))
+        stats["shard_unitigs"] = (u0, u1)
+    from . import hipapi
+    run.find_replay(outpre, [np.ascontiguousarray(r).view(hipapi.BFS_RECORD) for r in recs],
+                    [np.ascontiguousarray(p).view(np.uint32) for p in pools], write_file=rank == 0)
+
+
+def sharded_ploidy(run, outpre: str, lower: int, upper: int, device: torch.device, stats: dict | None = None):
+    """PloidyEstimation of one graph over all ranks; all ranks' `run` must share one output directory.
+    Returns (totals of the ten files in bytes, counters summed over ranks: sites with 2..5 alleles, coreCov, coreNum, called, bubbles)."""
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
+    n_bubbles = run.ploidy_select(lower, upper)
+    t0, t1 = shard_range(n_bubbles, rank, world)
+    called = run.ploidy_align(t0, t1)
+    base = int(all_gather_counters([called], device)[:rank, 0].sum())
+    sizes, counters = run.ploidy_text(base)
+    table = all_gather_counters([int(x) for x in sizes] + [int(x) for x in counters], device)
+    offsets = table[:rank, :10].sum(axis=0).astype(np.uint64)
+    totals = table[:, :10].sum(axis=0).astype(np.uint64)
+    run.ploidy_write(outpre, offsets, totals, truncate=True)
+    if stats is not None:
+        stats["slice"] = (t0, t1)
+        stats["n_bubbles"] = n_bubbles
+    return totals, table[:, 10:].sum(axis=0)

