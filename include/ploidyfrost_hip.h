@@ -56,7 +56,7 @@ int pf_synchronize(pf_ctx *);
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
     PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN,
-    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_COUNT_
+    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -256,12 +256,18 @@ int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t 
  * else runs on the device and comes back as text: owner / coverage-gate scan, path enumeration and sorting (strict: sortSeq_simple
  * :482-551; branching: two-stack walk :1364-1412 + sortSeq_branching :417-480), SequenceAlignment, per-site strings and their
  * readCov (:1448-1600, 29-60), and the rows of the ten result files with `ostream << double` formatting (:1259, 1303-1340,
- * 1552-1652).  Call order: pf_call_set_state, pf_call_coverage, pf_call_scan, pf_call_sides, pf_call_select, then pf_call_run /
+ * 1552-1652).  Call order: pf_call_set_state, pf_call_coverage, pf_call_scan, pf_call_resolve (or pf_call_sides + pf_call_select), then pf_call_run /
  * pf_call_fetch per batch.  Single-sample path (CDBG); the colored twin keeps pf_align_bubbles + pf_string_cov_colored. */
 
 /* T1: the MyUnitig state after findSuperBubble (src/MyUnitig.hpp:37-130): b bits; plus / minus partners (0 = NULL, id = u + 1).
  * n_unitigs entries each. [host|dev] */
 int pf_call_set_state(pf_ctx *, const uint8_t *flags, const uint32_t *plus, const uint32_t *minus);
+/* S1, second half: the rows of <outpre>_super_bubble.txt (src/CDBG.cpp:222-252) from that state, formatted on the device: one row
+ * `BubbleId<TAB>Entrance<TAB>Strand<TAB>Exit<TAB>isSimple<TAB>isComplex` per open endpoint side in unitig order, ids from 1 (the
+ * header line is the caller's).  colored_rule = 1: CCDBG's rule -- an open unitig lists every side whose partner is set, self
+ * included (src/CCDBG.cpp:2106-2132).  pf_superbubble_fetch copies the text out on a stream of its own (any thread). */
+int pf_superbubble_rows(pf_ctx *, int colored_rule, uint64_t *n_rows, uint64_t *text_len);
+int pf_superbubble_fetch(pf_ctx *, char *dst, uint64_t len);
 /* C1 for every unitig into device-resident arrays the scan reads (pf_unitig_cov / pf_unitig_cov_exact without the copy back; a
  * missing k-mer is reported by the scan only where the driver loop reads that unitig's coverage). */
 int pf_call_coverage(pf_ctx *);
@@ -278,7 +284,12 @@ typedef struct pf_call_side { /* one open endpoint side, in the driver loop's or
 /* part A of the driver loop for every open side, from static state only; *n_sides = number of records */
 int pf_call_scan(pf_ctx *, uint32_t lower, uint32_t upper, uint64_t *n_sides);
 int pf_call_sides(pf_ctx *, pf_call_side *out, uint64_t cap); /* [host|dev] */
-/* part B's verdict: the records (indices into the scan's output, ascending) whose bubble is called, in output order [host|dev] */
+/* part B of the driver loop on the device, exactly: which sides are still open when their unitig comes up (a handled owner closes
+ * the side its exit faces, :1656-1679) is a recursion over smaller indices, settled by rounds of a monotone propagation instead of
+ * a walk over the sides.  Leaves the selection (the called bubbles, in output order) in the context.  *err = 1 / 2 with *err_unitig
+ * when the first open side in order carries a missing k-mer / an unreachable exit: the reference exits there. */
+int pf_call_resolve(pf_ctx *, uint64_t *n_bubbles, uint32_t *err, uint32_t *err_unitig);
+/* the same verdict from the caller (it walked pf_call_sides' records itself): the records, ascending, whose bubble is called [host|dev] */
 int pf_call_select(pf_ctx *, const uint32_t *side_index, uint64_t n_bubbles);
 
 #define PF_CALL_STREAMS 10

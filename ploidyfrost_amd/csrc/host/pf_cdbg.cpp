@@ -103,7 +103,6 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
 int CDBG::join_pending_write() {
     if (pending_write_.joinable()) {
         pending_write_.join();
-        std::vector<std::string>().swap(pending_pieces_);
         if (pending_rc_) { pending_rc_ = 0; return fail(PF_ERR_ARG, "CDBG:: Open super_bubble file error"); }
     }
     return 0;
@@ -114,6 +113,7 @@ CDBG::~CDBG() {
     bx_.release_all();  // pinned buffers go before the context
     for (auto &a : ax_) a.release_all();
     cx_.release_all();
+    sb_text_.release();
     pf_destroy(ctx_);
 }
 

@@ -138,7 +138,6 @@ protected:
     std::string cov_err_;
     bool overlap_output_ = false;
     std::thread pending_write_;
-    std::vector<std::string> pending_pieces_;
     int pending_rc_ = 0;
     int ensure_dir();
     int write_file(const std::string &name, const std::string &data);
@@ -208,6 +207,8 @@ protected:
         void release_all() { sides.release(); kept.release(); slab[0].release(); slab[1].release(); }
     } cx_;
     bool resident_ = true;
+    bool state_on_device_ = false;   // pf_call_set_state holds the state findSuperBubble left (finish_find uploads it)
+    PinnedBuf<char> sb_text_;        // text of super_bubble.txt on its way from the device to the file
     PhaseTimes times_;
     std::string last_allfre_;
     uint64_t allele_[4] = {0, 0, 0, 0};

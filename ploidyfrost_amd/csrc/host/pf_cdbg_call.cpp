@@ -38,36 +38,50 @@ int CDBG::call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &
     if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + cov_err_);
     times_.cov_device_s = since(t0);
     t0 = clk::now();
-    st = pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    if (!state_on_device_) st = pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    state_on_device_ = false;   // (one PloidyEstimation per findSuperBubble, as in the reference's main(); a second one uploads again)
     uint64_t n_sides = 0;
     if (st == PF_OK) st = pf_call_scan(ctx_, low, up, &n_sides);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): scan: " + pf_last_error(ctx_));
+    uint64_t nk = 0;
+    static const bool host_pass = [] { const char *e = getenv("PF_SCAN"); return e && !strcmp(e, "host"); }();
+    if (!host_pass) {
+        // part B on the device (pf_call_resolve): no side record leaves the GPU
+        const auto t_serial = clk::now();
+        uint32_t err = 0, err_unitig = 0;
+        st = pf_call_resolve(ctx_, &nk, &err, &err_unitig);
+        if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): scan: " + pf_last_error(ctx_));
+        if (err == 1) return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of unitig " + std::to_string(err_unitig + 1) + " can not found .");
+        if (err == 2) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): exit of a bubble is not reachable");
+        times_.scan_serial_s = since(t_serial);
+    } else {
     cx_.sides.ensure(ctx_, std::max<uint64_t>(n_sides, 1));
     cx_.kept.ensure(ctx_, std::max<uint64_t>(n_sides, 1));
     st = pf_call_sides(ctx_, cx_.sides.p, cx_.sides.cap);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): scan: " + pf_last_error(ctx_));
-    // the driver loop itself: sequential, a few nanoseconds per side
+    // the driver loop itself, walked on the host (PF_SCAN=host: the independent check of pf_call_resolve)
     const auto t_serial = clk::now();
     const pf_call_side *sides = cx_.sides.p;
     uint32_t *kept = cx_.kept.p;
-    uint64_t nk = 0;
+    std::vector<uint8_t> fl(flags_);
     for (uint64_t ri = 0; ri < n_sides; ++ri) {
         const pf_call_side &r = sides[ri];
         const uint32_t u = r.u;
         const uint8_t own = r.plus_side ? B_PLUS : B_MINUS;
-        if (!(flags_[u] & own)) continue;
-        if (r.kind == 1) { flags_[u] &= (uint8_t)~own; continue; }
+        if (!(fl[u] & own)) continue;
+        if (r.kind == 1) { fl[u] &= (uint8_t)~own; continue; }
         if (r.err == 1)
             return fail(PF_ERR_MISSING_KMER, "CDBG::readCov(): a kmer of unitig " + std::to_string(r.err_unitig + 1) + " can not found .");
         if (r.err == 2) return fail(PF_ERR_ARG, "CDBG::PloidyEstimation(): exit of a bubble is not reachable");
-        flags_[u] &= (uint8_t)~own;
+        fl[u] &= (uint8_t)~own;
         if (r.kind == 2) continue;
         if (r.aligned) kept[nk++] = (uint32_t)ri;
-        flags_[r.exit_ov >> 1] &= (uint8_t) ~(plus_of(r.exit_ov) ? B_MINUS : B_PLUS);
+        fl[r.exit_ov >> 1] &= (uint8_t) ~(plus_of(r.exit_ov) ? B_MINUS : B_PLUS);
     }
     times_.scan_serial_s = since(t_serial);
     st = pf_call_select(ctx_, kept, nk);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+    }
     times_.scan_s = since(t0);
     n_tasks = nk;
     return 0;
@@ -142,7 +156,7 @@ int CDBG::ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL
             return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + kStreamSuffix[s] + " file error");
         }
     }
-    constexpr uint64_t PIECE = 4u << 20;
+    constexpr uint64_t PIECE = 1u << 20;
     struct Piece { int s; uint64_t at, len; };
     std::vector<Piece> pieces;
     for (int s = 0; s < PF_CALL_STREAMS; ++s)
@@ -266,7 +280,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             if (st != PF_OK) return;
             if (trace) fprintf(stderr, "[ploidy]   batch %zu fetched (%.1f MB) %.2f ms\n", b, total / 1e6, since(t_all) * 1e3);
             // append: every stream at its running offset, the large ones cut into pieces written side by side
-            constexpr uint64_t PIECE = 4u << 20;
+            constexpr uint64_t PIECE = 1u << 20;
             struct Piece { int s; uint64_t at, len; };
             std::vector<Piece> pieces;
             for (int s = 0; s < PF_CALL_STREAMS; ++s)

@@ -32,6 +32,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     const uint32_t N = g_.n();
     if (!quiet_) printf("%s::findSuperBubble(): There are %u unitigs \n", tag_, N);
     out_bytes_ = 0;
+    state_on_device_ = false;
     std::fill(flags_.begin(), flags_.end(), 0);
     std::fill(plus_.begin(), plus_.end(), 0);
     std::fill(minus_.begin(), minus_.end(), 0);
@@ -209,71 +210,56 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
 
 // second half of findSuperBubble (reference src/CDBG.cpp:222-252): the rows of <outpre>_super_bubble.txt from the final state
 int CDBG::finish_find(const std::string &outpre, const size_t &thr, clk_time t_all, bool write_file) {
-    const uint32_t N = g_.n();
+    (void)thr;
     const bool trace_find = getenv("PF_TRACE_FIND") != nullptr;
     auto tf = [&](const char *what) { if (trace_find) fprintf(stderr, "[find] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
     auto t0 = clk::now();
-    // super_bubble.txt: one row per open endpoint side in unitig order; rows are numbered with a prefix
-    // count so that unitig ranges can be formatted in parallel
-    const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
-    constexpr size_t UCH = 16384;
-    const size_t n_uch = n_chunks_of(N, UCH);
-    std::vector<uint64_t> row_base(n_uch + 1, 0);
-    parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
-        uint64_t c = 0;
-        if (col_) {  // src/CCDBG.cpp:2106-2132: an open unitig lists every side whose partner pointer is set, self included
-            for (size_t u = ub; u < ue; ++u)
-                if (flags_[u] & 3) c += (plus_[u] != 0) + (minus_[u] != 0);
-        } else {
-            for (size_t u = ub; u < ue; ++u) c += (flags_[u] & B_PLUS ? 1 : 0) + (flags_[u] & B_MINUS ? 1 : 0);
-        }
-        row_base[ci + 1] = c;
-    });
-    for (size_t c = 0; c < n_uch; ++c) row_base[c + 1] += row_base[c];
-    std::vector<std::string> pieces(n_uch + 1);
-    pieces[0] = "BubbleId\tEntrance\tStrand\tExit\tisSimple\tisComplex\n";
-    parallel_chunks(N, UCH, T, [&](size_t ci, size_t ub, size_t ue) {
-        std::string &out = pieces[ci + 1];
-        uint64_t nb = row_base[ci];
-        for (uint32_t u = (uint32_t)ub; u < (uint32_t)ue; ++u) {
-            const uint8_t f = flags_[u];
-            if ((f & 3) == 0) continue;
-            for (int side = 0; side < 2; ++side) {
-                const bool ps = side == 0;
-                if (col_ ? (ps ? plus_[u] : minus_[u]) == 0 : !(f & (ps ? B_PLUS : B_MINUS))) continue;
-                put_uint(out, ++nb);
-                out.push_back('\t');
-                put_uint(out, u + 1);
-                out += ps ? "\t+\t" : "\t-\t";
-                put_uint(out, ps ? plus_[u] : minus_[u]);
-                out += (f & (ps ? B_STRICT_P : B_STRICT_M)) ? "\t1" : "\t0";
-                out += (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? "\t1\n" : "\t0\n";
-            }
-        }
-    });
-    const uint64_t nb = row_base[n_uch];
+    // The state goes to the device once -- PloidyEstimation's scan reads it there as well -- and the rows of super_bubble.txt
+    // (one per open endpoint side in unitig order, numbered by a prefix count) are formatted there; the text comes back and is
+    // written by a helper thread, behind the caller's back when overlap_output is on.
+    int st = pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    uint64_t nb = 0, len = 0;
+    if (st == PF_OK) st = pf_superbubble_rows(ctx_, col_ != nullptr ? 1 : 0, &nb, &len);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::findSuperBubble(): " + pf_last_error(ctx_));
+    state_on_device_ = true;
+    tf("super_bubble rows on the device");
+    static const char kHeader[] = "BubbleId\tEntrance\tStrand\tExit\tisSimple\tisComplex\n";
     n_super_bubble_ = nb;
     times_.bubbles_out = nb;
-    if (!write_file) {
-        for (const std::string &pc : pieces) out_bytes_ += pc.size();
-    } else if (overlap_output_ && write_files_) {
-        // written behind the caller's back while PloidyEstimation starts; joined there (or by the next use of the file)
+    out_bytes_ += len + (sizeof(kHeader) - 1);
+    if (write_file && write_files_) {
         join_pending_write();
-        pending_pieces_ = std::move(pieces);
-        uint64_t bytes = 0;
-        for (const std::string &pc : pending_pieces_) bytes += pc.size();
-        out_bytes_ += bytes;
-        pending_write_ = std::thread([this, name = outpre + "_super_bubble.txt"] {
-            std::vector<const std::string *> ptrs;
-            for (const std::string &pc : pending_pieces_) ptrs.push_back(&pc);
-            uint64_t b = 0;
-            pending_rc_ = write_pieces(name, ptrs, b);
-        });
-    } else {
-        std::vector<std::pair<std::string, std::vector<const std::string *>>> files(1);
-        files[0].first = outpre + "_super_bubble.txt";
-        for (auto &pc : pieces) files[0].second.push_back(&pc);
-        if (write_many(files, T)) return status_;
+        sb_text_.ensure(ctx_, std::max<uint64_t>(len, 1));
+        const unsigned T = threads_ ? threads_ : 1;
+        auto job = [this, name = outpre + "_super_bubble.txt", len, T]() -> int {
+            if (pf_superbubble_fetch(ctx_, sb_text_.p, len) != PF_OK) return 1;
+            const int fd = open((outdir_ + "/" + name).c_str(), O_WRONLY | O_CREAT, 0666);
+            if (fd < 0) return 1;
+            const uint64_t hl = sizeof(kHeader) - 1;
+            int rc = pwrite(fd, kHeader, hl, 0) == (ssize_t)hl ? 0 : 1;
+            constexpr uint64_t PIECE = 2u << 20;
+            const size_t n_pieces = (size_t)((len + PIECE - 1) / PIECE);
+            std::vector<int> prc(n_pieces, 0);
+            parallel_chunks(n_pieces, 1, T, [&](size_t i, size_t, size_t) {
+                uint64_t at = (uint64_t)i * PIECE, left = std::min<uint64_t>(PIECE, len - at);
+                while (left) {
+                    const ssize_t w = pwrite(fd, sb_text_.p + at, left, (off_t)(hl + at));
+                    if (w <= 0) { prc[i] = 1; return; }
+                    left -= (uint64_t)w;
+                    at += (uint64_t)w;
+                }
+            });
+            for (int x : prc) rc |= x;
+            if (ftruncate(fd, (off_t)(hl + len)) != 0) rc = 1;
+            close(fd);
+            return rc;
+        };
+        if (overlap_output_) {
+            // written behind the caller's back while PloidyEstimation starts; joined there (or by the next use of the file)
+            pending_write_ = std::thread([this, job] { pending_rc_ = job(); });
+        } else if (job()) {
+            return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + "_super_bubble.txt file error");
+        }
     }
     times_.bubble_write_s = since(t0);
     times_.find_total_s = since(t_all);
@@ -345,6 +331,7 @@ int CDBG::find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs
     if (write_file && write_files_ && ensure_dir()) return status_;
     const auto t_all = clk::now();
     out_bytes_ = 0;
+    state_on_device_ = false;
     std::fill(flags_.begin(), flags_.end(), 0);
     std::fill(plus_.begin(), plus_.end(), 0);
     std::fill(minus_.begin(), minus_.end(), 0);

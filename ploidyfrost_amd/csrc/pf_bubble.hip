@@ -732,12 +732,15 @@ namespace pf {
 // queues back to back (class c: n_cls[c] task indices, heavy ones first); results / pools are device memory.
 // Leaves the pool heads in heads[4]; returns PF_ERR_OVERFLOW when a bubble exceeds the largest scratch tier
 // (its result then carries n_rows = 0xFFFFFFFF).
+unsigned long long *bubble_pool_heads(pf_ctx *ctx) { return (unsigned long long *)ctx_ws(ctx, WS_BUB_SMALL, 128); }
+
 int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]) {
     hipStream_t st = ctx->stream;
     uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 128);  // pool heads, retry count, one queue head per launch
     uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_BUB_RETRY, (size_t)std::max<uint32_t>(L.n_tasks, 1) * 4);
     if (!small || !d_retry) return PF_ERR_HIP;
-    PF_HIP(hipMemsetAsync(small, 0, 128, st));
+    if (L.keep_heads) PF_HIP(hipMemsetAsync(small + 32, 0, 96, st));
+    else PF_HIP(hipMemsetAsync(small, 0, 128, st));
     BubOut o;
     o.res = L.res; o.text = L.otext; o.sites = L.osites; o.groups = L.ogroups; o.ilen = L.oilen;
     o.text_cap = L.text_cap; o.site_cap = L.site_cap; o.group_cap = L.group_cap; o.ilen_cap = L.ilen_cap;
@@ -860,6 +863,22 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         for (auto c : srt) tot += c;
         fprintf(stderr, "[pf_align_bubbles] %u tasks: ticks(10ns) sum %llu  median %llu  p90 %llu  p99 %llu  p99.9 %llu  max %llu\n", n_tasks, tot,
                 srt[n_tasks / 2], srt[(size_t)(n_tasks * 0.9)], srt[(size_t)(n_tasks * 0.99)], srt[(size_t)(n_tasks * 0.999)], srt[n_tasks - 1]);
+        unsigned long long over[4] = {0, 0, 0, 0};
+        for (auto c : srt) { over[0] += c > 10000; over[1] += c > 30000; over[2] += c > 100000; if (c > 30000) over[3] += c; }
+        fprintf(stderr, "   tasks over 0.1 ms: %llu, over 0.3 ms: %llu (their sum %llu ticks), over 1 ms: %llu\n", over[0], over[1], over[3], over[2]);
+        for (int top = 0; top < 8 && top < (int)n_tasks; ++top) {
+            const uint32_t t = (uint32_t)(std::max_element(clk.begin(), clk.end()) - clk.begin());
+            pf_bubble_task tk;
+            PF_HIP(hipMemcpy(&tk, L.tasks + t, sizeof(tk), hipMemcpyDeviceToHost));
+            std::vector<pf_bubble_path> pp(std::min<uint32_t>(tk.n_paths, 12));
+            if (!pp.empty()) PF_HIP(hipMemcpy(pp.data(), L.paths + tk.path_first, pp.size() * sizeof(pf_bubble_path), hipMemcpyDeviceToHost));
+            pf_bubble_result rr;
+            PF_HIP(hipMemcpy(&rr, L.res + t, sizeof(rr), hipMemcpyDeviceToHost));
+            fprintf(stderr, "   slowest: task %u ticks %llu paths %u -> rows %u cols %u sites %u; lens", t, clk[t], tk.n_paths, rr.n_rows, rr.n_cols, rr.n_sites);
+            for (auto &x : pp) fprintf(stderr, " %u", x.len);
+            fprintf(stderr, "\n");
+            clk[t] = 0;
+        }
     }
     PF_HIP(hipMemcpy(heads, o.heads, 32, hipMemcpyDeviceToHost));
     if (status == PF_OK && (heads[0] > L.text_cap || heads[1] > L.site_cap || heads[2] > L.group_cap || heads[3] > L.ilen_cap)) {

@@ -43,7 +43,21 @@ struct BubbleLaunch {
     uint8_t *ogroups = nullptr;
     uint32_t *oilen = nullptr;
     uint64_t text_cap = 0, site_cap = 0, group_cap = 0, ilen_cap = 0;
+    // the pool heads (bubble_pool_heads) already hold what an earlier kernel of the caller took from the pools: do not reset them
+    bool keep_heads = false;
 };
+
+// device address of the four pool heads {text bytes, sites, group bytes, ilen entries} that K-BUBBLE bumps (first 32 bytes of a
+// 128-byte block the launch otherwise zeroes): a caller that publishes some bubbles itself allocates from the same heads
+unsigned long long *bubble_pool_heads(pf_ctx *ctx);
+
+// The single-SNP shortcut of K-BUBBLE as a predicate on the scores (proof in pf_bubble.hip): two equally long paths that differ
+// in exactly one base align as themselves, one SNP column, groups {1, 2}, whenever this holds.
+inline bool snp_shortcut_scores(double M, double D, double G) {
+    if (!(M < 1e6 && M > -1e6 && D < 1e6 && D > -1e6 && G < 1e6 && G > -1e6)) return false;
+    const bool integral = M == (double)(long long)M && D == (double)(long long)D && G == (double)(long long)G;
+    return integral && M >= D && M + 1 >= 2 * (G + 1) && D - 2 * G - 2 > 0;
+}
 
 int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]);
 

@@ -82,6 +82,7 @@ struct DevBuf {
 struct CallCounters {
     unsigned int q_n[8];            // work queues: class c heavy = q_n[2c], light = q_n[2c + 1]
     unsigned int n_branching;
+    unsigned int n_snp, n_snp_done;        // two-path bubbles of equal length: candidates for / takers of the single-SNP shortcut
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
@@ -102,14 +103,17 @@ struct CallState {
     DevBuf cov_sum, cov_min, cov_miss;
     bool have_cov = false, per_strand = false;
     // scan
-    DevBuf side_cnt, side_base, sides, ctask, scan_tmp;
+    DevBuf side_cnt, side_base, sides, ctask, scan_tmp, target, pending, killed, rstate, rflag, rsmall;
     uint64_t n_sides = 0;
     uint32_t low = 0, up = 0;
     // selection
     DevBuf kept;
+    // super_bubble.txt rows
+    DevBuf sb_cnt, sb_base, sb_sizes, sb_offs, sb_out;
+    uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
     // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, res, otext, osites, ogroups, oilen, sv_off, sv, has, vc, sizes, offs, totals,
+    DevBuf counters, btask, bpath, ptext, queues, blist, slist, res, otext, osites, ogroups, oilen, sv_off, sv, has, vc, sizes, offs, totals,
         scan_tmp2, paths_scr, sites_scr;
     uint64_t path_pool = 0, text_pool = 0, sv_pool = 0;   // capacities learnt from earlier batches
     uint64_t otext_cap = 0, osites_cap = 0, ogroups_cap = 0, oilen_cap = 0;
@@ -122,8 +126,8 @@ struct CallState {
     uint32_t cur_nb = 0;
     pf_call_result cur = {};
     void release_all() {
-        DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &kept, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &res, &otext, &osites, &ogroups, &oilen, &sv_off, &sv, &has, &vc, &sizes, &offs,
+        DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
+                         &btask, &bpath, &ptext, &queues, &blist, &slist, &res, &otext, &osites, &ogroups, &oilen, &sv_off, &sv, &has, &vc, &sizes, &offs,
                          &totals, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
         for (auto &s : out)
@@ -175,6 +179,7 @@ struct ScanArgs {
     const uint32_t *side_base;  // exclusive scan of the per-unitig side counts
     pf_call_side *sides;
     CallTask *tasks;
+    uint32_t *target;           // per side: the record of the side the bubble's exit faces (closed when this side is handled), or NONE
 };
 
 __global__ void k_call_count_sides(const uint8_t *__restrict__ flags, uint32_t N, uint32_t *__restrict__ cnt) {
@@ -276,6 +281,62 @@ __global__ __launch_bounds__(256) void k_call_sides(ScanArgs a) {
         } while (false);
         a.sides[my] = r;
         a.tasks[my] = t;
+        // handling this side as the owner clears the facing side of the exit (src/CDBG.cpp:1656-1679): which record is that?
+        uint32_t tg = NONE;
+        if (r.kind == 3) {
+            const uint32_t eu = r.exit_ov >> 1;
+            const uint8_t ef = a.flags[eu];
+            const bool facing_minus = (r.exit_ov & 1) == 0;   // '+' exit: its minus side faces the bubble
+            if (ef & (facing_minus ? B_MINUS : B_PLUS)) tg = a.side_base[eu] + ((facing_minus && (ef & B_PLUS)) ? 1u : 0u);
+        }
+        a.target[my] = tg;
+    }
+}
+
+// ---- part B of the driver loop, exactly, without walking the sides one after the other ------------------------------------
+// Sequentially (src/CDBG.cpp:1146-1186, 1656-1679): a side is handled only if its bit is still set when its unitig comes up, and
+// an owner that is handled clears the side its exit faces.  So side j is alive iff no owner i < j with target(i) = j is alive --
+// a recursion over strictly smaller indices.  Rounds of a monotone propagation settle it: `pending[j]` counts the potential
+// killers of j not yet known to be dead; a side with no pending killer is alive and kills its target, a killed side releases
+// its own target.  Symmetric bubbles settle in two rounds; chains through asymmetric state take one round per link.
+struct ResolveArgs {
+    const pf_call_side *sides;
+    const uint32_t *target;
+    uint32_t n;
+    int *pending;        // potential killers not yet dead
+    uint8_t *killed;     // some killer is alive
+    uint8_t *state;      // 0 undecided, 1 alive, 2 dead
+    uint32_t *flag;      // 1: called (alive owner that passes the gate)
+    unsigned int *undecided;
+    unsigned int *first_err;   // smallest index of an alive side with err != 0
+};
+
+__global__ void k_call_pending(ResolveArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    const uint32_t t = a.target[i];
+    if (a.sides[i].kind == 3 && t != NONE && t > i) atomicAdd(&a.pending[t], 1);
+}
+
+__global__ void k_call_resolve(ResolveArgs a) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= a.n || a.state[j]) return;
+    // (plain loads of values other threads update with atomics in this very launch: a stale value only postpones the decision)
+    const bool dead = __hip_atomic_load(&a.killed[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+    const int pend = __hip_atomic_load(&a.pending[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!dead && pend > 0) { atomicAdd(a.undecided, 1u); return; }
+    const pf_call_side r = a.sides[j];
+    const uint32_t t = a.target[j];
+    const bool kills = r.kind == 3 && t != NONE && t > j;
+    if (dead) {
+        a.state[j] = 2;
+        a.flag[j] = 0;
+        if (kills) atomicSub(&a.pending[t], 1);
+    } else {
+        a.state[j] = 1;
+        if (r.kind != 1 && r.err) atomicMin(a.first_err, j);
+        a.flag[j] = (r.kind == 3 && !r.err && r.aligned) ? 1u : 0u;
+        if (kills) __hip_atomic_store(&a.killed[t], (uint8_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
 
@@ -292,29 +353,33 @@ struct PrepArgs {
     pf_bubble_result *res;
     uint32_t *queues;  // 8 lists of nb entries
     uint32_t *blist;   // branching bubbles (batch-local indices)
+    uint32_t *slist;   // single-SNP candidates
+    int snp_ok;        // the scores allow the single-SNP shortcut
     CallCounters *cnt;
 };
 
-// appends `val` to one of 9 lists chosen by key (0..7 work queues, 8 branching list; 9 = none): one atomic per key and wave
-__device__ inline void wave_append(int key, uint32_t val, uint32_t *queues, uint32_t nb, uint32_t *blist, CallCounters *cnt) {
-    for (int x = 0; x < 9; ++x) {
+// appends `val` to one of 10 lists chosen by key (0..7 work queues, 8 branching list, 9 SNP candidates; 10 = none): one atomic
+// per key and wave
+__device__ inline void wave_append(int key, uint32_t val, uint32_t *queues, uint32_t nb, uint32_t *blist, uint32_t *slist, CallCounters *cnt) {
+    for (int x = 0; x < 10; ++x) {
         const unsigned long long m = __ballot(key == x);
         if (!m) continue;
         const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
-        if (lane_id() == leader) base = atomicAdd(x < 8 ? &cnt->q_n[x] : &cnt->n_branching, (unsigned int)__popcll(m));
+        if (lane_id() == leader) base = atomicAdd(x < 8 ? &cnt->q_n[x] : (x == 8 ? &cnt->n_branching : &cnt->n_snp), (unsigned int)__popcll(m));
         base = __shfl(base, leader, WAVE);
         if (key == x) {
             const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
             if (x < 8) queues[(size_t)x * nb + at] = val;
-            else blist[at] = val;
+            else if (x == 8) blist[at] = val;
+            else slist[at] = val;
         }
     }
 }
 
 __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    int key = 9;
+    int key = 10;
     unsigned long long need3 = 0, retry = 0;
     if (j < a.nb) {
         const CallTask &t = a.ct[a.kept[a.t0 + j]];
@@ -337,13 +402,15 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
                 key = 2 * c + ((t.n_inner > 2 || lmax > 64) ? 0 : 1);
                 if (c == 3) need3 = bubble_need(l0, lmax);
                 retry = job_bytes(sum < 60000u ? sum : 60000u, lmax);
+                // two paths of one length: K-SNP looks at them first (thread per bubble) and hands back what is not a single SNP
+                if (a.snp_ok && t.n_inner == 2 && sum == 2 * l0) key = 9;
             }
         } else {
             a.btask[j] = pf_bubble_task{0, 0, 0};
             key = 8;
         }
     }
-    wave_append(key, j, a.queues, a.nb, a.blist, a.cnt);
+    wave_append(key, j, a.queues, a.nb, a.blist, a.slist, a.cnt);
     // class 3 / retry sizing: rare, one atomic per wave that has any
     unsigned long long m3 = need3, mr = retry;
     for (int o = 32; o > 0; o >>= 1) {
@@ -356,6 +423,107 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
         if (m3) atomicMax(&a.cnt->max_need, m3);
         if (mr) atomicMax(&a.cnt->retry_need, mr);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-SNP: the bi-allelic SNP bubble -- two equally long inner unitigs that differ in one base, most of all bubbles -- needs no
+// dynamic programming (the single-SNP shortcut of K-BUBBLE, proof in pf_bubble.hip) and no wavefront either: its cost is a
+// chain of dependent loads (task -> unitig offsets -> 2-bit words), so one THREAD per bubble keeps 64 of them in flight per
+// wavefront instead of one.  The two rows, the SNP column and the groups {1, 2} go to the same pools K-BUBBLE publishes to
+// (one atomic per wavefront and pool); anything that is not exactly one mismatch goes to K-BUBBLE's queue of its size class.
+struct SnpArgs {
+    const CallTask *ct;
+    const uint32_t *kept;
+    uint64_t t0;
+    uint32_t nb;
+    const uint32_t *slist;
+    const uint64_t *seq, *off;
+    const uint32_t *len;
+    pf_bubble_result *res;
+    char *otext;
+    uint64_t text_cap;
+    pf_bubble_site *osites;
+    uint64_t site_cap;
+    uint8_t *ogroups;
+    uint64_t group_cap;
+    unsigned long long *heads;  // K-BUBBLE's pool heads: [0] text, [1] sites, [2] groups
+    uint32_t *queues;
+    CallCounters *cnt;
+};
+
+__global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = lane_id();
+    const uint32_t n = a.cnt->n_snp;
+    const bool active = i < n;
+    uint32_t j = 0, m = 0, ov0 = 0, ov1 = 0, col = 0, diff = 0;
+    if (active) {
+        j = a.slist[i];
+        const CallTask &t = a.ct[a.kept[a.t0 + j]];
+        ov0 = t.inner[0];
+        ov1 = t.inner[1];
+        m = a.len[ov0 >> 1];
+        for (uint32_t c = 0; c < m; ++c)
+            if (oriented_base(a.seq, a.off, a.len, ov0, c) != oriented_base(a.seq, a.off, a.len, ov1, c)) { ++diff; col = c; }
+    }
+    const bool take = active && diff == 1;
+    // pool space: one atomic per wavefront and pool
+    const unsigned long long tm = __ballot(take);
+    unsigned long long t_off = 0, s_off = 0;
+    if (tm) {
+        // exclusive prefix of 2 m over the taking lanes
+        uint32_t mine = take ? 2 * m : 0, incl = mine;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t x = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += x;
+        }
+        const uint32_t total = __shfl(incl, WAVE - 1, WAVE);
+        const uint32_t cnt = (uint32_t)__popcll(tm);
+        unsigned long long tb = 0, sb = 0;
+        if (lane == 0) {
+            tb = atomicAdd(&a.heads[0], (unsigned long long)total);
+            sb = atomicAdd(&a.heads[1], (unsigned long long)cnt);
+            atomicAdd(&a.heads[2], 2ull * cnt);   // groups: two bytes per site, at 2 * (site index)
+            atomicAdd(&a.cnt->n_snp_done, cnt);
+        }
+        tb = ((unsigned long long)__shfl((uint32_t)(tb >> 32), 0, WAVE) << 32) | __shfl((uint32_t)tb, 0, WAVE);
+        sb = ((unsigned long long)__shfl((uint32_t)(sb >> 32), 0, WAVE) << 32) | __shfl((uint32_t)sb, 0, WAVE);
+        t_off = tb + (incl - mine);
+        s_off = sb + (unsigned long long)__popcll(tm & ((1ull << lane) - 1));
+    }
+    if (take) {
+        // K-SNP is the first taker of a batch (heads zeroed before it, K-BUBBLE launched behind it on the stream): the group
+        // head moves two bytes for every site it takes, so its group offset is twice its site offset
+        pf_bubble_result r;
+        r.rows_off = t_off;
+        r.site_off = s_off;
+        r.group_off = 2 * s_off;
+        r.ilen_off = 0;
+        r.n_rows = 2;
+        r.n_cols = m;
+        r.n_sites = 1;
+        r.n_indel_len = 0;
+        a.res[j] = r;
+        if (t_off + 2ull * m <= a.text_cap && s_off + 1 <= a.site_cap && 2 * s_off + 2 <= a.group_cap) {
+            char *o = a.otext + t_off;
+            for (uint32_t c = 0; c < m; ++c) {
+                o[c] = "ACGT"[oriented_base(a.seq, a.off, a.len, ov0, c)];
+                o[m + c] = "ACGT"[oriented_base(a.seq, a.off, a.len, ov1, c)];
+            }
+            a.ogroups[2 * s_off] = 1;
+            a.ogroups[2 * s_off + 1] = 2;
+            pf_bubble_site sr;
+            sr.col = col;
+            sr.is_indel = 0;
+            sr.maxnum = 2;
+            sr.pad_ = 0;
+            a.osites[s_off] = sr;
+        }
+    }
+    // the rest: K-BUBBLE's queue of their size class (two paths: heavy only when longer than 64)
+    int key = 10;
+    if (active && !take) key = 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
+    wave_append(key, j, a.queues, a.nb, nullptr, nullptr, a.cnt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -987,6 +1155,63 @@ __global__ void k_call_totals(const uint64_t *__restrict__ offs, const uint32_t 
     (void)sizes;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// O1, first file: the rows of <outpre>_super_bubble.txt (src/CDBG.cpp:222-252; colored rule src/CCDBG.cpp:2106-2132) from the
+// state on the device: one row per open endpoint side in unitig order, numbered from 1.
+struct SbArgs {
+    const uint8_t *flags;
+    const uint32_t *plus, *minus;
+    uint32_t N;
+    int colored;
+    const uint32_t *row_base;   // exclusive scan of rows per unitig
+    uint32_t *sizes;            // bytes per unitig (N + 1 entries, the last 0)
+    const uint64_t *offs;
+    char *out;
+};
+
+__device__ inline uint32_t sb_rows_of(const SbArgs &a, uint32_t u, bool &p_row, bool &m_row) {
+    const uint8_t f = a.flags[u];
+    p_row = m_row = false;
+    if ((f & 3) == 0) return 0;
+    if (a.colored) { p_row = a.plus[u] != 0; m_row = a.minus[u] != 0; }   // an open unitig lists every side whose partner is set, self included
+    else { p_row = (f & B_PLUS) != 0; m_row = (f & B_MINUS) != 0; }
+    return (uint32_t)p_row + (uint32_t)m_row;
+}
+
+__global__ void k_sb_count(SbArgs a, uint32_t *cnt) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > a.N) return;
+    bool p, m;
+    cnt[u] = u < a.N ? sb_rows_of(a, u, p, m) : 0u;
+}
+
+template <bool W>
+__global__ void k_sb_format(SbArgs a) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > a.N) return;
+    if (u == a.N) { if (!W) a.sizes[u] = 0; return; }
+    bool rows[2];
+    const uint32_t n = sb_rows_of(a, u, rows[0], rows[1]);
+    Row<W> o{W ? a.out + a.offs[u] : nullptr, 0};
+    if (n) {
+        const uint8_t f = a.flags[u];
+        uint64_t nb = a.row_base[u];
+        for (int side = 0; side < 2; ++side) {
+            if (!rows[side]) continue;
+            const bool ps = side == 0;
+            put_uint(o, ++nb);
+            o.put('\t');
+            put_uint(o, (uint64_t)u + 1);
+            o.put('\t'); o.put(ps ? '+' : '-'); o.put('\t');
+            put_uint(o, ps ? a.plus[u] : a.minus[u]);
+            o.put('\t'); o.put((f & (ps ? B_STRICT_P : B_STRICT_M)) ? '1' : '0');
+            o.put('\t'); o.put((f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? '1' : '0');
+            o.put('\n');
+        }
+    }
+    if (!W) a.sizes[u] = o.n;
+}
+
 struct Widen {
     __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; }
 };
@@ -1039,6 +1264,62 @@ int pf_call_set_state(pf_ctx *ctx, const uint8_t *flags, const uint32_t *plus, c
     return PF_OK;
 }
 
+int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_t *text_len) {
+    if (!ctx || !n_rows || !text_len) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (!S || !S->have_state) { ctx->err = "pf_superbubble_rows: pf_call_set_state first"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t N = ctx->N;
+    const size_t n1 = (size_t)N + 1;
+    if (!S->sb_cnt.ensure(n1 * 4) || !S->sb_base.ensure(n1 * 4) || !S->sb_sizes.ensure(n1 * 4) || !S->sb_offs.ensure(n1 * 8)) {
+        ctx->err = "pf_superbubble_rows: out of device memory";
+        return PF_ERR_HIP;
+    }
+    SbArgs a;
+    a.flags = S->flags.as<uint8_t>(); a.plus = S->plus.as<uint32_t>(); a.minus = S->minus.as<uint32_t>(); a.N = N; a.colored = colored_rule;
+    a.row_base = S->sb_base.as<uint32_t>(); a.sizes = S->sb_sizes.as<uint32_t>(); a.offs = S->sb_offs.as<uint64_t>(); a.out = nullptr;
+    const unsigned grid = (unsigned)((n1 + 255) / 256);
+    k_sb_count<<<grid, 256, 0, st>>>(a, S->sb_cnt.as<uint32_t>());
+    size_t t1 = 0, t2 = 0;
+    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sb_sizes.as<uint32_t>(), Widen());
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, S->sb_cnt.as<uint32_t>(), S->sb_base.as<uint32_t>(), (int)n1, st));
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, wide, S->sb_offs.as<uint64_t>(), (int)n1, st));
+    if (!S->scan_tmp.ensure(std::max(t1, t2))) { ctx->err = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, t1, S->sb_cnt.as<uint32_t>(), S->sb_base.as<uint32_t>(), (int)n1, st));
+    ctx_begin(ctx, PF_K_CALL_FORMAT);
+    k_sb_format<false><<<grid, 256, 0, st>>>(a);
+    ctx_end(ctx);
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, t2, wide, S->sb_offs.as<uint64_t>(), (int)n1, st));
+    uint32_t rows = 0;
+    uint64_t len = 0;
+    PF_HIP(hipMemcpyAsync(&rows, S->sb_base.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&len, S->sb_offs.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    if (!S->sb_out.ensure(std::max<uint64_t>(len, 16))) { ctx->err = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
+    a.out = S->sb_out.as<char>();
+    ctx_begin(ctx, PF_K_CALL_FORMAT);
+    k_sb_format<true><<<grid, 256, 0, st>>>(a);
+    ctx_end(ctx);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(st));
+    S->sb_len = len;
+    *n_rows = rows;
+    *text_len = len;
+    return PF_OK;
+}
+
+int pf_superbubble_fetch(pf_ctx *ctx, char *dst, uint64_t len) {
+    if (!ctx || !ctx->call || (len && !dst)) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (len > S->sb_len) return PF_ERR_ARG;
+    if (len == 0) return PF_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess || !S->copy_stream) return PF_ERR_HIP;
+    if (hipMemcpyAsync(dst, S->sb_out.p, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    return PF_OK;
+}
+
 int pf_call_coverage(pf_ctx *ctx) {
     if (!ctx || !ctx->d_seq || !ctx->d_tab) { if (ctx) ctx->err = "pf_call_coverage: graph and count table first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
@@ -1085,7 +1366,8 @@ int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides)
     S->up = upper;
     *n_sides = total;
     if (total == 0) return PF_OK;
-    if (!S->sides.ensure((size_t)total * sizeof(pf_call_side)) || !S->ctask.ensure((size_t)total * sizeof(CallTask))) {
+    if (!S->sides.ensure((size_t)total * sizeof(pf_call_side)) || !S->ctask.ensure((size_t)total * sizeof(CallTask)) ||
+        !S->target.ensure((size_t)total * 4)) {
         ctx->err = "pf_call_scan: out of device memory";
         return PF_ERR_HIP;
     }
@@ -1095,10 +1377,70 @@ int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides)
     a.cov_sum = S->cov_sum.as<uint64_t>(); a.cov_min = S->cov_min.as<uint32_t>(); a.cov_miss = S->cov_miss.as<uint8_t>();
     a.per_strand = S->per_strand; a.low = lower; a.up = upper;
     a.side_base = S->side_base.as<uint32_t>(); a.sides = S->sides.as<pf_call_side>(); a.tasks = S->ctask.as<CallTask>();
+    a.target = S->target.as<uint32_t>();
     ctx_begin(ctx, PF_K_CALL_SCAN);
     k_call_sides<<<(N + 255) / 256, 256, 0, st>>>(a);
     ctx_end(ctx);
     PF_HIP(hipGetLastError());
+    return PF_OK;
+}
+
+int pf_call_resolve(pf_ctx *ctx, uint64_t *n_bubbles, uint32_t *err, uint32_t *err_unitig) {
+    if (!ctx || !ctx->call || !n_bubbles || !err || !err_unitig) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    *n_bubbles = 0;
+    *err = 0;
+    *err_unitig = 0;
+    S->n_tasks = 0;
+    const uint64_t n = S->n_sides;
+    if (n == 0) return PF_OK;
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    if (!S->pending.ensure(n * 4) || !S->killed.ensure(n) || !S->rstate.ensure(n) || !S->rflag.ensure(n * 4) || !S->rsmall.ensure(64) ||
+        !S->kept.ensure(n * 4)) {
+        ctx->err = "pf_call_resolve: out of device memory";
+        return PF_ERR_HIP;
+    }
+    PF_HIP(hipMemsetAsync(S->pending.p, 0, n * 4, st));
+    PF_HIP(hipMemsetAsync(S->killed.p, 0, n, st));
+    PF_HIP(hipMemsetAsync(S->rstate.p, 0, n, st));
+    unsigned int *small = S->rsmall.as<unsigned int>();   // [0] undecided, [1] first_err, [2] n selected
+    ResolveArgs a;
+    a.sides = S->sides.as<pf_call_side>(); a.target = S->target.as<uint32_t>(); a.n = (uint32_t)n; a.pending = S->pending.as<int>();
+    a.killed = S->killed.as<uint8_t>(); a.state = S->rstate.as<uint8_t>(); a.flag = S->rflag.as<uint32_t>();
+    a.undecided = small; a.first_err = small + 1;
+    const unsigned int init[3] = {0, 0xFFFFFFFFu, 0};
+    PF_HIP(hipMemcpyAsync(small, init, 12, hipMemcpyHostToDevice, st));
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    k_call_pending<<<grid, 256, 0, st>>>(a);
+    for (uint64_t round = 0;; ++round) {
+        if (round > n + 2) { ctx->err = "pf_call_resolve: the driver pass does not settle"; return PF_ERR_ARG; }
+        k_call_resolve<<<grid, 256, 0, st>>>(a);
+        PF_HIP(hipMemsetAsync(small, 0, 4, st));
+        k_call_resolve<<<grid, 256, 0, st>>>(a);   // two rounds per look at the counter: the common case needs exactly two
+        unsigned int h[2];
+        PF_HIP(hipMemcpyAsync(h, small, 8, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        if (h[1] != 0xFFFFFFFFu && h[0] == 0) {   // every side settled and an alive one carries an error: the first in order counts
+            pf_call_side bad;
+            PF_HIP(hipMemcpy(&bad, S->sides.as<pf_call_side>() + h[1], sizeof(bad), hipMemcpyDeviceToHost));
+            *err = bad.err;
+            *err_unitig = bad.err_unitig;
+            return PF_OK;
+        }
+        if (h[0] == 0) break;
+    }
+    // the called sides, ascending
+    size_t tmp = 0;
+    hipcub::CountingInputIterator<uint32_t> ids(0);
+    PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp, ids, S->rflag.as<uint32_t>(), S->kept.as<uint32_t>(), small + 2, (int)n, st));
+    if (!S->scan_tmp.ensure(tmp)) { ctx->err = "pf_call_resolve: out of device memory"; return PF_ERR_HIP; }
+    PF_HIP(hipcub::DeviceSelect::Flagged(S->scan_tmp.p, tmp, ids, S->rflag.as<uint32_t>(), S->kept.as<uint32_t>(), small + 2, (int)n, st));
+    unsigned int sel = 0;
+    PF_HIP(hipMemcpyAsync(&sel, small + 2, 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    S->n_tasks = sel;
+    *n_bubbles = sel;
     return PF_OK;
 }
 
@@ -1161,20 +1503,47 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
     const int paths_grid = ctx->n_cu * 8;
     NEED(S->paths_scr, paths_per_wave * paths_grid);
 
-    // ---- paths + queues; the pools grow until the batch fits ----
+    // ---- K-PREP, K-SNP, K-PATHS, K-BUBBLE; every pool grows until the batch fits (first batches of a run only) ----
+    NEED(S->slist, (size_t)nb * 4);
+    const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
+    unsigned long long heads[4] = {0, 0, 0, 0};
+    uint64_t n_jobs = 0;
     for (int attempt = 0;; ++attempt) {
+        if (attempt > 5) { ctx->err = "pf_call_align: pools do not converge"; return PF_ERR_OVERFLOW; }
         const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 1024);
         const uint64_t text_cap = std::max<uint64_t>(S->text_pool, (uint64_t)nb * 32 + (1u << 16));
+        const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, 160ull * nb + (1u << 16));
+        const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, 2ull * nb + 64);
+        const uint64_t cap_groups = std::max<uint64_t>(S->ogroups_cap, 4ull * nb + 64);
+        const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, nb / 2 + 64);
         NEED(S->bpath, ((size_t)4 * nb + path_cap) * sizeof(pf_bubble_path));
         NEED(S->ptext, text_cap);
+        NEED(S->otext, cap_text);
+        NEED(S->osites, cap_sites * sizeof(pf_bubble_site));
+        NEED(S->ogroups, cap_groups);
+        NEED(S->oilen, cap_ilen * 4);
+        unsigned long long *d_heads = bubble_pool_heads(ctx);
+        if (!d_heads) return PF_ERR_HIP;
         PF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(CallCounters), st));
+        PF_HIP(hipMemsetAsync(d_heads, 0, 32, st));
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
         pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = S->res.as<pf_bubble_result>();
-        pa.queues = S->queues.as<uint32_t>(); pa.blist = S->blist.as<uint32_t>(); pa.cnt = d_cnt;
+        pa.queues = S->queues.as<uint32_t>(); pa.blist = S->blist.as<uint32_t>(); pa.slist = S->slist.as<uint32_t>(); pa.snp_ok = snp_ok;
+        pa.cnt = d_cnt;
         ctx_begin(ctx, PF_K_CALL_PREP);
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
         ctx_end(ctx);
+        if (snp_ok) {
+            SnpArgs sn;
+            sn.ct = pa.ct; sn.kept = pa.kept; sn.t0 = t0; sn.nb = nb; sn.slist = pa.slist; sn.seq = ctx->d_seq; sn.off = ctx->d_off;
+            sn.len = ctx->d_len; sn.res = pa.res; sn.otext = S->otext.as<char>(); sn.text_cap = cap_text;
+            sn.osites = S->osites.as<pf_bubble_site>(); sn.site_cap = cap_sites; sn.ogroups = S->ogroups.as<uint8_t>(); sn.group_cap = cap_groups;
+            sn.heads = d_heads; sn.queues = pa.queues; sn.cnt = d_cnt;
+            ctx_begin(ctx, PF_K_CALL_SNP);
+            k_call_snp<<<(nb + 255) / 256, 256, 0, st>>>(sn);   // (the list length is on the device: surplus threads leave at once)
+            ctx_end(ctx);
+        }
         PathArgs ph;
         ph.ct = pa.ct; ph.kept = pa.kept; ph.t0 = t0; ph.nb = nb; ph.blist = pa.blist; ph.succ = ctx->d_succ; ph.seq = ctx->d_seq;
         ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
@@ -1188,71 +1557,56 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         PF_HIP(hipStreamSynchronize(st));
         if (hc.err & 1u) { ctx->err = "pf_call_run: a bubble has more than 255 paths"; return PF_ERR_ARG; }
         if (hc.err & 32u) { ctx->err = "pf_call_run: a bubble is deeper than the complex size allows"; return PF_ERR_ARG; }
+        S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
+        S->ogroups_cap = std::max(S->ogroups_cap, cap_groups); S->oilen_cap = std::max(S->oilen_cap, cap_ilen);
+        S->path_pool = std::max(S->path_pool, path_cap);
+        S->text_pool = std::max(S->text_pool, text_cap);
         if (hc.path_head > path_cap || hc.text_head > text_cap) {
-            if (attempt >= 3) { ctx->err = "pf_call_run: path pools do not converge"; return PF_ERR_OVERFLOW; }
             S->path_pool = std::max<uint64_t>(S->path_pool, hc.path_head + hc.path_head / 8 + 1024);
             S->text_pool = std::max<uint64_t>(S->text_pool, hc.text_head + hc.text_head / 8 + 4096);
             continue;
         }
-        S->path_pool = std::max(S->path_pool, path_cap);
-        S->text_pool = std::max(S->text_pool, text_cap);
+        // the aligned rows of the branching bubbles come on top of what K-SNP took: make room before K-BUBBLE runs
+        if (cap_text < 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb) {
+            S->otext_cap = 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb + 4096;
+            continue;
+        }
+        n_jobs = 0;
+        for (int x = 0; x < 8; ++x) n_jobs += hc.q_n[x];
+        // K-BUBBLE: the queues are heavy-then-light per class; compact them into one index array
+        NEED(S->scan_tmp2, std::max<size_t>((size_t)n_jobs, 1) * 4);
+        {
+            uint32_t *d_idx = S->scan_tmp2.as<uint32_t>();
+            size_t at = 0;
+            for (int x = 0; x < 8; ++x) {
+                if (!hc.q_n[x]) continue;
+                PF_HIP(hipMemcpyAsync(d_idx + at, S->queues.as<uint32_t>() + (size_t)x * nb, (size_t)hc.q_n[x] * 4, hipMemcpyDeviceToDevice, st));
+                at += hc.q_n[x];
+            }
+        }
+        BubbleLaunch BL;
+        BL.text = S->ptext.as<char>(); BL.paths = S->bpath.as<pf_bubble_path>(); BL.tasks = S->btask.as<pf_bubble_task>();
+        BL.n_tasks = nb; BL.idx = S->scan_tmp2.as<uint32_t>();
+        for (int c = 0; c < 4; ++c) BL.n_cls[c] = hc.q_n[2 * c] + hc.q_n[2 * c + 1];
+        BL.max_need = hc.max_need; BL.retry_need = hc.retry_need;
+        BL.match = match; BL.mismatch = mismatch; BL.gap = gap;
+        BL.res = S->res.as<pf_bubble_result>(); BL.otext = S->otext.as<char>(); BL.osites = S->osites.as<pf_bubble_site>();
+        BL.ogroups = S->ogroups.as<uint8_t>(); BL.oilen = S->oilen.as<uint32_t>();
+        BL.text_cap = cap_text; BL.site_cap = cap_sites; BL.group_cap = cap_groups; BL.ilen_cap = cap_ilen;
+        BL.keep_heads = true;
+        const int bst = bubble_launch(ctx, BL, heads);
+        if (bst == PF_ERR_OVERFLOW && (heads[0] > cap_text || heads[1] > cap_sites || heads[2] > cap_groups || heads[3] > cap_ilen)) {
+            S->otext_cap = std::max<uint64_t>(S->otext_cap, heads[0] + heads[0] / 8);
+            S->osites_cap = std::max<uint64_t>(S->osites_cap, heads[1] + heads[1] / 8);
+            S->ogroups_cap = std::max<uint64_t>(S->ogroups_cap, heads[2] + heads[2] / 8);
+            S->oilen_cap = std::max<uint64_t>(S->oilen_cap, heads[3] + heads[3] / 8);
+            continue;
+        }
+        if (bst != PF_OK) return bst;
         break;
     }
     out->n_branching = hc.n_branching;
-    uint64_t n_jobs = 0;
-    for (int x = 0; x < 8; ++x) n_jobs += hc.q_n[x];
-    out->align_jobs = n_jobs;
-
-    // ---- K-BUBBLE: the queues are heavy-then-light per class; compact them into one index array ----
-    NEED(S->scan_tmp2, std::max<size_t>((size_t)n_jobs, 1) * 4);
-    {
-        uint32_t *d_idx = S->scan_tmp2.as<uint32_t>();
-        size_t at = 0;
-        for (int x = 0; x < 8; ++x) {
-            if (!hc.q_n[x]) continue;
-            PF_HIP(hipMemcpyAsync(d_idx + at, S->queues.as<uint32_t>() + (size_t)x * nb, (size_t)hc.q_n[x] * 4, hipMemcpyDeviceToDevice, st));
-            at += hc.q_n[x];
-        }
-    }
-    unsigned long long heads[4] = {0, 0, 0, 0};
-    if (n_jobs) {
-        for (int attempt = 0;; ++attempt) {
-            const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, (hc.text_head + 128ull * nb) * 2 + 4096);
-            const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, 4ull * nb + 64);
-            const uint64_t cap_groups = std::max<uint64_t>(S->ogroups_cap, 16ull * nb + 64);
-            const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, 2ull * nb + 64);
-            NEED(S->otext, cap_text);
-            NEED(S->osites, cap_sites * sizeof(pf_bubble_site));
-            NEED(S->ogroups, cap_groups);
-            NEED(S->oilen, cap_ilen * 4);
-            BubbleLaunch BL;
-            BL.text = S->ptext.as<char>(); BL.paths = S->bpath.as<pf_bubble_path>(); BL.tasks = S->btask.as<pf_bubble_task>();
-            BL.n_tasks = nb; BL.idx = S->scan_tmp2.as<uint32_t>();
-            for (int c = 0; c < 4; ++c) BL.n_cls[c] = hc.q_n[2 * c] + hc.q_n[2 * c + 1];
-            BL.max_need = hc.max_need; BL.retry_need = hc.retry_need;
-            BL.match = match; BL.mismatch = mismatch; BL.gap = gap;
-            BL.res = S->res.as<pf_bubble_result>(); BL.otext = S->otext.as<char>(); BL.osites = S->osites.as<pf_bubble_site>();
-            BL.ogroups = S->ogroups.as<uint8_t>(); BL.oilen = S->oilen.as<uint32_t>();
-            BL.text_cap = cap_text; BL.site_cap = cap_sites; BL.group_cap = cap_groups; BL.ilen_cap = cap_ilen;
-            const int bst = bubble_launch(ctx, BL, heads);
-            S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
-            S->ogroups_cap = std::max(S->ogroups_cap, cap_groups); S->oilen_cap = std::max(S->oilen_cap, cap_ilen);
-            if (bst == PF_ERR_OVERFLOW && (heads[0] > cap_text || heads[1] > cap_sites || heads[2] > cap_groups || heads[3] > cap_ilen)) {
-                if (attempt >= 3) return bst;
-                S->otext_cap = std::max<uint64_t>(S->otext_cap, heads[0] + heads[0] / 8);
-                S->osites_cap = std::max<uint64_t>(S->osites_cap, heads[1] + heads[1] / 8);
-                S->ogroups_cap = std::max<uint64_t>(S->ogroups_cap, heads[2] + heads[2] / 8);
-                S->oilen_cap = std::max<uint64_t>(S->oilen_cap, heads[3] + heads[3] / 8);
-                // the results of the failed attempt are void: clear them (skipped bubbles must read n_rows == 0)
-                PF_HIP(hipMemsetAsync(S->res.p, 0, (size_t)nb * sizeof(pf_bubble_result), st));
-                continue;
-            }
-            if (bst != PF_OK) return bst;
-            break;
-        }
-    } else {
-        NEED(S->otext, 16); NEED(S->osites, 16); NEED(S->ogroups, 16); NEED(S->oilen, 16);
-    }
+    out->align_jobs = n_jobs + hc.n_snp_done;
 
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);

@@ -21,7 +21,7 @@ NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
            "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
-           "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format"]
+           "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
@@ -108,8 +108,11 @@ def load_library() -> C.CDLL:
         "pf_gmm_fit": (i, [vp, u32, C.c_double, C.c_double, C.c_int32, C.c_double, vp, vp, vp, vp, vp]),
         "pf_call_set_state": (i, [vp, vp, vp, vp]),
         "pf_call_coverage": (i, [vp]),
+        "pf_superbubble_rows": (i, [vp, i, C.POINTER(u64), C.POINTER(u64)]),
+        "pf_superbubble_fetch": (i, [vp, vp, u64]),
         "pf_call_scan": (i, [vp, u32, u32, C.POINTER(u64)]),
         "pf_call_sides": (i, [vp, vp, u64]),
+        "pf_call_resolve": (i, [vp, C.POINTER(u64), C.POINTER(u32), C.POINTER(u32)]),
         "pf_call_select": (i, [vp, vp, u64]),
         "pf_call_run": (i, [vp, i, u64, u64, u64, u32, C.c_double, C.c_double, C.c_double, vp]),
         "pf_call_align": (i, [vp, u64, u64, u32, C.c_double, C.c_double, C.c_double, vp]),
@@ -132,7 +135,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
                     "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
-                    "pf_call_set_state", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_select", "pf_call_run", "pf_call_align",
+                    "pf_call_set_state", "pf_superbubble_rows", "pf_superbubble_fetch", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_resolve", "pf_call_select", "pf_call_run", "pf_call_align",
                     "pf_call_text", "pf_call_fetch", "pf_format_doubles"]
 
 
