@@ -366,6 +366,8 @@ void pf_host_free(pf_ctx *, void *p);
 
 /* ---- introspection ---------------------------------------------------------------------- */
 int pf_device_name(pf_ctx *, char *buf, size_t cap);
+/* "domain:bus:device.function" of the context's GPU (the host layer looks up its NUMA node with it) */
+int pf_device_pci_bus_id(pf_ctx *, char *buf, size_t cap);
 uint64_t pf_table_capacity(const pf_ctx *);
 uint64_t pf_num_kmers(const pf_ctx *);
 

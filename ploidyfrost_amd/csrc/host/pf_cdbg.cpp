@@ -1,5 +1,6 @@
 // pfh::CDBG: construction, output plumbing, MyUnitig state and the order-dependent commit replay.
 #include <fcntl.h>
+#include <sched.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -22,11 +23,56 @@
 
 namespace pfh {
 
+// The host side of a pass is bound by memory latency (the commit replay chases per-unitig state at random) and feeds the GPU
+// over PCIe: on a multi-socket host both want the threads and their memory on the socket the GPU hangs off.  Restricts the
+// calling thread -- and with it every thread created from here on: the work pool, the pipeline stages -- to the CPUs of the
+// GPU's NUMA node.  Does nothing on single-node hosts, when sysfs does not tell, or with PF_NO_NUMA_BIND set.
+static void bind_to_device_node(pf_ctx *ctx) {
+    if (getenv("PF_NO_NUMA_BIND")) return;
+    char bdf[64] = {0};
+    if (pf_device_pci_bus_id(ctx, bdf, sizeof bdf) != PF_OK) return;
+    for (char *c = bdf; *c; ++c) *c = (char)tolower(*c);
+    int node = -1;
+    if (FILE *f = fopen((std::string("/sys/bus/pci/devices/") + bdf + "/numa_node").c_str(), "r")) {
+        if (fscanf(f, "%d", &node) != 1) node = -1;
+        fclose(f);
+    }
+    if (node < 0) return;
+    std::string list;
+    if (FILE *f = fopen(("/sys/devices/system/node/node" + std::to_string(node) + "/cpulist").c_str(), "r")) {
+        char buf[4096];
+        if (fgets(buf, sizeof buf, f)) list = buf;
+        fclose(f);
+    }
+    cpu_set_t now, want;
+    CPU_ZERO(&want);
+    if (sched_getaffinity(0, sizeof now, &now) != 0) return;
+    int n_want = 0;
+    for (size_t i = 0; i < list.size();) {   // "0-63,128-191"
+        char *end = nullptr;
+        const long a = strtol(list.c_str() + i, &end, 10);
+        if (end == list.c_str() + i) break;
+        long b = a;
+        i = (size_t)(end - list.c_str());
+        if (i < list.size() && list[i] == '-') {
+            b = strtol(list.c_str() + i + 1, &end, 10);
+            i = (size_t)(end - list.c_str());
+        }
+        for (long c = a; c <= b && c < CPU_SETSIZE; ++c)
+            if (CPU_ISSET((int)c, &now)) { CPU_SET((int)c, &want); ++n_want; }
+        if (i < list.size() && list[i] == ',') ++i;
+        else break;
+    }
+    if (n_want >= 4 && n_want < CPU_COUNT(&now)) (void)sched_setaffinity(0, sizeof want, &want);   // never widen, never starve
+    if (getenv("PF_TRACE_LOAD")) fprintf(stderr, "[load] GPU %s on NUMA node %d: host threads on %d of %d CPUs\n", bdf, node, n_want, CPU_COUNT(&now));
+}
+
 int CDBG::init_device(int device) {
     LoadTrace trace;
     int st = pf_create(device, &ctx_);
     trace.mark("device: context");
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: " + pf_last_error(nullptr));
+    bind_to_device_node(ctx_);
     st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));
     trace.mark("device: graph upload");

@@ -277,27 +277,43 @@ __device__ inline Metrics classify(const char *rows, uint32_t R, uint32_t L, uin
     uint8_t snp = 0, indel = 0;
     uint32_t ns = 0, ni = 0, nl = 0;
     bool open = false;
-    for (uint32_t j = 0; j < L; ++j) {
-        const uint8_t ci = colinfo[j];
-        const uint8_t t = ci & 3;
-        uint8_t lab = 0;  // bit 4: labelled column, bit 5: opens an indel
-        if (t != 2) {
-            if (open) { if (lane == 0) indel_len[nl] = j - indel_pos[(uint8_t)(indel - 1)]; nl++; open = false; }
-            if (t == 1) { if (lane == 0) snp_pos[ns] = j; ns++; snp++; lab = 16; }
-        } else {
-            const bool same_run = open && (ci & 4);
-            if (open && !same_run) { if (lane == 0) indel_len[nl] = j - indel_pos[(uint8_t)(indel - 1)]; nl++; }
-            if (!same_run) {
-                ++indel;
-                if (lane == 0) indel_pos[ni] = j;
-                ni++;
-                open = true;
-                lab = 16 | 32;  // (indel_pos is written and read back by lane 0 only)
-            } else if (ci & 8) {
-                lab = 16;
+    // List building (src/SeqAlign.cpp:56-157) is a state machine over the columns, but only two kinds of column can change its
+    // state or emit anything: variant columns, and the column right after a gap column (where an open indel closes).  Those are
+    // found 64 columns at a time by ballot and visited in order; the long runs of identical columns between them are skipped.
+    uint32_t prev_gap_carry = 0;  // was the last column of the previous 64-block a gap column?
+    for (uint32_t base = 0; base < L; base += WAVE) {
+        const uint32_t jj = base + lane;
+        const uint8_t cj = jj < L ? colinfo[jj] : 0;
+        const unsigned long long m_var = __ballot((cj & 3) != 0);
+        const unsigned long long m_gap = __ballot((cj & 3) == 2);
+        unsigned long long ev = m_var | (m_gap << 1) | (unsigned long long)prev_gap_carry;
+        if (base + WAVE > L && L - base < 64) ev &= (1ull << (L - base)) - 1;
+        prev_gap_carry = (uint32_t)(m_gap >> 63);
+        while (ev) {
+            const int b = __ffsll((long long)ev) - 1;
+            ev &= ev - 1;
+            const uint32_t j = base + (uint32_t)b;
+            const uint8_t ci = (uint8_t)read_lane((uint32_t)cj, b);
+            const uint8_t t = ci & 3;
+            uint8_t lab = 0;  // bit 4: labelled column, bit 5: opens an indel
+            if (t != 2) {
+                if (open) { if (lane == 0) indel_len[nl] = j - indel_pos[(uint8_t)(indel - 1)]; nl++; open = false; }
+                if (t == 1) { if (lane == 0) snp_pos[ns] = j; ns++; snp++; lab = 16; }
+            } else {
+                const bool same_run = open && (ci & 4);
+                if (open && !same_run) { if (lane == 0) indel_len[nl] = j - indel_pos[(uint8_t)(indel - 1)]; nl++; }
+                if (!same_run) {
+                    ++indel;
+                    if (lane == 0) indel_pos[ni] = j;
+                    ni++;
+                    open = true;
+                    lab = 16 | 32;  // (indel_pos is written and read back by lane 0 only)
+                } else if (ci & 8) {
+                    lab = 16;
+                }
             }
+            if (lane == 0 && lab) colinfo[j] = (uint8_t)(ci | lab);
         }
-        if (lane == 0 && lab) colinfo[j] = (uint8_t)(ci | lab);
     }
     aln_sync();
     m.snp = snp;

@@ -733,6 +733,12 @@ int pf_device_name(pf_ctx *ctx, char *buf, size_t cap) {
     return PF_OK;
 }
 
+int pf_device_pci_bus_id(pf_ctx *ctx, char *buf, size_t cap) {
+    if (!ctx || !buf || cap < 16) return PF_ERR_ARG;
+    PF_HIP(hipDeviceGetPCIBusId(buf, (int)cap, ctx->device));
+    return PF_OK;
+}
+
 uint64_t pf_table_capacity(const pf_ctx *ctx) { return ctx ? ctx->tab_cap : 0; }
 uint64_t pf_num_kmers(const pf_ctx *ctx) { return ctx ? ctx->n_kmers : 0; }
 

@@ -90,6 +90,7 @@ def load_library() -> C.CDLL:
         "pf_host_alloc": (i, [vp, C.c_size_t, C.POINTER(vp)]),
         "pf_host_free": (None, [vp, vp]),
         "pf_device_name": (i, [vp, C.c_char_p, C.c_size_t]),
+        "pf_device_pci_bus_id": (i, [vp, C.c_char_p, C.c_size_t]),
         "pf_table_capacity": (u64, [vp]),
         "pf_num_kmers": (u64, [vp]),
         "pf_upload_counts_colored": (i, [vp, u32, vp, vp, vp, vp, vp, vp]),
@@ -131,7 +132,7 @@ def load_library() -> C.CDLL:
 DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
                     "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
-                    "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_table_capacity", "pf_num_kmers",
+                    "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
                     "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
