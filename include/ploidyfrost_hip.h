@@ -262,6 +262,12 @@ int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t 
 /* T1: the MyUnitig state after findSuperBubble (src/MyUnitig.hpp:37-130): b bits; plus / minus partners (0 = NULL, id = u + 1).
  * n_unitigs entries each. [host|dev] */
 int pf_call_set_state(pf_ctx *, const uint8_t *flags, const uint32_t *plus, const uint32_t *minus);
+/* Which of the reference's two text formats the rows follow: 0 (default) = its `-t 1` functions (ids and var_count from 1,
+ * allele_frequency.txt in site order: src/CDBG.cpp:222-252, 1259-1340, 1552-1652); 1 = its `-t > 1` functions (BubbleId and
+ * var_count from 0 -- fetch_add returns the old value, :1829, 2056 --, the allele_frequency rows of a bubble grouped by arity,
+ * bi then tri then tetra then, in the strict branch only, penta, rows of other arities absent: :2158-2162, 2550).  Row ORDER
+ * across bubbles is the deterministic `-t 1` order in both (the reference's own order with threads depends on timing). */
+int pf_call_set_format(pf_ctx *, int reference_mt);
 /* S1, second half: the rows of <outpre>_super_bubble.txt (src/CDBG.cpp:222-252) from that state, formatted on the device: one row
  * `BubbleId<TAB>Entrance<TAB>Strand<TAB>Exit<TAB>isSimple<TAB>isComplex` per open endpoint side in unitig order, ids from 1 (the
  * header line is the caller's).  colored_rule = 1: CCDBG's rule -- an open unitig lists every side whose partner is set, self

@@ -46,6 +46,10 @@ void pfh_set_overlap_output(pfh_run *, int on);      /* 1: <outpre>_super_bubble
 /* K-BFS traversals beyond 4096 vertices: on host cores (default, pf_bfs_candidates_split + host/pf_bfs_host.cpp: one thread per
  * traversal) or, with on = 0, on the device (k_bfs_huge: one wavefront per traversal).  Same records either way. */
 void pfh_set_third_tier_on_host(pfh_run *, int on);
+/* n > 1: write the text format of the reference's `-t n` functions (ids and var_count from 0, allele_frequency rows of a bubble
+ * grouped by arity; src/CDBG.cpp:1829, 2056, 2158-2162, 2550) -- in the deterministic `-t 1` row order; n <= 1: the `-t 1` format.
+ * Single-sample path. */
+int pfh_set_reference_threads(pfh_run *, uint32_t n);
 void pfh_set_batch_bubbles(pfh_run *, uint64_t n);   /* bubbles per batch of the align/format pipeline (default 65536) */
 int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);

@@ -146,6 +146,13 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     init_device(device);
 }
 
+int CDBG::set_reference_threads(size_t n) {
+    if (n > 1 && col_) return fail(PF_ERR_ARG, "CCDBG:: the -t > 1 output format is built for the single-sample path only");
+    mt_format_ = n > 1;
+    const int st = pf_call_set_format(ctx_, mt_format_ ? 1 : 0);
+    return st == PF_OK ? 0 : fail(st, pf_last_error(ctx_));
+}
+
 int CDBG::join_pending_write() {
     if (pending_write_.joinable()) {
         pending_write_.join();

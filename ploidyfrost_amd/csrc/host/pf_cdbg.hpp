@@ -81,6 +81,10 @@ public:
     // PloidyEstimation through the device's resident calling pipeline (pf_call_*, the default for the single-sample path) or,
     // off, through the host-threaded pipeline around pf_align_bubbles / pf_string_cov (what the colored path uses)
     void set_resident_calling(bool on) { resident_ = on; }
+    // Text format of the reference's `-t N` run with N > 1 (single-sample path): BubbleId / var_count from 0, the allele_frequency
+    // rows of a bubble grouped by arity (src/CDBG.cpp:1829, 2056, 2158-2162, 2550) and its stdout wording; the order of rows
+    // stays the deterministic `-t 1` one (the reference's own depends on thread timing).
+    int set_reference_threads(size_t n);
     // ---- one graph over several GPUs (reference owner rule src/CDBG.cpp:1190, 1352, 1656-1679) -------------
     // findSuperBubble: every rank traverses the entrances of its unitig range (find_shard), the ranks exchange the records,
     // every rank replays all of them (find_replay; rank 0 writes the file).  PloidyEstimation: the scan and the sequential pass
@@ -207,6 +211,7 @@ protected:
         void release_all() { sides.release(); kept.release(); slab[0].release(); slab[1].release(); }
     } cx_;
     bool resident_ = true;
+    bool mt_format_ = false;
     bool state_on_device_ = false;   // pf_call_set_state holds the state findSuperBubble left (finish_find uploads it)
     PinnedBuf<char> sb_text_;        // text of super_bubble.txt on its way from the device to the file
     PhaseTimes times_;

@@ -378,8 +378,9 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     tp("files closed");
     times_.ploidy_total_s = since(t_all);
     if (!quiet_) {
-        printf("%s::PloidyEstimation():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
-        printf("%s::PloidyEstimation():  Real time : %gs\n", tag_, times_.ploidy_total_s);
+        printf(mt_format_ ? "%s::PloidyEstimation(): Cpu time : %gs\n" : "%s::PloidyEstimation():  Cpu time : %gs\n", tag_,
+               (double)(clock() - c0) / CLOCKS_PER_SEC);   // (src/CDBG.cpp:2612-2615 vs 1683-1686)
+        printf(mt_format_ ? "%s::PloidyEstimation(): Real time : %gs\n" : "%s::PloidyEstimation():  Real time : %gs\n", tag_, times_.ploidy_total_s);
         printf("%s::PloidyEstimation(): Alleles in SuperBubbles  :\t2 :%llu\t3 :%llu\t4 :%llu\t5 :%llu\n", tag_,
                (unsigned long long)allele_[0], (unsigned long long)allele_[1], (unsigned long long)allele_[2],
                (unsigned long long)allele_[3]);

@@ -202,8 +202,11 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     times_.bfs_deferred = n_deferred_total.load();
     times_.replay_s = replay_s;
     if (!quiet_) {
-        printf("%s::findSuperBubble():  Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);
-        printf("%s::findSuperBubble():  Real time : %gs\n", tag_, since(t_all));
+        // (the reference words these two lines differently in its threaded function, src/CDBG.cpp:1783-1786)
+        printf(mt_format_ ? "%s::findSuperBubble(): Finding superbubbles Cpu time : %gs\n" : "%s::findSuperBubble():  Cpu time : %gs\n", tag_,
+               (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf(mt_format_ ? "%s::findSuperBubble(): Finding superbubbles Real time : %gs\n" : "%s::findSuperBubble():  Real time : %gs\n", tag_,
+               since(t_all));
     }
     return finish_find(outpre, thr, t_all, true);
 }

@@ -161,6 +161,8 @@ void sort_inner_colored(const UnitigSet &g, size_t *pc, uint32_t *ov, double *co
 
 int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr) {
     if (status_) return status_;
+    if (mt_format_ && !resident_path())
+        return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): the -t > 1 output format needs the resident calling pipeline");
     if (resident_path()) {
         if (cutoff.size() != 1) return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): one (lower, upper) cutoff is required");
         return ploidy_estimation_resident(outpre, cutoff, thr);

@@ -126,6 +126,9 @@ void pfh_set_write_files(pfh_run *r, int on) { r->cdbg->set_write_files(on != 0)
 void pfh_set_threads(pfh_run *r, uint32_t threads) { r->cdbg->set_threads(threads); }
 void pfh_set_overlap_output(pfh_run *r, int on) { r->cdbg->set_overlap_output(on != 0); }
 void pfh_set_third_tier_on_host(pfh_run *r, int on) { r->cdbg->set_third_tier_on_host(on != 0); }
+int pfh_set_reference_threads(pfh_run *r, uint32_t n) {
+    return guarded(r, [&] { return r->cdbg->set_reference_threads(n); });
+}
 void pfh_set_batch_bubbles(pfh_run *r, uint64_t n) { r->cdbg->set_batch_bubbles((size_t)n); }
 int pfh_set_unitig_id(pfh_run *r, const char *outpre) {
     return guarded(r, [&] { return r->cdbg->setUnitigId(outpre, "", 1); });

@@ -47,7 +47,8 @@ void PrintUsage() {
          << "  -v,             Print information messages during construction" << endl
          << "  -i,             Output Information about Bifrost graph" << endl << endl
          << "  -h,             k-mer histogram file (with -f: a list of them): thresholds = cutoffL / cutoffU of it" << endl
-         << "  -q,             quantile for the upper threshold derived from -h (default : 0.998 )" << endl << endl
+         << "  -q,             quantile for the upper threshold derived from -h (default : 0.998 )" << endl
+         << "  --ref-threads N N > 1: text format of the reference's `-t N` run (ids from 0, allele_frequency grouped by arity)" << endl << endl
          << "Usage: PloidyFrost cutoffL kmer_histogram_file" << endl
          << "Usage: PloidyFrost cutoffU kmer_histogram_file (quantile[<1 ,default:0.998])" << endl << endl
          << "Not part of this build: `model`." << endl;
@@ -92,7 +93,7 @@ int cutoffH(const string &file, double frequency = 0.998) {
 
 struct Options {
     string graphfile, colorfile, outprefix = "output", db, coveragefile, hist;
-    size_t nb_threads = 1, complex_size = 8;
+    size_t nb_threads = 1, complex_size = 8, ref_threads = 1;
     bool verbose = false, info = false;
     int coverage_lower = 10, coverage_upper = 1000, k = 25;
     vector<pair<int, int>> coverage_vec;
@@ -198,6 +199,16 @@ int main(int argc, char **argv) {
         return 0;
     }
     Options opt;
+    // --ref-threads N (this build's own switch, taken out of argv before getopt sees it): write the text format of the reference's
+    // `-t N` functions -- with N > 1: ids and var_count from 0, allele_frequency rows grouped by arity per bubble -- whatever -t says
+    for (int i = 1; i < argc; ++i) {
+        if (strcmp(argv[i], "--ref-threads") == 0 && i + 1 < argc) {
+            opt.ref_threads = (size_t)atoi(argv[i + 1]);
+            for (int j = i; j + 2 <= argc; ++j) argv[j] = j + 2 < argc ? argv[j + 2] : nullptr;
+            argc -= 2;
+            --i;
+        }
+    }
     int oc;
     while ((oc = getopt(argc, argv, "M:D:G:z:a:l:q:u:e:C:R:o:t:g:f:k:d:m:n:h:ibvpNSc")) != -1) {
         switch (oc) {
@@ -366,6 +377,7 @@ int main(int argc, char **argv) {
         cout << "CompactedDBG::read(): " << graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
     g.set_threads((unsigned)opt.nb_threads);
     g.set_overlap_output(true);
+    if (opt.ref_threads > 1 && g.set_reference_threads(opt.ref_threads)) die();
     if (getenv("PF_BFS_HUGE_ON_DEVICE")) g.set_third_tier_on_host(false);   // experiments: giant traversals on one wavefront each
     if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
     if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();

@@ -122,6 +122,7 @@ struct CallState {
     uint64_t out_len[2][N_STREAMS] = {};
     hipStream_t copy_stream = nullptr;
     // the batch pf_call_align left resident for pf_call_text
+    bool mt_format = false;   // pf_call_set_format
     uint64_t cur_t0 = 0;
     uint32_t cur_nb = 0;
     pf_call_result cur = {};
@@ -991,6 +992,7 @@ struct FmtArgs {
     const double *sv;
     const uint32_t *vc;       // inclusive count of called bubbles inside the batch
     uint64_t vc_base;
+    int mt;                   // the reference's -t > 1 format: var_count from 0, allele_frequency rows grouped by arity per bubble
     const uint32_t *len;
     uint32_t *sizes;          // [N_STREAMS][nb + 1]
     const uint64_t *offs;     // exclusive scan of sizes, one run over all streams
@@ -1032,7 +1034,9 @@ __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
             const CallTask &t = a.ct[a.kept[a.t0 + j]];
             const uint32_t R = r.n_rows, L = r.n_cols;
             const char *rows = a.otext + r.rows_off;
-            const uint64_t my_vc = a.vc_base + a.vc[j];
+            const uint64_t my_vc = a.vc_base + a.vc[j] - (a.mt ? 1 : 0);   // fetch_add(1) returns the old value (src/CDBG.cpp:2056)
+            char *fre_start[4] = {s_fre[0].p, s_fre[1].p, s_fre[2].p, s_fre[3].p};
+            const uint32_t fre_n0[4] = {s_fre[0].n, s_fre[1].n, s_fre[2].n, s_fre[3].n};
             // alignseq: var_count, strict flag, entrance id, exit id, aligned row (src/CDBG.cpp:1259, 1428)
             for (uint32_t p = 0; p < R; ++p) {
                 put_uint(s_aln, my_vc);
@@ -1092,17 +1096,24 @@ __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
                         tc = vals[x];
                     }
                     if (filed) { put_double(cov, tc); cov.put('\t'); }
-                    // the frequency row goes to allele_frequency.txt and, for 2..5 alleles, to the arity's fre file
-                    if (W) {
-                        char *before = s_all.p;
-                        put_double(s_all, tc / denom);
+                    // the frequency row: the arity's fre file (2..5 alleles) and allele_frequency.txt -- there in site order, or,
+                    // in the -t > 1 format, grouped by arity at the end of the bubble (src/CDBG.cpp:2158-2162)
+                    const double fr = tc / denom;
+                    if (filed) {
+                        if (W) {
+                            char *before = fre.p;
+                            put_double(fre, fr);
+                            fre.put('\n');
+                            if (!a.mt) { for (char *c = before; c < fre.p; ++c) *s_all.p++ = *c; }
+                        } else {
+                            const uint32_t before = fre.n;
+                            put_double(fre, fr);
+                            fre.put('\n');
+                            if (!a.mt) s_all.n += fre.n - before;
+                        }
+                    } else if (!a.mt) {
+                        put_double(s_all, fr);
                         s_all.put('\n');
-                        if (filed) { for (char *c = before; c < s_all.p; ++c) *fre.p++ = *c; }
-                    } else {
-                        const uint32_t before = s_all.n;
-                        put_double(s_all, tc / denom);
-                        s_all.put('\n');
-                        if (filed) fre.n += s_all.n - before;
                     }
                 }
                 if (filed) {
@@ -1121,6 +1132,14 @@ __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
                     else if (ar == 1) { s_cov[1] = cov; s_fre[1] = fre; }
                     else if (ar == 2) { s_cov[2] = cov; s_fre[2] = fre; }
                     else { s_cov[3] = cov; s_fre[3] = fre; }
+                }
+            }
+            if (a.mt) {
+                // allfre << bifre_info << trifre_info << tetrafre_info (<< pentafre_info only in the strict branch, :2162 vs :2550)
+                const int n_ar = t.strict ? 4 : 3;
+                for (int x = 0; x < n_ar; ++x) {
+                    if (W) { for (char *c = fre_start[x]; c < s_fre[x].p; ++c) *s_all.p++ = *c; }
+                    else s_all.n += s_fre[x].n - fre_n0[x];
                 }
             }
         }
@@ -1163,6 +1182,7 @@ struct SbArgs {
     const uint32_t *plus, *minus;
     uint32_t N;
     int colored;
+    uint32_t first_id;          // 1; 0 in the reference's -t > 1 format (fetch_add, src/CDBG.cpp:1829)
     const uint32_t *row_base;   // exclusive scan of rows per unitig
     uint32_t *sizes;            // bytes per unitig (N + 1 entries, the last 0)
     const uint64_t *offs;
@@ -1195,11 +1215,11 @@ __global__ void k_sb_format(SbArgs a) {
     Row<W> o{W ? a.out + a.offs[u] : nullptr, 0};
     if (n) {
         const uint8_t f = a.flags[u];
-        uint64_t nb = a.row_base[u];
+        uint64_t nb = (uint64_t)a.row_base[u] + a.first_id;
         for (int side = 0; side < 2; ++side) {
             if (!rows[side]) continue;
             const bool ps = side == 0;
-            put_uint(o, ++nb);
+            put_uint(o, nb++);
             o.put('\t');
             put_uint(o, (uint64_t)u + 1);
             o.put('\t'); o.put(ps ? '+' : '-'); o.put('\t');
@@ -1264,6 +1284,12 @@ int pf_call_set_state(pf_ctx *ctx, const uint8_t *flags, const uint32_t *plus, c
     return PF_OK;
 }
 
+int pf_call_set_format(pf_ctx *ctx, int reference_mt) {
+    if (!ctx) return PF_ERR_ARG;
+    state_of(ctx)->mt_format = reference_mt != 0;
+    return PF_OK;
+}
+
 int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_t *text_len) {
     if (!ctx || !n_rows || !text_len) return PF_ERR_ARG;
     CallState *S = ctx->call;
@@ -1278,6 +1304,7 @@ int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_
     }
     SbArgs a;
     a.flags = S->flags.as<uint8_t>(); a.plus = S->plus.as<uint32_t>(); a.minus = S->minus.as<uint32_t>(); a.N = N; a.colored = colored_rule;
+    a.first_id = S->mt_format ? 0u : 1u;
     a.row_base = S->sb_base.as<uint32_t>(); a.sizes = S->sb_sizes.as<uint32_t>(); a.offs = S->sb_offs.as<uint64_t>(); a.out = nullptr;
     const unsigned grid = (unsigned)((n1 + 255) / 256);
     k_sb_count<<<grid, 256, 0, st>>>(a, S->sb_cnt.as<uint32_t>());
@@ -1691,7 +1718,7 @@ int pf_call_text(pf_ctx *ctx, int slab, uint64_t var_count_base, pf_call_result 
     fa.ct = S->ctask.as<CallTask>(); fa.kept = S->kept.as<uint32_t>(); fa.t0 = t0; fa.nb = nb; fa.res = S->res.as<pf_bubble_result>();
     fa.otext = S->otext.as<char>(); fa.osites = S->osites.as<pf_bubble_site>(); fa.ogroups = S->ogroups.as<uint8_t>();
     fa.oilen = S->oilen.as<uint32_t>(); fa.sv_off = S->sv_off.as<uint64_t>(); fa.sv = S->sv.as<double>(); fa.vc = S->vc.as<uint32_t>();
-    fa.vc_base = var_count_base; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
+    fa.vc_base = var_count_base; fa.mt = S->mt_format ? 1 : 0; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
     for (int s = 0; s < N_STREAMS; ++s) fa.out[s] = nullptr;
     ctx_begin(ctx, PF_K_CALL_FORMAT);
     k_call_format<false><<<(nb + 1 + 255) / 256, 256, 0, st>>>(fa);

@@ -109,6 +109,7 @@ def load_library() -> C.CDLL:
         "pf_gmm_fit": (i, [vp, u32, C.c_double, C.c_double, C.c_int32, C.c_double, vp, vp, vp, vp, vp]),
         "pf_call_set_state": (i, [vp, vp, vp, vp]),
         "pf_call_coverage": (i, [vp]),
+        "pf_call_set_format": (i, [vp, i]),
         "pf_superbubble_rows": (i, [vp, i, C.POINTER(u64), C.POINTER(u64)]),
         "pf_superbubble_fetch": (i, [vp, vp, u64]),
         "pf_call_scan": (i, [vp, u32, u32, C.POINTER(u64)]),
@@ -136,7 +137,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
                     "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
-                    "pf_call_set_state", "pf_superbubble_rows", "pf_superbubble_fetch", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_resolve", "pf_call_select", "pf_call_run", "pf_call_align",
+                    "pf_call_set_state", "pf_call_set_format", "pf_superbubble_rows", "pf_superbubble_fetch", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_resolve", "pf_call_select", "pf_call_run", "pf_call_align",
                     "pf_call_text", "pf_call_fetch", "pf_format_doubles"]
 
 

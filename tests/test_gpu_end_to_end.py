@@ -207,3 +207,49 @@ def _state_after_find(meta, op):
     st = run.state()
     run.close()
     return st
+
+
+T2_CASES = [c for c in ["dip20k", "tet60k", "hex30k", "weird12k", "k31_z16"] if os.path.exists(os.path.join(ROOT, "tests", "golden", c, "expected_t2.json"))]
+
+
+@pytest.mark.parametrize("case", T2_CASES)
+def test_reference_threads_format_matches_the_threaded_reference(case, tmp_path):
+    """the text format of the reference's `-t N` functions (N > 1) -- BubbleId / var_count from 0, the
+    allele_frequency rows of a bubble grouped by arity, rows of arity > 5 absent, penta rows absent for branching bubbles.  The
+    threaded reference numbers unitigs and bubbles and orders rows by thread timing, so the comparison is on the canonical form
+    of tests/t2_canonical.py against fixtures made from `oracle/_ref/PloidyFrost -t 2` (tests/golden/make_t2_golden.py)."""
+    import hashlib
+    import json
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from t2_canonical import canonical
+    meta = load_case(case)
+    op = meta["opts"]
+    want = json.load(open(os.path.join(meta["dir"], "expected_t2.json")))
+    out = tmp_path / "cli"
+    out.mkdir()
+    cmd = [CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "4", "--ref-threads", "2"] + meta["args"]
+    r = subprocess.run(cmd, cwd=str(out), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    assert r.returncode == 0, r.stdout[-2000:]
+    assert "CDBG::findSuperBubble(): Finding superbubbles Cpu time" in r.stdout and "CDBG::PloidyEstimation(): Cpu time" in r.stdout
+    got = canonical(str(out / "PloidyFrost_output"), "g")
+    bad = [k for k, v in want.items() if hashlib.sha256(got[k].encode()).hexdigest() != v["sha256"]]
+    assert not bad, {k: (got[k].count("\n"), want[k]["lines"]) for k in bad}
+    # and the same through the facade, against this run's own `-t 1` files: ids shifted by one, nothing else in the id-bearing files
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    run.set_reference_threads(3)
+    run.set_output_dir(str(tmp_path / "t3"))
+    run.set_unitig_id("g")
+    run.find_superbubbles("g")
+    run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+    exp = os.path.join(meta["dir"], "expected")
+    rows1 = open(os.path.join(exp, "g_super_bubble.txt")).read().splitlines()[1:]
+    rows3 = open(tmp_path / "t3" / "g_super_bubble.txt").read().splitlines()[1:]
+    assert [r.split("\t", 1)[1] for r in rows1] == [r.split("\t", 1)[1] for r in rows3]
+    assert [int(r.split("\t", 1)[0]) for r in rows3] == list(range(len(rows3)))
+    a1 = open(os.path.join(exp, "g_alignseq.txt")).read().splitlines()
+    a3 = open(tmp_path / "t3" / "g_alignseq.txt").read().splitlines()
+    assert [r.split("\t", 1)[1] for r in a1] == [r.split("\t", 1)[1] for r in a3]
+    assert [int(r.split("\t", 1)[0]) - 1 for r in a1] == [int(r.split("\t", 1)[0]) for r in a3]
+    for name in ("bifre", "trifre", "tetrafre", "pentafre"):
+        assert open(os.path.join(exp, "g_%s.txt" % name), "rb").read() == open(tmp_path / "t3" / ("g_%s.txt" % name), "rb").read()
+    run.close()
