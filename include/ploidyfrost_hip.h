@@ -46,6 +46,8 @@ typedef struct pf_ctx pf_ctx;
 
 /* ---- context ------------------------------------------------------------------------- */
 int pf_create(int device, pf_ctx **out);
+/* Optional: initialise the HIP runtime and the device ahead of pf_create, e.g. on a helper thread while input files are read. */
+int pf_warmup(int device);
 void pf_destroy(pf_ctx *);
 const char *pf_last_error(const pf_ctx *); /* ctx may be NULL: last creation error */
 /* Launch on this hipStream_t (e.g. torch's current stream) instead of the context's own. */

@@ -67,12 +67,53 @@ static void bind_to_device_node(pf_ctx *ctx) {
     if (getenv("PF_TRACE_LOAD")) fprintf(stderr, "[load] GPU %s on NUMA node %d: host threads on %d of %d CPUs\n", bdf, node, n_want, CPU_COUNT(&now));
 }
 
-int CDBG::init_device(int device) {
+CountsLoader::~CountsLoader() {
+    wait();
+    if (ctx) pf_destroy(ctx);
+}
+
+void CountsLoader::start(int device, const std::string &kmc_prefix) {
+    th_ = std::thread([this, device, kmc_prefix] {
+        LoadTrace trace;
+        status = pf_create(device, &ctx);
+        if (status != PF_OK) { error = std::string("CDBG::CDBG():Error: ") + pf_last_error(nullptr); return; }
+        trace.mark("device: context (beside the graph read)");
+        KmcRecords db;
+        std::string e;
+        if (!db.load(kmc_prefix, e)) { status = PF_ERR_ARG; error = "CDBG::CDBG():Error: Open kmc database error . (" + e + ")"; return; }
+        both_strands = db.both_strands;
+        k = (int)db.k;
+        uint64_t *dk = nullptr;
+        uint32_t *dc = nullptr;
+        status = pf_kmc_decode(ctx, db.records, db.total, db.suffix_bytes, db.counter_size, db.lut.data(), db.n_lut(), db.lut_prefix_len, db.k, &dk, &dc);
+        if (status == PF_OK) status = pf_upload_counts(ctx, dk, dc, db.total, db.min_count, db.max_count, db.both_strands);
+        pf_device_free(ctx, dk);
+        pf_device_free(ctx, dc);
+        if (status != PF_OK) error = std::string("CDBG::CDBG():Error: ") + pf_last_error(ctx);
+        trace.mark("kmc: device decode + table (beside the graph read)");
+    });
+}
+
+int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
     LoadTrace trace;
-    int st = pf_create(device, &ctx_);
+    int st = PF_OK;
+    if (adopt) ctx_ = adopt;
+    else st = pf_create(device, &ctx_);
     trace.mark("device: context");
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: " + pf_last_error(nullptr));
     bind_to_device_node(ctx_);
+    if (!getenv("PF_NO_PREALLOC")) {
+        const uint64_t n_est = g_.n();
+        prealloc_ = std::thread([this, n_est, colored] {
+            bx_.bfs_rec.ensure(ctx_, n_est * 7 / 10 + 4096);            // ~0.67 candidates per unitig
+            bx_.bfs_pool.ensure(ctx_, n_est * 7 / 10 * 6 + (5u << 20));
+            sb_text_.ensure(ctx_, n_est * 19 + 4096);                      // ~0.63 rows of ~29 bytes per unitig
+            if (!colored) {   // text slabs of the resident calling pipeline
+                cx_.slab[0].ensure(ctx_, 64u << 20);
+                cx_.slab[1].ensure(ctx_, 64u << 20);
+            }
+        });
+    }
     st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));
     trace.mark("device: graph upload");
@@ -109,12 +150,23 @@ int CDBG::init_device(int device) {
 }
 
 CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db, int device,
-           bool quiet)
+           bool quiet, CountsLoader *counts)
     : g_(graph), complex_size_(complexsize), quiet_(quiet) {
     sc_.match = m;
     sc_.mismatch = d;
     sc_.gap = g;
     if (const char *e = getenv("PF_CALL")) resident_ = strcmp(e, "host") != 0;  // measurements: the host-threaded pipeline
+    if (counts) {
+        // the count table was built while the graph file was read: adopt its context, then the graph goes in (the join of graph
+        // k-mers with the table runs as soon as both are there, whichever comes second)
+        counts->wait();
+        if (counts->status != PF_OK) { fail(counts->status, counts->error); return; }
+        if (counts->k != g_.k) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: k of the kmc database differs from the graph's"); return; }
+        both_strands_ = counts->both_strands;
+        if (init_device(device, counts->release())) return;
+        if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");
+        return;
+    }
     if (init_device(device)) return;
     if (!kmc_db.empty()) {
         LoadTrace trace;
@@ -143,7 +195,7 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     sc_.mismatch = d;
     sc_.gap = g;
     tag_ = "CCDBG";
-    init_device(device);
+    init_device(device, nullptr, true);
 }
 
 int CDBG::set_reference_threads(size_t n) {
@@ -151,6 +203,14 @@ int CDBG::set_reference_threads(size_t n) {
     mt_format_ = n > 1;
     const int st = pf_call_set_format(ctx_, mt_format_ ? 1 : 0);
     return st == PF_OK ? 0 : fail(st, pf_last_error(ctx_));
+}
+
+int CDBG::join_pending_ids() {
+    if (pending_ids_.joinable()) {
+        pending_ids_.join();
+        if (pending_ids_rc_) { pending_ids_rc_ = 0; return fail(PF_ERR_ARG, "CDBG:: Open Unitig_Id file error"); }
+    }
+    return 0;
 }
 
 int CDBG::join_pending_write() {
@@ -162,6 +222,8 @@ int CDBG::join_pending_write() {
 }
 
 CDBG::~CDBG() {
+    join_prealloc();
+    join_pending_ids();
     join_pending_write();
     bx_.release_all();  // pinned buffers go before the context
     for (auto &a : ax_) a.release_all();
@@ -230,27 +292,58 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
     if (!quiet_) printf("%s::setUnitigId(): Setting Unitig Id\n", tag_);
     clock_t c0 = clock();
     time_t w0 = time(nullptr);
-    // `id<TAB>sequence` rows, formatted in unitig ranges side by side and written in order
+    // `id<TAB>sequence` rows: every unitig range knows where its rows start (digits of the ids + lengths), formats them and writes
+    // them at that offset, ranges side by side.  With overlap_output the whole file is written behind the caller's back (it depends
+    // on nothing the phases compute) and is complete when PloidyEstimation, the next setUnitigId or the destructor returns.
     const unsigned T = threads_ ? threads_ : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
-    constexpr size_t UCH = 65536;
-    std::vector<std::string> parts(n_chunks_of(g_.n(), UCH));
-    parallel_chunks(g_.n(), UCH, T, [&](size_t ci, size_t u0, size_t u1) {
-        std::string &out = parts[ci];
-        out.reserve((size_t)(g_.off[u1] - g_.off[u0]) + (u1 - u0) * 10);
-        for (size_t u = u0; u < u1; ++u) {
-            put_uint(out, u + 1);
-            out.push_back('\t');
-            std::string_view s = g_.seq((uint32_t)u);
-            out.append(s.data(), s.size());
-            out.push_back('\n');
-        }
-    });
-    {
-        std::vector<const std::string *> pieces;
-        for (const std::string &p : parts) pieces.push_back(&p);
-        uint64_t bytes = 0;
-        if (write_pieces(outpre + "_Unitig_Id.txt", pieces, bytes)) return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + "_Unitig_Id.txt file error");
-        out_bytes_ += bytes;
+    if (join_pending_ids()) return status_;
+    auto job = [this, name = outpre + "_Unitig_Id.txt", T]() -> int {
+        constexpr size_t UCH = 32768;
+        const size_t N = g_.n(), n_ch = n_chunks_of(N, UCH);
+        std::vector<uint64_t> base(n_ch + 1, 0);
+        parallel_chunks(N, UCH, T, [&](size_t ci, size_t u0, size_t u1) {
+            uint64_t b = (uint64_t)(g_.off[u1] - g_.off[u0]) + 2 * (u1 - u0);
+            for (size_t u = u0; u < u1; ++u) {
+                uint64_t id = u + 1;
+                do { ++b; id /= 10; } while (id);
+            }
+            base[ci + 1] = b;
+        });
+        for (size_t c = 0; c < n_ch; ++c) base[c + 1] += base[c];
+        ids_bytes_ = base[n_ch];
+        if (!write_files_) return 0;
+        const int fd = open((outdir_ + "/" + name).c_str(), O_WRONLY | O_CREAT, 0666);
+        if (fd < 0) return 1;
+        std::vector<int> rc(n_ch, 0);
+        parallel_chunks(N, UCH, T, [&](size_t ci, size_t u0, size_t u1) {
+            std::string out;
+            out.reserve((size_t)(base[ci + 1] - base[ci]));
+            for (size_t u = u0; u < u1; ++u) {
+                put_uint(out, u + 1);
+                out.push_back('\t');
+                std::string_view sq = g_.seq((uint32_t)u);
+                out.append(sq.data(), sq.size());
+                out.push_back('\n');
+            }
+            uint64_t at = base[ci], left = out.size();
+            const char *src = out.data();
+            while (left) {
+                const ssize_t w = pwrite(fd, src, left, (off_t)at);
+                if (w <= 0) { rc[ci] = 1; return; }
+                left -= (uint64_t)w;
+                src += w;
+                at += (uint64_t)w;
+            }
+        });
+        int bad = ftruncate(fd, (off_t)base[n_ch]) != 0;
+        close(fd);
+        for (int x : rc) bad |= x;
+        return bad;
+    };
+    if (overlap_output_) {
+        pending_ids_ = std::thread([this, job] { pending_ids_rc_ = job(); });
+    } else {
+        if (job()) return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + "_Unitig_Id.txt file error");
     }
     if (!quiet_) {
         printf("%s::setUnitigId(): Cpu time : %gs\n", tag_, (double)(clock() - c0) / CLOCKS_PER_SEC);

@@ -51,10 +51,29 @@ struct PhaseTimes {
     uint64_t candidates = 0, bfs_deferred = 0, bubbles_out = 0, tasks = 0, align_jobs = 0, site_strings = 0;
 };
 
+// The count database on its way to HBM while the caller is still reading the graph file: context creation, header / prefix
+// table parse, K-KMC decode and the table build need nothing from the graph, so a front end starts them first
+// (CountsLoader::start) and hands the loader to the CDBG constructor, which waits for it and adopts its context.
+struct CountsLoader {
+    ~CountsLoader();
+    void start(int device, const std::string &kmc_prefix);
+    // valid after wait()
+    pf_ctx *ctx = nullptr;
+    int status = 0;
+    std::string error;
+    bool both_strands = true;
+    int k = 0;
+    void wait() { if (th_.joinable()) th_.join(); }
+    pf_ctx *release() { pf_ctx *c = ctx; ctx = nullptr; return c; }
+
+private:
+    std::thread th_;
+};
+
 class CDBG {
 public:
     CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db = "",
-         int device = 0, bool quiet = false);
+         int device = 0, bool quiet = false, CountsLoader *counts = nullptr);
     virtual ~CDBG();
     CDBG(const CDBG &) = delete;
     CDBG &operator=(const CDBG &) = delete;
@@ -117,7 +136,7 @@ protected:
     // graph + adjacency on the device, no count database yet (the colored subclass brings its own)
     struct NoCounts {};
     CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, int device, bool quiet, NoCounts);
-    int init_device(int device);
+    int init_device(int device, pf_ctx *adopt = nullptr, bool colored = false);
     // the path proper; cutoff holds one (lower, upper) pair (single sample) or one per colour
     int ploidy_estimation(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
     // the same through pf_call_* (pf_cdbg_call.cpp); call_select = scan + the sequential pass of the driver loop
@@ -136,6 +155,14 @@ protected:
     pf_call_result slice_res_ = {};
     int fail(int st, const std::string &msg);
     int join_pending_write();
+    int join_pending_ids();
+    // pinned exchange buffers of the first pass, allocated on a helper thread while the graph goes to the device (page-locking
+    // a few hundred MB costs tens of milliseconds; sizes are estimates from the unitig count, the phases grow them if needed)
+    std::thread prealloc_;
+    void join_prealloc() { if (prealloc_.joinable()) prealloc_.join(); }
+    std::thread pending_ids_;
+    int pending_ids_rc_ = 0;
+    uint64_t ids_bytes_ = 0;
     int launch_coverage();
     uint64_t find_passes_ = 0;
     bool cov_ready_ = false;  // the coverage arrays in bx_ are those of the current graph and count table

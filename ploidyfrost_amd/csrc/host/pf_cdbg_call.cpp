@@ -363,7 +363,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     }
     if (wst != PF_OK) return fail(wst, std::string(tag_) + "::PloidyEstimation(): " + werr);
     auto t0 = clk::now();
-    if (join_pending_write()) return status_;
+    if (join_pending_write() || join_pending_ids()) return status_;
     for (OutFile &of : files) {
         out_bytes_ += of.bytes;
         if (of.fd >= 0) {

@@ -24,6 +24,7 @@ namespace pfh {
 // ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
 int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thr) {
     if (status_) return status_;
+    join_prealloc();
     if (join_pending_write()) return status_;
     if (!quiet_) printf("%s::findSuperBubble(): Finding superbubbles\n", tag_);
     if (write_files_ && ensure_dir()) return status_;
@@ -42,11 +43,11 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // coverage kernel PloidyEstimation starts with -- while this thread replays the records of the finished slices in
     // the reference's visiting order, with its `partner == NULL` gate (src/CDBG.cpp:206, 211): records come in
     // ascending oriented-vertex order = unitig order, '+' before '-'.
-    // Slicing costs when a graph has chromosome-long traversals: each slice would run its own serially instead of all of
-    // them side by side.  So the first pass over a graph is one slice, and later passes are sliced only if none was seen.
+    // The unitig range is cut into slices so that the replay of slice i overlaps the traversal of slice i + 1.  With the long
+    // traversals on host cores a slice's own are walked in a few milliseconds, side by side; only with the device's third tier
+    // (one wavefront per giant traversal, run slice after slice) is the first pass over a graph kept in one piece.
     constexpr int kMaxSlices = 4;
-    // (with the long traversals on host cores a slice's own are walked in a few milliseconds: no reason to avoid slicing then)
-    const int kSlices = (find_passes_ > 0 && (times_.bfs_large == 0 || third_tier_on_host_)) ? kMaxSlices : 1;
+    const int kSlices = (third_tier_on_host_ || (find_passes_ > 0 && times_.bfs_large == 0)) ? kMaxSlices : 1;
     ++find_passes_;
     uint32_t s_u0[kMaxSlices + 1];
     uint64_t s_cand[kMaxSlices], s_rec0[kMaxSlices + 1], s_pool0[kMaxSlices + 1], s_nrec[kMaxSlices], s_used[kMaxSlices];
@@ -276,6 +277,7 @@ int CDBG::finish_find(const std::string &outpre, const size_t &thr, clk_time t_a
 // vertex lists are left self-contained in shard_rec_ / shard_pool_ (list_off relative to shard_pool_) for the exchange.
 int CDBG::find_shard(uint32_t u0, uint32_t u1) {
     if (status_) return status_;
+    join_prealloc();
     const uint32_t N = g_.n();
     if (u0 > u1 || u1 > N) return fail(PF_ERR_ARG, "CDBG::find_shard(): range outside the graph");
     const auto tb = clk::now();

@@ -1208,7 +1208,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     }
     tp("pipeline done");
     t0 = clk::now();
-    if (join_pending_write()) { close_files(); return status_; }
+    if (join_pending_write() || join_pending_ids()) { close_files(); return status_; }
     close_files();
     for (OutFile &of : files) {
         out_bytes_ += of.bytes;

@@ -9,6 +9,7 @@
 // path) is outside this build's scope and says so.
 #include <getopt.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <chrono>
 #include <cstdio>
@@ -356,9 +357,16 @@ int main(int argc, char **argv) {
         return 0;
     }
 
+    // the device context and the count table are built on a helper thread while the graph file is read
+    pfh::CountsLoader counts;
+    counts.start(0, opt.db);
     pfh::UnitigSet graph;
     std::string err;
     auto t0 = std::chrono::steady_clock::now();
+    const bool trace_main = getenv("PF_TRACE_LOAD") != nullptr;
+    auto mark = [&](const char *what) {
+        if (trace_main) fprintf(stderr, "[main] %-28s %.3fs since start\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+    };
     if (!graph.load_gfa(opt.graphfile, err, true)) {  // abundant k-mers are decided with the device (K-MINZ) in the CDBG constructor
         cout << "CompactedDBG::read(): Graph could not be loaded! Exit. (" << err << ")" << endl;
         exit(EXIT_FAILURE);
@@ -366,8 +374,12 @@ int main(int argc, char **argv) {
     cout << "CompactedDBG::read(): Graph loading successful" << endl;
 
     cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
+    mark("graph file read");
 
-    pfh::CDBG g(graph, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db);
+    // (on the heap and never destroyed: at the end of main the process leaves through quick_exit -- giving 12 GB of device and
+    // pinned memory back piece by piece takes longer than some of the phases)
+    pfh::CDBG &g = *new pfh::CDBG(graph, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db, 0, false, &counts);
+    mark("graph + counts on the device");
     auto die = [&]() {
         cerr << g.error() << endl;
         exit(EXIT_FAILURE);
@@ -381,10 +393,13 @@ int main(int argc, char **argv) {
     if (getenv("PF_BFS_HUGE_ON_DEVICE")) g.set_third_tier_on_host(false);   // experiments: giant traversals on one wavefront each
     if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
     if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
+    mark("setUnitigId");
     if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) die();
+    mark("findSuperBubble");
     cout << "CDBG:: Minimum Coverage:" << opt.coverage_lower << endl;
     cout << "CDBG:: Maximum Coverage:" << opt.coverage_upper << endl;
     if (g.ploidyEstimation_multithread_ptr(opt.outprefix, opt.coverage_lower, opt.coverage_upper, opt.nb_threads)) die();
+    mark("PloidyEstimation");
     if (opt.verbose) {
         const pfh::PhaseTimes &t = g.times();
         printf("[device] candidates %llu (big tier %llu)  bfs %.3fs replay %.3fs | cov %.3fs tasks %.3fs (%llu) align %.3fs (%llu jobs) "
@@ -398,5 +413,10 @@ int main(int argc, char **argv) {
         printf("[host]   scan %.3fs | align: build %.3fs device-call %.3fs post %.3fs choose %.3fs\n", t.scan_s, t.align_build_s,
                t.align_device_s, t.align_post_s, t.align_choose_s);
     }
-    return 0;
+    // every result file is complete (PloidyEstimation joined the background writers): leave without walking the destructors
+    cout.flush();
+    cerr.flush();
+    fflush(nullptr);
+    mark("done");
+    _exit(0);
 }

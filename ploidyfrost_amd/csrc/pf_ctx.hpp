@@ -56,7 +56,8 @@ struct pf_ctx {
     // k-mer count table (HBM): open addressing, 16-B slots, capacity = power of two >= 2n
     pf::Slot *d_tab = nullptr;
     uint64_t tab_cap = 0, tab_n = 0;
-    bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked at upload)
+    bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked once table and k are both known)
+    bool tab_strands_checked = false;
     bool tab_exact = false;       // database built without canonical counting: no composite lookups
     uint64_t tab_max_count = 0;   // upper count filter of the last upload (decides the width of K-COV's row sums)
 

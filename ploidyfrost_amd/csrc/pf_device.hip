@@ -189,6 +189,36 @@ __global__ void k_adj_probe(const Slot *__restrict__ t, uint64_t mask, const uin
     }
 }
 
+// graph upload: per-unitig checks and k-mer counts; then, from the scanned counts, the window / row -> unitig maps and the
+// unitig-start bits the k-mer-parallel kernels use
+__global__ void k_graph_check(const uint64_t *__restrict__ off, const uint32_t *__restrict__ len, uint32_t N, int k, uint64_t total_words,
+                              uint64_t *__restrict__ cnt, unsigned int *bad) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > N) return;
+    if (u == N) { cnt[u] = 0; return; }
+    const uint32_t L = len[u];
+    const uint64_t a = off[u], b = off[u + 1];
+    unsigned int e = 0;
+    if (L < (uint32_t)k) e |= 1;
+    if (b < a || (b - a) * 32 < L || b > total_words) e |= 2;
+    if (e) atomicOr(bad, e);
+    cnt[u] = L >= (uint32_t)k ? (uint64_t)(L - (uint32_t)k + 1) : 0;
+}
+__global__ void k_fill_u32(uint32_t *p, uint64_t n, uint32_t v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void k_graph_index(const uint64_t *__restrict__ kpre, uint32_t N, uint64_t n_win, uint64_t n_row, uint32_t *__restrict__ kwin,
+                              uint32_t *__restrict__ krow, uint64_t *__restrict__ khead) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u > N) return;
+    const uint64_t g0 = kpre[u];
+    atomicOr((unsigned long long *)&khead[g0 >> 6], 1ull << (g0 & 63));   // u == N: the bit behind the last k-mer
+    if (u == N) return;
+    const uint64_t g1 = kpre[u + 1];
+    for (uint64_t w = (g0 + 255) >> 8; w < n_win && (w << 8) < g1; ++w) kwin[w] = u;
+    for (uint64_t r = (g0 + 63) >> 6; r < n_row && (r << 6) < g1; ++r) krow[r] = u;
+}
+
 __global__ void k_mark_candidates(const uint32_t *__restrict__ succ, uint32_t n_ov, uint8_t *__restrict__ flag) {
     uint32_t ov = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t stride = gridDim.x * blockDim.x;
@@ -595,11 +625,21 @@ static int stage_in(pf_ctx *ctx, const T *src, size_t n, T **dev, bool *owned) {
     return PF_OK;
 }
 
+static int check_table_strands(pf_ctx *ctx);
+
 extern "C" {
 
 const char *pf_kernel_name(int kernel) { return (kernel >= 0 && kernel < PF_K_COUNT_) ? kKernelNames[kernel] : "?"; }
 
 const char *pf_last_error(const pf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+
+int pf_warmup(int device) {
+    // brings up the HIP runtime and the device's primary context (a tenth of a second): a caller with other work to do first --
+    // reading its input files -- runs this on a helper thread and finds pf_create instant later
+    if (hipSetDevice(device) != hipSuccess) { (void)hipGetLastError(); return PF_ERR_NO_DEVICE; }
+    if (hipFree(nullptr) != hipSuccess) { (void)hipGetLastError(); return PF_ERR_HIP; }
+    return PF_OK;
+}
 
 int pf_create(int device, pf_ctx **out) {
     if (!out) return PF_ERR_ARG;
@@ -762,58 +802,53 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
     PF_HIP(hipMemcpyAsync(ctx->d_off, seq_off, ((size_t)N + 1) * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ctx->d_len, len_bp, (size_t)N * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
-    // host-side validation of what the kernels assume (lengths >= k, offsets cover lengths)
-    std::vector<uint32_t> hl(N);
-    std::vector<uint64_t> ho((size_t)N + 1);
-    PF_HIP(hipMemcpy(hl.data(), ctx->d_len, (size_t)N * 4, hipMemcpyDeviceToHost));
-    PF_HIP(hipMemcpy(ho.data(), ctx->d_off, ((size_t)N + 1) * 8, hipMemcpyDeviceToHost));
-    uint64_t nk = 0;
-    for (uint32_t u = 0; u < N; ++u) {
-        if (hl[u] < (uint32_t)k) { ctx->err = "unitig shorter than k"; free_graph(ctx); return PF_ERR_ARG; }
-        if (ho[u + 1] < ho[u] || (ho[u + 1] - ho[u]) * 32 < hl[u] || ho[u + 1] > total_words) {
-            ctx->err = "seq_off does not cover len_bp";
+    // validation of what the kernels assume (lengths >= k, offsets cover lengths) and the k-mer numbering of the k-mer-parallel
+    // kernels, all on the device: d_kpre = exclusive scan of the k-mers per unitig; d_kwin[w] / d_krow[r] = the unitig holding
+    // k-mer 256 w / 64 r; d_khead = one bit per k-mer (unitig starts, plus the end of the last one)
+    {
+        DevTmp<uint64_t> cnt_;
+        DevTmp<unsigned int> bad_;
+        PF_HIP(cnt_.alloc(((size_t)N + 1) * 8));
+        PF_HIP(bad_.alloc(4));
+        PF_HIP(hipMemsetAsync(bad_.p, 0, 4, ctx->stream));
+        k_graph_check<<<(N + 1 + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_off, ctx->d_len, N, k, total_words, cnt_.p, bad_.p);
+        PF_HIP(hipMalloc(&ctx->d_kpre, ((size_t)N + 1) * 8));
+        size_t tmp_bytes = 0;
+        PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt_.p, ctx->d_kpre, (int)(N + 1), ctx->stream));
+        DevTmp<uint8_t> tmp_;
+        PF_HIP(tmp_.alloc(tmp_bytes));
+        PF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp_.p, tmp_bytes, cnt_.p, ctx->d_kpre, (int)(N + 1), ctx->stream));
+        unsigned int bad = 0;
+        uint64_t nk = 0;
+        PF_HIP(hipMemcpyAsync(&bad, bad_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipMemcpyAsync(&nk, ctx->d_kpre + N, 8, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+        if (bad) {
+            ctx->err = (bad & 1) ? "unitig shorter than k" : "seq_off does not cover len_bp";
             free_graph(ctx);
             return PF_ERR_ARG;
         }
-        nk += hl[u] - k + 1;
-    }
-    ctx->n_kmers = nk;
-    ctx->h_len = hl;
-    // k-mer numbering for the k-mer-parallel kernels
-    {
-        std::vector<uint64_t> kpre((size_t)N + 1);
+        ctx->n_kmers = nk;
         const uint64_t n_win = nk / 256 + 1;
-        std::vector<uint32_t> kwin(n_win);
-        uint64_t g = 0, w = 0;
-        for (uint32_t u = 0; u < N; ++u) {
-            kpre[u] = g;
-            g += hl[u] - k + 1;
-            for (; w < n_win && w * 256 < g; ++w) kwin[w] = u;
-        }
-        kpre[N] = g;
-        for (; w < n_win; ++w) kwin[w] = N - 1;
-        PF_HIP(hipMalloc(&ctx->d_kpre, ((size_t)N + 1) * 8));
-        PF_HIP(hipMalloc(&ctx->d_kwin, n_win * 4));
-        PF_HIP(hipMemcpy(ctx->d_kpre, kpre.data(), ((size_t)N + 1) * 8, hipMemcpyHostToDevice));
-        PF_HIP(hipMemcpy(ctx->d_kwin, kwin.data(), n_win * 4, hipMemcpyHostToDevice));
-        ctx->n_kwin = n_win;
-        // segment description for the streaming K-COV: one bit per k-mer (unitig starts, plus the end of the last one)
-        // and the unitig of every 64th k-mer
         const uint64_t n_row = nk / 64 + 1, n_row_pad = n_row + 8;  // padded: the four-per-lane kernel reads whole super-rows (4 words)
-        std::vector<uint64_t> khead(n_row_pad, 0);
-        std::vector<uint32_t> krow(n_row_pad, N - 1);
-        uint64_t r = 0;
-        for (uint32_t u = 0; u < N; ++u) {
-            khead[kpre[u] >> 6] |= 1ull << (kpre[u] & 63);
-            for (; r < n_row && r * 64 < kpre[u + 1]; ++r) krow[r] = u;
-        }
-        khead[nk >> 6] |= 1ull << (nk & 63);
-        for (; r < n_row; ++r) krow[r] = N - 1;
+        PF_HIP(hipMalloc(&ctx->d_kwin, n_win * 4));
         PF_HIP(hipMalloc(&ctx->d_khead, n_row_pad * 8));
         PF_HIP(hipMalloc(&ctx->d_krow, n_row_pad * 4));
-        PF_HIP(hipMemcpy(ctx->d_khead, khead.data(), n_row_pad * 8, hipMemcpyHostToDevice));
-        PF_HIP(hipMemcpy(ctx->d_krow, krow.data(), n_row_pad * 4, hipMemcpyHostToDevice));
+        PF_HIP(hipMemsetAsync(ctx->d_khead, 0, n_row_pad * 8, ctx->stream));
+        k_fill_u32<<<ctx_grid(ctx, n_win, 256, 8), 256, 0, ctx->stream>>>(ctx->d_kwin, n_win, N - 1);
+        k_fill_u32<<<ctx_grid(ctx, n_row_pad, 256, 8), 256, 0, ctx->stream>>>(ctx->d_krow, n_row_pad, N - 1);
+        k_graph_index<<<(N + 1 + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_kpre, N, n_win, n_row, ctx->d_kwin, ctx->d_krow, ctx->d_khead);
+        PF_HIP(hipGetLastError());
+        ctx->n_kwin = n_win;
         ctx->n_krow = n_row;
+        // host copy of the lengths (argument validation of later calls)
+        ctx->h_len.resize(N);
+        PF_HIP(hipMemcpyAsync(ctx->h_len.data(), ctx->d_len, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PF_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    if (ctx->d_tab && !ctx->tab_strands_checked) {
+        const int rc = check_table_strands(ctx);
+        if (rc) return rc;
     }
     if (ctx->d_tab && !ctx->tab_exact) return pf::join_graph_counts(ctx);
     return PF_OK;
@@ -929,6 +964,22 @@ int pf_copy_to_host(pf_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
     return PF_OK;
 }
 
+// one orientation per k-mer?  (decides the probe order of the composite lookup, never its result)
+static int check_table_strands(pf_ctx *ctx) {
+    ctx->tab_strands_checked = true;
+    ctx->tab_one_strand = false;
+    if (!ctx->d_tab || !ctx->tab_n || !ctx->k) return PF_OK;
+    DevTmp<unsigned int> flag_;
+    unsigned int h_flag = 0;
+    PF_HIP(flag_.alloc(4));
+    PF_HIP(hipMemsetAsync(flag_.p, 0, 4, ctx->stream));
+    k_table_two_strands<<<ctx_grid(ctx, ctx->tab_cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap, ctx->k, flag_.p);
+    PF_HIP(hipMemcpyAsync(&h_flag, flag_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->tab_one_strand = h_flag == 0;
+    return PF_OK;
+}
+
 int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t min_count,
                      uint64_t max_count, int both_strands) {
     if (!ctx || (n && (!kmers || !counts))) return PF_ERR_ARG;
@@ -968,18 +1019,11 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
         k_table_build<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap - 1, pk, pc, n, min_count, max_count);
         ctx_end(ctx);
     }
-    // one orientation per k-mer?  (decides the probe order of the composite lookup, never its result)
-    {
-        DevTmp<unsigned int> flag_;
-        unsigned int h_flag = 0;
-        PF_HIP(flag_.alloc(4));
-        unsigned int *d_flag = flag_.p;
-        PF_HIP(hipMemsetAsync(d_flag, 0, 4, ctx->stream));
-        if (n && ctx->k)
-            k_table_two_strands<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap, ctx->k, d_flag);
-        PF_HIP(hipMemcpyAsync(&h_flag, d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
-        PF_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->tab_one_strand = (n && ctx->k) ? h_flag == 0 : false;
+    ctx->tab_one_strand = false;
+    ctx->tab_strands_checked = false;
+    if (ctx->k) {   // k comes with the graph: a table uploaded first is checked when the graph arrives
+        const int rc = check_table_strands(ctx);
+        if (rc) return rc;
     }
     if (ctx->d_seq && !ctx->tab_exact) return pf::join_graph_counts(ctx);
     return PF_OK;

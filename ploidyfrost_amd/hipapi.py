@@ -66,6 +66,7 @@ def load_library() -> C.CDLL:
     vp, u32, u64, i = C.c_void_p, C.c_uint32, C.c_uint64, C.c_int
     sig = {
         "pf_create": (i, [i, C.POINTER(vp)]),
+        "pf_warmup": (i, [i]),
         "pf_destroy": (None, [vp]),
         "pf_last_error": (C.c_char_p, [vp]),
         "pf_set_stream": (i, [vp, vp]),
@@ -130,7 +131,7 @@ def load_library() -> C.CDLL:
     return L
 
 
-DECLARED_SYMBOLS = ["pf_create", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
+DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
                     "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
