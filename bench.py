@@ -230,7 +230,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--unitigs", type=int, default=5_000_000,
                     help="target unitigs of the graph (default 5 M = BASELINE.json configs[2], the config the metric and the north-star target are quoted on)")
-    ap.add_argument("--cpu-sample-unitigs", type=int, default=250_000)
+    ap.add_argument("--cpu-sample-unitigs", type=int, default=150_000,
+                    help="size of the reference's sample graph: ~6 s per -t 1 run at 150 k unitigs; its time grows faster than the graph "
+                         "(a 250 k sample with chromosome-long traversals takes 75 s, the 5 M graph 700 s)")
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per rank (0 = min(32, cpus/ranks))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -451,7 +453,8 @@ def main():
                                             "the shared files" % shard_stats.get("find_gathered_bytes", 0) if strong else
                                             "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
                                             "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0])},
-                "roofline": roof, "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
+                "roofline": roof, "roofline_issue": issue_roofline(dom, kernels[dom]["avg_ms"], n_unitigs) if dom else None,
+                "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for e in kernels.values()), 3),
                 "first_pass": first_pass, "load_s": round(load_s, 3), "sharded_output_check": sharded_identical,
                 "kernels": kernels, "k_cov_probe": probe,
@@ -484,6 +487,32 @@ def main():
             dist.destroy_process_group()
         if not args.keep:
             shutil.rmtree(workdir, ignore_errors=True)
+
+
+def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):
+    """Instruction-issue roofline of a kernel that is bound by issue, not by HBM (K-BUBBLE: its DP lives in registers and LDS):
+    vector instructions per launch (SQ_INSTS_VALU, rocprofv3 --pmc pass of this command on this workload, committed as
+    profiles/pmc_sq.json) / the launch's measured duration, against what the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4
+    cycles per wave64 vector instruction (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') = 614 G instructions/s.
+    None when the committed counters are of another workload."""
+    p = os.path.join(ROOT, "profiles", "pmc_sq.json")
+    try:
+        with open(p) as f:
+            d = json.load(f)
+    except (OSError, ValueError):
+        return None
+    if (d.get("_meta") or {}).get("unitigs") != n_unitigs or kernel not in d or not avg_ms:
+        return None
+    e = d[kernel]
+    valu, salu = e.get("SQ_INSTS_VALU"), e.get("SQ_INSTS_SALU")
+    if not valu:
+        return None
+    peak = 256 * 4 * 2.4e9 / 4
+    ach = valu / (avg_ms * 1e-3)
+    return {"kernel": kernel, "bound": "valu-issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instructions/s",
+            "frac": round(ach / peak, 4), "valu_per_launch": valu, "salu_per_launch": salu,
+            "wave_cycle_shares": {k[6:]: v for k, v in e.items() if k.startswith("share_")},
+            "source": "profiles/pmc_sq.json (SQ counters per launch) / live HIP-event duration"}
 
 
 def load_traffic(kernel: str, n_unitigs: int | None = None):

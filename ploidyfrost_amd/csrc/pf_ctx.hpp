@@ -119,7 +119,7 @@ void call_destroy(pf_ctx *ctx);     // pf_call.hip
 void call_invalidate(pf_ctx *ctx);  // graph or count table replaced
 enum WsSlot {
     WS_ALN_TEXT = 0, WS_ALN_JOBS, WS_ALN_SMALL, WS_ALN_RETRY, WS_ALN_IDX, WS_ALN_OFIRST, WS_ALN_OCOUNT, WS_ALN_OHITS, WS_ALN_OTEXT,
-    WS_ALN_OGAPS, WS_ALN_STTEXT, WS_ALN_STGAPS, WS_ALN_STHITS, WS_ALN_WORK, WS_BFS_REC, WS_BFS_POOL, WS_BFS_SMALL, WS_BFS_DEF,
+    WS_ALN_OGAPS, WS_ALN_STTEXT, WS_ALN_STGAPS, WS_ALN_STHITS, WS_ALN_WORK, WS_BFS_REC, WS_BFS_POOL, WS_BFS_SMALL, WS_BFS_DEF, WS_BFS_WLIST,
     WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS,
     WS_BUB_TEXT, WS_BUB_PATHS, WS_BUB_TASKS, WS_BUB_SMALL, WS_BUB_RETRY, WS_BUB_IDX, WS_BUB_RES, WS_BUB_OTEXT, WS_BUB_OSITES,
     WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_BUB_IDX2, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART, WS_COUNT_

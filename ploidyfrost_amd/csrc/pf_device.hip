@@ -420,8 +420,76 @@ __device__ inline void bfs_emit(const BfsOut &o, BfsAlloc &al, uint64_t ci, uint
     }
 }
 
+// thread tier (pf_bfs.hpp): one thread per candidate; what outgrows its 8-entry tables is listed for the wavefront tier
+__global__ __launch_bounds__(256) void k_bfs_thread(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
+                                                    const uint32_t *__restrict__ cand, uint64_t c0, uint64_t c1, BfsOut o, uint32_t *wave_list,
+                                                    unsigned int *n_wave_list) {
+    __shared__ uint32_t s_ent[BFS_THREAD_CAP * 256];
+    __shared__ uint32_t s_todo[BFS_THREAD_CAP * 256];
+    __shared__ uint32_t s_cyc[BFS_THREAD_CAP * 256];
+    __shared__ uint8_t s_meta[BFS_THREAD_CAP * 256];
+    const uint32_t tid = threadIdx.x;
+    const BfsThreadStore st{s_ent + tid, s_todo + tid, s_cyc + tid, s_meta + tid, 256};
+    const uint64_t c = c0 + (uint64_t)blockIdx.x * 256 + tid;
+    const int lane = lane_id();
+    const bool active = c < c1;
+    BfsResult r;
+    r.overflow = false;
+    r.outcome = PF_BFS_NONE;
+    r.n_seen = r.n_cyc = 0;
+    r.flag_cycle = 0;
+    uint32_t s = 0;
+    if (active) {
+        s = cand[c];
+        r = bfs_traverse_thread(succ, pred, st, s);
+    }
+    const bool done = active && !r.overflow;
+    // vertex lists: one atomic per wavefront for the space of all its lists
+    const bool want_seen = r.outcome != PF_BFS_NONE;
+    const uint32_t n_list = done ? (want_seen ? r.n_seen : (r.flag_cycle ? r.n_cyc : 0)) : 0;
+    uint32_t incl = n_list;
+    for (int d = 1; d < WAVE; d <<= 1) {
+        const uint32_t x = __shfl_up(incl, d, WAVE);
+        if (lane >= d) incl += x;
+    }
+    const uint32_t total = __shfl(incl, WAVE - 1, WAVE);
+    unsigned long long base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(o.pool_head, (unsigned long long)total);
+        base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, WAVE) << 32) | __shfl((uint32_t)base, 0, WAVE);
+    }
+    const unsigned long long off = base + (incl - n_list);
+    if (done) {
+        if (off + n_list <= o.pool_cap)
+            for (uint32_t i = 0; i < n_list; ++i) o.pool[off + i] = want_seen ? st.E(i) : st.C(i);
+        pf_bfs_record rec;
+        rec.entrance = s;
+        rec.exit = r.exit_ov;
+        rec.n_seen = r.n_seen;
+        rec.n_list = n_list;
+        rec.list_off = n_list ? off : 0;
+        rec.outcome = r.outcome;
+        rec.flag_cycle = r.flag_cycle;
+        rec.flag_tip = r.flag_tip;
+        rec.strict = r.strict;
+        rec.pad_ = 0;
+        o.rec[c - c0] = rec;
+    }
+    // the rest goes to the wavefront tier, in candidate order within the wavefront
+    const bool over = active && r.overflow;
+    const unsigned long long m = __ballot(over);
+    if (m) {
+        unsigned int b = 0;
+        if (lane == 0) b = atomicAdd(n_wave_list, (unsigned int)__popcll(m));
+        b = __shfl(b, 0, WAVE);
+        if (over) wave_list[b + (unsigned int)__popcll(m & ((1ull << lane) - 1))] = (uint32_t)(c - c0);
+    }
+}
+
+// wavefront tier: candidates c0 + [0, c1 - c0), or, with a list, the candidates c0 + list[0 .. *n_list)
 __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
-                                             const uint32_t *__restrict__ cand, uint64_t c0, uint64_t c1, BfsOut o) {
+                                             const uint32_t *__restrict__ cand, uint64_t c0, uint64_t c1, BfsOut o,
+                                             const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_list) {
     __shared__ uint32_t s_ent[4][BFS_LDS_CAP];
     __shared__ uint32_t s_todo[4][BFS_LDS_CAP];
     __shared__ uint32_t s_cyc[4][BFS_LDS_CAP];
@@ -431,7 +499,9 @@ __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, 
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     BfsAlloc al;
-    for (uint64_t c = c0 + wave; c < c1; c += n_waves) {
+    const uint64_t n_items = list ? (uint64_t)*n_list : c1 - c0;
+    for (uint64_t it = wave; it < n_items; it += n_waves) {
+        const uint64_t c = c0 + (list ? (uint64_t)list[it] : it);
         const uint32_t s = cand[c];
         BfsResult r = bfs_traverse(succ, pred, st, s);
         if (r.overflow) {
@@ -523,7 +593,7 @@ namespace pf {
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
                                                 "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
-                                                "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp"};
+                                                "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread"};
 
 int ctx_begin(pf_ctx *ctx, int kernel) {
     if (!ctx->timing) return 0;
@@ -1222,10 +1292,25 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     unsigned int *d_ndef2 = reinterpret_cast<unsigned int *>(small + 32);
     PF_HIP(hipMemsetAsync(small, 0, 64, ctx->stream));
     BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef, d_def + n + 4, d_ndef2};
-    const int grid = ctx_grid(ctx, n * 64, 256, 8);
-    ctx_begin(ctx, PF_K_BFS);
-    k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o);
-    ctx_end(ctx);
+    // thread tier first (one thread per candidate, 8-entry tables), then the wavefront tier for what outgrew it
+    uint32_t *d_wlist = (uint32_t *)ctx_ws(ctx, WS_BFS_WLIST, (n + 8) * 4);
+    if (!d_wlist) return PF_ERR_HIP;
+    unsigned int *d_nwlist = reinterpret_cast<unsigned int *>(small + 48);
+    static const bool thread_tier = [] { const char *e = getenv("PF_BFS_THREAD_TIER"); return !(e && e[0] == '0'); }();  // measurements
+    if (thread_tier) {
+        ctx_begin(ctx, PF_K_BFS_THREAD);
+        k_bfs_thread<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, d_wlist, d_nwlist);
+        ctx_end(ctx);
+        const int grid = ctx_grid(ctx, (n / 4 + 64) * 64, 256, 8);
+        ctx_begin(ctx, PF_K_BFS);
+        k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, d_wlist, d_nwlist);
+        ctx_end(ctx);
+    } else {
+        const int grid = ctx_grid(ctx, n * 64, 256, 8);
+        ctx_begin(ctx, PF_K_BFS);
+        k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, nullptr, nullptr);
+        ctx_end(ctx);
+    }
     unsigned int n_def = 0;
     PF_HIP(hipMemcpyAsync(&n_def, d_ndef, 4, hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));

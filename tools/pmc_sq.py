@@ -3,7 +3,9 @@
 where a kernel's wave-cycles go (SQ_ACTIVE_INST_ANY / SQ_WAIT_INST_ANY / SQ_WAIT_ANY are disjoint shares of SQ_WAVE_CYCLES,
 /opt/skills/guides/MI355X_MICROARCH.md "rocprofv3 PMC slots") and which pipe the issued instructions went to.
 
-usage: tools/pmc_sq.py <out.json> <dir> [<dir> ...]
+usage: tools/pmc_sq.py <out.json> <dir> [<dir> ...] [--bench <bench.json of the profiled command>]
+The bench line supplies `_meta` (unitigs, k-mers): bench.py prints an issue-rate roofline only for the workload the counters were
+taken on.
 """
 import collections
 import csv
@@ -17,6 +19,16 @@ from pmc_traffic import short  # noqa: E402
 
 
 def main(out, dirs):
+    meta = {}
+    if "--bench" in dirs:
+        i = dirs.index("--bench")
+        try:
+            with open(dirs[i + 1]) as f:
+                b = json.loads(f.read().strip().splitlines()[-1])
+            meta = {"unitigs": b["config"]["unitigs_total"], "kmers": b["config"]["kmers_per_gpu"]}
+        except (OSError, ValueError, KeyError, IndexError) as e:
+            print("pmc_sq: no _meta (%s)" % e, file=sys.stderr)
+        dirs = dirs[:i] + dirs[i + 2:]
     acc = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
     for d in dirs:
         for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -39,8 +51,11 @@ def main(out, dirs):
                 if c in e:
                     e["share_" + c[3:].lower()] = round(e[c] / wc, 4)
         res[k] = e
+    if not res:
+        print("pmc_sq: no counter rows found", file=sys.stderr)
+        sys.exit(1)
     with open(out, "w") as f:
-        json.dump(res, f, indent=1)
+        json.dump({"_meta": meta, **res}, f, indent=1)
     for k, e in res.items():
         print(k, {x: y for x, y in e.items() if x.startswith("share_") or x.startswith("SQ_INSTS")})
 

@@ -19,9 +19,8 @@ def main(src, out_prefix):
         with open(f) as fh:
             rows += list(csv.DictReader(fh))
     rows.sort(key=lambda r: -float(r["TotalDurationNs"]))
-    ours = [r for r in rows if "k_" in r["Name"] and ("pf::" in r["Name"] or "BfsOut" in r["Name"] or "AlnParams" in r["Name"]
-                                                      or "BubParams" in r["Name"] or "CTab" in r["Name"] or r["Name"].startswith("k_")
-                                                      or " k_" in r["Name"][:16])]
+    # this repository's kernels are all named k_*; library kernels (rocprim / hipcub scans and selects, fills) are not
+    ours = [r for r in rows if ("k_" in r["Name"]) and "rocprim" not in r["Name"] and "hipcub" not in r["Name"]]
     cols = ["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"]
     with open(out_prefix + "_kernels.csv", "w", newline="") as fh:
         w = csv.DictWriter(fh, fieldnames=cols)
