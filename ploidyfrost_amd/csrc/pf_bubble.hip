@@ -879,6 +879,23 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         for (auto c : srt) tot += c;
         fprintf(stderr, "[pf_align_bubbles] %u tasks: ticks(10ns) sum %llu  median %llu  p90 %llu  p99 %llu  p99.9 %llu  max %llu\n", n_tasks, tot,
                 srt[n_tasks / 2], srt[(size_t)(n_tasks * 0.9)], srt[(size_t)(n_tasks * 0.99)], srt[(size_t)(n_tasks * 0.999)], srt[n_tasks - 1]);
+        {   // where the time goes by kind of bubble: paths (2, 3, 4, 5+) x (strict: paths are unitigs / branching: text paths)
+            std::vector<pf_bubble_task> ht(n_tasks);
+            PF_HIP(hipMemcpy(ht.data(), L.tasks, (size_t)n_tasks * sizeof(pf_bubble_task), hipMemcpyDeviceToHost));
+            unsigned long long tk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}}, nk[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+            for (uint32_t t = 0; t < n_tasks; ++t) {
+                if (!clk[t] || ht[t].n_paths < 2) continue;
+                pf_bubble_path p0;
+                if (hipMemcpy(&p0, L.paths + ht[t].path_first, sizeof(p0), hipMemcpyDeviceToHost) != hipSuccess) break;
+                const int a = p0.ov == PF_NONE ? 1 : 0, b = ht[t].n_paths >= 5 ? 3 : (int)ht[t].n_paths - 2;
+                tk[a][b] += clk[t];
+                nk[a][b]++;
+                if (t > 60000) break;   // (one small copy per task: a sample is enough)
+            }
+            for (int a = 0; a < 2; ++a)
+                fprintf(stderr, "   %s: 2 paths %llu tasks %llu ticks | 3: %llu / %llu | 4: %llu / %llu | 5+: %llu / %llu\n", a ? "branching" : "strict   ",
+                        nk[a][0], tk[a][0], nk[a][1], tk[a][1], nk[a][2], tk[a][2], nk[a][3], tk[a][3]);
+        }
         unsigned long long over[4] = {0, 0, 0, 0};
         for (auto c : srt) { over[0] += c > 10000; over[1] += c > 30000; over[2] += c > 100000; if (c > 30000) over[3] += c; }
         fprintf(stderr, "   tasks over 0.1 ms: %llu, over 0.3 ms: %llu (their sum %llu ticks), over 1 ms: %llu\n", over[0], over[1], over[3], over[2]);
