@@ -37,6 +37,7 @@
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
 #include "pf_format_dev.hpp"
+#include "pf_pair_dev.hpp"
 #include "ploidyfrost_hip.h"
 
 using namespace pf;
@@ -83,6 +84,7 @@ struct CallCounters {
     unsigned int q_n[8];            // work queues: class c heavy = q_n[2c], light = q_n[2c + 1]
     unsigned int n_branching;
     unsigned int n_snp, n_snp_done;        // two-path bubbles of equal length: candidates for / takers of the single-SNP shortcut
+    unsigned int n_pair, n_pair_done;      // two short paths: K-PAIR's list / the bubbles it finished
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
@@ -113,7 +115,7 @@ struct CallState {
     uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
     // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, slist, res, otext, osites, ogroups, oilen, sv_off, sv, has, vc, sizes, offs, totals,
+    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, pair_scr, res, otext, osites, ogroups, oilen, sv_off, sv, has, vc, sizes, offs, totals,
         scan_tmp2, paths_scr, sites_scr;
     uint64_t path_pool = 0, text_pool = 0, sv_pool = 0;   // capacities learnt from earlier batches
     uint64_t otext_cap = 0, osites_cap = 0, ogroups_cap = 0, oilen_cap = 0;
@@ -128,7 +130,7 @@ struct CallState {
     pf_call_result cur = {};
     void release_all() {
         DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &slist, &res, &otext, &osites, &ogroups, &oilen, &sv_off, &sv, &has, &vc, &sizes, &offs,
+                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &pair_scr, &res, &otext, &osites, &ogroups, &oilen, &sv_off, &sv, &has, &vc, &sizes, &offs,
                          &totals, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
         for (auto &s : out)
@@ -341,6 +343,32 @@ __global__ void k_call_resolve(ResolveArgs a) {
     }
 }
 
+// appends `val` to one of 11 lists chosen by key (0..7 work queues, 8 branching list, 9 SNP candidates, 10 K-PAIR's list;
+// 11 = none): one atomic per key and wave
+struct CallLists {
+    uint32_t *queues;   // 8 lists of nb entries
+    uint32_t *blist, *slist, *plist;
+    uint32_t nb;
+};
+__device__ inline void wave_append(int key, uint32_t val, const CallLists &L, CallCounters *cnt) {
+    for (int x = 0; x < 11; ++x) {
+        const unsigned long long m = __ballot(key == x);
+        if (!m) continue;
+        const int leader = __ffsll((long long)m) - 1;
+        uint32_t base = 0;
+        if (lane_id() == leader)
+            base = atomicAdd(x < 8 ? &cnt->q_n[x] : (x == 8 ? &cnt->n_branching : (x == 9 ? &cnt->n_snp : &cnt->n_pair)), (unsigned int)__popcll(m));
+        base = __shfl(base, leader, WAVE);
+        if (key == x) {
+            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
+            if (x < 8) L.queues[(size_t)x * L.nb + at] = val;
+            else if (x == 8) L.blist[at] = val;
+            else if (x == 9) L.slist[at] = val;
+            else L.plist[at] = val;
+        }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K-PREP
 struct PrepArgs {
@@ -352,35 +380,14 @@ struct PrepArgs {
     pf_bubble_task *btask;
     pf_bubble_path *bpath;
     pf_bubble_result *res;
-    uint32_t *queues;  // 8 lists of nb entries
-    uint32_t *blist;   // branching bubbles (batch-local indices)
-    uint32_t *slist;   // single-SNP candidates
+    CallLists lists;   // work queues; branching bubbles; single-SNP candidates; two short paths (batch-local indices)
     int snp_ok;        // the scores allow the single-SNP shortcut
     CallCounters *cnt;
 };
 
-// appends `val` to one of 10 lists chosen by key (0..7 work queues, 8 branching list, 9 SNP candidates; 10 = none): one atomic
-// per key and wave
-__device__ inline void wave_append(int key, uint32_t val, uint32_t *queues, uint32_t nb, uint32_t *blist, uint32_t *slist, CallCounters *cnt) {
-    for (int x = 0; x < 10; ++x) {
-        const unsigned long long m = __ballot(key == x);
-        if (!m) continue;
-        const int leader = __ffsll((long long)m) - 1;
-        uint32_t base = 0;
-        if (lane_id() == leader) base = atomicAdd(x < 8 ? &cnt->q_n[x] : (x == 8 ? &cnt->n_branching : &cnt->n_snp), (unsigned int)__popcll(m));
-        base = __shfl(base, leader, WAVE);
-        if (key == x) {
-            const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
-            if (x < 8) queues[(size_t)x * nb + at] = val;
-            else if (x == 8) blist[at] = val;
-            else slist[at] = val;
-        }
-    }
-}
-
 __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    int key = 10;
+    int key = 11;
     unsigned long long need3 = 0, retry = 0;
     if (j < a.nb) {
         const CallTask &t = a.ct[a.kept[a.t0 + j]];
@@ -403,15 +410,19 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
                 key = 2 * c + ((t.n_inner > 2 || lmax > 64) ? 0 : 1);
                 if (c == 3) need3 = bubble_need(l0, lmax);
                 retry = job_bytes(sum < 60000u ? sum : 60000u, lmax);
-                // two paths of one length: K-SNP looks at them first (thread per bubble) and hands back what is not a single SNP
-                if (a.snp_ok && t.n_inner == 2 && sum == 2 * l0) key = 9;
+                // two paths of one length: K-SNP looks at them first (thread per bubble) and hands on what is not a single SNP;
+                // two short paths of any kind: K-PAIR (thread per bubble)
+                if (t.n_inner == 2) {
+                    if (a.snp_ok && sum == 2 * l0) key = 9;
+                    else if (lmax <= PAIR_MAX) key = 10;
+                }
             }
         } else {
             a.btask[j] = pf_bubble_task{0, 0, 0};
             key = 8;
         }
     }
-    wave_append(key, j, a.queues, a.nb, a.blist, a.slist, a.cnt);
+    wave_append(key, j, a.lists, a.cnt);
     // class 3 / retry sizing: rare, one atomic per wave that has any
     unsigned long long m3 = need3, mr = retry;
     for (int o = 32; o > 0; o >>= 1) {
@@ -448,7 +459,7 @@ struct SnpArgs {
     uint8_t *ogroups;
     uint64_t group_cap;
     unsigned long long *heads;  // K-BUBBLE's pool heads: [0] text, [1] sites, [2] groups
-    uint32_t *queues;
+    CallLists lists;
     CallCounters *cnt;
 };
 
@@ -521,10 +532,142 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
             a.osites[s_off] = sr;
         }
     }
-    // the rest: K-BUBBLE's queue of their size class (two paths: heavy only when longer than 64)
-    int key = 10;
-    if (active && !take) key = 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
-    wave_append(key, j, a.queues, a.nb, nullptr, nullptr, a.cnt);
+    // the rest: K-PAIR when short, else K-BUBBLE's queue of their size class
+    int key = 11;
+    if (active && !take) key = m <= PAIR_MAX ? 10 : 2 * bubble_class(m, m);
+    wave_append(key, j, a.lists, a.cnt);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-PAIR (pf_pair_dev.hpp): SequenceAlignment of two paths of at most 64 bases, one thread per bubble
+struct PairArgs {
+    const CallTask *ct;
+    const uint32_t *kept;
+    uint64_t t0;
+    const uint64_t *seq, *off;
+    const uint32_t *len;
+    double M, D, G;
+    int integral;
+    int unique_only;            // matrices with several optimal paths go to K-BUBBLE (see pair_traceback)
+    unsigned long long *prof;   // diagnostic (PF_PAIR_STATS): ticks of lane 0 in decode, fill, traceback, choose, publish; or nullptr
+    uint8_t *scratch;           // pair_scratch_bytes() per wavefront of the grid
+    pf_bubble_result *res;
+    char *otext;
+    uint64_t text_cap;
+    pf_bubble_site *osites;
+    uint64_t site_cap;
+    uint8_t *ogroups;
+    uint64_t group_cap;
+    uint32_t *oilen;
+    uint64_t ilen_cap;
+    unsigned long long *heads;  // [0] text, [1] sites, [2] groups, [3] ilen
+    CallLists lists;
+    CallCounters *cnt;
+};
+
+__device__ inline unsigned long long wave_take(unsigned long long *head, uint32_t mine, uint32_t &excl) {
+    // exclusive prefix of `mine` over the wavefront and one atomic for the total; returns the wavefront's base
+    const int lane = lane_id();
+    uint32_t incl = mine;
+    for (int o = 1; o < WAVE; o <<= 1) {
+        const uint32_t x = __shfl_up(incl, o, WAVE);
+        if (lane >= o) incl += x;
+    }
+    excl = incl - mine;
+    const uint32_t total = __shfl(incl, WAVE - 1, WAVE);
+    unsigned long long base = 0;
+    if (total) {
+        if (lane == 0) base = atomicAdd(head, (unsigned long long)total);
+        base = ((unsigned long long)__shfl((uint32_t)(base >> 32), 0, WAVE) << 32) | __shfl((uint32_t)base, 0, WAVE);
+    }
+    return base;
+}
+
+__global__ __launch_bounds__(64) void k_call_pair(PairArgs a) {
+    const int lane = lane_id();
+    PairMem mem;
+    uint8_t *g = a.scratch + (uint64_t)blockIdx.x * pair_scratch_bytes();
+    mem.dir = g + lane * 4;
+    mem.ra = reinterpret_cast<char *>(g + 64ull * PAIR_CELLS) + lane;
+    mem.rb = mem.ra + 64ull * PAIR_LEN;
+    mem.mv = reinterpret_cast<uint8_t *>(mem.rb + 64ull * PAIR_LEN);
+    mem.htext = reinterpret_cast<char *>(g + 64ull * (PAIR_CELLS + 3ull * PAIR_LEN)) + lane;
+    mem.hits = reinterpret_cast<PairHit *>(g + 64ull * (PAIR_CELLS + 3ull * PAIR_LEN + (uint64_t)PAIR_HITS * 2 * PAIR_LEN)) + lane;
+    const uint32_t n_list = a.cnt->n_pair;
+    for (uint32_t base = blockIdx.x * 64; base < n_list; base += gridDim.x * 64) {
+        const uint32_t i = base + lane;
+        const bool active = i < n_list;
+        uint32_t j = 0, L = 0, n_sites = 0, n_ilen = 0;
+        int best = -1, defer_key = 11;
+        bool defer = false;
+        if (active) {
+            j = a.lists.plist[i];
+            const CallTask &t = a.ct[a.kept[a.t0 + j]];
+            const uint32_t ov0 = t.inner[0], ov1 = t.inner[1];
+            const uint32_t m = a.len[ov0 >> 1], n = a.len[ov1 >> 1];
+            unsigned long long tq = a.prof ? wall_clock64() : 0;
+            auto mark = [&](int slot) {
+                if (!a.prof) return;
+                const unsigned long long now = wall_clock64();
+                if (lane == 0) atomicAdd(&a.prof[slot], now - tq);
+                tq = now;
+            };
+            mem.Aw[0] = mem.Aw[1] = mem.Bw[0] = mem.Bw[1] = 0;
+            for (uint32_t c = 0; c < m; ++c) mem.Aw[c >> 5] |= (uint64_t)oriented_base(a.seq, a.off, a.len, ov0, c) << (62 - 2 * (c & 31));
+            for (uint32_t c = 0; c < n; ++c) mem.Bw[c >> 5] |= (uint64_t)oriented_base(a.seq, a.off, a.len, ov1, c) << (62 - 2 * (c & 31));
+            mark(0);
+            pair_fill(mem, mem.Aw, mem.Bw, m, n, a.M, a.D, a.G, a.integral);
+            mark(1);
+            const uint32_t nh = pair_traceback(mem, m, n, a.M, a.D, a.G, a.unique_only != 0);
+            mark(2);
+            if (nh == 0xFFFFFFFFu) {   // more kept alignments than this tier holds: K-BUBBLE's queue of the bubble's size class
+                defer = true;
+                defer_key = 2 * bubble_class(m, m > n ? m : n) + 1;
+            } else {
+                best = pair_choose(mem, nh);
+                if (best >= 0) {
+                    L = PF_AT(mem.hits, best).len;
+                    const char *x = mem.htext + (size_t)best * 2 * PAIR_LEN * 64;
+                    const PairMetrics pm = pair_classify<false>(x, x + (size_t)PAIR_LEN * 64, L, L, nullptr, nullptr);
+                    n_sites = pm.n_sites;
+                    n_ilen = pm.n_indel_len;
+                }
+            }
+            mark(3);
+        }
+        const unsigned long long tp0 = a.prof ? wall_clock64() : 0;
+        const bool take = active && !defer && best >= 0;
+        // pool space for the whole wavefront: one atomic per pool
+        uint32_t e_text, e_sites, e_groups, e_ilen;
+        const unsigned long long b_text = wave_take(&a.heads[0], take ? 2 * L : 0, e_text);
+        const unsigned long long b_sites = wave_take(&a.heads[1], take ? n_sites : 0, e_sites);
+        const unsigned long long b_groups = wave_take(&a.heads[2], take ? 2 * n_sites : 0, e_groups);
+        const unsigned long long b_ilen = wave_take(&a.heads[3], take ? n_ilen : 0, e_ilen);
+        if (take) {
+            const unsigned long long t_off = b_text + e_text, s_off = b_sites + e_sites, g_off = b_groups + e_groups, l_off = b_ilen + e_ilen;
+            pf_bubble_result r;
+            r.rows_off = t_off;
+            r.site_off = s_off;
+            r.group_off = g_off;
+            r.ilen_off = l_off;
+            r.n_rows = 2;
+            r.n_cols = L;
+            r.n_sites = n_sites;
+            r.n_indel_len = n_ilen;
+            a.res[j] = r;
+            if (t_off + 2ull * L <= a.text_cap && s_off + n_sites <= a.site_cap && g_off + 2ull * n_sites <= a.group_cap && l_off + n_ilen <= a.ilen_cap) {
+                const char *x = mem.htext + (size_t)best * 2 * PAIR_LEN * 64, *y = x + (size_t)PAIR_LEN * 64;
+                char *o = a.otext + t_off;
+                for (uint32_t c = 0; c < L; ++c) { o[c] = PF_AT(x, c); o[L + c] = PF_AT(y, c); }
+                (void)pair_classify<true>(x, y, L, L, a.osites + s_off, a.oilen + l_off);
+                for (uint32_t q = 0; q < n_sites; ++q) { a.ogroups[g_off + 2 * q] = 1; a.ogroups[g_off + 2 * q + 1] = 2; }
+            }
+        }
+        const unsigned long long done_m = __ballot(active && !defer);
+        if (lane == 0 && done_m) atomicAdd(&a.cnt->n_pair_done, (unsigned int)__popcll(done_m));
+        wave_append(defer_key, j, a.lists, a.cnt);
+        if (a.prof && lane == 0) { atomicAdd(&a.prof[4], wall_clock64() - tp0); atomicAdd(&a.prof[5], 1ull); }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1532,7 +1675,14 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
 
     // ---- K-PREP, K-SNP, K-PATHS, K-BUBBLE; every pool grows until the batch fits (first batches of a run only) ----
     NEED(S->slist, (size_t)nb * 4);
+    NEED(S->plist, (size_t)nb * 4);
     const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
+    // K-PAIR: register-bound (the score row of the fill is 65 registers): eight wavefronts per CU, the grid loops over its list
+    // (its packed score row holds score * 8 in an int: scores of sane magnitude only)
+    static const bool pair_env = [] { const char *e = getenv("PF_PAIR_TIER"); return !(e && e[0] == '0'); }();  // measurements
+    const bool pair_tier = pair_env && std::fabs(match) < 1e5 && std::fabs(mismatch) < 1e5 && std::fabs(gap) < 1e5;
+    const int pair_grid = ctx->n_cu * 8;
+    if (pair_tier) NEED(S->pair_scr, pair_scratch_bytes() * pair_grid);
     unsigned long long heads[4] = {0, 0, 0, 0};
     uint64_t n_jobs = 0;
     for (int attempt = 0;; ++attempt) {
@@ -1556,26 +1706,56 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
         pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = S->res.as<pf_bubble_result>();
-        pa.queues = S->queues.as<uint32_t>(); pa.blist = S->blist.as<uint32_t>(); pa.slist = S->slist.as<uint32_t>(); pa.snp_ok = snp_ok;
+        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), nb};
+        pa.snp_ok = snp_ok;
         pa.cnt = d_cnt;
         ctx_begin(ctx, PF_K_CALL_PREP);
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
         ctx_end(ctx);
         if (snp_ok) {
             SnpArgs sn;
-            sn.ct = pa.ct; sn.kept = pa.kept; sn.t0 = t0; sn.nb = nb; sn.slist = pa.slist; sn.seq = ctx->d_seq; sn.off = ctx->d_off;
+            sn.ct = pa.ct; sn.kept = pa.kept; sn.t0 = t0; sn.nb = nb; sn.slist = pa.lists.slist; sn.seq = ctx->d_seq; sn.off = ctx->d_off;
             sn.len = ctx->d_len; sn.res = pa.res; sn.otext = S->otext.as<char>(); sn.text_cap = cap_text;
             sn.osites = S->osites.as<pf_bubble_site>(); sn.site_cap = cap_sites; sn.ogroups = S->ogroups.as<uint8_t>(); sn.group_cap = cap_groups;
-            sn.heads = d_heads; sn.queues = pa.queues; sn.cnt = d_cnt;
+            sn.heads = d_heads; sn.lists = pa.lists; sn.cnt = d_cnt;
             ctx_begin(ctx, PF_K_CALL_SNP);
             k_call_snp<<<(nb + 255) / 256, 256, 0, st>>>(sn);   // (the list length is on the device: surplus threads leave at once)
             ctx_end(ctx);
         }
+        if (pair_tier) {
+            PairArgs pr;
+            pr.ct = pa.ct; pr.kept = pa.kept; pr.t0 = t0; pr.seq = ctx->d_seq; pr.off = ctx->d_off; pr.len = ctx->d_len;
+            pr.M = match; pr.D = mismatch; pr.G = gap;
+            pr.integral = (match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap) && std::fabs(match) < 1e6 &&
+                           std::fabs(mismatch) < 1e6 && std::fabs(gap) < 1e6) ? 1 : 0;
+            static const bool pair_dfs = [] { const char *e = getenv("PF_PAIR_DFS"); return e && e[0] == '1'; }();  // measurements
+            pr.unique_only = pair_dfs ? 0 : 1;
+            pr.scratch = S->pair_scr.as<uint8_t>(); pr.res = pa.res; pr.otext = S->otext.as<char>(); pr.text_cap = cap_text;
+            pr.osites = S->osites.as<pf_bubble_site>(); pr.site_cap = cap_sites; pr.ogroups = S->ogroups.as<uint8_t>(); pr.group_cap = cap_groups;
+            pr.oilen = S->oilen.as<uint32_t>(); pr.ilen_cap = cap_ilen; pr.heads = d_heads; pr.lists = pa.lists; pr.cnt = d_cnt;
+            static const bool pair_stats = getenv("PF_PAIR_STATS") != nullptr;
+            DevTmp<unsigned long long> prof_;
+            pr.prof = nullptr;
+            if (pair_stats) {
+                PF_HIP(prof_.alloc(64));
+                PF_HIP(hipMemsetAsync(prof_.p, 0, 64, st));
+                pr.prof = prof_.p;
+            }
+            ctx_begin(ctx, PF_K_CALL_PAIR);
+            k_call_pair<<<pair_grid, 64, 0, st>>>(pr);
+            ctx_end(ctx);
+            if (pair_stats) {
+                unsigned long long h[8];
+                PF_HIP(hipMemcpy(h, prof_.p, 64, hipMemcpyDeviceToHost));
+                fprintf(stderr, "[k_call_pair] %llu wavefront rounds; lane-0 ticks (10 ns): decode %llu fill %llu traceback %llu choose+classify %llu publish %llu\n", h[5],
+                        h[0], h[1], h[2], h[3], h[4]);
+            }
+        }
         PathArgs ph;
-        ph.ct = pa.ct; ph.kept = pa.kept; ph.t0 = t0; ph.nb = nb; ph.blist = pa.blist; ph.succ = ctx->d_succ; ph.seq = ctx->d_seq;
+        ph.ct = pa.ct; ph.kept = pa.kept; ph.t0 = t0; ph.nb = nb; ph.blist = pa.lists.blist; ph.succ = ctx->d_succ; ph.seq = ctx->d_seq;
         ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
         ph.scratch_per_wave = paths_per_wave; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
-        ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.queues; ph.cnt = d_cnt;
+        ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
         ctx_begin(ctx, PF_K_CALL_PATHS);
         k_call_paths<<<paths_grid, 64, 0, st>>>(ph);
         ctx_end(ctx);
@@ -1633,7 +1813,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         break;
     }
     out->n_branching = hc.n_branching;
-    out->align_jobs = n_jobs + hc.n_snp_done;
+    out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done;
 
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);
