@@ -322,6 +322,10 @@ int pf_call_run(pf_ctx *, int slab, uint64_t t0, uint64_t t1, uint64_t var_count
 int pf_call_align(pf_ctx *, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
                   pf_call_result *out);
 int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *out);
+/* K-TEXT for bubbles [first, first + count) of the batch pf_call_align left resident: one large alignment launch (its kernels'
+ * tails are paid once) can be formatted, fetched and written in pieces.  var_count_base is the same for every piece: the bubbles
+ * called before the aligned batch; out->n_called = those called inside the piece. */
+int pf_call_text_range(pf_ctx *, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out);
 /* Copies the first len bytes of one stream of a slab to dst (host memory, pinned for speed) on a stream of its own: may be
  * called from another thread while pf_call_run fills the other slab. */
 int pf_call_fetch(pf_ctx *, int slab, int stream, char *dst, uint64_t len);

@@ -50,7 +50,10 @@ void pfh_set_third_tier_on_host(pfh_run *, int on);
  * grouped by arity; src/CDBG.cpp:1829, 2056, 2158-2162, 2550) -- in the deterministic `-t 1` row order; n <= 1: the `-t 1` format.
  * Single-sample path. */
 int pfh_set_reference_threads(pfh_run *, uint32_t n);
-void pfh_set_batch_bubbles(pfh_run *, uint64_t n);   /* bubbles per batch of the align/format pipeline (default 65536) */
+void pfh_set_batch_bubbles(pfh_run *, uint64_t n);
+/* single-sample path: text pieces (4 x batch_bubbles bubbles, formatted / fetched / written one after the other) per alignment
+ * launch; default 64 = the whole pass is aligned at once up to 2^24 bubbles.  Tests set small values to cross the boundaries. */
+void pfh_set_align_pieces(pfh_run *, uint64_t n);   /* bubbles per batch of the align/format pipeline (default 65536) */
 int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);
 int pfh_ploidy_estimation(pfh_run *, const char *outpre, int lower, int upper);

@@ -1,6 +1,7 @@
 // pfh::CDBG: construction, output plumbing, MyUnitig state and the order-dependent commit replay.
 #include <fcntl.h>
 #include <sched.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 
@@ -102,6 +103,7 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
     trace.mark("device: context");
     if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: " + pf_last_error(nullptr));
     bind_to_device_node(ctx_);
+    out_maps_.reset(new MappedOut[PF_CALL_STREAMS + 1]);   // ten streams of PloidyEstimation + super_bubble.txt
     if (!getenv("PF_NO_PREALLOC")) {
         const uint64_t n_est = g_.n();
         prealloc_ = std::thread([this, n_est, colored] {
@@ -196,6 +198,86 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
     sc_.gap = g;
     tag_ = "CCDBG";
     init_device(device, nullptr, true);
+}
+
+int write_span_parallel(int fd, uint64_t file_off, const char *src, uint64_t len, unsigned threads) {
+    if (len == 0) return 0;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return 1;
+    if ((uint64_t)sb.st_size < file_off + len && ftruncate(fd, (off_t)(file_off + len)) != 0) return 1;
+    const uint64_t page = (uint64_t)sysconf(_SC_PAGESIZE);
+    const uint64_t map_off = file_off & ~(page - 1), lead = file_off - map_off;
+    void *m = mmap(nullptr, (size_t)(len + lead), PROT_READ | PROT_WRITE, MAP_SHARED, fd, (off_t)map_off);
+    if (m == MAP_FAILED) {
+        // (a file system without shared writable mappings: plain positioned writes)
+        uint64_t at = 0;
+        while (at < len) {
+            const ssize_t w = pwrite(fd, src + at, len - at, (off_t)(file_off + at));
+            if (w <= 0) return 1;
+            at += (uint64_t)w;
+        }
+        return 0;
+    }
+    char *dst = static_cast<char *>(m) + lead;
+    constexpr uint64_t PIECE = 1u << 20;
+    parallel_chunks((size_t)((len + PIECE - 1) / PIECE), 1, threads, [&](size_t i, size_t, size_t) {
+        const uint64_t at = (uint64_t)i * PIECE;
+        memcpy(dst + at, src + at, (size_t)std::min<uint64_t>(PIECE, len - at));
+    });
+    return munmap(m, (size_t)(len + lead)) != 0;
+}
+
+void MappedOut::close_file() {
+    if (base) munmap(base, map_len);
+    if (fd >= 0) close(fd);
+    base = nullptr;
+    map_len = 0;
+    fd = -1;
+    path.clear();
+}
+
+int MappedOut::open_for(const std::string &p) {
+    if (fd >= 0 && p == path) {
+        struct stat a, b;
+        if (fstat(fd, &a) == 0 && stat(p.c_str(), &b) == 0 && a.st_ino == b.st_ino && a.st_dev == b.st_dev && a.st_nlink > 0) return 0;
+    }
+    close_file();
+    fd = open(p.c_str(), O_RDWR | O_CREAT, 0666);
+    if (fd < 0) return 1;
+    path = p;
+    return 0;
+}
+
+int MappedOut::write(uint64_t off, const char *src, uint64_t len, unsigned threads) {
+    if (len == 0) return 0;
+    if (fd < 0) return 1;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return 1;
+    if ((uint64_t)sb.st_size < off + len && ftruncate(fd, (off_t)(off + len)) != 0) return 1;
+    if (off + len > map_len) {
+        if (base) munmap(base, map_len);
+        base = nullptr;
+        const size_t want = (size_t)((off + len) + (off + len) / 4 + (8u << 20));   // (mapping past the end of the file is fine: never touched)
+        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) { map_len = 0; return write_span_parallel(fd, off, src, len, threads); }
+        base = static_cast<char *>(m);
+        map_len = want;
+    }
+    char *dst = base + off;
+    constexpr uint64_t PIECE = 1u << 20;
+    parallel_chunks((size_t)((len + PIECE - 1) / PIECE), 1, threads, [&](size_t i, size_t, size_t) {
+        const uint64_t at = (uint64_t)i * PIECE;
+        memcpy(dst + at, src + at, (size_t)std::min<uint64_t>(PIECE, len - at));
+    });
+    return 0;
+}
+
+int MappedOut::finish(uint64_t final_len) {
+    if (fd < 0) return 1;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return 1;
+    if ((uint64_t)sb.st_size != final_len && ftruncate(fd, (off_t)final_len) != 0) return 1;
+    return 0;
 }
 
 int CDBG::set_reference_threads(size_t n) {

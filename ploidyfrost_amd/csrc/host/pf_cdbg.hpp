@@ -94,6 +94,9 @@ public:
     void set_third_tier_on_host(bool on) { third_tier_on_host_ = on; }   // default on; off = one wavefront per giant traversal
     void set_write_files(bool w) { write_files_ = w; }              // bench: format but do not touch the disk
     void set_batch_bubbles(size_t n) { batch_bubbles_ = n; }
+    // resident pipeline: text pieces (4 x batch_bubbles bubbles each) per alignment launch; default 64: a whole pass of up
+    // to 2^24 bubbles is aligned in one launch sequence
+    void set_align_pieces(size_t n) { align_pieces_ = n ? n : 1; }
     // write <outpre>_super_bubble.txt in the background while PloidyEstimation runs (complete when that call, the next
     // findSuperBubble or the destructor returns); off by default: the file is complete when findSuperBubble returns
     void set_overlap_output(bool on) { overlap_output_ = on; }
@@ -215,7 +218,7 @@ protected:
             ogroups.release(); oilen.release();
         }
     } ax_[3];
-    size_t batch_bubbles_ = 1u << 16;
+    size_t batch_bubbles_ = 1u << 16, align_pieces_ = 64;
     // pinned buffers of the whole-graph device calls
     struct BubbleExchange {
         PinnedBuf<pf_bfs_record> bfs_rec;
@@ -239,6 +242,8 @@ protected:
     } cx_;
     bool resident_ = true;
     bool mt_format_ = false;
+    // the result files of the resident pipeline and super_bubble.txt, kept open and mapped between passes (pf_cdbg_impl.hpp)
+    std::unique_ptr<struct MappedOut[]> out_maps_;
     bool state_on_device_ = false;   // pf_call_set_state holds the state findSuperBubble left (finish_find uploads it)
     PinnedBuf<char> sb_text_;        // text of super_bubble.txt on its way from the device to the file
     PhaseTimes times_;

@@ -148,37 +148,16 @@ int CDBG::ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL
         if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): copy of a text slab failed");
     }
     last_allfre_.assign(hb.p + off[0], slice_res_.text_len[0]);
-    int fds[PF_CALL_STREAMS];
-    for (int s = 0; s < PF_CALL_STREAMS; ++s) {
-        fds[s] = open((outdir_ + "/" + outpre + kStreamSuffix[s]).c_str(), O_WRONLY | O_CREAT, 0666);
-        if (fds[s] < 0) {
-            for (int x = 0; x < s; ++x) close(fds[x]);
-            return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + kStreamSuffix[s] + " file error");
-        }
-    }
-    constexpr uint64_t PIECE = 1u << 20;
-    struct Piece { int s; uint64_t at, len; };
-    std::vector<Piece> pieces;
+    MappedOut *maps = out_maps_.get();
     for (int s = 0; s < PF_CALL_STREAMS; ++s)
-        for (uint64_t at = 0; at < slice_res_.text_len[s]; at += PIECE) pieces.push_back({s, at, std::min<uint64_t>(PIECE, slice_res_.text_len[s] - at)});
-    std::vector<int> prc(pieces.size(), 0);
-    parallel_chunks(pieces.size(), 1, T, [&](size_t i, size_t, size_t) {
-        const Piece &pc = pieces[i];
-        const char *src = hb.p + off[pc.s] + pc.at;
-        uint64_t left = pc.len, fo = offsets[pc.s] + pc.at;
-        while (left) {
-            const ssize_t w = pwrite(fds[pc.s], src, left, (off_t)fo);
-            if (w <= 0) { prc[i] = 1; return; }
-            left -= (uint64_t)w;
-            src += w;
-            fo += (uint64_t)w;
-        }
-    });
+        if (maps[s].open_for(outdir_ + "/" + outpre + kStreamSuffix[s])) return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + kStreamSuffix[s] + " file error");
+    // every rank first gives the files their final length -- the same value from all of them, so the order does not matter and no
+    // rank ever cuts off what another has written -- and then stores its slabs at its offsets
     int rc = 0;
-    for (int x : prc) rc |= x;
+    if (truncate)
+        for (int s = 0; s < PF_CALL_STREAMS; ++s) rc |= maps[s].finish(totals[s]);
     for (int s = 0; s < PF_CALL_STREAMS; ++s) {
-        if (truncate && ftruncate(fds[s], (off_t)totals[s]) != 0) rc = 1;
-        close(fds[s]);
+        rc |= maps[s].write(offsets[s], hb.p + off[s], slice_res_.text_len[s], T);
         out_bytes_ += slice_res_.text_len[s];
     }
     times_.write_s = since(t);
@@ -200,34 +179,28 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     const bool trace = getenv("PF_TRACE_PLOIDY") != nullptr;
     auto tp = [&](const char *what) { if (trace) fprintf(stderr, "[ploidy] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
 
-    // The ten result files are opened without truncation (freeing the pages of an earlier run costs milliseconds) and cut to
-    // their final length at the end; a helper thread opens them while the scan runs.
+    // The ten result files stay open and mapped between passes (MappedOut); nothing is truncated up front (freeing the pages of
+    // an earlier run costs milliseconds): each file is cut to its final length at the end.  A helper thread (re)opens them
+    // while the scan runs.
     struct OutFile {
         std::string name;
-        int fd = -1;
         uint64_t bytes = 0;
         int rc = 0;
     };
     std::vector<OutFile> files(PF_CALL_STREAMS);
     for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].name = outpre + kStreamSuffix[s];
+    MappedOut *maps = out_maps_.get();
     int open_failed = -1;
     std::thread opener;
     if (write_files_)
         opener = std::thread([&] {
-            for (size_t i = 0; i < files.size(); ++i) {
-                files[i].fd = open((outdir_ + "/" + files[i].name).c_str(), O_WRONLY | O_CREAT, 0666);
-                if (files[i].fd < 0) { open_failed = (int)i; return; }
-            }
+            for (size_t i = 0; i < files.size(); ++i)
+                if (maps[i].open_for(outdir_ + "/" + files[i].name)) { open_failed = (int)i; return; }
         });
-    struct OpenerGuard {  // every early return below must not leave the helper running or files open
+    struct OpenerGuard {  // every early return below must not leave the helper running
         std::thread &t;
-        std::vector<OutFile> &f;
-        ~OpenerGuard() {
-            if (t.joinable()) t.join();
-            for (OutFile &of : f)
-                if (of.fd >= 0) { close(of.fd); of.fd = -1; }
-        }
-    } opener_guard{opener, files};
+        ~OpenerGuard() { if (t.joinable()) t.join(); }
+    } opener_guard{opener};
 
     uint64_t n_tasks = 0;
     if (call_select(cutoff, n_tasks)) return status_;
@@ -238,7 +211,6 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
 
     // ---- batches: device (this thread) | copy back + append (writer thread) ----
     const size_t CHUNK = std::min<size_t>(std::max<size_t>(batch_bubbles_ ? batch_bubbles_ * 4 : 1, 1), (size_t)1 << 24);
-    const size_t n_batches = (n_tasks + CHUNK - 1) / CHUNK;
     struct Done {
         pf_call_result res;
         int slab;
@@ -279,29 +251,11 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             cv.notify_all();
             if (st != PF_OK) return;
             if (trace) fprintf(stderr, "[ploidy]   batch %zu fetched (%.1f MB) %.2f ms\n", b, total / 1e6, since(t_all) * 1e3);
-            // append: every stream at its running offset, the large ones cut into pieces written side by side
-            constexpr uint64_t PIECE = 1u << 20;
-            struct Piece { int s; uint64_t at, len; };
-            std::vector<Piece> pieces;
-            for (int s = 0; s < PF_CALL_STREAMS; ++s)
-                for (uint64_t at = 0; at < d.res.text_len[s]; at += PIECE) pieces.push_back({s, at, std::min<uint64_t>(PIECE, d.res.text_len[s] - at)});
-            std::vector<int> prc(pieces.size(), 0);
+            // append: every stream at its running offset through a shared mapping, copied by all threads side by side
             if (write_files_)
-                parallel_chunks(pieces.size(), 1, T, [&](size_t i, size_t, size_t) {
-                    const Piece &pc = pieces[i];
-                    const char *src = hb.p + off[pc.s] + pc.at;
-                    uint64_t left = pc.len, fo = files[(size_t)pc.s].bytes + pc.at;
-                    while (left) {
-                        const ssize_t w = pwrite(files[(size_t)pc.s].fd, src, left, (off_t)fo);
-                        if (w <= 0) { prc[i] = 1; return; }
-                        left -= (uint64_t)w;
-                        src += w;
-                        fo += (uint64_t)w;
-                    }
-                });
+                for (int s = 0; s < PF_CALL_STREAMS; ++s)
+                    if (maps[s].write(files[(size_t)s].bytes, hb.p + off[s], d.res.text_len[s], T)) files[(size_t)s].rc = 1;
             last_allfre_.append(hb.p + off[0], d.res.text_len[0]);
-            for (size_t i = 0; i < pieces.size(); ++i)
-                if (prc[i]) files[(size_t)pieces[i].s].rc = 1;
             for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].bytes += d.res.text_len[s];
             write_s += since(tw);
             if (trace) fprintf(stderr, "[ploidy]   batch %zu written %.2f ms\n", b, since(t_all) * 1e3);
@@ -325,28 +279,38 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     int rc = PF_OK;
     std::string rc_err;
     const auto t_dev = clk::now();
-    for (size_t b = 0; b < n_batches; ++b) {
-        {   // slab b % 2 was last used by batch b - 2
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return stop || b < fetched + 2; });
-            if (stop) break;
-        }
-        const uint64_t t0 = (uint64_t)b * CHUNK, t1 = std::min<uint64_t>(n_tasks, t0 + CHUNK);
-        Done d;
-        d.slab = (int)(b & 1);
-        const int st = pf_call_run(ctx_, d.slab, t0, t1, var_count, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch,
-                                   sc_.gap, &d.res);
+    // Alignment in large launches (every kernel's tail -- one wavefront finishing the heaviest bubble -- is paid once per
+    // launch), text in pieces of CHUNK bubbles that are fetched and written while the next piece is formatted.
+    const uint64_t ALIGN = std::min<uint64_t>((uint64_t)CHUNK * std::max<size_t>(align_pieces_, 1), (uint64_t)1 << 24);
+    size_t b = 0;   // text piece number: slabs alternate
+    for (uint64_t a0 = 0; a0 < n_tasks && rc == PF_OK; a0 += ALIGN) {
+        const uint64_t a1 = std::min<uint64_t>(n_tasks, a0 + ALIGN);
+        pf_call_result ar;
+        int st = pf_call_align(ctx_, a0, a1, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch, sc_.gap, &ar);
         if (st != PF_OK) { rc = st; rc_err = pf_last_error(ctx_); break; }
-        if (trace) fprintf(stderr, "[ploidy]   batch %zu on the device done %.2f ms\n", b, since(t_all) * 1e3);
-        var_count += d.res.n_called;
-        times_.tasks += t1 - t0;
-        times_.align_jobs += d.res.align_jobs;
-        times_.site_strings += d.res.site_strings;
-        for (int a = 0; a < 4; ++a) allele_[a] += d.res.allele[a];
-        core_cov_ += d.res.core_cov;
-        core_num_ += d.res.core_num;
-        { std::lock_guard<std::mutex> lk(mu); ready.push_back(d); }
-        cv.notify_all();
+        if (trace) fprintf(stderr, "[ploidy]   %llu bubbles aligned on the device %.2f ms\n", (unsigned long long)(a1 - a0), since(t_all) * 1e3);
+        times_.tasks += a1 - a0;
+        times_.align_jobs += ar.align_jobs;
+        times_.site_strings += ar.site_strings;
+        for (uint64_t p0 = 0; p0 < a1 - a0; p0 += CHUNK, ++b) {
+            {   // slab b % 2 was last used by piece b - 2
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || b < fetched + 2; });
+                if (stop) break;
+            }
+            Done d;
+            d.slab = (int)(b & 1);
+            st = pf_call_text_range(ctx_, d.slab, p0, std::min<uint64_t>(CHUNK, a1 - a0 - p0), var_count, &d.res);
+            if (st != PF_OK) { rc = st; rc_err = pf_last_error(ctx_); break; }
+            if (trace) fprintf(stderr, "[ploidy]   piece %zu formatted on the device %.2f ms\n", b, since(t_all) * 1e3);
+            for (int a = 0; a < 4; ++a) allele_[a] += d.res.allele[a];
+            core_cov_ += d.res.core_cov;
+            core_num_ += d.res.core_num;
+            { std::lock_guard<std::mutex> lk(mu); ready.push_back(d); }
+            cv.notify_all();
+        }
+        var_count += ar.n_called;
+        { std::lock_guard<std::mutex> lk(mu); if (stop) break; }
     }
     times_.align_s = since(t_dev);
     {
@@ -364,13 +328,10 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     if (wst != PF_OK) return fail(wst, std::string(tag_) + "::PloidyEstimation(): " + werr);
     auto t0 = clk::now();
     if (join_pending_write() || join_pending_ids()) return status_;
-    for (OutFile &of : files) {
+    for (size_t i = 0; i < files.size(); ++i) {
+        OutFile &of = files[i];
         out_bytes_ += of.bytes;
-        if (of.fd >= 0) {
-            if (ftruncate(of.fd, (off_t)of.bytes) != 0) of.rc = 1;
-            close(of.fd);
-            of.fd = -1;
-        }
+        if (write_files_ && maps[i].finish(of.bytes)) of.rc = 1;
         if (of.rc) return fail(PF_ERR_ARG, "CDBG:: write error on " + of.name);
     }
     write_s += since(t0);

@@ -237,25 +237,12 @@ int CDBG::finish_find(const std::string &outpre, const size_t &thr, clk_time t_a
         const unsigned T = threads_ ? threads_ : 1;
         auto job = [this, name = outpre + "_super_bubble.txt", len, T]() -> int {
             if (pf_superbubble_fetch(ctx_, sb_text_.p, len) != PF_OK) return 1;
-            const int fd = open((outdir_ + "/" + name).c_str(), O_WRONLY | O_CREAT, 0666);
-            if (fd < 0) return 1;
+                    MappedOut &mo = out_maps_[PF_CALL_STREAMS];   // (the slot after the ten streams of PloidyEstimation)
+            if (mo.open_for(outdir_ + "/" + name)) return 1;
             const uint64_t hl = sizeof(kHeader) - 1;
-            int rc = pwrite(fd, kHeader, hl, 0) == (ssize_t)hl ? 0 : 1;
-            constexpr uint64_t PIECE = 2u << 20;
-            const size_t n_pieces = (size_t)((len + PIECE - 1) / PIECE);
-            std::vector<int> prc(n_pieces, 0);
-            parallel_chunks(n_pieces, 1, T, [&](size_t i, size_t, size_t) {
-                uint64_t at = (uint64_t)i * PIECE, left = std::min<uint64_t>(PIECE, len - at);
-                while (left) {
-                    const ssize_t w = pwrite(fd, sb_text_.p + at, left, (off_t)(hl + at));
-                    if (w <= 0) { prc[i] = 1; return; }
-                    left -= (uint64_t)w;
-                    at += (uint64_t)w;
-                }
-            });
-            for (int x : prc) rc |= x;
-            if (ftruncate(fd, (off_t)(hl + len)) != 0) rc = 1;
-            close(fd);
+            int rc = mo.write(0, kHeader, hl, 1);
+            rc |= mo.write(hl, sb_text_.p, len, T);
+            rc |= mo.finish(hl + len);
             return rc;
         };
         if (overlap_output_) {

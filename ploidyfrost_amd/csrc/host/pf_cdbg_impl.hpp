@@ -36,6 +36,30 @@ inline void put_uint(std::string &s, uint64_t x) {
 }
 }  // namespace
 
+// len bytes of src into the file at file_off, by `threads` threads side by side.  Concurrent write()s to ONE file serialise on
+// the inode lock (tmpfs and ext4 alike), so a 400 MB result file written in pieces by 32 threads moves at the speed of one;
+// stores into a shared mapping of the same range do not.  The file is extended first when it is too short.  0 = ok.
+int write_span_parallel(int fd, uint64_t file_off, const char *src, uint64_t len, unsigned threads);
+
+// A result file that stays open and mapped from pass to pass.  A service that runs pass after pass over a resident graph
+// rewrites files of (nearly) the same size every time; with the mapping kept, a pass's text goes into pages whose table
+// entries already exist -- plain memory copies by all threads -- instead of faulting every page in again.  The file is
+// re-opened when the path changes or the file was replaced behind our back.
+struct MappedOut {
+    std::string path;
+    int fd = -1;
+    char *base = nullptr;
+    size_t map_len = 0;
+    MappedOut() = default;
+    MappedOut(const MappedOut &) = delete;
+    MappedOut &operator=(const MappedOut &) = delete;
+    ~MappedOut() { close_file(); }
+    int open_for(const std::string &p);                                            // 0 = ok
+    int write(uint64_t off, const char *src, uint64_t len, unsigned threads);      // grows file and mapping as needed
+    int finish(uint64_t final_len);                                                // the file's length after this pass
+    void close_file();
+};
+
 // one bubble to call, in output order
 struct CDBG::Task {
     uint32_t u = 0;        // owner endpoint (unitig index)

@@ -130,6 +130,7 @@ int pfh_set_reference_threads(pfh_run *r, uint32_t n) {
     return guarded(r, [&] { return r->cdbg->set_reference_threads(n); });
 }
 void pfh_set_batch_bubbles(pfh_run *r, uint64_t n) { r->cdbg->set_batch_bubbles((size_t)n); }
+void pfh_set_align_pieces(pfh_run *r, uint64_t n) { r->cdbg->set_align_pieces((size_t)n); }
 int pfh_set_unitig_id(pfh_run *r, const char *outpre) {
     return guarded(r, [&] { return r->cdbg->setUnitigId(outpre, "", 1); });
 }

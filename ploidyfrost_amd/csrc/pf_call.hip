@@ -154,6 +154,8 @@ void call_invalidate(pf_ctx *ctx) {  // a new graph or count table: resident sca
 
 }  // namespace pf
 
+#define NEED_TEXT(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = "pf_call_text: out of device memory"; return PF_ERR_HIP; } } while (0)
+
 namespace {
 
 CallState *state_of(pf_ctx *ctx) {
@@ -1124,8 +1126,9 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
 struct FmtArgs {
     const CallTask *ct;
     const uint32_t *kept;
-    uint64_t t0;
-    uint32_t nb;
+    uint64_t t0;              // selection index of the aligned batch's first bubble
+    uint32_t j0;              // first bubble of this text batch inside the aligned batch
+    uint32_t nb;              // bubbles of this text batch
     const pf_bubble_result *res;
     const char *otext;
     const pf_bubble_site *osites;
@@ -1157,19 +1160,20 @@ __global__ void k_call_has(const pf_bubble_result *__restrict__ res, uint32_t nb
 
 template <bool W>
 __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index inside the text batch (sizes / offsets)
+    const uint32_t j = a.j0 + jj;                                // ... inside the aligned batch (results, numbering, site values)
     unsigned long long allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
-    if (j < a.nb) {
+    if (jj < a.nb) {
         const size_t stride = (size_t)a.nb + 1;
         Row<W> s_all{nullptr, 0}, s_aln{nullptr, 0}, s_fre[4], s_cov[4];
         for (int x = 0; x < 4; ++x) { s_fre[x] = Row<W>{nullptr, 0}; s_cov[x] = Row<W>{nullptr, 0}; }
         if (W) {
-            s_all.p = a.out[0] + (a.offs[0 * stride + j] - a.offs[0 * stride]);
-            s_aln.p = a.out[1] + (a.offs[1 * stride + j] - a.offs[1 * stride]);
+            s_all.p = a.out[0] + (a.offs[0 * stride + jj] - a.offs[0 * stride]);
+            s_aln.p = a.out[1] + (a.offs[1 * stride + jj] - a.offs[1 * stride]);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                s_fre[x].p = a.out[2 + x] + (a.offs[(2 + x) * stride + j] - a.offs[(2 + x) * stride]);
-                s_cov[x].p = a.out[6 + x] + (a.offs[(6 + x) * stride + j] - a.offs[(6 + x) * stride]);
+                s_fre[x].p = a.out[2 + x] + (a.offs[(2 + x) * stride + jj] - a.offs[(2 + x) * stride]);
+                s_cov[x].p = a.out[6 + x] + (a.offs[(6 + x) * stride + jj] - a.offs[(6 + x) * stride]);
             }
         }
         const pf_bubble_result r = a.res[j];
@@ -1287,12 +1291,12 @@ __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
             }
         }
         if (!W) {
-            a.sizes[0 * stride + j] = s_all.n;
-            a.sizes[1 * stride + j] = s_aln.n;
+            a.sizes[0 * stride + jj] = s_all.n;
+            a.sizes[1 * stride + jj] = s_aln.n;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
-                a.sizes[(2 + x) * stride + j] = s_fre[x].n;
-                a.sizes[(6 + x) * stride + j] = s_cov[x].n;
+                a.sizes[(2 + x) * stride + jj] = s_fre[x].n;
+                a.sizes[(6 + x) * stride + jj] = s_cov[x].n;
             }
         }
     }
@@ -1303,7 +1307,7 @@ __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
             const unsigned long long s = wave_sum_u64(v[x]);
             if (lane_id() == 0 && s) atomicAdd(x < 4 ? &a.cnt->allele[x] : (x == 4 ? &a.cnt->core_cov : &a.cnt->core_num), s);
         }
-        if (j <= a.nb && j == a.nb) {
+        if (jj == a.nb) {
             const size_t stride = (size_t)a.nb + 1;
             for (int s = 0; s < N_STREAMS; ++s) a.sizes[s * stride + a.nb] = 0;
         }
@@ -1662,8 +1666,6 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
     NEED(S->sv_off, (size_t)nb * 8);
     NEED(S->has, (size_t)nb * 4);
     NEED(S->vc, (size_t)nb * 4);
-    NEED(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
-    NEED(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
     NEED(S->totals, 16 * 8);
     CallCounters *d_cnt = S->counters.as<CallCounters>();
     CallCounters hc;
@@ -1873,17 +1875,28 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
 }
 
 // one batch, second half: K-TEXT of the bubbles pf_call_align left resident, into slab 0 or 1
-int pf_call_text(pf_ctx *ctx, int slab, uint64_t var_count_base, pf_call_result *out) {
+int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
     if (!ctx || !out || slab < 0 || slab > 1) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S) return PF_ERR_ARG;
+    if (first + count > S->cur_nb) { ctx->err = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
     for (int s = 0; s < N_STREAMS; ++s) S->out_len[slab][s] = 0;
     *out = S->cur;
-    if (S->cur_nb == 0) return PF_OK;
+    out->n_called = 0;
+    if (count == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
-    const uint32_t nb = S->cur_nb;
+    const uint32_t nb = (uint32_t)count;
     const uint64_t t0 = S->cur_t0;
+    {   // bubbles called inside the range: difference of the batch-wide running count
+        uint32_t c[2] = {0, 0};
+        PF_HIP(hipMemcpyAsync(&c[1], S->vc.as<uint32_t>() + (first + count - 1), 4, hipMemcpyDeviceToHost, st));
+        if (first) PF_HIP(hipMemcpyAsync(&c[0], S->vc.as<uint32_t>() + (first - 1), 4, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        out->n_called = c[1] - c[0];
+    }
+    NEED_TEXT(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
+    NEED_TEXT(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
     const char *oom = "pf_call_text: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = oom; return PF_ERR_HIP; } } while (0)
     CallCounters *d_cnt = S->counters.as<CallCounters>();
@@ -1895,7 +1908,8 @@ int pf_call_text(pf_ctx *ctx, int slab, uint64_t var_count_base, pf_call_result 
     NEED(S->scan_tmp, tmp2);
     PF_HIP(hipMemsetAsync(&d_cnt->allele[0], 0, 6 * 8, st));  // allele[4], core_cov, core_num
     FmtArgs fa;
-    fa.ct = S->ctask.as<CallTask>(); fa.kept = S->kept.as<uint32_t>(); fa.t0 = t0; fa.nb = nb; fa.res = S->res.as<pf_bubble_result>();
+    fa.ct = S->ctask.as<CallTask>(); fa.kept = S->kept.as<uint32_t>(); fa.t0 = t0; fa.j0 = (uint32_t)first; fa.nb = nb;
+    fa.res = S->res.as<pf_bubble_result>();
     fa.otext = S->otext.as<char>(); fa.osites = S->osites.as<pf_bubble_site>(); fa.ogroups = S->ogroups.as<uint8_t>();
     fa.oilen = S->oilen.as<uint32_t>(); fa.sv_off = S->sv_off.as<uint64_t>(); fa.sv = S->sv.as<double>(); fa.vc = S->vc.as<uint32_t>();
     fa.vc_base = var_count_base; fa.mt = S->mt_format ? 1 : 0; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
@@ -1925,6 +1939,13 @@ int pf_call_text(pf_ctx *ctx, int slab, uint64_t var_count_base, pf_call_result 
     out->core_num = hc.core_num;
 #undef NEED
     return PF_OK;
+}
+
+int pf_call_text(pf_ctx *ctx, int slab, uint64_t var_count_base, pf_call_result *out) {
+    if (!ctx || !ctx->call) return PF_ERR_ARG;
+    const int st = pf_call_text_range(ctx, slab, 0, ctx->call->cur_nb, var_count_base, out);
+    if (st == PF_OK) out->n_called = ctx->call->cur.n_called;
+    return st;
 }
 
 int pf_call_run(pf_ctx *ctx, int slab, uint64_t t0, uint64_t t1, uint64_t var_count_base, uint32_t complex_size, double match,

@@ -23,7 +23,7 @@ class Times(C.Structure):
 
 
 _lib = None
-DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_reference_threads", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_unitig_id",
+DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_align_pieces", "pfh_set_reference_threads", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_unitig_id",
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
@@ -51,6 +51,7 @@ def load_library() -> C.CDLL:
     L.pfh_set_write_files.argtypes = [vp, C.c_int]
     L.pfh_set_threads.argtypes = [vp, C.c_uint32]
     L.pfh_set_batch_bubbles.argtypes = [vp, C.c_uint64]
+    L.pfh_set_align_pieces.argtypes = [vp, C.c_uint64]
     L.pfh_set_reference_threads.argtypes = [vp, C.c_uint32]
     L.pfh_set_overlap_output.argtypes = [vp, C.c_int]
     L.pfh_set_third_tier_on_host.argtypes = [vp, C.c_int]
@@ -224,6 +225,9 @@ class Run:
 
     def set_threads(self, threads: int):
         self.L.pfh_set_threads(self.h, threads)
+
+    def set_align_pieces(self, n: int):
+        self.L.pfh_set_align_pieces(self.h, n)
 
     def set_reference_threads(self, n: int):
         """n > 1: the text format of the reference's `-t n` run (deterministic row order)"""
