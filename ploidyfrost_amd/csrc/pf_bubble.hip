@@ -797,13 +797,13 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         attr_set = true;
     }
     uint32_t idx_off = 0;
-    for (int c = 0; c < 3; ++c) {
+    for (int c = 0; c < kBubLdsClasses; ++c) {
         const uint32_t nc = L.n_cls[c];
         if (nc == 0) continue;
         p.idx = L.idx + idx_off;
         p.n = nc;
         p.work_bytes = (uint32_t)kBubClassBytes[c];
-        const int per_cu = c == 0 ? 24 : (c == 1 ? 7 : 2);
+        const int per_cu = bubble_class_waves_per_cu(c);
         const int grid = (int)std::min<uint32_t>(nc, (uint32_t)(ctx->n_cu * per_cu));
         p.next = queue_heads + n_launch++;
         ctx_begin(ctx, PF_K_BUBBLE);
@@ -811,8 +811,8 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         ctx_end(ctx);
         idx_off += nc;
     }
-    if (L.n_cls[3]) {
-        const uint32_t nc = L.n_cls[3];
+    if (L.n_cls[kBubLdsClasses]) {
+        const uint32_t nc = L.n_cls[kBubLdsClasses];
         const int grid = (int)std::min<uint32_t>(nc, 256);
         const uint64_t per = (std::min<uint64_t>(L.max_need * 2, 1ull << 31) + 255) & ~255ull;
         uint8_t *work = (uint8_t *)ctx_ws(ctx, WS_BUB_WORK, per * grid);
@@ -957,7 +957,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         hp = hp_own.data();
     }
     const std::vector<uint32_t> &hlen = ctx->h_len;  // unitig lengths for ov paths
-    std::vector<uint32_t> cls[4];
+    std::vector<uint32_t> cls[kBubLdsClasses + 1];
     std::vector<char> heavy;
     heavy.reserve(n_tasks);
     uint64_t max_need = 0, retry_need = 0;
@@ -986,7 +986,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         const int c = bubble_class(l0, lmax);
         cls[c].push_back(t);
         heavy.push_back(tk.n_paths > 2 || lmax > 64);
-        if (c == 3) max_need = std::max(max_need, bubble_need(l0, lmax));
+        if (c == kBubLdsClasses) max_need = std::max(max_need, bubble_need(l0, lmax));
         retry_need = std::max(retry_need, job_bytes((uint32_t)std::min<uint64_t>(sum, 60000), lmax));
     }
     for (auto &v : cls)  // multi-path / long bubbles first (stable: the order inside each half is kept)
@@ -1021,7 +1021,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     L.text = d_text; L.paths = d_paths; L.tasks = d_tasks; L.n_tasks = n_tasks;
     L.match = match; L.mismatch = mismatch; L.gap = gap;
     uint32_t idx_off = 0;
-    for (int c = 0; c < 4; ++c) {
+    for (int c = 0; c <= kBubLdsClasses; ++c) {
         L.n_cls[c] = (uint32_t)cls[c].size();
         if (cls[c].empty()) continue;
         PF_HIP(hipMemcpyAsync(d_idx + idx_off, cls[c].data(), cls[c].size() * 4, hipMemcpyHostToDevice, st));

@@ -10,8 +10,15 @@ struct pf_ctx;
 
 namespace pf {
 
-// LDS size classes of the Needleman-Wunsch working storage (bytes per wavefront); class 3 = global memory
-constexpr uint64_t kBubClassBytes[3] = {5 * 1024, 20 * 1024, 64 * 1024};
+// LDS size classes of the Needleman-Wunsch working storage (bytes per wavefront): the finer the classes, the more wavefronts of
+// the mid-sized bubbles fit a CU's 160 KB (a 100 x 100 matrix needs 16 KB: ten per CU, where a 20 KB class gave seven).
+// Class kBubLdsClasses = global memory.
+constexpr int kBubLdsClasses = 6;
+constexpr uint64_t kBubClassBytes[kBubLdsClasses] = {5 * 1024, 10 * 1024, 16 * 1024, 24 * 1024, 40 * 1024, 64 * 1024};
+__host__ __device__ inline int bubble_class_waves_per_cu(int c) {
+    const int fit = (int)((160 * 1024) / kBubClassBytes[c]);
+    return fit > 24 ? 24 : fit;
+}
 
 // working storage a bubble whose first path has l0 characters and whose longest has lmax may need: row 0 can grow by the gaps
 // opened in later rounds, so there is headroom; the device re-checks every job against its tier
@@ -20,9 +27,9 @@ __host__ __device__ inline uint64_t bubble_need(uint32_t l0, uint32_t lmax) {
 }
 __host__ __device__ inline int bubble_class(uint32_t l0, uint32_t lmax) {
     const uint64_t need = bubble_need(l0, lmax);
-    for (int x = 0; x < 3; ++x)
+    for (int x = 0; x < kBubLdsClasses; ++x)
         if (need <= kBubClassBytes[x]) return x;
-    return 3;
+    return kBubLdsClasses;
 }
 
 struct BubbleLaunch {
@@ -32,8 +39,8 @@ struct BubbleLaunch {
     const pf_bubble_task *tasks = nullptr;
     uint32_t n_tasks = 0;             // size of tasks / res (queues may list fewer)
     const uint32_t *idx = nullptr;    // class queues back to back
-    uint32_t n_cls[4] = {0, 0, 0, 0};
-    uint64_t max_need = 0;            // largest bubble_need among class 3
+    uint32_t n_cls[kBubLdsClasses + 1] = {};
+    uint64_t max_need = 0;            // largest bubble_need in the global-memory class
     uint64_t retry_need = 0;          // working storage bound for the retry tier
     double match = 2, mismatch = -1, gap = -3;
     // outputs, device memory

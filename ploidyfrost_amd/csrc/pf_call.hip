@@ -55,6 +55,9 @@ namespace {
 
 constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_STRICT_M = 0x08, B_STRICT_P = 0x10, B_COMPLEX_M = 0x20, B_COMPLEX_P = 0x40;
 constexpr int N_STREAMS = PF_CALL_STREAMS;
+// work lists of a batch: K-BUBBLE's queues (heavy and light per size class), then the three lists of the other kernels
+constexpr int NQ = 2 * (kBubLdsClasses + 1);
+constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_NONE = NQ + 3;
 
 struct DevBuf {
     void *p = nullptr;
@@ -81,7 +84,7 @@ struct DevBuf {
 
 // counters of one batch, device side (zeroed per batch)
 struct CallCounters {
-    unsigned int q_n[8];            // work queues: class c heavy = q_n[2c], light = q_n[2c + 1]
+    unsigned int q_n[NQ];           // work queues: class c heavy = q_n[2c], light = q_n[2c + 1]
     unsigned int n_branching;
     unsigned int n_snp, n_snp_done;        // two-path bubbles of equal length: candidates for / takers of the single-SNP shortcut
     unsigned int n_pair, n_pair_done;      // two short paths: K-PAIR's list / the bubbles it finished
@@ -345,27 +348,31 @@ __global__ void k_call_resolve(ResolveArgs a) {
     }
 }
 
-// appends `val` to one of 11 lists chosen by key (0..7 work queues, 8 branching list, 9 SNP candidates, 10 K-PAIR's list;
-// 11 = none): one atomic per key and wave
+// appends `val` to one of the lists chosen by key (0 .. NQ-1 K-BUBBLE's queues, KEY_BRANCHING, KEY_SNP, KEY_PAIR; KEY_NONE =
+// nowhere): one atomic per key and wave
 struct CallLists {
-    uint32_t *queues;   // 8 lists of nb entries
+    uint32_t *queues;   // NQ lists of nb entries
     uint32_t *blist, *slist, *plist;
     uint32_t nb;
 };
 __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, CallCounters *cnt) {
-    for (int x = 0; x < 11; ++x) {
+    unsigned long long todo = __ballot(key != KEY_NONE);
+    while (todo) {
+        // the key of the first lane still waiting, and every lane with the same key
+        const int x = __shfl(key, __ffsll((long long)todo) - 1, WAVE);
         const unsigned long long m = __ballot(key == x);
-        if (!m) continue;
+        todo &= ~m;
         const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
         if (lane_id() == leader)
-            base = atomicAdd(x < 8 ? &cnt->q_n[x] : (x == 8 ? &cnt->n_branching : (x == 9 ? &cnt->n_snp : &cnt->n_pair)), (unsigned int)__popcll(m));
+            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : &cnt->n_pair)),
+                             (unsigned int)__popcll(m));
         base = __shfl(base, leader, WAVE);
         if (key == x) {
             const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
-            if (x < 8) L.queues[(size_t)x * L.nb + at] = val;
-            else if (x == 8) L.blist[at] = val;
-            else if (x == 9) L.slist[at] = val;
+            if (x < NQ) L.queues[(size_t)x * L.nb + at] = val;
+            else if (x == KEY_BRANCHING) L.blist[at] = val;
+            else if (x == KEY_SNP) L.slist[at] = val;
             else L.plist[at] = val;
         }
     }
@@ -384,12 +391,13 @@ struct PrepArgs {
     pf_bubble_result *res;
     CallLists lists;   // work queues; branching bubbles; single-SNP candidates; two short paths (batch-local indices)
     int snp_ok;        // the scores allow the single-SNP shortcut
+    int pair_ok;       // K-PAIR runs
     CallCounters *cnt;
 };
 
 __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    int key = 11;
+    int key = KEY_NONE;
     unsigned long long need3 = 0, retry = 0;
     if (j < a.nb) {
         const CallTask &t = a.ct[a.kept[a.t0 + j]];
@@ -410,18 +418,18 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
             if (t.n_inner >= 2) {  // fewer than two paths: the reference indexes str[1] blindly; skipped
                 const int c = bubble_class(l0, lmax);
                 key = 2 * c + ((t.n_inner > 2 || lmax > 64) ? 0 : 1);
-                if (c == 3) need3 = bubble_need(l0, lmax);
+                if (c == kBubLdsClasses) need3 = bubble_need(l0, lmax);
                 retry = job_bytes(sum < 60000u ? sum : 60000u, lmax);
                 // two paths of one length: K-SNP looks at them first (thread per bubble) and hands on what is not a single SNP;
                 // two short paths of any kind: K-PAIR (thread per bubble)
                 if (t.n_inner == 2) {
-                    if (a.snp_ok && sum == 2 * l0) key = 9;
-                    else if (lmax <= PAIR_MAX) key = 10;
+                    if (a.snp_ok && sum == 2 * l0) key = KEY_SNP;
+                    else if (a.pair_ok && lmax <= PAIR_MAX) key = KEY_PAIR;
                 }
             }
         } else {
             a.btask[j] = pf_bubble_task{0, 0, 0};
-            key = 8;
+            key = KEY_BRANCHING;
         }
     }
     wave_append(key, j, a.lists, a.cnt);
@@ -462,6 +470,7 @@ struct SnpArgs {
     uint64_t group_cap;
     unsigned long long *heads;  // K-BUBBLE's pool heads: [0] text, [1] sites, [2] groups
     CallLists lists;
+    int pair_ok;
     CallCounters *cnt;
 };
 
@@ -535,8 +544,8 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
         }
     }
     // the rest: K-PAIR when short, else K-BUBBLE's queue of their size class
-    int key = 11;
-    if (active && !take) key = m <= PAIR_MAX ? 10 : 2 * bubble_class(m, m);
+    int key = KEY_NONE;
+    if (active && !take) key = (a.pair_ok && m <= PAIR_MAX) ? KEY_PAIR : 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
     wave_append(key, j, a.lists, a.cnt);
 }
 
@@ -600,7 +609,7 @@ __global__ __launch_bounds__(64) void k_call_pair(PairArgs a) {
         const uint32_t i = base + lane;
         const bool active = i < n_list;
         uint32_t j = 0, L = 0, n_sites = 0, n_ilen = 0;
-        int best = -1, defer_key = 11;
+        int best = -1, defer_key = KEY_NONE;
         bool defer = false;
         if (active) {
             j = a.lists.plist[i];
@@ -839,7 +848,7 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
                 const int key = 2 * c + ((n_paths > 2 || lmax > 64) ? 0 : 1);
                 const uint32_t at = atomicAdd(&a.cnt->q_n[key], 1u);
                 a.queues[(size_t)key * a.nb + at] = j;
-                if (c == 3) atomicMax(&a.cnt->max_need, (unsigned long long)bubble_need(lmax, lmax));
+                if (c == kBubLdsClasses) atomicMax(&a.cnt->max_need, (unsigned long long)bubble_need(lmax, lmax));
                 atomicMax(&a.cnt->retry_need, (unsigned long long)job_bytes((uint32_t)(sum < 60000 ? sum : 60000), lmax));
             }
         }
@@ -1660,7 +1669,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = oom; return PF_ERR_HIP; } } while (0)
     NEED(S->counters, sizeof(CallCounters));
     NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
-    NEED(S->queues, (size_t)8 * nb * 4);
+    NEED(S->queues, (size_t)NQ * nb * 4);
     NEED(S->blist, (size_t)nb * 4);
     NEED(S->res, (size_t)nb * sizeof(pf_bubble_result));
     NEED(S->sv_off, (size_t)nb * 8);
@@ -1710,6 +1719,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = S->res.as<pf_bubble_result>();
         pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), nb};
         pa.snp_ok = snp_ok;
+        pa.pair_ok = pair_tier ? 1 : 0;
         pa.cnt = d_cnt;
         ctx_begin(ctx, PF_K_CALL_PREP);
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
@@ -1719,7 +1729,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
             sn.ct = pa.ct; sn.kept = pa.kept; sn.t0 = t0; sn.nb = nb; sn.slist = pa.lists.slist; sn.seq = ctx->d_seq; sn.off = ctx->d_off;
             sn.len = ctx->d_len; sn.res = pa.res; sn.otext = S->otext.as<char>(); sn.text_cap = cap_text;
             sn.osites = S->osites.as<pf_bubble_site>(); sn.site_cap = cap_sites; sn.ogroups = S->ogroups.as<uint8_t>(); sn.group_cap = cap_groups;
-            sn.heads = d_heads; sn.lists = pa.lists; sn.cnt = d_cnt;
+            sn.heads = d_heads; sn.lists = pa.lists; sn.pair_ok = pa.pair_ok; sn.cnt = d_cnt;
             ctx_begin(ctx, PF_K_CALL_SNP);
             k_call_snp<<<(nb + 255) / 256, 256, 0, st>>>(sn);   // (the list length is on the device: surplus threads leave at once)
             ctx_end(ctx);
@@ -1781,13 +1791,13 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
             continue;
         }
         n_jobs = 0;
-        for (int x = 0; x < 8; ++x) n_jobs += hc.q_n[x];
+        for (int x = 0; x < NQ; ++x) n_jobs += hc.q_n[x];
         // K-BUBBLE: the queues are heavy-then-light per class; compact them into one index array
         NEED(S->scan_tmp2, std::max<size_t>((size_t)n_jobs, 1) * 4);
         {
             uint32_t *d_idx = S->scan_tmp2.as<uint32_t>();
             size_t at = 0;
-            for (int x = 0; x < 8; ++x) {
+            for (int x = 0; x < NQ; ++x) {
                 if (!hc.q_n[x]) continue;
                 PF_HIP(hipMemcpyAsync(d_idx + at, S->queues.as<uint32_t>() + (size_t)x * nb, (size_t)hc.q_n[x] * 4, hipMemcpyDeviceToDevice, st));
                 at += hc.q_n[x];
@@ -1796,7 +1806,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         BubbleLaunch BL;
         BL.text = S->ptext.as<char>(); BL.paths = S->bpath.as<pf_bubble_path>(); BL.tasks = S->btask.as<pf_bubble_task>();
         BL.n_tasks = nb; BL.idx = S->scan_tmp2.as<uint32_t>();
-        for (int c = 0; c < 4; ++c) BL.n_cls[c] = hc.q_n[2 * c] + hc.q_n[2 * c + 1];
+        for (int c = 0; c <= kBubLdsClasses; ++c) BL.n_cls[c] = hc.q_n[2 * c] + hc.q_n[2 * c + 1];
         BL.max_need = hc.max_need; BL.retry_need = hc.retry_need;
         BL.match = match; BL.mismatch = mismatch; BL.gap = gap;
         BL.res = S->res.as<pf_bubble_result>(); BL.otext = S->otext.as<char>(); BL.osites = S->osites.as<pf_bubble_site>();
