@@ -474,6 +474,8 @@ struct SnpArgs {
     CallCounters *cnt;
 };
 
+constexpr uint32_t SNP_STAGE = 8192;   // bytes of LDS per wavefront for its rows (64 bubbles of two 64-base paths)
+
 __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     const int lane = lane_id();
@@ -514,6 +516,25 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
         t_off = tb + (incl - mine);
         s_off = sb + (unsigned long long)__popcll(tm & ((1ull << lane) - 1));
     }
+    // The rows leave through LDS: a wavefront's rows are one contiguous span of the text pool (lane order), so they are staged
+    // per lane and copied out by consecutive lanes -- whole 64-byte segments per store instead of 64 scattered single bytes
+    // (which cost 39 bytes of HBM write traffic per byte written, by the PMC counters).
+    __shared__ char s_rows[4][SNP_STAGE];
+    char *stage = s_rows[threadIdx.x >> 6];
+    uint32_t my_excl = 0, wave_total = 0;
+    {
+        uint32_t mine = take ? 2 * m : 0, incl = mine;
+        for (int o = 1; o < WAVE; o <<= 1) {
+            const uint32_t x = __shfl_up(incl, o, WAVE);
+            if (lane >= o) incl += x;
+        }
+        my_excl = incl - mine;
+        wave_total = __shfl(incl, WAVE - 1, WAVE);
+    }
+    const unsigned long long wave_base = t_off - my_excl;   // (uniform over the taking lanes)
+    const unsigned long long wb = ((unsigned long long)__shfl((uint32_t)(wave_base >> 32), tm ? __ffsll((long long)tm) - 1 : 0, WAVE) << 32) |
+                                  __shfl((uint32_t)wave_base, tm ? __ffsll((long long)tm) - 1 : 0, WAVE);
+    const bool staged = wave_total <= SNP_STAGE;
     if (take) {
         // K-SNP is the first taker of a batch (heads zeroed before it, K-BUBBLE launched behind it on the stream): the group
         // head moves two bytes for every site it takes, so its group offset is twice its site offset
@@ -528,7 +549,7 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
         r.n_indel_len = 0;
         a.res[j] = r;
         if (t_off + 2ull * m <= a.text_cap && s_off + 1 <= a.site_cap && 2 * s_off + 2 <= a.group_cap) {
-            char *o = a.otext + t_off;
+            char *o = staged ? stage + my_excl : a.otext + t_off;
             for (uint32_t c = 0; c < m; ++c) {
                 o[c] = "ACGT"[oriented_base(a.seq, a.off, a.len, ov0, c)];
                 o[m + c] = "ACGT"[oriented_base(a.seq, a.off, a.len, ov1, c)];
@@ -542,6 +563,11 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
             sr.pad_ = 0;
             a.osites[s_off] = sr;
         }
+    }
+    if (tm && staged && wb + wave_total <= a.text_cap) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t x = lane; x < wave_total; x += WAVE) a.otext[wb + x] = stage[x];
     }
     // the rest: K-PAIR when short, else K-BUBBLE's queue of their size class
     int key = KEY_NONE;
@@ -1167,11 +1193,41 @@ __global__ void k_call_has(const pf_bubble_result *__restrict__ res, uint32_t nb
     if (j < nb) has[j] = (res[j].n_rows != 0 && res[j].n_rows != 0xFFFFFFFFu) ? 1u : 0u;
 }
 
+// The write pass stages the four large streams in LDS: consecutive lanes hold consecutive bubbles, so a wavefront's text in a
+// stream is one contiguous span of the output; it is formatted into LDS and copied out by consecutive lanes (whole 64-byte
+// segments per store).  A span that does not fit its stage (long rows) is written directly, byte by byte, as before.
+constexpr uint32_t FMT_BLOCK = 128;
+constexpr uint32_t FMT_STAGE[4] = {12288, 2048, 2048, 3072};   // alignseq, allele_frequency, bifre, bicov
+constexpr int FMT_STAGED_STREAM[4] = {1, 0, 2, 6};
+
 template <bool W>
-__global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
+__global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
     const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index inside the text batch (sizes / offsets)
     const uint32_t j = a.j0 + jj;                                // ... inside the aligned batch (results, numbering, site values)
     unsigned long long allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
+    __shared__ char s_stage[W ? (FMT_BLOCK / 64) * (12288 + 2048 + 2048 + 3072) : 4];
+    bool staged[4] = {false, false, false, false};
+    uint64_t span0[4] = {0, 0, 0, 0};
+    uint32_t span_len[4] = {0, 0, 0, 0};
+    char *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    if (W) {
+        const size_t stride = (size_t)a.nb + 1;
+        const uint32_t w_first = jj & ~63u;
+        if (w_first < a.nb) {   // (wave-uniform)
+            const uint32_t w_end = w_first + 64 < a.nb ? w_first + 64 : a.nb;
+            char *base = s_stage + (threadIdx.x >> 6) * (12288 + 2048 + 2048 + 3072);
+            uint32_t acc = 0;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int st_ = FMT_STAGED_STREAM[q];
+                span0[q] = a.offs[st_ * stride + w_first];
+                span_len[q] = (uint32_t)(a.offs[st_ * stride + w_end] - span0[q]);
+                staged[q] = span_len[q] <= FMT_STAGE[q];
+                stage[q] = base + acc;
+                acc += FMT_STAGE[q];
+            }
+        }
+    }
     if (jj < a.nb) {
         const size_t stride = (size_t)a.nb + 1;
         Row<W> s_all{nullptr, 0}, s_aln{nullptr, 0}, s_fre[4], s_cov[4];
@@ -1184,6 +1240,10 @@ __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
                 s_fre[x].p = a.out[2 + x] + (a.offs[(2 + x) * stride + jj] - a.offs[(2 + x) * stride]);
                 s_cov[x].p = a.out[6 + x] + (a.offs[(6 + x) * stride + jj] - a.offs[(6 + x) * stride]);
             }
+            if (staged[0]) s_aln.p = stage[0] + (a.offs[1 * stride + jj] - span0[0]);
+            if (staged[1]) s_all.p = stage[1] + (a.offs[0 * stride + jj] - span0[1]);
+            if (staged[2]) s_fre[0].p = stage[2] + (a.offs[2 * stride + jj] - span0[2]);
+            if (staged[3]) s_cov[0].p = stage[3] + (a.offs[6 * stride + jj] - span0[3]);
         }
         const pf_bubble_result r = a.res[j];
         if (r.n_rows != 0 && r.n_rows != 0xFFFFFFFFu) {
@@ -1309,6 +1369,18 @@ __global__ __launch_bounds__(256) void k_call_format(FmtArgs a) {
             }
         }
     }
+    if (W) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        const size_t stride = (size_t)a.nb + 1;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            if (!staged[q]) continue;
+            const int st_ = FMT_STAGED_STREAM[q];
+            char *dst = a.out[st_] + (span0[q] - a.offs[st_ * stride]);
+            for (uint32_t x = lane_id(); x < span_len[q]; x += WAVE) dst[x] = stage[q][x];
+        }
+    }
     if (!W) {
         // counters: one atomic per wave and counter
         unsigned long long v[7] = {allele[0], allele[1], allele[2], allele[3], core_cov, core_num, 0};
@@ -1361,31 +1433,56 @@ __global__ void k_sb_count(SbArgs a, uint32_t *cnt) {
     cnt[u] = u < a.N ? sb_rows_of(a, u, p, m) : 0u;
 }
 
+constexpr uint32_t SB_STAGE = 4096;   // bytes of LDS per wavefront for its rows (64 unitigs, at most two rows of < 50 bytes each)
+
 template <bool W>
-__global__ void k_sb_format(SbArgs a) {
+__global__ __launch_bounds__(256) void k_sb_format(SbArgs a) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
-    if (u > a.N) return;
-    if (u == a.N) { if (!W) a.sizes[u] = 0; return; }
-    bool rows[2];
-    const uint32_t n = sb_rows_of(a, u, rows[0], rows[1]);
-    Row<W> o{W ? a.out + a.offs[u] : nullptr, 0};
-    if (n) {
-        const uint8_t f = a.flags[u];
-        uint64_t nb = (uint64_t)a.row_base[u] + a.first_id;
-        for (int side = 0; side < 2; ++side) {
-            if (!rows[side]) continue;
-            const bool ps = side == 0;
-            put_uint(o, nb++);
-            o.put('\t');
-            put_uint(o, (uint64_t)u + 1);
-            o.put('\t'); o.put(ps ? '+' : '-'); o.put('\t');
-            put_uint(o, ps ? a.plus[u] : a.minus[u]);
-            o.put('\t'); o.put((f & (ps ? B_STRICT_P : B_STRICT_M)) ? '1' : '0');
-            o.put('\t'); o.put((f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? '1' : '0');
-            o.put('\n');
+    // write pass: a wavefront's rows are one contiguous span of the file; staged in LDS and copied out by consecutive lanes
+    __shared__ char s_stage[W ? 4 * SB_STAGE : 4];
+    char *stage = s_stage + (threadIdx.x >> 6) * SB_STAGE;
+    uint64_t span0 = 0;
+    uint32_t span_len = 0;
+    bool staged = false;
+    if (W) {
+        const uint32_t w_first = u & ~63u;
+        if (w_first < a.N) {
+            const uint32_t w_end = w_first + 64 < a.N ? w_first + 64 : a.N;
+            span0 = a.offs[w_first];
+            span_len = (uint32_t)(a.offs[w_end] - span0);
+            staged = span_len <= SB_STAGE;
         }
     }
-    if (!W) a.sizes[u] = o.n;
+    if (u < a.N) {
+        bool rows[2];
+        const uint32_t n = sb_rows_of(a, u, rows[0], rows[1]);
+        Row<W> o{W ? (staged ? stage + (a.offs[u] - span0) : a.out + a.offs[u]) : nullptr, 0};
+        if (n) {
+            const uint8_t f = a.flags[u];
+            uint64_t nb = (uint64_t)a.row_base[u] + a.first_id;
+            for (int side = 0; side < 2; ++side) {
+                if (!rows[side]) continue;
+                const bool ps = side == 0;
+                put_uint(o, nb++);
+                o.put('\t');
+                put_uint(o, (uint64_t)u + 1);
+                o.put('\t'); o.put(ps ? '+' : '-'); o.put('\t');
+                put_uint(o, ps ? a.plus[u] : a.minus[u]);
+                o.put('\t'); o.put((f & (ps ? B_STRICT_P : B_STRICT_M)) ? '1' : '0');
+                o.put('\t'); o.put((f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) ? '1' : '0');
+                o.put('\n');
+            }
+        }
+        if (!W) a.sizes[u] = o.n;
+    } else if (u == a.N && !W) {
+        a.sizes[u] = 0;
+    }
+    if (W && staged) {
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        char *dst = a.out + span0;
+        for (uint32_t x = lane_id(); x < span_len; x += WAVE) dst[x] = stage[x];
+    }
 }
 
 struct Widen {
@@ -1925,7 +2022,7 @@ int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, ui
     fa.vc_base = var_count_base; fa.mt = S->mt_format ? 1 : 0; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
     for (int s = 0; s < N_STREAMS; ++s) fa.out[s] = nullptr;
     ctx_begin(ctx, PF_K_CALL_FORMAT);
-    k_call_format<false><<<(nb + 1 + 255) / 256, 256, 0, st>>>(fa);
+    k_call_format<false><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end(ctx);
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
     k_call_totals<<<1, 64, 0, st>>>(S->offs.as<uint64_t>(), S->sizes.as<uint32_t>(), nb, S->totals.as<uint64_t>());
@@ -1940,7 +2037,7 @@ int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, ui
         out->text_len[s] = totals[s];
     }
     ctx_begin(ctx, PF_K_CALL_FORMAT);
-    k_call_format<true><<<(nb + 255) / 256, 256, 0, st>>>(fa);
+    k_call_format<true><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end(ctx);
     PF_HIP(hipGetLastError());
     PF_HIP(hipStreamSynchronize(st));
