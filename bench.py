@@ -451,8 +451,9 @@ def main():
                                             "(%d bytes per pass) and replayed on every rank; bubble list in contiguous slices, two small "
                                             "all-gathers (bubbles called; slab sizes + allele histograms), every rank writes its slabs into "
                                             "the shared files" % shard_stats.get("find_gathered_bytes", 0) if strong else
-                                            "independent unitig partitions per rank; per-pass RCCL all-gather of site counters "
-                                            "and allele-frequency record slabs (%d bytes)" % gathered_bytes[0])},
+                                            "one rank, whole graph" if world == 1 else
+                                            "one independent graph per rank (weak scaling), no data-path collective; "
+                                            "per-pass all-gather of the site counters only (%d bytes)" % gathered_bytes[0])},
                 "roofline": roof, "roofline_issue": issue_roofline(dom, kernels[dom]["avg_ms"], n_unitigs) if dom else None,
                 "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for e in kernels.values()), 3),
