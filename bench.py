@@ -190,15 +190,19 @@ def cpu_model() -> str:
 
 
 # algorithmic HBM bytes per launch (restated in DESIGN.md)
-def algorithmic_bytes(kernel: str, t: dict) -> float | None:
+def algorithmic_bytes(kernel: str, t: dict, units: float | None = None) -> float | None:
+    """Per pass.  `units` = work items the kernel's launches were given per pass (pf_kernel_units): the tiers of K-BFS and of
+    the alignment (K-SNP / K-PAIR / K-BUBBLE) share one per-unit figure and are priced on what each of them actually took."""
     if kernel == "k_cov":  # streaming form: 4 B count + 1 head bit per k-mer, 4 B row id per 64 k-mers, 16 B of results per unitig
         return (4.0 + 1.0 / 8 + 4.0 / 64) * t["kmers"] + 16.0 * t["unitigs"]
     if kernel in ("k_cov_probe", "k_cov_join"):  # SURVEY.md 8(d): 0.25 B sequence + 12 B table slot per k-mer (+ 4 B joined count / 16 B result)
         return 12.25 * t["kmers"] + 16.0 * t["unitigs"]
-    if kernel == "k_bfs":
-        return 600.0 * t["candidates"]
-    if kernel in ("k_align", "k_bubble"):
-        return 300.0 * t["align_jobs"]
+    if kernel in ("k_bfs", "k_bfs_thread"):
+        return 600.0 * (units if units is not None else t["candidates"])
+    if kernel in ("k_align", "k_bubble", "k_call_snp", "k_call_pair"):
+        return 300.0 * (units if units is not None else t["align_jobs"])
+    if kernel == "k_call_format":  # K-TEXT: the result text itself (written once; its inputs are a fraction of it)
+        return float(t["output_bytes"])
     if kernel == "k_strcov":
         return 12.0 * 2.0 * t["site_strings"]
     if kernel == "k_cov_colored":  # streaming form: 4 B count per (k-mer, colour), head bit + row id per k-mer, 17 B of results per (colour, unitig)
@@ -350,12 +354,15 @@ def main():
         tt = run.times()
 
         # kernel times from HIP events recorded by the library on its launch stream
-        ktimes = {}
+        ktimes, kunits = {}, {}
         for i, name in enumerate(hipapi.KERNELS):
             ms, n = C.c_double(), C.c_uint64()
             L.pf_kernel_time(ctx, i, C.byref(ms), C.byref(n))
             if n.value:
                 ktimes[name] = (ms.value, n.value)
+                u = C.c_uint64()
+                L.pf_kernel_units(ctx, i, C.byref(u))
+                kunits[name] = u.value
 
         # outside the timed region: C1 computed the other way (every k-mer probed in the hash table, what K-COV-JOIN does once
         # at load) -- its duration, and that both routes agree on this graph
@@ -412,11 +419,14 @@ def main():
             kernels = {}
             dom, dom_ms = None, -1.0
             for name, (ms, n) in ktimes.items():
-                ab = algorithmic_bytes(name, tt)
+                units = kunits.get(name) / args.steps if kunits.get(name) else None
+                ab = algorithmic_bytes(name, tt, units)
                 avg_ms = ms / n
                 launches_per_step = n / args.steps
                 entry = {"avg_ms": round(avg_ms, 4), "launches_per_step": launches_per_step,
                          "ms_per_step": round(ms / args.steps, 3)}
+                if units is not None:
+                    entry["units_per_step"] = round(units, 1)
                 if ab is not None:
                     per_launch = ab / launches_per_step
                     entry["algorithmic_bytes_per_launch"] = per_launch
@@ -468,6 +478,7 @@ def main():
                 "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"],
                            "bubbles_called": shard_stats["counters"][7] if strong else tt["tasks"],
                            "align_jobs": tt["align_jobs"], "site_strings": tt["site_strings"],
+                           "align_jobs_by_kernel": {"k_call_snp": tt["snp_jobs"], "k_call_pair": tt["pair_jobs"], "k_bubble": tt["wave_jobs"]},
                            "sites": shard_stats["counters"][:4] if strong else tt["allele"],
                            "output_bytes": shard_stats["output_bytes"] if strong else tt["output_bytes"]},
             }

@@ -63,6 +63,9 @@ enum pf_kernel {
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
 int pf_reset_timing(pf_ctx *);
+/* Work items the timed launches of a kernel were given since the last reset, in the unit its algorithmic bytes are quoted per
+ * (DESIGN.md 3): candidates for K-BFS's tiers, bubbles for K-SNP / K-PAIR / K-BUBBLE / K-PATHS / K-SITES / K-TEXT, sides for K-SCAN. */
+int pf_kernel_units(pf_ctx *, int kernel, uint64_t *units);
 const char *pf_kernel_name(int kernel);
 
 /* ---- graph (replaces Bifrost's CompactedDBG storage for this path) --------------------- */
@@ -311,6 +314,7 @@ typedef struct pf_call_result {
     uint64_t core_cov, core_num;        /* coreCov / coreNum (:1261-1262) */
     uint64_t n_called;                  /* bubbles whose alignment left rows: var_count advances by this */
     uint64_t align_jobs, site_strings, n_branching;
+    uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: finished by K-SNP, by K-PAIR, sent to K-BUBBLE */
 } pf_call_result;
 /* Bubbles [t0, t1) of the selection (at most 2^24): everything up to the text of the ten streams, left in slab 0 or 1 of the
  * context; var_count_base = bubbles called by earlier batches.  complex_size = -z (bounds the walk stacks). */

@@ -30,6 +30,7 @@ typedef struct pfh_times {
     double scan_s, scan_serial_s; /* owner/order scan of PloidyEstimation: whole, and its sequential part */
     uint64_t bfs_large, bfs_max_seen; /* K-BFS traversals of more than 4096 vertices in the last findSuperBubble; the longest one */
     uint64_t bfs_deferred;            /* candidates that left the device's LDS tier (128 entries) for the host walkers */
+    uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: bubbles finished by K-SNP, by K-PAIR, sent to K-BUBBLE (resident pipeline) */
 } pfh_times;
 
 /* NULL on failure: message via pfh_last_error(NULL) */

@@ -809,6 +809,7 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         ctx_begin(ctx, PF_K_BUBBLE);
         k_bubble<true><<<grid, 64, kBubClassBytes[c], st>>>(p, o);
         ctx_end(ctx);
+        ctx_units(ctx, PF_K_BUBBLE, nc);
         idx_off += nc;
     }
     if (L.n_cls[kBubLdsClasses]) {
@@ -826,6 +827,7 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         ctx_begin(ctx, PF_K_BUBBLE_BIG);
         k_bubble<false><<<grid, 64, 0, st>>>(p, o);
         ctx_end(ctx);
+        ctx_units(ctx, PF_K_BUBBLE_BIG, nc);
     }
     unsigned int n_retry = 0;
     PF_HIP(hipMemcpyAsync(&n_retry, o.n_retry, 4, hipMemcpyDeviceToHost, st));

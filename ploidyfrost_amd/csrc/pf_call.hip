@@ -1661,6 +1661,7 @@ int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides)
     ctx_begin(ctx, PF_K_CALL_SCAN);
     k_call_sides<<<(N + 255) / 256, 256, 0, st>>>(a);
     ctx_end(ctx);
+    ctx_units(ctx, PF_K_CALL_SCAN, N);
     PF_HIP(hipGetLastError());
     return PF_OK;
 }
@@ -1871,6 +1872,10 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
+        ctx_units(ctx, PF_K_CALL_PREP, nb);
+        if (snp_ok) ctx_units(ctx, PF_K_CALL_SNP, hc.n_snp);
+        if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair);
+        ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (hc.err & 1u) { ctx->err = "pf_call_run: a bubble has more than 255 paths"; return PF_ERR_ARG; }
         if (hc.err & 32u) { ctx->err = "pf_call_run: a bubble is deeper than the complex size allows"; return PF_ERR_ARG; }
         S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
@@ -1923,6 +1928,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
     }
     out->n_branching = hc.n_branching;
     out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done;
+    out->snp_jobs = hc.n_snp_done; out->pair_jobs = hc.n_pair_done; out->wave_jobs = n_jobs;
 
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);
@@ -1946,6 +1952,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
             ctx_begin(ctx, PF_K_CALL_SITES);
             k_call_sites<<<sites_grid, 64, 0, st>>>(sa);
             ctx_end(ctx);
+            ctx_units(ctx, PF_K_CALL_SITES, hc.n_branching);
             PF_HIP(hipGetLastError());
             PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
             PF_HIP(hipStreamSynchronize(st));
@@ -2039,6 +2046,7 @@ int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, ui
     ctx_begin(ctx, PF_K_CALL_FORMAT);
     k_call_format<true><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end(ctx);
+    ctx_units(ctx, PF_K_CALL_FORMAT, nb);
     PF_HIP(hipGetLastError());
     PF_HIP(hipStreamSynchronize(st));
     for (int x = 0; x < 4; ++x) out->allele[x] = hc.allele[x];

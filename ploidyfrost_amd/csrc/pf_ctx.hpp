@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "pf_device_common.hpp"
+#include "ploidyfrost_hip.h"
 
 namespace pf {
 // device allocation that lives until the end of the enclosing call, freed on every return path
@@ -103,6 +104,7 @@ struct pf_ctx {
 
     bool timing = false;
     std::vector<pf::TimedLaunch> launches;
+    uint64_t units[PF_K_COUNT_] = {};  // work items handed to the timed launches of each kernel (pf_kernel_units)
 };
 
 namespace pf {
@@ -110,6 +112,7 @@ struct Kc4Args;
 int launch_cov_stream(pf_ctx *ctx, Kc4Args a, uint32_t n_colors, bool wide, bool colored);  // pf_device.hip
 int ctx_begin(pf_ctx *ctx, int kernel);
 void ctx_end(pf_ctx *ctx);
+inline void ctx_units(pf_ctx *ctx, int kernel, uint64_t n) { if (ctx->timing) ctx->units[kernel] += n; }
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
 int join_graph_counts(pf_ctx *ctx);
 int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the joined table of all colours (pf_ctx::d_gcov_c)  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident

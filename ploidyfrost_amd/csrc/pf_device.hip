@@ -804,6 +804,13 @@ int pf_reset_timing(pf_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
     ctx->launches.clear();
+    memset(ctx->units, 0, sizeof(ctx->units));
+    return PF_OK;
+}
+
+int pf_kernel_units(pf_ctx *ctx, int kernel, uint64_t *units) {
+    if (!ctx || kernel < 0 || kernel >= PF_K_COUNT_ || !units) return PF_ERR_ARG;
+    *units = ctx->units[kernel];
     return PF_OK;
 }
 
@@ -1311,9 +1318,12 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
         k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, nullptr, nullptr);
         ctx_end(ctx);
     }
-    unsigned int n_def = 0;
+    unsigned int n_def = 0, n_wl = 0;
     PF_HIP(hipMemcpyAsync(&n_def, d_ndef, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (ctx->timing && thread_tier) PF_HIP(hipMemcpyAsync(&n_wl, d_nwlist, 4, hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx_units(ctx, PF_K_BFS, thread_tier ? n_wl : n);
+    if (thread_tier) ctx_units(ctx, PF_K_BFS_THREAD, n);
     int status = PF_OK;
     if (n_def && deferred) {
         // the caller walks everything that outgrew the LDS tier itself (a host core needs ~20 ns per vertex; the 4096-entry

@@ -31,7 +31,8 @@ ALIGN_HIT = np.dtype([("text_off", "<u8"), ("gap_off", "<u8"), ("len", "<u4"), (
 CALL_SIDE = np.dtype([("u", "<u4"), ("exit_ov", "<u4"), ("err_unitig", "<u4"), ("plus_side", "u1"), ("kind", "u1"), ("aligned", "u1"),
                       ("err", "u1")])
 CALL_RESULT = np.dtype([("text_len", "<u8", (10,)), ("allele", "<u8", (4,)), ("core_cov", "<u8"), ("core_num", "<u8"), ("n_called", "<u8"),
-                        ("align_jobs", "<u8"), ("site_strings", "<u8"), ("n_branching", "<u8")])
+                        ("align_jobs", "<u8"), ("site_strings", "<u8"), ("n_branching", "<u8"),
+                        ("snp_jobs", "<u8"), ("pair_jobs", "<u8"), ("wave_jobs", "<u8")])
 CALL_STREAMS = ["allele_frequency", "alignseq", "bifre", "trifre", "tetrafre", "pentafre", "bicov", "tricov", "tetracov", "pentacov"]
 BUBBLE_PATH = np.dtype([("text_off", "<u8"), ("len", "<u4"), ("ov", "<u4")])
 BUBBLE_TASK = np.dtype([("path_first", "<u8"), ("n_paths", "<u4"), ("pad", "<u4")])
@@ -74,6 +75,7 @@ def load_library() -> C.CDLL:
         "pf_enable_timing": (i, [vp, i]),
         "pf_kernel_time": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(u64)]),
         "pf_reset_timing": (i, [vp]),
+        "pf_kernel_units": (i, [vp, i, C.POINTER(u64)]),
         "pf_kernel_name": (C.c_char_p, [i]),
         "pf_upload_graph": (i, [vp, vp, vp, vp, u32, i]),
         "pf_build_adjacency": (i, [vp, vp, vp]),
@@ -133,7 +135,7 @@ def load_library() -> C.CDLL:
 
 
 DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
-                    "pf_kernel_time", "pf_reset_timing", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
+                    "pf_kernel_time", "pf_reset_timing", "pf_kernel_units", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
