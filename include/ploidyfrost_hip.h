@@ -337,6 +337,22 @@ int pf_call_fetch(pf_ctx *, int slab, int stream, char *dst, uint64_t len);
  * [host|dev] */
 int pf_format_doubles(pf_ctx *, const double *values, uint64_t n, char *text, uint8_t *len);
 
+/* ---- K-CC: which traversal records may be committed side by side (pf_cc.hip) ------------------------------------------
+ * The commits of findSuperBubble are order-dependent (src/CDBG.cpp:206-214: candidate entrances in unitig order behind the
+ * `partner == NULL` gate), but two records whose footprints -- the unitig sides they can touch -- are disjoint commute.
+ * pf_side_components adds the records of one slice of a pass to a union-find over the 2N sides (reset != 0 starts a pass):
+ *   records == NULL: the n_records records and the vertex pool the last pf_bfs_candidates* call left on the device;
+ *   otherwise records / pool [host|dev] as pf_bfs_candidates returns them (list_off into pool).
+ *   extra: n_extra records [host|dev] with lists in extra_pool -- the traversals a caller of pf_bfs_candidates_split walked
+ *   itself; they add their footprints only (their labels come from their entrances like everyone's).
+ * pf_replay_order then labels every record of that slice with its component and deals the components into n_classes (<= 1024)
+ * work units: order[n_records] = record indices grouped by class, ascending inside a class; class_off[n_classes + 1] (host);
+ * labels (optional, [host|dev]) = the component label of each record's entrance side.  A record naming a vertex outside the
+ * graph or a list outside its pool is refused (PF_ERR_ARG). */
+int pf_side_components(pf_ctx *, int reset, const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint64_t pool_len,
+                       const pf_bfs_record *extra, uint64_t n_extra, const uint32_t *extra_pool, uint64_t extra_pool_len);
+int pf_replay_order(pf_ctx *, uint32_t n_classes, uint32_t *order, uint32_t *class_off, uint32_t *labels);
+
 /* ---- colored (multi-sample) coverage: reference src/CCDBG.cpp ------------------------------------- */
 /* CCDBG::CCDBG (src/CCDBG.cpp:13-43) opens one KMC database per colour.  Here the records of all colours
  * are joined into one HBM table keyed by the stored k-mer with one count per colour, so a k-mer costs one

@@ -153,8 +153,15 @@ int pfh_host_walk(const uint32_t *succ, const uint32_t *pred, uint32_t n_unitigs
 int pfh_find_shard(pfh_run *, uint32_t u0, uint32_t u1);
 const pf_bfs_record *pfh_shard_records(const pfh_run *, uint64_t *n_records);
 const uint32_t *pfh_shard_pool(const pfh_run *, uint64_t *n_entries);
+/* pool_lens (entries of each pool; NULL = sequential replay): the commits run on host threads, component by component
+ * (pfh_set_replay_threads; csrc/host/pf_replay_par.hpp), the components found on the device -- from dev_records / dev_pools when the
+ * shards already lie in device memory (the all-gather's output), else from an upload of records / pools. */
 int pfh_find_replay(pfh_run *, const char *outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
-                    const uint32_t *const *pools, int write_file);
+                    const uint32_t *const *pools, int write_file, const uint64_t *pool_lens, const pf_bfs_record *const *dev_records,
+                    const uint32_t *const *dev_pools);
+/* host threads of the commit replay in findSuperBubble / pfh_find_replay: 0 = the sequential loop, -1 = default (min(threads, 16),
+ * single-sample path only) */
+void pfh_set_replay_threads(pfh_run *, int threads);
 int pfh_ploidy_select(pfh_run *, int lower, int upper, uint64_t *n_bubbles);
 int pfh_ploidy_align(pfh_run *, uint64_t t0, uint64_t t1, uint64_t *n_called);
 int pfh_ploidy_text(pfh_run *, uint64_t var_count_base, uint64_t sizes[10], uint64_t counters[8]);
@@ -171,6 +178,16 @@ pfh_replay *pfh_replay_open(uint32_t n_unitigs, uint32_t complex_size);
 void pfh_replay_close(pfh_replay *);
 int pfh_replay_apply(pfh_replay *, const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool);
 void pfh_replay_state(const pfh_replay *, uint8_t *flags, uint32_t *plus, uint32_t *minus);
+/* The same replay spread over `threads` host threads: records whose footprints (the unitig sides they can touch) are disjoint
+ * commute, so the connected components of {sides, "touched by one record"} are replayed side by side, each in record order
+ * (csrc/host/pf_replay_par.hpp).  A handle takes either this call or pfh_replay_apply.  pfh_side_components: the component
+ * label of every record's entrance side (what pf_side_components computes on the device); pfh_replay_check_footprints: the
+ * sequential replay with every state access checked against those components, `slice` records at a time (0 = all at once)
+ * -> number of accesses outside the running record's component (0 = the model holds), *first_bad = the first such record. */
+int pfh_replay_apply_parallel(pfh_replay *, const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t threads);
+void pfh_side_components(const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t n_unitigs, uint32_t *labels);
+uint64_t pfh_replay_check_footprints(const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t n_unitigs,
+                                     uint32_t complex_size, uint64_t slice, uint64_t *first_bad);
 
 /* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);

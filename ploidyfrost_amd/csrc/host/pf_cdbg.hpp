@@ -32,6 +32,7 @@
 #include "pf_host_colors.hpp"
 #include "pf_host_graph.hpp"
 #include "pf_pinned.hpp"
+#include "pf_replay_par.hpp"
 #include "pf_state.hpp"
 #include "ploidyfrost_hip.h"
 
@@ -117,8 +118,13 @@ public:
     int find_shard(uint32_t u0, uint32_t u1);
     const std::vector<pf_bfs_record> &shard_records() const { return shard_rec_; }
     const std::vector<uint32_t> &shard_pool() const { return shard_pool_; }
+    // dev_records / dev_pools (optional): the same shards where they already lie in device memory (after an all-gather), so that
+    // the components of the parallel replay are found without another upload; pool_lens = entries of each pool
     int find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
-                    const uint32_t *const *pools, bool write_file);
+                    const uint32_t *const *pools, bool write_file, const uint64_t *pool_lens = nullptr,
+                    const pf_bfs_record *const *dev_records = nullptr, const uint32_t *const *dev_pools = nullptr);
+    // the commit replay on host threads (pf_replay_par.hpp): 0 = sequential; default min(threads, 16) for the single-sample path
+    void set_replay_threads(int t) { replay_threads_ = t; }
     int ploidy_select(int lower, int upper, uint64_t &n_bubbles);
     int ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called);
     int ploidy_text(uint64_t var_count_base, uint64_t sizes[PF_CALL_STREAMS], uint64_t counters[8]);
@@ -190,6 +196,9 @@ protected:
     bool quiet_ = false, write_files_ = true;
     bool both_strands_ = true;
     unsigned threads_ = 0;
+    int replay_threads_ = -1;   // -1: default
+    ParallelReplay par_;
+    unsigned replay_threads(size_t thr) const;
     // third K-BFS tier (traversals beyond 4096 vertices) on host cores, pf_bfs_host.hpp; false = the device's k_bfs_huge
     bool third_tier_on_host_ = true;
     std::vector<std::unique_ptr<HugeWalker>> walkers_;
@@ -224,13 +233,14 @@ protected:
     struct BubbleExchange {
         PinnedBuf<pf_bfs_record> bfs_rec;
         PinnedBuf<uint32_t> bfs_pool;
+        PinnedBuf<uint32_t> bfs_order;   // parallel replay: record indices grouped by class (pf_replay_order)
         PinnedBuf<uint64_t> cov_sum;
         PinnedBuf<uint32_t> cov_min;
         PinnedBuf<uint8_t> cov_miss;
         PinnedBuf<uint32_t> cov_max;  // colored path: per (colour, unitig) arrays, colour-major
         void release_all() {
             cov_max.release();
-            bfs_rec.release(); bfs_pool.release(); cov_sum.release(); cov_min.release();
+            bfs_rec.release(); bfs_pool.release(); bfs_order.release(); cov_sum.release(); cov_min.release();
             cov_miss.release();
         }
     } bx_;

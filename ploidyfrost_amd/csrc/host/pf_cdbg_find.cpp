@@ -21,6 +21,17 @@
 
 namespace pfh {
 
+// Threads of the parallel commit replay: the single-sample path only (the colour gates of CCDBG's accept commit write NON_SUPER
+// on endpoints, outside the footprint model), PF_REPLAY=seq or one thread keep the sequential loop.
+unsigned CDBG::replay_threads(size_t thr) const {
+    if (col_ != nullptr) return 0;
+    static const char *env = getenv("PF_REPLAY");
+    if (env && !strcmp(env, "seq")) return 0;
+    static const int env_t = [] { const char *e = getenv("PF_REPLAY_THREADS"); return e ? atoi(e) : -1; }();
+    int t = replay_threads_ >= 0 ? replay_threads_ : env_t >= 0 ? env_t : (int)std::min<size_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), 16);
+    return t >= 2 ? (unsigned)t : 0;
+}
+
 // ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
 int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thr) {
     if (status_) return status_;
@@ -34,9 +45,14 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     if (!quiet_) printf("%s::findSuperBubble(): There are %u unitigs \n", tag_, N);
     out_bytes_ = 0;
     state_on_device_ = false;
-    std::fill(flags_.begin(), flags_.end(), 0);
-    std::fill(plus_.begin(), plus_.end(), 0);
-    std::fill(minus_.begin(), minus_.end(), 0);
+    const unsigned rt = replay_threads(thr);
+    const unsigned zt = std::max<unsigned>(rt, (unsigned)std::min<size_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), 8));
+    parallel_chunks(N, 1u << 19, zt, [&](size_t, size_t b, size_t e) {
+        memset(flags_.data() + b, 0, e - b);
+        memset(plus_.data() + b, 0, (e - b) * 4);
+        memset(minus_.data() + b, 0, (e - b) * 4);
+    });
+    if (rt) par_.begin(N, plus_.data(), minus_.data(), complex_size_, rt);
 
     // Every candidate entrance is traversed on the device, one wavefront each.  The unitig range is cut into slices:
     // a helper thread (the only one issuing device calls here) runs K-BFS slice by slice and, after the last one, the
@@ -67,6 +83,8 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     tf("candidates counted");
     bx_.bfs_rec.ensure(ctx_, s_rec0[kSlices]);
     bx_.bfs_pool.ensure(ctx_, s_pool0[kSlices]);
+    if (rt) bx_.bfs_order.ensure(ctx_, s_rec0[kSlices]);
+    uint32_t class_off[kMaxSlices][kReplayClasses + 1];
     tf("pinned record buffers");
     pf_bfs_record *rec = bx_.bfs_rec.p;
     // a slice whose pool guess was too small gets a buffer of its own
@@ -136,6 +154,23 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                     }
                 });
             }
+            if (st1 == PF_OK && rt) {
+                // K-CC: the slice's records join the components (they are still on the device; the traversals walked on the host
+                // add their footprints from here), then the slice's commit order by component class
+                std::vector<pf_bfs_record> xrec;
+                std::vector<uint32_t> xpool;
+                const pf_bfs_record *srec = rec + s_rec0[i];
+                for (uint64_t d = 0; d < n_deferred; ++d) {
+                    pf_bfs_record r = srec[deferred[d]];
+                    const std::vector<uint32_t> &l = huge_lists_[i][(size_t)d];
+                    r.list_off = xpool.size();
+                    r.pad_ = 0;
+                    xpool.insert(xpool.end(), l.begin(), l.begin() + r.n_list);
+                    xrec.push_back(r);
+                }
+                st1 = pf_side_components(ctx_, i == 0, nullptr, s_nrec[i], nullptr, 0, xrec.data(), xrec.size(), xpool.data(), xpool.size());
+                if (st1 == PF_OK) st1 = pf_replay_order(ctx_, kReplayClasses, bx_.bfs_order.p + s_rec0[i], class_off[i], nullptr);
+            }
             bfs_s += since(tb);
             {
                 std::lock_guard<std::mutex> lk(mu);
@@ -165,6 +200,14 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         const uint64_t n_rec = s_nrec[sl];
         const uint32_t *pool = slice_pool[sl];
         n_rec_total += n_rec;
+        if (rt) {
+            ReplayStats rs;
+            auto list_of = [&](const pf_bfs_record &r) { return r.pad_ ? huge_lists_[sl][r.list_off].data() : pool + r.list_off; };
+            par_.run(srec, list_of, bx_.bfs_order.p + s_rec0[sl], class_off[sl], kReplayClasses, rt, rs);
+            times_.bfs_large += rs.large; times_.bfs_large_seen += rs.large_seen; times_.bfs_large_used += rs.large_used;
+            times_.bfs_max_seen = std::max<uint64_t>(times_.bfs_max_seen, rs.max_seen);
+            times_.bfs_large_used_max = std::max<uint64_t>(times_.bfs_large_used_max, rs.large_used_max);
+        } else
         for (uint64_t i = 0; i < n_rec; ++i) {
             // the commits chase per-unitig state at random: pull the state of a record a few iterations ahead into cache
             if (i + 12 < n_rec) {
@@ -192,6 +235,11 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             if (r.n_seen > 4096) { times_.bfs_large_used++; if (r.n_seen > times_.bfs_large_used_max) times_.bfs_large_used_max = r.n_seen; }
             replay(r, r.pad_ ? huge_lists_[sl][r.list_off].data() : pool + r.list_off);
         }
+        replay_s += since(tr);
+    }
+    if (rt && st == PF_OK) {
+        const auto tr = clk::now();
+        par_.finish(flags_.data(), rt);
         replay_s += since(tr);
     }
     tf("replay done");
@@ -317,7 +365,8 @@ int CDBG::find_shard(uint32_t u0, uint32_t u1) {
 // The commit replay over the records of all shards, in shard order = entrance order (reference visiting order, src/CDBG.cpp:
 // 206-214), then the rows of super_bubble.txt; every rank ends with the same state.
 int CDBG::find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
-                      const uint32_t *const *pools, bool write_file) {
+                      const uint32_t *const *pools, bool write_file, const uint64_t *pool_lens, const pf_bfs_record *const *dev_records,
+                      const uint32_t *const *dev_pools) {
     if (status_) return status_;
     if (join_pending_write()) return status_;
     if (write_file && write_files_ && ensure_dir()) return status_;
@@ -332,11 +381,35 @@ int CDBG::find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs
     const auto tr = clk::now();
     uint64_t total = 0;
     uint32_t last = 0;
+    // the parallel replay needs the lengths of the pools (the device refuses lists outside them)
+    const unsigned rt = pool_lens ? replay_threads(threads_ ? threads_ : 1) : 0;
+    if (rt) par_.begin(g_.n(), plus_.data(), minus_.data(), complex_size_, rt);
+    std::vector<uint32_t> order;
+    bool seen_any = false;
     for (uint32_t sh = 0; sh < n_shards; ++sh) {
         const pf_bfs_record *rec = records[sh];
         const uint32_t *pool = pools[sh];
         const uint64_t n = n_records[sh];
         total += n;
+        if (rt) {
+            for (uint64_t i = 0; i < n; ++i) {
+                const pf_bfs_record &r = rec[i];
+                if ((r.entrance >> 1) >= g_.n() || (seen_any && r.entrance < last)) return fail(PF_ERR_ARG, "CDBG::find_replay(): records out of order");
+                last = r.entrance;
+                seen_any = true;
+            }
+            const bool on_dev = dev_records && dev_pools && dev_records[sh] && dev_pools[sh];
+            int st = pf_side_components(ctx_, sh == 0, on_dev ? dev_records[sh] : rec, n, on_dev ? dev_pools[sh] : pool, pool_lens[sh], nullptr, 0, nullptr, 0);
+            uint32_t class_off[kReplayClasses + 1];
+            order.resize(std::max<uint64_t>(n, 1));
+            if (st == PF_OK) st = pf_replay_order(ctx_, kReplayClasses, order.data(), class_off, nullptr);
+            if (st != PF_OK) return fail(st, std::string("CDBG::find_replay(): ") + pf_last_error(ctx_));
+            ReplayStats rs;
+            par_.run(rec, [&](const pf_bfs_record &r) { return pool + r.list_off; }, order.data(), class_off, kReplayClasses, rt, rs);
+            times_.bfs_large += rs.large; times_.bfs_large_seen += rs.large_seen;
+            times_.bfs_max_seen = std::max<uint64_t>(times_.bfs_max_seen, rs.max_seen);
+            continue;
+        }
         for (uint64_t i = 0; i < n; ++i) {
             if (i + 8 < n) {
                 const pf_bfs_record &nx = rec[i + 8];
@@ -353,6 +426,7 @@ int CDBG::find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs
             replay(r, pool + r.list_off);
         }
     }
+    if (rt) par_.finish(flags_.data(), rt);
     times_.replay_s = since(tr);
     times_.candidates = total;
     return finish_find(outpre, 1, t_all, write_file);

@@ -9,6 +9,7 @@
 #include "pf_cdbg.hpp"
 #include "pf_gmm_model.hpp"
 #include "pf_host_colors.hpp"
+#include "pf_replay_par.hpp"
 #include "ploidyfrost_host.h"
 
 struct pfh_run {
@@ -155,9 +156,11 @@ const uint32_t *pfh_shard_pool(const pfh_run *r, uint64_t *n) {
     return r->cdbg->shard_pool().data();
 }
 int pfh_find_replay(pfh_run *r, const char *outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
-                    const uint32_t *const *pools, int write_file) {
-    return guarded(r, [&] { return r->cdbg->find_replay(outpre, n_shards, records, n_records, pools, write_file != 0); });
+                    const uint32_t *const *pools, int write_file, const uint64_t *pool_lens, const pf_bfs_record *const *dev_records,
+                    const uint32_t *const *dev_pools) {
+    return guarded(r, [&] { return r->cdbg->find_replay(outpre, n_shards, records, n_records, pools, write_file != 0, pool_lens, dev_records, dev_pools); });
 }
+void pfh_set_replay_threads(pfh_run *r, int threads) { r->cdbg->set_replay_threads(threads); }
 int pfh_ploidy_select(pfh_run *r, int lower, int upper, uint64_t *n_bubbles) {
     return guarded(r, [&] { uint64_t n = 0; const int rc = r->cdbg->ploidy_select(lower, upper, n); if (n_bubbles) *n_bubbles = n; return rc; });
 }
@@ -207,6 +210,10 @@ struct pfh_replay {
     pfh::UnitigState st;
     uint32_t last = 0;
     bool any = false;
+    // pfh_replay_apply_parallel
+    bool par = false;
+    pfh::SideComponents cc;
+    pfh::ParallelReplay pr;
 };
 extern "C" {
 pfh_replay *pfh_replay_open(uint32_t n_unitigs, uint32_t complex_size) {
@@ -232,6 +239,43 @@ int pfh_replay_apply(pfh_replay *h, const pf_bfs_record *records, uint64_t n_rec
         h->st.replay(r, pool + r.list_off);
     }
     return 0;
+}
+// The same shard through the parallel replay (pf_replay_par.hpp): components on the host, `threads` workers.  One handle takes
+// either this call or pfh_replay_apply, not both.
+int pfh_replay_apply_parallel(pfh_replay *h, const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t threads) {
+    if (!h || (n_records && (!records || !pool))) return 1;
+    if (h->any && !h->par) return 3;
+    const uint32_t N = (uint32_t)h->st.flags.size();
+    for (uint64_t i = 0; i < n_records; ++i) {
+        const pf_bfs_record &r = records[i];
+        if ((r.entrance >> 1) >= N || ((h->any || i) && r.entrance < h->last)) return 2;
+        h->last = r.entrance;
+    }
+    if (!h->par) {
+        h->par = true;
+        h->cc.reset(N);
+        h->pr.begin(N, h->st.plus.data(), h->st.minus.data(), h->st.complex_size, threads ? threads : 1);
+    }
+    h->any = true;
+    auto list_of = [&](const pf_bfs_record &r) { return pool + r.list_off; };
+    h->cc.add(records, n_records, list_of);
+    std::vector<uint32_t> order, class_off;
+    h->cc.order(records, n_records, pfh::kReplayClasses, order, class_off);
+    pfh::ReplayStats st;
+    h->pr.run(records, list_of, order.data(), class_off.data(), pfh::kReplayClasses, threads ? threads : 1, st);
+    h->pr.finish(h->st.flags.data(), threads ? threads : 1);
+    return 0;
+}
+uint64_t pfh_replay_check_footprints(const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t n_unitigs,
+                                     uint32_t complex_size, uint64_t slice, uint64_t *first_bad) {
+    return pfh::check_footprints(records, n_records, pool, n_unitigs, complex_size, slice, first_bad);
+}
+// component label of every record's entrance side after the records were added (test hook for the device's labels)
+void pfh_side_components(const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t n_unitigs, uint32_t *labels) {
+    pfh::SideComponents cc;
+    cc.reset(n_unitigs);
+    cc.add(records, n_records, [&](const pf_bfs_record &r) { return pool + r.list_off; });
+    for (uint64_t i = 0; i < n_records; ++i) labels[i] = cc.label(pfh::entrance_side(records[i].entrance));
 }
 void pfh_replay_state(const pfh_replay *h, uint8_t *flags, uint32_t *plus, uint32_t *minus) {
     const size_t N = h->st.flags.size();

@@ -3,14 +3,12 @@
 // Needs no device: the records may come from K-BFS, from the host walkers, or from another rank.
 #include "pf_state.hpp"
 
+#include "pf_state_ops.hpp"
+
 namespace pfh {
 
-namespace {
-constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_NON_SUPER = 0x04, B_STRICT_M = 0x08, B_STRICT_P = 0x10, B_COMPLEX_M = 0x20,
-                  B_COMPLEX_P = 0x40;
+using namespace state_bits;
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-inline bool plus_side_of(uint32_t ov) { return (ov & 1) == 0; }
-}  // namespace
 
 void UnitigState::reset(uint32_t n) {
     flags.assign(n, 0);
@@ -18,93 +16,24 @@ void UnitigState::reset(uint32_t n) {
     minus.assign(n, 0);
 }
 
-// ---- MyUnitig state -------------------------------------------------------------------------
-void UnitigState::side_self(uint32_t u, bool plus_side) {
-    if (plus_side) { plus[u] = u + 1; flags[u] &= (uint8_t)~B_PLUS; }
-    else { minus[u] = u + 1; flags[u] &= (uint8_t)~B_MINUS; }
-}
-// "if (ex->get_plus() == me) ex->set_plus_self(); else ex->set_minus_self();"
-void UnitigState::release(uint32_t ex, uint32_t me) { side_self(ex, plus[ex] == me + 1); }
-// interior vertex of any committed traversal (e.g. src/CDBG.cpp:800-826)
-void UnitigState::poison(uint32_t u) {
-    uint32_t p = plus[u];
-    if (p != 0 && p != u + 1) release(p - 1, u);
-    side_self(u, true);
-    p = minus[u];
-    if (p != 0 && p != u + 1) release(p - 1, u);
-    side_self(u, false);
-    flags[u] |= B_NON_SUPER;
-}
+namespace {
+// the colored accept commit's gate as the hook Commits<> calls (UnitigState::colours_allow below)
+struct ColourGate {
+    static constexpr bool colored = true;
+    UnitigState *st;
+    template <class A> bool allow(A &, const pf_bfs_record &r, const uint32_t *list) const { return st->colours_allow(r, list); }
+};
+}  // namespace
 
-// Order-dependent part of extractSuperBubble_ptr: the three setNoBubble commits
-// (src/CDBG.cpp:552-846) and the no-exit tail (:373-413), applied to one device record.
+// One traversal record in the reference's visiting order (the text of the commits: pf_state_ops.hpp).
 void UnitigState::replay(const pf_bfs_record &r, const uint32_t *list) {
-    const uint32_t s = r.entrance, su = s >> 1;
-    if (r.outcome == PF_BFS_NONE) {
-        if (!r.flag_cycle) return;
-        for (uint32_t i = 0; i < r.n_list; ++i) poison(list[i] >> 1);
-        side_self(su, plus_side_of(s));
-        return;
+    if (col) {
+        Commits<FlagsPerUnitig, ColourGate> c{FlagsPerUnitig{flags.data(), plus.data(), minus.data()}, complex_size, ColourGate{this}};
+        c.replay(r, list);
+    } else {
+        Commits<FlagsPerUnitig> c{FlagsPerUnitig{flags.data(), plus.data(), minus.data()}, complex_size, NoColours{}};
+        c.replay(r, list);
     }
-    const uint32_t t = r.exit, tu = t >> 1;
-    if (r.outcome == PF_BFS_CYCLE_EXIT) {  // setNoBubble_ptr_cycle
-        if (col) {
-            // src/CCDBG.cpp:2351-2384: a side is self-marked only if it held a real partner
-            for (uint32_t i = 0; i < r.n_list; ++i) {
-                const uint32_t w = list[i] >> 1;
-                uint32_t p = plus[w];
-                if (p != 0 && p != w + 1) { release(p - 1, w); side_self(w, true); }
-                p = minus[w];
-                if (p != 0 && p != w + 1) { release(p - 1, w); side_self(w, false); }
-                flags[w] |= B_NON_SUPER;
-            }
-        } else
-        for (uint32_t i = 0; i < r.n_list; ++i) poison(list[i] >> 1);
-        side_self(su, plus_side_of(s));
-        side_self(tu, !plus_side_of(t));
-        return;
-    }
-    if (r.outcome == PF_BFS_REJECT) {  // setNoBubble_ptr(seen, p)
-        uint32_t p = plus_side_of(s) ? plus[su] : minus[su];
-        if (p != 0) release(p - 1, su);
-        side_self(su, plus_side_of(s));
-        p = !plus_side_of(t) ? plus[tu] : minus[tu];
-        if (p != 0) release(p - 1, tu);
-        side_self(tu, !plus_side_of(t));
-        for (uint32_t i = 0; i < r.n_list; ++i)
-            if (list[i] != s && list[i] != t) poison(list[i] >> 1);
-        return;
-    }
-    // PF_BFS_ACCEPT: setNoBubble_ptr(p, seen)
-    if (r.n_seen < 4) return;
-    if ((flags[tu] & B_NON_SUPER) || (flags[su] & B_NON_SUPER)) {
-        for (uint32_t i = 0; i < r.n_list; ++i) {
-            const uint32_t w = list[i];
-            if (w == s) side_self(su, plus_side_of(s));
-            else if (w == t) side_self(tu, !plus_side_of(t));
-            else poison(w >> 1);
-        }
-        return;
-    }
-    if (r.strict) {  // n_seen <= 6 and the structural test, evaluated on the device
-        flags[su] |= plus_side_of(s) ? B_STRICT_P : B_STRICT_M;
-        flags[tu] |= !plus_side_of(t) ? B_STRICT_P : B_STRICT_M;
-    }
-    if (r.n_seen > complex_size) {
-        flags[su] |= plus_side_of(s) ? B_COMPLEX_P : B_COMPLEX_M;
-        flags[tu] |= !plus_side_of(t) ? B_COMPLEX_P : B_COMPLEX_M;
-    }
-    for (uint32_t i = 0; i < r.n_list; ++i)
-        if (list[i] != s && list[i] != t) poison(list[i] >> 1);
-    if (col && !colours_allow(r, list)) {
-        side_self(su, plus_side_of(s));
-        side_self(tu, !plus_side_of(t));
-        return;
-    }
-    if (plus_side_of(s)) { plus[su] = tu + 1; flags[su] |= B_PLUS; }
-    else { minus[su] = tu + 1; flags[su] |= B_MINUS; }
-    if (plus_side_of(t)) { minus[tu] = su + 1; flags[tu] |= B_MINUS; }
-    else { plus[tu] = su + 1; flags[tu] |= B_PLUS; }
 }
 
 // The colored accept commit's extra gates (src/CCDBG.cpp:2530-2621): both endpoints carry every colour on every

@@ -24,10 +24,7 @@ struct UnitigState {
     void replay(const pf_bfs_record &r, const uint32_t *list);
     bool gate_open(uint32_t entrance_ov) const { return ((entrance_ov & 1) == 0 ? plus[entrance_ov >> 1] : minus[entrance_ov >> 1]) == 0; }
 
-private:
-    void side_self(uint32_t u, bool plus_side);
-    void release(uint32_t ex, uint32_t me);
-    void poison(uint32_t u);
+    // the colored accept commit's extra gates (src/CCDBG.cpp:2530-2621); called by the commits when `col` is set
     bool colours_allow(const pf_bfs_record &r, const uint32_t *list);
 };
 

@@ -97,6 +97,14 @@ struct pf_ctx {
 
     pf::CallState *call = nullptr;
 
+    // K-CC (pf_cc.hip): union-find over unitig sides for the parallel commit replay; the records and vertex pool of the last
+    // K-BFS call as they lie in the workspace
+    void *cc = nullptr;
+    const void *cc_rec = nullptr;
+    const pf_bfs_record *bfs_last_rec = nullptr;
+    const uint32_t *bfs_last_pool = nullptr;
+    uint64_t bfs_last_n = 0, bfs_last_pool_len = 0;
+
     unsigned int bfs_deferred = 0;  // candidates of the last pf_bfs_candidates that needed the big tier
 
     // grow-only device workspaces reused across calls (slot ids: enum pf::WsSlot)
@@ -119,6 +127,7 @@ int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the
 // device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
 void call_destroy(pf_ctx *ctx);     // pf_call.hip
+void cc_destroy(pf_ctx *ctx);       // pf_cc.hip
 void call_invalidate(pf_ctx *ctx);  // graph or count table replaced
 enum WsSlot {
     WS_ALN_TEXT = 0, WS_ALN_JOBS, WS_ALN_SMALL, WS_ALN_RETRY, WS_ALN_IDX, WS_ALN_OFIRST, WS_ALN_OCOUNT, WS_ALN_OHITS, WS_ALN_OTEXT,

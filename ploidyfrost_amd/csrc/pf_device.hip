@@ -772,6 +772,7 @@ void pf_destroy(pf_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
     call_destroy(ctx);
+    cc_destroy(ctx);
     free_graph(ctx);
     hipFree(ctx->d_tab);
     hipFree(ctx->d_ctab);
@@ -1365,6 +1366,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
         }
     }
     ctx->bfs_deferred = n_def;
+    ctx->bfs_last_rec = d_rec; ctx->bfs_last_pool = d_pool; ctx->bfs_last_n = n; ctx->bfs_last_pool_len = pool_cap;
     unsigned long long head = 0;
     PF_HIP(hipMemcpy(&head, d_head, 8, hipMemcpyDeviceToHost));
     *pool_used = head;

@@ -67,12 +67,13 @@ def all_gather_counters(values: list[int], device: torch.device) -> np.ndarray:
     return torch.stack(out).cpu().numpy()
 
 
-def all_gather_slabs(slab: np.ndarray, device: torch.device) -> list[np.ndarray]:
+def all_gather_slabs(slab: np.ndarray, device: torch.device, keep_device: bool = False):
     """Variable-length byte slabs of every rank, in rank order (sizes first, then one all-gather of
-    max-padded payloads: a single direct exchange, no ring of small messages)."""
+    max-padded payloads: a single direct exchange, no ring of small messages).  keep_device: also return the gathered
+    device tensors (padded), for consumers that read the slabs on the device."""
     slab = np.ascontiguousarray(slab, dtype=np.uint8)
     if not dist.is_initialized() or dist.get_world_size() == 1:
-        return [slab]
+        return ([slab], None) if keep_device else [slab]
     world = dist.get_world_size()
     sizes = all_gather_counters([slab.size], device)[:, 0]
     cap = int(sizes.max())
@@ -81,6 +82,8 @@ def all_gather_slabs(slab: np.ndarray, device: torch.device) -> list[np.ndarray]
         buf[: slab.size] = torch.from_numpy(slab).to(device)
     out = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
+    if keep_device:
+        return [o[: int(n)].cpu().numpy() for o, n in zip(out, sizes)], out
     return [o[: int(n)].cpu().numpy() for o, n in zip(out, sizes)]
 
 
@@ -99,14 +102,18 @@ def sharded_find(run, outpre: str, device: torch.device, stats: dict | None = No
     n = run.times()["unitigs"]
     u0, u1 = shard_range(n, rank, world)
     rec, pool = run.find_shard(u0, u1)
-    recs = all_gather_slabs(rec.view(np.uint8).reshape(-1), device)
-    pools = all_gather_slabs(pool.view(np.uint8).reshape(-1), device)
+    on_gpu = device.type == "cuda"
+    recs, d_recs = all_gather_slabs(rec.view(np.uint8).reshape(-1), device, keep_device=True)
+    pools, d_pools = all_gather_slabs(pool.view(np.uint8).reshape(-1), device, keep_device=True)
     if stats is not None:
         stats["find_gathered_bytes"] = int(sum(x.size for x in recs) + sum(x.size for x in pools))
         stats["shard_unitigs"] = (u0, u1)
     from . import hipapi
+    # the gathered shards still lie in device memory: the components of the parallel replay are found there
     run.find_replay(outpre, [np.ascontiguousarray(r).view(hipapi.BFS_RECORD) for r in recs],
-                    [np.ascontiguousarray(p).view(np.uint32) for p in pools], write_file=rank == 0)
+                    [np.ascontiguousarray(p).view(np.uint32) for p in pools], write_file=rank == 0,
+                    dev_records=[t.data_ptr() for t in d_recs] if on_gpu and d_recs else None,
+                    dev_pools=[t.data_ptr() for t in d_pools] if on_gpu and d_pools else None)
 
 
 def sharded_ploidy(run, outpre: str, lower: int, upper: int, device: torch.device, stats: dict | None = None):

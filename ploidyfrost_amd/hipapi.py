@@ -76,6 +76,8 @@ def load_library() -> C.CDLL:
         "pf_kernel_time": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(u64)]),
         "pf_reset_timing": (i, [vp]),
         "pf_kernel_units": (i, [vp, i, C.POINTER(u64)]),
+        "pf_side_components": (i, [vp, i, vp, u64, vp, u64, vp, u64, vp, u64]),
+        "pf_replay_order": (i, [vp, C.c_uint32, vp, vp, vp]),
         "pf_kernel_name": (C.c_char_p, [i]),
         "pf_upload_graph": (i, [vp, vp, vp, vp, u32, i]),
         "pf_build_adjacency": (i, [vp, vp, vp]),
@@ -135,7 +137,7 @@ def load_library() -> C.CDLL:
 
 
 DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
-                    "pf_kernel_time", "pf_reset_timing", "pf_kernel_units", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
+                    "pf_kernel_time", "pf_reset_timing", "pf_kernel_units", "pf_side_components", "pf_replay_order", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
@@ -386,6 +388,32 @@ class Device:
                 continue
             self._check(st)
             return rec[: nr.value], pool[: used.value]
+
+    def side_components(self, records=None, pool=None, n_records=None, reset=True, extra=None, extra_pool=None):
+        """K-CC: the records (default: the ones the last bfs() call left on the device) join the union-find over unitig sides"""
+        if records is None:
+            rp, pp, n, pl = None, None, int(n_records), 0
+        else:
+            records = np.ascontiguousarray(records)
+            pool = np.ascontiguousarray(pool, dtype=np.uint32) if len(pool) else np.zeros(1, dtype=np.uint32)
+            rp, pp, n, pl = records.ctypes.data, pool.ctypes.data, len(records), len(pool)
+        xr = xp = None
+        nx = nxp = 0
+        if extra is not None and len(extra):
+            extra = np.ascontiguousarray(extra)
+            extra_pool = np.ascontiguousarray(extra_pool, dtype=np.uint32) if len(extra_pool) else np.zeros(1, dtype=np.uint32)
+            xr, xp, nx, nxp = extra.ctypes.data, extra_pool.ctypes.data, len(extra), len(extra_pool)
+        self._check(self.L.pf_side_components(self.h, int(reset), rp, n, pp, pl, xr, nx, xp, nxp))
+        self._cc_n = n
+
+    def replay_order(self, n_classes: int = 64):
+        """(order, class_off, labels) of the records of the last side_components call"""
+        n = self._cc_n
+        order = np.zeros(max(n, 1), dtype=np.uint32)
+        labels = np.zeros(max(n, 1), dtype=np.uint32)
+        off = np.zeros(n_classes + 1, dtype=np.uint32)
+        self._check(self.L.pf_replay_order(self.h, n_classes, order.ctypes.data, off.ctypes.data, labels.ctypes.data))
+        return order[:n], off, labels[:n]
 
     def string_cov(self, strings: list[bytes], low: int, up: int):
         n = len(strings)

@@ -28,8 +28,8 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
-                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state",
-                    "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_ploidy_select", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints",
+                    "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_set_replay_threads", "pfh_ploidy_select", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
                     "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
                     "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
 
@@ -95,7 +95,9 @@ def load_library() -> C.CDLL:
     L.pfh_shard_records.argtypes = [vp, C.POINTER(u64)]
     L.pfh_shard_pool.restype = vp
     L.pfh_shard_pool.argtypes = [vp, C.POINTER(u64)]
-    L.pfh_find_replay.argtypes = [vp, C.c_char_p, u32, vp, vp, vp, C.c_int]
+    L.pfh_find_replay.argtypes = [vp, C.c_char_p, u32, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.pfh_set_replay_threads.argtypes = [vp, C.c_int]
+    L.pfh_set_replay_threads.restype = None
     L.pfh_ploidy_select.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u64)]
     L.pfh_ploidy_align.argtypes = [vp, u64, u64, C.POINTER(u64)]
     L.pfh_ploidy_text.argtypes = [vp, u64, vp, vp]
@@ -106,6 +108,12 @@ def load_library() -> C.CDLL:
     L.pfh_replay_open.argtypes = [u32, u32]
     L.pfh_replay_close.argtypes = [vp]
     L.pfh_replay_apply.argtypes = [vp, vp, u64, vp]
+    L.pfh_replay_apply_parallel.argtypes = [vp, vp, u64, vp, C.c_uint32]
+    L.pfh_replay_apply_parallel.restype = C.c_int
+    L.pfh_side_components.argtypes = [vp, u64, vp, C.c_uint32, vp]
+    L.pfh_side_components.restype = None
+    L.pfh_replay_check_footprints.argtypes = [vp, u64, vp, C.c_uint32, C.c_uint32, u64, C.POINTER(u64)]
+    L.pfh_replay_check_footprints.restype = u64
     L.pfh_replay_state.argtypes = [vp, vp, vp, vp]
     L.pfh_bifrost_kmer_hash.restype = C.c_uint64
     L.pfh_bifrost_kmer_hash.argtypes = [C.c_uint64, C.c_uint64]
@@ -133,6 +141,27 @@ def host_walk_range(succ: np.ndarray, pred: np.ndarray, u0: int, u1: int):
         cap = used.value + 1024
 
 
+def side_components(records: np.ndarray, pool: np.ndarray, n_unitigs: int) -> np.ndarray:
+    """component label of every record's entrance side (host union-find over the records' footprints)"""
+    L = load_library()
+    records = np.ascontiguousarray(records)
+    pool = np.ascontiguousarray(pool, dtype=np.uint32) if len(pool) else np.zeros(1, dtype=np.uint32)
+    labels = np.zeros(len(records), dtype=np.uint32)
+    L.pfh_side_components(records.ctypes.data if len(records) else None, len(records), pool.ctypes.data, n_unitigs, labels.ctypes.data)
+    return labels
+
+
+def check_footprints(records: np.ndarray, pool: np.ndarray, n_unitigs: int, complex_size: int = 8, slice_len: int = 0):
+    """(accesses outside the running record's component, index of the first such record or None)"""
+    L = load_library()
+    records = np.ascontiguousarray(records)
+    pool = np.ascontiguousarray(pool, dtype=np.uint32) if len(pool) else np.zeros(1, dtype=np.uint32)
+    first = C.c_uint64()
+    bad = L.pfh_replay_check_footprints(records.ctypes.data if len(records) else None, len(records), pool.ctypes.data, n_unitigs,
+                                        complex_size, slice_len, C.byref(first))
+    return int(bad), (None if first.value == 0xFFFFFFFFFFFFFFFF else int(first.value))
+
+
 class Replay:
     """The commit replay on a bare MyUnitig state (no device): shards of records in, state out."""
 
@@ -141,10 +170,14 @@ class Replay:
         self.n = n_unitigs
         self.h = self.L.pfh_replay_open(n_unitigs, complex_size)
 
-    def apply(self, records: np.ndarray, pool: np.ndarray):
+    def apply(self, records: np.ndarray, pool: np.ndarray, threads: int = 0):
+        """threads > 0: the parallel replay (components of record footprints side by side); 0: the sequential one"""
         records = np.ascontiguousarray(records)
         pool = np.ascontiguousarray(pool, dtype=np.uint32) if len(pool) else np.zeros(1, dtype=np.uint32)
-        rc = self.L.pfh_replay_apply(self.h, records.ctypes.data if len(records) else None, len(records), pool.ctypes.data)
+        if threads:
+            rc = self.L.pfh_replay_apply_parallel(self.h, records.ctypes.data if len(records) else None, len(records), pool.ctypes.data, threads)
+        else:
+            rc = self.L.pfh_replay_apply(self.h, records.ctypes.data if len(records) else None, len(records), pool.ctypes.data)
         if rc:
             raise RuntimeError("pfh_replay_apply: %d (shards must arrive in entrance order)" % rc)
 
@@ -282,14 +315,23 @@ class Run:
         pool = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint32)), shape=(n.value,)).copy() if n.value else np.zeros(0, dtype=np.uint32)
         return rec, pool
 
-    def find_replay(self, outpre: str, records: list, pools: list, write_file: bool = True):
+    def find_replay(self, outpre: str, records: list, pools: list, write_file: bool = True, dev_records: list | None = None,
+                    dev_pools: list | None = None):
+        """dev_records / dev_pools: device addresses (ints) of the same shards where they already lie in device memory"""
         recs = [np.ascontiguousarray(r) for r in records]
         pls = [np.ascontiguousarray(p, dtype=np.uint32) if len(p) else np.zeros(1, dtype=np.uint32) for p in pools]
         n = len(recs)
         rp = (C.c_void_p * n)(*[r.ctypes.data if len(r) else None for r in recs])
         pp = (C.c_void_p * n)(*[p.ctypes.data for p in pls])
         nr = (C.c_uint64 * n)(*[len(r) for r in recs])
-        self._check(self.L.pfh_find_replay(self.h, outpre.encode(), n, rp, nr, pp, int(write_file)))
+        pl = (C.c_uint64 * n)(*[len(p) for p in pools])
+        dr = (C.c_void_p * n)(*[int(a) if a else None for a in dev_records]) if dev_records else None
+        dp = (C.c_void_p * n)(*[int(a) if a else None for a in dev_pools]) if dev_pools else None
+        self._check(self.L.pfh_find_replay(self.h, outpre.encode(), n, rp, nr, pp, int(write_file), pl, dr, dp))
+
+    def set_replay_threads(self, threads: int):
+        """host threads of the commit replay: 0 = sequential, -1 = default"""
+        self.L.pfh_set_replay_threads(self.h, threads)
 
     def ploidy_select(self, lower: int, upper: int) -> int:
         n = C.c_uint64()

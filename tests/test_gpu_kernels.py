@@ -204,6 +204,50 @@ def test_bfs_records_match_oracle(case):
     assert np.array_equal(r2["exit"], full["exit"]) and np.array_equal(r2["strict"], full["strict"])
 
 
+@pytest.mark.parametrize("case", golden_cases())
+def test_side_components_match_the_host_union_find(case):
+    """K-CC (pf_cc.hip): the components the parallel commit replay is scheduled by.  Labels = smallest side of the component on
+    both sides, so they must agree number for number; the order groups the records by class, ascending inside a class; records
+    given in two slices (cumulative) end in the same components; a record pointing outside the graph is refused."""
+    from ploidyfrost_amd import hostapi
+    meta, o, dev, _ = setup_case(case)
+    dev.build_adjacency()
+    rec, pool = dev.bfs()
+    want = hostapi.side_components(rec, pool, dev.n)
+    # the records K-BFS left on the device
+    dev.side_components(n_records=len(rec))
+    order, off, lab = dev.replay_order(64)
+    assert np.array_equal(lab, want)
+    assert off[0] == 0 and off[-1] == len(rec) and (np.diff(off.astype(np.int64)) >= 0).all()
+    cls = ((lab.astype(np.uint64) * np.uint64(0x9E3779B1) & np.uint64(0xFFFFFFFF)) * np.uint64(64)) >> np.uint64(32)
+    for c in range(64):
+        idx = order[off[c]:off[c + 1]]
+        assert (cls[idx] == c).all() and (np.diff(idx.astype(np.int64)) > 0).all()
+    assert np.array_equal(np.sort(order), np.arange(len(rec), dtype=np.uint32))
+    # the same records from the host, in two slices
+    h = len(rec) // 2
+    dev.side_components(rec[:h], pool, reset=True)
+    dev.side_components(rec[h:], pool, reset=False)
+    _, _, lab2 = dev.replay_order(64)
+    assert np.array_equal(lab2, want[h:])
+    # long lists through the block-per-record path: every record as an "extra" of an empty slice
+    dev.side_components(rec[:0], pool, reset=True, extra=rec, extra_pool=pool)
+    dev.side_components(rec, pool[:0] if not len(rec) else pool, reset=False)
+    _, _, lab3 = dev.replay_order(64)
+    assert np.array_equal(lab3, want)
+    if len(rec):
+        bad = rec.copy()
+        bad["entrance"][len(bad) // 2] = 2 * dev.n + 5
+        with pytest.raises(hipapi.DeviceError):
+            dev.side_components(bad, pool)
+        worse = rec.copy()
+        eff = np.nonzero(worse["n_list"] > 0)[0]
+        if len(eff):
+            worse["list_off"][eff[0]] = len(pool) + 7
+            with pytest.raises(hipapi.DeviceError):
+                dev.side_components(worse, pool)
+
+
 def test_bfs_tiny_pool_reports_needed_size():
     meta, o, dev, _ = setup_case("tet60k")
     dev.build_adjacency()

@@ -50,7 +50,8 @@ def repeat_rich(rng, n):
     return np.concatenate(parts)
 
 
-def one_case(seed, tmp, dev):
+def build_case(seed, tmp, dev):
+    """inputs of one random case: a dict, or a string when the seed is skipped"""
     rng = np.random.default_rng(seed)
     k = int(rng.choice([21, 25, 25, 31]))
     ploidy = int(rng.integers(2, 7))
@@ -129,6 +130,18 @@ def one_case(seed, tmp, dev):
             synth.write_kmc1(db, g["kmers"], synth.synth_counts(g["kmers"], g["mult"]), k)
     except RuntimeError as e:
         return "skipped (%s)" % str(e)[:60]
+    return dict(k=k, ploidy=ploidy, z=z, L=L, scores=scores, lower=lower, upper=upper, colored=colored, gfa=gfa, n_unitigs=n_unitigs,
+                db=None if colored else db, dbs=dbs if colored else None, colors=colors if colored else None, use_reference=use_reference,
+                giant=giant, crowd=crowd)
+
+
+def one_case(seed, tmp, dev):
+    c = build_case(seed, tmp, dev)
+    if isinstance(c, str):
+        return c
+    k, ploidy, z, L, scores, lower, upper, colored, gfa, n_unitigs = (c[x] for x in ("k", "ploidy", "z", "L", "scores", "lower", "upper", "colored",
+                                                                                      "gfa", "n_unitigs"))
+    db, dbs, colors, use_reference, giant, crowd = c["db"], c["dbs"], c["colors"], c["use_reference"], c["giant"], c["crowd"]
     common = ["-o", "x", "-z", str(z), "-M", str(scores[0]), "-D", str(scores[1]), "-G", str(scores[2])]
     og, gg = os.path.join(tmp, "oracle"), os.path.join(tmp, "gpu")
     os.makedirs(og), os.makedirs(gg)
