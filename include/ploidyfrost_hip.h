@@ -171,6 +171,15 @@ int pf_bfs_candidates(pf_ctx *, uint32_t u0, uint32_t u1, pf_bfs_record *records
 int pf_bfs_candidates_split(pf_ctx *, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
                             uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint64_t deferred_cap,
                             uint64_t *n_deferred);
+/* pf_bfs_candidates_split in two steps, so that the copy of the records to the host (183 MB for the 5 M-unitig graph) runs
+ * beside the caller's walk of the deferred traversals: _begin returns once the device tiers have run, with the deferred
+ * candidates' indices and entrances (oriented vertices) and with records / pool on their way on a copy stream; _end waits for
+ * them and marks the deferred records as pf_bfs_candidates_split does.  Between the two calls the caller must not touch
+ * records / pool; it may call pf_side_components(records = NULL). */
+int pf_bfs_candidates_begin(pf_ctx *, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool, uint64_t pool_cap,
+                            uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint32_t *deferred_entrance, uint64_t deferred_cap,
+                            uint64_t *n_deferred);
+int pf_bfs_candidates_end(pf_ctx *);
 
 /* ---- A1: SeqAlign::needlemanWunch + traceback (src/SeqAlign.cpp:480-549, 306-478) ------- */
 /* One job = one pairwise alignment A x B.  Sequences are ASCII over {A,C,G,T,-}
@@ -344,7 +353,8 @@ int pf_format_doubles(pf_ctx *, const double *values, uint64_t n, char *text, ui
  *   records == NULL: the n_records records and the vertex pool the last pf_bfs_candidates* call left on the device;
  *   otherwise records / pool [host|dev] as pf_bfs_candidates returns them (list_off into pool).
  *   extra: n_extra records [host|dev] with lists in extra_pool -- the traversals a caller of pf_bfs_candidates_split walked
- *   itself; they add their footprints only (their labels come from their entrances like everyone's).
+ *   itself; they add their footprints only (their labels come from their entrances like everyone's).  A second call with
+ *   records == NULL for the same K-BFS call adds only its `extra` (the device-resident records went in with the first).
  * pf_replay_order then labels every record of that slice with its component and deals the components into n_classes (<= 1024)
  * work units: order[n_records] = record indices grouped by class, ascending inside a class; class_off[n_classes + 1] (host);
  * labels (optional, [host|dev]) = the component label of each record's entrance side.  A record naming a vertex outside the

@@ -159,7 +159,7 @@ const uint32_t *pfh_shard_pool(const pfh_run *, uint64_t *n_entries);
 int pfh_find_replay(pfh_run *, const char *outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
                     const uint32_t *const *pools, int write_file, const uint64_t *pool_lens, const pf_bfs_record *const *dev_records,
                     const uint32_t *const *dev_pools);
-/* host threads of the commit replay in findSuperBubble / pfh_find_replay: 0 = the sequential loop, -1 = default (min(threads, 16),
+/* host threads of the commit replay in findSuperBubble / pfh_find_replay: 0 = the sequential loop, -1 = default (min(threads, 32),
  * single-sample path only) */
 void pfh_set_replay_threads(pfh_run *, int threads);
 int pfh_ploidy_select(pfh_run *, int lower, int upper, uint64_t *n_bubbles);

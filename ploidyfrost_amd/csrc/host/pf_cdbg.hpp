@@ -123,7 +123,7 @@ public:
     int find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
                     const uint32_t *const *pools, bool write_file, const uint64_t *pool_lens = nullptr,
                     const pf_bfs_record *const *dev_records = nullptr, const uint32_t *const *dev_pools = nullptr);
-    // the commit replay on host threads (pf_replay_par.hpp): 0 = sequential; default min(threads, 16) for the single-sample path
+    // the commit replay on host threads (pf_replay_par.hpp): 0 = sequential; default min(threads, 32) for the single-sample path
     void set_replay_threads(int t) { replay_threads_ = t; }
     int ploidy_select(int lower, int upper, uint64_t &n_bubbles);
     int ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called);
@@ -204,6 +204,7 @@ protected:
     std::vector<std::unique_ptr<HugeWalker>> walkers_;
     std::mutex walkers_mu_;
     std::vector<uint32_t> deferred_;   // record indices pf_bfs_candidates_split leaves to the host walkers
+    std::vector<uint32_t> deferred_ent_;   // their entrances (pf_bfs_candidates_begin)
     // vertex lists of the records walked on the host (pf_bfs_record::pad_ == 1, list_off = index), per K-BFS slice: a slice's
     // lists are complete before its records are handed to the replay
     std::vector<std::vector<uint32_t>> huge_lists_[4];

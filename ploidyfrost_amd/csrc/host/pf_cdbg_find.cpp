@@ -28,7 +28,7 @@ unsigned CDBG::replay_threads(size_t thr) const {
     static const char *env = getenv("PF_REPLAY");
     if (env && !strcmp(env, "seq")) return 0;
     static const int env_t = [] { const char *e = getenv("PF_REPLAY_THREADS"); return e ? atoi(e) : -1; }();
-    int t = replay_threads_ >= 0 ? replay_threads_ : env_t >= 0 ? env_t : (int)std::min<size_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), 16);
+    int t = replay_threads_ >= 0 ? replay_threads_ : env_t >= 0 ? env_t : (int)std::min<size_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), 32);
     return t >= 2 ? (unsigned)t : 0;
 }
 
@@ -63,7 +63,9 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // traversals on host cores a slice's own are walked in a few milliseconds, side by side; only with the device's third tier
     // (one wavefront per giant traversal, run slice after slice) is the first pass over a graph kept in one piece.
     constexpr int kMaxSlices = 4;
-    const int kSlices = (third_tier_on_host_ || (find_passes_ > 0 && times_.bfs_large == 0)) ? kMaxSlices : 1;
+    // (with the commits spread over host threads a slice's replay takes a millisecond: slicing only pays for the sequential replay)
+    static const int env_slices = [] { const char *e = getenv("PF_FIND_SLICES"); return e ? std::max(1, std::min(4, atoi(e))) : 0; }();
+    const int kSlices = env_slices ? env_slices : replay_threads(thr) ? 1 : (third_tier_on_host_ || (find_passes_ > 0 && times_.bfs_large == 0)) ? kMaxSlices : 1;
     ++find_passes_;
     uint32_t s_u0[kMaxSlices + 1];
     uint64_t s_cand[kMaxSlices], s_rec0[kMaxSlices + 1], s_pool0[kMaxSlices + 1], s_nrec[kMaxSlices], s_used[kMaxSlices];
@@ -110,12 +112,19 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             uint64_t cap = s_pool0[i + 1] - s_pool0[i];
             uint64_t n_deferred = 0;
             if (third_tier_on_host_ && deferred.size() < 4096) deferred.resize(4096);
+            std::vector<uint32_t> &deferred_ent = deferred_ent_;
+            if (deferred_ent.size() < deferred.size()) deferred_ent.resize(deferred.size());
             int st1;
             for (;;) {
                 if (third_tier_on_host_) {
-                    st1 = pf_bfs_candidates_split(ctx_, s_u0[i], s_u0[i + 1], rec + s_rec0[i], s_rec0[i + 1] - s_rec0[i], pl, cap, &s_nrec[i], &s_used[i],
-                                                  deferred.data(), deferred.size(), &n_deferred);
-                    if (st1 == PF_ERR_OVERFLOW && n_deferred > deferred.size()) { deferred.resize(n_deferred + n_deferred / 4); continue; }
+                    // the records travel to the host while the long traversals are walked (pf_bfs_candidates_end below)
+                    st1 = pf_bfs_candidates_begin(ctx_, s_u0[i], s_u0[i + 1], rec + s_rec0[i], s_rec0[i + 1] - s_rec0[i], pl, cap, &s_nrec[i], &s_used[i],
+                                                  deferred.data(), deferred_ent.data(), deferred.size(), &n_deferred);
+                    if (st1 == PF_ERR_OVERFLOW && n_deferred > deferred.size()) {
+                        deferred.resize(n_deferred + n_deferred / 4);
+                        deferred_ent.resize(deferred.size());
+                        continue;
+                    }
                 } else
                 st1 = pf_bfs_candidates(ctx_, s_u0[i], s_u0[i + 1], rec + s_rec0[i], s_rec0[i + 1] - s_rec0[i], pl, cap, &s_nrec[i], &s_used[i]);
                 if (st1 == PF_ERR_OVERFLOW && s_used[i] > cap) {
@@ -129,31 +138,49 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             }
             n_deferred_total += n_deferred;
             if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] device tiers of slice %d: %.2f ms, %llu candidates left for the third tier\n", i, since(tb) * 1e3, (unsigned long long)n_deferred);
+            std::vector<pf_bfs_record> walked((size_t)n_deferred);
+            std::thread walk;
             if (st1 == PF_OK && n_deferred) {
-                // third tier: one host thread per giant traversal, side by side; lists go to huge_pool_
-                pf_bfs_record *srec = rec + s_rec0[i];
+                // third tier: one host thread per giant traversal, side by side; lists go to huge_lists_
                 huge_lists_[i].assign((size_t)n_deferred, std::vector<uint32_t>());
-                parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
-                    std::unique_ptr<HugeWalker> w;
-                    {
-                        std::lock_guard<std::mutex> lk(walkers_mu_);
-                        if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
-                    }
-                    if (!w) w = std::make_unique<HugeWalker>();
-                    pf_bfs_record &r = srec[deferred[d]];
-                    const uint32_t s = r.entrance;
-                    const auto tw = clk::now();
-                    const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, s, r);
-                    if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] host walk from %u: %u vertices, outcome %d, %.2f ms\n", s, r.n_seen, (int)r.outcome, since(tw) * 1e3);
-                    huge_lists_[i][d].assign(list.begin(), list.begin() + r.n_list);
-                    r.list_off = d;
-                    r.pad_ = 1;
-                    {
-                        std::lock_guard<std::mutex> lk(walkers_mu_);
-                        walkers_.push_back(std::move(w));
-                    }
+                walk = std::thread([&, i] {
+                    parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
+                        std::unique_ptr<HugeWalker> w;
+                        {
+                            std::lock_guard<std::mutex> lk(walkers_mu_);
+                            if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
+                        }
+                        if (!w) w = std::make_unique<HugeWalker>();
+                        pf_bfs_record &r = walked[d];
+                        memset(&r, 0, sizeof r);
+                        const uint32_t s = deferred_ent[d];
+                        r.entrance = s;
+                        r.exit = 0xFFFFFFFFu;
+                        const auto tw = clk::now();
+                        const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, s, r);
+                        if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] host walk from %u: %u vertices, outcome %d, %.2f ms\n", s, r.n_seen, (int)r.outcome, since(tw) * 1e3);
+                        huge_lists_[i][d].assign(list.begin(), list.begin() + r.n_list);
+                        r.list_off = d;
+                        r.pad_ = 1;
+                        {
+                            std::lock_guard<std::mutex> lk(walkers_mu_);
+                            walkers_.push_back(std::move(w));
+                        }
+                    });
                 });
             }
+            // K-CC for the records that are on the device, beside the walkers and the copy
+            if (st1 == PF_OK && rt) st1 = pf_side_components(ctx_, i == 0, nullptr, s_nrec[i], nullptr, 0, nullptr, 0, nullptr, 0);
+            if (walk.joinable()) walk.join();
+            if (third_tier_on_host_) {
+                const int ste = pf_bfs_candidates_end(ctx_);
+                if (st1 == PF_OK) st1 = ste;
+            }
+            if (st1 == PF_OK)
+                for (uint64_t d = 0; d < n_deferred; ++d) rec[s_rec0[i] + deferred[d]] = walked[(size_t)d];
+            const auto t_cc = clk::now();
+            if (trace_find) fprintf(stderr, "[find]   slice %d traversed (%llu records, %llu walked on host cores) %.2f ms (+%.2f)\n", i, (unsigned long long)s_nrec[i],
+                                    (unsigned long long)n_deferred, since(t_all) * 1e3, since(tb) * 1e3);
             if (st1 == PF_OK && rt) {
                 // K-CC: the slice's records join the components (they are still on the device; the traversals walked on the host
                 // add their footprints from here), then the slice's commit order by component class
@@ -168,8 +195,9 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                     xpool.insert(xpool.end(), l.begin(), l.begin() + r.n_list);
                     xrec.push_back(r);
                 }
-                st1 = pf_side_components(ctx_, i == 0, nullptr, s_nrec[i], nullptr, 0, xrec.data(), xrec.size(), xpool.data(), xpool.size());
+                if (!xrec.empty()) st1 = pf_side_components(ctx_, 0, nullptr, s_nrec[i], nullptr, 0, xrec.data(), xrec.size(), xpool.data(), xpool.size());
                 if (st1 == PF_OK) st1 = pf_replay_order(ctx_, kReplayClasses, bx_.bfs_order.p + s_rec0[i], class_off[i], nullptr);
+                if (trace_find) fprintf(stderr, "[find]   slice %d components + order %.2f ms (+%.2f)\n", i, since(t_all) * 1e3, since(t_cc) * 1e3);
             }
             bfs_s += since(tb);
             {
@@ -204,6 +232,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             ReplayStats rs;
             auto list_of = [&](const pf_bfs_record &r) { return r.pad_ ? huge_lists_[sl][r.list_off].data() : pool + r.list_off; };
             par_.run(srec, list_of, bx_.bfs_order.p + s_rec0[sl], class_off[sl], kReplayClasses, rt, rs);
+            if (trace_find) fprintf(stderr, "[find]   slice %d replayed on %u threads %.2f ms (+%.2f)\n", sl, rt, since(t_all) * 1e3, since(tr) * 1e3);
             times_.bfs_large += rs.large; times_.bfs_large_seen += rs.large_seen; times_.bfs_large_used += rs.large_used;
             times_.bfs_max_seen = std::max<uint64_t>(times_.bfs_max_seen, rs.max_seen);
             times_.bfs_large_used_max = std::max<uint64_t>(times_.bfs_large_used_max, rs.large_used_max);

@@ -23,9 +23,12 @@
 
 namespace pfh {
 
-constexpr uint32_t kReplayClasses = 64;   // components are dealt into this many work units (>= threads, dynamically scheduled)
+constexpr uint32_t kReplayClasses = 256;   // components are dealt into this many work units (>= threads, dynamically scheduled)
 
-inline uint32_t replay_class_of(uint32_t label, uint32_t n_classes) { return (uint32_t)(((uint64_t)(label * 0x9E3779B1u) * n_classes) >> 32); }
+// A component's label is its smallest side, and records come in entrance order: runs of 2048 consecutive labels go to one class, so
+// that a class reads (mostly) runs of neighbouring records -- streams the hardware prefetcher follows -- instead of every n-th one.
+constexpr uint32_t kReplayClassShift = 11;
+inline uint32_t replay_class_of(uint32_t label, uint32_t n_classes) { return (label >> kReplayClassShift) % n_classes; }
 
 class SideComponents {
 public:
@@ -92,6 +95,7 @@ public:
             const size_t n = class_off[c + 1] - class_off[c];
             for (size_t j = 0; j < n; ++j) {
                 // the commits chase per-unitig state at random: pull the state of a record a few iterations ahead into cache
+                if (j + 32 < n) __builtin_prefetch(&rec[o[j + 32]]);
                 if (j + 12 < n) {
                     const pf_bfs_record &nx = rec[o[j + 12]];
                     __builtin_prefetch(list_of(nx));

@@ -63,6 +63,7 @@ __device__ inline void cc_unite(uint32_t *parent, uint32_t a, uint32_t b) {
 }
 
 __device__ inline bool cc_effective(const pf_bfs_record &r) {
+    if (r.outcome > PF_BFS_ACCEPT) return false;   // K-BFS's own marks (deferred to the caller's walkers): the caller passes those as `extra`
     if (r.outcome == PF_BFS_NONE) return r.flag_cycle != 0;
     if (r.outcome == PF_BFS_ACCEPT) return r.n_seen >= 4;
     return true;
@@ -121,7 +122,7 @@ __global__ __launch_bounds__(256) void k_cc_edges(const pf_bfs_record *__restric
     for (uint32_t q = 0; q < r.n_list; ++q) cc_entry(r, l[q], parent, n_sides, bad);
 }
 
-// one block per record: the long lists of the traversals the caller walked itself
+// up to 64 blocks per record (grid y): the long lists of the traversals the caller walked itself
 __global__ __launch_bounds__(256) void k_cc_edges_long(const pf_bfs_record *__restrict__ rec, uint64_t n, const uint32_t *__restrict__ pool,
                                                        uint64_t pool_len, uint32_t n_sides, uint32_t *parent, uint32_t *first, uint8_t *multi,
                                                        uint32_t *bad) {
@@ -130,9 +131,24 @@ __global__ __launch_bounds__(256) void k_cc_edges_long(const pf_bfs_record *__re
     const pf_bfs_record r = rec[i];
     if (!cc_effective(r)) return;
     if (!cc_valid(r, n_sides, pool_len)) { *bad = 1; return; }   // (block-uniform)
-    if (threadIdx.x == 0) cc_endpoints(r, parent, first, multi);
+    if (threadIdx.x == 0 && blockIdx.y == 0) cc_endpoints(r, parent, first, multi);
     const uint32_t *l = pool + r.list_off;
-    for (uint32_t q = threadIdx.x; q < r.n_list; q += blockDim.x) cc_entry(r, l[q], parent, n_sides, bad);
+    // Every entry joins the entry at half its index (a binary tree over the list positions) instead of the entrance: the same
+    // component, but the hooks spread over the list instead of all landing on one root (a 36 000-entry list cost 8 ms that way).
+    const bool all_interior = r.outcome == PF_BFS_NONE || r.outcome == PF_BFS_CYCLE_EXIT;
+    for (uint32_t q = blockIdx.y * blockDim.x + threadIdx.x; q < r.n_list; q += gridDim.y * blockDim.x) {
+        const uint32_t w = l[q];
+        if (w >= n_sides) { *bad = 1; continue; }
+        if (!all_interior && (w == r.entrance || w == r.exit)) continue;   // an endpoint: its side is joined by cc_endpoints
+        const uint32_t a = 2 * (w >> 1);
+        cc_unite(parent, a, a + 1);
+        uint32_t up = r.entrance;
+        if (q) {
+            const uint32_t pw = l[(q - 1) >> 1];
+            if (pw < n_sides) up = (!all_interior && pw == r.entrance) ? r.entrance : (!all_interior && pw == r.exit) ? (r.exit ^ 1u) : 2 * (pw >> 1);
+        }
+        cc_unite(parent, a, up);
+    }
 }
 
 __global__ void k_cc_multi(const uint8_t *__restrict__ multi, uint32_t n_unitigs, uint32_t *parent) {
@@ -150,7 +166,7 @@ __global__ void k_cc_labels(const pf_bfs_record *__restrict__ rec, uint64_t n, u
     const uint32_t e = rec[i].entrance;
     const uint32_t lab = e < n_sides ? cc_find(parent, e) : 0u;   // (refused by pf_side_components already)
     labels[i] = lab;
-    const uint32_t c = (uint32_t)(((uint64_t)(lab * 0x9E3779B1u) * n_classes) >> 32);   // = pfh::replay_class_of
+    const uint32_t c = (lab >> 11) % n_classes;   // = pfh::replay_class_of: runs of neighbouring components share a class
     cls[i] = c;
     idx[i] = (uint32_t)i;
     atomicAdd(s_hist + c, 1u);
@@ -175,6 +191,7 @@ struct CcState {
     uint32_t *up_pool = nullptr;
     uint64_t up_pool_cap = 0;
     uint64_t n_last = 0;
+    uint64_t added_call = 0;   // the K-BFS call whose device-resident records are already in the union-find
     bool labelled = false;
     void release() {
         for (void *p : {(void *)parent, (void *)first, (void *)multi, (void *)bad, (void *)labels, (void *)cls, (void *)idx, (void *)cls2, (void *)idx2, (void *)hist,
@@ -259,7 +276,10 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
         d_rec = S->up_rec;
         d_pool = S->up_pool;
     }
-    if (n_records) {
+    // a second call for the same K-BFS call (the caller adds the traversals it walked itself once they are done) adds only those
+    const bool again = !records && !reset && S->added_call == ctx->bfs_call_id;
+    if (!records) S->added_call = ctx->bfs_call_id;
+    if (n_records && !again) {
         k_cc_edges<<<(unsigned)((n_records + 255) / 256), 256, 0, st>>>(d_rec, n_records, d_pool, pool_len, n_sides, S->parent, S->first, S->multi, S->bad);
         PF_HIP(hipGetLastError());
     }
@@ -275,7 +295,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
         d_xpool = xp.p;
         PF_HIP(hipMemcpyAsync(d_xrec, extra, n_extra * sizeof(pf_bfs_record), hipMemcpyDefault, st));
         if (extra_pool_len) PF_HIP(hipMemcpyAsync(d_xpool, extra_pool, extra_pool_len * 4, hipMemcpyDefault, st));
-        k_cc_edges_long<<<(unsigned)n_extra, 256, 0, st>>>(d_xrec, n_extra, d_xpool, extra_pool_len, n_sides, S->parent, S->first, S->multi, S->bad);
+        k_cc_edges_long<<<dim3((unsigned)n_extra, 64), 256, 0, st>>>(d_xrec, n_extra, d_xpool, extra_pool_len, n_sides, S->parent, S->first, S->multi, S->bad);
         PF_HIP(hipGetLastError());
         PF_HIP(hipStreamSynchronize(st));   // (the temporaries are freed on return)
     }

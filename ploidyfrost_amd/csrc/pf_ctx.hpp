@@ -104,6 +104,15 @@ struct pf_ctx {
     const pf_bfs_record *bfs_last_rec = nullptr;
     const uint32_t *bfs_last_pool = nullptr;
     uint64_t bfs_last_n = 0, bfs_last_pool_len = 0;
+    uint64_t bfs_call_id = 0;
+    // pf_bfs_candidates_begin .. _end: the copy of records and pool to the host in flight on copy_stream
+    hipStream_t copy_stream = nullptr;
+    struct {
+        bool active = false;
+        pf_bfs_record *records = nullptr;
+        uint64_t c0 = 0;
+        std::vector<uint32_t> deferred;
+    } bfs_pending;
 
     unsigned int bfs_deferred = 0;  // candidates of the last pf_bfs_candidates that needed the big tier
 

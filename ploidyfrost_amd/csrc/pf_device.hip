@@ -778,6 +778,7 @@ void pf_destroy(pf_ctx *ctx) {
     hipFree(ctx->d_ctab);
     hipFree(ctx->d_cov_sum); hipFree(ctx->d_cov_min); hipFree(ctx->d_cov_miss);
     for (auto &w : ctx->ws) hipFree(w.first);
+    if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -1269,10 +1270,13 @@ int pf_count_candidates(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *n) {
 }
 
 // deferred != nullptr: the third tier is left to the caller (pf_bfs_candidates_split)
+// async_copy (pf_bfs_candidates_begin): the records and the pool are sent to the host on the copy stream and the call returns;
+// pf_bfs_candidates_end waits for them and marks the deferred records.
 static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
                                uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint64_t deferred_cap,
-                               uint64_t *n_deferred) {
+                               uint64_t *n_deferred, bool async_copy = false, uint32_t *deferred_entrance = nullptr) {
     if (!ctx || !ctx->has_adj || u0 > u1 || u1 > ctx->N || !records || !pool || !n_records || !pool_used) return PF_ERR_ARG;
+    if (ctx->bfs_pending.active) { ctx->err = "pf_bfs_candidates_end first"; return PF_ERR_ARG; }
     if (n_deferred) *n_deferred = 0;
     PF_HIP(hipSetDevice(ctx->device));
     uint64_t c0, c1;
@@ -1367,12 +1371,25 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     }
     ctx->bfs_deferred = n_def;
     ctx->bfs_last_rec = d_rec; ctx->bfs_last_pool = d_pool; ctx->bfs_last_n = n; ctx->bfs_last_pool_len = pool_cap;
+    ctx->bfs_call_id++;
     unsigned long long head = 0;
     PF_HIP(hipMemcpy(&head, d_head, 8, hipMemcpyDeviceToHost));
     *pool_used = head;
     if (head > pool_cap) {
         ctx->err = "vertex pool too small";
         status = PF_ERR_OVERFLOW;
+    }
+    if (!dev_out && status == PF_OK && async_copy) {
+        if (!ctx->copy_stream) PF_HIP(hipStreamCreateWithFlags(&ctx->copy_stream, hipStreamNonBlocking));
+        PF_HIP(hipMemcpyAsync(records, d_rec, n * sizeof(pf_bfs_record), hipMemcpyDeviceToHost, ctx->copy_stream));
+        PF_HIP(hipMemcpyAsync(pool, d_pool, (size_t)head * 4, hipMemcpyDeviceToHost, ctx->copy_stream));
+        ctx->bfs_pending.active = true;
+        ctx->bfs_pending.records = records;
+        ctx->bfs_pending.c0 = c0;
+        ctx->bfs_pending.deferred.assign(deferred, deferred + (n_deferred ? *n_deferred : 0));
+        if (deferred_entrance && n_deferred)
+            for (uint64_t d = 0; d < *n_deferred; ++d) deferred_entrance[d] = ctx->h_cand[c0 + deferred[d]];
+        return PF_OK;
     }
     if (!dev_out) {
         if (status == PF_OK) {
@@ -1414,6 +1431,37 @@ int pf_bfs_candidates_split(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record
         (void)hipGetLastError();
     }
     return bfs_candidates_impl(ctx, u0, u1, records, rec_cap, pool, pool_cap, n_records, pool_used, deferred, deferred_cap, n_deferred);
+}
+
+int pf_bfs_candidates_begin(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record *records, uint64_t rec_cap, uint32_t *pool,
+                            uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint32_t *deferred_entrance,
+                            uint64_t deferred_cap, uint64_t *n_deferred) {
+    if (!deferred || !deferred_entrance || !n_deferred) return PF_ERR_ARG;
+    if (ctx) {
+        hipPointerAttribute_t at;
+        if (records && hipPointerGetAttributes(&at, records) == hipSuccess && at.type == hipMemoryTypeDevice) {
+            ctx->err = "pf_bfs_candidates_begin fills host records";
+            return PF_ERR_ARG;
+        }
+        (void)hipGetLastError();
+    }
+    return bfs_candidates_impl(ctx, u0, u1, records, rec_cap, pool, pool_cap, n_records, pool_used, deferred, deferred_cap, n_deferred, true,
+                               deferred_entrance);
+}
+
+int pf_bfs_candidates_end(pf_ctx *ctx) {
+    if (!ctx) return PF_ERR_ARG;
+    if (!ctx->bfs_pending.active) return PF_OK;
+    ctx->bfs_pending.active = false;
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipStreamSynchronize(ctx->copy_stream));
+    for (uint32_t idx : ctx->bfs_pending.deferred) {  // records the caller fills: entrance set, everything else empty
+        pf_bfs_record &r = ctx->bfs_pending.records[idx];
+        memset(&r, 0, sizeof r);
+        r.entrance = ctx->h_cand[ctx->bfs_pending.c0 + idx];
+        r.exit = NONE;
+    }
+    return PF_OK;
 }
 
 }  // extern "C"

@@ -219,7 +219,7 @@ def test_side_components_match_the_host_union_find(case):
     order, off, lab = dev.replay_order(64)
     assert np.array_equal(lab, want)
     assert off[0] == 0 and off[-1] == len(rec) and (np.diff(off.astype(np.int64)) >= 0).all()
-    cls = ((lab.astype(np.uint64) * np.uint64(0x9E3779B1) & np.uint64(0xFFFFFFFF)) * np.uint64(64)) >> np.uint64(32)
+    cls = (lab >> 11) % 64
     for c in range(64):
         idx = order[off[c]:off[c + 1]]
         assert (cls[idx] == c).all() and (np.diff(idx.astype(np.int64)) > 0).all()
