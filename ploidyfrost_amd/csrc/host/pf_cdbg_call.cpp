@@ -212,7 +212,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     if (open_failed >= 0) return fail(PF_ERR_ARG, "CDBG:: Open " + files[(size_t)open_failed].name + " file error");
     last_allfre_.clear();
 
-    // ---- batches: device (this thread) | copy back + append (writer thread) ----
+    // ---- pieces: device (this thread) | copy back (fetcher thread) | append to the files (writer thread) ----
     const size_t CHUNK = std::min<size_t>(std::max<size_t>(batch_bubbles_ ? batch_bubbles_ * 4 : 1, 1), (size_t)1 << 24);
     struct Done {
         pf_call_result res;
@@ -220,27 +220,30 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     };
     std::mutex mu;
     std::condition_variable cv;
-    std::deque<Done> ready;
-    size_t fetched = 0;  // batches whose slabs have been copied off the device
+    std::deque<Done> ready, towrite;
+    size_t fetched = 0;  // pieces whose slabs have been copied off the device
+    size_t written = 0;  // pieces whose text is in the files (their host slab is free again)
+    bool fetcher_done = false;
     bool stop = false, producer_done = false;
     int wst = PF_OK;
     std::string werr;
     double write_s = 0;
-    std::thread writer([&] {
+    // piece b travels device slab b % 2 -> host slab b % 2 -> files; the PCIe copy of piece b + 1 runs beside the file copy of piece b
+    std::thread fetcher([&] {
         size_t b = 0;
         for (;;) {
             Done d;
             {
                 std::unique_lock<std::mutex> lk(mu);
                 cv.wait(lk, [&] { return stop || !ready.empty() || producer_done; });
-                if (stop || ready.empty()) return;
+                if (stop || ready.empty()) { fetcher_done = true; lk.unlock(); cv.notify_all(); return; }
                 d = ready.front();
                 ready.pop_front();
+                cv.wait(lk, [&] { return stop || b < written + 2; });   // host slab b % 2 was last used by piece b - 2
+                if (stop) { fetcher_done = true; lk.unlock(); cv.notify_all(); return; }
             }
-            const auto tw = clk::now();
             uint64_t total = 0, off[PF_CALL_STREAMS + 1];
             for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
-            off[PF_CALL_STREAMS] = total;
             PinnedBuf<char> &hb = cx_.slab[d.slab];
             hb.ensure(ctx_, std::max<uint64_t>(total, 1));
             int st = PF_OK;
@@ -249,11 +252,30 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             {
                 std::lock_guard<std::mutex> lk(mu);
                 fetched = b + 1;
-                if (st != PF_OK) { wst = st; werr = "copy of a text slab failed"; stop = true; }
+                if (st != PF_OK) { wst = st; werr = "copy of a text slab failed"; stop = true; fetcher_done = true; }
+                else towrite.push_back(d);
             }
             cv.notify_all();
             if (st != PF_OK) return;
             if (trace) fprintf(stderr, "[ploidy]   batch %zu fetched (%.1f MB) %.2f ms\n", b, total / 1e6, since(t_all) * 1e3);
+            ++b;
+        }
+    });
+    std::thread writer([&] {
+        size_t b = 0;
+        for (;;) {
+            Done d;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !towrite.empty() || fetcher_done; });
+                if (stop || towrite.empty()) return;
+                d = towrite.front();
+                towrite.pop_front();
+            }
+            const auto tw = clk::now();
+            uint64_t total = 0, off[PF_CALL_STREAMS + 1];
+            for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
+            PinnedBuf<char> &hb = cx_.slab[d.slab];
             // append: every stream at its running offset through a shared mapping, copied by all threads side by side
             if (write_files_)
                 for (int s = 0; s < PF_CALL_STREAMS; ++s)
@@ -263,20 +285,23 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             write_s += since(tw);
             if (trace) fprintf(stderr, "[ploidy]   batch %zu written %.2f ms\n", b, since(t_all) * 1e3);
             ++b;
+            { std::lock_guard<std::mutex> lk(mu); written = b; }
+            cv.notify_all();
         }
     });
     struct WriterGuard {  // joined on every way out
-        std::thread &t;
+        std::thread &t, &t2;
         std::mutex &mu;
         std::condition_variable &cv;
         bool &stop;
         ~WriterGuard() {
-            if (!t.joinable()) return;
+            if (!t.joinable() && !t2.joinable()) return;
             { std::lock_guard<std::mutex> lk(mu); stop = true; }
             cv.notify_all();
-            t.join();
+            if (t.joinable()) t.join();
+            if (t2.joinable()) t2.join();
         }
-    } writer_guard{writer, mu, cv, stop};
+    } writer_guard{fetcher, writer, mu, cv, stop};
 
     uint64_t var_count = 0;
     int rc = PF_OK;
@@ -323,6 +348,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         if (rc != PF_OK) stop = true;
     }
     cv.notify_all();
+    fetcher.join();
     writer.join();
     tp("pipeline done");
     if (rc != PF_OK) {

@@ -126,6 +126,9 @@ struct CallState {
     DevBuf out[2][N_STREAMS];
     uint64_t out_len[2][N_STREAMS] = {};
     hipStream_t copy_stream = nullptr;
+    // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
+    hipStream_t side_stream = nullptr;
+    hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
     // the batch pf_call_align left resident for pf_call_text
     bool mt_format = false;   // pf_call_set_format
     uint64_t cur_t0 = 0;
@@ -139,6 +142,9 @@ struct CallState {
         for (auto &s : out)
             for (DevBuf &b : s) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+        if (side_stream) { (void)hipStreamDestroy(side_stream); side_stream = nullptr; }
+        if (ev_prep) { (void)hipEventDestroy(ev_prep); ev_prep = nullptr; }
+        if (ev_paths) { (void)hipEventDestroy(ev_paths); ev_paths = nullptr; }
     }
 };
 
@@ -482,14 +488,24 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
     const uint32_t n = a.cnt->n_snp;
     const bool active = i < n;
     uint32_t j = 0, m = 0, ov0 = 0, ov1 = 0, col = 0, diff = 0;
+    const uint64_t *w0 = nullptr, *w1 = nullptr;
     if (active) {
         j = a.slist[i];
         const CallTask &t = a.ct[a.kept[a.t0 + j]];
         ov0 = t.inner[0];
         ov1 = t.inner[1];
         m = a.len[ov0 >> 1];
-        for (uint32_t c = 0; c < m; ++c)
-            if (oriented_base(a.seq, a.off, a.len, ov0, c) != oriented_base(a.seq, a.off, a.len, ov1, c)) { ++diff; col = c; }
+        w0 = a.seq + a.off[ov0 >> 1];
+        w1 = a.seq + a.off[ov1 >> 1];
+        // 32 bases per step from two packed words (the paths are equally long: K-PREP's condition for this list)
+        for (uint32_t c = 0; 32 * c < m; ++c) {
+            const uint64_t x = oriented_chunk(w0, m, (ov0 & 1) != 0, c) ^ oriented_chunk(w1, m, (ov1 & 1) != 0, c);
+            const uint64_t d = (x | (x >> 1)) & 0x5555555555555555ull;   // one bit per differing base
+            if (d) {
+                diff += (uint32_t)__popcll(d);
+                col = 32 * c + (uint32_t)(__clzll((long long)d) >> 1);
+            }
+        }
     }
     const bool take = active && diff == 1;
     // pool space: one atomic per wavefront and pool
@@ -550,9 +566,13 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
         a.res[j] = r;
         if (t_off + 2ull * m <= a.text_cap && s_off + 1 <= a.site_cap && 2 * s_off + 2 <= a.group_cap) {
             char *o = staged ? stage + my_excl : a.otext + t_off;
-            for (uint32_t c = 0; c < m; ++c) {
-                o[c] = "ACGT"[oriented_base(a.seq, a.off, a.len, ov0, c)];
-                o[m + c] = "ACGT"[oriented_base(a.seq, a.off, a.len, ov1, c)];
+            for (uint32_t c = 0; 32 * c < m; ++c) {
+                const uint64_t x0 = oriented_chunk(w0, m, (ov0 & 1) != 0, c), x1 = oriented_chunk(w1, m, (ov1 & 1) != 0, c);
+                const uint32_t e = m - 32 * c < 32 ? m - 32 * c : 32;
+                for (uint32_t q = 0; q < e; ++q) {
+                    o[32 * c + q] = "ACGT"[(x0 >> (62 - 2 * q)) & 3];
+                    o[m + 32 * c + q] = "ACGT"[(x1 >> (62 - 2 * q)) & 3];
+                }
             }
             a.ogroups[2 * s_off] = 1;
             a.ogroups[2 * s_off + 1] = 2;
@@ -1779,7 +1799,8 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
     // K-PATHS scratch: stacks sized by the complex size (a non-complex bubble has at most that many vertices)
     const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
     const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (6ull * depth_cap + 4) * 4) + 255) & ~255ull;
-    const int paths_grid = ctx->n_cu * 8;
+    static const int paths_per_cu = [] { const char *e = getenv("PF_PATHS_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
+    const int paths_grid = ctx->n_cu * paths_per_cu;
     NEED(S->paths_scr, paths_per_wave * paths_grid);
 
     // ---- K-PREP, K-SNP, K-PATHS, K-BUBBLE; every pool grows until the batch fits (first batches of a run only) ----
@@ -1822,6 +1843,30 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         ctx_begin(ctx, PF_K_CALL_PREP);
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
         ctx_end(ctx);
+        // K-PATHS (branching bubbles) beside K-SNP and K-PAIR (two-path bubbles): latency-bound walks next to an issue-bound fill
+        static const bool fork_paths = [] { const char *e = getenv("PF_PATHS_STREAM"); return !(e && e[0] == '0'); }();   // measurements
+        hipStream_t pst = st;
+        if (fork_paths) {
+            if (!S->side_stream) {
+                PF_HIP(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
+                PF_HIP(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
+                PF_HIP(hipEventCreateWithFlags(&S->ev_paths, hipEventDisableTiming));
+            }
+            pst = S->side_stream;
+            PF_HIP(hipEventRecord(S->ev_prep, st));
+            PF_HIP(hipStreamWaitEvent(pst, S->ev_prep, 0));
+        }
+        {
+            PathArgs ph;
+            ph.ct = pa.ct; ph.kept = pa.kept; ph.t0 = t0; ph.nb = nb; ph.blist = pa.lists.blist; ph.succ = ctx->d_succ; ph.seq = ctx->d_seq;
+            ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
+            ph.scratch_per_wave = paths_per_wave; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
+            ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
+            ctx_begin_on(ctx, PF_K_CALL_PATHS, pst);
+            k_call_paths<<<paths_grid, 64, 0, pst>>>(ph);
+            ctx_end_on(ctx, pst);
+            if (fork_paths) PF_HIP(hipEventRecord(S->ev_paths, pst));
+        }
         if (snp_ok) {
             SnpArgs sn;
             sn.ct = pa.ct; sn.kept = pa.kept; sn.t0 = t0; sn.nb = nb; sn.slist = pa.lists.slist; sn.seq = ctx->d_seq; sn.off = ctx->d_off;
@@ -1861,14 +1906,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
                         h[0], h[1], h[2], h[3], h[4]);
             }
         }
-        PathArgs ph;
-        ph.ct = pa.ct; ph.kept = pa.kept; ph.t0 = t0; ph.nb = nb; ph.blist = pa.lists.blist; ph.succ = ctx->d_succ; ph.seq = ctx->d_seq;
-        ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
-        ph.scratch_per_wave = paths_per_wave; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
-        ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
-        ctx_begin(ctx, PF_K_CALL_PATHS);
-        k_call_paths<<<paths_grid, 64, 0, st>>>(ph);
-        ctx_end(ctx);
+        if (fork_paths) PF_HIP(hipStreamWaitEvent(st, S->ev_paths, 0));
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
@@ -1934,7 +1972,8 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
     const uint32_t KS = (uint32_t)(2 * k + 64);
     if (hc.n_branching) {
         const uint64_t sites_per_wave = (((uint64_t)512 * KS + 256ull * (4 + 4 + 4 + 1 + 1 + 8)) + 255) & ~255ull;
-        const int sites_grid = (int)std::min<uint32_t>(hc.n_branching, (uint32_t)ctx->n_cu * 4);
+        static const int sites_per_cu = [] { const char *e = getenv("PF_SITES_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
+        const int sites_grid = (int)std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu));
         NEED(S->sites_scr, sites_per_wave * sites_grid);
         for (int attempt = 0;; ++attempt) {
             const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * hc.n_branching + 1024);

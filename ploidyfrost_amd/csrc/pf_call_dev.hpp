@@ -30,6 +30,29 @@ __device__ inline uint32_t oriented_base(const uint64_t *__restrict__ seq, const
     return rev ? 3 - b : b;
 }
 
+// reverse complement of 32 packed bases (first base most significant)
+__device__ inline uint64_t revcomp32(uint64_t x) {
+    uint64_t r = __brevll(x);                                                        // bit order reversed: pairs reversed and swapped inside
+    r = ((r & 0xAAAAAAAAAAAAAAAAull) >> 1) | ((r & 0x5555555555555555ull) << 1);     // swap back inside every pair
+    return ~r;
+}
+
+// bases [32 c, 32 c + 32) of an oriented unitig as one packed word (first base most significant, zero beyond the end):
+// w = its stored words, L = its length.  Two loads at most -- against three per base through oriented_base.
+__device__ inline uint64_t oriented_chunk(const uint64_t *__restrict__ w, uint32_t L, bool rev, uint32_t c) {
+    if (!rev) return w[c];
+    const int32_t hi = (int32_t)L - 32 * (int32_t)c;   // stored bases [hi - 32, hi) in reverse
+    if (hi <= 0) return 0;
+    if (hi < 32) {
+        const uint64_t x = w[0] >> (2 * (32 - hi));    // bases 0 .. hi-1, right-aligned
+        return revcomp32(x) & (~0ull << (2 * (32 - hi)));
+    }
+    const uint32_t lo = (uint32_t)hi - 32, sh = 2 * (lo & 31);
+    uint64_t x = w[lo >> 5] << sh;
+    if (sh) x |= w[(lo >> 5) + 1] >> (64 - sh);        // (lo & 31 != 0 and hi <= L: the next word belongs to the unitig)
+    return revcomp32(x);
+}
+
 // strcmp(referenceUnitigToString(a), referenceUnitigToString(b)): words hold the first base most significant with zero
 // padding, so whole words compare like the strings; the last word is masked to the shorter length and a proper prefix is
 // the smaller string.

@@ -121,6 +121,7 @@ struct pf_ctx {
 
     bool timing = false;
     std::vector<pf::TimedLaunch> launches;
+    size_t side_launch = (size_t)-1;   // ctx_begin_on .. ctx_end_on
     uint64_t units[PF_K_COUNT_] = {};  // work items handed to the timed launches of each kernel (pf_kernel_units)
 };
 
@@ -129,6 +130,8 @@ struct Kc4Args;
 int launch_cov_stream(pf_ctx *ctx, Kc4Args a, uint32_t n_colors, bool wide, bool colored);  // pf_device.hip
 int ctx_begin(pf_ctx *ctx, int kernel);
 void ctx_end(pf_ctx *ctx);
+int ctx_begin_on(pf_ctx *ctx, int kernel, hipStream_t stream);   // the same for a launch on another stream
+void ctx_end_on(pf_ctx *ctx, hipStream_t stream);
 inline void ctx_units(pf_ctx *ctx, int kernel, uint64_t n) { if (ctx->timing) ctx->units[kernel] += n; }
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
 int join_graph_counts(pf_ctx *ctx);

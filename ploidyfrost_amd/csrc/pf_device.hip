@@ -608,6 +608,24 @@ void ctx_end(pf_ctx *ctx) {
     if (!ctx->timing || ctx->launches.empty()) return;
     hipEventRecord(ctx->launches.back().b, ctx->stream);
 }
+// a launch on a side stream: its pair of events is kept aside until ctx_end_on, so that launches on the main stream may be
+// bracketed in between
+int ctx_begin_on(pf_ctx *ctx, int kernel, hipStream_t stream) {
+    if (!ctx->timing) return 0;
+    TimedLaunch tl;
+    tl.kernel = kernel;
+    if (hipEventCreate(&tl.a) != hipSuccess || hipEventCreate(&tl.b) != hipSuccess) return 1;
+    hipEventRecord(tl.a, stream);
+    hipEventRecord(tl.b, stream);   // (re-recorded by ctx_end_on)
+    ctx->launches.push_back(tl);
+    ctx->side_launch = ctx->launches.size() - 1;
+    return 0;
+}
+void ctx_end_on(pf_ctx *ctx, hipStream_t stream) {
+    if (!ctx->timing || ctx->side_launch >= ctx->launches.size()) return;
+    hipEventRecord(ctx->launches[ctx->side_launch].b, stream);
+    ctx->side_launch = (size_t)-1;
+}
 
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes) {
     if (ctx->ws.size() < (size_t)WS_COUNT_) ctx->ws.resize(WS_COUNT_, {nullptr, 0});
