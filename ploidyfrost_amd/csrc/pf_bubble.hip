@@ -775,11 +775,29 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
     // waves in flight: the kernel is a chain of dependent LDS / global accesses per bubble, so it wants
     // every wave slot the LDS budget allows (5 KiB class: 32 per CU by LDS, capped at 24)
-    const int max_waves = ctx->n_cu * 24;
+    // PF_BUBBLE_STREAMS=1 launches the size classes side by side on streams of their own, each with its slice of the scratch.
+    // Measured at 5 M unitigs: no gain (46.20 vs 46.26 ms per pass) -- the classes' tails are not what bounds the kernel, its
+    // instruction issue is -- so the classes run one after the other by default.
+    static const bool class_streams = [] { const char *e = getenv("PF_BUBBLE_STREAMS"); return e && e[0] == '1'; }();   // measurements
+    int grids[kBubLdsClasses];
+    uint64_t waves_total = 0;
+    for (int c = 0; c < kBubLdsClasses; ++c) {
+        grids[c] = L.n_cls[c] ? (int)std::min<uint32_t>(L.n_cls[c], (uint32_t)(ctx->n_cu * bubble_class_waves_per_cu(c))) : 0;
+        waves_total += (uint64_t)grids[c];
+    }
+    const uint64_t max_waves = class_streams ? std::max<uint64_t>(waves_total, (uint64_t)ctx->n_cu * 24) : (uint64_t)ctx->n_cu * 24;
     p.caps = std_caps;
     p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
-    p.scratch = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
+    uint8_t *const scratch0 = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
+    p.scratch = scratch0;
     if (!p.scratch) return PF_ERR_HIP;
+    if (class_streams && !ctx->bub_streams[0]) {
+        for (int c = 0; c < kBubLdsClasses; ++c) {
+            PF_HIP(hipStreamCreateWithFlags(&ctx->bub_streams[c], hipStreamNonBlocking));
+            PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[c], hipEventDisableTiming));
+        }
+        PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[kBubLdsClasses], hipEventDisableTiming));
+    }
 
     DevTmp<unsigned long long> clk_;
     unsigned long long *d_clk = nullptr;
@@ -797,21 +815,37 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         attr_set = true;
     }
     uint32_t idx_off = 0;
-    for (int c = 0; c < kBubLdsClasses; ++c) {
+    uint64_t wave_off = 0;
+    if (class_streams) PF_HIP(hipEventRecord(ctx->bub_events[kBubLdsClasses], st));
+    // largest class first: its tail is the longest
+    for (int c = kBubLdsClasses - 1; c >= 0; --c) {
         const uint32_t nc = L.n_cls[c];
         if (nc == 0) continue;
-        p.idx = L.idx + idx_off;
+        uint32_t first = 0;   // (the queues lie class after class in L.idx)
+        for (int q = 0; q < c; ++q) first += L.n_cls[q];
+        p.idx = L.idx + first;
         p.n = nc;
         p.work_bytes = (uint32_t)kBubClassBytes[c];
-        const int per_cu = bubble_class_waves_per_cu(c);
-        const int grid = (int)std::min<uint32_t>(nc, (uint32_t)(ctx->n_cu * per_cu));
+        const int grid = grids[c];
         p.next = queue_heads + n_launch++;
-        ctx_begin(ctx, PF_K_BUBBLE);
-        k_bubble<true><<<grid, 64, kBubClassBytes[c], st>>>(p, o);
-        ctx_end(ctx);
+        hipStream_t cst = st;
+        if (class_streams) {
+            cst = ctx->bub_streams[c];
+            PF_HIP(hipStreamWaitEvent(cst, ctx->bub_events[kBubLdsClasses], 0));
+            p.scratch = scratch0 + wave_off * p.scratch_per_wave;
+            wave_off += (uint64_t)grid;
+        }
+        ctx_begin_on(ctx, PF_K_BUBBLE, cst);
+        k_bubble<true><<<grid, 64, kBubClassBytes[c], cst>>>(p, o);
+        ctx_end_on(ctx, cst);
         ctx_units(ctx, PF_K_BUBBLE, nc);
+        if (class_streams) {
+            PF_HIP(hipEventRecord(ctx->bub_events[c], cst));
+            PF_HIP(hipStreamWaitEvent(st, ctx->bub_events[c], 0));
+        }
         idx_off += nc;
     }
+    p.scratch = scratch0;
     if (L.n_cls[kBubLdsClasses]) {
         const uint32_t nc = L.n_cls[kBubLdsClasses];
         const int grid = (int)std::min<uint32_t>(nc, 256);

@@ -96,6 +96,9 @@ struct pf_ctx {
     bool gmm_loaded = false;
 
     pf::CallState *call = nullptr;
+    // K-BUBBLE: one stream per LDS size class (pf_bubble.hip), [6] = the event the class streams wait for
+    hipStream_t bub_streams[6] = {};
+    hipEvent_t bub_events[7] = {};
 
     // K-CC (pf_cc.hip): union-find over unitig sides for the parallel commit replay; the records and vertex pool of the last
     // K-BFS call as they lie in the workspace

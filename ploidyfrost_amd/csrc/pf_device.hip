@@ -797,6 +797,8 @@ void pf_destroy(pf_ctx *ctx) {
     hipFree(ctx->d_cov_sum); hipFree(ctx->d_cov_min); hipFree(ctx->d_cov_miss);
     for (auto &w : ctx->ws) hipFree(w.first);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
+    for (auto &s : ctx->bub_streams) if (s) hipStreamDestroy(s);
+    for (auto &e : ctx->bub_events) if (e) hipEventDestroy(e);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
