@@ -74,6 +74,23 @@ const char *pf_kernel_name(int kernel);
  * most significant), padding bits zero.  seq_off has n_unitigs + 1 entries. [host|dev] */
 int pf_upload_graph(pf_ctx *, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp,
                     uint32_t n_unitigs, int k);
+/* K-GFA (pf_gfa.hip): the same graph straight from the bytes of a Bifrost GFA file -- the parse half of CompactedDBG::read
+ * (bifrost/src/CompactedDBG.tcc:823-960, 7888-7908; GFA_Parser.cpp:380-520) on the device.  body = the file after its header
+ * line [host|dev], gfa_version 1 or 2 (the header's VN:Z), k from its KL:Z.  Segment lines are located, their sequences packed two
+ * bits per base, the k-length ones canonicalised; the graph is resident afterwards as after pf_upload_graph, in the unitig order
+ * of pf_upload_graph's callers before abundant k-mers are moved (segments longer than k in file order, then the k-length ones).
+ * PF_ERR_ARG with the loader's messages: "missing fields in a segment line", "segment shorter than k", "non-ACGT base in a
+ * segment", "no segments in the GFA file".  pf_gfa_segments hands the host what it keeps per unitig (once per ingest; any
+ * pointer may be NULL): length, offset of the sequence field inside body, file rank among the segments, the DA:Z tag (-1 =
+ * none; *any_da = some segment had one), and whether a k-length unitig is stored as its reverse complement. */
+int pf_gfa_ingest(pf_ctx *, const char *body, uint64_t n_bytes, int gfa_version, int k, uint32_t *n_unitigs, uint32_t *n_short);
+/* The same in two steps: pf_gfa_parse (locate + pack, on a stream of its own, touching nothing else of the context: it may run
+ * on one thread while another feeds the count table to the same context; its error text: pf_gfa_error) and pf_gfa_upload (the
+ * packed arrays become the context's graph, as pf_upload_graph). */
+int pf_gfa_parse(pf_ctx *, const char *body, uint64_t n_bytes, int gfa_version, int k, uint32_t *n_unitigs, uint32_t *n_short);
+int pf_gfa_upload(pf_ctx *);
+const char *pf_gfa_error(const pf_ctx *);
+int pf_gfa_segments(pf_ctx *, uint32_t *len_bp, uint64_t *seq_off, uint32_t *file_rank, int16_t *da_tag, uint8_t *stored_rc, int *any_da);
 /* G2: neighbour discovery (bifrost/src/NeighborIterator.tcc:25-47 via
  * CompactedDBG::find(km, extremities_only=true), CompactedDBG.tcc:1403-1523): joins the
  * end k-mers of all unitigs on the device and fills the CSR kept in the context.

@@ -77,6 +77,11 @@ void CountsLoader::start(int device, const std::string &kmc_prefix) {
     th_ = std::thread([this, device, kmc_prefix] {
         LoadTrace trace;
         status = pf_create(device, &ctx);
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            ctx_known_ = true;
+        }
+        cv_.notify_all();
         if (status != PF_OK) { error = std::string("CDBG::CDBG():Error: ") + pf_last_error(nullptr); return; }
         trace.mark("device: context (beside the graph read)");
         KmcRecords db;
@@ -105,7 +110,7 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
     bind_to_device_node(ctx_);
     out_maps_.reset(new MappedOut[PF_CALL_STREAMS + 1]);   // ten streams of PloidyEstimation + super_bubble.txt
     if (!getenv("PF_NO_PREALLOC")) {
-        const uint64_t n_est = g_.n();
+        const uint64_t n_est = g_.ingest_pending() ? g_.estimated_unitigs() : g_.n();
         prealloc_ = std::thread([this, n_est, colored] {
             bx_.bfs_rec.ensure(ctx_, n_est * 7 / 10 + 4096);            // ~0.67 candidates per unitig
             bx_.bfs_pool.ensure(ctx_, n_est * 7 / 10 * 6 + (5u << 20));
@@ -116,8 +121,15 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
             }
         });
     }
-    st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
-    if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));
+    if (g_.ingest_pending()) {
+        // K-GFA: the S-lines are parsed and packed on the device; the host keeps the segment table
+        std::string e;
+        st = g_.ingest_on_device(ctx_, e);
+        if (st != PF_OK) return fail(st, "CompactedDBG::read(): Graph could not be loaded! Exit. (" + e + ")");
+    } else {
+        st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
+        if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));
+    }
     trace.mark("device: graph upload");
     if (g_.numbering_deferred) {
         // unitig numbering, last part: K-MINZ bounds the fill of every minimizer bucket; only a graph that can crowd one
@@ -380,6 +392,7 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
     const unsigned T = threads_ ? threads_ : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     if (join_pending_ids()) return status_;
     auto job = [this, name = outpre + "_Unitig_Id.txt", T]() -> int {
+        g_.ensure_text();   // (after a device ingest the sequences are still in the mapped file only)
         constexpr size_t UCH = 32768;
         const size_t N = g_.n(), n_ch = n_chunks_of(N, UCH);
         std::vector<uint64_t> base(n_ch + 1, 0);

@@ -19,6 +19,7 @@
 #pragma once
 #include <chrono>
 #include <memory>
+#include <condition_variable>
 #include <mutex>
 
 #include "pf_bfs_host.hpp"
@@ -67,9 +68,19 @@ struct CountsLoader {
     int k = 0;
     void wait() { if (th_.joinable()) th_.join(); }
     pf_ctx *release() { pf_ctx *c = ctx; ctx = nullptr; return c; }
+    // the context as soon as it exists (the count table is still on its way): nullptr when its creation failed.  Only calls
+    // that are safe beside the table's ingest may use it before wait() (pf_gfa_parse).
+    pf_ctx *wait_context() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return ctx_known_; });
+        return ctx;
+    }
 
 private:
     std::thread th_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    bool ctx_known_ = false;
 };
 
 class CDBG {

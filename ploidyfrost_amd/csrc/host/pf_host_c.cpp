@@ -66,7 +66,9 @@ pfh_run *pfh_open(const char *gfa_path, const char *kmc_prefix, uint32_t complex
     try {
     auto r = std::make_unique<pfh_run>();
     auto t0 = clk::now();
-    if (!r->graph.load_gfa(gfa_path, g_open_err, true)) return nullptr;  // numbering finished by the CDBG constructor (K-MINZ)
+    // K-GFA: parsed and packed on the device by the CDBG constructor, where the numbering is finished as well (K-MINZ)
+    static const bool host_gfa = [] { const char *e = getenv("PF_GFA"); return e && !strcmp(e, "host"); }();
+    if (!(host_gfa ? r->graph.load_gfa(gfa_path, g_open_err, true) : r->graph.open_gfa(gfa_path, g_open_err))) return nullptr;
     r->load_s = std::chrono::duration<double>(clk::now() - t0).count();
     r->z = complex_size;
     r->z_M = match; r->z_D = mismatch; r->z_G = gap;

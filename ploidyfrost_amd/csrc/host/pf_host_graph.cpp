@@ -11,9 +11,12 @@
 #include <algorithm>
 #include <cstdio>
 #include <atomic>
+#include "ploidyfrost_hip.h"
+
 #include <chrono>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <thread>
 
 namespace pfh {
@@ -220,7 +223,123 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err, bool defer_n
     return true;
 }
 
+// ---- device ingest ----------------------------------------------------------------------------------------------------
+struct GfaSource {
+    Mapped file;
+    const char *body = nullptr;
+    uint64_t body_n = 0;
+    int version = 1;
+    std::vector<uint64_t> file_off;   // per unitig: its sequence field inside body
+    std::mutex mu;
+    bool text_ready = false;
+};
+
+static bool parse_gfa_header(const char *p, const char *end, int &version, int &k, int &g, const char *&body, std::string &err) {
+    const char *le = (const char *)memchr(p, '\n', (size_t)(end - p));
+    if (!le || p == le || *p != 'H') { err = "GFA header line missing"; return false; }
+    version = 1;
+    if (le - p >= 10 && memcmp(p, "H\tVN:Z:2.0", 10) == 0) version = 2;
+    const char *q = p + 2;   // tags of the header line (CompactedDBG.tcc:868-884)
+    while (q < le) {
+        const char *t = (const char *)memchr(q, '\t', (size_t)(le - q));
+        if (!t) t = le;
+        if (t - q > 5 && memcmp(q, "KL:Z:", 5) == 0) k = atoi(std::string(q + 5, t).c_str());
+        else if (t - q > 5 && memcmp(q, "ML:Z:", 5) == 0) g = atoi(std::string(q + 5, t).c_str());
+        q = t + 1;
+    }
+    if (k < 3 || k > 31) { err = "k outside 3..31"; return false; }
+    body = le + 1;
+    return true;
+}
+
+bool UnitigSet::open_gfa(const std::string &path, std::string &err) {
+    auto s = std::make_shared<GfaSource>();
+    if (!s->file.open(path)) { err = "cannot open " + path; return false; }
+    const char *body = nullptr;
+    if (!parse_gfa_header(s->file.p, s->file.p + s->file.n, s->version, k, g, body, err)) return false;
+    s->body = body;
+    s->body_n = (uint64_t)(s->file.p + s->file.n - body);
+    src_ = s;
+    ingested_ = false;
+    return true;
+}
+
+uint64_t UnitigSet::estimated_unitigs() const { return src_ ? src_->body_n / 75 + 1024 : n(); }
+
+int UnitigSet::parse_on_device(pf_ctx *ctx) {
+    LoadTrace trace;
+    parsed_on_ = ctx;
+    parse_status_ = pf_gfa_parse(ctx, src_->body, src_->body_n, src_->version, k, &parsed_n_, &parsed_short_);
+    trace.mark("gfa: parse + 2-bit pack on the device");
+    return parse_status_;
+}
+
+int UnitigSet::ingest_on_device(pf_ctx *ctx, std::string &err) {
+    if (parsed_on_ != ctx) parse_on_device(ctx);
+    LoadTrace trace;
+    if (parse_status_ != PF_OK) { err = pf_gfa_error(ctx); return parse_status_; }
+    uint32_t N = parsed_n_, ns = parsed_short_;
+    int st = pf_gfa_upload(ctx);
+    if (st != PF_OK) { err = pf_last_error(ctx); return st; }
+    trace.mark("gfa: packed graph adopted by the context");
+    n_short = ns;
+    len_bp.resize(N);
+    src_->file_off.resize(N);
+    file_rank.resize(N);
+    std::vector<int16_t> da(N);
+    int any_da = 0;
+    st = pf_gfa_segments(ctx, len_bp.data(), src_->file_off.data(), file_rank.data(), da.data(), nullptr, &any_da);
+    if (st != PF_OK) { err = pf_last_error(ctx); return st; }
+    if (any_da) da_tag.swap(da); else da_tag.clear();
+    off.resize((size_t)N + 1);
+    n_kmers = 0;
+    uint64_t at = 0;
+    for (size_t u = 0; u < N; ++u) { off[u] = at; at += len_bp[u]; n_kmers += len_bp[u] - (uint32_t)k + 1; }
+    off[N] = at;
+    text.clear();
+    words.clear();
+    word_off.clear();
+    n_abundant = 0;
+    numbering_replays = 0;
+    numbering_deferred = true;
+    ingested_ = true;
+    trace.mark("gfa: segment table on the host");
+    return PF_OK;
+}
+
+// the sequences as load_gfa leaves them (upper case, k-length ones canonical), from the mapped file
+void UnitigSet::ensure_text() {
+    if (!src_ || !ingested_) return;
+    std::lock_guard<std::mutex> lk(src_->mu);
+    if (src_->text_ready) return;
+    const size_t N = len_bp.size();
+    text.resize(off[N]);
+    const unsigned T = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
+    const char *body = src_->body;
+    const std::vector<uint64_t> &fo = src_->file_off;
+    parallel_chunks(N, 8192, T, [&](size_t, size_t b0, size_t b1) {
+        char fw[32], rc[32];
+        for (size_t u = b0; u < b1; ++u) {
+            const char *s = body + fo[u];
+            char *dst = text.data() + off[u];
+            const uint32_t L = len_bp[u];
+            if ((int)L == k) {
+                for (int j = 0; j < k; ++j) {
+                    const int c = code_of(s[j]);
+                    fw[j] = kBase[c & 3];
+                    rc[k - 1 - j] = kBase[3 - (c & 3)];
+                }
+                memcpy(dst, memcmp(rc, fw, (size_t)k) < 0 ? rc : fw, (size_t)k);
+            } else {
+                for (uint32_t j = 0; j < L; ++j) dst[j] = kBase[code_of(s[j]) & 3];
+            }
+        }
+    });
+    src_->text_ready = true;
+}
+
 void UnitigSet::finish_numbering(std::vector<uint8_t> *counters) {
+    ensure_text();
     const size_t N = len_bp.size(), n_long = N - (size_t)n_short;
     if (numbering_deferred && n_short && g >= 1 && g <= k - 2 && g <= 31 && file_rank.size() == N) {
         const unsigned T = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));

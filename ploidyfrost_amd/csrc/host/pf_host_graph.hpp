@@ -7,11 +7,16 @@
 // discovery and k-mer lookups happen on the GPU (include/ploidyfrost_hip.h).
 #pragma once
 #include <cstdint>
+#include <memory>
 #include <string>
 #include <string_view>
 #include <vector>
 
+struct pf_ctx;
+
 namespace pfh {
+
+struct GfaSource;   // the mapped GFA file of a device ingest (pf_host_graph.cpp)
 
 struct UnitigSet {
     int k = 31;
@@ -50,9 +55,30 @@ struct UnitigSet {
     // (length > k) in file order, then k-length ones, each stored as min(seq, revcomp)
     // (SURVEY.md 3.1), the abundant ones last (pf_host_minz.hpp).  A last line without '\n' is ignored, as in bifrost/src/GFA_Parser.cpp:486.
     bool load_gfa(const std::string &path, std::string &err, bool defer_numbering = false);
+    // Device ingest (K-GFA, csrc/pf_gfa.hip): open_gfa maps the file and reads its header line; the owner of the device context
+    // calls ingest_on_device, which parses and packs the segments THERE (the graph is resident afterwards: no pf_upload_graph)
+    // and keeps on the host what it needs per unitig -- length, place in the file, file rank, DA tag.  `text` (and with it
+    // seq(), append_mapped(), words) is made from the mapped file only when somebody asks: ensure_text().  Same unitig order,
+    // same error messages as load_gfa(defer_numbering = true).
+    bool open_gfa(const std::string &path, std::string &err);
+    bool ingest_pending() const { return src_ != nullptr && !ingested_; }
+    uint64_t estimated_unitigs() const;   // before the ingest: from the size of the file
+    // parse_on_device: the parse + pack half alone (pf_gfa_parse: may run while another thread feeds the count table to the same
+    // context); ingest_on_device then only adopts the packed arrays as the context's graph and fetches the segment table
+    int parse_on_device(pf_ctx *ctx);
+    int ingest_on_device(pf_ctx *ctx, std::string &err);
+    bool on_device() const { return ingested_; }
+    void ensure_text();
     // builds from already ordered sequences (tests, generators)
     void from_sequences(const std::vector<std::string> &seqs, int k_);
     void pack();
+
+private:
+    std::shared_ptr<GfaSource> src_;
+    bool ingested_ = false;
+    pf_ctx *parsed_on_ = nullptr;   // parse_on_device ran on this context
+    int parse_status_ = 0;
+    uint32_t parsed_n_ = 0, parsed_short_ = 0;
 };
 
 // A KMC database opened for the device: header and prefix table parsed on the host (a few KB .. MB), the record area of

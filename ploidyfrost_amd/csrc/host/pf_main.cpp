@@ -402,13 +402,19 @@ int main(int argc, char **argv) {
     auto mark = [&](const char *what) {
         if (trace_main) fprintf(stderr, "[main] %-28s %.3fs since start\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
     };
-    if (!graph.load_gfa(opt.graphfile, err, true)) {  // abundant k-mers are decided with the device (K-MINZ) in the CDBG constructor
+    // K-GFA: the file is mapped and its header read here; the segments are parsed and packed on the device by the CDBG constructor
+    // (PF_GFA=host: the host loader).  Abundant k-mers are decided there as well (K-MINZ).
+    static const bool host_gfa = [] { const char *e = getenv("PF_GFA"); return e && !strcmp(e, "host"); }();
+    if (!(host_gfa ? graph.load_gfa(opt.graphfile, err, true) : graph.open_gfa(opt.graphfile, err))) {
         cout << "CompactedDBG::read(): Graph could not be loaded! Exit. (" << err << ")" << endl;
         exit(EXIT_FAILURE);
     }
-    cout << "CompactedDBG::read(): Graph loading successful" << endl;
-
-    cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
+    if (host_gfa) {
+        cout << "CompactedDBG::read(): Graph loading successful" << endl;
+        cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
+    } else if (pf_ctx *c = counts.wait_context()) {
+        graph.parse_on_device(c);   // beside the count table's ingest; a refusal is reported by the constructor
+    }
     mark("graph file read");
 
     // (on the heap and never destroyed: at the end of main the process leaves through quick_exit -- giving 12 GB of device and
@@ -419,7 +425,14 @@ int main(int argc, char **argv) {
         cerr << g.error() << endl;
         exit(EXIT_FAILURE);
     };
-    if (!g.good()) die();
+    if (!g.good()) {
+        if (g.error().rfind("CompactedDBG::read()", 0) == 0) { cout << g.error() << endl; exit(EXIT_FAILURE); }   // (the ingest's word for it)
+        die();
+    }
+    if (!host_gfa) {
+        cout << "CompactedDBG::read(): Graph loading successful" << endl;
+        cout << "CDBG: Graph loading Real time : " << std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() << "s" << endl;
+    }
     if (opt.verbose && graph.n_abundant)
         cout << "CompactedDBG::read(): " << graph.n_abundant << " k-length unitigs are abundant k-mers (numbered last, in Bifrost's hash table order)" << endl;
     g.set_threads((unsigned)opt.nb_threads);

@@ -103,6 +103,7 @@ struct pf_ctx {
     // K-CC (pf_cc.hip): union-find over unitig sides for the parallel commit replay; the records and vertex pool of the last
     // K-BFS call as they lie in the workspace
     void *cc = nullptr;
+    void *gfa = nullptr;   // K-GFA (pf_gfa.hip): segment table of the last pf_gfa_ingest until pf_gfa_segments fetches it
     const void *cc_rec = nullptr;
     const pf_bfs_record *bfs_last_rec = nullptr;
     const uint32_t *bfs_last_pool = nullptr;
@@ -143,6 +144,7 @@ int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
 void call_destroy(pf_ctx *ctx);     // pf_call.hip
 void cc_destroy(pf_ctx *ctx);       // pf_cc.hip
+void gfa_destroy(pf_ctx *ctx);      // pf_gfa.hip
 void call_invalidate(pf_ctx *ctx);  // graph or count table replaced
 enum WsSlot {
     WS_ALN_TEXT = 0, WS_ALN_JOBS, WS_ALN_SMALL, WS_ALN_RETRY, WS_ALN_IDX, WS_ALN_OFIRST, WS_ALN_OCOUNT, WS_ALN_OHITS, WS_ALN_OTEXT,

@@ -791,6 +791,7 @@ void pf_destroy(pf_ctx *ctx) {
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
     call_destroy(ctx);
     cc_destroy(ctx);
+    gfa_destroy(ctx);
     free_graph(ctx);
     hipFree(ctx->d_tab);
     hipFree(ctx->d_ctab);
