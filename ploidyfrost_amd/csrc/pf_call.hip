@@ -91,6 +91,7 @@ struct CallCounters {
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
+    unsigned int err_entrance, err_exit;   // the bubble bits 0 / 5 speak of (oriented vertices; whichever wavefront wrote last)
     unsigned long long path_head, text_head, sv_head;
     unsigned long long max_need, retry_need;
     unsigned long long allele[4], core_cov, core_num, n_called, site_strings;
@@ -846,7 +847,12 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if (too_many || too_deep) {
-            if (lane == 0) { atomicOr(&a.cnt->err, too_many ? 1u : 32u); a.btask[j] = pf_bubble_task{0, 0, 0}; }
+            if (lane == 0) {
+                atomicOr(&a.cnt->err, too_many ? 1u : 32u);
+                a.cnt->err_entrance = t.entrance_ov;
+                a.cnt->err_exit = t.exit_ov;
+                a.btask[j] = pf_bubble_task{0, 0, 0};
+            }
             continue;
         }
         // ---- sortSeq_branching (src/CDBG.cpp:417-480): descending length, ties by descending strcmp.  Distinct walks spell
@@ -1914,8 +1920,14 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         if (snp_ok) ctx_units(ctx, PF_K_CALL_SNP, hc.n_snp);
         if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
-        if (hc.err & 1u) { ctx->err = "pf_call_run: a bubble has more than 255 paths"; return PF_ERR_ARG; }
-        if (hc.err & 32u) { ctx->err = "pf_call_run: a bubble is deeper than the complex size allows"; return PF_ERR_ARG; }
+        if (hc.err & 33u) {
+            // (path indices in the allele groups are bytes; the reference has no such limit but needs minutes for such a bubble)
+            char where[96];
+            snprintf(where, sizeof where, " (superbubble from unitig %u%c to unitig %u%c)", (hc.err_entrance >> 1) + 1, (hc.err_entrance & 1) ? '-' : '+',
+                     (hc.err_exit >> 1) + 1, (hc.err_exit & 1) ? '-' : '+');
+            ctx->err = std::string(hc.err & 1u ? "pf_call_run: a bubble has more than 255 paths" : "pf_call_run: a bubble is deeper than the complex size allows") + where;
+            return PF_ERR_ARG;
+        }
         S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
         S->ogroups_cap = std::max(S->ogroups_cap, cap_groups); S->oilen_cap = std::max(S->oilen_cap, cap_ilen);
         S->path_pool = std::max(S->path_pool, path_cap);

@@ -253,3 +253,54 @@ def test_reference_threads_format_matches_the_threaded_reference(case, tmp_path)
     for name in ("bifre", "trifre", "tetrafre", "pentafre"):
         assert open(os.path.join(exp, "g_%s.txt" % name), "rb").read() == open(tmp_path / "t3" / ("g_%s.txt" % name), "rb").read()
     run.close()
+
+
+def _braid(tmp_path, k, layers, seed=11):
+    """A superbubble of 2^layers paths over 2 * layers + 2 unitigs: every unitig of a layer is followed by both unitigs of the
+    next one (they share their last k-1 bases), so no inner pair of layers closes into a bubble of its own."""
+    from ploidyfrost_amd import synth
+    rng = np.random.default_rng(seed)
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+
+    def rnd(n):
+        return bytes(rng.choice(list(b"ACGT"), size=n).tolist())
+
+    junction = [rnd(k - 1) for _ in range(layers + 1)]
+    segs = [rnd(40) + junction[0]]
+    for i in range(layers):
+        segs.append(junction[i] + b"A" + rnd(6) + junction[i + 1])
+        segs.append(junction[i] + b"C" + rnd(6) + junction[i + 1])
+    segs.append(junction[layers] + b"G" + rnd(40))
+    gfa = str(tmp_path / "braid.gfa")
+    with open(gfa, "wb") as f:
+        f.write(b"H\tVN:Z:1.0\tKL:Z:%d\tML:Z:%d\n" % (k, k - 8))
+        for i, s in enumerate(segs):
+            f.write(b"S\t%d\t%s\n" % (i + 1, s))
+    # the database holds the k-mers of four walks that use every edge between the layers
+    walks = []
+    for pick in (lambda i: 0, lambda i: 1, lambda i: i % 2, lambda i: 1 - i % 2):
+        w = segs[0]
+        for i in range(layers):
+            w += segs[1 + 2 * i + pick(i)][k - 1:]
+        w += segs[-1][k - 1:]
+        walks.append(np.array([code[c] for c in w], dtype=np.uint8))
+    km, mult = synth.canonical_counts(walks, k)
+    db = str(tmp_path / "braid_db")
+    synth.write_kmc1(db, km, np.full(len(km), 20, dtype=np.uint32), k)
+    return gfa, db, len(segs)
+
+
+def test_more_than_255_paths_are_refused_by_name(tmp_path):
+    """path indices inside the allele groups are bytes: a bubble of 256 paths is refused -- with its endpoints named, not with a
+    crash -- and one of 128 paths goes through"""
+    gfa, db, n = _braid(tmp_path, 25, 8)
+    r = subprocess.run([CLI, "-g", gfa, "-d", db, "-o", "g", "-z", "40", "-l", "1", "-u", "1000", "-t", "2"], cwd=tmp_path, capture_output=True, text=True)
+    assert r.returncode != 0
+    assert "a bubble has more than 255 paths (superbubble from unitig " in r.stdout + r.stderr, (r.stdout[-400:], r.stderr[-400:])
+    sub = tmp_path / "seven"
+    sub.mkdir()
+    gfa, db, n = _braid(sub, 25, 7)
+    r = subprocess.run([CLI, "-g", gfa, "-d", db, "-o", "g", "-z", "40", "-l", "1", "-u", "1000", "-t", "2"], cwd=sub, capture_output=True, text=True)
+    assert r.returncode == 0, (r.stdout[-400:], r.stderr[-400:])
+    rows = open(os.path.join(str(sub), "PloidyFrost_output", "g_alignseq.txt")).read()
+    assert rows.count("\n") > 128
