@@ -1921,7 +1921,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (hc.err & 33u) {
-            // (path indices in the allele groups are bytes; the reference has no such limit but needs minutes for such a bubble)
+            // (the per-wave tables of K-PATHS / K-SITES and K-BUBBLE's standard tier hold 256 rows; the reference has no such limit)
             char where[96];
             snprintf(where, sizeof where, " (superbubble from unitig %u%c to unitig %u%c)", (hc.err_entrance >> 1) + 1, (hc.err_entrance & 1) ? '-' : '+',
                      (hc.err_exit >> 1) + 1, (hc.err_exit & 1) ? '-' : '+');
