@@ -229,7 +229,18 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     std::string werr;
     double write_s = 0;
     // piece b travels device slab b % 2 -> host slab b % 2 -> files; the PCIe copy of piece b + 1 runs beside the file copy of piece b
+    auto thread_failed = [&](const char *who, const std::exception &e) {   // an exception in a helper thread ends the pipeline, not the process
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            wst = PF_ERR_HIP;
+            werr = std::string(who) + ": " + e.what();
+            stop = true;
+            fetcher_done = true;
+        }
+        cv.notify_all();
+    };
     std::thread fetcher([&] {
+        try {
         size_t b = 0;
         for (;;) {
             Done d;
@@ -260,8 +271,10 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             if (trace) fprintf(stderr, "[ploidy]   batch %zu fetched (%.1f MB) %.2f ms\n", b, total / 1e6, since(t_all) * 1e3);
             ++b;
         }
+        } catch (const std::exception &e) { thread_failed("copy of a text slab", e); }
     });
     std::thread writer([&] {
+        try {
         size_t b = 0;
         for (;;) {
             Done d;
@@ -288,6 +301,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             { std::lock_guard<std::mutex> lk(mu); written = b; }
             cv.notify_all();
         }
+        } catch (const std::exception &e) { thread_failed("writing the result files", e); }
     });
     struct WriterGuard {  // joined on every way out
         std::thread &t, &t2;

@@ -95,7 +95,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     std::mutex mu;
     std::condition_variable cv;
     int done = 0, dev_st = PF_OK;
-    std::string dev_err;
+    std::string dev_err, walk_err;
     double bfs_s = 0;
     const bool prefetch_cov = overlap_output_;  // the same switch: work of the next call started behind the caller's back
     cov_ready_ = false;
@@ -105,6 +105,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
     std::atomic<uint64_t> n_deferred_total{0};
     std::thread device([&] {
+        try {
         std::vector<uint32_t> &deferred = deferred_;   // keeps its size from pass to pass
         for (int i = 0; i < kSlices; ++i) {
             const auto tb = clk::now();
@@ -144,6 +145,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                 // third tier: one host thread per giant traversal, side by side; lists go to huge_lists_
                 huge_lists_[i].assign((size_t)n_deferred, std::vector<uint32_t>());
                 walk = std::thread([&, i] {
+                    try {
                     parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
                         std::unique_ptr<HugeWalker> w;
                         {
@@ -167,11 +169,19 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
                             walkers_.push_back(std::move(w));
                         }
                     });
+                    } catch (const std::exception &e) {
+                        std::lock_guard<std::mutex> lk(mu);
+                        walk_err = e.what();
+                    }
                 });
             }
             // K-CC for the records that are on the device, beside the walkers and the copy
             if (st1 == PF_OK && rt) st1 = pf_side_components(ctx_, i == 0, nullptr, s_nrec[i], nullptr, 0, nullptr, 0, nullptr, 0);
             if (walk.joinable()) walk.join();
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (!walk_err.empty()) throw std::runtime_error("walk of a long traversal: " + walk_err);
+            }
             if (third_tier_on_host_) {
                 const int ste = pf_bfs_candidates_end(ctx_);
                 if (st1 == PF_OK) st1 = ste;
@@ -210,6 +220,15 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
             if (st1 != PF_OK) return;
         }
         if (prefetch_cov) cov_ready_ = launch_coverage() == PF_OK;
+        } catch (const std::exception &e) {   // (bad_alloc of a list or a buffer: reported like a device error, not std::terminate)
+            (void)pf_bfs_candidates_end(ctx_);   // (a copy of records may still be in flight)
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                dev_st = PF_ERR_HIP;
+                dev_err = std::string("host layer: ") + e.what();
+            }
+            cv.notify_all();
+        }
     });
     times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = 0;  // (kSlices above looked at the previous pass)
     times_.bfs_deferred = 0;

@@ -29,6 +29,7 @@ static std::string g_open_err;
 // no C++ exception may cross the C boundary
 template <class F>
 static int guarded(pfh_run *r, F &&f) {
+    r->err.clear();   // (a message of an earlier call must not outlive it: pfh_last_error prefers this string)
     try {
         return f();
     } catch (const std::exception &e) {

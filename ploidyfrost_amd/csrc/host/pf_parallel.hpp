@@ -10,6 +10,7 @@
 #include <condition_variable>
 #include <cstddef>
 #include <deque>
+#include <exception>
 #include <functional>
 #include <mutex>
 #include <thread>
@@ -46,6 +47,7 @@ public:
         for (auto it = jobs_.begin(); it != jobs_.end(); ++it)
             if (*it == &job) { jobs_.erase(it); break; }  // no new worker can join from here on
         done_cv_.wait(lk, [&] { return job.active == 0 && job.completed.load(std::memory_order_acquire) == n_chunks; });
+        if (job.failed) std::rethrow_exception(job.failed);
     }
 
 private:
@@ -55,6 +57,7 @@ private:
         std::atomic<size_t> next{0}, completed{0};
         int slots = 0;   // workers that may still join (guarded by mu_)
         int active = 0;  // workers inside work_on (guarded by mu_)
+        std::exception_ptr failed;   // first exception thrown by a chunk (guarded by mu_)
     };
 
     WorkPool() = default;
@@ -75,7 +78,12 @@ private:
         for (;;) {
             const size_t c = job.next.fetch_add(1, std::memory_order_relaxed);
             if (c >= job.n_chunks) return;
-            (*job.fn)(c);
+            try {
+                (*job.fn)(c);
+            } catch (...) {   // rethrown on the thread that called run(): a worker must not take the process down
+                std::lock_guard<std::mutex> lk(mu_);
+                if (!job.failed) job.failed = std::current_exception();
+            }
             job.completed.fetch_add(1, std::memory_order_release);
         }
     }

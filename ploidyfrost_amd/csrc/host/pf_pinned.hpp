@@ -1,6 +1,7 @@
 // Grow-only pinned host buffer for the exchange with the device layer (falls back to pageable
 // memory if pinning fails).  Contents are not preserved across ensure().
 #pragma once
+#include <new>
 #include <cstddef>
 #include <cstdlib>
 
@@ -31,7 +32,11 @@ struct PinnedBuf {
         const size_t want = n + n / 4 + 64;
         void *q = nullptr;
         if (pf_host_alloc(c, want * sizeof(T), &q) == PF_OK) { p = (T *)q; pinned = true; }
-        else { p = (T *)malloc(want * sizeof(T)); pinned = false; }
+        else {
+            p = (T *)malloc(want * sizeof(T));
+            pinned = false;
+            if (!p) { cap = 0; throw std::bad_alloc(); }
+        }
         cap = want;
     }
 };
