@@ -56,13 +56,17 @@ SHARDED_FIND = textwrap.dedent("""
     assert (np.diff(rec["entrance"].astype(np.int64)) > 0).all() and (len(rec) == 0 or (rec["entrance"][0] >> 1) >= u0)
     recs = pfdist.all_gather_slabs(rec.view(np.uint8).reshape(-1), dev)
     pools = pfdist.all_gather_slabs(pool.view(np.uint8).reshape(-1), dev)
-    rp = hostapi.Replay(n, z)
+    # the replicated replay: sequentially, and spread over host threads by the components of the records' footprints
+    # (csrc/host/pf_replay_par.hpp) -- shard after shard, the components growing with every shard
+    rp, rq = hostapi.Replay(n, z), hostapi.Replay(n, z)
     total = 0
     for r, p in zip(recs, pools):
         r = np.ascontiguousarray(r).view(hipapi.BFS_RECORD)
         total += len(r)
         rp.apply(r, np.ascontiguousarray(p).view(np.uint32))
+        rq.apply(r, np.ascontiguousarray(p).view(np.uint32), threads=3 + rank)
     f, p, m = rp.state()
+    assert all(np.array_equal(a, b) for a, b in zip(rq.state(), (f, p, m))), "parallel replay differs from the sequential one"
     o.find_superbubbles(z=z)
     ef, ep, em = o.state()
     assert total == int(((np.asarray(succ).reshape(-1, 4) != hipapi.NONE).sum(axis=1) > 1).sum())
