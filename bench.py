@@ -10,9 +10,12 @@ parsing, upload and Unitig_Id writing are outside the timed region (BASELINE.md 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
 N > 1: one process per GPU, ONE graph (BASELINE.json configs[2]: "5 M-unitig ... 1->8 MI355X scaling"), replicated in every
-GPU's HBM and cut by entrance vertex (ploidyfrost_amd/dist.py): each rank traverses the candidate entrances of its unitig range,
-the traversal records are all-gathered over RCCL and replayed on every rank; each rank aligns, formats and writes its slice of the
-bubble list into the shared result files after two small all-gathers (bubbles called, slab sizes + allele histograms).
+GPU's HBM (ploidyfrost_amd/dist.py).  PloidyEstimation -- two thirds of a pass -- is cut over the ranks: each rank aligns, formats
+and writes its slice of the bubble list into the shared result files after two small all-gathers (bubbles called, slab sizes +
+allele histograms).  findSuperBubble is run by every rank by default: its device part is 1.6 ms of a 12 ms phase whose rest --
+the copy of the records to the host, the commits, the state upload -- every rank needs in full, so cutting it by entrance vertex
+(--shard-find: each rank traverses the entrances of its unitig range, the records are all-gathered over RCCL and replayed on every
+rank) adds an exchange of 183 MB to save a millisecond; the protocol is built, tested and selectable, not the default.
 "scaling": "strong"; value = unitigs of the graph * steps / max-over-ranks time.  --scaling weak keeps the other reading (every
 rank its own graph, no data-path collective).
 """
@@ -245,6 +248,9 @@ def main():
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
                     help="strong (default: the metric's config is one 5 M-unitig graph at 1..8 GPUs): ONE graph of --unitigs unitigs cut "
                          "by entrance vertex over the ranks (SURVEY.md 8e); weak: every rank its own graph of --unitigs unitigs")
+    ap.add_argument("--shard-find", action="store_true",
+                    help="strong scaling: cut findSuperBubble by entrance vertex as well (all-gather of the traversal records) instead of "
+                         "running it on every rank")
     ap.add_argument("--workload", choices=["single", "colored"], default="single",
                     help="single = the headline metric (BASELINE.json configs[1]); colored = the CCDBG path on 3 diploid "
                          "samples (configs[3]), same JSON line with config.workload saying so")
@@ -297,6 +303,8 @@ def main():
             run.set_output_dir(pfdist.broadcast_str(os.path.join(workdir, "PloidyFrost_output")))
         if not strong or rank == 0:
             run.set_unitig_id("b")
+        if strong and rank != 0:
+            run.set_write_super_bubble(False)
         load_s = time.time() - t0
         log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, load_s, torch.cuda.get_device_name(gpu_index)))
         L = hipapi.load_library()
@@ -309,7 +317,10 @@ def main():
 
         def step():
             if strong:
-                pfdist.sharded_find(run, "b", xdev, shard_stats)
+                if args.shard_find:
+                    pfdist.sharded_find(run, "b", xdev, shard_stats)
+                else:
+                    run.find_superbubbles("b")   # on every rank; rank 0 writes b_super_bubble.txt
                 totals_, counters_ = pfdist.sharded_ploidy(run, "b", LOWER, UPPER, xdev, shard_stats)
                 shard_stats["counters"] = [int(x) for x in counters_]
                 shard_stats["output_bytes"] = int(totals_.sum())
@@ -460,7 +471,12 @@ def main():
                            "partitioning": ("one graph replicated on every rank, cut by entrance vertex: K-BFS records all-gathered over RCCL "
                                             "(%d bytes per pass) and replayed on every rank; bubble list in contiguous slices, two small "
                                             "all-gathers (bubbles called; slab sizes + allele histograms), every rank writes its slabs into "
-                                            "the shared files" % shard_stats.get("find_gathered_bytes", 0) if strong else
+                                            "the shared files" % shard_stats.get("find_gathered_bytes", 0) if strong and args.shard_find else
+                                            "one graph replicated on every rank; findSuperBubble run by every rank (its device part is "
+                                            "1.6 ms; --shard-find cuts it by entrance vertex with an all-gather of the records), "
+                                            "PloidyEstimation cut into contiguous slices of the bubble list: two small all-gathers "
+                                            "(bubbles called; slab sizes + allele histograms), every rank writes its slabs into the "
+                                            "shared files" if strong else
                                             "one rank, whole graph" if world == 1 else
                                             "one independent graph per rank (weak scaling), no data-path collective; "
                                             "per-pass all-gather of the site counters only (%d bytes)" % gathered_bytes[0])},

@@ -421,6 +421,8 @@ int pf_gmm_fit(pf_ctx *, uint32_t gauss, double m_thre, double n_thre, int32_t m
 
 /* ---- pinned host memory for the exchange buffers (optional: pageable memory works, slower) ---- */
 int pf_host_alloc(pf_ctx *, size_t bytes, void **out);
+/* bytes from device memory to (pinned) host memory, synchronous: for callers that hold device pointers but no HIP runtime */
+int pf_fetch(pf_ctx *, void *dst_host, const void *src_dev, uint64_t bytes);
 void pf_host_free(pf_ctx *, void *p);
 
 /* ---- introspection ---------------------------------------------------------------------- */

@@ -162,6 +162,9 @@ int pfh_find_replay(pfh_run *, const char *outpre, uint32_t n_shards, const pf_b
 /* host threads of the commit replay in findSuperBubble / pfh_find_replay: 0 = the sequential loop, -1 = default (min(threads, 32),
  * single-sample path only) */
 void pfh_set_replay_threads(pfh_run *, int threads);
+/* several ranks running findSuperBubble on the same graph into one output directory: 0 on all but the rank that writes
+ * <outpre>_super_bubble.txt (the rows are computed everywhere; PloidyEstimation does not need the file) */
+void pfh_set_write_super_bubble(pfh_run *, int on);
 int pfh_ploidy_select(pfh_run *, int lower, int upper, uint64_t *n_bubbles);
 int pfh_ploidy_align(pfh_run *, uint64_t t0, uint64_t t1, uint64_t *n_called);
 int pfh_ploidy_text(pfh_run *, uint64_t var_count_base, uint64_t sizes[10], uint64_t counters[8]);

@@ -136,6 +136,8 @@ public:
                     const pf_bfs_record *const *dev_records = nullptr, const uint32_t *const *dev_pools = nullptr);
     // the commit replay on host threads (pf_replay_par.hpp): 0 = sequential; default min(threads, 32) for the single-sample path
     void set_replay_threads(int t) { replay_threads_ = t; }
+    // one graph on several ranks with findSuperBubble run by each of them: only one rank writes <outpre>_super_bubble.txt
+    void set_write_super_bubble(bool on) { write_sb_ = on; }
     int ploidy_select(int lower, int upper, uint64_t &n_bubbles);
     int ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called);
     int ploidy_text(uint64_t var_count_base, uint64_t sizes[PF_CALL_STREAMS], uint64_t counters[8]);
@@ -208,6 +210,7 @@ protected:
     bool both_strands_ = true;
     unsigned threads_ = 0;
     int replay_threads_ = -1;   // -1: default
+    bool write_sb_ = true;
     ParallelReplay par_;
     unsigned replay_threads(size_t thr) const;
     // third K-BFS tier (traversals beyond 4096 vertices) on host cores, pf_bfs_host.hpp; false = the device's k_bfs_huge

@@ -305,7 +305,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
         printf(mt_format_ ? "%s::findSuperBubble(): Finding superbubbles Real time : %gs\n" : "%s::findSuperBubble():  Real time : %gs\n", tag_,
                since(t_all));
     }
-    return finish_find(outpre, thr, t_all, true);
+    return finish_find(outpre, thr, t_all, write_sb_);
 }
 
 // second half of findSuperBubble (reference src/CDBG.cpp:222-252): the rows of <outpre>_super_bubble.txt from the final state
@@ -434,9 +434,40 @@ int CDBG::find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs
     if (rt) par_.begin(g_.n(), plus_.data(), minus_.data(), complex_size_, rt);
     std::vector<uint32_t> order;
     bool seen_any = false;
+    // shards given as device memory only (the all-gather's output): their host copies come down into the pinned exchange buffers
+    std::vector<const pf_bfs_record *> h_rec(n_shards);
+    std::vector<const uint32_t *> h_pool(n_shards);
+    {
+        uint64_t need_rec = 0, need_pool = 0;
+        for (uint32_t sh = 0; sh < n_shards; ++sh) {
+            h_rec[sh] = records ? records[sh] : nullptr;
+            h_pool[sh] = pools ? pools[sh] : nullptr;
+            if (!h_rec[sh] || !h_pool[sh]) {
+                if (!pool_lens || !dev_records || !dev_pools || !dev_records[sh] || !dev_pools[sh])
+                    return fail(PF_ERR_ARG, "CDBG::find_replay(): a shard has neither host nor device arrays");
+                need_rec += n_records[sh];
+                need_pool += pool_lens[sh];
+            }
+        }
+        if (need_rec) {
+            bx_.bfs_rec.ensure(ctx_, need_rec + 1);
+            bx_.bfs_pool.ensure(ctx_, need_pool + 1);
+            uint64_t ar = 0, ap = 0;
+            for (uint32_t sh = 0; sh < n_shards; ++sh) {
+                if (h_rec[sh] && h_pool[sh]) continue;
+                int st = pf_fetch(ctx_, bx_.bfs_rec.p + ar, dev_records[sh], n_records[sh] * sizeof(pf_bfs_record));
+                if (st == PF_OK) st = pf_fetch(ctx_, bx_.bfs_pool.p + ap, dev_pools[sh], pool_lens[sh] * 4);
+                if (st != PF_OK) return fail(st, std::string("CDBG::find_replay(): ") + pf_last_error(ctx_));
+                h_rec[sh] = bx_.bfs_rec.p + ar;
+                h_pool[sh] = bx_.bfs_pool.p + ap;
+                ar += n_records[sh];
+                ap += pool_lens[sh];
+            }
+        }
+    }
     for (uint32_t sh = 0; sh < n_shards; ++sh) {
-        const pf_bfs_record *rec = records[sh];
-        const uint32_t *pool = pools[sh];
+        const pf_bfs_record *rec = h_rec[sh];
+        const uint32_t *pool = h_pool[sh];
         const uint64_t n = n_records[sh];
         total += n;
         if (rt) {

@@ -164,6 +164,7 @@ int pfh_find_replay(pfh_run *r, const char *outpre, uint32_t n_shards, const pf_
     return guarded(r, [&] { return r->cdbg->find_replay(outpre, n_shards, records, n_records, pools, write_file != 0, pool_lens, dev_records, dev_pools); });
 }
 void pfh_set_replay_threads(pfh_run *r, int threads) { r->cdbg->set_replay_threads(threads); }
+void pfh_set_write_super_bubble(pfh_run *r, int on) { r->cdbg->set_write_super_bubble(on != 0); }
 int pfh_ploidy_select(pfh_run *r, int lower, int upper, uint64_t *n_bubbles) {
     return guarded(r, [&] { uint64_t n = 0; const int rc = r->cdbg->ploidy_select(lower, upper, n); if (n_bubbles) *n_bubbles = n; return rc; });
 }

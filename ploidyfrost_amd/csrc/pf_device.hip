@@ -862,6 +862,13 @@ int pf_host_alloc(pf_ctx *ctx, size_t bytes, void **out) {
     return PF_OK;
 }
 
+int pf_fetch(pf_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes) {
+    if (!ctx || (bytes && (!dst_host || !src_dev))) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (bytes) PF_HIP(hipMemcpy(dst_host, src_dev, bytes, hipMemcpyDeviceToHost));
+    return PF_OK;
+}
+
 void pf_host_free(pf_ctx *ctx, void *p) {
     (void)ctx;
     if (p) hipHostFree(p);

@@ -82,6 +82,8 @@ def all_gather_slabs(slab: np.ndarray, device: torch.device, keep_device: bool =
         buf[: slab.size] = torch.from_numpy(slab).to(device)
     out = [torch.zeros_like(buf) for _ in range(world)]
     dist.all_gather(out, buf)
+    if keep_device == "only":   # the consumer reads the slabs where they are: (byte sizes, padded device tensors)
+        return [int(n) for n in sizes], out
     if keep_device:
         return [o[: int(n)].cpu().numpy() for o, n in zip(out, sizes)], out
     return [o[: int(n)].cpu().numpy() for o, n in zip(out, sizes)]
@@ -103,12 +105,23 @@ def sharded_find(run, outpre: str, device: torch.device, stats: dict | None = No
     u0, u1 = shard_range(n, rank, world)
     rec, pool = run.find_shard(u0, u1)
     on_gpu = device.type == "cuda"
+    from . import hipapi
+    if on_gpu and world > 1:
+        # the gathered shards stay in device memory: K-CC reads them there, and the host layer brings its copy down into pinned
+        # memory itself (57 GB/s) instead of through a pageable numpy array
+        rs, d_recs = all_gather_slabs(rec.view(np.uint8).reshape(-1), device, keep_device="only")
+        ps, d_pools = all_gather_slabs(pool.view(np.uint8).reshape(-1), device, keep_device="only")
+        if stats is not None:
+            stats["find_gathered_bytes"] = int(sum(rs) + sum(ps))
+            stats["shard_unitigs"] = (u0, u1)
+        run.find_replay(outpre, None, [(a // hipapi.BFS_RECORD.itemsize, b // 4) for a, b in zip(rs, ps)], write_file=rank == 0,
+                        dev_records=[t.data_ptr() for t in d_recs], dev_pools=[t.data_ptr() for t in d_pools])
+        return
     recs, d_recs = all_gather_slabs(rec.view(np.uint8).reshape(-1), device, keep_device=True)
     pools, d_pools = all_gather_slabs(pool.view(np.uint8).reshape(-1), device, keep_device=True)
     if stats is not None:
         stats["find_gathered_bytes"] = int(sum(x.size for x in recs) + sum(x.size for x in pools))
         stats["shard_unitigs"] = (u0, u1)
-    from . import hipapi
     # the gathered shards still lie in device memory: the components of the parallel replay are found there
     run.find_replay(outpre, [np.ascontiguousarray(r).view(hipapi.BFS_RECORD) for r in recs],
                     [np.ascontiguousarray(p).view(np.uint32) for p in pools], write_file=rank == 0,

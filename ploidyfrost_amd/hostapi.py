@@ -29,7 +29,7 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
                     "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints",
-                    "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_set_replay_threads", "pfh_ploidy_select", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
+                    "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_set_replay_threads", "pfh_set_write_super_bubble", "pfh_ploidy_select", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
                     "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
                     "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
 
@@ -98,6 +98,8 @@ def load_library() -> C.CDLL:
     L.pfh_find_replay.argtypes = [vp, C.c_char_p, u32, vp, vp, vp, C.c_int, vp, vp, vp]
     L.pfh_set_replay_threads.argtypes = [vp, C.c_int]
     L.pfh_set_replay_threads.restype = None
+    L.pfh_set_write_super_bubble.argtypes = [vp, C.c_int]
+    L.pfh_set_write_super_bubble.restype = None
     L.pfh_ploidy_select.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u64)]
     L.pfh_ploidy_align.argtypes = [vp, u64, u64, C.POINTER(u64)]
     L.pfh_ploidy_text.argtypes = [vp, u64, vp, vp]
@@ -318,16 +320,26 @@ class Run:
     def find_replay(self, outpre: str, records: list, pools: list, write_file: bool = True, dev_records: list | None = None,
                     dev_pools: list | None = None):
         """dev_records / dev_pools: device addresses (ints) of the same shards where they already lie in device memory"""
-        recs = [np.ascontiguousarray(r) for r in records]
-        pls = [np.ascontiguousarray(p, dtype=np.uint32) if len(p) else np.zeros(1, dtype=np.uint32) for p in pools]
-        n = len(recs)
-        rp = (C.c_void_p * n)(*[r.ctypes.data if len(r) else None for r in recs])
-        pp = (C.c_void_p * n)(*[p.ctypes.data for p in pls])
-        nr = (C.c_uint64 * n)(*[len(r) for r in recs])
-        pl = (C.c_uint64 * n)(*[len(p) for p in pools])
+        if records is None:   # device arrays only: (n_records, pool_len) per shard in `pools`
+            n = len(pools)
+            rp = pp = None
+            nr = (C.c_uint64 * n)(*[int(a) for a, _ in pools])
+            pl = (C.c_uint64 * n)(*[int(b) for _, b in pools])
+        else:
+            recs = [np.ascontiguousarray(r) for r in records]
+            pls = [np.ascontiguousarray(p, dtype=np.uint32) if len(p) else np.zeros(1, dtype=np.uint32) for p in pools]
+            n = len(recs)
+            rp = (C.c_void_p * n)(*[r.ctypes.data if len(r) else None for r in recs])
+            pp = (C.c_void_p * n)(*[p.ctypes.data for p in pls])
+            nr = (C.c_uint64 * n)(*[len(r) for r in recs])
+            pl = (C.c_uint64 * n)(*[len(p) for p in pools])
         dr = (C.c_void_p * n)(*[int(a) if a else None for a in dev_records]) if dev_records else None
         dp = (C.c_void_p * n)(*[int(a) if a else None for a in dev_pools]) if dev_pools else None
         self._check(self.L.pfh_find_replay(self.h, outpre.encode(), n, rp, nr, pp, int(write_file), pl, dr, dp))
+
+    def set_write_super_bubble(self, on: bool):
+        """several ranks running findSuperBubble on one graph into one directory: off on all but the rank that writes the file"""
+        self.L.pfh_set_write_super_bubble(self.h, int(on))
 
     def set_replay_threads(self, threads: int):
         """host threads of the commit replay: 0 = sequential, -1 = default"""
