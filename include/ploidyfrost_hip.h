@@ -380,6 +380,23 @@ int pf_side_components(pf_ctx *, int reset, const pf_bfs_record *records, uint64
                        const pf_bfs_record *extra, uint64_t n_extra, const uint32_t *extra_pool, uint64_t extra_pool_len);
 int pf_replay_order(pf_ctx *, uint32_t n_classes, uint32_t *order, uint32_t *class_off, uint32_t *labels);
 
+/* The commits on the device.  After pf_side_components over ALL records of a pass (one call with reset != 0, records == NULL:
+ * the records pf_bfs_candidates_resident left on the device; `extra` = the traversals the caller walked itself), every component
+ * of at most small_limit list entries is committed by one device thread, in record order, into the context's T1 state
+ * (MyUnitig bits and partner slots: what pf_call_set_state uploads).  Components above the limit and components holding an
+ * `extra` record are left to the caller: pf_replay_device returns how many device-resident records they have (and their list
+ * entries), pf_replay_big_fetch hands them over (index[] = their positions among the records, ascending; records with list_off
+ * into pool), the caller commits them together with its own records on a zeroed state of its own and passes what it changed to
+ * pf_replay_finish: sides[] (2u = plus side of unitig u, 2u + 1 = minus side), the partner slot of each and its per-side flag
+ * byte (csrc/host/pf_state_ops.hpp: S_LINK, S_STRICT, S_COMPLEX, S_NON_SUPER).  pf_replay_finish merges the per-side bytes into
+ * MyUnitig's and leaves the state resident for pf_superbubble_rows / pf_call_scan; pf_call_get_state copies it to the host. */
+int pf_bfs_candidates_resident(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred,
+                               uint32_t *deferred_entrance, uint64_t deferred_cap, uint64_t *n_deferred);
+int pf_replay_device(pf_ctx *, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries);
+int pf_replay_big_fetch(pf_ctx *, uint32_t *index, pf_bfs_record *records, uint32_t *pool);
+int pf_replay_finish(pf_ctx *, const uint32_t *sides, const uint32_t *links, const uint8_t *side_flags, uint64_t n_patch);
+int pf_call_get_state(pf_ctx *, uint8_t *flags, uint32_t *plus, uint32_t *minus);
+
 /* ---- colored (multi-sample) coverage: reference src/CCDBG.cpp ------------------------------------- */
 /* CCDBG::CCDBG (src/CCDBG.cpp:13-43) opens one KMC database per colour.  Here the records of all colours
  * are joined into one HBM table keyed by the stored k-mer with one count per colour, so a k-mer costs one

@@ -148,9 +148,11 @@ public:
     uint64_t core_cov() const { return core_cov_; }
     uint64_t core_num() const { return core_num_; }
     uint64_t n_superbubbles() const { return n_super_bubble_; }
-    const std::vector<uint8_t> &state_flags() const { return flags_; }
-    const std::vector<uint32_t> &state_plus() const { return plus_; }
-    const std::vector<uint32_t> &state_minus() const { return minus_; }
+    // (after commits on the device the host copy is fetched when somebody asks)
+    const std::vector<uint8_t> &state_flags() { sync_state_to_host(); return flags_; }
+    const std::vector<uint32_t> &state_plus() { sync_state_to_host(); return plus_; }
+    const std::vector<uint32_t> &state_minus() { sync_state_to_host(); return minus_; }
+    int sync_state_to_host();
     uint64_t output_bytes() const { return out_bytes_; }
     // text of <outpre>_allele_frequency.txt of the last run (the record slab a multi-GPU job gathers)
     const std::string &last_allele_frequency() const { return last_allfre_; }
@@ -211,6 +213,12 @@ protected:
     unsigned threads_ = 0;
     int replay_threads_ = -1;   // -1: default
     bool write_sb_ = true;
+    // commits on the device (pf_replay_device): the host arrays are stale until sync_state_to_host; big_f2_ = the per-side flag
+    // bytes of the few components committed on the host (kept all-zero between passes)
+    bool state_host_stale_ = false;
+    std::vector<uint8_t> big_f2_;
+    bool commits_on_device(size_t thr) const;
+    int find_superbubbles_device(const std::string &outpre, const size_t &thr);
     ParallelReplay par_;
     unsigned replay_threads(size_t thr) const;
     // third K-BFS tier (traversals beyond 4096 vertices) on host cores, pf_bfs_host.hpp; false = the device's k_bfs_huge

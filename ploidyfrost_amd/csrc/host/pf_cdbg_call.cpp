@@ -38,7 +38,10 @@ int CDBG::call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &
     if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + cov_err_);
     times_.cov_device_s = since(t0);
     t0 = clk::now();
-    if (!state_on_device_) st = pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    if (!state_on_device_) {
+        if (sync_state_to_host()) return status_;   // (committed on the device and already consumed once: back through the host copy)
+        st = pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    }
     state_on_device_ = false;   // (one PloidyEstimation per findSuperBubble, as in the reference's main(); a second one uploads again)
     uint64_t n_sides = 0;
     if (st == PF_OK) st = pf_call_scan(ctx_, low, up, &n_sides);
@@ -63,6 +66,7 @@ int CDBG::call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &
     const auto t_serial = clk::now();
     const pf_call_side *sides = cx_.sides.p;
     uint32_t *kept = cx_.kept.p;
+    if (sync_state_to_host()) return status_;
     std::vector<uint8_t> fl(flags_);
     for (uint64_t ri = 0; ri < n_sides; ++ri) {
         const pf_call_side &r = sides[ri];

@@ -32,6 +32,164 @@ unsigned CDBG::replay_threads(size_t thr) const {
     return t >= 2 ? (unsigned)t : 0;
 }
 
+// PF_REPLAY=device (single-sample path): the commits run on the device, one thread per component (pf_cc.hip)
+bool CDBG::commits_on_device(size_t thr) const {
+    (void)thr;
+    if (col_ != nullptr || !third_tier_on_host_) return false;
+    static const bool on = [] { const char *e = getenv("PF_REPLAY"); return e && !strcmp(e, "device"); }();
+    return on;
+}
+
+int CDBG::sync_state_to_host() {
+    if (!state_host_stale_) return 0;
+    const int st = pf_call_get_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::findSuperBubble(): " + pf_last_error(ctx_));
+    state_host_stale_ = false;
+    return 0;
+}
+
+// findSuperBubble with nothing but the long traversals on the host: K-BFS leaves its records in HBM, K-CC finds the components,
+// pf_replay_device commits every small component with one thread; the few large ones (and those of the traversals walked here)
+// are committed on this side and their sides patched into the device state.
+int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr) {
+    const auto t_all = clk::now();
+    clock_t c0 = clock();
+    const uint32_t N = g_.n();
+    const bool trace_find = getenv("PF_TRACE_FIND") != nullptr;
+    auto tf = [&](const char *what) { if (trace_find) fprintf(stderr, "[find] %-28s %.2f ms\n", what, since(t_all) * 1e3); };
+    out_bytes_ = 0;
+    state_on_device_ = false;
+    cov_ready_ = false;
+    for (auto &hl : huge_lists_) hl.clear();
+    std::vector<uint32_t> &deferred = deferred_;
+    std::vector<uint32_t> &deferred_ent = deferred_ent_;
+    if (deferred.size() < 4096) deferred.resize(4096);
+    if (deferred_ent.size() < deferred.size()) deferred_ent.resize(deferred.size());
+    uint64_t n_rec = 0, pool_used = 0, n_deferred = 0;
+    int st;
+    for (;;) {
+        st = pf_bfs_candidates_resident(ctx_, 0, N, &n_rec, &pool_used, deferred.data(), deferred_ent.data(), deferred.size(), &n_deferred);
+        if (st == PF_ERR_OVERFLOW && n_deferred > deferred.size()) {
+            deferred.resize(n_deferred + n_deferred / 4);
+            deferred_ent.resize(deferred.size());
+            continue;
+        }
+        break;
+    }
+    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    tf("traversed on the device");
+    // the long traversals on host cores, side by side
+    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
+    std::vector<pf_bfs_record> walked((size_t)n_deferred);
+    std::vector<std::vector<uint32_t>> lists((size_t)n_deferred);
+    parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
+        std::unique_ptr<HugeWalker> w;
+        {
+            std::lock_guard<std::mutex> lk(walkers_mu_);
+            if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
+        }
+        if (!w) w = std::make_unique<HugeWalker>();
+        pf_bfs_record &r = walked[d];
+        memset(&r, 0, sizeof r);
+        r.entrance = deferred_ent[d];
+        r.exit = 0xFFFFFFFFu;
+        const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, r.entrance, r);
+        lists[d].assign(list.begin(), list.begin() + r.n_list);
+        std::lock_guard<std::mutex> lk(walkers_mu_);
+        walkers_.push_back(std::move(w));
+    });
+    tf("long traversals walked");
+    // in candidate order (the device hands the deferred candidates over in the order their wavefronts gave up)
+    std::vector<uint32_t> xpool;
+    {
+        std::vector<size_t> by_index((size_t)n_deferred);
+        for (size_t d = 0; d < by_index.size(); ++d) by_index[d] = d;
+        std::sort(by_index.begin(), by_index.end(), [&](size_t a, size_t b) { return deferred[a] < deferred[b]; });
+        std::vector<pf_bfs_record> w2((size_t)n_deferred);
+        std::vector<uint32_t> d2((size_t)n_deferred);
+        for (size_t i = 0; i < by_index.size(); ++i) {
+            const size_t d = by_index[i];
+            w2[i] = walked[d];
+            w2[i].list_off = xpool.size();
+            w2[i].pad_ = 0;
+            xpool.insert(xpool.end(), lists[d].begin(), lists[d].end());
+            d2[i] = deferred[d];
+        }
+        walked.swap(w2);
+        std::copy(d2.begin(), d2.end(), deferred.begin());
+    }
+    st = pf_side_components(ctx_, 1, nullptr, n_rec, nullptr, 0, walked.data(), walked.size(), xpool.data(), xpool.size());
+    uint64_t n_big = 0, big_entries = 0;
+    if (st == PF_OK) st = pf_replay_device(ctx_, (uint32_t)std::min<size_t>(complex_size_, 0xFFFFFFFFu), 256, &n_big, &big_entries);
+    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    tf("components + commits on the device");
+    // what is left for this side: the records of the large components and of the components of the walked traversals, merged
+    // in record order
+    std::vector<uint32_t> big_idx((size_t)n_big);
+    std::vector<pf_bfs_record> big_rec((size_t)n_big);
+    std::vector<uint32_t> big_pool((size_t)big_entries + 1);
+    st = pf_replay_big_fetch(ctx_, big_idx.data(), big_rec.data(), big_pool.data());
+    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    if (big_f2_.size() != 2 * (size_t)N) big_f2_.assign(2 * (size_t)N, 0);
+    // (plus_ / minus_ / big_f2_ are all-zero here: every pass undoes what it touched, see below; a stale host copy is re-zeroed)
+    if (!state_host_stale_) {
+        const unsigned zt = (unsigned)std::min<size_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), 8);
+        parallel_chunks(N, 1u << 19, zt, [&](size_t, size_t b, size_t e) {
+            memset(plus_.data() + b, 0, (e - b) * 4);
+            memset(minus_.data() + b, 0, (e - b) * 4);
+        });
+    }
+    times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = times_.bfs_large_used = times_.bfs_large_used_max = 0;
+    std::vector<uint32_t> p_sides, p_links;
+    std::vector<uint8_t> p_bytes;
+    {
+        // (every side written is noted: exactly those go to the device afterwards)
+        Commits<FlagsPerSideLogged> cm{FlagsPerSideLogged{FlagsPerSide{big_f2_.data(), plus_.data(), minus_.data()}, &p_sides}, complex_size_, NoColours{}};
+        size_t a = 0, b = 0;   // a over big_idx, b over the walked records (ascending candidate index both)
+        auto commit = [&](const pf_bfs_record &r, const uint32_t *list) {
+            if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
+            if (r.n_seen > times_.bfs_max_seen) times_.bfs_max_seen = r.n_seen;
+            if (!record_effective(r)) return;
+            if (!cm.gate_open(r.entrance)) return;
+            if (r.n_seen > 4096) { times_.bfs_large_used++; times_.bfs_large_used_max = std::max<uint64_t>(times_.bfs_large_used_max, r.n_seen); }
+            cm.replay(r, list);
+        };
+        while (a < (size_t)n_big || b < (size_t)n_deferred) {
+            const bool take_walked = a >= (size_t)n_big || (b < (size_t)n_deferred && deferred[b] < big_idx[a]);
+            if (take_walked) { commit(walked[b], xpool.data() + walked[b].list_off); ++b; }
+            else { commit(big_rec[a], big_pool.data() + big_rec[a].list_off); ++a; }
+        }
+    }
+    p_links.resize(p_sides.size());
+    p_bytes.resize(p_sides.size());
+    for (size_t i = 0; i < p_sides.size(); ++i) {
+        const uint32_t s = p_sides[i];
+        p_links[i] = (s & 1) ? minus_[s >> 1] : plus_[s >> 1];
+        p_bytes[i] = big_f2_[s];
+    }
+    st = pf_replay_finish(ctx_, p_sides.data(), p_links.data(), p_bytes.data(), p_sides.size());
+    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    for (uint32_t s : p_sides) {   // back to all-zero for the next pass
+        ((s & 1) ? minus_ : plus_)[s >> 1] = 0;
+        big_f2_[s] = 0;
+    }
+    state_host_stale_ = true;
+    state_on_device_ = true;
+    tf("large components committed here");
+    times_.bfs_device_s = since(t_all);
+    times_.candidates = n_rec;
+    times_.bfs_deferred = n_deferred;
+    times_.replay_s = 0;
+    if (overlap_output_) cov_ready_ = launch_coverage() == PF_OK;
+    if (!quiet_) {
+        printf(mt_format_ ? "%s::findSuperBubble(): Finding superbubbles Cpu time : %gs\n" : "%s::findSuperBubble():  Cpu time : %gs\n", tag_,
+               (double)(clock() - c0) / CLOCKS_PER_SEC);
+        printf(mt_format_ ? "%s::findSuperBubble(): Finding superbubbles Real time : %gs\n" : "%s::findSuperBubble():  Real time : %gs\n", tag_,
+               since(t_all));
+    }
+    return finish_find(outpre, thr, t_all, write_sb_);
+}
+
 // ---- findSuperBubble (reference src/CDBG.cpp:178-252) -------------------------------------
 int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_t &thr) {
     if (status_) return status_;
@@ -39,6 +197,11 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     if (join_pending_write()) return status_;
     if (!quiet_) printf("%s::findSuperBubble(): Finding superbubbles\n", tag_);
     if (write_files_ && ensure_dir()) return status_;
+    if (commits_on_device(thr)) {
+        if (!quiet_) printf("%s::findSuperBubble(): There are %u unitigs \n", tag_, g_.n());
+        return find_superbubbles_device(outpre, thr);
+    }
+    state_host_stale_ = false;
     const auto t_all = clk::now();
     clock_t c0 = clock();
     const uint32_t N = g_.n();
@@ -317,7 +480,7 @@ int CDBG::finish_find(const std::string &outpre, const size_t &thr, clk_time t_a
     // The state goes to the device once -- PloidyEstimation's scan reads it there as well -- and the rows of super_bubble.txt
     // (one per open endpoint side in unitig order, numbered by a prefix count) are formatted there; the text comes back and is
     // written by a helper thread, behind the caller's back when overlap_output is on.
-    int st = pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
+    int st = state_on_device_ ? PF_OK : pf_call_set_state(ctx_, flags_.data(), plus_.data(), minus_.data());
     uint64_t nb = 0, len = 0;
     if (st == PF_OK) st = pf_superbubble_rows(ctx_, col_ != nullptr ? 1 : 0, &nb, &len);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::findSuperBubble(): " + pf_last_error(ctx_));
@@ -421,6 +584,7 @@ int CDBG::find_replay(const std::string &outpre, uint32_t n_shards, const pf_bfs
     const auto t_all = clk::now();
     out_bytes_ = 0;
     state_on_device_ = false;
+    state_host_stale_ = false;
     std::fill(flags_.begin(), flags_.end(), 0);
     std::fill(plus_.begin(), plus_.end(), 0);
     std::fill(minus_.begin(), minus_.end(), 0);

@@ -15,8 +15,16 @@
 //     joins both of its sides to that record's component.
 #pragma once
 #include <cstdint>
+#include <vector>
 
 #include "ploidyfrost_hip.h"
+
+// the commits compile for the host (g++) and, inside pf_replay.hip, for the device
+#if defined(__HIPCC__)
+#define PF_HD __host__ __device__
+#else
+#define PF_HD
+#endif
 
 namespace pfh {
 
@@ -27,7 +35,7 @@ constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_NON_SUPER = 0x04, B_STRICT_M 
 constexpr uint8_t S_LINK = 0x01, S_STRICT = 0x02, S_COMPLEX = 0x04, S_NON_SUPER = 0x08;
 }  // namespace state_bits
 
-inline bool plus_side_of(uint32_t ov) { return (ov & 1) == 0; }
+PF_HD inline bool plus_side_of(uint32_t ov) { return (ov & 1) == 0; }
 
 // one flag byte per unitig, plain accesses: the sequential replay
 struct FlagsPerUnitig {
@@ -67,7 +75,7 @@ struct FlagsPerSide {
         f2[2 * (size_t)u + 1] |= state_bits::S_NON_SUPER;
     }
     void begin_record(const pf_bfs_record &) {}
-    static uint8_t merged(uint8_t p, uint8_t m) {
+    PF_HD static uint8_t merged(uint8_t p, uint8_t m) {
         using namespace state_bits;
         return (uint8_t)(((p & S_LINK) ? B_PLUS : 0) | ((m & S_LINK) ? B_MINUS : 0) | (((p | m) & S_NON_SUPER) ? B_NON_SUPER : 0) |
                          ((p & S_STRICT) ? B_STRICT_P : 0) | ((m & S_STRICT) ? B_STRICT_M : 0) | ((p & S_COMPLEX) ? B_COMPLEX_P : 0) |
@@ -75,10 +83,24 @@ struct FlagsPerSide {
     }
 };
 
+// the same with every side written noted down: the caller ships exactly those sides somewhere else (pf_replay_finish)
+struct FlagsPerSideLogged {
+    FlagsPerSide base;
+    std::vector<uint32_t> *written;
+    uint32_t link(uint32_t u, bool ps) const { return base.link(u, ps); }
+    bool plus_points_to(uint32_t ex, uint32_t me) const { return base.plus_points_to(ex, me); }
+    void set_link(uint32_t u, bool ps, uint32_t v, bool real) { written->push_back(2 * u + (ps ? 0 : 1)); base.set_link(u, ps, v, real); }
+    void mark_strict(uint32_t u, bool ps) { written->push_back(2 * u + (ps ? 0 : 1)); base.mark_strict(u, ps); }
+    void mark_complex(uint32_t u, bool ps) { written->push_back(2 * u + (ps ? 0 : 1)); base.mark_complex(u, ps); }
+    bool non_super(uint32_t u, bool ps) const { return base.non_super(u, ps); }
+    void set_non_super(uint32_t u) { written->push_back(2 * u); written->push_back(2 * u + 1); base.set_non_super(u); }
+    void begin_record(const pf_bfs_record &) {}
+};
+
 // Hooks of the colored path (src/CCDBG.cpp:2351-2384, 2530-2621); the single-sample replay passes NoColours.
 struct NoColours {
     static constexpr bool colored = false;
-    template <class A> bool allow(A &, const pf_bfs_record &, const uint32_t *) const { return true; }
+    template <class A> PF_HD bool allow(A &, const pf_bfs_record &, const uint32_t *) const { return true; }
 };
 
 template <class Acc, class Col = NoColours>
@@ -87,11 +109,11 @@ struct Commits {
     size_t complex_size;
     Col col;
 
-    void side_self(uint32_t u, bool ps) { a.set_link(u, ps, u + 1, false); }
+    PF_HD void side_self(uint32_t u, bool ps) { a.set_link(u, ps, u + 1, false); }
     // "if (ex->get_plus() == me) ex->set_plus_self(); else ex->set_minus_self();"
-    void release(uint32_t ex, uint32_t me) { side_self(ex, a.plus_points_to(ex, me)); }
+    PF_HD void release(uint32_t ex, uint32_t me) { side_self(ex, a.plus_points_to(ex, me)); }
     // interior vertex of any committed traversal (e.g. src/CDBG.cpp:800-826)
-    void poison(uint32_t u) {
+    PF_HD void poison(uint32_t u) {
         uint32_t p = a.link(u, true);
         if (p != 0 && p != u + 1) release(p - 1, u);
         side_self(u, true);
@@ -100,11 +122,11 @@ struct Commits {
         side_self(u, false);
         a.set_non_super(u);
     }
-    bool gate_open(uint32_t entrance_ov) const { return a.link(entrance_ov >> 1, plus_side_of(entrance_ov)) == 0; }
+    PF_HD bool gate_open(uint32_t entrance_ov) const { return a.link(entrance_ov >> 1, plus_side_of(entrance_ov)) == 0; }
 
     // Order-dependent part of extractSuperBubble_ptr: the three setNoBubble commits (src/CDBG.cpp:552-846) and the no-exit
     // tail (:373-413), applied to one traversal record; the caller has applied the `partner == NULL` gate (:206, 211).
-    void replay(const pf_bfs_record &r, const uint32_t *list) {
+    PF_HD void replay(const pf_bfs_record &r, const uint32_t *list) {
         a.begin_record(r);
         const uint32_t s = r.entrance, su = s >> 1;
         if (r.outcome == PF_BFS_NONE) {
@@ -175,11 +197,11 @@ struct Commits {
 
 // sides: 2u = plus side of unitig u, 2u + 1 = its minus side.  A traversal leaves its entrance s = 2u + strand through side s
 // and enters its exit t through side t ^ 1.
-inline uint32_t entrance_side(uint32_t s) { return s; }
-inline uint32_t exit_side(uint32_t t) { return t ^ 1u; }
+PF_HD inline uint32_t entrance_side(uint32_t s) { return s; }
+PF_HD inline uint32_t exit_side(uint32_t t) { return t ^ 1u; }
 
 // true when a record can change state at all (whatever the gate says): what the component model has to look at
-inline bool record_effective(const pf_bfs_record &r) {
+PF_HD inline bool record_effective(const pf_bfs_record &r) {
     if (r.outcome == PF_BFS_NONE) return r.flag_cycle != 0;
     if (r.outcome == PF_BFS_ACCEPT) return r.n_seen >= 4;
     return true;

@@ -1526,6 +1526,26 @@ __global__ void k_format_doubles(const double *__restrict__ x, uint64_t n, char 
 }  // namespace
 
 // =====================================================================================================================
+// T1 state written on the device (pf_replay_device, pf_cc.hip): the arrays pf_call_set_state would fill, for their writer
+namespace pf {
+int call_state_arrays(pf_ctx *ctx, uint8_t **flags, uint32_t **plus, uint32_t **minus) {
+    if (!ctx->d_seq || !ctx->has_adj) { ctx->err = "T1 state: graph and adjacency first"; return PF_ERR_ARG; }
+    CallState *S = state_of(ctx);
+    const size_t N = ctx->N;
+    if (!S->flags.ensure(N + 1) || !S->plus.ensure(N * 4) || !S->minus.ensure(N * 4)) { ctx->err = "T1 state: out of device memory"; return PF_ERR_HIP; }
+    *flags = S->flags.as<uint8_t>();
+    *plus = S->plus.as<uint32_t>();
+    *minus = S->minus.as<uint32_t>();
+    S->have_state = false;
+    return PF_OK;
+}
+void call_state_resident(pf_ctx *ctx) {
+    CallState *S = state_of(ctx);
+    S->have_state = true;
+    S->n_sides = S->n_tasks = 0;
+}
+}  // namespace pf
+
 extern "C" {
 
 int pf_format_doubles(pf_ctx *ctx, const double *values, uint64_t n, char *text, uint8_t *len) {
@@ -1560,6 +1580,19 @@ int pf_call_set_state(pf_ctx *ctx, const uint8_t *flags, const uint32_t *plus, c
     PF_HIP(hipStreamSynchronize(ctx->stream));
     S->have_state = true;
     S->n_sides = S->n_tasks = 0;
+    return PF_OK;
+}
+
+int pf_call_get_state(pf_ctx *ctx, uint8_t *flags, uint32_t *plus, uint32_t *minus) {
+    if (!ctx || !ctx->call) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (!S->have_state) { ctx->err = "pf_call_get_state: no T1 state on the device"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    const size_t N = ctx->N;
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    if (flags) PF_HIP(hipMemcpy(flags, S->flags.p, N, hipMemcpyDeviceToHost));
+    if (plus) PF_HIP(hipMemcpy(plus, S->plus.p, N * 4, hipMemcpyDeviceToHost));
+    if (minus) PF_HIP(hipMemcpy(minus, S->minus.p, N * 4, hipMemcpyDeviceToHost));
     return PF_OK;
 }
 

@@ -18,8 +18,10 @@
 
 #include <algorithm>
 #include <cstring>
+#include <hipcub/hipcub.hpp>
 #include <rocprim/rocprim.hpp>
 
+#include "host/pf_state_ops.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
 #include "ploidyfrost_hip.h"
@@ -176,6 +178,104 @@ __global__ void k_cc_labels(const pf_bfs_record *__restrict__ rec, uint64_t n, u
         if (s_hist[c]) atomicAdd(hist + c, s_hist[c]);
 }
 
+// ---- the commits on the device ------------------------------------------------------------------------------------------
+// With the components known, a component is a unit of sequential work: one THREAD commits the records of one component in
+// record order (csrc/host/pf_state_ops.hpp: the same text of the commits as on the host), a million and a half components side
+// by side.  A component too large for one thread (the neighbourhood of a chromosome-long traversal: 130 000 list entries on
+// the 5 M-unitig graph) is left to the caller, and so is every component that holds a record the caller walked itself.
+struct FlagsDevice {
+    uint8_t *f2;   // [2u] plus side, [2u + 1] minus side
+    uint32_t *plus, *minus;
+    __device__ uint32_t link(uint32_t u, bool ps) const { return __hip_atomic_load(ps ? &plus[u] : &minus[u], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+    // (the plus slot of a unitig whose plus side may belong to another thread's component: cannot come out true then)
+    __device__ bool plus_points_to(uint32_t ex, uint32_t me) const { return __hip_atomic_load(&plus[ex], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == me + 1; }
+    __device__ void set_link(uint32_t u, bool ps, uint32_t v, bool real) {
+        __hip_atomic_store(ps ? &plus[u] : &minus[u], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint8_t *b = f2 + 2 * (size_t)u + (ps ? 0 : 1);
+        *b = real ? (uint8_t)(*b | pfh::state_bits::S_LINK) : (uint8_t)(*b & ~pfh::state_bits::S_LINK);
+    }
+    __device__ void mark_strict(uint32_t u, bool ps) { f2[2 * (size_t)u + (ps ? 0 : 1)] |= pfh::state_bits::S_STRICT; }
+    __device__ void mark_complex(uint32_t u, bool ps) { f2[2 * (size_t)u + (ps ? 0 : 1)] |= pfh::state_bits::S_COMPLEX; }
+    __device__ bool non_super(uint32_t u, bool ps) const { return (f2[2 * (size_t)u + (ps ? 0 : 1)] & pfh::state_bits::S_NON_SUPER) != 0; }
+    __device__ void set_non_super(uint32_t u) {
+        f2[2 * (size_t)u] |= pfh::state_bits::S_NON_SUPER;
+        f2[2 * (size_t)u + 1] |= pfh::state_bits::S_NON_SUPER;
+    }
+    __device__ void begin_record(const pf_bfs_record &) {}
+};
+
+__global__ void k_replay_label(const pf_bfs_record *__restrict__ rec, uint64_t n, uint32_t *parent, uint32_t n_sides, uint32_t *__restrict__ labels,
+                               uint32_t *__restrict__ idx, uint32_t *work) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const pf_bfs_record r = rec[i];
+    const uint32_t lab = r.entrance < n_sides ? cc_find(parent, r.entrance) : 0u;
+    labels[i] = lab;
+    idx[i] = (uint32_t)i;
+    if (cc_effective(r)) atomicAdd(work + lab, r.n_list + 1u);
+}
+
+__global__ void k_replay_force_big(const pf_bfs_record *__restrict__ xrec, uint64_t n, uint32_t *parent, uint32_t n_sides, uint8_t *big) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n && xrec[i].entrance < n_sides) big[cc_find(parent, xrec[i].entrance)] = 1;
+}
+
+// keys / vals: the records sorted by component label (stable: ascending record index inside a component)
+__global__ __launch_bounds__(256) void k_replay_small(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t n,
+                                                      const pf_bfs_record *__restrict__ rec, const uint32_t *__restrict__ pool, const uint8_t *__restrict__ big,
+                                                      const uint32_t *__restrict__ work, uint32_t limit, FlagsDevice acc, uint32_t complex_size) {
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const uint32_t key = keys[t];
+    if (t && keys[t - 1] == key) return;   // not the head of its component
+    if (big[key] || work[key] > limit) return;
+    pfh::Commits<FlagsDevice> cm{acc, complex_size, pfh::NoColours{}};
+    for (uint64_t j = t; j < n && keys[j] == key; ++j) {
+        const pf_bfs_record r = rec[vals[j]];
+        if (!cm.gate_open(r.entrance)) continue;
+        cm.replay(r, pool + r.list_off);
+    }
+}
+
+__global__ void k_replay_flag_big(const pf_bfs_record *__restrict__ rec, uint64_t n, const uint32_t *__restrict__ labels, const uint8_t *__restrict__ big,
+                                  const uint32_t *__restrict__ work, uint32_t limit, uint8_t *__restrict__ flag) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t lab = labels[i];
+    flag[i] = (cc_effective(rec[i]) && (big[lab] || work[lab] > limit)) ? 1 : 0;
+}
+
+__global__ void k_replay_big_sizes(const uint32_t *__restrict__ big_idx, uint64_t n_big, const pf_bfs_record *__restrict__ rec, uint64_t *__restrict__ sizes) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j <= n_big) sizes[j] = j < n_big ? (uint64_t)rec[big_idx[j]].n_list : 0;
+}
+
+__global__ void k_replay_big_gather(const uint32_t *__restrict__ big_idx, uint64_t n_big, const pf_bfs_record *__restrict__ rec, const uint32_t *__restrict__ pool,
+                                    const uint64_t *__restrict__ off, pf_bfs_record *__restrict__ out_rec, uint32_t *__restrict__ out_pool) {
+    const uint64_t j = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_big) return;
+    pf_bfs_record r = rec[big_idx[j]];
+    const uint32_t *l = pool + r.list_off;
+    r.list_off = off[j];
+    out_rec[j] = r;
+    for (uint32_t q = 0; q < r.n_list; ++q) out_pool[off[j] + q] = l[q];
+}
+
+__global__ void k_replay_patch(const uint32_t *__restrict__ sides, const uint32_t *__restrict__ links, const uint8_t *__restrict__ bytes, uint64_t n,
+                               uint32_t n_sides, uint32_t *plus, uint32_t *minus, uint8_t *f2) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t s = sides[i];
+    if (s >= n_sides) return;
+    ((s & 1) ? minus : plus)[s >> 1] = links[i];
+    f2[s] = bytes[i];
+}
+
+__global__ void k_replay_merge(const uint8_t *__restrict__ f2, uint32_t n_unitigs, uint8_t *__restrict__ flags) {
+    const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
+    if (u < n_unitigs) flags[u] = pfh::FlagsPerSide::merged(f2[2 * (size_t)u], f2[2 * (size_t)u + 1]);
+}
+
 struct CcState {
     uint32_t *parent = nullptr, *first = nullptr;
     uint8_t *multi = nullptr;
@@ -191,9 +291,24 @@ struct CcState {
     uint32_t *up_pool = nullptr;
     uint64_t up_pool_cap = 0;
     uint64_t n_last = 0;
+    // the commits on the device (pf_replay_device)
+    uint8_t *big = nullptr;        // [2N] by root: the component is left to the caller
+    uint32_t *work = nullptr;      // [2N] by root: list entries + records of the component
+    uint8_t *f2 = nullptr;         // [2N] per-side flag bytes during the commits
+    uint32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr;   // records sorted by component
+    uint64_t sort_cap = 0;
+    uint32_t *big_idx = nullptr;   // indices of the records of the components left to the caller, ascending
+    pf_bfs_record *big_rec = nullptr;
+    uint32_t *big_pool = nullptr;
+    uint64_t big_cap = 0, big_pool_cap = 0, n_big = 0, big_entries = 0;
+    pf_bfs_record *xrec = nullptr;   // (device copy of the last call's extra records, kept for pf_replay_device)
+    uint64_t n_xrec = 0;
     uint64_t added_call = 0;   // the K-BFS call whose device-resident records are already in the union-find
     bool labelled = false;
     void release() {
+        for (void *p : {(void *)big, (void *)work, (void *)f2, (void *)keys, (void *)keys2, (void *)vals, (void *)vals2, (void *)big_idx, (void *)big_rec,
+                        (void *)big_pool, (void *)xrec})
+            if (p) (void)hipFree(p);
         for (void *p : {(void *)parent, (void *)first, (void *)multi, (void *)bad, (void *)labels, (void *)cls, (void *)idx, (void *)cls2, (void *)idx2, (void *)hist,
                         sort_tmp, (void *)up_rec, (void *)up_pool})
             if (p) (void)hipFree(p);
@@ -252,7 +367,11 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
         S->n_unitigs = N;
         reset = 1;
     }
-    if (reset) k_cc_init<<<(n_sides + 255) / 256, 256, 0, st>>>(S->parent, S->first, S->multi, n_sides);
+    if (reset) {
+        k_cc_init<<<(n_sides + 255) / 256, 256, 0, st>>>(S->parent, S->first, S->multi, n_sides);
+        if (S->xrec) { (void)hipFree(S->xrec); S->xrec = nullptr; }
+        S->n_xrec = 0;
+    }
     S->labelled = false;
     PF_HIP(hipMemsetAsync(S->bad, 0, 4, st));
     // the records: the ones K-BFS left in its workspace, or the caller's
@@ -298,6 +417,11 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
         k_cc_edges_long<<<dim3((unsigned)n_extra, 64), 256, 0, st>>>(d_xrec, n_extra, d_xpool, extra_pool_len, n_sides, S->parent, S->first, S->multi, S->bad);
         PF_HIP(hipGetLastError());
         PF_HIP(hipStreamSynchronize(st));   // (the temporaries are freed on return)
+        // the records themselves stay (32 B each): pf_replay_device leaves their components to the caller, who holds their lists
+        if (S->xrec) (void)hipFree(S->xrec);
+        S->xrec = xr.p;
+        S->n_xrec = n_extra;
+        xr.p = nullptr;
     }
     k_cc_multi<<<(N + 255) / 256, 256, 0, st>>>(S->multi, N, S->parent);
     PF_HIP(hipGetLastError());
@@ -307,6 +431,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     if (bad) { ctx->err = "pf_side_components: a record names a vertex outside the graph or a list outside the pool"; S->n_last = 0; return PF_ERR_ARG; }
     S->n_last = n_records;
     ctx->cc_rec = d_rec;
+    ctx->cc_pool = d_pool;
     return PF_OK;
 }
 
@@ -353,6 +478,158 @@ int pf_replay_order(pf_ctx *ctx, uint32_t n_classes, uint32_t *order, uint32_t *
     class_off[0] = 0;
     for (uint32_t c = 0; c < n_classes; ++c) class_off[c + 1] = class_off[c] + hist[c];
     S->labelled = true;
+    return PF_OK;
+}
+
+// ---- the commits on the device: see the kernels above ----
+int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries) {
+    if (!ctx || !ctx->cc || !n_big || !big_entries) return PF_ERR_ARG;
+    CcState *S = static_cast<CcState *>(ctx->cc);
+    if (!S->parent || !ctx->cc_rec) { ctx->err = "pf_replay_device: pf_side_components first"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t N = S->n_unitigs, n_sides = 2 * N;
+    const uint64_t n = S->n_last;
+    if (n >> 32) { ctx->err = "pf_replay_device: more than 2^32 records"; return PF_ERR_ARG; }
+    const pf_bfs_record *rec = static_cast<const pf_bfs_record *>(ctx->cc_rec);
+    const uint32_t *pool = ctx->cc_pool;
+    if (!S->big) {
+        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->big), (size_t)n_sides + 4));
+        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->work), (size_t)n_sides * 4 + 4));
+        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->f2), (size_t)n_sides + 4));
+    }
+    if (S->sort_cap < n + 1) {
+        for (uint32_t **p : {&S->keys, &S->keys2, &S->vals, &S->vals2, &S->big_idx})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        S->sort_cap = n + n / 4 + 64;
+        for (uint32_t **p : {&S->keys, &S->keys2, &S->vals, &S->vals2, &S->big_idx})
+            PF_HIP(hipMalloc(reinterpret_cast<void **>(p), S->sort_cap * 4));
+    }
+    uint8_t *flags = nullptr;
+    uint32_t *plus = nullptr, *minus = nullptr;
+    const int sa = call_state_arrays(ctx, &flags, &plus, &minus);
+    if (sa != PF_OK) return sa;
+    PF_HIP(hipMemsetAsync(S->big, 0, n_sides, st));
+    PF_HIP(hipMemsetAsync(S->work, 0, (size_t)n_sides * 4, st));
+    PF_HIP(hipMemsetAsync(S->f2, 0, n_sides, st));
+    PF_HIP(hipMemsetAsync(plus, 0, (size_t)N * 4, st));
+    PF_HIP(hipMemsetAsync(minus, 0, (size_t)N * 4, st));
+    *n_big = *big_entries = 0;
+    S->n_big = S->big_entries = 0;
+    if (n == 0) return PF_OK;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    k_replay_label<<<grid, 256, 0, st>>>(rec, n, S->parent, n_sides, S->keys, S->vals, S->work);
+    if (S->n_xrec) k_replay_force_big<<<(unsigned)((S->n_xrec + 255) / 256), 256, 0, st>>>(S->xrec, S->n_xrec, S->parent, n_sides, S->big);
+    PF_HIP(hipGetLastError());
+    unsigned bits = 1;
+    while ((1ull << bits) < n_sides) ++bits;
+    size_t need = 0;
+    PF_HIP(rocprim::radix_sort_pairs(nullptr, need, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, st));
+    if (need > S->sort_tmp_bytes) {
+        if (S->sort_tmp) (void)hipFree(S->sort_tmp);
+        S->sort_tmp = nullptr;
+        PF_HIP(hipMalloc(&S->sort_tmp, need + 256));
+        S->sort_tmp_bytes = need + 256;
+    }
+    size_t have = S->sort_tmp_bytes;
+    PF_HIP(rocprim::radix_sort_pairs(S->sort_tmp, have, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, st));
+    FlagsDevice acc{S->f2, plus, minus};
+    k_replay_small<<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size);
+    PF_HIP(hipGetLastError());
+    // the records left to the caller, ascending
+    DevTmp<uint8_t> flag_;
+    DevTmp<uint64_t> cnt_;
+    PF_HIP(flag_.alloc(n + 8));
+    PF_HIP(cnt_.alloc(16));
+    k_replay_flag_big<<<grid, 256, 0, st>>>(rec, n, S->keys, S->big, S->work, small_limit, flag_.p);
+    size_t sel = 0;
+    hipcub::CountingInputIterator<uint32_t> iota(0);
+    PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, sel, iota, flag_.p, S->big_idx, cnt_.p, (int)n, st));
+    DevTmp<uint8_t> tmp_;
+    PF_HIP(tmp_.alloc(sel + 256));
+    sel += 256;
+    PF_HIP(hipcub::DeviceSelect::Flagged(tmp_.p, sel, iota, flag_.p, S->big_idx, cnt_.p, (int)n, st));
+    uint64_t nb = 0;
+    PF_HIP(hipMemcpyAsync(&nb, cnt_.p, 8, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipStreamSynchronize(st));
+    nb &= 0xFFFFFFFFull;   // (the selector counts in 32 bits)
+    uint64_t entries = 0;
+    if (nb) {
+        DevTmp<uint64_t> sz_, off_;
+        PF_HIP(sz_.alloc((nb + 1) * 8));
+        PF_HIP(off_.alloc((nb + 1) * 8));
+        k_replay_big_sizes<<<(unsigned)((nb + 1 + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, sz_.p);
+        size_t t2 = 0;
+        PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, sz_.p, off_.p, (int)(nb + 1), st));
+        DevTmp<uint8_t> tmp2_;
+        PF_HIP(tmp2_.alloc(t2 + 256));
+        t2 += 256;
+        PF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2_.p, t2, sz_.p, off_.p, (int)(nb + 1), st));
+        PF_HIP(hipMemcpyAsync(&entries, off_.p + nb, 8, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipStreamSynchronize(st));
+        if (S->big_cap < nb) {
+            if (S->big_rec) (void)hipFree(S->big_rec);
+            S->big_rec = nullptr;
+            S->big_cap = nb + nb / 4 + 64;
+            PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->big_rec), S->big_cap * sizeof(pf_bfs_record)));
+        }
+        if (S->big_pool_cap < entries + 1) {
+            if (S->big_pool) (void)hipFree(S->big_pool);
+            S->big_pool = nullptr;
+            S->big_pool_cap = entries + entries / 4 + 64;
+            PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->big_pool), S->big_pool_cap * 4));
+        }
+        k_replay_big_gather<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, pool, off_.p, S->big_rec, S->big_pool);
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipStreamSynchronize(st));
+    }
+    S->n_big = nb;
+    S->big_entries = entries;
+    *n_big = nb;
+    *big_entries = entries;
+    return PF_OK;
+}
+
+int pf_replay_big_fetch(pf_ctx *ctx, uint32_t *index, pf_bfs_record *records, uint32_t *pool) {
+    if (!ctx || !ctx->cc) return PF_ERR_ARG;
+    CcState *S = static_cast<CcState *>(ctx->cc);
+    PF_HIP(hipSetDevice(ctx->device));
+    if (S->n_big) {
+        if (index) PF_HIP(hipMemcpy(index, S->big_idx, S->n_big * 4, hipMemcpyDeviceToHost));
+        if (records) PF_HIP(hipMemcpy(records, S->big_rec, S->n_big * sizeof(pf_bfs_record), hipMemcpyDeviceToHost));
+        if (pool && S->big_entries) PF_HIP(hipMemcpy(pool, S->big_pool, S->big_entries * 4, hipMemcpyDeviceToHost));
+    }
+    return PF_OK;
+}
+
+int pf_replay_finish(pf_ctx *ctx, const uint32_t *sides, const uint32_t *links, const uint8_t *side_flags, uint64_t n_patch) {
+    if (!ctx || !ctx->cc || (n_patch && (!sides || !links || !side_flags))) return PF_ERR_ARG;
+    CcState *S = static_cast<CcState *>(ctx->cc);
+    if (!S->f2) { ctx->err = "pf_replay_finish: pf_replay_device first"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    hipStream_t st = ctx->stream;
+    const uint32_t N = S->n_unitigs;
+    uint8_t *flags = nullptr;
+    uint32_t *plus = nullptr, *minus = nullptr;
+    const int sa = call_state_arrays(ctx, &flags, &plus, &minus);   // (the same buffers: contents are kept)
+    if (sa != PF_OK) return sa;
+    if (n_patch) {
+        DevTmp<uint32_t> ds_, dl_;
+        DevTmp<uint8_t> db_;
+        PF_HIP(ds_.alloc(n_patch * 4));
+        PF_HIP(dl_.alloc(n_patch * 4));
+        PF_HIP(db_.alloc(n_patch));
+        PF_HIP(hipMemcpyAsync(ds_.p, sides, n_patch * 4, hipMemcpyDefault, st));
+        PF_HIP(hipMemcpyAsync(dl_.p, links, n_patch * 4, hipMemcpyDefault, st));
+        PF_HIP(hipMemcpyAsync(db_.p, side_flags, n_patch, hipMemcpyDefault, st));
+        k_replay_patch<<<(unsigned)((n_patch + 255) / 256), 256, 0, st>>>(ds_.p, dl_.p, db_.p, n_patch, 2 * N, plus, minus, S->f2);
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipStreamSynchronize(st));
+    }
+    k_replay_merge<<<(N + 255) / 256, 256, 0, st>>>(S->f2, N, flags);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipStreamSynchronize(st));
+    call_state_resident(ctx);
     return PF_OK;
 }
 

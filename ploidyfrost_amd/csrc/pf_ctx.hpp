@@ -105,10 +105,12 @@ struct pf_ctx {
     void *cc = nullptr;
     void *gfa = nullptr;   // K-GFA (pf_gfa.hip): segment table of the last pf_gfa_ingest until pf_gfa_segments fetches it
     const void *cc_rec = nullptr;
+    const uint32_t *cc_pool = nullptr;
     const pf_bfs_record *bfs_last_rec = nullptr;
     const uint32_t *bfs_last_pool = nullptr;
     uint64_t bfs_last_n = 0, bfs_last_pool_len = 0;
     uint64_t bfs_call_id = 0;
+    uint64_t bfs_res_pool_cap = 0;   // pf_bfs_candidates_resident: pool size that sufficed last time
     // pf_bfs_candidates_begin .. _end: the copy of records and pool to the host in flight on copy_stream
     hipStream_t copy_stream = nullptr;
     struct {
@@ -146,9 +148,12 @@ void call_destroy(pf_ctx *ctx);     // pf_call.hip
 void cc_destroy(pf_ctx *ctx);       // pf_cc.hip
 void gfa_destroy(pf_ctx *ctx);      // pf_gfa.hip
 void call_invalidate(pf_ctx *ctx);  // graph or count table replaced
+int call_state_arrays(pf_ctx *ctx, uint8_t **flags, uint32_t **plus, uint32_t **minus);   // pf_call.hip: T1 state arrays for a device-side writer
+void call_state_resident(pf_ctx *ctx);
 enum WsSlot {
     WS_ALN_TEXT = 0, WS_ALN_JOBS, WS_ALN_SMALL, WS_ALN_RETRY, WS_ALN_IDX, WS_ALN_OFIRST, WS_ALN_OCOUNT, WS_ALN_OHITS, WS_ALN_OTEXT,
     WS_ALN_OGAPS, WS_ALN_STTEXT, WS_ALN_STGAPS, WS_ALN_STHITS, WS_ALN_WORK, WS_BFS_REC, WS_BFS_POOL, WS_BFS_SMALL, WS_BFS_DEF, WS_BFS_WLIST,
+    WS_BFS_RES_REC, WS_BFS_RES_POOL,
     WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS,
     WS_BUB_TEXT, WS_BUB_PATHS, WS_BUB_TASKS, WS_BUB_SMALL, WS_BUB_RETRY, WS_BUB_IDX, WS_BUB_RES, WS_BUB_OTEXT, WS_BUB_OSITES,
     WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_BUB_IDX2, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART, WS_COUNT_

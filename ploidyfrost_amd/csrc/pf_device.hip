@@ -1477,6 +1477,32 @@ int pf_bfs_candidates_begin(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record
                                deferred_entrance);
 }
 
+// K-BFS with records and vertex pool left in the context's own device buffers (for K-CC and the device-side commits): nothing
+// travels to the host but the deferred candidates' indices and entrances.
+int pf_bfs_candidates_resident(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred,
+                               uint32_t *deferred_entrance, uint64_t deferred_cap, uint64_t *n_deferred) {
+    if (!ctx || !n_records || !pool_used || !deferred || !deferred_entrance || !n_deferred) return PF_ERR_ARG;
+    if (!ctx->has_adj || u0 > u1 || u1 > ctx->N) return PF_ERR_ARG;
+    uint64_t c0, c1;
+    cand_range(ctx, u0, u1, &c0, &c1);
+    const uint64_t n = c1 - c0;
+    uint64_t cap = std::max<uint64_t>(ctx->bfs_res_pool_cap, n * 6 + (1u << 20));
+    for (int attempt = 0; attempt < 4; ++attempt) {
+        pf_bfs_record *d_rec = (pf_bfs_record *)ctx_ws(ctx, WS_BFS_RES_REC, (n + 1) * sizeof(pf_bfs_record));
+        uint32_t *d_pool = (uint32_t *)ctx_ws(ctx, WS_BFS_RES_POOL, (cap + 1) * 4);
+        if (!d_rec || !d_pool) return PF_ERR_HIP;
+        const int st = bfs_candidates_impl(ctx, u0, u1, d_rec, n + 1, d_pool, cap, n_records, pool_used, deferred, deferred_cap, n_deferred);
+        if (st == PF_ERR_OVERFLOW && *pool_used > cap) { cap = *pool_used + *pool_used / 8 + 1024; continue; }
+        if (st == PF_OK) {
+            ctx->bfs_res_pool_cap = cap;
+            for (uint64_t d = 0; d < *n_deferred; ++d) deferred_entrance[d] = ctx->h_cand[c0 + deferred[d]];
+        }
+        return st;
+    }
+    ctx->err = "pf_bfs_candidates_resident: the vertex pool does not converge";
+    return PF_ERR_OVERFLOW;
+}
+
 int pf_bfs_candidates_end(pf_ctx *ctx) {
     if (!ctx) return PF_ERR_ARG;
     if (!ctx->bfs_pending.active) return PF_OK;
