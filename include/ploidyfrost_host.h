@@ -159,8 +159,9 @@ const uint32_t *pfh_shard_pool(const pfh_run *, uint64_t *n_entries);
 int pfh_find_replay(pfh_run *, const char *outpre, uint32_t n_shards, const pf_bfs_record *const *records, const uint64_t *n_records,
                     const uint32_t *const *pools, int write_file, const uint64_t *pool_lens, const pf_bfs_record *const *dev_records,
                     const uint32_t *const *dev_pools);
-/* host threads of the commit replay in findSuperBubble / pfh_find_replay: 0 = the sequential loop, -1 = default (min(threads, 32),
- * single-sample path only) */
+/* where the commits of findSuperBubble run: -1 = default (single-sample path: on the device, one thread per component,
+ * pf_replay_device; pfh_find_replay and the colored path: host threads / sequential), 0 = the sequential loop on the host,
+ * n >= 2 = n host threads, component by component */
 void pfh_set_replay_threads(pfh_run *, int threads);
 /* several ranks running findSuperBubble on the same graph into one output directory: 0 on all but the rank that writes
  * <outpre>_super_bubble.txt (the rows are computed everywhere; PloidyEstimation does not need the file) */

@@ -32,12 +32,14 @@ unsigned CDBG::replay_threads(size_t thr) const {
     return t >= 2 ? (unsigned)t : 0;
 }
 
-// PF_REPLAY=device (single-sample path): the commits run on the device, one thread per component (pf_cc.hip)
+// The commits run on the device, one thread per component (pf_cc.hip), on the single-sample path unless the caller asked for
+// host threads (set_replay_threads >= 0) or PF_REPLAY says host (components on host threads) or seq (the sequential loop).
 bool CDBG::commits_on_device(size_t thr) const {
     (void)thr;
-    if (col_ != nullptr || !third_tier_on_host_) return false;
-    static const bool on = [] { const char *e = getenv("PF_REPLAY"); return e && !strcmp(e, "device"); }();
-    return on;
+    if (col_ != nullptr || !third_tier_on_host_ || replay_threads_ >= 0) return false;
+    static const bool off = [] { const char *e = getenv("PF_REPLAY"); return e && (!strcmp(e, "host") || !strcmp(e, "seq")); }();
+    static const bool env_threads = getenv("PF_REPLAY_THREADS") != nullptr;
+    return !off && !env_threads;
 }
 
 int CDBG::sync_state_to_host() {
@@ -82,22 +84,32 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
     std::vector<pf_bfs_record> walked((size_t)n_deferred);
     std::vector<std::vector<uint32_t>> lists((size_t)n_deferred);
-    parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
-        std::unique_ptr<HugeWalker> w;
-        {
-            std::lock_guard<std::mutex> lk(walkers_mu_);
-            if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
-        }
-        if (!w) w = std::make_unique<HugeWalker>();
-        pf_bfs_record &r = walked[d];
-        memset(&r, 0, sizeof r);
-        r.entrance = deferred_ent[d];
-        r.exit = 0xFFFFFFFFu;
-        const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, r.entrance, r);
-        lists[d].assign(list.begin(), list.begin() + r.n_list);
-        std::lock_guard<std::mutex> lk(walkers_mu_);
-        walkers_.push_back(std::move(w));
+    std::string walk_err;
+    std::thread walk([&] {
+        try {
+            parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
+                std::unique_ptr<HugeWalker> w;
+                {
+                    std::lock_guard<std::mutex> lk(walkers_mu_);
+                    if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
+                }
+                if (!w) w = std::make_unique<HugeWalker>();
+                pf_bfs_record &r = walked[d];
+                memset(&r, 0, sizeof r);
+                r.entrance = deferred_ent[d];
+                r.exit = 0xFFFFFFFFu;
+                const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, r.entrance, r);
+                lists[d].assign(list.begin(), list.begin() + r.n_list);
+                std::lock_guard<std::mutex> lk(walkers_mu_);
+                walkers_.push_back(std::move(w));
+            });
+        } catch (const std::exception &e) { walk_err = e.what(); }
     });
+    // K-CC over the records that are on the device, beside the walkers
+    st = pf_side_components(ctx_, 1, nullptr, n_rec, nullptr, 0, nullptr, 0, nullptr, 0);
+    walk.join();
+    if (!walk_err.empty()) return fail(PF_ERR_HIP, "CDBG::findSuperBubble(): walk of a long traversal: " + walk_err);
+    if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
     tf("long traversals walked");
     // in candidate order (the device hands the deferred candidates over in the order their wavefronts gave up)
     std::vector<uint32_t> xpool;
@@ -118,7 +130,7 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
         walked.swap(w2);
         std::copy(d2.begin(), d2.end(), deferred.begin());
     }
-    st = pf_side_components(ctx_, 1, nullptr, n_rec, nullptr, 0, walked.data(), walked.size(), xpool.data(), xpool.size());
+    if (!walked.empty()) st = pf_side_components(ctx_, 0, nullptr, n_rec, nullptr, 0, walked.data(), walked.size(), xpool.data(), xpool.size());
     uint64_t n_big = 0, big_entries = 0;
     if (st == PF_OK) st = pf_replay_device(ctx_, (uint32_t)std::min<size_t>(complex_size_, 0xFFFFFFFFu), 256, &n_big, &big_entries);
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
