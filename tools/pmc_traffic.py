@@ -42,6 +42,7 @@ def short(name):
         return "k_cov_probe"
     for k in ("k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_call_pair", "k_call_resolve", "k_sb_format",
               "k_cc_edges_long", "k_cc_edges", "k_cc_labels", "k_cc_multi", "k_cc_init", "k_bfs_thread",
+              "k_replay_small", "k_replay_label", "k_replay_flag_big", "k_replay_merge", "k_gfa_lines", "k_gfa_pack",
               "k_cov_init", "k_cov_colored", "k_cov", "k_bfs_huge", "k_bfs_big", "k_bfs", "k_bubble", "k_strcov_colored", "k_align", "k_strcov", "k_table_build", "k_adj_insert", "k_adj_probe"):
         if k + "(" in name or k + "<" in name:
             if k == "k_bubble" and "Lb0" in name:
