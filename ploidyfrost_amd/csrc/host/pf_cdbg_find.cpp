@@ -107,6 +107,8 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     });
     // K-CC over the records that are on the device, beside the walkers
     st = pf_side_components(ctx_, 1, nullptr, n_rec, nullptr, 0, nullptr, 0, nullptr, 0);
+    // ... and the coverage kernel PloidyEstimation starts with (it depends on nothing this phase computes)
+    if (st == PF_OK && overlap_output_) cov_ready_ = launch_coverage() == PF_OK;
     walk.join();
     if (!walk_err.empty()) return fail(PF_ERR_HIP, "CDBG::findSuperBubble(): walk of a long traversal: " + walk_err);
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
@@ -132,7 +134,9 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     }
     if (!walked.empty()) st = pf_side_components(ctx_, 0, nullptr, n_rec, nullptr, 0, walked.data(), walked.size(), xpool.data(), xpool.size());
     uint64_t n_big = 0, big_entries = 0;
-    if (st == PF_OK) st = pf_replay_device(ctx_, (uint32_t)std::min<size_t>(complex_size_, 0xFFFFFFFFu), 256, &n_big, &big_entries);
+    // (PF_REPLAY_SMALL_LIMIT: tests push more components -- all of them with 0 -- through the host half and its patch)
+    static const uint32_t small_limit = [] { const char *e = getenv("PF_REPLAY_SMALL_LIMIT"); return e ? (uint32_t)atoi(e) : 256u; }();
+    if (st == PF_OK) st = pf_replay_device(ctx_, (uint32_t)std::min<size_t>(complex_size_, 0xFFFFFFFFu), small_limit, &n_big, &big_entries);
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
     tf("components + commits on the device");
     // what is left for this side: the records of the large components and of the components of the walked traversals, merged
@@ -192,7 +196,6 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     times_.candidates = n_rec;
     times_.bfs_deferred = n_deferred;
     times_.replay_s = 0;
-    if (overlap_output_) cov_ready_ = launch_coverage() == PF_OK;
     if (!quiet_) {
         printf(mt_format_ ? "%s::findSuperBubble(): Finding superbubbles Cpu time : %gs\n" : "%s::findSuperBubble():  Cpu time : %gs\n", tag_,
                (double)(clock() - c0) / CLOCKS_PER_SEC);

@@ -316,3 +316,21 @@ def test_more_than_255_paths_are_refused_by_name(tmp_path):
                             capture_output=True, text=True)
         assert ro.returncode == 0, ro.stderr[-300:]
         assert not compare_outputs(str(want / "PloidyFrost_output"), os.path.join(str(sub), "PloidyFrost_output")), (layers, seed)
+
+
+@pytest.mark.parametrize("case", ["weird12k", "giant7k", "hex30k", "tet_frac"])
+@pytest.mark.parametrize("mode", ["limit0", "limit6", "host", "seq"])
+def test_commits_on_the_device_the_host_and_both(case, mode, tmp_path):
+    """findSuperBubble's commits: on the device one thread per component (default, the other tests), with the components above a
+    tiny limit -- or all of them -- committed on the host and patched into the device state, on host threads, and in the
+    sequential loop: the same twelve files."""
+    meta = load_case(case)
+    env = dict(os.environ)
+    env.pop("PF_REPLAY", None)
+    if mode.startswith("limit"):
+        env["PF_REPLAY_SMALL_LIMIT"] = mode[5:]
+    else:
+        env["PF_REPLAY"] = mode
+    r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "4"] + meta["args"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-400:] + r.stdout[-400:]
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(str(tmp_path), "PloidyFrost_output")), (case, mode)
