@@ -377,7 +377,9 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     // the records: the ones K-BFS left in its workspace, or the caller's
     const pf_bfs_record *d_rec = nullptr;
     const uint32_t *d_pool = nullptr;
-    if (!records) {
+    if (!records && n_records == 0) {
+        // a graph without a candidate entrance: nothing to add
+    } else if (!records) {
         if (ctx->bfs_last_n != n_records || !ctx->bfs_last_rec) { ctx->err = "pf_side_components: no records of that length from the last K-BFS call"; return PF_ERR_ARG; }
         d_rec = ctx->bfs_last_rec;
         d_pool = ctx->bfs_last_pool;
@@ -485,7 +487,7 @@ int pf_replay_order(pf_ctx *ctx, uint32_t n_classes, uint32_t *order, uint32_t *
 int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries) {
     if (!ctx || !ctx->cc || !n_big || !big_entries) return PF_ERR_ARG;
     CcState *S = static_cast<CcState *>(ctx->cc);
-    if (!S->parent || !ctx->cc_rec) { ctx->err = "pf_replay_device: pf_side_components first"; return PF_ERR_ARG; }
+    if (!S->parent || (!ctx->cc_rec && S->n_last)) { ctx->err = "pf_replay_device: pf_side_components first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t N = S->n_unitigs, n_sides = 2 * N;

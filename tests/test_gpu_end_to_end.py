@@ -334,3 +334,29 @@ def test_commits_on_the_device_the_host_and_both(case, mode, tmp_path):
     r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "4"] + meta["args"], cwd=tmp_path, capture_output=True, text=True, env=env)
     assert r.returncode == 0, r.stderr[-400:] + r.stdout[-400:]
     assert not compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(str(tmp_path), "PloidyFrost_output")), (case, mode)
+
+
+def test_graph_without_a_candidate_entrance(tmp_path):
+    """three unitigs that share no k-mer overlap: no vertex has two successors, findSuperBubble has nothing to traverse or commit"""
+    from ploidyfrost_amd import synth
+    rng = np.random.default_rng(3)
+    segs = [bytes(rng.choice(list(b"ACGT"), size=n).tolist()) for n in (80, 25, 140)]
+    gfa = str(tmp_path / "lone.gfa")
+    with open(gfa, "wb") as f:
+        f.write(b"H\tVN:Z:1.0\tKL:Z:25\tML:Z:17\n")
+        for i, sq in enumerate(segs):
+            f.write(b"S\t%d\t%s\n" % (i + 1, sq))
+    code = {ord("A"): 0, ord("C"): 1, ord("G"): 2, ord("T"): 3}
+    km, mult = synth.canonical_counts([np.array([code[c] for c in sq], dtype=np.uint8) for sq in segs], 25)
+    db = str(tmp_path / "lone_db")
+    synth.write_kmc1(db, km, np.full(len(km), 20, dtype=np.uint32), 25)
+    for mode in ("device", "host"):
+        d = tmp_path / mode
+        d.mkdir()
+        r = subprocess.run([CLI, "-g", gfa, "-d", db, "-o", "g", "-l", "1", "-u", "1000", "-t", "2"], cwd=d, capture_output=True, text=True,
+                           env=dict(os.environ, PF_REPLAY=mode))
+        # (no site at all: the reference divides by zero at the very end, after its files are written; this CLI skips that line)
+        assert r.returncode == 0, (mode, r.stdout[-300:], r.stderr[-300:])
+        sb = open(os.path.join(str(d), "PloidyFrost_output", "g_super_bubble.txt")).read()
+        assert sb == "BubbleId\tEntrance\tStrand\tExit\tisSimple\tisComplex\n"
+        assert open(os.path.join(str(d), "PloidyFrost_output", "g_Unitig_Id.txt")).read().count("\n") == 3
