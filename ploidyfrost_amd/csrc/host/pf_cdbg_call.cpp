@@ -324,6 +324,11 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     uint64_t var_count = 0;
     int rc = PF_OK;
     std::string rc_err;
+    std::thread prefault;
+    struct PrefaultGuard {
+        std::thread &t;
+        ~PrefaultGuard() { if (t.joinable()) t.join(); }
+    } prefault_guard{prefault};
     const auto t_dev = clk::now();
     // Alignment in large launches (every kernel's tail -- one wavefront finishing the heaviest bubble -- is paid once per
     // launch), text in pieces of CHUNK bubbles that are fetched and written while the next piece is formatted.
@@ -350,6 +355,32 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             st = pf_call_text_range(ctx_, d.slab, p0, std::min<uint64_t>(CHUNK, a1 - a0 - p0), var_count, &d.res);
             if (st != PF_OK) { rc = st; rc_err = pf_last_error(ctx_); break; }
             if (trace) fprintf(stderr, "[ploidy]   piece %zu formatted on the device %.2f ms\n", b, since(t_all) * 1e3);
+            if (b == 0 && write_files_ && a0 == 0) {
+                // first piece of a pass: fresh result files get their final size (extrapolated from this piece, cut to the true
+                // one at the end) and their pages now, on helper threads, instead of fault by fault under the writer
+                const double scale = 1.05 * (double)n_tasks / (double)std::max<uint64_t>(1, std::min<uint64_t>(CHUNK, a1 - a0 - p0));
+                std::vector<std::pair<int, uint64_t>> fresh;
+                for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+                    const uint64_t est = (uint64_t)((double)d.res.text_len[s] * scale) + 4096;
+                    if (d.res.text_len[s] && maps[s].reserve(est) == 0) fresh.push_back({s, est});
+                }
+                if (!fresh.empty())
+                    prefault = std::thread([maps, fresh, T] {
+                        constexpr uint64_t STEP = 4u << 20;
+                        std::vector<std::pair<int, uint64_t>> spans;   // (stream, offset) in 4 MB steps, files interleaved
+                        uint64_t longest = 0;
+                        for (auto &f : fresh) longest = std::max(longest, f.second);
+                        for (uint64_t at = 0; at < longest; at += STEP)
+                            for (auto &f : fresh)
+                                if (at < f.second) spans.push_back({f.first, at});
+                        parallel_chunks(spans.size(), 1, std::max(2u, T / 2), [&](size_t i, size_t, size_t) {
+                            const int s = spans[i].first;
+                            uint64_t end = spans[i].second + STEP;
+                            for (auto &f : fresh) if (f.first == s) end = std::min(end, f.second);
+                            maps[s].populate(spans[i].second, end);
+                        });
+                    });
+            }
             for (int a = 0; a < 4; ++a) allele_[a] += d.res.allele[a];
             core_cov_ += d.res.core_cov;
             core_num_ += d.res.core_num;
@@ -368,6 +399,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     cv.notify_all();
     fetcher.join();
     writer.join();
+    if (prefault.joinable()) prefault.join();
     tp("pipeline done");
     if (rc != PF_OK) {
         // the device layer words the reference's own messages (missing k-mer, site string outside its row)
