@@ -393,6 +393,11 @@ int pf_replay_order(pf_ctx *, uint32_t n_classes, uint32_t *order, uint32_t *cla
 int pf_bfs_candidates_resident(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred,
                                uint32_t *deferred_entrance, uint64_t deferred_cap, uint64_t *n_deferred);
 int pf_replay_device(pf_ctx *, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries);
+/* Colored path (CCDBG): the colour gate of the accept commit (src/CCDBG.cpp:2530-2621) reads, per unitig, the mask of colours
+ * present on every k-mer, UnitigColors::size() with the unitig's own mapping, and how many colours the pair encoding stores as
+ * "full" [host|dev].  Set once per graph; pf_side_components and pf_replay_device then apply the colored commits
+ * (n_colors == 0: back to the single-sample ones). */
+int pf_replay_set_colours(pf_ctx *, uint32_t n_colors, const uint64_t *full_mask, const uint64_t *size_total, const uint32_t *n_full_enc);
 int pf_replay_big_fetch(pf_ctx *, uint32_t *index, pf_bfs_record *records, uint32_t *pool);
 int pf_replay_finish(pf_ctx *, const uint32_t *sides, const uint32_t *links, const uint8_t *side_flags, uint64_t n_patch);
 int pf_call_get_state(pf_ctx *, uint8_t *flags, uint32_t *plus, uint32_t *minus);

@@ -192,6 +192,10 @@ int pfh_replay_apply_parallel(pfh_replay *, const pf_bfs_record *records, uint64
 void pfh_side_components(const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t n_unitigs, uint32_t *labels);
 uint64_t pfh_replay_check_footprints(const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint32_t n_unitigs,
                                      uint32_t complex_size, uint64_t slice, uint64_t *first_bad);
+/* the same with the colored commits (CCDBG): colour sets of an opened (graph, colours) pair, succ = the graph's CSR rows [2N][4] */
+struct pfh_colors;
+uint64_t pfh_colors_check_footprints(const struct pfh_colors *, const uint32_t *succ, const pf_bfs_record *records, uint64_t n_records,
+                                     const uint32_t *pool, uint32_t complex_size, uint64_t slice, uint64_t *first_bad);
 
 /* Kmer::hash(seed) of the reference's Bifrost build (wyhash over the 8-byte left-aligned k-mer) */
 uint64_t pfh_bifrost_kmer_hash(uint64_t left_aligned_kmer, uint64_t seed);

@@ -43,6 +43,10 @@ CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, doub
     st_.col = col_;
     const uint32_t C = cg_.colors.n_colors;
     if (C > PF_MAX_COLORS) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: more colours than the device table holds"); return; }
+    {   // the colour gate of the accept commit goes to the device with the graph: the commits run there (pf_replay_device)
+        const int st = pf_replay_set_colours(ctx_, C, cg_.colors.full_mask.data(), cg_.colors.size_total.data(), cg_.colors.n_full_enc.data());
+        colours_on_device_ = st == PF_OK;
+    }
     if (!kmc_db_list.empty()) {
         // src/CCDBG.cpp:13-43: one database name per line, one line per colour
         FILE *f = fopen(kmc_db_list.c_str(), "r");

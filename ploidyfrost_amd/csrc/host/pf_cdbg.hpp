@@ -219,6 +219,7 @@ protected:
     // commits on the device (pf_replay_device): the host arrays are stale until sync_state_to_host; big_f2_ = the per-side flag
     // bytes of the few components committed on the host (kept all-zero between passes)
     bool state_host_stale_ = false;
+    bool colours_on_device_ = false;   // colored path: pf_replay_set_colours succeeded
     std::vector<uint8_t> big_f2_;
     bool commits_on_device(size_t thr) const;
     int find_superbubbles_device(const std::string &outpre, const size_t &thr);

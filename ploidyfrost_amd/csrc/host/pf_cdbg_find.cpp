@@ -36,7 +36,7 @@ unsigned CDBG::replay_threads(size_t thr) const {
 // host threads (set_replay_threads >= 0) or PF_REPLAY says host (components on host threads) or seq (the sequential loop).
 bool CDBG::commits_on_device(size_t thr) const {
     (void)thr;
-    if (col_ != nullptr || !third_tier_on_host_ || replay_threads_ >= 0) return false;
+    if ((col_ != nullptr && !colours_on_device_) || !third_tier_on_host_ || replay_threads_ >= 0) return false;
     static const bool off = [] { const char *e = getenv("PF_REPLAY"); return e && (!strcmp(e, "host") || !strcmp(e, "seq")); }();
     static const bool env_threads = getenv("PF_REPLAY_THREADS") != nullptr;
     return !off && !env_threads;
@@ -160,7 +160,9 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     std::vector<uint8_t> p_bytes;
     {
         // (every side written is noted: exactly those go to the device afterwards)
-        Commits<FlagsPerSideLogged> cm{FlagsPerSideLogged{FlagsPerSide{big_f2_.data(), plus_.data(), minus_.data()}, &p_sides}, complex_size_, NoColours{}};
+        const FlagsPerSideLogged acc{FlagsPerSide{big_f2_.data(), plus_.data(), minus_.data()}, &p_sides};
+        Commits<FlagsPerSideLogged> cm{acc, complex_size_, NoColours{}};
+        Commits<FlagsPerSideLogged, ColourGate> cmc{acc, complex_size_, col_ ? st_.colour_gate() : ColourGate{}};
         size_t a = 0, b = 0;   // a over big_idx, b over the walked records (ascending candidate index both)
         auto commit = [&](const pf_bfs_record &r, const uint32_t *list) {
             if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
@@ -168,7 +170,7 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
             if (!record_effective(r)) return;
             if (!cm.gate_open(r.entrance)) return;
             if (r.n_seen > 4096) { times_.bfs_large_used++; times_.bfs_large_used_max = std::max<uint64_t>(times_.bfs_large_used_max, r.n_seen); }
-            cm.replay(r, list);
+            if (col_) cmc.replay(r, list); else cm.replay(r, list);
         };
         while (a < (size_t)n_big || b < (size_t)n_deferred) {
             const bool take_walked = a >= (size_t)n_big || (b < (size_t)n_deferred && deferred[b] < big_idx[a]);

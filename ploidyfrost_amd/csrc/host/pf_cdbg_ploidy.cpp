@@ -172,6 +172,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     if (!quiet_) printf("%s::PloidyEstimation():  Analyzing superbubbles to generate sites' information\n", tag_);
     if (write_files_ && ensure_dir()) return status_;
     g_.ensure_text();   // this pipeline compares and copies sequences on the host
+    if (sync_state_to_host()) return status_;   // ... and reads the state findSuperBubble left (committed on the device)
     const uint32_t N = g_.n();
     const int k = g_.k;
     const bool colored = col_ != nullptr;

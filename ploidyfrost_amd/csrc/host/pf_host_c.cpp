@@ -309,6 +309,20 @@ pfh_colors *pfh_colors_open(const char *gfa_path, const char *colors_path, uint3
         return nullptr;
     }
 }
+
+// the footprint check with the colored commits: colour sets of an opened (graph, colours) pair, CSR rows from the caller
+uint64_t pfh_colors_check_footprints(const pfh_colors *c, const uint32_t *succ, const pf_bfs_record *records, uint64_t n_records,
+                                     const uint32_t *pool, uint32_t complex_size, uint64_t slice, uint64_t *first_bad) {
+    pfh::ColourGate g;
+    g.n_colors = c->sets.n_colors;
+    g.k = c->graph.k;
+    g.len_bp = c->graph.len_bp.data();
+    g.full_mask = c->sets.full_mask.data();
+    g.size_total = c->sets.size_total.data();
+    g.n_full_enc = c->sets.n_full_enc.data();
+    g.succ = succ;
+    return pfh::check_footprints(records, n_records, pool, c->graph.n(), complex_size, slice, first_bad, &g);
+}
 void pfh_colors_close(pfh_colors *c) { delete c; }
 uint32_t pfh_colors_count(const pfh_colors *c) { return c->sets.n_colors; }
 uint32_t pfh_colors_unitigs(const pfh_colors *c) { return c->graph.n(); }

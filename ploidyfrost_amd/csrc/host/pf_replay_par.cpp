@@ -7,7 +7,7 @@ namespace pfh {
 
 namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
-// test hook: PF_CC_WITHOUT=2 drops the two-partner rule, =4 the rejected-exit rule (the footprint check must then find accesses
+// test hook: PF_CC_WITHOUT=2 drops the two-partner rule, =4 the rejected-exit rule, =8 the colored path's incomplete-endpoint rule (the footprint check must then find accesses
 // outside the components: tests/test_replay_parallel_cpu.py holds the check itself to that)
 int rules_dropped() {
     const char *e = getenv("PF_CC_WITHOUT");
@@ -47,6 +47,10 @@ void SideComponents::add_record(const pf_bfs_record &r, const uint32_t *list) {
     if (r.outcome == PF_BFS_ACCEPT) {
         partner(entrance_side(s), exit_side(t));
         partner(exit_side(t), entrance_side(s));
+        if (gate_ && !(rules_dropped() & 8)) {   // NON_SUPER on an endpoint with an incomplete colour set: a write to the whole unitig
+            if (gate_->incomplete_entrance(s >> 1)) unite(2 * (s >> 1), 2 * (s >> 1) + 1);
+            if (gate_->incomplete_exit(t >> 1, s >> 1)) unite(2 * (t >> 1), 2 * (t >> 1) + 1);
+        }
     }
     // setNoBubble_ptr(seen, p) releases whatever the exit's side holds, a self-mark included ("release(t, t)" resolves to the plus
     // side when that is self-marked too): the exit counts as one unit
@@ -92,16 +96,19 @@ struct FlagsChecked {
 };
 }  // namespace
 
-uint64_t check_footprints(const pf_bfs_record *rec, uint64_t n, const uint32_t *pool, uint32_t n_unitigs, size_t complex_size, uint64_t slice,
-                          uint64_t *first_bad) {
+namespace {
+template <class Col>
+uint64_t check_with(const pf_bfs_record *rec, uint64_t n, const uint32_t *pool, uint32_t n_unitigs, size_t complex_size, uint64_t slice,
+                    uint64_t *first_bad, Col col, const ColourGate *gate) {
     std::vector<uint8_t> flags(n_unitigs, 0);
     std::vector<uint32_t> plus(n_unitigs, 0), minus(n_unitigs, 0);
     SideComponents cc;
     cc.reset(n_unitigs);
+    cc.set_colour_gate(gate);
     uint64_t bad = 0;
     if (first_bad) *first_bad = UINT64_MAX;
     if (slice == 0) slice = n ? n : 1;
-    Commits<FlagsChecked> cm{FlagsChecked{FlagsPerUnitig{flags.data(), plus.data(), minus.data()}, &cc, &bad, 0}, complex_size, NoColours{}};
+    Commits<FlagsChecked, Col> cm{FlagsChecked{FlagsPerUnitig{flags.data(), plus.data(), minus.data()}, &cc, &bad, 0}, complex_size, col};
     auto list_of = [&](const pf_bfs_record &r) { return pool + r.list_off; };
     for (uint64_t a = 0; a < n; a += slice) {
         const uint64_t b = std::min(n, a + slice);
@@ -115,6 +122,13 @@ uint64_t check_footprints(const pf_bfs_record *rec, uint64_t n, const uint32_t *
         }
     }
     return bad;
+}
+}  // namespace
+
+uint64_t check_footprints(const pf_bfs_record *rec, uint64_t n, const uint32_t *pool, uint32_t n_unitigs, size_t complex_size, uint64_t slice,
+                          uint64_t *first_bad, const ColourGate *gate) {
+    if (gate) return check_with<ColourGate>(rec, n, pool, n_unitigs, complex_size, slice, first_bad, *gate, gate);
+    return check_with<NoColours>(rec, n, pool, n_unitigs, complex_size, slice, first_bad, NoColours{}, nullptr);
 }
 
 }  // namespace pfh

@@ -40,6 +40,8 @@ public:
             if (record_effective(rec[i])) add_record(rec[i], list_of(rec[i]));
     }
     uint32_t label(uint32_t side) { return find(side); }
+    // colored path: the accept commit may mark an endpoint with an incomplete colour set NON_SUPER (pf_state_ops.hpp)
+    void set_colour_gate(const ColourGate *g) { gate_ = g; }
     // order[] = record indices grouped by class (ascending inside a class), class_off[n_classes + 1]
     void order(const pf_bfs_record *rec, uint64_t n, uint32_t n_classes, std::vector<uint32_t> &order, std::vector<uint32_t> &class_off);
 
@@ -60,6 +62,7 @@ private:
     }
     void partner(uint32_t side, uint32_t other_side);
     std::vector<uint32_t> parent_, first_;
+    const ColourGate *gate_ = nullptr;
 };
 
 struct ReplayStats {
@@ -144,6 +147,6 @@ private:
 // components known when the slice starts to run (cumulative, as the executor sees them): returns the number of accesses to a side
 // outside the running record's component; `first_bad` = index of the first such record (or UINT64_MAX).
 uint64_t check_footprints(const pf_bfs_record *rec, uint64_t n, const uint32_t *pool, uint32_t n_unitigs, size_t complex_size, uint64_t slice,
-                          uint64_t *first_bad);
+                          uint64_t *first_bad, const ColourGate *gate = nullptr);
 
 }  // namespace pfh

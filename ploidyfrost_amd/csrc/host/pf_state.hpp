@@ -24,8 +24,8 @@ struct UnitigState {
     void replay(const pf_bfs_record &r, const uint32_t *list);
     bool gate_open(uint32_t entrance_ov) const { return ((entrance_ov & 1) == 0 ? plus[entrance_ov >> 1] : minus[entrance_ov >> 1]) == 0; }
 
-    // the colored accept commit's extra gates (src/CCDBG.cpp:2530-2621); called by the commits when `col` is set
-    bool colours_allow(const pf_bfs_record &r, const uint32_t *list);
+    // the colored accept commit's extra gates (src/CCDBG.cpp:2530-2621) over this state's colour sets, graph and CSR
+    struct ColourGate colour_gate() const;
 };
 
 }  // namespace pfh

@@ -103,6 +103,52 @@ struct NoColours {
     template <class A> PF_HD bool allow(A &, const pf_bfs_record &, const uint32_t *) const { return true; }
 };
 
+// The colored accept commit's extra gates (src/CCDBG.cpp:2530-2621) over plain arrays (host vectors or device buffers): both
+// endpoints carry every colour on every k-mer, and every colour a vertex of the bubble carries in full continues, in full, on
+// one of its successors.  An endpoint whose colour set is incomplete is marked NON_SUPER -- a write to the whole unitig by a
+// record that owns one side of it: the component model joins both sides of such endpoints (incomplete_entrance / _exit).
+struct ColourGate {
+    static constexpr bool colored = true;
+    uint32_t n_colors = 0;
+    int k = 0;
+    const uint32_t *len_bp = nullptr;       // unitig lengths
+    const uint64_t *full_mask = nullptr;    // bit c: colour c on every k-mer of the unitig
+    const uint64_t *size_total = nullptr;   // UnitigColors::size(um) with the unitig's own mapping
+    const uint32_t *n_full_enc = nullptr;   // colours the file's pair encoding stores as "full"
+    const uint32_t *succ = nullptr;         // CSR rows [2N][4]
+
+    PF_HD uint64_t km(uint32_t u) const { return (uint64_t)len_bp[u] - (uint32_t)k + 1; }
+    // UnitigColors::size(um) of unitig u's set evaluated with a mapping of km_of k-mers (only the pair encoding looks at the
+    // mapping, ColorSet.cpp:902-907; CCDBG.cpp:2552 passes the ENTRANCE's mapping to the exit's set)
+    PF_HD uint64_t size_with(uint32_t u, uint64_t km_own, uint64_t km_of) const {
+        return size_total[u] - (uint64_t)n_full_enc[u] * km_own + (uint64_t)n_full_enc[u] * km_of;
+    }
+    PF_HD bool incomplete_entrance(uint32_t su) const { const uint64_t m = km(su); return size_with(su, m, m) != m * n_colors; }
+    PF_HD bool incomplete_exit(uint32_t tu, uint32_t su) const { const uint64_t m = km(tu); return size_with(tu, m, km(su)) != m * n_colors; }
+
+    template <class A>
+    PF_HD bool allow(A &a, const pf_bfs_record &r, const uint32_t *list) const {
+        const uint32_t s = r.entrance, su = s >> 1, t = r.exit, tu = t >> 1;
+        bool f = true;
+        if (incomplete_entrance(su)) { f = false; a.set_non_super(su); }
+        if (incomplete_exit(tu, su)) { f = false; a.set_non_super(tu); }
+        if (!f) return false;
+        const uint64_t all = n_colors == 64 ? ~0ull : ((1ull << n_colors) - 1);
+        for (uint32_t i = 0; i < r.n_list; ++i) {
+            const uint32_t w = list[i];
+            if (w == t) continue;
+            // the reference keys its colour lists by unitig id and pre-loads both endpoints with every colour
+            const uint64_t mine = ((w >> 1) == su || (w >> 1) == tu) ? all : full_mask[w >> 1];
+            uint64_t cont = 0;
+            const uint32_t *row = &succ[(size_t)w * 4];
+            for (int b = 0; b < 4; ++b)
+                if (row[b] != 0xFFFFFFFFu) cont |= full_mask[row[b] >> 1];
+            if ((cont & mine) != mine) return false;
+        }
+        return true;
+    }
+};
+
 template <class Acc, class Col = NoColours>
 struct Commits {
     Acc a;

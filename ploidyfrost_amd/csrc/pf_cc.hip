@@ -78,12 +78,18 @@ __device__ inline void cc_partner(uint32_t *first, uint8_t *multi, uint32_t side
 }
 
 // the part of a record's footprint that does not depend on the list position (one thread of the record's group does it)
-__device__ inline void cc_endpoints(const pf_bfs_record &r, uint32_t *parent, uint32_t *first, uint8_t *multi) {
+// gate: the colored path's (nullptr otherwise) -- an accepted record may mark an endpoint with an incomplete colour set
+// NON_SUPER, a write to the whole unitig: such endpoints count as one unit
+__device__ inline void cc_endpoints(const pf_bfs_record &r, uint32_t *parent, uint32_t *first, uint8_t *multi, const pfh::ColourGate *gate) {
     const uint32_t s = r.entrance, t = r.exit;
     if (r.outcome != PF_BFS_NONE) cc_unite(parent, s, t ^ 1u);
     if (r.outcome == PF_BFS_ACCEPT) {
         cc_partner(first, multi, s, t ^ 1u);
         cc_partner(first, multi, t ^ 1u, s);
+        if (gate) {
+            if (gate->incomplete_entrance(s >> 1)) multi[s >> 1] = 1;
+            if (gate->incomplete_exit(t >> 1, s >> 1)) multi[t >> 1] = 1;
+        }
     }
     if (r.outcome == PF_BFS_REJECT) multi[t >> 1] = 1;
 }
@@ -112,14 +118,15 @@ __device__ inline bool cc_valid(const pf_bfs_record &r, uint32_t n_sides, uint64
 
 // one thread per record (lists of the device tiers: at most 128 entries, four on average)
 __global__ __launch_bounds__(256) void k_cc_edges(const pf_bfs_record *__restrict__ rec, uint64_t n, const uint32_t *__restrict__ pool, uint64_t pool_len,
-                                                  uint32_t n_sides, uint32_t *parent, uint32_t *first, uint8_t *multi, uint32_t *bad) {
+                                                  uint32_t n_sides, uint32_t *parent, uint32_t *first, uint8_t *multi, uint32_t *bad,
+                                                  pfh::ColourGate gate) {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const pf_bfs_record r = rec[i];
     if (r.entrance >= n_sides) { *bad = 1; return; }
     if (!cc_effective(r)) return;
     if (!cc_valid(r, n_sides, pool_len)) { *bad = 1; return; }
-    cc_endpoints(r, parent, first, multi);
+    cc_endpoints(r, parent, first, multi, gate.n_colors ? &gate : nullptr);
     const uint32_t *l = pool + r.list_off;
     for (uint32_t q = 0; q < r.n_list; ++q) cc_entry(r, l[q], parent, n_sides, bad);
 }
@@ -127,13 +134,13 @@ __global__ __launch_bounds__(256) void k_cc_edges(const pf_bfs_record *__restric
 // up to 64 blocks per record (grid y): the long lists of the traversals the caller walked itself
 __global__ __launch_bounds__(256) void k_cc_edges_long(const pf_bfs_record *__restrict__ rec, uint64_t n, const uint32_t *__restrict__ pool,
                                                        uint64_t pool_len, uint32_t n_sides, uint32_t *parent, uint32_t *first, uint8_t *multi,
-                                                       uint32_t *bad) {
+                                                       uint32_t *bad, pfh::ColourGate gate) {
     const uint64_t i = blockIdx.x;
     if (i >= n) return;
     const pf_bfs_record r = rec[i];
     if (!cc_effective(r)) return;
     if (!cc_valid(r, n_sides, pool_len)) { *bad = 1; return; }   // (block-uniform)
-    if (threadIdx.x == 0 && blockIdx.y == 0) cc_endpoints(r, parent, first, multi);
+    if (threadIdx.x == 0 && blockIdx.y == 0) cc_endpoints(r, parent, first, multi, gate.n_colors ? &gate : nullptr);
     const uint32_t *l = pool + r.list_off;
     // Every entry joins the entry at half its index (a binary tree over the list positions) instead of the entrance: the same
     // component, but the hooks spread over the list instead of all landing on one root (a 36 000-entry list cost 8 ms that way).
@@ -221,15 +228,16 @@ __global__ void k_replay_force_big(const pf_bfs_record *__restrict__ xrec, uint6
 }
 
 // keys / vals: the records sorted by component label (stable: ascending record index inside a component)
+template <class Col>
 __global__ __launch_bounds__(256) void k_replay_small(const uint32_t *__restrict__ keys, const uint32_t *__restrict__ vals, uint64_t n,
                                                       const pf_bfs_record *__restrict__ rec, const uint32_t *__restrict__ pool, const uint8_t *__restrict__ big,
-                                                      const uint32_t *__restrict__ work, uint32_t limit, FlagsDevice acc, uint32_t complex_size) {
+                                                      const uint32_t *__restrict__ work, uint32_t limit, FlagsDevice acc, uint32_t complex_size, Col col) {
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n) return;
     const uint32_t key = keys[t];
     if (t && keys[t - 1] == key) return;   // not the head of its component
     if (big[key] || work[key] > limit) return;
-    pfh::Commits<FlagsDevice> cm{acc, complex_size, pfh::NoColours{}};
+    pfh::Commits<FlagsDevice, Col> cm{acc, complex_size, col};
     for (uint64_t j = t; j < n && keys[j] == key; ++j) {
         const pf_bfs_record r = rec[vals[j]];
         if (!cm.gate_open(r.entrance)) continue;
@@ -301,13 +309,17 @@ struct CcState {
     pf_bfs_record *big_rec = nullptr;
     uint32_t *big_pool = nullptr;
     uint64_t big_cap = 0, big_pool_cap = 0, n_big = 0, big_entries = 0;
+    // colored path (pf_replay_set_colours): what the colour gate of the accept commit reads, per unitig
+    uint64_t *full_mask = nullptr, *size_total = nullptr;
+    uint32_t *n_full_enc = nullptr;
+    uint32_t n_colors = 0;
     pf_bfs_record *xrec = nullptr;   // (device copy of the last call's extra records, kept for pf_replay_device)
     uint64_t n_xrec = 0;
     uint64_t added_call = 0;   // the K-BFS call whose device-resident records are already in the union-find
     bool labelled = false;
     void release() {
         for (void *p : {(void *)big, (void *)work, (void *)f2, (void *)keys, (void *)keys2, (void *)vals, (void *)vals2, (void *)big_idx, (void *)big_rec,
-                        (void *)big_pool, (void *)xrec})
+                        (void *)big_pool, (void *)xrec, (void *)full_mask, (void *)size_total, (void *)n_full_enc})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)parent, (void *)first, (void *)multi, (void *)bad, (void *)labels, (void *)cls, (void *)idx, (void *)cls2, (void *)idx2, (void *)hist,
                         sort_tmp, (void *)up_rec, (void *)up_pool})
@@ -325,11 +337,27 @@ bool grow(T *&p, uint64_t &cap, uint64_t want) {
     return hipMalloc(reinterpret_cast<void **>(&p), cap * sizeof(T)) == hipSuccess;
 }
 
+struct CcState;
+pfh::ColourGate gate_of(const pf_ctx *ctx, const CcState *S);
+
 bool is_device(const void *p) {
     hipPointerAttribute_t at;
     const bool dev = hipPointerGetAttributes(&at, p) == hipSuccess && at.type == hipMemoryTypeDevice;
     (void)hipGetLastError();
     return dev;
+}
+
+pfh::ColourGate gate_of(const pf_ctx *ctx, const CcState *S) {
+    pfh::ColourGate g;
+    if (!S->n_colors) return g;   // (n_colors == 0: no gate)
+    g.n_colors = S->n_colors;
+    g.k = ctx->k;
+    g.len_bp = ctx->d_len;
+    g.full_mask = S->full_mask;
+    g.size_total = S->size_total;
+    g.n_full_enc = S->n_full_enc;
+    g.succ = ctx->d_succ;
+    return g;
 }
 
 }  // namespace
@@ -356,7 +384,14 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     const uint32_t N = ctx->N;
     const uint32_t n_sides = 2 * N;
     if (S->n_unitigs != N || !S->parent) {
+        // (the colour gate's arrays belong to the graph, not to a pass: they survive)
+        uint64_t *fm = S->full_mask, *stt = S->size_total;
+        uint32_t *nf = S->n_full_enc;
+        const uint32_t nc = S->n_colors;
+        S->full_mask = S->size_total = nullptr;
+        S->n_full_enc = nullptr;
         S->release();   // (resets the fields, the object stays)
+        S->full_mask = fm; S->size_total = stt; S->n_full_enc = nf; S->n_colors = nc;
         if (hipMalloc(reinterpret_cast<void **>(&S->bad), 16) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&S->parent), (size_t)n_sides * 4 + 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&S->first), (size_t)n_sides * 4 + 4) != hipSuccess ||
@@ -397,11 +432,12 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
         d_rec = S->up_rec;
         d_pool = S->up_pool;
     }
+    const pfh::ColourGate gate = gate_of(ctx, S);
     // a second call for the same K-BFS call (the caller adds the traversals it walked itself once they are done) adds only those
     const bool again = !records && !reset && S->added_call == ctx->bfs_call_id;
     if (!records) S->added_call = ctx->bfs_call_id;
     if (n_records && !again) {
-        k_cc_edges<<<(unsigned)((n_records + 255) / 256), 256, 0, st>>>(d_rec, n_records, d_pool, pool_len, n_sides, S->parent, S->first, S->multi, S->bad);
+        k_cc_edges<<<(unsigned)((n_records + 255) / 256), 256, 0, st>>>(d_rec, n_records, d_pool, pool_len, n_sides, S->parent, S->first, S->multi, S->bad, gate);
         PF_HIP(hipGetLastError());
     }
     if (n_extra) {
@@ -416,7 +452,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
         d_xpool = xp.p;
         PF_HIP(hipMemcpyAsync(d_xrec, extra, n_extra * sizeof(pf_bfs_record), hipMemcpyDefault, st));
         if (extra_pool_len) PF_HIP(hipMemcpyAsync(d_xpool, extra_pool, extra_pool_len * 4, hipMemcpyDefault, st));
-        k_cc_edges_long<<<dim3((unsigned)n_extra, 64), 256, 0, st>>>(d_xrec, n_extra, d_xpool, extra_pool_len, n_sides, S->parent, S->first, S->multi, S->bad);
+        k_cc_edges_long<<<dim3((unsigned)n_extra, 64), 256, 0, st>>>(d_xrec, n_extra, d_xpool, extra_pool_len, n_sides, S->parent, S->first, S->multi, S->bad, gate);
         PF_HIP(hipGetLastError());
         PF_HIP(hipStreamSynchronize(st));   // (the temporaries are freed on return)
         // the records themselves stay (32 B each): pf_replay_device leaves their components to the caller, who holds their lists
@@ -483,6 +519,27 @@ int pf_replay_order(pf_ctx *ctx, uint32_t n_classes, uint32_t *order, uint32_t *
     return PF_OK;
 }
 
+// colored path: what the colour gate of the accept commit reads (src/CCDBG.cpp:2530-2621), per unitig; n_colors == 0 removes it
+int pf_replay_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_mask, const uint64_t *size_total, const uint32_t *n_full_enc) {
+    if (!ctx || !ctx->has_adj || n_colors > 64 || (n_colors && (!full_mask || !size_total || !n_full_enc))) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (!ctx->cc) ctx->cc = new CcState();
+    CcState *S = static_cast<CcState *>(ctx->cc);
+    for (void **p : {(void **)&S->full_mask, (void **)&S->size_total, (void **)&S->n_full_enc})
+        if (*p) { (void)hipFree(*p); *p = nullptr; }
+    S->n_colors = 0;
+    if (!n_colors) return PF_OK;
+    const size_t N = ctx->N;
+    PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->full_mask), N * 8));
+    PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->size_total), N * 8));
+    PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->n_full_enc), N * 4));
+    PF_HIP(hipMemcpy(S->full_mask, full_mask, N * 8, hipMemcpyDefault));
+    PF_HIP(hipMemcpy(S->size_total, size_total, N * 8, hipMemcpyDefault));
+    PF_HIP(hipMemcpy(S->n_full_enc, n_full_enc, N * 4, hipMemcpyDefault));
+    S->n_colors = n_colors;
+    return PF_OK;
+}
+
 // ---- the commits on the device: see the kernels above ----
 int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries) {
     if (!ctx || !ctx->cc || !n_big || !big_entries) return PF_ERR_ARG;
@@ -536,7 +593,8 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     size_t have = S->sort_tmp_bytes;
     PF_HIP(rocprim::radix_sort_pairs(S->sort_tmp, have, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, st));
     FlagsDevice acc{S->f2, plus, minus};
-    k_replay_small<<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size);
+    if (S->n_colors) k_replay_small<pfh::ColourGate><<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size, gate_of(ctx, S));
+    else k_replay_small<pfh::NoColours><<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size, pfh::NoColours{});
     PF_HIP(hipGetLastError());
     // the records left to the caller, ascending
     DevTmp<uint8_t> flag_;

@@ -28,7 +28,7 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
-                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints",
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints", "pfh_colors_check_footprints",
                     "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_set_replay_threads", "pfh_set_write_super_bubble", "pfh_ploidy_select", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
                     "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
                     "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
@@ -116,6 +116,8 @@ def load_library() -> C.CDLL:
     L.pfh_side_components.restype = None
     L.pfh_replay_check_footprints.argtypes = [vp, u64, vp, C.c_uint32, C.c_uint32, u64, C.POINTER(u64)]
     L.pfh_replay_check_footprints.restype = u64
+    L.pfh_colors_check_footprints.argtypes = [vp, vp, vp, u64, vp, C.c_uint32, u64, C.POINTER(u64)]
+    L.pfh_colors_check_footprints.restype = u64
     L.pfh_replay_state.argtypes = [vp, vp, vp, vp]
     L.pfh_bifrost_kmer_hash.restype = C.c_uint64
     L.pfh_bifrost_kmer_hash.argtypes = [C.c_uint64, C.c_uint64]
@@ -218,6 +220,16 @@ class Colors:
             self.close()
         except Exception:
             pass
+
+    def check_footprints(self, succ: np.ndarray, records: np.ndarray, pool: np.ndarray, complex_size: int = 8, slice_len: int = 0):
+        """the footprint check of the parallel commits with the colored gate: (accesses outside the component, first such record)"""
+        succ = np.ascontiguousarray(succ, dtype=np.uint32)
+        records = np.ascontiguousarray(records)
+        pool = np.ascontiguousarray(pool, dtype=np.uint32) if len(pool) else np.zeros(1, dtype=np.uint32)
+        first = C.c_uint64()
+        bad = self.L.pfh_colors_check_footprints(self.h, succ.ctypes.data, records.ctypes.data if len(records) else None, len(records), pool.ctypes.data,
+                                                 complex_size, slice_len, C.byref(first))
+        return int(bad), (None if first.value == 0xFFFFFFFFFFFFFFFF else int(first.value))
 
     def unitig(self, u: int):
         """(presence[colour, kmer] uint8, UnitigColors::size(um), n_full_enc)"""

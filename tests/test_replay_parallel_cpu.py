@@ -8,7 +8,7 @@ import sys
 import numpy as np
 import pytest
 
-from conftest import ROOT, golden_cases, load_case
+from conftest import ROOT, colored_cases, golden_cases, load_case
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle  # noqa: E402
@@ -136,5 +136,41 @@ def test_the_check_notices_a_missing_rule(dropped):
         "    hits += hostapi.check_footprints(rec, pool, n, 8, 0)[0] > 0\n"
         "print('hits', hits)\n" % (ROOT, os.path.join(ROOT, "tests")))
     out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PF_CC_WITHOUT=str(dropped)), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-500:]
+    assert int(out.stdout.split()[-1]) > 0
+
+
+@pytest.mark.parametrize("case", colored_cases())
+def test_colored_commits_stay_inside_their_components(case):
+    """CCDBG's accept commit may mark an endpoint whose colour set is incomplete NON_SUPER -- a write to the whole unitig by a record
+    that came in through one side: the components join both sides of such endpoints, and with that the model holds for the
+    colored commits too (which is what lets them run on the device, one thread per component)."""
+    meta = load_case(case)
+    o = pyoracle.Oracle(meta["gfa"], None)
+    succ, pred = o.adjacency()
+    n = len(succ) // 2
+    rec, pool = hostapi.host_walk_range(succ, pred, 0, n)
+    col = hostapi.Colors(meta["gfa"], meta["colors"])
+    z = int(meta["opts"]["-z"])
+    for slice_len in (0, 53, max(1, len(rec) // 3)):
+        bad, first = col.check_footprints(succ, rec, pool, z, slice_len)
+        assert bad == 0, "record %s of %s touches a side outside its component (slices of %d)" % (first, case, slice_len)
+
+
+def test_the_check_notices_the_missing_colour_rule():
+    """... and without the incomplete-endpoint rule the fixture with partial colours is caught"""
+    import subprocess
+    code = (
+        "import sys; sys.path.insert(0, %r); sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import pyoracle\n"
+        "from conftest import load_case\n"
+        "from ploidyfrost_amd import hostapi\n"
+        "meta = load_case('col4_mix')\n"
+        "o = pyoracle.Oracle(meta['gfa'], None)\n"
+        "succ, pred = o.adjacency()\n"
+        "rec, pool = hostapi.host_walk_range(succ, pred, 0, len(succ) // 2)\n"
+        "print('bad', hostapi.Colors(meta['gfa'], meta['colors']).check_footprints(succ, rec, pool, int(meta['opts']['-z']), 0)[0])\n"
+        % (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")))
+    out = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, PF_CC_WITHOUT="8"), capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-500:]
     assert int(out.stdout.split()[-1]) > 0
