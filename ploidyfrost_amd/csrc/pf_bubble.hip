@@ -410,6 +410,8 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
     // ---- round 0 ---------------------------------------------------------------------------------
     int cur = 0;
     uint32_t n_kept = 0, used[2] = {0, 0};
+    bool shortcut_scores = false;   // the scores make a single mismatch on the diagonal the strict optimum (proof below)
+    bool gapless = false;           // the one kept alignment is the paths themselves, stacked (every round so far took the shortcut)
     {
         const uint32_t m = paths[0].len, n = paths[1].len;
         if (job_bytes(m, n) > p.work_bytes) return 1;
@@ -423,7 +425,8 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
         // If D - 2G - 2b > 0 every diagonal cell carries the single flag DIAG, the traceback finds exactly one
         // alignment -- the two strings unchanged -- and all the tie-breaking machinery has nothing to decide.
         bool snp_only = false;
-        if (p.integral && m == n && p.M >= p.D && p.M + 1 >= 2 * (p.G + 1) && p.D - 2 * p.G - 2 > 0) {
+        shortcut_scores = p.integral && p.M >= p.D && p.M + 1 >= 2 * (p.G + 1) && p.D - 2 * p.G - 2 > 0;
+        if (shortcut_scores && m == n) {
             const char *x = path_ptr(0), *y = path_ptr(1);
             uint32_t diff = 0;
             for (uint32_t t = lane; t < m; t += WAVE) diff += x[t] != y[t];
@@ -478,6 +481,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
             used[cur] = 2 * m;
             nh = 0;
             n_kept = 1;
+            gapless = true;
             aln_sync();
         } else {
         if (!align_job(nw_base, path_ptr(0), path_ptr(1), m, n, p.M, p.D, p.G, p.integral, st, nh, tu, gu, p.prof)) return 1;
@@ -505,6 +509,30 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
         int best_total = INT_MIN;
         const char *pi = path_ptr(i);
         const uint32_t li = paths[i].len;
+        if (gapless && n_kept == 1 && shortcut_scores && list[cur][0].len == li) {
+            // The shortcut of round 0 again: row 0 is path 0 itself (no gap so far) and path i is as long and differs from it in
+            // exactly one base -- needlemanWunch(row 0, path i) then has the single optimal alignment "both unchanged" (the
+            // same proof: h = 1), the one candidate re-opens no gap in the older rows and survives every ranking alone.
+            // The new alignment is the old one with path i underneath.
+            const MsaRef M = list[cur][0];
+            const char *mrows = arena[cur] + M.off;
+            uint32_t diff = 0;
+            for (uint32_t t = lane; t < li; t += WAVE) diff += mrows[t] != pi[t];
+            if (read_lane((uint32_t)wave_sum_u64(diff), 0) == 1) {
+                const uint32_t rows = i + 1;
+                if ((uint64_t)rows * li > C.arena || C.list < 1) return 1;
+                char *dst = arena[nxt];
+                for (uint32_t t = lane; t < i * li; t += WAVE) dst[t] = mrows[t];
+                for (uint32_t t = lane; t < li; t += WAVE) dst[(size_t)i * li + t] = pi[t];
+                if (lane == 0) list[nxt][0] = MsaRef{0, li, rows};
+                used[nxt] = rows * li;
+                aln_sync();
+                cur = nxt;
+                n_kept = 1;
+                continue;
+            }
+        }
+        gapless = false;
         for (uint32_t kk = 0; kk < n_kept; ++kk) {
             const MsaRef M = list[cur][kk];
             const char *mrows = arena[cur] + M.off;
