@@ -356,6 +356,14 @@ int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *ou
  * tails are paid once) can be formatted, fetched and written in pieces.  var_count_base is the same for every piece: the bubbles
  * called before the aligned batch; out->n_called = those called inside the piece. */
 int pf_call_text_range(pf_ctx *, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out);
+/* The two with a choice of where the aligned batch lies ("lane" 0 or 1; the calls above use lane 0): the rows of one range of
+ * bubbles are formatted from one host thread (pf_call_text_range_lane: a stream, scratch and counters of its own) while another
+ * aligns the next range into the other lane -- the copy of the text to the host, the slowest stage of a large pass, then runs
+ * beside the alignment kernels instead of after them.  At most one call of each kind at a time, never on the same lane. */
+int pf_call_align_lane(pf_ctx *, int lane, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch,
+                       double gap, pf_call_result *out);
+int pf_call_text_range_lane(pf_ctx *, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base,
+                            pf_call_result *out);
 /* Copies the first len bytes of one stream of a slab to dst (host memory, pinned for speed) on a stream of its own: may be
  * called from another thread while pf_call_run fills the other slab. */
 int pf_call_fetch(pf_ctx *, int slab, int stream, char *dst, uint64_t len);

@@ -331,72 +331,140 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     } prefault_guard{prefault};
     const auto t_dev = clk::now();
     // Alignment in large launches (every kernel's tail -- one wavefront finishing the heaviest bubble -- is paid once per
-    // launch), text in pieces of CHUNK bubbles that are fetched and written while the next piece is formatted.
-    const uint64_t ALIGN = std::min<uint64_t>((uint64_t)CHUNK * std::max<size_t>(align_pieces_, 1), (uint64_t)1 << 24);
-    size_t b = 0;   // text piece number: slabs alternate
-    for (uint64_t a0 = 0; a0 < n_tasks && rc == PF_OK; a0 += ALIGN) {
+    // launch), text in pieces of CHUNK bubbles that are fetched and written while the next piece is formatted.  A long list is
+    // aligned in a few ranges, alternately into the two result lanes of the context: the formatter thread turns range r into
+    // text -- and the fetcher moves it over PCIe, the slowest stage -- while this thread aligns range r + 1.
+    uint64_t ALIGN = std::min<uint64_t>((uint64_t)CHUNK * std::max<size_t>(align_pieces_, 1), (uint64_t)1 << 24);
+    {
+        static const int ranges_env = [] { const char *e = getenv("PF_ALIGN_RANGES"); return e ? atoi(e) : 0; }();   // measurements
+        const uint64_t pieces = (n_tasks + CHUNK - 1) / CHUNK;
+        const uint64_t n_ranges = ranges_env > 0 ? (uint64_t)ranges_env : (pieces >= 4 ? 2 : 1);
+        if (n_ranges > 1) ALIGN = std::min<uint64_t>(ALIGN, std::max<uint64_t>(1, (pieces + n_ranges - 1) / n_ranges) * CHUNK);
+    }
+    struct Range {
+        int lane;
+        uint64_t n, var_base;
+    };
+    std::deque<Range> aligned;     // aligned, not yet formatted
+    size_t ranges_formatted = 0;   // ranges whose last piece has been formatted: their lane may be aligned into again
+    bool align_done = false;
+    std::thread formatter([&] {
+        struct Last {   // on every way out: the fetcher learns that no further piece will come
+            std::mutex &mu;
+            std::condition_variable &cv;
+            bool &producer_done;
+            ~Last() {
+                { std::lock_guard<std::mutex> lk(mu); producer_done = true; }
+                cv.notify_all();
+            }
+        } last{mu, cv, producer_done};
+        try {
+        size_t b = 0;   // text piece number: slabs alternate
+        for (;;) {
+            Range r;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv.wait(lk, [&] { return stop || !aligned.empty() || align_done; });
+                if (stop || aligned.empty()) return;
+                r = aligned.front();
+                aligned.pop_front();
+            }
+            for (uint64_t p0 = 0; p0 < r.n; p0 += CHUNK, ++b) {
+                {   // slab b % 2 was last used by piece b - 2
+                    std::unique_lock<std::mutex> lk(mu);
+                    cv.wait(lk, [&] { return stop || b < fetched + 2; });
+                    if (stop) return;
+                }
+                Done d;
+                d.slab = (int)(b & 1);
+                const uint64_t count = std::min<uint64_t>(CHUNK, r.n - p0);
+                const int st = pf_call_text_range_lane(ctx_, r.lane, d.slab, p0, count, r.var_base, &d.res);
+                if (st != PF_OK) {
+                    { std::lock_guard<std::mutex> lk(mu); if (rc == PF_OK) { rc = st; rc_err = pf_last_error(ctx_); } stop = true; }
+                    cv.notify_all();
+                    return;
+                }
+                if (trace) fprintf(stderr, "[ploidy]   piece %zu formatted on the device %.2f ms\n", b, since(t_all) * 1e3);
+                if (b == 0 && write_files_) {
+                    // first piece of a pass: fresh result files get their final size (extrapolated from this piece, cut to the true
+                    // one at the end) and their pages now, on helper threads, instead of fault by fault under the writer
+                    const double scale = 1.05 * (double)n_tasks / (double)std::max<uint64_t>(1, count);
+                    std::vector<std::pair<int, uint64_t>> fresh;
+                    for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+                        const uint64_t est = (uint64_t)((double)d.res.text_len[s] * scale) + 4096;
+                        if (d.res.text_len[s] && maps[s].reserve(est) == 0) fresh.push_back({s, est});
+                    }
+                    if (!fresh.empty())
+                        prefault = std::thread([maps, fresh, T] {
+                            constexpr uint64_t STEP = 4u << 20;
+                            std::vector<std::pair<int, uint64_t>> spans;   // (stream, offset) in 4 MB steps, files interleaved
+                            uint64_t longest = 0;
+                            for (auto &f : fresh) longest = std::max(longest, f.second);
+                            for (uint64_t at = 0; at < longest; at += STEP)
+                                for (auto &f : fresh)
+                                    if (at < f.second) spans.push_back({f.first, at});
+                            parallel_chunks(spans.size(), 1, std::max(2u, T / 2), [&](size_t i, size_t, size_t) {
+                                const int s = spans[i].first;
+                                uint64_t end = spans[i].second + STEP;
+                                for (auto &f : fresh) if (f.first == s) end = std::min(end, f.second);
+                                maps[s].populate(spans[i].second, end);
+                            });
+                        });
+                }
+                for (int a = 0; a < 4; ++a) allele_[a] += d.res.allele[a];
+                core_cov_ += d.res.core_cov;
+                core_num_ += d.res.core_num;
+                { std::lock_guard<std::mutex> lk(mu); ready.push_back(d); }
+                cv.notify_all();
+            }
+            { std::lock_guard<std::mutex> lk(mu); ++ranges_formatted; }
+            cv.notify_all();
+        }
+        } catch (const std::exception &e) { thread_failed("formatting the result rows", e); }
+    });
+    struct FormatterGuard {  // joined on every way out, before the prefault thread it may have started
+        std::thread &t;
+        std::mutex &mu;
+        std::condition_variable &cv;
+        bool &stop;
+        ~FormatterGuard() {
+            if (!t.joinable()) return;
+            { std::lock_guard<std::mutex> lk(mu); stop = true; }
+            cv.notify_all();
+            t.join();
+        }
+    } formatter_guard{formatter, mu, cv, stop};
+    size_t ri = 0;
+    for (uint64_t a0 = 0; a0 < n_tasks; a0 += ALIGN, ++ri) {
         const uint64_t a1 = std::min<uint64_t>(n_tasks, a0 + ALIGN);
+        {   // lane ri % 2 was last read by the text of range ri - 2
+            std::unique_lock<std::mutex> lk(mu);
+            cv.wait(lk, [&] { return stop || ri < ranges_formatted + 2; });
+            if (stop) break;
+        }
         pf_call_result ar;
-        int st = pf_call_align(ctx_, a0, a1, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch, sc_.gap, &ar);
-        if (st != PF_OK) { rc = st; rc_err = pf_last_error(ctx_); break; }
+        const int st = pf_call_align_lane(ctx_, (int)(ri & 1), a0, a1, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch, sc_.gap, &ar);
+        if (st != PF_OK) {
+            { std::lock_guard<std::mutex> lk(mu); if (rc == PF_OK) { rc = st; rc_err = pf_last_error(ctx_); } stop = true; }
+            cv.notify_all();
+            break;
+        }
         if (trace) fprintf(stderr, "[ploidy]   %llu bubbles aligned on the device %.2f ms\n", (unsigned long long)(a1 - a0), since(t_all) * 1e3);
         times_.tasks += a1 - a0;
         times_.align_jobs += ar.align_jobs;
         times_.snp_jobs += ar.snp_jobs; times_.pair_jobs += ar.pair_jobs; times_.wave_jobs += ar.wave_jobs;
         times_.site_strings += ar.site_strings;
-        for (uint64_t p0 = 0; p0 < a1 - a0; p0 += CHUNK, ++b) {
-            {   // slab b % 2 was last used by piece b - 2
-                std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || b < fetched + 2; });
-                if (stop) break;
-            }
-            Done d;
-            d.slab = (int)(b & 1);
-            st = pf_call_text_range(ctx_, d.slab, p0, std::min<uint64_t>(CHUNK, a1 - a0 - p0), var_count, &d.res);
-            if (st != PF_OK) { rc = st; rc_err = pf_last_error(ctx_); break; }
-            if (trace) fprintf(stderr, "[ploidy]   piece %zu formatted on the device %.2f ms\n", b, since(t_all) * 1e3);
-            if (b == 0 && write_files_ && a0 == 0) {
-                // first piece of a pass: fresh result files get their final size (extrapolated from this piece, cut to the true
-                // one at the end) and their pages now, on helper threads, instead of fault by fault under the writer
-                const double scale = 1.05 * (double)n_tasks / (double)std::max<uint64_t>(1, std::min<uint64_t>(CHUNK, a1 - a0 - p0));
-                std::vector<std::pair<int, uint64_t>> fresh;
-                for (int s = 0; s < PF_CALL_STREAMS; ++s) {
-                    const uint64_t est = (uint64_t)((double)d.res.text_len[s] * scale) + 4096;
-                    if (d.res.text_len[s] && maps[s].reserve(est) == 0) fresh.push_back({s, est});
-                }
-                if (!fresh.empty())
-                    prefault = std::thread([maps, fresh, T] {
-                        constexpr uint64_t STEP = 4u << 20;
-                        std::vector<std::pair<int, uint64_t>> spans;   // (stream, offset) in 4 MB steps, files interleaved
-                        uint64_t longest = 0;
-                        for (auto &f : fresh) longest = std::max(longest, f.second);
-                        for (uint64_t at = 0; at < longest; at += STEP)
-                            for (auto &f : fresh)
-                                if (at < f.second) spans.push_back({f.first, at});
-                        parallel_chunks(spans.size(), 1, std::max(2u, T / 2), [&](size_t i, size_t, size_t) {
-                            const int s = spans[i].first;
-                            uint64_t end = spans[i].second + STEP;
-                            for (auto &f : fresh) if (f.first == s) end = std::min(end, f.second);
-                            maps[s].populate(spans[i].second, end);
-                        });
-                    });
-            }
-            for (int a = 0; a < 4; ++a) allele_[a] += d.res.allele[a];
-            core_cov_ += d.res.core_cov;
-            core_num_ += d.res.core_num;
-            { std::lock_guard<std::mutex> lk(mu); ready.push_back(d); }
-            cv.notify_all();
-        }
+        { std::lock_guard<std::mutex> lk(mu); aligned.push_back(Range{(int)(ri & 1), a1 - a0, var_count}); }
+        cv.notify_all();
         var_count += ar.n_called;
-        { std::lock_guard<std::mutex> lk(mu); if (stop) break; }
     }
-    times_.align_s = since(t_dev);
     {
         std::lock_guard<std::mutex> lk(mu);
-        producer_done = true;
-        if (rc != PF_OK) stop = true;
+        align_done = true;
     }
     cv.notify_all();
+    formatter.join();
+    times_.align_s = since(t_dev);
     fetcher.join();
     writer.join();
     if (prefault.joinable()) prefault.join();

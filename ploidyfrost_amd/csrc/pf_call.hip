@@ -119,8 +119,18 @@ struct CallState {
     uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
     // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, pair_scr, res, otext, osites, ogroups, oilen, sv_off, sv, has, vc, sizes, offs, totals,
-        scan_tmp2, paths_scr, sites_scr;
+    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, pair_scr, has, scan_tmp2, paths_scr, sites_scr;
+    // what pf_call_align leaves resident for pf_call_text_range: two sets ("lanes"), so that the rows of one range of bubbles
+    // can be formatted, fetched and written while the next range is aligned into the other set
+    struct AlignOut {
+        DevBuf res, otext, osites, ogroups, oilen, sv_off, sv, vc;
+        uint64_t t0 = 0;
+        uint32_t nb = 0;
+        pf_call_result cur = {};
+    } lane[2];
+    // K-TEXT's own scratch, counters and stream: it may run from another host thread beside pf_call_align (other lane)
+    DevBuf sizes, offs, totals, tcounters, tscan;
+    hipStream_t text_stream = nullptr;
     uint64_t path_pool = 0, text_pool = 0, sv_pool = 0;   // capacities learnt from earlier batches
     uint64_t otext_cap = 0, osites_cap = 0, ogroups_cap = 0, oilen_cap = 0;
     // output slabs: two sets, so that one can be fetched while the next batch is formatted
@@ -130,16 +140,15 @@ struct CallState {
     // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
-    // the batch pf_call_align left resident for pf_call_text
     bool mt_format = false;   // pf_call_set_format
-    uint64_t cur_t0 = 0;
-    uint32_t cur_nb = 0;
-    pf_call_result cur = {};
     void release_all() {
         DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &pair_scr, &res, &otext, &osites, &ogroups, &oilen, &sv_off, &sv, &has, &vc, &sizes, &offs,
-                         &totals, &scan_tmp2, &paths_scr, &sites_scr};
+                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &pair_scr, &has, &sizes, &offs,
+                         &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
+        for (AlignOut &o : lane)
+            for (DevBuf *b : {&o.res, &o.otext, &o.osites, &o.ogroups, &o.oilen, &o.sv_off, &o.sv, &o.vc}) b->release();
+        if (text_stream) { (void)hipStreamDestroy(text_stream); text_stream = nullptr; }
         for (auto &s : out)
             for (DevBuf &b : s) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
@@ -1808,14 +1817,15 @@ int pf_call_select(pf_ctx *ctx, const uint32_t *side_index, uint64_t n_tasks) {
 }
 
 // one batch, first half: bubbles [t0, t1) of the selection up to the site coverages; out->n_called tells how far var_count advances
-int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
-                  pf_call_result *out) {
-    if (!ctx || !out) return PF_ERR_ARG;
+int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
+                       pf_call_result *out) {
+    if (!ctx || !out || lane < 0 || lane > 1) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S || t0 > t1 || t1 > S->n_tasks) { ctx->err = "pf_call_align: range outside the selection"; return PF_ERR_ARG; }
     memset(out, 0, sizeof(*out));
-    S->cur_nb = 0;
-    S->cur_t0 = t0;
+    CallState::AlignOut &O = S->lane[lane];
+    O.nb = 0;
+    O.t0 = t0;
     if (t1 == t0) return PF_OK;
     if (t1 - t0 > (1u << 24)) { ctx->err = "pf_call_align: at most 2^24 bubbles per batch"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
@@ -1828,11 +1838,10 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
     NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
     NEED(S->queues, (size_t)NQ * nb * 4);
     NEED(S->blist, (size_t)nb * 4);
-    NEED(S->res, (size_t)nb * sizeof(pf_bubble_result));
-    NEED(S->sv_off, (size_t)nb * 8);
+    NEED(O.res, (size_t)nb * sizeof(pf_bubble_result));
+    NEED(O.sv_off, (size_t)nb * 8);
     NEED(S->has, (size_t)nb * 4);
-    NEED(S->vc, (size_t)nb * 4);
-    NEED(S->totals, 16 * 8);
+    NEED(O.vc, (size_t)nb * 4);
     CallCounters *d_cnt = S->counters.as<CallCounters>();
     CallCounters hc;
     // K-PATHS scratch: stacks sized by the complex size (a non-complex bubble has at most that many vertices)
@@ -1864,17 +1873,17 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, nb / 2 + 64);
         NEED(S->bpath, ((size_t)4 * nb + path_cap) * sizeof(pf_bubble_path));
         NEED(S->ptext, text_cap);
-        NEED(S->otext, cap_text);
-        NEED(S->osites, cap_sites * sizeof(pf_bubble_site));
-        NEED(S->ogroups, cap_groups);
-        NEED(S->oilen, cap_ilen * 4);
+        NEED(O.otext, cap_text);
+        NEED(O.osites, cap_sites * sizeof(pf_bubble_site));
+        NEED(O.ogroups, cap_groups);
+        NEED(O.oilen, cap_ilen * 4);
         unsigned long long *d_heads = bubble_pool_heads(ctx);
         if (!d_heads) return PF_ERR_HIP;
         PF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(CallCounters), st));
         PF_HIP(hipMemsetAsync(d_heads, 0, 32, st));
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
-        pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = S->res.as<pf_bubble_result>();
+        pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = O.res.as<pf_bubble_result>();
         pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), nb};
         pa.snp_ok = snp_ok;
         pa.pair_ok = pair_tier ? 1 : 0;
@@ -1909,8 +1918,8 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         if (snp_ok) {
             SnpArgs sn;
             sn.ct = pa.ct; sn.kept = pa.kept; sn.t0 = t0; sn.nb = nb; sn.slist = pa.lists.slist; sn.seq = ctx->d_seq; sn.off = ctx->d_off;
-            sn.len = ctx->d_len; sn.res = pa.res; sn.otext = S->otext.as<char>(); sn.text_cap = cap_text;
-            sn.osites = S->osites.as<pf_bubble_site>(); sn.site_cap = cap_sites; sn.ogroups = S->ogroups.as<uint8_t>(); sn.group_cap = cap_groups;
+            sn.len = ctx->d_len; sn.res = pa.res; sn.otext = O.otext.as<char>(); sn.text_cap = cap_text;
+            sn.osites = O.osites.as<pf_bubble_site>(); sn.site_cap = cap_sites; sn.ogroups = O.ogroups.as<uint8_t>(); sn.group_cap = cap_groups;
             sn.heads = d_heads; sn.lists = pa.lists; sn.pair_ok = pa.pair_ok; sn.cnt = d_cnt;
             ctx_begin(ctx, PF_K_CALL_SNP);
             k_call_snp<<<(nb + 255) / 256, 256, 0, st>>>(sn);   // (the list length is on the device: surplus threads leave at once)
@@ -1924,9 +1933,9 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
                            std::fabs(mismatch) < 1e6 && std::fabs(gap) < 1e6) ? 1 : 0;
             static const bool pair_dfs = [] { const char *e = getenv("PF_PAIR_DFS"); return e && e[0] == '1'; }();  // measurements
             pr.unique_only = pair_dfs ? 0 : 1;
-            pr.scratch = S->pair_scr.as<uint8_t>(); pr.res = pa.res; pr.otext = S->otext.as<char>(); pr.text_cap = cap_text;
-            pr.osites = S->osites.as<pf_bubble_site>(); pr.site_cap = cap_sites; pr.ogroups = S->ogroups.as<uint8_t>(); pr.group_cap = cap_groups;
-            pr.oilen = S->oilen.as<uint32_t>(); pr.ilen_cap = cap_ilen; pr.heads = d_heads; pr.lists = pa.lists; pr.cnt = d_cnt;
+            pr.scratch = S->pair_scr.as<uint8_t>(); pr.res = pa.res; pr.otext = O.otext.as<char>(); pr.text_cap = cap_text;
+            pr.osites = O.osites.as<pf_bubble_site>(); pr.site_cap = cap_sites; pr.ogroups = O.ogroups.as<uint8_t>(); pr.group_cap = cap_groups;
+            pr.oilen = O.oilen.as<uint32_t>(); pr.ilen_cap = cap_ilen; pr.heads = d_heads; pr.lists = pa.lists; pr.cnt = d_cnt;
             static const bool pair_stats = getenv("PF_PAIR_STATS") != nullptr;
             DevTmp<unsigned long long> prof_;
             pr.prof = nullptr;
@@ -1994,8 +2003,8 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         for (int c = 0; c <= kBubLdsClasses; ++c) BL.n_cls[c] = hc.q_n[2 * c] + hc.q_n[2 * c + 1];
         BL.max_need = hc.max_need; BL.retry_need = hc.retry_need;
         BL.match = match; BL.mismatch = mismatch; BL.gap = gap;
-        BL.res = S->res.as<pf_bubble_result>(); BL.otext = S->otext.as<char>(); BL.osites = S->osites.as<pf_bubble_site>();
-        BL.ogroups = S->ogroups.as<uint8_t>(); BL.oilen = S->oilen.as<uint32_t>();
+        BL.res = O.res.as<pf_bubble_result>(); BL.otext = O.otext.as<char>(); BL.osites = O.osites.as<pf_bubble_site>();
+        BL.ogroups = O.ogroups.as<uint8_t>(); BL.oilen = O.oilen.as<uint32_t>();
         BL.text_cap = cap_text; BL.site_cap = cap_sites; BL.group_cap = cap_groups; BL.ilen_cap = cap_ilen;
         BL.keep_heads = true;
         const int bst = bubble_launch(ctx, BL, heads);
@@ -2022,14 +2031,14 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
         NEED(S->sites_scr, sites_per_wave * sites_grid);
         for (int attempt = 0;; ++attempt) {
             const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * hc.n_branching + 1024);
-            NEED(S->sv, sv_cap * 8);
+            NEED(O.sv, sv_cap * 8);
             SiteArgs sa;
             sa.ct = S->ctask.as<CallTask>(); sa.kept = S->kept.as<uint32_t>(); sa.t0 = t0; sa.blist = S->blist.as<uint32_t>();
-            sa.res = S->res.as<pf_bubble_result>(); sa.otext = S->otext.as<char>(); sa.osites = S->osites.as<pf_bubble_site>();
-            sa.ogroups = S->ogroups.as<uint8_t>(); sa.k = k; sa.tab = ctx->d_tab; sa.mask = ctx->tab_cap - 1;
+            sa.res = O.res.as<pf_bubble_result>(); sa.otext = O.otext.as<char>(); sa.osites = O.osites.as<pf_bubble_site>();
+            sa.ogroups = O.ogroups.as<uint8_t>(); sa.k = k; sa.tab = ctx->d_tab; sa.mask = ctx->tab_cap - 1;
             sa.one_strand = ctx->tab_one_strand; sa.tab_exact = ctx->tab_exact; sa.low = S->low; sa.up = S->up; sa.ks = KS;
-            sa.scratch = S->sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = S->sv_off.as<uint64_t>();
-            sa.sv = S->sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
+            sa.scratch = S->sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
+            sa.sv = O.sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
             PF_HIP(hipMemsetAsync(&d_cnt->sites_next, 0, 4, st));
             PF_HIP(hipMemsetAsync(&d_cnt->sv_head, 0, 8, st));
             PF_HIP(hipMemsetAsync(&d_cnt->site_strings, 0, 8, st));
@@ -2052,44 +2061,53 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
             break;
         }
     } else {
-        NEED(S->sv, 16);
+        NEED(O.sv, 16);
     }
     out->site_strings = hc.site_strings;
 
     // ---- bubble numbering inside the batch ----
-    k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(S->res.as<pf_bubble_result>(), nb, S->has.as<uint32_t>());
+    k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(O.res.as<pf_bubble_result>(), nb, S->has.as<uint32_t>());
     size_t tmp1 = 0;
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, S->has.as<uint32_t>(), S->vc.as<uint32_t>(), (int)nb, st));
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
     NEED(S->scan_tmp, tmp1);
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(S->scan_tmp.p, tmp1, S->has.as<uint32_t>(), S->vc.as<uint32_t>(), (int)nb, st));
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(S->scan_tmp.p, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
     uint32_t n_called = 0;
-    PF_HIP(hipMemcpyAsync(&n_called, S->vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&n_called, O.vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     out->n_called = n_called;
-    S->cur_nb = nb;
-    S->cur = *out;
+    O.nb = nb;
+    O.cur = *out;
 #undef NEED
     return PF_OK;
 }
 
+int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
+                  pf_call_result *out) {
+    return pf_call_align_lane(ctx, 0, t0, t1, complex_size, match, mismatch, gap, out);
+}
+
 // one batch, second half: K-TEXT of the bubbles pf_call_align left resident, into slab 0 or 1
-int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
-    if (!ctx || !out || slab < 0 || slab > 1) return PF_ERR_ARG;
+// (any host thread: a stream, scratch and counters of its own, launch timing by place -- one pf_call_text_range at a time,
+// beside at most one pf_call_align_lane on the OTHER lane)
+int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
+    if (!ctx || !out || slab < 0 || slab > 1 || lane < 0 || lane > 1) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S) return PF_ERR_ARG;
-    if (first + count > S->cur_nb) { ctx->err = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
+    const CallState::AlignOut &O = S->lane[lane];
+    if (first + count > O.nb) { ctx->err = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
     for (int s = 0; s < N_STREAMS; ++s) S->out_len[slab][s] = 0;
-    *out = S->cur;
+    *out = O.cur;
     out->n_called = 0;
     if (count == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    if (!S->text_stream) PF_HIP(hipStreamCreateWithFlags(&S->text_stream, hipStreamNonBlocking));
+    hipStream_t st = S->text_stream;
     const uint32_t nb = (uint32_t)count;
-    const uint64_t t0 = S->cur_t0;
+    const uint64_t t0 = O.t0;
     {   // bubbles called inside the range: difference of the batch-wide running count
         uint32_t c[2] = {0, 0};
-        PF_HIP(hipMemcpyAsync(&c[1], S->vc.as<uint32_t>() + (first + count - 1), 4, hipMemcpyDeviceToHost, st));
-        if (first) PF_HIP(hipMemcpyAsync(&c[0], S->vc.as<uint32_t>() + (first - 1), 4, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipMemcpyAsync(&c[1], O.vc.as<uint32_t>() + (first + count - 1), 4, hipMemcpyDeviceToHost, st));
+        if (first) PF_HIP(hipMemcpyAsync(&c[0], O.vc.as<uint32_t>() + (first - 1), 4, hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
         out->n_called = c[1] - c[0];
     }
@@ -2097,25 +2115,28 @@ int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, ui
     NEED_TEXT(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
     const char *oom = "pf_call_text: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = oom; return PF_ERR_HIP; } } while (0)
-    CallCounters *d_cnt = S->counters.as<CallCounters>();
+    NEED(S->totals, 16 * 8);
+    NEED(S->tcounters, sizeof(CallCounters));
+    CallCounters *d_cnt = S->tcounters.as<CallCounters>();
     CallCounters hc;
     size_t tmp2 = 0;
     const size_t n_sizes = (size_t)N_STREAMS * (nb + 1);
     hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
-    NEED(S->scan_tmp, tmp2);
+    NEED(S->tscan, tmp2);
     PF_HIP(hipMemsetAsync(&d_cnt->allele[0], 0, 6 * 8, st));  // allele[4], core_cov, core_num
     FmtArgs fa;
     fa.ct = S->ctask.as<CallTask>(); fa.kept = S->kept.as<uint32_t>(); fa.t0 = t0; fa.j0 = (uint32_t)first; fa.nb = nb;
-    fa.res = S->res.as<pf_bubble_result>();
-    fa.otext = S->otext.as<char>(); fa.osites = S->osites.as<pf_bubble_site>(); fa.ogroups = S->ogroups.as<uint8_t>();
-    fa.oilen = S->oilen.as<uint32_t>(); fa.sv_off = S->sv_off.as<uint64_t>(); fa.sv = S->sv.as<double>(); fa.vc = S->vc.as<uint32_t>();
+    fa.res = O.res.as<pf_bubble_result>();
+    fa.otext = O.otext.as<char>(); fa.osites = O.osites.as<pf_bubble_site>(); fa.ogroups = O.ogroups.as<uint8_t>();
+    fa.oilen = O.oilen.as<uint32_t>(); fa.sv_off = O.sv_off.as<uint64_t>(); fa.sv = O.sv.as<double>(); fa.vc = O.vc.as<uint32_t>();
     fa.vc_base = var_count_base; fa.mt = S->mt_format ? 1 : 0; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
     for (int s = 0; s < N_STREAMS; ++s) fa.out[s] = nullptr;
-    ctx_begin(ctx, PF_K_CALL_FORMAT);
+    size_t at = 0;
+    ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
     k_call_format<false><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
-    ctx_end(ctx);
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
+    ctx_end_at(ctx, at, st);
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->tscan.p, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
     k_call_totals<<<1, 64, 0, st>>>(S->offs.as<uint64_t>(), S->sizes.as<uint32_t>(), nb, S->totals.as<uint64_t>());
     uint64_t totals[N_STREAMS + 1] = {};
     PF_HIP(hipMemcpyAsync(totals, S->totals.p, N_STREAMS * 8, hipMemcpyDeviceToHost, st));
@@ -2127,9 +2148,9 @@ int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, ui
         S->out_len[slab][s] = totals[s];
         out->text_len[s] = totals[s];
     }
-    ctx_begin(ctx, PF_K_CALL_FORMAT);
+    ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
     k_call_format<true><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
-    ctx_end(ctx);
+    ctx_end_at(ctx, at, st);
     ctx_units(ctx, PF_K_CALL_FORMAT, nb);
     PF_HIP(hipGetLastError());
     PF_HIP(hipStreamSynchronize(st));
@@ -2140,10 +2161,14 @@ int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, ui
     return PF_OK;
 }
 
+int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
+    return pf_call_text_range_lane(ctx, 0, slab, first, count, var_count_base, out);
+}
+
 int pf_call_text(pf_ctx *ctx, int slab, uint64_t var_count_base, pf_call_result *out) {
     if (!ctx || !ctx->call) return PF_ERR_ARG;
-    const int st = pf_call_text_range(ctx, slab, 0, ctx->call->cur_nb, var_count_base, out);
-    if (st == PF_OK) out->n_called = ctx->call->cur.n_called;
+    const int st = pf_call_text_range(ctx, slab, 0, ctx->call->lane[0].nb, var_count_base, out);
+    if (st == PF_OK) out->n_called = ctx->call->lane[0].cur.n_called;
     return st;
 }
 

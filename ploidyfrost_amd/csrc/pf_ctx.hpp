@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -128,6 +129,8 @@ struct pf_ctx {
     bool timing = false;
     std::vector<pf::TimedLaunch> launches;
     size_t side_launch = (size_t)-1;   // ctx_begin_on .. ctx_end_on
+    size_t main_launch = (size_t)-1;   // ctx_begin .. ctx_end
+    std::mutex launch_mu;              // `launches` is appended to by the thread that formats text as well (ctx_begin_at)
     uint64_t units[PF_K_COUNT_] = {};  // work items handed to the timed launches of each kernel (pf_kernel_units)
 };
 
@@ -138,6 +141,9 @@ int ctx_begin(pf_ctx *ctx, int kernel);
 void ctx_end(pf_ctx *ctx);
 int ctx_begin_on(pf_ctx *ctx, int kernel, hipStream_t stream);   // the same for a launch on another stream
 void ctx_end_on(pf_ctx *ctx, hipStream_t stream);
+// the same for a caller that keeps the place of its launch itself: any thread, any stream
+int ctx_begin_at(pf_ctx *ctx, int kernel, hipStream_t stream, size_t *at);
+void ctx_end_at(pf_ctx *ctx, size_t at, hipStream_t stream);
 inline void ctx_units(pf_ctx *ctx, int kernel, uint64_t n) { if (ctx->timing) ctx->units[kernel] += n; }
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
 int join_graph_counts(pf_ctx *ctx);

@@ -595,36 +595,55 @@ static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert",
                                                 "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
                                                 "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair"};
 
-int ctx_begin(pf_ctx *ctx, int kernel) {
-    if (!ctx->timing) return 0;
+static size_t launch_push(pf_ctx *ctx, int kernel, hipStream_t stream) {
     TimedLaunch tl;
     tl.kernel = kernel;
-    if (hipEventCreate(&tl.a) != hipSuccess || hipEventCreate(&tl.b) != hipSuccess) return 1;
-    hipEventRecord(tl.a, ctx->stream);
+    if (hipEventCreate(&tl.a) != hipSuccess || hipEventCreate(&tl.b) != hipSuccess) return (size_t)-1;
+    hipEventRecord(tl.a, stream);
+    hipEventRecord(tl.b, stream);   // (re-recorded when the launch is closed)
+    std::lock_guard<std::mutex> lk(ctx->launch_mu);
     ctx->launches.push_back(tl);
-    return 0;
+    return ctx->launches.size() - 1;
+}
+static void launch_close(pf_ctx *ctx, size_t at, hipStream_t stream) {
+    hipEvent_t b;
+    {
+        std::lock_guard<std::mutex> lk(ctx->launch_mu);
+        if (at >= ctx->launches.size()) return;
+        b = ctx->launches[at].b;
+    }
+    hipEventRecord(b, stream);
+}
+int ctx_begin(pf_ctx *ctx, int kernel) {
+    if (!ctx->timing) return 0;
+    ctx->main_launch = launch_push(ctx, kernel, ctx->stream);
+    return ctx->main_launch == (size_t)-1;
 }
 void ctx_end(pf_ctx *ctx) {
-    if (!ctx->timing || ctx->launches.empty()) return;
-    hipEventRecord(ctx->launches.back().b, ctx->stream);
+    if (!ctx->timing) return;
+    launch_close(ctx, ctx->main_launch, ctx->stream);
 }
 // a launch on a side stream: its pair of events is kept aside until ctx_end_on, so that launches on the main stream may be
 // bracketed in between
 int ctx_begin_on(pf_ctx *ctx, int kernel, hipStream_t stream) {
     if (!ctx->timing) return 0;
-    TimedLaunch tl;
-    tl.kernel = kernel;
-    if (hipEventCreate(&tl.a) != hipSuccess || hipEventCreate(&tl.b) != hipSuccess) return 1;
-    hipEventRecord(tl.a, stream);
-    hipEventRecord(tl.b, stream);   // (re-recorded by ctx_end_on)
-    ctx->launches.push_back(tl);
-    ctx->side_launch = ctx->launches.size() - 1;
-    return 0;
+    ctx->side_launch = launch_push(ctx, kernel, stream);
+    return ctx->side_launch == (size_t)-1;
 }
 void ctx_end_on(pf_ctx *ctx, hipStream_t stream) {
-    if (!ctx->timing || ctx->side_launch >= ctx->launches.size()) return;
-    hipEventRecord(ctx->launches[ctx->side_launch].b, stream);
+    if (!ctx->timing) return;
+    launch_close(ctx, ctx->side_launch, stream);
     ctx->side_launch = (size_t)-1;
+}
+int ctx_begin_at(pf_ctx *ctx, int kernel, hipStream_t stream, size_t *at) {
+    *at = (size_t)-1;
+    if (!ctx->timing) return 0;
+    *at = launch_push(ctx, kernel, stream);
+    return *at == (size_t)-1;
+}
+void ctx_end_at(pf_ctx *ctx, size_t at, hipStream_t stream) {
+    if (!ctx->timing) return;
+    launch_close(ctx, at, stream);
 }
 
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes) {
