@@ -336,11 +336,12 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     // text -- and the fetcher moves it over PCIe, the slowest stage -- while this thread aligns range r + 1.
     uint64_t ALIGN = std::min<uint64_t>((uint64_t)CHUNK * std::max<size_t>(align_pieces_, 1), (uint64_t)1 << 24);
     {
-        static const int ranges_env = [] { const char *e = getenv("PF_ALIGN_RANGES"); return e ? atoi(e) : 0; }();   // measurements
+        const int ranges_env = [] { const char *e = getenv("PF_ALIGN_RANGES"); return e ? atoi(e) : 0; }();   // measurements (read per pass: tools/ab_pass.py)
         const uint64_t pieces = (n_tasks + CHUNK - 1) / CHUNK;
         const uint64_t n_ranges = ranges_env > 0 ? (uint64_t)ranges_env : (pieces >= 4 ? 2 : 1);
         if (n_ranges > 1) ALIGN = std::min<uint64_t>(ALIGN, std::max<uint64_t>(1, (pieces + n_ranges - 1) / n_ranges) * CHUNK);
     }
+    const int first_env = [] { const char *e = getenv("PF_ALIGN_FIRST"); return e ? atoi(e) : 0; }();   // measurements: pieces in the first range
     struct Range {
         int lane;
         uint64_t n, var_base;
@@ -435,8 +436,8 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         }
     } formatter_guard{formatter, mu, cv, stop};
     size_t ri = 0;
-    for (uint64_t a0 = 0; a0 < n_tasks; a0 += ALIGN, ++ri) {
-        const uint64_t a1 = std::min<uint64_t>(n_tasks, a0 + ALIGN);
+    for (uint64_t a0 = 0, a1 = 0; a0 < n_tasks; a0 = a1, ++ri) {
+        a1 = std::min<uint64_t>(n_tasks, a0 + (first_env > 0 && ri == 0 ? (uint64_t)first_env * CHUNK : ALIGN));
         {   // lane ri % 2 was last read by the text of range ri - 2
             std::unique_lock<std::mutex> lk(mu);
             cv.wait(lk, [&] { return stop || ri < ranges_formatted + 2; });

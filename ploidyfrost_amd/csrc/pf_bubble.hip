@@ -803,10 +803,11 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
     // waves in flight: the kernel is a chain of dependent LDS / global accesses per bubble, so it wants
     // every wave slot the LDS budget allows (5 KiB class: 32 per CU by LDS, capped at 24)
-    // PF_BUBBLE_STREAMS=1 launches the size classes side by side on streams of their own, each with its slice of the scratch.
-    // Measured at 5 M unitigs: no gain (46.20 vs 46.26 ms per pass) -- the classes' tails are not what bounds the kernel, its
-    // instruction issue is -- so the classes run one after the other by default.
-    static const bool class_streams = [] { const char *e = getenv("PF_BUBBLE_STREAMS"); return e && e[0] == '1'; }();   // measurements
+    // The size classes run side by side on streams of their own, each with its slice of the scratch: every launch lasts at least
+    // as long as its slowest bubble (an 8-path bubble: 0.8 ms of dependent steps on one wavefront), and the three tails overlap.
+    // Measured with the passes of both settings alternating in one process (tools/ab_pass.py, 5 M unitigs, two align ranges):
+    // 28.1 -> 26.0 ms per pass.  PF_BUBBLE_STREAMS=0: one after the other.
+    const bool class_streams = [] { const char *e = getenv("PF_BUBBLE_STREAMS"); return !(e && e[0] == '0'); }();   // (read per call: tools/ab_pass.py)
     int grids[kBubLdsClasses];
     uint64_t waves_total = 0;
     for (int c = 0; c < kBubLdsClasses; ++c) {

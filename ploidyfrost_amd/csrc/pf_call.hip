@@ -1974,14 +1974,21 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         S->ogroups_cap = std::max(S->ogroups_cap, cap_groups); S->oilen_cap = std::max(S->oilen_cap, cap_ilen);
         S->path_pool = std::max(S->path_pool, path_cap);
         S->text_pool = std::max(S->text_pool, text_cap);
+        static const bool trace_retry = getenv("PF_TRACE_ALIGN") != nullptr;
+        if (trace_retry)
+            fprintf(stderr, "[pf_call_align] attempt %d: %u bubbles, path pool %llu of %llu, path text %llu of %llu, rows text cap %llu (needs %llu)\n", attempt, nb,
+                    (unsigned long long)hc.path_head, (unsigned long long)path_cap, (unsigned long long)hc.text_head, (unsigned long long)text_cap,
+                    (unsigned long long)cap_text, (unsigned long long)(3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb));
         if (hc.path_head > path_cap || hc.text_head > text_cap) {
             S->path_pool = std::max<uint64_t>(S->path_pool, hc.path_head + hc.path_head / 8 + 1024);
             S->text_pool = std::max<uint64_t>(S->text_pool, hc.text_head + hc.text_head / 8 + 4096);
             continue;
         }
         // the aligned rows of the branching bubbles come on top of what K-SNP took: make room before K-BUBBLE runs
+        // (the path text is handed out in per-wavefront chunks: its size varies by a few per mille from pass to pass, hence the margin)
         if (cap_text < 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb) {
-            S->otext_cap = 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb + 4096;
+            const uint64_t need = 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb;
+            S->otext_cap = need + need / 16 + 4096;
             continue;
         }
         n_jobs = 0;
@@ -2008,6 +2015,9 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         BL.text_cap = cap_text; BL.site_cap = cap_sites; BL.group_cap = cap_groups; BL.ilen_cap = cap_ilen;
         BL.keep_heads = true;
         const int bst = bubble_launch(ctx, BL, heads);
+        if (trace_retry)
+            fprintf(stderr, "[pf_call_align] attempt %d: K-BUBBLE status %d, pools text %llu of %llu, sites %llu of %llu, groups %llu of %llu, indel lengths %llu of %llu\n", attempt, bst,
+                    heads[0], (unsigned long long)cap_text, heads[1], (unsigned long long)cap_sites, heads[2], (unsigned long long)cap_groups, heads[3], (unsigned long long)cap_ilen);
         if (bst == PF_ERR_OVERFLOW && (heads[0] > cap_text || heads[1] > cap_sites || heads[2] > cap_groups || heads[3] > cap_ilen)) {
             S->otext_cap = std::max<uint64_t>(S->otext_cap, heads[0] + heads[0] / 8);
             S->osites_cap = std::max<uint64_t>(S->osites_cap, heads[1] + heads[1] / 8);
