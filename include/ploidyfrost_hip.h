@@ -342,7 +342,8 @@ typedef struct pf_call_result {
     uint64_t align_jobs, site_strings, n_branching;
     uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: finished by K-SNP, by K-PAIR, sent to K-BUBBLE */
 } pf_call_result;
-/* Bubbles [t0, t1) of the selection (at most 2^24): everything up to the text of the ten streams, left in slab 0 or 1 of the
+#define PF_CALL_SLABS 4 /* text slabs of a context: a slab is free again once pf_call_fetch has copied it */
+/* Bubbles [t0, t1) of the selection (at most 2^24): everything up to the text of the ten streams, left in slab 0 .. 3 of the
  * context; var_count_base = bubbles called by earlier batches.  complex_size = -z (bounds the walk stacks). */
 int pf_call_run(pf_ctx *, int slab, uint64_t t0, uint64_t t1, uint64_t var_count_base, uint32_t complex_size, double match,
                 double mismatch, double gap, pf_call_result *out);

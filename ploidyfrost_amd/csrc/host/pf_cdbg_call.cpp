@@ -220,7 +220,9 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     const size_t CHUNK = std::min<size_t>(std::max<size_t>(batch_bubbles_ ? batch_bubbles_ * 4 : 1, 1), (size_t)1 << 24);
     struct Done {
         pf_call_result res;
-        int slab;
+        int slab;    // on the device (PF_CALL_SLABS of them: a whole range can be formatted before the alignment kernels of
+                     // the next range fill the device); the pinned host slabs alternate, piece b -> b % 2
+        int hslab;
     };
     std::mutex mu;
     std::condition_variable cv;
@@ -232,7 +234,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     int wst = PF_OK;
     std::string werr;
     double write_s = 0;
-    // piece b travels device slab b % 2 -> host slab b % 2 -> files; the PCIe copy of piece b + 1 runs beside the file copy of piece b
+    // piece b travels device slab b % PF_CALL_SLABS -> host slab b % 2 -> files; the PCIe copy of piece b + 1 runs beside the file copy of piece b
     auto thread_failed = [&](const char *who, const std::exception &e) {   // an exception in a helper thread ends the pipeline, not the process
         {
             std::lock_guard<std::mutex> lk(mu);
@@ -259,7 +261,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             }
             uint64_t total = 0, off[PF_CALL_STREAMS + 1];
             for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
-            PinnedBuf<char> &hb = cx_.slab[d.slab];
+            PinnedBuf<char> &hb = cx_.slab[d.hslab];
             hb.ensure(ctx_, std::max<uint64_t>(total, 1));
             int st = PF_OK;
             for (int s = 0; s < PF_CALL_STREAMS && st == PF_OK; ++s)
@@ -292,7 +294,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             const auto tw = clk::now();
             uint64_t total = 0, off[PF_CALL_STREAMS + 1];
             for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
-            PinnedBuf<char> &hb = cx_.slab[d.slab];
+            PinnedBuf<char> &hb = cx_.slab[d.hslab];
             // append: every stream at its running offset through a shared mapping, copied by all threads side by side
             if (write_files_)
                 for (int s = 0; s < PF_CALL_STREAMS; ++s)
@@ -371,13 +373,14 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 aligned.pop_front();
             }
             for (uint64_t p0 = 0; p0 < r.n; p0 += CHUNK, ++b) {
-                {   // slab b % 2 was last used by piece b - 2
+                {   // its device slab was last used by piece b - PF_CALL_SLABS
                     std::unique_lock<std::mutex> lk(mu);
-                    cv.wait(lk, [&] { return stop || b < fetched + 2; });
+                    cv.wait(lk, [&] { return stop || b < fetched + PF_CALL_SLABS; });
                     if (stop) return;
                 }
                 Done d;
-                d.slab = (int)(b & 1);
+                d.slab = (int)(b % PF_CALL_SLABS);
+                d.hslab = (int)(b & 1);
                 const uint64_t count = std::min<uint64_t>(CHUNK, r.n - p0);
                 const int st = pf_call_text_range_lane(ctx_, r.lane, d.slab, p0, count, r.var_base, &d.res);
                 if (st != PF_OK) {

@@ -134,8 +134,8 @@ struct CallState {
     uint64_t path_pool = 0, text_pool = 0, sv_pool = 0;   // capacities learnt from earlier batches
     uint64_t otext_cap = 0, osites_cap = 0, ogroups_cap = 0, oilen_cap = 0;
     // output slabs: two sets, so that one can be fetched while the next batch is formatted
-    DevBuf out[2][N_STREAMS];
-    uint64_t out_len[2][N_STREAMS] = {};
+    DevBuf out[PF_CALL_SLABS][N_STREAMS];
+    uint64_t out_len[PF_CALL_SLABS][N_STREAMS] = {};
     hipStream_t copy_stream = nullptr;
     // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
     hipStream_t side_stream = nullptr;
@@ -2100,7 +2100,7 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
 // (any host thread: a stream, scratch and counters of its own, launch timing by place -- one pf_call_text_range at a time,
 // beside at most one pf_call_align_lane on the OTHER lane)
 int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
-    if (!ctx || !out || slab < 0 || slab > 1 || lane < 0 || lane > 1) return PF_ERR_ARG;
+    if (!ctx || !out || slab < 0 || slab >= PF_CALL_SLABS || lane < 0 || lane > 1) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S) return PF_ERR_ARG;
     const CallState::AlignOut &O = S->lane[lane];
@@ -2110,7 +2110,14 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     out->n_called = 0;
     if (count == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
-    if (!S->text_stream) PF_HIP(hipStreamCreateWithFlags(&S->text_stream, hipStreamNonBlocking));
+    if (!S->text_stream) {
+        // highest priority: its short kernels go ahead of the alignment kernels of the other lane, whose grids fill the device
+        // for milliseconds -- the text has a PCIe copy and a file copy still before it
+        int least = 0, greatest = 0;
+        PF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool prio = [] { const char *e = getenv("PF_TEXT_PRIORITY"); return !(e && e[0] == '0'); }();   // measurements
+        PF_HIP(hipStreamCreateWithPriority(&S->text_stream, hipStreamNonBlocking, prio ? greatest : least));
+    }
     hipStream_t st = S->text_stream;
     const uint32_t nb = (uint32_t)count;
     const uint64_t t0 = O.t0;
@@ -2190,7 +2197,7 @@ int pf_call_run(pf_ctx *ctx, int slab, uint64_t t0, uint64_t t1, uint64_t var_co
 }
 
 int pf_call_fetch(pf_ctx *ctx, int slab, int stream, char *dst, uint64_t len) {
-    if (!ctx || !ctx->call || slab < 0 || slab > 1 || stream < 0 || stream >= N_STREAMS) return PF_ERR_ARG;
+    if (!ctx || !ctx->call || slab < 0 || slab >= PF_CALL_SLABS || stream < 0 || stream >= N_STREAMS) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (len > S->out_len[slab][stream] || (len && !dst)) return PF_ERR_ARG;
     if (len == 0) return PF_OK;
