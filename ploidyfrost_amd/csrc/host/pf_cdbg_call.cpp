@@ -217,7 +217,10 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     last_allfre_.clear();
 
     // ---- pieces: device (this thread) | copy back (fetcher thread) | append to the files (writer thread) ----
-    const size_t CHUNK = std::min<size_t>(std::max<size_t>(batch_bubbles_ ? batch_bubbles_ * 4 : 1, 1), (size_t)1 << 24);
+    // (PF_BATCH_BUBBLES: tools/fuzz_parity.py drives the CLI through many small pieces and ranges with it)
+    const size_t batch_env = [] { const char *e = getenv("PF_BATCH_BUBBLES"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)0; }();
+    const size_t batch_now = batch_env ? batch_env : batch_bubbles_;
+    const size_t CHUNK = std::min<size_t>(std::max<size_t>(batch_now ? batch_now * 4 : 1, 1), (size_t)1 << 24);
     struct Done {
         pf_call_result res;
         int slab;    // on the device (PF_CALL_SLABS of them: a whole range can be formatted before the alignment kernels of
