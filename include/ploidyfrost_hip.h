@@ -368,6 +368,9 @@ int pf_call_text_range_lane(pf_ctx *, int lane, int slab, uint64_t first, uint64
 /* Copies the first len bytes of one stream of a slab to dst (host memory, pinned for speed) on a stream of its own: may be
  * called from another thread while pf_call_run fills the other slab. */
 int pf_call_fetch(pf_ctx *, int slab, int stream, char *dst, uint64_t len);
+/* All PF_CALL_STREAMS streams of a slab, packed one after the other into dst (len[s] bytes of stream s): the copies are issued
+ * together and waited for once. */
+int pf_call_fetch_slab(pf_ctx *, int slab, char *dst, const uint64_t *len);
 /* O1's number formatting alone (test hook): text + 32 * i receives printf("%g", values[i]) without terminator, len[i] its length
  * [host|dev] */
 int pf_format_doubles(pf_ctx *, const double *values, uint64_t n, char *text, uint8_t *len);

@@ -262,13 +262,11 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 cv.wait(lk, [&] { return stop || b < written + 2; });   // host slab b % 2 was last used by piece b - 2
                 if (stop) { fetcher_done = true; lk.unlock(); cv.notify_all(); return; }
             }
-            uint64_t total = 0, off[PF_CALL_STREAMS + 1];
-            for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
+            uint64_t total = 0;
+            for (int s = 0; s < PF_CALL_STREAMS; ++s) total += d.res.text_len[s];
             PinnedBuf<char> &hb = cx_.slab[d.hslab];
             hb.ensure(ctx_, std::max<uint64_t>(total, 1));
-            int st = PF_OK;
-            for (int s = 0; s < PF_CALL_STREAMS && st == PF_OK; ++s)
-                st = pf_call_fetch(ctx_, d.slab, s, hb.p + off[s], d.res.text_len[s]);
+            const int st = pf_call_fetch_slab(ctx_, d.slab, hb.p, d.res.text_len);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 fetched = b + 1;
@@ -376,6 +374,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 aligned.pop_front();
             }
             for (uint64_t p0 = 0; p0 < r.n; p0 += CHUNK, ++b) {
+                const uint64_t count = std::min<uint64_t>(CHUNK, r.n - p0);
                 {   // its device slab was last used by piece b - PF_CALL_SLABS
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return stop || b < fetched + PF_CALL_SLABS; });
@@ -384,7 +383,6 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 Done d;
                 d.slab = (int)(b % PF_CALL_SLABS);
                 d.hslab = (int)(b & 1);
-                const uint64_t count = std::min<uint64_t>(CHUNK, r.n - p0);
                 const int st = pf_call_text_range_lane(ctx_, r.lane, d.slab, p0, count, r.var_base, &d.res);
                 if (st != PF_OK) {
                     { std::lock_guard<std::mutex> lk(mu); if (rc == PF_OK) { rc = st; rc_err = pf_last_error(ctx_); } stop = true; }

@@ -2209,4 +2209,21 @@ int pf_call_fetch(pf_ctx *ctx, int slab, int stream, char *dst, uint64_t len) {
     return PF_OK;
 }
 
+// all ten streams of a slab, one after the other into dst (stream s at off[s] = sum of the lengths before it): ten copies in
+// flight, one wait
+int pf_call_fetch_slab(pf_ctx *ctx, int slab, char *dst, const uint64_t *len) {
+    if (!ctx || !ctx->call || slab < 0 || slab >= PF_CALL_SLABS || !len) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
+    if (!S->copy_stream) return PF_ERR_HIP;
+    uint64_t at = 0;
+    for (int s = 0; s < N_STREAMS; ++s) {
+        if (len[s] > S->out_len[slab][s] || (len[s] && !dst)) return PF_ERR_ARG;
+        if (len[s] && hipMemcpyAsync(dst + at, S->out[slab][s].p, (size_t)len[s], hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+        at += len[s];
+    }
+    if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    return PF_OK;
+}
+
 }  // extern "C"
