@@ -112,6 +112,27 @@ def test_pipeline_batches_do_not_change_a_byte(case, batch, tmp_path):
         assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
 
 
+@pytest.mark.parametrize("ranges", ["2", "3", "5"])
+def test_align_ranges_and_text_lanes_soak(ranges, tmp_path, monkeypatch):
+    """The calling pipeline is four threads -- align range r + 1 | format range r | fetch | write -- over two result lanes and
+    four device slabs.  Tiny pieces (4 bubbles) and forced range counts make every hand-over happen dozens of times per pass;
+    forty passes must give the reference's bytes every time."""
+    monkeypatch.setenv("PF_ALIGN_RANGES", ranges)
+    meta = load_case("tet60k")
+    op = meta["opts"]
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    run.set_threads(6)
+    run.set_batch_bubbles(1)
+    run.set_overlap_output(True)
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    for _ in range(40):
+        run.find_superbubbles("g")
+        run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+        assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+    run.close()
+
+
 def test_overlapped_output_is_complete_when_ploidy_returns(tmp_path):
     meta = load_case("tet60k")
     run = hostapi.Run(meta["gfa"], meta["db"])
