@@ -939,6 +939,7 @@ struct SiteArgs {
     double *sv;                 // per site: maxnum group coverages, then their sum
     uint64_t sv_cap;
     CallCounters *cnt;
+    unsigned long long *prof;   // PF_SITES_STATS: per wavefront {total, pop + load, strings, ranks + probes, groups, bubbles}
 };
 
 __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
@@ -957,36 +958,152 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
     double *mean = reinterpret_cast<double *>(sok + 256);
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t n_branching = a.cnt->n_branching;
+    unsigned long long my_strings = 0;   // (added to the batch's count once, at the end)
+    unsigned long long pk[6] = {0, 0, 0, 0, 0, 0};
+    const unsigned long long pk0 = a.prof ? wall_clock64() : 0;
     auto sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
     };
+    // No shared queue head and one bump of the value pool per SV_CHUNK values instead of one per bubble: two atomics per bubble on
+    // two addresses -- 60 000 per launch, served one after the other by the L2 -- were what the launch took, whatever its
+    // wavefronts did in between.  Wavefront w takes bubbles w, w + grid, ...
+    constexpr uint32_t SV_CHUNK = 1024;
+    unsigned long long chunk_at = 0;
+    uint32_t chunk_left = 0;
+    // (... for all but the last two rounds, which are handed out one bubble at a time: the wavefronts finish together)
+    const uint32_t rounds = n_branching / gridDim.x;
+    const uint32_t n_static = rounds > 2 ? (rounds - 2) * gridDim.x : 0;
+    uint32_t q_static = blockIdx.x;
     for (;;) {
-        uint32_t q = 0;
-        if (lane == 0) q = atomicAdd(&a.cnt->sites_next, 1u);
-        q = read_lane(q, 0);
-        if (q >= n_branching) break;
+        uint32_t q;
+        if (q_static < n_static) {
+            q = q_static;
+            q_static += gridDim.x;
+        } else {
+            q = 0;
+            if (lane == 0) q = atomicAdd(&a.cnt->sites_next, 1u);
+            q = n_static + read_lane(q, 0);
+            if (q >= n_branching) break;
+        }
+        const unsigned long long pa = a.prof ? wall_clock64() : 0;
         const uint32_t j = a.blist[q];
         const pf_bubble_result r = a.res[j];
         if (r.n_rows == 0 || r.n_rows == 0xFFFFFFFFu) continue;
+        ++pk[5];
         const uint32_t R = r.n_rows, L = r.n_cols;
         const char *rows = a.otext + r.rows_off;
         // values: one slot per allele group and site, plus the site's sum
         uint32_t n_val = 0;
         for (uint32_t si = 0; si < r.n_sites; ++si) n_val += (uint32_t)a.osites[r.site_off + si].maxnum + 1;
         unsigned long long v0 = 0;
-        if (lane == 0) v0 = atomicAdd(&a.cnt->sv_head, (unsigned long long)n_val);
-        v0 = ((unsigned long long)read_lane((uint32_t)(v0 >> 32), 0) << 32) | read_lane((uint32_t)v0, 0);
+        if (n_val > chunk_left) {   // (wave-uniform)
+            const uint32_t take = n_val > SV_CHUNK ? n_val : SV_CHUNK;
+            if (lane == 0) v0 = atomicAdd(&a.cnt->sv_head, (unsigned long long)take);
+            chunk_at = ((unsigned long long)read_lane((uint32_t)(v0 >> 32), 0) << 32) | read_lane((uint32_t)v0, 0);
+            chunk_left = take;
+        }
+        v0 = chunk_at;
+        chunk_at += n_val;
+        chunk_left -= n_val;
         if (lane == 0) a.sv_off[j] = v0;
         const bool room = v0 + n_val <= a.sv_cap;
         uint32_t err = 0, n_strings = 0;
         uint32_t indel = 0;
         unsigned long long vcur = v0;
+        if (a.prof) pk[1] += wall_clock64() - pa;
         for (uint32_t si = 0; si < r.n_sites && !err; ++si) {
+            const unsigned long long pb = a.prof ? wall_clock64() : 0;
             const pf_bubble_site sr = a.osites[r.site_off + si];
             const uint8_t *grp = a.ogroups + r.group_off + (uint64_t)si * R;
             const uint32_t site = sr.col;
             const uint32_t maxnum = sr.maxnum;
+            // A site that is no indel in a bubble that has met none so far -- most sites -- takes k raw columns of every row
+            // (src/CDBG.cpp:1559-1596): equally long strings over {-, A, C, G, T}, k <= 31.  Lane p holds row p's string as
+            // order-preserving 3-bit codes in two registers (comparing them = comparing the strings) next to the 2-bit k-mer
+            // the probe wants; ranks, duplicates and the groups' sums go through lane reads instead of the scratch arrays,
+            // whose every access is a step in a chain of dependent loads.  Same decisions, same order of the additions.
+            const long plain_from = (long)site - k + 1;
+            if (!sr.is_indel && indel == 0 && plain_from >= 0 && (uint64_t)plain_from + (uint64_t)k <= L && k <= 31 && R <= WAVE) {
+                const uint32_t p = (uint32_t)lane;
+                const bool mine = p < R;
+                uint64_t hi = 0, lo = 0, km = 0;
+                uint32_t g = 0;
+                if (mine) {
+                    // (all 32 bytes asked for at once -- a loop of loads would wait for each in turn; the row pool is allocated
+                    // with slack, so the bytes past the k-th exist)
+                    unsigned char cs[32];
+                    __builtin_memcpy(cs, rows + (size_t)p * L + plain_from, 32);
+#pragma unroll
+                    for (int x = 0; x < 31; ++x) {   // (constant indices: cs stays in registers)
+                        if (x >= k) continue;
+                        const char ch = (char)cs[x];
+                        const uint64_t c3 = ch == '-' ? 0 : ch == 'A' ? 1 : ch == 'C' ? 2 : ch == 'G' ? 3 : 4;
+                        hi = (hi << 3) | (lo >> 61);
+                        lo = (lo << 3) | c3;
+                        km = (km << 2) | (ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3);
+                    }
+                    km &= kmask;
+                    g = grp[p];
+                }
+                bool d = false;
+                uint32_t rk = 0;
+                for (uint32_t o = 0; o < R; ++o) {
+                    const uint64_t ohi = ((uint64_t)read_lane((uint32_t)(hi >> 32), (int)o) << 32) | read_lane((uint32_t)hi, (int)o);
+                    const uint64_t olo = ((uint64_t)read_lane((uint32_t)(lo >> 32), (int)o) << 32) | read_lane((uint32_t)lo, (int)o);
+                    const uint32_t og = read_lane(g, (int)o);
+                    if (!mine || o == p || og != g) continue;
+                    if (ohi == hi && olo == lo) { if (o < p) d = true; }
+                    else if (ohi < hi || (ohi == hi && olo < lo)) ++rk;
+                }
+                const unsigned long long pc = a.prof ? wall_clock64() : 0;
+                pk[2] += pc - pb;
+                bool miss = false, okp = true;
+                double mn = 0.0;
+                if (mine && !d) {
+                    uint64_t sum = 0;
+                    if (!a.tab_exact) {
+                        uint32_t cnt;
+                        if (!canonical_count(a.tab, a.mask, km, k, cnt, a.one_strand != 0)) miss = true;
+                        else if (cnt > a.low && cnt < a.up) sum = cnt;
+                        else okp = false;   // src/CDBG.cpp:45-50
+                    }
+                    mn = (double)sum;   // (one k-mer: the mean is its count)
+                }
+                n_strings += (uint32_t)__popcll(__ballot(mine && !d));
+                const unsigned long long pd = a.prof ? wall_clock64() : 0;
+                pk[3] += pd - pc;
+                if (__ballot(miss)) { err = 2; break; }
+                // group coverages in set order; the first string out of range drops the site (src/CDBG.cpp:1527-1551)
+                bool ok = true;
+                double total = 0.0;
+                for (uint32_t gi = 0; gi < maxnum; ++gi) {
+                    double tc = 0.0;
+                    if (ok) {
+                        uint32_t last = 0;
+                        bool have_last = false;
+                        for (;;) {
+                            const bool cand = mine && g == gi + 1 && !d && (!have_last || rk > last);
+                            const unsigned long long m = __ballot(cand);
+                            if (!m) break;
+                            const uint32_t best = read_lane(wave_min_u32(cand ? rk : 0xFFFFFFFFu), 0);
+                            const int bp = __ffsll((long long)__ballot(cand && rk == best)) - 1;   // (distinct strings of a group: distinct ranks)
+                            if (!read_lane(okp ? 1u : 0u, bp)) { ok = false; break; }
+                            const uint64_t mb = (uint64_t)__double_as_longlong(mn);
+                            tc += __longlong_as_double((long long)(((uint64_t)read_lane((uint32_t)(mb >> 32), bp) << 32) | read_lane((uint32_t)mb, bp)));
+                            last = best;
+                            have_last = true;
+                        }
+                        if (ok) total += tc;
+                    }
+                    if (lane == 0 && room) a.sv[vcur + gi] = tc;
+                }
+                if (lane == 0 && room) a.sv[vcur + maxnum] = total;
+                if (lane == 0) a.osites[r.site_off + si].pad_ = ok ? 1 : 0;
+                vcur += maxnum + 1;
+                if (a.prof) pk[4] += wall_clock64() - pd;
+                continue;
+            }
             uint32_t napp = 0;
             if (sr.is_indel) {
                 // every path: the next non-gap character at / after the site, again and again until the characters just appended
@@ -1099,6 +1216,8 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
             }
             if (sr.is_indel) ++indel;
             sync();
+            const unsigned long long pc = a.prof ? wall_clock64() : 0;
+            pk[2] += pc - pb;
             if (row_err) { err = (row_err & 4) ? 4 : 16; break; }
             // distinct strings per allele group in std::set order, their coverage (readCov(string), src/CDBG.cpp:29-60)
             uint32_t miss_any = 0;
@@ -1151,6 +1270,8 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                 n_strings += (uint32_t)__popcll(__ballot(p < R && !dup[p]));
             }
             sync();
+            const unsigned long long pd = a.prof ? wall_clock64() : 0;
+            pk[3] += pd - pc;
             if (miss_any) { err = 2; break; }
             // group coverages in set order; the first string out of range drops the site (src/CDBG.cpp:1527-1551)
             bool ok = true;
@@ -1183,11 +1304,15 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
             if (lane == 0) a.osites[r.site_off + si].pad_ = ok ? 1 : 0;
             vcur += maxnum + 1;
             sync();
+            if (a.prof) pk[4] += wall_clock64() - pd;
         }
-        if (lane == 0) {
-            if (err) atomicOr(&a.cnt->err, err);
-            atomicAdd(&a.cnt->site_strings, (unsigned long long)n_strings);
-        }
+        if (lane == 0 && err) atomicOr(&a.cnt->err, err);
+        my_strings += n_strings;
+    }
+    if (lane == 0 && my_strings) atomicAdd(&a.cnt->site_strings, my_strings);
+    if (a.prof && lane == 0) {
+        pk[0] = wall_clock64() - pk0;
+        for (int x = 0; x < 6; ++x) a.prof[(size_t)blockIdx.x * 6 + x] = pk[x];
     }
 }
 
@@ -2040,7 +2165,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         const int sites_grid = (int)std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu));
         NEED(S->sites_scr, sites_per_wave * sites_grid);
         for (int attempt = 0;; ++attempt) {
-            const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * hc.n_branching + 1024);
+            const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * hc.n_branching + 1024ull * sites_grid + 1024);   // (a started chunk per wavefront)
             NEED(O.sv, sv_cap * 8);
             SiteArgs sa;
             sa.ct = S->ctask.as<CallTask>(); sa.kept = S->kept.as<uint32_t>(); sa.t0 = t0; sa.blist = S->blist.as<uint32_t>();
@@ -2049,6 +2174,14 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sa.one_strand = ctx->tab_one_strand; sa.tab_exact = ctx->tab_exact; sa.low = S->low; sa.up = S->up; sa.ks = KS;
             sa.scratch = S->sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
             sa.sv = O.sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
+            static const bool sites_stats = getenv("PF_SITES_STATS") != nullptr;   // measurements: where a wavefront's time goes
+            DevTmp<unsigned long long> sprof_;
+            sa.prof = nullptr;
+            if (sites_stats) {
+                PF_HIP(sprof_.alloc((size_t)sites_grid * 48));
+                PF_HIP(hipMemsetAsync(sprof_.p, 0, (size_t)sites_grid * 48, st));
+                sa.prof = sprof_.p;
+            }
             PF_HIP(hipMemsetAsync(&d_cnt->sites_next, 0, 4, st));
             PF_HIP(hipMemsetAsync(&d_cnt->sv_head, 0, 8, st));
             PF_HIP(hipMemsetAsync(&d_cnt->site_strings, 0, 8, st));
@@ -2057,6 +2190,19 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ctx_end(ctx);
             ctx_units(ctx, PF_K_CALL_SITES, hc.n_branching);
             PF_HIP(hipGetLastError());
+            if (sa.prof) {
+                PF_HIP(hipStreamSynchronize(st));
+                std::vector<unsigned long long> h((size_t)sites_grid * 6);
+                PF_HIP(hipMemcpy(h.data(), sprof_.p, h.size() * 8, hipMemcpyDeviceToHost));
+                unsigned long long sum[6] = {0, 0, 0, 0, 0, 0}, mx = 0;
+                for (int w = 0; w < sites_grid; ++w) {
+                    for (int x = 0; x < 6; ++x) sum[x] += h[(size_t)w * 6 + x];
+                    mx = std::max(mx, h[(size_t)w * 6]);
+                }
+                fprintf(stderr, "[k_call_sites] %d wavefronts, %llu bubbles; ticks (10 ns) per wavefront: total %.0f (max %llu) = pop + load %.0f, strings %.0f, ranks + probes %.0f, groups %.0f\n",
+                        sites_grid, sum[5], (double)sum[0] / sites_grid, mx, (double)sum[1] / sites_grid, (double)sum[2] / sites_grid, (double)sum[3] / sites_grid,
+                        (double)sum[4] / sites_grid);
+            }
             PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
             PF_HIP(hipStreamSynchronize(st));
             if (hc.err & 2u) { ctx->err = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
