@@ -540,7 +540,9 @@ def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):
     return {"kernel": kernel, "bound": "valu-issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instructions/s",
             "frac": round(ach / peak, 4), "valu_per_launch": valu, "salu_per_launch": salu,
             "wave_cycle_shares": {k[6:]: v for k, v in e.items() if k.startswith("share_")},
-            "source": "profiles/pmc_sq.json (SQ counters per launch) / live HIP-event duration"}
+            "source": "profiles/pmc_sq.json (SQ counters per launch) / live HIP-event duration",
+            "note": "per launch: the launches of K-BUBBLE's size classes run side by side (up to three at once, beside the text kernels "
+                    "of the previous align range), so a launch gets a share of the chip and the chip issues up to three times this"}
 
 
 def load_traffic(kernel: str, n_unitigs: int | None = None):
