@@ -313,13 +313,24 @@ struct CcState {
     uint64_t *full_mask = nullptr, *size_total = nullptr;
     uint32_t *n_full_enc = nullptr;
     uint32_t n_colors = 0;
-    pf_bfs_record *xrec = nullptr;   // (device copy of the last call's extra records, kept for pf_replay_device)
+    pf_bfs_record *xrec = nullptr;   // (device copy of the last call's extra records, kept for pf_replay_device: t_xrec below)
     uint64_t n_xrec = 0;
     uint64_t added_call = 0;   // the K-BFS call whose device-resident records are already in the union-find
     bool labelled = false;
+    // scratch of the calls below, kept from pass to pass (a hipMalloc / hipFree pair per temporary is a device-wide
+    // synchronisation and a tenth of a millisecond each: a dozen of them were a fifth of findSuperBubble's time)
+    pf_bfs_record *t_xrec = nullptr;
+    uint32_t *t_xpool = nullptr, *t_sides = nullptr, *t_links = nullptr;
+    uint8_t *t_flag = nullptr, *t_sel = nullptr, *t_scan = nullptr, *t_bytes = nullptr;
+    uint64_t *t_cnt = nullptr, *t_sz = nullptr, *t_off = nullptr;
+    uint64_t t_xrec_cap = 0, t_xpool_cap = 0, t_sides_cap = 0, t_links_cap = 0, t_flag_cap = 0, t_sel_cap = 0, t_scan_cap = 0, t_bytes_cap = 0, t_cnt_cap = 0,
+             t_sz_cap = 0, t_off_cap = 0;
     void release() {
+        for (void *p : {(void *)t_xrec, (void *)t_xpool, (void *)t_sides, (void *)t_links, (void *)t_flag, (void *)t_sel, (void *)t_scan, (void *)t_bytes, (void *)t_cnt,
+                        (void *)t_sz, (void *)t_off})
+            if (p) (void)hipFree(p);
         for (void *p : {(void *)big, (void *)work, (void *)f2, (void *)keys, (void *)keys2, (void *)vals, (void *)vals2, (void *)big_idx, (void *)big_rec,
-                        (void *)big_pool, (void *)xrec, (void *)full_mask, (void *)size_total, (void *)n_full_enc})
+                        (void *)big_pool, (void *)full_mask, (void *)size_total, (void *)n_full_enc})
             if (p) (void)hipFree(p);
         for (void *p : {(void *)parent, (void *)first, (void *)multi, (void *)bad, (void *)labels, (void *)cls, (void *)idx, (void *)cls2, (void *)idx2, (void *)hist,
                         sort_tmp, (void *)up_rec, (void *)up_pool})
@@ -404,7 +415,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     }
     if (reset) {
         k_cc_init<<<(n_sides + 255) / 256, 256, 0, st>>>(S->parent, S->first, S->multi, n_sides);
-        if (S->xrec) { (void)hipFree(S->xrec); S->xrec = nullptr; }
+        S->xrec = nullptr;   // (it points into t_xrec)
         S->n_xrec = 0;
     }
     S->labelled = false;
@@ -442,24 +453,17 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     }
     if (n_extra) {
         // traversals the caller walked itself: their records (list_off relative to extra_pool) contribute edges only
-        pf_bfs_record *d_xrec = nullptr;
-        uint32_t *d_xpool = nullptr;
-        DevTmp<pf_bfs_record> xr;
-        DevTmp<uint32_t> xp;
-        PF_HIP(xr.alloc(n_extra * sizeof(pf_bfs_record)));
-        PF_HIP(xp.alloc((extra_pool_len + 1) * 4));
-        d_xrec = xr.p;
-        d_xpool = xp.p;
+        if (!grow(S->t_xrec, S->t_xrec_cap, n_extra) || !grow(S->t_xpool, S->t_xpool_cap, extra_pool_len + 1)) { ctx->err = "pf_side_components: out of device memory"; return PF_ERR_HIP; }
+        pf_bfs_record *d_xrec = S->t_xrec;
+        uint32_t *d_xpool = S->t_xpool;
         PF_HIP(hipMemcpyAsync(d_xrec, extra, n_extra * sizeof(pf_bfs_record), hipMemcpyDefault, st));
         if (extra_pool_len) PF_HIP(hipMemcpyAsync(d_xpool, extra_pool, extra_pool_len * 4, hipMemcpyDefault, st));
         k_cc_edges_long<<<dim3((unsigned)n_extra, 64), 256, 0, st>>>(d_xrec, n_extra, d_xpool, extra_pool_len, n_sides, S->parent, S->first, S->multi, S->bad, gate);
         PF_HIP(hipGetLastError());
-        PF_HIP(hipStreamSynchronize(st));   // (the temporaries are freed on return)
-        // the records themselves stay (32 B each): pf_replay_device leaves their components to the caller, who holds their lists
-        if (S->xrec) (void)hipFree(S->xrec);
-        S->xrec = xr.p;
+        PF_HIP(hipStreamSynchronize(st));   // (the caller's buffers may go)
+        // the records themselves stay where they are: pf_replay_device leaves their components to the caller, who holds their lists
+        S->xrec = S->t_xrec;
         S->n_xrec = n_extra;
-        xr.p = nullptr;
     }
     k_cc_multi<<<(N + 255) / 256, 256, 0, st>>>(S->multi, N, S->parent);
     PF_HIP(hipGetLastError());
@@ -597,35 +601,29 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     else k_replay_small<pfh::NoColours><<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size, pfh::NoColours{});
     PF_HIP(hipGetLastError());
     // the records left to the caller, ascending
-    DevTmp<uint8_t> flag_;
-    DevTmp<uint64_t> cnt_;
-    PF_HIP(flag_.alloc(n + 8));
-    PF_HIP(cnt_.alloc(16));
-    k_replay_flag_big<<<grid, 256, 0, st>>>(rec, n, S->keys, S->big, S->work, small_limit, flag_.p);
+    const char *oom = "pf_replay_device: out of device memory";
+    if (!grow(S->t_flag, S->t_flag_cap, n + 8) || !grow(S->t_cnt, S->t_cnt_cap, 2)) { ctx->err = oom; return PF_ERR_HIP; }
+    k_replay_flag_big<<<grid, 256, 0, st>>>(rec, n, S->keys, S->big, S->work, small_limit, S->t_flag);
     size_t sel = 0;
     hipcub::CountingInputIterator<uint32_t> iota(0);
-    PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, sel, iota, flag_.p, S->big_idx, cnt_.p, (int)n, st));
-    DevTmp<uint8_t> tmp_;
-    PF_HIP(tmp_.alloc(sel + 256));
+    PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, sel, iota, S->t_flag, S->big_idx, S->t_cnt, (int)n, st));
+    if (!grow(S->t_sel, S->t_sel_cap, sel + 256)) { ctx->err = oom; return PF_ERR_HIP; }
     sel += 256;
-    PF_HIP(hipcub::DeviceSelect::Flagged(tmp_.p, sel, iota, flag_.p, S->big_idx, cnt_.p, (int)n, st));
+    PF_HIP(hipcub::DeviceSelect::Flagged(S->t_sel, sel, iota, S->t_flag, S->big_idx, S->t_cnt, (int)n, st));
     uint64_t nb = 0;
-    PF_HIP(hipMemcpyAsync(&nb, cnt_.p, 8, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(&nb, S->t_cnt, 8, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     nb &= 0xFFFFFFFFull;   // (the selector counts in 32 bits)
     uint64_t entries = 0;
     if (nb) {
-        DevTmp<uint64_t> sz_, off_;
-        PF_HIP(sz_.alloc((nb + 1) * 8));
-        PF_HIP(off_.alloc((nb + 1) * 8));
-        k_replay_big_sizes<<<(unsigned)((nb + 1 + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, sz_.p);
+        if (!grow(S->t_sz, S->t_sz_cap, nb + 1) || !grow(S->t_off, S->t_off_cap, nb + 1)) { ctx->err = oom; return PF_ERR_HIP; }
+        k_replay_big_sizes<<<(unsigned)((nb + 1 + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, S->t_sz);
         size_t t2 = 0;
-        PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, sz_.p, off_.p, (int)(nb + 1), st));
-        DevTmp<uint8_t> tmp2_;
-        PF_HIP(tmp2_.alloc(t2 + 256));
+        PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, S->t_sz, S->t_off, (int)(nb + 1), st));
+        if (!grow(S->t_scan, S->t_scan_cap, t2 + 256)) { ctx->err = oom; return PF_ERR_HIP; }
         t2 += 256;
-        PF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2_.p, t2, sz_.p, off_.p, (int)(nb + 1), st));
-        PF_HIP(hipMemcpyAsync(&entries, off_.p + nb, 8, hipMemcpyDeviceToHost, st));
+        PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->t_scan, t2, S->t_sz, S->t_off, (int)(nb + 1), st));
+        PF_HIP(hipMemcpyAsync(&entries, S->t_off + nb, 8, hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
         if (S->big_cap < nb) {
             if (S->big_rec) (void)hipFree(S->big_rec);
@@ -639,7 +637,7 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
             S->big_pool_cap = entries + entries / 4 + 64;
             PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->big_pool), S->big_pool_cap * 4));
         }
-        k_replay_big_gather<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, pool, off_.p, S->big_rec, S->big_pool);
+        k_replay_big_gather<<<(unsigned)((nb + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, pool, S->t_off, S->big_rec, S->big_pool);
         PF_HIP(hipGetLastError());
         PF_HIP(hipStreamSynchronize(st));
     }
@@ -674,17 +672,15 @@ int pf_replay_finish(pf_ctx *ctx, const uint32_t *sides, const uint32_t *links, 
     const int sa = call_state_arrays(ctx, &flags, &plus, &minus);   // (the same buffers: contents are kept)
     if (sa != PF_OK) return sa;
     if (n_patch) {
-        DevTmp<uint32_t> ds_, dl_;
-        DevTmp<uint8_t> db_;
-        PF_HIP(ds_.alloc(n_patch * 4));
-        PF_HIP(dl_.alloc(n_patch * 4));
-        PF_HIP(db_.alloc(n_patch));
-        PF_HIP(hipMemcpyAsync(ds_.p, sides, n_patch * 4, hipMemcpyDefault, st));
-        PF_HIP(hipMemcpyAsync(dl_.p, links, n_patch * 4, hipMemcpyDefault, st));
-        PF_HIP(hipMemcpyAsync(db_.p, side_flags, n_patch, hipMemcpyDefault, st));
-        k_replay_patch<<<(unsigned)((n_patch + 255) / 256), 256, 0, st>>>(ds_.p, dl_.p, db_.p, n_patch, 2 * N, plus, minus, S->f2);
+        if (!grow(S->t_sides, S->t_sides_cap, n_patch) || !grow(S->t_links, S->t_links_cap, n_patch) || !grow(S->t_bytes, S->t_bytes_cap, n_patch)) {
+            ctx->err = "pf_replay_finish: out of device memory";
+            return PF_ERR_HIP;
+        }
+        PF_HIP(hipMemcpyAsync(S->t_sides, sides, n_patch * 4, hipMemcpyDefault, st));
+        PF_HIP(hipMemcpyAsync(S->t_links, links, n_patch * 4, hipMemcpyDefault, st));
+        PF_HIP(hipMemcpyAsync(S->t_bytes, side_flags, n_patch, hipMemcpyDefault, st));
+        k_replay_patch<<<(unsigned)((n_patch + 255) / 256), 256, 0, st>>>(S->t_sides, S->t_links, S->t_bytes, n_patch, 2 * N, plus, minus, S->f2);
         PF_HIP(hipGetLastError());
-        PF_HIP(hipStreamSynchronize(st));
     }
     k_replay_merge<<<(N + 255) / 256, 256, 0, st>>>(S->f2, N, flags);
     PF_HIP(hipGetLastError());
