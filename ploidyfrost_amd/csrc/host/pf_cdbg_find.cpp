@@ -146,6 +146,7 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     std::vector<uint32_t> big_pool((size_t)big_entries + 1);
     st = pf_replay_big_fetch(ctx_, big_idx.data(), big_rec.data(), big_pool.data());
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    tf("large components fetched");
     if (big_f2_.size() != 2 * (size_t)N) big_f2_.assign(2 * (size_t)N, 0);
     // (plus_ / minus_ / big_f2_ are all-zero here: every pass undoes what it touched, see below; a stale host copy is re-zeroed)
     if (!state_host_stale_) {
@@ -178,6 +179,7 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
             else { commit(big_rec[a], big_pool.data() + big_rec[a].list_off); ++a; }
         }
     }
+    tf("large components replayed");
     p_links.resize(p_sides.size());
     p_bytes.resize(p_sides.size());
     for (size_t i = 0; i < p_sides.size(); ++i) {
