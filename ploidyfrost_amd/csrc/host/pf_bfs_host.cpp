@@ -1,6 +1,9 @@
 #include "pf_bfs_host.hpp"
 
+#include <sys/mman.h>
+
 #include <algorithm>
+#include <cstdlib>
 #include <unordered_set>
 
 namespace pfh {
@@ -9,8 +12,22 @@ namespace {
 constexpr uint32_t NONE = 0xFFFFFFFFu;
 }
 
+void advise_huge_pages(const void *p, size_t bytes) {
+    static const bool on = [] { const char *e = getenv("PF_HUGE_PAGES"); return !(e && e[0] == '0'); }();   // measurements
+    if (!on || !p) return;
+    constexpr uintptr_t H = (uintptr_t)2 << 20;
+    const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + bytes) & ~(H - 1);
+    if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);
+}
+
 const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32_t *pred, uint32_t N, uint32_t s, pf_bfs_record &r) {
-    if (info.size() != N) { info.assign(N, 0); first.assign(N, 0); epoch = 0; }
+    if (info.size() != N) {
+        info.clear(); first.clear();
+        info.reserve(N); first.reserve(N);
+        advise_huge_pages(info.data(), (size_t)N * 4);
+        advise_huge_pages(first.data(), (size_t)N * 4);
+        info.assign(N, 0); first.assign(N, 0); epoch = 0;
+    }
     if (++epoch >= (1u << 28)) { std::fill(info.begin(), info.end(), 0); epoch = 1; }
     const uint32_t tag = epoch << 4;
     auto state_of = [&](uint32_t unitig) -> uint32_t { const uint32_t x = info[unitig]; return (x >> 4) == epoch ? (x & 15) : 0; };  // 0 = not in state_map

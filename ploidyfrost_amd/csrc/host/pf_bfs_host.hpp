@@ -19,6 +19,9 @@
 
 namespace pfh {
 
+// advice only (Linux transparent huge pages in "madvise" mode): the 2 MB-aligned part of [p, p + bytes), before its first touch
+void advise_huge_pages(const void *p, size_t bytes);
+
 struct HugeWalker {
     std::vector<uint32_t> info, first, seen, todo, cyc;
     uint32_t epoch = 0;

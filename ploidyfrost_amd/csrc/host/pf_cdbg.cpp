@@ -140,6 +140,10 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
             std::vector<std::unique_ptr<HugeWalker>> made(want);
             parallel_chunks(want, 1, want, [&](size_t i, size_t, size_t) {
                 made[i] = std::make_unique<HugeWalker>();
+                made[i]->info.reserve(n_now);
+                made[i]->first.reserve(n_now);
+                advise_huge_pages(made[i]->info.data(), (size_t)n_now * 4);
+                advise_huge_pages(made[i]->first.data(), (size_t)n_now * 4);
                 made[i]->info.assign(n_now, 0);
                 made[i]->first.assign(n_now, 0);
             });
@@ -167,6 +171,12 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
         trace.mark(most >= 15 ? "device: numbering (replayed)" : "device: numbering (K-MINZ)");
     }
     const uint32_t N = g_.n();
+    // (the host walkers chase these rows at random: 2 MB pages where the kernel hands them out on advice, asked for before the
+    // first touch)
+    succ_.reserve((size_t)N * 8);
+    pred_.reserve((size_t)N * 8);
+    advise_huge_pages(succ_.data(), (size_t)N * 8 * 4);
+    advise_huge_pages(pred_.data(), (size_t)N * 8 * 4);
     succ_.resize((size_t)N * 8);
     pred_.resize((size_t)N * 8);
     st = pf_build_adjacency(ctx_, succ_.data(), pred_.data());
