@@ -596,11 +596,7 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     }
     size_t have = S->sort_tmp_bytes;
     PF_HIP(rocprim::radix_sort_pairs(S->sort_tmp, have, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, st));
-    FlagsDevice acc{S->f2, plus, minus};
-    if (S->n_colors) k_replay_small<pfh::ColourGate><<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size, gate_of(ctx, S));
-    else k_replay_small<pfh::NoColours><<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size, pfh::NoColours{});
-    PF_HIP(hipGetLastError());
-    // the records left to the caller, ascending
+    // the records left to the caller, ascending (gathered first: the caller commits them while the device commits the rest)
     const char *oom = "pf_replay_device: out of device memory";
     if (!grow(S->t_flag, S->t_flag_cap, n + 8) || !grow(S->t_cnt, S->t_cnt_cap, 2)) { ctx->err = oom; return PF_ERR_HIP; }
     k_replay_flag_big<<<grid, 256, 0, st>>>(rec, n, S->keys, S->big, S->work, small_limit, S->t_flag);
@@ -645,6 +641,12 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     S->big_entries = entries;
     *n_big = nb;
     *big_entries = entries;
+    // the small components: left in flight on the context's stream -- disjoint from what the caller commits meanwhile; the
+    // patch of pf_replay_finish queues behind them and waits
+    FlagsDevice acc{S->f2, plus, minus};
+    if (S->n_colors) k_replay_small<pfh::ColourGate><<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size, gate_of(ctx, S));
+    else k_replay_small<pfh::NoColours><<<grid, 256, 0, st>>>(S->keys2, S->vals2, n, rec, pool, S->big, S->work, small_limit, acc, complex_size, pfh::NoColours{});
+    PF_HIP(hipGetLastError());
     return PF_OK;
 }
 
