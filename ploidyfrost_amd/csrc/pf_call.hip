@@ -134,8 +134,9 @@ struct CallState {
     uint64_t path_pool = 0, text_pool = 0, sv_pool = 0;   // capacities learnt from earlier batches
     uint64_t otext_cap = 0, osites_cap = 0, ogroups_cap = 0, oilen_cap = 0;
     // output slabs: two sets, so that one can be fetched while the next batch is formatted
-    DevBuf out[PF_CALL_SLABS][N_STREAMS];
-    uint64_t out_len[PF_CALL_SLABS][N_STREAMS] = {};
+    // (the ten streams of a slab lie one after the other in one buffer, as the host wants them: one copy fetches a slab)
+    DevBuf out[PF_CALL_SLABS];
+    uint64_t out_len[PF_CALL_SLABS][N_STREAMS] = {}, out_off[PF_CALL_SLABS][N_STREAMS] = {};
     hipStream_t copy_stream = nullptr;
     // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
     hipStream_t side_stream = nullptr;
@@ -149,8 +150,7 @@ struct CallState {
         for (AlignOut &o : lane)
             for (DevBuf *b : {&o.res, &o.otext, &o.osites, &o.ogroups, &o.oilen, &o.sv_off, &o.sv, &o.vc}) b->release();
         if (text_stream) { (void)hipStreamDestroy(text_stream); text_stream = nullptr; }
-        for (auto &s : out)
-            for (DevBuf &b : s) b.release();
+        for (DevBuf &b : out) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         if (side_stream) { (void)hipStreamDestroy(side_stream); side_stream = nullptr; }
         if (ev_prep) { (void)hipEventDestroy(ev_prep); ev_prep = nullptr; }
@@ -2305,11 +2305,16 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     PF_HIP(hipMemcpyAsync(totals, S->totals.p, N_STREAMS * 8, hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
+    uint64_t all = 0;
+    for (int s = 0; s < N_STREAMS; ++s) all += totals[s];
+    NEED(S->out[slab], std::max<uint64_t>(all, 16));
+    all = 0;
     for (int s = 0; s < N_STREAMS; ++s) {
-        NEED(S->out[slab][s], std::max<uint64_t>(totals[s], 16));
-        fa.out[s] = S->out[slab][s].as<char>();
+        fa.out[s] = S->out[slab].as<char>() + all;
+        S->out_off[slab][s] = all;
         S->out_len[slab][s] = totals[s];
         out->text_len[s] = totals[s];
+        all += totals[s];
     }
     ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
     k_call_format<true><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
@@ -2350,7 +2355,7 @@ int pf_call_fetch(pf_ctx *ctx, int slab, int stream, char *dst, uint64_t len) {
     // its own stream, and no context state written: safe beside a pf_call_run on the other slab
     if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
     if (!S->copy_stream) return PF_ERR_HIP;
-    if (hipMemcpyAsync(dst, S->out[slab][stream].p, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (hipMemcpyAsync(dst, S->out[slab].as<char>() + S->out_off[slab][stream], (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
 }
@@ -2363,10 +2368,21 @@ int pf_call_fetch_slab(pf_ctx *ctx, int slab, char *dst, const uint64_t *len) {
     if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
     if (!S->copy_stream) return PF_ERR_HIP;
     uint64_t at = 0;
+    bool whole = true;
     for (int s = 0; s < N_STREAMS; ++s) {
         if (len[s] > S->out_len[slab][s] || (len[s] && !dst)) return PF_ERR_ARG;
-        if (len[s] && hipMemcpyAsync(dst + at, S->out[slab][s].p, (size_t)len[s], hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+        whole = whole && len[s] == S->out_len[slab][s];
         at += len[s];
+    }
+    if (whole) {   // the slab as it lies: one copy
+        if (at && hipMemcpyAsync(dst, S->out[slab].p, (size_t)at, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    } else {
+        at = 0;
+        for (int s = 0; s < N_STREAMS; ++s) {
+            if (len[s] && hipMemcpyAsync(dst + at, S->out[slab].as<char>() + S->out_off[slab][s], (size_t)len[s], hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess)
+                return PF_ERR_HIP;
+            at += len[s];
+        }
     }
     if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
