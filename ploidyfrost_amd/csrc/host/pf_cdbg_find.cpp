@@ -187,8 +187,10 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
         p_links[i] = (s & 1) ? minus_[s >> 1] : plus_[s >> 1];
         p_bytes[i] = big_f2_[s];
     }
+    tf("patch gathered");
     st = pf_replay_finish(ctx_, p_sides.data(), p_links.data(), p_bytes.data(), p_sides.size());
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
+    if (trace_find) fprintf(stderr, "[find] %zu sides patched on the device %.2f ms\n", p_sides.size(), since(t_all) * 1e3);
     for (uint32_t s : p_sides) {   // back to all-zero for the next pass
         ((s & 1) ? minus_ : plus_)[s >> 1] = 0;
         big_f2_[s] = 0;
