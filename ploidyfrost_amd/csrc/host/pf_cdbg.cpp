@@ -310,6 +310,32 @@ int MappedOut::write(uint64_t off, const char *src, uint64_t len, unsigned threa
     return 0;
 }
 
+char *MappedOut::prepare(uint64_t off, uint64_t len) {
+    if (fd < 0) return nullptr;
+    struct stat sb;
+    if (fstat(fd, &sb) != 0) return nullptr;
+    if ((uint64_t)sb.st_size < off + len && ftruncate(fd, (off_t)(off + len)) != 0) return nullptr;
+    if (off + len > map_len) {
+        if (base) munmap(base, map_len);
+        base = nullptr;
+        const size_t want = (size_t)((off + len) + (off + len) / 4 + (8u << 20));
+        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+        if (m == MAP_FAILED) { map_len = 0; return nullptr; }
+        base = static_cast<char *>(m);
+        map_len = want;
+    }
+    return base + off;
+}
+
+void copy_spans(const CopySpan *spans, size_t n, unsigned threads) {
+    constexpr uint64_t PIECE = 1u << 20;
+    std::vector<CopySpan> cut;
+    for (size_t i = 0; i < n; ++i)
+        for (uint64_t at = 0; at < spans[i].len; at += PIECE)
+            cut.push_back(CopySpan{spans[i].dst + at, spans[i].src + at, std::min<uint64_t>(PIECE, spans[i].len - at)});
+    parallel_chunks(cut.size(), 1, threads, [&](size_t i, size_t, size_t) { memcpy(cut[i].dst, cut[i].src, (size_t)cut[i].len); });
+}
+
 int MappedOut::reserve(uint64_t bytes) {
     if (fd < 0) return 1;
     struct stat sb;

@@ -297,9 +297,17 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
             PinnedBuf<char> &hb = cx_.slab[d.hslab];
             // append: every stream at its running offset through a shared mapping, copied by all threads side by side
-            if (write_files_)
-                for (int s = 0; s < PF_CALL_STREAMS; ++s)
-                    if (maps[s].write(files[(size_t)s].bytes, hb.p + off[s], d.res.text_len[s], T)) files[(size_t)s].rc = 1;
+            if (write_files_) {
+                CopySpan spans[PF_CALL_STREAMS];
+                size_t n_spans = 0;
+                for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+                    if (!d.res.text_len[s]) continue;
+                    char *dst = maps[s].prepare(files[(size_t)s].bytes, d.res.text_len[s]);
+                    if (dst) spans[n_spans++] = CopySpan{dst, hb.p + off[s], d.res.text_len[s]};
+                    else if (maps[s].write(files[(size_t)s].bytes, hb.p + off[s], d.res.text_len[s], T)) files[(size_t)s].rc = 1;   // (no mapping: pwrite)
+                }
+                copy_spans(spans, n_spans, T);   // all ten streams in one dispatch of the pool
+            }
             last_allfre_.append(hb.p + off[0], d.res.text_len[0]);
             for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].bytes += d.res.text_len[s];
             write_s += since(tw);

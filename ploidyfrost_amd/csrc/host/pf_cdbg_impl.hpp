@@ -56,6 +56,10 @@ struct MappedOut {
     ~MappedOut() { close_file(); }
     int open_for(const std::string &p);                                            // 0 = ok
     int write(uint64_t off, const char *src, uint64_t len, unsigned threads);      // grows file and mapping as needed
+    // the first half of write() alone: file and mapping hold [off, off + len) afterwards; where to copy to (nullptr: no mapping,
+    // use write()).  copy_spans() below then copies the spans of several files in ONE dispatch of the thread pool -- a
+    // dispatch per file costs more than the copy of a small stream.
+    char *prepare(uint64_t off, uint64_t len);
     int finish(uint64_t final_len);                                                // the file's length after this pass
     // A file about to receive ~bytes for the first time: sized and mapped now (before anybody writes), its pages are then
     // faulted in by populate() on helper threads while the first pieces are still on their way -- a fresh page costs the kernel
@@ -64,6 +68,13 @@ struct MappedOut {
     void populate(uint64_t from, uint64_t to) const;
     void close_file();
 };
+
+struct CopySpan {
+    char *dst;
+    const char *src;
+    uint64_t len;
+};
+void copy_spans(const CopySpan *spans, size_t n, unsigned threads);
 
 // one bubble to call, in output order
 struct CDBG::Task {
