@@ -360,7 +360,8 @@ int pf_call_text_range(pf_ctx *, int slab, uint64_t first, uint64_t count, uint6
 /* The two with a choice of where the aligned batch lies ("lane" 0 or 1; the calls above use lane 0): the rows of one range of
  * bubbles are formatted from one host thread (pf_call_text_range_lane: a stream, scratch and counters of its own) while another
  * aligns the next range into the other lane -- the copy of the text to the host, the slowest stage of a large pass, then runs
- * beside the alignment kernels instead of after them.  At most one call of each kind at a time, never on the same lane. */
+ * beside the alignment kernels instead of after them.  At most one call of each kind at a time, never on the same lane.  Their
+ * error messages are set under a lock, and pf_last_error hands every calling thread a copy of its own. */
 int pf_call_align_lane(pf_ctx *, int lane, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch,
                        double gap, pf_call_result *out);
 int pf_call_text_range_lane(pf_ctx *, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base,

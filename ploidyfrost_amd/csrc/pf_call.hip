@@ -46,7 +46,7 @@ using namespace pf;
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -173,7 +173,7 @@ void call_invalidate(pf_ctx *ctx) {  // a new graph or count table: resident sca
 
 }  // namespace pf
 
-#define NEED_TEXT(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = "pf_call_text: out of device memory"; return PF_ERR_HIP; } } while (0)
+#define NEED_TEXT(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = "pf_call_text: out of device memory"; return PF_ERR_HIP; } } while (0)
 
 namespace {
 
@@ -1663,10 +1663,10 @@ __global__ void k_format_doubles(const double *__restrict__ x, uint64_t n, char 
 // T1 state written on the device (pf_replay_device, pf_cc.hip): the arrays pf_call_set_state would fill, for their writer
 namespace pf {
 int call_state_arrays(pf_ctx *ctx, uint8_t **flags, uint32_t **plus, uint32_t **minus) {
-    if (!ctx->d_seq || !ctx->has_adj) { ctx->err = "T1 state: graph and adjacency first"; return PF_ERR_ARG; }
+    if (!ctx->d_seq || !ctx->has_adj) { pf::CtxErr{ctx} = "T1 state: graph and adjacency first"; return PF_ERR_ARG; }
     CallState *S = state_of(ctx);
     const size_t N = ctx->N;
-    if (!S->flags.ensure(N + 1) || !S->plus.ensure(N * 4) || !S->minus.ensure(N * 4)) { ctx->err = "T1 state: out of device memory"; return PF_ERR_HIP; }
+    if (!S->flags.ensure(N + 1) || !S->plus.ensure(N * 4) || !S->minus.ensure(N * 4)) { pf::CtxErr{ctx} = "T1 state: out of device memory"; return PF_ERR_HIP; }
     *flags = S->flags.as<uint8_t>();
     *plus = S->plus.as<uint32_t>();
     *minus = S->minus.as<uint32_t>();
@@ -1703,11 +1703,11 @@ int pf_format_doubles(pf_ctx *ctx, const double *values, uint64_t n, char *text,
 
 int pf_call_set_state(pf_ctx *ctx, const uint8_t *flags, const uint32_t *plus, const uint32_t *minus) {
     if (!ctx || !flags || !plus || !minus) return PF_ERR_ARG;
-    if (!ctx->d_seq || !ctx->has_adj) { ctx->err = "pf_call_set_state: graph and adjacency first"; return PF_ERR_ARG; }
+    if (!ctx->d_seq || !ctx->has_adj) { pf::CtxErr{ctx} = "pf_call_set_state: graph and adjacency first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     CallState *S = state_of(ctx);
     const size_t N = ctx->N;
-    if (!S->flags.ensure(N + 1) || !S->plus.ensure(N * 4) || !S->minus.ensure(N * 4)) { ctx->err = "pf_call_set_state: out of device memory"; return PF_ERR_HIP; }
+    if (!S->flags.ensure(N + 1) || !S->plus.ensure(N * 4) || !S->minus.ensure(N * 4)) { pf::CtxErr{ctx} = "pf_call_set_state: out of device memory"; return PF_ERR_HIP; }
     PF_HIP(hipMemcpyAsync(S->flags.p, flags, N, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(S->plus.p, plus, N * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(S->minus.p, minus, N * 4, hipMemcpyDefault, ctx->stream));
@@ -1720,7 +1720,7 @@ int pf_call_set_state(pf_ctx *ctx, const uint8_t *flags, const uint32_t *plus, c
 int pf_call_get_state(pf_ctx *ctx, uint8_t *flags, uint32_t *plus, uint32_t *minus) {
     if (!ctx || !ctx->call) return PF_ERR_ARG;
     CallState *S = ctx->call;
-    if (!S->have_state) { ctx->err = "pf_call_get_state: no T1 state on the device"; return PF_ERR_ARG; }
+    if (!S->have_state) { pf::CtxErr{ctx} = "pf_call_get_state: no T1 state on the device"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     const size_t N = ctx->N;
     PF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1739,13 +1739,13 @@ int pf_call_set_format(pf_ctx *ctx, int reference_mt) {
 int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_t *text_len) {
     if (!ctx || !n_rows || !text_len) return PF_ERR_ARG;
     CallState *S = ctx->call;
-    if (!S || !S->have_state) { ctx->err = "pf_superbubble_rows: pf_call_set_state first"; return PF_ERR_ARG; }
+    if (!S || !S->have_state) { pf::CtxErr{ctx} = "pf_superbubble_rows: pf_call_set_state first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t N = ctx->N;
     const size_t n1 = (size_t)N + 1;
     if (!S->sb_cnt.ensure(n1 * 4) || !S->sb_base.ensure(n1 * 4) || !S->sb_sizes.ensure(n1 * 4) || !S->sb_offs.ensure(n1 * 8)) {
-        ctx->err = "pf_superbubble_rows: out of device memory";
+        pf::CtxErr{ctx} = "pf_superbubble_rows: out of device memory";
         return PF_ERR_HIP;
     }
     SbArgs a;
@@ -1758,7 +1758,7 @@ int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_
     hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sb_sizes.as<uint32_t>(), Widen());
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, S->sb_cnt.as<uint32_t>(), S->sb_base.as<uint32_t>(), (int)n1, st));
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, wide, S->sb_offs.as<uint64_t>(), (int)n1, st));
-    if (!S->scan_tmp.ensure(std::max(t1, t2))) { ctx->err = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
+    if (!S->scan_tmp.ensure(std::max(t1, t2))) { pf::CtxErr{ctx} = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, t1, S->sb_cnt.as<uint32_t>(), S->sb_base.as<uint32_t>(), (int)n1, st));
     ctx_begin(ctx, PF_K_CALL_FORMAT);
     k_sb_format<false><<<grid, 256, 0, st>>>(a);
@@ -1769,7 +1769,7 @@ int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_
     PF_HIP(hipMemcpyAsync(&rows, S->sb_base.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&len, S->sb_offs.as<uint64_t>() + N, 8, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
-    if (!S->sb_out.ensure(std::max<uint64_t>(len, 16))) { ctx->err = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
+    if (!S->sb_out.ensure(std::max<uint64_t>(len, 16))) { pf::CtxErr{ctx} = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
     a.out = S->sb_out.as<char>();
     ctx_begin(ctx, PF_K_CALL_FORMAT);
     k_sb_format<true><<<grid, 256, 0, st>>>(a);
@@ -1794,13 +1794,13 @@ int pf_superbubble_fetch(pf_ctx *ctx, char *dst, uint64_t len) {
 }
 
 int pf_call_coverage(pf_ctx *ctx) {
-    if (!ctx || !ctx->d_seq || !ctx->d_tab) { if (ctx) ctx->err = "pf_call_coverage: graph and count table first"; return PF_ERR_ARG; }
+    if (!ctx || !ctx->d_seq || !ctx->d_tab) { if (ctx) pf::CtxErr{ctx} = "pf_call_coverage: graph and count table first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     CallState *S = state_of(ctx);
     const size_t N = ctx->N;
     const int slots = ctx->tab_exact ? 2 : 1;
     if (!S->cov_sum.ensure(N * slots * 8) || !S->cov_min.ensure(N * slots * 4) || !S->cov_miss.ensure(N * slots)) {
-        ctx->err = "pf_call_coverage: out of device memory";
+        pf::CtxErr{ctx} = "pf_call_coverage: out of device memory";
         return PF_ERR_HIP;
     }
     int st;
@@ -1820,15 +1820,15 @@ int pf_call_coverage(pf_ctx *ctx) {
 int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides) {
     if (!ctx || !n_sides) return PF_ERR_ARG;
     CallState *S = ctx->call;
-    if (!S || !S->have_state || !S->have_cov) { ctx->err = "pf_call_scan: pf_call_set_state and pf_call_coverage first"; return PF_ERR_ARG; }
+    if (!S || !S->have_state || !S->have_cov) { pf::CtxErr{ctx} = "pf_call_scan: pf_call_set_state and pf_call_coverage first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t N = ctx->N;
-    if (!S->side_cnt.ensure(((size_t)N + 1) * 4) || !S->side_base.ensure(((size_t)N + 1) * 4)) { ctx->err = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
+    if (!S->side_cnt.ensure(((size_t)N + 1) * 4) || !S->side_base.ensure(((size_t)N + 1) * 4)) { pf::CtxErr{ctx} = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
     k_call_count_sides<<<(N + 1 + 255) / 256, 256, 0, st>>>(S->flags.as<uint8_t>(), N, S->side_cnt.as<uint32_t>());
     size_t tmp = 0;
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, S->side_cnt.as<uint32_t>(), S->side_base.as<uint32_t>(), (int)(N + 1), st));
-    if (!S->scan_tmp.ensure(tmp)) { ctx->err = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
+    if (!S->scan_tmp.ensure(tmp)) { pf::CtxErr{ctx} = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, tmp, S->side_cnt.as<uint32_t>(), S->side_base.as<uint32_t>(), (int)(N + 1), st));
     uint32_t total = 0;
     PF_HIP(hipMemcpyAsync(&total, S->side_base.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
@@ -1841,7 +1841,7 @@ int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides)
     if (total == 0) return PF_OK;
     if (!S->sides.ensure((size_t)total * sizeof(pf_call_side)) || !S->ctask.ensure((size_t)total * sizeof(CallTask)) ||
         !S->target.ensure((size_t)total * 4)) {
-        ctx->err = "pf_call_scan: out of device memory";
+        pf::CtxErr{ctx} = "pf_call_scan: out of device memory";
         return PF_ERR_HIP;
     }
     ScanArgs a;
@@ -1872,7 +1872,7 @@ int pf_call_resolve(pf_ctx *ctx, uint64_t *n_bubbles, uint32_t *err, uint32_t *e
     hipStream_t st = ctx->stream;
     if (!S->pending.ensure(n * 4) || !S->killed.ensure(n) || !S->rstate.ensure(n) || !S->rflag.ensure(n * 4) || !S->rsmall.ensure(64) ||
         !S->kept.ensure(n * 4)) {
-        ctx->err = "pf_call_resolve: out of device memory";
+        pf::CtxErr{ctx} = "pf_call_resolve: out of device memory";
         return PF_ERR_HIP;
     }
     PF_HIP(hipMemsetAsync(S->pending.p, 0, n * 4, st));
@@ -1888,7 +1888,7 @@ int pf_call_resolve(pf_ctx *ctx, uint64_t *n_bubbles, uint32_t *err, uint32_t *e
     const unsigned grid = (unsigned)((n + 255) / 256);
     k_call_pending<<<grid, 256, 0, st>>>(a);
     for (uint64_t round = 0;; ++round) {
-        if (round > n + 2) { ctx->err = "pf_call_resolve: the driver pass does not settle"; return PF_ERR_ARG; }
+        if (round > n + 2) { pf::CtxErr{ctx} = "pf_call_resolve: the driver pass does not settle"; return PF_ERR_ARG; }
         k_call_resolve<<<grid, 256, 0, st>>>(a);
         PF_HIP(hipMemsetAsync(small, 0, 4, st));
         k_call_resolve<<<grid, 256, 0, st>>>(a);   // two rounds per look at the counter: the common case needs exactly two
@@ -1908,7 +1908,7 @@ int pf_call_resolve(pf_ctx *ctx, uint64_t *n_bubbles, uint32_t *err, uint32_t *e
     size_t tmp = 0;
     hipcub::CountingInputIterator<uint32_t> ids(0);
     PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp, ids, S->rflag.as<uint32_t>(), S->kept.as<uint32_t>(), small + 2, (int)n, st));
-    if (!S->scan_tmp.ensure(tmp)) { ctx->err = "pf_call_resolve: out of device memory"; return PF_ERR_HIP; }
+    if (!S->scan_tmp.ensure(tmp)) { pf::CtxErr{ctx} = "pf_call_resolve: out of device memory"; return PF_ERR_HIP; }
     PF_HIP(hipcub::DeviceSelect::Flagged(S->scan_tmp.p, tmp, ids, S->rflag.as<uint32_t>(), S->kept.as<uint32_t>(), small + 2, (int)n, st));
     unsigned int sel = 0;
     PF_HIP(hipMemcpyAsync(&sel, small + 2, 4, hipMemcpyDeviceToHost, st));
@@ -1932,9 +1932,9 @@ int pf_call_sides(pf_ctx *ctx, pf_call_side *out, uint64_t cap) {
 int pf_call_select(pf_ctx *ctx, const uint32_t *side_index, uint64_t n_tasks) {
     if (!ctx || !ctx->call || (n_tasks && !side_index)) return PF_ERR_ARG;
     CallState *S = ctx->call;
-    if (n_tasks > S->n_sides) { ctx->err = "pf_call_select: more bubbles than open sides"; return PF_ERR_ARG; }
+    if (n_tasks > S->n_sides) { pf::CtxErr{ctx} = "pf_call_select: more bubbles than open sides"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
-    if (!S->kept.ensure(std::max<size_t>(n_tasks, 1) * 4)) { ctx->err = "pf_call_select: out of device memory"; return PF_ERR_HIP; }
+    if (!S->kept.ensure(std::max<size_t>(n_tasks, 1) * 4)) { pf::CtxErr{ctx} = "pf_call_select: out of device memory"; return PF_ERR_HIP; }
     if (n_tasks) PF_HIP(hipMemcpyAsync(S->kept.p, side_index, (size_t)n_tasks * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
     S->n_tasks = n_tasks;
@@ -1946,19 +1946,19 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
                        pf_call_result *out) {
     if (!ctx || !out || lane < 0 || lane > 1) return PF_ERR_ARG;
     CallState *S = ctx->call;
-    if (!S || t0 > t1 || t1 > S->n_tasks) { ctx->err = "pf_call_align: range outside the selection"; return PF_ERR_ARG; }
+    if (!S || t0 > t1 || t1 > S->n_tasks) { pf::CtxErr{ctx} = "pf_call_align: range outside the selection"; return PF_ERR_ARG; }
     memset(out, 0, sizeof(*out));
     CallState::AlignOut &O = S->lane[lane];
     O.nb = 0;
     O.t0 = t0;
     if (t1 == t0) return PF_OK;
-    if (t1 - t0 > (1u << 24)) { ctx->err = "pf_call_align: at most 2^24 bubbles per batch"; return PF_ERR_ARG; }
+    if (t1 - t0 > (1u << 24)) { pf::CtxErr{ctx} = "pf_call_align: at most 2^24 bubbles per batch"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t nb = (uint32_t)(t1 - t0);
     const int k = ctx->k;
     const char *oom = "pf_call_run: out of device memory";
-#define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = oom; return PF_ERR_HIP; } } while (0)
+#define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
     NEED(S->counters, sizeof(CallCounters));
     NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
     NEED(S->queues, (size_t)NQ * nb * 4);
@@ -1989,7 +1989,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     unsigned long long heads[4] = {0, 0, 0, 0};
     uint64_t n_jobs = 0;
     for (int attempt = 0;; ++attempt) {
-        if (attempt > 5) { ctx->err = "pf_call_align: pools do not converge"; return PF_ERR_OVERFLOW; }
+        if (attempt > 5) { pf::CtxErr{ctx} = "pf_call_align: pools do not converge"; return PF_ERR_OVERFLOW; }
         const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 1024);
         const uint64_t text_cap = std::max<uint64_t>(S->text_pool, (uint64_t)nb * 32 + (1u << 16));
         const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, 160ull * nb + (1u << 16));
@@ -2092,7 +2092,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             char where[96];
             snprintf(where, sizeof where, " (superbubble from unitig %u%c to unitig %u%c)", (hc.err_entrance >> 1) + 1, (hc.err_entrance & 1) ? '-' : '+',
                      (hc.err_exit >> 1) + 1, (hc.err_exit & 1) ? '-' : '+');
-            ctx->err = std::string(hc.err & 1u ? "pf_call_run: a bubble has more than 255 paths" : "pf_call_run: a bubble is deeper than the complex size allows") + where;
+            pf::CtxErr{ctx} = std::string(hc.err & 1u ? "pf_call_run: a bubble has more than 255 paths" : "pf_call_run: a bubble is deeper than the complex size allows") + where;
             return PF_ERR_ARG;
         }
         S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
@@ -2205,11 +2205,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             }
             PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
             PF_HIP(hipStreamSynchronize(st));
-            if (hc.err & 2u) { ctx->err = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
-            if (hc.err & 4u) { ctx->err = "CDBG::PloidyEstimation(): site string outside an aligned row"; return PF_ERR_ARG; }
-            if (hc.err & 16u) { ctx->err = "CDBG::PloidyEstimation(): site string longer than 2k + 64"; return PF_ERR_ARG; }
+            if (hc.err & 2u) { pf::CtxErr{ctx} = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
+            if (hc.err & 4u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): site string outside an aligned row"; return PF_ERR_ARG; }
+            if (hc.err & 16u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): site string longer than 2k + 64"; return PF_ERR_ARG; }
             if (hc.sv_head > sv_cap) {
-                if (attempt >= 2) { ctx->err = "pf_call_run: site value pool does not converge"; return PF_ERR_OVERFLOW; }
+                if (attempt >= 2) { pf::CtxErr{ctx} = "pf_call_run: site value pool does not converge"; return PF_ERR_OVERFLOW; }
                 S->sv_pool = hc.sv_head + hc.sv_head / 8 + 1024;
                 continue;
             }
@@ -2250,7 +2250,7 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     CallState *S = ctx->call;
     if (!S) return PF_ERR_ARG;
     const CallState::AlignOut &O = S->lane[lane];
-    if (first + count > O.nb) { ctx->err = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
+    if (first + count > O.nb) { pf::CtxErr{ctx} = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
     for (int s = 0; s < N_STREAMS; ++s) S->out_len[slab][s] = 0;
     *out = O.cur;
     out->n_called = 0;
@@ -2277,7 +2277,7 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     NEED_TEXT(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
     NEED_TEXT(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
     const char *oom = "pf_call_text: out of device memory";
-#define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { ctx->err = oom; return PF_ERR_HIP; } } while (0)
+#define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
     NEED(S->totals, 16 * 8);
     NEED(S->tcounters, sizeof(CallCounters));
     CallCounters *d_cnt = S->tcounters.as<CallCounters>();

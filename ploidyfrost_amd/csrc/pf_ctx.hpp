@@ -135,6 +135,15 @@ struct pf_ctx {
 };
 
 namespace pf {
+// pf_ctx::err written from a call that may run beside another one on the same context (pf_call_align_lane on one host thread,
+// pf_call_text_range_lane on another): `CtxErr{ctx} = "..."` assigns under the context's lock; pf_last_error copies under it
+struct CtxErr {
+    pf_ctx *c;
+    void operator=(std::string s) const {
+        std::lock_guard<std::mutex> lk(c->launch_mu);
+        c->err = std::move(s);
+    }
+};
 struct Kc4Args;
 int launch_cov_stream(pf_ctx *ctx, Kc4Args a, uint32_t n_colors, bool wide, bool colored);  // pf_device.hip
 int ctx_begin(pf_ctx *ctx, int kernel);

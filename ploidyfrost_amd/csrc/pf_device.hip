@@ -738,7 +738,16 @@ extern "C" {
 
 const char *pf_kernel_name(int kernel) { return (kernel >= 0 && kernel < PF_K_COUNT_) ? kKernelNames[kernel] : "?"; }
 
-const char *pf_last_error(const pf_ctx *ctx) { return ctx ? ctx->err.c_str() : g_create_err.c_str(); }
+const char *pf_last_error(const pf_ctx *ctx) {
+    if (!ctx) return g_create_err.c_str();
+    // (a copy per calling thread: two calls of the calling pipeline may run side by side on one context, see pf::CtxErr)
+    static thread_local std::string mine;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<pf_ctx *>(ctx)->launch_mu);
+        mine = ctx->err;
+    }
+    return mine.c_str();
+}
 
 int pf_warmup(int device) {
     // brings up the HIP runtime and the device's primary context (a tenth of a second): a caller with other work to do first --
