@@ -372,6 +372,10 @@ int pf_call_fetch(pf_ctx *, int slab, int stream, char *dst, uint64_t len);
 /* All PF_CALL_STREAMS streams of a slab, packed one after the other into dst (len[s] bytes of stream s): the copies are issued
  * together and waited for once. */
 int pf_call_fetch_slab(pf_ctx *, int slab, char *dst, const uint64_t *len);
+/* The same packed slab in byte ranges, without waiting: range `slot` (0 / 1, alternating) is complete when pf_call_fetch_wait(slot)
+ * returns, so that the caller copies one range into its files while the next crosses PCIe (a rank's one large slab of a sliced run). */
+int pf_call_fetch_range(pf_ctx *, int slab, uint64_t first_byte, char *dst, uint64_t len, int slot);
+int pf_call_fetch_wait(pf_ctx *, int slot);
 /* O1's number formatting alone (test hook): text + 32 * i receives printf("%g", values[i]) without terminator, len[i] its length
  * [host|dev] */
 int pf_format_doubles(pf_ctx *, const double *values, uint64_t n, char *text, uint8_t *len);

@@ -149,23 +149,44 @@ int CDBG::ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL
     for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += slice_res_.text_len[s]; }
     PinnedBuf<char> &hb = cx_.slab[0];
     hb.ensure(ctx_, std::max<uint64_t>(total, 1));
-    for (int s = 0; s < PF_CALL_STREAMS; ++s) {
-        const int st = pf_call_fetch(ctx_, 0, s, hb.p + off[s], slice_res_.text_len[s]);
-        if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): copy of a text slab failed");
-    }
-    last_allfre_.assign(hb.p + off[0], slice_res_.text_len[0]);
     MappedOut *maps = out_maps_.get();
     for (int s = 0; s < PF_CALL_STREAMS; ++s)
         if (maps[s].open_for(outdir_ + "/" + outpre + kStreamSuffix[s])) return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + kStreamSuffix[s] + " file error");
     // every rank first gives the files their final length -- the same value from all of them, so the order does not matter and no
-    // rank ever cuts off what another has written -- and then stores its slabs at its offsets
+    // rank ever cuts off what another has written -- and then stores its slab at its offsets
     int rc = 0;
     if (truncate)
         for (int s = 0; s < PF_CALL_STREAMS; ++s) rc |= maps[s].finish(totals[s]);
+    char *dst[PF_CALL_STREAMS];
+    bool mapped = true;
     for (int s = 0; s < PF_CALL_STREAMS; ++s) {
-        rc |= maps[s].write(offsets[s], hb.p + off[s], slice_res_.text_len[s], T);
-        out_bytes_ += slice_res_.text_len[s];
+        dst[s] = slice_res_.text_len[s] ? maps[s].prepare(offsets[s], slice_res_.text_len[s]) : nullptr;
+        if (slice_res_.text_len[s] && !dst[s]) mapped = false;
     }
+    // The slab comes over PCIe in ranges of its packed layout (stream after stream); range i is copied into the mapped files --
+    // the parts of the streams it covers, one dispatch of the thread pool -- while range i + 1 is on its way.
+    constexpr uint64_t RANGE = 32u << 20;
+    const uint64_t n_ranges = (total + RANGE - 1) / RANGE;
+    auto fetch = [&](uint64_t i) { return pf_call_fetch_range(ctx_, 0, i * RANGE, hb.p + i * RANGE, std::min<uint64_t>(RANGE, total - i * RANGE), (int)(i & 1)); };
+    int st = n_ranges ? fetch(0) : PF_OK;
+    for (uint64_t i = 0; i < n_ranges && st == PF_OK; ++i) {
+        if (i + 1 < n_ranges) st = fetch(i + 1);
+        if (st == PF_OK) st = pf_call_fetch_wait(ctx_, (int)(i & 1));
+        if (st != PF_OK || !mapped) continue;
+        const uint64_t a = i * RANGE, b = std::min<uint64_t>(total, a + RANGE);
+        CopySpan spans[PF_CALL_STREAMS];
+        size_t n_spans = 0;
+        for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+            const uint64_t lo = std::max<uint64_t>(a, off[s]), hi = std::min<uint64_t>(b, off[s] + slice_res_.text_len[s]);
+            if (lo < hi) spans[n_spans++] = CopySpan{dst[s] + (lo - off[s]), hb.p + lo, hi - lo};
+        }
+        copy_spans(spans, n_spans, T);
+    }
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): copy of a text slab failed");
+    if (!mapped)   // (a file that cannot be mapped: written through the descriptor)
+        for (int s = 0; s < PF_CALL_STREAMS; ++s) rc |= maps[s].write(offsets[s], hb.p + off[s], slice_res_.text_len[s], T);
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) out_bytes_ += slice_res_.text_len[s];
+    last_allfre_.assign(hb.p + off[0], slice_res_.text_len[0]);
     times_.write_s = since(t);
     if (rc) return fail(PF_ERR_ARG, "CDBG:: write error on the result files");
     return 0;

@@ -138,6 +138,7 @@ struct CallState {
     DevBuf out[PF_CALL_SLABS];
     uint64_t out_len[PF_CALL_SLABS][N_STREAMS] = {}, out_off[PF_CALL_SLABS][N_STREAMS] = {};
     hipStream_t copy_stream = nullptr;
+    hipEvent_t fetch_ev[2] = {nullptr, nullptr};   // pf_call_fetch_range / pf_call_fetch_wait
     // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
@@ -152,6 +153,8 @@ struct CallState {
         if (text_stream) { (void)hipStreamDestroy(text_stream); text_stream = nullptr; }
         for (DevBuf &b : out) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
+        for (hipEvent_t &e : fetch_ev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (side_stream) { (void)hipStreamDestroy(side_stream); side_stream = nullptr; }
         if (ev_prep) { (void)hipEventDestroy(ev_prep); ev_prep = nullptr; }
         if (ev_paths) { (void)hipEventDestroy(ev_paths); ev_paths = nullptr; }
@@ -2386,6 +2389,28 @@ int pf_call_fetch_slab(pf_ctx *ctx, int slab, char *dst, const uint64_t *len) {
     }
     if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
+}
+
+// A slab fetched in byte ranges of its packed layout (stream after stream, as pf_call_fetch_slab delivers it), without waiting:
+// range number `slot` (0 or 1, alternating) is complete when pf_call_fetch_wait(slot) returns -- the caller copies range i into its
+// files while range i + 1 crosses PCIe.
+int pf_call_fetch_range(pf_ctx *ctx, int slab, uint64_t first_byte, char *dst, uint64_t len, int slot) {
+    if (!ctx || !ctx->call || slab < 0 || slab >= PF_CALL_SLABS || slot < 0 || slot > 1 || (len && !dst)) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    uint64_t all = 0;
+    for (int s = 0; s < N_STREAMS; ++s) all += S->out_len[slab][s];
+    if (first_byte + len > all) return PF_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess || !S->copy_stream) return PF_ERR_HIP;
+    if (!S->fetch_ev[slot] && hipEventCreateWithFlags(&S->fetch_ev[slot], hipEventDisableTiming) != hipSuccess) return PF_ERR_HIP;
+    if (len && hipMemcpyAsync(dst, S->out[slab].as<char>() + first_byte, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (hipEventRecord(S->fetch_ev[slot], S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    return PF_OK;
+}
+
+int pf_call_fetch_wait(pf_ctx *ctx, int slot) {
+    if (!ctx || !ctx->call || slot < 0 || slot > 1 || !ctx->call->fetch_ev[slot]) return PF_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
+    return hipEventSynchronize(ctx->call->fetch_ev[slot]) == hipSuccess ? PF_OK : PF_ERR_HIP;
 }
 
 }  // extern "C"
