@@ -80,7 +80,9 @@ int pf_upload_graph(pf_ctx *, const uint64_t *seq_words, const uint64_t *seq_off
  * bits per base, the k-length ones canonicalised; the graph is resident afterwards as after pf_upload_graph, in the unitig order
  * of pf_upload_graph's callers before abundant k-mers are moved (segments longer than k in file order, then the k-length ones).
  * PF_ERR_ARG with the loader's messages: "missing fields in a segment line", "segment shorter than k", "non-ACGT base in a
- * segment", "no segments in the GFA file".  pf_gfa_segments hands the host what it keeps per unitig (once per ingest; any
+ * segment", "no segments in the GFA file".  A sequence field is every byte between its tabs / the line feed, as GFA_Parser.cpp:497-520
+ * takes it: the '\r' that ends the sequence of a CRLF file is its last base (A in a segment longer than k, CompressedSequence.cpp:597-614;
+ * T in a k-length one, Kmer.cpp:92-107), as in the reference; any other byte that is no base is refused.  pf_gfa_segments hands the host what it keeps per unitig (once per ingest; any
  * pointer may be NULL): length, offset of the sequence field inside body, file rank among the segments, the DA:Z tag (-1 =
  * none; *any_da = some segment had one), and whether a k-length unitig is stored as its reverse complement. */
 int pf_gfa_ingest(pf_ctx *, const char *body, uint64_t n_bytes, int gfa_version, int k, uint32_t *n_unitigs, uint32_t *n_short);
@@ -353,6 +355,22 @@ int pf_call_run(pf_ctx *, int slab, uint64_t t0, uint64_t t1, uint64_t var_count
 int pf_call_align(pf_ctx *, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
                   pf_call_result *out);
 int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *out);
+/* What pf_call_align(_lane) left resident for the bubbles of its range, before any text is made of it -- the kernel-level view the
+ * parity tests hold against SeqAlign::SequenceAlignment (src/SeqAlign.cpp:550-640) bubble by bubble: per bubble its endpoints and,
+ * for a strict one, its sorted inner unitigs with their mean coverages (sortSeq_simple, src/CDBG.cpp:482-551); its pf_bubble_result
+ * (aligned rows, variant columns, allele groups, indel lengths: offsets into the pools below, as pf_align_bubbles returns them;
+ * pf_bubble_site.pad_ of a branching bubble's site = 1 when every site string passed readCov's range test, src/CDBG.cpp:1548-1551);
+ * and for a branching bubble, from sv[sv_off[bubble]], per site maxnum group coverages and their sum (src/CDBG.cpp:1527-1551).
+ * cap[5] / used[1..5]: row text bytes, sites, group bytes, indel lengths, site values; used[0] = bubbles.  All pointers NULL:
+ * sizes only.  [host] */
+typedef struct pf_call_bubble {
+    uint32_t entrance_ov, exit_ov;
+    uint32_t strict, n_inner;
+    uint32_t inner[4];
+    double cov[4], core_mean, cov_sum;
+} pf_call_bubble;
+int pf_call_peek(pf_ctx *, int lane, pf_call_bubble *bubbles, pf_bubble_result *results, uint64_t *sv_off, uint64_t bubble_cap, char *text,
+                 pf_bubble_site *sites, uint8_t *groups, uint32_t *ilen, double *sv, const uint64_t cap[5], uint64_t used[6]);
 /* K-TEXT for bubbles [first, first + count) of the batch pf_call_align left resident: one large alignment launch (its kernels'
  * tails are paid once) can be formatted, fetched and written in pieces.  var_count_base is the same for every piece: the bubbles
  * called before the aligned batch; out->n_called = those called inside the piece. */

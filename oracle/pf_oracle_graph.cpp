@@ -240,6 +240,10 @@ bool Graph::load_gfa(const std::string &path) {
         size_t si = (version == 1) ? 1 : 2;
         if (f.size() <= si) { err = "missing fields in segment line"; return false; }
         std::string s = f[si];
+        // the field is taken up to the tab / line feed (GFA_Parser.cpp:497-520): the '\r' of a CRLF line that ends with the
+        // sequence is its last byte -- stored as A in a segment longer than k (CompressedSequence.cpp:597-614: bits['\r'] = 0),
+        // as T in a k-length one (Kmer::set_kmer, Kmer.cpp:92-107: ((c & 4) >> 1) + ... = 3)
+        if (!s.empty() && s.back() == '\r') s.back() = (int)s.size() == k ? 'T' : 'A';
         for (auto &c : s) {
             int bc = base_code(c);
             if (bc < 0) { err = "non-ACGT base in segment"; return false; }

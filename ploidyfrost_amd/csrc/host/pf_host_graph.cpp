@@ -32,6 +32,11 @@ inline int code_of(char c) {
     }
 }
 const char kBase[4] = {'A', 'C', 'G', 'T'};
+// The byte at the end of a sequence field.  GFA_Parser.cpp:497-520 takes the field up to the tab / line feed, so the '\r' of a
+// CRLF file whose segment line ends with the sequence is the sequence's last byte; Bifrost stores it as A in a segment longer
+// than k (CompressedSequence::bits, CompressedSequence.cpp:597-614) and as T in a k-length one (Kmer::set_kmer, Kmer.cpp:92-107),
+// and no minimizer ever covers it (minHashIterator.hpp:63-119).  Every other byte that is no base: -1 (refused, csrc/pf_gfa.hip).
+inline int code_of_last(char c, bool k_length) { return c == '\r' ? (k_length ? 3 : 0) : code_of(c); }
 
 struct Mapped {
     const char *p = nullptr;
@@ -124,8 +129,7 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err, bool defer_n
                 if (!fld) { pc.err = "missing fields in a segment line"; return; }
                 const char *t = (const char *)memchr(fld, '\t', (size_t)(e - fld));
                 if (!t) t = e;
-                uint32_t len = (uint32_t)(t - fld);
-                if (len && fld[len - 1] == '\r') len--;
+                const uint32_t len = (uint32_t)(t - fld);   // (a '\r' before the line feed is part of the field)
                 if ((int)len < k) { pc.err = "segment shorter than k"; return; }
                 int16_t da = -1;
                 for (const char *tag = t; tag < e;) {  // optional tags after the sequence
@@ -181,7 +185,7 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err, bool defer_n
             const Seg &sg = longs[i];
             char *dst = text.data() + off[i];
             for (uint32_t j = 0; j < sg.len; ++j) {
-                const int c = code_of(sg.s[j]);
+                const int c = j + 1 == sg.len ? code_of_last(sg.s[j], false) : code_of(sg.s[j]);
                 if (c < 0) { bad_base.store(true, std::memory_order_relaxed); return; }
                 dst[j] = kBase[c];
             }
@@ -192,7 +196,7 @@ bool UnitigSet::load_gfa(const std::string &path, std::string &err, bool defer_n
         for (size_t i = b0; i < b1; ++i) {
             const Seg &sg = shorts[i];
             for (int j = 0; j < k; ++j) {
-                const int c = code_of(sg.s[j]);
+                const int c = j + 1 == k ? code_of_last(sg.s[j], true) : code_of(sg.s[j]);
                 if (c < 0) { bad_base.store(true, std::memory_order_relaxed); return; }
                 fw[j] = kBase[c];
                 rc[k - 1 - j] = kBase[3 - c];
@@ -325,13 +329,14 @@ void UnitigSet::ensure_text() {
             const uint32_t L = len_bp[u];
             if ((int)L == k) {
                 for (int j = 0; j < k; ++j) {
-                    const int c = code_of(s[j]);
+                    const int c = j + 1 == k ? code_of_last(s[j], true) : code_of(s[j]);
                     fw[j] = kBase[c & 3];
                     rc[k - 1 - j] = kBase[3 - (c & 3)];
                 }
                 memcpy(dst, memcmp(rc, fw, (size_t)k) < 0 ? rc : fw, (size_t)k);
             } else {
-                for (uint32_t j = 0; j < L; ++j) dst[j] = kBase[code_of(s[j]) & 3];
+                for (uint32_t j = 0; j + 1 < L; ++j) dst[j] = kBase[code_of(s[j]) & 3];
+                dst[L - 1] = kBase[code_of_last(s[L - 1], false) & 3];
             }
         }
     });

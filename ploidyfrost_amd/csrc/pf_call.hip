@@ -127,6 +127,7 @@ struct CallState {
         uint64_t t0 = 0;
         uint32_t nb = 0;
         pf_call_result cur = {};
+        uint64_t used[5] = {};   // pool fill after the last pf_call_align_lane: row text, sites, group bytes, indel lengths, site values
     } lane[2];
     // K-TEXT's own scratch, counters and stream: it may run from another host thread beside pf_call_align (other lane)
     DevBuf sizes, offs, totals, tcounters, tscan;
@@ -1954,6 +1955,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     CallState::AlignOut &O = S->lane[lane];
     O.nb = 0;
     O.t0 = t0;
+    O.cur = pf_call_result{};   // (an empty slice -- fewer bubbles than ranks -- must not hand pf_call_text the previous pass's counters)
     if (t1 == t0) return PF_OK;
     if (t1 - t0 > (1u << 24)) { pf::CtxErr{ctx} = "pf_call_align: at most 2^24 bubbles per batch"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
@@ -2236,7 +2238,46 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     out->n_called = n_called;
     O.nb = nb;
     O.cur = *out;
+    for (int x = 0; x < 4; ++x) O.used[x] = heads[x];
+    O.used[4] = hc.n_branching ? hc.sv_head : 0;
 #undef NEED
+    return PF_OK;
+}
+
+int pf_call_peek(pf_ctx *ctx, int lane, pf_call_bubble *bubbles, pf_bubble_result *results, uint64_t *sv_off, uint64_t bubble_cap, char *text,
+                 pf_bubble_site *sites, uint8_t *groups, uint32_t *ilen, double *sv, const uint64_t cap[5], uint64_t used[6]) {
+    if (!ctx || lane < 0 || lane > 1 || !used) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (!S) { pf::CtxErr{ctx} = "pf_call_peek: pf_call_align first"; return PF_ERR_ARG; }
+    const CallState::AlignOut &O = S->lane[lane];
+    used[0] = O.nb;
+    for (int x = 0; x < 5; ++x) used[x + 1] = O.used[x];
+    if (!O.nb) return PF_OK;
+    if (!bubbles && !results && !text && !sites && !groups && !ilen && !sv && !sv_off) return PF_OK;   // sizes only
+    if (bubble_cap < O.nb || !cap) return PF_ERR_ARG;
+    for (int x = 0; x < 5; ++x)
+        if (cap[x] < O.used[x]) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (bubbles) {
+        std::vector<uint32_t> kept(O.nb);
+        PF_HIP(hipMemcpy(kept.data(), S->kept.as<uint32_t>() + O.t0, (size_t)O.nb * 4, hipMemcpyDeviceToHost));
+        std::vector<CallTask> ct(S->n_sides);
+        if (S->n_sides) PF_HIP(hipMemcpy(ct.data(), S->ctask.p, (size_t)S->n_sides * sizeof(CallTask), hipMemcpyDeviceToHost));
+        for (uint32_t j = 0; j < O.nb; ++j) {
+            const CallTask &t = ct[kept[j]];
+            pf_call_bubble &b = bubbles[j];
+            b.entrance_ov = t.entrance_ov; b.exit_ov = t.exit_ov; b.strict = t.strict; b.n_inner = t.n_inner;
+            for (int x = 0; x < 4; ++x) { b.inner[x] = t.inner[x]; b.cov[x] = t.cov[x]; }
+            b.core_mean = t.core_mean; b.cov_sum = t.cov_sum;
+        }
+    }
+    if (results) PF_HIP(hipMemcpy(results, O.res.p, (size_t)O.nb * sizeof(pf_bubble_result), hipMemcpyDeviceToHost));
+    if (sv_off) PF_HIP(hipMemcpy(sv_off, O.sv_off.p, (size_t)O.nb * 8, hipMemcpyDeviceToHost));
+    if (text && O.used[0]) PF_HIP(hipMemcpy(text, O.otext.p, O.used[0], hipMemcpyDeviceToHost));
+    if (sites && O.used[1]) PF_HIP(hipMemcpy(sites, O.osites.p, O.used[1] * sizeof(pf_bubble_site), hipMemcpyDeviceToHost));
+    if (groups && O.used[2]) PF_HIP(hipMemcpy(groups, O.ogroups.p, O.used[2], hipMemcpyDeviceToHost));
+    if (ilen && O.used[3]) PF_HIP(hipMemcpy(ilen, O.oilen.p, O.used[3] * 4, hipMemcpyDeviceToHost));
+    if (sv && O.used[4]) PF_HIP(hipMemcpy(sv, O.sv.p, O.used[4] * 8, hipMemcpyDeviceToHost));
     return PF_OK;
 }
 

@@ -3,8 +3,15 @@
 // Replaces, for this path, the parse half of CompactedDBG<U>::read (bifrost/src/CompactedDBG.tcc:823-960, 7888-7908 with
 // GFA_Parser.cpp:380-520): segment lines of GFA 1 ("S\t<name>\t<sequence>[\ttags]") or GFA 2 ("S\t<name>\t<length>\t<sequence>
 // [\ttags]"), any other line skipped, a last line without '\n' dropped (GFA_Parser.cpp:486), "DA:Z:<n>" kept for the colored
-// path.  Unitig order = Bifrost's iteration order before the abundant k-mers are moved (host/pf_host_graph.hpp): segments longer
-// than k in file order, then the k-length ones, each stored as min(sequence, reverse complement).
+// path.  The sequence field is every byte up to the next tab or the line feed, as the reference's getline + strchr take it: the
+// carriage return of a CRLF file whose segment line ends with the sequence IS the last byte of that sequence.  Bifrost stores it as
+// a base -- A through CompressedSequence::bits in a segment longer than k (CompressedSequence.cpp:231-239, 597-614), T through
+// Kmer::set_kmer's bit arithmetic in a k-length one (Kmer.cpp:92-107) -- and never hashes it (a minimizer may not end on the last
+// base of a k-mer, minHashIterator.hpp:63-119), so the same graph is built here.  Any other byte that is no base is refused:
+// Bifrost would file such a unitig under minimizers hashed from the raw bytes (RepHash.hpp:109-117) that its stored bases do not
+// have, and what its look-ups then find is an accident of that index.  Unitig order = Bifrost's iteration order before the abundant
+// k-mers are moved (host/pf_host_graph.hpp): segments longer than k in file order, then the k-length ones, each stored as
+// min(sequence, reverse complement).
 //
 //   k_gfa_lines<count / write>  one thread per 2 KiB tile of the file walks the lines that START in its tile (a line start is
 //                               byte 0 or the byte after a '\n'), finds the sequence field of every S-line, and counts /
@@ -100,8 +107,7 @@ __device__ inline LineSeg parse_segment(const char *__restrict__ t, uint64_t q, 
         fld = tab + 1;
     }
     const uint64_t end = find_byte(t, fld, e, '\t');
-    uint32_t len = (uint32_t)(end - fld);
-    if (len && t[fld + len - 1] == '\r') len--;
+    const uint32_t len = (uint32_t)(end - fld);   // (a '\r' before the line end stays: GFA_Parser.cpp:497-503)
     if ((int)len < k) { atomicOr(err, ERR_SHORT); return s; }
     // optional tags after the sequence: "DA:Z:<n>"
     for (uint64_t tag = end; tag < e;) {
@@ -205,13 +211,18 @@ __global__ __launch_bounds__(256) void k_gfa_pack(const char *__restrict__ t, co
     const char *s = t + seg_off[u] + j0;
     uint64_t x = 0;
     bool bad = false;
+    const bool is_short = (int)L == k;
     for (uint32_t j = 0; j < m; ++j) {
-        const int c = base_code(s[j]);
-        if (c < 0) bad = true;
+        int c = base_code(s[j]);
+        if (c < 0) {
+            // the '\r' that ends a CRLF line's sequence: CompressedSequence::bits['\r'] = 0, Kmer::set_kmer('\r') = 3
+            if (s[j] == '\r' && j0 + j + 1 == L) c = is_short ? 3 : 0;
+            else bad = true;
+        }
         x |= (uint64_t)(c & 3) << (62 - 2 * j);
     }
     if (bad) { atomicOr(err, ERR_BASE); return; }
-    if ((int)L == k) {   // km.rep() (CompactedDBG.tcc:3945-3954): the smaller of the k-mer and its twin
+    if (is_short) {   // km.rep() (CompactedDBG.tcc:3945-3954): the smaller of the k-mer and its twin
         const uint64_t rc = revcomp_words(x) << (2 * (32 - k));
         const bool take_rc = rc < x;
         stored_rc[u] = take_rc ? 1 : 0;

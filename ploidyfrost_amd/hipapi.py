@@ -39,6 +39,9 @@ BUBBLE_TASK = np.dtype([("path_first", "<u8"), ("n_paths", "<u4"), ("pad", "<u4"
 BUBBLE_SITE = np.dtype([("col", "<u4"), ("is_indel", "u1"), ("maxnum", "u1"), ("pad", "<u2")])
 BUBBLE_RESULT = np.dtype([("rows_off", "<u8"), ("site_off", "<u8"), ("group_off", "<u8"), ("ilen_off", "<u8"), ("n_rows", "<u4"),
                           ("n_cols", "<u4"), ("n_sites", "<u4"), ("n_indel_len", "<u4")])
+CALL_BUBBLE = np.dtype([("entrance_ov", "<u4"), ("exit_ov", "<u4"), ("strict", "<u4"), ("n_inner", "<u4"), ("inner", "<u4", (4,)),
+                        ("cov", "<f8", (4,)), ("core_mean", "<f8"), ("cov_sum", "<f8")])
+assert CALL_BUBBLE.itemsize == 80
 assert BFS_RECORD.itemsize == 32 and ALIGN_JOB.itemsize == 24 and ALIGN_HIT.itemsize == 40
 assert BUBBLE_PATH.itemsize == 16 and BUBBLE_TASK.itemsize == 16 and BUBBLE_SITE.itemsize == 8 and BUBBLE_RESULT.itemsize == 48
 
@@ -138,6 +141,7 @@ def load_library() -> C.CDLL:
         "pf_call_run": (i, [vp, i, u64, u64, u64, u32, C.c_double, C.c_double, C.c_double, vp]),
         "pf_call_align": (i, [vp, u64, u64, u32, C.c_double, C.c_double, C.c_double, vp]),
         "pf_call_text": (i, [vp, i, u64, vp]),
+        "pf_call_peek": (i, [vp, i, vp, vp, vp, u64, vp, vp, vp, vp, vp, vp, vp]),
         "pf_call_text_range": (i, [vp, i, u64, u64, u64, vp]),
         "pf_call_align_lane": (i, [vp, i, u64, u64, u32, C.c_double, C.c_double, C.c_double, vp]),
         "pf_call_text_range_lane": (i, [vp, i, i, u64, u64, u64, vp]),
@@ -163,7 +167,60 @@ DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
                     "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
                     "pf_call_set_state", "pf_call_set_format", "pf_superbubble_rows", "pf_superbubble_fetch", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_resolve", "pf_call_select", "pf_call_run", "pf_call_align",
-                    "pf_call_text", "pf_call_text_range", "pf_call_align_lane", "pf_call_text_range_lane", "pf_call_fetch", "pf_call_fetch_slab", "pf_call_fetch_range", "pf_call_fetch_wait", "pf_format_doubles"]
+                    "pf_call_text", "pf_call_peek", "pf_call_text_range", "pf_call_align_lane", "pf_call_text_range_lane", "pf_call_fetch", "pf_call_fetch_slab", "pf_call_fetch_range", "pf_call_fetch_wait", "pf_format_doubles"]
+
+
+def call_peek(ctx_handle, lane: int = 0):
+    """pf_call_peek on a raw pf_ctx (e.g. hostapi.Run.device_ctx()): what pf_call_align left resident, per bubble a dict with
+    entrance_ov / exit_ov / strict / inner / cov, and -- when an alignment survived -- rows, sites [(col, is_indel, maxnum, groups,
+    ok)], indel_len and, for a branching bubble, site_cov = per site (group coverages, their sum)."""
+    L = load_library()
+    h = C.c_void_p(ctx_handle)
+    used = (C.c_uint64 * 6)()
+    st = L.pf_call_peek(h, lane, None, None, None, 0, None, None, None, None, None, None, used)
+    if st != PF_OK:
+        raise DeviceError(st, L.pf_last_error(h).decode())
+    nb = int(used[0])
+    if nb == 0:
+        return []
+    cap = (C.c_uint64 * 5)(*[int(used[x + 1]) for x in range(5)])
+    bub = np.zeros(nb, dtype=CALL_BUBBLE)
+    res = np.zeros(nb, dtype=BUBBLE_RESULT)
+    sv_off = np.zeros(nb, dtype=np.uint64)
+    text = np.zeros(max(1, cap[0]), dtype=np.uint8)
+    sites = np.zeros(max(1, cap[1]), dtype=BUBBLE_SITE)
+    groups = np.zeros(max(1, cap[2]), dtype=np.uint8)
+    ilen = np.zeros(max(1, cap[3]), dtype=np.uint32)
+    sv = np.zeros(max(1, cap[4]), dtype=np.float64)
+    st = L.pf_call_peek(h, lane, bub.ctypes.data, res.ctypes.data, sv_off.ctypes.data, nb, text.ctypes.data, sites.ctypes.data,
+                        groups.ctypes.data, ilen.ctypes.data, sv.ctypes.data, cap, used)
+    if st != PF_OK:
+        raise DeviceError(st, L.pf_last_error(h).decode())
+    tb = text.tobytes()
+    out = []
+    for j in range(nb):
+        b, r = bub[j], res[j]
+        d = dict(entrance_ov=int(b["entrance_ov"]), exit_ov=int(b["exit_ov"]), strict=bool(b["strict"]),
+                 inner=[int(x) for x in b["inner"][: int(b["n_inner"])]], cov=[float(x) for x in b["cov"][: int(b["n_inner"])]],
+                 core_mean=float(b["core_mean"]), cov_sum=float(b["cov_sum"]), rows=None)
+        R, Lc = int(r["n_rows"]), int(r["n_cols"])
+        if R:
+            o = int(r["rows_off"])
+            d["rows"] = [tb[o + i * Lc: o + (i + 1) * Lc] for i in range(R)]
+            d["sites"] = []
+            d["site_cov"] = []
+            v = int(sv_off[j])
+            for i in range(int(r["n_sites"])):
+                srec = sites[int(r["site_off"]) + i]
+                g0 = int(r["group_off"]) + i * R
+                mx = int(srec["maxnum"])
+                d["sites"].append((int(srec["col"]), int(srec["is_indel"]), mx, groups[g0: g0 + R].tolist(), int(srec["pad"])))
+                if not d["strict"]:
+                    d["site_cov"].append((sv[v: v + mx].tolist(), float(sv[v + mx])))
+                    v += mx + 1
+            d["indel_len"] = ilen[int(r["ilen_off"]): int(r["ilen_off"]) + int(r["n_indel_len"])].tolist()
+        out.append(d)
+    return out
 
 
 def pack_unitigs(seqs: list[bytes]):

@@ -44,6 +44,24 @@ def colored_cases():
     return _cases(True)
 
 
+def dialect_cases():
+    """tests/golden/dialects/<base>__<dialect>: a base fixture's graph in another GFA dialect, with what the REFERENCE binary
+    wrote for it (tests/golden/make_dialect_golden.py)"""
+    d = os.path.join(GOLDEN, "dialects")
+    return sorted(x for x in os.listdir(d) if os.path.isfile(os.path.join(d, x, "meta.json"))) if os.path.isdir(d) else []
+
+
+def load_dialect(name):
+    d = os.path.join(GOLDEN, "dialects", name)
+    with open(os.path.join(d, "meta.json")) as f:
+        dm = json.load(f)
+    meta = load_case(dm["base"])
+    meta["gfa"] = os.path.join(d, "graph.gfa")
+    meta["dir"] = d
+    meta["dialect"] = dm
+    return meta
+
+
 def load_case(name):
     d = os.path.join(GOLDEN, name)
     with open(os.path.join(d, "args.json")) as f:

@@ -192,7 +192,7 @@ def test_one_graph_partitioned_over_ranks(case, world, tmp_path):
     runs[0].set_unitig_id("g")
     n = runs[0].times()["unitigs"]
     shards = [runs[r].find_shard(*pfdist.shard_range(n, r, world)) for r in range(world)]
-    assert sum(len(s[0]) for s in shards) == runs[0].times()["candidates"] or True
+    n_shard_records = sum(len(s[0]) for s in shards)
     for r in range(world):   # all-gather: every rank sees every shard
         runs[r].find_replay("g", [s[0] for s in shards], [s[1] for s in shards], write_file=r == 0)
     states = [run.state() for run in runs]
@@ -216,9 +216,56 @@ def test_one_graph_partitioned_over_ranks(case, world, tmp_path):
     whole.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
     tw = whole.times()
     assert list(counters[:4]) == tw["allele"] and int(counters[7]) == tw["tasks"] == nb[0]
+    assert n_shard_records == tw["candidates"]   # every candidate entrance belongs to exactly one rank's unitig range
     assert all(np.array_equal(a, b) for a, b in zip(states[0], _state_after_find(meta, op)))
     for run in runs + [whole]:
         run.close()
+
+
+@pytest.mark.parametrize("case,world", [("tet60k", 2), ("giant7k", 3), ("weird12k", 4)])
+def test_shards_replayed_from_device_memory(case, world, tmp_path):
+    """The branch of dist.sharded_find an RCCL run takes (ploidyfrost_amd/dist.py: `on_gpu and world > 1`): after the all-gather the
+    shards of all ranks lie in DEVICE memory only, and pfh_find_replay is given their device addresses and sizes -- no host
+    copy (records=None).  Here the gathered buffers are torch.cuda tensors filled from each rank's shard; the per-unitig state
+    afterwards is the oracle's (reference CDBG::findSuperBubble_ptr, src/CDBG.cpp:178-252 with the commits of :552-846) and
+    super_bubble.txt the reference's."""
+    import torch
+    from ploidyfrost_amd import dist as pfdist, hipapi
+    meta = load_case(case)
+    op = meta["opts"]
+    o = pyoracle.Oracle(meta["gfa"], meta["db"])
+    nb = o.find_superbubbles(z=int(op["-z"]))
+    want = o.state()
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]))
+    run.set_threads(3)
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    n = run.times()["unitigs"]
+    dev = torch.device("cuda:0")
+    d_recs, d_pools, sizes = [], [], []
+    for r in range(world):
+        rec, pool = run.find_shard(*pfdist.shard_range(n, r, world))
+        # (an all-gather pads every shard to the longest one: the sizes say how much of each buffer counts)
+        tr = torch.zeros(rec.nbytes + 64 * r + 8, dtype=torch.uint8, device=dev)
+        tp = torch.zeros(pool.nbytes + 32 * r + 8, dtype=torch.uint8, device=dev)
+        if rec.nbytes:
+            tr[:rec.nbytes] = torch.from_numpy(rec.view(np.uint8).reshape(-1).copy()).to(dev)
+        if pool.nbytes:
+            tp[:pool.nbytes] = torch.from_numpy(pool.view(np.uint8).reshape(-1).copy()).to(dev)
+        d_recs.append(tr)
+        d_pools.append(tp)
+        sizes.append((len(rec), len(pool)))
+    torch.cuda.synchronize()
+    run.find_replay("g", None, sizes, write_file=True, dev_records=[t.data_ptr() for t in d_recs], dev_pools=[t.data_ptr() for t in d_pools])
+    got = run.state()
+    assert all(np.array_equal(a, b) for a, b in zip(got, want)), case
+    assert run.times()["superbubbles"] == nb
+    with open(os.path.join(meta["dir"], "expected", "g_super_bubble.txt"), "rb") as f, open(str(tmp_path / "g_super_bubble.txt"), "rb") as g:
+        assert f.read() == g.read()
+    # and the calling phase on that state gives the reference's files
+    run.ploidy_estimation("g", int(op["-l"]), int(op["-u"]))
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+    run.close()
 
 
 def _state_after_find(meta, op):

@@ -1,7 +1,7 @@
-"""K-GFA (csrc/pf_gfa.hip): the S-lines of a GFA file parsed and 2-bit packed on the device, against the host loader
-(csrc/host/pf_host_graph.cpp, PF_GFA=host) -- the loader every byte-identical run of round 1 went through -- on the dialects
-and the malformed files the reference's GFA_Parser meets: GFA 1 and 2, CRLF line ends, lower-case bases, extra tags, link lines
-between the segments, a last line without a newline, and the three refusals.  (That the twelve files of every fixture match the
+"""K-GFA (csrc/pf_gfa.hip): the S-lines of a GFA file parsed and 2-bit packed on the device -- and the host loader
+(csrc/host/pf_host_graph.cpp, PF_GFA=host) -- against the files the REFERENCE binary wrote for the same input on the dialects the
+reference's GFA_Parser meets (tests/golden/dialects): GFA 1 and 2, CRLF line ends, lower-case bases, extra tags, link lines
+between the segments, a last line without a newline; and the three refusals.  (That the twelve files of every fixture match the
 reference through this ingest is what tests/test_gpu_end_to_end.py checks: pfh_open and the CLI use it by default.)"""
 import os
 import subprocess
@@ -9,7 +9,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import OUTPUT_SUFFIXES, ROOT, load_case
+from conftest import ROOT, compare_outputs, dialect_cases, load_case, load_dialect
 from ploidyfrost_amd import hipapi
 
 CLI = os.path.join(ROOT, "ploidyfrost_amd", "csrc", "ploidyfrost")
@@ -19,36 +19,6 @@ pytestmark = pytest.mark.gpu
 def _lines(meta):
     with open(meta["gfa"]) as f:
         return f.read().split("\n")[:-1]
-
-
-def _variants(meta):
-    lines = _lines(meta)
-    head, body = lines[0], lines[1:]
-    seg = [i for i, ln in enumerate(body) if ln.startswith("S\t")]
-    rng = np.random.default_rng(5)
-    out = {}
-    out["crlf"] = "\r\n".join([head] + body) + "\r\n"
-    lower = list(body)
-    for i in seg[::3]:
-        f = lower[i].split("\t")
-        f[2] = f[2].lower() if i % 2 else "".join(c.lower() if j % 3 == 0 else c for j, c in enumerate(f[2]))
-        lower[i] = "\t".join(f)
-    out["lowercase"] = "\n".join([head] + lower) + "\n"
-    tags = list(body)
-    for n, i in enumerate(seg):
-        tags[i] += "\tKC:i:%d" % (n * 7) + ("\tDA:Z:%d" % (n % 5) if n % 2 else "") + "\txx:Z:S\tS"
-    out["tags"] = "\n".join([head] + tags) + "\n"
-    gfa2 = []
-    for ln in body:
-        f = ln.split("\t")
-        gfa2.append("\t".join(["S", f[1], str(len(f[2])), f[2]] + f[3:]) if f[0] == "S" else ln)
-    out["gfa2"] = "\n".join([head.replace("VN:Z:1.0", "VN:Z:2.0")] + gfa2) + "\n"
-    shuffled = list(body)   # segments and links interleaved, comment lines, an empty line
-    rng.shuffle(shuffled)
-    shuffled[len(shuffled) // 2:len(shuffled) // 2] = ["# a comment", "", "P\tpath\t1+,2-\t*"]
-    out["interleaved"] = "\n".join([head] + shuffled) + "\n"
-    out["no_final_newline"] = "\n".join([head] + body)   # the last line is dropped (GFA_Parser.cpp:486)
-    return out
 
 
 def _run(gfa, meta, tmp, host):
@@ -62,24 +32,20 @@ def _run(gfa, meta, tmp, host):
     return r
 
 
-@pytest.mark.parametrize("case", ["dip20k", "k31_z16"])
-def test_dialects_give_the_host_loaders_files(case, tmp_path):
-    meta = load_case(case)
-    if "VN:Z:1.0" not in _lines(meta)[0]:
-        pytest.skip("fixture header without a version tag")
-    for name, text in _variants(meta).items():
-        gfa = str(tmp_path / (name + ".gfa"))
-        with open(gfa, "w", newline="") as f:
-            f.write(text)
-        a = _run(gfa, meta, str(tmp_path / (name + "_host")), True)
-        b = _run(gfa, meta, str(tmp_path / (name + "_dev")), False)
-        assert a.returncode == b.returncode, (name, a.stdout[-300:], b.stdout[-300:], b.stderr[-300:])
-        if a.returncode != 0:
-            continue   # (e.g. a k-mer of a dropped segment's neighbour missing: both must fail alike)
-        for suf in OUTPUT_SUFFIXES:
-            x = open(os.path.join(str(tmp_path / (name + "_host")), "PloidyFrost_output", "g_%s.txt" % suf), "rb").read()
-            y = open(os.path.join(str(tmp_path / (name + "_dev")), "PloidyFrost_output", "g_%s.txt" % suf), "rb").read()
-            assert x == y, (case, name, suf)
+@pytest.mark.parametrize("case", dialect_cases())
+def test_dialects_give_the_references_files(case, tmp_path):
+    """Both loaders (K-GFA on the device, the host loader behind PF_GFA=host) against what the REFERENCE binary wrote for the
+    dialect (tests/golden/dialects/<base>__<dialect>/expected, made by tests/golden/make_dialect_golden.py).  `crlf`: the
+    reference reads the '\\r' that ends a segment's sequence as a base (bifrost/src/GFA_Parser.cpp:497-520), finds no superbubble
+    in the graph that gives and dies of its division by zero after the files are complete (src/CDBG.cpp:1703; return code -8 in
+    meta.json); the product writes the same files and returns.  `crlf_exact` places the '\\r' where it restores the base graph."""
+    meta = load_dialect(case)
+    for host in (False, True):
+        out = str(tmp_path / ("host" if host else "dev"))
+        r = _run(meta["gfa"], meta, out, host)
+        assert r.returncode == 0, (case, host, r.stdout[-300:], r.stderr[-300:])
+        bad = compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(out, "PloidyFrost_output"))
+        assert not bad, (case, "host loader" if host else "K-GFA", bad)
 
 
 @pytest.mark.parametrize("kind,message", [("base", "non-ACGT base in a segment"), ("short", "segment shorter than k"),

@@ -211,6 +211,20 @@ def test_unitig_numbering_of_every_fixture(tmp_path):
     assert abundant_cases()
 
 
+def test_host_loader_reads_gfa_dialects_like_the_reference(tmp_path):
+    """Unitig_Id.txt as the REFERENCE wrote it for every dialect fixture (tests/golden/dialects, made by make_dialect_golden.py):
+    GFA 1 / 2, tags, lower case, interleaved lines, no final line feed, and CRLF, whose '\\r' after a sequence is that sequence's
+    last base (A in a segment longer than k, T in a k-length one; bifrost/src/GFA_Parser.cpp:497-520)."""
+    from conftest import dialect_cases, load_dialect
+    from ploidyfrost_amd import hostapi
+    L = hostapi.load_library()
+    assert len(dialect_cases()) >= 14
+    for case in dialect_cases():
+        meta = load_dialect(case)
+        with open(os.path.join(meta["dir"], "expected", "g_Unitig_Id.txt"), "rb") as f:
+            assert _ids_written_by_the_loader(L, meta["gfa"], tmp_path) == f.read(), case
+
+
 def test_abundant_kmers_move_to_the_end(tmp_path):
     from ploidyfrost_amd import hostapi
     L = hostapi.load_library()

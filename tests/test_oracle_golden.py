@@ -6,7 +6,7 @@ import sys
 
 import pytest
 
-from conftest import ROOT, colored_cases, compare_outputs, golden_cases, load_case
+from conftest import ROOT, colored_cases, compare_outputs, dialect_cases, golden_cases, load_case, load_dialect
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import pyoracle  # noqa: E402
@@ -22,6 +22,33 @@ def test_oracle_matches_reference_outputs(case, tmp_path):
           D=float(op["-D"]), G=float(op["-G"]))
     bad = compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
     assert not bad, "files differ from the reference: %s" % bad
+
+
+@pytest.mark.parametrize("case", dialect_cases())
+def test_oracle_reads_gfa_dialects_like_the_reference(case, tmp_path):
+    """GFA 1 / 2, tags, lower case, interleaved lines, a last line without a line feed, and CRLF -- where the reference takes the
+    '\\r' that ends a segment line's sequence as that sequence's last base (bifrost/src/GFA_Parser.cpp:497-520): the files the
+    reference binary wrote for each dialect (tests/golden/make_dialect_golden.py)."""
+    meta = load_dialect(case)
+    o = pyoracle.Oracle(meta["gfa"], meta["db"])
+    op = meta["opts"]
+    o.run(str(tmp_path), "g", z=int(op["-z"]), lower=int(op["-l"]), upper=int(op["-u"]), M=float(op["-M"]),
+          D=float(op["-D"]), G=float(op["-G"]))
+    bad = compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
+    assert not bad, "files differ from the reference: %s" % bad
+
+
+def test_dialect_fixtures_cover_what_they_claim():
+    names = {c.split("__")[1] for c in dialect_cases()}
+    assert {"crlf", "crlf_exact", "lowercase", "tags", "gfa2", "interleaved", "no_final_newline"} <= names
+    m = load_dialect("weird12k__crlf_exact")
+    assert m["dialect"]["same_as_base_expected"] and m["dialect"]["reference_returncode"] == 0
+    with open(m["gfa"], newline="") as f:
+        rows = [ln.split("\t") for ln in f.read().split("\n") if ln.startswith("S\t")]
+    # k-length segments written as k - 1 bases + '\\r' (read back as ...T) and longer ones that lost their final A to it
+    assert sum(1 for f in rows if len(f) == 3 and len(f[2]) == m["k"] and f[2].endswith("\r")) >= 3
+    assert sum(1 for f in rows if len(f) == 3 and len(f[2]) > m["k"] and f[2].endswith("\r")) >= 20
+    assert load_dialect("dip20k__crlf")["dialect"]["reference_returncode"] == -8
 
 
 @pytest.mark.parametrize("case", colored_cases())

@@ -50,18 +50,21 @@ def repeat_rich(rng, n):
     return np.concatenate(parts)
 
 
-def build_case(seed, tmp, dev):
-    """inputs of one random case: a dict, or a string when the seed is skipped"""
+def build_case(seed, tmp, dev, force_colored=None, force_giant=None):
+    """inputs of one random case: a dict, or a string when the seed is skipped.  force_colored / force_giant (tests/test_gpu_fuzz.py):
+    the kind of case is chosen by the caller instead of by the seed / the environment."""
     rng = np.random.default_rng(seed)
     k = int(rng.choice([21, 25, 25, 31]))
     ploidy = int(rng.integers(2, 7))
+    if force_colored:
+        ploidy = 4 if ploidy < 5 else 6
     z = int(rng.integers(4, 13))
     L = int(rng.integers(8000, 40000))
     spec = synth.HapSpec(L, ploidy, seed=seed, gap_lo=int(rng.integers(5, 30)), gap_hi=int(rng.integers(40, 500)),
                          p_multi=float(rng.choice([0.0, 0.05, 0.15])), max_ins=int(rng.choice([3, 6, 12, 30])),
                          p_snp=float(rng.choice([0.5, 0.75, 0.9])), p_del=0.1)
     crowd = os.environ.get("PF_FUZZ_CROWD") == "1"
-    giant = os.environ.get("PF_FUZZ_GIANT")
+    giant = os.environ.get("PF_FUZZ_GIANT") if force_giant is None else ("1" if force_giant else None)
     edit = None
     if giant:
         L = int(rng.integers(250000, 400000))
@@ -87,6 +90,8 @@ def build_case(seed, tmp, dev):
     scores = [(2, -1, -3), (2, -1, -3), (1, -1, -1), (3, -2, -4), (1.5, -0.5, -2.25), (2, -1, -2)][int(rng.integers(0, 6))]
     lower, upper = [(5, 1000), (5, 1000), (15, 70), (1, 100000)][int(rng.integers(0, 4))]
     colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4 and not giant
+    if force_colored is not None:
+        colored = bool(force_colored) and not giant
     use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1" or crowd or bool(giant)
     use_reference = os.environ.get("PF_FUZZ_REFERENCE") == "1" or crowd
     try:
@@ -135,8 +140,8 @@ def build_case(seed, tmp, dev):
                 giant=giant, crowd=crowd)
 
 
-def one_case(seed, tmp, dev):
-    c = build_case(seed, tmp, dev)
+def one_case(seed, tmp, dev, force_colored=None, force_giant=None):
+    c = build_case(seed, tmp, dev, force_colored, force_giant)
     if isinstance(c, str):
         return c
     k, ploidy, z, L, scores, lower, upper, colored, gfa, n_unitigs = (c[x] for x in ("k", "ploidy", "z", "L", "scores", "lower", "upper", "colored",
