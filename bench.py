@@ -364,6 +364,10 @@ def main():
         elapsed = time.perf_counter() - t0
         tt = run.times()
 
+        # device-busy time of the timed passes: the union of the launches' intervals (the pipeline runs kernels side by side, so
+        # the per-kernel sums below overlap)
+        busy_ms, span_ms = C.c_double(), C.c_double()
+        L.pf_device_busy(ctx, C.byref(busy_ms), C.byref(span_ms))
         # kernel times from HIP events recorded by the library on its launch stream
         ktimes, kunits = {}, {}
         for i, name in enumerate(hipapi.KERNELS):
@@ -483,6 +487,10 @@ def main():
                 "roofline": roof, "roofline_issue": issue_roofline(dom, kernels[dom]["avg_ms"], n_unitigs) if dom else None,
                 "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for e in kernels.values()), 3),
+                # union of the launches' [start, end] intervals (HIP events on their streams) over the timed passes / passes;
+                # tools/summarize_prof.py gives the same figure from the rocprofv3 kernel trace (profiles/*_device_busy.json)
+                "device_busy_ms_per_step": round(busy_ms.value / args.steps, 3),
+                "device_busy_frac": round(busy_ms.value / (max_elapsed * 1e3), 4),
                 "first_pass": first_pass, "load_s": round(load_s, 3), "sharded_output_check": sharded_identical,
                 "kernels": kernels, "k_cov_probe": probe,
                 "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},
@@ -520,8 +528,10 @@ def main():
 def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):
     """Instruction-issue roofline of a kernel that is bound by issue, not by HBM (K-BUBBLE: its DP lives in registers and LDS):
     vector instructions per launch (SQ_INSTS_VALU, rocprofv3 --pmc pass of this command on this workload, committed as
-    profiles/pmc_sq.json) / the launch's measured duration, against what the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 4
-    cycles per wave64 vector instruction (MI355X_MICROARCH.md, 'vector-instruction ISSUE cost') = 614 G instructions/s.
+    profiles/pmc_sq.json) / the launch's measured duration, against what the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 2
+    cycles per wave64 vector instruction on a SIMD-32 (MI355X_MICROARCH.md, 'Wave scheduling' and the constants row
+    `v_fma_f32 (wave64) 2 cyc (SIMD-32)`: the figure for a SIMD that has more than one wave to issue from, which is K-BUBBLE's and
+    K-PAIR's case; a lone wave sustains one instruction per 4 cycles) = 1 229 G wave-instructions/s.
     None when the committed counters are of another workload."""
     p = os.path.join(ROOT, "profiles", "pmc_sq.json")
     try:
@@ -535,7 +545,7 @@ def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):
     valu, salu = e.get("SQ_INSTS_VALU"), e.get("SQ_INSTS_SALU")
     if not valu:
         return None
-    peak = 256 * 4 * 2.4e9 / 4
+    peak = 256 * 4 * 2.4e9 / 2
     ach = valu / (avg_ms * 1e-3)
     return {"kernel": kernel, "bound": "valu-issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instructions/s",
             "frac": round(ach / peak, 4), "valu_per_launch": valu, "salu_per_launch": salu,

@@ -63,6 +63,11 @@ enum pf_kernel {
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
 int pf_reset_timing(pf_ctx *);
+/* Device-busy time of everything timed since the last reset: the UNION of the launches' [start, end] intervals (HIP events on the
+ * streams they were launched on), in ms -- the launches of the calling pipeline overlap (two align ranges, K-BUBBLE's classes on
+ * streams of their own, K-TEXT beside the next range's alignment), so the sum pf_kernel_time gives counts overlapped time twice;
+ * *span_ms = first start to last end.  Library launches between them (rocPRIM scans / sorts, copies, fills) are not timed. */
+int pf_device_busy(pf_ctx *, double *busy_ms, double *span_ms);
 /* Work items the timed launches of a kernel were given since the last reset, in the unit its algorithmic bytes are quoted per
  * (DESIGN.md 3): candidates for K-BFS's tiers, bubbles for K-SNP / K-PAIR / K-BUBBLE / K-PATHS / K-SITES / K-TEXT, sides for K-SCAN. */
 int pf_kernel_units(pf_ctx *, int kernel, uint64_t *units);

@@ -266,10 +266,12 @@ int write_span_parallel(int fd, uint64_t file_off, const char *src, uint64_t len
 }
 
 void MappedOut::close_file() {
+    std::lock_guard<std::mutex> lk(remap_mu);
     if (base) munmap(base, map_len);
     if (fd >= 0) close(fd);
     base = nullptr;
     map_len = 0;
+    backed_lo = backed_hi = 0;
     fd = -1;
     path.clear();
 }
@@ -286,21 +288,41 @@ int MappedOut::open_for(const std::string &p) {
     return 0;
 }
 
+// Blocks for [off, off + len): posix_fallocate extends the file and reserves what it covers -- ENOSPC / EDQUOT come back here as
+// a return value instead of as a SIGBUS under a memcpy into the mapping.  Ranges already backed cost nothing (a pass over a
+// resident graph rewrites the same ranges every time).
+bool MappedOut::back(uint64_t off, uint64_t len) {
+    if (len == 0) return true;
+    if (off >= backed_lo && off + len <= backed_hi) return true;
+    if (posix_fallocate(fd, (off_t)off, (off_t)len) != 0) return false;
+    if (backed_hi > backed_lo && off <= backed_hi && off + len >= backed_lo) {   // touches what is known: one interval
+        backed_lo = std::min(backed_lo, off);
+        backed_hi = std::max(backed_hi, off + len);
+    } else {
+        backed_lo = off;
+        backed_hi = off + len;
+    }
+    return true;
+}
+
+bool MappedOut::map_at_least(uint64_t bytes) {
+    if (bytes <= map_len) return true;
+    std::lock_guard<std::mutex> lk(remap_mu);
+    if (base) munmap(base, map_len);
+    base = nullptr;
+    const size_t want = (size_t)(bytes + bytes / 4 + (8u << 20));   // (mapping past the end of the file is fine: never touched)
+    void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
+    if (m == MAP_FAILED) { map_len = 0; return false; }
+    base = static_cast<char *>(m);
+    map_len = want;
+    return true;
+}
+
 int MappedOut::write(uint64_t off, const char *src, uint64_t len, unsigned threads) {
     if (len == 0) return 0;
     if (fd < 0) return 1;
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) return 1;
-    if ((uint64_t)sb.st_size < off + len && ftruncate(fd, (off_t)(off + len)) != 0) return 1;
-    if (off + len > map_len) {
-        if (base) munmap(base, map_len);
-        base = nullptr;
-        const size_t want = (size_t)((off + len) + (off + len) / 4 + (8u << 20));   // (mapping past the end of the file is fine: never touched)
-        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) { map_len = 0; return write_span_parallel(fd, off, src, len, threads); }
-        base = static_cast<char *>(m);
-        map_len = want;
-    }
+    if (!back(off, len)) return 1;
+    if (!map_at_least(off + len)) return write_span_parallel(fd, off, src, len, threads);
     char *dst = base + off;
     constexpr uint64_t PIECE = 1u << 20;
     parallel_chunks((size_t)((len + PIECE - 1) / PIECE), 1, threads, [&](size_t i, size_t, size_t) {
@@ -312,18 +334,8 @@ int MappedOut::write(uint64_t off, const char *src, uint64_t len, unsigned threa
 
 char *MappedOut::prepare(uint64_t off, uint64_t len) {
     if (fd < 0) return nullptr;
-    struct stat sb;
-    if (fstat(fd, &sb) != 0) return nullptr;
-    if ((uint64_t)sb.st_size < off + len && ftruncate(fd, (off_t)(off + len)) != 0) return nullptr;
-    if (off + len > map_len) {
-        if (base) munmap(base, map_len);
-        base = nullptr;
-        const size_t want = (size_t)((off + len) + (off + len) / 4 + (8u << 20));
-        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) { map_len = 0; return nullptr; }
-        base = static_cast<char *>(m);
-        map_len = want;
-    }
+    if (!back(off, len)) return nullptr;   // (the caller falls back to write(), which reports the error)
+    if (!map_at_least(off + len)) return nullptr;
     return base + off;
 }
 
@@ -341,24 +353,19 @@ int MappedOut::reserve(uint64_t bytes) {
     struct stat sb;
     if (fstat(fd, &sb) != 0) return 1;
     if ((uint64_t)sb.st_size >= bytes / 2) return 1;   // (it has been written before: its pages exist)
+    // sized now, backed piece by piece: by populate() on the helper threads, or by prepare() where the writer gets there first
     if (ftruncate(fd, (off_t)bytes) != 0) return 1;
-    if (bytes > map_len) {
-        if (base) munmap(base, map_len);
-        base = nullptr;
-        const size_t want = (size_t)(bytes + bytes / 4 + (8u << 20));
-        void *m = mmap(nullptr, want, PROT_READ | PROT_WRITE, MAP_SHARED, fd, 0);
-        if (m == MAP_FAILED) { map_len = 0; return 1; }
-        base = static_cast<char *>(m);
-        map_len = want;
-    }
-    return 0;
+    return map_at_least(bytes) ? 0 : 1;
 }
 
-void MappedOut::populate(uint64_t from, uint64_t to) const {
+// [from, to) of a reserved file: its blocks (posix_fallocate: a full disk shows here and leaves the range to prepare(), which
+// reports it), then its page-table entries.  Holds the mapping in place while it works.
+void MappedOut::populate(uint64_t from, uint64_t to) {
+    if (to <= from || fd < 0) return;
+    if (posix_fallocate(fd, (off_t)from, (off_t)(to - from)) != 0) return;
 #ifdef MADV_POPULATE_WRITE
-    if (base && to > from && to <= map_len) (void)madvise(base + (from & ~4095ull), (size_t)(to - (from & ~4095ull)), MADV_POPULATE_WRITE);
-#else
-    (void)from; (void)to;
+    std::lock_guard<std::mutex> lk(remap_mu);
+    if (base && to <= map_len) (void)madvise(base + (from & ~4095ull), (size_t)(to - (from & ~4095ull)), MADV_POPULATE_WRITE);
 #endif
 }
 
@@ -367,6 +374,9 @@ int MappedOut::finish(uint64_t final_len) {
     struct stat sb;
     if (fstat(fd, &sb) != 0) return 1;
     if ((uint64_t)sb.st_size != final_len && ftruncate(fd, (off_t)final_len) != 0) return 1;
+    // what lay beyond is gone (whoever cut it: every rank of a sharded run passes the same length here before it stores anything)
+    backed_hi = std::min(backed_hi, final_len);
+    if (backed_hi <= backed_lo) backed_lo = backed_hi = 0;
     return 0;
 }
 

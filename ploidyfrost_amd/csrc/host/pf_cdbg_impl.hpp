@@ -2,6 +2,7 @@
 // output plumbing, MyUnitig state and the commit replay; pf_cdbg_find.cpp: findSuperBubble; pf_cdbg_ploidy.cpp:
 // PloidyEstimation; pf_ccdbg.cpp: the colored front end).
 #pragma once
+#include <mutex>
 #include <charconv>
 #include <chrono>
 #include <cstdint>
@@ -50,6 +51,11 @@ struct MappedOut {
     int fd = -1;
     char *base = nullptr;
     size_t map_len = 0;
+    // [backed_lo, backed_hi): bytes of the file whose blocks are known to exist (posix_fallocate by this object).  A store through
+    // the mapping into a hole of a sparse file is the first to learn that the disk (or /dev/shm) is full -- as a SIGBUS that takes
+    // the process, and the Python interpreter hosting this library, with it; so nothing is stored outside this interval.
+    uint64_t backed_lo = 0, backed_hi = 0;
+    std::mutex remap_mu;   // populate() on a helper thread against a remap by prepare() / write() / reserve()
     MappedOut() = default;
     MappedOut(const MappedOut &) = delete;
     MappedOut &operator=(const MappedOut &) = delete;
@@ -65,8 +71,11 @@ struct MappedOut {
     // faulted in by populate() on helper threads while the first pieces are still on their way -- a fresh page costs the kernel
     // more than the copy into it (57 MB took 10 ms through first-touch faults).  No-op for a file that already has its pages.
     int reserve(uint64_t bytes);
-    void populate(uint64_t from, uint64_t to) const;
+    void populate(uint64_t from, uint64_t to);
     void close_file();
+private:
+    bool back(uint64_t off, uint64_t len);   // blocks for [off, off + len) (extends the file); false: no space / not supported
+    bool map_at_least(uint64_t bytes);
 };
 
 struct CopySpan {

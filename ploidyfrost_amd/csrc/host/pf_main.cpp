@@ -53,7 +53,8 @@ void PrintUsage() {
          << "  -i,             Output Information about Bifrost graph" << endl << endl
          << "  -h,             k-mer histogram file (with -f: a list of them): thresholds = cutoffL / cutoffU of it" << endl
          << "  -q,             quantile for the upper threshold derived from -h (default : 0.998 )" << endl
-         << "  --ref-threads N N > 1: text format of the reference's `-t N` run (ids from 0, allele_frequency grouped by arity)" << endl << endl
+         << "  --ref-threads N N > 1: text format of the reference's `-t N` run (ids from 0, allele_frequency grouped by arity)" << endl
+         << "  --detach-teardown  return as soon as the result files are complete; a child process gives the device memory back" << endl << endl
          << "Usage: PloidyFrost cutoffL kmer_histogram_file" << endl
          << "Usage: PloidyFrost cutoffU kmer_histogram_file (quantile[<1 ,default:0.998])" << endl << endl
          << "Not part of this build: `model`." << endl;
@@ -99,7 +100,7 @@ int cutoffH(const string &file, double frequency = 0.998) {
 struct Options {
     string graphfile, colorfile, outprefix = "output", db, coveragefile, hist;
     size_t nb_threads = 1, complex_size = 8, ref_threads = 1;
-    bool verbose = false, info = false;
+    bool verbose = false, info = false, detach_teardown = false;
     int coverage_lower = 10, coverage_upper = 1000, k = 25;
     vector<pair<int, int>> coverage_vec;
     double match = 2, mismatch = -1, gap = -3, frequency = 0.998;
@@ -211,6 +212,11 @@ int main(int argc, char **argv) {
             opt.ref_threads = (size_t)atoi(argv[i + 1]);
             for (int j = i; j + 2 <= argc; ++j) argv[j] = j + 2 < argc ? argv[j + 2] : nullptr;
             argc -= 2;
+            --i;
+        } else if (strcmp(argv[i], "--detach-teardown") == 0) {
+            opt.detach_teardown = true;
+            for (int j = i; j + 1 <= argc; ++j) argv[j] = j + 1 < argc ? argv[j + 1] : nullptr;
+            argc -= 1;
             --i;
         }
     }
@@ -362,11 +368,12 @@ int main(int argc, char **argv) {
     }
 
     // Giving 12 GB of device memory and the pinned buffers back is 0.35-0.4 s of driver work at process exit (5 M unitigs) --
-    // a third of the whole run.  The work is therefore done by a child process: the parent returns the moment the child reports
-    // that the last result file is complete, the child finishes its exit with nobody waiting for it.  PF_WAIT_TEARDOWN=1 keeps
-    // one process.  (Forked here, before the first thread and the first device call.)
+    // a third of the whole run.  On request (--detach-teardown, or PF_DETACH_TEARDOWN=1) that work is done by a child process:
+    // the parent returns the moment the child reports that the last result file is complete, the child finishes its exit with
+    // nobody waiting for it -- and still holds its device memory for those 0.4 s, which a scheduler that starts the next job on
+    // the parent's return has to know; hence not the default.  (Forked here, before the first thread and the first device call.)
     int done_fd = -1;
-    if (!getenv("PF_WAIT_TEARDOWN")) {
+    if (opt.detach_teardown || (getenv("PF_DETACH_TEARDOWN") && getenv("PF_DETACH_TEARDOWN")[0] == '1')) {
         int fds[2];
         if (pipe(fds) == 0) {
             cout.flush();

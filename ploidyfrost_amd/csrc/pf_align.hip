@@ -34,7 +34,7 @@ using namespace pf;
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -141,7 +141,7 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
         const pf_align_job &jb = hj[j];
         if (jb.a_len == 0 || jb.b_len == 0 || jb.a_len > LIM || jb.b_len > LIM || jb.a_off + jb.a_len > text_len ||
             jb.b_off + jb.b_len > text_len || (uint64_t)(jb.a_len + 1) * (jb.b_len + 1) > (1ull << 31)) {
-            ctx->err = "pf_align_batch: job outside the text buffer or longer than 60000 bases";
+            pf::CtxErr{ctx} = "pf_align_batch: job outside the text buffer or longer than 60000 bases";
             return PF_ERR_ARG;
         }
         const uint64_t need = job_bytes(jb.a_len, jb.b_len);
@@ -282,7 +282,7 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
     PF_HIP(hipMemcpy(heads, d_heads, 24, hipMemcpyDeviceToHost));
     used[0] = heads[0]; used[1] = heads[1]; used[2] = heads[2];
     if (heads[0] > hit_cap || heads[1] > text_cap || heads[2] > gap_cap) {
-        ctx->err = "pf_align_batch: output buffers too small";
+        pf::CtxErr{ctx} = "pf_align_batch: output buffers too small";
         status = PF_ERR_OVERFLOW;
     }
     if (!dev_out) {
@@ -295,7 +295,7 @@ extern "C" int pf_align_batch(pf_ctx *ctx, const char *text, uint64_t text_len, 
             if (n_retry)
                 for (uint32_t j = 0; j < n_jobs; ++j)
                     if (hit_count[j] == 0xFFFFFFFFu) {
-                        ctx->err = "pf_align_batch: a job has more co-optimal alignments than the staging area holds";
+                        pf::CtxErr{ctx} = "pf_align_batch: a job has more co-optimal alignments than the staging area holds";
                         status = PF_ERR_OVERFLOW;
                         break;
                     }

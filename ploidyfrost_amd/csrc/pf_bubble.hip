@@ -41,7 +41,7 @@ using namespace pf;
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -927,7 +927,7 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         PF_HIP(hipMemcpyAsync(&bad, bad_.p, 4, hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
         if (bad) {
-            ctx->err = "pf_align_bubbles: a bubble exceeds the largest scratch tier";
+            pf::CtxErr{ctx} = "pf_align_bubbles: a bubble exceeds the largest scratch tier";
             status = PF_ERR_OVERFLOW;
         }
     }
@@ -980,7 +980,7 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     }
     PF_HIP(hipMemcpy(heads, o.heads, 32, hipMemcpyDeviceToHost));
     if (status == PF_OK && (heads[0] > L.text_cap || heads[1] > L.site_cap || heads[2] > L.group_cap || heads[3] > L.ilen_cap)) {
-        ctx->err = "pf_align_bubbles: output pools too small";
+        pf::CtxErr{ctx} = "pf_align_bubbles: output pools too small";
         status = PF_ERR_OVERFLOW;
     }
     return status;
@@ -997,7 +997,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         return PF_ERR_ARG;
     used[0] = used[1] = used[2] = used[3] = 0;
     if (n_tasks == 0) return PF_OK;
-    if (!ctx->d_seq) { ctx->err = "pf_align_bubbles: no graph uploaded"; return PF_ERR_ARG; }
+    if (!ctx->d_seq) { pf::CtxErr{ctx} = "pf_align_bubbles: no graph uploaded"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     auto is_dev = [](const void *p) {
@@ -1029,7 +1029,7 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     for (uint32_t t = 0; t < n_tasks; ++t) {
         const pf_bubble_task &tk = ht[t];
         if (tk.n_paths < 2 || tk.n_paths > 255 || tk.path_first + tk.n_paths > n_paths) {
-            ctx->err = "pf_align_bubbles: a bubble needs 2..255 paths inside the path array";
+            pf::CtxErr{ctx} = "pf_align_bubbles: a bubble needs 2..255 paths inside the path array";
             return PF_ERR_ARG;
         }
         uint32_t l0 = 0, lmax = 0;
@@ -1037,13 +1037,13 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
         for (uint32_t i = 0; i < tk.n_paths; ++i) {
             const pf_bubble_path &pp = hp[tk.path_first + i];
             if (pp.ov != PF_NONE) {
-                if ((pp.ov >> 1) >= ctx->N) { ctx->err = "pf_align_bubbles: path unitig out of range"; return PF_ERR_ARG; }
-                if (pp.len != hlen[pp.ov >> 1]) { ctx->err = "pf_align_bubbles: path length differs from the unitig's"; return PF_ERR_ARG; }
+                if ((pp.ov >> 1) >= ctx->N) { pf::CtxErr{ctx} = "pf_align_bubbles: path unitig out of range"; return PF_ERR_ARG; }
+                if (pp.len != hlen[pp.ov >> 1]) { pf::CtxErr{ctx} = "pf_align_bubbles: path length differs from the unitig's"; return PF_ERR_ARG; }
             } else if (pp.text_off + pp.len > text_len) {
-                ctx->err = "pf_align_bubbles: path outside the text buffer";
+                pf::CtxErr{ctx} = "pf_align_bubbles: path outside the text buffer";
                 return PF_ERR_ARG;
             }
-            if (pp.len == 0 || pp.len > 60000) { ctx->err = "pf_align_bubbles: empty path or longer than 60000"; return PF_ERR_ARG; }
+            if (pp.len == 0 || pp.len > 60000) { pf::CtxErr{ctx} = "pf_align_bubbles: empty path or longer than 60000"; return PF_ERR_ARG; }
             if (i == 0) l0 = pp.len;
             lmax = std::max(lmax, pp.len);
             sum += pp.len;

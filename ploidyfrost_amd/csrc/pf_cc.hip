@@ -32,7 +32,7 @@ using namespace pf;
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -407,7 +407,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
             hipMalloc(reinterpret_cast<void **>(&S->parent), (size_t)n_sides * 4 + 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&S->first), (size_t)n_sides * 4 + 4) != hipSuccess ||
             hipMalloc(reinterpret_cast<void **>(&S->multi), (size_t)N + 4) != hipSuccess) {
-            ctx->err = "pf_side_components: out of device memory";
+            pf::CtxErr{ctx} = "pf_side_components: out of device memory";
             return PF_ERR_HIP;
         }
         S->n_unitigs = N;
@@ -426,7 +426,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     if (!records && n_records == 0) {
         // a graph without a candidate entrance: nothing to add
     } else if (!records) {
-        if (ctx->bfs_last_n != n_records || !ctx->bfs_last_rec) { ctx->err = "pf_side_components: no records of that length from the last K-BFS call"; return PF_ERR_ARG; }
+        if (ctx->bfs_last_n != n_records || !ctx->bfs_last_rec) { pf::CtxErr{ctx} = "pf_side_components: no records of that length from the last K-BFS call"; return PF_ERR_ARG; }
         d_rec = ctx->bfs_last_rec;
         d_pool = ctx->bfs_last_pool;
         pool_len = ctx->bfs_last_pool_len;
@@ -435,7 +435,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
         d_pool = pool;
     } else {
         if (!grow(S->up_rec, S->up_rec_cap, n_records + n_extra + 1) || !grow(S->up_pool, S->up_pool_cap, pool_len + extra_pool_len + 1)) {
-            ctx->err = "pf_side_components: out of device memory";
+            pf::CtxErr{ctx} = "pf_side_components: out of device memory";
             return PF_ERR_HIP;
         }
         PF_HIP(hipMemcpyAsync(S->up_rec, records, n_records * sizeof(pf_bfs_record), hipMemcpyHostToDevice, st));
@@ -453,7 +453,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     }
     if (n_extra) {
         // traversals the caller walked itself: their records (list_off relative to extra_pool) contribute edges only
-        if (!grow(S->t_xrec, S->t_xrec_cap, n_extra) || !grow(S->t_xpool, S->t_xpool_cap, extra_pool_len + 1)) { ctx->err = "pf_side_components: out of device memory"; return PF_ERR_HIP; }
+        if (!grow(S->t_xrec, S->t_xrec_cap, n_extra) || !grow(S->t_xpool, S->t_xpool_cap, extra_pool_len + 1)) { pf::CtxErr{ctx} = "pf_side_components: out of device memory"; return PF_ERR_HIP; }
         pf_bfs_record *d_xrec = S->t_xrec;
         uint32_t *d_xpool = S->t_xpool;
         PF_HIP(hipMemcpyAsync(d_xrec, extra, n_extra * sizeof(pf_bfs_record), hipMemcpyDefault, st));
@@ -470,7 +470,7 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     uint32_t bad = 0;
     PF_HIP(hipMemcpyAsync(&bad, S->bad, 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
-    if (bad) { ctx->err = "pf_side_components: a record names a vertex outside the graph or a list outside the pool"; S->n_last = 0; return PF_ERR_ARG; }
+    if (bad) { pf::CtxErr{ctx} = "pf_side_components: a record names a vertex outside the graph or a list outside the pool"; S->n_last = 0; return PF_ERR_ARG; }
     S->n_last = n_records;
     ctx->cc_rec = d_rec;
     ctx->cc_pool = d_pool;
@@ -483,14 +483,14 @@ int pf_replay_order(pf_ctx *ctx, uint32_t n_classes, uint32_t *order, uint32_t *
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint64_t n = S->n_last;
-    if (n >> 32) { ctx->err = "pf_replay_order: more than 2^32 records"; return PF_ERR_ARG; }
+    if (n >> 32) { pf::CtxErr{ctx} = "pf_replay_order: more than 2^32 records"; return PF_ERR_ARG; }
     uint64_t cap = S->cap;
     if (!S->labels || S->cap < n + 1) {
         for (uint32_t **p : {&S->labels, &S->cls, &S->idx, &S->cls2, &S->idx2})
             if (*p) { (void)hipFree(*p); *p = nullptr; }
         cap = n + n / 4 + 64;
         for (uint32_t **p : {&S->labels, &S->cls, &S->idx, &S->cls2, &S->idx2})
-            if (hipMalloc(reinterpret_cast<void **>(p), cap * 4) != hipSuccess) { ctx->err = "pf_replay_order: out of device memory"; return PF_ERR_HIP; }
+            if (hipMalloc(reinterpret_cast<void **>(p), cap * 4) != hipSuccess) { pf::CtxErr{ctx} = "pf_replay_order: out of device memory"; return PF_ERR_HIP; }
         S->cap = cap;
     }
     if (!S->hist) PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->hist), 1025 * 4));
@@ -548,12 +548,12 @@ int pf_replay_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_m
 int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries) {
     if (!ctx || !ctx->cc || !n_big || !big_entries) return PF_ERR_ARG;
     CcState *S = static_cast<CcState *>(ctx->cc);
-    if (!S->parent || (!ctx->cc_rec && S->n_last)) { ctx->err = "pf_replay_device: pf_side_components first"; return PF_ERR_ARG; }
+    if (!S->parent || (!ctx->cc_rec && S->n_last)) { pf::CtxErr{ctx} = "pf_replay_device: pf_side_components first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t N = S->n_unitigs, n_sides = 2 * N;
     const uint64_t n = S->n_last;
-    if (n >> 32) { ctx->err = "pf_replay_device: more than 2^32 records"; return PF_ERR_ARG; }
+    if (n >> 32) { pf::CtxErr{ctx} = "pf_replay_device: more than 2^32 records"; return PF_ERR_ARG; }
     const pf_bfs_record *rec = static_cast<const pf_bfs_record *>(ctx->cc_rec);
     const uint32_t *pool = ctx->cc_pool;
     if (!S->big) {
@@ -598,12 +598,12 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     PF_HIP(rocprim::radix_sort_pairs(S->sort_tmp, have, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, st));
     // the records left to the caller, ascending (gathered first: the caller commits them while the device commits the rest)
     const char *oom = "pf_replay_device: out of device memory";
-    if (!grow(S->t_flag, S->t_flag_cap, n + 8) || !grow(S->t_cnt, S->t_cnt_cap, 2)) { ctx->err = oom; return PF_ERR_HIP; }
+    if (!grow(S->t_flag, S->t_flag_cap, n + 8) || !grow(S->t_cnt, S->t_cnt_cap, 2)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
     k_replay_flag_big<<<grid, 256, 0, st>>>(rec, n, S->keys, S->big, S->work, small_limit, S->t_flag);
     size_t sel = 0;
     hipcub::CountingInputIterator<uint32_t> iota(0);
     PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, sel, iota, S->t_flag, S->big_idx, S->t_cnt, (int)n, st));
-    if (!grow(S->t_sel, S->t_sel_cap, sel + 256)) { ctx->err = oom; return PF_ERR_HIP; }
+    if (!grow(S->t_sel, S->t_sel_cap, sel + 256)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
     sel += 256;
     PF_HIP(hipcub::DeviceSelect::Flagged(S->t_sel, sel, iota, S->t_flag, S->big_idx, S->t_cnt, (int)n, st));
     uint64_t nb = 0;
@@ -612,11 +612,11 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     nb &= 0xFFFFFFFFull;   // (the selector counts in 32 bits)
     uint64_t entries = 0;
     if (nb) {
-        if (!grow(S->t_sz, S->t_sz_cap, nb + 1) || !grow(S->t_off, S->t_off_cap, nb + 1)) { ctx->err = oom; return PF_ERR_HIP; }
+        if (!grow(S->t_sz, S->t_sz_cap, nb + 1) || !grow(S->t_off, S->t_off_cap, nb + 1)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
         k_replay_big_sizes<<<(unsigned)((nb + 1 + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, S->t_sz);
         size_t t2 = 0;
         PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, S->t_sz, S->t_off, (int)(nb + 1), st));
-        if (!grow(S->t_scan, S->t_scan_cap, t2 + 256)) { ctx->err = oom; return PF_ERR_HIP; }
+        if (!grow(S->t_scan, S->t_scan_cap, t2 + 256)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
         t2 += 256;
         PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->t_scan, t2, S->t_sz, S->t_off, (int)(nb + 1), st));
         PF_HIP(hipMemcpyAsync(&entries, S->t_off + nb, 8, hipMemcpyDeviceToHost, st));
@@ -665,7 +665,7 @@ int pf_replay_big_fetch(pf_ctx *ctx, uint32_t *index, pf_bfs_record *records, ui
 int pf_replay_finish(pf_ctx *ctx, const uint32_t *sides, const uint32_t *links, const uint8_t *side_flags, uint64_t n_patch) {
     if (!ctx || !ctx->cc || (n_patch && (!sides || !links || !side_flags))) return PF_ERR_ARG;
     CcState *S = static_cast<CcState *>(ctx->cc);
-    if (!S->f2) { ctx->err = "pf_replay_finish: pf_replay_device first"; return PF_ERR_ARG; }
+    if (!S->f2) { pf::CtxErr{ctx} = "pf_replay_finish: pf_replay_device first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     hipStream_t st = ctx->stream;
     const uint32_t N = S->n_unitigs;
@@ -675,7 +675,7 @@ int pf_replay_finish(pf_ctx *ctx, const uint32_t *sides, const uint32_t *links, 
     if (sa != PF_OK) return sa;
     if (n_patch) {
         if (!grow(S->t_sides, S->t_sides_cap, n_patch) || !grow(S->t_links, S->t_links_cap, n_patch) || !grow(S->t_bytes, S->t_bytes_cap, n_patch)) {
-            ctx->err = "pf_replay_finish: out of device memory";
+            pf::CtxErr{ctx} = "pf_replay_finish: out of device memory";
             return PF_ERR_HIP;
         }
         PF_HIP(hipMemcpyAsync(S->t_sides, sides, n_patch * 4, hipMemcpyDefault, st));

@@ -28,7 +28,7 @@ using namespace pf;
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -272,7 +272,7 @@ uint32_t pf_num_colors(const pf_ctx *ctx) { return ctx ? ctx->n_colors : 0; }
 int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *const *kmers, const uint32_t *const *counts,
                              const uint64_t *n, const uint64_t *min_count, const uint64_t *max_count, const int *both_strands) {
     if (!ctx || n_colors == 0 || !kmers || !counts || !n || !min_count || !max_count || !both_strands) return PF_ERR_ARG;
-    if (n_colors > PF_MAX_COLORS) { ctx->err = "more colours than the device table holds (PF_MAX_COLORS)"; return PF_ERR_ARG; }
+    if (n_colors > PF_MAX_COLORS) { pf::CtxErr{ctx} = "more colours than the device table holds (PF_MAX_COLORS)"; return PF_ERR_ARG; }
     uint64_t total = 0, biggest = 0;
     for (uint32_t c = 0; c < n_colors; ++c) {
         if (n[c] && (!kmers[c] || !counts[c])) return PF_ERR_ARG;

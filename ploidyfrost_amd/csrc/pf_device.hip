@@ -30,7 +30,7 @@ static std::string g_create_err;
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -653,7 +653,7 @@ void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes) {
     if (w.first) { hipFree(w.first); w.first = nullptr; w.second = 0; }
     const size_t want = bytes + bytes / 4 + 256;
     void *p = nullptr;
-    if (hipMalloc(&p, want) != hipSuccess) { ctx->err = "hipMalloc of a workspace failed"; return nullptr; }
+    if (hipMalloc(&p, want) != hipSuccess) { pf::CtxErr{ctx} = "hipMalloc of a workspace failed"; return nullptr; }
     w.first = p;
     w.second = want;
     return p;
@@ -882,6 +882,40 @@ int pf_kernel_time(pf_ctx *ctx, int kernel, double *total_ms, uint64_t *launches
     return PF_OK;
 }
 
+int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) {
+    if (!ctx) return PF_ERR_ARG;
+    PF_HIP(hipDeviceSynchronize());
+    std::vector<std::pair<float, float>> iv;
+    {
+        std::lock_guard<std::mutex> lk(ctx->launch_mu);
+        iv.reserve(ctx->launches.size());
+        for (auto &tl : ctx->launches) {
+            float a = 0, b = 0;
+            if (hipEventElapsedTime(&a, ctx->launches[0].a, tl.a) != hipSuccess || hipEventElapsedTime(&b, ctx->launches[0].a, tl.b) != hipSuccess) {
+                (void)hipGetLastError();
+                continue;
+            }
+            if (b > a) iv.emplace_back(a, b);
+        }
+    }
+    std::sort(iv.begin(), iv.end());
+    double busy = 0, lo = 0, hi = 0;
+    bool open = false;
+    for (auto &x : iv) {
+        if (!open) { lo = x.first; hi = x.second; open = true; }
+        else if (x.first <= hi) hi = std::max<double>(hi, x.second);
+        else { busy += hi - lo; lo = x.first; hi = x.second; }
+    }
+    if (open) busy += hi - lo;
+    if (busy_ms) *busy_ms = busy;
+    if (span_ms) {
+        float mx = 0;
+        for (auto &x : iv) mx = std::max(mx, x.second);
+        *span_ms = iv.empty() ? 0.0 : (double)mx - (double)iv.front().first;
+    }
+    return PF_OK;
+}
+
 int pf_host_alloc(pf_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return PF_ERR_ARG;
     PF_HIP(hipSetDevice(ctx->device));
@@ -920,7 +954,7 @@ uint64_t pf_num_kmers(const pf_ctx *ctx) { return ctx ? ctx->n_kmers : 0; }
 int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp,
                     uint32_t N, int k) {
     if (!ctx || !seq_words || !seq_off || !len_bp || N == 0 || k < 3 || k > 31) return PF_ERR_ARG;
-    if (N >= (1u << 30)) { ctx->err = "more than 2^30 unitigs"; return PF_ERR_ARG; }
+    if (N >= (1u << 30)) { pf::CtxErr{ctx} = "more than 2^30 unitigs"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     free_graph(ctx);
     // seq_off[N] = total words; fetch it (host or device pointer)
@@ -959,7 +993,7 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         PF_HIP(hipMemcpyAsync(&nk, ctx->d_kpre + N, 8, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
         if (bad) {
-            ctx->err = (bad & 1) ? "unitig shorter than k" : "seq_off does not cover len_bp";
+            pf::CtxErr{ctx} = (bad & 1) ? "unitig shorter than k" : "seq_off does not cover len_bp";
             free_graph(ctx);
             return PF_ERR_ARG;
         }
@@ -1045,15 +1079,15 @@ int pf_kmc_decode(pf_ctx *ctx, const uint8_t *records, uint64_t n_records, uint3
                   const uint64_t *lut, uint64_t n_lut, uint32_t lut_prefix_len, uint32_t k, uint64_t **kmers_dev, uint32_t **counts_dev) {
     if (!ctx || !kmers_dev || !counts_dev || (n_records && (!records || !lut)) || n_lut == 0 || lut_prefix_len == 0 || lut_prefix_len > 15 ||
         k > 31 || lut_prefix_len >= k || (k - lut_prefix_len) != suffix_bytes * 4 || counter_bytes == 0 || counter_bytes > 8) {
-        if (ctx) ctx->err = "pf_kmc_decode: inconsistent k / lut_prefix_len / suffix_bytes / counter_bytes";
+        if (ctx) pf::CtxErr{ctx} = "pf_kmc_decode: inconsistent k / lut_prefix_len / suffix_bytes / counter_bytes";
         return PF_ERR_ARG;
     }
     *kmers_dev = nullptr;
     *counts_dev = nullptr;
     PF_HIP(hipSetDevice(ctx->device));
-    if (lut[0] != 0 || lut[n_lut] != n_records) { ctx->err = "pf_kmc_decode: lut must start at 0 and end (entry n_lut) at n_records"; return PF_ERR_ARG; }
+    if (lut[0] != 0 || lut[n_lut] != n_records) { pf::CtxErr{ctx} = "pf_kmc_decode: lut must start at 0 and end (entry n_lut) at n_records"; return PF_ERR_ARG; }
     for (uint64_t e = 0; e < n_lut; ++e)
-        if (lut[e] > lut[e + 1]) { ctx->err = "pf_kmc_decode: lut is not non-decreasing"; return PF_ERR_ARG; }
+        if (lut[e] > lut[e + 1]) { pf::CtxErr{ctx} = "pf_kmc_decode: lut is not non-decreasing"; return PF_ERR_ARG; }
     DevTmp<uint8_t> drec;
     DevTmp<uint64_t> dlut;
     uint64_t *dk = nullptr;
@@ -1062,7 +1096,7 @@ int pf_kmc_decode(pf_ctx *ctx, const uint8_t *records, uint64_t n_records, uint3
     PF_HIP(drec.alloc(rec_bytes));
     PF_HIP(dlut.alloc((n_lut + 1) * 8));
     PF_HIP(hipMalloc(&dk, n_records ? n_records * 8 : 8));
-    if (hipMalloc(&dc, n_records ? n_records * 4 : 4) != hipSuccess) { hipFree(dk); ctx->err = "hipMalloc of the decoded counts failed"; return PF_ERR_HIP; }
+    if (hipMalloc(&dc, n_records ? n_records * 4 : 4) != hipSuccess) { hipFree(dk); pf::CtxErr{ctx} = "hipMalloc of the decoded counts failed"; return PF_ERR_HIP; }
     hipError_t e1 = hipMemcpyAsync(drec.p, records, rec_bytes, hipMemcpyDefault, ctx->stream);
     hipError_t e2 = hipMemcpyAsync(dlut.p, lut, (n_lut + 1) * 8, hipMemcpyDefault, ctx->stream);
     if (e1 == hipSuccess && e2 == hipSuccess && n_records) {
@@ -1077,7 +1111,7 @@ int pf_kmc_decode(pf_ctx *ctx, const uint8_t *records, uint64_t n_records, uint3
     if (e1 != hipSuccess) {
         hipFree(dk);
         hipFree(dc);
-        ctx->err = std::string("pf_kmc_decode: ") + hipGetErrorString(e1);
+        pf::CtxErr{ctx} = std::string("pf_kmc_decode: ") + hipGetErrorString(e1);
         return PF_ERR_HIP;
     }
     *kmers_dev = dk;
@@ -1244,14 +1278,14 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
         PF_HIP(hipMemcpyAsync(miss, dx, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
         for (uint32_t i = 0; i < n; ++i)
-            if (miss[i]) { ctx->err = "a k-mer of the graph is missing from the count table"; return PF_ERR_MISSING_KMER; }
+            if (miss[i]) { pf::CtxErr{ctx} = "a k-mer of the graph is missing from the count table"; return PF_ERR_MISSING_KMER; }
     }
     return PF_OK;
 }
 
 int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
     if (ctx && ctx->tab_exact) {
-        ctx->err = "the count database was built without canonical counting: pf_unitig_cov_exact gives its per-orientation coverage";
+        pf::CtxErr{ctx} = "the count database was built without canonical counting: pf_unitig_cov_exact gives its per-orientation coverage";
         return PF_ERR_ARG;
     }
     return unitig_cov_impl(ctx, u0, u1, 0, sum, mn, miss);
@@ -1259,7 +1293,7 @@ int pf_unitig_cov(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t
 
 int pf_unitig_cov_probe(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *sum, uint32_t *mn, uint8_t *miss) {
     if (ctx && ctx->tab_exact) {
-        ctx->err = "the count database was built without canonical counting: pf_unitig_cov_exact gives its per-orientation coverage";
+        pf::CtxErr{ctx} = "the count database was built without canonical counting: pf_unitig_cov_exact gives its per-orientation coverage";
         return PF_ERR_ARG;
     }
     return unitig_cov_impl(ctx, u0, u1, 0, sum, mn, miss, true);
@@ -1332,7 +1366,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
                                uint64_t pool_cap, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred, uint64_t deferred_cap,
                                uint64_t *n_deferred, bool async_copy = false, uint32_t *deferred_entrance = nullptr) {
     if (!ctx || !ctx->has_adj || u0 > u1 || u1 > ctx->N || !records || !pool || !n_records || !pool_used) return PF_ERR_ARG;
-    if (ctx->bfs_pending.active) { ctx->err = "pf_bfs_candidates_end first"; return PF_ERR_ARG; }
+    if (ctx->bfs_pending.active) { pf::CtxErr{ctx} = "pf_bfs_candidates_end first"; return PF_ERR_ARG; }
     if (n_deferred) *n_deferred = 0;
     PF_HIP(hipSetDevice(ctx->device));
     uint64_t c0, c1;
@@ -1340,7 +1374,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     const uint64_t n = c1 - c0;
     *n_records = n;
     *pool_used = 0;
-    if (n > rec_cap) { ctx->err = "record buffer too small"; return PF_ERR_OVERFLOW; }
+    if (n > rec_cap) { pf::CtxErr{ctx} = "record buffer too small"; return PF_ERR_OVERFLOW; }
     if (n == 0) return PF_OK;
     hipPointerAttribute_t at;
     const bool dev_out = hipPointerGetAttributes(&at, records) == hipSuccess && at.type == hipMemoryTypeDevice;
@@ -1390,7 +1424,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
         // the caller walks everything that outgrew the LDS tier itself (a host core needs ~20 ns per vertex; the 4096-entry
         // tier below searches its tables linearly and is quadratic in the traversal's size)
         if (n_deferred) *n_deferred = n_def;
-        if (n_def > deferred_cap) { ctx->err = "deferred-candidate buffer too small"; status = PF_ERR_OVERFLOW; }
+        if (n_def > deferred_cap) { pf::CtxErr{ctx} = "deferred-candidate buffer too small"; status = PF_ERR_OVERFLOW; }
         else PF_HIP(hipMemcpy(deferred, d_def, (size_t)n_def * 4, hipMemcpyDeviceToHost));
     } else if (n_def) {
         const unsigned int waves = std::min<unsigned int>(n_def, 256);
@@ -1432,7 +1466,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     PF_HIP(hipMemcpy(&head, d_head, 8, hipMemcpyDeviceToHost));
     *pool_used = head;
     if (head > pool_cap) {
-        ctx->err = "vertex pool too small";
+        pf::CtxErr{ctx} = "vertex pool too small";
         status = PF_ERR_OVERFLOW;
     }
     if (!dev_out && status == PF_OK && async_copy) {
@@ -1460,7 +1494,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
                 }
             for (uint64_t i = 0; i < n; ++i)
                 if (records[i].outcome == BFS_TOO_LARGE) {
-                    ctx->err = "a traversal exceeded the direct-indexed tier (internal limit)";
+                    pf::CtxErr{ctx} = "a traversal exceeded the direct-indexed tier (internal limit)";
                     status = PF_ERR_OVERFLOW;
                     break;
                 }
@@ -1481,7 +1515,7 @@ int pf_bfs_candidates_split(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record
     if (ctx) {
         hipPointerAttribute_t at;
         if (records && hipPointerGetAttributes(&at, records) == hipSuccess && at.type == hipMemoryTypeDevice) {
-            ctx->err = "pf_bfs_candidates_split fills host records";
+            pf::CtxErr{ctx} = "pf_bfs_candidates_split fills host records";
             return PF_ERR_ARG;
         }
         (void)hipGetLastError();
@@ -1496,7 +1530,7 @@ int pf_bfs_candidates_begin(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_record
     if (ctx) {
         hipPointerAttribute_t at;
         if (records && hipPointerGetAttributes(&at, records) == hipSuccess && at.type == hipMemoryTypeDevice) {
-            ctx->err = "pf_bfs_candidates_begin fills host records";
+            pf::CtxErr{ctx} = "pf_bfs_candidates_begin fills host records";
             return PF_ERR_ARG;
         }
         (void)hipGetLastError();
@@ -1527,7 +1561,7 @@ int pf_bfs_candidates_resident(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *
         }
         return st;
     }
-    ctx->err = "pf_bfs_candidates_resident: the vertex pool does not converge";
+    pf::CtxErr{ctx} = "pf_bfs_candidates_resident: the vertex pool does not converge";
     return PF_ERR_OVERFLOW;
 }
 

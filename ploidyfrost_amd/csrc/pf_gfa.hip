@@ -37,7 +37,7 @@ using namespace pf;
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -360,7 +360,7 @@ int pf_gfa_parse(pf_ctx *ctx, const char *body, uint64_t n_bytes, int gfa_versio
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -372,7 +372,7 @@ const char *pf_gfa_error(const pf_ctx *ctx) {
 int pf_gfa_upload(pf_ctx *ctx) {
     if (!ctx || !ctx->gfa) return PF_ERR_ARG;
     GfaState *S = static_cast<GfaState *>(ctx->gfa);
-    if (!S->n || !S->words) { ctx->err = S->err.empty() ? "pf_gfa_upload: pf_gfa_parse first" : S->err; return PF_ERR_ARG; }
+    if (!S->n || !S->words) { pf::CtxErr{ctx} = S->err.empty() ? "pf_gfa_upload: pf_gfa_parse first" : S->err; return PF_ERR_ARG; }
     const int up = pf_upload_graph(ctx, S->words, S->word_off, S->seg_len, S->n, S->k);
     (void)hipFree(S->words);
     (void)hipFree(S->word_off);
@@ -383,7 +383,7 @@ int pf_gfa_upload(pf_ctx *ctx) {
 int pf_gfa_ingest(pf_ctx *ctx, const char *body, uint64_t n_bytes, int gfa_version, int k, uint32_t *n_unitigs, uint32_t *n_short) {
     const int st = pf_gfa_parse(ctx, body, n_bytes, gfa_version, k, n_unitigs, n_short);
     if (st != PF_OK) {
-        if (ctx && ctx->gfa) ctx->err = static_cast<GfaState *>(ctx->gfa)->err;
+        if (ctx && ctx->gfa) pf::CtxErr{ctx} = static_cast<GfaState *>(ctx->gfa)->err;
         return st;
     }
     return pf_gfa_upload(ctx);
@@ -392,7 +392,7 @@ int pf_gfa_ingest(pf_ctx *ctx, const char *body, uint64_t n_bytes, int gfa_versi
 int pf_gfa_segments(pf_ctx *ctx, uint32_t *len_bp, uint64_t *seq_off, uint32_t *file_rank, int16_t *da_tag, uint8_t *stored_rc, int *any_da) {
     if (!ctx || !ctx->gfa) return PF_ERR_ARG;
     GfaState *S = static_cast<GfaState *>(ctx->gfa);
-    if (!S->n) { ctx->err = "pf_gfa_segments: pf_gfa_ingest first"; return PF_ERR_ARG; }
+    if (!S->n) { pf::CtxErr{ctx} = "pf_gfa_segments: pf_gfa_ingest first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     const size_t N = S->n;
     if (len_bp) PF_HIP(hipMemcpy(len_bp, S->seg_len, N * 4, hipMemcpyDeviceToHost));

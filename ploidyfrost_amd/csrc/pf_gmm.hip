@@ -23,7 +23,7 @@
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -194,7 +194,7 @@ uint64_t pf_gmm_count(const pf_ctx *ctx) { return ctx && ctx->gmm_loaded ? ctx->
 int pf_gmm_fit(pf_ctx *ctx, uint32_t gauss, double m_thre, double n_thre, int32_t max_iter, double max_delta, double *weights,
                double *means, double *vars, double *loglik, uint32_t *iterations) {
     if (!ctx || !ctx->gmm_loaded || gauss < 1 || gauss > (uint32_t)GMM_MAXG || max_iter < 0 || !weights || !means || !vars || !loglik) {
-        if (ctx) ctx->err = "pf_gmm_fit: values not uploaded, or gauss outside 1..PF_GMM_MAX_GAUSS";
+        if (ctx) pf::CtxErr{ctx} = "pf_gmm_fit: values not uploaded, or gauss outside 1..PF_GMM_MAX_GAUSS";
         return PF_ERR_ARG;
     }
     PF_HIP(hipSetDevice(ctx->device));
@@ -233,7 +233,7 @@ int pf_gmm_fit(pf_ctx *ctx, uint32_t gauss, double m_thre, double n_thre, int32_
         if (ce == hipSuccess && graph) ce = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
         if (ce != hipSuccess || !exec) {
             if (graph) hipGraphDestroy(graph);
-            ctx->err = std::string("K-GMM graph capture: ") + hipGetErrorString(ce);
+            pf::CtxErr{ctx} = std::string("K-GMM graph capture: ") + hipGetErrorString(ce);
             return PF_ERR_HIP;
         }
     } else {
@@ -249,13 +249,13 @@ int pf_gmm_fit(pf_ctx *ctx, uint32_t gauss, double m_thre, double n_thre, int32_
         ctx_end(ctx);
         if (ce == hipSuccess) ce = hipMemcpyAsync(&h, dst, sizeof h, hipMemcpyDeviceToHost, ctx->stream);
         if (ce == hipSuccess) ce = hipStreamSynchronize(ctx->stream);
-        if (ce != hipSuccess) { ctx->err = std::string("K-GMM launch: ") + hipGetErrorString(ce); rc = PF_ERR_HIP; break; }
+        if (ce != hipSuccess) { pf::CtxErr{ctx} = std::string("K-GMM launch: ") + hipGetErrorString(ce); rc = PF_ERR_HIP; break; }
         if (h.done) break;
     }
     if (exec) hipGraphExecDestroy(exec);
     if (graph) hipGraphDestroy(graph);
     if (rc != PF_OK) return rc;
-    if (!h.done) { ctx->err = "K-GMM did not finish within its iteration bound"; return PF_ERR_HIP; }
+    if (!h.done) { pf::CtxErr{ctx} = "K-GMM did not finish within its iteration bound"; return PF_ERR_HIP; }
     for (uint32_t i = 0; i < gauss; ++i) { weights[i] = h.w[i]; means[i] = h.mean[i]; vars[i] = h.var[i]; }
     *loglik = h.ll;
     if (iterations) *iterations = h.count;

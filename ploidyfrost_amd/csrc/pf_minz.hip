@@ -25,7 +25,7 @@
     do {                                                                                     \
         hipError_t e_ = (call);                                                              \
         if (e_ != hipSuccess) {                                                              \
-            ctx->err = std::string(#call) + ": " + hipGetErrorString(e_);                   \
+            pf::CtxErr{ctx} = std::string(#call) + ": " + hipGetErrorString(e_);                   \
             return PF_ERR_HIP;                                                               \
         }                                                                                    \
     } while (0)
@@ -139,7 +139,7 @@ uint64_t pf_minimizer_table_slots(uint64_t n_kmers) {
 
 int pf_minimizer_crowding(pf_ctx *ctx, int g, uint32_t limit, uint32_t *max_occurrences, uint64_t *crowded_slots, uint32_t *table_out) {
     if (!ctx || !ctx->d_seq || !max_occurrences || g < 1 || g > 31 || g > ctx->k - 2 || limit == 0) {
-        if (ctx) ctx->err = "pf_minimizer_crowding: no graph uploaded, or g outside 1 .. min(31, k - 2)";
+        if (ctx) pf::CtxErr{ctx} = "pf_minimizer_crowding: no graph uploaded, or g outside 1 .. min(31, k - 2)";
         return PF_ERR_ARG;
     }
     PF_HIP(hipSetDevice(ctx->device));

@@ -78,6 +78,7 @@ def load_library() -> C.CDLL:
         "pf_enable_timing": (i, [vp, i]),
         "pf_kernel_time": (i, [vp, i, C.POINTER(C.c_double), C.POINTER(u64)]),
         "pf_reset_timing": (i, [vp]),
+        "pf_device_busy": (i, [vp, vp, vp]),
         "pf_kernel_units": (i, [vp, i, C.POINTER(u64)]),
         "pf_side_components": (i, [vp, i, vp, u64, vp, u64, vp, u64, vp, u64]),
         "pf_bfs_candidates_begin": (i, [vp, C.c_uint32, C.c_uint32, vp, u64, vp, u64, C.POINTER(u64), C.POINTER(u64), vp, vp, u64, C.POINTER(u64)]),
@@ -160,7 +161,7 @@ def load_library() -> C.CDLL:
 
 
 DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
-                    "pf_kernel_time", "pf_reset_timing", "pf_kernel_units", "pf_side_components", "pf_replay_order", "pf_bfs_candidates_begin", "pf_bfs_candidates_end", "pf_fetch", "pf_bfs_candidates_resident", "pf_replay_device", "pf_replay_big_fetch", "pf_replay_set_colours", "pf_replay_finish", "pf_call_get_state", "pf_gfa_ingest", "pf_gfa_segments", "pf_gfa_parse", "pf_gfa_upload", "pf_gfa_error", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
+                    "pf_kernel_time", "pf_reset_timing", "pf_device_busy", "pf_kernel_units", "pf_side_components", "pf_replay_order", "pf_bfs_candidates_begin", "pf_bfs_candidates_end", "pf_fetch", "pf_bfs_candidates_resident", "pf_replay_device", "pf_replay_big_fetch", "pf_replay_set_colours", "pf_replay_finish", "pf_call_get_state", "pf_gfa_ingest", "pf_gfa_segments", "pf_gfa_parse", "pf_gfa_upload", "pf_gfa_error", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",

@@ -268,6 +268,26 @@ def test_shards_replayed_from_device_memory(case, world, tmp_path):
     run.close()
 
 
+def test_a_rank_with_an_empty_slice_reports_nothing(tmp_path):
+    """fewer bubbles than ranks (dist.sharded_ploidy): the rank whose slice is empty must report zero called bubbles, zero sizes and
+    zero counters -- not the figures of the pass before (pf_call_align_lane left them in the lane)"""
+    meta = load_case("dip20k")
+    op = meta["opts"]
+    run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]))
+    run.set_output_dir(str(tmp_path))
+    run.set_unitig_id("g")
+    run.find_superbubbles("g")
+    nb = run.ploidy_select(int(op["-l"]), int(op["-u"]))
+    assert run.ploidy_align(0, nb) > 0
+    sizes, counters = run.ploidy_text(0)
+    assert sizes.sum() > 0 and counters[6] > 0
+    for t in (0, nb // 2, nb):
+        assert run.ploidy_align(t, t) == 0
+        sizes, counters = run.ploidy_text(7)
+        assert sizes.sum() == 0 and not counters[:7].any(), (t, sizes, counters)
+    run.close()
+
+
 def _state_after_find(meta, op):
     run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]))
     run.set_write_files(False)

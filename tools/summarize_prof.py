@@ -2,7 +2,12 @@
 """Condense a `rocprofv3 --kernel-trace --stats --output-format csv` run into the small files kept
 under profiles/: the per-kernel stats of this repository's kernels (k_*), and the top rows overall.
 
-usage: tools/summarize_prof.py <dir with *_kernel_stats.csv> <profiles/out_prefix>
+Also: the device-busy time per pass from the kernel trace (*_kernel_trace.csv: one row per dispatch with its start and end
+timestamps) -- the UNION of the dispatch intervals, since the calling pipeline runs kernels side by side and the per-kernel totals
+count overlapped time twice.  Passes are told apart by the K-BFS tier-1 launch that opens each findSuperBubble (k_bfs_thread); the
+last `steps` passes of the run are the timed ones.  Written to <out_prefix>_device_busy.json.
+
+usage: tools/summarize_prof.py <dir with *_kernel_stats.csv> <profiles/out_prefix> [steps]
 """
 import csv
 import glob
@@ -41,5 +46,55 @@ def main(src, out_prefix):
                                                                 float(r["TotalDurationNs"]) / 1e6))
 
 
+def union_ms(iv):
+    iv.sort()
+    busy, lo, hi = 0, None, None
+    for a, b in iv:
+        if lo is None:
+            lo, hi = a, b
+        elif a <= hi:
+            hi = max(hi, b)
+        else:
+            busy += hi - lo
+            lo, hi = a, b
+    if lo is not None:
+        busy += hi - lo
+    return busy / 1e6
+
+
+def device_busy(src, out_prefix, steps):
+    import json
+    files = glob.glob(os.path.join(src, "**", "*_kernel_trace.csv"), recursive=True)
+    if not files:
+        print("no *_kernel_trace.csv under " + src)
+        return
+    rows = []
+    for f in files:
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
+    rows.sort()
+    starts = [a for a, b, n in rows if "k_bfs_thread" in n]   # one per findSuperBubble = one per pass
+    if len(starts) < steps + 1:
+        print("fewer passes in the trace than steps: no busy figure")
+        return
+    # the timed passes are the last `steps` (bench.py runs nothing pass-shaped after them when --no-cpu-baseline, except the K-COV
+    # probe comparison, which launches no k_bfs_thread); a pass = from its k_bfs_thread to the next one's
+    first = starts[-steps]
+    after_last = [a for a, b, n in rows if a >= starts[-1] and ("k_call_format" in n or "k_sb_format" in n)]
+    end = max(b for a, b, n in rows if a >= starts[-1] and a <= (max(after_last) if after_last else starts[-1]))
+    timed = [(a, b) for a, b, n in rows if a >= first and a <= end]
+    ours = [(a, b) for a, b, n in rows if a >= first and a <= end and "k_" in n and "rocprim" not in n and "hipcub" not in n]
+    out = {"steps": steps, "dispatches": len(timed), "span_ms_per_step": round((end - first) / 1e6 / steps, 3),
+           "device_busy_ms_per_step": round(union_ms(timed) / steps, 3),
+           "device_busy_ms_per_step_own_kernels_only": round(union_ms(ours) / steps, 3),
+           "sum_of_durations_ms_per_step": round(sum(b - a for a, b in timed) / 1e6 / steps, 3)}
+    out["device_busy_frac_of_span"] = round(out["device_busy_ms_per_step"] / out["span_ms_per_step"], 4)
+    with open(out_prefix + "_device_busy.json", "w") as fh:
+        json.dump(out, fh, indent=1)
+    print("device busy:", out)
+
+
 if __name__ == "__main__":
     main(sys.argv[1], sys.argv[2])
+    device_busy(sys.argv[1], sys.argv[2], int(sys.argv[3]) if len(sys.argv) > 3 else 5)
