@@ -57,7 +57,7 @@ constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_STRICT_M = 0x08, B_STRICT_P =
 constexpr int N_STREAMS = PF_CALL_STREAMS;
 // work lists of a batch: K-BUBBLE's queues (heavy and light per size class), then the three lists of the other kernels
 constexpr int NQ = 2 * (kBubLdsClasses + 1);
-constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_NONE = NQ + 3;
+constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_PAIR2 = NQ + 3, KEY_NONE = NQ + 4;
 
 struct DevBuf {
     void *p = nullptr;
@@ -88,6 +88,7 @@ struct CallCounters {
     unsigned int n_branching;
     unsigned int n_snp, n_snp_done;        // two-path bubbles of equal length: candidates for / takers of the single-SNP shortcut
     unsigned int n_pair, n_pair_done;      // two short paths: K-PAIR's list / the bubbles it finished
+    unsigned int n_pair2, n_pair2_done;    // two paths of up to 128 bases: the list of K-PAIR's second tier
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
@@ -119,7 +120,7 @@ struct CallState {
     uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
     // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, pair_scr, has, scan_tmp2, paths_scr, sites_scr;
+    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
     // what pf_call_align leaves resident for pf_call_text_range: two sets ("lanes"), so that the rows of one range of bubbles
     // can be formatted, fetched and written while the next range is aligned into the other set
     struct AlignOut {
@@ -146,7 +147,7 @@ struct CallState {
     bool mt_format = false;   // pf_call_set_format
     void release_all() {
         DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &pair_scr, &has, &sizes, &offs,
+                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &pair_scr, &pair_scr2, &has, &sizes, &offs,
                          &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
         for (AlignOut &o : lane)
@@ -372,7 +373,7 @@ __global__ void k_call_resolve(ResolveArgs a) {
 // nowhere): one atomic per key and wave
 struct CallLists {
     uint32_t *queues;   // NQ lists of nb entries
-    uint32_t *blist, *slist, *plist;
+    uint32_t *blist, *slist, *plist, *plist2;
     uint32_t nb;
 };
 __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, CallCounters *cnt) {
@@ -385,7 +386,7 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
         const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
         if (lane_id() == leader)
-            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : &cnt->n_pair)),
+            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : (x == KEY_PAIR ? &cnt->n_pair : &cnt->n_pair2))),
                              (unsigned int)__popcll(m));
         base = __shfl(base, leader, WAVE);
         if (key == x) {
@@ -393,7 +394,8 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
             if (x < NQ) L.queues[(size_t)x * L.nb + at] = val;
             else if (x == KEY_BRANCHING) L.blist[at] = val;
             else if (x == KEY_SNP) L.slist[at] = val;
-            else L.plist[at] = val;
+            else if (x == KEY_PAIR) L.plist[at] = val;
+            else L.plist2[at] = val;
         }
     }
 }
@@ -443,8 +445,10 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
                 // two paths of one length: K-SNP looks at them first (thread per bubble) and hands on what is not a single SNP;
                 // two short paths of any kind: K-PAIR (thread per bubble)
                 if (t.n_inner == 2) {
+                    const uint32_t l1 = sum - l0;
                     if (a.snp_ok && sum == 2 * l0) key = KEY_SNP;
-                    else if (a.pair_ok && lmax <= PAIR_MAX) key = KEY_PAIR;
+                    else if (a.pair_ok && pair_fits<PAIR_MAX>(l0, l1)) key = KEY_PAIR;
+                    else if (a.pair_ok && pair_fits<PAIR_MAX2>(l0, l1)) key = KEY_PAIR2;
                 }
             }
         } else {
@@ -605,12 +609,12 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
     }
     // the rest: K-PAIR when short, else K-BUBBLE's queue of their size class
     int key = KEY_NONE;
-    if (active && !take) key = (a.pair_ok && m <= PAIR_MAX) ? KEY_PAIR : 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
+    if (active && !take) key = (a.pair_ok && m <= PAIR_MAX) ? KEY_PAIR : (a.pair_ok && m <= PAIR_MAX2) ? KEY_PAIR2 : 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
     wave_append(key, j, a.lists, a.cnt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// K-PAIR (pf_pair_dev.hpp): SequenceAlignment of two paths of at most 64 bases, one thread per bubble
+// K-PAIR (pf_pair_dev.hpp): SequenceAlignment of two paths of at most 64 (tier 1) / 128 (tier 2) bases, one thread per bubble
 struct PairArgs {
     const CallTask *ct;
     const uint32_t *kept;
@@ -618,10 +622,12 @@ struct PairArgs {
     const uint64_t *seq, *off;
     const uint32_t *len;
     double M, D, G;
-    int integral;
-    int unique_only;            // matrices with several optimal paths go to K-BUBBLE (see pair_traceback)
-    unsigned long long *prof;   // diagnostic (PF_PAIR_STATS): ticks of lane 0 in decode, fill, traceback, choose, publish; or nullptr
-    uint8_t *scratch;           // pair_scratch_bytes() per wavefront of the grid
+    int Mi, Di, Gi;               // the same as ints (integral scores)
+    const uint32_t *list;         // this tier's bubbles (batch-local indices) ...
+    const unsigned int *n_list;   // ... and how many (on the device: K-PREP and K-SNP fill the list)
+    unsigned int *n_done;
+    unsigned long long *prof;   // diagnostic (PF_PAIR_STATS): ticks of lane 0 in decode, fill, traceback, classify, publish; or nullptr
+    uint8_t *scratch;           // PairGeom<NMAX>::scratch_bytes per wavefront of the grid
     pf_bubble_result *res;
     char *otext;
     uint64_t text_cap;
@@ -654,25 +660,41 @@ __device__ inline unsigned long long wave_take(unsigned long long *head, uint32_
     return base;
 }
 
-__global__ __launch_bounds__(64) void k_call_pair(PairArgs a) {
+// too few bubbles for the second tier to fill the device (a launch lasts as long as one wavefront's 64 bubbles whatever their
+// number): they join K-BUBBLE's queues of their size classes instead
+__global__ __launch_bounds__(256) void k_call_pair2_reroute(PairArgs a) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    int key = KEY_NONE;
+    uint32_t j = 0;
+    if (i < *a.n_list) {
+        j = a.list[i];
+        const CallTask &t = a.ct[a.kept[a.t0 + j]];
+        const uint32_t m = a.len[t.inner[0] >> 1], n = a.len[t.inner[1] >> 1];
+        key = 2 * bubble_class(m, m > n ? m : n) + (m > 64 || n > 64 ? 0 : 1);
+    }
+    wave_append(key, j, a.lists, a.cnt);
+}
+
+template <int NMAX, bool INTEGRAL>
+__global__ __launch_bounds__(64, NMAX == 64 ? 3 : 2) void k_call_pair(PairArgs a) {
+    using Gm = PairGeom<NMAX>;
     const int lane = lane_id();
     PairMem mem;
-    uint8_t *g = a.scratch + (uint64_t)blockIdx.x * pair_scratch_bytes();
-    mem.dir = g + lane * 4;
-    mem.ra = reinterpret_cast<char *>(g + 64ull * PAIR_CELLS) + lane;
-    mem.rb = mem.ra + 64ull * PAIR_LEN;
-    mem.mv = reinterpret_cast<uint8_t *>(mem.rb + 64ull * PAIR_LEN);
-    mem.htext = reinterpret_cast<char *>(g + 64ull * (PAIR_CELLS + 3ull * PAIR_LEN)) + lane;
-    mem.hits = reinterpret_cast<PairHit *>(g + 64ull * (PAIR_CELLS + 3ull * PAIR_LEN + (uint64_t)PAIR_HITS * 2 * PAIR_LEN)) + lane;
-    const uint32_t n_list = a.cnt->n_pair;
+    uint8_t *g = a.scratch + (uint64_t)blockIdx.x * Gm::scratch_bytes;
+    mem.dir = reinterpret_cast<uint32_t *>(g) + lane;
+    mem.ra = reinterpret_cast<char *>(g + Gm::dir_bytes) + lane;
+    mem.rb = mem.ra + 64ull * Gm::LEN;
+    mem.fa = mem.rb + 64ull * Gm::LEN;
+    mem.fb = mem.fa + 64ull * Gm::LEN;
+    const uint32_t n_list = *a.n_list;
     for (uint32_t base = blockIdx.x * 64; base < n_list; base += gridDim.x * 64) {
         const uint32_t i = base + lane;
         const bool active = i < n_list;
         uint32_t j = 0, L = 0, n_sites = 0, n_ilen = 0;
-        int best = -1, defer_key = KEY_NONE;
+        int defer_key = KEY_NONE;
         bool defer = false;
         if (active) {
-            j = a.lists.plist[i];
+            j = a.list[i];
             const CallTask &t = a.ct[a.kept[a.t0 + j]];
             const uint32_t ov0 = t.inner[0], ov1 = t.inner[1];
             const uint32_t m = a.len[ov0 >> 1], n = a.len[ov1 >> 1];
@@ -683,31 +705,33 @@ __global__ __launch_bounds__(64) void k_call_pair(PairArgs a) {
                 if (lane == 0) atomicAdd(&a.prof[slot], now - tq);
                 tq = now;
             };
-            mem.Aw[0] = mem.Aw[1] = mem.Bw[0] = mem.Bw[1] = 0;
-            for (uint32_t c = 0; c < m; ++c) mem.Aw[c >> 5] |= (uint64_t)oriented_base(a.seq, a.off, a.len, ov0, c) << (62 - 2 * (c & 31));
-            for (uint32_t c = 0; c < n; ++c) mem.Bw[c >> 5] |= (uint64_t)oriented_base(a.seq, a.off, a.len, ov1, c) << (62 - 2 * (c & 31));
+            uint64_t Aw[Gm::NA], Bw[Gm::NA];
+            uint32_t b0[Gm::NA], b1[Gm::NA];
+            const uint64_t *w0 = a.seq + a.off[ov0 >> 1], *w1 = a.seq + a.off[ov1 >> 1];
+#pragma unroll
+            for (int c = 0; c < Gm::NA; ++c) {
+                Aw[c] = 32u * c < m ? oriented_chunk(w0, m, (ov0 & 1) != 0, (uint32_t)c) : 0;
+                Bw[c] = 32u * c < n ? oriented_chunk(w1, n, (ov1 & 1) != 0, (uint32_t)c) : 0;
+                pair_planes(Bw[c], b0[c], b1[c]);
+            }
+            const int dmin = n < m ? (int)n - (int)m : 0;
             mark(0);
-            pair_fill(mem, mem.Aw, mem.Bw, m, n, a.M, a.D, a.G, a.integral);
+            pair_fill<NMAX, INTEGRAL>(mem.dir, Aw, b0, b1, m, dmin, a.M, a.D, a.G, a.Mi, a.Di, a.Gi);
             mark(1);
-            const uint32_t nh = pair_traceback(mem, m, n, a.M, a.D, a.G, a.unique_only != 0);
+            L = pair_traceback<NMAX>(mem, Aw, Bw, m, n, dmin);
             mark(2);
-            if (nh == 0xFFFFFFFFu) {   // more kept alignments than this tier holds: K-BUBBLE's queue of the bubble's size class
+            if (L == 0) {   // several optimal paths, a gap-open budget in the way, or a walk outside the band: K-BUBBLE's queue of the bubble's size class
                 defer = true;
-                defer_key = 2 * bubble_class(m, m > n ? m : n) + 1;
+                defer_key = 2 * bubble_class(m, m > n ? m : n) + (m > 64 || n > 64 ? 0 : 1);
             } else {
-                best = pair_choose(mem, nh);
-                if (best >= 0) {
-                    L = PF_AT(mem.hits, best).len;
-                    const char *x = mem.htext + (size_t)best * 2 * PAIR_LEN * 64;
-                    const PairMetrics pm = pair_classify<false>(x, x + (size_t)PAIR_LEN * 64, L, L, nullptr, nullptr);
-                    n_sites = pm.n_sites;
-                    n_ilen = pm.n_indel_len;
-                }
+                const PairCounts pc = pair_classify<false>(mem.fa, mem.fb, L, nullptr, nullptr);
+                n_sites = pc.n_sites;
+                n_ilen = pc.n_indel_len;
             }
             mark(3);
         }
         const unsigned long long tp0 = a.prof ? wall_clock64() : 0;
-        const bool take = active && !defer && best >= 0;
+        const bool take = active && !defer;
         // pool space for the whole wavefront: one atomic per pool
         uint32_t e_text, e_sites, e_groups, e_ilen;
         const unsigned long long b_text = wave_take(&a.heads[0], take ? 2 * L : 0, e_text);
@@ -727,15 +751,14 @@ __global__ __launch_bounds__(64) void k_call_pair(PairArgs a) {
             r.n_indel_len = n_ilen;
             a.res[j] = r;
             if (t_off + 2ull * L <= a.text_cap && s_off + n_sites <= a.site_cap && g_off + 2ull * n_sites <= a.group_cap && l_off + n_ilen <= a.ilen_cap) {
-                const char *x = mem.htext + (size_t)best * 2 * PAIR_LEN * 64, *y = x + (size_t)PAIR_LEN * 64;
                 char *o = a.otext + t_off;
-                for (uint32_t c = 0; c < L; ++c) { o[c] = PF_AT(x, c); o[L + c] = PF_AT(y, c); }
-                (void)pair_classify<true>(x, y, L, L, a.osites + s_off, a.oilen + l_off);
+                for (uint32_t c = 0; c < L; ++c) { o[c] = PF_AT(mem.fa, c); o[L + c] = PF_AT(mem.fb, c); }
+                (void)pair_classify<true>(mem.fa, mem.fb, L, a.osites + s_off, a.oilen + l_off);
                 for (uint32_t q = 0; q < n_sites; ++q) { a.ogroups[g_off + 2 * q] = 1; a.ogroups[g_off + 2 * q + 1] = 2; }
             }
         }
-        const unsigned long long done_m = __ballot(active && !defer);
-        if (lane == 0 && done_m) atomicAdd(&a.cnt->n_pair_done, (unsigned int)__popcll(done_m));
+        const unsigned long long done_m = __ballot(take);
+        if (lane == 0 && done_m) atomicAdd(a.n_done, (unsigned int)__popcll(done_m));
         wave_append(defer_key, j, a.lists, a.cnt);
         if (a.prof && lane == 0) { atomicAdd(&a.prof[4], wall_clock64() - tp0); atomicAdd(&a.prof[5], 1ull); }
     }
@@ -1984,13 +2007,15 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     // ---- K-PREP, K-SNP, K-PATHS, K-BUBBLE; every pool grows until the batch fits (first batches of a run only) ----
     NEED(S->slist, (size_t)nb * 4);
     NEED(S->plist, (size_t)nb * 4);
+    NEED(S->plist2, (size_t)nb * 4);
     const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
-    // K-PAIR: register-bound (the score row of the fill is 65 registers): eight wavefronts per CU, the grid loops over its list
-    // (its packed score row holds score * 8 in an int: scores of sane magnitude only)
+    // K-PAIR: register-bound (the score row of the fill is 65 / 129 registers): 3 / 2 wavefronts per SIMD, the grid loops over its list
+    // (scores of sane magnitude only: the fill adds them in ints)
     static const bool pair_env = [] { const char *e = getenv("PF_PAIR_TIER"); return !(e && e[0] == '0'); }();  // measurements
     const bool pair_tier = pair_env && std::fabs(match) < 1e5 && std::fabs(mismatch) < 1e5 && std::fabs(gap) < 1e5;
-    const int pair_grid = ctx->n_cu * 8;
-    if (pair_tier) NEED(S->pair_scr, pair_scratch_bytes() * pair_grid);
+    const bool pair_integral = match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap);
+    const int pair_grid = ctx->n_cu * 12, pair_grid2 = ctx->n_cu * 4;
+    if (pair_tier) NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * pair_grid);
     unsigned long long heads[4] = {0, 0, 0, 0};
     uint64_t n_jobs = 0;
     for (int attempt = 0;; ++attempt) {
@@ -2014,7 +2039,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
         pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = O.res.as<pf_bubble_result>();
-        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), nb};
+        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), nb};
         pa.snp_ok = snp_ok;
         pa.pair_ok = pair_tier ? 1 : 0;
         pa.cnt = d_cnt;
@@ -2055,19 +2080,17 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             k_call_snp<<<(nb + 255) / 256, 256, 0, st>>>(sn);   // (the list length is on the device: surplus threads leave at once)
             ctx_end(ctx);
         }
+        PairArgs pr;
+        static const bool pair_stats = getenv("PF_PAIR_STATS") != nullptr;
+        DevTmp<unsigned long long> prof_;
         if (pair_tier) {
-            PairArgs pr;
             pr.ct = pa.ct; pr.kept = pa.kept; pr.t0 = t0; pr.seq = ctx->d_seq; pr.off = ctx->d_off; pr.len = ctx->d_len;
             pr.M = match; pr.D = mismatch; pr.G = gap;
-            pr.integral = (match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap) && std::fabs(match) < 1e6 &&
-                           std::fabs(mismatch) < 1e6 && std::fabs(gap) < 1e6) ? 1 : 0;
-            static const bool pair_dfs = [] { const char *e = getenv("PF_PAIR_DFS"); return e && e[0] == '1'; }();  // measurements
-            pr.unique_only = pair_dfs ? 0 : 1;
+            pr.Mi = (int)match; pr.Di = (int)mismatch; pr.Gi = (int)gap;
+            pr.list = pa.lists.plist; pr.n_list = &d_cnt->n_pair; pr.n_done = &d_cnt->n_pair_done;
             pr.scratch = S->pair_scr.as<uint8_t>(); pr.res = pa.res; pr.otext = O.otext.as<char>(); pr.text_cap = cap_text;
             pr.osites = O.osites.as<pf_bubble_site>(); pr.site_cap = cap_sites; pr.ogroups = O.ogroups.as<uint8_t>(); pr.group_cap = cap_groups;
             pr.oilen = O.oilen.as<uint32_t>(); pr.ilen_cap = cap_ilen; pr.heads = d_heads; pr.lists = pa.lists; pr.cnt = d_cnt;
-            static const bool pair_stats = getenv("PF_PAIR_STATS") != nullptr;
-            DevTmp<unsigned long long> prof_;
             pr.prof = nullptr;
             if (pair_stats) {
                 PF_HIP(prof_.alloc(64));
@@ -2075,12 +2098,13 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
                 pr.prof = prof_.p;
             }
             ctx_begin(ctx, PF_K_CALL_PAIR);
-            k_call_pair<<<pair_grid, 64, 0, st>>>(pr);
+            if (pair_integral) k_call_pair<PAIR_MAX, true><<<pair_grid, 64, 0, st>>>(pr);
+            else k_call_pair<PAIR_MAX, false><<<pair_grid, 64, 0, st>>>(pr);
             ctx_end(ctx);
             if (pair_stats) {
                 unsigned long long h[8];
                 PF_HIP(hipMemcpy(h, prof_.p, 64, hipMemcpyDeviceToHost));
-                fprintf(stderr, "[k_call_pair] %llu wavefront rounds; lane-0 ticks (10 ns): decode %llu fill %llu traceback %llu choose+classify %llu publish %llu\n", h[5],
+                fprintf(stderr, "[k_call_pair] %llu wavefront rounds; lane-0 ticks (10 ns): decode %llu fill %llu traceback %llu classify %llu publish %llu\n", h[5],
                         h[0], h[1], h[2], h[3], h[4]);
             }
         }
@@ -2088,9 +2112,30 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
+        if (pair_tier && hc.n_pair2) {
+            // second tier (paths of 65 .. 128 bases, or a longer indel than the first tier's band follows): few on most graphs, so
+            // its scratch and its launch wait until the host knows there are any; its rejects join K-BUBBLE's queues
+            const int g2 = (int)std::min<uint32_t>((hc.n_pair2 + 63) / 64, (uint32_t)pair_grid2);
+            pr.list = pa.lists.plist2; pr.n_list = &d_cnt->n_pair2; pr.n_done = &d_cnt->n_pair2_done;
+            pr.prof = nullptr;
+            const uint32_t tier2_min = [] { const char *e = getenv("PF_PAIR2_MIN"); return e ? (uint32_t)atoi(e) : 0u; }();   // (read per call: tests run the tier on a few bubbles)
+            if (hc.n_pair2 < (tier2_min ? tier2_min : (uint32_t)ctx->n_cu * 32u)) {
+                k_call_pair2_reroute<<<(hc.n_pair2 + 255) / 256, 256, 0, st>>>(pr);
+            } else {
+                NEED(S->pair_scr2, PairGeom<PAIR_MAX2>::scratch_bytes * g2);
+                pr.scratch = S->pair_scr2.as<uint8_t>();
+                ctx_begin(ctx, PF_K_CALL_PAIR);
+                if (pair_integral) k_call_pair<PAIR_MAX2, true><<<g2, 64, 0, st>>>(pr);
+                else k_call_pair<PAIR_MAX2, false><<<g2, 64, 0, st>>>(pr);
+                ctx_end(ctx);
+            }
+            PF_HIP(hipGetLastError());
+            PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+            PF_HIP(hipStreamSynchronize(st));
+        }
         ctx_units(ctx, PF_K_CALL_PREP, nb);
         if (snp_ok) ctx_units(ctx, PF_K_CALL_SNP, hc.n_snp);
-        if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair);
+        if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair + hc.n_pair2);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (hc.err & 33u) {
             // (the per-wave tables of K-PATHS / K-SITES and K-BUBBLE's standard tier hold 256 rows; the reference has no such limit)
@@ -2159,8 +2204,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         break;
     }
     out->n_branching = hc.n_branching;
-    out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done;
-    out->snp_jobs = hc.n_snp_done; out->pair_jobs = hc.n_pair_done; out->wave_jobs = n_jobs;
+    out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done + hc.n_pair2_done;
+    out->snp_jobs = hc.n_snp_done; out->pair_jobs = hc.n_pair_done + hc.n_pair2_done; out->wave_jobs = n_jobs;
 
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);

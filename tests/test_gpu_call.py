@@ -286,7 +286,7 @@ def check_pipeline(tmp, gfa, db, z=8, lower=5, upper=1000, scores=(2.0, -1.0, -3
     M, D, Gp = scores
     o = pyoracle.Oracle(gfa, db)
     want_dir = os.path.join(tmp, "oracle_%g_%g_%g" % scores)
-    os.makedirs(want_dir)
+    os.makedirs(want_dir, exist_ok=True)
     o.run(want_dir, "g", z=z, lower=lower, upper=upper, M=M, D=D, G=Gp)
     G = Graph(o)
     run = hostapi.Run(gfa, db, z=z, M=M, D=D, G=Gp)
@@ -400,7 +400,14 @@ def multi_path_graphs(tmp_path_factory):
     return out
 
 
-def test_two_path_bubbles_kernel_by_kernel(two_path_graph):
+@pytest.fixture
+def second_pair_tier(monkeypatch):
+    """K-PAIR's tier for paths of 65 .. 128 bases (or an indel longer than the first tier's band follows) runs from a few thousand
+    bubbles on -- fewer join K-BUBBLE's queues; the tests run it whatever the number"""
+    monkeypatch.setenv("PF_PAIR2_MIN", "1")
+
+
+def test_two_path_bubbles_kernel_by_kernel(two_path_graph, second_pair_tier):
     tmp, gfa, db, kinds = two_path_graph
     s = check_pipeline(tmp, gfa, db)
     assert s["two_path"] >= 2000, s
@@ -409,10 +416,20 @@ def test_two_path_bubbles_kernel_by_kernel(two_path_graph):
     # co-optimal ties and long paths (K-BUBBLE)
     assert s["snp_jobs"] >= 300 and s["pair_jobs"] >= 300 and s["wave_jobs"] >= 100, s
     assert s["snp_jobs"] + s["pair_jobs"] + s["wave_jobs"] == s["bubbles"], s
+    # the long insertions are aligned by K-PAIR's second tier, not by K-BUBBLE: what is left there are the ties
+    assert s["wave_jobs"] < s["gt64"] + s["two_path"] // 4 and s["pair_jobs"] >= s["gt64"] // 2, s
+
+
+def test_second_pair_tier_off_gives_the_same(two_path_graph, monkeypatch):
+    """... and with that tier's list handed to K-BUBBLE (the default for a short list) nothing changes but the counters"""
+    monkeypatch.delenv("PF_PAIR2_MIN", raising=False)
+    tmp, gfa, db, kinds = two_path_graph
+    s = check_pipeline(tmp + "/off", gfa, db)
+    assert s["two_path"] >= 2000 and s["wave_jobs"] >= s["gt64"], s
 
 
 @pytest.mark.parametrize("scores", [(1.5, -0.5, -2.25), (1.0, -1.0, -1.0), (3.0, -2.0, -4.0)])
-def test_two_path_bubbles_under_other_scores(two_path_graph, scores):
+def test_two_path_bubbles_under_other_scores(two_path_graph, scores, second_pair_tier):
     """fractional scores (the NW fill in doubles truncated to int, src/SeqAlign.cpp:480-549; no single-mismatch shortcut) and
     scores under which gaps are cheap"""
     tmp, gfa, db, kinds = two_path_graph

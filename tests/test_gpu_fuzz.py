@@ -35,5 +35,7 @@ def test_random_inputs_give_the_oracles_files(seed, colored, giant):
             break
     assert ("colored" in msg) == colored or "skipped" in msg, msg
     assert msg.endswith("identical"), msg
-    if giant:
-        assert "giants=" in msg and "giants=0" not in msg and "giants=?" not in msg, msg
+    if giant:   # a traversal that outgrew the 128-entry LDS tier of K-BFS: walked by the third tier
+        import re
+        mm = re.search(r"largest=(\d+)", msg)
+        assert mm and int(mm.group(1)) > 128, msg
