@@ -38,6 +38,7 @@
 #include "pf_device_common.hpp"
 #include "pf_format_dev.hpp"
 #include "pf_pair_dev.hpp"
+#include "pf_stack_dev.hpp"
 #include "ploidyfrost_hip.h"
 
 using namespace pf;
@@ -57,7 +58,7 @@ constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_STRICT_M = 0x08, B_STRICT_P =
 constexpr int N_STREAMS = PF_CALL_STREAMS;
 // work lists of a batch: K-BUBBLE's queues (heavy and light per size class), then the three lists of the other kernels
 constexpr int NQ = 2 * (kBubLdsClasses + 1);
-constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_PAIR2 = NQ + 3, KEY_NONE = NQ + 4;
+constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_PAIR2 = NQ + 3, KEY_STACK = NQ + 4, KEY_NONE = NQ + 5;
 
 struct DevBuf {
     void *p = nullptr;
@@ -89,6 +90,7 @@ struct CallCounters {
     unsigned int n_snp, n_snp_done;        // two-path bubbles of equal length: candidates for / takers of the single-SNP shortcut
     unsigned int n_pair, n_pair_done;      // two short paths: K-PAIR's list / the bubbles it finished
     unsigned int n_pair2, n_pair2_done;    // two paths of up to 128 bases: the list of K-PAIR's second tier
+    unsigned int n_stack, n_stack_done;    // paths of one length: K-STACK's list / the bubbles whose alignment it certified
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
@@ -120,7 +122,7 @@ struct CallState {
     uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
     // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
+    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, klist, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
     // what pf_call_align leaves resident for pf_call_text_range: two sets ("lanes"), so that the rows of one range of bubbles
     // can be formatted, fetched and written while the next range is aligned into the other set
     struct AlignOut {
@@ -147,7 +149,7 @@ struct CallState {
     bool mt_format = false;   // pf_call_set_format
     void release_all() {
         DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &pair_scr, &pair_scr2, &has, &sizes, &offs,
+                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &pair_scr, &pair_scr2, &has, &sizes, &offs,
                          &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
         for (AlignOut &o : lane)
@@ -373,7 +375,7 @@ __global__ void k_call_resolve(ResolveArgs a) {
 // nowhere): one atomic per key and wave
 struct CallLists {
     uint32_t *queues;   // NQ lists of nb entries
-    uint32_t *blist, *slist, *plist, *plist2;
+    uint32_t *blist, *slist, *plist, *plist2, *klist;
     uint32_t nb;
 };
 __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, CallCounters *cnt) {
@@ -386,7 +388,7 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
         const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
         if (lane_id() == leader)
-            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : (x == KEY_PAIR ? &cnt->n_pair : &cnt->n_pair2))),
+            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : (x == KEY_PAIR ? &cnt->n_pair : (x == KEY_PAIR2 ? &cnt->n_pair2 : &cnt->n_stack)))),
                              (unsigned int)__popcll(m));
         base = __shfl(base, leader, WAVE);
         if (key == x) {
@@ -395,7 +397,8 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
             else if (x == KEY_BRANCHING) L.blist[at] = val;
             else if (x == KEY_SNP) L.slist[at] = val;
             else if (x == KEY_PAIR) L.plist[at] = val;
-            else L.plist2[at] = val;
+            else if (x == KEY_PAIR2) L.plist2[at] = val;
+            else L.klist[at] = val;
         }
     }
 }
@@ -414,6 +417,7 @@ struct PrepArgs {
     CallLists lists;   // work queues; branching bubbles; single-SNP candidates; two short paths (batch-local indices)
     int snp_ok;        // the scores allow the single-SNP shortcut
     int pair_ok;       // K-PAIR runs
+    int stack_ok;      // K-STACK runs
     CallCounters *cnt;
 };
 
@@ -444,6 +448,7 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
                 retry = job_bytes(sum < 60000u ? sum : 60000u, lmax);
                 // two paths of one length: K-SNP looks at them first (thread per bubble) and hands on what is not a single SNP;
                 // two short paths of any kind: K-PAIR (thread per bubble)
+                if (t.n_inner > 2 && a.stack_ok && sum == t.n_inner * l0 && l0 <= STACK_MAX) key = KEY_STACK;   // one length: K-STACK first
                 if (t.n_inner == 2) {
                     const uint32_t l1 = sum - l0;
                     if (a.snp_ok && sum == 2 * l0) key = KEY_SNP;
@@ -765,6 +770,164 @@ __global__ __launch_bounds__(64, NMAX == 64 ? 3 : 2) void k_call_pair(PairArgs a
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// K-STACK (pf_stack_dev.hpp): bubbles whose paths are all of one length -- the alignment is the paths stacked once every
+// needlemanWunch(path 0, path p) is certified to have the diagonal as its single optimal path; one thread per bubble
+struct StackArgs {
+    const uint32_t *list;
+    const pf_bubble_task *btask;
+    const pf_bubble_path *bpath;
+    const char *ptext;          // path text of the branching bubbles (K-PATHS)
+    const uint64_t *seq, *off;
+    const uint32_t *len;
+    int M, D, G;
+    pf_bubble_result *res;
+    char *otext;
+    uint64_t text_cap;
+    pf_bubble_site *osites;
+    uint64_t site_cap;
+    uint8_t *ogroups;
+    uint64_t group_cap;
+    unsigned long long *heads;  // [0] text, [1] sites, [2] groups, [3] ilen
+    CallLists lists;
+    CallCounters *cnt;
+};
+
+__device__ inline void stack_load(const StackArgs &a, const pf_bubble_path &pp, StackPlanes &P) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) P.lo[w] = P.hi[w] = 0;
+    if (pp.ov != NONE) {
+        const uint64_t *w = a.seq + a.off[pp.ov >> 1];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+            if (32u * c < pp.len) pair_planes(oriented_chunk(w, pp.len, (pp.ov & 1) != 0, (uint32_t)c), P.lo[c], P.hi[c]);
+    } else {
+        const char *s = a.ptext + pp.text_off;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            uint32_t lo = 0, hi = 0;
+            const uint32_t e = 32u * c < pp.len ? (pp.len - 32u * c < 32u ? pp.len - 32u * c : 32u) : 0u;
+            for (uint32_t q = 0; q < e; ++q) {
+                const uint32_t x = ((uint32_t)(unsigned char)s[32 * c + q] >> 1) & 3u;   // A 0, C 1, T 2, G 3
+                const uint32_t code = x ^ (x >> 1);                                       // A 0, C 1, G 2, T 3
+                lo |= (code & 1u) << q;
+                hi |= (code >> 1) << q;
+            }
+            P.lo[c] = lo;
+            P.hi[c] = hi;
+        }
+    }
+}
+
+__device__ inline uint32_t stack_code(const StackPlanes &P, uint32_t c) {
+    uint32_t lo = P.lo[0], hi = P.hi[0];
+#pragma unroll
+    for (int w = 1; w < 4; ++w) { lo = (c >> 5) == (uint32_t)w ? P.lo[w] : lo; hi = (c >> 5) == (uint32_t)w ? P.hi[w] : hi; }
+    return ((lo >> (c & 31)) & 1u) | (((hi >> (c & 31)) & 1u) << 1);
+}
+
+__global__ __launch_bounds__(64) void k_call_stack(StackArgs a) {
+    const int lane = lane_id();
+    const uint32_t n_list = a.cnt->n_stack;
+    for (uint32_t base = blockIdx.x * 64; base < n_list; base += gridDim.x * 64) {
+        const uint32_t i = base + lane;
+        const bool active = i < n_list;
+        uint32_t j = 0, L = 0, n = 0, n_sites = 0;
+        uint64_t first = 0;
+        uint32_t U[4] = {0, 0, 0, 0};   // columns in which some path differs from path 0
+        bool ok = false;
+        if (active) {
+            j = a.list[i];
+            const pf_bubble_task bt = a.btask[j];
+            n = bt.n_paths;
+            first = bt.path_first;
+            const pf_bubble_path p0 = a.bpath[first];
+            L = p0.len;
+            StackPlanes X, Y;
+            stack_load(a, p0, X);
+            ok = true;
+            for (uint32_t p = 1; p < n && ok; ++p) {
+                stack_load(a, a.bpath[first + p], Y);
+                ok = stack_certify(X, Y, L, a.M, a.D, a.G);
+#pragma unroll
+                for (int w = 0; w < 4; ++w) U[w] |= (X.lo[w] ^ Y.lo[w]) | (X.hi[w] ^ Y.hi[w]);
+            }
+            n_sites = __popc(U[0]) + __popc(U[1]) + __popc(U[2]) + __popc(U[3]);
+        }
+        const bool take = active && ok;
+        uint32_t e_text, e_sites, e_groups;
+        const unsigned long long b_text = wave_take(&a.heads[0], take ? n * L : 0, e_text);
+        const unsigned long long b_sites = wave_take(&a.heads[1], take ? n_sites : 0, e_sites);
+        const unsigned long long b_groups = wave_take(&a.heads[2], take ? n * n_sites : 0, e_groups);
+        if (take) {
+            const unsigned long long t_off = b_text + e_text, s_off = b_sites + e_sites, g_off = b_groups + e_groups;
+            pf_bubble_result r;
+            r.rows_off = t_off;
+            r.site_off = s_off;
+            r.group_off = g_off;
+            r.ilen_off = 0;
+            r.n_rows = n;
+            r.n_cols = L;
+            r.n_sites = n_sites;
+            r.n_indel_len = 0;
+            a.res[j] = r;
+            if (t_off + (uint64_t)n * L <= a.text_cap && s_off + n_sites <= a.site_cap && g_off + (uint64_t)n * n_sites <= a.group_cap) {
+                // the rows, and per variant column the bases of all rows
+                for (uint32_t p = 0; p < n; ++p) {
+                    const pf_bubble_path pp = a.bpath[first + p];
+                    StackPlanes Y;
+                    stack_load(a, pp, Y);
+                    char *o = a.otext + t_off + (uint64_t)p * L;
+                    for (uint32_t c = 0; c < L; ++c) o[c] = "ACGT"[stack_code(Y, c)];
+                    // this row's base in every variant column, kept in the group bytes for now
+                    uint32_t q = 0;
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) {
+                        uint32_t m = U[w];
+                        while (m) {
+                            const uint32_t c = 32u * w + (uint32_t)__ffs((int)m) - 1;
+                            m &= m - 1;
+                            a.ogroups[g_off + (uint64_t)q * n + p] = (uint8_t)stack_code(Y, c);
+                            ++q;
+                        }
+                    }
+                }
+                // groups numbered by first appearance over the rows (src/SeqAlign.cpp:59-120), the site records
+                uint32_t q = 0;
+#pragma unroll
+                for (int w = 0; w < 4; ++w) {
+                    uint32_t m = U[w];
+                    while (m) {
+                        const uint32_t c = 32u * w + (uint32_t)__ffs((int)m) - 1;
+                        m &= m - 1;
+                        uint32_t tab = 0, maxnum = 0;   // group of base b in byte b
+                        uint8_t *gp = a.ogroups + g_off + (uint64_t)q * n;
+                        for (uint32_t p = 0; p < n; ++p) {
+                            const uint32_t b = gp[p];
+                            uint32_t gr = (tab >> (8 * b)) & 0xFFu;
+                            if (!gr) { gr = ++maxnum; tab |= gr << (8 * b); }
+                            gp[p] = (uint8_t)gr;
+                        }
+                        pf_bubble_site sr;
+                        sr.col = c;
+                        sr.is_indel = 0;
+                        sr.maxnum = (uint8_t)maxnum;
+                        sr.pad_ = 0;
+                        a.osites[s_off + q] = sr;
+                        ++q;
+                    }
+                }
+            }
+        }
+        const unsigned long long done_m = __ballot(take);
+        if (lane == 0 && done_m) atomicAdd(&a.cnt->n_stack_done, (unsigned int)__popcll(done_m));
+        // not certified: K-BUBBLE's queue of the bubble's size class
+        int key = KEY_NONE;
+        if (active && !ok) key = 2 * bubble_class(L, L) + ((n > 2 || L > 64) ? 0 : 1);
+        wave_append(key, j, a.lists, a.cnt);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // K-PATHS
 struct PathArgs {
     const CallTask *ct;
@@ -785,6 +948,8 @@ struct PathArgs {
     char *text;
     uint64_t text_cap;
     uint32_t *queues;
+    uint32_t *klist;        // K-STACK's list
+    int stack_ok;
     CallCounters *cnt;
 };
 
@@ -931,7 +1096,11 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
         }
         if (lane == 0) {
             a.btask[j] = pf_bubble_task{(uint64_t)4 * a.nb + first, n_paths, 0};
-            if (n_paths >= 2 && fits && text_ok) {
+            if (n_paths >= 2 && fits && text_ok && a.stack_ok && sum == (uint64_t)n_paths * lmax && n_paths <= STACK_PATHS && lmax <= STACK_MAX) {
+                // paths of one length: K-STACK looks at them first (thread per bubble) and hands on what it cannot certify
+                a.klist[atomicAdd(&a.cnt->n_stack, 1u)] = j;
+                atomicMax(&a.cnt->retry_need, (unsigned long long)job_bytes((uint32_t)(sum < 60000 ? sum : 60000), lmax));
+            } else if (n_paths >= 2 && fits && text_ok) {
                 const int c = bubble_class(lmax, lmax);  // sorted by length: the first path is the longest
                 const int key = 2 * c + ((n_paths > 2 || lmax > 64) ? 0 : 1);
                 const uint32_t at = atomicAdd(&a.cnt->q_n[key], 1u);
@@ -2008,11 +2177,14 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     NEED(S->slist, (size_t)nb * 4);
     NEED(S->plist, (size_t)nb * 4);
     NEED(S->plist2, (size_t)nb * 4);
+    NEED(S->klist, (size_t)nb * 4);
     const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
     // K-PAIR: register-bound (the score row of the fill is 65 / 129 registers): 3 / 2 wavefronts per SIMD, the grid loops over its list
     // (scores of sane magnitude only: the fill adds them in ints)
     static const bool pair_env = [] { const char *e = getenv("PF_PAIR_TIER"); return !(e && e[0] == '0'); }();  // measurements
     const bool pair_tier = pair_env && std::fabs(match) < 1e5 && std::fabs(mismatch) < 1e5 && std::fabs(gap) < 1e5;
+    static const bool stack_env = [] { const char *e = getenv("PF_STACK_TIER"); return !(e && e[0] == '0'); }();  // measurements
+    const bool stack_tier = stack_env && stack_scores(match, mismatch, gap);
     const bool pair_integral = match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap);
     const int pair_grid = ctx->n_cu * 12, pair_grid2 = ctx->n_cu * 4;
     if (pair_tier) NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * pair_grid);
@@ -2039,9 +2211,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
         pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = O.res.as<pf_bubble_result>();
-        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), nb};
+        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), S->klist.as<uint32_t>(), nb};
         pa.snp_ok = snp_ok;
         pa.pair_ok = pair_tier ? 1 : 0;
+        pa.stack_ok = stack_tier ? 1 : 0;
         pa.cnt = d_cnt;
         ctx_begin(ctx, PF_K_CALL_PREP);
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
@@ -2065,6 +2238,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
             ph.scratch_per_wave = paths_per_wave; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
             ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
+            ph.klist = pa.lists.klist; ph.stack_ok = pa.stack_ok;
             ctx_begin_on(ctx, PF_K_CALL_PATHS, pst);
             k_call_paths<<<paths_grid, 64, 0, pst>>>(ph);
             ctx_end_on(ctx, pst);
@@ -2109,6 +2283,18 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             }
         }
         if (fork_paths) PF_HIP(hipStreamWaitEvent(st, S->ev_paths, 0));
+        if (stack_tier) {
+            // K-STACK: behind K-PREP (strict bubbles of three and four equally long paths) and K-PATHS (branching ones)
+            StackArgs sk;
+            sk.list = pa.lists.klist; sk.btask = pa.btask; sk.bpath = pa.bpath; sk.ptext = S->ptext.as<char>();
+            sk.seq = ctx->d_seq; sk.off = ctx->d_off; sk.len = ctx->d_len;
+            sk.M = (int)match; sk.D = (int)mismatch; sk.G = (int)gap;
+            sk.res = pa.res; sk.otext = O.otext.as<char>(); sk.text_cap = cap_text; sk.osites = O.osites.as<pf_bubble_site>(); sk.site_cap = cap_sites;
+            sk.ogroups = O.ogroups.as<uint8_t>(); sk.group_cap = cap_groups; sk.heads = d_heads; sk.lists = pa.lists; sk.cnt = d_cnt;
+            ctx_begin(ctx, PF_K_CALL_STACK);
+            k_call_stack<<<ctx->n_cu * 8, 64, 0, st>>>(sk);
+            ctx_end(ctx);
+        }
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
@@ -2136,6 +2322,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         ctx_units(ctx, PF_K_CALL_PREP, nb);
         if (snp_ok) ctx_units(ctx, PF_K_CALL_SNP, hc.n_snp);
         if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair + hc.n_pair2);
+        if (stack_tier) ctx_units(ctx, PF_K_CALL_STACK, hc.n_stack);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (hc.err & 33u) {
             // (the per-wave tables of K-PATHS / K-SITES and K-BUBBLE's standard tier hold 256 rows; the reference has no such limit)
@@ -2204,8 +2391,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         break;
     }
     out->n_branching = hc.n_branching;
-    out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done + hc.n_pair2_done;
-    out->snp_jobs = hc.n_snp_done; out->pair_jobs = hc.n_pair_done + hc.n_pair2_done; out->wave_jobs = n_jobs;
+    out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done + hc.n_pair2_done + hc.n_stack_done;
+    out->snp_jobs = hc.n_snp_done; out->pair_jobs = hc.n_pair_done + hc.n_pair2_done; out->wave_jobs = n_jobs; out->stack_jobs = hc.n_stack_done;
 
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);

@@ -367,7 +367,7 @@ def check_pipeline(tmp, gfa, db, z=8, lower=5, upper=1000, scores=(2.0, -1.0, -3
     bad = compare_outputs(want_dir, got_dir)
     assert not bad, bad
     t = run.times()
-    stats.update(snp_jobs=t["snp_jobs"], pair_jobs=t["pair_jobs"], wave_jobs=t["wave_jobs"])
+    stats.update(snp_jobs=t["snp_jobs"], pair_jobs=t["pair_jobs"], wave_jobs=t["wave_jobs"], stack_jobs=t["stack_jobs"])
     run.close()
     o.close()
     return stats
@@ -415,7 +415,7 @@ def test_two_path_bubbles_kernel_by_kernel(two_path_graph, second_pair_tier):
     # all three alignment kernels took their share: single mismatches (K-SNP), short pairs with one best alignment (K-PAIR),
     # co-optimal ties and long paths (K-BUBBLE)
     assert s["snp_jobs"] >= 300 and s["pair_jobs"] >= 300 and s["wave_jobs"] >= 100, s
-    assert s["snp_jobs"] + s["pair_jobs"] + s["wave_jobs"] == s["bubbles"], s
+    assert s["snp_jobs"] + s["pair_jobs"] + s["wave_jobs"] + s["stack_jobs"] == s["bubbles"], s
     # the long insertions are aligned by K-PAIR's second tier, not by K-BUBBLE: what is left there are the ties
     assert s["wave_jobs"] < s["gt64"] + s["two_path"] // 4 and s["pair_jobs"] >= s["gt64"] // 2, s
 
@@ -438,7 +438,7 @@ def test_two_path_bubbles_under_other_scores(two_path_graph, scores, second_pair
 
 
 def test_multi_path_bubbles_kernel_by_kernel(multi_path_graphs):
-    tot = dict(multi_path=0, strict_multi=0, branching=0, site_checks=0, indel_sites=0, max_paths=0)
+    tot = dict(multi_path=0, strict_multi=0, branching=0, site_checks=0, indel_sites=0, max_paths=0, stack_jobs=0, wave_jobs=0)
     for sub, gfa, db in multi_path_graphs:
         for scores in ((2.0, -1.0, -3.0), (1.5, -0.5, -2.25)):
             s = check_pipeline(sub, gfa, db, z=16, scores=scores)
@@ -446,6 +446,8 @@ def test_multi_path_bubbles_kernel_by_kernel(multi_path_graphs):
                 tot[k_] = max(tot[k_], s[k_]) if k_ == "max_paths" else tot[k_] + s[k_]
     assert tot["multi_path"] >= 500 and tot["strict_multi"] >= 100 and tot["branching"] >= 400, tot
     assert tot["site_checks"] >= 500 and tot["indel_sites"] >= 100 and tot["max_paths"] >= 6, tot
+    # K-STACK (paths of one length, alignment certified to be the paths stacked) and K-BUBBLE (the rest) both took bubbles
+    assert tot["stack_jobs"] >= 100 and tot["wave_jobs"] >= 100, tot
 
 
 def test_paths_and_sites_of_hex30k(tmp_path):
