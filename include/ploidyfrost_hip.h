@@ -58,7 +58,7 @@ int pf_synchronize(pf_ctx *);
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
     PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN,
-    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_BFS_THREAD, PF_K_CALL_PAIR, PF_K_CALL_STACK, PF_K_COUNT_
+    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_BFS_THREAD, PF_K_CALL_PAIR, PF_K_CALL_STACK, PF_K_CALL_TRIO, PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
@@ -349,6 +349,7 @@ typedef struct pf_call_result {
     uint64_t align_jobs, site_strings, n_branching;
     uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: finished by K-SNP, by K-PAIR, sent to K-BUBBLE */
     uint64_t stack_jobs;                     /* ... finished by K-STACK (paths of one length, alignment = the paths stacked) */
+    uint64_t trio_jobs;                      /* ... finished by K-TRIO (3-8 short paths, every round one alignment that leaves row 0 alone) */
 } pf_call_result;
 #define PF_CALL_SLABS 4 /* text slabs of a context: a slab is free again once pf_call_fetch has copied it */
 /* Bubbles [t0, t1) of the selection (at most 2^24): everything up to the text of the ten streams, left in slab 0 .. 3 of the

@@ -58,7 +58,7 @@ constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_STRICT_M = 0x08, B_STRICT_P =
 constexpr int N_STREAMS = PF_CALL_STREAMS;
 // work lists of a batch: K-BUBBLE's queues (heavy and light per size class), then the three lists of the other kernels
 constexpr int NQ = 2 * (kBubLdsClasses + 1);
-constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_PAIR2 = NQ + 3, KEY_STACK = NQ + 4, KEY_NONE = NQ + 5;
+constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_PAIR2 = NQ + 3, KEY_STACK = NQ + 4, KEY_TRIO = NQ + 5, KEY_TRIO4 = NQ + 6, KEY_NONE = NQ + 7;
 
 struct DevBuf {
     void *p = nullptr;
@@ -91,6 +91,7 @@ struct CallCounters {
     unsigned int n_pair, n_pair_done;      // two short paths: K-PAIR's list / the bubbles it finished
     unsigned int n_pair2, n_pair2_done;    // two paths of up to 128 bases: the list of K-PAIR's second tier
     unsigned int n_stack, n_stack_done;    // paths of one length: K-STACK's list / the bubbles whose alignment it certified
+    unsigned int n_trio, n_trio4, n_trio_done;   // three / four short paths: K-TRIO's lists / the bubbles it finished
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
@@ -122,7 +123,7 @@ struct CallState {
     uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
     // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, klist, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
+    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, klist, tlist, tlist4, trio_scr, trio_rows, trio_ok, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
     // what pf_call_align leaves resident for pf_call_text_range: two sets ("lanes"), so that the rows of one range of bubbles
     // can be formatted, fetched and written while the next range is aligned into the other set
     struct AlignOut {
@@ -149,7 +150,7 @@ struct CallState {
     bool mt_format = false;   // pf_call_set_format
     void release_all() {
         DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &pair_scr, &pair_scr2, &has, &sizes, &offs,
+                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &tlist, &tlist4, &trio_scr, &trio_rows, &trio_ok, &pair_scr, &pair_scr2, &has, &sizes, &offs,
                          &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
         for (AlignOut &o : lane)
@@ -375,7 +376,7 @@ __global__ void k_call_resolve(ResolveArgs a) {
 // nowhere): one atomic per key and wave
 struct CallLists {
     uint32_t *queues;   // NQ lists of nb entries
-    uint32_t *blist, *slist, *plist, *plist2, *klist;
+    uint32_t *blist, *slist, *plist, *plist2, *klist, *tlist, *tlist4;
     uint32_t nb;
 };
 __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, CallCounters *cnt) {
@@ -388,7 +389,7 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
         const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
         if (lane_id() == leader)
-            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : (x == KEY_PAIR ? &cnt->n_pair : (x == KEY_PAIR2 ? &cnt->n_pair2 : &cnt->n_stack)))),
+            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : (x == KEY_PAIR ? &cnt->n_pair : (x == KEY_PAIR2 ? &cnt->n_pair2 : (x == KEY_STACK ? &cnt->n_stack : (x == KEY_TRIO ? &cnt->n_trio : &cnt->n_trio4)))))),
                              (unsigned int)__popcll(m));
         base = __shfl(base, leader, WAVE);
         if (key == x) {
@@ -398,7 +399,9 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
             else if (x == KEY_SNP) L.slist[at] = val;
             else if (x == KEY_PAIR) L.plist[at] = val;
             else if (x == KEY_PAIR2) L.plist2[at] = val;
-            else L.klist[at] = val;
+            else if (x == KEY_STACK) L.klist[at] = val;
+            else if (x == KEY_TRIO) L.tlist[at] = val;
+            else L.tlist4[at] = val;
         }
     }
 }
@@ -418,6 +421,7 @@ struct PrepArgs {
     int snp_ok;        // the scores allow the single-SNP shortcut
     int pair_ok;       // K-PAIR runs
     int stack_ok;      // K-STACK runs
+    int trio_ok;       // K-TRIO runs
     CallCounters *cnt;
 };
 
@@ -432,12 +436,13 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
         z.n_rows = z.n_cols = z.n_sites = z.n_indel_len = 0;
         a.res[j] = z;
         if (t.strict) {
-            uint32_t l0 = 0, lmax = 0, sum = 0;
+            uint32_t l0 = 0, lmax = 0, lmin = 0xFFFFFFFFu, sum = 0;
             for (int q = 0; q < t.n_inner; ++q) {
                 const uint32_t L = a.len[t.inner[q] >> 1];
                 a.bpath[(size_t)4 * j + q] = pf_bubble_path{0, L, t.inner[q]};
                 if (q == 0) l0 = L;
                 lmax = L > lmax ? L : lmax;
+                lmin = L < lmin ? L : lmin;
                 sum += L;
             }
             a.btask[j] = pf_bubble_task{(uint64_t)4 * j, t.n_inner, 0};
@@ -449,6 +454,7 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
                 // two paths of one length: K-SNP looks at them first (thread per bubble) and hands on what is not a single SNP;
                 // two short paths of any kind: K-PAIR (thread per bubble)
                 if (t.n_inner > 2 && a.stack_ok && sum == t.n_inner * l0 && l0 <= STACK_MAX) key = KEY_STACK;   // one length: K-STACK first
+                else if (t.n_inner > 2 && a.trio_ok && lmax <= TRIO_MAX && lmax - lmin <= (uint32_t)PairGeom<TRIO_MAX>::MAX_SKEW) key = t.n_inner == 3 ? KEY_TRIO : KEY_TRIO4;
                 if (t.n_inner == 2) {
                     const uint32_t l1 = sum - l0;
                     if (a.snp_ok && sum == 2 * l0) key = KEY_SNP;
@@ -789,6 +795,7 @@ struct StackArgs {
     uint64_t group_cap;
     unsigned long long *heads;  // [0] text, [1] sites, [2] groups, [3] ilen
     CallLists lists;
+    int trio_ok;                // what is not certified goes to K-TRIO when it qualifies
     CallCounters *cnt;
 };
 
@@ -922,9 +929,224 @@ __global__ __launch_bounds__(64) void k_call_stack(StackArgs a) {
         if (lane == 0 && done_m) atomicAdd(&a.cnt->n_stack_done, (unsigned int)__popcll(done_m));
         // not certified: K-BUBBLE's queue of the bubble's size class
         int key = KEY_NONE;
-        if (active && !ok) key = 2 * bubble_class(L, L) + ((n > 2 || L > 64) ? 0 : 1);
+        if (active && !ok) key = (a.trio_ok && (n == 3 || n == 4) && L <= TRIO_MAX) ? (n == 3 ? KEY_TRIO : KEY_TRIO4) : 2 * bubble_class(L, L) + ((n > 2 || L > 64) ? 0 : 1);
         wave_append(key, j, a.lists, a.cnt);
     }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// K-TRIO: SeqAlign::SequenceAlignment (src/SeqAlign.cpp:550-640) for a bubble of three or four short paths -- when every round of
+// the progressive alignment keeps ONE alignment that leaves row 0 as it is.  The paths of a branching bubble are sorted by
+// descending length, so path 0 is the longest; a later path that differs from it by substitutions and a deletion aligns to it
+// with gaps in its own row only.  Then round p is needlemanWunch(path 0, path p) of two gap-free strings, its one candidate
+// re-opens no gap in the older rows, and the last round's one alignment is what compareStrPair (:8-236) receives: row 0 = path 0,
+// row p = path p with its gaps.  Two kernels: K-TRIO-ALIGN, one THREAD per (bubble, path p >= 1) -- K-STACK's certificate when the
+// two are equally long, else K-PAIR's fill and single-path traceback (pf_pair_dev.hpp); every lane of a wavefront has one fill
+// to do, where a thread per bubble ran its rounds one after the other with the wavefront waiting for its longest lane --, and
+// K-TRIO-FINISH, one thread per bubble: the column pass (:56-157) and the allele groups over the rows the first kernel left, or,
+// when a round had several optimal paths, a gap in row 0, or a walk outside K-PAIR's band, the bubble's place in K-BUBBLE's queues.
+constexpr uint32_t TRIO_ROW = TRIO_MAX;   // bytes of one row in the rows buffer
+
+struct TrioArgs {
+    const uint32_t *list;       // bubbles of NP paths ...
+    uint32_t n_list;            // ... and how many (the host read the counter)
+    const pf_bubble_task *btask;
+    const pf_bubble_path *bpath;
+    const char *ptext;
+    const uint64_t *seq, *off;
+    const uint32_t *len;
+    int M, D, G;
+    uint8_t *scratch;           // PairGeom<TRIO_MAX>::scratch_bytes per wavefront of the align grid
+    char *rows;                 // n_list * NP rows of TRIO_ROW bytes: slot i of the list, row p
+    uint8_t *okflag;            // n_list flags, preset to 1: a round that this tier cannot decide clears its bubble's
+    pf_bubble_result *res;
+    char *otext;
+    uint64_t text_cap;
+    pf_bubble_site *osites;
+    uint64_t site_cap;
+    uint8_t *ogroups;
+    uint64_t group_cap;
+    uint32_t *oilen;
+    uint64_t ilen_cap;
+    unsigned long long *heads;
+    CallLists lists;
+    CallCounters *cnt;
+};
+
+template <int NA>
+__device__ inline void trio_load(const TrioArgs &a, const pf_bubble_path &pp, uint64_t (&W)[NA]) {
+    if (pp.ov != NONE) {
+        const uint64_t *w = a.seq + a.off[pp.ov >> 1];
+#pragma unroll
+        for (int c = 0; c < NA; ++c) W[c] = 32u * c < pp.len ? oriented_chunk(w, pp.len, (pp.ov & 1) != 0, (uint32_t)c) : 0;
+    } else {
+        const char *s = a.ptext + pp.text_off;
+#pragma unroll
+        for (int c = 0; c < NA; ++c) {
+            uint64_t x = 0;
+            const uint32_t e = 32u * c < pp.len ? (pp.len - 32u * c < 32u ? pp.len - 32u * c : 32u) : 0u;
+            for (uint32_t q = 0; q < e; ++q) {
+                const uint32_t y = ((uint32_t)(unsigned char)s[32 * c + q] >> 1) & 3u;   // A 0, C 1, T 2, G 3
+                x |= (uint64_t)(y ^ (y >> 1)) << (62 - 2 * q);                            // A 0, C 1, G 2, T 3
+            }
+            W[c] = x;
+        }
+    }
+}
+
+template <int NP>
+__global__ __launch_bounds__(64, 2) void k_call_trio_align(TrioArgs a) {
+    using Gm = PairGeom<TRIO_MAX>;
+    const int lane = lane_id();
+    PairMem mem;
+    uint8_t *g = a.scratch + (uint64_t)blockIdx.x * Gm::scratch_bytes;
+    mem.dir = reinterpret_cast<uint32_t *>(g) + lane;
+    mem.ra = reinterpret_cast<char *>(g + Gm::dir_bytes) + lane;
+    mem.rb = mem.ra + 64ull * Gm::LEN;
+    mem.fa = mem.rb + 64ull * Gm::LEN;
+    mem.fb = mem.fa + 64ull * Gm::LEN;
+    const uint32_t n_pairs = a.n_list * (NP - 1);
+    for (uint32_t base = blockIdx.x * 64; base < n_pairs; base += gridDim.x * 64) {
+        const uint32_t t = base + lane;
+        if (t >= n_pairs) continue;
+        const uint32_t slot = t / (NP - 1), p = 1 + t % (NP - 1);
+        const uint32_t j = a.list[slot];
+        const uint64_t first = a.btask[j].path_first;
+        const pf_bubble_path p0 = a.bpath[first], pp = a.bpath[first + p];
+        const uint32_t m = p0.len, n = pp.len;
+        uint64_t Aw[Gm::NA], Bw[Gm::NA];
+        trio_load<Gm::NA>(a, p0, Aw);
+        trio_load<Gm::NA>(a, pp, Bw);
+        StackPlanes X, Y;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) X.lo[w] = X.hi[w] = Y.lo[w] = Y.hi[w] = 0;
+#pragma unroll
+        for (int c = 0; c < Gm::NA; ++c) { pair_planes(Aw[c], X.lo[c], X.hi[c]); pair_planes(Bw[c], Y.lo[c], Y.hi[c]); }
+        char *row = a.rows + ((size_t)slot * NP + p) * TRIO_ROW;
+        if (p == 1) {   // row 0 is path 0 itself
+            char *r0 = a.rows + (size_t)slot * NP * TRIO_ROW;
+            for (uint32_t c = 0; c < m; ++c) r0[c] = pair_base<TRIO_MAX>(Aw, c);
+        }
+        if (n == m && stack_certify(X, Y, m, a.M, a.D, a.G)) {
+            for (uint32_t c = 0; c < m; ++c) row[c] = pair_base<TRIO_MAX>(Bw, c);
+            continue;
+        }
+        const int dmin = n < m ? (int)n - (int)m : 0;
+        uint32_t b0[Gm::NA], b1[Gm::NA];
+#pragma unroll
+        for (int c = 0; c < Gm::NA; ++c) { b0[c] = Y.lo[c]; b1[c] = Y.hi[c]; }
+        pair_fill<TRIO_MAX, true>(mem.dir, Aw, b0, b1, m, dmin, 0.0, 0.0, 0.0, a.M, a.D, a.G);
+        const uint32_t L = pair_traceback<TRIO_MAX>(mem, Aw, Bw, m, n, dmin);
+        if (L != m) { a.okflag[slot] = 0; continue; }   // several optimal paths / outside the band (0), or a gap in row 0 (longer than m)
+        for (uint32_t c = 0; c < m; ++c) row[c] = PF_AT(mem.fb, c);
+    }
+}
+
+// The column pass over R rows of length L (row r at rows + r * TRIO_ROW), src/SeqAlign.cpp:56-157 as K-BUBBLE's classify + publish
+// restate it: which columns are sites, which of them open an indel, the allele groups by first appearance over the rows, the
+// indel lengths.  Counted, or with EMIT written out.
+struct TrioCounts {
+    uint32_t n_sites, n_ilen;
+};
+template <bool EMIT>
+__device__ inline TrioCounts trio_classify(const char *rows, uint32_t R, uint32_t L, pf_bubble_site *sites, uint8_t *groups, uint32_t *ilen) {
+    uint32_t ns = 0, nl = 0, last_indel_pos = 0;
+    bool open = false;
+    uint32_t prev_gap = 0;   // bit r: row r had a gap in the previous column
+    for (uint32_t j = 0; j < L; ++j) {
+        uint32_t seen = 0, n_seen = 0, gap = 0;   // `seen`: one bit per character class (A C G T -)
+        for (uint32_t r = 0; r < R; ++r) {
+            const char c = rows[(size_t)r * TRIO_ROW + j];
+            const uint32_t cls = c == '-' ? 4u : (((uint32_t)(unsigned char)c >> 1) & 3u);
+            if (!((seen >> cls) & 1u)) { seen |= 1u << cls; ++n_seen; }
+            gap |= (c == '-' ? 1u : 0u) << r;
+        }
+        const bool same_status = j > 0 && gap == prev_gap;
+        const int t = n_seen > 1 ? (gap ? 2 : 1) : 0;
+        bool site = false, opens = false;
+        if (t != 2) {
+            if (open) { if (EMIT) ilen[nl] = j - last_indel_pos; nl++; open = false; }
+            if (t == 1) site = true;
+        } else {
+            const bool same_run = open && same_status;
+            if (open && !same_run) { if (EMIT) ilen[nl] = j - last_indel_pos; nl++; }
+            if (!same_run) { last_indel_pos = j; open = true; site = true; opens = true; }
+            else if (n_seen > 2) site = true;
+        }
+        if (site) {
+            if (EMIT) {
+                uint8_t *grp = groups + (size_t)ns * R;
+                uint32_t tab = 0, next = 0;   // group of character class c in nibble c
+                for (uint32_t r = 0; r < R; ++r) {
+                    const char c = rows[(size_t)r * TRIO_ROW + j];
+                    const uint32_t cls = c == '-' ? 4u : (((uint32_t)(unsigned char)c >> 1) & 3u);
+                    uint32_t gq = (tab >> (4 * cls)) & 15u;
+                    if (!gq) { gq = ++next; tab |= gq << (4 * cls); }
+                    grp[r] = (uint8_t)gq;
+                }
+                pf_bubble_site sr;
+                sr.col = j;
+                sr.is_indel = opens ? 1 : 0;
+                sr.maxnum = (uint8_t)next;
+                sr.pad_ = 0;
+                sites[ns] = sr;
+            }
+            ns++;
+        }
+        prev_gap = gap;
+    }
+    return TrioCounts{ns, nl};
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void k_call_trio_finish(TrioArgs a) {
+    const int lane = lane_id();
+    const uint32_t slot = blockIdx.x * blockDim.x + threadIdx.x;
+    const bool active = slot < a.n_list;
+    uint32_t j = 0, m = 0, n_sites = 0, n_ilen = 0;
+    bool ok = false;
+    const char *rows = a.rows + (size_t)slot * NP * TRIO_ROW;
+    if (active) {
+        j = a.list[slot];
+        m = a.bpath[a.btask[j].path_first].len;
+        ok = a.okflag[slot] != 0;
+        if (ok) {
+            const TrioCounts tc = trio_classify<false>(rows, NP, m, nullptr, nullptr, nullptr);
+            n_sites = tc.n_sites;
+            n_ilen = tc.n_ilen;
+        }
+    }
+    const bool take = active && ok;
+    uint32_t e_text, e_sites, e_groups, e_ilen;
+    const unsigned long long b_text = wave_take(&a.heads[0], take ? NP * m : 0, e_text);
+    const unsigned long long b_sites = wave_take(&a.heads[1], take ? n_sites : 0, e_sites);
+    const unsigned long long b_groups = wave_take(&a.heads[2], take ? NP * n_sites : 0, e_groups);
+    const unsigned long long b_ilen = wave_take(&a.heads[3], take ? n_ilen : 0, e_ilen);
+    if (take) {
+        const unsigned long long t_off = b_text + e_text, s_off = b_sites + e_sites, g_off = b_groups + e_groups, l_off = b_ilen + e_ilen;
+        pf_bubble_result r;
+        r.rows_off = t_off;
+        r.site_off = s_off;
+        r.group_off = g_off;
+        r.ilen_off = l_off;
+        r.n_rows = NP;
+        r.n_cols = m;
+        r.n_sites = n_sites;
+        r.n_indel_len = n_ilen;
+        a.res[j] = r;
+        if (t_off + (uint64_t)NP * m <= a.text_cap && s_off + n_sites <= a.site_cap && g_off + (uint64_t)NP * n_sites <= a.group_cap &&
+            l_off + n_ilen <= a.ilen_cap) {
+            char *o = a.otext + t_off;
+            for (uint32_t p = 0; p < NP; ++p)
+                for (uint32_t c = 0; c < m; ++c) o[(size_t)p * m + c] = rows[(size_t)p * TRIO_ROW + c];
+            (void)trio_classify<true>(rows, NP, m, a.osites + s_off, a.ogroups + g_off, a.oilen + l_off);
+        }
+    }
+    const unsigned long long done_m = __ballot(take);
+    if (lane == 0 && done_m) atomicAdd(&a.cnt->n_trio_done, (unsigned int)__popcll(done_m));
+    int key = KEY_NONE;
+    if (active && !ok) key = 2 * bubble_class(m, m);   // (three paths or more: the class's heavy queue)
+    wave_append(key, j, a.lists, a.cnt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -950,6 +1172,8 @@ struct PathArgs {
     uint32_t *queues;
     uint32_t *klist;        // K-STACK's list
     int stack_ok;
+    uint32_t *tlist, *tlist4;   // K-TRIO's lists (three / four paths)
+    int trio_ok;
     CallCounters *cnt;
 };
 
@@ -1063,11 +1287,12 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
         first = ((unsigned long long)read_lane((uint32_t)(first >> 32), 0) << 32) | read_lane((uint32_t)first, 0);
         const bool fits = first + n_paths <= a.path_cap;
         bool text_ok = true;
-        uint32_t lmax = 0;
+        uint32_t lmax = 0, lmin = 0xFFFFFFFFu;
         uint64_t sum = 0;
         for (uint32_t i = 0; i < n_paths; ++i) {
             const uint32_t L = plen[i];
             lmax = L > lmax ? L : lmax;
+            lmin = L < lmin ? L : lmin;
             sum += L;
             if (poff[i] + L > a.text_cap) text_ok = false;
         }
@@ -1100,6 +1325,13 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
                 // paths of one length: K-STACK looks at them first (thread per bubble) and hands on what it cannot certify
                 a.klist[atomicAdd(&a.cnt->n_stack, 1u)] = j;
                 atomicMax(&a.cnt->retry_need, (unsigned long long)job_bytes((uint32_t)(sum < 60000 ? sum : 60000), lmax));
+            } else if (n_paths >= 3 && fits && text_ok && a.trio_ok && n_paths <= 4 && lmax <= TRIO_MAX &&
+                       lmax - lmin <= (uint32_t)PairGeom<TRIO_MAX>::MAX_SKEW) {
+                // a few short paths: K-TRIO (thread per bubble) aligns each to the first and hands on what needs more than that
+                if (n_paths == 3) a.tlist[atomicAdd(&a.cnt->n_trio, 1u)] = j;
+                else a.tlist4[atomicAdd(&a.cnt->n_trio4, 1u)] = j;
+                atomicMax(&a.cnt->retry_need, (unsigned long long)job_bytes((uint32_t)(sum < 60000 ? sum : 60000), lmax));
+                if (bubble_class(lmax, lmax) == kBubLdsClasses) atomicMax(&a.cnt->max_need, (unsigned long long)bubble_need(lmax, lmax));
             } else if (n_paths >= 2 && fits && text_ok) {
                 const int c = bubble_class(lmax, lmax);  // sorted by length: the first path is the longest
                 const int key = 2 * c + ((n_paths > 2 || lmax > 64) ? 0 : 1);
@@ -2178,6 +2410,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     NEED(S->plist, (size_t)nb * 4);
     NEED(S->plist2, (size_t)nb * 4);
     NEED(S->klist, (size_t)nb * 4);
+    NEED(S->tlist, (size_t)nb * 4);
+    NEED(S->tlist4, (size_t)nb * 4);
     const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
     // K-PAIR: register-bound (the score row of the fill is 65 / 129 registers): 3 / 2 wavefronts per SIMD, the grid loops over its list
     // (scores of sane magnitude only: the fill adds them in ints)
@@ -2185,6 +2419,14 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     const bool pair_tier = pair_env && std::fabs(match) < 1e5 && std::fabs(mismatch) < 1e5 && std::fabs(gap) < 1e5;
     static const bool stack_env = [] { const char *e = getenv("PF_STACK_TIER"); return !(e && e[0] == '0'); }();  // measurements
     const bool stack_tier = stack_env && stack_scores(match, mismatch, gap);
+    // K-TRIO is OFF unless asked for: measured at BASELINE.json's configs[2] (profiles/r3_trio_ab.txt) it takes 24 k of K-BUBBLE's 34 k
+    // bubbles and saves K-BUBBLE 1.0 ms per pass, but costs 3.2 ms itself -- a whole 96 x 70 fill per THREAD is 0.9 ms of dependent
+    // instructions on a wavefront that has the SIMD to itself, whatever the number of bubbles; K-BUBBLE's wavefront per bubble
+    // spreads the same cells over 64 lanes.  Kept (and held to the oracle by tests/test_gpu_call.py) for graphs with enough such
+    // bubbles to fill the device several times over.  PF_TRIO_TIER=1 switches it on (read per call).
+    const bool trio_env = [] { const char *e = getenv("PF_TRIO_TIER"); return e && e[0] == '1'; }();
+    const bool trio_tier = trio_env && stack_tier && pair_tier;
+    const int trio_grid = ctx->n_cu * 8;
     const bool pair_integral = match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap);
     const int pair_grid = ctx->n_cu * 12, pair_grid2 = ctx->n_cu * 4;
     if (pair_tier) NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * pair_grid);
@@ -2211,10 +2453,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
         pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = O.res.as<pf_bubble_result>();
-        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), S->klist.as<uint32_t>(), nb};
+        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), S->klist.as<uint32_t>(), S->tlist.as<uint32_t>(), S->tlist4.as<uint32_t>(), nb};
         pa.snp_ok = snp_ok;
         pa.pair_ok = pair_tier ? 1 : 0;
         pa.stack_ok = stack_tier ? 1 : 0;
+        pa.trio_ok = trio_tier ? 1 : 0;
         pa.cnt = d_cnt;
         ctx_begin(ctx, PF_K_CALL_PREP);
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
@@ -2239,6 +2482,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ph.scratch_per_wave = paths_per_wave; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
             ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
             ph.klist = pa.lists.klist; ph.stack_ok = pa.stack_ok;
+            ph.tlist = pa.lists.tlist; ph.tlist4 = pa.lists.tlist4; ph.trio_ok = pa.trio_ok;
             ctx_begin_on(ctx, PF_K_CALL_PATHS, pst);
             k_call_paths<<<paths_grid, 64, 0, pst>>>(ph);
             ctx_end_on(ctx, pst);
@@ -2291,6 +2535,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sk.M = (int)match; sk.D = (int)mismatch; sk.G = (int)gap;
             sk.res = pa.res; sk.otext = O.otext.as<char>(); sk.text_cap = cap_text; sk.osites = O.osites.as<pf_bubble_site>(); sk.site_cap = cap_sites;
             sk.ogroups = O.ogroups.as<uint8_t>(); sk.group_cap = cap_groups; sk.heads = d_heads; sk.lists = pa.lists; sk.cnt = d_cnt;
+            sk.trio_ok = pa.trio_ok;
             ctx_begin(ctx, PF_K_CALL_STACK);
             k_call_stack<<<ctx->n_cu * 8, 64, 0, st>>>(sk);
             ctx_end(ctx);
@@ -2298,6 +2543,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
+        bool again = false;   // kernels launched once the host knows their lists' lengths: the counters are read once more behind them
         if (pair_tier && hc.n_pair2) {
             // second tier (paths of 65 .. 128 bases, or a longer indel than the first tier's band follows): few on most graphs, so
             // its scratch and its launch wait until the host knows there are any; its rejects join K-BUBBLE's queues
@@ -2315,6 +2561,40 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
                 else k_call_pair<PAIR_MAX2, false><<<g2, 64, 0, st>>>(pr);
                 ctx_end(ctx);
             }
+            again = true;
+        }
+        if (trio_tier && (hc.n_trio || hc.n_trio4)) {
+            // K-TRIO: behind K-PATHS (its lists), K-PREP (strict bubbles of three and four paths) and K-STACK (what that could not
+            // certify): one thread per (bubble, later path) aligns the path to path 0, one thread per bubble finishes
+            const uint64_t n3 = hc.n_trio, n4 = hc.n_trio4, pairs = 2 * n3 + 3 * n4;
+            const int ga = (int)std::min<uint64_t>((pairs + 63) / 64, (uint64_t)trio_grid);
+            NEED(S->trio_scr, PairGeom<TRIO_MAX>::scratch_bytes * ga);
+            NEED(S->trio_rows, (3 * n3 + 4 * n4) * TRIO_ROW);
+            NEED(S->trio_ok, n3 + n4);
+            PF_HIP(hipMemsetAsync(S->trio_ok.p, 1, n3 + n4, st));
+            TrioArgs tr;
+            tr.btask = pa.btask; tr.bpath = pa.bpath; tr.ptext = S->ptext.as<char>();
+            tr.seq = ctx->d_seq; tr.off = ctx->d_off; tr.len = ctx->d_len;
+            tr.M = (int)match; tr.D = (int)mismatch; tr.G = (int)gap;
+            tr.scratch = S->trio_scr.as<uint8_t>();
+            tr.res = pa.res; tr.otext = O.otext.as<char>(); tr.text_cap = cap_text; tr.osites = O.osites.as<pf_bubble_site>(); tr.site_cap = cap_sites;
+            tr.ogroups = O.ogroups.as<uint8_t>(); tr.group_cap = cap_groups; tr.oilen = O.oilen.as<uint32_t>(); tr.ilen_cap = cap_ilen;
+            tr.heads = d_heads; tr.lists = pa.lists; tr.cnt = d_cnt;
+            ctx_begin(ctx, PF_K_CALL_TRIO);
+            if (n3) {
+                tr.list = pa.lists.tlist; tr.n_list = (uint32_t)n3; tr.rows = S->trio_rows.as<char>(); tr.okflag = S->trio_ok.as<uint8_t>();
+                k_call_trio_align<3><<<(int)std::min<uint64_t>((2 * n3 + 63) / 64, (uint64_t)ga), 64, 0, st>>>(tr);
+                k_call_trio_finish<3><<<(unsigned)((n3 + 255) / 256), 256, 0, st>>>(tr);
+            }
+            if (n4) {
+                tr.list = pa.lists.tlist4; tr.n_list = (uint32_t)n4; tr.rows = S->trio_rows.as<char>() + 3 * n3 * TRIO_ROW; tr.okflag = S->trio_ok.as<uint8_t>() + n3;
+                k_call_trio_align<4><<<(int)std::min<uint64_t>((3 * n4 + 63) / 64, (uint64_t)ga), 64, 0, st>>>(tr);
+                k_call_trio_finish<4><<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(tr);
+            }
+            ctx_end(ctx);
+            again = true;
+        }
+        if (again) {
             PF_HIP(hipGetLastError());
             PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
             PF_HIP(hipStreamSynchronize(st));
@@ -2323,6 +2603,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         if (snp_ok) ctx_units(ctx, PF_K_CALL_SNP, hc.n_snp);
         if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair + hc.n_pair2);
         if (stack_tier) ctx_units(ctx, PF_K_CALL_STACK, hc.n_stack);
+        if (trio_tier) ctx_units(ctx, PF_K_CALL_TRIO, hc.n_trio + hc.n_trio4);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (hc.err & 33u) {
             // (the per-wave tables of K-PATHS / K-SITES and K-BUBBLE's standard tier hold 256 rows; the reference has no such limit)
@@ -2391,8 +2672,9 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         break;
     }
     out->n_branching = hc.n_branching;
-    out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done + hc.n_pair2_done + hc.n_stack_done;
+    out->align_jobs = n_jobs + hc.n_snp_done + hc.n_pair_done + hc.n_pair2_done + hc.n_stack_done + hc.n_trio_done;
     out->snp_jobs = hc.n_snp_done; out->pair_jobs = hc.n_pair_done + hc.n_pair2_done; out->wave_jobs = n_jobs; out->stack_jobs = hc.n_stack_done;
+    out->trio_jobs = hc.n_trio_done;
 
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);

@@ -39,7 +39,7 @@ enum : uint32_t { PC_LEFT = 1, PC_DIAG = 2, PC_UP = 4 };
 template <int NMAX>
 struct PairGeom {
     static constexpr int NW = NMAX / 8;                    // dwords of direction codes per matrix row (columns 1 .. NMAX)
-    static constexpr int STRIDE = NMAX == 64 ? 4 : 12;     // dwords of a row kept in scratch
+    static constexpr int STRIDE = NMAX == 128 ? 12 : 4;    // dwords of a row kept in scratch (NMAX = 64, 96: an indel of up to 8 bases)
     static constexpr int NA = NMAX / 32;                   // 64-bit words of a packed path / 32-bit words of a bit plane
     static constexpr uint32_t LEN = 2 * NMAX;              // longest alignment
     // |m - n| the band can follow whatever the alignment of its window to dword boundaries

@@ -32,6 +32,8 @@ namespace pf {
 constexpr uint32_t STACK_MAX = 128;    // longest path
 constexpr uint32_t STACK_PATHS = 16;   // most paths
 constexpr int STACK_W = 3;             // cells of the band on either side of the diagonal
+constexpr uint32_t TRIO_MAX = 96;      // K-TRIO (pf_call.hip): longest path ...
+constexpr uint32_t TRIO_PATHS = 8;     // ... and most paths
 
 // scores under which the bound for the cells beyond the band holds (and the arithmetic is the reference's integer arithmetic)
 inline bool stack_scores(double M, double D, double G) {
@@ -48,13 +50,14 @@ struct StackPlanes {   // a path as two bit planes, base c at bit (c & 31) of wo
 template <int WB, int D>
 __device__ inline uint32_t stack_shifted(const uint32_t (&y)[4]) {
     const uint32_t cur = y[WB];
-    if (D == 0) return cur;
-    if (D > 0) {
+    if constexpr (D == 0) return cur;
+    else if constexpr (D > 0) {
         const uint32_t nxt = WB + 1 < 4 ? y[WB + 1 < 4 ? WB + 1 : 3] : 0u;
         return (cur >> D) | (nxt << (32 - D));
+    } else {
+        const uint32_t prv = WB >= 1 ? y[WB >= 1 ? WB - 1 : 0] : 0u;
+        return (cur << (-D)) | (prv >> (32 + D));
     }
-    const uint32_t prv = WB >= 1 ? y[WB >= 1 ? WB - 1 : 0] : 0u;
-    return (cur << (-D)) | (prv >> (32 + D));
 }
 
 template <int WB, int D>
