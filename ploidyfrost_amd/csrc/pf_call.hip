@@ -1798,6 +1798,9 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
     uint64_t span0[4] = {0, 0, 0, 0};
     uint32_t span_len[4] = {0, 0, 0, 0};
     char *stage[4] = {nullptr, nullptr, nullptr, nullptr};
+    char *cp_dst = nullptr;          // this lane's bubble: where row 0's characters go, where the rows lie, their length and number,
+    const char *cp_src = nullptr;    // and the distance from one row's characters to the next row's in the output
+    uint32_t cp_L = 0, cp_R = 0, cp_step = 0;
     if (W) {
         const size_t stride = (size_t)a.nb + 1;
         const uint32_t w_first = jj & ~63u;
@@ -1843,15 +1846,20 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
             const uint32_t fre_n0[4] = {s_fre[0].n, s_fre[1].n, s_fre[2].n, s_fre[3].n};
             // alignseq: var_count, strict flag, entrance id, exit id, aligned row (src/CDBG.cpp:1259, 1428)
             for (uint32_t p = 0; p < R; ++p) {
+                char *const row_start = s_aln.p;
                 put_uint(s_aln, my_vc);
                 s_aln.put('\t'); s_aln.put(t.strict ? '1' : '0'); s_aln.put('\t');
                 put_uint(s_aln, (uint64_t)t.u + 1);
                 s_aln.put('\t');
                 put_uint(s_aln, (uint64_t)(t.exit_ov >> 1) + 1);
                 s_aln.put('\t');
-                if (W) { for (uint32_t x = 0; x < L; ++x) s_aln.p[x] = rows[(size_t)p * L + x]; s_aln.p += L; }
+                // the aligned row itself is copied by the whole wavefront further down (every row of a bubble has the same prefix, so
+                // row p's characters start p * (prefix + L + 1) behind row 0's): a lane copying its own rows byte by byte touches 64
+                // different lines per load instruction -- the copies were what the write pass waited for
+                if (W) { if (p == 0) { cp_dst = s_aln.p; cp_src = rows; cp_L = L; cp_R = R; } s_aln.p += L; }
                 else s_aln.n += L;
                 s_aln.put('\n');
+                if (W && p == 0) cp_step = (uint32_t)(s_aln.p - row_start);
             }
             core_cov = (unsigned long long)t.core_mean;
             core_num = 1;
@@ -1958,6 +1966,20 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
         }
     }
     if (W) {
+        {   // the aligned rows, bubble after bubble, by all lanes
+            unsigned long long todo = __ballot(cp_R != 0);
+            const int lane = lane_id();
+            while (todo) {
+                const int b = __ffsll((long long)todo) - 1;
+                todo &= todo - 1;
+                const uint32_t Lb = read_lane(cp_L, b), Rb = read_lane(cp_R, b), step = read_lane(cp_step, b);
+                const uint64_t d64 = (uint64_t)(uintptr_t)cp_dst, s64 = (uint64_t)(uintptr_t)cp_src;
+                char *dst = reinterpret_cast<char *>((uintptr_t)(((uint64_t)read_lane((uint32_t)(d64 >> 32), b) << 32) | read_lane((uint32_t)d64, b)));
+                const char *src = reinterpret_cast<const char *>((uintptr_t)(((uint64_t)read_lane((uint32_t)(s64 >> 32), b) << 32) | read_lane((uint32_t)s64, b)));
+                for (uint32_t p = 0; p < Rb; ++p)
+                    for (uint32_t x = (uint32_t)lane; x < Lb; x += WAVE) dst[(size_t)p * step + x] = src[(size_t)p * Lb + x];
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
         const size_t stride = (size_t)a.nb + 1;
