@@ -362,6 +362,11 @@ int pf_call_run(pf_ctx *, int slab, uint64_t t0, uint64_t t1, uint64_t var_count
 int pf_call_align(pf_ctx *, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
                   pf_call_result *out);
 int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *out);
+/* Takes the device buffers pf_call_align(_lane) would take on its first call for ranges of up to n_bubbles bubbles -- to be called
+ * beside the load, so that a one-shot run does not pay its first alignment launch with two dozen allocations.  A hint: sizes that
+ * turn out too small grow in pf_call_align as before.  Needs pf_call_set_state / pf_call_coverage / any other pf_call_* call first
+ * only in that the graph must be resident. */
+int pf_call_reserve(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size);
 /* What pf_call_align(_lane) left resident for the bubbles of its range, before any text is made of it -- the kernel-level view the
  * parity tests hold against SeqAlign::SequenceAlignment (src/SeqAlign.cpp:550-640) bubble by bubble: per bubble its endpoints and,
  * for a strict one, its sorted inner unitigs with their mean coverages (sortSeq_simple, src/CDBG.cpp:482-551); its pf_bubble_result

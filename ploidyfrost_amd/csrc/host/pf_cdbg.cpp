@@ -186,6 +186,14 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
     st_.complex_size = complex_size_;
     st_.g = &g_;
     st_.succ = succ_.data();
+    if (!getenv("PF_NO_PREALLOC") && !colored && resident_) {
+        // the device buffers of the first alignment launch, taken beside what follows the load on the host (the unitig id file):
+        // nothing else calls into the context before findSuperBubble, which waits for this thread.  About a third of the unitigs
+        // end up as called bubbles, aligned in two ranges of whole text pieces.
+        const uint64_t piece = (uint64_t)std::max<size_t>(batch_bubbles_, 1) * 4;
+        const uint64_t est = std::min<uint64_t>(1u << 24, ((uint64_t)(0.17 * (double)N) + piece - 1) / piece * piece);
+        prealloc_call_ = std::thread([this, est] { (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_); });
+    }
     return 0;
 }
 

@@ -10,6 +10,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
 #include <condition_variable>
 #include <cstdio>
 #include <cstring>
@@ -236,6 +237,44 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     if (opener.joinable()) opener.join();
     if (open_failed >= 0) return fail(PF_ERR_ARG, "CDBG:: Open " + files[(size_t)open_failed].name + " file error");
     last_allfre_.clear();
+    // Fresh result files (a one-shot run: every run of the CLI) get their pages NOW, on helper threads, while the device aligns the
+    // first range -- 438 MB of first-touch faults under the writer were half of a first PloidyEstimation at 5 M unitigs.  The sizes
+    // are estimates from the number of bubbles and k (a bubble of two paths of 2k - 1 bases, one site); what they miss is extended
+    // when it is written, what they overshoot is cut off at the end (MappedOut::finish).  Files that already have their pages
+    // (a later pass) are left alone.
+    std::thread prefault0;
+    std::atomic<bool> prefault0_stop{false};   // set once the last piece is in the files: what the estimates overshoot need not be touched
+    struct Prefault0Guard {
+        std::thread &t;
+        std::atomic<bool> &stop;
+        ~Prefault0Guard() { stop.store(true); if (t.joinable()) t.join(); }
+    } prefault0_guard{prefault0, prefault0_stop};
+    if (write_files_ && n_tasks && !getenv("PF_NO_EARLY_PREFAULT")) {
+        const double nbub = 1.1 * (double)n_tasks;
+        const double per_bubble[PF_CALL_STREAMS] = {20, 2.0 * (2 * g_.k + 26), 20, 2, 1, 0, 52, 3, 1, 0};   // (order: pf_call_stream)
+        std::vector<std::pair<int, uint64_t>> fresh;
+        for (int s = 0; s < PF_CALL_STREAMS; ++s) {
+            const uint64_t est = (uint64_t)(per_bubble[s] * nbub);
+            if (est >= (1u << 20) && maps[s].reserve(est) == 0) fresh.push_back({s, est});
+        }
+        if (!fresh.empty())
+            prefault0 = std::thread([maps, fresh, T, &prefault0_stop] {
+                constexpr uint64_t STEP = 4u << 20;
+                std::vector<std::pair<int, uint64_t>> spans;   // (stream, offset) in 4 MB steps, files interleaved
+                uint64_t longest = 0;
+                for (auto &f : fresh) longest = std::max(longest, f.second);
+                for (uint64_t at = 0; at < longest; at += STEP)
+                    for (auto &f : fresh)
+                        if (at < f.second) spans.push_back({f.first, at});
+                parallel_chunks(spans.size(), 1, std::max(2u, T), [&](size_t i, size_t, size_t) {
+                    if (prefault0_stop.load(std::memory_order_relaxed)) return;
+                    const int s = spans[i].first;
+                    uint64_t end = spans[i].second + STEP;
+                    for (auto &f : fresh) if (f.first == s) end = std::min(end, f.second);
+                    maps[s].populate(spans[i].second, end);
+                });
+            });
+    }
 
     // ---- pieces: device (this thread) | copy back (fetcher thread) | append to the files (writer thread) ----
     // (PF_BATCH_BUBBLES: tools/fuzz_parity.py drives the CLI through many small pieces and ranges with it)
@@ -502,6 +541,8 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     fetcher.join();
     writer.join();
     if (prefault.joinable()) prefault.join();
+    prefault0_stop.store(true);
+    if (prefault0.joinable()) prefault0.join();
     tp("pipeline done");
     if (rc != PF_OK) {
         // the device layer words the reference's own messages (missing k-mer, site string outside its row)

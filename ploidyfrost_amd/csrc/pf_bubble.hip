@@ -778,6 +778,23 @@ namespace pf {
 // (its result then carries n_rows = 0xFFFFFFFF).
 unsigned long long *bubble_pool_heads(pf_ctx *ctx) { return (unsigned long long *)ctx_ws(ctx, WS_BUB_SMALL, 128); }
 
+// K-BUBBLE's workspaces for batches of up to n_tasks bubbles, ahead of the first launch (pf_call_reserve)
+int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks) {
+    const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
+    const uint64_t per = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
+    if (!ctx_ws(ctx, WS_BUB_SMALL, 128) || !ctx_ws(ctx, WS_BUB_RETRY, (size_t)std::max<uint32_t>(n_tasks, 1) * 4) ||
+        !ctx_ws(ctx, WS_BUB_SCRATCH, per * (uint64_t)ctx->n_cu * 24))
+        return PF_ERR_HIP;
+    if (!ctx->bub_streams[0]) {
+        for (int c = 0; c < kBubLdsClasses; ++c) {
+            PF_HIP(hipStreamCreateWithFlags(&ctx->bub_streams[c], hipStreamNonBlocking));
+            PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[c], hipEventDisableTiming));
+        }
+        PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[kBubLdsClasses], hipEventDisableTiming));
+    }
+    return PF_OK;
+}
+
 int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]) {
     hipStream_t st = ctx->stream;
     uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 128);  // pool heads, retry count, one queue head per launch

@@ -67,5 +67,6 @@ inline bool snp_shortcut_scores(double M, double D, double G) {
 }
 
 int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]);
+int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks);
 
 }  // namespace pf

@@ -2458,7 +2458,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         if (attempt > 5) { pf::CtxErr{ctx} = "pf_call_align: pools do not converge"; return PF_ERR_OVERFLOW; }
         const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 1024);
         const uint64_t text_cap = std::max<uint64_t>(S->text_pool, (uint64_t)nb * 32 + (1u << 16));
-        const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, 160ull * nb + (1u << 16));
+        const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, 256ull * nb + (1u << 16));   // (what a first pass takes: 230 B per bubble at k = 25; learnt afterwards)
         const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, 2ull * nb + 64);
         const uint64_t cap_groups = std::max<uint64_t>(S->ogroups_cap, 4ull * nb + 64);
         const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, nb / 2 + 64);
@@ -2815,6 +2815,46 @@ int pf_call_peek(pf_ctx *ctx, int lane, pf_call_bubble *bubbles, pf_bubble_resul
     if (ilen && O.used[3]) PF_HIP(hipMemcpy(ilen, O.oilen.p, O.used[3] * 4, hipMemcpyDeviceToHost));
     if (sv && O.used[4]) PF_HIP(hipMemcpy(sv, O.sv.p, O.used[4] * 8, hipMemcpyDeviceToHost));
     return PF_OK;
+}
+
+// The buffers pf_call_align_lane asks for on its first call for ranges of up to nb bubbles, taken NOW (a caller does this beside the
+// load): a first pass then starts with its pools in place instead of two dozen hipMallocs, 20 ms at 5 M unitigs.  Sizes are the
+// first-call formulas of pf_call_align_lane; whatever turns out too small there grows as before.
+int pf_call_reserve(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size) {
+    if (!ctx || nb64 == 0) return PF_ERR_ARG;
+    CallState *S = state_of(ctx);
+    PF_HIP(hipSetDevice(ctx->device));
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(nb64, 1u << 24);
+    const char *oom = "pf_call_reserve: out of device memory";
+#define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
+    NEED(S->counters, sizeof(CallCounters));
+    NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
+    NEED(S->queues, (size_t)NQ * nb * 4);
+    for (DevBuf *b : {&S->blist, &S->slist, &S->plist, &S->plist2, &S->klist, &S->tlist, &S->tlist4, &S->has}) NEED(*b, (size_t)nb * 4);
+    const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
+    const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (6ull * depth_cap + 4) * 4) + 255) & ~255ull;
+    NEED(S->paths_scr, paths_per_wave * (uint64_t)(ctx->n_cu * 16));
+    NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * (uint64_t)(ctx->n_cu * 12));
+    NEED(S->bpath, ((size_t)4 * nb + (uint64_t)nb / 2 + 1024) * sizeof(pf_bubble_path));
+    NEED(S->ptext, (uint64_t)nb * 32 + (1u << 16));
+    NEED(S->scan_tmp2, (size_t)nb / 4 * 4 + 4096);
+    for (CallState::AlignOut &O : S->lane) {
+        NEED(O.res, (size_t)nb * sizeof(pf_bubble_result));
+        NEED(O.sv_off, (size_t)nb * 8);
+        NEED(O.vc, (size_t)nb * 4);
+        NEED(O.otext, 256ull * nb + (1u << 16));
+        NEED(O.osites, (2ull * nb + 64) * sizeof(pf_bubble_site));
+        NEED(O.ogroups, 4ull * nb + 64);
+        NEED(O.oilen, ((uint64_t)nb / 2 + 64) * 4);
+        NEED(O.sv, ((uint64_t)nb / 4 + 1024ull * ctx->n_cu * 16 + 1024) * 8);
+    }
+#undef NEED
+    if (!S->side_stream) {
+        PF_HIP(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
+        PF_HIP(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
+        PF_HIP(hipEventCreateWithFlags(&S->ev_paths, hipEventDisableTiming));
+    }
+    return bubble_reserve(ctx, nb);
 }
 
 int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
