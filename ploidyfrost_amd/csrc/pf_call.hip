@@ -90,7 +90,7 @@ struct CallCounters {
     unsigned int n_snp, n_snp_done;        // two-path bubbles of equal length: candidates for / takers of the single-SNP shortcut
     unsigned int n_pair, n_pair_done;      // two short paths: K-PAIR's list / the bubbles it finished
     unsigned int n_pair2, n_pair2_done;    // two paths of up to 128 bases: the list of K-PAIR's second tier
-    unsigned int n_stack, n_stack_done;    // paths of one length: K-STACK's list / the bubbles whose alignment it certified
+    unsigned int n_stack, n_stack_b, n_stack_done;   // K-STACK's lists (strict bubbles; branching ones, filled by K-PATHS) / the bubbles whose alignment it certified
     unsigned int n_trio, n_trio4, n_trio_done;   // three / four short paths: K-TRIO's lists / the bubbles it finished
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
@@ -123,7 +123,7 @@ struct CallState {
     uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
     // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, klist, tlist, tlist4, trio_scr, trio_rows, trio_ok, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
+    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, klist, klist_b, stack_scr, tlist, tlist4, trio_scr, trio_rows, trio_ok, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
     // what pf_call_align leaves resident for pf_call_text_range: two sets ("lanes"), so that the rows of one range of bubbles
     // can be formatted, fetched and written while the next range is aligned into the other set
     struct AlignOut {
@@ -150,7 +150,7 @@ struct CallState {
     bool mt_format = false;   // pf_call_set_format
     void release_all() {
         DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &tlist, &tlist4, &trio_scr, &trio_rows, &trio_ok, &pair_scr, &pair_scr2, &has, &sizes, &offs,
+                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &klist_b, &stack_scr, &tlist, &tlist4, &trio_scr, &trio_rows, &trio_ok, &pair_scr, &pair_scr2, &has, &sizes, &offs,
                          &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
         for (AlignOut &o : lane)
@@ -376,7 +376,7 @@ __global__ void k_call_resolve(ResolveArgs a) {
 // nowhere): one atomic per key and wave
 struct CallLists {
     uint32_t *queues;   // NQ lists of nb entries
-    uint32_t *blist, *slist, *plist, *plist2, *klist, *tlist, *tlist4;
+    uint32_t *blist, *slist, *plist, *plist2, *klist, *klist_b, *tlist, *tlist4;
     uint32_t nb;
 };
 __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, CallCounters *cnt) {
@@ -453,11 +453,13 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
                 retry = job_bytes(sum < 60000u ? sum : 60000u, lmax);
                 // two paths of one length: K-SNP looks at them first (thread per bubble) and hands on what is not a single SNP;
                 // two short paths of any kind: K-PAIR (thread per bubble)
-                if (t.n_inner > 2 && a.stack_ok && sum == t.n_inner * l0 && l0 <= STACK_MAX) key = KEY_STACK;   // one length: K-STACK first
+                // K-STACK first (thread per bubble, a certificate instead of the dynamic programming) for whatever it can hold
+                if (t.n_inner > 2 && a.stack_ok && lmax <= STACK_MAX && (a.stack_ok >= 2 || sum == t.n_inner * l0)) key = KEY_STACK;
                 else if (t.n_inner > 2 && a.trio_ok && lmax <= TRIO_MAX && lmax - lmin <= (uint32_t)PairGeom<TRIO_MAX>::MAX_SKEW) key = t.n_inner == 3 ? KEY_TRIO : KEY_TRIO4;
                 if (t.n_inner == 2) {
                     const uint32_t l1 = sum - l0;
                     if (a.snp_ok && sum == 2 * l0) key = KEY_SNP;
+                    else if (a.stack_ok >= 3 && lmax <= STACK_MAX) key = KEY_STACK;
                     else if (a.pair_ok && pair_fits<PAIR_MAX>(l0, l1)) key = KEY_PAIR;
                     else if (a.pair_ok && pair_fits<PAIR_MAX2>(l0, l1)) key = KEY_PAIR2;
                 }
@@ -505,7 +507,7 @@ struct SnpArgs {
     uint64_t group_cap;
     unsigned long long *heads;  // K-BUBBLE's pool heads: [0] text, [1] sites, [2] groups
     CallLists lists;
-    int pair_ok;
+    int pair_ok, stack_ok;
     CallCounters *cnt;
 };
 
@@ -620,7 +622,7 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
     }
     // the rest: K-PAIR when short, else K-BUBBLE's queue of their size class
     int key = KEY_NONE;
-    if (active && !take) key = (a.pair_ok && m <= PAIR_MAX) ? KEY_PAIR : (a.pair_ok && m <= PAIR_MAX2) ? KEY_PAIR2 : 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
+    if (active && !take) key = (a.stack_ok >= 3 && m <= STACK_MAX) ? KEY_STACK : (a.pair_ok && m <= PAIR_MAX) ? KEY_PAIR : (a.pair_ok && m <= PAIR_MAX2) ? KEY_PAIR2 : 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
     wave_append(key, j, a.lists, a.cnt);
 }
 
@@ -775,11 +777,76 @@ __global__ __launch_bounds__(64, NMAX == 64 ? 3 : 2) void k_call_pair(PairArgs a
     }
 }
 
+// The column pass over R rows of length L (character j of row r at rows[r * row_stride + j * col_stride]), src/SeqAlign.cpp:56-157 as K-BUBBLE's classify + publish
+// restate it: which columns are sites, which of them open an indel, the allele groups by first appearance over the rows, the
+// indel lengths.  Counted, or with EMIT written out.
+struct TrioCounts {
+    uint32_t n_sites, n_ilen;
+};
+template <bool EMIT>
+__device__ inline TrioCounts trio_classify(const char *rows, size_t row_stride, size_t col_stride, uint32_t R, uint32_t L, pf_bubble_site *sites, uint8_t *groups,
+                                           uint32_t *ilen) {
+    uint32_t ns = 0, nl = 0, last_indel_pos = 0;
+    bool open = false;
+    uint32_t prev_gap = 0;   // bit r: row r had a gap in the previous column
+    for (uint32_t j = 0; j < L; ++j) {
+        uint32_t seen = 0, n_seen = 0, gap = 0;   // `seen`: one bit per character class (A C G T -)
+        for (uint32_t r = 0; r < R; ++r) {
+            const char c = rows[(size_t)r * row_stride + (size_t)j * col_stride];
+            const uint32_t cls = c == '-' ? 4u : (((uint32_t)(unsigned char)c >> 1) & 3u);
+            if (!((seen >> cls) & 1u)) { seen |= 1u << cls; ++n_seen; }
+            gap |= (c == '-' ? 1u : 0u) << r;
+        }
+        const bool same_status = j > 0 && gap == prev_gap;
+        const int t = n_seen > 1 ? (gap ? 2 : 1) : 0;
+        bool site = false, opens = false;
+        if (t != 2) {
+            if (open) { if (EMIT) ilen[nl] = j - last_indel_pos; nl++; open = false; }
+            if (t == 1) site = true;
+        } else {
+            const bool same_run = open && same_status;
+            if (open && !same_run) { if (EMIT) ilen[nl] = j - last_indel_pos; nl++; }
+            if (!same_run) { last_indel_pos = j; open = true; site = true; opens = true; }
+            else if (n_seen > 2) site = true;
+        }
+        if (site) {
+            if (EMIT) {
+                uint8_t *grp = groups + (size_t)ns * R;
+                uint32_t tab = 0, next = 0;   // group of character class c in nibble c
+                for (uint32_t r = 0; r < R; ++r) {
+                    const char c = rows[(size_t)r * row_stride + (size_t)j * col_stride];
+                    const uint32_t cls = c == '-' ? 4u : (((uint32_t)(unsigned char)c >> 1) & 3u);
+                    uint32_t gq = (tab >> (4 * cls)) & 15u;
+                    if (!gq) { gq = ++next; tab |= gq << (4 * cls); }
+                    grp[r] = (uint8_t)gq;
+                }
+                pf_bubble_site sr;
+                sr.col = j;
+                sr.is_indel = opens ? 1 : 0;
+                sr.maxnum = (uint8_t)next;
+                sr.pad_ = 0;
+                sites[ns] = sr;
+            }
+            ns++;
+        }
+        prev_gap = gap;
+    }
+    return TrioCounts{ns, nl};
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K-STACK (pf_stack_dev.hpp): bubbles whose paths are all of one length -- the alignment is the paths stacked once every
 // needlemanWunch(path 0, path p) is certified to have the diagonal as its single optimal path; one thread per bubble
+constexpr uint32_t STACK_GAP_ROWS = 8;   // most rows of a bubble whose paths differ in length (its rows go through the wavefront's scratch)
+__host__ __device__ inline uint64_t stack_scratch_bytes() { return (uint64_t)STACK_GAP_ROWS * STACK_MAX * 64; }
+
 struct StackArgs {
     const uint32_t *list;
+    const unsigned int *n_list;   // how many (on the device)
+    uint8_t *scratch;             // stack_scratch_bytes() per wavefront of the grid
+    uint32_t *oilen;
+    uint64_t ilen_cap;
+    int pair_ok;                  // two-path bubbles of the strict list that are not certified go to K-PAIR when they fit it (it runs behind this launch)
     const pf_bubble_task *btask;
     const pf_bubble_path *bpath;
     const char *ptext;          // path text of the branching bubbles (K-PATHS)
@@ -834,50 +901,107 @@ __device__ inline uint32_t stack_code(const StackPlanes &P, uint32_t c) {
 
 __global__ __launch_bounds__(64) void k_call_stack(StackArgs a) {
     const int lane = lane_id();
-    const uint32_t n_list = a.cnt->n_stack;
+    const uint32_t n_list = *a.n_list;
+    char *grows = reinterpret_cast<char *>(a.scratch + (uint64_t)blockIdx.x * stack_scratch_bytes()) + lane;   // rows of a gapped alignment, lane-interleaved
+    constexpr size_t RS = (size_t)STACK_MAX * 64, CS = 64;
     for (uint32_t base = blockIdx.x * 64; base < n_list; base += gridDim.x * 64) {
         const uint32_t i = base + lane;
         const bool active = i < n_list;
-        uint32_t j = 0, L = 0, n = 0, n_sites = 0;
+        uint32_t j = 0, L = 0, n = 0, n_sites = 0, n_ilen = 0, l0 = 0, l1 = 0, lmax = 0;
         uint64_t first = 0;
-        uint32_t U[4] = {0, 0, 0, 0};   // columns in which some path differs from path 0
-        bool ok = false;
+        uint32_t U[4] = {0, 0, 0, 0};   // columns in which some path differs from path 0 (paths of one length)
+        bool ok = false, gapped = false;
         if (active) {
             j = a.list[i];
             const pf_bubble_task bt = a.btask[j];
             n = bt.n_paths;
             first = bt.path_first;
             const pf_bubble_path p0 = a.bpath[first];
-            L = p0.len;
+            l0 = L = lmax = p0.len;
             StackPlanes X, Y;
             stack_load(a, p0, X);
-            ok = true;
-            for (uint32_t p = 1; p < n && ok; ++p) {
-                stack_load(a, a.bpath[first + p], Y);
-                ok = stack_certify(X, Y, L, a.M, a.D, a.G);
-#pragma unroll
-                for (int w = 0; w < 4; ++w) U[w] |= (X.lo[w] ^ Y.lo[w]) | (X.hi[w] ^ Y.hi[w]);
+            // which kind: all paths as long as the first, or some shorter (a gap run in their rows); two paths may also have the
+            // longer one second (strict bubbles are sorted by coverage): then row 0 takes the gaps
+            for (uint32_t p = 1; p < n; ++p) {
+                const uint32_t lp = a.bpath[first + p].len;
+                if (p == 1) l1 = lp;
+                if (lp != L) gapped = true;
+                lmax = lp > lmax ? lp : lmax;
             }
-            n_sites = __popc(U[0]) + __popc(U[1]) + __popc(U[2]) + __popc(U[3]);
+            ok = true;
+            if (!gapped) {
+                for (uint32_t p = 1; p < n && ok; ++p) {
+                    stack_load(a, a.bpath[first + p], Y);
+                    ok = stack_certify(X, Y, L, a.M, a.D, a.G);
+#pragma unroll
+                    for (int w = 0; w < 4; ++w) U[w] |= (X.lo[w] ^ Y.lo[w]) | (X.hi[w] ^ Y.hi[w]);
+                }
+                n_sites = __popc(U[0]) + __popc(U[1]) + __popc(U[2]) + __popc(U[3]);
+            } else if (n > STACK_GAP_ROWS) {
+                ok = false;
+            } else if (n == 2 && l1 > l0) {
+                // the second path is the longer: the same certificate with the roles swapped (the recurrence is symmetric in its
+                // two strings: UP and LEFT change places), and the gap run lies in row 0
+                stack_load(a, a.bpath[first + 1], Y);
+                const uint32_t d = l1 - l0, at = indel_place(Y, X, l0, d);
+                ok = at != 0xFFFFFFFFu && indel_certify(Y, X, l1, l0, at, a.M, a.D, a.G);
+                if (ok) {
+                    L = l1;
+                    for (uint32_t c = 0; c < L; ++c) {
+                        grows[(size_t)c * CS] = (c < at) ? "ACGT"[stack_code(X, c)] : (c < at + d ? '-' : "ACGT"[stack_code(X, c - d)]);
+                        grows[RS + (size_t)c * CS] = "ACGT"[stack_code(Y, c)];
+                    }
+                }
+            } else {
+                for (uint32_t c = 0; c < L; ++c) grows[(size_t)c * CS] = "ACGT"[stack_code(X, c)];
+                for (uint32_t p = 1; p < n && ok; ++p) {
+                    const pf_bubble_path pp = a.bpath[first + p];
+                    stack_load(a, pp, Y);
+                    char *row = grows + (size_t)p * RS;
+                    if (pp.len == L) {
+                        ok = stack_certify(X, Y, L, a.M, a.D, a.G);
+                        if (ok) for (uint32_t c = 0; c < L; ++c) row[(size_t)c * CS] = "ACGT"[stack_code(Y, c)];
+                    } else if (pp.len < L) {
+                        const uint32_t d = L - pp.len, at = indel_place(X, Y, pp.len, d);
+                        ok = at != 0xFFFFFFFFu && indel_certify(X, Y, L, pp.len, at, a.M, a.D, a.G);
+                        if (ok) for (uint32_t c = 0; c < L; ++c) row[(size_t)c * CS] = (c < at) ? "ACGT"[stack_code(Y, c)] : (c < at + d ? '-' : "ACGT"[stack_code(Y, c - d)]);
+                    } else {
+                        ok = false;   // a later path longer than the first: row 0 would take a gap
+                    }
+                }
+            }
+            if (ok && gapped) {
+                const TrioCounts tc = trio_classify<false>(grows, RS, CS, n, L, nullptr, nullptr, nullptr);
+                n_sites = tc.n_sites;
+                n_ilen = tc.n_ilen;
+            }
         }
         const bool take = active && ok;
-        uint32_t e_text, e_sites, e_groups;
+        uint32_t e_text, e_sites, e_groups, e_ilen;
         const unsigned long long b_text = wave_take(&a.heads[0], take ? n * L : 0, e_text);
         const unsigned long long b_sites = wave_take(&a.heads[1], take ? n_sites : 0, e_sites);
         const unsigned long long b_groups = wave_take(&a.heads[2], take ? n * n_sites : 0, e_groups);
+        const unsigned long long b_ilen = wave_take(&a.heads[3], take ? n_ilen : 0, e_ilen);
         if (take) {
-            const unsigned long long t_off = b_text + e_text, s_off = b_sites + e_sites, g_off = b_groups + e_groups;
+            const unsigned long long t_off = b_text + e_text, s_off = b_sites + e_sites, g_off = b_groups + e_groups, l_off = b_ilen + e_ilen;
             pf_bubble_result r;
             r.rows_off = t_off;
             r.site_off = s_off;
             r.group_off = g_off;
-            r.ilen_off = 0;
+            r.ilen_off = l_off;
             r.n_rows = n;
             r.n_cols = L;
             r.n_sites = n_sites;
-            r.n_indel_len = 0;
+            r.n_indel_len = n_ilen;
             a.res[j] = r;
-            if (t_off + (uint64_t)n * L <= a.text_cap && s_off + n_sites <= a.site_cap && g_off + (uint64_t)n * n_sites <= a.group_cap) {
+            const bool room = t_off + (uint64_t)n * L <= a.text_cap && s_off + n_sites <= a.site_cap && g_off + (uint64_t)n * n_sites <= a.group_cap &&
+                              l_off + n_ilen <= a.ilen_cap;
+            if (room && gapped) {
+                char *o = a.otext + t_off;
+                for (uint32_t p = 0; p < n; ++p)
+                    for (uint32_t c = 0; c < L; ++c) o[(size_t)p * L + c] = grows[(size_t)p * RS + (size_t)c * CS];
+                (void)trio_classify<true>(grows, RS, CS, n, L, a.osites + s_off, a.ogroups + g_off, a.oilen + l_off);
+            } else if (room) {
                 // the rows, and per variant column the bases of all rows
                 for (uint32_t p = 0; p < n; ++p) {
                     const pf_bubble_path pp = a.bpath[first + p];
@@ -927,9 +1051,16 @@ __global__ __launch_bounds__(64) void k_call_stack(StackArgs a) {
         }
         const unsigned long long done_m = __ballot(take);
         if (lane == 0 && done_m) atomicAdd(&a.cnt->n_stack_done, (unsigned int)__popcll(done_m));
-        // not certified: K-BUBBLE's queue of the bubble's size class
+        // not certified: two paths to K-PAIR (its fill decides, or finds the tie), the others to K-TRIO when that runs, else K-BUBBLE's
+        // queue of the bubble's size class
         int key = KEY_NONE;
-        if (active && !ok) key = (a.trio_ok && (n == 3 || n == 4) && L <= TRIO_MAX) ? (n == 3 ? KEY_TRIO : KEY_TRIO4) : 2 * bubble_class(L, L) + ((n > 2 || L > 64) ? 0 : 1);
+        if (active && !ok) {
+            if (n == 2 && a.pair_ok && pair_fits<PAIR_MAX>(l0, l1)) key = KEY_PAIR;
+            else if (n == 2 && a.pair_ok && pair_fits<PAIR_MAX2>(l0, l1)) key = KEY_PAIR2;
+            else if (n == 2) key = 2 * bubble_class(l0, lmax) + (lmax > 64 ? 0 : 1);
+            else if (a.trio_ok && (n == 3 || n == 4) && lmax <= TRIO_MAX && !gapped) key = n == 3 ? KEY_TRIO : KEY_TRIO4;
+            else key = 2 * bubble_class(l0, lmax);
+        }
         wave_append(key, j, a.lists, a.cnt);
     }
 }
@@ -1042,62 +1173,6 @@ __global__ __launch_bounds__(64, 2) void k_call_trio_align(TrioArgs a) {
     }
 }
 
-// The column pass over R rows of length L (row r at rows + r * TRIO_ROW), src/SeqAlign.cpp:56-157 as K-BUBBLE's classify + publish
-// restate it: which columns are sites, which of them open an indel, the allele groups by first appearance over the rows, the
-// indel lengths.  Counted, or with EMIT written out.
-struct TrioCounts {
-    uint32_t n_sites, n_ilen;
-};
-template <bool EMIT>
-__device__ inline TrioCounts trio_classify(const char *rows, uint32_t R, uint32_t L, pf_bubble_site *sites, uint8_t *groups, uint32_t *ilen) {
-    uint32_t ns = 0, nl = 0, last_indel_pos = 0;
-    bool open = false;
-    uint32_t prev_gap = 0;   // bit r: row r had a gap in the previous column
-    for (uint32_t j = 0; j < L; ++j) {
-        uint32_t seen = 0, n_seen = 0, gap = 0;   // `seen`: one bit per character class (A C G T -)
-        for (uint32_t r = 0; r < R; ++r) {
-            const char c = rows[(size_t)r * TRIO_ROW + j];
-            const uint32_t cls = c == '-' ? 4u : (((uint32_t)(unsigned char)c >> 1) & 3u);
-            if (!((seen >> cls) & 1u)) { seen |= 1u << cls; ++n_seen; }
-            gap |= (c == '-' ? 1u : 0u) << r;
-        }
-        const bool same_status = j > 0 && gap == prev_gap;
-        const int t = n_seen > 1 ? (gap ? 2 : 1) : 0;
-        bool site = false, opens = false;
-        if (t != 2) {
-            if (open) { if (EMIT) ilen[nl] = j - last_indel_pos; nl++; open = false; }
-            if (t == 1) site = true;
-        } else {
-            const bool same_run = open && same_status;
-            if (open && !same_run) { if (EMIT) ilen[nl] = j - last_indel_pos; nl++; }
-            if (!same_run) { last_indel_pos = j; open = true; site = true; opens = true; }
-            else if (n_seen > 2) site = true;
-        }
-        if (site) {
-            if (EMIT) {
-                uint8_t *grp = groups + (size_t)ns * R;
-                uint32_t tab = 0, next = 0;   // group of character class c in nibble c
-                for (uint32_t r = 0; r < R; ++r) {
-                    const char c = rows[(size_t)r * TRIO_ROW + j];
-                    const uint32_t cls = c == '-' ? 4u : (((uint32_t)(unsigned char)c >> 1) & 3u);
-                    uint32_t gq = (tab >> (4 * cls)) & 15u;
-                    if (!gq) { gq = ++next; tab |= gq << (4 * cls); }
-                    grp[r] = (uint8_t)gq;
-                }
-                pf_bubble_site sr;
-                sr.col = j;
-                sr.is_indel = opens ? 1 : 0;
-                sr.maxnum = (uint8_t)next;
-                sr.pad_ = 0;
-                sites[ns] = sr;
-            }
-            ns++;
-        }
-        prev_gap = gap;
-    }
-    return TrioCounts{ns, nl};
-}
-
 template <int NP>
 __global__ __launch_bounds__(256) void k_call_trio_finish(TrioArgs a) {
     const int lane = lane_id();
@@ -1111,7 +1186,7 @@ __global__ __launch_bounds__(256) void k_call_trio_finish(TrioArgs a) {
         m = a.bpath[a.btask[j].path_first].len;
         ok = a.okflag[slot] != 0;
         if (ok) {
-            const TrioCounts tc = trio_classify<false>(rows, NP, m, nullptr, nullptr, nullptr);
+            const TrioCounts tc = trio_classify<false>(rows, TRIO_ROW, 1, NP, m, nullptr, nullptr, nullptr);
             n_sites = tc.n_sites;
             n_ilen = tc.n_ilen;
         }
@@ -1139,7 +1214,7 @@ __global__ __launch_bounds__(256) void k_call_trio_finish(TrioArgs a) {
             char *o = a.otext + t_off;
             for (uint32_t p = 0; p < NP; ++p)
                 for (uint32_t c = 0; c < m; ++c) o[(size_t)p * m + c] = rows[(size_t)p * TRIO_ROW + c];
-            (void)trio_classify<true>(rows, NP, m, a.osites + s_off, a.ogroups + g_off, a.oilen + l_off);
+            (void)trio_classify<true>(rows, TRIO_ROW, 1, NP, m, a.osites + s_off, a.ogroups + g_off, a.oilen + l_off);
         }
     }
     const unsigned long long done_m = __ballot(take);
@@ -1170,7 +1245,7 @@ struct PathArgs {
     char *text;
     uint64_t text_cap;
     uint32_t *queues;
-    uint32_t *klist;        // K-STACK's list
+    uint32_t *klist;        // K-STACK's list of branching bubbles
     int stack_ok;
     uint32_t *tlist, *tlist4;   // K-TRIO's lists (three / four paths)
     int trio_ok;
@@ -1321,9 +1396,11 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
         }
         if (lane == 0) {
             a.btask[j] = pf_bubble_task{(uint64_t)4 * a.nb + first, n_paths, 0};
-            if (n_paths >= 2 && fits && text_ok && a.stack_ok && sum == (uint64_t)n_paths * lmax && n_paths <= STACK_PATHS && lmax <= STACK_MAX) {
-                // paths of one length: K-STACK looks at them first (thread per bubble) and hands on what it cannot certify
-                a.klist[atomicAdd(&a.cnt->n_stack, 1u)] = j;
+            if (n_paths >= 2 && fits && text_ok && a.stack_ok && lmax <= STACK_MAX &&
+                (sum == (uint64_t)n_paths * lmax ? n_paths <= STACK_PATHS : (a.stack_ok >= 2 && n_paths <= STACK_GAP_ROWS))) {
+                // K-STACK looks at them first (thread per bubble: paths of one length, or shorter than the first by one gap run) and
+                // hands on what it cannot certify
+                a.klist[atomicAdd(&a.cnt->n_stack_b, 1u)] = j;
                 atomicMax(&a.cnt->retry_need, (unsigned long long)job_bytes((uint32_t)(sum < 60000 ? sum : 60000), lmax));
             } else if (n_paths >= 3 && fits && text_ok && a.trio_ok && n_paths <= 4 && lmax <= TRIO_MAX &&
                        lmax - lmin <= (uint32_t)PairGeom<TRIO_MAX>::MAX_SKEW) {
@@ -2432,6 +2509,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     NEED(S->plist, (size_t)nb * 4);
     NEED(S->plist2, (size_t)nb * 4);
     NEED(S->klist, (size_t)nb * 4);
+    NEED(S->klist_b, (size_t)nb * 4);
     NEED(S->tlist, (size_t)nb * 4);
     NEED(S->tlist4, (size_t)nb * 4);
     const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
@@ -2441,6 +2519,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     const bool pair_tier = pair_env && std::fabs(match) < 1e5 && std::fabs(mismatch) < 1e5 && std::fabs(gap) < 1e5;
     static const bool stack_env = [] { const char *e = getenv("PF_STACK_TIER"); return !(e && e[0] == '0'); }();  // measurements
     const bool stack_tier = stack_env && stack_scores(match, mismatch, gap);
+    // what K-STACK is given (read per call: tools/ab_pass.py): 1 = bubbles of three and more paths of one length, 2 = also those whose
+    // later paths are shorter than the first (one gap run each), 3 = also the two-path bubbles ahead of K-PAIR
+    const int stack_level = [] { const char *e = getenv("PF_STACK_LEVEL"); return e ? std::max(1, std::min(3, atoi(e))) : 1; }();
+    const int stack_grid = ctx->n_cu * 8;
+    if (stack_tier) NEED(S->stack_scr, stack_scratch_bytes() * stack_grid);
     // K-TRIO is OFF unless asked for: measured at BASELINE.json's configs[2] (profiles/r3_trio_ab.txt) it takes 24 k of K-BUBBLE's 34 k
     // bubbles and saves K-BUBBLE 1.0 ms per pass, but costs 3.2 ms itself -- a whole 96 x 70 fill per THREAD is 0.9 ms of dependent
     // instructions on a wavefront that has the SIMD to itself, whatever the number of bubbles; K-BUBBLE's wavefront per bubble
@@ -2475,10 +2558,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
         pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = O.res.as<pf_bubble_result>();
-        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), S->klist.as<uint32_t>(), S->tlist.as<uint32_t>(), S->tlist4.as<uint32_t>(), nb};
+        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), S->klist.as<uint32_t>(), S->klist_b.as<uint32_t>(), S->tlist.as<uint32_t>(), S->tlist4.as<uint32_t>(), nb};
         pa.snp_ok = snp_ok;
         pa.pair_ok = pair_tier ? 1 : 0;
-        pa.stack_ok = stack_tier ? 1 : 0;
+        pa.stack_ok = stack_tier ? stack_level : 0;
         pa.trio_ok = trio_tier ? 1 : 0;
         pa.cnt = d_cnt;
         ctx_begin(ctx, PF_K_CALL_PREP);
@@ -2503,7 +2586,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
             ph.scratch_per_wave = paths_per_wave; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
             ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
-            ph.klist = pa.lists.klist; ph.stack_ok = pa.stack_ok;
+            ph.klist = pa.lists.klist_b; ph.stack_ok = pa.stack_ok;
             ph.tlist = pa.lists.tlist; ph.tlist4 = pa.lists.tlist4; ph.trio_ok = pa.trio_ok;
             ctx_begin_on(ctx, PF_K_CALL_PATHS, pst);
             k_call_paths<<<paths_grid, 64, 0, pst>>>(ph);
@@ -2515,9 +2598,25 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sn.ct = pa.ct; sn.kept = pa.kept; sn.t0 = t0; sn.nb = nb; sn.slist = pa.lists.slist; sn.seq = ctx->d_seq; sn.off = ctx->d_off;
             sn.len = ctx->d_len; sn.res = pa.res; sn.otext = O.otext.as<char>(); sn.text_cap = cap_text;
             sn.osites = O.osites.as<pf_bubble_site>(); sn.site_cap = cap_sites; sn.ogroups = O.ogroups.as<uint8_t>(); sn.group_cap = cap_groups;
-            sn.heads = d_heads; sn.lists = pa.lists; sn.pair_ok = pa.pair_ok; sn.cnt = d_cnt;
+            sn.heads = d_heads; sn.lists = pa.lists; sn.pair_ok = pa.pair_ok; sn.stack_ok = pa.stack_ok; sn.cnt = d_cnt;
             ctx_begin(ctx, PF_K_CALL_SNP);
             k_call_snp<<<(nb + 255) / 256, 256, 0, st>>>(sn);   // (the list length is on the device: surplus threads leave at once)
+            ctx_end(ctx);
+        }
+        StackArgs sk;
+        if (stack_tier) {
+            // K-STACK, first launch: the strict bubbles K-PREP and K-SNP listed (two paths that are not a single mismatch, three and
+            // four paths); what it cannot certify is K-PAIR's (launched behind it), K-TRIO's or K-BUBBLE's
+            sk.list = pa.lists.klist; sk.n_list = &d_cnt->n_stack; sk.scratch = S->stack_scr.as<uint8_t>();
+            sk.btask = pa.btask; sk.bpath = pa.bpath; sk.ptext = S->ptext.as<char>();
+            sk.seq = ctx->d_seq; sk.off = ctx->d_off; sk.len = ctx->d_len;
+            sk.M = (int)match; sk.D = (int)mismatch; sk.G = (int)gap;
+            sk.res = pa.res; sk.otext = O.otext.as<char>(); sk.text_cap = cap_text; sk.osites = O.osites.as<pf_bubble_site>(); sk.site_cap = cap_sites;
+            sk.ogroups = O.ogroups.as<uint8_t>(); sk.group_cap = cap_groups; sk.oilen = O.oilen.as<uint32_t>(); sk.ilen_cap = cap_ilen;
+            sk.heads = d_heads; sk.lists = pa.lists; sk.cnt = d_cnt;
+            sk.trio_ok = pa.trio_ok; sk.pair_ok = pa.pair_ok;
+            ctx_begin(ctx, PF_K_CALL_STACK);
+            k_call_stack<<<stack_grid, 64, 0, st>>>(sk);
             ctx_end(ctx);
         }
         PairArgs pr;
@@ -2550,16 +2649,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         }
         if (fork_paths) PF_HIP(hipStreamWaitEvent(st, S->ev_paths, 0));
         if (stack_tier) {
-            // K-STACK: behind K-PREP (strict bubbles of three and four equally long paths) and K-PATHS (branching ones)
-            StackArgs sk;
-            sk.list = pa.lists.klist; sk.btask = pa.btask; sk.bpath = pa.bpath; sk.ptext = S->ptext.as<char>();
-            sk.seq = ctx->d_seq; sk.off = ctx->d_off; sk.len = ctx->d_len;
-            sk.M = (int)match; sk.D = (int)mismatch; sk.G = (int)gap;
-            sk.res = pa.res; sk.otext = O.otext.as<char>(); sk.text_cap = cap_text; sk.osites = O.osites.as<pf_bubble_site>(); sk.site_cap = cap_sites;
-            sk.ogroups = O.ogroups.as<uint8_t>(); sk.group_cap = cap_groups; sk.heads = d_heads; sk.lists = pa.lists; sk.cnt = d_cnt;
-            sk.trio_ok = pa.trio_ok;
+            // K-STACK, second launch: the branching bubbles K-PATHS listed (their two-path rejects cannot go to K-PAIR, which reads
+            // the inner unitigs of a strict bubble: K-BUBBLE's)
+            sk.list = pa.lists.klist_b; sk.n_list = &d_cnt->n_stack_b; sk.pair_ok = 0;
             ctx_begin(ctx, PF_K_CALL_STACK);
-            k_call_stack<<<ctx->n_cu * 8, 64, 0, st>>>(sk);
+            k_call_stack<<<stack_grid, 64, 0, st>>>(sk);
             ctx_end(ctx);
         }
         PF_HIP(hipGetLastError());
@@ -2624,7 +2718,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         ctx_units(ctx, PF_K_CALL_PREP, nb);
         if (snp_ok) ctx_units(ctx, PF_K_CALL_SNP, hc.n_snp);
         if (pair_tier) ctx_units(ctx, PF_K_CALL_PAIR, hc.n_pair + hc.n_pair2);
-        if (stack_tier) ctx_units(ctx, PF_K_CALL_STACK, hc.n_stack);
+        if (stack_tier) ctx_units(ctx, PF_K_CALL_STACK, hc.n_stack + hc.n_stack_b);
         if (trio_tier) ctx_units(ctx, PF_K_CALL_TRIO, hc.n_trio + hc.n_trio4);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (hc.err & 33u) {
@@ -2830,7 +2924,8 @@ int pf_call_reserve(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size) {
     NEED(S->counters, sizeof(CallCounters));
     NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
     NEED(S->queues, (size_t)NQ * nb * 4);
-    for (DevBuf *b : {&S->blist, &S->slist, &S->plist, &S->plist2, &S->klist, &S->tlist, &S->tlist4, &S->has}) NEED(*b, (size_t)nb * 4);
+    for (DevBuf *b : {&S->blist, &S->slist, &S->plist, &S->plist2, &S->klist, &S->klist_b, &S->tlist, &S->tlist4, &S->has}) NEED(*b, (size_t)nb * 4);
+    NEED(S->stack_scr, stack_scratch_bytes() * (uint64_t)(ctx->n_cu * 8));
     const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
     const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (6ull * depth_cap + 4) * 4) + 255) & ~255ull;
     NEED(S->paths_scr, paths_per_wave * (uint64_t)(ctx->n_cu * 16));

@@ -121,4 +121,111 @@ __device__ inline bool stack_certify(const StackPlanes &x, const StackPlanes &y,
            stack_rows<3>(x, y, L, M, D, G, V);
 }
 
+// ---- one gap run -------------------------------------------------------------------------------------------------------------
+// The same certificate for two gap-free strings of DIFFERENT length, A (m bases) the longer: the candidate path runs down the
+// diagonal for `a` bases, then UP for d = m - n cells (d bases of A against gaps in B's row), then down the diagonal to (m, n) --
+// what needlemanWunch finds for a deletion of d bases after base a.  Exact values along the path (the bonus for continuing a
+// direction is known there: every path cell carries the one flag of the move that entered it), upper bounds in a band of STACK_W
+// cells on either side of it, the cells beyond bounded as above; certified when at every path cell the path's move beats the
+// bounds of the two others strictly.  Then the matrix has this one optimal path, the traceback keeps this one alignment (one gap
+// opened: inside the budget of five), and B's row is B with d gaps behind its first a bases.  The caller picks `a` (indel_place:
+// the split with the most matching bases); a wrong pick cannot be certified, so nothing rests on how it was picked.
+
+__device__ inline uint32_t plane_bit(const uint32_t (&p)[4], int idx) {   // 0 outside 0 .. 127
+    if (idx < 0 || idx > 127) return 0;
+    uint32_t w = p[0];
+#pragma unroll
+    for (int x = 1; x < 4; ++x) w = (idx >> 5) == x ? p[x] : w;
+    return (w >> (idx & 31)) & 1u;
+}
+
+// seven plane bits from index i0 (any of them outside 0 .. 127: 0), bit t of the result = plane bit i0 + t
+__device__ inline uint32_t plane_window7(const uint32_t (&p)[4], int i0) {
+    const int w = i0 >> 5;   // (arithmetic shift: floor)
+    auto word = [&](int x) -> uint32_t {
+        uint32_t v = 0;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v = x == q ? p[q] : v;
+        return v;
+    };
+    const uint64_t two = ((uint64_t)word(w + 1) << 32) | word(w);
+    return (uint32_t)(two >> (i0 & 31)) & 0x7Fu;
+}
+
+// the split with the most matching bases: bases [0, a) of B against A's, bases [a, n) against A's d further on; 0xFFFFFFFF when
+// two splits tie for it (a repeat: the matrix has several optimal paths)
+__device__ inline uint32_t indel_place(const StackPlanes &A, const StackPlanes &B, uint32_t n, uint32_t d) {
+    int best = -1, cur = 0;
+    uint32_t best_a = 0;
+    bool tie = false;
+    for (uint32_t i = 0; i < n; ++i)   // a = 0: every base of B against A's base d further on
+        cur += (plane_bit(A.lo, (int)(i + d)) == plane_bit(B.lo, (int)i) && plane_bit(A.hi, (int)(i + d)) == plane_bit(B.hi, (int)i)) ? 1 : 0;
+    best = cur;
+    for (uint32_t a = 1; a <= n; ++a) {   // base a - 1 moves from the shifted part to the unshifted one
+        const uint32_t i = a - 1;
+        const uint32_t bl = plane_bit(B.lo, (int)i), bh = plane_bit(B.hi, (int)i);
+        cur += ((plane_bit(A.lo, (int)i) == bl && plane_bit(A.hi, (int)i) == bh) ? 1 : 0) -
+               ((plane_bit(A.lo, (int)(i + d)) == bl && plane_bit(A.hi, (int)(i + d)) == bh) ? 1 : 0);
+        if (cur > best) { best = cur; best_a = a; tie = false; }
+        else if (cur == best) tie = true;
+    }
+    return tie ? 0xFFFFFFFFu : best_a;
+}
+
+__device__ inline bool indel_certify(const StackPlanes &A, const StackPlanes &B, uint32_t m, uint32_t n, uint32_t a, int M, int D, int G) {
+    constexpr int W = STACK_W;
+    constexpr int NEG = INT_MIN / 4;
+    const int Gb = G + 1, Mb = M + 1;
+    const uint32_t d = m - n;
+    auto ugen = [&](int p, int q) -> int {   // bound of the cell (p, q) beyond the band; exact on the borders, NEG where there is no cell
+        if (p < 0 || q < 0 || q > (int)n) return NEG;
+        if (q == 0) return G * p;
+        if (p == 0) return G * q;
+        const int mn = p < q ? p : q, df = p < q ? q - p : p - q;
+        return mn * Mb + df * Gb;
+    };
+    int V[2 * W + 1];
+#pragma unroll
+    for (int q = -W; q <= W; ++q) V[q + W] = q >= 0 && q <= (int)n ? G * q : NEG;   // row 0, centred on column 0
+    int fprev = 0;   // the move that entered the path cell of the row above: 0 none ((0, 0) or a border cell), 1 DIAG, 2 UP
+    for (uint32_t r = 1; r <= m; ++r) {
+        const bool diag_row = r <= a || r > a + d;
+        const int sg = diag_row ? 1 : 0;
+        const int c = r <= a ? (int)r : (r <= a + d ? (int)a : (int)(r - d));   // the path's column in this row
+        // does A's base r - 1 equal B's base at the columns c - W .. c + W (base index column - 1)?
+        const uint32_t al = plane_bit(A.lo, (int)r - 1), ah = plane_bit(A.hi, (int)r - 1);
+        const uint32_t wl = plane_window7(B.lo, c - W - 1), wh = plane_window7(B.hi, c - W - 1);
+        const uint32_t eq = ~((wl ^ (0u - al)) | (wh ^ (0u - ah))) & 0x7Fu;
+        int N[2 * W + 1];
+#pragma unroll
+        for (int q = -W; q <= W; ++q) {
+            const int col = c + q;
+            const int ui = q + sg, di = q + sg - 1, li = q - 1;   // band indices of the up / diagonal neighbour in the row above, of the left one in this row
+            const int upv = (ui >= -W && ui <= W) ? V[(ui < -W ? -W : (ui > W ? W : ui)) + W] : ugen((int)r - 1, col);
+            const int dgv = (di >= -W && di <= W) ? V[(di < -W ? -W : (di > W ? W : di)) + W] : ugen((int)r - 1, col - 1);
+            const int lfv = li >= -W ? N[(li < -W ? -W : li) + W] : ugen((int)r, col - 1);
+            const int s = ((eq >> (q + W)) & 1u) ? M : D;
+            // a move out of a path cell continues that cell's one flag or nothing; any other move is credited with the bonus
+            const int cu = upv + G + (ui == 0 ? (fprev == 2 ? 1 : 0) : 1);
+            const int cd = dgv + s + (di == 0 ? (fprev == 1 ? 1 : 0) : 1);
+            const int cl = lfv + G + (li == 0 ? 0 : 1);
+            int v;
+            if (q == 0) {
+                if (diag_row) { if (!(cd > cu && cd > cl)) { if (col > 0) return false; } v = cd; }
+                else { if (!(cu > cd && cu > cl)) { if (col > 0) return false; } v = cu; }
+            } else {
+                v = cu > cd ? cu : cd;
+                v = v > cl ? v : cl;
+            }
+            if (col < 0 || col > (int)n) v = NEG;   // no such cell
+            else if (col == 0) v = G * (int)r;    // the border (:486-496): exact, flag UP, nothing to certify
+            N[q + W] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 2 * W + 1; ++q) V[q] = N[q];
+        fprev = c == 0 ? 0 : (diag_row ? 1 : 2);   // (a border cell's UP flag continues no interior move out of it but UP -- which leaves through column 0 itself)
+    }
+    return true;
+}
+
 }  // namespace pf
