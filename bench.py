@@ -177,9 +177,9 @@ def cpu_baseline(workdir: str, target_unitigs: int, device, runs: int = 3):
 
 
 # The reference binary on the full configs[2] graph (same generator, seed 1000), timed once per build on the GPU box's host and
-# committed: a 12-minute run cannot sit inside the default bench.  Source: profiles/r01_fullscale_parity.txt.
+# committed: a 12-minute run cannot sit inside the default bench.  Source: profiles/history/r01_fullscale_parity.txt.
 REFERENCE_FULL_SIZE = {"unitigs": 4990608, "seconds": 697.96, "unitigs_per_s": 7150.3, "cores": 1,
-                       "source": "profiles/r01_fullscale_parity.txt (committed measurement, not part of this run)"}
+                       "source": "profiles/history/r01_fullscale_parity.txt (committed measurement, not part of this run)"}
 
 
 def cpu_model() -> str:

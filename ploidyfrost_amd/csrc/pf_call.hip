@@ -2524,7 +2524,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     const int stack_level = [] { const char *e = getenv("PF_STACK_LEVEL"); return e ? std::max(1, std::min(3, atoi(e))) : 1; }();
     const int stack_grid = ctx->n_cu * 8;
     if (stack_tier) NEED(S->stack_scr, stack_scratch_bytes() * stack_grid);
-    // K-TRIO is OFF unless asked for: measured at BASELINE.json's configs[2] (profiles/r3_trio_ab.txt) it takes 24 k of K-BUBBLE's 34 k
+    // K-TRIO is OFF unless asked for: measured at BASELINE.json's configs[2] (profiles/r07_experiments.txt) it takes 24 k of K-BUBBLE's 34 k
     // bubbles and saves K-BUBBLE 1.0 ms per pass, but costs 3.2 ms itself -- a whole 96 x 70 fill per THREAD is 0.9 ms of dependent
     // instructions on a wavefront that has the SIMD to itself, whatever the number of bubbles; K-BUBBLE's wavefront per bubble
     // spreads the same cells over 64 lanes.  Kept (and held to the oracle by tests/test_gpu_call.py) for graphs with enough such

@@ -41,7 +41,7 @@ __device__ inline unsigned long long dpp_any(unsigned long long old, unsigned lo
 //   the carry for lane 0, + pre), plain store if that unitig began inside the window, atomics otherwise;
 //   further starts inside the same lane delimit unitigs of <= 3 k-mers, stored directly;
 //   the open unitig at the end of the window is flushed with atomics.
-constexpr int KC4_SR = 8;   // measured at 1 M unitigs: 4 -> 0.093 ms, 8 -> 0.072 ms, 16 -> 0.081 ms (profiles/r01j_kcov_stream.txt)
+constexpr int KC4_SR = 8;   // measured at 1 M unitigs: 4 -> 0.093 ms, 8 -> 0.072 ms, 16 -> 0.081 ms (profiles/history/r01j_kcov_stream.txt)
 
 // Segmented inclusive scan (sum, min[, max]) over the 64 lanes; segments begin at the lanes set in `heads`.  `d` = distance
 // from the lane to the last segment start at or below it (>= 64: none) turns every "same segment?" test into a 32-bit compare.
@@ -279,7 +279,7 @@ __device__ inline void kc4_load(uint4 (&c)[NSR], const uint32_t *__restrict__ gc
 // COLORED: blockIdx.y = colour; its counts at gcov + colour * g_stride, its results at out_* + colour * n_out
 // (colour-major, the layout of pf_unitig_cov_colored); colours in `unread` are left as the init kernel wrote them.
 // One wavefront per window of KC4_SR super-rows, uncapped grid.  Measured alternatives at 1 M unitigs (0.072 ms for this form,
-// profiles/r01o_kcov_forms.txt): a persistent grid of resident wavefronts with round-robin windows of 4 super-rows and the
+// profiles/history/r01o_kcov_forms.txt): a persistent grid of resident wavefronts with round-robin windows of 4 super-rows and the
 // next window's loads in flight during the reduction: 0.106-0.115 ms (4-7 blocks per CU); the same with windows handed out
 // through one atomic counter: 0.59 ms (45 000 returning atomics on one address).
 template <bool WIDE, bool COLORED>
