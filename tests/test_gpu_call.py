@@ -505,3 +505,26 @@ def test_paths_of_a_braid(layers, seed, tmp_path):
     gfa, db, n = _braid(tmp_path, K, layers, seed=seed)
     s = check_pipeline(str(tmp_path), gfa, db, z=40, lower=1, upper=1000)
     assert s["branching"] == 1 and s["max_paths"] >= 4, s
+
+
+@pytest.mark.parametrize("case", ["multi", "hex30k", "braid"])
+def test_paths_walked_in_scratch_give_the_same(case, multi_path_graphs, tmp_path, monkeypatch):
+    """K-PATHS keeps its two stacks in registers and repeats a bubble with them in global scratch when one outgrows the registers
+    (64 / 256 entries); PF_PATHS_SCRATCH=1 sends every bubble down that second road"""
+    monkeypatch.setenv("PF_PATHS_SCRATCH", "1")
+    if case == "multi":
+        sub, gfa, db = multi_path_graphs[0]
+        s = check_pipeline(sub + "/scratch", gfa, db, z=16)
+        assert s["branching"] >= 100, s
+    elif case == "hex30k":
+        meta = load_case("hex30k")
+        op = meta["opts"]
+        sc = (float(op["-M"]), float(op["-D"]), float(op["-G"]))
+        s = check_pipeline(str(tmp_path), meta["gfa"], meta["db"], z=int(op["-z"]), lower=int(op["-l"]), upper=int(op["-u"]), scores=sc)
+        assert s["branching"] >= 50, s
+        assert not compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(str(tmp_path), "gpu_%g_%g_%g" % sc))
+    else:
+        from test_gpu_end_to_end import _braid
+        gfa, db, n = _braid(tmp_path, K, 7, seed=11)
+        s = check_pipeline(str(tmp_path), gfa, db, z=40, lower=1, upper=1000)
+        assert s["branching"] == 1 and s["max_paths"] >= 4, s
