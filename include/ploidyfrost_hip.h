@@ -297,6 +297,22 @@ int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t 
  * 1552-1652).  Call order: pf_call_set_state, pf_call_coverage, pf_call_scan, pf_call_resolve (or pf_call_sides + pf_call_select), then pf_call_run /
  * pf_call_fetch per batch.  Single-sample path (CDBG); the colored twin keeps pf_align_bubbles + pf_string_cov_colored. */
 
+/* The colored twin, CCDBG::ploidyEstimation_ptr (src/CCDBG.cpp:2759-3531), on the same pipeline.  pf_call_set_colours (once per
+ * graph, after pf_upload_counts_colored) hands over what the calling phase asks of the colour sets: full_mask[u] = colours on every
+ * k-mer of unitig u; size_total[u] = UnitigColors::size() with the unitig's own mapping; and for a colour on part of a unitig one
+ * bit per k-mer, reference orientation: entries part_first[u] .. part_first[u + 1] (N + 1 prefix) = {part_colour[e], first word
+ * part_word[e] in part_bits}.  [host|dev]  With colours set, pf_call_coverage leaves readCovUni (src/CCDBG.cpp:123-156) of every
+ * (colour, unitig) resident; pf_call_scan applies the per-colour gates of :2838-2931 (its lower / upper arguments are ignored:
+ * pf_call_set_cutoffs gives one pair per colour, before every pf_call_scan) and the colored sortSeq_simple (:368-480); K-PATHS
+ * records the unitigs each bubble's walks visit, K-SITES maps every site string to its unitig (findUnitig, :3251, 3390), asks the
+ * colour sets which colours cover it (UnitigColors::contains) and reads every colour's count of its k-mers from the joined table
+ * (readCov(string, low, up, colour), :89-122); K-TEXT writes one row per colour that sees two allele groups or more, with the
+ * colour id and the largest Cramer's V over the colour pairs (:330-366, 2964-3059, 3285-3339).  n_colors = 0: back to the
+ * single-sample path.  The -t > 1 format (pf_call_set_format) and pf_call_peek are the single-sample path's. */
+int pf_call_set_colours(pf_ctx *, uint32_t n_colors, const uint64_t *full_mask, const uint64_t *size_total, const uint32_t *part_first,
+                        const uint32_t *part_colour, const uint64_t *part_word, const uint64_t *part_bits, uint64_t n_part, uint64_t n_words);
+int pf_call_set_cutoffs(pf_ctx *, uint32_t n_colors, const uint32_t *lower, const uint32_t *upper);
+
 /* T1: the MyUnitig state after findSuperBubble (src/MyUnitig.hpp:37-130): b bits; plus / minus partners (0 = NULL, id = u + 1).
  * n_unitigs entries each. [host|dev] */
 int pf_call_set_state(pf_ctx *, const uint8_t *flags, const uint32_t *plus, const uint32_t *minus);

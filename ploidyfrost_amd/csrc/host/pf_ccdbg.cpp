@@ -89,6 +89,30 @@ CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, doub
         if (st == PF_OK) st = pf_upload_counts_colored(ctx_, C, pk.data(), pc.data(), n.data(), mn.data(), mx.data(), both.data());
         for (uint32_t c = 0; c < C; ++c) { pf_device_free(ctx_, pk[c]); pf_device_free(ctx_, pc[c]); }
         if (st != PF_OK) { fail(st, std::string("CCDBG::CCDBG():Error: ") + pf_last_error(ctx_)); return; }
+        // the colour sets the calling phase asks about go to the device as well (pf_call_set_colours): the mask of colours on every
+        // k-mer, UnitigColors::size(), and one bit per k-mer for a colour on part of a unitig
+        if (const char *e = getenv("PF_CALL")) resident_ = strcmp(e, "host") != 0;
+        if (resident_) {
+            const ColorSets &cs = cg_.colors;
+            const uint32_t N = g_.n();
+            std::vector<uint32_t> us;
+            us.reserve(cs.partial.size());
+            for (const auto &kv : cs.partial) us.push_back(kv.first);
+            std::sort(us.begin(), us.end());
+            std::vector<uint32_t> part_first((size_t)N + 1, 0), part_colour;
+            std::vector<uint64_t> part_word, bits;
+            for (uint32_t u : us) part_first[(size_t)u + 1] = (uint32_t)cs.partial.at(u).size();
+            for (uint32_t u = 0; u < N; ++u) part_first[(size_t)u + 1] += part_first[u];
+            for (uint32_t u : us)
+                for (const ColorSets::Partial &pt : cs.partial.at(u)) {
+                    part_colour.push_back(pt.colour);
+                    part_word.push_back(bits.size());
+                    bits.insert(bits.end(), pt.bits.begin(), pt.bits.end());
+                }
+            st = pf_call_set_colours(ctx_, C, cs.full_mask.data(), cs.size_total.data(), part_first.data(), part_colour.data(), part_word.data(), bits.data(),
+                                     part_colour.size(), bits.size());
+            colored_resident_ = st == PF_OK;
+        }
     }
     if (!quiet_) printf("CCDBG::CCDBG():CCDBG initialized!\n");
 }

@@ -167,7 +167,7 @@ protected:
     // the same through pf_call_* (pf_cdbg_call.cpp); call_select = scan + the sequential pass of the driver loop
     int ploidy_estimation_resident(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
     int call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &n_tasks);
-    bool resident_path() const { return resident_ && col_ == nullptr; }
+    bool resident_path() const { return resident_ && (col_ == nullptr || colored_resident_); }
     // set by CCDBG: the colour sets of the graph's unitigs (reference src/CCDBG.cpp path) and the stdout tag
     const ColorSets *col_ = nullptr;
     const char *tag_ = "CDBG";
@@ -221,6 +221,7 @@ protected:
     // bytes of the few components committed on the host (kept all-zero between passes)
     bool state_host_stale_ = false;
     bool colours_on_device_ = false;   // colored path: pf_replay_set_colours succeeded
+    bool colored_resident_ = false;    // colored path: pf_call_set_colours succeeded -- the calling phase runs on the resident pipeline
     std::vector<uint8_t> big_f2_;
     bool commits_on_device(size_t thr) const;
     int find_superbubbles_device(const std::string &outpre, const size_t &thr);

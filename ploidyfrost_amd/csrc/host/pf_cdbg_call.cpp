@@ -34,6 +34,12 @@ int CDBG::call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &
     const uint32_t low = (uint32_t)cutoff[0].first, up = (uint32_t)cutoff[0].second;
     auto t0 = clk::now();
     int st = PF_OK;
+    if (col_) {   // colored: one (lower, upper) per colour
+        std::vector<uint32_t> lows(cutoff.size()), ups(cutoff.size());
+        for (size_t c = 0; c < cutoff.size(); ++c) { lows[c] = (uint32_t)cutoff[c].first; ups[c] = (uint32_t)cutoff[c].second; }
+        st = pf_call_set_cutoffs(ctx_, (uint32_t)cutoff.size(), lows.data(), ups.data());
+        if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+    }
     if (!cov_ready_) st = launch_coverage();
     cov_ready_ = false;
     if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + cov_err_);

@@ -163,8 +163,11 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     if (status_) return status_;
     if (mt_format_ && !resident_path())
         return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): the -t > 1 output format needs the resident calling pipeline");
+    if (mt_format_ && col_)
+        return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): the -t > 1 output format is the single-sample path's");
     if (resident_path()) {
-        if (cutoff.size() != 1) return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): one (lower, upper) cutoff is required");
+        if (cutoff.size() != (col_ ? col_->n_colors : 1u))
+            return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): one (lower, upper) cutoff" + (col_ ? " per colour" : "") + " is required");
         return ploidy_estimation_resident(outpre, cutoff, thr);
     }
     const auto t_all = clk::now();

@@ -34,6 +34,7 @@
 
 #include "pf_bubble_launch.hpp"
 #include "pf_call_dev.hpp"
+#include "pf_colored_dev.hpp"
 #include "pf_cov_stream.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
@@ -97,7 +98,7 @@ struct CallCounters {
     unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
     unsigned int err_entrance, err_exit;   // the bubble bits 0 / 5 speak of (oriented vertices; whichever wavefront wrote last)
-    unsigned long long path_head, text_head, sv_head;
+    unsigned long long path_head, text_head, sv_head, walk_head;
     unsigned long long max_need, retry_need;
     unsigned long long allele[4], core_cov, core_num, n_called, site_strings;
 };
@@ -113,6 +114,14 @@ struct CallState {
     // C1 results, one slot per unitig (two per unitig for a database without canonical counting)
     DevBuf cov_sum, cov_min, cov_miss;
     bool have_cov = false, per_strand = false;
+    // colored path (pf_call_set_colours): cutoffs per colour, the colour sets the calling phase asks about -- per unitig the mask of
+    // colours on every k-mer and UnitigColors::size(); for a colour on part of a unitig one bit per k-mer (reference orientation):
+    // entries part_first[u] .. part_first[u + 1] = {colour, first word in part_bits} -- and K-COV-C's results, colour-major
+    uint32_t n_colors = 0;
+    DevBuf col_low, col_up, col_full, col_size, part_first, part_colour, part_word, part_bits;
+    DevBuf ccov_sum, ccov_min, ccov_max, ccov_miss;
+    DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
+    uint64_t walk_cap = 0;
     // scan
     DevBuf side_cnt, side_base, sides, ctask, scan_tmp, target, pending, killed, rstate, rflag, rsmall;
     uint64_t n_sides = 0;
@@ -150,7 +159,8 @@ struct CallState {
     hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
     bool mt_format = false;   // pf_call_set_format
     void release_all() {
-        DevBuf *all[] = {&flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
+        DevBuf *all[] = {&col_low, &col_up, &col_full, &col_size, &part_first, &part_colour, &part_word, &part_bits, &ccov_sum, &ccov_min, &ccov_max, &ccov_miss, &walk_off, &walk_pool,
+                         &flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
                          &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &klist_b, &stack_scr, &tlist, &tlist4, &trio_scr, &trio_rows, &trio_ok, &pair_scr, &pair_scr2, &has, &sizes, &offs,
                          &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
         for (DevBuf *b : all) b->release();
@@ -213,7 +223,71 @@ struct ScanArgs {
     pf_call_side *sides;
     CallTask *tasks;
     uint32_t *target;           // per side: the record of the side the bubble's exit faces (closed when this side is handled), or NONE
+    // colored (CCDBG): K-COV-C's results colour-major ([c * N + u]), one (low, up) per colour, the colour sets
+    uint32_t n_colors;
+    const uint64_t *ccov_sum;
+    const uint32_t *ccov_min, *ccov_max;
+    const uint8_t *ccov_miss;
+    const uint32_t *clow, *cup;
+    const uint64_t *full, *size_total;
 };
+
+// readCovUni(u, low, up, c) of src/CCDBG.cpp:123-156 from K-COV-C's resident results: (sum / len, true) iff every k-mer is in colour
+// c's database with low < count < up, else (0, false)
+struct ColourCov {
+    const uint64_t *sum;
+    const uint32_t *mn, *mx;
+    const uint8_t *miss;
+    const uint32_t *low, *up;
+    uint32_t N;
+    __device__ inline bool ok(uint32_t c, uint32_t u) const {
+        const size_t o = (size_t)c * N + u;
+        return !miss[o] && mn[o] > low[c] && mx[o] < up[c];
+    }
+    __device__ inline double mean(uint32_t c, uint32_t u, uint32_t len_km) const { return (double)sum[(size_t)c * N + u] / (double)len_km; }
+};
+
+// colored sortSeq_simple (src/CCDBG.cpp:368-480) with its exact partition scheme: descending number of colours, then descending
+// length, then descending reference string.  n <= 4.
+__device__ inline void sort_inner_colored_dev(const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off, const uint32_t *__restrict__ len,
+                                              uint32_t *pc, uint32_t *ov, int n) {
+    int stack_lo[8], stack_hi[8];
+    int sp = 1;
+    stack_lo[0] = 0;
+    stack_hi[0] = n - 1;
+    auto ref_cmp = [&](int x, int y) -> int {   // length first, then the strings (equal lengths: strcmp)
+        const uint32_t lx = len[ov[x] >> 1], ly = len[ov[y] >> 1];
+        if (lx != ly) return lx > ly ? 1 : -1;
+        return unitig_cmp(seq, off, len, ov[x] >> 1, ov[y] >> 1);
+    };
+    while (sp > 0) {
+        --sp;
+        const int low = stack_lo[sp], high = stack_hi[sp];
+        if (high <= low) continue;
+        int i = low, j = high;
+        for (;;) {
+            while (pc[i] >= pc[low]) {
+                if (pc[i] > pc[low] || ref_cmp(i, low) > 0) i++;
+                else break;
+                if (i == high) break;
+            }
+            while (pc[j] <= pc[low]) {
+                if (pc[j] < pc[low] || ref_cmp(j, low) < 0) j--;
+                else break;
+                if (j == low) break;
+            }
+            if (i >= j) break;
+            const uint32_t tp = pc[i]; pc[i] = pc[j]; pc[j] = tp;
+            const uint32_t to = ov[i]; ov[i] = ov[j]; ov[j] = to;
+        }
+        {
+            const uint32_t tp = pc[low]; pc[low] = pc[j]; pc[j] = tp;
+            const uint32_t to = ov[low]; ov[low] = ov[j]; ov[j] = to;
+        }
+        stack_lo[sp] = low; stack_hi[sp] = j - 1; ++sp;
+        stack_lo[sp] = j + 1; stack_hi[sp] = high; ++sp;
+    }
+}
 
 __global__ void k_call_count_sides(const uint8_t *__restrict__ flags, uint32_t N, uint32_t *__restrict__ cnt) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
@@ -228,6 +302,7 @@ __device__ inline uint32_t first_succ(const uint32_t *__restrict__ succ, uint32_
     return r.w;
 }
 
+template <bool COLORED>
 __global__ __launch_bounds__(256) void k_call_sides(ScanArgs a) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= a.N) return;
@@ -260,7 +335,7 @@ __global__ __launch_bounds__(256) void k_call_sides(ScanArgs a) {
             if (f & (ps ? B_COMPLEX_P : B_COMPLEX_M)) { r.kind = 1; break; }
             const uint32_t uo = 2 * u + (ps ? 0 : 1);
             const bool strict = (f & (ps ? B_STRICT_P : B_STRICT_M)) != 0;
-            if (a.cov_miss[cslot(uo)]) { r.err = 1; r.err_unitig = u; break; }  // core = readCov(u), u oriented
+            if (!COLORED && a.cov_miss[cslot(uo)]) { r.err = 1; r.err_unitig = u; break; }  // core = readCov(u), u oriented
             uint32_t exit_ov;
             if (strict) {
                 exit_ov = first_succ(a.succ, uo);
@@ -282,6 +357,57 @@ __global__ __launch_bounds__(256) void k_call_sides(ScanArgs a) {
             t.strict = strict;
             if (unitig_cmp(a.seq, a.off, a.len, u, eu) < 0) { r.kind = 2; break; }  // the other endpoint owns this bubble
             r.kind = 3;
+            if (COLORED) {
+                // src/CCDBG.cpp:2838-2853: the per-colour means are summed until a colour fails its range test (the `flag == false;`
+                // there is a no-op, so the bubble is processed regardless)
+                const ColourCov cc{a.ccov_sum, a.ccov_min, a.ccov_max, a.ccov_miss, a.clow, a.cup, N};
+                const uint32_t C = a.n_colors;
+                double core = 0;
+                for (uint32_t c = 0; c < C; ++c) {
+                    if (!cc.ok(c, u)) break;
+                    core += cc.mean(c, u, len_km(u));
+                }
+                t.core_mean = core;
+                bool flag = true;
+                if (strict) {   // :2867-2931: the [colour][path] matrix of mean coverages, its gates, the colored sortSeq_simple
+                    uint32_t pc[4] = {0, 0, 0, 0};
+                    uint32_t path = 0;
+                    const uint32_t *row = a.succ + (size_t)uo * 4;
+                    for (int b = 0; b < 4 && flag; ++b) {
+                        const uint32_t w = row[b];
+                        if (w == NONE) continue;
+                        const uint32_t wu = w >> 1;
+                        t.inner[t.n_inner++] = w;
+                        const uint64_t fm = a.full[wu];
+                        uint32_t jn = 0;
+                        for (uint32_t c = 0; c < C; ++c) {
+                            if (!((fm >> c) & 1)) continue;
+                            ++jn;
+                            if (!cc.ok(c, wu)) { flag = false; break; }
+                        }
+                        if (!flag) break;
+                        if (a.size_total[wu] != (uint64_t)jn * len_km(wu)) { flag = false; break; }  // a colour on part of it
+                        pc[path++] = jn;
+                    }
+                    if (flag) {   // some colour must see more than one of the paths (an entry of the matrix is its mean, 0 if absent)
+                        flag = false;
+                        for (uint32_t c = 0; c < C && !flag; ++c) {
+                            int nz = 0;
+                            for (uint32_t q = 0; q < path; ++q) {
+                                const uint32_t wu = t.inner[q] >> 1;
+                                nz += ((a.full[wu] >> c) & 1) && cc.mean(c, wu, len_km(wu)) != 0.0;
+                            }
+                            flag = nz > 1;
+                        }
+                    }
+                    if (flag) {
+                        sort_inner_colored_dev(a.seq, a.off, a.len, pc, t.inner, (int)path);
+                        t.n_cov = (uint8_t)path;
+                    }
+                }
+                r.aligned = flag;
+                break;
+            }
             t.core_mean = mean_ov(uo);
             bool aligned = true;
             if (strict) {
@@ -1241,6 +1367,11 @@ struct PathArgs {
     uint8_t *scratch;       // per wave, for the bubbles whose stacks outgrow the registers: major[depth_cap], minor[4 depth_cap], seg_start
     uint64_t scratch_per_wave;
     int force_scratch;      // (tests) every bubble walks with the stacks in scratch
+    // colored: the distinct oriented unitigs the walks of a bubble visit, in the order of their first visit (what CCDBG searches for
+    // the first k-mer of a site string, src/CCDBG.cpp:3251, 3390): walk_off[j] = first entry in walk_pool | count << 40
+    uint32_t *walk_pool;    // nullptr: single-sample
+    uint64_t *walk_off;
+    uint64_t walk_cap;
     pf_bubble_task *btask;
     pf_bubble_path *bpath;  // strict region [0, 4 nb), then the pool
     uint64_t path_cap;      // entries available behind the strict region
@@ -1262,10 +1393,11 @@ struct WalkOut {
     bool too_many, too_deep, text_ok;
     uint32_t lmax, lmin;
     uint64_t sum;
+    uint32_t n_seen, seen_reg;   // colored: distinct vertices visited (seen_reg: entry x in lane x; after the scratch walk they lie in its scratch)
 };
 struct TextChunk { unsigned long long cur, end; };   // a wave's piece of the text pool (one atomic per ~40 paths)
 
-__device__ inline void walk_reset(WalkOut &o) { o = WalkOut{0, false, false, true, 0, 0xFFFFFFFFu, 0}; }
+__device__ inline void walk_reset(WalkOut &o) { o = WalkOut{0, false, false, true, 0, 0xFFFFFFFFu, 0, 0, 0}; }
 
 __device__ inline unsigned long long take_text(const PathArgs &a, TextChunk &tx, uint32_t total, int lane) {
     if (total > tx.end - tx.cur) {
@@ -1316,6 +1448,8 @@ __device__ inline bool walk_in_registers(const PathArgs &a, const CallTask &t, T
     unsigned long long mo = 0;
     uint32_t mn0 = 0, mn1 = 0, mn2 = 0, mn3 = 0;
     uint32_t n_major = 0, n_minor = 1;
+    uint32_t seen = NONE;   // colored: distinct vertices in the order of their first visit, entry x in lane x
+    o.n_seen = 0;
     if (lane == 0) mn0 = t.entrance_ov;
     auto minor_top = [&]() {
         const uint32_t x = n_minor - 1, r = x >> 6;
@@ -1327,6 +1461,11 @@ __device__ inline bool walk_in_registers(const PathArgs &a, const CallTask &t, T
         --n_minor;
         if (n_major >= a.depth_cap) { o.too_deep = true; return true; }
         if (n_major >= 64) return false;
+        if (a.walk_pool && !__ballot((uint32_t)lane < o.n_seen && seen == w)) {
+            if (o.n_seen >= WAVE) return false;
+            if ((uint32_t)lane == o.n_seen) seen = w;
+            ++o.n_seen;
+        }
         const uint32_t u = w >> 1;
         const bool at_exit = u == eu;
         uint32_t r0 = NONE, r1 = NONE, r2 = NONE, r3 = NONE;
@@ -1390,15 +1529,17 @@ __device__ inline bool walk_in_registers(const PathArgs &a, const CallTask &t, T
             }
         }
     }
+    o.seen_reg = seen;
     return true;
 }
 
 // The same walk with the stacks in the wave's global scratch: any depth the complex size allows.
 __device__ __noinline__ void walk_in_scratch(const PathArgs &a, const CallTask &t, TextChunk &tx, unsigned long long *poff, uint32_t *plen,
-                                             WalkOut &o, uint32_t *major, uint32_t *minor, uint32_t *seg_start, const int lane) {
+                                             WalkOut &o, uint32_t *major, uint32_t *minor, uint32_t *seg_start, uint32_t *seen, const int lane) {
     const uint32_t eu = t.exit_ov >> 1;
     const uint32_t ulen = a.len[t.u] - (uint32_t)a.k + 1;
     uint32_t n_major = 0, n_minor = 0;
+    o.n_seen = 0;
     if (lane == 0) minor[0] = t.entrance_ov;
     n_minor = 1;
     __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -1409,6 +1550,15 @@ __device__ __noinline__ void walk_in_scratch(const PathArgs &a, const CallTask &
         if (n_major >= a.depth_cap) { o.too_deep = true; break; }
         if (lane == 0) major[n_major] = w;
         ++n_major;
+        if (a.walk_pool) {
+            bool known = false;
+            for (uint32_t x0 = 0; x0 < o.n_seen && !known; x0 += WAVE) known = __ballot(x0 + lane < o.n_seen && seen[x0 + lane] == w) != 0;
+            if (!known) {
+                if (o.n_seen >= 4 * a.depth_cap) { o.too_deep = true; break; }
+                if (lane == 0) seen[o.n_seen] = w;
+                ++o.n_seen;
+            }
+        }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if ((w >> 1) == eu) {
@@ -1479,8 +1629,9 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
     uint32_t *major = reinterpret_cast<uint32_t *>(scr);                        // depth_cap
     uint32_t *minor = major + a.depth_cap;                                      // 4 depth_cap
     uint32_t *seg_start = minor + 4 * a.depth_cap;                              // depth_cap + 1
+    uint32_t *seen_scr = seg_start + a.depth_cap + 1;                           // 4 depth_cap (colored)
     const uint32_t n_branching = a.cnt->n_branching;
-    TextChunk tx{0, 0}, px{0, 0};
+    TextChunk tx{0, 0}, px{0, 0}, wx{0, 0};
     uint32_t pend_key = PK_NONE, pend_j = 0, n_pend = 0;   // list entries not yet appended: entry x in lane x
     unsigned long long need_retry = 0, need_max = 0;
     for (uint32_t q = blockIdx.x; q < n_branching; q += gridDim.x) {   // (bubbles cost about the same: no queue head to fight over)
@@ -1489,9 +1640,11 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
         WalkOut wo;
         walk_reset(wo);
         __builtin_amdgcn_wave_barrier();   // (the loop before may still be reading poff / plen)
+        bool seen_in_scratch = false;
         if (a.force_scratch || !walk_in_registers(a, t, tx, poff, plen, wo, lane)) {
             walk_reset(wo);
-            walk_in_scratch(a, t, tx, poff, plen, wo, major, minor, seg_start, lane);
+            walk_in_scratch(a, t, tx, poff, plen, wo, major, minor, seg_start, seen_scr, lane);
+            seen_in_scratch = true;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -1507,6 +1660,24 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
         }
         // ---- sortSeq_branching (src/CDBG.cpp:417-480): descending length, ties by descending strcmp.  Distinct walks spell
         //      distinct strings, so the order is total and a rank sort gives what the reference's quicksort gives ----
+        if (a.walk_pool) {   // colored: the vertices visited, for K-SITES
+            const uint32_t ns = wo.n_seen;
+            if (ns > wx.end - wx.cur) {
+                const unsigned long long want = ns > 256u ? ns : 256u;
+                unsigned long long got = 0;
+                if (lane == 0) got = atomicAdd(&a.cnt->walk_head, want);
+                got = ((unsigned long long)read_lane((uint32_t)(got >> 32), 0) << 32) | read_lane((uint32_t)got, 0);
+                wx.cur = got;
+                wx.end = got + want;
+            }
+            const unsigned long long at = wx.cur;
+            wx.cur += ns;
+            if (at + ns <= a.walk_cap) {
+                if (seen_in_scratch) { for (uint32_t x = lane; x < ns; x += WAVE) a.walk_pool[at + x] = seen_scr[x]; }
+                else if ((uint32_t)lane < ns) a.walk_pool[at + lane] = wo.seen_reg;
+            }
+            if (lane == 0) a.walk_off[j] = at | ((unsigned long long)ns << 40);
+        }
         if (n_paths > px.end - px.cur) {   // path entries come in pieces of 128 like the text (holes in the pool are harmless)
             const unsigned long long want = n_paths > 128u ? n_paths : 128u;
             unsigned long long got = 0;
@@ -1636,11 +1807,98 @@ struct SiteArgs {
     uint64_t sv_cap;
     CallCounters *cnt;
     unsigned long long *prof;   // PF_SITES_STATS: per wavefront {total, pop + load, strings, ranks + probes, groups, bubbles}
+    // colored (CCDBG): the joined table of all colours with one (low, up) per colour, the colour sets, the graph and the vertices
+    // each bubble's walks visit (K-PATHS).  A site then has n_colors * maxnum values -- group coverage [colour][group] -- and its
+    // verdict: pad_ = 1 iff no string failed a colour's range test and every colour covers some string in full.
+    uint32_t n_colors;
+    CTab ctab;
+    int c_one_strand;
+    uint64_t c_unread;
+    const uint32_t *clow, *cup;
+    const uint64_t *full;
+    const uint32_t *part_first, *part_colour;
+    const uint64_t *part_word, *part_bits;
+    const uint32_t *walk_pool;
+    const uint64_t *walk_off;
+    const uint64_t *seq, *off;
+    const uint32_t *len;
 };
 
+// UnitigColors::contains(um, colour) (bifrost/src/ColorSet.cpp:776-823) for the mapping [dist, dist + n_km) of unitig u: the colour
+// on every one of those k-mers
+__device__ inline bool colour_contains(const SiteArgs &a, uint32_t u, uint32_t c, uint32_t dist, uint32_t n_km) {
+    if ((a.full[u] >> c) & 1) return true;
+    for (uint32_t e = a.part_first[u]; e < a.part_first[u + 1]; ++e) {
+        if (a.part_colour[e] != c) continue;
+        const uint64_t *bits = a.part_bits + a.part_word[e];
+        for (uint32_t i = dist; i < dist + n_km; ++i)
+            if (!((bits[i >> 6] >> (i & 63)) & 1)) return false;
+        return true;
+    }
+    return false;
+}
+
+// cdbg.findUnitig(s, 0, len) of src/CCDBG.cpp:3251, 3390 followed by UnitigColors::contains on that mapping, for one site string:
+// its first k-mer lies on one of the bubble's unitigs (a k-mer occurs once in the graph, in one orientation); the mapping is extended
+// along that unitig while the characters agree (CompactedDBG.tcc:3815-3837, CompressedSequence.cpp:497-520).  Returns the mask of
+// colours present on every k-mer of the mapping; found = false when no unitig of the bubble holds the first k-mer.
+__device__ inline uint64_t colours_of_string(const SiteArgs &a, const char *sp, uint32_t lp, const uint32_t *walk, uint32_t n_walk, bool &found) {
+    const int k = a.k;
+    const uint64_t kmask = (1ull << (2 * k)) - 1;
+    found = false;
+    if (lp < (uint32_t)k) return 0;
+    auto code = [](char ch) -> int { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; };
+    uint64_t head = 0;
+    for (int i = 0; i < k; ++i) {
+        const int b = code(sp[i]);
+        if (b < 0) return 0;   // (a gap character never matches a unitig)
+        head = (head << 2) | (uint64_t)b;
+    }
+    const uint64_t rhead = rc_kmer(head, k);
+    for (uint32_t q = 0; q < n_walk; ++q) {
+        const uint32_t u = walk[q] >> 1;
+        const uint32_t Lu = a.len[u];
+        const uint64_t *w = a.seq + a.off[u];
+        auto base_at = [&](uint32_t x) -> int { return (int)((w[x >> 5] >> (62 - 2 * (x & 31))) & 3u); };
+        uint64_t y = 0, word = 0;
+        int hit = 0;   // 1 forward, 2 reverse complement
+        uint32_t p0 = 0;
+        // (std::string::find(head) over the whole unitig first, then find(rhead): a unitig holds at most one of the two)
+        for (uint32_t pos = 0; pos < Lu && hit != 1; ++pos) {
+            if ((pos & 31) == 0) word = w[pos >> 5];
+            y = ((y << 2) | ((word >> (62 - 2 * (pos & 31))) & 3u)) & kmask;
+            if (pos + 1 < (uint32_t)k) continue;
+            if (y == head) { hit = 1; p0 = pos + 1 - (uint32_t)k; }
+            else if (y == rhead && !hit) { hit = 2; p0 = pos + 1 - (uint32_t)k; }
+        }
+        if (!hit) continue;
+        uint32_t dist, n_km;
+        if (hit == 1) {
+            uint32_t jn = (uint32_t)k;
+            while (jn < lp && p0 + jn < Lu && code(sp[jn]) == base_at(p0 + jn)) ++jn;
+            n_km = jn - (uint32_t)k + 1;
+            dist = p0;
+        } else {
+            long ps = (long)p0 + k - 1;
+            uint32_t jn = 0;
+            while (jn < lp && ps >= 0 && code(sp[jn]) == 3 - base_at((uint32_t)ps)) { ++jn; --ps; }
+            n_km = jn - (uint32_t)k + 1;
+            dist = p0 - (n_km - 1);
+        }
+        uint64_t m = 0;
+        for (uint32_t c = 0; c < a.n_colors; ++c)
+            if (colour_contains(a, u, c, dist, n_km)) m |= 1ull << c;
+        found = true;
+        return m;
+    }
+    return 0;
+}
+
+template <bool COLORED>
 __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
     const int lane = lane_id();
     const uint32_t KS = a.ks;
+    const uint32_t C = COLORED ? a.n_colors : 1;
     const int k = a.k;
     uint8_t *scr = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
     // per row (256 rows): appended characters, final string, and the per-row scalars
@@ -1652,6 +1910,10 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
     uint8_t *dup = reinterpret_cast<uint8_t *>(rank + 256);
     uint8_t *sok = dup + 256;
     double *mean = reinterpret_cast<double *>(sok + 256);
+    // colored, per row: the colours its string's mapping carries in full, the colours whose range test it passed, its mean per colour
+    uint64_t *cmask = reinterpret_cast<uint64_t *>(mean + 256);
+    uint64_t *cokm = cmask + 256;
+    double *cmean = reinterpret_cast<double *>(cokm + 256);   // [256][C]
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t n_branching = a.cnt->n_branching;
     unsigned long long my_strings = 0;   // (added to the batch's count once, at the end)
@@ -1691,7 +1953,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
         const char *rows = a.otext + r.rows_off;
         // values: one slot per allele group and site, plus the site's sum
         uint32_t n_val = 0;
-        for (uint32_t si = 0; si < r.n_sites; ++si) n_val += (uint32_t)a.osites[r.site_off + si].maxnum + 1;
+        for (uint32_t si = 0; si < r.n_sites; ++si) n_val += C * (uint32_t)a.osites[r.site_off + si].maxnum + 1;
         unsigned long long v0 = 0;
         if (n_val > chunk_left) {   // (wave-uniform)
             const uint32_t take = n_val > SV_CHUNK ? n_val : SV_CHUNK;
@@ -1720,7 +1982,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
             // the probe wants; ranks, duplicates and the groups' sums go through lane reads instead of the scratch arrays,
             // whose every access is a step in a chain of dependent loads.  Same decisions, same order of the additions.
             const long plain_from = (long)site - k + 1;
-            if (!sr.is_indel && indel == 0 && plain_from >= 0 && (uint64_t)plain_from + (uint64_t)k <= L && k <= 31 && R <= WAVE) {
+            if (!COLORED && !sr.is_indel && indel == 0 && plain_from >= 0 && (uint64_t)plain_from + (uint64_t)k <= L && k <= 31 && R <= WAVE) {
                 const uint32_t p = (uint32_t)lane;
                 const bool mine = p < R;
                 uint64_t hi = 0, lo = 0, km = 0;
@@ -1942,7 +2204,35 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                     rank[p] = rk;   // counts duplicates of smaller strings as well: only the order of the ranks matters
                     uint8_t ok = 1;
                     double mn = 0.0;
-                    if (!d) {
+                    if (COLORED) {
+                        if (!d) {
+                            // readCov(string, low, up, c) (src/CCDBG.cpp:89-122) for every colour: one look at the joined table per k-mer
+                            uint64_t okm = C >= 64 ? ~0ull : ((1ull << C) - 1);
+                            uint64_t *cs = reinterpret_cast<uint64_t *>(cmean + (size_t)p * C);
+                            for (uint32_t c = 0; c < C; ++c) cs[c] = 0;
+                            uint64_t x = 0;
+                            for (uint32_t c0 = 0; c0 < lp; ++c0) {
+                                const char ch = sp[c0];
+                                const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
+                                x = ((x << 2) | b) & kmask;
+                                if (c0 + 1 < (uint32_t)k) continue;
+                                const uint8_t *sa, *sb;
+                                colored_slots(a.ctab, x, k, a.c_one_strand != 0, sa, sb);
+                                for (uint32_t c = 0; c < C; ++c) {
+                                    if (!((okm >> c) & 1) || ((a.c_unread >> c) & 1)) continue;   // (a colour never looked up: (0, true))
+                                    const uint32_t cnt = ctab_count(sa, sb, c);
+                                    if (cnt != CTAB_MISSING && cnt > a.clow[c] && cnt < a.cup[c]) cs[c] += cnt;
+                                    else { cs[c] = 0; okm &= ~(1ull << c); }   // missing or outside (low, up): (0, false), :105-117
+                                }
+                            }
+                            for (uint32_t c = 0; c < C; ++c) cmean[(size_t)p * C + c] = (double)cs[c] / (double)((uint64_t)lp - (uint64_t)k + 1);
+                            cokm[p] = okm;
+                            const uint64_t wf = a.walk_off[j];
+                            bool found;
+                            cmask[p] = colours_of_string(a, sp, lp, a.walk_pool + (wf & ((1ull << 40) - 1)), (uint32_t)(wf >> 40), found);
+                            if (!found) miss = true;
+                        }
+                    } else if (!d) {
                         uint64_t sum = 0, x = 0;
                         if (!a.tab_exact) {
                             for (uint32_t c = 0; c < lp; ++c) {
@@ -1968,7 +2258,44 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
             sync();
             const unsigned long long pd = a.prof ? wall_clock64() : 0;
             pk[3] += pd - pc;
-            if (miss_any) { err = 2; break; }
+            if (miss_any) { err = COLORED ? 64 : 2; break; }
+            if (COLORED) {
+                // src/CCDBG.cpp:3236-3339, 3374-3475: per allele group its strings in set order; a colour the string's mapping carries
+                // in full adds the string's mean to [colour][group]; a failed range test of such a colour, or a colour no string
+                // carries, drops the site.  Lane c keeps colour c's sums.
+                bool ok = true;
+                uint64_t seen = 0;
+                for (uint32_t gi = 0; gi < maxnum; ++gi) {
+                    double tc = 0.0;
+                    uint32_t last = 0;
+                    bool have_last = false;
+                    while (ok) {
+                        uint32_t best = 0xFFFFFFFFu, bp = 0;
+                        for (uint32_t p = 0; p < R; ++p) {
+                            if (grp[p] != gi + 1 || dup[p]) continue;
+                            const uint32_t rk = rank[p];
+                            if (have_last && rk <= last) continue;
+                            if (rk < best) { best = rk; bp = p; }
+                        }
+                        if (best == 0xFFFFFFFFu) break;
+                        const uint64_t m = cmask[bp];
+                        seen |= m;
+                        if (m & ~cokm[bp]) { ok = false; break; }
+                        if ((uint32_t)lane < C && ((m >> lane) & 1)) tc += cmean[(size_t)bp * C + lane];
+                        last = best;
+                        have_last = true;
+                    }
+                    if ((uint32_t)lane < C && room) a.sv[vcur + (uint64_t)lane * maxnum + gi] = tc;
+                }
+                const uint64_t all_colours = C >= 64 ? ~0ull : ((1ull << C) - 1);
+                const bool valid = ok && seen == all_colours;
+                if (lane == 0 && room) a.sv[vcur + (uint64_t)C * maxnum] = valid ? 1.0 : 0.0;
+                if (lane == 0) a.osites[r.site_off + si].pad_ = valid ? 1 : 0;
+                vcur += (uint64_t)C * maxnum + 1;
+                sync();
+                if (a.prof) pk[4] += wall_clock64() - pd;
+                continue;
+            }
             // group coverages in set order; the first string out of range drops the site (src/CDBG.cpp:1527-1551)
             bool ok = true;
             double total = 0.0;
@@ -2035,7 +2362,47 @@ struct FmtArgs {
     const uint64_t *offs;     // exclusive scan of sizes, one run over all streams
     char *out[N_STREAMS];
     CallCounters *cnt;
+    // colored (CCDBG): a site gives one row per colour that sees two allele groups or more (src/CCDBG.cpp:2971-3059, 3236-3339)
+    uint32_t n_colors, N;
+    int k;
+    const uint64_t *full, *ccov_sum;
 };
+
+// computeCramerVCoefficient (src/CCDBG.cpp:330-366) on rows ca and cb of a [colour][allele] coverage matrix given as val(colour, allele)
+template <class Val>
+__device__ inline double cramer_v_dev(const Val &val, uint32_t ca, uint32_t cb, uint32_t n_alleles) {
+#pragma clang fp contract(off)
+    double n = 0, nA = 0, nB = 0, chi = 0;
+    uint32_t count = 0;
+    for (uint32_t i = 0; i < n_alleles; ++i) {
+        const double A = val(ca, i), B = val(cb, i), p = A + B;
+        nA += A;
+        nB += B;
+        n = n + p;
+        if (p != 0) ++count;
+    }
+    if ((count & 255u) < 2) return 0;   // (the reference counts in a uint8_t)
+    for (uint32_t i = 0; i < n_alleles; ++i) {
+        const double A = val(ca, i), B = val(cb, i), p = A + B;
+        if (p == 0) continue;
+        const double exA = nA * p / n, exB = nB * p / n;
+        const double dA = A - exA, dB = B - exB;
+        chi += dA * dA / exA;   // pow(x, 2) is x * x, correctly rounded, in glibc as here
+        chi += dB * dB / exB;
+    }
+    return sqrt(chi / n);
+}
+// the largest over all colour pairs (:2964-2970, 3285-3291); std::max keeps its first argument when the second is NaN
+template <class Val>
+__device__ inline double max_cramer_v_dev(const Val &val, uint32_t n_colors, uint32_t n_alleles) {
+    double c = 0;
+    for (uint32_t ci = 0; ci + 1 < n_colors; ++ci)
+        for (uint32_t cj = ci + 1; cj < n_colors; ++cj) {
+            const double v = cramer_v_dev(val, ci, cj, n_alleles);
+            c = c < v ? v : c;
+        }
+    return c;
+}
 
 template <bool W>
 struct Row {  // one output stream position: a pointer when writing, a byte count when measuring
@@ -2056,7 +2423,7 @@ constexpr uint32_t FMT_BLOCK = 128;
 constexpr uint32_t FMT_STAGE[4] = {12288, 2048, 2048, 3072};   // alignseq, allele_frequency, bifre, bicov
 constexpr int FMT_STAGED_STREAM[4] = {1, 0, 2, 6};
 
-template <bool W>
+template <bool W, bool COLORED>
 __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
     const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index inside the text batch (sizes / offsets)
     const uint32_t j = a.j0 + jj;                                // ... inside the aligned batch (results, numbering, site values)
@@ -2152,6 +2519,94 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                 }
                 const uint32_t maxnum = sr.maxnum;
                 if (sr.is_indel) ++indel;  // counted even when the site is dropped below (src/CDBG.cpp:1526)
+                if (COLORED) {
+                    const uint32_t C = a.n_colors;
+                    const double *cvals = nullptr;
+                    if (!t.strict) {
+                        cvals = a.sv + vcur;
+                        vcur += (uint64_t)C * maxnum + 1;
+                        if (!sr.pad_) continue;   // a string failed a colour's range test, or some colour covers no string (:3292-3300)
+                    }
+                    // strict: the [colour][path] matrix of the scan, again from K-COV-C's results (an entry = the mean coverage of the
+                    // path's unitig in a colour that has it in full, else 0), paths as sorted there
+                    uint64_t fm[4] = {0, 0, 0, 0};
+                    uint32_t wu[4] = {0, 0, 0, 0}, lk[4] = {1, 1, 1, 1};
+                    if (t.strict)
+                        for (uint32_t p = 0; p < R && p < 4; ++p) {
+                            wu[p] = t.inner[p] >> 1;
+                            fm[p] = a.full[wu[p]];
+                            lk[p] = a.len[wu[p]] - (uint32_t)a.k + 1;
+                        }
+                    auto m_at = [&](uint32_t c, uint32_t p) -> double {
+                        const uint32_t q = p < 4 ? p : 3;
+                        return ((fm[q] >> c) & 1) ? (double)a.ccov_sum[(size_t)c * a.N + wu[q]] / (double)lk[q] : 0.0;
+                    };
+                    auto gc_at = [&](uint32_t c, uint32_t x) -> double {   // coverage of allele group x in colour c
+                        if (!t.strict) return cvals[(size_t)c * maxnum + x];
+                        double tc = 0.0;
+                        for (uint32_t p = 0; p < R; ++p)
+                            if ((uint32_t)grp[p] - 1 == x) tc += m_at(c, p);
+                        return tc;
+                    };
+                    const double coefficient = t.strict ? max_cramer_v_dev(m_at, C, R) : max_cramer_v_dev(gc_at, C, maxnum);
+                    for (uint32_t c = 0; c < C; ++c) {
+                        uint32_t n_res = 0;
+                        double sum = 0;
+                        for (uint32_t x = 0; x < maxnum; ++x) {
+                            const double v = gc_at(c, x);
+                            if (v > 0.0) { ++n_res; sum += v; }
+                        }
+                        if (n_res < 2) continue;
+                        const int ar = (int)n_res - 2;
+                        Row<W> cov = ar == 0 ? s_cov[0] : ar == 1 ? s_cov[1] : ar == 2 ? s_cov[2] : s_cov[3];
+                        Row<W> fre = ar == 0 ? s_fre[0] : ar == 1 ? s_fre[1] : ar == 2 ? s_fre[2] : s_fre[3];
+                        const bool filed = ar <= 3;
+                        for (uint32_t x = 0; x < maxnum; ++x) {
+                            const double v = gc_at(c, x);
+                            if (!(v > 0.0)) continue;
+                            if (filed) { put_double(cov, v); cov.put('\t'); }
+                            const double fr = v / sum;
+                            if (filed) {
+                                if (W) {
+                                    char *before = fre.p;
+                                    put_double(fre, fr);
+                                    fre.put('\n');
+                                    for (char *ch = before; ch < fre.p; ++ch) *s_all.p++ = *ch;
+                                } else {
+                                    const uint32_t before = fre.n;
+                                    put_double(fre, fr);
+                                    fre.put('\n');
+                                    s_all.n += fre.n - before;
+                                }
+                            } else {
+                                put_double(s_all, fr);
+                                s_all.put('\n');
+                            }
+                        }
+                        if (filed) {
+                            put_uint(cov, c);
+                            cov.put('\t');
+                            cov.put(t.strict ? '1' : '0'); cov.put('\t');
+                            if (sr.is_indel) put_uint(cov, ilen[indel - 1]);
+                            else cov.put('0');
+                            cov.put('\t');
+                            put_uint(cov, my_vc);
+                            cov.put('\t');
+                            put_uint(cov, ns);
+                            cov.put('\t');
+                            put_double(cov, coefficient);
+                            cov.put('\t');
+                            put_uint(cov, vd);
+                            cov.put('\t'); cov.put('\n');
+                            ++allele[ar];
+                            if (ar == 0) { s_cov[0] = cov; s_fre[0] = fre; }
+                            else if (ar == 1) { s_cov[1] = cov; s_fre[1] = fre; }
+                            else if (ar == 2) { s_cov[2] = cov; s_fre[2] = fre; }
+                            else { s_cov[3] = cov; s_fre[3] = fre; }
+                        }
+                    }
+                    continue;
+                }
                 double denom;
                 const double *vals = nullptr;
                 if (t.strict) {
@@ -2511,7 +2966,72 @@ int pf_superbubble_fetch(pf_ctx *ctx, char *dst, uint64_t len) {
     return PF_OK;
 }
 
+int pf_call_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_mask, const uint64_t *size_total, const uint32_t *part_first,
+                        const uint32_t *part_colour, const uint64_t *part_word, const uint64_t *part_bits, uint64_t n_part, uint64_t n_words) {
+    if (!ctx || !ctx->d_seq) { if (ctx) pf::CtxErr{ctx} = "pf_call_set_colours: graph first"; return PF_ERR_ARG; }
+    PF_HIP(hipSetDevice(ctx->device));
+    CallState *S = state_of(ctx);
+    S->n_colors = 0;
+    S->have_cov = false;
+    if (!n_colors) return PF_OK;
+    if (n_colors > PF_MAX_COLORS || n_colors != ctx->n_colors || !full_mask || !size_total || !part_first || (n_part && (!part_colour || !part_word)) ||
+        (n_words && !part_bits)) {
+        pf::CtxErr{ctx} = "pf_call_set_colours: the colour sets of every unitig, for the colours of the uploaded databases, are required";
+        return PF_ERR_ARG;
+    }
+    const size_t N = ctx->N;
+    if (!S->col_low.ensure((size_t)n_colors * 4) || !S->col_up.ensure((size_t)n_colors * 4) || !S->col_full.ensure(N * 8) || !S->col_size.ensure(N * 8) ||
+        !S->part_first.ensure((N + 1) * 4) || !S->part_colour.ensure((n_part + 1) * 4) || !S->part_word.ensure((n_part + 1) * 8) ||
+        !S->part_bits.ensure((n_words + 1) * 8)) {
+        pf::CtxErr{ctx} = "pf_call_set_colours: out of device memory";
+        return PF_ERR_HIP;
+    }
+    hipStream_t st = ctx->stream;
+    PF_HIP(hipMemsetAsync(S->col_low.p, 0, (size_t)n_colors * 4, st));
+    PF_HIP(hipMemsetAsync(S->col_up.p, 0xFF, (size_t)n_colors * 4, st));
+    PF_HIP(hipMemcpyAsync(S->col_full.p, full_mask, N * 8, hipMemcpyDefault, st));
+    PF_HIP(hipMemcpyAsync(S->col_size.p, size_total, N * 8, hipMemcpyDefault, st));
+    PF_HIP(hipMemcpyAsync(S->part_first.p, part_first, (N + 1) * 4, hipMemcpyDefault, st));
+    if (n_part) {
+        PF_HIP(hipMemcpyAsync(S->part_colour.p, part_colour, n_part * 4, hipMemcpyDefault, st));
+        PF_HIP(hipMemcpyAsync(S->part_word.p, part_word, n_part * 8, hipMemcpyDefault, st));
+    }
+    if (n_words) PF_HIP(hipMemcpyAsync(S->part_bits.p, part_bits, n_words * 8, hipMemcpyDefault, st));
+    PF_HIP(hipStreamSynchronize(st));
+    S->n_colors = n_colors;
+    return PF_OK;
+}
+
+int pf_call_set_cutoffs(pf_ctx *ctx, uint32_t n_colors, const uint32_t *lower, const uint32_t *upper) {
+    if (!ctx || !ctx->call || !ctx->call->n_colors || n_colors != ctx->call->n_colors || !lower || !upper) {
+        if (ctx) pf::CtxErr{ctx} = "pf_call_set_cutoffs: pf_call_set_colours first; one (lower, upper) per colour";
+        return PF_ERR_ARG;
+    }
+    PF_HIP(hipSetDevice(ctx->device));
+    CallState *S = ctx->call;
+    PF_HIP(hipMemcpyAsync(S->col_low.p, lower, (size_t)n_colors * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(S->col_up.p, upper, (size_t)n_colors * 4, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    return PF_OK;
+}
+
 int pf_call_coverage(pf_ctx *ctx) {
+    if (ctx && ctx->call && ctx->call->n_colors) {
+        // colored: CCDBG::readCovUni for every (colour, unitig), left where the scan, K-SITES and K-TEXT read it
+        if (!ctx->d_seq || !ctx->d_ctab) { pf::CtxErr{ctx} = "pf_call_coverage: graph and count tables first"; return PF_ERR_ARG; }
+        PF_HIP(hipSetDevice(ctx->device));
+        CallState *S = ctx->call;
+        const size_t n = (size_t)ctx->N * S->n_colors;
+        if (!S->ccov_sum.ensure(n * 8) || !S->ccov_min.ensure(n * 4) || !S->ccov_max.ensure(n * 4) || !S->ccov_miss.ensure(n)) {
+            pf::CtxErr{ctx} = "pf_call_coverage: out of device memory";
+            return PF_ERR_HIP;
+        }
+        const int st = pf_unitig_cov_colored(ctx, 0, ctx->N, S->ccov_sum.as<uint64_t>(), S->ccov_min.as<uint32_t>(), S->ccov_max.as<uint32_t>(), S->ccov_miss.as<uint8_t>());
+        if (st != PF_OK) return st;
+        S->per_strand = false;
+        S->have_cov = true;
+        return PF_OK;
+    }
     if (!ctx || !ctx->d_seq || !ctx->d_tab) { if (ctx) pf::CtxErr{ctx} = "pf_call_coverage: graph and count table first"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     CallState *S = state_of(ctx);
@@ -2569,8 +3089,12 @@ int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides)
     a.per_strand = S->per_strand; a.low = lower; a.up = upper;
     a.side_base = S->side_base.as<uint32_t>(); a.sides = S->sides.as<pf_call_side>(); a.tasks = S->ctask.as<CallTask>();
     a.target = S->target.as<uint32_t>();
+    a.n_colors = S->n_colors;
+    a.ccov_sum = S->ccov_sum.as<uint64_t>(); a.ccov_min = S->ccov_min.as<uint32_t>(); a.ccov_max = S->ccov_max.as<uint32_t>(); a.ccov_miss = S->ccov_miss.as<uint8_t>();
+    a.clow = S->col_low.as<uint32_t>(); a.cup = S->col_up.as<uint32_t>(); a.full = S->col_full.as<uint64_t>(); a.size_total = S->col_size.as<uint64_t>();
     ctx_begin(ctx, PF_K_CALL_SCAN);
-    k_call_sides<<<(N + 255) / 256, 256, 0, st>>>(a);
+    if (S->n_colors) k_call_sides<true><<<(N + 255) / 256, 256, 0, st>>>(a);
+    else k_call_sides<false><<<(N + 255) / 256, 256, 0, st>>>(a);
     ctx_end(ctx);
     ctx_units(ctx, PF_K_CALL_SCAN, N);
     PF_HIP(hipGetLastError());
@@ -2690,7 +3214,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     CallCounters hc;
     // K-PATHS scratch: stacks sized by the complex size (a non-complex bubble has at most that many vertices)
     const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
-    const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (6ull * depth_cap + 4) * 4) + 255) & ~255ull;
+    const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (10ull * depth_cap + 4) * 4) + 255) & ~255ull;
     static const int paths_per_cu = [] { const char *e = getenv("PF_PATHS_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
     const int paths_grid = ctx->n_cu * paths_per_cu;
     NEED(S->paths_scr, paths_per_wave * paths_grid);
@@ -2731,7 +3255,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     uint64_t n_jobs = 0;
     for (int attempt = 0;; ++attempt) {
         if (attempt > 5) { pf::CtxErr{ctx} = "pf_call_align: pools do not converge"; return PF_ERR_OVERFLOW; }
-        const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 1024);
+        const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 128ull * paths_grid + 1024);   // (a started piece per wavefront)
         const uint64_t text_cap = std::max<uint64_t>(S->text_pool, (uint64_t)nb * 32 + (1u << 16));
         const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, 256ull * nb + (1u << 16));   // (what a first pass takes: 230 B per bubble at k = 25; learnt afterwards)
         const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, 2ull * nb + 64);
@@ -2739,6 +3263,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, nb / 2 + 64);
         NEED(S->bpath, ((size_t)4 * nb + path_cap) * sizeof(pf_bubble_path));
         NEED(S->ptext, text_cap);
+        const uint64_t walk_cap = S->n_colors ? std::max<uint64_t>(S->walk_cap, (uint64_t)nb * 2 + 256ull * paths_grid + 1024) : 0;
+        if (S->n_colors) {
+            NEED(S->walk_pool, walk_cap * 4);
+            NEED(S->walk_off, (size_t)nb * 8);
+        }
         NEED(O.otext, cap_text);
         NEED(O.osites, cap_sites * sizeof(pf_bubble_site));
         NEED(O.ogroups, cap_groups);
@@ -2780,6 +3309,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
             ph.klist = pa.lists.klist_b; ph.stack_ok = pa.stack_ok;
             ph.tlist = pa.lists.tlist; ph.tlist4 = pa.lists.tlist4; ph.trio_ok = pa.trio_ok;
+            ph.walk_pool = S->n_colors ? S->walk_pool.as<uint32_t>() : nullptr; ph.walk_off = S->walk_off.as<uint64_t>(); ph.walk_cap = walk_cap;
             ctx_begin_on(ctx, PF_K_CALL_PATHS, pst);
             k_call_paths<<<paths_grid, 64, 0, pst>>>(ph);
             ctx_end_on(ctx, pst);
@@ -2930,11 +3460,13 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             fprintf(stderr, "[pf_call_align] attempt %d: %u bubbles, path pool %llu of %llu, path text %llu of %llu, rows text cap %llu (needs %llu)\n", attempt, nb,
                     (unsigned long long)hc.path_head, (unsigned long long)path_cap, (unsigned long long)hc.text_head, (unsigned long long)text_cap,
                     (unsigned long long)cap_text, (unsigned long long)(3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb));
-        if (hc.path_head > path_cap || hc.text_head > text_cap) {
+        if (hc.path_head > path_cap || hc.text_head > text_cap || hc.walk_head > walk_cap) {
             S->path_pool = std::max<uint64_t>(S->path_pool, hc.path_head + hc.path_head / 8 + 1024);
             S->text_pool = std::max<uint64_t>(S->text_pool, hc.text_head + hc.text_head / 8 + 4096);
+            if (S->n_colors) S->walk_cap = std::max<uint64_t>(S->walk_cap, hc.walk_head + hc.walk_head / 8 + 1024);
             continue;
         }
+        if (S->n_colors) S->walk_cap = std::max(S->walk_cap, walk_cap);
         // the aligned rows of the branching bubbles come on top of what K-SNP took: make room before K-BUBBLE runs
         // (the path text is handed out in per-wavefront chunks: its size varies by a few per mille from pass to pass, hence the margin)
         if (cap_text < 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb) {
@@ -2987,12 +3519,13 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);
     if (hc.n_branching) {
-        const uint64_t sites_per_wave = (((uint64_t)512 * KS + 256ull * (4 + 4 + 4 + 1 + 1 + 8)) + 255) & ~255ull;
+        const uint32_t C = S->n_colors;
+        const uint64_t sites_per_wave = (((uint64_t)512 * KS + 256ull * (4 + 4 + 4 + 1 + 1 + 8) + (C ? 256ull * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
         static const int sites_per_cu = [] { const char *e = getenv("PF_SITES_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
         const int sites_grid = (int)std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu));
         NEED(S->sites_scr, sites_per_wave * sites_grid);
         for (int attempt = 0;; ++attempt) {
-            const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * hc.n_branching + 1024ull * sites_grid + 1024);   // (a started chunk per wavefront)
+            const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * std::max<uint32_t>(C, 1) * hc.n_branching + 1024ull * sites_grid + 1024);   // (a started chunk per wavefront)
             NEED(O.sv, sv_cap * 8);
             SiteArgs sa;
             sa.ct = S->ctask.as<CallTask>(); sa.kept = S->kept.as<uint32_t>(); sa.t0 = t0; sa.blist = S->blist.as<uint32_t>();
@@ -3001,6 +3534,12 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sa.one_strand = ctx->tab_one_strand; sa.tab_exact = ctx->tab_exact; sa.low = S->low; sa.up = S->up; sa.ks = KS;
             sa.scratch = S->sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
             sa.sv = O.sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
+            sa.n_colors = C;
+            sa.ctab = CTab{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift}; sa.c_one_strand = ctx->ctab_one_strand; sa.c_unread = ctx->ctab_unread;
+            sa.clow = S->col_low.as<uint32_t>(); sa.cup = S->col_up.as<uint32_t>(); sa.full = S->col_full.as<uint64_t>();
+            sa.part_first = S->part_first.as<uint32_t>(); sa.part_colour = S->part_colour.as<uint32_t>(); sa.part_word = S->part_word.as<uint64_t>();
+            sa.part_bits = S->part_bits.as<uint64_t>(); sa.walk_pool = S->walk_pool.as<uint32_t>(); sa.walk_off = S->walk_off.as<uint64_t>();
+            sa.seq = ctx->d_seq; sa.off = ctx->d_off; sa.len = ctx->d_len;
             static const bool sites_stats = getenv("PF_SITES_STATS") != nullptr;   // measurements: where a wavefront's time goes
             DevTmp<unsigned long long> sprof_;
             sa.prof = nullptr;
@@ -3013,7 +3552,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             PF_HIP(hipMemsetAsync(&d_cnt->sv_head, 0, 8, st));
             PF_HIP(hipMemsetAsync(&d_cnt->site_strings, 0, 8, st));
             ctx_begin(ctx, PF_K_CALL_SITES);
-            k_call_sites<<<sites_grid, 64, 0, st>>>(sa);
+            if (C) k_call_sites<true><<<sites_grid, 64, 0, st>>>(sa);
+            else k_call_sites<false><<<sites_grid, 64, 0, st>>>(sa);
             ctx_end(ctx);
             ctx_units(ctx, PF_K_CALL_SITES, hc.n_branching);
             PF_HIP(hipGetLastError());
@@ -3035,6 +3575,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             if (hc.err & 2u) { pf::CtxErr{ctx} = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
             if (hc.err & 4u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): site string outside an aligned row"; return PF_ERR_ARG; }
             if (hc.err & 16u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): site string longer than 2k + 64"; return PF_ERR_ARG; }
+            if (hc.err & 64u) { pf::CtxErr{ctx} = "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble"; return PF_ERR_ARG; }
             if (hc.sv_head > sv_cap) {
                 if (attempt >= 2) { pf::CtxErr{ctx} = "pf_call_run: site value pool does not converge"; return PF_ERR_OVERFLOW; }
                 S->sv_pool = hc.sv_head + hc.sv_head / 8 + 1024;
@@ -3119,10 +3660,10 @@ int pf_call_reserve(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size) {
     for (DevBuf *b : {&S->blist, &S->slist, &S->plist, &S->plist2, &S->klist, &S->klist_b, &S->tlist, &S->tlist4, &S->has}) NEED(*b, (size_t)nb * 4);
     NEED(S->stack_scr, stack_scratch_bytes() * (uint64_t)(ctx->n_cu * 8));
     const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
-    const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (6ull * depth_cap + 4) * 4) + 255) & ~255ull;
+    const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (10ull * depth_cap + 4) * 4) + 255) & ~255ull;
     NEED(S->paths_scr, paths_per_wave * (uint64_t)(ctx->n_cu * 16));
     NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * (uint64_t)(ctx->n_cu * 12));
-    NEED(S->bpath, ((size_t)4 * nb + (uint64_t)nb / 2 + 1024) * sizeof(pf_bubble_path));
+    NEED(S->bpath, ((size_t)4 * nb + (uint64_t)nb / 2 + 128ull * (ctx->n_cu * 16) + 1024) * sizeof(pf_bubble_path));
     NEED(S->ptext, (uint64_t)nb * 32 + (1u << 16));
     NEED(S->scan_tmp2, (size_t)nb / 4 * 4 + 4096);
     for (CallState::AlignOut &O : S->lane) {
@@ -3204,7 +3745,9 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     for (int s = 0; s < N_STREAMS; ++s) fa.out[s] = nullptr;
     size_t at = 0;
     ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
-    k_call_format<false><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
+    fa.n_colors = S->n_colors; fa.N = ctx->N; fa.k = ctx->k; fa.full = S->col_full.as<uint64_t>(); fa.ccov_sum = S->ccov_sum.as<uint64_t>();
+    if (S->n_colors) k_call_format<false, true><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
+    else k_call_format<false, false><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end_at(ctx, at, st);
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->tscan.p, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
     k_call_totals<<<1, 64, 0, st>>>(S->offs.as<uint64_t>(), S->sizes.as<uint32_t>(), nb, S->totals.as<uint64_t>());
@@ -3224,7 +3767,8 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
         all += totals[s];
     }
     ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
-    k_call_format<true><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
+    if (S->n_colors) k_call_format<true, true><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
+    else k_call_format<true, false><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end_at(ctx, at, st);
     ctx_units(ctx, PF_K_CALL_FORMAT, nb);
     PF_HIP(hipGetLastError());

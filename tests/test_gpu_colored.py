@@ -203,3 +203,29 @@ def test_pipeline_batches_colored(tmp_path):
     run.find_superbubbles("g")
     run.ploidy_estimation("g", meta["cutoffs"])
     assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path / "out"))
+
+
+@pytest.mark.parametrize("case", colored_cases())
+def test_colored_calling_on_the_resident_pipeline_and_on_the_host(case, tmp_path, monkeypatch):
+    """CCDBG::ploidyEstimation_ptr runs on the resident pipeline (pf_call_set_colours: colored K-SCAN, K-SITES, K-TEXT around the
+    shared alignment tiers); PF_CALL=host keeps round 1's host-threaded pipeline.  Both give the reference's files."""
+    meta = load_case(case)
+    op = meta["opts"]
+    kw = dict(z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    jobs = {}
+    for mode in ("resident", "host"):
+        if mode == "host":
+            monkeypatch.setenv("PF_CALL", "host")
+        else:
+            monkeypatch.delenv("PF_CALL", raising=False)
+        out = tmp_path / mode
+        run = hostapi.ColoredRun(meta["gfa"], meta["colors"], meta["dbs"], str(tmp_path), **kw)
+        run.set_output_dir(str(out))
+        run.set_unitig_id("g")
+        run.find_superbubbles("g")
+        run.ploidy_estimation("g", meta["cutoffs"])
+        assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(out)), mode
+        t = run.times()
+        jobs[mode] = (t["align_jobs"], t["snp_jobs"] + t["pair_jobs"] + t["stack_jobs"] + t["trio_jobs"] + t["wave_jobs"])
+    assert jobs["resident"][0] > 0 and jobs["resident"][1] == jobs["resident"][0], jobs   # every job accounted to a device tier
+    assert jobs["host"][1] == 0, jobs
