@@ -89,6 +89,7 @@ def make_colored_inputs(workdir: str, name: str, genome_len: int, seed: int, dev
     off = np.asarray(g["off"], dtype=np.int64)
     codes = np.asarray(g["codes"], dtype=np.uint8)
     n_unitigs = len(off) - 1
+    log("colored inputs %s: graph of %d unitigs built (%.1fs); colour sets and databases next" % (name, n_unitigs, time.time() - t0))
     sizes = np.diff(off)
     km_per = sizes - k + 1
     # canonical k-mer of every (unitig, position): all windows of the concatenated text minus those spanning a boundary
@@ -115,6 +116,7 @@ def make_colored_inputs(workdir: str, name: str, genome_len: int, seed: int, dev
         cnt = np.add.reduceat(has.astype(np.int64), first)
         full_mask |= (cnt == km_per).astype(np.uint64) << np.uint64(s_)
         present.append((has, cnt))
+        log("colored inputs %s: database and colour of sample %d (%.1fs)" % (name, s_, time.time() - t0))
     partial_ids = {}
     part = np.zeros(n_unitigs, dtype=bool)
     for has, cnt in present:
@@ -128,6 +130,7 @@ def make_colored_inputs(workdir: str, name: str, genome_len: int, seed: int, dev
     colors = os.path.join(workdir, name + ".bfg_colors")
     da = bfg_colors.write_bfg_colors(colors, heads, sizes, k, ["sample%d" % s_ for s_ in range(samples)], full_mask=full_mask,
                                      partial_ids=partial_ids)
+    log("colored inputs %s: colour file written (%.1fs)" % (name, time.time() - t0))
     gfa = os.path.join(workdir, name + ".gfa")
     cdbg_build.write_gfa(gfa, g, da_tags=da)
     log("colored inputs %s: genome %d bp, %d samples x%d -> %d unitigs, %d k-mers, %d unitigs with a partial colour (%.1fs)" %
@@ -279,7 +282,7 @@ def main():
         genome = int(args.unitigs / UNITIGS_PER_BP)
         colored = args.workload == "colored"
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
-        strong = args.scaling == "strong" and world > 1 and args.workload == "single"
+        strong = args.scaling == "strong" and world > 1
         seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + (0 if strong else rank)
         if colored:
             n_samples = 3
@@ -321,7 +324,7 @@ def main():
                     pfdist.sharded_find(run, "b", xdev, shard_stats)
                 else:
                     run.find_superbubbles("b")   # on every rank; rank 0 writes b_super_bubble.txt
-                totals_, counters_ = pfdist.sharded_ploidy(run, "b", LOWER, UPPER, xdev, shard_stats)
+                totals_, counters_ = pfdist.sharded_ploidy(run, "b", LOWER, UPPER, xdev, shard_stats, cutoffs=cutoffs if colored else None)
                 shard_stats["counters"] = [int(x) for x in counters_]
                 shard_stats["output_bytes"] = int(totals_.sum())
                 return
@@ -417,7 +420,10 @@ def main():
                 run.set_output_dir(alone)
                 run.set_unitig_id("b")
                 run.find_superbubbles("b")
-                run.ploidy_estimation("b", LOWER, UPPER)
+                if colored:
+                    run.ploidy_estimation("b", cutoffs)
+                else:
+                    run.ploidy_estimation("b", LOWER, UPPER)
                 want = digest(alone)
                 sharded_identical = {"files": len(names), "identical": got == want,
                                      "differing": [f for f in names if got[f] != want.get(f)]}

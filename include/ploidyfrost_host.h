@@ -169,6 +169,8 @@ void pfh_set_replay_threads(pfh_run *, int threads);
  * <outpre>_super_bubble.txt (the rows are computed everywhere; PloidyEstimation does not need the file) */
 void pfh_set_write_super_bubble(pfh_run *, int on);
 int pfh_ploidy_select(pfh_run *, int lower, int upper, uint64_t *n_bubbles);
+/* the same for a colored run (pfh_open_colored): one (lower, upper) per colour, the reference's -C file (src/Main.cpp:775-810) */
+int pfh_ploidy_select_colored(pfh_run *, const int *lower, const int *upper, int n_cutoffs, uint64_t *n_bubbles);
 int pfh_ploidy_align(pfh_run *, uint64_t t0, uint64_t t1, uint64_t *n_called);
 int pfh_ploidy_text(pfh_run *, uint64_t var_count_base, uint64_t sizes[10], uint64_t counters[8]);
 int pfh_ploidy_write(pfh_run *, const char *outpre, const uint64_t offsets[10], const uint64_t totals[10], int truncate);

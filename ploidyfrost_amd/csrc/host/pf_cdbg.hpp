@@ -139,6 +139,7 @@ public:
     // one graph on several ranks with findSuperBubble run by each of them: only one rank writes <outpre>_super_bubble.txt
     void set_write_super_bubble(bool on) { write_sb_ = on; }
     int ploidy_select(int lower, int upper, uint64_t &n_bubbles);
+    int ploidy_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &n_bubbles);   // colored: one pair per colour
     int ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called);
     int ploidy_text(uint64_t var_count_base, uint64_t sizes[PF_CALL_STREAMS], uint64_t counters[8]);
     int ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL_STREAMS], const uint64_t totals[PF_CALL_STREAMS], bool truncate);

@@ -99,16 +99,20 @@ int CDBG::call_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &
 }
 
 // ---- the same in steps, for a bubble list cut over several ranks ----
-int CDBG::ploidy_select(int lower, int upper, uint64_t &n_bubbles) {
+int CDBG::ploidy_select(int lower, int upper, uint64_t &n_bubbles) { return ploidy_select(std::vector<std::pair<int, int>>{{lower, upper}}, n_bubbles); }
+
+int CDBG::ploidy_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t &n_bubbles) {
     if (status_) return status_;
-    if (col_) return fail(PF_ERR_ARG, "CDBG::ploidy_select(): single-sample path only");
+    if (col_ && !colored_resident_) return fail(PF_ERR_ARG, "CCDBG::ploidy_select(): the colour sets are not on the device (PF_CALL=host?)");
+    if (cutoff.size() != (col_ ? col_->n_colors : 1u))
+        return fail(PF_ERR_ARG, std::string(tag_) + "::ploidy_select(): one (lower, upper) cutoff" + (col_ ? " per colour" : "") + " is required");
     times_.tasks = times_.align_jobs = times_.site_strings = 0;
     times_.snp_jobs = times_.pair_jobs = times_.wave_jobs = times_.stack_jobs = times_.trio_jobs = 0;
     allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
     core_cov_ = core_num_ = 0;
     const bool keep = resident_;
     resident_ = true;   // coverage must land in the device arrays the scan reads
-    const int rc = call_select({{lower, upper}}, n_bubbles);
+    const int rc = call_select(cutoff, n_bubbles);
     resident_ = keep;
     return rc;
 }

@@ -168,6 +168,16 @@ void pfh_set_write_super_bubble(pfh_run *r, int on) { r->cdbg->set_write_super_b
 int pfh_ploidy_select(pfh_run *r, int lower, int upper, uint64_t *n_bubbles) {
     return guarded(r, [&] { uint64_t n = 0; const int rc = r->cdbg->ploidy_select(lower, upper, n); if (n_bubbles) *n_bubbles = n; return rc; });
 }
+int pfh_ploidy_select_colored(pfh_run *r, const int *lower, const int *upper, int n_cutoffs, uint64_t *n_bubbles) {
+    return guarded(r, [&] {
+        std::vector<std::pair<int, int>> cut;
+        for (int c = 0; c < n_cutoffs; ++c) cut.push_back({lower[c], upper[c]});
+        uint64_t n = 0;
+        const int rc = r->cdbg->ploidy_select(cut, n);
+        if (n_bubbles) *n_bubbles = n;
+        return rc;
+    });
+}
 int pfh_ploidy_align(pfh_run *r, uint64_t t0, uint64_t t1, uint64_t *n_called) {
     return guarded(r, [&] { uint64_t n = 0; const int rc = r->cdbg->ploidy_align(t0, t1, n); if (n_called) *n_called = n; return rc; });
 }

@@ -3612,6 +3612,7 @@ int pf_call_peek(pf_ctx *ctx, int lane, pf_call_bubble *bubbles, pf_bubble_resul
     if (!ctx || lane < 0 || lane > 1 || !used) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S) { pf::CtxErr{ctx} = "pf_call_peek: pf_call_align first"; return PF_ERR_ARG; }
+    if (S->n_colors) { pf::CtxErr{ctx} = "pf_call_peek: the single-sample path's view (a colored site holds one value per colour and group)"; return PF_ERR_ARG; }
     const CallState::AlignOut &O = S->lane[lane];
     used[0] = O.nb;
     for (int x = 0; x < 5; ++x) used[x + 1] = O.used[x];
@@ -3699,6 +3700,7 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     if (!S) return PF_ERR_ARG;
     const CallState::AlignOut &O = S->lane[lane];
     if (first + count > O.nb) { pf::CtxErr{ctx} = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
+    if (S->n_colors && S->mt_format) { pf::CtxErr{ctx} = "pf_call_text_range: the -t > 1 format is the single-sample path's"; return PF_ERR_ARG; }
     for (int s = 0; s < N_STREAMS; ++s) S->out_len[slab][s] = 0;
     *out = O.cur;
     out->n_called = 0;

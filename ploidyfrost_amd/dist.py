@@ -129,11 +129,12 @@ def sharded_find(run, outpre: str, device: torch.device, stats: dict | None = No
                     dev_pools=[t.data_ptr() for t in d_pools] if on_gpu and d_pools else None)
 
 
-def sharded_ploidy(run, outpre: str, lower: int, upper: int, device: torch.device, stats: dict | None = None):
-    """PloidyEstimation of one graph over all ranks; all ranks' `run` must share one output directory.
+def sharded_ploidy(run, outpre: str, lower: int, upper: int, device: torch.device, stats: dict | None = None, cutoffs=None):
+    """PloidyEstimation of one graph over all ranks; all ranks' `run` must share one output directory.  cutoffs: a colored run's
+    (lower, upper) per colour (lower / upper are then ignored).
     Returns (totals of the ten files in bytes, counters summed over ranks: sites with 2..5 alleles, coreCov, coreNum, called, bubbles)."""
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_initialized() else (0, 1)
-    n_bubbles = run.ploidy_select(lower, upper)
+    n_bubbles = run.ploidy_select(cutoffs) if cutoffs is not None else run.ploidy_select(lower, upper)
     t0, t1 = shard_range(n_bubbles, rank, world)
     called = run.ploidy_align(t0, t1)
     base = int(all_gather_counters([called], device)[:rank, 0].sum())

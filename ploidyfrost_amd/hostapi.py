@@ -29,7 +29,7 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
                     "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints", "pfh_colors_check_footprints",
-                    "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_set_replay_threads", "pfh_set_write_super_bubble", "pfh_ploidy_select", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
+                    "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_set_replay_threads", "pfh_set_write_super_bubble", "pfh_ploidy_select", "pfh_ploidy_select_colored", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
                     "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
                     "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
 
@@ -101,6 +101,7 @@ def load_library() -> C.CDLL:
     L.pfh_set_write_super_bubble.argtypes = [vp, C.c_int]
     L.pfh_set_write_super_bubble.restype = None
     L.pfh_ploidy_select.argtypes = [vp, C.c_int, C.c_int, C.POINTER(u64)]
+    L.pfh_ploidy_select_colored.argtypes = [vp, vp, vp, C.c_int, C.POINTER(u64)]
     L.pfh_ploidy_align.argtypes = [vp, u64, u64, C.POINTER(u64)]
     L.pfh_ploidy_text.argtypes = [vp, u64, vp, vp]
     L.pfh_ploidy_write.argtypes = [vp, C.c_char_p, vp, vp, C.c_int]
@@ -408,6 +409,14 @@ class ColoredRun(Run):
         lo = (C.c_int * self.n_colors)(*[int(c[0]) for c in cutoffs])
         up = (C.c_int * self.n_colors)(*[int(c[1]) for c in cutoffs])
         self._check(self.L.pfh_ploidy_estimation_colored(self.h, outpre.encode(), lo, up, len(cutoffs)))
+
+    def ploidy_select(self, cutoffs) -> int:
+        """scan + sequential pass with one (lower, upper) per colour; then ploidy_align / ploidy_text / ploidy_write as for Run"""
+        lo = (C.c_int * len(cutoffs))(*[int(c[0]) for c in cutoffs])
+        up = (C.c_int * len(cutoffs))(*[int(c[1]) for c in cutoffs])
+        n = C.c_uint64()
+        self._check(self.L.pfh_ploidy_select_colored(self.h, C.cast(lo, C.c_void_p), C.cast(up, C.c_void_p), len(cutoffs), C.byref(n)))
+        return n.value
 
 
 class Gmm:

@@ -229,3 +229,38 @@ def test_colored_calling_on_the_resident_pipeline_and_on_the_host(case, tmp_path
         jobs[mode] = (t["align_jobs"], t["snp_jobs"] + t["pair_jobs"] + t["stack_jobs"] + t["trio_jobs"] + t["wave_jobs"])
     assert jobs["resident"][0] > 0 and jobs["resident"][1] == jobs["resident"][0], jobs   # every job accounted to a device tier
     assert jobs["host"][1] == 0, jobs
+
+
+@pytest.mark.parametrize("case,world", [("col4_mix", 3), ("col2_weird", 2)])
+def test_colored_graph_cut_over_ranks_in_process(case, world, tmp_path):
+    """ploidyfrost_amd/dist.py with a CCDBG: `world` ranks (here: runs in one process) hold the same colored graph, find their shards
+    of findSuperBubble, replay all of them, select the same bubble list (one cutoff pair per colour), align and format their slices
+    and write their slabs into shared files -- which must be the reference's."""
+    from ploidyfrost_amd import dist as pfdist
+    meta = load_case(case)
+    op = meta["opts"]
+    kw = dict(z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
+    out = str(tmp_path / "shared")
+    runs = []
+    for rank in range(world):
+        run = hostapi.ColoredRun(meta["gfa"], meta["colors"], meta["dbs"], str(tmp_path), **kw)
+        run.set_threads(3)
+        run.set_output_dir(out)
+        runs.append(run)
+    runs[0].set_unitig_id("g")
+    n = runs[0].times()["unitigs"]
+    shards = [runs[r].find_shard(*pfdist.shard_range(n, r, world)) for r in range(world)]
+    for r in range(world):
+        runs[r].find_replay("g", [s[0] for s in shards], [s[1] for s in shards], write_file=r == 0)
+    nb = [run.ploidy_select(meta["cutoffs"]) for run in runs]
+    assert len(set(nb)) == 1 and nb[0] > 0
+    slices = [pfdist.shard_range(nb[0], r, world) for r in range(world)]
+    called = [runs[r].ploidy_align(*slices[r]) for r in range(world)]
+    texts = [runs[r].ploidy_text(int(sum(called[:r]))) for r in range(world)]
+    sizes = np.array([t[0] for t in texts], dtype=np.uint64)
+    totals = sizes.sum(axis=0)
+    for r in reversed(range(world)):
+        runs[r].ploidy_write("g", sizes[:r].sum(axis=0), totals, truncate=True)
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), out)
+    for run in runs:
+        run.close()
