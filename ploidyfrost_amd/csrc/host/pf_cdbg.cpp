@@ -280,6 +280,7 @@ void MappedOut::close_file() {
     base = nullptr;
     map_len = 0;
     backed_lo = backed_hi = 0;
+    finished_once = false;
     fd = -1;
     path.clear();
 }
@@ -360,7 +361,7 @@ int MappedOut::reserve(uint64_t bytes) {
     if (fd < 0) return 1;
     struct stat sb;
     if (fstat(fd, &sb) != 0) return 1;
-    if ((uint64_t)sb.st_size >= bytes / 2) return 1;   // (it has been written before: its pages exist)
+    if (finished_once || (uint64_t)sb.st_size >= bytes / 2) return 1;   // (it has been written before: its pages exist)
     // sized now, backed piece by piece: by populate() on the helper threads, or by prepare() where the writer gets there first
     if (ftruncate(fd, (off_t)bytes) != 0) return 1;
     return map_at_least(bytes) ? 0 : 1;
@@ -381,10 +382,14 @@ int MappedOut::finish(uint64_t final_len) {
     if (fd < 0) return 1;
     struct stat sb;
     if (fstat(fd, &sb) != 0) return 1;
-    if ((uint64_t)sb.st_size != final_len && ftruncate(fd, (off_t)final_len) != 0) return 1;
+    if ((uint64_t)sb.st_size != final_len) {
+        if (getenv("PF_TRACE_PLOIDY")) fprintf(stderr, "[ploidy]   %s cut from %llu to %llu bytes\n", path.c_str(), (unsigned long long)sb.st_size, (unsigned long long)final_len);
+        if (ftruncate(fd, (off_t)final_len) != 0) return 1;
+    }
     // what lay beyond is gone (whoever cut it: every rank of a sharded run passes the same length here before it stores anything)
     backed_hi = std::min(backed_hi, final_len);
     if (backed_hi <= backed_lo) backed_lo = backed_hi = 0;
+    finished_once = true;   // a later pass over the same graph writes about as much: no estimate sizes the file again
     return 0;
 }
 

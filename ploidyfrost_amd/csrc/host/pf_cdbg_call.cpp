@@ -561,10 +561,13 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     if (wst != PF_OK) return fail(wst, std::string(tag_) + "::PloidyEstimation(): " + werr);
     auto t0 = clk::now();
     if (join_pending_write() || join_pending_ids()) return status_;
+    tp("super_bubble.txt joined");
     for (size_t i = 0; i < files.size(); ++i) {
         OutFile &of = files[i];
         out_bytes_ += of.bytes;
+        const auto tfin = clk::now();
         if (write_files_ && maps[i].finish(of.bytes)) of.rc = 1;
+        if (trace) fprintf(stderr, "[ploidy]   %s finished at %llu bytes in %.3f ms\n", of.name.c_str(), (unsigned long long)of.bytes, since(tfin) * 1e3);
         if (of.rc) return fail(PF_ERR_ARG, "CDBG:: write error on " + of.name);
     }
     write_s += since(t0);

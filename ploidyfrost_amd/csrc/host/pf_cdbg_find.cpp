@@ -515,14 +515,17 @@ int CDBG::finish_find(const std::string &outpre, const size_t &thr, clk_time t_a
         join_pending_write();
         sb_text_.ensure(ctx_, std::max<uint64_t>(len, 1));
         const unsigned T = threads_ ? threads_ : 1;
-        auto job = [this, name = outpre + "_super_bubble.txt", len, T]() -> int {
+        auto job = [this, name = outpre + "_super_bubble.txt", len, T, trace_find]() -> int {
+            const auto tj = clk::now();
             if (pf_superbubble_fetch(ctx_, sb_text_.p, len) != PF_OK) return 1;
-                    MappedOut &mo = out_maps_[PF_CALL_STREAMS];   // (the slot after the ten streams of PloidyEstimation)
+            const double t_fetch = since(tj);
+            MappedOut &mo = out_maps_[PF_CALL_STREAMS];   // (the slot after the ten streams of PloidyEstimation)
             if (mo.open_for(outdir_ + "/" + name)) return 1;
             const uint64_t hl = sizeof(kHeader) - 1;
             int rc = mo.write(0, kHeader, hl, 1);
             rc |= mo.write(hl, sb_text_.p, len, T);
             rc |= mo.finish(hl + len);
+            if (trace_find) fprintf(stderr, "[find]   super_bubble.txt: fetched after %.2f ms, in the file after %.2f ms (%.1f MB)\n", t_fetch * 1e3, since(tj) * 1e3, len / 1e6);
             return rc;
         };
         if (overlap_output_) {

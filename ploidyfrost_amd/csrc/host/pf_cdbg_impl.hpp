@@ -55,6 +55,7 @@ struct MappedOut {
     // the mapping into a hole of a sparse file is the first to learn that the disk (or /dev/shm) is full -- as a SIGBUS that takes
     // the process, and the Python interpreter hosting this library, with it; so nothing is stored outside this interval.
     uint64_t backed_lo = 0, backed_hi = 0;
+    bool finished_once = false;   // finish() has given this file a length: reserve() leaves it alone from then on
     std::mutex remap_mu;   // populate() on a helper thread against a remap by prepare() / write() / reserve()
     MappedOut() = default;
     MappedOut(const MappedOut &) = delete;

@@ -2944,11 +2944,14 @@ int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_
     PF_HIP(hipStreamSynchronize(st));
     if (!S->sb_out.ensure(std::max<uint64_t>(len, 16))) { pf::CtxErr{ctx} = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
     a.out = S->sb_out.as<char>();
-    ctx_begin(ctx, PF_K_CALL_FORMAT);
-    k_sb_format<true><<<grid, 256, 0, st>>>(a);
-    ctx_end(ctx);
+    // the write pass runs on the copy stream, in front of pf_superbubble_fetch's copy and beside whatever the caller launches next
+    // (PloidyEstimation's coverage and scan only read the state): the caller has the counts and does not wait for the text
+    hipStream_t wst = S->copy_stream ? S->copy_stream : st;
+    ctx_begin_on(ctx, PF_K_CALL_FORMAT, wst);
+    k_sb_format<true><<<grid, 256, 0, wst>>>(a);
+    ctx_end_on(ctx, wst);
     PF_HIP(hipGetLastError());
-    PF_HIP(hipStreamSynchronize(st));
+    if (wst == st) PF_HIP(hipStreamSynchronize(st));
     S->sb_len = len;
     *n_rows = rows;
     *text_len = len;
