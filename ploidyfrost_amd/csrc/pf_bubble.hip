@@ -1045,8 +1045,8 @@ extern "C" int pf_align_bubbles(pf_ctx *ctx, const char *text, uint64_t text_len
     uint64_t max_need = 0, retry_need = 0;
     for (uint32_t t = 0; t < n_tasks; ++t) {
         const pf_bubble_task &tk = ht[t];
-        if (tk.n_paths < 2 || tk.n_paths > 255 || tk.path_first + tk.n_paths > n_paths) {
-            pf::CtxErr{ctx} = "pf_align_bubbles: a bubble needs 2..255 paths inside the path array";
+        if (tk.n_paths < 2 || tk.n_paths > 65535 || tk.path_first + tk.n_paths > n_paths) {
+            pf::CtxErr{ctx} = "pf_align_bubbles: a bubble needs 2..65535 paths inside the path array";
             return PF_ERR_ARG;
         }
         uint32_t l0 = 0, lmax = 0;

@@ -26,6 +26,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstddef>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -95,13 +96,16 @@ struct CallCounters {
     unsigned int n_stack, n_stack_b, n_stack_done;   // K-STACK's lists (strict bubbles; branching ones, filled by K-PATHS) / the bubbles whose alignment it certified
     unsigned int n_trio, n_trio4, n_trio_done;   // three / four short paths: K-TRIO's lists / the bubbles it finished
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
-    unsigned int err;               // bit 0: > 255 paths, 1: missing k-mer in a site string, 2: site string outside its row,
+    unsigned int n_many, max_rows;         // bubbles of more than 255 walks (K-PATHS' second launch takes them) / the most walks of any bubble
+    unsigned int err;               // bit 0: > 65535 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
     unsigned int err_entrance, err_exit;   // the bubble bits 0 / 5 speak of (oriented vertices; whichever wavefront wrote last)
     unsigned long long path_head, text_head, sv_head, walk_head;
     unsigned long long max_need, retry_need;
     unsigned long long allele[4], core_cov, core_num, n_called, site_strings;
 };
+
+static_assert(offsetof(CallCounters, core_cov) == offsetof(CallCounters, allele) + 32 && offsetof(CallCounters, core_num) == offsetof(CallCounters, allele) + 40, "allele[4], core_cov, core_num are contiguous");
 
 }  // namespace
 
@@ -120,6 +124,7 @@ struct CallState {
     uint32_t n_colors = 0;
     DevBuf col_low, col_up, col_full, col_size, part_first, part_colour, part_word, part_bits;
     DevBuf ccov_sum, ccov_min, ccov_max, ccov_miss;
+    DevBuf mlist, paths_big_scr;  // K-PATHS: bubbles of more than 255 walks, and the scratch of the launch that takes them
     DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
     uint64_t walk_cap = 0;
     // scan
@@ -159,7 +164,7 @@ struct CallState {
     hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
     bool mt_format = false;   // pf_call_set_format
     void release_all() {
-        DevBuf *all[] = {&col_low, &col_up, &col_full, &col_size, &part_first, &part_colour, &part_word, &part_bits, &ccov_sum, &ccov_min, &ccov_max, &ccov_miss, &walk_off, &walk_pool,
+        DevBuf *all[] = {&mlist, &paths_big_scr, &col_low, &col_up, &col_full, &col_size, &part_first, &part_colour, &part_word, &part_bits, &ccov_sum, &ccov_min, &ccov_max, &ccov_miss, &walk_off, &walk_pool,
                          &flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
                          &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &klist_b, &stack_scr, &tlist, &tlist4, &trio_scr, &trio_rows, &trio_ok, &pair_scr, &pair_scr2, &has, &sizes, &offs,
                          &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
@@ -515,9 +520,17 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
         todo &= ~m;
         const int leader = __ffsll((long long)m) - 1;
         uint32_t base = 0;
+        // (the counter's place by one integer select after the other; see paths_flush for why not a nested choice of pointers)
+        uint32_t c_off = (uint32_t)offsetof(CallCounters, n_trio4);
+        c_off = x == KEY_TRIO ? (uint32_t)offsetof(CallCounters, n_trio) : c_off;
+        c_off = x == KEY_STACK ? (uint32_t)offsetof(CallCounters, n_stack) : c_off;
+        c_off = x == KEY_PAIR2 ? (uint32_t)offsetof(CallCounters, n_pair2) : c_off;
+        c_off = x == KEY_PAIR ? (uint32_t)offsetof(CallCounters, n_pair) : c_off;
+        c_off = x == KEY_SNP ? (uint32_t)offsetof(CallCounters, n_snp) : c_off;
+        c_off = x == KEY_BRANCHING ? (uint32_t)offsetof(CallCounters, n_branching) : c_off;
+        c_off = x < NQ ? (uint32_t)offsetof(CallCounters, q_n) + 4u * (uint32_t)x : c_off;
         if (lane_id() == leader)
-            base = atomicAdd(x < NQ ? &cnt->q_n[x] : (x == KEY_BRANCHING ? &cnt->n_branching : (x == KEY_SNP ? &cnt->n_snp : (x == KEY_PAIR ? &cnt->n_pair : (x == KEY_PAIR2 ? &cnt->n_pair2 : (x == KEY_STACK ? &cnt->n_stack : (x == KEY_TRIO ? &cnt->n_trio : &cnt->n_trio4)))))),
-                             (unsigned int)__popcll(m));
+            base = atomicAdd(reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + c_off), (unsigned int)__popcll(m));
         base = __shfl(base, leader, WAVE);
         if (key == x) {
             const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane_id()) - 1));
@@ -1367,6 +1380,12 @@ struct PathArgs {
     uint8_t *scratch;       // per wave, for the bubbles whose stacks outgrow the registers: major[depth_cap], minor[4 depth_cap], seg_start
     uint64_t scratch_per_wave;
     int force_scratch;      // (tests) every bubble walks with the stacks in scratch
+    // A bubble of more than 255 walks leaves the first launch for a list (mlist) and is walked again by a second launch of a few
+    // wavefronts whose path tables lie in global scratch (max_paths entries) instead of LDS.
+    uint32_t max_paths;     // 255 (tables in LDS) or PATHS_BIG
+    const unsigned int *n_list;   // how many entries of blist count
+    uint32_t *mlist;
+    uint32_t mlist_cap;
     // colored: the distinct oriented unitigs the walks of a bubble visit, in the order of their first visit (what CCDBG searches for
     // the first k-mer of a site string, src/CCDBG.cpp:3251, 3390): walk_off[j] = first entry in walk_pool | count << 40
     uint32_t *walk_pool;    // nullptr: single-sample
@@ -1385,7 +1404,8 @@ struct PathArgs {
     CallCounters *cnt;
 };
 
-constexpr uint32_t MAX_PATHS = 255;
+constexpr uint32_t MAX_PATHS = 255;        // walks of one bubble whose tables fit LDS
+constexpr uint32_t PATHS_BIG = 65535;      // ... in the second launch's global tables
 
 // what the walk of one bubble leaves behind; everything wave-uniform
 struct WalkOut {
@@ -1476,7 +1496,7 @@ __device__ inline bool walk_in_registers(const PathArgs &a, const CallTask &t, T
         if ((uint32_t)lane == n_major) { mj = w; ml = a.len[u]; mo = a.off[u]; s0 = r0; s1 = r1; s2 = r2; s3 = r3; }
         ++n_major;
         if (at_exit) {
-            if (o.n_paths >= MAX_PATHS) { o.too_many = true; return true; }
+            if (o.n_paths >= a.max_paths) { o.too_many = true; return true; }
             const uint32_t cnt = (uint32_t)lane < n_major ? (lane == 0 ? 1u : ((uint32_t)lane + 1 == n_major ? K : ml - K + 1)) : 0u;
             const uint32_t incl = scan_u32_dpp<0>(cnt);
             const uint32_t start = incl - cnt;
@@ -1562,7 +1582,7 @@ __device__ __noinline__ void walk_in_scratch(const PathArgs &a, const CallTask &
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
         if ((w >> 1) == eu) {
-            if (o.n_paths >= MAX_PATHS) { o.too_many = true; break; }
+            if (o.n_paths >= a.max_paths) { o.too_many = true; break; }
             uint32_t total = 0;
             for (uint32_t x = 0; x < n_major; ++x) {
                 if (lane == 0) seg_start[x] = total;
@@ -1609,8 +1629,18 @@ __device__ inline void paths_flush(const PathArgs &a, uint32_t pend_key, uint32_
         const uint32_t key = read_lane(pend_key, __ffsll((long long)todo) - 1);
         const bool mine = have && pend_key == key;
         const unsigned long long m = __ballot(mine);
-        unsigned int *counter = key < (uint32_t)NQ ? &a.cnt->q_n[key] : key == PK_STACK ? &a.cnt->n_stack_b : key == PK_TRIO3 ? &a.cnt->n_trio : &a.cnt->n_trio4;
-        uint32_t *list = key < (uint32_t)NQ ? a.queues + (size_t)key * a.nb : key == PK_STACK ? a.klist : key == PK_TRIO3 ? a.tlist : a.tlist4;
+        // (one select after the other on integers, no nested choice of pointers: hipcc 7.2 turned the nested form into branches that
+        // left the counter's address unset for the last key -- found with rocgdb on a bubble list that had all four kinds)
+        uint32_t c_off = (uint32_t)offsetof(CallCounters, n_trio4);
+        c_off = key == PK_TRIO3 ? (uint32_t)offsetof(CallCounters, n_trio) : c_off;
+        c_off = key == PK_STACK ? (uint32_t)offsetof(CallCounters, n_stack_b) : c_off;
+        c_off = key < (uint32_t)NQ ? (uint32_t)offsetof(CallCounters, q_n) + 4u * key : c_off;
+        unsigned int *counter = reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(a.cnt) + c_off);
+        uint64_t l_at = (uint64_t)(uintptr_t)a.tlist4;
+        l_at = key == PK_TRIO3 ? (uint64_t)(uintptr_t)a.tlist : l_at;
+        l_at = key == PK_STACK ? (uint64_t)(uintptr_t)a.klist : l_at;
+        l_at = key < (uint32_t)NQ ? (uint64_t)(uintptr_t)(a.queues + (size_t)key * a.nb) : l_at;
+        uint32_t *list = reinterpret_cast<uint32_t *>((uintptr_t)l_at);
         uint32_t base = 0;
         if (lane == 0) base = atomicAdd(counter, (unsigned int)__popcll(m));
         base = read_lane(base, 0);
@@ -1621,16 +1651,20 @@ __device__ inline void paths_flush(const PathArgs &a, uint32_t pend_key, uint32_
 
 constexpr uint32_t PATHS_PAIRWISE = 8;   // up to this many walks the wave orders them pair by pair, 64 characters per step
 
+template <bool BIG>
 __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
     const int lane = lane_id();
-    __shared__ unsigned long long poff[256];
-    __shared__ uint32_t plen[256];
+    __shared__ unsigned long long poff_lds[BIG ? 1 : 256];
+    __shared__ uint32_t plen_lds[BIG ? 1 : 256];
     uint8_t *scr = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
     uint32_t *major = reinterpret_cast<uint32_t *>(scr);                        // depth_cap
     uint32_t *minor = major + a.depth_cap;                                      // 4 depth_cap
     uint32_t *seg_start = minor + 4 * a.depth_cap;                              // depth_cap + 1
     uint32_t *seen_scr = seg_start + a.depth_cap + 1;                           // 4 depth_cap (colored)
-    const uint32_t n_branching = a.cnt->n_branching;
+    // (BIG: the path tables behind them, 8-aligned)
+    unsigned long long *poff = BIG ? reinterpret_cast<unsigned long long *>(scr + ((((uint64_t)10 * a.depth_cap + 4) * 4 + 7) & ~7ull)) : poff_lds;
+    uint32_t *plen = BIG ? reinterpret_cast<uint32_t *>(poff + a.max_paths + 1) : plen_lds;
+    const uint32_t n_branching = *a.n_list;
     TextChunk tx{0, 0}, px{0, 0}, wx{0, 0};
     uint32_t pend_key = PK_NONE, pend_j = 0, n_pend = 0;   // list entries not yet appended: entry x in lane x
     unsigned long long need_retry = 0, need_max = 0;
@@ -1651,9 +1685,15 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
         const uint32_t n_paths = wo.n_paths;
         if (wo.too_many || wo.too_deep) {
             if (lane == 0) {
-                atomicOr(&a.cnt->err, wo.too_many ? 1u : 32u);
-                a.cnt->err_entrance = t.entrance_ov;
-                a.cnt->err_exit = t.exit_ov;
+                if (!BIG && !wo.too_deep && a.mlist) {   // more walks than the LDS tables hold: the second launch's
+                    const uint32_t at = atomicAdd(&a.cnt->n_many, 1u);
+                    if (at < a.mlist_cap) a.mlist[at] = j;
+                    else atomicOr(&a.cnt->err, 1u);
+                } else {
+                    atomicOr(&a.cnt->err, wo.too_many ? 1u : 32u);
+                    a.cnt->err_entrance = t.entrance_ov;
+                    a.cnt->err_exit = t.exit_ov;
+                }
                 a.btask[j] = pf_bubble_task{0, 0, 0};
             }
             continue;
@@ -1743,6 +1783,7 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
             atomicOr(&a.cnt->err, 8u);
         }
         if (lane == 0) a.btask[j] = pf_bubble_task{(uint64_t)4 * a.nb + first, n_paths, 0};
+        if (BIG && lane == 0) atomicMax(&a.cnt->max_rows, n_paths);
         // where the bubble goes next (all of this is wave-uniform): the list entry waits in the wave's registers, the two sizes in
         // its running maxima -- one atomic per list and 64 bubbles instead of three per bubble on one cache line, which is what
         // bounded this kernel (profiles/r08_experiments.txt)
@@ -1800,6 +1841,7 @@ struct SiteArgs {
     int one_strand, tab_exact;
     uint32_t low, up;
     uint32_t ks;                // capacity of one site string
+    uint32_t rows_cap;          // rows the per-wave tables hold (a multiple of 64, >= the most walks of any bubble)
     uint8_t *scratch;
     uint64_t scratch_per_wave;
     uint64_t *sv_off;           // per bubble: first value in sv
@@ -1901,19 +1943,20 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
     const uint32_t C = COLORED ? a.n_colors : 1;
     const int k = a.k;
     uint8_t *scr = a.scratch + (uint64_t)blockIdx.x * a.scratch_per_wave;
-    // per row (256 rows): appended characters, final string, and the per-row scalars
+    // per row (rows_cap rows: 256, more when a bubble of the batch has more walks): appended characters, final string, and the per-row scalars
+    const size_t RC = a.rows_cap;
     char *app = reinterpret_cast<char *>(scr);
-    char *fin = app + (size_t)256 * KS;
-    uint32_t *flen = reinterpret_cast<uint32_t *>(fin + (size_t)256 * KS);
-    uint32_t *at = flen + 256;
-    uint32_t *rank = at + 256;
-    uint8_t *dup = reinterpret_cast<uint8_t *>(rank + 256);
-    uint8_t *sok = dup + 256;
-    double *mean = reinterpret_cast<double *>(sok + 256);
+    char *fin = app + RC * KS;
+    uint32_t *flen = reinterpret_cast<uint32_t *>(fin + RC * KS);
+    uint32_t *at = flen + RC;
+    uint32_t *rank = at + RC;
+    uint8_t *dup = reinterpret_cast<uint8_t *>(rank + RC);
+    uint8_t *sok = dup + RC;
+    double *mean = reinterpret_cast<double *>(sok + RC);
     // colored, per row: the colours its string's mapping carries in full, the colours whose range test it passed, its mean per colour
-    uint64_t *cmask = reinterpret_cast<uint64_t *>(mean + 256);
-    uint64_t *cokm = cmask + 256;
-    double *cmean = reinterpret_cast<double *>(cokm + 256);   // [256][C]
+    uint64_t *cmask = reinterpret_cast<uint64_t *>(mean + RC);
+    uint64_t *cokm = cmask + RC;
+    double *cmean = reinterpret_cast<double *>(cokm + RC);   // [rows_cap][C]
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t n_branching = a.cnt->n_branching;
     unsigned long long my_strings = 0;   // (added to the batch's count once, at the end)
@@ -2719,7 +2762,8 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
         unsigned long long v[7] = {allele[0], allele[1], allele[2], allele[3], core_cov, core_num, 0};
         for (int x = 0; x < 6; ++x) {
             const unsigned long long s = wave_sum_u64(v[x]);
-            if (lane_id() == 0 && s) atomicAdd(x < 4 ? &a.cnt->allele[x] : (x == 4 ? &a.cnt->core_cov : &a.cnt->core_num), s);
+            // (allele[4], core_cov, core_num lie one after the other: the host zeroes them as six words as well)
+            if (lane_id() == 0 && s) atomicAdd(reinterpret_cast<unsigned long long *>(reinterpret_cast<char *>(a.cnt) + offsetof(CallCounters, allele)) + x, s);
         }
         if (jj == a.nb) {
             const size_t stride = (size_t)a.nb + 1;
@@ -3221,6 +3265,9 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     static const int paths_per_cu = [] { const char *e = getenv("PF_PATHS_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
     const int paths_grid = ctx->n_cu * paths_per_cu;
     NEED(S->paths_scr, paths_per_wave * paths_grid);
+    constexpr uint32_t MLIST_CAP = 4096;   // bubbles of more than 255 walks in one range (more: refused)
+    NEED(S->mlist, (size_t)MLIST_CAP * 4);
+    PathArgs ph_keep = {};
     const int paths_force_scratch = [] { const char *e = getenv("PF_PATHS_SCRATCH"); return e && atoi(e) ? 1 : 0; }();   // (read per call: tests)
 
     // ---- K-PREP, K-SNP, K-PATHS, K-BUBBLE; every pool grows until the batch fits (first batches of a run only) ----
@@ -3313,8 +3360,15 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ph.klist = pa.lists.klist_b; ph.stack_ok = pa.stack_ok;
             ph.tlist = pa.lists.tlist; ph.tlist4 = pa.lists.tlist4; ph.trio_ok = pa.trio_ok;
             ph.walk_pool = S->n_colors ? S->walk_pool.as<uint32_t>() : nullptr; ph.walk_off = S->walk_off.as<uint64_t>(); ph.walk_cap = walk_cap;
+            ph.max_paths = MAX_PATHS; ph.n_list = &d_cnt->n_branching; ph.mlist = S->mlist.as<uint32_t>(); ph.mlist_cap = MLIST_CAP;
+            ph_keep = ph;
+            if (getenv("PF_TRACE_ALIGN_ARGS"))
+                fprintf(stderr, "[pf_call_align] K-PATHS args: ct %p kept %p blist %p succ %p seq %p off %p len %p scratch %p (%llu per wave, grid %d) n_list %p mlist %p walk_pool %p btask %p bpath %p text %p queues %p klist %p tlist %p tlist4 %p cnt %p depth_cap %u nb %u stack_ok %d trio_ok %d\n",
+                        (const void *)ph.ct, (const void *)ph.kept, (const void *)ph.blist, (const void *)ph.succ, (const void *)ph.seq, (const void *)ph.off, (const void *)ph.len, (void *)ph.scratch,
+                        (unsigned long long)ph.scratch_per_wave, paths_grid, (const void *)ph.n_list, (void *)ph.mlist, (void *)ph.walk_pool, (void *)ph.btask, (void *)ph.bpath, (void *)ph.text, (void *)ph.queues,
+                        (void *)ph.klist, (void *)ph.tlist, (void *)ph.tlist4, (void *)ph.cnt, ph.depth_cap, ph.nb, ph.stack_ok, ph.trio_ok);
             ctx_begin_on(ctx, PF_K_CALL_PATHS, pst);
-            k_call_paths<<<paths_grid, 64, 0, pst>>>(ph);
+            k_call_paths<false><<<paths_grid, 64, 0, pst>>>(ph);
             ctx_end_on(ctx, pst);
             if (fork_paths) PF_HIP(hipEventRecord(S->ev_paths, pst));
         }
@@ -3446,12 +3500,28 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         if (stack_tier) ctx_units(ctx, PF_K_CALL_STACK, hc.n_stack + hc.n_stack_b);
         if (trio_tier) ctx_units(ctx, PF_K_CALL_TRIO, hc.n_trio + hc.n_trio4);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
+        if (getenv("PF_TRACE_ALIGN")) fprintf(stderr, "[pf_call_align] bubbles of more than 255 walks: %u, err %u\n", hc.n_many, hc.err);
+        if (hc.n_many && !(hc.err & 33u)) {
+            // bubbles of more than 255 walks: walked again by a few wavefronts with room for PATHS_BIG walks each
+            const uint32_t n_many = std::min<uint32_t>(hc.n_many, MLIST_CAP);
+            const int big_grid = (int)std::min<uint32_t>(n_many, 32);
+            const uint64_t big_per_wave = (((((uint64_t)10 * depth_cap + 4) * 4 + 7) & ~7ull) + ((uint64_t)PATHS_BIG + 1) * 12 + 255) & ~255ull;
+            NEED(S->paths_big_scr, big_per_wave * big_grid);
+            PathArgs pb = ph_keep;
+            pb.blist = S->mlist.as<uint32_t>(); pb.n_list = &d_cnt->n_many; pb.max_paths = PATHS_BIG; pb.mlist = nullptr; pb.mlist_cap = 0;
+            pb.scratch = S->paths_big_scr.as<uint8_t>(); pb.scratch_per_wave = big_per_wave;
+            ctx_begin(ctx, PF_K_CALL_PATHS);
+            k_call_paths<true><<<big_grid, 64, 0, st>>>(pb);
+            ctx_end(ctx);
+            PF_HIP(hipGetLastError());
+            PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
+            PF_HIP(hipStreamSynchronize(st));
+        }
         if (hc.err & 33u) {
-            // (the per-wave tables of K-PATHS / K-SITES and K-BUBBLE's standard tier hold 256 rows; the reference has no such limit)
             char where[96];
             snprintf(where, sizeof where, " (superbubble from unitig %u%c to unitig %u%c)", (hc.err_entrance >> 1) + 1, (hc.err_entrance & 1) ? '-' : '+',
                      (hc.err_exit >> 1) + 1, (hc.err_exit & 1) ? '-' : '+');
-            pf::CtxErr{ctx} = std::string(hc.err & 1u ? "pf_call_run: a bubble has more than 255 paths" : "pf_call_run: a bubble is deeper than the complex size allows") + where;
+            pf::CtxErr{ctx} = std::string(hc.err & 1u ? "pf_call_run: a bubble has more than 65535 paths" : "pf_call_run: a bubble is deeper than the complex size allows") + where;
             return PF_ERR_ARG;
         }
         S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
@@ -3523,9 +3593,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     const uint32_t KS = (uint32_t)(2 * k + 64);
     if (hc.n_branching) {
         const uint32_t C = S->n_colors;
-        const uint64_t sites_per_wave = (((uint64_t)512 * KS + 256ull * (4 + 4 + 4 + 1 + 1 + 8) + (C ? 256ull * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
+        const uint64_t rows_cap = std::max<uint64_t>(256, ((uint64_t)hc.max_rows + 63) & ~63ull);
+        const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8) + (C ? rows_cap * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
         static const int sites_per_cu = [] { const char *e = getenv("PF_SITES_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
-        const int sites_grid = (int)std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu));
+        // (tables for thousands of rows: fewer wavefronts, at most 2 GB of them)
+        const int sites_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu)), (2ull << 30) / sites_per_wave));
         NEED(S->sites_scr, sites_per_wave * sites_grid);
         for (int attempt = 0;; ++attempt) {
             const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * std::max<uint32_t>(C, 1) * hc.n_branching + 1024ull * sites_grid + 1024);   // (a started chunk per wavefront)
@@ -3534,7 +3606,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sa.ct = S->ctask.as<CallTask>(); sa.kept = S->kept.as<uint32_t>(); sa.t0 = t0; sa.blist = S->blist.as<uint32_t>();
             sa.res = O.res.as<pf_bubble_result>(); sa.otext = O.otext.as<char>(); sa.osites = O.osites.as<pf_bubble_site>();
             sa.ogroups = O.ogroups.as<uint8_t>(); sa.k = k; sa.tab = ctx->d_tab; sa.mask = ctx->tab_cap - 1;
-            sa.one_strand = ctx->tab_one_strand; sa.tab_exact = ctx->tab_exact; sa.low = S->low; sa.up = S->up; sa.ks = KS;
+            sa.one_strand = ctx->tab_one_strand; sa.tab_exact = ctx->tab_exact; sa.low = S->low; sa.up = S->up; sa.ks = KS; sa.rows_cap = (uint32_t)rows_cap;
             sa.scratch = S->sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
             sa.sv = O.sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
             sa.n_colors = C;
