@@ -1554,7 +1554,8 @@ __device__ inline bool walk_in_registers(const PathArgs &a, const CallTask &t, T
 }
 
 // The same walk with the stacks in the wave's global scratch: any depth the complex size allows.
-__device__ __noinline__ void walk_in_scratch(const PathArgs &a, const CallTask &t, TextChunk &tx, unsigned long long *poff, uint32_t *plen,
+// (its arguments by value: a reference to the kernel's argument block would move the whole block into private memory for every use)
+__device__ __noinline__ void walk_in_scratch(const PathArgs a, const CallTask &t, TextChunk &tx, unsigned long long *poff, uint32_t *plen,
                                              WalkOut &o, uint32_t *major, uint32_t *minor, uint32_t *seg_start, uint32_t *seen, const int lane) {
     const uint32_t eu = t.exit_ov >> 1;
     const uint32_t ulen = a.len[t.u] - (uint32_t)a.k + 1;
