@@ -2455,6 +2455,14 @@ struct Row {  // one output stream position: a pointer when writing, a byte coun
     __device__ inline void put(char c) { if (W) *p++ = c; else ++n; }
 };
 
+// two streams that receive the same characters (a frequency row goes to its arity's file and to allele_frequency.txt): formatted
+// once, stored twice -- copying the first stream's bytes back out of memory made every character wait for the store before it
+template <bool W>
+struct Tee {
+    Row<W> &a, &b;
+    __device__ inline void put(char c) { a.put(c); b.put(c); }
+};
+
 __global__ void k_call_has(const pf_bubble_result *__restrict__ res, uint32_t nb, uint32_t *__restrict__ has) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     if (j < nb) has[j] = (res[j].n_rows != 0 && res[j].n_rows != 0xFFFFFFFFu) ? 1u : 0u;
@@ -2611,17 +2619,9 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                             if (filed) { put_double(cov, v); cov.put('\t'); }
                             const double fr = v / sum;
                             if (filed) {
-                                if (W) {
-                                    char *before = fre.p;
-                                    put_double(fre, fr);
-                                    fre.put('\n');
-                                    for (char *ch = before; ch < fre.p; ++ch) *s_all.p++ = *ch;
-                                } else {
-                                    const uint32_t before = fre.n;
-                                    put_double(fre, fr);
-                                    fre.put('\n');
-                                    s_all.n += fre.n - before;
-                                }
+                                Tee<W> both{fre, s_all};
+                                put_double(both, fr);
+                                both.put('\n');
                             } else {
                                 put_double(s_all, fr);
                                 s_all.put('\n');
@@ -2679,16 +2679,13 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                     // in the -t > 1 format, grouped by arity at the end of the bubble (src/CDBG.cpp:2158-2162)
                     const double fr = tc / denom;
                     if (filed) {
-                        if (W) {
-                            char *before = fre.p;
-                            put_double(fre, fr);
-                            fre.put('\n');
-                            if (!a.mt) { for (char *c = before; c < fre.p; ++c) *s_all.p++ = *c; }
+                        if (!a.mt) {
+                            Tee<W> both{fre, s_all};
+                            put_double(both, fr);
+                            both.put('\n');
                         } else {
-                            const uint32_t before = fre.n;
                             put_double(fre, fr);
                             fre.put('\n');
-                            if (!a.mt) s_all.n += fre.n - before;
                         }
                     } else if (!a.mt) {
                         put_double(s_all, fr);

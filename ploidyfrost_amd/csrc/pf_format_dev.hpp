@@ -37,12 +37,41 @@ struct BufSink {
     __host__ __device__ inline void put_n(const char *s, uint32_t len) { for (uint32_t i = 0; i < len; ++i) p[i] = s[i]; p += len; }
 };
 
+// Decimal digits without an array: a local buffer indexed by a running count lives in private memory on the device, and every
+// digit then costs a store and a load with memory latency behind each other (K-TEXT's threads spent most of their time there).
+// The digits are collected least significant first into the low byte of a register that is shifted up as they come, so the
+// most significant one ends in the lowest byte and the bytes leave in printing order.
 template <class Sink>
 __host__ __device__ inline void put_uint(Sink &s, uint64_t x) {
-    char buf[20];
+    if (x <= 0xFFFFFFFFull) {   // (ids, counts, lengths: at most ten digits, 32-bit arithmetic)
+        uint32_t y = (uint32_t)x;
+        uint64_t w0 = 0;
+        uint32_t w1 = 0;
+        int n = 0;
+        do {
+            const uint32_t q = y / 10u, d = y - q * 10u;
+            if (n < 8) w0 = (w0 << 8) | (uint64_t)('0' + d);
+            else w1 = (w1 << 8) | (uint32_t)('0' + d);
+            y = q;
+            ++n;
+        } while (y);
+        for (int i = 8; i < n; ++i) { s.put((char)(w1 & 0xFFu)); w1 >>= 8; }
+        for (int i = 0; i < (n < 8 ? n : 8); ++i) { s.put((char)(w0 & 0xFFu)); w0 >>= 8; }
+        return;
+    }
+    uint64_t w0 = 0, w1 = 0, w2 = 0;
     int n = 0;
-    do { buf[n++] = (char)('0' + x % 10); x /= 10; } while (x);
-    while (n) s.put(buf[--n]);
+    do {
+        const uint64_t q = x / 10u, d = x - q * 10u;
+        if (n < 8) w0 = (w0 << 8) | (uint64_t)('0' + d);
+        else if (n < 16) w1 = (w1 << 8) | (uint64_t)('0' + d);
+        else w2 = (w2 << 8) | (uint64_t)('0' + d);
+        x = q;
+        ++n;
+    } while (x);
+    for (int i = 16; i < n; ++i) { s.put((char)(w2 & 0xFFu)); w2 >>= 8; }
+    for (int i = 8; i < (n < 16 ? n : 16); ++i) { s.put((char)(w1 & 0xFFu)); w1 >>= 8; }
+    for (int i = 0; i < 8; ++i) { s.put((char)(w0 & 0xFFu)); w0 >>= 8; }
 }
 __host__ __device__ inline uint32_t uint_digits(uint64_t x) {
     uint32_t n = 1;
@@ -188,7 +217,10 @@ __host__ __device__ inline G6 g6_of(double v) {  // v finite, > 0
     int k = 0, x = 0;
     if (I) {
         // decimal digits of the integer part (at most 16)
-        uint32_t nd = uint_digits(I);
+        // (an integer part below 2^32 -- every coverage -- counts its digits by comparisons instead of divisions)
+        uint32_t nd = I > 0xFFFFFFFFull ? uint_digits(I)
+                                        : 1u + ((uint32_t)I >= 10u) + ((uint32_t)I >= 100u) + ((uint32_t)I >= 1000u) + ((uint32_t)I >= 10000u) + ((uint32_t)I >= 100000u) +
+                                              ((uint32_t)I >= 1000000u) + ((uint32_t)I >= 10000000u) + ((uint32_t)I >= 100000000u) + ((uint32_t)I >= 1000000000u);
         x = (int)nd - 1;
         if (nd > 6) {
             uint64_t p = 1;
@@ -238,29 +270,41 @@ __host__ __device__ inline void put_double(Sink &s, double v) {
     if (mag == 0x7FF0000000000000ull) { s.put('i'); s.put('n'); s.put('f'); return; }
     if (mag == 0) { s.put('0'); return; }
     const G6 g = g6_of(fmt_double(mag));
-    char d[6];
-    uint32_t n = g.n;
-    for (int i = 5; i >= 0; --i) { d[i] = (char)('0' + n % 10); n /= 10; }
-    int last = 5;
-    while (last > 0 && d[last] == '0') --last;  // significant digits kept: d[0..last]
+    // the six digits in one register (no array: see put_uint), the most significant in the lowest byte; digit i = DG(i)
+    uint64_t dw = 0;
+    int last = 5;   // significant digits kept: 0 .. last (trailing zeros dropped, the first digit stays)
+    {
+        uint32_t n = g.n;
+        bool tz = true;
+#pragma unroll
+        for (int i = 5; i >= 0; --i) {
+            const uint32_t q = n / 10u, dg = n - q * 10u;
+            n = q;
+            dw = (dw << 8) | (uint64_t)('0' + dg);
+            if (tz && dg == 0 && i > 0) last = i - 1;
+            else tz = false;
+        }
+    }
+#define PF_DG(i) ((char)((dw >> (8 * (i))) & 0xFFu))
     const int X = g.x;
     if (X < -4 || X >= 6) {
-        s.put(d[0]);
-        if (last > 0) { s.put('.'); for (int i = 1; i <= last; ++i) s.put(d[i]); }
+        s.put(PF_DG(0));
+        if (last > 0) { s.put('.'); for (int i = 1; i <= last; ++i) s.put(PF_DG(i)); }
         s.put('e');
         uint32_t ax;
         if (X < 0) { s.put('-'); ax = (uint32_t)(-X); } else { s.put('+'); ax = (uint32_t)X; }
         if (ax < 10) s.put('0');
         put_uint(s, ax);
     } else if (X >= 0) {
-        for (int i = 0; i <= X; ++i) s.put(i <= last ? d[i] : '0');
-        if (last > X) { s.put('.'); for (int i = X + 1; i <= last; ++i) s.put(d[i]); }
+        for (int i = 0; i <= X; ++i) s.put(i <= last ? PF_DG(i) : '0');
+        if (last > X) { s.put('.'); for (int i = X + 1; i <= last; ++i) s.put(PF_DG(i)); }
     } else {
         s.put('0');
         s.put('.');
         for (int i = 0; i < -X - 1; ++i) s.put('0');
-        for (int i = 0; i <= last; ++i) s.put(d[i]);
+        for (int i = 0; i <= last; ++i) s.put(PF_DG(i));
     }
+#undef PF_DG
 }
 
 }  // namespace pf
