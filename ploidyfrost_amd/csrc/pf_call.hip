@@ -2480,7 +2480,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
     const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index inside the text batch (sizes / offsets)
     const uint32_t j = a.j0 + jj;                                // ... inside the aligned batch (results, numbering, site values)
     unsigned long long allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
-    __shared__ char s_stage[W ? (FMT_BLOCK / 64) * (12288 + 2048 + 2048 + 3072) : 4];
+    __shared__ __attribute__((aligned(16))) char s_stage[W ? (FMT_BLOCK / 64) * (12288 + 2048 + 2048 + 3072) : 4];
     bool staged[4] = {false, false, false, false};
     uint64_t span0[4] = {0, 0, 0, 0};
     uint32_t span_len[4] = {0, 0, 0, 0};
@@ -2752,7 +2752,14 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
             if (!staged[q]) continue;
             const int st_ = FMT_STAGED_STREAM[q];
             char *dst = a.out[st_] + (span0[q] - a.offs[st_ * stride]);
-            for (uint32_t x = lane_id(); x < span_len[q]; x += WAVE) dst[x] = stage[q][x];
+            // four bytes per lane and step (the stage is word-aligned in LDS; the span lies where it lies in the stream: global
+            // memory takes the unaligned word), the last one to three bytes singly
+            const uint32_t n_words = span_len[q] >> 2;
+            for (uint32_t x = lane_id(); x < n_words; x += WAVE) {
+                const uint32_t w = reinterpret_cast<const uint32_t *>(stage[q])[x];
+                __builtin_memcpy(dst + 4 * (size_t)x, &w, 4);
+            }
+            for (uint32_t x = (n_words << 2) + lane_id(); x < span_len[q]; x += WAVE) dst[x] = stage[q][x];
         }
     }
     if (!W) {
