@@ -2821,7 +2821,7 @@ template <bool W>
 __global__ __launch_bounds__(256) void k_sb_format(SbArgs a) {
     const uint32_t u = blockIdx.x * blockDim.x + threadIdx.x;
     // write pass: a wavefront's rows are one contiguous span of the file; staged in LDS and copied out by consecutive lanes
-    __shared__ char s_stage[W ? 4 * SB_STAGE : 4];
+    __shared__ __attribute__((aligned(16))) char s_stage[W ? 4 * SB_STAGE : 4];
     char *stage = s_stage + (threadIdx.x >> 6) * SB_STAGE;
     uint64_t span0 = 0;
     uint32_t span_len = 0;
@@ -2863,7 +2863,12 @@ __global__ __launch_bounds__(256) void k_sb_format(SbArgs a) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
         char *dst = a.out + span0;
-        for (uint32_t x = lane_id(); x < span_len; x += WAVE) dst[x] = stage[x];
+        const uint32_t n_words = span_len >> 2;   // (in words, as K-TEXT's stages leave)
+        for (uint32_t x = lane_id(); x < n_words; x += WAVE) {
+            const uint32_t w = reinterpret_cast<const uint32_t *>(stage)[x];
+            __builtin_memcpy(dst + 4 * (size_t)x, &w, 4);
+        }
+        for (uint32_t x = (n_words << 2) + lane_id(); x < span_len; x += WAVE) dst[x] = stage[x];
     }
 }
 
