@@ -479,5 +479,7 @@ int main(int argc, char **argv) {
         if (write(done_fd, &ok, 1) != 1) {}
         close(done_fd);
     }
+    // (PF_ORDERLY_EXIT: leave through exit() -- a profiler that writes its report from an exit handler needs that)
+    if (getenv("PF_ORDERLY_EXIT")) exit(0);
     _exit(0);
 }
