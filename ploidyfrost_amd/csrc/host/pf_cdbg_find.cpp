@@ -98,7 +98,9 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
                 memset(&r, 0, sizeof r);
                 r.entrance = deferred_ent[d];
                 r.exit = 0xFFFFFFFFu;
+                const auto tw = clk::now();
                 const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, r.entrance, r);
+                if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] host walk from %u: %u vertices, outcome %d, %.3f ms (started %.3f ms into findSuperBubble)\n", r.entrance, r.n_seen, (int)r.outcome, since(tw) * 1e3, (std::chrono::duration<double>(tw - t_all).count()) * 1e3);
                 lists[d].assign(list.begin(), list.begin() + r.n_list);
                 std::lock_guard<std::mutex> lk(walkers_mu_);
                 walkers_.push_back(std::move(w));
