@@ -159,6 +159,7 @@ struct CallState {
     uint64_t out_len[PF_CALL_SLABS][N_STREAMS] = {}, out_off[PF_CALL_SLABS][N_STREAMS] = {};
     hipStream_t copy_stream = nullptr;
     hipEvent_t fetch_ev[2] = {nullptr, nullptr};   // pf_call_fetch_range / pf_call_fetch_wait
+    hipEvent_t text_ev[PF_CALL_SLABS] = {};        // the write pass of the piece in a slab has finished (the fetches wait for it on their stream)
     // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
     hipStream_t side_stream = nullptr;
     hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
@@ -175,6 +176,8 @@ struct CallState {
         for (DevBuf &b : out) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         for (hipEvent_t &e : fetch_ev)
+            if (e) { (void)hipEventDestroy(e); e = nullptr; }
+        for (hipEvent_t &e : text_ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
         if (side_stream) { (void)hipStreamDestroy(side_stream); side_stream = nullptr; }
         if (ev_prep) { (void)hipEventDestroy(ev_prep); ev_prep = nullptr; }
@@ -3802,13 +3805,10 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     hipStream_t st = S->text_stream;
     const uint32_t nb = (uint32_t)count;
     const uint64_t t0 = O.t0;
-    {   // bubbles called inside the range: difference of the batch-wide running count
-        uint32_t c[2] = {0, 0};
-        PF_HIP(hipMemcpyAsync(&c[1], O.vc.as<uint32_t>() + (first + count - 1), 4, hipMemcpyDeviceToHost, st));
-        if (first) PF_HIP(hipMemcpyAsync(&c[0], O.vc.as<uint32_t>() + (first - 1), 4, hipMemcpyDeviceToHost, st));
-        PF_HIP(hipStreamSynchronize(st));
-        out->n_called = c[1] - c[0];
-    }
+    // bubbles called inside the range: difference of the batch-wide running count (read with the sizes below: one wait)
+    uint32_t vc_edge[2] = {0, 0};
+    PF_HIP(hipMemcpyAsync(&vc_edge[1], O.vc.as<uint32_t>() + (first + count - 1), 4, hipMemcpyDeviceToHost, st));
+    if (first) PF_HIP(hipMemcpyAsync(&vc_edge[0], O.vc.as<uint32_t>() + (first - 1), 4, hipMemcpyDeviceToHost, st));
     NEED_TEXT(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
     NEED_TEXT(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
     const char *oom = "pf_call_text: out of device memory";
@@ -3842,6 +3842,7 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     PF_HIP(hipMemcpyAsync(totals, S->totals.p, N_STREAMS * 8, hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
+    out->n_called = vc_edge[1] - vc_edge[0];
     uint64_t all = 0;
     for (int s = 0; s < N_STREAMS; ++s) all += totals[s];
     NEED(S->out[slab], std::max<uint64_t>(all, 16));
@@ -3859,7 +3860,10 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     ctx_end_at(ctx, at, st);
     ctx_units(ctx, PF_K_CALL_FORMAT, nb);
     PF_HIP(hipGetLastError());
-    PF_HIP(hipStreamSynchronize(st));
+    // no wait for the write pass: the fetches of this slab wait for it on their own stream (text_ev), and the next piece's count
+    // pass queues behind it on this one
+    if (!S->text_ev[slab]) PF_HIP(hipEventCreateWithFlags(&S->text_ev[slab], hipEventDisableTiming));
+    PF_HIP(hipEventRecord(S->text_ev[slab], st));
     for (int x = 0; x < 4; ++x) out->allele[x] = hc.allele[x];
     out->core_cov = hc.core_cov;
     out->core_num = hc.core_num;
@@ -3893,6 +3897,7 @@ int pf_call_fetch(pf_ctx *ctx, int slab, int stream, char *dst, uint64_t len) {
     // its own stream, and no context state written: safe beside a pf_call_run on the other slab
     if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
     if (!S->copy_stream) return PF_ERR_HIP;
+    if (S->text_ev[slab] && hipStreamWaitEvent(S->copy_stream, S->text_ev[slab], 0) != hipSuccess) return PF_ERR_HIP;
     if (hipMemcpyAsync(dst, S->out[slab].as<char>() + S->out_off[slab][stream], (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
@@ -3905,6 +3910,7 @@ int pf_call_fetch_slab(pf_ctx *ctx, int slab, char *dst, const uint64_t *len) {
     CallState *S = ctx->call;
     if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
     if (!S->copy_stream) return PF_ERR_HIP;
+    if (S->text_ev[slab] && hipStreamWaitEvent(S->copy_stream, S->text_ev[slab], 0) != hipSuccess) return PF_ERR_HIP;
     uint64_t at = 0;
     bool whole = true;
     for (int s = 0; s < N_STREAMS; ++s) {
@@ -3937,6 +3943,7 @@ int pf_call_fetch_range(pf_ctx *ctx, int slab, uint64_t first_byte, char *dst, u
     if (first_byte + len > all) return PF_ERR_ARG;
     if (hipSetDevice(ctx->device) != hipSuccess || !S->copy_stream) return PF_ERR_HIP;
     if (!S->fetch_ev[slot] && hipEventCreateWithFlags(&S->fetch_ev[slot], hipEventDisableTiming) != hipSuccess) return PF_ERR_HIP;
+    if (S->text_ev[slab] && hipStreamWaitEvent(S->copy_stream, S->text_ev[slab], 0) != hipSuccess) return PF_ERR_HIP;
     if (len && hipMemcpyAsync(dst, S->out[slab].as<char>() + first_byte, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     if (hipEventRecord(S->fetch_ev[slot], S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
