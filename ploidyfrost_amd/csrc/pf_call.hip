@@ -3602,6 +3602,15 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     out->snp_jobs = hc.n_snp_done; out->pair_jobs = hc.n_pair_done + hc.n_pair2_done; out->wave_jobs = n_jobs; out->stack_jobs = hc.n_stack_done;
     out->trio_jobs = hc.n_trio_done;
 
+    // ---- bubble numbering inside the batch (launched ahead of K-SITES, read with its counters: one wait for both) ----
+    k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(O.res.as<pf_bubble_result>(), nb, S->has.as<uint32_t>());
+    size_t tmp1 = 0;
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
+    NEED(S->scan_tmp, tmp1);
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(S->scan_tmp.p, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
+    uint32_t n_called = 0;
+    PF_HIP(hipMemcpyAsync(&n_called, O.vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
+
     // ---- K-SITES ----
     const uint32_t KS = (uint32_t)(2 * k + 64);
     if (hc.n_branching) {
@@ -3674,18 +3683,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         }
     } else {
         NEED(O.sv, 16);
+        PF_HIP(hipStreamSynchronize(st));   // (n_called)
     }
     out->site_strings = hc.site_strings;
 
-    // ---- bubble numbering inside the batch ----
-    k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(O.res.as<pf_bubble_result>(), nb, S->has.as<uint32_t>());
-    size_t tmp1 = 0;
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
-    NEED(S->scan_tmp, tmp1);
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(S->scan_tmp.p, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
-    uint32_t n_called = 0;
-    PF_HIP(hipMemcpyAsync(&n_called, O.vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
-    PF_HIP(hipStreamSynchronize(st));
     out->n_called = n_called;
     O.nb = nb;
     O.cur = *out;
