@@ -264,3 +264,38 @@ def test_colored_graph_cut_over_ranks_in_process(case, world, tmp_path):
     assert not compare_outputs(os.path.join(meta["dir"], "expected"), out)
     for run in runs:
         run.close()
+
+
+def test_colored_calling_refusals_are_by_name(tmp_path):
+    """what the colored resident pipeline does not do says so: the -t > 1 text format and the kernel-level view are the single-sample
+    path's, the colour sets must match the uploaded databases, cutoffs come after the colour sets -- an error code and a message,
+    never a crash or a silent fallback"""
+    import ctypes as C
+    meta = load_case("col3_dip")
+    dead = hostapi.ColoredRun(meta["gfa"], meta["colors"], meta["dbs"], str(tmp_path))
+    with pytest.raises(hipapi.DeviceError, match="single-sample"):
+        dead.set_reference_threads(4)   # (an error is sticky, as the reference's exit() is final: this run is over)
+    dead.close()
+    run = hostapi.ColoredRun(meta["gfa"], meta["colors"], meta["dbs"], str(tmp_path))
+    run.set_output_dir(str(tmp_path / "out"))
+    run.set_unitig_id("g")
+    run.find_superbubbles("g")
+    nb = run.ploidy_select(meta["cutoffs"])
+    assert nb > 0 and run.ploidy_align(0, nb) > 0
+    L = hipapi.load_library()
+    ctx = C.c_void_p(run.device_ctx())
+    used = (C.c_uint64 * 6)()
+    dummy = (C.c_uint64 * 5)(1 << 40, 1 << 40, 1 << 40, 1 << 40, 1 << 40)
+    buf = (C.c_char * 64)()
+    rc = L.pf_call_peek(ctx, 0, C.cast(buf, C.c_void_p), None, None, 1 << 30, None, None, None, None, None, C.cast(dummy, C.c_void_p), C.cast(used, C.c_void_p))
+    assert rc != 0 and b"single-sample" in L.pf_last_error(ctx)
+    lo = (C.c_uint32 * 8)(*([5] * 8))
+    hi = (C.c_uint32 * 8)(*([1000] * 8))
+    assert L.pf_call_set_cutoffs(ctx, 2, C.cast(lo, C.c_void_p), C.cast(hi, C.c_void_p)) != 0   # (three colours were uploaded)
+    assert b"per colour" in L.pf_last_error(ctx)
+    n = run.times()["unitigs"]
+    full = (C.c_uint64 * n)()
+    first = (C.c_uint32 * (n + 1))()
+    assert L.pf_call_set_colours(ctx, 5, C.cast(full, C.c_void_p), C.cast(full, C.c_void_p), C.cast(first, C.c_void_p), None, None, None, 0, 0) != 0
+    assert b"colour sets" in L.pf_last_error(ctx)
+    run.close()
