@@ -412,6 +412,10 @@ int pf_call_align_lane(pf_ctx *, int lane, uint64_t t0, uint64_t t1, uint32_t co
                        double gap, pf_call_result *out);
 int pf_call_text_range_lane(pf_ctx *, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base,
                             pf_call_result *out);
+/* The count pass of pf_call_text_range_lane alone: text_len, allele, core_* and n_called of the range, nothing written.  A rank of a
+ * sharded run learns the sizes of its whole slice with it, the ranks exchange them, and the slice is then written piece by piece
+ * (pf_call_text_range_lane) at offsets that are known -- format, fetch and file copy of consecutive pieces side by side. */
+int pf_call_text_sizes(pf_ctx *, int lane, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out);
 /* Copies the first len bytes of one stream of a slab to dst (host memory, pinned for speed) on a stream of its own: may be
  * called from another thread while pf_call_run fills the other slab. */
 int pf_call_fetch(pf_ctx *, int slab, int stream, char *dst, uint64_t len);

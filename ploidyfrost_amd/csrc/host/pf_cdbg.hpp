@@ -179,6 +179,7 @@ protected:
     std::vector<pf_bfs_record> shard_rec_;
     std::vector<uint32_t> shard_pool_;
     pf_call_result slice_res_ = {};
+    uint64_t slice_nb_ = 0, slice_var_base_ = 0;   // ploidy_align's range and ploidy_text's numbering base, for ploidy_write's pieces
     int fail(int st, const std::string &msg);
     int join_pending_write();
     int join_pending_ids();

@@ -126,6 +126,7 @@ int CDBG::ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called) {
         return fail(st, e.rfind("CDBG::", 0) == 0 ? e : std::string(tag_) + "::PloidyEstimation(): " + e);
     }
     n_called = slice_res_.n_called;
+    slice_nb_ = t1 - t0;
     times_.tasks = t1 - t0;
     times_.align_jobs = slice_res_.align_jobs;
     times_.snp_jobs = slice_res_.snp_jobs; times_.pair_jobs = slice_res_.pair_jobs; times_.wave_jobs = slice_res_.wave_jobs; times_.stack_jobs = slice_res_.stack_jobs; times_.trio_jobs = slice_res_.trio_jobs;
@@ -137,9 +138,14 @@ int CDBG::ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called) {
 int CDBG::ploidy_text(uint64_t var_count_base, uint64_t sizes[PF_CALL_STREAMS], uint64_t counters[8]) {
     if (status_) return status_;
     const auto t = clk::now();
-    const int st = pf_call_text(ctx_, 0, var_count_base, &slice_res_);
+    // the count pass over the whole slice: the sizes the ranks exchange; the text itself is made piece by piece in ploidy_write, each
+    // piece formatted while the one before crosses PCIe and the one before that is copied into the files
+    slice_var_base_ = var_count_base;
+    const uint64_t called = slice_res_.n_called;
+    const int st = pf_call_text_sizes(ctx_, 0, 0, slice_nb_, var_count_base, &slice_res_);
     if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
-    for (int s = 0; s < PF_CALL_STREAMS; ++s) sizes[s] = slice_res_.text_len[s];
+    slice_res_.n_called = called;
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) sizes[s] = slice_nb_ ? slice_res_.text_len[s] : 0;
     for (int a = 0; a < 4; ++a) { counters[a] = slice_res_.allele[a]; allele_[a] = slice_res_.allele[a]; }
     counters[4] = core_cov_ = slice_res_.core_cov;
     counters[5] = core_num_ = slice_res_.core_num;
@@ -156,10 +162,6 @@ int CDBG::ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL
     if (ensure_dir()) return status_;
     const auto t = clk::now();
     const unsigned T = threads_ ? threads_ : 1;
-    uint64_t total = 0, off[PF_CALL_STREAMS + 1];
-    for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += slice_res_.text_len[s]; }
-    PinnedBuf<char> &hb = cx_.slab[0];
-    hb.ensure(ctx_, std::max<uint64_t>(total, 1));
     MappedOut *maps = out_maps_.get();
     for (int s = 0; s < PF_CALL_STREAMS; ++s)
         if (maps[s].open_for(outdir_ + "/" + outpre + kStreamSuffix[s])) return fail(PF_ERR_ARG, "CDBG:: Open " + outpre + kStreamSuffix[s] + " file error");
@@ -168,36 +170,59 @@ int CDBG::ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL
     int rc = 0;
     if (truncate)
         for (int s = 0; s < PF_CALL_STREAMS; ++s) rc |= maps[s].finish(totals[s]);
-    char *dst[PF_CALL_STREAMS];
-    bool mapped = true;
-    for (int s = 0; s < PF_CALL_STREAMS; ++s) {
-        dst[s] = slice_res_.text_len[s] ? maps[s].prepare(offsets[s], slice_res_.text_len[s]) : nullptr;
-        if (slice_res_.text_len[s] && !dst[s]) mapped = false;
-    }
-    // The slab comes over PCIe in ranges of its packed layout (stream after stream); range i is copied into the mapped files --
-    // the parts of the streams it covers, one dispatch of the thread pool -- while range i + 1 is on its way.
-    constexpr uint64_t RANGE = 32u << 20;
-    const uint64_t n_ranges = (total + RANGE - 1) / RANGE;
-    auto fetch = [&](uint64_t i) { return pf_call_fetch_range(ctx_, 0, i * RANGE, hb.p + i * RANGE, std::min<uint64_t>(RANGE, total - i * RANGE), (int)(i & 1)); };
-    int st = n_ranges ? fetch(0) : PF_OK;
-    for (uint64_t i = 0; i < n_ranges && st == PF_OK; ++i) {
-        if (i + 1 < n_ranges) st = fetch(i + 1);
+    // The slice in pieces of whole text batches: piece i + 1 is formatted on the device (K-TEXT's write pass is not waited for) while
+    // piece i crosses PCIe into one of two pinned buffers and piece i - 1 is copied from the other into the mapped files.
+    const uint64_t CHUNK = std::min<uint64_t>(std::max<uint64_t>((uint64_t)batch_bubbles_ * 4, 1), (uint64_t)1 << 24);
+    const uint64_t n_pieces = (slice_nb_ + CHUNK - 1) / CHUNK;
+    std::vector<pf_call_result> pres((size_t)n_pieces);
+    uint64_t running[PF_CALL_STREAMS];
+    for (int s = 0; s < PF_CALL_STREAMS; ++s) running[s] = offsets[s];
+    last_allfre_.clear();
+    int st = PF_OK;
+    auto format = [&](uint64_t i) {
+        const uint64_t first = i * CHUNK, count = std::min<uint64_t>(CHUNK, slice_nb_ - first);
+        return pf_call_text_range_lane(ctx_, 0, (int)(i % PF_CALL_SLABS), first, count, slice_var_base_, &pres[(size_t)i]);
+    };
+    auto piece_bytes = [&](uint64_t i) {
+        uint64_t all = 0;
+        for (int s = 0; s < PF_CALL_STREAMS; ++s) all += pres[(size_t)i].text_len[s];
+        return all;
+    };
+    auto fetch = [&](uint64_t i) {
+        PinnedBuf<char> &hb = cx_.slab[i & 1];
+        const uint64_t all = piece_bytes(i);
+        hb.ensure(ctx_, std::max<uint64_t>(all, 1));
+        return pf_call_fetch_range(ctx_, (int)(i % PF_CALL_SLABS), 0, hb.p, all, (int)(i & 1));
+    };
+    if (n_pieces) st = format(0);
+    if (st == PF_OK && n_pieces) st = fetch(0);
+    for (uint64_t i = 0; i < n_pieces && st == PF_OK; ++i) {
+        if (i + 1 < n_pieces) st = format(i + 1);
         if (st == PF_OK) st = pf_call_fetch_wait(ctx_, (int)(i & 1));
-        if (st != PF_OK || !mapped) continue;
-        const uint64_t a = i * RANGE, b = std::min<uint64_t>(total, a + RANGE);
+        if (st == PF_OK && i + 1 < n_pieces) st = fetch(i + 1);   // (its buffer was copied out two pieces ago)
+        if (st != PF_OK) break;
+        const pf_call_result &r = pres[(size_t)i];
+        const char *src = cx_.slab[i & 1].p;
         CopySpan spans[PF_CALL_STREAMS];
         size_t n_spans = 0;
+        uint64_t at = 0;
         for (int s = 0; s < PF_CALL_STREAMS; ++s) {
-            const uint64_t lo = std::max<uint64_t>(a, off[s]), hi = std::min<uint64_t>(b, off[s] + slice_res_.text_len[s]);
-            if (lo < hi) spans[n_spans++] = CopySpan{dst[s] + (lo - off[s]), hb.p + lo, hi - lo};
+            const uint64_t len = r.text_len[s];
+            if (len) {
+                char *dst = maps[s].prepare(running[s], len);
+                if (dst) spans[n_spans++] = CopySpan{dst, src + at, len};
+                else rc |= maps[s].write(running[s], src + at, len, T);   // (a file that cannot be mapped: through the descriptor)
+            }
+            if (s == 0) last_allfre_.append(src + at, len);
+            running[s] += len;
+            at += len;
+            out_bytes_ += len;
         }
         copy_spans(spans, n_spans, T);
     }
-    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): copy of a text slab failed");
-    if (!mapped)   // (a file that cannot be mapped: written through the descriptor)
-        for (int s = 0; s < PF_CALL_STREAMS; ++s) rc |= maps[s].write(offsets[s], hb.p + off[s], slice_res_.text_len[s], T);
-    for (int s = 0; s < PF_CALL_STREAMS; ++s) out_bytes_ += slice_res_.text_len[s];
-    last_allfre_.assign(hb.p + off[0], slice_res_.text_len[0]);
+    if (st != PF_OK) return fail(st, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+    for (int s = 0; s < PF_CALL_STREAMS; ++s)
+        if (running[s] - offsets[s] != (slice_nb_ ? slice_res_.text_len[s] : 0)) return fail(PF_ERR_ARG, std::string(tag_) + "::PloidyEstimation(): the pieces of a slice do not add up to its size");
     times_.write_s = since(t);
     if (rc) return fail(PF_ERR_ARG, "CDBG:: write error on the result files");
     return 0;

@@ -3783,14 +3783,15 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
 // one batch, second half: K-TEXT of the bubbles pf_call_align left resident, into slab 0 or 1
 // (any host thread: a stream, scratch and counters of its own, launch timing by place -- one pf_call_text_range at a time,
 // beside at most one pf_call_align_lane on the OTHER lane)
-int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
+static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out, bool sizes_only) {
     if (!ctx || !out || slab < 0 || slab >= PF_CALL_SLABS || lane < 0 || lane > 1) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S) return PF_ERR_ARG;
     const CallState::AlignOut &O = S->lane[lane];
     if (first + count > O.nb) { pf::CtxErr{ctx} = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
     if (S->n_colors && S->mt_format) { pf::CtxErr{ctx} = "pf_call_text_range: the -t > 1 format is the single-sample path's"; return PF_ERR_ARG; }
-    for (int s = 0; s < N_STREAMS; ++s) S->out_len[slab][s] = 0;
+    if (!sizes_only)
+        for (int s = 0; s < N_STREAMS; ++s) S->out_len[slab][s] = 0;
     *out = O.cur;
     out->n_called = 0;
     if (count == 0) return PF_OK;
@@ -3846,6 +3847,13 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     out->n_called = vc_edge[1] - vc_edge[0];
     uint64_t all = 0;
     for (int s = 0; s < N_STREAMS; ++s) all += totals[s];
+    if (sizes_only) {   // pf_call_text_sizes: the count pass alone
+        for (int s = 0; s < N_STREAMS; ++s) out->text_len[s] = totals[s];
+        for (int x = 0; x < 4; ++x) out->allele[x] = hc.allele[x];
+        out->core_cov = hc.core_cov;
+        out->core_num = hc.core_num;
+        return PF_OK;
+    }
     NEED(S->out[slab], std::max<uint64_t>(all, 16));
     all = 0;
     for (int s = 0; s < N_STREAMS; ++s) {
@@ -3870,6 +3878,14 @@ int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uin
     out->core_num = hc.core_num;
 #undef NEED
     return PF_OK;
+}
+
+int pf_call_text_range_lane(pf_ctx *ctx, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
+    return call_text_impl(ctx, lane, slab, first, count, var_count_base, out, false);
+}
+
+int pf_call_text_sizes(pf_ctx *ctx, int lane, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
+    return call_text_impl(ctx, lane, 0, first, count, var_count_base, out, true);
 }
 
 int pf_call_text_range(pf_ctx *ctx, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out) {
