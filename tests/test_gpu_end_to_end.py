@@ -188,6 +188,8 @@ def test_one_graph_partitioned_over_ranks(case, world, tmp_path):
         run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
         run.set_threads(3)
         run.set_output_dir(out)
+        if case in ("hex30k", "k31_z16"):
+            run.set_batch_bubbles(4)   # (a slice is written in pieces of 4 x this many bubbles: dozens of pieces here, one elsewhere)
         runs.append(run)
     runs[0].set_unitig_id("g")
     n = runs[0].times()["unitigs"]
