@@ -709,7 +709,7 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
     // The rows leave through LDS: a wavefront's rows are one contiguous span of the text pool (lane order), so they are staged
     // per lane and copied out by consecutive lanes -- whole 64-byte segments per store instead of 64 scattered single bytes
     // (which cost 39 bytes of HBM write traffic per byte written, by the PMC counters).
-    __shared__ char s_rows[4][SNP_STAGE];
+    __shared__ __attribute__((aligned(16))) char s_rows[4][SNP_STAGE];
     char *stage = s_rows[threadIdx.x >> 6];
     uint32_t my_excl = 0, wave_total = 0;
     {
@@ -761,7 +761,14 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
     if (tm && staged && wb + wave_total <= a.text_cap) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __builtin_amdgcn_wave_barrier();
-        for (uint32_t x = lane; x < wave_total; x += WAVE) a.otext[wb + x] = stage[x];
+        // (in words: the stage is word-aligned, global memory takes the unaligned word; the last one to three bytes singly)
+        const uint32_t n_words = wave_total >> 2;
+        char *dst = a.otext + wb;
+        for (uint32_t x = lane; x < n_words; x += WAVE) {
+            const uint32_t w = reinterpret_cast<const uint32_t *>(stage)[x];
+            __builtin_memcpy(dst + 4 * (size_t)x, &w, 4);
+        }
+        for (uint32_t x = (n_words << 2) + lane; x < wave_total; x += WAVE) dst[x] = stage[x];
     }
     // the rest: K-PAIR when short, else K-BUBBLE's queue of their size class
     int key = KEY_NONE;
