@@ -270,6 +270,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         bool have = false;
         long long last_score = 0;
         uint32_t last_npos = 0, last_indel = 0;
+        char top_a = '\0', top_b = '\0';   // ra[len - 1], rb[len - 1] ('\0' on an empty stack)
         for (;;) {
             const uint32_t c = i * W + j;
             if (i == 0 && j == 0 && open_a <= lim_a && open_b <= lim_b) {
@@ -334,10 +335,13 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                     last_indel = indel;
                 }
             }
+            // (the three loads of a step -- the cell's flags and the two characters a move would consume -- leave together; the top of
+            // the stack is carried in registers: a step that waits for one memory round trip where it waited for three in a row)
             const uint8_t dc = dir[c];
+            const char na = i ? A[i - 1] : '\0', nb = j ? B[j - 1] : '\0';
             const uint8_t work = dc >> 4;
-            const char fa = len ? ra[len - 1] : '\0';
-            const char fb = len ? rb[len - 1] : '\0';
+            const char fa = top_a;
+            const char fb = top_b;
             if (work & LEFT) {
                 bool go;
                 if (open_a < lim_a) {
@@ -354,7 +358,9 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 }
                 dir[c] = dc & (uint8_t) ~(LEFT << 4);
                 ra[len] = '+';
-                rb[len] = B[j - 1];
+                rb[len] = nb;
+                top_a = '+';
+                top_b = nb;
                 mv[len] = LEFT;
                 gp[ng++] = (uint16_t)i;
                 len++;
@@ -374,15 +380,19 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                     continue;
                 }
                 dir[c] = dc & (uint8_t) ~(UP << 4);
-                ra[len] = A[i - 1];
+                ra[len] = na;
                 rb[len] = '-';
+                top_a = na;
+                top_b = '-';
                 mv[len] = UP;
                 len++;
                 i -= 1;
             } else if (work & DIAG) {
                 dir[c] = dc & (uint8_t) ~(DIAG << 4);
-                ra[len] = A[i - 1];
-                rb[len] = B[j - 1];
+                ra[len] = na;
+                rb[len] = nb;
+                top_a = na;
+                top_b = nb;
                 mv[len] = DIAG;
                 len++;
                 i -= 1;
@@ -390,16 +400,19 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
             } else {
                 if (len == 0) break;
                 dir[c] = (uint8_t)((dc & 0x0F) | ((dc & 0x0F) << 4));  // matrix_temp[p] = matrix[p]
+                const char pa = len >= 2 ? ra[len - 2] : '\0', pb = len >= 2 ? rb[len - 2] : '\0';   // the new top
+                const uint8_t mvv = mv[len - 1];
                 if (fa == '+') {
-                    if (len >= 2) { if (ra[len - 2] != '+') --open_a; }
+                    if (len >= 2) { if (pa != '+') --open_a; }
                     else --open_a;
                 }
                 if (fb == '-') {
-                    if (len >= 2) { if (rb[len - 2] != '-') --open_b; }
+                    if (len >= 2) { if (pb != '-') --open_b; }
                     else --open_b;
                 }
                 if (fa == '+') ng--;
-                const uint8_t mvv = mv[len - 1];
+                top_a = pa;
+                top_b = pb;
                 if (mvv == LEFT) j += 1;
                 else if (mvv == UP) i += 1;
                 else { i += 1; j += 1; }
