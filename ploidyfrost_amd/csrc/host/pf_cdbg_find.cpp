@@ -15,6 +15,7 @@
 #include <set>
 #include <stdexcept>
 #include <thread>
+#include <unordered_map>
 
 #include "pf_cdbg_impl.hpp"
 #include "pf_parallel.hpp"
@@ -69,6 +70,74 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     if (deferred_ent.size() < deferred.size()) deferred_ent.resize(deferred.size());
     uint64_t n_rec = 0, pool_used = 0, n_deferred = 0;
     int st;
+    // The long traversals are walked on host cores, side by side -- and from the moment the device gives each of them up: the wave
+    // tier reports its give-ups into pinned host memory as they happen (pf_bfs_live_deferred), the walkers poll it while
+    // pf_bfs_candidates_resident is still running.  The longest walk bounds this phase (136 k vertices = 2.7 ms at 5 M unitigs); it
+    // no longer waits for the device to finish with the other candidates first.  A walk is a function of its entrance alone, so the
+    // results are keyed by candidate index: whatever the live list missed (more give-ups than it holds, a repeated call after a pool
+    // overflow) is walked afterwards.
+    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
+    constexpr uint64_t LIVE_CAP = 4096;
+    static const bool live_on = [] { const char *e = getenv("PF_BFS_LIVE"); return !(e && e[0] == '0'); }();   // measurements
+    volatile uint64_t *live = nullptr;
+    if (pf_bfs_live_deferred(ctx_, live_on ? LIVE_CAP : 0, &live) != PF_OK) live = nullptr;
+    struct Walked {
+        pf_bfs_record rec;
+        std::vector<uint32_t> list;
+        uint32_t cand = 0;   // candidate index + 1; 0 = slot unused
+    };
+    std::vector<Walked> early(live ? LIVE_CAP : 0);
+    std::atomic<uint64_t> next_slot{0};
+    std::atomic<int64_t> final_n{-1};   // how many entries the live list ends with; -1 = the device is still at it
+    std::string walk_err;
+    auto walk_one = [&](uint32_t entrance, pf_bfs_record &r, std::vector<uint32_t> &out) {
+        std::unique_ptr<HugeWalker> w;
+        {
+            std::lock_guard<std::mutex> lk(walkers_mu_);
+            if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
+        }
+        if (!w) w = std::make_unique<HugeWalker>();
+        memset(&r, 0, sizeof r);
+        r.entrance = entrance;
+        r.exit = 0xFFFFFFFFu;
+        const auto tw = clk::now();
+        const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, r.entrance, r);
+        if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] host walk from %u: %u vertices, outcome %d, %.3f ms (started %.3f ms into findSuperBubble)\n", r.entrance, r.n_seen, (int)r.outcome, since(tw) * 1e3, (std::chrono::duration<double>(tw - t_all).count()) * 1e3);
+        out.assign(list.begin(), list.begin() + r.n_list);
+        std::lock_guard<std::mutex> lk(walkers_mu_);
+        walkers_.push_back(std::move(w));
+    };
+    std::thread early_walk;
+    if (live)
+        early_walk = std::thread([&] {
+            try {
+                parallel_chunks(walk_threads, 1, walk_threads, [&](size_t, size_t, size_t) {
+                    for (;;) {
+                        const uint64_t k = next_slot.fetch_add(1);
+                        if (k >= LIVE_CAP) return;
+                        uint64_t e = 0;
+                        for (;;) {   // entry k, or the end of the list
+                            e = __atomic_load_n(const_cast<const uint64_t *>(&live[k]), __ATOMIC_ACQUIRE);
+                            if (e) break;
+                            const int64_t fn = final_n.load(std::memory_order_acquire);
+                            if (fn >= 0 && (int64_t)k >= fn) return;
+                            __builtin_ia32_pause();
+                        }
+                        Walked &wk = early[(size_t)k];
+                        walk_one((uint32_t)(e >> 32), wk.rec, wk.list);
+                        wk.cand = (uint32_t)e;   // (index + 1)
+                    }
+                });
+            } catch (const std::exception &e) { walk_err = e.what(); }
+        });
+    struct EarlyGuard {   // every way out of this function: the walkers learn that the list has ended, and are waited for
+        std::thread &t;
+        std::atomic<int64_t> &fin;
+        ~EarlyGuard() {
+            if (fin.load() < 0) fin.store(0);
+            if (t.joinable()) t.join();
+        }
+    } early_guard{early_walk, final_n};
     for (;;) {
         st = pf_bfs_candidates_resident(ctx_, 0, N, &n_rec, &pool_used, deferred.data(), deferred_ent.data(), deferred.size(), &n_deferred);
         if (st == PF_ERR_OVERFLOW && n_deferred > deferred.size()) {
@@ -78,39 +147,39 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
         }
         break;
     }
+    final_n.store(st == PF_OK ? (int64_t)std::min<uint64_t>(n_deferred, LIVE_CAP) : 0, std::memory_order_release);
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
     tf("traversed on the device");
-    // the long traversals on host cores, side by side
-    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
     std::vector<pf_bfs_record> walked((size_t)n_deferred);
     std::vector<std::vector<uint32_t>> lists((size_t)n_deferred);
-    std::string walk_err;
     std::thread walk([&] {
         try {
-            parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
-                std::unique_ptr<HugeWalker> w;
-                {
-                    std::lock_guard<std::mutex> lk(walkers_mu_);
-                    if (!walkers_.empty()) { w = std::move(walkers_.back()); walkers_.pop_back(); }
+            if (early_walk.joinable()) early_walk.join();
+            // pair the early walks with the device's list by candidate index; walk what is left
+            std::unordered_map<uint32_t, size_t> by_cand;
+            for (size_t k = 0; k < early.size(); ++k)
+                if (early[k].cand) by_cand.emplace(early[k].cand - 1, k);
+            std::vector<size_t> todo;
+            for (size_t d = 0; d < (size_t)n_deferred; ++d) {
+                auto it = by_cand.find(deferred[d]);
+                if (it != by_cand.end() && early[it->second].rec.entrance == deferred_ent[d]) {
+                    walked[d] = early[it->second].rec;
+                    lists[d].swap(early[it->second].list);
+                    by_cand.erase(it);
+                } else {
+                    todo.push_back(d);
                 }
-                if (!w) w = std::make_unique<HugeWalker>();
-                pf_bfs_record &r = walked[d];
-                memset(&r, 0, sizeof r);
-                r.entrance = deferred_ent[d];
-                r.exit = 0xFFFFFFFFu;
-                const auto tw = clk::now();
-                const std::vector<uint32_t> &list = w->walk(succ_.data(), pred_.data(), N, r.entrance, r);
-                if (getenv("PF_TRACE_BFS")) fprintf(stderr, "[bfs] host walk from %u: %u vertices, outcome %d, %.3f ms (started %.3f ms into findSuperBubble)\n", r.entrance, r.n_seen, (int)r.outcome, since(tw) * 1e3, (std::chrono::duration<double>(tw - t_all).count()) * 1e3);
-                lists[d].assign(list.begin(), list.begin() + r.n_list);
-                std::lock_guard<std::mutex> lk(walkers_mu_);
-                walkers_.push_back(std::move(w));
-            });
+            }
+            if (!todo.empty())
+                parallel_chunks(todo.size(), 1, walk_threads, [&](size_t x, size_t, size_t) { walk_one(deferred_ent[todo[x]], walked[todo[x]], lists[todo[x]]); });
         } catch (const std::exception &e) { walk_err = e.what(); }
     });
     // K-CC over the records that are on the device, beside the walkers
     st = pf_side_components(ctx_, 1, nullptr, n_rec, nullptr, 0, nullptr, 0, nullptr, 0);
+    tf("  components of the device's records");
     // ... and the coverage kernel PloidyEstimation starts with (it depends on nothing this phase computes)
     if (st == PF_OK && overlap_output_) cov_ready_ = launch_coverage() == PF_OK;
+    tf("  coverage launched");
     walk.join();
     if (!walk_err.empty()) return fail(PF_ERR_HIP, "CDBG::findSuperBubble(): walk of a long traversal: " + walk_err);
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
@@ -134,7 +203,9 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
         walked.swap(w2);
         std::copy(d2.begin(), d2.end(), deferred.begin());
     }
+    tf("  walked records in candidate order");
     if (!walked.empty()) st = pf_side_components(ctx_, 0, nullptr, n_rec, nullptr, 0, walked.data(), walked.size(), xpool.data(), xpool.size());
+    tf("  their components");
     uint64_t n_big = 0, big_entries = 0;
     // (PF_REPLAY_SMALL_LIMIT: tests push more components -- all of them with 0 -- through the host half and its patch)
     static const uint32_t small_limit = [] { const char *e = getenv("PF_REPLAY_SMALL_LIMIT"); return e ? (uint32_t)atoi(e) : 256u; }();

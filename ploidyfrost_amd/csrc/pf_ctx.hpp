@@ -122,6 +122,8 @@ struct pf_ctx {
     } bfs_pending;
 
     unsigned int bfs_deferred = 0;  // candidates of the last pf_bfs_candidates that needed the big tier
+    unsigned long long *h_live = nullptr;   // pf_bfs_live_deferred: pinned, coherent host memory the wave tier reports its give-ups into
+    uint64_t live_cap = 0;
 
     // grow-only device workspaces reused across calls (slot ids: enum pf::WsSlot)
     std::vector<std::pair<void *, size_t>> ws;

@@ -373,6 +373,10 @@ struct BfsOut {
     unsigned int *n_deferred;
     uint32_t *deferred2;            // ... and for the direct-indexed tier
     unsigned int *n_deferred2;
+    // pf_bfs_live_deferred: the same hand-over, at once, in host memory the caller polls while the kernel runs: entry d =
+    // entrance << 32 | (candidate index + 1)
+    unsigned long long *live;
+    uint32_t live_cap;
 };
 
 // Per-wave bump allocation in the vertex pool: a wave reserves BFS_POOL_CHUNK entries with one
@@ -514,6 +518,9 @@ __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, 
                 o.rec[c - c0] = rec;
                 const unsigned int d = atomicAdd(o.n_deferred, 1u);
                 o.deferred[d] = (uint32_t)(c - c0);
+                if (o.live && d < o.live_cap) {
+                    __hip_atomic_store(&o.live[d], ((unsigned long long)s << 32) | (unsigned long long)(c - c0 + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                }
             }
         } else {
             bfs_emit(o, al, c - c0, s, r, st);
@@ -825,6 +832,7 @@ void pf_destroy(pf_ctx *ctx) {
     hipFree(ctx->d_ctab);
     hipFree(ctx->d_cov_sum); hipFree(ctx->d_cov_min); hipFree(ctx->d_cov_miss);
     for (auto &w : ctx->ws) hipFree(w.first);
+    if (ctx->h_live) hipHostFree(ctx->h_live);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
     for (auto &s : ctx->bub_streams) if (s) hipStreamDestroy(s);
     for (auto &e : ctx->bub_events) if (e) hipEventDestroy(e);
@@ -1393,7 +1401,13 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     unsigned int *d_ndef = reinterpret_cast<unsigned int *>(small + 16);
     unsigned int *d_ndef2 = reinterpret_cast<unsigned int *>(small + 32);
     PF_HIP(hipMemsetAsync(small, 0, 64, ctx->stream));
-    BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef, d_def + n + 4, d_ndef2};
+    BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef, d_def + n + 4, d_ndef2, nullptr, 0};
+    if (ctx->h_live && deferred) {   // (armed by pf_bfs_live_deferred: the caller polls the list while the kernels below run)
+        for (uint64_t x = 0; x < ctx->live_cap; ++x) __atomic_store_n(&ctx->h_live[x], 0ull, __ATOMIC_RELAXED);
+        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        o.live = reinterpret_cast<unsigned long long *>(ctx->h_live);
+        o.live_cap = (uint32_t)ctx->live_cap;
+    }
     // thread tier first (one thread per candidate, 8-entry tables), then the wavefront tier for what outgrew it
     uint32_t *d_wlist = (uint32_t *)ctx_ws(ctx, WS_BFS_WLIST, (n + 8) * 4);
     if (!d_wlist) return PF_ERR_HIP;
@@ -1563,6 +1577,28 @@ int pf_bfs_candidates_resident(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *
     }
     pf::CtxErr{ctx} = "pf_bfs_candidates_resident: the vertex pool does not converge";
     return PF_ERR_OVERFLOW;
+}
+
+int pf_bfs_live_deferred(pf_ctx *ctx, uint64_t cap, volatile uint64_t **list) {
+    if (!ctx || !list) return PF_ERR_ARG;
+    *list = nullptr;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (cap == 0) {   // off
+        if (ctx->h_live) (void)hipHostFree(ctx->h_live);
+        ctx->h_live = nullptr;
+        ctx->live_cap = 0;
+        return PF_OK;
+    }
+    if (ctx->h_live && ctx->live_cap != cap) { (void)hipHostFree(ctx->h_live); ctx->h_live = nullptr; ctx->live_cap = 0; }
+    if (!ctx->h_live) {
+        void *p = nullptr;
+        if (hipHostMalloc(&p, cap * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); pf::CtxErr{ctx} = "pf_bfs_live_deferred: no pinned host memory"; return PF_ERR_HIP; }
+        ctx->h_live = static_cast<unsigned long long *>(p);
+        ctx->live_cap = cap;
+        memset(p, 0, cap * 8);
+    }
+    *list = reinterpret_cast<volatile uint64_t *>(ctx->h_live);
+    return PF_OK;
 }
 
 int pf_bfs_candidates_end(pf_ctx *ctx) {
