@@ -1,0 +1,36 @@
+#!/usr/bin/env python3
+"""The dispatches of the LAST pass of a `rocprofv3 --kernel-trace --output-format csv` run of bench.py, in start order, with the gaps in which
+no kernel of the process was running (host waits, launch latency): where the device idles inside a pass.
+usage: tools/pass_timeline.py <dir with *_kernel_trace.csv> [min gap us]"""
+import csv
+import glob
+import os
+import sys
+
+src = sys.argv[1]
+min_gap = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
+rows = []
+for f in glob.glob(os.path.join(src, "**", "*_kernel_trace.csv"), recursive=True):
+    with open(f) as fh:
+        rows += list(csv.DictReader(fh))
+ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
+starts = [i for i, e in enumerate(ev) if "k_bfs_thread" in e[2]]
+if len(starts) < 2:
+    raise SystemExit("fewer than two passes in the trace")
+a, b = starts[-2], starts[-1]
+seg = ev[a:b]
+t0 = seg[0][0]
+busy_end = seg[0][0]
+idle = 0
+print("pass of %d dispatches, %.3f ms from its first kernel to the next pass's" % (len(seg), (ev[b][0] - t0) / 1e6))
+for s, e, n in seg:
+    if s > busy_end:
+        gap = (s - busy_end) / 1e3
+        idle += s - busy_end
+        if gap >= min_gap:
+            print("      -- idle %7.1f us --" % gap)
+    short = n.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:60]
+    print("%9.3f ms  %8.1f us  %s" % ((s - t0) / 1e6, (e - s) / 1e3, short))
+    busy_end = max(busy_end, e)
+tail = ev[b][0] - busy_end
+print("idle inside the pass: %.3f ms (+ %.3f ms after its last kernel)" % (idle / 1e6, tail / 1e6))
