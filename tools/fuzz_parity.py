@@ -13,7 +13,8 @@ genome, so that Bifrost files some k-length unitigs as "abundant" k-mers and num
 part of the unitig numbering the oracle's loader does not restate (pf_host_minz.hpp).
 With PF_FUZZ_GIANT=1 the genomes are 250-400 kb long and carry one to three copied segments (k .. 2k bp) near their start: the
 shared unitig's traversal cannot close before it has walked a whole locus to the end of the chromosome -- traversals of more
-than 4096 vertices, the third K-BFS tier (host walkers by default; PF_FUZZ_GIANT=device switches every other case to k_bfs_huge)."""
+than 4096 vertices, the third K-BFS tier (host walkers by default; PF_FUZZ_GIANT=device switches every other case to k_bfs_huge).
+With PF_FUZZ_COLORED=1 every case is a colored one (two to three samples; CCDBG's calling phase on the resident pipeline)."""
 import os
 import subprocess
 import sys
@@ -209,7 +210,7 @@ def main():
     failures = 0
     for seed in range(first, first + n):
         with tempfile.TemporaryDirectory() as tmp:
-            msg = one_case(seed, tmp, dev)
+            msg = one_case(seed, tmp, dev, force_colored=True if os.environ.get("PF_FUZZ_COLORED") == "1" else None)
         print("seed %d: %s" % (seed, msg), flush=True)
         failures += "DIFFERENT" in msg or "MISMATCH" in msg
     print("%d cases, %d failures" % (n, failures))
