@@ -1,5 +1,6 @@
 #include "pf_bfs_host.hpp"
 
+#include <emmintrin.h>
 #include <sys/mman.h>
 
 #include <algorithm>
@@ -22,11 +23,10 @@ void advise_huge_pages(const void *p, size_t bytes) {
 
 const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32_t *pred, uint32_t N, uint32_t s, pf_bfs_record &r) {
     if (info.size() != N) {
-        info.clear(); first.clear();
-        info.reserve(N); first.reserve(N);
+        info.clear();
+        info.reserve(N);
         advise_huge_pages(info.data(), (size_t)N * 4);
-        advise_huge_pages(first.data(), (size_t)N * 4);
-        info.assign(N, 0); first.assign(N, 0); epoch = 0;
+        info.assign(N, 0); epoch = 0;
     }
     if (++epoch >= (1u << 28)) { std::fill(info.begin(), info.end(), 0); epoch = 1; }
     const uint32_t tag = epoch << 4;
@@ -42,29 +42,38 @@ const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32
     };
     uint64_t n_pending = 0;  // unitigs in state `seen` (0x02)
     seen.push_back(s);
-    first[s >> 1] = s;
     todo.push_back(s);
     r.entrance = s;
     r.exit = NONE;
     r.outcome = PF_BFS_NONE;
     r.strict = 0;
     r.pad_ = 0;
+    // The slots of a CSR row are indexed by base: which of the four hold a vertex is as good as random, so a branch per slot
+    // mispredicts every other time (three to five times per popped vertex; the walk is bound by exactly that, not by memory: 26 ns
+    // per vertex with everything in L1).  The rows are therefore turned into bit masks of their occupied slots -- one vector
+    // compare -- and the loops run over the set bits.
+    auto occupied = [](const uint32_t *row) -> unsigned {
+        const __m128i x = _mm_loadu_si128(reinterpret_cast<const __m128i *>(row));
+        return ~(unsigned)_mm_movemask_ps(_mm_castsi128_ps(_mm_cmpeq_epi32(x, _mm_set1_epi32(-1)))) & 15u;
+    };
     while (!todo.empty()) {
         const uint32_t v = todo.back();
         todo.pop_back();
-        if ((state_of(v >> 1) & 3) == 2) --n_pending;
+        {
+            const uint32_t x = info[v >> 1];
+            n_pending -= (uint64_t)(((x >> 4) == epoch) & ((x & 3) == 2));
+        }
         info[v >> 1] = tag | 1u | strand_bit(v);  // state_map[id] = 0x01; strand_map[id] = v.strand
         const uint32_t *row = succ + (size_t)v * 4;
-        for (int b = 0; b < 4; ++b)
-            if (row[b] != NONE) {
-                __builtin_prefetch(pred + (size_t)row[b] * 4);
-                __builtin_prefetch(&info[row[b] >> 1]);
-            }
-        bool any = false;
-        for (int b = 0; b < 4; ++b) {
-            const uint32_t u = row[b];
-            if (u == NONE) continue;
-            any = true;
+        const unsigned sm = occupied(row);
+        for (unsigned m = sm; m; m &= m - 1) {
+            const uint32_t u = row[__builtin_ctz(m)];
+            __builtin_prefetch(pred + (size_t)u * 4);
+            __builtin_prefetch(&info[u >> 1]);
+            __builtin_prefetch(succ + (size_t)u * 4);   // u is popped soon (LIFO) when all its predecessors are in
+        }
+        for (unsigned m = sm; m; m &= m - 1) {
+            const uint32_t u = row[__builtin_ctz(m)];
             if (u == s) {
                 flag_cycle = true;
                 cyc_add(s);
@@ -72,10 +81,9 @@ const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32
                 continue;
             }
             const uint32_t um = state_of(u >> 1);
-            if (um == 0 || (um & 3) != 1) {
+            if ((um & 3) != 1) {   // not in the map, or seen and not yet visited
                 if (um == 0) {
                     seen.push_back(u);
-                    first[u >> 1] = u;
                     info[u >> 1] = tag | 2u | strand_bit(u);
                     ++n_pending;
                 } else {
@@ -88,37 +96,30 @@ const std::vector<uint32_t> &HugeWalker::walk(const uint32_t *succ, const uint32
                 }
                 bool all_pred = true;
                 const uint32_t *prow = pred + (size_t)u * 4;
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t p = prow[j];
-                    if (p == NONE) continue;
+                for (unsigned pm4 = occupied(prow); pm4; pm4 &= pm4 - 1) {
+                    const uint32_t p = prow[__builtin_ctz(pm4)];
                     const uint32_t pm = state_of(p >> 1);
-                    if (pm != 0) {
-                        if ((pm & 3) != 1) all_pred = false;
-                        if ((pm & 4) != strand_bit(p)) {
-                            flag_cycle = true;
-                            cyc_add(u);
-                            cyc_add(p);
-                        }
-                    } else {
-                        all_pred = false;
+                    all_pred &= (pm & 3) == 1;   // (0 = not in the map, 2 = seen only)
+                    if (pm != 0 && (pm & 4) != strand_bit(p)) {
+                        flag_cycle = true;
+                        cyc_add(u);
+                        cyc_add(p);
                     }
                 }
-                if (all_pred) {
-                    todo.push_back(u);
-                    __builtin_prefetch(succ + (size_t)u * 4);   // u is popped soon (LIFO): its own row first
-                }
+                if (all_pred) todo.push_back(u);
             } else {
                 flag_cycle = true;
                 cyc_add(v);
                 cyc_add(u);
             }
         }
-        if (!any) flag_tip = true;
+        if (!sm) flag_tip = true;
         if (todo.size() == 1) {
             // "no other entry of vec_km_seen is in state 0x02" (src/CDBG.cpp:337-351) by counting
             const uint32_t t0 = todo[0];
             const uint32_t tm = state_of(t0 >> 1);
-            const uint64_t mine = ((tm & 3) == 2 && first[t0 >> 1] == t0) ? 1 : 0;
+            // (is t0 itself the pending entry of its unitig?  A `seen` entry keeps the strand of its first sighting.)
+            const uint64_t mine = ((tm & 3) == 2 && (tm & 4) == strand_bit(t0)) ? 1 : 0;
             if (n_pending == mine) {
                 r.exit = t0;
                 bool back = false;

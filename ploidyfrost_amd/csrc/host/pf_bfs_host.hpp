@@ -9,8 +9,8 @@
 // but each visits 10^4 - 10^6 vertices, so they decide the length of a pass.  The small and the 4096-entry tiers stay on the
 // device (one wavefront per candidate, hundreds of thousands side by side); pf_bfs_candidates_split hands the rest over.
 //
-// State per walker: info[u] = (epoch << 4) | (recorded strand << 2) | state  and first[u] = the oriented vertex first seen,
-// direct-indexed by unitig and stamped with a per-traversal epoch -- the layout of the device's third tier.
+// State per walker: info[u] = (epoch << 4) | (recorded strand << 2) | state, direct-indexed by unitig and stamped with a
+// per-traversal epoch (the strand of a `seen` entry is that of its first sighting: which oriented vertex the entry stands for).
 #pragma once
 #include <cstdint>
 #include <vector>
@@ -23,7 +23,7 @@ namespace pfh {
 void advise_huge_pages(const void *p, size_t bytes);
 
 struct HugeWalker {
-    std::vector<uint32_t> info, first, seen, todo, cyc;
+    std::vector<uint32_t> info, seen, todo, cyc;
     uint32_t epoch = 0;
     // walks from the oriented vertex s over the CSR rows (4 slots per oriented vertex, PF_NONE = empty); fills every field
     // of `r` except list_off and returns the list the replay needs (seen[] when an exit was found, the cycle set otherwise)

@@ -132,7 +132,7 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
     }
     trace.mark("device: graph upload");
     if (!getenv("PF_NO_PREALLOC") && !colored) {
-        // the walkers of the long traversals keep 8 bytes of state per unitig each: zero-filled here, beside the rest of the load,
+        // the walkers of the long traversals keep 4 bytes of state per unitig each: zero-filled here, beside the rest of the load,
         // instead of inside the first findSuperBubble (23 ms at 5 M unitigs)
         const uint32_t n_now = g_.n();
         prealloc_walkers_ = std::thread([this, n_now] {
@@ -141,11 +141,8 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
             parallel_chunks(want, 1, want, [&](size_t i, size_t, size_t) {
                 made[i] = std::make_unique<HugeWalker>();
                 made[i]->info.reserve(n_now);
-                made[i]->first.reserve(n_now);
                 advise_huge_pages(made[i]->info.data(), (size_t)n_now * 4);
-                advise_huge_pages(made[i]->first.data(), (size_t)n_now * 4);
                 made[i]->info.assign(n_now, 0);
-                made[i]->first.assign(n_now, 0);
             });
             std::lock_guard<std::mutex> lk(walkers_mu_);
             for (auto &w : made) walkers_.push_back(std::move(w));

@@ -76,7 +76,7 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     // no longer waits for the device to finish with the other candidates first.  A walk is a function of its entrance alone, so the
     // results are keyed by candidate index: whatever the live list missed (more give-ups than it holds, a repeated call after a pool
     // overflow) is walked afterwards.
-    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
+    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (4ull * std::max<uint32_t>(N, 1))));
     constexpr uint64_t LIVE_CAP = 4096;
     static const bool live_on = [] { const char *e = getenv("PF_BFS_LIVE"); return !(e && e[0] == '0'); }();   // measurements
     volatile uint64_t *live = nullptr;
@@ -364,8 +364,8 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     cov_ready_ = false;
     static_assert(kMaxSlices <= 4, "huge_lists_ holds four slices");
     for (auto &hl : huge_lists_) hl.clear();
-    // host walkers of the long traversals: each keeps 8 bytes of state per unitig, at most ~4 GiB of it in total
-    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
+    // host walkers of the long traversals: each keeps 4 bytes of state per unitig, at most ~4 GiB of it in total
+    const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (4ull * std::max<uint32_t>(N, 1))));
     std::atomic<uint64_t> n_deferred_total{0};
     std::thread device([&] {
         try {
@@ -649,7 +649,7 @@ int CDBG::find_shard(uint32_t u0, uint32_t u1) {
     shard_rec_.assign(bx_.bfs_rec.p, bx_.bfs_rec.p + n_rec);
     shard_pool_.assign(bx_.bfs_pool.p, bx_.bfs_pool.p + used);
     if (n_deferred) {
-        const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : 1, (4ull << 30) / (8ull * std::max<uint32_t>(N, 1))));
+        const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : 1, (4ull << 30) / (4ull * std::max<uint32_t>(N, 1))));
         std::vector<std::vector<uint32_t>> lists((size_t)n_deferred);
         parallel_chunks((size_t)n_deferred, 1, walk_threads, [&](size_t d, size_t, size_t) {
             std::unique_ptr<HugeWalker> w;

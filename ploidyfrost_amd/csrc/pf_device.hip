@@ -493,13 +493,13 @@ __global__ __launch_bounds__(256) void k_bfs_thread(const uint32_t *__restrict__
 // wavefront tier: candidates c0 + [0, c1 - c0), or, with a list, the candidates c0 + list[0 .. *n_list)
 __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, const uint32_t *__restrict__ pred,
                                              const uint32_t *__restrict__ cand, uint64_t c0, uint64_t c1, BfsOut o,
-                                             const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_list) {
+                                             const uint32_t *__restrict__ list, const unsigned int *__restrict__ n_list, uint32_t cap) {
     __shared__ uint32_t s_ent[4][BFS_LDS_CAP];
     __shared__ uint32_t s_todo[4][BFS_LDS_CAP];
     __shared__ uint32_t s_cyc[4][BFS_LDS_CAP];
     __shared__ uint8_t s_meta[4][BFS_LDS_CAP];
     const int wv = threadIdx.x >> 6;
-    BfsStore st{s_ent[wv], s_meta[wv], s_todo[wv], s_cyc[wv], BFS_LDS_CAP};
+    BfsStore st{s_ent[wv], s_meta[wv], s_todo[wv], s_cyc[wv], cap};   // cap <= BFS_LDS_CAP: where this tier gives a traversal up
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     BfsAlloc al;
@@ -1413,18 +1413,20 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     if (!d_wlist) return PF_ERR_HIP;
     unsigned int *d_nwlist = reinterpret_cast<unsigned int *>(small + 48);
     static const bool thread_tier = [] { const char *e = getenv("PF_BFS_THREAD_TIER"); return !(e && e[0] == '0'); }();  // measurements
+    // (PF_BFS_WAVE_CAP, read per call: measurements of where the wavefront tier should give up)
+    const uint32_t wave_cap = [] { const char *e = getenv("PF_BFS_WAVE_CAP"); return e ? (uint32_t)std::max(16, std::min((int)BFS_LDS_CAP, atoi(e))) : BFS_LDS_CAP; }();
     if (thread_tier) {
         ctx_begin(ctx, PF_K_BFS_THREAD);
         k_bfs_thread<<<(unsigned)((n + 255) / 256), 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, d_wlist, d_nwlist);
         ctx_end(ctx);
         const int grid = ctx_grid(ctx, (n / 4 + 64) * 64, 256, 8);
         ctx_begin(ctx, PF_K_BFS);
-        k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, d_wlist, d_nwlist);
+        k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, d_wlist, d_nwlist, wave_cap);
         ctx_end(ctx);
     } else {
         const int grid = ctx_grid(ctx, n * 64, 256, 8);
         ctx_begin(ctx, PF_K_BFS);
-        k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, nullptr, nullptr);
+        k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, nullptr, nullptr, wave_cap);
         ctx_end(ctx);
     }
     unsigned int n_def = 0, n_wl = 0;
