@@ -458,11 +458,15 @@ int pf_replay_order(pf_ctx *, uint32_t n_classes, uint32_t *order, uint32_t *cla
  * byte (csrc/host/pf_state_ops.hpp: S_LINK, S_STRICT, S_COMPLEX, S_NON_SUPER).  pf_replay_finish merges the per-side bytes into
  * MyUnitig's and leaves the state resident for pf_superbubble_rows / pf_call_scan; pf_call_get_state copies it to the host. */
 /* The candidates the device tiers give up on (traversals of more than 128 vertices: the caller walks them on host cores) are also
- * reported AT ONCE: *list = cap entries of pinned host memory that every later pf_bfs_candidates* call of this context with a
- * `deferred` array zeroes when it starts and fills while its kernels run -- entry d = entrance (oriented vertex) << 32 | (candidate
- * index + 1), in the order of `deferred` -- so that the caller's walkers start on the first long traversal while the device is still
- * busy with the other candidates instead of after the call has returned.  cap = 0 switches it off. */
+ * reported AHEAD of the call's return: *list = cap entries of pinned host memory that every later pf_bfs_candidates* call of this
+ * context with a `deferred` array zeroes when it starts and fills while its kernels run -- entry = entrance (oriented vertex) << 32
+ * | (candidate index + 1), in no particular order -- so that the caller's walkers start on the first long traversal while the device
+ * is still busy instead of after the call has returned.  An entry is a NOTICE, written when a traversal reaches 48 vertices: the
+ * traversal goes on on the device and may yet end there (it is then absent from `deferred`, and the caller drops its walk); every
+ * candidate of `deferred` has an entry unless the list ran out of room.  pf_bfs_live_count: the entries the last call wrote (may
+ * exceed cap: the surplus was dropped).  cap = 0 switches the list off. */
 int pf_bfs_live_deferred(pf_ctx *, uint64_t cap, volatile uint64_t **list);
+int pf_bfs_live_count(pf_ctx *, uint64_t *n);
 int pf_bfs_candidates_resident(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred,
                                uint32_t *deferred_entrance, uint64_t deferred_cap, uint64_t *n_deferred);
 int pf_replay_device(pf_ctx *, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries);

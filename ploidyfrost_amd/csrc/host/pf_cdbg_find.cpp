@@ -147,7 +147,13 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
         }
         break;
     }
-    final_n.store(st == PF_OK ? (int64_t)std::min<uint64_t>(n_deferred, LIVE_CAP) : 0, std::memory_order_release);
+    {
+        // (the live list holds notices: of every traversal that reached 48 vertices, whether the device gave it up afterwards or not)
+        uint64_t n_live = 0;
+        if (st == PF_OK && live) (void)pf_bfs_live_count(ctx_, &n_live);
+        final_n.store(st == PF_OK ? (int64_t)std::min<uint64_t>(n_live, LIVE_CAP) : 0, std::memory_order_release);
+        if (trace_find) fprintf(stderr, "[find]   %llu notices in the live list, %llu traversals given up\n", (unsigned long long)n_live, (unsigned long long)n_deferred);
+    }
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
     tf("traversed on the device");
     std::vector<pf_bfs_record> walked((size_t)n_deferred);

@@ -27,6 +27,11 @@ struct BfsStore {
     uint32_t *todo;  // LIFO
     uint32_t *cyc;   // cycle set (insertion order, deduplicated)
     uint32_t cap;
+    // early notice to the caller's walkers (pf_bfs_live_deferred): a traversal that reaches hint_at vertices is entered into the
+    // live list at once -- entrance << 32 | hint_tag -- while it goes on here; nullptr = no notices
+    unsigned long long *live = nullptr;
+    unsigned int *n_live = nullptr;
+    uint32_t live_cap = 0, hint_at = 0, hint_tag = 0;
 };
 
 struct BfsResult {
@@ -34,6 +39,7 @@ struct BfsResult {
     uint32_t n_seen, n_cyc;
     uint8_t outcome, flag_cycle, flag_tip, strict;
     bool overflow;
+    bool hinted;   // the live list has this traversal already
 };
 
 // lane 0 writes the tables, every lane reads them: order the wave's memory traffic
@@ -78,6 +84,7 @@ __device__ inline BfsResult bfs_traverse(const uint32_t *__restrict__ succ, cons
     r.outcome = PF_BFS_NONE;
     r.flag_cycle = r.flag_tip = r.strict = 0;
     r.overflow = false;
+    r.hinted = false;
 
     uint32_t n = 0, top = 0, n_cyc = 0;
     bool cyc_flag = false, tip_flag = false;
@@ -126,6 +133,14 @@ __device__ inline BfsResult bfs_traverse(const uint32_t *__restrict__ succ, cons
                         if (lane == 0) st.ent[n] = u;
                         n++;
                         new_meta = (uint8_t)(2 | (((u & 1) == 0) ? 4 : 0));
+                        if (st.live && n == st.hint_at) {
+                            r.hinted = true;
+                            if (lane == 0) {
+                                const unsigned int d = atomicAdd(st.n_live, 1u);
+                                if (d < st.live_cap)
+                                    __hip_atomic_store(&st.live[d], ((unsigned long long)s << 32) | (unsigned long long)st.hint_tag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                            }
+                        }
                     } else {  // :295-303  seen before: strand must agree
                         if (((um >> 2) & 1) != ((u & 1) == 0 ? 1u : 0u)) {
                             cyc_flag = true;

@@ -122,6 +122,7 @@ struct pf_ctx {
     } bfs_pending;
 
     unsigned int bfs_deferred = 0;  // candidates of the last pf_bfs_candidates that needed the big tier
+    unsigned int bfs_live_n = 0;    // entries the last pf_bfs_candidates call put into the live list (pf_bfs_live_count)
     unsigned long long *h_live = nullptr;   // pf_bfs_live_deferred: pinned, coherent host memory the wave tier reports its give-ups into
     uint64_t live_cap = 0;
 

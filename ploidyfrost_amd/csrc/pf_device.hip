@@ -377,6 +377,8 @@ struct BfsOut {
     // entrance << 32 | (candidate index + 1)
     unsigned long long *live;
     uint32_t live_cap;
+    unsigned int *n_live;   // entries of the live list (notices of traversals still running on the device included)
+    uint32_t hint_at;       // a traversal is entered when it reaches this many vertices
 };
 
 // Per-wave bump allocation in the vertex pool: a wave reserves BFS_POOL_CHUNK entries with one
@@ -500,6 +502,7 @@ __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, 
     __shared__ uint8_t s_meta[4][BFS_LDS_CAP];
     const int wv = threadIdx.x >> 6;
     BfsStore st{s_ent[wv], s_meta[wv], s_todo[wv], s_cyc[wv], cap};   // cap <= BFS_LDS_CAP: where this tier gives a traversal up
+    st.live = o.live; st.n_live = o.n_live; st.live_cap = o.live_cap; st.hint_at = o.hint_at;
     const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
     const uint64_t n_waves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     BfsAlloc al;
@@ -507,6 +510,7 @@ __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, 
     for (uint64_t it = wave; it < n_items; it += n_waves) {
         const uint64_t c = c0 + (list ? (uint64_t)list[it] : it);
         const uint32_t s = cand[c];
+        st.hint_tag = (uint32_t)(c - c0 + 1);
         BfsResult r = bfs_traverse(succ, pred, st, s);
         if (r.overflow) {
             if (lane_id() == 0) {
@@ -518,8 +522,10 @@ __global__ __launch_bounds__(256) void k_bfs(const uint32_t *__restrict__ succ, 
                 o.rec[c - c0] = rec;
                 const unsigned int d = atomicAdd(o.n_deferred, 1u);
                 o.deferred[d] = (uint32_t)(c - c0);
-                if (o.live && d < o.live_cap) {
-                    __hip_atomic_store(&o.live[d], ((unsigned long long)s << 32) | (unsigned long long)(c - c0 + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+                if (o.live && !r.hinted) {   // (a table other than the seen list ran over before the notice went out)
+                    const unsigned int l = atomicAdd(o.n_live, 1u);
+                    if (l < o.live_cap)
+                        __hip_atomic_store(&o.live[l], ((unsigned long long)s << 32) | (unsigned long long)(c - c0 + 1), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
             }
         } else {
@@ -1401,13 +1407,17 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     unsigned int *d_ndef = reinterpret_cast<unsigned int *>(small + 16);
     unsigned int *d_ndef2 = reinterpret_cast<unsigned int *>(small + 32);
     PF_HIP(hipMemsetAsync(small, 0, 64, ctx->stream));
-    BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef, d_def + n + 4, d_ndef2, nullptr, 0};
+    unsigned int *d_nlive = reinterpret_cast<unsigned int *>(small + 56);
+    BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef, d_def + n + 4, d_ndef2, nullptr, 0, d_nlive, 0};
     if (ctx->h_live && deferred) {   // (armed by pf_bfs_live_deferred: the caller polls the list while the kernels below run)
         for (uint64_t x = 0; x < ctx->live_cap; ++x) __atomic_store_n(&ctx->h_live[x], 0ull, __ATOMIC_RELAXED);
         __atomic_thread_fence(__ATOMIC_SEQ_CST);
         o.live = reinterpret_cast<unsigned long long *>(ctx->h_live);
         o.live_cap = (uint32_t)ctx->live_cap;
+        // (PF_BFS_HINT_AT, read per call: measurements; beyond the tier's tables = notice only when it gives up)
+        o.hint_at = [] { const char *e = getenv("PF_BFS_HINT_AT"); return e ? (uint32_t)std::max(9, atoi(e)) : 48u; }();
     }
+    ctx->bfs_live_n = 0;
     // thread tier first (one thread per candidate, 8-entry tables), then the wavefront tier for what outgrew it
     uint32_t *d_wlist = (uint32_t *)ctx_ws(ctx, WS_BFS_WLIST, (n + 8) * 4);
     if (!d_wlist) return PF_ERR_HIP;
@@ -1429,10 +1439,12 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
         k_bfs<<<grid, 256, 0, ctx->stream>>>(ctx->d_succ, ctx->d_pred, ctx->d_cand, c0, c1, o, nullptr, nullptr, wave_cap);
         ctx_end(ctx);
     }
-    unsigned int n_def = 0, n_wl = 0;
+    unsigned int n_def = 0, n_wl = 0, n_live = 0;
     PF_HIP(hipMemcpyAsync(&n_def, d_ndef, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (o.live) PF_HIP(hipMemcpyAsync(&n_live, d_nlive, 4, hipMemcpyDeviceToHost, ctx->stream));
     if (ctx->timing && thread_tier) PF_HIP(hipMemcpyAsync(&n_wl, d_nwlist, 4, hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
+    ctx->bfs_live_n = n_live;
     ctx_units(ctx, PF_K_BFS, thread_tier ? n_wl : n);
     if (thread_tier) ctx_units(ctx, PF_K_BFS_THREAD, n);
     int status = PF_OK;
@@ -1579,6 +1591,12 @@ int pf_bfs_candidates_resident(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64_t *
     }
     pf::CtxErr{ctx} = "pf_bfs_candidates_resident: the vertex pool does not converge";
     return PF_ERR_OVERFLOW;
+}
+
+int pf_bfs_live_count(pf_ctx *ctx, uint64_t *n) {
+    if (!ctx || !n) return PF_ERR_ARG;
+    *n = ctx->bfs_live_n;
+    return PF_OK;
 }
 
 int pf_bfs_live_deferred(pf_ctx *ctx, uint64_t cap, volatile uint64_t **list) {

@@ -151,6 +151,7 @@ def load_library() -> C.CDLL:
         "pf_call_text_range_lane": (i, [vp, i, i, u64, u64, u64, vp]),
         "pf_call_text_sizes": (i, [vp, i, u64, u64, u64, vp]),
         "pf_bfs_live_deferred": (i, [vp, u64, vp]),
+        "pf_bfs_live_count": (i, [vp, vp]),
         "pf_call_fetch": (i, [vp, i, i, vp, u64]),
         "pf_call_fetch_slab": (i, [vp, i, vp, vp]),
         "pf_call_fetch_range": (i, [vp, i, u64, vp, u64, i]),
@@ -166,7 +167,7 @@ def load_library() -> C.CDLL:
 
 
 DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
-                    "pf_kernel_time", "pf_reset_timing", "pf_device_busy", "pf_kernel_units", "pf_side_components", "pf_replay_order", "pf_bfs_candidates_begin", "pf_bfs_candidates_end", "pf_fetch", "pf_bfs_candidates_resident", "pf_bfs_live_deferred", "pf_replay_device", "pf_replay_big_fetch", "pf_replay_set_colours", "pf_replay_finish", "pf_call_get_state", "pf_gfa_ingest", "pf_gfa_segments", "pf_gfa_parse", "pf_gfa_upload", "pf_gfa_error", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
+                    "pf_kernel_time", "pf_reset_timing", "pf_device_busy", "pf_kernel_units", "pf_side_components", "pf_replay_order", "pf_bfs_candidates_begin", "pf_bfs_candidates_end", "pf_fetch", "pf_bfs_candidates_resident", "pf_bfs_live_deferred", "pf_bfs_live_count", "pf_replay_device", "pf_replay_big_fetch", "pf_replay_set_colours", "pf_replay_finish", "pf_call_get_state", "pf_gfa_ingest", "pf_gfa_segments", "pf_gfa_parse", "pf_gfa_upload", "pf_gfa_error", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
                     "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
