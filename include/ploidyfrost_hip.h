@@ -383,6 +383,9 @@ int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *ou
  * turn out too small grow in pf_call_align as before.  Needs pf_call_set_state / pf_call_coverage / any other pf_call_* call first
  * only in that the graph must be resident. */
 int pf_call_reserve(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size);
+/* The same for the text stage: what the first pf_call_text_range(_lane) of a run would take for pieces of up to piece_bubbles
+ * bubbles (its stream, the size tables, the text slabs by an estimate from k). */
+int pf_call_reserve_text(pf_ctx *, uint64_t piece_bubbles);
 /* What pf_call_align(_lane) left resident for the bubbles of its range, before any text is made of it -- the kernel-level view the
  * parity tests hold against SeqAlign::SequenceAlignment (src/SeqAlign.cpp:550-640) bubble by bubble: per bubble its endpoints and,
  * for a strict one, its sorted inner unitigs with their mean coverages (sortSeq_simple, src/CDBG.cpp:482-551); its pf_bubble_result

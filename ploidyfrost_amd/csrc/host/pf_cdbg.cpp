@@ -189,7 +189,10 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
         // end up as called bubbles, aligned in two ranges of whole text pieces.
         const uint64_t piece = (uint64_t)std::max<size_t>(batch_bubbles_, 1) * 4;
         const uint64_t est = std::min<uint64_t>(1u << 24, ((uint64_t)(0.17 * (double)N) + piece - 1) / piece * piece);
-        prealloc_call_ = std::thread([this, est] { (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_); });
+        prealloc_call_ = std::thread([this, est, piece] {
+            (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_);
+            (void)pf_call_reserve_text(ctx_, piece);
+        });
     }
     return 0;
 }
@@ -490,7 +493,10 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
     const unsigned T = threads_ ? threads_ : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
     if (join_pending_ids()) return status_;
     auto job = [this, name = outpre + "_Unitig_Id.txt", T]() -> int {
-        g_.ensure_text();   // (after a device ingest the sequences are still in the mapped file only)
+        const bool trace_ids = getenv("PF_TRACE_PLOIDY") != nullptr;
+        const auto t_job = clk::now();
+        auto ti = [&](const char *what) { if (trace_ids) fprintf(stderr, "[unitig ids] %-28s %.2f ms\n", what, since(t_job) * 1e3); };
+        // (after a device ingest the sequences are still in the mapped file only: the rows are made from there)
         constexpr size_t UCH = 32768;
         const size_t N = g_.n(), n_ch = n_chunks_of(N, UCH);
         std::vector<uint64_t> base(n_ch + 1, 0);
@@ -504,6 +510,7 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
         });
         for (size_t c = 0; c < n_ch; ++c) base[c + 1] += base[c];
         ids_bytes_ = base[n_ch];
+        ti("row offsets");
         if (!write_files_) return 0;
         const int fd = open((outdir_ + "/" + name).c_str(), O_WRONLY | O_CREAT, 0666);
         if (fd < 0) return 1;
@@ -514,8 +521,9 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
             for (size_t u = u0; u < u1; ++u) {
                 put_uint(out, u + 1);
                 out.push_back('\t');
-                std::string_view sq = g_.seq((uint32_t)u);
-                out.append(sq.data(), sq.size());
+                const size_t at0 = out.size(), L = g_.size_bp((uint32_t)u);
+                out.resize(at0 + L);
+                g_.copy_seq((uint32_t)u, &out[at0]);
                 out.push_back('\n');
             }
             uint64_t at = base[ci], left = out.size();
@@ -528,6 +536,7 @@ int CDBG::setUnitigId(const std::string &outpre, const std::string &, const size
                 at += (uint64_t)w;
             }
         });
+        ti("rows written");
         int bad = ftruncate(fd, (off_t)base[n_ch]) != 0;
         close(fd);
         for (int x : rc) bad |= x;

@@ -235,7 +235,7 @@ struct GfaSource {
     int version = 1;
     std::vector<uint64_t> file_off;   // per unitig: its sequence field inside body
     std::mutex mu;
-    bool text_ready = false;
+    std::atomic<bool> text_ready{false};   // set once `text` is complete (copy_seq reads it without the lock)
 };
 
 static bool parse_gfa_header(const char *p, const char *end, int &version, int &k, int &g, const char *&body, std::string &err) {
@@ -311,6 +311,29 @@ int UnitigSet::ingest_on_device(pf_ctx *ctx, std::string &err) {
     return PF_OK;
 }
 
+// one sequence as load_gfa leaves it (upper case, a k-length one canonical), from the mapped file
+void UnitigSet::text_from_file(uint32_t u, char *dst) const {
+    const char *s = src_->body + src_->file_off[u];
+    const uint32_t L = len_bp[u];
+    if ((int)L == k) {
+        char fw[32], rc[32];
+        for (int j = 0; j < k; ++j) {
+            const int c = j + 1 == k ? code_of_last(s[j], true) : code_of(s[j]);
+            fw[j] = kBase[c & 3];
+            rc[k - 1 - j] = kBase[3 - (c & 3)];
+        }
+        memcpy(dst, memcmp(rc, fw, (size_t)k) < 0 ? rc : fw, (size_t)k);
+    } else {
+        for (uint32_t j = 0; j + 1 < L; ++j) dst[j] = kBase[code_of(s[j]) & 3];
+        dst[L - 1] = kBase[code_of_last(s[L - 1], false) & 3];
+    }
+}
+
+void UnitigSet::copy_seq(uint32_t u, char *dst) const {
+    if (src_ && ingested_ && !src_->text_ready.load(std::memory_order_acquire)) text_from_file(u, dst);
+    else memcpy(dst, text.data() + off[u], len_bp[u]);
+}
+
 // the sequences as load_gfa leaves them (upper case, k-length ones canonical), from the mapped file
 void UnitigSet::ensure_text() {
     if (!src_ || !ingested_) return;
@@ -319,28 +342,10 @@ void UnitigSet::ensure_text() {
     const size_t N = len_bp.size();
     text.resize(off[N]);
     const unsigned T = std::min(64u, std::max(1u, std::thread::hardware_concurrency()));
-    const char *body = src_->body;
-    const std::vector<uint64_t> &fo = src_->file_off;
     parallel_chunks(N, 8192, T, [&](size_t, size_t b0, size_t b1) {
-        char fw[32], rc[32];
-        for (size_t u = b0; u < b1; ++u) {
-            const char *s = body + fo[u];
-            char *dst = text.data() + off[u];
-            const uint32_t L = len_bp[u];
-            if ((int)L == k) {
-                for (int j = 0; j < k; ++j) {
-                    const int c = j + 1 == k ? code_of_last(s[j], true) : code_of(s[j]);
-                    fw[j] = kBase[c & 3];
-                    rc[k - 1 - j] = kBase[3 - (c & 3)];
-                }
-                memcpy(dst, memcmp(rc, fw, (size_t)k) < 0 ? rc : fw, (size_t)k);
-            } else {
-                for (uint32_t j = 0; j + 1 < L; ++j) dst[j] = kBase[code_of(s[j]) & 3];
-                dst[L - 1] = kBase[code_of_last(s[L - 1], false) & 3];
-            }
-        }
+        for (size_t u = b0; u < b1; ++u) text_from_file((uint32_t)u, text.data() + off[u]);
     });
-    src_->text_ready = true;
+    src_->text_ready.store(true, std::memory_order_release);
 }
 
 void UnitigSet::finish_numbering(std::vector<uint8_t> *counters) {

@@ -69,11 +69,15 @@ struct UnitigSet {
     int ingest_on_device(pf_ctx *ctx, std::string &err);
     bool on_device() const { return ingested_; }
     void ensure_text();
+    // the sequence of unitig u (len_bp[u] characters) copied to dst -- from `text` when that exists, else straight from the mapped
+    // file (what ensure_text would store): a caller that only streams the sequences out need not build `text` at all
+    void copy_seq(uint32_t u, char *dst) const;
     // builds from already ordered sequences (tests, generators)
     void from_sequences(const std::vector<std::string> &seqs, int k_);
     void pack();
 
 private:
+    void text_from_file(uint32_t u, char *dst) const;
     std::shared_ptr<GfaSource> src_;
     bool ingested_ = false;
     pf_ctx *parsed_on_ = nullptr;   // parse_on_device ran on this context

@@ -25,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstddef>
 #include <cstdio>
@@ -3267,6 +3268,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     hipStream_t st = ctx->stream;
     const uint32_t nb = (uint32_t)(t1 - t0);
     const int k = ctx->k;
+    const bool trace_stages = getenv("PF_TRACE_ALIGN") != nullptr;   // where a call's time goes (a first call above all)
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto ta = [&](const char *what) {
+        if (trace_stages) fprintf(stderr, "[pf_call_align]   %-34s %.2f ms\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() * 1e3);
+    };
     const char *oom = "pf_call_run: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
     NEED(S->counters, sizeof(CallCounters));
@@ -3323,6 +3329,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     if (pair_tier) NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * pair_grid);
     unsigned long long heads[4] = {0, 0, 0, 0};
     uint64_t n_jobs = 0;
+    ta("lists and scratch");
     for (int attempt = 0;; ++attempt) {
         if (attempt > 5) { pf::CtxErr{ctx} = "pf_call_align: pools do not converge"; return PF_ERR_OVERFLOW; }
         const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 128ull * paths_grid + 1024);   // (a started piece per wavefront)
@@ -3458,6 +3465,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
+        ta("K-PREP .. K-STACK done");
         bool again = false;   // kernels launched once the host knows their lists' lengths: the counters are read once more behind them
         if (pair_tier && hc.n_pair2) {
             // second tier (paths of 65 .. 128 bases, or a longer indel than the first tier's band follows): few on most graphs, so
@@ -3590,7 +3598,9 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         BL.ogroups = O.ogroups.as<uint8_t>(); BL.oilen = O.oilen.as<uint32_t>();
         BL.text_cap = cap_text; BL.site_cap = cap_sites; BL.group_cap = cap_groups; BL.ilen_cap = cap_ilen;
         BL.keep_heads = true;
+        ta("K-BUBBLE launching");
         const int bst = bubble_launch(ctx, BL, heads);
+        ta("K-BUBBLE done");
         if (trace_retry)
             fprintf(stderr, "[pf_call_align] attempt %d: K-BUBBLE status %d, pools text %llu of %llu, sites %llu of %llu, groups %llu of %llu, indel lengths %llu of %llu\n", attempt, bst,
                     heads[0], (unsigned long long)cap_text, heads[1], (unsigned long long)cap_sites, heads[2], (unsigned long long)cap_groups, heads[3], (unsigned long long)cap_ilen);
@@ -3693,6 +3703,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         PF_HIP(hipStreamSynchronize(st));   // (n_called)
     }
     out->site_strings = hc.site_strings;
+    ta("K-SITES done");
 
     out->n_called = n_called;
     O.nb = nb;
@@ -3773,6 +3784,11 @@ int pf_call_reserve(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size) {
         NEED(O.oilen, ((uint64_t)nb / 2 + 64) * 4);
         NEED(O.sv, ((uint64_t)nb / 4 + 1024ull * ctx->n_cu * 16 + 1024) * 8);
     }
+    {   // K-SITES' tables for bubbles of up to 256 walks (single-sample), K-SCAN's scan space
+        const uint64_t KS = (uint64_t)(2 * ctx->k + 64), rows_cap = 256;
+        const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8)) + 255) & ~255ull;
+        NEED(S->sites_scr, sites_per_wave * (uint64_t)(ctx->n_cu * 16));
+    }
 #undef NEED
     if (!S->side_stream) {
         PF_HIP(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
@@ -3790,6 +3806,38 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
 // one batch, second half: K-TEXT of the bubbles pf_call_align left resident, into slab 0 or 1
 // (any host thread: a stream, scratch and counters of its own, launch timing by place -- one pf_call_text_range at a time,
 // beside at most one pf_call_align_lane on the OTHER lane)
+static int text_stream_of(pf_ctx *ctx, pf::CallState *S) {
+    if (!S->text_stream) {
+        // highest priority: its short kernels go ahead of the alignment kernels of the other lane, whose grids fill the device
+        // for milliseconds -- the text has a PCIe copy and a file copy still before it
+        int least = 0, greatest = 0;
+        PF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        static const bool prio = [] { const char *e = getenv("PF_TEXT_PRIORITY"); return !(e && e[0] == '0'); }();   // measurements
+        PF_HIP(hipStreamCreateWithPriority(&S->text_stream, hipStreamNonBlocking, prio ? greatest : least));
+    }
+    return PF_OK;
+}
+
+// what the first pf_call_text_range of a run would take (see pf_call_reserve): the text stream, the size tables of a piece of
+// piece_bubbles bubbles and the text slabs (an estimate from k: rows of two to four aligned paths; grows as before when short)
+int pf_call_reserve_text(pf_ctx *ctx, uint64_t piece_bubbles) {
+    if (!ctx || piece_bubbles == 0) return PF_ERR_ARG;
+    pf::CallState *S = state_of(ctx);
+    PF_HIP(hipSetDevice(ctx->device));
+    const uint32_t nb = (uint32_t)std::min<uint64_t>(piece_bubbles, 1u << 24);
+    { const int ts = text_stream_of(ctx, S); if (ts != PF_OK) return ts; }
+    NEED_TEXT(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
+    NEED_TEXT(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
+    NEED_TEXT(S->totals, 16 * 8);
+    NEED_TEXT(S->tcounters, sizeof(CallCounters));
+    size_t tmp2 = 0;
+    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)((size_t)N_STREAMS * (nb + 1)), S->text_stream));
+    NEED_TEXT(S->tscan, tmp2);
+    for (int slab = 0; slab < PF_CALL_SLABS; ++slab) NEED_TEXT(S->out[slab], (11ull * (uint64_t)ctx->k + 40) * nb);
+    return PF_OK;
+}
+
 static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out, bool sizes_only) {
     if (!ctx || !out || slab < 0 || slab >= PF_CALL_SLABS || lane < 0 || lane > 1) return PF_ERR_ARG;
     CallState *S = ctx->call;
@@ -3803,14 +3851,12 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     out->n_called = 0;
     if (count == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
-    if (!S->text_stream) {
-        // highest priority: its short kernels go ahead of the alignment kernels of the other lane, whose grids fill the device
-        // for milliseconds -- the text has a PCIe copy and a file copy still before it
-        int least = 0, greatest = 0;
-        PF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        static const bool prio = [] { const char *e = getenv("PF_TEXT_PRIORITY"); return !(e && e[0] == '0'); }();   // measurements
-        PF_HIP(hipStreamCreateWithPriority(&S->text_stream, hipStreamNonBlocking, prio ? greatest : least));
-    }
+    const bool trace_stages = getenv("PF_TRACE_ALIGN") != nullptr;
+    const auto t_enter = std::chrono::steady_clock::now();
+    auto ta = [&](const char *what) {
+        if (trace_stages) fprintf(stderr, "[pf_call_text]    %-34s %.2f ms\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() * 1e3);
+    };
+    { const int ts = text_stream_of(ctx, S); if (ts != PF_OK) return ts; }
     hipStream_t st = S->text_stream;
     const uint32_t nb = (uint32_t)count;
     const uint64_t t0 = O.t0;
@@ -3831,6 +3877,7 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
     NEED(S->tscan, tmp2);
+    ta("stream and size tables");
     PF_HIP(hipMemsetAsync(&d_cnt->allele[0], 0, 6 * 8, st));  // allele[4], core_cov, core_num
     FmtArgs fa;
     fa.ct = S->ctask.as<CallTask>(); fa.kept = S->kept.as<uint32_t>(); fa.t0 = t0; fa.j0 = (uint32_t)first; fa.nb = nb;
@@ -3861,7 +3908,9 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
         out->core_num = hc.core_num;
         return PF_OK;
     }
+    ta("sizes counted");
     NEED(S->out[slab], std::max<uint64_t>(all, 16));
+    ta("slab taken");
     all = 0;
     for (int s = 0; s < N_STREAMS; ++s) {
         fa.out[s] = S->out[slab].as<char>() + all;
