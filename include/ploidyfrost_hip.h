@@ -472,6 +472,9 @@ int pf_bfs_live_deferred(pf_ctx *, uint64_t cap, volatile uint64_t **list);
 int pf_bfs_live_count(pf_ctx *, uint64_t *n);
 int pf_bfs_candidates_resident(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *n_records, uint64_t *pool_used, uint32_t *deferred,
                                uint32_t *deferred_entrance, uint64_t deferred_cap, uint64_t *n_deferred);
+/* Takes the device buffers the first pf_side_components / pf_replay_device pass over n_records records would take (a hint, to be
+ * called beside the load like pf_call_reserve; the adjacency must be resident). */
+int pf_find_reserve(pf_ctx *, uint64_t n_records);
 int pf_replay_device(pf_ctx *, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries);
 /* Colored path (CCDBG): the colour gate of the accept commit (src/CCDBG.cpp:2530-2621) reads, per unitig, the mask of colours
  * present on every k-mer, UnitigColors::size() with the unitig's own mapping, and how many colours the pair encoding stores as

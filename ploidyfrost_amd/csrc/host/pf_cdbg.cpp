@@ -136,13 +136,15 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
         // instead of inside the first findSuperBubble (23 ms at 5 M unitigs)
         const uint32_t n_now = g_.n();
         prealloc_walkers_ = std::thread([this, n_now] {
-            const unsigned want = std::min(16u, std::max(1u, std::thread::hardware_concurrency() / 4));
+            const unsigned want = std::min(32u, std::max(1u, std::thread::hardware_concurrency() / 4));
             std::vector<std::unique_ptr<HugeWalker>> made(want);
             parallel_chunks(want, 1, want, [&](size_t i, size_t, size_t) {
                 made[i] = std::make_unique<HugeWalker>();
                 made[i]->info.reserve(n_now);
                 advise_huge_pages(made[i]->info.data(), (size_t)n_now * 4);
                 made[i]->info.assign(n_now, 0);
+                made[i]->seen.reserve(1u << 18);
+                made[i]->todo.reserve(1u << 12);
             });
             std::lock_guard<std::mutex> lk(walkers_mu_);
             for (auto &w : made) walkers_.push_back(std::move(w));
@@ -189,7 +191,9 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
         // end up as called bubbles, aligned in two ranges of whole text pieces.
         const uint64_t piece = (uint64_t)std::max<size_t>(batch_bubbles_, 1) * 4;
         const uint64_t est = std::min<uint64_t>(1u << 24, ((uint64_t)(0.17 * (double)N) + piece - 1) / piece * piece);
-        prealloc_call_ = std::thread([this, est, piece] {
+        prealloc_call_ = std::thread([this, est, piece, N] {
+            uint64_t n_cand = 0;   // findSuperBubble's buffers first: it is the first to run
+            if (commits_on_device(1) && pf_count_candidates(ctx_, 0, N, &n_cand) == PF_OK) (void)pf_find_reserve(ctx_, n_cand);
             (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_);
             (void)pf_call_reserve_text(ctx_, piece);
         });

@@ -305,6 +305,7 @@ struct CcState {
     uint8_t *f2 = nullptr;         // [2N] per-side flag bytes during the commits
     uint32_t *keys = nullptr, *keys2 = nullptr, *vals = nullptr, *vals2 = nullptr;   // records sorted by component
     uint64_t sort_cap = 0;
+    bool ready = false;            // parent / first / multi have been initialised (pf_find_reserve only takes them)
     uint32_t *big_idx = nullptr;   // indices of the records of the components left to the caller, ascending
     pf_bfs_record *big_rec = nullptr;
     uint32_t *big_pool = nullptr;
@@ -382,7 +383,75 @@ void cc_destroy(pf_ctx *ctx) {
 }
 }  // namespace pf
 
+// the per-graph arrays of K-CC
+static int cc_graph_arrays(pf_ctx *ctx, CcState *S, uint32_t N) {
+    const uint32_t n_sides = 2 * N;
+    // (the colour gate's arrays belong to the graph, not to a pass: they survive)
+    uint64_t *fm = S->full_mask, *stt = S->size_total;
+    uint32_t *nf = S->n_full_enc;
+    const uint32_t nc = S->n_colors;
+    S->full_mask = S->size_total = nullptr;
+    S->n_full_enc = nullptr;
+    S->release();   // (resets the fields, the object stays)
+    S->full_mask = fm; S->size_total = stt; S->n_full_enc = nf; S->n_colors = nc;
+    if (hipMalloc(reinterpret_cast<void **>(&S->bad), 16) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&S->parent), (size_t)n_sides * 4 + 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&S->first), (size_t)n_sides * 4 + 4) != hipSuccess ||
+        hipMalloc(reinterpret_cast<void **>(&S->multi), (size_t)N + 4) != hipSuccess) {
+        pf::CtxErr{ctx} = "pf_side_components: out of device memory";
+        return PF_ERR_HIP;
+    }
+    S->n_unitigs = N;
+    S->ready = false;
+    return PF_OK;
+}
+
+// the buffers of pf_replay_device for n records
+static int cc_replay_arrays(pf_ctx *ctx, CcState *S, uint64_t n) {
+    const uint32_t n_sides = 2 * S->n_unitigs;
+    if (!S->big) {
+        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->big), (size_t)n_sides + 4));
+        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->work), (size_t)n_sides * 4 + 4));
+        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->f2), (size_t)n_sides + 4));
+    }
+    if (S->sort_cap < n + 1) {
+        for (uint32_t **p : {&S->keys, &S->keys2, &S->vals, &S->vals2, &S->big_idx})
+            if (*p) { (void)hipFree(*p); *p = nullptr; }
+        S->sort_cap = n + n / 4 + 64;
+        for (uint32_t **p : {&S->keys, &S->keys2, &S->vals, &S->vals2, &S->big_idx})
+            PF_HIP(hipMalloc(reinterpret_cast<void **>(p), S->sort_cap * 4));
+    }
+    unsigned bits = 1;
+    while ((1ull << bits) < n_sides) ++bits;
+    size_t need = 0;
+    PF_HIP(rocprim::radix_sort_pairs(nullptr, need, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, ctx->stream));
+    if (need > S->sort_tmp_bytes) {
+        if (S->sort_tmp) (void)hipFree(S->sort_tmp);
+        S->sort_tmp = nullptr;
+        PF_HIP(hipMalloc(&S->sort_tmp, need + 256));
+        S->sort_tmp_bytes = need + 256;
+    }
+    return PF_OK;
+}
+
 extern "C" {
+
+int pf_find_reserve(pf_ctx *ctx, uint64_t n_records) {
+    if (!ctx || !ctx->has_adj || (n_records >> 32)) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
+    if (!ctx->cc) ctx->cc = new CcState();
+    CcState *S = static_cast<CcState *>(ctx->cc);
+    if (S->n_unitigs != ctx->N || !S->parent) {
+        const int ga = cc_graph_arrays(ctx, S, ctx->N);
+        if (ga != PF_OK) return ga;
+    }
+    const int ra = cc_replay_arrays(ctx, S, std::max<uint64_t>(n_records, 1));
+    if (ra != PF_OK) return ra;
+    if (!grow(S->t_flag, S->t_flag_cap, n_records + 8) || !grow(S->t_cnt, S->t_cnt_cap, 2)) { pf::CtxErr{ctx} = "pf_find_reserve: out of device memory"; return PF_ERR_HIP; }
+    uint8_t *flags = nullptr;
+    uint32_t *plus = nullptr, *minus = nullptr;
+    return call_state_arrays(ctx, &flags, &plus, &minus);
+}
 
 int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uint64_t n_records, const uint32_t *pool, uint64_t pool_len,
                        const pf_bfs_record *extra, uint64_t n_extra, const uint32_t *extra_pool, uint64_t extra_pool_len) {
@@ -395,24 +464,12 @@ int pf_side_components(pf_ctx *ctx, int reset, const pf_bfs_record *records, uin
     const uint32_t N = ctx->N;
     const uint32_t n_sides = 2 * N;
     if (S->n_unitigs != N || !S->parent) {
-        // (the colour gate's arrays belong to the graph, not to a pass: they survive)
-        uint64_t *fm = S->full_mask, *stt = S->size_total;
-        uint32_t *nf = S->n_full_enc;
-        const uint32_t nc = S->n_colors;
-        S->full_mask = S->size_total = nullptr;
-        S->n_full_enc = nullptr;
-        S->release();   // (resets the fields, the object stays)
-        S->full_mask = fm; S->size_total = stt; S->n_full_enc = nf; S->n_colors = nc;
-        if (hipMalloc(reinterpret_cast<void **>(&S->bad), 16) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&S->parent), (size_t)n_sides * 4 + 4) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&S->first), (size_t)n_sides * 4 + 4) != hipSuccess ||
-            hipMalloc(reinterpret_cast<void **>(&S->multi), (size_t)N + 4) != hipSuccess) {
-            pf::CtxErr{ctx} = "pf_side_components: out of device memory";
-            return PF_ERR_HIP;
-        }
-        S->n_unitigs = N;
+        const int ga = cc_graph_arrays(ctx, S, N);
+        if (ga != PF_OK) return ga;
         reset = 1;
     }
+    if (!S->ready) reset = 1;   // (arrays taken by pf_find_reserve: never initialised)
+    S->ready = true;
     if (reset) {
         k_cc_init<<<(n_sides + 255) / 256, 256, 0, st>>>(S->parent, S->first, S->multi, n_sides);
         S->xrec = nullptr;   // (it points into t_xrec)
@@ -556,17 +613,9 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     if (n >> 32) { pf::CtxErr{ctx} = "pf_replay_device: more than 2^32 records"; return PF_ERR_ARG; }
     const pf_bfs_record *rec = static_cast<const pf_bfs_record *>(ctx->cc_rec);
     const uint32_t *pool = ctx->cc_pool;
-    if (!S->big) {
-        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->big), (size_t)n_sides + 4));
-        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->work), (size_t)n_sides * 4 + 4));
-        PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->f2), (size_t)n_sides + 4));
-    }
-    if (S->sort_cap < n + 1) {
-        for (uint32_t **p : {&S->keys, &S->keys2, &S->vals, &S->vals2, &S->big_idx})
-            if (*p) { (void)hipFree(*p); *p = nullptr; }
-        S->sort_cap = n + n / 4 + 64;
-        for (uint32_t **p : {&S->keys, &S->keys2, &S->vals, &S->vals2, &S->big_idx})
-            PF_HIP(hipMalloc(reinterpret_cast<void **>(p), S->sort_cap * 4));
+    {
+        const int ra = cc_replay_arrays(ctx, S, std::max<uint64_t>(n, 1));
+        if (ra != PF_OK) return ra;
     }
     uint8_t *flags = nullptr;
     uint32_t *plus = nullptr, *minus = nullptr;
@@ -586,15 +635,7 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     PF_HIP(hipGetLastError());
     unsigned bits = 1;
     while ((1ull << bits) < n_sides) ++bits;
-    size_t need = 0;
-    PF_HIP(rocprim::radix_sort_pairs(nullptr, need, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, st));
-    if (need > S->sort_tmp_bytes) {
-        if (S->sort_tmp) (void)hipFree(S->sort_tmp);
-        S->sort_tmp = nullptr;
-        PF_HIP(hipMalloc(&S->sort_tmp, need + 256));
-        S->sort_tmp_bytes = need + 256;
-    }
-    size_t have = S->sort_tmp_bytes;
+    size_t have = S->sort_tmp_bytes;   // (sized by cc_replay_arrays)
     PF_HIP(rocprim::radix_sort_pairs(S->sort_tmp, have, S->keys, S->keys2, S->vals, S->vals2, (size_t)n, 0, bits, st));
     // the records left to the caller, ascending (gathered first: the caller commits them while the device commits the rest)
     const char *oom = "pf_replay_device: out of device memory";
