@@ -259,7 +259,9 @@ protected:
             ogroups.release(); oilen.release();
         }
     } ax_[3];
-    size_t batch_bubbles_ = 1u << 16, align_pieces_ = 64;
+    // (a text piece = four batches: 196 608 bubbles, 44 MB of text at k = 25 -- pieces short enough that the last one's PCIe copy and file
+    // copy, which nothing overlaps, stay small; tools/ab_pass.py BATCH=n, profiles/r08_experiments.txt)
+    size_t batch_bubbles_ = 49152, align_pieces_ = 64;
     // pinned buffers of the whole-graph device calls
     struct BubbleExchange {
         PinnedBuf<pf_bfs_record> bfs_rec;
