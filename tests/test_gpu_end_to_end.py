@@ -424,6 +424,31 @@ def test_commits_on_the_device_the_host_and_both(case, mode, tmp_path):
     assert not compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(str(tmp_path), "PloidyFrost_output")), (case, mode)
 
 
+@pytest.mark.parametrize("case", ["weird12k", "giant7k", "hex30k"])
+@pytest.mark.parametrize("knob", ["PF_BFS_HINT_AT=9", "PF_BFS_WAVE_CAP=16", "PF_BFS_HINT_AT=9 PF_BFS_WAVE_CAP=16"])
+def test_live_notices_and_early_give_ups_do_not_change_a_byte(case, knob, tmp_path):
+    """K-BFS's wave tier enters a traversal into the live list the host walkers poll when it reaches 48 vertices -- a notice: the
+    traversal goes on on the device, and a walk whose traversal ends there is dropped.  With the notice at 9 vertices most notices are
+    of that kind; with the tier giving up at 16 vertices instead of 128 many more traversals are walked on the host and their
+    components committed there.  The same twelve files either way."""
+    meta = load_case(case)
+    env = dict(os.environ)
+    env.update(dict(kv.split("=") for kv in knob.split()))
+    env["PF_TRACE_FIND"] = "1"
+    r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "4"] + meta["args"], cwd=tmp_path, capture_output=True, text=True, env=env)
+    assert r.returncode == 0, r.stderr[-400:] + r.stdout[-400:]
+    assert not compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(str(tmp_path), "PloidyFrost_output")), (case, knob)
+    import re
+    m = re.search(r"(\d+) notices in the live list, (\d+) traversals given up", r.stderr)
+    assert m, r.stderr[-400:]
+    notices, given_up = int(m.group(1)), int(m.group(2))
+    assert notices >= given_up, (notices, given_up)
+    if case == "giant7k":
+        assert given_up > 0
+    if case == "weird12k" and "WAVE_CAP" not in knob:
+        assert notices > given_up, (notices, given_up)   # noticed traversals that ended on the device: their walks were dropped
+
+
 def test_graph_without_a_candidate_entrance(tmp_path):
     """three unitigs that share no k-mer overlap: no vertex has two successors, findSuperBubble has nothing to traverse or commit"""
     from ploidyfrost_amd import synth
