@@ -156,7 +156,9 @@ public:
     int sync_state_to_host();
     uint64_t output_bytes() const { return out_bytes_; }
     // text of <outpre>_allele_frequency.txt of the last run (the record slab a multi-GPU job gathers)
-    const std::string &last_allele_frequency() const { return last_allfre_; }
+    // (after a pass that wrote its files the rows are read back from <outpre>_allele_frequency.txt when somebody asks, instead of
+    // being copied aside piece by piece under the writer of every pass)
+    const std::string &last_allele_frequency() const;
 
 protected:
     // graph + adjacency on the device, no count database yet (the colored subclass brings its own)
@@ -291,7 +293,8 @@ protected:
     bool state_on_device_ = false;   // pf_call_set_state holds the state findSuperBubble left (finish_find uploads it)
     PinnedBuf<char> sb_text_;        // text of super_bubble.txt on its way from the device to the file
     PhaseTimes times_;
-    std::string last_allfre_;
+    mutable std::string last_allfre_, last_allfre_file_;
+    mutable uint64_t last_allfre_bytes_ = 0;
     uint64_t allele_[4] = {0, 0, 0, 0};
     uint64_t core_cov_ = 0, core_num_ = 0, n_super_bubble_ = 0, out_bytes_ = 0;
 };

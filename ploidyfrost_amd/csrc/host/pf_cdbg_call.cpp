@@ -178,6 +178,7 @@ int CDBG::ploidy_write(const std::string &outpre, const uint64_t offsets[PF_CALL
     uint64_t running[PF_CALL_STREAMS];
     for (int s = 0; s < PF_CALL_STREAMS; ++s) running[s] = offsets[s];
     last_allfre_.clear();
+    last_allfre_file_.clear();
     int st = PF_OK;
     auto format = [&](uint64_t i) {
         const uint64_t first = i * CHUNK, count = std::min<uint64_t>(CHUNK, slice_nb_ - first);
@@ -272,6 +273,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     if (opener.joinable()) opener.join();
     if (open_failed >= 0) return fail(PF_ERR_ARG, "CDBG:: Open " + files[(size_t)open_failed].name + " file error");
     last_allfre_.clear();
+    last_allfre_file_.clear();
     // Fresh result files (a one-shot run: every run of the CLI) get their pages NOW, on helper threads, while the device aligns the
     // first range -- 438 MB of first-touch faults under the writer were half of a first PloidyEstimation at 5 M unitigs.  The sizes
     // are estimates from the number of bubbles and k (a bubble of two paths of 2k - 1 bases, one site); what they miss is extended
@@ -403,7 +405,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 }
                 copy_spans(spans, n_spans, T);   // all ten streams in one dispatch of the pool
             }
-            last_allfre_.append(hb.p + off[0], d.res.text_len[0]);
+            if (!write_files_) last_allfre_.append(hb.p + off[0], d.res.text_len[0]);   // (else: read back from the file on demand)
             for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].bytes += d.res.text_len[s];
             write_s += since(tw);
             if (trace) fprintf(stderr, "[ploidy]   batch %zu written %.2f ms\n", b, since(t_all) * 1e3);
@@ -595,6 +597,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         if (trace) fprintf(stderr, "[ploidy]   %s finished at %llu bytes in %.3f ms\n", of.name.c_str(), (unsigned long long)of.bytes, since(tfin) * 1e3);
         if (of.rc) return fail(PF_ERR_ARG, "CDBG:: write error on " + of.name);
     }
+    if (write_files_) { last_allfre_file_ = outdir_ + "/" + files[0].name; last_allfre_bytes_ = files[0].bytes; }
     write_s += since(t0);
     times_.write_s = write_s;
     tp("files closed");
@@ -610,6 +613,20 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         if (core_num_) printf("%s::PloidyEstimation(): Sites' Average Coverage:%d\n", tag_, (int)(core_cov_ / core_num_));
     }
     return 0;
+}
+
+const std::string &CDBG::last_allele_frequency() const {
+    if (!last_allfre_file_.empty()) {
+        last_allfre_.clear();
+        if (FILE *f = fopen(last_allfre_file_.c_str(), "rb")) {
+            last_allfre_.resize(last_allfre_bytes_);
+            const size_t got = fread(&last_allfre_[0], 1, last_allfre_bytes_, f);
+            last_allfre_.resize(got);
+            fclose(f);
+        }
+        last_allfre_file_.clear();
+    }
+    return last_allfre_;
 }
 
 }  // namespace pfh

@@ -1045,6 +1045,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
     if (opener.joinable()) opener.join();
     if (open_failed >= 0) { close_files(); return fail(PF_ERR_ARG, "CDBG:: Open " + files[(size_t)open_failed].name + " file error"); }
     last_allfre_.clear();
+    last_allfre_file_.clear();
     tp("files open");
     double write_s = 0;
     auto write_batch = [&](std::vector<ChunkOut> &outs) {

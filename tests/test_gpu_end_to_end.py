@@ -67,6 +67,14 @@ def test_facade_full_run_and_no_disk_mode(tmp_path):
     run2.find_superbubbles("g")
     run2.ploidy_estimation("g", 5, 1000)
     assert run2.times()["output_bytes"] == t["output_bytes"] and not d2.exists()
+    # the rows of allele_frequency.txt as the caller's ranks exchange them: read back from the file after a pass that wrote it,
+    # kept in memory by a pass that wrote nothing
+    want = open(os.path.join(meta["dir"], "expected", "g_allele_frequency.txt"), "rb").read()
+    assert run.last_allele_frequency().tobytes() == want
+    assert run2.last_allele_frequency().tobytes() == want
+    run.find_superbubbles("g")
+    run.ploidy_estimation("g", 5, 1000)   # (a second pass over the same files)
+    assert run.last_allele_frequency().tobytes() == want
 
 
 @pytest.mark.parametrize("case", ["hex30k", "k31_z16", "tet_frac"])
