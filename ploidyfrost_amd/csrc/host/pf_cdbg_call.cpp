@@ -449,7 +449,14 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         const uint64_t n_ranges = ranges_env > 0 ? (uint64_t)ranges_env : (pieces >= 4 ? 2 : 1);
         if (n_ranges > 1) ALIGN = std::min<uint64_t>(ALIGN, std::max<uint64_t>(1, (pieces + n_ranges - 1) / n_ranges) * CHUNK);
     }
-    const int first_env = [] { const char *e = getenv("PF_ALIGN_FIRST"); return e ? atoi(e) : 0; }();   // measurements: pieces in the first range
+    int first_env = [] { const char *e = getenv("PF_ALIGN_FIRST"); return e ? atoi(e) : 0; }();   // measurements: pieces in the first range
+    {
+        // Two ranges are not cut in the middle: what a pass ends with is the PCIe copy of the LAST range's text (0.8 ms per piece, nothing
+        // beside it), so the first range takes five eighths of the pieces (tools/ab_pass.py PF_ALIGN_FIRST: 5 + 3 of eight pieces 20.08 ms,
+        // 4 + 4 20.28, 6 + 2 20.50, 3 + 5 20.90)
+        const uint64_t pieces = (n_tasks + CHUNK - 1) / CHUNK;
+        if (first_env <= 0 && !getenv("PF_ALIGN_RANGES") && pieces >= 4) first_env = (int)std::min<uint64_t>((pieces * 5 + 7) / 8, ((uint64_t)1 << 24) / CHUNK);
+    }
     struct Range {
         int lane;
         uint64_t n, var_base;
