@@ -270,16 +270,20 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
         }
     });
     tf("patch gathered");
+    // (the host arrays go back to all-zero for the next pass beside the device's patch: that reads the gathered copies only)
+    std::thread undo([&] {
+        parallel_chunks(p_sides.size(), 1u << 14, pt, [&](size_t, size_t b, size_t e) {
+            for (size_t i = b; i < e; ++i) {   // (a side logged twice may be zeroed from two threads: relaxed atomic stores of the same value)
+                const uint32_t s = p_sides[i];
+                __atomic_store_n(&((s & 1) ? minus_ : plus_)[s >> 1], 0u, __ATOMIC_RELAXED);
+                __atomic_store_n(&big_f2_[s], (uint8_t)0, __ATOMIC_RELAXED);
+            }
+        });
+    });
     st = pf_replay_finish(ctx_, p_sides.data(), p_links.data(), p_bytes.data(), p_sides.size());
+    undo.join();
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
     if (trace_find) fprintf(stderr, "[find] %zu sides patched on the device %.2f ms\n", p_sides.size(), since(t_all) * 1e3);
-    parallel_chunks(p_sides.size(), 1u << 14, pt, [&](size_t, size_t b, size_t e) {   // back to all-zero for the next pass
-        for (size_t i = b; i < e; ++i) {   // (a side logged twice may be zeroed from two threads: relaxed atomic stores of the same value)
-            const uint32_t s = p_sides[i];
-            __atomic_store_n(&((s & 1) ? minus_ : plus_)[s >> 1], 0u, __ATOMIC_RELAXED);
-            __atomic_store_n(&big_f2_[s], (uint8_t)0, __ATOMIC_RELAXED);
-        }
-    });
     state_host_stale_ = true;
     state_on_device_ = true;
     tf("large components committed here");
