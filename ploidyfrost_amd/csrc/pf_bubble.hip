@@ -393,7 +393,7 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
                 for (uint32_t t = lane; t < pp.len; t += WAVE) {
                     const uint32_t j = rev ? pp.len - 1 - t : t;
                     const uint32_t b = (uint32_t)(w[j >> 5] >> (62 - 2 * (j & 31))) & 3u;
-                    pbuf[at + t] = "ACGT"[rev ? 3 - b : b];
+                    pbuf[at + t] = pf::base_char((uint32_t)(rev ? 3 - b : b));
                 }
             }
             at += pp.len;

@@ -740,13 +740,26 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
         r.n_indel_len = 0;
         a.res[j] = r;
         if (t_off + 2ull * m <= a.text_cap && s_off + 1 <= a.site_cap && 2 * s_off + 2 <= a.group_cap) {
-            char *o = staged ? stage + my_excl : a.otext + t_off;
-            for (uint32_t c = 0; 32 * c < m; ++c) {
-                const uint64_t x0 = oriented_chunk(w0, m, (ov0 & 1) != 0, c), x1 = oriented_chunk(w1, m, (ov1 & 1) != 0, c);
-                const uint32_t e = m - 32 * c < 32 ? m - 32 * c : 32;
-                for (uint32_t q = 0; q < e; ++q) {
-                    o[32 * c + q] = "ACGT"[(x0 >> (62 - 2 * q)) & 3];
-                    o[m + 32 * c + q] = "ACGT"[(x1 >> (62 - 2 * q)) & 3];
+            // (two loops, so that the staged one stores through an LDS pointer: one pointer for both would be a generic one, flat stores)
+            if (staged) {
+                char *o = stage + my_excl;
+                for (uint32_t c = 0; 32 * c < m; ++c) {
+                    const uint64_t x0 = oriented_chunk(w0, m, (ov0 & 1) != 0, c), x1 = oriented_chunk(w1, m, (ov1 & 1) != 0, c);
+                    const uint32_t e = m - 32 * c < 32 ? m - 32 * c : 32;
+                    for (uint32_t q = 0; q < e; ++q) {
+                        o[32 * c + q] = pf::base_char((uint32_t)((x0 >> (62 - 2 * q)) & 3));
+                        o[m + 32 * c + q] = pf::base_char((uint32_t)((x1 >> (62 - 2 * q)) & 3));
+                    }
+                }
+            } else {
+                char *o = a.otext + t_off;
+                for (uint32_t c = 0; 32 * c < m; ++c) {
+                    const uint64_t x0 = oriented_chunk(w0, m, (ov0 & 1) != 0, c), x1 = oriented_chunk(w1, m, (ov1 & 1) != 0, c);
+                    const uint32_t e = m - 32 * c < 32 ? m - 32 * c : 32;
+                    for (uint32_t q = 0; q < e; ++q) {
+                        o[32 * c + q] = pf::base_char((uint32_t)((x0 >> (62 - 2 * q)) & 3));
+                        o[m + 32 * c + q] = pf::base_char((uint32_t)((x1 >> (62 - 2 * q)) & 3));
+                    }
                 }
             }
             a.ogroups[2 * s_off] = 1;
@@ -1099,23 +1112,23 @@ __global__ __launch_bounds__(64) void k_call_stack(StackArgs a) {
                 if (ok) {
                     L = l1;
                     for (uint32_t c = 0; c < L; ++c) {
-                        grows[(size_t)c * CS] = (c < at) ? "ACGT"[stack_code(X, c)] : (c < at + d ? '-' : "ACGT"[stack_code(X, c - d)]);
-                        grows[RS + (size_t)c * CS] = "ACGT"[stack_code(Y, c)];
+                        grows[(size_t)c * CS] = (c < at) ? pf::base_char((uint32_t)(stack_code(X, c))) : (c < at + d ? '-' : pf::base_char((uint32_t)(stack_code(X, c - d))));
+                        grows[RS + (size_t)c * CS] = pf::base_char((uint32_t)(stack_code(Y, c)));
                     }
                 }
             } else {
-                for (uint32_t c = 0; c < L; ++c) grows[(size_t)c * CS] = "ACGT"[stack_code(X, c)];
+                for (uint32_t c = 0; c < L; ++c) grows[(size_t)c * CS] = pf::base_char((uint32_t)(stack_code(X, c)));
                 for (uint32_t p = 1; p < n && ok; ++p) {
                     const pf_bubble_path pp = a.bpath[first + p];
                     stack_load(a, pp, Y);
                     char *row = grows + (size_t)p * RS;
                     if (pp.len == L) {
                         ok = stack_certify(X, Y, L, a.M, a.D, a.G);
-                        if (ok) for (uint32_t c = 0; c < L; ++c) row[(size_t)c * CS] = "ACGT"[stack_code(Y, c)];
+                        if (ok) for (uint32_t c = 0; c < L; ++c) row[(size_t)c * CS] = pf::base_char((uint32_t)(stack_code(Y, c)));
                     } else if (pp.len < L) {
                         const uint32_t d = L - pp.len, at = indel_place(X, Y, pp.len, d);
                         ok = at != 0xFFFFFFFFu && indel_certify(X, Y, L, pp.len, at, a.M, a.D, a.G);
-                        if (ok) for (uint32_t c = 0; c < L; ++c) row[(size_t)c * CS] = (c < at) ? "ACGT"[stack_code(Y, c)] : (c < at + d ? '-' : "ACGT"[stack_code(Y, c - d)]);
+                        if (ok) for (uint32_t c = 0; c < L; ++c) row[(size_t)c * CS] = (c < at) ? pf::base_char((uint32_t)(stack_code(Y, c))) : (c < at + d ? '-' : pf::base_char((uint32_t)(stack_code(Y, c - d))));
                     } else {
                         ok = false;   // a later path longer than the first: row 0 would take a gap
                     }
@@ -1159,7 +1172,7 @@ __global__ __launch_bounds__(64) void k_call_stack(StackArgs a) {
                     StackPlanes Y;
                     stack_load(a, pp, Y);
                     char *o = a.otext + t_off + (uint64_t)p * L;
-                    for (uint32_t c = 0; c < L; ++c) o[c] = "ACGT"[stack_code(Y, c)];
+                    for (uint32_t c = 0; c < L; ++c) o[c] = pf::base_char((uint32_t)(stack_code(Y, c)));
                     // this row's base in every variant column, kept in the group bytes for now
                     uint32_t q = 0;
 #pragma unroll
@@ -1460,7 +1473,7 @@ __device__ inline char path_char(const PathArgs &a, const uint32_t *major, const
     uint32_t x = 0;
     while (x + 1 < n_seg && seg_start[x + 1] <= pos) ++x;
     const uint32_t idx = pos - seg_start[x] + (x == 0 ? first_idx : 0);
-    return "ACGT"[oriented_base(a.seq, a.off, a.len, major[x], idx)];
+    return pf::base_char((uint32_t)(oriented_base(a.seq, a.off, a.len, major[x], idx)));
 }
 
 // Two-stack enumeration of every s -> t walk (src/CDBG.cpp:1364-1412) with both stacks in REGISTERS: entry x of the major stack

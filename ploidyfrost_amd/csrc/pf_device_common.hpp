@@ -133,4 +133,8 @@ __device__ inline int lane_id() { return (int)(threadIdx.x & (WAVE - 1)); }
 // general __shfl is an LDS-crossbar ds_bpermute with LDS latency
 __device__ inline uint32_t read_lane(uint32_t x, int i) { return (uint32_t)__builtin_amdgcn_readlane((int)x, i); }
 
+// "ACGT"[b] without the table: a string literal indexed by a lane-dependent value is a byte load from constant memory per character
+// (K-SNP's rows cost two of them per column); the four characters fit one register
+__device__ inline char base_char(uint32_t b) { return (char)((0x54474341u >> (8u * (b & 3u))) & 0xFFu); }
+
 }  // namespace pf

@@ -159,7 +159,7 @@ __device__ inline char pair_base(const uint64_t (&w)[PairGeom<NMAX>::NA], uint32
     uint64_t x = w[0];
 #pragma unroll
     for (int q = 1; q < PairGeom<NMAX>::NA; ++q) x = (idx >> 5) == (uint32_t)q ? w[q] : x;
-    return "ACGT"[(uint32_t)(x >> (62 - 2 * (idx & 31))) & 3u];
+    return pf::base_char((uint32_t)((uint32_t)(x >> (62 - 2 * (idx & 31))) & 3u));
 }
 
 // traceback (src/SeqAlign.cpp:306-478) when the matrix has one optimal path within the 5-gap-open budgets: the reference's
