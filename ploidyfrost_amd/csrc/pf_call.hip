@@ -683,37 +683,13 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
         }
     }
     const bool take = active && diff == 1;
-    // pool space: one atomic per wavefront and pool
+    // pool space: one set of atomics per BLOCK.  The pool heads share a cache line and every taker of the batch adds to them: atomics on
+    // one line queue one behind the other (~11 ns each), and a wavefront's four were what this launch took -- 40 000 of them, 0.45 of its
+    // 0.6 ms (SQ: 81 % of the wave-cycles waiting, 1.5 % issuing VALU).  The four wavefronts of a block pool their totals through LDS.
     const unsigned long long tm = __ballot(take);
-    unsigned long long t_off = 0, s_off = 0;
-    if (tm) {
-        // exclusive prefix of 2 m over the taking lanes
-        uint32_t mine = take ? 2 * m : 0, incl = mine;
-        for (int o = 1; o < WAVE; o <<= 1) {
-            const uint32_t x = __shfl_up(incl, o, WAVE);
-            if (lane >= o) incl += x;
-        }
-        const uint32_t total = __shfl(incl, WAVE - 1, WAVE);
-        const uint32_t cnt = (uint32_t)__popcll(tm);
-        unsigned long long tb = 0, sb = 0;
-        if (lane == 0) {
-            tb = atomicAdd(&a.heads[0], (unsigned long long)total);
-            sb = atomicAdd(&a.heads[1], (unsigned long long)cnt);
-            atomicAdd(&a.heads[2], 2ull * cnt);   // groups: two bytes per site, at 2 * (site index)
-            atomicAdd(&a.cnt->n_snp_done, cnt);
-        }
-        tb = ((unsigned long long)__shfl((uint32_t)(tb >> 32), 0, WAVE) << 32) | __shfl((uint32_t)tb, 0, WAVE);
-        sb = ((unsigned long long)__shfl((uint32_t)(sb >> 32), 0, WAVE) << 32) | __shfl((uint32_t)sb, 0, WAVE);
-        t_off = tb + (incl - mine);
-        s_off = sb + (unsigned long long)__popcll(tm & ((1ull << lane) - 1));
-    }
-    // The rows leave through LDS: a wavefront's rows are one contiguous span of the text pool (lane order), so they are staged
-    // per lane and copied out by consecutive lanes -- whole 64-byte segments per store instead of 64 scattered single bytes
-    // (which cost 39 bytes of HBM write traffic per byte written, by the PMC counters).
-    __shared__ __attribute__((aligned(16))) char s_rows[4][SNP_STAGE];
-    char *stage = s_rows[threadIdx.x >> 6];
     uint32_t my_excl = 0, wave_total = 0;
     {
+        // exclusive prefix of 2 m over the taking lanes
         uint32_t mine = take ? 2 * m : 0, incl = mine;
         for (int o = 1; o < WAVE; o <<= 1) {
             const uint32_t x = __shfl_up(incl, o, WAVE);
@@ -722,9 +698,37 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
         my_excl = incl - mine;
         wave_total = __shfl(incl, WAVE - 1, WAVE);
     }
-    const unsigned long long wave_base = t_off - my_excl;   // (uniform over the taking lanes)
-    const unsigned long long wb = ((unsigned long long)__shfl((uint32_t)(wave_base >> 32), tm ? __ffsll((long long)tm) - 1 : 0, WAVE) << 32) |
-                                  __shfl((uint32_t)wave_base, tm ? __ffsll((long long)tm) - 1 : 0, WAVE);
+    __shared__ uint32_t s_wtot[4], s_wcnt[4];
+    __shared__ unsigned long long s_tb, s_sb;
+    const int wv = (int)(threadIdx.x >> 6);
+    if (lane == 0) {
+        s_wtot[wv] = wave_total;
+        s_wcnt[wv] = (uint32_t)__popcll(tm);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t total = s_wtot[0] + s_wtot[1] + s_wtot[2] + s_wtot[3], cnt = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+        unsigned long long tb = 0, sb = 0;
+        if (cnt) {
+            tb = atomicAdd(&a.heads[0], (unsigned long long)total);
+            sb = atomicAdd(&a.heads[1], (unsigned long long)cnt);
+            atomicAdd(&a.heads[2], 2ull * cnt);   // groups: two bytes per site, at 2 * (site index)
+            atomicAdd(&a.cnt->n_snp_done, cnt);
+        }
+        s_tb = tb;
+        s_sb = sb;
+    }
+    __syncthreads();
+    uint32_t before_t = 0, before_c = 0;
+    for (int w = 0; w < wv; ++w) { before_t += s_wtot[w]; before_c += s_wcnt[w]; }
+    const unsigned long long wb = s_tb + before_t;   // where this wavefront's rows start
+    const unsigned long long t_off = wb + my_excl;
+    const unsigned long long s_off = s_sb + before_c + (unsigned long long)__popcll(tm & ((1ull << lane) - 1));
+    // The rows leave through LDS: a wavefront's rows are one contiguous span of the text pool (lane order), so they are staged
+    // per lane and copied out by consecutive lanes -- whole 64-byte segments per store instead of 64 scattered single bytes
+    // (which cost 39 bytes of HBM write traffic per byte written, by the PMC counters).
+    __shared__ __attribute__((aligned(16))) char s_rows[4][SNP_STAGE];
+    char *stage = s_rows[wv];
     const bool staged = wave_total <= SNP_STAGE;
     if (take) {
         // K-SNP is the first taker of a batch (heads zeroed before it, K-BUBBLE launched behind it on the stream): the group
