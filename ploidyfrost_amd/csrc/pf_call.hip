@@ -550,6 +550,60 @@ __device__ inline void wave_append(int key, uint32_t val, const CallLists &L, Ca
     }
 }
 
+// The same for a block of four wavefronts (every thread of the block must call it): the counters of all lists share a cache line or two,
+// and atomics on one line queue one behind the other -- a wavefront's three or four were most of K-PREP's launch.  The wavefronts leave
+// their counts per key in LDS, one thread per key adds the block's total, every lane takes its place behind the wavefronts before its own.
+constexpr int N_KEYS = NQ + 7;
+__device__ inline void block_append(int key, uint32_t val, const CallLists &L, CallCounters *cnt) {
+    __shared__ uint32_t s_n[4][N_KEYS];
+    __shared__ uint32_t s_base[N_KEYS];
+    const int lane = lane_id(), wv = (int)(threadIdx.x >> 6);
+    if (lane < N_KEYS) s_n[wv][lane] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    uint32_t rank = 0;
+    unsigned long long todo = __ballot(key != KEY_NONE);
+    while (todo) {
+        const int x = __shfl(key, __ffsll((long long)todo) - 1, WAVE);
+        const unsigned long long m = __ballot(key == x);
+        todo &= ~m;
+        if (key == x) rank = (uint32_t)__popcll(m & ((1ull << lane) - 1));
+        if (lane == __ffsll((long long)m) - 1) s_n[wv][x] = (uint32_t)__popcll(m);
+    }
+    __syncthreads();
+    if (threadIdx.x < (unsigned)N_KEYS) {
+        const int x = (int)threadIdx.x;
+        const uint32_t total = s_n[0][x] + s_n[1][x] + s_n[2][x] + s_n[3][x];
+        uint32_t base = 0;
+        if (total) {
+            uint32_t c_off = (uint32_t)offsetof(CallCounters, n_trio4);
+            c_off = x == KEY_TRIO ? (uint32_t)offsetof(CallCounters, n_trio) : c_off;
+            c_off = x == KEY_STACK ? (uint32_t)offsetof(CallCounters, n_stack) : c_off;
+            c_off = x == KEY_PAIR2 ? (uint32_t)offsetof(CallCounters, n_pair2) : c_off;
+            c_off = x == KEY_PAIR ? (uint32_t)offsetof(CallCounters, n_pair) : c_off;
+            c_off = x == KEY_SNP ? (uint32_t)offsetof(CallCounters, n_snp) : c_off;
+            c_off = x == KEY_BRANCHING ? (uint32_t)offsetof(CallCounters, n_branching) : c_off;
+            c_off = x < NQ ? (uint32_t)offsetof(CallCounters, q_n) + 4u * (uint32_t)x : c_off;
+            base = atomicAdd(reinterpret_cast<unsigned int *>(reinterpret_cast<char *>(cnt) + c_off), total);
+        }
+        s_base[x] = base;
+    }
+    __syncthreads();
+    if (key != KEY_NONE) {
+        uint32_t at = s_base[key] + rank;
+        for (int w = 0; w < wv; ++w) at += s_n[w][key];
+        if (key < NQ) L.queues[(size_t)key * L.nb + at] = val;
+        else if (key == KEY_BRANCHING) L.blist[at] = val;
+        else if (key == KEY_SNP) L.slist[at] = val;
+        else if (key == KEY_PAIR) L.plist[at] = val;
+        else if (key == KEY_PAIR2) L.plist2[at] = val;
+        else if (key == KEY_STACK) L.klist[at] = val;
+        else if (key == KEY_TRIO) L.tlist[at] = val;
+        else L.tlist4[at] = val;
+    }
+    __syncthreads();   // (the tables may be used again by the caller's next call)
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // K-PREP
 struct PrepArgs {
@@ -613,7 +667,7 @@ __global__ __launch_bounds__(256) void k_call_prep(PrepArgs a) {
             key = KEY_BRANCHING;
         }
     }
-    wave_append(key, j, a.lists, a.cnt);
+    block_append(key, j, a.lists, a.cnt);
     // class 3 / retry sizing: rare, one atomic per wave that has any
     unsigned long long m3 = need3, mr = retry;
     for (int o = 32; o > 0; o >>= 1) {
@@ -791,7 +845,7 @@ __global__ __launch_bounds__(256) void k_call_snp(SnpArgs a) {
     // the rest: K-PAIR when short, else K-BUBBLE's queue of their size class
     int key = KEY_NONE;
     if (active && !take) key = (a.stack_ok >= 3 && m <= STACK_MAX) ? KEY_STACK : (a.pair_ok && m <= PAIR_MAX) ? KEY_PAIR : (a.pair_ok && m <= PAIR_MAX2) ? KEY_PAIR2 : 2 * bubble_class(m, m) + (m > 64 ? 0 : 1);
-    wave_append(key, j, a.lists, a.cnt);
+    block_append(key, j, a.lists, a.cnt);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
