@@ -209,15 +209,15 @@ int unitig_cov(const pfo_ctx &c, uint32_t ov, uint64_t &sum, uint32_t &mn) {
 }
 
 // readCov(const string&, low, up), CDBG.cpp:29-60
-int string_cov(const pfo_ctx &c, const std::string &s, uint32_t low, uint32_t up, uint64_t &sum, bool &ok) {
+int string_cov(const pfo_ctx &c, const std::string &s, uint32_t low, uint32_t up, uint64_t &sum, bool &ok, uint64_t *lost = nullptr) {
     const int k = c.g.k;
     sum = 0;
     ok = true;
     if (!c.db.both_strands) return 0;
+    StringProbe probe(c.db, k);
     for (size_t i = 0; i + k <= s.size(); ++i) {
-        uint64_t x = pack_kmer(s.data() + i, k);
         uint32_t cnt = 0;
-        if (!c.db.canonical_count(x, cnt)) return 1;
+        if (!probe.count(s.data() + i, cnt)) { if (lost) *lost = probe.held; return 1; }
         if (cnt > low && cnt < up) sum += cnt;
         else { sum = 0; ok = false; return 0; }
     }
@@ -516,12 +516,16 @@ int pfo_ploidy_estimation(pfo_ctx *c, const char *outdir, const char *prefix, in
     std::ofstream *cov_by[4] = {&bicov, &tricov, &tetracov, &pentacov};
     uint64_t allele[4] = {0, 0, 0, 0};
     size_t coreNum = 0, coreCov = 0, var_count = 0;
-    auto emit = [&](unsigned short maxnum, const std::string &fre, const std::string &cov) {
+    UbLog ub_log;  // cells whose value is undefined in the reference (indel_len_at), for the tests' masks
+    uint64_t cov_lines[4] = {0, 0, 0, 0};
+    auto emit = [&](unsigned short maxnum, const std::string &fre, const std::string &cov, bool ub) {
         allfre << fre;
         if (maxnum >= 2 && maxnum <= 5) {
             ++allele[maxnum - 2];
             *fre_by[maxnum - 2] << fre;
             *cov_by[maxnum - 2] << cov;
+            ++cov_lines[maxnum - 2];
+            if (ub) ub_log.cell(maxnum - 2, cov_lines[maxnum - 2]);
         }
     };
     auto var_dist = [&](const std::vector<uint32_t> &vs, uint32_t i, size_t usize, size_t esize) -> uint32_t {
@@ -623,14 +627,15 @@ int pfo_ploidy_estimation(pfo_ctx *c, const char *outdir, const char *prefix, in
                                 cov_info << x << "\t";
                                 fre_info << (double)x / sum << "\n";
                             }
+                            bool ub = false;
                             if (std::find(ar.indel_pos.begin(), ar.indel_pos.end(), var_site[i]) != ar.indel_pos.end()) {
                                 ++indel;
-                                cov_info << 1 << "\t" << ar.indel_len[indel - 1] << "\t" << var_count << "\t" << var_site.size()
+                                cov_info << 1 << "\t" << indel_len_at(ar, indel - 1, &ub) << "\t" << var_count << "\t" << var_site.size()
                                          << "\t" << vd << "\t" << "\n";
                             } else {
                                 cov_info << 1 << "\t" << "0\t" << var_count << "\t" << var_site.size() << "\t" << vd << "\t" << "\n";
                             }
-                            emit(maxnum, fre_info.str(), cov_info.str());
+                            emit(maxnum, fre_info.str(), cov_info.str(), ub);
                         }
                     }
                 }
@@ -696,11 +701,17 @@ int pfo_ploidy_estimation(pfo_ctx *c, const char *outdir, const char *prefix, in
                             while (true) {
                                 std::set<char> cs;
                                 for (size_t p = 0; p < rows.size(); ++p) {
-                                    while (rows[p].at(at[p]) == '-') at[p] += 1;
-                                    char ch = rows[p].at(at[p]);
+                                    // std::string::substr(pos, 1): one character, the EMPTY string at pos == size() (a row
+                                    // that ends in gaps: nothing is appended and c[0] == '\0' joins the set), out_of_range
+                                    // beyond -- the reference then terminates (CDBG.cpp:1478-1488, CCDBG.cpp:3188-3198)
+                                    std::string ch = rows[p].substr(at[p], 1);
+                                    while (ch.compare("-") == 0) {
+                                        at[p] += 1;
+                                        ch = rows[p].substr(at[p], 1);
+                                    }
                                     at[p] += 1;
                                     kstr[p] += ch;
-                                    cs.insert(ch);
+                                    cs.insert(ch[0]);
                                 }
                                 if (cs.size() > 1) break;
                             }
@@ -716,8 +727,8 @@ int pfo_ploidy_estimation(pfo_ctx *c, const char *outdir, const char *prefix, in
                                     if (tmp.length() < (size_t)(k - n)) {
                                         kstr[p] = tmp + kstr[p];
                                         for (int x = at[p]; kstr[p].length() < (size_t)k; ++x) {
-                                            char ch = rows[p].at(x);
-                                            if (ch != '-') kstr[p] += ch;
+                                            std::string ch = rows[p].substr(x, 1);
+                                            if (ch.compare("-") != 0) kstr[p] += ch;
                                         }
                                     } else {
                                         kstr[p] = tmp.substr(tmp.length() - k + n, k - n) + kstr[p];
@@ -731,8 +742,8 @@ int pfo_ploidy_estimation(pfo_ctx *c, const char *outdir, const char *prefix, in
                                 if (tmp.length() < (size_t)k) {
                                     kstr[p] = tmp;
                                     for (int x = site + 1; kstr[p].length() < (size_t)k; ++x) {
-                                        char ch = rows[p].at(x);
-                                        if (ch != '-') kstr[p] += ch;
+                                        std::string ch = rows[p].substr(x, 1);
+                                        if (ch.compare("-") != 0) kstr[p] += ch;
                                     }
                                 } else {
                                     kstr[p] = tmp.substr(tmp.length() - k, k);
@@ -749,8 +760,12 @@ int pfo_ploidy_estimation(pfo_ctx *c, const char *outdir, const char *prefix, in
                             for (const auto &s : groups[gi]) {
                                 uint64_t ssum;
                                 bool ok;
-                                if (string_cov(*c, s, (uint32_t)lower, (uint32_t)upper, ssum, ok)) {
-                                    g_err = "k-mer of a site string missing from the database";
+                                uint64_t lost = 0;
+                                if (string_cov(*c, s, (uint32_t)lower, (uint32_t)upper, ssum, ok, &lost)) {
+                                    // the reference's own line (src/CDBG.cpp:54): the object as it was looked up
+                                    std::string km((size_t)k, 'A');
+                                    for (int x = 0; x < k; ++x) km[x] = "ACGT"[(lost >> (2 * (k - 1 - x))) & 3];
+                                    g_err = "CDBG::readCov():" + km + " kmer can not found .";
                                     return 2;
                                 }
                                 if (!ok) { site_ok = false; break; }
@@ -763,12 +778,13 @@ int pfo_ploidy_estimation(pfo_ctx *c, const char *outdir, const char *prefix, in
                             cov_info << x << "\t";
                             fre_info << x / sum << "\n";
                         }
+                        bool ub = false;
                         if (is_indel)
-                            cov_info << 0 << "\t" << ar.indel_len[indel - 1] << "\t" << var_count << "\t" << var_site.size()
+                            cov_info << 0 << "\t" << indel_len_at(ar, indel - 1, &ub) << "\t" << var_count << "\t" << var_site.size()
                                      << "\t" << vd << "\t" << "\n";
                         else
                             cov_info << 0 << "\t" << "0\t" << var_count << "\t" << var_site.size() << "\t" << vd << "\t" << "\n";
-                        emit(maxnum, fre_info.str(), cov_info.str());
+                        emit(maxnum, fre_info.str(), cov_info.str(), ub);
                     }
                 }
             }

@@ -23,6 +23,19 @@ struct AlignResult {
     std::vector<std::vector<uint16_t>> partition;  // [col][row]
 };
 
+// indel_len[i] as the callers print it (src/CDBG.cpp:1310, 1565; src/CCDBG.cpp:3034, 3315, 3450).  An indel run that is still
+// open at the last column of the alignment never has its length pushed (the column loop of compareStrPair, SeqAlign.cpp:56-157,
+// closes a run only on a later column), so for that last indel site the reference's `indel_len[indel - 1]` reads one element past
+// the vector: heap garbage that changes from run to run (ASLR), or a null dereference (SIGSEGV) when the vector is empty.  It can
+// only happen with gap-friendly scores (rows ending in gaps).  UNDEFINED in the reference; this restatement and the product
+// define it as the length of the open run (columns - its first column) and flag the cell (*ub) so the tests can mask it.
+inline uint32_t indel_len_at(const AlignResult &ar, uint32_t i, bool *ub) {
+    if (i < ar.indel_len.size()) return ar.indel_len[i];
+    *ub = true;
+    const uint32_t cols = (uint32_t)ar.partition.size();
+    return i < ar.indel_pos.size() ? cols - ar.indel_pos[i] : 0;
+}
+
 struct Scoring {
     double match = 2, mismatch = -1, gap = -3;
 };

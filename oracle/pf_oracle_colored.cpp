@@ -235,9 +235,10 @@ Cov cov_str(const pfo_ctx &c, uint32_t colour, const std::string &s, uint32_t lo
     const int k = c.g.k;
     double sum = 0;
     if (db.both_strands) {
+        StringProbe probe(db, k);
         for (size_t i = 0; i + k <= s.size(); ++i) {
             uint32_t cnt = 0;
-            if (!db.canonical_count(pack_kmer(s.data() + i, k), cnt)) return {0, false};
+            if (!probe.count(s.data() + i, cnt)) return {0, false};
             if (cnt > low && cnt < up) sum += cnt;
             else return {0, false};
         }
@@ -400,12 +401,16 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
     std::ofstream *cov_by[4] = {&bicov, &tricov, &tetracov, &pentacov};
     uint64_t allele[4] = {0, 0, 0, 0};
     size_t coreNum = 0, coreCov = 0, var_count = 0;
-    auto emit = [&](size_t arity, const std::string &fre, const std::string &cov) {
+    UbLog ub_log;  // cells whose value is undefined in the reference (indel_len_at), for the tests' masks
+    uint64_t cov_lines[4] = {0, 0, 0, 0};
+    auto emit = [&](size_t arity, const std::string &fre, const std::string &cov, bool ub) {
         allfre << fre;
         if (arity >= 2 && arity <= 5) {
             ++allele[arity - 2];
             *fre_by[arity - 2] << fre;
             *cov_by[arity - 2] << cov;
+            ++cov_lines[arity - 2];
+            if (ub) ub_log.cell((int)arity - 2, cov_lines[arity - 2]);
         }
     };
     auto var_dist = [&](const std::vector<uint32_t> &vs, uint32_t i, size_t usize, size_t esize) -> uint32_t {
@@ -421,7 +426,7 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
         return d;
     };
     // one row per colour with at least two non-zero allele groups (:3006-3058, :3292-3339, :3427-3475)
-    auto emit_rows = [&](const std::vector<std::vector<double>> &group_cov, const std::string &tail) {
+    auto emit_rows = [&](const std::vector<std::vector<double>> &group_cov, const std::string &tail, bool ub) {
         for (uint32_t ci = 0; ci < C; ++ci) {
             std::vector<double> res;
             double sum = 0;
@@ -434,7 +439,7 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
                 fre_info << (double)x / sum << "\n";
             }
             cov_info << ci << "\t" << tail;
-            emit(res.size(), fre_info.str(), cov_info.str());
+            emit(res.size(), fre_info.str(), cov_info.str(), ub);
         }
     };
     for (uint32_t u = 0; u < N; ++u) {
@@ -526,9 +531,10 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
                             const std::vector<uint16_t> &part = ar.partition[var_site[i]];
                             unsigned short maxnum = *std::max_element(part.begin(), part.end());
                             uint32_t vd = var_dist(var_site, i, usize, esize);
+                            bool ub = false;
                             if (std::find(ar.indel_pos.begin(), ar.indel_pos.end(), var_site[i]) != ar.indel_pos.end()) {
                                 ++indel;
-                                tail << 1 << "\t" << ar.indel_len[indel - 1] << "\t" << var_count << "\t" << var_site.size() << "\t"
+                                tail << 1 << "\t" << indel_len_at(ar, indel - 1, &ub) << "\t" << var_count << "\t" << var_site.size() << "\t"
                                      << coefficient << "\t" << vd << "\t" << "\n";
                             } else {
                                 tail << 1 << "\t" << "0\t" << var_count << "\t" << var_site.size() << "\t" << coefficient << "\t" << vd
@@ -537,7 +543,7 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
                             std::vector<std::vector<double>> group_cov(C, std::vector<double>(maxnum, 0.0));
                             for (uint32_t ci = 0; ci < C; ++ci)
                                 for (size_t j = 0; j < part.size(); ++j) group_cov[ci][part[j] - 1] += cov[ci][j];
-                            emit_rows(group_cov, tail.str());
+                            emit_rows(group_cov, tail.str(), ub);
                         }
                     }
                 }
@@ -601,11 +607,17 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
                             while (true) {
                                 std::set<char> cs;
                                 for (size_t p = 0; p < rows.size(); ++p) {
-                                    while (rows[p].at(at[p]) == '-') at[p] += 1;
-                                    char ch = rows[p].at(at[p]);
+                                    // std::string::substr(pos, 1): one character, the EMPTY string at pos == size() (a row
+                                    // that ends in gaps: nothing is appended and c[0] == '\0' joins the set), out_of_range
+                                    // beyond -- the reference then terminates (CDBG.cpp:1478-1488, CCDBG.cpp:3188-3198)
+                                    std::string ch = rows[p].substr(at[p], 1);
+                                    while (ch.compare("-") == 0) {
+                                        at[p] += 1;
+                                        ch = rows[p].substr(at[p], 1);
+                                    }
                                     at[p] += 1;
                                     kstr[p] += ch;
-                                    cs.insert(ch);
+                                    cs.insert(ch[0]);
                                 }
                                 if (cs.size() > 1) break;
                             }
@@ -621,8 +633,8 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
                                     if (tmp.length() < (size_t)(k - n)) {
                                         kstr[p] = tmp + kstr[p];
                                         for (int x = at[p]; kstr[p].length() < (size_t)k; ++x) {
-                                            char ch = rows[p].at(x);
-                                            if (ch != '-') kstr[p] += ch;
+                                            std::string ch = rows[p].substr(x, 1);
+                                            if (ch.compare("-") != 0) kstr[p] += ch;
                                         }
                                     } else {
                                         kstr[p] = tmp.substr(tmp.length() - k + n, k - n) + kstr[p];
@@ -636,8 +648,8 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
                                 if (tmp.length() < (size_t)k) {
                                     kstr[p] = tmp;
                                     for (int x = site + 1; kstr[p].length() < (size_t)k; ++x) {
-                                        char ch = rows[p].at(x);
-                                        if (ch != '-') kstr[p] += ch;
+                                        std::string ch = rows[p].substr(x, 1);
+                                        if (ch.compare("-") != 0) kstr[p] += ch;
                                     }
                                 } else {
                                     kstr[p] = tmp.substr(tmp.length() - k, k);
@@ -670,13 +682,14 @@ int pfo_ploidy_estimation_colored(pfo_ctx *c, const char *outdir, const char *pr
                         if (!site_ok) continue;
                         const double coefficient = max_cramer_v(group_cov);
                         std::stringstream tail;
+                        bool ub = false;
                         if (is_indel)
-                            tail << 0 << "\t" << ar.indel_len[indel - 1] << "\t" << var_count << "\t" << var_site.size() << "\t" << coefficient
+                            tail << 0 << "\t" << indel_len_at(ar, indel - 1, &ub) << "\t" << var_count << "\t" << var_site.size() << "\t" << coefficient
                                  << "\t" << vd << "\t" << "\n";
                         else
                             tail << 0 << "\t" << "0\t" << var_count << "\t" << var_site.size() << "\t" << coefficient << "\t" << vd << "\t"
                                  << "\n";
-                        emit_rows(group_cov, tail.str());
+                        emit_rows(group_cov, tail.str(), ub);
                     }
                 }
             }

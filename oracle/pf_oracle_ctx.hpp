@@ -3,6 +3,8 @@
 // reference src/CCDBG.cpp).
 #pragma once
 #include <cstdint>
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -67,6 +69,22 @@ struct Traversal {
 };
 
 extern std::string g_err;
+
+// Cells of the *cov.txt files whose value is UNDEFINED in the reference (pfo::indel_len_at): when the environment variable
+// PFO_UB_LOG names a file, one line "<bi|tri|tetra|penta>cov\t<1-based line>" per such cell is appended to it, so a test can hold
+// every other byte of the reference binary's output to this restatement and leave exactly these cells out.
+struct UbLog {
+    FILE *f = nullptr;
+    UbLog() {
+        const char *p = getenv("PFO_UB_LOG");
+        if (p && *p) f = fopen(p, "a");
+    }
+    ~UbLog() { if (f) fclose(f); }
+    void cell(int arity_idx, uint64_t line) {
+        static const char *name[4] = {"bicov", "tricov", "tetracov", "pentacov"};
+        if (f) fprintf(f, "%s\t%llu\n", name[arity_idx], (unsigned long long)line);
+    }
+};
 
 }  // namespace pfo_int
 

@@ -63,6 +63,26 @@ struct KmcDb {
     uint32_t signature(uint64_t kmer) const;  // CKmerAPI::get_signature (kmer_api.h:653-673)
 };
 
+// readCov(string)'s look-up of the k characters at s (src/CDBG.cpp:36-43, src/CCDBG.cpp:96-103): ONE CKmerAPI object per call,
+// created as k times 'A'; CKmerAPI::from_string (kmer_api.h:502-510) returns false and leaves the object UNTOUCHED when the k
+// characters hold anything but ACGT -- the '-' of an aligned row, which reaches a site string when it takes raw columns up to the
+// row's end (substr with a negative count, src/CDBG.cpp:1499).  Such a window is then looked up with what the object held before:
+// the previous window's k-mer in the form that was found (reversed or not), or poly-A before any.
+struct StringProbe {
+    const KmcDb &db;
+    int k;
+    uint64_t held = 0;  // the object's content, 2 bits per base
+    StringProbe(const KmcDb &d, int kk) : db(d), k(kk) {}
+    bool count(const char *s, uint32_t &cnt) {
+        bool acgt = true;
+        for (int i = 0; i < k; ++i) acgt = acgt && (s[i] == 'A' || s[i] == 'C' || s[i] == 'G' || s[i] == 'T');
+        if (acgt) held = pack_kmer(s, k);
+        uint32_t c0;
+        if (!db.check(held, c0)) held = rc_kmer(held, k);  // if (!IsKmer(kmer_object)) kmer_object.reverse();
+        return db.check(held, cnt);                        // CheckKmer(kmer_object, count)
+    }
+};
+
 // ---- graph (G1, G2) -------------------------------------------------------------------
 struct Graph {
     int k = 31;

@@ -339,3 +339,49 @@ class GmmOracle:
 
     def run(self, outprefix, lo=1, hi=9, m_thre=5.0, n_thre=2.0, max_iter=1000, max_delta=0.01):
         self._check(self.L.pfo_gmm_run(self.h, lo, hi, m_thre, n_thre, max_iter, max_delta, outprefix.encode()))
+
+
+# ---- cells the reference leaves undefined (pfo::indel_len_at, pf_oracle_align.hpp) ---------------------------------------
+
+OUTPUT_SUFFIXES = ["Unitig_Id", "super_bubble", "alignseq", "allele_frequency", "bicov", "bifre", "tricov", "trifre", "tetracov",
+                   "tetrafre", "pentacov", "pentafre"]
+
+
+def read_ub_log(path: str) -> dict:
+    """{'bicov': {line, ...}, ...} from a PFO_UB_LOG file (1-based lines)."""
+    cells: dict = {}
+    if path and os.path.exists(path):
+        for ln in open(path):
+            name, line = ln.split("\t")
+            cells.setdefault(name, set()).add(int(line))
+    return cells
+
+
+def mask_ub(data: bytes, lines: set, colored: bool) -> bytes:
+    """A *cov.txt file with the indel-length field of the given lines replaced by '?'.  Field position counted from the
+    row's end (rows end in a tab): single-sample ... strict, LEN, var_count, sites, dist, '' ; colored ... strict, LEN,
+    var_count, sites, Cramer V, dist, ''."""
+    if not lines:
+        return data
+    rows = data.split(b"\n")
+    at = -6 if colored else -5
+    for ln in lines:
+        if ln - 1 < len(rows):
+            f = rows[ln - 1].split(b"\t")
+            if len(f) >= -at:
+                f[at] = b"?"
+                rows[ln - 1] = b"\t".join(f)
+    return b"\n".join(rows)
+
+
+def compare_outputs(dir_a: str, dir_b: str, prefix: str, ub_cells: dict | None = None, colored: bool = False) -> list:
+    """Suffixes of the twelve files that differ between two output directories, the undefined cells left out."""
+    bad = []
+    for suf in OUTPUT_SUFFIXES:
+        a = open(os.path.join(dir_a, "%s_%s.txt" % (prefix, suf)), "rb").read()
+        b = open(os.path.join(dir_b, "%s_%s.txt" % (prefix, suf)), "rb").read()
+        if ub_cells and suf in ub_cells:
+            a, b = mask_ub(a, ub_cells[suf], colored), mask_ub(b, ub_cells[suf], colored)
+        if a != b:
+            bad.append(suf)
+    return bad

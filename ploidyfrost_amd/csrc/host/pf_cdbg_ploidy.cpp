@@ -721,9 +721,15 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                     if (x >= L) { sc.err = 1; return 'A'; }
                     return rows[p * L + x];
                 };
-                auto sub = [&](size_t p, long from, long n) -> std::string {  // substr(from, n)
-                    if (from < 0 || (size_t)from > L || n < 0) { sc.err = 1; return std::string(); }
-                    return std::string(rows + p * L + from, std::min<size_t>((size_t)n, L - (size_t)from));
+                auto sub = [&](size_t p, long from, long n) -> std::string {  // substr(from, n): a negative count is npos
+                    if (from < 0 || (size_t)from > L) { sc.err = 1; return std::string(); }
+                    return std::string(rows + p * L + from, n < 0 ? L - (size_t)from : std::min<size_t>((size_t)n, L - (size_t)from));
+                };
+                // substr(x, 1): one character, NOTHING at x == size() (a row that ends in gaps), fatal beyond
+                auto sub1 = [&](size_t p, size_t x, bool &none) -> char {
+                    none = x >= L;
+                    if (x > L) sc.err = 1;
+                    return none ? '\0' : rows[p * L + x];
                 };
                 auto ungapped_prefix = [&](size_t p, size_t n) {
                     std::string o;
@@ -745,10 +751,11 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                             char first = 0;
                             bool differ = false;
                             for (size_t p = 0; p < R; ++p) {
-                                while (row_at(p, (size_t)at[p]) == '-') at[p]++;
-                                const char ch = row_at(p, (size_t)at[p]);
+                                bool none;
+                                char ch = sub1(p, (size_t)at[p], none);
+                                while (!none && ch == '-') ch = sub1(p, (size_t)++at[p], none);
                                 at[p]++;
-                                kstr[p].push_back(ch);
+                                if (!none) kstr[p].push_back(ch);   // ('\0' joins the reference's set of characters all the same)
                                 if (p == 0) first = ch;
                                 else if (ch != first) differ = true;
                             }
@@ -807,7 +814,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         });
         for (auto &scx : schunks) {
             if (scx.err == 2) { B.err = "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble"; return PF_ERR_ARG; }
-            if (scx.err) { B.err = "CDBG::PloidyEstimation(): site string outside an aligned row"; return PF_ERR_ARG; }
+            if (scx.err) { B.err = "CDBG::PloidyEstimation(): a site string runs past the end of an aligned row (the reference terminates here: std::out_of_range from substr, src/CDBG.cpp:1478-1590)"; return PF_ERR_ARG; }
         }
         std::vector<uint64_t> &chunk_base = B.chunk_base;
         chunk_base.assign(n_pch + 1, 0);
@@ -946,7 +953,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                         }
                         tail.clear();
                         tail += t.strict ? "1\t" : "0\t";
-                        if (sr.is_indel) put_uint(tail, ilen[indel - 1]);
+                        if (sr.is_indel) put_uint(tail, indel - 1 < r.n_indel_len ? ilen[indel - 1] : r.n_cols - sr.col);  // (open run: pf_call.hip open_run_len)
                         else tail.push_back('0');
                         tail.push_back('\t');
                         put_uint(tail, my_vc);
@@ -1015,7 +1022,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                         fre_info.push_back('\n');
                     }
                     cov_info += t.strict ? "1\t" : "0\t";
-                    if (sr.is_indel) put_uint(cov_info, ilen[indel - 1]);
+                    if (sr.is_indel) put_uint(cov_info, indel - 1 < r.n_indel_len ? ilen[indel - 1] : r.n_cols - sr.col);  // (open run: pf_call.hip open_run_len)
                     else cov_info.push_back('0');
                     cov_info.push_back('\t');
                     put_uint(cov_info, my_vc);

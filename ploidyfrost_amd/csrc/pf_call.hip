@@ -2194,6 +2194,10 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                 // are not all equal (src/CDBG.cpp:1474-1493)
                 for (uint32_t p = lane; p < R; p += WAVE) at[p] = site;
                 sync();
+                // A row that ends in gaps runs out here: the reference's `substr(pos, 1)` at pos == size() is the EMPTY string --
+                // nothing is appended to that row, '\0' joins the set of characters (so the loop ends unless every row ran out at
+                // once) and pos moves on to size() + 1, where the next substr throws and the reference terminates.  A row that ran
+                // out keeps at[p] = L + 1 and has one character fewer than the others.
                 for (;;) {
                     uint32_t bad = 0;
                     for (uint32_t base = 0; base < R; base += WAVE) {
@@ -2201,10 +2205,10 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                         bool e = false;
                         if (p < R) {
                             uint32_t x = at[p];
-                            while (x < L && rows[(size_t)p * L + x] == '-') ++x;
-                            if (x >= L) e = true;
+                            if (x > L) e = true;   // (every row ran out in the round before: std::out_of_range in the reference)
                             else {
-                                if (napp < KS) app[(size_t)p * KS + napp] = rows[(size_t)p * L + x];
+                                while (x < L && rows[(size_t)p * L + x] == '-') ++x;
+                                if (napp < KS) app[(size_t)p * KS + napp] = x < L ? rows[(size_t)p * L + x] : '\0';
                                 at[p] = x + 1;
                             }
                         }
@@ -2235,14 +2239,16 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                     uint32_t n = 0;
                     auto push = [&](char c) { if (n < KS) out[n] = c; ++n; };
                     if (sr.is_indel) {
-                        const long need = (long)k - (long)napp;
+                        const uint32_t napp_p = at[p] > L ? napp - 1 : napp;   // (a row that ran out in the last round)
+                        const long need = (long)k - (long)napp_p;
                         if (indel == 0) {
-                            const long from = (long)site - k + (long)napp;
-                            if (from < 0 || (uint64_t)from > L || need < 0) e = 4;
+                            // substr(site - k + n, k - n): a start below zero or past the row throws; a negative count is npos
+                            const long from = (long)site - k + (long)napp_p;
+                            if (from < 0 || (uint64_t)from > L) e = 4;
                             else {
-                                const uint32_t take = (uint32_t)std::min<uint64_t>((uint64_t)need, L - (uint64_t)from);
+                                const uint32_t take = need < 0 ? (uint32_t)(L - (uint64_t)from) : (uint32_t)std::min<uint64_t>((uint64_t)need, L - (uint64_t)from);
                                 for (uint32_t x = 0; x < take; ++x) push(row[from + x]);
-                                for (uint32_t x = 0; x < napp; ++x) push(app[(size_t)p * KS + x]);
+                                for (uint32_t x = 0; x < napp_p; ++x) push(app[(size_t)p * KS + x]);
                             }
                         } else {
                             uint32_t c = 0;
@@ -2250,7 +2256,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             if (need < 0 || (long)c < need) {
                                 for (uint32_t x = 0; x < site && x < L; ++x)
                                     if (row[x] != '-') push(row[x]);
-                                for (uint32_t x = 0; x < napp; ++x) push(app[(size_t)p * KS + x]);
+                                for (uint32_t x = 0; x < napp_p; ++x) push(app[(size_t)p * KS + x]);
                                 for (uint32_t x = at[p]; n < (uint32_t)k; ++x) {
                                     if (x >= L) { e = 4; break; }
                                     if (row[x] != '-') push(row[x]);
@@ -2263,7 +2269,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                                     if (skip) { --skip; continue; }
                                     push(row[x]);
                                 }
-                                for (uint32_t x = 0; x < napp; ++x) push(app[(size_t)p * KS + x]);
+                                for (uint32_t x = 0; x < napp_p; ++x) push(app[(size_t)p * KS + x]);
                             }
                         }
                     } else if (indel > 0) {
@@ -2336,11 +2342,9 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             uint64_t okm = C >= 64 ? ~0ull : ((1ull << C) - 1);
                             uint64_t *cs = reinterpret_cast<uint64_t *>(cmean + (size_t)p * C);
                             for (uint32_t c = 0; c < C; ++c) cs[c] = 0;
-                            uint64_t x = 0;
+                            StringWindow win;
                             for (uint32_t c0 = 0; c0 < lp; ++c0) {
-                                const char ch = sp[c0];
-                                const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-                                x = ((x << 2) | b) & kmask;
+                                const uint64_t x = win.push(sp[c0], kmask, (uint32_t)k);
                                 if (c0 + 1 < (uint32_t)k) continue;
                                 const uint8_t *sa, *sb;
                                 colored_slots(a.ctab, x, k, a.c_one_strand != 0, sa, sb);
@@ -2359,12 +2363,11 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             if (!found) miss = true;
                         }
                     } else if (!d) {
-                        uint64_t sum = 0, x = 0;
+                        uint64_t sum = 0;
                         if (!a.tab_exact) {
+                            StringWindow win;
                             for (uint32_t c = 0; c < lp; ++c) {
-                                const char ch = sp[c];
-                                const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-                                x = ((x << 2) | b) & kmask;
+                                const uint64_t x = win.push(sp[c], kmask, (uint32_t)k);
                                 if (c + 1 >= (uint32_t)k) {
                                     uint32_t cnt;
                                     if (!canonical_count(a.tab, a.mask, x, k, cnt, a.one_strand != 0)) { miss = true; break; }
@@ -2467,6 +2470,15 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
 
 // ---------------------------------------------------------------------------------------------------------------------
 // K-TEXT
+// indel_len[indel - 1] as the callers print it (src/CDBG.cpp:1310, 1565; src/CCDBG.cpp:3034, 3315, 3450).  An indel run still open
+// at the last column never has its length pushed (compareStrPair closes a run only on a later column, src/SeqAlign.cpp:56-157), so
+// for that last indel site the reference reads one element past the vector: heap garbage that changes from run to run, or a null
+// dereference when the vector is empty -- rows ending in gaps, i.e. gap-friendly scores only.  Undefined there; defined here (and in
+// the oracle, pfo::indel_len_at) as the length of the open run: columns - the site's column.
+__device__ __forceinline__ uint32_t open_run_len(const uint32_t *ilen, uint32_t i, uint32_t n_ilen, uint32_t n_cols, uint32_t col) {
+    return i < n_ilen ? ilen[i] : n_cols - col;
+}
+
 struct FmtArgs {
     const CallTask *ct;
     const uint32_t *kept;
@@ -2713,7 +2725,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                             put_uint(cov, c);
                             cov.put('\t');
                             cov.put(t.strict ? '1' : '0'); cov.put('\t');
-                            if (sr.is_indel) put_uint(cov, ilen[indel - 1]);
+                            if (sr.is_indel) put_uint(cov, open_run_len(ilen, indel - 1, r.n_indel_len, r.n_cols, sr.col));
                             else cov.put('0');
                             cov.put('\t');
                             put_uint(cov, my_vc);
@@ -2776,7 +2788,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                 }
                 if (filed) {
                     cov.put(t.strict ? '1' : '0'); cov.put('\t');
-                    if (sr.is_indel) put_uint(cov, ilen[indel - 1]);
+                    if (sr.is_indel) put_uint(cov, open_run_len(ilen, indel - 1, r.n_indel_len, r.n_cols, sr.col));
                     else cov.put('0');
                     cov.put('\t');
                     put_uint(cov, my_vc);
@@ -3758,7 +3770,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
             PF_HIP(hipStreamSynchronize(st));
             if (hc.err & 2u) { pf::CtxErr{ctx} = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
-            if (hc.err & 4u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): site string outside an aligned row"; return PF_ERR_ARG; }
+            if (hc.err & 4u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): a site string runs past the end of an aligned row (the reference terminates here: std::out_of_range from substr, src/CDBG.cpp:1478-1590)"; return PF_ERR_ARG; }
             if (hc.err & 16u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): site string longer than 2k + 64"; return PF_ERR_ARG; }
             if (hc.err & 64u) { pf::CtxErr{ctx} = "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble"; return PF_ERR_ARG; }
             if (hc.sv_head > sv_cap) {

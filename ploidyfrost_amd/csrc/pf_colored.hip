@@ -158,17 +158,16 @@ __global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colo
         const char *s = text + str_off[i];
         const uint32_t L = (uint32_t)(str_off[i + 1] - str_off[i]);
         const uint32_t lo = low[c], hi = up[c];
-        uint64_t sum = 0, x = 0;
+        uint64_t sum = 0;
         uint8_t ok = 1;
+        StringWindow win;
         if ((unread >> c) & 1) {  // readCov(s, low, up, c) without canonical counting: (0, true), no lookup (src/CCDBG.cpp:94, 121)
             out_sum[id] = 0;
             out_ok[id] = 1;
             continue;
         }
         for (uint32_t j = 0; j < L; ++j) {
-            const char ch = s[j];
-            const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-            x = ((x << 2) | b) & kmask;
+            const uint64_t x = win.push(s[j], kmask, (uint32_t)k);
             if (j + 1 >= (uint32_t)k) {
                 uint32_t cnt[CPP];
                 colored_counts(t, x, k, one_strand, c, 1, cnt);

@@ -341,12 +341,11 @@ __global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, bool 
     for (; i < n_str; i += stride) {
         const char *s = text + str_off[i];
         const uint32_t L = (uint32_t)(str_off[i + 1] - str_off[i]);
-        uint64_t sum = 0, x = 0;
+        uint64_t sum = 0;
         uint8_t ok = 1, miss = 0;
+        StringWindow win;
         for (uint32_t j = 0; j < L; ++j) {
-            const char ch = s[j];
-            const uint64_t b = ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3;
-            x = ((x << 2) | b) & kmask;
+            const uint64_t x = win.push(s[j], kmask, (uint32_t)k);
             if (j + 1 >= (uint32_t)k) {
                 uint32_t c;
                 if (!canonical_count(t, mask, x, k, c, one_strand)) { miss = 1; break; }

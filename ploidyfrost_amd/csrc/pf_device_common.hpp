@@ -82,6 +82,24 @@ __device__ inline bool canonical_count(const Slot *__restrict__ t, uint64_t mask
     return table_find(t, mask, first == fwd ? rc : fwd, cnt);
 }
 
+// The rolling window of readCov(string) (src/CDBG.cpp:36-43, src/CCDBG.cpp:96-103).  The reference keeps ONE CKmerAPI object per
+// call, created as k times 'A', and CKmerAPI::from_string (KMC/kmc_api/kmer_api.h:502-510) leaves it UNTOUCHED when the k characters
+// hold anything but ACGT -- the '-' of an aligned row, which reaches a site string that takes raw columns up to its row's end
+// (substr with a negative count, src/CDBG.cpp:1499).  Such a window is looked up with what the object held before: the previous
+// clean window's k-mer in the form that was found (the composite look-up of that k-mer gives the same count again), or poly-A before
+// any.  push() returns the k-mer to look up for the window that ends at this character.
+struct StringWindow {
+    uint64_t x = 0, held = 0;
+    uint32_t clean = 0;   // ACGT characters in a row up to here
+    __device__ __forceinline__ uint64_t push(char ch, uint64_t kmask, uint32_t k) {
+        const bool acgt = ch == 'A' || ch == 'C' || ch == 'G' || ch == 'T';
+        x = ((x << 2) | (uint64_t)(ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : 3)) & kmask;
+        clean = acgt ? clean + 1 : 0;
+        if (clean >= k) held = x;
+        return held;
+    }
+};
+
 // The same lookup split in two so that a lane can keep several k-mers in flight: count_probe() issues the first
 // 16-B probe of the form that is tried first, count_finish() consumes it and walks on only if it has to.
 struct CountProbe {

@@ -93,3 +93,58 @@ def compare_outputs(expected_dir, got_dir, prefix_expected="g", prefix_got="g"):
             if fe.read() != fg.read():
                 bad.append(suf)
     return bad
+
+
+# ---- tests/golden/scores/<case>__<tag>: the reference under scores outside the default fixtures' region --------------------
+
+def score_cases():
+    d = os.path.join(GOLDEN, "scores")
+    return sorted(x for x in os.listdir(d) if os.path.isfile(os.path.join(d, x, "meta.json"))) if os.path.isdir(d) else []
+
+
+def load_score_case(name):
+    """the base case's inputs + what the reference made of them under meta['extra_args'] (tests/golden/make_score_golden.py)"""
+    d = os.path.join(GOLDEN, "scores", name)
+    with open(os.path.join(d, "meta.json")) as f:
+        sm = json.load(f)
+    meta = load_case(sm["case"])
+    a = sm["extra_args"]
+    for i in range(0, len(a), 2):
+        meta["opts"][a[i]] = a[i + 1]
+    meta["score"] = sm
+    meta["score_dir"] = d
+    meta["ub_cells"] = {k: set(v) for k, v in sm["ub_cells"].items()}
+    return meta
+
+
+def mask_ub(data, lines, colored):
+    """a *cov.txt file with the indel-length field of the given (1-based) lines replaced by '?': the cells whose value the
+    reference leaves undefined (oracle/pf_oracle_align.hpp: indel_len_at).  Rows end in a tab; counted from the end the field is
+    ... strict, LEN, var_count, sites, dist, '' (single-sample) or ... strict, LEN, var_count, sites, Cramer V, dist, ''."""
+    rows = data.split(b"\n")
+    at = -6 if colored else -5
+    for ln in lines:
+        f = rows[ln - 1].split(b"\t")
+        f[at] = b"?"
+        rows[ln - 1] = b"\t".join(f)
+    return b"\n".join(rows)
+
+
+def compare_score_outputs(meta, got_dir, mask=True):
+    """the twelve files of a score case against the reference's (files equal to the base case's are taken from there), the
+    undefined cells masked on both sides; with mask=False every byte counts (product against oracle: both define those cells)."""
+    sm = meta["score"]
+    bad = []
+    for suf in OUTPUT_SUFFIXES:
+        f = "g_%s.txt" % suf
+        src = os.path.join(meta["dir"], "expected", f) if suf in sm["same_as_base_case"] else os.path.join(meta["score_dir"], "expected", f)
+        e = open(src, "rb").read()
+        g = open(os.path.join(got_dir, f), "rb").read()
+        if mask and suf in meta["ub_cells"]:
+            if e.count(b"\n") != g.count(b"\n"):
+                bad.append(suf + " (rows)")
+                continue
+            e, g = mask_ub(e, meta["ub_cells"][suf], sm["colored"]), mask_ub(g, meta["ub_cells"][suf], sm["colored"])
+        if e != g:
+            bad.append(suf)
+    return bad

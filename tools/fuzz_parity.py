@@ -51,7 +51,19 @@ def repeat_rich(rng, n):
     return np.concatenate(parts)
 
 
-def build_case(seed, tmp, dev, force_colored=None, force_giant=None):
+def draw_scores(rng):
+    """(M, D, G) from the whole region the reference accepts (src/Main.cpp:470-479: D <= M and G <= M, nothing else): zero and
+    positive gap scores, D = M, G = M, fractions, negative match scores, magnitudes to 1e5."""
+    M = float(rng.choice([0, 0.5, 1, 1, 1.5, 2, 2, 2, 3, 5, 10, 100, 1e5, -1, -0.5]))
+    d_pool = [M, M - 0.5, M - 1, M - 3, 0.0, -1.0, -M, -2.5, -7.0, -1e5, M - 0.25]
+    g_pool = [M, M - 1, M - 5, 1.0, 0.5, 0.0, -0.5, -1.0, -2.0, -3.0, -2.25, -10.0, -1e5, M - 0.75]
+    D = float(rng.choice([x for x in d_pool if x <= M]))
+    G = float(rng.choice([x for x in g_pool if x <= M]))
+    f = lambda x: int(x) if x == int(x) else x  # noqa: E731
+    return (f(M), f(D), f(G))
+
+
+def build_case(seed, tmp, dev, force_colored=None, force_giant=None, wide_scores=None):
     """inputs of one random case: a dict, or a string when the seed is skipped.  force_colored / force_giant (tests/test_gpu_fuzz.py):
     the kind of case is chosen by the caller instead of by the seed / the environment."""
     rng = np.random.default_rng(seed)
@@ -90,6 +102,8 @@ def build_case(seed, tmp, dev, force_colored=None, force_giant=None):
         haps = [np.concatenate([rep[: len(rep) // 2], h[200:-200], rep[len(rep) // 2:]]) for h in haps]
     scores = [(2, -1, -3), (2, -1, -3), (1, -1, -1), (3, -2, -4), (1.5, -0.5, -2.25), (2, -1, -2)][int(rng.integers(0, 6))]
     lower, upper = [(5, 1000), (5, 1000), (15, 70), (1, 100000)][int(rng.integers(0, 4))]
+    if wide_scores if wide_scores is not None else os.environ.get("PF_FUZZ_SCORES") == "wide":
+        scores = draw_scores(np.random.default_rng(seed + 77))   # its own stream: the rest of the case stays what the seed made it
     colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4 and not giant
     if force_colored is not None:
         colored = bool(force_colored) and not giant
