@@ -461,10 +461,11 @@ int pf_replay_order(pf_ctx *, uint32_t n_classes, uint32_t *order, uint32_t *cla
  * byte (csrc/host/pf_state_ops.hpp: S_LINK, S_STRICT, S_COMPLEX, S_NON_SUPER).  pf_replay_finish merges the per-side bytes into
  * MyUnitig's and leaves the state resident for pf_superbubble_rows / pf_call_scan; pf_call_get_state copies it to the host. */
 /* The candidates the device tiers give up on (traversals of more than 128 vertices: the caller walks them on host cores) are also
- * reported AHEAD of the call's return: *list = cap entries of pinned host memory that every later pf_bfs_candidates* call of this
- * context with a `deferred` array zeroes when it starts and fills while its kernels run -- entry = entrance (oriented vertex) << 32
- * | (candidate index + 1), in no particular order -- so that the caller's walkers start on the first long traversal while the device
- * is still busy instead of after the call has returned.  An entry is a NOTICE, written when a traversal reaches 48 vertices: the
+ * reported AHEAD of the call's return: *list = cap entries of pinned host memory, zeroed by THIS call (call it once per pass,
+ * before the threads that poll the list are started), that the next pf_bfs_candidates* call of this context with a `deferred` array
+ * fills while its kernels run -- entry = entrance (oriented vertex) << 32 | (candidate index + 1), in no particular order -- so that
+ * the caller's walkers start on the first long traversal while the device is still busy instead of after the call has returned.  A
+ * pf_bfs_candidates_resident that repeats itself after a pool overflow writes the list again from its first slot.  An entry is a NOTICE, written when a traversal reaches 48 vertices: the
  * traversal goes on on the device and may yet end there (it is then absent from `deferred`, and the caller drops its walk); every
  * candidate of `deferred` has an entry unless the list ran out of room.  pf_bfs_live_count: the entries the last call wrote (may
  * exceed cap: the surplus was dropped).  cap = 0 switches the list off. */

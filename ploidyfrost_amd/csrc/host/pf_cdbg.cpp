@@ -185,10 +185,17 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
     st_.complex_size = complex_size_;
     st_.g = &g_;
     st_.succ = succ_.data();
-    if (!getenv("PF_NO_PREALLOC") && !colored && resident_) {
-        // the device buffers of the first alignment launch, taken beside what follows the load on the host (the unitig id file):
-        // nothing else calls into the context before findSuperBubble, which waits for this thread.  About a third of the unitigs
-        // end up as called bubbles, aligned in two ranges of whole text pieces.
+    return 0;
+}
+
+void CDBG::start_prealloc() {
+    if (!getenv("PF_NO_PREALLOC") && resident_ && ctx_ && status_ == PF_OK) {
+        // the device buffers of the first alignment launch, taken beside what follows the load on the host (the unitig id file).
+        // Started when the constructor has made its last call into the context -- the count table is in; started from init_device
+        // it ran beside pf_kmc_decode / pf_upload_counts of the pfh_open path (advisor, round 3) -- so nothing else calls into the
+        // context before findSuperBubble, which waits for this thread.  About a third of the unitigs end up as called bubbles,
+        // aligned in two ranges of whole text pieces.
+        const uint32_t N = g_.n();
         const uint64_t piece = (uint64_t)std::max<size_t>(batch_bubbles_, 1) * 4;
         const uint64_t est = std::min<uint64_t>(1u << 24, ((uint64_t)(0.17 * (double)N) + piece - 1) / piece * piece);
         prealloc_call_ = std::thread([this, est, piece, N] {
@@ -198,7 +205,6 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
             (void)pf_call_reserve_text(ctx_, piece);
         });
     }
-    return 0;
 }
 
 CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, std::string kmc_db, int device,
@@ -216,6 +222,7 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
         if (counts->k != g_.k) { fail(PF_ERR_ARG, "CDBG::CDBG():Error: k of the kmc database differs from the graph's"); return; }
         both_strands_ = counts->both_strands;
         if (init_device(device, counts->release())) return;
+        start_prealloc();
         if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");
         return;
     }
@@ -238,6 +245,7 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
         trace.mark("kmc: device decode + table");
         if (st != PF_OK) { fail(st, std::string("CDBG::CDBG():Error: ") + pf_last_error(ctx_)); return; }
     }
+    start_prealloc();
     if (!quiet_) printf("CDBG::CDBG():CDBG initialized!\n");
 }
 
@@ -285,6 +293,7 @@ void MappedOut::close_file() {
     map_len = 0;
     backed_lo = backed_hi = 0;
     finished_once = false;
+    no_fallocate = false;
     fd = -1;
     path.clear();
 }
@@ -307,7 +316,18 @@ int MappedOut::open_for(const std::string &p) {
 bool MappedOut::back(uint64_t off, uint64_t len) {
     if (len == 0) return true;
     if (off >= backed_lo && off + len <= backed_hi) return true;
-    if (posix_fallocate(fd, (off_t)off, (off_t)len) != 0) return false;
+    // fallocate(2) itself, not posix_fallocate: where the file system cannot do it (EOPNOTSUPP: some NFS / FUSE mounts) glibc's
+    // stand-in writes a byte per block -- beside a writer that stores through the mapping that can zero a byte just stored (advisor,
+    // round 3).  Such a file is only extended (ftruncate) and a full disk shows when the pages are written back.
+    if (!no_fallocate && fallocate(fd, 0, (off_t)off, (off_t)len) != 0) {
+        if (errno != EOPNOTSUPP && errno != ENOSYS && errno != EINVAL) return false;
+        no_fallocate = true;
+    }
+    if (no_fallocate) {
+        struct stat sb;
+        if (fstat(fd, &sb) != 0) return false;
+        if ((uint64_t)sb.st_size < off + len && ftruncate(fd, (off_t)(off + len)) != 0) return false;
+    }
     if (backed_hi > backed_lo && off <= backed_hi && off + len >= backed_lo) {   // touches what is known: one interval
         backed_lo = std::min(backed_lo, off);
         backed_hi = std::max(backed_hi, off + len);
@@ -375,7 +395,11 @@ int MappedOut::reserve(uint64_t bytes) {
 // reports it), then its page-table entries.  Holds the mapping in place while it works.
 void MappedOut::populate(uint64_t from, uint64_t to) {
     if (to <= from || fd < 0) return;
-    if (posix_fallocate(fd, (off_t)from, (off_t)(to - from)) != 0) return;
+    if (no_fallocate) return;   // (no early prefault for a file whose blocks cannot be reserved)
+    if (fallocate(fd, 0, (off_t)from, (off_t)(to - from)) != 0) {
+        if (errno == EOPNOTSUPP || errno == ENOSYS || errno == EINVAL) no_fallocate = true;
+        return;
+    }
 #ifdef MADV_POPULATE_WRITE
     std::lock_guard<std::mutex> lk(remap_mu);
     if (base && to <= map_len) (void)madvise(base + (from & ~4095ull), (size_t)(to - (from & ~4095ull)), MADV_POPULATE_WRITE);

@@ -165,6 +165,7 @@ protected:
     struct NoCounts {};
     CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, double &g, int device, bool quiet, NoCounts);
     int init_device(int device, pf_ctx *adopt = nullptr, bool colored = false);
+    void start_prealloc();  // the first launches' device buffers, on a helper thread (single-sample, resident pipeline)
     // the path proper; cutoff holds one (lower, upper) pair (single sample) or one per colour
     int ploidy_estimation(const std::string &outpre, const std::vector<std::pair<int, int>> &cutoff, const size_t &thr);
     // the same through pf_call_* (pf_cdbg_call.cpp); call_select = scan + the sequential pass of the driver loop

@@ -56,6 +56,7 @@ struct MappedOut {
     // the process, and the Python interpreter hosting this library, with it; so nothing is stored outside this interval.
     uint64_t backed_lo = 0, backed_hi = 0;
     bool finished_once = false;   // finish() has given this file a length: reserve() leaves it alone from then on
+    bool no_fallocate = false;    // the file system cannot reserve blocks (EOPNOTSUPP): extended by ftruncate, no early prefault
     std::mutex remap_mu;   // populate() on a helper thread against a remap by prepare() / write() / reserve()
     MappedOut() = default;
     MappedOut(const MappedOut &) = delete;

@@ -126,6 +126,7 @@ struct CallState {
     DevBuf col_low, col_up, col_full, col_size, part_first, part_colour, part_word, part_bits;
     DevBuf ccov_sum, ccov_min, ccov_max, ccov_miss;
     DevBuf mlist, paths_big_scr;  // K-PATHS: bubbles of more than 255 walks, and the scratch of the launch that takes them
+    uint32_t mlist_cap = 0;
     DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
     uint64_t walk_cap = 0;
     // scan
@@ -1770,8 +1771,7 @@ __global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
             if (lane == 0) {
                 if (!BIG && !wo.too_deep && a.mlist) {   // more walks than the LDS tables hold: the second launch's
                     const uint32_t at = atomicAdd(&a.cnt->n_many, 1u);
-                    if (at < a.mlist_cap) a.mlist[at] = j;
-                    else atomicOr(&a.cnt->err, 1u);
+                    if (at < a.mlist_cap) a.mlist[at] = j;   // (beyond: the host sees n_many > mlist_cap, grows the list and repeats the attempt)
                 } else {
                     atomicOr(&a.cnt->err, wo.too_many ? 1u : 32u);
                     a.cnt->err_entrance = t.entrance_ov;
@@ -3374,8 +3374,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     static const int paths_per_cu = [] { const char *e = getenv("PF_PATHS_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
     const int paths_grid = ctx->n_cu * paths_per_cu;
     NEED(S->paths_scr, paths_per_wave * paths_grid);
-    constexpr uint32_t MLIST_CAP = 4096;   // bubbles of more than 255 walks in one range (more: refused)
-    NEED(S->mlist, (size_t)MLIST_CAP * 4);
+    // bubbles of more than 255 walks in one range: the list grows to what an attempt asked for (advisor, round 3: an overflow used
+    // to be reported as "more than 65535 paths", a refusal of a run no bubble of which had that many)
+    if (S->mlist_cap < 4096) S->mlist_cap = 4096;
+    NEED(S->mlist, (size_t)S->mlist_cap * 4);
     PathArgs ph_keep = {};
     const int paths_force_scratch = [] { const char *e = getenv("PF_PATHS_SCRATCH"); return e && atoi(e) ? 1 : 0; }();   // (read per call: tests)
 
@@ -3470,7 +3472,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ph.klist = pa.lists.klist_b; ph.stack_ok = pa.stack_ok;
             ph.tlist = pa.lists.tlist; ph.tlist4 = pa.lists.tlist4; ph.trio_ok = pa.trio_ok;
             ph.walk_pool = S->n_colors ? S->walk_pool.as<uint32_t>() : nullptr; ph.walk_off = S->walk_off.as<uint64_t>(); ph.walk_cap = walk_cap;
-            ph.max_paths = MAX_PATHS; ph.n_list = &d_cnt->n_branching; ph.mlist = S->mlist.as<uint32_t>(); ph.mlist_cap = MLIST_CAP;
+            ph.max_paths = MAX_PATHS; ph.n_list = &d_cnt->n_branching; ph.mlist = S->mlist.as<uint32_t>(); ph.mlist_cap = S->mlist_cap;
             ph_keep = ph;
             if (getenv("PF_TRACE_ALIGN_ARGS"))
                 fprintf(stderr, "[pf_call_align] K-PATHS args: ct %p kept %p blist %p succ %p seq %p off %p len %p scratch %p (%llu per wave, grid %d) n_list %p mlist %p walk_pool %p btask %p bpath %p text %p queues %p klist %p tlist %p tlist4 %p cnt %p depth_cap %u nb %u stack_ok %d trio_ok %d\n",
@@ -3612,9 +3614,14 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         if (trio_tier) ctx_units(ctx, PF_K_CALL_TRIO, hc.n_trio + hc.n_trio4);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (getenv("PF_TRACE_ALIGN")) fprintf(stderr, "[pf_call_align] bubbles of more than 255 walks: %u, err %u\n", hc.n_many, hc.err);
+        if (hc.n_many > S->mlist_cap && !(hc.err & 33u)) {
+            S->mlist_cap = hc.n_many + hc.n_many / 8 + 64;
+            NEED(S->mlist, (size_t)S->mlist_cap * 4);
+            continue;
+        }
         if (hc.n_many && !(hc.err & 33u)) {
             // bubbles of more than 255 walks: walked again by a few wavefronts with room for PATHS_BIG walks each
-            const uint32_t n_many = std::min<uint32_t>(hc.n_many, MLIST_CAP);
+            const uint32_t n_many = hc.n_many;
             const int big_grid = (int)std::min<uint32_t>(n_many, 32);
             const uint64_t big_per_wave = (((((uint64_t)10 * depth_cap + 4) * 4 + 7) & ~7ull) + ((uint64_t)PATHS_BIG + 1) * 12 + 255) & ~255ull;
             NEED(S->paths_big_scr, big_per_wave * big_grid);

@@ -897,15 +897,19 @@ int pf_kernel_time(pf_ctx *ctx, int kernel, double *total_ms, uint64_t *launches
 
 int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) {
     if (!ctx) return PF_ERR_ARG;
+    PF_HIP(hipSetDevice(ctx->device));
     PF_HIP(hipDeviceSynchronize());
     std::vector<std::pair<float, float>> iv;
+    size_t unread = 0;
     {
         std::lock_guard<std::mutex> lk(ctx->launch_mu);
         iv.reserve(ctx->launches.size());
         for (auto &tl : ctx->launches) {
             float a = 0, b = 0;
             if (hipEventElapsedTime(&a, ctx->launches[0].a, tl.a) != hipSuccess || hipEventElapsedTime(&b, ctx->launches[0].a, tl.b) != hipSuccess) {
+                // (the device was synchronized above: an event that cannot be read was never recorded -- a launch that failed)
                 (void)hipGetLastError();
+                ++unread;
                 continue;
             }
             if (b > a) iv.emplace_back(a, b);
@@ -925,6 +929,10 @@ int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) {
         float mx = 0;
         for (auto &x : iv) mx = std::max(mx, x.second);
         *span_ms = iv.empty() ? 0.0 : (double)mx - (double)iv.front().first;
+    }
+    if (unread) {
+        pf::CtxErr{ctx} = "pf_device_busy: " + std::to_string(unread) + " launch intervals could not be read (busy_ms leaves them out)";
+        return PF_ERR_HIP;
     }
     return PF_OK;
 }
@@ -1409,8 +1417,10 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     unsigned int *d_nlive = reinterpret_cast<unsigned int *>(small + 56);
     BfsOut o{d_rec, d_pool, pool_cap, d_head, d_def, d_ndef, d_def + n + 4, d_ndef2, nullptr, 0, d_nlive, 0};
     if (ctx->h_live && deferred) {   // (armed by pf_bfs_live_deferred: the caller polls the list while the kernels below run)
-        for (uint64_t x = 0; x < ctx->live_cap; ++x) __atomic_store_n(&ctx->h_live[x], 0ull, __ATOMIC_RELAXED);
-        __atomic_thread_fence(__ATOMIC_SEQ_CST);
+        // The list is zeroed by pf_bfs_live_deferred -- once per arming, BEFORE the caller starts the threads that poll it.  Zeroing it
+        // here raced with them (they saw the pass before's entries first; advisor, round 3) and a retry after a pool overflow wiped
+        // what they were reading.  A retry writes the list again from slot 0: an entry a poller took before and the one that replaces
+        // it are both real candidates of this graph, walks are keyed by (candidate, entrance), what no poller saw is walked afterwards.
         o.live = reinterpret_cast<unsigned long long *>(ctx->h_live);
         o.live_cap = (uint32_t)ctx->live_cap;
         // (PF_BFS_HINT_AT, read per call: measurements; beyond the tier's tables = notice only when it gives up)
@@ -1614,8 +1624,9 @@ int pf_bfs_live_deferred(pf_ctx *ctx, uint64_t cap, volatile uint64_t **list) {
         if (hipHostMalloc(&p, cap * 8, hipHostMallocCoherent | hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); pf::CtxErr{ctx} = "pf_bfs_live_deferred: no pinned host memory"; return PF_ERR_HIP; }
         ctx->h_live = static_cast<unsigned long long *>(p);
         ctx->live_cap = cap;
-        memset(p, 0, cap * 8);
     }
+    for (uint64_t x = 0; x < cap; ++x) __atomic_store_n(&ctx->h_live[x], 0ull, __ATOMIC_RELAXED);   // (per arming: see bfs_candidates_impl)
+    __atomic_thread_fence(__ATOMIC_SEQ_CST);
     *list = reinterpret_cast<volatile uint64_t *>(ctx->h_live);
     return PF_OK;
 }

@@ -213,8 +213,21 @@ def reference_paths(G, s_ov, t_ov):
     return out
 
 
+class OutOfRange(Exception):
+    """std::out_of_range from std::string::substr: the reference terminates"""
+
+
+def substr(s, pos, count=None):
+    """std::string::substr(pos, count): the empty string at pos == size(), a throw beyond, a negative count (as size_t) = npos"""
+    if pos < 0 or pos > len(s):
+        raise OutOfRange()
+    return s[pos:] if count is None or count < 0 else s[pos: pos + count]
+
+
 def site_strings(rows, sites):
-    """per site the k-length string of every path, src/CDBG.cpp:1471-1525 (indel sites) and :1559-1596 (others); SURVEY.md B.1"""
+    """per site the string of every path, src/CDBG.cpp:1471-1525 (indel sites) and :1559-1596 (others), statement for statement;
+    SURVEY.md B.1.  A row that ends in gaps runs out inside the indel loop: substr(size(), 1) is empty, nothing is appended to that
+    row and '\\0' (c[0] of the empty string) joins the set of characters."""
     R = len(rows)
     out, indel = [], 0
     for col, is_indel, maxnum, groups, _ok in sites:
@@ -225,42 +238,45 @@ def site_strings(rows, sites):
             while True:
                 last = []
                 for p in range(R):
-                    while rows[p][pos[p]: pos[p] + 1] == b"-":
+                    c = substr(rows[p], pos[p], 1)
+                    while c == b"-":
                         pos[p] += 1
-                    c = rows[p][pos[p]: pos[p] + 1]
+                        c = substr(rows[p], pos[p], 1)
                     pos[p] += 1
                     app[p] += c
                     last.append(c)
                 if len(set(last)) != 1:
                     break
-            n = len(app[0])
             for p in range(R):
+                n = len(app[p])
                 if indel == 0:
-                    ks[p] = rows[p][col - K + n: col - K + n + (K - n)] + app[p]
+                    ks[p] = substr(rows[p], col - K + n, K - n) + app[p]
                 else:
                     tmp = rows[p][:col].replace(b"-", b"")
-                    if len(tmp) < K - n:
+                    if K - n < 0 or len(tmp) < K - n:     # (size_t < int: a negative right-hand side is huge)
                         s = tmp + app[p]
                         q = pos[p]
                         while len(s) < K:
-                            if rows[p][q: q + 1] != b"-":
-                                s += rows[p][q: q + 1]
+                            c = substr(rows[p], q, 1)
+                            if c != b"-":
+                                s += c
                             q += 1
                         ks[p] = s
                     else:
-                        ks[p] = (tmp[len(tmp) - (K - n):] if K - n > 0 else b"") + app[p]
+                        ks[p] = tmp[len(tmp) - (K - n):] + app[p] if K - n > 0 else app[p]
             indel += 1
         else:
             for p in range(R):
                 if indel == 0:
-                    ks[p] = rows[p][col - K + 1: col + 1]
+                    ks[p] = substr(rows[p], col - K + 1, K)
                 else:
                     tmp = rows[p][: col + 1].replace(b"-", b"")
                     if len(tmp) < K:
                         q = col + 1
                         while len(tmp) < K:
-                            if rows[p][q: q + 1] != b"-":
-                                tmp += rows[p][q: q + 1]
+                            c = substr(rows[p], q, 1)
+                            if c != b"-":
+                                tmp += c
                             q += 1
                         ks[p] = tmp
                     else:
@@ -528,3 +544,29 @@ def test_paths_walked_in_scratch_give_the_same(case, multi_path_graphs, tmp_path
         gfa, db, n = _braid(tmp_path, K, 7, seed=11)
         s = check_pipeline(str(tmp_path), gfa, db, z=40, lower=1, upper=1000)
         assert s["branching"] == 1 and s["max_paths"] >= 4, s
+
+
+GAP_FRIENDLY = [(2.0, -1.0, 1.0), (0.0, 0.0, 0.0), (2.0, -1.0, 0.0), (1.0, -1.0, 0.5), (2.0, 2.0, -3.0), (1e5, -1e5, -3.0), (3.0, 1.0, 2.0),
+                (-1.0, -7.0, -1.0)]
+
+
+@pytest.mark.parametrize("scores", GAP_FRIENDLY)
+def test_two_path_bubbles_under_gap_friendly_scores(two_path_graph, scores, second_pair_tier):
+    """the rest of the region the reference accepts (D <= M, G <= M and nothing else, src/Main.cpp:470-479): a gap that scores
+    better than a mismatch, all-zero scores, D = M, a positive gap, magnitudes of 1e5, a negative match.  Rows end in gaps; the last
+    indel run is open at the last column; the score-dependent gates of K-SNP / K-STACK / K-PAIR must send such bubbles on."""
+    tmp, gfa, db, kinds = two_path_graph
+    s = check_pipeline(tmp, gfa, db, scores=scores)
+    print(s)
+    assert s["two_path"] >= 2000, s
+
+
+@pytest.mark.parametrize("scores", [(2.0, -1.0, 1.0), (0.0, 0.0, 0.0), (2.0, -1.0, -0.5), (1.0, 0.5, -1.0)])
+def test_multi_path_bubbles_under_gap_friendly_scores(multi_path_graphs, scores):
+    """the same for branching bubbles: site strings that run to the end of a row (K-SITES), k-mers holding a '-'"""
+    tot = dict(multi_path=0, branching=0, site_checks=0, indel_sites=0)
+    for sub, gfa, db in multi_path_graphs[:3]:
+        s = check_pipeline(sub, gfa, db, z=16, scores=scores)
+        for k_ in tot:
+            tot[k_] += s[k_]
+    assert tot["multi_path"] >= 300 and tot["branching"] >= 200, tot

@@ -14,7 +14,10 @@ part of the unitig numbering the oracle's loader does not restate (pf_host_minz.
 With PF_FUZZ_GIANT=1 the genomes are 250-400 kb long and carry one to three copied segments (k .. 2k bp) near their start: the
 shared unitig's traversal cannot close before it has walked a whole locus to the end of the chromosome -- traversals of more
 than 4096 vertices, the third K-BFS tier (host walkers by default; PF_FUZZ_GIANT=device switches every other case to k_bfs_huge).
-With PF_FUZZ_COLORED=1 every case is a colored one (two to three samples; CCDBG's calling phase on the resident pipeline)."""
+With PF_FUZZ_COLORED=1 every case is a colored one (two to three samples; CCDBG's calling phase on the resident pipeline).
+With PF_FUZZ_SCORES=wide the scores are drawn from the whole region the reference accepts (draw_scores: D <= M, G <= M -- zero and
+positive gap scores, D = M, G = M, fractions, a negative match, magnitudes to 1e5); both sides then often end the run themselves
+(a site string's k-mer that is in no database): "oracle rc 1, product rc 1" is agreement."""
 import os
 import subprocess
 import sys
@@ -155,14 +158,16 @@ def build_case(seed, tmp, dev, force_colored=None, force_giant=None, wide_scores
                 giant=giant, crowd=crowd)
 
 
-def one_case(seed, tmp, dev, force_colored=None, force_giant=None):
-    c = build_case(seed, tmp, dev, force_colored, force_giant)
+def one_case(seed, tmp, dev, force_colored=None, force_giant=None, wide_scores=None):
+    c = build_case(seed, tmp, dev, force_colored, force_giant, wide_scores)
     if isinstance(c, str):
         return c
     k, ploidy, z, L, scores, lower, upper, colored, gfa, n_unitigs = (c[x] for x in ("k", "ploidy", "z", "L", "scores", "lower", "upper", "colored",
                                                                                       "gfa", "n_unitigs"))
     db, dbs, colors, use_reference, giant, crowd = c["db"], c["dbs"], c["colors"], c["use_reference"], c["giant"], c["crowd"]
-    common = ["-o", "x", "-z", str(z), "-M", str(scores[0]), "-D", str(scores[1]), "-G", str(scores[2])]
+    common = ["-o", "x", "-z", str(z), "-M", repr(scores[0]), "-D", repr(scores[1]), "-G", repr(scores[2])]
+    ub_log = os.path.join(tmp, "ub_cells.txt")   # the cells the reference leaves undefined (pfo::indel_len_at), listed by the oracle
+    oenv = dict(os.environ, PFO_UB_LOG=ub_log)
     og, gg = os.path.join(tmp, "oracle"), os.path.join(tmp, "gpu")
     os.makedirs(og), os.makedirs(gg)
     if colored:
@@ -176,7 +181,7 @@ def one_case(seed, tmp, dev, force_colored=None, force_giant=None):
             ro = subprocess.run([pyoracle.REF_BIN, "-g", gfa, "-f", colors, "-d", lst, "-C", cut, "-t", "1"] + common, cwd=og, capture_output=True, text=True)
         else:
             ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-f", dump, "-d", lst, "-C", cut, "-O", os.path.join(og, "PloidyFrost_output")] + common,
-                                cwd=og, capture_output=True, text=True)
+                                cwd=og, capture_output=True, text=True, env=oenv)
         rg = subprocess.run([CLI, "-g", gfa, "-f", colors, "-d", lst, "-C", cut, "-t", "8"] + common, cwd=gg, capture_output=True, text=True)
     else:
         if use_reference:
@@ -184,12 +189,25 @@ def one_case(seed, tmp, dev, force_colored=None, force_giant=None):
                                 capture_output=True, text=True)
         else:
             ro = subprocess.run([pyoracle.CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-O", os.path.join(og, "PloidyFrost_output")]
-                                + common, cwd=og, capture_output=True, text=True)
+                                + common, cwd=og, capture_output=True, text=True, env=oenv)
         env = dict(os.environ)
         if giant == "device" and seed % 2:
             env["PF_BFS_HUGE_ON_DEVICE"] = "1"
         rg = subprocess.run([CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-t", "8", "-v"] + common, cwd=gg, capture_output=True,
                             text=True, env=env)
+    cells = {}
+    if use_reference:
+        # the reference's files hold heap garbage in the cells it leaves undefined: the oracle lists them (and is itself held to the
+        # reference on every other byte by tools/fuzz_scores_cpu.py)
+        side = os.path.join(tmp, "oracle_side")
+        os.makedirs(side)
+        if colored:
+            subprocess.run([pyoracle.CLI, "-g", gfa, "-f", dump, "-d", lst, "-C", cut, "-O", os.path.join(side, "out")] + common, cwd=side,
+                           capture_output=True, text=True, env=oenv)
+        else:
+            subprocess.run([pyoracle.CLI, "-g", gfa, "-d", db, "-l", str(lower), "-u", str(upper), "-O", os.path.join(side, "out")] + common,
+                           cwd=side, capture_output=True, text=True, env=oenv)
+        cells = pyoracle.read_ub_log(ub_log)
     desc = "k=%d ploidy=%d z=%d L=%d scores=%s cut=%d/%d %s unitigs=%d" % (k, ploidy, z, L, scores, lower, upper,
                                                                           "colored" if colored else "single", n_unitigs)
     if giant and not colored:
@@ -202,16 +220,13 @@ def one_case(seed, tmp, dev, force_colored=None, force_giant=None):
     if use_reference and ro.returncode == -8 and rg.returncode == 0:
         # the reference divides by the number of sites it found (src/CDBG.cpp:1703): no site -> SIGFPE before its files are flushed
         return "%s: skipped (the reference died of its own division by zero: no site passed the cutoffs)" % desc
+    if use_reference and ro.returncode in (-11, -6) and rg.returncode == 0 and cells:
+        return "%s: skipped (the reference died of its own out-of-bounds read: %d undefined cells)" % (desc, sum(len(v) for v in cells.values()))
     if ro.returncode != 0 or rg.returncode != 0:
         # both must fail alike (e.g. a k-mer missing from the database)
         return "%s: oracle rc %d, product rc %d%s" % (desc, ro.returncode, rg.returncode, "" if (ro.returncode != 0) == (rg.returncode != 0)
                                                       else "  MISMATCH\n" + ro.stderr[-300:] + rg.stderr[-300:] + rg.stdout[-300:])
-    bad = []
-    for suf in FILES:
-        a = open(os.path.join(og, "PloidyFrost_output", "x_%s.txt" % suf), "rb").read()
-        b = open(os.path.join(gg, "PloidyFrost_output", "x_%s.txt" % suf), "rb").read()
-        if a != b:
-            bad.append(suf)
+    bad = pyoracle.compare_outputs(os.path.join(og, "PloidyFrost_output"), os.path.join(gg, "PloidyFrost_output"), "x", cells, colored)
     return "%s: %s" % (desc, "identical" if not bad else "DIFFERENT " + ",".join(bad))
 
 
@@ -224,7 +239,7 @@ def main():
     failures = 0
     for seed in range(first, first + n):
         with tempfile.TemporaryDirectory() as tmp:
-            msg = one_case(seed, tmp, dev, force_colored=True if os.environ.get("PF_FUZZ_COLORED") == "1" else None)
+            msg = one_case(seed, tmp, dev, force_colored=True if os.environ.get("PF_FUZZ_COLORED") == "1" else None)   # (PF_FUZZ_SCORES=wide: draw_scores)
         print("seed %d: %s" % (seed, msg), flush=True)
         failures += "DIFFERENT" in msg or "MISMATCH" in msg
     print("%d cases, %d failures" % (n, failures))
