@@ -169,6 +169,36 @@ def cpu_baseline(workdir: str, target_unitigs: int, device, runs: int = 3):
         each.append(sum(secs))
         log("cpu baseline (%s) run %d/%d: %d unitigs in %.2fs (find %.2fs + ploidy %.2fs)" % (kind, i + 1, runs, n_unitigs, each[-1], secs[0], secs[1]))
     t = sorted(each)[len(each) // 2]
+    # context: the same sample with every core the reference accepts (-t must not exceed
+    # hardware_concurrency, src/Main.cpp:287-291).  With -t > 1 the reference times only PloidyEstimation, in whole seconds
+    # (time(), src/CDBG.cpp:2668-2690), so the figure here is the program's wall time, load included, next to the -t 1 run's.
+    all_cores = None
+    if kind == "reference":
+        nt = os.cpu_count() or 1
+        wall = {}
+        for th in (1, nt):
+            tw = time.time()
+            r = subprocess.run(cmd[:cmd.index("-t") + 1] + [str(th)] + cmd[cmd.index("-t") + 2:], cwd=cwd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            wall[th] = time.time() - tw
+            if r.returncode != 0:
+                wall = None
+                break
+        if wall:
+            load_est = max(0.0, wall[1] - t)   # what -t 1 spends outside its two timed phases
+            all_cores = {"threads": nt, "program_wall_s": round(wall[nt], 2), "program_wall_s_t1": round(wall[1], 2),
+                         "phases_wall_s_estimate": round(max(wall[nt] - load_est, 1e-9), 2),
+                         "unitigs_per_s_estimate": round(n_unitigs / max(wall[nt] - load_est, 1e-9), 1),
+                         "note": "whole-program wall times; the phases' share of the -t %d run is estimated by taking off what the -t 1 run "
+                                 "spends outside its own phase timers (graph + database load)" % nt}
+            log("cpu baseline -t %d: program wall %.2fs (-t 1: %.2fs)" % (nt, wall[nt], wall[1]))
+    full = reference_digests().get(str(CONFIG_UNITIGS)) or {}
+    if "t1" in full and "findSuperBubble_cpu_s" in full["t1"]:
+        secs = full["t1"]["findSuperBubble_cpu_s"] + full["t1"]["PloidyEstimation_cpu_s"]
+        at_size = {"unitigs": full["unitigs"], "seconds": round(secs, 2), "unitigs_per_s": round(full["unitigs"] / secs, 1), "cores": 1,
+                   "measured": "%s on %s by tools/reference_digests.py (committed in profiles/reference_digests.json; NOT part of this run)" % (full.get("date"), full.get("host")),
+                   "all_cores": {k_: v for k_, v in full.items() if k_.startswith("t") and k_ != "t1" and isinstance(v, dict)}}
+    else:
+        at_size = dict(REFERENCE_FULL_SIZE, stale_constant=True)
     return {"value": n_unitigs / t, "unit": "unitigs/s", "cores": 1, "kind": kind, "runs": runs, "seconds": t,
             "seconds_each": [round(x, 3) for x in each], "sample_unitigs": n_unitigs,
             "sample": "same generator (tetraploid, k=25, z=8, -l %d -u %d), %d-unitig graph, findSuperBubble+PloidyEstimation "
@@ -176,13 +206,15 @@ def cpu_baseline(workdir: str, target_unitigs: int, device, runs: int = 3):
             # not like-for-like in size: the reference's unitigs/s FALLS as the graph grows (its per-k-mer binary search and
             # std::map traversals lose cache), so the ratio against this sample understates the ratio at the config's size
             "note": "bounded sample, smaller than the timed config; the reference's rate falls with graph size",
-            "reference_at_config_size": REFERENCE_FULL_SIZE}
+            "all_cores": all_cores, "reference_at_config_size": at_size}
 
 
 # The reference binary on the full configs[2] graph (same generator, seed 1000), timed once per build on the GPU box's host and
 # committed: a 12-minute run cannot sit inside the default bench.  Source: profiles/history/r01_fullscale_parity.txt.
 REFERENCE_FULL_SIZE = {"unitigs": 4990608, "seconds": 697.96, "unitigs_per_s": 7150.3, "cores": 1,
-                       "source": "profiles/history/r01_fullscale_parity.txt (committed measurement, not part of this run)"}
+                       "source": "profiles/history/r01_fullscale_parity.txt (a round-1 measurement: used only when profiles/reference_digests.json "
+                                 "holds no run of the config's graph, and then marked stale_constant)"}
+CONFIG_UNITIGS = 4990608   # bench.make_inputs(5 000 000 target, seed 1000): BASELINE.json configs[2]
 
 
 def cpu_model() -> str:
@@ -259,11 +291,26 @@ def main():
                          "samples (configs[3]), same JSON line with config.workload saying so")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: start the N ranks here -- a child process of torch.distributed.run, before
+        # anything in this process has touched the GPU (this parent never does) -- and leave with the child's exit code
+        import socket
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        log("--gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)))
+        sys.exit(subprocess.run(cmd).returncode)
+
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: one rank per GPU (launch with --nproc-per-node %d, or without a launcher)"
+                         % (args.gpus, world, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # PF_BENCH_SHARE_GPU=1 (debugging on a one-GPU box only): every rank uses GPU 0 and the end-of-pass
@@ -278,6 +325,7 @@ def main():
     xdev = torch.device("cpu") if share else dev  # where the collectives' tensors live
     workdir = tempfile.mkdtemp(prefix="pf_bench_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     ok = False
+    bad_output = False
     try:
         genome = int(args.unitigs / UNITIGS_PER_BP)
         colored = args.workload == "colored"
@@ -291,11 +339,13 @@ def main():
         else:
             gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, seed, dev)
         torch.cuda.empty_cache()
+        hostapi.load_trace(reset=True)
         t0 = time.time()
         if colored:
             run = hostapi.ColoredRun(gfa, colors, dbs, workdir, z=Z, threads=host_threads, device=gpu_index)
         else:
             run = hostapi.Run(gfa, db, z=Z, device=gpu_index)
+        open_s = time.time() - t0
         run.set_threads(host_threads)
         run.set_overlap_output(True)  # super_bubble.txt is written while PloidyEstimation runs; complete when it returns
         if os.environ.get("PF_BATCH_BUBBLES"):  # experiments: bubbles per batch of the align/format pipeline
@@ -309,6 +359,10 @@ def main():
         if strong and rank != 0:
             run.set_write_super_bubble(False)
         load_s = time.time() - t0
+        # where load_s went: the host layer's own steps (pfh_load_trace; steps of helper threads overlap the caller's, so the sum can
+        # exceed the wall time) + the unitig id file
+        load_breakdown = {"open_wall_s": round(open_s, 3), "unitig_id_file_and_settings_s": round(load_s - open_s, 3),
+                          "steps_s": {name: round(sec, 4) for name, sec in hostapi.load_trace(reset=True)}}
         log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, load_s, torch.cuda.get_device_name(gpu_index)))
         L = hipapi.load_library()
         import ctypes as C
@@ -398,6 +452,16 @@ def main():
             if n.value:
                 probe = {"avg_ms": round(ms.value / n.value, 4),
                          "equals_streamed": bool(all(np.array_equal(a, b) for a, b in zip(res[0], res[1])))}
+
+        # the twelve files the timed passes left, against the digests of what the REFERENCE binary wrote for this very graph
+        # (profiles/reference_digests.json, made by tools/reference_digests.py: oracle/_ref/PloidyFrost -t 1 on bench.make_inputs'
+        # graph of this size and seed); outside the timed region
+        output_check = None
+        if world > 1:
+            dist.barrier()
+        if rank == 0 and not colored:
+            output_check = check_outputs(os.path.join(workdir, "PloidyFrost_output"), "b", n_unitigs, seed)
+            log("output check: %s" % output_check)
 
         # one graph over several ranks: hold the shared files against a pass of rank 0 alone, once, outside the timed region
         sharded_identical = None
@@ -497,7 +561,8 @@ def main():
                 # tools/summarize_prof.py gives the same figure from the rocprofv3 kernel trace (profiles/*_device_busy.json)
                 "device_busy_ms_per_step": round(busy_ms.value / args.steps, 3),
                 "device_busy_frac": round(busy_ms.value / (max_elapsed * 1e3), 4),
-                "first_pass": first_pass, "load_s": round(load_s, 3), "sharded_output_check": sharded_identical,
+                "first_pass": first_pass, "load_s": round(load_s, 3), "load_breakdown": load_breakdown,
+                "output_check": output_check, "sharded_output_check": sharded_identical,
                 "kernels": kernels, "k_cov_probe": probe,
                 "host_phases_s_per_step": {k: round(v / args.steps, 4) for k, v in phase.items()},
                 # rank 0's graph; for one graph over all ranks (strong) the per-slice counters are added up
@@ -517,9 +582,12 @@ def main():
                 # the north-star bar: >= 10x the reference's single-threaded throughput at 1 GPU
                 out["north_star"] = {"target": ">= 10x reference -t 1 on the 5 M-unitig k=25 graph at 1 GPU",
                                      "ratio_vs_sample": out["speedup_vs_cpu_1core"],
-                                     "ratio_vs_reference_at_config_size": round(value / REFERENCE_FULL_SIZE["unitigs_per_s"], 1),
+                                     "ratio_vs_reference_at_config_size": round(value / cpu["reference_at_config_size"]["unitigs_per_s"], 1),
                                      "met": bool(value >= 10 * cpu["value"])}
             print(json.dumps(out), flush=True)
+            if output_check and output_check.get("identical_to_reference") is False:
+                log("OUTPUT DIFFERS FROM THE REFERENCE: %s" % output_check["differing"])
+                bad_output = True
         run.close()
         ok = True
     finally:
@@ -529,6 +597,42 @@ def main():
             dist.destroy_process_group()
         if not args.keep:
             shutil.rmtree(workdir, ignore_errors=True)
+    if bad_output:
+        sys.exit(3)
+
+
+def reference_digests():
+    p = os.path.join(ROOT, "profiles", "reference_digests.json")
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except (OSError, ValueError):
+        return {}
+
+
+def check_outputs(outdir: str, prefix: str, n_unitigs: int, seed: int):
+    """md5 of the twelve files in `outdir` against the committed digests of the reference's output for this graph.  None of the
+    digests' making is part of this run: `digest_source` says where they come from."""
+    import hashlib
+    ent = reference_digests().get(str(n_unitigs))
+    if not ent or ent.get("seed") != seed or "files" not in ent:
+        return {"files": 0, "identical_to_reference": None,
+                "note": "no committed reference digests for a graph of %d unitigs, seed %d (tools/reference_digests.py makes them)" % (n_unitigs, seed)}
+    differing = []
+    for name, want in sorted(ent["files"].items()):
+        h = hashlib.md5()
+        try:
+            with open(os.path.join(outdir, "%s_%s" % (prefix, name)), "rb") as fh:
+                for blk in iter(lambda: fh.read(1 << 24), b""):
+                    h.update(blk)
+        except OSError:
+            differing.append(name + " (missing)")
+            continue
+        if h.hexdigest() != want["md5"]:
+            differing.append(name)
+    return {"files": len(ent["files"]), "identical_to_reference": not differing, "differing": differing,
+            "digest_source": "profiles/reference_digests.json: md5 of what oracle/_ref/PloidyFrost -t 1 wrote for this graph (%d unitigs, seed %d; "
+                             "run on %s, %s, by tools/reference_digests.py)" % (n_unitigs, seed, ent.get("host", "?"), ent.get("date", "?"))}
 
 
 def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):

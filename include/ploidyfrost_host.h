@@ -61,6 +61,10 @@ int pfh_set_unitig_id(pfh_run *, const char *outpre);
 int pfh_find_superbubbles(pfh_run *, const char *outpre);
 int pfh_ploidy_estimation(pfh_run *, const char *outpre, int lower, int upper);
 void pfh_get_times(const pfh_run *, pfh_times *out);
+/* Where the loads of this process spent their time (GFA map / parse / upload, count database, join, adjacency, numbering, ...):
+ * "step\tseconds\n" per step since the last reset, in the order the steps ended (steps of helper threads overlap those of the
+ * caller's).  Returns the length of the text; at most cap - 1 bytes and a NUL are written.  reset != 0 empties the log afterwards. */
+uint64_t pfh_load_trace(char *out, uint64_t cap, int reset);
 /* the pf_ctx of include/ploidyfrost_hip.h that this run drives (timing, stream control) */
 void *pfh_device_ctx(pfh_run *);
 /* <outpre>_allele_frequency.txt of the last pfh_ploidy_estimation, in memory (valid until the next

@@ -7,6 +7,7 @@
 
 #include "pf_bfs_host.hpp"
 #include "pf_cdbg.hpp"
+#include "pf_trace.hpp"
 #include "pf_gmm_model.hpp"
 #include "pf_host_colors.hpp"
 #include "pf_replay_par.hpp"
@@ -186,6 +187,25 @@ int pfh_ploidy_text(pfh_run *r, uint64_t var_count_base, uint64_t sizes[10], uin
 }
 int pfh_ploidy_write(pfh_run *r, const char *outpre, const uint64_t offsets[10], const uint64_t totals[10], int truncate) {
     return guarded(r, [&] { return r->cdbg->ploidy_write(outpre, offsets, totals, truncate != 0); });
+}
+
+uint64_t pfh_load_trace(char *out, uint64_t cap, int reset) {
+    pfh::LoadLog &l = pfh::LoadLog::get();
+    std::lock_guard<std::mutex> lk(l.mu);
+    std::string text;
+    char num[32];
+    for (auto &st : l.steps) {
+        snprintf(num, sizeof num, "\t%.6f\n", st.second);
+        text += st.first;
+        text += num;
+    }
+    if (out && cap) {
+        const uint64_t n = std::min<uint64_t>(cap - 1, text.size());
+        memcpy(out, text.data(), n);
+        out[n] = 0;
+    }
+    if (reset) l.steps.clear();
+    return text.size();
 }
 
 void pfh_get_times(const pfh_run *r, pfh_times *o) {

@@ -1,18 +1,37 @@
-// PF_TRACE_LOAD=1: where loading and construction spend their time, one line per step on stderr.
+// Where loading and construction spend their time.  Every step is kept in a process-wide log that the C facade hands out
+// (pfh_load_trace: bench.py's `load_breakdown`); PF_TRACE_LOAD=1 also prints one line per step on stderr.
 #pragma once
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <mutex>
+#include <string>
+#include <utility>
+#include <vector>
 
 namespace pfh {
+
+struct LoadLog {
+    std::mutex mu;
+    std::vector<std::pair<std::string, double>> steps;
+    static LoadLog &get() {
+        static LoadLog l;
+        return l;
+    }
+};
 
 struct LoadTrace {
     bool on = getenv("PF_TRACE_LOAD") != nullptr;
     std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
     void mark(const char *what) {
-        if (!on) return;
         const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[load] %-28s %.3fs\n", what, std::chrono::duration<double>(now - t).count());
+        const double s = std::chrono::duration<double>(now - t).count();
+        {
+            LoadLog &l = LoadLog::get();
+            std::lock_guard<std::mutex> lk(l.mu);
+            l.steps.emplace_back(what, s);
+        }
+        if (on) fprintf(stderr, "[load] %-28s %.3fs\n", what, s);
         t = now;
     }
 };

@@ -98,6 +98,7 @@ struct CallCounters {
     unsigned int n_trio, n_trio4, n_trio_done;   // three / four short paths: K-TRIO's lists / the bubbles it finished
     unsigned int paths_next, sites_next;   // queue heads of K-PATHS / K-SITES
     unsigned int n_many, max_rows;         // bubbles of more than 255 walks (K-PATHS' second launch takes them) / the most walks of any bubble
+    unsigned int ks_need;                  // K-SITES: the longest site string a wavefront had no room for (err bit 4: the launch is repeated with room)
     unsigned int err;               // bit 0: > 65535 paths, 1: missing k-mer in a site string, 2: site string outside its row,
                                     // 3: a path pool overflowed (sizes below tell how much is needed), 4: site string too long
     unsigned int err_entrance, err_exit;   // the bubble bits 0 / 5 speak of (oriented vertices; whichever wavefront wrote last)
@@ -127,6 +128,7 @@ struct CallState {
     DevBuf ccov_sum, ccov_min, ccov_max, ccov_miss;
     DevBuf mlist, paths_big_scr;  // K-PATHS: bubbles of more than 255 walks, and the scratch of the launch that takes them
     uint32_t mlist_cap = 0;
+    uint32_t sites_ks = 0;        // K-SITES: room per site string once a launch asked for more than 2k + 64
     DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
     uint64_t walk_cap = 0;
     // scan
@@ -2214,7 +2216,10 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                         }
                         if (__ballot(e)) bad = 1;
                     }
-                    if (napp >= KS) bad = 16;
+                    if (napp >= KS) {   // (still growing: ask for the most a string can reach -- a row's characters and its raw columns)
+                        bad = 16;
+                        if (lane == 0) atomicMax(&a.cnt->ks_need, 2 * L + (uint32_t)k + 2);
+                    }
                     sync();
                     if (bad) { err = bad == 16 ? 16 : 4; break; }
                     const char first = app[napp];
@@ -2298,7 +2303,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             for (uint32_t x = 0; x < take; ++x) push(row[from + x]);
                         }
                     }
-                    if (n > KS) e = 16;
+                    if (n > KS) { e = 16; atomicMax(&a.cnt->ks_need, n); }
                     flen[p] = n;
                 }
                 if (__ballot(e == 4)) row_err |= 4;
@@ -3719,16 +3724,19 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     PF_HIP(hipMemcpyAsync(&n_called, O.vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
 
     // ---- K-SITES ----
-    const uint32_t KS = (uint32_t)(2 * k + 64);
+    // (a site string is k characters long unless it takes the raw columns up to its row's end -- substr with a negative count,
+    // src/CDBG.cpp:1499 -- or more than k characters agree behind an indel: a launch that meets one longer than its room says how
+    // long, ks_need, and is repeated with that much)
+    uint32_t KS = std::max<uint32_t>((uint32_t)(2 * k + 64), S->sites_ks);
     if (hc.n_branching) {
         const uint32_t C = S->n_colors;
         const uint64_t rows_cap = std::max<uint64_t>(256, ((uint64_t)hc.max_rows + 63) & ~63ull);
-        const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8) + (C ? rows_cap * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
         static const int sites_per_cu = [] { const char *e = getenv("PF_SITES_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
-        // (tables for thousands of rows: fewer wavefronts, at most 2 GB of them)
-        const int sites_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu)), (2ull << 30) / sites_per_wave));
-        NEED(S->sites_scr, sites_per_wave * sites_grid);
-        for (int attempt = 0;; ++attempt) {
+        for (int attempt = 0, ks_attempt = 0;; ++attempt) {
+            const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8) + (C ? rows_cap * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
+            // (tables for thousands of rows: fewer wavefronts, at most 2 GB of them)
+            const int sites_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu)), (2ull << 30) / sites_per_wave));
+            NEED(S->sites_scr, sites_per_wave * sites_grid);
             const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * std::max<uint32_t>(C, 1) * hc.n_branching + 1024ull * sites_grid + 1024);   // (a started chunk per wavefront)
             NEED(O.sv, sv_cap * 8);
             SiteArgs sa;
@@ -3776,9 +3784,18 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             }
             PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
             PF_HIP(hipStreamSynchronize(st));
+            if (hc.err & 16u) {
+                if (++ks_attempt > 3 || hc.ks_need <= KS) { pf::CtxErr{ctx} = "pf_call_run: the room for a site string does not converge"; return PF_ERR_OVERFLOW; }
+                KS = (hc.ks_need + 63u) & ~63u;
+                S->sites_ks = KS;
+                hc.err = 0; hc.ks_need = 0;   // (the other bits are looked at when every string had room: a string cut short has no verdict)
+                PF_HIP(hipMemsetAsync(&d_cnt->err, 0, 4, st));
+                PF_HIP(hipMemsetAsync(&d_cnt->ks_need, 0, 4, st));
+                --attempt;
+                continue;
+            }
             if (hc.err & 2u) { pf::CtxErr{ctx} = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
             if (hc.err & 4u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): a site string runs past the end of an aligned row (the reference terminates here: std::out_of_range from substr, src/CDBG.cpp:1478-1590)"; return PF_ERR_ARG; }
-            if (hc.err & 16u) { pf::CtxErr{ctx} = "CDBG::PloidyEstimation(): site string longer than 2k + 64"; return PF_ERR_ARG; }
             if (hc.err & 64u) { pf::CtxErr{ctx} = "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble"; return PF_ERR_ARG; }
             if (hc.sv_head > sv_cap) {
                 if (attempt >= 2) { pf::CtxErr{ctx} = "pf_call_run: site value pool does not converge"; return PF_ERR_OVERFLOW; }
