@@ -65,6 +65,12 @@ void pfh_get_times(const pfh_run *, pfh_times *out);
  * "step\tseconds\n" per step since the last reset, in the order the steps ended (steps of helper threads overlap those of the
  * caller's).  Returns the length of the text; at most cap - 1 bytes and a NUL are written.  reset != 0 empties the log afterwards. */
 uint64_t pfh_load_trace(char *out, uint64_t cap, int reset);
+/* The row filters behind the path (reference script/Filter.R, script/Filter-multi.R; csrc/host/pf_filter.hpp; PARITY UNPINNED --
+ * no R in the build image): argv as the scripts take it (argv[0], argv[1] are skipped like "ploidyfrost filter"), multi != 0 = the
+ * colored tables.  pfh_r_format_double: one number as R's write.table renders it (15 significant digits, fixed or scientific by
+ * width); returns the length, writes at most cap - 1 bytes and a NUL. */
+int pfh_filter(int argc, char **argv, int multi);
+uint64_t pfh_r_format_double(double x, char *out, uint64_t cap);
 /* the pf_ctx of include/ploidyfrost_hip.h that this run drives (timing, stream control) */
 void *pfh_device_ctx(pfh_run *);
 /* <outpre>_allele_frequency.txt of the last pfh_ploidy_estimation, in memory (valid until the next

@@ -8,6 +8,7 @@
 #include "pf_bfs_host.hpp"
 #include "pf_cdbg.hpp"
 #include "pf_trace.hpp"
+#include "pf_filter.hpp"
 #include "pf_gmm_model.hpp"
 #include "pf_host_colors.hpp"
 #include "pf_replay_par.hpp"
@@ -187,6 +188,18 @@ int pfh_ploidy_text(pfh_run *r, uint64_t var_count_base, uint64_t sizes[10], uin
 }
 int pfh_ploidy_write(pfh_run *r, const char *outpre, const uint64_t offsets[10], const uint64_t totals[10], int truncate) {
     return guarded(r, [&] { return r->cdbg->ploidy_write(outpre, offsets, totals, truncate != 0); });
+}
+
+int pfh_filter(int argc, char **argv, int multi) { return pfh::filter_main(argc, argv, multi != 0); }
+
+uint64_t pfh_r_format_double(double x, char *out, uint64_t cap) {
+    const std::string s = pfh::r_format_double(x);
+    if (out && cap) {
+        const uint64_t n = std::min<uint64_t>(cap - 1, s.size());
+        memcpy(out, s.data(), n);
+        out[n] = 0;
+    }
+    return s.size();
 }
 
 uint64_t pfh_load_trace(char *out, uint64_t cap, int reset) {

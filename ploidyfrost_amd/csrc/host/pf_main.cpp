@@ -5,8 +5,9 @@
 // Output: ./PloidyFrost_output/<prefix>_*.txt, byte-identical to the reference run with -t 1.
 // The coverage thresholds of the path can be derived from k-mer histograms exactly as in the reference: the
 // `cutoffL` / `cutoffU` sub-commands and `-h <histogram>` (with -f: a list of histograms) with `-q <quantile>`
-// (src/Main.cpp:200-277, 354-396, 721-762).  The `model` sub-command (GMM ploidy inference, downstream of the
-// path) is outside this build's scope and says so.
+// (src/Main.cpp:200-277, 354-396, 721-762).  `model` (GMM ploidy inference, src/Main.cpp:636-719; the EM on the device) and
+// `filter` / `filter-multi` (the row predicates of script/Filter.R, script/Filter-multi.R; host/pf_filter.cpp) are the steps behind
+// the path.
 #include <sys/prctl.h>
 #include <sys/wait.h>
 #include <signal.h>
@@ -27,6 +28,7 @@
 #include <vector>
 
 #include "pf_cdbg.hpp"
+#include "pf_filter.hpp"
 #include "pf_gmm_model.hpp"
 #include "ploidyfrost_hip.h"
 
@@ -57,7 +59,9 @@ void PrintUsage() {
          << "  --detach-teardown  return as soon as the result files are complete; a child process gives the device memory back" << endl << endl
          << "Usage: PloidyFrost cutoffL kmer_histogram_file" << endl
          << "Usage: PloidyFrost cutoffU kmer_histogram_file (quantile[<1 ,default:0.998])" << endl << endl
-         << "Not part of this build: `model`." << endl;
+         << "Usage: PloidyFrost model ...          (GMM ploidy inference from the coverage / frequency files; `PloidyFrost model` prints its options)" << endl
+         << "Usage: PloidyFrost filter ...         (the row predicates of script/Filter.R over <prefix>_*cov.txt; -h prints its options)" << endl
+         << "Usage: PloidyFrost filter-multi ...   (script/Filter-multi.R: the colored tables, with -c colour and -v Cramer's V)" << endl;
 }
 
 // lower threshold: 1.25 x the position of the first local minimum of the histogram (src/Main.cpp:200-235)
@@ -184,6 +188,8 @@ int model_main(int argc, char **argv) {
 int main(int argc, char **argv) {
     if (argc < 2) { PrintUsage(); return 0; }
     if (!strcmp(argv[1], "model")) return model_main(argc, argv);
+    if (!strcmp(argv[1], "filter")) return pfh::filter_main(argc, argv, false);         // script/Filter.R
+    if (!strcmp(argv[1], "filter-multi")) return pfh::filter_main(argc, argv, true);    // script/Filter-multi.R
     if (!strcmp(argv[1], "cutoffL")) {  // src/Main.cpp:721-730
         if (argc != 3) { cout << "Usage:PloidyFrost cutoffL kmer_histogram_file" << endl; exit(EXIT_FAILURE); }
         cout << max(10, cutoffL(argv[2])) << endl;

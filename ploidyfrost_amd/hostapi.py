@@ -25,7 +25,7 @@ class Times(C.Structure):
 
 _lib = None
 DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_dir", "pfh_set_write_files", "pfh_set_threads", "pfh_set_batch_bubbles", "pfh_set_align_pieces", "pfh_set_reference_threads", "pfh_set_overlap_output", "pfh_set_third_tier_on_host", "pfh_set_unitig_id",
-                    "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_load_trace", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
+                    "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_load_trace", "pfh_filter", "pfh_r_format_double", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
                     "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints", "pfh_colors_check_footprints",
@@ -60,6 +60,8 @@ def load_library() -> C.CDLL:
     L.pfh_find_superbubbles.argtypes = [vp, C.c_char_p]
     L.pfh_ploidy_estimation.argtypes = [vp, C.c_char_p, C.c_int, C.c_int]
     L.pfh_get_times.argtypes = [vp, C.POINTER(Times)]
+    L.pfh_r_format_double.restype = C.c_uint64
+    L.pfh_r_format_double.argtypes = [C.c_double, C.c_char_p, C.c_uint64]
     L.pfh_load_trace.restype = C.c_uint64
     L.pfh_load_trace.argtypes = [C.c_char_p, C.c_uint64, C.c_int]
     L.pfh_device_ctx.restype = vp
