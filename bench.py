@@ -49,13 +49,14 @@ def log(*a):
 
 
 def make_inputs(workdir: str, name: str, genome_len: int, seed: int, device, k: int = K, max_ins: int = 6, ploidy: int = 4,
-                p_snp: float = 0.75, p_del: float = 0.13):
-    """haplotypes -> compacted dBG (GFA) + KMC1 count database; returns (gfa, db_prefix, n_unitigs, n_kmers)."""
+                p_snp: float = 0.75, p_del: float = 0.13, repeats: bool = False):
+    """haplotypes -> compacted dBG (GFA) + KMC1 count database; returns (gfa, db_prefix, n_unitigs, n_kmers).  repeats: the base
+    genome carries repeat families, inverted repeats and tandem arrays on 8 % of its length (synth.repeat_rich_edit)."""
     from ploidyfrost_amd import cdbg_build, synth
     t0 = time.time()
     spec = synth.HapSpec(genome_len=genome_len, ploidy=ploidy, seed=seed, gap_lo=GAP_LO, gap_hi=GAP_HI, p_multi=0.03,
                          max_ins=max_ins, p_snp=p_snp, p_del=p_del)
-    haps = synth.make_haplotypes(spec)
+    haps = synth.make_haplotypes(spec, synth.repeat_rich_edit(seed + 1) if repeats else None)
     g = cdbg_build.build_cdbg(haps, k, device)
     gfa = os.path.join(workdir, name + ".gfa")
     n_unitigs = cdbg_build.write_gfa(gfa, g)
@@ -286,9 +287,11 @@ def main():
     ap.add_argument("--shard-find", action="store_true",
                     help="strong scaling: cut findSuperBubble by entrance vertex as well (all-gather of the traversal records) instead of "
                          "running it on every rank")
-    ap.add_argument("--workload", choices=["single", "colored"], default="single",
+    ap.add_argument("--workload", choices=["single", "colored", "repeats"], default="single",
                     help="single = the headline metric (BASELINE.json configs[1]); colored = the CCDBG path on 3 diploid "
-                         "samples (configs[3]), same JSON line with config.workload saying so")
+                         "samples (configs[3]), same JSON line with config.workload saying so; repeats = the single-sample path on a "
+                         "repeat-rich genome (50 repeat families, inverted repeats, tandem arrays on 8 %% of it): the stress case of the "
+                         "host tiers -- traversals that do not close for thousands of unitigs, giant commit components")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -337,7 +340,7 @@ def main():
             gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(workdir, "graph", genome, seed, dev, samples=n_samples)
             cutoffs = [(LOWER, UPPER)] * n_samples
         else:
-            gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, seed, dev)
+            gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, seed, dev, repeats=args.workload == "repeats")
         torch.cuda.empty_cache()
         hostapi.load_trace(reset=True)
         t0 = time.time()
@@ -540,7 +543,9 @@ def main():
                 "config": {"workload": ("colored graph of 3 synthetic diploid samples (CCDBG path, configs[3]), %d unitigs/GPU, k=25 z=8, "
                                         "cutoffs %d/%d per sample, M=2 D=-1 G=-3" if colored else
                                         "single-sample synthetic tetraploid graph, %d unitigs (BASELINE.json configs[2] = 5 M; configs[1] = 1 M with --unitigs 1000000), k=25 z=8, "
-                                        "-l %d -u %d, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER),
+                                        "-l %d -u %d, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER) +
+                                       (" -- REPEAT-RICH genome (stress workload, not the metric's config): 50 repeat families of 300-3000 bp at 1-3 %% divergence, "
+                                        "inverted copies and tandem arrays on 8 %% of the genome" if args.workload == "repeats" else ""),
                            "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
                            "partitioning": ("one graph replicated on every rank, cut by entrance vertex: K-BFS records all-gathered over RCCL "
                                             "(%d bytes per pass) and replayed on every rank; bubble list in contiguous slices, two small "
@@ -569,7 +574,10 @@ def main():
                 # K-BFS tiers: candidates that outgrew the 128-entry LDS tier were walked on host cores
                 "bfs": {"candidates": tt["candidates"], "bfs_deferred": tt["bfs_deferred"],
                         "deferred_frac": round(tt["bfs_deferred"] / max(tt["candidates"], 1), 8),
-                        "traversals_beyond_4096": tt["bfs_large"], "longest_traversal": tt["bfs_max_seen"]},
+                        "traversals_beyond_4096": tt["bfs_large"], "longest_traversal": tt["bfs_max_seen"],
+                        # findSuperBubble's host share: vertices the host walkers visited for the deferred traversals; records committed on a
+                        # host thread (the large components of K-CC and the walked traversals)
+                        "host_walk_vertices": tt["host_walk_vertices"], "host_commit_records": tt["host_commit_records"]},
                 "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"],
                            "bubbles_called": shard_stats["counters"][7] if strong else tt["tasks"],
                            "align_jobs": tt["align_jobs"], "site_strings": tt["site_strings"],

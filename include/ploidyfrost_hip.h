@@ -366,6 +366,7 @@ typedef struct pf_call_result {
     uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: finished by K-SNP, by K-PAIR, sent to K-BUBBLE */
     uint64_t stack_jobs;                     /* ... finished by K-STACK (paths of one length, alignment = the paths stacked) */
     uint64_t trio_jobs;                      /* ... finished by K-TRIO (3-8 short paths, every round one alignment that leaves row 0 alone) */
+    uint64_t alignseq_packed_len;            /* pf_call_set_alignseq_packed: bytes stream PF_OUT_ALIGNSEQ takes in the slab (text_len keeps the text's) */
 } pf_call_result;
 #define PF_CALL_SLABS 4 /* text slabs of a context: a slab is free again once pf_call_fetch has copied it */
 /* Bubbles [t0, t1) of the selection (at most 2^24): everything up to the text of the ten streams, left in slab 0 .. 3 of the
@@ -378,6 +379,13 @@ int pf_call_run(pf_ctx *, int slab, uint64_t t0, uint64_t t1, uint64_t var_count
 int pf_call_align(pf_ctx *, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
                   pf_call_result *out);
 int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *out);
+/* alignseq.txt is more than half of the text of a pass and every row of a bubble repeats the bubble's four numbers in front of a row
+ * over five letters.  on != 0: the pf_call_text* calls that follow leave stream PF_OUT_ALIGNSEQ of a slab PACKED -- an index, then per
+ * bubble one header and its rows at 3 bits per character (csrc/pf_alnpack.hpp: layout, and the host routine that writes the text out
+ * of it, pf::alnpack_expand) -- 2.5 x fewer bytes over PCIe.  pf_call_result.text_len[PF_OUT_ALIGNSEQ] stays the length of the TEXT
+ * (file offsets); .alignseq_packed_len is what the stream takes in the slab, i.e. the length to pass to pf_call_fetch /
+ * pf_call_fetch_slab for it.  Default off. */
+int pf_call_set_alignseq_packed(pf_ctx *, int on);
 /* Takes the device buffers pf_call_align(_lane) would take on its first call for ranges of up to n_bubbles bubbles -- to be called
  * beside the load, so that a one-shot run does not pay its first alignment launch with two dozen allocations.  A hint: sizes that
  * turn out too small grow in pf_call_align as before.  Needs pf_call_set_state / pf_call_coverage / any other pf_call_* call first

@@ -19,6 +19,7 @@
 #include <mutex>
 #include <thread>
 
+#include "../pf_alnpack.hpp"
 #include "pf_cdbg_impl.hpp"
 #include "pf_parallel.hpp"
 
@@ -313,6 +314,17 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             });
     }
 
+    // alignseq leaves the device packed (pf_alnpack.hpp: a header per bubble, rows at 3 bits per character) and becomes text in the
+    // writer below; PF_ALIGNSEQ_ASCII=1 keeps the device writing the text itself (measurements, and the check that both give one file)
+    const bool aln_packed = !getenv("PF_ALIGNSEQ_ASCII");
+    if (pf_call_set_alignseq_packed(ctx_, aln_packed ? 1 : 0) != PF_OK) return fail(PF_ERR_HIP, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+    struct PackGuard {   // the sliced calls (ploidy_text, one graph over several ranks) read the text as the device writes it
+        pf_ctx *c;
+        ~PackGuard() { (void)pf_call_set_alignseq_packed(c, 0); }
+    } pack_guard{ctx_};
+    // what stream s of a piece takes in a slab
+    auto slab_len = [](const pf_call_result &r, int s) { return (s == PF_OUT_ALIGNSEQ && r.alignseq_packed_len) ? r.alignseq_packed_len : r.text_len[s]; };
+
     // ---- pieces: device (this thread) | copy back (fetcher thread) | append to the files (writer thread) ----
     // (PF_BATCH_BUBBLES: tools/fuzz_parity.py drives the CLI through many small pieces and ranges with it)
     const size_t batch_env = [] { const char *e = getenv("PF_BATCH_BUBBLES"); return e ? (size_t)std::max(1, atoi(e)) : (size_t)0; }();
@@ -359,11 +371,11 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 cv.wait(lk, [&] { return stop || b < written + 2; });   // host slab b % 2 was last used by piece b - 2
                 if (stop) { fetcher_done = true; lk.unlock(); cv.notify_all(); return; }
             }
-            uint64_t total = 0;
-            for (int s = 0; s < PF_CALL_STREAMS; ++s) total += d.res.text_len[s];
+            uint64_t total = 0, fetch_len[PF_CALL_STREAMS];
+            for (int s = 0; s < PF_CALL_STREAMS; ++s) { fetch_len[s] = slab_len(d.res, s); total += fetch_len[s]; }
             PinnedBuf<char> &hb = cx_.slab[d.hslab];
             hb.ensure(ctx_, std::max<uint64_t>(total, 1));
-            const int st = pf_call_fetch_slab(ctx_, d.slab, hb.p, d.res.text_len);
+            const int st = pf_call_fetch_slab(ctx_, d.slab, hb.p, fetch_len);
             {
                 std::lock_guard<std::mutex> lk(mu);
                 fetched = b + 1;
@@ -391,19 +403,48 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             }
             const auto tw = clk::now();
             uint64_t total = 0, off[PF_CALL_STREAMS + 1];
-            for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += d.res.text_len[s]; }
+            for (int s = 0; s < PF_CALL_STREAMS; ++s) { off[s] = total; total += slab_len(d.res, s); }
             PinnedBuf<char> &hb = cx_.slab[d.hslab];
             // append: every stream at its running offset through a shared mapping, copied by all threads side by side
             if (write_files_) {
                 CopySpan spans[PF_CALL_STREAMS];
                 size_t n_spans = 0;
+                pf::AlnPackPiece packed;   // alignseq of this piece, when it came packed: written out of its records, group by group
+                char *packed_dst = nullptr;
+                std::vector<char> packed_tmp;
                 for (int s = 0; s < PF_CALL_STREAMS; ++s) {
                     if (!d.res.text_len[s]) continue;
                     char *dst = maps[s].prepare(files[(size_t)s].bytes, d.res.text_len[s]);
+                    if (s == PF_OUT_ALIGNSEQ && d.res.alignseq_packed_len) {
+                        if (!packed.parse(reinterpret_cast<const uint8_t *>(hb.p + off[s]), d.res.alignseq_packed_len)) { files[(size_t)s].rc = 1; continue; }
+                        if (!dst) { packed_tmp.resize(d.res.text_len[s]); dst = packed_tmp.data(); }   // (no mapping: text first, then pwrite)
+                        packed_dst = dst;
+                        continue;
+                    }
                     if (dst) spans[n_spans++] = CopySpan{dst, hb.p + off[s], d.res.text_len[s]};
                     else if (maps[s].write(files[(size_t)s].bytes, hb.p + off[s], d.res.text_len[s], T)) files[(size_t)s].rc = 1;   // (no mapping: pwrite)
                 }
-                copy_spans(spans, n_spans, T);   // all ten streams in one dispatch of the pool
+                // the other streams' copies and alignseq's groups in one dispatch of the pool
+                constexpr uint64_t PIECE = 1u << 20;
+                std::vector<CopySpan> cut;
+                for (size_t i = 0; i < n_spans; ++i)
+                    for (uint64_t at = 0; at < spans[i].len; at += PIECE) cut.push_back(CopySpan{spans[i].dst + at, spans[i].src + at, std::min<uint64_t>(PIECE, spans[i].len - at)});
+                constexpr uint64_t GROUPS_PER_TASK = 16;   // 4096 bubbles, about 600 KB of text
+                const size_t n_aln = packed_dst ? (size_t)((packed.n_groups + GROUPS_PER_TASK - 1) / GROUPS_PER_TASK) : 0;
+                std::atomic<int> bad{0};
+                parallel_chunks(n_aln + cut.size(), 1, T, [&](size_t i, size_t, size_t) {
+                    if (i >= n_aln) { const CopySpan &c = cut[i - n_aln]; memcpy(c.dst, c.src, (size_t)c.len); return; }   // (alignseq first: the larger tasks)
+                    const uint64_t g0 = (uint64_t)i * GROUPS_PER_TASK, g1 = std::min<uint64_t>(packed.n_groups, g0 + GROUPS_PER_TASK);
+                    uint64_t t0_, r0_, t1_, r1_;
+                    packed.entry(g0, t0_, r0_);
+                    packed.entry(g1, t1_, r1_);
+                    if (t1_ > d.res.text_len[PF_OUT_ALIGNSEQ] || t0_ > t1_ || r0_ > r1_ ||
+                        (uint64_t)(packed.records - packed.base) + r1_ > d.res.alignseq_packed_len) { bad = 1; return; }
+                    char *end = pf::alnpack_expand(packed.records + r0_, packed.records + r1_, packed_dst + t0_);
+                    if (end != packed_dst + t1_) bad = 1;
+                });
+                if (bad) files[PF_OUT_ALIGNSEQ].rc = 1;
+                if (!packed_tmp.empty() && maps[PF_OUT_ALIGNSEQ].write(files[PF_OUT_ALIGNSEQ].bytes, packed_tmp.data(), packed_tmp.size(), T)) files[PF_OUT_ALIGNSEQ].rc = 1;
             }
             if (!write_files_) last_allfre_.append(hb.p + off[0], d.res.text_len[0]);   // (else: read back from the file on demand)
             for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].bytes += d.res.text_len[s];

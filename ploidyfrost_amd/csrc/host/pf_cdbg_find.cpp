@@ -290,6 +290,9 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     times_.bfs_device_s = since(t_all);
     times_.candidates = n_rec;
     times_.bfs_deferred = n_deferred;
+    times_.host_commit_records = n_big + n_deferred;
+    times_.host_walk_vertices = 0;
+    for (const auto &w : walked) times_.host_walk_vertices += w.n_seen;
     times_.replay_s = 0;
     if (!quiet_) {
         printf(mt_format_ ? "%s::findSuperBubble(): Finding superbubbles Cpu time : %gs\n" : "%s::findSuperBubble():  Cpu time : %gs\n", tag_,

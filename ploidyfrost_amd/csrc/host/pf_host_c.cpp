@@ -235,6 +235,7 @@ void pfh_get_times(const pfh_run *r, pfh_times *o) {
     o->scan_s = t.scan_s; o->scan_serial_s = t.scan_serial_s;
     o->bfs_large = t.bfs_large; o->bfs_max_seen = t.bfs_max_seen;
     o->bfs_deferred = t.bfs_deferred;
+    o->host_commit_records = t.host_commit_records; o->host_walk_vertices = t.host_walk_vertices;
     o->snp_jobs = t.snp_jobs; o->pair_jobs = t.pair_jobs; o->wave_jobs = t.wave_jobs; o->stack_jobs = t.stack_jobs; o->trio_jobs = t.trio_jobs;
 }
 

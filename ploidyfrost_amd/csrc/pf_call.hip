@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "pf_bubble_launch.hpp"
+#include "pf_alnpack.hpp"
 #include "pf_call_dev.hpp"
 #include "pf_colored_dev.hpp"
 #include "pf_cov_stream.hpp"
@@ -60,6 +61,8 @@ namespace {
 
 constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_STRICT_M = 0x08, B_STRICT_P = 0x10, B_COMPLEX_M = 0x20, B_COMPLEX_P = 0x40;
 constexpr int N_STREAMS = PF_CALL_STREAMS;
+constexpr int N_INT = N_STREAMS + 1;   // size / offset tables: the ten streams + the packed form of alignseq (pf_alnpack.hpp)
+constexpr int S_PACK = N_STREAMS;
 // work lists of a batch: K-BUBBLE's queues (heavy and light per size class), then the three lists of the other kernels
 constexpr int NQ = 2 * (kBubLdsClasses + 1);
 constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_PAIR2 = NQ + 3, KEY_STACK = NQ + 4, KEY_TRIO = NQ + 5, KEY_TRIO4 = NQ + 6, KEY_NONE = NQ + 7;
@@ -129,6 +132,7 @@ struct CallState {
     DevBuf mlist, paths_big_scr;  // K-PATHS: bubbles of more than 255 walks, and the scratch of the launch that takes them
     uint32_t mlist_cap = 0;
     uint32_t sites_ks = 0;        // K-SITES: room per site string once a launch asked for more than 2k + 64
+    bool pack_alignseq = false;   // pf_call_set_alignseq_packed
     DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
     uint64_t walk_cap = 0;
     // scan
@@ -2501,9 +2505,10 @@ struct FmtArgs {
     uint64_t vc_base;
     int mt;                   // the reference's -t > 1 format: var_count from 0, allele_frequency rows grouped by arity per bubble
     const uint32_t *len;
-    uint32_t *sizes;          // [N_STREAMS][nb + 1]
+    uint32_t *sizes;          // [N_INT][nb + 1]
     const uint64_t *offs;     // exclusive scan of sizes, one run over all streams
-    char *out[N_STREAMS];
+    char *out[N_INT];
+    int packed;               // alignseq leaves as out[S_PACK] = index + records (pf_alnpack.hpp); out[PF_OUT_ALIGNSEQ] is not written
     CallCounters *cnt;
     // colored (CCDBG): a site gives one row per colour that sees two allele groups or more (src/CCDBG.cpp:2971-3059, 3236-3339)
     uint32_t n_colors, N;
@@ -2599,7 +2604,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                 const int st_ = FMT_STAGED_STREAM[q];
                 span0[q] = a.offs[st_ * stride + w_first];
                 span_len[q] = (uint32_t)(a.offs[st_ * stride + w_end] - span0[q]);
-                staged[q] = span_len[q] <= FMT_STAGE[q];
+                staged[q] = span_len[q] <= FMT_STAGE[q] && !(q == 0 && a.packed);
                 stage[q] = base + acc;
                 acc += FMT_STAGE[q];
             }
@@ -2611,7 +2616,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
         for (int x = 0; x < 4; ++x) { s_fre[x] = Row<W>{nullptr, 0}; s_cov[x] = Row<W>{nullptr, 0}; }
         if (W) {
             s_all.p = a.out[0] + (a.offs[0 * stride + jj] - a.offs[0 * stride]);
-            s_aln.p = a.out[1] + (a.offs[1 * stride + jj] - a.offs[1 * stride]);
+            if (!a.packed) s_aln.p = a.out[1] + (a.offs[1 * stride + jj] - a.offs[1 * stride]);
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 s_fre[x].p = a.out[2 + x] + (a.offs[(2 + x) * stride + jj] - a.offs[(2 + x) * stride]);
@@ -2630,8 +2635,17 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
             const uint64_t my_vc = a.vc_base + a.vc[j] - (a.mt ? 1 : 0);   // fetch_add(1) returns the old value (src/CDBG.cpp:2056)
             char *fre_start[4] = {s_fre[0].p, s_fre[1].p, s_fre[2].p, s_fre[3].p};
             const uint32_t fre_n0[4] = {s_fre[0].n, s_fre[1].n, s_fre[2].n, s_fre[3].n};
+            if (W && a.packed) {
+                // alignseq, packed: this lane writes its bubble's header; the rows are packed by the whole wavefront further down
+                char *rec = a.out[S_PACK] + alnpack_index_bytes(a.nb) + (a.offs[(size_t)S_PACK * stride + jj] - a.offs[(size_t)S_PACK * stride]);
+                const uint64_t vc64 = my_vc;
+                const uint32_t h[4] = {t.u + 1, (t.exit_ov >> 1) + 1, L, R | (t.strict ? 0x80000000u : 0u)};
+                __builtin_memcpy(rec, &vc64, 8);
+                __builtin_memcpy(rec + 8, h, 16);
+                cp_dst = rec + ALNPACK_HEADER; cp_src = rows; cp_L = L; cp_R = R;
+            }
             // alignseq: var_count, strict flag, entrance id, exit id, aligned row (src/CDBG.cpp:1259, 1428)
-            for (uint32_t p = 0; p < R; ++p) {
+            for (uint32_t p = 0; p < R && !(W && a.packed); ++p) {
                 char *const row_start = s_aln.p;
                 put_uint(s_aln, my_vc);
                 s_aln.put('\t'); s_aln.put(t.strict ? '1' : '0'); s_aln.put('\t');
@@ -2821,6 +2835,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
         if (!W) {
             a.sizes[0 * stride + jj] = s_all.n;
             a.sizes[1 * stride + jj] = s_aln.n;
+            a.sizes[(size_t)S_PACK * stride + jj] = (a.packed && s_aln.n) ? ALNPACK_HEADER + r.n_rows * alnpack_row_bytes(r.n_cols) : 0u;
 #pragma unroll
             for (int x = 0; x < 4; ++x) {
                 a.sizes[(2 + x) * stride + jj] = s_fre[x].n;
@@ -2839,8 +2854,38 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                 const uint64_t d64 = (uint64_t)(uintptr_t)cp_dst, s64 = (uint64_t)(uintptr_t)cp_src;
                 char *dst = reinterpret_cast<char *>((uintptr_t)(((uint64_t)read_lane((uint32_t)(d64 >> 32), b) << 32) | read_lane((uint32_t)d64, b)));
                 const char *src = reinterpret_cast<const char *>((uintptr_t)(((uint64_t)read_lane((uint32_t)(s64 >> 32), b) << 32) | read_lane((uint32_t)s64, b)));
+                if (a.packed) {
+                    // eight characters = three bytes, a lane per group of eight (pf_alnpack.hpp)
+                    const uint32_t rb = alnpack_row_bytes(Lb), n8 = (Lb + 7) >> 3;
+                    for (uint32_t p = 0; p < Rb; ++p)
+                        for (uint32_t x = (uint32_t)lane; x < n8; x += WAVE) {
+                            const char *c = src + (size_t)p * Lb + 8 * (size_t)x;
+                            const uint32_t m = Lb - 8 * x < 8 ? Lb - 8 * x : 8;
+                            uint32_t v = 0;
+                            for (uint32_t i = 0; i < m; ++i) v |= alnpack_code(c[i]) << (3 * i);
+                            char *d = dst + (size_t)p * rb + 3 * (size_t)x;
+                            d[0] = (char)v; d[1] = (char)(v >> 8); d[2] = (char)(v >> 16);
+                        }
+                    continue;
+                }
                 for (uint32_t p = 0; p < Rb; ++p)
                     for (uint32_t x = (uint32_t)lane; x < Lb; x += WAVE) dst[(size_t)p * step + x] = src[(size_t)p * Lb + x];
+            }
+        }
+        if (a.packed && jj < a.nb && (jj % ALNPACK_GROUP == 0 || jj + 1 == a.nb)) {
+            // the index of the piece: where the text and the records of every 256th bubble begin, and where both end
+            const size_t stride = (size_t)a.nb + 1;
+            char *idx = a.out[S_PACK];
+            auto entry = [&](uint64_t g, uint32_t at) {
+                const uint64_t e[2] = {a.offs[1 * stride + at] - a.offs[1 * stride], a.offs[(size_t)S_PACK * stride + at] - a.offs[(size_t)S_PACK * stride]};
+                __builtin_memcpy(idx + 16 + 16 * g, e, 16);
+            };
+            if (jj % ALNPACK_GROUP == 0) entry(jj / ALNPACK_GROUP, jj);
+            if (jj + 1 == a.nb) {
+                const uint64_t n_groups = ((uint64_t)a.nb + ALNPACK_GROUP - 1) / ALNPACK_GROUP;
+                const uint64_t head[2] = {n_groups, ALNPACK_GROUP};
+                __builtin_memcpy(idx, head, 16);
+                entry(n_groups, a.nb);
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
@@ -2871,7 +2916,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
         }
         if (jj == a.nb) {
             const size_t stride = (size_t)a.nb + 1;
-            for (int s = 0; s < N_STREAMS; ++s) a.sizes[s * stride + a.nb] = 0;
+            for (int s = 0; s < N_INT; ++s) a.sizes[s * stride + a.nb] = 0;
         }
     }
 }
@@ -2879,7 +2924,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
 __global__ void k_call_totals(const uint64_t *__restrict__ offs, const uint32_t *__restrict__ sizes, uint32_t nb, uint64_t *__restrict__ totals) {
     const int s = threadIdx.x;
     const size_t stride = (size_t)nb + 1;
-    if (s < N_STREAMS) totals[s] = offs[s * stride + nb] - offs[s * stride];
+    if (s < N_INT) totals[s] = offs[s * stride + nb] - offs[s * stride];
     (void)sizes;
 }
 
@@ -3933,13 +3978,13 @@ int pf_call_reserve_text(pf_ctx *ctx, uint64_t piece_bubbles) {
     PF_HIP(hipSetDevice(ctx->device));
     const uint32_t nb = (uint32_t)std::min<uint64_t>(piece_bubbles, 1u << 24);
     { const int ts = text_stream_of(ctx, S); if (ts != PF_OK) return ts; }
-    NEED_TEXT(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
-    NEED_TEXT(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
+    NEED_TEXT(S->sizes, (size_t)N_INT * (nb + 1) * 4);
+    NEED_TEXT(S->offs, ((size_t)N_INT * (nb + 1) + 1) * 8);
     NEED_TEXT(S->totals, 16 * 8);
     NEED_TEXT(S->tcounters, sizeof(CallCounters));
     size_t tmp2 = 0;
     hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)((size_t)N_STREAMS * (nb + 1)), S->text_stream));
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)((size_t)N_INT * (nb + 1)), S->text_stream));
     NEED_TEXT(S->tscan, tmp2);
     for (int slab = 0; slab < PF_CALL_SLABS; ++slab) NEED_TEXT(S->out[slab], (11ull * (uint64_t)ctx->k + 40) * nb);
     return PF_OK;
@@ -3971,8 +4016,8 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     uint32_t vc_edge[2] = {0, 0};
     PF_HIP(hipMemcpyAsync(&vc_edge[1], O.vc.as<uint32_t>() + (first + count - 1), 4, hipMemcpyDeviceToHost, st));
     if (first) PF_HIP(hipMemcpyAsync(&vc_edge[0], O.vc.as<uint32_t>() + (first - 1), 4, hipMemcpyDeviceToHost, st));
-    NEED_TEXT(S->sizes, (size_t)N_STREAMS * (nb + 1) * 4);
-    NEED_TEXT(S->offs, ((size_t)N_STREAMS * (nb + 1) + 1) * 8);
+    NEED_TEXT(S->sizes, (size_t)N_INT * (nb + 1) * 4);
+    NEED_TEXT(S->offs, ((size_t)N_INT * (nb + 1) + 1) * 8);
     const char *oom = "pf_call_text: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
     NEED(S->totals, 16 * 8);
@@ -3980,7 +4025,7 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     CallCounters *d_cnt = S->tcounters.as<CallCounters>();
     CallCounters hc;
     size_t tmp2 = 0;
-    const size_t n_sizes = (size_t)N_STREAMS * (nb + 1);
+    const size_t n_sizes = (size_t)N_INT * (nb + 1);
     hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
     NEED(S->tscan, tmp2);
@@ -3992,7 +4037,8 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     fa.otext = O.otext.as<char>(); fa.osites = O.osites.as<pf_bubble_site>(); fa.ogroups = O.ogroups.as<uint8_t>();
     fa.oilen = O.oilen.as<uint32_t>(); fa.sv_off = O.sv_off.as<uint64_t>(); fa.sv = O.sv.as<double>(); fa.vc = O.vc.as<uint32_t>();
     fa.vc_base = var_count_base; fa.mt = S->mt_format ? 1 : 0; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
-    for (int s = 0; s < N_STREAMS; ++s) fa.out[s] = nullptr;
+    for (int s = 0; s < N_INT; ++s) fa.out[s] = nullptr;
+    fa.packed = S->pack_alignseq ? 1 : 0;
     size_t at = 0;
     ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
     fa.n_colors = S->n_colors; fa.N = ctx->N; fa.k = ctx->k; fa.full = S->col_full.as<uint64_t>(); fa.ccov_sum = S->ccov_sum.as<uint64_t>();
@@ -4001,13 +4047,17 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     ctx_end_at(ctx, at, st);
     PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->tscan.p, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
     k_call_totals<<<1, 64, 0, st>>>(S->offs.as<uint64_t>(), S->sizes.as<uint32_t>(), nb, S->totals.as<uint64_t>());
-    uint64_t totals[N_STREAMS + 1] = {};
-    PF_HIP(hipMemcpyAsync(totals, S->totals.p, N_STREAMS * 8, hipMemcpyDeviceToHost, st));
+    uint64_t totals[N_INT + 1] = {};
+    PF_HIP(hipMemcpyAsync(totals, S->totals.p, N_INT * 8, hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     out->n_called = vc_edge[1] - vc_edge[0];
+    // what a stream takes in the slab: its text -- alignseq, when packed, its index and records instead
+    const uint64_t packed_len = (fa.packed && totals[PF_OUT_ALIGNSEQ]) ? alnpack_index_bytes(nb) + totals[S_PACK] : 0;
+    auto slab_len = [&](int s) { return (s == PF_OUT_ALIGNSEQ && fa.packed) ? packed_len : totals[s]; };
+    out->alignseq_packed_len = packed_len;
     uint64_t all = 0;
-    for (int s = 0; s < N_STREAMS; ++s) all += totals[s];
+    for (int s = 0; s < N_STREAMS; ++s) all += slab_len(s);
     if (sizes_only) {   // pf_call_text_sizes: the count pass alone
         for (int s = 0; s < N_STREAMS; ++s) out->text_len[s] = totals[s];
         for (int x = 0; x < 4; ++x) out->allele[x] = hc.allele[x];
@@ -4022,10 +4072,11 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     for (int s = 0; s < N_STREAMS; ++s) {
         fa.out[s] = S->out[slab].as<char>() + all;
         S->out_off[slab][s] = all;
-        S->out_len[slab][s] = totals[s];
+        S->out_len[slab][s] = slab_len(s);
         out->text_len[s] = totals[s];
-        all += totals[s];
+        all += slab_len(s);
     }
+    if (fa.packed) { fa.out[S_PACK] = fa.out[PF_OUT_ALIGNSEQ]; fa.out[PF_OUT_ALIGNSEQ] = nullptr; }
     ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
     if (S->n_colors) k_call_format<true, true><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     else k_call_format<true, false><<<(nb + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
@@ -4040,6 +4091,14 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     out->core_cov = hc.core_cov;
     out->core_num = hc.core_num;
 #undef NEED
+    return PF_OK;
+}
+
+int pf_call_set_alignseq_packed(pf_ctx *ctx, int on) {
+    if (!ctx) return PF_ERR_ARG;
+    CallState *S = state_of(ctx);
+    if (!S) return PF_ERR_HIP;
+    S->pack_alignseq = on != 0;
     return PF_OK;
 }
 

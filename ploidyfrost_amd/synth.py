@@ -429,3 +429,36 @@ def plant_crowded_minimizer(rng, base, g, copies, tries=3000):
         at = (i + 1) * step + int(rng.integers(-step // 4, step // 4))
         out[at: at + g] = core
     return out
+
+
+# --------------------------------------------------------------------------
+# repeat-rich genomes (the stress workload of bench.py --workload repeats)
+# --------------------------------------------------------------------------
+def repeat_rich_edit(seed: int, frac: float = 0.08, families: int = 50, fam_len=(300, 3000), divergence=(0.01, 0.03),
+                     p_inverted: float = 0.25, p_tandem: float = 0.15):
+    """A ``base_edit`` for make_haplotypes: about ``frac`` of the genome is overwritten with copies of ``families`` repeat
+    families (consensus of fam_len bases, every copy with its own 1-3 % of substitutions), a quarter of the copies reverse
+    complemented (inverted repeats: hairpins when two lie close), some as tandem arrays of a 20-200 bp unit (cycles).  What a
+    random genome lacks: traversals that do not close for thousands of unitigs, components of thousands of commit records."""
+    def edit(base: np.ndarray) -> np.ndarray:
+        rng = np.random.default_rng(seed)
+        L = len(base)
+        out = base.copy()
+        cons = [rng.integers(0, 4, size=int(rng.integers(fam_len[0], fam_len[1] + 1)), dtype=np.uint8) for _ in range(families)]
+        target, placed = int(frac * L), 0
+        while placed < target:
+            copy = cons[int(rng.integers(0, families))].copy()
+            hit = rng.random(len(copy)) < rng.uniform(*divergence)
+            copy[hit] = (copy[hit] + rng.integers(1, 4, size=int(hit.sum())).astype(np.uint8)) & 3
+            kind = rng.random()
+            if kind < p_inverted:
+                copy = (3 - copy)[::-1].copy()
+            elif kind < p_inverted + p_tandem:
+                copy = np.tile(copy[: int(rng.integers(20, 201))], int(rng.integers(2, 7)))
+            if len(copy) + 4000 >= L:
+                break
+            at = int(rng.integers(2000, L - len(copy) - 2000))
+            out[at: at + len(copy)] = copy
+            placed += len(copy)
+        return out
+    return edit

@@ -32,6 +32,22 @@ def test_cli_outputs_match_reference(case, tmp_path):
         assert line.strip() in r.stdout.replace("\r", ""), line
 
 
+@pytest.mark.parametrize("case", ["hex30k", "k31_z16", "giant7k"])
+def test_alignseq_written_as_text_on_the_device_gives_the_same(case, tmp_path):
+    """alignseq.txt leaves the device packed by default (csrc/pf_alnpack.hpp: a header per bubble, rows at 3 bits per character)
+    and becomes text in the host's writer; PF_ALIGNSEQ_ASCII=1 keeps the device writing the rows itself.  Small pieces too, so that
+    pieces end inside index groups."""
+    meta = load_case(case)
+    for env in ({"PF_ALIGNSEQ_ASCII": "1"}, {"PF_BATCH_BUBBLES": "97"}, {"PF_BATCH_BUBBLES": "64", "PF_ALIGNSEQ_ASCII": "1"}):
+        out = tmp_path / "_".join(env)
+        out.mkdir()
+        r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "4"] + meta["args"], cwd=out, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout
+        bad = compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(out, "PloidyFrost_output"))
+        assert not bad, "%s: files differ from the reference: %s" % (env, bad)
+
+
 @pytest.mark.parametrize("case", ["tet60k", "weird12k", "hex30k"])
 def test_state_after_find_superbubbles_matches_oracle(case, tmp_path):
     meta = load_case(case)

@@ -284,6 +284,20 @@ def test_work_pool(tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
 
 
+def test_packed_alignseq_round_trip(tmp_path):
+    """alignseq.txt leaves the device packed (csrc/pf_alnpack.hpp) and becomes text in the host's writer: the host half on its own,
+    tests/cpp/test_alnpack.cpp (the device half is held to the reference's files by every end-to-end test, both ways: PF_ALIGNSEQ_ASCII)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "test_alnpack")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "ploidyfrost_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "test_alnpack.cpp"), "-o", exe],
+                   check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
+
+
 def test_bench_cov_roofline_picks_the_streaming_kernel_of_the_workload():
     """bench.py `roofline_k_cov`: K-COV for the single-sample workload (with the committed PMC traffic), K-COV-C for the colored."""
     import bench
