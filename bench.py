@@ -266,7 +266,23 @@ def cov_roofline(kernels: dict, colored: bool, n_unitigs: int):
             "traffic_frac": round(tr / (e["avg_ms"] * 1e-3) / 8e12, 4) if tr else None}
 
 
+def make_inputs_child(spec_json: str) -> None:
+    """`bench.py --_make-inputs <json>`: the input generator in a process of its own (see main()); prints one JSON line."""
+    spec = json.loads(spec_json)
+    import torch
+    dev = torch.device("cuda", spec["gpu"]) if torch.cuda.is_available() else torch.device("cpu")
+    if spec["workload"] == "colored":
+        gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(spec["workdir"], "graph", spec["genome"], spec["seed"], dev, samples=3)
+        out = {"gfa": gfa, "colors": colors, "dbs": dbs, "n_unitigs": n_unitigs, "n_kmers": n_kmers}
+    else:
+        gfa, db, n_unitigs, n_kmers = make_inputs(spec["workdir"], "graph", spec["genome"], spec["seed"], dev, repeats=spec["workload"] == "repeats")
+        out = {"gfa": gfa, "db": db, "n_unitigs": n_unitigs, "n_kmers": n_kmers}
+    print(json.dumps(out), flush=True)
+
+
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--_make-inputs":
+        return make_inputs_child(sys.argv[2])
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -335,13 +351,21 @@ def main():
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
         strong = args.scaling == "strong" and world > 1
         seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + (0 if strong else rank)
+        # The inputs are made by a CHILD process (this file with --_make-inputs; it uses this rank's GPU for the graph construction and
+        # exits): the generator's tens of GB of device memory are gone with it.  Made in this process they were handed back by
+        # torch.cuda.empty_cache() just before the load was timed, and on some boxes the first allocations of the load then waited two
+        # seconds for the driver to reclaim them -- time of the generator's, booked on the product's load_s.
+        gen = subprocess.run([sys.executable, os.path.abspath(__file__), "--_make-inputs", json.dumps(
+            {"workdir": workdir, "genome": genome, "seed": seed, "gpu": gpu_index, "workload": args.workload})], stdout=subprocess.PIPE, text=True)
+        if gen.returncode != 0:
+            raise SystemExit("bench.py: the input generator failed")
+        made = json.loads(gen.stdout.strip().splitlines()[-1])
         if colored:
             n_samples = 3
-            gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(workdir, "graph", genome, seed, dev, samples=n_samples)
+            gfa, colors, dbs, n_unitigs, n_kmers = made["gfa"], made["colors"], made["dbs"], made["n_unitigs"], made["n_kmers"]
             cutoffs = [(LOWER, UPPER)] * n_samples
         else:
-            gfa, db, n_unitigs, n_kmers = make_inputs(workdir, "graph", genome, seed, dev, repeats=args.workload == "repeats")
-        torch.cuda.empty_cache()
+            gfa, db, n_unitigs, n_kmers = made["gfa"], made["db"], made["n_unitigs"], made["n_kmers"]
         hostapi.load_trace(reset=True)
         t0 = time.time()
         if colored:

@@ -2601,10 +2601,11 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
             uint32_t acc = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const int st_ = FMT_STAGED_STREAM[q];
+                // (alignseq's stage holds the wavefront's packed records instead of its text when the stream leaves packed)
+                const int st_ = (q == 0 && a.packed) ? S_PACK : FMT_STAGED_STREAM[q];
                 span0[q] = a.offs[st_ * stride + w_first];
                 span_len[q] = (uint32_t)(a.offs[st_ * stride + w_end] - span0[q]);
-                staged[q] = span_len[q] <= FMT_STAGE[q] && !(q == 0 && a.packed);
+                staged[q] = span_len[q] <= FMT_STAGE[q];
                 stage[q] = base + acc;
                 acc += FMT_STAGE[q];
             }
@@ -2622,7 +2623,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                 s_fre[x].p = a.out[2 + x] + (a.offs[(2 + x) * stride + jj] - a.offs[(2 + x) * stride]);
                 s_cov[x].p = a.out[6 + x] + (a.offs[(6 + x) * stride + jj] - a.offs[(6 + x) * stride]);
             }
-            if (staged[0]) s_aln.p = stage[0] + (a.offs[1 * stride + jj] - span0[0]);
+            if (staged[0] && !a.packed) s_aln.p = stage[0] + (a.offs[1 * stride + jj] - span0[0]);
             if (staged[1]) s_all.p = stage[1] + (a.offs[0 * stride + jj] - span0[1]);
             if (staged[2]) s_fre[0].p = stage[2] + (a.offs[2 * stride + jj] - span0[2]);
             if (staged[3]) s_cov[0].p = stage[3] + (a.offs[6 * stride + jj] - span0[3]);
@@ -2637,7 +2638,8 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
             const uint32_t fre_n0[4] = {s_fre[0].n, s_fre[1].n, s_fre[2].n, s_fre[3].n};
             if (W && a.packed) {
                 // alignseq, packed: this lane writes its bubble's header; the rows are packed by the whole wavefront further down
-                char *rec = a.out[S_PACK] + alnpack_index_bytes(a.nb) + (a.offs[(size_t)S_PACK * stride + jj] - a.offs[(size_t)S_PACK * stride]);
+                char *rec = staged[0] ? stage[0] + (a.offs[(size_t)S_PACK * stride + jj] - span0[0])
+                                      : a.out[S_PACK] + alnpack_index_bytes(a.nb) + (a.offs[(size_t)S_PACK * stride + jj] - a.offs[(size_t)S_PACK * stride]);
                 const uint64_t vc64 = my_vc;
                 const uint32_t h[4] = {t.u + 1, (t.exit_ov >> 1) + 1, L, R | (t.strict ? 0x80000000u : 0u)};
                 __builtin_memcpy(rec, &vc64, 8);
@@ -2855,16 +2857,19 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                 char *dst = reinterpret_cast<char *>((uintptr_t)(((uint64_t)read_lane((uint32_t)(d64 >> 32), b) << 32) | read_lane((uint32_t)d64, b)));
                 const char *src = reinterpret_cast<const char *>((uintptr_t)(((uint64_t)read_lane((uint32_t)(s64 >> 32), b) << 32) | read_lane((uint32_t)s64, b)));
                 if (a.packed) {
-                    // eight characters = three bytes, a lane per group of eight (pf_alnpack.hpp)
-                    const uint32_t rb = alnpack_row_bytes(Lb), n8 = (Lb + 7) >> 3;
+                    // eight characters = three bytes (pf_alnpack.hpp).  A lane per character: consecutive lanes read consecutive bytes
+                    // of the row, the eight lanes of a group OR their 3-bit codes together (three exchanges), and the first three
+                    // lanes of the group store one byte each -- into the LDS stage when the wavefront's records fit it
+                    const uint32_t rb = alnpack_row_bytes(Lb);
                     for (uint32_t p = 0; p < Rb; ++p)
-                        for (uint32_t x = (uint32_t)lane; x < n8; x += WAVE) {
-                            const char *c = src + (size_t)p * Lb + 8 * (size_t)x;
-                            const uint32_t m = Lb - 8 * x < 8 ? Lb - 8 * x : 8;
-                            uint32_t v = 0;
-                            for (uint32_t i = 0; i < m; ++i) v |= alnpack_code(c[i]) << (3 * i);
-                            char *d = dst + (size_t)p * rb + 3 * (size_t)x;
-                            d[0] = (char)v; d[1] = (char)(v >> 8); d[2] = (char)(v >> 16);
+                        for (uint32_t x0 = 0; x0 < Lb; x0 += WAVE) {
+                            const uint32_t x = x0 + (uint32_t)lane;
+                            uint32_t v = x < Lb ? alnpack_code(src[(size_t)p * Lb + x]) << (3 * (lane & 7)) : 0u;
+                            v |= (uint32_t)__shfl_xor((int)v, 1, WAVE);
+                            v |= (uint32_t)__shfl_xor((int)v, 2, WAVE);
+                            v |= (uint32_t)__shfl_xor((int)v, 4, WAVE);
+                            const uint32_t g = x >> 3, byte = (uint32_t)lane & 7;
+                            if (byte < 3 && (g << 3) < Lb) dst[(size_t)p * rb + 3 * (size_t)g + byte] = (char)(v >> (8 * byte));
                         }
                     continue;
                 }
@@ -2894,8 +2899,9 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             if (!staged[q]) continue;
-            const int st_ = FMT_STAGED_STREAM[q];
-            char *dst = a.out[st_] + (span0[q] - a.offs[st_ * stride]);
+            const bool pk = q == 0 && a.packed;
+            const int st_ = pk ? S_PACK : FMT_STAGED_STREAM[q];
+            char *dst = a.out[st_] + (pk ? alnpack_index_bytes(a.nb) : 0) + (span0[q] - a.offs[st_ * stride]);
             // four bytes per lane and step (the stage is word-aligned in LDS; the span lies where it lies in the stream: global
             // memory takes the unaligned word), the last one to three bytes singly
             const uint32_t n_words = span_len[q] >> 2;

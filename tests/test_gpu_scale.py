@@ -114,3 +114,36 @@ def test_100k_unitig_three_colour_graph_matches_the_reference(tmp_path):
         run.ploidy_estimation("x", [(5, 1000)] * len(dbs))
         assert not _same(want, os.path.join(work, "gpu"), "x"), (kind, rep)
     run.close()
+
+
+def test_150k_unitig_repeat_rich_graph_matches_the_reference(tmp_path):
+    """bench.py --workload repeats at test size: 50 repeat families, inverted copies and tandem arrays on 8 % of the genome -- hundreds
+    of traversals that outgrow the device tiers and are walked on host cores, commit components of thousands of records, cycles and
+    hairpins at every scale -- against the reference binary; device commits and host commits both."""
+    import torch
+    import bench
+    work = str(tmp_path)
+    gfa, db, n_unitigs, n_kmers = bench.make_inputs(work, "g", int(150_000 / bench.UNITIGS_PER_BP), 2024, torch.device("cuda", 0), repeats=True)
+    assert n_unitigs > 100_000
+    common = ["-g", gfa, "-d", db, "-o", "x", "-l", "5", "-u", "1000", "-z", "8"]
+    kind, want = _checker(common, common, os.path.join(work, "cpu"))
+    run = hostapi.Run(gfa, db, z=8)
+    run.set_threads(8)
+    run.set_output_dir(os.path.join(work, "gpu"))
+    run.set_unitig_id("x")
+    for rep in range(2):
+        run.find_superbubbles("x")
+        run.ploidy_estimation("x", 5, 1000)
+        assert not _same(want, os.path.join(work, "gpu"), "x"), (kind, rep)
+    t = run.times()
+    # the host tiers had work: traversals the device gave up on, records committed on a host thread
+    assert t["bfs_deferred"] >= 50 and t["host_walk_vertices"] > 10 * t["bfs_deferred"] and t["host_commit_records"] >= t["bfs_deferred"], t
+    run.close()
+    # the same through the CLI with every long traversal on the device (k_bfs_big / k_bfs_huge) instead of the host walkers
+    out = os.path.join(work, "cli")
+    os.makedirs(out)
+    cli = os.path.join(ROOT, "ploidyfrost_amd", "csrc", "ploidyfrost")
+    r = subprocess.run([cli] + common + ["-t", "8"], cwd=out, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                       env=dict(os.environ, PF_BFS_HUGE_ON_DEVICE="1"))
+    assert r.returncode == 0, r.stdout
+    assert not _same(want, os.path.join(out, "PloidyFrost_output"), "x")
