@@ -521,6 +521,21 @@ int pf_unitig_cov_colored_probe(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *su
 int pf_string_cov_colored(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t n_str, const uint32_t *low,
                           const uint32_t *up, uint64_t *sum, uint8_t *ok);
 
+/* ---- (e) one graph over the GPUs of a node: the exchange step -------------------------------------------------------------
+ * the graph, the CSR and the count table are replicated in every GPU's HBM, every rank (one process per GPU) runs
+ * findSuperBubble and the owner scan, and rank r aligns, formats and writes its contiguous slice of the bubble list.  What the ranks
+ * must tell each other is small: how many bubbles each of them called (var_count numbers bubbles across the whole run, src/CDBG.cpp:
+ * 1254-1258), then the sizes of their ten text slabs with their allele histograms and coverage counters -- two all-gathers of a few
+ * 64-bit words, over RCCL (xGMI between the GPUs).  No payload crosses ranks.
+ * pf_comm_unique_id: called by one rank, the 128 bytes reach the others by any means (the CLI: a socket pair made before fork);
+ * pf_comm_init: every rank, on its context (= its GPU); collective.  librccl is loaded here, not at start-up.
+ * pf_gather: all[r * n + i] = word i of rank r, n <= 64, host pointers; collective. */
+#define PF_COMM_ID_BYTES 128
+int pf_comm_unique_id(unsigned char id[PF_COMM_ID_BYTES]);
+int pf_comm_init(pf_ctx *, const unsigned char id[PF_COMM_ID_BYTES], int rank, int world);
+int pf_gather(pf_ctx *, const uint64_t *mine, uint32_t n, uint64_t *all);
+void pf_comm_destroy(pf_ctx *);
+
 /* ---- `PloidyFrost model`: the Gaussian-mixture fit of the allele frequencies (src/GmmModel.cpp, src/Main.cpp:636-692) ----
  * pf_gmm_upload keeps the values (GmmModel::allele_fre, after the reader's frequency filter) in HBM; pf_gmm_fit is
  * GmmModel::resize(gauss) + emIterate() (src/GmmModel.cpp:8-20, 371-385) on them: means fixed at i/(gauss+1), weights and

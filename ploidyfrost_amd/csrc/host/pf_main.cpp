@@ -29,6 +29,7 @@
 
 #include "pf_cdbg.hpp"
 #include "pf_filter.hpp"
+#include "pf_multi.hpp"
 #include "pf_gmm_model.hpp"
 #include "ploidyfrost_hip.h"
 
@@ -56,6 +57,8 @@ void PrintUsage() {
          << "  -h,             k-mer histogram file (with -f: a list of them): thresholds = cutoffL / cutoffU of it" << endl
          << "  -q,             quantile for the upper threshold derived from -h (default : 0.998 )" << endl
          << "  --ref-threads N N > 1: text format of the reference's `-t N` run (ids from 0, allele_frequency grouped by arity)" << endl
+         << "  --gpus N        one graph over N GPUs of this node (single-sample path): one process per GPU, the bubble list cut into N slices," << endl
+         << "                  two small all-gathers over RCCL, every rank writes its slabs into the shared result files" << endl
          << "  --detach-teardown  return as soon as the result files are complete; a child process gives the device memory back" << endl << endl
          << "Usage: PloidyFrost cutoffL kmer_histogram_file" << endl
          << "Usage: PloidyFrost cutoffU kmer_histogram_file (quantile[<1 ,default:0.998])" << endl << endl
@@ -103,7 +106,7 @@ int cutoffH(const string &file, double frequency = 0.998) {
 
 struct Options {
     string graphfile, colorfile, outprefix = "output", db, coveragefile, hist;
-    size_t nb_threads = 1, complex_size = 8, ref_threads = 1;
+    size_t nb_threads = 1, complex_size = 8, ref_threads = 1, gpus = 1;
     bool verbose = false, info = false, detach_teardown = false;
     int coverage_lower = 10, coverage_upper = 1000, k = 25;
     vector<pair<int, int>> coverage_vec;
@@ -219,6 +222,11 @@ int main(int argc, char **argv) {
             for (int j = i; j + 2 <= argc; ++j) argv[j] = j + 2 < argc ? argv[j + 2] : nullptr;
             argc -= 2;
             --i;
+        } else if (strcmp(argv[i], "--gpus") == 0 && i + 1 < argc) {
+            opt.gpus = (size_t)std::max(1, atoi(argv[i + 1]));
+            for (int j = i; j + 2 <= argc; ++j) argv[j] = j + 2 < argc ? argv[j + 2] : nullptr;
+            argc -= 2;
+            --i;
         } else if (strcmp(argv[i], "--detach-teardown") == 0) {
             opt.detach_teardown = true;
             for (int j = i; j + 1 <= argc; ++j) argv[j] = j + 1 < argc ? argv[j + 1] : nullptr;
@@ -331,6 +339,7 @@ int main(int argc, char **argv) {
     else if (!file_exists(opt.graphfile)) { cerr << "Error: The graph file does not exist." << endl; ok = false; }
     if (!ok) { PrintUsage(); return 0; }
 
+    if (!opt.colorfile.empty() && opt.gpus > 1) { cerr << "Error: --gpus cuts the single-sample path (-g / -d); the colored one runs on one GPU" << endl; return 1; }
     if (!opt.colorfile.empty()) {  // src/Main.cpp:775-810
         pfh::ColoredUnitigSet cdbg;
         auto t0 = std::chrono::steady_clock::now();
@@ -405,9 +414,21 @@ int main(int argc, char **argv) {
             }
         }
     }
+    // --gpus N: the other ranks are forked here, before anything has touched the GPU (pf_multi.hpp); from here on every rank runs the
+    // same program on its own device, rank 0 speaks
+    pfh::RankGroup ranks;
+    if (opt.gpus > 1) {
+        if (opt.ref_threads > 1) { cerr << "Error: --gpus and --ref-threads do not go together" << endl; return 1; }
+        cout.flush();
+        fflush(nullptr);
+        if (!ranks.start((int)opt.gpus)) { cerr << "Error: --gpus " << opt.gpus << ": " << ranks.err << endl; return 1; }
+        if (ranks.rank != 0) {   // the other ranks say nothing
+            if (!freopen("/dev/null", "w", stdout)) {}
+        }
+    }
     // the device context and the count table are built on a helper thread while the graph file is read
     pfh::CountsLoader counts;
-    counts.start(0, opt.db);
+    counts.start(ranks.device(), opt.db);
     pfh::UnitigSet graph;
     std::string err;
     auto t0 = std::chrono::steady_clock::now();
@@ -432,7 +453,7 @@ int main(int argc, char **argv) {
 
     // (on the heap and never destroyed: at the end of main the process leaves through quick_exit -- giving 12 GB of device and
     // pinned memory back piece by piece takes longer than some of the phases)
-    pfh::CDBG &g = *new pfh::CDBG(graph, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db, 0, false, &counts);
+    pfh::CDBG &g = *new pfh::CDBG(graph, opt.complex_size, opt.match, opt.mismatch, opt.gap, opt.db, ranks.device(), false, &counts);
     mark("graph + counts on the device");
     auto die = [&]() {
         cerr << g.error() << endl;
@@ -452,6 +473,67 @@ int main(int argc, char **argv) {
     g.set_overlap_output(true);
     if (opt.ref_threads > 1 && g.set_reference_threads(opt.ref_threads)) die();
     if (getenv("PF_BFS_HUGE_ON_DEVICE")) g.set_third_tier_on_host(false);   // experiments: giant traversals on one wavefront each
+    if (ranks.world > 1) {
+        // ---- one graph over the GPUs of the node (the protocol of ploidyfrost_amd/dist.py from the C++ side) ----
+        auto leave = [&](const std::string &why) {
+            cerr << "rank " << ranks.rank << ": " << why << endl;
+            cerr.flush();
+            _exit(EXIT_FAILURE);   // (the others see a closed socket or a failed collective and leave as well)
+        };
+        if (!ranks.connect(g.device())) leave("--gpus: " + ranks.err);
+        mark("communicator");
+        g.set_write_super_bubble(ranks.rank == 0);
+        if (ranks.rank == 0) {
+            if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) leave(g.error());
+            if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) leave(g.error());
+        }
+        if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) leave(g.error());   // every rank: the same state everywhere
+        mark("findSuperBubble");
+        cout << "CDBG:: Minimum Coverage:" << opt.coverage_lower << endl;
+        cout << "CDBG:: Maximum Coverage:" << opt.coverage_upper << endl;
+        const auto tp0 = std::chrono::steady_clock::now();
+        cout << "CDBG::PloidyEstimation():  Analyzing superbubbles to generate sites' information" << endl;
+        uint64_t nb = 0;
+        if (g.ploidy_select(opt.coverage_lower, opt.coverage_upper, nb)) leave(g.error());
+        const uint64_t W = (uint64_t)ranks.world, R = (uint64_t)ranks.rank;
+        const uint64_t t0b = nb / W * R + std::min<uint64_t>(R, nb % W), t1b = t0b + nb / W + (R < nb % W ? 1 : 0);
+        uint64_t called = 0;
+        if (g.ploidy_align(t0b, t1b, called)) leave(g.error());
+        std::vector<uint64_t> all((size_t)W * 18);
+        if (!ranks.gather(g.device(), &called, 1, all.data())) leave("--gpus: " + ranks.err);
+        uint64_t base = 0;
+        for (uint64_t r = 0; r < R; ++r) base += all[r];
+        uint64_t mine[18];
+        if (g.ploidy_text(base, mine, mine + PF_CALL_STREAMS)) leave(g.error());
+        if (!ranks.gather(g.device(), mine, 18, all.data())) leave("--gpus: " + ranks.err);
+        uint64_t offsets[PF_CALL_STREAMS] = {}, totals[PF_CALL_STREAMS] = {}, sums[8] = {};
+        for (uint64_t r = 0; r < W; ++r) {
+            for (int s_ = 0; s_ < PF_CALL_STREAMS; ++s_) {
+                if (r < R) offsets[s_] += all[r * 18 + (uint64_t)s_];
+                totals[s_] += all[r * 18 + (uint64_t)s_];
+            }
+            for (int c = 0; c < 8; ++c) sums[c] += all[r * 18 + PF_CALL_STREAMS + (uint64_t)c];
+        }
+        if (g.ploidy_write(opt.outprefix, offsets, totals, true)) leave(g.error());
+        uint64_t done = 1;   // nobody returns before everybody's slabs are in the files
+        if (!ranks.gather(g.device(), &done, 1, all.data())) leave("--gpus: " + ranks.err);
+        mark("PloidyEstimation");
+        if (ranks.rank != 0) {
+            fflush(nullptr);
+            _exit(0);
+        }
+        printf("CDBG::PloidyEstimation():  Real time : %gs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - tp0).count());
+        printf("CDBG::PloidyEstimation(): Alleles in SuperBubbles  :\t2 :%llu\t3 :%llu\t4 :%llu\t5 :%llu\n", (unsigned long long)sums[0],
+               (unsigned long long)sums[1], (unsigned long long)sums[2], (unsigned long long)sums[3]);
+        if (sums[5]) printf("CDBG::PloidyEstimation(): Sites' Average Coverage:%d\n", (int)(sums[4] / sums[5]));
+        if (opt.verbose) printf("[ranks]  %d ranks, %llu bubbles in the list, %llu called; this rank's slice %llu .. %llu\n", ranks.world, (unsigned long long)nb,
+                                (unsigned long long)sums[6], (unsigned long long)t0b, (unsigned long long)t1b);
+        cout.flush();
+        fflush(nullptr);
+        const int rc = ranks.finish();
+        if (rc) { cerr << "a rank ended with status " << rc << endl; _exit(rc); }
+        _exit(0);
+    }
     if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) die();
     if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) die();
     mark("setUnitigId");

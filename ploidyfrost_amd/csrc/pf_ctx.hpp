@@ -105,6 +105,7 @@ struct pf_ctx {
     // K-BFS call as they lie in the workspace
     void *cc = nullptr;
     void *gfa = nullptr;   // K-GFA (pf_gfa.hip): segment table of the last pf_gfa_ingest until pf_gfa_segments fetches it
+    void *comm = nullptr;  // pf_gather.hip: this rank's RCCL communicator and its two small device buffers
     const void *cc_rec = nullptr;
     const uint32_t *cc_pool = nullptr;
     const pf_bfs_record *bfs_last_rec = nullptr;
@@ -165,6 +166,7 @@ void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
 void call_destroy(pf_ctx *ctx);     // pf_call.hip
 void cc_destroy(pf_ctx *ctx);       // pf_cc.hip
 void gfa_destroy(pf_ctx *ctx);      // pf_gfa.hip
+void comm_destroy(pf_ctx *ctx);     // pf_gather.hip
 void call_invalidate(pf_ctx *ctx);  // graph or count table replaced
 int call_state_arrays(pf_ctx *ctx, uint8_t **flags, uint32_t **plus, uint32_t **minus);   // pf_call.hip: T1 state arrays for a device-side writer
 void call_state_resident(pf_ctx *ctx);

@@ -832,6 +832,7 @@ void pf_destroy(pf_ctx *ctx) {
     call_destroy(ctx);
     cc_destroy(ctx);
     gfa_destroy(ctx);
+    comm_destroy(ctx);
     free_graph(ctx);
     hipFree(ctx->d_tab);
     hipFree(ctx->d_ctab);

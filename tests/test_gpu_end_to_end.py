@@ -48,6 +48,37 @@ def test_alignseq_written_as_text_on_the_device_gives_the_same(case, tmp_path):
         assert not bad, "%s: files differ from the reference: %s" % (env, bad)
 
 
+@pytest.mark.parametrize("case,world", [("tet60k", 2), ("hex30k", 3), ("giant7k", 2), ("stranded20k", 4)])
+def test_cli_cuts_one_graph_over_ranks(case, world, tmp_path):
+    """`ploidyfrost --gpus N` (csrc/host/pf_multi.hpp): N processes forked before anything touches the GPU, every rank the whole
+    graph, rank r its slice of the bubble list, two small all-gathers, every rank's slabs straight into the shared files.  On this
+    one-GPU box the ranks share the device (PF_SHARE_GPU=1: the words then travel over the socket pairs instead of RCCL, which refuses
+    two ranks on one device); the files must be the reference's, the summary lines rank 0's."""
+    meta = load_case(case)
+    r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "2", "--gpus", str(world), "-v"] + meta["args"], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, PF_SHARE_GPU="1"), timeout=600)
+    assert r.returncode == 0, r.stdout
+    bad = compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(tmp_path, "PloidyFrost_output"))
+    assert not bad, "files differ from the reference: %s\n%s" % (bad, r.stdout)
+    for line in meta["reference_log"]:
+        assert line.strip() in r.stdout.replace("\r", ""), line
+    assert "[ranks]  %d ranks" % world in r.stdout
+
+
+def test_cli_ranks_end_together_when_one_fails(tmp_path):
+    """a k-mer of the graph that is in no database ends the reference's run (src/CDBG.cpp:92-96): every rank of a cut run leaves, rank 0
+    with a non-zero status"""
+    from ploidyfrost_amd import synth
+    meta = load_case("dip20k")
+    kmers, counts, km = synth.read_kmc(meta["db"])
+    keep = np.ones(len(kmers), dtype=bool)
+    keep[::3] = False
+    synth.write_kmc1(str(tmp_path / "holes"), kmers[keep], counts[keep], km["k"])
+    r = subprocess.run([CLI, "-g", meta["gfa"], "-d", str(tmp_path / "holes"), "-o", "g", "-l", "5", "--gpus", "2"], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, PF_SHARE_GPU="1"), timeout=300)
+    assert r.returncode != 0 and "can not found" in r.stdout
+
+
 @pytest.mark.parametrize("case", ["tet60k", "weird12k", "hex30k"])
 def test_state_after_find_superbubbles_matches_oracle(case, tmp_path):
     meta = load_case(case)
