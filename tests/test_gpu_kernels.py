@@ -504,3 +504,26 @@ def test_database_without_canonical_counting_is_read_per_orientation():
         dev._check(dev.L.pf_unitig_cov(dev.h, 0, dev.n, s0.ctypes.data, m0.ctypes.data, x0.ctypes.data))
     ssum, ok, smiss = dev.string_cov([seqs[0][:40], seqs[1][:30]], 5, 1000)
     assert list(ssum) == [0, 0] and list(ok) == [1, 1] and not smiss.any()
+
+
+def test_gather_over_rccl_with_one_rank():
+    """pf_comm_unique_id / pf_comm_init / pf_gather (csrc/pf_gather.hip): the exchange step of a graph cut over GPUs -- an all-gather of
+    a few 64-bit words over RCCL, librccl loaded on first use.  One rank is all a one-GPU box allows (RCCL refuses two ranks on a
+    device; the N-rank protocol itself is run by test_cli_cuts_one_graph_over_ranks over socket pairs and by tests/test_dist_cpu.py
+    over gloo): the communicator is made, the collective runs on the context's stream, the words come back."""
+    import ctypes as C
+    L = hipapi.load_library()
+    dev = hipapi.Device(0)
+    ident = (C.c_ubyte * 128)()
+    assert L.pf_comm_unique_id(ident) == 0
+    assert any(ident)
+    assert L.pf_comm_init(dev.h, ident, 0, 1) == 0, L.pf_last_error(dev.h)
+    mine = np.arange(18, dtype=np.uint64) * np.uint64(0x0123456789) + np.uint64(7)
+    got = np.zeros(18, dtype=np.uint64)
+    for _ in range(3):
+        assert L.pf_gather(dev.h, mine.ctypes.data, 18, got.ctypes.data) == 0, L.pf_last_error(dev.h)
+        assert np.array_equal(got, mine)
+    assert L.pf_gather(dev.h, mine.ctypes.data, 65, got.ctypes.data) != 0   # at most 64 words per call
+    L.pf_comm_destroy(dev.h)
+    assert L.pf_gather(dev.h, mine.ctypes.data, 18, got.ctypes.data) != 0   # no communicator any more
+    dev.close()
