@@ -295,6 +295,8 @@ def main():
     ap.add_argument("--cpu-runs", type=int, default=3)
     ap.add_argument("--host-threads", type=int, default=0, help="host threads per rank (0 = min(32, cpus/ranks))")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gen-in-process", action="store_true",
+                    help="make the inputs in this process instead of a child (for runs under rocprofv3, which must not have children)")
     ap.add_argument("--keep", action="store_true")
     ap.add_argument("--no-verify", action="store_true", help="N > 1: skip the comparison of the shared result files with a pass of rank 0 alone")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="strong",
@@ -322,44 +324,57 @@ def main():
         log("--gpus %d without WORLD_SIZE: launching %s" % (args.gpus, " ".join(cmd)))
         sys.exit(subprocess.run(cmd).returncode)
 
-    import torch
-    import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: one rank per GPU (launch with --nproc-per-node %d, or without a launcher)"
                          % (args.gpus, world, args.gpus))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     # PF_BENCH_SHARE_GPU=1 (debugging on a one-GPU box only): every rank uses GPU 0 and the end-of-pass
     # exchange runs over gloo on CPU tensors, because RCCL refuses two ranks on one device.
     share = os.environ.get("PF_BENCH_SHARE_GPU") == "1"
     gpu_index = 0 if share else local_rank
+    workdir = tempfile.mkdtemp(prefix="pf_bench_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
+    genome = int(args.unitigs / UNITIGS_PER_BP)
+    colored = args.workload == "colored"
+    strong = args.scaling == "strong" and world > 1
+    seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + (0 if strong else rank)
+    made = None
+    if not args.gen_in_process:
+        # The inputs are made by a CHILD process (this file with --_make-inputs; it uses this rank's GPU for the graph construction and
+        # exits), started before this process has touched the GPU: the generator's tens of GB of device memory are gone with it.  Made
+        # in this process they were handed back by torch.cuda.empty_cache() just before the load was timed, and on some boxes the first
+        # allocations of the load then waited two seconds for the driver to reclaim them -- time of the generator's, booked on the
+        # product's load_s.  (--gen-in-process: under a profiler, whose preloaded library forbids children.)
+        gen = subprocess.run([sys.executable, os.path.abspath(__file__), "--_make-inputs", json.dumps(
+            {"workdir": workdir, "genome": genome, "seed": seed, "gpu": gpu_index, "workload": args.workload})], stdout=subprocess.PIPE, text=True)
+        if gen.returncode != 0:
+            shutil.rmtree(workdir, ignore_errors=True)
+            raise SystemExit("bench.py: the input generator failed")
+        made = json.loads(gen.stdout.strip().splitlines()[-1])
+
+    import torch
+    import torch.distributed as dist
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the hot path has no CPU fallback")
     torch.cuda.set_device(gpu_index)
     dev = torch.device("cuda", gpu_index)
     from ploidyfrost_amd import dist as pfdist
     from ploidyfrost_amd import hipapi, hostapi
     pfdist.init("gloo" if share else "nccl", None if share else dev)
     xdev = torch.device("cpu") if share else dev  # where the collectives' tensors live
-    workdir = tempfile.mkdtemp(prefix="pf_bench_r%d_" % rank, dir="/dev/shm" if os.path.isdir("/dev/shm") else None)
     ok = False
     bad_output = False
     try:
-        genome = int(args.unitigs / UNITIGS_PER_BP)
-        colored = args.workload == "colored"
         host_threads = args.host_threads or max(1, min(32, (os.cpu_count() or 1) // max(world, 1)))
-        strong = args.scaling == "strong" and world > 1
-        seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + (0 if strong else rank)
-        # The inputs are made by a CHILD process (this file with --_make-inputs; it uses this rank's GPU for the graph construction and
-        # exits): the generator's tens of GB of device memory are gone with it.  Made in this process they were handed back by
-        # torch.cuda.empty_cache() just before the load was timed, and on some boxes the first allocations of the load then waited two
-        # seconds for the driver to reclaim them -- time of the generator's, booked on the product's load_s.
-        gen = subprocess.run([sys.executable, os.path.abspath(__file__), "--_make-inputs", json.dumps(
-            {"workdir": workdir, "genome": genome, "seed": seed, "gpu": gpu_index, "workload": args.workload})], stdout=subprocess.PIPE, text=True)
-        if gen.returncode != 0:
-            raise SystemExit("bench.py: the input generator failed")
-        made = json.loads(gen.stdout.strip().splitlines()[-1])
+        if made is None:
+            if colored:
+                m_ = make_colored_inputs(workdir, "graph", genome, seed, dev, samples=3)
+                made = {"gfa": m_[0], "colors": m_[1], "dbs": m_[2], "n_unitigs": m_[3], "n_kmers": m_[4]}
+            else:
+                m_ = make_inputs(workdir, "graph", genome, seed, dev, repeats=args.workload == "repeats")
+                made = {"gfa": m_[0], "db": m_[1], "n_unitigs": m_[2], "n_kmers": m_[3]}
+            torch.cuda.empty_cache()
         if colored:
             n_samples = 3
             gfa, colors, dbs, n_unitigs, n_kmers = made["gfa"], made["colors"], made["dbs"], made["n_unitigs"], made["n_kmers"]
