@@ -500,7 +500,10 @@ int pf_call_get_state(pf_ctx *, uint8_t *flags, uint32_t *plus, uint32_t *minus)
  * random access whatever the number of colours.  kmers[c] / counts[c]: n[c] records of colour c (exact
  * k-mers as stored, any order); min_count / max_count / both_strands per colour as in pf_upload_counts.
  * Requires pf_upload_graph first (k).  [host|dev per array] */
-#define PF_MAX_COLORS 62
+#define PF_MAX_COLORS 62          /* colours of the RESIDENT calling pipeline (pf_call_set_colours) and of the commits on the device
+                                     (pf_replay_set_colours): colour sets as one 64-bit mask, a lane per colour in K-SITES */
+#define PF_MAX_COLORS_TABLE 1024  /* colours of the joined table, K-COV-C and K-STRCOV-C: what the host-threaded pipeline needs; graphs of
+                                     more than PF_MAX_COLORS colours run on that one (csrc/host/pf_ccdbg.cpp) */
 int pf_upload_counts_colored(pf_ctx *, uint32_t n_colors, const uint64_t *const *kmers, const uint32_t *const *counts,
                              const uint64_t *n, const uint64_t *min_count, const uint64_t *max_count, const int *both_strands);
 uint32_t pf_num_colors(const pf_ctx *);

@@ -486,7 +486,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         std::vector<std::string> strings;
         std::vector<GroupRef> groups;      // per (branching bubble, site, allele group), in order
         std::vector<uint32_t> first_group;  // per bubble of the chunk: index of its first GroupRef
-        std::vector<uint64_t> mask;         // colored, per string: colours its findUnitig() mapping carries in full
+        std::vector<uint64_t> mask;         // colored, per string: colours its findUnitig() mapping carries in full (CW words per string)
         int err = 0;
     };
     struct Batch {
@@ -670,7 +670,10 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         // first k-mer of a site string lies on one of the bubble's unitigs (each k-mer occurs once in the graph); the
         // mapping is extended along that unitig while the characters agree (CompactedDBG.tcc:3815-3837,
         // CompressedSequence.cpp:497-520).  Returns the mask of colours present on every k-mer of the mapping.
-        auto colours_of_string = [&](const std::string &sx, const uint32_t *ovs, size_t n_ovs, int &err) -> uint64_t {
+        const uint32_t CW = (C + 63) / 64;   // 64-bit words of a colour set
+        auto colours_of_string = [&](const std::string &sx, const uint32_t *ovs, size_t n_ovs, int &err, std::vector<uint64_t> &into) {
+            const size_t at = into.size();
+            into.resize(at + CW, 0);
             std::string rc((size_t)k, 'A');
             for (int i = 0; i < k; ++i) {
                 const char ch = sx[(size_t)k - 1 - i];
@@ -697,13 +700,11 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 } else {
                     continue;
                 }
-                uint64_t m = 0;
                 for (uint32_t c = 0; c < C; ++c)
-                    if (col_->contains(u, c, dist, len)) m |= 1ull << c;
-                return m;
+                    if (col_->contains(u, c, dist, len)) into[at + (c >> 6)] |= 1ull << (c & 63);
+                return;
             }
             err = 2;
-            return 0;
         };
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
             SiteChunk &sc = schunks[ci];
@@ -805,7 +806,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                             if (colored) {
                                 const PathChunk &pc = pchunks[ci];
                                 const uint32_t w0 = pc.walk_first[ti - tb], w1 = pc.walk_first[ti - tb + 1];
-                                sc.mask.push_back(colours_of_string(sx, pc.walk_ovs.data() + w0, w1 - w0, sc.err));
+                                colours_of_string(sx, pc.walk_ovs.data() + w0, w1 - w0, sc.err, sc.mask);
                             }
                         }
                     }
@@ -878,7 +879,8 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             std::string cov_info, fre_info, tail;
             double tc[256];
             std::vector<double> gc;  // colored: [colour][allele group] coverage of the site
-            const uint64_t all_colours = C == 64 ? ~0ull : ((1ull << C) - 1);
+            const uint32_t CW = (C + 63) / 64;
+            std::vector<uint64_t> seen_colours(CW);
             for (size_t ti = tb; ti < te; ++ti) {
                 const Task &t = tasks[ti];
                 const pf_bubble_result &r = result_of(ti);
@@ -933,22 +935,28 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                             coefficient = max_cramer_v(m, C, 4, R);
                         } else {
                             const uint64_t base = chunk_base[ci];
-                            uint64_t seen_colours = 0;
+                            std::fill(seen_colours.begin(), seen_colours.end(), 0);
                             bool ok = true;
                             for (uint32_t gi = 0; gi < maxnum && ok; ++gi) {
                                 const GroupRef &gr = sc.groups[gcur + gi];
                                 for (uint32_t qi = gr.first; qi < gr.first + gr.count && ok; ++qi) {
-                                    const uint64_t q = base + qi, mask = sc.mask[qi];
+                                    const uint64_t q = base + qi;
+                                    const uint64_t *mask = &sc.mask[(size_t)qi * CW];
                                     for (uint32_t c = 0; c < C; ++c) {
-                                        if (!((mask >> c) & 1)) continue;
-                                        seen_colours |= 1ull << c;
+                                        if (!((mask[c >> 6] >> (c & 63)) & 1)) continue;
+                                        seen_colours[c >> 6] |= 1ull << (c & 63);
                                         if (!str_ok[q * C + c]) { ok = false; break; }
                                         gc[(size_t)c * maxnum + gi] += (double)str_sum[q * C + c] / (double)(str_len[q] - (size_t)k + 1);
                                     }
                                 }
                             }
                             gcur += maxnum;
-                            if (seen_colours != all_colours || !ok) continue;
+                            bool every_colour = true;   // (colour_set.size() == C, src/CCDBG.cpp:3292, 3427)
+                            for (uint32_t x = 0; x < CW; ++x) {
+                                const uint32_t left = C - 64 * x;
+                                every_colour = every_colour && seen_colours[x] == (left >= 64 ? ~0ull : ((1ull << left) - 1));
+                            }
+                            if (!every_colour || !ok) continue;
                             coefficient = max_cramer_v(gc.data(), C, maxnum, maxnum);
                         }
                         tail.clear();

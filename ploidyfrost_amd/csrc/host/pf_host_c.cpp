@@ -361,6 +361,7 @@ uint64_t pfh_colors_check_footprints(const pfh_colors *c, const uint32_t *succ, 
     g.n_colors = c->sets.n_colors;
     g.k = c->graph.k;
     g.len_bp = c->graph.len_bp.data();
+    g.words = c->sets.words;
     g.full_mask = c->sets.full_mask.data();
     g.size_total = c->sets.size_total.data();
     g.n_full_enc = c->sets.n_full_enc.data();

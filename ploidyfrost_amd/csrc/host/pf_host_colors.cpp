@@ -215,8 +215,8 @@ struct PairHash {
 }  // namespace
 
 bool ColorSets::contains(uint32_t u, uint32_t colour, uint32_t dist, uint32_t len) const {
-    if ((full_mask[u] >> colour) & 1) return true;
-    if (!((any_mask[u] >> colour) & 1)) return false;
+    if (full(u, colour)) return true;
+    if (!any(u, colour)) return false;
     auto it = partial.find(u);
     if (it == partial.end()) return false;
     for (const Partial &p : it->second) {
@@ -276,8 +276,9 @@ bool ColorSets::load(const std::string &path, const UnitigSet &g, unsigned threa
     }
     const uint32_t N = g.n();
     if (g.da_tag.size() != N) { err = "ColoredCDBG::read(): One sequence line in GFA file has no DataAccessor tag. Operation aborted."; return false; }
-    full_mask.assign(N, 0);
-    any_mask.assign(N, 0);
+    words = (n_colors + 63) / 64;
+    full_mask.assign((size_t)N * words, 0);
+    any_mask.assign((size_t)N * words, 0);
     size_total.assign(N, 0);
     n_full_enc.assign(N, 0);
     partial.clear();
@@ -331,14 +332,14 @@ bool ColorSets::load(const std::string &path, const UnitigSet &g, unsigned threa
                 }
             }
             if (bad) { fail("colour set refers to a (colour, k-mer) pair outside the unitig: wrong slot or damaged file"); return; }
-            uint64_t fm = 0, am = 0;
+            uint64_t *fm = &full_mask[u * words], *am = &any_mask[u * words];   // (this thread's unitigs only)
             std::vector<Partial> parts;
             for (uint32_t c = 0; c < n_colors; ++c) {
                 total += cnt[c];
                 if (cnt[c] > km) { bad = true; break; }
-                if (cnt[c] == km) { fm |= 1ull << c; am |= 1ull << c; }
+                if (cnt[c] == km) { fm[c >> 6] |= 1ull << (c & 63); am[c >> 6] |= 1ull << (c & 63); }
                 else if (cnt[c]) {
-                    am |= 1ull << c;
+                    am[c >> 6] |= 1ull << (c & 63);
                     Partial p;
                     p.colour = c;
                     p.bits.assign((km + 63) / 64, 0);
@@ -350,8 +351,6 @@ bool ColorSets::load(const std::string &path, const UnitigSet &g, unsigned threa
                 }
             }
             if (bad) { fail("colour set counts a colour more than once per k-mer"); return; }
-            full_mask[u] = fm;
-            any_mask[u] = am;
             size_total[u] = total;
             n_full_enc[u] = d.pair_form ? (uint32_t)nf : 0;
             if (!parts.empty()) {

@@ -24,23 +24,31 @@ struct ColorSets {
     uint32_t n_colors = 0;
     std::vector<std::string> names;
     // per unitig (graph id order)
-    std::vector<uint64_t> full_mask;   // bit c: colour c on every k-mer
-    std::vector<uint64_t> any_mask;    // bit c: colour c on at least one k-mer
+    uint32_t words = 1;                // 64-bit words per unitig in the two masks below: (n_colors + 63) / 64
+    std::vector<uint64_t> full_mask;   // [u * words + c / 64] bit c % 64: colour c on every k-mer
+    std::vector<uint64_t> any_mask;    // ... colour c on at least one k-mer
     std::vector<uint64_t> size_total;  // UnitigColors::size(um) with the unitig's own mapping
     std::vector<uint32_t> n_full_enc;  // colours the file's encoding stores as "full" (the pair form); see size_with
     // colours present on part of a unitig: one bit per k-mer, reference orientation
     struct Partial { uint32_t colour; std::vector<uint64_t> bits; };
     std::unordered_map<uint32_t, std::vector<Partial>> partial;
 
-    static constexpr uint32_t kMaxColors = 64;
+    // (the joined count table of the device holds as many, PF_MAX_COLORS_TABLE; graphs of more than 62 colours are called by the
+    // host-threaded pipeline and committed on host threads: the resident pipeline keeps a colour set in one 64-bit register)
+    static constexpr uint32_t kMaxColors = 1024;
 
     // threads: worker threads for decoding (the result does not depend on it)
     bool load(const std::string &path, const UnitigSet &g, unsigned threads, std::string &err);
 
     // UnitigColors::contains(um, colour): colour on every k-mer of [dist, dist + len)
     bool contains(uint32_t u, uint32_t colour, uint32_t dist, uint32_t len) const;
-    bool full(uint32_t u, uint32_t colour) const { return (full_mask[u] >> colour) & 1; }
-    uint32_t n_full(uint32_t u) const { return (uint32_t)__builtin_popcountll(full_mask[u]); }
+    bool full(uint32_t u, uint32_t colour) const { return (full_mask[(size_t)u * words + (colour >> 6)] >> (colour & 63)) & 1; }
+    bool any(uint32_t u, uint32_t colour) const { return (any_mask[(size_t)u * words + (colour >> 6)] >> (colour & 63)) & 1; }
+    uint32_t n_full(uint32_t u) const {
+        uint32_t n = 0;
+        for (uint32_t w = 0; w < words; ++w) n += (uint32_t)__builtin_popcountll(full_mask[(size_t)u * words + w]);
+        return n;
+    }
     // UnitigColors::size(um) of unitig u's set evaluated with a mapping of km_of k-mers: only the pair
     // encoding looks at the mapping (ColorSet.cpp:902-907) -- CCDBG.cpp:2552 passes the *entrance's*
     // mapping to the exit's set

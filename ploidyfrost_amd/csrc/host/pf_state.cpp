@@ -22,6 +22,7 @@ ColourGate UnitigState::colour_gate() const {
     cg.n_colors = col->n_colors;
     cg.k = g->k;
     cg.len_bp = g->len_bp.data();
+    cg.words = col->words;
     cg.full_mask = col->full_mask.data();
     cg.size_total = col->size_total.data();
     cg.n_full_enc = col->n_full_enc.data();

@@ -112,7 +112,8 @@ struct ColourGate {
     uint32_t n_colors = 0;
     int k = 0;
     const uint32_t *len_bp = nullptr;       // unitig lengths
-    const uint64_t *full_mask = nullptr;    // bit c: colour c on every k-mer of the unitig
+    uint32_t words = 1;                     // 64-bit words per unitig in full_mask: (n_colors + 63) / 64 (1 on the device: at most 62 colours there)
+    const uint64_t *full_mask = nullptr;    // [u * words + c / 64] bit c % 64: colour c on every k-mer of the unitig
     const uint64_t *size_total = nullptr;   // UnitigColors::size(um) with the unitig's own mapping
     const uint32_t *n_full_enc = nullptr;   // colours the file's pair encoding stores as "full"
     const uint32_t *succ = nullptr;         // CSR rows [2N][4]
@@ -133,17 +134,21 @@ struct ColourGate {
         if (incomplete_entrance(su)) { f = false; a.set_non_super(su); }
         if (incomplete_exit(tu, su)) { f = false; a.set_non_super(tu); }
         if (!f) return false;
-        const uint64_t all = n_colors == 64 ? ~0ull : ((1ull << n_colors) - 1);
         for (uint32_t i = 0; i < r.n_list; ++i) {
             const uint32_t w = list[i];
             if (w == t) continue;
-            // the reference keys its colour lists by unitig id and pre-loads both endpoints with every colour
-            const uint64_t mine = ((w >> 1) == su || (w >> 1) == tu) ? all : full_mask[w >> 1];
-            uint64_t cont = 0;
             const uint32_t *row = &succ[(size_t)w * 4];
-            for (int b = 0; b < 4; ++b)
-                if (row[b] != 0xFFFFFFFFu) cont |= full_mask[row[b] >> 1];
-            if ((cont & mine) != mine) return false;
+            const bool endpoint = (w >> 1) == su || (w >> 1) == tu;
+            for (uint32_t x = 0; x < words; ++x) {
+                // the reference keys its colour lists by unitig id and pre-loads both endpoints with every colour
+                const uint32_t left = n_colors - 64 * x;   // colours of this word
+                const uint64_t all = left >= 64 ? ~0ull : ((1ull << left) - 1);
+                const uint64_t mine = endpoint ? all : full_mask[(size_t)(w >> 1) * words + x];
+                uint64_t cont = 0;
+                for (int b = 0; b < 4; ++b)
+                    if (row[b] != 0xFFFFFFFFu) cont |= full_mask[(size_t)(row[b] >> 1) * words + x];
+                if ((cont & mine) != mine) return false;
+            }
         }
         return true;
     }

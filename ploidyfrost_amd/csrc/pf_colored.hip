@@ -79,7 +79,7 @@ __global__ void k_ctab_two_strands(const uint8_t *base, uint64_t cap, uint32_t s
 // out_*[c * n + (u - u0)], n = u1 - u0.
 __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                      const uint32_t *__restrict__ len, int k, bool one_strand, uint32_t n_colors,
-                                                     uint32_t u0, uint32_t u1, uint64_t unread, uint64_t *__restrict__ out_sum,
+                                                     uint32_t u0, uint32_t u1, const uint8_t *__restrict__ unread, uint64_t *__restrict__ out_sum,
                                                      uint32_t *__restrict__ out_min, uint32_t *__restrict__ out_max,
                                                      uint8_t *__restrict__ out_miss, const uint64_t *__restrict__ kpre,
                                                      uint32_t *__restrict__ gcov, uint64_t g_stride) {
@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256) void k_cov_colored(CTab t, const uint64_t *__r
                     const size_t o = (size_t)(c0 + j) * n + (u - u0);
                     // a colour whose database was written without canonical counting is never looked up: readCovUni returns
                     // (0, true) for it (src/CCDBG.cpp:128, 155) -- sum 0, nothing missing, every count "inside" any cutoffs
-                    const bool skip = (unread >> (c0 + j)) & 1;
+                    const bool skip = unread[c0 + j] != 0;
                     out_sum[o] = skip ? 0 : s;
                     out_min[o] = skip ? MISSING : lo;
                     out_max[o] = skip ? 0 : hi;
@@ -146,7 +146,7 @@ __global__ void k_ccov_init(uint64_t n, uint64_t *__restrict__ out_sum, uint32_t
 }
 
 // K-STRCOV-C: one thread per (string, colour); out_*[i * n_colors + c]
-__global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colors, uint64_t unread, const char *__restrict__ text,
+__global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colors, const uint8_t *__restrict__ unread, const char *__restrict__ text,
                                  const uint64_t *__restrict__ str_off, uint32_t n_str, const uint32_t *__restrict__ low,
                                  const uint32_t *__restrict__ up, uint64_t *__restrict__ out_sum, uint8_t *__restrict__ out_ok) {
     uint64_t id = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -161,7 +161,7 @@ __global__ void k_strcov_colored(CTab t, int k, bool one_strand, uint32_t n_colo
         uint64_t sum = 0;
         uint8_t ok = 1;
         StringWindow win;
-        if ((unread >> c) & 1) {  // readCov(s, low, up, c) without canonical counting: (0, true), no lookup (src/CCDBG.cpp:94, 121)
+        if (unread[c]) {  // readCov(s, low, up, c) without canonical counting: (0, true), no lookup (src/CCDBG.cpp:94, 121)
             out_sum[id] = 0;
             out_ok[id] = 1;
             continue;
@@ -213,7 +213,7 @@ int join_graph_counts_colored(pf_ctx *ctx) {
     const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
     ctx_begin(ctx, PF_K_COV_JOIN);
     k_cov_colored<<<ctx_grid(ctx, (uint64_t)ctx->N * 64, 256, 16), 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand,
-                                                                                        ctx->n_colors, 0, ctx->N, ctx->ctab_unread, nullptr, nullptr,
+                                                                                        ctx->n_colors, 0, ctx->N, ctx->d_unread, nullptr, nullptr,
                                                                                         nullptr, nullptr, ctx->d_kpre, ctx->d_gcov_c, stride);
     ctx_end(ctx);
     PF_HIP(hipGetLastError());
@@ -230,7 +230,7 @@ uint32_t pf_num_colors(const pf_ctx *ctx) { return ctx ? ctx->n_colors : 0; }
 int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *const *kmers, const uint32_t *const *counts,
                              const uint64_t *n, const uint64_t *min_count, const uint64_t *max_count, const int *both_strands) {
     if (!ctx || n_colors == 0 || !kmers || !counts || !n || !min_count || !max_count || !both_strands) return PF_ERR_ARG;
-    if (n_colors > PF_MAX_COLORS) { pf::CtxErr{ctx} = "more colours than the device table holds (PF_MAX_COLORS)"; return PF_ERR_ARG; }
+    if (n_colors > PF_MAX_COLORS_TABLE) { pf::CtxErr{ctx} = "more colours than the device table holds (PF_MAX_COLORS_TABLE)"; return PF_ERR_ARG; }
     uint64_t total = 0, biggest = 0;
     for (uint32_t c = 0; c < n_colors; ++c) {
         if (n[c] && (!kmers[c] || !counts[c])) return PF_ERR_ARG;
@@ -240,14 +240,18 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
     }
     ctx->ctab_unread = 0;
     ctx->ctab_max_count = 0;
+    std::vector<uint8_t> unread(n_colors, 0);
     for (uint32_t c = 0; c < n_colors; ++c) {
-        if (!both_strands[c]) ctx->ctab_unread |= 1ull << c;
+        if (!both_strands[c]) { unread[c] = 1; if (c < 64) ctx->ctab_unread |= 1ull << c; }
         else ctx->ctab_max_count = std::max<uint64_t>(ctx->ctab_max_count, max_count[c]);
     }
     if (ctx->d_gcov_c) { (void)hipFree(ctx->d_gcov_c); ctx->d_gcov_c = nullptr; }
     ctx->gcov_c_valid = false;
     PF_HIP(hipSetDevice(ctx->device));
     if (ctx->d_ctab) { (void)hipFree(ctx->d_ctab); ctx->d_ctab = nullptr; }
+    if (ctx->d_unread) { (void)hipFree(ctx->d_unread); ctx->d_unread = nullptr; }
+    PF_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_unread), n_colors));
+    PF_HIP(hipMemcpy(ctx->d_unread, unread.data(), n_colors, hipMemcpyHostToDevice));
     ctx->n_colors = 0;
     // distinct keys <= total: a capacity above 1.25 * total always leaves empty slots; colours that share most
     // k-mers (samples of one species) end at a load factor near max(n) / cap <= 0.5
@@ -327,7 +331,7 @@ static int unitig_cov_colored_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64
     if (stream) {
         // streaming form (pf_cov_stream.hpp): one grid row per colour over that colour's slice of the coverage SoA
         k_ccov_init<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(n, ds, dlo, dhi, dx);
-        Kc4Args a{ctx->d_gcov_c, ctx->gcov_c_stride, ctx->ctab_unread, ctx->d_khead, ctx->d_krow, u0, u1 - u0, g_range[0], g_range[1],
+        Kc4Args a{ctx->d_gcov_c, ctx->gcov_c_stride, ctx->d_unread, ctx->d_khead, ctx->d_krow, u0, u1 - u0, g_range[0], g_range[1],
                   g_range[0] / 256, (g_range[1] + 255) / 256, ds, dlo, dhi, dx};
         const int rc = launch_cov_stream(ctx, a, ctx->n_colors, ctx->ctab_max_count >= (1ull << 20), true);
         if (rc) return rc;
@@ -335,7 +339,7 @@ static int unitig_cov_colored_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64
         const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
         const int grid = ctx_grid(ctx, (uint64_t)(u1 - u0) * 64, 256, 16);
         k_cov_colored<<<grid, 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand, ctx->n_colors, u0, u1,
-                                                     ctx->ctab_unread, ds, dlo, dhi, dx, nullptr, nullptr, 0);
+                                                     ctx->d_unread, ds, dlo, dhi, dx, nullptr, nullptr, 0);
     }
     ctx_end(ctx);
     if (!dev_out) {
@@ -376,7 +380,7 @@ int pf_string_cov_colored(pf_ctx *ctx, const char *text, const uint64_t *str_off
     PF_HIP(hipMemcpyAsync(dcut + C, up, (size_t)C * 4, hipMemcpyDefault, ctx->stream));
     const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
     ctx_begin(ctx, PF_K_STRCOV_COLORED);
-    k_strcov_colored<<<ctx_grid(ctx, (uint64_t)n_str * C, 256, 8), 256, 0, ctx->stream>>>(t, ctx->k, ctx->ctab_one_strand, C, ctx->ctab_unread, dt, doff, n_str,
+    k_strcov_colored<<<ctx_grid(ctx, (uint64_t)n_str * C, 256, 8), 256, 0, ctx->stream>>>(t, ctx->k, ctx->ctab_one_strand, C, ctx->d_unread, dt, doff, n_str,
                                                                                           dcut, dcut + C, ds, dk);
     ctx_end(ctx);
     PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n_str * C * 8, hipMemcpyDefault, ctx->stream));

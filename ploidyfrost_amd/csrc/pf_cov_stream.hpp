@@ -141,7 +141,8 @@ __device__ inline unsigned long long readlane63<unsigned long long>(unsigned lon
 // what a launch of the streaming kernels works on
 struct Kc4Args {
     const uint32_t *gcov;
-    uint64_t g_stride, unread;      // colored: slice stride of gcov, colours never looked up
+    uint64_t g_stride;              // colored: slice stride of gcov
+    const uint8_t *unread;          // colored: one byte per colour, 1 = never looked up
     const uint64_t *khead;
     const uint32_t *krow;
     uint32_t u0, n_out;
@@ -286,7 +287,7 @@ template <bool WIDE, bool COLORED>
 __global__ __launch_bounds__(256) void k_cov_stream4(Kc4Args a) {
     if (COLORED) {
         const uint32_t colour = blockIdx.y;
-        if ((a.unread >> colour) & 1) return;
+        if (a.unread[colour]) return;
         a.gcov += (uint64_t)colour * a.g_stride;
         a.out_sum += (uint64_t)colour * a.n_out;
         a.out_min += (uint64_t)colour * a.n_out;

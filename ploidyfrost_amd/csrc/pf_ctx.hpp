@@ -79,7 +79,8 @@ struct pf_ctx {
     uint64_t ctab_cap = 0;
     uint32_t ctab_shift = 4, n_colors = 0;
     bool ctab_one_strand = false;
-    uint64_t ctab_unread = 0;   // colours whose database was written without canonical counting: never looked up
+    uint64_t ctab_unread = 0;   // colours whose database was written without canonical counting: never looked up (the first 64 colours: the resident pipeline's)
+    uint8_t *d_unread = nullptr;   // the same per colour, one byte each (any number of colours)
     uint64_t ctab_max_count = 0;  // largest upper count filter among the colours that are looked up
     // colored per-k-mer coverage SoA: colour c's count of graph k-mer g at d_gcov_c[c * gcov_c_stride + g] (K-COV-C-JOIN)
     uint32_t *d_gcov_c = nullptr;

@@ -836,6 +836,7 @@ void pf_destroy(pf_ctx *ctx) {
     free_graph(ctx);
     hipFree(ctx->d_tab);
     hipFree(ctx->d_ctab);
+    hipFree(ctx->d_unread);
     hipFree(ctx->d_cov_sum); hipFree(ctx->d_cov_min); hipFree(ctx->d_cov_miss);
     for (auto &w : ctx->ws) hipFree(w.first);
     if (ctx->h_live) hipHostFree(ctx->h_live);
@@ -1283,7 +1284,7 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
     if (!exact && !probe && ctx->gcov_valid) {
         // streaming form (pf_cov_stream.hpp): four k-mers per lane, windows of KC4_SR super-rows of 256 k-mers.  Earlier forms of
         // this round -- one k-mer per lane with the scan on DPP (0.111 ms) or ds_bpermute (0.123 ms) -- are in profiles/history/r01j_kcov_stream.txt
-        Kc4Args a{ctx->d_gcov, 0, 0, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], g_range[0] / 256, (g_range[1] + 255) / 256,
+        Kc4Args a{ctx->d_gcov, 0, nullptr, ctx->d_khead, ctx->d_krow, u0, n, g_range[0], g_range[1], g_range[0] / 256, (g_range[1] + 255) / 256,
                   ds, dm, nullptr, dx};
         const bool wide = ctx->tab_max_count >= (1ull << 20);  // a window's carry sums up to KC4_SR * 256 counts in the narrow type
         const int rc = launch_cov_stream(ctx, a, 1, wide, false);

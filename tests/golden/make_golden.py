@@ -173,8 +173,26 @@ def col2_weird():
     return [[h0, h1], [g0, h1[200:-150]]]
 
 
+def col100():
+    """One hundred diploid samples (the reference has no colour limit: src/CCDBG.cpp:2759-2853 loops over getNbColors(); the device's
+    resident pipeline keeps a colour set in 64 bits and hands such graphs to the host-threaded one): sample i carries haplotypes i and
+    i + 1 (mod 10) of a ten-haplotype genome, loses a few bases at its ends (colours on part of a unitig), and the last ten samples
+    have a private tail (unitigs that lack most colours)."""
+    haps = synth.make_haplotypes(synth.HapSpec(1300, 10, seed=61, gap_lo=18, gap_hi=110, p_multi=0.05, max_ins=5))
+    rng = np.random.default_rng(6100)
+    samples = []
+    for i in range(100):
+        hs = [haps[i % 10], haps[(i + 1) % 10]]
+        hs = [h[(3 * i + 5 * j) % 37: len(h) - ((7 * i + 3 * j) % 41)] for j, h in enumerate(hs)]
+        if i >= 90:
+            hs = [np.concatenate([h, rng.integers(0, 4, size=90, dtype=np.uint8)]) for h in hs]
+        samples.append(hs)
+    return samples
+
+
 # name: (sample factory -> list of per-sample haplotype lists, k, PloidyFrost args, per-colour cutoffs)
 COLORED_CASES = {
+    "col100": (col100, 25, ["-z", "10"], [(5, 1000)] * 100, set(), 1),
     "col3_dip": (col3_dip, 25, [], [(5, 1000)] * 3),
     "col4_mix": (col4_mix, 25, ["-z", "10"], [(5, 1000), (5, 1000), (25, 70), (5, 1000)]),
     "col2_weird": (col2_weird, 31, ["-M", "1.5", "-D", "-0.5", "-G", "-2.25"], [(5, 1000), (10, 400)]),
@@ -231,6 +249,7 @@ def make_case(name: str) -> None:
 def make_colored_case(name: str) -> None:
     factory, k, args, cutoffs = COLORED_CASES[name][:4]
     stranded = COLORED_CASES[name][4] if len(COLORED_CASES[name]) > 4 else set()
+    lut_p = COLORED_CASES[name][5] if len(COLORED_CASES[name]) > 5 else None   # (a short prefix table keeps a hundred databases small)
     out = os.path.join(HERE, name)
     shutil.rmtree(out, ignore_errors=True)
     os.makedirs(os.path.join(out, "expected"))
@@ -244,9 +263,9 @@ def make_colored_case(name: str) -> None:
             km, mult = synth.canonical_counts(hs, k)
             if i in stranded:
                 skm, scnt = synth.stranded_counts(km, mult, k)
-                synth.write_kmc1(os.path.join(out, "db%d" % i), skm, scnt, k, both_strands=False)
+                synth.write_kmc1(os.path.join(out, "db%d" % i), skm, scnt, k, both_strands=False, p=lut_p)
             else:
-                synth.write_kmc1(os.path.join(out, "db%d" % i), km, synth.synth_counts(km, mult), k)
+                synth.write_kmc1(os.path.join(out, "db%d" % i), km, synth.synth_counts(km, mult), k, p=lut_p)
         with open(os.path.join(tmp, "refs.txt"), "w") as f:
             f.write("".join(p + "\n" for p in fas))
         run([os.path.join(REF, "Bifrost"), "build", "-c", "-r", os.path.join(tmp, "refs.txt"), "-k", str(k), "-o",
