@@ -487,13 +487,14 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         std::vector<GroupRef> groups;      // per (branching bubble, site, allele group), in order
         std::vector<uint32_t> first_group;  // per bubble of the chunk: index of its first GroupRef
         std::vector<uint64_t> mask;         // colored, per string: colours its findUnitig() mapping carries in full (CW words per string)
+        std::vector<uint32_t> nowhere;      // colored: strings (chunk-local index, ascending) whose first k-mer is on no unitig of the bubble
         int err = 0;
     };
     struct Batch {
         size_t batch0 = 0, NT = 0;
         std::vector<SiteChunk> schunks;
         std::vector<uint64_t> chunk_base, str_sum, str_len;
-        std::vector<uint8_t> str_ok;
+        std::vector<uint8_t> str_ok, str_miss;
         uint64_t site_strings = 0;
         double sites_s = 0;
         AlignExchange *ax = nullptr;
@@ -671,7 +672,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         // mapping is extended along that unitig while the characters agree (CompactedDBG.tcc:3815-3837,
         // CompressedSequence.cpp:497-520).  Returns the mask of colours present on every k-mer of the mapping.
         const uint32_t CW = (C + 63) / 64;   // 64-bit words of a colour set
-        auto colours_of_string = [&](const std::string &sx, const uint32_t *ovs, size_t n_ovs, int &err, std::vector<uint64_t> &into) {
+        auto colours_of_string = [&](const std::string &sx, const uint32_t *ovs, size_t n_ovs, int &err, std::vector<uint64_t> &into, std::vector<uint32_t> &nowhere) {
             const size_t at = into.size();
             into.resize(at + CW, 0);
             std::string rc((size_t)k, 'A');
@@ -704,7 +705,10 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                     if (col_->contains(u, c, dist, len)) into[at + (c >> 6)] |= 1ull << (c & 63);
                 return;
             }
-            err = 2;
+            // findUnitig finds nothing: the reference dereferences the empty mapping -- IF it gets to this string.  The walk over a
+            // site's strings ends at the first one out of range (src/CCDBG.cpp:3262-3276), so the verdict is the walker's (consume).
+            (void)err;
+            nowhere.push_back((uint32_t)(at / CW));
         };
         parallel_chunks(NT, PCH, T, [&](size_t ci, size_t tb, size_t te) {
             SiteChunk &sc = schunks[ci];
@@ -806,7 +810,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                             if (colored) {
                                 const PathChunk &pc = pchunks[ci];
                                 const uint32_t w0 = pc.walk_first[ti - tb], w1 = pc.walk_first[ti - tb + 1];
-                                colours_of_string(sx, pc.walk_ovs.data() + w0, w1 - w0, sc.err, sc.mask);
+                                colours_of_string(sx, pc.walk_ovs.data() + w0, w1 - w0, sc.err, sc.mask, sc.nowhere);
                             }
                         }
                     }
@@ -841,8 +845,9 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 st = pf_string_cov(ctx_, text.data(), soff.data(), (uint32_t)n_strings, low, up, str_sum.data(), str_ok.data(),
                                    str_miss.data());
             if (st != PF_OK) { B.err = std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_); return st; }
-            for (size_t i = 0; i < str_miss.size(); ++i)
-                if (str_miss[i]) { B.err = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
+            // (a k-mer that is in no database ends the reference's run inside readCov -- if the walk over the site's strings gets to
+            // that string; it ends at the first string out of range, src/CDBG.cpp:1527-1551: judged in order by consume)
+            B.str_miss.swap(str_miss);
             B.site_strings = n_strings;
         }
         B.sites_s = since(t0);
@@ -859,7 +864,8 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
         const std::vector<uint32_t> &dev_index = B.dev_index;
         const std::vector<SiteChunk> &schunks = B.schunks;
         const std::vector<uint64_t> &chunk_base = B.chunk_base, &str_sum = B.str_sum, &str_len = B.str_len;
-        const std::vector<uint8_t> &str_ok = B.str_ok;
+        const std::vector<uint8_t> &str_ok = B.str_ok, &str_miss = B.str_miss;
+        std::atomic<int> fatal{0};   // 1: a k-mer in no database, 2: a site string on no unitig -- reached by the reference's walk
         auto result_of = [&](size_t ti) -> const pf_bubble_result & {
             return dev_index[ti] == NONE ? kNoResult : X.res.p[dev_index[ti]];
         };
@@ -941,6 +947,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                                 const GroupRef &gr = sc.groups[gcur + gi];
                                 for (uint32_t qi = gr.first; qi < gr.first + gr.count && ok; ++qi) {
                                     const uint64_t q = base + qi;
+                                    if (std::binary_search(sc.nowhere.begin(), sc.nowhere.end(), qi)) { fatal = 2; ok = false; break; }
                                     const uint64_t *mask = &sc.mask[(size_t)qi * CW];
                                     for (uint32_t c = 0; c < C; ++c) {
                                         if (!((mask[c >> 6] >> (c & 63)) & 1)) continue;
@@ -1011,6 +1018,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                             const GroupRef &gr = sc.groups[gcur + gi];
                             if (ok) {
                                 for (uint64_t q = base + gr.first; q < base + gr.first + gr.count; ++q) {
+                                    if (!str_miss.empty() && str_miss[q]) { fatal = 1; ok = false; break; }
                                     if (!str_ok[q]) { ok = false; break; }
                                     tc[gi] += (double)str_sum[q] / (double)(str_len[q] - (size_t)k + 1);
                                 }
@@ -1048,6 +1056,8 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
                 }
             }
         });
+        if (fatal == 1) { B.err = "CDBG::readCov(): a kmer of a site string can not found ."; return PF_ERR_MISSING_KMER; }
+        if (fatal == 2) { B.err = "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble"; return PF_ERR_ARG; }
         for (ChunkOut &o : outs) {
             for (int a = 0; a < 4; ++a) allele_[a] += o.allele[a];
             core_cov_ += o.core_cov;
@@ -1190,6 +1200,7 @@ int CDBG::ploidy_estimation(const std::string &outpre, const std::vector<std::pa
             times_.sites_s += B.sites_s;
             if (B.st != PF_OK) { rc = B.st; rc_err = B.err; break; }
             rc = consume(B);
+            if (rc != PF_OK && rc_err.empty()) rc_err = B.err;
             tp("  batch consumed (format)");
             if (rc == PF_OK && !B.count_only) {
                 { std::lock_guard<std::mutex> lk(wmu); wqueue.push_back(&all_outs.back()); }

@@ -2163,9 +2163,10 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                 n_strings += (uint32_t)__popcll(__ballot(mine && !d));
                 const unsigned long long pd = a.prof ? wall_clock64() : 0;
                 pk[3] += pd - pc;
-                if (__ballot(miss)) { err = 2; break; }
-                // group coverages in set order; the first string out of range drops the site (src/CDBG.cpp:1527-1551)
-                bool ok = true;
+                // group coverages in set order; the first string out of range drops the site (src/CDBG.cpp:1527-1551) -- and ends the
+                // loop: a string BEHIND it is never looked up, so a k-mer of such a string that is in no database ends nothing
+                // (the reference's exit sits inside readCov, :52-56).  Only a missing k-mer the walk reaches is the run's end.
+                bool ok = true, fatal = false;
                 double total = 0.0;
                 for (uint32_t gi = 0; gi < maxnum; ++gi) {
                     double tc = 0.0;
@@ -2178,7 +2179,9 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             if (!m) break;
                             const uint32_t best = read_lane(wave_min_u32(cand ? rk : 0xFFFFFFFFu), 0);
                             const int bp = __ffsll((long long)__ballot(cand && rk == best)) - 1;   // (distinct strings of a group: distinct ranks)
-                            if (!read_lane(okp ? 1u : 0u, bp)) { ok = false; break; }
+                            const uint32_t verdict = read_lane(miss ? 2u : (okp ? 1u : 0u), bp);
+                            if (verdict == 2) { fatal = true; ok = false; break; }
+                            if (!verdict) { ok = false; break; }
                             const uint64_t mb = (uint64_t)__double_as_longlong(mn);
                             tc += __longlong_as_double((long long)(((uint64_t)read_lane((uint32_t)(mb >> 32), bp) << 32) | read_lane((uint32_t)mb, bp)));
                             last = best;
@@ -2188,6 +2191,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                     }
                     if (lane == 0 && room) a.sv[vcur + gi] = tc;
                 }
+                if (fatal) { err = 2; break; }
                 if (lane == 0 && room) a.sv[vcur + maxnum] = total;
                 if (lane == 0) a.osites[r.site_off + si].pad_ = ok ? 1 : 0;
                 vcur += maxnum + 1;
@@ -2319,7 +2323,6 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
             pk[2] += pc - pb;
             if (row_err) { err = (row_err & 4) ? 4 : 16; break; }
             // distinct strings per allele group in std::set order, their coverage (readCov(string), src/CDBG.cpp:29-60)
-            uint32_t miss_any = 0;
             for (uint32_t base = 0; base < R; base += WAVE) {
                 const uint32_t p = base + lane;
                 bool miss = false;
@@ -2369,7 +2372,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             const uint64_t wf = a.walk_off[j];
                             bool found;
                             cmask[p] = colours_of_string(a, sp, lp, a.walk_pool + (wf & ((1ull << 40) - 1)), (uint32_t)(wf >> 40), found);
-                            if (!found) miss = true;
+                            if (!found) cmask[p] = 1ull << 63;   // (findUnitig finds nothing: fatal in the reference IF the walk below reaches this string)
                         }
                     } else if (!d) {
                         uint64_t sum = 0;
@@ -2387,16 +2390,15 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                         }
                         mn = (double)sum / (double)((uint64_t)lp - (uint64_t)k + 1);
                     }
-                    sok[p] = ok;
+                    sok[p] = miss ? 2 : ok;   // (2: a k-mer in no database -- the reference's exit, if the walk below reaches this string)
                     mean[p] = mn;
                 }
-                if (__ballot(miss)) miss_any = 1;
                 n_strings += (uint32_t)__popcll(__ballot(p < R && !dup[p]));
             }
             sync();
             const unsigned long long pd = a.prof ? wall_clock64() : 0;
             pk[3] += pd - pc;
-            if (miss_any) { err = COLORED ? 64 : 2; break; }
+            bool fatal = false;
             if (COLORED) {
                 // src/CCDBG.cpp:3236-3339, 3374-3475: per allele group its strings in set order; a colour the string's mapping carries
                 // in full adds the string's mean to [colour][group]; a failed range test of such a colour, or a colour no string
@@ -2417,6 +2419,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                         }
                         if (best == 0xFFFFFFFFu) break;
                         const uint64_t m = cmask[bp];
+                        if (m >> 63) { fatal = true; ok = false; break; }
                         seen |= m;
                         if (m & ~cokm[bp]) { ok = false; break; }
                         if ((uint32_t)lane < C && ((m >> lane) & 1)) tc += cmean[(size_t)bp * C + lane];
@@ -2425,6 +2428,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                     }
                     if ((uint32_t)lane < C && room) a.sv[vcur + (uint64_t)lane * maxnum + gi] = tc;
                 }
+                if (fatal) { err = 64; break; }
                 const uint64_t all_colours = C >= 64 ? ~0ull : ((1ull << C) - 1);
                 const bool valid = ok && seen == all_colours;
                 if (lane == 0 && room) a.sv[vcur + (uint64_t)C * maxnum] = valid ? 1.0 : 0.0;
@@ -2452,6 +2456,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             if (rk < best) { best = rk; bp = p; }
                         }
                         if (best == 0xFFFFFFFFu) break;
+                        if (sok[bp] == 2) { fatal = true; ok = false; break; }
                         if (!sok[bp]) { ok = false; break; }
                         tc += mean[bp];
                         last = best;
@@ -2461,6 +2466,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                 }
                 if (lane == 0 && room) a.sv[vcur + gi] = tc;
             }
+            if (fatal) { err = 2; break; }
             if (lane == 0 && room) a.sv[vcur + maxnum] = total;
             if (lane == 0) a.osites[r.site_off + si].pad_ = ok ? 1 : 0;
             vcur += maxnum + 1;

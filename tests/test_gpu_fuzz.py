@@ -19,6 +19,10 @@ CASES = [(101, False, False, False), (102, False, False, False), (103, False, Fa
          (201, True, False, False), (202, True, False, False), (203, True, False, False), (301, False, True, False), (302, False, True, False)]
 # scores drawn from the whole region the reference accepts (fuzz_parity.draw_scores): gap-friendly, zero, D = M, 1e5, negative match
 CASES += [(s, False, False, True) for s in (401, 402, 403, 404, 405, 406, 407, 408, 409, 410, 411, 412)] + [(s, True, False, True) for s in (501, 502, 503, 504)]
+# seed 4028 (colored, scores 0.5 / 0 / -4.5, cutoffs 15 / 70): a site whose first strings fail their range test and whose LATER string lies on
+# no unitig of the bubble -- the reference never looks that string up (its walk over a site's strings ends at the first failure,
+# src/CCDBG.cpp:3262-3276), so it is no error; K-SITES looks all strings up side by side and must judge in the walk's order
+CASES += [(4028, True, False, True)]
 
 
 @pytest.mark.parametrize("seed,colored,giant,wide", CASES)

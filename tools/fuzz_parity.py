@@ -240,6 +240,9 @@ def main():
     for seed in range(first, first + n):
         with tempfile.TemporaryDirectory() as tmp:
             msg = one_case(seed, tmp, dev, force_colored=True if os.environ.get("PF_FUZZ_COLORED") == "1" else None)   # (PF_FUZZ_SCORES=wide: draw_scores)
+            if ("DIFFERENT" in msg or "MISMATCH" in msg) and os.environ.get("PF_FUZZ_KEEP"):   # the inputs of a failing case, for a closer look
+                import shutil
+                shutil.copytree(tmp, os.path.join(os.environ["PF_FUZZ_KEEP"], "seed%d" % seed), dirs_exist_ok=True)
         print("seed %d: %s" % (seed, msg), flush=True)
         failures += "DIFFERENT" in msg or "MISMATCH" in msg
     print("%d cases, %d failures" % (n, failures))
