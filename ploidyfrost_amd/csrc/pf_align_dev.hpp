@@ -4,6 +4,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <limits.h>
+
+#include <algorithm>
 #include <stdint.h>
 
 #include "pf_device_common.hpp"
@@ -48,32 +50,14 @@ __device__ inline void aln_sync() {
     __builtin_amdgcn_wave_barrier();
 }
 
-// One job on one wavefront.  `base` = working storage (LDS or global), job_bytes(m, n) bytes.
-// Returns false when the staging area overflowed.
-__device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, const char *__restrict__ gb, uint32_t m, uint32_t n,
-                          double M, double D, double G, int integral, const AlnScratch &sc, uint32_t &n_hits_out,
-                          uint32_t &text_out, uint32_t &gaps_out, unsigned long long *prof = nullptr) {
+// The fill of align_job (reference src/SeqAlign.cpp:497-549), compiled once for integral scores -- the default 2 / -1 / -3: the
+// reference's `int = long + double` is plain integer arithmetic -- and once for the fp64 form with its truncation: the choice is made
+// per job, outside the loop over the anti-diagonals (inside it the branch, and the fp64 instructions of the road not taken, were
+// issued at every step).
+template <bool INTEGRAL>
+__device__ inline void nw_fill(uint8_t *dir, int *s0, const char *A, const char *B, uint32_t m, uint32_t n, double M, double D, double G) {
     const int lane = lane_id();
     const uint32_t W = n + 1;
-    const uint32_t cells = (m + 1) * W;
-    uint8_t *dir = base;
-    int *s0 = reinterpret_cast<int *>(base + ((cells + 3) & ~3u));
-    const uint32_t mx = m > n ? m : n;
-    char *A = reinterpret_cast<char *>(s0 + 3 * (mx + 1));
-    char *B = A + al4(m);
-    char *ra = B + al4(n);
-    char *rb = ra + al4(m + n);
-    uint8_t *mv = reinterpret_cast<uint8_t *>(rb + al4(m + n));
-    uint16_t *gp = reinterpret_cast<uint16_t *>(mv + al4(m + n));
-
-    const unsigned long long pc0 = prof ? wall_clock64() : 0;
-    for (uint32_t i = lane; i < m; i += WAVE) A[i] = ga[i];
-    for (uint32_t j = lane; j < n; j += WAVE) B[j] = gb[j];
-    // borders (src/SeqAlign.cpp:486-496)
-    for (uint32_t i = lane; i <= m; i += WAVE) dir[i * W] = i ? (uint8_t)(UP | (UP << 4)) : 0;
-    for (uint32_t j = 1 + lane; j <= n; j += WAVE) dir[j] = (uint8_t)(LEFT | (LEFT << 4));
-    aln_sync();
-    // ---- fill ---------------------------------------------------------------------------------
     // Rows are processed in blocks of 64, one row per lane; inside a block the anti-diagonal
     // wavefront lives in registers: at step t lane l owns cell (row, t - l + 1), its left neighbour is
     // its own previous cell, the cells above / above-left are what lane l-1 produced one / two steps
@@ -93,9 +77,9 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         // integral scores (the default 2 / -1 / -3): the reference's `int = long + double` is plain
         // integer arithmetic; otherwise the fp64 form with its truncation is kept
         const int Mi = (int)M, Di = (int)D, Gi = (int)G;
-        int last_s = integral ? Gi * (int)r : (int)(long)(G * (double)r), last2_s = 0;  // (r, 0): border, flag Up
+        int last_s = INTEGRAL ? Gi * (int)r : (int)(long)(G * (double)r), last2_s = 0;  // (r, 0): border, flag Up
         int last_f = UP, last2_f = 0;
-        int carry_s = blk == 0 ? 0 : (integral ? Gi * (int)row0 : (int)(long)(G * (double)row0));  // (row0, 0)
+        int carry_s = blk == 0 ? 0 : (INTEGRAL ? Gi * (int)row0 : (int)(long)(G * (double)row0));  // (row0, 0)
         int carry_f = blk == 0 ? 0 : UP;
         int b_reg = 0;
         const uint32_t steps = n + rows_here - 1;
@@ -112,7 +96,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 dg_s = carry_s;
                 dg_f = carry_f;
                 if (t < n) {
-                    if (blk == 0) { up_s = integral ? Gi * j : (int)(long)(G * (double)j); up_f = LEFT; }
+                    if (blk == 0) { up_s = INTEGRAL ? Gi * j : (int)(long)(G * (double)j); up_f = LEFT; }
                     else { up_s = brow_s[j]; up_f = brow_f[j]; }
                 }
                 carry_s = up_s;
@@ -121,7 +105,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
             if (row_ok && j >= 1 && j <= (int)n) {
                 const char b = (char)b_reg;
                 int up, dg, lf;
-                if (integral) {
+                if (INTEGRAL) {
                     up = up_s + Gi;
                     dg = dg_s + (a == b ? Mi : ((a == '-' || b == '-') ? Gi : Di));
                     lf = last_s + Gi;
@@ -153,6 +137,104 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
             }
         }
         aln_sync();
+    }
+
+}
+
+// The same fill for integral scores small enough that a cell's score and its three direction flags share one register
+// (score << 3 | flags; |score| <= (max |M|, |D|, |G| + 1) * (i + j) < 2^27 is the caller's condition): three DPP shifts per
+// anti-diagonal step instead of five, half the register moves around them.  Same cells, same values, same flags.
+__device__ inline void nw_fill_packed(uint8_t *dir, int *s0, const char *A, const char *B, uint32_t m, uint32_t n, int Mi, int Di, int Gi) {
+    const int lane = lane_id();
+    const uint32_t W = n + 1;
+    int *brow_s = s0;
+    uint8_t *brow_f = reinterpret_cast<uint8_t *>(s0 + (n + 1));
+    const uint32_t n_blocks = (m + 63) / 64;
+    for (uint32_t blk = 0; blk < n_blocks; ++blk) {
+        const uint32_t row0 = blk * 64;
+        const uint32_t r = row0 + lane + 1;
+        const bool row_ok = r <= m;
+        const char a = row_ok ? A[r - 1] : '\0';
+        const bool next_is_gap = row_ok && r != m && A[r] == '-';
+        const uint32_t rows_here = m - row0 < 64 ? m - row0 : 64;
+        const bool feeds_next = blk + 1 < n_blocks && lane == 63;
+        int last = ((Gi * (int)r) << 3) | UP, last2 = 0;                   // (r, 0): border, flag Up
+        int carry = blk == 0 ? 0 : (((Gi * (int)row0) << 3) | UP);          // (row0, 0)
+        int b_reg = 0;
+        const uint32_t steps = n + rows_here - 1;
+        for (uint32_t t = 0; t < steps; ++t) {
+            const int b_in = t < n ? (int)B[t] : 0;
+            b_reg = __builtin_amdgcn_update_dpp(0, b_reg, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            int up_sf = __builtin_amdgcn_update_dpp(0, last, 0x138, 0xf, 0xf, false);
+            int dg_sf = __builtin_amdgcn_update_dpp(0, last2, 0x138, 0xf, 0xf, false);
+            const int j = (int)t - lane + 1;
+            if (lane == 0) {
+                b_reg = b_in;
+                dg_sf = carry;
+                if (t < n) {
+                    if (blk == 0) up_sf = ((Gi * j) << 3) | LEFT;
+                    else up_sf = (brow_s[j] << 3) | (int)brow_f[j];
+                }
+                carry = up_sf;
+            }
+            if (row_ok && j >= 1 && j <= (int)n) {
+                const char b = (char)b_reg;
+                const int up = (up_sf >> 3) + Gi + (up_sf & 1);                                   // UP = 1
+                const int dg = (dg_sf >> 3) + (a == b ? Mi : ((a == '-' || b == '-') ? Gi : Di)) + ((dg_sf >> 1) & 1);   // DIAG = 2
+                int lf = (last >> 3) + Gi + ((last >> 2) & 1);                                   // LEFT = 4
+                const int ud = up > dg ? up : dg;
+                int best = ud > lf ? ud : lf;
+                if (best == lf && next_is_gap) {
+                    lf = INT_MIN;
+                    best = ud;
+                }
+                int f = 0;
+                if (up == best) f |= UP;
+                if (dg == best) f |= DIAG;
+                if (lf == best) f |= LEFT;
+                last2 = last;
+                last = (best << 3) | f;
+                dir[r * W + j] = (uint8_t)(f | (f << 4));
+                if (feeds_next) { brow_s[j] = best; brow_f[j] = (uint8_t)f; }
+            }
+        }
+        aln_sync();
+    }
+}
+
+// One job on one wavefront.  `base` = working storage (LDS or global), job_bytes(m, n) bytes.
+// Returns false when the staging area overflowed.
+__device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, const char *__restrict__ gb, uint32_t m, uint32_t n,
+                          double M, double D, double G, int integral, const AlnScratch &sc, uint32_t &n_hits_out,
+                          uint32_t &text_out, uint32_t &gaps_out, unsigned long long *prof = nullptr) {
+    const int lane = lane_id();
+    const uint32_t W = n + 1;
+    const uint32_t cells = (m + 1) * W;
+    uint8_t *dir = base;
+    int *s0 = reinterpret_cast<int *>(base + ((cells + 3) & ~3u));
+    const uint32_t mx = m > n ? m : n;
+    char *A = reinterpret_cast<char *>(s0 + 3 * (mx + 1));
+    char *B = A + al4(m);
+    char *ra = B + al4(n);
+    char *rb = ra + al4(m + n);
+    uint8_t *mv = reinterpret_cast<uint8_t *>(rb + al4(m + n));
+    uint16_t *gp = reinterpret_cast<uint16_t *>(mv + al4(m + n));
+
+    const unsigned long long pc0 = prof ? wall_clock64() : 0;
+    for (uint32_t i = lane; i < m; i += WAVE) A[i] = ga[i];
+    for (uint32_t j = lane; j < n; j += WAVE) B[j] = gb[j];
+    // borders (src/SeqAlign.cpp:486-496)
+    for (uint32_t i = lane; i <= m; i += WAVE) dir[i * W] = i ? (uint8_t)(UP | (UP << 4)) : 0;
+    for (uint32_t j = 1 + lane; j <= n; j += WAVE) dir[j] = (uint8_t)(LEFT | (LEFT << 4));
+    aln_sync();
+    // ---- fill ---------------------------------------------------------------------------------
+    if (integral) {
+        const long Ml = (long)M, Dl = (long)D, Gl = (long)G;
+        const long mag = std::max(std::max(Ml < 0 ? -Ml : Ml, Dl < 0 ? -Dl : Dl), Gl < 0 ? -Gl : Gl) + 1;   // (+ 1: the bonus for going on in a direction)
+        if (mag * (long)(m + n + 2) < (1L << 27)) nw_fill_packed(dir, s0, A, B, m, n, (int)M, (int)D, (int)G);
+        else nw_fill<true>(dir, s0, A, B, m, n, M, D, G);
+    } else {
+        nw_fill<false>(dir, s0, A, B, m, n, M, D, G);
     }
 
     const unsigned long long pc1 = prof ? wall_clock64() : 0;
