@@ -99,8 +99,8 @@ struct pf_ctx {
 
     pf::CallState *call = nullptr;
     // K-BUBBLE: one stream per LDS size class (pf_bubble.hip), [6] = the event the class streams wait for
-    hipStream_t bub_streams[6] = {};
-    hipEvent_t bub_events[7] = {};
+    hipStream_t bub_streams[12] = {};   // (pf_bubble_launch.hpp: kBubMaxClasses)
+    hipEvent_t bub_events[13] = {};
 
     // K-CC (pf_cc.hip): union-find over unitig sides for the parallel commit replay; the records and vertex pool of the last
     // K-BFS call as they lie in the workspace
