@@ -369,6 +369,7 @@ typedef struct pf_call_result {
     uint64_t alignseq_packed_len;            /* pf_call_set_alignseq_packed: bytes stream PF_OUT_ALIGNSEQ takes in the slab (text_len keeps the text's) */
 } pf_call_result;
 #define PF_CALL_SLABS 4 /* text slabs of a context: a slab is free again once pf_call_fetch has copied it */
+#define PF_CALL_LANES 4 /* aligned ranges a context keeps resident side by side (pf_call_align_lane) */
 /* Bubbles [t0, t1) of the selection (at most 2^24): everything up to the text of the ten streams, left in slab 0 .. 3 of the
  * context; var_count_base = bubbles called by earlier batches.  complex_size = -z (bounds the walk stacks). */
 int pf_call_run(pf_ctx *, int slab, uint64_t t0, uint64_t t1, uint64_t var_count_base, uint32_t complex_size, double match,
@@ -391,6 +392,9 @@ int pf_call_set_alignseq_packed(pf_ctx *, int on);
  * turn out too small grow in pf_call_align as before.  Needs pf_call_set_state / pf_call_coverage / any other pf_call_* call first
  * only in that the graph must be resident. */
 int pf_call_reserve(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size);
+/* The same for the first n_lanes lanes (1 .. PF_CALL_LANES; pf_call_reserve takes two): a caller that aligns several ranges side by
+ * side (pf_call_align_lane below) takes every lane's working set beside the load. */
+int pf_call_reserve_lanes(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size, int n_lanes);
 /* The same for the text stage: what the first pf_call_text_range(_lane) of a run would take for pieces of up to piece_bubbles
  * bubbles (its stream, the size tables, the text slabs by an estimate from k). */
 int pf_call_reserve_text(pf_ctx *, uint64_t piece_bubbles);
@@ -414,11 +418,14 @@ int pf_call_peek(pf_ctx *, int lane, pf_call_bubble *bubbles, pf_bubble_result *
  * tails are paid once) can be formatted, fetched and written in pieces.  var_count_base is the same for every piece: the bubbles
  * called before the aligned batch; out->n_called = those called inside the piece. */
 int pf_call_text_range(pf_ctx *, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out);
-/* The two with a choice of where the aligned batch lies ("lane" 0 or 1; the calls above use lane 0): the rows of one range of
- * bubbles are formatted from one host thread (pf_call_text_range_lane: a stream, scratch and counters of its own) while another
- * aligns the next range into the other lane -- the copy of the text to the host, the slowest stage of a large pass, then runs
- * beside the alignment kernels instead of after them.  At most one call of each kind at a time, never on the same lane.  Their
- * error messages are set under a lock, and pf_last_error hands every calling thread a copy of its own. */
+/* The two with a choice of where the aligned batch lies ("lane" 0 .. PF_CALL_LANES - 1; the calls above use lane 0): the rows of
+ * one range of bubbles are formatted from one host thread (pf_call_text_range_lane: a stream, scratch and counters of its own)
+ * while others align the next ranges into other lanes -- the copy of the text to the host, the slowest stage of a large pass,
+ * then runs beside the alignment kernels instead of after them.  A lane owns its results AND the working set of its alignment
+ * (lists, pools, per-wavefront scratch, counters, streams), so pf_call_align_lane calls on DIFFERENT lanes may run at the same time
+ * from different host threads: every kernel of a range ends in a tail of a few slow bubbles, which the kernels of the next range
+ * fill.  One pf_call_text_range_lane at a time; never two calls on the same lane.  Their error messages are set under a lock, and
+ * pf_last_error hands every calling thread a copy of its own. */
 int pf_call_align_lane(pf_ctx *, int lane, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch,
                        double gap, pf_call_result *out);
 int pf_call_text_range_lane(pf_ctx *, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base,

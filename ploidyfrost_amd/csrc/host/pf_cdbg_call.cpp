@@ -470,7 +470,6 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         }
     } writer_guard{fetcher, writer, mu, cv, stop};
 
-    uint64_t var_count = 0;
     int rc = PF_OK;
     std::string rc_err;
     std::thread prefault;
@@ -498,13 +497,29 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         const uint64_t pieces = (n_tasks + CHUNK - 1) / CHUNK;
         if (first_env <= 0 && !getenv("PF_ALIGN_RANGES") && pieces >= 4) first_env = (int)std::min<uint64_t>((pieces * 5 + 7) / 8, ((uint64_t)1 << 24) / CHUNK);
     }
+    // The ranges of this pass, and where each lies: range r is aligned into lane r % LANES by whichever aligner thread takes it
+    // next, and formatted -- in range order -- once it is there.  PF_ALIGN_THREADS=n (default 1) runs n aligners, i.e.
+    // pf_call_align_lane on n lanes side by side.  Measured (profiles/r16_experiments.txt): a range's chain of a dozen dependent
+    // launches costs 1.7 ms whatever it holds (196 k bubbles 2.3 ms, 983 k 4.5 ms, 1.55 M 6.6 ms), but a second range beside it
+    // does not hide that: its kernels are sized to fill the device too, the two time-slice, the FIRST text piece of the pass comes
+    // later, and the pass ends one PCIe chain after that piece (two aligners 19.3 ms, one 18.2; four ranges 20.3 / 22.4).
     struct Range {
-        int lane;
-        uint64_t n, var_base;
+        uint64_t a0 = 0, a1 = 0;
+        int lane = 0;
+        bool aligned = false;
+        uint64_t n_called = 0;
     };
-    std::deque<Range> aligned;     // aligned, not yet formatted
+    std::vector<Range> ranges;
+    const int LANES = [] { const char *e = getenv("PF_ALIGN_LANES"); return e ? std::max(1, std::min(PF_CALL_LANES, atoi(e))) : PF_CALL_LANES; }();   // measurements
+    for (uint64_t a0 = 0, a1 = 0; a0 < n_tasks; a0 = a1) {
+        a1 = std::min<uint64_t>(n_tasks, a0 + (first_env > 0 && ranges.empty() ? (uint64_t)first_env * CHUNK : ALIGN));
+        Range r;
+        r.a0 = a0; r.a1 = a1; r.lane = (int)(ranges.size() % (size_t)LANES);
+        ranges.push_back(r);
+    }
+    const int aligners = (int)std::min<size_t>(ranges.size(), (size_t)[&] { const char *e = getenv("PF_ALIGN_THREADS"); return e ? std::max(1, std::min(LANES, atoi(e))) : 1; }());
+    size_t next_range = 0;         // the next range an aligner takes
     size_t ranges_formatted = 0;   // ranges whose last piece has been formatted: their lane may be aligned into again
-    bool align_done = false;
     std::thread formatter([&] {
         struct Last {   // on every way out: the fetcher learns that no further piece will come
             std::mutex &mu;
@@ -517,17 +532,18 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         } last{mu, cv, producer_done};
         try {
         size_t b = 0;   // text piece number: slabs alternate
-        for (;;) {
+        uint64_t var_base = 0;
+        for (size_t ri = 0; ri < ranges.size(); ++ri) {
             Range r;
             {
                 std::unique_lock<std::mutex> lk(mu);
-                cv.wait(lk, [&] { return stop || !aligned.empty() || align_done; });
-                if (stop || aligned.empty()) return;
-                r = aligned.front();
-                aligned.pop_front();
+                cv.wait(lk, [&] { return stop || ranges[ri].aligned; });
+                if (stop) return;
+                r = ranges[ri];
             }
-            for (uint64_t p0 = 0; p0 < r.n; p0 += CHUNK, ++b) {
-                const uint64_t count = std::min<uint64_t>(CHUNK, r.n - p0);
+            const uint64_t rn = r.a1 - r.a0;
+            for (uint64_t p0 = 0; p0 < rn; p0 += CHUNK, ++b) {
+                const uint64_t count = std::min<uint64_t>(CHUNK, rn - p0);
                 {   // its device slab was last used by piece b - PF_CALL_SLABS
                     std::unique_lock<std::mutex> lk(mu);
                     cv.wait(lk, [&] { return stop || b < fetched + PF_CALL_SLABS; });
@@ -536,7 +552,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 Done d;
                 d.slab = (int)(b % PF_CALL_SLABS);
                 d.hslab = (int)(b & 1);
-                const int st = pf_call_text_range_lane(ctx_, r.lane, d.slab, p0, count, r.var_base, &d.res);
+                const int st = pf_call_text_range_lane(ctx_, r.lane, d.slab, p0, count, var_base, &d.res);
                 if (st != PF_OK) {
                     { std::lock_guard<std::mutex> lk(mu); if (rc == PF_OK) { rc = st; rc_err = pf_last_error(ctx_); } stop = true; }
                     cv.notify_all();
@@ -575,6 +591,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 { std::lock_guard<std::mutex> lk(mu); ready.push_back(d); }
                 cv.notify_all();
             }
+            var_base += r.n_called;
             { std::lock_guard<std::mutex> lk(mu); ++ranges_formatted; }
             cv.notify_all();
         }
@@ -592,35 +609,48 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             t.join();
         }
     } formatter_guard{formatter, mu, cv, stop};
-    size_t ri = 0;
-    for (uint64_t a0 = 0, a1 = 0; a0 < n_tasks; a0 = a1, ++ri) {
-        a1 = std::min<uint64_t>(n_tasks, a0 + (first_env > 0 && ri == 0 ? (uint64_t)first_env * CHUNK : ALIGN));
-        {   // lane ri % 2 was last read by the text of range ri - 2
-            std::unique_lock<std::mutex> lk(mu);
-            cv.wait(lk, [&] { return stop || ri < ranges_formatted + 2; });
-            if (stop) break;
-        }
-        pf_call_result ar;
-        const int st = pf_call_align_lane(ctx_, (int)(ri & 1), a0, a1, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch, sc_.gap, &ar);
-        if (st != PF_OK) {
-            { std::lock_guard<std::mutex> lk(mu); if (rc == PF_OK) { rc = st; rc_err = pf_last_error(ctx_); } stop = true; }
+    auto aligner = [&] {
+        try {
+        for (;;) {
+            size_t ri;
+            {   // the next range; its lane was last read by the text of range ri - LANES
+                std::unique_lock<std::mutex> lk(mu);
+                if (stop || next_range >= ranges.size()) return;
+                ri = next_range++;
+                cv.wait(lk, [&] { return stop || ri < ranges_formatted + (size_t)LANES; });
+                if (stop) return;
+            }
+            const Range r = ranges[ri];
+            pf_call_result ar;
+            const int st = pf_call_align_lane(ctx_, r.lane, r.a0, r.a1, (uint32_t)std::min<size_t>(complex_size_, 1u << 20), sc_.match, sc_.mismatch, sc_.gap, &ar);
+            if (st != PF_OK) {
+                { std::lock_guard<std::mutex> lk(mu); if (rc == PF_OK) { rc = st; rc_err = pf_last_error(ctx_); } stop = true; }
+                cv.notify_all();
+                return;
+            }
+            if (trace) fprintf(stderr, "[ploidy]   range %zu: %llu bubbles aligned on the device %.2f ms\n", ri, (unsigned long long)(r.a1 - r.a0), since(t_all) * 1e3);
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                times_.tasks += r.a1 - r.a0;
+                times_.align_jobs += ar.align_jobs;
+                times_.snp_jobs += ar.snp_jobs; times_.pair_jobs += ar.pair_jobs; times_.wave_jobs += ar.wave_jobs; times_.stack_jobs += ar.stack_jobs; times_.trio_jobs += ar.trio_jobs;
+                times_.site_strings += ar.site_strings;
+                ranges[ri].n_called = ar.n_called;
+                ranges[ri].aligned = true;
+            }
             cv.notify_all();
-            break;
         }
-        if (trace) fprintf(stderr, "[ploidy]   %llu bubbles aligned on the device %.2f ms\n", (unsigned long long)(a1 - a0), since(t_all) * 1e3);
-        times_.tasks += a1 - a0;
-        times_.align_jobs += ar.align_jobs;
-        times_.snp_jobs += ar.snp_jobs; times_.pair_jobs += ar.pair_jobs; times_.wave_jobs += ar.wave_jobs; times_.stack_jobs += ar.stack_jobs; times_.trio_jobs += ar.trio_jobs;
-        times_.site_strings += ar.site_strings;
-        { std::lock_guard<std::mutex> lk(mu); aligned.push_back(Range{(int)(ri & 1), a1 - a0, var_count}); }
-        cv.notify_all();
-        var_count += ar.n_called;
-    }
+        } catch (const std::exception &e) { thread_failed("aligning the bubbles", e); }
+    };
     {
-        std::lock_guard<std::mutex> lk(mu);
-        align_done = true;
+        std::vector<std::thread> extra;
+        struct ExtraGuard {
+            std::vector<std::thread> &v;
+            ~ExtraGuard() { for (auto &t : v) if (t.joinable()) t.join(); }
+        } extra_guard{extra};
+        for (int a = 1; a < aligners; ++a) extra.emplace_back(aligner);
+        aligner();
     }
-    cv.notify_all();
     formatter.join();
     times_.align_s = since(t_dev);
     fetcher.join();

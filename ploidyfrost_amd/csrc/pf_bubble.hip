@@ -776,29 +776,42 @@ namespace pf {
 // queues back to back (class c: n_cls[c] task indices, heavy ones first); results / pools are device memory.
 // Leaves the pool heads in heads[4]; returns PF_ERR_OVERFLOW when a bubble exceeds the largest scratch tier
 // (its result then carries n_rows = 0xFFFFFFFF).
-unsigned long long *bubble_pool_heads(pf_ctx *ctx) { return (unsigned long long *)ctx_ws(ctx, WS_BUB_SMALL, 128); }
+unsigned long long *bubble_pool_heads(pf_ctx *ctx, int lane) { return (unsigned long long *)ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128); }
 
-// K-BUBBLE's workspaces for batches of up to n_tasks bubbles, ahead of the first launch (pf_call_reserve)
-int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks) {
-    const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
-    const uint64_t per = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
-    if (!ctx_ws(ctx, WS_BUB_SMALL, 128) || !ctx_ws(ctx, WS_BUB_RETRY, (size_t)std::max<uint32_t>(n_tasks, 1) * 4) ||
-        !ctx_ws(ctx, WS_BUB_SCRATCH, per * (uint64_t)ctx->n_cu * 24))
-        return PF_ERR_HIP;
-    if (!ctx->bub_streams[0]) {
-        for (int c = 0; c < kBubLdsClasses; ++c) {
-            PF_HIP(hipStreamCreateWithFlags(&ctx->bub_streams[c], hipStreamNonBlocking));
-            PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[c], hipEventDisableTiming));
-        }
-        PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[kBubLdsClasses], hipEventDisableTiming));
+static int bubble_streams(pf_ctx *ctx, int lane) {
+    if (ctx->bub_streams[lane][0]) return PF_OK;
+    for (int c = 0; c < kBubLdsClasses; ++c) {
+        PF_HIP(hipStreamCreateWithFlags(&ctx->bub_streams[lane][c], hipStreamNonBlocking));
+        PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[lane][c], hipEventDisableTiming));
     }
+    PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[lane][kBubLdsClasses], hipEventDisableTiming));
+    return PF_OK;
+}
+static int bubble_func_attr(pf_ctx *ctx) {   // (once per process, whichever lane comes first)
+    static const hipError_t once = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bubble<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    PF_HIP(once);
     return PF_OK;
 }
 
+// K-BUBBLE's workspaces for batches of up to n_tasks bubbles, ahead of the first launch (pf_call_reserve)
+int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks, int lane) {
+    const BubCaps std_caps{64 * 1024, 8 * 1024, 512, 16 * 1024, 128 * 1024, 256, 8 * 1024};
+    const uint64_t per = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
+    if (!ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128) || !ctx_ws(ctx, bub_ws(WS_BUB_RETRY, lane), (size_t)std::max<uint32_t>(n_tasks, 1) * 4) ||
+        !ctx_ws(ctx, bub_ws(WS_BUB_SCRATCH, lane), per * (uint64_t)ctx->n_cu * 24))
+        return PF_ERR_HIP;
+    return bubble_streams(ctx, lane);
+}
+
 int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]) {
-    hipStream_t st = ctx->stream;
-    uint8_t *small = (uint8_t *)ctx_ws(ctx, WS_BUB_SMALL, 128);  // pool heads, retry count, one queue head per launch
-    uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, WS_BUB_RETRY, (size_t)std::max<uint32_t>(L.n_tasks, 1) * 4);
+    const int lane = L.lane;
+    hipStream_t st = L.stream ? L.stream : ctx->stream;
+    // launch timing by place (a call on another lane may time its launches at the same time)
+    size_t tl_at = (size_t)-1;
+    auto tbegin = [&](int kernel, hipStream_t s) { (void)ctx_begin_at(ctx, kernel, s, &tl_at); };
+    auto tend = [&](hipStream_t s) { ctx_end_at(ctx, tl_at, s); };
+    uint8_t *small = (uint8_t *)ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128);  // pool heads, retry count, one queue head per launch
+    uint32_t *d_retry = (uint32_t *)ctx_ws(ctx, bub_ws(WS_BUB_RETRY, lane), (size_t)std::max<uint32_t>(L.n_tasks, 1) * 4);
     if (!small || !d_retry) return PF_ERR_HIP;
     if (L.keep_heads) PF_HIP(hipMemsetAsync(small + 32, 0, 96, st));
     else PF_HIP(hipMemsetAsync(small, 0, 128, st));
@@ -834,16 +847,10 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     const uint64_t max_waves = class_streams ? std::max<uint64_t>(waves_total, (uint64_t)ctx->n_cu * 24) : (uint64_t)ctx->n_cu * 24;
     p.caps = std_caps;
     p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
-    uint8_t *const scratch0 = (uint8_t *)ctx_ws(ctx, WS_BUB_SCRATCH, p.scratch_per_wave * max_waves);
+    uint8_t *const scratch0 = (uint8_t *)ctx_ws(ctx, bub_ws(WS_BUB_SCRATCH, lane), p.scratch_per_wave * max_waves);
     p.scratch = scratch0;
     if (!p.scratch) return PF_ERR_HIP;
-    if (class_streams && !ctx->bub_streams[0]) {
-        for (int c = 0; c < kBubLdsClasses; ++c) {
-            PF_HIP(hipStreamCreateWithFlags(&ctx->bub_streams[c], hipStreamNonBlocking));
-            PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[c], hipEventDisableTiming));
-        }
-        PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[kBubLdsClasses], hipEventDisableTiming));
-    }
+    if (class_streams) { const int e = bubble_streams(ctx, lane); if (e != PF_OK) return e; }
 
     DevTmp<unsigned long long> clk_;
     unsigned long long *d_clk = nullptr;
@@ -855,14 +862,10 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         p.task_clk = d_clk;
         p.prof = d_clk + L.n_tasks;
     }
-    static bool attr_set = false;
-    if (!attr_set) {
-        PF_HIP(hipFuncSetAttribute(reinterpret_cast<const void *>(&k_bubble<true>), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024));
-        attr_set = true;
-    }
+    { const int e = bubble_func_attr(ctx); if (e != PF_OK) return e; }
     uint32_t idx_off = 0;
     uint64_t wave_off = 0;
-    if (class_streams) PF_HIP(hipEventRecord(ctx->bub_events[kBubLdsClasses], st));
+    if (class_streams) PF_HIP(hipEventRecord(ctx->bub_events[lane][kBubLdsClasses], st));
     // largest class first: its tail is the longest
     for (int c = kBubLdsClasses - 1; c >= 0; --c) {
         const uint32_t nc = L.n_cls[c];
@@ -876,18 +879,18 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         p.next = queue_heads + n_launch++;
         hipStream_t cst = st;
         if (class_streams) {
-            cst = ctx->bub_streams[c];
-            PF_HIP(hipStreamWaitEvent(cst, ctx->bub_events[kBubLdsClasses], 0));
+            cst = ctx->bub_streams[lane][c];
+            PF_HIP(hipStreamWaitEvent(cst, ctx->bub_events[lane][kBubLdsClasses], 0));
             p.scratch = scratch0 + wave_off * p.scratch_per_wave;
             wave_off += (uint64_t)grid;
         }
-        ctx_begin_on(ctx, PF_K_BUBBLE, cst);
+        tbegin(PF_K_BUBBLE, cst);
         k_bubble<true><<<grid, 64, kBubClassBytes[c], cst>>>(p, o);
-        ctx_end_on(ctx, cst);
+        tend(cst);
         ctx_units(ctx, PF_K_BUBBLE, nc);
         if (class_streams) {
-            PF_HIP(hipEventRecord(ctx->bub_events[c], cst));
-            PF_HIP(hipStreamWaitEvent(st, ctx->bub_events[c], 0));
+            PF_HIP(hipEventRecord(ctx->bub_events[lane][c], cst));
+            PF_HIP(hipStreamWaitEvent(st, ctx->bub_events[lane][c], 0));
         }
         idx_off += nc;
     }
@@ -896,7 +899,7 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         const uint32_t nc = L.n_cls[kBubLdsClasses];
         const int grid = (int)std::min<uint32_t>(nc, 256);
         const uint64_t per = (std::min<uint64_t>(L.max_need * 2, 1ull << 31) + 255) & ~255ull;
-        uint8_t *work = (uint8_t *)ctx_ws(ctx, WS_BUB_WORK, per * grid);
+        uint8_t *work = (uint8_t *)ctx_ws(ctx, bub_ws(WS_BUB_WORK, lane), per * grid);
         if (!work) return PF_ERR_HIP;
         p.idx = L.idx + idx_off;
         p.n = nc;
@@ -904,9 +907,9 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         p.work_per_wave = per;
         p.work_bytes = (uint32_t)std::min<uint64_t>(per, 0xFFFFFFFFu);
         p.next = queue_heads + n_launch++;
-        ctx_begin(ctx, PF_K_BUBBLE_BIG);
+        tbegin(PF_K_BUBBLE_BIG, st);
         k_bubble<false><<<grid, 64, 0, st>>>(p, o);
-        ctx_end(ctx);
+        tend(st);
         ctx_units(ctx, PF_K_BUBBLE_BIG, nc);
     }
     unsigned int n_retry = 0;
@@ -930,16 +933,16 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         PF_HIP(hipMemsetAsync(bad_.p, 0, 4, st));
         // the retry list becomes the queue of the last launch (copied: the kernel appends to o.retry again on failure paths only
         // in non-final tiers)
-        uint32_t *d_q = (uint32_t *)ctx_ws(ctx, WS_BUB_IDX2, (size_t)n_retry * 4);
+        uint32_t *d_q = (uint32_t *)ctx_ws(ctx, bub_ws(WS_BUB_IDX2, lane), (size_t)n_retry * 4);
         if (!d_q) return PF_ERR_HIP;
         PF_HIP(hipMemcpyAsync(d_q, d_retry, (size_t)n_retry * 4, hipMemcpyDeviceToDevice, st));
         p.idx = d_q; p.n = n_retry; p.caps = big; p.scratch = big_scratch_.p; p.scratch_per_wave = per_s;
         p.work = big_work_.p; p.work_per_wave = per_w; p.work_bytes = (uint32_t)per_w; p.final_tier = 1;
         p.bad = bad_.p;
         p.next = queue_heads + n_launch++;
-        ctx_begin(ctx, PF_K_BUBBLE_BIG);
+        tbegin(PF_K_BUBBLE_BIG, st);
         k_bubble<false><<<grid, 64, 0, st>>>(p, o);
-        ctx_end(ctx);
+        tend(st);
         unsigned int bad = 0;
         PF_HIP(hipMemcpyAsync(&bad, bad_.p, 4, hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));

@@ -1,6 +1,7 @@
 // K-BUBBLE launch interface shared by pf_bubble.hip (pf_align_bubbles: batches described by the host) and pf_call.hip (the
 // resident calling pipeline: paths, tasks and per-class work queues produced on the device).
 #pragma once
+#include <hip/hip_runtime.h>
 #include <stdint.h>
 
 #include "pf_align_dev.hpp"
@@ -63,11 +64,15 @@ struct BubbleLaunch {
     uint64_t text_cap = 0, site_cap = 0, group_cap = 0, ilen_cap = 0;
     // the pool heads (bubble_pool_heads) already hold what an earlier kernel of the caller took from the pools: do not reset them
     bool keep_heads = false;
+    // which set of K-BUBBLE's workspaces, class streams and events (the lane of the resident pipeline's pf_call_align_lane: calls on
+    // different lanes run side by side), and the stream the launch is ordered on (nullptr: the context's)
+    int lane = 0;
+    hipStream_t stream = nullptr;
 };
 
 // device address of the four pool heads {text bytes, sites, group bytes, ilen entries} that K-BUBBLE bumps (first 32 bytes of a
 // 128-byte block the launch otherwise zeroes): a caller that publishes some bubbles itself allocates from the same heads
-unsigned long long *bubble_pool_heads(pf_ctx *ctx);
+unsigned long long *bubble_pool_heads(pf_ctx *ctx, int lane = 0);
 
 // The single-SNP shortcut of K-BUBBLE as a predicate on the scores (proof in pf_bubble.hip): two equally long paths that differ
 // in exactly one base align as themselves, one SNP column, groups {1, 2}, whenever this holds.
@@ -78,6 +83,6 @@ inline bool snp_shortcut_scores(double M, double D, double G) {
 }
 
 int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]);
-int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks);
+int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks, int lane = 0);
 
 }  // namespace pf

@@ -25,6 +25,7 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
 #include <cstddef>
@@ -90,6 +91,13 @@ struct DevBuf {
     }
 };
 
+// a capacity learnt by whichever lane met the larger batch
+template <typename T, typename V>
+inline void amax(std::atomic<T> &a, V v) {
+    T cur = a.load(std::memory_order_relaxed);
+    while (cur < (T)v && !a.compare_exchange_weak(cur, (T)v, std::memory_order_relaxed)) {}
+}
+
 // counters of one batch, device side (zeroed per batch)
 struct CallCounters {
     unsigned int q_n[NQ];           // work queues: class c heavy = q_n[2c], light = q_n[2c + 1]
@@ -129,12 +137,8 @@ struct CallState {
     uint32_t n_colors = 0;
     DevBuf col_low, col_up, col_full, col_size, part_first, part_colour, part_word, part_bits;
     DevBuf ccov_sum, ccov_min, ccov_max, ccov_miss;
-    DevBuf mlist, paths_big_scr;  // K-PATHS: bubbles of more than 255 walks, and the scratch of the launch that takes them
-    uint32_t mlist_cap = 0;
-    uint32_t sites_ks = 0;        // K-SITES: room per site string once a launch asked for more than 2k + 64
+    std::atomic<uint32_t> sites_ks{0};   // K-SITES: room per site string once a launch asked for more than 2k + 64
     bool pack_alignseq = false;   // pf_call_set_alignseq_packed
-    DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
-    uint64_t walk_cap = 0;
     // scan
     DevBuf side_cnt, side_base, sides, ctask, scan_tmp, target, pending, killed, rstate, rflag, rsmall;
     uint64_t n_sides = 0;
@@ -145,22 +149,37 @@ struct CallState {
     DevBuf sb_cnt, sb_base, sb_sizes, sb_offs, sb_out;
     uint64_t sb_len = 0;
     uint64_t n_tasks = 0;
-    // per batch
-    DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, klist, klist_b, stack_scr, tlist, tlist4, trio_scr, trio_rows, trio_ok, pair_scr, pair_scr2, has, scan_tmp2, paths_scr, sites_scr;
-    // what pf_call_align leaves resident for pf_call_text_range: two sets ("lanes"), so that the rows of one range of bubbles
-    // can be formatted, fetched and written while the next range is aligned into the other set
+    // what pf_call_align leaves resident for pf_call_text_range: PF_CALL_LANES sets ("lanes"), so that the rows of one range of
+    // bubbles can be formatted, fetched and written while the next ranges are aligned into the other sets
     struct AlignOut {
         DevBuf res, otext, osites, ogroups, oilen, sv_off, sv, vc;
         uint64_t t0 = 0;
         uint32_t nb = 0;
         pf_call_result cur = {};
         uint64_t used[5] = {};   // pool fill after the last pf_call_align_lane: row text, sites, group bytes, indel lengths, site values
-    } lane[2];
+        hipEvent_t read_ev = nullptr;   // the last write pass of K-TEXT over this lane has finished (the next alignment into it waits for that on its stream)
+    } lane[PF_CALL_LANES];
+    // the working set of one pf_call_align_lane call, one per lane as well: lists, queues, path pools, per-wavefront scratch,
+    // counters, streams -- calls on different lanes run side by side from different host threads (every kernel of a range ends in
+    // a tail of a few slow bubbles: the next range's kernels fill the device meanwhile)
+    struct AlignWork {
+        DevBuf counters, btask, bpath, ptext, queues, blist, slist, plist, plist2, klist, klist_b, stack_scr, tlist, tlist4, trio_scr, trio_rows, trio_ok, pair_scr, pair_scr2, has, scan_tmp, scan_tmp2, paths_scr, sites_scr;
+        DevBuf mlist, paths_big_scr;  // K-PATHS: bubbles of more than 255 walks, and the scratch of the launch that takes them
+        uint32_t mlist_cap = 0;
+        DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
+        uint64_t walk_cap = 0;
+        hipStream_t stream = nullptr;   // lane 0: the context's; other lanes: their own
+        bool own_stream = false;
+        // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
+        hipStream_t side_stream = nullptr;
+        hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
+    } work[PF_CALL_LANES];
     // K-TEXT's own scratch, counters and stream: it may run from another host thread beside pf_call_align (other lane)
     DevBuf sizes, offs, totals, tcounters, tscan;
     hipStream_t text_stream = nullptr;
-    uint64_t path_pool = 0, text_pool = 0, sv_pool = 0;   // capacities learnt from earlier batches
-    uint64_t otext_cap = 0, osites_cap = 0, ogroups_cap = 0, oilen_cap = 0;
+    // capacities learnt from earlier batches (any lane)
+    std::atomic<uint64_t> path_pool{0}, text_pool{0}, sv_pool{0};
+    std::atomic<uint64_t> otext_cap{0}, osites_cap{0}, ogroups_cap{0}, oilen_cap{0};
     // output slabs: two sets, so that one can be fetched while the next batch is formatted
     // (the ten streams of a slab lie one after the other in one buffer, as the host wants them: one copy fetches a slab)
     DevBuf out[PF_CALL_SLABS];
@@ -168,18 +187,26 @@ struct CallState {
     hipStream_t copy_stream = nullptr;
     hipEvent_t fetch_ev[2] = {nullptr, nullptr};   // pf_call_fetch_range / pf_call_fetch_wait
     hipEvent_t text_ev[PF_CALL_SLABS] = {};        // the write pass of the piece in a slab has finished (the fetches wait for it on their stream)
-    // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
-    hipStream_t side_stream = nullptr;
-    hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
     bool mt_format = false;   // pf_call_set_format
     void release_all() {
-        DevBuf *all[] = {&mlist, &paths_big_scr, &col_low, &col_up, &col_full, &col_size, &part_first, &part_colour, &part_word, &part_bits, &ccov_sum, &ccov_min, &ccov_max, &ccov_miss, &walk_off, &walk_pool,
-                         &flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out, &counters,
-                         &btask, &bpath, &ptext, &queues, &blist, &slist, &plist, &plist2, &klist, &klist_b, &stack_scr, &tlist, &tlist4, &trio_scr, &trio_rows, &trio_ok, &pair_scr, &pair_scr2, &has, &sizes, &offs,
-                         &totals, &tcounters, &tscan, &scan_tmp2, &paths_scr, &sites_scr};
+        DevBuf *all[] = {&col_low, &col_up, &col_full, &col_size, &part_first, &part_colour, &part_word, &part_bits, &ccov_sum, &ccov_min, &ccov_max, &ccov_miss,
+                         &flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out,
+                         &sizes, &offs, &totals, &tcounters, &tscan};
         for (DevBuf *b : all) b->release();
-        for (AlignOut &o : lane)
+        for (AlignOut &o : lane) {
             for (DevBuf *b : {&o.res, &o.otext, &o.osites, &o.ogroups, &o.oilen, &o.sv_off, &o.sv, &o.vc}) b->release();
+            if (o.read_ev) { (void)hipEventDestroy(o.read_ev); o.read_ev = nullptr; }
+        }
+        for (AlignWork &w : work) {
+            for (DevBuf *b : {&w.counters, &w.btask, &w.bpath, &w.ptext, &w.queues, &w.blist, &w.slist, &w.plist, &w.plist2, &w.klist, &w.klist_b, &w.stack_scr, &w.tlist, &w.tlist4, &w.trio_scr, &w.trio_rows,
+                              &w.trio_ok, &w.pair_scr, &w.pair_scr2, &w.has, &w.scan_tmp, &w.scan_tmp2, &w.paths_scr, &w.sites_scr, &w.mlist, &w.paths_big_scr, &w.walk_off, &w.walk_pool})
+                b->release();
+            if (w.own_stream && w.stream) (void)hipStreamDestroy(w.stream);
+            w.stream = nullptr; w.own_stream = false;
+            if (w.side_stream) { (void)hipStreamDestroy(w.side_stream); w.side_stream = nullptr; }
+            if (w.ev_prep) { (void)hipEventDestroy(w.ev_prep); w.ev_prep = nullptr; }
+            if (w.ev_paths) { (void)hipEventDestroy(w.ev_paths); w.ev_paths = nullptr; }
+        }
         if (text_stream) { (void)hipStreamDestroy(text_stream); text_stream = nullptr; }
         for (DevBuf &b : out) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
@@ -187,9 +214,6 @@ struct CallState {
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
         for (hipEvent_t &e : text_ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
-        if (side_stream) { (void)hipStreamDestroy(side_stream); side_stream = nullptr; }
-        if (ev_prep) { (void)hipEventDestroy(ev_prep); ev_prep = nullptr; }
-        if (ev_paths) { (void)hipEventDestroy(ev_paths); ev_paths = nullptr; }
     }
 };
 
@@ -3399,7 +3423,7 @@ int pf_call_select(pf_ctx *ctx, const uint32_t *side_index, uint64_t n_tasks) {
 // one batch, first half: bubbles [t0, t1) of the selection up to the site coverages; out->n_called tells how far var_count advances
 int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
                        pf_call_result *out) {
-    if (!ctx || !out || lane < 0 || lane > 1) return PF_ERR_ARG;
+    if (!ctx || !out || lane < 0 || lane >= PF_CALL_LANES) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S || t0 > t1 || t1 > S->n_tasks) { pf::CtxErr{ctx} = "pf_call_align: range outside the selection"; return PF_ERR_ARG; }
     memset(out, 0, sizeof(*out));
@@ -3410,7 +3434,20 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     if (t1 == t0) return PF_OK;
     if (t1 - t0 > (1u << 24)) { pf::CtxErr{ctx} = "pf_call_align: at most 2^24 bubbles per batch"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
-    hipStream_t st = ctx->stream;
+    CallState::AlignWork &W = S->work[lane];
+    if (!W.stream) {
+        if (lane == 0) W.stream = ctx->stream;
+        else { PF_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking)); W.own_stream = true; }
+    }
+    hipStream_t st = W.stream;
+    // the write pass of K-TEXT over what this lane held may still be running (pf_call_text_range_lane does not wait for it)
+    if (O.read_ev) PF_HIP(hipStreamWaitEvent(st, O.read_ev, 0));
+    // (another lane's stream needs no event to wait for: the scan and the selection on the context's stream ended in host waits --
+    // pf_call_resolve / pf_call_select hand the host the number of bubbles this call's range is cut from)
+    // launch timing by place: calls on other lanes time their launches at the same time
+    size_t tl_at = (size_t)-1;
+    auto tbegin = [&](int kernel, hipStream_t s) { (void)ctx_begin_at(ctx, kernel, s, &tl_at); };
+    auto tend = [&](hipStream_t s) { ctx_end_at(ctx, tl_at, s); };
     const uint32_t nb = (uint32_t)(t1 - t0);
     const int k = ctx->k;
     const bool trace_stages = getenv("PF_TRACE_ALIGN") != nullptr;   // where a call's time goes (a first call above all)
@@ -3420,37 +3457,37 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     };
     const char *oom = "pf_call_run: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
-    NEED(S->counters, sizeof(CallCounters));
-    NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
-    NEED(S->queues, (size_t)NQ * nb * 4);
-    NEED(S->blist, (size_t)nb * 4);
+    NEED(W.counters, sizeof(CallCounters));
+    NEED(W.btask, (size_t)nb * sizeof(pf_bubble_task));
+    NEED(W.queues, (size_t)NQ * nb * 4);
+    NEED(W.blist, (size_t)nb * 4);
     NEED(O.res, (size_t)nb * sizeof(pf_bubble_result));
     NEED(O.sv_off, (size_t)nb * 8);
-    NEED(S->has, (size_t)nb * 4);
+    NEED(W.has, (size_t)nb * 4);
     NEED(O.vc, (size_t)nb * 4);
-    CallCounters *d_cnt = S->counters.as<CallCounters>();
+    CallCounters *d_cnt = W.counters.as<CallCounters>();
     CallCounters hc;
     // K-PATHS scratch: stacks sized by the complex size (a non-complex bubble has at most that many vertices)
     const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
     const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (10ull * depth_cap + 4) * 4) + 255) & ~255ull;
     static const int paths_per_cu = [] { const char *e = getenv("PF_PATHS_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
     const int paths_grid = ctx->n_cu * paths_per_cu;
-    NEED(S->paths_scr, paths_per_wave * paths_grid);
+    NEED(W.paths_scr, paths_per_wave * paths_grid);
     // bubbles of more than 255 walks in one range: the list grows to what an attempt asked for (advisor, round 3: an overflow used
     // to be reported as "more than 65535 paths", a refusal of a run no bubble of which had that many)
-    if (S->mlist_cap < 4096) S->mlist_cap = 4096;
-    NEED(S->mlist, (size_t)S->mlist_cap * 4);
+    if (W.mlist_cap < 4096) W.mlist_cap = 4096;
+    NEED(W.mlist, (size_t)W.mlist_cap * 4);
     PathArgs ph_keep = {};
     const int paths_force_scratch = [] { const char *e = getenv("PF_PATHS_SCRATCH"); return e && atoi(e) ? 1 : 0; }();   // (read per call: tests)
 
     // ---- K-PREP, K-SNP, K-PATHS, K-BUBBLE; every pool grows until the batch fits (first batches of a run only) ----
-    NEED(S->slist, (size_t)nb * 4);
-    NEED(S->plist, (size_t)nb * 4);
-    NEED(S->plist2, (size_t)nb * 4);
-    NEED(S->klist, (size_t)nb * 4);
-    NEED(S->klist_b, (size_t)nb * 4);
-    NEED(S->tlist, (size_t)nb * 4);
-    NEED(S->tlist4, (size_t)nb * 4);
+    NEED(W.slist, (size_t)nb * 4);
+    NEED(W.plist, (size_t)nb * 4);
+    NEED(W.plist2, (size_t)nb * 4);
+    NEED(W.klist, (size_t)nb * 4);
+    NEED(W.klist_b, (size_t)nb * 4);
+    NEED(W.tlist, (size_t)nb * 4);
+    NEED(W.tlist4, (size_t)nb * 4);
     const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
     // K-PAIR: register-bound (the score row of the fill is 65 / 129 registers): 3 / 2 wavefronts per SIMD, the grid loops over its list
     // (scores of sane magnitude only: the fill adds them in ints)
@@ -3462,7 +3499,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     // later paths are shorter than the first (one gap run each), 3 = also the two-path bubbles ahead of K-PAIR
     const int stack_level = [] { const char *e = getenv("PF_STACK_LEVEL"); return e ? std::max(1, std::min(3, atoi(e))) : 1; }();
     const int stack_grid = ctx->n_cu * 8;
-    if (stack_tier) NEED(S->stack_scr, stack_scratch_bytes() * stack_grid);
+    if (stack_tier) NEED(W.stack_scr, stack_scratch_bytes() * stack_grid);
     // K-TRIO is OFF unless asked for: measured at BASELINE.json's configs[2] (profiles/r07_experiments.txt) it takes 24 k of K-BUBBLE's 34 k
     // bubbles and saves K-BUBBLE 1.0 ms per pass, but costs 3.2 ms itself -- a whole 96 x 70 fill per THREAD is 0.9 ms of dependent
     // instructions on a wavefront that has the SIMD to itself, whatever the number of bubbles; K-BUBBLE's wavefront per bubble
@@ -3473,7 +3510,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     const int trio_grid = ctx->n_cu * 8;
     const bool pair_integral = match == std::floor(match) && mismatch == std::floor(mismatch) && gap == std::floor(gap);
     const int pair_grid = ctx->n_cu * 12, pair_grid2 = ctx->n_cu * 4;
-    if (pair_tier) NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * pair_grid);
+    if (pair_tier) NEED(W.pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * pair_grid);
     unsigned long long heads[4] = {0, 0, 0, 0};
     uint64_t n_jobs = 0;
     ta("lists and scratch");
@@ -3485,66 +3522,66 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, 2ull * nb + 64);
         const uint64_t cap_groups = std::max<uint64_t>(S->ogroups_cap, 4ull * nb + 64);
         const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, nb / 2 + 64);
-        NEED(S->bpath, ((size_t)4 * nb + path_cap) * sizeof(pf_bubble_path));
-        NEED(S->ptext, text_cap);
-        const uint64_t walk_cap = S->n_colors ? std::max<uint64_t>(S->walk_cap, (uint64_t)nb * 2 + 256ull * paths_grid + 1024) : 0;
+        NEED(W.bpath, ((size_t)4 * nb + path_cap) * sizeof(pf_bubble_path));
+        NEED(W.ptext, text_cap);
+        const uint64_t walk_cap = S->n_colors ? std::max<uint64_t>(W.walk_cap, (uint64_t)nb * 2 + 256ull * paths_grid + 1024) : 0;
         if (S->n_colors) {
-            NEED(S->walk_pool, walk_cap * 4);
-            NEED(S->walk_off, (size_t)nb * 8);
+            NEED(W.walk_pool, walk_cap * 4);
+            NEED(W.walk_off, (size_t)nb * 8);
         }
         NEED(O.otext, cap_text);
         NEED(O.osites, cap_sites * sizeof(pf_bubble_site));
         NEED(O.ogroups, cap_groups);
         NEED(O.oilen, cap_ilen * 4);
-        unsigned long long *d_heads = bubble_pool_heads(ctx);
+        unsigned long long *d_heads = bubble_pool_heads(ctx, lane);
         if (!d_heads) return PF_ERR_HIP;
         PF_HIP(hipMemsetAsync(d_cnt, 0, sizeof(CallCounters), st));
         PF_HIP(hipMemsetAsync(d_heads, 0, 32, st));
         PrepArgs pa;
         pa.ct = S->ctask.as<CallTask>(); pa.kept = S->kept.as<uint32_t>(); pa.t0 = t0; pa.nb = nb; pa.len = ctx->d_len;
-        pa.btask = S->btask.as<pf_bubble_task>(); pa.bpath = S->bpath.as<pf_bubble_path>(); pa.res = O.res.as<pf_bubble_result>();
-        pa.lists = CallLists{S->queues.as<uint32_t>(), S->blist.as<uint32_t>(), S->slist.as<uint32_t>(), S->plist.as<uint32_t>(), S->plist2.as<uint32_t>(), S->klist.as<uint32_t>(), S->klist_b.as<uint32_t>(), S->tlist.as<uint32_t>(), S->tlist4.as<uint32_t>(), nb};
+        pa.btask = W.btask.as<pf_bubble_task>(); pa.bpath = W.bpath.as<pf_bubble_path>(); pa.res = O.res.as<pf_bubble_result>();
+        pa.lists = CallLists{W.queues.as<uint32_t>(), W.blist.as<uint32_t>(), W.slist.as<uint32_t>(), W.plist.as<uint32_t>(), W.plist2.as<uint32_t>(), W.klist.as<uint32_t>(), W.klist_b.as<uint32_t>(), W.tlist.as<uint32_t>(), W.tlist4.as<uint32_t>(), nb};
         pa.snp_ok = snp_ok;
         pa.pair_ok = pair_tier ? 1 : 0;
         pa.stack_ok = stack_tier ? stack_level : 0;
         pa.trio_ok = trio_tier ? 1 : 0;
         pa.cnt = d_cnt;
-        ctx_begin(ctx, PF_K_CALL_PREP);
+        tbegin(PF_K_CALL_PREP, st);
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
-        ctx_end(ctx);
+        tend(st);
         // K-PATHS (branching bubbles) beside K-SNP and K-PAIR (two-path bubbles): latency-bound walks next to an issue-bound fill
         static const bool fork_paths = [] { const char *e = getenv("PF_PATHS_STREAM"); return !(e && e[0] == '0'); }();   // measurements
         hipStream_t pst = st;
         if (fork_paths) {
-            if (!S->side_stream) {
-                PF_HIP(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
-                PF_HIP(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
-                PF_HIP(hipEventCreateWithFlags(&S->ev_paths, hipEventDisableTiming));
+            if (!W.side_stream) {
+                PF_HIP(hipStreamCreateWithFlags(&W.side_stream, hipStreamNonBlocking));
+                PF_HIP(hipEventCreateWithFlags(&W.ev_prep, hipEventDisableTiming));
+                PF_HIP(hipEventCreateWithFlags(&W.ev_paths, hipEventDisableTiming));
             }
-            pst = S->side_stream;
-            PF_HIP(hipEventRecord(S->ev_prep, st));
-            PF_HIP(hipStreamWaitEvent(pst, S->ev_prep, 0));
+            pst = W.side_stream;
+            PF_HIP(hipEventRecord(W.ev_prep, st));
+            PF_HIP(hipStreamWaitEvent(pst, W.ev_prep, 0));
         }
         {
             PathArgs ph;
             ph.ct = pa.ct; ph.kept = pa.kept; ph.t0 = t0; ph.nb = nb; ph.blist = pa.lists.blist; ph.succ = ctx->d_succ; ph.seq = ctx->d_seq;
-            ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = S->paths_scr.as<uint8_t>();
+            ph.off = ctx->d_off; ph.len = ctx->d_len; ph.k = k; ph.depth_cap = depth_cap; ph.scratch = W.paths_scr.as<uint8_t>();
             ph.scratch_per_wave = paths_per_wave; ph.force_scratch = paths_force_scratch; ph.btask = pa.btask; ph.bpath = pa.bpath; ph.path_cap = path_cap;
-            ph.text = S->ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
+            ph.text = W.ptext.as<char>(); ph.text_cap = text_cap; ph.queues = pa.lists.queues; ph.cnt = d_cnt;
             ph.klist = pa.lists.klist_b; ph.stack_ok = pa.stack_ok;
             ph.tlist = pa.lists.tlist; ph.tlist4 = pa.lists.tlist4; ph.trio_ok = pa.trio_ok;
-            ph.walk_pool = S->n_colors ? S->walk_pool.as<uint32_t>() : nullptr; ph.walk_off = S->walk_off.as<uint64_t>(); ph.walk_cap = walk_cap;
-            ph.max_paths = MAX_PATHS; ph.n_list = &d_cnt->n_branching; ph.mlist = S->mlist.as<uint32_t>(); ph.mlist_cap = S->mlist_cap;
+            ph.walk_pool = S->n_colors ? W.walk_pool.as<uint32_t>() : nullptr; ph.walk_off = W.walk_off.as<uint64_t>(); ph.walk_cap = walk_cap;
+            ph.max_paths = MAX_PATHS; ph.n_list = &d_cnt->n_branching; ph.mlist = W.mlist.as<uint32_t>(); ph.mlist_cap = W.mlist_cap;
             ph_keep = ph;
             if (getenv("PF_TRACE_ALIGN_ARGS"))
                 fprintf(stderr, "[pf_call_align] K-PATHS args: ct %p kept %p blist %p succ %p seq %p off %p len %p scratch %p (%llu per wave, grid %d) n_list %p mlist %p walk_pool %p btask %p bpath %p text %p queues %p klist %p tlist %p tlist4 %p cnt %p depth_cap %u nb %u stack_ok %d trio_ok %d\n",
                         (const void *)ph.ct, (const void *)ph.kept, (const void *)ph.blist, (const void *)ph.succ, (const void *)ph.seq, (const void *)ph.off, (const void *)ph.len, (void *)ph.scratch,
                         (unsigned long long)ph.scratch_per_wave, paths_grid, (const void *)ph.n_list, (void *)ph.mlist, (void *)ph.walk_pool, (void *)ph.btask, (void *)ph.bpath, (void *)ph.text, (void *)ph.queues,
                         (void *)ph.klist, (void *)ph.tlist, (void *)ph.tlist4, (void *)ph.cnt, ph.depth_cap, ph.nb, ph.stack_ok, ph.trio_ok);
-            ctx_begin_on(ctx, PF_K_CALL_PATHS, pst);
+            tbegin(PF_K_CALL_PATHS, pst);
             k_call_paths<false><<<paths_grid, 64, 0, pst>>>(ph);
-            ctx_end_on(ctx, pst);
-            if (fork_paths) PF_HIP(hipEventRecord(S->ev_paths, pst));
+            tend(pst);
+            if (fork_paths) PF_HIP(hipEventRecord(W.ev_paths, pst));
         }
         if (snp_ok) {
             SnpArgs sn;
@@ -3552,25 +3589,25 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sn.len = ctx->d_len; sn.res = pa.res; sn.otext = O.otext.as<char>(); sn.text_cap = cap_text;
             sn.osites = O.osites.as<pf_bubble_site>(); sn.site_cap = cap_sites; sn.ogroups = O.ogroups.as<uint8_t>(); sn.group_cap = cap_groups;
             sn.heads = d_heads; sn.lists = pa.lists; sn.pair_ok = pa.pair_ok; sn.stack_ok = pa.stack_ok; sn.cnt = d_cnt;
-            ctx_begin(ctx, PF_K_CALL_SNP);
+            tbegin(PF_K_CALL_SNP, st);
             k_call_snp<<<(nb + 255) / 256, 256, 0, st>>>(sn);   // (the list length is on the device: surplus threads leave at once)
-            ctx_end(ctx);
+            tend(st);
         }
         StackArgs sk;
         if (stack_tier) {
             // K-STACK, first launch: the strict bubbles K-PREP and K-SNP listed (two paths that are not a single mismatch, three and
             // four paths); what it cannot certify is K-PAIR's (launched behind it), K-TRIO's or K-BUBBLE's
-            sk.list = pa.lists.klist; sk.n_list = &d_cnt->n_stack; sk.scratch = S->stack_scr.as<uint8_t>();
-            sk.btask = pa.btask; sk.bpath = pa.bpath; sk.ptext = S->ptext.as<char>();
+            sk.list = pa.lists.klist; sk.n_list = &d_cnt->n_stack; sk.scratch = W.stack_scr.as<uint8_t>();
+            sk.btask = pa.btask; sk.bpath = pa.bpath; sk.ptext = W.ptext.as<char>();
             sk.seq = ctx->d_seq; sk.off = ctx->d_off; sk.len = ctx->d_len;
             sk.M = (int)match; sk.D = (int)mismatch; sk.G = (int)gap;
             sk.res = pa.res; sk.otext = O.otext.as<char>(); sk.text_cap = cap_text; sk.osites = O.osites.as<pf_bubble_site>(); sk.site_cap = cap_sites;
             sk.ogroups = O.ogroups.as<uint8_t>(); sk.group_cap = cap_groups; sk.oilen = O.oilen.as<uint32_t>(); sk.ilen_cap = cap_ilen;
             sk.heads = d_heads; sk.lists = pa.lists; sk.cnt = d_cnt;
             sk.trio_ok = pa.trio_ok; sk.pair_ok = pa.pair_ok;
-            ctx_begin(ctx, PF_K_CALL_STACK);
+            tbegin(PF_K_CALL_STACK, st);
             k_call_stack<<<stack_grid, 64, 0, st>>>(sk);
-            ctx_end(ctx);
+            tend(st);
         }
         PairArgs pr;
         static const bool pair_stats = getenv("PF_PAIR_STATS") != nullptr;
@@ -3580,7 +3617,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             pr.M = match; pr.D = mismatch; pr.G = gap;
             pr.Mi = (int)match; pr.Di = (int)mismatch; pr.Gi = (int)gap;
             pr.list = pa.lists.plist; pr.n_list = &d_cnt->n_pair; pr.n_done = &d_cnt->n_pair_done;
-            pr.scratch = S->pair_scr.as<uint8_t>(); pr.res = pa.res; pr.otext = O.otext.as<char>(); pr.text_cap = cap_text;
+            pr.scratch = W.pair_scr.as<uint8_t>(); pr.res = pa.res; pr.otext = O.otext.as<char>(); pr.text_cap = cap_text;
             pr.osites = O.osites.as<pf_bubble_site>(); pr.site_cap = cap_sites; pr.ogroups = O.ogroups.as<uint8_t>(); pr.group_cap = cap_groups;
             pr.oilen = O.oilen.as<uint32_t>(); pr.ilen_cap = cap_ilen; pr.heads = d_heads; pr.lists = pa.lists; pr.cnt = d_cnt;
             pr.prof = nullptr;
@@ -3589,10 +3626,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
                 PF_HIP(hipMemsetAsync(prof_.p, 0, 64, st));
                 pr.prof = prof_.p;
             }
-            ctx_begin(ctx, PF_K_CALL_PAIR);
+            tbegin(PF_K_CALL_PAIR, st);
             if (pair_integral) k_call_pair<PAIR_MAX, true><<<pair_grid, 64, 0, st>>>(pr);
             else k_call_pair<PAIR_MAX, false><<<pair_grid, 64, 0, st>>>(pr);
-            ctx_end(ctx);
+            tend(st);
             if (pair_stats) {
                 unsigned long long h[8];
                 PF_HIP(hipMemcpy(h, prof_.p, 64, hipMemcpyDeviceToHost));
@@ -3600,14 +3637,14 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
                         h[0], h[1], h[2], h[3], h[4]);
             }
         }
-        if (fork_paths) PF_HIP(hipStreamWaitEvent(st, S->ev_paths, 0));
+        if (fork_paths) PF_HIP(hipStreamWaitEvent(st, W.ev_paths, 0));
         if (stack_tier) {
             // K-STACK, second launch: the branching bubbles K-PATHS listed (their two-path rejects cannot go to K-PAIR, which reads
             // the inner unitigs of a strict bubble: K-BUBBLE's)
             sk.list = pa.lists.klist_b; sk.n_list = &d_cnt->n_stack_b; sk.pair_ok = 0;
-            ctx_begin(ctx, PF_K_CALL_STACK);
+            tbegin(PF_K_CALL_STACK, st);
             k_call_stack<<<stack_grid, 64, 0, st>>>(sk);
-            ctx_end(ctx);
+            tend(st);
         }
         PF_HIP(hipGetLastError());
         PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
@@ -3624,12 +3661,12 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             if (hc.n_pair2 < (tier2_min ? tier2_min : (uint32_t)ctx->n_cu * 32u)) {
                 k_call_pair2_reroute<<<(hc.n_pair2 + 255) / 256, 256, 0, st>>>(pr);
             } else {
-                NEED(S->pair_scr2, PairGeom<PAIR_MAX2>::scratch_bytes * g2);
-                pr.scratch = S->pair_scr2.as<uint8_t>();
-                ctx_begin(ctx, PF_K_CALL_PAIR);
+                NEED(W.pair_scr2, PairGeom<PAIR_MAX2>::scratch_bytes * g2);
+                pr.scratch = W.pair_scr2.as<uint8_t>();
+                tbegin(PF_K_CALL_PAIR, st);
                 if (pair_integral) k_call_pair<PAIR_MAX2, true><<<g2, 64, 0, st>>>(pr);
                 else k_call_pair<PAIR_MAX2, false><<<g2, 64, 0, st>>>(pr);
-                ctx_end(ctx);
+                tend(st);
             }
             again = true;
         }
@@ -3638,30 +3675,30 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             // certify): one thread per (bubble, later path) aligns the path to path 0, one thread per bubble finishes
             const uint64_t n3 = hc.n_trio, n4 = hc.n_trio4, pairs = 2 * n3 + 3 * n4;
             const int ga = (int)std::min<uint64_t>((pairs + 63) / 64, (uint64_t)trio_grid);
-            NEED(S->trio_scr, PairGeom<TRIO_MAX>::scratch_bytes * ga);
-            NEED(S->trio_rows, (3 * n3 + 4 * n4) * TRIO_ROW);
-            NEED(S->trio_ok, n3 + n4);
-            PF_HIP(hipMemsetAsync(S->trio_ok.p, 1, n3 + n4, st));
+            NEED(W.trio_scr, PairGeom<TRIO_MAX>::scratch_bytes * ga);
+            NEED(W.trio_rows, (3 * n3 + 4 * n4) * TRIO_ROW);
+            NEED(W.trio_ok, n3 + n4);
+            PF_HIP(hipMemsetAsync(W.trio_ok.p, 1, n3 + n4, st));
             TrioArgs tr;
-            tr.btask = pa.btask; tr.bpath = pa.bpath; tr.ptext = S->ptext.as<char>();
+            tr.btask = pa.btask; tr.bpath = pa.bpath; tr.ptext = W.ptext.as<char>();
             tr.seq = ctx->d_seq; tr.off = ctx->d_off; tr.len = ctx->d_len;
             tr.M = (int)match; tr.D = (int)mismatch; tr.G = (int)gap;
-            tr.scratch = S->trio_scr.as<uint8_t>();
+            tr.scratch = W.trio_scr.as<uint8_t>();
             tr.res = pa.res; tr.otext = O.otext.as<char>(); tr.text_cap = cap_text; tr.osites = O.osites.as<pf_bubble_site>(); tr.site_cap = cap_sites;
             tr.ogroups = O.ogroups.as<uint8_t>(); tr.group_cap = cap_groups; tr.oilen = O.oilen.as<uint32_t>(); tr.ilen_cap = cap_ilen;
             tr.heads = d_heads; tr.lists = pa.lists; tr.cnt = d_cnt;
-            ctx_begin(ctx, PF_K_CALL_TRIO);
+            tbegin(PF_K_CALL_TRIO, st);
             if (n3) {
-                tr.list = pa.lists.tlist; tr.n_list = (uint32_t)n3; tr.rows = S->trio_rows.as<char>(); tr.okflag = S->trio_ok.as<uint8_t>();
+                tr.list = pa.lists.tlist; tr.n_list = (uint32_t)n3; tr.rows = W.trio_rows.as<char>(); tr.okflag = W.trio_ok.as<uint8_t>();
                 k_call_trio_align<3><<<(int)std::min<uint64_t>((2 * n3 + 63) / 64, (uint64_t)ga), 64, 0, st>>>(tr);
                 k_call_trio_finish<3><<<(unsigned)((n3 + 255) / 256), 256, 0, st>>>(tr);
             }
             if (n4) {
-                tr.list = pa.lists.tlist4; tr.n_list = (uint32_t)n4; tr.rows = S->trio_rows.as<char>() + 3 * n3 * TRIO_ROW; tr.okflag = S->trio_ok.as<uint8_t>() + n3;
+                tr.list = pa.lists.tlist4; tr.n_list = (uint32_t)n4; tr.rows = W.trio_rows.as<char>() + 3 * n3 * TRIO_ROW; tr.okflag = W.trio_ok.as<uint8_t>() + n3;
                 k_call_trio_align<4><<<(int)std::min<uint64_t>((3 * n4 + 63) / 64, (uint64_t)ga), 64, 0, st>>>(tr);
                 k_call_trio_finish<4><<<(unsigned)((n4 + 255) / 256), 256, 0, st>>>(tr);
             }
-            ctx_end(ctx);
+            tend(st);
             again = true;
         }
         if (again) {
@@ -3676,9 +3713,9 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         if (trio_tier) ctx_units(ctx, PF_K_CALL_TRIO, hc.n_trio + hc.n_trio4);
         ctx_units(ctx, PF_K_CALL_PATHS, hc.n_branching);
         if (getenv("PF_TRACE_ALIGN")) fprintf(stderr, "[pf_call_align] bubbles of more than 255 walks: %u, err %u\n", hc.n_many, hc.err);
-        if (hc.n_many > S->mlist_cap && !(hc.err & 33u)) {
-            S->mlist_cap = hc.n_many + hc.n_many / 8 + 64;
-            NEED(S->mlist, (size_t)S->mlist_cap * 4);
+        if (hc.n_many > W.mlist_cap && !(hc.err & 33u)) {
+            W.mlist_cap = hc.n_many + hc.n_many / 8 + 64;
+            NEED(W.mlist, (size_t)W.mlist_cap * 4);
             continue;
         }
         if (hc.n_many && !(hc.err & 33u)) {
@@ -3686,13 +3723,13 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             const uint32_t n_many = hc.n_many;
             const int big_grid = (int)std::min<uint32_t>(n_many, 32);
             const uint64_t big_per_wave = (((((uint64_t)10 * depth_cap + 4) * 4 + 7) & ~7ull) + ((uint64_t)PATHS_BIG + 1) * 12 + 255) & ~255ull;
-            NEED(S->paths_big_scr, big_per_wave * big_grid);
+            NEED(W.paths_big_scr, big_per_wave * big_grid);
             PathArgs pb = ph_keep;
-            pb.blist = S->mlist.as<uint32_t>(); pb.n_list = &d_cnt->n_many; pb.max_paths = PATHS_BIG; pb.mlist = nullptr; pb.mlist_cap = 0;
-            pb.scratch = S->paths_big_scr.as<uint8_t>(); pb.scratch_per_wave = big_per_wave;
-            ctx_begin(ctx, PF_K_CALL_PATHS);
+            pb.blist = W.mlist.as<uint32_t>(); pb.n_list = &d_cnt->n_many; pb.max_paths = PATHS_BIG; pb.mlist = nullptr; pb.mlist_cap = 0;
+            pb.scratch = W.paths_big_scr.as<uint8_t>(); pb.scratch_per_wave = big_per_wave;
+            tbegin(PF_K_CALL_PATHS, st);
             k_call_paths<true><<<big_grid, 64, 0, st>>>(pb);
-            ctx_end(ctx);
+            tend(st);
             PF_HIP(hipGetLastError());
             PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
             PF_HIP(hipStreamSynchronize(st));
@@ -3704,45 +3741,45 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             pf::CtxErr{ctx} = std::string(hc.err & 1u ? "pf_call_run: a bubble has more than 65535 paths" : "pf_call_run: a bubble is deeper than the complex size allows") + where;
             return PF_ERR_ARG;
         }
-        S->otext_cap = std::max(S->otext_cap, cap_text); S->osites_cap = std::max(S->osites_cap, cap_sites);
-        S->ogroups_cap = std::max(S->ogroups_cap, cap_groups); S->oilen_cap = std::max(S->oilen_cap, cap_ilen);
-        S->path_pool = std::max(S->path_pool, path_cap);
-        S->text_pool = std::max(S->text_pool, text_cap);
+        amax(S->otext_cap, cap_text); amax(S->osites_cap, cap_sites);
+        amax(S->ogroups_cap, cap_groups); amax(S->oilen_cap, cap_ilen);
+        amax(S->path_pool, path_cap);
+        amax(S->text_pool, text_cap);
         static const bool trace_retry = getenv("PF_TRACE_ALIGN") != nullptr;
         if (trace_retry)
             fprintf(stderr, "[pf_call_align] attempt %d: %u bubbles, path pool %llu of %llu, path text %llu of %llu, rows text cap %llu (needs %llu)\n", attempt, nb,
                     (unsigned long long)hc.path_head, (unsigned long long)path_cap, (unsigned long long)hc.text_head, (unsigned long long)text_cap,
                     (unsigned long long)cap_text, (unsigned long long)(3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb));
         if (hc.path_head > path_cap || hc.text_head > text_cap || hc.walk_head > walk_cap) {
-            S->path_pool = std::max<uint64_t>(S->path_pool, hc.path_head + hc.path_head / 8 + 1024);
-            S->text_pool = std::max<uint64_t>(S->text_pool, hc.text_head + hc.text_head / 8 + 4096);
-            if (S->n_colors) S->walk_cap = std::max<uint64_t>(S->walk_cap, hc.walk_head + hc.walk_head / 8 + 1024);
+            amax(S->path_pool, hc.path_head + hc.path_head / 8 + 1024);
+            amax(S->text_pool, hc.text_head + hc.text_head / 8 + 4096);
+            if (S->n_colors) W.walk_cap = std::max<uint64_t>(W.walk_cap, hc.walk_head + hc.walk_head / 8 + 1024);
             continue;
         }
-        if (S->n_colors) S->walk_cap = std::max(S->walk_cap, walk_cap);
+        if (S->n_colors) W.walk_cap = std::max(W.walk_cap, walk_cap);
         // the aligned rows of the branching bubbles come on top of what K-SNP took: make room before K-BUBBLE runs
         // (the path text is handed out in per-wavefront chunks: its size varies by a few per mille from pass to pass, hence the margin)
         if (cap_text < 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb) {
             const uint64_t need = 3 * hc.text_head + 128ull * hc.n_branching + 160ull * nb;
-            S->otext_cap = need + need / 16 + 4096;
+            amax(S->otext_cap, need + need / 16 + 4096);
             continue;
         }
         n_jobs = 0;
         for (int x = 0; x < NQ; ++x) n_jobs += hc.q_n[x];
         // K-BUBBLE: the queues are heavy-then-light per class; compact them into one index array
-        NEED(S->scan_tmp2, std::max<size_t>((size_t)n_jobs, 1) * 4);
+        NEED(W.scan_tmp2, std::max<size_t>((size_t)n_jobs, 1) * 4);
         {
-            uint32_t *d_idx = S->scan_tmp2.as<uint32_t>();
+            uint32_t *d_idx = W.scan_tmp2.as<uint32_t>();
             size_t at = 0;
             for (int x = 0; x < NQ; ++x) {
                 if (!hc.q_n[x]) continue;
-                PF_HIP(hipMemcpyAsync(d_idx + at, S->queues.as<uint32_t>() + (size_t)x * nb, (size_t)hc.q_n[x] * 4, hipMemcpyDeviceToDevice, st));
+                PF_HIP(hipMemcpyAsync(d_idx + at, W.queues.as<uint32_t>() + (size_t)x * nb, (size_t)hc.q_n[x] * 4, hipMemcpyDeviceToDevice, st));
                 at += hc.q_n[x];
             }
         }
         BubbleLaunch BL;
-        BL.text = S->ptext.as<char>(); BL.paths = S->bpath.as<pf_bubble_path>(); BL.tasks = S->btask.as<pf_bubble_task>();
-        BL.n_tasks = nb; BL.idx = S->scan_tmp2.as<uint32_t>();
+        BL.text = W.ptext.as<char>(); BL.paths = W.bpath.as<pf_bubble_path>(); BL.tasks = W.btask.as<pf_bubble_task>();
+        BL.n_tasks = nb; BL.idx = W.scan_tmp2.as<uint32_t>();
         for (int c = 0; c <= kBubLdsClasses; ++c) BL.n_cls[c] = hc.q_n[2 * c] + hc.q_n[2 * c + 1];
         BL.max_need = hc.max_need; BL.retry_need = hc.retry_need;
         BL.match = match; BL.mismatch = mismatch; BL.gap = gap;
@@ -3750,6 +3787,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         BL.ogroups = O.ogroups.as<uint8_t>(); BL.oilen = O.oilen.as<uint32_t>();
         BL.text_cap = cap_text; BL.site_cap = cap_sites; BL.group_cap = cap_groups; BL.ilen_cap = cap_ilen;
         BL.keep_heads = true;
+        BL.lane = lane; BL.stream = st;
         ta("K-BUBBLE launching");
         const int bst = bubble_launch(ctx, BL, heads);
         ta("K-BUBBLE done");
@@ -3757,10 +3795,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             fprintf(stderr, "[pf_call_align] attempt %d: K-BUBBLE status %d, pools text %llu of %llu, sites %llu of %llu, groups %llu of %llu, indel lengths %llu of %llu\n", attempt, bst,
                     heads[0], (unsigned long long)cap_text, heads[1], (unsigned long long)cap_sites, heads[2], (unsigned long long)cap_groups, heads[3], (unsigned long long)cap_ilen);
         if (bst == PF_ERR_OVERFLOW && (heads[0] > cap_text || heads[1] > cap_sites || heads[2] > cap_groups || heads[3] > cap_ilen)) {
-            S->otext_cap = std::max<uint64_t>(S->otext_cap, heads[0] + heads[0] / 8);
-            S->osites_cap = std::max<uint64_t>(S->osites_cap, heads[1] + heads[1] / 8);
-            S->ogroups_cap = std::max<uint64_t>(S->ogroups_cap, heads[2] + heads[2] / 8);
-            S->oilen_cap = std::max<uint64_t>(S->oilen_cap, heads[3] + heads[3] / 8);
+            amax(S->otext_cap, heads[0] + heads[0] / 8);
+            amax(S->osites_cap, heads[1] + heads[1] / 8);
+            amax(S->ogroups_cap, heads[2] + heads[2] / 8);
+            amax(S->oilen_cap, heads[3] + heads[3] / 8);
             continue;
         }
         if (bst != PF_OK) return bst;
@@ -3772,11 +3810,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     out->trio_jobs = hc.n_trio_done;
 
     // ---- bubble numbering inside the batch (launched ahead of K-SITES, read with its counters: one wait for both) ----
-    k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(O.res.as<pf_bubble_result>(), nb, S->has.as<uint32_t>());
+    k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(O.res.as<pf_bubble_result>(), nb, W.has.as<uint32_t>());
     size_t tmp1 = 0;
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
-    NEED(S->scan_tmp, tmp1);
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(S->scan_tmp.p, tmp1, S->has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, W.has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
+    NEED(W.scan_tmp, tmp1);
+    PF_HIP(hipcub::DeviceScan::InclusiveSum(W.scan_tmp.p, tmp1, W.has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
     uint32_t n_called = 0;
     PF_HIP(hipMemcpyAsync(&n_called, O.vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
 
@@ -3784,7 +3822,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     // (a site string is k characters long unless it takes the raw columns up to its row's end -- substr with a negative count,
     // src/CDBG.cpp:1499 -- or more than k characters agree behind an indel: a launch that meets one longer than its room says how
     // long, ks_need, and is repeated with that much)
-    uint32_t KS = std::max<uint32_t>((uint32_t)(2 * k + 64), S->sites_ks);
+    uint32_t KS = std::max<uint32_t>((uint32_t)(2 * k + 64), S->sites_ks.load());
     if (hc.n_branching) {
         const uint32_t C = S->n_colors;
         const uint64_t rows_cap = std::max<uint64_t>(256, ((uint64_t)hc.max_rows + 63) & ~63ull);
@@ -3793,21 +3831,21 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8) + (C ? rows_cap * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
             // (tables for thousands of rows: fewer wavefronts, at most 2 GB of them)
             const int sites_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu)), (2ull << 30) / sites_per_wave));
-            NEED(S->sites_scr, sites_per_wave * sites_grid);
+            NEED(W.sites_scr, sites_per_wave * sites_grid);
             const uint64_t sv_cap = std::max<uint64_t>(S->sv_pool, 8ull * std::max<uint32_t>(C, 1) * hc.n_branching + 1024ull * sites_grid + 1024);   // (a started chunk per wavefront)
             NEED(O.sv, sv_cap * 8);
             SiteArgs sa;
-            sa.ct = S->ctask.as<CallTask>(); sa.kept = S->kept.as<uint32_t>(); sa.t0 = t0; sa.blist = S->blist.as<uint32_t>();
+            sa.ct = S->ctask.as<CallTask>(); sa.kept = S->kept.as<uint32_t>(); sa.t0 = t0; sa.blist = W.blist.as<uint32_t>();
             sa.res = O.res.as<pf_bubble_result>(); sa.otext = O.otext.as<char>(); sa.osites = O.osites.as<pf_bubble_site>();
             sa.ogroups = O.ogroups.as<uint8_t>(); sa.k = k; sa.tab = ctx->d_tab; sa.mask = ctx->tab_cap - 1;
             sa.one_strand = ctx->tab_one_strand; sa.tab_exact = ctx->tab_exact; sa.low = S->low; sa.up = S->up; sa.ks = KS; sa.rows_cap = (uint32_t)rows_cap;
-            sa.scratch = S->sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
+            sa.scratch = W.sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
             sa.sv = O.sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
             sa.n_colors = C;
             sa.ctab = CTab{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift}; sa.c_one_strand = ctx->ctab_one_strand; sa.c_unread = ctx->ctab_unread;
             sa.clow = S->col_low.as<uint32_t>(); sa.cup = S->col_up.as<uint32_t>(); sa.full = S->col_full.as<uint64_t>();
             sa.part_first = S->part_first.as<uint32_t>(); sa.part_colour = S->part_colour.as<uint32_t>(); sa.part_word = S->part_word.as<uint64_t>();
-            sa.part_bits = S->part_bits.as<uint64_t>(); sa.walk_pool = S->walk_pool.as<uint32_t>(); sa.walk_off = S->walk_off.as<uint64_t>();
+            sa.part_bits = S->part_bits.as<uint64_t>(); sa.walk_pool = W.walk_pool.as<uint32_t>(); sa.walk_off = W.walk_off.as<uint64_t>();
             sa.seq = ctx->d_seq; sa.off = ctx->d_off; sa.len = ctx->d_len;
             static const bool sites_stats = getenv("PF_SITES_STATS") != nullptr;   // measurements: where a wavefront's time goes
             DevTmp<unsigned long long> sprof_;
@@ -3820,10 +3858,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             PF_HIP(hipMemsetAsync(&d_cnt->sites_next, 0, 4, st));
             PF_HIP(hipMemsetAsync(&d_cnt->sv_head, 0, 8, st));
             PF_HIP(hipMemsetAsync(&d_cnt->site_strings, 0, 8, st));
-            ctx_begin(ctx, PF_K_CALL_SITES);
+            tbegin(PF_K_CALL_SITES, st);
             if (C) k_call_sites<true><<<sites_grid, 64, 0, st>>>(sa);
             else k_call_sites<false><<<sites_grid, 64, 0, st>>>(sa);
-            ctx_end(ctx);
+            tend(st);
             ctx_units(ctx, PF_K_CALL_SITES, hc.n_branching);
             PF_HIP(hipGetLastError());
             if (sa.prof) {
@@ -3844,7 +3882,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             if (hc.err & 16u) {
                 if (++ks_attempt > 3 || hc.ks_need <= KS) { pf::CtxErr{ctx} = "pf_call_run: the room for a site string does not converge"; return PF_ERR_OVERFLOW; }
                 KS = (hc.ks_need + 63u) & ~63u;
-                S->sites_ks = KS;
+                amax(S->sites_ks, KS);
                 hc.err = 0; hc.ks_need = 0;   // (the other bits are looked at when every string had room: a string cut short has no verdict)
                 PF_HIP(hipMemsetAsync(&d_cnt->err, 0, 4, st));
                 PF_HIP(hipMemsetAsync(&d_cnt->ks_need, 0, 4, st));
@@ -3856,10 +3894,10 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             if (hc.err & 64u) { pf::CtxErr{ctx} = "CCDBG::PloidyEstimation(): a site string does not start on a unitig of its bubble"; return PF_ERR_ARG; }
             if (hc.sv_head > sv_cap) {
                 if (attempt >= 2) { pf::CtxErr{ctx} = "pf_call_run: site value pool does not converge"; return PF_ERR_OVERFLOW; }
-                S->sv_pool = hc.sv_head + hc.sv_head / 8 + 1024;
+                amax(S->sv_pool, hc.sv_head + hc.sv_head / 8 + 1024);
                 continue;
             }
-            S->sv_pool = std::max(S->sv_pool, sv_cap);
+            amax(S->sv_pool, sv_cap);
             break;
         }
     } else {
@@ -3880,7 +3918,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
 
 int pf_call_peek(pf_ctx *ctx, int lane, pf_call_bubble *bubbles, pf_bubble_result *results, uint64_t *sv_off, uint64_t bubble_cap, char *text,
                  pf_bubble_site *sites, uint8_t *groups, uint32_t *ilen, double *sv, const uint64_t cap[5], uint64_t used[6]) {
-    if (!ctx || lane < 0 || lane > 1 || !used) return PF_ERR_ARG;
+    if (!ctx || lane < 0 || lane >= PF_CALL_LANES || !used) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S) { pf::CtxErr{ctx} = "pf_call_peek: pf_call_align first"; return PF_ERR_ARG; }
     if (S->n_colors) { pf::CtxErr{ctx} = "pf_call_peek: the single-sample path's view (a colored site holds one value per colour and group)"; return PF_ERR_ARG; }
@@ -3919,26 +3957,33 @@ int pf_call_peek(pf_ctx *ctx, int lane, pf_call_bubble *bubbles, pf_bubble_resul
 // The buffers pf_call_align_lane asks for on its first call for ranges of up to nb bubbles, taken NOW (a caller does this beside the
 // load): a first pass then starts with its pools in place instead of two dozen hipMallocs, 20 ms at 5 M unitigs.  Sizes are the
 // first-call formulas of pf_call_align_lane; whatever turns out too small there grows as before.
-int pf_call_reserve(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size) {
-    if (!ctx || nb64 == 0) return PF_ERR_ARG;
+int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int n_lanes) {
+    if (!ctx || nb64 == 0 || n_lanes < 1 || n_lanes > PF_CALL_LANES) return PF_ERR_ARG;
     CallState *S = state_of(ctx);
     PF_HIP(hipSetDevice(ctx->device));
     const uint32_t nb = (uint32_t)std::min<uint64_t>(nb64, 1u << 24);
     const char *oom = "pf_call_reserve: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
-    NEED(S->counters, sizeof(CallCounters));
-    NEED(S->btask, (size_t)nb * sizeof(pf_bubble_task));
-    NEED(S->queues, (size_t)NQ * nb * 4);
-    for (DevBuf *b : {&S->blist, &S->slist, &S->plist, &S->plist2, &S->klist, &S->klist_b, &S->tlist, &S->tlist4, &S->has}) NEED(*b, (size_t)nb * 4);
-    NEED(S->stack_scr, stack_scratch_bytes() * (uint64_t)(ctx->n_cu * 8));
-    const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
-    const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (10ull * depth_cap + 4) * 4) + 255) & ~255ull;
-    NEED(S->paths_scr, paths_per_wave * (uint64_t)(ctx->n_cu * 16));
-    NEED(S->pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * (uint64_t)(ctx->n_cu * 12));
-    NEED(S->bpath, ((size_t)4 * nb + (uint64_t)nb / 2 + 128ull * (ctx->n_cu * 16) + 1024) * sizeof(pf_bubble_path));
-    NEED(S->ptext, (uint64_t)nb * 32 + (1u << 16));
-    NEED(S->scan_tmp2, (size_t)nb / 4 * 4 + 4096);
-    for (CallState::AlignOut &O : S->lane) {
+    for (int lane = 0; lane < n_lanes; ++lane) {
+        CallState::AlignWork &W = S->work[lane];
+        NEED(W.counters, sizeof(CallCounters));
+        NEED(W.btask, (size_t)nb * sizeof(pf_bubble_task));
+        NEED(W.queues, (size_t)NQ * nb * 4);
+        for (DevBuf *b : {&W.blist, &W.slist, &W.plist, &W.plist2, &W.klist, &W.klist_b, &W.tlist, &W.tlist4, &W.has}) NEED(*b, (size_t)nb * 4);
+        NEED(W.stack_scr, stack_scratch_bytes() * (uint64_t)(ctx->n_cu * 8));
+        const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
+        const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (10ull * depth_cap + 4) * 4) + 255) & ~255ull;
+        NEED(W.paths_scr, paths_per_wave * (uint64_t)(ctx->n_cu * 16));
+        NEED(W.pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * (uint64_t)(ctx->n_cu * 12));
+        NEED(W.bpath, ((size_t)4 * nb + (uint64_t)nb / 2 + 128ull * (ctx->n_cu * 16) + 1024) * sizeof(pf_bubble_path));
+        NEED(W.ptext, (uint64_t)nb * 32 + (1u << 16));
+        NEED(W.scan_tmp2, (size_t)nb / 4 * 4 + 4096);
+        {   // K-SITES' tables for bubbles of up to 256 walks (single-sample)
+            const uint64_t KS = (uint64_t)(2 * ctx->k + 64), rows_cap = 256;
+            const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8)) + 255) & ~255ull;
+            NEED(W.sites_scr, sites_per_wave * (uint64_t)(ctx->n_cu * 16));
+        }
+        CallState::AlignOut &O = S->lane[lane];
         NEED(O.res, (size_t)nb * sizeof(pf_bubble_result));
         NEED(O.sv_off, (size_t)nb * 8);
         NEED(O.vc, (size_t)nb * 4);
@@ -3947,20 +3992,23 @@ int pf_call_reserve(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size) {
         NEED(O.ogroups, 4ull * nb + 64);
         NEED(O.oilen, ((uint64_t)nb / 2 + 64) * 4);
         NEED(O.sv, ((uint64_t)nb / 4 + 1024ull * ctx->n_cu * 16 + 1024) * 8);
-    }
-    {   // K-SITES' tables for bubbles of up to 256 walks (single-sample), K-SCAN's scan space
-        const uint64_t KS = (uint64_t)(2 * ctx->k + 64), rows_cap = 256;
-        const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8)) + 255) & ~255ull;
-        NEED(S->sites_scr, sites_per_wave * (uint64_t)(ctx->n_cu * 16));
+        if (!W.stream) {
+            if (lane == 0) W.stream = ctx->stream;
+            else { PF_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking)); W.own_stream = true; }
+        }
+        if (!W.side_stream) {
+            PF_HIP(hipStreamCreateWithFlags(&W.side_stream, hipStreamNonBlocking));
+            PF_HIP(hipEventCreateWithFlags(&W.ev_prep, hipEventDisableTiming));
+            PF_HIP(hipEventCreateWithFlags(&W.ev_paths, hipEventDisableTiming));
+        }
+        const int st = bubble_reserve(ctx, nb, lane);
+        if (st != PF_OK) return st;
     }
 #undef NEED
-    if (!S->side_stream) {
-        PF_HIP(hipStreamCreateWithFlags(&S->side_stream, hipStreamNonBlocking));
-        PF_HIP(hipEventCreateWithFlags(&S->ev_prep, hipEventDisableTiming));
-        PF_HIP(hipEventCreateWithFlags(&S->ev_paths, hipEventDisableTiming));
-    }
-    return bubble_reserve(ctx, nb);
+    return PF_OK;
 }
+
+int pf_call_reserve(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size) { return pf_call_reserve_lanes(ctx, nb64, complex_size, 2); }
 
 int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, double match, double mismatch, double gap,
                   pf_call_result *out) {
@@ -4003,10 +4051,10 @@ int pf_call_reserve_text(pf_ctx *ctx, uint64_t piece_bubbles) {
 }
 
 static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint64_t count, uint64_t var_count_base, pf_call_result *out, bool sizes_only) {
-    if (!ctx || !out || slab < 0 || slab >= PF_CALL_SLABS || lane < 0 || lane > 1) return PF_ERR_ARG;
+    if (!ctx || !out || slab < 0 || slab >= PF_CALL_SLABS || lane < 0 || lane >= PF_CALL_LANES) return PF_ERR_ARG;
     CallState *S = ctx->call;
     if (!S) return PF_ERR_ARG;
-    const CallState::AlignOut &O = S->lane[lane];
+    CallState::AlignOut &O = S->lane[lane];
     if (first + count > O.nb) { pf::CtxErr{ctx} = "pf_call_text_range: range outside the aligned batch"; return PF_ERR_ARG; }
     if (S->n_colors && S->mt_format) { pf::CtxErr{ctx} = "pf_call_text_range: the -t > 1 format is the single-sample path's"; return PF_ERR_ARG; }
     if (!sizes_only)
@@ -4099,6 +4147,9 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     // pass queues behind it on this one
     if (!S->text_ev[slab]) PF_HIP(hipEventCreateWithFlags(&S->text_ev[slab], hipEventDisableTiming));
     PF_HIP(hipEventRecord(S->text_ev[slab], st));
+    // ... and neither does the caller, who may hand the lane to the next pf_call_align_lane at once: that call's stream waits here
+    if (!O.read_ev) PF_HIP(hipEventCreateWithFlags(&O.read_ev, hipEventDisableTiming));
+    PF_HIP(hipEventRecord(O.read_ev, st));
     for (int x = 0; x < 4; ++x) out->allele[x] = hc.allele[x];
     out->core_cov = hc.core_cov;
     out->core_num = hc.core_num;

@@ -98,9 +98,10 @@ struct pf_ctx {
     bool gmm_loaded = false;
 
     pf::CallState *call = nullptr;
-    // K-BUBBLE: one stream per LDS size class (pf_bubble.hip), [6] = the event the class streams wait for
-    hipStream_t bub_streams[12] = {};   // (pf_bubble_launch.hpp: kBubMaxClasses)
-    hipEvent_t bub_events[13] = {};
+    // K-BUBBLE: one stream per LDS size class (pf_bubble.hip), [classes] = the event the class streams wait for; a set per lane of
+    // the calling pipeline (PF_CALL_LANES)
+    hipStream_t bub_streams[PF_CALL_LANES][12] = {};   // (pf_bubble_launch.hpp: kBubMaxClasses)
+    hipEvent_t bub_events[PF_CALL_LANES][13] = {};
 
     // K-CC (pf_cc.hip): union-find over unitig sides for the parallel commit replay; the records and vertex pool of the last
     // K-BFS call as they lie in the workspace
@@ -158,7 +159,7 @@ void ctx_end_on(pf_ctx *ctx, hipStream_t stream);
 // the same for a caller that keeps the place of its launch itself: any thread, any stream
 int ctx_begin_at(pf_ctx *ctx, int kernel, hipStream_t stream, size_t *at);
 void ctx_end_at(pf_ctx *ctx, size_t at, hipStream_t stream);
-inline void ctx_units(pf_ctx *ctx, int kernel, uint64_t n) { if (ctx->timing) ctx->units[kernel] += n; }
+inline void ctx_units(pf_ctx *ctx, int kernel, uint64_t n) { if (ctx->timing) __atomic_fetch_add(&ctx->units[kernel], n, __ATOMIC_RELAXED); }
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
 int join_graph_counts(pf_ctx *ctx);
 int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the joined table of all colours (pf_ctx::d_gcov_c)  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
@@ -177,6 +178,14 @@ enum WsSlot {
     WS_BFS_RES_REC, WS_BFS_RES_POOL,
     WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS,
     WS_BUB_TEXT, WS_BUB_PATHS, WS_BUB_TASKS, WS_BUB_SMALL, WS_BUB_RETRY, WS_BUB_IDX, WS_BUB_RES, WS_BUB_OTEXT, WS_BUB_OSITES,
-    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_BUB_IDX2, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART, WS_COUNT_
+    WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_BUB_IDX2, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART,
+    WS_BUB_LANES,   // K-BUBBLE's five launch workspaces (small, retry, scratch, work, idx2) of lanes 1 .. PF_CALL_LANES - 1 (bub_ws)
+    WS_COUNT_ = WS_BUB_LANES + 5 * (PF_CALL_LANES - 1)
 };
+// K-BUBBLE's launch workspaces: lane 0 uses the slots of old, the other lanes their own
+inline int bub_ws(int slot, int lane) {
+    if (lane == 0) return slot;
+    const int j = slot == WS_BUB_SMALL ? 0 : slot == WS_BUB_RETRY ? 1 : slot == WS_BUB_SCRATCH ? 2 : slot == WS_BUB_WORK ? 3 : 4;
+    return WS_BUB_LANES + 5 * (lane - 1) + j;
+}
 }  // namespace pf

@@ -659,7 +659,10 @@ void ctx_end_at(pf_ctx *ctx, size_t at, hipStream_t stream) {
 }
 
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes) {
-    if (ctx->ws.size() < (size_t)WS_COUNT_) ctx->ws.resize(WS_COUNT_, {nullptr, 0});
+    {
+        std::lock_guard<std::mutex> lk(ctx->launch_mu);   // (pf_call_align_lane on two lanes may ask for their first workspace at once)
+        if (ctx->ws.size() < (size_t)WS_COUNT_) ctx->ws.resize(WS_COUNT_, {nullptr, 0});
+    }
     auto &w = ctx->ws[slot];
     if (w.second >= bytes && w.first) return w.first;
     if (w.first) { hipFree(w.first); w.first = nullptr; w.second = 0; }
@@ -841,8 +844,8 @@ void pf_destroy(pf_ctx *ctx) {
     for (auto &w : ctx->ws) hipFree(w.first);
     if (ctx->h_live) hipHostFree(ctx->h_live);
     if (ctx->copy_stream) { hipStreamSynchronize(ctx->copy_stream); hipStreamDestroy(ctx->copy_stream); }
-    for (auto &s : ctx->bub_streams) if (s) hipStreamDestroy(s);
-    for (auto &e : ctx->bub_events) if (e) hipEventDestroy(e);
+    for (auto &lane : ctx->bub_streams) for (auto &s : lane) if (s) hipStreamDestroy(s);
+    for (auto &lane : ctx->bub_events) for (auto &e : lane) if (e) hipEventDestroy(e);
     hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }

@@ -191,7 +191,10 @@ def test_wrong_number_of_cutoffs_is_an_error(tmp_path):
         run.ploidy_estimation("g", meta["cutoffs"][:-1])
 
 
-def test_pipeline_batches_colored(tmp_path):
+@pytest.mark.parametrize("aligners", ["1", "3"])
+def test_pipeline_batches_colored(aligners, tmp_path, monkeypatch):
+    monkeypatch.setenv("PF_ALIGN_RANGES", "7")
+    monkeypatch.setenv("PF_ALIGN_THREADS", aligners)   # (aligners side by side, a lane each: walk pools and colour tables per lane)
     meta = load_case("col2_weird")
     op = meta["opts"]
     run = hostapi.ColoredRun(meta["gfa"], meta["colors"], meta["dbs"], str(tmp_path), z=int(op["-z"]), M=float(op["-M"]),
@@ -200,9 +203,10 @@ def test_pipeline_batches_colored(tmp_path):
     run.set_threads(4)
     run.set_output_dir(str(tmp_path / "out"))
     run.set_unitig_id("g")
-    run.find_superbubbles("g")
-    run.ploidy_estimation("g", meta["cutoffs"])
-    assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path / "out"))
+    for _ in range(3):
+        run.find_superbubbles("g")
+        run.ploidy_estimation("g", meta["cutoffs"])
+        assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path / "out"))
 
 
 @pytest.mark.parametrize("case", colored_cases())

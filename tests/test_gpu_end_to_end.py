@@ -167,12 +167,14 @@ def test_pipeline_batches_do_not_change_a_byte(case, batch, tmp_path):
         assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(tmp_path))
 
 
-@pytest.mark.parametrize("ranges", ["2", "3", "5"])
-def test_align_ranges_and_text_lanes_soak(ranges, tmp_path, monkeypatch):
-    """The calling pipeline is four threads -- align range r + 1 | format range r | fetch | write -- over two result lanes and
-    four device slabs.  Tiny pieces (4 bubbles) and forced range counts make every hand-over happen dozens of times per pass;
-    forty passes must give the reference's bytes every time."""
+@pytest.mark.parametrize("ranges,aligners", [("2", "1"), ("3", "1"), ("5", "1"), ("6", "2"), ("9", "4"), ("13", "3")])
+def test_align_ranges_and_text_lanes_soak(ranges, aligners, tmp_path, monkeypatch):
+    """The calling pipeline is four threads and more -- aligners (PF_ALIGN_THREADS of them, each pf_call_align_lane on a lane of
+    its own) | format range r | fetch | write -- over PF_CALL_LANES result lanes and four device slabs.  Tiny pieces (4 bubbles)
+    and forced range counts make every hand-over happen dozens of times per pass; forty passes must give the reference's bytes
+    every time."""
     monkeypatch.setenv("PF_ALIGN_RANGES", ranges)
+    monkeypatch.setenv("PF_ALIGN_THREADS", aligners)
     meta = load_case("tet60k")
     op = meta["opts"]
     run = hostapi.Run(meta["gfa"], meta["db"], z=int(op["-z"]), M=float(op["-M"]), D=float(op["-D"]), G=float(op["-G"]))
