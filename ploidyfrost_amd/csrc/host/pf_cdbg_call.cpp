@@ -490,19 +490,26 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         if (n_ranges > 1) ALIGN = std::min<uint64_t>(ALIGN, std::max<uint64_t>(1, (pieces + n_ranges - 1) / n_ranges) * CHUNK);
     }
     int first_env = [] { const char *e = getenv("PF_ALIGN_FIRST"); return e ? atoi(e) : 0; }();   // measurements: pieces in the first range
+    const int LANES = [] { const char *e = getenv("PF_ALIGN_LANES"); return e ? std::max(1, std::min(PF_CALL_LANES, atoi(e))) : PF_CALL_LANES; }();   // measurements
+    // aligner threads: pf_call_align_lane on that many lanes side by side (below)
+    const int aligners_wanted = [&] { const char *e = getenv("PF_ALIGN_THREADS"); return e ? std::max(1, std::min(LANES, atoi(e))) : std::min(2, LANES); }();
     {
-        // Two ranges are not cut in the middle: what a pass ends with is the PCIe copy of the LAST range's text (0.8 ms per piece, nothing
-        // beside it), so the first range takes five eighths of the pieces (tools/ab_pass.py PF_ALIGN_FIRST: 5 + 3 of eight pieces 20.08 ms,
-        // 4 + 4 20.28, 6 + 2 20.50, 3 + 5 20.90)
+        // Where two ranges are cut.  One aligner: what a pass ends with is the text of the LAST range, formatted and copied with nothing
+        // beside it, so the first range takes five eighths of the pieces (tools/ab_pass.py PF_ALIGN_FIRST: 5 + 3 of eight pieces
+        // 20.08 ms, 4 + 4 20.28, 6 + 2 20.50, 3 + 5 20.90).  Two aligners: both ranges are on the device from the start and end
+        // within half a millisecond of each other; in halves (4 + 4 17.19 ms, 5 + 3 17.66, 3 + 5 17.45, 2 + 6 17.89).
         const uint64_t pieces = (n_tasks + CHUNK - 1) / CHUNK;
-        if (first_env <= 0 && !getenv("PF_ALIGN_RANGES") && pieces >= 4) first_env = (int)std::min<uint64_t>((pieces * 5 + 7) / 8, ((uint64_t)1 << 24) / CHUNK);
+        if (first_env <= 0 && !getenv("PF_ALIGN_RANGES") && pieces >= 4)
+            first_env = (int)std::min<uint64_t>(aligners_wanted >= 2 ? (pieces + 1) / 2 : (pieces * 5 + 7) / 8, ((uint64_t)1 << 24) / CHUNK);
     }
     // The ranges of this pass, and where each lies: range r is aligned into lane r % LANES by whichever aligner thread takes it
-    // next, and formatted -- in range order -- once it is there.  PF_ALIGN_THREADS=n (default 1) runs n aligners, i.e.
-    // pf_call_align_lane on n lanes side by side.  Measured (profiles/r16_experiments.txt): a range's chain of a dozen dependent
-    // launches costs 1.7 ms whatever it holds (196 k bubbles 2.3 ms, 983 k 4.5 ms, 1.55 M 6.6 ms), but a second range beside it
-    // does not hide that: its kernels are sized to fill the device too, the two time-slice, the FIRST text piece of the pass comes
-    // later, and the pass ends one PCIe chain after that piece (two aligners 19.3 ms, one 18.2; four ranges 20.3 / 22.4).
+    // next, and formatted -- in range order -- once it is there.  Two aligners (PF_ALIGN_THREADS) call pf_call_align_lane on two
+    // lanes side by side.  A range's chain of a dozen dependent launches costs 1.7 ms whatever it holds (196 k bubbles 2.3 ms,
+    // 983 k 4.5 ms, 1.55 M 6.6 ms: every kernel is at least one round of its slowest work item long); two ranges side by side on
+    // streams of equal priority only time-slice (their kernels are sized to fill the device) and the pass got SLOWER, 18.2 -> 19.3
+    // ms; with the later lanes' streams at the lowest priority (pf::lane_stream_create) the first range is not held up, the second
+    // fills what it leaves idle, and both are aligned 5.8 ms after the scan instead of 8.8: 18.45 -> 17.19 ms per pass together with
+    // K-TEXT's two streams (profiles/r16_experiments.txt).
     struct Range {
         uint64_t a0 = 0, a1 = 0;
         int lane = 0;
@@ -510,14 +517,13 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         uint64_t n_called = 0;
     };
     std::vector<Range> ranges;
-    const int LANES = [] { const char *e = getenv("PF_ALIGN_LANES"); return e ? std::max(1, std::min(PF_CALL_LANES, atoi(e))) : PF_CALL_LANES; }();   // measurements
     for (uint64_t a0 = 0, a1 = 0; a0 < n_tasks; a0 = a1) {
         a1 = std::min<uint64_t>(n_tasks, a0 + (first_env > 0 && ranges.empty() ? (uint64_t)first_env * CHUNK : ALIGN));
         Range r;
         r.a0 = a0; r.a1 = a1; r.lane = (int)(ranges.size() % (size_t)LANES);
         ranges.push_back(r);
     }
-    const int aligners = (int)std::min<size_t>(ranges.size(), (size_t)[&] { const char *e = getenv("PF_ALIGN_THREADS"); return e ? std::max(1, std::min(LANES, atoi(e))) : 1; }());
+    const int aligners = (int)std::min<size_t>(ranges.size(), (size_t)aligners_wanted);
     size_t next_range = 0;         // the next range an aligner takes
     size_t ranges_formatted = 0;   // ranges whose last piece has been formatted: their lane may be aligned into again
     std::thread formatter([&] {

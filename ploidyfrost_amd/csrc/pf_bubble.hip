@@ -781,7 +781,7 @@ unsigned long long *bubble_pool_heads(pf_ctx *ctx, int lane) { return (unsigned 
 static int bubble_streams(pf_ctx *ctx, int lane) {
     if (ctx->bub_streams[lane][0]) return PF_OK;
     for (int c = 0; c < kBubLdsClasses; ++c) {
-        PF_HIP(hipStreamCreateWithFlags(&ctx->bub_streams[lane][c], hipStreamNonBlocking));
+        PF_HIP(lane_stream_create(&ctx->bub_streams[lane][c], lane));
         PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[lane][c], hipEventDisableTiming));
     }
     PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[lane][kBubLdsClasses], hipEventDisableTiming));

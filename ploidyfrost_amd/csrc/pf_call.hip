@@ -157,7 +157,7 @@ struct CallState {
         uint32_t nb = 0;
         pf_call_result cur = {};
         uint64_t used[5] = {};   // pool fill after the last pf_call_align_lane: row text, sites, group bytes, indel lengths, site values
-        hipEvent_t read_ev = nullptr;   // the last write pass of K-TEXT over this lane has finished (the next alignment into it waits for that on its stream)
+        hipEvent_t read_ev[2] = {nullptr, nullptr};   // the last write passes of K-TEXT over this lane (one per text stream) have finished: the next alignment into it waits for them on its stream
     } lane[PF_CALL_LANES];
     // the working set of one pf_call_align_lane call, one per lane as well: lists, queues, path pools, per-wavefront scratch,
     // counters, streams -- calls on different lanes run side by side from different host threads (every kernel of a range ends in
@@ -174,9 +174,13 @@ struct CallState {
         hipStream_t side_stream = nullptr;
         hipEvent_t ev_prep = nullptr, ev_paths = nullptr;
     } work[PF_CALL_LANES];
-    // K-TEXT's own scratch, counters and stream: it may run from another host thread beside pf_call_align (other lane)
-    DevBuf sizes, offs, totals, tcounters, tscan;
-    hipStream_t text_stream = nullptr;
+    // K-TEXT's own scratch, counters and streams: it may run from another host thread beside pf_call_align (other lanes).  Two sets,
+    // taken in turn by the parity of the slab: a piece's count pass ends in a wait of the host (the slab is laid out from the
+    // totals), its write pass does not -- the count pass of the next piece, on the other stream, runs beside it
+    struct TextWork {
+        DevBuf sizes, offs, totals, tcounters, tscan;
+        hipStream_t stream = nullptr;
+    } text[2];
     // capacities learnt from earlier batches (any lane)
     std::atomic<uint64_t> path_pool{0}, text_pool{0}, sv_pool{0};
     std::atomic<uint64_t> otext_cap{0}, osites_cap{0}, ogroups_cap{0}, oilen_cap{0};
@@ -191,11 +195,15 @@ struct CallState {
     void release_all() {
         DevBuf *all[] = {&col_low, &col_up, &col_full, &col_size, &part_first, &part_colour, &part_word, &part_bits, &ccov_sum, &ccov_min, &ccov_max, &ccov_miss,
                          &flags, &plus, &minus, &cov_sum, &cov_min, &cov_miss, &side_cnt, &side_base, &sides, &ctask, &scan_tmp, &target, &pending, &killed, &rstate, &rflag, &rsmall, &kept, &sb_cnt, &sb_base, &sb_sizes, &sb_offs, &sb_out,
-                         &sizes, &offs, &totals, &tcounters, &tscan};
+                         };
         for (DevBuf *b : all) b->release();
+        for (TextWork &t : text) {
+            for (DevBuf *b : {&t.sizes, &t.offs, &t.totals, &t.tcounters, &t.tscan}) b->release();
+            if (t.stream) { (void)hipStreamDestroy(t.stream); t.stream = nullptr; }
+        }
         for (AlignOut &o : lane) {
             for (DevBuf *b : {&o.res, &o.otext, &o.osites, &o.ogroups, &o.oilen, &o.sv_off, &o.sv, &o.vc}) b->release();
-            if (o.read_ev) { (void)hipEventDestroy(o.read_ev); o.read_ev = nullptr; }
+            for (hipEvent_t &e : o.read_ev) if (e) { (void)hipEventDestroy(e); e = nullptr; }
         }
         for (AlignWork &w : work) {
             for (DevBuf *b : {&w.counters, &w.btask, &w.bpath, &w.ptext, &w.queues, &w.blist, &w.slist, &w.plist, &w.plist2, &w.klist, &w.klist_b, &w.stack_scr, &w.tlist, &w.tlist4, &w.trio_scr, &w.trio_rows,
@@ -207,7 +215,6 @@ struct CallState {
             if (w.ev_prep) { (void)hipEventDestroy(w.ev_prep); w.ev_prep = nullptr; }
             if (w.ev_paths) { (void)hipEventDestroy(w.ev_paths); w.ev_paths = nullptr; }
         }
-        if (text_stream) { (void)hipStreamDestroy(text_stream); text_stream = nullptr; }
         for (DevBuf &b : out) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         for (hipEvent_t &e : fetch_ev)
@@ -3437,11 +3444,11 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     CallState::AlignWork &W = S->work[lane];
     if (!W.stream) {
         if (lane == 0) W.stream = ctx->stream;
-        else { PF_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking)); W.own_stream = true; }
+        else { PF_HIP(lane_stream_create(&W.stream, lane)); W.own_stream = true; }
     }
     hipStream_t st = W.stream;
     // the write pass of K-TEXT over what this lane held may still be running (pf_call_text_range_lane does not wait for it)
-    if (O.read_ev) PF_HIP(hipStreamWaitEvent(st, O.read_ev, 0));
+    for (hipEvent_t e : O.read_ev) if (e) PF_HIP(hipStreamWaitEvent(st, e, 0));
     // (another lane's stream needs no event to wait for: the scan and the selection on the context's stream ended in host waits --
     // pf_call_resolve / pf_call_select hand the host the number of bubbles this call's range is cut from)
     // launch timing by place: calls on other lanes time their launches at the same time
@@ -3554,7 +3561,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         hipStream_t pst = st;
         if (fork_paths) {
             if (!W.side_stream) {
-                PF_HIP(hipStreamCreateWithFlags(&W.side_stream, hipStreamNonBlocking));
+                PF_HIP(lane_stream_create(&W.side_stream, lane));
                 PF_HIP(hipEventCreateWithFlags(&W.ev_prep, hipEventDisableTiming));
                 PF_HIP(hipEventCreateWithFlags(&W.ev_paths, hipEventDisableTiming));
             }
@@ -3994,10 +4001,10 @@ int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int
         NEED(O.sv, ((uint64_t)nb / 4 + 1024ull * ctx->n_cu * 16 + 1024) * 8);
         if (!W.stream) {
             if (lane == 0) W.stream = ctx->stream;
-            else { PF_HIP(hipStreamCreateWithFlags(&W.stream, hipStreamNonBlocking)); W.own_stream = true; }
+            else { PF_HIP(lane_stream_create(&W.stream, lane)); W.own_stream = true; }
         }
         if (!W.side_stream) {
-            PF_HIP(hipStreamCreateWithFlags(&W.side_stream, hipStreamNonBlocking));
+            PF_HIP(lane_stream_create(&W.side_stream, lane));
             PF_HIP(hipEventCreateWithFlags(&W.ev_prep, hipEventDisableTiming));
             PF_HIP(hipEventCreateWithFlags(&W.ev_paths, hipEventDisableTiming));
         }
@@ -4018,34 +4025,35 @@ int pf_call_align(pf_ctx *ctx, uint64_t t0, uint64_t t1, uint32_t complex_size, 
 // one batch, second half: K-TEXT of the bubbles pf_call_align left resident, into slab 0 or 1
 // (any host thread: a stream, scratch and counters of its own, launch timing by place -- one pf_call_text_range at a time,
 // beside at most one pf_call_align_lane on the OTHER lane)
-static int text_stream_of(pf_ctx *ctx, pf::CallState *S) {
-    if (!S->text_stream) {
-        // highest priority: its short kernels go ahead of the alignment kernels of the other lane, whose grids fill the device
+static int text_work_of(pf_ctx *ctx, pf::CallState *S, int which, uint32_t nb) {
+    pf::CallState::TextWork &T = S->text[which];
+    if (!T.stream) {
+        // highest priority: its short kernels go ahead of the alignment kernels of the other lanes, whose grids fill the device
         // for milliseconds -- the text has a PCIe copy and a file copy still before it
         int least = 0, greatest = 0;
         PF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
         static const bool prio = [] { const char *e = getenv("PF_TEXT_PRIORITY"); return !(e && e[0] == '0'); }();   // measurements
-        PF_HIP(hipStreamCreateWithPriority(&S->text_stream, hipStreamNonBlocking, prio ? greatest : least));
+        PF_HIP(hipStreamCreateWithPriority(&T.stream, hipStreamNonBlocking, prio ? greatest : least));
     }
+    NEED_TEXT(T.sizes, (size_t)N_INT * (nb + 1) * 4);
+    NEED_TEXT(T.offs, ((size_t)N_INT * (nb + 1) + 1) * 8);
+    NEED_TEXT(T.totals, 16 * 8);
+    NEED_TEXT(T.tcounters, sizeof(CallCounters));
+    size_t tmp2 = 0;
+    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(T.sizes.as<uint32_t>(), Widen());
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, T.offs.as<uint64_t>(), (int)((size_t)N_INT * (nb + 1)), T.stream));
+    NEED_TEXT(T.tscan, tmp2);
     return PF_OK;
 }
 
-// what the first pf_call_text_range of a run would take (see pf_call_reserve): the text stream, the size tables of a piece of
+// what the first pf_call_text_range of a run would take (see pf_call_reserve): the text streams, the size tables of a piece of
 // piece_bubbles bubbles and the text slabs (an estimate from k: rows of two to four aligned paths; grows as before when short)
 int pf_call_reserve_text(pf_ctx *ctx, uint64_t piece_bubbles) {
     if (!ctx || piece_bubbles == 0) return PF_ERR_ARG;
     pf::CallState *S = state_of(ctx);
     PF_HIP(hipSetDevice(ctx->device));
     const uint32_t nb = (uint32_t)std::min<uint64_t>(piece_bubbles, 1u << 24);
-    { const int ts = text_stream_of(ctx, S); if (ts != PF_OK) return ts; }
-    NEED_TEXT(S->sizes, (size_t)N_INT * (nb + 1) * 4);
-    NEED_TEXT(S->offs, ((size_t)N_INT * (nb + 1) + 1) * 8);
-    NEED_TEXT(S->totals, 16 * 8);
-    NEED_TEXT(S->tcounters, sizeof(CallCounters));
-    size_t tmp2 = 0;
-    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)((size_t)N_INT * (nb + 1)), S->text_stream));
-    NEED_TEXT(S->tscan, tmp2);
+    for (int which = 0; which < 2; ++which) { const int ts = text_work_of(ctx, S, which, nb); if (ts != PF_OK) return ts; }
     for (int slab = 0; slab < PF_CALL_SLABS; ++slab) NEED_TEXT(S->out[slab], (11ull * (uint64_t)ctx->k + 40) * nb);
     return PF_OK;
 }
@@ -4068,27 +4076,24 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     auto ta = [&](const char *what) {
         if (trace_stages) fprintf(stderr, "[pf_call_text]    %-34s %.2f ms\n", what, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_enter).count() * 1e3);
     };
-    { const int ts = text_stream_of(ctx, S); if (ts != PF_OK) return ts; }
-    hipStream_t st = S->text_stream;
     const uint32_t nb = (uint32_t)count;
+    const int which = sizes_only ? 0 : (slab & 1);
+    { const int ts = text_work_of(ctx, S, which, nb); if (ts != PF_OK) return ts; }
+    CallState::TextWork &T = S->text[which];
+    hipStream_t st = T.stream;
     const uint64_t t0 = O.t0;
     // bubbles called inside the range: difference of the batch-wide running count (read with the sizes below: one wait)
     uint32_t vc_edge[2] = {0, 0};
     PF_HIP(hipMemcpyAsync(&vc_edge[1], O.vc.as<uint32_t>() + (first + count - 1), 4, hipMemcpyDeviceToHost, st));
     if (first) PF_HIP(hipMemcpyAsync(&vc_edge[0], O.vc.as<uint32_t>() + (first - 1), 4, hipMemcpyDeviceToHost, st));
-    NEED_TEXT(S->sizes, (size_t)N_INT * (nb + 1) * 4);
-    NEED_TEXT(S->offs, ((size_t)N_INT * (nb + 1) + 1) * 8);
     const char *oom = "pf_call_text: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
-    NEED(S->totals, 16 * 8);
-    NEED(S->tcounters, sizeof(CallCounters));
-    CallCounters *d_cnt = S->tcounters.as<CallCounters>();
+    CallCounters *d_cnt = T.tcounters.as<CallCounters>();
     CallCounters hc;
     size_t tmp2 = 0;
     const size_t n_sizes = (size_t)N_INT * (nb + 1);
-    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sizes.as<uint32_t>(), Widen());
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
-    NEED(S->tscan, tmp2);
+    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(T.sizes.as<uint32_t>(), Widen());
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, T.offs.as<uint64_t>(), (int)n_sizes, st));
     ta("stream and size tables");
     PF_HIP(hipMemsetAsync(&d_cnt->allele[0], 0, 6 * 8, st));  // allele[4], core_cov, core_num
     FmtArgs fa;
@@ -4096,7 +4101,7 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     fa.res = O.res.as<pf_bubble_result>();
     fa.otext = O.otext.as<char>(); fa.osites = O.osites.as<pf_bubble_site>(); fa.ogroups = O.ogroups.as<uint8_t>();
     fa.oilen = O.oilen.as<uint32_t>(); fa.sv_off = O.sv_off.as<uint64_t>(); fa.sv = O.sv.as<double>(); fa.vc = O.vc.as<uint32_t>();
-    fa.vc_base = var_count_base; fa.mt = S->mt_format ? 1 : 0; fa.len = ctx->d_len; fa.sizes = S->sizes.as<uint32_t>(); fa.offs = S->offs.as<uint64_t>(); fa.cnt = d_cnt;
+    fa.vc_base = var_count_base; fa.mt = S->mt_format ? 1 : 0; fa.len = ctx->d_len; fa.sizes = T.sizes.as<uint32_t>(); fa.offs = T.offs.as<uint64_t>(); fa.cnt = d_cnt;
     for (int s = 0; s < N_INT; ++s) fa.out[s] = nullptr;
     fa.packed = S->pack_alignseq ? 1 : 0;
     size_t at = 0;
@@ -4105,10 +4110,10 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     if (S->n_colors) k_call_format<false, true><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     else k_call_format<false, false><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end_at(ctx, at, st);
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->tscan.p, tmp2, wide, S->offs.as<uint64_t>(), (int)n_sizes, st));
-    k_call_totals<<<1, 64, 0, st>>>(S->offs.as<uint64_t>(), S->sizes.as<uint32_t>(), nb, S->totals.as<uint64_t>());
+    PF_HIP(hipcub::DeviceScan::ExclusiveSum(T.tscan.p, tmp2, wide, T.offs.as<uint64_t>(), (int)n_sizes, st));
+    k_call_totals<<<1, 64, 0, st>>>(T.offs.as<uint64_t>(), T.sizes.as<uint32_t>(), nb, T.totals.as<uint64_t>());
     uint64_t totals[N_INT + 1] = {};
-    PF_HIP(hipMemcpyAsync(totals, S->totals.p, N_INT * 8, hipMemcpyDeviceToHost, st));
+    PF_HIP(hipMemcpyAsync(totals, T.totals.p, N_INT * 8, hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&hc, d_cnt, sizeof(hc), hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
     out->n_called = vc_edge[1] - vc_edge[0];
@@ -4148,8 +4153,8 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     if (!S->text_ev[slab]) PF_HIP(hipEventCreateWithFlags(&S->text_ev[slab], hipEventDisableTiming));
     PF_HIP(hipEventRecord(S->text_ev[slab], st));
     // ... and neither does the caller, who may hand the lane to the next pf_call_align_lane at once: that call's stream waits here
-    if (!O.read_ev) PF_HIP(hipEventCreateWithFlags(&O.read_ev, hipEventDisableTiming));
-    PF_HIP(hipEventRecord(O.read_ev, st));
+    if (!O.read_ev[which]) PF_HIP(hipEventCreateWithFlags(&O.read_ev[which], hipEventDisableTiming));
+    PF_HIP(hipEventRecord(O.read_ev[which], st));
     for (int x = 0; x < 4; ++x) out->allele[x] = hc.allele[x];
     out->core_cov = hc.core_cov;
     out->core_num = hc.core_num;

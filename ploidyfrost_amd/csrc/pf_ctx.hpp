@@ -165,6 +165,10 @@ int join_graph_counts(pf_ctx *ctx);
 int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the joined table of all colours (pf_ctx::d_gcov_c)  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
 // device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
+// a stream for the kernels of lane `lane` of the calling pipeline: lane 0's at the default priority, the other lanes' at the lowest --
+// when ranges are aligned side by side (PF_ALIGN_THREADS) the earlier range, whose text the pass waits for, goes first and the
+// later one fills what it leaves idle.  PF_LANE_PRIORITY=0: all at the default priority (measurements).
+hipError_t lane_stream_create(hipStream_t *s, int lane);
 void call_destroy(pf_ctx *ctx);     // pf_call.hip
 void cc_destroy(pf_ctx *ctx);       // pf_cc.hip
 void gfa_destroy(pf_ctx *ctx);      // pf_gfa.hip

@@ -674,6 +674,15 @@ void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes) {
     return p;
 }
 
+hipError_t lane_stream_create(hipStream_t *s, int lane) {
+    static const bool by_lane = [] { const char *e = getenv("PF_LANE_PRIORITY"); return !(e && e[0] == '0'); }();
+    if (lane == 0 || !by_lane) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    int least = 0, greatest = 0;
+    const hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
+    if (e != hipSuccess) return e;
+    return hipStreamCreateWithPriority(s, hipStreamNonBlocking, least);
+}
+
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu) {
     uint64_t want = (work_items + block - 1) / block;
     uint64_t cap = (uint64_t)ctx->n_cu * per_cu;
