@@ -63,6 +63,10 @@ enum pf_kernel {
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);
 int pf_reset_timing(pf_ctx *);
+/* Which kernels pf_enable_timing times: bit k of the mask = launches of kernel k (default: all).  Two events per launch are not
+ * free on a pass of a hundred launches from four host threads; a caller that wants one kernel's durations inside a region it
+ * also times as a whole (bench.py: K-BUBBLE for the roofline) selects that kernel alone. */
+int pf_timing_select(pf_ctx *, uint64_t kernel_mask);
 /* Device-busy time of everything timed since the last reset: the UNION of the launches' [start, end] intervals (HIP events on the
  * streams they were launched on), in ms -- the launches of the calling pipeline overlap (two align ranges, K-BUBBLE's classes on
  * streams of their own, K-TEXT beside the next range's alignment), so the sum pf_kernel_time gives counts overlapped time twice;

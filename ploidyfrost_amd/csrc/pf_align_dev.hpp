@@ -346,6 +346,9 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
             gaps_used = f_ng;
         }
     } else if (lane == 0) {
+        // one lane, a chain of dependent steps: ahead of the other wavefronts of the SIMD at issue (their fills are throughput work)
+        __builtin_amdgcn_s_setprio(3);
+        unsigned long long st_steps = 0, st_leaves = 0, st_takes = 0, st_leaf_ticks = 0;   // diagnostic (prof)
         uint64_t open_a = 0, open_b = 0, lim_a = 5, lim_b = 5;  // size_t in the reference
         uint32_t len = 0, ng = 0;
         uint32_t i = m, j = n;
@@ -355,7 +358,10 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         char top_a = '\0', top_b = '\0';   // ra[len - 1], rb[len - 1] ('\0' on an empty stack)
         for (;;) {
             const uint32_t c = i * W + j;
+            if (prof) ++st_steps;
             if (i == 0 && j == 0 && open_a <= lim_a && open_b <= lim_b) {
+                const unsigned long long tl0 = prof ? wall_clock64() : 0;
+                if (prof) ++st_leaves;
                 // variantAnalyze over the forward strings (stored back to front)
                 long long score = 0;
                 uint32_t npos = 0, indel = 0;
@@ -415,11 +421,39 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                     last_score = score;
                     last_npos = npos;
                     last_indel = indel;
+                    if (prof) ++st_takes;
                 }
+                if (prof) st_leaf_ticks += wall_clock64() - tl0;
             }
             // (the three loads of a step -- the cell's flags and the two characters a move would consume -- leave together; the top of
             // the stack is carried in registers: a step that waits for one memory round trip where it waited for three in a row)
             const uint8_t dc = dir[c];
+            if ((dc >> 4) == DIAG) {
+                // The commonest step by far, in a loop of its own: a run of cells whose only open direction is the diagonal (the
+                // general step below does exactly this for each of them, behind its tests for the leaf and the two gap moves)
+                uint32_t ii = i, jj = j, ll = len, cc = c;
+                uint8_t d2 = dc;
+                char na2, nb2;
+                for (;;) {
+                    na2 = A[ii - 1];
+                    nb2 = B[jj - 1];
+                    dir[cc] = d2 & (uint8_t) ~(DIAG << 4);
+                    ra[ll] = na2;
+                    rb[ll] = nb2;
+                    mv[ll] = DIAG;
+                    ++ll;
+                    --ii;
+                    --jj;
+                    if (ii == 0 || jj == 0) break;   // (a border cell: the general step)
+                    cc = ii * W + jj;
+                    d2 = dir[cc];
+                    if ((d2 >> 4) != DIAG) break;
+                    if (prof) ++st_steps;
+                }
+                i = ii; j = jj; len = ll;
+                top_a = na2; top_b = nb2;
+                continue;
+            }
             const char na = i ? A[i - 1] : '\0', nb = j ? B[j - 1] : '\0';
             const uint8_t work = dc >> 4;
             const char fa = top_a;
@@ -480,32 +514,50 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 i -= 1;
                 j -= 1;
             } else {
-                if (len == 0) break;
-                dir[c] = (uint8_t)((dc & 0x0F) | ((dc & 0x0F) << 4));  // matrix_temp[p] = matrix[p]
-                const char pa = len >= 2 ? ra[len - 2] : '\0', pb = len >= 2 ? rb[len - 2] : '\0';   // the new top
-                const uint8_t mvv = mv[len - 1];
-                if (fa == '+') {
-                    if (len >= 2) { if (pa != '+') --open_a; }
-                    else --open_a;
+                // nothing left to try at this cell: back up -- and on, in this loop, through every cell that has nothing left either
+                // (the unwinding behind a complete path: a hundred cells with one direction each)
+                uint32_t cc = c;
+                uint8_t d2 = dc;
+                char ta = fa, tb = fb;
+                bool out = false;
+                for (;;) {
+                    if (len == 0) { out = true; break; }
+                    dir[cc] = (uint8_t)((d2 & 0x0F) | ((d2 & 0x0F) << 4));  // matrix_temp[p] = matrix[p]
+                    const char pa = len >= 2 ? ra[len - 2] : '\0', pb = len >= 2 ? rb[len - 2] : '\0';   // the new top
+                    const uint8_t mvv = mv[len - 1];
+                    if (ta == '+') {
+                        if (len >= 2) { if (pa != '+') --open_a; }
+                        else --open_a;
+                    }
+                    if (tb == '-') {
+                        if (len >= 2) { if (pb != '-') --open_b; }
+                        else --open_b;
+                    }
+                    if (ta == '+') ng--;
+                    ta = pa;
+                    tb = pb;
+                    if (mvv == LEFT) j += 1;
+                    else if (mvv == UP) i += 1;
+                    else { i += 1; j += 1; }
+                    len--;
+                    cc = i * W + j;
+                    d2 = dir[cc];
+                    if (d2 >> 4) break;   // a direction is left here: the general step
+                    if (prof) ++st_steps;
                 }
-                if (fb == '-') {
-                    if (len >= 2) { if (pb != '-') --open_b; }
-                    else --open_b;
-                }
-                if (fa == '+') ng--;
-                top_a = pa;
-                top_b = pb;
-                if (mvv == LEFT) j += 1;
-                else if (mvv == UP) i += 1;
-                else { i += 1; j += 1; }
-                len--;
+                top_a = ta;
+                top_b = tb;
+                if (out) break;
             }
         }
+        __builtin_amdgcn_s_setprio(0);
+        if (prof) { atomicAdd(&prof[8], st_steps); atomicAdd(&prof[9], st_leaves); atomicAdd(&prof[10], st_takes); atomicAdd(&prof[11], st_leaf_ticks); atomicAdd(&prof[12], 1ull); }
     }
     aln_sync();
     if (prof && lane == 0) {
         atomicAdd(&prof[0], pc1 - pc0);
         atomicAdd(&prof[1], wall_clock64() - pc1);
+        if (unique) atomicAdd(&prof[13], 1ull);
     }
     n_hits_out = __shfl(n_hits, 0, WAVE);
     text_out = __shfl(text_used, 0, WAVE);

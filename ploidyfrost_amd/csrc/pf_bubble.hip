@@ -856,9 +856,9 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     unsigned long long *d_clk = nullptr;
     const bool want_clk = getenv("PF_BUBBLE_STATS") != nullptr;
     if (want_clk) {
-        PF_HIP(clk_.alloc(((size_t)L.n_tasks + 8) * 8));
+        PF_HIP(clk_.alloc(((size_t)L.n_tasks + 16) * 8));
         d_clk = clk_.p;
-        PF_HIP(hipMemsetAsync(d_clk, 0, ((size_t)L.n_tasks + 8) * 8, st));
+        PF_HIP(hipMemsetAsync(d_clk, 0, ((size_t)L.n_tasks + 16) * 8, st));
         p.task_clk = d_clk;
         p.prof = d_clk + L.n_tasks;
     }
@@ -953,8 +953,10 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     }
     if (want_clk) {
         const uint32_t n_tasks = L.n_tasks;
-        std::vector<unsigned long long> clk(n_tasks + 8);
-        PF_HIP(hipMemcpy(clk.data(), d_clk, ((size_t)n_tasks + 8) * 8, hipMemcpyDeviceToHost));
+        std::vector<unsigned long long> clk(n_tasks + 16);
+        PF_HIP(hipMemcpy(clk.data(), d_clk, ((size_t)n_tasks + 16) * 8, hipMemcpyDeviceToHost));
+        fprintf(stderr, "[pf_align_bubbles] traceback: %llu jobs on the one-path fast road, %llu through the depth-first walk: %llu steps, %llu complete paths (%llu ticks in their analysis and copy), %llu kept\n",
+                clk[n_tasks + 13], clk[n_tasks + 12], clk[n_tasks + 8], clk[n_tasks + 9], clk[n_tasks + 11], clk[n_tasks + 10]);
         fprintf(stderr, "[pf_align_bubbles] ticks by phase: fill %llu traceback %llu | decode %llu round0(incl. NW) %llu rounds %llu choose %llu publish %llu\n",
                 clk[n_tasks], clk[n_tasks + 1], clk[n_tasks + 2], clk[n_tasks + 3], clk[n_tasks + 4], clk[n_tasks + 5], clk[n_tasks + 6]);
         clk.resize(n_tasks);

@@ -25,6 +25,7 @@ struct DevTmp {
 struct TimedLaunch {
     int kernel;
     hipEvent_t a, b;
+    bool closed;   // b has been recorded
 };
 struct CallState;  // pf_call.hip: buffers of the resident calling pipeline
 }  // namespace pf
@@ -133,6 +134,8 @@ struct pf_ctx {
     std::vector<std::pair<void *, size_t>> ws;
 
     bool timing = false;
+    uint64_t timing_mask = ~0ull;          // pf_timing_select: bit k = launches of kernel k are timed
+    std::vector<hipEvent_t> event_pool;    // events of launches pf_reset_timing has dropped, for the launches to come
     std::vector<pf::TimedLaunch> launches;
     size_t side_launch = (size_t)-1;   // ctx_begin_on .. ctx_end_on
     size_t main_launch = (size_t)-1;   // ctx_begin .. ctx_end

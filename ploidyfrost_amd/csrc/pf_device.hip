@@ -607,12 +607,25 @@ static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert",
                                                 "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
                                                 "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_call_trio"};
 
+// (events come from a pool that pf_reset_timing refills: creating two per launch cost more than the launch)
 static size_t launch_push(pf_ctx *ctx, int kernel, hipStream_t stream) {
+    if (!((ctx->timing_mask >> kernel) & 1ull)) return (size_t)-1;
     TimedLaunch tl;
     tl.kernel = kernel;
-    if (hipEventCreate(&tl.a) != hipSuccess || hipEventCreate(&tl.b) != hipSuccess) return (size_t)-1;
+    tl.a = tl.b = nullptr;
+    {
+        std::lock_guard<std::mutex> lk(ctx->launch_mu);
+        if (ctx->event_pool.size() >= 2) {
+            tl.a = ctx->event_pool.back(); ctx->event_pool.pop_back();
+            tl.b = ctx->event_pool.back(); ctx->event_pool.pop_back();
+        }
+    }
+    // (no system-scope fence when an event completes: a launch's timestamps need none, and the fence of twenty events a pass held the
+    // kernels on the other streams up -- K-BUBBLE's launches timed cost the pass 1 ms.  PF_EVENT_FENCE=1: plain events, measurements)
+    static const unsigned ev_flags = [] { const char *e = getenv("PF_EVENT_FENCE"); return (e && e[0] == '1') ? hipEventDefault : hipEventDisableSystemFence; }();
+    if (!tl.a && (hipEventCreateWithFlags(&tl.a, ev_flags) != hipSuccess || hipEventCreateWithFlags(&tl.b, ev_flags) != hipSuccess)) return (size_t)-1;
     hipEventRecord(tl.a, stream);
-    hipEventRecord(tl.b, stream);   // (re-recorded when the launch is closed)
+    tl.closed = false;
     std::lock_guard<std::mutex> lk(ctx->launch_mu);
     ctx->launches.push_back(tl);
     return ctx->launches.size() - 1;
@@ -623,6 +636,7 @@ static void launch_close(pf_ctx *ctx, size_t at, hipStream_t stream) {
         std::lock_guard<std::mutex> lk(ctx->launch_mu);
         if (at >= ctx->launches.size()) return;
         b = ctx->launches[at].b;
+        ctx->launches[at].closed = true;
     }
     hipEventRecord(b, stream);
 }
@@ -791,6 +805,11 @@ int pf_create(int device, pf_ctx **out) {
     }
     if (device < 0 || device >= n) { g_create_err = "device index out of range"; return PF_ERR_ARG; }
     hipDeviceProp_t prop;
+    if (const char *e = getenv("PF_SYNC_MODE")) {   // measurements: how a host thread waits for a stream (s = spin, y = yield, b = block)
+        (void)hipSetDevice(device);
+        (void)hipSetDeviceFlags(e[0] == 's' ? hipDeviceScheduleSpin : e[0] == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
+        (void)hipGetLastError();
+    }
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
         g_create_err = "hipSetDevice / hipGetDeviceProperties failed";
         return PF_ERR_HIP;
@@ -841,6 +860,7 @@ void pf_destroy(pf_ctx *ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
+    for (auto &e : ctx->event_pool) hipEventDestroy(e);
     call_destroy(ctx);
     cc_destroy(ctx);
     gfa_destroy(ctx);
@@ -877,10 +897,18 @@ int pf_enable_timing(pf_ctx *ctx, int on) {
     return PF_OK;
 }
 
+int pf_timing_select(pf_ctx *ctx, uint64_t kernel_mask) {
+    if (!ctx) return PF_ERR_ARG;
+    ctx->timing_mask = kernel_mask;
+    return PF_OK;
+}
+
 int pf_reset_timing(pf_ctx *ctx) {
     if (!ctx) return PF_ERR_ARG;
-    hipStreamSynchronize(ctx->stream);
-    for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipDeviceSynchronize());   // (launches on every stream of the pipeline)
+    std::lock_guard<std::mutex> lk(ctx->launch_mu);
+    for (auto &tl : ctx->launches) { ctx->event_pool.push_back(tl.a); ctx->event_pool.push_back(tl.b); }
     ctx->launches.clear();
     memset(ctx->units, 0, sizeof(ctx->units));
     return PF_OK;
@@ -898,7 +926,7 @@ int pf_kernel_time(pf_ctx *ctx, int kernel, double *total_ms, uint64_t *launches
     double tot = 0;
     uint64_t n = 0;
     for (auto &tl : ctx->launches) {
-        if (tl.kernel != kernel) continue;
+        if (tl.kernel != kernel || !tl.closed) continue;
         float ms = 0;
         PF_HIP(hipEventElapsedTime(&ms, tl.a, tl.b));
         tot += ms;
@@ -920,6 +948,7 @@ int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) {
         iv.reserve(ctx->launches.size());
         for (auto &tl : ctx->launches) {
             float a = 0, b = 0;
+            if (!tl.closed) { ++unread; continue; }
             if (hipEventElapsedTime(&a, ctx->launches[0].a, tl.a) != hipSuccess || hipEventElapsedTime(&b, ctx->launches[0].a, tl.b) != hipSuccess) {
                 // (the device was synchronized above: an event that cannot be read was never recorded -- a launch that failed)
                 (void)hipGetLastError();
