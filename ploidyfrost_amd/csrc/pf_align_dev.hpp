@@ -356,6 +356,10 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         long long last_score = 0;
         uint32_t last_npos = 0, last_indel = 0;
         char top_a = '\0', top_b = '\0';   // ra[len - 1], rb[len - 1] ('\0' on an empty stack)
+        // cells below the current one on the stack that still have a direction to try.  None, and nothing left at the current cell:
+        // all that remains of the walk is its unwinding, which finds nothing and whose restored flags nobody will read -- the walk
+        // ends there (a hundred steps of the two hundred a job takes: one complete path, kept, and the way back)
+        uint32_t alts = 0;
         for (;;) {
             const uint32_t c = i * W + j;
             if (prof) ++st_steps;
@@ -473,6 +477,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                     continue;
                 }
                 dir[c] = dc & (uint8_t) ~(LEFT << 4);
+                alts += (work & (uint8_t) ~LEFT) != 0;
                 ra[len] = '+';
                 rb[len] = nb;
                 top_a = '+';
@@ -496,6 +501,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                     continue;
                 }
                 dir[c] = dc & (uint8_t) ~(UP << 4);
+                alts += (work & (uint8_t) ~UP) != 0;
                 ra[len] = na;
                 rb[len] = '-';
                 top_a = na;
@@ -521,7 +527,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 char ta = fa, tb = fb;
                 bool out = false;
                 for (;;) {
-                    if (len == 0) { out = true; break; }
+                    if (len == 0 || alts == 0) { out = true; break; }
                     dir[cc] = (uint8_t)((d2 & 0x0F) | ((d2 & 0x0F) << 4));  // matrix_temp[p] = matrix[p]
                     const char pa = len >= 2 ? ra[len - 2] : '\0', pb = len >= 2 ? rb[len - 2] : '\0';   // the new top
                     const uint8_t mvv = mv[len - 1];
@@ -542,7 +548,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                     len--;
                     cc = i * W + j;
                     d2 = dir[cc];
-                    if (d2 >> 4) break;   // a direction is left here: the general step
+                    if (d2 >> 4) { --alts; break; }   // a direction is left here (the cell was counted when it was left): the general step
                     if (prof) ++st_steps;
                 }
                 top_a = ta;

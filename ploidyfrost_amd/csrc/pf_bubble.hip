@@ -22,6 +22,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -844,10 +845,29 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         grids[c] = L.n_cls[c] ? (int)std::min<uint32_t>(L.n_cls[c], (uint32_t)(ctx->n_cu * bubble_class_waves_per_cu(c))) : 0;
         waves_total += (uint64_t)grids[c];
     }
-    const uint64_t max_waves = class_streams ? std::max<uint64_t>(waves_total, (uint64_t)ctx->n_cu * 24) : (uint64_t)ctx->n_cu * 24;
+    // The class launches run side by side and every wavefront has its slice of the scratch (0.5 MB): all classes populated, their
+    // grids add up to 22 k wavefronts = 11 GB, and taking that -- 173 ms for 5.6 GB at configs[4]'s parameters -- was most of a one-shot
+    // PloidyEstimation there.  The device holds 24-32 wavefronts a CU whatever their class, and every wavefront loops over its
+    // class's queue: the grids are scaled down together to the 24 a CU that bubble_reserve took beside the load.
+    const uint64_t wave_budget = (uint64_t)ctx->n_cu * 24;
+    if (class_streams && waves_total > wave_budget) {
+        uint64_t sum = 0;
+        for (int c = 0; c < kBubLdsClasses; ++c) {
+            if (!grids[c]) continue;
+            grids[c] = (int)std::max<uint64_t>(1, (uint64_t)grids[c] * wave_budget / waves_total);
+            sum += (uint64_t)grids[c];
+        }
+        waves_total = sum;
+    }
+    const uint64_t max_waves = class_streams ? std::max<uint64_t>(waves_total, wave_budget) : wave_budget;
     p.caps = std_caps;
     p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
+    const bool trace_ws = getenv("PF_TRACE_ALIGN") != nullptr;
+    const auto t_ws = std::chrono::steady_clock::now();
     uint8_t *const scratch0 = (uint8_t *)ctx_ws(ctx, bub_ws(WS_BUB_SCRATCH, lane), p.scratch_per_wave * max_waves);
+    if (trace_ws)
+        fprintf(stderr, "[bubble_launch] scratch for %llu wavefronts x %llu bytes = %.1f MB taken in %.2f ms\n", (unsigned long long)max_waves, (unsigned long long)p.scratch_per_wave,
+                (double)(p.scratch_per_wave * max_waves) / 1e6, std::chrono::duration<double>(std::chrono::steady_clock::now() - t_ws).count() * 1e3);
     p.scratch = scratch0;
     if (!p.scratch) return PF_ERR_HIP;
     if (class_streams) { const int e = bubble_streams(ctx, lane); if (e != PF_OK) return e; }

@@ -64,6 +64,9 @@ constexpr uint8_t B_PLUS = 0x01, B_MINUS = 0x02, B_STRICT_M = 0x08, B_STRICT_P =
 constexpr int N_STREAMS = PF_CALL_STREAMS;
 constexpr int N_INT = N_STREAMS + 1;   // size / offset tables: the ten streams + the packed form of alignseq (pf_alnpack.hpp)
 constexpr int S_PACK = N_STREAMS;
+// first-pass pool sizes per bubble of a range (pf_call_align_lane, pf_call_reserve_lanes): bytes of aligned rows, sites, group bytes,
+// indel lengths, bytes of path text
+constexpr uint32_t FIRST_ROW_TEXT = 384, FIRST_SITES = 4, FIRST_GROUPS = 12, FIRST_ILEN = 2, FIRST_PATH_TEXT = 64;
 // work lists of a batch: K-BUBBLE's queues (heavy and light per size class), then the three lists of the other kernels
 constexpr int NQ = 2 * (kBubLdsClasses + 1);
 constexpr int KEY_BRANCHING = NQ, KEY_SNP = NQ + 1, KEY_PAIR = NQ + 2, KEY_PAIR2 = NQ + 3, KEY_STACK = NQ + 4, KEY_TRIO = NQ + 5, KEY_TRIO4 = NQ + 6, KEY_NONE = NQ + 7;
@@ -3524,11 +3527,14 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     for (int attempt = 0;; ++attempt) {
         if (attempt > 5) { pf::CtxErr{ctx} = "pf_call_align: pools do not converge"; return PF_ERR_OVERFLOW; }
         const uint64_t path_cap = std::max<uint64_t>(S->path_pool, (uint64_t)nb / 2 + 128ull * paths_grid + 1024);   // (a started piece per wavefront)
-        const uint64_t text_cap = std::max<uint64_t>(S->text_pool, (uint64_t)nb * 32 + (1u << 16));
-        const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, 256ull * nb + (1u << 16));   // (what a first pass takes: 230 B per bubble at k = 25; learnt afterwards)
-        const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, 2ull * nb + 64);
-        const uint64_t cap_groups = std::max<uint64_t>(S->ogroups_cap, 4ull * nb + 64);
-        const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, nb / 2 + 64);
+        // (first-pass sizes, learnt afterwards; a pool that turns out too small costs a repeated attempt -- at configs[4]'s parameters,
+        // k = 31 and insertions to 50 bp, a whole K-BUBBLE run thrown away: 334 B of rows, 2.4 sites, 8 group bytes, 1.1 indel lengths
+        // and 55 B of path text per bubble there; 216 B / 1.2 / 2.7 / 0.03 / 17 B at configs[2]'s)
+        const uint64_t text_cap = std::max<uint64_t>(S->text_pool, (uint64_t)nb * FIRST_PATH_TEXT + (1u << 16));
+        const uint64_t cap_text = std::max<uint64_t>(S->otext_cap, (uint64_t)FIRST_ROW_TEXT * nb + (1u << 16));
+        const uint64_t cap_sites = std::max<uint64_t>(S->osites_cap, (uint64_t)FIRST_SITES * nb + 64);
+        const uint64_t cap_groups = std::max<uint64_t>(S->ogroups_cap, (uint64_t)FIRST_GROUPS * nb + 64);
+        const uint64_t cap_ilen = std::max<uint64_t>(S->oilen_cap, (uint64_t)FIRST_ILEN * nb + 64);
         NEED(W.bpath, ((size_t)4 * nb + path_cap) * sizeof(pf_bubble_path));
         NEED(W.ptext, text_cap);
         const uint64_t walk_cap = S->n_colors ? std::max<uint64_t>(W.walk_cap, (uint64_t)nb * 2 + 256ull * paths_grid + 1024) : 0;
@@ -3983,7 +3989,7 @@ int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int
         NEED(W.paths_scr, paths_per_wave * (uint64_t)(ctx->n_cu * 16));
         NEED(W.pair_scr, PairGeom<PAIR_MAX>::scratch_bytes * (uint64_t)(ctx->n_cu * 12));
         NEED(W.bpath, ((size_t)4 * nb + (uint64_t)nb / 2 + 128ull * (ctx->n_cu * 16) + 1024) * sizeof(pf_bubble_path));
-        NEED(W.ptext, (uint64_t)nb * 32 + (1u << 16));
+        NEED(W.ptext, (uint64_t)nb * FIRST_PATH_TEXT + (1u << 16));
         NEED(W.scan_tmp2, (size_t)nb / 4 * 4 + 4096);
         {   // K-SITES' tables for bubbles of up to 256 walks (single-sample)
             const uint64_t KS = (uint64_t)(2 * ctx->k + 64), rows_cap = 256;
@@ -3994,10 +4000,10 @@ int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int
         NEED(O.res, (size_t)nb * sizeof(pf_bubble_result));
         NEED(O.sv_off, (size_t)nb * 8);
         NEED(O.vc, (size_t)nb * 4);
-        NEED(O.otext, 256ull * nb + (1u << 16));
-        NEED(O.osites, (2ull * nb + 64) * sizeof(pf_bubble_site));
-        NEED(O.ogroups, 4ull * nb + 64);
-        NEED(O.oilen, ((uint64_t)nb / 2 + 64) * 4);
+        NEED(O.otext, (uint64_t)FIRST_ROW_TEXT * nb + (1u << 16));
+        NEED(O.osites, ((uint64_t)FIRST_SITES * nb + 64) * sizeof(pf_bubble_site));
+        NEED(O.ogroups, (uint64_t)FIRST_GROUPS * nb + 64);
+        NEED(O.oilen, ((uint64_t)FIRST_ILEN * nb + 64) * 4);
         NEED(O.sv, ((uint64_t)nb / 4 + 1024ull * ctx->n_cu * 16 + 1024) * 8);
         if (!W.stream) {
             if (lane == 0) W.stream = ctx->stream;
