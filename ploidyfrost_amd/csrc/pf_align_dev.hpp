@@ -283,9 +283,9 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
             f_len++;
         }
     }
-    if (unique) {
-        aln_sync();
-        // variantAnalyze (src/SeqAlign.cpp:237-305), lane-parallel over the columns
+    // One complete path on the stack (ra / rb / gp, back to front), the only alignment so far: variantAnalyze (src/SeqAlign.cpp:237-305)
+    // lane-parallel over its columns, the rows and the gap positions copied out by all lanes, hit 0 written.
+    auto keep_only_path = [&](uint32_t f_len, uint32_t f_ng) {
         long long isum = 0, score = 0;
         uint32_t npos = 0, nind = 0;
         const int Mi = (int)M, Di = (int)D, Gi = (int)G;
@@ -345,6 +345,12 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
             text_used = 2 * f_len;
             gaps_used = f_ng;
         }
+    };
+    // the depth-first walk's first complete path, when the walk ended without touching its stack again (below): kept by all lanes
+    uint32_t pending = 0, pend_len = 0, pend_ng = 0;
+    if (unique) {
+        aln_sync();
+        keep_only_path(f_len, f_ng);
     } else if (lane == 0) {
         // one lane, a chain of dependent steps: ahead of the other wavefronts of the SIMD at issue (their fills are throughput work)
         __builtin_amdgcn_s_setprio(3);
@@ -363,7 +369,24 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         for (;;) {
             const uint32_t c = i * W + j;
             if (prof) ++st_steps;
-            if (i == 0 && j == 0 && open_a <= lim_a && open_b <= lim_b) {
+            if (i == 0 && j == 0 && open_a <= lim_a && open_b <= lim_b && !have) {
+                // The first complete path is kept whatever it scores.  Nineteen walks of twenty find no second one and end a few steps
+                // later without touching the stack again (alts below): its analysis and its copy -- two loops over its columns on this
+                // one lane, a quarter of the walk's time -- are left to all lanes behind the walk (keep_only_path).  A walk that goes
+                // on does them itself, as before, before it takes the first entry off the stack (pend_flush).
+                if (prof) { ++st_leaves; ++st_takes; }
+                if (sc.hit_cap < 1 || 2 * len > sc.text_cap || ng > sc.gap_cap) {
+                    overflow = true;
+                    break;
+                }
+                pending = 1; pend_len = len; pend_ng = ng;
+                n_hits = 1;
+                text_used = 2 * len;
+                gaps_used = ng;
+                lim_a = open_a;
+                lim_b = open_b;
+                have = true;
+            } else if (i == 0 && j == 0 && open_a <= lim_a && open_b <= lim_b) {
                 const unsigned long long tl0 = prof ? wall_clock64() : 0;
                 if (prof) ++st_leaves;
                 // variantAnalyze over the forward strings (stored back to front)
@@ -528,6 +551,47 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 bool out = false;
                 for (;;) {
                     if (len == 0 || alts == 0) { out = true; break; }
+                    if (pending) {
+                        // the walk goes on: the first complete path, still whole on the stack, is analysed and copied out here
+                        const unsigned long long tl0 = prof ? wall_clock64() : 0;
+                        long long score = 0;
+                        uint32_t npos = 0, indel = 0;
+                        uint8_t run = 0;
+                        for (uint32_t t = pend_len; t-- > 0;) {
+                            const char a = ra[t] == '+' ? '-' : ra[t];
+                            const char b = rb[t];
+                            const double s = (a == '-' || b == '-') ? G : (a == b ? M : D);
+                            score = (long long)((double)score + s);
+                            if (a != b) {
+                                if (a == '-') { if (run != 1) { run = 1; indel++; npos++; } }
+                                else if (b == '-') { if (run != 2) { run = 2; indel++; npos++; } }
+                                else { run = 0; npos++; }
+                            } else {
+                                run = 0;
+                            }
+                        }
+                        pf_align_hit h;
+                        h.text_off = 0;
+                        h.gap_off = 0;
+                        h.len = pend_len;
+                        h.n_gaps = pend_ng;
+                        h.score = score;
+                        h.n_pos = npos;
+                        h.n_indel = indel;
+                        sc.hits[0] = h;
+                        char *ta = sc.text, *tb = ta + pend_len;
+                        for (uint32_t t = 0; t < pend_len; ++t) {
+                            const char a = ra[pend_len - 1 - t];
+                            ta[t] = a == '+' ? '-' : a;
+                            tb[t] = rb[pend_len - 1 - t];
+                        }
+                        for (uint32_t t = 0; t < pend_ng; ++t) sc.gaps[t] = gp[t];
+                        last_score = score;
+                        last_npos = npos;
+                        last_indel = indel;
+                        pending = 0;
+                        if (prof) st_leaf_ticks += wall_clock64() - tl0;
+                    }
                     dir[cc] = (uint8_t)((d2 & 0x0F) | ((d2 & 0x0F) << 4));  // matrix_temp[p] = matrix[p]
                     const char pa = len >= 2 ? ra[len - 2] : '\0', pb = len >= 2 ? rb[len - 2] : '\0';   // the new top
                     const uint8_t mvv = mv[len - 1];
@@ -560,6 +624,14 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         if (prof) { atomicAdd(&prof[8], st_steps); atomicAdd(&prof[9], st_leaves); atomicAdd(&prof[10], st_takes); atomicAdd(&prof[11], st_leaf_ticks); atomicAdd(&prof[12], 1ull); }
     }
     aln_sync();
+    if (!unique) {
+        pending = __shfl(pending, 0, WAVE);
+        if (pending && __shfl((int)overflow, 0, WAVE) == 0) {
+            n_hits = text_used = gaps_used = 0;   // (lane 0's 1, 2 * len, ng: set again by keep_only_path, on every lane)
+            keep_only_path(__shfl(pend_len, 0, WAVE), __shfl(pend_ng, 0, WAVE));
+            aln_sync();
+        }
+    }
     if (prof && lane == 0) {
         atomicAdd(&prof[0], pc1 - pc0);
         atomicAdd(&prof[1], wall_clock64() - pc1);
