@@ -163,20 +163,17 @@ __device__ inline void nw_fill_packed(uint8_t *dir, int *s0, const char *A, cons
         int b_reg = 0;
         const uint32_t steps = n + rows_here - 1;
         for (uint32_t t = 0; t < steps; ++t) {
-            const int b_in = t < n ? (int)B[t] : 0;
-            b_reg = __builtin_amdgcn_update_dpp(0, b_reg, 0x138, 0xf, 0xf, false);  // wave_shr:1
-            int up_sf = __builtin_amdgcn_update_dpp(0, last, 0x138, 0xf, 0xf, false);
-            int dg_sf = __builtin_amdgcn_update_dpp(0, last2, 0x138, 0xf, 0xf, false);
+            // What lane 0 takes in at this step -- B's next character, and the cell above its own (row row0: the border, or the last
+            // row of the block before, from LDS) -- is handed to the shifts as their `old` operand: a wave_shr leaves lane 0, which has
+            // no lane to read from, with exactly that.  (It was a branch of lane 0's own at every step.)
+            const uint32_t j0 = t < n ? t + 1 : n;   // lane 0's column (t >= n: lane 0 has left its row; any value will do)
+            const int b_in = (int)B[j0 - 1];
+            const int up_in = blk == 0 ? (((Gi * (int)j0) << 3) | LEFT) : ((brow_s[j0] << 3) | (int)brow_f[j0]);
+            b_reg = __builtin_amdgcn_update_dpp(b_in, b_reg, 0x138, 0xf, 0xf, false);  // wave_shr:1
+            const int up_sf = __builtin_amdgcn_update_dpp(up_in, last, 0x138, 0xf, 0xf, false);
+            const int dg_sf = __builtin_amdgcn_update_dpp(carry, last2, 0x138, 0xf, 0xf, false);
+            carry = up_in;   // (the cell above this step's is the cell above-left of the next step's)
             const int j = (int)t - lane + 1;
-            if (lane == 0) {
-                b_reg = b_in;
-                dg_sf = carry;
-                if (t < n) {
-                    if (blk == 0) up_sf = ((Gi * j) << 3) | LEFT;
-                    else up_sf = (brow_s[j] << 3) | (int)brow_f[j];
-                }
-                carry = up_sf;
-            }
             if (row_ok && j >= 1 && j <= (int)n) {
                 const char b = (char)b_reg;
                 const int up = (up_sf >> 3) + Gi + (up_sf & 1);                                   // UP = 1
