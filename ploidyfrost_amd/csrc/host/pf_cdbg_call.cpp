@@ -289,7 +289,9 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     } prefault0_guard{prefault0, prefault0_stop};
     if (write_files_ && n_tasks && !getenv("PF_NO_EARLY_PREFAULT")) {
         const double nbub = 1.1 * (double)n_tasks;
-        const double per_bubble[PF_CALL_STREAMS] = {20, 2.0 * (2 * g_.k + 26), 20, 2, 1, 0, 52, 3, 1, 0};   // (order: pf_call_stream)
+        // (order: pf_call_stream.  Measured at k = 25, tetraploid: 18.4, 157, 18.0, 0.34, 0.07, 0, 30.2, 0.45, 0.08, 0 bytes per bubble;
+        // what is reserved beyond the final size is touched here and cut off again at the end -- 8 ms for 60 MB too many)
+        const double per_bubble[PF_CALL_STREAMS] = {20, 2.0 * (2 * g_.k + 26), 20, 0.5, 0.25, 0, 34, 0.75, 0.25, 0};
         std::vector<std::pair<int, uint64_t>> fresh;
         for (int s = 0; s < PF_CALL_STREAMS; ++s) {
             const uint64_t est = (uint64_t)(per_bubble[s] * nbub);
