@@ -755,8 +755,9 @@ def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):
             "frac": round(ach / peak, 4), "valu_per_launch": valu, "salu_per_launch": salu,
             "wave_cycle_shares": {k[6:]: v for k, v in e.items() if k.startswith("share_")},
             "source": "profiles/pmc_sq.json (SQ counters per launch) / live HIP-event duration",
-            "note": "per launch: the launches of K-BUBBLE's size classes run side by side (up to three at once, beside the text kernels "
-                    "of the previous align range), so a launch gets a share of the chip and the chip issues up to three times this"}
+            "note": "per launch: the launches of K-BUBBLE's size classes run side by side (five populated classes in each of two align "
+                    "ranges that are on the device at once, beside K-TEXT), so a launch gets a share of the chip -- the chip issues several "
+                    "times this, and splitting the work over more launches lowers the figure without slowing anything"}
 
 
 def load_traffic(kernel: str, n_unitigs: int | None = None):

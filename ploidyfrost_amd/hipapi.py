@@ -318,6 +318,11 @@ class Device:
     def reset_timing(self):
         self._check(self.L.pf_reset_timing(self.h))
 
+    def timing_select(self, kernels=None):
+        """pf_timing_select: time the launches of these kernels only (names of KERNELS; None = all)"""
+        mask = (1 << 64) - 1 if kernels is None else sum(1 << KERNELS.index(k) for k in kernels)
+        self._check(self.L.pf_timing_select(self.h, mask))
+
     def kernel_times(self) -> dict:
         out = {}
         for i, name in enumerate(KERNELS):

@@ -126,6 +126,31 @@ def test_cov_join_is_timed_as_its_own_kernel():
     d.close()
 
 
+def test_timing_can_be_limited_to_some_kernels_and_reuses_its_events():
+    """pf_timing_select: events around the launches of the selected kernels only (bench.py times K-BUBBLE and K-COV inside its
+    timed region, everything in further passes); pf_reset_timing hands the events to a pool the next launches draw from."""
+    meta, o, dev, seqs = setup_case("dip20k")
+    kmers, counts, km = synth.read_kmc(meta["db"])
+    d = hipapi.Device(0)
+    d.enable_timing(True)
+    d.timing_select(["k_cov"])
+    d.upload_graph(*hipapi.pack_unitigs(seqs), o.k)
+    d.upload_counts(kmers, counts, 1, 65535, True)
+    d.unitig_cov()
+    t = d.kernel_times()
+    assert set(t) == {"k_cov"} and t["k_cov"][1] == 1 and t["k_cov"][0] > 0
+    d.timing_select(None)
+    for _ in range(3):   # (the second and third round take their events from the pool)
+        d.reset_timing()
+        d.upload_graph(*hipapi.pack_unitigs(seqs), o.k)
+        s, m, x, st = d.unitig_cov()
+        t = d.kernel_times()
+        assert t["k_cov_join"][1] == 1 and t["k_cov"][1] == 1 and t["k_cov"][0] > 0
+    es, em, _ = o.unitig_cov()
+    assert np.array_equal(s, es) and np.array_equal(m, em)
+    d.close()
+
+
 def test_missing_kmer_is_reported():
     meta, o, dev, _ = setup_case("dip20k")
     kmers, counts, km = synth.read_kmc(meta["db"])
