@@ -29,8 +29,31 @@ for s, e, n in seg:
         idle += s - busy_end
         if gap >= min_gap:
             print("      -- idle %7.1f us --" % gap)
-    short = n.split("(")[0].replace("(anonymous namespace)::", "").replace("void ", "")[:60]
+    short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0][:60]
     print("%9.3f ms  %8.1f us  %s" % ((s - t0) / 1e6, (e - s) / 1e3, short))
     busy_end = max(busy_end, e)
 tail = ev[b][0] - busy_end
 print("idle inside the pass: %.3f ms (+ %.3f ms after its last kernel)" % (idle / 1e6, tail / 1e6))
+# how many dispatches are on the device at once, in slices of a quarter of a millisecond: time with none, mean number, the longest
+STEP = 250_000
+span = ev[b][0] - t0
+print("\nslice start ms | share of the slice with no dispatch | mean dispatches running | kernels (share of the slice each is running)")
+for k in range(0, (span + STEP - 1) // STEP):
+    lo, hi = t0 + k * STEP, min(t0 + (k + 1) * STEP, ev[b][0])
+    pts, per = [], {}
+    for s, e, n in seg:
+        a_, b_ = max(s, lo), min(e, hi)
+        if b_ > a_:
+            pts += [(a_, 1), (b_, -1)]
+            short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+            per[short] = per.get(short, 0) + (b_ - a_)
+    pts.sort()
+    cur, last, none, area = 0, lo, 0, 0
+    for t, d in pts:
+        if cur == 0: none += t - last
+        area += cur * (t - last)
+        cur += d
+        last = t
+    none += hi - last
+    top = sorted(per.items(), key=lambda kv: -kv[1])[:4]
+    print("%6.2f | %4.2f | %4.1f | %s" % (k * STEP / 1e6, none / (hi - lo), area / (hi - lo), ", ".join("%s %.1f" % (n_[:22], v / (hi - lo)) for n_, v in top)))
