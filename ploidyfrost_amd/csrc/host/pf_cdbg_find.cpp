@@ -252,11 +252,24 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
             if (r.n_seen > 4096) { times_.bfs_large_used++; times_.bfs_large_used_max = std::max<uint64_t>(times_.bfs_large_used_max, r.n_seen); }
             if (col_) cmc.replay(r, list); else cm.replay(r, list);
         };
+        double t_walked = 0, t_big = 0;
+        uint64_t l_walked = 0, l_big = 0, e_walked = 0, e_big = 0;
         while (a < (size_t)n_big || b < (size_t)n_deferred) {
             const bool take_walked = a >= (size_t)n_big || (b < (size_t)n_deferred && deferred[b] < big_idx[a]);
-            if (take_walked) { commit(walked[b], xpool.data() + walked[b].list_off); ++b; }
-            else { commit(big_rec[a], big_pool.data() + big_rec[a].list_off); ++a; }
+            const auto tc = trace_find ? clk::now() : clk::time_point();
+            if (take_walked) {
+                if (trace_find && record_effective(walked[b]) && cm.gate_open(walked[b].entrance)) { l_walked += walked[b].n_list; ++e_walked; }
+                commit(walked[b], xpool.data() + walked[b].list_off); ++b;
+                if (trace_find) t_walked += since(tc);
+            } else {
+                if (trace_find && record_effective(big_rec[a]) && cm.gate_open(big_rec[a].entrance)) { l_big += big_rec[a].n_list; ++e_big; }
+                commit(big_rec[a], big_pool.data() + big_rec[a].list_off); ++a;
+                if (trace_find) t_big += since(tc);
+            }
         }
+        if (trace_find)
+            fprintf(stderr, "[find]   replayed here: %zu walked records (%llu take effect, %llu list entries) %.3f ms, %llu records of large components (%llu, %llu) %.3f ms\n",
+                    (size_t)n_deferred, (unsigned long long)e_walked, (unsigned long long)l_walked, t_walked * 1e3, (unsigned long long)n_big, (unsigned long long)e_big, (unsigned long long)l_big, t_big * 1e3);
     }
     tf("large components replayed");
     p_links.resize(p_sides.size());
