@@ -499,6 +499,10 @@ def main():
                     ku[name] = u.value
             return kt, ku
         ktimes_live, kunits_live = kernel_times()
+        # K-BUBBLE is launched once per size class and align range, side by side: what it occupies of a pass is the union of those
+        # launches' intervals, not their sum
+        bub_union = C.c_double()
+        L.pf_kernel_busy(ctx, sum(1 << hipapi.KERNELS.index(k) for k in ("k_bubble", "k_bubble_big") if k in hipapi.KERNELS), C.byref(bub_union))
 
         # the kernel table and the device-busy time (the union of the launches' intervals: the pipeline runs kernels side by side, so
         # the per-kernel sums overlap): further passes, every launch timed, outside the timed region
@@ -601,6 +605,9 @@ def main():
                     per_launch = ab / launches_per_step
                     entry["algorithmic_bytes_per_launch"] = per_launch
                     entry["achieved_GBps"] = round(per_launch / (avg_ms * 1e-3) / 1e9, 2)
+                if name == "k_bubble":
+                    entry["union_ms_per_step"] = round(bub_union.value / args.steps, 3)
+                    entry["note"] = "launches run side by side (a launch per size class and align range): ms_per_step is their SUM, union_ms_per_step what K-BUBBLE occupies of a pass"
                 kernels[name] = entry
                 if ms > dom_ms and ab is not None:
                     dom, dom_ms = name, ms
@@ -641,7 +648,7 @@ def main():
                                             "one rank, whole graph" if world == 1 else
                                             "one independent graph per rank (weak scaling), no data-path collective; "
                                             "per-pass all-gather of the site counters only (%d bytes)" % gathered_bytes[0])},
-                "roofline": roof, "roofline_issue": issue_roofline(dom, kernels[dom]["avg_ms"], n_unitigs) if dom else None,
+                "roofline": roof, "roofline_issue": issue_roofline(dom, kernels[dom]["avg_ms"], n_unitigs, kernels[dom]) if dom else None,
                 "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
                 "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for e in kernels.values()), 3),
                 # union of the launches' [start, end] intervals (HIP events on their streams) over the timed passes / passes;
@@ -729,7 +736,7 @@ def check_outputs(outdir: str, prefix: str, n_unitigs: int, seed: int):
                              "run on %s, %s, by tools/reference_digests.py)" % (n_unitigs, seed, ent.get("host", "?"), ent.get("date", "?"))}
 
 
-def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):
+def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int, entry: dict | None = None):
     """Instruction-issue roofline of a kernel that is bound by issue, not by HBM (K-BUBBLE: its DP lives in registers and LDS):
     vector instructions per launch (SQ_INSTS_VALU, rocprofv3 --pmc pass of this command on this workload, committed as
     profiles/pmc_sq.json) / the launch's measured duration, against what the chip can issue: 256 CUs x 4 SIMDs x 2.4 GHz / 2
@@ -751,8 +758,12 @@ def issue_roofline(kernel: str, avg_ms: float, n_unitigs: int):
         return None
     peak = 256 * 4 * 2.4e9 / 2
     ach = valu / (avg_ms * 1e-3)
+    over_union = None
+    if entry and entry.get("union_ms_per_step") and entry.get("launches_per_step"):
+        # all launches of a pass together, over the time any of them is running
+        over_union = round(valu * entry["launches_per_step"] / (entry["union_ms_per_step"] * 1e-3) / peak, 4)
     return {"kernel": kernel, "bound": "valu-issue", "achieved": round(ach / 1e9, 2), "peak": round(peak / 1e9, 1), "unit": "G wave-instructions/s",
-            "frac": round(ach / peak, 4), "valu_per_launch": valu, "salu_per_launch": salu,
+            "frac": round(ach / peak, 4), "frac_all_launches_over_their_union": over_union, "valu_per_launch": valu, "salu_per_launch": salu,
             "wave_cycle_shares": {k[6:]: v for k, v in e.items() if k.startswith("share_")},
             "source": "profiles/pmc_sq.json (SQ counters per launch) / live HIP-event duration",
             "note": "per launch: the launches of K-BUBBLE's size classes run side by side (five populated classes in each of two align "

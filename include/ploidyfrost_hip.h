@@ -67,6 +67,10 @@ int pf_reset_timing(pf_ctx *);
  * free on a pass of a hundred launches from four host threads; a caller that wants one kernel's durations inside a region it
  * also times as a whole (bench.py: K-BUBBLE for the roofline) selects that kernel alone. */
 int pf_timing_select(pf_ctx *, uint64_t kernel_mask);
+/* The union of the timed launches' intervals of the kernels of the mask, in ms: what a kernel that is launched several times side by
+ * side (K-BUBBLE: a launch per size class and align range) really occupies of a pass -- the sum pf_kernel_time gives counts the
+ * overlap as often as there are launches. */
+int pf_kernel_busy(pf_ctx *, uint64_t kernel_mask, double *busy_ms);
 /* Device-busy time of everything timed since the last reset: the UNION of the launches' [start, end] intervals (HIP events on the
  * streams they were launched on), in ms -- the launches of the calling pipeline overlap (two align ranges, K-BUBBLE's classes on
  * streams of their own, K-TEXT beside the next range's alignment), so the sum pf_kernel_time gives counts overlapped time twice;

@@ -937,7 +937,8 @@ int pf_kernel_time(pf_ctx *ctx, int kernel, double *total_ms, uint64_t *launches
     return PF_OK;
 }
 
-int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) {
+// union of the timed launches' intervals: of every kernel (kernel_mask all ones), or of the kernels of the mask
+static int busy_union(pf_ctx *ctx, uint64_t kernel_mask, double *busy_ms, double *span_ms) {
     if (!ctx) return PF_ERR_ARG;
     PF_HIP(hipSetDevice(ctx->device));
     PF_HIP(hipDeviceSynchronize());
@@ -948,6 +949,7 @@ int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) {
         iv.reserve(ctx->launches.size());
         for (auto &tl : ctx->launches) {
             float a = 0, b = 0;
+            if (!((kernel_mask >> tl.kernel) & 1ull)) continue;
             if (!tl.closed) { ++unread; continue; }
             if (hipEventElapsedTime(&a, ctx->launches[0].a, tl.a) != hipSuccess || hipEventElapsedTime(&b, ctx->launches[0].a, tl.b) != hipSuccess) {
                 // (the device was synchronized above: an event that cannot be read was never recorded -- a launch that failed)
@@ -979,6 +981,9 @@ int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) {
     }
     return PF_OK;
 }
+
+int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) { return busy_union(ctx, ~0ull, busy_ms, span_ms); }
+int pf_kernel_busy(pf_ctx *ctx, uint64_t kernel_mask, double *busy_ms) { return busy_union(ctx, kernel_mask, busy_ms, nullptr); }
 
 int pf_host_alloc(pf_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return PF_ERR_ARG;

@@ -49,8 +49,8 @@ def table_kernels():
         ab = e.get("algorithmic_bytes_per_launch")
         t = tr.get(name)
         s = sq.get(name, {})
-        rows.append("| `%s` %s | %s | %g | %.2f | %s | %s | %s | %s | %s |" % (
-            name, WHAT[name][0], WHAT[name][1], e["launches_per_step"], e["ms_per_step"],
+        rows.append("| `%s` %s | %s | %g | %s | %s | %s | %s | %s | %s |" % (
+            name, WHAT[name][0], WHAT[name][1], e["launches_per_step"], ("%.2f (their union: %.2f)" % (e["ms_per_step"], e["union_ms_per_step"])) if "union_ms_per_step" in e else "%.2f" % e["ms_per_step"],
             ("{:,.0f}".format(e["units_per_step"])) if "units_per_step" in e else "",
             mb(ab) if ab else "",
             ("%.4g GB/s = %.2g %% of 8 TB/s" % (e["achieved_GBps"], e["achieved_GBps"] / 80.0)) if "achieved_GBps" in e else "",
@@ -74,7 +74,10 @@ def table_headline():
             "| `roofline` | %s: %.3g GB/s algorithmic = %.2g of the HBM roof |" % (b["roofline"]["kernel"], b["roofline"]["achieved"], b["roofline"]["frac"]),
             "| `roofline_k_cov` | %.0f GB/s = %.2f of the HBM roof |" % (b["roofline_k_cov"]["achieved"], b["roofline_k_cov"]["frac"])]
     if b.get("roofline_issue"):
-        rows.append("| `roofline_issue` | %s: %.0f G wave-instructions/s = %.2f of the VALU issue roof |" % (b["roofline_issue"]["kernel"], b["roofline_issue"]["achieved"], b["roofline_issue"]["frac"]))
+        ri = b["roofline_issue"]
+        rows.append("| `roofline_issue` | %s: %.0f G wave-instructions/s = %.2f of the VALU issue roof per launch%s |" % (
+            ri["kernel"], ri["achieved"], ri["frac"],
+            ("; all launches of a pass over the time any of them runs: %.2f" % ri["frac_all_launches_over_their_union"]) if ri.get("frac_all_launches_over_their_union") else ""))
     return "\n".join(rows)
 
 
