@@ -122,6 +122,13 @@ int pf_build_adjacency(pf_ctx *, uint32_t *succ, uint32_t *pred);
  * file order.  crowded_slots (optional): slots that reached `limit`; table_out (optional, host or device): the u32 counters. */
 uint64_t pf_minimizer_table_slots(uint64_t n_kmers);
 int pf_minimizer_crowding(pf_ctx *, int g, uint32_t limit, uint32_t *max_occurrences, uint64_t *crowded_slots, uint32_t *table_out);
+/* For a graph that CAN crowd a bucket (max_occurrences >= limit), what the host replay of Bifrost's bookkeeping
+ * (csrc/host/pf_host_minz.cpp) otherwise computes in two passes of its own over every unitig: the census table narrowed to
+ * saturating bytes (pf_minimizer_table_slots(n_kmers) of them) and, per unitig in upload order, whether one of its counted positions
+ * falls into a slot that reached `limit` -- the unitigs that have to go through addUnitig's replay.  Both are upper bounds of the
+ * host's own (ties inside a window count twice here), which only makes the replay follow a few more buckets and unitigs.
+ * counters8_out, unitig_flags_out: [host|dev] */
+int pf_minimizer_replay_inputs(pf_ctx *, int g, uint32_t limit, uint8_t *counters8_out, uint8_t *unitig_flags_out);
 
 /* K-KMC: KMC database ingest on the device.  `records` = the record area of <db>.kmc_suf (after its 4-byte marker): n_records
  * records of suffix_bytes = (k - lut_prefix_len) / 4 suffix bytes (most significant first) + counter_bytes counter bytes (least

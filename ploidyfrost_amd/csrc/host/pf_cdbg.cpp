@@ -159,7 +159,16 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
             if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: minimizer census: " + pf_last_error(ctx_));
         }
         if (most >= 15) {
-            g_.finish_numbering();
+            // (the census table and the unitigs that meet a crowded slot come from the device: the host replay's own two passes over
+            // every unitig were 2.5 of a 3.9 s CLI run at BASELINE.json configs[4]; PF_MINZ_HOST_PASSES=1: as before, measurements)
+            std::vector<uint8_t> cnt8, flg;
+            if (!getenv("PF_MINZ_HOST_PASSES")) {
+                cnt8.resize(pf_minimizer_table_slots(g_.n_kmers));
+                flg.resize(g_.n());
+                st = pf_minimizer_replay_inputs(ctx_, g_.g, 15, cnt8.data(), flg.data());
+                if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: minimizer census: " + pf_last_error(ctx_));
+            }
+            g_.finish_numbering(nullptr, cnt8.empty() ? nullptr : cnt8.data(), flg.empty() ? nullptr : flg.data(), cnt8.size());
             if (g_.n_abundant) {
                 st = pf_upload_graph(ctx_, g_.words.data(), g_.word_off.data(), g_.len_bp.data(), g_.n(), g_.k);
                 if (st != PF_OK) return fail(st, std::string(tag_) + "::" + tag_ + "():Error: graph upload: " + pf_last_error(ctx_));

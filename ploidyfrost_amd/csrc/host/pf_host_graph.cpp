@@ -348,7 +348,7 @@ void UnitigSet::ensure_text() {
     src_->text_ready.store(true, std::memory_order_release);
 }
 
-void UnitigSet::finish_numbering(std::vector<uint8_t> *counters) {
+void UnitigSet::finish_numbering(std::vector<uint8_t> *counters, const uint8_t *dev_counters, const uint8_t *dev_flags, uint64_t dev_counters_len) {
     ensure_text();
     const size_t N = len_bp.size(), n_long = N - (size_t)n_short;
     if (numbering_deferred && n_short && g >= 1 && g <= k - 2 && g <= 31 && file_rank.size() == N) {
@@ -360,7 +360,12 @@ void UnitigSet::finish_numbering(std::vector<uint8_t> *counters) {
             if (u >= n_long) short_of_rank[file_rank[u]] = (uint32_t)(u - n_long);
         }
         UnitigNumbering num;
-        bifrost_numbering(k, g, refs, T, num, counters);
+        std::vector<uint8_t> touches_in;
+        if (dev_counters && dev_flags) {   // (the device's flags are per unitig in the current order; the replay goes by file order)
+            touches_in.resize(N);
+            for (size_t u = 0; u < N; ++u) touches_in[file_rank[u]] = dev_flags[u];
+        }
+        bifrost_numbering(k, g, refs, T, num, counters, touches_in.empty() ? nullptr : dev_counters, touches_in.empty() ? nullptr : touches_in.data(), dev_counters_len);
         numbering_replays = num.replays;
         if (!num.abundant.empty()) {
             n_abundant = num.abundant.size();

@@ -40,7 +40,9 @@ struct UnitigSet {
     // rank of unitig u.  The owner of the device decides with K-MINZ and calls finish_numbering() only if it has to.
     bool numbering_deferred = false;
     std::vector<uint32_t> file_rank;
-    void finish_numbering(std::vector<uint8_t> *counters = nullptr);   // host replay (pf_host_minz.hpp); repacks when the order changed
+    // host replay (pf_host_minz.hpp); repacks when the order changed.  dev_counters / dev_flags: pf_minimizer_replay_inputs' two
+    // arrays (flags per unitig in the current order), sparing the replay its two passes over every unitig
+    void finish_numbering(std::vector<uint8_t> *counters = nullptr, const uint8_t *dev_counters = nullptr, const uint8_t *dev_flags = nullptr, uint64_t dev_counters_len = 0);
     void numbering_settled() { numbering_deferred = false; std::vector<uint32_t>().swap(file_rank); }
 
     uint32_t n() const { return (uint32_t)len_bp.size(); }

@@ -283,7 +283,8 @@ struct Replay {
 
 }  // namespace
 
-void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned threads, UnitigNumbering &out, std::vector<uint8_t> *counters) {
+void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned threads, UnitigNumbering &out, std::vector<uint8_t> *counters,
+                       const uint8_t *counters_in, const uint8_t *touches_in, uint64_t counters_in_len) {
     const bool trace = getenv("PF_TRACE_LOAD") != nullptr;
     auto t_last = std::chrono::steady_clock::now();
     auto mark = [&](const char *what) {
@@ -301,12 +302,13 @@ void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned t
     while (cap < n_kmers / 2 && cap < (1ull << 30)) cap <<= 1;
     std::unique_ptr<std::atomic<uint8_t>[]> cnt(new std::atomic<uint8_t>[cap]);
     const size_t kChunk = 4096;
+    const bool from_device = counters_in != nullptr && touches_in != nullptr && counters_in_len == cap;   // (same table geometry, or not used)
     parallel_chunks((size_t)cap, (size_t)1 << 20, threads, [&](size_t, size_t b0, size_t b1) {
-        for (size_t i = b0; i < b1; ++i) cnt[i].store(0, std::memory_order_relaxed);
+        for (size_t i = b0; i < b1; ++i) cnt[i].store(from_device ? counters_in[i] : (uint8_t)0, std::memory_order_relaxed);
     });
     mark("counter table");
-    std::atomic<bool> any_crowded{false};
-    parallel_chunks(S, kChunk, threads, [&](size_t, size_t s0, size_t s1) {
+    std::atomic<bool> any_crowded{from_device};
+    if (!from_device) parallel_chunks(S, kChunk, threads, [&](size_t, size_t s0, size_t s1) {
         std::vector<MinRes> scratch;
         bool crowded = false;
         for (size_t i = s0; i < s1; ++i) {
@@ -334,7 +336,8 @@ void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned t
         rp.cnt = cnt.get();
         rp.cnt_mask = cap - 1;
         rp.extra = &extra;
-        parallel_chunks(S, kChunk, threads, [&](size_t, size_t s0, size_t s1) {
+        if (from_device && extra.empty()) memcpy(touches.data(), touches_in, S);   // (first round: the device's flags)
+        else parallel_chunks(S, kChunk, threads, [&](size_t, size_t s0, size_t s1) {
             std::vector<MinRes> scratch;
             for (size_t i = s0; i < s1; ++i) {
                 const SegRef &sg = segs[i];

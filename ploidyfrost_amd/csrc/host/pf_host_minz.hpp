@@ -32,7 +32,10 @@ struct UnitigNumbering {
 
 // segs in file order; g <= k - 2 (bifrost/src/CompactedDBG.tcc:8383).  counters (optional): the saturating occurrence
 // counters of step 1, slot = mix(canonical minimizer) & (size - 1) -- the table the device pass (K-MINZ) bounds from above.
+// counters_in / touches_in (optional, both or neither): what the device pass already knows (pf_minimizer_replay_inputs) -- the counter
+// table (upper bounds of step 1's, same geometry) and per seg whether it meets a slot that reached the limit: steps 1 and 2 of this
+// function, each a pass over every unitig, are then skipped (a later round of the replay, after a redirect, still flags on its own).
 void bifrost_numbering(int k, int g, const std::vector<SegRef> &segs, unsigned threads, UnitigNumbering &out,
-                       std::vector<uint8_t> *counters = nullptr);
+                       std::vector<uint8_t> *counters = nullptr, const uint8_t *counters_in = nullptr, const uint8_t *touches_in = nullptr, uint64_t counters_in_len = 0);
 
 }  // namespace pfh

@@ -65,10 +65,15 @@ __device__ inline uint64_t gmer_hash_rep(uint64_t fw, int g, uint64_t &rep) {
     return wymix(wyp1 ^ 16, wymix(a ^ wyp1, b ^ wyp0));
 }
 
+// FLAG = false: the census (every counted position adds one to its slot).  FLAG = true, behind the census: a unitig is flagged when
+// one of its counted positions falls into a slot that reached `limit` -- the unitigs the host replay has to run through
+// Bifrost's addUnitig (host/pf_host_minz.cpp: its own pass over all unitigs, 1.3 s at 10 M unitigs, for the same answer).
+template <bool FLAG>
 __global__ __launch_bounds__(256) void k_minz_count(const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
                                                     const uint32_t *__restrict__ len, uint32_t N, int k, int g,
                                                     uint32_t *__restrict__ table, uint64_t mask, uint32_t limit,
-                                                    unsigned int *__restrict__ out /* [0] max count, [1] slots that reached limit */) {
+                                                    unsigned int *__restrict__ out /* [0] max count, [1] slots that reached limit */,
+                                                    uint8_t *__restrict__ flags /* FLAG: one byte per unitig */) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (uint32_t)(((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6);
     const uint32_t n_waves = (uint32_t)(((uint64_t)gridDim.x * blockDim.x) >> 6);
@@ -79,6 +84,7 @@ __global__ __launch_bounds__(256) void k_minz_count(const uint64_t *__restrict__
         const uint64_t *w = seq + off[u];
         const int L = (int)len[u];
         const int n_km = L - k + 1, pmax = L - g - 1;   // positions 1 .. pmax carry minimizers
+        bool hit = false;
         for (int q0 = 1; q0 <= pmax; q0 += TQ) {
             const int ts = q0 - (W - 1);
             const int q = ts + lane;
@@ -108,12 +114,21 @@ __global__ __launch_bounds__(256) void k_minz_count(const uint64_t *__restrict__
                 if (interior && j >= 0 && ((wvalid >> j) & 1) && m == h) counted = true;
             }
             if (counted) {
-                const uint32_t c = atomicAdd(&table[mix64_minz(rep) & mask], 1u) + 1;
-                if (c > my_max) my_max = c;
-                if (c == limit) ++my_crowded;
+                if (FLAG) {
+                    if (table[mix64_minz(rep) & mask] >= limit) hit = true;
+                } else {
+                    const uint32_t c = atomicAdd(&table[mix64_minz(rep) & mask], 1u) + 1;
+                    if (c > my_max) my_max = c;
+                    if (c == limit) ++my_crowded;
+                }
             }
         }
+        if (FLAG) {
+            const unsigned long long any = __ballot(hit);
+            if (lane == 0) flags[u] = any ? 1 : 0;
+        }
     }
+    if (FLAG) return;
     for (int o = 32; o > 0; o >>= 1) {
         const uint32_t m = __shfl_down(my_max, o, 64), c = __shfl_down(my_crowded, o, 64);
         if (m > my_max) my_max = m;
@@ -123,6 +138,11 @@ __global__ __launch_bounds__(256) void k_minz_count(const uint64_t *__restrict__
         if (my_max) atomicMax(&out[0], my_max);
         if (my_crowded) atomicAdd(&out[1], my_crowded);
     }
+}
+
+__global__ void k_minz_narrow(const uint32_t *__restrict__ table, uint64_t slots, uint8_t *__restrict__ out) {
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < slots) out[i] = (uint8_t)(table[i] < 255u ? table[i] : 255u);
 }
 
 }  // namespace pf
@@ -151,8 +171,8 @@ int pf_minimizer_crowding(pf_ctx *ctx, int g, uint32_t limit, uint32_t *max_occu
     PF_HIP(hipMemsetAsync(table.p, 0, slots * 4, ctx->stream));
     PF_HIP(hipMemsetAsync(out.p, 0, 8, ctx->stream));
     ctx_begin(ctx, PF_K_MINZ);
-    k_minz_count<<<ctx_grid(ctx, (uint64_t)ctx->N * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_seq, ctx->d_off, ctx->d_len, ctx->N, ctx->k, g, table.p,
-                                                                                         slots - 1, limit, out.p);
+    k_minz_count<false><<<ctx_grid(ctx, (uint64_t)ctx->N * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_seq, ctx->d_off, ctx->d_len, ctx->N, ctx->k, g, table.p,
+                                                                                                slots - 1, limit, out.p, nullptr);
     ctx_end(ctx);
     unsigned int h[2] = {0, 0};
     PF_HIP(hipMemcpyAsync(h, out.p, 8, hipMemcpyDeviceToHost, ctx->stream));
@@ -160,6 +180,35 @@ int pf_minimizer_crowding(pf_ctx *ctx, int g, uint32_t limit, uint32_t *max_occu
     PF_HIP(hipStreamSynchronize(ctx->stream));
     *max_occurrences = h[0];
     if (crowded_slots) *crowded_slots = h[1];
+    return PF_OK;
+}
+
+int pf_minimizer_replay_inputs(pf_ctx *ctx, int g, uint32_t limit, uint8_t *counters8_out, uint8_t *unitig_flags_out) {
+    if (!ctx || !ctx->d_seq || !counters8_out || !unitig_flags_out || g < 1 || g > 31 || g > ctx->k - 2 || limit == 0) {
+        if (ctx) pf::CtxErr{ctx} = "pf_minimizer_replay_inputs: no graph uploaded, or g outside 1 .. min(31, k - 2)";
+        return PF_ERR_ARG;
+    }
+    PF_HIP(hipSetDevice(ctx->device));
+    const uint64_t slots = pf_minimizer_table_slots(ctx->n_kmers);
+    DevTmp<uint32_t> table;
+    DevTmp<unsigned int> out;
+    DevTmp<uint8_t> narrow, flags;
+    PF_HIP(table.alloc(slots * 4));
+    PF_HIP(out.alloc(8));
+    PF_HIP(narrow.alloc(slots));
+    PF_HIP(flags.alloc(ctx->N));
+    PF_HIP(hipMemsetAsync(table.p, 0, slots * 4, ctx->stream));
+    PF_HIP(hipMemsetAsync(out.p, 0, 8, ctx->stream));
+    const int grid = ctx_grid(ctx, (uint64_t)ctx->N * 64, 256, 16);
+    ctx_begin(ctx, PF_K_MINZ);
+    k_minz_count<false><<<grid, 256, 0, ctx->stream>>>(ctx->d_seq, ctx->d_off, ctx->d_len, ctx->N, ctx->k, g, table.p, slots - 1, limit, out.p, nullptr);
+    k_minz_count<true><<<grid, 256, 0, ctx->stream>>>(ctx->d_seq, ctx->d_off, ctx->d_len, ctx->N, ctx->k, g, table.p, slots - 1, limit, out.p, flags.p);
+    k_minz_narrow<<<(unsigned)((slots + 255) / 256), 256, 0, ctx->stream>>>(table.p, slots, narrow.p);
+    ctx_end(ctx);
+    PF_HIP(hipGetLastError());
+    PF_HIP(hipMemcpyAsync(counters8_out, narrow.p, slots, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(unitig_flags_out, flags.p, ctx->N, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
     return PF_OK;
 }
 

@@ -125,6 +125,7 @@ def load_library() -> C.CDLL:
         "pf_unitig_cov_exact": (i, [vp, u32, u32, i, vp, vp, vp]),
         "pf_minimizer_table_slots": (u64, [u64]),
         "pf_minimizer_crowding": (i, [vp, i, u32, vp, vp, vp]),
+        "pf_minimizer_replay_inputs": (i, [vp, i, C.c_uint32, vp, vp]),
         "pf_kmc_decode": (i, [vp, vp, u64, u32, u32, vp, u64, u32, u32, vp, vp]),
         "pf_device_free": (None, [vp, vp]),
         "pf_copy_to_host": (i, [vp, vp, vp, C.c_size_t]),
@@ -183,7 +184,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
-                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
+                    "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_minimizer_replay_inputs", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
                     "pf_call_set_state", "pf_call_set_format", "pf_superbubble_rows", "pf_superbubble_fetch", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_resolve", "pf_call_select", "pf_call_run", "pf_call_align",
                     "pf_call_text", "pf_call_set_alignseq_packed", "pf_comm_unique_id", "pf_comm_init", "pf_gather", "pf_comm_destroy", "pf_call_reserve", "pf_call_reserve_lanes", "pf_timing_select", "pf_kernel_busy", "pf_call_reserve_text", "pf_find_reserve", "pf_call_set_colours", "pf_call_set_cutoffs", "pf_call_peek", "pf_call_text_range", "pf_call_align_lane", "pf_call_text_range_lane", "pf_call_text_sizes", "pf_call_fetch", "pf_call_fetch_slab", "pf_call_fetch_range", "pf_call_fetch_wait", "pf_format_doubles"]
 
