@@ -122,6 +122,9 @@ uint32_t pfh_gfa_numbering_replays(const char *gfa_path);
  * the number of slots (0 when the graph has no k-length unitig to decide about) and fills counters when slots suffices */
 uint64_t pfh_gfa_minimizer_counts(const char *gfa_path, uint8_t *counters, uint64_t slots);
 int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path);
+/* [tests] the same file through the numbering replay with its inputs handed in (as pf_minimizer_replay_inputs hands them over): the host's
+ * own counters + bump (saturating upper bounds), every unitig flagged */
+int pfh_gfa_write_unitig_ids_given_inputs(const char *gfa_path, const char *out_path, int bump);
 /* ---- `PloidyFrost model`: class GmmModel (src/GmmModel.hpp:5-49) and the driver of src/Main.cpp:636-692 ------------------
  * pfh_gmm_open needs no device; the readers are the reference's text parsers (readFreFile src/GmmModel.cpp:240-257,
  * readCovFile :21-239); pfh_gmm_fit = setMThreshold/setNThreshold/setMaxIterNum/setMaxDeltaNum + resize(gauss) +

@@ -479,6 +479,35 @@ int pfh_gfa_write_unitig_ids(const char *gfa_path, const char *out_path) {
         return 1;
     }
 }
+// The numbering with the replay's inputs handed in, as the device layer hands them over (pf_minimizer_replay_inputs): `bump` is added to
+// every counter of the host's own pass (saturating: upper bounds, as K-MINZ's are) and every unitig is flagged.  Must write the same
+// file as pfh_gfa_write_unitig_ids.  [tests]
+int pfh_gfa_write_unitig_ids_given_inputs(const char *gfa_path, const char *out_path, int bump) {
+    try {
+        std::vector<uint8_t> c;
+        {
+            pfh::UnitigSet probe;
+            if (!probe.load_gfa(gfa_path, g_open_err, true)) return 1;
+            probe.finish_numbering(&c);
+        }
+        for (uint8_t &x : c) x = (uint8_t)std::min<int>(255, (int)x + bump);
+        pfh::UnitigSet g;
+        if (!g.load_gfa(gfa_path, g_open_err, true)) return 1;
+        const std::vector<uint8_t> flags(g.n(), 1);
+        g.finish_numbering(nullptr, c.empty() ? nullptr : c.data(), c.empty() ? nullptr : flags.data(), c.size());
+        FILE *f = fopen(out_path, "w");
+        if (!f) { g_open_err = std::string("cannot write ") + out_path; return 1; }
+        for (uint32_t u = 0; u < g.n(); ++u) {
+            const std::string_view s = g.seq(u);
+            fprintf(f, "%u\t%.*s\n", u + 1, (int)s.size(), s.data());
+        }
+        fclose(f);
+        return 0;
+    } catch (const std::exception &e) {
+        g_open_err = std::string("ploidyfrost host layer: ") + e.what();
+        return 1;
+    }
+}
 // ---- `PloidyFrost model` ---------------------------------------------------------------------------------------------
 pfh_gmm *pfh_gmm_open(int device) {
     try {

@@ -29,7 +29,7 @@ DECLARED_SYMBOLS = ["pfh_open", "pfh_close", "pfh_last_error", "pfh_set_output_d
                     "pfh_find_superbubbles", "pfh_ploidy_estimation", "pfh_get_times", "pfh_load_trace", "pfh_filter", "pfh_r_format_double", "pfh_device_ctx", "pfh_state", "pfh_last_allele_frequency",
                     "pfh_open_colored", "pfh_num_colors", "pfh_ploidy_estimation_colored",
                     "pfh_colors_open", "pfh_colors_close", "pfh_colors_count", "pfh_colors_unitigs", "pfh_colors_name",
-                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints", "pfh_colors_check_footprints",
+                    "pfh_colors_unitig", "pfh_bifrost_kmer_hash", "pfh_gfa_abundant_kmers", "pfh_gfa_write_unitig_ids", "pfh_gfa_write_unitig_ids_given_inputs", "pfh_gfa_numbering_replays", "pfh_gfa_minimizer_counts", "pfh_host_walk", "pfh_host_walk_range", "pfh_replay_open", "pfh_replay_close", "pfh_replay_apply", "pfh_replay_state", "pfh_replay_apply_parallel", "pfh_side_components", "pfh_replay_check_footprints", "pfh_colors_check_footprints",
                     "pfh_find_shard", "pfh_shard_records", "pfh_shard_pool", "pfh_find_replay", "pfh_set_replay_threads", "pfh_set_write_super_bubble", "pfh_ploidy_select", "pfh_ploidy_select_colored", "pfh_ploidy_align", "pfh_ploidy_text", "pfh_ploidy_write",
                     "pfh_gmm_open", "pfh_gmm_close", "pfh_gmm_last_error", "pfh_gmm_read_fre", "pfh_gmm_read_cov", "pfh_gmm_set_values",
                     "pfh_gmm_size", "pfh_gmm_values", "pfh_gmm_fit", "pfh_gmm_run", "pfh_gmm_kernel_time"]
@@ -94,6 +94,8 @@ def load_library() -> C.CDLL:
     L.pfh_gfa_minimizer_counts.argtypes = [C.c_char_p, C.c_void_p, C.c_uint64]
     L.pfh_gfa_write_unitig_ids.restype = C.c_int
     L.pfh_gfa_write_unitig_ids.argtypes = [C.c_char_p, C.c_char_p]
+    L.pfh_gfa_write_unitig_ids_given_inputs.restype = C.c_int
+    L.pfh_gfa_write_unitig_ids_given_inputs.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
     u32, u64 = C.c_uint32, C.c_uint64
     L.pfh_find_shard.argtypes = [vp, u32, u32]
     L.pfh_shard_records.restype = vp

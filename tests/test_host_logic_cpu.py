@@ -271,6 +271,24 @@ def test_abundant_numbering_agrees_with_the_reference(tmp_path, k, g):
     assert replays >= 2   # redirects into buckets the first replay had not followed
 
 
+@pytest.mark.parametrize("k,g", [(25, 17), (31, 23), (15, 8)])
+def test_numbering_replay_with_its_inputs_handed_in(tmp_path, k, g):
+    """On a GPU box the replay's two passes over every unitig come from K-MINZ (pf_minimizer_replay_inputs): a counter table that bounds
+    the host's from above, and flags that cover the unitigs the host would flag.  Here the host's own counters, raised by 0 / 1 / 3
+    (saturating), with every unitig flagged: the numbering must not change -- upper bounds only make the replay follow more buckets."""
+    from ploidyfrost_amd import hostapi
+    L = hostapi.load_library()
+    for name, seqs in _crowded_graphs(k + 1, k, g).items():
+        gfa = str(tmp_path / ("%s.gfa" % name))
+        _write_gfa(gfa, seqs, k, g)
+        want = str(tmp_path / "want.txt")
+        assert L.pfh_gfa_write_unitig_ids(gfa.encode(), want.encode()) == 0
+        for bump in (0, 1, 3):
+            got = str(tmp_path / "got.txt")
+            assert L.pfh_gfa_write_unitig_ids_given_inputs(gfa.encode(), got.encode(), bump) == 0
+            assert open(got, "rb").read() == open(want, "rb").read(), (name, bump)
+
+
 def test_work_pool(tmp_path):
     """The host layer's persistent fork-join pool, on its own (no GPU, no library): tests/cpp/test_workpool.cpp."""
     import shutil
