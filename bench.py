@@ -519,6 +519,11 @@ def main():
             dist.barrier()
         busy_ms, span_ms = C.c_double(), C.c_double()
         L.pf_device_busy(ctx, C.byref(busy_ms), C.byref(span_ms))
+        # ... and without the copies of the result text to the host (the runtime moves them with a kernel of its own on the device:
+        # rocprofv3 lists it as __amd_rocclr_copyBuffer; the library times them as "copy_text_to_host")
+        busy_own = C.c_double()
+        copy_bit = 1 << hipapi.KERNELS.index("copy_text_to_host")
+        L.pf_kernel_busy(ctx, ((1 << len(hipapi.KERNELS)) - 1) & ~copy_bit, C.byref(busy_own))
         ktimes, kunits = kernel_times()
 
         # outside the timed region: C1 computed the other way (every k-mer probed in the hash table, what K-COV-JOIN does once
@@ -650,12 +655,13 @@ def main():
                                             "per-pass all-gather of the site counters only (%d bytes)" % gathered_bytes[0])},
                 "roofline": roof, "roofline_issue": issue_roofline(dom, kernels[dom]["avg_ms"], n_unitigs, kernels[dom]) if dom else None,
                 "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
-                "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for e in kernels.values()), 3),
+                "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for n_, e in kernels.items() if n_ != "copy_text_to_host"), 3),
                 # union of the launches' [start, end] intervals (HIP events on their streams) over the timed passes / passes;
                 # tools/summarize_prof.py gives the same figure from the rocprofv3 kernel trace (profiles/*_device_busy.json)
                 # (of the table passes, where every launch carries events; their own wall time is the denominator)
                 "device_busy_ms_per_step": round(busy_ms.value / TABLE_PASSES, 3),
                 "device_busy_frac": round(busy_ms.value / (table_elapsed * 1e3), 4),
+                "device_busy_frac_own_kernels_only": round(busy_own.value / (table_elapsed * 1e3), 4),
                 "kernel_table": {"passes": TABLE_PASSES, "ms_per_pass_with_every_launch_timed": round(table_elapsed / TABLE_PASSES * 1e3, 2),
                                  "note": "inside the timed region only the roofline kernels' launches carry HIP events (" + ", ".join(sorted(ktimes_live)) +
                                          "); the other rows of `kernels`, gpu_kernel_ms_per_step and device_busy_* are from these further passes"},

@@ -58,7 +58,9 @@ int pf_synchronize(pf_ctx *);
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
     PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN,
-    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_BFS_THREAD, PF_K_CALL_PAIR, PF_K_CALL_STACK, PF_K_CALL_TRIO, PF_K_COUNT_
+    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_BFS_THREAD, PF_K_CALL_PAIR, PF_K_CALL_STACK, PF_K_CALL_TRIO,
+    PF_K_COPY_TEXT, /* not a kernel of this library: the copies of result text to the host (the runtime moves them with a kernel of its own) */
+    PF_K_COUNT_
 };
 int pf_enable_timing(pf_ctx *, int on);
 int pf_kernel_time(pf_ctx *, int kernel, double *total_ms, uint64_t *launches);

@@ -3208,7 +3208,10 @@ int pf_superbubble_fetch(pf_ctx *ctx, char *dst, uint64_t len) {
     if (len > S->sb_len) return PF_ERR_ARG;
     if (len == 0) return PF_OK;
     if (hipSetDevice(ctx->device) != hipSuccess || !S->copy_stream) return PF_ERR_HIP;
+    size_t tl_at = (size_t)-1;
+    (void)ctx_begin_at(ctx, PF_K_COPY_TEXT, S->copy_stream, &tl_at);
     if (hipMemcpyAsync(dst, S->sb_out.p, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    ctx_end_at(ctx, tl_at, S->copy_stream);
     if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
 }
@@ -4231,6 +4234,8 @@ int pf_call_fetch_slab(pf_ctx *ctx, int slab, char *dst, const uint64_t *len) {
         whole = whole && len[s] == S->out_len[slab][s];
         at += len[s];
     }
+    size_t tl_at = (size_t)-1;
+    (void)ctx_begin_at(ctx, PF_K_COPY_TEXT, S->copy_stream, &tl_at);
     if (whole) {   // the slab as it lies: one copy
         if (at && hipMemcpyAsync(dst, S->out[slab].p, (size_t)at, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     } else {
@@ -4241,6 +4246,7 @@ int pf_call_fetch_slab(pf_ctx *ctx, int slab, char *dst, const uint64_t *len) {
             at += len[s];
         }
     }
+    ctx_end_at(ctx, tl_at, S->copy_stream);
     if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
 }
@@ -4257,7 +4263,10 @@ int pf_call_fetch_range(pf_ctx *ctx, int slab, uint64_t first_byte, char *dst, u
     if (hipSetDevice(ctx->device) != hipSuccess || !S->copy_stream) return PF_ERR_HIP;
     if (!S->fetch_ev[slot] && hipEventCreateWithFlags(&S->fetch_ev[slot], hipEventDisableTiming) != hipSuccess) return PF_ERR_HIP;
     if (S->text_ev[slab] && hipStreamWaitEvent(S->copy_stream, S->text_ev[slab], 0) != hipSuccess) return PF_ERR_HIP;
+    size_t tl_at = (size_t)-1;
+    (void)ctx_begin_at(ctx, PF_K_COPY_TEXT, S->copy_stream, &tl_at);
     if (len && hipMemcpyAsync(dst, S->out[slab].as<char>() + first_byte, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    ctx_end_at(ctx, tl_at, S->copy_stream);
     if (hipEventRecord(S->fetch_ev[slot], S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
 }
