@@ -18,8 +18,13 @@ enum : uint8_t { UP = 1, DIAG = 2, LEFT = 4 };
 __host__ __device__ inline uint32_t al4(uint32_t x) { return (x + 3u) & ~3u; }
 
 // bytes of working storage one job needs (must match the carve-up in align_job)
+// The direction matrix takes four bits a cell (the three flags of src/SeqAlign.cpp:497-549), two cells a byte, every row on a byte
+// boundary: row i begins at byte i * dir_row_bytes(n), cell (i, j) is nibble j & 1 of byte j >> 1 of its row.  (Rounds 1-3 kept a
+// byte a cell: the flags, and above them the flags the depth-first traceback had not tried yet; those now live on the walk's own
+// stack.  Half the matrix = twice the wavefronts of a size class in a CU's LDS.)
+__host__ __device__ inline uint32_t dir_row_bytes(uint32_t n) { return (n + 2u) >> 1; }
 __host__ __device__ inline uint64_t job_bytes(uint32_t m, uint32_t n) {
-    const uint64_t cells = (uint64_t)(m + 1) * (n + 1);
+    const uint64_t cells = (uint64_t)(m + 1) * dir_row_bytes(n);
     const uint64_t mx = m > n ? m : n;
     return ((cells + 3) & ~3ull) + 12ull * (mx + 1) + al4(m) + al4(n) + 3ull * al4(m + n) + al4(2 * (m + n)) + 16;
 }
@@ -57,7 +62,7 @@ __device__ inline void aln_sync() {
 template <bool INTEGRAL>
 __device__ inline void nw_fill(uint8_t *dir, int *s0, const char *A, const char *B, uint32_t m, uint32_t n, double M, double D, double G) {
     const int lane = lane_id();
-    const uint32_t W = n + 1;
+    const uint32_t RB = dir_row_bytes(n);
     // Rows are processed in blocks of 64, one row per lane; inside a block the anti-diagonal
     // wavefront lives in registers: at step t lane l owns cell (row, t - l + 1), its left neighbour is
     // its own previous cell, the cells above / above-left are what lane l-1 produced one / two steps
@@ -69,6 +74,7 @@ __device__ inline void nw_fill(uint8_t *dir, int *s0, const char *A, const char 
     for (uint32_t blk = 0; blk < n_blocks; ++blk) {
         const uint32_t row0 = blk * 64;  // the row above this block
         const uint32_t r = row0 + lane + 1;
+        int pend = UP;   // the flags of the cell before the one being computed: column 0 of a row below the first is the border's UP
         const bool row_ok = r <= m;
         const char a = row_ok ? A[r - 1] : '\0';
         const bool next_is_gap = row_ok && r != m && A[r] == '-';  // the look-ahead of :528-532
@@ -132,7 +138,10 @@ __device__ inline void nw_fill(uint8_t *dir, int *s0, const char *A, const char 
                 last2_f = last_f;
                 last_s = best;
                 last_f = f;
-                dir[r * W + j] = (uint8_t)(f | (f << 4));
+                // one store a step, no branch: an even column writes its byte with the upper half empty, the odd column after it writes
+                // the same byte again with both halves (cells j - 1 and j of this lane's row)
+                dir[r * RB + ((uint32_t)j >> 1)] = (uint8_t)((j & 1) ? (pend | (f << 4)) : f);
+                pend = f;
                 if (feeds_next) { brow_s[j] = best; brow_f[j] = (uint8_t)f; }
             }
         }
@@ -146,13 +155,14 @@ __device__ inline void nw_fill(uint8_t *dir, int *s0, const char *A, const char 
 // anti-diagonal step instead of five, half the register moves around them.  Same cells, same values, same flags.
 __device__ inline void nw_fill_packed(uint8_t *dir, int *s0, const char *A, const char *B, uint32_t m, uint32_t n, int Mi, int Di, int Gi) {
     const int lane = lane_id();
-    const uint32_t W = n + 1;
+    const uint32_t RB = dir_row_bytes(n);
     int *brow_s = s0;
     uint8_t *brow_f = reinterpret_cast<uint8_t *>(s0 + (n + 1));
     const uint32_t n_blocks = (m + 63) / 64;
     for (uint32_t blk = 0; blk < n_blocks; ++blk) {
         const uint32_t row0 = blk * 64;
         const uint32_t r = row0 + lane + 1;
+        int pend = UP;   // the flags of the cell before the one being computed: column 0 of a row below the first is the border's UP
         const bool row_ok = r <= m;
         const char a = row_ok ? A[r - 1] : '\0';
         const bool next_is_gap = row_ok && r != m && A[r] == '-';
@@ -191,7 +201,10 @@ __device__ inline void nw_fill_packed(uint8_t *dir, int *s0, const char *A, cons
                 if (lf == best) f |= LEFT;
                 last2 = last;
                 last = (best << 3) | f;
-                dir[r * W + j] = (uint8_t)(f | (f << 4));
+                // one store a step, no branch: an even column writes its byte with the upper half empty, the odd column after it writes
+                // the same byte again with both halves (cells j - 1 and j of this lane's row)
+                dir[r * RB + ((uint32_t)j >> 1)] = (uint8_t)((j & 1) ? (pend | (f << 4)) : f);
+                pend = f;
                 if (feeds_next) { brow_s[j] = best; brow_f[j] = (uint8_t)f; }
             }
         }
@@ -205,9 +218,11 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                           double M, double D, double G, int integral, const AlnScratch &sc, uint32_t &n_hits_out,
                           uint32_t &text_out, uint32_t &gaps_out, unsigned long long *prof = nullptr) {
     const int lane = lane_id();
-    const uint32_t W = n + 1;
-    const uint32_t cells = (m + 1) * W;
+    const uint32_t RB = dir_row_bytes(n);
+    const uint32_t cells = (m + 1) * RB;
     uint8_t *dir = base;
+    // the three flags of cell (i, j)
+    auto flags_at = [&](uint32_t i, uint32_t j) -> uint8_t { return (uint8_t)((dir[i * RB + (j >> 1)] >> ((j & 1u) << 2)) & 7u); };
     int *s0 = reinterpret_cast<int *>(base + ((cells + 3) & ~3u));
     const uint32_t mx = m > n ? m : n;
     char *A = reinterpret_cast<char *>(s0 + 3 * (mx + 1));
@@ -221,8 +236,11 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
     for (uint32_t i = lane; i < m; i += WAVE) A[i] = ga[i];
     for (uint32_t j = lane; j < n; j += WAVE) B[j] = gb[j];
     // borders (src/SeqAlign.cpp:486-496)
-    for (uint32_t i = lane; i <= m; i += WAVE) dir[i * W] = i ? (uint8_t)(UP | (UP << 4)) : 0;
-    for (uint32_t j = 1 + lane; j <= n; j += WAVE) dir[j] = (uint8_t)(LEFT | (LEFT << 4));
+    // (row 0: LEFT from column 1 on; column 0 of the rows below, UP, is written by the fill together with their column 1)
+    for (uint32_t q = lane; q < RB; q += WAVE)
+        dir[q] = (uint8_t)((q != 0 && 2 * q <= n ? LEFT : 0) | ((2 * q + 1 <= n ? LEFT : 0) << 4));
+    if (n == 0)
+        for (uint32_t i = 1 + lane; i <= m; i += WAVE) dir[i * RB] = UP;
     aln_sync();
     // ---- fill ---------------------------------------------------------------------------------
     if (integral) {
@@ -249,7 +267,7 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         uint32_t i = m, j = n, oa = 0, ob = 0;
         char fa = '\0', fb = '\0';
         while (i > 0 || j > 0) {
-            const uint8_t f = dir[i * W + j] & 7;
+            const uint8_t f = flags_at(i, j);
             char ca, cb;
             if (f == DIAG) {
                 ca = A[i - 1];
@@ -363,8 +381,16 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
         // all that remains of the walk is its unwinding, which finds nothing and whose restored flags nobody will read -- the walk
         // ends there (a hundred steps of the two hundred a job takes: one complete path, kept, and the way back)
         uint32_t alts = 0;
+        // The directions still to be tried at the current cell (the reference's matrix_temp entry, src/SeqAlign.cpp:306-478): the
+        // cell's flags when the walk arrives, less what it has tried from there.  For the cells below on the stack they are kept with
+        // the move that left them (mv: move in the low nibble, what was left to try in the high one) -- the matrix itself is only
+        // written when a gap move is refused for lack of budget, which removes that direction from the cell for good.
+        uint8_t work = flags_at(i, j);
+        auto drop_flag = [&](uint32_t ci, uint32_t cj, uint8_t f) {
+            uint8_t &b = dir[ci * RB + (cj >> 1)];
+            b = (uint8_t)(b & ~(f << ((cj & 1u) << 2)));
+        };
         for (;;) {
-            const uint32_t c = i * W + j;
             if (prof) ++st_steps;
             if (i == 0 && j == 0 && open_a <= lim_a && open_b <= lim_b && !have) {
                 // The first complete path is kept whatever it scores.  Nineteen walks of twenty find no second one and end a few steps
@@ -449,37 +475,28 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 }
                 if (prof) st_leaf_ticks += wall_clock64() - tl0;
             }
-            // (the three loads of a step -- the cell's flags and the two characters a move would consume -- leave together; the top of
-            // the stack is carried in registers: a step that waits for one memory round trip where it waited for three in a row)
-            const uint8_t dc = dir[c];
-            if ((dc >> 4) == DIAG) {
+            if (work == DIAG) {
                 // The commonest step by far, in a loop of its own: a run of cells whose only open direction is the diagonal (the
                 // general step below does exactly this for each of them, behind its tests for the leaf and the two gap moves)
-                uint32_t ii = i, jj = j, ll = len, cc = c;
-                uint8_t d2 = dc;
                 char na2, nb2;
                 for (;;) {
-                    na2 = A[ii - 1];
-                    nb2 = B[jj - 1];
-                    dir[cc] = d2 & (uint8_t) ~(DIAG << 4);
-                    ra[ll] = na2;
-                    rb[ll] = nb2;
-                    mv[ll] = DIAG;
-                    ++ll;
-                    --ii;
-                    --jj;
-                    if (ii == 0 || jj == 0) break;   // (a border cell: the general step)
-                    cc = ii * W + jj;
-                    d2 = dir[cc];
-                    if ((d2 >> 4) != DIAG) break;
+                    na2 = A[i - 1];
+                    nb2 = B[j - 1];
+                    ra[len] = na2;
+                    rb[len] = nb2;
+                    mv[len] = DIAG;   // (nothing left to try at the cell that is left)
+                    ++len;
+                    --i;
+                    --j;
+                    work = flags_at(i, j);
+                    if (i == 0 || j == 0) break;   // (a border cell: the general step)
+                    if (work != DIAG) break;
                     if (prof) ++st_steps;
                 }
-                i = ii; j = jj; len = ll;
                 top_a = na2; top_b = nb2;
                 continue;
             }
             const char na = i ? A[i - 1] : '\0', nb = j ? B[j - 1] : '\0';
-            const uint8_t work = dc >> 4;
             const char fa = top_a;
             const char fb = top_b;
             if (work & LEFT) {
@@ -492,20 +509,21 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 } else {
                     go = false;
                 }
+                work &= (uint8_t) ~LEFT;
                 if (!go) {
-                    dir[c] = dc & (uint8_t) ~(LEFT | (LEFT << 4));
+                    drop_flag(i, j, LEFT);
                     continue;
                 }
-                dir[c] = dc & (uint8_t) ~(LEFT << 4);
-                alts += (work & (uint8_t) ~LEFT) != 0;
+                alts += work != 0;
                 ra[len] = '+';
                 rb[len] = nb;
                 top_a = '+';
                 top_b = nb;
-                mv[len] = LEFT;
+                mv[len] = (uint8_t)(LEFT | (work << 4));
                 gp[ng++] = (uint16_t)i;
                 len++;
                 j -= 1;
+                work = flags_at(i, j);
             } else if (work & UP) {
                 bool go;
                 if (open_b < lim_b) {
@@ -516,21 +534,21 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 } else {
                     go = false;
                 }
+                work &= (uint8_t) ~UP;
                 if (!go) {
-                    dir[c] = dc & (uint8_t) ~(UP | (UP << 4));
+                    drop_flag(i, j, UP);
                     continue;
                 }
-                dir[c] = dc & (uint8_t) ~(UP << 4);
-                alts += (work & (uint8_t) ~UP) != 0;
+                alts += work != 0;
                 ra[len] = na;
                 rb[len] = '-';
                 top_a = na;
                 top_b = '-';
-                mv[len] = UP;
+                mv[len] = (uint8_t)(UP | (work << 4));
                 len++;
                 i -= 1;
+                work = flags_at(i, j);
             } else if (work & DIAG) {
-                dir[c] = dc & (uint8_t) ~(DIAG << 4);
                 ra[len] = na;
                 rb[len] = nb;
                 top_a = na;
@@ -539,11 +557,10 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                 len++;
                 i -= 1;
                 j -= 1;
+                work = flags_at(i, j);
             } else {
                 // nothing left to try at this cell: back up -- and on, in this loop, through every cell that has nothing left either
                 // (the unwinding behind a complete path: a hundred cells with one direction each)
-                uint32_t cc = c;
-                uint8_t d2 = dc;
                 char ta = fa, tb = fb;
                 bool out = false;
                 for (;;) {
@@ -589,7 +606,6 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                         pending = 0;
                         if (prof) st_leaf_ticks += wall_clock64() - tl0;
                     }
-                    dir[cc] = (uint8_t)((d2 & 0x0F) | ((d2 & 0x0F) << 4));  // matrix_temp[p] = matrix[p]
                     const char pa = len >= 2 ? ra[len - 2] : '\0', pb = len >= 2 ? rb[len - 2] : '\0';   // the new top
                     const uint8_t mvv = mv[len - 1];
                     if (ta == '+') {
@@ -603,13 +619,13 @@ __device__ inline bool align_job(uint8_t *base, const char *__restrict__ ga, con
                     if (ta == '+') ng--;
                     ta = pa;
                     tb = pb;
-                    if (mvv == LEFT) j += 1;
-                    else if (mvv == UP) i += 1;
+                    const uint8_t went = mvv & 7;
+                    if (went == LEFT) j += 1;
+                    else if (went == UP) i += 1;
                     else { i += 1; j += 1; }
                     len--;
-                    cc = i * W + j;
-                    d2 = dir[cc];
-                    if (d2 >> 4) { --alts; break; }   // a direction is left here (the cell was counted when it was left): the general step
+                    work = mvv >> 4;   // what was left to try at the cell the walk is back at
+                    if (work) { --alts; break; }   // (the cell was counted when it was left): the general step
                     if (prof) ++st_steps;
                 }
                 top_a = ta;

@@ -14,18 +14,13 @@ namespace pf {
 // LDS size classes of the Needleman-Wunsch working storage (bytes per wavefront): the finer the classes, the more wavefronts of
 // the mid-sized bubbles fit a CU's 160 KB (a 100 x 100 matrix needs 16 KB: ten per CU, where a 20 KB class gave seven).
 // Class kBubLdsClasses = global memory.
-#if defined(PF_BUB_CLASSES6)    // (measurements: round 3's classes)
-constexpr int kBubLdsClasses = 6;
-constexpr uint64_t kBubClassBytes[kBubLdsClasses] = {5 * 1024, 10 * 1024, 16 * 1024, 24 * 1024, 40 * 1024, 64 * 1024};
-#elif defined(PF_BUB_CLASSES10)
-constexpr int kBubLdsClasses = 10;
-constexpr uint64_t kBubClassBytes[kBubLdsClasses] = {5 * 1024, 7 * 1024, 9 * 1024, 12 * 1024, 14 * 1024, 16 * 1024, 20 * 1024, 24 * 1024, 40 * 1024, 64 * 1024};
-#else
-// (round 4: eight classes instead of six -- a 100 x 100 bubble with its head-room needs 16.2 KB and sat in the 24 KB class, six
-// wavefronts per CU; in a 20 KB class eight fit.  Two more launches per range, a pass 0.3 ms faster: profiles/r14_experiments.txt)
-constexpr int kBubLdsClasses = 8;
-constexpr uint64_t kBubClassBytes[kBubLdsClasses] = {5 * 1024, 8 * 1024, 12 * 1024, 16 * 1024, 20 * 1024, 24 * 1024, 40 * 1024, 64 * 1024};
-#endif
+// (round 4: eight classes instead of six; and, with the direction matrix at four bits a cell -- pf_align_dev.hpp -- every boundary at
+// half of what it was, so that a bubble sits in the class it sat in before with twice as many wavefronts of that class fitting a CU:
+// a 100 x 100 bubble needs 7.4 KB where it needed 12.5.  Halving the matrix WITHOUT moving the boundaries put the heavy bubbles
+// into the classes of the many medium ones and made the metric's config slower: profiles/r16_experiments.txt.)
+// A ninth class, 64 KB, takes what used to leave for the global-memory tier (matrices of 64 - 128 KB at a byte a cell).
+constexpr int kBubLdsClasses = 9;
+constexpr uint64_t kBubClassBytes[kBubLdsClasses] = {3072, 4608, 6 * 1024, 8 * 1024, 10 * 1024, 12 * 1024, 20 * 1024, 32 * 1024, 64 * 1024};
 constexpr int kBubMaxClasses = 12;   // (sizes of the per-class streams and events of a context)
 __host__ __device__ inline int bubble_class_waves_per_cu(int c) {
     const int fit = (int)((160 * 1024) / kBubClassBytes[c]);
