@@ -264,7 +264,7 @@ protected:
     } ax_[3];
     // (a text piece = four batches: 196 608 bubbles, 44 MB of text at k = 25 -- pieces short enough that the last one's PCIe copy and file
     // copy, which nothing overlaps, stay small; tools/ab_pass.py BATCH=n, profiles/r08_experiments.txt)
-    size_t batch_bubbles_ = 49152, align_pieces_ = 64;
+    size_t batch_bubbles_ = 32768, align_pieces_ = 64;   // (text pieces of 4 x 32768 bubbles: tools/ab_pass.py BATCH=n, profiles/r16_experiments.txt)
     // pinned buffers of the whole-graph device calls
     struct BubbleExchange {
         PinnedBuf<pf_bfs_record> bfs_rec;

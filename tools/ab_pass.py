@@ -41,7 +41,7 @@ def main():
         for k in names:
             os.environ.pop(k, None)
         os.environ.update({k: v for k, v in cfg.items() if k != "BATCH"})
-        run.set_batch_bubbles(int(cfg.get("BATCH", 49152)))   # (BATCH=n: bubbles per batch, four batches to a text piece)
+        run.set_batch_bubbles(int(cfg.get("BATCH", 32768)))   # (BATCH=n: bubbles per batch, four batches to a text piece)
         t = time.perf_counter()
         run.find_superbubbles("b")
         run.ploidy_estimation("b", bench.LOWER, bench.UPPER)
