@@ -171,7 +171,7 @@ struct CallState {
         uint32_t mlist_cap = 0;
         DevBuf walk_off, walk_pool;   // per batch: the oriented unitigs each branching bubble's walks visit (findUnitig of its site strings)
         uint64_t walk_cap = 0;
-        hipStream_t stream = nullptr;   // lane 0: the context's; other lanes: their own
+        hipStream_t stream = nullptr;   // lanes 1 ..: their own (lane 0 runs on the context's stream)
         bool own_stream = false;
         // K-PATHS runs beside K-SNP / K-PAIR (disjoint bubbles, shared atomic counters) on a stream of its own
         hipStream_t side_stream = nullptr;
@@ -3448,11 +3448,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     if (t1 - t0 > (1u << 24)) { pf::CtxErr{ctx} = "pf_call_align: at most 2^24 bubbles per batch"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     CallState::AlignWork &W = S->work[lane];
-    if (!W.stream) {
-        if (lane == 0) W.stream = ctx->stream;
-        else { PF_HIP(lane_stream_create(&W.stream, lane)); W.own_stream = true; }
-    }
-    hipStream_t st = W.stream;
+    if (lane != 0 && !W.stream) { PF_HIP(lane_stream_create(&W.stream, lane)); W.own_stream = true; }
+    hipStream_t st = lane == 0 ? ctx->stream : W.stream;   // (lane 0: the context's stream, whatever pf_set_stream made it since)
     // the write pass of K-TEXT over what this lane held may still be running (pf_call_text_range_lane does not wait for it)
     for (hipEvent_t e : O.read_ev) if (e) PF_HIP(hipStreamWaitEvent(st, e, 0));
     // (another lane's stream needs no event to wait for: the scan and the selection on the context's stream ended in host waits --
@@ -4008,10 +4005,7 @@ int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int
         NEED(O.ogroups, (uint64_t)FIRST_GROUPS * nb + 64);
         NEED(O.oilen, ((uint64_t)FIRST_ILEN * nb + 64) * 4);
         NEED(O.sv, ((uint64_t)nb / 4 + 1024ull * ctx->n_cu * 16 + 1024) * 8);
-        if (!W.stream) {
-            if (lane == 0) W.stream = ctx->stream;
-            else { PF_HIP(lane_stream_create(&W.stream, lane)); W.own_stream = true; }
-        }
+        if (lane != 0 && !W.stream) { PF_HIP(lane_stream_create(&W.stream, lane)); W.own_stream = true; }
         if (!W.side_stream) {
             PF_HIP(lane_stream_create(&W.side_stream, lane));
             PF_HIP(hipEventCreateWithFlags(&W.ev_prep, hipEventDisableTiming));
