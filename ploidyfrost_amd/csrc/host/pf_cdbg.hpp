@@ -223,11 +223,12 @@ protected:
     unsigned threads_ = 0;
     int replay_threads_ = -1;   // -1: default
     bool write_sb_ = true;
-    // commits on the device (pf_replay_device): the host arrays are stale until sync_state_to_host
+    // commits on the device (pf_replay_device): the host arrays are stale until sync_state_to_host; big_f2_ = the per-side flag
+    // bytes of the few components committed on the host (kept all-zero between passes)
     bool state_host_stale_ = false;
     bool colours_on_device_ = false;   // colored path: pf_replay_set_colours succeeded
     bool colored_resident_ = false;    // colored path: pf_call_set_colours succeeded -- the calling phase runs on the resident pipeline
-    std::vector<PackedUnitig> big_state_;   // scratch state of the few large components committed on this side (pf_state_ops.hpp); all-zero between passes
+    std::vector<uint8_t> big_f2_;
     bool commits_on_device(size_t thr) const;
     int find_superbubbles_device(const std::string &outpre, const size_t &thr);
     ParallelReplay par_;

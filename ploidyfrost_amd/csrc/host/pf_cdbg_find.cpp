@@ -226,17 +226,23 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     st = pf_replay_big_fetch(ctx_, big_idx.data(), big_rec.data(), big_pool.data());
     if (st != PF_OK) return fail(st, std::string("CDBG::findSuperBubble(): ") + pf_last_error(ctx_));
     tf("large components fetched");
-    // The replay's scratch state: a unitig's two links and two side bytes in one 16-byte entry (PackedUnitig), all-zero between passes
-    // (every pass undoes what it touched, below).  plus_ / minus_ / flags_ -- the host's copy of the real state -- are left alone.
-    if (big_state_.size() != (size_t)N) big_state_.assign((size_t)N, PackedUnitig{});
+    if (big_f2_.size() != 2 * (size_t)N) big_f2_.assign(2 * (size_t)N, 0);
+    // (plus_ / minus_ / big_f2_ are all-zero here: every pass undoes what it touched, see below; a stale host copy is re-zeroed)
+    if (!state_host_stale_) {
+        const unsigned zt = (unsigned)std::min<size_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), 8);
+        parallel_chunks(N, 1u << 19, zt, [&](size_t, size_t b, size_t e) {
+            memset(plus_.data() + b, 0, (e - b) * 4);
+            memset(minus_.data() + b, 0, (e - b) * 4);
+        });
+    }
     times_.bfs_large = times_.bfs_large_seen = times_.bfs_max_seen = times_.bfs_large_used = times_.bfs_large_used_max = 0;
     std::vector<uint32_t> p_sides, p_links;
     std::vector<uint8_t> p_bytes;
     {
         // (every side written is noted: exactly those go to the device afterwards)
-        const PackedSidesLogged acc{big_state_.data(), &p_sides};
-        Commits<PackedSidesLogged> cm{acc, complex_size_, NoColours{}};
-        Commits<PackedSidesLogged, ColourGate> cmc{acc, complex_size_, col_ ? st_.colour_gate() : ColourGate{}};
+        const FlagsPerSideLogged acc{FlagsPerSide{big_f2_.data(), plus_.data(), minus_.data()}, &p_sides};
+        Commits<FlagsPerSideLogged> cm{acc, complex_size_, NoColours{}};
+        Commits<FlagsPerSideLogged, ColourGate> cmc{acc, complex_size_, col_ ? st_.colour_gate() : ColourGate{}};
         size_t a = 0, b = 0;   // a over big_idx, b over the walked records (ascending candidate index both)
         auto commit = [&](const pf_bfs_record &r, const uint32_t *list) {
             if (r.n_seen > 4096) { times_.bfs_large++; times_.bfs_large_seen += r.n_seen; }
@@ -272,9 +278,8 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     parallel_chunks(p_sides.size(), 1u << 14, pt, [&](size_t, size_t b, size_t e) {
         for (size_t i = b; i < e; ++i) {
             const uint32_t s = p_sides[i];
-            const PackedUnitig &pu = big_state_[s >> 1];
-            p_links[i] = (s & 1) ? pu.minus : pu.plus;
-            p_bytes[i] = pu.f2[s & 1];
+            p_links[i] = (s & 1) ? minus_[s >> 1] : plus_[s >> 1];
+            p_bytes[i] = big_f2_[s];
         }
     });
     tf("patch gathered");
@@ -283,9 +288,8 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
         parallel_chunks(p_sides.size(), 1u << 14, pt, [&](size_t, size_t b, size_t e) {
             for (size_t i = b; i < e; ++i) {   // (a side logged twice may be zeroed from two threads: relaxed atomic stores of the same value)
                 const uint32_t s = p_sides[i];
-                PackedUnitig &pu = big_state_[s >> 1];
-                __atomic_store_n((s & 1) ? &pu.minus : &pu.plus, 0u, __ATOMIC_RELAXED);
-                __atomic_store_n(&pu.f2[s & 1], (uint8_t)0, __ATOMIC_RELAXED);
+                __atomic_store_n(&((s & 1) ? minus_ : plus_)[s >> 1], 0u, __ATOMIC_RELAXED);
+                __atomic_store_n(&big_f2_[s], (uint8_t)0, __ATOMIC_RELAXED);
             }
         });
     });

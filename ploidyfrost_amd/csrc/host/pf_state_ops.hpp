@@ -97,37 +97,6 @@ struct FlagsPerSideLogged {
     void begin_record(const pf_bfs_record &) {}
 };
 
-// The same state for ONE replaying thread, a unitig's two links and two side bytes in one 16-byte entry: the records of a large
-// component touch unitigs all over the graph, and three arrays (plus, minus, side bytes) were three cache misses per unitig where
-// this is one.  Every side written is noted down (as FlagsPerSideLogged does).
-struct PackedUnitig {
-    uint32_t plus, minus;
-    uint8_t f2[2];
-    uint8_t pad_[6];
-};
-struct PackedSidesLogged {
-    PackedUnitig *e;
-    std::vector<uint32_t> *written;
-    uint32_t link(uint32_t u, bool ps) const { return ps ? e[u].plus : e[u].minus; }
-    bool plus_points_to(uint32_t ex, uint32_t me) const { return e[ex].plus == me + 1; }
-    void set_link(uint32_t u, bool ps, uint32_t v, bool real) {
-        written->push_back(2 * u + (ps ? 0 : 1));
-        (ps ? e[u].plus : e[u].minus) = v;
-        uint8_t &b = e[u].f2[ps ? 0 : 1];
-        if (real) b |= state_bits::S_LINK; else b &= (uint8_t)~state_bits::S_LINK;
-    }
-    void mark_strict(uint32_t u, bool ps) { written->push_back(2 * u + (ps ? 0 : 1)); e[u].f2[ps ? 0 : 1] |= state_bits::S_STRICT; }
-    void mark_complex(uint32_t u, bool ps) { written->push_back(2 * u + (ps ? 0 : 1)); e[u].f2[ps ? 0 : 1] |= state_bits::S_COMPLEX; }
-    bool non_super(uint32_t u, bool ps) const { return (e[u].f2[ps ? 0 : 1] & state_bits::S_NON_SUPER) != 0; }
-    void set_non_super(uint32_t u) {
-        written->push_back(2 * u);
-        written->push_back(2 * u + 1);
-        e[u].f2[0] |= state_bits::S_NON_SUPER;
-        e[u].f2[1] |= state_bits::S_NON_SUPER;
-    }
-    void begin_record(const pf_bfs_record &) {}
-};
-
 // Hooks of the colored path (src/CCDBG.cpp:2351-2384, 2530-2621); the single-sample replay passes NoColours.
 struct NoColours {
     static constexpr bool colored = false;
