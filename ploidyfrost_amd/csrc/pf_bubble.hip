@@ -801,7 +801,23 @@ int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks, int lane) {
     if (!ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128) || !ctx_ws(ctx, bub_ws(WS_BUB_RETRY, lane), (size_t)std::max<uint32_t>(n_tasks, 1) * 4) ||
         !ctx_ws(ctx, bub_ws(WS_BUB_SCRATCH, lane), per * (uint64_t)ctx->n_cu * 24))
         return PF_ERR_HIP;
-    return bubble_streams(ctx, lane);
+    { const int e = bubble_streams(ctx, lane); if (e != PF_OK) return e; }
+    { const int e = bubble_func_attr(ctx); if (e != PF_OK) return e; }
+    // One empty launch per class stream, now, beside the load: the first K-BUBBLE launch of a stream pays for the queue's scratch
+    // (the kernel spills) and its first use of that much LDS -- 13 ms for the nine launches of a first PloidyEstimation when they
+    // were paid there.  (n = 0: every wavefront leaves at its first look at the queue.)
+    uint8_t *small = (uint8_t *)ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128);
+    PF_HIP(hipMemsetAsync(small, 0, 128, ctx->bub_streams[lane][0]));
+    PF_HIP(hipStreamSynchronize(ctx->bub_streams[lane][0]));
+    BubParams p;
+    memset(&p, 0, sizeof(p));
+    BubOut o;
+    memset(&o, 0, sizeof(o));
+    p.next = reinterpret_cast<unsigned int *>(small + 64);
+    for (int c = 0; c < kBubLdsClasses; ++c) k_bubble<true><<<1, 64, kBubClassBytes[c], ctx->bub_streams[lane][c]>>>(p, o);
+    PF_HIP(hipGetLastError());
+    for (int c = 0; c < kBubLdsClasses; ++c) PF_HIP(hipStreamSynchronize(ctx->bub_streams[lane][c]));
+    return PF_OK;
 }
 
 int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4]) {
