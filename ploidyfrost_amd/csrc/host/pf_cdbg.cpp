@@ -209,7 +209,11 @@ void CDBG::start_prealloc() {
         const uint64_t est = std::min<uint64_t>(1u << 24, ((uint64_t)(0.17 * (double)N) + piece - 1) / piece * piece);
         prealloc_call_ = std::thread([this, est, piece, N] {
             uint64_t n_cand = 0;   // findSuperBubble's buffers first: it is the first to run
-            if (commits_on_device(1) && pf_count_candidates(ctx_, 0, N, &n_cand) == PF_OK) (void)pf_find_reserve(ctx_, n_cand);
+            if (commits_on_device(1) && pf_count_candidates(ctx_, 0, N, &n_cand) == PF_OK) {
+                (void)pf_find_reserve(ctx_, n_cand);
+                // (K-CC once over no records: what its first call of a run pays beyond its 0.6 ms is paid here)
+                if (!getenv("PF_NO_CC_WARMUP")) (void)pf_side_components(ctx_, 1, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0);
+            }
             (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_);
             (void)pf_call_reserve_text(ctx_, piece);
         });
