@@ -4058,6 +4058,18 @@ int pf_call_reserve_text(pf_ctx *ctx, uint64_t piece_bubbles) {
     const uint32_t nb = (uint32_t)std::min<uint64_t>(piece_bubbles, 1u << 24);
     for (int which = 0; which < 2; ++which) { const int ts = text_work_of(ctx, S, which, nb); if (ts != PF_OK) return ts; }
     for (int slab = 0; slab < PF_CALL_SLABS; ++slab) NEED_TEXT(S->out[slab], (11ull * (uint64_t)ctx->k + 40) * nb);
+    // K-TEXT's two passes once over no bubbles on each of its streams: what the first launch of a kernel this size pays on a stream
+    // (scratch for its spills: 2.3 ms of a first piece's count pass) is paid here, beside the load
+    for (int which = 0; which < 2; ++which) {
+        pf::CallState::TextWork &T = S->text[which];
+        FmtArgs fa;
+        memset(&fa, 0, sizeof(fa));
+        fa.sizes = T.sizes.as<uint32_t>(); fa.offs = T.offs.as<uint64_t>(); fa.cnt = T.tcounters.as<CallCounters>();
+        if (S->n_colors) { k_call_format<false, true><<<1, FMT_BLOCK, 0, T.stream>>>(fa); k_call_format<true, true><<<1, FMT_BLOCK, 0, T.stream>>>(fa); }
+        else { k_call_format<false, false><<<1, FMT_BLOCK, 0, T.stream>>>(fa); k_call_format<true, false><<<1, FMT_BLOCK, 0, T.stream>>>(fa); }
+        PF_HIP(hipGetLastError());
+        PF_HIP(hipStreamSynchronize(T.stream));
+    }
     return PF_OK;
 }
 
