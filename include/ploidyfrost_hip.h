@@ -413,7 +413,9 @@ int pf_call_reserve(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size);
  * side (pf_call_align_lane below) takes every lane's working set beside the load. */
 int pf_call_reserve_lanes(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size, int n_lanes);
 /* The same for the text stage: what the first pf_call_text_range(_lane) of a run would take for pieces of up to piece_bubbles
- * bubbles (its stream, the size tables, the text slabs by an estimate from k). */
+ * bubbles (its two streams, the size tables, the text slabs by an estimate from k), and K-TEXT's two passes once over no bubbles on
+ * each stream: the first launch of a kernel that spills pays for the queue's scratch (2 ms inside a first piece otherwise).
+ * pf_call_reserve does the same for K-BUBBLE's class streams (13 ms of a first PloidyEstimation at 5 M unitigs). */
 int pf_call_reserve_text(pf_ctx *, uint64_t piece_bubbles);
 /* What pf_call_align(_lane) left resident for the bubbles of its range, before any text is made of it -- the kernel-level view the
  * parity tests hold against SeqAlign::SequenceAlignment (src/SeqAlign.cpp:550-640) bubble by bubble: per bubble its endpoints and,
