@@ -263,8 +263,8 @@ protected:
             ogroups.release(); oilen.release();
         }
     } ax_[3];
-    // (a text piece = four batches: 196 608 bubbles, 44 MB of text at k = 25 -- pieces short enough that the last one's PCIe copy and file
-    // copy, which nothing overlaps, stay small; tools/ab_pass.py BATCH=n, profiles/r08_experiments.txt)
+    // (a text piece = four batches: 131 072 bubbles, 18 MB over PCIe at k = 25 -- pieces short enough that the last one's PCIe copy and file
+    // copy, which nothing overlaps, stay small)
     size_t batch_bubbles_ = 32768, align_pieces_ = 64;   // (text pieces of 4 x 32768 bubbles: tools/ab_pass.py BATCH=n, profiles/r16_experiments.txt)
     // pinned buffers of the whole-graph device calls
     struct BubbleExchange {

@@ -482,7 +482,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     const auto t_dev = clk::now();
     // Alignment in large launches (every kernel's tail -- one wavefront finishing the heaviest bubble -- is paid once per
     // launch), text in pieces of CHUNK bubbles that are fetched and written while the next piece is formatted.  A long list is
-    // aligned in a few ranges, alternately into the two result lanes of the context: the formatter thread turns range r into
+    // aligned in a few ranges, in turn into the result lanes of the context: the formatter thread turns range r into
     // text -- and the fetcher moves it over PCIe, the slowest stage -- while this thread aligns range r + 1.
     uint64_t ALIGN = std::min<uint64_t>((uint64_t)CHUNK * std::max<size_t>(align_pieces_, 1), (uint64_t)1 << 24);
     {
