@@ -39,6 +39,15 @@ sys.path.insert(0, ROOT)
 K = 25
 Z = 8
 LOWER, UPPER = 5, 1000
+# BASELINE.json configs by --workload: generator parameters, k, -z, default size and seed.  `stress` = configs[4] (k=31, z=16, long
+# indels: the SeqAlign band widened, K-BUBBLE's traceback the phase); its 1 M-unitig setting has committed reference digests.
+WORKLOADS = {
+    "single":  {"k": 25, "z": 8,  "gen": {}, "seed": 1000, "unitigs": 5_000_000, "config": "configs[2] (5 M) / configs[1] (1 M)"},
+    "repeats": {"k": 25, "z": 8,  "gen": {"repeats": True}, "seed": 1000, "unitigs": 5_000_000, "config": "stress of the host tiers, not a BASELINE config"},
+    "colored": {"k": 25, "z": 8,  "gen": {}, "seed": 1000, "unitigs": 2_000_000, "config": "configs[3] (3 samples, 2 M unitigs)"},
+    "stress":  {"k": 31, "z": 16, "gen": {"max_ins": 50, "p_snp": 0.5, "p_del": 0.1}, "seed": 7, "unitigs": 10_000_000,
+                "config": "configs[4] (z=16, long indels, k=31, 10 M unitigs; --unitigs 1000000 = the setting with committed reference digests)"},
+}
 # ~26 unitigs per kb of genome at ploidy 4 with these gaps (SURVEY.md 8d ratios)
 GAP_LO, GAP_HI = 15, 215
 UNITIGS_PER_BP = 0.0262
@@ -139,14 +148,16 @@ def make_colored_inputs(workdir: str, name: str, genome_len: int, seed: int, dev
     return gfa, colors, dbs, n_unitigs, len(g["kmers"])
 
 
-def cpu_baseline(workdir: str, target_unitigs: int, device, runs: int = 3):
+def cpu_baseline(workdir: str, target_unitigs: int, device, runs: int = 3, workload: str = "single", config_unitigs: int | None = None):
     """The reference (oracle/_ref/PloidyFrost -t 1) -- or, where that binary is absent, the oracle
     restatement -- on a bounded sample of the same workload, timed on this host's CPU: `runs` runs, median
     (the reference's own phase timers, src/CDBG.cpp:217-220, 1683-1686)."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle
+    wl = WORKLOADS[workload]
+    Z = wl["z"]
     genome = int(target_unitigs / UNITIGS_PER_BP)
-    gfa, db, n_unitigs, _ = make_inputs(workdir, "cpu_sample", genome, 4242, device)
+    gfa, db, n_unitigs, _ = make_inputs(workdir, "cpu_sample", genome, 4242, device, k=wl["k"], **wl["gen"])
     cwd = os.path.join(workdir, "cpu_run")
     os.makedirs(cwd, exist_ok=True)
     if os.path.exists(pyoracle.REF_BIN):
@@ -192,18 +203,18 @@ def cpu_baseline(workdir: str, target_unitigs: int, device, runs: int = 3):
                          "note": "whole-program wall times; the phases' share of the -t %d run is estimated by taking off what the -t 1 run "
                                  "spends outside its own phase timers (graph + database load)" % nt}
             log("cpu baseline -t %d: program wall %.2fs (-t 1: %.2fs)" % (nt, wall[nt], wall[1]))
-    full = reference_digests().get(str(CONFIG_UNITIGS)) or {}
+    full = reference_digests().get(digest_key(workload, config_unitigs or CONFIG_UNITIGS)) or {}
     if "t1" in full and "findSuperBubble_cpu_s" in full["t1"]:
         secs = full["t1"]["findSuperBubble_cpu_s"] + full["t1"]["PloidyEstimation_cpu_s"]
         at_size = {"unitigs": full["unitigs"], "seconds": round(secs, 2), "unitigs_per_s": round(full["unitigs"] / secs, 1), "cores": 1,
                    "measured": "%s on %s by tools/reference_digests.py (committed in profiles/reference_digests.json; NOT part of this run)" % (full.get("date"), full.get("host")),
                    "all_cores": {k_: v for k_, v in full.items() if k_.startswith("t") and k_ != "t1" and isinstance(v, dict)}}
     else:
-        at_size = dict(REFERENCE_FULL_SIZE, stale_constant=True)
+        at_size = dict(REFERENCE_FULL_SIZE, stale_constant=True) if workload == "single" else None
     return {"value": n_unitigs / t, "unit": "unitigs/s", "cores": 1, "kind": kind, "runs": runs, "seconds": t,
             "seconds_each": [round(x, 3) for x in each], "sample_unitigs": n_unitigs,
-            "sample": "same generator (tetraploid, k=25, z=8, -l %d -u %d), %d-unitig graph, findSuperBubble+PloidyEstimation "
-                      "Cpu time of `-t 1`, median of %d runs on %s" % (LOWER, UPPER, n_unitigs, runs, cpu_model()),
+            "sample": "same generator (tetraploid, k=%d, z=%d, -l %d -u %d), %d-unitig graph, findSuperBubble+PloidyEstimation "
+                      "Cpu time of `-t 1`, median of %d runs on %s" % (wl["k"], Z, LOWER, UPPER, n_unitigs, runs, cpu_model()),
             # not like-for-like in size: the reference's unitigs/s FALLS as the graph grows (its per-k-mer binary search and
             # std::map traversals lose cache), so the ratio against this sample understates the ratio at the config's size
             "note": "bounded sample, smaller than the timed config; the reference's rate falls with graph size",
@@ -234,8 +245,8 @@ def algorithmic_bytes(kernel: str, t: dict, units: float | None = None) -> float
     the alignment (K-SNP / K-PAIR / K-BUBBLE) share one per-unit figure and are priced on what each of them actually took."""
     if kernel == "k_cov":  # streaming form: 4 B count + 1 head bit per k-mer, 4 B row id per 64 k-mers, 16 B of results per unitig
         return (4.0 + 1.0 / 8 + 4.0 / 64) * t["kmers"] + 16.0 * t["unitigs"]
-    if kernel in ("k_cov_probe", "k_cov_join"):  # SURVEY.md 8(d): 0.25 B sequence + 12 B table slot per k-mer (+ 4 B joined count / 16 B result)
-        return 12.25 * t["kmers"] + 16.0 * t["unitigs"]
+    if kernel in ("k_cov_probe", "k_cov_join"):  # SURVEY.md 8(d): 0.25 B sequence + 12 B table slot per k-mer (+ 16 B result per unitig), per colour
+        return (12.25 * t["kmers"] + 16.0 * t["unitigs"]) * max(1, t.get("n_colors", 1))
     if kernel in ("k_bfs", "k_bfs_thread"):
         return 600.0 * (units if units is not None else t["candidates"])
     if kernel in ("k_align", "k_bubble", "k_call_snp", "k_call_pair", "k_call_stack", "k_call_trio"):
@@ -275,7 +286,8 @@ def make_inputs_child(spec_json: str) -> None:
         gfa, colors, dbs, n_unitigs, n_kmers = make_colored_inputs(spec["workdir"], "graph", spec["genome"], spec["seed"], dev, samples=3)
         out = {"gfa": gfa, "colors": colors, "dbs": dbs, "n_unitigs": n_unitigs, "n_kmers": n_kmers}
     else:
-        gfa, db, n_unitigs, n_kmers = make_inputs(spec["workdir"], "graph", spec["genome"], spec["seed"], dev, repeats=spec["workload"] == "repeats")
+        wl = WORKLOADS[spec["workload"]]
+        gfa, db, n_unitigs, n_kmers = make_inputs(spec["workdir"], "graph", spec["genome"], spec["seed"], dev, k=wl["k"], **wl["gen"])
         out = {"gfa": gfa, "db": db, "n_unitigs": n_unitigs, "n_kmers": n_kmers}
     print(json.dumps(out), flush=True)
 
@@ -287,8 +299,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--unitigs", type=int, default=5_000_000,
-                    help="target unitigs of the graph (default 5 M = BASELINE.json configs[2], the config the metric and the north-star target are quoted on)")
+    ap.add_argument("--unitigs", type=int, default=0,
+                    help="target unitigs of the graph (default: the workload's config size -- single 5 M = BASELINE.json configs[2], the config "
+                         "the metric and the north-star target are quoted on; colored 2 M = configs[3]; stress 10 M = configs[4])")
     ap.add_argument("--cpu-sample-unitigs", type=int, default=150_000,
                     help="size of the reference's sample graph: ~6 s per -t 1 run at 150 k unitigs; its time grows faster than the graph "
                          "(a 250 k sample with chromosome-long traversals takes 75 s, the 5 M graph 700 s)")
@@ -305,12 +318,18 @@ def main():
     ap.add_argument("--shard-find", action="store_true",
                     help="strong scaling: cut findSuperBubble by entrance vertex as well (all-gather of the traversal records) instead of "
                          "running it on every rank")
-    ap.add_argument("--workload", choices=["single", "colored", "repeats"], default="single",
+    ap.add_argument("--workload", choices=["single", "colored", "repeats", "stress"], default="single",
                     help="single = the headline metric (BASELINE.json configs[1]); colored = the CCDBG path on 3 diploid "
                          "samples (configs[3]), same JSON line with config.workload saying so; repeats = the single-sample path on a "
                          "repeat-rich genome (50 repeat families, inverted repeats, tandem arrays on 8 %% of it): the stress case of the "
-                         "host tiers -- traversals that do not close for thousands of unitigs, giant commit components")
+                         "host tiers -- traversals that do not close for thousands of unitigs, giant commit components; stress = configs[4]: "
+                         "k=31, -z 16, insertions up to 50 bp (K-BUBBLE's traceback is the phase), 10 M unitigs (--unitigs 1000000: the "
+                         "setting whose reference digests are committed)")
     args = ap.parse_args()
+    wl = WORKLOADS[args.workload]
+    if not args.unitigs:
+        args.unitigs = wl["unitigs"]
+    Z = wl["z"]
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` without a launcher: start the N ranks here -- a child process of torch.distributed.run, before
@@ -338,7 +357,7 @@ def main():
     genome = int(args.unitigs / UNITIGS_PER_BP)
     colored = args.workload == "colored"
     strong = args.scaling == "strong" and world > 1
-    seed = int(os.environ.get("PF_BENCH_SEED", "1000")) + (0 if strong else rank)
+    seed = int(os.environ.get("PF_BENCH_SEED", str(wl["seed"]))) + (0 if strong else rank)
     made = None
     if not args.gen_in_process:
         # The inputs are made by a CHILD process (this file with --_make-inputs; it uses this rank's GPU for the graph construction and
@@ -372,7 +391,7 @@ def main():
                 m_ = make_colored_inputs(workdir, "graph", genome, seed, dev, samples=3)
                 made = {"gfa": m_[0], "colors": m_[1], "dbs": m_[2], "n_unitigs": m_[3], "n_kmers": m_[4]}
             else:
-                m_ = make_inputs(workdir, "graph", genome, seed, dev, repeats=args.workload == "repeats")
+                m_ = make_inputs(workdir, "graph", genome, seed, dev, k=wl["k"], **wl["gen"])
                 made = {"gfa": m_[0], "db": m_[1], "n_unitigs": m_[2], "n_kmers": m_[3]}
             torch.cuda.empty_cache()
         if colored:
@@ -427,7 +446,19 @@ def main():
 
         shard_stats = {}
 
+        # The reference's timed phases hold every readCov look-up (src/CDBG.cpp:66-120 inside :1187-1220; 48 % of its time).  The
+        # product makes them ONCE per (graph, database), as the load-time join K-COV-JOIN, and a pass only streams the joined
+        # coverage array -- so a pass alone is not like-for-like with the reference's phases.  The headline step therefore repeats
+        # the join: one pf_join_counts (233 M look-ups at 5 M unitigs) + findSuperBubble + PloidyEstimation.  `*_excl_join` is
+        # the pass without it, measured in a region of its own (what rounds 1-4 reported as `value`).
+        join_in_step = [True]
+
         def step():
+            if join_in_step[0]:
+                # on a stream of its own, beside findSuperBubble (which reads no coverage); PloidyEstimation's K-COV waits for it
+                st_ = L.pf_join_counts_begin(ctx)
+                if st_ != 0:
+                    raise SystemExit("bench.py: pf_join_counts_begin failed (%d)" % st_)
             if strong:
                 if args.shard_find:
                     pfdist.sharded_find(run, "b", xdev, shard_stats)
@@ -461,7 +492,7 @@ def main():
         # launches from five host threads, and two events around every one of them cost the pass 2 ms (20.4 ms with all launches
         # timed, 17.3-18.4 ms with none: profiles/r16_experiments.txt).  The other kernels' rows of `kernels` and the device-busy figure
         # come from TABLE_PASSES further passes behind the timed region, with every launch timed.
-        roof_kernels = [k for k in ("k_bubble", "k_bubble_big", "k_cov", "k_cov_colored") if k in hipapi.KERNELS]
+        roof_kernels = [k for k in ("k_bubble", "k_bubble_big", "k_cov", "k_cov_colored", "k_cov_join", "k_cov_join_rest") if k in hipapi.KERNELS]
         roof_mask = 0
         for k in roof_kernels:
             roof_mask |= 1 << hipapi.KERNELS.index(k)
@@ -475,8 +506,11 @@ def main():
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         phase = {}
+        step_s = []
         for _ in range(args.steps):
+            ts_ = time.perf_counter()
             step()
+            step_s.append(time.perf_counter() - ts_)   # a step ends with its files complete: nothing of it is still in flight
             tt = run.times()
             for key in ("bfs_device_s", "replay_s", "bubble_write_s", "cov_device_s", "tasks_s", "align_s", "sites_s", "format_s",
                         "write_s", "scan_s", "scan_serial_s", "find_total_s", "ploidy_total_s"):
@@ -486,6 +520,23 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         tt = run.times()
+        # the same K steps without the join (the pass over the joined coverage array alone), timed the same way
+        elapsed_excl, step_s_excl = None, []
+        if join_in_step[0]:
+            join_in_step[0] = False
+            if world > 1:
+                dist.barrier()
+            torch.cuda.synchronize()
+            te_ = time.perf_counter()
+            for _ in range(args.steps):
+                ts_ = time.perf_counter()
+                step()
+                step_s_excl.append(time.perf_counter() - ts_)
+            torch.cuda.synchronize()
+            if world > 1:
+                dist.barrier()
+            elapsed_excl = time.perf_counter() - te_
+            join_in_step[0] = True
 
         def kernel_times():   # kernel times from HIP events recorded by the library on the launches' own streams
             kt, ku = {}, {}
@@ -549,8 +600,8 @@ def main():
         output_check = None
         if world > 1:
             dist.barrier()
-        if rank == 0 and not colored:
-            output_check = check_outputs(os.path.join(workdir, "PloidyFrost_output"), "b", n_unitigs, seed)
+        if rank == 0:
+            output_check = check_outputs(os.path.join(workdir, "PloidyFrost_output"), "b", n_unitigs, seed, args.workload)
             log("output check: %s" % output_check)
 
         # one graph over several ranks: hold the shared files against a pass of rank 0 alone, once, outside the timed region
@@ -585,11 +636,14 @@ def main():
             dist.barrier()
 
         allstats = pfdist.all_gather_counters([n_unitigs, tt["superbubbles"], tt["tasks"], tt["output_bytes"]] + tt["allele"] +
-                                              [int(elapsed * 1e6)], xdev)
+                                              [int((elapsed_excl or 0.0) * 1e6), int(elapsed * 1e6)], xdev)
         max_elapsed = allstats[:, -1].max() / 1e6
+        max_elapsed_excl = allstats[:, -2].max() / 1e6 if elapsed_excl else None
         total_unitigs = int(allstats[0, 0]) if strong else int(allstats[:, 0].sum())
 
         if rank == 0:
+            if colored:
+                tt["n_colors"] = n_samples
             value = total_unitigs * args.steps / max_elapsed
             kernels = {}
             dom, dom_ms = None, -1.0
@@ -626,21 +680,72 @@ def main():
             # the streaming kernel of the path, next to the dominant one: K-COV is the kernel SURVEY.md 8(d) names as able to
             # approach the HBM roof; `traffic_frac` = PMC-measured HBM bytes per launch / its duration / peak
             roof_cov = cov_roofline(kernels, colored, n_unitigs)
+            # the look-up kernel itself (SURVEY.md 8d's probing form: 12.25 B per graph k-mer + 16 B per unitig) -- the farthest-from-roof
+            # kernel of the account: one launch per step inside the timed region
+            roof_join = None
+            ej, er = kernels.get("k_cov_join"), kernels.get("k_cov_join_rest")
+            if ej and "algorithmic_bytes_per_launch" in ej:
+                # K-COV-JOIN is two kernels back to back on one stream: the pipelined look-up of every k-mer's first line, then the
+                # look-ups it handed on (first line full); priced together on the one algorithmic figure
+                join_ms = ej["avg_ms"] + (er["avg_ms"] if er else 0.0)
+                ach = ej["algorithmic_bytes_per_launch"] / (join_ms * 1e-3) / 1e9
+                trj, trr = load_traffic("k_cov_join", n_unitigs), load_traffic("k_cov_join_rest", n_unitigs)
+                if trj and trr:
+                    trj += trr
+                roof_join = {"kernel": "k_cov_join + k_cov_join_rest", "bound": "hbm", "achieved": round(ach, 2), "peak": 8000.0, "unit": "GB/s",
+                             "frac": round(ach / 8000.0, 5), "avg_ms": round(join_ms, 4), "avg_ms_each": [ej["avg_ms"], er["avg_ms"] if er else None],
+                             "algorithmic_bytes_per_launch": ej["algorithmic_bytes_per_launch"], "traffic": trj,
+                             "traffic_over_algorithmic": round(trj / ej["algorithmic_bytes_per_launch"], 2) if trj else None,
+                             "traffic_frac": round(trj / (join_ms * 1e-3) / 8e12, 4) if trj else None,
+                             "note": "every graph k-mer looked up in the count table (CKMCFile::CheckKmer, kmc_file.cpp:330-366): the table is "
+                                     "addressed by the k-mer's minimizer, so the k-mers a wavefront's lanes hold share their 128-B lines; inside a step "
+                                     "the two kernels run on their own stream beside findSuperBubble's, so avg_ms is what they take with the device shared"}
+
+            def dist_ms(xs):
+                xs = sorted(xs)
+                if not xs:
+                    return None
+                q = lambda f: xs[min(len(xs) - 1, int(round(f * (len(xs) - 1))))]
+                return {"min": round(xs[0] * 1e3, 3), "median": round(q(0.5) * 1e3, 3), "p95": round(q(0.95) * 1e3, 3), "max": round(xs[-1] * 1e3, 3)}
+            d_incl, d_excl = dist_ms(step_s), dist_ms(step_s_excl)
+            try:
+                output_fs = next((ln.split()[2] for ln in reversed(open("/proc/mounts").read().splitlines())
+                                  if (workdir + "/").startswith(ln.split()[1].rstrip("/") + "/")), "?")
+            except (OSError, IndexError):
+                output_fs = "?"
             cpu = None
             if not args.no_cpu_baseline and not colored:
-                cpu = cpu_baseline(workdir, args.cpu_sample_unitigs, dev, args.cpu_runs)
+                cpu = cpu_baseline(workdir, args.cpu_sample_unitigs, dev, args.cpu_runs, args.workload, n_unitigs)
             out = {
-                "metric": "unitigs/s through superbubble+SeqAlign (k=25, z=8)",
+                "metric": "unitigs/s through superbubble+SeqAlign (k=%d, z=%d)" % (wl["k"], Z),
                 "value": round(value, 1), "unit": "unitigs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-                "ms_per_step": round(max_elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak" if (world > 1 and not strong) else "strong",
+                "ms_per_step": round(max_elapsed / args.steps * 1e3, 2),
+                # rank 0's own steps (a step returns with its files complete)
+                "ms_per_step_min": d_incl["min"], "ms_per_step_median": d_incl["median"], "ms_per_step_p95": d_incl["p95"],
+                "timed_region": {"per_step": ("K-COV-JOIN (every graph k-mer looked up in the count table; on its own stream beside findSuperBubble) + findSuperBubble + PloidyEstimation"
+                                              if join_in_step[0] else "findSuperBubble + PloidyEstimation"),
+                                 "seconds": round(max_elapsed, 3),
+                                 "consistency_note": ("timed region shorter than 2 s (%d steps x %.1f ms): use --steps %d or more for a region of 2 s"
+                                                      % (args.steps, max_elapsed / args.steps * 1e3, int(2.0 / (max_elapsed / args.steps)) + 1))
+                                 if max_elapsed < 2.0 else None},
+                # the pass alone, the look-ups left to the load-time join (what rounds 1-4 reported as `value`): its own timed region
+                "value_excl_join": round(total_unitigs * args.steps / max_elapsed_excl, 1) if max_elapsed_excl else None,
+                "ms_per_step_excl_join": round(max_elapsed_excl / args.steps * 1e3, 2) if max_elapsed_excl else None,
+                "ms_per_step_excl_join_dist": d_excl,
+                "higher_is_better": True, "scaling": "weak" if (world > 1 and not strong) else "strong",
                 "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-                "config": {"workload": ("colored graph of 3 synthetic diploid samples (CCDBG path, configs[3]), %d unitigs/GPU, k=25 z=8, "
-                                        "cutoffs %d/%d per sample, M=2 D=-1 G=-3" if colored else
-                                        "single-sample synthetic tetraploid graph, %d unitigs (BASELINE.json configs[2] = 5 M; configs[1] = 1 M with --unitigs 1000000), k=25 z=8, "
-                                        "-l %d -u %d, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER) +
+                "config": {"workload": (("colored graph of 3 synthetic diploid samples (CCDBG path, BASELINE.json configs[3] = 2 M unitigs), %d unitigs/GPU, k=25 z=8, "
+                                         "cutoffs %d/%d per sample, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER) if colored else
+                                        ("single-sample synthetic tetraploid graph with insertions up to 50 bp, %d unitigs (BASELINE.json configs[4] = 10 M; "
+                                         "--unitigs 1000000 = the setting with committed reference digests), k=31 z=16, -l %d -u %d, M=2 D=-1 G=-3")
+                                        % (n_unitigs, LOWER, UPPER) if args.workload == "stress" else
+                                        ("single-sample synthetic tetraploid graph, %d unitigs (BASELINE.json configs[2] = 5 M; configs[1] = 1 M with --unitigs 1000000), k=25 z=8, "
+                                         "-l %d -u %d, M=2 D=-1 G=-3") % (n_unitigs, LOWER, UPPER)) +
                                        (" -- REPEAT-RICH genome (stress workload, not the metric's config): 50 repeat families of 300-3000 bp at 1-3 %% divergence, "
                                         "inverted copies and tandem arrays on 8 %% of the genome" if args.workload == "repeats" else ""),
+                           "k": wl["k"], "z": Z,
                            "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
+                           "output_fs": "%s (%s): the result files of the timed passes -- and of the reference in cpu_baseline -- are written there" % (output_fs, workdir),
                            "partitioning": ("one graph replicated on every rank, cut by entrance vertex: K-BFS records all-gathered over RCCL "
                                             "(%d bytes per pass) and replayed on every rank; bubble list in contiguous slices, two small "
                                             "all-gathers (bubbles called; slab sizes + allele histograms), every rank writes its slabs into "
@@ -654,7 +759,7 @@ def main():
                                             "one independent graph per rank (weak scaling), no data-path collective; "
                                             "per-pass all-gather of the site counters only (%d bytes)" % gathered_bytes[0])},
                 "roofline": roof, "roofline_issue": issue_roofline(dom, kernels[dom]["avg_ms"], n_unitigs, kernels[dom]) if dom else None,
-                "roofline_k_cov": roof_cov, "cpu_baseline": cpu,
+                "roofline_k_cov": roof_cov, "roofline_k_cov_join": roof_join, "cpu_baseline": cpu,
                 "gpu_kernel_ms_per_step": round(sum(e["ms_per_step"] for n_, e in kernels.items() if n_ != "copy_text_to_host"), 3),
                 # union of the launches' [start, end] intervals (HIP events on their streams) over the timed passes / passes;
                 # tools/summarize_prof.py gives the same figure from the rocprofv3 kernel trace (profiles/*_device_busy.json)
@@ -717,11 +822,17 @@ def reference_digests():
         return {}
 
 
-def check_outputs(outdir: str, prefix: str, n_unitigs: int, seed: int):
+def digest_key(workload: str, n_unitigs: int) -> str:
+    """profiles/reference_digests.json: the single-sample graphs under their unitig count (as rounds 1-4 wrote them), the others
+    under '<workload>:<unitigs>'"""
+    return str(n_unitigs) if workload == "single" else "%s:%d" % (workload, n_unitigs)
+
+
+def check_outputs(outdir: str, prefix: str, n_unitigs: int, seed: int, workload: str = "single"):
     """md5 of the twelve files in `outdir` against the committed digests of the reference's output for this graph.  None of the
     digests' making is part of this run: `digest_source` says where they come from."""
     import hashlib
-    ent = reference_digests().get(str(n_unitigs))
+    ent = reference_digests().get(digest_key(workload, n_unitigs))
     if not ent or ent.get("seed") != seed or "files" not in ent:
         return {"files": 0, "identical_to_reference": None,
                 "note": "no committed reference digests for a graph of %d unitigs, seed %d (tools/reference_digests.py makes them)" % (n_unitigs, seed)}

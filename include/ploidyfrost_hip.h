@@ -59,6 +59,7 @@ enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
     PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN,
     PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_BFS_THREAD, PF_K_CALL_PAIR, PF_K_CALL_STACK, PF_K_CALL_TRIO,
+    PF_K_COV_JOIN_REST, /* second kernel of K-COV-JOIN: the look-ups whose first line was full */
     PF_K_COPY_TEXT, /* not a kernel of this library: the copies of result text to the host (the runtime moves them with a kernel of its own) */
     PF_K_COUNT_
 };
@@ -145,10 +146,22 @@ int pf_copy_to_host(pf_ctx *, void *dst, const void *src_dev, size_t bytes);
 
 /* K1/K2: builds the device hash table from the database records (exact k-mers as stored, any
  * order).  Records with count outside [min_count, max_count] are not retrievable, as in
- * CKMCFile::BinarySearch (kmc_file.cpp:1459).  both_strands mirrors GetBothStrands();
- * only both_strands = 1 databases are supported.  [host|dev] */
-int pf_upload_counts(pf_ctx *, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t min_count,
+ * CKMCFile::BinarySearch (kmc_file.cpp:1459).  both_strands mirrors GetBothStrands().
+ * k = the database's k-mer length (CKMCFileInfo::kmer_length; it must equal the graph's, whichever of the two is uploaded
+ * first): the table is addressed by the MINIMIZER of a key, not by a hash of the whole key, so that the k-mers of a unitig --
+ * which CDBG::readCov asks for one after the other (src/CDBG.cpp:66-120) -- lie in the same few 128-B lines
+ * (csrc/pf_device_common.hpp, "minimizer-local addressing").  [host|dev] */
+int pf_upload_counts(pf_ctx *, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint32_t k, uint64_t min_count,
                      uint64_t max_count, int both_strands);
+/* K-COV-JOIN again (it runs by itself when graph and table are both resident): every look-up CDBG::readCov(UnitigMap) makes in one
+ * run of the reference -- one CheckKmer per graph k-mer (src/CDBG.cpp:66-120 inside :1187-1220) -- as one kernel launch.  For
+ * callers that account for those look-ups per pass (bench.py's value_incl_join).  PF_ERR_ARG without a graph and a canonical table. */
+int pf_join_counts(pf_ctx *);
+/* The same in two halves: _begin launches the look-ups on a stream of their own (lowest priority) and returns; whatever the caller
+ * runs next on the context that reads no coverage -- pf_bfs_candidates ... pf_replay_device: findSuperBubble -- shares the device
+ * with them; _end waits.  Every reader of the joined array (pf_unitig_cov, pf_call_coverage) waits by itself, so _end may be left out. */
+int pf_join_counts_begin(pf_ctx *);
+int pf_join_counts_end(pf_ctx *);
 /* K2+K3 composite of src/CDBG.cpp:38-56 for a batch of k-mers:
  * "if (!IsKmer(fwd)) reverse(); CheckKmer()".  found[i] = 0 when absent. [host|dev] */
 int pf_lookup_kmers(pf_ctx *, const uint64_t *kmers, uint64_t n, uint32_t *counts, uint8_t *found);

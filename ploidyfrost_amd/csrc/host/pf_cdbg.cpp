@@ -92,7 +92,7 @@ void CountsLoader::start(int device, const std::string &kmc_prefix) {
         uint64_t *dk = nullptr;
         uint32_t *dc = nullptr;
         status = pf_kmc_decode(ctx, db.records, db.total, db.suffix_bytes, db.counter_size, db.lut.data(), db.n_lut(), db.lut_prefix_len, db.k, &dk, &dc);
-        if (status == PF_OK) status = pf_upload_counts(ctx, dk, dc, db.total, db.min_count, db.max_count, db.both_strands);
+        if (status == PF_OK) status = pf_upload_counts(ctx, dk, dc, db.total, db.k, db.min_count, db.max_count, db.both_strands);
         pf_device_free(ctx, dk);
         pf_device_free(ctx, dc);
         if (status != PF_OK) error = std::string("CDBG::CDBG():Error: ") + pf_last_error(ctx);
@@ -252,7 +252,7 @@ CDBG::CDBG(UnitigSet &graph, const size_t &complexsize, double &m, double &d, do
         uint64_t *dk = nullptr;
         uint32_t *dc = nullptr;
         int st = pf_kmc_decode(ctx_, db.records, db.total, db.suffix_bytes, db.counter_size, db.lut.data(), db.n_lut(), db.lut_prefix_len, db.k, &dk, &dc);
-        if (st == PF_OK) st = pf_upload_counts(ctx_, dk, dc, db.total, db.min_count, db.max_count, db.both_strands);
+        if (st == PF_OK) st = pf_upload_counts(ctx_, dk, dc, db.total, db.k, db.min_count, db.max_count, db.both_strands);
         pf_device_free(ctx_, dk);
         pf_device_free(ctx_, dc);
         trace.mark("kmc: device decode + table");

@@ -1959,7 +1959,7 @@ struct SiteArgs {
     pf_bubble_site *osites;     // pad_ receives the site's ok flag
     const uint8_t *ogroups;
     int k;
-    const Slot *tab;
+    const CountLine *tab;
     uint64_t mask;
     int one_strand, tab_exact;
     uint32_t low, up;

@@ -39,25 +39,38 @@ namespace {
 constexpr uint32_t MISSING = pf::CTAB_MISSING;
 
 // K-TABLE-C: one thread per record of colour `colour`
-__global__ void k_ctab_build(uint8_t *base, uint64_t mask, uint32_t shift, const uint64_t *__restrict__ kmers,
-                             const uint32_t *__restrict__ counts, uint64_t n, uint64_t min_count, uint64_t max_count, uint32_t colour) {
+__global__ void k_ctab_build(uint8_t *base, uint64_t mask, uint32_t shift, int k, const uint64_t *__restrict__ kmers,
+                             const uint32_t *__restrict__ counts, uint64_t n, uint64_t min_count, uint64_t max_count, uint32_t colour,
+                             unsigned int *noncanon) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool nc = false;
     for (; i < n; i += stride) {
         const uint32_t c = counts[i];
         if (c < min_count || c > max_count) continue;  // not retrievable (kmc_file.cpp:1459)
         const uint64_t key = kmers[i];
-        uint64_t s = mix64(key) & mask;
-        for (;;) {
+        const uint64_t rc = rc_kmer(key, k);
+        nc |= rc < key;
+        const CTab t{base, mask, shift};
+        const CSeq sq = ctab_seq(t, key, rc, k);
+        const uint32_t per = 1u << sq.ls;
+        bool done = false;
+        for (int tr = 0; tr < LINE_TRIES && !done; ++tr) {
+            const uint64_t b = ctab_bucket(t, sq, tr);
+            for (uint32_t j = 0; j < per && !done; ++j) {
+                uint8_t *slot = base + ((b + j) << shift);
+                unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(slot);
+                if (old == EMPTY_KEY) old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), EMPTY_KEY, key);
+                if (old == EMPTY_KEY || old == key) { *reinterpret_cast<uint32_t *>(slot + 8 + 4 * colour) = c; done = true; }
+            }
+        }
+        for (uint64_t s = mix64(key) & mask; !done; s = (s + 1) & mask) {
             uint8_t *slot = base + (s << shift);
             unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), EMPTY_KEY, key);
-            if (old == EMPTY_KEY || old == key) {
-                *reinterpret_cast<uint32_t *>(slot + 8 + 4 * colour) = c;
-                break;
-            }
-            s = (s + 1) & mask;
+            if (old == EMPTY_KEY || old == key) { *reinterpret_cast<uint32_t *>(slot + 8 + 4 * colour) = c; done = true; }
         }
     }
+    if (__any(nc) && lane_id() == 0) atomicOr(noncanon, 1u);
 }
 
 // is some k-mer a key in both orientations (whatever the colours)?  one thread per slot
@@ -71,7 +84,7 @@ __global__ void k_ctab_two_strands(const uint8_t *base, uint64_t cap, uint32_t s
         if (key == EMPTY_KEY) continue;
         const uint64_t r = rc_kmer(key, k);
         if (r == key) continue;
-        if (ctab_find(t, r)) atomicOr(flag, 1u);
+        if (ctab_find(t, r, ctab_seq(t, key, r, k))) atomicOr(flag, 1u);
     }
 }
 
@@ -231,6 +244,7 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
                              const uint64_t *n, const uint64_t *min_count, const uint64_t *max_count, const int *both_strands) {
     if (!ctx || n_colors == 0 || !kmers || !counts || !n || !min_count || !max_count || !both_strands) return PF_ERR_ARG;
     if (n_colors > PF_MAX_COLORS_TABLE) { pf::CtxErr{ctx} = "more colours than the device table holds (PF_MAX_COLORS_TABLE)"; return PF_ERR_ARG; }
+    if (!ctx->d_seq || !ctx->k) { pf::CtxErr{ctx} = "pf_upload_counts_colored: the graph comes first (the table is addressed by minimizers of length-k keys)"; return PF_ERR_ARG; }
     uint64_t total = 0, biggest = 0;
     for (uint32_t c = 0; c < n_colors; ++c) {
         if (n[c] && (!kmers[c] || !counts[c])) return PF_ERR_ARG;
@@ -263,6 +277,9 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
     PF_HIP(hipMemsetAsync(ctx->d_ctab, 0xFF, cap << shift, ctx->stream));  // EMPTY_KEY keys, MISSING counts
     ctx->ctab_cap = cap;
     ctx->ctab_shift = shift;
+    DevTmp<unsigned int> noncanon_;
+    PF_HIP(noncanon_.alloc(4));
+    PF_HIP(hipMemsetAsync(noncanon_.p, 0, 4, ctx->stream));
     for (uint32_t c = 0; c < n_colors; ++c) {
         if (!n[c] || !both_strands[c]) continue;
         DevTmp<uint64_t> dk_;
@@ -278,21 +295,25 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
             pc = dc_.p;
         }
         ctx_begin(ctx, PF_K_TABLE_BUILD);
-        k_ctab_build<<<ctx_grid(ctx, n[c], 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap - 1, shift, pk, pc, n[c], min_count[c],
-                                                                           max_count[c], c);
+        k_ctab_build<<<ctx_grid(ctx, n[c], 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap - 1, shift, ctx->k, pk, pc, n[c], min_count[c],
+                                                                           max_count[c], c, noncanon_.p);
         ctx_end(ctx);
         PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffers die at the end of this iteration
     }
     {
-        DevTmp<unsigned int> flag_;
-        unsigned int h_flag = 0;
-        PF_HIP(flag_.alloc(4));
-        PF_HIP(hipMemsetAsync(flag_.p, 0, 4, ctx->stream));
-        if (total && ctx->k)
-            k_ctab_two_strands<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap, shift, ctx->k, flag_.p);
-        PF_HIP(hipMemcpyAsync(&h_flag, flag_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+        // a table whose keys are all canonical holds no k-mer in both orientations: only one with other keys is searched for a pair
+        unsigned int h_noncanon = 0, h_flag = 0;
+        PF_HIP(hipMemcpyAsync(&h_noncanon, noncanon_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->ctab_one_strand = (total && ctx->k) ? h_flag == 0 : false;
+        if (total && h_noncanon) {
+            DevTmp<unsigned int> flag_;
+            PF_HIP(flag_.alloc(4));
+            PF_HIP(hipMemsetAsync(flag_.p, 0, 4, ctx->stream));
+            k_ctab_two_strands<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap, shift, ctx->k, flag_.p);
+            PF_HIP(hipMemcpyAsync(&h_flag, flag_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+            PF_HIP(hipStreamSynchronize(ctx->stream));
+        }
+        ctx->ctab_one_strand = total ? h_flag == 0 : false;
     }
     ctx->n_colors = n_colors;
     return join_graph_counts_colored(ctx);

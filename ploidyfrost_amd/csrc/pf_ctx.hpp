@@ -57,10 +57,14 @@ struct pf_ctx {
     std::vector<uint32_t> h_len;   // host copy of the unitig lengths (argument validation)
 
     // k-mer count table (HBM): open addressing, 16-B slots, capacity = power of two >= 2n
-    pf::Slot *d_tab = nullptr;
+    pf::CountLine *d_tab = nullptr;   // count table: tab_cap lines of ten keys (pf_device_common.hpp)
     uint64_t tab_cap = 0, tab_n = 0;
-    bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked once table and k are both known)
-    bool tab_strands_checked = false;
+    // K-COV-JOIN between pf_join_counts_begin and the first reader of d_gcov (join_finish)
+    hipStream_t join_stream = nullptr;
+    hipEvent_t join_done = nullptr;
+    bool join_inflight = false;
+    int tab_k = 0;                // k of the database: a count table is addressed by the minimizers of its keys (pf_device_common.hpp)
+    bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked when the table is built)
     bool tab_exact = false;       // database built without canonical counting: no composite lookups
     uint64_t tab_max_count = 0;   // upper count filter of the last upload (decides the width of K-COV's row sums)
 
@@ -165,6 +169,8 @@ void ctx_end_at(pf_ctx *ctx, size_t at, hipStream_t stream);
 inline void ctx_units(pf_ctx *ctx, int kernel, uint64_t n) { if (ctx->timing) __atomic_fetch_add(&ctx->units[kernel], n, __ATOMIC_RELAXED); }
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
 int join_graph_counts(pf_ctx *ctx);
+int join_graph_counts_begin(pf_ctx *ctx);   // pf_device.hip: the kernels on a stream of their own; join_finish() before d_gcov is read
+int join_finish(pf_ctx *ctx);
 int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the joined table of all colours (pf_ctx::d_gcov_c)  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
 // device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
@@ -186,6 +192,7 @@ enum WsSlot {
     WS_STR_TEXT, WS_STR_OFF, WS_STR_SUM, WS_STR_OK, WS_STR_MISS,
     WS_BUB_TEXT, WS_BUB_PATHS, WS_BUB_TASKS, WS_BUB_SMALL, WS_BUB_RETRY, WS_BUB_IDX, WS_BUB_RES, WS_BUB_OTEXT, WS_BUB_OSITES,
     WS_BUB_OGROUPS, WS_BUB_OILEN, WS_BUB_SCRATCH, WS_BUB_WORK, WS_BUB_IDX2, WS_CCOV_SUM, WS_CCOV_MIN, WS_CCOV_MAX, WS_CCOV_MISS, WS_GMM_X, WS_GMM_STATE, WS_GMM_PART,
+    WS_JOIN_REST, WS_JOIN_REST_N,   // K-COV-JOIN: the look-ups its pipeline hands on (pf_device.hip)
     WS_BUB_LANES,   // K-BUBBLE's five launch workspaces (small, retry, scratch, work, idx2) of lanes 1 .. PF_CALL_LANES - 1 (bub_ws)
     WS_COUNT_ = WS_BUB_LANES + 5 * (PF_CALL_LANES - 1)
 };

@@ -49,22 +49,22 @@ __global__ void k_fill_slots(Slot *t, uint64_t n) {
     }
 }
 
-// K-TABLE: one thread per database record.
-__global__ void k_table_build(Slot *t, uint64_t mask, const uint64_t *__restrict__ kmers,
-                              const uint32_t *__restrict__ counts, uint64_t n, uint64_t min_count, uint64_t max_count) {
+// K-TABLE: one thread per database record.  `noncanon` is set when some key is larger than its reverse complement: only then can
+// the table hold a k-mer in both orientations (check_table_strands).
+__global__ void k_table_build(CountLine *t, uint64_t mask, int k, const uint64_t *__restrict__ kmers,
+                              const uint32_t *__restrict__ counts, uint64_t n, uint64_t min_count, uint64_t max_count, unsigned int *noncanon) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    bool nc = false;
     for (; i < n; i += stride) {
         const uint32_t c = counts[i];
         if (c < min_count || c > max_count) continue;  // not retrievable (kmc_file.cpp:1459)
         const uint64_t key = kmers[i];
-        uint64_t s = mix64(key) & mask;
-        for (;;) {
-            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(&t[s].key), EMPTY_KEY, key);
-            if (old == EMPTY_KEY || old == key) { t[s].val = c; break; }
-            s = (s + 1) & mask;
-        }
+        const uint64_t rc = rc_kmer(key, k);
+        nc |= rc < key;
+        *count_claim(t, mask, key, kmer_lines(key, rc, k, mask)) = c;
     }
+    if (__any(nc) && lane_id() == 0) atomicOr(noncanon, 1u);
 }
 
 // K-KMC: the records of a KMC database as they lie in <db>.kmc_suf -- (k-p)/4 suffix bytes, most significant first, then the
@@ -98,20 +98,21 @@ __global__ void k_kmc_decode(const uint8_t *__restrict__ rec, uint64_t n, uint32
     }
 }
 
-// Does the table hold both orientations of some k-mer?  One thread per slot.
-__global__ void k_table_two_strands(const Slot *__restrict__ t, uint64_t cap, int k, unsigned int *flag) {
+// Does the table hold both orientations of some k-mer?  One thread per slot.  (Run only for a table with keys that are not
+// canonical: when every key is at most its reverse complement, the reverse complement of a key is not a key.)
+__global__ void k_table_two_strands(const CountLine *__restrict__ t, uint64_t n_lines, int k, unsigned int *flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    for (; i < cap; i += stride) {
-        const Slot s = load_slot(t, i);
-        if (s.key == EMPTY_KEY) continue;
-        const uint64_t r = rc_kmer(s.key, k);
+    for (; i < n_lines * LINE_KEYS; i += stride) {
+        const uint64_t key = t[i / LINE_KEYS].key[i % LINE_KEYS];
+        if (key == EMPTY_KEY) continue;
+        const uint64_t r = rc_kmer(key, k);
         uint32_t c;
-        if (r != s.key && table_find(t, cap - 1, r, c)) atomicOr(flag, 1u);
+        if (r != key && count_find(t, n_lines - 1, r, kmer_lines(key, r, k, n_lines - 1), c)) atomicOr(flag, 1u);
     }
 }
 
-__global__ void k_lookup(const Slot *__restrict__ t, uint64_t mask, int k, bool one_strand, const uint64_t *__restrict__ kmers,
+__global__ void k_lookup(const CountLine *__restrict__ t, uint64_t mask, int k, bool one_strand, const uint64_t *__restrict__ kmers,
                          uint64_t n, uint32_t *__restrict__ counts, uint8_t *__restrict__ found) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
@@ -245,7 +246,7 @@ __global__ void k_cov_init(uint32_t n, uint64_t *__restrict__ out_sum, uint32_t 
     for (; i < n; i += stride) { out_sum[i] = 0; out_min[i] = 10000; out_miss[i] = 0; }
 }
 
-__global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_t mask, int k, const uint64_t *__restrict__ seq,
+__global__ __launch_bounds__(256) void k_cov(const CountLine *__restrict__ t, uint64_t mask, int k, const uint64_t *__restrict__ seq,
                                              const uint64_t *__restrict__ off, const uint64_t *__restrict__ kpre, const uint32_t *__restrict__ kwin, uint32_t N,
                                              bool one_strand, int exact, uint32_t u0, uint64_t g_begin, uint64_t g_end, uint64_t w_begin,
                                              uint64_t n_win, uint64_t *__restrict__ out_sum, uint32_t *__restrict__ out_min,
@@ -285,8 +286,7 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
                 const uint64_t fwd = kmer_at(seq + off[uu[j]], (uint32_t)(g - P[lo]), k);
                 if (exact) {  // database without canonical counting: the k-mer as it reads in the wanted orientation, nothing else
                     const uint64_t key = exact == 2 ? rc_kmer(fwd, k) : fwd;
-                    pr[j].first = pr[j].second = key;
-                    pr[j].s = load_slot(t, mix64(key) & mask);
+                    count_probe_at(t, key, kmer_lines(key, exact == 2 ? fwd : rc_kmer(fwd, k), k, mask), pr[j]);
                 } else {
                     count_probe(t, mask, fwd, k, one_strand, pr[j]);
                 }
@@ -331,8 +331,166 @@ __global__ __launch_bounds__(256) void k_cov(const Slot *__restrict__ t, uint64_
     }
 }
 
+// K-COV-JOIN: every graph k-mer looked up in the count table, its count left at the k-mer's place in graph order (gcov).
+// A wavefront takes rows of 64 consecutive k-mers, a k-mer per lane.  A look-up is a chain of five dependent loads --
+//   S1 the row's khead word (a bit per k-mer, set at unitig starts) and krow (unitig of the row's first k-mer): the lane's unitig
+//      is a population count away, no search;
+//   S2 kpre / off of that unitig;   S3 the two sequence words that hold the k-mer;
+//   S4 the ten keys of the line its minimizer names (the lanes of a run of k-mers fetch the same line);   S5 the count of the slot
+//      that matched
+// -- and a wavefront that walks the chain row by row spends its time waiting (measured: 8 us a row at eight wavefronts a SIMD).  So
+// the loop is software-pipelined: iteration i issues S1 of row i + 1, S2 of row i, S3 of row i - 1, S4 of row i - 2, S5 of row
+// i - 3 and stores row i - 4, each stage consuming what the iteration before issued: five rows in flight per wavefront, the loads
+// retired in the order they were issued.
+// A key that is not in the first line of its sequence (one in six: the line was full) would stall that pipeline for the three
+// further loads of its buddy line: the lane writes (k-mer index, k-mer) to its wavefront's slice of `rest` instead, and
+// k_cov_join_rest looks those up afterwards (a slice that is full -- four k-mers in ten of the wavefront's rows missed their first
+// line: a stretch of repeats -- makes k_cov_join_rest look all of those rows up again).
+struct JoinRest {
+    uint64_t g, fwd;
+};
+template <int K>
+__global__ __launch_bounds__(256) void k_cov_join(const CountLine *__restrict__ t, uint64_t mask, int k_rt, const uint64_t *__restrict__ seq,
+                                                  const uint64_t *__restrict__ off, const uint64_t *__restrict__ kpre,
+                                                  const uint64_t *__restrict__ khead, const uint32_t *__restrict__ krow, bool one_strand,
+                                                  uint64_t n_kmers, uint32_t *__restrict__ gcov, JoinRest *__restrict__ rest,
+                                                  uint32_t *__restrict__ rest_n, uint32_t rest_cap, uint32_t rows_per_wave) {
+    const int k = K ? K : k_rt;
+    const int lane = lane_id();
+    // (wave-uniform by construction; said so, the row's khead / krow come through the scalar cache, beside the vector loads)
+    const uint64_t wave = (((uint64_t)blockIdx.x * blockDim.x) >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t n_rows = (n_kmers + 63) >> 6;
+    // rows wave * rows_per_wave ...: a wavefront is short-lived (64 rows: a tenth of a millisecond), so that the kernels of streams
+    // of higher priority -- the join runs beside findSuperBubble's -- get the CUs it gives back
+    const uint64_t row0 = wave * rows_per_wave;
+    const long n_it = row0 < n_rows ? (long)(n_rows - row0 < rows_per_wave ? n_rows - row0 : rows_per_wave) : 0;
+    const uint64_t below = lane == 63 ? ~1ull : (((2ull << lane) - 1) & ~1ull);   // bits 1 .. lane
+    JoinRest *my_rest = rest + wave * (rest_cap + 1);
+    uint32_t n_rest = 0;
+    // what a stage leaves for the next iteration
+    uint64_t s1_hd = 0;  uint32_t s1_kr = 0;
+    uint64_t s2_pre = 0, s2_wo = 0;
+    uint64_t s3_w0 = 0, s3_w1 = 0;  int s3_s = 0;
+    LineKeys s4_keys;  uint64_t s4_first = 0, s4_fwd = 0, s4_line = 0;
+    uint32_t s5_val = 0;  bool s5_miss = false;  uint64_t s5_fwd = 0;
+#pragma unroll
+    for (int i = 0; i < LINE_KEYS / 2; ++i) s4_keys.q[i] = make_uint4(0, 0, 0, 0);
+    if (n_it == 0) {
+        if (lane == 0) rest_n[wave] = 0;
+        return;
+    }
+    // Every stage runs in every iteration, on a row clamped to the wavefront's own rows, and every lane stores: no branch stands
+    // between the loads of one iteration and their use in the next, so the compiler waits for exactly the load a stage needs
+    // (s_waitcnt vmcnt(n), n > 0) instead of for all of them.  What the first four and the last four iterations compute for rows
+    // that are not there is overwritten (a row's real store comes after, from the same lane) or never used.
+    const long last = n_it - 1;
+    auto row_of = [&](long i) { return row0 + (uint64_t)(i < 0 ? 0 : i > last ? last : i); };
+    s1_hd = khead[row0];
+    s1_kr = krow[row0];
+    uint64_t s0_hd = khead[row_of(1)];   // two rows ahead: what an iteration loads is not asked for before the next one
+    uint32_t s0_kr = krow[row_of(1)];
+    for (long it = 0; it < n_it + 4; ++it) {
+        // row it - 4: its count has arrived
+        {
+            const uint64_t g = row_of(it - 4) * 64 + lane;
+            const bool miss = s5_miss && it >= 4 && g < n_kmers;
+            const uint64_t mm = __ballot(miss);
+            const uint32_t at = n_rest + (uint32_t)__popcll(mm & ((1ull << lane) - 1));
+            my_rest[miss && at < rest_cap ? at : rest_cap] = JoinRest{g, s5_fwd};   // slot rest_cap of a slice: nobody reads it
+            n_rest += (uint32_t)__popcll(mm);
+            gcov[g] = s5_miss ? GCOV_MISSING : s5_val;   // (a row's padding lanes included: gcov holds whole rows)
+        }
+        // row it - 3: its line's keys have arrived
+        {
+            bool open;
+            const int at = line_slot(s4_keys, s4_first, open);
+            s5_miss = at < 0;
+            s5_fwd = s4_fwd;
+            s5_val = t[s4_line].val[at < 0 ? 0 : at];
+        }
+        // row it - 2: its sequence words have arrived
+        {
+            uint64_t x = s3_w0 << s3_s;
+            x |= s3_s ? s3_w1 >> (64 - s3_s) : 0;
+            const uint64_t fwd = x >> (64 - 2 * k);
+            const uint64_t rc = rc_kmer(fwd, k);
+            const LineSeq sq = kmer_lines(fwd, rc, k, mask);
+            s4_first = (one_strand && rc < fwd) ? rc : fwd;
+            s4_fwd = fwd;
+            s4_line = sq.line;
+            s4_keys = load_line_keys(t, sq.line);
+        }
+        // row it - 1: kpre / off of its lanes' unitigs have arrived
+        {
+            uint64_t g = row_of(it - 1) * 64 + lane;
+            g = g < n_kmers ? g : n_kmers - 1;
+            const uint32_t p = (uint32_t)(g - s2_pre);
+            const uint64_t *w = seq + s2_wo + (p >> 5);
+            s3_s = (int)(p & 31) * 2;
+            s3_w0 = w[0];
+            s3_w1 = w[1];   // (the sequence array is padded by two words)
+        }
+        // row it: its khead / krow have arrived
+        {
+            const uint64_t r = row_of(it);
+            uint64_t hd = s1_hd & below;
+            hd &= r == n_rows - 1 ? (2ull << ((n_kmers - 1) & 63)) - 1 : ~0ull;   // lanes beyond the last k-mer: its unitig (the bit behind it is set)
+            const uint32_t u = s1_kr + (uint32_t)__popcll(hd);
+            s2_pre = kpre[u];
+            s2_wo = off[u];
+        }
+        // rows it + 1, it + 2
+        {
+            s1_hd = s0_hd;
+            s1_kr = s0_kr;
+            const uint64_t r = row_of(it + 2);
+            s0_hd = khead[r];
+            s0_kr = krow[r];
+        }
+    }
+    if (lane == 0) rest_n[wave] = n_rest;   // above rest_cap: the slice was full, k_cov_join_rest takes the wavefront's rows again
+}
+
+// the look-ups K-COV-JOIN's pipeline handed on: wavefront w takes slice w.  A slice that was full (more than four k-mers in ten of
+// the wavefront's rows missed their first line: a stretch of repeats) holds only some of them: that wavefront's rows are looked up
+// again from the graph, every look-up walked to its end where it stands.
+__global__ __launch_bounds__(256) void k_cov_join_rest(const CountLine *__restrict__ t, uint64_t mask, int k, bool one_strand,
+                                                       const JoinRest *__restrict__ rest, const uint32_t *__restrict__ rest_n, uint32_t rest_cap,
+                                                       uint32_t *__restrict__ gcov, const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                       const uint64_t *__restrict__ kpre, const uint64_t *__restrict__ khead,
+                                                       const uint32_t *__restrict__ krow, uint64_t n_kmers, uint32_t rows_per_wave) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const uint32_t n = rest_n[wave];
+    if (n > rest_cap) {
+        const uint64_t n_rows = (n_kmers + 63) >> 6;
+        const uint64_t below = lane == 63 ? ~1ull : (((2ull << lane) - 1) & ~1ull);
+        for (uint64_t r = wave * rows_per_wave; r < (wave + 1) * rows_per_wave && r < n_rows; ++r) {
+            const uint64_t g = r * 64 + lane;
+            if (g >= n_kmers) break;
+            const uint32_t u = krow[r] + (uint32_t)__popcll(khead[r] & below);
+            uint32_t c;
+            gcov[g] = canonical_count(t, mask, kmer_at(seq + off[u], (uint32_t)(g - kpre[u]), k), k, c, one_strand) ? c : GCOV_MISSING;
+        }
+        return;
+    }
+    const JoinRest *mine = rest + wave * (rest_cap + 1);
+    for (uint32_t e = lane; e < n; e += WAVE) {
+        const JoinRest x = mine[e];
+        uint32_t c;
+        bool found;
+        if (one_strand) {   // one form to look for, and its first line is known to be full of other keys
+            const uint64_t rc = rc_kmer(x.fwd, k);
+            found = count_find(t, mask, rc < x.fwd ? rc : x.fwd, kmer_lines(x.fwd, rc, k, mask), c, 1);
+        } else {
+            found = canonical_count(t, mask, x.fwd, k, c, false);
+        }
+        gcov[x.g] = found ? c : GCOV_MISSING;
+    }
+}
+
 // K-STRCOV: one thread per string (strings are k .. k+few bases long).
-__global__ void k_strcov(const Slot *__restrict__ t, uint64_t mask, int k, bool one_strand, const char *__restrict__ text,
+__global__ void k_strcov(const CountLine *__restrict__ t, uint64_t mask, int k, bool one_strand, const char *__restrict__ text,
                          const uint64_t *__restrict__ str_off, uint32_t n_str, uint32_t low, uint32_t up,
                          uint64_t *__restrict__ out_sum, uint8_t *__restrict__ out_ok, uint8_t *__restrict__ out_miss) {
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -605,7 +763,7 @@ namespace pf {
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
                                                 "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
-                                                "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_call_trio", "copy_text_to_host"};
+                                                "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_call_trio", "k_cov_join_rest", "copy_text_to_host"};
 
 // (events come from a pool that pf_reset_timing refills: creating two per launch cost more than the launch)
 static size_t launch_push(pf_ctx *ctx, int kernel, hipStream_t stream) {
@@ -730,9 +888,22 @@ int launch_cov_stream(pf_ctx *ctx, Kc4Args a, uint32_t n_colors, bool wide, bool
 // This is the load-time counterpart of K-ADJ: what CDBG::readCov looks up k-mer by k-mer (src/CDBG.cpp:66-120) becomes a
 // per-k-mer coverage SoA next to the 2-bit sequence SoA.  A count equal to the marker value cannot be represented: such a
 // database (max_count = 2^32 - 1) keeps the probing K-COV.
+// begin / finish: the kernels go to a stream of their own (lowest priority: what else the context launches goes first), so that a
+// caller with other work for the device -- findSuperBubble does not read a coverage -- runs it beside the look-ups;
+// join_finish() is what every reader of the joined array calls first.
 namespace pf {
-int join_graph_counts(pf_ctx *ctx) {
+static hipStream_t join_stream(pf_ctx *ctx) {
+    if (!ctx->join_stream) {
+        int least = 0, greatest = 0;
+        (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+        if (hipStreamCreateWithPriority(&ctx->join_stream, hipStreamNonBlocking, least) != hipSuccess) { (void)hipGetLastError(); ctx->join_stream = nullptr; }
+    }
+    return ctx->join_stream ? ctx->join_stream : ctx->stream;
+}
+
+int join_graph_counts_begin(pf_ctx *ctx) {
     ctx->gcov_valid = false;
+    ctx->join_inflight = false;
     if (!ctx->d_seq || !ctx->d_tab || ctx->tab_exact || ctx->tab_max_count >= GCOV_MISSING || ctx->n_kmers == 0) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
     if (!ctx->d_gcov && hipMalloc(&ctx->d_gcov, ((ctx->n_krow + 4) * 64) * sizeof(uint32_t)) != hipSuccess) {  // whole super-rows of 256
@@ -740,16 +911,54 @@ int join_graph_counts(pf_ctx *ctx) {
         ctx->d_gcov = nullptr;
         return PF_OK;
     }
-    const uint64_t n_win = (ctx->n_kmers + KCOV_WIN - 1) / KCOV_WIN;
-    ctx_begin(ctx, PF_K_COV_JOIN);
-    k_cov<<<ctx_grid(ctx, n_win * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
-                                                                        ctx->d_kwin, ctx->N, ctx->tab_one_strand, 0, 0, 0, ctx->n_kmers, 0, n_win,
-                                                                        nullptr, nullptr, nullptr, ctx->d_gcov);
-    ctx_end(ctx);
+    // a wavefront takes JOIN_ROWS_PER_WAVE consecutive rows (the pipeline's four iterations of filling and draining: 6 %) and has its
+    // slice of the hand-over list -- three in ten of its k-mers (one in six is expected)
+    // a wavefront takes JOIN_ROWS_PER_WAVE consecutive rows (the pipeline's four iterations of filling and draining: 6 %) -- a tenth
+    // of a millisecond, so that kernels of other streams get the CUs it gives back: the join runs beside findSuperBubble's -- and
+    // has its slice of the hand-over list: four in ten of its k-mers (one in six is expected)
+    constexpr uint32_t JOIN_ROWS_PER_WAVE = 64;
+    const uint64_t n_rows = (ctx->n_kmers + 63) / 64;
+    const uint64_t n_waves = ((n_rows + JOIN_ROWS_PER_WAVE - 1) / JOIN_ROWS_PER_WAVE + 3) / 4 * 4;
+    const int blocks = (int)(n_waves / 4);
+    const uint32_t rest_cap = JOIN_ROWS_PER_WAVE * 64 * 4 / 10;
+    const uint32_t rest_stride = rest_cap + 1;   // + the slot the lanes with nothing to hand on write to
+    JoinRest *rest = (JoinRest *)ctx_ws(ctx, WS_JOIN_REST, n_waves * rest_stride * sizeof(JoinRest));
+    uint32_t *rest_n = (uint32_t *)ctx_ws(ctx, WS_JOIN_REST_N, n_waves * 4);
+    if (!rest || !rest_n) { pf::CtxErr{ctx} = "no room for K-COV-JOIN's hand-over list"; return PF_ERR_HIP; }
+    if (!ctx->join_done) PF_HIP(hipEventCreateWithFlags(&ctx->join_done, hipEventDisableTiming));
+    const hipStream_t st = join_stream(ctx);
+    // (the join's stream does not wait for the context's by itself: what is resident was complete when its upload returned)
+    size_t at = 0;
+    (void)ctx_begin_at(ctx, PF_K_COV_JOIN, st, &at);
+#define PF_JOIN_LAUNCH(KK) k_cov_join<KK><<<blocks, 256, 0, st>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre, ctx->d_khead, \
+        ctx->d_krow, ctx->tab_one_strand, ctx->n_kmers, ctx->d_gcov, rest, rest_n, rest_cap, JOIN_ROWS_PER_WAVE)
+    if (ctx->k == 25) PF_JOIN_LAUNCH(25);
+    else if (ctx->k == 31) PF_JOIN_LAUNCH(31);
+    else PF_JOIN_LAUNCH(0);
+#undef PF_JOIN_LAUNCH
+    ctx_end_at(ctx, at, st);
+    (void)ctx_begin_at(ctx, PF_K_COV_JOIN_REST, st, &at);
+    k_cov_join_rest<<<blocks, 256, 0, st>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->tab_one_strand, rest, rest_n, rest_cap, ctx->d_gcov, ctx->d_seq, ctx->d_off,
+                                            ctx->d_kpre, ctx->d_khead, ctx->d_krow, ctx->n_kmers, JOIN_ROWS_PER_WAVE);
+    ctx_end_at(ctx, at, st);
     PF_HIP(hipGetLastError());
-    PF_HIP(hipStreamSynchronize(ctx->stream));
+    PF_HIP(hipEventRecord(ctx->join_done, st));
+    ctx->join_inflight = true;
+    return PF_OK;
+}
+
+int join_finish(pf_ctx *ctx) {
+    if (!ctx->join_inflight) return PF_OK;
+    ctx->join_inflight = false;
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipEventSynchronize(ctx->join_done));
     ctx->gcov_valid = true;
     return PF_OK;
+}
+
+int join_graph_counts(pf_ctx *ctx) {
+    const int rc = join_graph_counts_begin(ctx);
+    return rc ? rc : join_finish(ctx);
 }
 }  // namespace pf
 
@@ -770,7 +979,6 @@ static int stage_in(pf_ctx *ctx, const T *src, size_t n, T **dev, bool *owned) {
     return PF_OK;
 }
 
-static int check_table_strands(pf_ctx *ctx);
 
 extern "C" {
 
@@ -859,6 +1067,8 @@ void pf_destroy(pf_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    if (ctx->join_stream) { hipStreamSynchronize(ctx->join_stream); hipStreamDestroy(ctx->join_stream); }
+    if (ctx->join_done) hipEventDestroy(ctx->join_done);
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
     for (auto &e : ctx->event_pool) hipEventDestroy(e);
     call_destroy(ctx);
@@ -1017,14 +1227,16 @@ int pf_device_pci_bus_id(pf_ctx *ctx, char *buf, size_t cap) {
     return PF_OK;
 }
 
-uint64_t pf_table_capacity(const pf_ctx *ctx) { return ctx ? ctx->tab_cap : 0; }
+uint64_t pf_table_capacity(const pf_ctx *ctx) { return ctx ? ctx->tab_cap * pf::LINE_KEYS : 0; }
 uint64_t pf_num_kmers(const pf_ctx *ctx) { return ctx ? ctx->n_kmers : 0; }
 
 int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp,
                     uint32_t N, int k) {
     if (!ctx || !seq_words || !seq_off || !len_bp || N == 0 || k < 3 || k > 31) return PF_ERR_ARG;
     if (N >= (1u << 30)) { pf::CtxErr{ctx} = "more than 2^30 unitigs"; return PF_ERR_ARG; }
+    if (ctx->d_tab && ctx->tab_k != k) { pf::CtxErr{ctx} = "pf_upload_graph: k differs from the k of the resident count table"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
+    (void)join_finish(ctx);
     free_graph(ctx);
     // seq_off[N] = total words; fetch it (host or device pointer)
     uint64_t total_words = 0;
@@ -1083,10 +1295,6 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         ctx->h_len.resize(N);
         PF_HIP(hipMemcpyAsync(ctx->h_len.data(), ctx->d_len, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
-    }
-    if (ctx->d_tab && !ctx->tab_strands_checked) {
-        const int rc = check_table_strands(ctx);
-        if (rc) return rc;
     }
     if (ctx->d_tab && !ctx->tab_exact) return pf::join_graph_counts(ctx);
     return PF_OK;
@@ -1202,25 +1410,29 @@ int pf_copy_to_host(pf_ctx *ctx, void *dst, const void *src_dev, size_t bytes) {
     return PF_OK;
 }
 
-// one orientation per k-mer?  (decides the probe order of the composite lookup, never its result)
-static int check_table_strands(pf_ctx *ctx) {
-    ctx->tab_strands_checked = true;
+// one orientation per k-mer?  (decides the probe order of the composite lookup, never its result)  A table whose keys are all
+// canonical -- what K-TABLE saw while it hashed them -- cannot hold a key's reverse complement; only a table with other keys is
+// searched for such a pair (233 M probes saved for every database written with canonical counting).
+static int check_table_strands(pf_ctx *ctx, bool keys_all_canonical) {
     ctx->tab_one_strand = false;
-    if (!ctx->d_tab || !ctx->tab_n || !ctx->k) return PF_OK;
+    if (!ctx->d_tab || !ctx->tab_n) return PF_OK;
+    if (keys_all_canonical) { ctx->tab_one_strand = true; return PF_OK; }
     DevTmp<unsigned int> flag_;
     unsigned int h_flag = 0;
     PF_HIP(flag_.alloc(4));
     PF_HIP(hipMemsetAsync(flag_.p, 0, 4, ctx->stream));
-    k_table_two_strands<<<ctx_grid(ctx, ctx->tab_cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap, ctx->k, flag_.p);
+    k_table_two_strands<<<ctx_grid(ctx, ctx->tab_cap * LINE_KEYS, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap, ctx->tab_k, flag_.p);
     PF_HIP(hipMemcpyAsync(&h_flag, flag_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
     ctx->tab_one_strand = h_flag == 0;
     return PF_OK;
 }
 
-int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint64_t min_count,
+int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts, uint64_t n, uint32_t k, uint64_t min_count,
                      uint64_t max_count, int both_strands) {
-    if (!ctx || (n && (!kmers || !counts))) return PF_ERR_ARG;
+    if (!ctx || (n && (!kmers || !counts)) || k < 3 || k > 31) return PF_ERR_ARG;
+    if (ctx->d_seq && (int)k != ctx->k) { pf::CtxErr{ctx} = "pf_upload_counts: k differs from the k of the resident graph"; return PF_ERR_ARG; }
+    (void)join_finish(ctx);
     ctx->tab_exact = !both_strands;   // GetBothStrands() == false: lookups take the k-mer as it reads (src/CDBG.cpp:94-117)
     ctx->tab_max_count = max_count;
     call_invalidate(ctx);
@@ -1230,12 +1442,14 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
     hipFree(ctx->d_gcov);
     ctx->d_gcov = nullptr;
     ctx->gcov_valid = false;
-    uint64_t cap = 1024;
-    while (cap < n * 2) cap <<= 1;
-    PF_HIP(hipMalloc(&ctx->d_tab, cap * sizeof(Slot)));
+    // lines of ten keys, 2 to 4 of them taken on average: a line overflows for one key in ten
+    uint64_t cap = 128;
+    while (cap * 4 < n) cap <<= 1;
+    PF_HIP(hipMalloc(&ctx->d_tab, cap * sizeof(CountLine)));
     ctx->tab_cap = cap;
     ctx->tab_n = n;
-    k_fill_slots<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap);
+    ctx->tab_k = (int)k;
+    PF_HIP(hipMemsetAsync(ctx->d_tab, 0xFF, cap * sizeof(CountLine), ctx->stream));   // every key free
     // stage the records on the device if the caller passed host memory
     hipPointerAttribute_t at;
     const bool on_dev = n && hipPointerGetAttributes(&at, kmers) == hipSuccess && at.type == hipMemoryTypeDevice;
@@ -1252,19 +1466,49 @@ int pf_upload_counts(pf_ctx *ctx, const uint64_t *kmers, const uint32_t *counts,
         pk = dk_.p;
         pc = dc_.p;
     }
+    DevTmp<unsigned int> noncanon_;
+    unsigned int h_noncanon = 0;
+    PF_HIP(noncanon_.alloc(4));
+    PF_HIP(hipMemsetAsync(noncanon_.p, 0, 4, ctx->stream));
     if (n) {
         ctx_begin(ctx, PF_K_TABLE_BUILD);
-        k_table_build<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap - 1, pk, pc, n, min_count, max_count);
+        k_table_build<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, cap - 1, (int)k, pk, pc, n, min_count, max_count, noncanon_.p);
         ctx_end(ctx);
     }
-    ctx->tab_one_strand = false;
-    ctx->tab_strands_checked = false;
-    if (ctx->k) {   // k comes with the graph: a table uploaded first is checked when the graph arrives
-        const int rc = check_table_strands(ctx);
-        if (rc) return rc;
-    }
+    PF_HIP(hipMemcpyAsync(&h_noncanon, noncanon_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    const int rc = check_table_strands(ctx, h_noncanon == 0);
+    if (rc) return rc;
     if (ctx->d_seq && !ctx->tab_exact) return pf::join_graph_counts(ctx);
     return PF_OK;
+}
+
+int pf_join_counts_begin(pf_ctx *ctx) {
+    if (!ctx || !ctx->d_seq) return PF_ERR_ARG;
+    const bool single = ctx->d_tab && !ctx->tab_exact, colored = ctx->d_ctab && ctx->n_colors;
+    if (!single && !colored) { pf::CtxErr{ctx} = "pf_join_counts: no canonical count table resident"; return PF_ERR_ARG; }
+    { const int rc = pf::join_finish(ctx); if (rc) return rc; }
+    if (single) {
+        const int rc = pf::join_graph_counts_begin(ctx);
+        if (rc) return rc;
+        if (!ctx->join_inflight) { pf::CtxErr{ctx} = "pf_join_counts: no joined coverage array for this table (max_count = 2^32 - 1, or no room)"; return PF_ERR_ARG; }
+    }
+    if (colored) {   // (the colored join is one kernel on the context's stream: it has ended when this returns)
+        const int rc = pf::join_graph_counts_colored(ctx);
+        if (rc) return rc;
+        if (!ctx->gcov_c_valid) { pf::CtxErr{ctx} = "pf_join_counts: no joined coverage array for these databases (max_count = 2^32 - 1, or no room)"; return PF_ERR_ARG; }
+    }
+    return PF_OK;
+}
+
+int pf_join_counts_end(pf_ctx *ctx) {
+    if (!ctx) return PF_ERR_ARG;
+    return pf::join_finish(ctx);
+}
+
+int pf_join_counts(pf_ctx *ctx) {
+    const int rc = pf_join_counts_begin(ctx);
+    return rc ? rc : pf_join_counts_end(ctx);
 }
 
 int pf_lookup_kmers(pf_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *counts, uint8_t *found) {
@@ -1283,7 +1527,7 @@ int pf_lookup_kmers(pf_ctx *ctx, const uint64_t *kmers, uint64_t n, uint32_t *co
     PF_HIP(df_.alloc(n));
     uint32_t *dc = dc_.p;
     uint8_t *df = df_.p;
-    k_lookup<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->tab_one_strand, dk, n, dc, df);
+    k_lookup<<<ctx_grid(ctx, n, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->tab_k, ctx->tab_one_strand, dk, n, dc, df);
     PF_HIP(hipMemcpyAsync(counts, dc, n * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(found, df, n, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
@@ -1321,6 +1565,7 @@ static int unitig_cov_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, int exact, uin
     const uint64_t w_begin = g_range[0] / KCOV_WIN, w_end = (g_range[1] + KCOV_WIN - 1) / KCOV_WIN;
     static const bool env_probe = [] { const char *e = getenv("PF_KCOV_SCAN"); return e && !strcmp(e, "probe"); }();  // measurements: the probing form in whole runs
     probe = probe || env_probe;
+    { const int rc = join_finish(ctx); if (rc) return rc; }   // look-ups of pf_join_counts_begin still on their way
     if (!exact && !probe && !ctx->gcov_valid) {  // graph and table were uploaded before the join existed for them
         const int rc = join_graph_counts(ctx);
         if (rc) return rc;
@@ -1405,7 +1650,7 @@ int pf_string_cov(pf_ctx *ctx, const char *text, const uint64_t *str_off, uint32
     PF_HIP(hipMemcpyAsync(dt, text, (size_t)total, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(doff, str_off, ((size_t)n_str + 1) * 8, hipMemcpyDefault, ctx->stream));
     ctx_begin(ctx, PF_K_STRCOV);
-    k_strcov<<<ctx_grid(ctx, n_str, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->tab_one_strand, dt, doff, n_str, low, up, ds, dk, dm);
+    k_strcov<<<ctx_grid(ctx, n_str, 256, 8), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->tab_k, ctx->tab_one_strand, dt, doff, n_str, low, up, ds, dk, dm);
     ctx_end(ctx);
     PF_HIP(hipMemcpyAsync(sum, ds, (size_t)n_str * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ok, dk, n_str, hipMemcpyDefault, ctx->stream));

@@ -56,7 +56,7 @@ __device__ inline Slot load_slot(const Slot *t, uint64_t i) {
     return s;
 }
 
-// exact-key probe; returns true and the value when present
+// exact-key probe of a table addressed by mix64 alone (K-ADJ's end-k-mer table); returns true and the value when present
 __device__ inline bool table_find(const Slot *__restrict__ t, uint64_t mask, uint64_t key, uint32_t &val) {
     uint64_t i = mix64(key) & mask;
     for (;;) {
@@ -67,6 +67,121 @@ __device__ inline bool table_find(const Slot *__restrict__ t, uint64_t mask, uin
     }
 }
 
+// ---- count tables: lines of ten keys, addressed by the key's minimizer ---------------------------------------------------------
+// CKMCFile::CheckKmer (KMC/kmc_api/kmc_file.cpp:330-366) is asked for the k-mers of a unitig one after the other
+// (src/CDBG.cpp:66-120): neighbours that overlap in k - 1 bases.  A table addressed by a hash of the whole k-mer sends each of
+// them to a line of its own -- 233 M random lines for the 5 M-unitig graph, which is what the row-activation rate of the HBM
+// stacks gives (measured: 7.8 ms).  Here a k-mer's line is chosen by its MINIMIZER: the canonical 16-mer of smallest hash among
+// the k - 15 it holds.  The k-mers of a unitig share a minimizer in runs of up to k - 15 (ten at k = 25: a quarter of the runs,
+// 44 % of the k-mers; 5.8 on average), and the lanes of a wavefront that hold a run fetch one 128-B line between them.  The
+// minimizer of a k-mer and of its reverse complement are the same (the set of canonical m-mers is), so the second probe of the
+// composite look-up reads the same line.
+//   line: 128 B = ten keys (all ones = free) + their ten counts: a look-up loads the 80 bytes of keys, then one count.
+//   probe sequence of key x: the minimizer's line, its buddy (line ^ 1: the same DRAM page; takes what a run of more than ten keys
+//   or two minimizers on one line leave over -- one key in six at 3.3 keys a line), a second pair of lines elsewhere (double
+//   hashing: full lines do not grow into clusters), and then, only when all four are full (a minimizer shared by dozens of
+//   k-mers: a repeat family), the lines from mix64(x) on, one after the other.  Nothing is ever removed: "a free slot in a line of
+//   the sequence ends the search" holds throughout.
+// k < HOME_M + 2: the line is chosen by mix64 of the canonical k-mer.
+constexpr int HOME_M = 16;
+constexpr int LINE_KEYS = 10;
+constexpr int LINE_TRIES = 4;
+
+struct __attribute__((aligned(128))) CountLine {
+    uint64_t key[LINE_KEYS];
+    uint32_t val[LINE_KEYS];
+    uint32_t pad[2];
+};
+
+struct LineSeq {
+    uint64_t line, step;   // step: even, so that a second pair is another pair
+};
+__device__ inline uint64_t seq_line(const LineSeq &sq, int i, uint64_t mask) { return ((sq.line + (uint64_t)(i >> 1) * sq.step) & mask) ^ (uint64_t)(i & 1); }
+
+__device__ inline LineSeq kmer_lines(uint64_t fwd, uint64_t rc, int k, uint64_t mask) {
+    uint64_t h;
+    if (k < HOME_M + 2) {
+        h = mix64(fwd < rc ? fwd : rc);
+    } else {
+        static_assert(HOME_M == 16, "the m-mers are taken as whole 32-bit words");
+        uint64_t a = fwd;                  // low word of a >> 2j: the m-mer that ends j bases before the k-mer's end
+        uint64_t b = rc << (64 - 2 * k);   // high word of b << 2j: the reverse complement of that m-mer
+        uint32_t best = 0xFFFFFFFFu;
+        for (int j = k - HOME_M; j >= 0; --j) {
+            const uint32_t f = (uint32_t)a;
+            const uint32_t r = (uint32_t)(b >> 32);
+            const uint32_t c = f < r ? f : r;
+            const uint32_t x = c * 0x9E3779B1u;   // odd multiplier: a bijection of the m-mers, so the smallest product names one m-mer
+            best = x < best ? x : best;
+            a >>= 2;
+            b <<= 2;
+        }
+        // the smallest of ten products is small: mixed again before it names a line (murmur3's finalizer, twice for line and step)
+        uint32_t x = best;
+        x ^= x >> 16; x *= 0x85EBCA6Bu; x ^= x >> 13; x *= 0xC2B2AE35u; x ^= x >> 16;
+        uint32_t y = x * 0x9E3779B1u;
+        y ^= y >> 15;
+        h = ((uint64_t)y << 32) | x;
+    }
+    return LineSeq{(h ^ (h >> 32)) & mask, ((h >> 32) | 1) << 1};
+}
+
+// the ten keys of a line in registers
+struct LineKeys {
+    uint4 q[LINE_KEYS / 2];
+    __device__ inline uint64_t key(int i) const { return (i & 1) ? (((uint64_t)q[i >> 1].w << 32) | q[i >> 1].z) : (((uint64_t)q[i >> 1].y << 32) | q[i >> 1].x); }
+};
+__device__ inline LineKeys load_line_keys(const CountLine *__restrict__ t, uint64_t line) {
+    LineKeys k;
+    const uint4 *p = reinterpret_cast<const uint4 *>(t[line].key);
+#pragma unroll
+    for (int i = 0; i < LINE_KEYS / 2; ++i) k.q[i] = p[i];
+    return k;
+}
+// slot of `key` among the loaded keys (-1: not there); open = a free slot lies before the end of the line
+__device__ inline int line_slot(const LineKeys &k, uint64_t key, bool &open) {
+    int at = -1;
+    open = false;
+#pragma unroll
+    for (int i = 0; i < LINE_KEYS; ++i) {
+        const uint64_t x = k.key(i);
+        if (x == key) at = i;
+        if (x == EMPTY_KEY) open = true;
+    }
+    return at;
+}
+
+// exact-key probe of a count table along the key's line sequence, from try `first_try` on
+__device__ inline bool count_find(const CountLine *__restrict__ t, uint64_t mask, uint64_t key, const LineSeq &sq, uint32_t &val, int first_try = 0) {
+    for (int i = first_try; i < LINE_TRIES; ++i) {
+        const uint64_t line = seq_line(sq, i, mask);
+        bool open;
+        const int at = line_slot(load_line_keys(t, line), key, open);
+        if (at >= 0) { val = t[line].val[at]; return true; }
+        if (open) return false;
+    }
+    for (uint64_t line = mix64(key) & mask;; line = (line + 1) & mask) {
+        bool open;
+        const int at = line_slot(load_line_keys(t, line), key, open);
+        if (at >= 0) { val = t[line].val[at]; return true; }
+        if (open) return false;
+    }
+}
+
+// the place of a key's count, claiming the first free slot of its probe sequence (K-TABLE)
+__device__ inline uint32_t *count_claim(CountLine *t, uint64_t mask, uint64_t key, const LineSeq &sq) {
+    uint64_t line = 0;
+    for (int i = 0;; ++i) {
+        line = i < LINE_TRIES ? seq_line(sq, i, mask) : i == LINE_TRIES ? (mix64(key) & mask) : ((line + 1) & mask);
+        for (int s = 0; s < LINE_KEYS; ++s) {
+            unsigned long long *slot = reinterpret_cast<unsigned long long *>(&t[line].key[s]);
+            unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(slot);
+            if (old == EMPTY_KEY) old = atomicCAS(slot, EMPTY_KEY, key);
+            if (old == EMPTY_KEY || old == key) return &t[line].val[s];
+        }
+    }
+}
+
 // The hot path's composite lookup (reference src/CDBG.cpp:38-56):
 // "if (!IsKmer(fwd)) reverse(); CheckKmer(...)", i.e. the count of whichever orientation the database
 // holds, the forward one first.  When the table is known to hold at most one orientation of every
@@ -74,12 +189,13 @@ __device__ inline bool table_find(const Slot *__restrict__ t, uint64_t mask, uin
 // counting is like that) the order of the two probes cannot change the answer, so the canonical
 // form, the one such databases store, is probed first: one probe per k-mer instead of ~1.5 plus the
 // miss chain.
-__device__ inline bool canonical_count(const Slot *__restrict__ t, uint64_t mask, uint64_t fwd, int k, uint32_t &cnt,
+__device__ inline bool canonical_count(const CountLine *__restrict__ t, uint64_t mask, uint64_t fwd, int k, uint32_t &cnt,
                                        bool one_strand) {
     const uint64_t rc = rc_kmer(fwd, k);
+    const LineSeq sq = kmer_lines(fwd, rc, k, mask);
     const uint64_t first = (one_strand && rc < fwd) ? rc : fwd;
-    if (table_find(t, mask, first, cnt)) return true;
-    return table_find(t, mask, first == fwd ? rc : fwd, cnt);
+    if (count_find(t, mask, first, sq, cnt)) return true;
+    return count_find(t, mask, first == fwd ? rc : fwd, sq, cnt);
 }
 
 // The rolling window of readCov(string) (src/CDBG.cpp:36-43, src/CCDBG.cpp:96-103).  The reference keeps ONE CKmerAPI object per
@@ -100,30 +216,33 @@ struct StringWindow {
     }
 };
 
-// The same lookup split in two so that a lane can keep several k-mers in flight: count_probe() issues the first
-// 16-B probe of the form that is tried first, count_finish() consumes it and walks on only if it has to.
+// The same lookup split in two so that a lane can keep several k-mers in flight: count_probe() issues the loads of the keys of
+// the first line of the sequence (both forms of the k-mer have the same), count_finish() consumes them and goes on only if it has to.
 struct CountProbe {
     uint64_t first, second;
-    Slot s;
+    LineSeq sq;
+    LineKeys keys;
 };
-__device__ inline void count_probe(const Slot *__restrict__ t, uint64_t mask, uint64_t fwd, int k, bool one_strand, CountProbe &p) {
-    const uint64_t rc = rc_kmer(fwd, k);
-    p.first = (one_strand && rc < fwd) ? rc : fwd;
-    p.second = p.first == fwd ? rc : fwd;
-    p.s = load_slot(t, mix64(p.first) & mask);
+__device__ inline void count_probe_at(const CountLine *__restrict__ t, uint64_t key, const LineSeq &sq, CountProbe &p) {
+    p.first = p.second = key;
+    p.sq = sq;
+    p.keys = load_line_keys(t, sq.line);
 }
-__device__ inline bool count_finish(const Slot *__restrict__ t, uint64_t mask, const CountProbe &p, uint32_t &cnt) {
-    if (p.s.key == p.first) { cnt = p.s.val; return true; }
-    if (p.s.key != EMPTY_KEY) {  // occupied by another key: continue the linear probe behind it
-        uint64_t i = (mix64(p.first) + 1) & mask;
-        for (;;) {
-            const Slot s = load_slot(t, i);
-            if (s.key == p.first) { cnt = s.val; return true; }
-            if (s.key == EMPTY_KEY) break;
-            i = (i + 1) & mask;
-        }
-    }
-    return table_find(t, mask, p.second, cnt);
+__device__ inline void count_probe(const CountLine *__restrict__ t, uint64_t mask, uint64_t fwd, int k, bool one_strand, CountProbe &p) {
+    const uint64_t rc = rc_kmer(fwd, k);
+    const uint64_t first = (one_strand && rc < fwd) ? rc : fwd;
+    count_probe_at(t, first, kmer_lines(fwd, rc, k, mask), p);
+    p.second = first == fwd ? rc : fwd;
+}
+__device__ inline bool count_finish(const CountLine *__restrict__ t, uint64_t mask, const CountProbe &p, uint32_t &cnt) {
+    bool open;
+    int at = line_slot(p.keys, p.first, open);
+    if (at >= 0) { cnt = t[p.sq.line].val[at]; return true; }
+    if (!open && count_find(t, mask, p.first, p.sq, cnt, 1)) return true;   // the line is full of other keys: the rest of the sequence
+    if (p.second == p.first) return false;
+    at = line_slot(p.keys, p.second, open);
+    if (at >= 0) { cnt = t[p.sq.line].val[at]; return true; }
+    return !open && count_find(t, mask, p.second, p.sq, cnt, 1);
 }
 
 __device__ inline uint64_t wave_sum_u64(uint64_t v) {

@@ -21,7 +21,7 @@ NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
            "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
-           "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_call_trio", "copy_text_to_host"]
+           "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_call_trio", "k_cov_join_rest", "copy_text_to_host"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
@@ -100,7 +100,10 @@ def load_library() -> C.CDLL:
         "pf_kernel_name": (C.c_char_p, [i]),
         "pf_upload_graph": (i, [vp, vp, vp, vp, u32, i]),
         "pf_build_adjacency": (i, [vp, vp, vp]),
-        "pf_upload_counts": (i, [vp, vp, vp, u64, u64, u64, i]),
+        "pf_upload_counts": (i, [vp, vp, vp, u64, u32, u64, u64, i]),
+        "pf_join_counts": (i, [vp]),
+        "pf_join_counts_begin": (i, [vp]),
+        "pf_join_counts_end": (i, [vp]),
         "pf_lookup_kmers": (i, [vp, vp, u64, vp, vp]),
         "pf_unitig_cov": (i, [vp, u32, u32, vp, vp, vp]),
         "pf_unitig_cov_probe": (i, [vp, u32, u32, vp, vp, vp]),
@@ -180,7 +183,7 @@ def load_library() -> C.CDLL:
 
 DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf_set_stream", "pf_synchronize", "pf_enable_timing",
                     "pf_kernel_time", "pf_reset_timing", "pf_device_busy", "pf_kernel_units", "pf_side_components", "pf_replay_order", "pf_bfs_candidates_begin", "pf_bfs_candidates_end", "pf_fetch", "pf_bfs_candidates_resident", "pf_bfs_live_deferred", "pf_bfs_live_count", "pf_replay_device", "pf_replay_big_fetch", "pf_replay_set_colours", "pf_replay_finish", "pf_call_get_state", "pf_gfa_ingest", "pf_gfa_segments", "pf_gfa_parse", "pf_gfa_upload", "pf_gfa_error", "pf_kernel_name", "pf_upload_graph", "pf_build_adjacency",
-                    "pf_upload_counts", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
+                    "pf_upload_counts", "pf_join_counts", "pf_join_counts_begin", "pf_join_counts_end", "pf_lookup_kmers", "pf_unitig_cov", "pf_count_candidates", "pf_bfs_candidates",
                     "pf_align_batch", "pf_align_bubbles", "pf_string_cov", "pf_host_alloc", "pf_host_free", "pf_device_name", "pf_device_pci_bus_id", "pf_table_capacity", "pf_num_kmers",
                     "pf_upload_counts_colored", "pf_num_colors", "pf_unitig_cov_colored", "pf_string_cov_colored",
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
@@ -358,10 +361,18 @@ class Device:
         self._check(self.L.pf_build_adjacency(self.h, None, None))
         return None
 
-    def upload_counts(self, kmers, counts, min_count=1, max_count=0xFFFFFFFF, both_strands=True):
+    def upload_counts(self, kmers, counts, min_count=1, max_count=0xFFFFFFFF, both_strands=True, k=None):
+        """k: the database's k-mer length (default: the uploaded graph's) -- the table is addressed by minimizers of its keys"""
         self.both_strands = bool(both_strands)
         n = int(kmers.shape[0])
-        self._check(self.L.pf_upload_counts(self.h, _ptr(kmers), _ptr(counts), n, min_count, max_count, int(both_strands)))
+        k = int(k if k is not None else getattr(self, "k", 0))
+        if not k:
+            raise ValueError("upload_counts before upload_graph needs k")
+        self._check(self.L.pf_upload_counts(self.h, _ptr(kmers), _ptr(counts), n, k, min_count, max_count, int(both_strands)))
+
+    def join_counts(self):
+        """pf_join_counts: K-COV-JOIN once more (every graph k-mer looked up in the count table)"""
+        self._check(self.L.pf_join_counts(self.h))
 
     def minimizer_crowding(self, g: int, limit: int = 15, want_table: bool = False):
         """K-MINZ: (max occurrences of a minimizer slot, slots that reached `limit`[, the u32 counter table])."""

@@ -337,6 +337,51 @@ def test_two_strand_database_keeps_forward_first_order():
     assert f.all() and np.array_equal(c, counts[500:1000])
 
 
+def test_count_table_with_a_minimizer_shared_by_thousands_of_kmers():
+    """The count table is addressed by a key's MINIMIZER (pf_device_common.hpp: the minimizer's line of ten keys, its buddy, a
+    second pair of lines, then the lines from mix64 of the whole key on).  Keys that share one minimizer by the thousand -- a repeat
+    family -- fill those four lines and must still all be found, in both orientations, next to keys that are absent; k below the
+    minimizer length + 2 falls back to hashing the canonical k-mer."""
+    K_MUL, M = 0x9E3779B1, 16
+    inv = pow(K_MUL, -1, 1 << 32)
+
+    def rcn(x, n):
+        r = 0
+        for j in range(n):
+            r |= (3 - ((x >> (2 * j)) & 3)) << (2 * (n - 1 - j))
+        return r
+
+    # the canonical 16-mer whose hash c * K_MUL mod 2^32 is smallest: no other 16-mer of a key can beat it, so every key that
+    # holds it has it as its minimizer
+    mmer = next(c for c in ((h * inv) & 0xFFFFFFFF for h in range(1, 1 << 20)) if c <= rcn(c, M))
+    rng = np.random.default_rng(11)
+    for k in (25, 31, 18, 17):
+        left = (k - M) // 2
+        right = k - M - left
+        if k >= M + 2:
+            flank = rng.integers(0, 1 << (2 * (k - M)), size=6000, dtype=np.uint64)
+            keys = ((flank >> np.uint64(2 * right)) << np.uint64(2 * (M + right))) | (np.uint64(mmer) << np.uint64(2 * right)) | (flank & np.uint64((1 << (2 * right)) - 1))
+        else:
+            keys = rng.integers(0, 1 << (2 * k), size=6000, dtype=np.uint64)
+        keys = np.unique(np.concatenate([keys, rng.integers(0, 1 << (2 * k), size=20000, dtype=np.uint64)]))
+        can = np.array([min(int(x), rcn(int(x), k)) for x in keys], dtype=np.uint64)
+        can = np.unique(can)
+        counts = (np.arange(len(can), dtype=np.uint32) * 7 + 3) % 60000 + 1
+        d = hipapi.Device(0)
+        d.upload_counts(can, counts, 1, 65535, True, k=k)      # before any graph: k comes with the call
+        c, f = d.lookup(can)
+        assert f.all() and np.array_equal(c, counts), k
+        other = np.array([rcn(int(x), k) for x in can[:3000]], dtype=np.uint64)   # queried in the other orientation
+        c, f = d.lookup(other)
+        assert f.all() and np.array_equal(c, counts[:3000]), k
+        absent = np.setdiff1d(rng.integers(0, 1 << (2 * k), size=5000, dtype=np.uint64), np.concatenate([can, np.array([rcn(int(x), k) for x in can], dtype=np.uint64)]))
+        c, f = d.lookup(absent)
+        assert not f.any(), k
+        # a graph of another k is refused, and so is a table of another k beside a graph
+        with pytest.raises(RuntimeError):
+            d.upload_graph(*hipapi.pack_unitigs([b"ACGT" * 20]), k + 2 if k < 30 else k - 2)
+
+
 def lattice_gfa(path, k=25, depth=7, seed=3):
     """A superbubble wider than the LDS tables of K-BFS: a binary tree of `depth` levels fanning out
     from one entrance and its mirror image collapsing into one exit (2^depth unitigs in the middle)."""

@@ -38,7 +38,11 @@ STREAMING = {"k_cov", "k_cov_init", "k_cov_colored", "k_kmc_decode"}
 def short(name):
     if "k_cov_stream" in name:    # the per-pass K-COV (k_cov_stream4 / k_cov_stream: streams the joined per-k-mer coverage SoA)
         return "k_cov"
-    if "k_cov(" in name:          # the probing form: K-COV-JOIN at load, pf_unitig_cov_probe
+    if "k_cov_join_rest" in name:  # K-COV-JOIN, second kernel: the look-ups whose first line was full
+        return "k_cov_join_rest"
+    if "k_cov_join" in name:       # K-COV-JOIN: every graph k-mer looked up in the count table
+        return "k_cov_join"
+    if "k_cov(" in name:          # the probing form of K-COV (pf_unitig_cov_probe, databases without canonical counting)
         return "k_cov_probe"
     for k in ("k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_call_pair", "k_call_resolve", "k_sb_format",
               "k_cc_edges_long", "k_cc_edges", "k_cc_labels", "k_cc_multi", "k_cc_init", "k_bfs_thread",
