@@ -102,31 +102,53 @@ def make_colored_inputs(workdir: str, name: str, genome_len: int, seed: int, dev
     log("colored inputs %s: graph of %d unitigs built (%.1fs); colour sets and databases next" % (name, n_unitigs, time.time() - t0))
     sizes = np.diff(off)
     km_per = sizes - k + 1
-    # canonical k-mer of every (unitig, position): all windows of the concatenated text minus those spanning a boundary
-    fw, rc = synth.kmers_u64(codes, k)
-    start = np.repeat(off[:-1], km_per) + (np.arange(int(km_per.sum())) - np.repeat(np.cumsum(km_per) - km_per, km_per))
+    # Membership of every graph k-mer in every sample, on `device` (torch: the GPU of the box, or the CPU): the canonical k-mer of
+    # every (unitig, position) -- all windows of the concatenated text minus those spanning a boundary -- looked up in each sample's
+    # sorted distinct canonical k-mers.  Integer work throughout: the files are the same on either device.
+    import torch
+    tdev = torch.device(device) if not isinstance(device, torch.device) else device
+    t_codes = torch.from_numpy(codes).to(tdev)
+    t_off = torch.from_numpy(off).to(tdev)
+    t_km = torch.from_numpy(km_per.astype(np.int64)).to(tdev)
+    fw, rc = cdbg_build._kmers(t_codes, k)
+    t_first = torch.cumsum(t_km, 0) - t_km
+    start = torch.repeat_interleave(t_off[:-1] - t_first, t_km) + torch.arange(int(km_per.sum()), device=tdev, dtype=torch.int64)
     # the colour set of a unitig is placed by the hash of its head k-mer as the graph stores it: k-length unitigs are
     # kept canonical (bifrost/src/CompactedDBG.tcc:3945-3954)
-    head_fw, head_rc = fw[off[:-1]], rc[off[:-1]]
-    heads = bfg_colors.left_align(np.where(sizes == k, np.minimum(head_fw, head_rc), head_fw), k)
-    can = np.minimum(fw[start], rc[start])
-    del fw, rc, start
-    first = np.cumsum(km_per) - km_per
+    head_fw, head_rc = fw[t_off[:-1]], rc[t_off[:-1]]
+    heads_t = torch.where(torch.from_numpy(sizes == k).to(tdev), torch.minimum(head_fw, head_rc), head_fw)
+    heads = bfg_colors.left_align(heads_t.cpu().numpy().astype(np.uint64), k)
+    can = torch.minimum(fw[start], rc[start])
+    del fw, rc, start, head_fw, head_rc, heads_t
+    first = (np.cumsum(km_per) - km_per)
+    t_last = t_first + t_km - 1
     full_mask = np.zeros(n_unitigs, dtype=np.uint64)
     present = []
     dbs = []
     for s_, hs in enumerate(groups):
-        km_s, mult_s = synth.canonical_counts(hs, k)
+        parts = []
+        for h in hs:
+            hf, hr = cdbg_build._kmers(torch.from_numpy(np.ascontiguousarray(h)).to(tdev), k)
+            parts.append(torch.minimum(hf, hr))
+            del hf, hr
+        km_t, mult_t = torch.unique(torch.cat(parts), return_counts=True)
+        del parts
+        km_s, mult_s = km_t.cpu().numpy().astype(np.uint64), mult_t.cpu().numpy()
         db = os.path.join(workdir, "%s_kmc%d" % (name, s_))
         synth.write_kmc1(db, km_s, synth.synth_counts(km_s, mult_s), k)
         dbs.append(db)
-        idx = np.searchsorted(km_s, can)
-        idx[idx >= len(km_s)] = len(km_s) - 1
-        has = km_s[idx] == can
-        cnt = np.add.reduceat(has.astype(np.int64), first)
+        idx = torch.searchsorted(km_t, can).clamp_(max=km_t.numel() - 1)
+        has_t = km_t[idx] == can
+        del idx, km_t, mult_t
+        cs = torch.cumsum(has_t.to(torch.int64), 0)
+        cnt_t = cs[t_last] - cs[t_first] + has_t[t_first].to(torch.int64)
+        del cs
+        has, cnt = has_t.cpu().numpy(), cnt_t.cpu().numpy()
+        del has_t, cnt_t
         full_mask |= (cnt == km_per).astype(np.uint64) << np.uint64(s_)
         present.append((has, cnt))
         log("colored inputs %s: database and colour of sample %d (%.1fs)" % (name, s_, time.time() - t0))
+    del can, t_codes
     partial_ids = {}
     part = np.zeros(n_unitigs, dtype=bool)
     for has, cnt in present:
@@ -331,7 +353,20 @@ def main():
         args.unitigs = wl["unitigs"]
     Z = wl["z"]
 
+    if args.gpus > 1 and os.environ.get("PF_BENCH_SHARE_GPU") != "1":
+        import torch   # (counting devices does not initialise the GPU)
+        have = torch.cuda.device_count()
+        if have < args.gpus:
+            raise SystemExit("bench.py: --gpus %d but this node shows %d GPU(s): one rank per GPU (PF_BENCH_SHARE_GPU=1 puts every rank on GPU 0, "
+                             "for debugging on a one-GPU box only)" % (args.gpus, have))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        if args.gen_in_process:
+            # --gen-in-process is the mode for runs under a profiler, whose preloaded library has initialised the GPU in this
+            # process already: starting the ranks from here would be the fork-after-GPU-init the pool forbids, and the trace would
+            # be of a parent that launches no kernel
+            raise SystemExit("bench.py: --gen-in-process with --gpus %d needs a launcher (python -m torch.distributed.run --nproc-per-node %d ... "
+                             "bench.py --gpus %d --gen-in-process): the ranks are not started from a process a profiler is attached to"
+                             % (args.gpus, args.gpus, args.gpus))
         # `python bench.py --gpus N` without a launcher: start the N ranks here -- a child process of torch.distributed.run, before
         # anything in this process has touched the GPU (this parent never does) -- and leave with the child's exit code
         import socket
@@ -520,6 +555,24 @@ def main():
             dist.barrier()
         elapsed = time.perf_counter() - t0
         tt = run.times()
+        def kernel_times():   # kernel times from HIP events recorded by the library on the launches' own streams
+            kt, ku = {}, {}
+            for i, name in enumerate(hipapi.KERNELS):
+                ms, n = C.c_double(), C.c_uint64()
+                L.pf_kernel_time(ctx, i, C.byref(ms), C.byref(n))
+                if n.value:
+                    kt[name] = (ms.value, n.value)
+                    u = C.c_uint64()
+                    L.pf_kernel_units(ctx, i, C.byref(u))
+                    ku[name] = u.value
+            return kt, ku
+        ktimes_live, kunits_live = kernel_times()
+        # K-BUBBLE is launched once per size class and align range, side by side: what it occupies of a pass is the union of those
+        # launches' intervals, not their sum
+        bub_union = C.c_double()
+        L.pf_kernel_busy(ctx, sum(1 << hipapi.KERNELS.index(k) for k in ("k_bubble", "k_bubble_big") if k in hipapi.KERNELS), C.byref(bub_union))
+
+        L.pf_timing_select(ctx, 0)   # the second region is timed as a whole only
         # the same K steps without the join (the pass over the joined coverage array alone), timed the same way
         elapsed_excl, step_s_excl = None, []
         if join_in_step[0]:
@@ -537,23 +590,6 @@ def main():
                 dist.barrier()
             elapsed_excl = time.perf_counter() - te_
             join_in_step[0] = True
-
-        def kernel_times():   # kernel times from HIP events recorded by the library on the launches' own streams
-            kt, ku = {}, {}
-            for i, name in enumerate(hipapi.KERNELS):
-                ms, n = C.c_double(), C.c_uint64()
-                L.pf_kernel_time(ctx, i, C.byref(ms), C.byref(n))
-                if n.value:
-                    kt[name] = (ms.value, n.value)
-                    u = C.c_uint64()
-                    L.pf_kernel_units(ctx, i, C.byref(u))
-                    ku[name] = u.value
-            return kt, ku
-        ktimes_live, kunits_live = kernel_times()
-        # K-BUBBLE is launched once per size class and align range, side by side: what it occupies of a pass is the union of those
-        # launches' intervals, not their sum
-        bub_union = C.c_double()
-        L.pf_kernel_busy(ctx, sum(1 << hipapi.KERNELS.index(k) for k in ("k_bubble", "k_bubble_big") if k in hipapi.KERNELS), C.byref(bub_union))
 
         # the kernel table and the device-busy time (the union of the launches' intervals: the pipeline runs kernels side by side, so
         # the per-kernel sums overlap): further passes, every launch timed, outside the timed region
@@ -635,6 +671,19 @@ def main():
                 log("sharded run vs rank 0 alone: %s" % sharded_identical)
             dist.barrier()
 
+        # proof for the scaling line that RCCL saw N ranks on N distinct devices: the process group's size and every rank's PCI bus id
+        rccl_ranks_seen, rank_devices = (dist.get_world_size() if world > 1 and dist.is_initialized() else 1), None
+        busbuf = C.create_string_buffer(32)
+        L.pf_device_pci_bus_id(ctx, busbuf, 32)
+        if world > 1:
+            tb_ = torch.zeros(32, dtype=torch.uint8, device=xdev)
+            raw_ = busbuf.value[:31]
+            tb_[:len(raw_)] = torch.tensor(list(raw_), dtype=torch.uint8)
+            allb_ = [torch.zeros(32, dtype=torch.uint8, device=xdev) for _ in range(world)]
+            dist.all_gather(allb_, tb_)
+            rank_devices = [bytes(x.cpu().tolist()).split(b"\0")[0].decode() for x in allb_]
+        else:
+            rank_devices = [busbuf.value.decode()]
         allstats = pfdist.all_gather_counters([n_unitigs, tt["superbubbles"], tt["tasks"], tt["output_bytes"]] + tt["allele"] +
                                               [int((elapsed_excl or 0.0) * 1e6), int(elapsed * 1e6)], xdev)
         max_elapsed = allstats[:, -1].max() / 1e6
@@ -745,6 +794,9 @@ def main():
                                         "inverted copies and tandem arrays on 8 %% of the genome" if args.workload == "repeats" else ""),
                            "k": wl["k"], "z": Z,
                            "unitigs_total": total_unitigs, "kmers_per_gpu": n_kmers, "host_threads_per_rank": host_threads,
+                           "backend": ("gloo (PF_BENCH_SHARE_GPU: every rank on GPU 0)" if share else "nccl (RCCL)") if world > 1 else None,
+                           "rccl_ranks_seen": rccl_ranks_seen, "rank_pci_bus_ids": rank_devices,
+                           "distinct_devices": len(set(rank_devices)),
                            "output_fs": "%s (%s): the result files of the timed passes -- and of the reference in cpu_baseline -- are written there" % (output_fs, workdir),
                            "partitioning": ("one graph replicated on every rank, cut by entrance vertex: K-BFS records all-gathered over RCCL "
                                             "(%d bytes per pass) and replayed on every rank; bubble list in contiguous slices, two small "
@@ -789,6 +841,19 @@ def main():
                            "sites": shard_stats["counters"][:4] if strong else tt["allele"],
                            "output_bytes": shard_stats["output_bytes"] if strong else tt["output_bytes"]},
             }
+            # the model the first hardware scaling curve can be checked against: every rank repeats the look-ups, findSuperBubble and the
+            # owner scan; only the rest of PloidyEstimation (alignment, text, files) is cut over the ranks; two small all-gathers
+            hp_ = {k_: v_ / args.steps for k_, v_ in phase.items()}
+            cut_ms = max(0.0, (hp_["ploidy_total_s"] - hp_["scan_s"]) * 1e3) * (world if strong else 1)   # (a cut run measures its own slice)
+            step_ms = max_elapsed / args.steps * 1e3
+            rep_ms = max(0.0, step_ms - cut_ms / (world if strong else 1))
+            out["predicted_scaling"] = {
+                "model": "ms(N) = replicated + cut / N; replicated = K-COV-JOIN + findSuperBubble + owner scan of this run, cut = the rest of PloidyEstimation "
+                         "(alignment, text, files); the two all-gathers (< 0.1 ms over xGMI) left out",
+                "replicated_ms": round(rep_ms, 2), "cut_ms_at_1_gpu": round(cut_ms, 2),
+                "ms": {str(n_): round(rep_ms + cut_ms / n_, 2) for n_ in (1, 2, 4, 8)},
+                "speedup": {str(n_): round((rep_ms + cut_ms) / (rep_ms + cut_ms / n_), 2) for n_ in (1, 2, 4, 8)},
+                "ceiling": round((rep_ms + cut_ms) / rep_ms, 2) if rep_ms > 0 else None}
             if cpu:
                 out["speedup_vs_cpu_1core"] = round(value / cpu["value"], 2)
                 # the north-star bar: >= 10x the reference's single-threaded throughput at 1 GPU

@@ -459,9 +459,18 @@ int main(int argc, char **argv) {
         cerr << g.error() << endl;
         exit(EXIT_FAILURE);
     };
-    if (!g.good()) {
+    if (!g.good() && ranks.world <= 1) {
         if (g.error().rfind("CompactedDBG::read()", 0) == 0) { cout << g.error() << endl; exit(EXIT_FAILURE); }   // (the ingest's word for it)
         die();
+    }
+    if (ranks.world > 1) {   // a rank without its graph or table says so to the others before they wait for it in the communicator
+        if (!g.good()) cerr << "rank " << ranks.rank << ": " << g.error() << endl;
+        if (!ranks.agree(g.good(), "load")) {
+            if (g.good()) cerr << "rank " << ranks.rank << ": " << ranks.err << endl;
+            cerr.flush();
+            if (ranks.rank == 0) (void)ranks.finish();
+            _exit(EXIT_FAILURE);
+        }
     }
     if (!host_gfa) {
         cout << "CompactedDBG::read(): Graph loading successful" << endl;
@@ -475,36 +484,47 @@ int main(int argc, char **argv) {
     if (getenv("PF_BFS_HUGE_ON_DEVICE")) g.set_third_tier_on_host(false);   // experiments: giant traversals on one wavefront each
     if (ranks.world > 1) {
         // ---- one graph over the GPUs of the node (the protocol of ploidyfrost_amd/dist.py from the C++ side) ----
+        // every step that ends in a collective: the rank's own outcome first, then whether everybody is still there (pf_multi.hpp,
+        // RankGroup::agree) -- a rank that failed alone must not leave the others waiting in RCCL
         auto leave = [&](const std::string &why) {
             cerr << "rank " << ranks.rank << ": " << why << endl;
             cerr.flush();
-            _exit(EXIT_FAILURE);   // (the others see a closed socket or a failed collective and leave as well)
+            if (ranks.rank == 0) (void)ranks.finish();
+            _exit(EXIT_FAILURE);
+        };
+        auto together = [&](bool failed, const std::string &why, const char *stage) {
+            if (failed) cerr << "rank " << ranks.rank << ": " << why << endl;
+            if (!ranks.agree(!failed, stage)) leave(failed ? std::string("leaving") : ranks.err);
         };
         if (!ranks.connect(g.device())) leave("--gpus: " + ranks.err);
         mark("communicator");
         g.set_write_super_bubble(ranks.rank == 0);
+        int bad = 0;
         if (ranks.rank == 0) {
-            if (g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads)) leave(g.error());
-            if (opt.info && g.printInfo(opt.verbose, opt.outprefix)) leave(g.error());
+            bad = g.setUnitigId(opt.outprefix, opt.graphfile, opt.nb_threads);
+            if (!bad && opt.info) bad = g.printInfo(opt.verbose, opt.outprefix);
         }
-        if (g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads)) leave(g.error());   // every rank: the same state everywhere
+        if (!bad) bad = g.findSuperBubble_multithread_ptr(opt.outprefix, opt.nb_threads);   // every rank: the same state everywhere
+        together(bad != 0, g.error(), "findSuperBubble");
         mark("findSuperBubble");
         cout << "CDBG:: Minimum Coverage:" << opt.coverage_lower << endl;
         cout << "CDBG:: Maximum Coverage:" << opt.coverage_upper << endl;
         const auto tp0 = std::chrono::steady_clock::now();
         cout << "CDBG::PloidyEstimation():  Analyzing superbubbles to generate sites' information" << endl;
         uint64_t nb = 0;
-        if (g.ploidy_select(opt.coverage_lower, opt.coverage_upper, nb)) leave(g.error());
+        bad = g.ploidy_select(opt.coverage_lower, opt.coverage_upper, nb);
         const uint64_t W = (uint64_t)ranks.world, R = (uint64_t)ranks.rank;
         const uint64_t t0b = nb / W * R + std::min<uint64_t>(R, nb % W), t1b = t0b + nb / W + (R < nb % W ? 1 : 0);
         uint64_t called = 0;
-        if (g.ploidy_align(t0b, t1b, called)) leave(g.error());
+        if (!bad) bad = g.ploidy_align(t0b, t1b, called);
+        together(bad != 0, g.error(), "align");
         std::vector<uint64_t> all((size_t)W * 18);
         if (!ranks.gather(g.device(), &called, 1, all.data())) leave("--gpus: " + ranks.err);
         uint64_t base = 0;
         for (uint64_t r = 0; r < R; ++r) base += all[r];
         uint64_t mine[18];
-        if (g.ploidy_text(base, mine, mine + PF_CALL_STREAMS)) leave(g.error());
+        bad = g.ploidy_text(base, mine, mine + PF_CALL_STREAMS);
+        together(bad != 0, g.error(), "text");
         if (!ranks.gather(g.device(), mine, 18, all.data())) leave("--gpus: " + ranks.err);
         uint64_t offsets[PF_CALL_STREAMS] = {}, totals[PF_CALL_STREAMS] = {}, sums[8] = {};
         for (uint64_t r = 0; r < W; ++r) {
@@ -514,7 +534,8 @@ int main(int argc, char **argv) {
             }
             for (int c = 0; c < 8; ++c) sums[c] += all[r * 18 + PF_CALL_STREAMS + (uint64_t)c];
         }
-        if (g.ploidy_write(opt.outprefix, offsets, totals, true)) leave(g.error());
+        bad = g.ploidy_write(opt.outprefix, offsets, totals, true);
+        together(bad != 0, g.error(), "write");
         uint64_t done = 1;   // nobody returns before everybody's slabs are in the files
         if (!ranks.gather(g.device(), &done, 1, all.data())) leave("--gpus: " + ranks.err);
         mark("PloidyEstimation");

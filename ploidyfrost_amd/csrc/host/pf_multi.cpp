@@ -18,7 +18,7 @@ namespace {
 bool write_all(int fd, const void *p, size_t n) {
     const char *c = static_cast<const char *>(p);
     while (n) {
-        const ssize_t w = write(fd, c, n);
+        const ssize_t w = send(fd, c, n, MSG_NOSIGNAL);   // a peer that is gone is an error to report, not a SIGPIPE
         if (w < 0) { if (errno == EINTR) continue; return false; }
         c += w;
         n -= (size_t)w;
@@ -74,16 +74,45 @@ bool RankGroup::start(int world_size) {
 bool RankGroup::connect(pf_ctx *ctx) {
     if (world <= 1 || share_gpu) return true;
     unsigned char id[PF_COMM_ID_BYTES];
+    memset(id, 0, sizeof id);
+    bool ok = true;
+    if (rank == 0 && pf_comm_unique_id(id) != PF_OK) { err = "pf_comm_unique_id failed (librccl)"; ok = false; }
+    if (!agree(ok, "communicator id")) return false;   // (nobody waits in ncclCommInitRank for an id that does not exist)
     if (rank == 0) {
-        if (pf_comm_unique_id(id) != PF_OK) { err = "pf_comm_unique_id failed (librccl)"; memset(id, 0, sizeof id); for (int fd : peers) (void)write_all(fd, id, sizeof id); return false; }
         for (int fd : peers)
-            if (!write_all(fd, id, sizeof id)) { err = "a rank left before the communicator was made"; return false; }
+            if (!write_all(fd, id, sizeof id)) { err = "a rank left before the communicator was made"; ok = false; }
     } else if (!read_all(peers[0], id, sizeof id)) {
         err = "rank 0 left before the communicator was made";
-        return false;
+        ok = false;
     }
-    if (pf_comm_init(ctx, id, rank, world) != PF_OK) { err = pf_last_error(ctx); return false; }
-    return true;
+    if (!agree(ok, "communicator")) return false;
+    if (pf_comm_init(ctx, id, rank, world) != PF_OK) { err = pf_last_error(ctx); ok = false; }
+    return agree(ok, "communicator ready");
+}
+
+// Everybody or nobody goes on.  RCCL has no timeout: a rank that entered ncclCommInitRank or an all-gather waits for ever for a peer
+// that left after an error of its own (a k-mer of its slice in no database, no memory on its device ...).  So before every step that
+// ends in a collective the ranks tell rank 0 over the socket pairs whether they are still well, and rank 0 tells them whether
+// everybody is; a socket that closed counts as a rank that is not.
+bool RankGroup::agree(bool ok, const char *stage) {
+    if (const char *e = getenv("PF_FAIL_RANK")) {   // test seam: "<rank>:<stage>" makes that rank report a failure of its own there
+        const std::string want = std::to_string(rank) + ":" + stage;
+        if (want == e) { ok = false; err = std::string("injected failure at ") + stage; }
+    }
+    if (world <= 1) return ok;
+    unsigned char mine = ok ? 1 : 0, all = mine;
+    if (rank == 0) {
+        for (int fd : peers) {
+            unsigned char theirs = 0;
+            if (!read_all(fd, &theirs, 1)) theirs = 0;
+            all &= theirs;
+        }
+        for (int fd : peers) (void)write_all(fd, &all, 1);
+    } else if (!write_all(peers[0], &mine, 1) || !read_all(peers[0], &all, 1)) {
+        all = 0;
+    }
+    if (ok && !all && err.empty()) err = std::string("another rank failed before ") + stage;
+    return all != 0;
 }
 
 bool RankGroup::gather(pf_ctx *ctx, const uint64_t *mine, uint32_t n, uint64_t *all) {

@@ -29,6 +29,9 @@ struct RankGroup {
     // forks world - 1 children (call before any HIP call of the process); returns false in no process on failure paths that matter:
     // a failed fork leaves rank 0 alone with err set
     bool start(int world_size);
+    // collective over the socket pairs: true iff every rank passed ok = true (a rank that is gone counts as false).  Called before
+    // every step that ends in an RCCL call, which would wait for ever for a rank that left.  `stage` names the step in messages.
+    bool agree(bool ok, const char *stage);
     // RCCL communicator on this rank's context (or nothing, when the ranks share a GPU)
     bool connect(pf_ctx *ctx);
     // all[r * n + i] = word i of rank r; collective

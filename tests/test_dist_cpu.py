@@ -106,3 +106,30 @@ def test_world_size_2_gloo(tmp_path):
 def test_find_superbubbles_sharded_by_entrance_matches_the_oracle(case, world, tmp_path):
     meta = load_case(case)
     _run_world(tmp_path, SHARDED_FIND, 29617 + world, args=(meta["gfa"], meta["db"], int(meta["opts"]["-z"])), world=world)
+
+
+def test_rank_group_around_rccl_without_rccl(tmp_path):
+    """csrc/host/pf_multi.cpp (`ploidyfrost --gpus N`) linked against stand-ins for the device layer's four calls
+    (tests/cpp/test_multi.cpp): rank r on device r, rank 0's communicator id reaches every rank across the fork, the gathered words;
+    a rank that fails alone -- or is gone without a word -- ends every rank non-zero BEFORE the next collective (RCCL would wait for
+    ever), and nothing hangs."""
+    import subprocess
+    exe = str(tmp_path / "test_multi")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "ploidyfrost_amd", "csrc", "host"),
+                    os.path.join(ROOT, "tests", "cpp", "test_multi.cpp"), os.path.join(ROOT, "ploidyfrost_amd", "csrc", "host", "pf_multi.cpp"),
+                    "-o", exe, "-lpthread"], check=True)
+
+    def run(*a):
+        return subprocess.run([exe] + [str(x) for x in a], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=60)
+    for world in (2, 4, 8):
+        r = run("ok", world)
+        assert r.returncode == 0 and "OK %d ranks, %d gathers entered" % (world, 2 * world) in r.stdout, r.stderr
+    for world, who, stage, gathers in ((4, 2, "align", 0), (3, 0, "text", 3), (4, 3, "communicator id", 0), (2, 1, "load", 0), (4, 1, "write", 8)):
+        r = run("fail", world, who, stage)
+        assert r.returncode != 0, (stage, r.stderr)
+        assert "rank %d: " % who in r.stderr and "injected failure at %s" % stage in r.stderr
+        assert "gathers entered: %d" % gathers in r.stderr, r.stderr   # nobody went into the collective behind the failed step
+        for q in range(world):
+            assert "rank %d:" % q in r.stderr   # every rank said why it left
+    r = run("die", 4, 1)
+    assert r.returncode != 0 and "gathers entered: 0" in r.stderr and "another rank failed" in r.stderr

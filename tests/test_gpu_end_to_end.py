@@ -79,6 +79,19 @@ def test_cli_ranks_end_together_when_one_fails(tmp_path):
     assert r.returncode != 0 and "can not found" in r.stdout
 
 
+@pytest.mark.parametrize("who,stage", [(1, "align"), (0, "text"), (2, "load"), (1, "findSuperBubble")])
+def test_cli_one_rank_failing_alone_ends_every_rank(who, stage, tmp_path):
+    """A rank that fails ALONE (PF_FAIL_RANK, the test seam of RankGroup::agree: over RCCL the others would wait for it for ever in
+    ncclCommInitRank / the all-gather): every rank says why it leaves, rank 0 ends non-zero, nothing hangs."""
+    meta = load_case("dip20k")
+    r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "2", "--gpus", "3"] + meta["args"], cwd=tmp_path,
+                       stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, env=dict(os.environ, PF_SHARE_GPU="1", PF_FAIL_RANK="%d:%s" % (who, stage)),
+                       timeout=120)
+    assert r.returncode != 0, r.stdout
+    assert "rank %d: injected failure at %s" % (who, stage) in r.stdout or "rank %d: leaving" % who in r.stdout, r.stdout
+    assert "another rank failed before %s" % stage in r.stdout, r.stdout
+
+
 @pytest.mark.parametrize("case", ["tet60k", "weird12k", "hex30k"])
 def test_state_after_find_superbubbles_matches_oracle(case, tmp_path):
     meta = load_case(case)
