@@ -14,8 +14,7 @@ constexpr uint32_t NONE = 0xFFFFFFFFu;
 }
 
 void advise_huge_pages(const void *p, size_t bytes) {
-    static const bool on = [] { const char *e = getenv("PF_HUGE_PAGES"); return !(e && e[0] == '0'); }();   // measurements
-    if (!on || !p) return;
+    if (!p) return;
     constexpr uintptr_t H = (uintptr_t)2 << 20;
     const uintptr_t a = ((uintptr_t)p + H - 1) & ~(H - 1), e = ((uintptr_t)p + bytes) & ~(H - 1);
     if (e > a) (void)madvise(reinterpret_cast<void *>(a), e - a, MADV_HUGEPAGE);

@@ -160,9 +160,9 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
         }
         if (most >= 15) {
             // (the census table and the unitigs that meet a crowded slot come from the device: the host replay's own two passes over
-            // every unitig were 2.5 of a 3.9 s CLI run at BASELINE.json configs[4]; PF_MINZ_HOST_PASSES=1: as before, measurements)
+            // every unitig were 2.5 of a 3.9 s CLI run at BASELINE.json configs[4])
             std::vector<uint8_t> cnt8, flg;
-            if (!getenv("PF_MINZ_HOST_PASSES")) {
+            {
                 cnt8.resize(pf_minimizer_table_slots(g_.n_kmers));
                 flg.resize(g_.n());
                 st = pf_minimizer_replay_inputs(ctx_, g_.g, 15, cnt8.data(), flg.data());
@@ -212,7 +212,7 @@ void CDBG::start_prealloc() {
             if (commits_on_device(1) && pf_count_candidates(ctx_, 0, N, &n_cand) == PF_OK) {
                 (void)pf_find_reserve(ctx_, n_cand);
                 // (K-CC once over no records: what its first call of a run pays beyond its 0.6 ms is paid here)
-                if (!getenv("PF_NO_CC_WARMUP")) (void)pf_side_components(ctx_, 1, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0);
+                (void)pf_side_components(ctx_, 1, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0);
             }
             (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_);
             (void)pf_call_reserve_text(ctx_, piece);

@@ -287,7 +287,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         std::atomic<bool> &stop;
         ~Prefault0Guard() { stop.store(true); if (t.joinable()) t.join(); }
     } prefault0_guard{prefault0, prefault0_stop};
-    if (write_files_ && n_tasks && !getenv("PF_NO_EARLY_PREFAULT")) {
+    if (write_files_ && n_tasks) {
         const double nbub = 1.1 * (double)n_tasks;
         // (order: pf_call_stream.  Measured at k = 25, tetraploid: 18.4, 157, 18.0, 0.34, 0.07, 0, 30.2, 0.45, 0.08, 0 bytes per bubble;
         // what is reserved beyond the final size is touched here and cut off again at the end -- 8 ms for 60 MB too many)
@@ -491,13 +491,13 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         const uint64_t n_ranges = ranges_env > 0 ? (uint64_t)ranges_env : (pieces >= 4 ? 2 : 1);
         if (n_ranges > 1) ALIGN = std::min<uint64_t>(ALIGN, std::max<uint64_t>(1, (pieces + n_ranges - 1) / n_ranges) * CHUNK);
     }
-    int first_env = [] { const char *e = getenv("PF_ALIGN_FIRST"); return e ? atoi(e) : 0; }();   // measurements: pieces in the first range
-    const int LANES = [] { const char *e = getenv("PF_ALIGN_LANES"); return e ? std::max(1, std::min(PF_CALL_LANES, atoi(e))) : PF_CALL_LANES; }();   // measurements
+    int first_env = 0;   // pieces in the first range
+    constexpr int LANES = PF_CALL_LANES;
     // aligner threads: pf_call_align_lane on that many lanes side by side (below)
     const int aligners_wanted = [&] { const char *e = getenv("PF_ALIGN_THREADS"); return e ? std::max(1, std::min(LANES, atoi(e))) : std::min(2, LANES); }();
     {
         // Where two ranges are cut.  One aligner: what a pass ends with is the text of the LAST range, formatted and copied with nothing
-        // beside it, so the first range takes five eighths of the pieces (tools/ab_pass.py PF_ALIGN_FIRST: 5 + 3 of eight pieces
+        // beside it, so the first range takes five eighths of the pieces (measured with a knob since removed: 5 + 3 of eight pieces
         // 20.08 ms, 4 + 4 20.28, 6 + 2 20.50, 3 + 5 20.90).  Two aligners: both ranges are on the device from the start and end
         // within half a millisecond of each other; in halves (4 + 4 17.19 ms, 5 + 3 17.66, 3 + 5 17.45, 2 + 6 17.89).
         const uint64_t pieces = (n_tasks + CHUNK - 1) / CHUNK;

@@ -78,7 +78,7 @@ int CDBG::find_superbubbles_device(const std::string &outpre, const size_t &thr)
     // overflow) is walked afterwards.
     const unsigned walk_threads = (unsigned)std::max<uint64_t>(1, std::min<uint64_t>(threads_ ? threads_ : std::max<size_t>(thr, 1), (4ull << 30) / (4ull * std::max<uint32_t>(N, 1))));
     constexpr uint64_t LIVE_CAP = 4096;
-    static const bool live_on = [] { const char *e = getenv("PF_BFS_LIVE"); return !(e && e[0] == '0'); }();   // measurements
+    constexpr bool live_on = true;
     volatile uint64_t *live = nullptr;
     if (pf_bfs_live_deferred(ctx_, live_on ? LIVE_CAP : 0, &live) != PF_OK) live = nullptr;
     struct Walked {
@@ -353,8 +353,7 @@ int CDBG::findSuperBubble_multithread_ptr(const std::string &outpre, const size_
     // (one wavefront per giant traversal, run slice after slice) is the first pass over a graph kept in one piece.
     constexpr int kMaxSlices = 4;
     // (with the commits spread over host threads a slice's replay takes a millisecond: slicing only pays for the sequential replay)
-    static const int env_slices = [] { const char *e = getenv("PF_FIND_SLICES"); return e ? std::max(1, std::min(4, atoi(e))) : 0; }();
-    const int kSlices = env_slices ? env_slices : replay_threads(thr) ? 1 : (third_tier_on_host_ || (find_passes_ > 0 && times_.bfs_large == 0)) ? kMaxSlices : 1;
+    const int kSlices = replay_threads(thr) ? 1 : (third_tier_on_host_ || (find_passes_ > 0 && times_.bfs_large == 0)) ? kMaxSlices : 1;
     ++find_passes_;
     uint32_t s_u0[kMaxSlices + 1];
     uint64_t s_cand[kMaxSlices], s_rec0[kMaxSlices + 1], s_pool0[kMaxSlices + 1], s_nrec[kMaxSlices], s_used[kMaxSlices];

@@ -383,12 +383,12 @@ int main(int argc, char **argv) {
     }
 
     // Giving 12 GB of device memory and the pinned buffers back is 0.35-0.4 s of driver work at process exit (5 M unitigs) --
-    // a third of the whole run.  On request (--detach-teardown, or PF_DETACH_TEARDOWN=1) that work is done by a child process:
+    // a third of the whole run.  On request (--detach-teardown) that work is done by a child process:
     // the parent returns the moment the child reports that the last result file is complete, the child finishes its exit with
     // nobody waiting for it -- and still holds its device memory for those 0.4 s, which a scheduler that starts the next job on
     // the parent's return has to know; hence not the default.  (Forked here, before the first thread and the first device call.)
     int done_fd = -1;
-    if (opt.detach_teardown || (getenv("PF_DETACH_TEARDOWN") && getenv("PF_DETACH_TEARDOWN")[0] == '1')) {
+    if (opt.detach_teardown) {
         int fds[2];
         if (pipe(fds) == 0) {
             cout.flush();

@@ -854,7 +854,7 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     // as long as its slowest bubble (an 8-path bubble: 0.8 ms of dependent steps on one wavefront), and the three tails overlap.
     // Measured with the passes of both settings alternating in one process (tools/ab_pass.py, 5 M unitigs, two align ranges):
     // 28.1 -> 26.0 ms per pass.  PF_BUBBLE_STREAMS=0: one after the other.
-    const bool class_streams = [] { const char *e = getenv("PF_BUBBLE_STREAMS"); return !(e && e[0] == '0'); }();   // (read per call: tools/ab_pass.py)
+    constexpr bool class_streams = true;   // a launch per size class, side by side on streams of their own
     int grids[kBubLdsClasses];
     uint64_t waves_total = 0;
     for (int c = 0; c < kBubLdsClasses; ++c) {

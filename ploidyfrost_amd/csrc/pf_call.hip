@@ -3480,7 +3480,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     // K-PATHS scratch: stacks sized by the complex size (a non-complex bubble has at most that many vertices)
     const uint32_t depth_cap = std::max<uint32_t>(complex_size + 4, 16);
     const uint64_t paths_per_wave = ((256 * 8 + 256 * 4 + (10ull * depth_cap + 4) * 4) + 255) & ~255ull;
-    static const int paths_per_cu = [] { const char *e = getenv("PF_PATHS_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
+    constexpr int paths_per_cu = 16;
     const int paths_grid = ctx->n_cu * paths_per_cu;
     NEED(W.paths_scr, paths_per_wave * paths_grid);
     // bubbles of more than 255 walks in one range: the list grows to what an attempt asked for (advisor, round 3: an overflow used
@@ -3501,10 +3501,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     const int snp_ok = snp_shortcut_scores(match, mismatch, gap) ? 1 : 0;
     // K-PAIR: register-bound (the score row of the fill is 65 / 129 registers): 3 / 2 wavefronts per SIMD, the grid loops over its list
     // (scores of sane magnitude only: the fill adds them in ints)
-    static const bool pair_env = [] { const char *e = getenv("PF_PAIR_TIER"); return !(e && e[0] == '0'); }();  // measurements
-    const bool pair_tier = pair_env && std::fabs(match) < 1e5 && std::fabs(mismatch) < 1e5 && std::fabs(gap) < 1e5;
-    static const bool stack_env = [] { const char *e = getenv("PF_STACK_TIER"); return !(e && e[0] == '0'); }();  // measurements
-    const bool stack_tier = stack_env && stack_scores(match, mismatch, gap);
+    const bool pair_tier = std::fabs(match) < 1e5 && std::fabs(mismatch) < 1e5 && std::fabs(gap) < 1e5;
+    const bool stack_tier = stack_scores(match, mismatch, gap);
     // what K-STACK is given (read per call: tools/ab_pass.py): 1 = bubbles of three and more paths of one length, 2 = also those whose
     // later paths are shorter than the first (one gap run each), 3 = also the two-path bubbles ahead of K-PAIR
     const int stack_level = [] { const char *e = getenv("PF_STACK_LEVEL"); return e ? std::max(1, std::min(3, atoi(e))) : 1; }();
@@ -3563,7 +3561,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         k_call_prep<<<(nb + 255) / 256, 256, 0, st>>>(pa);
         tend(st);
         // K-PATHS (branching bubbles) beside K-SNP and K-PAIR (two-path bubbles): latency-bound walks next to an issue-bound fill
-        static const bool fork_paths = [] { const char *e = getenv("PF_PATHS_STREAM"); return !(e && e[0] == '0'); }();   // measurements
+        constexpr bool fork_paths = true;
         hipStream_t pst = st;
         if (fork_paths) {
             if (!W.side_stream) {
@@ -3586,11 +3584,6 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             ph.walk_pool = S->n_colors ? W.walk_pool.as<uint32_t>() : nullptr; ph.walk_off = W.walk_off.as<uint64_t>(); ph.walk_cap = walk_cap;
             ph.max_paths = MAX_PATHS; ph.n_list = &d_cnt->n_branching; ph.mlist = W.mlist.as<uint32_t>(); ph.mlist_cap = W.mlist_cap;
             ph_keep = ph;
-            if (getenv("PF_TRACE_ALIGN_ARGS"))
-                fprintf(stderr, "[pf_call_align] K-PATHS args: ct %p kept %p blist %p succ %p seq %p off %p len %p scratch %p (%llu per wave, grid %d) n_list %p mlist %p walk_pool %p btask %p bpath %p text %p queues %p klist %p tlist %p tlist4 %p cnt %p depth_cap %u nb %u stack_ok %d trio_ok %d\n",
-                        (const void *)ph.ct, (const void *)ph.kept, (const void *)ph.blist, (const void *)ph.succ, (const void *)ph.seq, (const void *)ph.off, (const void *)ph.len, (void *)ph.scratch,
-                        (unsigned long long)ph.scratch_per_wave, paths_grid, (const void *)ph.n_list, (void *)ph.mlist, (void *)ph.walk_pool, (void *)ph.btask, (void *)ph.bpath, (void *)ph.text, (void *)ph.queues,
-                        (void *)ph.klist, (void *)ph.tlist, (void *)ph.tlist4, (void *)ph.cnt, ph.depth_cap, ph.nb, ph.stack_ok, ph.trio_ok);
             tbegin(PF_K_CALL_PATHS, pst);
             k_call_paths<false><<<paths_grid, 64, 0, pst>>>(ph);
             tend(pst);
@@ -3839,7 +3832,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
     if (hc.n_branching) {
         const uint32_t C = S->n_colors;
         const uint64_t rows_cap = std::max<uint64_t>(256, ((uint64_t)hc.max_rows + 63) & ~63ull);
-        static const int sites_per_cu = [] { const char *e = getenv("PF_SITES_WAVES_PER_CU"); return e ? std::max(1, atoi(e)) : 16; }();   // measurements
+        constexpr int sites_per_cu = 16;
         for (int attempt = 0, ks_attempt = 0;; ++attempt) {
             const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8) + (C ? rows_cap * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
             // (tables for thousands of rows: fewer wavefronts, at most 2 GB of them)
@@ -4035,8 +4028,7 @@ static int text_work_of(pf_ctx *ctx, pf::CallState *S, int which, uint32_t nb) {
         // for milliseconds -- the text has a PCIe copy and a file copy still before it
         int least = 0, greatest = 0;
         PF_HIP(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        static const bool prio = [] { const char *e = getenv("PF_TEXT_PRIORITY"); return !(e && e[0] == '0'); }();   // measurements
-        PF_HIP(hipStreamCreateWithPriority(&T.stream, hipStreamNonBlocking, prio ? greatest : least));
+        PF_HIP(hipStreamCreateWithPriority(&T.stream, hipStreamNonBlocking, greatest));
     }
     NEED_TEXT(T.sizes, (size_t)N_INT * (nb + 1) * 4);
     NEED_TEXT(T.offs, ((size_t)N_INT * (nb + 1) + 1) * 8);

@@ -335,7 +335,7 @@ static int unitig_cov_colored_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64
         dx = (uint8_t *)ctx_ws(ctx, WS_CCOV_MISS, n);
         if (!ds || !dlo || !dhi || !dx) return PF_ERR_HIP;
     }
-    static const bool env_probe = [] { const char *e = getenv("PF_KCOV_COLORED"); return e && !strcmp(e, "probe"); }();  // measurements: A/B of the two forms
+    constexpr bool env_probe = false;
     probe = probe || env_probe;
     if (!probe && !ctx->gcov_c_valid) {  // the graph was replaced under the table
         const int rc = join_graph_counts_colored(ctx);

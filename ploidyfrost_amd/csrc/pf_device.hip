@@ -780,7 +780,7 @@ static size_t launch_push(pf_ctx *ctx, int kernel, hipStream_t stream) {
     }
     // (no system-scope fence when an event completes: a launch's timestamps need none, and the fence of twenty events a pass held the
     // kernels on the other streams up -- K-BUBBLE's launches timed cost the pass 1 ms.  PF_EVENT_FENCE=1: plain events, measurements)
-    static const unsigned ev_flags = [] { const char *e = getenv("PF_EVENT_FENCE"); return (e && e[0] == '1') ? hipEventDefault : hipEventDisableSystemFence; }();
+    constexpr unsigned ev_flags = hipEventDisableSystemFence;   // (a system-scope fence at every event cost a pass 1.5 ms: profiles/r16_experiments.txt)
     if (!tl.a && (hipEventCreateWithFlags(&tl.a, ev_flags) != hipSuccess || hipEventCreateWithFlags(&tl.b, ev_flags) != hipSuccess)) return (size_t)-1;
     hipEventRecord(tl.a, stream);
     tl.closed = false;
@@ -847,8 +847,7 @@ void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes) {
 }
 
 hipError_t lane_stream_create(hipStream_t *s, int lane) {
-    static const bool by_lane = [] { const char *e = getenv("PF_LANE_PRIORITY"); return !(e && e[0] == '0'); }();
-    if (lane == 0 || !by_lane) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
+    if (lane == 0) return hipStreamCreateWithFlags(s, hipStreamNonBlocking);
     int least = 0, greatest = 0;
     const hipError_t e = hipDeviceGetStreamPriorityRange(&least, &greatest);
     if (e != hipSuccess) return e;
@@ -1013,11 +1012,6 @@ int pf_create(int device, pf_ctx **out) {
     }
     if (device < 0 || device >= n) { g_create_err = "device index out of range"; return PF_ERR_ARG; }
     hipDeviceProp_t prop;
-    if (const char *e = getenv("PF_SYNC_MODE")) {   // measurements: how a host thread waits for a stream (s = spin, y = yield, b = block)
-        (void)hipSetDevice(device);
-        (void)hipSetDeviceFlags(e[0] == 's' ? hipDeviceScheduleSpin : e[0] == 'y' ? hipDeviceScheduleYield : hipDeviceScheduleBlockingSync);
-        (void)hipGetLastError();
-    }
     if (hipSetDevice(device) != hipSuccess || hipGetDeviceProperties(&prop, device) != hipSuccess) {
         g_create_err = "hipSetDevice / hipGetDeviceProperties failed";
         return PF_ERR_HIP;
@@ -1724,7 +1718,7 @@ static int bfs_candidates_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, pf_bfs_rec
     uint32_t *d_wlist = (uint32_t *)ctx_ws(ctx, WS_BFS_WLIST, (n + 8) * 4);
     if (!d_wlist) return PF_ERR_HIP;
     unsigned int *d_nwlist = reinterpret_cast<unsigned int *>(small + 48);
-    static const bool thread_tier = [] { const char *e = getenv("PF_BFS_THREAD_TIER"); return !(e && e[0] == '0'); }();  // measurements
+    constexpr bool thread_tier = true;
     // (PF_BFS_WAVE_CAP, read per call: measurements of where the wavefront tier should give up)
     const uint32_t wave_cap = [] { const char *e = getenv("PF_BFS_WAVE_CAP"); return e ? (uint32_t)std::max(16, std::min((int)BFS_LDS_CAP, atoi(e))) : BFS_LDS_CAP; }();
     if (thread_tier) {

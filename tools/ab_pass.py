@@ -2,7 +2,7 @@
 box-to-box and run-to-run spread (a few ms on a 30 ms pass: host threads, page placement) cancels out.
   python tools/ab_pass.py [--unitigs N] [--rounds R] "NAME=VALUE ..." "NAME=VALUE ..." [...]
 Each argument is one configuration: a space-separated list of environment settings the library reads per pass
-(PF_ALIGN_RANGES, PF_ALIGN_FIRST, PF_BUBBLE_STREAMS), or BATCH=n for Run.set_batch_bubbles(n); "-" is the default configuration.  Prints per configuration the median,
+(PF_ALIGN_RANGES, PF_ALIGN_THREADS, PF_BATCH_BUBBLES: the knobs that are left -- INTEGRATION.md lists them), or BATCH=n for Run.set_batch_bubbles(n); "-" is the default configuration.  Prints per configuration the median,
 the minimum and the mean pass time over the rounds."""
 import argparse
 import os
