@@ -207,13 +207,19 @@ def pair_ids(n_kmers: int, full_colors, partial: dict | None = None) -> list[int
 
 def write_bfg_colors(path: str, heads: np.ndarray, sizes_bp: np.ndarray, k: int, names: list[str], sets: list[bytes] | None = None, *,
                      full_mask: np.ndarray | None = None, partial_ids: dict | None = None, nb_seeds: int = 31, seed: int = 12345, overflow_every: int = 0,
-                     slack: float = 1.0) -> np.ndarray:
+                     slack: float = 1.0, shared_sets: list[tuple[bytes, int]] | None = None, shared_refs: set | None = None) -> np.ndarray:
     """Write the colour file of a graph whose unitig u has head k-mer ``heads[u]`` (Bifrost layout, see
     ``left_align``) and ``sizes_bp[u]`` bases.  Colour sets come either encoded (``sets[u]`` from ``encode_set``) or, for
     large graphs, as ``full_mask[u]`` (bit c = colour c on every k-mer; encoded with the natural encoding) plus
     ``partial_ids[u]`` = the complete sorted id list of the few unitigs that carry a colour on part of their k-mers.
+    ``shared_sets``: (encoded set, reference count) pairs written as the file's SharedUnitigColors section
+    (DataStorage.tcc:619-627, 747-755: between the link bits and the colour sets; block positions for them come first);
+    ``shared_refs``: unitigs whose colour set is written the way UnitigColors::write writes a reference to a shared set -- the flag
+    word 0x5 alone (ColorSet.cpp:1190-1194: which set it referred to is not in the file).
     Returns the ``DA:Z:`` tag of every unitig (0 = overflow table) for the GFA segment lines."""
     n = len(heads)
+    shared_sets = shared_sets or []
+    shared_refs = shared_refs or set()
     heads = heads.astype(np.uint64)
     sizes_bp = np.asarray(sizes_bp, dtype=np.uint64)
     rng = np.random.default_rng(seed)
@@ -265,9 +271,10 @@ def write_bfg_colors(path: str, heads: np.ndarray, sizes_bp: np.ndarray, k: int,
             return b
     empty = _enc_bitvector([])
     block_sz = 1024
-    n_pos = sz_cs // block_sz + (sz_cs % block_sz != 0)
+    n_shared = len(shared_sets)
+    n_pos = (n_shared // block_sz + (n_shared % block_sz != 0)) + (sz_cs // block_sz + (sz_cs % block_sz != 0))
     with open(path, "wb") as f:
-        f.write(struct.pack("<7Q", 2, nb_seeds, C, nb_cs, sz_cs, 0, len(over)))
+        f.write(struct.pack("<7Q", 2, nb_seeds, C, nb_cs, sz_cs, n_shared, len(over)))
         f.write(seeds.tobytes())
         f.write(struct.pack("<Q", block_sz))
         pos_at = f.tell()
@@ -281,11 +288,17 @@ def write_bfg_colors(path: str, heads: np.ndarray, sizes_bp: np.ndarray, k: int,
         positions = []
         buf = []
         at = f.tell()
+        for i, (enc, refs) in enumerate(shared_sets):
+            if i % block_sz == 0:
+                positions.append(at)
+            b = enc + struct.pack("<Q", refs)
+            buf.append(b)
+            at += len(b)
         for i in range(sz_cs):
             if i % block_sz == 0:
                 positions.append(at)
             u = owner[i]
-            b = empty if u < 0 else (sets[u] if sets is not None else natural(u))
+            b = empty if u < 0 else struct.pack("<Q", 5) if u in shared_refs else (sets[u] if sets is not None else natural(u))
             buf.append(b)
             at += len(b)
             if len(buf) >= 65536:

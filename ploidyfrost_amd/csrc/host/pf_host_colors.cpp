@@ -188,8 +188,12 @@ bool decode_set(Reader &r, std::vector<Run> *runs, Decoded *top, int depth, std:
             if (!decode_set(r, top ? &top->full : nullptr, nullptr, depth + 1, err)) return false;
             return decode_set(r, runs, nullptr, depth + 1, err);
         case 0x5:
-            err = "shared colour sets are not supported (Bifrost 1.0.6 does not write them)";
-            return false;
+            // A reference to a shared colour set is written as this flag word alone (UnitigColors::write, ColorSet.cpp:1190-1194:
+            // `copy_UnitigColors` is false in DataStorage::write) and UnitigColors::read has no case for it (:1228-1283): the file
+            // does not say WHICH shared set, the reference is left with flag 5 on a null pointer and dies at the unitig's first
+            // colour query.  Skipped over like the reference does; an error once a unitig's colours are asked of it.
+            if (runs || top) { err = "colour set is a reference to a shared colour set, which the file format does not resolve (the reference's reader leaves a null pointer there: ColorSet.cpp:1190-1194, 1228-1283)"; return false; }
+            return true;
         default:
             err = "unknown colour set encoding";
             return false;
@@ -240,15 +244,15 @@ bool ColorSets::load(const std::string &path, const UnitigSet &g, unsigned threa
     if (format_version != 1 && format_version != 2) { err = "unsupported colour file format version"; return false; }
     if (nb_seeds >= 256) { err = "DataStorage::read(): Does not support more than 255 hash seeds"; return false; }
     if (nb_colors == 0 || nb_colors > kMaxColors) { err = "number of colours outside 1.." + std::to_string(kMaxColors); return false; }
-    if (sz_shared_cs != 0) { err = "shared colour sets are not supported (Bifrost 1.0.6 does not write them)"; return false; }
-    if (nb_cs > sz_cs || sz_cs > buf.size()) { err = "colour file header damaged"; return false; }
+    if (nb_cs > sz_cs || sz_cs > buf.size() || sz_shared_cs > buf.size()) { err = "colour file header damaged"; return false; }
     std::vector<uint64_t> seeds(nb_seeds);
     for (auto &s : seeds) s = r.get<uint64_t>();
     if (format_version == 2) {
         const uint64_t block_sz = r.get<uint64_t>();
         if (!r.ok || block_sz == 0) { err = "colour file header damaged"; return false; }
-        const uint64_t n_pos = (sz_cs / block_sz) + ((sz_cs % block_sz) != 0);
-        r.take((size_t)n_pos * 16);  // std::streampos of every block, only used by the reference's threaded reader
+        // std::streampos of every block of shared sets, then of colour sets (DataStorage.tcc:887-897): only used by the reference's threaded reader
+        const uint64_t n_pos = (sz_shared_cs / block_sz) + ((sz_shared_cs % block_sz) != 0) + (sz_cs / block_sz) + ((sz_cs % block_sz) != 0);
+        r.take((size_t)n_pos * 16);
     }
     n_colors = (uint32_t)nb_colors;
     names.clear();
@@ -260,6 +264,12 @@ bool ColorSets::load(const std::string &path, const UnitigSet &g, unsigned threa
     }
     r.take((size_t)((sz_cs >> 6) + ((sz_cs & 0x3F) != 0)) * 8);  // unitig_cs_link occupancy bits
     if (!r.ok) { err = "colour file truncated before the colour sets"; return false; }
+    // the shared colour sets, each with its reference count (DataStorage.tcc:811-820): read and, like in the reference, linked to nothing
+    for (uint64_t i = 0; i < sz_shared_cs; ++i) {
+        if (!decode_set(r, nullptr, nullptr, 0, err)) { err += " (shared colour set " + std::to_string(i) + ")"; return false; }
+        (void)r.get<uint64_t>();
+        if (!r.ok) { err = "shared colour sets truncated"; return false; }
+    }
     // offsets of the sz_cs colour sets (variable length)
     std::vector<const uint8_t *> at(sz_cs);
     for (uint64_t i = 0; i < sz_cs; ++i) {

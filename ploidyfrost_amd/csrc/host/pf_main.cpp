@@ -464,10 +464,13 @@ int main(int argc, char **argv) {
         die();
     }
     if (ranks.world > 1) {   // a rank without its graph or table says so to the others before they wait for it in the communicator
-        if (!g.good()) cerr << "rank " << ranks.rank << ": " << g.error() << endl;
+        auto say0 = [&](const std::string &what) {   // (one write per line: the ranks share the terminal)
+            const std::string line = "rank " + std::to_string(ranks.rank) + ": " + what + "\n";
+            if (write(2, line.data(), line.size()) < 0) {}
+        };
+        if (!g.good()) say0(g.error());
         if (!ranks.agree(g.good(), "load")) {
-            if (g.good()) cerr << "rank " << ranks.rank << ": " << ranks.err << endl;
-            cerr.flush();
+            if (g.good()) say0(ranks.err);
             if (ranks.rank == 0) (void)ranks.finish();
             _exit(EXIT_FAILURE);
         }
@@ -486,14 +489,18 @@ int main(int argc, char **argv) {
         // ---- one graph over the GPUs of the node (the protocol of ploidyfrost_amd/dist.py from the C++ side) ----
         // every step that ends in a collective: the rank's own outcome first, then whether everybody is still there (pf_multi.hpp,
         // RankGroup::agree) -- a rank that failed alone must not leave the others waiting in RCCL
+        // (one write per line: the ranks share the terminal)
+        auto say = [&](const std::string &what) {
+            const std::string line = "rank " + std::to_string(ranks.rank) + ": " + what + "\n";
+            if (write(2, line.data(), line.size()) < 0) {}
+        };
         auto leave = [&](const std::string &why) {
-            cerr << "rank " << ranks.rank << ": " << why << endl;
-            cerr.flush();
+            say(why);
             if (ranks.rank == 0) (void)ranks.finish();
             _exit(EXIT_FAILURE);
         };
         auto together = [&](bool failed, const std::string &why, const char *stage) {
-            if (failed) cerr << "rank " << ranks.rank << ": " << why << endl;
+            if (failed) say(why);
             if (!ranks.agree(!failed, stage)) leave(failed ? std::string("leaving") : ranks.err);
         };
         if (!ranks.connect(g.device())) leave("--gpus: " + ranks.err);

@@ -168,15 +168,21 @@ __device__ inline bool count_find(const CountLine *__restrict__ t, uint64_t mask
     }
 }
 
-// the place of a key's count, claiming the first free slot of its probe sequence (K-TABLE)
+// the place of a key's count, claiming the first free slot of its probe sequence (K-TABLE).  The ten keys of a line are read at
+// once (ten independent loads that bypass the XCD's L2, which is not coherent with the other XCDs' atomics): what they show as taken
+// stays taken, what they show as free is claimed by compare-and-swap, which tells when another insert was quicker.
 __device__ inline uint32_t *count_claim(CountLine *t, uint64_t mask, uint64_t key, const LineSeq &sq) {
     uint64_t line = 0;
     for (int i = 0;; ++i) {
         line = i < LINE_TRIES ? seq_line(sq, i, mask) : i == LINE_TRIES ? (mix64(key) & mask) : ((line + 1) & mask);
+        unsigned long long seen[LINE_KEYS];
+#pragma unroll
+        for (int s = 0; s < LINE_KEYS; ++s)
+            seen[s] = __hip_atomic_load(reinterpret_cast<unsigned long long *>(&t[line].key[s]), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
         for (int s = 0; s < LINE_KEYS; ++s) {
-            unsigned long long *slot = reinterpret_cast<unsigned long long *>(&t[line].key[s]);
-            unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(slot);
-            if (old == EMPTY_KEY) old = atomicCAS(slot, EMPTY_KEY, key);
+            unsigned long long old = seen[s];
+            if (old == EMPTY_KEY) old = atomicCAS(reinterpret_cast<unsigned long long *>(&t[line].key[s]), EMPTY_KEY, key);
             if (old == EMPTY_KEY || old == key) return &t[line].val[s];
         }
     }

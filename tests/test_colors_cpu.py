@@ -54,8 +54,10 @@ def test_missing_colour_file_is_an_error(tmp_path):
 
 
 # ---- every encoding UnitigColors::write has, through this repository's writer ---------------------------
-def _synthetic_colored_graph(tmp_path, k=25, n_colors=5, seed=3):
-    """Isolated random unitigs of many lengths with assorted colour patterns, one encoding each."""
+def _synthetic_colored_graph(tmp_path, k=25, n_colors=5, seed=3, shared=False, shared_refs=None):
+    """Isolated random unitigs of many lengths with assorted colour patterns, one encoding each.  shared: the file also holds a
+    SharedUnitigColors section (three sets of different encodings, with reference counts); shared_refs: unitigs written as
+    references to a shared set (the flag word 0x5 alone)."""
     from ploidyfrost_amd import bfg_colors, synth
     rng = np.random.default_rng(seed)
     lengths = [k] * 6 + [k + 1, k + 5, 40, 60, 100, 133, 700, 3000, 3001, 9000, 30000] * 2 + [k] * 3
@@ -91,8 +93,13 @@ def _synthetic_colored_graph(tmp_path, k=25, n_colors=5, seed=3):
     heads = bfg_colors.left_align(np.array(heads, dtype=np.uint64), k)
     sizes = np.array([len(s) for s in seqs])
     colors = str(tmp_path / "g.bfg_colors")
+    extra = {}
+    if shared:
+        extra["shared_sets"] = [(bfg_colors.encode_set([0, 3, 4], "bitvector"), 2), (bfg_colors.encode_set(list(range(0, 4000, 3)), "roaring_array"), 1),
+                                (bfg_colors.encode_set([7], "single"), 0)]
+        extra["shared_refs"] = set(shared_refs or ())
     da = bfg_colors.write_bfg_colors(colors, heads, sizes, k, ["c%d" % i for i in range(n_colors)], sets, overflow_every=7,
-                                     slack=0.8)
+                                     slack=0.8, **extra)
     gfa = str(tmp_path / "g.gfa")
     with open(gfa, "wb") as f:
         f.write(b"H\tVN:Z:1.0\tBV:Z:1.0.6\tKL:Z:%d\tML:Z:17\n" % k)
@@ -112,6 +119,43 @@ def test_reader_understands_every_encoding(tmp_path):
         assert size == int(pres.sum())
         km = pres.shape[1]
         assert n_full == (int((pres.sum(axis=1) == km).sum()) if encs[u] == "pair" else 0)
+
+
+def test_shared_colour_sets_are_read_like_the_reference_reads_them(tmp_path):
+    """A file with a SharedUnitigColors section (sz_shared_cs > 0; DataStorage.tcc:811-820, 832-917): the shared sets are parsed and,
+    as in the reference, linked to nothing -- every unitig's colours are what they are without the section.  A unitig whose own set
+    is a REFERENCE to a shared set (flag 5) has no colours anybody could tell: UnitigColors::write stores the flag alone and
+    UnitigColors::read has no case for it (ColorSet.cpp:1190-1194, 1228-1283) -- an error that says so, where the reference
+    dereferences a null pointer."""
+    gfa, colors, want, encs = _synthetic_colored_graph(tmp_path, shared=True)
+    c = hostapi.Colors(gfa, colors, 2)
+    assert c.n == len(want)
+    for u, pres in enumerate(want):
+        got, size, n_full = c.unitig(u)
+        assert np.array_equal(got, pres), "unitig %d (%s)" % (u + 1, encs[u])
+        assert size == int(pres.sum())
+    sub = tmp_path / "refs"
+    sub.mkdir()
+    gfa2, colors2, _, _ = _synthetic_colored_graph(sub, shared=True, shared_refs=[4])
+    with pytest.raises(RuntimeError, match="reference to a shared colour set"):
+        hostapi.Colors(gfa2, colors2, 2)
+    # the real Bifrost (where built) reads the first file the same way
+    import subprocess
+    import sys
+    from conftest import ROOT
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle
+    if os.path.exists(pyoracle.REF_COLORS_DUMP):
+        dump = tmp_path / "dump.txt"
+        with open(dump, "w") as f:
+            subprocess.run([pyoracle.REF_COLORS_DUMP, gfa, colors], check=True, stdout=f)
+        _, _, rows = read_dump(str(dump))
+        assert len(rows) == len(want)
+        for u, (km, size, n_full, bits) in enumerate(rows):
+            assert np.array_equal(bits, want[u]) and size == int(want[u].sum()), "unitig %d (%s)" % (u + 1, encs[u])
+        # ... and does not survive the file with a reference
+        r = subprocess.run([pyoracle.REF_COLORS_DUMP, gfa2, colors2], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        assert r.returncode != 0
 
 
 def test_writer_is_read_the_same_way_by_the_real_bifrost(tmp_path):
