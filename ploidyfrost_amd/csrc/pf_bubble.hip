@@ -855,27 +855,43 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     // Measured with the passes of both settings alternating in one process (tools/ab_pass.py, 5 M unitigs, two align ranges):
     // 28.1 -> 26.0 ms per pass.  PF_BUBBLE_STREAMS=0: one after the other.
     constexpr bool class_streams = true;   // a launch per size class, side by side on streams of their own
+    // Every wavefront has its slice of the scratch (0.5 MB) and loops over its class's queue; bubble_reserve took scratch for 24
+    // wavefronts a CU beside the load.  How the classes share them: the device runs the kernels of at most three or four streams of a
+    // process at a time (its hardware queues; measured at configs[4]'s parameters: of seven class launches on seven streams three ran,
+    // the fourth began when the first had ended -- with grids sized as if all seven ran together the device held ten wavefronts a CU
+    // where it could hold twenty-four).  So the class launches go on THREE streams ("trains"), each class on the train that has the
+    // least work so far (work = bubbles x the class's bytes: a bubble's time grows with its matrix -- 13 k ticks in the 6 KB class, 165 k
+    // in the 64 KB one), heaviest class first; a launch gets a third of the wavefronts (never more than it has bubbles, or than its LDS
+    // lets a CU hold) and the launches of a train, one after the other, use the same third of the scratch.
+    // (measured, passes of 17.3 ms / 17.9 ms at configs[4]'s parameters, 1 M unitigs / configs[2]: one train 23.5 / 19.4, two 18.8 / 19.0,
+    // four 22.3 / 17.9: profiles/r5_experiments.txt)
+    constexpr int kTrains = 3;
     int grids[kBubLdsClasses];
-    uint64_t waves_total = 0;
-    for (int c = 0; c < kBubLdsClasses; ++c) {
-        grids[c] = L.n_cls[c] ? (int)std::min<uint32_t>(L.n_cls[c], (uint32_t)(ctx->n_cu * bubble_class_waves_per_cu(c))) : 0;
-        waves_total += (uint64_t)grids[c];
-    }
-    // The class launches run side by side and every wavefront has its slice of the scratch (0.5 MB): all classes populated, their
-    // grids add up to 22 k wavefronts = 11 GB, and taking that -- 173 ms for 5.6 GB at configs[4]'s parameters -- was most of a one-shot
-    // PloidyEstimation there.  The device holds 24-32 wavefronts a CU whatever their class, and every wavefront loops over its
-    // class's queue: the grids are scaled down together to the 24 a CU that bubble_reserve took beside the load.
+    int train_of[kBubLdsClasses];
+    int order[kBubLdsClasses];
+    int n_order = 0;
     const uint64_t wave_budget = (uint64_t)ctx->n_cu * 24;
-    if (class_streams && waves_total > wave_budget) {
-        uint64_t sum = 0;
+    const uint64_t train_waves = wave_budget / kTrains;
+    {
+        double load[kTrains] = {0, 0, 0};
         for (int c = 0; c < kBubLdsClasses; ++c) {
-            if (!grids[c]) continue;
-            grids[c] = (int)std::max<uint64_t>(1, (uint64_t)grids[c] * wave_budget / waves_total);
-            sum += (uint64_t)grids[c];
+            grids[c] = 0;
+            train_of[c] = 0;
+            if (L.n_cls[c]) order[n_order++] = c;
         }
-        waves_total = sum;
+        auto work_of = [&](int c) { return (double)L.n_cls[c] * (double)kBubClassBytes[c]; };
+        std::sort(order, order + n_order, [&](int x, int y) { return work_of(x) > work_of(y) || (work_of(x) == work_of(y) && x > y); });
+        for (int i = 0; i < n_order; ++i) {
+            const int c = order[i];
+            int tr = 0;
+            for (int q = 1; q < kTrains; ++q)
+                if (load[q] < load[tr]) tr = q;
+            train_of[c] = tr;
+            load[tr] += work_of(c);
+            grids[c] = (int)std::min<uint64_t>(std::min<uint64_t>(L.n_cls[c], (uint64_t)ctx->n_cu * bubble_class_waves_per_cu(c)), class_streams ? train_waves : wave_budget);
+        }
     }
-    const uint64_t max_waves = class_streams ? std::max<uint64_t>(waves_total, wave_budget) : wave_budget;
+    const uint64_t max_waves = wave_budget;
     p.caps = std_caps;
     p.scratch_per_wave = (bub_scratch_bytes(std_caps) + 255) & ~255ull;
     const bool trace_ws = getenv("PF_TRACE_ALIGN") != nullptr;
@@ -900,12 +916,12 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     }
     { const int e = bubble_func_attr(ctx); if (e != PF_OK) return e; }
     uint32_t idx_off = 0;
-    uint64_t wave_off = 0;
+    for (int c = 0; c < kBubLdsClasses; ++c) idx_off += L.n_cls[c];   // (the global-memory class's queue lies behind the LDS classes')
     if (class_streams) PF_HIP(hipEventRecord(ctx->bub_events[lane][kBubLdsClasses], st));
-    // largest class first: its tail is the longest
-    for (int c = kBubLdsClasses - 1; c >= 0; --c) {
+    bool train_used[kTrains] = {false, false, false};
+    for (int i = 0; i < n_order; ++i) {   // heaviest class first: its tail is the longest
+        const int c = order[i];
         const uint32_t nc = L.n_cls[c];
-        if (nc == 0) continue;
         uint32_t first = 0;   // (the queues lie class after class in L.idx)
         for (int q = 0; q < c; ++q) first += L.n_cls[q];
         p.idx = L.idx + first;
@@ -915,21 +931,23 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         p.next = queue_heads + n_launch++;
         hipStream_t cst = st;
         if (class_streams) {
-            cst = ctx->bub_streams[lane][c];
-            PF_HIP(hipStreamWaitEvent(cst, ctx->bub_events[lane][kBubLdsClasses], 0));
-            p.scratch = scratch0 + wave_off * p.scratch_per_wave;
-            wave_off += (uint64_t)grid;
+            const int tr = train_of[c];
+            cst = ctx->bub_streams[lane][tr];
+            if (!train_used[tr]) PF_HIP(hipStreamWaitEvent(cst, ctx->bub_events[lane][kBubLdsClasses], 0));
+            train_used[tr] = true;
+            p.scratch = scratch0 + (uint64_t)tr * train_waves * p.scratch_per_wave;
         }
         tbegin(PF_K_BUBBLE, cst);
         k_bubble<true><<<grid, 64, kBubClassBytes[c], cst>>>(p, o);
         tend(cst);
         ctx_units(ctx, PF_K_BUBBLE, nc);
-        if (class_streams) {
-            PF_HIP(hipEventRecord(ctx->bub_events[lane][c], cst));
-            PF_HIP(hipStreamWaitEvent(st, ctx->bub_events[lane][c], 0));
-        }
-        idx_off += nc;
     }
+    if (class_streams)
+        for (int tr = 0; tr < kTrains; ++tr) {
+            if (!train_used[tr]) continue;
+            PF_HIP(hipEventRecord(ctx->bub_events[lane][tr], ctx->bub_streams[lane][tr]));
+            PF_HIP(hipStreamWaitEvent(st, ctx->bub_events[lane][tr], 0));
+        }
     p.scratch = scratch0;
     if (L.n_cls[kBubLdsClasses]) {
         const uint32_t nc = L.n_cls[kBubLdsClasses];
@@ -996,6 +1014,22 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
         fprintf(stderr, "[pf_align_bubbles] ticks by phase: fill %llu traceback %llu | decode %llu round0(incl. NW) %llu rounds %llu choose %llu publish %llu\n",
                 clk[n_tasks], clk[n_tasks + 1], clk[n_tasks + 2], clk[n_tasks + 3], clk[n_tasks + 4], clk[n_tasks + 5], clk[n_tasks + 6]);
         clk.resize(n_tasks);
+        {   // per size class: bubbles, wavefronts of its launch, ticks, and the longest bubble -- ticks / wavefronts is what the launch takes at best
+            uint32_t tot_q = 0;
+            for (int c = 0; c <= kBubLdsClasses; ++c) tot_q += L.n_cls[c];
+            std::vector<uint32_t> hq(tot_q);
+            if (tot_q) PF_HIP(hipMemcpy(hq.data(), L.idx, (size_t)tot_q * 4, hipMemcpyDeviceToHost));
+            uint32_t at = 0;
+            for (int c = 0; c <= kBubLdsClasses; ++c) {
+                unsigned long long sum = 0, mx = 0;
+                for (uint32_t q = 0; q < L.n_cls[c]; ++q) { const unsigned long long t = hq[at + q] < n_tasks ? clk[hq[at + q]] : 0; sum += t; mx = std::max(mx, t); }
+                at += L.n_cls[c];
+                if (L.n_cls[c])
+                    fprintf(stderr, "   class %d (%s): %u bubbles on %d wavefronts, %llu ticks (%.2f ms if spread evenly), longest %llu ticks\n", c,
+                            c == kBubLdsClasses ? "global" : "LDS", L.n_cls[c], c < kBubLdsClasses ? grids[c] : 0, sum,
+                            c < kBubLdsClasses && grids[c] ? (double)sum / grids[c] * 1e-5 : 0.0, mx);
+            }
+        }
         std::vector<unsigned long long> srt(clk);
         std::sort(srt.begin(), srt.end());
         unsigned long long tot = 0;
