@@ -471,7 +471,9 @@ def main():
         # where load_s went: the host layer's own steps (pfh_load_trace; steps of helper threads overlap the caller's, so the sum can
         # exceed the wall time) + the unitig id file
         load_breakdown = {"open_wall_s": round(open_s, 3), "unitig_id_file_and_settings_s": round(load_s - open_s, 3),
-                          "steps_s": {name: round(sec, 4) for name, sec in hostapi.load_trace(reset=True)}}
+                          "steps_s": {}}
+        for name_, sec_ in hostapi.load_trace(reset=True):   # (a step name that comes more than once -- a database per colour -- adds up)
+            load_breakdown["steps_s"][name_] = round(load_breakdown["steps_s"].get(name_, 0.0) + sec_, 4)
         log("rank %d: load+upload+adjacency+table %.1fs on %s" % (rank, load_s, torch.cuda.get_device_name(gpu_index)))
         L = hipapi.load_library()
         import ctypes as C

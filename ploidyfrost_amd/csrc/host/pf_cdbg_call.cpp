@@ -442,8 +442,8 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                     packed.entry(g1, t1_, r1_);
                     if (t1_ > d.res.text_len[PF_OUT_ALIGNSEQ] || t0_ > t1_ || r0_ > r1_ ||
                         (uint64_t)(packed.records - packed.base) + r1_ > d.res.alignseq_packed_len) { bad = 1; return; }
-                    char *end = pf::alnpack_expand(packed.records + r0_, packed.records + r1_, packed_dst + t0_);
-                    if (end != packed_dst + t1_) bad = 1;
+                    char *end = pf::alnpack_expand(packed.records + r0_, packed.records + r1_, packed_dst + t0_, packed_dst + t1_);
+                    if (end != packed_dst + t1_) bad = 1;   // (nullptr: a record outside its group's bytes, or rows beyond the group's text)
                 });
                 if (bad) files[PF_OUT_ALIGNSEQ].rc = 1;
                 if (!packed_tmp.empty() && maps[PF_OUT_ALIGNSEQ].write(files[PF_OUT_ALIGNSEQ].bytes, packed_tmp.data(), packed_tmp.size(), T)) files[PF_OUT_ALIGNSEQ].rc = 1;

@@ -78,11 +78,14 @@ struct AlnPackPiece {
     }
 };
 
-// the text of the records in [rec, rec_end) to dst; returns the end of what was written
-inline char *alnpack_expand(const uint8_t *rec, const uint8_t *rec_end, char *dst) {
+// the text of the records in [rec, rec_end) to [dst, dst_end); returns the end of what was written, or nullptr when a record does not
+// lie inside [rec, rec_end) or its rows would cross dst_end (a damaged record must not write over the bytes of other pieces or ranks
+// in the mapped result file: nothing beyond the row before the damage is written)
+inline char *alnpack_expand(const uint8_t *rec, const uint8_t *rec_end, char *dst, const char *dst_end) {
     const AlnPackTables &T = alnpack_tables();
     char prefix[96];
     while (rec < rec_end) {
+        if ((size_t)(rec_end - rec) < ALNPACK_HEADER) return nullptr;
         uint64_t vc;
         uint32_t ent, ext, L, R;
         memcpy(&vc, rec, 8);
@@ -101,6 +104,7 @@ inline char *alnpack_expand(const uint8_t *rec, const uint8_t *rec_end, char *ds
         *q++ = '\t';
         const size_t np = (size_t)(q - prefix);
         const uint32_t rb = alnpack_row_bytes(L);
+        if ((uint64_t)R * rb > (uint64_t)(rec_end - rec) || (uint64_t)R * (np + L + 1) > (uint64_t)(dst_end - dst)) return nullptr;
         for (uint32_t r = 0; r < R; ++r, rec += rb) {
             memcpy(dst, prefix, np);
             dst += np;

@@ -56,10 +56,21 @@ int main() {
             uint64_t t0, r0, t1, r1;
             p.entry(g, t0, r0);
             p.entry(g + 1, t1, r1);
-            char *end = pf::alnpack_expand(p.records + r0, p.records + r1, &got[0] + t0);
+            char *end = pf::alnpack_expand(p.records + r0, p.records + r1, &got[0] + t0, &got[0] + t1);
             if (end != &got[0] + t1) { printf("group %llu ends at %lld, not %llu\n", (unsigned long long)g, (long long)(end - &got[0]), (unsigned long long)t1); return 1; }
         }
         if (got != text) { printf("text differs in trial %d\n", trial); return 1; }
+        // a destination one byte short, and records cut one byte short: refused before anything is written beyond the bounds
+        if (n_groups) {
+            uint64_t t0, r0, t1, r1;
+            p.entry(0, t0, r0);
+            p.entry(1, t1, r1);
+            if (t1 > t0 && r1 > r0) {
+                std::string small(t1 - t0, '?');
+                if (pf::alnpack_expand(p.records + r0, p.records + r1, &small[0], &small[0] + small.size() - 1) != nullptr) { printf("short destination accepted\n"); return 1; }
+                if (pf::alnpack_expand(p.records + r0, p.records + r1 - 1, &small[0], &small[0] + small.size()) != nullptr) { printf("cut records accepted\n"); return 1; }
+            }
+        }
     }
     printf("ok\n");
     return 0;

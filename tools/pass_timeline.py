@@ -14,7 +14,11 @@ for f in glob.glob(os.path.join(src, "**", "*_kernel_trace.csv"), recursive=True
     with open(f) as fh:
         rows += list(csv.DictReader(fh))
 ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in rows))
-starts = [i for i, e in enumerate(ev) if "k_bfs_thread" in e[2]]
+finds = [i for i, e in enumerate(ev) if "k_bfs_thread" in e[2]]
+starts = []
+for f in finds:   # a step opens with its K-COV-JOIN launch when bench.py repeats the join (round 5), else with K-BFS
+    j = [i for i in range(max(0, f - 40), f) if "k_cov_join<" in ev[i][2]]
+    starts.append(j[-1] if j else f)
 if len(starts) < 2:
     raise SystemExit("fewer than two passes in the trace")
 a, b = starts[-2], starts[-1]

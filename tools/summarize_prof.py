@@ -74,7 +74,17 @@ def device_busy(src, out_prefix, steps):
             for r in csv.DictReader(fh):
                 rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]))
     rows.sort()
-    starts = [a for a, b, n in rows if "k_bfs_thread" in n]   # one per findSuperBubble = one per pass
+    # one per step: the K-COV-JOIN launch that opens it (bench.py's steps since round 5), else the K-BFS launch that opens findSuperBubble
+    starts = [a for a, b, n in rows if "k_cov_join<" in n] or [a for a, b, n in rows if "k_bfs_thread" in n]
+    n_find = len([1 for a, b, n in rows if "k_bfs_thread" in n])
+    if len(starts) > n_find:   # (the join also runs at load and in the look-up comparison: keep the ones that a findSuperBubble follows)
+        finds = sorted(a for a, b, n in rows if "k_bfs_thread" in n)
+        keep = []
+        for f in finds:
+            before = [x for x in starts if x <= f]
+            if before and (not keep or before[-1] != keep[-1]):
+                keep.append(before[-1])
+        starts = keep
     if len(starts) < steps + 1:
         print("fewer passes in the trace than steps: no busy figure")
         return
