@@ -168,7 +168,6 @@ int ctx_begin_at(pf_ctx *ctx, int kernel, hipStream_t stream, size_t *at);
 void ctx_end_at(pf_ctx *ctx, size_t at, hipStream_t stream);
 inline void ctx_units(pf_ctx *ctx, int kernel, uint64_t n) { if (ctx->timing) __atomic_fetch_add(&ctx->units[kernel], n, __ATOMIC_RELAXED); }
 int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
-int upload_graph_impl(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp, uint32_t N, int k, bool adopt);   // pf_device.hip
 int join_graph_counts(pf_ctx *ctx);
 int join_graph_counts_begin(pf_ctx *ctx);   // pf_device.hip: the kernels on a stream of their own; join_finish() before d_gcov is read
 int join_finish(pf_ctx *ctx);

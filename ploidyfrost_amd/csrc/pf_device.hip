@@ -9,7 +9,6 @@
 #include <hipcub/hipcub.hpp>
 
 #include <algorithm>
-#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <string>
@@ -344,10 +343,12 @@ __global__ __launch_bounds__(256) void k_cov(const CountLine *__restrict__ t, ui
 // i - 3 and stores row i - 4, each stage consuming what the iteration before issued: five rows in flight per wavefront, the loads
 // retired in the order they were issued.
 // A key that is not in the first line of its sequence (one in six: the line was full) would stall that pipeline for the three
-// further loads of its buddy line: the lane writes its k-mer's index (4 bytes) to its wavefront's slice of `rest` instead, and
+// further loads of its buddy line: the lane writes (k-mer index, k-mer) to its wavefront's slice of `rest` instead, and
 // k_cov_join_rest looks those up afterwards (a slice that is full -- four k-mers in ten of the wavefront's rows missed their first
 // line: a stretch of repeats -- makes k_cov_join_rest look all of those rows up again).
-typedef uint32_t JoinRest;   // the index of a graph k-mer (graphs of 2^32 k-mers and more are joined by k_cov)
+struct JoinRest {
+    uint64_t g, fwd;
+};
 template <int K>
 __global__ __launch_bounds__(256) void k_cov_join(const CountLine *__restrict__ t, uint64_t mask, int k_rt, const uint64_t *__restrict__ seq,
                                                   const uint64_t *__restrict__ off, const uint64_t *__restrict__ kpre,
@@ -370,8 +371,8 @@ __global__ __launch_bounds__(256) void k_cov_join(const CountLine *__restrict__ 
     uint64_t s1_hd = 0;  uint32_t s1_kr = 0;
     uint64_t s2_pre = 0, s2_wo = 0;
     uint64_t s3_w0 = 0, s3_w1 = 0;  int s3_s = 0;
-    LineKeys s4_keys;  uint64_t s4_first = 0, s4_line = 0;
-    uint32_t s5_val = 0;  bool s5_miss = false;
+    LineKeys s4_keys;  uint64_t s4_first = 0, s4_fwd = 0, s4_line = 0;
+    uint32_t s5_val = 0;  bool s5_miss = false;  uint64_t s5_fwd = 0;
 #pragma unroll
     for (int i = 0; i < LINE_KEYS / 2; ++i) s4_keys.q[i] = make_uint4(0, 0, 0, 0);
     if (n_it == 0) {
@@ -395,7 +396,7 @@ __global__ __launch_bounds__(256) void k_cov_join(const CountLine *__restrict__ 
             const bool miss = s5_miss && it >= 4 && g < n_kmers;
             const uint64_t mm = __ballot(miss);
             const uint32_t at = n_rest + (uint32_t)__popcll(mm & ((1ull << lane) - 1));
-            my_rest[miss && at < rest_cap ? at : rest_cap] = (JoinRest)g;   // slot rest_cap of a slice: nobody reads it
+            my_rest[miss && at < rest_cap ? at : rest_cap] = JoinRest{g, s5_fwd};   // slot rest_cap of a slice: nobody reads it
             n_rest += (uint32_t)__popcll(mm);
             gcov[g] = s5_miss ? GCOV_MISSING : s5_val;   // (a row's padding lanes included: gcov holds whole rows)
         }
@@ -404,6 +405,7 @@ __global__ __launch_bounds__(256) void k_cov_join(const CountLine *__restrict__ 
             bool open;
             const int at = line_slot(s4_keys, s4_first, open);
             s5_miss = at < 0;
+            s5_fwd = s4_fwd;
             s5_val = t[s4_line].val[at < 0 ? 0 : at];
         }
         // row it - 2: its sequence words have arrived
@@ -414,6 +416,7 @@ __global__ __launch_bounds__(256) void k_cov_join(const CountLine *__restrict__ 
             const uint64_t rc = rc_kmer(fwd, k);
             const LineSeq sq = kmer_lines(fwd, rc, k, mask);
             s4_first = (one_strand && rc < fwd) ? rc : fwd;
+            s4_fwd = fwd;
             s4_line = sq.line;
             s4_keys = load_line_keys(t, sq.line);
         }
@@ -473,21 +476,16 @@ __global__ __launch_bounds__(256) void k_cov_join_rest(const CountLine *__restri
     }
     const JoinRest *mine = rest + wave * (rest_cap + 1);
     for (uint32_t e = lane; e < n; e += WAVE) {
-        const uint64_t g = mine[e];
-        const uint64_t r = g >> 6;
-        const int gl = (int)(g & 63);
-        const uint64_t le = gl == 63 ? ~1ull : (((2ull << gl) - 1) & ~1ull);   // bits 1 .. gl: the unitig starts of the row up to this k-mer
-        const uint32_t u = krow[r] + (uint32_t)__popcll(khead[r] & le);
-        const uint64_t fwd = kmer_at(seq + off[u], (uint32_t)(g - kpre[u]), k);
+        const JoinRest x = mine[e];
         uint32_t c;
         bool found;
         if (one_strand) {   // one form to look for, and its first line is known to be full of other keys
-            const uint64_t rc = rc_kmer(fwd, k);
-            found = count_find(t, mask, rc < fwd ? rc : fwd, kmer_lines(fwd, rc, k, mask), c, 1);
+            const uint64_t rc = rc_kmer(x.fwd, k);
+            found = count_find(t, mask, rc < x.fwd ? rc : x.fwd, kmer_lines(x.fwd, rc, k, mask), c, 1);
         } else {
-            found = canonical_count(t, mask, fwd, k, c, false);
+            found = canonical_count(t, mask, x.fwd, k, c, false);
         }
-        gcov[g] = found ? c : GCOV_MISSING;
+        gcov[x.g] = found ? c : GCOV_MISSING;
     }
 }
 
@@ -912,18 +910,6 @@ int join_graph_counts_begin(pf_ctx *ctx) {
         ctx->d_gcov = nullptr;
         return PF_OK;
     }
-    if (ctx->n_kmers >= (1ull << 32)) {   // (the hand-over list holds 32-bit k-mer indices) every look-up walked to its end where it stands
-        const uint64_t n_win = (ctx->n_kmers + KCOV_WIN - 1) / KCOV_WIN;
-        ctx_begin(ctx, PF_K_COV_JOIN);
-        k_cov<<<ctx_grid(ctx, n_win * 64, 256, 16), 256, 0, ctx->stream>>>(ctx->d_tab, ctx->tab_cap - 1, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre,
-                                                                            ctx->d_kwin, ctx->N, ctx->tab_one_strand, 0, 0, 0, ctx->n_kmers, 0, n_win,
-                                                                            nullptr, nullptr, nullptr, ctx->d_gcov);
-        ctx_end(ctx);
-        PF_HIP(hipGetLastError());
-        PF_HIP(hipStreamSynchronize(ctx->stream));
-        ctx->gcov_valid = true;
-        return PF_OK;
-    }
     // a wavefront takes JOIN_ROWS_PER_WAVE consecutive rows (the pipeline's four iterations of filling and draining: 6 %) and has its
     // slice of the hand-over list -- three in ten of its k-mers (one in six is expected)
     // a wavefront takes JOIN_ROWS_PER_WAVE consecutive rows (the pipeline's four iterations of filling and draining: 6 %) -- a tenth
@@ -1238,31 +1224,8 @@ int pf_device_pci_bus_id(pf_ctx *ctx, char *buf, size_t cap) {
 uint64_t pf_table_capacity(const pf_ctx *ctx) { return ctx ? ctx->tab_cap * pf::LINE_KEYS : 0; }
 uint64_t pf_num_kmers(const pf_ctx *ctx) { return ctx ? ctx->n_kmers : 0; }
 
-namespace {
-// PF_TRACE_LOAD: where an upload's time goes, on stderr (the host layer's LoadTrace has the steps around it)
-struct DevTrace {
-    bool on = getenv("PF_TRACE_LOAD") != nullptr;
-    std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
-    void mark(const char *what) {
-        if (!on) return;
-        const auto t1 = std::chrono::steady_clock::now();
-        fprintf(stderr, "[load]   device layer: %-40s %.3fs\n", what, std::chrono::duration<double>(t1 - t0).count());
-        t0 = t1;
-    }
-};
-}  // namespace
-
 int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp,
                     uint32_t N, int k) {
-    return pf::upload_graph_impl(ctx, seq_words, seq_off, len_bp, N, k, false);
-}
-
-}  // extern "C"
-
-// adopt: seq_words (with two words of zero padding behind the last) and seq_off are device allocations of this context's device that
-// become the context's own (K-GFA packed them there: no second copy of the graph, no allocations beside the count table's)
-int pf::upload_graph_impl(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_off, const uint32_t *len_bp, uint32_t N, int k, bool adopt) {
-    DevTrace dtrace;
     if (!ctx || !seq_words || !seq_off || !len_bp || N == 0 || k < 3 || k > 31) return PF_ERR_ARG;
     if (N >= (1u << 30)) { pf::CtxErr{ctx} = "more than 2^30 unitigs"; return PF_ERR_ARG; }
     if (ctx->d_tab && ctx->tab_k != k) { pf::CtxErr{ctx} = "pf_upload_graph: k differs from the k of the resident count table"; return PF_ERR_ARG; }
@@ -1275,20 +1238,14 @@ int pf::upload_graph_impl(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t
     ctx->N = N;
     ctx->k = k;
     ctx->n_words = total_words;
-    if (adopt) {
-        ctx->d_seq = const_cast<uint64_t *>(seq_words);
-        ctx->d_off = const_cast<uint64_t *>(seq_off);
-    } else {
-        PF_HIP(hipMalloc(&ctx->d_seq, (total_words + 2) * 8));
-        PF_HIP(hipMemsetAsync(ctx->d_seq, 0, (total_words + 2) * 8, ctx->stream));
-        PF_HIP(hipMalloc(&ctx->d_off, ((size_t)N + 1) * 8));
-        PF_HIP(hipMemcpyAsync(ctx->d_seq, seq_words, total_words * 8, hipMemcpyDefault, ctx->stream));
-        PF_HIP(hipMemcpyAsync(ctx->d_off, seq_off, ((size_t)N + 1) * 8, hipMemcpyDefault, ctx->stream));
-    }
+    PF_HIP(hipMalloc(&ctx->d_seq, (total_words + 2) * 8));
+    PF_HIP(hipMemsetAsync(ctx->d_seq, 0, (total_words + 2) * 8, ctx->stream));
+    PF_HIP(hipMalloc(&ctx->d_off, ((size_t)N + 1) * 8));
     PF_HIP(hipMalloc(&ctx->d_len, (size_t)N * 4));
+    PF_HIP(hipMemcpyAsync(ctx->d_seq, seq_words, total_words * 8, hipMemcpyDefault, ctx->stream));
+    PF_HIP(hipMemcpyAsync(ctx->d_off, seq_off, ((size_t)N + 1) * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ctx->d_len, len_bp, (size_t)N * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
-    dtrace.mark("graph arrays allocated and copied");
     // validation of what the kernels assume (lengths >= k, offsets cover lengths) and the k-mer numbering of the k-mer-parallel
     // kernels, all on the device: d_kpre = exclusive scan of the k-mers per unitig; d_kwin[w] / d_krow[r] = the unitig holding
     // k-mer 256 w / 64 r; d_khead = one bit per k-mer (unitig starts, plus the end of the last one)
@@ -1333,16 +1290,9 @@ int pf::upload_graph_impl(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t
         PF_HIP(hipMemcpyAsync(ctx->h_len.data(), ctx->d_len, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
     }
-    dtrace.mark("k-mer numbering, row index, lengths to the host");
-    if (ctx->d_tab && !ctx->tab_exact) {
-        const int rc = pf::join_graph_counts(ctx);
-        dtrace.mark("K-COV-JOIN (with its buffers)");
-        return rc;
-    }
+    if (ctx->d_tab && !ctx->tab_exact) return pf::join_graph_counts(ctx);
     return PF_OK;
 }
-
-extern "C" {
 
 int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
     if (!ctx || !ctx->d_seq) return PF_ERR_ARG;

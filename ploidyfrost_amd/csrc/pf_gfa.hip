@@ -373,11 +373,10 @@ int pf_gfa_upload(pf_ctx *ctx) {
     if (!ctx || !ctx->gfa) return PF_ERR_ARG;
     GfaState *S = static_cast<GfaState *>(ctx->gfa);
     if (!S->n || !S->words) { pf::CtxErr{ctx} = S->err.empty() ? "pf_gfa_upload: pf_gfa_parse first" : S->err; return PF_ERR_ARG; }
-    // the packed words (two zero words behind them) and their offsets become the context's graph as they lie
-    uint64_t *words = S->words, *word_off = S->word_off;
+    const int up = pf_upload_graph(ctx, S->words, S->word_off, S->seg_len, S->n, S->k);
+    (void)hipFree(S->words);
+    (void)hipFree(S->word_off);
     S->words = S->word_off = nullptr;
-    const int up = pf::upload_graph_impl(ctx, words, word_off, S->seg_len, S->n, S->k, true);
-    if (up != PF_OK && !(ctx->d_seq == words)) { (void)hipFree(words); (void)hipFree(word_off); }   // (refused before it was adopted)
     return up;
 }
 
