@@ -2392,7 +2392,7 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                             for (uint32_t c0 = 0; c0 < lp; ++c0) {
                                 const uint64_t x = win.push(sp[c0], kmask, (uint32_t)k);
                                 if (c0 + 1 < (uint32_t)k) continue;
-                                const uint8_t *sa, *sb;
+                                const uint32_t *sa, *sb;
                                 colored_slots(a.ctab, x, k, a.c_one_strand != 0, sa, sb);
                                 for (uint32_t c = 0; c < C; ++c) {
                                     if (!((okm >> c) & 1) || ((a.c_unread >> c) & 1)) continue;   // (a colour never looked up: (0, true))
@@ -3848,7 +3848,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sa.scratch = W.sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
             sa.sv = O.sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
             sa.n_colors = C;
-            sa.ctab = CTab{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift}; sa.c_one_strand = ctx->ctab_one_strand; sa.c_unread = ctx->ctab_unread;
+            sa.ctab = CTab{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_line_bytes}; sa.c_one_strand = ctx->ctab_one_strand; sa.c_unread = ctx->ctab_unread;
             sa.clow = S->col_low.as<uint32_t>(); sa.cup = S->col_up.as<uint32_t>(); sa.full = S->col_full.as<uint64_t>();
             sa.part_first = S->part_first.as<uint32_t>(); sa.part_colour = S->part_colour.as<uint32_t>(); sa.part_word = S->part_word.as<uint64_t>();
             sa.part_bits = S->part_bits.as<uint64_t>(); sa.walk_pool = W.walk_pool.as<uint32_t>(); sa.walk_off = W.walk_off.as<uint64_t>();

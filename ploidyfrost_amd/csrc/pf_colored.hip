@@ -2,13 +2,13 @@
 // readCovUni (:123-156) and readCov(string, low, up, colour) (:89-122) over *one* count database per colour
 // (CCDBG::CCDBG, :13-43).
 //
-// MI355X layout: the C databases are joined into ONE open-addressing table keyed by the stored k-mer,
-// each slot = { u64 key, u32 count[C] } padded to a power-of-two stride (16 B for C <= 2, 32 B for C <= 6,
-// 64 B for C <= 14, ...), so that a k-mer costs one random HBM access for all colours instead of C.  An absent
-// (k-mer, colour) pair is the all-ones count.  K-COV-C walks the unitigs exactly like K-COV (one wavefront per
-// unitig, lanes over its k-mers) and reduces sum / min / max / missing per colour, four colours per pass
-// in registers; the range test of readCovUni ("low < count < up" for every k-mer) is min > low && max < up on
-// the host, which keeps the cutoffs out of the resident result.  Integer / index work: no MFMA.
+// MI355X layout: the C databases are joined into ONE table keyed by the stored k-mer -- the single-sample table's lines of ten
+// keys chosen by the key's minimizer (pf_device_common.hpp), with one count per colour and slot behind the keys (pf_colored_dev.hpp:
+// a line is 80 + 40 C bytes rounded up to 128), so that a k-mer costs one random HBM access for all colours instead of C, and the
+// k-mers of a unitig share their lines.  An absent (k-mer, colour) pair is the all-ones count.  K-COV-C walks the unitigs (one
+// wavefront per unitig, lanes over its k-mers) and reduces sum / min / max / missing per colour, four colours per pass in registers;
+// the range test of readCovUni ("low < count < up" for every k-mer) is min > low && max < up on the host, which keeps the cutoffs out
+// of the resident result.  Integer / index work: no MFMA.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -39,7 +39,7 @@ namespace {
 constexpr uint32_t MISSING = pf::CTAB_MISSING;
 
 // K-TABLE-C: one thread per record of colour `colour`
-__global__ void k_ctab_build(uint8_t *base, uint64_t mask, uint32_t shift, int k, const uint64_t *__restrict__ kmers,
+__global__ void k_ctab_build(uint8_t *base, uint64_t mask, uint32_t line_bytes, int k, const uint64_t *__restrict__ kmers,
                              const uint32_t *__restrict__ counts, uint64_t n, uint64_t min_count, uint64_t max_count, uint32_t colour,
                              unsigned int *noncanon) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -51,40 +51,37 @@ __global__ void k_ctab_build(uint8_t *base, uint64_t mask, uint32_t shift, int k
         const uint64_t key = kmers[i];
         const uint64_t rc = rc_kmer(key, k);
         nc |= rc < key;
-        const CTab t{base, mask, shift};
-        const CSeq sq = ctab_seq(t, key, rc, k);
-        const uint32_t per = 1u << sq.ls;
+        const LineSeq sq = kmer_lines(key, rc, k, mask);
+        uint64_t line = 0;
         bool done = false;
-        for (int tr = 0; tr < LINE_TRIES && !done; ++tr) {
-            const uint64_t b = ctab_bucket(t, sq, tr);
-            for (uint32_t j = 0; j < per && !done; ++j) {
-                uint8_t *slot = base + ((b + j) << shift);
-                unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(slot);
-                if (old == EMPTY_KEY) old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), EMPTY_KEY, key);
-                if (old == EMPTY_KEY || old == key) { *reinterpret_cast<uint32_t *>(slot + 8 + 4 * colour) = c; done = true; }
+        for (int tr = 0; !done; ++tr) {   // the single-sample table's probe sequence (count_claim), the count at this colour's place
+            line = tr < LINE_TRIES ? seq_line(sq, tr, mask) : tr == LINE_TRIES ? (mix64(key) & mask) : ((line + 1) & mask);
+            uint8_t *L = base + line * line_bytes;
+            for (int s = 0; s < LINE_KEYS && !done; ++s) {
+                unsigned long long *slot = reinterpret_cast<unsigned long long *>(L) + s;
+                unsigned long long old = __hip_atomic_load(slot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (old == EMPTY_KEY) old = atomicCAS(slot, EMPTY_KEY, key);
+                if (old == EMPTY_KEY || old == key) {
+                    reinterpret_cast<uint32_t *>(L + 8 * LINE_KEYS)[LINE_KEYS * colour + s] = c;
+                    done = true;
+                }
             }
-        }
-        for (uint64_t s = mix64(key) & mask; !done; s = (s + 1) & mask) {
-            uint8_t *slot = base + (s << shift);
-            unsigned long long old = atomicCAS(reinterpret_cast<unsigned long long *>(slot), EMPTY_KEY, key);
-            if (old == EMPTY_KEY || old == key) { *reinterpret_cast<uint32_t *>(slot + 8 + 4 * colour) = c; done = true; }
         }
     }
     if (__any(nc) && lane_id() == 0) atomicOr(noncanon, 1u);
 }
 
 // is some k-mer a key in both orientations (whatever the colours)?  one thread per slot
-__global__ void k_ctab_two_strands(const uint8_t *base, uint64_t cap, uint32_t shift, int k, unsigned int *flag) {
+__global__ void k_ctab_two_strands(const uint8_t *base, uint64_t n_lines, uint32_t line_bytes, int k, unsigned int *flag) {
     uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
-    CTab t{base, cap - 1, shift};
-    for (; i < cap; i += stride) {
-        const uint8_t *s = ctab_slot(t, i);
-        const uint64_t key = *reinterpret_cast<const uint64_t *>(s);
+    CTab t{base, n_lines - 1, line_bytes};
+    for (; i < n_lines * LINE_KEYS; i += stride) {
+        const uint64_t key = reinterpret_cast<const uint64_t *>(ctab_line(t, i / LINE_KEYS))[i % LINE_KEYS];
         if (key == EMPTY_KEY) continue;
         const uint64_t r = rc_kmer(key, k);
         if (r == key) continue;
-        if (ctab_find(t, r, ctab_seq(t, key, r, k))) atomicOr(flag, 1u);
+        if (ctab_find(t, r, kmer_lines(key, r, k, t.mask))) atomicOr(flag, 1u);
     }
 }
 
@@ -208,9 +205,154 @@ bool on_device(const T *p) {
 // k-mer leaves every colour's count (all ones = the colour's database lacks the k-mer) at the k-mer's position in graph
 // order, colour-major.  Once per (graph, set of databases); pf_unitig_cov_colored then streams it.  A count equal to the
 // marker cannot be represented: such a set of databases keeps the probing K-COV-C.
+// The kernel is pf_device.hip's k_cov_join over this table's lines: the same software pipeline (five rows of 64 k-mers in flight a
+// wavefront), the last load stage fetching the matching slot's count of every colour; a key that is not in its first line goes
+// to the wavefront's slice of a list that k_cov_join_colored_rest looks up.  It takes tables without a k-mer in both orientations
+// (every canonically counted set of databases) of up to JOINC_MAX colours; the others keep the loop of k_cov_colored.
+namespace {
+
+constexpr int JOINC_MAX = 8;
+struct JoinRestC {
+    uint64_t g, fwd;
+};
+
+template <int K>
+__global__ __launch_bounds__(256) void k_cov_join_colored(CTab t, int k_rt, const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                          const uint64_t *__restrict__ kpre, const uint64_t *__restrict__ khead,
+                                                          const uint32_t *__restrict__ krow, uint32_t n_colors, uint64_t n_kmers,
+                                                          uint32_t *__restrict__ gcov, uint64_t g_stride, JoinRestC *__restrict__ rest,
+                                                          uint32_t *__restrict__ rest_n, uint32_t rest_cap, uint32_t rows_per_wave) {
+    const int k = K ? K : k_rt;
+    const int lane = lane_id();
+    const uint64_t wave = (((uint64_t)blockIdx.x * blockDim.x) >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint64_t n_rows = (n_kmers + 63) >> 6;
+    const uint64_t row0 = wave * rows_per_wave;
+    const long n_it = row0 < n_rows ? (long)(n_rows - row0 < rows_per_wave ? n_rows - row0 : rows_per_wave) : 0;
+    const uint64_t below = lane == 63 ? ~1ull : (((2ull << lane) - 1) & ~1ull);   // bits 1 .. lane
+    JoinRestC *my_rest = rest + wave * (rest_cap + 1);
+    uint32_t n_rest = 0;
+    if (n_it == 0) {
+        if (lane == 0) rest_n[wave] = 0;
+        return;
+    }
+    // (stage by stage as in k_cov_join: every stage in every iteration on a clamped row, every lane stores)
+    uint64_t s1_hd, s2_pre = 0, s2_wo = 0, s3_w0 = 0, s3_w1 = 0, s4_first = 0, s4_fwd = 0, s4_line = 0, s5_fwd = 0;
+    uint32_t s1_kr;
+    int s3_s = 0;
+    LineKeys s4_keys;
+    uint32_t s5_val[JOINC_MAX];
+    bool s5_miss = false;
+#pragma unroll
+    for (int i = 0; i < LINE_KEYS / 2; ++i) s4_keys.q[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int c = 0; c < JOINC_MAX; ++c) s5_val[c] = 0;
+    const long last = n_it - 1;
+    auto row_of = [&](long i) { return row0 + (uint64_t)(i < 0 ? 0 : i > last ? last : i); };
+    s1_hd = khead[row0];
+    s1_kr = krow[row0];
+    uint64_t s0_hd = khead[row_of(1)];
+    uint32_t s0_kr = krow[row_of(1)];
+    for (long it = 0; it < n_it + 4; ++it) {
+        {   // row it - 4: its counts have arrived
+            const uint64_t g = row_of(it - 4) * 64 + lane;
+            const bool miss = s5_miss && it >= 4 && g < n_kmers;
+            const uint64_t mm = __ballot(miss);
+            const uint32_t at = n_rest + (uint32_t)__popcll(mm & ((1ull << lane) - 1));
+            my_rest[miss && at < rest_cap ? at : rest_cap] = JoinRestC{g, s5_fwd};
+            n_rest += (uint32_t)__popcll(mm);
+#pragma unroll
+            for (int c = 0; c < JOINC_MAX; ++c)
+                if ((uint32_t)c < n_colors) gcov[(uint64_t)c * g_stride + g] = s5_miss ? CTAB_MISSING : s5_val[c];
+        }
+        {   // row it - 3: its line's keys have arrived
+            bool open;
+            const int at = line_slot(s4_keys, s4_first, open);
+            s5_miss = at < 0;
+            s5_fwd = s4_fwd;
+            const uint32_t *cnt = ctab_counts(t, s4_line, at < 0 ? 0 : at);
+#pragma unroll
+            for (int c = 0; c < JOINC_MAX; ++c) s5_val[c] = (uint32_t)c < n_colors ? cnt[LINE_KEYS * c] : 0;
+        }
+        {   // row it - 2: its sequence words have arrived
+            uint64_t x = s3_w0 << s3_s;
+            x |= s3_s ? s3_w1 >> (64 - s3_s) : 0;
+            const uint64_t fwd = x >> (64 - 2 * k);
+            const uint64_t rc = rc_kmer(fwd, k);
+            const LineSeq sq = kmer_lines(fwd, rc, k, t.mask);
+            s4_first = rc < fwd ? rc : fwd;   // (one orientation per k-mer in this table: the canonical form is the one to look for)
+            s4_fwd = fwd;
+            s4_line = sq.line;
+            s4_keys = ctab_keys(t, sq.line);
+        }
+        {   // row it - 1: kpre / off of its lanes' unitigs have arrived
+            uint64_t g = row_of(it - 1) * 64 + lane;
+            g = g < n_kmers ? g : n_kmers - 1;
+            const uint32_t p = (uint32_t)(g - s2_pre);
+            const uint64_t *w = seq + s2_wo + (p >> 5);
+            s3_s = (int)(p & 31) * 2;
+            s3_w0 = w[0];
+            s3_w1 = w[1];
+        }
+        {   // row it: its khead / krow have arrived
+            const uint64_t r = row_of(it);
+            uint64_t hd = s1_hd & below;
+            hd &= r == n_rows - 1 ? (2ull << ((n_kmers - 1) & 63)) - 1 : ~0ull;
+            const uint32_t u = s1_kr + (uint32_t)__popcll(hd);
+            s2_pre = kpre[u];
+            s2_wo = off[u];
+        }
+        {   // rows it + 1, it + 2
+            s1_hd = s0_hd;
+            s1_kr = s0_kr;
+            const uint64_t r = row_of(it + 2);
+            s0_hd = khead[r];
+            s0_kr = krow[r];
+        }
+    }
+    if (lane == 0) rest_n[wave] = n_rest;
+}
+
+__global__ __launch_bounds__(256) void k_cov_join_colored_rest(CTab t, int k, uint32_t n_colors, const JoinRestC *__restrict__ rest,
+                                                               const uint32_t *__restrict__ rest_n, uint32_t rest_cap, uint32_t *__restrict__ gcov,
+                                                               uint64_t g_stride, const uint64_t *__restrict__ seq, const uint64_t *__restrict__ off,
+                                                               const uint64_t *__restrict__ kpre, const uint64_t *__restrict__ khead,
+                                                               const uint32_t *__restrict__ krow, uint64_t n_kmers, uint32_t rows_per_wave) {
+    const uint64_t wave = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const int lane = lane_id();
+    const uint32_t n = rest_n[wave];
+    auto look_up = [&](uint64_t g, uint64_t fwd) {
+        for (uint32_t c0 = 0; c0 < n_colors; c0 += CPP) {
+            const uint32_t n_here = min((uint32_t)CPP, n_colors - c0);
+            uint32_t cnt[CPP];
+            colored_counts(t, fwd, k, true, c0, n_here, cnt);
+#pragma unroll
+            for (int j = 0; j < CPP; ++j)
+                if ((uint32_t)j < n_here) gcov[(uint64_t)(c0 + j) * g_stride + g] = cnt[j];
+        }
+    };
+    if (n > rest_cap) {   // the slice was full: this wavefront's rows again, from the graph
+        const uint64_t n_rows = (n_kmers + 63) >> 6;
+        const uint64_t below = lane == 63 ? ~1ull : (((2ull << lane) - 1) & ~1ull);
+        for (uint64_t r = wave * rows_per_wave; r < (wave + 1) * rows_per_wave && r < n_rows; ++r) {
+            const uint64_t g = r * 64 + lane;
+            if (g >= n_kmers) break;
+            const uint32_t u = krow[r] + (uint32_t)__popcll(khead[r] & below);
+            look_up(g, kmer_at(seq + off[u], (uint32_t)(g - kpre[u]), k));
+        }
+        return;
+    }
+    const JoinRestC *mine = rest + wave * (rest_cap + 1);
+    for (uint32_t e = lane; e < n; e += WAVE) look_up(mine[e].g, mine[e].fwd);
+}
+
+}  // namespace
+
 namespace pf {
-int join_graph_counts_colored(pf_ctx *ctx) {
+// begin / finish like the single-sample join's (pf_device.hip): the kernels on the join's own stream, join_colored_finish() before
+// the joined array is read
+int join_graph_counts_colored_begin(pf_ctx *ctx) {
     ctx->gcov_c_valid = false;
+    ctx->join_c_inflight = false;
     if (!ctx->d_seq || !ctx->d_ctab || !ctx->n_colors || !ctx->d_kpre || ctx->n_kmers == 0 || ctx->ctab_max_count >= MISSING) return PF_OK;
     PF_HIP(hipSetDevice(ctx->device));
     const uint64_t stride = (ctx->n_krow + 4) * 64;  // whole super-rows of 256 k-mers, 16-byte aligned slices
@@ -223,16 +365,56 @@ int join_graph_counts_colored(pf_ctx *ctx) {
         }
         ctx->gcov_c_stride = stride;
     }
-    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
-    ctx_begin(ctx, PF_K_COV_JOIN);
-    k_cov_colored<<<ctx_grid(ctx, (uint64_t)ctx->N * 64, 256, 16), 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand,
-                                                                                        ctx->n_colors, 0, ctx->N, ctx->d_unread, nullptr, nullptr,
-                                                                                        nullptr, nullptr, ctx->d_kpre, ctx->d_gcov_c, stride);
-    ctx_end(ctx);
+    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_line_bytes};
+    if (!ctx->join_c_done) PF_HIP(hipEventCreateWithFlags(&ctx->join_c_done, hipEventDisableTiming));
+    const hipStream_t st = join_stream(ctx);
+    size_t at = 0;
+    if (ctx->ctab_one_strand && ctx->n_colors <= (uint32_t)JOINC_MAX && ctx->ctab_unread == 0) {
+        constexpr uint32_t ROWS = 64;
+        const uint64_t n_rows = (ctx->n_kmers + 63) / 64;
+        const uint64_t n_waves = ((n_rows + ROWS - 1) / ROWS + 3) / 4 * 4;
+        const int blocks = (int)(n_waves / 4);
+        const uint32_t rest_cap = ROWS * 64 * 4 / 10;
+        JoinRestC *rest = (JoinRestC *)ctx_ws(ctx, WS_JOIN_REST, n_waves * (rest_cap + 1) * sizeof(JoinRestC));
+        uint32_t *rest_n = (uint32_t *)ctx_ws(ctx, WS_JOIN_REST_N, n_waves * 4);
+        if (!rest || !rest_n) { pf::CtxErr{ctx} = "no room for K-COV-C-JOIN's hand-over list"; return PF_ERR_HIP; }
+        (void)ctx_begin_at(ctx, PF_K_COV_JOIN, st, &at);
+#define PF_JOINC_LAUNCH(KK) k_cov_join_colored<KK><<<blocks, 256, 0, st>>>(t, ctx->k, ctx->d_seq, ctx->d_off, ctx->d_kpre, ctx->d_khead, ctx->d_krow, \
+        ctx->n_colors, ctx->n_kmers, ctx->d_gcov_c, stride, rest, rest_n, rest_cap, ROWS)
+        if (ctx->k == 25) PF_JOINC_LAUNCH(25);
+        else if (ctx->k == 31) PF_JOINC_LAUNCH(31);
+        else PF_JOINC_LAUNCH(0);
+#undef PF_JOINC_LAUNCH
+        ctx_end_at(ctx, at, st);
+        (void)ctx_begin_at(ctx, PF_K_COV_JOIN_REST, st, &at);
+        k_cov_join_colored_rest<<<blocks, 256, 0, st>>>(t, ctx->k, ctx->n_colors, rest, rest_n, rest_cap, ctx->d_gcov_c, stride, ctx->d_seq, ctx->d_off,
+                                                                  ctx->d_kpre, ctx->d_khead, ctx->d_krow, ctx->n_kmers, ROWS);
+        ctx_end_at(ctx, at, st);
+    } else {
+        (void)ctx_begin_at(ctx, PF_K_COV_JOIN, st, &at);
+        k_cov_colored<<<ctx_grid(ctx, (uint64_t)ctx->N * 64, 256, 16), 256, 0, st>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand,
+                                                                                            ctx->n_colors, 0, ctx->N, ctx->d_unread, nullptr, nullptr,
+                                                                                            nullptr, nullptr, ctx->d_kpre, ctx->d_gcov_c, stride);
+        ctx_end_at(ctx, at, st);
+    }
     PF_HIP(hipGetLastError());
-    PF_HIP(hipStreamSynchronize(ctx->stream));
+    PF_HIP(hipEventRecord(ctx->join_c_done, st));
+    ctx->join_c_inflight = true;
+    return PF_OK;
+}
+
+int join_colored_finish(pf_ctx *ctx) {
+    if (!ctx->join_c_inflight) return PF_OK;
+    ctx->join_c_inflight = false;
+    PF_HIP(hipSetDevice(ctx->device));
+    PF_HIP(hipEventSynchronize(ctx->join_c_done));
     ctx->gcov_c_valid = true;
     return PF_OK;
+}
+
+int join_graph_counts_colored(pf_ctx *ctx) {
+    const int rc = join_graph_counts_colored_begin(ctx);
+    return rc ? rc : join_colored_finish(ctx);
 }
 }  // namespace pf
 
@@ -259,6 +441,7 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
         if (!both_strands[c]) { unread[c] = 1; if (c < 64) ctx->ctab_unread |= 1ull << c; }
         else ctx->ctab_max_count = std::max<uint64_t>(ctx->ctab_max_count, max_count[c]);
     }
+    (void)join_colored_finish(ctx);
     if (ctx->d_gcov_c) { (void)hipFree(ctx->d_gcov_c); ctx->d_gcov_c = nullptr; }
     ctx->gcov_c_valid = false;
     PF_HIP(hipSetDevice(ctx->device));
@@ -267,16 +450,15 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
     PF_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_unread), n_colors));
     PF_HIP(hipMemcpy(ctx->d_unread, unread.data(), n_colors, hipMemcpyHostToDevice));
     ctx->n_colors = 0;
-    // distinct keys <= total: a capacity above 1.25 * total always leaves empty slots; colours that share most
-    // k-mers (samples of one species) end at a load factor near max(n) / cap <= 0.5
-    uint64_t cap = 1024;
-    while (cap < 2 * biggest || cap < total + total / 4 + 1) cap <<= 1;
-    uint32_t shift = 4;
-    while ((1u << shift) < 8 + 4 * n_colors) ++shift;
-    PF_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_ctab), cap << shift));
-    PF_HIP(hipMemsetAsync(ctx->d_ctab, 0xFF, cap << shift, ctx->stream));  // EMPTY_KEY keys, MISSING counts
+    // lines of ten keys: distinct keys <= total, and colours that share most k-mers (samples of one species) end near max(n) keys:
+    // ten slots for every four keys of the largest database, and never fewer slots than 1.25 * total
+    uint64_t cap = 128;
+    while (cap * 4 < biggest || cap * LINE_KEYS < total + total / 4 + 1) cap <<= 1;
+    const uint32_t line_bytes = ctab_line_bytes(n_colors);
+    PF_HIP(hipMalloc(reinterpret_cast<void **>(&ctx->d_ctab), cap * line_bytes));
+    PF_HIP(hipMemsetAsync(ctx->d_ctab, 0xFF, cap * line_bytes, ctx->stream));  // EMPTY_KEY keys, MISSING counts
     ctx->ctab_cap = cap;
-    ctx->ctab_shift = shift;
+    ctx->ctab_line_bytes = line_bytes;
     DevTmp<unsigned int> noncanon_;
     PF_HIP(noncanon_.alloc(4));
     PF_HIP(hipMemsetAsync(noncanon_.p, 0, 4, ctx->stream));
@@ -295,7 +477,7 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
             pc = dc_.p;
         }
         ctx_begin(ctx, PF_K_TABLE_BUILD);
-        k_ctab_build<<<ctx_grid(ctx, n[c], 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap - 1, shift, ctx->k, pk, pc, n[c], min_count[c],
+        k_ctab_build<<<ctx_grid(ctx, n[c], 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap - 1, line_bytes, ctx->k, pk, pc, n[c], min_count[c],
                                                                            max_count[c], c, noncanon_.p);
         ctx_end(ctx);
         PF_HIP(hipStreamSynchronize(ctx->stream));  // the staging buffers die at the end of this iteration
@@ -309,7 +491,7 @@ int pf_upload_counts_colored(pf_ctx *ctx, uint32_t n_colors, const uint64_t *con
             DevTmp<unsigned int> flag_;
             PF_HIP(flag_.alloc(4));
             PF_HIP(hipMemsetAsync(flag_.p, 0, 4, ctx->stream));
-            k_ctab_two_strands<<<ctx_grid(ctx, cap, 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap, shift, ctx->k, flag_.p);
+            k_ctab_two_strands<<<ctx_grid(ctx, cap * LINE_KEYS, 256, 8), 256, 0, ctx->stream>>>(ctx->d_ctab, cap, line_bytes, ctx->k, flag_.p);
             PF_HIP(hipMemcpyAsync(&h_flag, flag_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
             PF_HIP(hipStreamSynchronize(ctx->stream));
         }
@@ -337,6 +519,7 @@ static int unitig_cov_colored_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64
     }
     constexpr bool env_probe = false;
     probe = probe || env_probe;
+    { const int rc = join_colored_finish(ctx); if (rc) return rc; }   // look-ups of pf_join_counts_begin still on their way
     if (!probe && !ctx->gcov_c_valid) {  // the graph was replaced under the table
         const int rc = join_graph_counts_colored(ctx);
         if (rc) return rc;
@@ -357,7 +540,7 @@ static int unitig_cov_colored_impl(pf_ctx *ctx, uint32_t u0, uint32_t u1, uint64
         const int rc = launch_cov_stream(ctx, a, ctx->n_colors, ctx->ctab_max_count >= (1ull << 20), true);
         if (rc) return rc;
     } else {
-        const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
+        const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_line_bytes};
         const int grid = ctx_grid(ctx, (uint64_t)(u1 - u0) * 64, 256, 16);
         k_cov_colored<<<grid, 256, 0, ctx->stream>>>(t, ctx->d_seq, ctx->d_off, ctx->d_len, ctx->k, ctx->ctab_one_strand, ctx->n_colors, u0, u1,
                                                      ctx->d_unread, ds, dlo, dhi, dx, nullptr, nullptr, 0);
@@ -399,7 +582,7 @@ int pf_string_cov_colored(pf_ctx *ctx, const char *text, const uint64_t *str_off
     PF_HIP(hipMemcpyAsync(doff, str_off, ((size_t)n_str + 1) * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(dcut, low, (size_t)C * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(dcut + C, up, (size_t)C * 4, hipMemcpyDefault, ctx->stream));
-    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_shift};
+    const CTab t{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_line_bytes};
     ctx_begin(ctx, PF_K_STRCOV_COLORED);
     k_strcov_colored<<<ctx_grid(ctx, (uint64_t)n_str * C, 256, 8), 256, 0, ctx->stream>>>(t, ctx->k, ctx->ctab_one_strand, C, ctx->d_unread, dt, doff, n_str,
                                                                                           dcut, dcut + C, ds, dk);

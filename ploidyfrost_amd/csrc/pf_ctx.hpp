@@ -63,6 +63,8 @@ struct pf_ctx {
     hipStream_t join_stream = nullptr;
     hipEvent_t join_done = nullptr;
     bool join_inflight = false;
+    hipEvent_t join_c_done = nullptr;   // the same for the colored join (pf_colored.hip)
+    bool join_c_inflight = false;
     int tab_k = 0;                // k of the database: a count table is addressed by the minimizers of its keys (pf_device_common.hpp)
     bool tab_one_strand = false;  // no k-mer is stored in both orientations (checked when the table is built)
     bool tab_exact = false;       // database built without canonical counting: no composite lookups
@@ -82,7 +84,7 @@ struct pf_ctx {
     // padded to 1 << ctab_shift bytes (pf_colored.hip)
     uint8_t *d_ctab = nullptr;
     uint64_t ctab_cap = 0;
-    uint32_t ctab_shift = 4, n_colors = 0;
+    uint32_t ctab_line_bytes = 128, n_colors = 0;   // ctab_cap lines of ctab_line_bytes (pf_colored_dev.hpp)
     bool ctab_one_strand = false;
     uint64_t ctab_unread = 0;   // colours whose database was written without canonical counting: never looked up (the first 64 colours: the resident pipeline's)
     uint8_t *d_unread = nullptr;   // the same per colour, one byte each (any number of colours)
@@ -171,6 +173,9 @@ int ctx_grid(const pf_ctx *ctx, uint64_t work_items, int block, int per_cu);
 int join_graph_counts(pf_ctx *ctx);
 int join_graph_counts_begin(pf_ctx *ctx);   // pf_device.hip: the kernels on a stream of their own; join_finish() before d_gcov is read
 int join_finish(pf_ctx *ctx);
+int join_graph_counts_colored_begin(pf_ctx *ctx);
+int join_colored_finish(pf_ctx *ctx);
+hipStream_t join_stream(pf_ctx *ctx);   // pf_device.hip: the stream both joins run on
 int join_graph_counts_colored(pf_ctx *ctx);  // pf_colored.hip: the same for the joined table of all colours (pf_ctx::d_gcov_c)  // K-COV-JOIN (pf_device.hip): fills pf_ctx::d_gcov when graph and canonical count table are both resident
 // device workspace `slot`, at least `bytes` large (contents undefined); nullptr on allocation failure
 void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);

@@ -891,7 +891,7 @@ int launch_cov_stream(pf_ctx *ctx, Kc4Args a, uint32_t n_colors, bool wide, bool
 // caller with other work for the device -- findSuperBubble does not read a coverage -- runs it beside the look-ups;
 // join_finish() is what every reader of the joined array calls first.
 namespace pf {
-static hipStream_t join_stream(pf_ctx *ctx) {
+hipStream_t join_stream(pf_ctx *ctx) {
     if (!ctx->join_stream) {
         int least = 0, greatest = 0;
         (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
@@ -1063,6 +1063,7 @@ void pf_destroy(pf_ctx *ctx) {
     hipStreamSynchronize(ctx->stream);
     if (ctx->join_stream) { hipStreamSynchronize(ctx->join_stream); hipStreamDestroy(ctx->join_stream); }
     if (ctx->join_done) hipEventDestroy(ctx->join_done);
+    if (ctx->join_c_done) hipEventDestroy(ctx->join_c_done);
     for (auto &tl : ctx->launches) { hipEventDestroy(tl.a); hipEventDestroy(tl.b); }
     for (auto &e : ctx->event_pool) hipEventDestroy(e);
     call_destroy(ctx);
@@ -1231,6 +1232,7 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
     if (ctx->d_tab && ctx->tab_k != k) { pf::CtxErr{ctx} = "pf_upload_graph: k differs from the k of the resident count table"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
     (void)join_finish(ctx);
+    (void)join_colored_finish(ctx);
     free_graph(ctx);
     // seq_off[N] = total words; fetch it (host or device pointer)
     uint64_t total_words = 0;
@@ -1482,22 +1484,24 @@ int pf_join_counts_begin(pf_ctx *ctx) {
     const bool single = ctx->d_tab && !ctx->tab_exact, colored = ctx->d_ctab && ctx->n_colors;
     if (!single && !colored) { pf::CtxErr{ctx} = "pf_join_counts: no canonical count table resident"; return PF_ERR_ARG; }
     { const int rc = pf::join_finish(ctx); if (rc) return rc; }
+    { const int rc = pf::join_colored_finish(ctx); if (rc) return rc; }
     if (single) {
         const int rc = pf::join_graph_counts_begin(ctx);
         if (rc) return rc;
         if (!ctx->join_inflight) { pf::CtxErr{ctx} = "pf_join_counts: no joined coverage array for this table (max_count = 2^32 - 1, or no room)"; return PF_ERR_ARG; }
     }
-    if (colored) {   // (the colored join is one kernel on the context's stream: it has ended when this returns)
-        const int rc = pf::join_graph_counts_colored(ctx);
+    if (colored) {
+        const int rc = pf::join_graph_counts_colored_begin(ctx);
         if (rc) return rc;
-        if (!ctx->gcov_c_valid) { pf::CtxErr{ctx} = "pf_join_counts: no joined coverage array for these databases (max_count = 2^32 - 1, or no room)"; return PF_ERR_ARG; }
+        if (!ctx->join_c_inflight) { pf::CtxErr{ctx} = "pf_join_counts: no joined coverage array for these databases (max_count = 2^32 - 1, or no room)"; return PF_ERR_ARG; }
     }
     return PF_OK;
 }
 
 int pf_join_counts_end(pf_ctx *ctx) {
     if (!ctx) return PF_ERR_ARG;
-    return pf::join_finish(ctx);
+    const int rc = pf::join_finish(ctx);
+    return rc ? rc : pf::join_colored_finish(ctx);
 }
 
 int pf_join_counts(pf_ctx *ctx) {
