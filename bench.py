@@ -271,7 +271,7 @@ def algorithmic_bytes(kernel: str, t: dict, units: float | None = None) -> float
         return (12.25 * t["kmers"] + 16.0 * t["unitigs"]) * max(1, t.get("n_colors", 1))
     if kernel in ("k_bfs", "k_bfs_thread"):
         return 600.0 * (units if units is not None else t["candidates"])
-    if kernel in ("k_align", "k_bubble", "k_call_snp", "k_call_pair", "k_call_stack", "k_call_trio"):
+    if kernel in ("k_align", "k_bubble", "k_call_snp", "k_call_pair", "k_call_stack"):
         return 300.0 * (units if units is not None else t["align_jobs"])
     if kernel == "k_call_format":  # K-TEXT: the result text itself (written once; its inputs are a fraction of it)
         return float(t["output_bytes"])
@@ -839,7 +839,7 @@ def main():
                 "counts": {"candidates": tt["candidates"], "superbubble_rows": tt["superbubbles"],
                            "bubbles_called": shard_stats["counters"][7] if strong else tt["tasks"],
                            "align_jobs": tt["align_jobs"], "site_strings": tt["site_strings"],
-                           "align_jobs_by_kernel": {"k_call_snp": tt["snp_jobs"], "k_call_pair": tt["pair_jobs"], "k_call_stack": tt["stack_jobs"], "k_call_trio": tt["trio_jobs"], "k_bubble": tt["wave_jobs"]},
+                           "align_jobs_by_kernel": {"k_call_snp": tt["snp_jobs"], "k_call_pair": tt["pair_jobs"], "k_call_stack": tt["stack_jobs"], "k_bubble": tt["wave_jobs"]},
                            "sites": shard_stats["counters"][:4] if strong else tt["allele"],
                            "output_bytes": shard_stats["output_bytes"] if strong else tt["output_bytes"]},
             }

@@ -58,7 +58,7 @@ int pf_synchronize(pf_ctx *);
 enum pf_kernel {
     PF_K_TABLE_BUILD = 0, PF_K_ADJ_INSERT, PF_K_ADJ_PROBE, PF_K_COV, PF_K_BFS, PF_K_BFS_BIG,
     PF_K_ALIGN, PF_K_ALIGN_BIG, PF_K_STRCOV, PF_K_BUBBLE, PF_K_BUBBLE_BIG, PF_K_COV_COLORED, PF_K_STRCOV_COLORED, PF_K_GMM, PF_K_KMC_DECODE, PF_K_MINZ, PF_K_COV_JOIN,
-    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_BFS_THREAD, PF_K_CALL_PAIR, PF_K_CALL_STACK, PF_K_CALL_TRIO,
+    PF_K_CALL_SCAN, PF_K_CALL_PREP, PF_K_CALL_PATHS, PF_K_CALL_SITES, PF_K_CALL_FORMAT, PF_K_CALL_SNP, PF_K_BFS_THREAD, PF_K_CALL_PAIR, PF_K_CALL_STACK,
     PF_K_COV_JOIN_REST, /* second kernel of K-COV-JOIN: the look-ups whose first line was full */
     PF_K_COPY_TEXT, /* not a kernel of this library: the copies of result text to the host (the runtime moves them with a kernel of its own) */
     PF_K_COUNT_
@@ -395,7 +395,6 @@ typedef struct pf_call_result {
     uint64_t align_jobs, site_strings, n_branching;
     uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: finished by K-SNP, by K-PAIR, sent to K-BUBBLE */
     uint64_t stack_jobs;                     /* ... finished by K-STACK (paths of one length, alignment = the paths stacked) */
-    uint64_t trio_jobs;                      /* ... finished by K-TRIO (3-8 short paths, every round one alignment that leaves row 0 alone) */
     uint64_t alignseq_packed_len;            /* pf_call_set_alignseq_packed: bytes stream PF_OUT_ALIGNSEQ takes in the slab (text_len keeps the text's) */
 } pf_call_result;
 #define PF_CALL_SLABS 4 /* text slabs of a context: a slab is free again once pf_call_fetch has copied it */

@@ -32,7 +32,6 @@ typedef struct pfh_times {
     uint64_t bfs_deferred;            /* candidates that left the device's LDS tier (128 entries) for the host walkers */
     uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: bubbles finished by K-SNP, by K-PAIR, sent to K-BUBBLE (resident pipeline) */
     uint64_t stack_jobs;                     /* ... finished by K-STACK (paths of one length; the alignment certified to be the paths stacked) */
-    uint64_t trio_jobs;                      /* ... finished by K-TRIO (three to eight short paths, thread per bubble) */
     uint64_t host_commit_records;            /* findSuperBubble: records committed on a host thread (large components, walked traversals) */
     uint64_t host_walk_vertices;             /* ... vertices the host walkers visited for the traversals the device gave up on */
 } pfh_times;

@@ -52,7 +52,7 @@ struct PhaseTimes {
     uint64_t bfs_large_used = 0, bfs_large_used_max = 0;            // ... that the replay's gate let through, and the longest of those
     uint64_t candidates = 0, bfs_deferred = 0, bubbles_out = 0, tasks = 0, align_jobs = 0, site_strings = 0;
     uint64_t host_commit_records = 0, host_walk_vertices = 0;   // findSuperBubble's host share: records committed on a host thread (large components + walked traversals), vertices the walkers visited
-    uint64_t snp_jobs = 0, pair_jobs = 0, wave_jobs = 0, stack_jobs = 0, trio_jobs = 0;   // of align_jobs: by K-SNP, by K-PAIR, by K-BUBBLE, by K-STACK
+    uint64_t snp_jobs = 0, pair_jobs = 0, wave_jobs = 0, stack_jobs = 0;   // of align_jobs: by K-SNP, by K-PAIR, by K-BUBBLE, by K-STACK
 };
 
 // The count database on its way to HBM while the caller is still reading the graph file: context creation, header / prefix

@@ -108,7 +108,7 @@ int CDBG::ploidy_select(const std::vector<std::pair<int, int>> &cutoff, uint64_t
     if (cutoff.size() != (col_ ? col_->n_colors : 1u))
         return fail(PF_ERR_ARG, std::string(tag_) + "::ploidy_select(): one (lower, upper) cutoff" + (col_ ? " per colour" : "") + " is required");
     times_.tasks = times_.align_jobs = times_.site_strings = 0;
-    times_.snp_jobs = times_.pair_jobs = times_.wave_jobs = times_.stack_jobs = times_.trio_jobs = 0;
+    times_.snp_jobs = times_.pair_jobs = times_.wave_jobs = times_.stack_jobs = 0;
     allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
     core_cov_ = core_num_ = 0;
     const bool keep = resident_;
@@ -130,7 +130,7 @@ int CDBG::ploidy_align(uint64_t t0, uint64_t t1, uint64_t &n_called) {
     slice_nb_ = t1 - t0;
     times_.tasks = t1 - t0;
     times_.align_jobs = slice_res_.align_jobs;
-    times_.snp_jobs = slice_res_.snp_jobs; times_.pair_jobs = slice_res_.pair_jobs; times_.wave_jobs = slice_res_.wave_jobs; times_.stack_jobs = slice_res_.stack_jobs; times_.trio_jobs = slice_res_.trio_jobs;
+    times_.snp_jobs = slice_res_.snp_jobs; times_.pair_jobs = slice_res_.pair_jobs; times_.wave_jobs = slice_res_.wave_jobs; times_.stack_jobs = slice_res_.stack_jobs;
     times_.site_strings = slice_res_.site_strings;
     times_.align_s = since(t);
     return 0;
@@ -238,7 +238,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     const unsigned T = threads_ ? threads_ : (unsigned)std::max<size_t>(thr, 1);
     times_.cov_device_s = times_.tasks_s = times_.align_s = times_.sites_s = times_.format_s = times_.write_s = 0;
     times_.tasks = times_.align_jobs = times_.site_strings = 0;
-    times_.snp_jobs = times_.pair_jobs = times_.wave_jobs = times_.stack_jobs = times_.trio_jobs = 0;
+    times_.snp_jobs = times_.pair_jobs = times_.wave_jobs = times_.stack_jobs = 0;
     times_.align_build_s = times_.align_device_s = times_.align_post_s = times_.align_choose_s = times_.scan_s = 0;
     allele_[0] = allele_[1] = allele_[2] = allele_[3] = 0;
     core_cov_ = core_num_ = 0;
@@ -641,7 +641,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 std::lock_guard<std::mutex> lk(mu);
                 times_.tasks += r.a1 - r.a0;
                 times_.align_jobs += ar.align_jobs;
-                times_.snp_jobs += ar.snp_jobs; times_.pair_jobs += ar.pair_jobs; times_.wave_jobs += ar.wave_jobs; times_.stack_jobs += ar.stack_jobs; times_.trio_jobs += ar.trio_jobs;
+                times_.snp_jobs += ar.snp_jobs; times_.pair_jobs += ar.pair_jobs; times_.wave_jobs += ar.wave_jobs; times_.stack_jobs += ar.stack_jobs;
                 times_.site_strings += ar.site_strings;
                 ranges[ri].n_called = ar.n_called;
                 ranges[ri].aligned = true;

@@ -236,7 +236,7 @@ void pfh_get_times(const pfh_run *r, pfh_times *o) {
     o->bfs_large = t.bfs_large; o->bfs_max_seen = t.bfs_max_seen;
     o->bfs_deferred = t.bfs_deferred;
     o->host_commit_records = t.host_commit_records; o->host_walk_vertices = t.host_walk_vertices;
-    o->snp_jobs = t.snp_jobs; o->pair_jobs = t.pair_jobs; o->wave_jobs = t.wave_jobs; o->stack_jobs = t.stack_jobs; o->trio_jobs = t.trio_jobs;
+    o->snp_jobs = t.snp_jobs; o->pair_jobs = t.pair_jobs; o->wave_jobs = t.wave_jobs; o->stack_jobs = t.stack_jobs;
 }
 
 const char *pfh_last_allele_frequency(const pfh_run *r, uint64_t *len) {

@@ -763,7 +763,7 @@ namespace pf {
 static const char *kKernelNames[PF_K_COUNT_] = {"k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs",
                                                 "k_bfs_big",     "k_align",      "k_align_big", "k_strcov",    "k_bubble",
                                                 "k_bubble_big",  "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
-                                                "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_call_trio", "k_cov_join_rest", "copy_text_to_host"};
+                                                "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_cov_join_rest", "copy_text_to_host"};
 
 // (events come from a pool that pf_reset_timing refills: creating two per launch cost more than the launch)
 static size_t launch_push(pf_ctx *ctx, int kernel, hipStream_t stream) {

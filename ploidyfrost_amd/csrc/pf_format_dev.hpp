@@ -93,7 +93,7 @@ __host__ __device__ inline G6 g6_round(uint32_t n, int x, int tail /* -1 below h
 }
 
 // generic route: any finite non-zero double; 32-bit limbs, little endian.  1100 bits cover 2^-1074 .. 2^1024.
-__host__ __device__ __noinline__ G6 g6_wide(uint64_t m, int E) {
+__host__ __device__ __noinline__ inline G6 g6_wide(uint64_t m, int E) {
     constexpr int LIMBS = 36;
     uint32_t a[LIMBS];
     for (int i = 0; i < LIMBS; ++i) a[i] = 0;

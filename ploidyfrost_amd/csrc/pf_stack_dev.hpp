@@ -32,8 +32,6 @@ namespace pf {
 constexpr uint32_t STACK_MAX = 128;    // longest path
 constexpr uint32_t STACK_PATHS = 16;   // most paths
 constexpr int STACK_W = 3;             // cells of the band on either side of the diagonal
-constexpr uint32_t TRIO_MAX = 96;      // K-TRIO (pf_call.hip): longest path ...
-constexpr uint32_t TRIO_PATHS = 8;     // ... and most paths
 
 // scores under which the bound for the cells beyond the band holds (and the arithmetic is the reference's integer arithmetic)
 inline bool stack_scores(double M, double D, double G) {

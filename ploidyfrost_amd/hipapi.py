@@ -21,7 +21,7 @@ NONE = 0xFFFFFFFF
 PF_OK, PF_ERR_ARG, PF_ERR_HIP, PF_ERR_NO_DEVICE, PF_ERR_OVERFLOW, PF_ERR_MISSING_KMER = range(6)
 KERNELS = ["k_table_build", "k_adj_insert", "k_adj_probe", "k_cov", "k_bfs", "k_bfs_big", "k_align", "k_align_big",
            "k_strcov", "k_bubble", "k_bubble_big", "k_cov_colored", "k_strcov_colored", "k_gmm", "k_kmc_decode", "k_minz_count", "k_cov_join",
-           "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_call_trio", "k_cov_join_rest", "copy_text_to_host"]
+           "k_call_sides", "k_call_prep", "k_call_paths", "k_call_sites", "k_call_format", "k_call_snp", "k_bfs_thread", "k_call_pair", "k_call_stack", "k_cov_join_rest", "copy_text_to_host"]
 
 BFS_RECORD = np.dtype([("entrance", "<u4"), ("exit", "<u4"), ("n_seen", "<u4"), ("n_list", "<u4"), ("list_off", "<u8"),
                        ("outcome", "u1"), ("flag_cycle", "u1"), ("flag_tip", "u1"), ("strict", "u1"), ("pad", "<u4")])
@@ -32,7 +32,7 @@ CALL_SIDE = np.dtype([("u", "<u4"), ("exit_ov", "<u4"), ("err_unitig", "<u4"), (
                       ("err", "u1")])
 CALL_RESULT = np.dtype([("text_len", "<u8", (10,)), ("allele", "<u8", (4,)), ("core_cov", "<u8"), ("core_num", "<u8"), ("n_called", "<u8"),
                         ("align_jobs", "<u8"), ("site_strings", "<u8"), ("n_branching", "<u8"),
-                        ("snp_jobs", "<u8"), ("pair_jobs", "<u8"), ("wave_jobs", "<u8"), ("stack_jobs", "<u8"), ("trio_jobs", "<u8"),
+                        ("snp_jobs", "<u8"), ("pair_jobs", "<u8"), ("wave_jobs", "<u8"), ("stack_jobs", "<u8"),
                         ("alignseq_packed_len", "<u8")])
 CALL_STREAMS = ["allele_frequency", "alignseq", "bifre", "trifre", "tetrafre", "pentafre", "bicov", "tricov", "tetracov", "pentacov"]
 BUBBLE_PATH = np.dtype([("text_off", "<u8"), ("len", "<u4"), ("ov", "<u4")])

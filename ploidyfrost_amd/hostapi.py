@@ -20,7 +20,7 @@ class Times(C.Structure):
                                           "output_bytes")] + [("allele", C.c_uint64 * 4), ("core_cov", C.c_uint64),
                                                               ("core_num", C.c_uint64), ("scan_s", C.c_double), ("scan_serial_s", C.c_double),
                                                               ("bfs_large", C.c_uint64), ("bfs_max_seen", C.c_uint64), ("bfs_deferred", C.c_uint64),
-                                                              ("snp_jobs", C.c_uint64), ("pair_jobs", C.c_uint64), ("wave_jobs", C.c_uint64), ("stack_jobs", C.c_uint64), ("trio_jobs", C.c_uint64),
+                                                              ("snp_jobs", C.c_uint64), ("pair_jobs", C.c_uint64), ("wave_jobs", C.c_uint64), ("stack_jobs", C.c_uint64),
                                                               ("host_commit_records", C.c_uint64), ("host_walk_vertices", C.c_uint64)]
 
 

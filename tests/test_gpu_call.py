@@ -384,7 +384,7 @@ def check_pipeline(tmp, gfa, db, z=8, lower=5, upper=1000, scores=(2.0, -1.0, -3
     bad = compare_outputs(want_dir, got_dir)
     assert not bad, bad
     t = run.times()
-    stats.update(snp_jobs=t["snp_jobs"], pair_jobs=t["pair_jobs"], wave_jobs=t["wave_jobs"], stack_jobs=t["stack_jobs"], trio_jobs=t["trio_jobs"])
+    stats.update(snp_jobs=t["snp_jobs"], pair_jobs=t["pair_jobs"], wave_jobs=t["wave_jobs"], stack_jobs=t["stack_jobs"])
     run.close()
     o.close()
     return stats
@@ -456,7 +456,7 @@ def test_two_path_bubbles_kernel_by_kernel(two_path_graph, second_pair_tier):
     # co-optimal ties and long paths (K-BUBBLE)
     print(s)
     assert s["snp_jobs"] >= 300 and s["pair_jobs"] >= 300 and s["wave_jobs"] >= 100, s
-    assert s["snp_jobs"] + s["pair_jobs"] + s["wave_jobs"] + s["stack_jobs"] + s["trio_jobs"] == s["bubbles"], s
+    assert s["snp_jobs"] + s["pair_jobs"] + s["wave_jobs"] + s["stack_jobs"] == s["bubbles"], s
     # the long insertions are aligned by K-PAIR's second tier, not by K-BUBBLE: what is left there are the ties
     assert s["wave_jobs"] < s["gt64"] + s["two_path"] // 4 and s["pair_jobs"] + s["stack_jobs"] >= s["gt64"] // 2, s
 
@@ -480,9 +480,8 @@ def test_two_path_bubbles_under_other_scores(two_path_graph, scores, second_pair
     assert s["two_path"] >= 2000 and s["pair_jobs"] + s["snp_jobs"] + s["stack_jobs"] >= 300 and s["wave_jobs"] >= 100, s
 
 
-def test_multi_path_bubbles_kernel_by_kernel(multi_path_graphs, monkeypatch):
-    monkeypatch.setenv("PF_TRIO_TIER", "1")   # K-TRIO (off by default: a loss below a few hundred thousand such bubbles) runs here
-    tot = dict(multi_path=0, strict_multi=0, branching=0, site_checks=0, indel_sites=0, max_paths=0, stack_jobs=0, trio_jobs=0, wave_jobs=0)
+def test_multi_path_bubbles_kernel_by_kernel(multi_path_graphs):
+    tot = dict(multi_path=0, strict_multi=0, branching=0, site_checks=0, indel_sites=0, max_paths=0, stack_jobs=0, wave_jobs=0)
     for sub, gfa, db in multi_path_graphs:
         for scores in ((2.0, -1.0, -3.0), (1.5, -0.5, -2.25)):
             s = check_pipeline(sub, gfa, db, z=16, scores=scores)
@@ -491,7 +490,7 @@ def test_multi_path_bubbles_kernel_by_kernel(multi_path_graphs, monkeypatch):
     assert tot["multi_path"] >= 500 and tot["strict_multi"] >= 100 and tot["branching"] >= 400, tot
     assert tot["site_checks"] >= 500 and tot["indel_sites"] >= 100 and tot["max_paths"] >= 6, tot
     # K-STACK (paths of one length, alignment certified to be the paths stacked) and K-BUBBLE (the rest) both took bubbles
-    assert tot["stack_jobs"] >= 300 and tot["wave_jobs"] >= 50, tot   # (K-TRIO gets what K-STACK cannot certify among the three- and four-path bubbles of one length: few)
+    assert tot["stack_jobs"] >= 300 and tot["wave_jobs"] >= 50, tot
 
 
 def test_paths_and_sites_of_hex30k(tmp_path):
@@ -502,14 +501,6 @@ def test_paths_and_sites_of_hex30k(tmp_path):
                        scores=(float(op["-M"]), float(op["-D"]), float(op["-G"])))
     assert s["branching"] >= 50 and s["site_checks"] >= 100, s
     assert not compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(str(tmp_path), "gpu_%g_%g_%g" % (float(op["-M"]), float(op["-D"]), float(op["-G"]))))
-
-
-def test_multi_path_bubbles_without_the_trio_tier(multi_path_graphs, monkeypatch):
-    """the default routing: what K-STACK cannot certify is K-BUBBLE's"""
-    monkeypatch.delenv("PF_TRIO_TIER", raising=False)
-    sub, gfa, db = multi_path_graphs[1]
-    s = check_pipeline(sub + "/default", gfa, db, z=16)
-    assert s["trio_jobs"] == 0 and s["stack_jobs"] >= 30 and s["wave_jobs"] >= 30, s
 
 
 @pytest.mark.parametrize("layers,seed", [(3, 11), (5, 11), (6, 12), (7, 11), (8, 11)])

@@ -230,7 +230,7 @@ def test_colored_calling_on_the_resident_pipeline_and_on_the_host(case, tmp_path
         run.ploidy_estimation("g", meta["cutoffs"])
         assert not compare_outputs(os.path.join(meta["dir"], "expected"), str(out)), mode
         t = run.times()
-        jobs[mode] = (t["align_jobs"], t["snp_jobs"] + t["pair_jobs"] + t["stack_jobs"] + t["trio_jobs"] + t["wave_jobs"])
+        jobs[mode] = (t["align_jobs"], t["snp_jobs"] + t["pair_jobs"] + t["stack_jobs"] + t["wave_jobs"])
     if meta["n_colors"] > 62:
         # more colours than one 64-bit register holds (col100): the reference has no limit (src/CCDBG.cpp:2759-2853); the resident
         # pipeline keeps a colour set in a register, so such a graph is committed on host threads (multi-word colour sets in the same

@@ -32,9 +32,9 @@ for i in range(3):
     run.find_superbubbles("b")
     run.ploidy_estimation("b", 5, 1000)
     t = run.times()
-    print("pass %d: %.1f ms (find %.1f, ploidy %.1f); bubbles %d: snp %d pair %d stack %d trio %d wave %d; site strings %d" %
+    print("pass %d: %.1f ms (find %.1f, ploidy %.1f); bubbles %d: snp %d pair %d stack %d wave %d; site strings %d" %
           (i, (time.perf_counter() - t0) * 1e3, t["find_total_s"] * 1e3, t["ploidy_total_s"] * 1e3, t["tasks"], t["snp_jobs"], t["pair_jobs"],
-           t["stack_jobs"], t["trio_jobs"], t["wave_jobs"], t["site_strings"]), flush=True)
+           t["stack_jobs"], t["wave_jobs"], t["site_strings"]), flush=True)
 for kid, name in enumerate(hipapi.KERNELS):
     ms, cnt = C.c_double(), C.c_uint64()
     L.pf_kernel_time(ctx, kid, C.byref(ms), C.byref(cnt))

@@ -33,7 +33,7 @@ for s, e, n in seg:
         idle += s - busy_end
         if gap >= min_gap:
             print("      -- idle %7.1f us --" % gap)
-    short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0][:60]
+    short = n.replace("(anonymous namespace)::", "").replace("pf_call::", "").replace("void ", "").split("(")[0].split("<")[0][:60]
     print("%9.3f ms  %8.1f us  %s" % ((s - t0) / 1e6, (e - s) / 1e3, short))
     busy_end = max(busy_end, e)
 tail = ev[b][0] - busy_end
@@ -49,7 +49,7 @@ for k in range(0, (span + STEP - 1) // STEP):
         a_, b_ = max(s, lo), min(e, hi)
         if b_ > a_:
             pts += [(a_, 1), (b_, -1)]
-            short = n.replace("(anonymous namespace)::", "").replace("void ", "").split("(")[0].split("<")[0]
+            short = n.replace("(anonymous namespace)::", "").replace("pf_call::", "").replace("void ", "").split("(")[0].split("<")[0]
             per[short] = per.get(short, 0) + (b_ - a_)
     pts.sort()
     cur, last, none, area = 0, lo, 0, 0
