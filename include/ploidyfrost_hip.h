@@ -328,8 +328,8 @@ int pf_string_cov(pf_ctx *, const char *text, const uint64_t *str_off, uint32_t 
  * pf_call_fetch per batch.  Single-sample path (CDBG); the colored twin keeps pf_align_bubbles + pf_string_cov_colored. */
 
 /* The colored twin, CCDBG::ploidyEstimation_ptr (src/CCDBG.cpp:2759-3531), on the same pipeline.  pf_call_set_colours (once per
- * graph, after pf_upload_counts_colored) hands over what the calling phase asks of the colour sets: full_mask[u] = colours on every
- * k-mer of unitig u; size_total[u] = UnitigColors::size() with the unitig's own mapping; and for a colour on part of a unitig one
+ * graph, after pf_upload_counts_colored) hands over what the calling phase asks of the colour sets: full_mask = the colours on every
+ * k-mer of unitig u as (n_colors + 63) / 64 64-bit words per unitig (colour c = bit c % 64 of word u * words + c / 64); size_total[u] = UnitigColors::size() with the unitig's own mapping; and for a colour on part of a unitig one
  * bit per k-mer, reference orientation: entries part_first[u] .. part_first[u + 1] (N + 1 prefix) = {part_colour[e], first word
  * part_word[e] in part_bits}.  [host|dev]  With colours set, pf_call_coverage leaves readCovUni (src/CCDBG.cpp:123-156) of every
  * (colour, unitig) resident; pf_call_scan applies the per-colour gates of :2838-2931 (its lower / upper arguments are ignored:
@@ -523,8 +523,8 @@ int pf_bfs_candidates_resident(pf_ctx *, uint32_t u0, uint32_t u1, uint64_t *n_r
  * called beside the load like pf_call_reserve; the adjacency must be resident). */
 int pf_find_reserve(pf_ctx *, uint64_t n_records);
 int pf_replay_device(pf_ctx *, uint32_t complex_size, uint32_t small_limit, uint64_t *n_big, uint64_t *big_entries);
-/* Colored path (CCDBG): the colour gate of the accept commit (src/CCDBG.cpp:2530-2621) reads, per unitig, the mask of colours
- * present on every k-mer, UnitigColors::size() with the unitig's own mapping, and how many colours the pair encoding stores as
+/* Colored path (CCDBG): the colour gate of the accept commit (src/CCDBG.cpp:2530-2621) reads, per unitig, the set of colours
+ * present on every k-mer (full_mask: (n_colors + 63) / 64 words per unitig, as for pf_call_set_colours), UnitigColors::size() with the unitig's own mapping, and how many colours the pair encoding stores as
  * "full" [host|dev].  Set once per graph; pf_side_components and pf_replay_device then apply the colored commits
  * (n_colors == 0: back to the single-sample ones). */
 int pf_replay_set_colours(pf_ctx *, uint32_t n_colors, const uint64_t *full_mask, const uint64_t *size_total, const uint32_t *n_full_enc);
@@ -538,10 +538,9 @@ int pf_call_get_state(pf_ctx *, uint8_t *flags, uint32_t *plus, uint32_t *minus)
  * random access whatever the number of colours.  kmers[c] / counts[c]: n[c] records of colour c (exact
  * k-mers as stored, any order); min_count / max_count / both_strands per colour as in pf_upload_counts.
  * Requires pf_upload_graph first (k).  [host|dev per array] */
-#define PF_MAX_COLORS 62          /* colours of the RESIDENT calling pipeline (pf_call_set_colours) and of the commits on the device
-                                     (pf_replay_set_colours): colour sets as one 64-bit mask, a lane per colour in K-SITES */
-#define PF_MAX_COLORS_TABLE 1024  /* colours of the joined table, K-COV-C and K-STRCOV-C: what the host-threaded pipeline needs; graphs of
-                                     more than PF_MAX_COLORS colours run on that one (csrc/host/pf_ccdbg.cpp) */
+#define PF_MAX_COLORS_TABLE 1024  /* colours of the joined table, K-COV-C and K-STRCOV-C */
+#define PF_MAX_COLORS PF_MAX_COLORS_TABLE /* colours of the resident calling pipeline (pf_call_set_colours) and of the commits on the device
+                                     (pf_replay_set_colours): colour sets of (n_colors + 63) / 64 words, a lane per colour of a word in K-SITES */
 int pf_upload_counts_colored(pf_ctx *, uint32_t n_colors, const uint64_t *const *kmers, const uint32_t *const *counts,
                              const uint64_t *n, const uint64_t *min_count, const uint64_t *max_count, const int *both_strands);
 uint32_t pf_num_colors(const pf_ctx *);

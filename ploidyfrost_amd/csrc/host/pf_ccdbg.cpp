@@ -43,12 +43,10 @@ CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, doub
     st_.col = col_;
     const uint32_t C = cg_.colors.n_colors;
     if (C > PF_MAX_COLORS_TABLE) { fail(PF_ERR_ARG, "CCDBG::CCDBG():Error: more colours than the device table holds"); return; }
-    // More than PF_MAX_COLORS (62) colours: the reference has no limit (src/CCDBG.cpp:2759-2853 loops over getNbColors()).  The
-    // device's commits and its resident calling pipeline keep a colour set in one 64-bit register; such a graph is committed on host
-    // threads (the same Commits<> text with multi-word colour sets) and called by the host-threaded pipeline around K-COV-C,
-    // K-BUBBLE and K-STRCOV-C, whose joined table holds up to PF_MAX_COLORS_TABLE colours.
-    const bool wide = C > PF_MAX_COLORS;
-    if (!wide) {   // the colour gate of the accept commit goes to the device with the graph: the commits run there (pf_replay_device)
+    // the colour gate of the accept commit goes to the device with the graph: the commits run there (pf_replay_device).  Colour sets
+    // are (C + 63) / 64 words per unitig, on the host and on the device alike: the reference has no limit on the number of colours
+    // (src/CCDBG.cpp:2759-2853 loops over getNbColors()), the joined table's PF_MAX_COLORS_TABLE is the only one here.
+    {
         const int st = pf_replay_set_colours(ctx_, C, cg_.colors.full_mask.data(), cg_.colors.size_total.data(), cg_.colors.n_full_enc.data());
         colours_on_device_ = st == PF_OK;
     }
@@ -97,7 +95,6 @@ CCDBG::CCDBG(ColoredUnitigSet &graph, const size_t &complexsize, double &m, doub
         // the colour sets the calling phase asks about go to the device as well (pf_call_set_colours): the mask of colours on every
         // k-mer, UnitigColors::size(), and one bit per k-mer for a colour on part of a unitig
         if (const char *e = getenv("PF_CALL")) resident_ = strcmp(e, "host") != 0;
-        if (wide) resident_ = false;
         if (resident_) {
             const ColorSets &cs = cg_.colors;
             const uint32_t N = g_.n();

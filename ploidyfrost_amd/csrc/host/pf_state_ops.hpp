@@ -112,7 +112,7 @@ struct ColourGate {
     uint32_t n_colors = 0;
     int k = 0;
     const uint32_t *len_bp = nullptr;       // unitig lengths
-    uint32_t words = 1;                     // 64-bit words per unitig in full_mask: (n_colors + 63) / 64 (1 on the device: at most 62 colours there)
+    uint32_t words = 1;                     // 64-bit words per unitig in full_mask: (n_colors + 63) / 64
     const uint64_t *full_mask = nullptr;    // [u * words + c / 64] bit c % 64: colour c on every k-mer of the unitig
     const uint64_t *size_total = nullptr;   // UnitigColors::size(um) with the unitig's own mapping
     const uint32_t *n_full_enc = nullptr;   // colours the file's pair encoding stores as "full"

@@ -234,8 +234,8 @@ int pf_call_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_mas
         pf::CtxErr{ctx} = "pf_call_set_colours: the colour sets of every unitig, for the colours of the uploaded databases, are required";
         return PF_ERR_ARG;
     }
-    const size_t N = ctx->N;
-    if (!S->col_low.ensure((size_t)n_colors * 4) || !S->col_up.ensure((size_t)n_colors * 4) || !S->col_full.ensure(N * 8) || !S->col_size.ensure(N * 8) ||
+    const size_t N = ctx->N, CW = (n_colors + 63) / 64;
+    if (!S->col_low.ensure((size_t)n_colors * 4) || !S->col_up.ensure((size_t)n_colors * 4) || !S->col_full.ensure(N * CW * 8) || !S->col_size.ensure(N * 8) ||
         !S->part_first.ensure((N + 1) * 4) || !S->part_colour.ensure((n_part + 1) * 4) || !S->part_word.ensure((n_part + 1) * 8) ||
         !S->part_bits.ensure((n_words + 1) * 8)) {
         pf::CtxErr{ctx} = "pf_call_set_colours: out of device memory";
@@ -244,7 +244,7 @@ int pf_call_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_mas
     hipStream_t st = ctx->stream;
     PF_HIP(hipMemsetAsync(S->col_low.p, 0, (size_t)n_colors * 4, st));
     PF_HIP(hipMemsetAsync(S->col_up.p, 0xFF, (size_t)n_colors * 4, st));
-    PF_HIP(hipMemcpyAsync(S->col_full.p, full_mask, N * 8, hipMemcpyDefault, st));
+    PF_HIP(hipMemcpyAsync(S->col_full.p, full_mask, N * CW * 8, hipMemcpyDefault, st));
     PF_HIP(hipMemcpyAsync(S->col_size.p, size_total, N * 8, hipMemcpyDefault, st));
     PF_HIP(hipMemcpyAsync(S->part_first.p, part_first, (N + 1) * 4, hipMemcpyDefault, st));
     if (n_part) {
@@ -254,6 +254,7 @@ int pf_call_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_mas
     if (n_words) PF_HIP(hipMemcpyAsync(S->part_bits.p, part_bits, n_words * 8, hipMemcpyDefault, st));
     PF_HIP(hipStreamSynchronize(st));
     S->n_colors = n_colors;
+    S->col_words = (uint32_t)CW;
     return PF_OK;
 }
 
@@ -346,7 +347,7 @@ int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides)
     a.target = S->target.as<uint32_t>();
     a.n_colors = S->n_colors;
     a.ccov_sum = S->ccov_sum.as<uint64_t>(); a.ccov_min = S->ccov_min.as<uint32_t>(); a.ccov_max = S->ccov_max.as<uint32_t>(); a.ccov_miss = S->ccov_miss.as<uint8_t>();
-    a.clow = S->col_low.as<uint32_t>(); a.cup = S->col_up.as<uint32_t>(); a.full = S->col_full.as<uint64_t>(); a.size_total = S->col_size.as<uint64_t>();
+    a.clow = S->col_low.as<uint32_t>(); a.cup = S->col_up.as<uint32_t>(); a.full = S->col_full.as<uint64_t>(); a.cwords = S->col_words; a.size_total = S->col_size.as<uint64_t>();
     ctx_begin(ctx, PF_K_CALL_SCAN);
     if (S->n_colors) k_call_sides<true><<<(N + 255) / 256, 256, 0, st>>>(a);
     else k_call_sides<false><<<(N + 255) / 256, 256, 0, st>>>(a);
@@ -795,7 +796,7 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
         const uint64_t rows_cap = std::max<uint64_t>(256, ((uint64_t)hc.max_rows + 63) & ~63ull);
         constexpr int sites_per_cu = 16;
         for (int attempt = 0, ks_attempt = 0;; ++attempt) {
-            const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8) + (C ? rows_cap * (8 + 8 + 8ull * C) : 0)) + 255) & ~255ull;
+            const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8) + (C ? rows_cap * (16ull * S->col_words + 8ull * C + 1) : 0)) + 255) & ~255ull;
             // (tables for thousands of rows: fewer wavefronts, at most 2 GB of them)
             const int sites_grid = (int)std::max<uint64_t>(1, std::min<uint64_t>(std::min<uint32_t>(hc.n_branching, (uint32_t)(ctx->n_cu * sites_per_cu)), (2ull << 30) / sites_per_wave));
             NEED(W.sites_scr, sites_per_wave * sites_grid);
@@ -809,8 +810,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
             sa.scratch = W.sites_scr.as<uint8_t>(); sa.scratch_per_wave = sites_per_wave; sa.sv_off = O.sv_off.as<uint64_t>();
             sa.sv = O.sv.as<double>(); sa.sv_cap = sv_cap; sa.cnt = d_cnt;
             sa.n_colors = C;
-            sa.ctab = CTab{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_line_bytes}; sa.c_one_strand = ctx->ctab_one_strand; sa.c_unread = ctx->ctab_unread;
-            sa.clow = S->col_low.as<uint32_t>(); sa.cup = S->col_up.as<uint32_t>(); sa.full = S->col_full.as<uint64_t>();
+            sa.ctab = CTab{ctx->d_ctab, ctx->ctab_cap - 1, ctx->ctab_line_bytes}; sa.c_one_strand = ctx->ctab_one_strand; sa.unread = ctx->d_unread;
+            sa.clow = S->col_low.as<uint32_t>(); sa.cup = S->col_up.as<uint32_t>(); sa.full = S->col_full.as<uint64_t>(); sa.cwords = S->col_words;
             sa.part_first = S->part_first.as<uint32_t>(); sa.part_colour = S->part_colour.as<uint32_t>(); sa.part_word = S->part_word.as<uint64_t>();
             sa.part_bits = S->part_bits.as<uint64_t>(); sa.walk_pool = W.walk_pool.as<uint32_t>(); sa.walk_off = W.walk_off.as<uint64_t>();
             sa.seq = ctx->d_seq; sa.off = ctx->d_off; sa.len = ctx->d_len;
@@ -1074,7 +1075,7 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     fa.packed = S->pack_alignseq ? 1 : 0;
     size_t at = 0;
     ctx_begin_at(ctx, PF_K_CALL_FORMAT, st, &at);
-    fa.n_colors = S->n_colors; fa.N = ctx->N; fa.k = ctx->k; fa.full = S->col_full.as<uint64_t>(); fa.ccov_sum = S->ccov_sum.as<uint64_t>();
+    fa.n_colors = S->n_colors; fa.N = ctx->N; fa.k = ctx->k; fa.full = S->col_full.as<uint64_t>(); fa.cwords = S->col_words; fa.ccov_sum = S->ccov_sum.as<uint64_t>();
     if (S->n_colors) k_call_format<false, true><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     else k_call_format<false, false><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end_at(ctx, at, st);

@@ -108,10 +108,10 @@ struct CallState {
     // C1 results, one slot per unitig (two per unitig for a database without canonical counting)
     DevBuf cov_sum, cov_min, cov_miss;
     bool have_cov = false, per_strand = false;
-    // colored path (pf_call_set_colours): cutoffs per colour, the colour sets the calling phase asks about -- per unitig the mask of
-    // colours on every k-mer and UnitigColors::size(); for a colour on part of a unitig one bit per k-mer (reference orientation):
+    // colored path (pf_call_set_colours): cutoffs per colour, the colour sets the calling phase asks about -- per unitig the set of
+    // colours on every k-mer (col_words 64-bit words) and UnitigColors::size(); for a colour on part of a unitig one bit per k-mer (reference orientation):
     // entries part_first[u] .. part_first[u + 1] = {colour, first word in part_bits} -- and K-COV-C's results, colour-major
-    uint32_t n_colors = 0;
+    uint32_t n_colors = 0, col_words = 1;
     DevBuf col_low, col_up, col_full, col_size, part_first, part_colour, part_word, part_bits;
     DevBuf ccov_sum, ccov_min, ccov_max, ccov_miss;
     std::atomic<uint32_t> sites_ks{0};   // K-SITES: room per site string once a launch asked for more than 2k + 64
@@ -204,6 +204,11 @@ struct CallState {
 
 namespace pf_call {
 
+// colour c in the set of unitig u: sets of `words` 64-bit words per unitig, bit c % 64 of word c / 64
+__device__ inline bool colour_in(const uint64_t *__restrict__ full, uint32_t words, uint32_t u, uint32_t c) {
+    return (full[(size_t)u * words + (c >> 6)] >> (c & 63)) & 1;
+}
+
 inline CallState *state_of(pf_ctx *ctx) {
     if (!ctx->call) {
         ctx->call = new CallState();
@@ -235,7 +240,8 @@ struct ScanArgs {
     const uint32_t *ccov_min, *ccov_max;
     const uint8_t *ccov_miss;
     const uint32_t *clow, *cup;
-    const uint64_t *full, *size_total;
+    const uint64_t *full, *size_total;   // full: cwords 64-bit words per unitig (colour_in)
+    uint32_t cwords;
 };
 
 struct ResolveArgs {
@@ -498,9 +504,10 @@ struct SiteArgs {
     uint32_t n_colors;
     CTab ctab;
     int c_one_strand;
-    uint64_t c_unread;
+    const uint8_t *unread;    // per colour: its database is never looked up (written without canonical counting)
     const uint32_t *clow, *cup;
     const uint64_t *full;
+    uint32_t cwords;          // 64-bit words of a colour set: (n_colors + 63) / 64
     const uint32_t *part_first, *part_colour;
     const uint64_t *part_word, *part_bits;
     const uint32_t *walk_pool;
@@ -532,7 +539,7 @@ struct FmtArgs {
     int packed;               // alignseq leaves as out[S_PACK] = index + records (pf_alnpack.hpp); out[PF_OUT_ALIGNSEQ] is not written
     CallCounters *cnt;
     // colored (CCDBG): a site gives one row per colour that sees two allele groups or more (src/CCDBG.cpp:2971-3059, 3236-3339)
-    uint32_t n_colors, N;
+    uint32_t n_colors, N, cwords;
     int k;
     const uint64_t *full, *ccov_sum;
 };

@@ -152,10 +152,9 @@ __global__ __launch_bounds__(256) void k_call_sides(ScanArgs a) {
                         if (w == NONE) continue;
                         const uint32_t wu = w >> 1;
                         t.inner[t.n_inner++] = w;
-                        const uint64_t fm = a.full[wu];
                         uint32_t jn = 0;
                         for (uint32_t c = 0; c < C; ++c) {
-                            if (!((fm >> c) & 1)) continue;
+                            if (!colour_in(a.full, a.cwords, wu, c)) continue;
                             ++jn;
                             if (!cc.ok(c, wu)) { flag = false; break; }
                         }
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(256) void k_call_sides(ScanArgs a) {
                             int nz = 0;
                             for (uint32_t q = 0; q < path; ++q) {
                                 const uint32_t wu = t.inner[q] >> 1;
-                                nz += ((a.full[wu] >> c) & 1) && cc.mean(c, wu, len_km(wu)) != 0.0;
+                                nz += colour_in(a.full, a.cwords, wu, c) && cc.mean(c, wu, len_km(wu)) != 0.0;
                             }
                             flag = nz > 1;
                         }

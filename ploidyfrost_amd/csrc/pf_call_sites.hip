@@ -9,7 +9,7 @@ namespace pf_call {
 // UnitigColors::contains(um, colour) (bifrost/src/ColorSet.cpp:776-823) for the mapping [dist, dist + n_km) of unitig u: the colour
 // on every one of those k-mers
 __device__ inline bool colour_contains(const SiteArgs &a, uint32_t u, uint32_t c, uint32_t dist, uint32_t n_km) {
-    if ((a.full[u] >> c) & 1) return true;
+    if (colour_in(a.full, a.cwords, u, c)) return true;
     for (uint32_t e = a.part_first[u]; e < a.part_first[u + 1]; ++e) {
         if (a.part_colour[e] != c) continue;
         const uint64_t *bits = a.part_bits + a.part_word[e];
@@ -22,18 +22,19 @@ __device__ inline bool colour_contains(const SiteArgs &a, uint32_t u, uint32_t c
 
 // cdbg.findUnitig(s, 0, len) of src/CCDBG.cpp:3251, 3390 followed by UnitigColors::contains on that mapping, for one site string:
 // its first k-mer lies on one of the bubble's unitigs (a k-mer occurs once in the graph, in one orientation); the mapping is extended
-// along that unitig while the characters agree (CompactedDBG.tcc:3815-3837, CompressedSequence.cpp:497-520).  Returns the mask of
-// colours present on every k-mer of the mapping; found = false when no unitig of the bubble holds the first k-mer.
-__device__ inline uint64_t colours_of_string(const SiteArgs &a, const char *sp, uint32_t lp, const uint32_t *walk, uint32_t n_walk, bool &found) {
+// along that unitig while the characters agree (CompactedDBG.tcc:3815-3837, CompressedSequence.cpp:497-520).  Leaves the set of
+// colours present on every k-mer of the mapping in out[0 .. a.cwords) (bit c % 64 of word c / 64); false when no unitig of the
+// bubble holds the first k-mer.
+__device__ inline bool colours_of_string(const SiteArgs &a, const char *sp, uint32_t lp, const uint32_t *walk, uint32_t n_walk, uint64_t *out) {
     const int k = a.k;
     const uint64_t kmask = (1ull << (2 * k)) - 1;
-    found = false;
-    if (lp < (uint32_t)k) return 0;
+    for (uint32_t w = 0; w < a.cwords; ++w) out[w] = 0;
+    if (lp < (uint32_t)k) return false;
     auto code = [](char ch) -> int { return ch == 'A' ? 0 : ch == 'C' ? 1 : ch == 'G' ? 2 : ch == 'T' ? 3 : -1; };
     uint64_t head = 0;
     for (int i = 0; i < k; ++i) {
         const int b = code(sp[i]);
-        if (b < 0) return 0;   // (a gap character never matches a unitig)
+        if (b < 0) return false;   // (a gap character never matches a unitig)
         head = (head << 2) | (uint64_t)b;
     }
     const uint64_t rhead = rc_kmer(head, k);
@@ -67,13 +68,11 @@ __device__ inline uint64_t colours_of_string(const SiteArgs &a, const char *sp, 
             n_km = jn - (uint32_t)k + 1;
             dist = p0 - (n_km - 1);
         }
-        uint64_t m = 0;
         for (uint32_t c = 0; c < a.n_colors; ++c)
-            if (colour_contains(a, u, c, dist, n_km)) m |= 1ull << c;
-        found = true;
-        return m;
+            if (colour_contains(a, u, c, dist, n_km)) out[c >> 6] |= 1ull << (c & 63);
+        return true;
     }
-    return 0;
+    return false;
 }
 
 template <bool COLORED>
@@ -93,10 +92,13 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
     uint8_t *dup = reinterpret_cast<uint8_t *>(rank + RC);
     uint8_t *sok = dup + RC;
     double *mean = reinterpret_cast<double *>(sok + RC);
-    // colored, per row: the colours its string's mapping carries in full, the colours whose range test it passed, its mean per colour
-    uint64_t *cmask = reinterpret_cast<uint64_t *>(mean + RC);
-    uint64_t *cokm = cmask + RC;
-    double *cmean = reinterpret_cast<double *>(cokm + RC);   // [rows_cap][C]
+    // colored, per row: the colours its string's mapping carries in full and the colours whose range test it passed (sets of CW
+    // 64-bit words), its mean per colour, and whether findUnitig found nothing for it
+    const uint32_t CW = COLORED ? a.cwords : 1;
+    uint64_t *cmask = reinterpret_cast<uint64_t *>(mean + RC);   // [rows_cap][CW]
+    uint64_t *cokm = cmask + RC * CW;                            // [rows_cap][CW]
+    double *cmean = reinterpret_cast<double *>(cokm + RC * CW);  // [rows_cap][C]
+    uint8_t *cnf = reinterpret_cast<uint8_t *>(cmean + RC * C);  // [rows_cap]
     const uint64_t kmask = (1ull << (2 * k)) - 1;
     const uint32_t n_branching = a.cnt->n_branching;
     unsigned long long my_strings = 0;   // (added to the batch's count once, at the end)
@@ -402,7 +404,8 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                     if (COLORED) {
                         if (!d) {
                             // readCov(string, low, up, c) (src/CCDBG.cpp:89-122) for every colour: one look at the joined table per k-mer
-                            uint64_t okm = C >= 64 ? ~0ull : ((1ull << C) - 1);
+                            uint64_t *okw = cokm + (size_t)p * CW;
+                            for (uint32_t w = 0; w < CW; ++w) okw[w] = C - 64 * w >= 64 ? ~0ull : ((1ull << (C - 64 * w)) - 1);
                             uint64_t *cs = reinterpret_cast<uint64_t *>(cmean + (size_t)p * C);
                             for (uint32_t c = 0; c < C; ++c) cs[c] = 0;
                             StringWindow win;
@@ -411,19 +414,22 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
                                 if (c0 + 1 < (uint32_t)k) continue;
                                 const uint32_t *sa, *sb;
                                 colored_slots(a.ctab, x, k, a.c_one_strand != 0, sa, sb);
-                                for (uint32_t c = 0; c < C; ++c) {
-                                    if (!((okm >> c) & 1) || ((a.c_unread >> c) & 1)) continue;   // (a colour never looked up: (0, true))
-                                    const uint32_t cnt = ctab_count(sa, sb, c);
-                                    if (cnt != CTAB_MISSING && cnt > a.clow[c] && cnt < a.cup[c]) cs[c] += cnt;
-                                    else { cs[c] = 0; okm &= ~(1ull << c); }   // missing or outside (low, up): (0, false), :105-117
+                                for (uint32_t w = 0; w < CW; ++w) {
+                                    uint64_t okm = okw[w];
+                                    const uint32_t c_end = C - 64 * w >= 64 ? 64 * w + 64 : C;
+                                    for (uint32_t c = 64 * w; c < c_end; ++c) {
+                                        if (!((okm >> (c & 63)) & 1) || a.unread[c]) continue;   // (a colour never looked up: (0, true))
+                                        const uint32_t cnt = ctab_count(sa, sb, c);
+                                        if (cnt != CTAB_MISSING && cnt > a.clow[c] && cnt < a.cup[c]) cs[c] += cnt;
+                                        else { cs[c] = 0; okm &= ~(1ull << (c & 63)); }   // missing or outside (low, up): (0, false), :105-117
+                                    }
+                                    okw[w] = okm;
                                 }
                             }
                             for (uint32_t c = 0; c < C; ++c) cmean[(size_t)p * C + c] = (double)cs[c] / (double)((uint64_t)lp - (uint64_t)k + 1);
-                            cokm[p] = okm;
                             const uint64_t wf = a.walk_off[j];
-                            bool found;
-                            cmask[p] = colours_of_string(a, sp, lp, a.walk_pool + (wf & ((1ull << 40) - 1)), (uint32_t)(wf >> 40), found);
-                            if (!found) cmask[p] = 1ull << 63;   // (findUnitig finds nothing: fatal in the reference IF the walk below reaches this string)
+                            // (findUnitig finds nothing: fatal in the reference IF the walk below reaches this string)
+                            cnf[p] = colours_of_string(a, sp, lp, a.walk_pool + (wf & ((1ull << 40) - 1)), (uint32_t)(wf >> 40), cmask + (size_t)p * CW) ? 0 : 1;
                         }
                     } else if (!d) {
                         uint64_t sum = 0;
@@ -453,35 +459,42 @@ __global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
             if (COLORED) {
                 // src/CCDBG.cpp:3236-3339, 3374-3475: per allele group its strings in set order; a colour the string's mapping carries
                 // in full adds the string's mean to [colour][group]; a failed range test of such a colour, or a colour no string
-                // carries, drops the site.  Lane c keeps colour c's sums.
-                bool ok = true;
-                uint64_t seen = 0;
-                for (uint32_t gi = 0; gi < maxnum; ++gi) {
-                    double tc = 0.0;
-                    uint32_t last = 0;
-                    bool have_last = false;
-                    while (ok) {
-                        uint32_t best = 0xFFFFFFFFu, bp = 0;
-                        for (uint32_t p = 0; p < R; ++p) {
-                            if (grp[p] != gi + 1 || dup[p]) continue;
-                            const uint32_t rk = rank[p];
-                            if (have_last && rk <= last) continue;
-                            if (rk < best) { best = rk; bp = p; }
+                // carries, drops the site.  Lane l keeps the sums of colour 64 w + l, one word w of the colour sets after the other (the
+                // walk over the strings does not depend on the word, so every round takes the same steps and ends the same way).
+                bool ok = true, all_seen = true;
+                for (uint32_t w = 0; w < CW && !fatal; ++w) {
+                    const uint32_t c = 64 * w + (uint32_t)lane;
+                    uint64_t seen = 0;
+                    ok = true;
+                    for (uint32_t gi = 0; gi < maxnum; ++gi) {
+                        double tc = 0.0;
+                        uint32_t last = 0;
+                        bool have_last = false;
+                        while (ok) {
+                            uint32_t best = 0xFFFFFFFFu, bp = 0;
+                            for (uint32_t p = 0; p < R; ++p) {
+                                if (grp[p] != gi + 1 || dup[p]) continue;
+                                const uint32_t rk = rank[p];
+                                if (have_last && rk <= last) continue;
+                                if (rk < best) { best = rk; bp = p; }
+                            }
+                            if (best == 0xFFFFFFFFu) break;
+                            if (cnf[bp]) { fatal = true; ok = false; break; }
+                            const uint64_t *mw = cmask + (size_t)bp * CW, *kw = cokm + (size_t)bp * CW;
+                            const uint64_t m = mw[w];
+                            seen |= m;
+                            for (uint32_t x = 0; x < CW && ok; ++x) ok = !(mw[x] & ~kw[x]);
+                            if (!ok) break;
+                            if (c < C && ((m >> lane) & 1)) tc += cmean[(size_t)bp * C + c];
+                            last = best;
+                            have_last = true;
                         }
-                        if (best == 0xFFFFFFFFu) break;
-                        const uint64_t m = cmask[bp];
-                        if (m >> 63) { fatal = true; ok = false; break; }
-                        seen |= m;
-                        if (m & ~cokm[bp]) { ok = false; break; }
-                        if ((uint32_t)lane < C && ((m >> lane) & 1)) tc += cmean[(size_t)bp * C + lane];
-                        last = best;
-                        have_last = true;
+                        if (c < C && room) a.sv[vcur + (uint64_t)c * maxnum + gi] = tc;
                     }
-                    if ((uint32_t)lane < C && room) a.sv[vcur + (uint64_t)lane * maxnum + gi] = tc;
+                    all_seen = all_seen && seen == (C - 64 * w >= 64 ? ~0ull : ((1ull << (C - 64 * w)) - 1));
                 }
                 if (fatal) { err = 64; break; }
-                const uint64_t all_colours = C >= 64 ? ~0ull : ((1ull << C) - 1);
-                const bool valid = ok && seen == all_colours;
+                const bool valid = ok && all_seen;
                 if (lane == 0 && room) a.sv[vcur + (uint64_t)C * maxnum] = valid ? 1.0 : 0.0;
                 if (lane == 0) a.osites[r.site_off + si].pad_ = valid ? 1 : 0;
                 vcur += (uint64_t)C * maxnum + 1;

@@ -194,17 +194,15 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
                     }
                     // strict: the [colour][path] matrix of the scan, again from K-COV-C's results (an entry = the mean coverage of the
                     // path's unitig in a colour that has it in full, else 0), paths as sorted there
-                    uint64_t fm[4] = {0, 0, 0, 0};
                     uint32_t wu[4] = {0, 0, 0, 0}, lk[4] = {1, 1, 1, 1};
                     if (t.strict)
                         for (uint32_t p = 0; p < R && p < 4; ++p) {
                             wu[p] = t.inner[p] >> 1;
-                            fm[p] = a.full[wu[p]];
                             lk[p] = a.len[wu[p]] - (uint32_t)a.k + 1;
                         }
                     auto m_at = [&](uint32_t c, uint32_t p) -> double {
                         const uint32_t q = p < 4 ? p : 3;
-                        return ((fm[q] >> c) & 1) ? (double)a.ccov_sum[(size_t)c * a.N + wu[q]] / (double)lk[q] : 0.0;
+                        return colour_in(a.full, a.cwords, wu[q], c) ? (double)a.ccov_sum[(size_t)c * a.N + wu[q]] / (double)lk[q] : 0.0;
                     };
                     auto gc_at = [&](uint32_t c, uint32_t x) -> double {   // coverage of allele group x in colour c
                         if (!t.strict) return cvals[(size_t)c * maxnum + x];

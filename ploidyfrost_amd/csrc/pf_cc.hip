@@ -363,6 +363,7 @@ pfh::ColourGate gate_of(const pf_ctx *ctx, const CcState *S) {
     pfh::ColourGate g;
     if (!S->n_colors) return g;   // (n_colors == 0: no gate)
     g.n_colors = S->n_colors;
+    g.words = (S->n_colors + 63) / 64;
     g.k = ctx->k;
     g.len_bp = ctx->d_len;
     g.full_mask = S->full_mask;
@@ -582,7 +583,7 @@ int pf_replay_order(pf_ctx *ctx, uint32_t n_classes, uint32_t *order, uint32_t *
 
 // colored path: what the colour gate of the accept commit reads (src/CCDBG.cpp:2530-2621), per unitig; n_colors == 0 removes it
 int pf_replay_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_mask, const uint64_t *size_total, const uint32_t *n_full_enc) {
-    if (!ctx || !ctx->has_adj || n_colors > 64 || (n_colors && (!full_mask || !size_total || !n_full_enc))) return PF_ERR_ARG;
+    if (!ctx || !ctx->has_adj || n_colors > PF_MAX_COLORS || (n_colors && (!full_mask || !size_total || !n_full_enc))) return PF_ERR_ARG;
     PF_HIP(hipSetDevice(ctx->device));
     if (!ctx->cc) ctx->cc = new CcState();
     CcState *S = static_cast<CcState *>(ctx->cc);
@@ -591,10 +592,11 @@ int pf_replay_set_colours(pf_ctx *ctx, uint32_t n_colors, const uint64_t *full_m
     S->n_colors = 0;
     if (!n_colors) return PF_OK;
     const size_t N = ctx->N;
-    PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->full_mask), N * 8));
+    const size_t CW = (n_colors + 63) / 64;   // 64-bit words of a colour set
+    PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->full_mask), N * CW * 8));
     PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->size_total), N * 8));
     PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->n_full_enc), N * 4));
-    PF_HIP(hipMemcpy(S->full_mask, full_mask, N * 8, hipMemcpyDefault));
+    PF_HIP(hipMemcpy(S->full_mask, full_mask, N * CW * 8, hipMemcpyDefault));
     PF_HIP(hipMemcpy(S->size_total, size_total, N * 8, hipMemcpyDefault));
     PF_HIP(hipMemcpy(S->n_full_enc, n_full_enc, N * 4, hipMemcpyDefault));
     S->n_colors = n_colors;
