@@ -108,6 +108,14 @@ int read_table(const std::string &path, size_t ncol, const std::vector<size_t> &
             t.col[c].is_int = false;
             char *end = nullptr;
             x = strtod(f[c].c_str(), &end);
+            // strtod takes more than R's scan() does ("nan", "-nan", "inf", hex floats), and what R does take of those (NA, NaN, Inf)
+            // turns a row predicate into NA, for which `x[cond, ]` emits a row of NAs instead of dropping the row.  The path's own
+            // files can hold such a cell (a Cramer's V of 0 / 0 prints as "-nan"); with nothing to pin R's answer to, refuse it.
+            if (f[c] == "NA" || (end != f[c].c_str() && !*end && (!std::isfinite(x) || f[c].find_first_of("xX") != std::string::npos))) {
+                err = "pf_filter: cell '" + f[c] + "' in line " + std::to_string(lineno) + " of " + path +
+                      " is not a finite decimal number; R reads it as NA/NaN/Inf (or not at all) and the scripts' row predicates then give NA rows -- refused (parity unpinned)";
+                return 1;
+            }
             if (end == f[c].c_str() || *end) {
                 err = "Error in scan(file = file, what = what, sep = sep, quote = quote, dec = dec,  : \n  scan() expected 'a real', got '" + f[c] + "' (" + path + ")";
                 return 1;

@@ -5,7 +5,9 @@
 // digits, fixed or scientific by width).
 //
 // PARITY UNPINNED: R is not installed in the build image, so no output of the reference's scripts exists to hold this to; the
-// expected rows of the tests are worked out by hand from the scripts' text (tests/test_filter_cpu.py).
+// expected rows of the tests are worked out by hand from the scripts' text (tests/test_filter_cpu.py).  One divergence is closed by
+// refusal rather than emulation: a cell that is not a finite decimal number ("nan", "-nan", "inf", "NA", hex floats) -- R would read
+// some of these as NA and write rows of NAs -- ends the run with an error that names the cell.
 #pragma once
 #include <string>
 #include <vector>

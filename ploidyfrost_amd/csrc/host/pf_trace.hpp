@@ -14,6 +14,7 @@ namespace pfh {
 struct LoadLog {
     std::mutex mu;
     std::vector<std::pair<std::string, double>> steps;
+    static constexpr size_t kMaxSteps = 4096;   // the log of a process that never asks for it (pfh_load_trace(reset = 1)) stays this small
     static LoadLog &get() {
         static LoadLog l;
         return l;
@@ -29,6 +30,7 @@ struct LoadTrace {
         {
             LoadLog &l = LoadLog::get();
             std::lock_guard<std::mutex> lk(l.mu);
+            if (l.steps.size() >= LoadLog::kMaxSteps) l.steps.erase(l.steps.begin(), l.steps.begin() + LoadLog::kMaxSteps / 2);   // (a long-lived embedder: the newest half stays)
             l.steps.emplace_back(what, s);
         }
         if (on) fprintf(stderr, "[load] %-28s %.3fs\n", what, s);

@@ -141,3 +141,16 @@ def test_numbers_as_write_table_renders_them():
     assert f(123456.0) == "123456" and f(0.0001) == "1e-04" and f(0.00012) == "0.00012" and f(1e-5) == "1e-05"
     assert f(1 / 3) == "0.333333333333333" and f(2 / 3) == "0.666666666666667" and f(-2.5) == "-2.5"
     assert f(0.3333333) == "0.3333333" and f(1e15) == "1e+15" and f(123456789012.0) == "123456789012"
+
+
+@pytest.mark.parametrize("cell", ["nan", "-nan", "inf", "NA", "0x1p3"])
+def test_a_cell_r_would_read_as_na_is_refused_by_name(tables, cell):
+    """R's scan() turns such a cell into NA (or stops), and `x[cond, ]` with an NA condition writes a row of NAs; with no R here to
+    pin that, the cell is an error -- never a silently different filter (pf_filter.hpp, PARITY UNPINNED)"""
+    lines = BICOV.splitlines()
+    f = lines[1].split("\t")
+    f[0] = cell
+    lines[1] = "\t".join(f)
+    (tables / "in_bicov.txt").write_text("\n".join(lines) + "\n")
+    r = run(["filter", "-i", "in", "-o", "out", "-l", "5", "-u", "1000"], tables)
+    assert r.returncode != 0 and cell in r.stderr and "line 2" in r.stderr, r.stderr
