@@ -846,9 +846,15 @@ def main():
             # the model the first hardware scaling curve can be checked against: every rank repeats the look-ups, findSuperBubble and the
             # owner scan; only the rest of PloidyEstimation (alignment, text, files) is cut over the ranks; two small all-gathers
             hp_ = {k_: v_ / args.steps for k_, v_ in phase.items()}
-            cut_ms = max(0.0, (hp_["ploidy_total_s"] - hp_["scan_s"]) * 1e3) * (world if strong else 1)   # (a cut run measures its own slice)
             step_ms = max_elapsed / args.steps * 1e3
-            rep_ms = max(0.0, step_ms - cut_ms / (world if strong else 1))
+            if strong:
+                # a cut run: rank 0's findSuperBubble (the look-ups run beside it) and owner scan are what every rank repeated; the
+                # rest of the step is this run's slice of the cut part
+                rep_ms = min(step_ms, (hp_["find_total_s"] + hp_["scan_s"]) * 1e3)
+                cut_ms = (step_ms - rep_ms) * world
+            else:
+                cut_ms = max(0.0, (hp_["ploidy_total_s"] - hp_["scan_s"]) * 1e3)
+                rep_ms = max(0.0, step_ms - cut_ms)
             out["predicted_scaling"] = {
                 "model": "ms(N) = replicated + cut / N; replicated = K-COV-JOIN + findSuperBubble + owner scan of this run, cut = the rest of PloidyEstimation "
                          "(alignment, text, files); the two all-gathers (< 0.1 ms over xGMI) left out",
