@@ -773,6 +773,7 @@ def main():
                 "ms_per_step": round(max_elapsed / args.steps * 1e3, 2),
                 # rank 0's own steps (a step returns with its files complete)
                 "ms_per_step_min": d_incl["min"], "ms_per_step_median": d_incl["median"], "ms_per_step_p95": d_incl["p95"],
+                "ms_each_step": [round(x_ * 1e3, 2) for x_ in step_s],
                 "timed_region": {"per_step": ("K-COV-JOIN (every graph k-mer looked up in the count table; on its own stream beside findSuperBubble) + findSuperBubble + PloidyEstimation"
                                               if join_in_step[0] else "findSuperBubble + PloidyEstimation"),
                                  "seconds": round(max_elapsed, 3),

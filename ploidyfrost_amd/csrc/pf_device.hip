@@ -919,9 +919,16 @@ int join_graph_counts_begin(pf_ctx *ctx) {
     const uint64_t n_rows = (ctx->n_kmers + 63) / 64;
     const uint64_t n_waves = ((n_rows + JOIN_ROWS_PER_WAVE - 1) / JOIN_ROWS_PER_WAVE + 3) / 4 * 4;
     const int blocks = (int)(n_waves / 4);
-    const uint32_t rest_cap = JOIN_ROWS_PER_WAVE * 64 * 4 / 10;
-    const uint32_t rest_stride = rest_cap + 1;   // + the slot the lanes with nothing to hand on write to
-    JoinRest *rest = (JoinRest *)ctx_ws(ctx, WS_JOIN_REST, n_waves * rest_stride * sizeof(JoinRest));
+    // a slice holds every k-mer of its wavefront's rows (16 B each: 3.7 GB at 233 M k-mers, of which the sixth that is written is
+    // touched): no slice is ever full.  Slices of four tenths made one wavefront in some dozens look its rows up a second time --
+    // 0.4 of the join's 4.4 ms.  (Where that much memory is not to be had, the slices are the smaller ones and the redo stays.)
+    uint32_t rest_cap = JOIN_ROWS_PER_WAVE * 64;
+    JoinRest *rest = (JoinRest *)ctx_ws(ctx, WS_JOIN_REST, n_waves * (rest_cap + 1) * sizeof(JoinRest));   // (+ 1: the slot the lanes with nothing to hand on write to)
+    if (!rest) {
+        (void)hipGetLastError();
+        rest_cap = JOIN_ROWS_PER_WAVE * 64 * 4 / 10;
+        rest = (JoinRest *)ctx_ws(ctx, WS_JOIN_REST, n_waves * (rest_cap + 1) * sizeof(JoinRest));
+    }
     uint32_t *rest_n = (uint32_t *)ctx_ws(ctx, WS_JOIN_REST_N, n_waves * 4);
     if (!rest || !rest_n) { pf::CtxErr{ctx} = "no room for K-COV-JOIN's hand-over list"; return PF_ERR_HIP; }
     if (!ctx->join_done) PF_HIP(hipEventCreateWithFlags(&ctx->join_done, hipEventDisableTiming));
