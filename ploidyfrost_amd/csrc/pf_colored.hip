@@ -374,13 +374,8 @@ int join_graph_counts_colored_begin(pf_ctx *ctx) {
         const uint64_t n_rows = (ctx->n_kmers + 63) / 64;
         const uint64_t n_waves = ((n_rows + ROWS - 1) / ROWS + 3) / 4 * 4;
         const int blocks = (int)(n_waves / 4);
-        uint32_t rest_cap = ROWS * 64;   // (every k-mer of the wavefront's rows: no slice is ever full; see join_graph_counts_begin)
+        const uint32_t rest_cap = ROWS * 64 / 2;   // (half of the k-mers of the wavefront's rows: join_graph_counts_begin says why)
         JoinRestC *rest = (JoinRestC *)ctx_ws(ctx, WS_JOIN_REST, n_waves * (rest_cap + 1) * sizeof(JoinRestC));
-        if (!rest) {
-            (void)hipGetLastError();
-            rest_cap = ROWS * 64 * 4 / 10;
-            rest = (JoinRestC *)ctx_ws(ctx, WS_JOIN_REST, n_waves * (rest_cap + 1) * sizeof(JoinRestC));
-        }
         uint32_t *rest_n = (uint32_t *)ctx_ws(ctx, WS_JOIN_REST_N, n_waves * 4);
         if (!rest || !rest_n) { pf::CtxErr{ctx} = "no room for K-COV-C-JOIN's hand-over list"; return PF_ERR_HIP; }
         (void)ctx_begin_at(ctx, PF_K_COV_JOIN, st, &at);

@@ -344,7 +344,7 @@ __global__ __launch_bounds__(256) void k_cov(const CountLine *__restrict__ t, ui
 // retired in the order they were issued.
 // A key that is not in the first line of its sequence (one in six: the line was full) would stall that pipeline for the three
 // further loads of its buddy line: the lane writes (k-mer index, k-mer) to its wavefront's slice of `rest` instead, and
-// k_cov_join_rest looks those up afterwards (a slice that is full -- four k-mers in ten of the wavefront's rows missed their first
+// k_cov_join_rest looks those up afterwards (a slice that is full -- every second k-mer of the wavefront's rows missed its first
 // line: a stretch of repeats -- makes k_cov_join_rest look all of those rows up again).
 struct JoinRest {
     uint64_t g, fwd;
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256) void k_cov_join(const CountLine *__restrict__ 
     if (lane == 0) rest_n[wave] = n_rest;   // above rest_cap: the slice was full, k_cov_join_rest takes the wavefront's rows again
 }
 
-// the look-ups K-COV-JOIN's pipeline handed on: wavefront w takes slice w.  A slice that was full (more than four k-mers in ten of
+// the look-ups K-COV-JOIN's pipeline handed on: wavefront w takes slice w.  A slice that was full (more than half of the k-mers of
 // the wavefront's rows missed their first line: a stretch of repeats) holds only some of them: that wavefront's rows are looked up
 // again from the graph, every look-up walked to its end where it stands.
 __global__ __launch_bounds__(256) void k_cov_join_rest(const CountLine *__restrict__ t, uint64_t mask, int k, bool one_strand,
@@ -919,16 +919,12 @@ int join_graph_counts_begin(pf_ctx *ctx) {
     const uint64_t n_rows = (ctx->n_kmers + 63) / 64;
     const uint64_t n_waves = ((n_rows + JOIN_ROWS_PER_WAVE - 1) / JOIN_ROWS_PER_WAVE + 3) / 4 * 4;
     const int blocks = (int)(n_waves / 4);
-    // a slice holds every k-mer of its wavefront's rows (16 B each: 3.7 GB at 233 M k-mers, of which the sixth that is written is
-    // touched): no slice is ever full.  Slices of four tenths made one wavefront in some dozens look its rows up a second time --
-    // 0.4 of the join's 4.4 ms.  (Where that much memory is not to be had, the slices are the smaller ones and the redo stays.)
-    uint32_t rest_cap = JOIN_ROWS_PER_WAVE * 64;
+    // a slice holds half of the k-mers of its wavefront's rows (a sixth is what the average wavefront hands on).  Slices of four
+    // tenths made one wavefront in some dozens look its rows up a second time -- 0.3 of the join's 4.4 ms; slices of five, six, eight,
+    // ten tenths measure alike (4.05 - 4.1 ms), and a list of every k-mer (3.7 GB) is a tenth of a second of hipMalloc and process
+    // exit that a run of one pass does not get back.
+    const uint32_t rest_cap = JOIN_ROWS_PER_WAVE * 64 / 2;
     JoinRest *rest = (JoinRest *)ctx_ws(ctx, WS_JOIN_REST, n_waves * (rest_cap + 1) * sizeof(JoinRest));   // (+ 1: the slot the lanes with nothing to hand on write to)
-    if (!rest) {
-        (void)hipGetLastError();
-        rest_cap = JOIN_ROWS_PER_WAVE * 64 * 4 / 10;
-        rest = (JoinRest *)ctx_ws(ctx, WS_JOIN_REST, n_waves * (rest_cap + 1) * sizeof(JoinRest));
-    }
     uint32_t *rest_n = (uint32_t *)ctx_ws(ctx, WS_JOIN_REST_N, n_waves * 4);
     if (!rest || !rest_n) { pf::CtxErr{ctx} = "no room for K-COV-JOIN's hand-over list"; return PF_ERR_HIP; }
     if (!ctx->join_done) PF_HIP(hipEventCreateWithFlags(&ctx->join_done, hipEventDisableTiming));
