@@ -418,16 +418,18 @@ int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *ou
 int pf_call_set_alignseq_packed(pf_ctx *, int on);
 /* Takes the device buffers pf_call_align(_lane) would take on its first call for ranges of up to n_bubbles bubbles -- to be called
  * beside the load, so that a one-shot run does not pay its first alignment launch with two dozen allocations.  A hint: sizes that
- * turn out too small grow in pf_call_align as before.  Needs pf_call_set_state / pf_call_coverage / any other pf_call_* call first
- * only in that the graph must be resident. */
+ * turn out too small grow in pf_call_align as before.  Needs nothing but the context: it may run on a helper thread while another
+ * thread loads graph and count table into the same context (pf_gfa_parse, pf_upload_graph, pf_kmc_decode, pf_upload_counts) -- it
+ * touches none of what those calls read or write; the first pf_call_* call of the run must come after it has returned. */
 int pf_call_reserve(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size);
 /* The same for the first n_lanes lanes (1 .. PF_CALL_LANES; pf_call_reserve takes two): a caller that aligns several ranges side by
  * side (pf_call_align_lane below) takes every lane's working set beside the load. */
 int pf_call_reserve_lanes(pf_ctx *, uint64_t n_bubbles, uint32_t complex_size, int n_lanes);
 /* The same for the text stage: what the first pf_call_text_range(_lane) of a run would take for pieces of up to piece_bubbles
- * bubbles (its two streams, the size tables, the text slabs by an estimate from k), and K-TEXT's two passes once over no bubbles on
+ * bubbles (its two streams, the size tables, the text slabs by an estimate for k = 31), and K-TEXT's two passes once over no bubbles on
  * each stream: the first launch of a kernel that spills pays for the queue's scratch (2 ms inside a first piece otherwise).
- * pf_call_reserve does the same for K-BUBBLE's class streams (13 ms of a first PloidyEstimation at 5 M unitigs). */
+ * pf_call_reserve does the same for K-BUBBLE's class streams (13 ms of a first PloidyEstimation at 5 M unitigs).  Beside the load
+ * like pf_call_reserve (single-sample path; with colours, after pf_call_set_colours). */
 int pf_call_reserve_text(pf_ctx *, uint64_t piece_bubbles);
 /* What pf_call_align(_lane) left resident for the bubbles of its range, before any text is made of it -- the kernel-level view the
  * parity tests hold against SeqAlign::SequenceAlignment (src/SeqAlign.cpp:550-640) bubble by bubble: per bubble its endpoints and,

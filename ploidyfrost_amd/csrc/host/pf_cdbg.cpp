@@ -121,6 +121,25 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
             }
         });
     }
+    if (!getenv("PF_NO_PREALLOC") && adopt && resident_ && !colored) {
+        // the device buffers of the first alignment launch and of the first text piece, K-BUBBLE's and K-TEXT's first launches on
+        // their streams: 0.13 s at 5 M unitigs, on a helper thread beside the rest of the load (graph upload, numbering,
+        // adjacency: 0.2 s) -- they need the context and nothing that is loaded (pf_call_reserve in ploidyfrost_hip.h).  Only when
+        // the count table came with the context (the CLI: it was built while the graph file was read): a constructor that still
+        // has the database to decode and the table to build keeps the runtime busy from this thread, two threads inside the runtime
+        // mostly wait for one another, and start_prealloc() at its end does the same beside the caller's next steps.  About a third
+        // of the unitigs end up as called bubbles, aligned in two ranges of whole text pieces.
+        const uint64_t n_est = g_.ingest_pending() ? g_.estimated_unitigs() : g_.n();
+        const uint64_t piece = (uint64_t)std::max<size_t>(batch_bubbles_, 1) * 4;
+        const uint64_t est = std::min<uint64_t>(1u << 24, ((uint64_t)(0.17 * (double)n_est) + piece - 1) / piece * piece);
+        prealloc_align_ = std::thread([this, est, piece] {
+            LoadTrace trace;
+            (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_);
+            trace.mark("reserve: alignment buffers of two lanes (beside the load)");
+            (void)pf_call_reserve_text(ctx_, piece);
+            trace.mark("reserve: text buffers (beside the load)");
+        });
+    }
     if (g_.ingest_pending()) {
         // K-GFA: the S-lines are parsed and packed on the device; the host keeps the segment table
         std::string e;
@@ -199,23 +218,30 @@ int CDBG::init_device(int device, pf_ctx *adopt, bool colored) {
 
 void CDBG::start_prealloc() {
     if (!getenv("PF_NO_PREALLOC") && resident_ && ctx_ && status_ == PF_OK) {
-        // the device buffers of the first alignment launch, taken beside what follows the load on the host (the unitig id file).
-        // Started when the constructor has made its last call into the context -- the count table is in; started from init_device
-        // it ran beside pf_kmc_decode / pf_upload_counts of the pfh_open path (advisor, round 3) -- so nothing else calls into the
-        // context before findSuperBubble, which waits for this thread.  About a third of the unitigs end up as called bubbles,
-        // aligned in two ranges of whole text pieces.
+        // findSuperBubble's device buffers, which are sized by the number of candidates (the adjacency must be resident), taken
+        // beside what follows the load on the host (the unitig id file); findSuperBubble waits for this thread.  The calling
+        // pipeline's buffers are taken here as well when init_device's helper did not take them beside the load (colored graphs:
+        // K-TEXT's colored form is chosen by pf_call_set_colours).
         const uint32_t N = g_.n();
         const uint64_t piece = (uint64_t)std::max<size_t>(batch_bubbles_, 1) * 4;
         const uint64_t est = std::min<uint64_t>(1u << 24, ((uint64_t)(0.17 * (double)N) + piece - 1) / piece * piece);
-        prealloc_call_ = std::thread([this, est, piece, N] {
+        const bool call_buffers = !prealloc_align_.joinable();
+        prealloc_call_ = std::thread([this, est, piece, N, call_buffers] {
+            LoadTrace trace;
             uint64_t n_cand = 0;   // findSuperBubble's buffers first: it is the first to run
             if (commits_on_device(1) && pf_count_candidates(ctx_, 0, N, &n_cand) == PF_OK) {
+                trace.mark("reserve: candidates counted");
                 (void)pf_find_reserve(ctx_, n_cand);
+                trace.mark("reserve: findSuperBubble's buffers");
                 // (K-CC once over no records: what its first call of a run pays beyond its 0.6 ms is paid here)
                 (void)pf_side_components(ctx_, 1, nullptr, 0, nullptr, 0, nullptr, 0, nullptr, 0);
+                trace.mark("reserve: K-CC's first call");
             }
+            if (!call_buffers) return;
             (void)pf_call_reserve(ctx_, est, (uint32_t)complex_size_);
+            trace.mark("reserve: alignment buffers of two lanes");
             (void)pf_call_reserve_text(ctx_, piece);
+            trace.mark("reserve: text buffers");
         });
     }
 }

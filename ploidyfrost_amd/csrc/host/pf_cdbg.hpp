@@ -189,11 +189,12 @@ protected:
     int join_pending_ids();
     // pinned exchange buffers of the first pass, allocated on a helper thread while the graph goes to the device (page-locking
     // a few hundred MB costs tens of milliseconds; sizes are estimates from the unitig count, the phases grow them if needed)
-    std::thread prealloc_, prealloc_walkers_, prealloc_call_;
+    std::thread prealloc_, prealloc_walkers_, prealloc_call_, prealloc_align_;
     void join_prealloc() {
         if (prealloc_.joinable()) prealloc_.join();
         if (prealloc_walkers_.joinable()) prealloc_walkers_.join();
         if (prealloc_call_.joinable()) prealloc_call_.join();
+        if (prealloc_align_.joinable()) prealloc_align_.join();
     }
     std::thread pending_ids_;
     int pending_ids_rc_ = 0;

@@ -268,7 +268,10 @@ bool UnitigSet::open_gfa(const std::string &path, std::string &err) {
     return true;
 }
 
-uint64_t UnitigSet::estimated_unitigs() const { return src_ ? src_->body_n / 75 + 1024 : n(); }
+uint64_t UnitigSet::estimated_unitigs() const {
+    if (parsed_on_ && parse_status_ == 0) return parsed_n_;   // (the device has parsed the file already: the count itself)
+    return src_ ? src_->body_n / 75 + 1024 : n();
+}
 
 int UnitigSet::parse_on_device(pf_ctx *ctx) {
     LoadTrace trace;

@@ -779,9 +779,11 @@ namespace pf {
 // (its result then carries n_rows = 0xFFFFFFFF).
 unsigned long long *bubble_pool_heads(pf_ctx *ctx, int lane) { return (unsigned long long *)ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128); }
 
+// the class launches of a lane go on three streams ("trains", bubble_launch): the device runs three kernels of a process at a time
+constexpr int kBubTrains = 3;
 static int bubble_streams(pf_ctx *ctx, int lane) {
     if (ctx->bub_streams[lane][0]) return PF_OK;
-    for (int c = 0; c < kBubLdsClasses; ++c) {
+    for (int c = 0; c < kBubTrains; ++c) {   // (a stream is milliseconds to create: no more of them than are used)
         PF_HIP(lane_stream_create(&ctx->bub_streams[lane][c], lane));
         PF_HIP(hipEventCreateWithFlags(&ctx->bub_events[lane][c], hipEventDisableTiming));
     }
@@ -801,11 +803,14 @@ int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks, int lane) {
     if (!ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128) || !ctx_ws(ctx, bub_ws(WS_BUB_RETRY, lane), (size_t)std::max<uint32_t>(n_tasks, 1) * 4) ||
         !ctx_ws(ctx, bub_ws(WS_BUB_SCRATCH, lane), per * (uint64_t)ctx->n_cu * 24))
         return PF_ERR_HIP;
+    DevLoadTrace trace;
     { const int e = bubble_streams(ctx, lane); if (e != PF_OK) return e; }
+    trace.mark("bubble: class streams");
     { const int e = bubble_func_attr(ctx); if (e != PF_OK) return e; }
-    // One empty launch per class stream, now, beside the load: the first K-BUBBLE launch of a stream pays for the queue's scratch
-    // (the kernel spills) and its first use of that much LDS -- 13 ms for the nine launches of a first PloidyEstimation when they
-    // were paid there.  (n = 0: every wavefront leaves at its first look at the queue.)
+    trace.mark("bubble: function attributes");
+    // One empty launch per class, over the train streams, now, beside the load: the first K-BUBBLE launch of a stream pays for the
+    // queue's scratch (the kernel spills) and its first use of that much LDS -- 13 ms for the nine launches of a first
+    // PloidyEstimation when they were paid there.  (n = 0: every wavefront leaves at its first look at the queue.)
     uint8_t *small = (uint8_t *)ctx_ws(ctx, bub_ws(WS_BUB_SMALL, lane), 128);
     PF_HIP(hipMemsetAsync(small, 0, 128, ctx->bub_streams[lane][0]));
     PF_HIP(hipStreamSynchronize(ctx->bub_streams[lane][0]));
@@ -814,9 +819,10 @@ int bubble_reserve(pf_ctx *ctx, uint32_t n_tasks, int lane) {
     BubOut o;
     memset(&o, 0, sizeof(o));
     p.next = reinterpret_cast<unsigned int *>(small + 64);
-    for (int c = 0; c < kBubLdsClasses; ++c) k_bubble<true><<<1, 64, kBubClassBytes[c], ctx->bub_streams[lane][c]>>>(p, o);
+    for (int c = 0; c < kBubLdsClasses; ++c) k_bubble<true><<<1, 64, kBubClassBytes[c], ctx->bub_streams[lane][c % kBubTrains]>>>(p, o);
     PF_HIP(hipGetLastError());
-    for (int c = 0; c < kBubLdsClasses; ++c) PF_HIP(hipStreamSynchronize(ctx->bub_streams[lane][c]));
+    for (int c = 0; c < kBubTrains; ++c) PF_HIP(hipStreamSynchronize(ctx->bub_streams[lane][c]));
+    trace.mark("bubble: an empty launch per class stream");
     return PF_OK;
 }
 
@@ -865,7 +871,7 @@ int bubble_launch(pf_ctx *ctx, const BubbleLaunch &L, unsigned long long heads[4
     // lets a CU hold) and the launches of a train, one after the other, use the same third of the scratch.
     // (measured, passes of 17.3 ms / 17.9 ms at configs[4]'s parameters, 1 M unitigs / configs[2]: one train 23.5 / 19.4, two 18.8 / 19.0,
     // four 22.3 / 17.9: profiles/r5_experiments.txt)
-    constexpr int kTrains = 3;
+    constexpr int kTrains = kBubTrains;
     int grids[kBubLdsClasses];
     int train_of[kBubLdsClasses];
     int order[kBubLdsClasses];

@@ -22,8 +22,6 @@
 // All integer / byte work with data-dependent control flow; HBM traffic is the text itself.  No MFMA.
 #include <hip/hip_runtime.h>
 
-#include <hipcub/hipcub.hpp>
-
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -44,6 +42,7 @@
 #include "pf_device_common.hpp"
 #include "pf_format_dev.hpp"
 #include "pf_pair_dev.hpp"
+#include "pf_scan.hpp"
 #include "pf_stack_dev.hpp"
 #include "ploidyfrost_hip.h"
 
@@ -66,6 +65,7 @@ using namespace pf_call;
 
 namespace pf {
 
+void call_state_create(pf_ctx *ctx) { (void)state_of(ctx); }
 void call_destroy(pf_ctx *ctx) {
     if (!ctx->call) return;
     ctx->call->release_all();
@@ -176,16 +176,12 @@ int pf_superbubble_rows(pf_ctx *ctx, int colored_rule, uint64_t *n_rows, uint64_
     a.row_base = S->sb_base.as<uint32_t>(); a.sizes = S->sb_sizes.as<uint32_t>(); a.offs = S->sb_offs.as<uint64_t>(); a.out = nullptr;
     const unsigned grid = (unsigned)((n1 + 255) / 256);
     k_sb_count<<<grid, 256, 0, st>>>(a, S->sb_cnt.as<uint32_t>());
-    size_t t1 = 0, t2 = 0;
-    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(S->sb_sizes.as<uint32_t>(), Widen());
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t1, S->sb_cnt.as<uint32_t>(), S->sb_base.as<uint32_t>(), (int)n1, st));
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, wide, S->sb_offs.as<uint64_t>(), (int)n1, st));
-    if (!S->scan_tmp.ensure(std::max(t1, t2))) { pf::CtxErr{ctx} = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, t1, S->sb_cnt.as<uint32_t>(), S->sb_base.as<uint32_t>(), (int)n1, st));
+    if (!S->scan_tmp.ensure(scan_scratch_bytes(n1))) { pf::CtxErr{ctx} = "pf_superbubble_rows: out of device memory"; return PF_ERR_HIP; }
+    PF_HIP(scan_exclusive_u32(S->sb_cnt.as<uint32_t>(), S->sb_base.as<uint32_t>(), n1, S->scan_tmp.p, st));
     ctx_begin(ctx, PF_K_CALL_FORMAT);
     k_sb_format<false><<<grid, 256, 0, st>>>(a);
     ctx_end(ctx);
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, t2, wide, S->sb_offs.as<uint64_t>(), (int)n1, st));
+    PF_HIP(scan_exclusive_u32_u64(S->sb_sizes.as<uint32_t>(), S->sb_offs.as<uint64_t>(), n1, S->scan_tmp.p, st));
     uint32_t rows = 0;
     uint64_t len = 0;
     PF_HIP(hipMemcpyAsync(&rows, S->sb_base.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
@@ -320,10 +316,8 @@ int pf_call_scan(pf_ctx *ctx, uint32_t lower, uint32_t upper, uint64_t *n_sides)
     const uint32_t N = ctx->N;
     if (!S->side_cnt.ensure(((size_t)N + 1) * 4) || !S->side_base.ensure(((size_t)N + 1) * 4)) { pf::CtxErr{ctx} = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
     k_call_count_sides<<<(N + 1 + 255) / 256, 256, 0, st>>>(S->flags.as<uint8_t>(), N, S->side_cnt.as<uint32_t>());
-    size_t tmp = 0;
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp, S->side_cnt.as<uint32_t>(), S->side_base.as<uint32_t>(), (int)(N + 1), st));
-    if (!S->scan_tmp.ensure(tmp)) { pf::CtxErr{ctx} = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->scan_tmp.p, tmp, S->side_cnt.as<uint32_t>(), S->side_base.as<uint32_t>(), (int)(N + 1), st));
+    if (!S->scan_tmp.ensure(scan_scratch_bytes((uint64_t)N + 1))) { pf::CtxErr{ctx} = "pf_call_scan: out of device memory"; return PF_ERR_HIP; }
+    PF_HIP(scan_exclusive_u32(S->side_cnt.as<uint32_t>(), S->side_base.as<uint32_t>(), (uint64_t)N + 1, S->scan_tmp.p, st));
     uint32_t total = 0;
     PF_HIP(hipMemcpyAsync(&total, S->side_base.as<uint32_t>() + N, 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
@@ -403,11 +397,8 @@ int pf_call_resolve(pf_ctx *ctx, uint64_t *n_bubbles, uint32_t *err, uint32_t *e
         if (h[0] == 0) break;
     }
     // the called sides, ascending
-    size_t tmp = 0;
-    hipcub::CountingInputIterator<uint32_t> ids(0);
-    PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp, ids, S->rflag.as<uint32_t>(), S->kept.as<uint32_t>(), small + 2, (int)n, st));
-    if (!S->scan_tmp.ensure(tmp)) { pf::CtxErr{ctx} = "pf_call_resolve: out of device memory"; return PF_ERR_HIP; }
-    PF_HIP(hipcub::DeviceSelect::Flagged(S->scan_tmp.p, tmp, ids, S->rflag.as<uint32_t>(), S->kept.as<uint32_t>(), small + 2, (int)n, st));
+    if (!S->scan_tmp.ensure(scan_scratch_bytes(n))) { pf::CtxErr{ctx} = "pf_call_resolve: out of device memory"; return PF_ERR_HIP; }
+    PF_HIP(select_flagged_u32(S->rflag.as<uint32_t>(), S->kept.as<uint32_t>(), small + 2, nullptr, n, S->scan_tmp.p, st));
     unsigned int sel = 0;
     PF_HIP(hipMemcpyAsync(&sel, small + 2, 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
@@ -779,10 +770,8 @@ int pf_call_align_lane(pf_ctx *ctx, int lane, uint64_t t0, uint64_t t1, uint32_t
 
     // ---- bubble numbering inside the batch (launched ahead of K-SITES, read with its counters: one wait for both) ----
     k_call_has<<<(nb + 255) / 256, 256, 0, st>>>(O.res.as<pf_bubble_result>(), nb, W.has.as<uint32_t>());
-    size_t tmp1 = 0;
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(nullptr, tmp1, W.has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
-    NEED(W.scan_tmp, tmp1);
-    PF_HIP(hipcub::DeviceScan::InclusiveSum(W.scan_tmp.p, tmp1, W.has.as<uint32_t>(), O.vc.as<uint32_t>(), (int)nb, st));
+    NEED(W.scan_tmp, scan_scratch_bytes(nb));
+    PF_HIP(scan_inclusive_u32(W.has.as<uint32_t>(), O.vc.as<uint32_t>(), nb, W.scan_tmp.p, st));
     uint32_t n_called = 0;
     PF_HIP(hipMemcpyAsync(&n_called, O.vc.as<uint32_t>() + (nb - 1), 4, hipMemcpyDeviceToHost, st));
 
@@ -932,6 +921,7 @@ int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int
     const uint32_t nb = (uint32_t)std::min<uint64_t>(nb64, 1u << 24);
     const char *oom = "pf_call_reserve: out of device memory";
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
+    DevLoadTrace trace;
     for (int lane = 0; lane < n_lanes; ++lane) {
         CallState::AlignWork &W = S->work[lane];
         NEED(W.counters, sizeof(CallCounters));
@@ -946,8 +936,8 @@ int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int
         NEED(W.bpath, ((size_t)4 * nb + (uint64_t)nb / 2 + 128ull * (ctx->n_cu * 16) + 1024) * sizeof(pf_bubble_path));
         NEED(W.ptext, (uint64_t)nb * FIRST_PATH_TEXT + (1u << 16));
         NEED(W.scan_tmp2, (size_t)nb / 4 * 4 + 4096);
-        {   // K-SITES' tables for bubbles of up to 256 walks (single-sample)
-            const uint64_t KS = (uint64_t)(2 * ctx->k + 64), rows_cap = 256;
+        {   // K-SITES' tables for bubbles of up to 256 walks (single-sample; for the longest k: the graph may still be on its way)
+            const uint64_t KS = (uint64_t)(2 * 31 + 64), rows_cap = 256;
             const uint64_t sites_per_wave = ((2 * rows_cap * KS + rows_cap * (4 + 4 + 4 + 1 + 1 + 8)) + 255) & ~255ull;
             NEED(W.sites_scr, sites_per_wave * (uint64_t)(ctx->n_cu * 16));
         }
@@ -960,14 +950,17 @@ int pf_call_reserve_lanes(pf_ctx *ctx, uint64_t nb64, uint32_t complex_size, int
         NEED(O.ogroups, (uint64_t)FIRST_GROUPS * nb + 64);
         NEED(O.oilen, ((uint64_t)FIRST_ILEN * nb + 64) * 4);
         NEED(O.sv, ((uint64_t)nb / 4 + 1024ull * ctx->n_cu * 16 + 1024) * 8);
+        trace.mark("reserve: a lane's buffers");
         if (lane != 0 && !W.stream) { PF_HIP(lane_stream_create(&W.stream, lane)); W.own_stream = true; }
         if (!W.side_stream) {
             PF_HIP(lane_stream_create(&W.side_stream, lane));
             PF_HIP(hipEventCreateWithFlags(&W.ev_prep, hipEventDisableTiming));
             PF_HIP(hipEventCreateWithFlags(&W.ev_paths, hipEventDisableTiming));
         }
+        trace.mark("reserve: a lane's streams and events");
         const int st = bubble_reserve(ctx, nb, lane);
         if (st != PF_OK) return st;
+        trace.mark("reserve: K-BUBBLE's workspaces and first launches");
     }
 #undef NEED
     return PF_OK;
@@ -996,10 +989,7 @@ static int text_work_of(pf_ctx *ctx, pf::CallState *S, int which, uint32_t nb) {
     NEED_TEXT(T.offs, ((size_t)N_INT * (nb + 1) + 1) * 8);
     NEED_TEXT(T.totals, 16 * 8);
     NEED_TEXT(T.tcounters, sizeof(CallCounters));
-    size_t tmp2 = 0;
-    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(T.sizes.as<uint32_t>(), Widen());
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, T.offs.as<uint64_t>(), (int)((size_t)N_INT * (nb + 1)), T.stream));
-    NEED_TEXT(T.tscan, tmp2);
+    NEED_TEXT(T.tscan, scan_scratch_bytes((uint64_t)N_INT * (nb + 1)));
     return PF_OK;
 }
 
@@ -1011,7 +1001,7 @@ int pf_call_reserve_text(pf_ctx *ctx, uint64_t piece_bubbles) {
     PF_HIP(hipSetDevice(ctx->device));
     const uint32_t nb = (uint32_t)std::min<uint64_t>(piece_bubbles, 1u << 24);
     for (int which = 0; which < 2; ++which) { const int ts = text_work_of(ctx, S, which, nb); if (ts != PF_OK) return ts; }
-    for (int slab = 0; slab < PF_CALL_SLABS; ++slab) NEED_TEXT(S->out[slab], (11ull * (uint64_t)ctx->k + 40) * nb);
+    for (int slab = 0; slab < PF_CALL_SLABS; ++slab) NEED_TEXT(S->out[slab], (11ull * 31 + 40) * nb);   // (the longest k: the graph may still be on its way)
     // K-TEXT's two passes once over no bubbles on each of its streams: what the first launch of a kernel this size pays on a stream
     // (scratch for its spills: 2.3 ms of a first piece's count pass) is paid here, beside the load
     for (int which = 0; which < 2; ++which) {
@@ -1059,10 +1049,7 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
 #define NEED(buf, bytes) do { if (!(buf).ensure(bytes)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; } } while (0)
     CallCounters *d_cnt = T.tcounters.as<CallCounters>();
     CallCounters hc;
-    size_t tmp2 = 0;
     const size_t n_sizes = (size_t)N_INT * (nb + 1);
-    hipcub::TransformInputIterator<uint64_t, Widen, const uint32_t *> wide(T.sizes.as<uint32_t>(), Widen());
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, wide, T.offs.as<uint64_t>(), (int)n_sizes, st));
     ta("stream and size tables");
     PF_HIP(hipMemsetAsync(&d_cnt->allele[0], 0, 6 * 8, st));  // allele[4], core_cov, core_num
     FmtArgs fa;
@@ -1079,7 +1066,7 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     if (S->n_colors) k_call_format<false, true><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     else k_call_format<false, false><<<(nb + 1 + FMT_BLOCK - 1) / FMT_BLOCK, FMT_BLOCK, 0, st>>>(fa);
     ctx_end_at(ctx, at, st);
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(T.tscan.p, tmp2, wide, T.offs.as<uint64_t>(), (int)n_sizes, st));
+    PF_HIP(scan_exclusive_u32_u64(T.sizes.as<uint32_t>(), T.offs.as<uint64_t>(), n_sizes, T.tscan.p, st));
     k_call_totals<<<1, 64, 0, st>>>(T.offs.as<uint64_t>(), T.sizes.as<uint32_t>(), nb, T.totals.as<uint64_t>());
     uint64_t totals[N_INT + 1] = {};
     PF_HIP(hipMemcpyAsync(totals, T.totals.p, N_INT * 8, hipMemcpyDeviceToHost, st));

@@ -558,10 +558,6 @@ struct SbArgs {
     char *out;
 };
 
-struct Widen {
-    __host__ __device__ uint64_t operator()(uint32_t x) const { return (uint64_t)x; }
-};
-
 // the kernels, by stage
 __global__ void k_call_count_sides(const uint8_t *, uint32_t, uint32_t *);   // pf_call_scan.hip
 template <bool COLORED> __global__ void k_call_sides(ScanArgs);   // pf_call_scan.hip

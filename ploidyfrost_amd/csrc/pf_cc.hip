@@ -18,12 +18,12 @@
 
 #include <algorithm>
 #include <cstring>
-#include <hipcub/hipcub.hpp>
 #include <rocprim/rocprim.hpp>
 
 #include "host/pf_state_ops.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
+#include "pf_scan.hpp"
 #include "ploidyfrost_hip.h"
 
 using namespace pf;
@@ -643,12 +643,8 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     const char *oom = "pf_replay_device: out of device memory";
     if (!grow(S->t_flag, S->t_flag_cap, n + 8) || !grow(S->t_cnt, S->t_cnt_cap, 2)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
     k_replay_flag_big<<<grid, 256, 0, st>>>(rec, n, S->keys, S->big, S->work, small_limit, S->t_flag);
-    size_t sel = 0;
-    hipcub::CountingInputIterator<uint32_t> iota(0);
-    PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, sel, iota, S->t_flag, S->big_idx, S->t_cnt, (int)n, st));
-    if (!grow(S->t_sel, S->t_sel_cap, sel + 256)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
-    sel += 256;
-    PF_HIP(hipcub::DeviceSelect::Flagged(S->t_sel, sel, iota, S->t_flag, S->big_idx, S->t_cnt, (int)n, st));
+    if (!grow(S->t_sel, S->t_sel_cap, scan_scratch_bytes(n))) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
+    PF_HIP(select_flagged_u8(S->t_flag, S->big_idx, nullptr, S->t_cnt, n, S->t_sel, st));
     uint64_t nb = 0;
     PF_HIP(hipMemcpyAsync(&nb, S->t_cnt, 8, hipMemcpyDeviceToHost, st));
     PF_HIP(hipStreamSynchronize(st));
@@ -657,11 +653,8 @@ int pf_replay_device(pf_ctx *ctx, uint32_t complex_size, uint32_t small_limit, u
     if (nb) {
         if (!grow(S->t_sz, S->t_sz_cap, nb + 1) || !grow(S->t_off, S->t_off_cap, nb + 1)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
         k_replay_big_sizes<<<(unsigned)((nb + 1 + 255) / 256), 256, 0, st>>>(S->big_idx, nb, rec, S->t_sz);
-        size_t t2 = 0;
-        PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, S->t_sz, S->t_off, (int)(nb + 1), st));
-        if (!grow(S->t_scan, S->t_scan_cap, t2 + 256)) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
-        t2 += 256;
-        PF_HIP(hipcub::DeviceScan::ExclusiveSum(S->t_scan, t2, S->t_sz, S->t_off, (int)(nb + 1), st));
+        if (!grow(S->t_scan, S->t_scan_cap, scan_scratch_bytes(nb + 1))) { pf::CtxErr{ctx} = oom; return PF_ERR_HIP; }
+        PF_HIP(scan_exclusive_u64(S->t_sz, S->t_off, nb + 1, S->t_scan, st));
         PF_HIP(hipMemcpyAsync(&entries, S->t_off + nb, 8, hipMemcpyDeviceToHost, st));
         PF_HIP(hipStreamSynchronize(st));
         if (S->big_cap < nb) {

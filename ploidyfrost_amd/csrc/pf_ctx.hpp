@@ -183,6 +183,18 @@ void *ctx_ws(pf_ctx *ctx, int slot, size_t bytes);
 // when ranges are aligned side by side (PF_ALIGN_THREADS) the earlier range, whose text the pass waits for, goes first and the
 // later one fills what it leaves idle.  PF_LANE_PRIORITY=0: all at the default priority (measurements).
 hipError_t lane_stream_create(hipStream_t *s, int lane);
+// PF_TRACE_LOAD: where a load call of this library spends its time (the host layer's LoadTrace prints the calls themselves)
+struct DevLoadTrace {
+    bool on = getenv("PF_TRACE_LOAD") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void mark(const char *what) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[load]   . %-42s %.3fs\n", what, std::chrono::duration<double>(now - t).count());
+        t = now;
+    }
+};
+void call_state_create(pf_ctx *ctx);   // pf_call.hip: the (empty) state of the calling pipeline, made with the context
 void call_destroy(pf_ctx *ctx);     // pf_call.hip
 void cc_destroy(pf_ctx *ctx);       // pf_cc.hip
 void gfa_destroy(pf_ctx *ctx);      // pf_gfa.hip

@@ -6,7 +6,7 @@
 //   K-STRCOV site-string coverage        (CDBG::readCov(string), src/CDBG.cpp:29-60)
 // K-ALN lives in pf_align.hip.  Integer / index-bound work: no MFMA anywhere.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <cstdio>
@@ -20,6 +20,7 @@
 #include "pf_cov_stream.hpp"
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
+#include "pf_scan.hpp"
 #include "ploidyfrost_hip.h"
 
 using namespace pf;
@@ -1033,6 +1034,10 @@ int pf_create(int device, pf_ctx **out) {
         return PF_ERR_HIP;
     }
     ctx->stream = ctx->own_stream;
+    // what a helper thread that takes buffers beside the load (pf_call_reserve*) would otherwise create on its first call, while the
+    // loading thread looks at the same fields: the workspace table at its final size and the calling pipeline's state
+    ctx->ws.resize(WS_COUNT_, {nullptr, 0});
+    call_state_create(ctx);
     *out = ctx;
     return PF_OK;
 }
@@ -1193,10 +1198,31 @@ static int busy_union(pf_ctx *ctx, uint64_t kernel_mask, double *busy_ms, double
 int pf_device_busy(pf_ctx *ctx, double *busy_ms, double *span_ms) { return busy_union(ctx, ~0ull, busy_ms, span_ms); }
 int pf_kernel_busy(pf_ctx *ctx, uint64_t kernel_mask, double *busy_ms) { return busy_union(ctx, kernel_mask, busy_ms, nullptr); }
 
+// Page-locked host memory.  The pages come from the kernel, populated (mmap: no runtime in it), and are then registered with the
+// runtime: hipHostMalloc of the few hundred MB a load takes held the runtime's allocation lock for 8 ms per 64 MB while it pinned
+// them -- a tenth of a second in which the loading thread's own hipMalloc / hipMemcpy calls stood still -- where populating takes
+// half that time outside any lock and registering 0.4 ms per 64 MB inside it (tools/exp/pin_cost.cpp).  Ordinary cached memory on
+// the CPU side (the host layer reads these buffers element by element after each copy).
+namespace {
+std::mutex g_host_mu;
+std::vector<std::pair<void *, size_t>> g_host_maps;   // what pf_host_free has to unmap
+}  // namespace
 int pf_host_alloc(pf_ctx *ctx, size_t bytes, void **out) {
     if (!ctx || !out) return PF_ERR_ARG;
     PF_HIP(hipSetDevice(ctx->device));
-    // cached on the CPU side (the host layer reads these buffers element by element after each copy)
+    const size_t page = 1u << 21;
+    const size_t size = ((bytes ? bytes : 1) + page - 1) & ~(page - 1);
+    void *p = mmap(nullptr, size, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_POPULATE, -1, 0);
+    if (p != MAP_FAILED) {
+        if (hipHostRegister(p, size, hipHostRegisterDefault) == hipSuccess) {
+            std::lock_guard<std::mutex> lk(g_host_mu);
+            g_host_maps.emplace_back(p, size);
+            *out = p;
+            return PF_OK;
+        }
+        (void)hipGetLastError();
+        munmap(p, size);
+    }
     PF_HIP(hipHostMalloc(out, bytes ? bytes : 1, hipHostMallocNonCoherent));
     return PF_OK;
 }
@@ -1210,7 +1236,15 @@ int pf_fetch(pf_ctx *ctx, void *dst_host, const void *src_dev, uint64_t bytes) {
 
 void pf_host_free(pf_ctx *ctx, void *p) {
     (void)ctx;
-    if (p) hipHostFree(p);
+    if (!p) return;
+    size_t size = 0;
+    {
+        std::lock_guard<std::mutex> lk(g_host_mu);
+        for (size_t i = 0; i < g_host_maps.size(); ++i)
+            if (g_host_maps[i].first == p) { size = g_host_maps[i].second; g_host_maps.erase(g_host_maps.begin() + (long)i); break; }
+    }
+    if (size) { (void)hipHostUnregister(p); munmap(p, size); }
+    else hipHostFree(p);
 }
 
 int pf_device_name(pf_ctx *ctx, char *buf, size_t cap) {
@@ -1234,12 +1268,15 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
     if (N >= (1u << 30)) { pf::CtxErr{ctx} = "more than 2^30 unitigs"; return PF_ERR_ARG; }
     if (ctx->d_tab && ctx->tab_k != k) { pf::CtxErr{ctx} = "pf_upload_graph: k differs from the k of the resident count table"; return PF_ERR_ARG; }
     PF_HIP(hipSetDevice(ctx->device));
+    DevLoadTrace trace;
     (void)join_finish(ctx);
     (void)join_colored_finish(ctx);
     free_graph(ctx);
+    trace.mark("graph: previous graph released");
     // seq_off[N] = total words; fetch it (host or device pointer)
     uint64_t total_words = 0;
     PF_HIP(hipMemcpy(&total_words, seq_off + N, 8, hipMemcpyDefault));
+    trace.mark("graph: (x) total words fetched");
     ctx->N = N;
     ctx->k = k;
     ctx->n_words = total_words;
@@ -1247,10 +1284,14 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
     PF_HIP(hipMemsetAsync(ctx->d_seq, 0, (total_words + 2) * 8, ctx->stream));
     PF_HIP(hipMalloc(&ctx->d_off, ((size_t)N + 1) * 8));
     PF_HIP(hipMalloc(&ctx->d_len, (size_t)N * 4));
+    trace.mark("graph: (x) mallocs");
+    PF_HIP(hipStreamSynchronize(ctx->stream));
+    trace.mark("graph: (x) memset done");
     PF_HIP(hipMemcpyAsync(ctx->d_seq, seq_words, total_words * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ctx->d_off, seq_off, ((size_t)N + 1) * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ctx->d_len, len_bp, (size_t)N * 4, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipStreamSynchronize(ctx->stream));
+    trace.mark("graph: arrays copied");
     // validation of what the kernels assume (lengths >= k, offsets cover lengths) and the k-mer numbering of the k-mer-parallel
     // kernels, all on the device: d_kpre = exclusive scan of the k-mers per unitig; d_kwin[w] / d_krow[r] = the unitig holding
     // k-mer 256 w / 64 r; d_khead = one bit per k-mer (unitig starts, plus the end of the last one)
@@ -1262,11 +1303,9 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         PF_HIP(hipMemsetAsync(bad_.p, 0, 4, ctx->stream));
         k_graph_check<<<(N + 1 + 255) / 256, 256, 0, ctx->stream>>>(ctx->d_off, ctx->d_len, N, k, total_words, cnt_.p, bad_.p);
         PF_HIP(hipMalloc(&ctx->d_kpre, ((size_t)N + 1) * 8));
-        size_t tmp_bytes = 0;
-        PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cnt_.p, ctx->d_kpre, (int)(N + 1), ctx->stream));
         DevTmp<uint8_t> tmp_;
-        PF_HIP(tmp_.alloc(tmp_bytes));
-        PF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp_.p, tmp_bytes, cnt_.p, ctx->d_kpre, (int)(N + 1), ctx->stream));
+        PF_HIP(tmp_.alloc(scan_scratch_bytes((uint64_t)N + 1)));
+        PF_HIP(scan_exclusive_u64(cnt_.p, ctx->d_kpre, (uint64_t)N + 1, tmp_.p, ctx->stream));
         unsigned int bad = 0;
         uint64_t nk = 0;
         PF_HIP(hipMemcpyAsync(&bad, bad_.p, 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -1277,6 +1316,7 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
             free_graph(ctx);
             return PF_ERR_ARG;
         }
+        trace.mark("graph: checked, k-mers numbered");
         ctx->n_kmers = nk;
         const uint64_t n_win = nk / 256 + 1;
         const uint64_t n_row = nk / 64 + 1, n_row_pad = n_row + 8;  // padded: the four-per-lane kernel reads whole super-rows (4 words)
@@ -1294,8 +1334,13 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
         ctx->h_len.resize(N);
         PF_HIP(hipMemcpyAsync(ctx->h_len.data(), ctx->d_len, (size_t)N * 4, hipMemcpyDeviceToHost, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
+        trace.mark("graph: row index, lengths to the host");
     }
-    if (ctx->d_tab && !ctx->tab_exact) return pf::join_graph_counts(ctx);
+    if (ctx->d_tab && !ctx->tab_exact) {
+        const int js = pf::join_graph_counts(ctx);
+        trace.mark("graph: first join with the count table");
+        return js;
+    }
     return PF_OK;
 }
 
@@ -1332,12 +1377,9 @@ int pf_build_adjacency(pf_ctx *ctx, uint32_t *succ, uint32_t *pred) {
     PF_HIP(hipMalloc(&ctx->d_cand, (size_t)N * 2 * 4));
     k_mark_candidates<<<ctx_grid(ctx, (uint64_t)N * 2, 256, 8), 256, 0, ctx->stream>>>(ctx->d_succ, N * 2, flag);
     {
-        hipcub::CountingInputIterator<uint32_t> ids(0);
-        size_t tmp_bytes = 0;
         DevTmp<uint8_t> tmp_;
-        PF_HIP(hipcub::DeviceSelect::Flagged(nullptr, tmp_bytes, ids, flag, ctx->d_cand, d_num, (int)(N * 2), ctx->stream));
-        PF_HIP(tmp_.alloc(tmp_bytes));
-        PF_HIP(hipcub::DeviceSelect::Flagged(tmp_.p, tmp_bytes, ids, flag, ctx->d_cand, d_num, (int)(N * 2), ctx->stream));
+        PF_HIP(tmp_.alloc(scan_scratch_bytes((uint64_t)N * 2)));
+        PF_HIP(select_flagged_u8(flag, ctx->d_cand, d_num, nullptr, (uint64_t)N * 2, tmp_.p, ctx->stream));
         PF_HIP(hipStreamSynchronize(ctx->stream));
     }
     uint32_t n_cand = 0;

@@ -24,11 +24,11 @@
 // The packed arrays then go through pf_upload_graph (device pointers), which validates them like any caller's.
 #include <hip/hip_runtime.h>
 
-#include <hipcub/hipcub.hpp>
 #include <string>
 
 #include "pf_ctx.hpp"
 #include "pf_device_common.hpp"
+#include "pf_scan.hpp"
 #include "ploidyfrost_hip.h"
 
 using namespace pf;
@@ -293,14 +293,10 @@ int pf_gfa_parse(pf_ctx *ctx, const char *body, uint64_t n_bytes, int gfa_versio
         k_gfa_lines<false><<<grid, 256, 0, st>>>(S->text, n_bytes, gfa_version, k, n_tiles, cl_.p, cs_.p, nullptr, nullptr, 0, nullptr, nullptr, nullptr, nullptr,
                                                  d_err, d_any_da);
     PF_HIP(hipGetLastError());
-    size_t tmp_bytes = 0;
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp_bytes, cl_.p, bl_.p, (int)(n_tiles + 1), st));
     DevTmp<uint8_t> tmp_;
-    PF_HIP(tmp_.alloc(tmp_bytes + 256));
-    size_t tb = tmp_bytes + 256;
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp_.p, tb, cl_.p, bl_.p, (int)(n_tiles + 1), st));
-    tb = tmp_bytes + 256;
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp_.p, tb, cs_.p, bs_.p, (int)(n_tiles + 1), st));
+    PF_HIP(tmp_.alloc(scan_scratch_bytes(n_tiles + 1)));
+    PF_HIP(scan_exclusive_u32(cl_.p, bl_.p, n_tiles + 1, tmp_.p, st));
+    PF_HIP(scan_exclusive_u32(cs_.p, bs_.p, n_tiles + 1, tmp_.p, st));
     uint32_t n_long = 0, n_sh = 0, err = 0;
     PF_HIP(hipMemcpyAsync(&n_long, bl_.p + n_tiles, 4, hipMemcpyDeviceToHost, st));
     PF_HIP(hipMemcpyAsync(&n_sh, bs_.p + n_tiles, 4, hipMemcpyDeviceToHost, st));
@@ -325,12 +321,9 @@ int pf_gfa_parse(pf_ctx *ctx, const char *body, uint64_t n_bytes, int gfa_versio
     PF_HIP(wc_.alloc((N + 1) * 8));
     PF_HIP(hipMalloc(reinterpret_cast<void **>(&S->word_off), (N + 1) * 8));
     k_gfa_words<<<(unsigned)((N + 1 + 255) / 256), 256, 0, st>>>(S->seg_len, (uint32_t)N, wc_.p);
-    size_t t2 = 0;
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(nullptr, t2, wc_.p, S->word_off, (int)(N + 1), st));
     DevTmp<uint8_t> tmp2_;
-    PF_HIP(tmp2_.alloc(t2 + 256));
-    t2 += 256;
-    PF_HIP(hipcub::DeviceScan::ExclusiveSum(tmp2_.p, t2, wc_.p, S->word_off, (int)(N + 1), st));
+    PF_HIP(tmp2_.alloc(scan_scratch_bytes(N + 1)));
+    PF_HIP(scan_exclusive_u64(wc_.p, S->word_off, N + 1, tmp2_.p, st));
     uint64_t n_words = 0;
     uint32_t any_da = 0;
     PF_HIP(hipMemcpyAsync(&n_words, S->word_off + N, 8, hipMemcpyDeviceToHost, st));

@@ -1,0 +1,172 @@
+// Prefix sums and flag selection (pf_scan.hpp): tile sums, their scan by one block, the tiles again with their offsets.
+// HBM-bound, three passes over the input at most (12 - 24 bytes an element); the arrays are a few million elements -- tens of
+// microseconds a call.
+#include "pf_scan.hpp"
+
+namespace pf {
+namespace {
+
+constexpr int SCAN_BLOCK = 256, SCAN_ITEMS = 8, SCAN_TILE = SCAN_BLOCK * SCAN_ITEMS;
+constexpr int OFFS_BLOCK = 1024;
+
+__device__ inline uint64_t shfl_up_u64(uint64_t v, int d) {
+    const uint32_t lo = __shfl_up((uint32_t)v, d, 64), hi = __shfl_up((uint32_t)(v >> 32), d, 64);
+    return ((uint64_t)hi << 32) | lo;
+}
+// inclusive scan over the 64 lanes of a wavefront
+__device__ inline uint64_t wave_scan(uint64_t v) {
+    const int lane = (int)(threadIdx.x & 63);
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t o = shfl_up_u64(v, d);
+        if (lane >= d) v += o;
+    }
+    return v;
+}
+// inclusive scan over the threads of a block (blockDim.x / 64 <= 16 wavefronts); total = the block's sum
+__device__ inline uint64_t block_scan(uint64_t v, uint64_t &total) {
+    __shared__ uint64_t s_wave[16];
+    const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), n_wv = (int)(blockDim.x >> 6);
+    const uint64_t incl = wave_scan(v);
+    __syncthreads();   // (s_wave of a previous call has been read)
+    if (lane == 63) s_wave[wv] = incl;
+    __syncthreads();
+    uint64_t before = 0, all = 0;
+    for (int w = 0; w < n_wv; ++w) {
+        const uint64_t x = s_wave[w];
+        if (w < wv) before += x;
+        all += x;
+    }
+    total = all;
+    return incl + before;
+}
+
+struct AsIs {
+    template <class T> __device__ uint64_t operator()(T x) const { return (uint64_t)x; }
+};
+struct NonZero {
+    template <class T> __device__ uint64_t operator()(T x) const { return x != 0 ? 1u : 0u; }
+};
+
+// a thread's SCAN_ITEMS consecutive elements of tile blockIdx.x (zero beyond n)
+template <class In, class Map>
+__device__ inline void load_items(const In *__restrict__ in, uint64_t n, uint64_t (&v)[SCAN_ITEMS], Map map) {
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+    if ((uint64_t)(blockIdx.x + 1) * SCAN_TILE <= n) {   // a whole tile: plain (vector) loads
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = map(in[base + i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < SCAN_ITEMS; ++i) v[i] = base + i < n ? map(in[base + i]) : 0;
+    }
+}
+
+template <class In, class Map>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_tile_sums(const In *__restrict__ in, uint64_t n, uint64_t *__restrict__ tile_sum, Map map) {
+    uint64_t v[SCAN_ITEMS];
+    load_items(in, n, v, map);
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+    uint64_t total;
+    (void)block_scan(s, total);
+    if (threadIdx.x == 0) tile_sum[blockIdx.x] = total;
+}
+
+// tile sums -> tile offsets in place (one block); the total behind them and, where asked for, as a count
+__global__ __launch_bounds__(OFFS_BLOCK) void k_scan_tile_offsets(uint64_t *__restrict__ tile, uint64_t n_tiles, uint32_t *__restrict__ count32,
+                                                                 uint64_t *__restrict__ count64) {
+    uint64_t carry = 0;
+    for (uint64_t t0 = 0; t0 < n_tiles; t0 += OFFS_BLOCK) {
+        const uint64_t t = t0 + threadIdx.x;
+        const uint64_t x = t < n_tiles ? tile[t] : 0;
+        uint64_t total;
+        const uint64_t incl = block_scan(x, total);
+        if (t < n_tiles) tile[t] = carry + incl - x;
+        carry += total;
+    }
+    if (threadIdx.x == 0) {
+        tile[n_tiles] = carry;
+        if (count32) *count32 = (uint32_t)carry;
+        if (count64) *count64 = carry;
+    }
+}
+
+template <class In, class Out, bool INCLUSIVE>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const In *__restrict__ in, Out *__restrict__ out, uint64_t n, const uint64_t *__restrict__ tile_off) {
+    uint64_t v[SCAN_ITEMS];
+    load_items(in, n, v, AsIs());
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+    uint64_t total;
+    uint64_t run = block_scan(s, total) - s + tile_off[blockIdx.x];   // what lies before this thread's first element
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (INCLUSIVE) run += v[i];
+        if (base + i < n) out[base + i] = (Out)run;
+        if (!INCLUSIVE) run += v[i];
+    }
+}
+
+template <class Flag>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_select_apply(const Flag *__restrict__ flags, uint32_t *__restrict__ ids, uint64_t n, const uint64_t *__restrict__ tile_off) {
+    uint64_t v[SCAN_ITEMS];
+    load_items(flags, n, v, NonZero());
+    uint64_t s = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+    uint64_t total;
+    uint64_t at = block_scan(s, total) - s + tile_off[blockIdx.x];
+    const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i)
+        if (v[i]) ids[at++] = (uint32_t)(base + i);
+}
+
+inline uint64_t tiles_of(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+
+template <class In, class Out, bool INCLUSIVE>
+hipError_t scan_impl(const In *in, Out *out, uint64_t n, void *scratch, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    if (!in || !out || !scratch || tiles_of(n) > 0x7FFFFFFFull) return hipErrorInvalidValue;
+    uint64_t *tile = static_cast<uint64_t *>(scratch);
+    const unsigned grid = (unsigned)tiles_of(n);
+    k_scan_tile_sums<In, AsIs><<<grid, SCAN_BLOCK, 0, st>>>(in, n, tile, AsIs());
+    k_scan_tile_offsets<<<1, OFFS_BLOCK, 0, st>>>(tile, grid, nullptr, nullptr);
+    k_scan_apply<In, Out, INCLUSIVE><<<grid, SCAN_BLOCK, 0, st>>>(in, out, n, tile);
+    return hipGetLastError();
+}
+
+template <class Flag>
+hipError_t select_impl(const Flag *flags, uint32_t *ids, uint32_t *count32, uint64_t *count64, uint64_t n, void *scratch, hipStream_t st) {
+    if (!scratch || (n && (!flags || !ids)) || n > 0xFFFFFFFFull) return hipErrorInvalidValue;
+    uint64_t *tile = static_cast<uint64_t *>(scratch);
+    const unsigned grid = (unsigned)tiles_of(n);
+    if (n == 0) {   // nothing to look at: the counts still say so
+        k_scan_tile_offsets<<<1, OFFS_BLOCK, 0, st>>>(tile, 0, count32, count64);
+        return hipGetLastError();
+    }
+    k_scan_tile_sums<Flag, NonZero><<<grid, SCAN_BLOCK, 0, st>>>(flags, n, tile, NonZero());
+    k_scan_tile_offsets<<<1, OFFS_BLOCK, 0, st>>>(tile, grid, count32, count64);
+    k_select_apply<Flag><<<grid, SCAN_BLOCK, 0, st>>>(flags, ids, n, tile);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+size_t scan_scratch_bytes(uint64_t n) { return (size_t)(tiles_of(n) + 2) * 8; }
+
+hipError_t scan_exclusive_u32(const uint32_t *in, uint32_t *out, uint64_t n, void *scratch, hipStream_t st) { return scan_impl<uint32_t, uint32_t, false>(in, out, n, scratch, st); }
+hipError_t scan_inclusive_u32(const uint32_t *in, uint32_t *out, uint64_t n, void *scratch, hipStream_t st) { return scan_impl<uint32_t, uint32_t, true>(in, out, n, scratch, st); }
+hipError_t scan_exclusive_u32_u64(const uint32_t *in, uint64_t *out, uint64_t n, void *scratch, hipStream_t st) { return scan_impl<uint32_t, uint64_t, false>(in, out, n, scratch, st); }
+hipError_t scan_exclusive_u64(const uint64_t *in, uint64_t *out, uint64_t n, void *scratch, hipStream_t st) { return scan_impl<uint64_t, uint64_t, false>(in, out, n, scratch, st); }
+hipError_t select_flagged_u8(const uint8_t *flags, uint32_t *ids, uint32_t *count32, uint64_t *count64, uint64_t n, void *scratch, hipStream_t st) {
+    return select_impl<uint8_t>(flags, ids, count32, count64, n, scratch, st);
+}
+hipError_t select_flagged_u32(const uint32_t *flags, uint32_t *ids, uint32_t *count32, uint64_t *count64, uint64_t n, void *scratch, hipStream_t st) {
+    return select_impl<uint32_t>(flags, ids, count32, count64, n, scratch, st);
+}
+
+}  // namespace pf
