@@ -596,6 +596,11 @@ int pf_host_alloc(pf_ctx *, size_t bytes, void **out);
 int pf_fetch(pf_ctx *, void *dst_host, const void *src_dev, uint64_t bytes);
 void pf_host_free(pf_ctx *, void *p);
 
+/* ---- self tests ---------------------------------------------------------------------------- */
+/* The prefix sums and the flag selection the library runs between its kernels (csrc/pf_scan.hpp), over n pseudo-random elements
+ * against sequential host arithmetic: PF_OK, or PF_ERR_HIP with the first difference in pf_last_error. */
+int pf_selftest_scan(pf_ctx *, uint64_t n, uint32_t seed);
+
 /* ---- introspection ---------------------------------------------------------------------- */
 int pf_device_name(pf_ctx *, char *buf, size_t cap);
 /* "domain:bus:device.function" of the context's GPU (the host layer looks up its NUMA node with it) */

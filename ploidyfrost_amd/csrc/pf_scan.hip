@@ -170,3 +170,80 @@ hipError_t select_flagged_u32(const uint32_t *flags, uint32_t *ids, uint32_t *co
 }
 
 }  // namespace pf
+
+// ---- self test (tests/test_gpu_kernels.py) ---------------------------------------------------------------------------------------
+#include <string>
+#include <vector>
+
+#include "pf_ctx.hpp"
+#include "ploidyfrost_hip.h"
+
+extern "C" int pf_selftest_scan(pf_ctx *ctx, uint64_t n, uint32_t seed) {
+    if (!ctx || n == 0 || n > (1ull << 28)) return PF_ERR_ARG;
+    if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
+    // values small enough that no 32-bit sum wraps (the 32-bit scans are then comparable with 64-bit host arithmetic)
+    std::vector<uint32_t> in(n);
+    std::vector<uint8_t> f8(n);
+    uint64_t x = 0x9E3779B97F4A7C15ull ^ seed;
+    for (uint64_t i = 0; i < n; ++i) {
+        x ^= x << 13; x ^= x >> 7; x ^= x << 17;
+        in[i] = (uint32_t)(x % 13);
+        f8[i] = (uint8_t)(((x >> 20) & 7) == 0 ? (1 + ((x >> 40) & 3)) : 0);   // one in eight flagged, with values other than 1
+    }
+    std::vector<uint64_t> ex(n), in64(n);
+    std::vector<uint32_t> want_ids;
+    uint64_t run = 0;
+    for (uint64_t i = 0; i < n; ++i) { ex[i] = run; run += in[i]; in64[i] = (uint64_t)in[i] << 20; if (f8[i]) want_ids.push_back((uint32_t)i); }
+    pf::DevTmp<uint32_t> d_in, d_o32, d_ids, d_f32, d_c32;
+    pf::DevTmp<uint64_t> d_in64, d_o64, d_c64;
+    pf::DevTmp<uint8_t> d_f8, d_tmp;
+    if (d_in.alloc(n * 4) != hipSuccess || d_o32.alloc(n * 4) != hipSuccess || d_ids.alloc(n * 4) != hipSuccess || d_f32.alloc(n * 4) != hipSuccess ||
+        d_c32.alloc(4) != hipSuccess || d_in64.alloc(n * 8) != hipSuccess || d_o64.alloc(n * 8) != hipSuccess || d_c64.alloc(8) != hipSuccess || d_f8.alloc(n) != hipSuccess ||
+        d_tmp.alloc(pf::scan_scratch_bytes(n)) != hipSuccess) {
+        pf::CtxErr{ctx} = "pf_selftest_scan: out of device memory";
+        return PF_ERR_HIP;
+    }
+    hipStream_t st = ctx->stream;
+    std::vector<uint32_t> f32(n), o32(n), ids(n);
+    std::vector<uint64_t> o64(n);
+    for (uint64_t i = 0; i < n; ++i) f32[i] = f8[i] ? 0x80000000u >> (i & 7) : 0;
+    int bad = 0;
+    auto fail = [&](const char *what, uint64_t i) { if (!bad) pf::CtxErr{ctx} = std::string("pf_selftest_scan: ") + what + " differs at " + std::to_string(i); ++bad; };
+#define PF_T(call) do { if ((call) != hipSuccess) { pf::CtxErr{ctx} = std::string(#call) + " failed"; return PF_ERR_HIP; } } while (0)
+    PF_T(hipMemcpyAsync(d_in.p, in.data(), n * 4, hipMemcpyHostToDevice, st));
+    PF_T(hipMemcpyAsync(d_in64.p, in64.data(), n * 8, hipMemcpyHostToDevice, st));
+    PF_T(hipMemcpyAsync(d_f8.p, f8.data(), n, hipMemcpyHostToDevice, st));
+    PF_T(hipMemcpyAsync(d_f32.p, f32.data(), n * 4, hipMemcpyHostToDevice, st));
+    PF_T(pf::scan_exclusive_u32(d_in.p, d_o32.p, n, d_tmp.p, st));
+    PF_T(hipMemcpyAsync(o32.data(), d_o32.p, n * 4, hipMemcpyDeviceToHost, st));
+    PF_T(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n && bad < 4; ++i) if (o32[i] != (uint32_t)ex[i]) fail("exclusive u32", i);
+    PF_T(pf::scan_inclusive_u32(d_in.p, d_o32.p, n, d_tmp.p, st));
+    PF_T(hipMemcpyAsync(o32.data(), d_o32.p, n * 4, hipMemcpyDeviceToHost, st));
+    PF_T(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n && bad < 4; ++i) if (o32[i] != (uint32_t)(ex[i] + in[i])) fail("inclusive u32", i);
+    PF_T(pf::scan_exclusive_u32_u64(d_in.p, d_o64.p, n, d_tmp.p, st));
+    PF_T(hipMemcpyAsync(o64.data(), d_o64.p, n * 8, hipMemcpyDeviceToHost, st));
+    PF_T(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n && bad < 4; ++i) if (o64[i] != ex[i]) fail("exclusive u32 -> u64", i);
+    PF_T(pf::scan_exclusive_u64(d_in64.p, d_o64.p, n, d_tmp.p, st));   // (sums beyond 32 bits)
+    PF_T(hipMemcpyAsync(o64.data(), d_o64.p, n * 8, hipMemcpyDeviceToHost, st));
+    PF_T(hipStreamSynchronize(st));
+    for (uint64_t i = 0; i < n && bad < 4; ++i) if (o64[i] != ex[i] << 20) fail("exclusive u64", i);
+    for (int kind = 0; kind < 2; ++kind) {
+        uint32_t c32 = 0;
+        uint64_t c64 = 0;
+        PF_T(hipMemsetAsync(d_ids.p, 0xFF, n * 4, st));
+        if (kind == 0) PF_T(pf::select_flagged_u8(d_f8.p, d_ids.p, d_c32.p, d_c64.p, n, d_tmp.p, st));
+        else PF_T(pf::select_flagged_u32(d_f32.p, d_ids.p, d_c32.p, d_c64.p, n, d_tmp.p, st));
+        PF_T(hipMemcpyAsync(ids.data(), d_ids.p, n * 4, hipMemcpyDeviceToHost, st));
+        PF_T(hipMemcpyAsync(&c32, d_c32.p, 4, hipMemcpyDeviceToHost, st));
+        PF_T(hipMemcpyAsync(&c64, d_c64.p, 8, hipMemcpyDeviceToHost, st));
+        PF_T(hipStreamSynchronize(st));
+        if (c32 != want_ids.size() || c64 != want_ids.size()) fail(kind ? "select u32: count" : "select u8: count", c64);
+        for (uint64_t i = 0; i < want_ids.size() && bad < 4; ++i) if (ids[i] != want_ids[i]) fail(kind ? "select u32" : "select u8", i);
+        if (want_ids.size() < n && ids[want_ids.size()] != 0xFFFFFFFFu) fail("select: wrote past its count", want_ids.size());
+    }
+#undef PF_T
+    return bad ? PF_ERR_HIP : PF_OK;
+}
