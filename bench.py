@@ -437,17 +437,17 @@ def main():
             gfa, db, n_unitigs, n_kmers = made["gfa"], made["db"], made["n_unitigs"], made["n_kmers"]
         # The device memory the input generator held (tens of GB, in a child process or in torch's cache) is handed back to the driver
         # lazily: on some boxes the load's first large allocation -- the 8.6 GB count table -- then waited a second for it
-        # (`kmc: device decode + table` 1.19 s instead of 0.12 s in one driver-style run).  One large allocation, touched and freed, here:
-        # the generator's leftovers are dealt with before the load is timed, not by it.
+        # (`kmc: device decode + table` 1.19 s instead of 0.12 s in one driver-style run).  One large allocation, touched, here: the
+        # generator's leftovers are dealt with before the load is timed, not by it.  It is HELD until the load is over: freeing it
+        # right here made the stall the rule (the driver clears freed memory before it hands it out again, and a hipMalloc that
+        # arrives meanwhile waits: load_s 2.3 - 2.6 s in four of five runs once the load had become quick enough to arrive in time).
+        scrub_ = None
         try:
             scrub_ = torch.empty(32 << 30, dtype=torch.uint8, device=dev)
             scrub_.zero_()
             torch.cuda.synchronize()
-            del scrub_
         except RuntimeError:
-            pass
-        torch.cuda.empty_cache()
-        torch.cuda.synchronize()
+            scrub_ = None
         hostapi.load_trace(reset=True)
         t0 = time.time()
         if colored:
@@ -455,6 +455,8 @@ def main():
         else:
             run = hostapi.Run(gfa, db, z=Z, device=gpu_index)
         open_s = time.time() - t0
+        del scrub_   # (see above; handed back while the unitig id file is written)
+        torch.cuda.empty_cache()
         run.set_threads(host_threads)
         run.set_overlap_output(True)  # super_bubble.txt is written while PloidyEstimation runs; complete when it returns
         if os.environ.get("PF_BATCH_BUBBLES"):  # experiments: bubbles per batch of the align/format pipeline

@@ -1,5 +1,5 @@
-// Prefix sums and flag selection (pf_scan.hpp): tile sums, their scan by one block, the tiles again with their offsets.
-// HBM-bound, three passes over the input at most (12 - 24 bytes an element); the arrays are a few million elements -- tens of
+// Prefix sums and flag selection (pf_scan.hpp): tile sums, then the tiles again, each block adding up the sums before its own
+// (arrays beyond 33 M elements: one block scans the sums in between).  HBM-bound, two passes over the input (12 - 24 bytes an element); the arrays are a few million elements -- tens of
 // microseconds a call.
 #include "pf_scan.hpp"
 
@@ -92,15 +92,29 @@ __global__ __launch_bounds__(OFFS_BLOCK) void k_scan_tile_offsets(uint64_t *__re
     }
 }
 
-template <class In, class Out, bool INCLUSIVE>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const In *__restrict__ in, Out *__restrict__ out, uint64_t n, const uint64_t *__restrict__ tile_off) {
+// what lies before tile blockIdx.x.  SUMS: `tile` holds the tiles' sums and the block adds up those before its own (a few
+// thousand tiles: some dozens of loads a thread from the L2 -- cheaper than a kernel of one block between the two passes); else it
+// holds the offsets k_scan_tile_offsets made of them.
+template <bool SUMS>
+__device__ inline uint64_t tile_offset(const uint64_t *__restrict__ tile) {
+    if (!SUMS) return tile[blockIdx.x];
+    uint64_t s = 0;
+    for (unsigned t = threadIdx.x; t < blockIdx.x; t += SCAN_BLOCK) s += tile[t];
+    uint64_t total;
+    (void)block_scan(s, total);
+    return total;
+}
+
+template <class In, class Out, bool INCLUSIVE, bool SUMS>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const In *__restrict__ in, Out *__restrict__ out, uint64_t n, const uint64_t *__restrict__ tile) {
     uint64_t v[SCAN_ITEMS];
     load_items(in, n, v, AsIs());
     uint64_t s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+    const uint64_t before = tile_offset<SUMS>(tile);
     uint64_t total;
-    uint64_t run = block_scan(s, total) - s + tile_off[blockIdx.x];   // what lies before this thread's first element
+    uint64_t run = block_scan(s, total) - s + before;   // what lies before this thread's first element
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) {
@@ -110,15 +124,21 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_apply(const In *__restrict_
     }
 }
 
-template <class Flag>
-__global__ __launch_bounds__(SCAN_BLOCK) void k_select_apply(const Flag *__restrict__ flags, uint32_t *__restrict__ ids, uint64_t n, const uint64_t *__restrict__ tile_off) {
+template <class Flag, bool SUMS>
+__global__ __launch_bounds__(SCAN_BLOCK) void k_select_apply(const Flag *__restrict__ flags, uint32_t *__restrict__ ids, uint64_t n, const uint64_t *__restrict__ tile,
+                                                             uint32_t *__restrict__ count32, uint64_t *__restrict__ count64) {
     uint64_t v[SCAN_ITEMS];
     load_items(flags, n, v, NonZero());
     uint64_t s = 0;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i) s += v[i];
+    const uint64_t before = tile_offset<SUMS>(tile);
     uint64_t total;
-    uint64_t at = block_scan(s, total) - s + tile_off[blockIdx.x];
+    uint64_t at = block_scan(s, total) - s + before;
+    if (SUMS && blockIdx.x + 1 == gridDim.x && threadIdx.x == 0) {   // (the last tile knows the count)
+        if (count32) *count32 = (uint32_t)(before + total);
+        if (count64) *count64 = before + total;
+    }
     const uint64_t base = (uint64_t)blockIdx.x * SCAN_TILE + (uint64_t)threadIdx.x * SCAN_ITEMS;
 #pragma unroll
     for (int i = 0; i < SCAN_ITEMS; ++i)
@@ -126,6 +146,9 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_select_apply(const Flag *__restr
 }
 
 inline uint64_t tiles_of(uint64_t n) { return (n + SCAN_TILE - 1) / SCAN_TILE; }
+// up to this many tiles (33 M elements) a block of the second pass adds up the sums of the tiles before its own; beyond, one
+// block turns the sums into offsets in between (the work of the adding grows with the square of the tiles)
+constexpr unsigned kSumsInApply = 16384;
 
 template <class In, class Out, bool INCLUSIVE>
 hipError_t scan_impl(const In *in, Out *out, uint64_t n, void *scratch, hipStream_t st) {
@@ -134,8 +157,12 @@ hipError_t scan_impl(const In *in, Out *out, uint64_t n, void *scratch, hipStrea
     uint64_t *tile = static_cast<uint64_t *>(scratch);
     const unsigned grid = (unsigned)tiles_of(n);
     k_scan_tile_sums<In, AsIs><<<grid, SCAN_BLOCK, 0, st>>>(in, n, tile, AsIs());
-    k_scan_tile_offsets<<<1, OFFS_BLOCK, 0, st>>>(tile, grid, nullptr, nullptr);
-    k_scan_apply<In, Out, INCLUSIVE><<<grid, SCAN_BLOCK, 0, st>>>(in, out, n, tile);
+    if (grid <= kSumsInApply) {
+        k_scan_apply<In, Out, INCLUSIVE, true><<<grid, SCAN_BLOCK, 0, st>>>(in, out, n, tile);
+    } else {
+        k_scan_tile_offsets<<<1, OFFS_BLOCK, 0, st>>>(tile, grid, nullptr, nullptr);
+        k_scan_apply<In, Out, INCLUSIVE, false><<<grid, SCAN_BLOCK, 0, st>>>(in, out, n, tile);
+    }
     return hipGetLastError();
 }
 
@@ -149,8 +176,12 @@ hipError_t select_impl(const Flag *flags, uint32_t *ids, uint32_t *count32, uint
         return hipGetLastError();
     }
     k_scan_tile_sums<Flag, NonZero><<<grid, SCAN_BLOCK, 0, st>>>(flags, n, tile, NonZero());
-    k_scan_tile_offsets<<<1, OFFS_BLOCK, 0, st>>>(tile, grid, count32, count64);
-    k_select_apply<Flag><<<grid, SCAN_BLOCK, 0, st>>>(flags, ids, n, tile);
+    if (grid <= kSumsInApply) {
+        k_select_apply<Flag, true><<<grid, SCAN_BLOCK, 0, st>>>(flags, ids, n, tile, count32, count64);
+    } else {
+        k_scan_tile_offsets<<<1, OFFS_BLOCK, 0, st>>>(tile, grid, count32, count64);
+        k_select_apply<Flag, false><<<grid, SCAN_BLOCK, 0, st>>>(flags, ids, n, tile, nullptr, nullptr);
+    }
     return hipGetLastError();
 }
 

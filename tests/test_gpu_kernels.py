@@ -599,10 +599,10 @@ def test_gather_over_rccl_with_one_rank():
     dev.close()
 
 
-@pytest.mark.parametrize("n", [1, 63, 2047, 2048, 2049, 100_000, 2048 * 1024, 2048 * 1024 + 1, 5_000_011])
+@pytest.mark.parametrize("n", [1, 63, 2047, 2048, 2049, 100_000, 2048 * 1024, 2048 * 1024 + 1, 5_000_011, 2048 * 16384 + 5])
 def test_prefix_sums_and_flag_selection_against_host_arithmetic(n):
     """csrc/pf_scan.hip (tile sums, their scan by one block, the tiles again): one element, a tile to the element, more tiles than
-    the offsets kernel takes in one round, the sizes of a pass -- the four scans and both selections, each against a sequential
+    the offsets kernel takes in one round, the sizes of a pass, more tiles than a block adds up by itself -- the four scans and both selections, each against a sequential
     loop on the host (pf_selftest_scan)"""
     d = hipapi.Device(0)
     try:
