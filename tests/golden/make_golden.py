@@ -190,9 +190,29 @@ def col100():
     return samples
 
 
+def col_n(n: int, seed: int):
+    """n diploid samples over one ten-haplotype genome, made like col100's: the widths of a colour set around the 64-bit words of
+    the device's colour sets -- 64 (one full word), 65 (a second word of one bit), 130 (three words)"""
+    def make():
+        haps = synth.make_haplotypes(synth.HapSpec(1100, 10, seed=seed, gap_lo=18, gap_hi=100, p_multi=0.06, max_ins=5))
+        rng = np.random.default_rng(seed * 100 + n)
+        samples = []
+        for i in range(n):
+            hs = [haps[i % 10], haps[(i + 3) % 10]]
+            hs = [h[(5 * i + 3 * j) % 31: len(h) - ((3 * i + 7 * j) % 43)] for j, h in enumerate(hs)]
+            if i >= n - 6:   # the last samples' private tails: unitigs that lack most colours, their own colours in the last word
+                hs = [np.concatenate([h, rng.integers(0, 4, size=80, dtype=np.uint8)]) for h in hs]
+            samples.append(hs)
+        return samples
+    return make
+
+
 # name: (sample factory -> list of per-sample haplotype lists, k, PloidyFrost args, per-colour cutoffs)
 COLORED_CASES = {
     "col100": (col100, 25, ["-z", "10"], [(5, 1000)] * 100, set(), 1),
+    "col64": (col_n(64, 64), 25, ["-z", "10"], [(5, 1000)] * 64, set(), 1),
+    "col65": (col_n(65, 65), 25, ["-z", "10"], [(5, 1000)] * 65, set(), 1),
+    "col130": (col_n(130, 67), 25, ["-z", "10"], [(5, 1000)] * 130, set(), 1),
     "col3_dip": (col3_dip, 25, [], [(5, 1000)] * 3),
     "col4_mix": (col4_mix, 25, ["-z", "10"], [(5, 1000), (5, 1000), (25, 70), (5, 1000)]),
     "col2_weird": (col2_weird, 31, ["-M", "1.5", "-D", "-0.5", "-G", "-2.25"], [(5, 1000), (10, 400)]),
