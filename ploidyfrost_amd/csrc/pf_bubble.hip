@@ -733,8 +733,12 @@ __device__ int bubble_task(const BubParams &p, const BubOut &o, BubAlloc &al, ui
     return 0;
 }
 
+// Three wavefronts a SIMD: left to itself the compiler takes 212 registers (two wavefronts a SIMD, eight a CU -- a third of what
+// the class grids ask for), and a kernel that spends its time on one lane's dependent steps gains more from a third wavefront
+// than it loses to the 45 registers that go to scratch: K-BUBBLE's share of a pass 56 -> 45 ms at configs[4] (10 M unitigs,
+// PloidyEstimation 93 -> 84 ms), 7.3 -> 6.7 ms at 1 M, 2.7 -> 2.5 ms at configs[2]; four (128 registers, 112 spilled) measures the same.
 template <bool LDS>
-__global__ __launch_bounds__(64) void k_bubble(BubParams p, BubOut o) {
+__global__ __launch_bounds__(64, 3) void k_bubble(BubParams p, BubOut o) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t *nw_base;
     if constexpr (LDS) nw_base = smem;
