@@ -249,7 +249,7 @@ __device__ inline void paths_flush(const PathArgs &a, uint32_t pend_key, uint32_
 constexpr uint32_t PATHS_PAIRWISE = 8;   // up to this many walks the wave orders them pair by pair, 64 characters per step
 
 template <bool BIG>
-__global__ __launch_bounds__(64) void k_call_paths(PathArgs a) {
+__global__ __launch_bounds__(64, 4) void k_call_paths(PathArgs a) {
     const int lane = lane_id();
     __shared__ unsigned long long poff_lds[BIG ? 1 : 256];
     __shared__ uint32_t plen_lds[BIG ? 1 : 256];

@@ -76,7 +76,7 @@ __device__ inline bool colours_of_string(const SiteArgs &a, const char *sp, uint
 }
 
 template <bool COLORED>
-__global__ __launch_bounds__(64) void k_call_sites(SiteArgs a) {
+__global__ __launch_bounds__(64, 4) void k_call_sites(SiteArgs a) {
     const int lane = lane_id();
     const uint32_t KS = a.ks;
     const uint32_t C = COLORED ? a.n_colors : 1;
