@@ -14,7 +14,9 @@ part of the unitig numbering the oracle's loader does not restate (pf_host_minz.
 With PF_FUZZ_GIANT=1 the genomes are 250-400 kb long and carry one to three copied segments (k .. 2k bp) near their start: the
 shared unitig's traversal cannot close before it has walked a whole locus to the end of the chromosome -- traversals of more
 than 4096 vertices, the third K-BFS tier (host walkers by default; PF_FUZZ_GIANT=device switches every other case to k_bfs_huge).
-With PF_FUZZ_COLORED=1 every case is a colored one (two to three samples; CCDBG's calling phase on the resident pipeline).
+With PF_FUZZ_COLORED=1 every case is a colored one (two to three samples; CCDBG's calling phase on the resident pipeline);
+PF_FUZZ_SAMPLES=lo,hi with it: lo .. hi diploid samples over the case's four or six haplotypes, graph and colour file by the
+reference's Bifrost (colour sets of more than one 64-bit word).
 With PF_FUZZ_SCORES=wide the scores are drawn from the whole region the reference accepts (draw_scores: D <= M, G <= M -- zero and
 positive gap scores, D = M, G = M, fractions, a negative match, magnitudes to 1e5); both sides then often end the run themselves
 (a site string's k-mer that is in no database): "oracle rc 1, product rc 1" is agreement."""
@@ -76,6 +78,8 @@ def build_case(seed, tmp, dev, force_colored=None, force_giant=None, wide_scores
         ploidy = 4 if ploidy < 5 else 6
     z = int(rng.integers(4, 13))
     L = int(rng.integers(8000, 40000))
+    if os.environ.get("PF_FUZZ_SAMPLES"):
+        L = 4000 + L % 8000   # (a hundred databases: a short genome)
     spec = synth.HapSpec(L, ploidy, seed=seed, gap_lo=int(rng.integers(5, 30)), gap_hi=int(rng.integers(40, 500)),
                          p_multi=float(rng.choice([0.0, 0.05, 0.15])), max_ins=int(rng.choice([3, 6, 12, 30])),
                          p_snp=float(rng.choice([0.5, 0.75, 0.9])), p_del=0.1)
@@ -110,12 +114,25 @@ def build_case(seed, tmp, dev, force_colored=None, force_giant=None, wide_scores
     colored = rng.random() < 0.35 and ploidy % 2 == 0 and ploidy >= 4 and not giant
     if force_colored is not None:
         colored = bool(force_colored) and not giant
-    use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1" or crowd or bool(giant)
+    many = tuple(int(x) for x in os.environ["PF_FUZZ_SAMPLES"].split(",")) if os.environ.get("PF_FUZZ_SAMPLES") and colored else None
+    use_bifrost = os.environ.get("PF_FUZZ_BIFROST") == "1" or crowd or bool(giant) or bool(many)
     use_reference = os.environ.get("PF_FUZZ_REFERENCE") == "1" or crowd
     try:
         if use_bifrost:
             groups = [haps[2 * i: 2 * i + 2] for i in range(ploidy // 2)] if colored else [haps]
-            if colored:  # samples that do not span the whole genome
+            if colored and many:
+                # lo .. hi diploid samples over the haplotypes drawn above, each short of a few bases at its ends; the last ones with a
+                # private tail (unitigs that lack most colours, their own colours in the last word of a colour set)
+                n_samples = int(np.random.default_rng(seed + 5).integers(many[0], many[1] + 1))
+                tail_rng = np.random.default_rng(seed + 6)
+                groups = []
+                for i in range(n_samples):
+                    hs = [haps[i % ploidy], haps[(i + 1 + i // ploidy) % ploidy]]
+                    hs = [h[(5 * i + 3 * j) % 31: len(h) - ((3 * i + 7 * j) % 43)] for j, h in enumerate(hs)]
+                    if i >= n_samples - 5:
+                        hs = [np.concatenate([h, tail_rng.integers(0, 4, size=80, dtype=np.uint8)]) for h in hs]
+                    groups.append(hs)
+            elif colored:  # samples that do not span the whole genome
                 groups = [[h[int(rng.integers(0, 1500)): len(h) - int(rng.integers(0, 1500))] for h in hs] if i else hs for i, hs in enumerate(groups)]
             fas = []
             for i, hs in enumerate(groups):
