@@ -1276,7 +1276,7 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
     // seq_off[N] = total words; fetch it (host or device pointer)
     uint64_t total_words = 0;
     PF_HIP(hipMemcpy(&total_words, seq_off + N, 8, hipMemcpyDefault));
-    trace.mark("graph: (x) total words fetched");
+    trace.mark("graph: size of the sequence array fetched");
     ctx->N = N;
     ctx->k = k;
     ctx->n_words = total_words;
@@ -1284,9 +1284,7 @@ int pf_upload_graph(pf_ctx *ctx, const uint64_t *seq_words, const uint64_t *seq_
     PF_HIP(hipMemsetAsync(ctx->d_seq, 0, (total_words + 2) * 8, ctx->stream));
     PF_HIP(hipMalloc(&ctx->d_off, ((size_t)N + 1) * 8));
     PF_HIP(hipMalloc(&ctx->d_len, (size_t)N * 4));
-    trace.mark("graph: (x) mallocs");
-    PF_HIP(hipStreamSynchronize(ctx->stream));
-    trace.mark("graph: (x) memset done");
+    trace.mark("graph: arrays allocated");
     PF_HIP(hipMemcpyAsync(ctx->d_seq, seq_words, total_words * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ctx->d_off, seq_off, ((size_t)N + 1) * 8, hipMemcpyDefault, ctx->stream));
     PF_HIP(hipMemcpyAsync(ctx->d_len, len_bp, (size_t)N * 4, hipMemcpyDefault, ctx->stream));
