@@ -203,6 +203,8 @@ hipError_t select_flagged_u32(const uint32_t *flags, uint32_t *ids, uint32_t *co
 }  // namespace pf
 
 // ---- self test (tests/test_gpu_kernels.py) ---------------------------------------------------------------------------------------
+#include <cstdio>
+#include <cstdlib>
 #include <string>
 #include <vector>
 
@@ -245,6 +247,29 @@ extern "C" int pf_selftest_scan(pf_ctx *ctx, uint64_t n, uint32_t seed) {
     PF_T(hipMemcpyAsync(d_in64.p, in64.data(), n * 8, hipMemcpyHostToDevice, st));
     PF_T(hipMemcpyAsync(d_f8.p, f8.data(), n, hipMemcpyHostToDevice, st));
     PF_T(hipMemcpyAsync(d_f32.p, f32.data(), n * 4, hipMemcpyHostToDevice, st));
+    if (getenv("PF_SCAN_TIMES")) {   // diag: the four scans and a selection over n elements, alone on the device
+        hipEvent_t a, b;
+        PF_T(hipEventCreate(&a));
+        PF_T(hipEventCreate(&b));
+        PF_T(hipStreamSynchronize(st));
+        auto timed = [&](const char *what, auto &&call) {
+            (void)call();   // (first launch)
+            (void)hipEventRecord(a, st);
+            for (int r = 0; r < 10; ++r) (void)call();
+            (void)hipEventRecord(b, st);
+            (void)hipEventSynchronize(b);
+            float ms = 0;
+            (void)hipEventElapsedTime(&ms, a, b);
+            fprintf(stderr, "[scan] %-22s n = %llu: %.1f us\n", what, (unsigned long long)n, ms * 100.0);
+        };
+        timed("exclusive u32", [&] { return pf::scan_exclusive_u32(d_in.p, d_o32.p, n, d_tmp.p, st); });
+        timed("inclusive u32", [&] { return pf::scan_inclusive_u32(d_in.p, d_o32.p, n, d_tmp.p, st); });
+        timed("exclusive u32 -> u64", [&] { return pf::scan_exclusive_u32_u64(d_in.p, d_o64.p, n, d_tmp.p, st); });
+        timed("exclusive u64", [&] { return pf::scan_exclusive_u64(d_in64.p, d_o64.p, n, d_tmp.p, st); });
+        timed("select u8", [&] { return pf::select_flagged_u8(d_f8.p, d_ids.p, d_c32.p, d_c64.p, n, d_tmp.p, st); });
+        (void)hipEventDestroy(a);
+        (void)hipEventDestroy(b);
+    }
     PF_T(pf::scan_exclusive_u32(d_in.p, d_o32.p, n, d_tmp.p, st));
     PF_T(hipMemcpyAsync(o32.data(), d_o32.p, n * 4, hipMemcpyDeviceToHost, st));
     PF_T(hipStreamSynchronize(st));
