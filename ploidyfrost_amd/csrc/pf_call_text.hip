@@ -74,15 +74,18 @@ __global__ void k_call_has(const pf_bubble_result *__restrict__ res, uint32_t nb
 // The write pass stages the four large streams in LDS: consecutive lanes hold consecutive bubbles, so a wavefront's text in a
 // stream is one contiguous span of the output; it is formatted into LDS and copied out by consecutive lanes (whole 64-byte
 // segments per store).  A span that does not fit its stage (long rows) is written directly, byte by byte, as before.
-constexpr uint32_t FMT_STAGE[4] = {12288, 2048, 2048, 3072};   // alignseq, allele_frequency, bifre, bicov
+// Stages of 13 KB a wavefront and 168 registers (launch bounds: three wavefronts a SIMD; 171 and two before): six blocks a CU
+// instead of four -- a launch 0.194 -> 0.177 ms, a step 20.4 -> 20.0 ms at configs[2]; stages of 9.7 KB with 128 registers (four a
+// SIMD) measure no better (0.181 ms).
+constexpr uint32_t FMT_STAGE[4] = {8192, 1536, 1536, 2048};   // alignseq, allele_frequency, bifre, bicov
 constexpr int FMT_STAGED_STREAM[4] = {1, 0, 2, 6};
 
 template <bool W, bool COLORED>
-__global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
+__global__ __launch_bounds__(FMT_BLOCK, W ? 3 : 4) void k_call_format(FmtArgs a) {
     const uint32_t jj = blockIdx.x * blockDim.x + threadIdx.x;   // index inside the text batch (sizes / offsets)
     const uint32_t j = a.j0 + jj;                                // ... inside the aligned batch (results, numbering, site values)
     unsigned long long allele[4] = {0, 0, 0, 0}, core_cov = 0, core_num = 0;
-    __shared__ __attribute__((aligned(16))) char s_stage[W ? (FMT_BLOCK / 64) * (12288 + 2048 + 2048 + 3072) : 4];
+    __shared__ __attribute__((aligned(16))) char s_stage[W ? (FMT_BLOCK / 64) * (FMT_STAGE[0] + FMT_STAGE[1] + FMT_STAGE[2] + FMT_STAGE[3]) : 4];
     bool staged[4] = {false, false, false, false};
     uint64_t span0[4] = {0, 0, 0, 0};
     uint32_t span_len[4] = {0, 0, 0, 0};
@@ -95,7 +98,7 @@ __global__ __launch_bounds__(FMT_BLOCK) void k_call_format(FmtArgs a) {
         const uint32_t w_first = jj & ~63u;
         if (w_first < a.nb) {   // (wave-uniform)
             const uint32_t w_end = w_first + 64 < a.nb ? w_first + 64 : a.nb;
-            char *base = s_stage + (threadIdx.x >> 6) * (12288 + 2048 + 2048 + 3072);
+            char *base = s_stage + (threadIdx.x >> 6) * (FMT_STAGE[0] + FMT_STAGE[1] + FMT_STAGE[2] + FMT_STAGE[3]);
             uint32_t acc = 0;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
