@@ -396,6 +396,7 @@ typedef struct pf_call_result {
     uint64_t snp_jobs, pair_jobs, wave_jobs; /* of align_jobs: finished by K-SNP, by K-PAIR, sent to K-BUBBLE */
     uint64_t stack_jobs;                     /* ... finished by K-STACK (paths of one length, alignment = the paths stacked) */
     uint64_t alignseq_packed_len;            /* pf_call_set_alignseq_packed: bytes stream PF_OUT_ALIGNSEQ takes in the slab (text_len keeps the text's) */
+    uint64_t numeric_packed;                 /* pf_call_set_numeric_packed: 1 when the slab's fetches deliver the numeric streams at four bits a character */
 } pf_call_result;
 #define PF_CALL_SLABS 4 /* text slabs of a context: a slab is free again once pf_call_fetch has copied it */
 #define PF_CALL_LANES 4 /* aligned ranges a context keeps resident side by side (pf_call_align_lane) */
@@ -416,6 +417,18 @@ int pf_call_text(pf_ctx *, int slab, uint64_t var_count_base, pf_call_result *ou
  * (file offsets); .alignseq_packed_len is what the stream takes in the slab, i.e. the length to pass to pf_call_fetch /
  * pf_call_fetch_slab for it.  Default off. */
 int pf_call_set_alignseq_packed(pf_ctx *, int on);
+/* The other nine streams are numbers: text over sixteen characters -- the digits, '.', tab, newline, '-', 'e', '+' -- and, with
+ * alignseq packed, half of what a pass sends over PCIe.  on != 0: the pf_call_text* calls that follow leave a second form of the slab
+ * for the fetches (K-NIB): every numeric stream at FOUR BITS a character (first character in the low nibble of a byte; code c of
+ * "0123456789.\t\n-e+"), PF_NUMERIC_PACKED_LEN(text_len) bytes; alignseq as before, its length rounded up to 16; and, behind the ten
+ * streams, 16 bytes whose first word has bit s set when stream s holds a character outside the sixteen ("nan", "inf": a frequency
+ * of 0 / 0) -- that stream's nibbles are then not its text, and pf_call_fetch_text hands its text over as K-TEXT wrote it.
+ * pf_call_fetch / pf_call_fetch_slab / pf_call_fetch_range speak of this form (lengths as above; pf_call_fetch_slab with every
+ * stream at its full length delivers the 16 bytes of the tail as well); pf_call_result.text_len stays the text's, .numeric_packed
+ * says the form is there.  Default off. */
+#define PF_NUMERIC_PACKED_LEN(text_len) (((((uint64_t)(text_len)) + 1) / 2 + 15) & ~15ull)
+int pf_call_set_numeric_packed(pf_ctx *, int on);
+int pf_call_fetch_text(pf_ctx *, int slab, int stream, char *dst, uint64_t len);
 /* Takes the device buffers pf_call_align(_lane) would take on its first call for ranges of up to n_bubbles bubbles -- to be called
  * beside the load, so that a one-shot run does not pay its first alignment launch with two dozen allocations.  A hint: sizes that
  * turn out too small grow in pf_call_align as before.  Needs nothing but the context: it may run on a helper thread while another

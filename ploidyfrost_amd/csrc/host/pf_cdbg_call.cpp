@@ -16,12 +16,39 @@
 #include <cstring>
 #include <ctime>
 #include <deque>
+#include <memory>
 #include <mutex>
 #include <thread>
 
 #include "../pf_alnpack.hpp"
 #include "pf_cdbg_impl.hpp"
 #include "pf_parallel.hpp"
+
+namespace {
+// K-NIB's four bits a character back to text: two characters a byte, first in the low nibble
+inline void nib_expand(char *dst, const uint8_t *src, uint64_t n) {
+    static const struct Lut {
+        uint16_t two[256];
+        Lut() {
+            static const char sym[17] = "0123456789.\t\n-e+";
+            for (int b = 0; b < 256; ++b) two[b] = (uint16_t)((uint8_t)sym[b & 15] | ((uint16_t)(uint8_t)sym[b >> 4] << 8));
+        }
+    } lut;
+    uint64_t i = 0;
+    for (; i + 16 <= n; i += 16) {   // eight bytes of nibbles -> sixteen characters
+        uint64_t in;
+        memcpy(&in, src + (i >> 1), 8);
+        uint16_t w[8];
+        for (int x = 0; x < 8; ++x) w[x] = lut.two[(in >> (8 * x)) & 0xFF];
+        memcpy(dst + i, w, 16);
+    }
+    for (; i + 2 <= n; i += 2) {
+        const uint16_t w = lut.two[src[i >> 1]];
+        memcpy(dst + i, &w, 2);
+    }
+    if (i < n) dst[i] = (char)(lut.two[src[i >> 1]] & 0xFF);
+}
+}  // namespace
 
 namespace pfh {
 
@@ -320,12 +347,21 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
     // writer below; PF_ALIGNSEQ_ASCII=1 keeps the device writing the text itself (measurements, and the check that both give one file)
     const bool aln_packed = !getenv("PF_ALIGNSEQ_ASCII");
     if (pf_call_set_alignseq_packed(ctx_, aln_packed ? 1 : 0) != PF_OK) return fail(PF_ERR_HIP, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
+    // the other nine streams -- numbers: sixteen characters -- leave it at four bits a character (K-NIB) and become text in the
+    // writer as well; PF_NUMERIC_ASCII=1 keeps them as text on the way (measurements, and the check that both give the same files).
+    // The copy to the host is what a pass ends with: 17.7 MB a piece at 55 GB/s, 0.33 ms each, twelve pieces behind the alignment.
+    const bool num_packed = !getenv("PF_NUMERIC_ASCII");
+    if (pf_call_set_numeric_packed(ctx_, num_packed ? 1 : 0) != PF_OK) return fail(PF_ERR_HIP, std::string(tag_) + "::PloidyEstimation(): " + pf_last_error(ctx_));
     struct PackGuard {   // the sliced calls (ploidy_text, one graph over several ranks) read the text as the device writes it
         pf_ctx *c;
-        ~PackGuard() { (void)pf_call_set_alignseq_packed(c, 0); }
+        ~PackGuard() { (void)pf_call_set_alignseq_packed(c, 0); (void)pf_call_set_numeric_packed(c, 0); }
     } pack_guard{ctx_};
     // what stream s of a piece takes in a slab
-    auto slab_len = [](const pf_call_result &r, int s) { return (s == PF_OUT_ALIGNSEQ && r.alignseq_packed_len) ? r.alignseq_packed_len : r.text_len[s]; };
+    auto slab_len = [](const pf_call_result &r, int s) -> uint64_t {
+        const uint64_t aln = (s == PF_OUT_ALIGNSEQ && r.alignseq_packed_len) ? r.alignseq_packed_len : r.text_len[s];
+        if (!r.numeric_packed) return aln;
+        return s == PF_OUT_ALIGNSEQ ? ((aln + 15) & ~15ull) : PF_NUMERIC_PACKED_LEN(r.text_len[s]);
+    };
 
     // ---- pieces: device (this thread) | copy back (fetcher thread) | append to the files (writer thread) ----
     // (PF_BATCH_BUBBLES: tools/fuzz_parity.py drives the CLI through many small pieces and ranges with it)
@@ -337,6 +373,8 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
         int slab;    // on the device (PF_CALL_SLABS of them: a whole range can be formatted before the alignment kernels of
                      // the next range fill the device); the pinned host slabs alternate, piece b -> b % 2
         int hslab;
+        // numeric streams whose nibbles are not their text (a character outside the sixteen): fetched as text by the fetcher
+        std::shared_ptr<std::vector<std::vector<char>>> plain;
     };
     std::mutex mu;
     std::condition_variable cv;
@@ -376,8 +414,20 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             uint64_t total = 0, fetch_len[PF_CALL_STREAMS];
             for (int s = 0; s < PF_CALL_STREAMS; ++s) { fetch_len[s] = slab_len(d.res, s); total += fetch_len[s]; }
             PinnedBuf<char> &hb = cx_.slab[d.hslab];
-            hb.ensure(ctx_, std::max<uint64_t>(total, 1));
-            const int st = pf_call_fetch_slab(ctx_, d.slab, hb.p, fetch_len);
+            hb.ensure(ctx_, std::max<uint64_t>(total, 1) + 16);
+            int st = pf_call_fetch_slab(ctx_, d.slab, hb.p, fetch_len);
+            if (st == PF_OK && d.res.numeric_packed) {
+                uint32_t flagged = 0;   // (the tail behind the streams: bit s = stream s holds something else than numbers)
+                memcpy(&flagged, hb.p + total, 4);
+                if (flagged) {
+                    d.plain = std::make_shared<std::vector<std::vector<char>>>((size_t)PF_CALL_STREAMS);
+                    for (int s = 0; s < PF_CALL_STREAMS && st == PF_OK; ++s)
+                        if (((flagged >> s) & 1) && d.res.text_len[s]) {
+                            (*d.plain)[(size_t)s].resize(d.res.text_len[s]);
+                            st = pf_call_fetch_text(ctx_, d.slab, s, (*d.plain)[(size_t)s].data(), d.res.text_len[s]);
+                        }
+                }
+            }
             {
                 std::lock_guard<std::mutex> lk(mu);
                 fetched = b + 1;
@@ -410,6 +460,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
             // append: every stream at its running offset through a shared mapping, copied by all threads side by side
             if (write_files_) {
                 CopySpan spans[PF_CALL_STREAMS];
+                bool nib_span[PF_CALL_STREAMS] = {};   // the span's source is nibbles: expanded instead of copied
                 size_t n_spans = 0;
                 pf::AlnPackPiece packed;   // alignseq of this piece, when it came packed: written out of its records, group by group
                 char *packed_dst = nullptr;
@@ -423,19 +474,40 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                         packed_dst = dst;
                         continue;
                     }
-                    if (dst) spans[n_spans++] = CopySpan{dst, hb.p + off[s], d.res.text_len[s]};
-                    else if (maps[s].write(files[(size_t)s].bytes, hb.p + off[s], d.res.text_len[s], T)) files[(size_t)s].rc = 1;   // (no mapping: pwrite)
+                    const char *src = hb.p + off[s];
+                    bool nib = d.res.numeric_packed != 0 && s != PF_OUT_ALIGNSEQ;   // (alignseq as text, PF_ALIGNSEQ_ASCII: copied)
+                    if (nib && d.plain && !(*d.plain)[(size_t)s].empty()) { src = (*d.plain)[(size_t)s].data(); nib = false; }   // (fetched as text)
+                    if (dst) {
+                        nib_span[n_spans] = nib;
+                        spans[n_spans++] = CopySpan{dst, src, d.res.text_len[s]};
+                    } else if (nib) {   // (no mapping: text first, then pwrite)
+                        std::vector<char> tmp(d.res.text_len[s]);
+                        nib_expand(tmp.data(), reinterpret_cast<const uint8_t *>(src), d.res.text_len[s]);
+                        if (maps[s].write(files[(size_t)s].bytes, tmp.data(), tmp.size(), T)) files[(size_t)s].rc = 1;
+                    } else if (maps[s].write(files[(size_t)s].bytes, src, d.res.text_len[s], T)) files[(size_t)s].rc = 1;   // (no mapping: pwrite)
                 }
                 // the other streams' copies and alignseq's groups in one dispatch of the pool
                 constexpr uint64_t PIECE = 1u << 20;
                 std::vector<CopySpan> cut;
-                for (size_t i = 0; i < n_spans; ++i)
-                    for (uint64_t at = 0; at < spans[i].len; at += PIECE) cut.push_back(CopySpan{spans[i].dst + at, spans[i].src + at, std::min<uint64_t>(PIECE, spans[i].len - at)});
+                std::vector<char> cut_nib;
+                constexpr uint64_t NIB_PIECE = 128u << 10;   // (expanding is a table look-up a byte: an eighth of what a thread copies in the same time)
+                for (size_t i = 0; i < n_spans; ++i) {
+                    const uint64_t step = nib_span[i] ? NIB_PIECE : PIECE;   // (both even: a piece of text starts on a byte of nibbles)
+                    for (uint64_t at = 0; at < spans[i].len; at += step) {
+                        cut.push_back(CopySpan{spans[i].dst + at, spans[i].src + (nib_span[i] ? at / 2 : at), std::min<uint64_t>(step, spans[i].len - at)});
+                        cut_nib.push_back(nib_span[i] ? 1 : 0);
+                    }
+                }
                 constexpr uint64_t GROUPS_PER_TASK = 16;   // 4096 bubbles, about 600 KB of text
                 const size_t n_aln = packed_dst ? (size_t)((packed.n_groups + GROUPS_PER_TASK - 1) / GROUPS_PER_TASK) : 0;
                 std::atomic<int> bad{0};
                 parallel_chunks(n_aln + cut.size(), 1, T, [&](size_t i, size_t, size_t) {
-                    if (i >= n_aln) { const CopySpan &c = cut[i - n_aln]; memcpy(c.dst, c.src, (size_t)c.len); return; }   // (alignseq first: the larger tasks)
+                    if (i >= n_aln) {   // (alignseq first: the larger tasks)
+                        const CopySpan &c = cut[i - n_aln];
+                        if (cut_nib[i - n_aln]) nib_expand(c.dst, reinterpret_cast<const uint8_t *>(c.src), c.len);
+                        else memcpy(c.dst, c.src, (size_t)c.len);
+                        return;
+                    }
                     const uint64_t g0 = (uint64_t)i * GROUPS_PER_TASK, g1 = std::min<uint64_t>(packed.n_groups, g0 + GROUPS_PER_TASK);
                     uint64_t t0_, r0_, t1_, r1_;
                     packed.entry(g0, t0_, r0_);
@@ -448,7 +520,14 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 if (bad) files[PF_OUT_ALIGNSEQ].rc = 1;
                 if (!packed_tmp.empty() && maps[PF_OUT_ALIGNSEQ].write(files[PF_OUT_ALIGNSEQ].bytes, packed_tmp.data(), packed_tmp.size(), T)) files[PF_OUT_ALIGNSEQ].rc = 1;
             }
-            if (!write_files_) last_allfre_.append(hb.p + off[0], d.res.text_len[0]);   // (else: read back from the file on demand)
+            if (!write_files_) {   // (else: read back from the file on demand)
+                if (d.plain && !(*d.plain)[0].empty()) last_allfre_.append((*d.plain)[0].data(), d.res.text_len[0]);
+                else if (d.res.numeric_packed) {
+                    const size_t at0 = last_allfre_.size();
+                    last_allfre_.resize(at0 + d.res.text_len[0]);
+                    nib_expand(&last_allfre_[at0], reinterpret_cast<const uint8_t *>(hb.p + off[0]), d.res.text_len[0]);
+                } else last_allfre_.append(hb.p + off[0], d.res.text_len[0]);
+            }
             for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].bytes += d.res.text_len[s];
             write_s += since(tw);
             if (trace) fprintf(stderr, "[ploidy]   batch %zu written %.2f ms\n", b, since(t_all) * 1e3);

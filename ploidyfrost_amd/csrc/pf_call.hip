@@ -1104,6 +1104,47 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     ctx_end_at(ctx, at, st);
     ctx_units(ctx, PF_K_CALL_FORMAT, nb);
     PF_HIP(hipGetLastError());
+    S->fetch_base[slab] = S->out[slab].as<char>();
+    S->nib[slab] = false;
+    out->numeric_packed = 0;
+    for (int s = 0; s < N_STREAMS; ++s) { S->txt_off[slab][s] = S->out_off[slab][s]; S->txt_len[slab][s] = S->out_len[slab][s]; }
+    if (S->pack_numeric) {
+        // K-NIB behind the write pass: what the fetches copy is a second buffer -- the numeric streams at four bits a character,
+        // alignseq as it lies in the slab, every region a multiple of 16 bytes, and a 16-byte tail whose first word says which
+        // streams held a character outside the sixteen (those are fetched as text: pf_call_fetch_text)
+        uint64_t foff[N_STREAMS], flen[N_STREAMS], fall = 0;
+        for (int s = 0; s < N_STREAMS; ++s) {
+            flen[s] = s == PF_OUT_ALIGNSEQ ? ((slab_len(s) + 15) & ~15ull) : PF_NUMERIC_PACKED_LEN(totals[s]);
+            foff[s] = fall;
+            fall += flen[s];
+        }
+        NEED(S->outp[slab], fall + 16);
+        char *pb = S->outp[slab].as<char>();
+        PF_HIP(hipMemsetAsync(pb + fall, 0, 16, st));
+        if (slab_len(PF_OUT_ALIGNSEQ))
+            PF_HIP(hipMemcpyAsync(pb + foff[PF_OUT_ALIGNSEQ], S->out[slab].as<char>() + S->txt_off[slab][PF_OUT_ALIGNSEQ], (size_t)slab_len(PF_OUT_ALIGNSEQ), hipMemcpyDeviceToDevice, st));
+        NibArgs na;
+        int x = 0;
+        uint64_t units = 0;
+        for (int s = 0; s < N_STREAMS; ++s) {
+            if (s == PF_OUT_ALIGNSEQ) continue;
+            na.src[x] = S->out[slab].as<char>() + S->txt_off[slab][s];
+            na.dst[x] = reinterpret_cast<uint8_t *>(pb + foff[s]);
+            na.len[x] = totals[s];
+            na.unit0[x] = units;
+            na.stream[x] = (uint32_t)s;
+            units += (totals[s] + 15) / 16;
+            ++x;
+        }
+        na.unit0[NIB_STREAMS] = units;
+        na.flag = reinterpret_cast<uint32_t *>(pb + fall);
+        if (units) k_text_nibbles<<<(unsigned)((units + 255) / 256), 256, 0, st>>>(na);
+        PF_HIP(hipGetLastError());
+        for (int s = 0; s < N_STREAMS; ++s) { S->out_off[slab][s] = foff[s]; S->out_len[slab][s] = flen[s]; }
+        S->fetch_base[slab] = pb;
+        S->nib[slab] = true;
+        out->numeric_packed = 1;
+    }
     // no wait for the write pass: the fetches of this slab wait for it on their own stream (text_ev), and the next piece's count
     // pass queues behind it on this one
     if (!S->text_ev[slab]) PF_HIP(hipEventCreateWithFlags(&S->text_ev[slab], hipEventDisableTiming));
@@ -1115,6 +1156,28 @@ static int call_text_impl(pf_ctx *ctx, int lane, int slab, uint64_t first, uint6
     out->core_cov = hc.core_cov;
     out->core_num = hc.core_num;
 #undef NEED
+    return PF_OK;
+}
+
+int pf_call_set_numeric_packed(pf_ctx *ctx, int on) {
+    if (!ctx) return PF_ERR_ARG;
+    CallState *S = state_of(ctx);
+    if (!S) return PF_ERR_HIP;
+    S->pack_numeric = on != 0;
+    return PF_OK;
+}
+
+// the text of one stream of a slab as K-TEXT wrote it, whatever the fetches otherwise copy (the way out for a numeric stream whose
+// bit is set in the flag word)
+int pf_call_fetch_text(pf_ctx *ctx, int slab, int stream, char *dst, uint64_t len) {
+    if (!ctx || !ctx->call || slab < 0 || slab >= PF_CALL_SLABS || stream < 0 || stream >= N_STREAMS) return PF_ERR_ARG;
+    CallState *S = ctx->call;
+    if (len > S->txt_len[slab][stream] || (len && !dst)) return PF_ERR_ARG;
+    if (len == 0) return PF_OK;
+    if (hipSetDevice(ctx->device) != hipSuccess || !S->copy_stream) return PF_ERR_HIP;
+    if (S->text_ev[slab] && hipStreamWaitEvent(S->copy_stream, S->text_ev[slab], 0) != hipSuccess) return PF_ERR_HIP;
+    if (hipMemcpyAsync(dst, S->out[slab].as<char>() + S->txt_off[slab][stream], (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
 }
 
@@ -1161,7 +1224,7 @@ int pf_call_fetch(pf_ctx *ctx, int slab, int stream, char *dst, uint64_t len) {
     if (hipSetDevice(ctx->device) != hipSuccess) return PF_ERR_HIP;
     if (!S->copy_stream) return PF_ERR_HIP;
     if (S->text_ev[slab] && hipStreamWaitEvent(S->copy_stream, S->text_ev[slab], 0) != hipSuccess) return PF_ERR_HIP;
-    if (hipMemcpyAsync(dst, S->out[slab].as<char>() + S->out_off[slab][stream], (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (hipMemcpyAsync(dst, S->fetch_base[slab] + S->out_off[slab][stream], (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     if (hipStreamSynchronize(S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;
 }
@@ -1183,12 +1246,13 @@ int pf_call_fetch_slab(pf_ctx *ctx, int slab, char *dst, const uint64_t *len) {
     }
     size_t tl_at = (size_t)-1;
     (void)ctx_begin_at(ctx, PF_K_COPY_TEXT, S->copy_stream, &tl_at);
-    if (whole) {   // the slab as it lies: one copy
-        if (at && hipMemcpyAsync(dst, S->out[slab].p, (size_t)at, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (whole) {   // the slab as it lies: one copy (with the 16-byte tail behind the streams when the numeric streams are packed)
+        const uint64_t tail = S->nib[slab] ? 16 : 0;
+        if (at + tail && hipMemcpyAsync(dst, S->fetch_base[slab], (size_t)(at + tail), hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     } else {
         at = 0;
         for (int s = 0; s < N_STREAMS; ++s) {
-            if (len[s] && hipMemcpyAsync(dst + at, S->out[slab].as<char>() + S->out_off[slab][s], (size_t)len[s], hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess)
+            if (len[s] && hipMemcpyAsync(dst + at, S->fetch_base[slab] + S->out_off[slab][s], (size_t)len[s], hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess)
                 return PF_ERR_HIP;
             at += len[s];
         }
@@ -1212,7 +1276,7 @@ int pf_call_fetch_range(pf_ctx *ctx, int slab, uint64_t first_byte, char *dst, u
     if (S->text_ev[slab] && hipStreamWaitEvent(S->copy_stream, S->text_ev[slab], 0) != hipSuccess) return PF_ERR_HIP;
     size_t tl_at = (size_t)-1;
     (void)ctx_begin_at(ctx, PF_K_COPY_TEXT, S->copy_stream, &tl_at);
-    if (len && hipMemcpyAsync(dst, S->out[slab].as<char>() + first_byte, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
+    if (len && hipMemcpyAsync(dst, S->fetch_base[slab] + first_byte, (size_t)len, hipMemcpyDeviceToHost, S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     ctx_end_at(ctx, tl_at, S->copy_stream);
     if (hipEventRecord(S->fetch_ev[slot], S->copy_stream) != hipSuccess) return PF_ERR_HIP;
     return PF_OK;

@@ -116,6 +116,7 @@ struct CallState {
     DevBuf ccov_sum, ccov_min, ccov_max, ccov_miss;
     std::atomic<uint32_t> sites_ks{0};   // K-SITES: room per site string once a launch asked for more than 2k + 64
     bool pack_alignseq = false;   // pf_call_set_alignseq_packed
+    bool pack_numeric = false;    // pf_call_set_numeric_packed
     // scan
     DevBuf side_cnt, side_base, sides, ctask, scan_tmp, target, pending, killed, rstate, rflag, rsmall;
     uint64_t n_sides = 0;
@@ -165,6 +166,13 @@ struct CallState {
     // (the ten streams of a slab lie one after the other in one buffer, as the host wants them: one copy fetches a slab)
     DevBuf out[PF_CALL_SLABS];
     uint64_t out_len[PF_CALL_SLABS][N_STREAMS] = {}, out_off[PF_CALL_SLABS][N_STREAMS] = {};
+    // pf_call_set_numeric_packed: what the fetches copy is then a second buffer per slab -- the numeric streams at four bits a
+    // character, alignseq as it lies in `out`, a 16-byte tail with the flag word -- and out_len / out_off speak of that one; the text
+    // stays where K-TEXT wrote it (txt_off / txt_len: pf_call_fetch_text, the way out for a stream with other characters)
+    DevBuf outp[PF_CALL_SLABS];
+    const char *fetch_base[PF_CALL_SLABS] = {};
+    bool nib[PF_CALL_SLABS] = {};
+    uint64_t txt_len[PF_CALL_SLABS][N_STREAMS] = {}, txt_off[PF_CALL_SLABS][N_STREAMS] = {};
     hipStream_t copy_stream = nullptr;
     hipEvent_t fetch_ev[2] = {nullptr, nullptr};   // pf_call_fetch_range / pf_call_fetch_wait
     hipEvent_t text_ev[PF_CALL_SLABS] = {};        // the write pass of the piece in a slab has finished (the fetches wait for it on their stream)
@@ -193,6 +201,7 @@ struct CallState {
             if (w.ev_paths) { (void)hipEventDestroy(w.ev_paths); w.ev_paths = nullptr; }
         }
         for (DevBuf &b : out) b.release();
+        for (DevBuf &b : outp) b.release();
         if (copy_stream) { (void)hipStreamDestroy(copy_stream); copy_stream = nullptr; }
         for (hipEvent_t &e : fetch_ev)
             if (e) { (void)hipEventDestroy(e); e = nullptr; }
@@ -546,6 +555,17 @@ struct FmtArgs {
 
 constexpr uint32_t FMT_BLOCK = 128;
 
+// K-NIB: the numeric streams of a text piece at four bits a character (pf_call_set_numeric_packed)
+constexpr int NIB_STREAMS = N_STREAMS - 1;   // all but alignseq
+struct NibArgs {
+    const char *src[NIB_STREAMS];
+    uint8_t *dst[NIB_STREAMS];
+    uint64_t len[NIB_STREAMS];
+    uint64_t unit0[NIB_STREAMS + 1];   // units of 16 characters before each stream's
+    uint32_t stream[NIB_STREAMS];      // which stream (bit of the flag word)
+    uint32_t *flag;                    // bit s: stream s holds a character outside the sixteen
+};
+
 struct SbArgs {
     const uint8_t *flags;
     const uint32_t *plus, *minus;
@@ -576,5 +596,6 @@ __global__ void k_call_totals(const uint64_t *, const uint32_t *, uint32_t, uint
 __global__ void k_sb_count(SbArgs, uint32_t *);   // pf_call_text.hip
 template <bool W> __global__ void k_sb_format(SbArgs);   // pf_call_text.hip
 __global__ void k_format_doubles(const double *, uint64_t, char *, uint8_t *);   // pf_call_text.hip
+__global__ void k_text_nibbles(NibArgs);   // pf_call_text.hip
 
 }  // namespace pf_call

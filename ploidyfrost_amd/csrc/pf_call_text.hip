@@ -519,6 +519,45 @@ __global__ void k_format_doubles(const double *__restrict__ x, uint64_t n, char 
     len[i] = (uint8_t)(s.p - (out + i * 32));
 }
 
+// K-NIB.  The nine numeric streams are written in sixteen characters -- the digits, '.', tab, newline, '-', 'e', '+' -- and half of
+// what a pass sends over PCIe is these streams: a thread takes sixteen characters of a stream's text (as K-TEXT left it in the
+// slab) and leaves eight bytes, first character in the low nibble.  A stream with any other character ("nan", "inf": a frequency
+// of 0 / 0) sets its bit of the flag word, and the caller fetches that stream as text.  HBM-bound, 1.5 bytes a character.
+__global__ __launch_bounds__(256) void k_text_nibbles(NibArgs a) {
+    const uint64_t u = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= a.unit0[NIB_STREAMS]) return;
+    int s = 0;
+#pragma unroll
+    for (int x = 1; x < NIB_STREAMS; ++x) s += u >= a.unit0[x] ? 1 : 0;
+    const uint64_t at = (u - a.unit0[s]) * 16;
+    const char *p = a.src[s] + at;
+    const uint64_t left = a.len[s] - at;
+    char c[16];
+    if (left >= 16) {
+        memcpy(c, p, 16);
+    } else {
+#pragma unroll
+        for (int j = 0; j < 16; ++j) c[j] = (uint64_t)j < left ? p[j] : '0';
+    }
+    uint64_t w = 0;
+    bool bad = false;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const unsigned ch = (unsigned char)c[j], d = ch - '0';
+        unsigned n = d;
+        n = ch == '.' ? 10u : n;
+        n = ch == '\t' ? 11u : n;
+        n = ch == '\n' ? 12u : n;
+        n = ch == '-' ? 13u : n;
+        n = ch == 'e' ? 14u : n;
+        n = ch == '+' ? 15u : n;
+        bad = bad || n > 15u;
+        w |= (uint64_t)(n & 15u) << (4 * j);
+    }
+    *reinterpret_cast<uint64_t *>(a.dst[s] + (u - a.unit0[s]) * 8) = w;
+    if (bad) atomicOr(a.flag, 1u << a.stream[s]);
+}
+
 // the forms pf_call.hip launches
 template __global__ void k_call_format<false, false>(FmtArgs);
 template __global__ void k_call_format<false, true>(FmtArgs);

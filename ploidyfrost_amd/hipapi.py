@@ -33,7 +33,7 @@ CALL_SIDE = np.dtype([("u", "<u4"), ("exit_ov", "<u4"), ("err_unitig", "<u4"), (
 CALL_RESULT = np.dtype([("text_len", "<u8", (10,)), ("allele", "<u8", (4,)), ("core_cov", "<u8"), ("core_num", "<u8"), ("n_called", "<u8"),
                         ("align_jobs", "<u8"), ("site_strings", "<u8"), ("n_branching", "<u8"),
                         ("snp_jobs", "<u8"), ("pair_jobs", "<u8"), ("wave_jobs", "<u8"), ("stack_jobs", "<u8"),
-                        ("alignseq_packed_len", "<u8")])
+                        ("alignseq_packed_len", "<u8"), ("numeric_packed", "<u8")])
 CALL_STREAMS = ["allele_frequency", "alignseq", "bifre", "trifre", "tetrafre", "pentafre", "bicov", "tricov", "tetracov", "pentacov"]
 BUBBLE_PATH = np.dtype([("text_off", "<u8"), ("len", "<u4"), ("ov", "<u4")])
 BUBBLE_TASK = np.dtype([("path_first", "<u8"), ("n_paths", "<u4"), ("pad", "<u4")])
@@ -116,6 +116,8 @@ def load_library() -> C.CDLL:
         "pf_string_cov": (i, [vp, vp, vp, u32, u32, u32, vp, vp, vp]),
         "pf_host_alloc": (i, [vp, C.c_size_t, C.POINTER(vp)]),
         "pf_selftest_scan": (i, [vp, u64, C.c_uint32]),
+        "pf_call_set_numeric_packed": (i, [vp, i]),
+        "pf_call_fetch_text": (i, [vp, i, i, vp, u64]),
         "pf_host_free": (None, [vp, vp]),
         "pf_device_name": (i, [vp, C.c_char_p, C.c_size_t]),
         "pf_device_pci_bus_id": (i, [vp, C.c_char_p, C.c_size_t]),
@@ -190,7 +192,7 @@ DECLARED_SYMBOLS = ["pf_create", "pf_warmup", "pf_destroy", "pf_last_error", "pf
                     "pf_gmm_upload", "pf_gmm_count", "pf_gmm_fit", "pf_kmc_decode", "pf_device_free", "pf_copy_to_host",
                     "pf_minimizer_table_slots", "pf_minimizer_crowding", "pf_minimizer_replay_inputs", "pf_bfs_candidates_split", "pf_unitig_cov_exact", "pf_unitig_cov_probe", "pf_unitig_cov_colored_probe",
                     "pf_call_set_state", "pf_call_set_format", "pf_superbubble_rows", "pf_superbubble_fetch", "pf_call_coverage", "pf_call_scan", "pf_call_sides", "pf_call_resolve", "pf_call_select", "pf_call_run", "pf_call_align",
-                    "pf_call_text", "pf_call_set_alignseq_packed", "pf_comm_unique_id", "pf_comm_init", "pf_gather", "pf_comm_destroy", "pf_call_reserve", "pf_call_reserve_lanes", "pf_timing_select", "pf_kernel_busy", "pf_call_reserve_text", "pf_selftest_scan", "pf_find_reserve", "pf_call_set_colours", "pf_call_set_cutoffs", "pf_call_peek", "pf_call_text_range", "pf_call_align_lane", "pf_call_text_range_lane", "pf_call_text_sizes", "pf_call_fetch", "pf_call_fetch_slab", "pf_call_fetch_range", "pf_call_fetch_wait", "pf_format_doubles"]
+                    "pf_call_text", "pf_call_set_alignseq_packed", "pf_comm_unique_id", "pf_comm_init", "pf_gather", "pf_comm_destroy", "pf_call_reserve", "pf_call_reserve_lanes", "pf_timing_select", "pf_kernel_busy", "pf_call_reserve_text", "pf_selftest_scan", "pf_call_set_numeric_packed", "pf_call_fetch_text", "pf_find_reserve", "pf_call_set_colours", "pf_call_set_cutoffs", "pf_call_peek", "pf_call_text_range", "pf_call_align_lane", "pf_call_text_range_lane", "pf_call_text_sizes", "pf_call_fetch", "pf_call_fetch_slab", "pf_call_fetch_range", "pf_call_fetch_wait", "pf_format_doubles"]
 
 
 def call_peek(ctx_handle, lane: int = 0):

@@ -48,6 +48,25 @@ def test_alignseq_written_as_text_on_the_device_gives_the_same(case, tmp_path):
         assert not bad, "%s: files differ from the reference: %s" % (env, bad)
 
 
+@pytest.mark.parametrize("case", ["tet60k", "stranded20k", "hex30k"])
+def test_numeric_streams_at_four_bits_a_character_and_as_text_give_the_same(case, tmp_path):
+    """the nine numeric streams leave the device at four bits a character (K-NIB) and become text in the host's writer; a stream
+    with other characters than the sixteen -- stranded20k: "nan" / "inf" in its frequencies -- is fetched as text instead;
+    PF_NUMERIC_ASCII=1 sends all of them as text.  Odd piece sizes too (pieces that end on an odd character)."""
+    meta = load_case(case)
+    if case == "stranded20k":   # (the fixture must keep exercising the way out)
+        exp = open(os.path.join(meta["dir"], "expected", "g_allele_frequency.txt")).read()
+        assert "nan" in exp or "inf" in exp
+    for env in ({}, {"PF_NUMERIC_ASCII": "1"}, {"PF_BATCH_BUBBLES": "97"}, {"PF_BATCH_BUBBLES": "33", "PF_ALIGNSEQ_ASCII": "1"}):
+        out = tmp_path / ("default" if not env else "_".join(env))
+        out.mkdir()
+        r = subprocess.run([CLI, "-g", meta["gfa"], "-d", meta["db"], "-o", "g", "-t", "4"] + meta["args"], cwd=out, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                           text=True, env=dict(os.environ, **env))
+        assert r.returncode == 0, r.stdout
+        bad = compare_outputs(os.path.join(meta["dir"], "expected"), os.path.join(out, "PloidyFrost_output"))
+        assert not bad, "%s: files differ from the reference: %s" % (env, bad)
+
+
 @pytest.mark.parametrize("case,world", [("tet60k", 2), ("hex30k", 3), ("giant7k", 2), ("stranded20k", 4)])
 def test_cli_cuts_one_graph_over_ranks(case, world, tmp_path):
     """`ploidyfrost --gpus N` (csrc/host/pf_multi.hpp): N processes forked before anything touches the GPU, every rank the whole
