@@ -21,34 +21,9 @@
 #include <thread>
 
 #include "../pf_alnpack.hpp"
+#include "../pf_nibble.hpp"
 #include "pf_cdbg_impl.hpp"
 #include "pf_parallel.hpp"
-
-namespace {
-// K-NIB's four bits a character back to text: two characters a byte, first in the low nibble
-inline void nib_expand(char *dst, const uint8_t *src, uint64_t n) {
-    static const struct Lut {
-        uint16_t two[256];
-        Lut() {
-            static const char sym[17] = "0123456789.\t\n-e+";
-            for (int b = 0; b < 256; ++b) two[b] = (uint16_t)((uint8_t)sym[b & 15] | ((uint16_t)(uint8_t)sym[b >> 4] << 8));
-        }
-    } lut;
-    uint64_t i = 0;
-    for (; i + 16 <= n; i += 16) {   // eight bytes of nibbles -> sixteen characters
-        uint64_t in;
-        memcpy(&in, src + (i >> 1), 8);
-        uint16_t w[8];
-        for (int x = 0; x < 8; ++x) w[x] = lut.two[(in >> (8 * x)) & 0xFF];
-        memcpy(dst + i, w, 16);
-    }
-    for (; i + 2 <= n; i += 2) {
-        const uint16_t w = lut.two[src[i >> 1]];
-        memcpy(dst + i, &w, 2);
-    }
-    if (i < n) dst[i] = (char)(lut.two[src[i >> 1]] & 0xFF);
-}
-}  // namespace
 
 namespace pfh {
 
@@ -482,7 +457,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                         spans[n_spans++] = CopySpan{dst, src, d.res.text_len[s]};
                     } else if (nib) {   // (no mapping: text first, then pwrite)
                         std::vector<char> tmp(d.res.text_len[s]);
-                        nib_expand(tmp.data(), reinterpret_cast<const uint8_t *>(src), d.res.text_len[s]);
+                        pf::nibble_expand(tmp.data(), reinterpret_cast<const uint8_t *>(src), d.res.text_len[s]);
                         if (maps[s].write(files[(size_t)s].bytes, tmp.data(), tmp.size(), T)) files[(size_t)s].rc = 1;
                     } else if (maps[s].write(files[(size_t)s].bytes, src, d.res.text_len[s], T)) files[(size_t)s].rc = 1;   // (no mapping: pwrite)
                 }
@@ -504,7 +479,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 parallel_chunks(n_aln + cut.size(), 1, T, [&](size_t i, size_t, size_t) {
                     if (i >= n_aln) {   // (alignseq first: the larger tasks)
                         const CopySpan &c = cut[i - n_aln];
-                        if (cut_nib[i - n_aln]) nib_expand(c.dst, reinterpret_cast<const uint8_t *>(c.src), c.len);
+                        if (cut_nib[i - n_aln]) pf::nibble_expand(c.dst, reinterpret_cast<const uint8_t *>(c.src), c.len);
                         else memcpy(c.dst, c.src, (size_t)c.len);
                         return;
                     }
@@ -525,7 +500,7 @@ int CDBG::ploidy_estimation_resident(const std::string &outpre, const std::vecto
                 else if (d.res.numeric_packed) {
                     const size_t at0 = last_allfre_.size();
                     last_allfre_.resize(at0 + d.res.text_len[0]);
-                    nib_expand(&last_allfre_[at0], reinterpret_cast<const uint8_t *>(hb.p + off[0]), d.res.text_len[0]);
+                    pf::nibble_expand(&last_allfre_[at0], reinterpret_cast<const uint8_t *>(hb.p + off[0]), d.res.text_len[0]);
                 } else last_allfre_.append(hb.p + off[0], d.res.text_len[0]);
             }
             for (int s = 0; s < PF_CALL_STREAMS; ++s) files[(size_t)s].bytes += d.res.text_len[s];

@@ -316,6 +316,21 @@ def test_packed_alignseq_round_trip(tmp_path):
     assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
 
 
+def test_packed_numeric_streams_round_trip(tmp_path):
+    """the nine numeric streams leave the device at four bits a character (csrc/pf_nibble.hpp, K-NIB) and become text in the host's
+    writer: the host half on its own, tests/cpp/test_nibble.cpp (the device half is held to the reference's files by every
+    end-to-end test, both ways: PF_NUMERIC_ASCII)."""
+    import shutil
+    import subprocess
+    if not shutil.which("g++"):
+        pytest.skip("no g++")
+    exe = str(tmp_path / "test_nibble")
+    subprocess.run(["g++", "-O2", "-std=c++17", "-I", os.path.join(ROOT, "ploidyfrost_amd", "csrc"), os.path.join(ROOT, "tests", "cpp", "test_nibble.cpp"), "-o", exe],
+                   check=True)
+    r = subprocess.run([exe], stdout=subprocess.PIPE, text=True, timeout=120)
+    assert r.returncode == 0 and r.stdout.strip() == "ok", r.stdout
+
+
 def test_bench_cov_roofline_picks_the_streaming_kernel_of_the_workload():
     """bench.py `roofline_k_cov`: K-COV for the single-sample workload (with the committed PMC traffic), K-COV-C for the colored."""
     import bench
